@@ -1,0 +1,95 @@
+/*
+ * oracle/ddn_oracle.h — CPU restatement of the dsd-neo sample-streaming hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked, imported or called by the product
+ * (dsd-neo_amd/, include/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and only as the checker / the timed CPU baseline.
+ *
+ * Every function cites the reference file:line it restates (paths relative to /root/reference).  The
+ * restatement is pinned against the reference's own compiled sources (oracle/_ref/libdsdneo_ref.so, built
+ * by oracle/Makefile from /root/reference in place) by tests/test_oracle_vs_ref.py, and against the
+ * committed golden vectors under tests/golden/ (generated from that same library by
+ * tests/golden/make_golden.py) everywhere else.
+ */
+#ifndef DDN_ORACLE_H
+#define DDN_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- front end: widen -> channel LPF -> power/squelch -> FSK discriminator ------------------------- */
+
+#define ORC_MAX_TAPS 144 /* kChannelLpfTaps, src/dsp/demod_pipeline.cpp:129 */
+
+/* DSD_CH_LPF_PROFILE_* ids, include/dsd-neo/dsp/demod_state.h:36-43 */
+enum {
+    ORC_LPF_WIDE = 0,
+    ORC_LPF_6K25 = 1,
+    ORC_LPF_12K5 = 2,
+    ORC_LPF_PROVOICE = 3,
+    ORC_LPF_P25_C4FM = 4,
+    ORC_LPF_P25_CQPSK = 5,
+};
+
+void orc_widen_u8(const uint8_t* src, float* dst, size_t len);
+int orc_channel_lpf_design(int rate_hz, int profile, float* taps_out, int max_taps);
+int orc_firdes_low_pass_blackman(double gain, double fs, double cutoff, double transition, float* taps_out,
+                                 int max_taps);
+
+/* fma_order=1: the reference's AVX2 unit (vector FMA chain); 0: the scalar/SSE2 unit (mul, then add). */
+void orc_fir_complex_apply(const float* in, int in_len, float* out, float* hist_i, float* hist_q, const float* taps,
+                           int taps_len, int fma_order);
+int orc_hb_decim2_complex(const float* in, int in_len, float* out, float* hist_i, float* hist_q, const float* taps,
+                          int taps_len, int fma_order);
+extern const float orc_hb15_taps[15];
+extern const float orc_hb31_taps[31];
+
+float orc_mean_power(const float* samples, int len, int step);
+
+typedef struct orc_fsk_state {
+    float prev_i, prev_q;
+    int have_prev;
+    float dc_est;
+    float peak_est;
+} orc_fsk_state;
+
+void orc_fsk_reset(orc_fsk_state* st);
+float orc_fsk_phase_delta(float cur_i, float cur_q, float prev_i, float prev_q);
+int orc_fsk_discriminator(orc_fsk_state* st, const float* iq, int len_interleaved, float* out, int max_out);
+
+/* one channel's carried front-end state (what struct demod_state carries for this path) */
+typedef struct orc_front_end {
+    int rate_hz;
+    int lpf_enable;
+    int taps_len;
+    int downsample_passes;
+    int fma_order;
+    float squelch_level;
+    float taps[ORC_MAX_TAPS];
+    float hist_i[ORC_MAX_TAPS];
+    float hist_q[ORC_MAX_TAPS];
+    float hb_hist_i[10][30];
+    float hb_hist_q[10][30];
+    orc_fsk_state fsk;
+    float channel_pwr;
+    int channel_squelched;
+} orc_front_end;
+
+void orc_fe_init(orc_front_end* fe, int rate_hz, int profile, int lpf_enable, float squelch_level,
+                 int downsample_passes, int fma_order);
+/* one full_demod() block: in = n_complex interleaved floats; returns discriminator samples written */
+int orc_fe_block_f32(orc_front_end* fe, const float* iq, int n_complex, float* out, float* scratch /* >=4*n */);
+long orc_fe_run_cu8(orc_front_end* fe, const uint8_t* iq, long n_complex, int block_len, float* out);
+long orc_fe_run_f32(orc_front_end* fe, const float* iq, long n_complex, int block_len, float* out);
+/* B independent channels, channel-major input/output (the batched shape the HIP path uses) */
+void orc_fe_run_batch_cu8(int n_channels, const uint8_t* iq, long n_complex, int block_len, int rate_hz, int profile,
+                          float squelch_level, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
