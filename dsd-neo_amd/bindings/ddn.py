@@ -1,0 +1,148 @@
+"""ctypes binding of libdsdneo_hip.so (include/ddn_hip.h) — the shape of stub a host application adds.
+
+This module is plumbing for tests/ and bench.py: it loads the in-tree shared library and declares the C-ABI
+prototypes.  It never falls back to a CPU implementation: if the library (or a GPU) is missing the calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
+LIB_PATH = os.path.join(ROOT, "dsd-neo_amd", "libdsdneo_hip.so")
+
+DDN_OK, DDN_EINVAL, DDN_ENODEV, DDN_ENOMEM, DDN_EHIP, DDN_ERANGE = 0, -1, -2, -3, -4, -5
+LPF_WIDE, LPF_6K25, LPF_12K5, LPF_PROVOICE, LPF_P25_C4FM, LPF_P25_CQPSK = range(6)
+IN_CU8, IN_CF32 = 0, 1
+
+
+class FrontEndConfig(C.Structure):
+    _fields_ = [
+        ("n_channels", C.c_int),
+        ("sample_rate_hz", C.c_int),
+        ("symbol_rate_hz", C.c_int),
+        ("levels", C.c_int),
+        ("lpf_profile", C.c_int),
+        ("input_format", C.c_int),
+        ("block_len", C.c_int),
+        ("squelch_level", C.c_float),
+    ]
+
+
+class FskModemState(C.Structure):
+    _fields_ = [
+        ("cfg_sample_rate_hz", C.c_int),
+        ("cfg_symbol_rate_hz", C.c_int),
+        ("cfg_levels", C.c_int),
+        ("cfg_channel_profile", C.c_int),
+        ("prev_i", C.c_float),
+        ("prev_q", C.c_float),
+        ("have_prev", C.c_int),
+        ("dc_est", C.c_float),
+        ("discriminator_peak_est", C.c_float),
+    ]
+
+
+# every symbol include/ddn_hip.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "ddn_last_error": (C.c_char_p, []),
+    "ddn_version": (C.c_char_p, []),
+    "ddn_batch_create": (C.c_int, [C.POINTER(FrontEndConfig), C.POINTER(C.c_void_p)]),
+    "ddn_batch_destroy": (None, [C.c_void_p]),
+    "ddn_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_batch_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "ddn_front_end_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_front_end_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_batch_get_fsk_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ddn_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_batch_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "simd_fir_complex_apply": (None, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "simd_hb_decim2_complex": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "simd_hb_decim2_real": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "simd_fir_get_impl_name": (C.c_char_p, []),
+    "widen_u8_to_f32_bias127": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "ddn_fsk_modem_discriminator_process": (C.c_int, [C.POINTER(FskModemState), C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libdsdneo_hip.so (RTLD_LOCAL) and bind prototypes.  Raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class DdnError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise DdnError("%s failed: rc=%d %s" % (what, rc, lib().ddn_last_error().decode()))
+    return rc
+
+
+class Batch:
+    """RAII wrapper over ddn_batch (B channels of the FSK front end on the current HIP device)."""
+
+    def __init__(self, n_channels, sample_rate_hz=48000, symbol_rate_hz=4800, levels=4, lpf_profile=LPF_P25_C4FM,
+                 input_format=IN_CU8, block_len=8192, squelch_level=0.0):
+        self.cfg = FrontEndConfig(n_channels, sample_rate_hz, symbol_rate_hz, levels, lpf_profile, input_format,
+                                  block_len, squelch_level)
+        self.h = C.c_void_p()
+        _check(lib().ddn_batch_create(C.byref(self.cfg), C.byref(self.h)), "ddn_batch_create")
+
+    def close(self):
+        if self.h:
+            lib().ddn_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=None):
+        _check(lib().ddn_batch_reset(self.h, stream), "ddn_batch_reset")
+
+    def taps(self):
+        import numpy as np
+        t = np.zeros(160, np.float32)
+        n = _check(lib().ddn_batch_get_taps(self.h, t.ctypes.data, 160), "ddn_batch_get_taps")
+        return t[:n].copy()
+
+    def run_device(self, d_iq_ptr, n, d_out_ptr, stream=None):
+        _check(lib().ddn_front_end_run(self.h, d_iq_ptr, n, d_out_ptr, stream), "ddn_front_end_run")
+
+    def run_host(self, iq, n):
+        """iq: numpy [B, n, 2] uint8 or float32 (channel-major).  Returns float32 [B, n]."""
+        import numpy as np
+        iq = np.ascontiguousarray(iq)
+        out = np.empty((self.cfg.n_channels, n), np.float32)
+        _check(lib().ddn_front_end_run_host(self.h, iq.ctypes.data, n, out.ctypes.data), "ddn_front_end_run_host")
+        return out
+
+    def fsk_state(self, ch):
+        import numpy as np
+        s = np.zeros(5, np.float32)
+        _check(lib().ddn_batch_get_fsk_state(self.h, ch, s.ctypes.data), "ddn_batch_get_fsk_state")
+        return s
+
+    def set_timing(self, on):
+        _check(lib().ddn_batch_set_timing(self.h, 1 if on else 0), "ddn_batch_set_timing")
+
+    def timing(self):
+        import numpy as np
+        t = np.zeros(3, np.float32)
+        _check(lib().ddn_batch_get_timing(self.h, t.ctypes.data), "ddn_batch_get_timing")
+        return t

@@ -1,0 +1,355 @@
+// ddn_api.cpp — C-ABI of libdsdneo_hip.so (batched front end).  See include/ddn_hip.h.
+//
+// Host-side counterpart of the reference's per-stream demod state (struct demod_state,
+// include/dsd-neo/dsp/demod_state.h:67-262) re-laid-out for B channels on one GPU: only the carried words
+// live on the device (FIR look-back, modem dc/peak/prev); the 10 MB of per-stream scratch buffers of the
+// reference are replaced by per-call tile side-buffers sized for the call.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "ddn_device.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void
+ddn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char*
+ddn_last_error(void) {
+    return g_err;
+}
+
+extern "C" const char*
+ddn_version(void) {
+    return "dsdneo-hip 0.1 (gfx950)";
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            ddn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);                  \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorNoBinaryForGpu              \
+                    || e_ == hipErrorInsufficientDriver)                                                               \
+                       ? DDN_ENODEV                                                                                    \
+                       : (e_ == hipErrorOutOfMemory ? DDN_ENOMEM : DDN_EHIP);                                          \
+        }                                                                                                              \
+    } while (0)
+
+struct ddn_batch {
+    ddn_front_end_config cfg;
+    float taps[DDN_MAX_TAPS + 1];
+    int taps_len;
+    int center;
+    int fir_tile;
+    float* d_taps;
+    ddn_f2* d_carry;      // [B][DDN_CARRY_LEN]
+    DdnFskState* d_state; // [B]
+    ddn_f2* d_edge;       // [B][n_tiles][2], grown on demand
+    size_t edge_cap;
+    float* d_pwr;
+    size_t pwr_cap;
+    // host-call staging
+    void* d_in;
+    size_t in_cap;
+    float* d_out;
+    size_t out_cap;
+    int timing;
+    hipEvent_t ev[3];
+    int ev_valid;
+};
+
+static int
+ensure_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        ddn_set_error("no HIP device available (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return DDN_ENODEV;
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_batch_create(const ddn_front_end_config* cfg, ddn_batch** out) {
+    if (!cfg || !out || cfg->n_channels <= 0 || cfg->sample_rate_hz <= 0) {
+        ddn_set_error("ddn_batch_create: bad config");
+        return DDN_EINVAL;
+    }
+    if (cfg->input_format != DDN_IN_CU8 && cfg->input_format != DDN_IN_CF32) {
+        ddn_set_error("ddn_batch_create: unknown input_format %d", cfg->input_format);
+        return DDN_EINVAL;
+    }
+    int rc = ensure_device();
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    ddn_batch* b = new (std::nothrow) ddn_batch();
+    if (!b) {
+        return DDN_ENOMEM;
+    }
+    memset(b, 0, sizeof(*b));
+    b->cfg = *cfg;
+    b->taps_len = ddn_design_channel_lpf(cfg->sample_rate_hz, cfg->lpf_profile, b->taps, DDN_MAX_TAPS);
+    if (b->taps_len < 3) {
+        ddn_set_error("channel LPF design failed for rate %d profile %d (taps=%d); the reference falls back to a "
+                      "fixed 63-tap table here, which this build does not carry",
+                      cfg->sample_rate_hz, cfg->lpf_profile, b->taps_len);
+        delete b;
+        return DDN_ERANGE;
+    }
+    b->center = (b->taps_len - 1) / 2;
+    b->fir_tile = ddn_dev_fir_tile(b->center);
+    // the reference routes blocks shorter than 2*taps_len floats to its non-FMA scalar unit
+    // (src/dsp/simd_fir.cpp:303-306); this build implements the FMA (AVX2-unit) order only.
+    if (cfg->block_len < b->taps_len) {
+        ddn_set_error("block_len %d < taps_len %d is not supported", cfg->block_len, b->taps_len);
+        delete b;
+        return DDN_ERANGE;
+    }
+    const size_t B = (size_t)cfg->n_channels;
+    auto fail = [&](int code) {
+        ddn_batch_destroy(b);
+        return code;
+    };
+    if (hipMalloc(&b->d_taps, sizeof(float) * (DDN_MAX_TAPS + 1)) != hipSuccess
+        || hipMalloc(&b->d_carry, sizeof(ddn_f2) * B * DDN_CARRY_LEN) != hipSuccess
+        || hipMalloc(&b->d_state, sizeof(DdnFskState) * B) != hipSuccess) {
+        ddn_set_error("hipMalloc failed for batch state");
+        return fail(DDN_ENOMEM);
+    }
+    if (hipMemcpy(b->d_taps, b->taps, sizeof(float) * (size_t)b->taps_len, hipMemcpyHostToDevice) != hipSuccess) {
+        ddn_set_error("tap upload failed");
+        return fail(DDN_EHIP);
+    }
+    for (int i = 0; i < 3; i++) {
+        if (hipEventCreate(&b->ev[i]) != hipSuccess) {
+            ddn_set_error("hipEventCreate failed");
+            return fail(DDN_EHIP);
+        }
+    }
+    rc = ddn_batch_reset(b, nullptr);
+    if (rc != DDN_OK) {
+        return fail(rc);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        return fail(DDN_EHIP);
+    }
+    *out = b;
+    return DDN_OK;
+}
+
+extern "C" void
+ddn_batch_destroy(ddn_batch* b) {
+    if (!b) {
+        return;
+    }
+    (void)hipFree(b->d_taps);
+    (void)hipFree(b->d_carry);
+    (void)hipFree(b->d_state);
+    (void)hipFree(b->d_edge);
+    (void)hipFree(b->d_pwr);
+    (void)hipFree(b->d_in);
+    (void)hipFree(b->d_out);
+    for (int i = 0; i < 3; i++) {
+        if (b->ev[i]) {
+            (void)hipEventDestroy(b->ev[i]);
+        }
+    }
+    delete b;
+}
+
+extern "C" int
+ddn_batch_reset(ddn_batch* b, void* hip_stream) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t B = (size_t)b->cfg.n_channels;
+    HIP_TRY(ddn_dev_zero(b->d_carry, sizeof(ddn_f2) * B * DDN_CARRY_LEN, st));
+    HIP_TRY(ddn_dev_zero(b->d_state, sizeof(DdnFskState) * B, st));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_batch_get_taps(const ddn_batch* b, float* taps_out, int cap) {
+    if (!b || !taps_out) {
+        return DDN_EINVAL;
+    }
+    for (int i = 0; i < b->taps_len && i < cap; i++) {
+        taps_out[i] = b->taps[i];
+    }
+    return b->taps_len;
+}
+
+static int
+grow(void** p, size_t* cap, size_t need) {
+    if (*cap >= need) {
+        return DDN_OK;
+    }
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    if (hipMalloc(p, need) != hipSuccess) {
+        ddn_set_error("hipMalloc(%zu) failed", need);
+        return DDN_ENOMEM;
+    }
+    *cap = need;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void* hip_stream) {
+    if (!b || !d_iq || !d_disc) {
+        ddn_set_error("ddn_front_end_run: null argument");
+        return DDN_EINVAL;
+    }
+    if (n == 0) {
+        return DDN_OK;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int B = b->cfg.n_channels;
+    const int block_len = b->cfg.block_len;
+    const int T = b->fir_tile;
+    const long n_blocks = (long)((n + (size_t)block_len - 1) / (size_t)block_len);
+    const int tiles_per_block = (block_len + T - 1) / T;
+    const long n_tiles = n_blocks * tiles_per_block;
+    if (n_tiles > 0x7fffffffL) {
+        ddn_set_error("ddn_front_end_run: too many tiles");
+        return DDN_ERANGE;
+    }
+    int rc = grow((void**)&b->d_edge, &b->edge_cap, sizeof(ddn_f2) * 2 * (size_t)B * (size_t)n_tiles);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    const int squelch_on = b->cfg.squelch_level > 0.0f ? 1 : 0;
+    if (squelch_on) {
+        rc = grow((void**)&b->d_pwr, &b->pwr_cap, sizeof(float) * (size_t)B * (size_t)n_blocks);
+        if (rc != DDN_OK) {
+            return rc;
+        }
+    }
+    DdnFirArgs fa;
+    fa.in = d_iq;
+    fa.out = d_disc;
+    fa.carry = b->d_carry;
+    fa.tile_edge = b->d_edge;
+    fa.blk_pwr = b->d_pwr;
+    fa.ch_stride = n;
+    fa.out_stride = n;
+    fa.n = (long)n;
+    fa.in_fmt = b->cfg.input_format;
+    fa.block_len = block_len;
+    fa.tiles_per_block = tiles_per_block;
+    fa.n_tiles = (int)n_tiles;
+    fa.n_blocks = (int)n_blocks;
+    fa.squelch_on = squelch_on;
+
+    DdnSerialArgs sa;
+    sa.buf = d_disc;
+    sa.tile_edge = b->d_edge;
+    sa.blk_pwr = b->d_pwr;
+    sa.state = b->d_state;
+    sa.stride = n;
+    sa.n = (long)n;
+    sa.n_channels = B;
+    sa.block_len = block_len;
+    sa.fir_tile = T;
+    sa.tiles_per_block = tiles_per_block;
+    sa.n_tiles = (int)n_tiles;
+    sa.n_blocks = (int)n_blocks;
+    sa.squelch_on = squelch_on;
+    sa.squelch_level = b->cfg.squelch_level;
+
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[0], st));
+    }
+    HIP_TRY(ddn_dev_launch_fir(&fa, b->taps, b->d_taps, b->center, B, st));
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[1], st));
+    }
+    HIP_TRY(ddn_dev_launch_serial(&sa, st));
+    HIP_TRY(ddn_dev_launch_carry(d_iq, b->cfg.input_format, n, (long)n, b->d_carry, B, st));
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[2], st));
+        b->ev_valid = 1;
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_front_end_run_host(ddn_batch* b, const void* h_iq, size_t n, float* h_disc) {
+    if (!b || !h_iq || !h_disc) {
+        return DDN_EINVAL;
+    }
+    if (n == 0) {
+        return DDN_OK;
+    }
+    const size_t B = (size_t)b->cfg.n_channels;
+    const size_t in_bytes = B * n * (b->cfg.input_format == DDN_IN_CU8 ? 2 : 8);
+    const size_t out_bytes = B * n * sizeof(float);
+    int rc = grow(&b->d_in, &b->in_cap, in_bytes);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    rc = grow((void**)&b->d_out, &b->out_cap, out_bytes);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    HIP_TRY(hipMemcpy(b->d_in, h_iq, in_bytes, hipMemcpyHostToDevice));
+    rc = ddn_front_end_run(b, b->d_in, n, b->d_out, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    HIP_TRY(hipMemcpy(h_disc, b->d_out, out_bytes, hipMemcpyDeviceToHost));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_batch_get_fsk_state(ddn_batch* b, int channel, float out5[5]) {
+    if (!b || !out5 || channel < 0 || channel >= b->cfg.n_channels) {
+        return DDN_EINVAL;
+    }
+    DdnFskState s;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&s, b->d_state + channel, sizeof(s), hipMemcpyDeviceToHost));
+    out5[0] = s.prev_i;
+    out5[1] = s.prev_q;
+    out5[2] = (float)s.have_prev;
+    out5[3] = s.dc_est;
+    out5[4] = s.peak_est;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_batch_set_timing(ddn_batch* b, int enable) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    b->timing = enable ? 1 : 0;
+    b->ev_valid = 0;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_batch_get_timing(ddn_batch* b, float out3[3]) {
+    if (!b || !out3 || !b->ev_valid) {
+        return DDN_EINVAL;
+    }
+    HIP_TRY(hipEventSynchronize(b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&out3[0], b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&out3[1], b->ev[1], b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&out3[2], b->ev[0], b->ev[2]));
+    return DDN_OK;
+}

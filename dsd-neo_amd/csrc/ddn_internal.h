@@ -1,0 +1,18 @@
+/* ddn_internal.h — shared between the C-ABI translation units of libdsdneo_hip.so (not installed). */
+#ifndef DDN_INTERNAL_H
+#define DDN_INTERNAL_H
+
+#include "../../include/ddn_hip.h"
+
+#define DDN_MAX_TAPS   143 /* odd; reference kChannelLpfTaps = 144 (src/dsp/demod_pipeline.cpp:129) */
+#define DDN_MAX_CENTER 71
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int ddn_design_channel_lpf(int rate_hz, int profile, float* taps, int max_taps);
+void ddn_set_error(const char* fmt, ...);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,121 @@
+/*
+ * include/ddn_hip.h — C-ABI of libdsdneo_hip.so: the MI355X (gfx950) implementation of dsd-neo's
+ * sample-streaming hot path.  Plain C, plain pointers and sizes; no torch/HIP types.
+ *
+ * Two families of entry points:
+ *
+ *  (1) Batched `ddn_*` calls — B independent channels (one I/Q capture each) per call.  These are what a
+ *      dsd-neo build would bind behind its demod thread / stream-read hook when it hosts many channels:
+ *        ddn_front_end_run       replaces the per-stream loop "widen -> full_demod()" of the demod thread
+ *                                (reference src/io/radio/rtl_device.cpp:1777 + src/io/radio/rtl_sdr_fm.cpp:3458-3516,
+ *                                 full_demod: include/dsd-neo/dsp/demod_pipeline.h:106)
+ *        ddn_hooks_read          serves include/dsd-neo/runtime/rtl_stream_io_hooks.h:25-28 `read`
+ *      Pointers named d_* are DEVICE pointers (hipMalloc / torch .data_ptr()), h_* are host pointers.
+ *
+ *  (2) Drop-in single-stream symbols with the reference's own names and signatures (host pointers), so the
+ *      reference's unit tests for this path can link against this library unchanged:
+ *        simd_fir_complex_apply, simd_hb_decim2_complex, simd_hb_decim2_real, simd_fir_get_impl_name
+ *                                (include/dsd-neo/dsp/simd_fir.h:41-77)
+ *        widen_u8_to_f32_bias127 (include/dsd-neo/dsp/simd_widen.h:51)
+ *        ddn_fsk_modem_discriminator_process (== dsd_fsk_modem_discriminator_process,
+ *                                include/dsd-neo/dsp/fsk_modem.h:42; state struct layout identical)
+ *      Per-call granularity is far too fine for a GPU; these exist for parity, not throughput.
+ *
+ * All functions return 0 (or a non-negative count) on success and a negative DDN_E* code on failure; they
+ * never fall back to a CPU path: if no gfx950 device / kernel image is available they fail with DDN_ENODEV.
+ */
+#ifndef DDN_HIP_H
+#define DDN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDN_OK       0
+#define DDN_EINVAL  -1 /* bad argument (mirrors the reference's silent no-op on bad args, but reported) */
+#define DDN_ENODEV  -2 /* no HIP device / kernel image for this device */
+#define DDN_ENOMEM  -3
+#define DDN_EHIP    -4 /* HIP runtime error; ddn_last_error() has the string */
+#define DDN_ERANGE  -5 /* unsupported size (e.g. taps_len > 143, block_len too small) */
+
+const char* ddn_last_error(void);
+const char* ddn_version(void);
+
+/* Channel LPF profile ids == DSD_CH_LPF_PROFILE_* (include/dsd-neo/dsp/demod_state.h:36-43) */
+enum {
+    DDN_LPF_WIDE = 0,
+    DDN_LPF_6K25 = 1,
+    DDN_LPF_12K5 = 2,
+    DDN_LPF_PROVOICE = 3,
+    DDN_LPF_P25_C4FM = 4,
+    DDN_LPF_P25_CQPSK = 5,
+};
+
+enum { DDN_IN_CU8 = 0, DDN_IN_CF32 = 1 };
+
+/* Per-batch front-end configuration: the subset of struct demod_state (include/dsd-neo/dsp/demod_state.h:67-262)
+ * that the FSK-discriminator path reads, fixed for all channels of the batch. */
+typedef struct ddn_front_end_config {
+    int n_channels;      /* B */
+    int sample_rate_hz;  /* demod rate (rate_out) */
+    int symbol_rate_hz;  /* informational (fsk modem cfg) */
+    int levels;          /* 2 or 4 */
+    int lpf_profile;     /* DDN_LPF_* */
+    int input_format;    /* DDN_IN_CU8 / DDN_IN_CF32 */
+    int block_len;       /* complex samples per reference full_demod() block (edge-replication granule) */
+    float squelch_level; /* channel_squelch_level; 0 = disabled (reference default) */
+} ddn_front_end_config;
+
+typedef struct ddn_batch ddn_batch;
+
+int ddn_batch_create(const ddn_front_end_config* cfg, ddn_batch** out);
+void ddn_batch_destroy(ddn_batch* b);
+/* forget all carried per-channel state (FIR history, modem dc/peak/prev): a fresh stream */
+int ddn_batch_reset(ddn_batch* b, void* hip_stream);
+/* taps actually in use (host-designed, same rule as channel_lpf_ensure_plan); returns taps_len */
+int ddn_batch_get_taps(const ddn_batch* b, float* taps_out, int cap);
+
+/* One pass of widen -> channel LPF -> (squelch) -> FSK discriminator over n complex samples per channel.
+ *   d_iq   : [B][n] interleaved I/Q, u8 pairs (CU8) or float pairs (CF32), channel-major
+ *   d_disc : [B][n] float discriminator samples (AGC'd to +-30000, clipped to int16 range)
+ * The call is equivalent to ceil(n / block_len) consecutive full_demod() calls per channel; carried state
+ * persists in `b` across calls.  Asynchronous on `hip_stream` (NULL = default stream). */
+int ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void* hip_stream);
+/* same, host buffers (H2D, run, D2H, synchronous) */
+int ddn_front_end_run_host(ddn_batch* b, const void* h_iq, size_t n, float* h_disc);
+
+/* per-channel modem state after the last run: {prev_i, prev_q, have_prev, dc_est, peak_est} (synchronous) */
+int ddn_batch_get_fsk_state(ddn_batch* b, int channel, float out5[5]);
+
+/* duration in ms of the dominant kernel(s) of the most recent ddn_front_end_run, measured with HIP events
+ * on the stream the kernels were launched on; valid after the stream has been synchronised.
+ * out3 = {fir_ms, serial_ms, total_ms}.  Only recorded when ddn_batch_set_timing(b,1) was called. */
+int ddn_batch_set_timing(ddn_batch* b, int enable);
+int ddn_batch_get_timing(ddn_batch* b, float out3[3]);
+
+/* ---- drop-in single-stream symbols (reference names; host pointers) ------------------------------- */
+void simd_fir_complex_apply(const float* in, int in_len, float* out, float* hist_i, float* hist_q, const float* taps,
+                            int taps_len);
+int simd_hb_decim2_complex(const float* in, int in_len, float* out, float* hist_i, float* hist_q, const float* taps,
+                           int taps_len);
+int simd_hb_decim2_real(const float* in, int in_len, float* out, float* hist, const float* taps, int taps_len);
+const char* simd_fir_get_impl_name(void);
+void widen_u8_to_f32_bias127(const unsigned char* src, float* dst, uint32_t len);
+
+typedef struct ddn_fsk_modem_state { /* layout == dsd_fsk_modem_state, include/dsd-neo/dsp/fsk_modem.h:22-36 */
+    int cfg_sample_rate_hz, cfg_symbol_rate_hz, cfg_levels, cfg_channel_profile;
+    float prev_i, prev_q;
+    int have_prev;
+    float dc_est;
+    float discriminator_peak_est;
+} ddn_fsk_modem_state;
+int ddn_fsk_modem_discriminator_process(ddn_fsk_modem_state* st, const float* iq_interleaved, int len_interleaved,
+                                        float* out_samples, int max_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDN_HIP_H */

@@ -1,0 +1,170 @@
+"""Test-side helpers: ctypes bindings of the CPU oracle (oracle/libddn_oracle.so), of the compiled reference
+(oracle/_ref/libdsdneo_ref.so, only present where /root/reference was available at build time) and the synthetic
+I/Q generators shared by tests/ and bench.py.  TEST INFRASTRUCTURE — never imported by the product."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libddn_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libdsdneo_ref.so")
+REFERENCE_ROOT = "/root/reference"
+
+_orc = None
+_ref = None
+
+
+def oracle():
+    global _orc
+    if _orc is None:
+        if not os.path.exists(ORACLE_SO):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+        o = C.CDLL(ORACLE_SO)
+        o.orc_fe_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
+        o.orc_fe_run_cu8.restype = C.c_long
+        o.orc_fe_run_cu8.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+        o.orc_fe_run_f32.restype = C.c_long
+        o.orc_fe_run_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+        o.orc_fe_run_batch_cu8.argtypes = [C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float,
+                                           C.c_void_p]
+        o.orc_channel_lpf_design.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+        o.orc_fir_complex_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int]
+        o.orc_hb_decim2_complex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int]
+        o.orc_fsk_discriminator.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        o.orc_widen_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        o.orc_mean_power.restype = C.c_float
+        o.orc_mean_power.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _orc = o
+    return _orc
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        r = C.CDLL(REF_SO)
+        r.refh_fe_create.restype = C.c_void_p
+        r.refh_fe_create.argtypes = [C.c_int] * 5 + [C.c_float, C.c_int]
+        r.refh_fe_destroy.argtypes = [C.c_void_p]
+        r.refh_fe_run_cu8.restype = C.c_long
+        r.refh_fe_run_cu8.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+        r.refh_fe_run_f32.restype = C.c_long
+        r.refh_fe_run_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+        r.refh_fe_get_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        r.refh_fe_get_state.argtypes = [C.c_void_p, C.c_void_p]
+        r.simd_fir_get_impl_name.restype = C.c_char_p
+        _ref = r
+    return _ref
+
+
+# ---------------------------------------------------------------------------------------------------------
+# oracle front end
+
+ORC_FE_BYTES = 16384  # >= sizeof(orc_front_end)
+
+
+class OracleFrontEnd:
+    def __init__(self, rate=48000, profile=4, lpf_enable=1, squelch=0.0, downsample_passes=0, fma_order=1):
+        self.buf = C.create_string_buffer(ORC_FE_BYTES)
+        oracle().orc_fe_init(self.buf, rate, profile, lpf_enable, squelch, downsample_passes, fma_order)
+
+    def run_cu8(self, iq_u8, block_len):
+        iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8).reshape(-1)
+        n = iq_u8.size // 2
+        out = np.zeros(n, np.float32)
+        w = oracle().orc_fe_run_cu8(self.buf, iq_u8.ctypes.data, n, block_len, out.ctypes.data)
+        return out[:w]
+
+    def run_f32(self, iq, block_len):
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        n = iq.size // 2
+        out = np.zeros(n, np.float32)
+        w = oracle().orc_fe_run_f32(self.buf, iq.ctypes.data, n, block_len, out.ctypes.data)
+        return out[:w]
+
+    def fsk_state(self):
+        # orc_front_end layout: 6 ints/floats header, taps[144], hist_i[144], hist_q[144], hb hists, fsk ...
+        raise NotImplementedError
+
+
+def oracle_batch_cu8(iq_u8, block_len, rate=48000, profile=4, squelch=0.0):
+    """iq_u8: [B, n, 2] uint8 -> float32 [B, n] (each channel an independent stream)."""
+    iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+    B, n = iq_u8.shape[0], iq_u8.shape[1]
+    out = np.zeros((B, n), np.float32)
+    oracle().orc_fe_run_batch_cu8(B, iq_u8.ctypes.data, n, block_len, rate, profile, squelch, out.ctypes.data)
+    return out
+
+
+def ref_front_end_cu8(iq_u8, block_len, rate=48000, sym=4800, levels=4, profile=4, lpf=1, squelch=0.0, passes=0):
+    iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8).reshape(-1)
+    n = iq_u8.size // 2
+    h = ref().refh_fe_create(rate, sym, levels, profile, lpf, squelch, passes)
+    out = np.zeros(n, np.float32)
+    w = ref().refh_fe_run_cu8(h, iq_u8.ctypes.data, n, block_len, out.ctypes.data)
+    taps = np.zeros(160, np.float32)
+    nt = ref().refh_fe_get_taps(h, taps.ctypes.data, 160)
+    st = np.zeros(7, np.float32)
+    ref().refh_fe_get_state(h, st.ctypes.data)
+    ref().refh_fe_destroy(h)
+    return out[:w], taps[:nt].copy(), st
+
+
+# ---------------------------------------------------------------------------------------------------------
+# synthetic C4FM-like I/Q (SURVEY.md §8d "C2 synthetic input"; modelled on the reference bench's 4-level FSK
+# generator tests/dsp/bench_dsp.cpp:183-226): per channel c an LCG x <- 1664525 x + 1013904223 seeded
+# 0xC0FFEE11 + c picks one of {-3,-1,+1,+3} per symbol from (x>>30)&3, the phase advances 0.028*level rad per
+# sample (sps = 10), amplitude 0.85, initial phase 0.19, additive uniform noise at -20 dBc from a
+# counter-based 32-bit hash, quantised to cu8 with round-half-even of 127.5 + 127.5*x clipped to [0,255].
+
+LEVELS = np.array([-3.0, -1.0, 1.0, 3.0])
+
+
+def _hash32(x):
+    x = np.asarray(x, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    x = (x ^ (x >> np.uint64(16))) * np.uint64(0x7FEB352D) & np.uint64(0xFFFFFFFF)
+    x = (x ^ (x >> np.uint64(15))) * np.uint64(0x846CA68B) & np.uint64(0xFFFFFFFF)
+    x = x ^ (x >> np.uint64(16))
+    return x
+
+
+def synth_symbols(ch_first, n_ch, n_sym):
+    x = (np.uint64(0xC0FFEE11) + np.arange(ch_first, ch_first + n_ch, dtype=np.uint64)) & np.uint64(0xFFFFFFFF)
+    sym = np.empty((n_ch, n_sym), np.int8)
+    for s in range(n_sym):
+        x = (x * np.uint64(1664525) + np.uint64(1013904223)) & np.uint64(0xFFFFFFFF)
+        sym[:, s] = ((x >> np.uint64(30)) & np.uint64(3)).astype(np.int8)
+    return sym
+
+
+def synth_c4fm_cu8(ch_first, n_ch, n, sps=10, noise_dbc=-20.0):
+    """Returns uint8 [n_ch, n, 2]."""
+    n_sym = (n + sps - 1) // sps
+    sym = synth_symbols(ch_first, n_ch, n_sym)
+    lv = LEVELS[sym]                                  # [n_ch, n_sym]
+    step = np.repeat(lv * 0.028, sps, axis=1)[:, :n]   # rad / sample
+    ph = 0.19 + np.cumsum(step, axis=1)
+    i = 0.85 * np.cos(ph)
+    q = 0.85 * np.sin(ph)
+    a = np.sqrt(3.0 * 0.5 * (0.85 ** 2) * 10.0 ** (noise_dbc / 10.0))
+    idx = (np.arange(ch_first, ch_first + n_ch, dtype=np.uint64)[:, None] * np.uint64(2 * n)
+           + np.arange(n, dtype=np.uint64)[None, :] * np.uint64(2))
+    ni = (_hash32(idx).astype(np.float64) / 4294967296.0 * 2.0 - 1.0) * a
+    nq = (_hash32(idx + np.uint64(1)).astype(np.float64) / 4294967296.0 * 2.0 - 1.0) * a
+    out = np.empty((n_ch, n, 2), np.uint8)
+    out[:, :, 0] = np.clip(np.rint(127.5 + 127.5 * (i + ni)), 0, 255).astype(np.uint8)
+    out[:, :, 1] = np.clip(np.rint(127.5 + 127.5 * (q + nq)), 0, 255).astype(np.uint8)
+    return out
+
+
+def load_fixture_cu8(name):
+    """Reference IQ fixture bytes -> uint8 [n, 2]; from tests/golden (committed excerpt) or /root/reference."""
+    p = os.path.join(REFERENCE_ROOT, "tests", "fixtures", "iq", name)
+    return np.fromfile(p, dtype=np.uint8).reshape(-1, 2)

@@ -1,0 +1,50 @@
+"""CPU: libdsdneo_hip.so loads without a GPU and exports every symbol include/ddn_hip.h declares; compute calls
+fail loudly (DDN_ENODEV) instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import ddn
+
+
+def declared_functions():
+    text = open(os.path.join(ddn.ROOT, "include", "ddn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([a-z_0-9]+)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(n for n in names if n.startswith(("ddn_", "simd_", "widen_"))))
+
+
+def test_header_and_binding_agree(built):
+    assert declared_functions() == sorted(ddn.PROTOTYPES.keys())
+
+
+def test_library_exports_every_declared_symbol(built):
+    l = C.CDLL(ddn.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(l, name), name
+    assert ddn.lib().ddn_version().startswith(b"dsdneo-hip")
+    assert ddn.lib().simd_fir_get_impl_name() == b"hip-gfx950"
+
+
+def test_no_cpu_fallback_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ddn.DdnError) as e:
+        ddn.Batch(4)
+    assert "rc=-2" in str(e.value)
+
+
+def test_product_does_not_reference_oracle():
+    """The shipped sources never include/link anything under oracle/."""
+    for sub in ("dsd-neo_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ddn.ROOT, sub)):
+            if "build" in dp:
+                continue
+            for fn in fns:
+                if fn.endswith((".so", ".o", ".pyc")):
+                    continue
+                t = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "ddn_oracle" not in t and "oracle/" not in t.replace("oracle/_ref", ""), os.path.join(dp, fn)
