@@ -9,7 +9,7 @@ A "step" is one pass of the hot path over one batch of synthetic input resident 
 n = 48000 complex cu8 samples (1 s of air time) per channel, block 8192.  Weak scaling: every rank owns its
 own 4096 channels (channels are independent streams — no data-path collective).
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel = k_fir_phase, timed with
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel = k_front_end_fused, timed with
 HIP events on the launch stream inside the C-ABI) and `cpu_baseline` (the oracle's C restatement — or the
 compiled reference when oracle/_ref is present — timed on the host, bounded sample).
 """
@@ -177,9 +177,9 @@ def main():
         msps = total_samples / dt / 1e6
         fir_avg = sum(fir_ms) / len(fir_ms)
         ser_avg = sum(ser_ms) / len(ser_ms)
-        # dominant kernel: k_fir_phase — algorithmic bytes per launch = 6 B/sample x B*n samples
+        # dominant kernel: k_front_end_fused — algorithmic bytes per launch = 6 B/sample x B*n samples
         alg_bytes = BYTES_PER_SAMPLE * B * n
-        dom_ms, dom_name = (fir_avg, "k_fir_phase") if fir_avg >= ser_avg else (ser_avg, "k_fsk_serial")
+        dom_ms, dom_name = fir_avg, "k_front_end_fused"
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "I/Q Msamples/s end-to-end (demod->FEC->MBE) per GPU; % HBM roofline",
@@ -200,7 +200,7 @@ def main():
                        "channels_per_gpu": B, "samples_per_channel": n, "block_len": BLOCK,
                        "parallelism": "channel-sharded x%d" % world, "stages": "widen+lpf+discriminator"},
             "parity": {"checked_channels": len(pick), "bit_exact": exact, "max_abs_err": max_err},
-            "kernels_ms": {"k_fir_phase": round(fir_avg, 4), "k_fsk_serial+carry": round(ser_avg, 4)},
+            "kernels_ms": {"k_front_end_fused": round(fir_avg, 4), "k_carry_update": round(ser_avg, 4)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "bytes_per_sample": BYTES_PER_SAMPLE, "launch_ms": round(dom_ms, 4)},

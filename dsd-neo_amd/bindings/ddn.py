@@ -70,6 +70,12 @@ def lib():
     """Load libdsdneo_hip.so (RTLD_LOCAL) and bind prototypes.  Raises if the library is not built."""
     global _lib
     if _lib is None:
+        try:
+            # When PyTorch is in the process it must load ITS HIP runtime first: two different libamdhip64
+            # images in one process leave the second one without a device ("No HIP GPUs are available").
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
         l = C.CDLL(LIB_PATH)

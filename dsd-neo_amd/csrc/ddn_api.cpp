@@ -52,14 +52,10 @@ struct ddn_batch {
     float taps[DDN_MAX_TAPS + 1];
     int taps_len;
     int center;
-    int fir_tile;
+    int group; // channels per workgroup of the fused kernel (8 or 16)
     float* d_taps;
     ddn_f2* d_carry;      // [B][DDN_CARRY_LEN]
     DdnFskState* d_state; // [B]
-    ddn_f2* d_edge;       // [B][n_tiles][2], grown on demand
-    size_t edge_cap;
-    float* d_pwr;
-    size_t pwr_cap;
     // host-call staging
     void* d_in;
     size_t in_cap;
@@ -110,7 +106,10 @@ ddn_batch_create(const ddn_front_end_config* cfg, ddn_batch** out) {
         return DDN_ERANGE;
     }
     b->center = (b->taps_len - 1) / 2;
-    b->fir_tile = ddn_dev_fir_tile(b->center);
+    {
+        const char* gsel = getenv("DDN_GROUP");
+        b->group = (gsel && atoi(gsel) == 16) ? 16 : ((gsel && atoi(gsel) == 8) ? 8 : DDN_DEFAULT_GROUP);
+    }
     // the reference routes blocks shorter than 2*taps_len floats to its non-FMA scalar unit
     // (src/dsp/simd_fir.cpp:303-306); this build implements the FMA (AVX2-unit) order only.
     if (cfg->block_len < b->taps_len) {
@@ -158,8 +157,6 @@ ddn_batch_destroy(ddn_batch* b) {
     (void)hipFree(b->d_taps);
     (void)hipFree(b->d_carry);
     (void)hipFree(b->d_state);
-    (void)hipFree(b->d_edge);
-    (void)hipFree(b->d_pwr);
     (void)hipFree(b->d_in);
     (void)hipFree(b->d_out);
     for (int i = 0; i < 3; i++) {
@@ -221,65 +218,33 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     hipStream_t st = (hipStream_t)hip_stream;
     const int B = b->cfg.n_channels;
     const int block_len = b->cfg.block_len;
-    const int T = b->fir_tile;
     const long n_blocks = (long)((n + (size_t)block_len - 1) / (size_t)block_len);
-    const int tiles_per_block = (block_len + T - 1) / T;
-    const long n_tiles = n_blocks * tiles_per_block;
-    if (n_tiles > 0x7fffffffL) {
-        ddn_set_error("ddn_front_end_run: too many tiles");
-        return DDN_ERANGE;
-    }
-    int rc = grow((void**)&b->d_edge, &b->edge_cap, sizeof(ddn_f2) * 2 * (size_t)B * (size_t)n_tiles);
-    if (rc != DDN_OK) {
-        return rc;
-    }
-    const int squelch_on = b->cfg.squelch_level > 0.0f ? 1 : 0;
-    if (squelch_on) {
-        rc = grow((void**)&b->d_pwr, &b->pwr_cap, sizeof(float) * (size_t)B * (size_t)n_blocks);
-        if (rc != DDN_OK) {
-            return rc;
-        }
-    }
-    DdnFirArgs fa;
+    const int tiles_per_block = (block_len + DDN_TILE - 1) / DDN_TILE;
+
+    DdnFusedArgs fa;
     fa.in = d_iq;
     fa.out = d_disc;
     fa.carry = b->d_carry;
-    fa.tile_edge = b->d_edge;
-    fa.blk_pwr = b->d_pwr;
+    fa.state = b->d_state;
     fa.ch_stride = n;
     fa.out_stride = n;
     fa.n = (long)n;
+    fa.n_tiles = n_blocks * tiles_per_block;
+    fa.n_channels = B;
     fa.in_fmt = b->cfg.input_format;
     fa.block_len = block_len;
     fa.tiles_per_block = tiles_per_block;
-    fa.n_tiles = (int)n_tiles;
-    fa.n_blocks = (int)n_blocks;
-    fa.squelch_on = squelch_on;
-
-    DdnSerialArgs sa;
-    sa.buf = d_disc;
-    sa.tile_edge = b->d_edge;
-    sa.blk_pwr = b->d_pwr;
-    sa.state = b->d_state;
-    sa.stride = n;
-    sa.n = (long)n;
-    sa.n_channels = B;
-    sa.block_len = block_len;
-    sa.fir_tile = T;
-    sa.tiles_per_block = tiles_per_block;
-    sa.n_tiles = (int)n_tiles;
-    sa.n_blocks = (int)n_blocks;
-    sa.squelch_on = squelch_on;
-    sa.squelch_level = b->cfg.squelch_level;
+    fa.center = b->center;
+    fa.squelch_on = b->cfg.squelch_level > 0.0f ? 1 : 0;
+    fa.squelch_level = b->cfg.squelch_level;
 
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[0], st));
     }
-    HIP_TRY(ddn_dev_launch_fir(&fa, b->taps, b->d_taps, b->center, B, st));
+    HIP_TRY(ddn_dev_launch_fused(&fa, b->taps, b->group, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[1], st));
     }
-    HIP_TRY(ddn_dev_launch_serial(&sa, st));
     HIP_TRY(ddn_dev_launch_carry(d_iq, b->cfg.input_format, n, (long)n, b->d_carry, B, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));

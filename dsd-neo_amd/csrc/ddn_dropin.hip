@@ -14,6 +14,7 @@
 #include <cstring>
 #include <vector>
 
+#include "ddn_atan2f.h"
 #include "ddn_device.h"
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -101,7 +102,7 @@ k_fsk_single(ddn_fsk_modem_state* st, const f2* __restrict__ iq, int pairs, floa
             const float x2 = x * x;
             fr = x * (1.0f + x2 * (-0.3333333333333333f + x2 * 0.2f));
         } else {
-            fr = (float)atan2((double)im, (double)re);
+            fr = ddn_atan2f(im, re);
         }
         dc += 0.00025f * (fr - dc);
         const float c = fr - dc;

@@ -1,29 +1,50 @@
-// ddn_front_end.hip — gfx950 kernels for the dsd-neo FSK front end:
-//   cu8/cf32 widen -> zero-latency symmetric complex channel LPF -> phase delta      (k_fir_phase)
-//   dc centring + peak AGC + clip (serial recurrences) + squelch gate                 (k_fsk_serial)
+// ddn_front_end.hip — gfx950 kernel for the dsd-neo FSK front end, one persistent launch per call:
+//
+//   cu8/cf32 widen -> zero-latency symmetric complex channel LPF -> phase delta   (sample-parallel, VALU-bound)
+//   dc centring + asymmetric peak AGC                                              (per-channel serial chains)
+//   scale to +-30000, clip, store                                                  (sample-parallel)
 //
 // Reference behaviour reproduced (paths relative to the dsd-neo tree):
 //   widen                     src/dsp/simd_widen.cpp:139-149
 //   channel LPF               src/dsp/simd_fir_avx2.cpp:119-143 (per-output FMA chain: centre tap, then
-//                             k = 0..centre-1 of fma(h[k], x[n-d] + x[n+d], acc)), block-edge sample
+//                             k = 0..centre-1 of fma(h[k], x[n-d] + x[n+d], acc)); block-edge sample
 //                             replication src/dsp/simd_fir.cpp:66-85
 //   power / squelch           src/dsp/demod_pipeline.cpp:926-945,1003-1020,1173-1190
 //   discriminator             src/dsp/fsk_modem.c:23-35,89-164
 //
-// Arithmetic contract: every float op below is an IEEE-754 binary32 op in the reference's order; the file is
-// compiled with -ffp-contract=off and fused multiply-adds appear only where the reference's AVX2 unit has
+// Arithmetic contract: every float op is an IEEE-754 binary32 op in the reference's order; the file is compiled
+// with -ffp-contract=off and fused multiply-adds appear only where the reference's AVX2 unit has
 // _mm256_fmadd_ps.  No MFMA: the symmetric pre-add makes the contraction a VALU (v_pk_add/v_pk_fma) job.
 //
-// Data layout in HBM: input [B][n] interleaved I/Q (2 B or 8 B per complex sample), output [B][n] f32,
-// both channel-major so one channel's stream is contiguous (that is what the stream-read hook hands out).
-// Per-channel carried state: CENTER widened samples of FIR history, 5 words of modem state.
+// Work decomposition (MI355X-first, not a translation of the reference's per-stream loop):
+//   * one workgroup owns G channels for the whole call and walks time in tiles of TT = 256 samples;
+//   * G*32 "filter" threads (half a wave per channel, R = 8 outputs per thread, sliding register windows fed
+//     from a padded, bank-conflict-free LDS window) do widen + LPF + phase delta for tile i;
+//   * one extra "recurrence" wave (lane = channel) runs the dc / peak recurrences of tile i-1 sample by sample
+//     in the exact reference order while the filter threads are busy — the recurrences are only parallel
+//     across channels, so they ride on an otherwise idle issue slot instead of a second kernel;
+//   * the filter threads finish tile i-2 (30000/peak scaling, clip, coalesced store) before staging tile i.
+//   HBM traffic is the algorithmic minimum: input read once (+ a 2*CENTER halo per tile from L2), output
+//   written once.  Two barriers per tile; everything else stays in LDS / registers.
+//
+// Data layout in HBM: input [B][n] interleaved I/Q (2 B or 8 B per complex sample), output [B][n] f32, both
+// channel-major so one channel's stream is contiguous (what the stream-read hook hands out).  Per-channel
+// carried state: DDN_CARRY_LEN widened samples of FIR look-back + 5 words of modem state.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ddn_atan2f.h"
 #include "ddn_device.h"
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define DDN_TT 256
+#ifndef DDN_GROUP
+#define DDN_GROUP 16 /* channels per workgroup */
+#endif
+#define DDN_R  8
 
 // ------------------------------------------------------------------------------------------------------
 // helpers
@@ -53,415 +74,484 @@ ddn_phase_delta(f2 cur, f2 prev) {
         const float x2 = x * x;
         return x * (1.0f + x2 * (-0.3333333333333333f + x2 * 0.2f));
     }
-    // large-angle branch: libm atan2f in the reference.  Evaluate in binary64 and round once; this equals
-    // the correctly-rounded binary32 result except in astronomically rare double-rounding cases, and is
-    // within 1 ulp of any faithful libm (tolerance stated in tests/test_front_end_gpu.py).
-    return (float)atan2((double)im, (double)re);
+    return ddn_atan2f(im, re);
+}
+
+// One sample of the modem recurrences (src/dsp/fsk_modem.c:98-133), state in registers.
+// Emits the centred value and the peak to divide by; the division itself is done by the finishing threads.
+__device__ __forceinline__ void
+ddn_modem_step(float fr, float& dc, float& peak, float& c_out, float& pk_out) {
+    dc += 0.00025f * (fr - dc);
+    const float c = fr - dc;
+    const float mag = fabsf(c);
+    const float d = mag - peak;
+    const float up = peak + 0.125f * d;
+    const float dn = peak + 0.00005f * d;
+    float pn = (mag > peak) ? up : dn;
+    if (peak <= 1.0e-7f) {
+        pn = mag;
+    }
+    if (!(mag > 1.0e-7f)) {
+        pn = peak;
+    }
+    peak = pn;
+    c_out = c;
+    pk_out = (pn <= 1.0e-7f) ? 1.0f : pn;
+}
+
+// Same recurrences with the two rare guards (|centred| <= 1e-7, peak <= 1e-7) hoisted out of the dependent
+// chain: the common-case update is computed unconditionally and `rare` records whether either guard would
+// have fired, in which case the caller replays the group through ddn_modem_step.  Identical results.
+__device__ __forceinline__ void
+ddn_modem_step_fast(float fr, float& dc, float& peak, float& c_out, bool& rare) {
+    dc += 0.00025f * (fr - dc);
+    const float c = fr - dc;
+    const float mag = fabsf(c);
+    rare = rare || (peak <= 1.0e-7f) || !(mag > 1.0e-7f);
+    const float d = mag - peak;
+    const float up = peak + 0.125f * d;
+    const float dn = peak + 0.00005f * d;
+    peak = (mag > peak) ? up : dn;
+    c_out = c;
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K1: widen + channel LPF + phase delta.  grid = (tiles, B), 256 threads, R outputs per thread.
-//
-// LDS window: logical element i (0 <= i < T + 2*CENTER) = input sample (tile_start - CENTER + i), already
-// edge-replicated, stored at physical slot i + i/R: thread t's run of R consecutive elements then starts at
-// t*(R+1), an odd multiple of 8 bytes, so a wave's ds_read_b64 at a common logical offset touches all 64
-// banks exactly once (conflict-free) while every address is (thread base + compile-time constant).
 
-template <int CENTER>
-struct DdnTaps {
+struct DdnTapsK {
     float centre;
-    float side[CENTER]; // side[k] multiplies x[n - (CENTER-k)] + x[n + (CENTER-k)]
+    float side[DDN_MAX_CENTER]; // side[k] multiplies x[n - (C-k)] + x[n + (C-k)]
 };
 
-template <int CENTER, int R, bool SKIPZ>
-__global__ __launch_bounds__(256) void
-k_fir_phase(DdnFirArgs a, DdnTaps<CENTER> taps) {
-    constexpr int T = 256 * R;
-    constexpr int W = T + 2 * CENTER;
+struct TileDesc {
+    long start;   // first sample of the tile (call-relative)
+    long blk_start;
+    long blk_end; // end of the reference block the tile belongs to
+    int valid;    // samples in the tile (<= TT)
+    int first;    // 1 = first tile of its block
+};
+
+__device__ __forceinline__ TileDesc
+ddn_tile_at(long it, const DdnFusedArgs& a) {
+    TileDesc t;
+    const long blk = it / a.tiles_per_block;
+    const long j = it - blk * a.tiles_per_block;
+    const long bs = blk * (long)a.block_len;
+    long be = bs + a.block_len;
+    if (be > a.n) {
+        be = a.n;
+    }
+    t.start = bs + j * DDN_TT;
+    t.blk_start = bs;
+    t.blk_end = be;
+    long v = be - t.start;
+    t.valid = (int)(v < 0 ? 0 : (v > DDN_TT ? DDN_TT : v));
+    t.first = (j == 0);
+    return t;
+}
+
+// CENTER_T > 0: fully unrolled sliding-window FIR for that half-length; CENTER_T == 0: run-time half-length
+// (taps in LDS, no register windows) for sample rates without an unrolled instance.
+template <int CENTER_T, int G, bool SKIPZ, int FMT>
+__global__ __launch_bounds__(G * 32 + 64) void
+k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
+    constexpr int TT = DDN_TT;
+    constexpr int R = DDN_R;
+    constexpr int CMAX = (CENTER_T > 0) ? CENTER_T : DDN_MAX_CENTER;
+    constexpr int W = TT + 2 * CMAX;
     constexpr int WP = W + W / R + 1;
-    __shared__ f2 win[WP];
-    __shared__ f2 ylast[256];
+    constexpr int FS = TT + 4; // row stride of the tile buffers (floats), keeps 16-B alignment
+    constexpr int NF = G * 32; // filter threads
+    constexpr int NPRE = (W + 31) / 32; // window samples each filter thread stages per tile
 
-    const int tid = threadIdx.x;
-    const int ch = blockIdx.y;
-    const int blk = blockIdx.x / a.tiles_per_block;
-    const int jt = blockIdx.x - blk * a.tiles_per_block;
-    const long blk_start = (long)blk * a.block_len;
-    long blk_end = blk_start + a.block_len;
-    if (blk_end > a.n) {
-        blk_end = a.n;
-    }
-    const long start = blk_start + (long)jt * T;
-    if (start >= blk_end) {
-        return; // short last block: surplus tiles
-    }
-    const int valid = (int)((blk_end - start) < T ? (blk_end - start) : T);
-
-    // ---- stage the window -------------------------------------------------------------------------
-    const f2* carry = a.carry + (size_t)ch * DDN_CARRY_LEN;
-    for (int i = tid; i < W; i += 256) {
-        long p = start - CENTER + i;
-        f2 v;
-        if (p < 0) {
-            v = carry[DDN_CARRY_LEN + p]; // last samples of the previous call (zeros on a fresh stream)
-        } else {
-            if (p > blk_end - 1) {
-                p = blk_end - 1; // the reference replicates the block's last sample
-            }
-            v = ddn_load_iq(a.in, a.in_fmt, a.ch_stride, ch, p);
-        }
-        win[i + i / R] = v;
-    }
-    __syncthreads();
-
-    // ---- symmetric FIR, R outputs per thread, sliding register windows ------------------------------
-#define PH(off) ((off) + (off) / R)
-    const f2* w = win + tid * (R + 1);
-    f2 acc[R], xm[R], xp[R];
-    const f2 zero = {0.0f, 0.0f};
-    const f2 hc = {taps.centre, taps.centre};
-#pragma unroll
-    for (int j = 0; j < R; j++) {
-        acc[j] = __builtin_elementwise_fma(hc, w[PH(CENTER + j)], zero);
-        xm[j] = w[PH(j)];
-        xp[j] = w[PH(2 * CENTER + j)];
-    }
-#pragma unroll
-    for (int k = 0; k < CENTER; k++) {
-        const float h = taps.side[k];
-        if (!SKIPZ || h != 0.0f) {
-            const f2 hh = {h, h};
-#pragma unroll
-            for (int j = 0; j < R; j++) {
-                acc[j] = __builtin_elementwise_fma(hh, xm[j] + xp[j], acc[j]);
-            }
-        }
-        if (k + 1 < CENTER) {
-#pragma unroll
-            for (int j = 0; j < R - 1; j++) {
-                xm[j] = xm[j + 1];
-            }
-            xm[R - 1] = w[PH(k + 1 + R - 1)];
-#pragma unroll
-            for (int j = R - 1; j > 0; j--) {
-                xp[j] = xp[j - 1];
-            }
-            xp[0] = w[PH(2 * CENTER - (k + 1))];
-        }
-    }
-#undef PH
-
-    // ---- phase delta against the previous output ----------------------------------------------------
-    ylast[tid] = acc[R - 1];
-    __syncthreads();
-    f2 prev = (tid > 0) ? ylast[tid - 1] : zero;
-    float fq[R];
-#pragma unroll
-    for (int j = 0; j < R; j++) {
-        fq[j] = ddn_phase_delta(acc[j], prev);
-        prev = acc[j];
-    }
-    // tile edges: first output (the serial kernel forms its phase delta against the previous tile's last
-    // output) and last valid output
-    f2* edge = a.tile_edge + ((size_t)ch * a.n_tiles + blockIdx.x) * 2;
-    if (tid == 0) {
-        edge[0] = acc[0];
-        fq[0] = 0.0f;
-    }
-    const int lastv = valid - 1;
-    if (tid == lastv / R) {
-        f2 yl = acc[0];
-#pragma unroll
-        for (int j = 1; j < R; j++) {
-            if (j == lastv % R) {
-                yl = acc[j];
-            }
-        }
-        edge[1] = yl;
-    }
-
-    // ---- block power for the squelch gate: first <=512 floats of the block's LPF output, sequential
-    //      binary64 accumulation exactly like mean_power() -------------------------------------------
-    if (a.squelch_on && jt == 0) {
-        __syncthreads();
-        f2* ybuf = win; // window no longer needed
-        if (tid * R < 256) {
-#pragma unroll
-            for (int j = 0; j < R; j++) {
-                if (tid * R + j < 256) {
-                    ybuf[tid * R + j] = acc[j];
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            const int len = (valid * 2 > 512) ? 512 : valid * 2;
-            const float* s = (const float*)ybuf;
-            double p = 0.0, t = 0.0;
-            for (int i = 0; i < len; i++) {
-                const double v = (double)s[i];
-                t += v;
-                p += v * v;
-            }
-            const double dc = (t * t) / (double)len;
-            double e = p - dc;
-            if (e < 0.0) {
-                e = 0.0;
-            }
-            a.blk_pwr[(size_t)ch * a.n_blocks + blk] = (float)(e / (double)len);
-        }
-    }
-
-    // ---- store raw phase deltas ----------------------------------------------------------------------
-    float* o = a.out + (size_t)ch * a.out_stride + start + (long)tid * R;
-    if ((tid + 1) * R <= valid) {
-        if constexpr ((R % 4) == 0) {
-            if ((((size_t)o) & 15) == 0) {
-#pragma unroll
-                for (int j = 0; j < R; j += 4) {
-                    float4 v4 = make_float4(fq[j], fq[j + 1], fq[j + 2], fq[j + 3]);
-                    *(float4*)(o + j) = v4;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < R; j++) {
-                    o[j] = fq[j];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < R; j++) {
-                o[j] = fq[j];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            if (tid * R + j < valid) {
-                o[j] = fq[j];
-            }
-        }
-    }
-}
-
-// Generic-centre variant (any odd taps_len <= 143): one output per thread per step, taps in LDS.  Used for
-// sample rates whose tap count has no unrolled instance.  Same arithmetic order.
-__global__ __launch_bounds__(256) void
-k_fir_phase_generic(DdnFirArgs a, const float* __restrict__ taps_dev, int center) {
-    constexpr int T = 1024;
-    __shared__ f2 win[T + 2 * DDN_MAX_CENTER];
-    __shared__ f2 ybuf[T];
+    __shared__ f2 win[G][WP];
+    __shared__ __attribute__((aligned(16))) float Fb[2][G][FS]; // raw phase delta -> centred value (in place)
+    __shared__ __attribute__((aligned(16))) float Pb[2][G][FS]; // peak to divide by
+    __shared__ f2 chan_last[2][G];                              // last LPF output of the previous tile
     __shared__ float stap[DDN_MAX_CENTER + 1];
-    const int tid = threadIdx.x;
-    const int ch = blockIdx.y;
-    const int blk = blockIdx.x / a.tiles_per_block;
-    const int jt = blockIdx.x - blk * a.tiles_per_block;
-    const long blk_start = (long)blk * a.block_len;
-    long blk_end = blk_start + a.block_len;
-    if (blk_end > a.n) {
-        blk_end = a.n;
-    }
-    const long start = blk_start + (long)jt * T;
-    if (start >= blk_end) {
-        return;
-    }
-    const int valid = (int)((blk_end - start) < T ? (blk_end - start) : T);
-    const int W = T + 2 * center;
-    const f2* carry = a.carry + (size_t)ch * DDN_CARRY_LEN;
-    for (int i = tid; i < W; i += 256) {
-        long p = start - center + i;
-        f2 v;
-        if (p < 0) {
-            v = carry[DDN_CARRY_LEN + p];
-        } else {
-            if (p > blk_end - 1) {
-                p = blk_end - 1;
-            }
-            v = ddn_load_iq(a.in, a.in_fmt, a.ch_stride, ch, p);
-        }
-        win[i] = v;
-    }
-    if (tid <= center) {
-        stap[tid] = taps_dev[tid];
-    }
-    __syncthreads();
-    const f2 zero = {0.0f, 0.0f};
-    for (int o = tid; o < T; o += 256) {
-        const f2 hc = {stap[center], stap[center]};
-        f2 acc = __builtin_elementwise_fma(hc, win[o + center], zero);
-        for (int k = 0; k < center; k++) {
-            const float h = stap[k];
-            if (h == 0.0f) {
-                continue;
-            }
-            const int d = center - k;
-            const f2 hh = {h, h};
-            acc = __builtin_elementwise_fma(hh, win[o + center - d] + win[o + center + d], acc);
-        }
-        ybuf[o] = acc;
-    }
-    __syncthreads();
-    f2* edge = a.tile_edge + ((size_t)ch * a.n_tiles + blockIdx.x) * 2;
-    if (tid == 0) {
-        edge[0] = ybuf[0];
-        edge[1] = ybuf[valid - 1];
-    }
-    float* out = a.out + (size_t)ch * a.out_stride + start;
-    for (int o = tid; o < valid; o += 256) {
-        out[o] = (o == 0) ? 0.0f : ddn_phase_delta(ybuf[o], ybuf[o - 1]);
-    }
-    if (a.squelch_on && jt == 0 && tid == 0) {
-        const int len = (valid * 2 > 512) ? 512 : valid * 2;
-        const float* s = (const float*)ybuf;
-        double p = 0.0, t = 0.0;
-        for (int i = 0; i < len; i++) {
-            const double v = (double)s[i];
-            t += v;
-            p += v * v;
-        }
-        const double dc = (t * t) / (double)len;
-        double e = p - dc;
-        if (e < 0.0) {
-            e = 0.0;
-        }
-        a.blk_pwr[(size_t)ch * a.n_blocks + blk] = (float)(e / (double)len);
-    }
-}
+    extern __shared__ f2 ysq[]; // [G][256] first LPF outputs of a block (squelch builds only)
 
-// ------------------------------------------------------------------------------------------------------
-// K2: the per-channel serial recurrences.  One workgroup owns G channels and walks time in tiles of TT
-// samples: all 256 threads move a [G][TT] tile of raw phase deltas HBM -> LDS (coalesced along time),
-// lanes 0..G-1 of wave 0 run the dc / peak recurrences sample by sample (exact reference order), then all
-// threads move the finished tile LDS -> HBM.
-
-template <int G, int TT>
-__global__ __launch_bounds__(256) void
-k_fsk_serial(DdnSerialArgs a) {
-    __shared__ float f[G][TT + 1];
     const int tid = threadIdx.x;
+    const bool is_filter = tid < NF;
+    const int g = is_filter ? (tid >> 5) : (tid - NF); // channel slot
+    const int u = tid & 31;
     const int ch0 = blockIdx.x * G;
     const int nch = (a.n_channels - ch0) < G ? (a.n_channels - ch0) : G;
+    const int C = (CENTER_T > 0) ? CENTER_T : a.center;
+    const int ch = ch0 + (g < nch ? g : 0); // clamp: surplus slots recompute channel ch0, never store
+    const bool ch_ok = g < nch;
+    const long NT = a.n_tiles;
 
-    // per-lane carried state
-    float prev_i = 0.f, prev_q = 0.f, dc = 0.f, peak = 0.f;
+    // recurrence-wave state
+    float dc = 0.f, peak = 0.f;
     int have_prev = 0;
-    const int my = (tid < nch) ? (ch0 + tid) : -1;
-    if (my >= 0) {
-        const DdnFskState s = a.state[my];
-        prev_i = s.prev_i;
-        prev_q = s.prev_q;
-        have_prev = s.have_prev;
+    int squelched = 0;
+    if (!is_filter && ch_ok && g < G) {
+        const DdnFskState s = a.state[ch];
         dc = s.dc_est;
         peak = s.peak_est;
+        have_prev = s.have_prev;
+        const f2 pv = {s.prev_i, s.prev_q};
+        chan_last[0][g] = pv;
+    }
+    if (tid <= C) {
+        stap[tid] = (tid == C) ? taps.centre : taps.side[tid];
+    }
+    if (!is_filter) {
+        // the recurrence wave is latency-bound and issues little: let it win arbitration on its SIMD
+        __builtin_amdgcn_s_setprio(3);
+    }
+    // raw samples of the NEXT tile, fetched while the current one is filtered (hides HBM latency)
+    uint32_t pre_u[(FMT == DDN_IN_CU8) ? NPRE : 1];
+    f2 pre_f[(FMT == DDN_IN_CF32) ? NPRE : 1];
+    __syncthreads();
+
+    for (long it = 0; it < NT + 2; it++) {
+        // ================= phase A: finish tile it-2, stage tile it =====================================
+        if (is_filter) {
+            if (it >= 2) {
+                const TileDesc t2 = ddn_tile_at(it - 2, a);
+                const int b = (int)((it - 2) & 1);
+                float* o = a.out + (size_t)ch * a.out_stride + t2.start;
+                const bool al = ((((size_t)o) & 15) == 0);
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int t = half * 128 + u * 4;
+                    const f4 c4 = *(const f4*)&Fb[b][g][t];
+                    const f4 p4 = *(const f4*)&Pb[b][g][t];
+                    f4 y;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float v = c4[k] * (30000.0f / p4[k]);
+                        v = (v > 32767.0f) ? 32767.0f : ((v < -32768.0f) ? -32768.0f : v);
+                        y[k] = v;
+                    }
+                    if (ch_ok) {
+                        if (al && t + 4 <= t2.valid) {
+                            *(f4*)(o + t) = y;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (t + k < t2.valid) {
+                                    o[t + k] = y[k];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (it < NT) {
+                const int Weff = TT + 2 * C;
+                if (it == 0) {
+                    // first tile of the call: look-back comes from the carried history, fetched synchronously
+                    const TileDesc tc = ddn_tile_at(it, a);
+                    const f2* carry = a.carry + (size_t)ch * DDN_CARRY_LEN;
+                    for (int i = u; i < Weff; i += 32) {
+                        long p = tc.start - C + i;
+                        f2 v;
+                        if (p < 0) {
+                            v = carry[DDN_CARRY_LEN + p];
+                        } else {
+                            if (p > tc.blk_end - 1) {
+                                p = tc.blk_end - 1; // the reference replicates the block's last sample
+                            }
+                            v = ddn_load_iq(a.in, FMT, a.ch_stride, ch, p);
+                        }
+                        win[g][i + i / R] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPRE; k++) {
+                        const int i = u + 32 * k;
+                        if (i < Weff) {
+                            f2 v;
+                            if constexpr (FMT == DDN_IN_CU8) {
+                                const uint32_t r = pre_u[k];
+                                const float inv = 1.0f / 127.5f;
+                                v.x = ((float)(r & 0xFF) - 127.5f) * inv;
+                                v.y = ((float)(r >> 8) - 127.5f) * inv;
+                            } else {
+                                v = pre_f[k];
+                            }
+                            win[g][i + i / R] = v;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ================= phase B: filter tile it  ||  recurrences of tile it-1 ========================
+        if (is_filter) {
+            if (it + 1 < NT) {
+                const TileDesc tn = ddn_tile_at(it + 1, a);
+                const int Weff = TT + 2 * C;
+                if (tn.valid > 0) {
+#pragma unroll
+                    for (int k = 0; k < NPRE; k++) {
+                        const int i = u + 32 * k;
+                        long p = tn.start - C + i;
+                        if (p > tn.blk_end - 1) {
+                            p = tn.blk_end - 1;
+                        }
+                        if (i < Weff) {
+                            if constexpr (FMT == DDN_IN_CU8) {
+                                pre_u[k] = *((const uint16_t*)a.in + (size_t)ch * a.ch_stride + p);
+                            } else {
+                                pre_f[k] = *((const f2*)a.in + (size_t)ch * a.ch_stride + p);
+                            }
+                        }
+                    }
+                }
+            }
+            const TileDesc tc = ddn_tile_at(it < NT ? it : 0, a);
+            if (it < NT && tc.valid <= 0 && u == 0) {
+                chan_last[(it & 1) ^ 1][g] = chan_last[it & 1][g]; // surplus tile of a short last block
+            }
+            if (it < NT && tc.valid > 0) {
+                f2 acc[R];
+                const f2 zero = {0.0f, 0.0f};
+                // a block shorter than taps_len samples goes to the reference's non-fused scalar unit
+                // (src/dsp/simd_fir.cpp:303-306,350-356): separate multiply and add roundings
+                const bool short_blk = (tc.blk_end - tc.blk_start) < (long)(2 * C + 1);
+                if (short_blk) {
+                    const f2* w = &win[g][0];
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        const int o = u * R + j + C;
+                        acc[j] = zero + stap[C] * w[o + o / R];
+                    }
+                    for (int k = 0; k < C; k++) {
+                        const float h = stap[k];
+                        if (h == 0.0f) {
+                            continue;
+                        }
+                        const int d = C - k;
+#pragma unroll
+                        for (int j = 0; j < R; j++) {
+                            const int om = u * R + j + C - d;
+                            const int op = u * R + j + C + d;
+                            acc[j] = acc[j] + h * (w[om + om / R] + w[op + op / R]);
+                        }
+                    }
+                } else if constexpr (CENTER_T > 0) {
+#define PH(off) ((off) + (off) / R)
+                    const f2* w = &win[g][u * (R + 1)];
+                    f2 xm[R], xp[R];
+                    const f2 hc = {taps.centre, taps.centre};
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        acc[j] = __builtin_elementwise_fma(hc, w[PH(CENTER_T + j)], zero);
+                        xm[j] = w[PH(j)];
+                        xp[j] = w[PH(2 * CENTER_T + j)];
+                    }
+#pragma unroll
+                    for (int k = 0; k < CENTER_T; k++) {
+                        const float h = taps.side[k];
+                        if (!SKIPZ || h != 0.0f) {
+                            const f2 hh = {h, h};
+#pragma unroll
+                            for (int j = 0; j < R; j++) {
+                                acc[j] = __builtin_elementwise_fma(hh, xm[j] + xp[j], acc[j]);
+                            }
+                        }
+                        if (k + 1 < CENTER_T) {
+#pragma unroll
+                            for (int j = 0; j < R - 1; j++) {
+                                xm[j] = xm[j + 1];
+                            }
+                            xm[R - 1] = w[PH(k + 1 + R - 1)];
+#pragma unroll
+                            for (int j = R - 1; j > 0; j--) {
+                                xp[j] = xp[j - 1];
+                            }
+                            xp[0] = w[PH(2 * CENTER_T - (k + 1))];
+                        }
+                    }
+#undef PH
+                } else {
+                    const f2* w = &win[g][0];
+                    const f2 hc = {stap[C], stap[C]};
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        const int o = u * R + j + C;
+                        acc[j] = __builtin_elementwise_fma(hc, w[o + o / R], zero);
+                    }
+                    for (int k = 0; k < C; k++) {
+                        const float h = stap[k];
+                        if (h == 0.0f) {
+                            continue;
+                        }
+                        const int d = C - k;
+                        const f2 hh = {h, h};
+#pragma unroll
+                        for (int j = 0; j < R; j++) {
+                            const int om = u * R + j + C - d;
+                            const int op = u * R + j + C + d;
+                            acc[j] = __builtin_elementwise_fma(hh, w[om + om / R] + w[op + op / R], acc[j]);
+                        }
+                    }
+                }
+                // phase delta against the previous output (previous lane / previous tile)
+                const int b = (int)(it & 1);
+                f2 prev;
+                prev.x = __shfl_up(acc[R - 1].x, 1);
+                prev.y = __shfl_up(acc[R - 1].y, 1);
+                if (u == 0) {
+                    prev = chan_last[b][g];
+                }
+                const int lastv = tc.valid - 1;
+                if (u == lastv / R) {
+                    f2 yl = acc[0];
+#pragma unroll
+                    for (int j = 1; j < R; j++) {
+                        if (j == lastv % R) {
+                            yl = acc[j];
+                        }
+                    }
+                    chan_last[b ^ 1][g] = yl;
+                }
+                f4 q0, q1;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const float fq = ddn_phase_delta(acc[j], prev);
+                    prev = acc[j];
+                    if (j < 4) {
+                        q0[j] = fq;
+                    } else {
+                        q1[j - 4] = fq;
+                    }
+                }
+                *(f4*)&Fb[b][g][u * R] = q0;
+                *(f4*)&Fb[b][g][u * R + 4] = q1;
+                if (a.squelch_on && tc.first) {
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        ysq[g * 256 + u * R + j] = acc[j];
+                    }
+                }
+            }
+        } else if (it >= 1 && it <= NT && ch_ok && g < G) {
+            const TileDesc tp = ddn_tile_at(it - 1, a);
+            const int b = (int)((it - 1) & 1);
+            float* F = &Fb[b][g][0];
+            float* P = &Pb[b][g][0];
+            if (a.squelch_on && tp.first) {
+                // block power: first <=512 floats of the block's LPF output, sequential binary64 sums
+                // exactly like mean_power() (src/dsp/demod_pipeline.cpp:926-945)
+                const int len = (int)((tp.blk_end - tp.start) * 2 > 512 ? 512 : (tp.blk_end - tp.start) * 2);
+                const float* s = (const float*)&ysq[g * 256];
+                double pw = 0.0, tot = 0.0;
+                for (int i = 0; i < len; i++) {
+                    const double v = (double)s[i];
+                    tot += v;
+                    pw += v * v;
+                }
+                const double dcc = (tot * tot) / (double)len;
+                double e = pw - dcc;
+                if (e < 0.0) {
+                    e = 0.0;
+                }
+                const float chp = (float)(e / (double)len);
+                squelched = (chp < a.squelch_level) ? 1 : 0;
+            }
+            if (squelched) {
+                // zeros out + modem reset (src/dsp/demod_pipeline.cpp:1179-1184)
+                have_prev = 0;
+                dc = 0.f;
+                peak = 0.f;
+                for (int t = 0; t < tp.valid; t++) {
+                    F[t] = 0.0f;
+                    P[t] = 1.0f;
+                }
+            } else {
+                int t = 0;
+                if (!have_prev && tp.valid > 0) {
+                    // first sample of a (re)started stream: output 0, remember it (src/dsp/fsk_modem.c:148-153)
+                    have_prev = 1;
+                    F[0] = 0.0f;
+                    P[0] = 1.0f;
+                    t = 1;
+                }
+                // peel to a 16-byte boundary, then groups of 8 samples: the next group's LDS reads are issued
+                // before the current group's dependent chain so their latency hides behind it
+                for (; t < tp.valid && (t & 3) != 0; t++) {
+                    float c, pk;
+                    ddn_modem_step(F[t], dc, peak, c, pk);
+                    F[t] = c;
+                    P[t] = pk;
+                }
+                f4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
+                if (t + 8 <= tp.valid) {
+                    fa = *(const f4*)&F[t];
+                    fb = *(const f4*)&F[t + 4];
+                }
+                for (; t + 8 <= tp.valid; t += 8) {
+                    f4 na = fa, nb = fb;
+                    if (t + 16 <= tp.valid) {
+                        na = *(const f4*)&F[t + 8];
+                        nb = *(const f4*)&F[t + 12];
+                    }
+                    const float dc0 = dc, pk0 = peak;
+                    bool rare = false;
+                    f4 ca, cb, pa, pb;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float c;
+                        ddn_modem_step_fast(fa[k], dc, peak, c, rare);
+                        ca[k] = c;
+                        pa[k] = peak;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float c;
+                        ddn_modem_step_fast(fb[k], dc, peak, c, rare);
+                        cb[k] = c;
+                        pb[k] = peak;
+                    }
+                    if (rare) {
+                        dc = dc0;
+                        peak = pk0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            float c, pk;
+                            ddn_modem_step(fa[k], dc, peak, c, pk);
+                            ca[k] = c;
+                            pa[k] = pk;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            float c, pk;
+                            ddn_modem_step(fb[k], dc, peak, c, pk);
+                            cb[k] = c;
+                            pb[k] = pk;
+                        }
+                    }
+                    *(f4*)&F[t] = ca;
+                    *(f4*)&F[t + 4] = cb;
+                    *(f4*)&P[t] = pa;
+                    *(f4*)&P[t + 4] = pb;
+                    fa = na;
+                    fb = nb;
+                }
+                for (; t < tp.valid; t++) {
+                    float c, pk;
+                    ddn_modem_step(F[t], dc, peak, c, pk);
+                    F[t] = c;
+                    P[t] = pk;
+                }
+            }
+        }
+        __syncthreads();
     }
 
-    for (long t0 = 0; t0 < a.n; t0 += TT) {
-        const int tn = (int)((a.n - t0) < TT ? (a.n - t0) : TT);
-        // ---- load tile; patch K1-tile-first samples with the cross-tile phase delta ------------------
-        for (int idx = tid; idx < G * TT; idx += 256) {
-            const int g = idx / TT, t = idx - g * TT;
-            if (g < nch && t < tn) {
-                const long p = t0 + t;
-                float v = a.buf[(size_t)(ch0 + g) * a.stride + p];
-                const long blk = p / a.block_len;
-                const long rel = p - blk * a.block_len;
-                if ((rel % a.fir_tile) == 0) {
-                    const long tile = blk * a.tiles_per_block + rel / a.fir_tile;
-                    const f2* e = a.tile_edge + ((size_t)(ch0 + g) * a.n_tiles + tile) * 2;
-                    const f2 cur = e[0];
-                    if (p > 0) {
-                        long ptile = tile - 1;
-                        if (rel == 0) { // previous block may have fewer tiles in use: its last tile
-                            const long pblk = blk - 1;
-                            ptile = pblk * a.tiles_per_block + (a.block_len - 1) / a.fir_tile;
-                        }
-                        const f2 pv = (a.tile_edge + ((size_t)(ch0 + g) * a.n_tiles + ptile) * 2)[1];
-                        v = ddn_phase_delta(cur, pv);
-                    } else {
-                        const DdnFskState s = a.state[ch0 + g];
-                        const f2 pv = {s.prev_i, s.prev_q};
-                        v = ddn_phase_delta(cur, pv); // only used when have_prev
-                    }
-                }
-                f[g][t] = v;
-            }
-        }
-        __syncthreads();
-        // ---- serial part -----------------------------------------------------------------------------
-        if (my >= 0) {
-            for (int t = 0; t < tn; t++) {
-                const long p = t0 + t;
-                const long blk = p / a.block_len;
-                const long rel = p - blk * a.block_len;
-                if (a.squelch_on) {
-                    const float pw = a.blk_pwr[(size_t)my * a.n_blocks + blk];
-                    if (pw < a.squelch_level) {
-                        // squelched block: zeros out, modem reset (src/dsp/demod_pipeline.cpp:1179-1184)
-                        have_prev = 0;
-                        dc = 0.f;
-                        peak = 0.f;
-                        prev_i = 0.f;
-                        prev_q = 0.f;
-                        f[tid][t] = 0.0f;
-                        continue;
-                    }
-                }
-                (void)rel;
-                if (!have_prev) {
-                    have_prev = 1;
-                    f[tid][t] = 0.0f;
-                    continue;
-                }
-                const float fr = f[tid][t];
-                dc += 0.00025f * (fr - dc);
-                const float c = fr - dc;
-                const float mag = fabsf(c);
-                if (mag > 1.0e-7f) {
-                    if (peak <= 1.0e-7f) {
-                        peak = mag;
-                    } else if (mag > peak) {
-                        peak += 0.125f * (mag - peak);
-                    } else {
-                        peak += 0.00005f * (mag - peak);
-                    }
-                }
-                float pk = peak;
-                if (pk <= 1.0e-7f) {
-                    pk = 1.0f;
-                }
-                float y = c * (30000.0f / pk);
-                if (y > 32767.0f) {
-                    y = 32767.0f;
-                } else if (y < -32768.0f) {
-                    y = -32768.0f;
-                }
-                f[tid][t] = y;
-            }
-        }
-        __syncthreads();
-        // ---- store ----------------------------------------------------------------------------------
-        for (int idx = tid; idx < G * TT; idx += 256) {
-            const int g = idx / TT, t = idx - g * TT;
-            if (g < nch && t < tn) {
-                a.buf[(size_t)(ch0 + g) * a.stride + t0 + t] = f[g][t];
-            }
-        }
-        __syncthreads();
-    }
-    if (my >= 0 && a.n > 0) {
-        // prev sample = last LPF output of this call (only meaningful when have_prev)
-        const long lastp = a.n - 1;
-        const long blk = lastp / a.block_len;
-        const long rel = lastp - blk * a.block_len;
-        const long tile = blk * a.tiles_per_block + rel / a.fir_tile;
-        const f2 yl = (a.tile_edge + ((size_t)my * a.n_tiles + tile) * 2)[1];
+    if (!is_filter && ch_ok && g < G && a.n > 0) {
+        const f2 yl = chan_last[(int)(NT & 1)][g];
         DdnFskState s;
         s.prev_i = have_prev ? yl.x : 0.f;
         s.prev_q = have_prev ? yl.y : 0.f;
         s.have_prev = have_prev;
         s.dc_est = dc;
         s.peak_est = peak;
-        a.state[my] = s;
+        a.state[ch] = s;
     }
 }
 
@@ -493,56 +583,47 @@ k_zero_u32(uint32_t* p, size_t n) {
 // ------------------------------------------------------------------------------------------------------
 // launchers (called from ddn_api.cpp)
 
-template <int CENTER, int R>
+template <int CENTER_T, int G, int FMT>
 static hipError_t
-launch_fir_t(const DdnFirArgs& a, const float* taps, bool has_zero, dim3 grid, hipStream_t st) {
-    DdnTaps<CENTER> tp;
-    tp.centre = taps[CENTER];
-    for (int k = 0; k < CENTER; k++) {
-        tp.side[k] = taps[k];
-    }
+launch_fused_t(const DdnFusedArgs& a, const DdnTapsK& tp, bool has_zero, hipStream_t st) {
+    dim3 grid((unsigned)((a.n_channels + G - 1) / G));
+    dim3 block(G * 32 + 64);
+    const size_t dyn = a.squelch_on ? (size_t)G * 256 * sizeof(f2) : 0;
     if (has_zero) {
-        hipLaunchKernelGGL((k_fir_phase<CENTER, R, true>), grid, dim3(256), 0, st, a, tp);
+        hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, true, FMT>), grid, block, dyn, st, a, tp);
     } else {
-        hipLaunchKernelGGL((k_fir_phase<CENTER, R, false>), grid, dim3(256), 0, st, a, tp);
+        hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, false, FMT>), grid, block, dyn, st, a, tp);
     }
     return hipGetLastError();
 }
 
-extern "C" int
-ddn_dev_fir_tile(int center) {
-    switch (center) {
-        case 67: return 256 * DDN_FIR_R;
-        case 33: return 256 * DDN_FIR_R;
-        default: return 1024;
+template <int G, int FMT>
+static hipError_t
+launch_fused_c(const DdnFusedArgs& a, const DdnTapsK& tp, bool has_zero, hipStream_t st) {
+    switch (a.center) {
+        case 67: return launch_fused_t<67, G, FMT>(a, tp, has_zero, st);
+        case 33: return launch_fused_t<33, G, FMT>(a, tp, has_zero, st);
+        default: return launch_fused_t<0, G, FMT>(a, tp, true, st);
     }
 }
 
 extern "C" hipError_t
-ddn_dev_launch_fir(const DdnFirArgs* a, const float* taps_host, const float* taps_dev, int center, int n_channels,
-                   hipStream_t st) {
+ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, hipStream_t st) {
+    const int C = a->center;
+    DdnTapsK tp;
     bool has_zero = false;
-    for (int k = 0; k < center; k++) {
-        if (taps_host[k] == 0.0f) {
+    tp.centre = taps_host[C];
+    for (int k = 0; k < DDN_MAX_CENTER; k++) {
+        tp.side[k] = (k < C) ? taps_host[k] : 0.0f;
+        if (k < C && taps_host[k] == 0.0f) {
             has_zero = true;
         }
     }
-    dim3 grid((unsigned)a->n_tiles, (unsigned)n_channels);
-    switch (center) {
-        case 67: return launch_fir_t<67, DDN_FIR_R>(*a, taps_host, has_zero, grid, st);
-        case 33: return launch_fir_t<33, DDN_FIR_R>(*a, taps_host, has_zero, grid, st);
-        default:
-            hipLaunchKernelGGL(k_fir_phase_generic, grid, dim3(256), 0, st, *a, taps_dev, center);
-            return hipGetLastError();
+    (void)group;
+    if (a->in_fmt == DDN_IN_CU8) {
+        return launch_fused_c<DDN_GROUP, DDN_IN_CU8>(*a, tp, has_zero, st);
     }
-}
-
-extern "C" hipError_t
-ddn_dev_launch_serial(const DdnSerialArgs* a, hipStream_t st) {
-    constexpr int G = 16;
-    dim3 grid((unsigned)((a->n_channels + G - 1) / G));
-    hipLaunchKernelGGL((k_fsk_serial<G, 256>), grid, dim3(256), 0, st, *a);
-    return hipGetLastError();
+    return launch_fused_c<DDN_GROUP, DDN_IN_CF32>(*a, tp, has_zero, st);
 }
 
 extern "C" hipError_t
