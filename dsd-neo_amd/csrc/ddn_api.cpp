@@ -237,6 +237,18 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     fa.center = b->center;
     fa.squelch_on = b->cfg.squelch_level > 0.0f ? 1 : 0;
     fa.squelch_level = b->cfg.squelch_level;
+    {
+        const char* d = getenv("DDN_DBG");
+        fa.dbg = d ? atoi(d) : 0;
+        fa.dbg_out = nullptr;
+        if (fa.dbg & 64) {
+            static long long* dbg_buf = nullptr;
+            if (!dbg_buf) {
+                (void)hipMalloc(&dbg_buf, 64 * 4 * sizeof(long long));
+            }
+            fa.dbg_out = dbg_buf;
+        }
+    }
 
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[0], st));
@@ -249,6 +261,16 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
         b->ev_valid = 1;
+    }
+    if (fa.dbg_out && getenv("DDN_DBG_PRINT")) {
+        long long h[64 * 4];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, fa.dbg_out, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 10; w++) {
+            fprintf(stderr, "wave %d: simd %lld  phaseA %lld  phaseB %lld  barrier-wait %lld cycles/tile\n", w, h[w * 4],
+                    h[w * 4 + 1] / (long long)fa.n_tiles, h[w * 4 + 2] / (long long)fa.n_tiles,
+                    h[w * 4 + 3] / (long long)fa.n_tiles);
+        }
     }
     return DDN_OK;
 }

@@ -67,7 +67,7 @@ ddn_atanf_core(float x) {
     return (hx < 0) ? -r : r;
 }
 
-__device__ __forceinline__ float
+__device__ __noinline__ float
 ddn_atan2f(float y, float x) {
     const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
                 pi_lo = -8.7422776573e-08f;

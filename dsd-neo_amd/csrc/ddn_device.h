@@ -36,6 +36,8 @@ typedef struct DdnFusedArgs {
     int center;
     int squelch_on;
     float squelch_level;
+    long long* dbg_out; /* optional: per-wave phase timings of workgroup 0 (DDN_DBG bit 6) */
+    int dbg; /* timing experiments only (DDN_DBG env): 1 skip recurrences, 2 skip filter, 4 skip finish, 8 skip staging */
 } DdnFusedArgs;
 
 #ifdef __cplusplus

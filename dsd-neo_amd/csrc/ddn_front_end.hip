@@ -77,42 +77,33 @@ ddn_phase_delta(f2 cur, f2 prev) {
     return ddn_atan2f(im, re);
 }
 
-// One sample of the modem recurrences (src/dsp/fsk_modem.c:98-133), state in registers.
-// Emits the centred value and the peak to divide by; the division itself is done by the finishing threads.
-__device__ __forceinline__ void
-ddn_modem_step(float fr, float& dc, float& peak, float& c_out, float& pk_out) {
-    dc += 0.00025f * (fr - dc);
-    const float c = fr - dc;
+// One sample of the peak-tracking AGC recurrence (src/dsp/fsk_modem.c:116-133) on the centred value c.
+// Returns the peak to divide by; the division itself is done by the finishing threads.
+__device__ __forceinline__ float
+ddn_peak_step(float c, float& peak) {
     const float mag = fabsf(c);
-    const float d = mag - peak;
-    const float up = peak + 0.125f * d;
-    const float dn = peak + 0.00005f * d;
-    float pn = (mag > peak) ? up : dn;
-    if (peak <= 1.0e-7f) {
-        pn = mag;
+    if (mag > 1.0e-7f) {
+        if (peak <= 1.0e-7f) {
+            peak = mag;
+        } else if (mag > peak) {
+            peak += 0.125f * (mag - peak);
+        } else {
+            peak += 0.00005f * (mag - peak);
+        }
     }
-    if (!(mag > 1.0e-7f)) {
-        pn = peak;
-    }
-    peak = pn;
-    c_out = c;
-    pk_out = (pn <= 1.0e-7f) ? 1.0f : pn;
+    return (peak <= 1.0e-7f) ? 1.0f : peak;
 }
 
-// Same recurrences with the two rare guards (|centred| <= 1e-7, peak <= 1e-7) hoisted out of the dependent
-// chain: the common-case update is computed unconditionally and `rare` records whether either guard would
-// have fired, in which case the caller replays the group through ddn_modem_step.  Identical results.
-__device__ __forceinline__ void
-ddn_modem_step_fast(float fr, float& dc, float& peak, float& c_out, bool& rare) {
-    dc += 0.00025f * (fr - dc);
-    const float c = fr - dc;
-    const float mag = fabsf(c);
-    rare = rare || (peak <= 1.0e-7f) || !(mag > 1.0e-7f);
-    const float d = mag - peak;
-    const float up = peak + 0.125f * d;
-    const float dn = peak + 0.00005f * d;
-    peak = (mag > peak) ? up : dn;
-    c_out = c;
+// Common-case form with both rare guards (|c| <= 1e-7, peak <= 1e-7) hoisted out; the caller checks once per
+// group whether a guard could have fired and replays the group through ddn_peak_step if so.
+//   (mag > peak ? 0.125f : 0.00005f) * d == max(0.125f*d, 0.00005f*d)   with d = mag - peak:
+// d > 0 makes the 0.125 product the larger one, d < 0 the 0.00005 product, d == 0 gives +0 for both — the same
+// rounded product without a compare/select in the dependent chain.
+__device__ __forceinline__ float
+ddn_peak_step_fast(float c, float& peak) {
+    const float d = fabsf(c) - peak;
+    peak = peak + fmaxf(0.125f * d, 0.00005f * d);
+    return peak;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -130,29 +121,45 @@ struct TileDesc {
     int first;    // 1 = first tile of its block
 };
 
+// Tiles are enumerated block by block (tiles never straddle a reference block); the walk is incremental so no
+// 64-bit division sits in the per-tile path.  Tiles past the end of a short last block have valid == 0.
+struct TileWalk {
+    long blk_start;
+    int j;
+};
+
 __device__ __forceinline__ TileDesc
-ddn_tile_at(long it, const DdnFusedArgs& a) {
+ddn_tile_next(TileWalk& w, const DdnFusedArgs& a) {
     TileDesc t;
-    const long blk = it / a.tiles_per_block;
-    const long j = it - blk * a.tiles_per_block;
-    const long bs = blk * (long)a.block_len;
-    long be = bs + a.block_len;
+    long be = w.blk_start + a.block_len;
     if (be > a.n) {
         be = a.n;
     }
-    t.start = bs + j * DDN_TT;
-    t.blk_start = bs;
+    t.start = w.blk_start + (long)w.j * DDN_TT;
+    t.blk_start = w.blk_start;
     t.blk_end = be;
-    long v = be - t.start;
+    const long v = be - t.start;
     t.valid = (int)(v < 0 ? 0 : (v > DDN_TT ? DDN_TT : v));
-    t.first = (j == 0);
+    t.first = (w.j == 0);
+    if (++w.j == a.tiles_per_block) {
+        w.j = 0;
+        w.blk_start += a.block_len;
+    }
     return t;
 }
 
 // CENTER_T > 0: fully unrolled sliding-window FIR for that half-length; CENTER_T == 0: run-time half-length
 // (taps in LDS, no register windows) for sample rates without an unrolled instance.
+//
+// Pipeline per tile index i (two barriers per iteration `it`):
+//   phase A  filter threads: finish tile it-3 (scale, clip, store), stage the window of tile it
+//   phase B  filter threads: LPF + phase delta of tile it           -> Fb[it % 3]
+//            wave S1 (lane = channel): dc centring of tile it-1     -> Fb[(it-1) % 3] in place (centred value)
+//            wave S2 (lane = channel): peak AGC recurrence, tile it-2 -> Pb[(it-2) % 2] (peak to divide by)
+// A single wave issues roughly one VALU instruction per 5 cycles whatever the lane count, so the two
+// recurrences are split over two waves to keep each under the filter threads' time per tile.
 template <int CENTER_T, int G, bool SKIPZ, int FMT>
-__global__ __launch_bounds__(G * 32 + 64) void
+__global__ __launch_bounds__(G * 32 + 128) void
 k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
     constexpr int TT = DDN_TT;
     constexpr int R = DDN_R;
@@ -160,20 +167,25 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
     constexpr int W = TT + 2 * CMAX;
     constexpr int WP = W + W / R + 1;
     constexpr int FS = TT + 4; // row stride of the tile buffers (floats), keeps 16-B alignment
-    constexpr int NF = G * 32; // filter threads
     constexpr int NPRE = (W + 31) / 32; // window samples each filter thread stages per tile
 
     __shared__ f2 win[G][WP];
-    __shared__ __attribute__((aligned(16))) float Fb[2][G][FS]; // raw phase delta -> centred value (in place)
+    __shared__ __attribute__((aligned(16))) float Fb[3][G][FS]; // raw phase delta -> centred value (in place)
     __shared__ __attribute__((aligned(16))) float Pb[2][G][FS]; // peak to divide by
     __shared__ f2 chan_last[2][G];                              // last LPF output of the previous tile
+    __shared__ int tflag[3][G]; // per tile/channel: 1 = squelched (zeros + modem reset), 2 = first sample skipped
     __shared__ float stap[DDN_MAX_CENTER + 1];
     extern __shared__ f2 ysq[]; // [G][256] first LPF outputs of a block (squelch builds only)
 
+    // The two recurrence waves are the FIRST waves of the workgroup: VALU issue on a SIMD is arbitrated by age
+    // (measured: a youngest-wave dependent chain runs 2x slower beside busy filter waves, an oldest-wave one at
+    // full speed; s_setprio makes no difference), and they are the per-tile critical path.
     const int tid = threadIdx.x;
-    const bool is_filter = tid < NF;
-    const int g = is_filter ? (tid >> 5) : (tid - NF); // channel slot
-    const int u = tid & 31;
+    const bool is_filter = tid >= 128;
+    const int role = is_filter ? 0 : (tid < 64 ? 1 : 2);      // 0 filter, 1 = S1 (dc), 2 = S2 (peak)
+    const int ft = tid - 128;                                  // filter-thread index
+    const int g = is_filter ? (ft >> 5) : (tid & 63);          // channel slot
+    const int u = ft & 31;
     const int ch0 = blockIdx.x * G;
     const int nch = (a.n_channels - ch0) < G ? (a.n_channels - ch0) : G;
     const int C = (CENTER_T > 0) ? CENTER_T : a.center;
@@ -181,43 +193,62 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
     const bool ch_ok = g < nch;
     const long NT = a.n_tiles;
 
-    // recurrence-wave state
+    // recurrence state (S1: dc / have_prev / squelched, S2: peak)
     float dc = 0.f, peak = 0.f;
     int have_prev = 0;
     int squelched = 0;
-    if (!is_filter && ch_ok && g < G) {
+    if (role != 0 && ch_ok) {
         const DdnFskState s = a.state[ch];
         dc = s.dc_est;
         peak = s.peak_est;
         have_prev = s.have_prev;
-        const f2 pv = {s.prev_i, s.prev_q};
-        chan_last[0][g] = pv;
+        if (role == 1) {
+            const f2 pv = {s.prev_i, s.prev_q};
+            chan_last[0][g] = pv;
+        }
     }
     if (tid <= C) {
         stap[tid] = (tid == C) ? taps.centre : taps.side[tid];
-    }
-    if (!is_filter) {
-        // the recurrence wave is latency-bound and issues little: let it win arbitration on its SIMD
-        __builtin_amdgcn_s_setprio(3);
     }
     // raw samples of the NEXT tile, fetched while the current one is filtered (hides HBM latency)
     uint32_t pre_u[(FMT == DDN_IN_CU8) ? NPRE : 1];
     f2 pre_f[(FMT == DDN_IN_CF32) ? NPRE : 1];
     __syncthreads();
 
-    for (long it = 0; it < NT + 2; it++) {
-        // ================= phase A: finish tile it-2, stage tile it =====================================
+    // tile descriptors in flight: tq[0] = tile it+1 (prefetch), tq[1] = it, tq[2] = it-1, tq[3] = it-2, tq[4] = it-3
+    TileWalk walk = {0, 0};
+    TileDesc tq[5];
+    for (int k = 0; k < 5; k++) {
+        tq[k].start = 0;
+        tq[k].blk_start = 0;
+        tq[k].blk_end = 0;
+        tq[k].valid = 0;
+        tq[k].first = 0;
+    }
+    tq[0] = ddn_tile_next(walk, a); // tile 0
+    long long tA = 0, tB = 0, tW = 0, tm0 = 0, tm1 = 0, tm2 = 0;
+    for (long it = 0; it < NT + 3; it++) {
+        tq[4] = tq[3];
+        tq[3] = tq[2];
+        tq[2] = tq[1];
+        tq[1] = tq[0];
+        tq[0] = ddn_tile_next(walk, a);
+        if (a.dbg & 64) {
+            tm0 = __builtin_readcyclecounter();
+        }
+        // ================= phase A: finish tile it-3, stage tile it =====================================
         if (is_filter) {
-            if (it >= 2) {
-                const TileDesc t2 = ddn_tile_at(it - 2, a);
-                const int b = (int)((it - 2) & 1);
-                float* o = a.out + (size_t)ch * a.out_stride + t2.start;
+            if (it >= 3 && !(a.dbg & 4)) {
+                const TileDesc t3 = tq[4];
+                const int bf = (int)((it - 3) % 3);
+                const int bp = (int)((it - 3) & 1);
+                float* o = a.out + (size_t)ch * a.out_stride + t3.start;
                 const bool al = ((((size_t)o) & 15) == 0);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     const int t = half * 128 + u * 4;
-                    const f4 c4 = *(const f4*)&Fb[b][g][t];
-                    const f4 p4 = *(const f4*)&Pb[b][g][t];
+                    const f4 c4 = *(const f4*)&Fb[bf][g][t];
+                    const f4 p4 = *(const f4*)&Pb[bp][g][t];
                     f4 y;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -226,12 +257,12 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                         y[k] = v;
                     }
                     if (ch_ok) {
-                        if (al && t + 4 <= t2.valid) {
+                        if (al && t + 4 <= t3.valid) {
                             *(f4*)(o + t) = y;
                         } else {
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
-                                if (t + k < t2.valid) {
+                                if (t + k < t3.valid) {
                                     o[t + k] = y[k];
                                 }
                             }
@@ -239,11 +270,11 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                     }
                 }
             }
-            if (it < NT) {
+            if (it < NT && !(a.dbg & 8)) {
                 const int Weff = TT + 2 * C;
                 if (it == 0) {
                     // first tile of the call: look-back comes from the carried history, fetched synchronously
-                    const TileDesc tc = ddn_tile_at(it, a);
+                    const TileDesc tc = tq[1];
                     const f2* carry = a.carry + (size_t)ch * DDN_CARRY_LEN;
                     for (int i = u; i < Weff; i += 32) {
                         long p = tc.start - C + i;
@@ -278,11 +309,20 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                 }
             }
         }
+        if (a.dbg & 64) {
+            tm1 = __builtin_readcyclecounter();
+            tA += tm1 - tm0;
+        }
         __syncthreads();
-        // ================= phase B: filter tile it  ||  recurrences of tile it-1 ========================
-        if (is_filter) {
-            if (it + 1 < NT) {
-                const TileDesc tn = ddn_tile_at(it + 1, a);
+        if (a.dbg & 64) {
+            tm2 = __builtin_readcyclecounter();
+            tW += tm2 - tm1;
+        }
+        // ================= phase B ======================================================================
+        if (role == 0) {
+            // ---- filter threads: prefetch tile it+1, LPF + phase delta of tile it ------------------------
+            if (it + 1 < NT && !(a.dbg & 8)) {
+                const TileDesc tn = tq[0];
                 const int Weff = TT + 2 * C;
                 if (tn.valid > 0) {
 #pragma unroll
@@ -302,11 +342,11 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                     }
                 }
             }
-            const TileDesc tc = ddn_tile_at(it < NT ? it : 0, a);
+            const TileDesc tc = tq[1];
             if (it < NT && tc.valid <= 0 && u == 0) {
                 chan_last[(it & 1) ^ 1][g] = chan_last[it & 1][g]; // surplus tile of a short last block
             }
-            if (it < NT && tc.valid > 0) {
+            if (it < NT && tc.valid > 0 && !(a.dbg & 2)) {
                 f2 acc[R];
                 const f2 zero = {0.0f, 0.0f};
                 // a block shorter than taps_len samples goes to the reference's non-fused scalar unit
@@ -392,6 +432,7 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                 }
                 // phase delta against the previous output (previous lane / previous tile)
                 const int b = (int)(it & 1);
+                const int bf = (int)(it % 3);
                 f2 prev;
                 prev.x = __shfl_up(acc[R - 1].x, 1);
                 prev.y = __shfl_up(acc[R - 1].y, 1);
@@ -420,8 +461,8 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                         q1[j - 4] = fq;
                     }
                 }
-                *(f4*)&Fb[b][g][u * R] = q0;
-                *(f4*)&Fb[b][g][u * R + 4] = q1;
+                *(f4*)&Fb[bf][g][u * R] = q0;
+                *(f4*)&Fb[bf][g][u * R + 4] = q1;
                 if (a.squelch_on && tc.first) {
 #pragma unroll
                     for (int j = 0; j < R; j++) {
@@ -429,129 +470,194 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                     }
                 }
             }
-        } else if (it >= 1 && it <= NT && ch_ok && g < G) {
-            const TileDesc tp = ddn_tile_at(it - 1, a);
-            const int b = (int)((it - 1) & 1);
-            float* F = &Fb[b][g][0];
-            float* P = &Pb[b][g][0];
-            if (a.squelch_on && tp.first) {
-                // block power: first <=512 floats of the block's LPF output, sequential binary64 sums
-                // exactly like mean_power() (src/dsp/demod_pipeline.cpp:926-945)
-                const int len = (int)((tp.blk_end - tp.start) * 2 > 512 ? 512 : (tp.blk_end - tp.start) * 2);
-                const float* s = (const float*)&ysq[g * 256];
-                double pw = 0.0, tot = 0.0;
-                for (int i = 0; i < len; i++) {
-                    const double v = (double)s[i];
-                    tot += v;
-                    pw += v * v;
+        } else if (role == 1) {
+            // ---- S1: dc centring (src/dsp/fsk_modem.c:98-105) of tile it-1, squelch gate, stream restart ----
+            if (it >= 1 && it <= NT && ch_ok && g < G && !(a.dbg & 1)) {
+                const TileDesc tp = tq[2];
+                const int bf = (int)((it - 1) % 3);
+                float* F = &Fb[bf][g][0];
+                int flag = 0;
+                if (a.squelch_on && tp.first && tp.valid > 0) {
+                    // block power: first <=512 floats of the block's LPF output, sequential binary64 sums
+                    // exactly like mean_power() (src/dsp/demod_pipeline.cpp:926-945)
+                    const int len = (int)((tp.blk_end - tp.start) * 2 > 512 ? 512 : (tp.blk_end - tp.start) * 2);
+                    const float* sq = (const float*)&ysq[g * 256];
+                    double pw = 0.0, tot = 0.0;
+                    for (int i = 0; i < len; i++) {
+                        const double v = (double)sq[i];
+                        tot += v;
+                        pw += v * v;
+                    }
+                    const double dcc = (tot * tot) / (double)len;
+                    double e = pw - dcc;
+                    if (e < 0.0) {
+                        e = 0.0;
+                    }
+                    const float chp = (float)(e / (double)len);
+                    squelched = (chp < a.squelch_level) ? 1 : 0;
                 }
-                const double dcc = (tot * tot) / (double)len;
-                double e = pw - dcc;
-                if (e < 0.0) {
-                    e = 0.0;
+                if (squelched) {
+                    // zeros out + modem reset (src/dsp/demod_pipeline.cpp:1179-1184)
+                    flag = 1;
+                    have_prev = 0;
+                    dc = 0.f;
+                    for (int t = 0; t < tp.valid; t++) {
+                        F[t] = 0.0f;
+                    }
+                } else {
+                    int t = 0;
+                    if (!have_prev && tp.valid > 0) {
+                        // first sample of a (re)started stream: output 0, remember it (src/dsp/fsk_modem.c:148-153)
+                        have_prev = 1;
+                        flag = 2;
+                        F[0] = 0.0f;
+                        t = 1;
+                    }
+                    for (; t < tp.valid && (t & 3) != 0; t++) {
+                        const float fr = F[t];
+                        dc += 0.00025f * (fr - dc);
+                        F[t] = fr - dc;
+                    }
+                    // 8 samples per trip; the next trip's LDS reads are issued ahead of the dependent chain
+                    const long long tl0 = (a.dbg & 64) ? __builtin_readcyclecounter() : 0;
+                    f4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
+                    if (t + 8 <= tp.valid) {
+                        fa = *(const f4*)&F[t];
+                        fb = *(const f4*)&F[t + 4];
+                    }
+                    for (; t + 8 <= tp.valid; t += 8) {
+                        f4 na = fa, nb = fb;
+                        if (t + 16 <= tp.valid) {
+                            na = *(const f4*)&F[t + 8];
+                            nb = *(const f4*)&F[t + 12];
+                        }
+                        f4 ca, cb;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            dc += 0.00025f * (fa[k] - dc);
+                            ca[k] = fa[k] - dc;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            dc += 0.00025f * (fb[k] - dc);
+                            cb[k] = fb[k] - dc;
+                        }
+                        *(f4*)&F[t] = ca;
+                        *(f4*)&F[t + 4] = cb;
+                        fa = na;
+                        fb = nb;
+                    }
+                    if (a.dbg & 64) {
+                        tA += __builtin_readcyclecounter() - tl0;
+                    }
+                    for (; t < tp.valid; t++) {
+                        const float fr = F[t];
+                        dc += 0.00025f * (fr - dc);
+                        F[t] = fr - dc;
+                    }
                 }
-                const float chp = (float)(e / (double)len);
-                squelched = (chp < a.squelch_level) ? 1 : 0;
+                tflag[bf][g] = flag;
             }
-            if (squelched) {
-                // zeros out + modem reset (src/dsp/demod_pipeline.cpp:1179-1184)
-                have_prev = 0;
-                dc = 0.f;
-                peak = 0.f;
-                for (int t = 0; t < tp.valid; t++) {
-                    F[t] = 0.0f;
-                    P[t] = 1.0f;
-                }
-            } else {
-                int t = 0;
-                if (!have_prev && tp.valid > 0) {
-                    // first sample of a (re)started stream: output 0, remember it (src/dsp/fsk_modem.c:148-153)
-                    have_prev = 1;
-                    F[0] = 0.0f;
-                    P[0] = 1.0f;
-                    t = 1;
-                }
-                // peel to a 16-byte boundary, then groups of 8 samples: the next group's LDS reads are issued
-                // before the current group's dependent chain so their latency hides behind it
-                for (; t < tp.valid && (t & 3) != 0; t++) {
-                    float c, pk;
-                    ddn_modem_step(F[t], dc, peak, c, pk);
-                    F[t] = c;
-                    P[t] = pk;
-                }
-                f4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
-                if (t + 8 <= tp.valid) {
-                    fa = *(const f4*)&F[t];
-                    fb = *(const f4*)&F[t + 4];
-                }
-                for (; t + 8 <= tp.valid; t += 8) {
-                    f4 na = fa, nb = fb;
-                    if (t + 16 <= tp.valid) {
-                        na = *(const f4*)&F[t + 8];
-                        nb = *(const f4*)&F[t + 12];
+        } else {
+            // ---- S2: asymmetric peak AGC recurrence (src/dsp/fsk_modem.c:116-133) of tile it-2 -------------
+            if (it >= 2 && it <= NT + 1 && ch_ok && g < G && !(a.dbg & 1)) {
+                const TileDesc tp = tq[3];
+                const int bf = (int)((it - 2) % 3);
+                const int bp = (int)((it - 2) & 1);
+                const float* Cc = &Fb[bf][g][0];
+                float* P = &Pb[bp][g][0];
+                const int flag = tflag[bf][g];
+                if (flag == 1) {
+                    peak = 0.f;
+                    for (int t = 0; t < tp.valid; t++) {
+                        P[t] = 1.0f;
                     }
-                    const float dc0 = dc, pk0 = peak;
-                    bool rare = false;
-                    f4 ca, cb, pa, pb;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float c;
-                        ddn_modem_step_fast(fa[k], dc, peak, c, rare);
-                        ca[k] = c;
-                        pa[k] = peak;
+                } else {
+                    int t = 0;
+                    if (flag == 2) {
+                        P[0] = 1.0f;
+                        t = 1;
                     }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float c;
-                        ddn_modem_step_fast(fb[k], dc, peak, c, rare);
-                        cb[k] = c;
-                        pb[k] = peak;
+                    for (; t < tp.valid && (t & 3) != 0; t++) {
+                        P[t] = ddn_peak_step(Cc[t], peak);
                     }
-                    if (rare) {
-                        dc = dc0;
-                        peak = pk0;
+                    f4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
+                    if (t + 8 <= tp.valid) {
+                        fa = *(const f4*)&Cc[t];
+                        fb = *(const f4*)&Cc[t + 4];
+                    }
+                    for (; t + 8 <= tp.valid; t += 8) {
+                        f4 na = fa, nb = fb;
+                        if (t + 16 <= tp.valid) {
+                            na = *(const f4*)&Cc[t + 8];
+                            nb = *(const f4*)&Cc[t + 12];
+                        }
+                        const float pk0 = peak;
+                        f4 pa, pb;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            float c, pk;
-                            ddn_modem_step(fa[k], dc, peak, c, pk);
-                            ca[k] = c;
-                            pa[k] = pk;
+                            pa[k] = ddn_peak_step_fast(fa[k], peak);
                         }
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            float c, pk;
-                            ddn_modem_step(fb[k], dc, peak, c, pk);
-                            cb[k] = c;
-                            pb[k] = pk;
+                            pb[k] = ddn_peak_step_fast(fb[k], peak);
                         }
+                        // Did a rare guard fire in this group?  Every new peak lies between the old peak and
+                        // |centred| (monotone rounding), so "old peak > 1e-7 and every |centred| > 1e-7" rules
+                        // both guards out; non-finite values also replay (fmaxf drops NaNs).
+                        const float m0 = fminf(fminf(fabsf(fa[0]), fabsf(fa[1])), fminf(fabsf(fa[2]), fabsf(fa[3])));
+                        const float m1 = fminf(fminf(fabsf(fb[0]), fabsf(fb[1])), fminf(fabsf(fb[2]), fabsf(fb[3])));
+                        if (!(fminf(fminf(m0, m1), pk0) > 1.0e-7f) || !(peak <= 3.0e38f)) {
+                            peak = pk0;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                pa[k] = ddn_peak_step(fa[k], peak);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                pb[k] = ddn_peak_step(fb[k], peak);
+                            }
+                        }
+                        *(f4*)&P[t] = pa;
+                        *(f4*)&P[t + 4] = pb;
+                        fa = na;
+                        fb = nb;
                     }
-                    *(f4*)&F[t] = ca;
-                    *(f4*)&F[t + 4] = cb;
-                    *(f4*)&P[t] = pa;
-                    *(f4*)&P[t + 4] = pb;
-                    fa = na;
-                    fb = nb;
-                }
-                for (; t < tp.valid; t++) {
-                    float c, pk;
-                    ddn_modem_step(F[t], dc, peak, c, pk);
-                    F[t] = c;
-                    P[t] = pk;
+                    for (; t < tp.valid; t++) {
+                        P[t] = ddn_peak_step(Cc[t], peak);
+                    }
                 }
             }
         }
+        if (a.dbg & 64) {
+            tm0 = __builtin_readcyclecounter();
+            tB += tm0 - tm2;
+        }
         __syncthreads();
+        if (a.dbg & 64) {
+            tW += __builtin_readcyclecounter() - tm0;
+        }
+    }
+    if ((a.dbg & 64) && a.dbg_out && blockIdx.x == 0 && (tid & 63) == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        long long* o = a.dbg_out + (is_filter ? (ft >> 6) : (8 + (tid >> 6))) * 4;
+        o[0] = (hw >> 4) & 3;
+        o[1] = tA;
+        o[2] = tB;
+        o[3] = tW;
     }
 
-    if (!is_filter && ch_ok && g < G && a.n > 0) {
+    if (role == 1 && ch_ok && g < G && a.n > 0) {
         const f2 yl = chan_last[(int)(NT & 1)][g];
-        DdnFskState s;
-        s.prev_i = have_prev ? yl.x : 0.f;
-        s.prev_q = have_prev ? yl.y : 0.f;
-        s.have_prev = have_prev;
-        s.dc_est = dc;
-        s.peak_est = peak;
-        a.state[ch] = s;
+        DdnFskState* s = &a.state[ch];
+        s->prev_i = have_prev ? yl.x : 0.f;
+        s->prev_q = have_prev ? yl.y : 0.f;
+        s->have_prev = have_prev;
+        s->dc_est = dc;
+    }
+    if (role == 2 && ch_ok && g < G && a.n > 0) {
+        a.state[ch].peak_est = peak;
     }
 }
 
@@ -587,7 +693,7 @@ template <int CENTER_T, int G, int FMT>
 static hipError_t
 launch_fused_t(const DdnFusedArgs& a, const DdnTapsK& tp, bool has_zero, hipStream_t st) {
     dim3 grid((unsigned)((a.n_channels + G - 1) / G));
-    dim3 block(G * 32 + 64);
+    dim3 block(G * 32 + 128);
     const size_t dyn = a.squelch_on ? (size_t)G * 256 * sizeof(f2) : 0;
     if (has_zero) {
         hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, true, FMT>), grid, block, dyn, st, a, tp);
@@ -620,6 +726,14 @@ ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, h
         }
     }
     (void)group;
+    if (a->squelch_on) {
+        // squelch builds keep the first 256 LPF outputs of each block in LDS for the block-power sum: use the
+        // 8-channel workgroup so everything still fits in 160 KB
+        if (a->in_fmt == DDN_IN_CU8) {
+            return launch_fused_c<8, DDN_IN_CU8>(*a, tp, has_zero, st);
+        }
+        return launch_fused_c<8, DDN_IN_CF32>(*a, tp, has_zero, st);
+    }
     if (a->in_fmt == DDN_IN_CU8) {
         return launch_fused_c<DDN_GROUP, DDN_IN_CU8>(*a, tp, has_zero, st);
     }
