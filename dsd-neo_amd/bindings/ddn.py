@@ -60,6 +60,28 @@ PROTOTYPES = {
     "simd_hb_decim2_real": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "simd_fir_get_impl_name": (C.c_char_p, []),
     "widen_u8_to_f32_bias127": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "ddn_fec_p25_12_soft_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_12_soft_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_r34_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_r34_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_fec_nxdn_conv_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p]),
+    "ddn_fec_nxdn_conv_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int]),
+    "ddn_fec_viterbi_k5_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p]),
+    "ddn_fec_viterbi_k5_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                          C.c_void_p]),
+    "p25_12_soft_llr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dmr_r34_viterbi_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dmr_r34_viterbi_decode_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "viterbi_decode": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_uint16]),
+    "viterbi_decode_punctured": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16, C.c_uint16]),
+    "CNXDNConvolution_init": (None, []),
+    "CNXDNConvolution_start": (None, []),
+    "CNXDNConvolution_decode": (None, [C.c_uint8, C.c_uint8]),
+    "CNXDNConvolution_decode_soft": (None, [C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8]),
+    "CNXDNConvolution_chainback": (None, [C.c_void_p, C.c_uint]),
     "ddn_fsk_modem_discriminator_process": (C.c_int, [C.POINTER(FskModemState), C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
 }
 

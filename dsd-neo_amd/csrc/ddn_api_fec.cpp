@@ -1,0 +1,337 @@
+// ddn_api_fec.cpp — C-ABI for the batched trellis / Viterbi decoders (include/ddn_hip.h, "FEC" section) and the
+// single-codeword drop-in symbols with the reference's names.
+//
+// Batched calls take DEVICE pointers and a stream; `_host` variants stage host buffers through the device
+// (synchronous).  Nothing here computes on the CPU: without a GPU every call fails with DDN_ENODEV/DDN_EHIP.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ddn_device.h"
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            ddn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);                  \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorNoBinaryForGpu)             \
+                       ? DDN_ENODEV                                                                                    \
+                       : (e_ == hipErrorOutOfMemory ? DDN_ENOMEM : DDN_EHIP);                                          \
+        }                                                                                                              \
+    } while (0)
+
+namespace {
+struct Dev {
+    void* p = nullptr;
+    size_t bytes;
+    explicit Dev(size_t b) : bytes(b) {
+        if (hipMalloc(&p, b ? b : 4) != hipSuccess) {
+            p = nullptr;
+        }
+    }
+    ~Dev() { (void)hipFree(p); }
+    Dev(const Dev&) = delete;
+    Dev& operator=(const Dev&) = delete;
+    int up(const void* h) { return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+    int down(void* h) { return hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+};
+
+int
+no_dev() {
+    ddn_set_error("device allocation/copy failed (no HIP device?)");
+    return DDN_ENODEV;
+}
+
+int
+build_puncture(const uint8_t* punct, int p_len, int in_len, DdnPuncture* pu, int* u_len) {
+    memset(pu, 0, sizeof(*pu));
+    if (!punct || p_len <= 0) {
+        *u_len = in_len;
+        return DDN_OK;
+    }
+    if (p_len > 64) {
+        ddn_set_error("puncture pattern longer than 64 entries");
+        return DDN_ERANGE;
+    }
+    pu->p_len = p_len;
+    int ones = 0;
+    for (int r = 0; r < p_len; r++) {
+        pu->keep[r] = punct[r] ? 1 : 0;
+        pu->ones_before[r] = (uint8_t)ones;
+        ones += pu->keep[r];
+    }
+    pu->ones_total = ones;
+    if (ones == 0) {
+        ddn_set_error("puncture pattern keeps nothing");
+        return DDN_EINVAL;
+    }
+    int i = 0, u = 0, p = 0;
+    while (i < in_len) { // same walk as viterbi_decode_punctured (reference src/core/util/dsd_misc.c:160-173)
+        if (pu->keep[p]) {
+            i++;
+        }
+        u++;
+        p = (p + 1) % p_len;
+    }
+    *u_len = u;
+    return DDN_OK;
+}
+} // namespace
+
+extern "C" int
+ddn_fec_p25_12_soft_batch(const int16_t* d_llr196, size_t n, uint8_t* d_out12, int32_t* d_metric, void* hip_stream) {
+    if (!d_llr196 || !d_out12) {
+        ddn_set_error("ddn_fec_p25_12_soft_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_p25_half_rate(d_llr196, (int)n, d_out12, d_metric, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_r34_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, uint8_t* d_out18, void* hip_stream) {
+    if (!d_dibits98 || !d_out18) {
+        ddn_set_error("ddn_fec_r34_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_r34(d_dibits98, d_reliab98, (int)n, d_out18, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_nxdn_conv_batch(const uint8_t* d_sym, const uint8_t* d_rel, size_t n, int n_steps, int n_bits,
+                        uint16_t* d_metrics_io, uint8_t* d_out, int out_stride, void* hip_stream) {
+    if (!d_sym || !d_out || n_steps <= 0 || n_steps > 1024 || n_bits < 0 || n_bits > n_steps
+        || out_stride < (n_bits + 7) / 8) {
+        ddn_set_error("ddn_fec_nxdn_conv_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_k5_nxdn(d_sym, d_rel, (int)n, n_steps, n_bits, d_metrics_io, d_out, out_stride,
+                            (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_viterbi_k5_batch(const uint16_t* d_soft, size_t n, int in_len, const uint8_t* punct, int p_len, uint8_t* d_out,
+                         int out_stride, uint32_t* d_cost, void* hip_stream) {
+    if (!d_soft || !d_out || in_len < 2) {
+        ddn_set_error("ddn_fec_viterbi_k5_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    DdnPuncture pu;
+    int u_len = 0;
+    int rc = build_puncture(punct, p_len, in_len, &pu, &u_len);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (u_len > 244 * 2) {
+        ddn_set_error("viterbi_k5: %d soft bits exceed the decoder's 244-step history", u_len);
+        return DDN_ERANGE;
+    }
+    if (out_stride < (u_len / 2 + 3) / 8 + 1) {
+        ddn_set_error("viterbi_k5: out_stride %d too small for %d steps", out_stride, u_len / 2);
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_k5_m17(d_soft, (int)n, in_len, u_len, &pu, d_out, out_stride, d_cost, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+// ---- host-buffer variants ------------------------------------------------------------------------------
+extern "C" int
+ddn_fec_p25_12_soft_host(const int16_t* llr196, size_t n, uint8_t* out12, int32_t* metric) {
+    Dev a(n * 196 * 2), b(n * 12), m(n * 4);
+    if (!a.p || !b.p || !m.p || a.up(llr196)) {
+        return no_dev();
+    }
+    int rc = ddn_fec_p25_12_soft_batch((const int16_t*)a.p, n, (uint8_t*)b.p, (int32_t*)m.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (b.down(out12) || (metric && m.down(metric))) {
+        return no_dev();
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_r34_host(const uint8_t* dibits98, const uint8_t* reliab98, size_t n, uint8_t* out18) {
+    Dev a(n * 98), r(n * 98), b(n * 18);
+    if (!a.p || !r.p || !b.p || a.up(dibits98) || (reliab98 && r.up(reliab98))) {
+        return no_dev();
+    }
+    int rc = ddn_fec_r34_batch((const uint8_t*)a.p, reliab98 ? (const uint8_t*)r.p : nullptr, n, (uint8_t*)b.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return b.down(out18) ? no_dev() : DDN_OK;
+}
+
+extern "C" int
+ddn_fec_nxdn_conv_host(const uint8_t* sym, const uint8_t* rel, size_t n, int n_steps, int n_bits, uint16_t* metrics_io,
+                       uint8_t* out, int out_stride) {
+    if (n_steps <= 0 || out_stride <= 0) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * 2 * (size_t)n_steps), r(n * 2 * (size_t)n_steps), m(n * 32), b(n * (size_t)out_stride);
+    if (!a.p || !r.p || !m.p || !b.p || a.up(sym) || (rel && r.up(rel)) || (metrics_io && m.up(metrics_io))
+        || hipMemset(b.p, 0, b.bytes) != hipSuccess) {
+        return no_dev();
+    }
+    int rc = ddn_fec_nxdn_conv_batch((const uint8_t*)a.p, rel ? (const uint8_t*)r.p : nullptr, n, n_steps, n_bits,
+                                     metrics_io ? (uint16_t*)m.p : nullptr, (uint8_t*)b.p, out_stride, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (b.down(out) || (metrics_io && m.down(metrics_io))) {
+        return no_dev();
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_viterbi_k5_host(const uint16_t* soft, size_t n, int in_len, const uint8_t* punct, int p_len, uint8_t* out,
+                        int out_stride, uint32_t* cost) {
+    if (in_len < 2 || out_stride <= 0) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * (size_t)in_len * 2), b(n * (size_t)out_stride), c(n * 4);
+    if (!a.p || !b.p || !c.p || a.up(soft)) {
+        return no_dev();
+    }
+    int rc = ddn_fec_viterbi_k5_batch((const uint16_t*)a.p, n, in_len, punct, p_len, (uint8_t*)b.p, out_stride,
+                                      (uint32_t*)c.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (b.down(out) || (cost && c.down(cost))) {
+        return no_dev();
+    }
+    return DDN_OK;
+}
+
+// ---- drop-in single-codeword symbols (reference names) ---------------------------------------------------
+// include/dsd-neo/protocol/p25/p25_12.h:21, include/dsd-neo/protocol/dmr/r34_viterbi.h:19-26,
+// include/dsd-neo/fec/viterbi.h:23-25, include/dsd-neo/protocol/nxdn/nxdn_convolution.h:24-28
+extern "C" int
+p25_12_soft_llr(const uint8_t* input, const int16_t* bit_llr196, uint8_t treturn[12]) {
+    (void)input;
+    int32_t metric = 0;
+    if (ddn_fec_p25_12_soft_host(bit_llr196, 1, treturn, &metric) != DDN_OK) {
+        return -1;
+    }
+    return metric;
+}
+
+extern "C" int
+dmr_r34_viterbi_decode(const uint8_t* dibits98, uint8_t out_bytes18[18]) {
+    if (!dibits98 || !out_bytes18) {
+        return -1;
+    }
+    return ddn_fec_r34_host(dibits98, nullptr, 1, out_bytes18) == DDN_OK ? 0 : -1;
+}
+
+extern "C" int
+dmr_r34_viterbi_decode_soft(const uint8_t* dibits98, const uint8_t* reliab98, uint8_t out_bytes18[18]) {
+    if (!dibits98 || !reliab98 || !out_bytes18) {
+        return -1;
+    }
+    return ddn_fec_r34_host(dibits98, reliab98, 1, out_bytes18) == DDN_OK ? 0 : -1;
+}
+
+extern "C" uint32_t
+viterbi_decode(uint8_t* out, const uint16_t* in, const uint16_t len) {
+    uint32_t cost = 0;
+    const int stride = (len / 2 + 3) / 8 + 1;
+    std::vector<uint8_t> tmp((size_t)stride);
+    if (ddn_fec_viterbi_k5_host(in, 1, len, nullptr, 0, tmp.data(), stride, &cost) != DDN_OK) {
+        return 0xFFFFFFFFu;
+    }
+    memcpy(out, tmp.data(), (size_t)stride);
+    return cost;
+}
+
+extern "C" uint32_t
+viterbi_decode_punctured(uint8_t* out, const uint16_t* in, const uint8_t* punct, const uint16_t in_len,
+                         const uint16_t p_len) {
+    uint32_t cost = 0;
+    DdnPuncture pu;
+    int u_len = 0;
+    if (build_puncture(punct, p_len, in_len, &pu, &u_len) != DDN_OK) {
+        return 0xFFFFFFFFu;
+    }
+    const int stride = (u_len / 2 + 3) / 8 + 1;
+    std::vector<uint8_t> tmp((size_t)stride);
+    if (ddn_fec_viterbi_k5_host(in, 1, in_len, punct, p_len, tmp.data(), stride, &cost) != DDN_OK) {
+        return 0xFFFFFFFFu;
+    }
+    memcpy(out, tmp.data(), (size_t)stride);
+    return cost;
+}
+
+// The reference keeps the NXDN decoder's symbols-in-flight and path metrics in file-static storage
+// (src/protocol/nxdn/nxdn_convolution.c:48-53); the drop-in keeps the same per-thread streaming contract and runs
+// the accumulated steps on the device at chainback time.
+namespace {
+thread_local std::vector<uint8_t> g_nx_sym, g_nx_rel;
+thread_local bool g_nx_soft = false;
+thread_local uint16_t g_nx_metrics[16] = {0};
+} // namespace
+
+extern "C" void
+CNXDNConvolution_init(void) {
+    memset(g_nx_metrics, 0, sizeof(g_nx_metrics));
+    g_nx_sym.clear();
+    g_nx_rel.clear();
+    g_nx_soft = false;
+}
+
+extern "C" void
+CNXDNConvolution_start(void) {
+    g_nx_sym.clear();
+    g_nx_rel.clear();
+    g_nx_soft = false;
+}
+
+extern "C" void
+CNXDNConvolution_decode(uint8_t s0, uint8_t s1) {
+    g_nx_sym.push_back(s0);
+    g_nx_sym.push_back(s1);
+    g_nx_rel.push_back(0);
+    g_nx_rel.push_back(0);
+}
+
+extern "C" void
+CNXDNConvolution_decode_soft(uint8_t s0, uint8_t s1, uint8_t r0, uint8_t r1) {
+    g_nx_sym.push_back(s0);
+    g_nx_sym.push_back(s1);
+    g_nx_rel.push_back(r0);
+    g_nx_rel.push_back(r1);
+    g_nx_soft = true;
+}
+
+extern "C" void
+CNXDNConvolution_chainback(unsigned char* out, unsigned int nBits) {
+    const int n_steps = (int)(g_nx_sym.size() / 2);
+    if (!out || n_steps <= 0 || (int)nBits > n_steps) {
+        return;
+    }
+    const int stride = ((int)nBits + 7) / 8;
+    std::vector<uint8_t> tmp((size_t)(stride > 0 ? stride : 1));
+    if (ddn_fec_nxdn_conv_host(g_nx_sym.data(), g_nx_soft ? g_nx_rel.data() : nullptr, 1, n_steps, (int)nBits,
+                               g_nx_metrics, tmp.data(), stride > 0 ? stride : 1)
+        != DDN_OK) {
+        return;
+    }
+    // the reference writes exactly nBits bits and leaves the rest of the last byte alone
+    for (unsigned int i = 0; i < nBits; i++) {
+        const uint8_t mask = (uint8_t)(0x80u >> (i & 7));
+        if (tmp[i >> 3] & mask) {
+            out[i >> 3] |= mask;
+        } else {
+            out[i >> 3] &= (uint8_t)~mask;
+        }
+    }
+}

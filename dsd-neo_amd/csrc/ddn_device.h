@@ -40,9 +40,22 @@ typedef struct DdnFusedArgs {
     int dbg; /* timing experiments only (DDN_DBG env): 1 skip recurrences, 2 skip filter, 4 skip finish, 8 skip staging */
 } DdnFusedArgs;
 
+typedef struct DdnPuncture { /* puncture pattern of the K=5 decoder, expanded on the host */
+    int p_len;               /* 0 = not punctured */
+    int ones_total;
+    uint8_t keep[64];
+    uint8_t ones_before[64]; /* kept positions before pattern index r */
+} DdnPuncture;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st);
+hipError_t ddn_dev_r34(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* out, hipStream_t st);
+hipError_t ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int n_bits, uint16_t* metrics_io,
+                           uint8_t* out, int out_stride, hipStream_t st);
+hipError_t ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out,
+                          int out_stride, uint32_t* cost, hipStream_t st);
 hipError_t ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, hipStream_t st);
 hipError_t ddn_dev_launch_carry(const void* in, int in_fmt, size_t ch_stride, long n, void* carry, int n_channels,
                                 hipStream_t st);

@@ -1,0 +1,448 @@
+// ddn_trellis.hip — batched trellis / Viterbi decoders for gfx950 (bit-exact integer arithmetic).
+//
+// One codeword per group of S lanes (S = number of trellis states: 4, 8 or 16), 64/S codewords per wavefront:
+//   * add-compare-select: lane (codeword, next_state) pulls the predecessor metrics it needs from its
+//     neighbours with wave shuffles (ds_bpermute within the S-lane group) — no LDS round trip for metrics;
+//   * K=5 decoders: the 16 decision bits of a step are one __ballot() slice, stored once per step to LDS;
+//   * 4/8-state decoders: back-pointers stay in registers (2/3 bits per step per lane), traceback fetches them
+//     with shuffles;
+//   * observations (LLRs / dibits / soft symbols) are staged once, coalesced, into LDS, de-interleaved on the fly.
+//
+// Reference behaviour reproduced (tie-breaks included):
+//   k_p25_half_rate   src/protocol/p25/p25_12.c:204-283      4 states x 49 steps, LLR disagreement costs,
+//                                                             start bias 256, strict '<' keeps the lowest predecessor
+//   k_r34             src/protocol/dmr/dmr_34_viterbi.c:205-255,365-407   8 states x 49 steps, hard or weighted
+//   k_k5_nxdn         src/protocol/nxdn/nxdn_convolution.c:57-99,124-160  16 states, uint16 metrics that wrap,
+//                                                             decision = (m0 >= m1), chainback from state 0
+//   k_k5_m17          src/core/util/dsd_misc.c:118-283        16 states, uint32 metrics, 0x1FFFE complement costs
+// Tables: TIA-102.BAAA / ETSI TS 102 361-1 trellis constants (reference src/fec/trellis34.c, p25_12.c:19).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+
+namespace {
+
+__constant__ uint8_t c_half_rate_nibble[16] = {2, 12, 1, 15, 14, 0, 13, 3, 9, 7, 10, 4, 5, 11, 6, 8};
+__constant__ uint8_t c_r34_point_to_nibble[16] = {2, 10, 7, 15, 14, 6, 11, 3, 13, 5, 8, 0, 1, 9, 4, 12};
+__constant__ uint8_t c_r34_nibble_to_point[16] = {11, 12, 0, 7, 14, 9, 5, 2, 10, 13, 1, 6, 15, 8, 4, 3};
+__constant__ uint8_t c_r34_fsm[64] = {0, 8,  4, 12, 2, 10, 6, 14, 4, 12, 2, 10, 6, 14, 0, 8, 1, 9,  5, 13, 3, 11,
+                                      7, 15, 5, 13, 3, 11, 7, 15, 1, 9,  3, 11, 7, 15, 1, 9, 5, 13, 7, 15, 1, 9,
+                                      5, 13, 3, 11, 2, 10, 6, 14, 0, 8,  4, 12, 6, 14, 0, 8, 4, 12, 2, 10};
+
+// position of received dibit i inside the de-interleaved block: 49 dibit pairs dealt to 4 lanes round-robin
+__device__ __forceinline__ int
+deinterleave98(int i) {
+    // received order: lane 0 pairs (0,4,8,...,48) [13 pairs], lane 1 (1,5,...,45) [12], lane 2 [12], lane 3 [12]
+    const int pair_rx = i >> 1;
+    int lane, k;
+    if (pair_rx < 13) {
+        lane = 0;
+        k = pair_rx;
+    } else {
+        lane = 1 + (pair_rx - 13) / 12;
+        k = (pair_rx - 13) % 12;
+    }
+    return 2 * (lane + 4 * k) + (i & 1);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// P25 1/2-rate: 4 lanes per codeword
+__global__ __launch_bounds__(256) void
+k_p25_half_rate(const int16_t* __restrict__ llr, int n, uint8_t* __restrict__ out, int32_t* __restrict__ metric_out) {
+    constexpr int CW = 64;               // codewords per block
+    __shared__ int32_t d[CW][98 + 1];    // de-interleaved LLR pairs (hi 16 = second llr of the dibit)
+    const int tid = threadIdx.x;
+    const int cw0 = blockIdx.x * CW;
+    for (int idx = tid; idx < CW * 98; idx += 256) {
+        const int c = idx / 98, i = idx - c * 98;
+        if (cw0 + c < n) {
+            const int32_t pair = *(const int32_t*)(llr + ((size_t)(cw0 + c) * 196 + 2 * i));
+            d[c][deinterleave98(i)] = pair;
+        }
+    }
+    __syncthreads();
+    const int c = tid >> 2, ns = tid & 3;
+    const int lane = tid & 63, base = lane & ~3;
+    const bool live = (cw0 + c) < n;
+    uint32_t prev = (ns == 0) ? 0u : 256u;
+    uint64_t bp0 = 0, bp1 = 0;
+    uint8_t e[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+        e[ps] = c_half_rate_nibble[(ps << 2) | ns];
+    }
+    for (int t = 0; t < 49; t++) {
+        const int32_t p0 = live ? d[c][2 * t] : 0, p1 = live ? d[c][2 * t + 1] : 0;
+        int l[4] = {(int16_t)(p0 & 0xFFFF), (int16_t)(p0 >> 16), (int16_t)(p1 & 0xFFFF), (int16_t)(p1 >> 16)};
+        uint32_t c0[4], c1[4]; // cost if the expected bit is 0 / 1
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            c0[b] = l[b] > 0 ? (uint32_t)l[b] : 0u;
+            c1[b] = l[b] < 0 ? (uint32_t)(-l[b]) : 0u;
+        }
+        uint32_t best = 0xFFFFFFFFu;
+        uint32_t arg = 0;
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            const uint32_t pm = __shfl(prev, base + ps);
+            uint32_t cost = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                cost += ((e[ps] >> (3 - b)) & 1) ? c1[b] : c0[b];
+            }
+            const uint32_t m = pm + cost;
+            if (m < best) {
+                best = m;
+                arg = ps;
+            }
+        }
+        prev = best;
+        if (t < 32) {
+            bp0 |= (uint64_t)arg << (2 * t);
+        } else {
+            bp1 |= (uint64_t)arg << (2 * (t - 32));
+        }
+    }
+    // best final state (lowest index wins ties), traceback on lane ns == 0
+    uint32_t bestm = __shfl(prev, base);
+    int st = 0;
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+        const uint32_t m = __shfl(prev, base + j);
+        if (m < bestm) {
+            bestm = m;
+            st = j;
+        }
+    }
+    uint32_t w[3] = {0, 0, 0}; // 12 output bytes, MSB-first dibits
+#pragma unroll
+    for (int t = 48; t >= 0; t--) {
+        if (t < 48) {
+            const int byte = t >> 2;
+            w[byte >> 2] |= (uint32_t)st << (8 * (byte & 3) + 6 - 2 * (t & 3));
+        }
+        const uint64_t word = (t < 32) ? bp0 : bp1;
+        const int sh = (t < 32) ? 2 * t : 2 * (t - 32);
+        const uint32_t lo = __shfl((uint32_t)(word & 0xFFFFFFFFu), base + st);
+        const uint32_t hi = __shfl((uint32_t)(word >> 32), base + st);
+        const uint64_t src = ((uint64_t)hi << 32) | lo;
+        st = (int)((src >> sh) & 3);
+    }
+    if (live && ns == 0) {
+        uint32_t* o = (uint32_t*)(out + (size_t)(cw0 + c) * 12);
+        o[0] = w[0];
+        o[1] = w[1];
+        o[2] = w[2];
+        if (metric_out) {
+            metric_out[cw0 + c] = (int32_t)(bestm >> 8);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 3/4-rate: 8 lanes per codeword
+template <bool SOFT>
+__global__ __launch_bounds__(256) void
+k_r34(const uint8_t* __restrict__ dibits, const uint8_t* __restrict__ reliab, int n, uint8_t* __restrict__ out) {
+    constexpr int CW = 32;
+    constexpr int INF = 1000000000;
+    __shared__ uint8_t dd[CW][100];
+    __shared__ uint8_t rr[CW][100];
+    const int tid = threadIdx.x;
+    const int cw0 = blockIdx.x * CW;
+    for (int idx = tid; idx < CW * 98; idx += 256) {
+        const int c = idx / 98, i = idx - c * 98;
+        if (cw0 + c < n) {
+            const int p = deinterleave98(i);
+            dd[c][p] = dibits[(size_t)(cw0 + c) * 98 + i] & 3u;
+            if (SOFT) {
+                rr[c][p] = reliab[(size_t)(cw0 + c) * 98 + i];
+            }
+        }
+    }
+    __syncthreads();
+    const int c = tid >> 3, ns = tid & 7;
+    const int lane = tid & 63, base = lane & ~7;
+    const bool live = (cw0 + c) < n;
+    int prev = (ns == 0) ? 0 : INF;
+    uint64_t bp[3] = {0, 0, 0}; // 21 steps x 3 bits per word
+    uint8_t en[8], ep[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ps++) {
+        ep[ps] = c_r34_fsm[ps * 8 + ns];
+        en[ps] = c_r34_point_to_nibble[ep[ps]];
+    }
+    for (int t = 0; t < 49; t++) {
+        const int d0 = live ? dd[c][2 * t] : 0, d1 = live ? dd[c][2 * t + 1] : 0;
+        const int nib = (d0 << 2) | d1;
+        const int point = c_r34_nibble_to_point[nib];
+        const int rhi = (SOFT && live) ? rr[c][2 * t] : 1, rlo = (SOFT && live) ? rr[c][2 * t + 1] : 1;
+        int cur = INF;
+        int arg = 0;
+#pragma unroll
+        for (int ps = 0; ps < 8; ps++) {
+            const int pm = __shfl(prev, base + ps);
+            int cost;
+            if (SOFT) {
+                const int x = en[ps] ^ nib;
+                cost = ((x >> 3) & 1) * rhi + ((x >> 2) & 1) * rhi + ((x >> 1) & 1) * rlo + (x & 1) * rlo;
+            } else {
+                cost = __popc((unsigned)((ep[ps] ^ point) & 15));
+            }
+            const int m = pm + cost;
+            if (pm < INF && m < cur) {
+                cur = m;
+                arg = ps;
+            }
+        }
+        prev = cur;
+        bp[t / 21] |= (uint64_t)arg << (3 * (t % 21));
+    }
+    int st = 0; // terminated trellis: traceback from state 0
+    uint32_t grp = 0;
+    uint8_t bytes[18];
+#pragma unroll
+    for (int t = 48; t >= 0; t--) {
+        if (t < 48) {
+            grp |= (uint32_t)(st & 7) << (3 * (7 - (t & 7)));
+            if ((t & 7) == 0) {
+                const int g = t >> 3;
+                bytes[3 * g] = (uint8_t)(grp >> 16);
+                bytes[3 * g + 1] = (uint8_t)(grp >> 8);
+                bytes[3 * g + 2] = (uint8_t)grp;
+                grp = 0;
+            }
+        }
+        const uint64_t word = bp[t / 21];
+        const uint32_t lo = __shfl((uint32_t)(word & 0xFFFFFFFFu), base + st);
+        const uint32_t hi = __shfl((uint32_t)(word >> 32), base + st);
+        const uint64_t src = ((uint64_t)hi << 32) | lo;
+        st = (int)((src >> (3 * (t % 21))) & 7);
+    }
+    if (live && ns == 0) {
+        uint16_t* o = (uint16_t*)(out + (size_t)(cw0 + c) * 18);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            o[k] = (uint16_t)(bytes[2 * k] | (bytes[2 * k + 1] << 8));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K=5, NXDN flavour: 16 lanes per codeword, uint16 metrics
+template <bool SOFT>
+__global__ __launch_bounds__(256) void
+k_k5_nxdn(const uint8_t* __restrict__ sym, const uint8_t* __restrict__ rel, int n, int n_steps, int n_bits,
+          uint16_t* __restrict__ metrics_io, uint8_t* __restrict__ out, int out_stride) {
+    constexpr int CW = 16;
+    extern __shared__ uint8_t smem[];
+    const int row = 2 * n_steps + 2;                 // bytes per codeword of symbols
+    uint8_t* s = smem;                               // [CW][row]
+    uint8_t* r = s + CW * row;                       // [CW][row] (SOFT only)
+    uint16_t* dec = (uint16_t*)(r + (SOFT ? CW * row : 0)); // [CW][n_steps]
+    const int tid = threadIdx.x;
+    const int cw0 = blockIdx.x * CW;
+    for (int idx = tid; idx < CW * 2 * n_steps; idx += 256) {
+        const int c = idx / (2 * n_steps), i = idx - c * 2 * n_steps;
+        if (cw0 + c < n) {
+            s[c * row + i] = sym[(size_t)(cw0 + c) * 2 * n_steps + i];
+            if (SOFT) {
+                r[c * row + i] = rel[(size_t)(cw0 + c) * 2 * n_steps + i];
+            }
+        }
+    }
+    __syncthreads();
+    const int c = tid >> 4, j = tid & 15;
+    const int lane = tid & 63, base = lane & ~15, grp = (lane >> 4);
+    const bool live = (cw0 + c) < n;
+    const int i = j >> 1, b = j & 1;
+    const int t1 = (i >= 4) ? 2 : 0;
+    const int t2 = (((i & 3) == 1) || ((i & 3) == 2)) ? 2 : 0;
+    uint32_t m = (live && metrics_io) ? metrics_io[(size_t)(cw0 + c) * 16 + j] : 0u;
+    for (int t = 0; t < n_steps; t++) {
+        const int s0 = live ? s[c * row + 2 * t] : 0, s1 = live ? s[c * row + 2 * t + 1] : 0;
+        const uint32_t lo = __shfl(m, base + i), hi = __shfl(m, base + i + 8);
+        const int a0 = t1 - s0, a1 = t2 - s1;
+        const uint32_t diff0 = (uint32_t)(a0 < 0 ? -a0 : a0), diff1 = (uint32_t)(a1 < 0 ? -a1 : a1);
+        int dbit;
+        uint32_t nm;
+        if (SOFT) {
+            const uint32_t r0 = live ? r[c * row + 2 * t] : 0, r1 = live ? r[c * row + 2 * t + 1] : 0;
+            uint32_t metric = (diff0 * r0 + diff1 * r1) / 128u;
+            if (metric > 8u) {
+                metric = 8u;
+            }
+            const uint32_t x = b ? (8u - metric) : metric;
+            const uint32_t m0 = lo + x, m1 = hi + (8u - x);
+            dbit = m0 >= m1;
+            nm = (dbit ? m1 : m0) & 0xFFFFu;
+        } else {
+            const uint32_t metric = diff0 + diff1;
+            const uint32_t x = b ? (4u - metric) : metric;
+            const uint32_t m0 = (lo + x) & 0xFFFFu, m1 = (hi + (4u - x)) & 0xFFFFu;
+            dbit = m0 >= m1;
+            nm = dbit ? m1 : m0;
+        }
+        const unsigned long long mask = __ballot(dbit);
+        if (j == 0 && live) {
+            dec[c * n_steps + t] = (uint16_t)((mask >> (16 * grp)) & 0xFFFFull);
+        }
+        m = nm;
+    }
+    if (live && metrics_io) {
+        metrics_io[(size_t)(cw0 + c) * 16 + j] = (uint16_t)m;
+    }
+    if (live && j == 0) {
+        uint8_t* o = out + (size_t)(cw0 + c) * out_stride;
+        uint32_t state = 0;
+        int t = n_steps;
+        uint32_t cur = 0;
+        for (int nb = n_bits; nb-- > 0;) {
+            --t;
+            const uint32_t bit = (dec[c * n_steps + t] >> (state >> 4)) & 1u;
+            state = (bit << 7) | (state >> 1);
+            cur |= bit << (7 - (nb & 7));
+            if ((nb & 7) == 0) {
+                o[nb >> 3] = (uint8_t)cur;
+                cur = 0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K=5, libM17 flavour: 16 lanes per codeword, uint32 metrics, uint16 soft symbols, optional depuncture
+__global__ __launch_bounds__(256) void
+k_k5_m17(const uint16_t* __restrict__ in, int n, int in_len, int u_len, DdnPuncture pu, uint8_t* __restrict__ out,
+         int out_stride, uint32_t* __restrict__ cost_out) {
+    constexpr int CW = 16;
+    extern __shared__ uint8_t smem[];
+    uint16_t* um = (uint16_t*)smem;                 // [CW][u_len + 2]
+    const int row = u_len + 2;
+    const int n_steps = u_len >> 1;
+    uint16_t* hist = um + CW * row;                 // [CW][n_steps]
+    const int tid = threadIdx.x;
+    const int cw0 = blockIdx.x * CW;
+    for (int idx = tid; idx < CW * u_len; idx += 256) {
+        const int c = idx / u_len, u = idx - c * u_len;
+        if (cw0 + c < n) {
+            uint16_t v;
+            if (pu.p_len > 0) {
+                const int full = u / pu.p_len, rem = u - full * pu.p_len;
+                const int i = full * pu.ones_total + pu.ones_before[rem];
+                v = (pu.keep[rem] && i < in_len) ? in[(size_t)(cw0 + c) * in_len + i] : (uint16_t)0x7FFF;
+            } else {
+                v = in[(size_t)(cw0 + c) * in_len + u];
+            }
+            um[c * row + u] = v;
+        }
+    }
+    __syncthreads();
+    const int c = tid >> 4, j = tid & 15;
+    const int lane = tid & 63, base = lane & ~15, grp = (lane >> 4);
+    const bool live = (cw0 + c) < n;
+    const int i = j >> 1, b = j & 1;
+    const uint32_t k0 = (i >= 4) ? 0xFFFFu : 0u;
+    const uint32_t k1 = (((i & 3) == 1) || ((i & 3) == 2)) ? 0xFFFFu : 0u;
+    uint32_t m = 0;
+    for (int t = 0; t < n_steps; t++) {
+        const uint32_t s0 = live ? um[c * row + 2 * t] : 0u, s1 = live ? um[c * row + 2 * t + 1] : 0u;
+        const uint32_t lo = __shfl(m, base + i), hi = __shfl(m, base + i + 8);
+        const uint32_t metric = (k0 > s0 ? k0 - s0 : s0 - k0) + (k1 > s1 ? k1 - s1 : s1 - k1);
+        const uint32_t x = b ? (0x1FFFEu - metric) : metric;
+        const uint32_t m0 = lo + x, m1 = hi + (0x1FFFEu - x);
+        const int dbit = m0 >= m1;
+        const unsigned long long mask = __ballot(dbit);
+        if (j == 0 && live) {
+            hist[c * n_steps + t] = (uint16_t)((mask >> (16 * grp)) & 0xFFFFull);
+        }
+        m = dbit ? m1 : m0;
+    }
+    // minimum final metric over the 16 states
+    uint32_t best = m;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+    }
+    if (live && j == 0) {
+        uint8_t* o = out + (size_t)(cw0 + c) * out_stride;
+        for (int k = 0; k < out_stride; k++) {
+            o[k] = 0;
+        }
+        uint32_t state = 0;
+        int bitpos = n_steps + 4;
+        for (int pos = n_steps; pos > 0;) {
+            bitpos--;
+            pos--;
+            const uint32_t bit = hist[c * n_steps + pos] & (1u << (state >> 4));
+            state >>= 1;
+            if (bit) {
+                state |= 0x80u;
+                o[bitpos >> 3] |= (uint8_t)(1u << (7 - (bitpos & 7)));
+            }
+        }
+        if (cost_out) {
+            cost_out[cw0 + c] = best - (uint32_t)(u_len - in_len) * 0x7FFFu;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+extern "C" hipError_t
+ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p25_half_rate, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, llr, n, out, metric);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_r34(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* out, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    dim3 grid((unsigned)((n + 31) / 32));
+    if (reliab) {
+        hipLaunchKernelGGL((k_r34<true>), grid, dim3(256), 0, st, dibits, reliab, n, out);
+    } else {
+        hipLaunchKernelGGL((k_r34<false>), grid, dim3(256), 0, st, dibits, reliab, n, out);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int n_bits, uint16_t* metrics_io,
+                uint8_t* out, int out_stride, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    dim3 grid((unsigned)((n + 15) / 16));
+    const size_t row = 2 * (size_t)n_steps + 2;
+    const size_t shm = 16 * row * (rel ? 2 : 1) + 16 * (size_t)n_steps * 2 + 16;
+    if (rel) {
+        hipLaunchKernelGGL((k_k5_nxdn<true>), grid, dim3(256), shm, st, sym, rel, n, n_steps, n_bits, metrics_io, out,
+                           out_stride);
+    } else {
+        hipLaunchKernelGGL((k_k5_nxdn<false>), grid, dim3(256), shm, st, sym, rel, n, n_steps, n_bits, metrics_io, out,
+                           out_stride);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out, int out_stride,
+               uint32_t* cost, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    dim3 grid((unsigned)((n + 15) / 16));
+    const size_t shm = 16 * ((size_t)u_len + 2) * 2 + 16 * (size_t)(u_len / 2) * 2 + 16;
+    hipLaunchKernelGGL(k_k5_m17, grid, dim3(256), shm, st, in, n, in_len, u_len, *pu, out, out_stride, cost);
+    return hipGetLastError();
+}

@@ -96,6 +96,46 @@ int ddn_batch_get_fsk_state(ddn_batch* b, int channel, float out5[5]);
 int ddn_batch_set_timing(ddn_batch* b, int enable);
 int ddn_batch_get_timing(ddn_batch* b, float out3[3]);
 
+/* ---- batched trellis / Viterbi decoders (bit-exact integer) ------------------------------------------
+ * d_* = device pointers, asynchronous on hip_stream; *_host = host pointers, synchronous.
+ *   ddn_fec_p25_12_soft_*   P25 1/2-rate 4-state trellis on bit LLRs: [n][196] int16 -> [n][12] bytes (+ metric>>8)
+ *                           == p25_12_soft_llr (include/dsd-neo/protocol/p25/p25_12.h:21)
+ *   ddn_fec_r34_*           3/4-rate 8-state trellis: [n][98] dibits (+ optional [n][98] reliabilities) -> [n][18]
+ *                           == dmr_r34_viterbi_decode / _decode_soft (include/dsd-neo/protocol/dmr/r34_viterbi.h:19-26)
+ *   ddn_fec_nxdn_conv_*     K=5 R=1/2, uint16 wrapping metrics: [n][n_steps][2] symbols 0..2 (+ optional reliabilities)
+ *                           -> [n][out_stride] bytes holding n_bits chained-back bits, MSB first; metrics_io ([n][16],
+ *                           optional) carries the path metrics in and out like the reference's static state
+ *                           == CNXDNConvolution_start/decode[_soft]/chainback (.../nxdn/nxdn_convolution.h:24-28)
+ *   ddn_fec_viterbi_k5_*    K=5 R=1/2, uint32 metrics on uint16 soft bits, optional puncture pattern (host array):
+ *                           [n][in_len] -> [n][out_stride] bytes (bit position = step + 4), cost per codeword
+ *                           == viterbi_decode / viterbi_decode_punctured (include/dsd-neo/fec/viterbi.h:23-25)   */
+int ddn_fec_p25_12_soft_batch(const int16_t* d_llr196, size_t n, uint8_t* d_out12, int32_t* d_metric, void* hip_stream);
+int ddn_fec_p25_12_soft_host(const int16_t* llr196, size_t n, uint8_t* out12, int32_t* metric);
+int ddn_fec_r34_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, uint8_t* d_out18,
+                      void* hip_stream);
+int ddn_fec_r34_host(const uint8_t* dibits98, const uint8_t* reliab98, size_t n, uint8_t* out18);
+int ddn_fec_nxdn_conv_batch(const uint8_t* d_sym, const uint8_t* d_rel, size_t n, int n_steps, int n_bits,
+                            uint16_t* d_metrics_io, uint8_t* d_out, int out_stride, void* hip_stream);
+int ddn_fec_nxdn_conv_host(const uint8_t* sym, const uint8_t* rel, size_t n, int n_steps, int n_bits,
+                           uint16_t* metrics_io, uint8_t* out, int out_stride);
+int ddn_fec_viterbi_k5_batch(const uint16_t* d_soft, size_t n, int in_len, const uint8_t* punct, int p_len,
+                             uint8_t* d_out, int out_stride, uint32_t* d_cost, void* hip_stream);
+int ddn_fec_viterbi_k5_host(const uint16_t* soft, size_t n, int in_len, const uint8_t* punct, int p_len, uint8_t* out,
+                            int out_stride, uint32_t* cost);
+
+/* single-codeword drop-ins with the reference's names */
+int p25_12_soft_llr(const uint8_t* input, const int16_t* bit_llr196, uint8_t treturn[12]);
+int dmr_r34_viterbi_decode(const uint8_t* dibits98, uint8_t out_bytes18[18]);
+int dmr_r34_viterbi_decode_soft(const uint8_t* dibits98, const uint8_t* reliab98, uint8_t out_bytes18[18]);
+uint32_t viterbi_decode(uint8_t* out, const uint16_t* in, const uint16_t len);
+uint32_t viterbi_decode_punctured(uint8_t* out, const uint16_t* in, const uint8_t* punct, const uint16_t in_len,
+                                  const uint16_t p_len);
+void CNXDNConvolution_init(void);
+void CNXDNConvolution_start(void);
+void CNXDNConvolution_decode(uint8_t s0, uint8_t s1);
+void CNXDNConvolution_decode_soft(uint8_t s0, uint8_t s1, uint8_t r0, uint8_t r1);
+void CNXDNConvolution_chainback(unsigned char* out, unsigned int nBits);
+
 /* ---- drop-in single-stream symbols (reference names; host pointers) ------------------------------- */
 void simd_fir_complex_apply(const float* in, int in_len, float* out, float* hist_i, float* hist_q, const float* taps,
                             int taps_len);

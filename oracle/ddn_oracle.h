@@ -89,6 +89,20 @@ long orc_fe_run_f32(orc_front_end* fe, const float* iq, long n_complex, int bloc
 void orc_fe_run_batch_cu8(int n_channels, const uint8_t* iq, long n_complex, int block_len, int rate_hz, int profile,
                           float squelch_level, float* out);
 
+/* ---- trellis / Viterbi decoders (oracle/ddn_oracle_fec.c) -------------------------------------------- */
+void orc_trellis_interleave_98(uint8_t tbl[98]);
+const uint8_t* orc_tbl_p25_half_rate_nibble(void);
+const uint8_t* orc_tbl_r34_point_to_nibble(void);
+const uint8_t* orc_tbl_r34_nibble_to_point(void);
+const uint8_t* orc_tbl_r34_fsm(void);
+int orc_p25_12_soft_llr(const int16_t* llr196, uint8_t out12[12]);
+int orc_r34_decode(const uint8_t* dibits98, const uint8_t* reliab98 /* NULL = hard */, uint8_t out18[18]);
+void orc_nxdn_conv_decode(const uint8_t* sym, const uint8_t* rel /* NULL = hard */, int n_steps,
+                          uint16_t metrics16[16], uint8_t* out, int n_bits);
+uint32_t orc_m17_viterbi_decode(uint8_t* out, const uint16_t* in, int len);
+uint32_t orc_m17_viterbi_decode_punctured(uint8_t* out, const uint16_t* in, const uint8_t* punct, int in_len,
+                                          int p_len);
+
 #ifdef __cplusplus
 }
 #endif

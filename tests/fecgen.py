@@ -1,0 +1,176 @@
+"""Test-side generators for the trellis / Viterbi decoders: encoders for valid codewords (from the TIA-102 /
+ETSI FSM tables the oracle exposes), channel noise, and ctypes helpers.  TEST INFRASTRUCTURE."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+
+VP = C.c_void_p
+
+
+def _tbl(fn, n):
+    fn.restype = C.POINTER(C.c_uint8)
+    return np.array([fn()[i] for i in range(n)], np.uint8)
+
+
+def tables():
+    o = orc.oracle()
+    il = np.zeros(98, np.uint8)
+    o.orc_trellis_interleave_98.argtypes = [VP]
+    o.orc_trellis_interleave_98(il.ctypes.data)
+    return dict(il=il, half=_tbl(o.orc_tbl_p25_half_rate_nibble, 16), p2n=_tbl(o.orc_tbl_r34_point_to_nibble, 16),
+                n2p=_tbl(o.orc_tbl_r34_nibble_to_point, 16), fsm=_tbl(o.orc_tbl_r34_fsm, 64))
+
+
+def bind_oracle_fec():
+    o = orc.oracle()
+    o.orc_p25_12_soft_llr.argtypes = [VP, VP]
+    o.orc_r34_decode.argtypes = [VP, VP, VP]
+    o.orc_nxdn_conv_decode.argtypes = [VP, VP, C.c_int, VP, VP, C.c_int]
+    o.orc_m17_viterbi_decode.argtypes = [VP, VP, C.c_int]
+    o.orc_m17_viterbi_decode.restype = C.c_uint32
+    o.orc_m17_viterbi_decode_punctured.argtypes = [VP, VP, VP, C.c_int, C.c_int]
+    o.orc_m17_viterbi_decode_punctured.restype = C.c_uint32
+    return o
+
+
+def gen_p25_half_rate(rng, n, amp=600, sigma=250.0, random_frac=0.2):
+    """-> (llr [n,196] int16 in received order, states [n,49])."""
+    t = tables()
+    st = rng.integers(0, 4, (n, 49)).astype(np.int64)
+    prev = np.concatenate([np.zeros((n, 1), np.int64), st[:, :-1]], axis=1)
+    nib = t["half"][(prev << 2) | st].astype(np.int64)                # [n,49]
+    bits = np.stack([(nib >> 3) & 1, (nib >> 2) & 1, (nib >> 1) & 1, nib & 1], axis=2).reshape(n, 196)
+    llr_dei = (2 * bits - 1) * amp + rng.normal(0.0, sigma, (n, 196))
+    k = int(n * random_frac)
+    if k:
+        llr_dei[:k] = rng.integers(-32768, 32768, (k, 196))
+    llr_dei = np.clip(np.rint(llr_dei), -32768, 32767).astype(np.int16)
+    rx = np.zeros((n, 196), np.int16)
+    il = t["il"].astype(np.int64)
+    rx[:, 0::2] = llr_dei[:, 2 * il]
+    rx[:, 1::2] = llr_dei[:, 2 * il + 1]
+    return np.ascontiguousarray(rx), st
+
+
+def gen_r34(rng, n, p_err=0.03, random_frac=0.2):
+    """-> (dibits [n,98] uint8 received order, reliab [n,98] uint8, tribits [n,49])."""
+    t = tables()
+    tri = rng.integers(0, 8, (n, 49)).astype(np.int64)
+    tri[:, 48] = 0
+    prev = np.concatenate([np.zeros((n, 1), np.int64), tri[:, :-1]], axis=1)
+    point = t["fsm"][prev * 8 + tri].astype(np.int64)
+    nib = t["p2n"][point].astype(np.int64)
+    dei = np.zeros((n, 98), np.int64)
+    dei[:, 0::2] = nib >> 2
+    dei[:, 1::2] = nib & 3
+    flip = rng.random((n, 98)) < p_err
+    dei = np.where(flip, rng.integers(0, 4, (n, 98)), dei)
+    k = int(n * random_frac)
+    if k:
+        dei[:k] = rng.integers(0, 4, (k, 98))
+    il = t["il"].astype(np.int64)
+    rx = dei[:, il].astype(np.uint8)
+    rel = np.where(flip[:, il], rng.integers(0, 80, (n, 98)), rng.integers(100, 256, (n, 98))).astype(np.uint8)
+    return np.ascontiguousarray(rx), np.ascontiguousarray(rel), tri
+
+
+def conv_k5_encode(bits):
+    """K=5 R=1/2 encoder, G1 = 0x19, G2 = 0x17 on a 5-bit register (NXDN / M17 / YSF).  bits [n, L] -> [n, 2L]."""
+    n, L = bits.shape
+    reg = np.zeros(n, np.int64)
+    out = np.zeros((n, 2 * L), np.uint8)
+    par = np.array([bin(i).count("1") & 1 for i in range(32)], np.uint8)
+    for i in range(L):
+        reg = ((reg << 1) | bits[:, i]) & 0x1F
+        out[:, 2 * i] = par[reg & 0x19]
+        out[:, 2 * i + 1] = par[reg & 0x17]
+    return out
+
+
+def gen_nxdn(rng, n, n_steps, p_err=0.04, p_erase=0.05, random_frac=0.2):
+    """-> (sym [n, 2*n_steps] uint8 in {0,1,2}, rel [n, 2*n_steps] uint8)."""
+    data = rng.integers(0, 2, (n, n_steps)).astype(np.int64)
+    data[:, -4:] = 0
+    enc = conv_k5_encode(data).astype(np.int64)
+    flip = rng.random(enc.shape) < p_err
+    enc = np.where(flip, 1 - enc, enc)
+    sym = 2 * enc
+    er = rng.random(enc.shape) < p_erase
+    sym = np.where(er, 1, sym)
+    k = int(n * random_frac)
+    if k:
+        sym[:k] = rng.integers(0, 3, (k, 2 * n_steps))
+    rel = np.where(flip | er, rng.integers(0, 90, enc.shape), rng.integers(120, 256, enc.shape)).astype(np.uint8)
+    return np.ascontiguousarray(sym.astype(np.uint8)), np.ascontiguousarray(rel)
+
+
+def gen_m17(rng, n, in_len, sigma=9000.0, random_frac=0.2):
+    """-> soft [n, in_len] uint16 (0 = strong 0, 0xFFFF = strong 1)."""
+    L = in_len // 2
+    data = rng.integers(0, 2, (n, L)).astype(np.int64)
+    data[:, -4:] = 0
+    enc = conv_k5_encode(data).astype(np.float64)[:, :in_len]
+    soft = enc * 65535.0 + rng.normal(0.0, sigma, enc.shape)
+    k = int(n * random_frac)
+    if k:
+        soft[:k] = rng.integers(0, 65536, (k, in_len))
+    return np.ascontiguousarray(np.clip(np.rint(soft), 0, 65535).astype(np.uint16))
+
+
+# oracle batch helpers ------------------------------------------------------------------------------------
+def oracle_p25_half_rate(llr):
+    o = bind_oracle_fec()
+    n = llr.shape[0]
+    out = np.zeros((n, 12), np.uint8)
+    met = np.zeros(n, np.int32)
+    for i in range(n):
+        met[i] = o.orc_p25_12_soft_llr(llr[i].ctypes.data, out[i].ctypes.data)
+    return out, met
+
+
+def oracle_r34(dibits, reliab=None):
+    o = bind_oracle_fec()
+    n = dibits.shape[0]
+    out = np.zeros((n, 18), np.uint8)
+    for i in range(n):
+        o.orc_r34_decode(dibits[i].ctypes.data, reliab[i].ctypes.data if reliab is not None else None,
+                         out[i].ctypes.data)
+    return out
+
+
+def oracle_nxdn(sym, rel, n_steps, n_bits, metrics=None):
+    o = bind_oracle_fec()
+    n = sym.shape[0]
+    stride = (n_bits + 7) // 8
+    out = np.zeros((n, stride), np.uint8)
+    m = np.zeros((n, 16), np.uint16) if metrics is None else metrics.copy()
+    for i in range(n):
+        o.orc_nxdn_conv_decode(sym[i].ctypes.data, rel[i].ctypes.data if rel is not None else None, n_steps,
+                               m[i].ctypes.data, out[i].ctypes.data, n_bits)
+    return out, m
+
+
+def oracle_m17(soft, punct=None):
+    o = bind_oracle_fec()
+    n, in_len = soft.shape
+    if punct is None:
+        u_len = in_len
+    else:
+        i = u = p = 0
+        while i < in_len:
+            i += int(punct[p] != 0)
+            u += 1
+            p = (p + 1) % len(punct)
+        u_len = u
+    stride = (u_len // 2 + 3) // 8 + 1
+    out = np.zeros((n, stride), np.uint8)
+    cost = np.zeros(n, np.uint32)
+    for k in range(n):
+        if punct is None:
+            cost[k] = o.orc_m17_viterbi_decode(out[k].ctypes.data, soft[k].ctypes.data, in_len)
+        else:
+            cost[k] = o.orc_m17_viterbi_decode_punctured(out[k].ctypes.data, soft[k].ctypes.data, punct.ctypes.data,
+                                                          in_len, len(punct))
+    return out, cost, stride

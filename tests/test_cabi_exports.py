@@ -12,8 +12,9 @@ import ddn
 def declared_functions():
     text = open(os.path.join(ddn.ROOT, "include", "ddn_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b([a-z_0-9]+)\s*\([^;{]*\)\s*;", text)
-    return sorted(set(n for n in names if n.startswith(("ddn_", "simd_", "widen_"))))
+    names = re.findall(r"\b([A-Za-z_0-9]+)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(n for n in names if n.startswith(("ddn_", "simd_", "widen_", "p25_", "dmr_", "viterbi_",
+                                                         "CNXDN", "check_", "hamming_", "golay_", "bch_"))))
 
 
 def test_header_and_binding_agree(built):
