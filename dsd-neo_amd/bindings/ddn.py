@@ -72,6 +72,12 @@ PROTOTYPES = {
                                            C.c_void_p, C.c_void_p]),
     "ddn_fec_viterbi_k5_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                           C.c_void_p]),
+    "ddn_p25p1_nid_decode_batch": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_nid_decode_host": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_size_t, C.c_void_p]),
+    "ddn_p25p1_nid_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_ubyte, C.c_uint8, C.c_int, C.c_void_p]),
+    "ddn_fec_hamming_10_6_3_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_hamming_10_6_3_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hamming_10_6_3_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "p25_12_soft_llr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmr_r34_viterbi_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dmr_r34_viterbi_decode_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

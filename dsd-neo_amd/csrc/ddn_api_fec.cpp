@@ -139,6 +139,29 @@ ddn_fec_viterbi_k5_batch(const uint16_t* d_soft, size_t n, int in_len, const uin
     return DDN_OK;
 }
 
+extern "C" int
+ddn_p25p1_nid_decode_batch(const uint8_t* d_bits63, const uint8_t* d_rel63, const int32_t* d_observed_nac,
+                           const uint8_t* d_parity, const uint8_t* d_parity_rel, int erasure_threshold, size_t n,
+                           int32_t* d_out4, void* hip_stream) {
+    if (!d_bits63 || !d_out4) {
+        ddn_set_error("ddn_p25p1_nid_decode_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_nid_decode(d_bits63, d_rel63, d_observed_nac, d_parity, d_parity_rel, erasure_threshold, (int)n,
+                               d_out4, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_hamming_10_6_3_batch(uint8_t* d_bits10, size_t n, uint8_t* d_errs, void* hip_stream) {
+    if (!d_bits10 || !d_errs) {
+        ddn_set_error("ddn_fec_hamming_10_6_3_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_hamming_10_6_3(d_bits10, (int)n, d_errs, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
 // ---- host-buffer variants ------------------------------------------------------------------------------
 extern "C" int
 ddn_fec_p25_12_soft_host(const int16_t* llr196, size_t n, uint8_t* out12, int32_t* metric) {
@@ -210,6 +233,80 @@ ddn_fec_viterbi_k5_host(const uint16_t* soft, size_t n, int in_len, const uint8_
         return no_dev();
     }
     return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p1_nid_decode_host(const uint8_t* bits63, const uint8_t* rel63, const int32_t* observed_nac,
+                          const uint8_t* parity, const uint8_t* parity_rel, int erasure_threshold, size_t n,
+                          int32_t* out4) {
+    Dev a(n * 63), r(n * 63), o(n * 4), p(n), q(n), out(n * 16);
+    if (!a.p || !r.p || !o.p || !p.p || !q.p || !out.p || a.up(bits63) || (rel63 && r.up(rel63))
+        || (observed_nac && o.up(observed_nac)) || (parity && p.up(parity)) || (parity_rel && q.up(parity_rel))) {
+        return no_dev();
+    }
+    int rc = ddn_p25p1_nid_decode_batch((const uint8_t*)a.p, rel63 ? (const uint8_t*)r.p : nullptr,
+                                        observed_nac ? (const int32_t*)o.p : nullptr,
+                                        parity ? (const uint8_t*)p.p : nullptr,
+                                        parity_rel ? (const uint8_t*)q.p : nullptr, erasure_threshold, n,
+                                        (int32_t*)out.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return out.down(out4) ? no_dev() : DDN_OK;
+}
+
+extern "C" int
+ddn_fec_hamming_10_6_3_host(uint8_t* bits10, size_t n, uint8_t* errs) {
+    Dev a(n * 10), e(n);
+    if (!a.p || !e.p || a.up(bits10)) {
+        return no_dev();
+    }
+    int rc = ddn_fec_hamming_10_6_3_batch((uint8_t*)a.p, n, (uint8_t*)e.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (a.down(bits10) || e.down(errs)) ? no_dev() : DDN_OK;
+}
+
+// reference: int hamming_10_6_3_decode(char* data, const char* parity)  (include/dsd-neo/fec/block_codes.h)
+extern "C" int
+hamming_10_6_3_decode(char* data, const char* parity) {
+    if (!data || !parity) {
+        return 2;
+    }
+    uint8_t b[10], e = 2;
+    for (int i = 0; i < 6; i++) {
+        b[i] = (uint8_t)data[i];
+    }
+    for (int i = 0; i < 4; i++) {
+        b[6 + i] = (uint8_t)parity[i];
+    }
+    if (ddn_fec_hamming_10_6_3_host(b, 1, &e) != DDN_OK) {
+        return 2;
+    }
+    if (e == 1) {
+        for (int i = 0; i < 6; i++) {
+            data[i] = (char)b[i];
+        }
+    }
+    return e;
+}
+
+// C-ABI-safe shape of p25p1_nid_decode() (the reference returns a struct by value,
+// include/dsd-neo/protocol/p25/p25p1_check_nid.h:38-39): out4 = {status, nac, duid, error_count}
+extern "C" int
+ddn_p25p1_nid_decode(const char bch_code[63], const uint8_t* reliab63, int observed_nac, unsigned char parity,
+                     uint8_t parity_reliab, int erasure_threshold, int out4[4]) {
+    if (!bch_code || !out4) {
+        return DDN_EINVAL;
+    }
+    int32_t obs = observed_nac, o[4];
+    int rc = ddn_p25p1_nid_decode_host((const uint8_t*)bch_code, reliab63, &obs, &parity, &parity_reliab,
+                                       erasure_threshold, 1, o);
+    for (int i = 0; i < 4 && rc == DDN_OK; i++) {
+        out4[i] = o[i];
+    }
+    return rc;
 }
 
 // ---- drop-in single-codeword symbols (reference names) ---------------------------------------------------

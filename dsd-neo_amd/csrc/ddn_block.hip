@@ -1,0 +1,376 @@
+// ddn_block.hip — batched block-code decoders of the P25 Phase 1 path (bit-exact integer arithmetic).
+//
+//   k_nid_decode        P25p1 NID: BCH(63,16,11) over GF(2^6) + DUID / parity validation + NAC-retry +
+//                       Chase search (<= 3 flips among the <= 8 least reliable bits)
+//                       reference: include/dsd-neo/fec/BCH_63_16.hpp:47-330,
+//                                  src/protocol/p25/phase1/p25p1_check_nid.cpp:200-354
+//   k_hamming_10_6_3    Hamming(10,6,3) single-error correct / double-error detect
+//                       reference: src/fec/hamming_10_6_3.cpp:20-105
+//
+// One codeword per lane: these codes are tiny (63 / 10 bits) and the work per codeword is data dependent
+// (0 .. 186 BCH trials on the soft path), so there is no useful intra-codeword parallelism; the batch supplies it.
+// GF(64) exp/log tables live in LDS (per-lane random access).  The BCH decoder is Massey's polynomial-domain
+// Berlekamp-Massey + Chien search: a bounded-distance decoder, hence the same (success, error count, data) as
+// the reference's index-form implementation for every input (pinned on 0..16-error patterns and random words).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+
+namespace {
+
+struct Gf {
+    const uint8_t* ex; // [128]
+    const uint8_t* lg; // [64]
+    __device__ __forceinline__ int mul(int a, int b) const { return (a && b) ? ex[lg[a] + lg[b]] : 0; }
+    __device__ __forceinline__ int div(int a, int b) const { return a ? ex[lg[a] + 63 - lg[b]] : 0; }
+};
+
+__device__ void
+gf_fill(uint8_t* ex, uint8_t* lg) { // one thread
+    int x = 1;
+    for (int i = 0; i < 63; i++) {
+        ex[i] = (uint8_t)x;
+        ex[i + 63] = (uint8_t)x;
+        lg[x] = (uint8_t)i;
+        x <<= 1;
+        if (x & 64) {
+            x ^= 0x43; // x^6 = x + 1
+        }
+    }
+    ex[126] = ex[0];
+    ex[127] = ex[1];
+    lg[0] = 0;
+}
+
+// w: bit p = received bit at input position p (0..62; data 0..15 MSB-first, parity 16..62).
+// Returns 1 on success with *fixed = corrected word and *nerr = flipped bits.
+__device__ int
+bch_63_16_decode(const Gf& gf, uint64_t w, uint64_t* fixed, int* nerr) {
+    uint8_t S[23];
+    int any = 0;
+    for (int i = 1; i <= 22; i++) {
+        int s = 0;
+        uint64_t m = w;
+        while (m) {
+            const int p = __builtin_ctzll(m);
+            m &= m - 1;
+            s ^= gf.ex[(i * (62 - p)) % 63];
+        }
+        S[i] = (uint8_t)s;
+        any |= s;
+    }
+    *nerr = 0;
+    *fixed = w;
+    if (!any) {
+        return 1;
+    }
+    uint8_t C[24], B[24], T[24];
+    for (int i = 0; i < 24; i++) {
+        C[i] = 0;
+        B[i] = 0;
+    }
+    C[0] = 1;
+    B[0] = 1;
+    int L = 0, m = 1, b = 1;
+    for (int n = 0; n < 22; n++) {
+        int d = S[n + 1];
+        for (int i = 1; i <= L; i++) {
+            d ^= gf.mul(C[i], S[n + 1 - i]);
+        }
+        if (d == 0) {
+            m++;
+            continue;
+        }
+        const int f = gf.div(d, b);
+        if (2 * L <= n) {
+            for (int i = 0; i < 24; i++) {
+                T[i] = C[i];
+            }
+            for (int i = 0; i + m < 24; i++) {
+                C[i + m] ^= (uint8_t)gf.mul(f, B[i]);
+            }
+            L = n + 1 - L;
+            for (int i = 0; i < 24; i++) {
+                B[i] = T[i];
+            }
+            b = d;
+            m = 1;
+        } else {
+            for (int i = 0; i + m < 24; i++) {
+                C[i + m] ^= (uint8_t)gf.mul(f, B[i]);
+            }
+            m++;
+        }
+        if (L > 11) {
+            return 0;
+        }
+    }
+    int count = 0;
+    uint64_t flips = 0;
+    for (int i = 1; i <= 63; i++) { // Chien search: root alpha^i <-> error at r-index 63-i <-> input position i-1
+        int q = 0;
+        for (int k = 0; k <= L; k++) {
+            if (C[k]) {
+                q ^= gf.ex[(gf.lg[C[k]] + i * k) % 63];
+            }
+        }
+        if (q == 0) {
+            if (count >= 11) {
+                break;
+            }
+            const int loc = (63 - i) % 63;
+            flips |= 1ull << (62 - loc);
+            count++;
+        }
+    }
+    if (count != L) {
+        return 0;
+    }
+    *fixed = w ^ flips;
+    *nerr = count;
+    return 1;
+}
+
+struct NidRes {
+    int status, nac, duid, errs;
+};
+
+__device__ NidRes
+nid_codeword(const Gf& gf, uint64_t w, int parity, int* bch_failed) {
+    NidRes r = {0, 0, 0, 0};
+    uint64_t fixed;
+    int errs;
+    if (bch_failed) {
+        *bch_failed = 0;
+    }
+    if (!bch_63_16_decode(gf, w, &fixed, &errs)) {
+        if (bch_failed) {
+            *bch_failed = 1;
+        }
+        return r;
+    }
+    r.errs = errs;
+    int nac = 0, duid = 0;
+    for (int i = 0; i < 12; i++) {
+        nac = (nac << 1) | (int)((fixed >> i) & 1);
+    }
+    for (int i = 12; i < 16; i++) {
+        duid = (duid << 1) | (int)((fixed >> i) & 1);
+    }
+    r.nac = nac;
+    r.duid = duid;
+    // DUIDs defined by TIA-102.BAAA-A table 8-4: 0 HDU, 3 TDU, 5 LDU1, 7 TSDU, A LDU2, C PDU, F TDULC
+    const unsigned valid = (1u << 0) | (1u << 3) | (1u << 5) | (1u << 7) | (1u << 10) | (1u << 12) | (1u << 15);
+    if (!((valid >> duid) & 1u)) {
+        r.errs = 0;
+        return r;
+    }
+    const int want = (duid == 5 || duid == 10) ? 1 : 0;
+    r.status = (want == parity) ? 1 : 2;
+    return r;
+}
+
+__device__ __forceinline__ int
+rx_nac(uint64_t w) {
+    int n = 0;
+    for (int i = 0; i < 12; i++) {
+        n = (n << 1) | (int)((w >> i) & 1);
+    }
+    return n;
+}
+
+__device__ __forceinline__ uint64_t
+put_nac(uint64_t w, int nac) {
+    for (int i = 0; i < 12; i++) {
+        const uint64_t bit = (uint64_t)((nac >> (11 - i)) & 1);
+        w = (w & ~(1ull << i)) | (bit << i);
+    }
+    return w;
+}
+
+struct ChaseBest {
+    int found;
+    NidRes dec;
+    int score, changes;
+};
+
+__device__ void
+chase_from(const Gf& gf, uint64_t base, const uint8_t* rel, const int* pool, int np, int parity, int parity_rel,
+           int threshold, ChaseBest* best) {
+    for (int mask = 0; mask < (1 << np); mask++) {
+        const int changed = __popc((unsigned)mask);
+        if (changed > 3) {
+            continue;
+        }
+        uint64_t cand = base;
+        int score = 0;
+        for (int b = 0; b < np; b++) {
+            if (mask & (1 << b)) {
+                cand ^= 1ull << pool[b];
+                score += rel[pool[b]];
+            }
+        }
+        if (changed && score > threshold * changed) {
+            continue;
+        }
+        const NidRes dec = nid_codeword(gf, cand, parity, nullptr);
+        if (dec.status <= 0) {
+            continue;
+        }
+        const int sc = score + (dec.status == 2 ? parity_rel : 0);
+        const bool better = !best->found || sc < best->score
+                            || (sc == best->score && dec.status == 1 && best->dec.status != 1)
+                            || (sc == best->score && dec.status == best->dec.status && dec.errs < best->dec.errs)
+                            || (sc == best->score && dec.status == best->dec.status && dec.errs == best->dec.errs
+                                && changed < best->changes);
+        if (better) {
+            best->found = 1;
+            best->dec = dec;
+            best->score = sc;
+            best->changes = changed;
+        }
+    }
+}
+
+} // namespace
+
+__global__ __launch_bounds__(64) void
+k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel63, const int32_t* __restrict__ obs_nac,
+             const uint8_t* __restrict__ parity, const uint8_t* __restrict__ parity_rel, int threshold, int n,
+             int32_t* __restrict__ out4) {
+    __shared__ uint8_t ex[128];
+    __shared__ uint8_t lg[64];
+    if (threadIdx.x == 0) {
+        gf_fill(ex, lg);
+    }
+    __syncthreads();
+    const Gf gf = {ex, lg};
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) {
+        return;
+    }
+    const uint8_t* bp = bits63 + (size_t)c * 63;
+    uint64_t w = 0;
+    for (int p = 0; p < 63; p++) {
+        w |= (uint64_t)(bp[p] ? 1 : 0) << p;
+    }
+    const int par = parity ? (parity[c] ? 1 : 0) : 0;
+    const int prel = parity_rel ? parity_rel[c] : 0;
+    const int obs = obs_nac ? obs_nac[c] : 0;
+    const bool obs_ok = obs > 0 && obs < 0xFFF;
+
+    int failed = 0;
+    NidRes hard = nid_codeword(gf, w, par, &failed);
+    if (hard.status == 0 && failed && obs_ok && rx_nac(w) != obs) {
+        hard = nid_codeword(gf, put_nac(w, obs), par, nullptr);
+    }
+    NidRes res = hard;
+    if (hard.status <= 0 && rel63) {
+        const uint8_t* rp = rel63 + (size_t)c * 63;
+        uint8_t rel[63];
+        for (int i = 0; i < 63; i++) {
+            rel[i] = rp[i];
+        }
+        // the 8 least reliable positions in (reliability, index) order; pool = first max(6, min(8, #below thr))
+        int pool[8];
+        uint64_t taken = 0;
+        int below = 0;
+        for (int i = 0; i < 63; i++) {
+            below += rel[i] < threshold;
+        }
+        for (int k = 0; k < 8; k++) {
+            int bi = -1, bv = 256;
+            for (int i = 0; i < 63; i++) {
+                if (!((taken >> i) & 1) && rel[i] < bv) {
+                    bv = rel[i];
+                    bi = i;
+                }
+            }
+            pool[k] = bi;
+            taken |= 1ull << bi;
+        }
+        int np = below < 8 ? below : 8;
+        if (np < 6) {
+            np = 6;
+        }
+        ChaseBest best = {0, {0, 0, 0, 0}, 0, 0};
+        chase_from(gf, w, rel, pool, np, par, prel, threshold, &best);
+        if (obs_ok && rx_nac(w) != obs) {
+            chase_from(gf, put_nac(w, obs), rel, pool, np, par, prel, threshold, &best);
+        }
+        if (best.found) {
+            res = best.dec;
+        }
+    }
+    int32_t* o = out4 + (size_t)c * 4;
+    o[0] = res.status;
+    o[1] = res.nac;
+    o[2] = res.duid;
+    o[3] = res.errs;
+}
+
+// bits10: [n][10] one bit per byte, 6 data bits then 4 parity bits.  data6 (in place: the first 6 bytes of each
+// row) is rewritten only for single-bit corrections, exactly like hamming_10_6_3_decode(); errs[n] = 0/1/2.
+__global__ void
+k_hamming_10_6_3(uint8_t* __restrict__ bits10, int n, uint8_t* __restrict__ errs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) {
+        return;
+    }
+    uint8_t* b = bits10 + (size_t)c * 10;
+    int word = 0;
+    bool bad = false;
+    for (int i = 0; i < 10; i++) {
+        bad |= b[i] > 1;
+        word = (word << 1) | (b[i] & 1);
+    }
+    if (bad) {
+        errs[c] = 2;
+        return;
+    }
+    const int masks[4] = {0x398, 0x354, 0x2E2, 0x1E1};
+    int syn = 0;
+    for (int k = 0; k < 4; k++) {
+        syn = (syn << 1) | (__popc((unsigned)(word & masks[k])) & 1);
+    }
+    int e = 0;
+    if (syn) {
+        // syndrome -> bit index (0..3 parity bits, 4..9 data bits), -1 = uncorrectable
+        const int8_t bad_bit[16] = {-2, 0, 1, 5, 2, -1, -1, 6, 3, -1, -1, 7, 4, 8, 9, -1};
+        const int bb = bad_bit[syn];
+        if (bb < 0) {
+            e = 2;
+        } else {
+            e = 1;
+            if (bb >= 4) {
+                word ^= 1 << bb;
+            }
+            for (int i = 0; i < 6; i++) {
+                b[i] = (uint8_t)((word >> (9 - i)) & 1);
+            }
+        }
+    }
+    errs[c] = (uint8_t)e;
+}
+
+extern "C" hipError_t
+ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
+                   const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_nid_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, bits63, rel63, obs_nac, parity,
+                       parity_rel, threshold, n, out4);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_hamming_10_6_3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits10, n, errs);
+    return hipGetLastError();
+}

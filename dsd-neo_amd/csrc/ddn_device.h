@@ -50,6 +50,9 @@ typedef struct DdnPuncture { /* puncture pattern of the K=5 decoder, expanded on
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
+                              const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st);
+hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);
 hipError_t ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st);
 hipError_t ddn_dev_r34(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* out, hipStream_t st);
 hipError_t ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int n_bits, uint16_t* metrics_io,

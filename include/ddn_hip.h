@@ -123,6 +123,27 @@ int ddn_fec_viterbi_k5_batch(const uint16_t* d_soft, size_t n, int in_len, const
 int ddn_fec_viterbi_k5_host(const uint16_t* soft, size_t n, int in_len, const uint8_t* punct, int p_len, uint8_t* out,
                             int out_stride, uint32_t* cost);
 
+/* ---- P25 Phase 1 block codes ----------------------------------------------------------------------------
+ *   ddn_p25p1_nid_decode_*   NID: BCH(63,16,11) + DUID/parity validation + observed-NAC retry + Chase search over
+ *                            the least reliable bits.  bits63 [n][63] one bit per byte (data first), rel63 [n][63]
+ *                            reliabilities (NULL = hard decision only), observed_nac [n] (NULL/0 = none),
+ *                            parity [n], parity_rel [n]; out4 [n][4] = {status, nac, duid, error_count} with
+ *                            status 0 fail / 1 ok / 2 parity override.  erasure_threshold: the reference default is 64
+ *                            == p25p1_nid_decode (include/dsd-neo/protocol/p25/p25p1_check_nid.h:38-39)
+ *   ddn_fec_hamming_10_6_3_* Hamming(10,6,3): bits10 [n][10] (6 data + 4 parity, bit per byte), data corrected in
+ *                            place on single errors, errs [n] = 0/1/2 == hamming_10_6_3_decode */
+int ddn_p25p1_nid_decode_batch(const uint8_t* d_bits63, const uint8_t* d_rel63, const int32_t* d_observed_nac,
+                               const uint8_t* d_parity, const uint8_t* d_parity_rel, int erasure_threshold, size_t n,
+                               int32_t* d_out4, void* hip_stream);
+int ddn_p25p1_nid_decode_host(const uint8_t* bits63, const uint8_t* rel63, const int32_t* observed_nac,
+                              const uint8_t* parity, const uint8_t* parity_rel, int erasure_threshold, size_t n,
+                              int32_t* out4);
+int ddn_p25p1_nid_decode(const char bch_code[63], const uint8_t* reliab63, int observed_nac, unsigned char parity,
+                         uint8_t parity_reliab, int erasure_threshold, int out4[4]);
+int ddn_fec_hamming_10_6_3_batch(uint8_t* d_bits10, size_t n, uint8_t* d_errs, void* hip_stream);
+int ddn_fec_hamming_10_6_3_host(uint8_t* bits10, size_t n, uint8_t* errs);
+int hamming_10_6_3_decode(char* data, const char* parity);
+
 /* single-codeword drop-ins with the reference's names */
 int p25_12_soft_llr(const uint8_t* input, const int16_t* bit_llr196, uint8_t treturn[12]);
 int dmr_r34_viterbi_decode(const uint8_t* dibits98, uint8_t out_bytes18[18]);

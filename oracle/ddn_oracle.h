@@ -103,6 +103,12 @@ uint32_t orc_m17_viterbi_decode(uint8_t* out, const uint16_t* in, int len);
 uint32_t orc_m17_viterbi_decode_punctured(uint8_t* out, const uint16_t* in, const uint8_t* punct, int in_len,
                                           int p_len);
 
+/* ---- block codes (oracle/ddn_oracle_block.c) ---------------------------------------------------------- */
+int orc_bch_63_16_decode(const uint8_t in63[63], uint8_t out16[16], int* err_count);
+void orc_p25p1_nid_decode(const uint8_t code[63], const uint8_t* rel63, int observed_nac, int parity, int parity_rel,
+                          int threshold, int out4[4]);
+int orc_hamming_10_6_3(int word10, int* fixed6);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,324 @@
+/*
+ * oracle/ddn_oracle_block.c — CPU restatement of the block codes on the P25 Phase 1 path
+ * (TEST INFRASTRUCTURE ONLY; integer arithmetic, bit-exact target).
+ *
+ *   BCH(63,16,11) over GF(2^6), x^6+x+1      include/dsd-neo/fec/BCH_63_16.hpp:47-330
+ *   P25p1 NID decode: hard + NAC retry + Chase   src/protocol/p25/phase1/p25p1_check_nid.cpp:200-354
+ *   Hamming(10,6,3)                          src/fec/hamming_10_6_3.cpp:20-105
+ *
+ * The BCH decoder is a bounded-distance decoder: for a received word within 11 bits of a codeword every correct
+ * Berlekamp-Massey formulation returns that codeword and the same error count; beyond that the connection
+ * polynomial of length L <= 11 is still unique (2L <= 22 syndromes) so "number of roots == L" fails or succeeds
+ * identically.  This file uses Massey's polynomial-domain form (not the reference's index-form table walk);
+ * tests/test_oracle_block.py pins it to the compiled reference on 0..16-error patterns.
+ */
+#include "ddn_oracle.h"
+
+#include <string.h>
+
+static uint8_t gexp[128], glog[64];
+static int gf_ready = 0;
+
+static void
+gf_init(void) {
+    if (gf_ready) {
+        return;
+    }
+    int x = 1;
+    for (int i = 0; i < 63; i++) {
+        gexp[i] = (uint8_t)x;
+        gexp[i + 63] = (uint8_t)x;
+        glog[x] = (uint8_t)i;
+        x <<= 1;
+        if (x & 64) {
+            x ^= 0x43; /* x^6 = x + 1 */
+        }
+    }
+    gexp[126] = gexp[0];
+    gf_ready = 1;
+}
+
+static inline int
+gmul(int a, int b) {
+    return (a && b) ? gexp[glog[a] + glog[b]] : 0;
+}
+
+static inline int
+gdiv(int a, int b) { /* b != 0 */
+    return a ? gexp[glog[a] + 63 - glog[b]] : 0;
+}
+
+/* in63: bit per byte, data bits first (positions 0..15), parity 16..62.  Returns 1 on success. */
+int
+orc_bch_63_16_decode(const uint8_t in63[63], uint8_t out16[16], int* err_count) {
+    gf_init();
+    uint8_t r[63]; /* r[j] multiplies alpha^(i*j): the reference reverses the input (BCH_63_16.hpp:84-90) */
+    for (int j = 0; j < 63; j++) {
+        r[j] = in63[62 - j] ? 1 : 0;
+    }
+    int S[23];
+    int any = 0;
+    for (int i = 1; i <= 22; i++) {
+        int s = 0;
+        for (int j = 0; j < 63; j++) {
+            if (r[j]) {
+                s ^= gexp[(i * j) % 63];
+            }
+        }
+        S[i] = s;
+        any |= s;
+    }
+    *err_count = 0;
+    if (any) {
+        int C[24] = {1}, B[24] = {1}, T[24];
+        int L = 0, m = 1, b = 1;
+        for (int n = 0; n < 22; n++) {
+            int d = S[n + 1];
+            for (int i = 1; i <= L; i++) {
+                d ^= gmul(C[i], S[n + 1 - i]);
+            }
+            if (d == 0) {
+                m++;
+                continue;
+            }
+            const int f = gdiv(d, b);
+            if (2 * L <= n) {
+                memcpy(T, C, sizeof(T));
+                for (int i = 0; i + m < 24; i++) {
+                    C[i + m] ^= gmul(f, B[i]);
+                }
+                L = n + 1 - L;
+                memcpy(B, T, sizeof(B));
+                b = d;
+                m = 1;
+            } else {
+                for (int i = 0; i + m < 24; i++) {
+                    C[i + m] ^= gmul(f, B[i]);
+                }
+                m++;
+            }
+            if (L > 11) {
+                return 0;
+            }
+        }
+        int count = 0;
+        int loc[11];
+        for (int i = 1; i <= 63; i++) { /* Chien: root alpha^i <-> error at position 63 - i */
+            int q = 0;
+            for (int k = 0; k <= L; k++) {
+                if (C[k]) {
+                    q ^= gexp[(glog[C[k]] + i * k) % 63];
+                }
+            }
+            if (q == 0) {
+                if (count >= 11) {
+                    break;
+                }
+                loc[count++] = (63 - i) % 63;
+            }
+        }
+        if (count != L) {
+            return 0;
+        }
+        for (int k = 0; k < count; k++) {
+            r[loc[k]] ^= 1;
+        }
+        *err_count = count;
+    }
+    for (int i = 0; i < 16; i++) {
+        out16[i] = r[62 - i];
+    }
+    return 1;
+}
+
+/* ---- P25p1 NID -------------------------------------------------------------------------------------- */
+enum { NID_FAIL = 0, NID_OK = 1, NID_PARITY_OVERRIDE = 2 };
+
+typedef struct {
+    int status, nac, duid, errs;
+} nid_res;
+
+static nid_res
+nid_codeword(const uint8_t code[63], int parity, int* bch_failed) {
+    /* DUIDs defined by TIA-102.BAAA-A table 8-4; parity bit is 1 only for LDU1 (5) and LDU2 (0xA) */
+    static const uint8_t duid_ok[16] = {1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 1, 0, 1, 0, 0, 1};
+    nid_res r = {NID_FAIL, 0, 0, 0};
+    uint8_t d[16];
+    int errs = 0;
+    if (bch_failed) {
+        *bch_failed = 0;
+    }
+    if (!orc_bch_63_16_decode(code, d, &errs)) {
+        if (bch_failed) {
+            *bch_failed = 1;
+        }
+        return r;
+    }
+    r.errs = errs;
+    for (int i = 0; i < 12; i++) {
+        r.nac = (r.nac << 1) | d[i];
+    }
+    r.duid = (d[12] << 3) | (d[13] << 2) | (d[14] << 1) | d[15];
+    if (!duid_ok[r.duid]) {
+        r.errs = 0;
+        return r;
+    }
+    const int want = (r.duid == 5 || r.duid == 10) ? 1 : 0;
+    r.status = (want == parity) ? NID_OK : NID_PARITY_OVERRIDE;
+    return r;
+}
+
+static int
+rx_nac(const uint8_t code[63]) {
+    int n = 0;
+    for (int i = 0; i < 12; i++) {
+        n = (n << 1) | (code[i] ? 1 : 0);
+    }
+    return n;
+}
+
+static void
+put_nac(uint8_t code[63], int nac) {
+    for (int i = 0; i < 12; i++) {
+        code[i] = (uint8_t)((nac >> (11 - i)) & 1);
+    }
+}
+
+static int
+nac_usable(int nac) {
+    return nac > 0 && nac < 0xFFF;
+}
+
+typedef struct {
+    int found;
+    nid_res dec;
+    int score, changes;
+} chase_best;
+
+static void
+chase_from(const uint8_t base[63], const uint8_t* rel, const int* pool, int np, int parity, int parity_rel,
+           int threshold, chase_best* best) {
+    for (int mask = 0; mask < (1 << np); mask++) {
+        if (__builtin_popcount((unsigned)mask) > 3) {
+            continue;
+        }
+        uint8_t cand[63];
+        memcpy(cand, base, 63);
+        int changed = 0, score = 0;
+        for (int b = 0; b < np; b++) {
+            if (mask & (1 << b)) {
+                cand[pool[b]] ^= 1;
+                changed++;
+                score += rel[pool[b]];
+            }
+        }
+        if (changed && score > threshold * changed) {
+            continue;
+        }
+        nid_res dec = nid_codeword(cand, parity, 0);
+        if (dec.status <= 0) {
+            continue;
+        }
+        int sc = score + (dec.status == NID_PARITY_OVERRIDE ? parity_rel : 0);
+        int better = !best->found || sc < best->score
+                     || (sc == best->score && dec.status == NID_OK && best->dec.status != NID_OK)
+                     || (sc == best->score && dec.status == best->dec.status && dec.errs < best->dec.errs)
+                     || (sc == best->score && dec.status == best->dec.status && dec.errs == best->dec.errs
+                         && changed < best->changes);
+        if (better) {
+            best->found = 1;
+            best->dec = dec;
+            best->score = sc;
+            best->changes = changed;
+        }
+    }
+}
+
+/* out4 = {status, nac, duid, error_count}; rel63 may be NULL (hard only).  threshold = erasure threshold
+ * (p25p1_get_erasure_threshold(), default 64: src/protocol/p25/phase1/p25p1_soft.cpp:21-40). */
+void
+orc_p25p1_nid_decode(const uint8_t code[63], const uint8_t* rel63, int observed_nac, int parity, int parity_rel,
+                     int threshold, int out4[4]) {
+    int failed = 0;
+    nid_res hard = nid_codeword(code, parity, &failed);
+    if (hard.status == NID_FAIL && failed && nac_usable(observed_nac) && rx_nac(code) != observed_nac) {
+        uint8_t retry[63];
+        memcpy(retry, code, 63);
+        put_nac(retry, observed_nac);
+        hard = nid_codeword(retry, parity, 0);
+    }
+    nid_res res = hard;
+    if (hard.status <= 0 && rel63) {
+        /* pool: up to 8 least-reliable positions below the threshold, topped up to 6 (stable order by
+         * (reliability, index)) — p25p1_check_nid.cpp:118-150 */
+        int order[63];
+        for (int i = 0; i < 63; i++) {
+            order[i] = i;
+        }
+        for (int i = 0; i < 63; i++) {
+            for (int j = i + 1; j < 63; j++) {
+                const int a = order[j], b = order[i];
+                const int c = (rel63[a] != rel63[b]) ? ((int)rel63[a] - (int)rel63[b]) : (a - b);
+                if (c < 0) {
+                    order[i] = a;
+                    order[j] = b;
+                }
+            }
+        }
+        int pool[8], np = 0, sel[63] = {0};
+        for (int i = 0; i < 63 && np < 8; i++) {
+            if (rel63[order[i]] < threshold) {
+                pool[np++] = order[i];
+                sel[i] = 1;
+            }
+        }
+        for (int i = 0; i < 63 && np < 6; i++) {
+            if (!sel[i]) {
+                pool[np++] = order[i];
+            }
+        }
+        if (np > 0) {
+            chase_best best = {0, {NID_FAIL, 0, 0, 0}, 0, 0};
+            chase_from(code, rel63, pool, np, parity, parity_rel, threshold, &best);
+            if (nac_usable(observed_nac) && rx_nac(code) != observed_nac) {
+                uint8_t retry[63];
+                memcpy(retry, code, 63);
+                put_nac(retry, observed_nac);
+                chase_from(retry, rel63, pool, np, parity, parity_rel, threshold, &best);
+            }
+            if (best.found) {
+                res = best.dec;
+            }
+        }
+    }
+    out4[0] = res.status;
+    out4[1] = res.nac;
+    out4[2] = res.duid;
+    out4[3] = res.errs;
+}
+
+/* ---- Hamming(10,6,3), src/fec/hamming_10_6_3.cpp:20-58,90-105 ------------------------------------------ */
+/* word10 = (6 data bits << 4) | 4 parity bits.  Returns error count 0/1/2; *fixed6 = corrected data. */
+int
+orc_hamming_10_6_3(int word10, int* fixed6) {
+    static const int8_t bad_bit[16] = {-2, 0, 1, 5, 2, -1, -1, 6, 3, -1, -1, 7, 4, 8, 9, -1};
+    static const int mask[4] = {0x398, 0x354, 0x2E2, 0x1E1};
+    int syn = 0;
+    for (int k = 0; k < 4; k++) {
+        syn = (syn << 1) | (__builtin_popcount((unsigned)(word10 & mask[k])) & 1);
+    }
+    int fixed = word10, errs = 0;
+    if (syn) {
+        const int bb = bad_bit[syn];
+        if (bb < 0) {
+            errs = 2;
+        } else {
+            errs = 1;
+            if (bb >= 4) {
+                fixed ^= 1 << bb;
+            }
+        }
+    }
+    *fixed6 = fixed >> 4;
+    return errs;
+}

@@ -155,3 +155,32 @@ refh_fe_get_state(void* h, float* out7) {
 }
 
 } // extern "C"
+
+// ---- block codes: thin value-returning wrappers around the reference's C++ entry points -----------------
+#include <dsd-neo/fec/BCH_63_16.hpp>
+#include <dsd-neo/protocol/p25/p25p1_check_nid.h>
+
+extern "C" {
+
+// returns success (0/1); *err_count = corrected bits
+int
+refh_bch_63_16_decode(const char* in63, char* out16, int* err_count) {
+    static BCH_63_16_11 bch;
+    BCH_63_16_Result r = bch.decode_with_result(in63, out16);
+    *err_count = r.error_count;
+    return r.success ? 1 : 0;
+}
+
+// out4 = {status, nac, duid, error_count}
+void
+refh_nid_decode(const char* bch_code63, const uint8_t* reliab63, int observed_nac, int parity, int parity_reliab,
+                int out4[4]) {
+    struct p25p1_nid_result r =
+        p25p1_nid_decode(bch_code63, reliab63, observed_nac, (unsigned char)parity, (uint8_t)parity_reliab);
+    out4[0] = (int)r.status;
+    out4[1] = r.nac;
+    out4[2] = r.duid;
+    out4[3] = r.error_count;
+}
+
+} // extern "C"

@@ -174,3 +174,83 @@ def oracle_m17(soft, punct=None):
             cost[k] = o.orc_m17_viterbi_decode_punctured(out[k].ctypes.data, soft[k].ctypes.data, punct.ctypes.data,
                                                           in_len, len(punct))
     return out, cost, stride
+
+
+# ---- BCH(63,16,11) / P25 NID test generators ---------------------------------------------------------------
+def _gf64():
+    exp = [0] * 126
+    log = [0] * 64
+    x = 1
+    for i in range(63):
+        exp[i] = exp[i + 63] = x
+        log[x] = i
+        x <<= 1
+        if x & 64:
+            x ^= 0x43
+    return exp, log
+
+
+def bch_63_16_generator():
+    """g(x) over GF(2) = lcm of the minimal polynomials of alpha^1..alpha^22 (alpha: x^6+x+1).  Bit i = coeff x^i."""
+    exp, log = _gf64()
+    roots = set()
+    for e in range(1, 23):
+        c = e
+        while c not in roots:
+            roots.add(c)
+            c = (2 * c) % 63
+    poly = [1]  # coefficients in GF(64), low degree first
+    for r in sorted(roots):
+        a = exp[r]
+        nxt = [0] * (len(poly) + 1)
+        for i, c in enumerate(poly):
+            nxt[i + 1] ^= c
+            if c:
+                nxt[i] ^= exp[(log[c] + log[a]) % 63]
+        poly = nxt
+    assert all(c in (0, 1) for c in poly) and len(poly) == 48
+    return sum(c << i for i, c in enumerate(poly))
+
+
+_G63 = None
+
+
+def bch_63_16_encode(data16):
+    """data16: iterable of 16 bits (MSB first, NAC then DUID) -> np.uint8[63] in the decoder's input order."""
+    global _G63
+    if _G63 is None:
+        _G63 = bch_63_16_generator()
+    d = 0
+    for b in data16:
+        d = (d << 1) | int(b)
+    rem = d << 47
+    for sh in range(62, 46, -1):
+        if rem & (1 << sh):
+            rem ^= _G63 << (sh - 47)
+    cw = (d << 47) | rem  # coefficient of x^j at bit j; input[i] = coeff x^(62-i)
+    return np.array([(cw >> (62 - i)) & 1 for i in range(63)], np.uint8)
+
+
+def gen_nid(rng, n, max_err=14):
+    """-> bits [n,63], reliab [n,63], observed_nac [n], parity [n], parity_rel [n] with 0..max_err bit errors."""
+    duids = np.array([0, 3, 5, 7, 10, 12, 15])
+    bits = np.zeros((n, 63), np.uint8)
+    rel = rng.integers(90, 256, (n, 63)).astype(np.uint8)
+    obs = np.zeros(n, np.int32)
+    par = np.zeros(n, np.uint8)
+    prel = rng.integers(0, 256, n).astype(np.uint8)
+    for i in range(n):
+        nac = int(rng.integers(1, 0xFFF))
+        duid = int(duids[rng.integers(0, len(duids))])
+        if i % 11 == 0:
+            duid = int(rng.integers(0, 16))  # sometimes an undefined DUID
+        data = [(nac >> (11 - k)) & 1 for k in range(12)] + [(duid >> (3 - k)) & 1 for k in range(4)]
+        cw = bch_63_16_encode(data)
+        ne = int(rng.integers(0, max_err + 1))
+        pos = rng.choice(63, ne, replace=False)
+        cw[pos] ^= 1
+        rel[i, pos] = rng.integers(0, 100, ne)
+        bits[i] = cw
+        par[i] = (1 if duid in (5, 10) else 0) ^ (1 if i % 7 == 0 else 0)
+        obs[i] = nac if i % 3 == 0 else (0 if i % 3 == 1 else int(rng.integers(0, 0x1000)))
+    return bits, rel, obs, par, prel
