@@ -72,6 +72,12 @@ PROTOTYPES = {
                                            C.c_void_p, C.c_void_p]),
     "ddn_fec_viterbi_k5_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                           C.c_void_p]),
+    "ddn_ted_batch_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_void_p)]),
+    "ddn_ted_batch_destroy": (None, [C.c_void_p]),
+    "ddn_ted_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_gardner_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_gardner_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_ted_batch_get_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25p1_nid_decode_batch": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_p25p1_nid_decode_host": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_size_t, C.c_void_p]),
     "ddn_p25p1_nid_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_ubyte, C.c_uint8, C.c_int, C.c_void_p]),

@@ -40,6 +40,13 @@ typedef struct DdnFusedArgs {
     int dbg; /* timing experiments only (DDN_DBG env): 1 skip recurrences, 2 skip filter, 4 skip finish, 8 skip staging */
 } DdnFusedArgs;
 
+#define DDN_TED_DL 100 /* == TED_DL_SIZE (include/dsd-neo/dsp/ted.h:19) */
+typedef struct DdnTedState { /* == the carried fields of ted_state_t */
+    float mu, omega, omega_mid, omega_min, omega_max, omega_rel;
+    float last_r, last_j, lock_accum;
+    int lock_count, dl_index, twice_sps, sps;
+} DdnTedState;
+
 typedef struct DdnPuncture { /* puncture pattern of the K=5 decoder, expanded on the host */
     int p_len;               /* 0 = not punctured */
     int ones_total;
@@ -50,6 +57,9 @@ typedef struct DdnPuncture { /* puncture pattern of the K=5 decoder, expanded on
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sps, float ted_gain,
+                           int symbol_rate_hz, DdnTedState* state, float* dl_store, void* out, size_t out_stride,
+                           int* out_count, hipStream_t st);
 hipError_t ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
                               const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);

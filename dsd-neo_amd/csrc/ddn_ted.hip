@@ -1,0 +1,256 @@
+// ddn_ted.hip — batched OP25-style Gardner symbol-timing recovery (CQPSK branch), one channel per lane.
+//
+// Reference behaviour reproduced, float op for float op (compiled -ffp-contract=off):
+//   op25_gardner_cc and helpers      src/dsp/costas.cpp:352-534,804-858
+//   8-tap MMSE interpolator          src/dsp/mmse_interp.cpp:17-99
+//   ted_state_t                      include/dsd-neo/dsp/ted.h:22-45
+//
+// The loop is a per-sample feedback recurrence (mu / omega), so the only parallelism is across channels: lane =
+// channel, 64 channels per wavefront.  What the GPU version changes is the data movement:
+//   * input is staged tile by tile (64 channels x 64 samples) with coalesced 512-B row loads into a padded LDS tile,
+//     so the per-lane sequential reads never touch HBM with a 1-of-64 sector efficiency;
+//   * each lane's circular delay line (2 x twice_sps complex samples, doubled for wrap-free reads) lives in LDS laid
+//     out [slot][lane], so every lane always hits its own bank whatever its write index is;
+//   * the MMSE tap table is copied to LDS (lanes index it with different fractional phases).
+// Block structure: the reference's early "fewer than 4 samples" return aside, results do not depend on how a stream
+// is cut into calls; carried state (mu, omega, last symbol, lock detector, delay line) persists in the batch.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+namespace {
+__constant__ float c_mmse[17][8] = {
+    {0.00000e+00f, 0.00000e+00f, 0.00000e+00f, 0.00000e+00f, 1.00000e+00f, 0.00000e+00f, 0.00000e+00f, 0.00000e+00f},
+    {-1.23337e-03f, 6.84261e-03f, -2.24178e-02f, 6.57852e-02f, 9.83392e-01f, -4.04519e-02f, 9.56876e-03f, -1.54221e-03f},
+    {-2.43121e-03f, 1.35716e-02f, -4.49929e-02f, 1.36968e-01f, 9.55956e-01f, -7.43154e-02f, 1.80759e-02f, -2.94361e-03f},
+    {-3.55283e-03f, 1.99599e-02f, -6.70018e-02f, 2.12443e-01f, 9.18329e-01f, -1.01501e-01f, 2.53295e-02f, -4.16581e-03f},
+    {-4.55932e-03f, 2.57844e-02f, -8.77011e-02f, 2.91006e-01f, 8.71305e-01f, -1.22047e-01f, 3.11866e-02f, -5.17776e-03f},
+    {-5.41467e-03f, 3.08323e-02f, -1.06342e-01f, 3.71376e-01f, 8.15826e-01f, -1.36111e-01f, 3.55525e-02f, -5.95620e-03f},
+    {-6.08674e-03f, 3.49066e-02f, -1.22185e-01f, 4.52218e-01f, 7.52958e-01f, -1.43968e-01f, 3.83800e-02f, -6.48585e-03f},
+    {-6.54823e-03f, 3.78315e-02f, -1.34515e-01f, 5.32164e-01f, 6.83875e-01f, -1.45993e-01f, 3.96678e-02f, -6.75943e-03f},
+    {-6.77751e-03f, 3.94578e-02f, -1.42658e-01f, 6.09836e-01f, 6.09836e-01f, -1.42658e-01f, 3.94578e-02f, -6.77751e-03f},
+    {-6.73929e-03f, 3.95900e-02f, -1.46043e-01f, 6.92808e-01f, 5.22267e-01f, -1.33190e-01f, 3.75341e-02f, -6.50285e-03f},
+    {-6.48585e-03f, 3.83800e-02f, -1.43968e-01f, 7.52958e-01f, 4.52218e-01f, -1.22185e-01f, 3.49066e-02f, -6.08674e-03f},
+    {-5.95620e-03f, 3.55525e-02f, -1.36111e-01f, 8.15826e-01f, 3.71376e-01f, -1.06342e-01f, 3.08323e-02f, -5.41467e-03f},
+    {-5.17776e-03f, 3.11866e-02f, -1.22047e-01f, 8.71305e-01f, 2.91006e-01f, -8.77011e-02f, 2.57844e-02f, -4.55932e-03f},
+    {-4.16581e-03f, 2.53295e-02f, -1.01501e-01f, 9.18329e-01f, 2.12443e-01f, -6.70018e-02f, 1.99599e-02f, -3.55283e-03f},
+    {-2.94361e-03f, 1.80759e-02f, -7.43154e-02f, 9.55956e-01f, 1.36968e-01f, -4.49929e-02f, 1.35716e-02f, -2.43121e-03f},
+    {-1.54221e-03f, 9.56876e-03f, -4.04519e-02f, 9.83392e-01f, 6.57852e-02f, -2.24178e-02f, 6.84261e-03f, -1.23337e-03f},
+    {0.00000e+00f, 0.00000e+00f, 0.00000e+00f, 1.00000e+00f, 0.00000e+00f, 0.00000e+00f, 0.00000e+00f, 0.00000e+00f}
+};
+
+__device__ __forceinline__ float
+clipf(float x, float lim) {
+    return x > lim ? lim : (x < -lim ? -lim : x);
+}
+
+// dl: this lane's delay line, element k (float) at dl[k * 64]; tap table in LDS
+__device__ __forceinline__ void
+mmse8(const float* dl, int first_complex, float mu, const float (*tbl)[8], float* re, float* im) {
+    float pos = mu * 16.0f;
+    int lo = (int)pos;
+    float fr = pos - (float)lo;
+    if (lo < 0) {
+        lo = 0;
+        fr = 0.0f;
+    }
+    if (lo >= 16) {
+        lo = 15;
+        fr = 1.0f;
+    }
+    const float lw = 1.0f - fr;
+    float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float tap = lw * tbl[lo][i] + fr * tbl[lo + 1][i];
+        const int k = 2 * (first_complex + 7 - i);
+        ar += tap * dl[(size_t)k * 64];
+        ai += tap * dl[(size_t)(k + 1) * 64];
+    }
+    *re = ar;
+    *im = ai;
+}
+} // namespace
+
+__global__ __launch_bounds__(64) void
+k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, int sps, float ted_gain,
+          int symbol_rate_hz, DdnTedState* __restrict__ state, float* __restrict__ dl_store, f2* __restrict__ out,
+          size_t out_stride, int* __restrict__ out_count) {
+    constexpr int TS = 64;
+    extern __shared__ float smem[];
+    float(*tbl)[8] = (float(*)[8])smem;            // [17][8]
+    f2* tile = (f2*)(smem + 17 * 8 + 8);            // [64][TS + 1]
+    float* dls = (float*)(tile + 64 * (TS + 1));    // [4 * tw][64]
+    const int lane = threadIdx.x;
+    const int ch0 = blockIdx.x * 64;
+    const int ch = ch0 + lane;
+    const bool live = ch < n_channels;
+    for (int i = lane; i < 17 * 8; i += 64) {
+        tbl[i / 8][i % 8] = c_mmse[i / 8][i % 8];
+    }
+    DdnTedState t;
+    if (live) {
+        t = state[ch];
+    } else {
+        t.mu = 0.f; t.omega = 0.f; t.omega_mid = 0.f; t.omega_min = 0.f; t.omega_max = 0.f; t.omega_rel = 0.f;
+        t.last_r = 0.f; t.last_j = 0.f; t.lock_accum = 0.f; t.lock_count = 0; t.dl_index = 0; t.twice_sps = 0; t.sps = 0;
+    }
+    int o = 0;
+    bool run = live && n >= 4;
+    // (re)initialisation, src/dsp/costas.cpp:352-398
+    float omega = t.omega;
+    if (run && ((t.omega_mid == 0.0f || t.twice_sps < 2) || (t.sps > 0 && t.sps != sps))) {
+        t.mu = (float)sps;
+        omega = (float)sps;
+        t.omega_rel = 0.002f;
+        t.omega_mid = omega;
+        t.omega_min = omega * (1.0f - t.omega_rel);
+        t.omega_max = omega * (1.0f + t.omega_rel);
+        const int a = 2 * (int)ceilf(t.omega_max);
+        const int b = (int)ceilf(t.omega_max / 2.0f) + 8 + 1;
+        const int need = a > b ? a : b;
+        if (need > DDN_TED_DL) {
+            run = false;
+        } else {
+            t.twice_sps = need;
+            t.dl_index = 0;
+            t.sps = sps;
+            if (live) {
+                dl_store[(size_t)ch * (DDN_TED_DL * 4)] = 0.0f;
+                dl_store[(size_t)ch * (DDN_TED_DL * 4) + 1] = 0.0f;
+            }
+        }
+    }
+    const int tw = t.twice_sps;
+    float* dl = dls + lane;
+    if (live) {
+        for (int k = 0; k < 4 * tw; k++) {
+            dl[(size_t)k * 64] = dl_store[(size_t)ch * (DDN_TED_DL * 4) + k];
+        }
+    }
+    // gain selection, src/dsp/costas.cpp:143-168 (no env / API override)
+    float gain_mu = ted_gain > 0.0f ? ted_gain : 0.025f;
+    if (symbol_rate_hz >= 5500 && t.lock_count >= 240 && !(t.lock_accum / (float)t.lock_count < 0.05f)) {
+        gain_mu = 0.018f;
+    }
+    const float gain_omega = 0.1f * gain_mu * gain_mu;
+    float mu = t.mu, last_r = t.last_r, last_j = t.last_j, lock = t.lock_accum;
+    int lock_n = t.lock_count, dli = t.dl_index;
+    f2* op = out + (size_t)ch * out_stride;
+    __syncthreads();
+
+    for (long t0 = 0; t0 < n; t0 += TS) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        // coalesced staging: row c of the tile = TS consecutive samples of channel ch0 + c
+        for (int c = 0; c < 64; c++) {
+            if (ch0 + c < n_channels && lane < tn) {
+                tile[c * (TS + 1) + lane] = in[(size_t)(ch0 + c) * in_stride + t0 + lane];
+            }
+        }
+        __syncthreads();
+        if (run) {
+            for (int s = 0; s < tn; s++) {
+                // produce symbols while the loop is "ready" and input remains (this sample exists); the trip
+                // bound only matters for a non-finite mu (the reference would then spin until its output is full)
+                int trips = 0;
+                while (!(mu > 1.0f) && trips++ < 8) {
+                    const float half_omega = omega / 2.0f;
+                    int hs = (int)floorf(half_omega);
+                    float hmu = mu + half_omega - (float)hs;
+                    if (hmu > 1.0f) {
+                        hmu -= 1.0f;
+                        hs += 1;
+                    }
+                    if (hs < 0) {
+                        hs = 0;
+                    }
+                    if (dli + 7 >= 2 * tw || dli + hs + 7 >= 2 * tw) {
+                        mu += omega;
+                        continue;
+                    }
+                    float mr, mj, sr, sj;
+                    mmse8(dl, dli, mu, tbl, &mr, &mj);
+                    mmse8(dl, dli + hs, hmu, tbl, &sr, &sj);
+                    float err = (last_r - sr) * mr + (last_j - sj) * mj;
+                    if (err != err) {
+                        err = 0.0f;
+                    }
+                    err = clipf(err, 1.0f);
+                    const float ie2 = sr * sr, io2 = mr * mr, qe2 = sj * sj, qo2 = mj * mj;
+                    const float yi = ((ie2 + io2) != 0.0f) ? (ie2 - io2) / (ie2 + io2) : 0.0f;
+                    const float yq = ((qe2 + qo2) != 0.0f) ? (qe2 - qo2) / (qe2 + qo2) : 0.0f;
+                    lock += yi + yq;
+                    lock_n++;
+                    const float mag = sqrtf(sr * sr + sj * sj);
+                    omega += gain_omega * err * mag;
+                    omega = t.omega_mid + clipf(omega - t.omega_mid, t.omega_rel);
+                    mu += omega + gain_mu * err;
+                    last_r = sr;
+                    last_j = sj;
+                    if ((size_t)o < out_stride) {
+                        const f2 v = {sr, sj};
+                        op[o] = v;
+                    }
+                    o++;
+                }
+                // consume one input sample into the doubled delay line
+                mu -= 1.0f;
+                f2 x = tile[lane * (TS + 1) + s];
+                if (x.x != x.x) {
+                    x.x = 0.0f;
+                }
+                if (x.y != x.y) {
+                    x.y = 0.0f;
+                }
+                dl[(size_t)(2 * dli) * 64] = x.x;
+                dl[(size_t)(2 * dli + 1) * 64] = x.y;
+                dl[(size_t)(2 * (dli + tw)) * 64] = x.x;
+                dl[(size_t)(2 * (dli + tw) + 1) * 64] = x.y;
+                if (++dli >= tw) {
+                    dli = 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        if (run) {
+            t.mu = mu;
+            t.omega = omega;
+            t.dl_index = dli;
+            t.last_r = last_r;
+            t.last_j = last_j;
+            t.lock_accum = lock;
+            t.lock_count = lock_n;
+            for (int k = 0; k < 4 * tw; k++) {
+                dl_store[(size_t)ch * (DDN_TED_DL * 4) + k] = dl[(size_t)k * 64];
+            }
+        }
+        state[ch] = t;
+        out_count[ch] = o;
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sps, float ted_gain, int symbol_rate_hz,
+                DdnTedState* state, float* dl_store, void* out, size_t out_stride, int* out_count, hipStream_t st) {
+    if (n_channels <= 0) {
+        return hipSuccess;
+    }
+    // twice_sps for this sps (uniform over the batch): max(2*ceil(1.002*sps), ceil(1.002*sps/2) + 9)
+    const float omax = (float)sps * (1.0f + 0.002f);
+    int a = 2 * (int)ceilf(omax), b = (int)ceilf(omax / 2.0f) + 9;
+    int tw = a > b ? a : b;
+    if (tw > DDN_TED_DL) {
+        tw = DDN_TED_DL;
+    }
+    const size_t shm = sizeof(float) * (17 * 8 + 8) + sizeof(f2) * 64 * 65 + sizeof(float) * 4 * (size_t)tw * 64;
+    hipLaunchKernelGGL(k_gardner, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), shm, st, (const f2*)in, n,
+                       in_stride, n_channels, sps, ted_gain, symbol_rate_hz, state, dl_store, (f2*)out, out_stride,
+                       out_count);
+    return hipGetLastError();
+}

@@ -96,6 +96,22 @@ int ddn_batch_get_fsk_state(ddn_batch* b, int channel, float out5[5]);
 int ddn_batch_set_timing(ddn_batch* b, int enable);
 int ddn_batch_get_timing(ddn_batch* b, float out3[3]);
 
+/* ---- Gardner symbol-timing recovery (CQPSK branch), batched ----------------------------------------------
+ * == op25_gardner_cc(struct demod_state*) (include/dsd-neo/dsp/costas.h; src/dsp/costas.cpp:804-858) applied to B
+ * channels at once; each channel's ted_state_t is carried inside the batch object.
+ *   d_iq  : [B][n] complex f32 at sample rate (post channel-LPF / AGC / FLL), channel-major
+ *   d_sym : [B][sym_stride] complex f32 at symbol rate; d_sym_count[B] = symbols produced this call (may exceed
+ *           sym_stride, in which case the surplus was dropped: size sym_stride >= n/sps*1.01 + 2)
+ * out8 of get_state = {mu, omega, last_r, last_j, lock_accum, lock_count, dl_index, twice_sps}. */
+typedef struct ddn_ted_batch ddn_ted_batch;
+int ddn_ted_batch_create(int n_channels, int sps, int symbol_rate_hz, float ted_gain, ddn_ted_batch** out);
+void ddn_ted_batch_destroy(ddn_ted_batch* b);
+int ddn_ted_batch_reset(ddn_ted_batch* b, void* hip_stream);
+int ddn_gardner_run(ddn_ted_batch* b, const float* d_iq, size_t n, float* d_sym, size_t sym_stride, int* d_sym_count,
+                    void* hip_stream);
+int ddn_gardner_run_host(ddn_ted_batch* b, const float* iq, size_t n, float* sym, size_t sym_stride, int* sym_count);
+int ddn_ted_batch_get_state(ddn_ted_batch* b, int channel, float out8[8]);
+
 /* ---- batched trellis / Viterbi decoders (bit-exact integer) ------------------------------------------
  * d_* = device pointers, asynchronous on hip_stream; *_host = host pointers, synchronous.
  *   ddn_fec_p25_12_soft_*   P25 1/2-rate 4-state trellis on bit LLRs: [n][196] int16 -> [n][12] bytes (+ metric>>8)

@@ -103,6 +103,22 @@ uint32_t orc_m17_viterbi_decode(uint8_t* out, const uint16_t* in, int len);
 uint32_t orc_m17_viterbi_decode_punctured(uint8_t* out, const uint16_t* in, const uint8_t* punct, int in_len,
                                           int p_len);
 
+/* ---- Gardner timing recovery (oracle/ddn_oracle_ted.c) ------------------------------------------------ */
+#define ORC_TED_DL 100 /* TED_DL_SIZE, include/dsd-neo/dsp/ted.h:19 */
+typedef struct orc_ted_state {
+    float mu, omega, omega_mid, omega_min, omega_max, omega_rel;
+    float last_r, last_j;
+    float lock_accum;
+    int lock_count;
+    float dl[ORC_TED_DL * 2 * 2];
+    int dl_index, twice_sps, sps;
+} orc_ted_state;
+const float* orc_mmse_table(void);
+void orc_mmse_interp_complex(const float* samples, float mu, float* re, float* im);
+void orc_ted_init(orc_ted_state* t);
+int orc_gardner_block(orc_ted_state* t, int sps, float ted_gain, int symbol_rate_hz, const float* iq, int n,
+                      float* out);
+
 /* ---- block codes (oracle/ddn_oracle_block.c) ---------------------------------------------------------- */
 int orc_bch_63_16_decode(const uint8_t in63[63], uint8_t out16[16], int* err_count);
 void orc_p25p1_nid_decode(const uint8_t code[63], const uint8_t* rel63, int observed_nac, int parity, int parity_rel,

@@ -184,3 +184,70 @@ refh_nid_decode(const char* bch_code63, const uint8_t* reliab63, int observed_na
 }
 
 } // extern "C"
+
+// ---- Gardner timing recovery: drive the reference's op25_gardner_cc() block by block ----------------------
+#include <dsd-neo/dsp/costas.h>
+#include "mmse_interp.h" /* src/dsp/mmse_interp.h (private header, on the -I path) */
+
+extern "C" {
+
+void*
+refh_ted_create(int sps, float ted_gain, int symbol_rate_hz) {
+    void* mem = dsd_neo_aligned_malloc(sizeof(demod_state));
+    if (!mem) {
+        return nullptr;
+    }
+    demod_state* d = new (mem) demod_state();
+    d->cqpsk_enable = 1;
+    d->ted_sps = sps;
+    d->ted_gain = ted_gain;
+    d->symbol_rate_hz = symbol_rate_hz;
+    d->rate_out = sps * symbol_rate_hz;
+    ted_init_state(&d->ted_state);
+    return d;
+}
+
+void
+refh_ted_destroy(void* h) {
+    demod_state* d = static_cast<demod_state*>(h);
+    if (d) {
+        d->~demod_state();
+        dsd_neo_aligned_free(d);
+    }
+}
+
+// returns floats written to out (symbol-rate interleaved I/Q)
+int
+refh_ted_block(void* h, const float* iq, int n_complex, float* out) {
+    demod_state* d = static_cast<demod_state*>(h);
+    std::memcpy(d->input_cb_buf, iq, (size_t)n_complex * 2 * sizeof(float));
+    d->lowpassed = d->input_cb_buf;
+    d->lp_len = n_complex * 2;
+    op25_gardner_cc(d);
+    if (d->lowpassed == d->input_cb_buf) {
+        return 0; // gardner returned early without producing symbols
+    }
+    std::memcpy(out, d->lowpassed, (size_t)d->lp_len * sizeof(float));
+    return d->lp_len;
+}
+
+// {mu, omega, last_r, last_j, lock_accum, lock_count, dl_index, twice_sps}
+void
+refh_ted_state(void* h, float* out8) {
+    const ted_state_t* t = &static_cast<demod_state*>(h)->ted_state;
+    out8[0] = t->mu;
+    out8[1] = t->omega;
+    out8[2] = t->last_r;
+    out8[3] = t->last_j;
+    out8[4] = t->lock_accum;
+    out8[5] = (float)t->lock_count;
+    out8[6] = (float)t->dl_index;
+    out8[7] = (float)t->twice_sps;
+}
+
+void
+refh_mmse(const float* samples, float mu, float* re, float* im) {
+    dsd_mmse_interp_complex_8tap(samples, mu, re, im);
+}
+
+} // extern "C"

@@ -168,3 +168,69 @@ def load_fixture_cu8(name):
     """Reference IQ fixture bytes -> uint8 [n, 2]; from tests/golden (committed excerpt) or /root/reference."""
     p = os.path.join(REFERENCE_ROOT, "tests", "fixtures", "iq", name)
     return np.fromfile(p, dtype=np.uint8).reshape(-1, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Gardner timing recovery helpers
+
+def synth_qpsk_f32(seed, n_ch, n_sym, sps, drift=1.0005, noise=0.05):
+    """Band-limited random QPSK at `sps` samples/symbol with a per-channel timing offset and a small clock drift,
+    amplitude 0.85 (the RMS-AGC reference level of the CQPSK chain).  -> float32 [n_ch, n, 2]."""
+    rng = np.random.default_rng(seed)
+    n = int(n_sym * sps / drift) - 40
+    out = np.empty((n_ch, n, 2), np.float32)
+    for c in range(n_ch):
+        ph = (rng.integers(0, 4, n_sym) * 2 + 1) * np.pi / 4
+        t = np.arange(n) * drift / sps + rng.random()
+        x = np.zeros(n, complex)
+        for off in range(-3, 4):
+            idx = np.clip(np.floor(t).astype(int) + off, 0, n_sym - 1)
+            tau = t - idx
+            x += np.exp(1j * ph[idx]) * np.sinc(tau) * np.cos(np.pi * 0.35 * tau) / (1 - (0.7 * tau) ** 2 + 1e-9)
+        x += noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        out[c, :, 0] = 0.85 * x.real
+        out[c, :, 1] = 0.85 * x.imag
+    return out
+
+
+class OracleTed:
+    def __init__(self, sps, symbol_rate_hz, ted_gain=0.0):
+        o = oracle()
+        o.orc_ted_init.argtypes = [C.c_void_p]
+        o.orc_gardner_block.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        self.st = C.create_string_buffer(4096)
+        o.orc_ted_init(self.st)
+        self.sps, self.rate, self.gain = sps, symbol_rate_hz, ted_gain
+
+    def block(self, iq):
+        iq = np.ascontiguousarray(iq, np.float32).reshape(-1)
+        n = iq.size // 2
+        out = np.zeros(2 * n + 8, np.float32)
+        w = oracle().orc_gardner_block(self.st, self.sps, self.gain, self.rate, iq.ctypes.data, n, out.ctypes.data)
+        return out[:w].reshape(-1, 2).copy()
+
+
+def ref_ted_blocks(iq, sps, symbol_rate_hz, ted_gain, blocks):
+    """Run the compiled reference's op25_gardner_cc over `iq` [n,2] cut into the given block lengths."""
+    r = ref()
+    r.refh_ted_create.restype = C.c_void_p
+    r.refh_ted_create.argtypes = [C.c_int, C.c_float, C.c_int]
+    r.refh_ted_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    r.refh_ted_state.argtypes = [C.c_void_p, C.c_void_p]
+    r.refh_ted_destroy.argtypes = [C.c_void_p]
+    h = r.refh_ted_create(sps, ted_gain, symbol_rate_hz)
+    iq = np.ascontiguousarray(iq, np.float32)
+    outs, pos = [], 0
+    for b in blocks:
+        m = min(b, iq.shape[0] - pos)
+        if m <= 0:
+            break
+        o = np.zeros(2 * m + 8, np.float32)
+        seg = np.ascontiguousarray(iq[pos:pos + m])
+        w = r.refh_ted_block(h, seg.ctypes.data, m, o.ctypes.data)
+        outs.append(o[:w].reshape(-1, 2).copy())
+        pos += m
+    st = np.zeros(8, np.float32)
+    r.refh_ted_state(h, st.ctypes.data)
+    r.refh_ted_destroy(h)
+    return outs, st
