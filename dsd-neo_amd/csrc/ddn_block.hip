@@ -44,40 +44,78 @@ gf_fill(uint8_t* ex, uint8_t* lg) { // one thread
     lg[0] = 0;
 }
 
+// Per-lane working arrays live in LDS, element k of this lane at base[k * 64] (no scratch memory, no bank
+// conflicts beyond byte-in-word sharing).  Exponent arithmetic mod 63 uses running sums with a conditional
+// subtract instead of integer division.
+struct Work {
+    uint8_t* S; // [23]
+    uint8_t* C; // [24]
+    uint8_t* B; // [24]
+    uint8_t* T; // [24]
+    __device__ __forceinline__ uint8_t& s(int i) const { return S[i * 64]; }
+    __device__ __forceinline__ uint8_t& c(int i) const { return C[i * 64]; }
+    __device__ __forceinline__ uint8_t& b(int i) const { return B[i * 64]; }
+    __device__ __forceinline__ uint8_t& t(int i) const { return T[i * 64]; }
+};
+
 // w: bit p = received bit at input position p (0..62; data 0..15 MSB-first, parity 16..62).
 // Returns 1 on success with *fixed = corrected word and *nerr = flipped bits.
 __device__ int
-bch_63_16_decode(const Gf& gf, uint64_t w, uint64_t* fixed, int* nerr) {
-    uint8_t S[23];
-    int any = 0;
-    for (int i = 1; i <= 22; i++) {
-        int s = 0;
+bch_63_16_decode(const Gf& gf, const Work& wk, uint64_t w, uint64_t* fixed, int* nerr) {
+    // Odd syndromes S1,S3,..,S21 accumulate in registers (static indices); even ones follow from the binary-code
+    // identity S_2i = S_i^2.  Running exponent e = i*j mod 63 advances by 2j per odd step.
+    int so[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        so[k] = 0;
+    }
+    {
         uint64_t m = w;
         while (m) {
             const int p = __builtin_ctzll(m);
             m &= m - 1;
-            s ^= gf.ex[(i * (62 - p)) % 63];
+            const int j = 62 - p; // r-index of this bit; contributes alpha^(i*j) to S_i
+            int j2 = 2 * j;
+            if (j2 >= 63) {
+                j2 -= 63;
+            }
+            int e = j;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                so[k] ^= gf.ex[e];
+                e += j2;
+                if (e >= 63) {
+                    e -= 63;
+                }
+            }
         }
-        S[i] = (uint8_t)s;
-        any |= s;
+    }
+    int any = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        wk.s(2 * k + 1) = (uint8_t)so[k];
+        any |= so[k];
+    }
+    for (int i = 2; i <= 22; i += 2) { // S_i = (S_{i/2})^2, ascending so the source is already final
+        const int h = wk.s(i / 2);
+        wk.s(i) = (uint8_t)(h ? gf.ex[(2 * gf.lg[h]) % 63] : 0);
     }
     *nerr = 0;
     *fixed = w;
     if (!any) {
         return 1;
     }
-    uint8_t C[24], B[24], T[24];
     for (int i = 0; i < 24; i++) {
-        C[i] = 0;
-        B[i] = 0;
+        wk.c(i) = 0;
+        wk.b(i) = 0;
     }
-    C[0] = 1;
-    B[0] = 1;
+    wk.c(0) = 1;
+    wk.b(0) = 1;
     int L = 0, m = 1, b = 1;
     for (int n = 0; n < 22; n++) {
-        int d = S[n + 1];
+        int d = wk.s(n + 1);
         for (int i = 1; i <= L; i++) {
-            d ^= gf.mul(C[i], S[n + 1 - i]);
+            d ^= gf.mul(wk.c(i), wk.s(n + 1 - i));
         }
         if (d == 0) {
             m++;
@@ -86,20 +124,20 @@ bch_63_16_decode(const Gf& gf, uint64_t w, uint64_t* fixed, int* nerr) {
         const int f = gf.div(d, b);
         if (2 * L <= n) {
             for (int i = 0; i < 24; i++) {
-                T[i] = C[i];
+                wk.t(i) = wk.c(i);
             }
             for (int i = 0; i + m < 24; i++) {
-                C[i + m] ^= (uint8_t)gf.mul(f, B[i]);
+                wk.c(i + m) ^= (uint8_t)gf.mul(f, wk.b(i));
             }
             L = n + 1 - L;
             for (int i = 0; i < 24; i++) {
-                B[i] = T[i];
+                wk.b(i) = wk.t(i);
             }
             b = d;
             m = 1;
         } else {
             for (int i = 0; i + m < 24; i++) {
-                C[i + m] ^= (uint8_t)gf.mul(f, B[i]);
+                wk.c(i + m) ^= (uint8_t)gf.mul(f, wk.b(i));
             }
             m++;
         }
@@ -107,14 +145,29 @@ bch_63_16_decode(const Gf& gf, uint64_t w, uint64_t* fixed, int* nerr) {
             return 0;
         }
     }
+    // Chien search: root alpha^i <-> error at r-index 63-i <-> input position i-1.  The <= 12 coefficients move
+    // to registers (static indices, terms above L predicated off); te[k] is the running exponent
+    // log(C[k]) + i*k (mod 63) of term k.
+    int te[12];
+    bool on[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int ck = (k <= L) ? wk.c(k) : 0;
+        on[k] = ck != 0;
+        te[k] = ck ? gf.lg[ck] : 0;
+    }
     int count = 0;
     uint64_t flips = 0;
-    for (int i = 1; i <= 63; i++) { // Chien search: root alpha^i <-> error at r-index 63-i <-> input position i-1
+    for (int i = 1; i <= 63; i++) {
         int q = 0;
-        for (int k = 0; k <= L; k++) {
-            if (C[k]) {
-                q ^= gf.ex[(gf.lg[C[k]] + i * k) % 63];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            int e = te[k] + k;
+            if (e >= 63) {
+                e -= 63;
             }
+            te[k] = e;
+            q ^= on[k] ? gf.ex[e] : 0;
         }
         if (q == 0) {
             if (count >= 11) {
@@ -138,14 +191,14 @@ struct NidRes {
 };
 
 __device__ NidRes
-nid_codeword(const Gf& gf, uint64_t w, int parity, int* bch_failed) {
+nid_codeword(const Gf& gf, const Work& wk, uint64_t w, int parity, int* bch_failed) {
     NidRes r = {0, 0, 0, 0};
     uint64_t fixed;
     int errs;
     if (bch_failed) {
         *bch_failed = 0;
     }
-    if (!bch_63_16_decode(gf, w, &fixed, &errs)) {
+    if (!bch_63_16_decode(gf, wk, w, &fixed, &errs)) {
         if (bch_failed) {
             *bch_failed = 1;
         }
@@ -197,7 +250,7 @@ struct ChaseBest {
 };
 
 __device__ void
-chase_from(const Gf& gf, uint64_t base, const uint8_t* rel, const int* pool, int np, int parity, int parity_rel,
+chase_from(const Gf& gf, const Work& wk, uint64_t base, const uint8_t* rel, uint64_t pool, int np, int parity, int parity_rel,
            int threshold, ChaseBest* best) {
     for (int mask = 0; mask < (1 << np); mask++) {
         const int changed = __popc((unsigned)mask);
@@ -208,14 +261,15 @@ chase_from(const Gf& gf, uint64_t base, const uint8_t* rel, const int* pool, int
         int score = 0;
         for (int b = 0; b < np; b++) {
             if (mask & (1 << b)) {
-                cand ^= 1ull << pool[b];
-                score += rel[pool[b]];
+                const int pos = (int)((pool >> (8 * b)) & 0xFF);
+                cand ^= 1ull << pos;
+                score += rel[pos];
             }
         }
         if (changed && score > threshold * changed) {
             continue;
         }
-        const NidRes dec = nid_codeword(gf, cand, parity, nullptr);
+        const NidRes dec = nid_codeword(gf, wk, cand, parity, nullptr);
         if (dec.status <= 0) {
             continue;
         }
@@ -242,11 +296,14 @@ k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel
              int32_t* __restrict__ out4) {
     __shared__ uint8_t ex[128];
     __shared__ uint8_t lg[64];
+    __shared__ uint8_t work[(23 + 24 + 24 + 24) * 64];
     if (threadIdx.x == 0) {
         gf_fill(ex, lg);
     }
     __syncthreads();
     const Gf gf = {ex, lg};
+    const Work wk = {work + threadIdx.x, work + 23 * 64 + threadIdx.x, work + 47 * 64 + threadIdx.x,
+                     work + 71 * 64 + threadIdx.x};
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) {
         return;
@@ -262,19 +319,15 @@ k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel
     const bool obs_ok = obs > 0 && obs < 0xFFF;
 
     int failed = 0;
-    NidRes hard = nid_codeword(gf, w, par, &failed);
+    NidRes hard = nid_codeword(gf, wk, w, par, &failed);
     if (hard.status == 0 && failed && obs_ok && rx_nac(w) != obs) {
-        hard = nid_codeword(gf, put_nac(w, obs), par, nullptr);
+        hard = nid_codeword(gf, wk, put_nac(w, obs), par, nullptr);
     }
     NidRes res = hard;
     if (hard.status <= 0 && rel63) {
-        const uint8_t* rp = rel63 + (size_t)c * 63;
-        uint8_t rel[63];
-        for (int i = 0; i < 63; i++) {
-            rel[i] = rp[i];
-        }
+        const uint8_t* rel = rel63 + (size_t)c * 63; // read in place (L1/L2-resident, 63 bytes per lane)
         // the 8 least reliable positions in (reliability, index) order; pool = first max(6, min(8, #below thr))
-        int pool[8];
+        uint64_t pool = 0; // 8 positions, one per byte
         uint64_t taken = 0;
         int below = 0;
         for (int i = 0; i < 63; i++) {
@@ -288,7 +341,7 @@ k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel
                     bi = i;
                 }
             }
-            pool[k] = bi;
+            pool |= (uint64_t)bi << (8 * k);
             taken |= 1ull << bi;
         }
         int np = below < 8 ? below : 8;
@@ -296,9 +349,9 @@ k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel
             np = 6;
         }
         ChaseBest best = {0, {0, 0, 0, 0}, 0, 0};
-        chase_from(gf, w, rel, pool, np, par, prel, threshold, &best);
+        chase_from(gf, wk, w, rel, pool, np, par, prel, threshold, &best);
         if (obs_ok && rx_nac(w) != obs) {
-            chase_from(gf, put_nac(w, obs), rel, pool, np, par, prel, threshold, &best);
+            chase_from(gf, wk, put_nac(w, obs), rel, pool, np, par, prel, threshold, &best);
         }
         if (best.found) {
             res = best.dec;

@@ -76,31 +76,32 @@ mmse8(const float* dl, int first_complex, float mu, const float (*tbl)[8], float
 }
 } // namespace
 
-__global__ __launch_bounds__(64) void
+__global__ __launch_bounds__(128) void
 k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, int sps, float ted_gain,
           int symbol_rate_hz, DdnTedState* __restrict__ state, float* __restrict__ dl_store, f2* __restrict__ out,
           size_t out_stride, int* __restrict__ out_count) {
     constexpr int TS = 64;
     extern __shared__ float smem[];
     float(*tbl)[8] = (float(*)[8])smem;            // [17][8]
-    f2* tile = (f2*)(smem + 17 * 8 + 8);            // [64][TS + 1]
-    float* dls = (float*)(tile + 64 * (TS + 1));    // [4 * tw][64]
-    const int lane = threadIdx.x;
+    f2* tile0 = (f2*)(smem + 17 * 8 + 8);           // [2][64][TS + 1] double-buffered input tile
+    float* dls = (float*)(tile0 + 2 * 64 * (TS + 1)); // [4 * tw][64]
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64; // wave 1 streams the next tile in while wave 0 runs the timing loop
     const int ch0 = blockIdx.x * 64;
     const int ch = ch0 + lane;
     const bool live = ch < n_channels;
-    for (int i = lane; i < 17 * 8; i += 64) {
+    for (int i = threadIdx.x; i < 17 * 8; i += 128) {
         tbl[i / 8][i % 8] = c_mmse[i / 8][i % 8];
     }
     DdnTedState t;
-    if (live) {
+    if (live && !loader) {
         t = state[ch];
     } else {
         t.mu = 0.f; t.omega = 0.f; t.omega_mid = 0.f; t.omega_min = 0.f; t.omega_max = 0.f; t.omega_rel = 0.f;
         t.last_r = 0.f; t.last_j = 0.f; t.lock_accum = 0.f; t.lock_count = 0; t.dl_index = 0; t.twice_sps = 0; t.sps = 0;
     }
     int o = 0;
-    bool run = live && n >= 4;
+    bool run = live && n >= 4 && !loader;
     // (re)initialisation, src/dsp/costas.cpp:352-398
     float omega = t.omega;
     if (run && ((t.omega_mid == 0.0f || t.twice_sps < 2) || (t.sps > 0 && t.sps != sps))) {
@@ -119,7 +120,7 @@ k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, i
             t.twice_sps = need;
             t.dl_index = 0;
             t.sps = sps;
-            if (live) {
+            if (live && !loader) {
                 dl_store[(size_t)ch * (DDN_TED_DL * 4)] = 0.0f;
                 dl_store[(size_t)ch * (DDN_TED_DL * 4) + 1] = 0.0f;
             }
@@ -127,7 +128,7 @@ k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, i
     }
     const int tw = t.twice_sps;
     float* dl = dls + lane;
-    if (live) {
+    if (live && !loader) {
         for (int k = 0; k < 4 * tw; k++) {
             dl[(size_t)k * 64] = dl_store[(size_t)ch * (DDN_TED_DL * 4) + k];
         }
@@ -143,81 +144,119 @@ k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, i
     f2* op = out + (size_t)ch * out_stride;
     __syncthreads();
 
-    for (long t0 = 0; t0 < n; t0 += TS) {
+    // coalesced staging: row c of a tile = TS consecutive samples of channel ch0 + c; all 64 row loads are issued
+    // before the first LDS store so one HBM round trip covers the whole tile
+    auto stage = [&](long t0, f2* tile) {
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
-        // coalesced staging: row c of the tile = TS consecutive samples of channel ch0 + c
-        for (int c = 0; c < 64; c++) {
-            if (ch0 + c < n_channels && lane < tn) {
-                tile[c * (TS + 1) + lane] = in[(size_t)(ch0 + c) * in_stride + t0 + lane];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            f2 r[32];
+#pragma unroll
+            for (int c = 0; c < 32; c++) {
+                const f2 z = {0.0f, 0.0f};
+                const int cc = 32 * h + c;
+                r[c] = (ch0 + cc < n_channels && lane < tn) ? in[(size_t)(ch0 + cc) * in_stride + t0 + lane] : z;
+            }
+#pragma unroll
+            for (int c = 0; c < 32; c++) {
+                tile[(32 * h + c) * (TS + 1) + lane] = r[c];
             }
         }
-        __syncthreads();
-        if (run) {
-            for (int s = 0; s < tn; s++) {
-                // produce symbols while the loop is "ready" and input remains (this sample exists); the trip
-                // bound only matters for a non-finite mu (the reference would then spin until its output is full)
-                int trips = 0;
-                while (!(mu > 1.0f) && trips++ < 8) {
-                    const float half_omega = omega / 2.0f;
-                    int hs = (int)floorf(half_omega);
-                    float hmu = mu + half_omega - (float)hs;
-                    if (hmu > 1.0f) {
-                        hmu -= 1.0f;
-                        hs += 1;
+    };
+    if (loader && n > 0) {
+        stage(0, tile0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (long t0 = 0; t0 < n; t0 += TS, buf ^= 1) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        const f2* tile = tile0 + buf * 64 * (TS + 1);
+        if (loader) {
+            if (t0 + TS < n) {
+                stage(t0 + TS, tile0 + (buf ^ 1) * 64 * (TS + 1));
+            }
+        } else {
+            // Lanes advance symbol by symbol, not sample by sample: every trip of this loop lets each lane consume
+            // input until its loop is ready (9-11 samples at sps 10) and then all ready lanes interpolate together.
+            // Producing "now" or after the next tile arrives is the same computation (the delay line only changes
+            // when a sample is consumed); the one thing the reference never does is produce after the call's last
+            // sample, hence `more`.
+            const bool more = (t0 + TS) < n;
+            int s = 0;
+            int spins = 0;
+            while (true) {
+                bool busy = false;
+                if (run) {
+                    while (mu > 1.0f && s < tn) {
+                        mu -= 1.0f;
+                        f2 x = tile[lane * (TS + 1) + s];
+                        if (x.x != x.x) {
+                            x.x = 0.0f;
+                        }
+                        if (x.y != x.y) {
+                            x.y = 0.0f;
+                        }
+                        dl[(size_t)(2 * dli) * 64] = x.x;
+                        dl[(size_t)(2 * dli + 1) * 64] = x.y;
+                        dl[(size_t)(2 * (dli + tw)) * 64] = x.x;
+                        dl[(size_t)(2 * (dli + tw) + 1) * 64] = x.y;
+                        if (++dli >= tw) {
+                            dli = 0;
+                        }
+                        s++;
                     }
-                    if (hs < 0) {
-                        hs = 0;
+                    if (!(mu > 1.0f) && (s < tn || more)) {
+                        const float half_omega = omega / 2.0f;
+                        int hs = (int)floorf(half_omega);
+                        float hmu = mu + half_omega - (float)hs;
+                        if (hmu > 1.0f) {
+                            hmu -= 1.0f;
+                            hs += 1;
+                        }
+                        if (hs < 0) {
+                            hs = 0;
+                        }
+                        if (dli + 7 >= 2 * tw || dli + hs + 7 >= 2 * tw) {
+                            mu += omega;
+                        } else {
+                            float mr, mj, sr, sj;
+                            mmse8(dl, dli, mu, tbl, &mr, &mj);
+                            mmse8(dl, dli + hs, hmu, tbl, &sr, &sj);
+                            float err = (last_r - sr) * mr + (last_j - sj) * mj;
+                            if (err != err) {
+                                err = 0.0f;
+                            }
+                            err = clipf(err, 1.0f);
+                            const float ie2 = sr * sr, io2 = mr * mr, qe2 = sj * sj, qo2 = mj * mj;
+                            const float yi = ((ie2 + io2) != 0.0f) ? (ie2 - io2) / (ie2 + io2) : 0.0f;
+                            const float yq = ((qe2 + qo2) != 0.0f) ? (qe2 - qo2) / (qe2 + qo2) : 0.0f;
+                            lock += yi + yq;
+                            lock_n++;
+                            const float mag = sqrtf(sr * sr + sj * sj);
+                            omega += gain_omega * err * mag;
+                            omega = t.omega_mid + clipf(omega - t.omega_mid, t.omega_rel);
+                            mu += omega + gain_mu * err;
+                            last_r = sr;
+                            last_j = sj;
+                            if ((size_t)o < out_stride) {
+                                const f2 v = {sr, sj};
+                                op[o] = v;
+                            }
+                            o++;
+                        }
                     }
-                    if (dli + 7 >= 2 * tw || dli + hs + 7 >= 2 * tw) {
-                        mu += omega;
-                        continue;
-                    }
-                    float mr, mj, sr, sj;
-                    mmse8(dl, dli, mu, tbl, &mr, &mj);
-                    mmse8(dl, dli + hs, hmu, tbl, &sr, &sj);
-                    float err = (last_r - sr) * mr + (last_j - sj) * mj;
-                    if (err != err) {
-                        err = 0.0f;
-                    }
-                    err = clipf(err, 1.0f);
-                    const float ie2 = sr * sr, io2 = mr * mr, qe2 = sj * sj, qo2 = mj * mj;
-                    const float yi = ((ie2 + io2) != 0.0f) ? (ie2 - io2) / (ie2 + io2) : 0.0f;
-                    const float yq = ((qe2 + qo2) != 0.0f) ? (qe2 - qo2) / (qe2 + qo2) : 0.0f;
-                    lock += yi + yq;
-                    lock_n++;
-                    const float mag = sqrtf(sr * sr + sj * sj);
-                    omega += gain_omega * err * mag;
-                    omega = t.omega_mid + clipf(omega - t.omega_mid, t.omega_rel);
-                    mu += omega + gain_mu * err;
-                    last_r = sr;
-                    last_j = sj;
-                    if ((size_t)o < out_stride) {
-                        const f2 v = {sr, sj};
-                        op[o] = v;
-                    }
-                    o++;
+                    // done with this tile once every sample is consumed and nothing is pending (a non-finite mu
+                    // would otherwise spin: bound the trips like the reference's output-buffer bound does)
+                    busy = (s < tn) || (!(mu > 1.0f) && more);
                 }
-                // consume one input sample into the doubled delay line
-                mu -= 1.0f;
-                f2 x = tile[lane * (TS + 1) + s];
-                if (x.x != x.x) {
-                    x.x = 0.0f;
-                }
-                if (x.y != x.y) {
-                    x.y = 0.0f;
-                }
-                dl[(size_t)(2 * dli) * 64] = x.x;
-                dl[(size_t)(2 * dli + 1) * 64] = x.y;
-                dl[(size_t)(2 * (dli + tw)) * 64] = x.x;
-                dl[(size_t)(2 * (dli + tw) + 1) * 64] = x.y;
-                if (++dli >= tw) {
-                    dli = 0;
+                if (!__any(busy) || ++spins > 4 * TS) {
+                    break;
                 }
             }
         }
         __syncthreads();
     }
-    if (live) {
+    if (live && !loader) {
         if (run) {
             t.mu = mu;
             t.omega = omega;
@@ -248,8 +287,8 @@ ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sp
     if (tw > DDN_TED_DL) {
         tw = DDN_TED_DL;
     }
-    const size_t shm = sizeof(float) * (17 * 8 + 8) + sizeof(f2) * 64 * 65 + sizeof(float) * 4 * (size_t)tw * 64;
-    hipLaunchKernelGGL(k_gardner, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), shm, st, (const f2*)in, n,
+    const size_t shm = sizeof(float) * (17 * 8 + 8) + sizeof(f2) * 2 * 64 * 65 + sizeof(float) * 4 * (size_t)tw * 64;
+    hipLaunchKernelGGL(k_gardner, dim3((unsigned)((n_channels + 63) / 64)), dim3(128), shm, st, (const f2*)in, n,
                        in_stride, n_channels, sps, ted_gain, symbol_rate_hz, state, dl_store, (f2*)out, out_stride,
                        out_count);
     return hipGetLastError();

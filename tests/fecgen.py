@@ -231,7 +231,7 @@ def bch_63_16_encode(data16):
     return np.array([(cw >> (62 - i)) & 1 for i in range(63)], np.uint8)
 
 
-def gen_nid(rng, n, max_err=14):
+def gen_nid(rng, n, max_err=14, invalid_duids=True):
     """-> bits [n,63], reliab [n,63], observed_nac [n], parity [n], parity_rel [n] with 0..max_err bit errors."""
     duids = np.array([0, 3, 5, 7, 10, 12, 15])
     bits = np.zeros((n, 63), np.uint8)
@@ -242,7 +242,7 @@ def gen_nid(rng, n, max_err=14):
     for i in range(n):
         nac = int(rng.integers(1, 0xFFF))
         duid = int(duids[rng.integers(0, len(duids))])
-        if i % 11 == 0:
+        if invalid_duids and i % 11 == 0:
             duid = int(rng.integers(0, 16))  # sometimes an undefined DUID
         data = [(nac >> (11 - k)) & 1 for k in range(12)] + [(duid >> (3 - k)) & 1 for k in range(4)]
         cw = bch_63_16_encode(data)

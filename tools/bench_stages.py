@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Per-stage throughput of the batched FEC / timing kernels on one MI355X, next to the CPU oracle on one core.
+Prints one JSON line per stage.  (bench.py stays the BASELINE metric; this is the per-row measurement of SURVEY §8.)
+
+    python tools/bench_stages.py [--reps 20]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(ROOT, "dsd-neo_amd", "bindings"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import ddn
+    import fecgen
+    import orc
+    l = ddn.lib()
+    rng = np.random.default_rng(1)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.reps
+
+    def cpu(fn, n_items):
+        t0 = time.perf_counter()
+        fn()
+        return n_items / (time.perf_counter() - t0)
+
+    def nid_case(tag, inv):
+        from test_oracle_block import oracle_nid
+        n2 = 4096 * 8
+        bits, rel63, obs, par, prel = fecgen.gen_nid(rng, 4096, max_err=9, invalid_duids=inv)
+        db = torch.from_numpy(np.tile(bits, (8, 1))).cuda()
+        drl = torch.from_numpy(np.tile(rel63, (8, 1))).cuda()
+        dob = torch.from_numpy(np.tile(obs, 8)).cuda()
+        dp = torch.from_numpy(np.tile(par, 8)).cuda()
+        dpr = torch.from_numpy(np.tile(prel, 8)).cuda()
+        dres = torch.zeros((n2, 4), dtype=torch.int32, device="cuda")
+        ms = timeit(lambda: l.ddn_p25p1_nid_decode_batch(db.data_ptr(), drl.data_ptr(), dob.data_ptr(), dp.data_ptr(),
+                                                         dpr.data_ptr(), 64, n2, dres.data_ptr(), st))
+        report(tag, n2, ms, 63 * 2 + 16, cpu(lambda: oracle_nid(bits[:512], rel63[:512], obs[:512], par[:512],
+                                                                  prel[:512]), 512), "NIDs")
+
+    def report(stage, n, ms, bytes_per_item, cpu_items_s, unit):
+        gps = n / (ms * 1e-3)
+        print(json.dumps({"stage": stage, "n": n, "ms": round(ms, 4), "items_per_s": round(gps, 1), "unit": unit,
+                          "algorithmic_GBps": round(gps * bytes_per_item / 1e9, 2),
+                          "cpu_oracle_items_per_s_1core": round(cpu_items_s, 1),
+                          "speedup_vs_1core": round(gps / cpu_items_s, 1)}))
+
+    # P25 1/2-rate trellis: 4096 channels x 26 blocks
+    n = 4096 * 26
+    llr, _ = fecgen.gen_p25_half_rate(rng, 4096, sigma=400.0)
+    d_in = torch.from_numpy(np.tile(llr, (26, 1))).cuda()
+    d_out = torch.zeros((n, 12), dtype=torch.uint8, device="cuda")
+    d_met = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: l.ddn_fec_p25_12_soft_batch(d_in.data_ptr(), n, d_out.data_ptr(), d_met.data_ptr(), st))
+    report("p25_half_rate_trellis", n, ms, 196 * 2 + 12 + 4, cpu(lambda: fecgen.oracle_p25_half_rate(llr[:512]), 512),
+           "codewords")
+
+    # 3/4-rate trellis (soft)
+    d, rel, _ = fecgen.gen_r34(rng, 4096)
+    dd = torch.from_numpy(np.tile(d, (26, 1))).cuda()
+    dr = torch.from_numpy(np.tile(rel, (26, 1))).cuda()
+    do = torch.zeros((n, 18), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: l.ddn_fec_r34_batch(dd.data_ptr(), dr.data_ptr(), n, do.data_ptr(), st))
+    report("r34_trellis_soft", n, ms, 98 * 2 + 18, cpu(lambda: fecgen.oracle_r34(d[:512], rel[:512]), 512), "codewords")
+
+    # K=5 NXDN (FACCH-sized) and M17 LSF
+    sym, rl = fecgen.gen_nxdn(rng, 4096, 96)
+    ds = torch.from_numpy(np.tile(sym, (26, 1))).cuda()
+    do2 = torch.zeros((n, 12), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: l.ddn_fec_nxdn_conv_batch(ds.data_ptr(), None, n, 96, 92, None, do2.data_ptr(), 12, st))
+    report("k5_nxdn_96steps", n, ms, 192 + 12, cpu(lambda: fecgen.oracle_nxdn(sym[:512], None, 96, 92), 512),
+           "codewords")
+    soft = fecgen.gen_m17(rng, 4096, 488)
+    dsf = torch.from_numpy(np.tile(soft, (8, 1))).cuda()
+    n2 = 4096 * 8
+    do3 = torch.zeros((n2, 32), dtype=torch.uint8, device="cuda")
+    dc = torch.zeros(n2, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: l.ddn_fec_viterbi_k5_batch(dsf.data_ptr(), n2, 488, None, 0, do3.data_ptr(), 32, dc.data_ptr(),
+                                                   st))
+    report("k5_m17_244steps", n2, ms, 488 * 2 + 32 + 4, cpu(lambda: fecgen.oracle_m17(soft[:256]), 256), "codewords")
+
+    # NID: first the common case (every NID decodes on the hard path), then a stress mix where ~9 % carry an
+    # undefined DUID and fall into the 93..186-trial Chase search
+    for tag, inv in (("p25p1_nid_hard_path", False), ("p25p1_nid_9pct_chase", True)):
+        nid_case(tag, inv)
+
+    # Gardner: 4096 channels x 48000 samples
+    B, sps = 4096, 10
+    iq1 = orc.synth_qpsk_f32(9, 8, 4900, sps)
+    nn = iq1.shape[1]
+    d_iq = torch.from_numpy(np.tile(iq1, (B // 8, 1, 1))).cuda()
+    h = C.c_void_p()
+    assert l.ddn_ted_batch_create(B, sps, 4800, 0.0, C.byref(h)) == 0
+    stride = nn // sps + 64
+    d_sym = torch.zeros((B, stride, 2), dtype=torch.float32, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: l.ddn_gardner_run(h, d_iq.data_ptr(), nn, d_sym.data_ptr(), stride, d_cnt.data_ptr(), st))
+    o = orc.OracleTed(sps, 4800)
+    report("gardner_ted_sps10", B * nn, ms, 8 + 0.8, cpu(lambda: o.block(iq1[0]), nn), "complex samples")
+
+
+if __name__ == "__main__":
+    main()
