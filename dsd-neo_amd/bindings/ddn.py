@@ -72,6 +72,14 @@ PROTOTYPES = {
                                            C.c_void_p, C.c_void_p]),
     "ddn_fec_viterbi_k5_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                           C.c_void_p]),
+    "ddn_slicer_batch_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ddn_slicer_batch_destroy": (None, [C.c_void_p]),
+    "ddn_slicer_batch_reset": (C.c_int, [C.c_void_p]),
+    "ddn_p25_slicer_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_p25_slicer_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_slicer_batch_get_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ddn_p25_matched_filter_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_p25_matched_filter_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddn_ted_batch_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_void_p)]),
     "ddn_ted_batch_destroy": (None, [C.c_void_p]),
     "ddn_ted_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -47,6 +47,12 @@ typedef struct DdnTedState { /* == the carried fields of ted_state_t */
     int lock_count, dl_index, twice_sps, sps;
 } DdnTedState;
 
+typedef struct DdnSlicerState { /* per-channel slicer words of dsd_state the P25p1 path carries */
+    float center, umid, lmid, max, min;
+    int sidx, midx, sums_valid;
+    double min_sum, max_sum;
+} DdnSlicerState;
+
 typedef struct DdnPuncture { /* puncture pattern of the K=5 decoder, expanded on the host */
     int p_len;               /* 0 = not punctured */
     int ones_total;
@@ -60,6 +66,11 @@ extern "C" {
 hipError_t ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sps, float ted_gain,
                            int symbol_rate_hz, DdnTedState* state, float* dl_store, void* out, size_t out_stride,
                            int* out_count, hipStream_t st);
+hipError_t ddn_dev_p25_slicer(const float* sym, long n, size_t sym_stride, int n_channels, int negative,
+                              DdnSlicerState* state, float* sbuf_store, float* minring, float* maxring, uint8_t* rec,
+                              size_t rec_stride, hipStream_t st);
+hipError_t ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channels, float* hist, float* out,
+                                      hipStream_t st);
 hipError_t ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
                               const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);

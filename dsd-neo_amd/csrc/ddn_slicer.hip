@@ -1,0 +1,328 @@
+// ddn_slicer.hip — batched P25 Phase 1 C4FM symbol slicer with soft decisions, and the per-sample P25 matched filter.
+//
+//   k_p25_slicer          symbols -> 10-byte capture records {dibit, reliability, llr0, llr1, f32 symbol}
+//       reference: get_dibit_and_analog_signal / use_symbol / digitize / compute_dibit_soft_metric
+//                  src/core/frames/dsd_dibit.c:194-299,456-547,609-721,963-1076; record layout :794-818;
+//                  moving min/max average include/dsd-neo/core/state.h:1399-1455; reset values
+//                  src/dsp/dsd_symbol.c:1306-1326.  Metrics hooks unset -> SNR weight 204/256 (as in the oracle run).
+//   k_p25_matched_filter  y[n] = sum_i taps[i] * x[n-90+i], products added oldest first, mul and add rounded
+//       separately.  reference: apply_sps_fir / p25_filter, src/dsp/dsd_filters.c:173-200,368 (taps: ddn_tables_p25.h)
+//
+// lrintf() on the reference's x86-64 host returns a 64-bit long that the code then narrows to int; the device does the
+// same (round to nearest even into 64 bits, then truncate) so that out-of-range magnitudes wrap identically.
+//
+// Slicer layout: one channel per lane (the thresholds are a per-symbol recurrence).  What makes it GPU-shaped:
+//   * the 128-symbol extrema window lives in LDS as [slot][lane]; instead of rescanning 128 values per symbol (the
+//     reference does) each lane keeps per-16-slot group summaries (two smallest, two largest) and recomputes only the
+//     group that received the new symbol, then merges the 8 groups — the same multiset statistics, no divergence;
+//   * the 1024-deep min/max rings stay in HBM laid out [slot][channel]: all lanes advance the same slot together, so
+//     every ring access is one coalesced row; their running sums are binary64 like the reference's.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+#include "ddn_tables_p25.h"
+
+namespace {
+__device__ __forceinline__ int
+clamp255(int v) {
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__device__ __forceinline__ void
+two_min_insert(float x, float& a1, float& a2) {
+    if (x < a1) {
+        a2 = a1;
+        a1 = x;
+    } else if (x < a2) {
+        a2 = x;
+    }
+}
+__device__ __forceinline__ void
+two_max_insert(float x, float& b1, float& b2) {
+    if (x > b1) {
+        b2 = b1;
+        b1 = x;
+    } else if (x > b2) {
+        b2 = x;
+    }
+}
+
+__device__ __forceinline__ int
+bit_magnitude(float sym, const float ideal[4], int bit_index) {
+    const float big = 3.4028234663852886e38f;
+    float best0 = big, best1 = big, spacing = big;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float d = (sym - ideal[i]) * (sym - ideal[i]);
+        if ((i >> (1 - bit_index)) & 1) {
+            if (d < best1) {
+                best1 = d;
+            }
+        } else if (d < best0) {
+            best0 = d;
+        }
+#pragma unroll
+        for (int j = i + 1; j < 4; j++) {
+            const float sp = fabsf(ideal[i] - ideal[j]);
+            if (sp > 1e-6f && sp < spacing) {
+                spacing = sp;
+            }
+        }
+    }
+    if (spacing == big) {
+        spacing = 2.0f;
+    }
+    const float scale = 255.0f / (spacing * spacing);
+    return clamp255((int)__float2ll_rn(fabsf(best0 - best1) * scale));
+}
+} // namespace
+
+__global__ __launch_bounds__(64) void
+k_p25_slicer(const float* __restrict__ sym, long n, size_t sym_stride, int n_channels, int negative,
+             DdnSlicerState* __restrict__ state, float* __restrict__ sbuf_store, float* __restrict__ minring,
+             float* __restrict__ maxring, uint8_t* __restrict__ rec, size_t rec_stride) {
+    constexpr int SS = 128, MS = 1024, GROUPS = 8, GSZ = 16;
+    __shared__ float sb[SS][64];
+    __shared__ float gs[GROUPS][4][64]; // per group: min1, min2, max1, max2
+    const int lane = threadIdx.x;
+    const int ch = blockIdx.x * 64 + lane;
+    const bool live = ch < n_channels;
+    const int chc = live ? ch : (n_channels - 1);
+    DdnSlicerState s = state[chc];
+    for (int k = 0; k < SS; k++) {
+        sb[k][lane] = sbuf_store[(size_t)k * n_channels + chc];
+    }
+    // group summaries of the carried window
+    for (int g = 0; g < GROUPS; g++) {
+        float a1 = sb[g * GSZ][lane], a2 = sb[g * GSZ + 1][lane];
+        float b1 = a1, b2 = a2;
+        if (a2 < a1) {
+            const float t = a1;
+            a1 = a2;
+            a2 = t;
+        }
+        if (b2 > b1) {
+            const float t = b1;
+            b1 = b2;
+            b2 = t;
+        }
+        for (int k = 2; k < GSZ; k++) {
+            const float x = sb[g * GSZ + k][lane];
+            two_min_insert(x, a1, a2);
+            two_max_insert(x, b1, b2);
+        }
+        gs[g][0][lane] = a1;
+        gs[g][1][lane] = a2;
+        gs[g][2][lane] = b1;
+        gs[g][3][lane] = b2;
+    }
+    if (!s.sums_valid) {
+        // first push after a reset: sums are rebuilt from the rings (include/dsd-neo/core/state.h:1407-1426)
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < MS; k++) {
+            a += (double)minring[(size_t)k * n_channels + chc];
+            b += (double)maxring[(size_t)k * n_channels + chc];
+        }
+        s.min_sum = a;
+        s.max_sum = b;
+        s.sums_valid = 1;
+        if (s.midx < 0 || s.midx >= MS) {
+            s.midx = 0;
+        }
+    }
+    const float* sp = sym + (size_t)chc * sym_stride;
+    uint8_t* rp = rec + (size_t)chc * rec_stride;
+    for (long i = 0; i < n; i++) {
+        const float x = sp[i];
+        // ---- window update: new symbol replaces slot sidx, refresh that slot's group, merge the groups --------
+        sb[s.sidx][lane] = x;
+        {
+            const int g = s.sidx >> 4;
+            float a1 = sb[g * GSZ][lane], a2 = sb[g * GSZ + 1][lane];
+            float b1 = a1, b2 = a2;
+            if (a2 < a1) {
+                const float t = a1;
+                a1 = a2;
+                a2 = t;
+            }
+            if (b2 > b1) {
+                const float t = b1;
+                b1 = b2;
+                b2 = t;
+            }
+#pragma unroll
+            for (int k = 2; k < GSZ; k++) {
+                const float v = sb[g * GSZ + k][lane];
+                two_min_insert(v, a1, a2);
+                two_max_insert(v, b1, b2);
+            }
+            gs[g][0][lane] = a1;
+            gs[g][1][lane] = a2;
+            gs[g][2][lane] = b1;
+            gs[g][3][lane] = b2;
+        }
+        float m1 = gs[0][0][lane], m2 = gs[0][1][lane], x1 = gs[0][2][lane], x2 = gs[0][3][lane];
+#pragma unroll
+        for (int g = 1; g < GROUPS; g++) {
+            two_min_insert(gs[g][0][lane], m1, m2);
+            two_min_insert(gs[g][1][lane], m1, m2);
+            two_max_insert(gs[g][2][lane], x1, x2);
+            two_max_insert(gs[g][3][lane], x1, x2);
+        }
+        const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
+        // ---- 1024-deep moving average of the window extrema (binary64 running sums) ---------------------------
+        const size_t ro = (size_t)s.midx * n_channels + chc;
+        s.min_sum += (double)lo - (double)minring[ro];
+        s.max_sum += (double)hi - (double)maxring[ro];
+        if (live) {
+            minring[ro] = lo;
+            maxring[ro] = hi;
+        }
+        s.midx = (s.midx + 1 >= MS) ? 0 : s.midx + 1;
+        s.min = (float)(s.min_sum / (double)MS);
+        s.max = (float)(s.max_sum / (double)MS);
+        s.center = (s.max + s.min) / 2.0f;
+        s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
+        s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
+        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+        // ---- slice + soft decision ---------------------------------------------------------------------------
+        int dibit;
+        if (x > s.center) {
+            dibit = (x > s.umid) ? (negative ? 3 : 1) : (negative ? 2 : 0);
+        } else {
+            dibit = (x < s.lmid) ? (negative ? 1 : 3) : (negative ? 0 : 2);
+        }
+        const float plus_one = 0.5f * (s.center + s.umid), minus_one = 0.5f * (s.lmid + s.center);
+        float ideal[4];
+        ideal[0] = negative ? minus_one : plus_one;
+        ideal[1] = negative ? s.min : s.max;
+        ideal[2] = negative ? plus_one : minus_one;
+        ideal[3] = negative ? s.max : s.min;
+        int mag0 = bit_magnitude(x, ideal, 0), mag1 = bit_magnitude(x, ideal, 1);
+        int rel;
+        {
+            const float eps = 1e-6f;
+            if (x > s.umid) {
+                float span = s.max - s.umid;
+                span = span < eps ? eps : span;
+                rel = (int)__float2ll_rn(((x - s.umid) * 255.0f) / span);
+            } else if (x > s.center) {
+                const float d1 = x - s.center, d2 = s.umid - x;
+                float span = s.umid - s.center;
+                span = span < eps ? eps : span;
+                rel = (int)__float2ll_rn(((d1 < d2 ? d1 : d2) * 510.0f) / span);
+            } else if (x >= s.lmid) {
+                const float d1 = s.center - x, d2 = x - s.lmid;
+                float span = s.center - s.lmid;
+                span = span < eps ? eps : span;
+                rel = (int)__float2ll_rn(((d1 < d2 ? d1 : d2) * 510.0f) / span);
+            } else {
+                float span = s.lmid - s.min;
+                span = span < eps ? eps : span;
+                rel = (int)__float2ll_rn(((s.lmid - x) * 255.0f) / span);
+            }
+            rel = clamp255((clamp255(rel) * 204) >> 8);
+        }
+        const int mn = mag0 < mag1 ? mag0 : mag1;
+        if (mn > 0 && rel < mn) {
+            mag0 = (mag0 * rel) / mn;
+            mag1 = (mag1 * rel) / mn;
+        }
+        const int l0 = ((dibit >> 1) & 1) ? clamp255(mag0) : -clamp255(mag0);
+        const int l1 = (dibit & 1) ? clamp255(mag1) : -clamp255(mag1);
+        const int a0 = l0 < 0 ? -l0 : l0, a1v = l1 < 0 ? -l1 : l1;
+        if (live) {
+            uint8_t* r = rp + (size_t)i * 10;
+            const uint32_t xb = __float_as_uint(x);
+            // 10-byte record, 2-byte aligned: three u16 + one split u32
+            ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (clamp255(a1v < a0 ? a1v : a0) << 8));
+            ((uint16_t*)r)[1] = (uint16_t)(int16_t)l0;
+            ((uint16_t*)r)[2] = (uint16_t)(int16_t)l1;
+            ((uint16_t*)r)[3] = (uint16_t)(xb & 0xFFFFu);
+            ((uint16_t*)r)[4] = (uint16_t)(xb >> 16);
+        }
+    }
+    if (live) {
+        state[ch] = s;
+        for (int k = 0; k < SS; k++) {
+            sbuf_store[(size_t)k * n_channels + ch] = sb[k][lane];
+        }
+    }
+}
+
+// Matched filter: one output per thread, 91 taps from constant memory, LDS-staged input tile + 90-sample halo.
+__global__ __launch_bounds__(256) void
+k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const float* __restrict__ hist,
+                     float* __restrict__ out) {
+    constexpr int T = 1024, NT = DDN_P25_FILTER_TAPS;
+    __shared__ float x[T + NT - 1];
+    __shared__ float taps[NT];
+    const int ch = blockIdx.y;
+    const long t0 = (long)blockIdx.x * T;
+    const int tid = threadIdx.x;
+    if (tid < NT) {
+        taps[tid] = __uint_as_float(ddn_p25_filter_bits[tid]);
+    }
+    for (int i = tid; i < T + NT - 1; i += 256) {
+        const long j = t0 - (NT - 1) + i;
+        float v = 0.0f;
+        if (j < 0) {
+            v = hist[(size_t)ch * (NT - 1) + (NT - 1) + j];
+        } else if (j < n) {
+            v = in[(size_t)ch * stride + j];
+        }
+        x[i] = v;
+    }
+    __syncthreads();
+    for (int o = tid; o < T; o += 256) {
+        if (t0 + o < n) {
+            float acc = 0.0f;
+#pragma unroll 13
+            for (int i = 0; i < NT; i++) {
+                acc += taps[i] * x[o + i];
+            }
+            out[(size_t)ch * stride + t0 + o] = acc;
+        }
+    }
+}
+
+__global__ void
+k_p25_filter_hist(const float* __restrict__ in, long n, size_t stride, float* __restrict__ hist) {
+    constexpr int H = DDN_P25_FILTER_TAPS - 1;
+    const int ch = blockIdx.x, i = threadIdx.x; // 0..H-1
+    float* h = hist + (size_t)ch * H;
+    const long j = n - H + i;
+    const float v = (j >= 0) ? in[(size_t)ch * stride + j] : h[H + j];
+    __syncthreads();
+    h[i] = v;
+}
+
+extern "C" hipError_t
+ddn_dev_p25_slicer(const float* sym, long n, size_t sym_stride, int n_channels, int negative, DdnSlicerState* state,
+                   float* sbuf_store, float* minring, float* maxring, uint8_t* rec, size_t rec_stride, hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p25_slicer, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, sym, n, sym_stride,
+                       n_channels, negative, state, sbuf_store, minring, maxring, rec, rec_stride);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channels, float* hist, float* out,
+                           hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p25_matched_filter, dim3((unsigned)((n + 1023) / 1024), (unsigned)n_channels), dim3(256), 0, st,
+                       in, n, stride, (const float*)hist, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_p25_filter_hist, dim3((unsigned)n_channels), dim3(DDN_P25_FILTER_TAPS - 1), 0, st, in, n,
+                       stride, hist);
+    return hipGetLastError();
+}

@@ -96,6 +96,23 @@ int ddn_batch_get_fsk_state(ddn_batch* b, int channel, float out5[5]);
 int ddn_batch_set_timing(ddn_batch* b, int enable);
 int ddn_batch_get_timing(ddn_batch* b, float out3[3]);
 
+/* ---- P25 Phase 1 C4FM slicer + soft decisions, and the per-sample P25 matched filter, batched --------------
+ * ddn_p25_slicer_run == one getDibitSoft() per symbol per channel (include/dsd-neo/core/dibit.h:43-52) for a stream
+ * whose last sync type is P25p1 (thresholds track continuously): symbols [B][n] f32 -> records [B][n][10], the
+ * reference's symbol-capture record {u8 dibit, u8 reliability, i16 llr0, i16 llr1, f32 symbol} little-endian
+ * (src/core/frames/dsd_dibit.c:794-818).  Slicer state starts from the reference's reset values and is carried.
+ * ddn_p25_matched_filter_run == p25_filter(sample, 10) over every sample of every channel (include/dsd-neo/dsp/
+ * sps_filters.h), 90-sample history carried in the batch; d_in != d_out. */
+typedef struct ddn_slicer_batch ddn_slicer_batch;
+int ddn_slicer_batch_create(int n_channels, int negative_polarity, ddn_slicer_batch** out);
+void ddn_slicer_batch_destroy(ddn_slicer_batch* b);
+int ddn_slicer_batch_reset(ddn_slicer_batch* b);
+int ddn_p25_slicer_run(ddn_slicer_batch* b, const float* d_symbols, size_t n, uint8_t* d_records10, void* hip_stream);
+int ddn_p25_slicer_run_host(ddn_slicer_batch* b, const float* symbols, size_t n, uint8_t* records10);
+int ddn_slicer_batch_get_thresholds(ddn_slicer_batch* b, int channel, float out5[5]);
+int ddn_p25_matched_filter_run(ddn_slicer_batch* b, const float* d_in, size_t n, float* d_out, void* hip_stream);
+int ddn_p25_matched_filter_run_host(ddn_slicer_batch* b, const float* in, size_t n, float* out);
+
 /* ---- Gardner symbol-timing recovery (CQPSK branch), batched ----------------------------------------------
  * == op25_gardner_cc(struct demod_state*) (include/dsd-neo/dsp/costas.h; src/dsp/costas.cpp:804-858) applied to B
  * channels at once; each channel's ted_state_t is carried inside the batch object.

@@ -119,6 +119,23 @@ void orc_ted_init(orc_ted_state* t);
 int orc_gardner_block(orc_ted_state* t, int sps, float ted_gain, int symbol_rate_hz, const float* iq, int n,
                       float* out);
 
+/* ---- P25p1 C4FM slicer / soft decisions / matched filter (oracle/ddn_oracle_sym.c) ------------------- */
+#define ORC_SLICER_SSIZE 128  /* opts->ssize, src/core/util/dsd_init.c:169 */
+#define ORC_SLICER_MSIZE 1024 /* opts->msize, src/core/util/dsd_init.c:170 */
+typedef struct orc_slicer {
+    int negative;
+    float center, umid, lmid, max, min, maxref, minref;
+    float sbuf[ORC_SLICER_SSIZE];
+    int sidx;
+    float minbuf[ORC_SLICER_MSIZE], maxbuf[ORC_SLICER_MSIZE];
+    int midx, sums_valid;
+    double min_sum, max_sum;
+} orc_slicer;
+void orc_slicer_init(orc_slicer* s, int negative_polarity);
+void orc_slicer_step(orc_slicer* s, float sym, int rec4[4]);
+void orc_slicer_run(orc_slicer* s, const float* sym, long n, int* rec4, float* thr5);
+void orc_p25_filter_run(float hist[90], const float* in, long n, float* out);
+
 /* ---- block codes (oracle/ddn_oracle_block.c) ---------------------------------------------------------- */
 int orc_bch_63_16_decode(const uint8_t in63[63], uint8_t out16[16], int* err_count);
 void orc_p25p1_nid_decode(const uint8_t code[63], const uint8_t* rel63, int observed_nac, int parity, int parity_rel,

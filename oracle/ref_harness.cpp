@@ -251,3 +251,140 @@ refh_mmse(const float* samples, float mu, float* re, float* im) {
 }
 
 } // extern "C"
+
+// ---- slicer / soft-decision path: the reference's own digitize()/use_symbol()/soft metrics (dsd_dibit.c) ------
+// src/dsp/dsd_symbol.c cannot be built here (it includes <sndfile.h>), so the sample source getSymbol() is supplied
+// by this harness the same way the reference's own unit tests substitute it (tests/CMakeLists.txt:1009-1015 wrap
+// get_dibit_and_analog_signal / processMbeFrame): it hands out a caller-provided symbol vector, nothing else.
+#include <cstdlib>
+#include <dsd-neo/core/dibit.h>
+#include <dsd-neo/core/opts.h>
+#include <dsd-neo/core/state.h>
+#include <dsd-neo/core/sync_patterns.h>
+#include <dsd-neo/core/synctype_ids.h>
+#include <dsd-neo/dsp/sps_filters.h>
+#include <dsd-neo/dsp/symbol.h>
+
+namespace {
+const float* g_sym_src = nullptr;
+long g_sym_n = 0, g_sym_pos = 0;
+} // namespace
+
+extern "C" {
+
+float
+getSymbol(dsd_opts* opts, dsd_state* state, int have_sync) {
+    (void)opts;
+    (void)have_sync;
+    if (!g_sym_src || g_sym_pos >= g_sym_n) {
+        return 0.0f;
+    }
+    const float v = g_sym_src[g_sym_pos++];
+    state->lastsample = v;
+    state->symbolcnt++;
+    return v;
+}
+
+struct RefSlicer {
+    dsd_opts* opts;
+    dsd_state* state;
+};
+
+// P25 Phase 1 C4FM receive context after a positive-polarity sync: rf_mod 0, synctype/lastsynctype P25P1_POS,
+// slicer reset exactly as symbol_reset_rtl_fsk_discriminator_slicer() does (src/dsp/dsd_symbol.c:1306-1326),
+// window sizes from initOpts (src/core/util/dsd_init.c:169-170: ssize 128, msize 1024).
+void*
+refh_slicer_create(int synctype) {
+    RefSlicer* s = new RefSlicer();
+    s->opts = static_cast<dsd_opts*>(calloc(1, sizeof(dsd_opts)));
+    s->state = static_cast<dsd_state*>(calloc(1, sizeof(dsd_state)));
+    dsd_opts* o = s->opts;
+    dsd_state* st = s->state;
+    o->ssize = 128;
+    o->msize = 1024;
+    o->audio_in_type = AUDIO_IN_PULSE; // anything but RTL / symbol-bin: no hook traffic, no replay overrides
+    st->rf_mod = 0;
+    st->synctype = synctype;
+    st->lastsynctype = synctype;
+    st->center = 0.0f;
+    st->min = -30000.0f;
+    st->max = 30000.0f;
+    st->lmid = -20000.0f;
+    st->umid = 20000.0f;
+    st->minref = -24000.0f;
+    st->maxref = 24000.0f;
+    const int cap = (int)(sizeof(st->minbuf) / sizeof(st->minbuf[0]));
+    for (int i = 0; i < cap; i++) {
+        st->minbuf[i] = st->min;
+        st->maxbuf[i] = st->max;
+    }
+    st->midx = 0;
+    dsd_state_invalidate_minmax_sums(st);
+    st->dibit_buf = static_cast<int*>(calloc(1000000, sizeof(int)));
+    st->dibit_buf_p = st->dibit_buf + 200;
+    st->dmr_payload_buf = static_cast<int*>(calloc(1000000, sizeof(int)));
+    st->dmr_payload_p = st->dmr_payload_buf + 200;
+    st->dmr_soft_buf = static_cast<dsd_dibit_soft_t*>(calloc(1000000, sizeof(dsd_dibit_soft_t)));
+    st->dmr_soft_p = st->dmr_soft_buf + 200;
+    return s;
+}
+
+void
+refh_slicer_destroy(void* h) {
+    RefSlicer* s = static_cast<RefSlicer*>(h);
+    free(s->state->dibit_buf);
+    free(s->state->dmr_payload_buf);
+    free(s->state->dmr_soft_buf);
+    free(s->state);
+    free(s->opts);
+    delete s;
+}
+
+// Feed n symbols through getDibitSoft(): out records = {dibit, reliability, llr0, llr1} as int32 x4 per symbol,
+// thresholds = {center, umid, lmid, max, min} after each symbol.
+void
+refh_slicer_run(void* h, const float* symbols, long n, int* out4, float* thr5) {
+    RefSlicer* s = static_cast<RefSlicer*>(h);
+    g_sym_src = symbols;
+    g_sym_n = n;
+    g_sym_pos = 0;
+    for (long i = 0; i < n; i++) {
+        dsd_dibit_soft_t soft;
+        const int d = getDibitSoft(s->opts, s->state, &soft);
+        out4[4 * i] = d;
+        out4[4 * i + 1] = soft.reliability;
+        out4[4 * i + 2] = soft.llr[0];
+        out4[4 * i + 3] = soft.llr[1];
+        if (thr5) {
+            thr5[5 * i] = s->state->center;
+            thr5[5 * i + 1] = s->state->umid;
+            thr5[5 * i + 2] = s->state->lmid;
+            thr5[5 * i + 3] = s->state->max;
+            thr5[5 * i + 4] = s->state->min;
+        }
+    }
+    g_sym_src = nullptr;
+}
+
+// P25 matched (de-emphasis) filter exactly as the symbolizer applies it per sample: p25_filter(sample, sps)
+// (src/dsp/dsd_filters.c:368).  reset != 0 clears the process-global filter memory first.
+void
+refh_p25_filter_run(const float* in, long n, int sps, int reset, float* out) {
+    if (reset) {
+        init_rrc_filter_memory();
+    }
+    for (long i = 0; i < n; i++) {
+        out[i] = p25_filter(in[i], sps);
+    }
+}
+
+int
+refh_sync_p25p1_pos(void) {
+    return DSD_SYNC_P25P1_POS;
+}
+int
+refh_sync_p25p1_neg(void) {
+    return DSD_SYNC_P25P1_NEG;
+}
+
+} // extern "C"

@@ -234,3 +234,57 @@ def ref_ted_blocks(iq, sps, symbol_rate_hz, ted_gain, blocks):
     r.refh_ted_state(h, st.ctypes.data)
     r.refh_ted_destroy(h)
     return outs, st
+
+
+# ---------------------------------------------------------------------------------------------------------
+# slicer helpers
+
+def synth_c4fm_symbols(seed, n, scale=1.0, noise=1500.0, drift=0.05):
+    """4-level symbol stream at the discriminator's +-30000 scale with noise, slow level drift and a few outliers."""
+    rng = np.random.default_rng(seed)
+    lv = np.array([-3.0, -1.0, 1.0, 3.0])[rng.integers(0, 4, n)]
+    s = lv * 8000.0 * scale + rng.normal(0.0, noise, n) + drift * np.arange(n)
+    s[n // 3:n // 3 + 12] = 0.0
+    s[n // 2] = 45000.0
+    return s.astype(np.float32)
+
+
+def oracle_slicer(sym, negative=0):
+    """sym: float32 [B, n] -> (records int32 [B, n, 4], last thresholds [B, 5])."""
+    o = oracle()
+    o.orc_slicer_init.argtypes = [C.c_void_p, C.c_int]
+    o.orc_slicer_run.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    sym = np.ascontiguousarray(sym, np.float32)
+    B, n = sym.shape
+    rec = np.zeros((B, n, 4), np.int32)
+    thr = np.zeros((B, 5), np.float32)
+    for c in range(B):
+        st = C.create_string_buffer(20000)
+        o.orc_slicer_init(st, negative)
+        t = np.zeros((n, 5), np.float32)
+        o.orc_slicer_run(st, sym[c].ctypes.data, n, rec[c].ctypes.data, t.ctypes.data)
+        thr[c] = t[-1]
+    return rec, thr
+
+
+def oracle_p25_filter(x):
+    o = oracle()
+    o.orc_p25_filter_run.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+    x = np.ascontiguousarray(x, np.float32)
+    B, n = x.shape
+    y = np.zeros((B, n), np.float32)
+    for c in range(B):
+        h = np.zeros(90, np.float32)
+        o.orc_p25_filter_run(h.ctypes.data, x[c].ctypes.data, n, y[c].ctypes.data)
+    return y
+
+
+def unpack_records10(rec):
+    """uint8 [..., 10] capture records -> (int32 [..., 4] {dibit, rel, llr0, llr1}, float32 [...] symbol)."""
+    rec = np.ascontiguousarray(rec, np.uint8)
+    d = rec[..., 0].astype(np.int32)
+    rl = rec[..., 1].astype(np.int32)
+    l0 = rec[..., 2:4].copy().view(np.int16)[..., 0].astype(np.int32)
+    l1 = rec[..., 4:6].copy().view(np.int16)[..., 0].astype(np.int32)
+    sym = rec[..., 6:10].copy().view(np.float32)[..., 0]
+    return np.stack([d, rl, l0, l1], axis=-1), sym
