@@ -106,6 +106,7 @@ def main():
     import torch
     import torch.distributed as dist
     import ddn
+    import ddn_shard
     import orc
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,8 +121,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    B, n = args.channels, args.samples
-    ch_first = rank * B  # channel-index block partition over ranks
+    # rank 0 owns the batch descriptor; every rank takes its block of the channel index.  Weak
+    # scaling: the job has world * channels_per_gpu channels, no data-path collective.
+    desc = ddn_shard.broadcast_descriptor({"B_total": args.channels * world, "n": args.samples, "blk": BLOCK}
+                                          if rank == 0 else None)
+    ch_first, B = ddn_shard.channel_range(rank, world, desc["B_total"])
+    n = desc["n"]
     d_in = torch.cat([gen_input_gpu(torch, dev, ch_first + c, min(256, B - c), n) for c in range(0, B, 256)], 0)
     d_out = torch.empty((B, n), dtype=torch.float32, device=dev)
     batch = ddn.Batch(B, block_len=BLOCK)
@@ -167,10 +172,7 @@ def main():
         t = batch.timing()
         fir_ms.append(float(t[0]))
         ser_ms.append(float(t[1]))
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = ddn_shard.reduce_max_seconds(dt, dev)
 
     if rank == 0:
         total_samples = float(world) * B * n * args.steps
