@@ -226,6 +226,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     fa.out = d_disc;
     fa.carry = b->d_carry;
     fa.state = b->d_state;
+    fa.taps_dev = b->d_taps;
     fa.ch_stride = n;
     fa.out_stride = n;
     fa.n = (long)n;

@@ -25,6 +25,7 @@ typedef struct DdnFusedArgs {
     float* out;           /* [B][out_stride] discriminator samples */
     const ddn_f2* carry;  /* [B][DDN_CARRY_LEN] FIR look-back from the previous call */
     DdnFskState* state;   /* [B] */
+    const float* taps_dev; /* [taps_len] channel LPF taps (first half + centre are read) */
     size_t ch_stride;
     size_t out_stride;
     long n;               /* complex samples per channel in this call */

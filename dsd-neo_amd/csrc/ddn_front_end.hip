@@ -44,7 +44,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef DDN_GROUP
 #define DDN_GROUP 16 /* channels per workgroup */
 #endif
-#define DDN_R  8
+#define DDN_R  4
 
 // ------------------------------------------------------------------------------------------------------
 // helpers
@@ -160,7 +160,7 @@ ddn_tile_next(TileWalk& w, const DdnFusedArgs& a) {
 // recurrences are split over two waves to keep each under the filter threads' time per tile.
 template <int CENTER_T, int G, bool SKIPZ, int FMT>
 __global__ __launch_bounds__(G * 32 + 128) void
-k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
+k_front_end_fused(DdnFusedArgs a) {
     constexpr int TT = DDN_TT;
     constexpr int R = DDN_R;
     constexpr int CMAX = (CENTER_T > 0) ? CENTER_T : DDN_MAX_CENTER;
@@ -173,7 +173,8 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
     __shared__ __attribute__((aligned(16))) float Fb[3][G][FS]; // raw phase delta -> centred value (in place)
     __shared__ __attribute__((aligned(16))) float Pb[2][G][FS]; // peak to divide by
     __shared__ f2 chan_last[2][G];                              // last LPF output of the previous tile
-    __shared__ int tflag[3][G]; // per tile/channel: 1 = squelched (zeros + modem reset), 2 = first sample skipped
+    __shared__ int tflag[3][G];
+    __shared__ int next_item; // filter work-item counter of the current tile // per tile/channel: 1 = squelched (zeros + modem reset), 2 = first sample skipped
     __shared__ float stap[DDN_MAX_CENTER + 1];
     extern __shared__ f2 ysq[]; // [G][256] first LPF outputs of a block (squelch builds only)
 
@@ -186,6 +187,7 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
     const int ft = tid - 128;                                  // filter-thread index
     const int g = is_filter ? (ft >> 5) : (tid & 63);          // channel slot
     const int u = ft & 31;
+    const int lane64 = tid & 63;
     const int ch0 = blockIdx.x * G;
     const int nch = (a.n_channels - ch0) < G ? (a.n_channels - ch0) : G;
     const int C = (CENTER_T > 0) ? CENTER_T : a.center;
@@ -208,7 +210,7 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
         }
     }
     if (tid <= C) {
-        stap[tid] = (tid == C) ? taps.centre : taps.side[tid];
+        stap[tid] = a.taps_dev[tid];
     }
     // raw samples of the NEXT tile, fetched while the current one is filtered (hides HBM latency)
     uint32_t pre_u[(FMT == DDN_IN_CU8) ? NPRE : 1];
@@ -309,6 +311,9 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                 }
             }
         }
+        if (tid == 128) {
+            next_item = 0;
+        }
         if (a.dbg & 64) {
             tm1 = __builtin_readcyclecounter();
             tA += tm1 - tm0;
@@ -346,7 +351,20 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
             if (it < NT && tc.valid <= 0 && u == 0) {
                 chan_last[(it & 1) ^ 1][g] = chan_last[it & 1][g]; // surplus tile of a short last block
             }
-            if (it < NT && tc.valid > 0 && !(a.dbg & 2)) {
+            // Filter work is handed out dynamically: one item = one channel's tile on a full wave (64 lanes x R = 4
+            // outputs).  Waves that share their SIMD with a recurrence wave simply come back for fewer items, so all
+            // four SIMDs finish together.  (Results do not depend on which wave computes which channel.)
+            while (it < NT && tc.valid > 0 && !(a.dbg & 2)) {
+                int item = 0;
+                if (lane64 == 0) {
+                    item = atomicAdd(&next_item, 1);
+                }
+                item = __shfl(item, 0);
+                if (item >= nch) {
+                    break;
+                }
+                const int g = item;      // channel slot of this item
+                const int u = lane64;    // position inside the tile: outputs u*R .. u*R+R-1
                 f2 acc[R];
                 const f2 zero = {0.0f, 0.0f};
                 // a block shorter than taps_len samples goes to the reference's non-fused scalar unit
@@ -374,9 +392,16 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                     }
                 } else if constexpr (CENTER_T > 0) {
 #define PH(off) ((off) + (off) / R)
+                    // Software-pipelined tap loop: the two window elements a step brings in are fetched from LDS
+                    // PF steps ahead (queues qm/qp) and a scheduling barrier per step keeps the compiler from sinking
+                    // those reads back next to their use, so no step waits on LDS latency.  Taps come from a uniform
+                    // global pointer (scalar loads), not from 68 kernel-argument SGPRs.
+                    constexpr int PF = 4;
                     const f2* w = &win[g][u * (R + 1)];
-                    f2 xm[R], xp[R];
-                    const f2 hc = {taps.centre, taps.centre};
+                    f2 xm[R], xp[R], qm[PF], qp[PF];
+                    float qh[PF]; // taps ride the same prefetch queue (LDS broadcast reads of stap[])
+                    const float hcs = stap[CENTER_T];
+                    const f2 hc = {hcs, hcs};
 #pragma unroll
                     for (int j = 0; j < R; j++) {
                         acc[j] = __builtin_elementwise_fma(hc, w[PH(CENTER_T + j)], zero);
@@ -384,13 +409,26 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                         xp[j] = w[PH(2 * CENTER_T + j)];
                     }
 #pragma unroll
+                    for (int q = 0; q < PF; q++) {
+                        if (q + 1 < CENTER_T) {
+                            qm[q] = w[PH(q + 1 + R - 1)];
+                            qp[q] = w[PH(2 * CENTER_T - (q + 1))];
+                            qh[q] = stap[q + 1];
+                        }
+                    }
+                    float h = stap[0];
+#pragma unroll
                     for (int k = 0; k < CENTER_T; k++) {
-                        const float h = taps.side[k];
                         if (!SKIPZ || h != 0.0f) {
                             const f2 hh = {h, h};
+                            f2 t[R];
 #pragma unroll
                             for (int j = 0; j < R; j++) {
-                                acc[j] = __builtin_elementwise_fma(hh, xm[j] + xp[j], acc[j]);
+                                t[j] = xm[j] + xp[j];
+                            }
+#pragma unroll
+                            for (int j = 0; j < R; j++) {
+                                acc[j] = __builtin_elementwise_fma(hh, t[j], acc[j]);
                             }
                         }
                         if (k + 1 < CENTER_T) {
@@ -398,13 +436,26 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                             for (int j = 0; j < R - 1; j++) {
                                 xm[j] = xm[j + 1];
                             }
-                            xm[R - 1] = w[PH(k + 1 + R - 1)];
+                            xm[R - 1] = qm[0];
 #pragma unroll
                             for (int j = R - 1; j > 0; j--) {
                                 xp[j] = xp[j - 1];
                             }
-                            xp[0] = w[PH(2 * CENTER_T - (k + 1))];
+                            xp[0] = qp[0];
+                            h = qh[0];
+#pragma unroll
+                            for (int q = 0; q < PF - 1; q++) {
+                                qm[q] = qm[q + 1];
+                                qp[q] = qp[q + 1];
+                                qh[q] = qh[q + 1];
+                            }
+                            if (k + 1 + PF < CENTER_T) {
+                                qm[PF - 1] = w[PH(k + 1 + PF + R - 1)];
+                                qp[PF - 1] = w[PH(2 * CENTER_T - (k + 1 + PF))];
+                                qh[PF - 1] = stap[k + 1 + PF];
+                            }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #undef PH
                 } else {
@@ -450,19 +501,14 @@ k_front_end_fused(DdnFusedArgs a, DdnTapsK taps) {
                     }
                     chan_last[b ^ 1][g] = yl;
                 }
-                f4 q0, q1;
+                f4 q0;
 #pragma unroll
                 for (int j = 0; j < R; j++) {
                     const float fq = ddn_phase_delta(acc[j], prev);
                     prev = acc[j];
-                    if (j < 4) {
-                        q0[j] = fq;
-                    } else {
-                        q1[j - 4] = fq;
-                    }
+                    q0[j] = fq;
                 }
                 *(f4*)&Fb[bf][g][u * R] = q0;
-                *(f4*)&Fb[bf][g][u * R + 4] = q1;
                 if (a.squelch_on && tc.first) {
 #pragma unroll
                     for (int j = 0; j < R; j++) {
@@ -696,9 +742,9 @@ launch_fused_t(const DdnFusedArgs& a, const DdnTapsK& tp, bool has_zero, hipStre
     dim3 block(G * 32 + 128);
     const size_t dyn = a.squelch_on ? (size_t)G * 256 * sizeof(f2) : 0;
     if (has_zero) {
-        hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, true, FMT>), grid, block, dyn, st, a, tp);
+        hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, true, FMT>), grid, block, dyn, st, a);
     } else {
-        hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, false, FMT>), grid, block, dyn, st, a, tp);
+        hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, false, FMT>), grid, block, dyn, st, a);
     }
     return hipGetLastError();
 }
