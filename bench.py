@@ -204,7 +204,11 @@ def main():
             "parity": {"checked_channels": len(pick), "bit_exact": exact, "max_abs_err": max_err},
             "kernels_ms": {"k_front_end_fused": round(fir_avg, 4), "k_carry_update": round(ser_avg, 4)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # HBM bytes per launch from rocprofv3 PMC passes on this exact shape (FETCH_SIZE x2 gfx950
+                         # correction + WRITE_SIZE; profiles/README.md) - only valid for the profiled shape
+                         "traffic": 1.184e9 if (B == B_PER_GPU and n == N_SAMPLES) else None,
+                         "algorithmic_bytes": alg_bytes,
                          "bytes_per_sample": BYTES_PER_SAMPLE, "launch_ms": round(dom_ms, 4)},
         }
         if not args.no_cpu_baseline:

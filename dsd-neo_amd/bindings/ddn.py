@@ -113,6 +113,8 @@ def lib():
     global _lib
     if _lib is None:
         try:
+            if os.environ.get("DDN_NO_TORCH"):
+                raise ImportError("torch import skipped on request")
             # When PyTorch is in the process it must load ITS HIP runtime first: two different libamdhip64
             # images in one process leave the second one without a device ("No HIP GPUs are available").
             import torch  # noqa: F401
