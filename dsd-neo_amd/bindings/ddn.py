@@ -80,6 +80,16 @@ PROTOTYPES = {
     "ddn_slicer_batch_get_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25_matched_filter_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_p25_matched_filter_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_p25_rx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ddn_p25_rx_destroy": (None, [C.c_void_p]),
+    "ddn_p25_rx_reset": (C.c_int, [C.c_void_p]),
+    "ddn_p25_rx_set_channels_per_wave": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_p25_rx_max_symbols": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "ddn_p25_rx_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                 C.c_void_p]),
+    "ddn_p25_rx_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t]),
+    "ddn_p25_rx_get_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_ted_batch_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_void_p)]),
     "ddn_ted_batch_destroy": (None, [C.c_void_p]),
     "ddn_ted_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -196,3 +206,49 @@ class Batch:
         t = np.zeros(3, np.float32)
         _check(lib().ddn_batch_get_timing(self.h, t.ctypes.data), "ddn_batch_get_timing")
         return t
+
+
+class P25RxConfig(C.Structure):
+    """ddn_p25_rx_config (include/ddn_hip.h)."""
+    _fields_ = [("n_channels", C.c_int), ("out_rate_hz", C.c_int), ("sym_rate_hz", C.c_int),
+                ("lock_symbols", C.c_int), ("use_matched_filter", C.c_int)]
+
+
+class P25Rx:
+    """Batched fixed-protocol P25p1 receive loop (ddn_p25_rx_*), host-buffer convenience wrapper."""
+
+    def __init__(self, n_channels, out_rate=48000, sym_rate=4800, lock_symbols=840, use_matched_filter=1,
+                 channels_per_wave=0):
+        import numpy as np
+        self.np = np
+        self.B = n_channels
+        cfg = P25RxConfig(n_channels, out_rate, sym_rate, lock_symbols, use_matched_filter)
+        self.h = C.c_void_p()
+        rc = lib().ddn_p25_rx_create(C.byref(cfg), C.byref(self.h))
+        _check(-abs(rc), "ddn_p25_rx_create")
+        if channels_per_wave:
+            assert lib().ddn_p25_rx_set_channels_per_wave(self.h, channels_per_wave) == 0
+
+    def run(self, disc):
+        """disc float32 [B, n] -> (records uint8 [B, max_sym, 10], flags uint8 [B, max_sym], counts int32 [B])."""
+        np = self.np
+        disc = np.ascontiguousarray(disc, np.float32)
+        n = disc.shape[1]
+        ms = lib().ddn_p25_rx_max_symbols(self.h, n)
+        rec = np.zeros((self.B, ms, 10), np.uint8)
+        fl = np.zeros((self.B, ms), np.uint8)
+        cnt = np.zeros(self.B, np.int32)
+        rc = lib().ddn_p25_rx_run_host(self.h, disc.ctypes.data, n, rec.ctypes.data, fl.ctypes.data, cnt.ctypes.data, ms)
+        _check(-abs(rc), "ddn_p25_rx_run_host")
+        return rec, fl, cnt
+
+    def thresholds(self, ch):
+        t = self.np.zeros(7, self.np.float32)
+        assert lib().ddn_p25_rx_get_thresholds(self.h, ch, t.ctypes.data) == 0
+        return t
+
+    def __del__(self):
+        try:
+            lib().ddn_p25_rx_destroy(self.h)
+        except Exception:
+            pass

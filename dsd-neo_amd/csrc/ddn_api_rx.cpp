@@ -1,0 +1,250 @@
+// ddn_api_rx.cpp — C-ABI of the batched fixed-protocol P25p1 receive loop (include/ddn_hip.h, kernel ddn_rx.hip).
+// Per-channel decoder words (timing, hunting window, thresholds, the 128-symbol window, the two 1024-deep extrema
+// rings, the matched filter's 90-sample memory) live on the device inside the batch object and persist across calls.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ddn_device.h"
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            ddn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);                  \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorNoBinaryForGpu)             \
+                       ? DDN_ENODEV                                                                                    \
+                       : (e_ == hipErrorOutOfMemory ? DDN_ENOMEM : DDN_EHIP);                                          \
+        }                                                                                                              \
+    } while (0)
+
+struct ddn_p25_rx {
+    ddn_p25_rx_config cfg;
+    DdnRxState* d_state;
+    float *d_sbuf, *d_lbuf, *d_shist, *d_minring, *d_maxring, *d_fhist;
+    float* d_filt; // always-on matched-filter output of the current call, [B][filt_cap]
+    size_t filt_cap;
+    int channels_per_wave;
+};
+
+static void
+rx_free(ddn_p25_rx* b) {
+    (void)hipFree(b->d_state);
+    (void)hipFree(b->d_sbuf);
+    (void)hipFree(b->d_lbuf);
+    (void)hipFree(b->d_shist);
+    (void)hipFree(b->d_minring);
+    (void)hipFree(b->d_maxring);
+    (void)hipFree(b->d_fhist);
+    (void)hipFree(b->d_filt);
+}
+
+static int
+rx_fill(ddn_p25_rx* b) {
+    // symbol_reset_rtl_fsk_timing_if_needed() + symbol_reset_rtl_fsk_discriminator_slicer()
+    // (reference src/dsp/dsd_symbol.c:1306-1341): jitter -1, accumulator 0, slicer words at their RTL-FSK reset values
+    const size_t B = (size_t)b->cfg.n_channels;
+    DdnRxState s;
+    memset(&s, 0, sizeof(s));
+    s.center = 0.0f;
+    s.min = -30000.0f;
+    s.max = 30000.0f;
+    s.lmid = -20000.0f;
+    s.umid = 20000.0f;
+    s.minref = -24000.0f;
+    s.maxref = 24000.0f;
+    s.fill_min = s.min;
+    s.fill_max = s.max;
+    s.since_fill = 0;
+    s.min_sum = (double)s.min * 1024.0;
+    s.max_sum = (double)s.max * 1024.0;
+    s.jitter = -1;
+    s.lmin = s.min;
+    s.lmax = s.max;
+    std::vector<DdnRxState> hs(B, s);
+    if (hipMemcpy(b->d_state, hs.data(), sizeof(s) * B, hipMemcpyHostToDevice) != hipSuccess
+        || hipMemset(b->d_sbuf, 0, sizeof(float) * 128 * B) != hipSuccess
+        || hipMemset(b->d_lbuf, 0, sizeof(float) * 24 * B) != hipSuccess
+        || hipMemset(b->d_shist, 0, sizeof(float) * 24 * B) != hipSuccess
+        || hipMemset(b->d_minring, 0, sizeof(float) * 1024 * B) != hipSuccess
+        || hipMemset(b->d_maxring, 0, sizeof(float) * 1024 * B) != hipSuccess
+        || hipMemset(b->d_fhist, 0, sizeof(float) * 90 * B) != hipSuccess) {
+        ddn_set_error("p25 rx state upload failed");
+        return DDN_EHIP;
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_rx_create(const ddn_p25_rx_config* cfg, ddn_p25_rx** out) {
+    if (!cfg || !out || cfg->n_channels <= 0 || cfg->out_rate_hz <= 0 || cfg->sym_rate_hz <= 0
+        || cfg->lock_symbols < 0) {
+        ddn_set_error("ddn_p25_rx_create: bad configuration");
+        return DDN_EINVAL;
+    }
+    if (cfg->use_matched_filter && (cfg->out_rate_hz != 10 * cfg->sym_rate_hz)) {
+        // the P25 matched filter's coefficient set is per samples/symbol (reference src/dsp/dsd_filters.c:368);
+        // this library carries the 10 samples/symbol set
+        ddn_set_error("ddn_p25_rx_create: matched filter needs out_rate == 10 * sym_rate");
+        return DDN_ERANGE;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        ddn_set_error("no HIP device available");
+        return DDN_ENODEV;
+    }
+    ddn_p25_rx* b = new (std::nothrow) ddn_p25_rx();
+    if (!b) {
+        return DDN_ENOMEM;
+    }
+    memset(b, 0, sizeof(*b));
+    b->cfg = *cfg;
+    const size_t B = (size_t)cfg->n_channels;
+    if (hipMalloc(&b->d_state, sizeof(DdnRxState) * B) != hipSuccess
+        || hipMalloc(&b->d_sbuf, sizeof(float) * 128 * B) != hipSuccess
+        || hipMalloc(&b->d_lbuf, sizeof(float) * 24 * B) != hipSuccess
+        || hipMalloc(&b->d_shist, sizeof(float) * 24 * B) != hipSuccess
+        || hipMalloc(&b->d_minring, sizeof(float) * 1024 * B) != hipSuccess
+        || hipMalloc(&b->d_maxring, sizeof(float) * 1024 * B) != hipSuccess
+        || hipMalloc(&b->d_fhist, sizeof(float) * 90 * B) != hipSuccess || rx_fill(b) != DDN_OK) {
+        ddn_set_error("ddn_p25_rx_create: device allocation failed");
+        rx_free(b);
+        delete b;
+        return DDN_ENOMEM;
+    }
+    *out = b;
+    return DDN_OK;
+}
+
+extern "C" void
+ddn_p25_rx_destroy(ddn_p25_rx* b) {
+    if (!b) {
+        return;
+    }
+    rx_free(b);
+    delete b;
+}
+
+extern "C" int
+ddn_p25_rx_reset(ddn_p25_rx* b) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return rx_fill(b);
+}
+
+extern "C" int
+ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave) {
+    if (!b || (channels_per_wave != 0 && channels_per_wave != 16 && channels_per_wave != 32 && channels_per_wave != 64)) {
+        return DDN_EINVAL;
+    }
+    b->channels_per_wave = channels_per_wave;
+    return DDN_OK;
+}
+
+extern "C" size_t
+ddn_p25_rx_max_symbols(const ddn_p25_rx* b, size_t n) {
+    if (!b) {
+        return 0;
+    }
+    int whole = b->cfg.out_rate_hz / b->cfg.sym_rate_hz;
+    whole = whole < 2 ? 2 : (whole > 64 ? 64 : whole);
+    // every symbol consumes at least whole - 1 samples (one-sample slip while hunting); + the one carried in
+    return n / (size_t)(whole - 1) + 2;
+}
+
+extern "C" int
+ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records10, uint8_t* d_flags, int32_t* d_counts,
+               size_t max_symbols, void* hip_stream) {
+    if (!b || !d_disc || !d_records10 || !d_flags || !d_counts) {
+        ddn_set_error("ddn_p25_rx_run: null argument");
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int B = b->cfg.n_channels;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)B, st));
+        return DDN_OK;
+    }
+    if (b->cfg.use_matched_filter) {
+        if (b->filt_cap < n) {
+            HIP_TRY(hipStreamSynchronize(st));
+            (void)hipFree(b->d_filt);
+            b->d_filt = nullptr;
+            b->filt_cap = 0;
+            HIP_TRY(hipMalloc(&b->d_filt, sizeof(float) * (size_t)B * n));
+            b->filt_cap = n;
+        }
+        HIP_TRY(ddn_dev_p25_matched_filter_only(d_disc, (long)n, n, B, b->d_fhist, b->d_filt, st));
+    }
+    DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0};
+    if (const char* e = getenv("DDN_RX_DBG")) {
+        dc.dbg = atoi(e);
+    }
+    HIP_TRY(ddn_dev_p25_rx(d_disc, b->d_filt, b->d_fhist, (long)n, n, B, &dc, b->d_state, b->d_sbuf, b->d_lbuf,
+                           b->d_shist, b->d_minring, b->d_maxring, d_records10, d_flags, d_counts, max_symbols,
+                           b->channels_per_wave, st));
+    // the filter memory (last 90 raw samples) moves on only after the loop has read the previous tail
+    HIP_TRY(ddn_dev_p25_filter_hist_update(d_disc, (long)n, n, B, b->d_fhist, st));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
+                    size_t max_symbols) {
+    if (!b || !disc || !records10 || !flags || !counts) {
+        return DDN_EINVAL;
+    }
+    const size_t B = (size_t)b->cfg.n_channels;
+    float* d_in = nullptr;
+    uint8_t *d_rec = nullptr, *d_fl = nullptr;
+    int32_t* d_cnt = nullptr;
+    int rc;
+    if (hipMalloc(&d_in, B * n * 4 + 4) != hipSuccess || hipMalloc(&d_rec, B * max_symbols * 10 + 4) != hipSuccess
+        || hipMalloc(&d_fl, B * max_symbols + 4) != hipSuccess || hipMalloc(&d_cnt, B * 4) != hipSuccess) {
+        ddn_set_error("ddn_p25_rx_run_host: device allocation failed (no device?)");
+        rc = DDN_ENODEV;
+    } else if (hipMemcpy(d_in, disc, B * n * 4, hipMemcpyHostToDevice) != hipSuccess
+               || hipMemset(d_rec, 0, B * max_symbols * 10) != hipSuccess
+               || hipMemset(d_fl, 0, B * max_symbols) != hipSuccess) {
+        rc = DDN_EHIP;
+    } else {
+        rc = ddn_p25_rx_run(b, d_in, n, d_rec, d_fl, d_cnt, max_symbols, nullptr);
+        if (rc == DDN_OK
+            && (hipDeviceSynchronize() != hipSuccess
+                || hipMemcpy(records10, d_rec, B * max_symbols * 10, hipMemcpyDeviceToHost) != hipSuccess
+                || hipMemcpy(flags, d_fl, B * max_symbols, hipMemcpyDeviceToHost) != hipSuccess
+                || hipMemcpy(counts, d_cnt, B * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+            ddn_set_error("ddn_p25_rx_run_host: %s", hipGetErrorString(hipGetLastError()));
+            rc = DDN_EHIP;
+        }
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_rec);
+    (void)hipFree(d_fl);
+    (void)hipFree(d_cnt);
+    return rc;
+}
+
+extern "C" int
+ddn_p25_rx_get_thresholds(ddn_p25_rx* b, int channel, float out7[7]) {
+    if (!b || !out7 || channel < 0 || channel >= b->cfg.n_channels) {
+        return DDN_EINVAL;
+    }
+    DdnRxState s;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&s, b->d_state + channel, sizeof(s), hipMemcpyDeviceToHost));
+    out7[0] = s.center;
+    out7[1] = s.umid;
+    out7[2] = s.lmid;
+    out7[3] = s.max;
+    out7[4] = s.min;
+    out7[5] = s.maxref;
+    out7[6] = s.minref;
+    return DDN_OK;
+}

@@ -54,6 +54,24 @@ typedef struct DdnSlicerState { /* per-channel slicer words of dsd_state the P25
     double min_sum, max_sum;
 } DdnSlicerState;
 
+typedef struct DdnRxConfig { /* fixed-protocol P25p1 receive loop (ddn_rx.hip) */
+    int out_rate, sym_rate, lock_symbols, use_filter;
+    int dbg; /* profiling only (env DDN_RX_DBG): 1 = skip symbol commit, 2 = skip record stores, 4 = skip sample loop body */
+} DdnRxConfig;
+
+typedef struct DdnRxState { /* per-channel words of dsd_state / frame_sync_runtime_ctx the P25p1 loop carries */
+    double min_sum, max_sum;
+    long long filt_start, n_abs; /* absolute sample index of the filter's first sample / of the next input sample */
+    float center, umid, lmid, max, min, maxref, minref;
+    float fill_min, fill_max; /* value the extrema rings were last refilled with */
+    float sum, lastsample, lmin, lmax;
+    int sidx, midx, since_fill; /* since_fill: ring pushes since the refill, saturating at 1024 */
+    int sps_accum, jitter, in_symbol, span, centre, i, count;
+    int filter_on, have_sync, lock_left, lastsync; /* lastsync: 0 none, 1 +P25p1, 2 -P25p1 */
+    int lidx, level_count, hist_count, shead, scount;
+    uint32_t hist_bits;
+} DdnRxState;
+
 typedef struct DdnPuncture { /* puncture pattern of the K=5 decoder, expanded on the host */
     int p_len;               /* 0 = not punctured */
     int ones_total;
@@ -72,6 +90,14 @@ hipError_t ddn_dev_p25_slicer(const float* sym, long n, size_t sym_stride, int n
                               size_t rec_stride, hipStream_t st);
 hipError_t ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channels, float* hist, float* out,
                                       hipStream_t st);
+hipError_t ddn_dev_p25_matched_filter_only(const float* in, long n, size_t stride, int n_channels, const float* hist,
+                                           float* out, hipStream_t st);
+hipError_t ddn_dev_p25_filter_hist_update(const float* in, long n, size_t stride, int n_channels, float* hist,
+                                          hipStream_t st);
+hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride,
+                          int n_channels, const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store,
+                          float* lbuf_store, float* shist_store, float* minring, float* maxring, uint8_t* rec,
+                          uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave, hipStream_t st);
 hipError_t ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
                               const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);

@@ -1,0 +1,514 @@
+// ddn_rx.hip — batched fixed-protocol P25 Phase 1 C4FM receive loop: discriminator samples -> capture records.
+//
+// One lane = one channel running what the reference's decoder thread runs per stream:
+//   getSymbol() (RTL-FSK discriminator path)   src/dsp/dsd_symbol.c:1343-1387,197-211,347-358,360-397,436-460,489-517,
+//                                              1769-1805,1839-1851; matched-filter gating :301-338
+//   getFrameSync() hunting loop                src/dsp/dsd_frame_sync.c:3098-3148 (ring :1747-1764, sign dibit
+//                                              :2110-2127, level window :2316-2336 + src/dsp/frame_sync_level.c:10-44,
+//                                              P25p1 pattern :698-716, accept :385-392,603-625)
+//   threshold warm start                       src/dsp/sync_calibration.c:156-233
+//   in-frame symbols                           get_dibit_and_analog_signal, src/core/frames/dsd_dibit.c (ddn_slicer_dev.h)
+// Scope and deviations: P25p1 only, modulation locked to C4FM, a caller-given in-frame
+// symbol count instead of the per-DUID handlers, no carrier-loss reset.
+//
+// GPU shape.  Everything here is a per-sample / per-symbol recurrence, so the only parallelism is across channels,
+// and one wavefront issues about one VALU instruction every ~5 cycles however many of its lanes are active.  At the
+// batch sizes this runs (thousands of channels) spreading channels over MORE wavefronts with FEWER active lanes each is
+// what shortens the critical path, so the kernel is templated on channels-per-wavefront (CPW = 16/32/64) and the
+// launcher picks the smallest CPW that still fits the grid.  Per workgroup: wave 0 runs the recurrence, wave 1 streams
+// the next 64-sample tile of every channel's row into LDS with coalesced 256-B row loads (raw discriminator samples and
+// the always-on matched-filter output F computed beforehand by k_p25_matched_filter).  The matched filter is a pure FIR,
+// so once it has been on for 90 samples its output IS F; only the 90 samples after its first enable are computed
+// inline (history = zeros before the enable sample, as the reference's static filter memory).
+// The two 1024-deep extrema rings stay in HBM; a ring refill (reset, warm start) is recorded as {fill value,
+// pushes since fill} instead of 2048 stores, and the refilled ring's binary64 sum is 1024*v exactly (k*v is exact in
+// binary64 for k <= 1024 and a binary32 v, so the reference's sequential rebuild gives the same bits).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+#include "ddn_slicer_dev.h"
+#include "ddn_tables_p25.h"
+
+using ddn_sl::two_max_insert;
+using ddn_sl::two_min_insert;
+
+namespace {
+constexpr int TS = 64;       // samples per staged tile
+constexpr int SS = 128;      // opts->ssize
+constexpr int MS = 1024;     // opts->msize
+constexpr int NT = DDN_P25_FILTER_TAPS;
+constexpr uint32_t kSyncBits = 0xFB30A0u; // P25P1_SYNC as sign bits, oldest symbol in bit 23
+
+__constant__ uint32_t c_taps[NT];
+
+template <int CPW>
+struct Lds {
+    float sb[SS][CPW];
+    float gs[8][4][CPW];
+    float lb[24][CPW];
+    float sh[24][CPW];
+    float raw[2][CPW][TS + 1];
+    float flt[2][CPW][TS + 1];
+};
+} // namespace
+
+template <int CPW>
+__global__ __launch_bounds__(128) void
+k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail, long n,
+         size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
+         float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
+         float* __restrict__ maxring, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags, int32_t* __restrict__ counts,
+         size_t max_sym) {
+    extern __shared__ unsigned char smem_raw[];
+    Lds<CPW>& L = *reinterpret_cast<Lds<CPW>*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;
+    const int ch0 = blockIdx.x * CPW;
+    const int ch = ch0 + lane;
+    const bool live = !loader && lane < CPW && ch < n_channels;
+    const int ln = lane < CPW ? lane : 0; // LDS column (idle lanes alias column 0 but never write)
+    const bool use_flt = cfg.use_filter != 0;
+
+    DdnRxState s;
+    if (live) {
+        s = state[ch];
+        for (int k = 0; k < SS; k++) {
+            L.sb[k][ln] = sbuf_store[(size_t)k * n_channels + ch];
+        }
+        for (int k = 0; k < 24; k++) {
+            L.lb[k][ln] = lbuf_store[(size_t)k * n_channels + ch];
+            L.sh[k][ln] = shist_store[(size_t)k * n_channels + ch];
+        }
+    } else {
+        s = DdnRxState{};
+    }
+    auto refresh_group = [&](int g) {
+        float a1 = L.sb[g * 16][ln], a2 = L.sb[g * 16 + 1][ln];
+        float b1 = a1, b2 = a2;
+        if (a2 < a1) {
+            const float t = a1;
+            a1 = a2;
+            a2 = t;
+        }
+        if (b2 > b1) {
+            const float t = b1;
+            b1 = b2;
+            b2 = t;
+        }
+#pragma unroll
+        for (int k = 2; k < 16; k++) {
+            const float v = L.sb[g * 16 + k][ln];
+            two_min_insert(v, a1, a2);
+            two_max_insert(v, b1, b2);
+        }
+        L.gs[g][0][ln] = a1;
+        L.gs[g][1][ln] = a2;
+        L.gs[g][2][ln] = b1;
+        L.gs[g][3][ln] = b2;
+    };
+    if (live) {
+        for (int g = 0; g < 8; g++) {
+            refresh_group(g);
+        }
+    }
+
+    // ---- coalesced staging by the loader wave -----------------------------------------------------------------
+    auto stage = [&](long t0, int buf) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+#pragma unroll
+        for (int h = 0; h < CPW / 16; h++) {
+            float r[16], f[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int cc = 16 * h + c;
+                const bool ok = (ch0 + cc < n_channels) && lane < tn;
+                const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + lane;
+                r[c] = ok ? raw[off] : 0.0f;
+                f[c] = (ok && use_flt) ? filt[off] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                L.raw[buf][16 * h + c][lane] = r[c];
+                L.flt[buf][16 * h + c][lane] = f[c];
+            }
+        }
+    };
+    if (loader && n > 0) {
+        stage(0, 0);
+    }
+    __syncthreads();
+
+    const int whole0 = cfg.out_rate / cfg.sym_rate, rem0 = cfg.out_rate % cfg.sym_rate;
+    const int whole = whole0 < 2 ? 2 : (whole0 > 64 ? 64 : whole0);
+    const int rem = (whole0 < 2 || whole0 > 64) ? 0 : rem0;
+    int o = 0;
+    uint8_t* rp = rec + (size_t)(live ? ch : 0) * max_sym * 10;
+    uint8_t* fp = flags + (size_t)(live ? ch : 0) * max_sym;
+    const long long abs0 = s.n_abs;
+
+    int buf = 0;
+    for (long t0 = 0; t0 < n; t0 += TS, buf ^= 1) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        if (loader) {
+            if (t0 + TS < n) {
+                stage(t0 + TS, buf ^ 1);
+            }
+        } else {
+            int sp = 0; // this lane's cursor in the tile
+            int guard = 0;
+            while (true) {
+                // ---- sample loop: run every lane to the end of its current symbol (or of the tile) ---------------
+                if (live && sp < tn && !s.in_symbol) {
+                    int sps = whole;
+                    if (rem > 0) {
+                        int acc = s.sps_accum + rem;
+                        if (acc >= cfg.sym_rate) {
+                            sps++;
+                            acc -= cfg.sym_rate;
+                        }
+                        s.sps_accum = acc;
+                        sps = sps > 64 ? 64 : sps;
+                    }
+                    s.span = sps;
+                    s.centre = (sps - 1) / 2;
+                    s.i = 0;
+                    s.sum = 0.0f;
+                    s.count = 0;
+                    s.in_symbol = 1;
+                    if (sps > 1 && s.have_sync == 0 && s.jitter >= 0) {
+                        if (s.jitter > 0 && s.jitter <= s.centre) {
+                            s.i--;
+                        } else if (s.jitter > s.centre && s.jitter < sps) {
+                            s.i++;
+                        }
+                        s.jitter = -1;
+                    }
+                }
+                // In-frame fast path.  With have_sync = 1 there is no slip, and once jitter is latched (>= 0) the
+                // per-sample crossing test cannot change it, so the symbol is just the mean of the five clipped
+                // window samples (added in sample order) and lastsample the clipped last sample.  Taken when the whole
+                // symbol lies inside the staged tile and the filter (if on) is past its 90-sample cold start.
+                if (live && s.in_symbol && s.i == 0 && s.have_sync && s.jitter >= 0 && s.span >= 6 && s.span != 20
+                    && sp + s.span <= tn && !(cfg.dbg & 8)
+                    && (!s.filter_on || (abs0 + t0 + sp - s.filt_start) >= (long long)(NT - 1))) {
+                    const bool fo = s.filter_on != 0;
+                    const int c = s.centre;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const int j = sp + c - 2 + k;
+                        float x = fo ? L.flt[buf][ln][j] : L.raw[buf][ln][j];
+                        x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        acc += x;
+                    }
+                    const int jl = sp + s.span - 1;
+                    float xl = fo ? L.flt[buf][ln][jl] : L.raw[buf][ln][jl];
+                    xl = xl > s.max ? s.max : (xl < s.min ? s.min : xl);
+                    s.sum = acc;
+                    s.count = 5;
+                    s.lastsample = xl;
+                    sp += s.span;
+                    s.i = s.span;
+                }
+                bool act = live && sp < tn && s.i < s.span;
+                while (__any(act)) {
+                    if (act && (cfg.dbg & 4)) {
+                        s.i++;
+                        sp++;
+                    } else if (act) {
+                        float x = L.raw[buf][ln][sp];
+                        if (s.filter_on) {
+                            const long long a = abs0 + t0 + sp;
+                            if (a - s.filt_start >= (long long)(NT - 1)) {
+                                x = L.flt[buf][ln][sp];
+                            } else {
+                                // first 90 samples after the enable: FIR over a zero-extended history
+                                const long k = t0 + sp;
+                                float acc = 0.0f;
+                                for (int i = 0; i < NT; i++) {
+                                    const long j = k - (NT - 1) + i;
+                                    float v = 0.0f;
+                                    if (abs0 + j >= s.filt_start) {
+                                        v = (j >= 0) ? raw[(size_t)ch * stride + j]
+                                                     : prev_tail[(size_t)ch * (NT - 1) + (NT - 1) + j];
+                                    }
+                                    acc += __uint_as_float(c_taps[i]) * v;
+                                }
+                                x = acc;
+                            }
+                        }
+                        if (s.have_sync) {
+                            x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        }
+                        const int i = s.i;
+                        if (s.jitter < 0) {
+                            if (x > s.center) {
+                                if (!(x > s.maxref * 1.25f) && s.lastsample < s.center) {
+                                    s.jitter = i;
+                                }
+                            } else if (!(x < s.minref * 1.25f) && s.lastsample > s.center) {
+                                s.jitter = i;
+                            }
+                        }
+                        if (s.span == 20 && i >= 7 && i <= 13) {
+                            s.sum += x;
+                            s.count++;
+                        }
+                        if ((s.span == 5 && i == 2) || (i >= s.centre - 2 && i <= s.centre + 2)) {
+                            s.sum += x;
+                            s.count++;
+                        }
+                        s.lastsample = x;
+                        s.i++;
+                        sp++;
+                    }
+                    act = live && sp < tn && s.i < s.span;
+                }
+                // ---- symbol commit ----------------------------------------------------------------------------
+                const bool done = live && s.in_symbol && s.i >= s.span;
+                if (done && (cfg.dbg & 1)) {
+                    s.in_symbol = 0;
+                    o++;
+                } else if (done) {
+                    const float sym = (s.count > 0) ? (s.sum / (float)s.count) : 0.0f;
+                    s.in_symbol = 0;
+                    L.sh[s.shead][ln] = sym;
+                    s.shead = (s.shead + 1 >= 24) ? 0 : s.shead + 1;
+                    s.scount = s.scount < 24 ? s.scount + 1 : 24;
+                    int dibit, relb = 0, l0 = 0, l1 = 0, fl = 0;
+                    if (s.have_sync) {
+                        // get_dibit_and_analog_signal(): window, extrema rings, thresholds, slice + soft decision
+                        const int neg = (s.lastsync == 2);
+                        L.sb[s.sidx][ln] = sym;
+                        refresh_group(s.sidx >> 4);
+                        float m1 = L.gs[0][0][ln], m2 = L.gs[0][1][ln], x1 = L.gs[0][2][ln], x2 = L.gs[0][3][ln];
+#pragma unroll
+                        for (int g = 1; g < 8; g++) {
+                            two_min_insert(L.gs[g][0][ln], m1, m2);
+                            two_min_insert(L.gs[g][1][ln], m1, m2);
+                            two_max_insert(L.gs[g][2][ln], x1, x2);
+                            two_max_insert(L.gs[g][3][ln], x1, x2);
+                        }
+                        const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
+                        const size_t ro = (size_t)s.midx * n_channels + ch;
+                        float old_lo = s.fill_min, old_hi = s.fill_max;
+                        if (s.since_fill >= MS) {
+                            old_lo = minring[ro];
+                            old_hi = maxring[ro];
+                        } else {
+                            s.since_fill++;
+                        }
+                        s.min_sum += (double)lo - (double)old_lo;
+                        s.max_sum += (double)hi - (double)old_hi;
+                        minring[ro] = lo;
+                        maxring[ro] = hi;
+                        s.midx = (s.midx + 1 >= MS) ? 0 : s.midx + 1;
+                        s.min = (float)(s.min_sum / (double)MS);
+                        s.max = (float)(s.max_sum / (double)MS);
+                        s.center = (s.max + s.min) / 2.0f;
+                        s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
+                        s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
+                        s.maxref = s.max * 0.80f;
+                        s.minref = s.min * 0.80f;
+                        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+                        const ddn_sl::Thr th = {s.center, s.umid, s.lmid, s.max, s.min};
+                        ddn_sl::slice_soft(sym, th, neg, dibit, relb, l0, l1);
+                        fl = 1 | (neg ? 4 : 0);
+                        if (--s.lock_left <= 0) {
+                            s.have_sync = 0;
+                            s.lidx = 0;
+                            s.level_count = 0;
+                            s.hist_count = 0;
+                            s.hist_bits = 0;
+                            s.lmin = s.min;
+                            s.lmax = s.max;
+                        }
+                    } else {
+                        // getFrameSync(): one hunting iteration
+                        L.lb[s.lidx][ln] = sym;
+                        s.level_count = s.level_count < 24 ? s.level_count + 1 : 24;
+                        L.sb[s.sidx][ln] = sym;
+                        refresh_group(s.sidx >> 4);
+                        s.lidx = (s.lidx == 23) ? 0 : s.lidx + 1;
+                        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+                        const uint32_t bit = sym > 0.0f ? 1u : 0u;
+                        s.hist_bits = ((s.hist_bits << 1) | bit) & 0xFFFFFFu;
+                        s.hist_count = s.hist_count < 24 ? s.hist_count + 1 : 24;
+                        dibit = bit ? 1 : 3;
+                        if (s.hist_count >= 8) {
+                            // five smallest (ascending) / five largest (descending) of the level window
+                            const float big = 3.4028234663852886e38f;
+                            float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
+                            float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
+                            const int cnt = s.level_count;
+                            for (int k = 0; k < 24; k++) {
+                                if (k < cnt) {
+                                    float v = L.lb[k][ln], t;
+                                    float w = v;
+                                    t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
+                                    t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
+                                    t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
+                                    t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
+                                    a4 = fminf(a4, v);
+                                    t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
+                                    t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
+                                    t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
+                                    t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
+                                    b4 = fmaxf(b4, w);
+                                }
+                            }
+                            if (cnt >= 13) {
+                                s.lmin = (a2 + a3 + a4) / 3.0f;
+                                s.lmax = (b4 + b3 + b2) / 3.0f;
+                            } else {
+                                s.lmin = (a0 + a1 + a2) / 3.0f;
+                                s.lmax = (b2 + b1 + b0) / 3.0f;
+                            }
+                            s.maxref = s.max;
+                            s.minref = s.min;
+                            int pol = 0;
+                            if (s.hist_count >= 24) {
+                                pol = (s.hist_bits == kSyncBits) ? 1 : ((s.hist_bits == (~kSyncBits & 0xFFFFFFu)) ? 2 : 0);
+                            }
+                            if (pol) {
+                                s.max = (s.max + s.lmax) / 2;
+                                s.min = (s.min + s.lmin) / 2;
+                                s.lastsync = pol;
+                                if (use_flt && !s.filter_on) {
+                                    s.filter_on = 1;
+                                    s.filt_start = abs0 + t0 + sp; // first sample the filter sees
+                                }
+                                if (s.scount >= 24) {
+                                    float sp_ = 0.0f, sn_ = 0.0f;
+                                    int np = 0, nn = 0;
+                                    int idx = s.shead;
+                                    for (int k = 0; k < 24; k++) {
+                                        idx = idx == 0 ? 23 : idx - 1;
+                                        const float v = L.sh[idx][ln];
+                                        if (v > 0.0f) {
+                                            sp_ += v;
+                                            np++;
+                                        } else {
+                                            sn_ += v;
+                                            nn++;
+                                        }
+                                    }
+                                    if (np != 0 && nn != 0) {
+                                        const float mp = sp_ / (float)np, mn = sn_ / (float)nn;
+                                        if (!(fabsf(mp - mn) < 1.0f)) {
+                                            s.max = mp;
+                                            s.min = mn;
+                                            s.center = (s.max + s.min) / 2.0f;
+                                            s.umid = s.center + (s.max - s.center) * 0.625f;
+                                            s.lmid = s.center + (s.min - s.center) * 0.625f;
+                                            s.maxref = s.max * 0.80f;
+                                            s.minref = s.min * 0.80f;
+                                            s.fill_max = s.max;
+                                            s.fill_min = s.min;
+                                            s.since_fill = 0;
+                                            s.max_sum = (double)s.max * (double)MS;
+                                            s.min_sum = (double)s.min * (double)MS;
+                                        }
+                                    }
+                                }
+                                s.have_sync = 1;
+                                s.lock_left = cfg.lock_symbols;
+                                fl = 2 | (pol == 2 ? 4 : 0);
+                                if (s.lock_left <= 0) {
+                                    s.have_sync = 0;
+                                    s.lidx = 0;
+                                    s.level_count = 0;
+                                    s.hist_count = 0;
+                                    s.hist_bits = 0;
+                                    s.lmin = s.min;
+                                    s.lmax = s.max;
+                                }
+                            }
+                        }
+                    }
+                    if ((size_t)o < max_sym && !(cfg.dbg & 2)) {
+                        uint8_t* r = rp + (size_t)o * 10;
+                        const uint32_t xb = __float_as_uint(sym);
+                        ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
+                        ((uint16_t*)r)[1] = (uint16_t)(int16_t)l0;
+                        ((uint16_t*)r)[2] = (uint16_t)(int16_t)l1;
+                        ((uint16_t*)r)[3] = (uint16_t)(xb & 0xFFFFu);
+                        ((uint16_t*)r)[4] = (uint16_t)(xb >> 16);
+                        fp[o] = (uint8_t)fl;
+                    }
+                    o++;
+                }
+                const bool busy = live && sp < tn;
+                if (!__any(busy) || ++guard > 2 * TS) {
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        s.n_abs = abs0 + n;
+        state[ch] = s;
+        counts[ch] = o;
+        for (int k = 0; k < SS; k++) {
+            sbuf_store[(size_t)k * n_channels + ch] = L.sb[k][ln];
+        }
+        for (int k = 0; k < 24; k++) {
+            lbuf_store[(size_t)k * n_channels + ch] = L.lb[k][ln];
+            shist_store[(size_t)k * n_channels + ch] = L.sh[k][ln];
+        }
+    }
+}
+
+template <int CPW>
+static hipError_t
+launch_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
+          const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
+          float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, hipStream_t st) {
+    const size_t shm = sizeof(Lds<CPW>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rx<CPW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_p25_rx<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shm, st, raw, filt,
+                       prev_tail, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
+                       maxring, rec, flags, counts, max_sym);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
+               const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
+               float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym,
+               int channels_per_wave, hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    static bool taps_up = false;
+    if (!taps_up) {
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_taps), ddn_p25_filter_bits, sizeof(uint32_t) * NT);
+        if (e != hipSuccess) {
+            return e;
+        }
+        taps_up = true;
+    }
+    int cpw = channels_per_wave;
+    if (cpw != 16 && cpw != 32 && cpw != 64) {
+        // fewest lanes per wavefront that still gives every CU (256) no more than ~2 workgroups
+        cpw = n_channels <= 16 * 512 ? 16 : (n_channels <= 32 * 512 ? 32 : 64);
+    }
+    switch (cpw) {
+        case 16:
+            return launch_rx<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                 shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+        case 32:
+            return launch_rx<32>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                 shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+        default:
+            return launch_rx<64>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                 shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+    }
+}

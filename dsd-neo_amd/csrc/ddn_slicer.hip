@@ -22,62 +22,11 @@
 #include <stdint.h>
 
 #include "ddn_device.h"
+#include "ddn_slicer_dev.h"
 #include "ddn_tables_p25.h"
 
-namespace {
-__device__ __forceinline__ int
-clamp255(int v) {
-    return v < 0 ? 0 : (v > 255 ? 255 : v);
-}
-
-__device__ __forceinline__ void
-two_min_insert(float x, float& a1, float& a2) {
-    if (x < a1) {
-        a2 = a1;
-        a1 = x;
-    } else if (x < a2) {
-        a2 = x;
-    }
-}
-__device__ __forceinline__ void
-two_max_insert(float x, float& b1, float& b2) {
-    if (x > b1) {
-        b2 = b1;
-        b1 = x;
-    } else if (x > b2) {
-        b2 = x;
-    }
-}
-
-__device__ __forceinline__ int
-bit_magnitude(float sym, const float ideal[4], int bit_index) {
-    const float big = 3.4028234663852886e38f;
-    float best0 = big, best1 = big, spacing = big;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float d = (sym - ideal[i]) * (sym - ideal[i]);
-        if ((i >> (1 - bit_index)) & 1) {
-            if (d < best1) {
-                best1 = d;
-            }
-        } else if (d < best0) {
-            best0 = d;
-        }
-#pragma unroll
-        for (int j = i + 1; j < 4; j++) {
-            const float sp = fabsf(ideal[i] - ideal[j]);
-            if (sp > 1e-6f && sp < spacing) {
-                spacing = sp;
-            }
-        }
-    }
-    if (spacing == big) {
-        spacing = 2.0f;
-    }
-    const float scale = 255.0f / (spacing * spacing);
-    return clamp255((int)__float2ll_rn(fabsf(best0 - best1) * scale));
-}
-} // namespace
+using ddn_sl::two_max_insert;
+using ddn_sl::two_min_insert;
 
 __global__ __launch_bounds__(64) void
 k_p25_slicer(const float* __restrict__ sym, long n, size_t sym_stride, int n_channels, int negative,
@@ -188,56 +137,16 @@ k_p25_slicer(const float* __restrict__ sym, long n, size_t sym_stride, int n_cha
         s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
         s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
         // ---- slice + soft decision ---------------------------------------------------------------------------
-        int dibit;
-        if (x > s.center) {
-            dibit = (x > s.umid) ? (negative ? 3 : 1) : (negative ? 2 : 0);
-        } else {
-            dibit = (x < s.lmid) ? (negative ? 1 : 3) : (negative ? 0 : 2);
-        }
-        const float plus_one = 0.5f * (s.center + s.umid), minus_one = 0.5f * (s.lmid + s.center);
-        float ideal[4];
-        ideal[0] = negative ? minus_one : plus_one;
-        ideal[1] = negative ? s.min : s.max;
-        ideal[2] = negative ? plus_one : minus_one;
-        ideal[3] = negative ? s.max : s.min;
-        int mag0 = bit_magnitude(x, ideal, 0), mag1 = bit_magnitude(x, ideal, 1);
-        int rel;
+        int dibit, relb, l0, l1;
         {
-            const float eps = 1e-6f;
-            if (x > s.umid) {
-                float span = s.max - s.umid;
-                span = span < eps ? eps : span;
-                rel = (int)__float2ll_rn(((x - s.umid) * 255.0f) / span);
-            } else if (x > s.center) {
-                const float d1 = x - s.center, d2 = s.umid - x;
-                float span = s.umid - s.center;
-                span = span < eps ? eps : span;
-                rel = (int)__float2ll_rn(((d1 < d2 ? d1 : d2) * 510.0f) / span);
-            } else if (x >= s.lmid) {
-                const float d1 = s.center - x, d2 = x - s.lmid;
-                float span = s.center - s.lmid;
-                span = span < eps ? eps : span;
-                rel = (int)__float2ll_rn(((d1 < d2 ? d1 : d2) * 510.0f) / span);
-            } else {
-                float span = s.lmid - s.min;
-                span = span < eps ? eps : span;
-                rel = (int)__float2ll_rn(((s.lmid - x) * 255.0f) / span);
-            }
-            rel = clamp255((clamp255(rel) * 204) >> 8);
+            const ddn_sl::Thr th = {s.center, s.umid, s.lmid, s.max, s.min};
+            ddn_sl::slice_soft(x, th, negative, dibit, relb, l0, l1);
         }
-        const int mn = mag0 < mag1 ? mag0 : mag1;
-        if (mn > 0 && rel < mn) {
-            mag0 = (mag0 * rel) / mn;
-            mag1 = (mag1 * rel) / mn;
-        }
-        const int l0 = ((dibit >> 1) & 1) ? clamp255(mag0) : -clamp255(mag0);
-        const int l1 = (dibit & 1) ? clamp255(mag1) : -clamp255(mag1);
-        const int a0 = l0 < 0 ? -l0 : l0, a1v = l1 < 0 ? -l1 : l1;
         if (live) {
             uint8_t* r = rp + (size_t)i * 10;
             const uint32_t xb = __float_as_uint(x);
             // 10-byte record, 2-byte aligned: three u16 + one split u32
-            ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (clamp255(a1v < a0 ? a1v : a0) << 8));
+            ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
             ((uint16_t*)r)[1] = (uint16_t)(int16_t)l0;
             ((uint16_t*)r)[2] = (uint16_t)(int16_t)l1;
             ((uint16_t*)r)[3] = (uint16_t)(xb & 0xFFFFu);
@@ -321,6 +230,27 @@ ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channel
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         return e;
+    }
+    hipLaunchKernelGGL(k_p25_filter_hist, dim3((unsigned)n_channels), dim3(DDN_P25_FILTER_TAPS - 1), 0, st, in, n,
+                       stride, hist);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_p25_matched_filter_only(const float* in, long n, size_t stride, int n_channels, const float* hist, float* out,
+                                hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p25_matched_filter, dim3((unsigned)((n + 1023) / 1024), (unsigned)n_channels), dim3(256), 0, st,
+                       in, n, stride, hist, out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_p25_filter_hist_update(const float* in, long n, size_t stride, int n_channels, float* hist, hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
     }
     hipLaunchKernelGGL(k_p25_filter_hist, dim3((unsigned)n_channels), dim3(DDN_P25_FILTER_TAPS - 1), 0, st, in, n,
                        stride, hist);

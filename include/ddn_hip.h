@@ -113,6 +113,45 @@ int ddn_slicer_batch_get_thresholds(ddn_slicer_batch* b, int channel, float out5
 int ddn_p25_matched_filter_run(ddn_slicer_batch* b, const float* d_in, size_t n, float* d_out, void* hip_stream);
 int ddn_p25_matched_filter_run_host(ddn_slicer_batch* b, const float* in, size_t n, float* out);
 
+/* ---- fixed-protocol P25 Phase 1 C4FM receive loop, batched ------------------------------------------------
+ * Discriminator samples -> symbol capture records, i.e. what one dsd-neo decoder thread does per stream between
+ * rtl_stream_read() and the protocol handler:
+ *   getSymbol(opts, state, have_sync)   include/dsd-neo/dsp/symbol.h; src/dsp/dsd_symbol.c:1854-1880 (jitter timing,
+ *                                       C4FM 5-sample window mean, matched filter once P25p1 has been seen, in-sync clip)
+ *   getFrameSync(opts, state)           include/dsd-neo/dsp/frame_sync.h; src/dsp/dsd_frame_sync.c:3098-3148 restricted
+ *                                       to the P25p1 pattern with the modulation locked to C4FM (-mc), incl. the
+ *                                       hunting level window and dsd_sync_warm_start_thresholds_outer_only()
+ *   getDibitSoft(opts, state, &soft)    include/dsd-neo/core/dibit.h:43-52 for every in-frame symbol
+ * Deviations from a full dsd-neo run (stated in DESIGN.md): after a sync the loop stays in frame for
+ * cfg.lock_symbols symbols (the reference's per-DUID handlers decide that per frame); carrier-loss reset is not
+ * modelled.  Parity: the slicer, warm start and level window are pinned to the compiled reference; the sample /
+ * hunting loops are restated from source (dsd_symbol.c / dsd_frame_sync.c do not build here) - "parity unpinned".
+ *   d_disc      : [B][n] f32 discriminator samples (ddn_front_end_run output), channel-major
+ *   d_records10 : [B][max_symbols][10] capture records {u8 dibit, u8 reliability, i16 llr0, i16 llr1, f32 symbol}
+ *                 (write_symbol_capture_record layout, src/core/frames/dsd_dibit.c:794-818); while hunting the dibit
+ *                 is the sign decision ('1'/'3') and the soft fields are 0
+ *   d_flags     : [B][max_symbols] bit0 = symbol read in frame (have_sync = 1), bit1 = frame sync accepted on this
+ *                 symbol, bit2 = negative polarity
+ *   d_counts    : [B] symbols produced by this call (<= ddn_p25_rx_max_symbols(n)) */
+typedef struct ddn_p25_rx_config {
+    int n_channels;
+    int out_rate_hz;        /* discriminator sample rate (48000) */
+    int sym_rate_hz;        /* 4800 */
+    int lock_symbols;       /* symbols read with have_sync = 1 after each accepted sync */
+    int use_matched_filter; /* opts->use_cosine_filter */
+} ddn_p25_rx_config;
+typedef struct ddn_p25_rx ddn_p25_rx;
+int ddn_p25_rx_create(const ddn_p25_rx_config* cfg, ddn_p25_rx** out);
+void ddn_p25_rx_destroy(ddn_p25_rx* b);
+int ddn_p25_rx_reset(ddn_p25_rx* b);
+int ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave); /* 0 = automatic, else 16 / 32 / 64 */
+size_t ddn_p25_rx_max_symbols(const ddn_p25_rx* b, size_t n);
+int ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records10, uint8_t* d_flags,
+                   int32_t* d_counts, size_t max_symbols, void* hip_stream);
+int ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags,
+                        int32_t* counts, size_t max_symbols);
+int ddn_p25_rx_get_thresholds(ddn_p25_rx* b, int channel, float out7[7]);
+
 /* ---- Gardner symbol-timing recovery (CQPSK branch), batched ----------------------------------------------
  * == op25_gardner_cc(struct demod_state*) (include/dsd-neo/dsp/costas.h; src/dsp/costas.cpp:804-858) applied to B
  * channels at once; each channel's ted_state_t is carried inside the batch object.

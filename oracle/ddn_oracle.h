@@ -136,6 +136,30 @@ void orc_slicer_step(orc_slicer* s, float sym, int rec4[4]);
 void orc_slicer_run(orc_slicer* s, const float* sym, long n, int* rec4, float* thr5);
 void orc_p25_filter_run(float hist[90], const float* in, long n, float* out);
 
+/* ---- fixed-protocol P25p1 C4FM receive loop: symbolizer + sync hunt + warm start + slicer (ddn_oracle_rx.c) -- */
+typedef struct orc_p25rx {
+    int out_rate, sym_rate, lock_symbols, use_filter;
+    /* getSymbol() */
+    int sps_accum, jitter, in_symbol, span, centre, i, count;
+    float sum, lastsample;
+    int filter_on;
+    float fhist[90];
+    /* getFrameSync() */
+    int have_sync, lock_left, lastsync; /* lastsync: 0 none, 1 +P25p1, 2 -P25p1 */
+    int lidx, level_count, hist_count;
+    uint32_t hist_bits;
+    float lbuf[24], lmin, lmax;
+    float shist[24];
+    int shead, scount;
+    orc_slicer sl;
+} orc_p25rx;
+void orc_level_estimate(const float* sorted, int count, float* lo, float* hi);
+int orc_slicer_warm_start(orc_slicer* s, const float* newest_first, int sync_len);
+void orc_p25rx_init(orc_p25rx* r, int out_rate_hz, int sym_rate_hz, int lock_symbols, int use_matched_filter);
+long orc_p25rx_run(orc_p25rx* r, const float* in, long n, float* out_sym, int* rec4, uint8_t* flags, long max_out);
+void orc_p25rx_get_thresholds(const orc_p25rx* r, float out7[7]);
+size_t orc_p25rx_sizeof(void);
+
 /* ---- block codes (oracle/ddn_oracle_block.c) ---------------------------------------------------------- */
 int orc_bch_63_16_decode(const uint8_t in63[63], uint8_t out16[16], int* err_count);
 void orc_p25p1_nid_decode(const uint8_t code[63], const uint8_t* rel63, int observed_nac, int parity, int parity_rel,

@@ -388,3 +388,44 @@ refh_sync_p25p1_neg(void) {
 }
 
 } // extern "C"
+
+// ---- sync-time threshold calibration (src/dsp/sync_calibration.c) and the hunting level window
+// ---- (src/dsp/frame_sync_level.c), driven on the same dsd_state the slicer harness owns -------------------------
+#include <dsd-neo/dsp/sync_calibration.h>
+#include "frame_sync_level.h" /* src/dsp/frame_sync_level.h (private header, on the -I path) */
+
+extern "C" {
+// Push `n` symbols (oldest first) through dsd_symbol_history_push(), then run the reference's
+// dsd_sync_warm_start_thresholds_outer_only(opts, state, sync_len).  out7 = center, umid, lmid, max, min, maxref,
+// minref after the call; returns the reference's result code.
+int
+refh_slicer_warm_start(void* h, const float* symbols_oldest_first, int n, int sync_len, float out7[7]) {
+    RefSlicer* s = static_cast<RefSlicer*>(h);
+    dsd_state* st = s->state;
+    if (st->symbol_history == nullptr) {
+        st->symbol_history_size = 2048;
+        st->symbol_history = static_cast<float*>(calloc((size_t)st->symbol_history_size, sizeof(float)));
+        st->symbol_history_head = 0;
+        st->symbol_history_count = 0;
+    }
+    for (int i = 0; i < n; i++) {
+        dsd_symbol_history_push(st, symbols_oldest_first[i]);
+    }
+    const int rc = (int)dsd_sync_warm_start_thresholds_outer_only(s->opts, st, sync_len);
+    out7[0] = st->center;
+    out7[1] = st->umid;
+    out7[2] = st->lmid;
+    out7[3] = st->max;
+    out7[4] = st->min;
+    out7[5] = st->maxref;
+    out7[6] = st->minref;
+    return rc;
+}
+
+// frame_sync_set_basic_lock()'s max/min averaging is two plain lines in a file that cannot be built here; the level
+// estimate feeding it can:
+void
+refh_level_estimate(const float* sorted, int count, float* lo, float* hi) {
+    dsd_frame_sync_estimate_sorted_window_levels(sorted, count, lo, hi);
+}
+} // extern "C"

@@ -288,3 +288,62 @@ def unpack_records10(rec):
     l1 = rec[..., 4:6].copy().view(np.int16)[..., 0].astype(np.int32)
     sym = rec[..., 6:10].copy().view(np.float32)[..., 0]
     return np.stack([d, rl, l0, l1], axis=-1), sym
+
+
+# ---- fixed-protocol P25p1 receive loop (oracle/ddn_oracle_rx.c) ---------------------------------------------------
+P25_FS_DIBITS = np.array([int(c) for c in "111113113311333313133333"], np.int8)
+_DIBIT_LEVEL = {0: 1.0, 1: 3.0, 2: -1.0, 3: -3.0}
+
+
+def synth_p25_disc(seed, n_ch, n, frame_dibits=864, sps=10, amp=7000.0, noise=400.0, negative=False):
+    """Discriminator-scale C4FM stream [n_ch, n] made of back-to-back frames (24-dibit P25p1 frame sync + random
+    payload), each channel with its own start offset and an idle (noise only) lead-in.  Returns (x float32,
+    dibits int8 [n_ch, n_sym], first_frame_start_sample int [n_ch])."""
+    rng = np.random.default_rng(seed)
+    n_sym = n // sps + 2
+    nfr = n_sym // frame_dibits + 2
+    dib = np.empty((n_ch, nfr * frame_dibits), np.int8)
+    for c in range(n_ch):
+        for f in range(nfr):
+            dib[c, f * frame_dibits:f * frame_dibits + 24] = P25_FS_DIBITS
+            dib[c, f * frame_dibits + 24:(f + 1) * frame_dibits] = rng.integers(0, 4, frame_dibits - 24)
+    lv = np.vectorize(_DIBIT_LEVEL.get)(dib).astype(np.float64) * (-1.0 if negative else 1.0)
+    win = np.hanning(sps + 3)[1:-1]
+    win /= win.sum()
+    x = np.zeros((n_ch, n), np.float64)
+    starts = rng.integers(3 * sps, 40 * sps, n_ch)
+    for c in range(n_ch):
+        nrz = np.repeat(lv[c], sps)
+        shaped = np.convolve(nrz, win, mode="same") * amp
+        m = n - starts[c]
+        x[c, starts[c]:] = shaped[:m]
+    x += rng.normal(0.0, noise, x.shape)
+    return x.astype(np.float32), dib, starts
+
+
+class OracleP25Rx:
+    def __init__(self, out_rate=48000, sym_rate=4800, lock_symbols=840, use_filter=1):
+        o = oracle()
+        o.orc_p25rx_sizeof.restype = C.c_size_t
+        o.orc_p25rx_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        o.orc_p25rx_run.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        o.orc_p25rx_run.restype = C.c_long
+        o.orc_p25rx_get_thresholds.argtypes = [C.c_void_p, C.c_void_p]
+        self.o = o
+        self.st = C.create_string_buffer(o.orc_p25rx_sizeof())
+        o.orc_p25rx_init(self.st, out_rate, sym_rate, lock_symbols, use_filter)
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        cap = x.size // 2 + 8
+        sym = np.zeros(cap, np.float32)
+        rec = np.zeros((cap, 4), np.int32)
+        fl = np.zeros(cap, np.uint8)
+        k = self.o.orc_p25rx_run(self.st, x.ctypes.data, x.size, sym.ctypes.data, rec.ctypes.data, fl.ctypes.data, cap)
+        assert k <= cap
+        return sym[:k].copy(), rec[:k].copy(), fl[:k].copy()
+
+    def thresholds(self):
+        t = np.zeros(7, np.float32)
+        self.o.orc_p25rx_get_thresholds(self.st, t.ctypes.data)
+        return t
