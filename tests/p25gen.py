@@ -1,0 +1,109 @@
+"""Synthetic P25 Phase 1 TSDU (single-block trunking) frames for the end-to-end tests: frame sync + NID
+(BCH(63,16,11) + parity) + one 1/2-rate-trellis coded block + status symbols, FM-modulated to cu8 IQ.
+
+Frame layout (TIA-102.BAAA): 180 dibits = 24 FS + 32 NID + 98 block + 21 nulls + 5 status symbols (one after every
+35 dibits).  The reference reads it as: NID = 33 dibits after the sync with the status symbol at index 11 dropped
+(src/protocol/p25/phase1/dispatch_p25p1.c:123-143); block dibits skip the status positions.
+"""
+import numpy as np
+
+import fecgen
+import orc
+
+FRAME = 180
+DUID_TSBK = 7
+_LEVEL = np.array([1.0, 3.0, -1.0, -3.0])  # dibit 0,1,2,3
+
+
+def status_positions():
+    return [35, 71, 107, 143, 179]
+
+
+def block_positions():
+    """Frame dibit indices of the 98 coded dibits."""
+    pos, i = [], 57
+    while len(pos) < 98:
+        if i not in status_positions():
+            pos.append(i)
+        i += 1
+    return pos
+
+
+def make_frames(rng, n_frames, nac):
+    """-> (dibits int8 [n_frames*180], states [n_frames,49])."""
+    t = fecgen.tables()
+    il = t["il"].astype(np.int64)
+    st = rng.integers(0, 4, (n_frames, 49)).astype(np.int64)
+    prev = np.concatenate([np.zeros((n_frames, 1), np.int64), st[:, :-1]], axis=1)
+    nib = t["half"][(prev << 2) | st].astype(np.int64)
+    dei = np.stack([(nib >> 2) & 3, nib & 3], axis=2).reshape(n_frames, 98)   # deinterleaved dibits
+    tx = dei[:, il]                                                          # transmit order
+    data16 = [(nac >> (11 - k)) & 1 for k in range(12)] + [(DUID_TSBK >> (3 - k)) & 1 for k in range(4)]
+    cw = list(fecgen.bch_63_16_encode(data16)) + [0]                          # parity bit 0 for DUID 7
+    nid = [(cw[2 * k] << 1) | cw[2 * k + 1] for k in range(32)]
+    out = np.zeros((n_frames, FRAME), np.int8)
+    bp = block_positions()
+    for f in range(n_frames):
+        fr = np.zeros(FRAME, np.int8)
+        fr[:24] = orc.P25_FS_DIBITS
+        nid_pos = [p for p in range(24, 57) if p != 35]
+        fr[nid_pos] = nid
+        fr[bp] = tx[f]
+        fr[status_positions()] = 2
+        out[f] = fr
+    return out.reshape(-1), st
+
+
+def modulate_cu8(dibits, n, sps=10, dev=0.06, lead=230, seed=0, noise=0.02):
+    """Dibit stream -> uint8 [n, 2] C4FM (smoothed 4-level FM), `lead` idle samples first."""
+    rng = np.random.default_rng(seed)
+    lv = _LEVEL[dibits]
+    nrz = np.repeat(lv, sps)
+    win = np.hanning(sps + 3)[1:-1]
+    win /= win.sum()
+    shaped = np.convolve(nrz, win, mode="same")
+    f = np.zeros(n)
+    m = min(n - lead, len(shaped))
+    f[lead:lead + m] = shaped[:m]
+    ph = 0.3 + np.cumsum(f * dev)
+    i = 0.8 * np.cos(ph) + rng.normal(0, noise, n)
+    q = 0.8 * np.sin(ph) + rng.normal(0, noise, n)
+    out = np.empty((n, 2), np.uint8)
+    out[:, 0] = np.clip(np.rint(127.5 + 127.5 * i), 0, 255)
+    out[:, 1] = np.clip(np.rint(127.5 + 127.5 * q), 0, 255)
+    return out
+
+
+def extract_frames(rec4, flags, count):
+    """Receive-loop output of one channel -> per accepted sync: (nid bits63, nid rel63, parity, parity_rel, llr196)."""
+    acc = np.flatnonzero(flags[:count] & 2)
+    bp = [p - 24 for p in block_positions()]
+    nid_idx = [k for k in range(33) if k != 11]
+    frames = []
+    for a in acc:
+        if a + 1 + (FRAME - 24) > count:
+            break
+        d = rec4[a + 1:a + 1 + FRAME - 24]
+        nd = d[nid_idx]
+        bits = np.stack([(nd[:, 0] >> 1) & 1, nd[:, 0] & 1], axis=1).reshape(64).astype(np.uint8)
+        rel = np.repeat(nd[:, 1], 2).astype(np.uint8)
+        blk = d[bp]
+        llr = np.stack([blk[:, 2], blk[:, 3]], axis=1).reshape(196).astype(np.int16)
+        frames.append((bits[:63], rel[:63], int(bits[63]), int(rel[63]), llr))
+    return acc, frames
+
+
+def expected_half_rate_output(states):
+    """What the 1/2-rate decoder returns for an error-free block: run the oracle on ideal LLRs of the same states."""
+    t = fecgen.tables()
+    n = states.shape[0]
+    prev = np.concatenate([np.zeros((n, 1), np.int64), states[:, :-1]], axis=1)
+    nib = t["half"][(prev << 2) | states].astype(np.int64)
+    bits = np.stack([(nib >> 3) & 1, (nib >> 2) & 1, (nib >> 1) & 1, nib & 1], axis=2).reshape(n, 196)
+    llr_dei = ((2 * bits - 1) * 200).astype(np.int16)
+    il = t["il"].astype(np.int64)
+    rx = np.zeros((n, 196), np.int16)
+    rx[:, 0::2] = llr_dei[:, 2 * il]
+    rx[:, 1::2] = llr_dei[:, 2 * il + 1]
+    out, _ = fecgen.oracle_p25_half_rate(np.ascontiguousarray(rx))
+    return out
