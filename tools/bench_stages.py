@@ -120,6 +120,33 @@ def main():
     o = orc.OracleTed(sps, 4800)
     report("gardner_ted_sps10", B * nn, ms, 8 + 0.8, cpu(lambda: o.block(iq1[0]), nn), "complex samples")
 
+    # P25p1 slicer + soft decisions (4096 channels x 4800 symbols) and the per-sample P25 matched filter
+    B, ns = 4096, 4800
+    sy1 = np.stack([orc.synth_c4fm_symbols(50 + c, ns) for c in range(8)])
+    d_sy = torch.from_numpy(np.tile(sy1, (B // 8, 1))).cuda()
+    hs = C.c_void_p()
+    assert l.ddn_slicer_batch_create(B, 0, C.byref(hs)) == 0
+    d_rec = torch.zeros((B, ns, 10), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: l.ddn_p25_slicer_run(hs, d_sy.data_ptr(), ns, d_rec.data_ptr(), st))
+    report("p25_slicer_soft", B * ns, ms, 4 + 10, cpu(lambda: orc.oracle_slicer(sy1[:1]), ns), "symbols")
+    nn = 48000
+    x1, _, _ = orc.synth_p25_disc(5, 8, nn, frame_dibits=864)
+    d_x = torch.from_numpy(np.tile(x1, (B // 8, 1))).cuda()
+    d_y = torch.zeros_like(d_x)
+    ms = timeit(lambda: l.ddn_p25_matched_filter_run(hs, d_x.data_ptr(), nn, d_y.data_ptr(), st))
+    report("p25_matched_filter_91tap", B * nn, ms, 8, cpu(lambda: orc.oracle_p25_filter(x1[:1]), nn), "samples")
+
+    # P25p1 receive loop: discriminator samples -> capture records (symbolizer + sync hunt + warm start + slicer)
+    rx = ddn.P25Rx(B, lock_symbols=840, use_matched_filter=1)
+    msym = l.ddn_p25_rx_max_symbols(rx.h, nn)
+    d_rec2 = torch.zeros((B, msym, 10), dtype=torch.uint8, device="cuda")
+    d_fl = torch.zeros((B, msym), dtype=torch.uint8, device="cuda")
+    d_cn = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: l.ddn_p25_rx_run(rx.h, d_x.data_ptr(), nn, d_rec2.data_ptr(), d_fl.data_ptr(), d_cn.data_ptr(),
+                                         msym, st))
+    orx = orc.OracleP25Rx(lock_symbols=840, use_filter=1)
+    report("p25_rx_loop_sps10", B * nn, ms, 4 + 1.1, cpu(lambda: orx.run(x1[0]), nn), "samples")
+
 
 if __name__ == "__main__":
     main()
