@@ -80,6 +80,7 @@ PROTOTYPES = {
     "ddn_slicer_batch_get_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25_matched_filter_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_p25_matched_filter_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_batch_set_decimation": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_p25_rx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ddn_p25_rx_destroy": (None, [C.c_void_p]),
     "ddn_p25_rx_reset": (C.c_int, [C.c_void_p]),
@@ -184,11 +185,15 @@ class Batch:
     def run_device(self, d_iq_ptr, n, d_out_ptr, stream=None):
         _check(lib().ddn_front_end_run(self.h, d_iq_ptr, n, d_out_ptr, stream), "ddn_front_end_run")
 
+    def set_decimation(self, passes):
+        _check(lib().ddn_batch_set_decimation(self.h, passes), "ddn_batch_set_decimation")
+        self.passes = passes
+
     def run_host(self, iq, n):
-        """iq: numpy [B, n, 2] uint8 or float32 (channel-major).  Returns float32 [B, n]."""
+        """iq: numpy [B, n, 2] uint8 or float32 (channel-major).  Returns float32 [B, n >> passes]."""
         import numpy as np
         iq = np.ascontiguousarray(iq)
-        out = np.empty((self.cfg.n_channels, n), np.float32)
+        out = np.empty((self.cfg.n_channels, n >> getattr(self, "passes", 0)), np.float32)
         _check(lib().ddn_front_end_run_host(self.h, iq.ctypes.data, n, out.ctypes.data), "ddn_front_end_run_host")
         return out
 

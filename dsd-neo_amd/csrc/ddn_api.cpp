@@ -64,6 +64,11 @@ struct ddn_batch {
     int timing;
     hipEvent_t ev[3];
     int ev_valid;
+    // half-band decimation cascade in front of the channel LPF (0 = none)
+    int passes;
+    void* d_hbhist[DDN_MAX_HB_PASSES]; // [B][taps_len-1] complex per stage
+    void* d_dec[2];                    // ping-pong decimated streams
+    size_t dec_cap[2];
 };
 
 static int
@@ -159,6 +164,11 @@ ddn_batch_destroy(ddn_batch* b) {
     (void)hipFree(b->d_state);
     (void)hipFree(b->d_in);
     (void)hipFree(b->d_out);
+    (void)hipFree(b->d_dec[0]);
+    (void)hipFree(b->d_dec[1]);
+    for (int i = 0; i < DDN_MAX_HB_PASSES; i++) {
+        (void)hipFree(b->d_hbhist[i]);
+    }
     for (int i = 0; i < 3; i++) {
         if (b->ev[i]) {
             (void)hipEventDestroy(b->ev[i]);
@@ -168,9 +178,35 @@ ddn_batch_destroy(ddn_batch* b) {
 }
 
 extern "C" int
+ddn_batch_set_decimation(ddn_batch* b, int passes) {
+    if (!b || passes < 0 || passes > DDN_MAX_HB_PASSES) {
+        ddn_set_error("ddn_batch_set_decimation: passes must be 0..%d", DDN_MAX_HB_PASSES);
+        return DDN_EINVAL;
+    }
+    if ((b->cfg.block_len & ((1 << passes) - 1)) != 0 || (b->cfg.block_len >> passes) < b->taps_len) {
+        ddn_set_error("ddn_batch_set_decimation: block_len %d must be a multiple of %d and leave >= %d samples",
+                      b->cfg.block_len, 1 << passes, b->taps_len);
+        return DDN_ERANGE;
+    }
+    const size_t B = (size_t)b->cfg.n_channels;
+    for (int i = 0; i < passes; i++) {
+        if (!b->d_hbhist[i] && hipMalloc(&b->d_hbhist[i], sizeof(ddn_f2) * B * 30) != hipSuccess) {
+            ddn_set_error("ddn_batch_set_decimation: hipMalloc failed");
+            return DDN_ENOMEM;
+        }
+    }
+    b->passes = passes;
+    return ddn_batch_reset(b, nullptr);
+}
+
+extern "C" int
 ddn_batch_reset(ddn_batch* b, void* hip_stream) {
     if (!b) {
         return DDN_EINVAL;
+    }
+    for (int i = 0; i < b->passes; i++) {
+        HIP_TRY(hipMemsetAsync(b->d_hbhist[i], 0, sizeof(ddn_f2) * (size_t)b->cfg.n_channels * 30,
+                               (hipStream_t)hip_stream));
     }
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t B = (size_t)b->cfg.n_channels;
@@ -217,7 +253,35 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     }
     hipStream_t st = (hipStream_t)hip_stream;
     const int B = b->cfg.n_channels;
-    const int block_len = b->cfg.block_len;
+    int block_len = b->cfg.block_len;
+    int in_fmt = b->cfg.input_format;
+    if (b->passes > 0) {
+        // half-band cascade: 31-tap first stage, 15-tap afterwards, each stage on the block partition it inherits
+        if ((n & (((size_t)1 << b->passes) - 1)) != 0) {
+            ddn_set_error("ddn_front_end_run: n = %zu must be a multiple of %d with %d decimation passes", n,
+                          1 << b->passes, b->passes);
+            return DDN_ERANGE;
+        }
+        for (int i = 0; i < b->passes; i++) {
+            const size_t n_in = n >> i, n_o = n_in >> 1;
+            const int w = i & 1;
+            const size_t need = sizeof(ddn_f2) * (size_t)B * n_o;
+            if (b->dec_cap[w] < need) {
+                HIP_TRY(hipStreamSynchronize(st));
+                (void)hipFree(b->d_dec[w]);
+                b->d_dec[w] = nullptr;
+                b->dec_cap[w] = 0;
+                HIP_TRY(hipMalloc(&b->d_dec[w], need));
+                b->dec_cap[w] = need;
+            }
+            HIP_TRY(ddn_dev_hb_decim2(d_iq, in_fmt, (long)n_in, n_in, block_len, B, i == 0 ? 31 : 15, b->d_hbhist[i],
+                                      b->d_dec[w], n_o, st));
+            d_iq = b->d_dec[w];
+            in_fmt = DDN_IN_CF32;
+            block_len >>= 1;
+        }
+        n >>= b->passes;
+    }
     const long n_blocks = (long)((n + (size_t)block_len - 1) / (size_t)block_len);
     const int tiles_per_block = (block_len + DDN_TILE - 1) / DDN_TILE;
 
@@ -232,7 +296,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     fa.n = (long)n;
     fa.n_tiles = n_blocks * tiles_per_block;
     fa.n_channels = B;
-    fa.in_fmt = b->cfg.input_format;
+    fa.in_fmt = in_fmt;
     fa.block_len = block_len;
     fa.tiles_per_block = tiles_per_block;
     fa.center = b->center;
@@ -258,7 +322,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[1], st));
     }
-    HIP_TRY(ddn_dev_launch_carry(d_iq, b->cfg.input_format, n, (long)n, b->d_carry, B, st));
+    HIP_TRY(ddn_dev_launch_carry(d_iq, in_fmt, n, (long)n, b->d_carry, B, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
         b->ev_valid = 1;
@@ -286,7 +350,7 @@ ddn_front_end_run_host(ddn_batch* b, const void* h_iq, size_t n, float* h_disc) 
     }
     const size_t B = (size_t)b->cfg.n_channels;
     const size_t in_bytes = B * n * (b->cfg.input_format == DDN_IN_CU8 ? 2 : 8);
-    const size_t out_bytes = B * n * sizeof(float);
+    const size_t out_bytes = B * (n >> b->passes) * sizeof(float);
     int rc = grow(&b->d_in, &b->in_cap, in_bytes);
     if (rc != DDN_OK) {
         return rc;

@@ -90,6 +90,9 @@ hipError_t ddn_dev_p25_slicer(const float* sym, long n, size_t sym_stride, int n
                               size_t rec_stride, hipStream_t st);
 hipError_t ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channels, float* hist, float* out,
                                       hipStream_t st);
+#define DDN_MAX_HB_PASSES 4
+hipError_t ddn_dev_hb_decim2(const void* in, int in_fmt, long n_in, size_t in_stride, int block_in, int n_channels,
+                             int taps_len, void* hist, void* out, size_t out_stride, hipStream_t st);
 hipError_t ddn_dev_p25_matched_filter_only(const float* in, long n, size_t stride, int n_channels, const float* hist,
                                            float* out, hipStream_t st);
 hipError_t ddn_dev_p25_filter_hist_update(const float* in, long n, size_t stride, int n_channels, float* hist,

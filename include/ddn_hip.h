@@ -78,6 +78,13 @@ int ddn_batch_reset(ddn_batch* b, void* hip_stream);
 /* taps actually in use (host-designed, same rule as channel_lpf_ensure_plan); returns taps_len */
 int ddn_batch_get_taps(const ddn_batch* b, float* taps_out, int cap);
 
+/* Half-band decimate-by-2 cascade in front of the channel LPF == demod_state.downsample_passes
+ * (full_demod_apply_halfband_decimation, src/dsp/demod_pipeline.cpp:983-1001: 31-tap first stage, 15-tap afterwards,
+ * src/dsp/halfband.cpp:35-74; each stage is simd_hb_decim2_complex on the block it inherits).  With passes = p the
+ * input runs at sample_rate_hz << p, cfg.block_len (input samples) must be a multiple of 2^p with
+ * block_len >> p >= taps_len, n must be a multiple of 2^p and d_disc holds [B][n >> p].  Resets the batch. */
+int ddn_batch_set_decimation(ddn_batch* b, int passes);
+
 /* One pass of widen -> channel LPF -> (squelch) -> FSK discriminator over n complex samples per channel.
  *   d_iq   : [B][n] interleaved I/Q, u8 pairs (CU8) or float pairs (CF32), channel-major
  *   d_disc : [B][n] float discriminator samples (AGC'd to +-30000, clipped to int16 range)

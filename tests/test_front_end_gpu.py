@@ -214,3 +214,26 @@ def test_full_size_c2_properties(built):
     pick = [0, 1, 255, 256, 1023, 2048, 4095] + list(range(17, 4096, 409))
     want = orc.oracle_batch_cu8(iq[pick].numpy(), blk)
     check(first[pick].cpu().numpy(), want, exact=True)
+
+
+@pytest.mark.parametrize("passes,blk,fmt", [(1, 8192, "cu8"), (2, 8192, "cu8"), (3, 4096, "cu8"), (1, 2048, "cf32"),
+                                            (2, 1200, "cu8")])
+def test_halfband_decimation_cascade(built, passes, blk, fmt):
+    """ddn_batch_set_decimation: 31-tap + 15-tap half-band stages ahead of the LPF, carried across calls, ragged last
+    block, both input formats — bit-exact with the oracle (itself pinned to full_demod with downsample_passes)."""
+    B = 6
+    n1, n2 = 3 * blk, blk + (blk // 2)            # second call ends in a half block
+    iq = orc.synth_c4fm_cu8(40, B, n1 + n2, sps=10 << passes)
+    if fmt == "cf32":
+        x = ((iq.astype(np.float32) - 127.5) * np.float32(1.0 / 127.5)).astype(np.float32)
+        b = ddn.Batch(B, block_len=blk, input_format=ddn.IN_CF32)
+    else:
+        x = iq
+        b = ddn.Batch(B, block_len=blk)
+    b.set_decimation(passes)
+    got = np.concatenate([b.run_host(x[:, :n1], n1), b.run_host(x[:, n1:], n2)], axis=1)
+    for c in range(B):
+        fe = orc.OracleFrontEnd(downsample_passes=passes)
+        want = np.concatenate([fe.run_cu8(iq[c, :n1], blk), fe.run_cu8(iq[c, n1:], blk)])
+        assert got.shape[1] == len(want)
+        assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), c

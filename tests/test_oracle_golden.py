@@ -79,3 +79,15 @@ def test_oracle_matches_reference_on_full_fixture(built):
     want, _, _ = orc.ref_front_end_cu8(iq, 8192)
     got = orc.OracleFrontEnd().run_cu8(iq, 8192)
     assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("passes,block_len", [(1, 8192), (2, 8192), (1, 600), (3, 4096), (2, 1000)])
+def test_halfband_cascade_oracle_matches_reference(built, passes, block_len):
+    """downsample_passes > 0: 31-tap + 15-tap half-band stages in front of the channel LPF (full_demod)."""
+    iq = orc.synth_c4fm_cu8(9, 1, 40000, sps=10 << passes)[0]
+    want, _, _ = orc.ref_front_end_cu8(iq, block_len, passes=passes)
+    fe = orc.OracleFrontEnd(downsample_passes=passes)
+    got = fe.run_cu8(iq, block_len)
+    assert len(want) == 40000 >> passes or block_len % (1 << passes)
+    assert np.array_equal(bits(got[:len(want)]), bits(want))
