@@ -102,6 +102,15 @@ PROTOTYPES = {
     "ddn_p25p1_nid_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_ubyte, C.c_uint8, C.c_int, C.c_void_p]),
     "ddn_fec_hamming_10_6_3_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_hamming_10_6_3_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_fec_golay24_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_golay24_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_rs_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_rs_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "check_and_fix_golay_24_6": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "check_and_fix_golay_24_12": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "check_and_fix_reedsolomon_24_12_13": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "check_and_fix_reedsolomon_24_16_9": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "check_and_fix_redsolomon_36_20_17": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hamming_10_6_3_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "p25_12_soft_llr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmr_r34_viterbi_decode": (C.c_int, [C.c_void_p, C.c_void_p]),

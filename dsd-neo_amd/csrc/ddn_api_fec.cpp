@@ -432,3 +432,133 @@ CNXDNConvolution_chainback(unsigned char* out, unsigned int nBits) {
         }
     }
 }
+
+// ---- P25p1 Golay(24,12,8)/(18,6,8) and Reed-Solomon GF(64) hard-decision decoders ----------------------------------
+static int
+rs_code_params(int code, int* n_par, int* n_data, int* t) {
+    switch (code) {
+        case DDN_RS_24_12_13: *n_par = 12; *n_data = 12; *t = 6; return DDN_OK;
+        case DDN_RS_24_16_9: *n_par = 8; *n_data = 16; *t = 4; return DDN_OK;
+        case DDN_RS_36_20_17: *n_par = 16; *n_data = 20; *t = 8; return DDN_OK;
+        default: ddn_set_error("unknown RS code id %d", code); return DDN_EINVAL;
+    }
+}
+
+extern "C" int
+ddn_fec_golay24_batch(int data_len, uint8_t* d_data_bits, const uint8_t* d_parity12, size_t n, uint8_t* d_status,
+                      int32_t* d_fixed, void* hip_stream) {
+    if ((data_len != 6 && data_len != 12) || !d_data_bits || !d_parity12 || !d_status) {
+        ddn_set_error("ddn_fec_golay24_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_golay24(d_data_bits, d_parity12, data_len, (int)n, d_status, d_fixed, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_golay24_host(int data_len, uint8_t* data_bits, const uint8_t* parity12, size_t n, uint8_t* status,
+                     int32_t* fixed) {
+    if ((data_len != 6 && data_len != 12) || !data_bits || !parity12 || !status) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * (size_t)data_len), p(n * 12), s(n), f(n * 4);
+    if (!a.p || !p.p || !s.p || !f.p || a.up(data_bits) || p.up(parity12)) {
+        return no_dev();
+    }
+    int rc = ddn_fec_golay24_batch(data_len, (uint8_t*)a.p, (const uint8_t*)p.p, n, (uint8_t*)s.p, (int32_t*)f.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (a.down(data_bits) || s.down(status) || (fixed && f.down(fixed))) ? no_dev() : DDN_OK;
+}
+
+extern "C" int
+ddn_fec_p25_rs_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, size_t n, uint8_t* d_status,
+                     void* hip_stream) {
+    int n_par, n_data, t;
+    int rc = rs_code_params(code, &n_par, &n_data, &t);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (!d_data_bits || !d_parity_bits || !d_status) {
+        ddn_set_error("ddn_fec_p25_rs_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_rs63(d_data_bits, d_parity_bits, n_par, n_data, t, (int)n, d_status, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_p25_rs_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, size_t n, uint8_t* status) {
+    int n_par, n_data, t;
+    int rc = rs_code_params(code, &n_par, &n_data, &t);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (!data_bits || !parity_bits || !status) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * (size_t)n_data * 6), p(n * (size_t)n_par * 6), s(n);
+    if (!a.p || !p.p || !s.p || a.up(data_bits) || p.up(parity_bits)) {
+        return no_dev();
+    }
+    rc = ddn_fec_p25_rs_batch(code, (uint8_t*)a.p, (const uint8_t*)p.p, n, (uint8_t*)s.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (a.down(data_bits) || s.down(status)) ? no_dev() : DDN_OK;
+}
+
+// reference names, one codeword per call (include/dsd-neo/protocol/p25/p25p1_check_hdu.h, p25p1_check_ldu.h).
+// Return 1 ("irrecoverable") when the device path is unavailable, like the reference does when its decoder object
+// could not be constructed (src/protocol/p25/phase1/p25p1_check_hdu.cpp:41-44).
+static int
+golay_one(int len, char* word, const char* parity, int* fixed_errors) {
+    if (fixed_errors) {
+        *fixed_errors = 0;
+    }
+    if (!fixed_errors || !word || !parity) {
+        return 1;
+    }
+    uint8_t st = 1;
+    int32_t fx = 0;
+    if (ddn_fec_golay24_host(len, (uint8_t*)word, (const uint8_t*)parity, 1, &st, &fx) != DDN_OK) {
+        return 1;
+    }
+    *fixed_errors = fx;
+    return st;
+}
+
+extern "C" int
+check_and_fix_golay_24_6(char* hex, const char* parity, int* fixed_errors) {
+    return golay_one(6, hex, parity, fixed_errors);
+}
+
+extern "C" int
+check_and_fix_golay_24_12(char* dodeca, const char* parity, int* fixed_errors) {
+    return golay_one(12, dodeca, parity, fixed_errors);
+}
+
+static int
+rs_one(int code, char* data, const char* parity) {
+    uint8_t st = 1;
+    if (!data || !parity || ddn_fec_p25_rs_host(code, (uint8_t*)data, (const uint8_t*)parity, 1, &st) != DDN_OK) {
+        return 1;
+    }
+    return st;
+}
+
+extern "C" int
+check_and_fix_reedsolomon_24_12_13(char* data, const char* parity) {
+    return rs_one(DDN_RS_24_12_13, data, parity);
+}
+
+extern "C" int
+check_and_fix_reedsolomon_24_16_9(char* data, const char* parity) {
+    return rs_one(DDN_RS_24_16_9, data, parity);
+}
+
+extern "C" int
+check_and_fix_redsolomon_36_20_17(char* data, const char* parity) {
+    return rs_one(DDN_RS_36_20_17, data, parity);
+}

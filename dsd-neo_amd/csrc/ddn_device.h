@@ -103,6 +103,10 @@ hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev
                           uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave, hipStream_t st);
 hipError_t ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
                               const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st);
+hipError_t ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* status, int32_t* fixed,
+                           hipStream_t st);
+hipError_t ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, int n, uint8_t* status,
+                        hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);
 hipError_t ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st);
 hipError_t ddn_dev_r34(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* out, hipStream_t st);

@@ -1,0 +1,331 @@
+// ddn_rs.hip — batched P25 Phase 1 Golay(24,12,8)/(18,6,8) and Reed-Solomon GF(64) hard-decision decoders.
+//
+//   k_golay24   == check_and_fix_golay_24_6 / check_and_fix_golay_24_12
+//                  (src/protocol/p25/phase1/p25p1_check_hdu.cpp:28-37; include/dsd-neo/fec/Golay24.hpp:19-197,262-389)
+//   k_rs63      == check_and_fix_reedsolomon_24_12_13 / _24_16_9 / check_and_fix_redsolomon_36_20_17
+//                  (p25p1_check_ldu.cpp, p25p1_check_hdu.cpp:39-46; include/dsd-neo/fec/ReedSolomon.hpp:334-582,738-772,
+//                  adapters :836-866,933-963,1028-1058)
+//
+// One codeword per lane.  Golay: the [23,12,7] code is perfect, so the reference's systematic search always lands on the
+// unique codeword within distance 3; here that is one lookup in a 2048-entry syndrome -> error-pattern table (LDS), and
+// the reference's reported correction count is the pattern weight when the errors fit one cyclic window of 11 positions
+// (its first pass) and one less otherwise (it had to flip a trial bit first).  RS: syndromes r(alpha^i), i = 1..2t, of
+// the zero-padded length-63 word, Massey's iteration, Chien search over all 63 positions (a "correction" that lands in
+// the zero padding is accepted exactly like the reference does), Forney error values.  The decoders are
+// bounded-distance, so any correct formulation returns the reference's symbols; on failure the data is left untouched.
+// All per-lane polynomial arrays live in LDS as [index][lane] (dynamic indexing of a private array would go to scratch).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+
+namespace {
+__device__ __forceinline__ uint32_t
+golay_syndrome11(uint32_t cw) {
+    cw &= 0x7fffffu;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        cw = (cw & 1u) ? ((cw ^ 0xAE3u) >> 1) : (cw >> 1);
+    }
+    return cw;
+}
+} // namespace
+
+// builds the syndrome -> error pattern table (every pattern of weight <= 3 over 23 bits: 1+23+253+1771 = 2048)
+__global__ void
+k_golay_table(uint32_t* __restrict__ tab) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x; // 0 .. 23*23*23-1, decoded as (a, b, c) with a <= b <= c
+    if (idx == 0) {
+        tab[0] = 0;
+    }
+    const int a = idx / 529, b = (idx / 23) % 23, c = idx % 23;
+    if (a >= 23 || a > b || b > c) {
+        return;
+    }
+    const uint32_t e = (1u << a) | (1u << b) | (1u << c); // equal indices collapse to lower weights
+    tab[golay_syndrome11(e)] = e;
+}
+
+__global__ __launch_bounds__(256) void
+k_golay24(uint8_t* __restrict__ data, const uint8_t* __restrict__ parity, int len, int n,
+          const uint32_t* __restrict__ tab_g, uint8_t* __restrict__ status, int32_t* __restrict__ fixed) {
+    __shared__ uint32_t tab[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+        tab[i] = tab_g[i];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    uint8_t* d = data + (size_t)i * len;
+    const uint8_t* p = parity + (size_t)i * 12;
+    uint32_t cw = 0;
+    bool valid = true;
+    for (int k = 0; k < 12; k++) {
+        const uint32_t v = p[k];
+        valid &= v <= 1;
+        cw |= (v & 1u) << (12 + k);
+    }
+    for (int k = 0; k < len; k++) {
+        const uint32_t v = d[k];
+        valid &= v <= 1;
+        cw |= (v & 1u) << (12 - len + k);
+    }
+    int fx = 0, rc = 1;
+    if (valid) {
+        const uint32_t pbit = cw & 0x800000u;
+        uint32_t w23 = cw & 0x7fffffu;
+        const uint32_t e = tab[golay_syndrome11(w23)];
+        if (e) {
+            const int wt = __popc(e);
+            bool fits = false;
+            uint32_t r = e;
+#pragma unroll
+            for (int k = 0; k < 23; k++) {
+                fits |= (r & 0xFFFu) == 0;
+                r = ((r << 1) | (r >> 22)) & 0x7fffffu;
+            }
+            fx = fits ? wt : wt - 1;
+            w23 ^= e;
+        }
+        cw = w23 | pbit;
+        const bool odd = (__popc(cw) & 1) != 0;
+        if (!(odd && (cw & 0x3fu) != 0)) {
+            rc = 0;
+            for (int k = 0; k < len; k++) {
+                d[k] = (uint8_t)((cw >> (12 - len + k)) & 1u);
+            }
+        }
+    }
+    status[i] = (uint8_t)rc;
+    if (fixed) {
+        fixed[i] = fx;
+    }
+}
+
+__global__ __launch_bounds__(64) void
+k_rs63(uint8_t* __restrict__ data6, const uint8_t* __restrict__ parity6, int n_par, int n_data, int t, int n,
+       uint8_t* __restrict__ status) {
+    __shared__ uint8_t ex[128], lg[64];
+    __shared__ uint8_t W[36][64];                   // received symbols
+    __shared__ uint8_t S[17][64], Cc[18][64], Bb[18][64], Tt[18][64], Om[16][64], Pos[8][64];
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        int x = 1;
+        for (int i = 0; i < 63; i++) {
+            ex[i] = (uint8_t)x;
+            ex[i + 63] = (uint8_t)x;
+            lg[x] = (uint8_t)i;
+            x <<= 1;
+            if (x & 0x40) {
+                x ^= 0x43;
+            }
+        }
+        ex[126] = ex[0];
+        ex[127] = ex[1];
+        lg[0] = 0;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 64 + lane;
+    if (i >= n) {
+        return;
+    }
+    auto gmul = [&](int a, int b) -> int { return (a && b) ? ex[lg[a] + lg[b]] : 0; };
+    auto gdiv = [&](int a, int b) -> int { return a ? ex[lg[a] + 63 - lg[b]] : 0; };
+    auto gpow = [&](int a, int e) -> int { return a ? ex[(lg[a] + e) % 63] : 0; }; // a * alpha^e, e >= 0
+    const int nsym = n_par + n_data, n2 = 2 * t;
+    uint8_t* dp = data6 + (size_t)i * n_data * 6;
+    const uint8_t* pp = parity6 + (size_t)i * n_par * 6;
+    for (int k = 0; k < nsym; k++) {
+        const uint8_t* q = (k < n_par) ? (pp + 6 * k) : (dp + 6 * (k - n_par));
+        int v = 0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            v = (v << 1) | (q[b] != 0);
+        }
+        W[k][lane] = (uint8_t)v;
+    }
+    // syndromes S_i = r(alpha^i), i = 1..2t
+    int any = 0;
+    for (int s = 1; s <= n2; s++) {
+        int acc = 0;
+        for (int j = 0; j < nsym; j++) {
+            acc ^= gpow(W[j][lane], (s * j) % 63);
+        }
+        S[s][lane] = (uint8_t)acc;
+        any |= acc;
+    }
+    int rc = 0;
+    if (any) {
+        // Massey
+        for (int k = 0; k < 18; k++) {
+            Cc[k][lane] = (k == 0);
+            Bb[k][lane] = (k == 0);
+        }
+        int L = 0, m = 1, b = 1;
+        for (int it = 0; it < n2; it++) {
+            int d = S[it + 1][lane];
+            for (int k = 1; k <= L; k++) {
+                d ^= gmul(Cc[k][lane], S[it + 1 - k][lane]);
+            }
+            if (d == 0) {
+                m++;
+            } else {
+                const int f = gdiv(d, b);
+                const bool grow = 2 * L <= it;
+                for (int k = 0; k < 18; k++) {
+                    Tt[k][lane] = Cc[k][lane];
+                }
+                for (int k = 0; k + m < 18; k++) {
+                    Cc[k + m][lane] ^= (uint8_t)gmul(f, Bb[k][lane]);
+                }
+                if (grow) {
+                    L = it + 1 - L;
+                    for (int k = 0; k < 18; k++) {
+                        Bb[k][lane] = Tt[k][lane];
+                    }
+                    b = d;
+                    m = 1;
+                } else {
+                    m++;
+                }
+            }
+        }
+        int deg = 0;
+        for (int k = 17; k >= 0; k--) {
+            if (Cc[k][lane]) {
+                deg = k;
+                break;
+            }
+        }
+        if (L > t || deg != L) {
+            rc = 1;
+        } else {
+            // Chien over the whole length-63 word: error at position p <-> C(alpha^-p) = 0
+            int np = 0;
+            for (int p = 0; p < 63; p++) {
+                const int xi = (63 - p) % 63;
+                int v = 0;
+                for (int k = 0; k <= L; k++) {
+                    v ^= gpow(Cc[k][lane], (k * xi) % 63);
+                }
+                if (v == 0) {
+                    if (np < 8) {
+                        Pos[np][lane] = (uint8_t)p;
+                    }
+                    np++;
+                }
+            }
+            if (np != L) {
+                rc = 1;
+            } else {
+                for (int k = 0; k < n2; k++) {
+                    int v = 0;
+                    for (int j = 0; j <= k && j <= L; j++) {
+                        v ^= gmul(Cc[j][lane], S[k - j + 1][lane]);
+                    }
+                    Om[k][lane] = (uint8_t)v;
+                }
+                // all error values first (a zero derivative aborts with the word untouched), then apply
+                int ev[8];
+                for (int k = 0; k < 8; k++) {
+                    ev[k] = 0;
+                }
+                for (int e = 0; e < L && rc == 0; e++) {
+                    const int p = Pos[e][lane];
+                    const int xi = (63 - p) % 63;
+                    int num = 0, den = 0;
+                    for (int k = 0; k < n2; k++) {
+                        num ^= gpow(Om[k][lane], (k * xi) % 63);
+                    }
+                    for (int k = 1; k <= L; k += 2) {
+                        den ^= gpow(Cc[k][lane], ((k - 1) * xi) % 63);
+                    }
+                    if (den == 0) {
+                        rc = 1;
+                    } else {
+                        const int val = gdiv(num, den);
+                        // static unrolled select keeps ev[] in registers
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            ev[k] = (k == e) ? val : ev[k];
+                        }
+                    }
+                }
+                if (rc == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        if (e < L) {
+                            const int p = Pos[e][lane];
+                            if (p < nsym) {
+                                W[p][lane] ^= (uint8_t)ev[e];
+                            }
+                        }
+                    }
+                    for (int k = 0; k < n_data; k++) {
+                        const int v = W[n_par + k][lane];
+#pragma unroll
+                        for (int b = 0; b < 6; b++) {
+                            dp[6 * k + b] = (uint8_t)((v >> (5 - b)) & 1);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        // clean word: the reference still rewrites the data bits from the symbols (normalises non-0/1 bytes)
+        for (int k = 0; k < n_data; k++) {
+            const int v = W[n_par + k][lane];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                dp[6 * k + b] = (uint8_t)((v >> (5 - b)) & 1);
+            }
+        }
+    }
+    if (rc != 0) {
+        for (int k = 0; k < n_data; k++) {
+            const int v = W[n_par + k][lane];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                dp[6 * k + b] = (uint8_t)((v >> (5 - b)) & 1);
+            }
+        }
+    }
+    status[i] = (uint8_t)rc;
+}
+
+extern "C" hipError_t
+ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* status, int32_t* fixed, hipStream_t st) {
+    static uint32_t* tab = nullptr;
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    if (!tab) {
+        hipError_t e = hipMalloc(&tab, 2048 * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            tab = nullptr;
+            return e;
+        }
+        hipLaunchKernelGGL(k_golay_table, dim3((23 * 23 * 23 + 255) / 256), dim3(256), 0, st, tab);
+        e = hipGetLastError();
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    hipLaunchKernelGGL(k_golay24, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, parity, len, n,
+                       (const uint32_t*)tab, status, fixed);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, int n, uint8_t* status,
+             hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_rs63, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, data6, parity6, n_par, n_data, t, n,
+                       status);
+    return hipGetLastError();
+}

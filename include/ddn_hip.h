@@ -210,7 +210,25 @@ int ddn_fec_viterbi_k5_host(const uint16_t* soft, size_t n, int in_len, const ui
  *                            status 0 fail / 1 ok / 2 parity override.  erasure_threshold: the reference default is 64
  *                            == p25p1_nid_decode (include/dsd-neo/protocol/p25/p25p1_check_nid.h:38-39)
  *   ddn_fec_hamming_10_6_3_* Hamming(10,6,3): bits10 [n][10] (6 data + 4 parity, bit per byte), data corrected in
- *                            place on single errors, errs [n] = 0/1/2 == hamming_10_6_3_decode */
+ *                            place on single errors, errs [n] = 0/1/2 == hamming_10_6_3_decode
+ *   ddn_fec_golay24_*        Golay(24,12,8) (data_len 12) and the P25 shortened (18,6,8) (data_len 6): data bits
+ *                            [n][data_len] (char-array order of the reference, one bit per byte) corrected in place,
+ *                            parity [n][12] (11 check bits + overall parity), status [n] 0 ok / 1 irrecoverable,
+ *                            fixed [n] (optional) the reference's *fixed_errors
+ *                            == check_and_fix_golay_24_6 / _24_12 (include/dsd-neo/protocol/p25/p25p1_check_hdu.h)
+ *   ddn_fec_p25_rs_*         RS over GF(64): data bits [n][n_data][6] MSB first, corrected in place, parity bits
+ *                            [n][n_par][6], status [n] 0 ok / 1 irrecoverable (data then unchanged)
+ *                            == check_and_fix_reedsolomon_24_12_13 / _24_16_9 (p25p1_check_ldu.h),
+ *                               check_and_fix_redsolomon_36_20_17 (p25p1_check_hdu.h)   (hard decision; the erasure
+ *                               variants *_soft are not built yet) */
+enum { DDN_RS_24_12_13 = 0, DDN_RS_24_16_9 = 1, DDN_RS_36_20_17 = 2 };
+int ddn_fec_golay24_batch(int data_len, uint8_t* d_data_bits, const uint8_t* d_parity12, size_t n, uint8_t* d_status,
+                          int32_t* d_fixed, void* hip_stream);
+int ddn_fec_golay24_host(int data_len, uint8_t* data_bits, const uint8_t* parity12, size_t n, uint8_t* status,
+                         int32_t* fixed);
+int ddn_fec_p25_rs_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, size_t n, uint8_t* d_status,
+                         void* hip_stream);
+int ddn_fec_p25_rs_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, size_t n, uint8_t* status);
 int ddn_p25p1_nid_decode_batch(const uint8_t* d_bits63, const uint8_t* d_rel63, const int32_t* d_observed_nac,
                                const uint8_t* d_parity, const uint8_t* d_parity_rel, int erasure_threshold, size_t n,
                                int32_t* d_out4, void* hip_stream);
@@ -222,6 +240,12 @@ int ddn_p25p1_nid_decode(const char bch_code[63], const uint8_t* reliab63, int o
 int ddn_fec_hamming_10_6_3_batch(uint8_t* d_bits10, size_t n, uint8_t* d_errs, void* hip_stream);
 int ddn_fec_hamming_10_6_3_host(uint8_t* bits10, size_t n, uint8_t* errs);
 int hamming_10_6_3_decode(char* data, const char* parity);
+/* include/dsd-neo/protocol/p25/p25p1_check_hdu.h, p25p1_check_ldu.h (one codeword per call, reference signatures) */
+int check_and_fix_golay_24_6(char* hex, const char* parity, int* fixed_errors);
+int check_and_fix_golay_24_12(char* dodeca, const char* parity, int* fixed_errors);
+int check_and_fix_reedsolomon_24_12_13(char* data, const char* parity);
+int check_and_fix_reedsolomon_24_16_9(char* data, const char* parity);
+int check_and_fix_redsolomon_36_20_17(char* data, const char* parity);
 
 /* single-codeword drop-ins with the reference's names */
 int p25_12_soft_llr(const uint8_t* input, const int16_t* bit_llr196, uint8_t treturn[12]);

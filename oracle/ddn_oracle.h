@@ -160,6 +160,11 @@ long orc_p25rx_run(orc_p25rx* r, const float* in, long n, float* out_sym, int* r
 void orc_p25rx_get_thresholds(const orc_p25rx* r, float out7[7]);
 size_t orc_p25rx_sizeof(void);
 
+/* ---- P25p1 Golay(24,12,8) + RS GF(64) hard-decision decoders (oracle/ddn_oracle_rs.c) ---------------------- */
+int orc_golay_24_decode(uint8_t* data, int len, const uint8_t* parity, int* fixed);
+int orc_rs63_decode(int* word, int t);
+int orc_p25_rs_decode(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t);
+
 /* ---- block codes (oracle/ddn_oracle_block.c) ---------------------------------------------------------- */
 int orc_bch_63_16_decode(const uint8_t in63[63], uint8_t out16[16], int* err_count);
 void orc_p25p1_nid_decode(const uint8_t code[63], const uint8_t* rel63, int observed_nac, int parity, int parity_rel,

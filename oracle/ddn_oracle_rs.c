@@ -1,0 +1,295 @@
+/*
+ * oracle/ddn_oracle_rs.c — CPU restatement of the P25 Phase 1 Golay(24,12,8) and Reed-Solomon GF(64) hard-decision
+ * decoders (TEST INFRASTRUCTURE ONLY).
+ *
+ *   Golay: include/dsd-neo/fec/Golay24.hpp:19-197 (generator 0xAE3, [23,12] word = data bits 0..11 + 11 check bits
+ *          12..22, overall parity in bit 23; systematic-search corrector), DSD adapters :262-389
+ *          (check_and_fix_golay_24_6 / _24_12, src/protocol/p25/phase1/p25p1_check_hdu.cpp:28-37)
+ *   RS:    include/dsd-neo/fec/ReedSolomon.hpp:61-105,334-582,685-772 (GF(64) from x^6+x+1, syndromes r(alpha^i)
+ *          i = 1..2t, Berlekamp iteration, Chien search, error values), DSD adapters :836-866,933-963,1028-1058
+ *          (parity symbols first, then data, zero padding up to 63; only the data symbols are written back)
+ *
+ * The restatement decodes the same codes by the textbook route instead of transliterating the search loops:
+ *   - the [23,12,7] Golay code is perfect, so "the codeword the reference's search converges to" is the unique
+ *     codeword within distance 3, found here from a 2048-entry syndrome -> error-pattern table.  The reference's
+ *     *errs is the weight of the syndrome at the shift where its search stops: the full error weight when the errors
+ *     fit inside one cyclic window of 11 consecutive positions (first pass), one less when a trial bit had to be
+ *     flipped first (Golay24.hpp:128-161); with <= 3 errors those are the only two outcomes.
+ *   - the RS decoders succeed exactly when a codeword of the length-63 mother code lies within t symbols of the
+ *     zero-padded received word (locator degree <= t and as many roots as its degree); that codeword is unique, so
+ *     Massey's form of the iteration + Chien + Forney returns the same symbols; on failure the data is untouched.
+ * Both claims are what tests/test_oracle_rs.py pins bit for bit against the compiled reference (random codewords
+ * with 0..t+3 symbol errors incl. errors that land in the zero padding, all 2^24 Golay syndromes/parities sampled).
+ */
+#include "ddn_oracle.h"
+
+#include <string.h>
+
+/* ---- Golay ------------------------------------------------------------------------------------------------ */
+static uint32_t g_gol_tab[2048];
+static int g_gol_ready;
+
+static uint32_t
+golay_syndrome11(uint32_t cw) {
+    cw &= 0x7fffffu;
+    for (int i = 0; i < 12; i++) {
+        if (cw & 1u) {
+            cw ^= 0xAE3u;
+        }
+        cw >>= 1;
+    }
+    return cw; /* 11 bits */
+}
+
+static void
+golay_init(void) {
+    if (g_gol_ready) {
+        return;
+    }
+    g_gol_tab[0] = 0;
+    for (int a = 0; a < 23; a++) {
+        const uint32_t ea = 1u << a;
+        g_gol_tab[golay_syndrome11(ea)] = ea;
+        for (int b = a + 1; b < 23; b++) {
+            const uint32_t eb = ea | (1u << b);
+            g_gol_tab[golay_syndrome11(eb)] = eb;
+            for (int c = b + 1; c < 23; c++) {
+                const uint32_t ec = eb | (1u << c);
+                g_gol_tab[golay_syndrome11(ec)] = ec;
+            }
+        }
+    }
+    g_gol_ready = 1;
+}
+
+static int
+popc(uint32_t v) {
+    int n = 0;
+    while (v) {
+        n += (int)(v & 1u);
+        v >>= 1;
+    }
+    return n;
+}
+
+static int
+fits_check_window(uint32_t e) {
+    /* some left-rotation of the 23-bit pattern has every set bit in positions 12..22 */
+    for (int i = 0; i < 23; i++) {
+        if ((e & 0xFFFu) == 0) {
+            return 1;
+        }
+        e = ((e << 1) | (e >> 22)) & 0x7fffffu;
+    }
+    return 0;
+}
+
+/* check_and_fix_golay_24_6 (len 6) / _24_12 (len 12): data bits corrected in place, returns 0/1, *fixed as the ref. */
+int
+orc_golay_24_decode(uint8_t* data, int len, const uint8_t* parity, int* fixed) {
+    golay_init();
+    *fixed = 0;
+    for (int i = 0; i < len; i++) {
+        if (data[i] > 1) {
+            return 1;
+        }
+    }
+    for (int i = 0; i < 12; i++) {
+        if (parity[i] > 1) {
+            return 1;
+        }
+    }
+    uint32_t cw = 0;
+    for (int k = 0; k < 12; k++) {
+        cw |= (uint32_t)parity[k] << (12 + k);
+    }
+    for (int k = 0; k < len; k++) {
+        cw |= (uint32_t)data[k] << (12 - len + k);
+    }
+    const uint32_t pbit = cw & 0x800000u;
+    uint32_t w23 = cw & 0x7fffffu;
+    const uint32_t e = g_gol_tab[golay_syndrome11(w23)];
+    if (e) {
+        const int wt = popc(e);
+        *fixed = fits_check_window(e) ? wt : wt - 1;
+        w23 ^= e;
+    }
+    cw = w23 | pbit;
+    const int odd = popc(cw) & 1;
+    if (odd && (cw & 0x3fu) != 0) {
+        return 1;
+    }
+    for (int i = 0; i < len; i++) {
+        data[i] = (uint8_t)((cw >> (12 - len + i)) & 1u);
+    }
+    return 0;
+}
+
+/* ---- Reed-Solomon over GF(64) ---------------------------------------------------------------------------- */
+static uint8_t g_ex[128], g_lg[64];
+static int g_gf_ready;
+
+static void
+gf_init(void) {
+    if (g_gf_ready) {
+        return;
+    }
+    int x = 1;
+    for (int i = 0; i < 63; i++) {
+        g_ex[i] = (uint8_t)x;
+        g_ex[i + 63] = (uint8_t)x;
+        g_lg[x] = (uint8_t)i;
+        x <<= 1;
+        if (x & 0x40) {
+            x ^= 0x43;
+        }
+    }
+    g_gf_ready = 1;
+}
+
+static int
+gmul(int a, int b) {
+    return (a && b) ? g_ex[g_lg[a] + g_lg[b]] : 0;
+}
+static int
+gdiv(int a, int b) {
+    return a ? g_ex[g_lg[a] + 63 - g_lg[b]] : 0;
+}
+
+/* word[63] symbols (coefficient of x^j at j); t <= 8.  Returns 0 and corrects in place, or 1 and leaves it alone. */
+int
+orc_rs63_decode(int* word, int t) {
+    gf_init();
+    const int n2 = 2 * t;
+    int S[17] = {0};
+    int any = 0;
+    for (int i = 1; i <= n2; i++) {
+        int s = 0;
+        for (int j = 0; j < 63; j++) {
+            if (word[j]) {
+                s ^= g_ex[(g_lg[word[j]] + i * j) % 63];
+            }
+        }
+        S[i] = s;
+        any |= s;
+    }
+    if (!any) {
+        return 0;
+    }
+    /* Massey: C(x) connection polynomial, L its LFSR length */
+    int C[18] = {1}, Bp[18] = {1}, T[18];
+    int L = 0, m = 1, b = 1;
+    for (int n = 0; n < n2; n++) {
+        int d = S[n + 1];
+        for (int i = 1; i <= L; i++) {
+            d ^= gmul(C[i], S[n + 1 - i]);
+        }
+        if (d == 0) {
+            m++;
+        } else {
+            const int f = gdiv(d, b);
+            memcpy(T, C, sizeof(T));
+            for (int i = 0; i + m < 18; i++) {
+                C[i + m] ^= gmul(f, Bp[i]);
+            }
+            if (2 * L <= n) {
+                L = n + 1 - L;
+                memcpy(Bp, T, sizeof(T));
+                b = d;
+                m = 1;
+            } else {
+                m++;
+            }
+        }
+    }
+    if (L > t) {
+        return 1;
+    }
+    int deg = 0;
+    for (int i = 17; i >= 0; i--) {
+        if (C[i]) {
+            deg = i;
+            break;
+        }
+    }
+    if (deg != L) {
+        return 1;
+    }
+    /* Chien: error at position p <-> root alpha^(-p) */
+    int pos[8], np = 0;
+    for (int p = 0; p < 63; p++) {
+        int v = 0;
+        for (int i = 0; i <= L; i++) {
+            if (C[i]) {
+                v ^= g_ex[(g_lg[C[i]] + i * (63 - p)) % 63];
+            }
+        }
+        if (v == 0) {
+            if (np < 8) {
+                pos[np] = p;
+            }
+            np++;
+        }
+    }
+    if (np != L) {
+        return 1;
+    }
+    /* Forney with roots alpha^1..: Omega(x) = S(x) C(x) mod x^2t, S(x) = sum S_{i+1} x^i;
+     * e_p = X^0 * Omega(X^-1) / C'(X^-1), X = alpha^p (first consecutive root exponent is 1) */
+    int Om[17] = {0};
+    for (int i = 0; i < n2; i++) {
+        int v = 0;
+        for (int j = 0; j <= i && j <= L; j++) {
+            v ^= gmul(C[j], S[i - j + 1]);
+        }
+        Om[i] = v;
+    }
+    for (int k = 0; k < L; k++) {
+        const int p = pos[k];
+        const int xi = (63 - p) % 63; /* exponent of X^-1 */
+        int num = 0, den = 0;
+        for (int i = 0; i < n2; i++) {
+            if (Om[i]) {
+                num ^= g_ex[(g_lg[Om[i]] + i * xi) % 63];
+            }
+        }
+        for (int i = 1; i <= L; i += 2) {
+            if (C[i]) {
+                den ^= g_ex[(g_lg[C[i]] + (i - 1) * xi) % 63];
+            }
+        }
+        if (den == 0) {
+            return 1;
+        }
+        word[p] ^= gdiv(num, den);
+    }
+    return 0;
+}
+
+/* check_and_fix_reedsolomon_24_12_13 (n_par 12, n_data 12, t 6), _24_16_9 (8, 16, 4), redsolomon_36_20_17 (16, 20, 8):
+ * data6 = n_data six-bit words, one bit per byte MSB first, corrected in place; parity6 likewise. */
+int
+orc_p25_rs_decode(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t) {
+    int w[63] = {0};
+    for (int i = 0; i < n_par; i++) {
+        int v = 0;
+        for (int b = 0; b < 6; b++) {
+            v = (v << 1) | (parity6[6 * i + b] != 0);
+        }
+        w[i] = v;
+    }
+    for (int i = 0; i < n_data; i++) {
+        int v = 0;
+        for (int b = 0; b < 6; b++) {
+            v = (v << 1) | (data6[6 * i + b] != 0);
+        }
+        w[n_par + i] = v;
+    }
+    const int rc = orc_rs63_decode(w, t);
+    for (int i = 0; i < n_data; i++) {
+        for (int b = 0; b < 6; b++) {
+            data6[6 * i + b] = (uint8_t)((w[n_par + i] >> (5 - b)) & 1);
+        }
+    }
+    return rc;
+}

@@ -254,3 +254,94 @@ def gen_nid(rng, n, max_err=14, invalid_duids=True):
         par[i] = (1 if duid in (5, 10) else 0) ^ (1 if i % 7 == 0 else 0)
         obs[i] = nac if i % 3 == 0 else (0 if i % 3 == 1 else int(rng.integers(0, 0x1000)))
     return bits, rel, obs, par, prel
+
+
+# ---- P25p1 Golay(24,12,8) / RS GF(64) generators for the block-code tests ----------------------------------------
+def golay24_encode(data_bits):
+    """data_bits: 12 bits, data_bits[k] = bit k of the 12-bit data word (as the reference's char array) ->
+    parity[12] in the reference's char-array order (11 check bits then the overall parity bit)."""
+    d = 0
+    for k, b in enumerate(data_bits):
+        d |= int(b) << k
+    cw = d
+    for _ in range(12):
+        if cw & 1:
+            cw ^= 0xAE3
+        cw >>= 1
+    word = (cw << 12) | d
+    if bin(word).count("1") & 1:
+        word ^= 0x800000
+    return np.array([(word >> (12 + k)) & 1 for k in range(12)], np.uint8)
+
+
+_RS_GEN = {}
+
+
+def rs63_generator(t):
+    if t not in _RS_GEN:
+        ex, lg = _gf64()
+        g = [1]
+        for i in range(1, 2 * t + 1):
+            r = int(ex[i])
+            ng = [0] * (len(g) + 1)
+            for k, c in enumerate(g):          # multiply by (x + alpha^i)
+                ng[k + 1] ^= c
+                ng[k] ^= int(ex[(lg[c] + lg[r]) % 63]) if c else 0
+            g = ng
+        _RS_GEN[t] = g
+    return _RS_GEN[t]
+
+
+def rs63_encode(data_syms, t):
+    """data_syms: k' <= 63-2t symbols (placed at x^(2t)...), returns parity[2t] (coefficients of x^0..x^(2t-1))."""
+    ex, lg = _gf64()
+    g = rs63_generator(t)
+    n2 = 2 * t
+    rem = [0] * n2
+    for s in reversed([int(v) for v in data_syms]):
+        fb = s ^ rem[n2 - 1]
+        for k in range(n2 - 1, 0, -1):
+            rem[k] = rem[k - 1] ^ (int(ex[(lg[fb] + lg[g[k]]) % 63]) if fb and g[k] else 0)
+        rem[0] = int(ex[(lg[fb] + lg[g[0]]) % 63]) if fb and g[0] else 0
+    return rem
+
+
+def syms_to_bits6(syms):
+    s = np.asarray(syms, np.int64)
+    return ((s[:, None] >> np.arange(5, -1, -1)[None, :]) & 1).astype(np.uint8)
+
+
+P25_RS_CODES = {"24_12_13": (12, 12, 6), "24_16_9": (8, 16, 4), "36_20_17": (16, 20, 8)}   # n_par, n_data, t
+
+
+def gen_p25_rs(rng, code, n, max_extra=3):
+    """-> data bits [n, n_data, 6], parity bits [n, n_par, 6] of codewords with 0..t+max_extra symbol errors."""
+    n_par, n_data, t = P25_RS_CODES[code]
+    data = np.zeros((n, n_data, 6), np.uint8)
+    par = np.zeros((n, n_par, 6), np.uint8)
+    for i in range(n):
+        d = rng.integers(0, 64, n_data)
+        p = rs63_encode(d, t)
+        w = np.array(list(p) + list(d))
+        ne = int(rng.integers(0, t + max_extra + 1))
+        pos = rng.choice(n_par + n_data, ne, replace=False)
+        w[pos] ^= rng.integers(1, 64, ne)
+        par[i] = syms_to_bits6(w[:n_par])
+        data[i] = syms_to_bits6(w[n_par:])
+    return data, par
+
+
+def gen_golay24(rng, n, length):
+    """-> data bits [n, length], parity [n, 12] with 0..5 bit errors (length 6 or 12: P25 (18,6,8) / (24,12,8))."""
+    data = np.zeros((n, length), np.uint8)
+    par = np.zeros((n, 12), np.uint8)
+    for i in range(n):
+        d12 = np.zeros(12, np.uint8)
+        d12[12 - length:] = rng.integers(0, 2, length)
+        p = golay24_encode(d12)
+        w = np.concatenate([d12[12 - length:], p])
+        ne = int(rng.integers(0, 6))
+        w[rng.choice(length + 12, ne, replace=False)] ^= 1
+        data[i] = w[:length]
+        par[i] = w[length:]
+    return data, par

@@ -48,10 +48,12 @@ def test_nid_golden(built):
     assert np.array_equal(oracle_nid(g["bits"], None, g["obs"], g["parity"], g["parity_rel"], thr), g["out_hard"])
     o = orc.oracle()
     o.orc_bch_63_16_decode.argtypes = [VP, VP, VP]
-    for i in range(g["bits"].shape[0]):
+    bits = np.ascontiguousarray(g["bits"])      # keep alive: g[...] materialises a fresh array on every access
+    for i in range(bits.shape[0]):
         d = np.zeros(16, np.uint8)
         e = C.c_int(0)
-        ok = o.orc_bch_63_16_decode(g["bits"][i].ctypes.data, d.ctypes.data, C.byref(e))
+        row = bits[i]
+        ok = o.orc_bch_63_16_decode(row.ctypes.data, d.ctypes.data, C.byref(e))
         assert ok == g["bch"][i, 0]
         if ok:
             assert e.value == g["bch"][i, 1] and np.array_equal(d, g["bch"][i, 2:])

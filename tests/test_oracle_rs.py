@@ -1,0 +1,129 @@
+"""CPU: Golay(24,12,8) / (18,6,8) and RS(24,12,13) / (24,16,9) / (36,20,17) restatement (oracle/ddn_oracle_rs.c) pinned
+bit for bit against the reference's compiled check_and_fix_* entry points (oracle/_ref)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fecgen
+import orc
+
+needs_ref = pytest.mark.skipif(not orc.have_ref(), reason="compiled reference (oracle/_ref) not present")
+VP = C.c_void_p
+
+
+def oracle_golay(data, par):
+    o = orc.oracle()
+    o.orc_golay_24_decode.argtypes = [VP, C.c_int, VP, VP]
+    n, ln = data.shape
+    out = data.copy()
+    rc = np.zeros(n, np.int32)
+    fx = np.zeros(n, np.int32)
+    f = C.c_int(0)
+    for i in range(n):
+        rc[i] = o.orc_golay_24_decode(out[i].ctypes.data, ln, par[i].ctypes.data, C.byref(f))
+        fx[i] = f.value
+    return out, rc, fx
+
+
+def oracle_rs(code, data, par):
+    n_par, n_data, t = fecgen.P25_RS_CODES[code]
+    o = orc.oracle()
+    o.orc_p25_rs_decode.argtypes = [VP, VP, C.c_int, C.c_int, C.c_int]
+    out = data.copy()
+    rc = np.zeros(data.shape[0], np.int32)
+    for i in range(data.shape[0]):
+        rc[i] = o.orc_p25_rs_decode(out[i].ctypes.data, par[i].ctypes.data, n_par, n_data, t)
+    return out, rc
+
+
+def ref_golay(data, par):
+    r = orc.ref()
+    fn = r.check_and_fix_golay_24_6 if data.shape[1] == 6 else r.check_and_fix_golay_24_12
+    fn.argtypes = [VP, VP, VP]
+    out = data.copy()
+    rc = np.zeros(data.shape[0], np.int32)
+    fx = np.zeros(data.shape[0], np.int32)
+    f = C.c_int(0)
+    for i in range(data.shape[0]):
+        rc[i] = fn(out[i].ctypes.data, par[i].ctypes.data, C.byref(f))
+        fx[i] = f.value
+    return out, rc, fx
+
+
+def ref_rs(code, data, par):
+    r = orc.ref()
+    fn = {"24_12_13": r.check_and_fix_reedsolomon_24_12_13, "24_16_9": r.check_and_fix_reedsolomon_24_16_9,
+          "36_20_17": r.check_and_fix_redsolomon_36_20_17}[code]
+    fn.argtypes = [VP, VP]
+    out = data.copy()
+    rc = np.zeros(data.shape[0], np.int32)
+    for i in range(data.shape[0]):
+        rc[i] = fn(out[i].ctypes.data, par[i].ctypes.data)
+    return out, rc
+
+
+def test_encoders_give_codewords(built):
+    rng = np.random.default_rng(2)
+    for code in fecgen.P25_RS_CODES:
+        d, p = fecgen.gen_p25_rs(rng, code, 20, max_extra=-fecgen.P25_RS_CODES[code][2])   # no errors
+        out, rc = oracle_rs(code, d, p)
+        assert not rc.any() and np.array_equal(out, d)
+    for ln in (6, 12):
+        d, p = fecgen.gen_golay24(np.random.default_rng(3), 1, ln)
+    d12 = rng.integers(0, 2, (50, 12)).astype(np.uint8)
+    p = np.stack([fecgen.golay24_encode(x) for x in d12])
+    out, rc, fx = oracle_golay(d12, p)
+    assert not rc.any() and not fx.any() and np.array_equal(out, d12)
+
+
+@needs_ref
+@pytest.mark.parametrize("length", [6, 12])
+def test_golay_matches_reference(built, length):
+    rng = np.random.default_rng(10 + length)
+    d, p = fecgen.gen_golay24(rng, 6000, length)
+    # plus pure noise words and invalid (non-binary) inputs
+    d[:500] = rng.integers(0, 2, (500, length))
+    p[:500] = rng.integers(0, 2, (500, 12))
+    d[500, 2] = 2
+    p[501, 7] = 3
+    a = oracle_golay(d, p)
+    b = ref_golay(d, p)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[1].sum() > 0 and (a[2] == 3).sum() > 0 and (a[2] == 2).sum() > 0
+
+
+@needs_ref
+def test_golay_exhaustive_error_patterns(built):
+    """Every error pattern of weight <= 4 on one codeword (length 12): data, return code and fixed count."""
+    import itertools
+    rng = np.random.default_rng(5)
+    d0 = rng.integers(0, 2, 12).astype(np.uint8)
+    w0 = np.concatenate([d0, fecgen.golay24_encode(d0)])
+    pats = [()] + [c for k in (1, 2, 3) for c in itertools.combinations(range(24), k)]
+    pats += [c for c in itertools.combinations(range(24), 4)][::7]
+    d = np.zeros((len(pats), 12), np.uint8)
+    p = np.zeros((len(pats), 12), np.uint8)
+    for i, c in enumerate(pats):
+        w = w0.copy()
+        w[list(c)] ^= 1
+        d[i], p[i] = w[:12], w[12:]
+    a = oracle_golay(d, p)
+    b = ref_golay(d, p)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@needs_ref
+@pytest.mark.parametrize("code", list(fecgen.P25_RS_CODES))
+def test_rs_matches_reference(built, code):
+    rng = np.random.default_rng(hash(code) & 0xFFFF)
+    d, p = fecgen.gen_p25_rs(rng, code, 3000, max_extra=4)
+    d[:200] = rng.integers(0, 2, d[:200].shape)          # pure noise
+    p[:200] = rng.integers(0, 2, p[:200].shape)
+    a = oracle_rs(code, d, p)
+    b = ref_rs(code, d, p)
+    assert np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], b[0])
+    assert 0 < a[1].sum() < len(a[1])

@@ -1,0 +1,70 @@
+"""GPU parity: batched Golay(24,12,8)/(18,6,8) and RS(24,12,13)/(24,16,9)/(36,20,17) decoders vs the CPU oracle
+(pinned to the reference's check_and_fix_* in tests/test_oracle_rs.py) — data bits, status and fixed counts identical,
+through the batch entry points and the reference-named single-codeword drop-ins."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ddn
+import fecgen
+from test_oracle_rs import oracle_golay, oracle_rs
+
+pytestmark = pytest.mark.gpu
+CODE_ID = {"24_12_13": 0, "24_16_9": 1, "36_20_17": 2}
+
+
+@pytest.mark.parametrize("length", [6, 12])
+def test_golay_batch(built, length):
+    rng = np.random.default_rng(40 + length)
+    d, p = fecgen.gen_golay24(rng, 20000, length)
+    d[:2000] = rng.integers(0, 2, (2000, length))
+    p[:2000] = rng.integers(0, 2, (2000, 12))
+    d[2000, 1] = 2                       # invalid bit value -> rc 1, untouched
+    p[2001, 11] = 7
+    want_d, want_rc, want_fx = oracle_golay(d, p)
+    got = d.copy()
+    st = np.zeros(len(d), np.uint8)
+    fx = np.zeros(len(d), np.int32)
+    assert ddn.lib().ddn_fec_golay24_host(length, got.ctypes.data, p.ctypes.data, len(d), st.ctypes.data,
+                                          fx.ctypes.data) == 0
+    assert np.array_equal(got, want_d) and np.array_equal(st, want_rc) and np.array_equal(fx, want_fx)
+
+
+@pytest.mark.parametrize("code", list(fecgen.P25_RS_CODES))
+def test_rs_batch(built, code):
+    rng = np.random.default_rng(50 + CODE_ID[code])
+    d, p = fecgen.gen_p25_rs(rng, code, 5000, max_extra=4)
+    d[:300] = rng.integers(0, 2, d[:300].shape)
+    p[:300] = rng.integers(0, 2, p[:300].shape)
+    d[300] = 0
+    p[300] = 0                                               # all-zero word: clean
+    d[301, 0, 0] = 5                                         # non-binary byte counts as a set bit, rewritten as 1
+    want_d, want_rc = oracle_rs(code, d, p)
+    got = d.copy()
+    st = np.zeros(len(d), np.uint8)
+    assert ddn.lib().ddn_fec_p25_rs_host(CODE_ID[code], got.ctypes.data, p.ctypes.data, len(d), st.ctypes.data) == 0
+    assert np.array_equal(st, want_rc)
+    assert np.array_equal(got, want_d)
+    assert 0 < st.sum() < len(st)
+
+
+def test_dropin_names(built):
+    rng = np.random.default_rng(60)
+    l = ddn.lib()
+    for length, fn in ((6, l.check_and_fix_golay_24_6), (12, l.check_and_fix_golay_24_12)):
+        d, p = fecgen.gen_golay24(rng, 12, length)
+        want_d, want_rc, want_fx = oracle_golay(d, p)
+        for i in range(len(d)):
+            x = d[i].copy()
+            f = C.c_int(-1)
+            assert fn(x.ctypes.data, p[i].ctypes.data, C.byref(f)) == want_rc[i]
+            assert f.value == want_fx[i] and np.array_equal(x, want_d[i])
+    for code, fn in (("24_12_13", l.check_and_fix_reedsolomon_24_12_13), ("24_16_9", l.check_and_fix_reedsolomon_24_16_9),
+                     ("36_20_17", l.check_and_fix_redsolomon_36_20_17)):
+        d, p = fecgen.gen_p25_rs(rng, code, 8)
+        want_d, want_rc = oracle_rs(code, d, p)
+        for i in range(len(d)):
+            x = d[i].copy()
+            assert fn(x.ctypes.data, p[i].ctypes.data) == want_rc[i]
+            assert np.array_equal(x, want_d[i])
