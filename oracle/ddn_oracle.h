@@ -119,6 +119,45 @@ void orc_ted_init(orc_ted_state* t);
 int orc_gardner_block(orc_ted_state* t, int sps, float ted_gain, int symbol_rate_hz, const float* iq, int n,
                       float* out);
 
+/* ---- CQPSK chain after the channel LPF (oracle/ddn_oracle_cqpsk.c) ----------------------------------------- */
+#define ORC_FLL_MAX_TAPS 48
+typedef struct orc_fll {
+    float phase, freq, alpha, beta, max_freq, min_freq;
+    float tlr[ORC_FLL_MAX_TAPS], tli[ORC_FLL_MAX_TAPS], tur[ORC_FLL_MAX_TAPS], tui[ORC_FLL_MAX_TAPS];
+    int n_taps;
+    float dr[2 * ORC_FLL_MAX_TAPS], di[2 * ORC_FLL_MAX_TAPS];
+    int delay_idx, sps, initialized;
+} orc_fll;
+typedef struct orc_costas {
+    float phase, freq, alpha, beta, error, error_smooth;
+    int initialized;
+} orc_costas;
+typedef struct orc_cqpsk {
+    int sps, sym_rate;
+    float ted_gain, agc_avg, diff_prev_r, diff_prev_j;
+    orc_fll fll;
+    orc_ted_state ted;
+    orc_costas cos;
+} orc_cqpsk;
+void orc_cqpsk_rms_agc(float* avg_io, float* iq, int pairs);
+void orc_fll_design(orc_fll* f, int sps);
+void orc_fll_block(orc_fll* f, int sps, float* iq, int pairs);
+void orc_diff_phasor(float* prev_r, float* prev_j, float* iq, int pairs);
+void orc_costas_block(orc_costas* c, float* iq, int pairs);
+float orc_atan2_qpsk(float y, float x);
+void orc_cqpsk_init(orc_cqpsk* c, int sps, int symbol_rate_hz, float ted_gain);
+int orc_cqpsk_block(orc_cqpsk* c, float* iq, int n, float* out, float* work);
+size_t orc_cqpsk_sizeof(void);
+typedef struct orc_cqpsk_fe {
+    int taps_len;
+    float taps[ORC_MAX_TAPS], hist_i[ORC_MAX_TAPS], hist_q[ORC_MAX_TAPS];
+    orc_cqpsk chain;
+} orc_cqpsk_fe;
+void orc_cqpsk_fe_init(orc_cqpsk_fe* fe, int rate_hz, int symbol_rate_hz, int profile, int lpf_enable, float ted_gain);
+long orc_cqpsk_fe_run_f32(orc_cqpsk_fe* fe, const float* iq, long n_complex, int block_len, float* out, float* scratch);
+size_t orc_cqpsk_fe_sizeof(void);
+void orc_cqpsk_fe_get_state(const orc_cqpsk_fe* fe, float out8[8]);
+
 /* ---- P25p1 C4FM slicer / soft decisions / matched filter (oracle/ddn_oracle_sym.c) ------------------- */
 #define ORC_SLICER_SSIZE 128  /* opts->ssize, src/core/util/dsd_init.c:169 */
 #define ORC_SLICER_MSIZE 1024 /* opts->msize, src/core/util/dsd_init.c:170 */

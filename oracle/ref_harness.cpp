@@ -429,3 +429,68 @@ refh_level_estimate(const float* sorted, int count, float* lo, float* hi) {
     dsd_frame_sync_estimate_sorted_window_levels(sorted, count, lo, hi);
 }
 } // extern "C"
+
+// ---- CQPSK: full_demod() with cqpsk_enable (channel LPF -> RMS AGC -> FLL -> Gardner -> diff phasor -> Costas ->
+// ---- phase extractor), field set after rtl_demod_init_for_mode()'s CQPSK branch ---------------------------------
+extern "C" {
+void*
+refh_cqpsk_create(int rate_hz, int symbol_rate_hz, int lpf_profile, int lpf_enable) {
+    void* mem = dsd_neo_aligned_malloc(sizeof(demod_state));
+    if (!mem) {
+        return nullptr;
+    }
+    demod_state* d = new (mem) demod_state();
+    d->rate_in = rate_hz;
+    d->rate_out = rate_hz;
+    d->mode_demod = &qpsk_differential_demod;
+    d->output_kind = DSD_DEMOD_OUTPUT_SYMBOL_CQPSK;
+    d->cqpsk_enable = 1;
+    d->symbol_rate_hz = symbol_rate_hz;
+    d->symbol_levels = 4;
+    d->ted_sps = (symbol_rate_hz > 0) ? rate_hz / symbol_rate_hz : 5;
+    d->sps_is_integer = 1;
+    d->channel_lpf_enable = lpf_enable;
+    d->channel_lpf_profile = lpf_profile;
+    d->squelch_env = 1.0f;
+    d->squelch_gate_open = 1;
+    return new RefFrontEnd{d};
+}
+
+// Whole capture of already-widened complex floats, `block_len` complex samples per full_demod() call.
+// Returns the number of symbols written.
+long
+refh_cqpsk_run_f32(void* h, const float* iq, long n_complex, int block_len, float* out, long out_cap) {
+    RefFrontEnd* fe = static_cast<RefFrontEnd*>(h);
+    demod_state* d = fe->d;
+    long done = 0, written = 0;
+    while (done < n_complex) {
+        long n = n_complex - done;
+        if (n > block_len) {
+            n = block_len;
+        }
+        std::memcpy(d->input_cb_buf, iq + 2 * done, (size_t)n * 2 * sizeof(float));
+        d->lowpassed = d->input_cb_buf;
+        d->lp_len = (int)(2 * n);
+        full_demod(d);
+        for (int k = 0; k < d->result_len && written < out_cap; k++) {
+            out[written++] = d->result[k];
+        }
+        done += n;
+    }
+    return written;
+}
+
+// out8 = {agc_avg, fll.freq, fll.phase, costas.phase, costas.freq, costas.error_smooth, ted.mu, ted.omega}
+void
+refh_cqpsk_get_state(void* h, float out8[8]) {
+    const demod_state* d = static_cast<RefFrontEnd*>(h)->d;
+    out8[0] = d->cqpsk_agc_avg;
+    out8[1] = d->fll_band_edge_state.freq;
+    out8[2] = d->fll_band_edge_state.phase;
+    out8[3] = d->costas_state.phase;
+    out8[4] = d->costas_state.freq;
+    out8[5] = d->costas_state.error_smooth;
+    out8[6] = d->ted_state.mu;
+    out8[7] = d->ted_state.omega;
+}
+} // extern "C"

@@ -347,3 +347,64 @@ class OracleP25Rx:
         t = np.zeros(7, np.float32)
         self.o.orc_p25rx_get_thresholds(self.st, t.ctypes.data)
         return t
+
+
+# ---- CQPSK front end (oracle/ddn_oracle_cqpsk.c) --------------------------------------------------------------------
+def synth_dqpsk_f32(seed, n_ch, n_sym, sps, cfo=0.002, noise=0.03, amp=0.6):
+    """pi/4-DQPSK-like stream (differential +-pi/4, +-3pi/4 steps) with a carrier offset (rad/sample), band-limited."""
+    rng = np.random.default_rng(seed)
+    n = n_sym * sps - 40
+    out = np.empty((n_ch, n, 2), np.float32)
+    steps = np.array([1, 3, -1, -3]) * np.pi / 4
+    for c in range(n_ch):
+        ph = np.cumsum(steps[rng.integers(0, 4, n_sym)])
+        t = np.arange(n) / sps + rng.random()
+        x = np.zeros(n, complex)
+        for off in range(-3, 4):
+            idx = np.clip(np.floor(t).astype(int) + off, 0, n_sym - 1)
+            tau = t - idx
+            x += np.exp(1j * ph[idx]) * np.sinc(tau) * np.cos(np.pi * 0.2 * tau) / (1 - (0.4 * tau) ** 2 + 1e-9)
+        x *= np.exp(1j * (cfo * (1 + 0.3 * c) * np.arange(n) + rng.random() * 6.28))
+        x += noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        out[c, :, 0] = amp * x.real
+        out[c, :, 1] = amp * x.imag
+    return out
+
+
+class OracleCqpskFe:
+    def __init__(self, rate=24000, sym_rate=4800, profile=5, lpf_enable=1, ted_gain=0.0):
+        o = oracle()
+        o.orc_cqpsk_fe_sizeof.restype = C.c_size_t
+        o.orc_cqpsk_fe_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+        o.orc_cqpsk_fe_run_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
+        o.orc_cqpsk_fe_run_f32.restype = C.c_long
+        self.o = o
+        self.st = C.create_string_buffer(o.orc_cqpsk_fe_sizeof())
+        o.orc_cqpsk_fe_init(self.st, rate, sym_rate, profile, lpf_enable, ted_gain)
+
+    def run(self, iq, block_len):
+        iq = np.ascontiguousarray(iq, np.float32)
+        n = iq.shape[0]
+        out = np.zeros(n + 16, np.float32)
+        scr = np.zeros(4 * block_len + 16, np.float32)
+        k = self.o.orc_cqpsk_fe_run_f32(self.st, iq.ctypes.data, n, block_len, out.ctypes.data, scr.ctypes.data)
+        return out[:k].copy()
+
+
+def ref_cqpsk_f32(iq, block_len, rate=24000, sym_rate=4800, profile=5, lpf=1):
+    r = ref()
+    r.refh_cqpsk_create.restype = C.c_void_p
+    r.refh_cqpsk_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    r.refh_cqpsk_run_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long]
+    r.refh_cqpsk_run_f32.restype = C.c_long
+    r.refh_cqpsk_get_state.argtypes = [C.c_void_p, C.c_void_p]
+    r.refh_fe_destroy.argtypes = [C.c_void_p]
+    iq = np.ascontiguousarray(iq, np.float32)
+    n = iq.shape[0]
+    h = r.refh_cqpsk_create(rate, sym_rate, profile, lpf)
+    out = np.zeros(n + 16, np.float32)
+    k = r.refh_cqpsk_run_f32(h, iq.ctypes.data, n, block_len, out.ctypes.data, len(out))
+    st = np.zeros(8, np.float32)
+    r.refh_cqpsk_get_state(h, st.ctypes.data)
+    r.refh_fe_destroy(h)
+    return out[:k].copy(), st
