@@ -81,6 +81,13 @@ PROTOTYPES = {
     "ddn_p25_matched_filter_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_p25_matched_filter_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddn_batch_set_decimation": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_cqpsk_batch_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ddn_cqpsk_batch_destroy": (None, [C.c_void_p]),
+    "ddn_cqpsk_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_cqpsk_max_symbols": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "ddn_cqpsk_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_cqpsk_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_cqpsk_get_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25_rx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ddn_p25_rx_destroy": (None, [C.c_void_p]),
     "ddn_p25_rx_reset": (C.c_int, [C.c_void_p]),
@@ -264,5 +271,47 @@ class P25Rx:
     def __del__(self):
         try:
             lib().ddn_p25_rx_destroy(self.h)
+        except Exception:
+            pass
+
+
+class CqpskConfig(C.Structure):
+    """ddn_cqpsk_config (include/ddn_hip.h)."""
+    _fields_ = [("n_channels", C.c_int), ("sample_rate_hz", C.c_int), ("symbol_rate_hz", C.c_int),
+                ("lpf_profile", C.c_int), ("lpf_enable", C.c_int), ("input_format", C.c_int), ("block_len", C.c_int),
+                ("ted_gain", C.c_float)]
+
+
+class CqpskBatch:
+    """Batched CQPSK front end (ddn_cqpsk_*), host-buffer convenience wrapper."""
+
+    def __init__(self, n_channels, rate=24000, sym_rate=4800, profile=5, lpf_enable=1, input_format=IN_CF32,
+                 block_len=4096, ted_gain=0.0):
+        self.B = n_channels
+        self.cfg = CqpskConfig(n_channels, rate, sym_rate, profile, lpf_enable, input_format, block_len, ted_gain)
+        self.h = C.c_void_p()
+        _check(-abs(lib().ddn_cqpsk_batch_create(C.byref(self.cfg), C.byref(self.h))), "ddn_cqpsk_batch_create")
+
+    def run(self, iq):
+        """iq [B, n, 2] -> (symbols float32 [B, stride], counts int32 [B])."""
+        import numpy as np
+        iq = np.ascontiguousarray(iq)
+        n = iq.shape[1]
+        stride = lib().ddn_cqpsk_max_symbols(self.h, n)
+        sym = np.zeros((self.B, stride), np.float32)
+        cnt = np.zeros(self.B, np.int32)
+        _check(-abs(lib().ddn_cqpsk_run_host(self.h, iq.ctypes.data, n, sym.ctypes.data, stride, cnt.ctypes.data)),
+               "ddn_cqpsk_run_host")
+        return sym, cnt
+
+    def state(self, ch):
+        import numpy as np
+        s = np.zeros(8, np.float32)
+        _check(lib().ddn_cqpsk_get_state(self.h, ch, s.ctypes.data), "ddn_cqpsk_get_state")
+        return s
+
+    def __del__(self):
+        try:
+            lib().ddn_cqpsk_batch_destroy(self.h)
         except Exception:
             pass

@@ -1,0 +1,505 @@
+// ddn_cqpsk.hip — batched P25 CQPSK/LSM chain around the Gardner kernel (ddn_ted.hip):
+//
+//   k_channel_lpf_c2c   channel LPF, complex in -> complex out (channel_lpf_apply, src/dsp/demod_pipeline.cpp:526-555 ->
+//                       simd_fir_complex_apply, src/dsp/simd_fir.cpp:55-133: zero latency, block-edge replication, FMA
+//                       order of the AVX2 unit for blocks >= taps_len samples, (mul, add) order for shorter ones)
+//   k_cqpsk_agc_fll     RMS AGC (src/dsp/demod_pipeline.cpp:796-842) + FLL band-edge (src/dsp/costas.cpp:636-781,1176-1207,
+//                       NCO polynomial :80-133), sample rate, one channel per lane
+//   k_cqpsk_symbols     differential phasor (costas.cpp:871-901) + Costas loop (:536-603,934-962, detector :179-259) +
+//                       phase extractor theta*4/pi (demod_pipeline.cpp:63-98,742-764), symbol rate, one channel per lane
+// Chain order: demod_pipeline.cpp:1100-1118,1250-1257.  Everything except the LPF is a feedback recurrence, parallel
+// across channels only; staging follows ddn_ted.hip (loader wave, [slot][lane] LDS state).  The FLL kernel rotates three
+// LDS tiles: while the recurrence wave works on tile t in place, the second wave stores the finished tile t-1 to HBM
+// with coalesced row writes and prefetches tile t+1.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+namespace {
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr float kPi = 3.14159265358979323846f;
+
+__constant__ float c_fll[4][DDN_FLL_MAX_TAPS]; // lower_r, lower_i, upper_r, upper_i (reversed, as the reference)
+
+__device__ __forceinline__ float
+clipf(float x, float lim) {
+    return x > lim ? lim : (x < -lim ? -lim : x);
+}
+__device__ __forceinline__ float
+clampr(float v, float lo, float hi) {
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+__device__ __forceinline__ bool
+finitef(float x) {
+    return fabsf(x) <= 3.4028234663852886e38f; // false for NaN and +-inf
+}
+
+__device__ __forceinline__ void
+sincos_half_pi(float phase, float* s, float* c) {
+    const float x2 = phase * phase;
+    *s = phase
+         * (1.0f
+            + x2
+                  * (-0.16666666666666666667f
+                     + x2
+                           * (0.00833333333333333333f
+                              + x2 * (-0.00019841269841269841f + x2 * (0.00000275573192239859f + x2 * -0.00000002505210838544f)))));
+    *c = 1.0f
+         + x2
+               * (-0.5f
+                  + x2
+                        * (0.04166666666666666667f
+                           + x2 * (-0.00138888888888888889f + x2 * (0.00002480158730158730f + x2 * -0.00000027557319223986f))));
+}
+
+// phase is kept inside [-2pi, 2pi] by the loop, which is the only range the reference's polynomial path covers
+// (outside it the reference calls libm; a non-finite phase cannot be reproduced and is passed through the same
+// polynomial so that the result is non-finite as well).
+__device__ __forceinline__ void
+sincos_two_pi(float phase, float* s, float* c) {
+    if (phase > kPi) {
+        phase -= kTwoPi;
+    } else if (phase < -kPi) {
+        phase += kTwoPi;
+    }
+    if (phase > (kPi / 2.0f)) {
+        float sv, cv;
+        sincos_half_pi(kPi - phase, &sv, &cv);
+        *s = sv;
+        *c = -cv;
+    } else if (phase < (-kPi / 2.0f)) {
+        float sv, cv;
+        sincos_half_pi(-kPi - phase, &sv, &cv);
+        *s = sv;
+        *c = -cv;
+    } else {
+        sincos_half_pi(phase, s, c);
+    }
+}
+
+__device__ __forceinline__ float
+smoothstep(float e0, float e1, float x) {
+    if (x <= e0) {
+        return 0.0f;
+    }
+    if (x >= e1) {
+        return 1.0f;
+    }
+    const float t = (x - e0) / (e1 - e0);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+__device__ __forceinline__ float
+atan_unit(float x) {
+    const float ax = fabsf(x);
+    return x * (0.78539816339744830962f - (ax - 1.0f) * (0.2447f + 0.0663f * ax));
+}
+
+__device__ __forceinline__ float
+atan2_qpsk(float y, float x) {
+    if (x == 0.0f && y == 0.0f) {
+        return 0.0f;
+    }
+    const float ax = fabsf(x), ay = fabsf(y);
+    if (ax >= ay) {
+        float a = atan_unit(y / x);
+        if (x < 0.0f) {
+            a += (y < 0.0f) ? -3.14159265358979323846f : 3.14159265358979323846f;
+        }
+        return a;
+    }
+    const float a = atan_unit(x / y);
+    return (y > 0.0f) ? (1.57079632679489661923f - a) : (-1.57079632679489661923f - a);
+}
+
+template <int FMT>
+__device__ __forceinline__ f2
+load_iq(const void* base, size_t idx) {
+    if (FMT == DDN_IN_CU8) {
+        const uchar2 v = ((const uchar2*)base)[idx];
+        f2 r = {((float)v.x - 127.5f) * (1.0f / 127.5f), ((float)v.y - 127.5f) * (1.0f / 127.5f)};
+        return r;
+    }
+    return ((const f2*)base)[idx];
+}
+} // namespace
+
+// ---- channel LPF, complex -> complex -------------------------------------------------------------------------------
+// One output per thread; the 256 outputs of a workgroup share a (256 + taps_len - 1)-sample window staged in LDS with
+// the block-edge rule already applied (left: previous samples of the stream / carried history; right: the block's last
+// sample replicated).  A workgroup never straddles a block: grid.x enumerates (block, tile-in-block).
+template <int FMT>
+__global__ __launch_bounds__(256) void
+k_channel_lpf_c2c(const void* __restrict__ in, long n, size_t in_stride, int block_len, int tiles_per_block,
+                  const float* __restrict__ taps_g, int taps_len, const f2* __restrict__ hist, f2* __restrict__ out,
+                  size_t out_stride) {
+    __shared__ f2 win[256 + DDN_MAX_TAPS];
+    __shared__ float taps[DDN_MAX_TAPS + 1];
+    const int ch = blockIdx.y;
+    const long b = blockIdx.x / tiles_per_block;
+    const int tile = blockIdx.x % tiles_per_block;
+    const long s = b * block_len;
+    if (s >= n) {
+        return;
+    }
+    const long L = (n - s) < block_len ? (n - s) : block_len;
+    const long t0 = s + (long)tile * 256;
+    if (t0 >= s + L) {
+        return;
+    }
+    const int H = taps_len - 1, CEN = H / 2;
+    const long last = s + L - 1;
+    const bool fused = L >= taps_len;
+    for (int i = threadIdx.x; i < taps_len; i += 256) {
+        taps[i] = taps_g[i];
+    }
+    for (int i = threadIdx.x; i < 256 + H; i += 256) {
+        long j = t0 - CEN + i;
+        j = j > last ? last : j;
+        f2 v;
+        if (j < 0) {
+            v = hist[(size_t)ch * H + (size_t)(H + j)];
+        } else {
+            v = load_iq<FMT>(in, (size_t)ch * in_stride + (size_t)j);
+        }
+        win[i] = v;
+    }
+    __syncthreads();
+    const long m = t0 + threadIdx.x;
+    if (m > last) {
+        return;
+    }
+    const int c = threadIdx.x + CEN;
+    const f2 z = {0.0f, 0.0f};
+    f2 acc;
+    {
+        const f2 h = {taps[CEN], taps[CEN]};
+        acc = fused ? __builtin_elementwise_fma(h, win[c], z) : (z + h * win[c]);
+    }
+    for (int k = 0; k < CEN; k++) {
+        const float hk = taps[k];
+        if (hk == 0.0f) {
+            continue;
+        }
+        const int d = CEN - k;
+        const f2 sm = win[c - d] + win[c + d];
+        const f2 h = {hk, hk};
+        acc = fused ? __builtin_elementwise_fma(h, sm, acc) : (acc + h * sm);
+    }
+    out[(size_t)ch * out_stride + (size_t)m] = acc;
+}
+
+template <int FMT>
+__global__ void
+k_lpf_hist(const void* __restrict__ in, long n, size_t in_stride, int H, f2* __restrict__ hist) {
+    const int ch = blockIdx.x, i = threadIdx.x;
+    f2 v = {0.0f, 0.0f};
+    if (i < H) {
+        const long j = n - H + i;
+        v = (j >= 0) ? load_iq<FMT>(in, (size_t)ch * in_stride + (size_t)j) : hist[(size_t)ch * H + (size_t)(H + j)];
+    }
+    __syncthreads();
+    if (i < H) {
+        hist[(size_t)ch * H + i] = v;
+    }
+}
+
+// ---- RMS AGC + FLL band-edge (sample rate) -------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void
+k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels, int nt, float alpha, float beta,
+                DdnCqpskState* __restrict__ state, float* __restrict__ delay_store, f2* __restrict__ out) {
+    constexpr int TS = 32;
+    extern __shared__ float smem[];
+    f2* tiles = (f2*)smem;                         // [3][64][TS + 1]
+    float* dlr = (float*)(tiles + 3 * 64 * (TS + 1)); // [2 nt][64]
+    float* dli = dlr + 2 * nt * 64;                   // [2 nt][64]
+    const int lane = threadIdx.x & 63;
+    const bool helper = threadIdx.x >= 64;
+    const int ch0 = blockIdx.x * 64;
+    const int ch = ch0 + lane;
+    const bool live = !helper && ch < n_channels;
+    DdnCqpskState s = {};
+    if (live) {
+        s = state[ch];
+        for (int k = 0; k < 2 * nt; k++) {
+            dlr[k * 64 + lane] = delay_store[((size_t)k * 2) * n_channels + ch];
+            dli[k * 64 + lane] = delay_store[((size_t)k * 2 + 1) * n_channels + ch];
+        }
+    }
+    float avg = s.agc_avg;
+    if (avg <= 0.0f) {
+        avg = 1.0f;
+    }
+    float phase = s.fll_phase, freq = s.fll_freq;
+    int idx = s.fll_idx;
+    auto stage = [&](long t0, int buf) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        const int half = lane >> 5, col = lane & 31; // two rows per pass: 32 lanes x 8 B = one 256-B row segment
+#pragma unroll 8
+        for (int r = 0; r < 64; r += 2) {
+            const int cc = r + half;
+            f2 v = {0.0f, 0.0f};
+            if (ch0 + cc < n_channels && col < tn) {
+                v = in[(size_t)(ch0 + cc) * stride + (size_t)t0 + col];
+            }
+            tiles[(buf * 64 + cc) * (TS + 1) + col] = v;
+        }
+    };
+    auto drain = [&](long t0, int buf) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        const int half = lane >> 5, col = lane & 31;
+#pragma unroll 8
+        for (int r = 0; r < 64; r += 2) {
+            const int cc = r + half;
+            if (ch0 + cc < n_channels && col < tn) {
+                out[(size_t)(ch0 + cc) * stride + (size_t)t0 + col] = tiles[(buf * 64 + cc) * (TS + 1) + col];
+            }
+        }
+    };
+    if (helper && n > 0) {
+        stage(0, 0);
+    }
+    __syncthreads();
+    long t0 = 0;
+    int it = 0;
+    for (; t0 < n; t0 += TS, it++) {
+        const int buf = it % 3;
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        if (helper) {
+            if (it > 0) {
+                drain(t0 - TS, (it + 2) % 3);
+            }
+            if (t0 + TS < n) {
+                stage(t0 + TS, (it + 1) % 3);
+            }
+        } else if (live) {
+            f2* row = tiles + (buf * 64 + lane) * (TS + 1);
+            for (int q = 0; q < tn; q++) {
+                f2 x = row[q];
+                // RMS AGC
+                const float m2 = x.x * x.x + x.y * x.y;
+                avg = 0.55f * avg + 0.45f * m2;
+                if (avg > 0.0f) {
+                    const float sc = 0.85f / sqrtf(avg);
+                    x.x = x.x * sc;
+                    x.y = x.y * sc;
+                }
+                // FLL: NCO rotation, band-edge filters on the rotated stream, loop update
+                float ns, nc;
+                sincos_two_pi(phase, &ns, &nc);
+                const float orr = x.x * nc - x.y * ns;
+                const float oi = x.x * ns + x.y * nc;
+                dlr[idx * 64 + lane] = orr;
+                dli[idx * 64 + lane] = oi;
+                dlr[(idx + nt) * 64 + lane] = orr;
+                dli[(idx + nt) * 64 + lane] = oi;
+                float lr = 0.0f, li = 0.0f, ur = 0.0f, ui = 0.0f;
+                const int base = idx + nt;
+                for (int k = 0; k < nt; k++) {
+                    const float dr = dlr[(base - k) * 64 + lane], di = dli[(base - k) * 64 + lane];
+                    const float a = c_fll[0][k], b = c_fll[1][k], c = c_fll[2][k], d = c_fll[3][k];
+                    lr += dr * a - di * b;
+                    li += dr * b + di * a;
+                    ur += dr * c - di * d;
+                    ui += dr * d + di * c;
+                }
+                idx = (idx + 1 == nt) ? 0 : idx + 1;
+                const float lm = lr * lr + li * li, um = ur * ur + ui * ui;
+                const float err = clipf(um - lm, 1.0f);
+                freq += beta * err;
+                freq = clampr(freq, -1.0f, 1.0f);
+                phase += freq + alpha * err;
+                for (int g = 0; g < 4 && phase > kTwoPi; g++) {
+                    phase -= kTwoPi;
+                }
+                for (int g = 0; g < 4 && phase < -kTwoPi; g++) {
+                    phase += kTwoPi;
+                }
+                const f2 y = {orr, oi};
+                row[q] = y;
+            }
+        }
+        __syncthreads();
+    }
+    if (helper && it > 0) {
+        drain(t0 - TS, (it + 2) % 3);
+    }
+    if (live) {
+        s.agc_avg = avg;
+        s.fll_phase = phase;
+        s.fll_freq = freq;
+        s.fll_idx = idx;
+        state[ch] = s;
+        for (int k = 0; k < 2 * nt; k++) {
+            delay_store[((size_t)k * 2) * n_channels + ch] = dlr[k * 64 + lane];
+            delay_store[((size_t)k * 2 + 1) * n_channels + ch] = dli[k * 64 + lane];
+        }
+    }
+}
+
+// ---- differential phasor + Costas + phase extractor (symbol rate) ---------------------------------------------------
+__global__ __launch_bounds__(64) void
+k_cqpsk_symbols(const f2* __restrict__ sym, size_t stride, const int* __restrict__ counts, int n_channels,
+                DdnCqpskState* __restrict__ state, float* __restrict__ out, size_t out_stride) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= n_channels) {
+        return;
+    }
+    DdnCqpskState s = state[ch];
+    if (!s.cos_init) {
+        const float loop_bw = 0.008f, damping = 0.70710678118654752440f;
+        const float denom = 1.0f + 2.0f * damping * loop_bw + loop_bw * loop_bw;
+        s.cos_alpha = (4.0f * damping * loop_bw) / denom;
+        s.cos_beta = (4.0f * loop_bw * loop_bw) / denom;
+        s.cos_init = 1;
+    }
+    int cnt = counts[ch];
+    cnt = cnt > (int)stride ? (int)stride : cnt;
+    cnt = cnt > (int)out_stride ? (int)out_stride : cnt;
+    if (cnt > 0) {
+        const float max_phase = kPi / 2.0f, min_phase = -max_phase;
+        float pr = s.diff_r, pj = s.diff_j;
+        float phase = finitef(s.cos_phase) ? clampr(s.cos_phase, min_phase, max_phase) : 0.0f;
+        float freq = s.cos_freq;
+        float es = finitef(s.cos_es) ? s.cos_es : 0.0f;
+        float last_error = 0.0f;
+        const f2* ip = sym + (size_t)ch * stride;
+        float* op = out + (size_t)ch * out_stride;
+        const float k4pi = 4.0f / 3.14159265358979323846f;
+        for (int n = 0; n < cnt; n++) {
+            const f2 cur = ip[n];
+            // y = x * conj(prev)
+            const float ir = cur.x * pr + cur.y * pj;
+            const float ij = cur.y * pr - cur.x * pj;
+            pr = cur.x;
+            pj = cur.y;
+            float nj, nr;
+            sincos_half_pi(-phase, &nj, &nr);
+            const float rr = ir * nr - ij * nj;
+            const float rj = ir * nj + ij * nr;
+            // detector normalisation + confidence
+            float dr, dj, conf;
+            {
+                const float mag2 = rr * rr + rj * rj;
+                if (!finitef(mag2)) {
+                    dr = 0.0f;
+                    dj = 0.0f;
+                    conf = 0.0f;
+                } else if (mag2 <= 0.10f * 0.10f) {
+                    dr = rr;
+                    dj = rj;
+                    conf = 0.0f;
+                } else {
+                    const float mag = sqrtf(mag2);
+                    conf = (mag2 >= 0.35f * 0.35f) ? 1.0f : (finitef(mag) ? smoothstep(0.10f, 0.35f, mag) : 0.0f);
+                    const float scale = (0.85f * 0.85f) / mag;
+                    if (!finitef(scale)) {
+                        dr = 0.0f;
+                        dj = 0.0f;
+                        conf = 0.0f;
+                    } else {
+                        dr = rr * scale;
+                        dj = rj * scale;
+                    }
+                }
+            }
+            float error = 0.0f;
+            if (conf <= 0.0f || !finitef(conf)) {
+                es = 0.0f;
+            } else {
+                const float pd = ((dr > 0.0f ? 1.0f : -1.0f) * dj - (dj > 0.0f ? 1.0f : -1.0f) * dr);
+                const float raw = clipf(pd * conf, 1.0f);
+                float a;
+                if (!finitef(raw) || !finitef(es) || fabsf(es) <= 1.0e-6f) {
+                    a = 0.25f;
+                } else {
+                    const float kick = smoothstep(0.02f, 0.18f, fabsf(raw - es));
+                    a = 0.25f + (0.10f - 0.25f) * kick;
+                }
+                es += a * (raw - es);
+                error = clipf(es, 1.0f);
+            }
+            last_error = error;
+            freq += s.cos_beta * error;
+            phase += freq + s.cos_alpha * error;
+            phase = clampr(phase, min_phase, max_phase);
+            freq = clampr(freq, -1.0f, 1.0f);
+            op[n] = atan2_qpsk(dj, dr) * k4pi;
+        }
+        s.diff_r = pr;
+        s.diff_j = pj;
+        s.cos_phase = phase;
+        s.cos_freq = freq;
+        s.cos_err = last_error;
+        s.cos_es = es;
+    }
+    state[ch] = s;
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------------
+extern "C" hipError_t
+ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, int block_len, int n_channels,
+                        const float* taps_dev, int taps_len, void* hist, void* out, size_t out_stride, hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    const int tiles_per_block = (block_len + 255) / 256;
+    const long n_blocks = (n + block_len - 1) / block_len;
+    const dim3 grid((unsigned)(n_blocks * tiles_per_block), (unsigned)n_channels), blk(256);
+    if (in_fmt == DDN_IN_CU8) {
+        hipLaunchKernelGGL((k_channel_lpf_c2c<DDN_IN_CU8>), grid, blk, 0, st, in, n, in_stride, block_len, tiles_per_block,
+                           taps_dev, taps_len, (const f2*)hist, (f2*)out, out_stride);
+    } else {
+        hipLaunchKernelGGL((k_channel_lpf_c2c<DDN_IN_CF32>), grid, blk, 0, st, in, n, in_stride, block_len, tiles_per_block,
+                           taps_dev, taps_len, (const f2*)hist, (f2*)out, out_stride);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        return e;
+    }
+    if (in_fmt == DDN_IN_CU8) {
+        hipLaunchKernelGGL((k_lpf_hist<DDN_IN_CU8>), dim3((unsigned)n_channels), dim3(192), 0, st, in, n, in_stride,
+                           taps_len - 1, (f2*)hist);
+    } else {
+        hipLaunchKernelGGL((k_lpf_hist<DDN_IN_CF32>), dim3((unsigned)n_channels), dim3(192), 0, st, in, n, in_stride,
+                           taps_len - 1, (f2*)hist);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_cqpsk_set_fll_taps(const float* taps4) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_fll), taps4, sizeof(float) * 4 * DDN_FLL_MAX_TAPS);
+}
+
+extern "C" hipError_t
+ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int nt, float alpha, float beta,
+                      DdnCqpskState* state, float* delay_store, void* out, hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    const size_t shm = sizeof(f2) * 3 * 64 * 33 + sizeof(float) * 2 * (size_t)(2 * nt) * 64;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cqpsk_agc_fll),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_cqpsk_agc_fll, dim3((unsigned)((n_channels + 63) / 64)), dim3(128), shm, st, (const f2*)in, n,
+                       stride, n_channels, nt, alpha, beta, state, delay_store, (f2*)out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_cqpsk_symbols(const void* sym, size_t stride, const int* counts, int n_channels, DdnCqpskState* state, float* out,
+                      size_t out_stride, hipStream_t st) {
+    if (n_channels <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_cqpsk_symbols, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, (const f2*)sym, stride,
+                       counts, n_channels, state, out, out_stride);
+    return hipGetLastError();
+}

@@ -72,6 +72,15 @@ typedef struct DdnRxState { /* per-channel words of dsd_state / frame_sync_runti
     uint32_t hist_bits;
 } DdnRxState;
 
+typedef struct DdnCqpskState { /* per-channel words of demod_state the CQPSK chain carries besides ted_state_t */
+    float agc_avg;                          /* cqpsk_agc_avg */
+    float fll_phase, fll_freq;              /* fll_band_edge_state */
+    int fll_idx;
+    float diff_r, diff_j;                   /* cqpsk_diff_prev_r/j */
+    float cos_phase, cos_freq, cos_err, cos_es, cos_alpha, cos_beta; /* costas_state */
+    int cos_init;
+} DdnCqpskState;
+
 typedef struct DdnPuncture { /* puncture pattern of the K=5 decoder, expanded on the host */
     int p_len;               /* 0 = not punctured */
     int ones_total;
@@ -101,6 +110,14 @@ hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev
                           int n_channels, const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store,
                           float* lbuf_store, float* shist_store, float* minring, float* maxring, uint8_t* rec,
                           uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave, hipStream_t st);
+hipError_t ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, int block_len, int n_channels,
+                                   const float* taps_dev, int taps_len, void* hist, void* out, size_t out_stride,
+                                   hipStream_t st);
+hipError_t ddn_dev_cqpsk_set_fll_taps(const float* taps4);
+hipError_t ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int nt, float alpha, float beta,
+                                 DdnCqpskState* state, float* delay_store, void* out, hipStream_t st);
+hipError_t ddn_dev_cqpsk_symbols(const void* sym, size_t stride, const int* counts, int n_channels, DdnCqpskState* state,
+                                 float* out, size_t out_stride, hipStream_t st);
 hipError_t ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
                               const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st);
 hipError_t ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* status, int32_t* fixed,

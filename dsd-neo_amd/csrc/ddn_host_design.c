@@ -68,3 +68,57 @@ ddn_design_channel_lpf(int rate_hz, int profile, float* taps, int max_taps) {
     }
     return nt;
 }
+
+/* FLL band-edge filter pair + loop gains for `sps` samples per symbol (host-side design, like the reference's
+ * fll_band_edge_design_filter / fll_configure_loop_params, src/dsp/costas.cpp:620-630,979-1070: GNU Radio's
+ * fll_band_edge_cc design with rolloff 0.2 and 2*sps+1 taps, loop bandwidth 2*pi/sps/350, damping sqrt(2)/2).
+ * taps4 = lower_r | lower_i | upper_r | upper_i, each DDN_FLL_MAX_TAPS long, stored reversed like the reference.
+ * Returns n_taps. */
+int
+ddn_design_fll_band_edge(int sps, float* taps4, float* alpha, float* beta) {
+    const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
+    const float rolloff = 0.2f;
+    int n_taps = 2 * sps + 1;
+    if (n_taps > DDN_FLL_MAX_TAPS) {
+        n_taps = DDN_FLL_MAX_TAPS;
+    }
+    if (n_taps < 3) {
+        n_taps = 3;
+    }
+    const float M = roundf((float)n_taps / (float)sps);
+    const int N = (n_taps - 1) / 2;
+    float bb[DDN_FLL_MAX_TAPS];
+    float power = 0.0f;
+    for (int i = 0; i < n_taps; i++) {
+        const float k = -M + (float)i * 2.0f / (float)sps;
+        const float am = rolloff * k - 0.5f, ap = rolloff * k + 0.5f;
+        const float sm = (fabsf(am) < 1e-6f) ? 1.0f : sinf(pi * am) / (pi * am);
+        const float sp = (fabsf(ap) < 1e-6f) ? 1.0f : sinf(pi * ap) / (pi * ap);
+        bb[i] = sm + sp;
+        power += bb[i] * bb[i];
+    }
+    if (power > 0.0f) {
+        const float norm = 1.0f / power;
+        for (int i = 0; i < n_taps; i++) {
+            bb[i] *= norm;
+        }
+    }
+    for (int i = 0; i < 4 * DDN_FLL_MAX_TAPS; i++) {
+        taps4[i] = 0.0f;
+    }
+    for (int i = 0; i < n_taps; i++) {
+        const float freq = (float)(-N + i) / (2.0f * (float)sps);
+        const float phase = two_pi * (1.0f + rolloff) * freq;
+        const int r = n_taps - 1 - i;
+        taps4[r] = bb[i] * cosf(-phase);
+        taps4[DDN_FLL_MAX_TAPS + r] = bb[i] * sinf(-phase);
+        taps4[2 * DDN_FLL_MAX_TAPS + r] = bb[i] * cosf(phase);
+        taps4[3 * DDN_FLL_MAX_TAPS + r] = bb[i] * sinf(phase);
+    }
+    const float loop_bw = two_pi / (float)sps / 350.0f;
+    const float damping = 0.70710678118654752440f;
+    const float denom = 1.0f + 2.0f * damping * loop_bw + loop_bw * loop_bw;
+    *alpha = (4.0f * damping * loop_bw) / denom;
+    *beta = (4.0f * loop_bw * loop_bw) / denom;
+    return n_taps;
+}

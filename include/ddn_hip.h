@@ -175,6 +175,37 @@ int ddn_gardner_run(ddn_ted_batch* b, const float* d_iq, size_t n, float* d_sym,
 int ddn_gardner_run_host(ddn_ted_batch* b, const float* iq, size_t n, float* sym, size_t sym_stride, int* sym_count);
 int ddn_ted_batch_get_state(ddn_ted_batch* b, int channel, float out8[8]);
 
+/* ---- P25 CQPSK / LSM front end, batched -------------------------------------------------------------------
+ * == full_demod(struct demod_state*) with cqpsk_enable (include/dsd-neo/dsp/demod_pipeline.h:106;
+ * src/dsp/demod_pipeline.cpp:1100-1118,1330-1350): channel LPF (profile DDN_LPF_P25_CQPSK) -> cqpsk_rms_agc ->
+ * op25_fll_band_edge_cc -> op25_gardner_cc -> op25_diff_phasor_cc -> op25_costas_loop_cc -> qpsk_differential_demod
+ * (include/dsd-neo/dsp/costas.h) for B channels; all loop state is carried inside the batch object.
+ *   d_iq      : [B][n] interleaved I/Q (cu8 or cf32), channel-major; block_len = the reference's block size (LPF edge
+ *               rule); every block must hold >= 4 samples
+ *   d_symbols : [B][sym_stride] f32 symbols (theta * 4/pi, nominal levels +-1 / +-3), sym_stride >=
+ *               ddn_cqpsk_max_symbols(n); d_counts[B] = symbols produced by this call
+ * get_state out8 = {agc_avg, fll.freq, fll.phase, costas.phase, costas.freq, costas.error_smooth, ted.mu, ted.omega} */
+typedef struct ddn_cqpsk_config {
+    int n_channels;
+    int sample_rate_hz; /* rate_out: 24000 (sps 5) or 48000 (sps 10) */
+    int symbol_rate_hz; /* 4800 (6000 for P25p2) */
+    int lpf_profile;    /* DDN_LPF_P25_CQPSK */
+    int lpf_enable;
+    int input_format;   /* DDN_IN_CU8 / DDN_IN_CF32 */
+    int block_len;
+    float ted_gain;     /* 0 = the reference default */
+} ddn_cqpsk_config;
+typedef struct ddn_cqpsk_batch ddn_cqpsk_batch;
+int ddn_cqpsk_batch_create(const ddn_cqpsk_config* cfg, ddn_cqpsk_batch** out);
+void ddn_cqpsk_batch_destroy(ddn_cqpsk_batch* b);
+int ddn_cqpsk_batch_reset(ddn_cqpsk_batch* b, void* hip_stream);
+size_t ddn_cqpsk_max_symbols(const ddn_cqpsk_batch* b, size_t n);
+int ddn_cqpsk_run(ddn_cqpsk_batch* b, const void* d_iq, size_t n, float* d_symbols, size_t sym_stride,
+                  int32_t* d_counts, void* hip_stream);
+int ddn_cqpsk_run_host(ddn_cqpsk_batch* b, const void* iq, size_t n, float* symbols, size_t sym_stride,
+                       int32_t* counts);
+int ddn_cqpsk_get_state(ddn_cqpsk_batch* b, int channel, float out8[8]);
+
 /* ---- batched trellis / Viterbi decoders (bit-exact integer) ------------------------------------------
  * d_* = device pointers, asynchronous on hip_stream; *_host = host pointers, synchronous.
  *   ddn_fec_p25_12_soft_*   P25 1/2-rate 4-state trellis on bit LLRs: [n][196] int16 -> [n][12] bytes (+ metric>>8)
