@@ -209,10 +209,14 @@ k_lpf_hist(const void* __restrict__ in, long n, size_t in_stride, int H, f2* __r
 }
 
 // ---- RMS AGC + FLL band-edge (sample rate) -------------------------------------------------------------------------
+// NT_T > 0: taps count known at compile time -> the 2*NT delay-line reads of a sample are issued back to back into
+// registers before the (order-preserving) accumulation, so one LDS round trip covers the whole convolution.
+template <int NT_T>
 __global__ __launch_bounds__(128) void
-k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels, int nt, float alpha, float beta,
+k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels, int nt_rt, float alpha, float beta,
                 DdnCqpskState* __restrict__ state, float* __restrict__ delay_store, f2* __restrict__ out) {
     constexpr int TS = 32;
+    const int nt = NT_T > 0 ? NT_T : nt_rt;
     extern __shared__ float smem[];
     f2* tiles = (f2*)smem;                         // [3][64][TS + 1]
     float* dlr = (float*)(tiles + 3 * 64 * (TS + 1)); // [2 nt][64]
@@ -299,13 +303,30 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
                 dli[(idx + nt) * 64 + lane] = oi;
                 float lr = 0.0f, li = 0.0f, ur = 0.0f, ui = 0.0f;
                 const int base = idx + nt;
-                for (int k = 0; k < nt; k++) {
-                    const float dr = dlr[(base - k) * 64 + lane], di = dli[(base - k) * 64 + lane];
-                    const float a = c_fll[0][k], b = c_fll[1][k], c = c_fll[2][k], d = c_fll[3][k];
-                    lr += dr * a - di * b;
-                    li += dr * b + di * a;
-                    ur += dr * c - di * d;
-                    ui += dr * d + di * c;
+                if (NT_T > 0) {
+                    float vr[NT_T > 0 ? NT_T : 1], vi[NT_T > 0 ? NT_T : 1];
+#pragma unroll
+                    for (int k = 0; k < NT_T; k++) {
+                        vr[k] = dlr[(base - k) * 64 + lane];
+                        vi[k] = dli[(base - k) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int k = 0; k < NT_T; k++) {
+                        const float a = c_fll[0][k], b = c_fll[1][k], c = c_fll[2][k], d = c_fll[3][k];
+                        lr += vr[k] * a - vi[k] * b;
+                        li += vr[k] * b + vi[k] * a;
+                        ur += vr[k] * c - vi[k] * d;
+                        ui += vr[k] * d + vi[k] * c;
+                    }
+                } else {
+                    for (int k = 0; k < nt; k++) {
+                        const float dr = dlr[(base - k) * 64 + lane], di = dli[(base - k) * 64 + lane];
+                        const float a = c_fll[0][k], b = c_fll[1][k], c = c_fll[2][k], d = c_fll[3][k];
+                        lr += dr * a - di * b;
+                        li += dr * b + di * a;
+                        ur += dr * c - di * d;
+                        ui += dr * d + di * c;
+                    }
                 }
                 idx = (idx + 1 == nt) ? 0 : idx + 1;
                 const float lm = lr * lr + li * li, um = ur * ur + ui * ui;
@@ -483,13 +504,27 @@ ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int
         return hipSuccess;
     }
     const size_t shm = sizeof(f2) * 3 * 64 * 33 + sizeof(float) * 2 * (size_t)(2 * nt) * 64;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cqpsk_agc_fll),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (e != hipSuccess) {
-        return e;
+    const dim3 grid((unsigned)((n_channels + 63) / 64)), blk(128);
+#define DDN_LAUNCH_FLL(NTT)                                                                                            \
+    do {                                                                                                               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cqpsk_agc_fll<NTT>),                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                      \
+        if (e != hipSuccess) {                                                                                         \
+            return e;                                                                                                  \
+        }                                                                                                              \
+        hipLaunchKernelGGL(k_cqpsk_agc_fll<NTT>, grid, blk, shm, st, (const f2*)in, n, stride, n_channels, nt, alpha,  \
+                           beta, state, delay_store, (f2*)out);                                                        \
+    } while (0)
+    if (nt == 11) {
+        DDN_LAUNCH_FLL(11); // sps 5
+    } else if (nt == 21) {
+        DDN_LAUNCH_FLL(21); // sps 10
+    } else if (nt == 9) {
+        DDN_LAUNCH_FLL(9); // sps 4 (P25p2 6000 sym/s at 24 ksps)
+    } else {
+        DDN_LAUNCH_FLL(0);
     }
-    hipLaunchKernelGGL(k_cqpsk_agc_fll, dim3((unsigned)((n_channels + 63) / 64)), dim3(128), shm, st, (const f2*)in, n,
-                       stride, n_channels, nt, alpha, beta, state, delay_store, (f2*)out);
+#undef DDN_LAUNCH_FLL
     return hipGetLastError();
 }
 

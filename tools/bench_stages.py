@@ -147,6 +147,19 @@ def main():
     orx = orc.OracleP25Rx(lock_symbols=840, use_filter=1)
     report("p25_rx_loop_sps10", B * nn, ms, 4 + 1.1, cpu(lambda: orx.run(x1[0]), nn), "samples")
 
+    # CQPSK front end: 4096 channels x 24000 samples @24 ksps (sps 5), cf32 in -> symbols
+    B, sps = 4096, 5
+    q1 = orc.synth_dqpsk_f32(12, 8, 4808, sps)
+    nq = q1.shape[1]
+    d_q = torch.from_numpy(np.tile(q1, (B // 8, 1, 1))).cuda()
+    cq = ddn.CqpskBatch(B, rate=24000, block_len=4096)
+    strd = l.ddn_cqpsk_max_symbols(cq.h, nq)
+    d_s = torch.zeros((B, strd), dtype=torch.float32, device="cuda")
+    d_c = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: l.ddn_cqpsk_run(cq.h, d_q.data_ptr(), nq, d_s.data_ptr(), strd, d_c.data_ptr(), st))
+    ocq = orc.OracleCqpskFe(rate=24000)
+    report("cqpsk_front_end_sps5", B * nq, ms, 8 + 0.8, cpu(lambda: ocq.run(q1[0], 4096), nq), "complex samples")
+
 
 if __name__ == "__main__":
     main()
