@@ -175,7 +175,7 @@ k_front_end_fused(DdnFusedArgs a) {
     __shared__ f2 chan_last[2][G];                              // last LPF output of the previous tile
     __shared__ int tflag[3][G];
     __shared__ int next_item; // filter work-item counter of the current tile // per tile/channel: 1 = squelched (zeros + modem reset), 2 = first sample skipped
-    __shared__ float stap[DDN_MAX_CENTER + 1];
+    __shared__ __attribute__((aligned(8))) float stap[DDN_MAX_CENTER + 4];
     extern __shared__ f2 ysq[]; // [G][256] first LPF outputs of a block (squelch builds only)
 
     // The two recurrence waves are the FIRST waves of the workgroup: VALU issue on a SIMD is arbitrated by age
@@ -398,6 +398,17 @@ k_front_end_fused(DdnFusedArgs a) {
                     // global pointer (scalar loads), not from 68 kernel-argument SGPRs.
                     constexpr int PF = 4;
                     const f2* w = &win[g][u * (R + 1)];
+                    // The descending and the ascending window are read through two base registers the compiler cannot
+                    // prove equal (opaque index copies; the pointers stay LDS pointers): with one base it fuses each step's pair of 8-byte reads into ds_read2_b64, which
+                    // gfx950 services at 128 B/clk (8 LDS cycles) where two ds_read_b64 take 2 + 2 cycles at 256 B/clk —
+                    // and at R = 4 the fused form makes the LDS, not the VALU, the busiest unit of the CU.
+                    int olo = u * (R + 1), ohi = u * (R + 1), otap = 0;
+                    asm volatile("" : "+v"(olo));
+                    asm volatile("" : "+v"(ohi));
+                    asm volatile("" : "+v"(otap));
+                    const f2* wlo = &win[g][olo];
+                    const f2* whi = &win[g][ohi];
+                    const float* tp = &stap[otap]; // a base register + immediate offsets instead of one v_mov per tap
                     f2 xm[R], xp[R], qm[PF], qp[PF];
                     float qh[PF]; // taps ride the same prefetch queue (LDS broadcast reads of stap[])
                     const float hcs = stap[CENTER_T];
@@ -411,12 +422,13 @@ k_front_end_fused(DdnFusedArgs a) {
 #pragma unroll
                     for (int q = 0; q < PF; q++) {
                         if (q + 1 < CENTER_T) {
-                            qm[q] = w[PH(q + 1 + R - 1)];
-                            qp[q] = w[PH(2 * CENTER_T - (q + 1))];
-                            qh[q] = stap[q + 1];
+                            qm[q] = wlo[PH(q + 1 + R - 1)];
+                            qp[q] = whi[PH(2 * CENTER_T - (q + 1))];
+                            qh[q] = tp[q + 1];
                         }
                     }
-                    float h = stap[0];
+                    float h = tp[0];
+                    float qh_odd = tp[PF + 1]; // second tap of the last 8-byte tap read (PF + 1 is odd: first use is step 0)
 #pragma unroll
                     for (int k = 0; k < CENTER_T; k++) {
                         if (!SKIPZ || h != 0.0f) {
@@ -450,9 +462,16 @@ k_front_end_fused(DdnFusedArgs a) {
                                 qh[q] = qh[q + 1];
                             }
                             if (k + 1 + PF < CENTER_T) {
-                                qm[PF - 1] = w[PH(k + 1 + PF + R - 1)];
-                                qp[PF - 1] = w[PH(2 * CENTER_T - (k + 1 + PF))];
-                                qh[PF - 1] = stap[k + 1 + PF];
+                                qm[PF - 1] = wlo[PH(k + 1 + PF + R - 1)];
+                                qp[PF - 1] = whi[PH(2 * CENTER_T - (k + 1 + PF))];
+                                // taps are fetched two at a time (one ds_read_b64 every other step)
+                                if (((k + 1 + PF) & 1) == 0) {
+                                    const f2 t2 = *(const f2*)&tp[k + 1 + PF];
+                                    qh[PF - 1] = t2.x;
+                                    qh_odd = t2.y;
+                                } else {
+                                    qh[PF - 1] = qh_odd;
+                                }
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
