@@ -119,6 +119,9 @@ PROTOTYPES = {
     "check_and_fix_reedsolomon_24_16_9": (C.c_int, [C.c_void_p, C.c_void_p]),
     "check_and_fix_redsolomon_36_20_17": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hamming_10_6_3_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_12_soft_list_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_12_soft_list_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "p25_12_soft_llr_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "p25_12_soft_llr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmr_r34_viterbi_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dmr_r34_viterbi_decode_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

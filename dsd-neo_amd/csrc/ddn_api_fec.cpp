@@ -562,3 +562,54 @@ extern "C" int
 check_and_fix_redsolomon_36_20_17(char* data, const char* parity) {
     return rs_one(DDN_RS_36_20_17, data, parity);
 }
+
+// ---- P25 1/2-rate list decoder -------------------------------------------------------------------------------------
+extern "C" int
+ddn_fec_p25_12_soft_list_batch(const int16_t* d_llr196, size_t n, int max_candidates, ddn_p25_12_candidate* d_candidates8,
+                               int32_t* d_counts, void* hip_stream) {
+    if (!d_llr196 || !d_candidates8 || !d_counts || max_candidates <= 0) {
+        ddn_set_error("ddn_fec_p25_12_soft_list_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_p25_half_rate_list(d_llr196, (int)n, max_candidates, (uint32_t*)d_candidates8, d_counts,
+                                       (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_p25_12_soft_list_host(const int16_t* llr196, size_t n, int max_candidates, ddn_p25_12_candidate* candidates8,
+                              int32_t* counts) {
+    if (!llr196 || !candidates8 || !counts || max_candidates <= 0) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * 196 * 2), c(n * 8 * sizeof(ddn_p25_12_candidate)), k(n * 4);
+    if (!a.p || !c.p || !k.p || a.up(llr196)) {
+        return no_dev();
+    }
+    int rc = ddn_fec_p25_12_soft_list_batch((const int16_t*)a.p, n, max_candidates, (ddn_p25_12_candidate*)c.p,
+                                            (int32_t*)k.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (c.down(candidates8) || k.down(counts)) ? no_dev() : DDN_OK;
+}
+
+// reference: int p25_12_soft_llr_list(const uint8_t* input, const int16_t* bit_llr196, p25_12_candidate_t* candidates,
+//                                     int max_candidates)   (include/dsd-neo/protocol/p25/p25_12.h:31-32)
+extern "C" int
+p25_12_soft_llr_list(const uint8_t* input, const int16_t* bit_llr196, ddn_p25_12_candidate* candidates,
+                     int max_candidates) {
+    (void)input;
+    if (!bit_llr196 || !candidates || max_candidates <= 0) {
+        return 0;
+    }
+    ddn_p25_12_candidate tmp[8];
+    int32_t cnt = 0;
+    if (ddn_fec_p25_12_soft_list_host(bit_llr196, 1, max_candidates, tmp, &cnt) != DDN_OK) {
+        return 0;
+    }
+    for (int i = 0; i < cnt; i++) {
+        candidates[i] = tmp[i];
+    }
+    return cnt;
+}

