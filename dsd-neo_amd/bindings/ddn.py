@@ -123,6 +123,9 @@ PROTOTYPES = {
     "ddn_fec_p25_12_soft_list_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "p25_12_soft_llr_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "p25_12_soft_llr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_r34_list_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_r34_list_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "dmr_r34_viterbi_decode_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dmr_r34_viterbi_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dmr_r34_viterbi_decode_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "viterbi_decode": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_uint16]),

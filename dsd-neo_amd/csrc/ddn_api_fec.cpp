@@ -613,3 +613,65 @@ p25_12_soft_llr_list(const uint8_t* input, const int16_t* bit_llr196, ddn_p25_12
     }
     return cnt;
 }
+
+// ---- 3/4-rate list decoder -------------------------------------------------------------------------------------------
+static uint8_t* g_r34_backs = nullptr; // [n][49][8][32] back-pointer scratch, grown on demand
+static size_t g_r34_backs_cap = 0;
+
+extern "C" int
+ddn_fec_r34_list_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, int max_candidates,
+                       ddn_r34_candidate* d_candidates32, int32_t* d_counts, void* hip_stream) {
+    if (!d_dibits98 || !d_candidates32 || !d_counts || max_candidates <= 0) {
+        ddn_set_error("ddn_fec_r34_list_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    const size_t need = n * 49 * 8 * 32;
+    if (g_r34_backs_cap < need) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(g_r34_backs);
+        g_r34_backs = nullptr;
+        g_r34_backs_cap = 0;
+        HIP_TRY(hipMalloc(&g_r34_backs, need));
+        g_r34_backs_cap = need;
+    }
+    HIP_TRY(ddn_dev_r34_list(d_dibits98, d_reliab98, (int)n, max_candidates, g_r34_backs, (uint32_t*)d_candidates32,
+                             d_counts, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_r34_list_host(const uint8_t* dibits98, const uint8_t* reliab98, size_t n, int max_candidates,
+                      ddn_r34_candidate* candidates32, int32_t* counts) {
+    if (!dibits98 || !candidates32 || !counts || max_candidates <= 0) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * 98), r(n * 98), c(n * 32 * sizeof(ddn_r34_candidate)), k(n * 4);
+    if (!a.p || !r.p || !c.p || !k.p || a.up(dibits98) || (reliab98 && r.up(reliab98))) {
+        return no_dev();
+    }
+    int rc = ddn_fec_r34_list_batch((const uint8_t*)a.p, reliab98 ? (const uint8_t*)r.p : nullptr, n, max_candidates,
+                                    (ddn_r34_candidate*)c.p, (int32_t*)k.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (c.down(candidates32) || k.down(counts)) ? no_dev() : DDN_OK;
+}
+
+// reference: dmr_r34_viterbi_decode_list (include/dsd-neo/protocol/dmr/r34_viterbi.h:51-70)
+extern "C" int
+dmr_r34_viterbi_decode_list(const uint8_t* dibits98, const uint8_t* reliab98, ddn_r34_candidate* out_candidates,
+                            int max_candidates, int* out_count) {
+    if (!dibits98 || !out_candidates || !out_count || max_candidates <= 0) {
+        return -1;
+    }
+    ddn_r34_candidate tmp[32];
+    int32_t cnt = 0;
+    if (ddn_fec_r34_list_host(dibits98, reliab98, 1, max_candidates, tmp, &cnt) != DDN_OK) {
+        return -1;
+    }
+    for (int i = 0; i < cnt; i++) {
+        out_candidates[i] = tmp[i];
+    }
+    *out_count = cnt;
+    return 0;
+}

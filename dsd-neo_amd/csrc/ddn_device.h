@@ -125,6 +125,8 @@ hipError_t ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n,
 hipError_t ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, int n, uint8_t* status,
                         hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);
+hipError_t ddn_dev_r34_list(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, uint8_t* backs,
+                            uint32_t* cand, int32_t* count, hipStream_t st);
 hipError_t ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, uint32_t* cand, int32_t* count,
                                       hipStream_t st);
 hipError_t ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st);

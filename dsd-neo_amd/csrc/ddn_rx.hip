@@ -338,39 +338,44 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                         s.hist_count = s.hist_count < 24 ? s.hist_count + 1 : 24;
                         dibit = bit ? 1 : 3;
                         if (s.hist_count >= 8) {
-                            // five smallest (ascending) / five largest (descending) of the level window
-                            const float big = 3.4028234663852886e38f;
-                            float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
-                            float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
-                            const int cnt = s.level_count;
-                            for (int k = 0; k < 24; k++) {
-                                if (k < cnt) {
-                                    float v = L.lb[k][ln], t;
-                                    float w = v;
-                                    t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
-                                    t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
-                                    t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
-                                    t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
-                                    a4 = fminf(a4, v);
-                                    t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
-                                    t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
-                                    t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
-                                    t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
-                                    b4 = fmaxf(b4, w);
-                                }
-                            }
-                            if (cnt >= 13) {
-                                s.lmin = (a2 + a3 + a4) / 3.0f;
-                                s.lmax = (b4 + b3 + b2) / 3.0f;
-                            } else {
-                                s.lmin = (a0 + a1 + a2) / 3.0f;
-                                s.lmax = (b2 + b1 + b0) / 3.0f;
-                            }
                             s.maxref = s.max;
                             s.minref = s.min;
                             int pol = 0;
                             if (s.hist_count >= 24) {
                                 pol = (s.hist_bits == kSyncBits) ? 1 : ((s.hist_bits == (~kSyncBits & 0xFFFFFFu)) ? 2 : 0);
+                            }
+                            // The level window (lmin / lmax of the last <= 24 hunting symbols) is recomputed from
+                            // scratch by the reference on every hunting symbol but only consumed when a sync is
+                            // accepted, so it is evaluated here only then: same values at the only point of use.
+                            if (pol) {
+                                // five smallest (ascending) / five largest (descending) of the level window
+                                const float big = 3.4028234663852886e38f;
+                                float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
+                                float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
+                                const int cnt = s.level_count;
+                                for (int k = 0; k < 24; k++) {
+                                    if (k < cnt) {
+                                        float v = L.lb[k][ln], t;
+                                        float w = v;
+                                        t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
+                                        t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
+                                        t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
+                                        t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
+                                        a4 = fminf(a4, v);
+                                        t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
+                                        t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
+                                        t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
+                                        t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
+                                        b4 = fmaxf(b4, w);
+                                    }
+                                }
+                                if (cnt >= 13) {
+                                    s.lmin = (a2 + a3 + a4) / 3.0f;
+                                    s.lmax = (b4 + b3 + b2) / 3.0f;
+                                } else {
+                                    s.lmin = (a0 + a1 + a2) / 3.0f;
+                                    s.lmax = (b2 + b1 + b0) / 3.0f;
+                                }
                             }
                             if (pol) {
                                 s.max = (s.max + s.lmax) / 2;

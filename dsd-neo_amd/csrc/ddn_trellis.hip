@@ -570,6 +570,163 @@ k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint3
 }
 
 // ------------------------------------------------------------------------------------------------------
+// 3/4-rate LIST decoder (src/protocol/dmr/dmr_34_viterbi.c:255-362,446-474): 32 survivors per state, 8 lanes per codeword.
+// The reference inserts an extension before the first survivor whose metric is >= its own, predecessor by predecessor and
+// rank by rank, i.e. it keeps the 32 smallest extensions under (metric ascending, arrival index DEscending).  Each
+// extension is therefore one 32-bit key (metric << 8) | (255 - (prev_state * 32 + prev_rank)) - metrics stay below 2^24,
+// all keys of a step are distinct - and a lane keeps its next-state's 32 smallest keys sorted in registers with a
+// min/max insertion ladder: c[i] = max(c[i-1], min(c[i], key)) walked from the top.  The key's low byte IS the back
+// pointer.  Back-pointers (32 bytes per state per step) go to a global scratch area; the candidates are state 0's
+// survivors in list order, each traced by one of the group's lanes.
+template <bool SOFT>
+__global__ __launch_bounds__(64) void
+k_r34_list(const uint8_t* __restrict__ dibits, const uint8_t* __restrict__ reliab, int n, int max_cand,
+           uint8_t* __restrict__ backs, uint32_t* __restrict__ cand_out, int32_t* __restrict__ count_out) {
+    constexpr int CW = 8, K = 32;
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    __shared__ uint8_t dd[CW][100];
+    __shared__ uint8_t rr[CW][100];
+    const int tid = threadIdx.x;
+    const int cw0 = blockIdx.x * CW;
+    for (int idx = tid; idx < CW * 98; idx += 64) {
+        const int c = idx / 98, i = idx - c * 98;
+        if (cw0 + c < n) {
+            const int p = deinterleave98(i);
+            dd[c][p] = dibits[(size_t)(cw0 + c) * 98 + i] & 3u;
+            if (SOFT) {
+                rr[c][p] = reliab[(size_t)(cw0 + c) * 98 + i];
+            }
+        }
+    }
+    __syncthreads();
+    const int c = tid >> 3, ns = tid & 7;
+    const int base = tid & ~7;
+    const bool live = (cw0 + c) < n;
+    const size_t cw = (size_t)(cw0 + (live ? c : 0));
+    uint32_t pk[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        pk[r] = EMPTY;
+    }
+    if (ns == 0) {
+        pk[0] = 255u; // metric 0
+    }
+    uint8_t en[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ps++) {
+        en[ps] = c_r34_point_to_nibble[c_r34_fsm[ps * 8 + ns]];
+    }
+    for (int t = 0; t < 49; t++) {
+        const int d0 = live ? dd[c][2 * t] : 0, d1 = live ? dd[c][2 * t + 1] : 0;
+        const int nib = (d0 << 2) | d1;
+        const int rhi = (SOFT && live) ? rr[c][2 * t] : 1, rlo = (SOFT && live) ? rr[c][2 * t + 1] : 1;
+        uint32_t ck[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            ck[r] = EMPTY;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 8; ps++) {
+            const int x = en[ps] ^ nib;
+            uint32_t cost;
+            if (SOFT) {
+                cost = (uint32_t)(((x >> 3) & 1) * rhi + ((x >> 2) & 1) * rhi + ((x >> 1) & 1) * rlo + (x & 1) * rlo);
+            } else {
+                cost = x ? (uint32_t)(256 + __popc((unsigned)x)) : 0u;
+            }
+#pragma unroll
+            for (int pr = 0; pr < K; pr++) {
+                const uint32_t q = __shfl(pk[pr], base + ps);
+                const uint32_t key = (q == EMPTY) ? EMPTY : ((((q >> 8) + cost) << 8) | (uint32_t)(255 - (ps * K + pr)));
+#pragma unroll
+                for (int i = K - 1; i >= 1; i--) {
+                    ck[i] = max(ck[i - 1], min(ck[i], key));
+                }
+                ck[0] = min(ck[0], key);
+            }
+        }
+        // back-pointers of this step: 32 bytes per (codeword, step, state)
+        if (live) {
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                w[j] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t k = ck[4 * j + b];
+                    const uint32_t bp = (k == EMPTY) ? 0u : (255u - (k & 255u));
+                    w[j] |= bp << (8 * b);
+                }
+            }
+            uint4* bo = (uint4*)(backs + ((cw * 49 + t) * 8 + ns) * 32);
+            bo[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            bo[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            pk[r] = ck[r];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // candidates = survivors of state 0 in list order; lane j of the group traces ranks j, j+8, j+16, j+24
+    const int mx = max_cand > K ? K : max_cand;
+    uint32_t mine[4];
+    int count = 0;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const uint32_t v = __shfl(pk[r], base);
+        count += (v != EMPTY) ? 1 : 0;
+        if ((r & 7) == ns) {
+            mine[r >> 3] = v;
+        }
+    }
+    count = count > mx ? mx : count; // survivors are packed at the front of the list
+    if (live) {
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+            const int r0 = ns + 8 * j;
+            uint32_t* o = cand_out + ((size_t)cw * K + r0) * 6; // {metric, 18 bytes, 2 pad} = 24 bytes
+            if (r0 < count) {
+                uint32_t g24[6] = {0, 0, 0, 0, 0, 0};
+                int s = 0, rk = r0;
+                for (int t = 48; t >= 0; t--) {
+                    if (t < 48) {
+                        g24[t >> 3] |= (uint32_t)s << (21 - 3 * (t & 7));
+                    }
+                    const uint32_t idx = backs[((cw * 49 + t) * 8 + s) * 32 + rk];
+                    s = (int)(idx >> 5);
+                    rk = (int)(idx & 31u);
+                }
+                uint8_t by[20];
+#pragma unroll
+                for (int g = 0; g < 6; g++) {
+                    by[3 * g] = (uint8_t)(g24[g] >> 16);
+                    by[3 * g + 1] = (uint8_t)(g24[g] >> 8);
+                    by[3 * g + 2] = (uint8_t)g24[g];
+                }
+                by[18] = 0;
+                by[19] = 0;
+                o[0] = mine[j] >> 8;
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    o[1 + q] = (uint32_t)by[4 * q] | ((uint32_t)by[4 * q + 1] << 8) | ((uint32_t)by[4 * q + 2] << 16)
+                               | ((uint32_t)by[4 * q + 3] << 24);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    o[q] = 0;
+                }
+            }
+        }
+        if (ns == 0) {
+            count_out[cw] = count;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 extern "C" hipError_t
 ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st) {
     if (n <= 0) {
@@ -631,5 +788,20 @@ ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, uint32_t* ca
     }
     hipLaunchKernelGGL(k_p25_half_rate_list, dim3((unsigned)((n + 31) / 32)), dim3(128), 0, st, llr, n, max_cand, cand,
                        count);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_r34_list(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, uint8_t* backs, uint32_t* cand,
+                 int32_t* count, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    const dim3 grid((unsigned)((n + 7) / 8)), blk(64);
+    if (reliab) {
+        hipLaunchKernelGGL((k_r34_list<true>), grid, blk, 0, st, dibits, reliab, n, max_cand, backs, cand, count);
+    } else {
+        hipLaunchKernelGGL((k_r34_list<false>), grid, blk, 0, st, dibits, reliab, n, max_cand, backs, cand, count);
+    }
     return hipGetLastError();
 }

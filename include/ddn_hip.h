@@ -235,6 +235,18 @@ int ddn_fec_p25_12_soft_host(const int16_t* llr196, size_t n, uint8_t* out12, in
 int ddn_fec_r34_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, uint8_t* d_out18,
                       void* hip_stream);
 int ddn_fec_r34_host(const uint8_t* dibits98, const uint8_t* reliab98, size_t n, uint8_t* out18);
+/* list variant == dmr_r34_viterbi_decode_list (include/dsd-neo/protocol/dmr/r34_viterbi.h:51-70;
+ * src/protocol/dmr/dmr_34_viterbi.c:255-362,446-474): 32 survivors per state, candidates = the survivors ending in
+ * state 0 in increasing metric, no de-duplication.  candidates32 is [n][32] of the reference's dmr_r34_candidate
+ * layout (entries >= counts[i] zeroed); reliab98 NULL = unweighted costs; max_candidates clamped to 32. */
+typedef struct ddn_r34_candidate {
+    int32_t metric;
+    uint8_t bytes18[18];
+} ddn_r34_candidate;
+int ddn_fec_r34_list_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, int max_candidates,
+                           ddn_r34_candidate* d_candidates32, int32_t* d_counts, void* hip_stream);
+int ddn_fec_r34_list_host(const uint8_t* dibits98, const uint8_t* reliab98, size_t n, int max_candidates,
+                          ddn_r34_candidate* candidates32, int32_t* counts);
 int ddn_fec_nxdn_conv_batch(const uint8_t* d_sym, const uint8_t* d_rel, size_t n, int n_steps, int n_bits,
                             uint16_t* d_metrics_io, uint8_t* d_out, int out_stride, void* hip_stream);
 int ddn_fec_nxdn_conv_host(const uint8_t* sym, const uint8_t* rel, size_t n, int n_steps, int n_bits,
@@ -293,6 +305,8 @@ int check_and_fix_redsolomon_36_20_17(char* data, const char* parity);
 int p25_12_soft_llr_list(const uint8_t* input, const int16_t* bit_llr196, ddn_p25_12_candidate* candidates,
                          int max_candidates);
 int p25_12_soft_llr(const uint8_t* input, const int16_t* bit_llr196, uint8_t treturn[12]);
+int dmr_r34_viterbi_decode_list(const uint8_t* dibits98, const uint8_t* reliab98, ddn_r34_candidate* out_candidates,
+                                int max_candidates, int* out_count);
 int dmr_r34_viterbi_decode(const uint8_t* dibits98, uint8_t out_bytes18[18]);
 int dmr_r34_viterbi_decode_soft(const uint8_t* dibits98, const uint8_t* reliab98, uint8_t out_bytes18[18]);
 uint32_t viterbi_decode(uint8_t* out, const uint16_t* in, const uint16_t len);

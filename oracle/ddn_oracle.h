@@ -98,6 +98,7 @@ const uint8_t* orc_tbl_r34_fsm(void);
 int orc_p25_12_soft_llr(const int16_t* llr196, uint8_t out12[12]);
 int orc_p25_12_soft_llr_list(const int16_t* llr196, uint8_t* out_bytes, uint32_t* out_metric, int max);
 int orc_r34_decode(const uint8_t* dibits98, const uint8_t* reliab98 /* NULL = hard */, uint8_t out18[18]);
+int orc_r34_decode_list(const uint8_t* dibits98, const uint8_t* reliab98, int max, int32_t* out_metric, uint8_t* out_bytes);
 void orc_nxdn_conv_decode(const uint8_t* sym, const uint8_t* rel /* NULL = hard */, int n_steps,
                           uint16_t metrics16[16], uint8_t* out, int n_bits);
 uint32_t orc_m17_viterbi_decode(uint8_t* out, const uint16_t* in, int len);

@@ -304,6 +304,99 @@ orc_r34_decode(const uint8_t* dibits98, const uint8_t* reliab98, uint8_t out18[1
     return 0;
 }
 
+/* 3/4-rate LIST decoder, src/protocol/dmr/dmr_34_viterbi.c:255-362,446-474: 32 survivors per state.  The reference
+ * inserts an extension before the first survivor whose metric is >= its own, feeding extensions predecessor by
+ * predecessor and rank by rank: the list therefore holds the 32 smallest extensions under the total order
+ * (metric ascending, arrival index ps*32+pr DESCENDING).  Here each extension carries the 32-bit key
+ * (metric << 8) | (255 - arrival index) and the 32 smallest keys are kept - all keys of a step are distinct, so the
+ * order is unambiguous; metrics stay below 2^24 (49 steps x <= 1020).  Candidates are the survivors of state 0 in
+ * list order (already non-decreasing in metric, so the reference's stable sort is the identity); no de-duplication.
+ * out_metric[i], out_bytes[18*i..]; returns the count (<= max). */
+int
+orc_r34_decode_list(const uint8_t* dibits98, const uint8_t* reliab98, int max, int32_t* out_metric, uint8_t* out_bytes) {
+    enum { T = 49, S = 8, K = 32 };
+    const uint32_t EMPTY = 0xFFFFFFFFu;
+    uint8_t il[98], dd[98], rr[98];
+    orc_trellis_interleave_98(il);
+    for (int i = 0; i < 98; i++) {
+        dd[il[i]] = dibits98[i] & 3u;
+        rr[il[i]] = reliab98 ? reliab98[i] : 1;
+    }
+    static uint32_t prev[S][K], cur[S][K];
+    static uint8_t back[T][S][K];
+    for (int s = 0; s < S; s++) {
+        for (int r = 0; r < K; r++) {
+            prev[s][r] = EMPTY;
+        }
+    }
+    prev[0][0] = 0u << 8 | 255u; /* metric 0; arrival index is irrelevant for the seed */
+    for (int t = 0; t < T; t++) {
+        const uint8_t nib = (uint8_t)((dd[2 * t] << 2) | dd[2 * t + 1]);
+        for (int ns = 0; ns < S; ns++) {
+            uint32_t* c = cur[ns];
+            for (int r = 0; r < K; r++) {
+                c[r] = EMPTY;
+            }
+            for (int ps = 0; ps < S; ps++) {
+                const uint8_t x = (uint8_t)(k_r34_point_to_nibble[k_r34_fsm[ps * 8 + ns]] ^ nib);
+                int cost;
+                if (reliab98) {
+                    cost = ((x >> 3) & 1) * rr[2 * t] + ((x >> 2) & 1) * rr[2 * t] + ((x >> 1) & 1) * rr[2 * t + 1]
+                           + (x & 1) * rr[2 * t + 1];
+                } else {
+                    cost = x ? 256 + __builtin_popcount(x) : 0;
+                }
+                for (int pr = 0; pr < K; pr++) {
+                    if (prev[ps][pr] == EMPTY) {
+                        continue;
+                    }
+                    const uint32_t m = (prev[ps][pr] >> 8) + (uint32_t)cost;
+                    uint32_t key = (m << 8) | (uint32_t)(255 - (ps * K + pr));
+                    /* sorted insert, keep the 32 smallest */
+                    for (int i = 0; i < K; i++) {
+                        if (key < c[i]) {
+                            const uint32_t tmp = c[i];
+                            c[i] = key;
+                            key = tmp;
+                        }
+                    }
+                }
+            }
+            for (int r = 0; r < K; r++) {
+                back[t][ns][r] = (c[r] == EMPTY) ? 0 : (uint8_t)(255 - (c[r] & 255u));
+            }
+        }
+        memcpy(prev, cur, sizeof(prev));
+    }
+    int count = 0;
+    for (int r = 0; r < K && count < max; r++) {
+        if (prev[0][r] == EMPTY) {
+            continue;
+        }
+        uint8_t path[T];
+        int s = 0, rk = r;
+        for (int t = T - 1; t >= 0; t--) {
+            path[t] = (uint8_t)s;
+            const int idx = back[t][s][rk];
+            s = idx >> 5;
+            rk = idx & 31;
+        }
+        uint8_t* o = out_bytes + 18 * count;
+        for (int g = 0; g < 6; g++) {
+            uint32_t v = 0;
+            for (int k = 0; k < 8; k++) {
+                v = (v << 3) | (path[8 * g + k] & 7u);
+            }
+            o[3 * g] = (uint8_t)(v >> 16);
+            o[3 * g + 1] = (uint8_t)(v >> 8);
+            o[3 * g + 2] = (uint8_t)v;
+        }
+        out_metric[count] = (int32_t)(prev[0][r] >> 8);
+        count++;
+    }
+    return count;
+}
+
 /* K=5 R=1/2, NXDN flavour: uint16 metrics that wrap, 16 decision bits per step, chainback from state 0.
  * sym = n_steps pairs (s0, s1) with values 0..2; rel (optional) = pairs (r0, r1).  metrics16 carries the
  * decoder's path metrics in and out (the reference keeps them in file-static storage across decodes).

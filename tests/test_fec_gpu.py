@@ -199,3 +199,29 @@ def test_p25_half_rate_list(built):
     one = (C.c_uint8 * (16 * 8))()
     k = ddn.lib().p25_12_soft_llr_list(None, llr[9].ctypes.data, C.addressof(one), 8)
     assert k == cnt[9] or True
+
+
+@pytest.mark.parametrize("weighted", [0, 1])
+def test_r34_list(built, weighted):
+    """3/4-rate list decoder (32 survivors/state) vs the oracle pinned to dmr_r34_viterbi_decode_list."""
+    import ctypes as C
+    rng = np.random.default_rng(93 + weighted)
+    d, rel, _ = fecgen.gen_r34(rng, 600, p_err=0.06, random_frac=0.3)
+    rel[3] = 0
+    rel[4] = 255
+    o = orc.oracle()
+    o.orc_r34_decode_list.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    for mx in (32, 5):
+        cand = np.zeros((len(d), 32, 24), np.uint8)
+        cnt = np.zeros(len(d), np.int32)
+        rp = rel.ctypes.data if weighted else None
+        assert ddn.lib().ddn_fec_r34_list_host(d.ctypes.data, rp, len(d), mx, cand.ctypes.data, cnt.ctypes.data) == 0
+        for i in range(len(d)):
+            om = np.zeros(32, np.int32)
+            ob = np.zeros((32, 18), np.uint8)
+            no = o.orc_r34_decode_list(d[i].ctypes.data, rel[i].ctypes.data if weighted else None, mx, om.ctypes.data,
+                                       ob.ctypes.data)
+            assert cnt[i] == no, (i, mx)
+            assert np.array_equal(cand[i, :no, 4:22], ob[:no]), (i, mx)
+            assert np.array_equal(cand[i, :no, :4].copy().view(np.int32)[:, 0], om[:no]), (i, mx)
+            assert not cand[i, no:].any()

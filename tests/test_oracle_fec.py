@@ -121,3 +121,33 @@ def test_p25_half_rate_list_matches_reference(built):
             assert no == nr, (i, mx)
             for k in range(nr):
                 assert bytes(cand[k].bytes) == ob[k].tobytes() and cand[k].metric == om[k], (i, mx, k)
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="compiled reference (oracle/_ref) not present")
+def test_r34_list_matches_reference(built):
+    """dmr_r34_viterbi_decode_list: 32 survivors per state, hard and reliability-weighted."""
+    import ctypes as C
+    o, r = orc.oracle(), orc.ref()
+
+    class Cand(C.Structure):
+        _fields_ = [("metric", C.c_int), ("bytes18", C.c_uint8 * 18)]
+
+    r.dmr_r34_viterbi_decode_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    o.orc_r34_decode_list.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(78)
+    d, rel, _ = fecgen.gen_r34(rng, 120, p_err=0.06, random_frac=0.3)
+    rel[3] = 0                      # every weighted cost 0: all paths tie
+    rel[4] = 255
+    for weighted in (0, 1):
+        for mx in (32, 5, 1):
+            for i in range(d.shape[0]):
+                cand = (Cand * 32)()
+                cnt = C.c_int(0)
+                rp = rel[i].ctypes.data if weighted else None
+                assert r.dmr_r34_viterbi_decode_list(d[i].ctypes.data, rp, C.addressof(cand), mx, C.byref(cnt)) == 0
+                om = np.zeros(32, np.int32)
+                ob = np.zeros((32, 18), np.uint8)
+                no = o.orc_r34_decode_list(d[i].ctypes.data, rp, mx, om.ctypes.data, ob.ctypes.data)
+                assert no == cnt.value, (i, weighted, mx)
+                for k in range(no):
+                    assert cand[k].metric == om[k] and bytes(cand[k].bytes18) == ob[k].tobytes(), (i, weighted, mx, k)
