@@ -159,7 +159,7 @@ ddn_tile_next(TileWalk& w, const DdnFusedArgs& a) {
 // A single wave issues roughly one VALU instruction per 5 cycles whatever the lane count, so the two
 // recurrences are split over two waves to keep each under the filter threads' time per tile.
 template <int CENTER_T, int G, bool SKIPZ, int FMT>
-__global__ __launch_bounds__(G * 32 + 128) void
+__global__ __launch_bounds__(G * 32 + 128, 3) void
 k_front_end_fused(DdnFusedArgs a) {
     constexpr int TT = DDN_TT;
     constexpr int R = DDN_R;
