@@ -113,6 +113,14 @@ PROTOTYPES = {
     "ddn_fec_golay24_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_p25_rs_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_p25_rs_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_fec_golay24_soft_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
+    "ddn_fec_golay24_soft_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_hamming_10_6_3_soft_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_hamming_10_6_3_soft_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "check_and_fix_golay_24_6_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "check_and_fix_golay_24_12_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hamming_10_6_3_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "check_and_fix_golay_24_6": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "check_and_fix_golay_24_12": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "check_and_fix_reedsolomon_24_12_13": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -675,3 +675,107 @@ dmr_r34_viterbi_decode_list(const uint8_t* dibits98, const uint8_t* reliab98, dd
     *out_count = cnt;
     return 0;
 }
+
+// ---- soft (Chase) Golay / Hamming ------------------------------------------------------------------------------------
+extern "C" int
+ddn_fec_golay24_soft_batch(int data_len, uint8_t* d_data_bits, const uint8_t* d_parity12, const int32_t* d_reliab,
+                           size_t n, uint8_t* d_status, int32_t* d_fixed, void* hip_stream) {
+    if ((data_len != 6 && data_len != 12) || !d_data_bits || !d_parity12 || !d_reliab || !d_status) {
+        ddn_set_error("ddn_fec_golay24_soft_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_golay24_soft(d_data_bits, d_parity12, d_reliab, data_len, (int)n, d_status, d_fixed,
+                                 (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_golay24_soft_host(int data_len, uint8_t* data_bits, const uint8_t* parity12, const int32_t* reliab, size_t n,
+                          uint8_t* status, int32_t* fixed) {
+    if ((data_len != 6 && data_len != 12) || !data_bits || !parity12 || !reliab || !status) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * (size_t)data_len), p(n * 12), r(n * (size_t)(data_len + 12) * 4), s(n), f(n * 4);
+    if (!a.p || !p.p || !r.p || !s.p || !f.p || a.up(data_bits) || p.up(parity12) || r.up(reliab)) {
+        return no_dev();
+    }
+    int rc = ddn_fec_golay24_soft_batch(data_len, (uint8_t*)a.p, (const uint8_t*)p.p, (const int32_t*)r.p, n,
+                                        (uint8_t*)s.p, (int32_t*)f.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (a.down(data_bits) || s.down(status) || (fixed && f.down(fixed))) ? no_dev() : DDN_OK;
+}
+
+extern "C" int
+ddn_fec_hamming_10_6_3_soft_batch(const uint8_t* d_bits10, const int32_t* d_reliab10, size_t n, uint8_t* d_out10,
+                                  uint8_t* d_status, void* hip_stream) {
+    if (!d_bits10 || !d_reliab10 || !d_out10 || !d_status) {
+        ddn_set_error("ddn_fec_hamming_10_6_3_soft_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_hamming_10_6_3_soft(d_bits10, d_reliab10, (int)n, d_out10, d_status, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_hamming_10_6_3_soft_host(const uint8_t* bits10, const int32_t* reliab10, size_t n, uint8_t* out10,
+                                 uint8_t* status) {
+    if (!bits10 || !reliab10 || !out10 || !status) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * 10), r(n * 40), o(n * 10), s(n);
+    if (!a.p || !r.p || !o.p || !s.p || a.up(bits10) || r.up(reliab10)) {
+        return no_dev();
+    }
+    int rc = ddn_fec_hamming_10_6_3_soft_batch((const uint8_t*)a.p, (const int32_t*)r.p, n, (uint8_t*)o.p, (uint8_t*)s.p,
+                                               nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (o.down(out10) || s.down(status)) ? no_dev() : DDN_OK;
+}
+
+// reference names (include/dsd-neo/protocol/p25/p25p1_soft.h): one codeword per call
+static int
+golay_soft_one(int len, char* data, const char* parity, const int* reliab, int* fixed) {
+    if (!fixed) {
+        return 1;
+    }
+    *fixed = 0;
+    if (!data || !parity || !reliab) {
+        return 1;
+    }
+    uint8_t st = 1;
+    int32_t fx = 0;
+    if (ddn_fec_golay24_soft_host(len, (uint8_t*)data, (const uint8_t*)parity, (const int32_t*)reliab, 1, &st, &fx)
+        != DDN_OK) {
+        return 1;
+    }
+    *fixed = fx;
+    return st;
+}
+
+extern "C" int
+check_and_fix_golay_24_6_soft(char* data, const char* parity, const int* reliab, int* fixed) {
+    return golay_soft_one(6, data, parity, reliab, fixed);
+}
+
+extern "C" int
+check_and_fix_golay_24_12_soft(char* data, const char* parity, const int* reliab, int* fixed) {
+    return golay_soft_one(12, data, parity, reliab, fixed);
+}
+
+extern "C" int
+hamming_10_6_3_soft(const char* bits, const int* reliab, char* out_bits) {
+    if (!bits || !reliab || !out_bits) {
+        return 2;
+    }
+    uint8_t st = 2;
+    if (ddn_fec_hamming_10_6_3_soft_host((const uint8_t*)bits, (const int32_t*)reliab, 1, (uint8_t*)out_bits, &st)
+        != DDN_OK) {
+        memcpy(out_bits, bits, 10);
+        return 2;
+    }
+    return st;
+}

@@ -122,6 +122,10 @@ hipError_t ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const
                               const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st);
 hipError_t ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* status, int32_t* fixed,
                            hipStream_t st);
+hipError_t ddn_dev_golay24_soft(uint8_t* data, const uint8_t* parity, const int32_t* reliab, int len, int n,
+                                uint8_t* status, int32_t* fixed, hipStream_t st);
+hipError_t ddn_dev_hamming_10_6_3_soft(const uint8_t* bits, const int32_t* reliab, int n, uint8_t* out, uint8_t* status,
+                                       hipStream_t st);
 hipError_t ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, int n, uint8_t* status,
                         hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);

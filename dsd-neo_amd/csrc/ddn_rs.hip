@@ -296,12 +296,320 @@ k_rs63(uint8_t* __restrict__ data6, const uint8_t* __restrict__ parity6, int n_p
     status[i] = (uint8_t)rc;
 }
 
-extern "C" hipError_t
-ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* status, int32_t* fixed, hipStream_t st) {
-    static uint32_t* tab = nullptr;
-    if (n <= 0) {
-        return hipSuccess;
+// ---- soft (Chase) variants: src/protocol/p25/phase1/p25p1_soft.cpp:175-593 ------------------------------------------
+// hamming_10_6_3_soft: seed with the hard decode, then flip every subset of <= 2 of the 5 least reliable bits and keep
+// valid codewords; check_and_fix_golay_24_{6,12}_soft: seed with the hard decode, then every subset of <= 4 of the 8
+// least reliable bits through the hard decoder.  Penalty = clamped reliability summed over the bits where the
+// re-encoded codeword differs from the received word, ties to fewer differing bits, masks in increasing order with
+// strict improvement only; a corrected hard decode wins unless the best candidate beats it by more than 8.
+namespace {
+__device__ __forceinline__ int
+clamp255d(int v) {
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// returns 0 and the corrected 24-bit word, or 1 (odd overall parity with non-zero low six bits: DSDGolay24::decode_*)
+__device__ __forceinline__ int
+golay_hard_word(uint32_t cw, const uint32_t* tab, uint32_t* out, int* fx) {
+    const uint32_t pbit = cw & 0x800000u;
+    uint32_t w23 = cw & 0x7fffffu;
+    const uint32_t e = tab[golay_syndrome11(w23)];
+    *fx = 0;
+    if (e) {
+        const int wt = __popc(e);
+        bool fits = false;
+        uint32_t r = e;
+#pragma unroll
+        for (int k = 0; k < 23; k++) {
+            fits |= (r & 0xFFFu) == 0;
+            r = ((r << 1) | (r >> 22)) & 0x7fffffu;
+        }
+        *fx = fits ? wt : wt - 1;
+        w23 ^= e;
     }
+    const uint32_t c2 = w23 | pbit;
+    *out = c2;
+    return ((__popc(c2) & 1) && (c2 & 0x3fu)) ? 1 : 0;
+}
+
+__device__ __forceinline__ uint32_t
+golay_encode_word(uint32_t d12) {
+    uint32_t cw = d12 & 0xFFFu;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        cw = (cw & 1u) ? ((cw ^ 0xAE3u) >> 1) : (cw >> 1);
+    }
+    uint32_t w = (cw << 12) | (d12 & 0xFFFu);
+    if (__popc(w) & 1) {
+        w ^= 0x800000u;
+    }
+    return w;
+}
+} // namespace
+
+template <int L>
+__global__ __launch_bounds__(256) void
+k_golay24_soft(uint8_t* __restrict__ data, const uint8_t* __restrict__ parity, const int32_t* __restrict__ reliab, int n,
+               const uint32_t* __restrict__ tab_g, uint8_t* __restrict__ status, int32_t* __restrict__ fixed) {
+    constexpr int N = L + 12, SH = 12 - L;
+    __shared__ uint32_t tab[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+        tab[i] = tab_g[i];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    uint8_t* d = data + (size_t)i * L;
+    const uint8_t* p = parity + (size_t)i * 12;
+    const int32_t* rp = reliab + (size_t)i * N;
+    uint32_t orig = 0;
+    bool valid = true;
+    int rel[N], key[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const uint32_t v = (k < L) ? d[k] : p[k - L];
+        valid &= v <= 1;
+        orig |= (v & 1u) << (k + SH);
+        rel[k] = clamp255d(rp[k]);
+        key[k] = rel[k] * 64 + k;
+    }
+    int rc = 1, fx_out = 0;
+    if (valid) {
+        const uint32_t nmask = ((1u << N) - 1u) << SH;
+        auto penalty = [&](uint32_t diff, int* nd) {
+            int pen = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                pen += ((diff >> (k + SH)) & 1u) ? rel[k] : 0;
+            }
+            *nd = __popc(diff);
+            return pen;
+        };
+        int best_pen = 999999, best_fixed = 0, hard_pen = 999999, hard_fixed = 0;
+        bool found = false, hard_valid = false, hard_corr = false;
+        uint32_t best_dw = 0, hard_dw = 0;
+        {
+            uint32_t c2;
+            if (golay_hard_word(orig, tab, &c2, &hard_fixed) == 0) {
+                hard_dw = c2 & (0xFFFu & ~((1u << SH) - 1u));
+                int nd;
+                hard_pen = penalty((orig ^ golay_encode_word(hard_dw)) & nmask, &nd);
+                best_pen = hard_pen;
+                best_fixed = nd;
+                best_dw = hard_dw;
+                hard_valid = true;
+                hard_corr = hard_fixed > 0;
+                found = true;
+            }
+        }
+        // the 8 least reliable positions in (reliability, position) order -> the word bits they flip
+        uint32_t flip[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int bk = key[0], bi = 0;
+#pragma unroll
+            for (int k = 1; k < N; k++) {
+                const bool lt = key[k] < bk;
+                bk = lt ? key[k] : bk;
+                bi = lt ? k : bi;
+            }
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                key[k] = (k == bi) ? 0x7fffffff : key[k];
+            }
+            flip[j] = 1u << (bi + SH);
+        }
+        for (int mask = 0; mask < 256; mask++) {
+            if (__popc((unsigned)mask) > 4) {
+                continue;
+            }
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                x ^= (mask & (1 << b)) ? flip[b] : 0u;
+            }
+            uint32_t c2;
+            int cf;
+            if (golay_hard_word(orig ^ x, tab, &c2, &cf) != 0) {
+                continue;
+            }
+            const uint32_t dw = c2 & (0xFFFu & ~((1u << SH) - 1u));
+            int nd;
+            const int pen = penalty((orig ^ golay_encode_word(dw)) & nmask, &nd);
+            if (pen < best_pen || (pen == best_pen && nd < best_fixed)) {
+                best_pen = pen;
+                best_fixed = nd;
+                best_dw = dw;
+                found = true;
+            }
+        }
+        if (found) {
+            rc = 0;
+            uint32_t out_dw = best_dw;
+            fx_out = best_fixed;
+            if (hard_valid && hard_corr && best_dw != hard_dw && best_pen + 8 >= hard_pen) {
+                out_dw = hard_dw;
+                fx_out = hard_fixed;
+            }
+#pragma unroll
+            for (int k = 0; k < L; k++) {
+                d[k] = (uint8_t)((out_dw >> (k + SH)) & 1u);
+            }
+        }
+    }
+    status[i] = (uint8_t)rc;
+    if (fixed) {
+        fixed[i] = fx_out;
+    }
+}
+
+__global__ __launch_bounds__(256) void
+k_hamming_10_6_3_soft(const uint8_t* __restrict__ bits, const int32_t* __restrict__ reliab, int n,
+                      uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint8_t* b = bits + (size_t)i * 10;
+    const int32_t* rp = reliab + (size_t)i * 10;
+    int rel[10], key[10];
+    uint32_t orig = 0; // bit (9 - k) = element k: (data << 4) | check, data[0] the MSB
+    bool valid = true;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        const uint32_t v = b[k];
+        valid &= v <= 1;
+        orig |= (v & 1u) << (9 - k);
+        rel[k] = clamp255d(rp[k]);
+        key[k] = rel[k] * 64 + k;
+    }
+    // hamming_10_6_3_decode on a word: 0 valid, 1 corrected (data bits only are rewritten), 2 uncorrectable
+    auto hard = [&](uint32_t w, uint32_t* fixed_w) -> int {
+        const uint32_t m[4] = {0x398u, 0x354u, 0x2E2u, 0x1E1u};
+        int syn = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            syn = (syn << 1) | (__popc(w & m[k]) & 1);
+        }
+        *fixed_w = w;
+        if (syn == 0) {
+            return 0;
+        }
+        // syndrome -> flipped word bit (4..9 = data bits), -1 = two or more errors; 0..3 = a parity bit
+        // -1 encoded as 15 in a packed nibble table: {-, 0, 1, 5, 2, x, x, 6, 3, x, x, 7, 4, 8, 9, x}
+        const uint32_t nib = (uint32_t)((0xF9847FF36FF2510Full >> (4 * syn)) & 15u);
+        const int bb = (nib == 15u) ? -1 : (int)nib;
+        if (bb < 0) {
+            return 2;
+        }
+        if (bb >= 4) {
+            *fixed_w = w ^ (1u << bb);
+        }
+        return 1;
+    };
+    auto encode = [&](uint32_t w) -> uint32_t {
+        const uint32_t d0 = (w >> 9) & 1, d1 = (w >> 8) & 1, d2 = (w >> 7) & 1, d3 = (w >> 6) & 1, d4 = (w >> 5) & 1,
+                       d5 = (w >> 4) & 1;
+        const uint32_t p0 = d0 ^ d1 ^ d2 ^ d5, p1 = d0 ^ d1 ^ d3 ^ d5, p2 = d0 ^ d2 ^ d3 ^ d4, p3 = d1 ^ d2 ^ d3 ^ d4;
+        return (w & 0x3F0u) | (p0 << 3) | (p1 << 2) | (p2 << 1) | p3;
+    };
+    auto penalty = [&](uint32_t diff) {
+        int pen = 0;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            pen += ((diff >> (9 - k)) & 1u) ? rel[k] : 0;
+        }
+        return pen;
+    };
+    int rc = 2;
+    uint32_t outw = orig;
+    if (valid) {
+        int best_pen = 999999, best_flips = 99, hard_pen = 999999;
+        bool found = false, hard_valid = false, hard_corr = false;
+        uint32_t best = 0, hardw = 0;
+        {
+            uint32_t fw;
+            const int r = hard(orig, &fw);
+            if (r == 0 || r == 1) {
+                hardw = encode(fw);
+                hard_valid = true;
+                hard_corr = (r == 1);
+                hard_pen = penalty(orig ^ hardw);
+                best_pen = hard_pen;
+                best_flips = __popc(orig ^ hardw);
+                best = hardw;
+                found = true;
+            }
+        }
+        uint32_t flip[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            int bk = key[0], bi = 0;
+#pragma unroll
+            for (int k = 1; k < 10; k++) {
+                const bool lt = key[k] < bk;
+                bk = lt ? key[k] : bk;
+                bi = lt ? k : bi;
+            }
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+                key[k] = (k == bi) ? 0x7fffffff : key[k];
+            }
+            flip[j] = 1u << (9 - bi);
+        }
+        for (int mask = 0; mask < 32; mask++) {
+            const int nf = __popc((unsigned)mask);
+            if (nf > 2) {
+                continue;
+            }
+            uint32_t x = 0;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                x ^= (mask & (1 << q)) ? flip[q] : 0u;
+            }
+            uint32_t fw;
+            if (hard(orig ^ x, &fw) != 0) {
+                continue;
+            }
+            const uint32_t c = orig ^ x;
+            const int pen = penalty(orig ^ c);
+            if (pen < best_pen || (pen == best_pen && nf < best_flips)) {
+                best_pen = pen;
+                best_flips = nf;
+                best = c;
+                found = true;
+            }
+        }
+        if (found) {
+            if (hard_valid && hard_corr && best != hardw && best_pen + 8 >= hard_pen) {
+                outw = hardw;
+                rc = 1;
+            } else {
+                outw = best;
+                rc = (best == orig) ? 0 : 1;
+            }
+        }
+    }
+    uint8_t* o = out + (size_t)i * 10;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            o[k] = (uint8_t)((outw >> (9 - k)) & 1u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            o[k] = b[k];
+        }
+    }
+    status[i] = (uint8_t)rc;
+}
+
+static hipError_t
+golay_table(uint32_t** out, hipStream_t st) {
+    static uint32_t* tab = nullptr;
     if (!tab) {
         hipError_t e = hipMalloc(&tab, 2048 * sizeof(uint32_t));
         if (e != hipSuccess) {
@@ -313,6 +621,55 @@ ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* s
         if (e != hipSuccess) {
             return e;
         }
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    *out = tab;
+    return hipSuccess;
+}
+
+extern "C" hipError_t
+ddn_dev_golay24_soft(uint8_t* data, const uint8_t* parity, const int32_t* reliab, int len, int n, uint8_t* status,
+                     int32_t* fixed, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    uint32_t* tab = nullptr;
+    hipError_t e = golay_table(&tab, st);
+    if (e != hipSuccess) {
+        return e;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    if (len == 6) {
+        hipLaunchKernelGGL((k_golay24_soft<6>), grid, blk, 0, st, data, parity, reliab, n, (const uint32_t*)tab, status, fixed);
+    } else {
+        hipLaunchKernelGGL((k_golay24_soft<12>), grid, blk, 0, st, data, parity, reliab, n, (const uint32_t*)tab, status, fixed);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_hamming_10_6_3_soft(const uint8_t* bits, const int32_t* reliab, int n, uint8_t* out, uint8_t* status,
+                            hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_hamming_10_6_3_soft, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits, reliab, n, out,
+                       status);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* status, int32_t* fixed, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    uint32_t* tab = nullptr;
+    hipError_t e0 = golay_table(&tab, st);
+    if (e0 != hipSuccess) {
+        return e0;
     }
     hipLaunchKernelGGL(k_golay24, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, parity, len, n,
                        (const uint32_t*)tab, status, fixed);

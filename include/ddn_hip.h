@@ -280,6 +280,19 @@ int ddn_fec_golay24_batch(int data_len, uint8_t* d_data_bits, const uint8_t* d_p
                           int32_t* d_fixed, void* hip_stream);
 int ddn_fec_golay24_host(int data_len, uint8_t* data_bits, const uint8_t* parity12, size_t n, uint8_t* status,
                          int32_t* fixed);
+/* soft (Chase) variants == check_and_fix_golay_24_6_soft / _24_12_soft, hamming_10_6_3_soft
+ * (include/dsd-neo/protocol/p25/p25p1_soft.h; src/protocol/p25/phase1/p25p1_soft.cpp:175-593): reliab = int32 per bit
+ * (data bits then parity bits; clamped to 0..255 like the reference), hard decode as seed, then every subset of <= 4 of
+ * the 8 least reliable bits (Golay) / <= 2 of the 5 least reliable bits (Hamming) through the hard decoder, least
+ * reliability penalty wins, hard-decision override margin 8.  Hamming: out10 [n][10], status 0 / 1 / 2. */
+int ddn_fec_golay24_soft_batch(int data_len, uint8_t* d_data_bits, const uint8_t* d_parity12, const int32_t* d_reliab,
+                               size_t n, uint8_t* d_status, int32_t* d_fixed, void* hip_stream);
+int ddn_fec_golay24_soft_host(int data_len, uint8_t* data_bits, const uint8_t* parity12, const int32_t* reliab, size_t n,
+                              uint8_t* status, int32_t* fixed);
+int ddn_fec_hamming_10_6_3_soft_batch(const uint8_t* d_bits10, const int32_t* d_reliab10, size_t n, uint8_t* d_out10,
+                                      uint8_t* d_status, void* hip_stream);
+int ddn_fec_hamming_10_6_3_soft_host(const uint8_t* bits10, const int32_t* reliab10, size_t n, uint8_t* out10,
+                                     uint8_t* status);
 int ddn_fec_p25_rs_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, size_t n, uint8_t* d_status,
                          void* hip_stream);
 int ddn_fec_p25_rs_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, size_t n, uint8_t* status);
@@ -295,6 +308,9 @@ int ddn_fec_hamming_10_6_3_batch(uint8_t* d_bits10, size_t n, uint8_t* d_errs, v
 int ddn_fec_hamming_10_6_3_host(uint8_t* bits10, size_t n, uint8_t* errs);
 int hamming_10_6_3_decode(char* data, const char* parity);
 /* include/dsd-neo/protocol/p25/p25p1_check_hdu.h, p25p1_check_ldu.h (one codeword per call, reference signatures) */
+int check_and_fix_golay_24_6_soft(char* data, const char* parity, const int* reliab, int* fixed);
+int check_and_fix_golay_24_12_soft(char* data, const char* parity, const int* reliab, int* fixed);
+int hamming_10_6_3_soft(const char* bits, const int* reliab, char* out_bits);
 int check_and_fix_golay_24_6(char* hex, const char* parity, int* fixed_errors);
 int check_and_fix_golay_24_12(char* dodeca, const char* parity, int* fixed_errors);
 int check_and_fix_reedsolomon_24_12_13(char* data, const char* parity);

@@ -204,6 +204,8 @@ size_t orc_p25rx_sizeof(void);
 /* ---- P25p1 Golay(24,12,8) + RS GF(64) hard-decision decoders (oracle/ddn_oracle_rs.c) ---------------------- */
 int orc_golay_24_decode(uint8_t* data, int len, const uint8_t* parity, int* fixed);
 int orc_rs63_decode(int* word, int t);
+int orc_hamming_10_6_3_soft(const uint8_t* bits, const int* reliab, uint8_t* out);
+int orc_golay_24_soft(uint8_t* data, int len, const uint8_t* parity, const int* reliab, int* fixed);
 int orc_p25_rs_decode(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t);
 
 /* ---- block codes (oracle/ddn_oracle_block.c) ---------------------------------------------------------- */

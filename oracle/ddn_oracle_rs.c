@@ -293,3 +293,230 @@ orc_p25_rs_decode(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data,
     }
     return rc;
 }
+
+/* ---- soft (Chase) variants, src/protocol/p25/phase1/p25p1_soft.cpp ------------------------------------------ */
+/* Reliabilities are clamped to 0..255; "least reliable k" = the first k positions in (reliability, position) order
+ * (p25p1_soft.cpp:175-205: the erasure threshold only reorders below-threshold entries first, which an ascending sort
+ * already does).  A candidate's penalty is the clamped reliability summed over the bits where the re-encoded
+ * codeword differs from the received word; ties go to fewer differing bits; masks are tried in increasing order and
+ * only strict improvements replace the incumbent.  Hard-decision override margin 8 (p25p1_soft.cpp:21,462-470). */
+static int
+clamp255i(int v) {
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+static void
+least_reliable(const int* reliab, int n, int k, int* out) {
+    int key[32], used[32] = {0};
+    for (int i = 0; i < n; i++) {
+        key[i] = clamp255i(reliab[i]) * 64 + i;
+    }
+    for (int j = 0; j < k; j++) {
+        int best = -1;
+        for (int i = 0; i < n; i++) {
+            if (!used[i] && (best < 0 || key[i] < key[best])) {
+                best = i;
+            }
+        }
+        used[best] = 1;
+        out[j] = best;
+    }
+}
+
+static void
+hamming_parity(const uint8_t d[6], uint8_t p[4]) {
+    p[0] = d[0] ^ d[1] ^ d[2] ^ d[5];
+    p[1] = d[0] ^ d[1] ^ d[3] ^ d[5];
+    p[2] = d[0] ^ d[2] ^ d[3] ^ d[4];
+    p[3] = d[1] ^ d[2] ^ d[3] ^ d[4];
+}
+
+/* == hamming_10_6_3_decode on a bit-per-byte word: returns 0/1/2, corrects data bits in place on 1 */
+static int
+hamming_hard_bits(uint8_t b[10]) {
+    int w = 0;
+    for (int i = 0; i < 10; i++) {
+        if (b[i] > 1) {
+            return 2;
+        }
+        w = (w << 1) | b[i];
+    }
+    int fixed6 = 0;
+    const int e = orc_hamming_10_6_3(w, &fixed6);
+    if (e == 1) {
+        for (int i = 0; i < 6; i++) {
+            b[i] = (uint8_t)((fixed6 >> (5 - i)) & 1);
+        }
+    }
+    return e;
+}
+
+int
+orc_hamming_10_6_3_soft(const uint8_t* bits, const int* reliab, uint8_t* out) {
+    int best_pen = 999999, best_flips = 99, found = 0, hard_valid = 0, hard_corr = 0, hard_pen = 999999;
+    uint8_t best[10], hard[10];
+    memset(best, 0, sizeof(best));
+    memset(hard, 0, sizeof(hard));
+    {
+        uint8_t t[10];
+        memcpy(t, bits, 10);
+        const int r = hamming_hard_bits(t);
+        if (r == 0 || r == 1) {
+            memcpy(hard, t, 6);
+            hamming_parity(hard, hard + 6);
+            hard_valid = 1;
+            hard_corr = (r == 1);
+            int pen = 0, nd = 0;
+            for (int i = 0; i < 10; i++) {
+                if (bits[i] != hard[i]) {
+                    pen += clamp255i(reliab[i]);
+                    nd++;
+                }
+            }
+            hard_pen = best_pen = pen;
+            best_flips = nd;
+            memcpy(best, hard, 10);
+            found = 1;
+        }
+    }
+    int lr[5];
+    least_reliable(reliab, 10, 5, lr);
+    for (int mask = 0; mask < 32; mask++) {
+        if (__builtin_popcount((unsigned)mask) > 2) {
+            continue;
+        }
+        uint8_t c[10];
+        memcpy(c, bits, 10);
+        for (int b = 0; b < 5; b++) {
+            if (mask & (1 << b)) {
+                c[lr[b]] ^= 1;
+            }
+        }
+        if (hamming_hard_bits(c) != 0) {
+            continue;
+        }
+        int pen = 0;
+        for (int i = 0; i < 10; i++) {
+            if (bits[i] != c[i]) {
+                pen += clamp255i(reliab[i]);
+            }
+        }
+        const int nf = __builtin_popcount((unsigned)mask);
+        if (pen < best_pen || (pen == best_pen && nf < best_flips)) {
+            best_pen = pen;
+            best_flips = nf;
+            memcpy(best, c, 10);
+            found = 1;
+        }
+    }
+    if (found) {
+        if (hard_valid && hard_corr && memcmp(best, hard, 10) != 0 && best_pen + 8 >= hard_pen) {
+            memcpy(out, hard, 10);
+            return 1;
+        }
+        memcpy(out, best, 10);
+        return memcmp(bits, best, 10) == 0 ? 0 : 1;
+    }
+    memcpy(out, bits, 10);
+    return 2;
+}
+
+static void
+golay_reencode(const uint8_t* data, int len, uint8_t* word /* len + 12 */) {
+    uint8_t d12[12] = {0};
+    memcpy(d12 + 12 - len, data, (size_t)len);
+    uint32_t d = 0;
+    for (int k = 0; k < 12; k++) {
+        d |= (uint32_t)d12[k] << k;
+    }
+    uint32_t cw = d;
+    for (int i = 0; i < 12; i++) {
+        if (cw & 1u) {
+            cw ^= 0xAE3u;
+        }
+        cw >>= 1;
+    }
+    uint32_t w = (cw << 12) | d;
+    if (popc(w) & 1) {
+        w ^= 0x800000u;
+    }
+    memcpy(word, data, (size_t)len);
+    for (int k = 0; k < 12; k++) {
+        word[len + k] = (uint8_t)((w >> (12 + k)) & 1u);
+    }
+}
+
+/* == check_and_fix_golay_24_6_soft (len 6) / _24_12_soft (len 12) */
+int
+orc_golay_24_soft(uint8_t* data, int len, const uint8_t* parity, const int* reliab, int* fixed) {
+    const int n = len + 12;
+    uint8_t orig[24], dec[24], best_data[12], hard_data[12];
+    *fixed = 0;
+    memcpy(orig, data, (size_t)len);
+    memcpy(orig + len, parity, 12);
+    int best_pen = 999999, best_fixed = 0, found = 0, hard_valid = 0, hard_corr = 0, hard_pen = 999999, hard_fixed = 0;
+    {
+        uint8_t t[12];
+        memcpy(t, data, (size_t)len);
+        if (orc_golay_24_decode(t, len, parity, &hard_fixed) == 0) {
+            golay_reencode(t, len, dec);
+            int pen = 0, nd = 0;
+            for (int i = 0; i < n; i++) {
+                if (orig[i] != dec[i]) {
+                    pen += clamp255i(reliab[i]);
+                    nd++;
+                }
+            }
+            hard_valid = 1;
+            hard_corr = hard_fixed > 0;
+            hard_pen = best_pen = pen;
+            best_fixed = nd;
+            memcpy(hard_data, t, (size_t)len);
+            memcpy(best_data, t, (size_t)len);
+            found = 1;
+        }
+    }
+    int lr[8];
+    least_reliable(reliab, n, 8, lr);
+    for (int mask = 0; mask < 256; mask++) {
+        if (__builtin_popcount((unsigned)mask) > 4) {
+            continue;
+        }
+        uint8_t c[24];
+        memcpy(c, orig, (size_t)n);
+        for (int b = 0; b < 8; b++) {
+            if (mask & (1 << b)) {
+                c[lr[b]] ^= 1;
+            }
+        }
+        int cf = 0;
+        if (orc_golay_24_decode(c, len, c + len, &cf) != 0) {
+            continue;
+        }
+        golay_reencode(c, len, dec);
+        int pen = 0, nd = 0;
+        for (int i = 0; i < n; i++) {
+            if (orig[i] != dec[i]) {
+                pen += clamp255i(reliab[i]);
+                nd++;
+            }
+        }
+        if (pen < best_pen || (pen == best_pen && nd < best_fixed)) {
+            best_pen = pen;
+            best_fixed = nd;
+            memcpy(best_data, c, (size_t)len);
+            found = 1;
+        }
+    }
+    if (!found) {
+        return 1;
+    }
+    if (hard_valid && hard_corr && memcmp(best_data, hard_data, (size_t)len) != 0 && best_pen + 8 >= hard_pen) {
+        memcpy(data, hard_data, (size_t)len);
+        *fixed = hard_fixed;
+        return 0;
+    }
+    memcpy(data, best_data, (size_t)len);
+    *fixed = best_fixed;
+    return 0;
+}

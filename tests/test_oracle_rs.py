@@ -127,3 +127,91 @@ def test_rs_matches_reference(built, code):
     assert np.array_equal(a[1], b[1])
     assert np.array_equal(a[0], b[0])
     assert 0 < a[1].sum() < len(a[1])
+
+
+def oracle_hamming_soft(bits, rel):
+    o = orc.oracle()
+    o.orc_hamming_10_6_3_soft.argtypes = [VP, VP, VP]
+    out = np.zeros_like(bits)
+    rc = np.zeros(len(bits), np.int32)
+    for i in range(len(bits)):
+        rc[i] = o.orc_hamming_10_6_3_soft(bits[i].ctypes.data, rel[i].ctypes.data, out[i].ctypes.data)
+    return out, rc
+
+
+def oracle_golay_soft(data, par, rel):
+    o = orc.oracle()
+    o.orc_golay_24_soft.argtypes = [VP, C.c_int, VP, VP, VP]
+    out = data.copy()
+    rc = np.zeros(len(data), np.int32)
+    fx = np.zeros(len(data), np.int32)
+    f = C.c_int(0)
+    for i in range(len(data)):
+        rc[i] = o.orc_golay_24_soft(out[i].ctypes.data, data.shape[1], par[i].ctypes.data, rel[i].ctypes.data, C.byref(f))
+        fx[i] = f.value
+    return out, rc, fx
+
+
+def gen_soft_reliab(rng, bits_shape, flipped_mask):
+    """Plausible reliabilities: flipped bits tend to be weak, with some confidently-wrong ones and out-of-range values."""
+    rel = rng.integers(60, 256, bits_shape).astype(np.int32)
+    weak = rng.integers(0, 90, bits_shape)
+    rel = np.where(flipped_mask & (rng.random(bits_shape) < 0.8), weak, rel)
+    rel[rng.random(bits_shape) < 0.02] = 400          # clamps to 255
+    rel[rng.random(bits_shape) < 0.02] = -7           # clamps to 0
+    return np.ascontiguousarray(rel, np.int32)
+
+
+@needs_ref
+def test_hamming_soft_matches_reference(built):
+    r = orc.ref()
+    r.hamming_10_6_3_soft.argtypes = [VP, VP, VP]
+    rng = np.random.default_rng(31)
+    n = 6000
+    d = rng.integers(0, 2, (n, 6)).astype(np.uint8)
+    p = np.stack([d[:, 0] ^ d[:, 1] ^ d[:, 2] ^ d[:, 5], d[:, 0] ^ d[:, 1] ^ d[:, 3] ^ d[:, 5],
+                  d[:, 0] ^ d[:, 2] ^ d[:, 3] ^ d[:, 4], d[:, 1] ^ d[:, 2] ^ d[:, 3] ^ d[:, 4]], axis=1)
+    bits = np.concatenate([d, p], axis=1).astype(np.uint8)
+    flips = rng.random(bits.shape) < rng.choice([0.0, 0.08, 0.2], (n, 1))
+    bits ^= flips.astype(np.uint8)
+    rel = gen_soft_reliab(rng, bits.shape, flips)
+    bits[10, 3] = 2                                      # invalid bit value
+    got, rc = oracle_hamming_soft(bits, rel)
+    for i in range(n):
+        out = np.zeros(10, np.uint8)
+        want = r.hamming_10_6_3_soft(bits[i].ctypes.data, rel[i].ctypes.data, out.ctypes.data)
+        assert want == rc[i], i
+        assert np.array_equal(out, got[i]), i
+    assert set(np.unique(rc)) == {0, 1, 2}
+
+
+@needs_ref
+@pytest.mark.parametrize("length", [6, 12])
+def test_golay_soft_matches_reference(built, length):
+    r = orc.ref()
+    fn = r.check_and_fix_golay_24_6_soft if length == 6 else r.check_and_fix_golay_24_12_soft
+    fn.argtypes = [VP, VP, VP, VP]
+    rng = np.random.default_rng(33 + length)
+    n = 2500
+    d = np.zeros((n, length), np.uint8)
+    p = np.zeros((n, 12), np.uint8)
+    flips = np.zeros((n, length + 12), bool)
+    for i in range(n):
+        d12 = np.zeros(12, np.uint8)
+        d12[12 - length:] = rng.integers(0, 2, length)
+        w = np.concatenate([d12[12 - length:], fecgen.golay24_encode(d12)])
+        ne = int(rng.integers(0, 7))
+        pos = rng.choice(length + 12, ne, replace=False)
+        w[pos] ^= 1
+        flips[i, pos] = True
+        d[i], p[i] = w[:length], w[length:]
+    rel = gen_soft_reliab(rng, flips.shape, flips)
+    d[20, 0] = 3                                          # invalid
+    got, rc, fx = oracle_golay_soft(d, p, rel)
+    f = C.c_int(0)
+    for i in range(n):
+        x = d[i].copy()
+        want = fn(x.ctypes.data, p[i].ctypes.data, rel[i].ctypes.data, C.byref(f))
+        assert want == rc[i] and f.value == fx[i], (i, want, rc[i], f.value, fx[i])
+        assert np.array_equal(x, got[i]), i
+    assert rc.sum() > 0 and (rc == 0).sum() > n // 2

@@ -68,3 +68,57 @@ def test_dropin_names(built):
             x = d[i].copy()
             assert fn(x.ctypes.data, p[i].ctypes.data) == want_rc[i]
             assert np.array_equal(x, want_d[i])
+
+
+def test_hamming_soft_batch(built):
+    from test_oracle_rs import gen_soft_reliab, oracle_hamming_soft
+    rng = np.random.default_rng(71)
+    n = 20000
+    d = rng.integers(0, 2, (n, 6)).astype(np.uint8)
+    p = np.stack([d[:, 0] ^ d[:, 1] ^ d[:, 2] ^ d[:, 5], d[:, 0] ^ d[:, 1] ^ d[:, 3] ^ d[:, 5],
+                  d[:, 0] ^ d[:, 2] ^ d[:, 3] ^ d[:, 4], d[:, 1] ^ d[:, 2] ^ d[:, 3] ^ d[:, 4]], axis=1)
+    bits = np.ascontiguousarray(np.concatenate([d, p], axis=1).astype(np.uint8))
+    flips = rng.random(bits.shape) < rng.choice([0.0, 0.08, 0.2], (n, 1))
+    bits ^= flips.astype(np.uint8)
+    rel = gen_soft_reliab(rng, bits.shape, flips)
+    bits[10, 3] = 2
+    want, wrc = oracle_hamming_soft(bits, rel)
+    out = np.zeros_like(bits)
+    st = np.zeros(n, np.uint8)
+    assert ddn.lib().ddn_fec_hamming_10_6_3_soft_host(bits.ctypes.data, rel.ctypes.data, n, out.ctypes.data, st.ctypes.data) == 0
+    assert np.array_equal(st, wrc) and np.array_equal(out, want)
+    one = np.zeros(10, np.uint8)
+    assert ddn.lib().hamming_10_6_3_soft(bits[7].ctypes.data, rel[7].ctypes.data, one.ctypes.data) == wrc[7]
+    assert np.array_equal(one, want[7])
+
+
+@pytest.mark.parametrize("length", [6, 12])
+def test_golay_soft_batch(built, length):
+    from test_oracle_rs import gen_soft_reliab, oracle_golay_soft
+    rng = np.random.default_rng(73 + length)
+    n = 6000
+    d = np.zeros((n, length), np.uint8)
+    p = np.zeros((n, 12), np.uint8)
+    flips = np.zeros((n, length + 12), bool)
+    for i in range(n):
+        d12 = np.zeros(12, np.uint8)
+        d12[12 - length:] = rng.integers(0, 2, length)
+        w = np.concatenate([d12[12 - length:], fecgen.golay24_encode(d12)])
+        pos = rng.choice(length + 12, int(rng.integers(0, 7)), replace=False)
+        w[pos] ^= 1
+        flips[i, pos] = True
+        d[i], p[i] = w[:length], w[length:]
+    rel = gen_soft_reliab(rng, flips.shape, flips)
+    d[20, 0] = 3
+    want, wrc, wfx = oracle_golay_soft(d, p, rel)
+    got = d.copy()
+    st = np.zeros(n, np.uint8)
+    fx = np.zeros(n, np.int32)
+    assert ddn.lib().ddn_fec_golay24_soft_host(length, got.ctypes.data, p.ctypes.data, rel.ctypes.data, n, st.ctypes.data,
+                                               fx.ctypes.data) == 0
+    assert np.array_equal(st, wrc) and np.array_equal(fx, wfx) and np.array_equal(got, want)
+    fn = ddn.lib().check_and_fix_golay_24_6_soft if length == 6 else ddn.lib().check_and_fix_golay_24_12_soft
+    x = d[5].copy()
+    f = C.c_int(-1)
+    assert fn(x.ctypes.data, p[5].ctypes.data, rel[5].ctypes.data, C.byref(f)) == wrc[5]
+    assert f.value == wfx[5] and np.array_equal(x, want[5])
