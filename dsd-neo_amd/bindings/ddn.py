@@ -118,6 +118,12 @@ PROTOTYPES = {
     "ddn_fec_golay24_soft_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_hamming_10_6_3_soft_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_fec_hamming_10_6_3_soft_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_rs_soft_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                            C.c_void_p]),
+    "ddn_fec_p25_rs_soft_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "p25p1_rs_24_12_13_soft_reliability": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "p25p1_rs_24_16_9_soft_reliability": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "p25p1_rs_36_20_17_soft_reliability": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "check_and_fix_golay_24_6_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "check_and_fix_golay_24_12_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hamming_10_6_3_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

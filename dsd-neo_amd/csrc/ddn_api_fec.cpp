@@ -779,3 +779,75 @@ hamming_10_6_3_soft(const char* bits, const int* reliab, char* out_bits) {
     }
     return st;
 }
+
+// ---- RS with reliability-ranked erasures -------------------------------------------------------------------------------
+extern "C" int
+ddn_fec_p25_rs_soft_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, const uint8_t* d_data_reliab,
+                          const uint8_t* d_parity_reliab, size_t n, uint8_t* d_status, void* hip_stream) {
+    int n_par, n_data, t;
+    int rc = rs_code_params(code, &n_par, &n_data, &t);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (!d_data_bits || !d_parity_bits || !d_data_reliab || !d_parity_reliab || !d_status) {
+        ddn_set_error("ddn_fec_p25_rs_soft_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_rs63_soft(d_data_bits, d_parity_bits, d_data_reliab, d_parity_reliab, n_par, n_data, t,
+                              /*P25P1_SOFT_ERASURE_THRESHOLD*/ 64, (int)n, d_status, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_p25_rs_soft_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, const uint8_t* data_reliab,
+                         const uint8_t* parity_reliab, size_t n, uint8_t* status) {
+    int n_par, n_data, t;
+    int rc = rs_code_params(code, &n_par, &n_data, &t);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (!data_bits || !parity_bits || !data_reliab || !parity_reliab || !status) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * (size_t)n_data * 6), p(n * (size_t)n_par * 6), dr(n * (size_t)n_data), pr(n * (size_t)n_par), s(n);
+    if (!a.p || !p.p || !dr.p || !pr.p || !s.p || a.up(data_bits) || p.up(parity_bits) || dr.up(data_reliab)
+        || pr.up(parity_reliab)) {
+        return no_dev();
+    }
+    rc = ddn_fec_p25_rs_soft_batch(code, (uint8_t*)a.p, (const uint8_t*)p.p, (const uint8_t*)dr.p, (const uint8_t*)pr.p, n,
+                                   (uint8_t*)s.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (a.down(data_bits) || s.down(status)) ? no_dev() : DDN_OK;
+}
+
+static int
+rs_soft_one(int code, char* data, const char* parity, const uint8_t* data_reliab, const uint8_t* parity_reliab) {
+    uint8_t st = 1;
+    if (!data || !parity || !data_reliab || !parity_reliab
+        || ddn_fec_p25_rs_soft_host(code, (uint8_t*)data, (const uint8_t*)parity, data_reliab, parity_reliab, 1, &st)
+               != DDN_OK) {
+        return 1;
+    }
+    return st;
+}
+
+// reference names (include/dsd-neo/protocol/p25/p25p1_soft.h:90-110)
+extern "C" int
+p25p1_rs_24_12_13_soft_reliability(char* data, const char* parity, const uint8_t* data_reliab,
+                                   const uint8_t* parity_reliab) {
+    return rs_soft_one(DDN_RS_24_12_13, data, parity, data_reliab, parity_reliab);
+}
+
+extern "C" int
+p25p1_rs_24_16_9_soft_reliability(char* data, const char* parity, const uint8_t* data_reliab,
+                                  const uint8_t* parity_reliab) {
+    return rs_soft_one(DDN_RS_24_16_9, data, parity, data_reliab, parity_reliab);
+}
+
+extern "C" int
+p25p1_rs_36_20_17_soft_reliability(char* data, const char* parity, const uint8_t* data_reliab,
+                                   const uint8_t* parity_reliab) {
+    return rs_soft_one(DDN_RS_36_20_17, data, parity, data_reliab, parity_reliab);
+}

@@ -296,6 +296,292 @@ k_rs63(uint8_t* __restrict__ data6, const uint8_t* __restrict__ parity6, int n_p
     status[i] = (uint8_t)rc;
 }
 
+// ---- RS errors-and-erasures with reliability-ranked erasures ------------------------------------------------------------
+// == p25p1_rs_24_12_13_soft_reliability / _24_16_9_ / _36_20_17_ (src/protocol/p25/phase1/p25p1_rs_soft_reliability.cpp,
+// p25p1_check_ldu.cpp:70-94, p25p1_check_hdu.cpp:48-69; DSDReedSolomon_*::decode_soft and ReedSolomon_63::decode_with_erasures,
+// include/dsd-neo/fec/ReedSolomon.hpp:175-262,585-690,774-802; ranking p25p1_soft.cpp:86-168).
+// Per codeword: hard decode; if that fails, the symbols are ranked by (reliability, position) and the n = 1, 2, ... weakest
+// are declared erasures until an errors-and-erasures decode succeeds (n up to max(#below-threshold, t), capped at 2t).
+// One attempt = erasure locator (grown by one factor per attempt), modified syndromes, Massey on the last 2t - n of
+// them, 2v + n <= 2t, combined locator, Chien over the 63 positions (root count = degree, every erasure a root), errata
+// values by Forney (the reference solves the equivalent Vandermonde system), and all 2t syndromes of the corrected word
+// must vanish - updated from the received word's syndromes instead of recomputed.  On failure the data is untouched.
+__global__ __launch_bounds__(64) void
+k_rs63_soft(uint8_t* __restrict__ data6, const uint8_t* __restrict__ parity6, const uint8_t* __restrict__ data_rel,
+            const uint8_t* __restrict__ parity_rel, int n_par, int n_data, int t, int threshold, int n,
+            uint8_t* __restrict__ status) {
+    __shared__ uint8_t ex[128], lg[64];
+    __shared__ uint8_t W[36][64], S[17][64], G[18][64], M[17][64], Cc[18][64], Bb[18][64], Tt[18][64], Lam[18][64],
+        Om[16][64], Loc[16][64], Val[16][64], Er[16][64];
+    __shared__ uint16_t Key[36][64];
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        int x = 1;
+        for (int i = 0; i < 63; i++) {
+            ex[i] = (uint8_t)x;
+            ex[i + 63] = (uint8_t)x;
+            lg[x] = (uint8_t)i;
+            x <<= 1;
+            if (x & 0x40) {
+                x ^= 0x43;
+            }
+        }
+        ex[126] = ex[0];
+        ex[127] = ex[1];
+        lg[0] = 0;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 64 + lane;
+    if (i >= n) {
+        return;
+    }
+    auto gmul = [&](int a, int b) -> int { return (a && b) ? ex[lg[a] + lg[b]] : 0; };
+    auto gdiv = [&](int a, int b) -> int { return a ? ex[lg[a] + 63 - lg[b]] : 0; };
+    auto gpow = [&](int a, int e) -> int { return a ? ex[(lg[a] + e) % 63] : 0; };
+    const int nsym = n_par + n_data, n2 = 2 * t;
+    uint8_t* dp = data6 + (size_t)i * n_data * 6;
+    const uint8_t* pp = parity6 + (size_t)i * n_par * 6;
+    for (int k = 0; k < nsym; k++) {
+        const uint8_t* q = (k < n_par) ? (pp + 6 * k) : (dp + 6 * (k - n_par));
+        int v = 0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            v = (v << 1) | (q[b] != 0);
+        }
+        W[k][lane] = (uint8_t)v;
+    }
+    int any = 0;
+    for (int s = 1; s <= n2; s++) {
+        int acc = 0;
+        for (int j = 0; j < nsym; j++) {
+            acc ^= gpow(W[j][lane], (s * j) % 63);
+        }
+        S[s][lane] = (uint8_t)acc;
+        any |= acc;
+    }
+    // Massey on sy[0..ns) (sy = S+1 for the hard attempt, M+n_er for an erasure attempt); returns the polynomial degree
+    auto massey = [&](bool on_m, int off, int ns) -> int {
+        for (int k = 0; k < 18; k++) {
+            Cc[k][lane] = (k == 0);
+            Bb[k][lane] = (k == 0);
+        }
+        auto sy = [&](int k) -> int { return on_m ? M[off + k][lane] : S[off + k][lane]; };
+        int L = 0, m = 1, b = 1;
+        for (int it = 0; it < ns; it++) {
+            int d = sy(it);
+            for (int k = 1; k <= L; k++) {
+                d ^= gmul(Cc[k][lane], sy(it - k));
+            }
+            if (d == 0) {
+                m++;
+                continue;
+            }
+            const int f = gdiv(d, b);
+            for (int k = 0; k < 18; k++) {
+                Tt[k][lane] = Cc[k][lane];
+            }
+            for (int k = 0; k + m < 18; k++) {
+                Cc[k + m][lane] ^= (uint8_t)gmul(f, Bb[k][lane]);
+            }
+            if (2 * L <= it) {
+                L = it + 1 - L;
+                for (int k = 0; k < 18; k++) {
+                    Bb[k][lane] = Tt[k][lane];
+                }
+                b = d;
+                m = 1;
+            } else {
+                m++;
+            }
+        }
+        int deg = 0;
+        for (int k = 17; k >= 0; k--) {
+            if (Cc[k][lane]) {
+                deg = k;
+                break;
+            }
+        }
+        return (L << 8) | deg;
+    };
+    // roots of Lam (degree ldeg) over all 63 positions -> Loc[]; returns the count
+    auto chien = [&](int ldeg) -> int {
+        int nl = 0;
+        for (int p = 0; p < 63; p++) {
+            const int xi = (63 - p) % 63;
+            int v = 0;
+            for (int k = 0; k <= ldeg; k++) {
+                v ^= gpow(Lam[k][lane], (k * xi) % 63);
+            }
+            if (v == 0) {
+                if (nl < 16) {
+                    Loc[nl][lane] = (uint8_t)p;
+                }
+                nl++;
+            }
+        }
+        return nl;
+    };
+    // errata values at Loc[0..nl) by Forney; false if a derivative vanishes
+    auto forney = [&](int ldeg, int nl) -> bool {
+        for (int k = 0; k < n2; k++) {
+            int v = 0;
+            for (int j = 0; j <= k && j <= ldeg; j++) {
+                v ^= gmul(Lam[j][lane], S[k - j + 1][lane]);
+            }
+            Om[k][lane] = (uint8_t)v;
+        }
+        for (int e = 0; e < nl; e++) {
+            const int xi = (63 - Loc[e][lane]) % 63;
+            int num = 0, den = 0;
+            for (int k = 0; k < n2; k++) {
+                num ^= gpow(Om[k][lane], (k * xi) % 63);
+            }
+            for (int k = 1; k <= ldeg; k += 2) {
+                den ^= gpow(Lam[k][lane], ((k - 1) * xi) % 63);
+            }
+            if (den == 0) {
+                return false;
+            }
+            Val[e][lane] = (uint8_t)gdiv(num, den);
+        }
+        return true;
+    };
+    auto write_back = [&](int nl) {
+        for (int e = 0; e < nl; e++) {
+            const int p = Loc[e][lane];
+            if (p < nsym) {
+                W[p][lane] ^= Val[e][lane];
+            }
+        }
+        for (int k = 0; k < n_data; k++) {
+            const int v = W[n_par + k][lane];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                dp[6 * k + b] = (uint8_t)((v >> (5 - b)) & 1);
+            }
+        }
+    };
+    int rc = 1;
+    if (!any) {
+        rc = 0;
+        write_back(0);
+    } else {
+        // hard attempt
+        const int r = massey(false, 1, n2);
+        const int L = r >> 8, deg = r & 255;
+        if (L <= t && deg == L) {
+            for (int k = 0; k < 18; k++) {
+                Lam[k][lane] = Cc[k][lane];
+            }
+            if (chien(L) == L && forney(L, L)) {
+                rc = 0;
+                write_back(L);
+            }
+        }
+    }
+    if (rc != 0) {
+        // rank the symbols: (reliability, position) ascending; position = parity index, then n_par + data index
+        int hits = 0;
+        for (int k = 0; k < nsym; k++) {
+            const int rel = (k < n_par) ? parity_rel[(size_t)i * n_par + k] : data_rel[(size_t)i * n_data + (k - n_par)];
+            hits += rel < threshold;
+            Key[k][lane] = (uint16_t)(rel * 64 + k);
+        }
+        int nr = hits > t ? hits : t;
+        nr = nr > nsym ? nsym : nr;
+        nr = nr > n2 ? n2 : nr;
+        for (int j = 0; j < nr; j++) { // selection of the nr smallest keys, in order
+            int bk = 0x7fffffff, bi = 0;
+            for (int k = 0; k < nsym; k++) {
+                const int kk = Key[k][lane];
+                if (kk < bk) {
+                    bk = kk;
+                    bi = k;
+                }
+            }
+            Key[bi][lane] = 0xFFFF;
+            Er[j][lane] = (uint8_t)bi;
+        }
+        for (int k = 0; k < 18; k++) {
+            G[k][lane] = (k == 0);
+        }
+        for (int ne = 1; ne <= nr && rc != 0; ne++) {
+            // erasure locator grows by (1 + alpha^pos x)
+            const int f = ex[Er[ne - 1][lane] % 63];
+            for (int k = ne - 1; k >= 0; k--) {
+                G[k + 1][lane] ^= (uint8_t)gmul(G[k][lane], f);
+            }
+            for (int k = 0; k < n2; k++) {
+                int v = 0;
+                for (int j = 0; j <= ne && j <= k; j++) {
+                    v ^= gmul(G[j][lane], S[k - j + 1][lane]);
+                }
+                M[k][lane] = (uint8_t)v;
+            }
+            const int r = massey(true, ne, n2 - ne);
+            const int udeg = r & 255;
+            if (2 * udeg + ne > n2) {
+                continue;
+            }
+            int gdeg = 0;
+            for (int k = 17; k >= 0; k--) {
+                if (G[k][lane]) {
+                    gdeg = k;
+                    break;
+                }
+            }
+            if (gdeg + udeg > n2) {
+                continue;
+            }
+            for (int k = 0; k < 18; k++) {
+                Lam[k][lane] = 0;
+            }
+            for (int a = 0; a <= gdeg; a++) {
+                for (int b = 0; b <= udeg; b++) {
+                    Lam[a + b][lane] ^= (uint8_t)gmul(G[a][lane], Cc[b][lane]);
+                }
+            }
+            int ldeg = 0;
+            for (int k = 17; k >= 0; k--) {
+                if (Lam[k][lane]) {
+                    ldeg = k;
+                    break;
+                }
+            }
+            const int nl = (ldeg > 0) ? chien(ldeg) : 0;
+            if (nl != ldeg || nl > n2) {
+                continue;
+            }
+            bool cover = true;
+            for (int e = 0; e < ne; e++) {
+                bool ok = false;
+                for (int k = 0; k < nl; k++) {
+                    ok |= (Loc[k][lane] == Er[e][lane]);
+                }
+                cover &= ok;
+            }
+            if (!cover || !forney(ldeg, nl)) {
+                continue;
+            }
+            // every syndrome of the corrected word must vanish: S_s ^ sum_k val_k alpha^(s loc_k)
+            int resid = 0;
+            for (int s2 = 1; s2 <= n2; s2++) {
+                int v = S[s2][lane];
+                for (int k = 0; k < nl; k++) {
+                    v ^= gpow(Val[k][lane], (s2 * Loc[k][lane]) % 63);
+                }
+                resid |= v;
+            }
+            if (resid) {
+                continue;
+            }
+            rc = 0;
+            write_back(nl);
+        }
+    }
+    status[i] = (uint8_t)rc;
+}
+
 // ---- soft (Chase) variants: src/protocol/p25/phase1/p25p1_soft.cpp:175-593 ------------------------------------------
 // hamming_10_6_3_soft: seed with the hard decode, then flip every subset of <= 2 of the 5 least reliable bits and keep
 // valid codewords; check_and_fix_golay_24_{6,12}_soft: seed with the hard decode, then every subset of <= 4 of the 8
@@ -684,5 +970,16 @@ ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int 
     }
     hipLaunchKernelGGL(k_rs63, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, data6, parity6, n_par, n_data, t, n,
                        status);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_rel, const uint8_t* parity_rel, int n_par,
+                  int n_data, int t, int threshold, int n, uint8_t* status, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_rs63_soft, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, data6, parity6, data_rel, parity_rel,
+                       n_par, n_data, t, threshold, n, status);
     return hipGetLastError();
 }

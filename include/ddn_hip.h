@@ -296,6 +296,14 @@ int ddn_fec_hamming_10_6_3_soft_host(const uint8_t* bits10, const int32_t* relia
 int ddn_fec_p25_rs_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, size_t n, uint8_t* d_status,
                          void* hip_stream);
 int ddn_fec_p25_rs_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, size_t n, uint8_t* status);
+/* == p25p1_rs_24_12_13_soft_reliability / _24_16_9_ / _36_20_17_ (include/dsd-neo/protocol/p25/p25p1_soft.h:90-110):
+ * hard decode, then errors-and-erasures decodes with the n = 1, 2, ... least reliable symbols erased (ranked by
+ * (reliability, position); n up to max(#symbols below the erasure threshold 64, t), capped at 2t).  data_reliab
+ * [n][n_data], parity_reliab [n][n_par] one byte per symbol.  status 0 ok / 1 irrecoverable (data unchanged). */
+int ddn_fec_p25_rs_soft_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, const uint8_t* d_data_reliab,
+                              const uint8_t* d_parity_reliab, size_t n, uint8_t* d_status, void* hip_stream);
+int ddn_fec_p25_rs_soft_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, const uint8_t* data_reliab,
+                             const uint8_t* parity_reliab, size_t n, uint8_t* status);
 int ddn_p25p1_nid_decode_batch(const uint8_t* d_bits63, const uint8_t* d_rel63, const int32_t* d_observed_nac,
                                const uint8_t* d_parity, const uint8_t* d_parity_rel, int erasure_threshold, size_t n,
                                int32_t* d_out4, void* hip_stream);
@@ -308,6 +316,12 @@ int ddn_fec_hamming_10_6_3_batch(uint8_t* d_bits10, size_t n, uint8_t* d_errs, v
 int ddn_fec_hamming_10_6_3_host(uint8_t* bits10, size_t n, uint8_t* errs);
 int hamming_10_6_3_decode(char* data, const char* parity);
 /* include/dsd-neo/protocol/p25/p25p1_check_hdu.h, p25p1_check_ldu.h (one codeword per call, reference signatures) */
+int p25p1_rs_24_12_13_soft_reliability(char* data, const char* parity, const uint8_t* data_reliab,
+                                       const uint8_t* parity_reliab);
+int p25p1_rs_24_16_9_soft_reliability(char* data, const char* parity, const uint8_t* data_reliab,
+                                      const uint8_t* parity_reliab);
+int p25p1_rs_36_20_17_soft_reliability(char* data, const char* parity, const uint8_t* data_reliab,
+                                       const uint8_t* parity_reliab);
 int check_and_fix_golay_24_6_soft(char* data, const char* parity, const int* reliab, int* fixed);
 int check_and_fix_golay_24_12_soft(char* data, const char* parity, const int* reliab, int* fixed);
 int hamming_10_6_3_soft(const char* bits, const int* reliab, char* out_bits);

@@ -204,6 +204,13 @@ size_t orc_p25rx_sizeof(void);
 /* ---- P25p1 Golay(24,12,8) + RS GF(64) hard-decision decoders (oracle/ddn_oracle_rs.c) ---------------------- */
 int orc_golay_24_decode(uint8_t* data, int len, const uint8_t* parity, int* fixed);
 int orc_rs63_decode(int* word, int t);
+int orc_rs63_decode_erasures(int* word, int t, const int* erasures, int n_er);
+int orc_p25_rs_decode_soft(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, const int* erasures,
+                           int n_er);
+int orc_p25_rs_ranked_erasures(const uint8_t* data_rel, int n_data, const uint8_t* parity_rel, int n_par, int min_er,
+                               int* out, int max_er);
+int orc_p25_rs_soft_reliability(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_rel,
+                                const uint8_t* parity_rel, int n_par, int n_data, int t);
 int orc_hamming_10_6_3_soft(const uint8_t* bits, const int* reliab, uint8_t* out);
 int orc_golay_24_soft(uint8_t* data, int len, const uint8_t* parity, const int* reliab, int* fixed);
 int orc_p25_rs_decode(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t);

@@ -520,3 +520,296 @@ orc_golay_24_soft(uint8_t* data, int len, const uint8_t* parity, const int* reli
     *fixed = best_fixed;
     return 0;
 }
+
+/* ---- RS errors-and-erasures (ReedSolomon.hpp:175-262,585-690,774-802) and the ranked-erasure retry loop -------- */
+/* word[63] in place; erasures = n distinct positions 0..62.  Same stages as the reference: erasure locator, modified
+ * syndromes, Massey on the last 2t - n of them, degree bound 2v + n <= 2t, combined locator, Chien (root count must equal
+ * the degree and cover every erasure), errata values, and a final all-syndromes-zero check.  The reference gets the
+ * values from a Vandermonde solve over the first n_loc syndromes; with distinct locations that system has exactly one
+ * solution, which Forney's formula on the combined locator gives as well.  Returns 0 (word corrected) or 1 (untouched). */
+static int
+rs63_syndromes(const int* word, int n2, int* S /* 1..n2 */) {
+    int any = 0;
+    for (int i = 1; i <= n2; i++) {
+        int s = 0;
+        for (int j = 0; j < 63; j++) {
+            if (word[j]) {
+                s ^= g_ex[(g_lg[word[j]] + i * j) % 63];
+            }
+        }
+        S[i] = s;
+        any |= s;
+    }
+    return any;
+}
+
+int
+orc_rs63_decode_erasures(int* word, int t, const int* erasures, int n_er) {
+    gf_init();
+    const int n2 = 2 * t;
+    if (n_er < 0 || n_er > n2) {
+        return 1;
+    }
+    int S[17] = {0};
+    if (n_er == 0) {
+        return rs63_syndromes(word, n2, S) ? 1 : 0;
+    }
+    uint8_t seen[63] = {0};
+    for (int i = 0; i < n_er; i++) {
+        if (erasures[i] < 0 || erasures[i] >= 63 || seen[erasures[i]]) {
+            return 1;
+        }
+        seen[erasures[i]] = 1;
+    }
+    if (!rs63_syndromes(word, n2, S)) {
+        return 0;
+    }
+    int G[18] = {1}; /* erasure locator prod (1 + alpha^pos x) */
+    for (int e = 0, deg = 0; e < n_er; e++, deg++) {
+        const int f = g_ex[erasures[e] % 63];
+        for (int i = deg; i >= 0; i--) {
+            G[i + 1] ^= gmul(G[i], f);
+        }
+    }
+    int M[17] = {0}; /* modified syndromes, index 0..n2-1 */
+    for (int i = 0; i < n2; i++) {
+        int v = 0;
+        for (int j = 0; j <= n_er && j <= i; j++) {
+            v ^= gmul(G[j], S[i - j + 1]);
+        }
+        M[i] = v;
+    }
+    /* Massey on M[n_er .. n2-1] */
+    const int ns = n2 - n_er;
+    const int* sy = M + n_er;
+    int C[18] = {1}, B[18] = {1}, T[18];
+    int L = 0, m = 1, bb = 1;
+    for (int n = 0; n < ns; n++) {
+        int d = sy[n];
+        for (int i = 1; i <= L; i++) {
+            d ^= gmul(C[i], sy[n - i]);
+        }
+        if (d == 0) {
+            m++;
+            continue;
+        }
+        memcpy(T, C, sizeof(T));
+        const int co = gdiv(d, bb);
+        for (int i = 0; i + m <= n2; i++) {
+            if (B[i]) {
+                C[i + m] ^= gmul(co, B[i]);
+            }
+        }
+        if (2 * L <= n) {
+            L = n + 1 - L;
+            memcpy(B, T, sizeof(T));
+            bb = d;
+            m = 1;
+        } else {
+            m++;
+        }
+    }
+    int udeg = 0;
+    for (int i = n2; i >= 0; i--) {
+        if (C[i]) {
+            udeg = i;
+            break;
+        }
+    }
+    if (2 * udeg + n_er > n2) {
+        return 1;
+    }
+    int gdeg = 0;
+    for (int i = n2; i >= 0; i--) {
+        if (G[i]) {
+            gdeg = i;
+            break;
+        }
+    }
+    if (gdeg + udeg > n2) {
+        return 1;
+    }
+    int Lam[18] = {0};
+    for (int i = 0; i <= gdeg; i++) {
+        for (int j = 0; j <= udeg; j++) {
+            Lam[i + j] ^= gmul(G[i], C[j]);
+        }
+    }
+    int ldeg = 0;
+    for (int i = n2; i >= 0; i--) {
+        if (Lam[i]) {
+            ldeg = i;
+            break;
+        }
+    }
+    int loc[17], nl = 0;
+    if (ldeg > 0) {
+        for (int p = 0; p < 63; p++) {
+            int v = 0;
+            for (int i = 0; i <= ldeg; i++) {
+                if (Lam[i]) {
+                    v ^= g_ex[(g_lg[Lam[i]] + i * ((63 - p) % 63)) % 63];
+                }
+            }
+            if (v == 0) {
+                if (nl >= n2) {
+                    nl++;
+                    break;
+                }
+                loc[nl++] = p;
+            }
+        }
+    }
+    if (nl != ldeg || nl > n2) {
+        return 1;
+    }
+    for (int i = 0; i < n_er; i++) {
+        int ok = 0;
+        for (int k = 0; k < nl; k++) {
+            ok |= (loc[k] == erasures[i]);
+        }
+        if (!ok) {
+            return 1;
+        }
+    }
+    /* errata values: Omega = S(x) Lam(x) mod x^2t, e = Omega(X^-1) / Lam'(X^-1) */
+    int Om[17] = {0};
+    for (int i = 0; i < n2; i++) {
+        int v = 0;
+        for (int j = 0; j <= i && j <= ldeg; j++) {
+            v ^= gmul(Lam[j], S[i - j + 1]);
+        }
+        Om[i] = v;
+    }
+    int out[63];
+    memcpy(out, word, sizeof(out));
+    for (int k = 0; k < nl; k++) {
+        const int xi = (63 - loc[k]) % 63;
+        int num = 0, den = 0;
+        for (int i = 0; i < n2; i++) {
+            if (Om[i]) {
+                num ^= g_ex[(g_lg[Om[i]] + i * xi) % 63];
+            }
+        }
+        for (int i = 1; i <= ldeg; i += 2) {
+            if (Lam[i]) {
+                den ^= g_ex[(g_lg[Lam[i]] + (i - 1) * xi) % 63];
+            }
+        }
+        if (den == 0) {
+            return 1;
+        }
+        out[loc[k]] ^= gdiv(num, den);
+    }
+    int S2[17];
+    if (rs63_syndromes(out, n2, S2)) {
+        return 1;
+    }
+    memcpy(word, out, sizeof(out));
+    return 0;
+}
+
+static void
+bits6_to_word(const uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int* w) {
+    memset(w, 0, 63 * sizeof(int));
+    for (int i = 0; i < n_par; i++) {
+        int v = 0;
+        for (int b = 0; b < 6; b++) {
+            v = (v << 1) | (parity6[6 * i + b] != 0);
+        }
+        w[i] = v;
+    }
+    for (int i = 0; i < n_data; i++) {
+        int v = 0;
+        for (int b = 0; b < 6; b++) {
+            v = (v << 1) | (data6[6 * i + b] != 0);
+        }
+        w[n_par + i] = v;
+    }
+}
+
+/* == check_and_fix_*_soft(data, parity, erasures, n) */
+int
+orc_p25_rs_decode_soft(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, const int* erasures,
+                       int n_er) {
+    int w[63];
+    bits6_to_word(data6, parity6, n_par, n_data, w);
+    /* the reference's hard attempt rewrites the data bits from the symbols whatever the outcome */
+    int h[63];
+    memcpy(h, w, sizeof(h));
+    const int hard = orc_rs63_decode(h, t);
+    for (int i = 0; i < n_data; i++) {
+        for (int b = 0; b < 6; b++) {
+            data6[6 * i + b] = (uint8_t)((h[n_par + i] >> (5 - b)) & 1);
+        }
+    }
+    if (hard == 0) {
+        return 0;
+    }
+    if (n_er <= 0 || n_er > 2 * t || erasures == NULL) {
+        return 1;
+    }
+    const int rc = orc_rs63_decode_erasures(w, t, erasures, n_er);
+    if (rc == 0) {
+        for (int i = 0; i < n_data; i++) {
+            for (int b = 0; b < 6; b++) {
+                data6[6 * i + b] = (uint8_t)((w[n_par + i] >> (5 - b)) & 1);
+            }
+        }
+    }
+    return rc;
+}
+
+/* == p25p1_build_rs_ranked_erasures(data_reliab, n_data, parity_reliab, n_par, min_erasures, out, max) with the default
+ * erasure threshold 64 (src/protocol/p25/phase1/p25p1_soft.cpp:20,141-168) */
+int
+orc_p25_rs_ranked_erasures(const uint8_t* data_rel, int n_data, const uint8_t* parity_rel, int n_par, int min_er,
+                           int* out, int max_er) {
+    int key[64], n = 0, hits = 0;
+    for (int i = 0; i < n_par && n < 64; i++) {
+        hits += parity_rel[i] < 64;
+        key[n++] = parity_rel[i] * 64 + i;
+    }
+    for (int i = 0; i < n_data && n < 64; i++) {
+        hits += data_rel[i] < 64;
+        key[n++] = data_rel[i] * 64 + (n_par + i);
+    }
+    for (int i = 1; i < n; i++) { /* (reliability, position) ascending */
+        const int k = key[i];
+        int j = i - 1;
+        while (j >= 0 && key[j] > k) {
+            key[j + 1] = key[j];
+            j--;
+        }
+        key[j + 1] = k;
+    }
+    int cnt = hits > min_er ? hits : min_er;
+    if (cnt > n) {
+        cnt = n;
+    }
+    if (cnt > max_er) {
+        cnt = max_er;
+    }
+    for (int i = 0; i < cnt; i++) {
+        out[i] = key[i] & 63;
+    }
+    return cnt;
+}
+
+/* == p25p1_rs_{24_12_13,24_16_9,36_20_17}_soft_reliability */
+int
+orc_p25_rs_soft_reliability(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_rel, const uint8_t* parity_rel,
+                            int n_par, int n_data, int t) {
+    int er[16];
+    const int nr = orc_p25_rs_ranked_erasures(data_rel, n_data, parity_rel, n_par, t, er, 2 * t);
+    uint8_t orig[20 * 6], cand[20 * 6];
+    memcpy(orig, data6, (size_t)n_data * 6);
+    for (int n = 1; n <= nr; n++) {
+        memcpy(cand, orig, (size_t)n_data * 6);
+        if (orc_p25_rs_decode_soft(cand, parity6, n_par, n_data, t, er, n) == 0) {
+            memcpy(data6, cand, (size_t)n_data * 6);
+            return 0;
+        }
+    }
+    return 1;
+}

@@ -215,3 +215,80 @@ def test_golay_soft_matches_reference(built, length):
         assert want == rc[i] and f.value == fx[i], (i, want, rc[i], f.value, fx[i])
         assert np.array_equal(x, got[i]), i
     assert rc.sum() > 0 and (rc == 0).sum() > n // 2
+
+
+def oracle_rs_soft_rel(code, data, par, drel, prel):
+    n_par, n_data, t = fecgen.P25_RS_CODES[code]
+    o = orc.oracle()
+    o.orc_p25_rs_soft_reliability.argtypes = [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int]
+    out = data.copy()
+    rc = np.zeros(data.shape[0], np.int32)
+    for i in range(data.shape[0]):
+        rc[i] = o.orc_p25_rs_soft_reliability(out[i].ctypes.data, par[i].ctypes.data, drel[i].ctypes.data,
+                                              prel[i].ctypes.data, n_par, n_data, t)
+    return out, rc
+
+
+def gen_rs_soft(rng, code, n):
+    """Codewords with up to 2t bad symbols; bad symbols mostly carry low reliability (so erasures help), some do not."""
+    n_par, n_data, t = fecgen.P25_RS_CODES[code]
+    data = np.zeros((n, n_data, 6), np.uint8)
+    par = np.zeros((n, n_par, 6), np.uint8)
+    drel = rng.integers(64, 256, (n, n_data)).astype(np.uint8)
+    prel = rng.integers(64, 256, (n, n_par)).astype(np.uint8)
+    for i in range(n):
+        d = rng.integers(0, 64, n_data)
+        w = np.array(list(fecgen.rs63_encode(d, t)) + list(d))
+        ne = int(rng.integers(0, 2 * t + 3))
+        pos = rng.choice(n_par + n_data, min(ne, n_par + n_data), replace=False)
+        w[pos] ^= rng.integers(1, 64, len(pos))
+        for q in pos:
+            low = rng.random() < 0.8
+            v = int(rng.integers(0, 64)) if low else int(rng.integers(64, 256))
+            if q < n_par:
+                prel[i, q] = v
+            else:
+                drel[i, q - n_par] = v
+        par[i] = fecgen.syms_to_bits6(w[:n_par])
+        data[i] = fecgen.syms_to_bits6(w[n_par:])
+    return data, par, drel, prel
+
+
+@needs_ref
+@pytest.mark.parametrize("code", list(fecgen.P25_RS_CODES))
+def test_rs_soft_reliability_matches_reference(built, code):
+    r = orc.ref()
+    fn = {"24_12_13": r.p25p1_rs_24_12_13_soft_reliability, "24_16_9": r.p25p1_rs_24_16_9_soft_reliability,
+          "36_20_17": r.p25p1_rs_36_20_17_soft_reliability}[code]
+    fn.argtypes = [VP, VP, VP, VP]
+    rng = np.random.default_rng(200 + len(code))
+    d, p, drel, prel = gen_rs_soft(rng, code, 1500)
+    got, rc = oracle_rs_soft_rel(code, d, p, drel, prel)
+    for i in range(len(d)):
+        x = d[i].copy()
+        want = fn(x.ctypes.data, p[i].ctypes.data, drel[i].ctypes.data, prel[i].ctypes.data)
+        assert want == rc[i], (i, want, rc[i])
+        assert np.array_equal(x, got[i]), i
+    assert 0 < rc.sum() < len(rc)
+
+
+@needs_ref
+def test_rs_explicit_erasures_match_reference(built):
+    """check_and_fix_*_soft with caller-given erasure lists, incl. duplicates / out-of-range / too many."""
+    r, o = orc.ref(), orc.oracle()
+    o.orc_p25_rs_decode_soft.argtypes = [VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int]
+    rng = np.random.default_rng(300)
+    fns = {"24_12_13": r.check_and_fix_reedsolomon_24_12_13_soft, "24_16_9": r.check_and_fix_reedsolomon_24_16_9_soft,
+           "36_20_17": r.check_and_fix_redsolomon_36_20_17_soft}
+    for code, fn in fns.items():
+        fn.argtypes = [VP, VP, VP, C.c_int]
+        n_par, n_data, t = fecgen.P25_RS_CODES[code]
+        d, p = fecgen.gen_p25_rs(rng, code, 800, max_extra=t)
+        for i in range(len(d)):
+            ne = int(rng.integers(0, 2 * t + 2))
+            er = rng.integers(0, n_par + n_data + (3 if i % 17 == 0 else 0), ne).astype(np.int32)   # may repeat / overflow
+            a, b = d[i].copy(), d[i].copy()
+            want = fn(a.ctypes.data, p[i].ctypes.data, er.ctypes.data if ne else None, ne)
+            got = o.orc_p25_rs_decode_soft(b.ctypes.data, p[i].ctypes.data, n_par, n_data, t, er.ctypes.data if ne else None, ne)
+            assert want == got, (code, i, want, got, ne)
+            assert np.array_equal(a, b), (code, i)

@@ -122,3 +122,25 @@ def test_golay_soft_batch(built, length):
     f = C.c_int(-1)
     assert fn(x.ctypes.data, p[5].ctypes.data, rel[5].ctypes.data, C.byref(f)) == wrc[5]
     assert f.value == wfx[5] and np.array_equal(x, want[5])
+
+
+@pytest.mark.parametrize("code", list(fecgen.P25_RS_CODES))
+def test_rs_soft_reliability_batch(built, code):
+    """Hard decode, then ranked-erasure retries: data and status equal the oracle pinned to p25p1_rs_*_soft_reliability."""
+    from test_oracle_rs import gen_rs_soft, oracle_rs_soft_rel
+    rng = np.random.default_rng(400 + CODE_ID[code])
+    d, p, drel, prel = gen_rs_soft(rng, code, 4000)
+    want, wrc = oracle_rs_soft_rel(code, d, p, drel, prel)
+    got = d.copy()
+    st = np.zeros(len(d), np.uint8)
+    assert ddn.lib().ddn_fec_p25_rs_soft_host(CODE_ID[code], got.ctypes.data, p.ctypes.data, drel.ctypes.data,
+                                              prel.ctypes.data, len(d), st.ctypes.data) == 0
+    assert np.array_equal(st, wrc)
+    assert np.array_equal(got, want)
+    assert 0 < st.sum() < len(st)
+    fn = {"24_12_13": ddn.lib().p25p1_rs_24_12_13_soft_reliability, "24_16_9": ddn.lib().p25p1_rs_24_16_9_soft_reliability,
+          "36_20_17": ddn.lib().p25p1_rs_36_20_17_soft_reliability}[code]
+    for i in (0, 1, 2, 3):
+        x = d[i].copy()
+        assert fn(x.ctypes.data, p[i].ctypes.data, drel[i].ctypes.data, prel[i].ctypes.data) == wrc[i]
+        assert np.array_equal(x, want[i])
