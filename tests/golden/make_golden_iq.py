@@ -1,0 +1,16 @@
+"""Copies two of the reference's own I/Q regression captures (data files under tests/fixtures/iq, cu8 @48 ksps) into
+tests/golden together with the known answers the reference's full-chain tests assert on them
+(tests/CMakeLists.txt:8888-8900: DECODE_IQ_P25P1_C4FM_CC expects "NAC/CC: 140", DECODE_IQ_P25P1_C4FM_VOICE expects
+"Group Voice Channel User", i.e. a voice call: LDU1/LDU2 frames).  Run in the build container only."""
+import os
+
+import numpy as np
+
+SRC = "/root/reference/tests/fixtures/iq"
+HERE = os.path.dirname(os.path.abspath(__file__))
+for name, nac_hex, note in (("p25p1_c4fm_cc", "140", "control channel: TSDU frames, expected payload field NAC/CC: 140"),
+                            ("p25p1_c4fm_vc", "", "voice channel: LDU1/LDU2 frames (Group Voice Channel User)")):
+    iq = np.fromfile(os.path.join(SRC, name + ".iq"), dtype=np.uint8).reshape(-1, 2)
+    np.savez_compressed(os.path.join(HERE, "iq_%s.npz" % name), iq=iq, rate=np.int32(48000),
+                        expected_nac_hex=np.bytes_(nac_hex), note=np.bytes_(note))
+    print(name, iq.shape)
