@@ -88,3 +88,72 @@ def test_real_capture_gpu_equals_oracle(built, name, lock):
 
     rows = nids_from_records(r4, fl[0], k)
     assert np.array_equal(decode_nids(rows, gpu_nid), decode_nids(rows, oracle_nid))
+
+
+# ---- CQPSK control-channel capture: the reference's full-chain test expects "WACN: 92065; SYS: 0D5" ----------------
+FS = np.array([int(c) for c in "111113113311333313133333"])
+
+
+def crc16_tsbk_ok(by12):
+    """TSBK CRC: CCITT x^16+x^12+x^5+1 over the first 80 bits, inverted, in the last two bytes (TIA-102.AABB)."""
+    bits = np.unpackbits(np.asarray(by12, np.uint8))
+    reg = 0
+    for b in bits[:80]:
+        fb = ((reg >> 15) & 1) ^ int(b)
+        reg = (reg << 1) & 0xFFFF
+        if fb:
+            reg ^= 0x1021
+    return (reg ^ 0xFFFF) == ((int(by12[10]) << 8) | int(by12[11]))
+
+
+def cqpsk_tsbk_inputs(sym):
+    """symbols -> fixed 4-level slice (frame_sync_slice_cqpsk_dibit, src/dsp/dsd_frame_sync.c:2076-2088, centre 0) ->
+    frame syncs -> per TSDU the 98 coded dibits as hard LLR pairs (+-100)."""
+    import p25gen
+    d = np.where(sym >= 2, 1, np.where(sym >= 0, 0, np.where(sym >= -2, 2, 3))).astype(np.int64)
+    hits = [i for i in range(len(d) - 180) if np.array_equal(d[i:i + 24], FS)]
+    bp = np.array(p25gen.block_positions())
+    llr = np.zeros((len(hits), 196), np.int16)
+    for k, h in enumerate(hits):
+        blk = d[h + bp]
+        llr[k, 0::2] = np.where((blk >> 1) & 1, 100, -100)
+        llr[k, 1::2] = np.where(blk & 1, 100, -100)
+    return hits, llr
+
+
+def check_cqpsk_payload(hits, blocks):
+    assert len(hits) >= 50 and np.all(np.diff(hits) % 180 == 0)       # TSDUs of one or two blocks
+    assert all(crc16_tsbk_ok(b) for b in blocks)
+    net = [b for b in blocks if (int(b[0]) & 0x3F) == 0x3B]          # Network Status Broadcast
+    assert len(net) >= 3
+    for b in net:
+        wacn = (int(b[3]) << 12) | (int(b[4]) << 4) | (int(b[5]) >> 4)
+        sysid = ((int(b[5]) & 0xF) << 8) | int(b[6])
+        assert (wacn, sysid) == (0x92065, 0x0D5)
+
+
+def test_cqpsk_control_channel_capture_decodes_reference_wacn_sysid(built):
+    import fecgen
+    g = golden("iq_p25p1_cqpsk_cc.npz")
+    x = ((g["iq"].astype(np.float32) - 127.5) * np.float32(1.0 / 127.5)).astype(np.float32)
+    sym = orc.OracleCqpskFe(rate=48000).run(x, 8192)
+    hits, llr = cqpsk_tsbk_inputs(sym)
+    blocks, _ = fecgen.oracle_p25_half_rate(llr)
+    check_cqpsk_payload(hits, blocks)
+
+
+@pytest.mark.gpu
+def test_cqpsk_real_capture_gpu(built):
+    import ddn
+    g = golden("iq_p25p1_cqpsk_cc.npz")
+    iq = np.ascontiguousarray(g["iq"])
+    x = ((iq.astype(np.float32) - 127.5) * np.float32(1.0 / 127.5)).astype(np.float32)
+    want = orc.OracleCqpskFe(rate=48000).run(x, 8192)
+    b = ddn.CqpskBatch(1, rate=48000, block_len=8192, input_format=ddn.IN_CU8)
+    sym, cnt = b.run(iq[None])
+    assert cnt[0] == len(want) and np.array_equal(sym[0, :cnt[0]].view(np.uint32), want.view(np.uint32))
+    hits, llr = cqpsk_tsbk_inputs(sym[0, :cnt[0]])
+    out = np.zeros((len(hits), 12), np.uint8)
+    met = np.zeros(len(hits), np.int32)
+    assert ddn.lib().ddn_fec_p25_12_soft_host(llr.ctypes.data, len(hits), out.ctypes.data, met.ctypes.data) == 0
+    check_cqpsk_payload(hits, out)
