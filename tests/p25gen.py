@@ -107,3 +107,49 @@ def expected_half_rate_output(states):
     rx[:, 1::2] = llr_dei[:, 2 * il + 1]
     out, _ = fecgen.oracle_p25_half_rate(np.ascontiguousarray(rx))
     return out
+
+
+# ---- LDU1 field map (reading order of src/protocol/p25/phase1/p25p1_ldu1.c:185-216; status dibit after every 35) ----
+def ldu1_positions():
+    """Frame dibit indices (0 = first dibit of the frame sync) of the 24 Hamming(10,6,3) words of an LDU1:
+    returns (data_pos[12][5], parity_pos[12][5]) with word index as in hex_data[w] / hex_parity[w]; each word is
+    3 data dibits then 2 parity dibits, dibit bit 1 first."""
+    idx = 57                                   # 24 FS + 33 NID (incl. its status dibit)
+
+    def take(n):
+        nonlocal idx
+        out = []
+        while len(out) < n:
+            if idx % 36 == 35:
+                idx += 1                       # status symbol
+                continue
+            out.append(idx)
+            idx += 1
+        return out
+
+    data = [None] * 12
+    par = [None] * 12
+    take(72)
+    take(72)
+    for w in (11, 10, 9, 8):
+        data[w] = take(5)
+    take(72)
+    for w in (7, 6, 5, 4):
+        data[w] = take(5)
+    take(72)
+    for w in (3, 2, 1, 0):
+        data[w] = take(5)
+    take(72)
+    for w in (11, 10, 9, 8):
+        par[w] = take(5)
+    take(72)
+    for w in (7, 6, 5, 4):
+        par[w] = take(5)
+    take(72)
+    for w in (3, 2, 1, 0):
+        par[w] = take(5)
+    take(72)
+    take(16)
+    take(72)
+    assert idx in (863, 864)
+    return np.array(data), np.array(par)

@@ -157,3 +157,96 @@ def test_cqpsk_real_capture_gpu(built):
     met = np.zeros(len(hits), np.int32)
     assert ddn.lib().ddn_fec_p25_12_soft_host(llr.ctypes.data, len(hits), out.ctypes.data, met.ctypes.data) == 0
     check_cqpsk_payload(hits, out)
+
+
+# ---- voice capture: LDU1 link control through Hamming(10,6,3) + RS(24,12,13) -----------------------------------------
+def ldu1_words(rec4, fl, count):
+    """-> for every LDU1 of the capture: (bits10 [24,10] (12 data words then 12 parity words), reliab [24,10])."""
+    import p25gen
+    dpos, ppos = p25gen.ldu1_positions()
+    pos = np.concatenate([dpos, ppos]) - 24            # relative to the first dibit after the sync
+    rows = nids_from_records(rec4, fl, count)
+    nid = decode_nids(rows, oracle_nid)
+    out = []
+    for (a, _, _), n in zip(rows, nid):
+        if n[0] != 1 or n[2] != 5 or a + 1 + 840 > count:
+            continue
+        d = rec4[a + 1:a + 1 + 840]
+        w = d[pos]                                      # [24, 5, 4]
+        bits = np.stack([(w[:, :, 0] >> 1) & 1, w[:, :, 0] & 1], axis=2).reshape(24, 10).astype(np.uint8)
+        rel = np.stack([np.abs(w[:, :, 2]), np.abs(w[:, :, 3])], axis=2).reshape(24, 10).astype(np.int32)
+        out.append((bits, rel))
+    return out
+
+
+def link_control(words, hamming_hard, rs_decode):
+    """The reference's order: Hamming per hex word (p25p1_ldu.c:189-221), then RS(24,12,13) over the 12 + 12 words
+    (p25p1_ldu1.c:233-245).  Returns the 72 link-control bits, most significant hex word first."""
+    bits, _ = words
+    fixed, errs = hamming_hard(np.ascontiguousarray(bits))
+    assert np.all(errs < 2)                             # clean capture: nothing the hard decoder cannot fix
+    data = np.ascontiguousarray(fixed[:12, :6].reshape(1, 12, 6))
+    par = np.ascontiguousarray(fixed[12:, :6].reshape(1, 12, 6))
+    out, rc = rs_decode(data, par)
+    assert rc[0] == 0
+    return out[0][::-1].reshape(72)                     # hex_data[11] is the first word on the air
+
+
+def _oracle_hamming(bits):
+    import ctypes as C
+    o = orc.oracle()
+    o.orc_hamming_10_6_3.argtypes = [C.c_int, C.c_void_p]
+    out = bits.copy()
+    errs = np.zeros(len(bits), np.int32)
+    for i in range(len(bits)):
+        w = 0
+        for b in bits[i]:
+            w = (w << 1) | int(b)
+        f = C.c_int(0)
+        errs[i] = o.orc_hamming_10_6_3(w, C.byref(f))
+        if errs[i] == 1:
+            out[i, :6] = [(f.value >> (5 - k)) & 1 for k in range(6)]
+    return out, errs
+
+
+def _check_lc(lcs):
+    assert len(lcs) >= 4
+    for lc in lcs:
+        lcf = int("".join(map(str, lc[:8])), 2)
+        mfid = int("".join(map(str, lc[8:16])), 2)
+        assert lcf == 0x00 and mfid == 0x00            # "Group Voice Channel User" (TIA-102.AABF LCO 0)
+    tg = {int("".join(map(str, lc[32:48])), 2) for lc in lcs}
+    src = {int("".join(map(str, lc[48:72])), 2) for lc in lcs}
+    assert len(tg) == 1 and len(src) == 1 and tg != {0} and src != {0}    # one call: same talkgroup and source throughout
+
+
+def test_voice_capture_link_control_is_group_voice_channel_user(built):
+    from test_oracle_rs import oracle_rs
+    g = golden("iq_p25p1_c4fm_vc.npz")
+    _, sym, rec4, fl = oracle_chain(g["iq"], 840)
+    lcs = [link_control(w, _oracle_hamming, lambda d, p: oracle_rs("24_12_13", d, p)) for w in ldu1_words(rec4, fl, len(sym))]
+    _check_lc(lcs)
+
+
+@pytest.mark.gpu
+def test_voice_capture_link_control_gpu(built):
+    import ddn
+    g = golden("iq_p25p1_c4fm_vc.npz")
+    iq = np.ascontiguousarray(g["iq"])
+    disc = ddn.Batch(1, block_len=8192).run_host(iq[None], iq.shape[0])
+    rec, fl, cnt = ddn.P25Rx(1, lock_symbols=840, use_matched_filter=1).run(disc)
+    r4, _ = orc.unpack_records10(rec[0, :cnt[0]])
+
+    def gpu_hamming(bits):
+        b = bits.copy()
+        e = np.zeros(len(b), np.uint8)
+        assert ddn.lib().ddn_fec_hamming_10_6_3_host(b.ctypes.data, len(b), e.ctypes.data) == 0
+        return b, e
+
+    def gpu_rs(d, p):
+        x = d.copy()
+        st = np.zeros(len(d), np.uint8)
+        assert ddn.lib().ddn_fec_p25_rs_host(0, x.ctypes.data, p.ctypes.data, len(d), st.ctypes.data) == 0
+        return x, st
+
+    _check_lc([link_control(w, gpu_hamming, gpu_rs) for w in ldu1_words(r4, fl[0], int(cnt[0]))])
