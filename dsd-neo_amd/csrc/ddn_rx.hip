@@ -39,6 +39,7 @@ constexpr int TS = 64;       // samples per staged tile
 constexpr int SS = 128;      // opts->ssize
 constexpr int MS = 1024;     // opts->msize
 constexpr int NT = DDN_P25_FILTER_TAPS;
+constexpr int QCAP = 10;     // symbols one lane can finish inside one 64-sample tile when sps >= 8 (64 / 7 + 1)
 constexpr uint32_t kSyncBits = 0xFB30A0u; // P25P1_SYNC as sign bits, oldest symbol in bit 23
 
 __constant__ uint32_t c_taps[NT];
@@ -51,6 +52,11 @@ struct Lds {
     float sh[24][CPW];
     float raw[2][CPW][TS + 1];
     float flt[2][CPW][TS + 1];
+    // symbol queue wave 0 -> wave 1 (soft decisions + record stores happen off the recurrence's critical path):
+    // per tile and lane up to QCAP symbols of {symbol, center, umid, lmid, max, min, flags}; qn = count, qo = first index
+    float q[2][QCAP][7][CPW];
+    int qn[2][CPW];
+    int qo[2][CPW];
 };
 } // namespace
 
@@ -148,14 +154,60 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
     uint8_t* fp = flags + (size_t)(live ? ch : 0) * max_sym;
     const long long abs0 = s.n_abs;
 
+    // With >= 8 samples per symbol a tile yields at most QCAP symbols per lane, and the slice / soft-decision /
+    // record-store work (a third of the per-symbol instructions, none of it feeding back) moves to wave 1.
+    const bool offload = whole >= 8 && !(cfg.dbg & 16);
+    const bool hlive = loader && lane < CPW && ch < n_channels;
+    uint8_t* hrp = rec + (size_t)(hlive ? ch : 0) * max_sym * 10;
+    uint8_t* hfp = flags + (size_t)(hlive ? ch : 0) * max_sym;
+    auto drain = [&](int qb) {
+        if (!hlive) {
+            return;
+        }
+        const int cnt = L.qn[qb][ln], o0 = L.qo[qb][ln];
+        for (int k = 0; k < QCAP; k++) {
+            if (k >= cnt) {
+                break;
+            }
+            const float sym = L.q[qb][k][0][ln];
+            const int fl = __float_as_int(L.q[qb][k][6][ln]);
+            int dibit, relb = 0, l0 = 0, l1 = 0;
+            if (fl & 1) {
+                const ddn_sl::Thr th = {L.q[qb][k][1][ln], L.q[qb][k][2][ln], L.q[qb][k][3][ln], L.q[qb][k][4][ln],
+                                        L.q[qb][k][5][ln]};
+                ddn_sl::slice_soft(sym, th, (fl >> 2) & 1, dibit, relb, l0, l1);
+            } else {
+                dibit = sym > 0.0f ? 1 : 3;
+            }
+            const size_t oo = (size_t)(o0 + k);
+            if (oo < max_sym) {
+                uint8_t* r = hrp + oo * 10;
+                const uint32_t xb = __float_as_uint(sym);
+                ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
+                ((uint16_t*)r)[1] = (uint16_t)(int16_t)l0;
+                ((uint16_t*)r)[2] = (uint16_t)(int16_t)l1;
+                ((uint16_t*)r)[3] = (uint16_t)(xb & 0xFFFFu);
+                ((uint16_t*)r)[4] = (uint16_t)(xb >> 16);
+                hfp[oo] = (uint8_t)fl;
+            }
+        }
+    };
     int buf = 0;
-    for (long t0 = 0; t0 < n; t0 += TS, buf ^= 1) {
+    int it = 0;
+    for (long t0 = 0; t0 < n; t0 += TS, buf ^= 1, it++) {
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
         if (loader) {
             if (t0 + TS < n) {
                 stage(t0 + TS, buf ^ 1);
             }
+            if (offload && it > 0) {
+                drain((it - 1) & 1);
+            }
         } else {
+            int qk = 0;
+            if (live && offload) {
+                L.qo[it & 1][ln] = o;
+            }
             int sp = 0; // this lane's cursor in the tile
             int guard = 0;
             while (true) {
@@ -313,9 +365,18 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                         s.maxref = s.max * 0.80f;
                         s.minref = s.min * 0.80f;
                         s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
-                        const ddn_sl::Thr th = {s.center, s.umid, s.lmid, s.max, s.min};
-                        ddn_sl::slice_soft(sym, th, neg, dibit, relb, l0, l1);
                         fl = 1 | (neg ? 4 : 0);
+                        if (offload) {
+                            L.q[it & 1][qk][1][ln] = s.center;
+                            L.q[it & 1][qk][2][ln] = s.umid;
+                            L.q[it & 1][qk][3][ln] = s.lmid;
+                            L.q[it & 1][qk][4][ln] = s.max;
+                            L.q[it & 1][qk][5][ln] = s.min;
+                            dibit = 0;
+                        } else {
+                            const ddn_sl::Thr th = {s.center, s.umid, s.lmid, s.max, s.min};
+                            ddn_sl::slice_soft(sym, th, neg, dibit, relb, l0, l1);
+                        }
                         if (--s.lock_left <= 0) {
                             s.have_sync = 0;
                             s.lidx = 0;
@@ -433,7 +494,11 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                             }
                         }
                     }
-                    if ((size_t)o < max_sym && !(cfg.dbg & 2)) {
+                    if (offload) {
+                        L.q[it & 1][qk][0][ln] = sym;
+                        L.q[it & 1][qk][6][ln] = __int_as_float(fl);
+                        qk++;
+                    } else if ((size_t)o < max_sym && !(cfg.dbg & 2)) {
                         uint8_t* r = rp + (size_t)o * 10;
                         const uint32_t xb = __float_as_uint(sym);
                         ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
@@ -450,8 +515,14 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                     break;
                 }
             }
+            if (live && offload) {
+                L.qn[it & 1][ln] = qk;
+            }
         }
         __syncthreads();
+    }
+    if (loader && offload && it > 0) {
+        drain((it - 1) & 1);
     }
     if (live) {
         s.n_abs = abs0 + n;
