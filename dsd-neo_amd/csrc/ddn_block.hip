@@ -293,7 +293,7 @@ chase_from(const Gf& gf, const Work& wk, uint64_t base, const uint8_t* rel, uint
 __global__ __launch_bounds__(64) void
 k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel63, const int32_t* __restrict__ obs_nac,
              const uint8_t* __restrict__ parity, const uint8_t* __restrict__ parity_rel, int threshold, int n,
-             int32_t* __restrict__ out4) {
+             int32_t* __restrict__ out4, int32_t* __restrict__ chase_list, int32_t* __restrict__ chase_count) {
     __shared__ uint8_t ex[128];
     __shared__ uint8_t lg[64];
     __shared__ uint8_t work[(23 + 24 + 24 + 24) * 64];
@@ -324,7 +324,10 @@ k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel
         hard = nid_codeword(gf, wk, put_nac(w, obs), par, nullptr);
     }
     NidRes res = hard;
-    if (hard.status <= 0 && rel63) {
+    if (hard.status <= 0 && rel63 && chase_list) {
+        // the Chase search runs in k_nid_chase, one wavefront per NID with one candidate per lane
+        chase_list[atomicAdd(chase_count, 1)] = c;
+    } else if (hard.status <= 0 && rel63) {
         const uint8_t* rel = rel63 + (size_t)c * 63; // read in place (L1/L2-resident, 63 bytes per lane)
         // the 8 least reliable positions in (reliability, index) order; pool = first max(6, min(8, #below thr))
         uint64_t pool = 0; // 8 positions, one per byte
@@ -408,14 +411,160 @@ k_hamming_10_6_3(uint8_t* __restrict__ bits10, int n, uint8_t* __restrict__ errs
     errs[c] = (uint8_t)e;
 }
 
+// Chase search of one NID per wavefront: lane t evaluates candidate t of the reference's sequence (base word, then the
+// base with the observed NAC written in; masks of <= 3 flips over the np least reliable bits in increasing order) and a
+// wave-wide minimum over the packed key (score, status != 1, error count, flips, sequence index) picks what the
+// reference's sequential "strictly better" scan would have kept (src/protocol/p25/phase1/p25p1_check_nid.cpp:204-322).
+__global__ __launch_bounds__(64) void
+k_nid_chase(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel63, const int32_t* __restrict__ obs_nac,
+            const uint8_t* __restrict__ parity, const uint8_t* __restrict__ parity_rel, int threshold,
+            const int32_t* __restrict__ chase_list, const int32_t* __restrict__ chase_count, int32_t* __restrict__ out4) {
+    __shared__ uint8_t ex[128];
+    __shared__ uint8_t lg[64];
+    __shared__ uint8_t work[(23 + 24 + 24 + 24) * 64];
+    __shared__ uint8_t masks[96];
+    if ((int)blockIdx.x >= *chase_count) {
+        return;
+    }
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        gf_fill(ex, lg);
+        int k = 0;
+        for (int m = 0; m < 256; m++) { // masks with at most three flips, increasing: 93 of them (42 below 64, 64 below 128)
+            if (__popc((unsigned)m) <= 3) {
+                masks[k++] = (uint8_t)m;
+            }
+        }
+    }
+    __syncthreads();
+    const Gf gf = {ex, lg};
+    const Work wk = {work + lane, work + 23 * 64 + lane, work + 47 * 64 + lane, work + 71 * 64 + lane};
+    const int c = chase_list[blockIdx.x];
+    const uint8_t* bp = bits63 + (size_t)c * 63;
+    const uint8_t* rel = rel63 + (size_t)c * 63;
+    uint64_t w = 0;
+    for (int p = 0; p < 63; p++) {
+        w |= (uint64_t)(bp[p] ? 1 : 0) << p;
+    }
+    const int par = parity ? (parity[c] ? 1 : 0) : 0;
+    const int prel = parity_rel ? parity_rel[c] : 0;
+    const int obs = obs_nac ? obs_nac[c] : 0;
+    const bool two_bases = obs > 0 && obs < 0xFFF && rx_nac(w) != obs;
+    uint64_t pool = 0, taken = 0;
+    int below = 0;
+    for (int i = 0; i < 63; i++) {
+        below += rel[i] < threshold;
+    }
+    for (int k = 0; k < 8; k++) {
+        int bi = -1, bv = 256;
+        for (int i = 0; i < 63; i++) {
+            if (!((taken >> i) & 1) && rel[i] < bv) {
+                bv = rel[i];
+                bi = i;
+            }
+        }
+        pool |= (uint64_t)bi << (8 * k);
+        taken |= 1ull << bi;
+    }
+    int np = below < 8 ? below : 8;
+    np = np < 6 ? 6 : np;
+    const int per_base = (np == 6) ? 42 : ((np == 7) ? 64 : 93);
+    const int total = two_bases ? 2 * per_base : per_base;
+    uint32_t best_key = 0xFFFFFFFFu;
+    NidRes best_dec = {0, 0, 0, 0};
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        uint32_t key = 0xFFFFFFFFu;
+        NidRes dec = {0, 0, 0, 0};
+        bool run = t < total;
+        int mask = 0, base_idx = 0, changed = 0, score = 0;
+        uint64_t cand = w;
+        if (run) {
+            base_idx = t / per_base;
+            mask = masks[t - base_idx * per_base];
+            changed = __popc((unsigned)mask);
+            cand = base_idx ? put_nac(w, obs) : w;
+            for (int b = 0; b < np; b++) {
+                if (mask & (1 << b)) {
+                    const int pos = (int)((pool >> (8 * b)) & 0xFF);
+                    cand ^= 1ull << pos;
+                    score += rel[pos];
+                }
+            }
+            run = !(changed && score > threshold * changed);
+        }
+        if (__any(run)) {
+            if (run) {
+                dec = nid_codeword(gf, wk, cand, par, nullptr);
+            }
+            if (run && dec.status > 0) {
+                const int sc = score + (dec.status == 2 ? prel : 0);
+                key = ((uint32_t)sc << 18) | ((uint32_t)(dec.status != 1) << 17) | ((uint32_t)(dec.errs & 63) << 11)
+                      | ((uint32_t)changed << 9) | (uint32_t)(base_idx * 256 + mask);
+            }
+        }
+        if (key < best_key) {
+            best_key = key;
+            best_dec = dec;
+        }
+    }
+    // wave minimum of the (unique) keys, then the owning lane publishes its decode
+    uint32_t m = best_key;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(m, off);
+        m = o < m ? o : m;
+    }
+    if (m != 0xFFFFFFFFu && best_key == m) {
+        int32_t* o = out4 + (size_t)c * 4;
+        o[0] = best_dec.status;
+        o[1] = best_dec.nac;
+        o[2] = best_dec.duid;
+        o[3] = best_dec.errs;
+    }
+}
+
 extern "C" hipError_t
 ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
                    const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
     }
+    // pass 1: hard decode (+ observed-NAC retry) for every NID, NIDs that need the Chase search are listed;
+    // pass 2: one wavefront per listed NID.  The list and its counter live in a grow-only scratch buffer.
+    static int32_t* scratch = nullptr;
+    static size_t scratch_cap = 0;
+    int32_t *list = nullptr, *count = nullptr;
+    if (rel63) {
+        if (scratch_cap < (size_t)n + 1) {
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                return e;
+            }
+            (void)hipFree(scratch);
+            scratch = nullptr;
+            scratch_cap = 0;
+            e = hipMalloc(&scratch, sizeof(int32_t) * ((size_t)n + 1));
+            if (e != hipSuccess) {
+                return e;
+            }
+            scratch_cap = (size_t)n + 1;
+        }
+        count = scratch;
+        list = scratch + 1;
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
     hipLaunchKernelGGL(k_nid_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, bits63, rel63, obs_nac, parity,
-                       parity_rel, threshold, n, out4);
+                       parity_rel, threshold, n, out4, list, count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !rel63) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_nid_chase, dim3((unsigned)n), dim3(64), 0, st, bits63, rel63, obs_nac, parity, parity_rel,
+                       threshold, (const int32_t*)list, (const int32_t*)count, out4);
     return hipGetLastError();
 }
 
