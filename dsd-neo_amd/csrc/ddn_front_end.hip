@@ -174,6 +174,7 @@ k_front_end_fused(DdnFusedArgs a) {
     __shared__ __attribute__((aligned(16))) float Pb[2][G][FS]; // peak to divide by
     __shared__ f2 chan_last[2][G];                              // last LPF output of the previous tile
     __shared__ int tflag[3][G];
+    __shared__ float gmin[3][G][TT / 8 + 1]; // min |centred| of each 8-sample group, written by S1 for S2's guard test
     __shared__ int next_item; // filter work-item counter of the current tile // per tile/channel: 1 = squelched (zeros + modem reset), 2 = first sample skipped
     __shared__ __attribute__((aligned(8))) float stap[DDN_MAX_CENTER + 4];
     extern __shared__ f2 ysq[]; // [G][256] first LPF outputs of a block (squelch builds only)
@@ -609,6 +610,10 @@ k_front_end_fused(DdnFusedArgs a) {
                         }
                         *(f4*)&F[t] = ca;
                         *(f4*)&F[t + 4] = cb;
+                        // the peak wave's rare-guard test needs min |centred| of this group; this wave has the slack
+                        gmin[bf][g][t >> 3] =
+                            fminf(fminf(fminf(fabsf(ca[0]), fabsf(ca[1])), fminf(fabsf(ca[2]), fabsf(ca[3]))),
+                                  fminf(fminf(fabsf(cb[0]), fabsf(cb[1])), fminf(fabsf(cb[2]), fabsf(cb[3]))));
                         fa = na;
                         fb = nb;
                     }
@@ -670,9 +675,8 @@ k_front_end_fused(DdnFusedArgs a) {
                         // Did a rare guard fire in this group?  Every new peak lies between the old peak and
                         // |centred| (monotone rounding), so "old peak > 1e-7 and every |centred| > 1e-7" rules
                         // both guards out; non-finite values also replay (fmaxf drops NaNs).
-                        const float m0 = fminf(fminf(fabsf(fa[0]), fabsf(fa[1])), fminf(fabsf(fa[2]), fabsf(fa[3])));
-                        const float m1 = fminf(fminf(fabsf(fb[0]), fabsf(fb[1])), fminf(fabsf(fb[2]), fabsf(fb[3])));
-                        if (!(fminf(fminf(m0, m1), pk0) > 1.0e-7f) || !(peak <= 3.0e38f)) {
+                        const float gm = gmin[bf][g][t >> 3]; // min |centred| of this group, from the dc wave
+                        if (!(fminf(gm, pk0) > 1.0e-7f) || !(peak <= 3.0e38f)) {
                             peak = pk0;
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
