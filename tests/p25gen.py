@@ -153,3 +153,19 @@ def ldu1_positions():
     take(72)
     assert idx in (863, 864)
     return np.array(data), np.array(par)
+
+
+def ldu2_positions():
+    """LDU2 (src/protocol/p25/phase1/p25p1_ldu2.c:211-236): same slot map as LDU1, 16 data words (hex_data[15..0]) in
+    the first four slots and 8 parity words (hex_parity[7..0]) in the next two."""
+    d1, p1 = ldu1_positions()
+    slots = [d1[[11, 10, 9, 8]], d1[[7, 6, 5, 4]], d1[[3, 2, 1, 0]], p1[[11, 10, 9, 8]], p1[[7, 6, 5, 4]], p1[[3, 2, 1, 0]]]
+    data = [None] * 16
+    par = [None] * 8
+    for s in range(4):
+        for k in range(4):
+            data[15 - 4 * s - k] = slots[s][k]
+    for s in range(2):
+        for k in range(4):
+            par[7 - 4 * s - k] = slots[4 + s][k]
+    return np.array(data), np.array(par)

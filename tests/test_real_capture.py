@@ -250,3 +250,68 @@ def test_voice_capture_link_control_gpu(built):
         return x, st
 
     _check_lc([link_control(w, gpu_hamming, gpu_rs) for w in ldu1_words(r4, fl[0], int(cnt[0]))])
+
+
+def ldu2_ess(rec4, fl, count, hamming_hard, rs_decode):
+    """Every LDU2 of the capture -> (algid, kid, mi bits) after Hamming(10,6,3) + RS(24,16,9)
+    (src/protocol/p25/phase1/p25p1_ldu2.c:141-170,256-262)."""
+    import p25gen
+    dpos, ppos = p25gen.ldu2_positions()
+    pos = np.concatenate([dpos, ppos]) - 24
+    rows = nids_from_records(rec4, fl, count)
+    nid = decode_nids(rows, oracle_nid)
+    out = []
+    for (a, _, _), n in zip(rows, nid):
+        if n[0] != 1 or n[2] != 10 or a + 1 + 840 > count:
+            continue
+        w = rec4[a + 1:a + 1 + 840][pos]
+        bits = np.ascontiguousarray(np.stack([(w[:, :, 0] >> 1) & 1, w[:, :, 0] & 1], axis=2).reshape(24, 10).astype(np.uint8))
+        fixed, errs = hamming_hard(bits)
+        assert np.all(errs < 2)
+        data = np.ascontiguousarray(fixed[:16, :6].reshape(1, 16, 6))
+        par = np.ascontiguousarray(fixed[16:, :6].reshape(1, 8, 6))
+        d, rc = rs_decode(data, par)
+        assert rc[0] == 0
+        hx = d[0]                                            # hex_data[0..15]
+        mi = np.concatenate([hx[r] for r in range(15, 3, -1)])
+        algid = int("".join(map(str, list(hx[3]) + list(hx[2][:2]))), 2)
+        kid = int("".join(map(str, list(hx[2][2:]) + list(hx[1]) + list(hx[0]))), 2)
+        out.append((algid, kid, mi))
+    return out
+
+
+def _check_ess(ess):
+    assert len(ess) >= 4
+    for algid, kid, mi in ess:
+        assert algid == 0x80 and kid == 0 and not mi.any()    # clear voice: ALGID 0x80, KID 0, MI 0
+
+
+def test_voice_capture_ldu2_encryption_sync_is_clear(built):
+    from test_oracle_rs import oracle_rs
+    g = golden("iq_p25p1_c4fm_vc.npz")
+    _, sym, rec4, fl = oracle_chain(g["iq"], 840)
+    _check_ess(ldu2_ess(rec4, fl, len(sym), _oracle_hamming, lambda d, p: oracle_rs("24_16_9", d, p)))
+
+
+@pytest.mark.gpu
+def test_voice_capture_ldu2_gpu(built):
+    import ddn
+    g = golden("iq_p25p1_c4fm_vc.npz")
+    iq = np.ascontiguousarray(g["iq"])
+    disc = ddn.Batch(1, block_len=8192).run_host(iq[None], iq.shape[0])
+    rec, fl, cnt = ddn.P25Rx(1, lock_symbols=840, use_matched_filter=1).run(disc)
+    r4, _ = orc.unpack_records10(rec[0, :cnt[0]])
+
+    def gpu_hamming(bits):
+        b = bits.copy()
+        e = np.zeros(len(b), np.uint8)
+        assert ddn.lib().ddn_fec_hamming_10_6_3_host(b.ctypes.data, len(b), e.ctypes.data) == 0
+        return b, e
+
+    def gpu_rs(d, p):
+        x = d.copy()
+        st = np.zeros(len(d), np.uint8)
+        assert ddn.lib().ddn_fec_p25_rs_host(1, x.ctypes.data, p.ctypes.data, len(d), st.ctypes.data) == 0
+        return x, st
+
+    _check_ess(ldu2_ess(r4, fl[0], int(cnt[0]), gpu_hamming, gpu_rs))
