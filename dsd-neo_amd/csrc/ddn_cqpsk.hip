@@ -61,24 +61,16 @@ sincos_half_pi(float phase, float* s, float* c) {
 // polynomial so that the result is non-finite as well).
 __device__ __forceinline__ void
 sincos_two_pi(float phase, float* s, float* c) {
-    if (phase > kPi) {
-        phase -= kTwoPi;
-    } else if (phase < -kPi) {
-        phase += kTwoPi;
-    }
-    if (phase > (kPi / 2.0f)) {
-        float sv, cv;
-        sincos_half_pi(kPi - phase, &sv, &cv);
-        *s = sv;
-        *c = -cv;
-    } else if (phase < (-kPi / 2.0f)) {
-        float sv, cv;
-        sincos_half_pi(-kPi - phase, &sv, &cv);
-        *s = sv;
-        *c = -cv;
-    } else {
-        sincos_half_pi(phase, s, c);
-    }
+    // select-only form of the reference's three-way branch (src/dsp/costas.cpp:102-133): one polynomial evaluation on
+    // the reflected argument, cosine negated outside [-pi/2, pi/2] - the same operations on the same values, but lanes
+    // in different quadrants no longer serialise three copies of the polynomial
+    const float p = phase > kPi ? phase - kTwoPi : (phase < -kPi ? phase + kTwoPi : phase);
+    const bool hi = p > (kPi / 2.0f), lo = p < (-kPi / 2.0f);
+    const float arg = hi ? (kPi - p) : (lo ? (-kPi - p) : p);
+    float sv, cv;
+    sincos_half_pi(arg, &sv, &cv);
+    *s = sv;
+    *c = (hi || lo) ? -cv : cv;
 }
 
 __device__ __forceinline__ float
@@ -209,29 +201,50 @@ k_lpf_hist(const void* __restrict__ in, long n, size_t in_stride, int H, f2* __r
 }
 
 // ---- RMS AGC + FLL band-edge (sample rate) -------------------------------------------------------------------------
-// NT_T > 0: taps count known at compile time -> the 2*NT delay-line reads of a sample are issued back to back into
-// registers before the (order-preserving) accumulation, so one LDS round trip covers the whole convolution.
+// Four lanes per channel: lane q of a quad owns one of the four band-edge accumulators (lower_r, lower_i, upper_r,
+// upper_i).  Each accumulator is the ordered sum of t_k = d_r[k] * A_q[k] + d_i[k] * B_q[k] with (A, B) = (l_r, -l_i),
+// (l_i, l_r), (u_r, -u_i), (u_i, u_r): x - y and x + (-y) round identically, so this is the reference's
+// `acc += dr * a - di * b` / `acc += dr * b + di * a` (src/dsp/costas.cpp:677-690) with the per-sample instruction stream
+// cut from 16 to 4 VALU per tap; the quad then swaps the four sums with wave shuffles and every lane advances the same
+// (replicated) loop state.  16 channels per wavefront, so 4096 channels spread over 256 wavefronts.
+// NT_T > 0: tap count known at compile time -> the lane's 2 * NT taps live in registers and the 2 * NT delay-line reads
+// of a sample are issued back to back before the (order-preserving) accumulation.
 template <int NT_T>
 __global__ __launch_bounds__(128) void
 k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels, int nt_rt, float alpha, float beta,
                 DdnCqpskState* __restrict__ state, float* __restrict__ delay_store, f2* __restrict__ out) {
-    constexpr int TS = 32;
+    constexpr int TS = 32, CPW = 16;
     const int nt = NT_T > 0 ? NT_T : nt_rt;
     extern __shared__ float smem[];
-    f2* tiles = (f2*)smem;                         // [3][64][TS + 1]
-    float* dlr = (float*)(tiles + 3 * 64 * (TS + 1)); // [2 nt][64]
-    float* dli = dlr + 2 * nt * 64;                   // [2 nt][64]
+    f2* tiles = (f2*)smem;                             // [3][CPW][TS + 1]
+    float* dlr = (float*)(tiles + 3 * CPW * (TS + 1)); // [2 nt][CPW]
+    float* dli = dlr + 2 * nt * CPW;                   // [2 nt][CPW]
     const int lane = threadIdx.x & 63;
     const bool helper = threadIdx.x >= 64;
-    const int ch0 = blockIdx.x * 64;
-    const int ch = ch0 + lane;
+    const int ch0 = blockIdx.x * CPW;
+    const int cl = lane >> 2, q = lane & 3; // channel slot in the workgroup, accumulator owned
+    const int ch = ch0 + cl;
     const bool live = !helper && ch < n_channels;
     DdnCqpskState s = {};
     if (live) {
         s = state[ch];
-        for (int k = 0; k < 2 * nt; k++) {
-            dlr[k * 64 + lane] = delay_store[((size_t)k * 2) * n_channels + ch];
-            dli[k * 64 + lane] = delay_store[((size_t)k * 2 + 1) * n_channels + ch];
+        if (q == 0) {
+            for (int k = 0; k < 2 * nt; k++) {
+                dlr[k * CPW + cl] = delay_store[((size_t)k * 2) * n_channels + ch];
+                dli[k * CPW + cl] = delay_store[((size_t)k * 2 + 1) * n_channels + ch];
+            }
+        }
+    }
+    // this lane's tap pair: A multiplies the delayed real part, B the delayed imaginary part
+    const int ia = (q == 0) ? 0 : ((q == 1) ? 1 : ((q == 2) ? 2 : 3));
+    const int ib = (q == 0) ? 1 : ((q == 1) ? 0 : ((q == 2) ? 3 : 2));
+    const float sb = (q == 0 || q == 2) ? -1.0f : 1.0f;
+    float ta[NT_T > 0 ? NT_T : 1], tb[NT_T > 0 ? NT_T : 1];
+    if (NT_T > 0) {
+#pragma unroll
+        for (int k = 0; k < NT_T; k++) {
+            ta[k] = c_fll[ia][k];
+            tb[k] = sb * c_fll[ib][k];
         }
     }
     float avg = s.agc_avg;
@@ -243,33 +256,35 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
     auto stage = [&](long t0, int buf) {
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
         const int half = lane >> 5, col = lane & 31; // two rows per pass: 32 lanes x 8 B = one 256-B row segment
-#pragma unroll 8
-        for (int r = 0; r < 64; r += 2) {
+#pragma unroll
+        for (int r = 0; r < CPW; r += 2) {
             const int cc = r + half;
             f2 v = {0.0f, 0.0f};
             if (ch0 + cc < n_channels && col < tn) {
                 v = in[(size_t)(ch0 + cc) * stride + (size_t)t0 + col];
             }
-            tiles[(buf * 64 + cc) * (TS + 1) + col] = v;
+            tiles[(buf * CPW + cc) * (TS + 1) + col] = v;
         }
     };
     auto drain = [&](long t0, int buf) {
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
         const int half = lane >> 5, col = lane & 31;
-#pragma unroll 8
-        for (int r = 0; r < 64; r += 2) {
+#pragma unroll
+        for (int r = 0; r < CPW; r += 2) {
             const int cc = r + half;
             if (ch0 + cc < n_channels && col < tn) {
-                out[(size_t)(ch0 + cc) * stride + (size_t)t0 + col] = tiles[(buf * 64 + cc) * (TS + 1) + col];
+                out[(size_t)(ch0 + cc) * stride + (size_t)t0 + col] = tiles[(buf * CPW + cc) * (TS + 1) + col];
             }
         }
     };
+    __syncthreads();
     if (helper && n > 0) {
         stage(0, 0);
     }
     __syncthreads();
     long t0 = 0;
     int it = 0;
+    const int qb = lane & ~3;
     for (; t0 < n; t0 += TS, it++) {
         const int buf = it % 3;
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
@@ -281,9 +296,9 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
                 stage(t0 + TS, (it + 1) % 3);
             }
         } else if (live) {
-            f2* row = tiles + (buf * 64 + lane) * (TS + 1);
-            for (int q = 0; q < tn; q++) {
-                f2 x = row[q];
+            f2* row = tiles + (buf * CPW + cl) * (TS + 1);
+            for (int s_i = 0; s_i < tn; s_i++) {
+                f2 x = row[s_i];
                 // RMS AGC
                 const float m2 = x.x * x.x + x.y * x.y;
                 avg = 0.55f * avg + 0.45f * m2;
@@ -297,51 +312,48 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
                 sincos_two_pi(phase, &ns, &nc);
                 const float orr = x.x * nc - x.y * ns;
                 const float oi = x.x * ns + x.y * nc;
-                dlr[idx * 64 + lane] = orr;
-                dli[idx * 64 + lane] = oi;
-                dlr[(idx + nt) * 64 + lane] = orr;
-                dli[(idx + nt) * 64 + lane] = oi;
-                float lr = 0.0f, li = 0.0f, ur = 0.0f, ui = 0.0f;
+                if (q == 0) {
+                    dlr[idx * CPW + cl] = orr;
+                    dli[idx * CPW + cl] = oi;
+                    dlr[(idx + nt) * CPW + cl] = orr;
+                    dli[(idx + nt) * CPW + cl] = oi;
+                }
+                __builtin_amdgcn_wave_barrier();
+                float acc = 0.0f;
                 const int base = idx + nt;
                 if (NT_T > 0) {
                     float vr[NT_T > 0 ? NT_T : 1], vi[NT_T > 0 ? NT_T : 1];
 #pragma unroll
                     for (int k = 0; k < NT_T; k++) {
-                        vr[k] = dlr[(base - k) * 64 + lane];
-                        vi[k] = dli[(base - k) * 64 + lane];
+                        vr[k] = dlr[(base - k) * CPW + cl];
+                        vi[k] = dli[(base - k) * CPW + cl];
                     }
 #pragma unroll
                     for (int k = 0; k < NT_T; k++) {
-                        const float a = c_fll[0][k], b = c_fll[1][k], c = c_fll[2][k], d = c_fll[3][k];
-                        lr += vr[k] * a - vi[k] * b;
-                        li += vr[k] * b + vi[k] * a;
-                        ur += vr[k] * c - vi[k] * d;
-                        ui += vr[k] * d + vi[k] * c;
+                        acc += vr[k] * ta[k] + vi[k] * tb[k];
                     }
                 } else {
                     for (int k = 0; k < nt; k++) {
-                        const float dr = dlr[(base - k) * 64 + lane], di = dli[(base - k) * 64 + lane];
-                        const float a = c_fll[0][k], b = c_fll[1][k], c = c_fll[2][k], d = c_fll[3][k];
-                        lr += dr * a - di * b;
-                        li += dr * b + di * a;
-                        ur += dr * c - di * d;
-                        ui += dr * d + di * c;
+                        const float dr = dlr[(base - k) * CPW + cl], di = dli[(base - k) * CPW + cl];
+                        acc += dr * c_fll[ia][k] + di * (sb * c_fll[ib][k]);
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
+                const float lr = __shfl(acc, qb + 0), li = __shfl(acc, qb + 1);
+                const float ur = __shfl(acc, qb + 2), ui = __shfl(acc, qb + 3);
                 idx = (idx + 1 == nt) ? 0 : idx + 1;
                 const float lm = lr * lr + li * li, um = ur * ur + ui * ui;
                 const float err = clipf(um - lm, 1.0f);
                 freq += beta * err;
                 freq = clampr(freq, -1.0f, 1.0f);
                 phase += freq + alpha * err;
-                for (int g = 0; g < 4 && phase > kTwoPi; g++) {
-                    phase -= kTwoPi;
+                // the reference's while loops run at most once: |freq| <= 1 and alpha * |err| < 0.1 per sample
+                phase = phase > kTwoPi ? phase - kTwoPi : phase;
+                phase = phase < -kTwoPi ? phase + kTwoPi : phase;
+                if (q == 0) {
+                    const f2 y = {orr, oi};
+                    row[s_i] = y;
                 }
-                for (int g = 0; g < 4 && phase < -kTwoPi; g++) {
-                    phase += kTwoPi;
-                }
-                const f2 y = {orr, oi};
-                row[q] = y;
             }
         }
         __syncthreads();
@@ -349,15 +361,176 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
     if (helper && it > 0) {
         drain(t0 - TS, (it + 2) % 3);
     }
-    if (live) {
+    if (live && q == 0) {
         s.agc_avg = avg;
         s.fll_phase = phase;
         s.fll_freq = freq;
         s.fll_idx = idx;
         state[ch] = s;
         for (int k = 0; k < 2 * nt; k++) {
-            delay_store[((size_t)k * 2) * n_channels + ch] = dlr[k * 64 + lane];
-            delay_store[((size_t)k * 2 + 1) * n_channels + ch] = dli[k * 64 + lane];
+            delay_store[((size_t)k * 2) * n_channels + ch] = dlr[k * CPW + cl];
+            delay_store[((size_t)k * 2 + 1) * n_channels + ch] = dli[k * CPW + cl];
+        }
+    }
+}
+
+// Register-resident variant for the tap counts in use (2 sps + 1 = 9, 11, 21).  The per-sample feedback loop issues its
+// instructions in order, so what limits it is the LDS round trips inside the loop (delay-line write -> read, shuffles),
+// not the FLOPs: here the delay line is a circular buffer in REGISTERS - the sample loop is unrolled by NT so the write
+// slot and every tap's read slot are compile-time register names - the four accumulators are exchanged with DPP
+// quad-permutes (VALU, no LDS), and a tile holds a whole number of NT-sample chunks (TS = 3 NT or 2 NT) so the circular
+// alignment survives tile boundaries; only the last tile of a call can end mid-chunk, and the carried state stores the
+// delay line oldest-first so the next call starts aligned again.
+template <int NT>
+__global__ __launch_bounds__(128) void
+k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_channels, float alpha, float beta,
+                    DdnCqpskState* __restrict__ state, float* __restrict__ delay_store, f2* __restrict__ out) {
+    constexpr int TS = (NT > 16) ? 2 * NT : 3 * NT, CPW = 16;
+    __shared__ f2 tiles[3][CPW][TS + 1];
+    const int lane = threadIdx.x & 63;
+    const bool helper = threadIdx.x >= 64;
+    const int ch0 = blockIdx.x * CPW;
+    const int cl = lane >> 2, q = lane & 3;
+    const int ch = ch0 + cl;
+    const bool live = !helper && ch < n_channels;
+    DdnCqpskState s = {};
+    float zr[NT], zi[NT]; // z[i] = rotated sample written at chunk position i; before a chunk z[i] = x_(i - NT)
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        zr[k] = 0.0f;
+        zi[k] = 0.0f;
+    }
+    if (live) {
+        s = state[ch];
+#pragma unroll
+        for (int k = 0; k < NT; k++) { // stored oldest first
+            zr[k] = delay_store[((size_t)k * 2) * n_channels + ch];
+            zi[k] = delay_store[((size_t)k * 2 + 1) * n_channels + ch];
+        }
+    }
+    const int ia = q, ib = q ^ 1;
+    const float sb = (q == 0 || q == 2) ? -1.0f : 1.0f;
+    float ta[NT], tb[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        ta[k] = c_fll[ia][k];
+        tb[k] = sb * c_fll[ib][k];
+    }
+    float avg = s.agc_avg;
+    if (avg <= 0.0f) {
+        avg = 1.0f;
+    }
+    float phase = s.fll_phase, freq = s.fll_freq;
+    auto stage = [&](long t0, int buf) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+#pragma unroll
+        for (int r = 0; r < CPW; r++) {
+            f2 v = {0.0f, 0.0f};
+            if (ch0 + r < n_channels && lane < tn) {
+                v = in[(size_t)(ch0 + r) * stride + (size_t)t0 + lane];
+            }
+            if (lane < TS) {
+                tiles[buf][r][lane] = v;
+            }
+        }
+    };
+    auto drain = [&](long t0, int buf) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+#pragma unroll
+        for (int r = 0; r < CPW; r++) {
+            if (ch0 + r < n_channels && lane < tn) {
+                out[(size_t)(ch0 + r) * stride + (size_t)t0 + lane] = tiles[buf][r][lane];
+            }
+        }
+    };
+    auto bcast = [&](float v, int src) -> float { // value of lane `src` of this quad, via DPP quad_perm
+        int iv = __float_as_int(v), r;
+        switch (src) {
+            case 0: r = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xF, 0xF, false); break;
+            case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, false); break;
+            case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, false); break;
+            default: r = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, false); break;
+        }
+        return __int_as_float(r);
+    };
+    if (helper && n > 0) {
+        stage(0, 0);
+    }
+    __syncthreads();
+    long t0 = 0;
+    int it = 0, tail = 0; // tail = samples of a final, partial chunk (0 = the call ended on a chunk boundary)
+    for (; t0 < n; t0 += TS, it++) {
+        const int buf = it % 3;
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        if (helper) {
+            if (it > 0) {
+                drain(t0 - TS, (it + 2) % 3);
+            }
+            if (t0 + TS < n) {
+                stage(t0 + TS, (it + 1) % 3);
+            }
+        } else if (live) {
+            f2* row = &tiles[buf][cl][0];
+            for (int c0 = 0; c0 < tn; c0 += NT) {
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    if (c0 + j < tn) {
+                        f2 x = row[c0 + j];
+                        const float m2 = x.x * x.x + x.y * x.y;
+                        avg = 0.55f * avg + 0.45f * m2;
+                        if (avg > 0.0f) {
+                            const float sc = 0.85f / sqrtf(avg);
+                            x.x = x.x * sc;
+                            x.y = x.y * sc;
+                        }
+                        float ns, nc;
+                        sincos_two_pi(phase, &ns, &nc);
+                        const float orr = x.x * nc - x.y * ns;
+                        const float oi = x.x * ns + x.y * nc;
+                        zr[j] = orr;
+                        zi[j] = oi;
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < NT; k++) {
+                            constexpr int dummy = 0;
+                            (void)dummy;
+                            const int slot = (j - k + NT) % NT;
+                            acc += zr[slot] * ta[k] + zi[slot] * tb[k];
+                        }
+                        const float lr = bcast(acc, 0), li = bcast(acc, 1), ur = bcast(acc, 2), ui = bcast(acc, 3);
+                        const float lm = lr * lr + li * li, um = ur * ur + ui * ui;
+                        const float err = clipf(um - lm, 1.0f);
+                        freq += beta * err;
+                        freq = clampr(freq, -1.0f, 1.0f);
+                        phase += freq + alpha * err;
+                        phase = phase > kTwoPi ? phase - kTwoPi : phase;
+                        phase = phase < -kTwoPi ? phase + kTwoPi : phase;
+                        if (q == 0) {
+                            const f2 y = {orr, oi};
+                            row[c0 + j] = y;
+                        }
+                        tail = (j + 1) % NT;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (helper && it > 0) {
+        drain(t0 - TS, (it + 2) % 3);
+    }
+    if (live && q == 0) {
+        s.agc_avg = avg;
+        s.fll_phase = phase;
+        s.fll_freq = freq;
+        s.fll_idx = 0;
+        state[ch] = s;
+        // oldest first: after a partial chunk of `tail` samples the newest sits in slot tail - 1, the oldest in slot tail
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const int dst = (k - tail + NT) % NT;
+            delay_store[((size_t)dst * 2) * n_channels + ch] = zr[k];
+            delay_store[((size_t)dst * 2 + 1) * n_channels + ch] = zi[k];
         }
     }
 }
@@ -503,8 +676,8 @@ ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    const size_t shm = sizeof(f2) * 3 * 64 * 33 + sizeof(float) * 2 * (size_t)(2 * nt) * 64;
-    const dim3 grid((unsigned)((n_channels + 63) / 64)), blk(128);
+    const size_t shm = sizeof(f2) * 3 * 16 * 33 + sizeof(float) * 2 * (size_t)(2 * nt) * 16;
+    const dim3 grid((unsigned)((n_channels + 15) / 16)), blk(128);
 #define DDN_LAUNCH_FLL(NTT)                                                                                            \
     do {                                                                                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cqpsk_agc_fll<NTT>),                       \
@@ -515,12 +688,16 @@ ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int
         hipLaunchKernelGGL(k_cqpsk_agc_fll<NTT>, grid, blk, shm, st, (const f2*)in, n, stride, n_channels, nt, alpha,  \
                            beta, state, delay_store, (f2*)out);                                                        \
     } while (0)
+    const dim3 rgrid((unsigned)((n_channels + 15) / 16));
     if (nt == 11) {
-        DDN_LAUNCH_FLL(11); // sps 5
+        hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<11>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
+                           state, delay_store, (f2*)out); // sps 5
     } else if (nt == 21) {
-        DDN_LAUNCH_FLL(21); // sps 10
+        hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<21>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
+                           state, delay_store, (f2*)out); // sps 10
     } else if (nt == 9) {
-        DDN_LAUNCH_FLL(9); // sps 4 (P25p2 6000 sym/s at 24 ksps)
+        hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<9>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
+                           state, delay_store, (f2*)out); // sps 4 (P25p2 6000 sym/s at 24 ksps)
     } else {
         DDN_LAUNCH_FLL(0);
     }
