@@ -101,6 +101,7 @@ PROTOTYPES = {
     "ddn_ted_batch_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_void_p)]),
     "ddn_ted_batch_destroy": (None, [C.c_void_p]),
     "ddn_ted_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_ted_batch_set_block_len": (C.c_int, [C.c_void_p, C.c_size_t]),
     "ddn_gardner_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_gardner_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddn_ted_batch_get_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -105,6 +105,7 @@ ddn_cqpsk_batch_create(const ddn_cqpsk_config* cfg, ddn_cqpsk_batch** out) {
         || (b->taps_len >= 3
             && hipMemcpy(b->d_taps, b->taps, sizeof(float) * (size_t)b->taps_len, hipMemcpyHostToDevice) != hipSuccess)
         || ddn_ted_batch_create(cfg->n_channels, b->sps, cfg->symbol_rate_hz, cfg->ted_gain, &b->ted) != DDN_OK
+        || ddn_ted_batch_set_block_len(b->ted, (size_t)cfg->block_len) != DDN_OK
         || cq_fill(b, nullptr) != DDN_OK || hipDeviceSynchronize() != hipSuccess) {
         ddn_set_error("ddn_cqpsk_batch_create: device allocation failed");
         cq_free(b);

@@ -23,6 +23,7 @@
 struct ddn_ted_batch {
     int n_channels, sps, symbol_rate_hz;
     float ted_gain;
+    long block_len; // 0: one reference call per ddn_gardner_run; else the reference's block size in samples
     DdnTedState* d_state;
     float* d_dl;
     int* d_count;
@@ -88,14 +89,24 @@ ddn_ted_batch_reset(ddn_ted_batch* b, void* hip_stream) {
 }
 
 extern "C" int
+ddn_ted_batch_set_block_len(ddn_ted_batch* b, size_t block_len) {
+    if (!b || (block_len != 0 && block_len < 4)) {
+        ddn_set_error("ddn_ted_batch_set_block_len: bad argument (block_len must be 0 or >= 4)");
+        return DDN_EINVAL;
+    }
+    b->block_len = (long)block_len;
+    return DDN_OK;
+}
+
+extern "C" int
 ddn_gardner_run(ddn_ted_batch* b, const float* d_iq, size_t n, float* d_sym, size_t sym_stride, int* d_sym_count,
                 void* hip_stream) {
     if (!b || !d_iq || !d_sym) {
         ddn_set_error("ddn_gardner_run: null argument");
         return DDN_EINVAL;
     }
-    HIP_TRY(ddn_dev_gardner(d_iq, (long)n, n, b->n_channels, b->sps, b->ted_gain, b->symbol_rate_hz, b->d_state,
-                            b->d_dl, d_sym, sym_stride, d_sym_count ? d_sym_count : b->d_count,
+    HIP_TRY(ddn_dev_gardner(d_iq, (long)n, n, b->n_channels, b->sps, b->ted_gain, b->symbol_rate_hz, b->block_len,
+                            b->d_state, b->d_dl, d_sym, sym_stride, d_sym_count ? d_sym_count : b->d_count,
                             (hipStream_t)hip_stream));
     return DDN_OK;
 }

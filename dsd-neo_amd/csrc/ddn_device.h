@@ -92,8 +92,8 @@ typedef struct DdnPuncture { /* puncture pattern of the K=5 decoder, expanded on
 extern "C" {
 #endif
 hipError_t ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sps, float ted_gain,
-                           int symbol_rate_hz, DdnTedState* state, float* dl_store, void* out, size_t out_stride,
-                           int* out_count, hipStream_t st);
+                           int symbol_rate_hz, long block_len, DdnTedState* state, float* dl_store, void* out,
+                           size_t out_stride, int* out_count, hipStream_t st);
 hipError_t ddn_dev_p25_slicer(const float* sym, long n, size_t sym_stride, int n_channels, int negative,
                               DdnSlicerState* state, float* sbuf_store, float* minring, float* maxring, uint8_t* rec,
                               size_t rec_stride, hipStream_t st);

@@ -78,8 +78,8 @@ mmse8(const float* dl, int first_complex, float mu, const float (*tbl)[8], float
 
 __global__ __launch_bounds__(128) void
 k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, int sps, float ted_gain,
-          int symbol_rate_hz, DdnTedState* __restrict__ state, float* __restrict__ dl_store, f2* __restrict__ out,
-          size_t out_stride, int* __restrict__ out_count) {
+          int symbol_rate_hz, long block_len, DdnTedState* __restrict__ state, float* __restrict__ dl_store,
+          f2* __restrict__ out, size_t out_stride, int* __restrict__ out_count) {
     constexpr int TS = 64;
     extern __shared__ float smem[];
     float(*tbl)[8] = (float(*)[8])smem;            // [17][8]
@@ -133,14 +133,22 @@ k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, i
             dl[(size_t)k * 64] = dl_store[(size_t)ch * (DDN_TED_DL * 4) + k];
         }
     }
-    // gain selection, src/dsp/costas.cpp:143-168 (no env / API override)
-    float gain_mu = ted_gain > 0.0f ? ted_gain : 0.025f;
-    if (symbol_rate_hz >= 5500 && t.lock_count >= 240 && !(t.lock_accum / (float)t.lock_count < 0.05f)) {
-        gain_mu = 0.018f;
-    }
-    const float gain_omega = 0.1f * gain_mu * gain_mu;
     float mu = t.mu, last_r = t.last_r, last_j = t.last_j, lock = t.lock_accum;
     int lock_n = t.lock_count, dli = t.dl_index;
+    // gain selection, src/dsp/costas.cpp:143-168 (no env / API override). The reference evaluates it once per
+    // op25_gardner_cc call, i.e. once per demodulator block: with block_len > 0 it is re-evaluated whenever the next
+    // unconsumed sample starts a new block, before anything is produced there (src/dsp/costas.cpp:804-858 never
+    // produces after a block's last sample, so a pending symbol falls under the next block's gain).
+    float gain_mu, gain_omega;
+    auto regain = [&]() {
+        gain_mu = ted_gain > 0.0f ? ted_gain : 0.025f;
+        if (symbol_rate_hz >= 5500 && lock_n >= 240 && !(lock / (float)lock_n < 0.05f)) {
+            gain_mu = 0.018f;
+        }
+        gain_omega = 0.1f * gain_mu * gain_mu;
+    };
+    regain();
+    long next_blk = block_len > 0 ? block_len : n + 1;
     f2* op = out + (size_t)ch * out_stride;
     __syncthreads();
 
@@ -188,6 +196,10 @@ k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, i
                 bool busy = false;
                 if (run) {
                     while (mu > 1.0f && s < tn) {
+                        if (t0 + s == next_blk) {
+                            regain();
+                            next_blk += block_len;
+                        }
                         mu -= 1.0f;
                         f2 x = tile[lane * (TS + 1) + s];
                         if (x.x != x.x) {
@@ -206,6 +218,10 @@ k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, i
                         s++;
                     }
                     if (!(mu > 1.0f) && (s < tn || more)) {
+                        if (t0 + s == next_blk) {
+                            regain();
+                            next_blk += block_len;
+                        }
                         const float half_omega = omega / 2.0f;
                         int hs = (int)floorf(half_omega);
                         float hmu = mu + half_omega - (float)hs;
@@ -276,7 +292,7 @@ k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, i
 
 extern "C" hipError_t
 ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sps, float ted_gain, int symbol_rate_hz,
-                DdnTedState* state, float* dl_store, void* out, size_t out_stride, int* out_count, hipStream_t st) {
+                long block_len, DdnTedState* state, float* dl_store, void* out, size_t out_stride, int* out_count, hipStream_t st) {
     if (n_channels <= 0) {
         return hipSuccess;
     }
@@ -289,7 +305,7 @@ ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sp
     }
     const size_t shm = sizeof(float) * (17 * 8 + 8) + sizeof(f2) * 2 * 64 * 65 + sizeof(float) * 4 * (size_t)tw * 64;
     hipLaunchKernelGGL(k_gardner, dim3((unsigned)((n_channels + 63) / 64)), dim3(128), shm, st, (const f2*)in, n,
-                       in_stride, n_channels, sps, ted_gain, symbol_rate_hz, state, dl_store, (f2*)out, out_stride,
-                       out_count);
+                       in_stride, n_channels, sps, ted_gain, symbol_rate_hz, block_len, state, dl_store, (f2*)out,
+                       out_stride, out_count);
     return hipGetLastError();
 }

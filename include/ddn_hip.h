@@ -170,6 +170,11 @@ typedef struct ddn_ted_batch ddn_ted_batch;
 int ddn_ted_batch_create(int n_channels, int sps, int symbol_rate_hz, float ted_gain, ddn_ted_batch** out);
 void ddn_ted_batch_destroy(ddn_ted_batch* b);
 int ddn_ted_batch_reset(ddn_ted_batch* b, void* hip_stream);
+/* One ddn_gardner_run() call == one op25_gardner_cc() call by default.  With block_len > 0 the call is equivalent to
+ * ceil(n / block_len) consecutive op25_gardner_cc() calls of block_len samples (the last one shorter): the loop gain is
+ * re-selected (src/dsp/costas.cpp:143-168, matters for symbol rates >= 5500) and a symbol pending at a block's last
+ * sample is deferred to the next block, exactly as when full_demod() drives it block by block. */
+int ddn_ted_batch_set_block_len(ddn_ted_batch* b, size_t block_len);
 int ddn_gardner_run(ddn_ted_batch* b, const float* d_iq, size_t n, float* d_sym, size_t sym_stride, int* d_sym_count,
                     void* hip_stream);
 int ddn_gardner_run_host(ddn_ted_batch* b, const float* iq, size_t n, float* sym, size_t sym_stride, int* sym_count);

@@ -74,3 +74,42 @@ def test_rx_random_splits(built, seed):
         assert np.array_equal(sy.view(np.uint32), sym.view(np.uint32)), (seed, c)
         assert np.array_equal(r4, rec4) and np.array_equal(np.concatenate(fls[c]), fl), (seed, c)
         assert np.array_equal(rx.thresholds(c).view(np.uint32), o.thresholds().view(np.uint32)), (seed, c)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_cqpsk_random_configs(built, seed):
+    rng = np.random.default_rng(3000 + seed)
+    sps = int(rng.choice([4, 5, 5, 10, 8]))
+    sym_rate = 6000 if sps == 4 else 4800
+    rate = sps * sym_rate
+    blk = int(rng.choice([333, 1000, 2048, 4096, 8192]))
+    lpf = int(rng.integers(0, 2))
+    B = int(rng.integers(1, 20))
+    iq = orc.synth_dqpsk_f32(int(rng.integers(0, 999)), B, int(rng.integers(600, 2500)), sps, cfo=float(rng.choice([0.0, 0.002, 0.01])))
+    n = iq.shape[1]
+    n_calls = int(rng.integers(1, 4))
+    lens = [int(rng.integers(1, 3)) * blk for _ in range(n_calls - 1)]
+    if sum(lens) >= n - 8:
+        lens = []
+    last = n - sum(lens)
+    if last % blk in (1, 2, 3):
+        last -= 4
+    lens.append(last)
+    b = ddn.CqpskBatch(B, rate=rate, sym_rate=sym_rate, lpf_enable=lpf, block_len=blk)
+    got = [[] for _ in range(B)]
+    pos = 0
+    for ln in lens:
+        sym, cnt = b.run(iq[:, pos:pos + ln])
+        for c in range(B):
+            got[c].append(sym[c, :cnt[c]])
+        pos += ln
+    for c in range(B):
+        fe = orc.OracleCqpskFe(rate=rate, sym_rate=sym_rate, lpf_enable=lpf)
+        want, pos = [], 0
+        for ln in lens:
+            want.append(fe.run(iq[c, pos:pos + ln], blk))
+            pos += ln
+        want = np.concatenate(want)
+        g = np.concatenate(got[c])
+        assert len(g) == len(want), (seed, c, sps, blk, lens)
+        assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), (seed, c, sps, blk, lpf, lens)

@@ -73,3 +73,28 @@ def test_gardner_batch_vs_oracle(built):
         o = orc.OracleTed(sps, 4800)
         wa, wb = o.block(iq[c, :n1]), o.block(iq[c, n1:])
         assert np.array_equal(bits(a[c]), bits(wa)) and np.array_equal(bits(b[c]), bits(wb)), c
+
+
+def test_gardner_block_len_regains_per_block(built):
+    """Symbol rate >= 5500: the reference re-selects the loop gain at every op25_gardner_cc call (= demodulator block,
+    src/dsp/costas.cpp:143-168); one batched call with block_len set must equal the per-block sequence."""
+    B, sps, blk = 70, 4, 333
+    iq = orc.synth_qpsk_f32(99, B, 1900, sps, noise=0.05)
+    t = GpuTed(B, sps, 6000)
+    assert ddn.lib().ddn_ted_batch_set_block_len(t.h, blk) == 0
+    assert ddn.lib().ddn_ted_batch_set_block_len(t.h, 3) != 0
+    n1 = 2 * blk
+    got = [np.concatenate([x, y]) for x, y in zip(t.run(iq[:, :n1]), t.run(iq[:, n1:]))]
+    switched = 0
+    for c in range(B):
+        o = orc.OracleTed(sps, 6000)
+        want = []
+        for lo, hi in ((0, n1), (n1, iq.shape[1])):
+            for p in range(lo, hi, blk):
+                want.append(o.block(iq[c, p:min(p + blk, hi)]))
+        want = np.concatenate(want)
+        assert np.array_equal(bits(got[c]), bits(want)), c
+        o2 = orc.OracleTed(sps, 6000)
+        whole = np.concatenate([o2.block(iq[c, :n1]), o2.block(iq[c, n1:])])
+        switched += (len(whole) != len(want)) or not np.array_equal(bits(whole), bits(want))
+    assert switched > 0  # the test would be vacuous if per-block and per-call gain selection agreed everywhere
