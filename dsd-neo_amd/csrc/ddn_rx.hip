@@ -338,6 +338,9 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                         float m1 = L.gs[0][0][ln], m2 = L.gs[0][1][ln], x1 = L.gs[0][2][ln], x2 = L.gs[0][3][ln];
 #pragma unroll
                         for (int g = 1; g < 8; g++) {
+                            if (cfg.dbg & 64) {
+                                break;
+                            }
                             two_min_insert(L.gs[g][0][ln], m1, m2);
                             two_min_insert(L.gs[g][1][ln], m1, m2);
                             two_max_insert(L.gs[g][2][ln], x1, x2);
@@ -346,7 +349,7 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                         const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
                         const size_t ro = (size_t)s.midx * n_channels + ch;
                         float old_lo = s.fill_min, old_hi = s.fill_max;
-                        if (s.since_fill >= MS) {
+                        if (s.since_fill >= MS && !(cfg.dbg & 32)) {
                             old_lo = minring[ro];
                             old_hi = maxring[ro];
                         } else {
@@ -538,6 +541,676 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
     }
 }
 
+
+// =====================================================================================================================
+// k_p25_rxw — the same loop for CPW <= 32 with three changes that cut the instructions on the per-channel chain:
+//  * the staged tiles form a ring of three (previous, current, next being loaded), so a symbol that would straddle a
+//    tile edge is simply deferred to the next tile and every symbol is evaluated whole: the five-sample latched path in
+//    frame, a straight per-sample pass (crossing search included) while hunting.  The sample-at-a-time loop is left for
+//    the matched filter's 90-sample cold start, spans > 24 and the last tile of a call (partial symbols are carried);
+//  * the 128-symbol window statistics are incremental.  The window is written in order, 16-slot group by group: inside
+//    the current group the summary is merge(prefix of new values, suffix of old values); wave 1 prepares, one tile
+//    ahead, the suffix summaries of the next group and the merge of the six groups that are neither current nor
+//    next, so the per-symbol cost is ~10 compare/select pairs instead of a 16-slot rescan plus a 7-group merge.  A
+//    lane whose next group was not prepared in time (first group of a call, sps < 8 corner cases) uses the rescan for
+//    that group - same statistics either way (multisets: the two smallest of a union are among the parts' two smallest);
+//  * the queue to wave 1 carries {symbol, max, min, flags}; centre / mid thresholds are recomputed there with the
+//    reference's expressions.
+constexpr int RT = 3 * TS;
+constexpr int QCW = 12; // (TS + deferred carry) / (8 - 1) symbols at most per lane and tile when sps >= 8
+constexpr int WMAX = 24;
+
+template <int CPW>
+struct LdsW {
+    float sb[SS][CPW];
+    float gs[8][4][CPW];
+    float lb[24][CPW];
+    float sh[24][CPW];
+    float raw[CPW][RT + 1];
+    float flt[CPW][RT + 1];
+    float q[2][QCW][4][CPW];
+    int qn[2][CPW];
+    int qo[2][CPW];
+    float suf[2][16][4][CPW]; // [entry & 1][k] = {min1, min2, max1, max2} of slots k..15 of the group being entered
+    float oth[2][4][CPW];     // same for the six groups other than that one and its predecessor
+    int want_e[CPW], want_g[CPW], done_e[CPW];
+};
+
+template <int CPW>
+__global__ __launch_bounds__(128) void
+k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail, long n,
+          size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
+          float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
+          float* __restrict__ maxring, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags,
+          int32_t* __restrict__ counts, size_t max_sym) {
+    extern __shared__ unsigned char smem_raw[];
+    LdsW<CPW>& L = *reinterpret_cast<LdsW<CPW>*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;
+    const int ch0 = blockIdx.x * CPW;
+    const int ch = ch0 + lane;
+    const bool live = !loader && lane < CPW && ch < n_channels;
+    const int ln = lane < CPW ? lane : 0;
+    const bool use_flt = cfg.use_filter != 0;
+    const float inf = __builtin_inff();
+
+    DdnRxState s;
+    if (live) {
+        s = state[ch];
+        for (int k = 0; k < SS; k++) {
+            L.sb[k][ln] = sbuf_store[(size_t)k * n_channels + ch];
+        }
+        for (int k = 0; k < 24; k++) {
+            L.lb[k][ln] = lbuf_store[(size_t)k * n_channels + ch];
+            L.sh[k][ln] = shist_store[(size_t)k * n_channels + ch];
+        }
+    } else {
+        s = DdnRxState{};
+    }
+    auto refresh_group = [&](int g) {
+        float a1 = L.sb[g * 16][ln], a2 = L.sb[g * 16 + 1][ln];
+        float b1 = a1, b2 = a2;
+        if (a2 < a1) {
+            const float t = a1;
+            a1 = a2;
+            a2 = t;
+        }
+        if (b2 > b1) {
+            const float t = b1;
+            b1 = b2;
+            b2 = t;
+        }
+#pragma unroll
+        for (int k = 2; k < 16; k++) {
+            const float v = L.sb[g * 16 + k][ln];
+            two_min_insert(v, a1, a2);
+            two_max_insert(v, b1, b2);
+        }
+        L.gs[g][0][ln] = a1;
+        L.gs[g][1][ln] = a2;
+        L.gs[g][2][ln] = b1;
+        L.gs[g][3][ln] = b2;
+    };
+    if (live) {
+        for (int g = 0; g < 8; g++) {
+            refresh_group(g);
+        }
+        L.want_e[ln] = 0;
+        L.want_g[ln] = 0;
+        L.done_e[ln] = 0;
+    }
+
+    auto stage = [&](long t0, int slot) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+#pragma unroll
+        for (int h = 0; h < CPW / 16; h++) {
+            float r[16], f[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int cc = 16 * h + c;
+                const bool ok = (ch0 + cc < n_channels) && lane < tn;
+                const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + lane;
+                r[c] = ok ? raw[off] : 0.0f;
+                f[c] = (ok && use_flt) ? filt[off] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                L.raw[16 * h + c][slot * TS + lane] = r[c];
+                L.flt[16 * h + c][slot * TS + lane] = f[c];
+            }
+        }
+    };
+    if (loader && n > 0) {
+        stage(0, 0);
+    }
+    __syncthreads();
+
+    const int whole0 = cfg.out_rate / cfg.sym_rate, rem0 = cfg.out_rate % cfg.sym_rate;
+    const int whole = whole0 < 2 ? 2 : (whole0 > 64 ? 64 : whole0);
+    const int rem = (whole0 < 2 || whole0 > 64) ? 0 : rem0;
+    int o = 0;
+    uint8_t* rp = rec + (size_t)(live ? ch : 0) * max_sym * 10;
+    uint8_t* fp = flags + (size_t)(live ? ch : 0) * max_sym;
+    const long long abs0 = s.n_abs;
+
+    const bool offload = whole >= 8;
+    const bool hlive = loader && lane < CPW && ch < n_channels;
+    uint8_t* hrp = rec + (size_t)(hlive ? ch : 0) * max_sym * 10;
+    uint8_t* hfp = flags + (size_t)(hlive ? ch : 0) * max_sym;
+    auto store_record = [&](uint8_t* r, uint8_t* f, float sym, int dibit, int relb, int l0, int l1, int fl) {
+        const uint32_t xb = __float_as_uint(sym);
+        ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
+        ((uint16_t*)r)[1] = (uint16_t)(int16_t)l0;
+        ((uint16_t*)r)[2] = (uint16_t)(int16_t)l1;
+        ((uint16_t*)r)[3] = (uint16_t)(xb & 0xFFFFu);
+        ((uint16_t*)r)[4] = (uint16_t)(xb >> 16);
+        *f = (uint8_t)fl;
+    };
+    auto drain = [&](int qb) {
+        if (!hlive) {
+            return;
+        }
+        const int cnt = L.qn[qb][ln], o0 = L.qo[qb][ln];
+        for (int k = 0; k < QCW; k++) {
+            if (k >= cnt) {
+                break;
+            }
+            const float sym = L.q[qb][k][0][ln];
+            const int fl = __float_as_int(L.q[qb][k][3][ln]);
+            int dibit, relb = 0, l0 = 0, l1 = 0;
+            if (fl & 1) {
+                const float mx = L.q[qb][k][1][ln], mn = L.q[qb][k][2][ln];
+                const float center = (mx + mn) / 2.0f;
+                const ddn_sl::Thr th = {center, ((mx - center) * 5.0f / 8.0f) + center,
+                                        ((mn - center) * 5.0f / 8.0f) + center, mx, mn};
+                ddn_sl::slice_soft(sym, th, (fl >> 2) & 1, dibit, relb, l0, l1);
+            } else {
+                dibit = sym > 0.0f ? 1 : 3;
+            }
+            const size_t oo = (size_t)(o0 + k);
+            if (oo < max_sym) {
+                store_record(hrp + oo * 10, hfp + oo, sym, dibit, relb, l0, l1, fl);
+            }
+        }
+    };
+    // wave 1, one tile ahead of need: suffix summaries of group want_g and the merge of the six uninvolved groups
+    int hdone = 0;
+    auto prepare = [&]() {
+        if (!hlive) {
+            return;
+        }
+        const int e = L.want_e[ln];
+        if (e == hdone) {
+            return;
+        }
+        const int g = L.want_g[ln];
+        float a1 = inf, a2 = inf, b1 = -inf, b2 = -inf;
+        for (int k = 15; k >= 0; k--) {
+            const float v = L.sb[g * 16 + k][ln];
+            two_min_insert(v, a1, a2);
+            two_max_insert(v, b1, b2);
+            L.suf[e & 1][k][0][ln] = a1;
+            L.suf[e & 1][k][1][ln] = a2;
+            L.suf[e & 1][k][2][ln] = b1;
+            L.suf[e & 1][k][3][ln] = b2;
+        }
+        a1 = inf, a2 = inf, b1 = -inf, b2 = -inf;
+        for (int d = 1; d <= 6; d++) {
+            const int h = (g + d) & 7;
+            two_min_insert(L.gs[h][0][ln], a1, a2);
+            two_min_insert(L.gs[h][1][ln], a1, a2);
+            two_max_insert(L.gs[h][2][ln], b1, b2);
+            two_max_insert(L.gs[h][3][ln], b1, b2);
+        }
+        L.oth[e & 1][0][ln] = a1;
+        L.oth[e & 1][1][ln] = a2;
+        L.oth[e & 1][2][ln] = b1;
+        L.oth[e & 1][3][ln] = b2;
+        L.done_e[ln] = e;
+        hdone = e;
+    };
+
+    // incremental window state of this lane (valid while fastwin)
+    float pm1 = inf, pm2 = inf, px1 = -inf, px2 = -inf; // new values written into the current group so far
+    float om1 = inf, om2 = inf, ox1 = -inf, ox2 = -inf; // the seven other groups
+    int gent = 0;                                       // groups entered during this call
+    bool fastwin = false;
+    // window push of one symbol at slot s.sidx; returns the whole-window extrema pairs when `global` is set
+    auto window_push = [&](float sym, bool global, float& m1, float& m2, float& x1, float& x2, int done_snap) {
+        const int k = s.sidx & 15, g = s.sidx >> 4;
+        L.sb[s.sidx][ln] = sym;
+        if (k == 0) {
+            gent++;
+            fastwin = (done_snap == gent);
+            if (fastwin) {
+                const int p = (g + 7) & 7;
+                om1 = L.oth[gent & 1][0][ln];
+                om2 = L.oth[gent & 1][1][ln];
+                ox1 = L.oth[gent & 1][2][ln];
+                ox2 = L.oth[gent & 1][3][ln];
+                two_min_insert(L.gs[p][0][ln], om1, om2);
+                two_min_insert(L.gs[p][1][ln], om1, om2);
+                two_max_insert(L.gs[p][2][ln], ox1, ox2);
+                two_max_insert(L.gs[p][3][ln], ox1, ox2);
+                pm1 = inf, pm2 = inf, px1 = -inf, px2 = -inf;
+            }
+        }
+        if (fastwin) {
+            two_min_insert(sym, pm1, pm2);
+            two_max_insert(sym, px1, px2);
+            if (k == 15) {
+                L.gs[g][0][ln] = pm1;
+                L.gs[g][1][ln] = pm2;
+                L.gs[g][2][ln] = px1;
+                L.gs[g][3][ln] = px2;
+            }
+            if (global) {
+                m1 = pm1, m2 = pm2, x1 = px1, x2 = px2;
+                const int k1 = k < 15 ? k + 1 : 15;
+                const float s0 = L.suf[gent & 1][k1][0][ln], s1 = L.suf[gent & 1][k1][1][ln];
+                const float s2 = L.suf[gent & 1][k1][2][ln], s3 = L.suf[gent & 1][k1][3][ln];
+                two_min_insert(k < 15 ? s0 : inf, m1, m2);
+                two_min_insert(k < 15 ? s1 : inf, m1, m2);
+                two_max_insert(k < 15 ? s2 : -inf, x1, x2);
+                two_max_insert(k < 15 ? s3 : -inf, x1, x2);
+                two_min_insert(om1, m1, m2);
+                two_min_insert(om2, m1, m2);
+                two_max_insert(ox1, x1, x2);
+                two_max_insert(ox2, x1, x2);
+            }
+        } else {
+            refresh_group(g);
+            if (global) {
+                m1 = L.gs[0][0][ln], m2 = L.gs[0][1][ln], x1 = L.gs[0][2][ln], x2 = L.gs[0][3][ln];
+#pragma unroll
+                for (int h = 1; h < 8; h++) {
+                    two_min_insert(L.gs[h][0][ln], m1, m2);
+                    two_min_insert(L.gs[h][1][ln], m1, m2);
+                    two_max_insert(L.gs[h][2][ln], x1, x2);
+                    two_max_insert(L.gs[h][3][ln], x1, x2);
+                }
+            }
+        }
+    };
+
+    const float* rrow = &L.raw[ln][0];
+    const float* frow = &L.flt[ln][0];
+    int sp = 0; // this lane's cursor relative to the current tile (negative: a deferred symbol begins in the previous one)
+    int it = 0;
+    for (long t0 = 0; t0 < n; t0 += TS, it++) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        const bool more = (t0 + TS) < n;
+        if (loader) {
+            if (more) {
+                stage(t0 + TS, (it + 1) % 3);
+            }
+            if (offload && it > 0) {
+                drain((it - 1) & 1);
+            }
+            prepare();
+        } else {
+            const int base = (it % 3) * TS;
+            auto rd = [&](const float* row, int j) {
+                int idx = base + j;
+                idx += idx < 0 ? RT : 0;
+                return row[idx];
+            };
+            const int done_snap = live ? L.done_e[ln] : 0;
+            int qk = 0;
+            if (live && offload) {
+                L.qo[it & 1][ln] = o;
+            }
+            int guard = 0;
+            while (true) {
+                // ---- symbol start ----------------------------------------------------------------------------------
+                if (live && sp < tn && !s.in_symbol) {
+                    int sps = whole;
+                    if (rem > 0) {
+                        int acc = s.sps_accum + rem;
+                        if (acc >= cfg.sym_rate) {
+                            sps++;
+                            acc -= cfg.sym_rate;
+                        }
+                        s.sps_accum = acc;
+                        sps = sps > 64 ? 64 : sps;
+                    }
+                    s.span = sps;
+                    s.centre = (sps - 1) / 2;
+                    s.i = 0;
+                    s.sum = 0.0f;
+                    s.count = 0;
+                    s.in_symbol = 1;
+                    if (sps > 1 && s.have_sync == 0 && s.jitter >= 0) {
+                        if (s.jitter > 0 && s.jitter <= s.centre) {
+                            s.i--;
+                        } else if (s.jitter > s.centre && s.jitter < sps) {
+                            s.i++;
+                        }
+                        s.jitter = -1;
+                    }
+                }
+                // ---- whole-symbol evaluation -----------------------------------------------------------------------
+                const int cnt = s.span - s.i; // samples this symbol still consumes
+                const bool cold = s.filter_on && (abs0 + t0 + sp - s.filt_start) < (long long)(NT - 1);
+                const bool wholeok = live && s.in_symbol && cnt > 0 && cnt <= WMAX && !cold;
+                const bool fits = sp + cnt <= tn;
+                const bool blocked = wholeok && !fits && more; // wait for the next tile, both tiles stay staged
+                const bool fo = s.filter_on != 0;
+                const float* row = fo ? frow : rrow;
+                const bool latched = wholeok && fits && s.i == 0 && s.have_sync && s.jitter >= 0 && s.span >= 6
+                                     && s.span != 20;
+                if (latched) {
+                    // in frame with the crossing latched: nothing per-sample can change state, the symbol is the mean
+                    // of the five clipped window samples (added in sample order)
+                    const int c = s.centre;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        float x = rd(row, sp + c - 2 + k);
+                        x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        acc += x;
+                    }
+                    float xl = rd(row, sp + s.span - 1);
+                    xl = xl > s.max ? s.max : (xl < s.min ? s.min : xl);
+                    s.sum = acc;
+                    s.count = 5;
+                    s.lastsample = xl;
+                    sp += s.span;
+                    s.i = s.span;
+                }
+                const bool gen = wholeok && fits && !latched;
+                if (__any(gen)) {
+                    for (int k = 0; k < WMAX; k++) {
+                        const bool on = gen && k < cnt;
+                        if (!__any(on)) {
+                            break;
+                        }
+                        if (on) {
+                            float x = rd(row, sp + k);
+                            if (s.have_sync) {
+                                x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                            }
+                            const int i = s.i + k;
+                            if (s.jitter < 0) {
+                                if (x > s.center) {
+                                    if (!(x > s.maxref * 1.25f) && s.lastsample < s.center) {
+                                        s.jitter = i;
+                                    }
+                                } else if (!(x < s.minref * 1.25f) && s.lastsample > s.center) {
+                                    s.jitter = i;
+                                }
+                            }
+                            if (s.span == 20 && i >= 7 && i <= 13) {
+                                s.sum += x;
+                                s.count++;
+                            }
+                            if ((s.span == 5 && i == 2) || (i >= s.centre - 2 && i <= s.centre + 2)) {
+                                s.sum += x;
+                                s.count++;
+                            }
+                            s.lastsample = x;
+                        }
+                    }
+                    if (gen) {
+                        sp += cnt;
+                        s.i = s.span;
+                    }
+                }
+                // ---- sample-at-a-time path (filter cold start, long spans, last tile of the call) --------------------
+                bool act = live && s.in_symbol && sp < tn && s.i < s.span && !blocked;
+                while (__any(act)) {
+                    if (act) {
+                        float x = rd(rrow, sp);
+                        if (s.filter_on) {
+                            const long long a = abs0 + t0 + sp;
+                            if (a - s.filt_start >= (long long)(NT - 1)) {
+                                x = rd(frow, sp);
+                            } else {
+                                // first 90 samples after the enable: FIR over a zero-extended history
+                                const long k = t0 + sp;
+                                float acc = 0.0f;
+                                for (int i = 0; i < NT; i++) {
+                                    const long j = k - (NT - 1) + i;
+                                    float v = 0.0f;
+                                    if (abs0 + j >= s.filt_start) {
+                                        v = (j >= 0) ? raw[(size_t)ch * stride + j]
+                                                     : prev_tail[(size_t)ch * (NT - 1) + (NT - 1) + j];
+                                    }
+                                    acc += __uint_as_float(c_taps[i]) * v;
+                                }
+                                x = acc;
+                            }
+                        }
+                        if (s.have_sync) {
+                            x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        }
+                        const int i = s.i;
+                        if (s.jitter < 0) {
+                            if (x > s.center) {
+                                if (!(x > s.maxref * 1.25f) && s.lastsample < s.center) {
+                                    s.jitter = i;
+                                }
+                            } else if (!(x < s.minref * 1.25f) && s.lastsample > s.center) {
+                                s.jitter = i;
+                            }
+                        }
+                        if (s.span == 20 && i >= 7 && i <= 13) {
+                            s.sum += x;
+                            s.count++;
+                        }
+                        if ((s.span == 5 && i == 2) || (i >= s.centre - 2 && i <= s.centre + 2)) {
+                            s.sum += x;
+                            s.count++;
+                        }
+                        s.lastsample = x;
+                        s.i++;
+                        sp++;
+                    }
+                    act = live && s.in_symbol && sp < tn && s.i < s.span && !blocked;
+                }
+                // ---- symbol commit ---------------------------------------------------------------------------------
+                const bool done = live && s.in_symbol && s.i >= s.span;
+                if (done) {
+                    const float sym = (s.count > 0) ? (s.sum / (float)s.count) : 0.0f;
+                    s.in_symbol = 0;
+                    L.sh[s.shead][ln] = sym;
+                    s.shead = (s.shead + 1 >= 24) ? 0 : s.shead + 1;
+                    s.scount = s.scount < 24 ? s.scount + 1 : 24;
+                    int fl = 0;
+                    float q_max = 0.0f, q_min = 0.0f;
+                    if (s.have_sync) {
+                        // get_dibit_and_analog_signal(): window, extrema rings, thresholds (slice + soft decision on wave 1)
+                        const int neg = (s.lastsync == 2);
+                        float m1, m2, x1, x2;
+                        window_push(sym, true, m1, m2, x1, x2, done_snap);
+                        const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
+                        const size_t ro = (size_t)s.midx * n_channels + ch;
+                        float old_lo = s.fill_min, old_hi = s.fill_max;
+                        if (s.since_fill >= MS) {
+                            old_lo = minring[ro];
+                            old_hi = maxring[ro];
+                        } else {
+                            s.since_fill++;
+                        }
+                        s.min_sum += (double)lo - (double)old_lo;
+                        s.max_sum += (double)hi - (double)old_hi;
+                        minring[ro] = lo;
+                        maxring[ro] = hi;
+                        s.midx = (s.midx + 1 >= MS) ? 0 : s.midx + 1;
+                        s.min = (float)(s.min_sum / (double)MS);
+                        s.max = (float)(s.max_sum / (double)MS);
+                        s.center = (s.max + s.min) / 2.0f;
+                        s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
+                        s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
+                        s.maxref = s.max * 0.80f;
+                        s.minref = s.min * 0.80f;
+                        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+                        fl = 1 | (neg ? 4 : 0);
+                        q_max = s.max;
+                        q_min = s.min;
+                        if (--s.lock_left <= 0) {
+                            s.have_sync = 0;
+                            s.lidx = 0;
+                            s.level_count = 0;
+                            s.hist_count = 0;
+                            s.hist_bits = 0;
+                            s.lmin = s.min;
+                            s.lmax = s.max;
+                        }
+                    } else {
+                        // getFrameSync(): one hunting iteration
+                        L.lb[s.lidx][ln] = sym;
+                        s.level_count = s.level_count < 24 ? s.level_count + 1 : 24;
+                        float u0, u1, u2, u3;
+                        window_push(sym, false, u0, u1, u2, u3, done_snap);
+                        s.lidx = (s.lidx == 23) ? 0 : s.lidx + 1;
+                        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+                        const uint32_t bit = sym > 0.0f ? 1u : 0u;
+                        s.hist_bits = ((s.hist_bits << 1) | bit) & 0xFFFFFFu;
+                        s.hist_count = s.hist_count < 24 ? s.hist_count + 1 : 24;
+                        if (s.hist_count >= 8) {
+                            s.maxref = s.max;
+                            s.minref = s.min;
+                            int pol = 0;
+                            if (s.hist_count >= 24) {
+                                pol = (s.hist_bits == kSyncBits) ? 1 : ((s.hist_bits == (~kSyncBits & 0xFFFFFFu)) ? 2 : 0);
+                            }
+                            // The level window (lmin / lmax of the last <= 24 hunting symbols) is recomputed from
+                            // scratch by the reference on every hunting symbol but only consumed when a sync is
+                            // accepted, so it is evaluated here only then: same values at the only point of use.
+                            if (pol) {
+                                const float big = 3.4028234663852886e38f;
+                                float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
+                                float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
+                                const int lc = s.level_count;
+                                for (int k = 0; k < 24; k++) {
+                                    if (k < lc) {
+                                        float v = L.lb[k][ln], t;
+                                        float w = v;
+                                        t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
+                                        t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
+                                        t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
+                                        t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
+                                        a4 = fminf(a4, v);
+                                        t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
+                                        t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
+                                        t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
+                                        t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
+                                        b4 = fmaxf(b4, w);
+                                    }
+                                }
+                                if (lc >= 13) {
+                                    s.lmin = (a2 + a3 + a4) / 3.0f;
+                                    s.lmax = (b4 + b3 + b2) / 3.0f;
+                                } else {
+                                    s.lmin = (a0 + a1 + a2) / 3.0f;
+                                    s.lmax = (b2 + b1 + b0) / 3.0f;
+                                }
+                                s.max = (s.max + s.lmax) / 2;
+                                s.min = (s.min + s.lmin) / 2;
+                                s.lastsync = pol;
+                                if (use_flt && !s.filter_on) {
+                                    s.filter_on = 1;
+                                    s.filt_start = abs0 + t0 + sp; // first sample the filter sees
+                                }
+                                if (s.scount >= 24) {
+                                    float sp_ = 0.0f, sn_ = 0.0f;
+                                    int np = 0, nn = 0;
+                                    int idx = s.shead;
+                                    for (int k = 0; k < 24; k++) {
+                                        idx = idx == 0 ? 23 : idx - 1;
+                                        const float v = L.sh[idx][ln];
+                                        if (v > 0.0f) {
+                                            sp_ += v;
+                                            np++;
+                                        } else {
+                                            sn_ += v;
+                                            nn++;
+                                        }
+                                    }
+                                    if (np != 0 && nn != 0) {
+                                        const float mp = sp_ / (float)np, mn = sn_ / (float)nn;
+                                        if (!(fabsf(mp - mn) < 1.0f)) {
+                                            s.max = mp;
+                                            s.min = mn;
+                                            s.center = (s.max + s.min) / 2.0f;
+                                            s.umid = s.center + (s.max - s.center) * 0.625f;
+                                            s.lmid = s.center + (s.min - s.center) * 0.625f;
+                                            s.maxref = s.max * 0.80f;
+                                            s.minref = s.min * 0.80f;
+                                            s.fill_max = s.max;
+                                            s.fill_min = s.min;
+                                            s.since_fill = 0;
+                                            s.max_sum = (double)s.max * (double)MS;
+                                            s.min_sum = (double)s.min * (double)MS;
+                                        }
+                                    }
+                                }
+                                s.have_sync = 1;
+                                s.lock_left = cfg.lock_symbols;
+                                fl = 2 | (pol == 2 ? 4 : 0);
+                                if (s.lock_left <= 0) {
+                                    s.have_sync = 0;
+                                    s.lidx = 0;
+                                    s.level_count = 0;
+                                    s.hist_count = 0;
+                                    s.hist_bits = 0;
+                                    s.lmin = s.min;
+                                    s.lmax = s.max;
+                                }
+                            }
+                        }
+                    }
+                    if (offload && qk < QCW) {
+                        L.q[it & 1][qk][0][ln] = sym;
+                        L.q[it & 1][qk][1][ln] = q_max;
+                        L.q[it & 1][qk][2][ln] = q_min;
+                        L.q[it & 1][qk][3][ln] = __int_as_float(fl);
+                        qk++;
+                    } else if ((size_t)o < max_sym) {
+                        int dibit, relb = 0, l0 = 0, l1 = 0;
+                        if (fl & 1) {
+                            const float center = (q_max + q_min) / 2.0f;
+                            const ddn_sl::Thr th = {center, ((q_max - center) * 5.0f / 8.0f) + center,
+                                                    ((q_min - center) * 5.0f / 8.0f) + center, q_max, q_min};
+                            ddn_sl::slice_soft(sym, th, (fl >> 2) & 1, dibit, relb, l0, l1);
+                        } else {
+                            dibit = sym > 0.0f ? 1 : 3;
+                        }
+                        store_record(rp + (size_t)o * 10, fp + o, sym, dibit, relb, l0, l1, fl);
+                    }
+                    o++;
+                }
+                const bool busy = live && sp < tn && !blocked;
+                if (!__any(busy) || ++guard > 4 * TS) {
+                    break;
+                }
+            }
+            if (live) {
+                if (offload) {
+                    L.qn[it & 1][ln] = qk;
+                }
+                L.want_e[ln] = gent + 1;
+                L.want_g[ln] = ((s.sidx >> 4) + ((s.sidx & 15) ? 1 : 0)) & 7;
+                sp -= TS;
+            }
+        }
+        __syncthreads();
+    }
+    if (loader && offload && it > 0) {
+        drain((it - 1) & 1);
+    }
+    if (live) {
+        s.n_abs = abs0 + n;
+        state[ch] = s;
+        counts[ch] = o;
+        for (int k = 0; k < SS; k++) {
+            sbuf_store[(size_t)k * n_channels + ch] = L.sb[k][ln];
+        }
+        for (int k = 0; k < 24; k++) {
+            lbuf_store[(size_t)k * n_channels + ch] = L.lb[k][ln];
+            shist_store[(size_t)k * n_channels + ch] = L.sh[k][ln];
+        }
+    }
+}
+
+template <int CPW>
+static hipError_t
+launch_rxw(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
+           const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
+           float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, hipStream_t st) {
+    const size_t shm = sizeof(LdsW<CPW>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rxw<CPW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_p25_rxw<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shm, st, raw, filt,
+                       prev_tail, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
+                       maxring, rec, flags, counts, max_sym);
+    return hipGetLastError();
+}
+
 template <int CPW>
 static hipError_t
 launch_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
@@ -575,6 +1248,16 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long
     if (cpw != 16 && cpw != 32 && cpw != 64) {
         // fewest lanes per wavefront that still gives every CU (256) no more than ~2 workgroups
         cpw = n_channels <= 16 * 512 ? 16 : (n_channels <= 32 * 512 ? 32 : 64);
+    }
+    // CPW 16 / 32 run the windowed variant (k_p25_rxw); 64 lanes per wavefront keeps the two-tile kernel, whose LDS
+    // footprint still fits (cfg.dbg bit 128 forces it for A/B timing)
+    if (cpw == 16 && !(cfg->dbg & 128)) {
+        return launch_rxw<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                              shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+    }
+    if (cpw == 32 && !(cfg->dbg & 128)) {
+        return launch_rxw<32>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                              shist_store, minring, maxring, rec, flags, counts, max_sym, st);
     }
     switch (cpw) {
         case 16:

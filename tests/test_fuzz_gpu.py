@@ -50,7 +50,7 @@ def test_front_end_random_configs(built, seed):
         assert len(bad) == 0, (seed, c, passes, profile, blk, squelch, fmt_cf32, lens, bad[:5])
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_rx_random_splits(built, seed):
     rng = np.random.default_rng(2000 + seed)
     B = int(rng.integers(1, 24))
@@ -58,9 +58,17 @@ def test_rx_random_splits(built, seed):
     lock = frame - 24 if rng.random() < 0.7 else int(rng.integers(0, frame))
     use_filter = int(rng.integers(0, 2))
     n = int(rng.integers(3000, 30000))
-    x, _, _ = orc.synth_p25_disc(int(rng.integers(0, 999)), B, n, frame_dibits=frame, noise=float(rng.choice([200, 800, 2500])))
+    # seeds < 24 keep the default 48 kHz / 10 samples per symbol; the rest walk the samples-per-symbol cases of
+    # getSymbol(): 5 (single-sample window), 8, 12, 20 (wide window), and a fractional rate (accumulator carries)
+    out_rate, sps = 48000, 10
+    if seed >= 24:
+        out_rate, sps = [(24000, 5), (38400, 8), (57600, 12), (96000, 20), (50000, 10), (48000, 10)][seed % 6]
+        use_filter = use_filter if out_rate == 48000 else 0  # the matched filter is designed for 48 kHz only
+    x, _, _ = orc.synth_p25_disc(int(rng.integers(0, 999)), B, n, frame_dibits=frame, sps=sps,
+                                 noise=float(rng.choice([200, 800, 2500])))
     cuts = sorted(set([0, n] + [int(v) for v in rng.integers(1, n, int(rng.integers(0, 5)))]))
-    rx = ddn.P25Rx(B, lock_symbols=lock, use_matched_filter=use_filter, channels_per_wave=int(rng.choice([0, 16, 32, 64])))
+    rx = ddn.P25Rx(B, out_rate=out_rate, lock_symbols=lock, use_matched_filter=use_filter,
+                   channels_per_wave=int(rng.choice([0, 16, 32, 64])))
     recs, fls = [[] for _ in range(B)], [[] for _ in range(B)]
     for a, e in zip(cuts[:-1], cuts[1:]):
         rec, fl, cnt = rx.run(x[:, a:e])
@@ -68,7 +76,7 @@ def test_rx_random_splits(built, seed):
             recs[c].append(rec[c, :cnt[c]])
             fls[c].append(fl[c, :cnt[c]])
     for c in range(B):
-        o = orc.OracleP25Rx(lock_symbols=lock, use_filter=use_filter)
+        o = orc.OracleP25Rx(out_rate=out_rate, lock_symbols=lock, use_filter=use_filter)
         sym, rec4, fl = o.run(x[c])
         r4, sy = orc.unpack_records10(np.concatenate(recs[c]))
         assert np.array_equal(sy.view(np.uint32), sym.view(np.uint32)), (seed, c)
