@@ -108,6 +108,18 @@ PROTOTYPES = {
     "ddn_p25p1_nid_decode_batch": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_p25p1_nid_decode_host": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_size_t, C.c_void_p]),
     "ddn_p25p1_nid_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_ubyte, C.c_uint8, C.c_int, C.c_void_p]),
+    "ddn_p25p1_imbe_deinterleave_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_imbe_deinterleave_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_resampler_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ddn_resampler_destroy": (None, [C.c_void_p]),
+    "ddn_resampler_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_resampler_out_len": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "ddn_resampler_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "ddn_resampler_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_resampler_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "dsd_resampler_process_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "ddn_fec_hamming_10_6_3_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_hamming_10_6_3_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddn_fec_golay24_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),

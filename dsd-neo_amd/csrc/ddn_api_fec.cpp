@@ -851,3 +851,42 @@ p25p1_rs_36_20_17_soft_reliability(char* data, const char* parity, const uint8_t
                                    const uint8_t* parity_reliab) {
     return rs_soft_one(DDN_RS_36_20_17, data, parity, data_reliab, parity_reliab);
 }
+
+
+// ---- IMBE de-interleave (process_IMBE) ------------------------------------------------------------------------------
+extern "C" int
+ddn_p25p1_imbe_deinterleave_batch(const uint8_t* d_records10, size_t n_records, const int64_t* d_first_record,
+                                  const int32_t* d_status_count, size_t n_frames, uint8_t* d_imbe_fr,
+                                  uint8_t* d_imbe_soft, uint8_t* d_flags, int32_t* d_status_count_out,
+                                  void* hip_stream) {
+    if (!d_records10 || !d_first_record || !d_status_count || !d_imbe_fr || !d_imbe_soft || !d_flags
+        || !d_status_count_out) {
+        ddn_set_error("ddn_p25p1_imbe_deinterleave_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_imbe_deinterleave(d_records10, (long)n_records, d_first_record, d_status_count, (int)n_frames,
+                                      d_imbe_fr, d_imbe_soft, d_flags, d_status_count_out, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p1_imbe_deinterleave_host(const uint8_t* records10, size_t n_records, const int64_t* first_record,
+                                 const int32_t* status_count, size_t n_frames, uint8_t* imbe_fr, uint8_t* imbe_soft,
+                                 uint8_t* flags, int32_t* status_count_out) {
+    if (!records10 || !first_record || !status_count || !imbe_fr || !imbe_soft || !flags || !status_count_out) {
+        return DDN_EINVAL;
+    }
+    Dev r(n_records * 10), f(n_frames * 8), c(n_frames * 4), o(n_frames * 184), so(n_frames * 368), fl(n_frames),
+        co(n_frames * 4);
+    if (!r.p || !f.p || !c.p || !o.p || !so.p || !fl.p || !co.p || r.up(records10) || f.up(first_record)
+        || c.up(status_count)) {
+        return no_dev();
+    }
+    int rc = ddn_p25p1_imbe_deinterleave_batch((const uint8_t*)r.p, n_records, (const int64_t*)f.p, (const int32_t*)c.p,
+                                               n_frames, (uint8_t*)o.p, (uint8_t*)so.p, (uint8_t*)fl.p, (int32_t*)co.p,
+                                               nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (o.down(imbe_fr) || so.down(imbe_soft) || fl.down(flags) || co.down(status_count_out)) ? no_dev() : DDN_OK;
+}

@@ -131,6 +131,11 @@ hipError_t ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8
 hipError_t ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, int n, uint8_t* status,
                         hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);
+hipError_t ddn_dev_resample(const float* in, long n, size_t in_stride, int n_channels, float* hist, const float* taps,
+                            int L, int M, int p0, long n_out, float* out, size_t out_stride, hipStream_t st);
+hipError_t ddn_dev_imbe_deinterleave(const uint8_t* rec, long n_records, const int64_t* first, const int32_t* status_count,
+                                     int n_frames, uint8_t* fr, uint8_t* soft, uint8_t* flags, int32_t* status_out,
+                                     hipStream_t st);
 hipError_t ddn_dev_r34_list(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, uint8_t* backs,
                             uint32_t* cand, int32_t* count, hipStream_t st);
 hipError_t ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, uint32_t* cand, int32_t* count,

@@ -122,3 +122,37 @@ ddn_design_fll_band_edge(int sps, float* taps4, float* alpha, float* beta) {
     *beta = (4.0f * loop_bw * loop_bw) / denom;
     return n_taps;
 }
+
+
+/* Polyphase prototype of the rational resampler (resampler_design_taps, src/dsp/resampler.cpp:166-190; 16 taps per
+ * phase :253-260): Hamming-windowed sinc at fc = 0.45 / max(L, M) evaluated in binary64, unity DC gain, times L,
+ * stored per phase with the oldest tap first.  taps holds 16 * L floats; returns 16 * L. */
+static double
+rs_sinc(double x) {
+    const double pi = 3.14159265358979323846;
+    return x == 0.0 ? 1.0 : sin(pi * x) / (pi * x);
+}
+
+int
+ddn_design_resampler(int L, int M, float* taps) {
+    const double pi = 3.14159265358979323846;
+    const int K = 16, total = K * L, mid = (total - 1) / 2;
+    const double fc = 0.45 / (double)((L > M) ? L : M);
+    double gain = 0.0;
+    for (int n = 0; n < total; n++) {
+        const double w = 0.54 - 0.46 * cos(2.0 * pi * (double)n / (double)(total - 1));
+        gain += 2.0 * fc * rs_sinc(2.0 * fc * (double)(n - mid)) * w;
+    }
+    if (gain == 0.0) {
+        gain = 1.0;
+    }
+    for (int phase = 0; phase < L; phase++) {
+        for (int k = 0; k < K; k++) {
+            const int src = phase + ((K - 1 - k) * L);
+            const double w = 0.54 - 0.46 * cos(2.0 * pi * (double)src / (double)(total - 1));
+            const double h = 2.0 * fc * rs_sinc(2.0 * fc * (double)(src - mid));
+            taps[phase * K + k] = (float)((h * w / gain) * (double)L);
+        }
+    }
+    return total;
+}

@@ -13,6 +13,8 @@ extern "C" {
 int ddn_design_channel_lpf(int rate_hz, int profile, float* taps, int max_taps);
 #define DDN_FLL_MAX_TAPS 48 /* FLL_BAND_EDGE_MAX_TAPS, include/dsd-neo/dsp/costas.h:60 */
 int ddn_design_fll_band_edge(int sps, float* taps4, float* alpha, float* beta);
+int ddn_design_resampler(int L, int M, float* taps);
+#define DDN_RESAMP_MAX_L 512
 void ddn_set_error(const char* fmt, ...);
 #ifdef __cplusplus
 }

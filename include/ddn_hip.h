@@ -180,6 +180,31 @@ int ddn_gardner_run(ddn_ted_batch* b, const float* d_iq, size_t n, float* d_sym,
 int ddn_gardner_run_host(ddn_ted_batch* b, const float* iq, size_t n, float* sym, size_t sym_stride, int* sym_count);
 int ddn_ted_batch_get_state(ddn_ted_batch* b, int channel, float out8[8]);
 
+/* ---- rational resampler, batched -------------------------------------------------------------------
+ * == dsd_resampler_design + dsd_resampler_process_block (include/dsd-neo/dsp/resampler.h:66-89;
+ * src/dsp/resampler.cpp:166-190,241-356), which the demodulator thread applies to the discriminator output when its
+ * rate differs from the symbol loop's (src/io/radio/rtl_sdr_fm.cpp:3311-3313): L/M polyphase, 16 taps per phase,
+ * Hamming-windowed sinc at 0.45 / max(L, M).  B channels share L, M and the polyphase index; a call is equivalent to one
+ * dsd_resampler_process_block() per channel.  d_in [B][n] f32, d_out [B][out_stride] f32 with
+ * ddn_resampler_out_len(b, n) <= out_stride outputs per channel (DDN_ERANGE and untouched state otherwise). */
+typedef struct ddn_resampler ddn_resampler;
+int ddn_resampler_create(int n_channels, int L, int M, ddn_resampler** out); /* 1 <= L <= 512 */
+void ddn_resampler_destroy(ddn_resampler* b);
+int ddn_resampler_reset(ddn_resampler* b, void* hip_stream);                 /* == dsd_resampler_clear_history */
+size_t ddn_resampler_out_len(const ddn_resampler* b, size_t n);              /* outputs the next run of n inputs gives */
+int ddn_resampler_get_taps(const ddn_resampler* b, float* taps, int cap);    /* [L][16], oldest tap first; returns 16 L */
+int ddn_resampler_run(ddn_resampler* b, const float* d_in, size_t n, float* d_out, size_t out_stride, void* hip_stream);
+int ddn_resampler_run_host(ddn_resampler* b, const float* in, size_t n, float* out, size_t out_stride);
+/* drop-in with the reference's name and state layout (include/dsd-neo/dsp/resampler.h:30-42, :89): one stream per call
+ * through the same kernel, caller-owned taps / mirrored history updated in place; returns outputs written or -1. */
+typedef struct ddn_dsd_resampler_state {
+    int enabled, target_hz, L, M, phase, taps_len, taps_per_phase, hist_head;
+    float* taps;
+    float* hist;
+    uint64_t internal_cookie;
+} ddn_dsd_resampler_state;
+int dsd_resampler_process_block(ddn_dsd_resampler_state* state, const float* in, int in_len, float* out, int out_cap);
+
 /* ---- P25 CQPSK / LSM front end, batched -------------------------------------------------------------------
  * == full_demod(struct demod_state*) with cqpsk_enable (include/dsd-neo/dsp/demod_pipeline.h:106;
  * src/dsp/demod_pipeline.cpp:1100-1118,1330-1350): channel LPF (profile DDN_LPF_P25_CQPSK) -> cqpsk_rms_agc ->
@@ -298,6 +323,25 @@ int ddn_fec_hamming_10_6_3_soft_batch(const uint8_t* d_bits10, const int32_t* d_
                                       uint8_t* d_status, void* hip_stream);
 int ddn_fec_hamming_10_6_3_soft_host(const uint8_t* bits10, const int32_t* reliab10, size_t n, uint8_t* out10,
                                      uint8_t* status);
+/* == the de-interleave of process_IMBE() (src/protocol/p25/phase1/p25p1_ldu.c:89-120) for n_frames voice frames at
+ * once, reading the receive loop's 10-byte capture records in place:
+ *   d_records10      flat record array (any number of channels back to back), n_records records long
+ *   d_first_record   [n_frames] index of the record holding the frame's first dibit
+ *   d_status_count   [n_frames] the reference's status_count on entry (dibits since the last status symbol, 0..35);
+ *                    a record is stepped over as status symbol whenever the counter shows 35 (:27-39)
+ *   d_imbe_fr        [n_frames][8][23] hard bits (char imbe_fr[8][23]; cells the schedule never writes stay 0)
+ *   d_imbe_soft      [n_frames][8][23][2] = dsd_vocoder_soft_bit {bit, reliability = min(|llr|, 255)}
+ *                    (include/dsd-neo/core/vocoder.h:25-38)
+ *   d_flags          [n_frames] 1 = c0 is the non-standard word the reference skips (:55-66), 0 = normal,
+ *                    0xFF = the frame runs past n_records (outputs for the missing dibits are 0)
+ *   d_status_count_out [n_frames] counter after the 72 dibits (what the next process_IMBE() call starts from) */
+int ddn_p25p1_imbe_deinterleave_batch(const uint8_t* d_records10, size_t n_records, const int64_t* d_first_record,
+                                      const int32_t* d_status_count, size_t n_frames, uint8_t* d_imbe_fr,
+                                      uint8_t* d_imbe_soft, uint8_t* d_flags, int32_t* d_status_count_out,
+                                      void* hip_stream);
+int ddn_p25p1_imbe_deinterleave_host(const uint8_t* records10, size_t n_records, const int64_t* first_record,
+                                     const int32_t* status_count, size_t n_frames, uint8_t* imbe_fr, uint8_t* imbe_soft,
+                                     uint8_t* flags, int32_t* status_count_out);
 int ddn_fec_p25_rs_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, size_t n, uint8_t* d_status,
                          void* hip_stream);
 int ddn_fec_p25_rs_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, size_t n, uint8_t* status);

@@ -212,6 +212,11 @@ int orc_p25_rs_ranked_erasures(const uint8_t* data_rel, int n_data, const uint8_
 int orc_p25_rs_soft_reliability(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_rel,
                                 const uint8_t* parity_rel, int n_par, int n_data, int t);
 int orc_hamming_10_6_3_soft(const uint8_t* bits, const int* reliab, uint8_t* out);
+/* process_IMBE() de-interleave of 72 dibits (+ skipped status symbols); returns 1 when c0 is the non-standard word,
+ * 0 otherwise, -1 when fewer than `consumed` dibits are available */
+int orc_p25p1_imbe_deinterleave(const uint8_t* dibits, const int16_t* llr0, const int16_t* llr1, long n_avail,
+                                int status_count, uint8_t fr[8][23], uint8_t soft[8][23][2], int* status_count_out,
+                                int* consumed);
 int orc_golay_24_soft(uint8_t* data, int len, const uint8_t* parity, const int* reliab, int* fixed);
 int orc_p25_rs_decode(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t);
 
@@ -220,6 +225,19 @@ int orc_bch_63_16_decode(const uint8_t in63[63], uint8_t out16[16], int* err_cou
 void orc_p25p1_nid_decode(const uint8_t code[63], const uint8_t* rel63, int observed_nac, int parity, int parity_rel,
                           int threshold, int out4[4]);
 int orc_hamming_10_6_3(int word10, int* fixed6);
+
+/* ---- rational L/M polyphase resampler (ddn_oracle_resamp.c) ---- */
+#define ORC_RESAMP_MAX_L 512
+typedef struct orc_resamp {
+    int L, M, phase;
+    float win[16];
+    float taps[16 * ORC_RESAMP_MAX_L];
+} orc_resamp;
+int orc_resamp_design(int L, int M, float* taps); /* taps[16 * L], per phase oldest tap first; returns 16 * L */
+size_t orc_resamp_sizeof(void);
+int orc_resamp_init(orc_resamp* r, int L, int M);
+long orc_resamp_run(orc_resamp* r, const float* in, long n, float* out, long cap);
+
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,7 @@
  *   BCH(63,16,11) over GF(2^6), x^6+x+1      include/dsd-neo/fec/BCH_63_16.hpp:47-330
  *   P25p1 NID decode: hard + NAC retry + Chase   src/protocol/p25/phase1/p25p1_check_nid.cpp:200-354
  *   Hamming(10,6,3)                          src/fec/hamming_10_6_3.cpp:20-105
+ *   IMBE de-interleave of one LDU voice frame    src/protocol/p25/phase1/p25p1_ldu.c:27-48,89-120
  *
  * The BCH decoder is a bounded-distance decoder: for a received word within 11 bits of a codeword every correct
  * Berlekamp-Massey formulation returns that codeword and the same error count; beyond that the connection
@@ -321,4 +322,67 @@ orc_hamming_10_6_3(int word10, int* fixed6) {
     }
     *fixed6 = fixed >> 4;
     return errs;
+}
+
+
+/* ---- IMBE de-interleave (process_IMBE, src/protocol/p25/phase1/p25p1_ldu.c:89-120) ---------------------------------
+ * The 144 bits of the eight IMBE code vectors c0..c3 (23 bits), c4..c6 (15), c7 (7), laid end to end most significant
+ * index first, are sent twelve bits per row r = 0..11: columns 0..5 carry stream bits 24k + 2r (k = column), columns
+ * 6..11 carry 24k + 2r + 1 for k = 1,0,3,2,5,4 (the schedule behind the p25p1_imbe_interleave_{w,x,y,z} tables of
+ * include/dsd-neo/protocol/p25/p25p1_const.h:30-47; tests pin this formula to those tables).  Dibit j holds
+ * transmitted bits 2j (high) and 2j+1 (low).  A status symbol is skipped whenever the running dibit counter shows 35
+ * (p25p1_ldu.c:27-39).  Soft bit = {hard bit, min(|llr|, 255)} (include/dsd-neo/core/vocoder.h:30-38). */
+static void
+imbe_cell(int p, int* vec, int* idx) {
+    static const int len[8] = {23, 23, 23, 23, 15, 15, 15, 7};
+    const int r = p / 12, m = p % 12;
+    int L = (m < 6) ? 24 * m + 2 * r : 24 * ((m - 6) ^ 1) + 2 * r + 1;
+    int v = 0;
+    while (L >= len[v]) {
+        L -= len[v];
+        v++;
+    }
+    *vec = v;
+    *idx = len[v] - 1 - L;
+}
+
+int
+orc_p25p1_imbe_deinterleave(const uint8_t* dibits, const int16_t* llr0, const int16_t* llr1, long n_avail,
+                            int status_count, uint8_t fr[8][23], uint8_t soft[8][23][2], int* status_count_out,
+                            int* consumed) {
+    memset(fr, 0, 8 * 23);
+    memset(soft, 0, 8 * 23 * 2);
+    long pos = 0;
+    for (int j = 0; j < 72; j++) {
+        if (status_count == 35) {
+            pos++; /* mid-frame status symbol */
+            status_count = 1;
+        } else {
+            status_count++;
+        }
+        if (pos >= n_avail) {
+            return -1;
+        }
+        const int d = dibits[pos];
+        const int l[2] = {llr0[pos], llr1[pos]};
+        pos++;
+        for (int h = 0; h < 2; h++) {
+            int v, i;
+            imbe_cell(2 * j + h, &v, &i);
+            const int bit = h == 0 ? ((d >> 1) & 1) : (d & 1);
+            int rel = l[h] < 0 ? -l[h] : l[h];
+            rel = rel > 255 ? 255 : rel;
+            fr[v][i] = (uint8_t)bit;
+            soft[v][i][0] = (uint8_t)bit;
+            soft[v][i][1] = (uint8_t)rel;
+        }
+    }
+    *status_count_out = status_count;
+    *consumed = (int)pos;
+    /* is_non_standard_c0_word(), p25p1_ldu.c:55-66: c0 == 0x000070 read index 0 first */
+    int ns = 1;
+    for (int i = 0; i < 23; i++) {
+        ns &= (fr[0][i] == ((i >= 15 && i <= 17) ? 1 : 0));
+    }
+    return ns;
 }

@@ -393,6 +393,8 @@ refh_sync_p25p1_neg(void) {
 // ---- (src/dsp/frame_sync_level.c), driven on the same dsd_state the slicer harness owns -------------------------
 #include <dsd-neo/dsp/sync_calibration.h>
 #include "frame_sync_level.h" /* src/dsp/frame_sync_level.h (private header, on the -I path) */
+#include <dsd-neo/core/vocoder.h>
+#include <dsd-neo/protocol/p25/p25p1_const.h>
 
 extern "C" {
 // Push `n` symbols (oldest first) through dsd_symbol_history_push(), then run the reference's
@@ -492,5 +494,37 @@ refh_cqpsk_get_state(void* h, float out8[8]) {
     out8[5] = d->costas_state.error_smooth;
     out8[6] = d->ted_state.mu;
     out8[7] = d->ted_state.omega;
+}
+
+// process_IMBE()'s store loop (src/protocol/p25/phase1/p25p1_ldu.c:89-112) on caller-supplied dibits: the tables and the
+// soft-bit conversion are the reference's own (p25p1_const.h, vocoder.h); getDibitSoft() is replaced by array reads.
+int
+refh_imbe_deinterleave(const uint8_t* dibits, const int16_t* llr0, const int16_t* llr1, int status_count,
+                       char fr[8][23], uint8_t soft[8][23][2], int* status_count_out) {
+    std::memset(fr, 0, 8 * 23);
+    std::memset(soft, 0, 8 * 23 * 2);
+    int pos = 0;
+    for (int j = 0; j < 72; j++) {
+        if (status_count == 35) {
+            pos++;
+            status_count = 1;
+        } else {
+            status_count++;
+        }
+        const int dibit = dibits[pos];
+        const int w = p25p1_imbe_interleave_w[j], x = p25p1_imbe_interleave_x[j];
+        const int y = p25p1_imbe_interleave_y[j], z = p25p1_imbe_interleave_z[j];
+        fr[w][x] = (char)(1 & (dibit >> 1));
+        fr[y][z] = (char)(1 & dibit);
+        const dsd_vocoder_soft_bit a = dsd_vocoder_soft_bit_from_hard_llr(fr[w][x], llr0[pos]);
+        const dsd_vocoder_soft_bit b = dsd_vocoder_soft_bit_from_hard_llr(fr[y][z], llr1[pos]);
+        soft[w][x][0] = a.bit;
+        soft[w][x][1] = a.reliability;
+        soft[y][z][0] = b.bit;
+        soft[y][z][1] = b.reliability;
+        pos++;
+    }
+    *status_count_out = status_count;
+    return pos;
 }
 } // extern "C"

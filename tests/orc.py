@@ -408,3 +408,91 @@ def ref_cqpsk_f32(iq, block_len, rate=24000, sym_rate=4800, profile=5, lpf=1):
     r.refh_cqpsk_get_state(h, st.ctypes.data)
     r.refh_fe_destroy(h)
     return out[:k].copy(), st
+
+
+# ---- IMBE de-interleave (oracle/ddn_oracle_block.c; reference harness refh_imbe_deinterleave) --------------------------
+def oracle_imbe_deinterleave(dibits, llr0, llr1, status_count):
+    """One voice frame: dibits uint8 [>= 75], llr int16 -> (fr uint8 [8,23], soft uint8 [8,23,2], flag, status_out,
+    records consumed)."""
+    o = oracle()
+    o.orc_p25p1_imbe_deinterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    d = np.ascontiguousarray(dibits, np.uint8)
+    a = np.ascontiguousarray(llr0, np.int16)
+    b = np.ascontiguousarray(llr1, np.int16)
+    fr = np.zeros((8, 23), np.uint8)
+    soft = np.zeros((8, 23, 2), np.uint8)
+    sc, used = C.c_int(0), C.c_int(0)
+    flag = o.orc_p25p1_imbe_deinterleave(d.ctypes.data, a.ctypes.data, b.ctypes.data, d.size, status_count,
+                                         fr.ctypes.data, soft.ctypes.data, C.byref(sc), C.byref(used))
+    return fr, soft, flag, sc.value, used.value
+
+
+def ref_imbe_deinterleave(dibits, llr0, llr1, status_count):
+    r = ref()
+    r.refh_imbe_deinterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    d = np.ascontiguousarray(dibits, np.uint8)
+    a = np.ascontiguousarray(llr0, np.int16)
+    b = np.ascontiguousarray(llr1, np.int16)
+    fr = np.zeros((8, 23), np.uint8)
+    soft = np.zeros((8, 23, 2), np.uint8)
+    sc = C.c_int(0)
+    used = r.refh_imbe_deinterleave(d.ctypes.data, a.ctypes.data, b.ctypes.data, status_count, fr.ctypes.data,
+                                    soft.ctypes.data, C.byref(sc))
+    return fr, soft, sc.value, used
+
+
+# ---- rational resampler (oracle/ddn_oracle_resamp.c; reference dsd_resampler_* called directly) ------------------------
+class RefResamplerState(C.Structure):  # include/dsd-neo/dsp/resampler.h:30-42
+    _fields_ = [("enabled", C.c_int), ("target_hz", C.c_int), ("L", C.c_int), ("M", C.c_int), ("phase", C.c_int),
+                ("taps_len", C.c_int), ("taps_per_phase", C.c_int), ("hist_head", C.c_int),
+                ("taps", C.POINTER(C.c_float)), ("hist", C.POINTER(C.c_float)), ("internal_cookie", C.c_uint64)]
+
+
+class RefResampler:
+    def __init__(self, L, M):
+        r = ref()
+        r.dsd_resampler_design.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        r.dsd_resampler_process_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        r.dsd_resampler_reset.argtypes = [C.c_void_p]
+        self.r = r
+        self.st = RefResamplerState()
+        assert r.dsd_resampler_design(C.byref(self.st), L, M) == 1
+
+    def taps(self):
+        return np.ctypeslib.as_array(self.st.taps, (self.st.taps_len,)).copy()
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(x.size * self.st.L // self.st.M + 4, np.float32)
+        k = self.r.dsd_resampler_process_block(C.byref(self.st), x.ctypes.data, x.size, out.ctypes.data, out.size)
+        assert k >= 0
+        return out[:k].copy()
+
+    def __del__(self):
+        self.r.dsd_resampler_reset(C.byref(self.st))
+
+
+class OracleResampler:
+    def __init__(self, L, M):
+        o = oracle()
+        o.orc_resamp_sizeof.restype = C.c_size_t
+        o.orc_resamp_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        o.orc_resamp_run.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        o.orc_resamp_run.restype = C.c_long
+        o.orc_resamp_design.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        self.o, self.L, self.M = o, L, M
+        self.st = C.create_string_buffer(o.orc_resamp_sizeof())
+        assert o.orc_resamp_init(self.st, L, M) == 16 * L
+
+    def taps(self):
+        t = np.zeros(16 * self.L, np.float32)
+        self.o.orc_resamp_design(self.L, self.M, t.ctypes.data)
+        return t
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(x.size * self.L // self.M + 4, np.float32)
+        k = self.o.orc_resamp_run(self.st, x.ctypes.data, x.size, out.ctypes.data, out.size)
+        assert k >= 0
+        return out[:k].copy()
