@@ -112,6 +112,7 @@ PROTOTYPES = {
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p1_imbe_deinterleave_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_batch_set_iq_conditioning": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
     "ddn_resampler_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ddn_resampler_destroy": (None, [C.c_void_p]),
     "ddn_resampler_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -237,6 +238,10 @@ class Batch:
     def set_decimation(self, passes):
         _check(lib().ddn_batch_set_decimation(self.h, passes), "ddn_batch_set_decimation")
         self.passes = passes
+
+    def set_iq_conditioning(self, dc_enable=0, dc_shift=11, bal_enable=0, bal_thr=0.0, bal_ema_a=0.0):
+        _check(lib().ddn_batch_set_iq_conditioning(self.h, dc_enable, dc_shift, bal_enable, bal_thr, bal_ema_a),
+               "ddn_batch_set_iq_conditioning")
 
     def run_host(self, iq, n):
         """iq: numpy [B, n, 2] uint8 or float32 (channel-major).  Returns float32 [B, n >> passes]."""

@@ -69,6 +69,12 @@ struct ddn_batch {
     void* d_hbhist[DDN_MAX_HB_PASSES]; // [B][taps_len-1] complex per stage
     void* d_dec[2];                    // ping-pong decimated streams
     size_t dec_cap[2];
+    // optional IQ conditioning (row a5): unfused route channel LPF -> k_iq_cond_disc
+    DdnIqCondConfig iqc;
+    DdnIqCondState* d_iqstate; // [B]
+    void* d_lpf_hist;          // [B][taps_len - 1] complex
+    void* d_lpf;               // [B][n] complex channel-LPF output
+    size_t lpf_cap;
 };
 
 static int
@@ -166,6 +172,9 @@ ddn_batch_destroy(ddn_batch* b) {
     (void)hipFree(b->d_out);
     (void)hipFree(b->d_dec[0]);
     (void)hipFree(b->d_dec[1]);
+    (void)hipFree(b->d_iqstate);
+    (void)hipFree(b->d_lpf_hist);
+    (void)hipFree(b->d_lpf);
     for (int i = 0; i < DDN_MAX_HB_PASSES; i++) {
         (void)hipFree(b->d_hbhist[i]);
     }
@@ -212,7 +221,35 @@ ddn_batch_reset(ddn_batch* b, void* hip_stream) {
     const size_t B = (size_t)b->cfg.n_channels;
     HIP_TRY(ddn_dev_zero(b->d_carry, sizeof(ddn_f2) * B * DDN_CARRY_LEN, st));
     HIP_TRY(ddn_dev_zero(b->d_state, sizeof(DdnFskState) * B, st));
+    if (b->d_iqstate) {
+        HIP_TRY(hipMemsetAsync(b->d_iqstate, 0, sizeof(DdnIqCondState) * B, st));
+        HIP_TRY(hipMemsetAsync(b->d_lpf_hist, 0, sizeof(ddn_f2) * B * (size_t)(b->taps_len - 1), st));
+    }
     return DDN_OK;
+}
+
+extern "C" int
+ddn_batch_set_iq_conditioning(ddn_batch* b, int dc_block_enable, int dc_shift, int iqbal_enable, float iqbal_thr,
+                              float iqbal_ema_alpha) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    if ((dc_block_enable || iqbal_enable) && !b->d_iqstate) {
+        const size_t B = (size_t)b->cfg.n_channels;
+        if (hipMalloc(&b->d_iqstate, sizeof(DdnIqCondState) * B) != hipSuccess
+            || hipMalloc(&b->d_lpf_hist, sizeof(ddn_f2) * B * (size_t)(b->taps_len - 1)) != hipSuccess) {
+            (void)hipFree(b->d_iqstate);
+            b->d_iqstate = nullptr;
+            ddn_set_error("ddn_batch_set_iq_conditioning: device allocation failed");
+            return DDN_ENOMEM;
+        }
+    }
+    b->iqc.dc_enable = dc_block_enable ? 1 : 0;
+    b->iqc.dc_shift = dc_shift;
+    b->iqc.bal_enable = iqbal_enable ? 1 : 0;
+    b->iqc.bal_thr = iqbal_thr;
+    b->iqc.bal_ema_a = iqbal_ema_alpha;
+    return ddn_batch_reset(b, nullptr);
 }
 
 extern "C" int
@@ -281,6 +318,36 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
             block_len >>= 1;
         }
         n >>= b->passes;
+    }
+    if (b->iqc.dc_enable || b->iqc.bal_enable) {
+        // IQ conditioning on: the stages sit between the channel LPF and the discriminator, so the LPF result goes
+        // through HBM once (8 B/sample each way) and the recurrences run one lane per channel (ddn_iqcond.hip)
+        const size_t need = sizeof(ddn_f2) * (size_t)B * n;
+        if (b->lpf_cap < need) {
+            HIP_TRY(hipStreamSynchronize(st));
+            (void)hipFree(b->d_lpf);
+            b->d_lpf = nullptr;
+            b->lpf_cap = 0;
+            HIP_TRY(hipMalloc(&b->d_lpf, need));
+            b->lpf_cap = need;
+        }
+        DdnIqCondConfig c = b->iqc;
+        c.squelch_on = b->cfg.squelch_level > 0.0f ? 1 : 0;
+        c.squelch_level = b->cfg.squelch_level;
+        if (b->timing) {
+            HIP_TRY(hipEventRecord(b->ev[0], st));
+        }
+        HIP_TRY(ddn_dev_channel_lpf_c2c(d_iq, in_fmt, (long)n, n, block_len, B, b->d_taps, b->taps_len, b->d_lpf_hist,
+                                        b->d_lpf, n, st));
+        if (b->timing) {
+            HIP_TRY(hipEventRecord(b->ev[1], st));
+        }
+        HIP_TRY(ddn_dev_iq_cond_disc(b->d_lpf, (long)n, n, block_len, B, &c, b->d_state, b->d_iqstate, d_disc, n, st));
+        if (b->timing) {
+            HIP_TRY(hipEventRecord(b->ev[2], st));
+            b->ev_valid = 1;
+        }
+        return DDN_OK;
     }
     const long n_blocks = (long)((n + (size_t)block_len - 1) / (size_t)block_len);
     const int tiles_per_block = (block_len + DDN_TILE - 1) / DDN_TILE;

@@ -20,6 +20,14 @@ typedef struct DdnFskState { /* == the fields of dsd_fsk_modem_state the path ca
 
 typedef float ddn_f2 __attribute__((ext_vector_type(2)));
 
+typedef struct DdnIqCondConfig { /* optional IQ conditioning switches of struct demod_state (row a5) + squelch gate */
+    int dc_enable, dc_shift, bal_enable, squelch_on;
+    float bal_thr, bal_ema_a, squelch_level;
+} DdnIqCondConfig;
+typedef struct DdnIqCondState { /* iq_dc_avg_r/i, iqbal_alpha_ema_r/i */
+    float dc_r, dc_i, er, ei;
+} DdnIqCondState;
+
 typedef struct DdnFusedArgs {
     const void* in;       /* [B][ch_stride] complex samples (cu8 pairs or float pairs) */
     float* out;           /* [B][out_stride] discriminator samples */
@@ -131,6 +139,9 @@ hipError_t ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8
 hipError_t ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, int n, uint8_t* status,
                         hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);
+hipError_t ddn_dev_iq_cond_disc(const void* in, long n, size_t stride, int block_len, int n_channels,
+                                const DdnIqCondConfig* cfg, DdnFskState* fsk, DdnIqCondState* cond, float* out,
+                                size_t out_stride, hipStream_t st);
 hipError_t ddn_dev_resample(const float* in, long n, size_t in_stride, int n_channels, float* hist, const float* taps,
                             int L, int M, int p0, long n_out, float* out, size_t out_stride, hipStream_t st);
 hipError_t ddn_dev_imbe_deinterleave(const uint8_t* rec, long n_records, const int64_t* first, const int32_t* status_count,

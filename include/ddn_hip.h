@@ -85,6 +85,18 @@ int ddn_batch_get_taps(const ddn_batch* b, float* taps_out, int cap);
  * block_len >> p >= taps_len, n must be a multiple of 2^p and d_disc holds [B][n >> p].  Resets the batch. */
 int ddn_batch_set_decimation(ddn_batch* b, int passes);
 
+/* Optional IQ conditioning between the channel LPF and the discriminator (all off by default like
+ * the reference, src/io/radio/rtl_demod_config.cpp:479-489):
+ *   dc_block_enable / dc_shift   == demod_state.iq_dc_block_enable / iq_dc_shift: iq_dc_block(), a per-sample leaky
+ *                                integrator with alpha = 2^-k, k clamped to 6..15 (src/dsp/demod_pipeline.cpp:948-978)
+ *   iqbal_enable / thr / ema     == iqbal_enable / iqbal_thr (0 -> 0.02) / iqbal_alpha_ema_a (0 -> 0.2):
+ *                                full_demod_apply_iq_balance(), per-block image estimate in binary64, EMA across blocks,
+ *                                correction applied once |alpha| >= thr (:1131-1171)
+ * With either switch on the batch runs the unfused route (channel LPF result through HBM, then one lane per channel);
+ * blocks closed by the squelch gate skip both stages like the reference.  Resets the batch. */
+int ddn_batch_set_iq_conditioning(ddn_batch* b, int dc_block_enable, int dc_shift, int iqbal_enable, float iqbal_thr,
+                                  float iqbal_ema_alpha);
+
 /* One pass of widen -> channel LPF -> (squelch) -> FSK discriminator over n complex samples per channel.
  *   d_iq   : [B][n] interleaved I/Q, u8 pairs (CU8) or float pairs (CF32), channel-major
  *   d_disc : [B][n] float discriminator samples (AGC'd to +-30000, clipped to int16 range)

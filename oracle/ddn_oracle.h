@@ -77,7 +77,12 @@ typedef struct orc_front_end {
     orc_fsk_state fsk;
     float channel_pwr;
     int channel_squelched;
+    /* optional IQ conditioning between the channel LPF and the discriminator (default off) */
+    int iq_dc_enable, iq_dc_shift, iqbal_enable;
+    float iq_dc_r, iq_dc_i, iqbal_thr, iqbal_ema_a, iqbal_er, iqbal_ei;
 } orc_front_end;
+void orc_fe_set_iq_options(orc_front_end* fe, int dc_enable, int dc_shift, int bal_enable, float bal_thr,
+                           float bal_ema_a);
 
 void orc_fe_init(orc_front_end* fe, int rate_hz, int profile, int lpf_enable, float squelch_level,
                  int downsample_passes, int fma_order);

@@ -7,6 +7,7 @@
  *   channel LPF design   src/dsp/firdes.cpp (Blackman low_pass), src/dsp/demod_pipeline.cpp:443-524
  *   channel LPF apply    src/dsp/simd_fir.cpp:55-133 (scalar), src/dsp/simd_fir_avx2.cpp:119-143,400-447 (FMA)
  *   power / squelch      src/dsp/demod_pipeline.cpp:926-945,1003-1020
+ *   IQ DC block / balance src/dsp/demod_pipeline.cpp:948-978,1131-1171 (optional, default off)
  *   FSK discriminator    src/dsp/fsk_modem.c:23-35,89-164
  *
  * Pinned against the reference's own objects by tests/test_oracle_vs_ref.py (bit-exact on this container's
@@ -375,7 +376,67 @@ orc_fe_block_f32(orc_front_end* fe, const float* iq, int n_complex, float* out, 
         return pairs;
     }
     fe->channel_squelched = 0;
+    if ((fe->iq_dc_enable || fe->iqbal_enable) && len >= 2) {
+        float* w = (cur == a) ? a : b;
+        if (cur != a && cur != b) { /* no stage ran yet: work on a copy, the caller's input stays untouched */
+            memcpy(b, cur, sizeof(float) * (size_t)len);
+        }
+        cur = w;
+        if (fe->iq_dc_enable) { /* iq_dc_block(), :948-978: leaky integrator, alpha = 2^-k, k clamped to 6..15 */
+            int k = fe->iq_dc_shift;
+            k = k < 6 ? 6 : (k > 15 ? 15 : k);
+            const float alpha = 1.0f / (float)(1 << k);
+            float dcI = fe->iq_dc_r, dcQ = fe->iq_dc_i;
+            for (int n = 0; n < pairs; n++) {
+                const float I = w[2 * n], Q = w[2 * n + 1];
+                dcI += (I - dcI) * alpha;
+                dcQ += (Q - dcQ) * alpha;
+                w[2 * n] = I - dcI;
+                w[2 * n + 1] = Q - dcQ;
+            }
+            fe->iq_dc_r = dcI;
+            fe->iq_dc_i = dcQ;
+        }
+        if (fe->iqbal_enable) { /* full_demod_apply_iq_balance(), :1131-1171 */
+            double s2r = 0.0, s2i = 0.0, p2 = 0.0;
+            for (int n = 0; n < pairs; n++) {
+                const double I = (double)w[2 * n], Q = (double)w[2 * n + 1];
+                s2r += I * I - Q * Q;
+                s2i += 2.0 * I * Q;
+                p2 += I * I + Q * Q;
+            }
+            if (p2 <= 1e-9) {
+                p2 = 1e-9;
+            }
+            float er = fe->iqbal_er, ei = fe->iqbal_ei;
+            const float ar = (float)(s2r / p2), ai = (float)(s2i / p2);
+            const float ema = fe->iqbal_ema_a > 0.0f ? fe->iqbal_ema_a : 0.2f;
+            er += ema * (ar - er);
+            ei += ema * (ai - ei);
+            fe->iqbal_er = er;
+            fe->iqbal_ei = ei;
+            const float thr = fe->iqbal_thr > 0.0f ? fe->iqbal_thr : 0.02f;
+            if (!((er * er + ei * ei) < (thr * thr))) {
+                for (int n = 0; n < pairs; n++) {
+                    const float I = w[2 * n], Q = w[2 * n + 1];
+                    const float tI = er * I + ei * Q;
+                    const float tQ = -er * Q + ei * I;
+                    w[2 * n] = I - tI;
+                    w[2 * n + 1] = Q - tQ;
+                }
+            }
+        }
+    }
     return orc_fsk_discriminator(&fe->fsk, cur, len, out, pairs > 0 ? pairs : 1);
+}
+
+void
+orc_fe_set_iq_options(orc_front_end* fe, int dc_enable, int dc_shift, int bal_enable, float bal_thr, float bal_ema_a) {
+    fe->iq_dc_enable = dc_enable;
+    fe->iq_dc_shift = dc_shift;
+    fe->iqbal_enable = bal_enable;
+    fe->iqbal_thr = bal_thr;
+    fe->iqbal_ema_a = bal_ema_a;
 }
 
 long

@@ -130,6 +130,17 @@ refh_fe_run_f32(void* h, const float* iq, long n_complex, int block_len, float* 
     return written;
 }
 
+// optional IQ conditioning switches of struct demod_state (iq_dc_block / iq balance, off by default)
+void
+refh_fe_set_iq_options(void* h, int dc_enable, int dc_shift, int bal_enable, float bal_thr, float bal_ema_a) {
+    demod_state* d = static_cast<RefFrontEnd*>(h)->d;
+    d->iq_dc_block_enable = dc_enable;
+    d->iq_dc_shift = dc_shift;
+    d->iqbal_enable = bal_enable;
+    d->iqbal_thr = bal_thr;
+    d->iqbal_alpha_ema_a = bal_ema_a;
+}
+
 int
 refh_fe_get_taps(void* h, float* taps, int cap) {
     RefFrontEnd* fe = static_cast<RefFrontEnd*>(h);

@@ -75,6 +75,12 @@ class OracleFrontEnd:
         self.buf = C.create_string_buffer(ORC_FE_BYTES)
         oracle().orc_fe_init(self.buf, rate, profile, lpf_enable, squelch, downsample_passes, fma_order)
 
+    def set_iq_options(self, dc_enable=0, dc_shift=11, bal_enable=0, bal_thr=0.0, bal_ema_a=0.0):
+        o = oracle()
+        o.orc_fe_set_iq_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+        o.orc_fe_set_iq_options(self.buf, dc_enable, dc_shift, bal_enable, bal_thr, bal_ema_a)
+        return self
+
     def run_cu8(self, iq_u8, block_len):
         iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8).reshape(-1)
         n = iq_u8.size // 2
@@ -103,10 +109,14 @@ def oracle_batch_cu8(iq_u8, block_len, rate=48000, profile=4, squelch=0.0):
     return out
 
 
-def ref_front_end_cu8(iq_u8, block_len, rate=48000, sym=4800, levels=4, profile=4, lpf=1, squelch=0.0, passes=0):
+def ref_front_end_cu8(iq_u8, block_len, rate=48000, sym=4800, levels=4, profile=4, lpf=1, squelch=0.0, passes=0,
+                      iq_options=None):
     iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8).reshape(-1)
     n = iq_u8.size // 2
     h = ref().refh_fe_create(rate, sym, levels, profile, lpf, squelch, passes)
+    if iq_options:
+        ref().refh_fe_set_iq_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+        ref().refh_fe_set_iq_options(h, *iq_options)
     out = np.zeros(n, np.float32)
     w = ref().refh_fe_run_cu8(h, iq_u8.ctypes.data, n, block_len, out.ctypes.data)
     taps = np.zeros(160, np.float32)
