@@ -140,7 +140,8 @@ ddn_p25_rx_reset(ddn_p25_rx* b) {
 
 extern "C" int
 ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave) {
-    if (!b || (channels_per_wave != 0 && channels_per_wave != 16 && channels_per_wave != 32 && channels_per_wave != 64)) {
+    if (!b || (channels_per_wave != 0 && channels_per_wave != 8 && channels_per_wave != 16 && channels_per_wave != 32
+               && channels_per_wave != 64)) {
         return DDN_EINVAL;
     }
     b->channels_per_wave = channels_per_wave;

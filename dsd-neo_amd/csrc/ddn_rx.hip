@@ -642,21 +642,22 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
 
     auto stage = [&](long t0, int slot) {
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        constexpr int RPP = CPW < 16 ? CPW : 16; // rows in flight per pass
 #pragma unroll
-        for (int h = 0; h < CPW / 16; h++) {
-            float r[16], f[16];
+        for (int h = 0; h < CPW / RPP; h++) {
+            float r[RPP], f[RPP];
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const int cc = 16 * h + c;
+            for (int c = 0; c < RPP; c++) {
+                const int cc = RPP * h + c;
                 const bool ok = (ch0 + cc < n_channels) && lane < tn;
                 const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + lane;
                 r[c] = ok ? raw[off] : 0.0f;
                 f[c] = (ok && use_flt) ? filt[off] : 0.0f;
             }
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                L.raw[16 * h + c][slot * TS + lane] = r[c];
-                L.flt[16 * h + c][slot * TS + lane] = f[c];
+            for (int c = 0; c < RPP; c++) {
+                L.raw[RPP * h + c][slot * TS + lane] = r[c];
+                L.flt[RPP * h + c][slot * TS + lane] = f[c];
             }
         }
     };
@@ -1245,12 +1246,16 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long
         taps_up = true;
     }
     int cpw = channels_per_wave;
-    if (cpw != 16 && cpw != 32 && cpw != 64) {
+    if (cpw != 8 && cpw != 16 && cpw != 32 && cpw != 64) {
         // fewest lanes per wavefront that still gives every CU (256) no more than ~2 workgroups
         cpw = n_channels <= 16 * 512 ? 16 : (n_channels <= 32 * 512 ? 32 : 64);
     }
     // CPW 16 / 32 run the windowed variant (k_p25_rxw); 64 lanes per wavefront keeps the two-tile kernel, whose LDS
     // footprint still fits (cfg.dbg bit 128 forces it for A/B timing)
+    if (cpw == 8) {
+        return launch_rxw<8>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                             shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+    }
     if (cpw == 16 && !(cfg->dbg & 128)) {
         return launch_rxw<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                               shist_store, minring, maxring, rec, flags, counts, max_sym, st);

@@ -160,6 +160,49 @@ def main():
     ocq = orc.OracleCqpskFe(rate=24000)
     report("cqpsk_front_end_sps5", B * nq, ms, 8 + 0.8, cpu(lambda: ocq.run(q1[0], 4096), nq), "complex samples")
 
+    # rational resampler 5/4 (e.g. 38.4 -> 48 ksps): 4096 channels x 48000 discriminator samples
+    B, nn = 4096, 48000
+    xr = (rng.normal(0, 9000, (8, nn))).astype(np.float32)
+    d_x = torch.from_numpy(np.tile(xr, (B // 8, 1))).cuda()
+    h = C.c_void_p()
+    assert l.ddn_resampler_create(B, 5, 4, C.byref(h)) == 0
+    no = nn * 5 // 4 + 4
+    d_y = torch.zeros((B, no), dtype=torch.float32, device="cuda")
+    ms = timeit(lambda: l.ddn_resampler_run(h, d_x.data_ptr(), nn, d_y.data_ptr(), no, st))
+    ors = orc.OracleResampler(5, 4)
+    report("resampler_5_4", B * nn, ms, 4 + 5, cpu(lambda: ors.run(xr[0]), nn), "input samples")
+    l.ddn_resampler_destroy(h)
+
+    # front end with the optional IQ conditioning on (unfused route): 4096 channels x 48000 cu8 samples
+    iq8 = orc.synth_c4fm_cu8(0, 8, nn)
+    d_i = torch.from_numpy(np.tile(iq8, (B // 8, 1, 1))).cuda()
+    d_o = torch.zeros((B, nn), dtype=torch.float32, device="cuda")
+    fb = ddn.Batch(B, block_len=8192)
+    fb.set_iq_conditioning(1, 11, 1, 0.0, 0.0)
+    ms = timeit(lambda: fb.run_device(d_i.data_ptr(), nn, d_o.data_ptr(), st))
+    ofe = orc.OracleFrontEnd().set_iq_options(1, 11, 1, 0.0, 0.0)
+    report("front_end_iq_conditioned", B * nn, ms, 2 + 4, cpu(lambda: ofe.run_cu8(iq8[0], 8192), nn), "complex samples")
+
+    # IMBE de-interleave: 4096 channels x 9 voice frames out of an LDU's records
+    nf = 4096 * 9
+    recs = torch.from_numpy(rng.integers(0, 256, (4096 * 900, 10), dtype=np.uint8)).cuda()
+    first = torch.from_numpy((np.arange(nf, dtype=np.int64) // 9) * 900 + (np.arange(nf) % 9) * 76 + 60).cuda()
+    sc = torch.from_numpy(rng.integers(0, 36, nf).astype(np.int32)).cuda()
+    o1 = torch.zeros((nf, 184), dtype=torch.uint8, device="cuda")
+    o2 = torch.zeros((nf, 368), dtype=torch.uint8, device="cuda")
+    o3 = torch.zeros(nf, dtype=torch.uint8, device="cuda")
+    o4 = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: l.ddn_p25p1_imbe_deinterleave_batch(recs.data_ptr(), 4096 * 900, first.data_ptr(), sc.data_ptr(),
+                                                            nf, o1.data_ptr(), o2.data_ptr(), o3.data_ptr(),
+                                                            o4.data_ptr(), st))
+    d80 = rng.integers(0, 4, 80).astype(np.uint8)
+    z80 = np.zeros(80, np.int16)
+
+    def cpu_imbe():
+        for _ in range(2000):
+            orc.oracle_imbe_deinterleave(d80, z80, z80, 7)
+    report("imbe_deinterleave", nf, ms, 72 * 10 + 184 * 3, cpu(cpu_imbe, 2000), "voice frames")
+
 
 if __name__ == "__main__":
     main()
