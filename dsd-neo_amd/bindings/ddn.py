@@ -113,6 +113,20 @@ PROTOTYPES = {
     "ddn_p25p1_imbe_deinterleave_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_batch_set_iq_conditioning": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
+    "ddn_p25p1_layout_nid": (C.c_int, [C.c_void_p]),
+    "ddn_p25p1_layout_trellis_block": (C.c_int, [C.c_int, C.c_void_p]),
+    "ddn_p25p1_layout_ldu_words": (C.c_int, [C.c_int, C.c_void_p]),
+    "ddn_p25p1_layout_ldu_imbe": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_framer_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ddn_p25p1_framer_destroy": (None, [C.c_void_p]),
+    "ddn_p25p1_framer_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_p25p1_framer_get_syncs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_framer_gather_nid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
+    "ddn_p25p1_framer_gather_trellis_block": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+                                              + [C.c_void_p] * 4),
+    "ddn_p25p1_framer_gather_ldu_words": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+                                          + [C.c_void_p] * 4),
+    "ddn_p25p1_framer_imbe_index": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_resampler_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ddn_resampler_destroy": (None, [C.c_void_p]),
     "ddn_resampler_reset": (C.c_int, [C.c_void_p, C.c_void_p]),

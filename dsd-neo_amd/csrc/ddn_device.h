@@ -142,6 +142,15 @@ hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStre
 hipError_t ddn_dev_iq_cond_disc(const void* in, long n, size_t stride, int block_len, int n_channels,
                                 const DdnIqCondConfig* cfg, DdnFskState* fsk, DdnIqCondState* cond, float* out,
                                 size_t out_stride, hipStream_t st);
+hipError_t ddn_dev_find_syncs(const uint8_t* flags, const int32_t* counts, int n_channels, size_t max_sym, int max_frames,
+                              int32_t* sync_pos, int32_t* n_syncs, hipStream_t st);
+hipError_t ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32_t* counts, const int32_t* sync_pos,
+                                 const int32_t* n_syncs, int n_channels, int max_frames, const int32_t* offsets, int n_off,
+                                 int max_off, uint8_t* bits, uint8_t* rel, int16_t* llr, int stride, int split_last,
+                                 uint8_t* last_bit, uint8_t* last_rel, uint8_t* valid, hipStream_t st);
+hipError_t ddn_dev_imbe_index(const int32_t* sync_pos, const int32_t* n_syncs, int n_channels, int max_frames,
+                              size_t max_sym, const int32_t* first9, const int32_t* status9, int64_t* first,
+                              int32_t* status, hipStream_t st);
 hipError_t ddn_dev_resample(const float* in, long n, size_t in_stride, int n_channels, float* hist, const float* taps,
                             int L, int M, int p0, long n_out, float* out, size_t out_stride, hipStream_t st);
 hipError_t ddn_dev_imbe_deinterleave(const uint8_t* rec, long n_records, const int64_t* first, const int32_t* status_count,

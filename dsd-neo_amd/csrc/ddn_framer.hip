@@ -1,0 +1,164 @@
+// ddn_framer.hip — from the receive loop's capture records to the FEC kernels' input layouts, on the device.
+//
+// reference: what the P25 Phase 1 frame handlers do with getDibitSoft() after a sync - read the NID's 32 dibits with the
+// status symbol dropped (src/protocol/p25/phase1/dispatch_p25p1.c:123-143), then walk the frame body dibit by dibit,
+// stepping over one status symbol after every 35 dibits (p25p1_ldu.c:27-39, p25p1_tsbk / p25p1_hdu readers).  Every
+// field of a frame therefore sits at a fixed dibit offset from the frame sync; the host builds those offset tables once
+// (ddn_host_p25_layout.c) and the device does two things:
+//   k_find_syncs     one wavefront per channel scans the flag row (bit 1 = "this symbol completed a frame sync"),
+//                    ballot + prefix popcount, and writes the record index of each sync's last dibit in order
+//   k_gather_fields  one thread per (frame slot, dibit of the field): record -> hard bits, per-bit reliability and/or
+//                    int16 LLRs in the layout the block-code / trellis kernels read.  Slots past a channel's sync count
+//                    and fields that run past the channel's records are zero-filled and marked invalid.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+
+namespace {
+__global__ __launch_bounds__(64) void
+k_find_syncs(const uint8_t* __restrict__ flags, const int32_t* __restrict__ counts, size_t max_sym, int max_frames,
+             int32_t* __restrict__ sync_pos, int32_t* __restrict__ n_syncs) {
+    const int ch = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int cnt = counts[ch];
+    const uint8_t* row = flags + (size_t)ch * max_sym;
+    int found = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        const bool hit = i < cnt && (row[i] & 2);
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int k = found + __popcll(m & ((1ull << lane) - 1ull));
+            if (k < max_frames) {
+                sync_pos[(size_t)ch * max_frames + k] = i;
+            }
+        }
+        found += __popcll(m);
+    }
+    if (lane == 0) {
+        n_syncs[ch] = found < max_frames ? found : max_frames;
+    }
+}
+
+__global__ __launch_bounds__(256) void
+k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* __restrict__ counts,
+                const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_syncs, int n_channels,
+                int max_frames, const int32_t* __restrict__ offsets, int n_off, int max_off, uint8_t* __restrict__ bits,
+                uint8_t* __restrict__ rel, int16_t* __restrict__ llr, int stride, int split_last,
+                uint8_t* __restrict__ last_bit, uint8_t* __restrict__ last_rel, uint8_t* __restrict__ valid) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long slot = t / n_off;
+    const int i = (int)(t % n_off);
+    if (slot >= (long)n_channels * max_frames) {
+        return;
+    }
+    const int ch = (int)(slot / max_frames), k = (int)(slot % max_frames);
+    const int cnt = counts[ch];
+    bool ok = k < n_syncs[ch];
+    int start = 0;
+    if (ok) {
+        start = sync_pos[slot] - 23; // record index of the frame sync's first dibit
+        ok = start + max_off < cnt;
+    }
+    int d = 0, r = 0, l0 = 0, l1 = 0;
+    if (ok) {
+        const uint8_t* q = rec + ((size_t)ch * max_sym + (size_t)(start + offsets[i])) * 10;
+        d = q[0];
+        r = q[1];
+        l0 = (int16_t)((uint16_t)q[2] | ((uint16_t)q[3] << 8));
+        l1 = (int16_t)((uint16_t)q[4] | ((uint16_t)q[5] << 8));
+    }
+    const int b0 = (d >> 1) & 1, b1 = d & 1;
+    const bool tail = split_last && i == n_off - 1; // NID: bit 63 is the parity bit, kept apart from the BCH word
+    const size_t o = (size_t)slot * stride + 2 * (size_t)i;
+    if (bits) {
+        bits[o] = (uint8_t)b0;
+        if (!tail) {
+            bits[o + 1] = (uint8_t)b1;
+        }
+    }
+    if (rel) {
+        rel[o] = (uint8_t)r;
+        if (!tail) {
+            rel[o + 1] = (uint8_t)r;
+        }
+    }
+    if (llr) {
+        llr[o] = (int16_t)l0;
+        if (!tail) {
+            llr[o + 1] = (int16_t)l1;
+        }
+    }
+    if (tail) {
+        if (last_bit) {
+            last_bit[slot] = (uint8_t)b1;
+        }
+        if (last_rel) {
+            last_rel[slot] = (uint8_t)r;
+        }
+    }
+    if (i == 0 && valid) {
+        valid[slot] = ok ? 1 : 0;
+    }
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_find_syncs(const uint8_t* flags, const int32_t* counts, int n_channels, size_t max_sym, int max_frames,
+                   int32_t* sync_pos, int32_t* n_syncs, hipStream_t st) {
+    if (n_channels <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_find_syncs, dim3((unsigned)n_channels), dim3(64), 0, st, flags, counts, max_sym, max_frames,
+                       sync_pos, n_syncs);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32_t* counts, const int32_t* sync_pos,
+                      const int32_t* n_syncs, int n_channels, int max_frames, const int32_t* offsets, int n_off,
+                      int max_off, uint8_t* bits, uint8_t* rel, int16_t* llr, int stride, int split_last,
+                      uint8_t* last_bit, uint8_t* last_rel, uint8_t* valid, hipStream_t st) {
+    const long total = (long)n_channels * max_frames * n_off;
+    if (total <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_gather_fields, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rec, max_sym, counts,
+                       sync_pos, n_syncs, n_channels, max_frames, offsets, n_off, max_off, bits, rel, llr, stride,
+                       split_last, last_bit, last_rel, valid);
+    return hipGetLastError();
+}
+
+namespace {
+// record index (into the flat [B][max_sym] record array) and status counter of the nine voice frames of every LDU slot,
+// the inputs of k_imbe_deinterleave; slots without a sync get first = -1 (flagged 0xFF there)
+__global__ void
+k_imbe_index(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_syncs, int n_channels, int max_frames,
+             size_t max_sym, const int32_t* __restrict__ first9, const int32_t* __restrict__ status9,
+             int64_t* __restrict__ first, int32_t* __restrict__ status) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long slot = t / 9;
+    const int v = (int)(t % 9);
+    if (slot >= (long)n_channels * max_frames) {
+        return;
+    }
+    const int ch = (int)(slot / max_frames), k = (int)(slot % max_frames);
+    const bool ok = k < n_syncs[ch];
+    first[t] = ok ? (int64_t)((size_t)ch * max_sym) + (sync_pos[slot] - 23) + first9[v] : -1;
+    status[t] = status9[v];
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_imbe_index(const int32_t* sync_pos, const int32_t* n_syncs, int n_channels, int max_frames, size_t max_sym,
+                   const int32_t* first9, const int32_t* status9, int64_t* first, int32_t* status, hipStream_t st) {
+    const long total = (long)n_channels * max_frames * 9;
+    if (total <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_imbe_index, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sync_pos, n_syncs,
+                       n_channels, max_frames, max_sym, first9, status9, first, status);
+    return hipGetLastError();
+}

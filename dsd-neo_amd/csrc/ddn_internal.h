@@ -15,6 +15,10 @@ int ddn_design_channel_lpf(int rate_hz, int profile, float* taps, int max_taps);
 int ddn_design_fll_band_edge(int sps, float* taps4, float* alpha, float* beta);
 int ddn_design_resampler(int L, int M, float* taps);
 #define DDN_RESAMP_MAX_L 512
+int ddn_p25p1_layout_nid(int32_t out32[32]);
+int ddn_p25p1_layout_trellis_block(int block, int32_t out98[98]);
+int ddn_p25p1_layout_ldu_words(int ldu, int32_t out120[120]);
+int ddn_p25p1_layout_ldu_imbe(int32_t first9[9], int32_t status9[9]);
 void ddn_set_error(const char* fmt, ...);
 #ifdef __cplusplus
 }

@@ -192,6 +192,43 @@ int ddn_gardner_run(ddn_ted_batch* b, const float* d_iq, size_t n, float* d_sym,
 int ddn_gardner_run_host(ddn_ted_batch* b, const float* iq, size_t n, float* sym, size_t sym_stride, int* sym_count);
 int ddn_ted_batch_get_state(ddn_ted_batch* b, int channel, float out8[8]);
 
+/* ---- P25 Phase 1 framer: receive-loop records -> FEC kernel inputs, on the device -------------------------------------
+ * What the reference's P25p1 handlers do with getDibitSoft() between the sync and the decoders, as gathers: every field of
+ * a frame sits at a fixed dibit offset from the frame sync (24 sync dibits; NID = 32 dibits + the status symbol at frame
+ * index 35, src/protocol/p25/phase1/dispatch_p25p1.c:123-143; one status symbol at every frame index = 35 mod 36,
+ * p25p1_ldu.c:27-39).  ddn_p25p1_layout_* are the host-side offset tables (0 = first sync dibit; pure functions, no
+ * device): NID 32 dibits; trellis block b = 0..2 of a TSDU / PDU (98 dibits each); LDU1 / LDU2 Hamming words as
+ * [24][5] dibits in the order hex_data[0..11], hex_parity[0..11] (LDU1) or hex_data[0..15], hex_parity[0..7] (LDU2)
+ * (p25p1_ldu1.c, p25p1_ldu2.c:211-236); the nine voice frames' first dibit + status counter (process_IMBE input).
+ * Frame slots: slot = channel * max_frames_per_channel + k for the k-th sync of the channel (ascending); slots beyond
+ * the channel's sync count, and fields that run past the channel's records, are zero-filled with valid = 0.
+ *   gather_nid            -> bits63 / reliab63 [slots][63], parity / parity_reliab [slots]: ddn_p25p1_nid_decode_batch input
+ *   gather_trellis_block  -> llr [slots][196] int16: ddn_fec_p25_12_soft_batch input (and/or hard bits [slots][196])
+ *   gather_ldu_words      -> bits [slots][24][10] (+ per-bit reliability): ddn_fec_hamming_10_6_3_* input
+ *   imbe_index            -> first record / status counter [slots][9]: ddn_p25p1_imbe_deinterleave_batch input */
+int ddn_p25p1_layout_nid(int32_t out32[32]);
+int ddn_p25p1_layout_trellis_block(int block, int32_t out98[98]);
+int ddn_p25p1_layout_ldu_words(int ldu, int32_t out120[120]);
+int ddn_p25p1_layout_ldu_imbe(int32_t first9[9], int32_t status9[9]);
+typedef struct ddn_p25p1_framer ddn_p25p1_framer;
+int ddn_p25p1_framer_create(int n_channels, int max_frames_per_channel, ddn_p25p1_framer** out);
+void ddn_p25p1_framer_destroy(ddn_p25p1_framer* f);
+/* scan the receive loop's flags (bit 1 = sync accepted at this symbol) of one ddn_p25_rx_run() call */
+int ddn_p25p1_framer_index(ddn_p25p1_framer* f, const uint8_t* d_flags, const int32_t* d_counts, size_t max_symbols,
+                           void* hip_stream);
+int ddn_p25p1_framer_get_syncs(ddn_p25p1_framer* f, int32_t* n_syncs, int32_t* sync_pos); /* host copies, synchronous */
+int ddn_p25p1_framer_gather_nid(ddn_p25p1_framer* f, const uint8_t* d_records10, const int32_t* d_counts,
+                                size_t max_symbols, uint8_t* d_bits63, uint8_t* d_reliab63, uint8_t* d_parity,
+                                uint8_t* d_parity_reliab, uint8_t* d_valid, void* hip_stream);
+int ddn_p25p1_framer_gather_trellis_block(ddn_p25p1_framer* f, int block, const uint8_t* d_records10,
+                                          const int32_t* d_counts, size_t max_symbols, int16_t* d_llr196,
+                                          uint8_t* d_dibit_bits196, uint8_t* d_valid, void* hip_stream);
+int ddn_p25p1_framer_gather_ldu_words(ddn_p25p1_framer* f, int ldu, const uint8_t* d_records10, const int32_t* d_counts,
+                                      size_t max_symbols, uint8_t* d_bits240, uint8_t* d_reliab240, uint8_t* d_valid,
+                                      void* hip_stream);
+int ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_first_record,
+                                int32_t* d_status_count, void* hip_stream);
+
 /* ---- rational resampler, batched -------------------------------------------------------------------
  * == dsd_resampler_design + dsd_resampler_process_block (include/dsd-neo/dsp/resampler.h:66-89;
  * src/dsp/resampler.cpp:166-190,241-356), which the demodulator thread applies to the discriminator output when its

@@ -1,0 +1,189 @@
+"""P25p1 framer: host offset tables (CPU) and the device-side sync index / field gathers / IMBE index (GPU).
+
+CPU: ddn_p25p1_layout_* vs the independent python walk in tests/p25gen.py (which the real-capture tests anchor on the
+reference's full-chain known answers).  GPU: everything downstream of the receive loop stays on the device - sync index,
+NID gather -> BCH, trellis-block gather -> 1/2-rate Viterbi, LDU word gather -> Hamming, voice-frame index -> IMBE
+de-interleave - and equals the host-side extraction + oracle chain slot by slot."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ddn
+import orc
+import p25gen
+from conftest import golden
+
+
+def test_layout_tables_match_python_walk(built):
+    l = ddn.lib()
+    nid = np.zeros(32, np.int32)
+    assert l.ddn_p25p1_layout_nid(nid.ctypes.data) == 57
+    assert list(nid) == [24 + k for k in range(33) if k != 11]
+    blk = np.zeros(98, np.int32)
+    assert l.ddn_p25p1_layout_trellis_block(0, blk.ctypes.data) > 0 and list(blk) == p25gen.block_positions()
+    b1 = np.zeros(98, np.int32)
+    l.ddn_p25p1_layout_trellis_block(1, b1.ctypes.data)
+    assert b1[0] > blk[-1] and not np.any(b1 % 36 == 35) and len(set(b1)) == 98
+    assert l.ddn_p25p1_layout_trellis_block(3, b1.ctypes.data) < 0
+    for ldu, fn in ((1, p25gen.ldu1_positions), (2, p25gen.ldu2_positions)):
+        w = np.zeros(120, np.int32)
+        end = l.ddn_p25p1_layout_ldu_words(ldu, w.ctypes.data)
+        d, p = fn()
+        assert np.array_equal(w.reshape(24, 5), np.concatenate([d, p])) and end in (863, 864)
+    first, st = np.zeros(9, np.int32), np.zeros(9, np.int32)
+    assert l.ddn_p25p1_layout_ldu_imbe(first.ctypes.data, st.ctypes.data) in (863, 864)
+    assert first[0] == 57 and st[0] == 21 and np.all(st == first % 36) and np.all(np.diff(first) >= 74)
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+class Framer:
+    def __init__(self, B, F):
+        self.h = C.c_void_p()
+        assert ddn.lib().ddn_p25p1_framer_create(B, F, C.byref(self.h)) == 0, ddn.lib().ddn_last_error()
+        self.B, self.F = B, F
+
+    def __del__(self):
+        ddn.lib().ddn_p25p1_framer_destroy(self.h)
+
+
+@pytest.mark.gpu
+def test_device_chain_tsdu_traffic(built):
+    """cu8 IQ -> front end -> rx loop -> framer -> NID BCH + 1/2-rate trellis without leaving the device."""
+    import torch
+    from test_e2e_p25 import B, N, NACS, _traffic, _oracle_chain, _check_decoded
+    l = ddn.lib()
+    iq, states = _traffic()
+    want = _oracle_chain(iq)
+    fe = ddn.Batch(B, block_len=8192)
+    d_iq = _dev(iq)
+    d_disc = torch.zeros((B, N), dtype=torch.float32, device="cuda")
+    fe.run_device(d_iq.data_ptr(), N, d_disc.data_ptr())
+    rx = ddn.P25Rx(B, lock_symbols=p25gen.FRAME - 24, use_matched_filter=1)
+    ms = l.ddn_p25_rx_max_symbols(rx.h, N)
+    rec = torch.zeros((B, ms, 10), dtype=torch.uint8, device="cuda")
+    fl = torch.zeros((B, ms), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    assert l.ddn_p25_rx_run(rx.h, d_disc.data_ptr(), N, rec.data_ptr(), fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    F = 32
+    fr = Framer(B, F)
+    assert l.ddn_p25p1_framer_index(fr.h, fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    S = B * F
+    bits = torch.zeros((S, 63), dtype=torch.uint8, device="cuda")
+    rel = torch.zeros((S, 63), dtype=torch.uint8, device="cuda")
+    par = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    prel = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    v_nid = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p1_framer_gather_nid(fr.h, rec.data_ptr(), cnt.data_ptr(), ms, bits.data_ptr(), rel.data_ptr(),
+                                         par.data_ptr(), prel.data_ptr(), v_nid.data_ptr(), None) == 0
+    obs = torch.zeros(S, dtype=torch.int32, device="cuda")
+    nid = torch.zeros((S, 4), dtype=torch.int32, device="cuda")
+    assert l.ddn_p25p1_nid_decode_batch(bits.data_ptr(), rel.data_ptr(), obs.data_ptr(), par.data_ptr(), prel.data_ptr(),
+                                        64, S, nid.data_ptr(), None) == 0
+    llr = torch.zeros((S, 196), dtype=torch.int16, device="cuda")
+    v_blk = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p1_framer_gather_trellis_block(fr.h, 0, rec.data_ptr(), cnt.data_ptr(), ms, llr.data_ptr(), None,
+                                                   v_blk.data_ptr(), None) == 0
+    out = torch.zeros((S, 12), dtype=torch.uint8, device="cuda")
+    met = torch.zeros(S, dtype=torch.int32, device="cuda")
+    assert l.ddn_fec_p25_12_soft_batch(llr.data_ptr(), S, out.data_ptr(), met.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    ns = np.zeros(B, np.int32)
+    pos = np.zeros((B, F), np.int32)
+    assert l.ddn_p25p1_framer_get_syncs(fr.h, ns.ctypes.data, pos.ctypes.data) == 0
+    nid, out, met = nid.cpu().numpy().reshape(B, F, 4), out.cpu().numpy().reshape(B, F, 12), met.cpu().numpy().reshape(B, F)
+    v_blk = v_blk.cpu().numpy().reshape(B, F)
+    for c in range(B):
+        w = want[c]
+        assert ns[c] == len(w["acc"]) and np.array_equal(pos[c, :ns[c]], w["acc"]), c   # every accepted sync, in order
+        k = len(w["nid"])                                  # frames the host extraction found complete
+        assert np.all(v_blk[c, :k] == 1) and np.all(v_blk[c, ns[c]:] == 0)
+        assert np.array_equal(nid[c, :k], w["nid"]), c
+        assert np.array_equal(out[c, :k], w["blocks"]) and np.array_equal(met[c, :k], w["met"]), c
+        _check_decoded(c, w["acc"], nid[c, :k], out[c, :k], states[c])
+
+
+@pytest.mark.gpu
+def test_device_chain_voice_capture(built):
+    """The reference's own voice capture: LDU word gathers -> Hamming, voice-frame index -> IMBE de-interleave, all
+    from device-resident records; compared with host-side extraction (tests/p25gen.py positions) + the oracles."""
+    import torch
+    from test_real_capture import nids_from_records, decode_nids
+    from test_oracle_block import oracle_nid
+    l = ddn.lib()
+    g = golden("iq_p25p1_c4fm_vc.npz")
+    iq = np.ascontiguousarray(g["iq"])
+    n = iq.shape[0]
+    disc = ddn.Batch(1, block_len=8192).run_host(iq[None], n)
+    rx = ddn.P25Rx(1, lock_symbols=840, use_matched_filter=1)
+    ms = l.ddn_p25_rx_max_symbols(rx.h, n)
+    d_disc = _dev(disc)
+    rec = torch.zeros((1, ms, 10), dtype=torch.uint8, device="cuda")
+    fl = torch.zeros((1, ms), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert l.ddn_p25_rx_run(rx.h, d_disc.data_ptr(), n, rec.data_ptr(), fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    F = 24
+    fr = Framer(1, F)
+    assert l.ddn_p25p1_framer_index(fr.h, fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    count = int(cnt.cpu()[0])
+    r4, _ = orc.unpack_records10(rec.cpu().numpy()[0, :count])
+    flh = fl.cpu().numpy()[0]
+    rows = nids_from_records(r4, flh, count)
+    nid = decode_nids(rows, oracle_nid)
+    ns = np.zeros(1, np.int32)
+    pos = np.zeros((1, F), np.int32)
+    assert l.ddn_p25p1_framer_get_syncs(fr.h, ns.ctypes.data, pos.ctypes.data) == 0
+    assert ns[0] >= len(rows) and np.array_equal(pos[0, :len(rows)], [r[0] for r in rows])
+    for ldu, duid, posfn in ((1, 5, p25gen.ldu1_positions), (2, 10, p25gen.ldu2_positions)):
+        wb = torch.zeros((F, 240), dtype=torch.uint8, device="cuda")
+        wr = torch.zeros((F, 240), dtype=torch.uint8, device="cuda")
+        vv = torch.zeros(F, dtype=torch.uint8, device="cuda")
+        assert l.ddn_p25p1_framer_gather_ldu_words(fr.h, ldu, rec.data_ptr(), cnt.data_ptr(), ms, wb.data_ptr(),
+                                                   wr.data_ptr(), vv.data_ptr(), None) == 0
+        errs = torch.zeros(F * 24, dtype=torch.uint8, device="cuda")
+        fixed = wb.clone()
+        assert l.ddn_fec_hamming_10_6_3_batch(fixed.data_ptr(), F * 24, errs.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        wbh, wrh, vvh = wb.cpu().numpy().reshape(F, 24, 10), wr.cpu().numpy().reshape(F, 24, 10), vv.cpu().numpy()
+        d, p = posfn()
+        rel_pos = np.concatenate([d, p]) - 24
+        seen = 0
+        for k, ((a, _, _), nd) in enumerate(zip(rows, nid)):
+            if nd[0] != 1 or nd[2] != duid or a + 1 + 840 > count:
+                continue
+            w = r4[a + 1:a + 1 + 840][rel_pos]              # [24, 5, 4]
+            bits = np.stack([(w[:, :, 0] >> 1) & 1, w[:, :, 0] & 1], axis=2).reshape(24, 10)
+            rl = np.repeat(w[:, :, 1], 2, axis=1)
+            assert vvh[k] == 1 and np.array_equal(wbh[k], bits) and np.array_equal(wrh[k], rl), (ldu, k)
+            seen += 1
+        assert seen >= 4
+        assert int(errs.cpu().numpy().reshape(F, 24)[vvh == 1].max()) <= 2
+    # voice frames: index -> de-interleave, against the oracle on host-extracted dibits
+    first = torch.zeros(F * 9, dtype=torch.int64, device="cuda")
+    sc = torch.zeros(F * 9, dtype=torch.int32, device="cuda")
+    assert l.ddn_p25p1_framer_imbe_index(fr.h, ms, first.data_ptr(), sc.data_ptr(), None) == 0
+    ofr = torch.zeros((F * 9, 8, 23), dtype=torch.uint8, device="cuda")
+    osf = torch.zeros((F * 9, 8, 23, 2), dtype=torch.uint8, device="cuda")
+    ofl = torch.zeros(F * 9, dtype=torch.uint8, device="cuda")
+    osc = torch.zeros(F * 9, dtype=torch.int32, device="cuda")
+    assert l.ddn_p25p1_imbe_deinterleave_batch(rec.data_ptr(), ms, first.data_ptr(), sc.data_ptr(), F * 9,
+                                               ofr.data_ptr(), osf.data_ptr(), ofl.data_ptr(), osc.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    ofr, osf, ofl = ofr.cpu().numpy(), osf.cpu().numpy(), ofl.cpu().numpy()
+    f9, s9 = np.zeros(9, np.int32), np.zeros(9, np.int32)
+    l.ddn_p25p1_layout_ldu_imbe(f9.ctypes.data, s9.ctypes.data)
+    checked = 0
+    for k, ((a, _, _), nd) in enumerate(zip(rows, nid)):
+        if nd[0] != 1 or nd[2] not in (5, 10) or a + 1 + 840 > count:
+            continue
+        for v in range(9):
+            s0 = a - 23 + int(f9[v])
+            want = orc.oracle_imbe_deinterleave(r4[s0:s0 + 80, 0], r4[s0:s0 + 80, 2], r4[s0:s0 + 80, 3], int(s9[v]))
+            i = k * 9 + v
+            assert ofl[i] == want[2] and np.array_equal(ofr[i], want[0]) and np.array_equal(osf[i], want[1]), (k, v)
+            checked += 1
+    assert checked >= 72 and np.all(ofl[ns[0] * 9:] == 0xFF)
