@@ -566,8 +566,10 @@ struct LdsW {
     float gs[8][4][CPW];
     float lb[24][CPW];
     float sh[24][CPW];
-    float raw[CPW][RT + 1];
-    float flt[CPW][RT + 1];
+    // a row = [mirror of slot 2 | slot 0 | slot 1 | slot 2] + pad: sample j (-TS <= j < TS + 12) of the tile in slot b
+    // is row[TS + b * TS + j] with no wrap test (slot 2 precedes slot 0 in the ring)
+    float raw[CPW][RT + TS + 13];
+    float flt[CPW][RT + TS + 13];
     float q[2][QCW][4][CPW];
     int qn[2][CPW];
     int qo[2][CPW];
@@ -656,8 +658,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
 #pragma unroll
             for (int c = 0; c < RPP; c++) {
-                L.raw[RPP * h + c][slot * TS + lane] = r[c];
-                L.flt[RPP * h + c][slot * TS + lane] = f[c];
+                L.raw[RPP * h + c][TS + slot * TS + lane] = r[c];
+                L.flt[RPP * h + c][TS + slot * TS + lane] = f[c];
+                if (slot == 2) {
+                    L.raw[RPP * h + c][lane] = r[c];
+                    L.flt[RPP * h + c][lane] = f[c];
+                }
             }
         }
     };
@@ -830,12 +836,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
             prepare();
         } else {
-            const int base = (it % 3) * TS;
-            auto rd = [&](const float* row, int j) {
-                int idx = base + j;
-                idx += idx < 0 ? RT : 0;
-                return row[idx];
-            };
+            const int base = TS + (it % 3) * TS;
+            auto rd = [&](const float* row, int j) { return row[base + j]; };
             const int done_snap = live ? L.done_e[ln] : 0;
             int qk = 0;
             if (live && offload) {
@@ -899,7 +901,49 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     sp += s.span;
                     s.i = s.span;
                 }
-                const bool gen = wholeok && fits && !latched;
+                // Unlatched symbol of ordinary length (every hunting symbol): the crossing search needs each sample once,
+                // in order, and nothing else; the window mean is the five centre samples.  Straight-line code, one
+                // compare chain per sample instead of the general per-sample body.
+                const bool genf = wholeok && fits && !latched && cnt <= 12 && s.span != 20 && s.span != 5;
+                if (__any(genf)) {
+                    const bool clip = s.have_sync != 0;
+                    const float hi_lim = s.maxref * 1.25f, lo_lim = s.minref * 1.25f;
+                    const float* rp0 = row + base + sp;
+                    float last = s.lastsample;
+                    int jit = s.jitter;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) {
+                        float x = rp0[k];
+                        const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        x = clip ? xc : x;
+                        const bool in = genf && k < cnt;
+                        const bool cross = (x > s.center) ? (!(x > hi_lim) && last < s.center)
+                                                          : (!(x < lo_lim) && last > s.center);
+                        jit = (in && jit < 0 && cross) ? s.i + k : jit;
+                        last = in ? x : last;
+                    }
+                    float acc = s.sum;
+                    int cw = s.count;
+#pragma unroll
+                    for (int w = 0; w < 5; w++) {
+                        const int k = s.centre - 2 + w - s.i;
+                        if (genf && k >= 0 && k < cnt) {
+                            float x = rp0[k];
+                            const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
+                            acc += clip ? xc : x;
+                            cw++;
+                        }
+                    }
+                    if (genf) {
+                        s.jitter = jit;
+                        s.lastsample = last;
+                        s.sum = acc;
+                        s.count = cw;
+                        sp += cnt;
+                        s.i = s.span;
+                    }
+                }
+                const bool gen = wholeok && fits && !latched && !genf;
                 if (__any(gen)) {
                     for (int k = 0; k < WMAX; k++) {
                         const bool on = gen && k < cnt;
