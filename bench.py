@@ -319,11 +319,11 @@ def main():
                          "algorithmic_bytes": alg_bytes,
                          "bytes_per_sample": BYTES_PER_SAMPLE, "launch_ms": round(dom_ms, 4)},
         }
-        if not args.no_chain:
+        # informational stage chains and the CPU baseline: single-GPU runs only (rank 0 at N = 1)
+        if not args.no_chain and world == 1:
             line["dibit_chain"] = dibit_chain(torch, ddn, orc, B, n, fir_avg)
-        if not args.no_chain:
             line["p25_e2e_chain"] = p25_e2e_chain(torch, ddn, B, n)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(d_in[:4].cpu().numpy())
             line["speedup_vs_cpu_1thread"] = round(msps / world / line["cpu_baseline"]["value"], 1)
             if "dibit_chain" in line:
