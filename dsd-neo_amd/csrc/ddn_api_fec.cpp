@@ -615,9 +615,6 @@ p25_12_soft_llr_list(const uint8_t* input, const int16_t* bit_llr196, ddn_p25_12
 }
 
 // ---- 3/4-rate list decoder -------------------------------------------------------------------------------------------
-static uint8_t* g_r34_backs = nullptr; // [n][49][8][32] back-pointer scratch, grown on demand
-static size_t g_r34_backs_cap = 0;
-
 extern "C" int
 ddn_fec_r34_list_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, int max_candidates,
                        ddn_r34_candidate* d_candidates32, int32_t* d_counts, void* hip_stream) {
@@ -625,17 +622,16 @@ ddn_fec_r34_list_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, siz
         ddn_set_error("ddn_fec_r34_list_batch: bad argument");
         return DDN_EINVAL;
     }
-    const size_t need = n * 49 * 8 * 32;
-    if (g_r34_backs_cap < need) {
-        HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(g_r34_backs);
-        g_r34_backs = nullptr;
-        g_r34_backs_cap = 0;
-        HIP_TRY(hipMalloc(&g_r34_backs, need));
-        g_r34_backs_cap = need;
+    if (n == 0) {
+        return DDN_OK;
     }
-    HIP_TRY(ddn_dev_r34_list(d_dibits98, d_reliab98, (int)n, max_candidates, g_r34_backs, (uint32_t*)d_candidates32,
-                             d_counts, (hipStream_t)hip_stream));
+    // [n][49][8][32] back-pointer scratch, stream-ordered so concurrent calls never share it
+    uint8_t* backs = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&backs, n * 49 * 8 * 32, (hipStream_t)hip_stream));
+    const hipError_t e = ddn_dev_r34_list(d_dibits98, d_reliab98, (int)n, max_candidates, backs,
+                                          (uint32_t*)d_candidates32, d_counts, (hipStream_t)hip_stream);
+    HIP_TRY(hipFreeAsync(backs, (hipStream_t)hip_stream));
+    HIP_TRY(e);
     return DDN_OK;
 }
 

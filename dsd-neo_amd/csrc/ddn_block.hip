@@ -531,29 +531,20 @@ ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* o
         return hipSuccess;
     }
     // pass 1: hard decode (+ observed-NAC retry) for every NID, NIDs that need the Chase search are listed;
-    // pass 2: one wavefront per listed NID.  The list and its counter live in a grow-only scratch buffer.
-    static int32_t* scratch = nullptr;
-    static size_t scratch_cap = 0;
+    // pass 2: one wavefront per listed NID.  The list and its counter are stream-ordered scratch (hipMallocAsync), so
+    // concurrent calls on different streams or host threads never share them.
+    int32_t* scratch = nullptr;
     int32_t *list = nullptr, *count = nullptr;
     if (rel63) {
-        if (scratch_cap < (size_t)n + 1) {
-            hipError_t e = hipStreamSynchronize(st);
-            if (e != hipSuccess) {
-                return e;
-            }
-            (void)hipFree(scratch);
-            scratch = nullptr;
-            scratch_cap = 0;
-            e = hipMalloc(&scratch, sizeof(int32_t) * ((size_t)n + 1));
-            if (e != hipSuccess) {
-                return e;
-            }
-            scratch_cap = (size_t)n + 1;
+        hipError_t e = hipMallocAsync((void**)&scratch, sizeof(int32_t) * ((size_t)n + 1), st);
+        if (e != hipSuccess) {
+            return e;
         }
         count = scratch;
         list = scratch + 1;
-        hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
+        e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
         if (e != hipSuccess) {
+            (void)hipFreeAsync(scratch, st);
             return e;
         }
     }
@@ -561,11 +552,16 @@ ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* o
                        parity_rel, threshold, n, out4, list, count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !rel63) {
+        if (scratch) {
+            (void)hipFreeAsync(scratch, st);
+        }
         return e;
     }
     hipLaunchKernelGGL(k_nid_chase, dim3((unsigned)n), dim3(64), 0, st, bits63, rel63, obs_nac, parity, parity_rel,
                        threshold, (const int32_t*)list, (const int32_t*)count, out4);
-    return hipGetLastError();
+    e = hipGetLastError();
+    const hipError_t ef = hipFreeAsync(scratch, st);
+    return e != hipSuccess ? e : ef;
 }
 
 extern "C" hipError_t

@@ -16,6 +16,8 @@
 // All per-lane polynomial arrays live in LDS as [index][lane] (dynamic indexing of a private array would go to scratch).
 
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 
 #include "ddn_device.h"
@@ -893,24 +895,28 @@ k_hamming_10_6_3_soft(const uint8_t* __restrict__ bits, const int32_t* __restric
     status[i] = (uint8_t)rc;
 }
 
+// syndrome -> error pattern table, built once per process on the device (immutable afterwards)
 static hipError_t
 golay_table(uint32_t** out, hipStream_t st) {
+    static std::mutex mu;
     static uint32_t* tab = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     if (!tab) {
-        hipError_t e = hipMalloc(&tab, 2048 * sizeof(uint32_t));
+        uint32_t* t = nullptr;
+        hipError_t e = hipMalloc(&t, 2048 * sizeof(uint32_t));
         if (e != hipSuccess) {
-            tab = nullptr;
             return e;
         }
-        hipLaunchKernelGGL(k_golay_table, dim3((23 * 23 * 23 + 255) / 256), dim3(256), 0, st, tab);
+        hipLaunchKernelGGL(k_golay_table, dim3((23 * 23 * 23 + 255) / 256), dim3(256), 0, st, t);
         e = hipGetLastError();
+        if (e == hipSuccess) {
+            e = hipStreamSynchronize(st);
+        }
         if (e != hipSuccess) {
+            (void)hipFree(t);
             return e;
         }
-        e = hipStreamSynchronize(st);
-        if (e != hipSuccess) {
-            return e;
-        }
+        tab = t;
     }
     *out = tab;
     return hipSuccess;

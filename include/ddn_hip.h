@@ -23,6 +23,12 @@
  *
  * All functions return 0 (or a non-negative count) on success and a negative DDN_E* code on failure; they
  * never fall back to a CPU path: if no gfx950 device / kernel image is available they fail with DDN_ENODEV.
+ *
+ * Threading: batch objects (ddn_batch, ddn_p25_rx, ddn_cqpsk_batch, ddn_ted_batch, ddn_slicer_batch, ddn_resampler,
+ * ddn_p25p1_framer) carry per-channel state and are not internally synchronised - one caller at a time per object,
+ * any number of objects in parallel.  The stateless ddn_fec_* / ddn_p25p1_* batch entry points take their scratch
+ * from the stream (hipMallocAsync) and may be called concurrently from several host threads / streams.
+ * ddn_last_error() is per thread.
  */
 #ifndef DDN_HIP_H
 #define DDN_HIP_H
