@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ddn_device.h"
 
@@ -290,6 +291,276 @@ k_gardner(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, i
     }
 }
 
+
+// =====================================================================================================================
+// k_gardner_ring — the same loop without a per-sample step.  Between two symbols the reference only moves samples into
+// its delay line (mu -= 1 per sample, exact in binary32 for mu >= 1, so ceil(mu) - 1 single steps equal one
+// subtraction); the interpolators then read the oldest 8 (+ half-symbol offset) of the last twice_sps samples.  With the
+// input staged as a ring of three tiles (previous, current, next being loaded; tile 2 mirrored in front of tile 0 so
+// look-back never wraps) those are plain reads at cursor - twice_sps + k, the delay line never has to be written, and a
+// lane advances one whole symbol per trip: ~4x fewer instructions on the per-channel chain.  The carried delay line is
+// rebuilt in the reference's doubled layout at the end of the call (state stays interchangeable with k_gardner).
+// CPW = channels per wavefront (16 / 32): the chain length, not the lane count, sets the time.
+namespace {
+constexpr int GTS = 64;
+constexpr int GROW = 4 * GTS + 16;
+constexpr int GTW_MAX = 48; // look-back must fit the previous tile
+
+template <int CPW>
+__global__ __launch_bounds__(128) void
+k_gardner_ring(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, int sps, float ted_gain,
+               int symbol_rate_hz, long block_len, DdnTedState* __restrict__ state, float* __restrict__ dl_store,
+               f2* __restrict__ out, size_t out_stride, int* __restrict__ out_count) {
+    extern __shared__ float smem[];
+    float(*tbl)[8] = (float(*)[8])smem;               // [17][8]
+    f2(*ring)[GROW] = (f2(*)[GROW])(smem + 17 * 8 + 8); // [CPW][GROW]: [mirror of slot 2 | slot 0 | slot 1 | slot 2 | pad]
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;
+    const int ch0 = blockIdx.x * CPW;
+    const int ch = ch0 + lane;
+    const bool live = !loader && lane < CPW && ch < n_channels;
+    const int ln = lane < CPW ? lane : 0;
+    for (int i = threadIdx.x; i < 17 * 8; i += 128) {
+        tbl[i / 8][i % 8] = c_mmse[i / 8][i % 8];
+    }
+    DdnTedState t;
+    if (live) {
+        t = state[ch];
+    } else {
+        t.mu = 0.f; t.omega = 0.f; t.omega_mid = 0.f; t.omega_min = 0.f; t.omega_max = 0.f; t.omega_rel = 0.f;
+        t.last_r = 0.f; t.last_j = 0.f; t.lock_accum = 0.f; t.lock_count = 0; t.dl_index = 0; t.twice_sps = 0; t.sps = 0;
+    }
+    int o = 0;
+    bool run = live && n >= 4;
+    // (re)initialisation, src/dsp/costas.cpp:352-398
+    float omega = t.omega;
+    if (run && ((t.omega_mid == 0.0f || t.twice_sps < 2) || (t.sps > 0 && t.sps != sps))) {
+        t.mu = (float)sps;
+        omega = (float)sps;
+        t.omega_rel = 0.002f;
+        t.omega_mid = omega;
+        t.omega_min = omega * (1.0f - t.omega_rel);
+        t.omega_max = omega * (1.0f + t.omega_rel);
+        const int a = 2 * (int)ceilf(t.omega_max);
+        const int b = (int)ceilf(t.omega_max / 2.0f) + 8 + 1;
+        const int need = a > b ? a : b;
+        if (need > DDN_TED_DL) {
+            run = false;
+        } else {
+            t.twice_sps = need;
+            t.dl_index = 0;
+            t.sps = sps;
+            dl_store[(size_t)ch * (DDN_TED_DL * 4)] = 0.0f;
+            dl_store[(size_t)ch * (DDN_TED_DL * 4) + 1] = 0.0f;
+        }
+    }
+    const int tw = t.twice_sps;
+    run = run && tw <= GTW_MAX; // the launcher only picks this kernel when that holds for the configured sps
+    // history: the last tw consumed samples, oldest at dl[dl_index] of the doubled line, go in front of tile 0
+    if (live && tw > 0 && tw <= GTW_MAX) {
+        const float* dl = dl_store + (size_t)ch * (DDN_TED_DL * 4);
+        for (int k = 0; k < tw; k++) {
+            const f2 v = {dl[2 * (t.dl_index + k)], dl[2 * (t.dl_index + k) + 1]};
+            ring[ln][GTS - tw + k] = v;
+        }
+    }
+    float mu = t.mu, last_r = t.last_r, last_j = t.last_j, lock = t.lock_accum;
+    int lock_n = t.lock_count, dli = t.dl_index;
+    // gain selection, src/dsp/costas.cpp:143-168; re-evaluated per demodulator block (see k_gardner)
+    float gain_mu, gain_omega;
+    auto regain = [&]() {
+        gain_mu = ted_gain > 0.0f ? ted_gain : 0.025f;
+        if (symbol_rate_hz >= 5500 && lock_n >= 240 && !(lock / (float)lock_n < 0.05f)) {
+            gain_mu = 0.018f;
+        }
+        gain_omega = 0.1f * gain_mu * gain_mu;
+    };
+    regain();
+    long next_blk = block_len > 0 ? block_len : n + 1;
+    f2* op = out + (size_t)ch * out_stride;
+
+    auto stage = [&](long t0, int slot) {
+        const int tn = (int)((n - t0) < GTS ? (n - t0) : GTS);
+        constexpr int RPP = CPW < 16 ? CPW : 16;
+#pragma unroll
+        for (int h = 0; h < CPW / RPP; h++) {
+            f2 r[RPP];
+#pragma unroll
+            for (int c = 0; c < RPP; c++) {
+                const f2 z = {0.0f, 0.0f};
+                const int cc = RPP * h + c;
+                f2 v = (ch0 + cc < n_channels && lane < tn) ? in[(size_t)(ch0 + cc) * in_stride + t0 + lane] : z;
+                v.x = (v.x != v.x) ? 0.0f : v.x; // the reference zeroes non-finite-NaN components as it consumes them
+                v.y = (v.y != v.y) ? 0.0f : v.y;
+                r[c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < RPP; c++) {
+                ring[RPP * h + c][GTS + slot * GTS + lane] = r[c];
+                if (slot == 2) {
+                    ring[RPP * h + c][lane] = r[c];
+                }
+            }
+        }
+    };
+    __syncthreads(); // history writes (wave 0) before the loader can touch the mirror (it does at it = 1 at the earliest)
+    if (loader && n > 0) {
+        stage(0, 0);
+    }
+    __syncthreads();
+
+    auto mmse = [&](const f2* w, float m, float* re, float* im) { // w[0..7] = the 8 samples, oldest first
+        float pos = m * 16.0f;
+        int lo = (int)pos;
+        float fr = pos - (float)lo;
+        if (lo < 0) {
+            lo = 0;
+            fr = 0.0f;
+        }
+        if (lo >= 16) {
+            lo = 15;
+            fr = 1.0f;
+        }
+        const float lw = 1.0f - fr;
+        float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float tap = lw * tbl[lo][i] + fr * tbl[lo + 1][i];
+            const f2 x = w[7 - i];
+            ar += tap * x.x;
+            ai += tap * x.y;
+        }
+        *re = ar;
+        *im = ai;
+    };
+
+    int sp = 0, base = GTS, tn_last = 0;
+    int it = 0;
+    for (long t0 = 0; t0 < n; t0 += GTS, it++) {
+        const int tn = (int)((n - t0) < GTS ? (n - t0) : GTS);
+        if (loader) {
+            if (t0 + GTS < n) {
+                stage(t0 + GTS, (it + 1) % 3);
+            }
+        } else {
+            base = GTS + (it % 3) * GTS;
+            tn_last = tn;
+            sp = 0;
+            int guard = 0;
+            while (true) {
+                bool busy = false;
+                if (run) {
+                    if (mu > 1.0f && sp < tn) {
+                        // the reference's "mu -= 1, push one sample" loop, all at once
+                        float need_f = ceilf(mu) - 1.0f;
+                        const int avail = tn - sp;
+                        const int take = (need_f < (float)avail) ? (int)need_f : avail;
+                        mu -= (float)take;
+                        sp += take;
+                        dli += take;
+                        dli = dli >= tw ? dli % tw : dli;
+                    }
+                    const long pos = t0 + sp;
+                    if (!(mu > 1.0f) && pos < n) {
+                        while (pos >= next_blk) {
+                            regain();
+                            next_blk += block_len;
+                        }
+                        const float half_omega = omega / 2.0f;
+                        int hs = (int)floorf(half_omega);
+                        float hmu = mu + half_omega - (float)hs;
+                        if (hmu > 1.0f) {
+                            hmu -= 1.0f;
+                            hs += 1;
+                        }
+                        if (hs < 0) {
+                            hs = 0;
+                        }
+                        if (dli + 7 >= 2 * tw || dli + hs + 7 >= 2 * tw) {
+                            mu += omega;
+                        } else {
+                            const f2* w = &ring[ln][base + sp - tw];
+                            float mr, mj, sr, sj;
+                            mmse(w, mu, &mr, &mj);
+                            mmse(w + hs, hmu, &sr, &sj);
+                            float err = (last_r - sr) * mr + (last_j - sj) * mj;
+                            if (err != err) {
+                                err = 0.0f;
+                            }
+                            err = clipf(err, 1.0f);
+                            const float ie2 = sr * sr, io2 = mr * mr, qe2 = sj * sj, qo2 = mj * mj;
+                            const float yi = ((ie2 + io2) != 0.0f) ? (ie2 - io2) / (ie2 + io2) : 0.0f;
+                            const float yq = ((qe2 + qo2) != 0.0f) ? (qe2 - qo2) / (qe2 + qo2) : 0.0f;
+                            lock += yi + yq;
+                            lock_n++;
+                            const float mag = sqrtf(sr * sr + sj * sj);
+                            omega += gain_omega * err * mag;
+                            omega = t.omega_mid + clipf(omega - t.omega_mid, t.omega_rel);
+                            mu += omega + gain_mu * err;
+                            last_r = sr;
+                            last_j = sj;
+                            if ((size_t)o < out_stride) {
+                                const f2 v = {sr, sj};
+                                op[o] = v;
+                            }
+                            o++;
+                        }
+                        busy = true;
+                    } else {
+                        busy = (mu > 1.0f) && sp < tn;
+                    }
+                }
+                if (!__any(busy) || ++guard > 4 * GTS) {
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        if (run) {
+            t.mu = mu;
+            t.omega = omega;
+            t.dl_index = dli;
+            t.last_r = last_r;
+            t.last_j = last_j;
+            t.lock_accum = lock;
+            t.lock_count = lock_n;
+            // the doubled delay line as tw pushes of the last tw samples leave it
+            float* dl = dl_store + (size_t)ch * (DDN_TED_DL * 4);
+            for (int k = 0; k < tw; k++) {
+                const f2 v = ring[ln][base + tn_last - tw + k];
+                int idx = dli + k;
+                idx = idx >= tw ? idx - tw : idx;
+                dl[2 * idx] = v.x;
+                dl[2 * idx + 1] = v.y;
+                dl[2 * (idx + tw)] = v.x;
+                dl[2 * (idx + tw) + 1] = v.y;
+            }
+        }
+        state[ch] = t;
+        out_count[ch] = o;
+    }
+}
+
+template <int CPW>
+hipError_t
+launch_gardner_ring(const void* in, long n, size_t in_stride, int n_channels, int sps, float ted_gain, int symbol_rate_hz,
+                    long block_len, DdnTedState* state, float* dl_store, void* out, size_t out_stride, int* out_count,
+                    hipStream_t st) {
+    const size_t shm = sizeof(float) * (17 * 8 + 8) + sizeof(f2) * (size_t)CPW * GROW;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gardner_ring<CPW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_gardner_ring<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shm, st,
+                       (const f2*)in, n, in_stride, n_channels, sps, ted_gain, symbol_rate_hz, block_len, state, dl_store,
+                       (f2*)out, out_stride, out_count);
+    return hipGetLastError();
+}
+} // namespace
+
 extern "C" hipError_t
 ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sps, float ted_gain, int symbol_rate_hz,
                 long block_len, DdnTedState* state, float* dl_store, void* out, size_t out_stride, int* out_count, hipStream_t st) {
@@ -302,6 +573,17 @@ ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sp
     int tw = a > b ? a : b;
     if (tw > DDN_TED_DL) {
         tw = DDN_TED_DL;
+    }
+    // ring variant while the look-back fits one tile and the batch is latency-bound (few wavefronts), unless
+    // DDN_TED_CLASSIC is set (A/B timing, tests)
+    static const bool classic = getenv("DDN_TED_CLASSIC") != nullptr;
+    if (!classic && tw <= GTW_MAX && n_channels <= 32 * 1024) {
+        if (n_channels <= 16 * 1024) {
+            return launch_gardner_ring<16>(in, n, in_stride, n_channels, sps, ted_gain, symbol_rate_hz, block_len, state,
+                                           dl_store, out, out_stride, out_count, st);
+        }
+        return launch_gardner_ring<32>(in, n, in_stride, n_channels, sps, ted_gain, symbol_rate_hz, block_len, state,
+                                       dl_store, out, out_stride, out_count, st);
     }
     const size_t shm = sizeof(float) * (17 * 8 + 8) + sizeof(f2) * 2 * 64 * 65 + sizeof(float) * 4 * (size_t)tw * 64;
     hipLaunchKernelGGL(k_gardner, dim3((unsigned)((n_channels + 63) / 64)), dim3(128), shm, st, (const f2*)in, n,
