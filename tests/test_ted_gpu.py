@@ -98,3 +98,20 @@ def test_gardner_block_len_regains_per_block(built):
         whole = np.concatenate([o2.block(iq[c, :n1]), o2.block(iq[c, n1:])])
         switched += (len(whole) != len(want)) or not np.array_equal(bits(whole), bits(want))
     assert switched > 0  # the test would be vacuous if per-block and per-call gain selection agreed everywhere
+
+
+@pytest.mark.parametrize("sps", [2, 3, 23, 24, 30])
+def test_gardner_kernel_variants_by_sps(built, sps):
+    """sps <= 23 (look-back <= 48 samples) runs k_gardner_ring, larger values the classic delay-line kernel; both carry
+    the same state layout, so splitting a stream across calls must not matter either."""
+    B = 9
+    iq = orc.synth_qpsk_f32(5 + sps, B, 150, sps, noise=0.08)
+    n = iq.shape[1]
+    t = GpuTed(B, sps, 4800)
+    cuts = [0, 7, 70, 71, n // 2, n]
+    got = [t.run(iq[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    for c in range(B):
+        o = orc.OracleTed(sps, 4800)
+        for (a, b), g in zip(zip(cuts[:-1], cuts[1:]), got):
+            want = o.block(iq[c, a:b])
+            assert np.array_equal(bits(g[c]), bits(want)), (sps, c, a, b)
