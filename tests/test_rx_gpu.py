@@ -95,3 +95,32 @@ def test_rx_fractional_sps_and_payload(built):
         payload = rec[c, a + 1:a + 1 + frame - 24, 0] & 3
         hits = [f for f in range(dib.shape[1] // frame) if np.array_equal(dib[c, f * frame + 24:(f + 1) * frame], payload)]
         assert len(hits) == 1, c
+
+
+def test_rx_full_batch_properties(built):
+    """BASELINE configs[2] shape: 4096 channels x 48000 discriminator samples.  Size-independent properties over the
+    whole batch (every replica of a channel yields byte-identical records whatever its position in the batch, symbol
+    counts agree with the oracle's) + a sample of channels bit for bit against the oracle."""
+    import torch
+    B, n, base_ch = 4096, 48000, 64
+    base, _, _ = orc.synth_p25_disc(9, base_ch, n, frame_dibits=864)
+    x = torch.from_numpy(np.tile(base, (B // base_ch, 1))).cuda()
+    rx = ddn.P25Rx(B, lock_symbols=840, use_matched_filter=1)
+    ms = ddn.lib().ddn_p25_rx_max_symbols(rx.h, n)
+    rec = torch.zeros((B, ms, 10), dtype=torch.uint8, device="cuda")
+    fl = torch.zeros((B, ms), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    assert ddn.lib().ddn_p25_rx_run(rx.h, x.data_ptr(), n, rec.data_ptr(), fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    torch.cuda.synchronize()
+    r = rec.view(B // base_ch, base_ch, ms, 10)
+    f = fl.view(B // base_ch, base_ch, ms)
+    c = cnt.view(B // base_ch, base_ch)
+    assert bool((c == c[0:1]).all()) and bool((f == f[0:1]).all()) and bool((r == r[0:1]).all())
+    cn = c[0].cpu().numpy()
+    for ch in (0, 17, 63):
+        o = orc.OracleP25Rx(lock_symbols=840, use_filter=1)
+        sym, rec4, flo = o.run(base[ch])
+        k = int(cn[ch])
+        r4, sy = orc.unpack_records10(rec[B - base_ch + ch, :k].cpu().numpy())   # the last replica
+        assert k == len(sym) and np.array_equal(sy.view(np.uint32), sym.view(np.uint32))
+        assert np.array_equal(r4, rec4) and np.array_equal(fl[B - base_ch + ch, :k].cpu().numpy(), flo)
