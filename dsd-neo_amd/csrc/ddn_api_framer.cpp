@@ -188,3 +188,15 @@ ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_
                                f->d_status9, d_first_record, d_status_count, (hipStream_t)hip_stream));
     return DDN_OK;
 }
+
+extern "C" int
+ddn_p25p1_framer_pack_ldu_rs(ddn_p25p1_framer* f, int ldu, const uint8_t* d_words240, uint8_t* d_data_bits,
+                             uint8_t* d_parity_bits, void* hip_stream) {
+    if (!f || (ldu != 1 && ldu != 2) || !d_words240 || !d_data_bits || !d_parity_bits) {
+        ddn_set_error("ddn_p25p1_framer_pack_ldu_rs: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_ldu_rs_pack(d_words240, (long)f->n_channels * f->max_frames, ldu == 1 ? 12 : 16, d_data_bits,
+                                d_parity_bits, (hipStream_t)hip_stream));
+    return DDN_OK;
+}

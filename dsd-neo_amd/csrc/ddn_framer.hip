@@ -151,6 +151,37 @@ k_imbe_index(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n
 }
 } // namespace
 
+namespace {
+// Hamming-corrected LDU words [slots][24][10] -> the RS decoder's hex-symbol layout: data [slots][n_data][6] and parity
+// [slots][24 - n_data][6] (the six data bits of each word, word order unchanged; p25p1_ldu1.c:233-245, p25p1_ldu2.c:256-262)
+__global__ void
+k_ldu_rs_pack(const uint8_t* __restrict__ words240, long n_slots, int n_data, uint8_t* __restrict__ data,
+              uint8_t* __restrict__ parity) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_slots * 144) {
+        return;
+    }
+    const long slot = t / 144;
+    const int r = (int)(t % 144), w = r / 6, b = r % 6;
+    const uint8_t v = words240[slot * 240 + w * 10 + b];
+    if (w < n_data) {
+        data[slot * (long)(n_data * 6) + w * 6 + b] = v;
+    } else {
+        parity[slot * (long)((24 - n_data) * 6) + (w - n_data) * 6 + b] = v;
+    }
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_ldu_rs_pack(const uint8_t* words240, long n_slots, int n_data, uint8_t* data, uint8_t* parity, hipStream_t st) {
+    if (n_slots <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_ldu_rs_pack, dim3((unsigned)((n_slots * 144 + 255) / 256)), dim3(256), 0, st, words240, n_slots,
+                       n_data, data, parity);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t
 ddn_dev_imbe_index(const int32_t* sync_pos, const int32_t* n_syncs, int n_channels, int max_frames, size_t max_sym,
                    const int32_t* first9, const int32_t* status9, int64_t* first, int32_t* status, hipStream_t st) {

@@ -232,6 +232,10 @@ int ddn_p25p1_framer_gather_trellis_block(ddn_p25p1_framer* f, int block, const 
 int ddn_p25p1_framer_gather_ldu_words(ddn_p25p1_framer* f, int ldu, const uint8_t* d_records10, const int32_t* d_counts,
                                       size_t max_symbols, uint8_t* d_bits240, uint8_t* d_reliab240, uint8_t* d_valid,
                                       void* hip_stream);
+/* Hamming-corrected LDU words [slots][24][10] -> ddn_fec_p25_rs_batch input: data [slots][12|16][6], parity
+ * [slots][12|8][6] (LDU1: RS(24,12,13), p25p1_ldu1.c:233-245; LDU2: RS(24,16,9), p25p1_ldu2.c:256-262) */
+int ddn_p25p1_framer_pack_ldu_rs(ddn_p25p1_framer* f, int ldu, const uint8_t* d_words240, uint8_t* d_data_bits,
+                                 uint8_t* d_parity_bits, void* hip_stream);
 int ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_first_record,
                                 int32_t* d_status_count, void* hip_stream);
 

@@ -162,6 +162,26 @@ def test_device_chain_voice_capture(built):
             seen += 1
         assert seen >= 4
         assert int(errs.cpu().numpy().reshape(F, 24)[vvh == 1].max()) <= 2
+        # ... and on through Reed-Solomon, still on the device: LDU1 link control / LDU2 encryption sync
+        nd = 12 if ldu == 1 else 16
+        dd = torch.zeros((F, nd, 6), dtype=torch.uint8, device="cuda")
+        pp = torch.zeros((F, 24 - nd, 6), dtype=torch.uint8, device="cuda")
+        rs_st = torch.zeros(F, dtype=torch.uint8, device="cuda")
+        assert l.ddn_p25p1_framer_pack_ldu_rs(fr.h, ldu, fixed.data_ptr(), dd.data_ptr(), pp.data_ptr(), None) == 0
+        assert l.ddn_fec_p25_rs_batch(0 if ldu == 1 else 1, dd.data_ptr(), pp.data_ptr(), F, rs_st.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        ddh, rsh = dd.cpu().numpy(), rs_st.cpu().numpy()
+        for k, ((a, _, _), nd_) in enumerate(zip(rows, nid)):
+            if nd_[0] != 1 or nd_[2] != duid or a + 1 + 840 > count:
+                continue
+            assert rsh[k] == 0, (ldu, k)
+            if ldu == 1:   # "Group Voice Channel User": LCO 0, MFID 0 (the reference's DECODE_IQ_P25P1_C4FM_VOICE answer)
+                lc = ddh[k][::-1].reshape(72)
+                assert int("".join(map(str, lc[:8])), 2) == 0 and int("".join(map(str, lc[8:16])), 2) == 0, k
+            else:          # clear voice: ALGID 0x80, KID 0
+                hx = ddh[k]
+                assert int("".join(map(str, list(hx[3]) + list(hx[2][:2]))), 2) == 0x80, k
+                assert int("".join(map(str, list(hx[2][2:]) + list(hx[1]) + list(hx[0]))), 2) == 0, k
     # voice frames: index -> de-interleave, against the oracle on host-extracted dibits
     first = torch.zeros(F * 9, dtype=torch.int64, device="cuda")
     sc = torch.zeros(F * 9, dtype=torch.int32, device="cuda")
