@@ -127,6 +127,9 @@ PROTOTYPES = {
     "ddn_p25p1_framer_gather_ldu_words": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
                                           + [C.c_void_p] * 4),
     "ddn_p25p1_framer_pack_ldu_rs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_layout_hdu": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_framer_gather_hdu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
+    "ddn_p25p1_framer_pack_hdu_rs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p1_framer_imbe_index": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_resampler_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ddn_resampler_destroy": (None, [C.c_void_p]),

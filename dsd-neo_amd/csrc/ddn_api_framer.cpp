@@ -20,7 +20,7 @@
         }                                                                                                              \
     } while (0)
 
-enum { T_NID = 0, T_BLK0, T_BLK1, T_BLK2, T_LDU1, T_LDU2, T_COUNT };
+enum { T_NID = 0, T_BLK0, T_BLK1, T_BLK2, T_LDU1, T_LDU2, T_HDU_HEX, T_HDU_PAR, T_COUNT };
 
 struct ddn_p25p1_framer {
     int n_channels, max_frames;
@@ -49,7 +49,7 @@ ddn_p25p1_framer_create(int n_channels, int max_frames_per_channel, ddn_p25p1_fr
     memset(f, 0, sizeof(*f));
     f->n_channels = n_channels;
     f->max_frames = max_frames_per_channel;
-    int32_t tab[T_COUNT][120];
+    int32_t tab[T_COUNT][216];
     f->n_off[T_NID] = 32;
     ddn_p25p1_layout_nid(tab[T_NID]);
     for (int b = 0; b < 3; b++) {
@@ -59,6 +59,9 @@ ddn_p25p1_framer_create(int n_channels, int max_frames_per_channel, ddn_p25p1_fr
     f->n_off[T_LDU1] = f->n_off[T_LDU2] = 120;
     ddn_p25p1_layout_ldu_words(1, tab[T_LDU1]);
     ddn_p25p1_layout_ldu_words(2, tab[T_LDU2]);
+    f->n_off[T_HDU_HEX] = 108;
+    f->n_off[T_HDU_PAR] = 216;
+    ddn_p25p1_layout_hdu(tab[T_HDU_HEX], tab[T_HDU_PAR]);
     int32_t first9[9], status9[9];
     ddn_p25p1_layout_ldu_imbe(first9, status9);
     const size_t slots = (size_t)n_channels * (size_t)max_frames_per_channel;
@@ -196,7 +199,37 @@ ddn_p25p1_framer_pack_ldu_rs(ddn_p25p1_framer* f, int ldu, const uint8_t* d_word
         ddn_set_error("ddn_p25p1_framer_pack_ldu_rs: bad argument");
         return DDN_EINVAL;
     }
-    HIP_TRY(ddn_dev_ldu_rs_pack(d_words240, (long)f->n_channels * f->max_frames, ldu == 1 ? 12 : 16, d_data_bits,
-                                d_parity_bits, (hipStream_t)hip_stream));
+    HIP_TRY(ddn_dev_rs_pack(d_words240, (long)f->n_channels * f->max_frames, 24, 10, ldu == 1 ? 12 : 16, d_data_bits,
+                            d_parity_bits, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p1_framer_gather_hdu(ddn_p25p1_framer* f, const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols,
+                            uint8_t* d_hex_bits216, uint8_t* d_parity_bits432, int16_t* d_hex_llr216,
+                            int16_t* d_parity_llr432, uint8_t* d_valid, void* hip_stream) {
+    if (!d_hex_bits216 || !d_parity_bits432) {
+        ddn_set_error("ddn_p25p1_framer_gather_hdu: null argument");
+        return DDN_EINVAL;
+    }
+    int rc = gather(f, T_HDU_HEX, d_records10, d_counts, max_symbols, d_hex_bits216, nullptr, d_hex_llr216, 216, 0,
+                    nullptr, nullptr, nullptr, hip_stream);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    // the parity field ends last, so its "fits inside this call's records" flag covers the whole header
+    return gather(f, T_HDU_PAR, d_records10, d_counts, max_symbols, d_parity_bits432, nullptr, d_parity_llr432, 432, 0,
+                  nullptr, nullptr, d_valid, hip_stream);
+}
+
+extern "C" int
+ddn_p25p1_framer_pack_hdu_rs(ddn_p25p1_framer* f, const uint8_t* d_hex_bits216, uint8_t* d_data_bits,
+                             uint8_t* d_parity_bits, void* hip_stream) {
+    if (!f || !d_hex_bits216 || !d_data_bits || !d_parity_bits) {
+        ddn_set_error("ddn_p25p1_framer_pack_hdu_rs: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_rs_pack(d_hex_bits216, (long)f->n_channels * f->max_frames, 36, 6, 20, d_data_bits, d_parity_bits,
+                            (hipStream_t)hip_stream));
     return DDN_OK;
 }

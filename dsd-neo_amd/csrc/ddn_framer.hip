@@ -152,33 +152,36 @@ k_imbe_index(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n
 } // namespace
 
 namespace {
-// Hamming-corrected LDU words [slots][24][10] -> the RS decoder's hex-symbol layout: data [slots][n_data][6] and parity
-// [slots][24 - n_data][6] (the six data bits of each word, word order unchanged; p25p1_ldu1.c:233-245, p25p1_ldu2.c:256-262)
+// decoded words [slots][n_words][wstride] (first six entries of a word = its hex symbol's bits) -> the RS decoder's
+// layout: data [slots][n_data][6] and parity [slots][n_words - n_data][6], word order unchanged
+// (LDU1 p25p1_ldu1.c:233-245, LDU2 p25p1_ldu2.c:256-262, HDU p25p1_hdu.c:252-270)
 __global__ void
-k_ldu_rs_pack(const uint8_t* __restrict__ words240, long n_slots, int n_data, uint8_t* __restrict__ data,
-              uint8_t* __restrict__ parity) {
+k_rs_pack(const uint8_t* __restrict__ words, long n_slots, int n_words, int wstride, int n_data,
+          uint8_t* __restrict__ data, uint8_t* __restrict__ parity) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_slots * 144) {
+    const int per = n_words * 6;
+    if (t >= n_slots * per) {
         return;
     }
-    const long slot = t / 144;
-    const int r = (int)(t % 144), w = r / 6, b = r % 6;
-    const uint8_t v = words240[slot * 240 + w * 10 + b];
+    const long slot = t / per;
+    const int r = (int)(t % per), w = r / 6, b = r % 6;
+    const uint8_t v = words[(slot * n_words + w) * (long)wstride + b];
     if (w < n_data) {
         data[slot * (long)(n_data * 6) + w * 6 + b] = v;
     } else {
-        parity[slot * (long)((24 - n_data) * 6) + (w - n_data) * 6 + b] = v;
+        parity[slot * (long)((n_words - n_data) * 6) + (w - n_data) * 6 + b] = v;
     }
 }
 } // namespace
 
 extern "C" hipError_t
-ddn_dev_ldu_rs_pack(const uint8_t* words240, long n_slots, int n_data, uint8_t* data, uint8_t* parity, hipStream_t st) {
+ddn_dev_rs_pack(const uint8_t* words, long n_slots, int n_words, int wstride, int n_data, uint8_t* data, uint8_t* parity,
+                hipStream_t st) {
     if (n_slots <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_ldu_rs_pack, dim3((unsigned)((n_slots * 144 + 255) / 256)), dim3(256), 0, st, words240, n_slots,
-                       n_data, data, parity);
+    hipLaunchKernelGGL(k_rs_pack, dim3((unsigned)((n_slots * n_words * 6 + 255) / 256)), dim3(256), 0, st, words, n_slots,
+                       n_words, wstride, n_data, data, parity);
     return hipGetLastError();
 }
 

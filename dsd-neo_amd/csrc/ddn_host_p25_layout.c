@@ -8,6 +8,8 @@
  *         parity 7..4 | IMBE 7 | parity 3..0 | IMBE 8 | LSD (16 dibits) | IMBE 9     (p25p1_ldu1.c; each word = 5
  *         dibits = one Hamming(10,6,3) codeword, high bit of each dibit first)
  *   LDU2: same slots, carrying ES words 15..0 (16 data) and parity words 7..0 (p25p1_ldu2.c:211-236)
+ *   HDU:  36 Golay(24,6) words of 3 data + 6 parity dibits, sent hex_data[19..0] then hex_parity[15..0]
+ *         (p25p1_hdu.c:191-200,252-268; status counter starts at 21 = frame index 57)
  * Pure host code, no device state: the tables are uploaded once and drive k_gather_fields. */
 #include "ddn_internal.h"
 
@@ -104,4 +106,20 @@ ddn_p25p1_layout_ldu_imbe(int32_t first9[9], int32_t status9[9]) {
         return -1;
     }
     return ldu_walk(1, 0, first9, status9, 0);
+}
+
+/* HDU: hex3 = [36][3] dibits carrying each word's 6 data bits, par6 = [36][6] dibits carrying its 12 Golay parity bits;
+ * word order hex_data[0..19] then hex_parity[0..15] (= the order the Reed-Solomon decoder takes them). */
+int
+ddn_p25p1_layout_hdu(int32_t hex3[36 * 3], int32_t par6[36 * 6]) {
+    if (!hex3 || !par6) {
+        return -1;
+    }
+    walker w = {57};
+    for (int seq = 0; seq < 36; seq++) {
+        const int word = seq < 20 ? 19 - seq : 20 + (15 - (seq - 20));
+        take(&w, 3, hex3 + 3 * word);
+        take(&w, 6, par6 + 6 * word);
+    }
+    return w.idx;
 }

@@ -236,6 +236,16 @@ int ddn_p25p1_framer_gather_ldu_words(ddn_p25p1_framer* f, int ldu, const uint8_
  * [slots][12|8][6] (LDU1: RS(24,12,13), p25p1_ldu1.c:233-245; LDU2: RS(24,16,9), p25p1_ldu2.c:256-262) */
 int ddn_p25p1_framer_pack_ldu_rs(ddn_p25p1_framer* f, int ldu, const uint8_t* d_words240, uint8_t* d_data_bits,
                                  uint8_t* d_parity_bits, void* hip_stream);
+/* HDU (p25p1_hdu.c:191-200,252-270): 36 Golay(24,6) words.  gather_hdu -> hex bits [slots][36][6] and parity bits
+ * [slots][36][12] (ddn_fec_golay24_batch / _soft_batch input with data_len 6, n = slots * 36; optional int16 LLRs per bit
+ * for the soft variant), word order hex_data[0..19], hex_parity[0..15]; pack_hdu_rs -> RS(36,20,17) input
+ * (ddn_fec_p25_rs_batch with DDN_RS_36_20_17): data [slots][20][6], parity [slots][16][6]. */
+int ddn_p25p1_layout_hdu(int32_t hex3[108], int32_t par6[216]);
+int ddn_p25p1_framer_gather_hdu(ddn_p25p1_framer* f, const uint8_t* d_records10, const int32_t* d_counts,
+                                size_t max_symbols, uint8_t* d_hex_bits216, uint8_t* d_parity_bits432,
+                                int16_t* d_hex_llr216, int16_t* d_parity_llr432, uint8_t* d_valid, void* hip_stream);
+int ddn_p25p1_framer_pack_hdu_rs(ddn_p25p1_framer* f, const uint8_t* d_hex_bits216, uint8_t* d_data_bits,
+                                 uint8_t* d_parity_bits, void* hip_stream);
 int ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_first_record,
                                 int32_t* d_status_count, void* hip_stream);
 

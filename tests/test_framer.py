@@ -207,3 +207,123 @@ def test_device_chain_voice_capture(built):
             assert ofl[i] == want[2] and np.array_equal(ofr[i], want[0]) and np.array_equal(osf[i], want[1]), (k, v)
             checked += 1
     assert checked >= 72 and np.all(ofl[ns[0] * 9:] == 0xFF)
+
+
+def _hdu_python_walk():
+    """Independent restatement of the HDU field order (p25p1_hdu.c:191-200,252-268): -> (hex [36][3], par [36][6])
+    frame dibit indices, word order hex_data[0..19], hex_parity[0..15]."""
+    idx = 57
+    hexp, parp = [None] * 36, [None] * 36
+
+    def take(n):
+        nonlocal idx
+        out = []
+        while len(out) < n:
+            if idx % 36 != 35:
+                out.append(idx)
+            idx += 1
+        return out
+    for seq in range(36):
+        word = 19 - seq if seq < 20 else 20 + (15 - (seq - 20))
+        hexp[word] = take(3)
+        parp[word] = take(6)
+    return np.array(hexp), np.array(parp), idx
+
+
+def test_hdu_layout_matches_python_walk(built):
+    hx, pr = np.zeros(108, np.int32), np.zeros(216, np.int32)
+    end = ddn.lib().ddn_p25p1_layout_hdu(hx.ctypes.data, pr.ctypes.data)
+    h, p, idx = _hdu_python_walk()
+    assert end == idx and np.array_equal(hx.reshape(36, 3), h) and np.array_equal(pr.reshape(36, 6), p)
+    assert hx[19 * 3] == 57 and not np.any(np.concatenate([hx, pr]) % 36 == 35)
+
+
+@pytest.mark.gpu
+def test_device_chain_hdu(built):
+    """Synthetic header data units: 20 random hex words -> RS(36,20,17) -> Golay(24,6) per word -> C4FM; the device chain
+    (front end, rx loop, framer gathers, Golay, RS) must return the words that were sent."""
+    import torch
+    import fecgen
+    l = ddn.lib()
+    rng = np.random.default_rng(31)
+    B, FR, NF = 4, 396, 9
+    N = 10 * FR * NF + 600
+    h, p, _ = _hdu_python_walk()
+    nac = 0x2A5
+    data16 = [(nac >> (11 - k)) & 1 for k in range(12)] + [0, 0, 0, 0]              # DUID 0 = HDU
+    cw = list(fecgen.bch_63_16_encode(data16)) + [0]
+    nid = [(cw[2 * k] << 1) | cw[2 * k + 1] for k in range(32)]
+    sent = np.zeros((B, NF, 20), np.int64)
+    iq = np.zeros((B, N, 2), np.uint8)
+    for c in range(B):
+        frames = np.zeros((NF, FR), np.int8)
+        for f in range(NF):
+            d = rng.integers(0, 64, 20)
+            sent[c, f] = d
+            syms = np.concatenate([d, fecgen.rs63_encode(d, 8)])                     # hex_data[0..19], hex_parity[0..15]
+            fr = np.full(FR, 2, np.int8)                                             # status / filler dibits
+            fr[:24] = orc.P25_FS_DIBITS
+            fr[[q for q in range(24, 57) if q != 35]] = nid
+            for w in range(36):
+                b6 = np.array([(int(syms[w]) >> (5 - k)) & 1 for k in range(6)], np.uint8)
+                d12 = np.zeros(12, np.uint8)
+                d12[6:] = b6
+                par = np.array(fecgen.golay24_encode(d12), np.uint8)
+                fr[h[w]] = (b6[0::2] << 1) | b6[1::2]
+                fr[p[w]] = (par[0::2] << 1) | par[1::2]
+            frames[f] = fr
+        iq[c] = p25gen.modulate_cu8(frames.reshape(-1), N, lead=210 + 29 * c, seed=40 + c)
+    fe = ddn.Batch(B, block_len=8192)
+    disc = fe.run_host(iq, N)
+    rx = ddn.P25Rx(B, lock_symbols=FR - 24, use_matched_filter=1)
+    ms = l.ddn_p25_rx_max_symbols(rx.h, N)
+    d_disc = _dev(disc)
+    rec = torch.zeros((B, ms, 10), dtype=torch.uint8, device="cuda")
+    fl = torch.zeros((B, ms), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    assert l.ddn_p25_rx_run(rx.h, d_disc.data_ptr(), N, rec.data_ptr(), fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    F = NF + 3
+    S = B * F
+    fr_ = Framer(B, F)
+    assert l.ddn_p25p1_framer_index(fr_.h, fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    hb = torch.zeros((S, 36, 6), dtype=torch.uint8, device="cuda")
+    pb = torch.zeros((S, 36, 12), dtype=torch.uint8, device="cuda")
+    hl = torch.zeros((S, 36, 6), dtype=torch.int16, device="cuda")
+    pl = torch.zeros((S, 36, 12), dtype=torch.int16, device="cuda")
+    vv = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p1_framer_gather_hdu(fr_.h, rec.data_ptr(), cnt.data_ptr(), ms, hb.data_ptr(), pb.data_ptr(),
+                                         hl.data_ptr(), pl.data_ptr(), vv.data_ptr(), None) == 0
+    raw_h = hb.clone()
+    gst = torch.zeros(S * 36, dtype=torch.uint8, device="cuda")
+    gfx = torch.zeros(S * 36, dtype=torch.int32, device="cuda")
+    assert l.ddn_fec_golay24_batch(6, hb.data_ptr(), pb.data_ptr(), S * 36, gst.data_ptr(), gfx.data_ptr(), None) == 0
+    dd = torch.zeros((S, 20, 6), dtype=torch.uint8, device="cuda")
+    pp = torch.zeros((S, 16, 6), dtype=torch.uint8, device="cuda")
+    rst = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p1_framer_pack_hdu_rs(fr_.h, hb.data_ptr(), dd.data_ptr(), pp.data_ptr(), None) == 0
+    assert l.ddn_fec_p25_rs_batch(2, dd.data_ptr(), pp.data_ptr(), S, rst.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    ns = np.zeros(B, np.int32)
+    pos = np.zeros((B, F), np.int32)
+    assert l.ddn_p25p1_framer_get_syncs(fr_.h, ns.ctypes.data, pos.ctypes.data) == 0
+    vvh, ddh, rsh = vv.cpu().numpy().reshape(B, F), dd.cpu().numpy().reshape(B, F, 20, 6), rst.cpu().numpy().reshape(B, F)
+    rawh, llh = raw_h.cpu().numpy().reshape(B, F, 36, 6), hl.cpu().numpy().reshape(B, F, 36, 6)
+    rech, cnth = rec.cpu().numpy(), cnt.cpu().numpy()
+    for c in range(B):
+        r4, _ = orc.unpack_records10(rech[c, :cnth[c]])
+        good = 0
+        for k in range(int(ns[c])):
+            if not vvh[c, k]:
+                continue
+            a = int(pos[c, k])
+            w = r4[a - 23 + h]                                  # [36, 3, 4] host-side gather of the same dibits
+            assert np.array_equal(rawh[c, k], np.stack([(w[:, :, 0] >> 1) & 1, w[:, :, 0] & 1], axis=2).reshape(36, 6))
+            assert np.array_equal(llh[c, k], np.stack([w[:, :, 2], w[:, :, 3]], axis=2).reshape(36, 6))
+            if k < 2:
+                continue                                        # matched-filter / threshold warm-up frames
+            assert rsh[c, k] == 0, (c, k)
+            got = (ddh[c, k] * (1 << np.arange(5, -1, -1))).sum(axis=1)
+            hits = [f for f in range(NF) if np.array_equal(sent[c, f], got)]
+            assert len(hits) == 1, (c, k)
+            good += 1
+        assert good >= NF - 3, (c, good)
