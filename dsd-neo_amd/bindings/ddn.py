@@ -131,6 +131,20 @@ PROTOTYPES = {
     "ddn_p25p1_framer_gather_hdu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
     "ddn_p25p1_framer_pack_hdu_rs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p1_framer_imbe_index": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_stream_set_create": (C.c_int, [C.c_int, C.c_size_t, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_void_p)]),
+    "ddn_stream_set_destroy": (None, [C.c_void_p]),
+    "ddn_stream_set_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ddn_stream_set_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "ddn_stream_set_set_power": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "ddn_stream_set_bump_generation": (C.c_int, [C.c_void_p]),
+    "ddn_stream_set_close": (None, [C.c_void_p]),
+    "ddn_hooks_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "ddn_hooks_return_pwr": (C.c_double, [C.c_void_p]),
+    "ddn_hooks_output_rate_hz": (C.c_uint, [C.c_void_p]),
+    "ddn_hooks_output_kind": (C.c_int, [C.c_void_p]),
+    "ddn_hooks_symbol_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ddn_hooks_stream_generation": (C.c_uint32, [C.c_void_p]),
     "ddn_resampler_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ddn_resampler_destroy": (None, [C.c_void_p]),
     "ddn_resampler_reset": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -9,7 +9,7 @@
  *        ddn_front_end_run       replaces the per-stream loop "widen -> full_demod()" of the demod thread
  *                                (reference src/io/radio/rtl_device.cpp:1777 + src/io/radio/rtl_sdr_fm.cpp:3458-3516,
  *                                 full_demod: include/dsd-neo/dsp/demod_pipeline.h:106)
- *        ddn_hooks_read          serves include/dsd-neo/runtime/rtl_stream_io_hooks.h:25-28 `read`
+ *        ddn_hooks_read / ddn_stream_set_*   serve include/dsd-neo/runtime/rtl_stream_io_hooks.h:25-28 `read`
  *      Pointers named d_* are DEVICE pointers (hipMalloc / torch .data_ptr()), h_* are host pointers.
  *
  *  (2) Drop-in single-stream symbols with the reference's own names and signatures (host pointers), so the
@@ -197,6 +197,34 @@ int ddn_gardner_run(ddn_ted_batch* b, const float* d_iq, size_t n, float* d_sym,
                     void* hip_stream);
 int ddn_gardner_run_host(ddn_ted_batch* b, const float* iq, size_t n, float* sym, size_t sym_stride, int* sym_count);
 int ddn_ted_batch_get_state(ddn_ted_batch* b, int channel, float out8[8]);
+
+/* ---- the consumer-side seam: serving dsd-neo's stream-read hook from batched results ---------------
+ * A dsd-neo decoder thread pulls samples through dsd_rtl_stream_io_hooks.read(rtl_ctx, out, count, &got)
+ * (include/dsd-neo/runtime/rtl_stream_io_hooks.h:25-32; callers src/dsp/dsd_symbol.c:889-920,1412-1435: count is 512 or
+ * 1, blocks until >= 1 sample, < 0 on end of stream).  A ddn_stream_set holds one single-producer / single-consumer
+ * float queue per channel: the producer pushes the rows of each batch interval (discriminator samples from
+ * ddn_front_end_run_host, or CQPSK symbols with their per-channel counts), every decoder instance gets
+ * state->rtl_ctx = ddn_stream_set_ctx(set, channel) and the host installs
+ *     dsd_rtl_stream_io_hooks h = { ddn_hooks_read, ddn_hooks_return_pwr };  dsd_rtl_stream_io_hooks_set(h);
+ * The metrics getters the symbol loop polls (rtl_stream_metrics_hooks.h:28-48: output_rate_hz, output_kind 0 = FSK
+ * discriminator / 1 = CQPSK symbols, symbol_profile, stream_generation) are argument-less in the reference (one stream
+ * per process); here they take the channel context.  Host-only, thread-safe, no device work. */
+typedef struct ddn_stream_set ddn_stream_set;
+int ddn_stream_set_create(int n_channels, size_t capacity_samples, unsigned output_rate_hz, int output_kind,
+                          int symbol_rate_hz, int levels, int channel_profile, ddn_stream_set** out);
+void ddn_stream_set_destroy(ddn_stream_set* s);
+void* ddn_stream_set_ctx(ddn_stream_set* s, int channel);
+/* rows [n_channels][row_stride], n samples each (or counts[c] <= n when counts != NULL); blocks while a queue is full */
+int ddn_stream_set_push(ddn_stream_set* s, const float* rows, size_t n, size_t row_stride, const int32_t* counts);
+int ddn_stream_set_set_power(ddn_stream_set* s, int channel, double mean_power); /* value return_pwr reports */
+int ddn_stream_set_bump_generation(ddn_stream_set* s); /* retune / restart: drop queued samples, generation + 1 */
+void ddn_stream_set_close(ddn_stream_set* s);          /* readers drain what is queued, then read() returns -1 */
+int ddn_hooks_read(void* rtl_ctx, float* out, size_t count, int* out_got);
+double ddn_hooks_return_pwr(const void* rtl_ctx);
+unsigned int ddn_hooks_output_rate_hz(const void* rtl_ctx);
+int ddn_hooks_output_kind(const void* rtl_ctx);
+int ddn_hooks_symbol_profile(const void* rtl_ctx, int* out_symbol_rate_hz, int* out_levels, int* out_channel_profile);
+uint32_t ddn_hooks_stream_generation(const void* rtl_ctx);
 
 /* ---- P25 Phase 1 framer: receive-loop records -> FEC kernel inputs, on the device -------------------------------------
  * What the reference's P25p1 handlers do with getDibitSoft() between the sync and the decoders, as gathers: every field of
