@@ -131,6 +131,16 @@ PROTOTYPES = {
     "ddn_p25p1_framer_gather_hdu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
     "ddn_p25p1_framer_pack_hdu_rs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p1_framer_imbe_index": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_iq_capture_read_info": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "ddn_iq_capture_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ddn_iq_capture_close": (None, [C.c_void_p]),
+    "ddn_iq_capture_get_info": (C.c_void_p, [C.c_void_p]),
+    "ddn_iq_capture_get_events": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ddn_iq_capture_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ddn_iq_capture_rewind": (C.c_int, [C.c_void_p]),
+    "ddn_iq_effective_bytes": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "ddn_iq_load_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]),
+    "ddn_iq_free": (None, [C.c_void_p]),
     "ddn_stream_set_create": (C.c_int, [C.c_int, C.c_size_t, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(C.c_void_p)]),
     "ddn_stream_set_destroy": (None, [C.c_void_p]),

@@ -198,6 +198,55 @@ int ddn_gardner_run(ddn_ted_batch* b, const float* d_iq, size_t n, float* d_sym,
 int ddn_gardner_run_host(ddn_ted_batch* b, const float* iq, size_t n, float* sym, size_t sym_stride, int* sym_count);
 int ddn_ted_batch_get_state(ddn_ted_batch* b, int channel, float out8[8]);
 
+/* ---- dsd-neo I/Q captures: the feeder side ------------------------------------------------------------
+ * Reader for the "dsd-neo-iq" capture format that --iq-capture writes and --iq-replay ingests (JSON sidecar v1 / v2 + raw
+ * cu8 / cf32 / cs16 samples; docs/iq-capture-replay.md:37-76, src/io/iq/iq_replay.c): same path resolution, required
+ * fields, validation and replayable-byte rule as dsd_iq_replay_read_metadata / _open / _read
+ * (include/dsd-neo/io/iq_replay.h:71-100); return values are the reference's dsd_iq_error codes
+ * (include/dsd-neo/io/iq_types.h:24-36).  Host-only C.  base_decimation = 2^p maps to ddn_batch_set_decimation(b, p),
+ * demod_rate_hz to the batch's sample_rate_hz. */
+enum {
+    DDN_IQ_OK = 0, DDN_IQ_ERR_IO = -1, DDN_IQ_ERR_INVALID_META = -2, DDN_IQ_ERR_UNSUPPORTED_VER = -3,
+    DDN_IQ_ERR_UNSUPPORTED_FMT = -4, DDN_IQ_ERR_ALIGNMENT = -5, DDN_IQ_ERR_RATE_CHAIN = -6, DDN_IQ_ERR_RETUNE_REJECT = -7,
+    DDN_IQ_ERR_ALLOC = -8, DDN_IQ_ERR_INVALID_ARG = -10
+};
+enum { DDN_IQ_FORMAT_CU8 = 1, DDN_IQ_FORMAT_CF32 = 2, DDN_IQ_FORMAT_CS16 = 3 };
+enum { DDN_IQ_EVENT_RETUNE = 1, DDN_IQ_EVENT_MUTE = 2, DDN_IQ_EVENT_RESET = 3 };
+typedef struct ddn_iq_event { /* == dsd_iq_event (iq_types.h:50-58) */
+    int kind;
+    uint64_t byte_offset, duration_bytes, center_frequency_hz, capture_center_frequency_hz;
+    uint32_t sample_rate_hz;
+    char reason[64];
+} ddn_iq_event;
+typedef struct ddn_iq_capture_info { /* the fields of dsd_iq_replay_config a feeder needs (iq_replay.h:26-66) */
+    uint32_t metadata_version;
+    int sample_format;
+    uint32_t sample_rate_hz, base_decimation, post_downsample, demod_rate_hz, capture_retune_count, event_count;
+    uint64_t center_frequency_hz, capture_center_frequency_hz, data_bytes, capture_drops, capture_drop_blocks,
+        input_ring_drops;
+    uint64_t actual_file_bytes, effective_bytes; /* on-disk size; replayable bytes (whole samples) */
+    int ppm, tuner_gain_tenth_db, rtl_dsp_bw_khz;
+    int offset_tuning_enabled, fs4_shift_enabled, combine_rotate_enabled, muted_bytes_excluded, contains_retunes,
+        size_limit_reached, size_mismatch;
+    char capture_stage[64];
+    char data_path[2048], metadata_path[2048];
+} ddn_iq_capture_info;
+typedef struct ddn_iq_capture ddn_iq_capture;
+int ddn_iq_capture_read_info(const char* path, ddn_iq_capture_info* out_info); /* == dsd_iq_replay_read_metadata */
+int ddn_iq_capture_open(const char* path, ddn_iq_capture** out);               /* == dsd_iq_replay_open */
+void ddn_iq_capture_close(ddn_iq_capture* c);
+const ddn_iq_capture_info* ddn_iq_capture_get_info(const ddn_iq_capture* c);
+const ddn_iq_event* ddn_iq_capture_get_events(const ddn_iq_capture* c, uint32_t* out_count);
+int ddn_iq_capture_read(ddn_iq_capture* c, void* out, size_t max_bytes, size_t* out_bytes); /* 0 bytes = end */
+int ddn_iq_capture_rewind(ddn_iq_capture* c);
+int ddn_iq_effective_bytes(uint64_t data_bytes, uint64_t actual_file_size, int sample_format, uint64_t* out_effective,
+                           int* out_size_mismatch); /* == dsd_iq_replay_compute_effective_bytes */
+/* B captures of one format / rate chain -> one malloc'ed channel-major buffer [B][n] (n = shortest capture), the input
+ * shape of ddn_front_end_run_host / ddn_cqpsk_run_host; release with ddn_iq_free */
+int ddn_iq_load_batch(const char* const* paths, int n_captures, void** out_buf, size_t* out_n_samples,
+                      ddn_iq_capture_info* out_info0);
+void ddn_iq_free(void* p);
+
 /* ---- the consumer-side seam: serving dsd-neo's stream-read hook from batched results ---------------
  * A dsd-neo decoder thread pulls samples through dsd_rtl_stream_io_hooks.read(rtl_ctx, out, count, &got)
  * (include/dsd-neo/runtime/rtl_stream_io_hooks.h:25-32; callers src/dsp/dsd_symbol.c:889-920,1412-1435: count is 512 or

@@ -405,6 +405,7 @@ refh_sync_p25p1_neg(void) {
 #include <dsd-neo/dsp/sync_calibration.h>
 #include "frame_sync_level.h" /* src/dsp/frame_sync_level.h (private header, on the -I path) */
 #include <dsd-neo/core/vocoder.h>
+#include <dsd-neo/io/iq_replay.h>
 #include <dsd-neo/protocol/p25/p25p1_const.h>
 
 extern "C" {
@@ -537,5 +538,86 @@ refh_imbe_deinterleave(const uint8_t* dibits, const int16_t* llr0, const int16_t
     }
     *status_count_out = status_count;
     return pos;
+}
+
+// ---- I/Q capture metadata / replay reader (src/io/iq/iq_replay.c), flattened for ctypes ------------------------------
+// out[] = version, format, sample_rate, base_decimation, post_downsample, demod_rate, retune_count, event_count,
+//         center, capture_center, data_bytes, drops, drop_blocks, ring_drops, ppm, gain, bw, offset_tuning, fs4,
+//         historical_cu8_two_pass, muted_excluded, contains_retunes, size_limit_reached
+int
+refh_iq_meta(const char* path, int for_replay, int64_t out[23], char* stage64, char* data_path2048, char* err256) {
+    dsd_iq_replay_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    err256[0] = 0;
+    int rc = for_replay ? dsd_iq_replay_open(path, &cfg, nullptr, err256, 256)
+                        : dsd_iq_replay_read_metadata(path, &cfg, err256, 256);
+    if (rc != 0) {
+        return rc;
+    }
+    const int64_t v[23] = {cfg.metadata_version, (int64_t)cfg.format, cfg.sample_rate_hz, cfg.base_decimation,
+                           cfg.post_downsample, cfg.demod_rate_hz, cfg.capture_retune_count, cfg.event_count,
+                           (int64_t)cfg.center_frequency_hz, (int64_t)cfg.capture_center_frequency_hz,
+                           (int64_t)cfg.data_bytes, (int64_t)cfg.capture_drops, (int64_t)cfg.capture_drop_blocks,
+                           (int64_t)cfg.input_ring_drops, cfg.ppm, cfg.tuner_gain_tenth_db, cfg.rtl_dsp_bw_khz,
+                           cfg.offset_tuning_enabled, cfg.fs4_shift_enabled, cfg.historical_cu8_two_pass,
+                           cfg.muted_bytes_excluded, cfg.contains_retunes, cfg.size_limit_reached};
+    std::memcpy(out, v, sizeof(v));
+    std::strncpy(stage64, cfg.capture_stage, 63);
+    stage64[63] = 0;
+    std::strncpy(data_path2048, cfg.data_path, 2047);
+    data_path2048[2047] = 0;
+    dsd_iq_replay_config_clear(&cfg);
+    return 0;
+}
+
+// event i of a capture: out[] = kind, byte_offset, duration_bytes, center, capture_center, sample_rate
+int
+refh_iq_event(const char* path, unsigned index, int64_t out[6]) {
+    dsd_iq_replay_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    char err[256];
+    int rc = dsd_iq_replay_read_metadata(path, &cfg, err, sizeof(err));
+    if (rc != 0) {
+        return rc;
+    }
+    if (index >= cfg.event_count) {
+        dsd_iq_replay_config_clear(&cfg);
+        return -100;
+    }
+    const dsd_iq_event& e = cfg.events[index];
+    out[0] = (int64_t)e.kind;
+    out[1] = (int64_t)e.byte_offset;
+    out[2] = (int64_t)e.duration_bytes;
+    out[3] = (int64_t)e.center_frequency_hz;
+    out[4] = (int64_t)e.capture_center_frequency_hz;
+    out[5] = e.sample_rate_hz;
+    dsd_iq_replay_config_clear(&cfg);
+    return 0;
+}
+
+// read a whole capture through dsd_iq_replay_open / _read in `chunk`-byte requests; returns bytes delivered or < 0
+long
+refh_iq_read_all(const char* path, uint8_t* buf, long cap, int chunk) {
+    dsd_iq_replay_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    dsd_iq_replay_source* src = nullptr;
+    char err[256];
+    int rc = dsd_iq_replay_open(path, &cfg, &src, err, sizeof(err));
+    if (rc != 0) {
+        return rc;
+    }
+    long total = 0;
+    while (total < cap) {
+        size_t got = 0;
+        size_t want = (size_t)(cap - total < chunk ? cap - total : chunk);
+        rc = dsd_iq_replay_read(src, buf + total, want, &got);
+        if (rc != 0 || got == 0) {
+            break;
+        }
+        total += (long)got;
+    }
+    dsd_iq_replay_close(src);
+    dsd_iq_replay_config_clear(&cfg);
+    return total;
 }
 } // extern "C"
