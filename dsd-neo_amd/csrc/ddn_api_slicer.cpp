@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -114,6 +115,20 @@ ddn_p25_slicer_run(ddn_slicer_batch* b, const float* d_symbols, size_t n, uint8_
     if (!b || !d_symbols || !d_records10) {
         ddn_set_error("ddn_p25_slicer_run: null argument");
         return DDN_EINVAL;
+    }
+    // The sequential kernel (one lane per channel walking every symbol) remains for short calls; from a few hundred
+    // symbols on the parallel decomposition (ddn_slicer_par.hip) wins.  DDN_SLICER_SEQ forces the sequential one (A/B).
+    static const bool force_seq = getenv("DDN_SLICER_SEQ") != nullptr;
+    if (n >= 256 && !force_seq) {
+        const size_t need = sizeof(float) * 4 * n * (size_t)b->n_channels;
+        float* scratch = nullptr;
+        HIP_TRY(hipMallocAsync((void**)&scratch, need, (hipStream_t)hip_stream));
+        const hipError_t e = ddn_dev_p25_slicer_par(d_symbols, (long)n, n, b->n_channels, b->negative, b->d_state, b->d_sbuf,
+                                                    b->d_minring, b->d_maxring, scratch, d_records10, n * 10,
+                                                    (hipStream_t)hip_stream);
+        HIP_TRY(hipFreeAsync(scratch, (hipStream_t)hip_stream));
+        HIP_TRY(e);
+        return DDN_OK;
     }
     HIP_TRY(ddn_dev_p25_slicer(d_symbols, (long)n, n, b->n_channels, b->negative, b->d_state, b->d_sbuf, b->d_minring,
                                b->d_maxring, d_records10, n * 10, (hipStream_t)hip_stream));

@@ -105,6 +105,9 @@ hipError_t ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_chann
 hipError_t ddn_dev_p25_slicer(const float* sym, long n, size_t sym_stride, int n_channels, int negative,
                               DdnSlicerState* state, float* sbuf_store, float* minring, float* maxring, uint8_t* rec,
                               size_t rec_stride, hipStream_t st);
+hipError_t ddn_dev_p25_slicer_par(const float* sym, long n, size_t sym_stride, int n_channels, int negative,
+                                  DdnSlicerState* state, float* sbuf_store, float* minring, float* maxring,
+                                  float* scratch4, uint8_t* rec, size_t rec_stride, hipStream_t st);
 hipError_t ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channels, float* hist, float* out,
                                       hipStream_t st);
 #define DDN_MAX_HB_PASSES 4

@@ -63,6 +63,22 @@ def test_slicer_batch_vs_oracle(built):
     assert np.array_equal(rec, want)
 
 
+def test_slicer_call_splits_mix_sequential_and_parallel_kernels(built):
+    """Calls shorter than 256 symbols take the one-lane-per-channel kernel, longer ones the parallel decomposition
+    (ddn_slicer_par.hip); both carry the same state (128-symbol window, 1024-deep rings, binary64 sums), so any split of a
+    stream - including one that wraps the 1024-deep ring several times - gives the oracle's records."""
+    B, n = 9, 5200
+    sym = np.stack([orc.synth_c4fm_symbols(300 + c, n, scale=0.7 + 0.05 * c, noise=500) for c in range(B)])
+    cuts = [0, 10, 300, 301, 557, 1700, 1955, 4100, 4130, n]
+    s = GpuSlicer(B, 1)
+    got = np.concatenate([s.run(sym[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])], axis=1)
+    rec, _ = orc.unpack_records10(got)
+    want, thr = orc.oracle_slicer(sym, negative=1)
+    assert np.array_equal(rec, want)
+    for c in (0, B - 1):
+        assert np.array_equal(s.thresholds(c).view(np.uint32), np.asarray(thr[c], np.float32).view(np.uint32))
+
+
 def test_matched_filter(built):
     g = golden("sym_p25_matched_filter.npz")
     s = GpuSlicer(1)
