@@ -124,6 +124,8 @@ PROTOTYPES = {
     "ddn_p25p1_framer_gather_nid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
     "ddn_p25p1_framer_gather_trellis_block": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
                                               + [C.c_void_p] * 4),
+    "ddn_p25p1_framer_gather_r34_block": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+                                          + [C.c_void_p] * 4),
     "ddn_p25p1_framer_gather_ldu_words": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
                                           + [C.c_void_p] * 4),
     "ddn_p25p1_framer_pack_ldu_rs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -133,14 +133,14 @@ ddn_p25p1_framer_get_syncs(ddn_p25p1_framer* f, int32_t* n_syncs, int32_t* sync_
 static int
 gather(ddn_p25p1_framer* f, int t, const uint8_t* d_rec, const int32_t* d_counts, size_t max_symbols, uint8_t* bits,
        uint8_t* rel, int16_t* llr, int stride, int split, uint8_t* last_bit, uint8_t* last_rel, uint8_t* valid,
-       void* hip_stream) {
+       void* hip_stream, uint8_t* dibits = nullptr, uint8_t* dibit_rel = nullptr) {
     if (!f || !d_rec || !d_counts) {
         ddn_set_error("ddn_p25p1_framer_gather_*: null argument");
         return DDN_EINVAL;
     }
     HIP_TRY(ddn_dev_gather_fields(d_rec, max_symbols, d_counts, f->d_sync_pos, f->d_n_syncs, f->n_channels, f->max_frames,
                                   f->d_tab[t], f->n_off[t], f->max_off[t], bits, rel, llr, stride, split, last_bit,
-                                  last_rel, valid, (hipStream_t)hip_stream));
+                                  last_rel, valid, dibits, dibit_rel, (hipStream_t)hip_stream));
     return DDN_OK;
 }
 
@@ -166,6 +166,18 @@ ddn_p25p1_framer_gather_trellis_block(ddn_p25p1_framer* f, int block, const uint
     }
     return gather(f, T_BLK0 + block, d_records10, d_counts, max_symbols, d_dibit_bits196, nullptr, d_llr196, 196, 0,
                   nullptr, nullptr, d_valid, hip_stream);
+}
+
+extern "C" int
+ddn_p25p1_framer_gather_r34_block(ddn_p25p1_framer* f, int block, const uint8_t* d_records10, const int32_t* d_counts,
+                                  size_t max_symbols, uint8_t* d_dibits98, uint8_t* d_reliab98, uint8_t* d_valid,
+                                  void* hip_stream) {
+    if (block < 0 || block > 2 || !d_dibits98) {
+        ddn_set_error("ddn_p25p1_framer_gather_r34_block: bad argument");
+        return DDN_EINVAL;
+    }
+    return gather(f, T_BLK0 + block, d_records10, d_counts, max_symbols, nullptr, nullptr, nullptr, 196, 0, nullptr,
+                  nullptr, d_valid, hip_stream, d_dibits98, d_reliab98);
 }
 
 extern "C" int

@@ -150,7 +150,8 @@ hipError_t ddn_dev_find_syncs(const uint8_t* flags, const int32_t* counts, int n
 hipError_t ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32_t* counts, const int32_t* sync_pos,
                                  const int32_t* n_syncs, int n_channels, int max_frames, const int32_t* offsets, int n_off,
                                  int max_off, uint8_t* bits, uint8_t* rel, int16_t* llr, int stride, int split_last,
-                                 uint8_t* last_bit, uint8_t* last_rel, uint8_t* valid, hipStream_t st);
+                                 uint8_t* last_bit, uint8_t* last_rel, uint8_t* valid, uint8_t* dibits,
+                                 uint8_t* dibit_rel, hipStream_t st);
 hipError_t ddn_dev_rs_pack(const uint8_t* words, long n_slots, int n_words, int wstride, int n_data, uint8_t* data,
                            uint8_t* parity, hipStream_t st);
 hipError_t ddn_dev_imbe_index(const int32_t* sync_pos, const int32_t* n_syncs, int n_channels, int max_frames,

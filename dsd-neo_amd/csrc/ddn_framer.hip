@@ -47,7 +47,8 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
                 const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_syncs, int n_channels,
                 int max_frames, const int32_t* __restrict__ offsets, int n_off, int max_off, uint8_t* __restrict__ bits,
                 uint8_t* __restrict__ rel, int16_t* __restrict__ llr, int stride, int split_last,
-                uint8_t* __restrict__ last_bit, uint8_t* __restrict__ last_rel, uint8_t* __restrict__ valid) {
+                uint8_t* __restrict__ last_bit, uint8_t* __restrict__ last_rel, uint8_t* __restrict__ valid,
+                uint8_t* __restrict__ dibits, uint8_t* __restrict__ dibit_rel) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const long slot = t / n_off;
     const int i = (int)(t % n_off);
@@ -99,6 +100,12 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
             last_rel[slot] = (uint8_t)r;
         }
     }
+    if (dibits) { // one byte per dibit (the 3/4-rate trellis decoder's input), reliability alongside
+        dibits[(size_t)slot * n_off + i] = (uint8_t)(d & 3);
+    }
+    if (dibit_rel) {
+        dibit_rel[(size_t)slot * n_off + i] = (uint8_t)r;
+    }
     if (i == 0 && valid) {
         valid[slot] = ok ? 1 : 0;
     }
@@ -120,14 +127,15 @@ extern "C" hipError_t
 ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32_t* counts, const int32_t* sync_pos,
                       const int32_t* n_syncs, int n_channels, int max_frames, const int32_t* offsets, int n_off,
                       int max_off, uint8_t* bits, uint8_t* rel, int16_t* llr, int stride, int split_last,
-                      uint8_t* last_bit, uint8_t* last_rel, uint8_t* valid, hipStream_t st) {
+                      uint8_t* last_bit, uint8_t* last_rel, uint8_t* valid, uint8_t* dibits, uint8_t* dibit_rel,
+                      hipStream_t st) {
     const long total = (long)n_channels * max_frames * n_off;
     if (total <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_gather_fields, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rec, max_sym, counts,
                        sync_pos, n_syncs, n_channels, max_frames, offsets, n_off, max_off, bits, rel, llr, stride,
-                       split_last, last_bit, last_rel, valid);
+                       split_last, last_bit, last_rel, valid, dibits, dibit_rel);
     return hipGetLastError();
 }
 

@@ -306,6 +306,11 @@ int ddn_p25p1_framer_gather_nid(ddn_p25p1_framer* f, const uint8_t* d_records10,
 int ddn_p25p1_framer_gather_trellis_block(ddn_p25p1_framer* f, int block, const uint8_t* d_records10,
                                           const int32_t* d_counts, size_t max_symbols, int16_t* d_llr196,
                                           uint8_t* d_dibit_bits196, uint8_t* d_valid, void* hip_stream);
+/* same 98 dibits as one byte per dibit + its reliability byte: ddn_fec_r34_batch / dmr_r34_viterbi_decode_soft input
+ * (confirmed-data and MBT blocks coded at rate 3/4, src/protocol/p25/phase1/p25p1_mbf34.c) */
+int ddn_p25p1_framer_gather_r34_block(ddn_p25p1_framer* f, int block, const uint8_t* d_records10, const int32_t* d_counts,
+                                      size_t max_symbols, uint8_t* d_dibits98, uint8_t* d_reliab98, uint8_t* d_valid,
+                                      void* hip_stream);
 int ddn_p25p1_framer_gather_ldu_words(ddn_p25p1_framer* f, int ldu, const uint8_t* d_records10, const int32_t* d_counts,
                                       size_t max_symbols, uint8_t* d_bits240, uint8_t* d_reliab240, uint8_t* d_valid,
                                       void* hip_stream);

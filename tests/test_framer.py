@@ -91,10 +91,21 @@ def test_device_chain_tsdu_traffic(built):
     out = torch.zeros((S, 12), dtype=torch.uint8, device="cuda")
     met = torch.zeros(S, dtype=torch.int32, device="cuda")
     assert l.ddn_fec_p25_12_soft_batch(llr.data_ptr(), S, out.data_ptr(), met.data_ptr(), None) == 0
+    dib = torch.zeros((S, 98), dtype=torch.uint8, device="cuda")
+    drl = torch.zeros((S, 98), dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p1_framer_gather_r34_block(fr.h, 0, rec.data_ptr(), cnt.data_ptr(), ms, dib.data_ptr(), drl.data_ptr(),
+                                               None, None) == 0
     torch.cuda.synchronize()
     ns = np.zeros(B, np.int32)
     pos = np.zeros((B, F), np.int32)
     assert l.ddn_p25p1_framer_get_syncs(fr.h, ns.ctypes.data, pos.ctypes.data) == 0
+    dibh, drlh, rech, cnth = dib.cpu().numpy().reshape(B, F, 98), drl.cpu().numpy().reshape(B, F, 98), rec.cpu().numpy(), cnt.cpu().numpy()
+    bp = np.array(p25gen.block_positions())
+    for c in range(B):
+        r4, _ = orc.unpack_records10(rech[c, :cnth[c]])
+        for k in range(len(want[c]["nid"])):
+            w = r4[int(pos[c, k]) - 23 + bp]
+            assert np.array_equal(dibh[c, k], w[:, 0]) and np.array_equal(drlh[c, k], w[:, 1]), (c, k)
     nid, out, met = nid.cpu().numpy().reshape(B, F, 4), out.cpu().numpy().reshape(B, F, 12), met.cpu().numpy().reshape(B, F)
     v_blk = v_blk.cpu().numpy().reshape(B, F)
     for c in range(B):
