@@ -132,6 +132,9 @@ PROTOTYPES = {
     "ddn_p25p1_layout_hdu": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25p1_framer_gather_hdu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
     "ddn_p25p1_framer_pack_hdu_rs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_layout_tdulc": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_framer_gather_tdulc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
+    "ddn_p25p1_framer_pack_tdulc_rs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p1_framer_imbe_index": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_iq_capture_read_info": (C.c_int, [C.c_char_p, C.c_void_p]),
     "ddn_iq_capture_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

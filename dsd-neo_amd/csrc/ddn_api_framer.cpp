@@ -20,7 +20,7 @@
         }                                                                                                              \
     } while (0)
 
-enum { T_NID = 0, T_BLK0, T_BLK1, T_BLK2, T_LDU1, T_LDU2, T_HDU_HEX, T_HDU_PAR, T_COUNT };
+enum { T_NID = 0, T_BLK0, T_BLK1, T_BLK2, T_LDU1, T_LDU2, T_HDU_HEX, T_HDU_PAR, T_TDULC_DATA, T_TDULC_PAR, T_COUNT };
 
 struct ddn_p25p1_framer {
     int n_channels, max_frames;
@@ -62,6 +62,8 @@ ddn_p25p1_framer_create(int n_channels, int max_frames_per_channel, ddn_p25p1_fr
     f->n_off[T_HDU_HEX] = 108;
     f->n_off[T_HDU_PAR] = 216;
     ddn_p25p1_layout_hdu(tab[T_HDU_HEX], tab[T_HDU_PAR]);
+    f->n_off[T_TDULC_DATA] = f->n_off[T_TDULC_PAR] = 72;
+    ddn_p25p1_layout_tdulc(tab[T_TDULC_DATA], tab[T_TDULC_PAR]);
     int32_t first9[9], status9[9];
     ddn_p25p1_layout_ldu_imbe(first9, status9);
     const size_t slots = (size_t)n_channels * (size_t)max_frames_per_channel;
@@ -243,5 +245,34 @@ ddn_p25p1_framer_pack_hdu_rs(ddn_p25p1_framer* f, const uint8_t* d_hex_bits216, 
     }
     HIP_TRY(ddn_dev_rs_pack(d_hex_bits216, (long)f->n_channels * f->max_frames, 36, 6, 20, d_data_bits, d_parity_bits,
                             (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p1_framer_gather_tdulc(ddn_p25p1_framer* f, const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols,
+                              uint8_t* d_data_bits144, uint8_t* d_parity_bits144, int16_t* d_data_llr144,
+                              int16_t* d_parity_llr144, uint8_t* d_valid, void* hip_stream) {
+    if (!d_data_bits144 || !d_parity_bits144) {
+        ddn_set_error("ddn_p25p1_framer_gather_tdulc: null argument");
+        return DDN_EINVAL;
+    }
+    int rc = gather(f, T_TDULC_DATA, d_records10, d_counts, max_symbols, d_data_bits144, nullptr, d_data_llr144, 144, 0,
+                    nullptr, nullptr, nullptr, hip_stream);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return gather(f, T_TDULC_PAR, d_records10, d_counts, max_symbols, d_parity_bits144, nullptr, d_parity_llr144, 144, 0,
+                  nullptr, nullptr, d_valid, hip_stream);
+}
+
+extern "C" int
+ddn_p25p1_framer_pack_tdulc_rs(ddn_p25p1_framer* f, const uint8_t* d_data_bits144, uint8_t* d_rs_data_bits,
+                               uint8_t* d_rs_parity_bits, void* hip_stream) {
+    if (!f || !d_data_bits144 || !d_rs_data_bits || !d_rs_parity_bits) {
+        ddn_set_error("ddn_p25p1_framer_pack_tdulc_rs: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_tdulc_rs_pack(d_data_bits144, (long)f->n_channels * f->max_frames, d_rs_data_bits, d_rs_parity_bits,
+                                  (hipStream_t)hip_stream));
     return DDN_OK;
 }

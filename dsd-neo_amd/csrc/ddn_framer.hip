@@ -193,6 +193,38 @@ ddn_dev_rs_pack(const uint8_t* words, long n_slots, int n_words, int wstride, in
     return hipGetLastError();
 }
 
+namespace {
+// TDULC: Golay-corrected dodeca words [slots][12][12] (dodeca_data[0..5], dodeca_parity[0..5]) -> RS(24,12,13) input with
+// the two hex halves of every dodeca word swapped (swap_hex_words, p25p1_tdulc.c:47-72,210-213): hex 2i = bits 6..11,
+// hex 2i + 1 = bits 0..5 of word i
+__global__ void
+k_tdulc_rs_pack(const uint8_t* __restrict__ words, long n_slots, uint8_t* __restrict__ data, uint8_t* __restrict__ parity) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_slots * 144) {
+        return;
+    }
+    const long slot = t / 144;
+    const int r = (int)(t % 144), hexw = r / 6, b = r % 6; // hexw 0..11 data, 12..23 parity
+    const int dodeca = hexw / 2, half = hexw & 1;
+    const uint8_t v = words[(slot * 12 + dodeca) * 12 + (half ? b : 6 + b)];
+    if (hexw < 12) {
+        data[slot * 72 + hexw * 6 + b] = v;
+    } else {
+        parity[slot * 72 + (hexw - 12) * 6 + b] = v;
+    }
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_tdulc_rs_pack(const uint8_t* words, long n_slots, uint8_t* data, uint8_t* parity, hipStream_t st) {
+    if (n_slots <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_tdulc_rs_pack, dim3((unsigned)((n_slots * 144 + 255) / 256)), dim3(256), 0, st, words, n_slots,
+                       data, parity);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t
 ddn_dev_imbe_index(const int32_t* sync_pos, const int32_t* n_syncs, int n_channels, int max_frames, size_t max_sym,
                    const int32_t* first9, const int32_t* status9, int64_t* first, int32_t* status, hipStream_t st) {

@@ -123,3 +123,19 @@ ddn_p25p1_layout_hdu(int32_t hex3[36 * 3], int32_t par6[36 * 6]) {
     }
     return w.idx;
 }
+
+/* TDULC (p25p1_tdulc.c:199-207,297): twelve Golay(24,12) words of 6 data + 6 parity dibits, sent dodeca_data[5..0] then
+ * dodeca_parity[5..0]; data6 / par6 = [12][6] dibits in the order dodeca_data[0..5], dodeca_parity[0..5]. */
+int
+ddn_p25p1_layout_tdulc(int32_t data6[72], int32_t par6[72]) {
+    if (!data6 || !par6) {
+        return -1;
+    }
+    walker w = {57};
+    for (int seq = 0; seq < 12; seq++) {
+        const int word = seq < 6 ? 5 - seq : 6 + (5 - (seq - 6));
+        take(&w, 6, data6 + 6 * word);
+        take(&w, 6, par6 + 6 * word);
+    }
+    return w.idx;
+}

@@ -328,6 +328,16 @@ int ddn_p25p1_framer_gather_hdu(ddn_p25p1_framer* f, const uint8_t* d_records10,
                                 int16_t* d_hex_llr216, int16_t* d_parity_llr432, uint8_t* d_valid, void* hip_stream);
 int ddn_p25p1_framer_pack_hdu_rs(ddn_p25p1_framer* f, const uint8_t* d_hex_bits216, uint8_t* d_data_bits,
                                  uint8_t* d_parity_bits, void* hip_stream);
+/* TDULC (p25p1_tdulc.c:199-224,297): twelve Golay(24,12) words.  gather_tdulc -> data bits [slots][12][12] and parity
+ * bits [slots][12][12] (ddn_fec_golay24_batch with data_len 12, n = slots * 12), word order dodeca_data[0..5],
+ * dodeca_parity[0..5]; pack_tdulc_rs swaps the hex halves of every word like swap_hex_words() and yields the
+ * RS(24,12,13) input data [slots][12][6], parity [slots][12][6]. */
+int ddn_p25p1_layout_tdulc(int32_t data6[72], int32_t par6[72]);
+int ddn_p25p1_framer_gather_tdulc(ddn_p25p1_framer* f, const uint8_t* d_records10, const int32_t* d_counts,
+                                  size_t max_symbols, uint8_t* d_data_bits144, uint8_t* d_parity_bits144,
+                                  int16_t* d_data_llr144, int16_t* d_parity_llr144, uint8_t* d_valid, void* hip_stream);
+int ddn_p25p1_framer_pack_tdulc_rs(ddn_p25p1_framer* f, const uint8_t* d_data_bits144, uint8_t* d_rs_data_bits,
+                                   uint8_t* d_rs_parity_bits, void* hip_stream);
 int ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_first_record,
                                 int32_t* d_status_count, void* hip_stream);
 

@@ -338,3 +338,103 @@ def test_device_chain_hdu(built):
             assert len(hits) == 1, (c, k)
             good += 1
         assert good >= NF - 3, (c, good)
+
+
+def _tdulc_python_walk():
+    """p25p1_tdulc.c:199-207: dodeca_data[5..0] then dodeca_parity[5..0], each 6 data + 6 Golay-parity dibits."""
+    idx = 57
+    d, p = [None] * 12, [None] * 12
+
+    def take(n):
+        nonlocal idx
+        out = []
+        while len(out) < n:
+            if idx % 36 != 35:
+                out.append(idx)
+            idx += 1
+        return out
+    for seq in range(12):
+        word = 5 - seq if seq < 6 else 6 + (5 - (seq - 6))
+        d[word] = take(6)
+        p[word] = take(6)
+    return np.array(d), np.array(p), idx
+
+
+def test_tdulc_layout_matches_python_walk(built):
+    a, b = np.zeros(72, np.int32), np.zeros(72, np.int32)
+    end = ddn.lib().ddn_p25p1_layout_tdulc(a.ctypes.data, b.ctypes.data)
+    d, p, idx = _tdulc_python_walk()
+    assert end == idx and np.array_equal(a.reshape(12, 6), d) and np.array_equal(b.reshape(12, 6), p)
+
+
+@pytest.mark.gpu
+def test_device_chain_tdulc(built):
+    """Synthetic terminator-with-link-control units: 12 hex words -> RS(24,12,13) -> pairs of hex words, halves swapped,
+    as Golay(24,12) codewords -> C4FM; device chain: gathers, Golay, half swap + RS must return the 12 words sent."""
+    import torch
+    import fecgen
+    l = ddn.lib()
+    rng = np.random.default_rng(77)
+    B, FR, NF = 3, 216, 12
+    N = 10 * FR * NF + 600
+    dpos, ppos, _ = _tdulc_python_walk()
+    nac = 0x1B7
+    data16 = [(nac >> (11 - k)) & 1 for k in range(12)] + [1, 1, 1, 1]              # DUID 15 = TDULC
+    cw = list(fecgen.bch_63_16_encode(data16)) + [0]
+    nid = [(cw[2 * k] << 1) | cw[2 * k + 1] for k in range(32)]
+    sent = np.zeros((B, NF, 12), np.int64)
+    iq = np.zeros((B, N, 2), np.uint8)
+    for c in range(B):
+        frames = np.zeros((NF, FR), np.int8)
+        for f in range(NF):
+            d = rng.integers(0, 64, 12)
+            sent[c, f] = d
+            hexw = np.concatenate([d, fecgen.rs63_encode(d, 6)])                     # hex data 0..11, hex parity 0..11
+            fr = np.full(FR, 2, np.int8)
+            fr[:24] = orc.P25_FS_DIBITS
+            fr[[q for q in range(24, 57) if q != 35]] = nid
+            for w in range(12):                                                      # dodeca word w = hex (2w+1, 2w)
+                hi, lo = int(hexw[2 * w + 1]), int(hexw[2 * w])
+                b12 = np.array([(hi >> (5 - k)) & 1 for k in range(6)] + [(lo >> (5 - k)) & 1 for k in range(6)], np.uint8)
+                par = np.array(fecgen.golay24_encode(b12), np.uint8)
+                fr[dpos[w]] = (b12[0::2] << 1) | b12[1::2]
+                fr[ppos[w]] = (par[0::2] << 1) | par[1::2]
+            frames[f] = fr
+        iq[c] = p25gen.modulate_cu8(frames.reshape(-1), N, lead=190 + 31 * c, seed=70 + c)
+    disc = ddn.Batch(B, block_len=8192).run_host(iq, N)
+    rx = ddn.P25Rx(B, lock_symbols=FR - 24, use_matched_filter=1)
+    ms = l.ddn_p25_rx_max_symbols(rx.h, N)
+    d_disc = _dev(disc)
+    rec = torch.zeros((B, ms, 10), dtype=torch.uint8, device="cuda")
+    fl = torch.zeros((B, ms), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    assert l.ddn_p25_rx_run(rx.h, d_disc.data_ptr(), N, rec.data_ptr(), fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    F = NF + 3
+    S = B * F
+    fr_ = Framer(B, F)
+    assert l.ddn_p25p1_framer_index(fr_.h, fl.data_ptr(), cnt.data_ptr(), ms, None) == 0
+    db = torch.zeros((S, 12, 12), dtype=torch.uint8, device="cuda")
+    pb = torch.zeros((S, 12, 12), dtype=torch.uint8, device="cuda")
+    vv = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p1_framer_gather_tdulc(fr_.h, rec.data_ptr(), cnt.data_ptr(), ms, db.data_ptr(), pb.data_ptr(), None,
+                                           None, vv.data_ptr(), None) == 0
+    gst = torch.zeros(S * 12, dtype=torch.uint8, device="cuda")
+    gfx = torch.zeros(S * 12, dtype=torch.int32, device="cuda")
+    assert l.ddn_fec_golay24_batch(12, db.data_ptr(), pb.data_ptr(), S * 12, gst.data_ptr(), gfx.data_ptr(), None) == 0
+    rd = torch.zeros((S, 12, 6), dtype=torch.uint8, device="cuda")
+    rp = torch.zeros((S, 12, 6), dtype=torch.uint8, device="cuda")
+    rst = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p1_framer_pack_tdulc_rs(fr_.h, db.data_ptr(), rd.data_ptr(), rp.data_ptr(), None) == 0
+    assert l.ddn_fec_p25_rs_batch(0, rd.data_ptr(), rp.data_ptr(), S, rst.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    vvh, rdh, rsh = vv.cpu().numpy().reshape(B, F), rd.cpu().numpy().reshape(B, F, 12, 6), rst.cpu().numpy().reshape(B, F)
+    for c in range(B):
+        good = 0
+        for k in range(2, F):
+            if not vvh[c, k]:
+                continue
+            assert rsh[c, k] == 0, (c, k)
+            got = (rdh[c, k] * (1 << np.arange(5, -1, -1))).sum(axis=1)
+            assert len([f for f in range(NF) if np.array_equal(sent[c, f], got)]) == 1, (c, k)
+            good += 1
+        assert good >= NF - 3, (c, good)
