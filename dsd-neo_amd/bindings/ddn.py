@@ -135,6 +135,12 @@ PROTOTYPES = {
     "ddn_p25p1_layout_tdulc": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25p1_framer_gather_tdulc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
     "ddn_p25p1_framer_pack_tdulc_rs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_layout_ldu_lsd": (C.c_int, [C.c_void_p]),
+    "ddn_p25p1_framer_gather_lsd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 4),
+    "ddn_fec_p25_lsd_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_lsd_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "p25_lsd_fec_16x8": (C.c_int, [C.c_void_p]),
+    "p25_lsd_fec_16x8_soft": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25p1_framer_imbe_index": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_iq_capture_read_info": (C.c_int, [C.c_char_p, C.c_void_p]),
     "ddn_iq_capture_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

@@ -886,3 +886,50 @@ ddn_p25p1_imbe_deinterleave_host(const uint8_t* records10, size_t n_records, con
     }
     return (o.down(imbe_fr) || so.down(imbe_soft) || fl.down(flags) || co.down(status_count_out)) ? no_dev() : DDN_OK;
 }
+
+
+// ---- P25p1 low speed data (16,8) -----------------------------------------------------------------------------------------
+extern "C" int
+ddn_fec_p25_lsd_batch(uint8_t* d_bits16, const int16_t* d_llr16, size_t n, uint8_t* d_ok, void* hip_stream) {
+    if (!d_bits16 || !d_ok) {
+        ddn_set_error("ddn_fec_p25_lsd_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_p25_lsd(d_bits16, d_llr16, (int)n, d_ok, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_p25_lsd_host(uint8_t* bits16, const int16_t* llr16, size_t n, uint8_t* ok) {
+    if (!bits16 || !ok) {
+        return DDN_EINVAL;
+    }
+    Dev b(n * 16), l(n * 32), o(n);
+    if (!b.p || !l.p || !o.p || b.up(bits16) || (llr16 && l.up(llr16))) {
+        return no_dev();
+    }
+    int rc = ddn_fec_p25_lsd_batch((uint8_t*)b.p, llr16 ? (const int16_t*)l.p : nullptr, n, (uint8_t*)o.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (b.down(bits16) || o.down(ok)) ? no_dev() : DDN_OK;
+}
+
+// reference names (include/dsd-neo/protocol/p25/p25_lsd.h): 1 = valid or corrected, 0 = uncorrectable (also on failure)
+extern "C" int
+p25_lsd_fec_16x8(uint8_t* bits16) {
+    uint8_t ok = 0;
+    if (!bits16 || ddn_fec_p25_lsd_host(bits16, nullptr, 1, &ok) != DDN_OK) {
+        return 0;
+    }
+    return ok;
+}
+
+extern "C" int
+p25_lsd_fec_16x8_soft(uint8_t* bits16, const int16_t llr16[16]) {
+    uint8_t ok = 0;
+    if (!bits16 || ddn_fec_p25_lsd_host(bits16, llr16, 1, &ok) != DDN_OK) {
+        return 0;
+    }
+    return ok;
+}

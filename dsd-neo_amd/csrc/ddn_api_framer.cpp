@@ -20,7 +20,7 @@
         }                                                                                                              \
     } while (0)
 
-enum { T_NID = 0, T_BLK0, T_BLK1, T_BLK2, T_LDU1, T_LDU2, T_HDU_HEX, T_HDU_PAR, T_TDULC_DATA, T_TDULC_PAR, T_COUNT };
+enum { T_NID = 0, T_BLK0, T_BLK1, T_BLK2, T_LDU1, T_LDU2, T_HDU_HEX, T_HDU_PAR, T_TDULC_DATA, T_TDULC_PAR, T_LSD, T_COUNT };
 
 struct ddn_p25p1_framer {
     int n_channels, max_frames;
@@ -64,6 +64,8 @@ ddn_p25p1_framer_create(int n_channels, int max_frames_per_channel, ddn_p25p1_fr
     ddn_p25p1_layout_hdu(tab[T_HDU_HEX], tab[T_HDU_PAR]);
     f->n_off[T_TDULC_DATA] = f->n_off[T_TDULC_PAR] = 72;
     ddn_p25p1_layout_tdulc(tab[T_TDULC_DATA], tab[T_TDULC_PAR]);
+    f->n_off[T_LSD] = 16;
+    ddn_p25p1_layout_ldu_lsd(tab[T_LSD]);
     int32_t first9[9], status9[9];
     ddn_p25p1_layout_ldu_imbe(first9, status9);
     const size_t slots = (size_t)n_channels * (size_t)max_frames_per_channel;
@@ -275,4 +277,15 @@ ddn_p25p1_framer_pack_tdulc_rs(ddn_p25p1_framer* f, const uint8_t* d_data_bits14
     HIP_TRY(ddn_dev_tdulc_rs_pack(d_data_bits144, (long)f->n_channels * f->max_frames, d_rs_data_bits, d_rs_parity_bits,
                                   (hipStream_t)hip_stream));
     return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p1_framer_gather_lsd(ddn_p25p1_framer* f, const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols,
+                            uint8_t* d_bits32, int16_t* d_llr32, uint8_t* d_valid, void* hip_stream) {
+    if (!d_bits32) {
+        ddn_set_error("ddn_p25p1_framer_gather_lsd: null argument");
+        return DDN_EINVAL;
+    }
+    return gather(f, T_LSD, d_records10, d_counts, max_symbols, d_bits32, nullptr, d_llr32, 32, 0, nullptr, nullptr, d_valid,
+                  hip_stream);
 }

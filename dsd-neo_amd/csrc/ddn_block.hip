@@ -572,3 +572,111 @@ ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st) {
     hipLaunchKernelGGL(k_hamming_10_6_3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits10, n, errs);
     return hipGetLastError();
 }
+
+// ---- P25p1 low speed data: (16,8) cyclic code, hard + soft (src/protocol/p25/p25_lsd.c:31-160) -----------------------------
+// g(x) = x^8 + x^5 + x^4 + x^3 + 1, parity = (data * x^8) mod g.  One thread per codeword; the soft search (every subset of
+// the <= 6 least reliable weak bits, cheapest that decodes) is at most 63 syndrome evaluations on 16-bit words.
+namespace {
+__device__ __forceinline__ int
+lsd_parity_of(int data) {
+    int v = data << 8;
+#pragma unroll
+    for (int i = 15; i >= 8; i--) {
+        if (v & (1 << i)) {
+            v ^= 0x139 << (i - 8);
+        }
+    }
+    return v & 0xFF;
+}
+
+// word = data byte << 8 | parity byte; returns the corrected word or -1
+__device__ __forceinline__ int
+lsd_hard(int word) {
+    const int data = (word >> 8) & 0xFF, parity = word & 0xFF;
+    const int synd = parity ^ lsd_parity_of(data);
+    if (synd == 0) {
+        return word;
+    }
+    if ((synd & (synd - 1)) == 0) {
+        return word ^ synd; // single parity-bit error
+    }
+#pragma unroll
+    for (int pos = 0; pos < 8; pos++) {
+        if (lsd_parity_of(1 << (7 - pos)) == synd) {
+            return word ^ (1 << (15 - pos));
+        }
+    }
+    return -1;
+}
+
+__global__ void
+k_p25_lsd(uint8_t* __restrict__ bits16, const int16_t* __restrict__ llr16, int n, uint8_t* __restrict__ ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    uint8_t* b = bits16 + (size_t)i * 16;
+    int word = 0;
+    for (int k = 0; k < 16; k++) {
+        word = (word << 1) | (b[k] & 1);
+    }
+    int fixed = lsd_hard(word);
+    if (fixed < 0 && llr16) {
+        const int16_t* l = llr16 + (size_t)i * 16;
+        // the <= 6 least reliable bits with |llr| < 64, ordered by (|llr|, position): selection by repeated minimum
+        int cand[6], rel[6], nc = 0;
+        unsigned taken = 0;
+        for (int c = 0; c < 6; c++) {
+            int bi = -1, br = 1 << 30;
+            for (int k = 0; k < 16; k++) {
+                const int r = l[k] < 0 ? -(int)l[k] : (int)l[k];
+                if (r < 64 && !(taken & (1u << k)) && r < br) {
+                    br = r;
+                    bi = k;
+                }
+            }
+            if (bi < 0) {
+                break;
+            }
+            taken |= 1u << bi;
+            cand[nc] = bi;
+            rel[nc] = br;
+            nc++;
+        }
+        int best = -1, best_pen = 999999;
+        for (int mask = 1; mask < (1 << nc); mask++) {
+            int w = word, pen = 0;
+            for (int c = 0; c < nc; c++) {
+                if (mask & (1 << c)) {
+                    w ^= 1 << (15 - cand[c]);
+                    pen += rel[c];
+                }
+            }
+            if (pen >= best_pen) {
+                continue;
+            }
+            const int f = lsd_hard(w);
+            if (f >= 0) {
+                best = f;
+                best_pen = pen;
+            }
+        }
+        fixed = best;
+    }
+    if (fixed >= 0) {
+        for (int k = 0; k < 16; k++) {
+            b[k] = (uint8_t)((fixed >> (15 - k)) & 1);
+        }
+    }
+    ok[i] = fixed >= 0 ? 1 : 0;
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_p25_lsd(uint8_t* bits16, const int16_t* llr16, int n, uint8_t* ok, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p25_lsd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits16, llr16, n, ok);
+    return hipGetLastError();
+}

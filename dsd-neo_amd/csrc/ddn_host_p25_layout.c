@@ -139,3 +139,12 @@ ddn_p25p1_layout_tdulc(int32_t data6[72], int32_t par6[72]) {
     }
     return w.idx;
 }
+
+/* the 16 LSD dibits of an LDU (p25p1_ldu1.c:145-183): two (16,8) codewords, each 4 data dibits then 4 parity dibits */
+int
+ddn_p25p1_layout_ldu_lsd(int32_t out16[16]) {
+    if (!out16) {
+        return -1;
+    }
+    return ldu_walk(1, 0, 0, 0, out16);
+}

@@ -21,6 +21,7 @@ int ddn_p25p1_layout_ldu_words(int ldu, int32_t out120[120]);
 int ddn_p25p1_layout_ldu_imbe(int32_t first9[9], int32_t status9[9]);
 int ddn_p25p1_layout_hdu(int32_t hex3[36 * 3], int32_t par6[36 * 6]);
 int ddn_p25p1_layout_tdulc(int32_t data6[72], int32_t par6[72]);
+int ddn_p25p1_layout_ldu_lsd(int32_t out16[16]);
 void ddn_set_error(const char* fmt, ...);
 #ifdef __cplusplus
 }

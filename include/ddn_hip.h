@@ -338,6 +338,12 @@ int ddn_p25p1_framer_gather_tdulc(ddn_p25p1_framer* f, const uint8_t* d_records1
                                   int16_t* d_data_llr144, int16_t* d_parity_llr144, uint8_t* d_valid, void* hip_stream);
 int ddn_p25p1_framer_pack_tdulc_rs(ddn_p25p1_framer* f, const uint8_t* d_data_bits144, uint8_t* d_rs_data_bits,
                                    uint8_t* d_rs_parity_bits, void* hip_stream);
+/* LDU low speed data (p25p1_ldu1.c:145-183,318-323): 16 dibits = two (16,8) cyclic codewords -> bits [slots][2][16]
+ * (+ int16 LLR per bit), the input of ddn_fec_p25_lsd_batch with n = slots * 2 */
+int ddn_p25p1_layout_ldu_lsd(int32_t out16[16]);
+int ddn_p25p1_framer_gather_lsd(ddn_p25p1_framer* f, const uint8_t* d_records10, const int32_t* d_counts,
+                                size_t max_symbols, uint8_t* d_bits32, int16_t* d_llr32, uint8_t* d_valid,
+                                void* hip_stream);
 int ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_first_record,
                                 int32_t* d_status_count, void* hip_stream);
 
@@ -503,6 +509,14 @@ int ddn_p25p1_imbe_deinterleave_batch(const uint8_t* d_records10, size_t n_recor
 int ddn_p25p1_imbe_deinterleave_host(const uint8_t* records10, size_t n_records, const int64_t* first_record,
                                      const int32_t* status_count, size_t n_frames, uint8_t* imbe_fr, uint8_t* imbe_soft,
                                      uint8_t* flags, int32_t* status_count_out);
+/* == p25_lsd_fec_16x8 / p25_lsd_fec_16x8_soft (include/dsd-neo/protocol/p25/p25_lsd.h; src/protocol/p25/p25_lsd.c:31-160):
+ * the (16,8) cyclic code of P25p1 low speed data, g(x) = x^8 + x^5 + x^4 + x^3 + 1.  bits16 [n][16] = 8 data bits then 8
+ * parity bits, MSB first, corrected in place; ok [n] = 1 valid / corrected, 0 uncorrectable.  With d_llr16 != NULL a
+ * failed hard decode is retried over every subset of the <= 6 least reliable bits whose |llr| < 64 (cheapest wins). */
+int ddn_fec_p25_lsd_batch(uint8_t* d_bits16, const int16_t* d_llr16, size_t n, uint8_t* d_ok, void* hip_stream);
+int ddn_fec_p25_lsd_host(uint8_t* bits16, const int16_t* llr16, size_t n, uint8_t* ok);
+int p25_lsd_fec_16x8(uint8_t* bits16);
+int p25_lsd_fec_16x8_soft(uint8_t* bits16, const int16_t llr16[16]);
 int ddn_fec_p25_rs_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, size_t n, uint8_t* d_status,
                          void* hip_stream);
 int ddn_fec_p25_rs_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, size_t n, uint8_t* status);

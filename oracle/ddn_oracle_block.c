@@ -6,6 +6,7 @@
  *   P25p1 NID decode: hard + NAC retry + Chase   src/protocol/p25/phase1/p25p1_check_nid.cpp:200-354
  *   Hamming(10,6,3)                          src/fec/hamming_10_6_3.cpp:20-105
  *   IMBE de-interleave of one LDU voice frame    src/protocol/p25/phase1/p25p1_ldu.c:27-48,89-120
+ *   low-speed-data cyclic (16,8) code, hard + soft  src/protocol/p25/p25_lsd.c:31-160
  *
  * The BCH decoder is a bounded-distance decoder: for a received word within 11 bits of a codeword every correct
  * Berlekamp-Massey formulation returns that codeword and the same error count; beyond that the connection
@@ -15,6 +16,7 @@
  */
 #include "ddn_oracle.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 static uint8_t gexp[128], glog[64];
@@ -385,4 +387,115 @@ orc_p25p1_imbe_deinterleave(const uint8_t* dibits, const int16_t* llr0, const in
         ns &= (fr[0][i] == ((i >= 15 && i <= 17) ? 1 : 0));
     }
     return ns;
+}
+
+
+/* ---- P25p1 low speed data: (16,8) cyclic code (src/protocol/p25/p25_lsd.c) --------------------------------------------
+ * Systematic cyclic code with g(x) = x^8 + x^5 + x^4 + x^3 + 1: parity byte = (data(x) * x^8) mod g(x) (this is what the
+ * reference's 256-entry lsd_parity table holds; tests pin all 256 values).  Decoder: zero syndrome, a one-hot syndrome
+ * (single parity-bit error) or the syndrome of a single data-bit error are accepted / corrected, anything else is
+ * uncorrectable.  bits16 = data bits MSB first, then parity bits MSB first.  Soft variant: hard decode first, then every
+ * non-empty subset of the <= 6 least reliable bits with |llr| below the erasure threshold (64; ties by position), the
+ * cheapest flip set (strictly smaller penalty wins, subsets in mask order) that hard-decodes is taken. */
+static int
+lsd_parity_of(int data) {
+    int v = data << 8;
+    for (int i = 15; i >= 8; i--) {
+        if (v & (1 << i)) {
+            v ^= 0x139 << (i - 8);
+        }
+    }
+    return v & 0xFF;
+}
+
+int
+orc_p25_lsd_parity(int data) {
+    return lsd_parity_of(data & 0xFF);
+}
+
+int
+orc_p25_lsd_fec_16x8(uint8_t* bits16) {
+    int data = 0, parity = 0;
+    for (int i = 0; i < 8; i++) {
+        data = (data << 1) | (bits16[i] & 1);
+        parity = (parity << 1) | (bits16[8 + i] & 1);
+    }
+    const int synd = parity ^ lsd_parity_of(data);
+    if (synd == 0) {
+        return 1;
+    }
+    if ((synd & (synd - 1)) == 0) {
+        int b = 7;
+        while (!(synd & (1 << b))) {
+            b--;
+        }
+        bits16[8 + (7 - b)] = (uint8_t)(1 - (bits16[8 + (7 - b)] & 1));
+        return 1;
+    }
+    for (int pos = 0; pos < 8; pos++) {
+        if (lsd_parity_of(1 << (7 - pos)) == synd) {
+            bits16[pos] = (uint8_t)(1 - (bits16[pos] & 1));
+            return 1;
+        }
+    }
+    return 0;
+}
+
+int
+orc_p25_lsd_fec_16x8_soft(uint8_t* bits16, const int16_t* llr16) {
+    if (orc_p25_lsd_fec_16x8(bits16)) {
+        return 1;
+    }
+    if (!llr16) {
+        return 0;
+    }
+    int cand[16], nc = 0;
+    for (int i = 0; i < 16; i++) {
+        const int r = llr16[i] < 0 ? -(int)llr16[i] : (int)llr16[i];
+        if (r < 64) {
+            cand[nc++] = i;
+        }
+    }
+    for (int i = 0; i < nc; i++) {
+        for (int j = i + 1; j < nc; j++) {
+            const int ri = abs((int)llr16[cand[i]]), rj = abs((int)llr16[cand[j]]);
+            if (rj < ri || (rj == ri && cand[j] < cand[i])) {
+                const int t = cand[i];
+                cand[i] = cand[j];
+                cand[j] = t;
+            }
+        }
+    }
+    if (nc > 6) {
+        nc = 6;
+    }
+    if (nc <= 0) {
+        return 0;
+    }
+    uint8_t best[16];
+    int best_pen = 999999, found = 0;
+    for (int mask = 1; mask < (1 << nc); mask++) {
+        uint8_t tmp[16];
+        memcpy(tmp, bits16, 16);
+        int pen = 0;
+        for (int b = 0; b < nc; b++) {
+            if (mask & (1 << b)) {
+                tmp[cand[b]] ^= 1u;
+                pen += abs((int)llr16[cand[b]]);
+            }
+        }
+        if (pen >= best_pen) {
+            continue;
+        }
+        if (orc_p25_lsd_fec_16x8(tmp)) {
+            memcpy(best, tmp, 16);
+            best_pen = pen;
+            found = 1;
+        }
+    }
+    if (!found) {
+        return 0;
+    }
+    memcpy(bits16, best, 16);
+    return 1;
 }
