@@ -137,6 +137,9 @@ PROTOTYPES = {
     "ddn_p25p1_framer_pack_tdulc_rs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p1_layout_ldu_lsd": (C.c_int, [C.c_void_p]),
     "ddn_p25p1_framer_gather_lsd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 4),
+    "ddn_fec_p25_crc16_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_crc16_host": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "crc16_lb_bridge": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_fec_p25_lsd_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_p25_lsd_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "p25_lsd_fec_16x8": (C.c_int, [C.c_void_p]),

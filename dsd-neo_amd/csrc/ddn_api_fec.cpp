@@ -933,3 +933,57 @@ p25_lsd_fec_16x8_soft(uint8_t* bits16, const int16_t llr16[16]) {
     }
     return ok;
 }
+
+
+// ---- CRC-CCITT16 of decoded trunking blocks ---------------------------------------------------------------------------------
+extern "C" int
+ddn_fec_p25_crc16_batch(const uint8_t* d_bytes, int item_bytes, size_t n, uint8_t* d_ok, void* hip_stream) {
+    if (!d_bytes || !d_ok || item_bytes < 3) {
+        ddn_set_error("ddn_fec_p25_crc16_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_p25_crc16(d_bytes, item_bytes, (int)n, d_ok, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_p25_crc16_host(const uint8_t* bytes, int item_bytes, size_t n, uint8_t* ok) {
+    if (!bytes || !ok || item_bytes < 3) {
+        return DDN_EINVAL;
+    }
+    Dev b(n * (size_t)item_bytes), o(n);
+    if (!b.p || !o.p || b.up(bytes)) {
+        return no_dev();
+    }
+    int rc = ddn_fec_p25_crc16_batch((const uint8_t*)b.p, item_bytes, n, (uint8_t*)o.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return o.down(ok) ? no_dev() : DDN_OK;
+}
+
+// reference name (include/dsd-neo/protocol/p25/p25_crc.h): payload = len + 16 ints holding one bit each; 0 good, 65535 bad
+// (the reference's helper returns (uint16_t)-1 through an int)
+extern "C" int
+crc16_lb_bridge(const int* payload, int len) {
+    if (!payload || len < 8 || (len & 7) || len + 16 > 190 * 1) {
+        return 65535;
+    }
+    uint8_t bytes[32];
+    const int nb = (len + 16) / 8;
+    if (nb > (int)sizeof(bytes)) {
+        return 65535;
+    }
+    for (int k = 0; k < nb; k++) {
+        unsigned v = 0;
+        for (int j = 0; j < 8; j++) {
+            v = (v << 1) | (unsigned)(payload[8 * k + j] & 1);
+        }
+        bytes[k] = (uint8_t)v;
+    }
+    uint8_t ok = 0;
+    if (ddn_fec_p25_crc16_host(bytes, nb, 1, &ok) != DDN_OK) {
+        return 65535;
+    }
+    return ok ? 0 : 65535;
+}

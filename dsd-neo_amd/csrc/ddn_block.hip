@@ -680,3 +680,37 @@ ddn_dev_p25_lsd(uint8_t* bits16, const int16_t* llr16, int n, uint8_t* ok, hipSt
     hipLaunchKernelGGL(k_p25_lsd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits16, llr16, n, ok);
     return hipGetLastError();
 }
+
+// ---- CRC-CCITT16 of decoded TSBK / LCCH blocks (src/protocol/p25/p25_crc.c:18-76) -------------------------------------------
+// polynomial 0x1021, zero start, MSB first, inverted; good when it equals the two bytes after the payload.  One thread per
+// block, a byte at a time through the 8-step bit recurrence (blocks are 12 bytes; there is nothing to tile).
+namespace {
+__global__ void
+k_p25_crc16(const uint8_t* __restrict__ bytes, int item_bytes, int n, uint8_t* __restrict__ ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint8_t* b = bytes + (size_t)i * item_bytes;
+    unsigned crc = 0;
+    for (int k = 0; k < item_bytes - 2; k++) {
+        const unsigned v = b[k];
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            const unsigned bit = (v >> j) & 1u;
+            crc = (((crc >> 15) & 1u) ^ bit) ? (((crc << 1) ^ 0x1021u) & 0xFFFFu) : ((crc << 1) & 0xFFFFu);
+        }
+    }
+    crc ^= 0xFFFFu;
+    ok[i] = crc == (((unsigned)b[item_bytes - 2] << 8) | b[item_bytes - 1]) ? 1 : 0;
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_p25_crc16(const uint8_t* bytes, int item_bytes, int n, uint8_t* ok, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p25_crc16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bytes, item_bytes, n, ok);
+    return hipGetLastError();
+}

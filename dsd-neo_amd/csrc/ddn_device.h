@@ -142,6 +142,7 @@ hipError_t ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8
 hipError_t ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, int n, uint8_t* status,
                         hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st);
+hipError_t ddn_dev_p25_crc16(const uint8_t* bytes, int item_bytes, int n, uint8_t* ok, hipStream_t st);
 hipError_t ddn_dev_p25_lsd(uint8_t* bits16, const int16_t* llr16, int n, uint8_t* ok, hipStream_t st);
 hipError_t ddn_dev_iq_cond_disc(const void* in, long n, size_t stride, int block_len, int n_channels,
                                 const DdnIqCondConfig* cfg, DdnFskState* fsk, DdnIqCondState* cond, float* out,

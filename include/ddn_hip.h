@@ -509,6 +509,13 @@ int ddn_p25p1_imbe_deinterleave_batch(const uint8_t* d_records10, size_t n_recor
 int ddn_p25p1_imbe_deinterleave_host(const uint8_t* records10, size_t n_records, const int64_t* first_record,
                                      const int32_t* status_count, size_t n_frames, uint8_t* imbe_fr, uint8_t* imbe_soft,
                                      uint8_t* flags, int32_t* status_count_out);
+/* == crc16_lb_bridge (include/dsd-neo/protocol/p25/p25_crc.h; src/protocol/p25/p25_crc.c:18-76): CRC-CCITT16 (0x1021, zero
+ * start, inverted) of decoded TSBK / LCCH blocks.  d_bytes [n][item_bytes] = payload then the two CRC bytes (12 for a
+ * TSBK out of ddn_fec_p25_12_soft_batch); ok [n] = 1 when the CRC matches.  The drop-in takes the reference's one-bit-per-
+ * int payload (byte-aligned lengths up to 240 bits) and returns 0 good / 65535 bad ((uint16_t)-1, as the reference). */
+int ddn_fec_p25_crc16_batch(const uint8_t* d_bytes, int item_bytes, size_t n, uint8_t* d_ok, void* hip_stream);
+int ddn_fec_p25_crc16_host(const uint8_t* bytes, int item_bytes, size_t n, uint8_t* ok);
+int crc16_lb_bridge(const int* payload, int len);
 /* == p25_lsd_fec_16x8 / p25_lsd_fec_16x8_soft (include/dsd-neo/protocol/p25/p25_lsd.h; src/protocol/p25/p25_lsd.c:31-160):
  * the (16,8) cyclic code of P25p1 low speed data, g(x) = x^8 + x^5 + x^4 + x^3 + 1.  bits16 [n][16] = 8 data bits then 8
  * parity bits, MSB first, corrected in place; ok [n] = 1 valid / corrected, 0 uncorrectable.  With d_llr16 != NULL a

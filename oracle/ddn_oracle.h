@@ -230,6 +230,7 @@ int orc_bch_63_16_decode(const uint8_t in63[63], uint8_t out16[16], int* err_cou
 void orc_p25p1_nid_decode(const uint8_t code[63], const uint8_t* rel63, int observed_nac, int parity, int parity_rel,
                           int threshold, int out4[4]);
 int orc_hamming_10_6_3(int word10, int* fixed6);
+int orc_p25_crc16_ok(const uint8_t* bytes, int payload_bytes); /* 0 good, 65535 bad */
 int orc_p25_lsd_parity(int data);
 int orc_p25_lsd_fec_16x8(uint8_t* bits16);                           /* 1 = valid / corrected, 0 = uncorrectable */
 int orc_p25_lsd_fec_16x8_soft(uint8_t* bits16, const int16_t* llr16);

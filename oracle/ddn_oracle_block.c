@@ -499,3 +499,20 @@ orc_p25_lsd_fec_16x8_soft(uint8_t* bits16, const int16_t* llr16) {
     memcpy(bits16, best, 16);
     return 1;
 }
+
+
+/* ---- CRC-CCITT16 of TSBK / LCCH blocks (src/protocol/p25/p25_crc.c:18-76): polynomial 0x1021, zero start, one bit per
+ * step MSB first, inverted at the end; the block is good when the 16 bits that follow the payload equal it.
+ * bytes = payload_bytes of payload followed by the two CRC bytes; returns 0 good / 65535 bad like crc16_lb_bridge
+ * (whose helper returns (uint16_t)-1). */
+int
+orc_p25_crc16_ok(const uint8_t* bytes, int payload_bytes) {
+    unsigned crc = 0;
+    for (int i = 0; i < payload_bytes * 8; i++) {
+        const unsigned bit = (bytes[i >> 3] >> (7 - (i & 7))) & 1u;
+        crc = (((crc >> 15) & 1u) ^ bit) ? (((crc << 1) ^ 0x1021u) & 0xFFFFu) : ((crc << 1) & 0xFFFFu);
+    }
+    crc ^= 0xFFFFu;
+    const unsigned rx = ((unsigned)bytes[payload_bytes] << 8) | bytes[payload_bytes + 1];
+    return crc == rx ? 0 : 65535;
+}

@@ -97,3 +97,49 @@ def test_lsd_layout(built):
     # the LSD sits between voice frames 8 and 9: after the last parity-word slot, skipping status positions
     d, p = p25gen.ldu1_positions()
     assert t[0] > p.max() + 72 and np.all(np.diff(t) >= 1) and not np.any(t % 36 == 35) and t[-1] < 864 - 72
+
+
+# ---- CRC-CCITT16 of trunking blocks (src/protocol/p25/p25_crc.c:18-76) ---------------------------------------------------------
+def _crc_cases(seed, n, nbytes=12):
+    rng = np.random.default_rng(seed)
+    b = rng.integers(0, 256, (n, nbytes), dtype=np.uint8)
+    o = orc.oracle()
+    o.orc_p25_crc16_ok.argtypes = [C.c_void_p, C.c_int]
+    for i in range(0, n, 2):                                  # make every other block valid: find its CRC by search-free algebra
+        crc = 0
+        for k in range(nbytes - 2):
+            for j in range(7, -1, -1):
+                bit = (int(b[i, k]) >> j) & 1
+                crc = ((crc << 1) ^ 0x1021) & 0xFFFF if ((crc >> 15) & 1) ^ bit else (crc << 1) & 0xFFFF
+        crc ^= 0xFFFF
+        b[i, nbytes - 2], b[i, nbytes - 1] = crc >> 8, crc & 0xFF
+    return b, o
+
+
+@needs_ref
+def test_crc16_oracle_vs_reference():
+    b, o = _crc_cases(1, 600)
+    r = orc.ref()
+    r.crc16_lb_bridge.argtypes = [C.c_void_p, C.c_int]
+    good = 0
+    for i in range(len(b)):
+        bits = np.unpackbits(b[i]).astype(np.int32)
+        want = r.crc16_lb_bridge(bits.ctypes.data, 80)
+        assert o.orc_p25_crc16_ok(np.ascontiguousarray(b[i]).ctypes.data, 10) == want
+        good += want == 0
+    assert good >= 300
+
+
+@pytest.mark.gpu
+def test_crc16_gpu_vs_oracle(built):
+    l = ddn.lib()
+    for nbytes in (12, 3, 30):
+        b, o = _crc_cases(2 + nbytes, 3000, nbytes)
+        ok = np.zeros(len(b), np.uint8)
+        assert l.ddn_fec_p25_crc16_host(b.ctypes.data, nbytes, len(b), ok.ctypes.data) == 0
+        want = np.array([o.orc_p25_crc16_ok(np.ascontiguousarray(b[i]).ctypes.data, nbytes - 2) == 0 for i in range(len(b))])
+        assert np.array_equal(ok.astype(bool), want) and 1400 < ok.sum() < 1600
+    b, _ = _crc_cases(9, 4, 12)
+    assert l.crc16_lb_bridge(np.unpackbits(b[0]).astype(np.int32).ctypes.data, 80) == 0
+    assert l.crc16_lb_bridge(np.unpackbits(b[1]).astype(np.int32).ctypes.data, 80) == 65535
+    assert l.crc16_lb_bridge(np.zeros(300, np.int32).ctypes.data, 224) == 65535   # beyond the reference's 190-bit buffer
