@@ -140,7 +140,7 @@ def p25_e2e_chain(torch, ddn, B, n):
     base = np.zeros((64, n, 2), np.uint8)
     nac = 0x293
     for c in range(64):
-        dib, _ = p25gen.make_frames(rng, n // (10 * p25gen.FRAME) + 1, nac)
+        dib, _ = p25gen.make_frames(rng, n // (10 * p25gen.FRAME) + 1, nac, crc=True)
         base[c] = p25gen.modulate_cu8(dib, n, lead=200 + 11 * c, seed=c)
     d_iq = torch.from_numpy(np.tile(base, (B // 64 + 1, 1, 1))[:B].copy()).cuda()
     d_disc = torch.zeros((B, n), dtype=torch.float32, device="cuda")
@@ -161,6 +161,7 @@ def p25_e2e_chain(torch, ddn, B, n):
     llr = torch.zeros((S, 196), dtype=torch.int16, device="cuda")
     out = u8(S, 12)
     met = torch.zeros(S, dtype=torch.int32, device="cuda")
+    crc_ok = u8(S)
     st = torch.cuda.current_stream().cuda_stream
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 
@@ -180,6 +181,7 @@ def p25_e2e_chain(torch, ddn, B, n):
         assert l.ddn_p25p1_framer_gather_trellis_block(fr, 0, rec.data_ptr(), cnt.data_ptr(), ms_, llr.data_ptr(), None,
                                                        valid.data_ptr(), st) == 0
         assert l.ddn_fec_p25_12_soft_batch(llr.data_ptr(), S, out.data_ptr(), met.data_ptr(), st) == 0
+        assert l.ddn_fec_p25_crc16_batch(out.data_ptr(), 12, S, crc_ok.data_ptr(), st) == 0
         ev[3].record()
         torch.cuda.synchronize()
         return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
@@ -190,13 +192,14 @@ def p25_e2e_chain(torch, ddn, B, n):
     nd = nid.cpu().numpy()[v]
     # the first two frames of a channel fall into the matched filter's turn-on transient (tests/test_e2e_p25.py)
     good = int(((nd[:, 0] == 1) & (nd[:, 1] == nac) & (nd[:, 2] == p25gen.DUID_TSBK)).sum())
+    crc_good = int(crc_ok.cpu().numpy().astype(bool)[v].sum())
     l.ddn_p25p1_framer_destroy(fr)
     total = sum(t)
-    return {"note": "informational; configs[2]: cu8 IQ -> front end -> rx loop -> framer -> NID BCH + 1/2-rate trellis, "
+    return {"note": "informational; configs[2]: cu8 IQ -> front end -> rx loop -> framer -> NID BCH + 1/2-rate trellis + CRC16, "
                     "all on the device, synthetic TSDU traffic",
             "front_end_ms": round(t[0], 3), "p25_rx_ms": round(t[1], 3), "framer_nid_trellis_ms": round(t[2], 3),
             "Msamples_per_s": round(B * n / (total * 1e-3) / 1e6, 1), "frames": int(v.sum()),
-            "frames_with_expected_nac_duid": good}
+            "frames_with_expected_nac_duid": good, "tsbk_crc_ok": crc_good}
 
 
 def main():

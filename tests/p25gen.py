@@ -29,11 +29,29 @@ def block_positions():
     return pos
 
 
-def make_frames(rng, n_frames, nac):
-    """-> (dibits int8 [n_frames*180], states [n_frames,49])."""
+def crc16_ccitt(bytes10):
+    """CRC the reference checks on TSBKs (src/protocol/p25/p25_crc.c:18-36): 0x1021, zero start, inverted."""
+    crc = 0
+    for v in bytes10:
+        for j in range(7, -1, -1):
+            bit = (int(v) >> j) & 1
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if ((crc >> 15) & 1) ^ bit else (crc << 1) & 0xFFFF
+    return crc ^ 0xFFFF
+
+
+def make_frames(rng, n_frames, nac, crc=False):
+    """-> (dibits int8 [n_frames*180], states [n_frames,49]).  With crc=True every block is a well-formed TSBK: ten random
+    bytes + their CRC16, two bits per trellis state, flushed with a zero state."""
     t = fecgen.tables()
     il = t["il"].astype(np.int64)
     st = rng.integers(0, 4, (n_frames, 49)).astype(np.int64)
+    if crc:
+        for f in range(n_frames):
+            pay = rng.integers(0, 256, 10)
+            c = crc16_ccitt(pay)
+            bits = np.unpackbits(np.array(list(pay) + [c >> 8, c & 0xFF], np.uint8)).astype(np.int64)
+            st[f, :48] = (bits[0::2] << 1) | bits[1::2]
+            st[f, 48] = 0
     prev = np.concatenate([np.zeros((n_frames, 1), np.int64), st[:, :-1]], axis=1)
     nib = t["half"][(prev << 2) | st].astype(np.int64)
     dei = np.stack([(nib >> 2) & 3, nib & 3], axis=2).reshape(n_frames, 98)   # deinterleaved dibits

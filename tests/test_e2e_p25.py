@@ -102,3 +102,18 @@ def test_e2e_gpu_chain_matches_oracle(built):
         assert ddn.lib().ddn_fec_p25_12_soft_host(llr.ctypes.data, n, out.ctypes.data, met.ctypes.data) == 0
         assert np.array_equal(nid, w["nid"]) and np.array_equal(out, w["blocks"]) and np.array_equal(met, w["met"]), c
         _check_decoded(c, acc, nid, out, states[c])
+
+
+def test_crc_valid_tsbk_generator(built):
+    """p25gen.make_frames(crc=True): the decoded block is ten payload bytes + their CRC16 (checked by the oracle's CRC)."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    _, st = p25gen.make_frames(rng, 6, 0x123, crc=True)
+    out = p25gen.expected_half_rate_output(st)
+    o = orc.oracle()
+    o.orc_p25_crc16_ok.argtypes = [C.c_void_p, C.c_int]
+    for b in out:
+        assert o.orc_p25_crc16_ok(np.ascontiguousarray(b).ctypes.data, 10) == 0
+    _, st2 = p25gen.make_frames(rng, 6, 0x123)
+    bad = [o.orc_p25_crc16_ok(np.ascontiguousarray(b).ctypes.data, 10) for b in p25gen.expected_half_rate_output(st2)]
+    assert any(v != 0 for v in bad)
