@@ -911,16 +911,28 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     const float* rp0 = row + base + sp;
                     float last = s.lastsample;
                     int jit = s.jitter;
+                    const bool anyclip = __any(genf && clip); // hunting lanes never clip: skip the selects for them
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
+                        // the search stops at the first crossing; once every lane has one, only the last sample matters
+                        if ((k & 3) == 0 && k > 0 && !__any(genf && k < cnt && jit < 0)) {
+                            break;
+                        }
                         float x = rp0[k];
-                        const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
-                        x = clip ? xc : x;
+                        if (anyclip) {
+                            const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
+                            x = clip ? xc : x;
+                        }
                         const bool in = genf && k < cnt;
                         const bool cross = (x > s.center) ? (!(x > hi_lim) && last < s.center)
                                                           : (!(x < lo_lim) && last > s.center);
                         jit = (in && jit < 0 && cross) ? s.i + k : jit;
                         last = in ? x : last;
+                    }
+                    if (genf) { // lastsample = the symbol's final sample, whether or not the loop ran that far
+                        float x = rp0[cnt - 1];
+                        const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        last = clip ? xc : x;
                     }
                     float acc = s.sum;
                     int cw = s.count;
