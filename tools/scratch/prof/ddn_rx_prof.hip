@@ -820,6 +820,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
     };
 
+    long long prof[10] = {0,0,0,0,0,0,0,0,0,0}; long long tlast = __builtin_readcyclecounter(); long long ntrip=0;
     const float* rrow = &L.raw[ln][0];
     const float* frow = &L.flt[ln][0];
     int sp = 0; // this lane's cursor relative to the current tile (negative: a deferred symbol begins in the previous one)
@@ -845,6 +846,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
             int guard = 0;
             while (true) {
+{ const long long t_=__builtin_readcyclecounter(); prof[0] += t_ - tlast; tlast = t_; }
+ntrip++;
                 // ---- symbol start ----------------------------------------------------------------------------------
                 if (live && sp < tn && !s.in_symbol) {
                     int sps = whole;
@@ -872,6 +875,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         s.jitter = -1;
                     }
                 }
+{ const long long t_=__builtin_readcyclecounter(); prof[1] += t_ - tlast; tlast = t_; }
                 // ---- whole-symbol evaluation -----------------------------------------------------------------------
                 const int cnt = s.span - s.i; // samples this symbol still consumes
                 const bool cold = s.filter_on && (abs0 + t0 + sp - s.filt_start) < (long long)(NT - 1);
@@ -882,6 +886,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const float* row = fo ? frow : rrow;
                 const bool latched = wholeok && fits && s.i == 0 && s.have_sync && s.jitter >= 0 && s.span >= 6
                                      && s.span != 20;
+{ const long long t_=__builtin_readcyclecounter(); prof[2] += t_ - tlast; tlast = t_; }
                 if (latched) {
                     // in frame with the crossing latched: nothing per-sample can change state, the symbol is the mean
                     // of the five clipped window samples (added in sample order)
@@ -904,6 +909,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 // Unlatched symbol of ordinary length (every hunting symbol): the crossing search needs each sample once,
                 // in order, and nothing else; the window mean is the five centre samples.  Straight-line code, one
                 // compare chain per sample instead of the general per-sample body.
+{ const long long t_=__builtin_readcyclecounter(); prof[3] += t_ - tlast; tlast = t_; }
                 const bool genf = wholeok && fits && !latched && cnt <= 12 && s.span != 20 && s.span != 5;
                 if (__any(genf)) {
                     const bool clip = s.have_sync != 0;
@@ -955,6 +961,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         s.i = s.span;
                     }
                 }
+{ const long long t_=__builtin_readcyclecounter(); prof[4] += t_ - tlast; tlast = t_; }
                 const bool gen = wholeok && fits && !latched && !genf;
                 if (__any(gen)) {
                     for (int k = 0; k < WMAX; k++) {
@@ -993,6 +1000,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         s.i = s.span;
                     }
                 }
+{ const long long t_=__builtin_readcyclecounter(); prof[5] += t_ - tlast; tlast = t_; }
                 // ---- sample-at-a-time path (filter cold start, long spans, last tile of the call) --------------------
                 bool act = live && s.in_symbol && sp < tn && s.i < s.span && !blocked;
                 while (__any(act)) {
@@ -1052,6 +1060,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     }
                     act = live && s.in_symbol && sp < tn && s.i < s.span && !blocked;
                 }
+{ const long long t_=__builtin_readcyclecounter(); prof[6] += t_ - tlast; tlast = t_; }
                 // ---- symbol commit ---------------------------------------------------------------------------------
                 const bool done = live && s.in_symbol && s.i >= s.span;
                 if (done) {
@@ -1205,6 +1214,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             }
                         }
                     }
+{ const long long t_=__builtin_readcyclecounter(); prof[7] += t_ - tlast; tlast = t_; }
                     if (offload && qk < QCW) {
                         L.q[it & 1][qk][0][ln] = sym;
                         L.q[it & 1][qk][1][ln] = q_max;
@@ -1225,6 +1235,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     }
                     o++;
                 }
+{ const long long t_=__builtin_readcyclecounter(); prof[8] += t_ - tlast; tlast = t_; }
                 const bool busy = live && sp < tn && !blocked;
                 if (!__any(busy) || ++guard > 4 * TS) {
                     break;
@@ -1241,6 +1252,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
         __syncthreads();
     }
+    if (!loader && blockIdx.x == 7 && lane == 0) { printf("PROF trips %lld  wait/other %lld start %lld whole %lld latched %lld genf %lld gen %lld slow %lld commit %lld queue %lld\n", ntrip, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6], prof[7], prof[8]); }
     if (loader && offload && it > 0) {
         drain((it - 1) & 1);
     }
