@@ -183,6 +183,13 @@ def main():
     ofe = orc.OracleFrontEnd().set_iq_options(1, 11, 1, 0.0, 0.0)
     report("front_end_iq_conditioned", B * nn, ms, 2 + 4, cpu(lambda: ofe.run_cu8(iq8[0], 8192), nn), "complex samples")
 
+    # BASELINE configs[3] mix: the same fused front end with the DMR (12.5 kHz) and NXDN48 (6.25 kHz) channel filters
+    for tag, prof in (("front_end_dmr_12k5", ddn.LPF_12K5), ("front_end_nxdn48_6k25", ddn.LPF_6K25)):
+        fb2 = ddn.Batch(B, lpf_profile=prof, block_len=8192)
+        ms = timeit(lambda: fb2.run_device(d_i.data_ptr(), nn, d_o.data_ptr(), st))
+        of2 = orc.OracleFrontEnd(profile=prof)
+        report(tag, B * nn, ms, 2 + 4, cpu(lambda: of2.run_cu8(iq8[0], 8192), nn), "complex samples")
+
     # IMBE de-interleave: 4096 channels x 9 voice frames out of an LDU's records
     nf = 4096 * 9
     recs = torch.from_numpy(rng.integers(0, 256, (4096 * 900, 10), dtype=np.uint8)).cuda()
