@@ -270,3 +270,23 @@ def test_capture_files_through_the_chain(built, tmp_path):
     out = decode_nids(nids_from_records(r4, fl[0], int(cnt[0])), oracle_nid)[1:]
     want_nac = int(bytes(golden("iq_p25p1_c4fm_cc.npz")["expected_nac_hex"]).decode(), 16)
     assert len(out) >= 24 and np.all(out[:, 0] == 1) and np.all(out[:, 1] == want_nac) and np.all(out[:, 2] == 7)
+
+
+@pytest.mark.gpu
+def test_decode_capture_tool_reports_the_reference_answers(built, tmp_path):
+    """tools/decode_capture.py on the reference's two C4FM captures (written out as dsd-neo-iq file pairs): its lines carry
+    the facts the reference's full-chain tests assert - "NAC/CC: 140" and "Group Voice Channel User" (tests/CMakeLists.txt
+    DECODE_IQ_P25P1_C4FM_CC / _VOICE)."""
+    import sys
+    sys.path.insert(0, os.path.join(ddn.ROOT, "tools"))
+    import decode_capture
+    tmp = str(tmp_path)
+    p_cc, _ = _write_golden_capture(tmp, "cc.iq", "iq_p25p1_c4fm_cc.npz")
+    p_vc, _ = _write_golden_capture(tmp, "vc.iq", "iq_p25p1_c4fm_vc.npz")
+    cc = decode_capture.decode(p_cc, lock=336, out=lambda s: None)      # three-block TSDUs, 360 symbols apart
+    good = [t for t in cc[1:] if "NAC 140  TSBK" in t and "crc ok" in t]
+    assert len(good) >= 20 and not any("CRC ERR" in t for t in cc[1:])
+    vc = decode_capture.decode(p_vc, lock=840, out=lambda s: None)
+    assert sum("Group Voice Channel User" in t and "LC ok" in t for t in vc) >= 4
+    assert sum("ESS ok: ALGID 80 KID 0000" in t for t in vc) >= 4
+    assert all("9 IMBE frames (0 flagged)" in t for t in vc if "LDU" in t and "LC ok" in t)
