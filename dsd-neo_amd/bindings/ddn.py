@@ -91,6 +91,7 @@ PROTOTYPES = {
     "ddn_p25_rx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ddn_p25_rx_destroy": (None, [C.c_void_p]),
     "ddn_p25_rx_reset": (C.c_int, [C.c_void_p]),
+    "ddn_p25_rx_set_lock_symbols": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_rx_set_channels_per_wave": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_p25_rx_max_symbols": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "ddn_p25_rx_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

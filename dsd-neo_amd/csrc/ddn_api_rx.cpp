@@ -29,6 +29,7 @@ struct ddn_p25_rx {
     float* d_filt; // always-on matched-filter output of the current call, [B][filt_cap]
     size_t filt_cap;
     int channels_per_wave;
+    int32_t* d_lock; // [B] in-frame symbols after a sync, per channel (cfg.lock_symbols unless overridden)
 };
 
 static void
@@ -41,6 +42,7 @@ rx_free(ddn_p25_rx* b) {
     (void)hipFree(b->d_maxring);
     (void)hipFree(b->d_fhist);
     (void)hipFree(b->d_filt);
+    (void)hipFree(b->d_lock);
 }
 
 static int
@@ -110,7 +112,9 @@ ddn_p25_rx_create(const ddn_p25_rx_config* cfg, ddn_p25_rx** out) {
         || hipMalloc(&b->d_shist, sizeof(float) * 24 * B) != hipSuccess
         || hipMalloc(&b->d_minring, sizeof(float) * 1024 * B) != hipSuccess
         || hipMalloc(&b->d_maxring, sizeof(float) * 1024 * B) != hipSuccess
-        || hipMalloc(&b->d_fhist, sizeof(float) * 90 * B) != hipSuccess || rx_fill(b) != DDN_OK) {
+        || hipMalloc(&b->d_fhist, sizeof(float) * 90 * B) != hipSuccess
+        || hipMalloc(&b->d_lock, sizeof(int32_t) * B) != hipSuccess || rx_fill(b) != DDN_OK
+        || ddn_p25_rx_set_lock_symbols(b, nullptr) != DDN_OK) {
         ddn_set_error("ddn_p25_rx_create: device allocation failed");
         rx_free(b);
         delete b;
@@ -136,6 +140,26 @@ ddn_p25_rx_reset(ddn_p25_rx* b) {
     }
     HIP_TRY(hipDeviceSynchronize());
     return rx_fill(b);
+}
+
+extern "C" int
+ddn_p25_rx_set_lock_symbols(ddn_p25_rx* b, const int32_t* per_channel) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    const size_t B = (size_t)b->cfg.n_channels;
+    std::vector<int32_t> v(B, b->cfg.lock_symbols);
+    if (per_channel) {
+        for (size_t c = 0; c < B; c++) {
+            if (per_channel[c] < 0) {
+                ddn_set_error("ddn_p25_rx_set_lock_symbols: channel %zu has a negative value", c);
+                return DDN_EINVAL;
+            }
+            v[c] = per_channel[c];
+        }
+    }
+    HIP_TRY(hipMemcpy(b->d_lock, v.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    return DDN_OK;
 }
 
 extern "C" int
@@ -189,7 +213,7 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
     }
     HIP_TRY(ddn_dev_p25_rx(d_disc, b->d_filt, b->d_fhist, (long)n, n, B, &dc, b->d_state, b->d_sbuf, b->d_lbuf,
                            b->d_shist, b->d_minring, b->d_maxring, d_records10, d_flags, d_counts, max_symbols,
-                           b->channels_per_wave, st));
+                           b->channels_per_wave, b->d_lock, st));
     // the filter memory (last 90 raw samples) moves on only after the loop has read the previous tail
     HIP_TRY(ddn_dev_p25_filter_hist_update(d_disc, (long)n, n, B, b->d_fhist, st));
     return DDN_OK;

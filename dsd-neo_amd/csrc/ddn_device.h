@@ -120,7 +120,8 @@ hipError_t ddn_dev_p25_filter_hist_update(const float* in, long n, size_t stride
 hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride,
                           int n_channels, const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store,
                           float* lbuf_store, float* shist_store, float* minring, float* maxring, uint8_t* rec,
-                          uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave, hipStream_t st);
+                          uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave,
+                          const int32_t* lock_cfg, hipStream_t st);
 hipError_t ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, int block_len, int n_channels,
                                    const float* taps_dev, int taps_len, void* hist, void* out, size_t out_stride,
                                    hipStream_t st);

@@ -66,7 +66,7 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
          size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
          float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
          float* __restrict__ maxring, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags, int32_t* __restrict__ counts,
-         size_t max_sym) {
+         size_t max_sym, const int32_t* __restrict__ lock_cfg) {
     extern __shared__ unsigned char smem_raw[];
     Lds<CPW>& L = *reinterpret_cast<Lds<CPW>*>(smem_raw);
     const int lane = threadIdx.x & 63;
@@ -483,7 +483,7 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                                     }
                                 }
                                 s.have_sync = 1;
-                                s.lock_left = cfg.lock_symbols;
+                                s.lock_left = lock_cfg[ch]; // in-frame symbols after a sync, per channel
                                 fl = 2 | (pol == 2 ? 4 : 0);
                                 if (s.lock_left <= 0) {
                                     s.have_sync = 0;
@@ -584,7 +584,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
           size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
           float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
           float* __restrict__ maxring, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags,
-          int32_t* __restrict__ counts, size_t max_sym) {
+          int32_t* __restrict__ counts, size_t max_sym, const int32_t* __restrict__ lock_cfg) {
     extern __shared__ unsigned char smem_raw[];
     LdsW<CPW>& L = *reinterpret_cast<LdsW<CPW>*>(smem_raw);
     const int lane = threadIdx.x & 63;
@@ -1191,7 +1191,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     }
                                 }
                                 s.have_sync = 1;
-                                s.lock_left = cfg.lock_symbols;
+                                s.lock_left = lock_cfg[ch]; // in-frame symbols after a sync, per channel
                                 fl = 2 | (pol == 2 ? 4 : 0);
                                 if (s.lock_left <= 0) {
                                     s.have_sync = 0;
@@ -1262,7 +1262,8 @@ template <int CPW>
 static hipError_t
 launch_rxw(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
            const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
-           float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, hipStream_t st) {
+           float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, const int32_t* lock_cfg,
+           hipStream_t st) {
     const size_t shm = sizeof(LdsW<CPW>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rxw<CPW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1271,7 +1272,7 @@ launch_rxw(const float* raw, const float* filt, const float* prev_tail, long n, 
     }
     hipLaunchKernelGGL(k_p25_rxw<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shm, st, raw, filt,
                        prev_tail, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
-                       maxring, rec, flags, counts, max_sym);
+                       maxring, rec, flags, counts, max_sym, lock_cfg);
     return hipGetLastError();
 }
 
@@ -1279,7 +1280,8 @@ template <int CPW>
 static hipError_t
 launch_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
           const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
-          float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, hipStream_t st) {
+          float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, const int32_t* lock_cfg,
+          hipStream_t st) {
     const size_t shm = sizeof(Lds<CPW>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rx<CPW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1288,7 +1290,7 @@ launch_rx(const float* raw, const float* filt, const float* prev_tail, long n, s
     }
     hipLaunchKernelGGL(k_p25_rx<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shm, st, raw, filt,
                        prev_tail, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
-                       maxring, rec, flags, counts, max_sym);
+                       maxring, rec, flags, counts, max_sym, lock_cfg);
     return hipGetLastError();
 }
 
@@ -1296,7 +1298,7 @@ extern "C" hipError_t
 ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
                const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
                float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym,
-               int channels_per_wave, hipStream_t st) {
+               int channels_per_wave, const int32_t* lock_cfg, hipStream_t st) {
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
@@ -1317,25 +1319,25 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long
     // footprint still fits (cfg.dbg bit 128 forces it for A/B timing)
     if (cpw == 8) {
         return launch_rxw<8>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                             shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+                             shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
     if (cpw == 16 && !(cfg->dbg & 128)) {
         return launch_rxw<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                              shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
     if (cpw == 32 && !(cfg->dbg & 128)) {
         return launch_rxw<32>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                              shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
     switch (cpw) {
         case 16:
             return launch_rx<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                                 shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+                                 shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
         case 32:
             return launch_rx<32>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                                 shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+                                 shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
         default:
             return launch_rx<64>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                                 shist_store, minring, maxring, rec, flags, counts, max_sym, st);
+                                 shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
 }

@@ -124,3 +124,29 @@ def test_rx_full_batch_properties(built):
         r4, sy = orc.unpack_records10(rec[B - base_ch + ch, :k].cpu().numpy())   # the last replica
         assert k == len(sym) and np.array_equal(sy.view(np.uint32), sym.view(np.uint32))
         assert np.array_equal(r4, rec4) and np.array_equal(fl[B - base_ch + ch, :k].cpu().numpy(), flo)
+
+
+def test_rx_per_channel_lock_symbols(built):
+    """One batch mixing traffic classes: every channel gets its own in-frame length (ddn_p25_rx_set_lock_symbols) and
+    must equal an oracle instance configured with that length."""
+    import ctypes as C
+    B, n = 20, 24000
+    frames = [180, 360, 432, 864]
+    xs = [orc.synth_p25_disc(40 + c, 1, n, frame_dibits=frames[c % 4])[0][0] for c in range(B)]
+    x = np.stack(xs)
+    locks = np.array([frames[c % 4] - 24 if c % 5 else 0 for c in range(B)], np.int32)     # some channels never lock
+    rx = ddn.P25Rx(B, lock_symbols=840, use_matched_filter=1)
+    assert ddn.lib().ddn_p25_rx_set_lock_symbols(rx.h, locks.ctypes.data) == 0
+    bad = locks.copy()
+    bad[3] = -1
+    assert ddn.lib().ddn_p25_rx_set_lock_symbols(rx.h, bad.ctypes.data) != 0
+    rec, fl, cnt = rx.run(x)
+    for c in range(B):
+        o = orc.OracleP25Rx(lock_symbols=int(locks[c]), use_filter=1)
+        sym, rec4, flo = o.run(x[c])
+        k = int(cnt[c])
+        r4, sy = orc.unpack_records10(rec[c, :k])
+        assert k == len(sym) and np.array_equal(sy.view(np.uint32), sym.view(np.uint32)), c
+        assert np.array_equal(r4, rec4) and np.array_equal(fl[c, :k], flo), c
+    # NULL restores the configured value everywhere
+    assert ddn.lib().ddn_p25_rx_set_lock_symbols(rx.h, None) == 0
