@@ -67,18 +67,24 @@ str(scan* k, char* out, size_t cap) {
     size_t o = 0;
     while (k->p < k->n && k->s[k->p] != '"') {
         unsigned char c = (unsigned char)k->s[k->p++];
+        if (c < 0x20) {
+            return -1; /* unescaped control character (the reference's tokenizer refuses it too) */
+        }
         if (c == '\\') {
             if (k->p >= k->n) {
                 return -1;
             }
             const char e = k->s[k->p++];
             switch (e) {
+                case '"': c = '"'; break;
+                case '\\': c = '\\'; break;
+                case '/': c = '/'; break;
                 case 'n': c = '\n'; break;
                 case 't': c = '\t'; break;
                 case 'r': c = '\r'; break;
                 case 'b': c = '\b'; break;
                 case 'f': c = '\f'; break;
-                case 'u': {
+                case 'u': { /* only 7-bit code points other than NUL are accepted, as in the reference */
                     if (k->p + 4 > k->n) {
                         return -1;
                     }
@@ -90,10 +96,13 @@ str(scan* k, char* out, size_t cap) {
                         }
                         v = v * 16 + (unsigned)(isdigit((unsigned char)h) ? h - '0' : (tolower(h) - 'a' + 10));
                     }
-                    c = v < 0x80 ? (unsigned char)v : '?';
+                    if (v == 0 || v > 0x7F) {
+                        return -1;
+                    }
+                    c = (unsigned char)v;
                     break;
                 }
-                default: c = (unsigned char)e; break; /* \" \\ \/ */
+                default: return -1; /* not a JSON escape */
             }
         }
         if (o + 1 >= cap) {

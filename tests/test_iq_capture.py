@@ -223,6 +223,48 @@ def test_synthetic_sidecars_match_reference(built, tmp_path):
     assert mine(q, 1)[0] == ref_meta(q, 1)[0] != 0
 
 
+@needs_ref
+def test_sidecar_differential_fuzz_vs_reference(built, tmp_path):
+    """900 randomly damaged sidecars (characters replaced / deleted / inserted, truncations): this reader and the
+    reference's return the same code for metadata-only and for replay opens, and the same fields when both accept."""
+    import random
+    tmp = str(tmp_path)
+    v2 = dict(BASE, version=2, contains_retunes=True, capture_retune_count=1, events=[
+        {"kind": "MUTE", "byte_offset": 100, "reason": "squelch", "duration_bytes": 64},
+        {"kind": "RETUNE", "byte_offset": 400, "reason": "t", "center_frequency_hz": 852000000,
+         "capture_center_frequency_hz": 852000000, "sample_rate_hz": 96000},
+        {"kind": "RESET", "byte_offset": 400, "reason": "t", "center_frequency_hz": 852000000,
+         "capture_center_frequency_hz": 852000000, "sample_rate_hz": 96000}])
+    np.zeros(2001, np.uint8).tofile(os.path.join(tmp, "cap.iq"))
+    q = os.path.join(tmp, "cap.iq.json")
+    rng = random.Random(11)
+    both_ok = 0
+    for i in range(900):
+        t = list(json.dumps(BASE if i % 3 else v2, indent=1))
+        for _ in range(rng.randint(1, 3)):
+            op, pos = rng.random(), rng.randrange(len(t))
+            if op < 0.35:
+                t[pos] = rng.choice('{}[],:"\\0123456789-.eEtfnu \n\t')
+            elif op < 0.6:
+                del t[pos]
+            elif op < 0.8:
+                t.insert(pos, rng.choice('{}[],:"\\0 9-'))
+            else:
+                t = t[:pos]
+            if not t:
+                t = ["{"]
+        with open(q, "w") as f:
+            f.write("".join(t))
+        for replay in (0, 1):
+            rc_r, out, stage, dp, err = ref_meta(q, replay)
+            rc_m, info = mine(q, replay)
+            assert rc_m == rc_r, (i, replay, rc_m, rc_r, err, "".join(t)[:200])
+            if rc_r == 0:
+                same_fields(info, out, stage, dp)
+                both_ok += 1
+    assert both_ok >= 40
+
+
 def _write_golden_capture(tmp, name, npz, rate=48000):
     g = golden(npz)
     iq = np.ascontiguousarray(g["iq"], np.uint8)
