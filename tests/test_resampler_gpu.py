@@ -59,6 +59,9 @@ def test_resampler_errors(built):
     h = C.c_void_p()
     assert ddn.lib().ddn_resampler_create(4, 0, 1, C.byref(h)) != 0
     assert ddn.lib().ddn_resampler_create(4, 513, 1, C.byref(h)) != 0
+    assert ddn.lib().ddn_resampler_create(4, 1, 200, C.byref(h)) == -5     # input span of 1024 outputs exceeds the LDS budget
+    g35 = GpuResampler(2, 1, 30)                                          # the largest plain decimations still fit
+    assert g35.run(np.ones((2, 3000), np.float32)).shape[1] == 100
     g = GpuResampler(2, 3, 2)
     x = np.ones((2, 100), np.float32)
     out = np.zeros((2, 10), np.float32)
