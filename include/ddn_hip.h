@@ -264,7 +264,7 @@ void ddn_iq_free(void* p);
 typedef struct ddn_stream_set ddn_stream_set;
 int ddn_stream_set_create(int n_channels, size_t capacity_samples, unsigned output_rate_hz, int output_kind,
                           int symbol_rate_hz, int levels, int channel_profile, ddn_stream_set** out);
-void ddn_stream_set_destroy(ddn_stream_set* s);
+void ddn_stream_set_destroy(ddn_stream_set* s); /* close first and let every reader return from read() before this */
 void* ddn_stream_set_ctx(ddn_stream_set* s, int channel);
 /* rows [n_channels][row_stride], n samples each (or counts[c] <= n when counts != NULL); blocks while a queue is full */
 int ddn_stream_set_push(ddn_stream_set* s, const float* rows, size_t n, size_t row_stride, const int32_t* counts);
