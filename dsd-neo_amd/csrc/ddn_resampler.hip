@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void
 k_resample(const float* __restrict__ in, long n, size_t in_stride, const float* __restrict__ hist,
            const float* __restrict__ taps, int L, int M, int p0, long n_out, float* __restrict__ out,
            size_t out_stride, int span_cap) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     float* st = sm;                 // [L][K]
     float* sx = sm + (size_t)L * K; // [span_cap] inputs n_lo - 15 ...
     const int ch = blockIdx.y;
@@ -42,21 +42,32 @@ k_resample(const float* __restrict__ in, long n, size_t in_stride, const float* 
         sx[i] = (j >= 0) ? row[j] : hist[(size_t)ch * (K - 1) + (K - 1) + j];
     }
     __syncthreads();
+    // Output q0 + j sits at upsampled position u0 + j * M: input offset (r0 + j * M) / L past n_lo and phase
+    // (r0 + j * M) % L, with r0 = u0 % L < L.  All of it fits 32 bits (j < 1024), and a thread's next output (j + 256)
+    // follows by adding the quotient and remainder of 256 * M / L with one carry - no division in the loop.
+    const unsigned r0 = (unsigned)(((long long)p0 + (long long)q0 * M) % L);
+    const unsigned step_q = (256u * (unsigned)M) / (unsigned)L, step_r = (256u * (unsigned)M) % (unsigned)L;
+    unsigned off = (r0 + threadIdx.x * (unsigned)M) / (unsigned)L;
+    unsigned ph = (r0 + threadIdx.x * (unsigned)M) % (unsigned)L;
     for (long q = q0 + threadIdx.x; q < q1; q += 256) {
-        const long long u = (long long)p0 + (long long)q * M;
-        const long nq = (long)(u / L);
-        const int ph = (int)(u % L);
-        const float* w = sx + (nq - n_lo);
-        const float* t = st + (size_t)ph * K;
+        const float* w = sx + off;
+        const float4* t4 = (const float4*)(st + (size_t)ph * K); // a phase's 16 taps are 64-byte aligned: four 16-byte reads
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; k += 4) {
-            a0 += w[k + 0] * t[k + 0];
-            a1 += w[k + 1] * t[k + 1];
-            a2 += w[k + 2] * t[k + 2];
-            a3 += w[k + 3] * t[k + 3];
+            const float4 t = t4[k >> 2];
+            a0 += w[k + 0] * t.x;
+            a1 += w[k + 1] * t.y;
+            a2 += w[k + 2] * t.z;
+            a3 += w[k + 3] * t.w;
         }
         out[(size_t)ch * out_stride + q] = (a0 + a1) + (a2 + a3);
+        off += step_q;
+        ph += step_r;
+        if (ph >= (unsigned)L) {
+            ph -= (unsigned)L;
+            off++;
+        }
     }
 }
 
