@@ -161,38 +161,50 @@ k_p25_slicer(const float* __restrict__ sym, long n, size_t sym_stride, int n_cha
     }
 }
 
-// Matched filter: one output per thread, 91 taps from constant memory, LDS-staged input tile + 90-sample halo.
+// Matched filter (apply_sps_fir order: acc += tap[i] * x[o + i], i ascending, product and sum rounded separately).
+// Two adjacent outputs per thread as one packed lane pair: the tile is staged in LDS as overlapping pairs
+// P[k] = {x[k], x[k + 1]}, so tap i of outputs (o, o + 1) is one aligned 8-byte read P[o + i], one v_pk_mul_f32 and one
+// v_pk_add_f32 (1.5 instructions per output and tap instead of 4: two 4-byte LDS reads, a multiply and an add).  Taps
+// are compile-time indices into the constant table (scalar operands) because the tap loop is fully unrolled.
+typedef float mf2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void
 k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const float* __restrict__ hist,
                      float* __restrict__ out) {
     constexpr int T = 1024, NT = DDN_P25_FILTER_TAPS;
-    __shared__ float x[T + NT - 1];
-    __shared__ float taps[NT];
+    __shared__ mf2 P[T + NT]; // P[k] = {x[k], x[k + 1]} for k = 0 .. T + NT - 2
     const int ch = blockIdx.y;
     const long t0 = (long)blockIdx.x * T;
     const int tid = threadIdx.x;
-    if (tid < NT) {
-        taps[tid] = __uint_as_float(ddn_p25_filter_bits[tid]);
-    }
-    for (int i = tid; i < T + NT - 1; i += 256) {
+    auto sample = [&](int i) -> float { // x[i], i = 0 .. T + NT - 1 (one past the tile for the last pair's high half)
         const long j = t0 - (NT - 1) + i;
-        float v = 0.0f;
         if (j < 0) {
-            v = hist[(size_t)ch * (NT - 1) + (NT - 1) + j];
-        } else if (j < n) {
-            v = in[(size_t)ch * stride + j];
+            return hist[(size_t)ch * (NT - 1) + (NT - 1) + j];
         }
-        x[i] = v;
+        return j < n ? in[(size_t)ch * stride + j] : 0.0f;
+    };
+    for (int i = tid; i < T + NT - 1; i += 256) {
+        const float v = sample(i);
+        P[i].x = v;
+        if (i > 0) {
+            P[i - 1].y = v;
+        }
+    }
+    if (tid == 0) {
+        P[T + NT - 2].y = 0.0f; // high half of the last pair: never part of a stored output
     }
     __syncthreads();
-    for (int o = tid; o < T; o += 256) {
-        if (t0 + o < n) {
-            float acc = 0.0f;
-#pragma unroll 13
-            for (int i = 0; i < NT; i++) {
-                acc += taps[i] * x[o + i];
-            }
-            out[(size_t)ch * stride + t0 + o] = acc;
+    for (int o = 2 * tid; o < T; o += 512) {
+        mf2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const float t = __uint_as_float(ddn_p25_filter_bits[i]);
+            const mf2 tt = {t, t};
+            acc += tt * P[o + i];
+        }
+        if (t0 + o + 1 < n) {
+            *(mf2*)&out[(size_t)ch * stride + t0 + o] = acc;
+        } else if (t0 + o < n) {
+            out[(size_t)ch * stride + t0 + o] = acc.x;
         }
     }
 }
