@@ -803,6 +803,14 @@ ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, h
         }
         return launch_fused_c<8, DDN_IN_CF32>(*a, tp, has_zero, st);
     }
+    // A workgroup walks its channels' whole call, so the grid is n_channels / G workgroups: below ~2048 channels the
+    // 16-channel shape leaves CUs idle and the 8-channel one (twice the workgroups, same work per thread) wins.
+    if (a->n_channels <= 2048) {
+        if (a->in_fmt == DDN_IN_CU8) {
+            return launch_fused_c<8, DDN_IN_CU8>(*a, tp, has_zero, st);
+        }
+        return launch_fused_c<8, DDN_IN_CF32>(*a, tp, has_zero, st);
+    }
     if (a->in_fmt == DDN_IN_CU8) {
         return launch_fused_c<DDN_GROUP, DDN_IN_CU8>(*a, tp, has_zero, st);
     }

@@ -190,6 +190,18 @@ def main():
         of2 = orc.OracleFrontEnd(profile=prof)
         report(tag, B * nn, ms, 2 + 4, cpu(lambda: of2.run_cu8(iq8[0], 8192), nn), "complex samples")
 
+    # wide capture: two half-band passes (192 ksps -> 48 ksps) in front of the same channel filter; 1024 channels
+    Bw = 1024
+    d_w = torch.from_numpy(np.tile(iq8, (Bw // 8, 4, 1))).cuda()          # [1024][192000][2] cu8
+    d_ow = torch.zeros((Bw, nn), dtype=torch.float32, device="cuda")
+    fw = ddn.Batch(Bw, block_len=32768)
+    fw.set_decimation(2)
+    ms = timeit(lambda: fw.run_device(d_w.data_ptr(), 4 * nn, d_ow.data_ptr(), st))
+    ofw = orc.OracleFrontEnd(downsample_passes=2)
+    wide1 = np.tile(iq8[0], (4, 1))
+    report("front_end_halfband_x4", Bw * 4 * nn, ms, 2 + 1, cpu(lambda: ofw.run_cu8(wide1, 32768), 4 * nn),
+           "input complex samples")
+
     # IMBE de-interleave: 4096 channels x 9 voice frames out of an LDU's records
     nf = 4096 * 9
     recs = torch.from_numpy(rng.integers(0, 256, (4096 * 900, 10), dtype=np.uint8)).cuda()
