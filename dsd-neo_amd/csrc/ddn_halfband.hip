@@ -39,37 +39,48 @@ load_iq(const void* base, size_t idx) {
 }
 } // namespace
 
+// One workgroup = 256 outputs of one reference block of one channel (grid.x enumerates (block, tile-in-block), so the
+// right-edge replication is one clamp per staged sample).  The 512 + NT - 1 inputs those outputs touch are widened and
+// staged in LDS once (each input feeds ~8 outputs); a thread then runs the centre tap and the non-zero symmetric pairs as
+// packed (I, Q) operations.
 template <int FMT, int NT>
 __global__ __launch_bounds__(256) void
-k_hb_decim2(const void* __restrict__ in, long n_in, size_t in_stride, int block_in, const f2* __restrict__ hist,
-            f2* __restrict__ out, size_t out_stride) {
+k_hb_decim2(const void* __restrict__ in, long n_in, size_t in_stride, int block_in, int tiles_per_block,
+            const f2* __restrict__ hist, f2* __restrict__ out, size_t out_stride) {
     constexpr int H = NT - 1, CEN = H / 2;
+    __shared__ f2 win[512 + H];
     const float* taps = (NT == 31) ? c_hb31 : c_hb15;
     const int ch = blockIdx.y;
-    const long m = (long)blockIdx.x * 256 + threadIdx.x;
-    const long n_out = n_in >> 1;
-    if (m >= n_out) {
+    const long b = blockIdx.x / tiles_per_block;
+    const int tile = blockIdx.x % tiles_per_block;
+    const long s = b * block_in;
+    if (s >= n_in) {
         return;
     }
-    const int block_out = block_in >> 1;
-    const long b = m / block_out;
-    const long s = b * block_in;
     const long L = (n_in - s) < block_in ? (n_in - s) : block_in;
-    const long c = s + 2 * (m - b * block_out);
+    const long m0 = (long)tile * 256; // first output of this tile inside the block
+    if (m0 >= (L >> 1)) {
+        return;
+    }
     const long last = s + L - 1;
     const bool fused = L >= NT;
-    auto x = [&](long j) -> f2 {
+    const long j0 = s + 2 * m0 - CEN; // input index of win[0]
+    for (int i = threadIdx.x; i < 512 + H; i += 256) {
+        long j = j0 + i;
         j = j > last ? last : j;
-        if (j < 0) {
-            return hist[(size_t)ch * H + (size_t)(H + j)];
-        }
-        return load_iq<FMT>(in, (size_t)ch * in_stride + (size_t)j);
-    };
+        win[i] = (j < 0) ? hist[(size_t)ch * H + (size_t)(H + j)] : load_iq<FMT>(in, (size_t)ch * in_stride + (size_t)j);
+    }
+    __syncthreads();
+    const long ml = m0 + threadIdx.x;
+    if (ml >= (L >> 1)) {
+        return;
+    }
+    const int c = 2 * threadIdx.x + CEN; // window index of this output's centre sample
     const f2 z = {0.0f, 0.0f};
     f2 acc;
     {
         const f2 h = {taps[CEN], taps[CEN]};
-        acc = fused ? __builtin_elementwise_fma(h, x(c), z) : (z + h * x(c));
+        acc = fused ? __builtin_elementwise_fma(h, win[c], z) : (z + h * win[c]);
     }
 #pragma unroll
     for (int k = 0; k < CEN; k += 2) {
@@ -78,11 +89,11 @@ k_hb_decim2(const void* __restrict__ in, long n_in, size_t in_stride, int block_
             continue;
         }
         const int d = CEN - k;
-        const f2 sm = x(c - d) + x(c + d);
+        const f2 sm = win[c - d] + win[c + d];
         const f2 h = {hk, hk};
         acc = fused ? __builtin_elementwise_fma(h, sm, acc) : (acc + h * sm);
     }
-    out[(size_t)ch * out_stride + (size_t)m] = acc;
+    out[(size_t)ch * out_stride + (size_t)((s >> 1) + ml)] = acc;
 }
 
 // hist <- last H samples of (hist ++ in[0..n))
@@ -107,20 +118,22 @@ ddn_dev_hb_decim2(const void* in, int in_fmt, long n_in, size_t in_stride, int b
     if (n_channels <= 0 || n_in < 2) {
         return hipSuccess;
     }
-    const dim3 grid((unsigned)(((n_in >> 1) + 255) / 256), (unsigned)n_channels), blk(256);
+    const long n_blocks = (n_in + block_in - 1) / block_in;
+    const int tiles_per_block = ((block_in >> 1) + 255) / 256;
+    const dim3 grid((unsigned)(n_blocks * tiles_per_block), (unsigned)n_channels), blk(256);
     const f2* h = (const f2*)hist;
     f2* o = (f2*)out;
     if (in_fmt == DDN_IN_CU8) {
         if (taps_len == 31) {
-            hipLaunchKernelGGL((k_hb_decim2<DDN_IN_CU8, 31>), grid, blk, 0, st, in, n_in, in_stride, block_in, h, o, out_stride);
+            hipLaunchKernelGGL((k_hb_decim2<DDN_IN_CU8, 31>), grid, blk, 0, st, in, n_in, in_stride, block_in, tiles_per_block, h, o, out_stride);
         } else {
-            hipLaunchKernelGGL((k_hb_decim2<DDN_IN_CU8, 15>), grid, blk, 0, st, in, n_in, in_stride, block_in, h, o, out_stride);
+            hipLaunchKernelGGL((k_hb_decim2<DDN_IN_CU8, 15>), grid, blk, 0, st, in, n_in, in_stride, block_in, tiles_per_block, h, o, out_stride);
         }
     } else {
         if (taps_len == 31) {
-            hipLaunchKernelGGL((k_hb_decim2<DDN_IN_CF32, 31>), grid, blk, 0, st, in, n_in, in_stride, block_in, h, o, out_stride);
+            hipLaunchKernelGGL((k_hb_decim2<DDN_IN_CF32, 31>), grid, blk, 0, st, in, n_in, in_stride, block_in, tiles_per_block, h, o, out_stride);
         } else {
-            hipLaunchKernelGGL((k_hb_decim2<DDN_IN_CF32, 15>), grid, blk, 0, st, in, n_in, in_stride, block_in, h, o, out_stride);
+            hipLaunchKernelGGL((k_hb_decim2<DDN_IN_CF32, 15>), grid, blk, 0, st, in, n_in, in_stride, block_in, tiles_per_block, h, o, out_stride);
         }
     }
     hipError_t e = hipGetLastError();
