@@ -35,6 +35,16 @@ ddn_version(void) {
     return "dsdneo-hip 0.1 (gfx950)";
 }
 
+static int
+taps_have_zero(const float* taps, int n) {
+    for (int i = 0; i < n; i++) {
+        if (taps[i] == 0.0f) {
+            return 1;
+        }
+    }
+    return 0;
+}
+
 #define HIP_TRY(expr)                                                                                                  \
     do {                                                                                                               \
         hipError_t e_ = (expr);                                                                                        \
@@ -337,7 +347,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
         if (b->timing) {
             HIP_TRY(hipEventRecord(b->ev[0], st));
         }
-        HIP_TRY(ddn_dev_channel_lpf_c2c(d_iq, in_fmt, (long)n, n, block_len, B, b->d_taps, b->taps_len, b->d_lpf_hist,
+        HIP_TRY(ddn_dev_channel_lpf_c2c(d_iq, in_fmt, (long)n, n, block_len, B, b->d_taps, b->taps_len, taps_have_zero(b->taps, b->taps_len), b->d_lpf_hist,
                                         b->d_lpf, n, st));
         if (b->timing) {
             HIP_TRY(hipEventRecord(b->ev[1], st));

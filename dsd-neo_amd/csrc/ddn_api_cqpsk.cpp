@@ -10,6 +10,16 @@
 
 #include "ddn_device.h"
 
+static int
+taps_have_zero(const float* taps, int n) {
+    for (int i = 0; i < n; i++) {
+        if (taps[i] == 0.0f) {
+            return 1;
+        }
+    }
+    return 0;
+}
+
 #define HIP_TRY(expr)                                                                                                  \
     do {                                                                                                               \
         hipError_t e_ = (expr);                                                                                        \
@@ -187,7 +197,7 @@ ddn_cqpsk_run(ddn_cqpsk_batch* b, const void* d_iq, size_t n, float* d_symbols, 
     const void* cur = d_iq;
     int fmt = b->cfg.input_format;
     if (b->taps_len >= 3) {
-        HIP_TRY(ddn_dev_channel_lpf_c2c(cur, fmt, (long)n, n, b->cfg.block_len, B, b->d_taps, b->taps_len, b->d_lpf_hist,
+        HIP_TRY(ddn_dev_channel_lpf_c2c(cur, fmt, (long)n, n, b->cfg.block_len, B, b->d_taps, b->taps_len, taps_have_zero(b->taps, b->taps_len), b->d_lpf_hist,
                                         b->d_a, n, st));
         cur = b->d_a;
         fmt = DDN_IN_CF32;

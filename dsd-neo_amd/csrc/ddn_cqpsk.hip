@@ -13,6 +13,8 @@
 // with coalesced row writes and prefetches tile t+1.
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #include "ddn_device.h"
@@ -183,6 +185,81 @@ k_channel_lpf_c2c(const void* __restrict__ in, long n, size_t in_stride, int blo
         acc = fused ? __builtin_elementwise_fma(h, sm, acc) : (acc + h * sm);
     }
     out[(size_t)ch * out_stride + (size_t)m] = acc;
+}
+
+// Same filter for the tap counts the channel-LPF design produces at the usual rates (135 taps at 48 kHz, 67 at 24 kHz):
+// the tap loop is fully unrolled, a thread owns two adjacent outputs and slides both symmetric window pairs through
+// registers (one new low-side and one new high-side sample per tap instead of four reads), taps come in as scalar operands.
+// Per output the operation order is the generic kernel's: centre tap, then (x[c-d] + x[c+d]) * h in ascending tap order.
+template <int FMT, int CEN_T, bool SKIPZ>
+__global__ __launch_bounds__(128) void
+k_channel_lpf_c2c_u(const void* __restrict__ in, long n, size_t in_stride, int block_len, int tiles_per_block,
+                    const float* __restrict__ taps_g, const f2* __restrict__ hist, f2* __restrict__ out,
+                    size_t out_stride) {
+    constexpr int H = 2 * CEN_T;
+    __shared__ f2 win[256 + H + 2];
+    const int ch = blockIdx.y;
+    const long b = blockIdx.x / tiles_per_block;
+    const int tile = blockIdx.x % tiles_per_block;
+    const long s = b * block_len;
+    if (s >= n) {
+        return;
+    }
+    const long L = (n - s) < block_len ? (n - s) : block_len;
+    const long t0 = s + (long)tile * 256;
+    if (t0 >= s + L) {
+        return;
+    }
+    const long last = s + L - 1;
+    const bool fused = L >= H + 1;
+    for (int i = threadIdx.x; i < 256 + H; i += 128) {
+        long j = t0 - CEN_T + i;
+        j = j > last ? last : j;
+        win[i] = (j < 0) ? hist[(size_t)ch * H + (size_t)(H + j)] : load_iq<FMT>(in, (size_t)ch * in_stride + (size_t)j);
+    }
+    __syncthreads();
+    const long m = t0 + 2 * threadIdx.x;
+    if (m > last) {
+        return;
+    }
+    const f2* w = &win[2 * threadIdx.x]; // w[CEN_T] is output m's centre sample
+    const f2 z = {0.0f, 0.0f};
+    f2 acc0, acc1;
+    // blocks of at least taps_len samples take the AVX2 unit's FMA order, shorter ones the scalar unit's multiply-then-add;
+    // the choice is uniform over the workgroup, so each order gets its own straight-line tap loop
+    auto run = [&](auto fused_c) {
+        constexpr bool FUSED = decltype(fused_c)::value;
+        const float hc = taps_g[CEN_T];
+        const f2 hcc = {hc, hc};
+        acc0 = FUSED ? __builtin_elementwise_fma(hcc, w[CEN_T], z) : (z + hcc * w[CEN_T]);
+        acc1 = FUSED ? __builtin_elementwise_fma(hcc, w[CEN_T + 1], z) : (z + hcc * w[CEN_T + 1]);
+        f2 a0 = w[0], a1 = w[1];                     // low side: x[c - d], x[c - d + 1] for d = CEN_T
+        f2 b0 = w[2 * CEN_T], b1 = w[2 * CEN_T + 1]; // high side: x[c + d], x[c + d + 1]
+#pragma unroll
+        for (int k = 0; k < CEN_T; k++) {
+            const float hk = taps_g[k];
+            if (!SKIPZ || hk != 0.0f) {
+                const f2 h = {hk, hk};
+                acc0 = FUSED ? __builtin_elementwise_fma(h, a0 + b0, acc0) : (acc0 + h * (a0 + b0));
+                acc1 = FUSED ? __builtin_elementwise_fma(h, a1 + b1, acc1) : (acc1 + h * (a1 + b1));
+            }
+            if (k + 1 < CEN_T) {
+                a0 = a1;
+                a1 = w[k + 2];
+                b1 = b0;
+                b0 = w[2 * CEN_T - (k + 1)];
+            }
+        }
+    };
+    if (fused) {
+        run(std::true_type{});
+    } else {
+        run(std::false_type{});
+    }
+    out[(size_t)ch * out_stride + (size_t)m] = acc0;
+    if (m + 1 <= last) {
+        out[(size_t)ch * out_stride + (size_t)m + 1] = acc1;
+    }
 }
 
 template <int FMT>
@@ -637,20 +714,40 @@ k_cqpsk_symbols(const f2* __restrict__ sym, size_t stride, const int* __restrict
 // ---- launchers -------------------------------------------------------------------------------------------------------
 extern "C" hipError_t
 ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, int block_len, int n_channels,
-                        const float* taps_dev, int taps_len, void* hist, void* out, size_t out_stride, hipStream_t st) {
+                        const float* taps_dev, int taps_len, int has_zero_tap, void* hist, void* out, size_t out_stride,
+                        hipStream_t st) {
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
     const int tiles_per_block = (block_len + 255) / 256;
     const long n_blocks = (n + block_len - 1) / block_len;
     const dim3 grid((unsigned)(n_blocks * tiles_per_block), (unsigned)n_channels), blk(256);
-    if (in_fmt == DDN_IN_CU8) {
+#define DDN_C2C_U(FMTV, CENV)                                                                                          \
+    do {                                                                                                               \
+        if (has_zero_tap) {                                                                                            \
+            hipLaunchKernelGGL((k_channel_lpf_c2c_u<FMTV, CENV, true>), grid, dim3(128), 0, st, in, n, in_stride,      \
+                               block_len, tiles_per_block, taps_dev, (const f2*)hist, (f2*)out, out_stride);           \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL((k_channel_lpf_c2c_u<FMTV, CENV, false>), grid, dim3(128), 0, st, in, n, in_stride,     \
+                               block_len, tiles_per_block, taps_dev, (const f2*)hist, (f2*)out, out_stride);           \
+        }                                                                                                              \
+    } while (0)
+    if (taps_len == 135 && in_fmt == DDN_IN_CU8) {
+        DDN_C2C_U(DDN_IN_CU8, 67);
+    } else if (taps_len == 135) {
+        DDN_C2C_U(DDN_IN_CF32, 67);
+    } else if (taps_len == 67 && in_fmt == DDN_IN_CU8) {
+        DDN_C2C_U(DDN_IN_CU8, 33);
+    } else if (taps_len == 67) {
+        DDN_C2C_U(DDN_IN_CF32, 33);
+    } else if (in_fmt == DDN_IN_CU8) {
         hipLaunchKernelGGL((k_channel_lpf_c2c<DDN_IN_CU8>), grid, blk, 0, st, in, n, in_stride, block_len, tiles_per_block,
                            taps_dev, taps_len, (const f2*)hist, (f2*)out, out_stride);
     } else {
         hipLaunchKernelGGL((k_channel_lpf_c2c<DDN_IN_CF32>), grid, blk, 0, st, in, n, in_stride, block_len, tiles_per_block,
                            taps_dev, taps_len, (const f2*)hist, (f2*)out, out_stride);
     }
+#undef DDN_C2C_U
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         return e;

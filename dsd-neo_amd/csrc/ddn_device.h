@@ -123,8 +123,8 @@ hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev
                           uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave,
                           const int32_t* lock_cfg, hipStream_t st);
 hipError_t ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, int block_len, int n_channels,
-                                   const float* taps_dev, int taps_len, void* hist, void* out, size_t out_stride,
-                                   hipStream_t st);
+                                   const float* taps_dev, int taps_len, int has_zero_tap, void* hist, void* out,
+                                   size_t out_stride, hipStream_t st);
 hipError_t ddn_dev_cqpsk_set_fll_taps(const float* taps4);
 hipError_t ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int nt, float alpha, float beta,
                                  DdnCqpskState* state, float* delay_store, void* out, hipStream_t st);
