@@ -311,7 +311,7 @@ __global__ __launch_bounds__(128) void
 k_gardner_ring(const f2* __restrict__ in, long n, size_t in_stride, int n_channels, int sps, float ted_gain,
                int symbol_rate_hz, long block_len, DdnTedState* __restrict__ state, float* __restrict__ dl_store,
                f2* __restrict__ out, size_t out_stride, int* __restrict__ out_count) {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float(*tbl)[8] = (float(*)[8])smem;               // [17][8]
     f2(*ring)[GROW] = (f2(*)[GROW])(smem + 17 * 8 + 8); // [CPW][GROW]: [mirror of slot 2 | slot 0 | slot 1 | slot 2 | pad]
     const int lane = threadIdx.x & 63;
@@ -423,9 +423,15 @@ k_gardner_ring(const f2* __restrict__ in, long n, size_t in_stride, int n_channe
         }
         const float lw = 1.0f - fr;
         float ar = 0.0f, ai = 0.0f;
+        // a table row is eight floats, 32-byte aligned: two 16-byte reads per row instead of eight scalar ones
+        const float4* r0 = (const float4*)&tbl[lo][0];
+        const float4* r1 = (const float4*)&tbl[lo + 1][0];
+        const float4 p0 = r0[0], p1 = r0[1], q0 = r1[0], q1 = r1[1];
+        const float t0[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        const float t1[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float tap = lw * tbl[lo][i] + fr * tbl[lo + 1][i];
+            const float tap = lw * t0[i] + fr * t1[i];
             const f2 x = w[7 - i];
             ar += tap * x.x;
             ai += tap * x.y;
