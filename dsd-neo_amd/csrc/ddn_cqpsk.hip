@@ -641,8 +641,22 @@ k_cqpsk_symbols(const f2* __restrict__ sym, size_t stride, const int* __restrict
         const f2* ip = sym + (size_t)ch * stride;
         float* op = out + (size_t)ch * out_stride;
         const float k4pi = 4.0f / 3.14159265358979323846f;
-        for (int n = 0; n < cnt; n++) {
-            const f2 cur = ip[n];
+        // The loop is a per-symbol recurrence and each lane reads its own row: eight symbols are fetched ahead of the
+        // dependent chain (independent loads, one wait) instead of one load-and-wait per symbol.
+        for (int n0 = 0; n0 < cnt; n0 += 8) {
+          f2 pre[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+              const f2 zz = {0.0f, 0.0f};
+              pre[k] = (n0 + k < cnt) ? ip[n0 + k] : zz;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int n = n0 + k;
+            if (n >= cnt) {
+                break;
+            }
+            const f2 cur = pre[k];
             // y = x * conj(prev)
             const float ir = cur.x * pr + cur.y * pj;
             const float ij = cur.y * pr - cur.x * pj;
@@ -700,6 +714,7 @@ k_cqpsk_symbols(const f2* __restrict__ sym, size_t stride, const int* __restrict
             phase = clampr(phase, min_phase, max_phase);
             freq = clampr(freq, -1.0f, 1.0f);
             op[n] = atan2_qpsk(dj, dr) * k4pi;
+          }
         }
         s.diff_r = pr;
         s.diff_j = pj;
