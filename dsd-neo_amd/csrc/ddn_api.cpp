@@ -366,6 +366,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     fa.in = d_iq;
     fa.out = d_disc;
     fa.carry = b->d_carry;
+    fa.carry_out = (n >= (size_t)DDN_CARRY_LEN && !getenv("DDN_CARRY_KERNEL")) ? (ddn_f2*)b->d_carry : nullptr;
     fa.state = b->d_state;
     fa.taps_dev = b->d_taps;
     fa.ch_stride = n;
@@ -399,7 +400,9 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[1], st));
     }
-    HIP_TRY(ddn_dev_launch_carry(d_iq, in_fmt, n, (long)n, b->d_carry, B, st));
+    if (!fa.carry_out) {
+        HIP_TRY(ddn_dev_launch_carry(d_iq, in_fmt, n, (long)n, b->d_carry, B, st));
+    }
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
         b->ev_valid = 1;

@@ -32,6 +32,7 @@ typedef struct DdnFusedArgs {
     const void* in;       /* [B][ch_stride] complex samples (cu8 pairs or float pairs) */
     float* out;           /* [B][out_stride] discriminator samples */
     const ddn_f2* carry;  /* [B][DDN_CARRY_LEN] FIR look-back from the previous call */
+    ddn_f2* carry_out;    /* same array when the kernel itself refreshes it at the end (n >= DDN_CARRY_LEN), else NULL */
     DdnFskState* state;   /* [B] */
     const float* taps_dev; /* [taps_len] channel LPF taps (first half + centre are read) */
     size_t ch_stride;

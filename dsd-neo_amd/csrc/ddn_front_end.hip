@@ -717,6 +717,14 @@ k_front_end_fused(DdnFusedArgs a) {
         o[3] = tW;
     }
 
+    if (is_filter && ch_ok && a.carry_out) {
+        // next call's FIR look-back: the channel's last DDN_CARRY_LEN widened samples.  Only this half-wave ever reads
+        // or writes this channel's row (it read it at tile 0), so no other ordering is needed.
+        f2* c = a.carry_out + (size_t)ch * DDN_CARRY_LEN;
+        for (int i = u; i < DDN_CARRY_LEN; i += 32) {
+            c[i] = ddn_load_iq(a.in, FMT, a.ch_stride, ch, a.n - DDN_CARRY_LEN + i);
+        }
+    }
     if (role == 1 && ch_ok && g < G && a.n > 0) {
         const f2 yl = chan_last[(int)(NT & 1)][g];
         DdnFskState* s = &a.state[ch];
