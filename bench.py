@@ -92,6 +92,39 @@ def cpu_baseline(iq_sample_u8):
                          else "oracle C restatement, FMA order")}
 
 
+def gardner_variant(torch, ddn, orc, B, n, front_end_ms):
+    """Informational, NOT part of `value`: configs[1]'s "FIR+discriminator+Gardner" shape - the
+    timing-error kernel (CQPSK Gardner + 8-tap MMSE, sps 10) on a batch of the same shape, float I/Q resident in HBM."""
+    import ctypes as C
+    import numpy as np
+    sps = 10
+    iq1 = orc.synth_qpsk_f32(9, 8, (n + 80) // sps + 8, sps)[:, :n]
+    d_iq = torch.from_numpy(np.tile(iq1, (B // 8 + 1, 1, 1))[:B].copy()).cuda()
+    h = C.c_void_p()
+    l = ddn.lib()
+    assert l.ddn_ted_batch_create(B, sps, 4800, 0.0, C.byref(h)) == 0
+    stride = n // sps + 64
+    d_sym = torch.zeros((B, stride, 2), dtype=torch.float32, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(5):
+        e0.record()
+        rc = l.ddn_gardner_run(h, d_iq.data_ptr(), n, d_sym.data_ptr(), stride, d_cnt.data_ptr(), st)
+        e1.record()
+        torch.cuda.synchronize()
+        assert rc == 0
+        t = e0.elapsed_time(e1)
+        best = t if best is None else min(best, t)
+    l.ddn_ted_batch_destroy(h)
+    return {"note": "informational; Gardner + MMSE timing-error kernel (sps 10) on 4096 x 48000 complex samples",
+            "gardner_ms": round(best, 3), "front_end_ms": round(front_end_ms, 4),
+            "gardner_Msamples_per_s": round(B * n / (best * 1e-3) / 1e6, 1),
+            "fir_disc_gardner_Msamples_per_s": round(B * n / ((best + front_end_ms) * 1e-3) / 1e6, 1),
+            "symbols": int(d_cnt.sum().item())}
+
+
 def dibit_chain(torch, ddn, orc, B, n, front_end_ms):
     """Informational, NOT part of `value`: the stage that turns the discriminator stream into the bit-exact dibit
     records (P25p1 symbolizer + sync hunt + slicer, ddn_p25_rx_run) timed on framed synthetic P25p1 traffic of the
@@ -326,6 +359,7 @@ def main():
         }
         # informational stage chains and the CPU baseline: single-GPU runs only (rank 0 at N = 1)
         if not args.no_chain and world == 1:
+            line["gardner_variant"] = gardner_variant(torch, ddn, orc, B, n, fir_avg)
             line["dibit_chain"] = dibit_chain(torch, ddn, orc, B, n, fir_avg)
             line["p25_e2e_chain"] = p25_e2e_chain(torch, ddn, B, n)
         if not args.no_cpu_baseline and world == 1:
