@@ -1,5 +1,7 @@
 """GPU differential fuzz: random front-end configurations (block length, call splits, channel counts, input format,
 decimation passes, squelch, LPF profile) against the oracle, bit-exact; random receive-loop call splits and lock lengths."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,10 +10,13 @@ import orc
 
 pytestmark = pytest.mark.gpu
 
+# DDN_FUZZ_BASE=<k> shifts every generator seed, for longer sweeps than the default suite
+BASE = int(os.environ.get("DDN_FUZZ_BASE", "0"))
+
 
 @pytest.mark.parametrize("seed", range(48))
 def test_front_end_random_configs(built, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + 7919 * BASE)
     passes = int(rng.choice([0, 0, 0, 1, 2]))
     profile = int(rng.choice([2, 4, 4, 5, 1]))
     blk = int(rng.choice([135, 200, 1000, 2048, 4096, 8192, 8191, 12345])) if passes == 0 else int(rng.choice([1024, 2048, 8192]))
@@ -52,7 +57,7 @@ def test_front_end_random_configs(built, seed):
 
 @pytest.mark.parametrize("seed", range(48))
 def test_rx_random_splits(built, seed):
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(2000 + seed + 7919 * BASE)
     B = int(rng.integers(1, 24))
     frame = int(rng.choice([180, 360, 432, 864]))
     lock = frame - 24 if rng.random() < 0.7 else int(rng.integers(0, frame))
@@ -86,7 +91,7 @@ def test_rx_random_splits(built, seed):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_cqpsk_random_configs(built, seed):
-    rng = np.random.default_rng(3000 + seed)
+    rng = np.random.default_rng(3000 + seed + 7919 * BASE)
     sps = int(rng.choice([4, 5, 5, 10, 8]))
     sym_rate = 6000 if sps == 4 else 4800
     rate = sps * sym_rate
