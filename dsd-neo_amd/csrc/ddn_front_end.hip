@@ -177,7 +177,7 @@ k_front_end_fused(DdnFusedArgs a) {
     __shared__ float gmin[3][G][TT / 8 + 1]; // min |centred| of each 8-sample group, written by S1 for S2's guard test
     __shared__ int next_item; // filter work-item counter of the current tile // per tile/channel: 1 = squelched (zeros + modem reset), 2 = first sample skipped
     __shared__ __attribute__((aligned(8))) float stap[DDN_MAX_CENTER + 4];
-    extern __shared__ f2 ysq[]; // [G][256] first LPF outputs of a block (squelch builds only)
+    extern __shared__ f2 ysq[]; // [1 or 2][G][256] first LPF outputs of a block (squelch builds only)
 
     // The two recurrence waves are the FIRST waves of the workgroup: VALU issue on a SIMD is arbitrated by age
     // (measured: a youngest-wave dependent chain runs 2x slower beside busy filter waves, an oldest-wave one at
@@ -530,9 +530,12 @@ k_front_end_fused(DdnFusedArgs a) {
                 }
                 *(f4*)&Fb[bf][g][u * R] = q0;
                 if (a.squelch_on && tc.first) {
+                    // one-tile blocks: every tile is a block's first, and S1 is still summing tile it-1's copy while
+                    // this one is written, so the copies alternate between two halves
+                    f2* yq = ysq + (a.tiles_per_block == 1 ? (int)(it & 1) * (G * 256) : 0);
 #pragma unroll
                     for (int j = 0; j < R; j++) {
-                        ysq[g * 256 + u * R + j] = acc[j];
+                        yq[g * 256 + u * R + j] = acc[j];
                     }
                 }
             }
@@ -547,7 +550,8 @@ k_front_end_fused(DdnFusedArgs a) {
                     // block power: first <=512 floats of the block's LPF output, sequential binary64 sums
                     // exactly like mean_power() (src/dsp/demod_pipeline.cpp:926-945)
                     const int len = (int)((tp.blk_end - tp.start) * 2 > 512 ? 512 : (tp.blk_end - tp.start) * 2);
-                    const float* sq = (const float*)&ysq[g * 256];
+                    const float* sq =
+                        (const float*)&ysq[(a.tiles_per_block == 1 ? (int)((it - 1) & 1) * (G * 256) : 0) + g * 256];
                     double pw = 0.0, tot = 0.0;
                     for (int i = 0; i < len; i++) {
                         const double v = (double)sq[i];
@@ -771,7 +775,16 @@ static hipError_t
 launch_fused_t(const DdnFusedArgs& a, const DdnTapsK& tp, bool has_zero, hipStream_t st) {
     dim3 grid((unsigned)((a.n_channels + G - 1) / G));
     dim3 block(G * 32 + 128);
-    const size_t dyn = a.squelch_on ? (size_t)G * 256 * sizeof(f2) : 0;
+    // squelch builds: the block's first 256 LPF outputs, twice when a block is a single tile (see the filter's store)
+    const size_t dyn = a.squelch_on ? (size_t)G * 256 * sizeof(f2) * (a.tiles_per_block == 1 ? 2 : 1) : 0;
+    if (dyn) {
+        const void* fn = has_zero ? (const void*)k_front_end_fused<CENTER_T, G, true, FMT>
+                                  : (const void*)k_front_end_fused<CENTER_T, G, false, FMT>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
     if (has_zero) {
         hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, true, FMT>), grid, block, dyn, st, a);
     } else {

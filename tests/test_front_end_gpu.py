@@ -106,6 +106,26 @@ def test_squelch_gate_mixed_blocks(built):
     check(got, want)
 
 
+@pytest.mark.parametrize("blk", [135, 200, 256, 257, 512])
+def test_squelch_gate_one_tile_blocks(built, blk):
+    """Blocks no longer than the kernel's 256-sample tile: every tile starts a block, so the block-power sum of one
+    tile runs beside the filter pass of the next (found by the DDN_FUZZ_BASE sweep: loud samples of the following
+    block reached the sum of a quiet one).  Quiet / loud edges on every block phase, two calls."""
+    B = 11
+    n1, n2 = 5 * blk, 7 * blk + 33
+    iq = orc.synth_c4fm_cu8(77, B, n1 + n2)
+    for c in range(B):
+        iq[c, 2 * blk + 17 * c: 6 * blk + 9 * c] = 127
+        iq[c, 9 * blk: 10 * blk] = 127 + (c & 1)
+    b = ddn.Batch(B, block_len=blk, squelch_level=0.02)
+    got = np.concatenate([b.run_host(iq[:, :n1], n1), b.run_host(iq[:, n1:], n2)], axis=1)
+    for c in range(B):
+        fe = orc.OracleFrontEnd(squelch=0.02)
+        want = np.concatenate([fe.run_cu8(iq[c, :n1], blk), fe.run_cu8(iq[c, n1:], blk)])
+        assert (want[4 * blk:5 * blk] == 0).all()
+        assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), (blk, c)
+
+
 def test_other_rates_and_profiles(built):
     # 24 kHz -> 67 taps (unrolled centre 33); 32 kHz -> 89 taps (generic kernel)
     for rate, prof in [(24000, 1), (32000, 2), (48000, 5), (48000, 0)]:
