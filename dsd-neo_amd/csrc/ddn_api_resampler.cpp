@@ -36,17 +36,9 @@ out_len_for(long long n, int L, int M, int phase) {
 
 extern "C" int
 ddn_resampler_create(int n_channels, int L, int M, ddn_resampler** out) {
-    if (!out || n_channels <= 0 || L < 1 || M < 1 || L > DDN_RESAMP_MAX_L) {
-        ddn_set_error("ddn_resampler_create: bad argument (1 <= L <= %d, M >= 1)", DDN_RESAMP_MAX_L);
+    if (!out || n_channels <= 0 || L < 1 || M < 1 || L > DDN_RESAMP_MAX_L || M > (1 << 22)) {
+        ddn_set_error("ddn_resampler_create: bad argument (1 <= L <= %d, 1 <= M <= 2^22)", DDN_RESAMP_MAX_L);
         return DDN_EINVAL;
-    }
-    // one workgroup stages the whole tap table and the input span of 1024 outputs in LDS (ddn_resampler.hip)
-    const size_t lds = sizeof(float) * ((size_t)16 * L + (size_t)((1023LL * M) / L) + 18);
-    if (lds > 140 * 1024) {
-        ddn_set_error("ddn_resampler_create: ratio %d/%d needs %zu bytes of LDS per workgroup (limit 140 KiB); decimate "
-                      "with the half-band cascade first",
-                      L, M, lds);
-        return DDN_ERANGE;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {

@@ -18,12 +18,12 @@
 
 namespace {
 constexpr int K = 16;
-constexpr int OT = 1024; // outputs per workgroup
+constexpr int OT_MAX = 1024; // outputs per workgroup (halved until the input span fits the LDS budget)
 
 __global__ __launch_bounds__(256) void
 k_resample(const float* __restrict__ in, long n, size_t in_stride, const float* __restrict__ hist,
            const float* __restrict__ taps, int L, int M, int p0, long n_out, float* __restrict__ out,
-           size_t out_stride, int span_cap) {
+           size_t out_stride, int span_cap, int OT) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* st = sm;                 // [L][K]
     float* sx = sm + (size_t)L * K; // [span_cap] inputs n_lo - 15 ...
@@ -43,7 +43,7 @@ k_resample(const float* __restrict__ in, long n, size_t in_stride, const float* 
     }
     __syncthreads();
     // Output q0 + j sits at upsampled position u0 + j * M: input offset (r0 + j * M) / L past n_lo and phase
-    // (r0 + j * M) % L, with r0 = u0 % L < L.  All of it fits 32 bits (j < 1024), and a thread's next output (j + 256)
+    // (r0 + j * M) % L, with r0 = u0 % L < L.  All of it fits 32 bits (j < OT <= 1024), and a thread's next output (j + 256)
     // follows by adding the quotient and remainder of 256 * M / L with one carry - no division in the loop.
     const unsigned r0 = (unsigned)(((long long)p0 + (long long)q0 * M) % L);
     const unsigned step_q = (256u * (unsigned)M) / (unsigned)L, step_r = (256u * (unsigned)M) % (unsigned)L;
@@ -96,7 +96,12 @@ ddn_dev_resample(const float* in, long n, size_t in_stride, int n_channels, floa
         return hipSuccess;
     }
     if (n_out > 0) {
-        // inputs one workgroup can touch: OT outputs advance (OT - 1) * M / L inputs, plus the 16-tap window
+        // inputs one workgroup can touch: OT outputs advance (OT - 1) * M / L inputs, plus the 16-tap window.  Steep
+        // decimations (M / L in the tens) shrink OT so that taps + span stay within 64 KB of LDS.
+        int OT = OT_MAX;
+        while (OT > 1 && sizeof(float) * ((size_t)L * K + (size_t)(((long long)(OT - 1) * M) / L) + K + 2) > 64 * 1024) {
+            OT >>= 1;
+        }
         const int span_cap = (int)(((long long)(OT - 1) * M) / L) + K + 2;
         const size_t shm = sizeof(float) * ((size_t)L * K + (size_t)span_cap);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resample),
@@ -105,7 +110,7 @@ ddn_dev_resample(const float* in, long n, size_t in_stride, int n_channels, floa
             return e;
         }
         hipLaunchKernelGGL(k_resample, dim3((unsigned)((n_out + OT - 1) / OT), (unsigned)n_channels), dim3(256), shm,
-                           st, in, n, in_stride, hist, taps, L, M, p0, n_out, out, out_stride, span_cap);
+                           st, in, n, in_stride, hist, taps, L, M, p0, n_out, out, out_stride, span_cap, OT);
         e = hipGetLastError();
         if (e != hipSuccess) {
             return e;

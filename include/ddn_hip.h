@@ -358,7 +358,7 @@ int ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t
  * dsd_resampler_process_block() per channel.  d_in [B][n] f32, d_out [B][out_stride] f32 with
  * ddn_resampler_out_len(b, n) <= out_stride outputs per channel (DDN_ERANGE and untouched state otherwise). */
 typedef struct ddn_resampler ddn_resampler;
-int ddn_resampler_create(int n_channels, int L, int M, ddn_resampler** out); /* 1 <= L <= 512 */
+int ddn_resampler_create(int n_channels, int L, int M, ddn_resampler** out); /* 1 <= L <= 512, 1 <= M <= 2^22 */
 void ddn_resampler_destroy(ddn_resampler* b);
 int ddn_resampler_reset(ddn_resampler* b, void* hip_stream);                 /* == dsd_resampler_clear_history */
 size_t ddn_resampler_out_len(const ddn_resampler* b, size_t n);              /* outputs the next run of n inputs gives */

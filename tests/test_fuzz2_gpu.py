@@ -1,0 +1,131 @@
+"""GPU differential fuzz, second set: the Gardner loop, the rational resampler, the P25 slicer and the IQ-conditioned
+front end on random shapes and call splits, bit-exact against the oracle.  DDN_FUZZ_BASE=<k> shifts the seeds."""
+import os
+
+import numpy as np
+import pytest
+
+import ddn
+import orc
+from test_iqcond_gpu import impaired_cu8
+from test_resampler_gpu import GpuResampler
+from test_slicer_gpu import GpuSlicer
+from test_ted_gpu import GpuTed
+
+pytestmark = pytest.mark.gpu
+
+BASE = int(os.environ.get("DDN_FUZZ_BASE", "0"))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def random_cuts(rng, n, k, lo=1):
+    """k call boundaries inside (0, n), each call at least `lo` long."""
+    if n <= 2 * lo:
+        return [0, n]
+    inner = sorted(set(int(v) for v in rng.integers(lo, n - lo, k)))
+    cuts = [0]
+    for v in inner:
+        if v - cuts[-1] >= lo:
+            cuts.append(v)
+    if n - cuts[-1] < lo:
+        cuts.pop()
+    return cuts + [n]
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gardner_random(built, seed):
+    rng = np.random.default_rng(4000 + seed + 7919 * BASE)
+    sps = int(rng.choice([2, 3, 4, 5, 8, 10, 12, 20, 23, 24, 25]))
+    rate = int(rng.choice([4800, 6000]))
+    B = int(rng.integers(1, 150))
+    n_sym = int(rng.integers(30, 400))
+    iq = orc.synth_qpsk_f32(int(rng.integers(0, 10000)), B, n_sym, sps, drift=float(rng.choice([1.0005, 0.9993, 1.002])),
+                            noise=float(rng.choice([0.02, 0.1, 0.4])))
+    n = iq.shape[1]
+    if rng.integers(0, 3) == 0:
+        iq[int(rng.integers(0, B)), n // 3: n // 3 + 25] = np.nan
+    cuts = random_cuts(rng, n, int(rng.integers(0, 5)))
+    t = GpuTed(B, sps, rate)
+    got = [t.run(iq[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    for c in range(B):
+        o = orc.OracleTed(sps, rate)
+        for (a, b), g in zip(zip(cuts[:-1], cuts[1:]), got):
+            want = o.block(iq[c, a:b])
+            assert np.array_equal(bits(g[c]), bits(want)), (seed, sps, rate, B, c, a, b, cuts)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_resampler_random(built, seed):
+    rng = np.random.default_rng(5000 + seed + 7919 * BASE)
+    L = int(rng.integers(1, 40))
+    M = int(rng.integers(1, 40))
+    B = int(rng.integers(1, 50))
+    n = int(rng.integers(1, 6000))
+    x = (rng.normal(0, 9000, (B, n)) + 12000 * np.sin(np.arange(n) * 0.07)).astype(np.float32)
+    cuts = random_cuts(rng, n, int(rng.integers(0, 6)))
+    g = GpuResampler(B, L, M)
+    got = [g.run(x[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    for c in range(B):
+        o = orc.OracleResampler(L, M)
+        for (a, b), gg in zip(zip(cuts[:-1], cuts[1:]), got):
+            want = o.run(x[c, a:b])
+            assert gg.shape[1] == len(want), (seed, L, M, c, a, b)
+            assert np.array_equal(bits(gg[c]), bits(want)), (seed, L, M, c, a, b, cuts)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_slicer_random(built, seed):
+    rng = np.random.default_rng(6000 + seed + 7919 * BASE)
+    B = int(rng.integers(1, 80))
+    n = int(rng.integers(1, 4500))
+    neg = int(rng.integers(0, 2))
+    sym = np.stack([orc.synth_c4fm_symbols(int(rng.integers(0, 10000)), n, scale=float(rng.uniform(0.05, 1.4)),
+                                           noise=float(rng.choice([50, 500, 3000]))) for _ in range(B)])
+    if rng.integers(0, 3) == 0:
+        sym[int(rng.integers(0, B)), n // 2:] = 0.0
+    cuts = random_cuts(rng, n, int(rng.integers(0, 7)))
+    s = GpuSlicer(B, neg)
+    got = np.concatenate([s.run(sym[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])], axis=1)
+    rec, _ = orc.unpack_records10(got)
+    want, thr = orc.oracle_slicer(sym, negative=neg)
+    assert np.array_equal(rec, want), (seed, B, n, neg, cuts)
+    for c in (0, B - 1):
+        assert np.array_equal(s.thresholds(c).view(np.uint32), np.asarray(thr[c], np.float32).view(np.uint32)), (seed, c)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_iq_conditioning_random(built, seed):
+    rng = np.random.default_rng(7000 + seed + 7919 * BASE)
+    dc = int(rng.integers(0, 2))
+    bal = int(rng.integers(0, 2)) if dc else 1
+    sh = int(rng.choice([6, 9, 11, 14]))
+    thr = float(rng.choice([0.0, 0.02, 0.2]))
+    ema = float(rng.choice([0.05, 0.2, 1.0]))
+    sq = float(rng.choice([0.0, 0.0, 0.004]))
+    blk = int(rng.choice([135, 200, 256, 1000, 4096, 8192]))
+    B = int(rng.integers(1, 100))
+    n_calls = int(rng.integers(1, 4))
+    lens = [int(rng.integers(1, 4)) * blk for _ in range(n_calls - 1)] + [int(rng.integers(1, 3 * blk))]
+    n = sum(lens)
+    iq = np.stack([impaired_cu8(int(rng.integers(0, 10000)), n) for _ in range(B)])
+    if sq > 0:
+        iq[:, n // 3: n // 2] = 127
+    b = ddn.Batch(B, block_len=blk, squelch_level=sq)
+    b.set_iq_conditioning(dc, sh, bal, thr, ema)
+    got, pos = [], 0
+    for ln in lens:
+        got.append(b.run_host(iq[:, pos:pos + ln], ln))
+        pos += ln
+    got = np.concatenate(got, axis=1)
+    for c in range(B):
+        fe = orc.OracleFrontEnd(squelch=sq).set_iq_options(dc, sh, bal, thr, ema)
+        want, pos = [], 0
+        for ln in lens:
+            want.append(fe.run_cu8(iq[c, pos:pos + ln], blk))
+            pos += ln
+        want = np.concatenate(want)
+        bad = np.flatnonzero(bits(got[c]) != bits(want))
+        assert len(bad) == 0, (seed, c, dc, sh, bal, thr, ema, sq, blk, lens, bad[:5])

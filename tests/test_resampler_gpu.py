@@ -59,9 +59,13 @@ def test_resampler_errors(built):
     h = C.c_void_p()
     assert ddn.lib().ddn_resampler_create(4, 0, 1, C.byref(h)) != 0
     assert ddn.lib().ddn_resampler_create(4, 513, 1, C.byref(h)) != 0
-    assert ddn.lib().ddn_resampler_create(4, 1, 200, C.byref(h)) == -5     # input span of 1024 outputs exceeds the LDS budget
-    g35 = GpuResampler(2, 1, 30)                                          # the largest plain decimations still fit
-    assert g35.run(np.ones((2, 3000), np.float32)).shape[1] == 100
+    assert ddn.lib().ddn_resampler_create(4, 1, (1 << 22) + 1, C.byref(h)) != 0
+    for L, M in ((1, 30), (1, 200), (3, 1000), (512, 511), (512, 40000)):  # steep decimations shrink the workgroup's output tile
+        g35 = GpuResampler(2, L, M)
+        x = np.sin(np.arange(50000) * 0.01).astype(np.float32) * np.ones((2, 1), np.float32)
+        got = g35.run(x)
+        want = orc.OracleResampler(L, M).run(x[0])
+        assert got.shape[1] == len(want) and np.array_equal(bits(got[1]), bits(want)), (L, M)
     g = GpuResampler(2, 3, 2)
     x = np.ones((2, 100), np.float32)
     out = np.zeros((2, 10), np.float32)
