@@ -2,6 +2,9 @@
 import ctypes as C
 
 import numpy as np
+
+import os as _os
+FZ = 7919 * int(_os.environ.get("DDN_FUZZ_BASE", "0"))  # seed shift for long sweeps
 import pytest
 
 import ddn
@@ -27,7 +30,7 @@ def test_nid_golden_and_fresh(built):
     obs = np.ascontiguousarray(g["obs"], np.int32)
     assert np.array_equal(gpu_nid(g["bits"], g["rel"], obs, g["parity"], g["parity_rel"]), g["out_soft"])
     assert np.array_equal(gpu_nid(g["bits"], None, obs, g["parity"], g["parity_rel"]), g["out_hard"])
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(FZ + 31)
     for n, thr in ((1, 64), (65, 64), (3000, 40), (500, 200)):
         bits, rel, obs, par, prel = fecgen.gen_nid(rng, n, max_err=16)
         rel[: n // 4] = rng.integers(0, 256, (n // 4, 63))  # ties / everything below threshold

@@ -6,6 +6,9 @@ import json
 import os
 
 import numpy as np
+
+import os as _os
+FZ = 7919 * int(_os.environ.get("DDN_FUZZ_BASE", "0"))  # seed shift for long sweeps
 import pytest
 
 import ddn
@@ -59,7 +62,7 @@ def test_p25_half_rate(built):
     g = golden("fec_p25_half_rate.npz")
     out, met = gpu_p25(g["llr"])
     assert np.array_equal(out, g["out"]) and np.array_equal(met, g["metric"])
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(FZ + 11)
     for n in (1, 63, 65, 1000):
         llr, _ = fecgen.gen_p25_half_rate(rng, n, sigma=500.0)
         llr[0, :] = 0          # all-erasure block: every tie-break in play
@@ -77,7 +80,7 @@ def test_r34(built):
     kat = json.load(open(os.path.join(HERE, "golden", "kat_r34_reference_vectors.json")))
     d = np.array([k["dibits"] for k in kat], np.uint8)
     assert np.array_equal(gpu_r34(d), np.array([k["payload"] for k in kat], np.uint8))
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(FZ + 12)
     for n in (1, 31, 33, 700):
         d, rel, _ = fecgen.gen_r34(rng, n, p_err=0.1)
         rel[0, :] = 0
@@ -91,7 +94,7 @@ def test_nxdn_conv(built):
         steps, nbits, soft = [int(x) for x in g[name + "_cfg"]]
         out, _ = gpu_nxdn(g[name + "_sym"], g[name + "_rel"] if soft else None, steps, nbits)
         assert np.array_equal(out, g[name + "_out"]), name
-    rng = np.random.default_rng(13)
+    rng = np.random.default_rng(FZ + 13)
     for n, steps, nbits in ((1, 36, 32), (17, 96, 96), (500, 182, 178)):
         sym, rel = fecgen.gen_nxdn(rng, n, steps, p_err=0.1)
         m0 = rng.integers(0, 65536, (n, 16)).astype(np.uint16)  # wrapped metrics carried in
@@ -107,7 +110,7 @@ def test_viterbi_k5(built):
         punct = g[name + "_punct"] if g[name + "_punct"].size else None
         out, cost = gpu_m17(g[name + "_soft"], punct, g[name + "_out"].shape[1])
         assert np.array_equal(out, g[name + "_out"]) and np.array_equal(cost, g[name + "_cost"]), name
-    rng = np.random.default_rng(14)
+    rng = np.random.default_rng(FZ + 14)
     p1 = np.array([1] * 60 + [0], np.uint8)
     for n, in_len, punct in ((1, 488, None), (33, 96, None), (400, 368, p1)):
         soft = fecgen.gen_m17(rng, n, in_len, sigma=20000.0)
@@ -118,7 +121,7 @@ def test_viterbi_k5(built):
 
 def test_dropin_symbols(built):
     l = ddn.lib()
-    rng = np.random.default_rng(15)
+    rng = np.random.default_rng(FZ + 15)
     llr, _ = fecgen.gen_p25_half_rate(rng, 4)
     wo, wm = fecgen.oracle_p25_half_rate(llr)
     for i in range(4):
@@ -155,7 +158,7 @@ def test_dropin_symbols(built):
 def test_device_pointer_batch_at_scale(built):
     """C3-scale batch on device pointers: 4096 channels x 26 TSBK-sized blocks, determinism + oracle sample."""
     import torch
-    rng = np.random.default_rng(16)
+    rng = np.random.default_rng(FZ + 16)
     n = 4096 * 26
     llr, _ = fecgen.gen_p25_half_rate(rng, 4096, sigma=500.0)
     big = np.tile(llr, (26, 1))
@@ -176,7 +179,7 @@ def test_p25_half_rate_list(built):
     """List variant: 8 survivors per state, candidates identical (bytes, metric, order, count) to the oracle, which is
     pinned to p25_12_soft_llr_list of the compiled reference."""
     import ctypes as C
-    rng = np.random.default_rng(91)
+    rng = np.random.default_rng(FZ + 91)
     llr, _ = fecgen.gen_p25_half_rate(rng, 3000, sigma=500.0, random_frac=0.3)
     llr[5] = 0
     llr[6] = 32767
@@ -205,7 +208,7 @@ def test_p25_half_rate_list(built):
 def test_r34_list(built, weighted):
     """3/4-rate list decoder (32 survivors/state) vs the oracle pinned to dmr_r34_viterbi_decode_list."""
     import ctypes as C
-    rng = np.random.default_rng(93 + weighted)
+    rng = np.random.default_rng(FZ + 93 + weighted)
     d, rel, _ = fecgen.gen_r34(rng, 600, p_err=0.06, random_frac=0.3)
     rel[3] = 0
     rel[4] = 255

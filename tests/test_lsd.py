@@ -4,6 +4,9 @@ LDU gather of the two LSD codewords."""
 import ctypes as C
 
 import numpy as np
+
+import os as _os
+FZ = 7919 * int(_os.environ.get("DDN_FUZZ_BASE", "0"))  # seed shift for long sweeps
 import pytest
 
 import ddn
@@ -25,7 +28,7 @@ def codeword(d):
 
 
 def cases(seed, n):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(FZ + seed)
     bits = np.zeros((n, 16), np.uint8)
     llr = np.zeros((n, 16), np.int16)
     for i in range(n):
@@ -101,7 +104,7 @@ def test_lsd_layout(built):
 
 # ---- CRC-CCITT16 of trunking blocks (src/protocol/p25/p25_crc.c:18-76) ---------------------------------------------------------
 def _crc_cases(seed, n, nbytes=12):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(FZ + seed)
     b = rng.integers(0, 256, (n, nbytes), dtype=np.uint8)
     o = orc.oracle()
     o.orc_p25_crc16_ok.argtypes = [C.c_void_p, C.c_int]

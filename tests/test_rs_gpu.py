@@ -4,6 +4,9 @@ through the batch entry points and the reference-named single-codeword drop-ins.
 import ctypes as C
 
 import numpy as np
+
+import os as _os
+FZ = 7919 * int(_os.environ.get("DDN_FUZZ_BASE", "0"))  # seed shift for long sweeps
 import pytest
 
 import ddn
@@ -16,7 +19,7 @@ CODE_ID = {"24_12_13": 0, "24_16_9": 1, "36_20_17": 2}
 
 @pytest.mark.parametrize("length", [6, 12])
 def test_golay_batch(built, length):
-    rng = np.random.default_rng(40 + length)
+    rng = np.random.default_rng(FZ + 40 + length)
     d, p = fecgen.gen_golay24(rng, 20000, length)
     d[:2000] = rng.integers(0, 2, (2000, length))
     p[:2000] = rng.integers(0, 2, (2000, 12))
@@ -33,7 +36,7 @@ def test_golay_batch(built, length):
 
 @pytest.mark.parametrize("code", list(fecgen.P25_RS_CODES))
 def test_rs_batch(built, code):
-    rng = np.random.default_rng(50 + CODE_ID[code])
+    rng = np.random.default_rng(FZ + 50 + CODE_ID[code])
     d, p = fecgen.gen_p25_rs(rng, code, 5000, max_extra=4)
     d[:300] = rng.integers(0, 2, d[:300].shape)
     p[:300] = rng.integers(0, 2, p[:300].shape)
@@ -50,7 +53,7 @@ def test_rs_batch(built, code):
 
 
 def test_dropin_names(built):
-    rng = np.random.default_rng(60)
+    rng = np.random.default_rng(FZ + 60)
     l = ddn.lib()
     for length, fn in ((6, l.check_and_fix_golay_24_6), (12, l.check_and_fix_golay_24_12)):
         d, p = fecgen.gen_golay24(rng, 12, length)
@@ -72,7 +75,7 @@ def test_dropin_names(built):
 
 def test_hamming_soft_batch(built):
     from test_oracle_rs import gen_soft_reliab, oracle_hamming_soft
-    rng = np.random.default_rng(71)
+    rng = np.random.default_rng(FZ + 71)
     n = 20000
     d = rng.integers(0, 2, (n, 6)).astype(np.uint8)
     p = np.stack([d[:, 0] ^ d[:, 1] ^ d[:, 2] ^ d[:, 5], d[:, 0] ^ d[:, 1] ^ d[:, 3] ^ d[:, 5],
@@ -95,7 +98,7 @@ def test_hamming_soft_batch(built):
 @pytest.mark.parametrize("length", [6, 12])
 def test_golay_soft_batch(built, length):
     from test_oracle_rs import gen_soft_reliab, oracle_golay_soft
-    rng = np.random.default_rng(73 + length)
+    rng = np.random.default_rng(FZ + 73 + length)
     n = 6000
     d = np.zeros((n, length), np.uint8)
     p = np.zeros((n, 12), np.uint8)
@@ -128,7 +131,7 @@ def test_golay_soft_batch(built, length):
 def test_rs_soft_reliability_batch(built, code):
     """Hard decode, then ranked-erasure retries: data and status equal the oracle pinned to p25p1_rs_*_soft_reliability."""
     from test_oracle_rs import gen_rs_soft, oracle_rs_soft_rel
-    rng = np.random.default_rng(400 + CODE_ID[code])
+    rng = np.random.default_rng(FZ + 400 + CODE_ID[code])
     d, p, drel, prel = gen_rs_soft(rng, code, 4000)
     want, wrc = oracle_rs_soft_rel(code, d, p, drel, prel)
     got = d.copy()
