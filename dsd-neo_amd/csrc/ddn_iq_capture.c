@@ -18,6 +18,7 @@
 #define _POSIX_C_SOURCE 200809L
 #include <ctype.h>
 #include <errno.h>
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,200 +34,284 @@ struct ddn_iq_capture {
     uint64_t pos;
 };
 
-/* ---- a small JSON scanner: enough for one flat object whose values are strings, integers, booleans, null and one
- * array of flat objects ("events") ---------------------------------------------------------------------------------- */
+/* ---- JSON tokenizer with the grammar of the reference's (src/io/iq/iq_replay.c:226-523): whitespace is exactly
+ * space / tab / LF / CR; strings refuse raw control bytes, take the eight short escapes and \uXXXX for 0x01..0x7f only,
+ * and are limited by a 4096-byte buffer; numbers follow RFC 8259 (no leading zeros, digits required after '.', 'e');
+ * true / false / null match as prefixes.  The first error is sticky. --------------------------------------------------- */
+enum { T_ERR = -1, T_EOF, T_LBRACE, T_RBRACE, T_LBRACKET, T_RBRACKET, T_COMMA, T_COLON, T_STR, T_INT, T_FLOAT, T_TRUE,
+       T_FALSE, T_NULL };
+
 typedef struct {
     const char* s;
     size_t n, p;
+    int err;
+    char buf[4096];
 } scan;
 
-static void
-ws(scan* k) {
-    while (k->p < k->n && isspace((unsigned char)k->s[k->p])) {
-        k->p++;
-    }
+typedef struct {
+    int type;
+    size_t str_len; /* T_STR: bytes in scan.buf (NUL-terminated) */
+    const char* num; /* T_INT / T_FLOAT: the literal */
+    size_t num_len;
+} token;
+
+static int
+is_dig(char c) {
+    return c >= '0' && c <= '9';
 }
 
 static int
-lit(scan* k, const char* w) {
-    const size_t m = strlen(w);
-    if (k->p + m <= k->n && memcmp(k->s + k->p, w, m) == 0) {
-        k->p += m;
-        return 1;
-    }
-    return 0;
-}
-
-static int
-str(scan* k, char* out, size_t cap) {
-    ws(k);
-    if (k->p >= k->n || k->s[k->p] != '"') {
-        return -1;
-    }
-    k->p++;
+tok_string(scan* k, token* t) {
     size_t o = 0;
-    while (k->p < k->n && k->s[k->p] != '"') {
+    k->p++;
+    while (k->p < k->n) {
         unsigned char c = (unsigned char)k->s[k->p++];
         if (c < 0x20) {
-            return -1; /* unescaped control character (the reference's tokenizer refuses it too) */
+            return 0;
+        }
+        if (c == '"') {
+            k->buf[o] = 0;
+            t->type = T_STR;
+            t->str_len = o;
+            return 1;
         }
         if (c == '\\') {
             if (k->p >= k->n) {
-                return -1;
+                return 0;
             }
             const char e = k->s[k->p++];
             switch (e) {
                 case '"': c = '"'; break;
                 case '\\': c = '\\'; break;
                 case '/': c = '/'; break;
-                case 'n': c = '\n'; break;
-                case 't': c = '\t'; break;
-                case 'r': c = '\r'; break;
                 case 'b': c = '\b'; break;
                 case 'f': c = '\f'; break;
-                case 'u': { /* only 7-bit code points other than NUL are accepted, as in the reference */
+                case 'n': c = '\n'; break;
+                case 'r': c = '\r'; break;
+                case 't': c = '\t'; break;
+                case 'u': {
                     if (k->p + 4 > k->n) {
-                        return -1;
+                        return 0;
                     }
                     unsigned v = 0;
                     for (int i = 0; i < 4; i++) {
-                        const char h = k->s[k->p++];
+                        const char h = k->s[k->p + i];
                         if (!isxdigit((unsigned char)h)) {
-                            return -1;
+                            return 0;
                         }
-                        v = v * 16 + (unsigned)(isdigit((unsigned char)h) ? h - '0' : (tolower(h) - 'a' + 10));
+                        v = v * 16 + (unsigned)(is_dig(h) ? h - '0' : (tolower((unsigned char)h) - 'a' + 10));
                     }
                     if (v == 0 || v > 0x7F) {
-                        return -1;
+                        return 0;
                     }
+                    k->p += 4;
                     c = (unsigned char)v;
                     break;
                 }
-                default: return -1; /* not a JSON escape */
+                default: return 0;
             }
         }
-        if (o + 1 >= cap) {
-            return -2; /* too long for the field */
-        }
-        out[o++] = (char)c;
-    }
-    if (k->p >= k->n) {
-        return -1;
-    }
-    k->p++;
-    out[o] = 0;
-    return 0;
-}
-
-static int
-u64v(scan* k, uint64_t* out, int* negative) {
-    ws(k);
-    int neg = 0;
-    if (k->p < k->n && k->s[k->p] == '-') {
-        neg = 1;
-        k->p++;
-    }
-    if (k->p >= k->n || !isdigit((unsigned char)k->s[k->p])) {
-        return -1;
-    }
-    uint64_t v = 0;
-    while (k->p < k->n && isdigit((unsigned char)k->s[k->p])) {
-        const uint64_t d = (uint64_t)(k->s[k->p] - '0');
-        if (v > (UINT64_MAX - d) / 10) {
-            return -1;
-        }
-        v = v * 10 + d;
-        k->p++;
-    }
-    if (k->p < k->n && (k->s[k->p] == '.' || k->s[k->p] == 'e' || k->s[k->p] == 'E')) {
-        return -1; /* the fields this reader takes are integers */
-    }
-    *out = v;
-    *negative = neg;
-    return 0;
-}
-
-static int skip_value(scan* k, int depth);
-
-static int
-skip_container(scan* k, char close, int depth) {
-    k->p++;
-    ws(k);
-    if (k->p < k->n && k->s[k->p] == close) {
-        k->p++;
-        return 0;
-    }
-    for (;;) {
-        if (close == '}') {
-            char key[256];
-            if (str(k, key, sizeof(key)) == -1) {
-                return -1;
-            }
-            ws(k);
-            if (k->p >= k->n || k->s[k->p++] != ':') {
-                return -1;
-            }
-        }
-        if (skip_value(k, depth + 1) != 0) {
-            return -1;
-        }
-        ws(k);
-        if (k->p >= k->n) {
-            return -1;
-        }
-        const char c = k->s[k->p++];
-        if (c == close) {
+        if (o + 1 >= sizeof(k->buf)) {
             return 0;
         }
-        if (c != ',') {
-            return -1;
-        }
+        k->buf[o++] = (char)c;
     }
+    return 0; /* unterminated */
 }
 
 static int
-skip_value(scan* k, int depth) {
-    ws(k);
-    if (k->p >= k->n || depth > 16) {
-        return -1;
+tok_number(scan* k, token* t) {
+    const size_t start = k->p;
+    size_t p = k->p;
+    int is_float = 0;
+    if (k->s[p] == '-') {
+        p++;
+        if (p >= k->n || !is_dig(k->s[p])) {
+            return 0;
+        }
+    }
+    if (p < k->n && k->s[p] == '0') {
+        p++;
+    } else {
+        if (p >= k->n || !is_dig(k->s[p])) {
+            return 0;
+        }
+        while (p < k->n && is_dig(k->s[p])) {
+            p++;
+        }
+    }
+    if (p < k->n && k->s[p] == '.') {
+        is_float = 1;
+        p++;
+        if (p >= k->n || !is_dig(k->s[p])) {
+            return 0;
+        }
+        while (p < k->n && is_dig(k->s[p])) {
+            p++;
+        }
+    }
+    if (p < k->n && (k->s[p] == 'e' || k->s[p] == 'E')) {
+        is_float = 1;
+        p++;
+        if (p < k->n && (k->s[p] == '+' || k->s[p] == '-')) {
+            p++;
+        }
+        if (p >= k->n || !is_dig(k->s[p])) {
+            return 0;
+        }
+        while (p < k->n && is_dig(k->s[p])) {
+            p++;
+        }
+    }
+    t->type = is_float ? T_FLOAT : T_INT;
+    t->num = k->s + start;
+    t->num_len = p - start;
+    k->p = p;
+    return 1;
+}
+
+static token
+next_tok(scan* k) {
+    token t;
+    memset(&t, 0, sizeof(t));
+    t.type = T_ERR;
+    if (k->err) {
+        return t;
+    }
+    while (k->p < k->n && (k->s[k->p] == ' ' || k->s[k->p] == '\t' || k->s[k->p] == '\n' || k->s[k->p] == '\r')) {
+        k->p++;
+    }
+    if (k->p >= k->n) {
+        t.type = T_EOF;
+        return t;
     }
     const char c = k->s[k->p];
-    if (c == '"') {
-        char tmp[4096];
-        const int r = str(k, tmp, sizeof(tmp));
-        return r == -1 ? -1 : 0;
+    int simple = T_ERR;
+    switch (c) {
+        case '{': simple = T_LBRACE; break;
+        case '}': simple = T_RBRACE; break;
+        case '[': simple = T_LBRACKET; break;
+        case ']': simple = T_RBRACKET; break;
+        case ',': simple = T_COMMA; break;
+        case ':': simple = T_COLON; break;
+        default: break;
     }
-    if (c == '{') {
-        return skip_container(k, '}', depth);
-    }
-    if (c == '[') {
-        return skip_container(k, ']', depth);
-    }
-    if (lit(k, "true") || lit(k, "false") || lit(k, "null")) {
-        return 0;
-    }
-    if (c == '-' || isdigit((unsigned char)c)) {
+    if (simple != T_ERR) {
         k->p++;
-        while (k->p < k->n && (isdigit((unsigned char)k->s[k->p]) || strchr("+-.eE", k->s[k->p]))) {
-            k->p++;
-        }
-        return 0;
+        t.type = simple;
+        return t;
     }
-    return -1;
+    int ok = 0;
+    if (c == '"') {
+        ok = tok_string(k, &t);
+    } else if (c == '-' || is_dig(c)) {
+        ok = tok_number(k, &t);
+    } else if (k->p + 4 <= k->n && memcmp(k->s + k->p, "true", 4) == 0) {
+        k->p += 4;
+        t.type = T_TRUE;
+        ok = 1;
+    } else if (k->p + 5 <= k->n && memcmp(k->s + k->p, "false", 5) == 0) {
+        k->p += 5;
+        t.type = T_FALSE;
+        ok = 1;
+    } else if (k->p + 4 <= k->n && memcmp(k->s + k->p, "null", 4) == 0) {
+        k->p += 4;
+        t.type = T_NULL;
+        ok = 1;
+    }
+    if (!ok) {
+        k->err = 1;
+        t.type = T_ERR;
+    }
+    return t;
+}
+
+/* string value into a field of `cap` bytes (copy_token_to_buffer, iq_replay.c:530-553): too long or, for every field
+ * but "notes", a control byte that came in through an escape -> invalid metadata */
+static int
+tok_to_str(const scan* k, const token* t, char* out, size_t cap, int reject_controls) {
+    if (t->type != T_STR || t->str_len + 1 > cap) {
+        return -1;
+    }
+    if (reject_controls) {
+        for (size_t i = 0; i < t->str_len; i++) {
+            if ((unsigned char)k->buf[i] < 0x20) {
+                return -1;
+            }
+        }
+    }
+    memcpy(out, k->buf, t->str_len);
+    out[t->str_len] = 0;
+    return 0;
+}
+
+/* token_to_u64 / token_to_u32 / token_to_i32 (iq_replay.c:555-621): integer tokens of at most 63 characters through
+ * strtoull / strtol */
+static int
+tok_to_u64(const token* t, uint64_t* out, uint64_t max) {
+    char b[64];
+    if (t->type != T_INT || t->num_len == 0 || t->num_len >= sizeof(b) || t->num[0] == '-') {
+        return -1;
+    }
+    memcpy(b, t->num, t->num_len);
+    b[t->num_len] = 0;
+    errno = 0;
+    char* end = NULL;
+    const unsigned long long v = strtoull(b, &end, 10);
+    if (errno != 0 || !end || *end || v > max) {
+        return -1;
+    }
+    *out = (uint64_t)v;
+    return 0;
 }
 
 static int
-boolv(scan* k, int* out) {
-    ws(k);
-    if (lit(k, "true")) {
-        *out = 1;
+tok_to_i32(const token* t, int* out) {
+    char b[64];
+    if (t->type != T_INT || t->num_len == 0 || t->num_len >= sizeof(b)) {
+        return -1;
+    }
+    memcpy(b, t->num, t->num_len);
+    b[t->num_len] = 0;
+    errno = 0;
+    char* end = NULL;
+    const long v = strtol(b, &end, 10);
+    if (errno != 0 || !end || *end || v < INT_MIN || v > INT_MAX) {
+        return -1;
+    }
+    *out = (int)v;
+    return 0;
+}
+
+static int
+tok_to_bool(const token* t, int* out) {
+    if (t->type != T_TRUE && t->type != T_FALSE) {
+        return -1;
+    }
+    *out = t->type == T_TRUE;
+    return 0;
+}
+
+/* "key" ':' value-token of an object, or its closing brace (a trailing comma before '}' is accepted, as in
+ * metadata_parse_key_value / parse_event_key_value).  Returns 1 = pair read, 0 = object closed, -1 = malformed. */
+static int
+next_pair(scan* k, char* key, size_t key_cap, token* val) {
+    const token kt = next_tok(k);
+    if (k->err) {
+        return -1;
+    }
+    if (kt.type == T_RBRACE) {
         return 0;
     }
-    if (lit(k, "false")) {
-        *out = 0;
-        return 0;
+    if (kt.type != T_STR || kt.str_len + 1 > key_cap) {
+        return -1;
     }
-    return -1;
+    memcpy(key, k->buf, kt.str_len + 1);
+    if (next_tok(k).type != T_COLON) {
+        return -1;
+    }
+    *val = next_tok(k);
+    return k->err ? -1 : 1;
 }
 
 #define FAIL(code, ...)                                                                                                \
@@ -260,102 +345,83 @@ ddn_iq_effective_bytes(uint64_t data_bytes, uint64_t actual_file_size, int sampl
     return DDN_IQ_OK;
 }
 
+/* the "events" array after its '[' (parse_events_array / parse_event_object, iq_replay.c:958-1058) */
 static int
 parse_events(scan* k, ddn_iq_event** out, uint32_t* count) {
-    ws(k);
-    if (k->p >= k->n || k->s[k->p] != '[') {
-        FAIL(DDN_IQ_ERR_INVALID_META, "events must be an array");
-    }
-    k->p++;
     ddn_iq_event* ev = NULL;
     uint32_t n = 0, cap = 0;
-    ws(k);
-    if (k->p < k->n && k->s[k->p] == ']') {
-        k->p++;
+    token t = next_tok(k);
+    if (t.type == T_RBRACKET) {
         *out = NULL;
         *count = 0;
         return DDN_IQ_OK;
     }
     for (;;) {
-        ws(k);
-        if (k->p >= k->n || k->s[k->p] != '{') {
+        if (t.type != T_LBRACE) {
             free(ev);
             FAIL(DDN_IQ_ERR_INVALID_META, "event %u is not an object", n);
         }
-        k->p++;
         ddn_iq_event e;
         memset(&e, 0, sizeof(e));
-        unsigned seen = 0; /* 1 kind, 2 byte_offset, 4 duration, 8 center, 16 capture center, 32 rate */
-        ws(k);
-        if (k->p < k->n && k->s[k->p] == '}') {
-            k->p++;
-        } else {
-            for (;;) {
-                char key[64];
-                if (str(k, key, sizeof(key)) != 0) {
-                    free(ev);
-                    FAIL(DDN_IQ_ERR_INVALID_META, "bad key in event %u", n);
-                }
-                ws(k);
-                if (k->p >= k->n || k->s[k->p++] != ':') {
-                    free(ev);
-                    FAIL(DDN_IQ_ERR_INVALID_META, "missing ':' in event %u", n);
-                }
-                uint64_t v = 0;
-                int neg = 0, rc = 0;
-                if (!strcmp(key, "kind")) {
-                    char kind[32];
-                    rc = str(k, kind, sizeof(kind));
+        unsigned seen = 0; /* 1 kind, 2 byte_offset, 4 duration, 8 center, 16 capture center, 32 rate, 64 reason */
+        for (;;) {
+            char key[128];
+            token v;
+            const int pr = next_pair(k, key, sizeof(key), &v);
+            if (pr < 0 || (pr > 0 && (v.type == T_LBRACE || v.type == T_LBRACKET))) {
+                free(ev);
+                FAIL(DDN_IQ_ERR_INVALID_META, "malformed field in event %u", n);
+            }
+            if (pr == 0) {
+                break;
+            }
+            uint64_t u = 0;
+            int rc = 0;
+            if (!strcmp(key, "kind")) {
+                char kind[32];
+                rc = tok_to_str(k, &v, kind, sizeof(kind), 1);
+                if (rc == 0) {
                     e.kind = !strcmp(kind, "RETUNE") ? DDN_IQ_EVENT_RETUNE
                                                      : (!strcmp(kind, "MUTE") ? DDN_IQ_EVENT_MUTE
                                                                               : (!strcmp(kind, "RESET") ? DDN_IQ_EVENT_RESET : 0));
-                    if (rc == 0 && e.kind == 0) {
-                        rc = -1;
-                    }
-                    seen |= 1;
-                } else if (!strcmp(key, "reason")) {
-                    rc = str(k, e.reason, sizeof(e.reason)) == -1 ? -1 : 0;
-                    seen |= 64;
-                } else if (!strcmp(key, "byte_offset")) {
-                    rc = u64v(k, &v, &neg) || neg;
-                    e.byte_offset = v;
-                    seen |= 2;
-                } else if (!strcmp(key, "duration_bytes")) {
-                    rc = u64v(k, &v, &neg) || neg;
-                    e.duration_bytes = v;
-                    seen |= 4;
-                } else if (!strcmp(key, "center_frequency_hz")) {
-                    rc = u64v(k, &v, &neg) || neg;
-                    e.center_frequency_hz = v;
-                    seen |= 8;
-                } else if (!strcmp(key, "capture_center_frequency_hz")) {
-                    rc = u64v(k, &v, &neg) || neg;
-                    e.capture_center_frequency_hz = v;
-                    seen |= 16;
-                } else if (!strcmp(key, "sample_rate_hz")) {
-                    rc = u64v(k, &v, &neg) || neg || v > 0xFFFFFFFFu;
-                    e.sample_rate_hz = (uint32_t)v;
-                    seen |= 32;
-                } else {
-                    rc = skip_value(k, 0);
+                    rc = e.kind == 0 ? -1 : 0;
                 }
-                if (rc != 0) {
-                    free(ev);
-                    FAIL(DDN_IQ_ERR_INVALID_META, "bad value for '%s' in event %u", key, n);
-                }
-                ws(k);
-                if (k->p >= k->n) {
-                    free(ev);
-                    FAIL(DDN_IQ_ERR_INVALID_META, "unterminated event %u", n);
-                }
-                const char c = k->s[k->p++];
-                if (c == '}') {
-                    break;
-                }
-                if (c != ',') {
-                    free(ev);
-                    FAIL(DDN_IQ_ERR_INVALID_META, "bad delimiter in event %u", n);
-                }
+                seen |= 1;
+            } else if (!strcmp(key, "reason")) {
+                rc = tok_to_str(k, &v, e.reason, sizeof(e.reason), 1);
+                seen |= 64;
+            } else if (!strcmp(key, "byte_offset")) {
+                rc = tok_to_u64(&v, &u, UINT64_MAX);
+                e.byte_offset = u;
+                seen |= 2;
+            } else if (!strcmp(key, "duration_bytes")) {
+                rc = tok_to_u64(&v, &u, UINT64_MAX);
+                e.duration_bytes = u;
+                seen |= 4;
+            } else if (!strcmp(key, "center_frequency_hz")) {
+                rc = tok_to_u64(&v, &u, UINT64_MAX);
+                e.center_frequency_hz = u;
+                seen |= 8;
+            } else if (!strcmp(key, "capture_center_frequency_hz")) {
+                rc = tok_to_u64(&v, &u, UINT64_MAX);
+                e.capture_center_frequency_hz = u;
+                seen |= 16;
+            } else if (!strcmp(key, "sample_rate_hz")) {
+                rc = tok_to_u64(&v, &u, 0xFFFFFFFFull);
+                e.sample_rate_hz = (uint32_t)u;
+                seen |= 32;
+            } /* any other key: whatever single token followed the colon is ignored, as in the reference */
+            if (rc != 0) {
+                free(ev);
+                FAIL(DDN_IQ_ERR_INVALID_META, "bad value for '%s' in event %u", key, n);
+            }
+            const token d = next_tok(k);
+            if (d.type == T_RBRACE) {
+                break;
+            }
+            if (d.type != T_COMMA) {
+                free(ev);
+                FAIL(DDN_IQ_ERR_INVALID_META, "bad delimiter in event %u", n);
             }
         }
         /* validate_event_object_fields, src/io/iq/iq_replay.c:935-958 */
@@ -368,27 +434,24 @@ parse_events(scan* k, ddn_iq_event** out, uint32_t* count) {
         }
         if (n == cap) {
             cap = cap ? cap * 2 : 8;
-            ddn_iq_event* t = (ddn_iq_event*)realloc(ev, sizeof(*t) * cap);
-            if (!t) {
+            ddn_iq_event* t2 = (ddn_iq_event*)realloc(ev, sizeof(*t2) * cap);
+            if (!t2) {
                 free(ev);
                 FAIL(DDN_IQ_ERR_ALLOC, "out of memory");
             }
-            ev = t;
+            ev = t2;
         }
         ev[n++] = e;
-        ws(k);
-        if (k->p >= k->n) {
-            free(ev);
-            FAIL(DDN_IQ_ERR_INVALID_META, "unterminated events array");
+        t = next_tok(k);
+        if (t.type == T_COMMA) {
+            t = next_tok(k);
+            continue;
         }
-        const char c = k->s[k->p++];
-        if (c == ']') {
+        if (t.type == T_RBRACKET) {
             break;
         }
-        if (c != ',') {
-            free(ev);
-            FAIL(DDN_IQ_ERR_INVALID_META, "bad delimiter in events array");
-        }
+        free(ev);
+        FAIL(DDN_IQ_ERR_INVALID_META, "bad delimiter in events array");
     }
     *out = ev;
     *count = n;
@@ -398,9 +461,14 @@ parse_events(scan* k, ddn_iq_event** out, uint32_t* count) {
 static int
 parse_metadata(const char* text, size_t len, ddn_iq_capture_info* c, ddn_iq_event** events, char* data_file,
                size_t data_file_cap) {
-    scan k = {text, len, 0};
-    char format[32] = "", sfmt[16] = "", order[8] = "", endian[16] = "";
-    char junk[2048];
+    scan* kp = (scan*)calloc(1, sizeof(scan));
+    if (!kp) {
+        FAIL(DDN_IQ_ERR_ALLOC, "out of memory");
+    }
+    kp->s = text;
+    kp->n = len;
+    char format[64] = "", sfmt[32] = "", order[16] = "", endian[16] = "";
+    char backend[32], args[256], started[64], notes[256];
     int version = 0, combine_rotate = 1, have_events = 0;
     unsigned long long seen = 0;
     static const char* const req[] = {"format", "version", "sample_format", "iq_order", "endianness", "capture_stage",
@@ -412,145 +480,148 @@ parse_metadata(const char* text, size_t len, ddn_iq_capture_info* c, ddn_iq_even
                                       "data_file", "data_bytes", "capture_drops", "capture_drop_blocks",
                                       "input_ring_drops", "notes"};
     const int n_req = (int)(sizeof(req) / sizeof(req[0]));
-    ws(&k);
-    if (k.p >= k.n || k.s[k.p] != '{') {
-        FAIL(DDN_IQ_ERR_INVALID_META, "metadata is not a JSON object");
+#define BAIL(code, ...)                                                                                                \
+    do {                                                                                                               \
+        free(kp);                                                                                                      \
+        FAIL(code, __VA_ARGS__);                                                                                       \
+    } while (0)
+    if (next_tok(kp).type != T_LBRACE) {
+        BAIL(DDN_IQ_ERR_INVALID_META, "metadata is not a JSON object");
     }
-    k.p++;
-    ws(&k);
-    if (k.p < k.n && k.s[k.p] == '}') {
-        k.p++;
-    } else {
-        for (;;) {
-            char key[64];
-            if (str(&k, key, sizeof(key)) != 0) {
-                FAIL(DDN_IQ_ERR_INVALID_META, "bad key at offset %zu", k.p);
+    for (;;) {
+        char key[128];
+        token v;
+        const int pr = next_pair(kp, key, sizeof(key), &v);
+        if (pr < 0) {
+            BAIL(DDN_IQ_ERR_INVALID_META, "malformed key / value near offset %zu", kp->p);
+        }
+        if (pr == 0) {
+            break;
+        }
+        for (int i = 0; i < n_req; i++) {
+            if (!strcmp(key, req[i])) {
+                seen |= 1ull << i;
             }
-            ws(&k);
-            if (k.p >= k.n || k.s[k.p++] != ':') {
-                FAIL(DDN_IQ_ERR_INVALID_META, "missing ':' after '%s'", key);
-            }
-            for (int i = 0; i < n_req; i++) {
-                if (!strcmp(key, req[i])) {
-                    seen |= 1ull << i;
-                }
-            }
-            uint64_t v = 0;
-            int neg = 0, rc = 0, b = 0;
-#define STR(field, cap) (rc = str(&k, field, cap))
+        }
+        uint64_t u = 0;
+        int rc = 0, b = 0;
+#define STR(field, cap) (rc = tok_to_str(kp, &v, field, cap, 1))
 #define U64(dst)                                                                                                       \
     do {                                                                                                               \
-        rc = u64v(&k, &v, &neg) || neg;                                                                                \
-        (dst) = v;                                                                                                     \
+        rc = tok_to_u64(&v, &u, UINT64_MAX);                                                                           \
+        (dst) = u;                                                                                                     \
     } while (0)
 #define U32(dst)                                                                                                       \
     do {                                                                                                               \
-        rc = u64v(&k, &v, &neg) || neg || v > 0xFFFFFFFFull;                                                           \
-        (dst) = (uint32_t)v;                                                                                           \
+        rc = tok_to_u64(&v, &u, 0xFFFFFFFFull);                                                                        \
+        (dst) = (uint32_t)u;                                                                                           \
     } while (0)
-#define I32(dst)                                                                                                       \
-    do {                                                                                                               \
-        rc = u64v(&k, &v, &neg) || v > 0x7FFFFFFFull;                                                                  \
-        (dst) = neg ? -(int)v : (int)v;                                                                                \
-    } while (0)
+#define I32(dst) (rc = tok_to_i32(&v, &(dst)))
 #define BOOL(dst)                                                                                                      \
     do {                                                                                                               \
-        rc = boolv(&k, &b);                                                                                            \
+        rc = tok_to_bool(&v, &b);                                                                                      \
         (dst) = b;                                                                                                     \
     } while (0)
-            if (!strcmp(key, "format")) {
-                STR(format, sizeof(format));
-            } else if (!strcmp(key, "version")) {
-                I32(version);
-            } else if (!strcmp(key, "sample_format")) {
-                STR(sfmt, sizeof(sfmt));
-            } else if (!strcmp(key, "iq_order")) {
-                STR(order, sizeof(order));
-            } else if (!strcmp(key, "endianness")) {
-                STR(endian, sizeof(endian));
-            } else if (!strcmp(key, "capture_stage")) {
-                STR(c->capture_stage, sizeof(c->capture_stage));
-            } else if (!strcmp(key, "sample_rate_hz")) {
-                U32(c->sample_rate_hz);
-            } else if (!strcmp(key, "center_frequency_hz")) {
-                U64(c->center_frequency_hz);
-            } else if (!strcmp(key, "capture_center_frequency_hz")) {
-                U64(c->capture_center_frequency_hz);
-            } else if (!strcmp(key, "ppm")) {
-                I32(c->ppm);
-            } else if (!strcmp(key, "tuner_gain_tenth_db")) {
-                I32(c->tuner_gain_tenth_db);
-            } else if (!strcmp(key, "rtl_dsp_bw_khz")) {
-                I32(c->rtl_dsp_bw_khz);
-            } else if (!strcmp(key, "base_decimation")) {
-                U32(c->base_decimation);
-            } else if (!strcmp(key, "post_downsample")) {
-                U32(c->post_downsample);
-            } else if (!strcmp(key, "demod_rate_hz")) {
-                U32(c->demod_rate_hz);
-            } else if (!strcmp(key, "offset_tuning_enabled")) {
-                BOOL(c->offset_tuning_enabled);
-            } else if (!strcmp(key, "fs4_shift_enabled")) {
-                BOOL(c->fs4_shift_enabled);
-            } else if (!strcmp(key, "combine_rotate_enabled")) {
-                BOOL(combine_rotate);
-            } else if (!strcmp(key, "muted_bytes_excluded")) {
-                BOOL(c->muted_bytes_excluded);
-            } else if (!strcmp(key, "contains_retunes")) {
-                BOOL(c->contains_retunes);
-            } else if (!strcmp(key, "size_limit_reached")) {
-                BOOL(c->size_limit_reached);
-            } else if (!strcmp(key, "capture_retune_count")) {
-                U32(c->capture_retune_count);
-            } else if (!strcmp(key, "data_file")) {
-                STR(data_file, data_file_cap);
-            } else if (!strcmp(key, "data_bytes")) {
-                U64(c->data_bytes);
-            } else if (!strcmp(key, "capture_drops")) {
-                U64(c->capture_drops);
-            } else if (!strcmp(key, "capture_drop_blocks")) {
-                U64(c->capture_drop_blocks);
-            } else if (!strcmp(key, "input_ring_drops")) {
-                U64(c->input_ring_drops);
-            } else if (!strcmp(key, "source_backend") || !strcmp(key, "source_args") || !strcmp(key, "capture_started_utc")
-                       || !strcmp(key, "notes")) {
-                rc = str(&k, junk, sizeof(junk)) == -1 ? -1 : 0; /* must be strings; content is not used here */
-            } else if (!strcmp(key, "events")) {
-                free(*events);
-                *events = NULL;
-                const int er = parse_events(&k, events, &c->event_count);
-                if (er != DDN_IQ_OK) {
-                    return er;
-                }
-                have_events = 1;
-            } else {
-                ws(&k); /* unknown scalar keys are ignored; nested values are refused like the reference does */
-                if (k.p < k.n && (k.s[k.p] == '{' || k.s[k.p] == '[')) {
-                    FAIL(DDN_IQ_ERR_INVALID_META, "nested structures are unsupported in metadata (key '%s')", key);
-                }
-                rc = skip_value(&k, 0);
+        if (!strcmp(key, "format")) {
+            STR(format, sizeof(format));
+        } else if (!strcmp(key, "version")) {
+            I32(version);
+        } else if (!strcmp(key, "sample_format")) {
+            STR(sfmt, sizeof(sfmt));
+        } else if (!strcmp(key, "iq_order")) {
+            STR(order, sizeof(order));
+        } else if (!strcmp(key, "endianness")) {
+            STR(endian, sizeof(endian));
+        } else if (!strcmp(key, "capture_stage")) {
+            STR(c->capture_stage, sizeof(c->capture_stage));
+        } else if (!strcmp(key, "sample_rate_hz")) {
+            U32(c->sample_rate_hz);
+        } else if (!strcmp(key, "center_frequency_hz")) {
+            U64(c->center_frequency_hz);
+        } else if (!strcmp(key, "capture_center_frequency_hz")) {
+            U64(c->capture_center_frequency_hz);
+        } else if (!strcmp(key, "ppm")) {
+            I32(c->ppm);
+        } else if (!strcmp(key, "tuner_gain_tenth_db")) {
+            I32(c->tuner_gain_tenth_db);
+        } else if (!strcmp(key, "rtl_dsp_bw_khz")) {
+            I32(c->rtl_dsp_bw_khz);
+        } else if (!strcmp(key, "base_decimation")) {
+            U32(c->base_decimation);
+        } else if (!strcmp(key, "post_downsample")) {
+            U32(c->post_downsample);
+        } else if (!strcmp(key, "demod_rate_hz")) {
+            U32(c->demod_rate_hz);
+        } else if (!strcmp(key, "offset_tuning_enabled")) {
+            BOOL(c->offset_tuning_enabled);
+        } else if (!strcmp(key, "fs4_shift_enabled")) {
+            BOOL(c->fs4_shift_enabled);
+        } else if (!strcmp(key, "combine_rotate_enabled")) {
+            BOOL(combine_rotate);
+        } else if (!strcmp(key, "muted_bytes_excluded")) {
+            BOOL(c->muted_bytes_excluded);
+        } else if (!strcmp(key, "contains_retunes")) {
+            BOOL(c->contains_retunes);
+        } else if (!strcmp(key, "size_limit_reached")) {
+            BOOL(c->size_limit_reached);
+        } else if (!strcmp(key, "capture_retune_count")) {
+            U32(c->capture_retune_count);
+        } else if (!strcmp(key, "data_file")) {
+            STR(data_file, data_file_cap < 2048 ? data_file_cap : 2048);
+        } else if (!strcmp(key, "data_bytes")) {
+            U64(c->data_bytes);
+        } else if (!strcmp(key, "capture_drops")) {
+            U64(c->capture_drops);
+        } else if (!strcmp(key, "capture_drop_blocks")) {
+            U64(c->capture_drop_blocks);
+        } else if (!strcmp(key, "input_ring_drops")) {
+            U64(c->input_ring_drops);
+        } else if (!strcmp(key, "source_backend")) { /* these four must be strings that fit the reference's fields */
+            STR(backend, sizeof(backend));
+        } else if (!strcmp(key, "source_args")) {
+            STR(args, sizeof(args));
+        } else if (!strcmp(key, "capture_started_utc")) {
+            STR(started, sizeof(started));
+        } else if (!strcmp(key, "notes")) {
+            rc = v.type == T_NULL ? 0 : tok_to_str(kp, &v, notes, sizeof(notes), 0);
+        } else if (!strcmp(key, "events")) {
+            if (v.type != T_LBRACKET) {
+                BAIL(DDN_IQ_ERR_INVALID_META, "field 'events' expects array");
             }
+            free(*events);
+            *events = NULL;
+            c->event_count = 0;
+            const int er = parse_events(kp, events, &c->event_count);
+            if (er != DDN_IQ_OK) {
+                free(kp);
+                return er;
+            }
+            have_events = 1;
+        } else if (v.type == T_LBRACE || v.type == T_LBRACKET) {
+            /* unknown keys: any single token is ignored; nested values are refused like the reference does */
+            BAIL(DDN_IQ_ERR_INVALID_META, "nested structures are unsupported in metadata (key '%s')", key);
+        }
 #undef STR
 #undef U64
 #undef U32
 #undef I32
 #undef BOOL
-            if (rc != 0) {
-                FAIL(DDN_IQ_ERR_INVALID_META, "bad value for '%s'", key);
-            }
-            ws(&k);
-            if (k.p >= k.n) {
-                FAIL(DDN_IQ_ERR_INVALID_META, "unterminated metadata object");
-            }
-            const char ch = k.s[k.p++];
-            if (ch == '}') {
-                break;
-            }
-            if (ch != ',') {
-                FAIL(DDN_IQ_ERR_INVALID_META, "bad delimiter after '%s'", key);
-            }
+        if (rc != 0) {
+            BAIL(DDN_IQ_ERR_INVALID_META, "bad value for '%s'", key);
+        }
+        const token d = next_tok(kp);
+        if (d.type == T_RBRACE) {
+            break;
+        }
+        if (d.type != T_COMMA) {
+            BAIL(DDN_IQ_ERR_INVALID_META, "bad delimiter after '%s'", key);
         }
     }
+    if (next_tok(kp).type != T_EOF) {
+        BAIL(DDN_IQ_ERR_INVALID_META, "trailing JSON content at offset %zu", kp->p);
+    }
+    free(kp);
+#undef BAIL
     for (int i = 0; i < n_req; i++) {
         if (!(seen & (1ull << i))) {
             FAIL(DDN_IQ_ERR_INVALID_META, "missing required field '%s'", req[i]);
@@ -738,9 +809,16 @@ load_info(const char* path, ddn_iq_capture_info* c, ddn_iq_event** events, int r
         *events = NULL;
         return rc;
     }
-    /* data_file is relative to the sidecar's directory unless absolute */
+    /* data_file is relative to the sidecar's directory unless absolute; "absolute" and the directory separator take the
+     * Windows spellings too, on every host (path_is_absolute / resolve_data_path, src/io/iq/iq_replay.c:66-78,194-224) */
     const char* slash = strrchr(c->metadata_path, '/');
-    if (data_file[0] == '/' || !slash) {
+    const char* bslash = strrchr(c->metadata_path, '\\');
+    if (bslash && (!slash || bslash > slash)) {
+        slash = bslash;
+    }
+    const int absolute = data_file[0] == '/' || data_file[0] == '\\'
+                         || (isalpha((unsigned char)data_file[0]) && (unsigned char)data_file[0] < 0x80 && data_file[1] == ':');
+    if (absolute || !slash) {
         snprintf(c->data_path, sizeof(c->data_path), "%s", data_file);
     } else {
         const size_t dir = (size_t)(slash - c->metadata_path + 1);

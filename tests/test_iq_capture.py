@@ -223,6 +223,51 @@ def test_synthetic_sidecars_match_reference(built, tmp_path):
     assert mine(q, 1)[0] == ref_meta(q, 1)[0] != 0
 
 
+GRAMMAR_CASES = [  # (edit of the BASE sidecar text, expected code of a metadata-only read); found by DDN_FUZZ_BASE sweeps
+    (lambda t: t.replace('"data_bytes": 2000', '"data_bytes": 02000'), -2),         # no leading zeros in numbers
+    (lambda t: t.replace('"data_bytes": 2000', '"data_bytes": 2000.0'), -2),        # integers only
+    (lambda t: t.replace('"ppm": -3', '"ppm": -'), -2),
+    (lambda t: t.replace('"ppm": -3', '"ppm": -03'), -2),
+    (lambda t: t.replace("post_mute_pre_widen", "post_mute_p\\re_widen"), -2),      # escaped control byte: invalid, not "unsupported stage"
+    (lambda t: t.replace("dev=0", "dev=\\u0007"), -2),
+    (lambda t: t.replace('a \\"quoted\\" note', "line\\nbreak"), 0),                 # ... but "notes" may hold them
+    (lambda t: t.replace('"notes": "a \\"quoted\\" note"', '"notes": null'), 0),
+    (lambda t: t.replace('"notes": "a \\"quoted\\" note"', '"notes": "' + "n" * 256 + '"'), -2),   # 255 characters fit
+    (lambda t: t.replace('"notes": "a \\"quoted\\" note"', '"notes": "' + "n" * 255 + '"'), 0),
+    (lambda t: t.replace('"source_backend": "rtl"', '"source_backend": "' + "b" * 32 + '"'), -2),
+    (lambda t: t.rstrip()[:-1].rstrip() + ",\n}", 0),                             # trailing comma before the closing brace
+    (lambda t: t + " x", -2),                                                       # trailing content
+    (lambda t: t + "\n\t \r", 0),
+    (lambda t: t + "\f", -2),                                                       # form feed is not JSON whitespace
+    (lambda t: t.replace('"extra_unknown": 7', '"' + "k" * 127 + '": 7'), 0),       # keys up to 127 bytes
+    (lambda t: t.replace('"extra_unknown": 7', '"' + "k" * 128 + '": 7'), -2),
+    (lambda t: t.replace('"extra_unknown": 7', '"extra_unknown": [7]'), -2),        # nested unknown value
+    (lambda t: t.replace('"third": null', '"third": nullx'), -2),
+    (lambda t: t.replace('"fs4_shift_enabled": true', '"fs4_shift_enabled": 1'), -2),
+]
+
+
+@pytest.mark.parametrize("i", range(len(GRAMMAR_CASES)))
+def test_sidecar_grammar_corner_cases(built, tmp_path, i):
+    edit, want = GRAMMAR_CASES[i]
+    text = edit(json.dumps(BASE, indent=1))
+    q = write_capture(str(tmp_path), text)
+    rc, _ = mine(q)
+    assert rc == want, (i, rc, want)
+    if orc.have_ref():
+        assert ref_meta(q)[0] == want, i
+
+
+def test_data_file_drive_letter_and_backslash_count_as_absolute(built, tmp_path):
+    """path_is_absolute (src/io/iq/iq_replay.c:66-78) takes '\\' and 'X:' for absolute on every host."""
+    for name in ("c:p.iq", "\\\\p.iq"):
+        q = write_capture(str(tmp_path), dict(BASE, data_file=name, data_bytes=0))
+        rc, info = mine(q)
+        assert rc == 0 and info.data_path == name.encode(), (name, rc, info.data_path)
+        if orc.have_ref():
+            assert ref_meta(q)[3] == name.encode()
+
+
 @needs_ref
 def test_sidecar_differential_fuzz_vs_reference(built, tmp_path):
     """900 randomly damaged sidecars (characters replaced / deleted / inserted, truncations): this reader and the
@@ -237,7 +282,7 @@ def test_sidecar_differential_fuzz_vs_reference(built, tmp_path):
          "capture_center_frequency_hz": 852000000, "sample_rate_hz": 96000}])
     np.zeros(2001, np.uint8).tofile(os.path.join(tmp, "cap.iq"))
     q = os.path.join(tmp, "cap.iq.json")
-    rng = random.Random(11)
+    rng = random.Random(11 + 7919 * int(os.environ.get("DDN_FUZZ_BASE", "0")))
     both_ok = 0
     for i in range(900):
         t = list(json.dumps(BASE if i % 3 else v2, indent=1))
