@@ -4,6 +4,9 @@ import json
 import os
 
 import numpy as np
+
+import os as _os
+FZ = 7919 * int(_os.environ.get("DDN_FUZZ_BASE", "0"))  # seed shift for long sweeps
 import pytest
 
 import fecgen
@@ -24,7 +27,7 @@ def test_p25_half_rate_golden(built):
 
 
 def test_p25_half_rate_recovers_clean_codewords(built):
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(FZ + 3)
     llr, st = fecgen.gen_p25_half_rate(rng, 64, sigma=0.0, random_frac=0.0)
     out, met = fecgen.oracle_p25_half_rate(llr)
     d = st[:, :48]
@@ -52,7 +55,7 @@ def test_nxdn_conv_golden(built):
 
 
 def test_nxdn_conv_decodes_clean_codeword_and_carries_metrics(built):
-    rng = np.random.default_rng(4)
+    rng = np.random.default_rng(FZ + 4)
     steps = 96
     data = rng.integers(0, 2, (8, steps)).astype(np.int64)
     data[:, -4:] = 0
@@ -80,7 +83,7 @@ def test_fresh_inputs_against_compiled_reference(built):
     r = orc.ref()
     r.p25_12_soft_llr.argtypes = [VP, VP, VP]
     r.dmr_r34_viterbi_decode_soft.argtypes = [VP, VP, VP]
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(FZ + 77)
     llr, _ = fecgen.gen_p25_half_rate(rng, 300, sigma=400.0)
     out, met = fecgen.oracle_p25_half_rate(llr)
     for i in range(300):
@@ -106,7 +109,7 @@ def test_p25_half_rate_list_matches_reference(built):
 
     r.p25_12_soft_llr_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     o.orc_p25_12_soft_llr_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(FZ + 77)
     llr, _ = fecgen.gen_p25_half_rate(rng, 300, sigma=500.0, random_frac=0.3)
     llr[5] = 0                      # all ties
     llr[6] = 32767
@@ -134,7 +137,7 @@ def test_r34_list_matches_reference(built):
 
     r.dmr_r34_viterbi_decode_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     o.orc_r34_decode_list.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-    rng = np.random.default_rng(78)
+    rng = np.random.default_rng(FZ + 78)
     d, rel, _ = fecgen.gen_r34(rng, 120, p_err=0.06, random_frac=0.3)
     rel[3] = 0                      # every weighted cost 0: all paths tie
     rel[4] = 255

@@ -3,6 +3,9 @@ bit for bit against the reference's compiled check_and_fix_* entry points (oracl
 import ctypes as C
 
 import numpy as np
+
+import os as _os
+FZ = 7919 * int(_os.environ.get("DDN_FUZZ_BASE", "0"))  # seed shift for long sweeps
 import pytest
 
 import fecgen
@@ -64,13 +67,13 @@ def ref_rs(code, data, par):
 
 
 def test_encoders_give_codewords(built):
-    rng = np.random.default_rng(2)
+    rng = np.random.default_rng(FZ + 2)
     for code in fecgen.P25_RS_CODES:
         d, p = fecgen.gen_p25_rs(rng, code, 20, max_extra=-fecgen.P25_RS_CODES[code][2])   # no errors
         out, rc = oracle_rs(code, d, p)
         assert not rc.any() and np.array_equal(out, d)
     for ln in (6, 12):
-        d, p = fecgen.gen_golay24(np.random.default_rng(3), 1, ln)
+        d, p = fecgen.gen_golay24(np.random.default_rng(FZ + 3), 1, ln)
     d12 = rng.integers(0, 2, (50, 12)).astype(np.uint8)
     p = np.stack([fecgen.golay24_encode(x) for x in d12])
     out, rc, fx = oracle_golay(d12, p)
@@ -80,7 +83,7 @@ def test_encoders_give_codewords(built):
 @needs_ref
 @pytest.mark.parametrize("length", [6, 12])
 def test_golay_matches_reference(built, length):
-    rng = np.random.default_rng(10 + length)
+    rng = np.random.default_rng(FZ + 10 + length)
     d, p = fecgen.gen_golay24(rng, 6000, length)
     # plus pure noise words and invalid (non-binary) inputs
     d[:500] = rng.integers(0, 2, (500, length))
@@ -98,7 +101,7 @@ def test_golay_matches_reference(built, length):
 def test_golay_exhaustive_error_patterns(built):
     """Every error pattern of weight <= 4 on one codeword (length 12): data, return code and fixed count."""
     import itertools
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(FZ + 5)
     d0 = rng.integers(0, 2, 12).astype(np.uint8)
     w0 = np.concatenate([d0, fecgen.golay24_encode(d0)])
     pats = [()] + [c for k in (1, 2, 3) for c in itertools.combinations(range(24), k)]
@@ -118,7 +121,7 @@ def test_golay_exhaustive_error_patterns(built):
 @needs_ref
 @pytest.mark.parametrize("code", list(fecgen.P25_RS_CODES))
 def test_rs_matches_reference(built, code):
-    rng = np.random.default_rng(hash(code) & 0xFFFF)
+    rng = np.random.default_rng(FZ + hash(code) & 0xFFFF)
     d, p = fecgen.gen_p25_rs(rng, code, 3000, max_extra=4)
     d[:200] = rng.integers(0, 2, d[:200].shape)          # pure noise
     p[:200] = rng.integers(0, 2, p[:200].shape)
@@ -166,7 +169,7 @@ def gen_soft_reliab(rng, bits_shape, flipped_mask):
 def test_hamming_soft_matches_reference(built):
     r = orc.ref()
     r.hamming_10_6_3_soft.argtypes = [VP, VP, VP]
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(FZ + 31)
     n = 6000
     d = rng.integers(0, 2, (n, 6)).astype(np.uint8)
     p = np.stack([d[:, 0] ^ d[:, 1] ^ d[:, 2] ^ d[:, 5], d[:, 0] ^ d[:, 1] ^ d[:, 3] ^ d[:, 5],
@@ -191,7 +194,7 @@ def test_golay_soft_matches_reference(built, length):
     r = orc.ref()
     fn = r.check_and_fix_golay_24_6_soft if length == 6 else r.check_and_fix_golay_24_12_soft
     fn.argtypes = [VP, VP, VP, VP]
-    rng = np.random.default_rng(33 + length)
+    rng = np.random.default_rng(FZ + 33 + length)
     n = 2500
     d = np.zeros((n, length), np.uint8)
     p = np.zeros((n, 12), np.uint8)
@@ -261,7 +264,7 @@ def test_rs_soft_reliability_matches_reference(built, code):
     fn = {"24_12_13": r.p25p1_rs_24_12_13_soft_reliability, "24_16_9": r.p25p1_rs_24_16_9_soft_reliability,
           "36_20_17": r.p25p1_rs_36_20_17_soft_reliability}[code]
     fn.argtypes = [VP, VP, VP, VP]
-    rng = np.random.default_rng(200 + len(code))
+    rng = np.random.default_rng(FZ + 200 + len(code))
     d, p, drel, prel = gen_rs_soft(rng, code, 1500)
     got, rc = oracle_rs_soft_rel(code, d, p, drel, prel)
     for i in range(len(d)):
@@ -277,7 +280,7 @@ def test_rs_explicit_erasures_match_reference(built):
     """check_and_fix_*_soft with caller-given erasure lists, incl. duplicates / out-of-range / too many."""
     r, o = orc.ref(), orc.oracle()
     o.orc_p25_rs_decode_soft.argtypes = [VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int]
-    rng = np.random.default_rng(300)
+    rng = np.random.default_rng(FZ + 300)
     fns = {"24_12_13": r.check_and_fix_reedsolomon_24_12_13_soft, "24_16_9": r.check_and_fix_reedsolomon_24_16_9_soft,
            "36_20_17": r.check_and_fix_redsolomon_36_20_17_soft}
     for code, fn in fns.items():
