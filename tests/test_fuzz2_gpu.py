@@ -129,3 +129,43 @@ def test_iq_conditioning_random(built, seed):
         want = np.concatenate(want)
         bad = np.flatnonzero(bits(got[c]) != bits(want))
         assert len(bad) == 0, (seed, c, dc, sh, bal, thr, ema, sq, blk, lens, bad[:5])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_rx_random_wide_batches(built, seed):
+    """The receive loop on batches wide enough for several wavefronts / workgroups of every kernel shape, with
+    per-channel in-frame lengths and channels that differ in framing, level and noise."""
+    rng = np.random.default_rng(8000 + seed + 7919 * BASE)
+    B = int(rng.integers(24, 300))
+    use_filter = int(rng.integers(0, 2))
+    n = int(rng.integers(2500, 9000))
+    parts, locks = [], []
+    left = B
+    while left > 0:
+        k = int(min(left, rng.integers(1, 64)))
+        frame = int(rng.choice([180, 360, 432, 864]))
+        xs, _, _ = orc.synth_p25_disc(int(rng.integers(0, 9999)), k, n, frame_dibits=frame,
+                                      noise=float(rng.choice([200, 800, 2500, 7000])))
+        parts.append(xs * np.float32(rng.choice([0.3, 1.0, 1.0, 1.6])))
+        locks += [frame - 24 if rng.random() < 0.6 else int(rng.integers(0, 900)) for _ in range(k)]
+        left -= k
+    x = np.concatenate(parts).astype(np.float32)
+    if rng.integers(0, 2):
+        x[int(rng.integers(0, B))] = 0.0
+    lock = np.asarray(locks, np.int32)
+    cuts = sorted(set([0, n] + [int(v) for v in rng.integers(1, n, int(rng.integers(0, 4)))]))
+    rx = ddn.P25Rx(B, lock_symbols=156, use_matched_filter=use_filter, channels_per_wave=int(rng.choice([0, 8, 16, 32, 64])))
+    assert ddn.lib().ddn_p25_rx_set_lock_symbols(rx.h, lock.ctypes.data) == 0
+    recs, fls = [[] for _ in range(B)], [[] for _ in range(B)]
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        rec, fl, cnt = rx.run(x[:, a:e])
+        for c in range(B):
+            recs[c].append(rec[c, :cnt[c]])
+            fls[c].append(fl[c, :cnt[c]])
+    for c in range(B):
+        o = orc.OracleP25Rx(lock_symbols=int(lock[c]), use_filter=use_filter)
+        sym, rec4, fl = o.run(x[c])
+        r4, sy = orc.unpack_records10(np.concatenate(recs[c]))
+        assert np.array_equal(sy.view(np.uint32), sym.view(np.uint32)), (seed, c, B, cuts)
+        assert np.array_equal(r4, rec4) and np.array_equal(np.concatenate(fls[c]), fl), (seed, c, B, cuts)
+        assert np.array_equal(rx.thresholds(c).view(np.uint32), o.thresholds().view(np.uint32)), (seed, c)
