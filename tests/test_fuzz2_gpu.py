@@ -169,3 +169,38 @@ def test_rx_random_wide_batches(built, seed):
         assert np.array_equal(sy.view(np.uint32), sym.view(np.uint32)), (seed, c, B, cuts)
         assert np.array_equal(r4, rec4) and np.array_equal(np.concatenate(fls[c]), fl), (seed, c, B, cuts)
         assert np.array_equal(rx.thresholds(c).view(np.uint32), o.thresholds().view(np.uint32)), (seed, c)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_front_end_random_configs_16_channel_workgroups(built, seed):
+    """More than 2048 channels select the 16-channels-per-workgroup shape of k_front_end_fused (the bench's shape);
+    same random block lengths / call splits / formats / profiles as the small-batch fuzz, a sample of channels checked."""
+    rng = np.random.default_rng(9000 + seed + 7919 * BASE)
+    profile = int(rng.choice([2, 4, 4, 5, 1]))
+    blk = int(rng.choice([135, 200, 256, 300, 1000, 2048, 8191]))
+    B = int(rng.integers(2049, 2400))
+    fmt_cf32 = bool(rng.integers(0, 2))
+    n_calls = int(rng.integers(1, 4))
+    lens = [int(rng.integers(1, 3)) * blk for _ in range(n_calls - 1)] + [int(rng.integers(1, 2 * blk))]
+    lens = [min(v, 4000) // blk * blk or blk for v in lens[:-1]] + [min(lens[-1], 3000)]
+    n = sum(lens)
+    base = orc.synth_c4fm_cu8(int(rng.integers(0, 1000)), 67, n)
+    iq = np.ascontiguousarray(np.tile(base, (B // 67 + 1, 1, 1))[:B])
+    iq[:, :, 0] ^= (np.arange(B, dtype=np.uint8) & 1)[:, None]      # neighbouring channels differ
+    x = ((iq.astype(np.float32) - 127.5) * np.float32(1.0 / 127.5)).astype(np.float32) if fmt_cf32 else iq
+    b = ddn.Batch(B, lpf_profile=profile, block_len=blk, input_format=ddn.IN_CF32 if fmt_cf32 else ddn.IN_CU8)
+    got, pos = [], 0
+    for ln in lens:
+        got.append(b.run_host(x[:, pos:pos + ln], ln))
+        pos += ln
+    got = np.concatenate(got, axis=1)
+    pick = sorted(set([0, 1, 15, 16, 17, B - 17, B - 16, B - 1] + [int(v) for v in rng.integers(0, B, 40)]))
+    for c in pick:
+        fe = orc.OracleFrontEnd(profile=profile)
+        want, pos = [], 0
+        for ln in lens:
+            want.append(fe.run_cu8(iq[c, pos:pos + ln], blk))
+            pos += ln
+        want = np.concatenate(want)
+        bad = np.flatnonzero(bits(got[c]) != bits(want))
+        assert len(bad) == 0, (seed, c, B, profile, blk, fmt_cf32, lens, bad[:5])
