@@ -204,3 +204,47 @@ def test_front_end_random_configs_16_channel_workgroups(built, seed):
         want = np.concatenate(want)
         bad = np.flatnonzero(bits(got[c]) != bits(want))
         assert len(bad) == 0, (seed, c, B, profile, blk, fmt_cf32, lens, bad[:5])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cqpsk_random_wide_batches(built, seed):
+    """The CQPSK chain (lane = channel kernels) on batches of several wavefronts with a ragged last one."""
+    rng = np.random.default_rng(10000 + seed + 7919 * BASE)
+    sps = int(rng.choice([4, 5, 5, 10, 8]))
+    sym_rate = 6000 if sps == 4 else 4800
+    rate = sps * sym_rate
+    blk = int(rng.choice([333, 1000, 2048, 4096]))
+    lpf = int(rng.integers(0, 2))
+    B = int(rng.integers(60, 260))
+    k = 12
+    base = orc.synth_dqpsk_f32(int(rng.integers(0, 999)), k, int(rng.integers(500, 1400)), sps,
+                               cfo=float(rng.choice([0.0, 0.002, 0.01])))
+    scale = (0.4 + 0.1 * (np.arange(B) % 13)).astype(np.float32)        # channels differ in level
+    iq = np.ascontiguousarray(np.tile(base, (B // k + 1, 1, 1))[:B] * scale[:, None, None])
+    n = iq.shape[1]
+    n_calls = int(rng.integers(1, 4))
+    lens = [int(rng.integers(1, 3)) * blk for _ in range(n_calls - 1)]
+    if sum(lens) >= n - 8:
+        lens = []
+    last = n - sum(lens)
+    if last % blk in (1, 2, 3):
+        last -= 4
+    lens.append(last)
+    b = ddn.CqpskBatch(B, rate=rate, sym_rate=sym_rate, lpf_enable=lpf, block_len=blk)
+    got = [[] for _ in range(B)]
+    pos = 0
+    for ln in lens:
+        sym, cnt = b.run(iq[:, pos:pos + ln])
+        for c in range(B):
+            got[c].append(sym[c, :cnt[c]])
+        pos += ln
+    for c in range(B):
+        fe = orc.OracleCqpskFe(rate=rate, sym_rate=sym_rate, lpf_enable=lpf)
+        want, pos = [], 0
+        for ln in lens:
+            want.append(fe.run(iq[c, pos:pos + ln], blk))
+            pos += ln
+        want = np.concatenate(want)
+        g = np.concatenate(got[c])
+        assert len(g) == len(want), (seed, c, B, sps, blk, lens)
+        assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), (seed, c, B, sps, blk, lpf, lens)
