@@ -248,3 +248,29 @@ def test_cqpsk_random_wide_batches(built, seed):
         g = np.concatenate(got[c])
         assert len(g) == len(want), (seed, c, B, sps, blk, lens)
         assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), (seed, c, B, sps, blk, lpf, lens)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_decimated_front_end_16_channel_workgroups(built, seed):
+    """Half-band cascade in front of the fused kernel, above 2048 channels (the 16-channel workgroup shape on the
+    decimated stream), two calls."""
+    rng = np.random.default_rng(11000 + seed + 7919 * BASE)
+    passes = int(rng.choice([1, 2]))
+    blk = int(rng.choice([1024, 2048, 4096]))
+    B = int(rng.integers(2049, 2300))
+    fmt_cf32 = bool(rng.integers(0, 2))
+    lens = [blk, max(1 << passes, (int(rng.integers(1, 2 * blk)) >> passes) << passes)]
+    n = sum(lens)
+    base = orc.synth_c4fm_cu8(int(rng.integers(0, 1000)), 33, n, sps=10 << passes)
+    iq = np.ascontiguousarray(np.tile(base, (B // 33 + 1, 1, 1))[:B])
+    iq[:, :, 1] ^= (np.arange(B, dtype=np.uint8) & 1)[:, None]
+    x = ((iq.astype(np.float32) - 127.5) * np.float32(1.0 / 127.5)).astype(np.float32) if fmt_cf32 else iq
+    b = ddn.Batch(B, block_len=blk, input_format=ddn.IN_CF32 if fmt_cf32 else ddn.IN_CU8)
+    b.set_decimation(passes)
+    got = np.concatenate([b.run_host(x[:, :lens[0]], lens[0]), b.run_host(x[:, lens[0]:], lens[1])], axis=1)
+    for c in sorted(set([0, 16, B - 1] + [int(v) for v in rng.integers(0, B, 20)])):
+        fe = orc.OracleFrontEnd(downsample_passes=passes)
+        want = np.concatenate([fe.run_cu8(iq[c, :lens[0]], blk), fe.run_cu8(iq[c, lens[0]:], blk)])
+        assert got.shape[1] == len(want), (seed, c)
+        bad = np.flatnonzero(bits(got[c]) != bits(want))
+        assert len(bad) == 0, (seed, c, B, passes, blk, fmt_cf32, lens, bad[:5])
