@@ -38,6 +38,7 @@ struct ddn_cqpsk_batch {
     float fll_taps[4 * DDN_FLL_MAX_TAPS];
     float fll_alpha, fll_beta;
     float* d_taps;
+    float* d_fll_taps;      // [4][DDN_FLL_MAX_TAPS], this batch's band-edge taps (uploaded once at create)
     void* d_lpf_hist;       // [B][taps_len-1] complex
     DdnCqpskState* d_state; // [B]
     float* d_delay;         // [2*nt][2][B]
@@ -52,6 +53,7 @@ struct ddn_cqpsk_batch {
 static void
 cq_free(ddn_cqpsk_batch* b) {
     (void)hipFree(b->d_taps);
+    (void)hipFree(b->d_fll_taps);
     (void)hipFree(b->d_lpf_hist);
     (void)hipFree(b->d_state);
     (void)hipFree(b->d_delay);
@@ -108,6 +110,8 @@ ddn_cqpsk_batch_create(const ddn_cqpsk_config* cfg, ddn_cqpsk_batch** out) {
     b->fll_nt = ddn_design_fll_band_edge(b->sps, b->fll_taps, &b->fll_alpha, &b->fll_beta);
     const size_t B = (size_t)cfg->n_channels;
     if (hipMalloc(&b->d_taps, sizeof(float) * (DDN_MAX_TAPS + 1)) != hipSuccess
+        || hipMalloc(&b->d_fll_taps, sizeof(b->fll_taps)) != hipSuccess
+        || hipMemcpy(b->d_fll_taps, b->fll_taps, sizeof(b->fll_taps), hipMemcpyHostToDevice) != hipSuccess
         || hipMalloc(&b->d_lpf_hist, sizeof(float) * 2 * DDN_MAX_TAPS * B) != hipSuccess
         || hipMalloc(&b->d_state, sizeof(DdnCqpskState) * B) != hipSuccess
         || hipMalloc(&b->d_delay, sizeof(float) * 4 * (size_t)b->fll_nt * B) != hipSuccess
@@ -205,8 +209,7 @@ ddn_cqpsk_run(ddn_cqpsk_batch* b, const void* d_iq, size_t n, float* d_symbols, 
         ddn_set_error("ddn_cqpsk_run: cu8 input needs the channel LPF stage (it does the widening)");
         return DDN_EINVAL;
     }
-    HIP_TRY(ddn_dev_cqpsk_set_fll_taps(b->fll_taps));
-    HIP_TRY(ddn_dev_cqpsk_agc_fll(cur, (long)n, n, B, b->fll_nt, b->fll_alpha, b->fll_beta, b->d_state, b->d_delay, b->d_b,
+    HIP_TRY(ddn_dev_cqpsk_agc_fll(cur, (long)n, n, B, b->fll_nt, b->fll_alpha, b->fll_beta, b->d_fll_taps, b->d_state, b->d_delay, b->d_b,
                                   st));
     int rc = ddn_gardner_run(b->ted, (const float*)b->d_b, n, (float*)b->d_sym, b->sym_cap, b->d_cnt, st);
     if (rc != DDN_OK) {

@@ -196,6 +196,12 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
         HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)B, st));
         return DDN_OK;
     }
+    if (max_symbols < ddn_p25_rx_max_symbols(b, n)) {
+        // the loop counts every symbol but stores only max_symbols of them: downstream readers (framer) trust counts
+        ddn_set_error("ddn_p25_rx_run: max_symbols %zu < ddn_p25_rx_max_symbols(n) = %zu", max_symbols,
+                      ddn_p25_rx_max_symbols(b, n));
+        return DDN_ERANGE;
+    }
     if (b->cfg.use_matched_filter) {
         if (b->filt_cap < n) {
             HIP_TRY(hipStreamSynchronize(st));

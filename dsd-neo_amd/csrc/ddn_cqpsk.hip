@@ -25,7 +25,9 @@ namespace {
 constexpr float kTwoPi = 6.28318530717958647692f;
 constexpr float kPi = 3.14159265358979323846f;
 
-__constant__ float c_fll[4][DDN_FLL_MAX_TAPS]; // lower_r, lower_i, upper_r, upper_i (reversed, as the reference)
+// FLL band-edge taps are a per-batch device buffer `fll` = [4][DDN_FLL_MAX_TAPS]: lower_r, lower_i, upper_r, upper_i
+// (reversed, as the reference), uploaded once when the batch is created - no module-global state, so batches with
+// different sps can run on different streams / threads at once
 
 __device__ __forceinline__ float
 clipf(float x, float lim) {
@@ -289,7 +291,8 @@ k_lpf_hist(const void* __restrict__ in, long n, size_t in_stride, int H, f2* __r
 template <int NT_T>
 __global__ __launch_bounds__(128) void
 k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels, int nt_rt, float alpha, float beta,
-                DdnCqpskState* __restrict__ state, float* __restrict__ delay_store, f2* __restrict__ out) {
+                const float* __restrict__ fll, DdnCqpskState* __restrict__ state, float* __restrict__ delay_store,
+                f2* __restrict__ out) {
     constexpr int TS = 32, CPW = 16;
     const int nt = NT_T > 0 ? NT_T : nt_rt;
     extern __shared__ float smem[];
@@ -320,8 +323,8 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
     if (NT_T > 0) {
 #pragma unroll
         for (int k = 0; k < NT_T; k++) {
-            ta[k] = c_fll[ia][k];
-            tb[k] = sb * c_fll[ib][k];
+            ta[k] = fll[ia * DDN_FLL_MAX_TAPS + k];
+            tb[k] = sb * fll[ib * DDN_FLL_MAX_TAPS + k];
         }
     }
     float avg = s.agc_avg;
@@ -412,7 +415,7 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
                 } else {
                     for (int k = 0; k < nt; k++) {
                         const float dr = dlr[(base - k) * CPW + cl], di = dli[(base - k) * CPW + cl];
-                        acc += dr * c_fll[ia][k] + di * (sb * c_fll[ib][k]);
+                        acc += dr * fll[ia * DDN_FLL_MAX_TAPS + k] + di * (sb * fll[ib * DDN_FLL_MAX_TAPS + k]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -461,7 +464,8 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
 template <int NT>
 __global__ __launch_bounds__(128) void
 k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_channels, float alpha, float beta,
-                    DdnCqpskState* __restrict__ state, float* __restrict__ delay_store, f2* __restrict__ out) {
+                    const float* __restrict__ fll, DdnCqpskState* __restrict__ state, float* __restrict__ delay_store,
+                    f2* __restrict__ out) {
     constexpr int TS = (NT > 16) ? 2 * NT : 3 * NT, CPW = 16;
     __shared__ f2 tiles[3][CPW][TS + 1];
     const int lane = threadIdx.x & 63;
@@ -490,8 +494,8 @@ k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_chan
     float ta[NT], tb[NT];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        ta[k] = c_fll[ia][k];
-        tb[k] = sb * c_fll[ib][k];
+        ta[k] = fll[ia * DDN_FLL_MAX_TAPS + k];
+        tb[k] = sb * fll[ib * DDN_FLL_MAX_TAPS + k];
     }
     float avg = s.agc_avg;
     if (avg <= 0.0f) {
@@ -778,13 +782,8 @@ ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, in
 }
 
 extern "C" hipError_t
-ddn_dev_cqpsk_set_fll_taps(const float* taps4) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_fll), taps4, sizeof(float) * 4 * DDN_FLL_MAX_TAPS);
-}
-
-extern "C" hipError_t
 ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int nt, float alpha, float beta,
-                      DdnCqpskState* state, float* delay_store, void* out, hipStream_t st) {
+                      const float* d_fll_taps, DdnCqpskState* state, float* delay_store, void* out, hipStream_t st) {
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
@@ -798,18 +797,18 @@ ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int
             return e;                                                                                                  \
         }                                                                                                              \
         hipLaunchKernelGGL(k_cqpsk_agc_fll<NTT>, grid, blk, shm, st, (const f2*)in, n, stride, n_channels, nt, alpha,  \
-                           beta, state, delay_store, (f2*)out);                                                        \
+                           beta, d_fll_taps, state, delay_store, (f2*)out);                                                        \
     } while (0)
     const dim3 rgrid((unsigned)((n_channels + 15) / 16));
     if (nt == 11) {
         hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<11>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
-                           state, delay_store, (f2*)out); // sps 5
+                           d_fll_taps, state, delay_store, (f2*)out); // sps 5
     } else if (nt == 21) {
         hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<21>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
-                           state, delay_store, (f2*)out); // sps 10
+                           d_fll_taps, state, delay_store, (f2*)out); // sps 10
     } else if (nt == 9) {
         hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<9>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
-                           state, delay_store, (f2*)out); // sps 4 (P25p2 6000 sym/s at 24 ksps)
+                           d_fll_taps, state, delay_store, (f2*)out); // sps 4 (P25p2 6000 sym/s at 24 ksps)
     } else {
         DDN_LAUNCH_FLL(0);
     }

@@ -126,8 +126,8 @@ hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev
 hipError_t ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, int block_len, int n_channels,
                                    const float* taps_dev, int taps_len, int has_zero_tap, void* hist, void* out,
                                    size_t out_stride, hipStream_t st);
-hipError_t ddn_dev_cqpsk_set_fll_taps(const float* taps4);
 hipError_t ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int nt, float alpha, float beta,
+                                 const float* d_fll_taps,
                                  DdnCqpskState* state, float* delay_store, void* out, hipStream_t st);
 hipError_t ddn_dev_cqpsk_symbols(const void* sym, size_t stride, const int* counts, int n_channels, DdnCqpskState* state,
                                  float* out, size_t out_stride, hipStream_t st);

@@ -22,7 +22,7 @@ k_find_syncs(const uint8_t* __restrict__ flags, const int32_t* __restrict__ coun
              int32_t* __restrict__ sync_pos, int32_t* __restrict__ n_syncs) {
     const int ch = blockIdx.x;
     const int lane = threadIdx.x;
-    const int cnt = counts[ch];
+    const int cnt = counts[ch] < (int)max_sym ? counts[ch] : (int)max_sym; // the rx loop counts symbols it could not store
     const uint8_t* row = flags + (size_t)ch * max_sym;
     int found = 0;
     for (int base = 0; base < cnt; base += 64) {
@@ -56,7 +56,7 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
         return;
     }
     const int ch = (int)(slot / max_frames), k = (int)(slot % max_frames);
-    const int cnt = counts[ch];
+    const int cnt = counts[ch] < (int)max_sym ? counts[ch] : (int)max_sym;
     bool ok = k < n_syncs[ch];
     int start = 0;
     if (ok) {
@@ -80,10 +80,15 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
             bits[o + 1] = (uint8_t)b1;
         }
     }
+    // per-BIT reliabilities are min(|llr|, 255) of that bit's own LLR (p25p1_llr_reliability dispatch_p25p1.c:59-66,
+    // p25p1_append_bch_bits :73-83, soft_abs_i16 p25p1_ldu.c:21-24,135-152, p25p1_hdu.c:128-139, p25p1_tdulc.c:82-90);
+    // the record's per-dibit byte (their minimum) is only what the 3/4-rate trellis takes (dibit_rel below)
+    const int a0 = l0 < 0 ? -l0 : l0, a1 = l1 < 0 ? -l1 : l1;
+    const int r0 = a0 > 255 ? 255 : a0, r1 = a1 > 255 ? 255 : a1;
     if (rel) {
-        rel[o] = (uint8_t)r;
+        rel[o] = (uint8_t)r0;
         if (!tail) {
-            rel[o + 1] = (uint8_t)r;
+            rel[o + 1] = (uint8_t)r1;
         }
     }
     if (llr) {
@@ -97,7 +102,7 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
             last_bit[slot] = (uint8_t)b1;
         }
         if (last_rel) {
-            last_rel[slot] = (uint8_t)r;
+            last_rel[slot] = (uint8_t)r1; // dispatch_p25p1.c:142
         }
     }
     if (dibits) { // one byte per dibit (the 3/4-rate trellis decoder's input), reliability alongside

@@ -895,15 +895,24 @@ k_hamming_10_6_3_soft(const uint8_t* __restrict__ bits, const int32_t* __restric
     status[i] = (uint8_t)rc;
 }
 
-// syndrome -> error pattern table, built once per process on the device (immutable afterwards)
+// syndrome -> error pattern table, built once per DEVICE (immutable afterwards): the pointer is device memory, so a
+// process that moves to another GPU with hipSetDevice() must not reuse the first device's table
 static hipError_t
 golay_table(uint32_t** out, hipStream_t st) {
     static std::mutex mu;
-    static uint32_t* tab = nullptr;
+    static uint32_t* tabs[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        return e;
+    }
+    if (dev < 0 || dev >= 64) {
+        return hipErrorInvalidDevice;
+    }
     std::lock_guard<std::mutex> lock(mu);
-    if (!tab) {
+    if (!tabs[dev]) {
         uint32_t* t = nullptr;
-        hipError_t e = hipMalloc(&t, 2048 * sizeof(uint32_t));
+        e = hipMalloc(&t, 2048 * sizeof(uint32_t));
         if (e != hipSuccess) {
             return e;
         }
@@ -916,9 +925,9 @@ golay_table(uint32_t** out, hipStream_t st) {
             (void)hipFree(t);
             return e;
         }
-        tab = t;
+        tabs[dev] = t;
     }
-    *out = tab;
+    *out = tabs[dev];
     return hipSuccess;
 }
 

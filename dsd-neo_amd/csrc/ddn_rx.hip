@@ -25,6 +25,7 @@
 // binary64 for k <= 1024 and a binary32 v, so the reference's sequential rebuild gives the same bits).
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 #include "ddn_device.h"
@@ -1302,13 +1303,24 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    static bool taps_up = false;
-    if (!taps_up) {
-        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_taps), ddn_p25_filter_bits, sizeof(uint32_t) * NT);
+    {   // the matched-filter taps are a __constant__ of this code object: one upload per device, under a lock
+        static std::mutex mu;
+        static bool taps_up[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) {
             return e;
         }
-        taps_up = true;
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= 64 || !taps_up[dev]) {
+            e = hipMemcpyToSymbol(HIP_SYMBOL(c_taps), ddn_p25_filter_bits, sizeof(uint32_t) * NT);
+            if (e != hipSuccess) {
+                return e;
+            }
+            if (dev >= 0 && dev < 64) {
+                taps_up[dev] = true;
+            }
+        }
     }
     int cpw = channels_per_wave;
     if (cpw != 8 && cpw != 16 && cpw != 32 && cpw != 64) {

@@ -104,7 +104,8 @@ def extract_frames(rec4, flags, count):
         d = rec4[a + 1:a + 1 + FRAME - 24]
         nd = d[nid_idx]
         bits = np.stack([(nd[:, 0] >> 1) & 1, nd[:, 0] & 1], axis=1).reshape(64).astype(np.uint8)
-        rel = np.repeat(nd[:, 1], 2).astype(np.uint8)
+        # per-bit reliability = min(|llr of that bit|, 255) (dispatch_p25p1.c:59-83,138-142), not the dibit's byte
+        rel = np.minimum(np.abs(np.stack([nd[:, 2], nd[:, 3]], axis=1)), 255).reshape(64).astype(np.uint8)
         blk = d[bp]
         llr = np.stack([blk[:, 2], blk[:, 3]], axis=1).reshape(196).astype(np.int16)
         frames.append((bits[:63], rel[:63], int(bits[63]), int(rel[63]), llr))

@@ -108,8 +108,15 @@ def test_device_chain_tsdu_traffic(built):
             assert np.array_equal(dibh[c, k], w[:, 0]) and np.array_equal(drlh[c, k], w[:, 1]), (c, k)
     nid, out, met = nid.cpu().numpy().reshape(B, F, 4), out.cpu().numpy().reshape(B, F, 12), met.cpu().numpy().reshape(B, F)
     v_blk = v_blk.cpu().numpy().reshape(B, F)
+    bith, relh = bits.cpu().numpy().reshape(B, F, 63), rel.cpu().numpy().reshape(B, F, 63)
+    parh, prelh = par.cpu().numpy().reshape(B, F), prel.cpu().numpy().reshape(B, F)
     for c in range(B):
         w = want[c]
+        k = len(w["nid"])
+        # the gathered NID fields themselves: hard bits, per-bit min(|llr|, 255) reliabilities, parity bit and its
+        # reliability, as p25p1_read_nid_fields builds them (dispatch_p25p1.c:123-143) from the same records
+        assert np.array_equal(bith[c, :k], w["bits"]) and np.array_equal(relh[c, :k], w["rel"]), c
+        assert np.array_equal(parh[c, :k], w["par"]) and np.array_equal(prelh[c, :k], w["prel"]), c
         assert ns[c] == len(w["acc"]) and np.array_equal(pos[c, :ns[c]], w["acc"]), c   # every accepted sync, in order
         k = len(w["nid"])                                  # frames the host extraction found complete
         assert np.all(v_blk[c, :k] == 1) and np.all(v_blk[c, ns[c]:] == 0)
@@ -168,7 +175,8 @@ def test_device_chain_voice_capture(built):
                 continue
             w = r4[a + 1:a + 1 + 840][rel_pos]              # [24, 5, 4]
             bits = np.stack([(w[:, :, 0] >> 1) & 1, w[:, :, 0] & 1], axis=2).reshape(24, 10)
-            rl = np.repeat(w[:, :, 1], 2, axis=1)
+            # soft_abs_i16 of each bit's own LLR (p25p1_ldu.c:135-152)
+            rl = np.minimum(np.abs(np.stack([w[:, :, 2], w[:, :, 3]], axis=2)), 255).reshape(24, 10)
             assert vvh[k] == 1 and np.array_equal(wbh[k], bits) and np.array_equal(wrh[k], rl), (ldu, k)
             seen += 1
         assert seen >= 4

@@ -22,7 +22,7 @@ def nids_from_records(rec4, fl, count):
             break
         nd = rec4[a + 1:a + 34][keep]
         bits = np.stack([(nd[:, 0] >> 1) & 1, nd[:, 0] & 1], axis=1).reshape(64).astype(np.uint8)
-        rel = np.repeat(nd[:, 1], 2).astype(np.uint8)
+        rel = np.minimum(np.abs(np.stack([nd[:, 2], nd[:, 3]], axis=1)), 255).reshape(64).astype(np.uint8)
         rows.append((int(a), bits, rel))
     return rows
 
