@@ -1,4 +1,4 @@
-"""ctypes binding of libdsdneo_hip.so (include/ddn_hip.h) — the shape of stub a host application adds.
+"""ctypes binding of libdsdneo_hip.so (include/ddn_hip.h, include/ddn_mbe.h) — the shape of stub a host application adds.
 
 This module is plumbing for tests/ and bench.py: it loads the in-tree shared library and declares the C-ABI
 prototypes.  It never falls back to a CPU implementation: if the library (or a GPU) is missing the calls raise.
@@ -222,6 +222,60 @@ PROTOTYPES = {
     "CNXDNConvolution_chainback": (None, [C.c_void_p, C.c_uint]),
     "ddn_fsk_modem_discriminator_process": (C.c_int, [C.POINTER(FskModemState), C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
 }
+
+# ---- include/ddn_mbe.h ------------------------------------------------------------------------------------------------
+class MbeParms(C.Structure):
+    _fields_ = [("w0", C.c_float), ("L", C.c_int), ("K", C.c_int), ("Vl", C.c_int * 57), ("Ml", C.c_float * 57),
+                ("log2Ml", C.c_float * 57), ("PHIl", C.c_float * 57), ("PSIl", C.c_float * 57), ("gamma", C.c_float),
+                ("un", C.c_int), ("repeat", C.c_int)]
+
+
+class MbeProcessResult(C.Structure):
+    _fields_ = [("flags", C.c_uint), ("c0_errors", C.c_int), ("c4_errors", C.c_int), ("total_errors", C.c_int),
+                ("protected_errors", C.c_int)]
+
+
+class MbeTables(C.Structure):
+    _fields_ = [("magic", C.c_uint32), ("synthetic", C.c_uint32),
+                ("imbe_gain_b2", C.c_float * 64), ("imbe_gain_step", C.c_float * 11), ("imbe_gain_sigma", C.c_float * 5),
+                ("imbe_hoc_step", C.c_float * 11), ("imbe_hoc_sigma", C.c_float * 9),
+                ("imbe_bits", (C.c_uint8 * 58) * 48), ("imbe_bit_order", ((C.c_uint8 * 2) * 88) * 48),
+                ("ambe_f0", C.c_float * 120), ("ambe_L", C.c_uint8 * 120), ("ambe_vuv", (C.c_uint8 * 8) * 32),
+                ("ambe_dg", C.c_float * 32), ("ambe_prba24", (C.c_float * 3) * 512), ("ambe_prba58", (C.c_float * 4) * 128),
+                ("ambe_hoc5", (C.c_float * 4) * 32), ("ambe_hoc6", (C.c_float * 4) * 16), ("ambe_hoc7", (C.c_float * 4) * 16),
+                ("ambe_hoc8", (C.c_float * 4) * 8), ("ambe_blocks", (C.c_uint8 * 4) * 57)]
+
+
+MBE_IMBE, MBE_AMBE = 0, 1
+_PP = C.POINTER(MbeParms)
+PROTOTYPES.update({
+    "ddn_mbe_default_tables": (C.c_int, [C.POINTER(MbeTables)]),
+    "ddn_mbe_validate_tables": (C.c_int, [C.POINTER(MbeTables)]),
+    "ddn_mbe_frame_decode_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_mbe_batch_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ddn_mbe_batch_destroy": (None, [C.c_void_p]),
+    "ddn_mbe_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_mbe_batch_set_tables": (C.c_int, [C.c_void_p, C.POINTER(MbeTables)]),
+    "ddn_mbe_batch_set_p25p1_tail_rule": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_mbe_synth_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_mbe_batch_get_state": (C.c_int, [C.c_void_p, C.c_int, _PP, _PP, _PP]),
+    "ddn_mbe_batch_set_state": (C.c_int, [C.c_void_p, C.c_int, _PP, _PP, _PP]),
+    "ddn_mbe_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_mbe_batch_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mbe_initMbeParms": (None, [_PP, _PP, _PP]),
+    "mbe_initProcessResult": (None, [C.POINTER(MbeProcessResult)]),
+    "mbe_synthesizeSilencef": (None, [C.c_void_p]),
+    "mbe_formatProcessResult": (None, [C.c_char_p, C.c_size_t, C.POINTER(MbeProcessResult)]),
+    "mbe_decodeImbe7200x4400Frame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MbeProcessResult)]),
+    "mbe_decodeImbe7200x4400SoftFrame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MbeProcessResult)]),
+    "mbe_decodeAmbe3600x2450Frame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MbeProcessResult)]),
+    "mbe_decodeAmbe3600x2450SoftFrame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MbeProcessResult)]),
+    "mbe_processImbe4400Dataf": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, _PP, _PP, _PP]),
+    "mbe_processAmbe2450Dataf": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, _PP, _PP, _PP]),
+    "mbe_processAmbe3600x2450Framef": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, C.c_void_p, _PP, _PP, _PP]),
+    "mbe_processAmbe3600x2450SoftFramef": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, C.c_void_p, _PP, _PP, _PP]),
+})
+
 
 _lib = None
 

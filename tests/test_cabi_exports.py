@@ -1,4 +1,4 @@
-"""CPU: libdsdneo_hip.so loads without a GPU and exports every symbol include/ddn_hip.h declares; compute calls
+"""CPU: libdsdneo_hip.so loads without a GPU and exports every symbol include/*.h declares; compute calls
 fail loudly (DDN_ENODEV) instead of falling back to a CPU path."""
 import ctypes as C
 import os
@@ -10,11 +10,11 @@ import ddn
 
 
 def declared_functions():
-    text = open(os.path.join(ddn.ROOT, "include", "ddn_hip.h")).read()
+    text = "".join(open(os.path.join(ddn.ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ddn.ROOT, "include"))))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b([A-Za-z_0-9]+)\s*\([^;{]*\)\s*;", text)
     return sorted(set(n for n in names if n.startswith(("ddn_", "simd_", "widen_", "p25_", "dmr_", "viterbi_",
-                                                         "CNXDN", "check_", "hamming_", "golay_", "bch_", "p25p1_", "dsd_", "crc16_"))))
+                                                         "CNXDN", "check_", "hamming_", "golay_", "bch_", "p25p1_", "dsd_", "crc16_", "mbe_"))))
 
 
 def test_header_and_binding_agree(built):
