@@ -188,3 +188,112 @@ def ldu2_positions():
         for k in range(4):
             par[7 - 4 * s - k] = slots[4 + s][k]
     return np.array(data), np.array(par)
+
+
+# ---- LDU1 / LDU2 voice traffic (encoder side; reading order as ldu1_positions above / ddn_host_p25_layout.c) ----------
+DUID_LDU1, DUID_LDU2 = 0x5, 0xA
+LDU = 864
+_NID_PARITY = {0x5: 1, 0xA: 1}       # k_duid_parity_table, src/protocol/p25/phase1/p25p1_check_nid.cpp:44-49
+_CACHE = {}
+
+
+def _hamming_10_6_3_parity():
+    """6 data bits -> 4 parity bits of the P25 Hamming(10,6,3) word: the one parity the oracle's decoder accepts with no
+    correction (src/fec/hamming_10_6_3.cpp restated in oracle/ddn_oracle_block.c)."""
+    if "ham" not in _CACHE:
+        import ctypes as C
+        o = orc.oracle()
+        o.orc_hamming_10_6_3.argtypes = [C.c_int, C.c_void_p]
+        tab = np.zeros(64, np.int64)
+        for d in range(64):
+            for p in range(16):
+                f = C.c_int(0)
+                if o.orc_hamming_10_6_3((d << 4) | p, C.byref(f)) == 0:
+                    tab[d] = p
+                    break
+            else:
+                raise AssertionError(d)
+        _CACHE["ham"] = tab
+    return _CACHE["ham"]
+
+
+def _imbe_interleave_map():
+    """(row, col) of the IMBE code vector array carried by bit b (0 = high bit of dibit 0) of a voice frame's 72 dibits:
+    the inverse of process_IMBE's schedule, read off the oracle's de-interleaver with status skipping out of the way."""
+    if "imbe" not in _CACHE:
+        m = []
+        for b in range(144):
+            d = np.zeros(80, np.uint8)
+            d[b // 2] = 2 if b % 2 == 0 else 1
+            fr, _, _, _, _ = orc.oracle_imbe_deinterleave(d, np.zeros(80, np.int16), np.zeros(80, np.int16), 36 + 40)
+            rc = np.argwhere(fr)
+            assert rc.shape == (1, 2), (b, rc)
+            m.append((int(rc[0, 0]), int(rc[0, 1])))
+        assert len(set(m)) == 144
+        _CACHE["imbe"] = m
+    return _CACHE["imbe"]
+
+
+def imbe_frame_to_dibits(fr):
+    """u8 [8][23] code vectors (mbelib layout) -> the 72 dibits that carry them on the air."""
+    bits = np.array([fr[r, c] for (r, c) in _imbe_interleave_map()], np.int64)
+    return ((bits[0::2] << 1) | bits[1::2]).astype(np.int8)
+
+
+def _lsd_codeword(d8):
+    import ctypes as C
+    o = orc.oracle()
+    p = o.orc_p25_lsd_parity(int(d8))
+    bits = [(d8 >> (7 - k)) & 1 for k in range(8)] + [(p >> (7 - k)) & 1 for k in range(8)]
+    return [(bits[2 * k] << 1) | bits[2 * k + 1] for k in range(8)]
+
+
+def make_ldus(rng, n_ldus, nac, imbe_frames):
+    """-> (dibits int8 [n_ldus * 864], hex words) for alternating LDU1 / LDU2 frames carrying imbe_frames
+    u8 [n_ldus * 9][8][23] (already FEC-encoded code vectors, tests/mbe.py:imbe_encode)."""
+    ham = _hamming_10_6_3_parity()
+    out = np.zeros((n_ldus, LDU), np.int8)
+    words_sent = []
+    for f in range(n_ldus):
+        ldu = 1 + (f & 1)
+        duid = DUID_LDU1 if ldu == 1 else DUID_LDU2
+        data16 = [(nac >> (11 - k)) & 1 for k in range(12)] + [(duid >> (3 - k)) & 1 for k in range(4)]
+        cw = list(fecgen.bch_63_16_encode(data16)) + [_NID_PARITY[duid]]
+        nid = [(cw[2 * k] << 1) | cw[2 * k + 1] for k in range(32)]
+        n_data, t = (12, 6) if ldu == 1 else (16, 4)
+        d = rng.integers(0, 64, n_data)
+        syms = list(d) + list(fecgen.rs63_encode(d, t))          # hex_data[0..], hex_parity[0..]
+        words_sent.append(np.array(syms))
+        word_dibits = []
+        for s in syms:
+            b10 = [(int(s) >> (5 - k)) & 1 for k in range(6)] + [(int(ham[int(s)]) >> (3 - k)) & 1 for k in range(4)]
+            word_dibits.append([(b10[2 * k] << 1) | b10[2 * k + 1] for k in range(5)])
+        dpos, ppos = ldu1_positions() if ldu == 1 else ldu2_positions()
+        fr = np.zeros(LDU, np.int8)
+        fr[:24] = orc.P25_FS_DIBITS
+        fr[[p for p in range(24, 57) if p != 35]] = nid
+        for w in range(n_data):
+            fr[dpos[w]] = word_dibits[w]
+        for w in range(24 - n_data):
+            fr[ppos[w]] = word_dibits[n_data + w]
+        import ddn
+        import ctypes as C
+        first9 = np.zeros(9, np.int32)
+        st9 = np.zeros(9, np.int32)
+        ddn.lib().ddn_p25p1_layout_ldu_imbe(first9.ctypes.data, st9.ctypes.data)
+        for v in range(9):
+            idx, got = int(first9[v]), 0
+            vd = imbe_frame_to_dibits(imbe_frames[f * 9 + v])
+            while got < 72:
+                if idx % 36 == 35:
+                    idx += 1
+                    continue
+                fr[idx] = vd[got]
+                got += 1
+                idx += 1
+        lsd = np.zeros(16, np.int32)
+        ddn.lib().ddn_p25p1_layout_ldu_lsd(lsd.ctypes.data)
+        fr[lsd] = _lsd_codeword(int(rng.integers(0, 256))) + _lsd_codeword(int(rng.integers(0, 256)))
+        fr[35::36] = 2                                               # status symbols
+        out[f] = fr
+    return out.reshape(-1), words_sent

@@ -158,8 +158,6 @@ def test_c5_shape_8192_frames_properties(built):
     a, _ = g2.run(bits[:, :50])
     b, _ = g2.run(bits[:, 50:])
     assert np.array_equal(np.concatenate([a, b], axis=1).view(np.uint32), pcm.view(np.uint32))
-    # windows cross-fade: consecutive frames of a voiced talk path join without a step larger than the signal's own
-    assert np.abs(pcm).max() < 1e6
 
 
 def test_dropin_process_matches_batch_and_tail_rule(built):
