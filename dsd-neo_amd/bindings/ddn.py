@@ -252,6 +252,8 @@ PROTOTYPES.update({
     "ddn_mbe_default_tables": (C.c_int, [C.POINTER(MbeTables)]),
     "ddn_mbe_validate_tables": (C.c_int, [C.POINTER(MbeTables)]),
     "ddn_mbe_frame_decode_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_mbe_result_skip_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_p25p1_framer_voice_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_mbe_batch_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ddn_mbe_batch_destroy": (None, [C.c_void_p]),
     "ddn_mbe_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),

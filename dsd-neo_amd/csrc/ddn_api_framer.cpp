@@ -209,6 +209,19 @@ ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_
 }
 
 extern "C" int
+ddn_p25p1_framer_voice_index(ddn_p25p1_framer* f, const int32_t* d_nid4, const int32_t* d_counts, int max_ldu_per_channel, size_t max_symbols,
+                             int64_t* d_first_record, int32_t* d_status_count, int32_t* d_n_ldu, void* hip_stream) {
+    if (!f || !d_nid4 || !d_counts || max_ldu_per_channel <= 0 || !d_first_record || !d_status_count) {
+        ddn_set_error("ddn_p25p1_framer_voice_index: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_voice_index(f->d_sync_pos, f->d_n_syncs, d_nid4, d_counts, f->n_channels, f->max_frames, max_ldu_per_channel,
+                                max_symbols, f->d_first9, f->d_status9, d_first_record, d_status_count, d_n_ldu,
+                                (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
 ddn_p25p1_framer_pack_ldu_rs(ddn_p25p1_framer* f, int ldu, const uint8_t* d_words240, uint8_t* d_data_bits,
                              uint8_t* d_parity_bits, void* hip_stream) {
     if (!f || (ldu != 1 && ldu != 2) || !d_words240 || !d_data_bits || !d_parity_bits) {

@@ -60,6 +60,16 @@ ddn_mbe_frame_decode_batch(int codec, const uint8_t* d_frames, const uint8_t* d_
     return DDN_OK;
 }
 
+extern "C" int
+ddn_mbe_result_skip_batch(const uint8_t* d_skip, size_t n, int32_t* d_result, void* hip_stream) {
+    if (n && (!d_skip || !d_result)) {
+        ddn_set_error("ddn_mbe_result_skip_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_mbe_result_skip(d_skip, n, d_result, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
 static void
 mbe_free(ddn_mbe_batch* b) {
     (void)hipFree(b->d_tables);

@@ -159,6 +159,9 @@ hipError_t ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32
 hipError_t ddn_dev_rs_pack(const uint8_t* words, long n_slots, int n_words, int wstride, int n_data, uint8_t* data,
                            uint8_t* parity, hipStream_t st);
 hipError_t ddn_dev_tdulc_rs_pack(const uint8_t* words, long n_slots, uint8_t* data, uint8_t* parity, hipStream_t st);
+hipError_t ddn_dev_voice_index(const int32_t* sync_pos, const int32_t* n_syncs, const int32_t* nid4, const int32_t* counts, int n_channels,
+                               int max_frames, int max_ldu, size_t max_sym, const int32_t* first9, const int32_t* status9,
+                               int64_t* first, int32_t* status, int32_t* n_ldu, hipStream_t st);
 hipError_t ddn_dev_imbe_index(const int32_t* sync_pos, const int32_t* n_syncs, int n_channels, int max_frames,
                               size_t max_sym, const int32_t* first9, const int32_t* status9, int64_t* first,
                               int32_t* status, hipStream_t st);

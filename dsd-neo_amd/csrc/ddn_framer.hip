@@ -241,3 +241,61 @@ ddn_dev_imbe_index(const int32_t* sync_pos, const int32_t* n_syncs, int n_channe
                        n_channels, max_frames, max_sym, first9, status9, first, status);
     return hipGetLastError();
 }
+
+namespace {
+// voice frames of every channel in air order, compacted: the slots whose NID decoded (status 1) to LDU1 / LDU2 - the
+// only callers of process_IMBE (processLDU1 / processLDU2, src/engine/dispatch/dispatch_p25p1.c) - in sync order, nine
+// frames each; unused entries get first = -1 (k_imbe_deinterleave flags those 0xFF).  One thread per channel: a
+// channel has a handful of frames per call.
+__global__ void
+k_voice_index(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_syncs, const int32_t* __restrict__ nid4,
+              const int32_t* __restrict__ counts, int n_channels, int max_frames, int max_ldu, size_t max_sym, const int32_t* __restrict__ first9,
+              const int32_t* __restrict__ status9, int64_t* __restrict__ first, int32_t* __restrict__ status,
+              int32_t* __restrict__ n_ldu) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= n_channels) {
+        return;
+    }
+    int k = 0;
+    const int ns = n_syncs[ch];
+    const int cnt = counts[ch] < (int)max_sym ? counts[ch] : (int)max_sym;
+    for (int slot = 0; slot < ns && k < max_ldu; slot++) {
+        const int32_t* nd = nid4 + ((size_t)ch * max_frames + slot) * 4;
+        if (nd[0] == 1 && (nd[2] == 0x5 || nd[2] == 0xA)) {
+            const int start = sync_pos[(size_t)ch * max_frames + slot] - 23;
+            const int64_t base = (int64_t)((size_t)ch * max_sym) + start;
+            for (int v = 0; v < 9; v++) {
+                // a frame whose 72 dibits (+ the status symbols stepped over on the way) run past this channel's records
+                // is left for the next call's records: -1 here (the flat record array continues with the next channel)
+                const int sc0 = status9[v], t1 = 35 - sc0;
+                const int last = start + first9[v] + 71 + ((sc0 <= 35 && 71 >= t1) ? 1 + (71 - t1) / 35 : 0);
+                first[((size_t)ch * max_ldu + k) * 9 + v] = last < cnt ? base + first9[v] : -1;
+                status[((size_t)ch * max_ldu + k) * 9 + v] = status9[v];
+            }
+            k++;
+        }
+    }
+    if (n_ldu) {
+        n_ldu[ch] = k;
+    }
+    for (; k < max_ldu; k++) {
+        for (int v = 0; v < 9; v++) {
+            first[((size_t)ch * max_ldu + k) * 9 + v] = -1;
+            status[((size_t)ch * max_ldu + k) * 9 + v] = 0;
+        }
+    }
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_voice_index(const int32_t* sync_pos, const int32_t* n_syncs, const int32_t* nid4, const int32_t* counts,
+                    int n_channels, int max_frames,
+                    int max_ldu, size_t max_sym, const int32_t* first9, const int32_t* status9, int64_t* first,
+                    int32_t* status, int32_t* n_ldu, hipStream_t st) {
+    if (n_channels <= 0 || max_ldu <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_voice_index, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, sync_pos, n_syncs, nid4,
+                       counts, n_channels, max_frames, max_ldu, max_sym, first9, status9, first, status, n_ldu);
+    return hipGetLastError();
+}

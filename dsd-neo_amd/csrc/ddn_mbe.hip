@@ -782,6 +782,14 @@ k_mbe_synth(const DdnMbeFrameRec* __restrict__ recs, float* __restrict__ pcm) {
 }
 
 __global__ void
+k_mbe_result_skip(const uint8_t* __restrict__ skip, size_t n, int32_t* __restrict__ result) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && skip[i]) {
+        result[i * 5] = (int32_t)((uint32_t)result[i * 5] | DDN_MBE_RESULT_INVALID);
+    }
+}
+
+__global__ void
 k_mbe_stream_init(DdnMbeStream* streams, int n, uint32_t seed0) {
     const int s = blockIdx.x;
     const int l = threadIdx.x;
@@ -847,5 +855,14 @@ ddn_dev_mbe_synth(const DdnMbeFrameRec* recs, size_t n_frames_total, float* pcm,
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_mbe_synth, dim3((unsigned)n_frames_total), dim3(64), 0, st, recs, pcm);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_mbe_result_skip(const uint8_t* skip, size_t n, int32_t* result, hipStream_t st) {
+    if (n == 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_mbe_result_skip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, skip, n, result);
     return hipGetLastError();
 }

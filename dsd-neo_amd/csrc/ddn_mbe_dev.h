@@ -31,6 +31,7 @@ struct DdnMbeFrameRec {
 extern "C" {
 hipError_t ddn_dev_mbe_frame_decode(int codec, const uint8_t* frames, const uint8_t* soft, size_t n, uint8_t* bits,
                                     int32_t* result, hipStream_t st);
+hipError_t ddn_dev_mbe_result_skip(const uint8_t* skip, size_t n, int32_t* result, hipStream_t st);
 hipError_t ddn_dev_mbe_stream_init(DdnMbeStream* streams, int n_streams, uint32_t seed0, hipStream_t st);
 hipError_t ddn_dev_mbe_params(int codec, const uint8_t* bits, const int32_t* res_in, int n_streams, int n_frames,
                               const ddn_mbe_tables* d_tables, const float* d_half_log2, DdnMbeStream* streams,

@@ -349,6 +349,15 @@ int ddn_p25p1_framer_gather_lsd(ddn_p25p1_framer* f, const uint8_t* d_records10,
                                 void* hip_stream);
 int ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_first_record,
                                 int32_t* d_status_count, void* hip_stream);
+/* The same index compacted to voice traffic: for every channel the slots whose decoded NID (d_nid4 [slots][4] from
+ * ddn_p25p1_nid_decode_batch: status 1, DUID 0x5 / 0xA - processLDU1 / processLDU2 are the only callers of process_IMBE,
+ * src/engine/dispatch/dispatch_p25p1.c) in sync order, nine voice frames each: d_first_record / d_status_count
+ * [n_channels][max_ldu_per_channel][9] (unused entries and frames that run past the channel's d_counts records: -1 -> ddn_p25p1_imbe_deinterleave_batch
+ * flags them 0xFF),
+ * d_n_ldu [n_channels] (optional).  The row of a channel is its talk path for ddn_mbe_synth_batch. */
+int ddn_p25p1_framer_voice_index(ddn_p25p1_framer* f, const int32_t* d_nid4, const int32_t* d_counts,
+                                 int max_ldu_per_channel, size_t max_symbols,
+                                 int64_t* d_first_record, int32_t* d_status_count, int32_t* d_n_ldu, void* hip_stream);
 
 /* ---- rational resampler, batched -------------------------------------------------------------------
  * == dsd_resampler_design + dsd_resampler_process_block (include/dsd-neo/dsp/resampler.h:66-89;

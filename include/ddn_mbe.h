@@ -136,6 +136,11 @@ enum { DDN_MBE_IMBE_7200X4400 = 0, DDN_MBE_AMBE_3600X2450 = 1 };
 int ddn_mbe_frame_decode_batch(int codec, const uint8_t* d_frames, const uint8_t* d_soft, size_t n, uint8_t* d_bits,
                                int32_t* d_result, void* hip_stream);
 
+/* marks result rows whose frame must not reach the decoder (d_skip [n] != 0): ddn_mbe_synth_batch then emits silence for
+ * that frame position and leaves the talk path's history untouched - how a batch expresses "no voice frame here"
+ * (a slot that is not an LDU, a frame cut off by the end of the call) */
+int ddn_mbe_result_skip_batch(const uint8_t* d_skip, size_t n, int32_t* d_result, void* hip_stream);
+
 typedef struct ddn_mbe_batch ddn_mbe_batch;
 
 /* S talk paths; every path's {cur, prev, prev_enhanced} starts as mbe_initMbeParms leaves it */
