@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json metric on its named config.
+"""bench.py - BASELINE.json's metric on its end-to-end configuration.
 
     python bench.py --gpus N --steps K --warmup W
     (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one batch of synthetic input resident in HBM: BASELINE config[1]
-("4096 synthetic C4FM channels @48 ksps, FIR+discriminator ... only, 1xMI355X"): B = 4096 channels per GPU,
-n = 48000 complex cu8 samples (1 s of air time) per channel, block 8192.  Weak scaling: every rank owns its
-own 4096 channels (channels are independent streams — no data-path collective).
+metric  "I/Q Msamples/s end-to-end (demod->FEC->MBE) per GPU; % HBM roofline"
+step    BASELINE configs[2] with the vocoder on: B = 4096 P25 Phase 1 channels per GPU x n = 48000 complex cu8 samples (1 s
+        of air time each), resident in HBM, through the whole chain on the device:
+          widen + 135-tap channel LPF + FSK discriminator -> P25 matched filter -> symbolizer + frame sync + slicer
+          (bit-exact 10-byte dibit records) -> framer -> NID BCH(63,16) -> TSDU 1/2-rate trellis + CRC16 /
+          LDU1-LDU2 24 x Hamming(10,6,3) + RS(24,12,13) / RS(24,16,9) -> 9 IMBE frames per LDU: de-interleave ->
+          Golay / Hamming / PN frame decode -> parameter unpack -> enhancement -> synthesis to f32 PCM.
+        Traffic: even channels carry voice (LDU1 / LDU2 back to back), odd channels a control channel (TSDUs); 64 distinct
+        channels of each kind tiled to B.  Carried state streams from step to step.
+Weak scaling: every rank owns its own B channels (independent streams, no data-path collective).
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel = k_front_end_fused, timed with
-HIP events on the launch stream inside the C-ABI) and `cpu_baseline` (the oracle's C restatement — or the
-compiled reference when oracle/_ref is present — timed on the host, bounded sample).
-"""
+Rank 0 prints ONE JSON line.  `roofline` describes the chain's dominant kernel (k_p25_rxw, timed with HIP events on the
+launch stream inside the C-ABI) against the chain's algorithmic bytes (2 B cu8 in + 10 B per symbol record
+out = 3.0 B/sample, + 640 B per synthesized voice frame).  `cpu_baseline` is the same chain on the host (compiled reference
+front end where oracle/_ref exists + the C restatement of everything after it), 1 core and all cores.  `front_end_stage`
+keeps BASELINE configs[1] (FIR + discriminator only) as a named sub-object with its own roofline."""
 import argparse
 import json
 import os
@@ -26,238 +33,191 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 B_PER_GPU = 4096
 N_SAMPLES = 48000
 BLOCK = 8192
-BYTES_PER_SAMPLE = 6.0       # 2 B cu8 in + 4 B f32 discriminator out
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
+N_BASE = 64                  # distinct channels of each traffic kind
 
 
-def gen_input_gpu(torch, dev, ch_first, n_ch, n, sps=10):
-    """Same signal model as tests/orc.py:synth_c4fm_cu8, evaluated on the GPU (cos/sin differ in the last ulp
-    from numpy, which only moves a few quantisation LSBs; parity is checked on the bytes actually used)."""
-    n_sym = (n + sps - 1) // sps
-    x = (torch.arange(ch_first, ch_first + n_ch, device=dev, dtype=torch.int64) + 0xC0FFEE11) & 0xFFFFFFFF
-    sym = torch.empty((n_ch, n_sym), device=dev, dtype=torch.int64)
-    for s in range(n_sym):
-        x = (x * 1664525 + 1013904223) & 0xFFFFFFFF
-        sym[:, s] = (x >> 30) & 3
-    lv = (sym * 2 - 3).to(torch.float64)
-    step = (lv * 0.028).repeat_interleave(sps, dim=1)[:, :n]
-    ph = 0.19 + torch.cumsum(step, dim=1)
-    i = 0.85 * torch.cos(ph)
-    q = 0.85 * torch.sin(ph)
-    a = (3.0 * 0.5 * 0.85 ** 2 * 10.0 ** (-20.0 / 10.0)) ** 0.5
+def make_base_traffic(n):
+    """-> (voice cu8 [N_BASE][n][2], control cu8 [N_BASE][n][2]); deterministic."""
+    import numpy as np
+    import mbe
+    import p25gen
+    rng = np.random.default_rng(20260928)
+    n_ldus = n // 8640 + 2
+    voice = np.zeros((N_BASE, n, 2), np.uint8)
+    ctrl = np.zeros((N_BASE, n, 2), np.uint8)
+    for c in range(N_BASE):
+        bits = mbe.random_imbe_bits(rng, (n_ldus * 9,))
+        frames = np.stack([mbe.imbe_encode(b) for b in bits])
+        dib, _ = p25gen.make_ldus(rng, n_ldus, 0x293, frames)
+        voice[c] = p25gen.modulate_cu8(dib, n, lead=200 + 11 * c, seed=c)
+        dib, _ = p25gen.make_frames(rng, n // 1800 + 1, 0x293, crc=True)
+        ctrl[c] = p25gen.modulate_cu8(dib, n, lead=200 + 13 * c, seed=1000 + c)
+    return voice, ctrl
 
-    def h32(v):
-        v = v & 0xFFFFFFFF
-        v = ((v ^ (v >> 16)) * 0x7FEB352D) & 0xFFFFFFFF
-        v = ((v ^ (v >> 15)) * 0x846CA68B) & 0xFFFFFFFF
-        return v ^ (v >> 16)
 
-    idx = (torch.arange(ch_first, ch_first + n_ch, device=dev, dtype=torch.int64)[:, None] * (2 * n)
-           + torch.arange(n, device=dev, dtype=torch.int64)[None, :] * 2)
-    ni = (h32(idx).to(torch.float64) / 4294967296.0 * 2.0 - 1.0) * a
-    nq = (h32(idx + 1).to(torch.float64) / 4294967296.0 * 2.0 - 1.0) * a
-    out = torch.empty((n_ch, n, 2), device=dev, dtype=torch.uint8)
-    out[:, :, 0] = torch.clamp(torch.round(127.5 + 127.5 * (i + ni)), 0, 255).to(torch.uint8)
-    out[:, :, 1] = torch.clamp(torch.round(127.5 + 127.5 * (q + nq)), 0, 255).to(torch.uint8)
+def channel_source(ch):
+    """global channel index -> (kind, base index)"""
+    return ("voice" if ch % 2 == 0 else "ctrl"), (ch // 2) % N_BASE
+
+
+def usable_cores():
+    """cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a container can see 256
+    logical CPUs and be allowed a handful)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _cpu_worker(args):
+    """One process of the CPU baseline: run the chain on `iq` (k channels) `reps` times; returns stage seconds."""
+    iq, locks, Fv, reps = args
+    import chain_oracle
+    T = {}
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for c in range(iq.shape[0]):
+            chain_oracle.run_channel(iq[c], locks[c], Fv, seed=c, timers=T, use_ref_front_end=True)
+    T["wall"] = time.perf_counter() - t0
+    return T
+
+
+def cpu_baseline(voice, ctrl, n, Fv):
+    """The same chain on the host, timed INSIDE the C calls (Python glue excluded): compiled reference front end
+    (oracle/_ref, AVX2 unit) where present, the C restatement for the receive loop, NID, trellis, IMBE and synthesis
+    (Hamming(10,6,3) / Reed-Solomon words of the LDUs are not in the CPU figure - in the CPU's favour)."""
+    import numpy as np
+    import multiprocessing as mp
+    import orc
+    iq = np.stack([voice[0], ctrl[0], voice[1], ctrl[1]])
+    locks = [840, 156, 840, 156]
+    _cpu_worker((iq, locks, Fv, 1))                      # warm-up (page-in, table builds)
+    reps, T = 0, {}
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 10.0:
+        t = _cpu_worker((iq, locks, Fv, 1))
+        for k, v in t.items():
+            T[k] = T.get(k, 0.0) + v
+        reps += 1
+    stages = {k: v for k, v in T.items() if k != "wall"}
+    c_seconds = sum(stages.values())
+    samples = reps * iq.shape[0] * n
+    one = samples / c_seconds / 1e6
+    cores = usable_cores()
+    all_cores = None
+    if cores > 1:
+        per = max(1, int(4.0 / (T["wall"] / reps)))          # ~4 s of work per worker
+        ctx = mp.get_context("fork")
+        with ctx.Pool(cores) as pool:
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_worker, [(iq, locks, Fv, per)] * cores)
+            wall = time.perf_counter() - t0
+        # aggregate rate over the pool, again counting only time inside the C calls of the slowest worker
+        slow = max(sum(v for k, v in r.items() if k != "wall") for r in res)
+        all_cores = {"value": round(cores * per * iq.shape[0] * n / slow / 1e6, 3), "unit": "Msamples/s", "cores": cores,
+                     "wall_s": round(wall, 2)}
+    kind = "reference+port" if orc.have_ref() else "port"
+    return {"value": round(one, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d channels (2 voice + 2 control) x %d samples x %d reps of the bench traffic through the whole chain on "
+                      "one core, time inside the C calls only; front end = %s, everything after it = oracle C restatement "
+                      "(kind=%s)" % (iq.shape[0], n, reps, "oracle/_ref compiled reference (AVX2 unit)" if orc.have_ref()
+                                     else "oracle C restatement", kind),
+            "stage_share": {k: round(v / c_seconds, 3) for k, v in sorted(stages.items())},
+            "all_cores": all_cores}
+
+
+def parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n):
+    """Before any timing: a sample of this rank's channels, first call of a fresh stream, against the chain of CPU oracles -
+    dibit records, NIDs, decoded voice parameter bits and PCM all bit-exact."""
+    import numpy as np
+    import chain_oracle
+    import orc
+    chain.run(d_iq)
+    torch.cuda.synchronize()
+    pick = sorted(set([0, 1, 2, 3, B // 2, B // 2 + 1, B - 2, B - 1]))
+    cnt = chain.cnt.cpu().numpy()
+    out = {"checked_channels": len(pick), "records_bit_exact": True, "nid_equal": True, "voice_bits_equal": True,
+           "pcm_bit_exact": True, "voice_frames_checked": 0}
+    for c in pick:
+        kind, bi = channel_source(ch_first + c)
+        iq_c = voice[bi] if kind == "voice" else ctrl[bi]
+        w = chain_oracle.run_channel(iq_c, 840 if kind == "voice" else 156, chain.Fv, seed=c)
+        rec = chain.rec[c, :cnt[c]].cpu().numpy()
+        r4, sym = orc.unpack_records10(rec)
+        if not (cnt[c] == len(w["sym"]) and np.array_equal(r4, w["rec4"]) and np.array_equal(sym.view(np.uint32), w["sym"].view(np.uint32))):
+            out["records_bit_exact"] = False
+        nid = chain.nid[c * chain.F:(c + 1) * chain.F].cpu().numpy()
+        for k, nd in enumerate(w["nids"]):
+            if nd is not None and not np.array_equal(nid[k], nd):
+                out["nid_equal"] = False
+        live = ~w["skip"]
+        d = chain.imbe_d[c * chain.Fv * 9:(c + 1) * chain.Fv * 9].cpu().numpy()
+        if not np.array_equal(d[live], w["imbe_d"][live]):
+            out["voice_bits_equal"] = False
+        pcm = chain.pcm[c].cpu().numpy()
+        if not np.array_equal(pcm.view(np.uint32), w["pcm"].view(np.uint32)):
+            out["pcm_bit_exact"] = False
+        out["voice_frames_checked"] += int(live.sum())
+    out["bit_exact"] = all(out[k] for k in ("records_bit_exact", "nid_equal", "voice_bits_equal", "pcm_bit_exact"))
     return out
 
 
-def cpu_baseline(iq_sample_u8):
-    """Time the CPU path on a bounded sample of the same workload: whole channels of n=48000 samples through
-    widen -> LPF -> discriminator, one thread (the reference's demod is single-threaded per stream)."""
-    import numpy as np
-    import orc
-    kind = "port"
-    n_ch, n = iq_sample_u8.shape[0], iq_sample_u8.shape[1]
-    if orc.have_ref():
-        kind = "reference"
-
-        def run():
-            for c in range(n_ch):
-                orc.ref_front_end_cu8(iq_sample_u8[c], BLOCK)
-    else:
-        def run():
-            orc.oracle_batch_cu8(iq_sample_u8, BLOCK)
-    run()  # warm-up (page-in, dispatch init)
-    reps, t_used = 0, 0.0
-    t0 = time.perf_counter()
-    while t_used < 12.0:
-        run()
-        reps += 1
-        t_used = time.perf_counter() - t0
-    msps = reps * n_ch * n / t_used / 1e6
-    return {"value": round(msps, 3), "unit": "Msamples/s", "cores": 1, "kind": kind,
-            "sample": "%d channels x %d samples x %d reps of the bench input, block %d, 1 thread (%s)"
-                      % (n_ch, n, reps, BLOCK, "oracle/_ref compiled reference, AVX2 unit" if kind == "reference"
-                         else "oracle C restatement, FMA order")}
-
-
-def gardner_variant(torch, ddn, orc, B, n, front_end_ms):
-    """Informational, NOT part of `value`: configs[1]'s "FIR+discriminator+Gardner" shape - the
-    timing-error kernel (CQPSK Gardner + 8-tap MMSE, sps 10) on a batch of the same shape, float I/Q resident in HBM."""
-    import ctypes as C
-    import numpy as np
-    sps = 10
-    iq1 = orc.synth_qpsk_f32(9, 8, (n + 80) // sps + 8, sps)[:, :n]
-    d_iq = torch.from_numpy(np.tile(iq1, (B // 8 + 1, 1, 1))[:B].copy()).cuda()
-    h = C.c_void_p()
-    l = ddn.lib()
-    assert l.ddn_ted_batch_create(B, sps, 4800, 0.0, C.byref(h)) == 0
-    stride = n // sps + 64
-    d_sym = torch.zeros((B, stride, 2), dtype=torch.float32, device="cuda")
-    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+def front_end_stage(torch, ddn, chain, d_iq, B, n, steps):
+    """BASELINE configs[1] (FIR + discriminator only) as a stage figure: the fused front-end kernel alone."""
     st = torch.cuda.current_stream().cuda_stream
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = None
-    for _ in range(5):
-        e0.record()
-        rc = l.ddn_gardner_run(h, d_iq.data_ptr(), n, d_sym.data_ptr(), stride, d_cnt.data_ptr(), st)
-        e1.record()
-        torch.cuda.synchronize()
-        assert rc == 0
-        t = e0.elapsed_time(e1)
-        best = t if best is None else min(best, t)
-    l.ddn_ted_batch_destroy(h)
-    return {"note": "informational; Gardner + MMSE timing-error kernel (sps 10) on 4096 x 48000 complex samples",
-            "gardner_ms": round(best, 3), "front_end_ms": round(front_end_ms, 4),
-            "gardner_Msamples_per_s": round(B * n / (best * 1e-3) / 1e6, 1),
-            "fir_disc_gardner_Msamples_per_s": round(B * n / ((best + front_end_ms) * 1e-3) / 1e6, 1),
-            "symbols": int(d_cnt.sum().item())}
-
-
-def dibit_chain(torch, ddn, orc, B, n, front_end_ms):
-    """Informational, NOT part of `value`: the stage that turns the discriminator stream into the bit-exact dibit
-    records (P25p1 symbolizer + sync hunt + slicer, ddn_p25_rx_run) timed on framed synthetic P25p1 traffic of the
-    same batch shape, so the JSON line also shows what front end + dibit extraction costs per step."""
-    import numpy as np
-    base, _, _ = orc.synth_p25_disc(5, 64, n, frame_dibits=864)
-    x = torch.from_numpy(np.tile(base, (B // 64 + 1, 1))[:B].copy()).cuda()
-    rx = ddn.P25Rx(B, lock_symbols=840, use_matched_filter=1)
-    ms = ddn.lib().ddn_p25_rx_max_symbols(rx.h, n)
-    rec = torch.zeros((B, ms, 10), dtype=torch.uint8, device="cuda")
-    fl = torch.zeros((B, ms), dtype=torch.uint8, device="cuda")
-    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = None
-    for _ in range(4):
-        e0.record()
-        rc = ddn.lib().ddn_p25_rx_run(rx.h, x.data_ptr(), n, rec.data_ptr(), fl.data_ptr(), cnt.data_ptr(), ms, st)
-        e1.record()
-        torch.cuda.synchronize()
-        assert rc == 0
-        t = e0.elapsed_time(e1)
-        best = t if best is None else min(best, t)
-    # the same loop on one host core: the oracle's C restatement on 8 of the channels (~0.2 s)
-    import time
-    t0 = time.perf_counter()
-    for c in range(8):
-        orc.OracleP25Rx(lock_symbols=840, use_filter=1).run(base[c])
-    cpu_rx = 8 * n / (time.perf_counter() - t0) / 1e6
-    return {"note": "informational; front end on the bench input + P25p1 receive loop on framed synthetic traffic",
-            "p25_rx_ms": round(best, 3), "front_end_ms": round(front_end_ms, 4),
-            "Msamples_per_s": round(B * n / ((best + front_end_ms) * 1e-3) / 1e6, 1),
-            "syncs_found": int((fl & 2).ne(0).sum().item()), "symbols": int(cnt.sum().item()),
-            "cpu_rx_port_Msamples_per_s_1core": round(cpu_rx, 2)}
-
-
-def p25_e2e_chain(torch, ddn, B, n):
-    """Informational, NOT part of `value`: BASELINE configs[2] - B P25p1 channels end to end on the device: cu8 IQ ->
-    front end -> receive loop -> framer (sync index, NID / trellis-block gathers) -> BCH(63,16) NID -> 1/2-rate
-    trellis, on synthetic TSDU traffic (64 distinct channels tiled to B), checked against what was transmitted."""
-    import ctypes as C
-    import numpy as np
-    import p25gen
-    l = ddn.lib()
-    rng = np.random.default_rng(4242)
-    base = np.zeros((64, n, 2), np.uint8)
-    nac = 0x293
-    for c in range(64):
-        dib, _ = p25gen.make_frames(rng, n // (10 * p25gen.FRAME) + 1, nac, crc=True)
-        base[c] = p25gen.modulate_cu8(dib, n, lead=200 + 11 * c, seed=c)
-    d_iq = torch.from_numpy(np.tile(base, (B // 64 + 1, 1, 1))[:B].copy()).cuda()
-    d_disc = torch.zeros((B, n), dtype=torch.float32, device="cuda")
-    fe = ddn.Batch(B, block_len=BLOCK)
-    rx = ddn.P25Rx(B, lock_symbols=p25gen.FRAME - 24, use_matched_filter=1)
-    ms_ = l.ddn_p25_rx_max_symbols(rx.h, n)
-    rec = torch.zeros((B, ms_, 10), dtype=torch.uint8, device="cuda")
-    fl = torch.zeros((B, ms_), dtype=torch.uint8, device="cuda")
-    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
-    F = n // (10 * p25gen.FRAME) + 4
-    S = B * F
-    fr = C.c_void_p()
-    assert l.ddn_p25p1_framer_create(B, F, C.byref(fr)) == 0
-    u8 = lambda *sh: torch.zeros(sh, dtype=torch.uint8, device="cuda")
-    bits, rel, par, prel, valid = u8(S, 63), u8(S, 63), u8(S), u8(S), u8(S)
-    obs = torch.zeros(S, dtype=torch.int32, device="cuda")
-    nid = torch.zeros((S, 4), dtype=torch.int32, device="cuda")
-    llr = torch.zeros((S, 196), dtype=torch.int16, device="cuda")
-    out = u8(S, 12)
-    met = torch.zeros(S, dtype=torch.int32, device="cuda")
-    crc_ok = u8(S)
-    st = torch.cuda.current_stream().cuda_stream
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-
-    def run():
-        # streaming regime like the headline steps: carried state is kept from run to run (a fresh stream additionally pays
-        # the matched filter's one-off 90-sample cold start per channel, ~3 ms per 4096 channels)
-        ev[0].record()
-        fe.run_device(d_iq.data_ptr(), n, d_disc.data_ptr(), st)
-        ev[1].record()
-        assert l.ddn_p25_rx_run(rx.h, d_disc.data_ptr(), n, rec.data_ptr(), fl.data_ptr(), cnt.data_ptr(), ms_, st) == 0
-        ev[2].record()
-        assert l.ddn_p25p1_framer_index(fr, fl.data_ptr(), cnt.data_ptr(), ms_, st) == 0
-        assert l.ddn_p25p1_framer_gather_nid(fr, rec.data_ptr(), cnt.data_ptr(), ms_, bits.data_ptr(), rel.data_ptr(),
-                                             par.data_ptr(), prel.data_ptr(), None, st) == 0
-        assert l.ddn_p25p1_nid_decode_batch(bits.data_ptr(), rel.data_ptr(), obs.data_ptr(), par.data_ptr(),
-                                            prel.data_ptr(), 64, S, nid.data_ptr(), st) == 0
-        assert l.ddn_p25p1_framer_gather_trellis_block(fr, 0, rec.data_ptr(), cnt.data_ptr(), ms_, llr.data_ptr(), None,
-                                                       valid.data_ptr(), st) == 0
-        assert l.ddn_fec_p25_12_soft_batch(llr.data_ptr(), S, out.data_ptr(), met.data_ptr(), st) == 0
-        assert l.ddn_fec_p25_crc16_batch(out.data_ptr(), 12, S, crc_ok.data_ptr(), st) == 0
-        ev[3].record()
-        torch.cuda.synchronize()
-        return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
-
-    run()
-    t = min((run() for _ in range(3)), key=sum)
-    v = valid.cpu().numpy().astype(bool)
-    nd = nid.cpu().numpy()[v]
-    # the first two frames of a channel fall into the matched filter's turn-on transient (tests/test_e2e_p25.py)
-    good = int(((nd[:, 0] == 1) & (nd[:, 1] == nac) & (nd[:, 2] == p25gen.DUID_TSBK)).sum())
-    crc_good = int(crc_ok.cpu().numpy().astype(bool)[v].sum())
-    l.ddn_p25p1_framer_destroy(fr)
-    total = sum(t)
-    return {"note": "informational; configs[2]: cu8 IQ -> front end -> rx loop -> framer -> NID BCH + 1/2-rate trellis + CRC16, "
-                    "all on the device, synthetic TSDU traffic",
-            "front_end_ms": round(t[0], 3), "p25_rx_ms": round(t[1], 3), "framer_nid_trellis_ms": round(t[2], 3),
-            "Msamples_per_s": round(B * n / (total * 1e-3) / 1e6, 1), "frames": int(v.sum()),
-            "frames_with_expected_nac_duid": good, "tsbk_crc_ok": crc_good}
+    chain.fe.set_timing(True)
+    ms = []
+    for _ in range(steps):
+        chain.front_end(d_iq, st)
+        ms.append(float(chain.fe.timing()[0]))
+    chain.fe.set_timing(False)
+    ms = sorted(ms)[:max(1, len(ms) // 2)]
+    avg = sum(ms) / len(ms)
+    alg = 6.0 * B * n
+    return {"workload": "configs[1]: widen + 135-tap channel LPF + FSK discriminator, cu8 in -> f32 out",
+            "kernel": "k_front_end_fused", "launch_ms": round(avg, 4), "Msamples_per_s": round(B * n / (avg * 1e-3) / 1e6, 1),
+            "roofline": {"bound": "hbm", "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": 6.0}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=20)  # the first ~15 launches after an idle gap run up to 20 % slow
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=B_PER_GPU)
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-chain", action="store_true", help="skip the informational dibit-chain stage timing")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stage breakdown / PCIe / front-end sub-objects")
     args = ap.parse_args()
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    import ddn
-    import ddn_shard
-    import orc
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    n = args.samples
+    voice, ctrl = make_base_traffic(n)
+    Fv = n // 8640 + 2
+
+    # the CPU leg runs first: its worker pool forks, which must happen before this process holds a HIP context
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(voice, ctrl, n, Fv)
+
+    import torch
+    import torch.distributed as dist
+    import ddn
+    import ddn_chain
+    import ddn_shard
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -265,67 +225,85 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    # rank 0 owns the batch descriptor; every rank takes its block of the channel index.  Weak
-    # scaling: the job has world * channels_per_gpu channels, no data-path collective.
-    desc = ddn_shard.broadcast_descriptor({"B_total": args.channels * world, "n": args.samples, "blk": BLOCK}
-                                          if rank == 0 else None)
+    # rank 0 owns the batch descriptor; every rank takes its block of the channel index
+    desc = ddn_shard.broadcast_descriptor({"B_total": args.channels * world, "n": n, "blk": BLOCK} if rank == 0 else None)
     ch_first, B = ddn_shard.channel_range(rank, world, desc["B_total"])
-    n = desc["n"]
-    d_in = torch.cat([gen_input_gpu(torch, dev, ch_first + c, min(256, B - c), n) for c in range(0, B, 256)], 0)
-    d_out = torch.empty((B, n), dtype=torch.float32, device=dev)
-    batch = ddn.Batch(B, block_len=BLOCK)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        batch.run_device(d_in.data_ptr(), n, d_out.data_ptr(), stream)
+    d_voice = torch.from_numpy(voice).to(dev)
+    d_ctrl = torch.from_numpy(ctrl).to(dev)
+    kinds = [channel_source(ch_first + c) for c in range(B)]
+    idx_v = torch.tensor([bi for (k, bi) in kinds if k == "voice"], device=dev, dtype=torch.long)
+    idx_c = torch.tensor([bi for (k, bi) in kinds if k == "ctrl"], device=dev, dtype=torch.long)
+    is_v = torch.tensor([k == "voice" for (k, _) in kinds], device=dev)
+    d_iq = torch.empty((B, n, 2), dtype=torch.uint8, device=dev)
+    d_iq[is_v] = d_voice[idx_v]
+    d_iq[~is_v] = d_ctrl[idx_c]
+    del d_voice, d_ctrl
+    lock = np.array([840 if k == "voice" else 156 for (k, _) in kinds], np.int32)
+    chain = ddn_chain.P25Chain(torch, B, n, lock, block_len=BLOCK)
+    st = torch.cuda.current_stream().cuda_stream
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # parity gate before any timing: a sample of this rank's channels against the oracle, bit-exact
-    batch.reset(stream)
-    step()
-    torch.cuda.synchronize()
-    pick = sorted(set([0, 1, B // 2, B - 1] + list(range(5, B, max(1, B // 12)))))
-    host_iq = d_in[pick].cpu().numpy()
-    want = orc.oracle_batch_cu8(host_iq, BLOCK)
-    got = d_out[pick].cpu().numpy()
-    exact = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
-    max_err = float(np.abs(got.astype(np.float64) - want).max())
-    if not exact and max_err > 0.02 and not os.environ.get("DDN_BENCH_NOPARITY"):
-        raise SystemExit("parity gate failed: max|err| = %g" % max_err)
+    parity = parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n)
+    if not parity["bit_exact"] and not os.environ.get("DDN_BENCH_NOPARITY"):
+        raise SystemExit("parity gate failed: %s" % json.dumps(parity))
 
     for _ in range(args.warmup):
-        step()
-    batch.set_timing(True)
-    fir_ms, ser_ms = [], []
+        chain.run(d_iq, st)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        chain.run(d_iq, st)
     barrier()
     dt = time.perf_counter() - t0
-    t = batch.timing()  # events of the last step (kernel-only, on the launch stream)
-    fir_ms.append(float(t[0]))
-    ser_ms.append(float(t[1]))
-    # per-kernel averages over a separate instrumented loop (event sync per step, outside the timed region)
-    for _ in range(min(args.steps, 10)):
-        step()
-        t = batch.timing()
-        fir_ms.append(float(t[0]))
-        ser_ms.append(float(t[1]))
     dt = ddn_shard.reduce_max_seconds(dt, dev)
+
+    # per-stage / per-kernel times: a separate instrumented loop outside the timed region
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    l = ddn.lib()
+    l.ddn_p25_rx_set_timing(chain.rx.h, 1)
+    l.ddn_mbe_batch_set_timing(chain.mbe, 1)
+    stage_ms = np.zeros(4)
+    rx_ms = np.zeros(2)
+    mbe_ms = np.zeros(2)
+    reps = min(args.steps, 8)
+    for _ in range(reps):
+        ev[0].record()
+        chain.front_end(d_iq, st)
+        ev[1].record()
+        chain.receive(st)
+        ev[2].record()
+        chain.frame_fec(st)
+        ev[3].record()
+        chain.voice(st)
+        ev[4].record()
+        torch.cuda.synchronize()
+        stage_ms += [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+        t2 = np.zeros(2, np.float32)
+        l.ddn_p25_rx_get_timing(chain.rx.h, t2.ctypes.data)
+        rx_ms += t2
+        l.ddn_mbe_batch_get_timing(chain.mbe, t2.ctypes.data)
+        mbe_ms += t2
+    stage_ms /= reps
+    rx_ms /= reps
+    mbe_ms /= reps
+    l.ddn_p25_rx_set_timing(chain.rx.h, 0)
+    l.ddn_mbe_batch_set_timing(chain.mbe, 0)
 
     if rank == 0:
         total_samples = float(world) * B * n * args.steps
         msps = total_samples / dt / 1e6
-        fir_avg = sum(fir_ms) / len(fir_ms)
-        ser_avg = sum(ser_ms) / len(ser_ms)
-        # dominant kernel: k_front_end_fused — algorithmic bytes per launch = 6 B/sample x B*n samples
-        alg_bytes = BYTES_PER_SAMPLE * B * n
-        dom_ms, dom_name = fir_avg, "k_front_end_fused"
+        res = chain.res_out.cpu().numpy()
+        skipv = (chain.imbe_res.cpu().numpy()[:, 0].view(np.uint32) & 0x80000000) != 0
+        voice_frames = int((~skipv).sum())
+        n_sym = int(chain.cnt.sum().item())
+        nidh = chain.nid.cpu().numpy()
+        # algorithmic bytes of one step: cu8 in, one 10-byte record per symbol out, 640 B per voice frame
+        alg_bytes = 2.0 * B * n + 10.0 * n_sym + 640.0 * voice_frames
+        dom_ms = float(rx_ms[1])
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "I/Q Msamples/s end-to-end (demod->FEC->MBE) per GPU; % HBM roofline",
@@ -340,40 +318,67 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic C4FM channels/GPU @48 ksps x %d samples, cu8 in -> "
-                                   "widen+135-tap channel LPF+FSK discriminator -> f32 out, block %d"
-                                   % (B, n, BLOCK),
+            "config": {"workload": "configs[2] + vocoder: %d P25 Phase 1 channels/GPU @48 ksps x %d cu8 samples, half voice (LDU1/LDU2) "
+                                   "half control (TSDU); front end -> matched filter -> symbolizer/sync/slicer -> framer -> NID BCH -> "
+                                   "1/2-rate trellis + CRC16 | Hamming(10,6,3) + RS -> IMBE de-interleave + Golay/Hamming/PN decode -> "
+                                   "MBE synthesis (PCM f32)" % (B, n),
                        "channels_per_gpu": B, "samples_per_channel": n, "block_len": BLOCK,
-                       "parallelism": "channel-sharded x%d" % world, "stages": "widen+lpf+discriminator"},
-            "parity": {"checked_channels": len(pick), "bit_exact": exact, "max_abs_err": max_err},
-            # the FIR look-back for the next call is refreshed by k_front_end_fused itself (n >= 72); the second span is
-            # the empty event-to-event gap after it
-            "kernels_ms": {"k_front_end_fused": round(fir_avg, 4), "post_kernel_gap": round(ser_avg, 4)},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # HBM bytes per launch from rocprofv3 PMC passes on this exact shape (FETCH_SIZE x2 gfx950
-                         # correction + WRITE_SIZE; profiles/README.md) - only valid for the profiled shape
-                         "traffic": 1.184e9 if (B == B_PER_GPU and n == N_SAMPLES) else None,
-                         "algorithmic_bytes": alg_bytes,
-                         "bytes_per_sample": BYTES_PER_SAMPLE, "launch_ms": round(dom_ms, 4)},
+                       "parallelism": "channel-sharded x%d" % world,
+                       "vocoder_tables": "synthetic default blob (include/ddn_mbe.h); mbelib-neo absent -> vocoder parity unpinned"},
+            "parity": parity,
+            "work_per_step": {"symbols": n_sym, "frames_with_valid_nid": int((nidh[:, 0] == 1).sum()),
+                              "tsbk_crc_ok": int(chain.crc_ok.sum().item()), "voice_frames_synthesized": voice_frames,
+                              "voice_frames_muted_or_repeated": int(((res[:, 0] & 0x18) != 0).sum())},
+            "stages_ms": {"front_end": round(float(stage_ms[0]), 3), "receive_loop": round(float(stage_ms[1]), 3),
+                          "framer_nid_trellis_hamming_rs": round(float(stage_ms[2]), 3),
+                          "imbe_deinterleave_decode_synthesis": round(float(stage_ms[3]), 3)},
+            "kernels_ms": {"k_p25_matched_filter": round(float(rx_ms[0]), 4), "k_p25_rxw": round(float(rx_ms[1]), 4),
+                           "k_mbe_params": round(float(mbe_ms[0]), 4), "k_mbe_synth": round(float(mbe_ms[1]), 4)},
+            "roofline": {"bound": "hbm", "kernel": "k_p25_rxw", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes": alg_bytes, "bytes_per_sample": round(alg_bytes / (B * n), 3),
+                         "launch_ms": round(dom_ms, 4),
+                         "chain_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
         }
-        # informational stage chains and the CPU baseline: single-GPU runs only (rank 0 at N = 1)
-        if not args.no_chain and world == 1:
-            line["gardner_variant"] = gardner_variant(torch, ddn, orc, B, n, fir_avg)
-            line["dibit_chain"] = dibit_chain(torch, ddn, orc, B, n, fir_avg)
-            line["p25_e2e_chain"] = p25_e2e_chain(torch, ddn, B, n)
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(d_in[:4].cpu().numpy())
-            line["speedup_vs_cpu_1thread"] = round(msps / world / line["cpu_baseline"]["value"], 1)
-            if "dibit_chain" in line:
-                dc = line["dibit_chain"]
-                # one core doing both stages back to back: reference front end, then the restated receive loop
-                cpu_chain = 1.0 / (1.0 / line["cpu_baseline"]["value"] + 1.0 / dc["cpu_rx_port_Msamples_per_s_1core"])
-                dc["cpu_chain_Msamples_per_s_1core"] = round(cpu_chain, 2)
-                dc["speedup_vs_cpu_1thread"] = round(dc["Msamples_per_s"] / cpu_chain, 1)
+        if world == 1 and not args.no_extras:
+            line["front_end_stage"] = front_end_stage(torch, ddn, chain, d_iq, B, n, 12)
+            line["pcie_inclusive"] = pcie_inclusive(torch, chain, d_iq, B, n)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+            line["speedup_vs_cpu_1core"] = round(msps / world / cpu["value"], 1)
+            if cpu.get("all_cores"):
+                line["speedup_vs_cpu_all_cores"] = round(msps / world / cpu["all_cores"]["value"], 1)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pcie_inclusive(torch, chain, d_iq, B, n):
+    """the same step with the raw I/Q coming from pinned host memory and the results (dibit records, counts,
+    NIDs, PCM) going back to it, serialised on one stream - never `value`."""
+    h_iq = torch.empty(d_iq.shape, dtype=torch.uint8).pin_memory()
+    h_iq.copy_(d_iq)
+    h_rec = torch.empty(chain.rec.shape, dtype=torch.uint8).pin_memory()
+    h_cnt = torch.empty(chain.cnt.shape, dtype=torch.int32).pin_memory()
+    h_nid = torch.empty(chain.nid.shape, dtype=torch.int32).pin_memory()
+    h_pcm = torch.empty(chain.pcm.shape, dtype=torch.float32).pin_memory()
+    st = torch.cuda.current_stream().cuda_stream
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d_iq.copy_(h_iq, non_blocking=True)
+        chain.run(d_iq, st)
+        h_rec.copy_(chain.rec, non_blocking=True)
+        h_cnt.copy_(chain.cnt, non_blocking=True)
+        h_nid.copy_(chain.nid, non_blocking=True)
+        h_pcm.copy_(chain.pcm, non_blocking=True)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        best = t if best is None else min(best, t)
+    moved = h_iq.numel() + h_rec.numel() + 4 * (h_cnt.numel() + h_nid.numel() + h_pcm.numel())
+    return {"note": "host pinned I/Q in, records + counts + NIDs + PCM out, no overlap", "ms_per_step": round(best * 1e3, 3),
+            "Msamples_per_s": round(B * n / best / 1e6, 1), "bytes_over_pcie": moved}
 
 
 if __name__ == "__main__":

@@ -249,6 +249,8 @@ class MbeTables(C.Structure):
 MBE_IMBE, MBE_AMBE = 0, 1
 _PP = C.POINTER(MbeParms)
 PROTOTYPES.update({
+    "ddn_p25_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_p25_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_mbe_default_tables": (C.c_int, [C.POINTER(MbeTables)]),
     "ddn_mbe_validate_tables": (C.c_int, [C.POINTER(MbeTables)]),
     "ddn_mbe_frame_decode_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),

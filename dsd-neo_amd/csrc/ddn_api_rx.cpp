@@ -30,6 +30,9 @@ struct ddn_p25_rx {
     size_t filt_cap;
     int channels_per_wave;
     int32_t* d_lock; // [B] in-frame symbols after a sync, per channel (cfg.lock_symbols unless overridden)
+    bool timing;
+    hipEvent_t ev[3];
+    float last_ms[2]; // matched filter, receive-loop kernel
 };
 
 static void
@@ -43,6 +46,11 @@ rx_free(ddn_p25_rx* b) {
     (void)hipFree(b->d_fhist);
     (void)hipFree(b->d_filt);
     (void)hipFree(b->d_lock);
+    for (int i = 0; i < 3; i++) {
+        if (b->ev[i]) {
+            (void)hipEventDestroy(b->ev[i]);
+        }
+    }
 }
 
 static int
@@ -202,6 +210,9 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
                       ddn_p25_rx_max_symbols(b, n));
         return DDN_ERANGE;
     }
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[0], st));
+    }
     if (b->cfg.use_matched_filter) {
         if (b->filt_cap < n) {
             HIP_TRY(hipStreamSynchronize(st));
@@ -213,6 +224,9 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
         }
         HIP_TRY(ddn_dev_p25_matched_filter_only(d_disc, (long)n, n, B, b->d_fhist, b->d_filt, st));
     }
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[1], st));
+    }
     DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0};
     if (const char* e = getenv("DDN_RX_DBG")) {
         dc.dbg = atoi(e);
@@ -220,8 +234,36 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
     HIP_TRY(ddn_dev_p25_rx(d_disc, b->d_filt, b->d_fhist, (long)n, n, B, &dc, b->d_state, b->d_sbuf, b->d_lbuf,
                            b->d_shist, b->d_minring, b->d_maxring, d_records10, d_flags, d_counts, max_symbols,
                            b->channels_per_wave, b->d_lock, st));
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[2], st));
+    }
     // the filter memory (last 90 raw samples) moves on only after the loop has read the previous tail
     HIP_TRY(ddn_dev_p25_filter_hist_update(d_disc, (long)n, n, B, b->d_fhist, st));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_rx_set_timing(ddn_p25_rx* b, int enable) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    if (enable && !b->ev[0]) {
+        for (int i = 0; i < 3; i++) {
+            HIP_TRY(hipEventCreate(&b->ev[i]));
+        }
+    }
+    b->timing = enable != 0;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_rx_get_timing(ddn_p25_rx* b, float* ms2) {
+    if (!b || !ms2 || !b->ev[0]) {
+        return DDN_EINVAL;
+    }
+    HIP_TRY(hipEventSynchronize(b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms2[0], b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms2[1], b->ev[1], b->ev[2]));
     return DDN_OK;
 }
 

@@ -172,6 +172,9 @@ int ddn_p25_rx_reset(ddn_p25_rx* b);
 /* in-frame symbol count after a sync, per channel (host array [n_channels]; NULL = cfg.lock_symbols everywhere): lets one
  * batch mix traffic classes, e.g. 840 for voice channels (LDUs) and 156 / 336 for one- / three-block TSDU control channels */
 int ddn_p25_rx_set_lock_symbols(ddn_p25_rx* b, const int32_t* per_channel);
+/* kernel times of the last ddn_p25_rx_run(), HIP events on the launch stream: ms2 = {matched filter, receive-loop kernel} */
+int ddn_p25_rx_set_timing(ddn_p25_rx* b, int enable);
+int ddn_p25_rx_get_timing(ddn_p25_rx* b, float* ms2);
 int ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave); /* 0 = automatic, else 16 / 32 / 64 */
 size_t ddn_p25_rx_max_symbols(const ddn_p25_rx* b, size_t n);
 int ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records10, uint8_t* d_flags,

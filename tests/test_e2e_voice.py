@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import chain_oracle
 import ddn
 import fecgen
 import mbe
@@ -36,64 +37,17 @@ def _traffic():
 
 
 def _oracle_chain(iq, lock, Fv):
-    first9 = np.zeros(9, np.int32)
-    st9 = np.zeros(9, np.int32)
-    ddn.lib().ddn_p25p1_layout_ldu_imbe(first9.ctypes.data, st9.ctypes.data)
+    """tests/chain_oracle.py per channel; talk path c is seeded with its channel index like the device batch"""
     out = []
     for c in range(B):
-        disc = orc.OracleFrontEnd().run_cu8(iq[c], 8192)
-        sym, rec4, fl = orc.OracleP25Rx(lock_symbols=int(lock[c]), use_filter=1).run(disc)
-        cnt = len(sym)
-        acc = np.flatnonzero(fl[:cnt] & 2)
-        keep = [k for k in range(33) if k != 11]
-        nids, imbe_d, imbe_res, skip = [], [], [], []
-        n_ldu = 0
-        for a in acc:
-            if a + 34 > cnt:                                    # framer: the NID must lie inside the call's records
-                nids.append(None)
-                continue
-            nd = rec4[a + 1:a + 34][keep]
-            b = np.stack([(nd[:, 0] >> 1) & 1, nd[:, 0] & 1], axis=1).reshape(64).astype(np.uint8)
-            r = np.minimum(np.abs(np.stack([nd[:, 2], nd[:, 3]], axis=1)), 255).reshape(64).astype(np.uint8)
-            nid = oracle_nid(b[None, :63], r[None, :63], np.zeros(1, np.int32), b[63:64], r[63:64])[0]
-            nids.append(nid)
-            if nid[0] == 1 and nid[2] in (5, 10) and n_ldu < Fv:
-                n_ldu += 1
-                for v in range(9):
-                    s0 = a - 23 + int(first9[v])
-                    d = rec4[s0:min(s0 + 76, cnt)]
-                    fr, soft, flag, _, _ = orc.oracle_imbe_deinterleave(d[:, 0].astype(np.uint8), d[:, 2].astype(np.int16),
-                                                                        d[:, 3].astype(np.int16), int(st9[v]))
-                    bits, res, rc = mbe.oracle_frame_decode(ddn.MBE_IMBE, fr[None])
-                    assert rc[0] == 0
-                    imbe_d.append(bits[0])
-                    imbe_res.append(res[0])
-                    skip.append(flag != 0)
-        pad = Fv * 9 - len(imbe_d)
-        imbe_d = np.array(imbe_d + [np.zeros(88, np.uint8)] * pad).reshape(Fv * 9, 88)
-        imbe_res = np.array(imbe_res + [np.zeros(5, np.int32)] * pad, np.int32).reshape(Fv * 9, 5)
-        skip = np.array(skip + [True] * pad)
-        imbe_res[skip, 0] |= np.int32(-2147483648)
-        imbe_d[skip] = 2                                        # restatement's way of saying "not a frame": invalid bits
-        out.append(dict(nids=nids, n_ldu=n_ldu, imbe_d=imbe_d, imbe_res=imbe_res, skip=skip))
+        w = chain_oracle.run_channel(iq[c], lock[c], Fv, seed=c)
+        w["imbe_res"][w["skip"], 0] |= np.int32(-2147483648)
+        out.append(w)
     return out
 
 
 def _oracle_pcm(want, Fv):
-    pcm = np.zeros((B, Fv * 9, 160), np.float32)
-    for c in range(B):
-        v = mbe.OracleVocoder(ddn.MBE_IMBE, 1, tail_rule=1)
-        for f in range(Fv * 9):
-            if want[c]["skip"][f]:
-                continue                                        # silence, history untouched
-            one = np.zeros((1, 160), np.float32)
-            r = want[c]["imbe_res"][f].copy()
-            rc = mbe._o().om_process_batch(ddn.MBE_IMBE, C.addressof(v.tab), np.ascontiguousarray(want[c]["imbe_d"][f]).ctypes.data,
-                                           r.ctypes.data, 1, c, 1, 1, one.ctypes.data, None, C.addressof(v.cur),
-                                           C.addressof(v.prev), C.addressof(v.enh))
-            assert rc == 0
-            pcm[c, f] = one[0]
-    return pcm
+    return np.stack([w["pcm"] for w in want])
 
 
 def _sent_offset(w, sent):
