@@ -683,8 +683,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
 
     const bool offload = whole >= 8;
     const bool hlive = loader && lane < CPW && ch < n_channels;
-    uint8_t* hrp = rec + (size_t)(hlive ? ch : 0) * max_sym * 10;
-    uint8_t* hfp = flags + (size_t)(hlive ? ch : 0) * max_sym;
     auto store_record = [&](uint8_t* r, uint8_t* f, float sym, int dibit, int relb, int l0, int l1, int fl) {
         const uint32_t xb = __float_as_uint(sym);
         ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
@@ -694,20 +692,30 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         ((uint16_t*)r)[4] = (uint16_t)(xb >> 16);
         *f = (uint8_t)fl;
     };
+    // slice + soft decision + record store of the symbols queued during one tile: entries are independent, so the wave's 64
+    // lanes take 64 / CPW queue entries of every channel at once (lane -> channel lane % CPW, entry lane / CPW + ...)
     auto drain = [&](int qb) {
-        if (!hlive) {
+        if (!loader) {
             return;
         }
-        const int cnt = L.qn[qb][ln], o0 = L.qo[qb][ln];
-        for (int k = 0; k < QCW; k++) {
+        constexpr int EPL = 64 / CPW;
+        const int dc = lane % CPW, de = lane / CPW;
+        const int dch = ch0 + dc;
+        if (dch >= n_channels) {
+            return;
+        }
+        const int cnt = L.qn[qb][dc], o0 = L.qo[qb][dc];
+        uint8_t* drp = rec + (size_t)dch * max_sym * 10;
+        uint8_t* dfp = flags + (size_t)dch * max_sym;
+        for (int k = de; k < QCW; k += EPL) {
             if (k >= cnt) {
                 break;
             }
-            const float sym = L.q[qb][k][0][ln];
-            const int fl = __float_as_int(L.q[qb][k][3][ln]);
+            const float sym = L.q[qb][k][0][dc];
+            const int fl = __float_as_int(L.q[qb][k][3][dc]);
             int dibit, relb = 0, l0 = 0, l1 = 0;
             if (fl & 1) {
-                const float mx = L.q[qb][k][1][ln], mn = L.q[qb][k][2][ln];
+                const float mx = L.q[qb][k][1][dc], mn = L.q[qb][k][2][dc];
                 const float center = (mx + mn) / 2.0f;
                 const ddn_sl::Thr th = {center, ((mx - center) * 5.0f / 8.0f) + center,
                                         ((mn - center) * 5.0f / 8.0f) + center, mx, mn};
@@ -717,7 +725,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
             const size_t oo = (size_t)(o0 + k);
             if (oo < max_sym) {
-                store_record(hrp + oo * 10, hfp + oo, sym, dibit, relb, l0, l1, fl);
+                store_record(drp + oo * 10, dfp + oo, sym, dibit, relb, l0, l1, fl);
             }
         }
     };
