@@ -549,22 +549,25 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
 //    tile edge is simply deferred to the next tile and every symbol is evaluated whole: the five-sample latched path in
 //    frame, a straight per-sample pass (crossing search included) while hunting.  The sample-at-a-time loop is left for
 //    the matched filter's 90-sample cold start, spans > 24 and the last tile of a call (partial symbols are carried);
-//  * the 128-symbol window statistics are incremental.  The window is written in order, 16-slot group by group: inside
-//    the current group the summary is merge(prefix of new values, suffix of old values); wave 1 prepares, one tile
-//    ahead, the suffix summaries of the next group and the merge of the six groups that are neither current nor
-//    next, so the per-symbol cost is ~10 compare/select pairs instead of a 16-slot rescan plus a 7-group merge.  A
-//    lane whose next group was not prepared in time (first group of a call, sps < 8 corner cases) uses the rescan for
-//    that group - same statistics either way (multisets: the two smallest of a union are among the parts' two smallest);
+//  * the 128-symbol window statistics never leave the tile rhythm.  The window after a push = (ring as it stood at a
+//    checkpoint, minus the m oldest entries) + (the m symbols pushed since).  The first part does not depend on the
+//    symbols being produced, so a third wavefront (wave 2) prepares, while tile t is processed, the suffix summaries
+//    S_m = {two smallest, two largest} of ring entries m+1..128 as of the START of tile t, for every m the next tile can
+//    ask for; tile t+1 uses them with checkpoint = start of tile t.  On the recurrence wave a push is then: insert the
+//    symbol into this tile's running summary (pc), and - in frame - merge {S_m, summary of the previous tile's pushes
+//    (pp), pc}: 4 LDS reads and ~30 ALU operations, no rescans, no per-group events, no handshake besides the tile
+//    barrier.  Same multiset statistics as the reference's rescan of the 128 values (src/core/frames/dsd_dibit.c:194-241);
 //  * the queue to wave 1 carries {symbol, max, min, flags}; centre / mid thresholds are recomputed there with the
 //    reference's expressions.
 constexpr int RT = 3 * TS;
 constexpr int QCW = 12; // (TS + deferred carry) / (8 - 1) symbols at most per lane and tile when sps >= 8
 constexpr int WMAX = 24;
 
+constexpr int WM = 32; // suffix summaries kept per checkpoint (pushes per two tiles: 2 * (ceil((TS + sps) / (sps - 1)) + 1) <= 30 for sps >= 6)
+
 template <int CPW>
 struct LdsW {
     float sb[SS][CPW];
-    float gs[8][4][CPW];
     float lb[24][CPW];
     float sh[24][CPW];
     // a row = [mirror of slot 2 | slot 0 | slot 1 | slot 2] + pad: sample j (-TS <= j < TS + 12) of the tile in slot b
@@ -574,13 +577,12 @@ struct LdsW {
     float q[2][QCW][4][CPW];
     int qn[2][CPW];
     int qo[2][CPW];
-    float suf[2][16][4][CPW]; // [entry & 1][k] = {min1, min2, max1, max2} of slots k..15 of the group being entered
-    float oth[2][4][CPW];     // same for the six groups other than that one and its predecessor
-    int want_e[CPW], want_g[CPW], done_e[CPW];
+    float sfx[2][WM][4][CPW]; // [checkpoint parity][m - 1] = {min1, min2, max1, max2} of ring entries m+1..128 at the checkpoint
+    int sidx0[2][CPW];        // [tile parity] ring slot of the oldest entry at the start of that tile
 };
 
 template <int CPW>
-__global__ __launch_bounds__(128) void
+__global__ __launch_bounds__(192) void
 k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail, long n,
           size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
           float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
@@ -589,10 +591,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     extern __shared__ unsigned char smem_raw[];
     LdsW<CPW>& L = *reinterpret_cast<LdsW<CPW>*>(smem_raw);
     const int lane = threadIdx.x & 63;
-    const bool loader = threadIdx.x >= 64;
+    const bool loader = (threadIdx.x >> 6) == 1;  // wave 1: tile staging, slice + record stores
+    const bool winprep = (threadIdx.x >> 6) == 2; // wave 2: suffix summaries of the symbol window
+    const bool recur = threadIdx.x < 64;          // wave 0: the per-channel recurrence
     const int ch0 = blockIdx.x * CPW;
     const int ch = ch0 + lane;
-    const bool live = !loader && lane < CPW && ch < n_channels;
+    const bool live = recur && lane < CPW && ch < n_channels;
     const int ln = lane < CPW ? lane : 0;
     const bool use_flt = cfg.use_filter != 0;
     const float inf = __builtin_inff();
@@ -610,39 +614,9 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     } else {
         s = DdnRxState{};
     }
-    auto refresh_group = [&](int g) {
-        float a1 = L.sb[g * 16][ln], a2 = L.sb[g * 16 + 1][ln];
-        float b1 = a1, b2 = a2;
-        if (a2 < a1) {
-            const float t = a1;
-            a1 = a2;
-            a2 = t;
-        }
-        if (b2 > b1) {
-            const float t = b1;
-            b1 = b2;
-            b2 = t;
-        }
-#pragma unroll
-        for (int k = 2; k < 16; k++) {
-            const float v = L.sb[g * 16 + k][ln];
-            two_min_insert(v, a1, a2);
-            two_max_insert(v, b1, b2);
-        }
-        L.gs[g][0][ln] = a1;
-        L.gs[g][1][ln] = a2;
-        L.gs[g][2][ln] = b1;
-        L.gs[g][3][ln] = b2;
-    };
     if (live) {
-        for (int g = 0; g < 8; g++) {
-            refresh_group(g);
-        }
-        L.want_e[ln] = 0;
-        L.want_g[ln] = 0;
-        L.done_e[ln] = 0;
+        L.sidx0[0][ln] = s.sidx;
     }
-
     auto stage = [&](long t0, int slot) {
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
         constexpr int RPP = CPW < 16 ? CPW : 16; // rows in flight per pass
@@ -672,17 +646,62 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         stage(0, 0);
     }
     __syncthreads();
-
     const int whole0 = cfg.out_rate / cfg.sym_rate, rem0 = cfg.out_rate % cfg.sym_rate;
     const int whole = whole0 < 2 ? 2 : (whole0 > 64 ? 64 : whole0);
     const int rem = (whole0 < 2 || whole0 > 64) ? 0 : rem0;
+    // most symbols two consecutive tiles can push (every symbol consumes at least sps - 1 samples)
+    const int mn_raw = 2 * ((TS + whole + whole - 2) / (whole > 1 ? whole - 1 : 1) + 1);
+    const int Mn = mn_raw > WM ? WM : mn_raw;
+    // wave 2: S_m for m = Mn .. 1 from the ring as it stands at L.sidx0 (entries being overwritten meanwhile are the
+    // oldest ones, which only feed summaries nobody will ask for)
+    auto compute_sfx = [&](int buf, int tile_parity) {
+        constexpr int EPL = 64 / CPW;
+        const int c = lane % CPW, part = lane / CPW;
+        const int s0 = L.sidx0[tile_parity][c];
+        const int total = SS - Mn, per = (total + EPL - 1) / EPL;
+        const int i_lo = Mn + 1 + part * per;
+        const int i_hi = (i_lo + per - 1) < SS ? (i_lo + per - 1) : SS;
+        float a1 = inf, a2 = inf, b1 = -inf, b2 = -inf;
+        for (int i = i_lo; i <= i_hi; i++) {
+            const float v = L.sb[(s0 + i - 1) & (SS - 1)][c];
+            two_min_insert(v, a1, a2);
+            two_max_insert(v, b1, b2);
+        }
+#pragma unroll
+        for (int d = CPW; d < 64; d <<= 1) {
+            const float o1 = __shfl_xor(a1, d), o2 = __shfl_xor(a2, d), p1 = __shfl_xor(b1, d), p2 = __shfl_xor(b2, d);
+            two_min_insert(o1, a1, a2);
+            two_min_insert(o2, a1, a2);
+            two_max_insert(p1, b1, b2);
+            two_max_insert(p2, b1, b2);
+        }
+        for (int m = Mn; m >= 1; m--) {
+            if (m < Mn) {
+                const float v = L.sb[(s0 + m) & (SS - 1)][c]; // entry m + 1
+                two_min_insert(v, a1, a2);
+                two_max_insert(v, b1, b2);
+            }
+            if (part == 0) {
+                L.sfx[buf][m - 1][0][c] = a1;
+                L.sfx[buf][m - 1][1][c] = a2;
+                L.sfx[buf][m - 1][2][c] = b1;
+                L.sfx[buf][m - 1][3][c] = b2;
+            }
+        }
+    };
+    if (winprep) {
+        compute_sfx(0, 0);
+    }
+    __syncthreads();
+
     int o = 0;
     uint8_t* rp = rec + (size_t)(live ? ch : 0) * max_sym * 10;
     uint8_t* fp = flags + (size_t)(live ? ch : 0) * max_sym;
     const long long abs0 = s.n_abs;
 
     const bool offload = whole >= 8;
-    const bool hlive = loader && lane < CPW && ch < n_channels;
+    // the ordinary symbol length: constant span with the five-sample window (src/dsp/dsd_symbol.c:405-426 special-cases 5 / 20)
+    const bool stdspan = rem == 0 && whole >= 6 && whole <= 11; // whole + 1 samples at most with a late slip: the search covers 12
     auto store_record = [&](uint8_t* r, uint8_t* f, float sym, int dibit, int relb, int l0, int l1, int fl) {
         const uint32_t xb = __float_as_uint(sym);
         ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
@@ -729,103 +748,29 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
         }
     };
-    // wave 1, one tile ahead of need: suffix summaries of group want_g and the merge of the six uninvolved groups
-    int hdone = 0;
-    auto prepare = [&]() {
-        if (!hlive) {
-            return;
-        }
-        const int e = L.want_e[ln];
-        if (e == hdone) {
-            return;
-        }
-        const int g = L.want_g[ln];
-        float a1 = inf, a2 = inf, b1 = -inf, b2 = -inf;
-        for (int k = 15; k >= 0; k--) {
-            const float v = L.sb[g * 16 + k][ln];
-            two_min_insert(v, a1, a2);
-            two_max_insert(v, b1, b2);
-            L.suf[e & 1][k][0][ln] = a1;
-            L.suf[e & 1][k][1][ln] = a2;
-            L.suf[e & 1][k][2][ln] = b1;
-            L.suf[e & 1][k][3][ln] = b2;
-        }
-        a1 = inf, a2 = inf, b1 = -inf, b2 = -inf;
-        for (int d = 1; d <= 6; d++) {
-            const int h = (g + d) & 7;
-            two_min_insert(L.gs[h][0][ln], a1, a2);
-            two_min_insert(L.gs[h][1][ln], a1, a2);
-            two_max_insert(L.gs[h][2][ln], b1, b2);
-            two_max_insert(L.gs[h][3][ln], b1, b2);
-        }
-        L.oth[e & 1][0][ln] = a1;
-        L.oth[e & 1][1][ln] = a2;
-        L.oth[e & 1][2][ln] = b1;
-        L.oth[e & 1][3][ln] = b2;
-        L.done_e[ln] = e;
-        hdone = e;
-    };
-
-    // incremental window state of this lane (valid while fastwin)
-    float pm1 = inf, pm2 = inf, px1 = -inf, px2 = -inf; // new values written into the current group so far
-    float om1 = inf, om2 = inf, ox1 = -inf, ox2 = -inf; // the seven other groups
-    int gent = 0;                                       // groups entered during this call
-    bool fastwin = false;
+    // window state of this lane: summaries {min1, min2, max1, max2} of the symbols pushed during this tile (pc) and during the
+    // previous one (pp), their counts, and which checkpoint's suffix summaries apply
+    float pc1 = inf, pc2 = inf, pc3 = -inf, pc4 = -inf;
+    float pp1 = inf, pp2 = inf, pp3 = -inf, pp4 = -inf;
+    int npc = 0, npp = 0, sbuf_sel = 0;
     // window push of one symbol at slot s.sidx; returns the whole-window extrema pairs when `global` is set
-    auto window_push = [&](float sym, bool global, float& m1, float& m2, float& x1, float& x2, int done_snap) {
-        const int k = s.sidx & 15, g = s.sidx >> 4;
+    auto window_push = [&](float sym, bool global, float& m1, float& m2, float& x1, float& x2, int) {
         L.sb[s.sidx][ln] = sym;
-        if (k == 0) {
-            gent++;
-            fastwin = (done_snap == gent);
-            if (fastwin) {
-                const int p = (g + 7) & 7;
-                om1 = L.oth[gent & 1][0][ln];
-                om2 = L.oth[gent & 1][1][ln];
-                ox1 = L.oth[gent & 1][2][ln];
-                ox2 = L.oth[gent & 1][3][ln];
-                two_min_insert(L.gs[p][0][ln], om1, om2);
-                two_min_insert(L.gs[p][1][ln], om1, om2);
-                two_max_insert(L.gs[p][2][ln], ox1, ox2);
-                two_max_insert(L.gs[p][3][ln], ox1, ox2);
-                pm1 = inf, pm2 = inf, px1 = -inf, px2 = -inf;
-            }
-        }
-        if (fastwin) {
-            two_min_insert(sym, pm1, pm2);
-            two_max_insert(sym, px1, px2);
-            if (k == 15) {
-                L.gs[g][0][ln] = pm1;
-                L.gs[g][1][ln] = pm2;
-                L.gs[g][2][ln] = px1;
-                L.gs[g][3][ln] = px2;
-            }
-            if (global) {
-                m1 = pm1, m2 = pm2, x1 = px1, x2 = px2;
-                const int k1 = k < 15 ? k + 1 : 15;
-                const float s0 = L.suf[gent & 1][k1][0][ln], s1 = L.suf[gent & 1][k1][1][ln];
-                const float s2 = L.suf[gent & 1][k1][2][ln], s3 = L.suf[gent & 1][k1][3][ln];
-                two_min_insert(k < 15 ? s0 : inf, m1, m2);
-                two_min_insert(k < 15 ? s1 : inf, m1, m2);
-                two_max_insert(k < 15 ? s2 : -inf, x1, x2);
-                two_max_insert(k < 15 ? s3 : -inf, x1, x2);
-                two_min_insert(om1, m1, m2);
-                two_min_insert(om2, m1, m2);
-                two_max_insert(ox1, x1, x2);
-                two_max_insert(ox2, x1, x2);
-            }
-        } else {
-            refresh_group(g);
-            if (global) {
-                m1 = L.gs[0][0][ln], m2 = L.gs[0][1][ln], x1 = L.gs[0][2][ln], x2 = L.gs[0][3][ln];
-#pragma unroll
-                for (int h = 1; h < 8; h++) {
-                    two_min_insert(L.gs[h][0][ln], m1, m2);
-                    two_min_insert(L.gs[h][1][ln], m1, m2);
-                    two_max_insert(L.gs[h][2][ln], x1, x2);
-                    two_max_insert(L.gs[h][3][ln], x1, x2);
-                }
-            }
+        two_min_insert(sym, pc1, pc2);
+        two_max_insert(sym, pc3, pc4);
+        npc++;
+        if (global) {
+            int m = npp + npc; // ring entries replaced since the checkpoint
+            m = m > WM ? WM : m;
+            const float s1 = L.sfx[sbuf_sel][m - 1][0][ln], s2 = L.sfx[sbuf_sel][m - 1][1][ln];
+            const float s3 = L.sfx[sbuf_sel][m - 1][2][ln], s4 = L.sfx[sbuf_sel][m - 1][3][ln];
+            // two smallest of three sorted pairs, two largest likewise (values are finite: min / max pick the same multiset)
+            float t1 = fminf(s1, pp1), t2 = fminf(fmaxf(s1, pp1), fminf(s2, pp2));
+            m1 = fminf(t1, pc1);
+            m2 = fminf(fmaxf(t1, pc1), fminf(t2, pc2));
+            float u1 = fmaxf(s3, pp3), u2 = fmaxf(fminf(s3, pp3), fmaxf(s4, pp4));
+            x1 = fmaxf(u1, pc3);
+            x2 = fmaxf(fminf(u1, pc3), fmaxf(u2, pc4));
         }
     };
 
@@ -833,7 +778,183 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const float* frow = &L.flt[ln][0];
     int sp = 0; // this lane's cursor relative to the current tile (negative: a deferred symbol begins in the previous one)
     int it = 0;
-    for (long t0 = 0; t0 < n; t0 += TS, it++) {
+    // ---- per-symbol commit, shared by the fast paths and the generic path of the trip loop ---------------------------
+    long t0 = 0;  // call-relative index of the current tile's first sample (the commit stamps filt_start with it)
+    int qk = 0;   // symbols queued to wave 1 during the current tile
+    int itq = 0;  // queue half of the current tile
+    // dsd_symbol_history_push()
+    auto commit_pre = [&](float sym) {
+        L.sh[s.shead][ln] = sym;
+        s.shead = (s.shead + 1 >= 24) ? 0 : s.shead + 1;
+        s.scount = s.scount < 24 ? s.scount + 1 : 24;
+    };
+    auto commit_inframe = [&](float sym, int done_snap, int& fl, float& q_max, float& q_min) {
+        // get_dibit_and_analog_signal(): window, extrema rings, thresholds (slice + soft decision on wave 1)
+        const int neg = (s.lastsync == 2);
+        float m1, m2, x1, x2;
+        window_push(sym, true, m1, m2, x1, x2, done_snap);
+        const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
+        const size_t ro = (size_t)s.midx * n_channels + ch;
+        float old_lo = s.fill_min, old_hi = s.fill_max;
+        if (s.since_fill >= MS) {
+            old_lo = minring[ro];
+            old_hi = maxring[ro];
+        } else {
+            s.since_fill++;
+        }
+        s.min_sum += (double)lo - (double)old_lo;
+        s.max_sum += (double)hi - (double)old_hi;
+        minring[ro] = lo;
+        maxring[ro] = hi;
+        s.midx = (s.midx + 1 >= MS) ? 0 : s.midx + 1;
+        s.min = (float)(s.min_sum / (double)MS);
+        s.max = (float)(s.max_sum / (double)MS);
+        s.center = (s.max + s.min) / 2.0f;
+        s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
+        s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
+        s.maxref = s.max * 0.80f;
+        s.minref = s.min * 0.80f;
+        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+        fl = 1 | (neg ? 4 : 0);
+        q_max = s.max;
+        q_min = s.min;
+        if (--s.lock_left <= 0) {
+            s.have_sync = 0;
+            s.lidx = 0;
+            s.level_count = 0;
+            s.hist_count = 0;
+            s.hist_bits = 0;
+            s.lmin = s.min;
+            s.lmax = s.max;
+        }
+    };
+    auto commit_hunt = [&](float sym, int done_snap, int& fl) {
+        // getFrameSync(): one hunting iteration
+        L.lb[s.lidx][ln] = sym;
+        s.level_count = s.level_count < 24 ? s.level_count + 1 : 24;
+        float u0, u1, u2, u3;
+        window_push(sym, false, u0, u1, u2, u3, done_snap);
+        s.lidx = (s.lidx == 23) ? 0 : s.lidx + 1;
+        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+        const uint32_t bit = sym > 0.0f ? 1u : 0u;
+        s.hist_bits = ((s.hist_bits << 1) | bit) & 0xFFFFFFu;
+        s.hist_count = s.hist_count < 24 ? s.hist_count + 1 : 24;
+        if (s.hist_count >= 8) {
+            s.maxref = s.max;
+            s.minref = s.min;
+            int pol = 0;
+            if (s.hist_count >= 24) {
+                pol = (s.hist_bits == kSyncBits) ? 1 : ((s.hist_bits == (~kSyncBits & 0xFFFFFFu)) ? 2 : 0);
+            }
+            // The level window (lmin / lmax of the last <= 24 hunting symbols) is recomputed from
+            // scratch by the reference on every hunting symbol but only consumed when a sync is
+            // accepted, so it is evaluated here only then: same values at the only point of use.
+            if (pol) {
+                const float big = 3.4028234663852886e38f;
+                float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
+                float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
+                const int lc = s.level_count;
+                for (int k = 0; k < 24; k++) {
+                    if (k < lc) {
+                        float v = L.lb[k][ln], t;
+                        float w = v;
+                        t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
+                        t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
+                        t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
+                        t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
+                        a4 = fminf(a4, v);
+                        t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
+                        t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
+                        t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
+                        t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
+                        b4 = fmaxf(b4, w);
+                    }
+                }
+                if (lc >= 13) {
+                    s.lmin = (a2 + a3 + a4) / 3.0f;
+                    s.lmax = (b4 + b3 + b2) / 3.0f;
+                } else {
+                    s.lmin = (a0 + a1 + a2) / 3.0f;
+                    s.lmax = (b2 + b1 + b0) / 3.0f;
+                }
+                s.max = (s.max + s.lmax) / 2;
+                s.min = (s.min + s.lmin) / 2;
+                s.lastsync = pol;
+                if (use_flt && !s.filter_on) {
+                    s.filter_on = 1;
+                    s.filt_start = abs0 + t0 + sp; // first sample the filter sees
+                }
+                if (s.scount >= 24) {
+                    float sp_ = 0.0f, sn_ = 0.0f;
+                    int np = 0, nn = 0;
+                    int idx = s.shead;
+                    for (int k = 0; k < 24; k++) {
+                        idx = idx == 0 ? 23 : idx - 1;
+                        const float v = L.sh[idx][ln];
+                        if (v > 0.0f) {
+                            sp_ += v;
+                            np++;
+                        } else {
+                            sn_ += v;
+                            nn++;
+                        }
+                    }
+                    if (np != 0 && nn != 0) {
+                        const float mp = sp_ / (float)np, mn = sn_ / (float)nn;
+                        if (!(fabsf(mp - mn) < 1.0f)) {
+                            s.max = mp;
+                            s.min = mn;
+                            s.center = (s.max + s.min) / 2.0f;
+                            s.umid = s.center + (s.max - s.center) * 0.625f;
+                            s.lmid = s.center + (s.min - s.center) * 0.625f;
+                            s.maxref = s.max * 0.80f;
+                            s.minref = s.min * 0.80f;
+                            s.fill_max = s.max;
+                            s.fill_min = s.min;
+                            s.since_fill = 0;
+                            s.max_sum = (double)s.max * (double)MS;
+                            s.min_sum = (double)s.min * (double)MS;
+                        }
+                    }
+                }
+                s.have_sync = 1;
+                s.lock_left = lock_cfg[ch]; // in-frame symbols after a sync, per channel
+                fl = 2 | (pol == 2 ? 4 : 0);
+                if (s.lock_left <= 0) {
+                    s.have_sync = 0;
+                    s.lidx = 0;
+                    s.level_count = 0;
+                    s.hist_count = 0;
+                    s.hist_bits = 0;
+                    s.lmin = s.min;
+                    s.lmax = s.max;
+                }
+            }
+        }
+    };
+    auto emit = [&](float sym, int fl, float q_max, float q_min) {
+    if (offload && qk < QCW) {
+        L.q[itq][qk][0][ln] = sym;
+        L.q[itq][qk][1][ln] = q_max;
+        L.q[itq][qk][2][ln] = q_min;
+        L.q[itq][qk][3][ln] = __int_as_float(fl);
+        qk++;
+    } else if ((size_t)o < max_sym) {
+        int dibit, relb = 0, l0 = 0, l1 = 0;
+        if (fl & 1) {
+            const float center = (q_max + q_min) / 2.0f;
+            const ddn_sl::Thr th = {center, ((q_max - center) * 5.0f / 8.0f) + center,
+                                    ((q_min - center) * 5.0f / 8.0f) + center, q_max, q_min};
+            ddn_sl::slice_soft(sym, th, (fl >> 2) & 1, dibit, relb, l0, l1);
+        } else {
+            dibit = sym > 0.0f ? 1 : 3;
+        }
+        store_record(rp + (size_t)o * 10, fp + o, sym, dibit, relb, l0, l1, fl);
+    }
+        o++;
+    };
+
+    for (t0 = 0; t0 < n; t0 += TS, it++) {
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
         const bool more = (t0 + TS) < n;
         if (loader) {
@@ -843,19 +964,128 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             if (offload && it > 0) {
                 drain((it - 1) & 1);
             }
-            prepare();
+        } else if (winprep) {
+            if (it >= 1) {
+                compute_sfx(it & 1, it & 1);
+            }
         } else {
             const int base = TS + (it % 3) * TS;
             auto rd = [&](const float* row, int j) { return row[base + j]; };
-            const int done_snap = live ? L.done_e[ln] : 0;
-            int qk = 0;
+            const int done_snap = 0;
+            if (it >= 1) { // the checkpoint moves to the start of the previous tile
+                pp1 = pc1, pp2 = pc2, pp3 = pc3, pp4 = pc4;
+                npp = npc;
+                sbuf_sel = (it - 1) & 1;
+            }
+            pc1 = inf, pc2 = inf, pc3 = -inf, pc4 = -inf;
+            npc = 0;
+            qk = 0;
+            itq = it & 1;
             if (live && offload) {
                 L.qo[it & 1][ln] = o;
             }
             int guard = 0;
+            bool gblocked = false; // generic path: this lane's symbol waits for the next tile
             while (true) {
+                // ---- trip classification -----------------------------------------------------------------------------
+                // Symbols of the ordinary length (std) that start fresh - or were deferred whole to this tile - take one
+                // of two straight-line paths: A = in frame (clip, five-sample mean, in-frame commit; the crossing search only
+                // while the latch is open), B = hunting (timing slip, crossing search, mean, hunting commit).  Everything
+                // else - matched-filter cold start, partly consumed symbols at a call's edges, odd spans - goes through the
+                // generic per-sample code below, which the wave skips when no lane needs it.
+                const bool cold0 = s.filter_on && (abs0 + t0 + sp - s.filt_start) < (long long)(NT - 1);
+                const bool ready = live && stdspan && sp < tn && !cold0;
+                const bool ea = ready && s.have_sync && (!s.in_symbol || (s.i == 0 && s.count == 0));
+                const bool eb = ready && !s.have_sync && (!s.in_symbol || (s.i >= -1 && s.i <= 1 && s.count == 0));
+                if (eb && !s.in_symbol) { // symbol start while hunting: one-sample slip by the latched crossing index
+                    s.span = whole;
+                    s.centre = (whole - 1) / 2;
+                    s.i = 0;
+                    s.sum = 0.0f;
+                    s.count = 0;
+                    s.in_symbol = 1;
+                    if (s.jitter >= 0) {
+                        if (s.jitter > 0 && s.jitter <= s.centre) {
+                            s.i = -1;
+                        } else if (s.jitter > s.centre && s.jitter < whole) {
+                            s.i = 1;
+                        }
+                        s.jitter = -1;
+                    }
+                }
+                const int cnt_b = whole - s.i;
+                const bool do_a = ea && (sp + whole <= tn);
+                const bool do_b = eb && (sp + cnt_b <= tn);
+                const bool wait_ab = (ea && !do_a && more) || (eb && !do_b && more);
+                const bool glive = live && !do_a && !do_b && !wait_ab && !gblocked;
+                const bool gneed = glive && (sp < tn || s.in_symbol);
+                if (!__any(do_a || do_b || (gneed && (sp < tn))) || ++guard > 4 * TS) {
+                    break;
+                }
+                if (__any(do_a || do_b)) {
+                    const bool fab = do_a || do_b;
+                    const float* p = (s.filter_on ? frow : rrow) + base + sp;
+                    const bool clip = do_a;
+                    const int cnt = do_a ? whole : cnt_b;
+                    const int i0 = do_a ? 0 : s.i;
+                    float last = s.lastsample;
+                    int jit = s.jitter;
+                    if (__any(fab && jit < 0)) {
+                        const float hi_lim = s.maxref * 1.25f, lo_lim = s.minref * 1.25f;
+                        const bool anyclip = __any(do_a && jit < 0);
+#pragma unroll
+                        for (int k = 0; k < 12; k++) {
+                            if ((k & 3) == 0 && k > 0 && !__any(fab && k < cnt && jit < 0)) {
+                                break;
+                            }
+                            float x = p[k];
+                            if (anyclip) {
+                                const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
+                                x = clip ? xc : x;
+                            }
+                            const bool in = fab && k < cnt;
+                            const bool cross = (x > s.center) ? (!(x > hi_lim) && last < s.center)
+                                                              : (!(x < lo_lim) && last > s.center);
+                            jit = (in && jit < 0 && cross) ? i0 + k : jit;
+                            last = in ? x : last;
+                        }
+                    }
+                    // the five window samples (indices centre - 2 .. centre + 2 of the symbol) and its last sample
+                    const int k0 = (whole - 1) / 2 - 2 - i0;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < 5; w++) {
+                        float x = p[k0 + w];
+                        const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        acc += clip ? xc : x;
+                    }
+                    {
+                        float x = p[cnt - 1];
+                        const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        last = clip ? xc : x;
+                    }
+                    if (fab) {
+                        const float sym = acc / 5.0f;
+                        s.jitter = jit;
+                        s.lastsample = last;
+                        sp += cnt;
+                        s.in_symbol = 0;
+                        commit_pre(sym);
+                        int fl = 0;
+                        float q_max = 0.0f, q_min = 0.0f;
+                        if (do_a) {
+                            commit_inframe(sym, done_snap, fl, q_max, q_min);
+                        } else {
+                            commit_hunt(sym, done_snap, fl);
+                        }
+                        emit(sym, fl, q_max, q_min);
+                    }
+                }
+                if (!__any(gneed)) {
+                    continue;
+                }
                 // ---- symbol start ----------------------------------------------------------------------------------
-                if (live && sp < tn && !s.in_symbol) {
+                if (glive && sp < tn && !s.in_symbol) {
                     int sps = whole;
                     if (rem > 0) {
                         int acc = s.sps_accum + rem;
@@ -884,7 +1114,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 // ---- whole-symbol evaluation -----------------------------------------------------------------------
                 const int cnt = s.span - s.i; // samples this symbol still consumes
                 const bool cold = s.filter_on && (abs0 + t0 + sp - s.filt_start) < (long long)(NT - 1);
-                const bool wholeok = live && s.in_symbol && cnt > 0 && cnt <= WMAX && !cold;
+                const bool wholeok = glive && s.in_symbol && cnt > 0 && cnt <= WMAX && !cold;
                 const bool fits = sp + cnt <= tn;
                 const bool blocked = wholeok && !fits && more; // wait for the next tile, both tiles stay staged
                 const bool fo = s.filter_on != 0;
@@ -1003,7 +1233,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     }
                 }
                 // ---- sample-at-a-time path (filter cold start, long spans, last tile of the call) --------------------
-                bool act = live && s.in_symbol && sp < tn && s.i < s.span && !blocked;
+                bool act = glive && s.in_symbol && sp < tn && s.i < s.span && !blocked;
                 while (__any(act)) {
                     if (act) {
                         float x = rd(rrow, sp);
@@ -1059,192 +1289,30 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         s.i++;
                         sp++;
                     }
-                    act = live && s.in_symbol && sp < tn && s.i < s.span && !blocked;
+                    act = glive && s.in_symbol && sp < tn && s.i < s.span && !blocked;
                 }
                 // ---- symbol commit ---------------------------------------------------------------------------------
-                const bool done = live && s.in_symbol && s.i >= s.span;
+                const bool done = glive && s.in_symbol && s.i >= s.span;
                 if (done) {
                     const float sym = (s.count > 0) ? (s.sum / (float)s.count) : 0.0f;
                     s.in_symbol = 0;
-                    L.sh[s.shead][ln] = sym;
-                    s.shead = (s.shead + 1 >= 24) ? 0 : s.shead + 1;
-                    s.scount = s.scount < 24 ? s.scount + 1 : 24;
+                    commit_pre(sym);
                     int fl = 0;
                     float q_max = 0.0f, q_min = 0.0f;
                     if (s.have_sync) {
-                        // get_dibit_and_analog_signal(): window, extrema rings, thresholds (slice + soft decision on wave 1)
-                        const int neg = (s.lastsync == 2);
-                        float m1, m2, x1, x2;
-                        window_push(sym, true, m1, m2, x1, x2, done_snap);
-                        const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
-                        const size_t ro = (size_t)s.midx * n_channels + ch;
-                        float old_lo = s.fill_min, old_hi = s.fill_max;
-                        if (s.since_fill >= MS) {
-                            old_lo = minring[ro];
-                            old_hi = maxring[ro];
-                        } else {
-                            s.since_fill++;
-                        }
-                        s.min_sum += (double)lo - (double)old_lo;
-                        s.max_sum += (double)hi - (double)old_hi;
-                        minring[ro] = lo;
-                        maxring[ro] = hi;
-                        s.midx = (s.midx + 1 >= MS) ? 0 : s.midx + 1;
-                        s.min = (float)(s.min_sum / (double)MS);
-                        s.max = (float)(s.max_sum / (double)MS);
-                        s.center = (s.max + s.min) / 2.0f;
-                        s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
-                        s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
-                        s.maxref = s.max * 0.80f;
-                        s.minref = s.min * 0.80f;
-                        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
-                        fl = 1 | (neg ? 4 : 0);
-                        q_max = s.max;
-                        q_min = s.min;
-                        if (--s.lock_left <= 0) {
-                            s.have_sync = 0;
-                            s.lidx = 0;
-                            s.level_count = 0;
-                            s.hist_count = 0;
-                            s.hist_bits = 0;
-                            s.lmin = s.min;
-                            s.lmax = s.max;
-                        }
+                        commit_inframe(sym, done_snap, fl, q_max, q_min);
                     } else {
-                        // getFrameSync(): one hunting iteration
-                        L.lb[s.lidx][ln] = sym;
-                        s.level_count = s.level_count < 24 ? s.level_count + 1 : 24;
-                        float u0, u1, u2, u3;
-                        window_push(sym, false, u0, u1, u2, u3, done_snap);
-                        s.lidx = (s.lidx == 23) ? 0 : s.lidx + 1;
-                        s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
-                        const uint32_t bit = sym > 0.0f ? 1u : 0u;
-                        s.hist_bits = ((s.hist_bits << 1) | bit) & 0xFFFFFFu;
-                        s.hist_count = s.hist_count < 24 ? s.hist_count + 1 : 24;
-                        if (s.hist_count >= 8) {
-                            s.maxref = s.max;
-                            s.minref = s.min;
-                            int pol = 0;
-                            if (s.hist_count >= 24) {
-                                pol = (s.hist_bits == kSyncBits) ? 1 : ((s.hist_bits == (~kSyncBits & 0xFFFFFFu)) ? 2 : 0);
-                            }
-                            // The level window (lmin / lmax of the last <= 24 hunting symbols) is recomputed from
-                            // scratch by the reference on every hunting symbol but only consumed when a sync is
-                            // accepted, so it is evaluated here only then: same values at the only point of use.
-                            if (pol) {
-                                const float big = 3.4028234663852886e38f;
-                                float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
-                                float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
-                                const int lc = s.level_count;
-                                for (int k = 0; k < 24; k++) {
-                                    if (k < lc) {
-                                        float v = L.lb[k][ln], t;
-                                        float w = v;
-                                        t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
-                                        t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
-                                        t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
-                                        t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
-                                        a4 = fminf(a4, v);
-                                        t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
-                                        t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
-                                        t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
-                                        t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
-                                        b4 = fmaxf(b4, w);
-                                    }
-                                }
-                                if (lc >= 13) {
-                                    s.lmin = (a2 + a3 + a4) / 3.0f;
-                                    s.lmax = (b4 + b3 + b2) / 3.0f;
-                                } else {
-                                    s.lmin = (a0 + a1 + a2) / 3.0f;
-                                    s.lmax = (b2 + b1 + b0) / 3.0f;
-                                }
-                                s.max = (s.max + s.lmax) / 2;
-                                s.min = (s.min + s.lmin) / 2;
-                                s.lastsync = pol;
-                                if (use_flt && !s.filter_on) {
-                                    s.filter_on = 1;
-                                    s.filt_start = abs0 + t0 + sp; // first sample the filter sees
-                                }
-                                if (s.scount >= 24) {
-                                    float sp_ = 0.0f, sn_ = 0.0f;
-                                    int np = 0, nn = 0;
-                                    int idx = s.shead;
-                                    for (int k = 0; k < 24; k++) {
-                                        idx = idx == 0 ? 23 : idx - 1;
-                                        const float v = L.sh[idx][ln];
-                                        if (v > 0.0f) {
-                                            sp_ += v;
-                                            np++;
-                                        } else {
-                                            sn_ += v;
-                                            nn++;
-                                        }
-                                    }
-                                    if (np != 0 && nn != 0) {
-                                        const float mp = sp_ / (float)np, mn = sn_ / (float)nn;
-                                        if (!(fabsf(mp - mn) < 1.0f)) {
-                                            s.max = mp;
-                                            s.min = mn;
-                                            s.center = (s.max + s.min) / 2.0f;
-                                            s.umid = s.center + (s.max - s.center) * 0.625f;
-                                            s.lmid = s.center + (s.min - s.center) * 0.625f;
-                                            s.maxref = s.max * 0.80f;
-                                            s.minref = s.min * 0.80f;
-                                            s.fill_max = s.max;
-                                            s.fill_min = s.min;
-                                            s.since_fill = 0;
-                                            s.max_sum = (double)s.max * (double)MS;
-                                            s.min_sum = (double)s.min * (double)MS;
-                                        }
-                                    }
-                                }
-                                s.have_sync = 1;
-                                s.lock_left = lock_cfg[ch]; // in-frame symbols after a sync, per channel
-                                fl = 2 | (pol == 2 ? 4 : 0);
-                                if (s.lock_left <= 0) {
-                                    s.have_sync = 0;
-                                    s.lidx = 0;
-                                    s.level_count = 0;
-                                    s.hist_count = 0;
-                                    s.hist_bits = 0;
-                                    s.lmin = s.min;
-                                    s.lmax = s.max;
-                                }
-                            }
-                        }
+                        commit_hunt(sym, done_snap, fl);
                     }
-                    if (offload && qk < QCW) {
-                        L.q[it & 1][qk][0][ln] = sym;
-                        L.q[it & 1][qk][1][ln] = q_max;
-                        L.q[it & 1][qk][2][ln] = q_min;
-                        L.q[it & 1][qk][3][ln] = __int_as_float(fl);
-                        qk++;
-                    } else if ((size_t)o < max_sym) {
-                        int dibit, relb = 0, l0 = 0, l1 = 0;
-                        if (fl & 1) {
-                            const float center = (q_max + q_min) / 2.0f;
-                            const ddn_sl::Thr th = {center, ((q_max - center) * 5.0f / 8.0f) + center,
-                                                    ((q_min - center) * 5.0f / 8.0f) + center, q_max, q_min};
-                            ddn_sl::slice_soft(sym, th, (fl >> 2) & 1, dibit, relb, l0, l1);
-                        } else {
-                            dibit = sym > 0.0f ? 1 : 3;
-                        }
-                        store_record(rp + (size_t)o * 10, fp + o, sym, dibit, relb, l0, l1, fl);
-                    }
-                    o++;
+                    emit(sym, fl, q_max, q_min);
                 }
-                const bool busy = live && sp < tn && !blocked;
-                if (!__any(busy) || ++guard > 4 * TS) {
-                    break;
-                }
+                gblocked = gblocked || blocked;
             }
             if (live) {
                 if (offload) {
                     L.qn[it & 1][ln] = qk;
                 }
-                L.want_e[ln] = gent + 1;
-                L.want_g[ln] = ((s.sidx >> 4) + ((s.sidx & 15) ? 1 : 0)) & 7;
+                L.sidx0[(it + 1) & 1][ln] = s.sidx;
                 sp -= TS;
             }
         }
@@ -1279,7 +1347,7 @@ launch_rxw(const float* raw, const float* filt, const float* prev_tail, long n, 
     if (e != hipSuccess) {
         return e;
     }
-    hipLaunchKernelGGL(k_p25_rxw<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shm, st, raw, filt,
+    hipLaunchKernelGGL(k_p25_rxw<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(192), shm, st, raw, filt,
                        prev_tail, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
                        maxring, rec, flags, counts, max_sym, lock_cfg);
     return hipGetLastError();
@@ -1337,6 +1405,20 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long
     }
     // CPW 16 / 32 run the windowed variant (k_p25_rxw); 64 lanes per wavefront keeps the two-tile kernel, whose LDS
     // footprint still fits (cfg.dbg bit 128 forces it for A/B timing)
+    // k_p25_rxw sizes its window bookkeeping for symbols of at least 6 samples; shorter ones keep the two-tile kernel
+    const int whole = cfg->sym_rate > 0 ? cfg->out_rate / cfg->sym_rate : 0;
+    if (whole < 6) {
+        if (cpw <= 16) {
+            return launch_rx<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                 shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
+        }
+        if (cpw == 32) {
+            return launch_rx<32>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                 shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
+        }
+        return launch_rx<64>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                             shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
+    }
     if (cpw == 8) {
         return launch_rxw<8>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
