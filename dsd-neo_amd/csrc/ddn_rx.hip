@@ -560,7 +560,7 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
 //  * the queue to wave 1 carries {symbol, max, min, flags}; centre / mid thresholds are recomputed there with the
 //    reference's expressions.
 constexpr int RT = 3 * TS;
-constexpr int QCW = 12; // (TS + deferred carry) / (8 - 1) symbols at most per lane and tile when sps >= 8
+constexpr int QT = 20;  // queue slots = trips of a tile that can hand a symbol to wave 1 (later trips store directly)
 constexpr int WMAX = 24;
 
 constexpr int WM = 32; // suffix summaries kept per checkpoint (pushes per two tiles: 2 * (ceil((TS + sps) / (sps - 1)) + 1) <= 30 for sps >= 6)
@@ -574,10 +574,10 @@ struct LdsW {
     // is row[TS + b * TS + j] with no wrap test (slot 2 precedes slot 0 in the ring)
     float raw[CPW][RT + TS + 13];
     float flt[CPW][RT + TS + 13];
-    float q[2][QCW][4][CPW];
-    int qn[2][CPW];
-    int qo[2][CPW];
-    float sfx[2][WM][4][CPW]; // [checkpoint parity][m - 1] = {min1, min2, max1, max2} of ring entries m+1..128 at the checkpoint
+    alignas(16) float q[2][QT][CPW][4]; // [tile parity][trip][lane] = {symbol, max, min, flags | output index << 8}
+    int qn[2];                          // trips of that tile
+    int qo[2][CPW];                     // output index of the lane's first symbol of that tile
+    alignas(16) float sfx[2][WM][CPW][4]; // [checkpoint parity][m - 1][lane] = {min1, min2, max1, max2} of ring entries m+1..128
     int sidx0[2][CPW];        // [tile parity] ring slot of the oldest entry at the start of that tile
 };
 
@@ -682,10 +682,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 two_max_insert(v, b1, b2);
             }
             if (part == 0) {
-                L.sfx[buf][m - 1][0][c] = a1;
-                L.sfx[buf][m - 1][1][c] = a2;
-                L.sfx[buf][m - 1][2][c] = b1;
-                L.sfx[buf][m - 1][3][c] = b2;
+                *reinterpret_cast<float4*>(&L.sfx[buf][m - 1][c][0]) = make_float4(a1, a2, b1, b2);
             }
         }
     };
@@ -723,18 +720,23 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         if (dch >= n_channels) {
             return;
         }
-        const int cnt = L.qn[qb][dc], o0 = L.qo[qb][dc];
+        const int cnt = L.qn[qb], o0 = L.qo[qb][dc];
         uint8_t* drp = rec + (size_t)dch * max_sym * 10;
         uint8_t* dfp = flags + (size_t)dch * max_sym;
-        for (int k = de; k < QCW; k += EPL) {
+        for (int k = de; k < QT; k += EPL) {
             if (k >= cnt) {
                 break;
             }
-            const float sym = L.q[qb][k][0][dc];
-            const int fl = __float_as_int(L.q[qb][k][3][dc]);
+            const float4 e = *reinterpret_cast<const float4*>(&L.q[qb][k][dc][0]);
+            const int fw = __float_as_int(e.w);
+            if (fw < 0) {
+                continue; // this lane handed nothing over in that trip
+            }
+            const float sym = e.x;
+            const int fl = fw & 0xFF;
             int dibit, relb = 0, l0 = 0, l1 = 0;
             if (fl & 1) {
-                const float mx = L.q[qb][k][1][dc], mn = L.q[qb][k][2][dc];
+                const float mx = e.y, mn = e.z;
                 const float center = (mx + mn) / 2.0f;
                 const ddn_sl::Thr th = {center, ((mx - center) * 5.0f / 8.0f) + center,
                                         ((mn - center) * 5.0f / 8.0f) + center, mx, mn};
@@ -742,7 +744,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             } else {
                 dibit = sym > 0.0f ? 1 : 3;
             }
-            const size_t oo = (size_t)(o0 + k);
+            const size_t oo = (size_t)(o0 + (fw >> 8));
             if (oo < max_sym) {
                 store_record(drp + oo * 10, dfp + oo, sym, dibit, relb, l0, l1, fl);
             }
@@ -762,8 +764,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         if (global) {
             int m = npp + npc; // ring entries replaced since the checkpoint
             m = m > WM ? WM : m;
-            const float s1 = L.sfx[sbuf_sel][m - 1][0][ln], s2 = L.sfx[sbuf_sel][m - 1][1][ln];
-            const float s3 = L.sfx[sbuf_sel][m - 1][2][ln], s4 = L.sfx[sbuf_sel][m - 1][3][ln];
+            const float4 sv = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
+            const float s1 = sv.x, s2 = sv.y, s3 = sv.z, s4 = sv.w;
             // two smallest of three sorted pairs, two largest likewise (values are finite: min / max pick the same multiset)
             float t1 = fminf(s1, pp1), t2 = fminf(fmaxf(s1, pp1), fminf(s2, pp2));
             m1 = fminf(t1, pc1);
@@ -778,9 +780,14 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const float* frow = &L.flt[ln][0];
     int sp = 0; // this lane's cursor relative to the current tile (negative: a deferred symbol begins in the previous one)
     int it = 0;
+    double fill_min_d = (double)s.fill_min, fill_max_d = (double)s.fill_max;
+    size_t ro = (size_t)s.midx * (size_t)n_channels + (size_t)ch; // this lane's slot in the [slot][channel] extrema rings
     // ---- per-symbol commit, shared by the fast paths and the generic path of the trip loop ---------------------------
     long t0 = 0;  // call-relative index of the current tile's first sample (the commit stamps filt_start with it)
-    int qk = 0;   // symbols queued to wave 1 during the current tile
+    int cold_until = 0; // see cold_limit()
+    int tk = 0;   // trip of the current tile (= queue slot handed to wave 1)
+    int o_tile = 0; // output index at the start of the current tile
+    float4 qv = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); // this trip's queue entry (-1: nothing handed over)
     int itq = 0;  // queue half of the current tile
     // dsd_symbol_history_push()
     auto commit_pre = [&](float sym) {
@@ -794,24 +801,25 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         float m1, m2, x1, x2;
         window_push(sym, true, m1, m2, x1, x2, done_snap);
         const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
-        const size_t ro = (size_t)s.midx * n_channels + ch;
-        float old_lo = s.fill_min, old_hi = s.fill_max;
+        double old_lo = fill_min_d, old_hi = fill_max_d; // a ring refilled by a warm start holds one value (k * v exact, §5b)
         if (s.since_fill >= MS) {
-            old_lo = minring[ro];
-            old_hi = maxring[ro];
+            old_lo = (double)minring[ro];
+            old_hi = (double)maxring[ro];
         } else {
             s.since_fill++;
         }
-        s.min_sum += (double)lo - (double)old_lo;
-        s.max_sum += (double)hi - (double)old_hi;
+        s.min_sum += (double)lo - old_lo;
+        s.max_sum += (double)hi - old_hi;
         minring[ro] = lo;
         maxring[ro] = hi;
-        s.midx = (s.midx + 1 >= MS) ? 0 : s.midx + 1;
+        ro += (size_t)n_channels;
+        if (++s.midx >= MS) {
+            s.midx = 0;
+            ro = (size_t)ch;
+        }
         s.min = (float)(s.min_sum / (double)MS);
         s.max = (float)(s.max_sum / (double)MS);
         s.center = (s.max + s.min) / 2.0f;
-        s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
-        s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
         s.maxref = s.max * 0.80f;
         s.minref = s.min * 0.80f;
         s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
@@ -819,6 +827,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         q_max = s.max;
         q_min = s.min;
         if (--s.lock_left <= 0) {
+            // the mid thresholds are read by nobody inside a frame (wave 1 derives its own from max / min): they are
+            // brought up to date when the frame ends (and at the end of the call, below)
+            s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
+            s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
             s.have_sync = 0;
             s.lidx = 0;
             s.level_count = 0;
@@ -883,6 +895,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 if (use_flt && !s.filter_on) {
                     s.filter_on = 1;
                     s.filt_start = abs0 + t0 + sp; // first sample the filter sees
+                    cold_until = sp + (NT - 1);
                 }
                 if (s.scount >= 24) {
                     float sp_ = 0.0f, sn_ = 0.0f;
@@ -911,6 +924,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             s.minref = s.min * 0.80f;
                             s.fill_max = s.max;
                             s.fill_min = s.min;
+                            fill_max_d = (double)s.max;
+                            fill_min_d = (double)s.min;
                             s.since_fill = 0;
                             s.max_sum = (double)s.max * (double)MS;
                             s.min_sum = (double)s.min * (double)MS;
@@ -933,12 +948,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
     };
     auto emit = [&](float sym, int fl, float q_max, float q_min) {
-    if (offload && qk < QCW) {
-        L.q[itq][qk][0][ln] = sym;
-        L.q[itq][qk][1][ln] = q_max;
-        L.q[itq][qk][2][ln] = q_min;
-        L.q[itq][qk][3][ln] = __int_as_float(fl);
-        qk++;
+    if (offload && tk <= QT) {
+        qv = make_float4(sym, q_max, q_min, __int_as_float(fl | ((o - o_tile) << 8)));
     } else if ((size_t)o < max_sym) {
         int dibit, relb = 0, l0 = 0, l1 = 0;
         if (fl & 1) {
@@ -961,17 +972,26 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             if (more) {
                 stage(t0 + TS, (it + 1) % 3);
             }
-            if (offload && it > 0) {
+            if (offload && it > 0 && !(cfg.dbg & 512)) {
                 drain((it - 1) & 1);
             }
         } else if (winprep) {
-            if (it >= 1) {
+            if (it >= 1 && !(cfg.dbg & 256)) {
                 compute_sfx(it & 1, it & 1);
             }
         } else {
             const int base = TS + (it % 3) * TS;
             auto rd = [&](const float* row, int j) { return row[base + j]; };
             const int done_snap = 0;
+            // tile-relative sample index from which the matched filter's output is usable (INT_MIN: filter off or warm)
+            auto cold_limit = [&]() {
+                if (!s.filter_on) {
+                    return -2147483647;
+                }
+                const long long d = (long long)(NT - 1) - (abs0 + t0 - s.filt_start);
+                return d <= -2147483647LL ? -2147483647 : (d > 1000000LL ? 1000000 : (int)d);
+            };
+            cold_until = cold_limit();
             if (it >= 1) { // the checkpoint moves to the start of the previous tile
                 pp1 = pc1, pp2 = pc2, pp3 = pc3, pp4 = pc4;
                 npp = npc;
@@ -979,21 +999,28 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
             pc1 = inf, pc2 = inf, pc3 = -inf, pc4 = -inf;
             npc = 0;
-            qk = 0;
+            tk = 0;
             itq = it & 1;
+            o_tile = o;
             if (live && offload) {
                 L.qo[it & 1][ln] = o;
             }
             int guard = 0;
             bool gblocked = false; // generic path: this lane's symbol waits for the next tile
             while (true) {
+                // hand the previous trip's symbols (one per lane at most) to wave 1: one 16-byte LDS write at a wave-uniform slot
+                if (offload && tk > 0 && tk <= QT && lane < CPW) {
+                    *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
+                }
+                qv.w = __int_as_float(-1);
+                tk++;
                 // ---- trip classification -----------------------------------------------------------------------------
                 // Symbols of the ordinary length (std) that start fresh - or were deferred whole to this tile - take one
                 // of two straight-line paths: A = in frame (clip, five-sample mean, in-frame commit; the crossing search only
                 // while the latch is open), B = hunting (timing slip, crossing search, mean, hunting commit).  Everything
                 // else - matched-filter cold start, partly consumed symbols at a call's edges, odd spans - goes through the
                 // generic per-sample code below, which the wave skips when no lane needs it.
-                const bool cold0 = s.filter_on && (abs0 + t0 + sp - s.filt_start) < (long long)(NT - 1);
+                const bool cold0 = sp < cold_until; // == filter_on && (abs0 + t0 + sp - filt_start) < NT - 1
                 const bool ready = live && stdspan && sp < tn && !cold0;
                 const bool ea = ready && s.have_sync && (!s.in_symbol || (s.i == 0 && s.count == 0));
                 const bool eb = ready && !s.have_sync && (!s.in_symbol || (s.i >= -1 && s.i <= 1 && s.count == 0));
@@ -1308,10 +1335,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 gblocked = gblocked || blocked;
             }
+            if (offload && lane == 0) {
+                L.qn[it & 1] = (tk - 1) < QT ? (tk - 1) : QT; // trips that may have queued (the last one broke out at its top)
+            }
             if (live) {
-                if (offload) {
-                    L.qn[it & 1][ln] = qk;
-                }
                 L.sidx0[(it + 1) & 1][ln] = s.sidx;
                 sp -= TS;
             }
@@ -1322,6 +1349,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         drain((it - 1) & 1);
     }
     if (live) {
+        if (s.have_sync) {
+            s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
+            s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
+        }
         s.n_abs = abs0 + n;
         state[ch] = s;
         counts[ch] = o;

@@ -16,7 +16,7 @@ def ins(anchor, code, after=False):
 
 T = "{ const long long t_=__builtin_readcyclecounter(); prof[%d] += t_ - tlast; tlast = t_; }\n"
 ins("    const float* rrow = &L.raw[ln][0];",
-    "    long long prof2[8] = {0,0,0,0,0,0,0,0}; long long prof[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; long long tlast = __builtin_readcyclecounter(); long long ntrip=0, nfast=0, ngen=0, nwp=0, nslowwp=0, nk0=0;\n")
+    "    long long prof2[8] = {0,0,0,0,0,0,0,0}; long long prof[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; long long tlast = __builtin_readcyclecounter(); long long ntrip=0, nfast=0, ngen=0;\n")
 ins("                // ---- trip classification ----", T % 0 + "ntrip++;\n")
 ins("                if (__any(do_a || do_b)) {\n", T % 1 + "nfast++;\n", after=True)
 ins("                    // the five window samples (indices centre - 2", T % 2)
@@ -33,12 +33,11 @@ ins("        fl = 1 | (neg ? 4 : 0);", U % 2)
 ins("        L.lb[s.lidx][ln] = sym;", U % 3)
 ins("        s.lidx = (s.lidx == 23) ? 0 : s.lidx + 1;", U % 4)
 ins("        if (s.hist_count >= 8) {", U % 5)
-ins("        if (fastwin) {\n            two_min_insert(sym, pm1, pm2);", "        nwp++; if (__any(live && !fastwin)) nslowwp++; if (__any(live && k == 0)) nk0++;\n")
 ins("                gblocked = gblocked || blocked;", T % 8)
 ins("    if (loader && offload && it > 0) {\n        drain((it - 1) & 1);\n    }",
     '    if (!loader && blockIdx.x == 7 && lane == 0) { printf("PROF trips %lld fast %lld generic %lld | loop/other %lld classify %lld search %lld '
     'window %lld div+pre %lld commit %lld emit %lld tail %lld generic %lld\\n", ntrip, nfast, ngen, prof[0], prof[1], prof[2], prof[3], '
-    "prof[4], prof[5], prof[6], prof[7], prof[8]); printf(\"PROF3 winpush calls %lld with-slow-lane %lld with-k0 %lld\\n\", nwp, nslowwp, nk0); printf(\"PROF2 pre-winpush %lld winpush_if %lld ring+sums %lld thresholds %lld | hunt-pre %lld winpush_h %lld idx+hist %lld\\n\", prof2[0]-0, prof2[0], prof2[1], prof2[2], prof2[3], prof2[4], prof2[5]); }\n")
+    "prof[4], prof[5], prof[6], prof[7], prof[8]); printf(\"PROF2 pre-winpush %lld winpush_if %lld ring+sums %lld thresholds %lld | hunt-pre %lld winpush_h %lld idx+hist %lld\\n\", prof2[0]-0, prof2[0], prof2[1], prof2[2], prof2[3], prof2[4], prof2[5]); }\n")
 here = os.path.dirname(os.path.abspath(__file__))
 open(os.path.join(here, "ddn_rx_prof.hip"), "w").write(head + body)
 amd = os.path.join(ROOT, "dsd-neo_amd")
