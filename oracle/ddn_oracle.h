@@ -206,6 +206,15 @@ long orc_p25rx_run(orc_p25rx* r, const float* in, long n, float* out_sym, int* r
 void orc_p25rx_get_thresholds(const orc_p25rx* r, float out7[7]);
 size_t orc_p25rx_sizeof(void);
 
+/* ---- getSymbol()'s sample loop in all its window / timing variants (oracle/ddn_oracle_symbolizer.c) ---------- */
+typedef struct orc_symbolizer {
+    int out_rate, sym_rate, rf_mod, l_edge, r_edge;
+    int sps_accum, jitter, last_sps, last_centre;
+    float lastsample, center, min, max, minref, maxref;
+} orc_symbolizer;
+void orc_symbolizer_init(orc_symbolizer* s, int out_rate_hz, int sym_rate_hz, int rf_mod, int l_edge, int r_edge);
+long orc_symbolizer_symbol(orc_symbolizer* s, const float* in, long n, int have_sync, float* out_sym);
+
 /* ---- P25p1 Golay(24,12,8) + RS GF(64) hard-decision decoders (oracle/ddn_oracle_rs.c) ---------------------- */
 int orc_golay_24_decode(uint8_t* data, int len, const uint8_t* parity, int* fixed);
 int orc_rs63_decode(int* word, int t);

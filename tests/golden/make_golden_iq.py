@@ -11,7 +11,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 for name, nac_hex, note in (("p25p1_c4fm_cc", "140", "control channel: TSDU frames, expected payload field NAC/CC: 140"),
                             ("p25p1_c4fm_vc", "", "voice channel: LDU1/LDU2 frames (Group Voice Channel User)"),
                             ("p25p1_cqpsk_cc", "", "CQPSK/LSM control channel; DECODE_IQ_P25P1_CQPSK_CC expects "
-                                                   "'WACN: 92065; SYS: 0D5' (tests/CMakeLists.txt:8901-8906)")):
+                                                   "'WACN: 92065; SYS: 0D5' (tests/CMakeLists.txt:8901-8906)"),
+                            ("p25p1_cqpsk_vc", "", "CQPSK/LSM voice channel; DECODE_IQ_P25P1_CQPSK_VOICE expects 'Group Voice "
+                                                   "Channel User' (tests/CMakeLists.txt:8907-8912)"),
+                            ("p25p1_cqpsk_cc_simulcast", "", "two-ray simulcast impairment of the CQPSK control channel; "
+                                                             "DECODE_IQ_P25P1_CQPSK_SIMULCAST_CC expects 'Group Voice Channel Grant "
+                                                             "Update - Implicit' (tests/CMakeLists.txt:8913-8921)")):
     iq = np.fromfile(os.path.join(SRC, name + ".iq"), dtype=np.uint8).reshape(-1, 2)
     np.savez_compressed(os.path.join(HERE, "iq_%s.npz" % name), iq=iq, rate=np.int32(48000),
                         expected_nac_hex=np.bytes_(nac_hex), note=np.bytes_(note))

@@ -315,3 +315,149 @@ def test_voice_capture_ldu2_gpu(built):
         return x, st
 
     _check_ess(ldu2_ess(r4, fl[0], int(cnt[0]), gpu_hamming, gpu_rs))
+
+
+# ---- the remaining P25 Phase 1 known answers the reference holds (tests/CMakeLists.txt:8907-8921) ----------------------
+# OP25-compatible orientation maps of the differential demodulator's dibits (include/dsd-neo/core/p25_cqpsk_dibit.h:29-35);
+# frame_sync_find_rotated_p25_cqpsk_map (src/dsp/dsd_frame_sync.c:580-597) tries X2400, N1200, P1200 once the plain and
+# reverse-polarity patterns failed
+CQPSK_MAPS = {"identity": (0, 1, 2, 3), "rev_p": (2, 3, 0, 1), "x2400": (3, 2, 1, 0), "n1200": (1, 3, 0, 2), "p1200": (2, 0, 3, 1)}
+
+
+def cqpsk_dibits(sym):
+    """fixed 4-level slice + the orientation map under which the first frame sync appears (reference search order)"""
+    raw = np.where(sym >= 2, 1, np.where(sym >= 0, 0, np.where(sym >= -2, 2, 3))).astype(np.int64)
+    first = {}
+    for name in ("identity", "rev_p", "x2400", "n1200", "p1200"):
+        d = np.array(CQPSK_MAPS[name])[raw]
+        hits = [i for i in range(len(d) - 24) if np.array_equal(d[i:i + 24], FS)]
+        if hits:
+            first[name] = hits[0]
+    assert first, "no P25p1 frame sync under any orientation"
+    name = min(first, key=lambda k: (first[k], list(CQPSK_MAPS).index(k)))
+    return np.array(CQPSK_MAPS[name])[raw], name
+
+
+def cqpsk_records(d):
+    """dibits -> the (rec4, flags) shape the record-based helpers above take: hard decisions at full confidence"""
+    rec4 = np.zeros((len(d), 4), np.int32)
+    rec4[:, 0] = d
+    rec4[:, 1] = 255
+    rec4[:, 2] = np.where((d >> 1) & 1, 255, -255)
+    rec4[:, 3] = np.where(d & 1, 255, -255)
+    fl = np.zeros(len(d), np.uint8)
+    for i in range(len(d) - 24):
+        if np.array_equal(d[i:i + 24], FS):
+            fl[i + 23] = 2
+    return rec4, fl
+
+
+def check_cqpsk_voice(sym, hamming, rs):
+    d, name = cqpsk_dibits(sym)
+    assert name == "n1200"                                   # this capture sits a quarter turn per symbol off: map N1200
+    rec4, fl = cqpsk_records(d)
+    rows = nids_from_records(rec4, fl, len(d))
+    nid = decode_nids(rows, oracle_nid)
+    assert np.all(nid[:, 0] == 1) and len(set(nid[:, 1])) == 1
+    duids = list(nid[:, 2])
+    assert duids.count(15) >= 5 and 0 in duids and duids[-6:] == [5, 10, 5, 10, 5, 10]   # TDULCs, HDU, then the voice call
+    lcs = [link_control(w, hamming, rs) for w in ldu1_words(rec4, fl, len(d))]
+    assert len(lcs) >= 3
+    lcf = [int("".join(map(str, lc[:8])), 2) for lc in lcs]
+    # this call alternates "Group Voice Channel Update" (LCF 0x42: implicit MFID, LCO 2) with "Group Voice Channel User"
+    # (LCF 0x00, MFID 0x00) - the string DECODE_IQ_P25P1_CQPSK_VOICE waits for
+    assert set(lcf) <= {0x00, 0x42} and 0x00 in lcf
+    user = [lc for lc, f in zip(lcs, lcf) if f == 0x00]
+    for lc in user:
+        assert int("".join(map(str, lc[8:16])), 2) == 0
+        assert int("".join(map(str, lc[32:48])), 2) != 0 and int("".join(map(str, lc[48:72])), 2) != 0   # talkgroup, source
+
+
+def check_simulcast(hits, blocks):
+    assert len(hits) >= 50 and all(crc16_tsbk_ok(b) for b in blocks)
+    ops = [int(b[0]) & 0x3F for b in blocks]
+    upd = [b for b in blocks if (int(b[0]) & 0x3F) == 0x02 and int(b[1]) == 0]
+    assert len(upd) >= 1, ops         # TSBK 0x02 = MAC 0x42 "Group Voice Channel Grant Update - Implicit" (p25p2_vpdu.c:1645-1653)
+
+
+def _cqpsk_sym(name):
+    g = golden(name)
+    x = ((g["iq"].astype(np.float32) - 127.5) * np.float32(1.0 / 127.5)).astype(np.float32)
+    return g, orc.OracleCqpskFe(rate=48000).run(x, 8192)
+
+
+def test_cqpsk_voice_capture_is_group_voice_channel_user(built):
+    """DECODE_IQ_P25P1_CQPSK_VOICE (tests/CMakeLists.txt:8907-8912)"""
+    from test_oracle_rs import oracle_rs
+    _, sym = _cqpsk_sym("iq_p25p1_cqpsk_vc.npz")
+    check_cqpsk_voice(sym, _oracle_hamming, lambda d, p: oracle_rs("24_12_13", d, p))
+
+
+def test_cqpsk_simulcast_capture_carries_grant_update(built):
+    """DECODE_IQ_P25P1_CQPSK_SIMULCAST_CC (tests/CMakeLists.txt:8913-8921): two-ray fading, every TSBK still passes its CRC"""
+    import fecgen
+    _, sym = _cqpsk_sym("iq_p25p1_cqpsk_cc_simulcast.npz")
+    hits, llr = cqpsk_tsbk_inputs(sym)
+    blocks, _ = fecgen.oracle_p25_half_rate(llr)
+    check_simulcast(hits, blocks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["iq_p25p1_cqpsk_vc.npz", "iq_p25p1_cqpsk_cc_simulcast.npz"])
+def test_cqpsk_remaining_known_answers_gpu(built, name):
+    import ddn
+    g, want = _cqpsk_sym(name)
+    iq = np.ascontiguousarray(g["iq"])
+    b = ddn.CqpskBatch(1, rate=48000, block_len=8192, input_format=ddn.IN_CU8)
+    sym, cnt = b.run(iq[None])
+    assert cnt[0] == len(want) and np.array_equal(sym[0, :cnt[0]].view(np.uint32), want.view(np.uint32))
+    if "simulcast" in name:
+        hits, llr = cqpsk_tsbk_inputs(sym[0, :cnt[0]])
+        out = np.zeros((len(hits), 12), np.uint8)
+        met = np.zeros(len(hits), np.int32)
+        assert ddn.lib().ddn_fec_p25_12_soft_host(llr.ctypes.data, len(hits), out.ctypes.data, met.ctypes.data) == 0
+        check_simulcast(hits, out)
+    else:
+        def gpu_hamming(bits):
+            x = bits.copy()
+            e = np.zeros(len(x), np.uint8)
+            assert ddn.lib().ddn_fec_hamming_10_6_3_host(x.ctypes.data, len(x), e.ctypes.data) == 0
+            return x, e
+
+        def gpu_rs(d, p):
+            x = d.copy()
+            st = np.zeros(len(d), np.uint8)
+            assert ddn.lib().ddn_fec_p25_rs_host(0, x.ctypes.data, p.ctypes.data, len(d), st.ctypes.data) == 0
+            return x, st
+        check_cqpsk_voice(sym[0, :cnt[0]], gpu_hamming, gpu_rs)
+
+
+def test_control_channel_capture_every_tsbk_passes_crc(built):
+    """Every trellis block of every TSDU of the reference's C4FM control-channel capture decodes to a TSBK whose CRC-16
+    holds (multi-block TSDUs are walked until the Last Block flag): a timing slip of one sample or a mis-sliced dibit the
+    trellis had to absorb would show up here as a failed CRC or a non-zero path metric."""
+    import ctypes as C
+    import ddn
+    import fecgen
+    g = golden("iq_p25p1_c4fm_cc.npz")
+    _, sym, rec4, fl = oracle_chain(g["iq"], 336)                 # 24 + 336 = the capture's three-block TSDUs
+    rows = nids_from_records(rec4, fl, len(sym))
+    nid = decode_nids(rows, oracle_nid)
+    n_blocks = n_frames = 0
+    for (a, _, _), nd in list(zip(rows, nid))[1:]:
+        if nd[0] != 1 or nd[2] != 7:
+            continue
+        n_frames += 1
+        for b in range(3):
+            pos = np.zeros(98, np.int32)
+            end = ddn.lib().ddn_p25p1_layout_trellis_block(b, pos.ctypes.data)
+            if a - 23 + end > len(sym):
+                break
+            blk = rec4[a - 23 + pos]
+            llr = np.stack([blk[:, 2], blk[:, 3]], axis=1).reshape(1, 196).astype(np.int16)
+            out, met = fecgen.oracle_p25_half_rate(np.ascontiguousarray(llr))
+            assert crc16_tsbk_ok(out[0]), (a, b)
+            n_blocks += 1
+            if out[0][0] & 0x80:                                  # Last Block
+                break
+    assert n_frames >= 24 and n_blocks >= 48
