@@ -215,6 +215,10 @@ PROTOTYPES = {
     "dmr_r34_viterbi_decode_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "viterbi_decode": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_uint16]),
     "viterbi_decode_punctured": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16, C.c_uint16]),
+    "viterbi_decode_bit": (None, [C.c_uint16, C.c_uint16, C.c_size_t]),
+    "viterbi_chainback": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint16]),
+    "viterbi_reset": (None, []),
+    "dsd_fsk_modem_discriminator_process": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "CNXDNConvolution_init": (None, []),
     "CNXDNConvolution_start": (None, []),
     "CNXDNConvolution_decode": (None, [C.c_uint8, C.c_uint8]),

@@ -368,6 +368,58 @@ viterbi_decode_punctured(uint8_t* out, const uint16_t* in, const uint8_t* punct,
     return cost;
 }
 
+// Step-wise form of the same decoder (src/core/util/dsd_misc.c:188-283: viterbi_decode_bit updates file-static path
+// metrics / history per symbol pair, viterbi_chainback walks them back, viterbi_reset clears them).  The drop-in keeps
+// the symbol pairs per thread and runs the accumulated steps on the device at chainback time - the add-compare-select
+// of step `pos` depends only on the pairs 0..pos, so the result is the one the incremental form reaches.
+namespace {
+thread_local std::vector<uint16_t> g_vb_soft;
+} // namespace
+
+extern "C" void
+viterbi_reset(void) {
+    g_vb_soft.clear();
+}
+
+extern "C" void
+viterbi_decode_bit(uint16_t s0, uint16_t s1, const size_t pos) {
+    if (pos >= 244) { // the reference's history array holds 244 steps
+        return;
+    }
+    if (g_vb_soft.size() < 2 * (pos + 1)) {
+        g_vb_soft.resize(2 * (pos + 1), 0x7FFF);
+    }
+    g_vb_soft[2 * pos] = s0;
+    g_vb_soft[2 * pos + 1] = s1;
+}
+
+extern "C" uint32_t
+viterbi_chainback(uint8_t* out, size_t pos, uint16_t len) {
+    if (!out || pos == 0 || 2 * pos > g_vb_soft.size() || pos > 244) {
+        return 0xFFFFFFFFu;
+    }
+    // viterbi_decode(out, in, 2 * pos) calls viterbi_chainback(out, pos, pos): bit position = step index + 4 there; a
+    // caller's `len` only shifts where the bits land
+    uint32_t cost = 0;
+    const int stride = (int)((pos + 3) / 8 + 1);
+    std::vector<uint8_t> tmp((size_t)stride);
+    if (ddn_fec_viterbi_k5_host(g_vb_soft.data(), 1, (int)(2 * pos), nullptr, 0, tmp.data(), stride, &cost) != DDN_OK) {
+        return 0xFFFFFFFFu;
+    }
+    if (len == pos) {
+        memcpy(out, tmp.data(), (size_t)((len - 1) / 8 + 1) < (size_t)stride ? (size_t)stride : (size_t)((len - 1) / 8 + 1));
+    } else {
+        memset(out, 0, (size_t)((len - 1) / 8 + 1));
+        for (size_t k = 0; k < pos; k++) { // step k's bit sits at k + 4 in tmp and at len + 4 - pos + k in `out`
+            const size_t src = k + 4, dst = (size_t)len + 4 - pos + k;
+            if ((tmp[src / 8] >> (7 - (src % 8))) & 1u) {
+                out[dst / 8] |= (uint8_t)(1u << (7 - (dst % 8)));
+            }
+        }
+    }
+    return cost;
+}
+
 // The reference keeps the NXDN decoder's symbols-in-flight and path metrics in file-static storage
 // (src/protocol/nxdn/nxdn_convolution.c:48-53); the drop-in keeps the same per-thread streaming contract and runs
 // the accumulated steps on the device at chainback time.

@@ -316,3 +316,11 @@ ddn_fsk_modem_discriminator_process(ddn_fsk_modem_state* st, const float* iq_int
     (void)hipMemcpy(st, dst.p, sizeof(*st), hipMemcpyDeviceToHost);
     return cnt;
 }
+
+// the reference's own name for the same entry point (include/dsd-neo/dsp/fsk_modem.h:42; dsd_fsk_modem_state has the
+// layout of ddn_fsk_modem_state), so tests/dsp/test_fsk_modem.c links against this library unchanged
+extern "C" int
+dsd_fsk_modem_discriminator_process(ddn_fsk_modem_state* st, const float* iq_interleaved, int len_interleaved,
+                                    float* out_samples, int max_samples) {
+    return ddn_fsk_modem_discriminator_process(st, iq_interleaved, len_interleaved, out_samples, max_samples);
+}

@@ -588,6 +588,11 @@ int dmr_r34_viterbi_decode_soft(const uint8_t* dibits98, const uint8_t* reliab98
 uint32_t viterbi_decode(uint8_t* out, const uint16_t* in, const uint16_t len);
 uint32_t viterbi_decode_punctured(uint8_t* out, const uint16_t* in, const uint8_t* punct, const uint16_t in_len,
                                   const uint16_t p_len);
+/* step-wise form (include/dsd-neo/fec/viterbi.h:26-28; src/core/util/dsd_misc.c:188-283): per-thread symbol history,
+ * decoded on the device at chainback */
+void viterbi_decode_bit(uint16_t s0, uint16_t s1, const size_t pos);
+uint32_t viterbi_chainback(uint8_t* out, size_t pos, uint16_t len);
+void viterbi_reset(void);
 void CNXDNConvolution_init(void);
 void CNXDNConvolution_start(void);
 void CNXDNConvolution_decode(uint8_t s0, uint8_t s1);
@@ -611,6 +616,9 @@ typedef struct ddn_fsk_modem_state { /* layout == dsd_fsk_modem_state, include/d
     float discriminator_peak_est;
 } ddn_fsk_modem_state;
 int ddn_fsk_modem_discriminator_process(ddn_fsk_modem_state* st, const float* iq_interleaved, int len_interleaved,
+                                        float* out_samples, int max_samples);
+/* the same under the reference's name (include/dsd-neo/dsp/fsk_modem.h:42; `dsd_fsk_modem_state` == ddn_fsk_modem_state) */
+int dsd_fsk_modem_discriminator_process(ddn_fsk_modem_state* st, const float* iq_interleaved, int len_interleaved,
                                         float* out_samples, int max_samples);
 
 #ifdef __cplusplus

@@ -141,6 +141,14 @@ def test_dropin_symbols(built):
         o = np.zeros(stride, np.uint8)
         assert l.viterbi_decode(o.ctypes.data, soft[i].ctypes.data, 488) == wc[i]
         assert np.array_equal(o, wo[i])
+    # step-wise libM17 form (dsd_misc.c:188-283): viterbi_reset, one viterbi_decode_bit per symbol pair, viterbi_chainback
+    for i in range(2):
+        l.viterbi_reset()
+        for t in range(244):
+            l.viterbi_decode_bit(int(soft[i, 2 * t]), int(soft[i, 2 * t + 1]), t)
+        o = np.zeros(stride, np.uint8)
+        assert l.viterbi_chainback(o.ctypes.data, 244, 244) == wc[i]
+        assert np.array_equal(o, wo[i])
     # streaming NXDN API: two decodes back to back, metrics carried like the reference's static state
     sym, _ = fecgen.gen_nxdn(rng, 2, 96)
     l.CNXDNConvolution_init()
