@@ -253,6 +253,27 @@ class MbeTables(C.Structure):
 MBE_IMBE, MBE_AMBE = 0, 1
 _PP = C.POINTER(MbeParms)
 PROTOTYPES.update({
+    "ddn_fec_block_code_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_block_code_host": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_fec_bptc_196x96_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_bptc_196x96_host": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_rs_12_9_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_rs_12_9_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "Hamming_7_4_init": (None, []), "Hamming_12_8_init": (None, []), "Hamming_13_9_init": (None, []),
+    "Hamming_15_11_init": (None, []), "Hamming_16_11_4_init": (None, []), "Golay_20_8_init": (None, []),
+    "Golay_24_12_init": (None, []), "QR_16_7_6_init": (None, []), "InitAllFecFunction": (None, []),
+    "Hamming_7_4_decode": (C.c_bool, [C.c_void_p]),
+    "Hamming_12_8_decode": (C.c_bool, [C.c_void_p, C.c_void_p, C.c_int]),
+    "Hamming_13_9_decode": (C.c_bool, [C.c_void_p, C.c_void_p, C.c_int]),
+    "Hamming_15_11_decode": (C.c_bool, [C.c_void_p, C.c_void_p, C.c_int]),
+    "Hamming_16_11_4_decode": (C.c_bool, [C.c_void_p, C.c_void_p, C.c_int]),
+    "Golay_20_8_decode": (C.c_bool, [C.c_void_p]), "Golay_24_12_decode": (C.c_bool, [C.c_void_p]),
+    "QR_16_7_6_decode": (C.c_bool, [C.c_void_p]),
+    "BPTCDeInterleaveDMRData": (None, [C.c_void_p, C.c_void_p]),
+    "BPTC_196x96_Extract_Data": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rs_12_9_calc_syndrome": (None, [C.c_void_p, C.c_void_p]),
+    "rs_12_9_check_syndrome": (C.c_uint8, [C.c_void_p]),
+    "rs_12_9_correct_errors": (C.c_uint8, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_p25_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_mbe_default_tables": (C.c_int, [C.POINTER(MbeTables)]),

@@ -608,6 +608,75 @@ int simd_hb_decim2_real(const float* in, int in_len, float* out, float* hist, co
 const char* simd_fir_get_impl_name(void);
 void widen_u8_to_f32_bias127(const unsigned char* src, float* dst, uint32_t len);
 
+/* ---- block codes downstream of the receive loop: DMR / NXDN ------------------------------------------
+ * == include/dsd-neo/fec/block_codes.h:19-43 (src/fec/fec.c:133-838), bptc.h:20-26 (src/fec/bptc.c), rs_12_9.h:38-42
+ * (src/fec/rs-12-9.c).  One bit per byte like the reference; results are the reference's, quirks included (see
+ * dsd-neo_amd/csrc/ddn_fec3.hip).
+ *   ddn_fec_block_code_batch   d_bits [n_items][nb_codewords][n] corrected in place, d_ok [n_items] = the bool the reference
+ *                              returns; the multi-code-word Hamming forms also write d_decoded [n_items][nb_codewords][k]
+ *                              (nb_codewords is 1 for the other codes)
+ *   ddn_fec_bptc_196x96_batch  d_in196 [n][196] (deinterleave != 0: still in air order, BPTCDeInterleaveDMRData is applied
+ *                              on the fly) -> d_out96 [n][96], d_r3 [n][3], d_errs [n] (irrecoverable Hamming checks of the
+ *                              second pass, BPTC_196x96_Extract_Data's return value)
+ *   ddn_fec_rs_12_9_batch      d_codewords12 [n][12] corrected in place; d_result [n] = RS_12_9_CORRECT_ERRORS_RESULT_* (0
+ *                              also for a zero syndrome), d_errors_found [n], d_syndrome3 [n][3] (optional) */
+enum {
+    DDN_CODE_HAMMING_7_4 = 0,
+    DDN_CODE_HAMMING_12_8 = 1,
+    DDN_CODE_HAMMING_13_9 = 2,
+    DDN_CODE_HAMMING_15_11 = 3,
+    DDN_CODE_HAMMING_16_11_4 = 4,
+    DDN_CODE_GOLAY_20_8 = 5,
+    DDN_CODE_GOLAY_24_12 = 6,
+    DDN_CODE_QR_16_7_6 = 7,
+};
+int ddn_fec_block_code_batch(int code, uint8_t* d_bits, size_t n_items, int nb_codewords, uint8_t* d_decoded, uint8_t* d_ok,
+                             void* hip_stream);
+int ddn_fec_block_code_host(int code, uint8_t* bits, size_t n_items, int nb_codewords, uint8_t* decoded, uint8_t* ok);
+int ddn_fec_bptc_196x96_batch(const uint8_t* d_in196, int deinterleave, size_t n, uint8_t* d_out96, uint8_t* d_r3,
+                              uint32_t* d_errs, void* hip_stream);
+int ddn_fec_bptc_196x96_host(const uint8_t* in196, int deinterleave, size_t n, uint8_t* out96, uint8_t* r3, uint32_t* errs);
+int ddn_fec_rs_12_9_batch(uint8_t* d_codewords12, size_t n, uint8_t* d_result, uint8_t* d_errors_found, uint8_t* d_syndrome3,
+                          void* hip_stream);
+int ddn_fec_rs_12_9_host(uint8_t* codewords12, size_t n, uint8_t* result, uint8_t* errors_found, uint8_t* syndrome3);
+/* drop-ins with the reference's names (single item, host pointers) */
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+void Hamming_7_4_init(void);
+bool Hamming_7_4_decode(unsigned char* rxBits);
+void Hamming_12_8_init(void);
+bool Hamming_12_8_decode(unsigned char* rxBits, unsigned char* decodedBits, int nbCodewords);
+void Hamming_13_9_init(void);
+bool Hamming_13_9_decode(unsigned char* rxBits, unsigned char* decodedBits, int nbCodewords);
+void Hamming_15_11_init(void);
+bool Hamming_15_11_decode(unsigned char* rxBits, unsigned char* decodedBits, int nbCodewords);
+void Hamming_16_11_4_init(void);
+bool Hamming_16_11_4_decode(unsigned char* rxBits, unsigned char* decodedBits, int nbCodewords);
+void Golay_20_8_init(void);
+bool Golay_20_8_decode(unsigned char* rxBits);
+void Golay_24_12_init(void);
+bool Golay_24_12_decode(unsigned char* rxBits);
+void QR_16_7_6_init(void);
+bool QR_16_7_6_decode(unsigned char* rxBits);
+void InitAllFecFunction(void);
+void BPTCDeInterleaveDMRData(const uint8_t* Input, uint8_t* Output);
+uint32_t BPTC_196x96_Extract_Data(uint8_t InputDeInteleavedData[196], uint8_t DMRDataExtracted[96], uint8_t R[3]);
+typedef struct {
+    uint8_t data[12];
+} rs_12_9_codeword_t;
+typedef struct {
+    uint8_t data[6];
+} rs_12_9_poly_t;
+#define RS_12_9_CORRECT_ERRORS_RESULT_NO_ERRORS_FOUND          0
+#define RS_12_9_CORRECT_ERRORS_RESULT_ERRORS_CORRECTED         1
+#define RS_12_9_CORRECT_ERRORS_RESULT_ERRORS_CANT_BE_CORRECTED 2
+typedef uint8_t rs_12_9_correct_errors_result_t;
+void rs_12_9_calc_syndrome(const rs_12_9_codeword_t* codeword, rs_12_9_poly_t* syndrome);
+uint8_t rs_12_9_check_syndrome(const rs_12_9_poly_t* syndrome);
+rs_12_9_correct_errors_result_t rs_12_9_correct_errors(rs_12_9_codeword_t* codeword, const rs_12_9_poly_t* syndrome,
+                                                       uint8_t* errors_found);
+
 typedef struct ddn_fsk_modem_state { /* layout == dsd_fsk_modem_state, include/dsd-neo/dsp/fsk_modem.h:22-36 */
     int cfg_sample_rate_hz, cfg_symbol_rate_hz, cfg_levels, cfg_channel_profile;
     float prev_i, prev_q;

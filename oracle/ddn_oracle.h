@@ -206,6 +206,15 @@ long orc_p25rx_run(orc_p25rx* r, const float* in, long n, float* out_sym, int* r
 void orc_p25rx_get_thresholds(const orc_p25rx* r, float out7[7]);
 size_t orc_p25rx_sizeof(void);
 
+/* ---- DMR / NXDN block codes (oracle/ddn_oracle_fec3.c) ------------------------------------------------------------ */
+int orc_hamming_7_4_decode(uint8_t* rx);
+int orc_hamming_multi_decode(int which, uint8_t* rx, uint8_t* dec, int nb); /* which: 0 (12,8) 1 (13,9) 2 (15,11) 3 (16,11,4) */
+int orc_golay_dmr_decode(int n, uint8_t* rx);                               /* n = 20 or 24 */
+int orc_qr_16_7_6_decode(uint8_t* rx);
+uint32_t orc_bptc_196x96(const uint8_t* in196, int deinterleave, uint8_t out96[96], uint8_t r3[3]);
+int orc_bptc_last_col0_failed(void);
+int orc_rs_12_9(uint8_t cw[12], uint8_t syn3[3], uint8_t* found);
+
 /* ---- getSymbol()'s sample loop in all its window / timing variants (oracle/ddn_oracle_symbolizer.c) ---------- */
 typedef struct orc_symbolizer {
     int out_rate, sym_rate, rf_mod, l_edge, r_edge;
