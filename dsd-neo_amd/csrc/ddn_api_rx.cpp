@@ -26,6 +26,7 @@ struct ddn_p25_rx {
     ddn_p25_rx_config cfg;
     DdnRxState* d_state;
     float *d_sbuf, *d_lbuf, *d_shist, *d_minring, *d_maxring, *d_fhist;
+    float* d_fstale; // [B][90] the matched filter's memory as the last carrier loss left it (zeros on a fresh stream)
     float* d_filt; // always-on matched-filter output of the current call, [B][filt_cap]
     size_t filt_cap;
     int channels_per_wave;
@@ -44,6 +45,7 @@ rx_free(ddn_p25_rx* b) {
     (void)hipFree(b->d_minring);
     (void)hipFree(b->d_maxring);
     (void)hipFree(b->d_fhist);
+    (void)hipFree(b->d_fstale);
     (void)hipFree(b->d_filt);
     (void)hipFree(b->d_lock);
     for (int i = 0; i < 3; i++) {
@@ -82,7 +84,8 @@ rx_fill(ddn_p25_rx* b) {
         || hipMemset(b->d_shist, 0, sizeof(float) * 24 * B) != hipSuccess
         || hipMemset(b->d_minring, 0, sizeof(float) * 1024 * B) != hipSuccess
         || hipMemset(b->d_maxring, 0, sizeof(float) * 1024 * B) != hipSuccess
-        || hipMemset(b->d_fhist, 0, sizeof(float) * 90 * B) != hipSuccess) {
+        || hipMemset(b->d_fhist, 0, sizeof(float) * 90 * B) != hipSuccess
+        || hipMemset(b->d_fstale, 0, sizeof(float) * 90 * B) != hipSuccess) {
         ddn_set_error("p25 rx state upload failed");
         return DDN_EHIP;
     }
@@ -121,6 +124,7 @@ ddn_p25_rx_create(const ddn_p25_rx_config* cfg, ddn_p25_rx** out) {
         || hipMalloc(&b->d_minring, sizeof(float) * 1024 * B) != hipSuccess
         || hipMalloc(&b->d_maxring, sizeof(float) * 1024 * B) != hipSuccess
         || hipMalloc(&b->d_fhist, sizeof(float) * 90 * B) != hipSuccess
+        || hipMalloc(&b->d_fstale, sizeof(float) * 90 * B) != hipSuccess
         || hipMalloc(&b->d_lock, sizeof(int32_t) * B) != hipSuccess || rx_fill(b) != DDN_OK
         || ddn_p25_rx_set_lock_symbols(b, nullptr) != DDN_OK) {
         ddn_set_error("ddn_p25_rx_create: device allocation failed");
@@ -231,7 +235,7 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
     if (const char* e = getenv("DDN_RX_DBG")) {
         dc.dbg = atoi(e);
     }
-    HIP_TRY(ddn_dev_p25_rx(d_disc, b->d_filt, b->d_fhist, (long)n, n, B, &dc, b->d_state, b->d_sbuf, b->d_lbuf,
+    HIP_TRY(ddn_dev_p25_rx(d_disc, b->d_filt, b->d_fhist, b->d_fstale, (long)n, n, B, &dc, b->d_state, b->d_sbuf, b->d_lbuf,
                            b->d_shist, b->d_minring, b->d_maxring, d_records10, d_flags, d_counts, max_symbols,
                            b->channels_per_wave, b->d_lock, st));
     if (b->timing) {

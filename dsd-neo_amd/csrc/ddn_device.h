@@ -79,6 +79,8 @@ typedef struct DdnRxState { /* per-channel words of dsd_state / frame_sync_runti
     int filter_on, have_sync, lock_left, lastsync; /* lastsync: 0 none, 1 +P25p1, 2 -P25p1 */
     int lidx, level_count, hist_count, shead, scount;
     uint32_t hist_bits;
+    int hunt_pos;   /* rt.synctest_pos: symbols hunted since the hunt (re)started */
+    int need_reset; /* noCarrier() ran: the next symbol start re-initialises timing and slicer */
 } DdnRxState;
 
 typedef struct DdnCqpskState { /* per-channel words of demod_state the CQPSK chain carries besides ted_state_t */
@@ -118,7 +120,7 @@ hipError_t ddn_dev_p25_matched_filter_only(const float* in, long n, size_t strid
                                            float* out, hipStream_t st);
 hipError_t ddn_dev_p25_filter_hist_update(const float* in, long n, size_t stride, int n_channels, float* hist,
                                           hipStream_t st);
-hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride,
+hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride,
                           int n_channels, const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store,
                           float* lbuf_store, float* shist_store, float* minring, float* maxring, uint8_t* rec,
                           uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave,

@@ -61,9 +61,55 @@ struct Lds {
 };
 } // namespace
 
+// Carrier loss (src/dsp/dsd_frame_sync.c:2753-2760,3037-3053): a hunt that saw 1800 symbols without a sync - 10200 while
+// the last sync was the inverted pattern - runs noCarrier() (src/engine/engine.c:1838-1847).  For this loop that is: the
+// crossing latch cleared, lastsynctype NONE (so the matched filter is gated off again; its memory stays as it is), max /
+// min / centre parked, and - because the timing ratio is zeroed - the next getSymbol() re-initialises the samples-per-
+// symbol accumulator and the whole slicer (src/dsp/dsd_symbol.c:1306-1341).
+__device__ __forceinline__ void
+rx_no_carrier(DdnRxState& s) {
+    s.jitter = -1;
+    s.lastsync = 0;
+    s.filter_on = 0;
+    s.max = 15000.0f;
+    s.min = -15000.0f;
+    s.center = 0.0f;
+    s.need_reset = 1;
+}
+__device__ __forceinline__ void
+rx_timing_reset(DdnRxState& s) {
+    s.need_reset = 0;
+    s.sps_accum = 0;
+    s.jitter = -1;
+    s.center = 0.0f;
+    s.min = -30000.0f;
+    s.max = 30000.0f;
+    s.lmid = -20000.0f;
+    s.umid = 20000.0f;
+    s.minref = -24000.0f;
+    s.maxref = 24000.0f;
+    s.fill_min = s.min; // the extrema rings are refilled: {value, pushes since} instead of 2048 stores
+    s.fill_max = s.max;
+    s.since_fill = 0;
+    s.midx = 0;
+    s.min_sum = (double)s.min * 1024.0;
+    s.max_sum = (double)s.max * 1024.0;
+}
+__device__ __forceinline__ void
+rx_hunt_restart(DdnRxState& s) { // frame_sync_runtime_init() of the next getFrameSync() call
+    s.hunt_pos = 0;
+    s.lidx = 0;
+    s.level_count = 0;
+    s.hist_count = 0;
+    s.hist_bits = 0;
+    s.lmin = s.min;
+    s.lmax = s.max;
+}
+
 template <int CPW>
 __global__ __launch_bounds__(128) void
-k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail, long n,
+k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
+          float* __restrict__ fstale, long n,
          size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
          float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
          float* __restrict__ maxring, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags, int32_t* __restrict__ counts,
@@ -211,9 +257,46 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
             }
             int sp = 0; // this lane's cursor in the tile
             int guard = 0;
+            // the matched filter's memory at the moment it is gated off (see rx_no_carrier): the last 90 samples it was fed
+            auto snapshot_filter = [&]() {
+                if (!s.filter_on) {
+                    return;
+                }
+                const long long tnext = abs0 + t0 + sp;
+                float* fs = fstale + (size_t)ch * (NT - 1);
+                for (int k = 0; k < NT - 1; k++) {
+                    const long long ja = tnext - (NT - 1) + k;
+                    float v;
+                    if (ja >= s.filt_start) {
+                        const long jc = (long)(ja - abs0);
+                        v = (jc >= 0) ? raw[(size_t)ch * stride + jc] : prev_tail[(size_t)ch * (NT - 1) + (NT - 1) + jc];
+                    } else {
+                        v = fs[(int)(ja - s.filt_start) + (NT - 1)];
+                    }
+                    fs[k] = v;
+                }
+            };
+            // frame_sync_advance_sync_window() + frame_sync_handle_no_sync_timeout() after a hunting symbol without a sync
+            auto hunt_advance = [&]() {
+                if (s.hunt_pos < 10200) {
+                    s.hunt_pos++;
+                } else {
+                    s.hunt_pos = 0;
+                    snapshot_filter();
+                    rx_no_carrier(s);
+                }
+                if (s.lastsync != 2 && s.hunt_pos >= 1800) {
+                    snapshot_filter();
+                    rx_no_carrier(s);
+                    rx_hunt_restart(s);
+                }
+            };
             while (true) {
                 // ---- sample loop: run every lane to the end of its current symbol (or of the tile) ---------------
                 if (live && sp < tn && !s.in_symbol) {
+                    if (s.need_reset) {
+                        rx_timing_reset(s);
+                    }
                     int sps = whole;
                     if (rem > 0) {
                         int acc = s.sps_accum + rem;
@@ -282,10 +365,12 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                                 float acc = 0.0f;
                                 for (int i = 0; i < NT; i++) {
                                     const long j = k - (NT - 1) + i;
-                                    float v = 0.0f;
+                                    float v; // before the enable sample: the filter's memory as the last hunt left it
                                     if (abs0 + j >= s.filt_start) {
                                         v = (j >= 0) ? raw[(size_t)ch * stride + j]
                                                      : prev_tail[(size_t)ch * (NT - 1) + (NT - 1) + j];
+                                    } else {
+                                        v = fstale[(size_t)ch * (NT - 1) + (size_t)((abs0 + j - s.filt_start) + (NT - 1))];
                                     }
                                     acc += __uint_as_float(c_taps[i]) * v;
                                 }
@@ -383,6 +468,7 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                         }
                         if (--s.lock_left <= 0) {
                             s.have_sync = 0;
+                            s.hunt_pos = 0;
                             s.lidx = 0;
                             s.level_count = 0;
                             s.hist_count = 0;
@@ -494,8 +580,12 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                                     s.hist_bits = 0;
                                     s.lmin = s.min;
                                     s.lmax = s.max;
+                                    s.hunt_pos = 0;
                                 }
                             }
+                        }
+                        if (!(fl & 2)) {
+                            hunt_advance();
                         }
                     }
                     if (offload) {
@@ -583,7 +673,8 @@ struct LdsW {
 
 template <int CPW>
 __global__ __launch_bounds__(192) void
-k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail, long n,
+k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
+          float* __restrict__ fstale, long n,
           size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
           float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
           float* __restrict__ maxring, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags,
@@ -789,6 +880,49 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     int o_tile = 0; // output index at the start of the current tile
     float4 qv = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); // this trip's queue entry (-1: nothing handed over)
     int itq = 0;  // queue half of the current tile
+    auto timing_reset = [&]() {
+        rx_timing_reset(s);
+        fill_min_d = (double)s.fill_min;
+        fill_max_d = (double)s.fill_max;
+        ro = (size_t)ch;
+    };
+    // the matched filter's memory at the moment it is gated off: the last 90 samples it was fed (older slots keep what
+    // an earlier memory held), kept per channel for the cold start of the next enable
+    auto snapshot_filter = [&]() {
+        if (!s.filter_on) {
+            return;
+        }
+        const long long tnext = abs0 + t0 + sp;
+        float* fs = fstale + (size_t)ch * (NT - 1);
+        for (int k = 0; k < NT - 1; k++) {
+            const long long ja = tnext - (NT - 1) + k;
+            float v;
+            if (ja >= s.filt_start) {
+                const long jc = (long)(ja - abs0);
+                v = (jc >= 0) ? raw[(size_t)ch * stride + jc] : prev_tail[(size_t)ch * (NT - 1) + (NT - 1) + jc];
+            } else {
+                v = fs[(int)(ja - s.filt_start) + (NT - 1)];
+            }
+            fs[k] = v;
+        }
+    };
+    // frame_sync_advance_sync_window() + frame_sync_handle_no_sync_timeout() after a hunting symbol without a sync
+    auto hunt_advance = [&]() {
+        if (s.hunt_pos < 10200) {
+            s.hunt_pos++;
+        } else {
+            s.hunt_pos = 0;
+            snapshot_filter();
+            rx_no_carrier(s);
+            cold_until = -2147483647;
+        }
+        if (s.lastsync != 2 && s.hunt_pos >= 1800) {
+            snapshot_filter();
+            rx_no_carrier(s);
+            cold_until = -2147483647;
+            rx_hunt_restart(s);
+        }
+    };
     // dsd_symbol_history_push()
     auto commit_pre = [&](float sym) {
         L.sh[s.shead][ln] = sym;
@@ -827,6 +961,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         q_max = s.max;
         q_min = s.min;
         if (--s.lock_left <= 0) {
+            s.hunt_pos = 0;
             // the mid thresholds are read by nobody inside a frame (wave 1 derives its own from max / min): they are
             // brought up to date when the frame ends (and at the end of the call, below)
             s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
@@ -943,8 +1078,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     s.hist_bits = 0;
                     s.lmin = s.min;
                     s.lmax = s.max;
+                    s.hunt_pos = 0;
                 }
             }
+        }
+        if (!(fl & 2)) {
+            hunt_advance();
         }
     };
     auto emit = [&](float sym, int fl, float q_max, float q_min) {
@@ -1025,6 +1164,9 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const bool ea = ready && s.have_sync && (!s.in_symbol || (s.i == 0 && s.count == 0));
                 const bool eb = ready && !s.have_sync && (!s.in_symbol || (s.i >= -1 && s.i <= 1 && s.count == 0));
                 if (eb && !s.in_symbol) { // symbol start while hunting: one-sample slip by the latched crossing index
+                    if (s.need_reset) {
+                        timing_reset();
+                    }
                     s.span = whole;
                     s.centre = (whole - 1) / 2;
                     s.i = 0;
@@ -1113,6 +1255,9 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 // ---- symbol start ----------------------------------------------------------------------------------
                 if (glive && sp < tn && !s.in_symbol) {
+                    if (s.need_reset) {
+                        timing_reset();
+                    }
                     int sps = whole;
                     if (rem > 0) {
                         int acc = s.sps_accum + rem;
@@ -1269,18 +1414,19 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             if (a - s.filt_start >= (long long)(NT - 1)) {
                                 x = rd(frow, sp);
                             } else {
-                                // first 90 samples after the enable: FIR over a zero-extended history.  Taps that
-                                // would reach before the enable sample see zeros and come first in the sum (+0 + t*0
-                                // stays +0), so the loop starts at the first tap with real history; samples of this
-                                // and the previous tile come from the LDS ring, older ones from HBM.
+                                // first 90 samples after the enable: taps that reach before the enable sample see the
+                                // filter's memory (zeros on a fresh stream, the samples of the hunt that ended in a
+                                // carrier loss otherwise); samples of this and the previous tile come from the LDS ring,
+                                // older ones from HBM.
                                 const long k = t0 + sp;
-                                const int i0 = (NT - 1) - (int)(a - s.filt_start);
                                 float acc = 0.0f;
-                                for (int i = i0 < 0 ? 0 : i0; i < NT; i++) {
+                                for (int i = 0; i < NT; i++) {
                                     const int jr = sp - (NT - 1) + i; // tile-relative
                                     const long j = k - (NT - 1) + i;  // call-relative
                                     float v;
-                                    if (jr >= (it > 0 ? -TS : 0)) { // the ring has no previous tile on a call's first
+                                    if (abs0 + j < s.filt_start) { // the filter's memory as the last hunt left it (zeros at first)
+                                        v = fstale[(size_t)ch * (NT - 1) + (size_t)((abs0 + j - s.filt_start) + (NT - 1))];
+                                    } else if (jr >= (it > 0 ? -TS : 0)) { // the ring has no previous tile on a call's first
                                         v = rd(rrow, jr);
                                     } else {
                                         v = (j >= 0) ? raw[(size_t)ch * stride + j]
@@ -1368,7 +1514,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
 
 template <int CPW>
 static hipError_t
-launch_rxw(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
+launch_rxw(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride, int n_channels,
            const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
            float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, const int32_t* lock_cfg,
            hipStream_t st) {
@@ -1379,14 +1525,14 @@ launch_rxw(const float* raw, const float* filt, const float* prev_tail, long n, 
         return e;
     }
     hipLaunchKernelGGL(k_p25_rxw<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(192), shm, st, raw, filt,
-                       prev_tail, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
+                       prev_tail, fstale, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
                        maxring, rec, flags, counts, max_sym, lock_cfg);
     return hipGetLastError();
 }
 
 template <int CPW>
 static hipError_t
-launch_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
+launch_rx(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride, int n_channels,
           const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
           float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, const int32_t* lock_cfg,
           hipStream_t st) {
@@ -1397,13 +1543,13 @@ launch_rx(const float* raw, const float* filt, const float* prev_tail, long n, s
         return e;
     }
     hipLaunchKernelGGL(k_p25_rx<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shm, st, raw, filt,
-                       prev_tail, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
+                       prev_tail, fstale, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
                        maxring, rec, flags, counts, max_sym, lock_cfg);
     return hipGetLastError();
 }
 
 extern "C" hipError_t
-ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long n, size_t stride, int n_channels,
+ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride, int n_channels,
                const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
                float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym,
                int channels_per_wave, const int32_t* lock_cfg, hipStream_t st) {
@@ -1440,37 +1586,37 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, long
     const int whole = cfg->sym_rate > 0 ? cfg->out_rate / cfg->sym_rate : 0;
     if (whole < 6) {
         if (cpw <= 16) {
-            return launch_rx<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+            return launch_rx<16>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                                  shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
         }
         if (cpw == 32) {
-            return launch_rx<32>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+            return launch_rx<32>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                                  shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
         }
-        return launch_rx<64>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+        return launch_rx<64>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
     if (cpw == 8) {
-        return launch_rxw<8>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+        return launch_rxw<8>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
     if (cpw == 16 && !(cfg->dbg & 128)) {
-        return launch_rxw<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+        return launch_rxw<16>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                               shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
     if (cpw == 32 && !(cfg->dbg & 128)) {
-        return launch_rxw<32>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+        return launch_rxw<32>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                               shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
     switch (cpw) {
         case 16:
-            return launch_rx<16>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+            return launch_rx<16>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                                  shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
         case 32:
-            return launch_rx<32>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+            return launch_rx<32>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                                  shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
         default:
-            return launch_rx<64>(raw, filt, prev_tail, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+            return launch_rx<64>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                                  shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
 }

@@ -198,6 +198,8 @@ typedef struct orc_p25rx {
     float shist[24];
     int shead, scount;
     orc_slicer sl;
+    int hunt_pos;     /* rt.synctest_pos: symbols hunted by this getFrameSync() call */
+    int need_reset;   /* noCarrier() zeroed the timing ratio: the next getSymbol() re-initialises timing and slicer */
 } orc_p25rx;
 void orc_level_estimate(const float* sorted, int count, float* lo, float* hi);
 int orc_slicer_warm_start(orc_slicer* s, const float* newest_first, int sync_len);

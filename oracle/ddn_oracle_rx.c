@@ -24,7 +24,10 @@
  *   - one protocol (P25p1), modulation locked to C4FM (opts->mod_cli_lock), so no modulation voting / SPS hunting;
  *   - after a sync the loop stays in-frame for a caller-given number of symbols (`lock_symbols`) instead of running
  *     the per-DUID handlers; the reference's handlers decide that count frame by frame;
- *   - carrier-loss handling (noCarrier() after 1800 symbols without sync) is not modelled.
+ * Carrier loss IS modelled: after 1800 symbols of one hunt without a sync (10200 when the last sync was the inverted
+ * pattern) noCarrier() runs - src/dsp/dsd_frame_sync.c:2753-2760,3037-3053, src/engine/engine.c:1838-1858 - which for this
+ * loop means: crossing latch cleared, lastsynctype NONE (matched filter off, its memory kept as it stands), timing ratio
+ * zeroed so that the next getSymbol() re-initialises the accumulator and the slicer (dsd_symbol.c:1306-1341).
  */
 #include "ddn_oracle.h"
 
@@ -111,9 +114,22 @@ orc_p25rx_init(orc_p25rx* r, int out_rate_hz, int sym_rate_hz, int lock_symbols,
     r->lmax = r->sl.max;
 }
 
+/* noCarrier() as far as this loop can see it (engine.c:1838-1847) */
+static void
+no_carrier(orc_p25rx* r) {
+    r->jitter = -1;
+    r->lastsync = 0;
+    r->filter_on = 0; /* the filter is gated by lastsynctype (dsd_symbol.c:301-338); its memory is not touched */
+    r->sl.max = 15000.0f;
+    r->sl.min = -15000.0f;
+    r->sl.center = 0.0f;
+    r->need_reset = 1; /* rtl_fsk_sps_num / _den = 0 */
+}
+
 static void
 hunt_enter(orc_p25rx* r) {
     /* a fresh getFrameSync() call: frame_sync_runtime_init() */
+    r->hunt_pos = 0;
     r->have_sync = 0;
     r->lidx = 0;
     r->level_count = 0;
@@ -140,6 +156,25 @@ matched_filter(orc_p25rx* r, float x) {
 
 static void
 symbol_begin(orc_p25rx* r) {
+    if (r->need_reset) { /* symbol_reset_rtl_fsk_timing_if_needed() + symbol_reset_rtl_fsk_discriminator_slicer() */
+        orc_slicer* s = &r->sl;
+        r->need_reset = 0;
+        r->sps_accum = 0;
+        r->jitter = -1;
+        s->center = 0.0f;
+        s->min = -30000.0f;
+        s->max = 30000.0f;
+        s->lmid = -20000.0f;
+        s->umid = 20000.0f;
+        s->minref = -24000.0f;
+        s->maxref = 24000.0f;
+        for (int i = 0; i < ORC_SLICER_MSIZE; i++) {
+            s->minbuf[i] = s->min;
+            s->maxbuf[i] = s->max;
+        }
+        s->midx = 0;
+        s->sums_valid = 0;
+    }
     int whole = r->out_rate / r->sym_rate, rem = r->out_rate % r->sym_rate;
     if (whole < 2) {
         whole = 2;
@@ -306,8 +341,20 @@ symbol_commit(orc_p25rx* r, float sym, int rec4[4]) {
                 if (r->lock_left <= 0) {
                     hunt_enter(r);
                 }
+                return flags;
             }
         }
+    }
+    /* frame_sync_advance_sync_window() then frame_sync_handle_no_sync_timeout() */
+    if (r->hunt_pos < 10200) {
+        r->hunt_pos++;
+    } else {
+        r->hunt_pos = 0;
+        no_carrier(r);
+    }
+    if (r->lastsync != 2 && r->hunt_pos >= 1800) {
+        no_carrier(r);
+        hunt_enter(r); /* getFrameSync() returns -1, the engine calls it again */
     }
     return flags;
 }
