@@ -335,7 +335,11 @@ def main():
             "kernels_ms": {"k_p25_matched_filter": round(float(rx_ms[0]), 4), "k_p25_rxw": round(float(rx_ms[1]), 4),
                            "k_mbe_params": round(float(mbe_ms[0]), 4), "k_mbe_synth": round(float(mbe_ms[1]), 4)},
             "roofline": {"bound": "hbm", "kernel": "k_p25_rxw", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         # HBM bytes per launch of k_p25_rxw from separate rocprofv3 --pmc passes of this command on this shape
+                         # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B;
+                         # profiles/r02_pmc_*.txt): the discriminator stream is read twice (raw + matched-filter output)
+                         "traffic": 2.018e9 if (B == B_PER_GPU and n == N_SAMPLES) else None,
                          "algorithmic_bytes": alg_bytes, "bytes_per_sample": round(alg_bytes / (B * n), 3),
                          "launch_ms": round(dom_ms, 4),
                          "chain_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
