@@ -28,6 +28,11 @@ class FrontEndConfig(C.Structure):
     ]
 
 
+class Cu8Moments(C.Structure):  # == dsd_input_level_cu8_moments (include/ddn_hip.h)
+    _fields_ = [("count", C.c_uint64), ("sum", C.c_uint64), ("sum_sq", C.c_uint64), ("clipped", C.c_uint64),
+                ("min_sample", C.c_uint8), ("max_sample", C.c_uint8)]
+
+
 class FskModemState(C.Structure):
     _fields_ = [
         ("cfg_sample_rate_hz", C.c_int),
@@ -60,6 +65,9 @@ PROTOTYPES = {
     "simd_hb_decim2_real": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "simd_fir_get_impl_name": (C.c_char_p, []),
     "widen_u8_to_f32_bias127": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "widen_u8_to_f32_bias127_moments": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "widen_rotate90_u8_to_f32_bias127_phase": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "widen_rotate90_u8_to_f32_bias127_phase_moments": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ddn_fec_p25_12_soft_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_fec_p25_12_soft_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_r34_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

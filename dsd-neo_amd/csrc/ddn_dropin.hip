@@ -76,6 +76,75 @@ k_widen_u8(const unsigned char* __restrict__ src, float* __restrict__ dst, uint3
     }
 }
 
+// rotate-by-j^n + widen (+ raw byte moments): reference src/dsp/simd_widen.cpp:167-199 (scalar), :24-43 (rotation table).
+// One thread per I/Q pair (rot) or per byte (plain).  The moments are integer sums, so any reduction order is exact:
+// wave-level shuffles, then one 64-bit atomic per wave.  mom = {sum, sum_sq, clipped, min, max} as five u64 words.
+__device__ inline void
+moments_reduce(unsigned long long sum, unsigned long long sq, unsigned int clip, unsigned int mn, unsigned int mx,
+               unsigned long long* mom) {
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o);
+        sq += __shfl_xor(sq, o);
+        clip += __shfl_xor(clip, o);
+        mn = min(mn, (unsigned int)__shfl_xor(mn, o));
+        mx = max(mx, (unsigned int)__shfl_xor(mx, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&mom[0], sum);
+        atomicAdd(&mom[1], sq);
+        atomicAdd(&mom[2], (unsigned long long)clip);
+        atomicMin(&mom[3], (unsigned long long)mn);
+        atomicMax(&mom[4], (unsigned long long)mx);
+    }
+}
+
+__global__ void
+k_widen_u8_moments(const unsigned char* __restrict__ src, float* __restrict__ dst, uint32_t len,
+                   unsigned long long* mom) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int b = 0, mn = 255, mx = 0, clip = 0;
+    unsigned long long sum = 0, sq = 0;
+    if (i < len) {
+        b = src[i];
+        dst[i] = ((float)b - 127.5f) * (1.0f / 127.5f);
+        sum = b;
+        sq = (unsigned long long)b * b;
+        clip = (b <= 1u || b >= 254u) ? 1u : 0u;
+        mn = mx = b;
+    }
+    moments_reduce(sum, sq, clip, mn, mx, mom);
+}
+
+__global__ void
+k_widen_rot_u8(const unsigned char* __restrict__ src, float* __restrict__ dst, uint32_t pairs, uint32_t phase,
+               unsigned long long* mom) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int mn = 255, mx = 0, clip = 0;
+    unsigned long long sum = 0, sq = 0;
+    if (n < pairs) {
+        const unsigned int bi = src[2 * n], bq = src[2 * n + 1];
+        const float i_raw = ((float)bi - 127.5f) * (1.0f / 127.5f);
+        const float q_raw = ((float)bq - 127.5f) * (1.0f / 127.5f);
+        float oi, oq;
+        switch ((phase + n) & 3u) {
+            case 0: oi = i_raw; oq = q_raw; break;
+            case 1: oi = -q_raw; oq = i_raw; break;
+            case 2: oi = -i_raw; oq = -q_raw; break;
+            default: oi = q_raw; oq = -i_raw; break;
+        }
+        dst[2 * n] = oi;
+        dst[2 * n + 1] = oq;
+        sum = bi + bq;
+        sq = (unsigned long long)bi * bi + (unsigned long long)bq * bq;
+        clip = ((bi <= 1u || bi >= 254u) ? 1u : 0u) + ((bq <= 1u || bq >= 254u) ? 1u : 0u);
+        mn = min(bi, bq);
+        mx = max(bi, bq);
+    }
+    if (mom) {
+        moments_reduce(sum, sq, clip, mn, mx, mom);
+    }
+}
+
 __global__ void
 k_fsk_single(ddn_fsk_modem_state* st, const f2* __restrict__ iq, int pairs, float* __restrict__ out, int max_out,
              int* out_count) {
@@ -287,6 +356,111 @@ widen_u8_to_f32_bias127(const unsigned char* src, float* dst, uint32_t len) {
     hipLaunchKernelGGL(k_widen_u8, dim3((len + 255) / 256), dim3(256), 0, 0, (const unsigned char*)ds.p, (float*)dd.p,
                        len);
     (void)hipMemcpy(dst, dd.p, (size_t)len * sizeof(float), hipMemcpyDeviceToHost);
+}
+
+// dsd_input_level_cu8_moments_merge (reference src/runtime/input_level.c:231-272): validity of both sides, overflow guards,
+// "empty accumulator takes the addend".
+static int
+moments_valid(const dsd_input_level_cu8_moments* m) {
+    if (!m || m->count == 0U || m->clipped > m->count || m->min_sample > m->max_sample) {
+        return 0;
+    }
+    if ((m->count <= UINT64_MAX / 255U && m->sum > m->count * 255U)
+        || (m->count <= UINT64_MAX / 65025U && m->sum_sq > m->count * 65025U)) {
+        return 0;
+    }
+    return 1;
+}
+
+static void
+moments_merge(dsd_input_level_cu8_moments* m, const dsd_input_level_cu8_moments* add) {
+    if (!m || !moments_valid(add)) {
+        return;
+    }
+    dsd_input_level_cu8_moments next = *m;
+    if (next.count == 0U) {
+        next = *add;
+    } else {
+        if (!moments_valid(&next) || UINT64_MAX - next.count < add->count || UINT64_MAX - next.sum < add->sum
+            || UINT64_MAX - next.sum_sq < add->sum_sq || UINT64_MAX - next.clipped < add->clipped) {
+            return;
+        }
+        next.count += add->count;
+        next.sum += add->sum;
+        next.sum_sq += add->sum_sq;
+        next.clipped += add->clipped;
+        next.min_sample = add->min_sample < next.min_sample ? add->min_sample : next.min_sample;
+        next.max_sample = add->max_sample > next.max_sample ? add->max_sample : next.max_sample;
+    }
+    *m = next;
+}
+
+// shared body of the three moment / rotate variants.  rot: pairs are rotated by j^(phase+n); count = bytes consumed.
+static int
+widen_variant(const unsigned char* src, float* dst, uint32_t len, int rot, uint32_t phase,
+              dsd_input_level_cu8_moments* moments) {
+    const uint32_t used = rot ? (len & ~1u) : len;
+    DevBuf ds(used), dd((size_t)used * sizeof(float)), dm(5 * sizeof(unsigned long long));
+    if (!ds.p || !dd.p || !dm.p) {
+        ddn_set_error("drop-in widen: hipMalloc failed (no device?)");
+        return -1;
+    }
+    const unsigned long long init[5] = {0, 0, 0, 255, 0};
+    (void)hipMemcpy(ds.p, src, used, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dm.p, init, sizeof(init), hipMemcpyHostToDevice);
+    if (rot) {
+        const uint32_t pairs = used >> 1;
+        hipLaunchKernelGGL(k_widen_rot_u8, dim3((pairs + 255) / 256), dim3(256), 0, 0, (const unsigned char*)ds.p,
+                           (float*)dd.p, pairs, phase, moments ? (unsigned long long*)dm.p : nullptr);
+    } else {
+        hipLaunchKernelGGL(k_widen_u8_moments, dim3((used + 255) / 256), dim3(256), 0, 0, (const unsigned char*)ds.p,
+                           (float*)dd.p, used, (unsigned long long*)dm.p);
+    }
+    unsigned long long got[5];
+    if (hipGetLastError() != hipSuccess
+        || hipMemcpy(dst, dd.p, (size_t)used * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess
+        || hipMemcpy(got, dm.p, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) {
+        ddn_set_error("drop-in widen: kernel/D2H failed");
+        return -1;
+    }
+    if (moments) {
+        dsd_input_level_cu8_moments local;
+        local.count = used;
+        local.sum = got[0];
+        local.sum_sq = got[1];
+        local.clipped = got[2];
+        local.min_sample = (uint8_t)got[3];
+        local.max_sample = (uint8_t)got[4];
+        moments_merge(moments, &local);
+    }
+    return 0;
+}
+
+extern "C" void
+widen_u8_to_f32_bias127_moments(const unsigned char* src, float* dst, uint32_t len,
+                                dsd_input_level_cu8_moments* moments) {
+    if (!src || !dst || !moments || len == 0U) {
+        return;
+    }
+    (void)widen_variant(src, dst, len, 0, 0, moments);
+}
+
+extern "C" uint32_t
+widen_rotate90_u8_to_f32_bias127_phase_moments(const unsigned char* src, float* dst, uint32_t len, uint32_t phase,
+                                               dsd_input_level_cu8_moments* moments) {
+    const uint32_t cur = phase & 3U;
+    if (!src || !dst || len < 2U) {
+        return cur;
+    }
+    if (widen_variant(src, dst, len, 1, cur, moments) != 0) {
+        return cur;
+    }
+    return (cur + (len >> 1)) & 3U;
+}
+
+extern "C" uint32_t
+widen_rotate90_u8_to_f32_bias127_phase(const unsigned char* src, float* dst, uint32_t len, uint32_t phase) {
+    return widen_rotate90_u8_to_f32_bias127_phase_moments(src, dst, len, phase, nullptr);
 }
 
 extern "C" int

@@ -954,8 +954,37 @@ ddn_iq_capture_rewind(ddn_iq_capture* c) {
     return DDN_IQ_OK;
 }
 
+/* Capture-side FS/4 shift of a CU8 row: pair n times j^n from the start of the capture, in the byte domain (negation is
+ * 255 - b, exact under the -127.5 bias) - what the reference's replay does before the widen, or fused into it
+ * (src/io/radio/rtl_device.cpp:479-500 policy, :518-560 two-pass rotation; src/dsp/simd_widen.cpp:167-199 combined).  The
+ * two give identical floats, so one byte pass covers both settings of combine_rotate_enabled. */
+static void
+fs4_rotate_cu8(unsigned char* row, size_t pairs) {
+    for (size_t n = 0; n < pairs; n++) {
+        const unsigned char i = row[2 * n], q = row[2 * n + 1];
+        switch (n & 3u) {
+            case 0: break;
+            case 1:
+                row[2 * n] = (unsigned char)(255u - q);
+                row[2 * n + 1] = i;
+                break;
+            case 2:
+                row[2 * n] = (unsigned char)(255u - i);
+                row[2 * n + 1] = (unsigned char)(255u - q);
+                break;
+            default:
+                row[2 * n] = q;
+                row[2 * n + 1] = (unsigned char)(255u - i);
+                break;
+        }
+    }
+}
+
 /* B captures with one sample format and one rate chain -> one channel-major buffer [B][n] (n = the shortest capture's
- * complex sample count), the shape ddn_front_end_run_host / ddn_cqpsk_run_host take.  *out_buf is malloc'ed. */
+ * complex sample count), the shape ddn_front_end_run_host / ddn_cqpsk_run_host take.  *out_buf is malloc'ed.
+ * The metadata's capture-side transforms are honoured, not dropped: fs4_shift_enabled on a CU8 capture rotates each row
+ * here (the batch kernels then see what the reference's demod thread sees); base_decimation is the caller's to configure
+ * on the front end (returned in out_info0); a post_downsample other than 1 has no stage in this library and is refused. */
 int
 ddn_iq_load_batch(const char* const* paths, int n_captures, void** out_buf, size_t* out_n_samples,
                   ddn_iq_capture_info* out_info0) {
@@ -977,8 +1006,14 @@ ddn_iq_load_batch(const char* const* paths, int n_captures, void** out_buf, size
         }
         const ddn_iq_capture_info* a = &caps[i]->info;
         const ddn_iq_capture_info* b = &caps[0]->info;
+        if (a->post_downsample != 1) {
+            ddn_set_error("capture %d ('%s'): post_downsample = %u has no stage in the batch front end (only 1 is supported)", i,
+                          paths[i], a->post_downsample);
+            rc = DDN_IQ_ERR_RATE_CHAIN;
+            break;
+        }
         if (a->sample_format != b->sample_format || a->sample_rate_hz != b->sample_rate_hz
-            || a->base_decimation != b->base_decimation || a->post_downsample != b->post_downsample) {
+            || a->base_decimation != b->base_decimation || a->fs4_shift_enabled != b->fs4_shift_enabled) {
             ddn_set_error("capture %d ('%s') has a different sample format or rate chain than capture 0", i, paths[i]);
             rc = DDN_IQ_ERR_RATE_CHAIN;
             break;
@@ -998,6 +1033,9 @@ ddn_iq_load_batch(const char* const* paths, int n_captures, void** out_buf, size
             rc = ddn_iq_capture_read(caps[i], buf + (size_t)i * row, row, &got);
             if (rc == DDN_IQ_OK && got != row) {
                 rc = DDN_IQ_ERR_IO;
+            }
+            if (rc == DDN_IQ_OK && caps[i]->info.sample_format == DDN_IQ_FORMAT_CU8 && caps[i]->info.fs4_shift_enabled) {
+                fs4_rotate_cu8((unsigned char*)buf + (size_t)i * row, (size_t)n_min);
             }
         }
         if (rc == DDN_IQ_OK) {

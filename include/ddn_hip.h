@@ -607,6 +607,19 @@ int simd_hb_decim2_complex(const float* in, int in_len, float* out, float* hist_
 int simd_hb_decim2_real(const float* in, int in_len, float* out, float* hist, const float* taps, int taps_len);
 const char* simd_fir_get_impl_name(void);
 void widen_u8_to_f32_bias127(const unsigned char* src, float* dst, uint32_t len);
+/* == include/dsd-neo/core/input_level.h:61-68 (raw CU8 byte moments; every I and Q byte is one sample) */
+typedef struct dsd_input_level_cu8_moments {
+    uint64_t count, sum, sum_sq, clipped;
+    uint8_t min_sample, max_sample;
+} dsd_input_level_cu8_moments;
+/* == include/dsd-neo/dsp/simd_widen.h:61-62, 72, 89-90 (src/dsp/simd_widen.cpp:151-204): widen + merge the block's raw
+ * moments into *moments by dsd_input_level_cu8_moments_merge's rules; the rotate variants multiply pair n by j^(phase+n)
+ * and return the phase after the block (an odd trailing byte is not consumed). */
+void widen_u8_to_f32_bias127_moments(const unsigned char* src, float* dst, uint32_t len,
+                                     dsd_input_level_cu8_moments* moments);
+uint32_t widen_rotate90_u8_to_f32_bias127_phase(const unsigned char* src, float* dst, uint32_t len, uint32_t phase);
+uint32_t widen_rotate90_u8_to_f32_bias127_phase_moments(const unsigned char* src, float* dst, uint32_t len,
+                                                        uint32_t phase, dsd_input_level_cu8_moments* moments);
 
 /* ---- block codes downstream of the receive loop: DMR / NXDN ------------------------------------------
  * == include/dsd-neo/fec/block_codes.h:19-43 (src/fec/fec.c:133-838), bptc.h:20-26 (src/fec/bptc.c), rs_12_9.h:38-42

@@ -169,7 +169,11 @@ def test_dropin_symbols_match_oracle(built):
     # half-band /2, 31 and 15 taps
     hb31 = np.ctypeslib.as_array((C.c_float * 31).in_dll(o, "orc_hb31_taps")).copy()
     hb15 = np.ctypeslib.as_array((C.c_float * 15).in_dll(o, "orc_hb15_taps")).copy()
-    for hb in (hb31, hb15):
+    # 23 taps: the third length include/dsd-neo/dsp/simd_fir.h:54,68 names (no prototype ships; a Hamming-windowed one here)
+    k = np.arange(23) - 11
+    hb23 = np.where(k == 0, 0.5, np.where(k % 2 != 0, np.sin(np.pi * k / 2) / (np.pi * np.where(k == 0, 1, k)), 0.0))
+    hb23 = (hb23 * np.hamming(23)).astype(np.float32)
+    for hb in (hb31, hb15, hb23):
         n = 3001
         x = rng.standard_normal(2 * n).astype(np.float32)
         hi = rng.standard_normal(len(hb) - 1).astype(np.float32)
@@ -191,6 +195,50 @@ def test_dropin_symbols_match_oracle(built):
     l.widen_u8_to_f32_bias127(u.ctypes.data, w1.ctypes.data, 5001)
     o.orc_widen_u8(u.ctypes.data, w2.ctypes.data, 5001)
     check(w1, w2, exact=True)
+    # widen + raw byte moments, rotate-by-j^n variants (block sizes that split waves; phases 0..3; an odd trailing byte)
+    def np_moments(b):
+        b = b.astype(np.uint64)
+        return (int(b.size), int(b.sum()), int((b * b).sum()), int(((b <= 1) | (b >= 254)).sum()), int(b.min()), int(b.max()))
+
+    def rot(u8, phase):
+        z = ((u8[:u8.size & ~1].astype(np.float32) - np.float32(127.5)) * np.float32(1.0 / 127.5)).reshape(-1, 2)
+        ph = (phase + np.arange(len(z))) & 3
+        out = np.empty_like(z)
+        out[:, 0] = np.select([ph == 0, ph == 1, ph == 2], [z[:, 0], -z[:, 1], -z[:, 0]], z[:, 1])
+        out[:, 1] = np.select([ph == 0, ph == 1, ph == 2], [z[:, 1], z[:, 0], -z[:, 1]], -z[:, 0])
+        return out.reshape(-1)
+
+    for ln, phase in [(5001, 0), (130, 1), (4096, 2), (2, 3), (777, 7)]:
+        u = rng.integers(0, 256, ln, dtype=np.uint8)
+        u[:3] = (0, 255, 254)
+        m = ddn.Cu8Moments(0, 0, 0, 0, 255, 0)
+        w = np.zeros(ln, np.float32)
+        l.widen_u8_to_f32_bias127_moments(u.ctypes.data, w.ctypes.data, ln, C.byref(m))
+        o.orc_widen_u8(u.ctypes.data, w2.ctypes.data, ln)
+        check(w, w2[:ln], exact=True)
+        assert (m.count, m.sum, m.sum_sq, m.clipped, m.min_sample, m.max_sample) == np_moments(u)
+        l.widen_u8_to_f32_bias127_moments(u.ctypes.data, w.ctypes.data, ln, C.byref(m))         # second block merges
+        assert (m.count, m.sum, m.clipped) == (2 * ln, 2 * int(u.astype(np.uint64).sum()), 2 * np_moments(u)[3])
+        m = ddn.Cu8Moments(0, 0, 0, 0, 255, 0)
+        w[:] = 7.0
+        nxt = l.widen_rotate90_u8_to_f32_bias127_phase_moments(u.ctypes.data, w.ctypes.data, ln, phase, C.byref(m))
+        assert nxt == ((phase & 3) + ln // 2) & 3
+        even = ln & ~1
+        check(w[:even], rot(u, phase & 3), exact=True)
+        assert np.all(w[even:] == 7.0)
+        assert (m.count, m.sum, m.sum_sq, m.clipped, m.min_sample, m.max_sample) == np_moments(u[:even])
+        w[:] = 0
+        assert l.widen_rotate90_u8_to_f32_bias127_phase(u.ctypes.data, w.ctypes.data, ln, phase) == nxt
+        check(w[:even], rot(u, phase & 3), exact=True)
+        if orc.have_ref():
+            r = orc.ref()
+            r.widen_rotate90_u8_to_f32_bias127_phase_moments.restype = C.c_uint32
+            r.widen_rotate90_u8_to_f32_bias127_phase_moments.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+            mr = ddn.Cu8Moments(0, 0, 0, 0, 255, 0)
+            wr = np.zeros(ln, np.float32)
+            assert r.widen_rotate90_u8_to_f32_bias127_phase_moments(u.ctypes.data, wr.ctypes.data, ln, phase, C.byref(mr)) == nxt
+            check(w[:even], wr[:even], exact=True)
+            assert bytes(m)[:34] == bytes(mr)[:34]
     # discriminator with carried state
     n = 3000
     ph = np.cumsum(rng.normal(0.0, 0.15, n))

@@ -310,11 +310,13 @@ def test_sidecar_differential_fuzz_vs_reference(built, tmp_path):
     assert both_ok >= 40
 
 
-def _write_golden_capture(tmp, name, npz, rate=48000):
+def _write_golden_capture(tmp, name, npz, rate=48000, **over):
     g = golden(npz)
     iq = np.ascontiguousarray(g["iq"], np.uint8)
     iq.tofile(os.path.join(tmp, name))
-    meta = dict(BASE, sample_rate_hz=rate, base_decimation=1, demod_rate_hz=rate, data_file=name, data_bytes=int(iq.size))
+    meta = dict(BASE, sample_rate_hz=rate, base_decimation=1, demod_rate_hz=rate, data_file=name, data_bytes=int(iq.size),
+                fs4_shift_enabled=False)
+    meta.update(over)
     with open(os.path.join(tmp, name + ".json"), "w") as f:
         json.dump(meta, f)
     return os.path.join(tmp, name), iq
@@ -335,6 +337,45 @@ def test_load_batch_shapes_and_mismatch(built, tmp_path):
     p3, _ = _write_golden_capture(tmp, "other.iq", "iq_p25p1_c4fm_cc.npz", rate=24000)
     paths = (C.c_char_p * 2)(p1.encode(), p3.encode())
     assert l.ddn_iq_load_batch(paths, 2, C.byref(buf), C.byref(n), None) == -6       # DSD_IQ_ERR_RATE_CHAIN
+
+
+def test_load_batch_applies_fs4_shift_and_refuses_post_downsample(built, tmp_path):
+    """fs4_shift_enabled CU8 captures come out of ddn_iq_load_batch rotated by j^n from the start of the capture: widened,
+    they equal the reference's widen_rotate90_u8_to_f32_bias127_phase(phase=0) of the raw bytes bit for bit (numpy
+    restatement always; the compiled reference when oracle/_ref is built).  post_downsample != 1 is refused, and a batch
+    mixing rotated and unrotated captures is a rate-chain mismatch."""
+    tmp = str(tmp_path)
+    p1, a = _write_golden_capture(tmp, "rot.iq", "iq_p25p1_c4fm_cc.npz", fs4_shift_enabled=True)
+    l = ddn.lib()
+    paths = (C.c_char_p * 1)(p1.encode())
+    buf, n, info = C.c_void_p(), C.c_size_t(), Info()
+    assert l.ddn_iq_load_batch(paths, 1, C.byref(buf), C.byref(n), C.byref(info)) == 0
+    assert info.fs4_shift_enabled == 1
+    rows = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), (n.value, 2)).copy()
+    l.ddn_iq_free(buf)
+    raw = a[:n.value].reshape(-1, 2)
+    wide = ((rows.astype(np.float32) - np.float32(127.5)) * np.float32(1.0 / 127.5)).astype(np.float32)
+    z = ((raw.astype(np.float32) - np.float32(127.5)) * np.float32(1.0 / 127.5)).astype(np.float32)
+    ph = np.arange(n.value) & 3
+    want = np.empty_like(z)
+    want[:, 0] = np.select([ph == 0, ph == 1, ph == 2], [z[:, 0], -z[:, 1], -z[:, 0]], z[:, 1])
+    want[:, 1] = np.select([ph == 0, ph == 1, ph == 2], [z[:, 1], z[:, 0], -z[:, 1]], -z[:, 0])
+    assert np.array_equal(wide.view(np.uint32), want.view(np.uint32))
+    if orc.have_ref():
+        r = orc.ref()
+        r.widen_rotate90_u8_to_f32_bias127_phase.restype = C.c_uint32
+        r.widen_rotate90_u8_to_f32_bias127_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        src = np.ascontiguousarray(raw)
+        out = np.zeros(raw.shape, np.float32)
+        assert r.widen_rotate90_u8_to_f32_bias127_phase(src.ctypes.data, out.ctypes.data, src.size, 0) == (n.value & 3)
+        assert np.array_equal(out.view(np.uint32), wide.view(np.uint32))
+    p2, _ = _write_golden_capture(tmp, "plain.iq", "iq_p25p1_c4fm_cc.npz")
+    paths = (C.c_char_p * 2)(p1.encode(), p2.encode())
+    assert l.ddn_iq_load_batch(paths, 2, C.byref(buf), C.byref(n), None) == -6
+    p3, _ = _write_golden_capture(tmp, "pd.iq", "iq_p25p1_c4fm_cc.npz", rate=96000, post_downsample=2, demod_rate_hz=48000)
+    paths = (C.c_char_p * 1)(p3.encode())
+    assert l.ddn_iq_load_batch(paths, 1, C.byref(buf), C.byref(n), None) == -6
+    assert b"post_downsample" in l.ddn_last_error()
 
 
 @pytest.mark.gpu
