@@ -210,7 +210,7 @@ def test_dropin_symbols_match_oracle(built):
 
     for ln, phase in [(5001, 0), (130, 1), (4096, 2), (2, 3), (777, 7)]:
         u = rng.integers(0, 256, ln, dtype=np.uint8)
-        u[:3] = (0, 255, 254)
+        u[:2] = (0, 255)
         m = ddn.Cu8Moments(0, 0, 0, 0, 255, 0)
         w = np.zeros(ln, np.float32)
         l.widen_u8_to_f32_bias127_moments(u.ctypes.data, w.ctypes.data, ln, C.byref(m))
