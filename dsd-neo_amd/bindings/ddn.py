@@ -293,6 +293,7 @@ PROTOTYPES.update({
     "ddn_mbe_batch_destroy": (None, [C.c_void_p]),
     "ddn_mbe_batch_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_mbe_batch_set_tables": (C.c_int, [C.c_void_p, C.POINTER(MbeTables)]),
+    "ddn_mbe_dropin_set_tables": (C.c_int, [C.c_void_p]),
     "ddn_mbe_batch_set_p25p1_tail_rule": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_mbe_synth_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_mbe_batch_get_state": (C.c_int, [C.c_void_p, C.c_int, _PP, _PP, _PP]),

@@ -389,6 +389,37 @@ decode_one(int codec, const uint8_t* bits_in, const uint8_t* soft_in, size_t nby
     return MBE_STATUS_OK;
 }
 
+} // namespace
+
+// The single-stream mbe_* entry points run on two cached one-path batches (one per codec); this loads the integrator's
+// table blob into both (creating them if needed).  Until it is called they use the built-in synthetic blob.
+extern "C" int
+ddn_mbe_dropin_set_tables(const ddn_mbe_tables* t) {
+    if (!t) {
+        return DDN_EINVAL;
+    }
+    Scratch& s = scratch();
+    std::lock_guard<std::mutex> lock(s.mu);
+    const int rc0 = scratch_ready(s);
+    if (rc0 != DDN_OK) {
+        return rc0;
+    }
+    for (int codec = 0; codec < 2; codec++) {
+        if (!s.batch[codec]) {
+            const int rc = ddn_mbe_batch_create(codec, 1, &s.batch[codec]);
+            if (rc != DDN_OK) {
+                return rc;
+            }
+        }
+        const int rc = ddn_mbe_batch_set_tables(s.batch[codec], t);
+        if (rc != DDN_OK) {
+            return rc;
+        }
+    }
+    return DDN_OK;
+}
+
+namespace {
 int
 process_one(int codec, float* aout_buf, mbe_process_result* result, const char* bits, size_t nbits, mbe_parms* cur,
             mbe_parms* prev, mbe_parms* enh) {

@@ -148,6 +148,8 @@ int ddn_mbe_batch_create(int codec, int n_streams, ddn_mbe_batch** out);
 void ddn_mbe_batch_destroy(ddn_mbe_batch* b);
 int ddn_mbe_batch_reset(ddn_mbe_batch* b, void* hip_stream);
 int ddn_mbe_batch_set_tables(ddn_mbe_batch* b, const ddn_mbe_tables* t);
+/* the same for the single-stream mbe_* entry points below (they run on two cached one-path batches, one per codec) */
+int ddn_mbe_dropin_set_tables(const ddn_mbe_tables* t);
 /* P25 Phase 1 teardown rule of mbe_process_p25p1 (dsd_mbe.c:447-463,540-566): a clear-mode frame that decodes to
  * FC.. with <= 24 set bits and >= 10 corrections is muted without touching the history.  Off by default. */
 int ddn_mbe_batch_set_p25p1_tail_rule(ddn_mbe_batch* b, int enable);

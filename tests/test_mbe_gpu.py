@@ -195,3 +195,38 @@ def test_dropin_process_matches_batch_and_tail_rule(built):
     sil = np.ones(160, np.float32)
     l.mbe_synthesizeSilencef(sil.ctypes.data)
     assert np.all(sil == 0)
+
+
+def test_dropin_table_blob_is_loadable(built):
+    """ddn_mbe_dropin_set_tables: an integrator's blob (here the default with the IMBE gain levels halved and an AMBE gain
+    delta changed) reaches the single-stream mbe_* entry points - PCM equals the CPU restatement run on the same blob and
+    differs from the default blob's; a blob that fails validation is refused and leaves the loaded one in place."""
+    l = ddn.lib()
+    rng = np.random.default_rng(17)
+    t = mbe.tables()
+    for i in range(64):
+        t.imbe_gain_b2[i] *= 0.5
+    for i in range(32):
+        t.ambe_dg[i] += 0.25
+    t.synthetic = 0
+    try:
+        assert l.ddn_mbe_dropin_set_tables(C.byref(t)) == 0
+        bad = mbe.tables()
+        bad.magic = 0
+        assert l.ddn_mbe_dropin_set_tables(C.byref(bad)) != 0
+        for codec, fn, gen in ((ddn.MBE_IMBE, l.mbe_processImbe4400Dataf, mbe.random_imbe_bits),
+                               (ddn.MBE_AMBE, l.mbe_processAmbe2450Dataf, mbe.random_ambe_bits)):
+            bits = gen(rng, (1, 4))
+            want, _, _ = mbe.OracleVocoder(codec, 1, tab=t).run(bits)
+            dflt, _, _ = mbe.OracleVocoder(codec, 1).run(bits)
+            assert not np.array_equal(want, dflt)
+            c, p, e = ddn.MbeParms(), ddn.MbeParms(), ddn.MbeParms()
+            l.mbe_initMbeParms(C.byref(c), C.byref(p), C.byref(e))
+            for f in range(4):
+                out = np.zeros(160, np.float32)
+                r = ddn.MbeProcessResult()
+                assert fn(out.ctypes.data, C.byref(r), np.ascontiguousarray(bits[0, f]).ctypes.data, C.byref(c), C.byref(p), C.byref(e)) == 0
+                assert np.array_equal(out.view(np.uint32), want[0, f].view(np.uint32)), (codec, f)
+    finally:
+        d = mbe.tables()
+        assert l.ddn_mbe_dropin_set_tables(C.byref(d)) == 0
