@@ -318,6 +318,75 @@ PROTOTYPES.update({
 _lib = None
 
 
+class Fsk4RxConfig(C.Structure):  # == ddn_fsk4_rx_config (include/ddn_fsk4.h)
+    _fields_ = [("n_channels", C.c_int), ("out_rate_hz", C.c_int), ("protocol", C.c_int), ("rf_mod", C.c_int),
+                ("inverted", C.c_int), ("use_matched_filter", C.c_int), ("lock_symbols", C.c_int * 4)]
+
+
+FSK4_DMR, FSK4_NXDN48, FSK4_PRE = 1, 2, 90
+PROTOTYPES.update({
+    "ddn_fsk4_rx_create": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_fsk4_rx_destroy": (None, [C.c_void_p]),
+    "ddn_fsk4_rx_reset": (C.c_int, [C.c_void_p]),
+    "ddn_fsk4_rx_max_symbols": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "ddn_fsk4_rx_max_syncs": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "ddn_fsk4_rx_set_lock_symbols": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_fsk4_rx_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 4 + [C.c_size_t] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
+    "ddn_fsk4_rx_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 4 + [C.c_size_t] + [C.c_void_p] * 5 + [C.c_size_t]),
+    "ddn_fsk4_rx_get_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ddn_fsk4_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_fsk4_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_dmr_burst_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int]
+                             + [C.c_void_p] * 5),
+})
+
+
+class Fsk4Rx:
+    """ddn_fsk4_rx batch object (host-buffer convenience wrapper used by the tests)"""
+
+    def __init__(self, n_channels, protocol, rf_mod=0, inverted=0, use_matched_filter=1, lock=None, out_rate=48000):
+        import numpy as np
+        self.np = np
+        cfg = Fsk4RxConfig(n_channels, out_rate, protocol, rf_mod, inverted, use_matched_filter)
+        for k in range(4):
+            cfg.lock_symbols[k] = (lock or [0, 0, 0, 0])[k]
+        self.h = C.c_void_p()
+        _check(lib().ddn_fsk4_rx_create(C.byref(cfg), C.byref(self.h)), "ddn_fsk4_rx_create")
+        self.B = n_channels
+
+    def close(self):
+        if self.h:
+            lib().ddn_fsk4_rx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_host(self, disc):
+        np = self.np
+        disc = np.ascontiguousarray(disc, np.float32)
+        B, n = disc.shape
+        assert B == self.B
+        l = lib()
+        ms, my = l.ddn_fsk4_rx_max_symbols(self.h, n), l.ddn_fsk4_rx_max_syncs(self.h, n)
+        rec, fl, pay = np.zeros((B, ms, 10), np.uint8), np.zeros((B, ms), np.uint8), np.zeros((B, ms, 2), np.uint8)
+        cnt, ns = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        spos, spat = np.zeros((B, my), np.int32), np.zeros((B, my), np.uint8)
+        pre, prel = np.zeros((B, my, FSK4_PRE), np.uint8), np.zeros((B, my, FSK4_PRE), np.uint8)
+        _check(l.ddn_fsk4_rx_run_host(self.h, disc.ctypes.data, n, rec.ctypes.data, fl.ctypes.data, pay.ctypes.data, cnt.ctypes.data, ms,
+                                      spos.ctypes.data, spat.ctypes.data, pre.ctypes.data, prel.ctypes.data, ns.ctypes.data, my),
+               "ddn_fsk4_rx_run_host")
+        return dict(rec=rec, fl=fl, pay=pay, cnt=cnt, sync_pos=spos, sync_pat=spat, pre=pre, pre_rel=prel, n_sync=ns)
+
+    def thresholds(self, ch):
+        t = self.np.zeros(7, self.np.float32)
+        _check(lib().ddn_fsk4_rx_get_thresholds(self.h, ch, t.ctypes.data), "ddn_fsk4_rx_get_thresholds")
+        return t
+
+
 def lib():
     """Load libdsdneo_hip.so (RTLD_LOCAL) and bind prototypes.  Raises if the library is not built."""
     global _lib

@@ -83,6 +83,28 @@ typedef struct DdnRxState { /* per-channel words of dsd_state / frame_sync_runti
     int need_reset; /* noCarrier() ran: the next symbol start re-initialises timing and slicer */
 } DdnRxState;
 
+/* ---- profile-driven 4-level FSK receive loop (DMR / NXDN48), ddn_rx4.hip ---- */
+#define DDN_FSK4_MAX_PAT  20
+#define DDN_FSK4_MAX_TAPS 135
+#define DDN_FSK4_HIST     96
+#define DDN_FSK4_PRE      90
+typedef struct DdnFsk4Config {
+    int out_rate, sym_rate, rf_mod, win_len, t_max, warm_len, n_pat;
+    uint32_t pat_bits[DDN_FSK4_MAX_PAT];
+    uint8_t pat_type[DDN_FSK4_MAX_PAT], pat_neg[DDN_FSK4_MAX_PAT], pat_class[DDN_FSK4_MAX_PAT];
+    int confirm, dmr_window, redigitize, slow_type, use_filter, nt;
+} DdnFsk4Config;
+typedef struct DdnFsk4State {
+    long long filt_start, n_abs;
+    float center, umid, lmid, max, min, maxref, minref;
+    float sum, lastsample, lmin, lmax;
+    int sps_accum, jitter, in_symbol, span, centre, i, count;
+    int filter_on, have_sync, lock_left, lastsync, cur_pat;
+    int lidx, level_count, hist_count, shead, scount;
+    uint32_t hist_bits;
+    int hunt_pos, need_reset;
+} DdnFsk4State;
+
 typedef struct DdnCqpskState { /* per-channel words of demod_state the CQPSK chain carries besides ted_state_t */
     float agc_avg;                          /* cqpsk_agc_avg */
     float fll_phase, fll_freq;              /* fll_band_edge_state */
@@ -125,6 +147,19 @@ hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev
                           float* lbuf_store, float* shist_store, float* minring, float* maxring, uint8_t* rec,
                           uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave,
                           const int32_t* lock_cfg, hipStream_t st);
+hipError_t ddn_dev_fsk4_matched_filter(int nt, const float* in, long n, size_t stride, int n_channels, const float* hist,
+                                       float* out, hipStream_t st);
+hipError_t ddn_dev_fsk4_filter_hist_update(int nt, const float* in, long n, size_t stride, int n_channels, float* hist,
+                                           hipStream_t st);
+hipError_t ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, float* fstale, const float* taps,
+                           long n, size_t stride, int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state,
+                           float* lbuf_store, float* shist_store, uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec,
+                           uint8_t* flags, uint8_t* pay, int32_t* counts, size_t max_sym, const int32_t* lock4,
+                           int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel, int32_t* n_sync,
+                           int max_sync, int channels_per_wave, hipStream_t st);
+hipError_t ddn_dev_dmr_burst_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
+                                    const uint8_t* pre, const int32_t* n_sync, int n_channels, int max_sync, int inverted,
+                                    uint8_t* slot_type, uint8_t* info, uint8_t* cach, uint8_t* valid, hipStream_t st);
 hipError_t ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, int block_len, int n_channels,
                                    const float* taps_dev, int taps_len, int has_zero_tap, void* hist, void* out,
                                    size_t out_stride, hipStream_t st);

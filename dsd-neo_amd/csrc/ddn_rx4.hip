@@ -1,0 +1,691 @@
+// ddn_rx4.hip - batched fixed-protocol receive loop for the other 4-level FSK protocols of BASELINE configs[3]: DMR and
+// NXDN48.  One lane = one channel running what the reference's decoder thread runs per stream between
+// rtl_stream_read() and the protocol handler, driven by a profile (DdnFsk4Config):
+//   getSymbol()      src/dsp/dsd_symbol.c:1343-1387,1769-1805; window selection :197-224 (C4FM left edge 1 once a DMR type
+//                    is the last sync; GFSK = the two samples next to the centre), accumulation :404-460 (sps-20 7..13 window
+//                    on top), slip rules :462-517 (sps 20 / GFSK / C4FM), clip only on C4FM :347-358, matched-filter family
+//                    by lastsynctype :301-338 (dmr_filter / nxdn_filter, src/dsp/dsd_filters.c:173-200,348-356)
+//   getFrameSync()   src/dsp/dsd_frame_sync.c:3098-3148; ring :1729-1764; sign dibit :2110-2127; 4-level payload dibit +
+//                    reliability stored while hunting :2161-2189; level window :2316-2336; timeouts :2753-2760,3037-3053
+//     DMR accept     :1102-1106,1108-1314: basic lock :385-392 + dmr_resample_on_sync() src/dsp/dmr_sync.c:63-131 (warm start
+//                    over the 24 sync symbols, re-digitisation of the 66 payload dibits before them)
+//     NXDN accept    :1507-1556 (10-symbol window, five patterns per polarity, accepted on the second consecutive match)
+//   in-frame symbol  get_dibit_and_analog_signal, src/core/frames/dsd_dibit.c:1045-1076; use_symbol :243-299 (no continuous
+//                    threshold update outside P25p1); digitize :1018-1043
+// Deviations from a full dsd-neo run (include/ddn_fsk4.h): modulation locked, one protocol, handler = configured symbol count.
+//
+// Outputs per symbol: the 10-byte capture record + flags as ddn_rx.hip, plus {payload dibit, reliability} - what the
+// reference appends to dmr_payload_buf / dmr_soft_buf for every symbol, hunting or not.  Per accepted sync: the index of its
+// last symbol and the 90 payload dibits ending there (CACH + first half + slot-type prefix + sync for a DMR burst) AFTER the
+// re-digitisation, so a burst decoder needs nothing from before the current call.
+//
+// GPU shape: as k_p25_rx (ddn_rx.hip) - wave 0 of a workgroup runs CPW channel recurrences, wave 1 stages the next
+// 64-sample tile of every channel (raw + always-on matched-filter output) with coalesced row loads; lanes advance symbol by
+// symbol.  P25p1 stays on its own kernels (live thresholds need the window / ring machinery of ddn_rx.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddn_device.h"
+#include "ddn_slicer_dev.h"
+#include "ddn_tables_fsk4.h"
+
+namespace {
+constexpr int TS = 64;
+constexpr int HN = DDN_FSK4_HIST;
+
+template <int CPW>
+struct Lds4 {
+    float lb[24][CPW];
+    float sh[HN][CPW];
+    uint8_t ph[HN][CPW];
+    uint8_t rh[HN][CPW];
+    float raw[2][CPW][TS + 1];
+    float flt[2][CPW][TS + 1];
+};
+
+__device__ __forceinline__ void
+no_carrier(DdnFsk4State& s) { // src/engine/engine.c:1838-1847 as far as this loop sees it
+    s.jitter = -1;
+    s.lastsync = 0;
+    s.filter_on = 0;
+    s.max = 15000.0f;
+    s.min = -15000.0f;
+    s.center = 0.0f;
+    s.need_reset = 1;
+}
+__device__ __forceinline__ void
+timing_reset(DdnFsk4State& s) { // dsd_symbol.c:1306-1341
+    s.need_reset = 0;
+    s.sps_accum = 0;
+    s.jitter = -1;
+    s.center = 0.0f;
+    s.min = -30000.0f;
+    s.max = 30000.0f;
+    s.lmid = -20000.0f;
+    s.umid = 20000.0f;
+    s.minref = -24000.0f;
+    s.maxref = 24000.0f;
+}
+__device__ __forceinline__ void
+hunt_restart(DdnFsk4State& s) {
+    s.hunt_pos = 0;
+    s.have_sync = 0;
+    s.lidx = 0;
+    s.level_count = 0;
+    s.hist_count = 0;
+    s.hist_bits = 0;
+    s.lmin = s.min;
+    s.lmax = s.max;
+}
+__device__ __forceinline__ int
+slice4(float x, const DdnFsk4State& s) {
+    return x > s.center ? (x > s.umid ? 1 : 0) : (x < s.lmid ? 3 : 2);
+}
+// how often sample i of the current symbol enters the sum (symbol_accumulate_sample)
+__device__ __forceinline__ int
+adds(int i, int span, int c, int rf_mod, int l_edge) {
+    int k = (span == 20 && i >= 7 && i <= 13) ? 1 : 0;
+    if (span == 5 && i == 2) {
+        return k + 1;
+    }
+    if (rf_mod == 0) {
+        return k + ((i >= c - l_edge && i <= c + 2) ? 1 : 0);
+    }
+    if (span <= 4) {
+        return k + (i == c ? 1 : 0);
+    }
+    return k + ((i == c - 1 || i == c + 1) ? 1 : 0);
+}
+
+template <int CPW>
+__global__ __launch_bounds__(128) void
+k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
+          float* __restrict__ fstale, const float* __restrict__ taps, long n, size_t stride, int n_channels,
+          DdnFsk4Config cfg, DdnFsk4State* __restrict__ state, float* __restrict__ lbuf_store,
+          float* __restrict__ shist_store, uint8_t* __restrict__ phist_store, uint8_t* __restrict__ rhist_store,
+          uint8_t* __restrict__ rec, uint8_t* __restrict__ flags, uint8_t* __restrict__ pay, int32_t* __restrict__ counts,
+          size_t max_sym, const int32_t* __restrict__ lock4, int32_t* __restrict__ sync_pos, uint8_t* __restrict__ sync_pat,
+          uint8_t* __restrict__ pre, uint8_t* __restrict__ pre_rel, int32_t* __restrict__ n_sync, int max_sync) {
+    extern __shared__ unsigned char smem_raw[];
+    Lds4<CPW>& L = *reinterpret_cast<Lds4<CPW>*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;
+    const int ch0 = blockIdx.x * CPW;
+    const int ch = ch0 + lane;
+    const bool live = !loader && lane < CPW && ch < n_channels;
+    const int ln = lane < CPW ? lane : 0;
+    const bool use_flt = cfg.use_filter != 0;
+    const int NT = cfg.nt;
+
+    DdnFsk4State s;
+    if (live) {
+        s = state[ch];
+        for (int k = 0; k < 24; k++) {
+            L.lb[k][ln] = lbuf_store[(size_t)k * n_channels + ch];
+        }
+        for (int k = 0; k < HN; k++) {
+            L.sh[k][ln] = shist_store[(size_t)k * n_channels + ch];
+            L.ph[k][ln] = phist_store[(size_t)k * n_channels + ch];
+            L.rh[k][ln] = rhist_store[(size_t)k * n_channels + ch];
+        }
+    } else {
+        s = DdnFsk4State{};
+    }
+    auto stage = [&](long t0, int buf) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+#pragma unroll
+        for (int h = 0; h < CPW / 16; h++) {
+            float r[16], f[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int cc = 16 * h + c;
+                const bool ok = (ch0 + cc < n_channels) && lane < tn;
+                const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + lane;
+                r[c] = ok ? raw[off] : 0.0f;
+                f[c] = (ok && use_flt) ? filt[off] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                L.raw[buf][16 * h + c][lane] = r[c];
+                L.flt[buf][16 * h + c][lane] = f[c];
+            }
+        }
+    };
+    if (loader && n > 0) {
+        stage(0, 0);
+    }
+    __syncthreads();
+
+    const int whole0 = cfg.out_rate / cfg.sym_rate, rem0 = cfg.out_rate % cfg.sym_rate;
+    const int whole = whole0 < 2 ? 2 : (whole0 > 64 ? 64 : whole0);
+    const int rem = (whole0 < 2 || whole0 > 64) ? 0 : rem0;
+    const uint32_t wmask = cfg.win_len >= 24 ? 0xFFFFFFu : ((1u << cfg.win_len) - 1u);
+    int o = 0, ns = 0;
+    uint8_t* rp = rec + (size_t)(live ? ch : 0) * max_sym * 10;
+    uint8_t* fp = flags + (size_t)(live ? ch : 0) * max_sym;
+    uint8_t* pp = pay + (size_t)(live ? ch : 0) * max_sym * 2;
+    const long long abs0 = s.n_abs;
+    int buf = 0;
+    for (long t0 = 0; t0 < n; t0 += TS, buf ^= 1) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        if (loader) {
+            if (t0 + TS < n) {
+                stage(t0 + TS, buf ^ 1);
+            }
+        } else {
+            int sp = 0, guard = 0;
+            auto snapshot_filter = [&]() { // the filter's memory at the moment it is gated off
+                if (!s.filter_on) {
+                    return;
+                }
+                const long long tnext = abs0 + t0 + sp;
+                float* fs = fstale + (size_t)ch * (DDN_FSK4_MAX_TAPS - 1);
+                for (int k = 0; k < NT - 1; k++) {
+                    const long long ja = tnext - (NT - 1) + k;
+                    float v;
+                    if (ja >= s.filt_start) {
+                        const long jc = (long)(ja - abs0);
+                        v = (jc >= 0) ? raw[(size_t)ch * stride + jc]
+                                      : prev_tail[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1) + (NT - 1) + jc];
+                    } else {
+                        v = fs[(int)(ja - s.filt_start) + (NT - 1)];
+                    }
+                    // in-place is safe: entry k is read from index >= k (ja - filt_start + NT-1 >= k  <=>  tnext >= filt_start)
+                    fs[k] = v;
+                }
+            };
+            auto hunt_advance = [&]() {
+                if (s.hunt_pos < 10200) {
+                    s.hunt_pos++;
+                } else {
+                    s.hunt_pos = 0;
+                    snapshot_filter();
+                    no_carrier(s);
+                }
+                if (!(cfg.slow_type && s.lastsync == cfg.slow_type) && s.hunt_pos >= 1800) {
+                    snapshot_filter();
+                    no_carrier(s);
+                    hunt_restart(s);
+                }
+            };
+            while (true) {
+                if (live && sp < tn && !s.in_symbol) {
+                    if (s.need_reset) {
+                        timing_reset(s);
+                    }
+                    int sps = whole;
+                    if (rem > 0) {
+                        int acc = s.sps_accum + rem;
+                        if (acc >= cfg.sym_rate) {
+                            sps++;
+                            acc -= cfg.sym_rate;
+                        }
+                        s.sps_accum = acc;
+                        sps = sps > 64 ? 64 : sps;
+                    }
+                    s.span = sps;
+                    s.centre = (sps - 1) / 2;
+                    s.i = 0;
+                    s.sum = 0.0f;
+                    s.count = 0;
+                    s.in_symbol = 1;
+                    if (sps > 1 && s.have_sync == 0 && s.jitter >= 0) {
+                        const int j = s.jitter, c = s.centre;
+                        if (sps == 20) {
+                            s.i += (j >= 7 && j <= 10) ? -1 : ((j >= 11 && j <= 14) ? 1 : 0);
+                        } else if (cfg.rf_mod == 2) {
+                            s.i += (j >= c - 1 && j <= c) ? -1 : ((j >= c + 1 && j <= c + 2) ? 1 : 0);
+                        } else {
+                            s.i += (j > 0 && j <= c) ? -1 : ((j > c && j < sps) ? 1 : 0);
+                        }
+                        s.jitter = -1;
+                    }
+                }
+                const int l_edge = (cfg.dmr_window && s.lastsync != 0) ? 1 : 2;
+                const bool clip = s.have_sync && cfg.rf_mod == 0;
+                // In-frame fast path: no slip, crossing latch already set -> only the window samples and the last one matter
+                if (live && s.in_symbol && s.i == 0 && s.have_sync && s.jitter >= 0 && s.span >= 6 && sp + s.span <= tn
+                    && (!s.filter_on || (abs0 + t0 + sp - s.filt_start) >= (long long)(NT - 1))) {
+                    const bool fo = s.filter_on != 0;
+                    const int c = s.centre;
+                    const int lo = s.span == 20 ? 7 : (cfg.rf_mod == 0 ? c - l_edge : c - 1);
+                    const int hi = s.span == 20 ? 13 : (cfg.rf_mod == 0 ? c + 2 : c + 1);
+                    float acc = 0.0f;
+                    int cnt = 0;
+                    for (int i = lo; i <= hi; i++) {
+                        const int a = adds(i, s.span, c, cfg.rf_mod, l_edge);
+                        if (a) {
+                            float x = fo ? L.flt[buf][ln][sp + i] : L.raw[buf][ln][sp + i];
+                            if (clip) {
+                                x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                            }
+                            acc += x;
+                            if (a > 1) {
+                                acc += x;
+                            }
+                            cnt += a;
+                        }
+                    }
+                    const int jl = sp + s.span - 1;
+                    float xl = fo ? L.flt[buf][ln][jl] : L.raw[buf][ln][jl];
+                    if (clip) {
+                        xl = xl > s.max ? s.max : (xl < s.min ? s.min : xl);
+                    }
+                    s.sum = acc;
+                    s.count = cnt;
+                    s.lastsample = xl;
+                    sp += s.span;
+                    s.i = s.span;
+                }
+                bool act = live && sp < tn && s.i < s.span;
+                while (__any(act)) {
+                    if (act) {
+                        float x = L.raw[buf][ln][sp];
+                        if (s.filter_on) {
+                            const long long a = abs0 + t0 + sp;
+                            if (a - s.filt_start >= (long long)(NT - 1)) {
+                                x = L.flt[buf][ln][sp];
+                            } else { // first NT-1 samples after the enable: FIR over the filter's stale memory + new samples
+                                const long k = t0 + sp;
+                                float acc = 0.0f;
+                                for (int i = 0; i < NT; i++) {
+                                    const long j = k - (NT - 1) + i;
+                                    float v;
+                                    if (abs0 + j >= s.filt_start) {
+                                        v = (j >= 0) ? raw[(size_t)ch * stride + j]
+                                                     : prev_tail[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1) + (NT - 1) + j];
+                                    } else {
+                                        v = fstale[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1)
+                                                   + (size_t)((abs0 + j - s.filt_start) + (NT - 1))];
+                                    }
+                                    acc += taps[i] * v;
+                                }
+                                x = acc;
+                            }
+                        }
+                        if (clip) {
+                            x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                        }
+                        const int i = s.i;
+                        if (s.jitter < 0) {
+                            if (x > s.center) {
+                                if (!(x > s.maxref * 1.25f) && s.lastsample < s.center) {
+                                    s.jitter = i;
+                                }
+                            } else if (!(x < s.minref * 1.25f) && s.lastsample > s.center) {
+                                s.jitter = i;
+                            }
+                        }
+                        const int a = adds(i, s.span, s.centre, cfg.rf_mod, l_edge);
+                        if (a) {
+                            s.sum += x;
+                            if (a > 1) {
+                                s.sum += x;
+                            }
+                            s.count += a;
+                        }
+                        s.lastsample = x;
+                        s.i++;
+                        sp++;
+                    }
+                    act = live && sp < tn && s.i < s.span;
+                }
+                // ---- symbol commit ----------------------------------------------------------------------------------
+                if (live && s.in_symbol && s.i >= s.span) {
+                    const float sym = (s.count > 0) ? (s.sum / (float)s.count) : 0.0f;
+                    s.in_symbol = 0;
+                    const int slot = s.shead;
+                    L.sh[slot][ln] = sym;
+                    s.shead = (s.shead + 1 >= HN) ? 0 : s.shead + 1;
+                    s.scount = s.scount < HN ? s.scount + 1 : HN;
+                    int dibit, relb = 0, l0 = 0, l1 = 0, fl = 0, pd, pr;
+                    const ddn_sl::Thr th = {s.center, s.umid, s.lmid, s.max, s.min};
+                    if (s.have_sync) {
+                        const int neg = cfg.pat_neg[s.cur_pat];
+                        s.maxref = s.max;
+                        s.minref = s.min;
+                        ddn_sl::slice_soft(sym, th, neg, dibit, relb, l0, l1);
+                        pd = neg ? (dibit ^ 2) : dibit;
+                        pr = relb;
+                        L.ph[slot][ln] = (uint8_t)pd;
+                        L.rh[slot][ln] = (uint8_t)pr;
+                        fl = 1 | (neg ? 4 : 0);
+                        if (--s.lock_left <= 0) {
+                            hunt_restart(s);
+                        }
+                    } else {
+                        L.lb[s.lidx][ln] = sym;
+                        s.level_count = s.level_count < cfg.t_max ? s.level_count + 1 : cfg.t_max;
+                        s.lidx = (s.lidx == cfg.t_max - 1) ? 0 : s.lidx + 1;
+                        const uint32_t bit = sym > 0.0f ? 1u : 0u;
+                        s.hist_bits = ((s.hist_bits << 1) | bit) & 0xFFFFFFu;
+                        s.hist_count = s.hist_count < 24 ? s.hist_count + 1 : 24;
+                        dibit = bit ? 1 : 3;
+                        pd = slice4(sym, s);
+                        pr = ddn_sl::rel_from_thresholds(sym, th);
+                        L.ph[slot][ln] = (uint8_t)pd;
+                        L.rh[slot][ln] = (uint8_t)pr;
+                        bool accepted = false;
+                        if (s.hist_count >= 8) {
+                            s.maxref = s.max;
+                            s.minref = s.min;
+                            int hit = -1;
+                            if (s.hist_count >= cfg.win_len) {
+                                const uint32_t w = s.hist_bits & wmask;
+                                for (int k = cfg.n_pat - 1; k >= 0; k--) {
+                                    hit = (w == cfg.pat_bits[k]) ? k : hit; // lowest matching index wins, as a forward scan
+                                }
+                            }
+                            if (hit >= 0) {
+                                // level window of the last level_count hunting symbols (frame_sync_level.c:10-44)
+                                const float big = 3.4028234663852886e38f;
+                                float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
+                                float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
+                                const int cnt = s.level_count;
+                                for (int k = 0; k < 24; k++) {
+                                    if (k < cnt) {
+                                        float v = L.lb[k][ln], t;
+                                        float w = v;
+                                        t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
+                                        t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
+                                        t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
+                                        t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
+                                        a4 = fminf(a4, v);
+                                        t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
+                                        t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
+                                        t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
+                                        t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
+                                        b4 = fmaxf(b4, w);
+                                    }
+                                }
+                                if (cnt >= 13) {
+                                    s.lmin = (a2 + a3 + a4) / 3.0f;
+                                    s.lmax = (b4 + b3 + b2) / 3.0f;
+                                } else {
+                                    s.lmin = (a0 + a1 + a2) / 3.0f;
+                                    s.lmax = (b2 + b1 + b0) / 3.0f;
+                                }
+                                const int type = cfg.pat_type[hit];
+                                s.max = (s.max + s.lmax) / 2;
+                                s.min = (s.min + s.lmin) / 2;
+                                accepted = !(cfg.confirm && s.lastsync != type);
+                                s.lastsync = type;
+                                if (use_flt && !s.filter_on) {
+                                    s.filter_on = 1;
+                                    s.filt_start = abs0 + t0 + sp;
+                                }
+                                if (accepted) {
+                                    const int wl = cfg.redigitize ? 24 : cfg.warm_len;
+                                    if (s.scount >= wl) { // dsd_sync_warm_start_thresholds_outer_only(opts, state, wl)
+                                        float sp_ = 0.0f, sn_ = 0.0f;
+                                        int np = 0, nn = 0, idx = s.shead;
+                                        for (int k = 0; k < wl; k++) {
+                                            idx = idx == 0 ? HN - 1 : idx - 1;
+                                            const float v = L.sh[idx][ln];
+                                            if (v > 0.0f) {
+                                                sp_ += v;
+                                                np++;
+                                            } else {
+                                                sn_ += v;
+                                                nn++;
+                                            }
+                                        }
+                                        if (np != 0 && nn != 0) {
+                                            const float mp = sp_ / (float)np, mn = sn_ / (float)nn;
+                                            if (!(fabsf(mp - mn) < 1.0f)) {
+                                                s.max = mp;
+                                                s.min = mn;
+                                                s.center = (s.max + s.min) / 2.0f;
+                                                s.umid = s.center + (s.max - s.center) * 0.625f;
+                                                s.lmid = s.center + (s.min - s.center) * 0.625f;
+                                                s.maxref = s.max * 0.80f;
+                                                s.minref = s.min * 0.80f;
+                                            }
+                                        }
+                                        if (cfg.redigitize && s.scount >= 90) { // dmr_resample_cach()
+                                            for (int i = 0; i < 66; i++) {
+                                                int q = s.shead - 90 + i;
+                                                q += q < 0 ? HN : 0;
+                                                L.ph[q][ln] = (uint8_t)slice4(L.sh[q][ln], s);
+                                            }
+                                        }
+                                    }
+                                    s.have_sync = 1;
+                                    s.cur_pat = hit;
+                                    s.lock_left = lock4[(size_t)ch * 4 + (cfg.pat_class[hit] & 3)];
+                                    fl = 2 | (cfg.pat_neg[hit] ? 4 : 0) | (hit << 3);
+                                    if (ns < max_sync) {
+                                        const size_t so = (size_t)ch * max_sync + ns;
+                                        sync_pos[so] = o;
+                                        sync_pat[so] = (uint8_t)hit;
+                                        for (int i = 0; i < DDN_FSK4_PRE; i++) {
+                                            int q = s.shead - DDN_FSK4_PRE + i;
+                                            q += q < 0 ? HN : 0;
+                                            const bool have = (DDN_FSK4_PRE - i) <= s.scount;
+                                            pre[so * DDN_FSK4_PRE + i] = have ? L.ph[q][ln] : 0;
+                                            pre_rel[so * DDN_FSK4_PRE + i] = have ? L.rh[q][ln] : 0;
+                                        }
+                                    }
+                                    ns++;
+                                    if (s.lock_left <= 0) {
+                                        hunt_restart(s);
+                                    }
+                                }
+                            }
+                        }
+                        if (!accepted) {
+                            hunt_advance();
+                        }
+                    }
+                    if ((size_t)o < max_sym) {
+                        uint8_t* r = rp + (size_t)o * 10;
+                        const uint32_t xb = __float_as_uint(sym);
+                        ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
+                        ((uint16_t*)r)[1] = (uint16_t)(int16_t)l0;
+                        ((uint16_t*)r)[2] = (uint16_t)(int16_t)l1;
+                        ((uint16_t*)r)[3] = (uint16_t)(xb & 0xFFFFu);
+                        ((uint16_t*)r)[4] = (uint16_t)(xb >> 16);
+                        fp[o] = (uint8_t)fl;
+                        ((uint16_t*)pp)[o] = (uint16_t)((pd & 3) | (pr << 8));
+                    }
+                    o++;
+                }
+                const bool busy = live && sp < tn;
+                if (!__any(busy) || ++guard > 2 * TS) {
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        s.n_abs = abs0 + n;
+        state[ch] = s;
+        counts[ch] = o;
+        n_sync[ch] = ns;
+        for (int k = 0; k < 24; k++) {
+            lbuf_store[(size_t)k * n_channels + ch] = L.lb[k][ln];
+        }
+        for (int k = 0; k < HN; k++) {
+            shist_store[(size_t)k * n_channels + ch] = L.sh[k][ln];
+            phist_store[(size_t)k * n_channels + ch] = L.ph[k][ln];
+            rhist_store[(size_t)k * n_channels + ch] = L.rh[k][ln];
+        }
+    }
+}
+
+// always-on matched-filter stream (apply_sps_fir order: products added oldest first, mul and add rounded separately);
+// hist = the NT-1 samples before this call, rows of DDN_FSK4_MAX_TAPS-1 floats, right-aligned use as in ddn_slicer.hip
+template <int NT>
+__global__ __launch_bounds__(256) void
+k_fsk4_matched_filter(const float* __restrict__ in, long n, size_t stride, const float* __restrict__ hist,
+                      float* __restrict__ out) {
+    constexpr int T = 1024;
+    __shared__ float X[T + NT];
+    const unsigned int* bits = NT == DDN_DMR_FILTER_TAPS ? ddn_dmr_filter_bits : ddn_nxdn48_filter_bits;
+    const int ch = blockIdx.y;
+    const long t0 = (long)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T + NT - 1; i += 256) {
+        const long j = t0 - (NT - 1) + i;
+        float v;
+        if (j < 0) {
+            v = hist[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1) + (NT - 1) + j];
+        } else {
+            v = j < n ? in[(size_t)ch * stride + j] : 0.0f;
+        }
+        X[i] = v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < T; o += 256) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            acc += __uint_as_float(bits[i]) * X[o + i];
+        }
+        if (t0 + o < n) {
+            out[(size_t)ch * stride + t0 + o] = acc;
+        }
+    }
+}
+
+__global__ void
+k_fsk4_filter_hist(int nt, const float* __restrict__ in, long n, size_t stride, float* __restrict__ hist) {
+    const int H = nt - 1;
+    const int ch = blockIdx.x, i = threadIdx.x;
+    float* h = hist + (size_t)ch * (DDN_FSK4_MAX_TAPS - 1);
+    float v = 0.0f;
+    if (i < H) {
+        const long j = n - H + i;
+        v = (j >= 0) ? in[(size_t)ch * stride + j] : h[H + j];
+    }
+    __syncthreads();
+    if (i < H) {
+        h[i] = v;
+    }
+}
+
+// DMR burst fields for every accepted sync: slot type (10 + 10 bits around the sync), the 196 info bits (98 + 98), the
+// CACH de-interleaved (ETSI TS 102 361-1 CACH interleave: TACT bits first) - dmr_data.c:117-262.  One workgroup per sync slot.
+__constant__ uint8_t c_cach_il[24] = {0, 7, 8, 9, 1, 10, 11, 12, 2, 13, 14, 15, 3, 16, 4, 17, 18, 19, 5, 20, 21, 22, 6, 23};
+__global__ void
+k_dmr_burst_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ counts, size_t max_sym,
+                   const int32_t* __restrict__ sync_pos, const uint8_t* __restrict__ pre, const int32_t* __restrict__ n_sync,
+                   int max_sync, int inverted, uint8_t* __restrict__ slot_type, uint8_t* __restrict__ info,
+                   uint8_t* __restrict__ cach, uint8_t* __restrict__ valid) {
+    const int k = blockIdx.x, ch = blockIdx.y, t = threadIdx.x; // 128 threads: t < 90 cached dibits, 90 <= t < 144 live
+    const size_t so = (size_t)ch * max_sync + k;
+    const bool have = k < n_sync[ch] && k < max_sync;
+    const long pos = have ? sync_pos[so] : 0;
+    const bool live_ok = have && (pos + 54 < (long)counts[ch]) && ((size_t)(pos + 54) < max_sym);
+    if (t == 0) {
+        valid[so] = live_ok ? 1 : 0;
+    }
+    for (int d = t; d < 144; d += blockDim.x) {
+        int dibit = 0;
+        if (d < 90) {
+            dibit = have ? pre[so * DDN_FSK4_PRE + d] : 0;
+            if (inverted) {
+                dibit ^= 2;
+            }
+        } else if (live_ok) {
+            dibit = rec[((size_t)ch * max_sym + (size_t)(pos + 1 + (d - 90))) * 10] & 3; // getDibitSoft()'s return value
+        }
+        const uint8_t hi = (uint8_t)((dibit >> 1) & 1), lo = (uint8_t)(dibit & 1);
+        if (d < 12) {
+            cach[so * 24 + c_cach_il[2 * d]] = hi;
+            cach[so * 24 + c_cach_il[2 * d + 1]] = lo;
+        } else if (d < 61) {
+            info[so * 196 + 2 * (d - 12)] = hi;
+            info[so * 196 + 2 * (d - 12) + 1] = lo;
+        } else if (d < 66) {
+            slot_type[so * 20 + 2 * (d - 61)] = hi;
+            slot_type[so * 20 + 2 * (d - 61) + 1] = lo;
+        } else if (d < 90) {
+            // the sync itself: not part of any field
+        } else if (d < 95) {
+            slot_type[so * 20 + 10 + 2 * (d - 90)] = hi;
+            slot_type[so * 20 + 10 + 2 * (d - 90) + 1] = lo;
+        } else {
+            info[so * 196 + 98 + 2 * (d - 95)] = hi;
+            info[so * 196 + 98 + 2 * (d - 95) + 1] = lo;
+        }
+    }
+}
+
+template <int CPW>
+hipError_t
+launch(const float* raw, const float* filt, const float* prev_tail, float* fstale, const float* taps, long n, size_t stride,
+       int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state, float* lbuf_store, float* shist_store,
+       uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec, uint8_t* flags, uint8_t* pay, int32_t* counts,
+       size_t max_sym, const int32_t* lock4, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel,
+       int32_t* n_sync, int max_sync, hipStream_t st) {
+    const size_t shmem = sizeof(Lds4<CPW>);
+    hipError_t e = hipFuncSetAttribute((const void*)k_fsk4_rx<CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL((k_fsk4_rx<CPW>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shmem, st, raw, filt,
+                       prev_tail, fstale, taps, n, stride, n_channels, *cfg, state, lbuf_store, shist_store, phist_store,
+                       rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel, n_sync,
+                       max_sync);
+    return hipGetLastError();
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, float* fstale, const float* taps, long n,
+                size_t stride, int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state, float* lbuf_store,
+                float* shist_store, uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec, uint8_t* flags, uint8_t* pay,
+                int32_t* counts, size_t max_sym, const int32_t* lock4, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre,
+                uint8_t* pre_rel, int32_t* n_sync, int max_sync, int channels_per_wave, hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    if (channels_per_wave <= 16) {
+        return launch<16>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store,
+                          phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel,
+                          n_sync, max_sync, st);
+    }
+    return launch<32>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store,
+                      phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel,
+                      n_sync, max_sync, st);
+}
+
+extern "C" hipError_t
+ddn_dev_dmr_burst_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos, const uint8_t* pre,
+                         const int32_t* n_sync, int n_channels, int max_sync, int inverted, uint8_t* slot_type, uint8_t* info,
+                         uint8_t* cach, uint8_t* valid, hipStream_t st) {
+    if (n_channels <= 0 || max_sync <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_dmr_burst_gather, dim3((unsigned)max_sync, (unsigned)n_channels), dim3(64), 0, st, rec, counts, max_sym,
+                       sync_pos, pre, n_sync, max_sync, inverted, slot_type, info, cach, valid);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_fsk4_matched_filter(int nt, const float* in, long n, size_t stride, int n_channels, const float* hist, float* out,
+                            hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    const dim3 grid((unsigned)((n + 1023) / 1024), (unsigned)n_channels);
+    if (nt == DDN_DMR_FILTER_TAPS) {
+        hipLaunchKernelGGL((k_fsk4_matched_filter<DDN_DMR_FILTER_TAPS>), grid, dim3(256), 0, st, in, n, stride, hist, out);
+    } else if (nt == DDN_NXDN48_FILTER_TAPS) {
+        hipLaunchKernelGGL((k_fsk4_matched_filter<DDN_NXDN48_FILTER_TAPS>), grid, dim3(256), 0, st, in, n, stride, hist, out);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_fsk4_filter_hist_update(int nt, const float* in, long n, size_t stride, int n_channels, float* hist,
+                                hipStream_t st) {
+    if (n_channels <= 0 || n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_fsk4_filter_hist, dim3((unsigned)n_channels), dim3(192), 0, st, nt, in, n, stride, hist);
+    return hipGetLastError();
+}

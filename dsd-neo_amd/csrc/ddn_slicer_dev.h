@@ -67,6 +67,34 @@ struct Thr {
     float center, umid, lmid, max, min;
 };
 
+// dmr_compute_reliability() on a C4FM / GFSK stream (dsd_dibit.c:548-568: c4fm_reliability_from_thresholds + the SNR weight
+// with every metrics hook unset, i.e. x 204/256): the reliability stored with a payload dibit while hunting.
+__device__ __forceinline__ int
+rel_from_thresholds(float x, const Thr& s) {
+    const float eps = 1e-6f;
+    int rel;
+    if (x > s.umid) {
+        float span = s.max - s.umid;
+        span = span < eps ? eps : span;
+        rel = (int)__float2ll_rn(((x - s.umid) * 255.0f) / span);
+    } else if (x > s.center) {
+        const float d1 = x - s.center, d2 = s.umid - x;
+        float span = s.umid - s.center;
+        span = span < eps ? eps : span;
+        rel = (int)__float2ll_rn(((d1 < d2 ? d1 : d2) * 510.0f) / span);
+    } else if (x >= s.lmid) {
+        const float d1 = s.center - x, d2 = x - s.lmid;
+        float span = s.center - s.lmid;
+        span = span < eps ? eps : span;
+        rel = (int)__float2ll_rn(((d1 < d2 ? d1 : d2) * 510.0f) / span);
+    } else {
+        float span = s.lmid - s.min;
+        span = span < eps ? eps : span;
+        rel = (int)__float2ll_rn(((s.lmid - x) * 255.0f) / span);
+    }
+    return clamp255((clamp255(rel) * 204) >> 8);
+}
+
 // One symbol against fixed thresholds: dibit, reliability, llr0, llr1 (the 10-byte record's first six bytes).
 __device__ __forceinline__ void
 slice_soft(float x, const Thr& s, int negative, int& dibit, int& reliab, int& l0, int& l1) {

@@ -1,0 +1,75 @@
+/* ddn_fsk4.h - C-ABI of the batched fixed-protocol receive loop for DMR and NXDN48 (BASELINE configs[3]);
+ * P25 Phase 1 has its own entry points in ddn_hip.h (ddn_p25_rx_*).  Device pointers + stream, like the rest of the library.
+ *
+ * Replaces, per channel and per call, the loop a dsd-neo decoder thread runs between rtl_stream_read() and the protocol
+ * handler for one enabled protocol: getFrameSync() (src/dsp/dsd_frame_sync.c:3098-3148; DMR matchers :1102-1314 with
+ * dmr_resample_on_sync() src/dsp/dmr_sync.c:63-131; NXDN matcher :1507-1556) around getSymbol()
+ * (src/dsp/dsd_symbol.c:1854-1880) and get_dibit_and_analog_signal() (src/core/frames/dsd_dibit.c:1045-1076).
+ * What is fixed per batch instead of decided at run time: one protocol, the modulation lock (-mc: rf_mod 0, -mg: rf_mod 2),
+ * signal polarity (inverted = the reference's -xr for DMR), and how many symbols the handler of a sync class consumes
+ * (lock_symbols[]: DMR data 120 = 54 live + 66 skipped, src/protocol/dmr/dmr_data.c:213-302; DMR voice = 54 + 288 per
+ * superframe pair the host expects, src/protocol/dmr/dmr_bs.c:840-948; NXDN 182).
+ */
+#ifndef DDN_FSK4_H
+#define DDN_FSK4_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DDN_FSK4_DMR = 1, DDN_FSK4_NXDN48 = 2 };
+enum { DDN_FSK4_CLASS_DATA = 0, DDN_FSK4_CLASS_VOICE = 1 }; /* index into lock_symbols[] */
+/* sync pattern index reported in flags bits 3..6 / d_sync_pat.  DMR: 0 BS data word, 1 BS voice word, 2 MS data, 3 MS voice,
+ * 4 / 5 direct-mode TS1 / TS2 data, 6 / 7 direct-mode TS1 / TS2 voice (with inverted = 1 the data words mark voice bursts and
+ * vice versa, as with -xr).  NXDN48: 0..4 FSW variants positive, 5..9 inverted. */
+#define DDN_FSK4_PRE 90 /* payload dibits handed over with every accepted sync */
+
+typedef struct ddn_fsk4_rx_config {
+    int n_channels;
+    int out_rate_hz;        /* discriminator sample rate (48000) */
+    int protocol;           /* DDN_FSK4_* */
+    int rf_mod;             /* 0 = C4FM window / slip / clip rules (-mc), 2 = GFSK rules (-mg; what an unlocked dsd-neo
+                               switches to on a DMR sync, dsd_frame_sync.c:595-600) */
+    int inverted;           /* DMR only: opts->inverted_dmr */
+    int use_matched_filter; /* opts->use_cosine_filter (default 1 in the reference) */
+    int lock_symbols[4];    /* per sync class; all zero = the defaults above (DMR voice default 54 + 6 * 288) */
+} ddn_fsk4_rx_config;
+typedef struct ddn_fsk4_rx ddn_fsk4_rx;
+
+int ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out);
+void ddn_fsk4_rx_destroy(ddn_fsk4_rx* b);
+int ddn_fsk4_rx_reset(ddn_fsk4_rx* b);
+size_t ddn_fsk4_rx_max_symbols(const ddn_fsk4_rx* b, size_t n);
+size_t ddn_fsk4_rx_max_syncs(const ddn_fsk4_rx* b, size_t n);
+/* per-channel handler lengths, host array int32 [n_channels][4] */
+int ddn_fsk4_rx_set_lock_symbols(ddn_fsk4_rx* b, const int32_t* lock4);
+/* d_disc f32 [B][n] -> d_records10 u8 [B][max_symbols][10] (the reference's symbol-capture record), d_flags u8 [B][max_symbols]
+ * (1 in frame, 2 sync accepted on this symbol, 4 negative polarity, pattern index << 3 on the accepting symbol), d_payload2
+ * u8 [B][max_symbols][2] = {payload dibit, reliability} (dmr_payload_buf / dmr_soft_buf contents), d_counts i32 [B];
+ * per accepted sync k < d_n_sync[c] (capacity max_syncs per channel): d_sync_pos i32 = index of the sync's last symbol,
+ * d_sync_pat u8, d_pre / d_pre_rel u8 [DDN_FSK4_PRE] = the payload dibits / reliabilities ending at that symbol, after DMR's
+ * re-digitisation.  State carries across calls. */
+int ddn_fsk4_rx_run(ddn_fsk4_rx* b, const float* d_disc, size_t n, uint8_t* d_records10, uint8_t* d_flags,
+                    uint8_t* d_payload2, int32_t* d_counts, size_t max_symbols, int32_t* d_sync_pos, uint8_t* d_sync_pat,
+                    uint8_t* d_pre, uint8_t* d_pre_rel, int32_t* d_n_sync, size_t max_syncs, void* hip_stream);
+int ddn_fsk4_rx_run_host(ddn_fsk4_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, uint8_t* payload2,
+                         int32_t* counts, size_t max_symbols, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre,
+                         uint8_t* pre_rel, int32_t* n_sync, size_t max_syncs);
+int ddn_fsk4_rx_get_thresholds(ddn_fsk4_rx* b, int channel, float out7[7]); /* center umid lmid max min maxref minref */
+int ddn_fsk4_rx_set_timing(ddn_fsk4_rx* b, int enable);
+int ddn_fsk4_rx_get_timing(ddn_fsk4_rx* b, float* ms2); /* {matched filter, receive loop} of the last run */
+
+/* DMR burst fields from the per-sync hand-over + the live symbols after the sync (SURVEY 8f rank 3 seam: what
+ * dmr_data_sync() / dmrBSBootstrap() assemble, src/protocol/dmr/dmr_data.c:117-262, dmr_bs.c:700-760).  For sync k of channel
+ * c (slot c * max_syncs + k): d_slot_type u8 [20] bits (Golay(20,8) input order), d_info u8 [196] bits (BPTC input order,
+ * first half from d_pre, second half live = the records' dibits, i.e. getDibitSoft()'s polarity-corrected return values),
+ * d_cach u8 [24] bits de-interleaved (TACT first), d_valid = 1 when the 54 live dibits lie inside this call's records.
+ * inverted != 0 applies the reference's dibit ^= 2 to the cached half (dmr_data.c:84-86). */
+int ddn_dmr_burst_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols, const int32_t* d_sync_pos,
+                         const uint8_t* d_pre, const int32_t* d_n_sync, int n_channels, size_t max_syncs, int inverted,
+                         uint8_t* d_slot_type, uint8_t* d_info, uint8_t* d_cach, uint8_t* d_valid, void* hip_stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -180,6 +180,9 @@ typedef struct orc_slicer {
 void orc_slicer_init(orc_slicer* s, int negative_polarity);
 void orc_slicer_step(orc_slicer* s, float sym, int rec4[4]);
 void orc_slicer_run(orc_slicer* s, const float* sym, long n, int* rec4, float* thr5);
+void orc_slicer_digitize(const orc_slicer* s, float sym, int rec4[4]);
+void orc_slicer_step_static(orc_slicer* s, float sym, int rec4[4]);
+int orc_slicer_reliability(const orc_slicer* s, float sym);
 void orc_p25_filter_run(float hist[90], const float* in, long n, float* out);
 
 /* ---- fixed-protocol P25p1 C4FM receive loop: symbolizer + sync hunt + warm start + slicer (ddn_oracle_rx.c) -- */
@@ -201,6 +204,60 @@ typedef struct orc_p25rx {
     int hunt_pos;     /* rt.synctest_pos: symbols hunted by this getFrameSync() call */
     int need_reset;   /* noCarrier() zeroed the timing ratio: the next getSymbol() re-initialises timing and slicer */
 } orc_p25rx;
+
+/* ---- fixed-protocol 4-level FSK receive loop, profile-driven: P25p1 / DMR / NXDN48 (ddn_oracle_rx4.c) ------------- */
+#define ORC_FSK4_MAX_PAT  20
+#define ORC_FSK4_MAX_TAPS 135
+#define ORC_FSK4_HIST     96 /* symbols of history kept per stream (>= 90: DMR re-digitisation reach) */
+#define ORC_FSK4_PRE      90 /* payload dibits handed over with every accepted sync */
+typedef struct orc_fsk4_profile {
+    int out_rate, sym_rate;
+    int rf_mod;          /* 0 = C4FM lock (-mc), 2 = GFSK lock (-mg) */
+    int win_len;         /* sync window in symbols: 24 (P25p1, DMR) or 10 (NXDN) */
+    int t_max;           /* level ring length: 24, NXDN48 12 */
+    int warm_len;        /* symbols the warm start averages: 24 / 10 */
+    int n_pat;
+    uint32_t pat_bits[ORC_FSK4_MAX_PAT]; /* sign bits ('1' -> 1, '3' -> 0), oldest symbol in bit win_len-1 */
+    uint8_t pat_type[ORC_FSK4_MAX_PAT];  /* sync-type id (> 0; lastsynctype value) */
+    uint8_t pat_neg[ORC_FSK4_MAX_PAT];   /* digitize() polarity of that type */
+    uint8_t pat_class[ORC_FSK4_MAX_PAT]; /* 0..3: which lock_symbols[] entry the handler of that type consumes */
+    int confirm;         /* NXDN: a match is accepted only when lastsynctype already is that type */
+    int live_thresholds; /* P25p1: use_symbol() keeps min / max / mids live in frame */
+    int dmr_window;      /* DMR: C4FM window left edge 1 once a DMR type is the last sync */
+    int redigitize;      /* DMR: dmr_resample_on_sync() */
+    int slow_type;       /* type id exempt from the 1800-symbol timeout (P25p1 NEG), or 0 */
+    int use_filter, nt;
+    uint32_t taps[ORC_FSK4_MAX_TAPS];
+    int lock_symbols[4];
+} orc_fsk4_profile;
+typedef struct orc_fsk4rx {
+    orc_fsk4_profile p;
+    int sps_accum, jitter, in_symbol, span, centre, i, count;
+    float sum, lastsample;
+    int filter_on;
+    float fhist[ORC_FSK4_MAX_TAPS];
+    int have_sync, lock_left, lastsync, cur_pat; /* lastsync = lastsynctype id (0 none); cur_pat = index of state->synctype */
+    int lidx, level_count, hist_count;
+    uint32_t hist_bits;
+    float lbuf[24], lmin, lmax;
+    float shist[ORC_FSK4_HIST];
+    uint8_t phist[ORC_FSK4_HIST], rhist[ORC_FSK4_HIST]; /* payload dibit / reliability history, same ring */
+    int shead, scount;
+    orc_slicer sl;
+    int hunt_pos, need_reset;
+} orc_fsk4rx;
+void orc_fsk4rx_init(orc_fsk4rx* r, const orc_fsk4_profile* p);
+/* per symbol: out_sym, rec4 {dibit, rel, llr0, llr1}, flags (1 in frame, 2 sync accepted, 4 negative, pattern index << 3
+ * on the accepting symbol), pay2 {payload dibit, reliability}.  per accepted sync (up to max_sync): sync_pos (index of the
+ * sync's last symbol in this call's output), sync_pat, pre[90] / pre_rel[90] = the payload history ending at that symbol
+ * after re-digitisation.  *n_sync = syncs accepted in this call.  returns the symbol count. */
+long orc_fsk4rx_run(orc_fsk4rx* r, const float* in, long n, float* out_sym, int* rec4, uint8_t* flags, uint8_t* pay2,
+                    long max_out, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel, int max_sync,
+                    int* n_sync);
+size_t orc_fsk4rx_sizeof(void);
+size_t orc_fsk4_profile_sizeof(void);
+void orc_fsk4rx_get_thresholds(const orc_fsk4rx* r, float out7[7]);
+
 void orc_level_estimate(const float* sorted, int count, float* lo, float* hi);
 int orc_slicer_warm_start(orc_slicer* s, const float* newest_first, int sync_len);
 void orc_p25rx_init(orc_p25rx* r, int out_rate_hz, int sym_rate_hz, int lock_symbols, int use_matched_filter);

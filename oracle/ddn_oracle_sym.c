@@ -172,7 +172,12 @@ orc_slicer_step(orc_slicer* s, float sym, int rec4[4]) {
     s->minref = s->min * 0.80f;
     s->sidx = (s->sidx >= ORC_SLICER_SSIZE - 1) ? 0 : s->sidx + 1;
 
-    /* digitize() */
+    orc_slicer_digitize(s, sym, rec4);
+}
+
+/* digitize() + compute_dibit_soft_metric() with the thresholds as they stand (dsd_dibit.c:963-1043,690-721) */
+void
+orc_slicer_digitize(const orc_slicer* s, float sym, int rec4[4]) {
     const int neg = s->negative;
     int dibit;
     if (sym > s->center) {
@@ -207,6 +212,25 @@ orc_slicer_step(orc_slicer* s, float sym, int rec4[4]) {
     rec4[1] = clamp255(a1 < a0 ? a1 : a0);
     rec4[2] = l0;
     rec4[3] = l1;
+}
+
+
+/* dmr_compute_reliability() for rf_mod != 1 (dsd_dibit.c:548-568) */
+int
+orc_slicer_reliability(const orc_slicer* s, float sym) {
+    return threshold_reliability(s, sym);
+}
+
+/* get_dibit_and_analog_signal() when use_symbol() takes its "no continuous update" branch (dsd_dibit.c:264-276: any
+ * protocol but P25p1 on a C4FM / GFSK stream): the window slot is written, the crossing references follow max / min,
+ * the thresholds stay as the last sync left them. */
+void
+orc_slicer_step_static(orc_slicer* s, float sym, int rec4[4]) {
+    s->sbuf[s->sidx] = sym;
+    s->maxref = s->max;
+    s->minref = s->min;
+    s->sidx = (s->sidx >= ORC_SLICER_SSIZE - 1) ? 0 : s->sidx + 1;
+    orc_slicer_digitize(s, sym, rec4);
 }
 
 void

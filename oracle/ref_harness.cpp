@@ -389,6 +389,20 @@ refh_p25_filter_run(const float* in, long n, int sps, int reset, float* out) {
     }
 }
 
+// the DMR (RRC alpha 0.7) and NXDN48 matched filters on the same terms (src/dsd_filters.c:348-356); which: 1 DMR, 2 NXDN
+void
+refh_fsk4_filter_run(int which, const float* in, long n, int sps, int reset, float* out) {
+    if (reset) {
+        init_rrc_filter_memory();
+    }
+    for (long i = 0; i < n; i++) {
+        out[i] = which == 1 ? dmr_filter(in[i], sps) : nxdn_filter(in[i], sps);
+    }
+}
+
+// dmr_compute_reliability on the slicer harness state is not needed: it is c4fm_reliability_from_thresholds + the SNR
+// weight, both already exercised through getDibitSoft (refh_slicer_*).
+
 int
 refh_sync_p25p1_pos(void) {
     return DSD_SYNC_P25P1_POS;

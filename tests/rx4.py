@@ -1,0 +1,182 @@
+"""Test helpers for the profile-driven 4-level FSK receive loop (P25p1 / DMR / NXDN48): profile construction shared by
+the oracle wrapper (oracle/ddn_oracle_rx4.c) and the C-ABI tests, burst generators, and DMR burst field extraction.
+TEST INFRASTRUCTURE - the product never imports this."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import orc
+
+MAX_PAT, MAX_TAPS, PRE = 20, 135, 90
+
+# sync words as the reference's dibit strings ('1' = +3, '3' = -3): include/dsd-neo/core/sync_patterns.h:33-34,58-80,
+# NXDN FSW variants src/dsp/dsd_frame_sync.c:1508-1512
+P25P1_SYNC = "111113113311333313133333"
+DMR_BS_DATA, DMR_BS_VOICE = "313333111331131131331131", "131111333113313313113313"
+DMR_MS_DATA, DMR_MS_VOICE = "311131133313133331131113", "133313311131311113313331"
+DMR_DM1_DATA, DMR_DM1_VOICE = "331333313111313133311111", "113111131333131311133333"
+DMR_DM2_DATA, DMR_DM2_VOICE = "311311111333113333133311", "133133333111331111311133"
+NXDN_POS = ["3131331131", "3331331131", "3131331111", "3331331111", "3131311131"]
+NXDN_NEG = ["1313113313", "1113113313", "1313113333", "1113113333", "1313133313"]
+
+PROTO_P25P1, PROTO_DMR, PROTO_NXDN48 = 0, 1, 2
+# sync type ids carried in lastsync (any non-zero numbering works; these mirror synctype_ids.h + 1 so 0 stays "none")
+T_P25_POS, T_P25_NEG = 1, 2
+T_DMR_BS_DATA, T_DMR_BS_VOICE, T_DMR_MS_VOICE, T_DMR_MS_DATA = 11, 13, 33, 34
+T_NXDN_POS, T_NXDN_NEG = 29, 30
+CLASS_DATA, CLASS_VOICE = 0, 1
+
+
+def bits_of(pattern):
+    v = 0
+    for ch in pattern:
+        v = (v << 1) | (1 if ch == "1" else 0)
+    return v
+
+
+class Profile(C.Structure):
+    _fields_ = [("out_rate", C.c_int), ("sym_rate", C.c_int), ("rf_mod", C.c_int), ("win_len", C.c_int), ("t_max", C.c_int),
+                ("warm_len", C.c_int), ("n_pat", C.c_int), ("pat_bits", C.c_uint32 * MAX_PAT), ("pat_type", C.c_uint8 * MAX_PAT),
+                ("pat_neg", C.c_uint8 * MAX_PAT), ("pat_class", C.c_uint8 * MAX_PAT), ("confirm", C.c_int),
+                ("live_thresholds", C.c_int), ("dmr_window", C.c_int), ("redigitize", C.c_int), ("slow_type", C.c_int),
+                ("use_filter", C.c_int), ("nt", C.c_int), ("taps", C.c_uint32 * MAX_TAPS), ("lock_symbols", C.c_int * 4)]
+
+
+def _taps(name):
+    """bit patterns of a generated tap table (oracle/ddn_tables_p25.h, oracle/ddn_tables_fsk4.h)"""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    fn = "ddn_tables_p25.h" if name == "p25" else "ddn_tables_fsk4.h"
+    txt = open(os.path.join(here, fn)).read()
+    m = re.search(r"ddn_%s_filter_bits\[[A-Z0-9_]+\] = \{(.*?)\};" % name, txt, re.S)
+    return [int(x.rstrip("u"), 16) for x in re.findall(r"0x[0-9a-f]+u", m.group(1))]
+
+
+def profile(proto, rf_mod=0, use_filter=1, lock=None, out_rate=48000, inverted=0):
+    p = Profile()
+    p.out_rate, p.rf_mod, p.use_filter = out_rate, rf_mod, use_filter
+    pats = []
+    if proto == PROTO_P25P1:
+        p.sym_rate, p.win_len, p.t_max, p.warm_len = 4800, 24, 24, 24
+        p.live_thresholds, p.slow_type = 1, T_P25_NEG
+        inv = "".join("1" if c == "3" else "3" for c in P25P1_SYNC)
+        pats = [(P25P1_SYNC, T_P25_POS, 0, 0), (inv, T_P25_NEG, 1, 0)]
+        taps = _taps("p25")
+        lock = lock or [840, 0, 0, 0]
+    elif proto == PROTO_DMR:
+        p.sym_rate, p.win_len, p.t_max, p.warm_len = 4800, 24, 24, 24
+        p.dmr_window, p.redigitize = 1, 1
+        pats = [(DMR_BS_DATA, T_DMR_BS_DATA, 0, CLASS_DATA), (DMR_BS_VOICE, T_DMR_BS_VOICE, 0, CLASS_VOICE),
+                (DMR_MS_DATA, T_DMR_MS_DATA, 0, CLASS_DATA), (DMR_MS_VOICE, T_DMR_MS_VOICE, 0, CLASS_VOICE),
+                (DMR_DM1_DATA, T_DMR_MS_DATA, 0, CLASS_DATA), (DMR_DM2_DATA, T_DMR_MS_DATA, 0, CLASS_DATA),
+                (DMR_DM1_VOICE, T_DMR_MS_VOICE, 0, CLASS_VOICE), (DMR_DM2_VOICE, T_DMR_MS_VOICE, 0, CLASS_VOICE)]
+        if inverted:   # opts->inverted_dmr (-xr): frame_sync_try_dmr_* swap the roles of the words; BS types become the NEG ones
+            T_BS_VOICE_NEG, T_BS_DATA_NEG = 12, 14
+            swap = {T_DMR_BS_DATA: (T_BS_VOICE_NEG, 1), T_DMR_BS_VOICE: (T_BS_DATA_NEG, 1), T_DMR_MS_DATA: (T_DMR_MS_VOICE, 0),
+                    T_DMR_MS_VOICE: (T_DMR_MS_DATA, 0)}
+            pats = [(s_, swap[t][0], swap[t][1], cl ^ 1) for (s_, t, neg, cl) in pats]
+        taps = _taps("dmr")
+        lock = lock or [120, 54 + 288 * 6, 0, 0]
+    else:
+        p.sym_rate, p.win_len, p.t_max, p.warm_len = 2400, 10, 12, 10
+        p.confirm = 1
+        pats = [(s, T_NXDN_POS, 0, 0) for s in NXDN_POS] + [(s, T_NXDN_NEG, 1, 0) for s in NXDN_NEG]
+        # the reference tests positive[i] then negative[i] for i = 0..4; patterns are distinct so the order is immaterial
+        taps = _taps("nxdn48")
+        lock = lock or [182, 0, 0, 0]
+    p.n_pat = len(pats)
+    for k, (s, t, neg, cl) in enumerate(pats):
+        assert len(s) == p.win_len
+        p.pat_bits[k], p.pat_type[k], p.pat_neg[k], p.pat_class[k] = bits_of(s), t, neg, cl
+    p.nt = len(taps)
+    for k, t in enumerate(taps):
+        p.taps[k] = t
+    for k in range(4):
+        p.lock_symbols[k] = lock[k]
+    return p
+
+
+class OracleFsk4Rx:
+    def __init__(self, prof):
+        o = orc.oracle()
+        o.orc_fsk4rx_sizeof.restype = C.c_size_t
+        o.orc_fsk4_profile_sizeof.restype = C.c_size_t
+        assert o.orc_fsk4_profile_sizeof() == C.sizeof(Profile)
+        o.orc_fsk4rx_init.argtypes = [C.c_void_p, C.c_void_p]
+        o.orc_fsk4rx_run.argtypes = [C.c_void_p, C.c_void_p, C.c_long] + [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
+        o.orc_fsk4rx_run.restype = C.c_long
+        o.orc_fsk4rx_get_thresholds.argtypes = [C.c_void_p, C.c_void_p]
+        self.o, self.prof = o, prof
+        self.st = C.create_string_buffer(o.orc_fsk4rx_sizeof())
+        o.orc_fsk4rx_init(self.st, C.byref(prof))
+
+    def run(self, x, max_sync=None):
+        """-> dict(sym, rec4, fl, pay [k][2], sync_pos, sync_pat, pre [ns][90], pre_rel)"""
+        x = np.ascontiguousarray(x, np.float32)
+        cap = x.size // 2 + 8
+        ms = max_sync or (x.size // 100 + 4)
+        sym, rec, fl = np.zeros(cap, np.float32), np.zeros((cap, 4), np.int32), np.zeros(cap, np.uint8)
+        pay = np.zeros((cap, 2), np.uint8)
+        spos, spat = np.zeros(ms, np.int32), np.zeros(ms, np.uint8)
+        pre, prel = np.zeros((ms, PRE), np.uint8), np.zeros((ms, PRE), np.uint8)
+        ns = C.c_int(0)
+        k = self.o.orc_fsk4rx_run(self.st, x.ctypes.data, x.size, sym.ctypes.data, rec.ctypes.data, fl.ctypes.data, pay.ctypes.data,
+                                  cap, spos.ctypes.data, spat.ctypes.data, pre.ctypes.data, prel.ctypes.data, ms, C.byref(ns))
+        assert k <= cap and ns.value <= ms
+        n = ns.value
+        return dict(sym=sym[:k].copy(), rec4=rec[:k].copy(), fl=fl[:k].copy(), pay=pay[:k].copy(), sync_pos=spos[:n].copy(),
+                    sync_pat=spat[:n].copy(), pre=pre[:n].copy(), pre_rel=prel[:n].copy())
+
+    def thresholds(self):
+        t = np.zeros(7, np.float32)
+        self.o.orc_fsk4rx_get_thresholds(self.st, t.ctypes.data)
+        return t
+
+
+# ---- DMR burst fields from the loop's outputs (what dmr_data_sync() assembles, src/protocol/dmr/dmr_data.c:117-262) ----------
+CACH_IL = [0, 7, 8, 9, 1, 10, 11, 12, 2, 13, 14, 15, 3, 16, 4, 17, 18, 19, 5, 20, 21, 22, 6, 23]
+
+
+def dmr_burst_fields(pre90, live54, inverted):
+    """-> (slot_type bits [20], info bits [196], cach bits [24]) from the 90 cached + 54 live payload dibits"""
+    d = [int(x) ^ (2 if inverted else 0) for x in pre90] + [int(x) for x in live54]
+    hi = [(x >> 1) & 1 for x in d]
+    lo = [x & 1 for x in d]
+    cach = [0] * 24
+    for i in range(12):
+        cach[CACH_IL[2 * i]], cach[CACH_IL[2 * i + 1]] = hi[i], lo[i]
+    info, st = [], []
+    for i in range(12, 61):
+        info += [hi[i], lo[i]]
+    for i in range(61, 66):
+        st += [hi[i], lo[i]]
+    for i in range(90, 95):
+        st += [hi[i], lo[i]]
+    for i in range(95, 144):
+        info += [hi[i], lo[i]]
+    return np.array(st, np.uint8), np.array(info, np.uint8), np.array(cach, np.uint8)
+
+
+def crc_ccitt_bits(bits):
+    crc = 0
+    for b in bits:
+        msb = (crc >> 15) & 1
+        crc = (crc << 1) & 0xFFFF
+        if msb ^ int(b):
+            crc ^= 0x1021
+    return crc
+
+
+def bits_int(bits):
+    v = 0
+    for b in bits:
+        v = (v << 1) | int(b)
+    return v
+
+
+def capture_disc(name, lpf_profile):
+    """discriminator stream of one of the reference's captures (tests/golden/iq_*.npz) through the pinned front end"""
+    from conftest import golden
+    g = golden(name)
+    return orc.OracleFrontEnd(profile=lpf_profile).run_cu8(np.ascontiguousarray(g["iq"], np.uint8), 8192)

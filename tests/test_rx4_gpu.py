@@ -1,0 +1,144 @@
+"""GPU parity of the DMR / NXDN48 receive loop (ddn_fsk4_rx_*, dsd-neo_amd/csrc/ddn_rx4.hip) against the CPU restatement
+(oracle/ddn_oracle_rx4.c), bit for bit through the C-ABI: records, flags, payload dibits + reliabilities, per-sync hand-over,
+carried state across ragged call splits; then the DMR known answers end to end on the device (burst gather -> Golay(20,8) ->
+BPTC(196,96))."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ddn
+import orc
+import rx4
+
+pytestmark = pytest.mark.gpu
+
+
+def rec4_of(rec):
+    """10-byte records -> [.., 4] int32 {dibit, rel, llr0, llr1} + float symbols"""
+    r = rec.reshape(-1, 10)
+    d = r[:, 0].astype(np.int32)
+    rel = r[:, 1].astype(np.int32)
+    l0 = r[:, 2:4].copy().view(np.int16).astype(np.int32).reshape(-1)
+    l1 = r[:, 4:6].copy().view(np.int16).astype(np.int32).reshape(-1)
+    sym = r[:, 6:10].copy().view(np.float32).reshape(-1)
+    return np.stack([d, rel, l0, l1], axis=1), sym
+
+
+def check_channel(got, c, want):
+    k = int(got["cnt"][c])
+    assert k == len(want["sym"]), (c, k, len(want["sym"]))
+    r4, sym = rec4_of(got["rec"][c, :k])
+    assert np.array_equal(sym.view(np.uint32), want["sym"].view(np.uint32)), c
+    assert np.array_equal(r4, want["rec4"]), c
+    assert np.array_equal(got["fl"][c, :k], want["fl"]), c
+    assert np.array_equal(got["pay"][c, :k], want["pay"]), c
+    ns = int(got["n_sync"][c])
+    assert ns == len(want["sync_pos"]), c
+    assert np.array_equal(got["sync_pos"][c, :ns], want["sync_pos"]) and np.array_equal(got["sync_pat"][c, :ns], want["sync_pat"])
+    assert np.array_equal(got["pre"][c, :ns], want["pre"]) and np.array_equal(got["pre_rel"][c, :ns], want["pre_rel"])
+
+
+CASES = [("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 0, 0), ("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 2, 0),
+         ("iq_dmr_voice.npz", 2, rx4.PROTO_DMR, 0, 1), ("iq_dmr_t3_cc.npz", 2, rx4.PROTO_DMR, 2, 1),
+         ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 0, 0), ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 2, 0)]
+
+
+@pytest.mark.parametrize("cap,lpf,proto,rf_mod,inv", CASES)
+@pytest.mark.parametrize("use_filter", [1, 0])
+def test_captures_bit_exact_with_call_splits(built, cap, lpf, proto, rf_mod, inv, use_filter):
+    disc = rx4.capture_disc(cap, lpf)[:96000]
+    n = len(disc)
+    # channel c = the capture delayed by 37 * c samples behind noise, channel 3 negated, channel 4 = silence then signal
+    B = 6
+    rng = np.random.default_rng(3)
+    x = np.zeros((B, n), np.float32)
+    for c in range(B):
+        d = 37 * c
+        x[c, :d] = rng.standard_normal(d) * 500
+        x[c, d:] = disc[:n - d]
+    x[3] = -x[3]
+    x[4, :25000] = 0
+    gpu = ddn.Fsk4Rx(B, ddn.FSK4_DMR if proto == rx4.PROTO_DMR else ddn.FSK4_NXDN48, rf_mod=rf_mod, inverted=inv,
+                     use_matched_filter=use_filter)
+    cpu = [rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf_mod, use_filter=use_filter, inverted=inv)) for _ in range(B)]
+    cuts = [0, 4097, 4097 + 63, 30000, 30001, 61000, n]
+    total_sync = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got = gpu.run_host(x[:, a:b])
+        for c in range(B):
+            want = cpu[c].run(x[c, a:b], max_sync=got["sync_pos"].shape[1])
+            check_channel(got, c, want)
+            total_sync += len(want["sync_pos"])
+            assert np.array_equal(gpu.thresholds(c).view(np.uint32), cpu[c].thresholds().view(np.uint32)), (c, a)
+    assert total_sync > 60
+
+
+def test_carrier_loss_and_custom_lock_lengths(built):
+    """gaps long enough for the 1800-symbol timeout (filter memory goes stale, slicer and timing reset), per-channel handler
+    lengths incl. 0 (sync reported, no in-frame symbols)"""
+    disc = rx4.capture_disc("iq_dmr_t3_ras_cc.npz", 2)
+    rng = np.random.default_rng(8)
+    gap = (rng.standard_normal(26000) * 300).astype(np.float32)
+    one = np.concatenate([disc[:30000], gap, disc[5000:45000], np.zeros(21000, np.float32), disc[:20000]])
+    B = 5
+    x = np.stack([np.roll(one, 11 * c) for c in range(B)])
+    lock = np.array([[120, 1782, 0, 0], [0, 0, 0, 0], [54, 54, 0, 0], [700, 1, 0, 0], [2000, 2000, 0, 0]], np.int32)
+    gpu = ddn.Fsk4Rx(B, ddn.FSK4_DMR, rf_mod=2)
+    assert ddn.lib().ddn_fsk4_rx_set_lock_symbols(gpu.h, lock.ctypes.data) == 0
+    cpu = [rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_DMR, rf_mod=2, lock=[int(v) for v in lock[c]])) for c in range(B)]
+    half = x.shape[1] // 2 + 5
+    for part in (slice(0, half), slice(half, None)):
+        got = gpu.run_host(x[:, part])
+        for c in range(B):
+            check_channel(got, c, cpu[c].run(x[c, part], max_sync=got["sync_pos"].shape[1]))
+    assert int(got["n_sync"][1]) > 50            # lock 0: every burst's sync is reported
+
+
+def test_wide_batch_both_wave_shapes(built):
+    """more channels than one workgroup row, and the 32-channel shape (> 8192 channels)"""
+    disc = rx4.capture_disc("iq_dmr_t3_ras_cc.npz", 2)[:20000]
+    for B in (70, 8200):
+        x = np.stack([np.roll(disc, 3 * (c % 97)) * (1.0 if c % 5 else -1.0) for c in range(B)]).astype(np.float32)
+        got = ddn.Fsk4Rx(B, ddn.FSK4_DMR).run_host(x)
+        for c in list(range(0, B, max(1, B // 9))) + [B - 1]:
+            check_channel(got, c, rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_DMR)).run(x[c], max_sync=got["sync_pos"].shape[1]))
+
+
+def test_dmr_known_answers_on_device(built):
+    """RAS control-channel capture, everything after the front end on the device: receive loop -> burst gather -> Golay(20,8)
+    slot type -> BPTC(196,96): colour code 0 on every burst ("Color Code=00") and C_ALOHA system identity Large / net 1 /
+    site 1 (tests/CMakeLists.txt:8936-8947)."""
+    import torch
+    l = ddn.lib()
+    disc = rx4.capture_disc("iq_dmr_t3_ras_cc.npz", 2)
+    B, n = 4, len(disc)
+    x = torch.from_numpy(np.stack([np.roll(disc, 17 * c) for c in range(B)])).cuda()
+    rx = ddn.Fsk4Rx(B, ddn.FSK4_DMR, rf_mod=2)
+    ms, my = l.ddn_fsk4_rx_max_symbols(rx.h, n), l.ddn_fsk4_rx_max_syncs(rx.h, n)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+    rec, fl, pay = z((B, ms, 10), torch.uint8), z((B, ms), torch.uint8), z((B, ms, 2), torch.uint8)
+    cnt, ns, spos = z((B,), torch.int32), z((B,), torch.int32), z((B, my), torch.int32)
+    spat, pre, prel = z((B, my), torch.uint8), z((B, my, 90), torch.uint8), z((B, my, 90), torch.uint8)
+    p = lambda t: t.data_ptr()
+    assert l.ddn_fsk4_rx_run(rx.h, p(x), n, p(rec), p(fl), p(pay), p(cnt), ms, p(spos), p(spat), p(pre), p(prel), p(ns), my, None) == 0
+    S = B * my
+    st, info, cach, valid = z((S, 20), torch.uint8), z((S, 196), torch.uint8), z((S, 24), torch.uint8), z((S,), torch.uint8)
+    assert l.ddn_dmr_burst_gather(p(rec), p(cnt), ms, p(spos), p(pre), p(ns), B, my, 0, p(st), p(info), p(cach), p(valid), None) == 0
+    ok = z((S,), torch.uint8)
+    assert l.ddn_fec_block_code_batch(5, p(st), S, 1, None, p(ok), None) == 0
+    out96, r3, errs = z((S, 96), torch.uint8), z((S, 3), torch.uint8), z((S,), torch.int32)
+    assert l.ddn_fec_bptc_196x96_batch(p(info), 1, S, p(out96), p(r3), p(errs), None) == 0
+    torch.cuda.synchronize()
+    valid, ok, st, out96, errs, ns_h = (t.cpu().numpy() for t in (valid, ok, st, out96, errs, ns))
+    n_aloha = 0
+    for c in range(B):
+        rows = [c * my + k for k in range(1, int(ns_h[c])) if valid[c * my + k]]
+        assert len(rows) >= 55
+        for r in rows:
+            assert ok[r] == 1 and rx4.bits_int(st[r][:4]) == 0 and rx4.bits_int(st[r][4:8]) == 3 and errs[r] == 0
+            pdu = out96[r]
+            if rx4.bits_int(pdu[2:8]) == 25:
+                n_aloha += 1
+                assert rx4.bits_int(pdu[40:42]) == 2 and rx4.bits_int(pdu[42:46]) == 1 and rx4.bits_int(pdu[46:54]) == 1
+    assert n_aloha >= 40
