@@ -92,7 +92,7 @@ def test_carrier_loss_and_custom_lock_lengths(built):
         got = gpu.run_host(x[:, part])
         for c in range(B):
             check_channel(got, c, cpu[c].run(x[c, part], max_sync=got["sync_pos"].shape[1]))
-    assert int(got["n_sync"][1]) > 50            # lock 0: every burst's sync is reported
+    assert int(got["n_sync"][1]) > 20            # lock 0: every burst of the second half reports its sync
 
 
 def test_wide_batch_both_wave_shapes(built):
