@@ -55,6 +55,7 @@ struct ddn_fsk4_rx {
     DdnFsk4Config dc;
     DdnFsk4State* d_state;
     float *d_lbuf, *d_shist, *d_fhist, *d_fstale, *d_filt, *d_taps;
+    DdnFsk4Config* d_cfg;
     uint8_t *d_phist, *d_rhist;
     int32_t* d_lock;
     size_t filt_cap;
@@ -74,6 +75,7 @@ rx4_free(ddn_fsk4_rx* b) {
     (void)hipFree(b->d_fstale);
     (void)hipFree(b->d_filt);
     (void)hipFree(b->d_taps);
+    (void)hipFree(b->d_cfg);
     (void)hipFree(b->d_lock);
     for (int i = 0; i < 3; i++) {
         if (b->ev[i]) {
@@ -206,7 +208,8 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         || hipMalloc(&b->d_phist, DDN_FSK4_HIST * B) != hipSuccess || hipMalloc(&b->d_rhist, DDN_FSK4_HIST * B) != hipSuccess
         || hipMalloc(&b->d_fhist, sizeof(float) * (DDN_FSK4_MAX_TAPS - 1) * B) != hipSuccess
         || hipMalloc(&b->d_fstale, sizeof(float) * (DDN_FSK4_MAX_TAPS - 1) * B) != hipSuccess
-        || hipMalloc(&b->d_taps, sizeof(taps)) != hipSuccess || hipMalloc(&b->d_lock, sizeof(int32_t) * 4 * B) != hipSuccess
+        || hipMalloc(&b->d_taps, sizeof(taps)) != hipSuccess || hipMalloc(&b->d_cfg, sizeof(DdnFsk4Config)) != hipSuccess
+        || hipMemcpy(b->d_cfg, &b->dc, sizeof(DdnFsk4Config), hipMemcpyHostToDevice) != hipSuccess || hipMalloc(&b->d_lock, sizeof(int32_t) * 4 * B) != hipSuccess
         || hipMemcpy(b->d_taps, taps, sizeof(taps), hipMemcpyHostToDevice) != hipSuccess
         || hipMemcpy(b->d_lock, lock.data(), sizeof(int32_t) * 4 * B, hipMemcpyHostToDevice) != hipSuccess) {
         ddn_set_error("ddn_fsk4_rx_create: device allocation failed");
@@ -308,9 +311,16 @@ ddn_fsk4_rx_run(ddn_fsk4_rx* b, const float* d_disc, size_t n, uint8_t* d_record
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[1], st));
     }
-    HIP_TRY(ddn_dev_fsk4_rx(d_disc, b->d_filt, b->d_fhist, b->d_fstale, b->d_taps, (long)n, n, B, &b->dc, b->d_state, b->d_lbuf,
+    if (const char* e = getenv("DDN_RX4_DBG")) {
+        if (b->dc.dbg != atoi(e)) {
+            b->dc.dbg = atoi(e);
+            HIP_TRY(hipMemcpy(b->d_cfg, &b->dc, sizeof(DdnFsk4Config), hipMemcpyHostToDevice));
+        }
+    }
+    HIP_TRY(ddn_dev_fsk4_rx(d_disc, b->d_filt, b->d_fhist, b->d_fstale, b->d_taps, (long)n, n, B, b->d_cfg, b->d_state, b->d_lbuf,
                             b->d_shist, b->d_phist, b->d_rhist, d_records10, d_flags, d_payload2, d_counts, max_symbols, b->d_lock,
-                            d_sync_pos, d_sync_pat, d_pre, d_pre_rel, d_n_sync, (int)max_syncs, b->channels_per_wave, st));
+                            d_sync_pos, d_sync_pat, d_pre, d_pre_rel, d_n_sync, (int)max_syncs, b->channels_per_wave,
+                            b->dc.out_rate / b->dc.sym_rate + (b->dc.out_rate % b->dc.sym_rate ? 1 : 0), st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
     }

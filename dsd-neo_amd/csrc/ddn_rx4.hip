@@ -31,6 +31,8 @@
 
 namespace {
 constexpr int TS = 64;
+constexpr int RTILES = 4;               // staged tiles per channel (power of two: ring index = sample index & RMASK)
+constexpr int RMASK = RTILES * TS - 1;
 constexpr int HN = DDN_FSK4_HIST;
 
 template <int CPW>
@@ -39,8 +41,8 @@ struct Lds4 {
     float sh[HN][CPW];
     uint8_t ph[HN][CPW];
     uint8_t rh[HN][CPW];
-    float raw[2][CPW][TS + 1];
-    float flt[2][CPW][TS + 1];
+    float raw[CPW][RTILES * TS + 1]; // ring of RTILES tiles per channel; the + 1 skews the rows over the LDS banks
+    float flt[CPW][RTILES * TS + 1];
 };
 
 __device__ __forceinline__ void
@@ -97,23 +99,32 @@ adds(int i, int span, int c, int rf_mod, int l_edge) {
     return k + ((i == c - 1 || i == c + 1) ? 1 : 0);
 }
 
-template <int CPW>
+template <int CPW, int MAXW>
 __global__ __launch_bounds__(128) void
 k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
-          float* __restrict__ fstale, const float* __restrict__ taps, long n, size_t stride, int n_channels,
-          DdnFsk4Config cfg, DdnFsk4State* __restrict__ state, float* __restrict__ lbuf_store,
+          float* __restrict__ fstale, const float* __restrict__ taps, long n_long, size_t stride, int n_channels,
+          const DdnFsk4Config* __restrict__ cfgp, DdnFsk4State* __restrict__ state, float* __restrict__ lbuf_store,
           float* __restrict__ shist_store, uint8_t* __restrict__ phist_store, uint8_t* __restrict__ rhist_store,
           uint8_t* __restrict__ rec, uint8_t* __restrict__ flags, uint8_t* __restrict__ pay, int32_t* __restrict__ counts,
           size_t max_sym, const int32_t* __restrict__ lock4, int32_t* __restrict__ sync_pos, uint8_t* __restrict__ sync_pat,
           uint8_t* __restrict__ pre, uint8_t* __restrict__ pre_rel, int32_t* __restrict__ n_sync, int max_sync) {
     extern __shared__ unsigned char smem_raw[];
     Lds4<CPW>& L = *reinterpret_cast<Lds4<CPW>*>(smem_raw);
+    const int n = (int)n_long; // the C-ABI keeps a call below 2^31 samples
     const int lane = threadIdx.x & 63;
     const bool loader = threadIdx.x >= 64;
     const int ch0 = blockIdx.x * CPW;
     const int ch = ch0 + lane;
     const bool live = !loader && lane < CPW && ch < n_channels;
     const int ln = lane < CPW ? lane : 0;
+    // the profile lives in device memory; its scalars are read once (uniform loads), its arrays only where a sync is handled
+    struct {
+        int out_rate, sym_rate, rf_mod, win_len, t_max, warm_len, n_pat, confirm, dmr_window, redigitize, slow_type, use_filter, nt, dbg;
+        const uint32_t* pat_bits;
+        const uint8_t *pat_type, *pat_neg, *pat_class;
+    } cfg = {cfgp->out_rate, cfgp->sym_rate, cfgp->rf_mod, cfgp->win_len, cfgp->t_max, cfgp->warm_len, cfgp->n_pat, cfgp->confirm,
+             cfgp->dmr_window, cfgp->redigitize, cfgp->slow_type, cfgp->use_filter, cfgp->nt, cfgp->dbg,
+             cfgp->pat_bits, cfgp->pat_type, cfgp->pat_neg, cfgp->pat_class};
     const bool use_flt = cfg.use_filter != 0;
     const int NT = cfg.nt;
 
@@ -131,8 +142,17 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     } else {
         s = DdnFsk4State{};
     }
-    auto stage = [&](long t0, int buf) {
+    // Staged input = a ring of four 64-sample tiles per channel (sample g of the call sits at ring index g & 255): while the
+    // symbols STARTING in tile t are evaluated, tile t + 1 is already complete and the loader wave fills t + 2, so a symbol is
+    // always read whole - no symbol straddles a staging boundary (with 16 unsynchronised channels per wavefront some lane
+    // would, on nearly every trip, and drag the whole wavefront through the sample-at-a-time loop).
+    auto stage = [&](int t) {
+        const long t0 = (long)t * TS;
+        if (t0 >= n) {
+            return;
+        }
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        const int slot = (t & (RTILES - 1)) * TS;
 #pragma unroll
         for (int h = 0; h < CPW / 16; h++) {
             float r[16], f[16];
@@ -146,13 +166,14 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                L.raw[buf][16 * h + c][lane] = r[c];
-                L.flt[buf][16 * h + c][lane] = f[c];
+                L.raw[16 * h + c][slot + lane] = r[c];
+                L.flt[16 * h + c][slot + lane] = f[c];
             }
         }
     };
-    if (loader && n > 0) {
-        stage(0, 0);
+    if (loader) {
+        stage(0);
+        stage(1);
     }
     __syncthreads();
 
@@ -165,20 +186,22 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     uint8_t* fp = flags + (size_t)(live ? ch : 0) * max_sym;
     uint8_t* pp = pay + (size_t)(live ? ch : 0) * max_sym * 2;
     const long long abs0 = s.n_abs;
-    int buf = 0;
-    for (long t0 = 0; t0 < n; t0 += TS, buf ^= 1) {
-        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+    int pos = 0; // call-relative index of this lane's next sample
+    const float* rrow = &L.raw[ln][0];
+    const float* frow = &L.flt[ln][0];
+    const int n_tiles = (n + TS - 1) / TS;
+    for (int t = 0; t < n_tiles; t++) {
+        const int tile_end = (t + 1) * TS < n ? (t + 1) * TS : n; // symbols starting before this index belong to this round
+        const int lim = (t + 2) * TS < n ? (t + 2) * TS : n;       // samples staged so far
         if (loader) {
-            if (t0 + TS < n) {
-                stage(t0 + TS, buf ^ 1);
-            }
+            stage(t + 2);
         } else {
-            int sp = 0, guard = 0;
+            int guard = 0;
             auto snapshot_filter = [&]() { // the filter's memory at the moment it is gated off
                 if (!s.filter_on) {
                     return;
                 }
-                const long long tnext = abs0 + t0 + sp;
+                const long long tnext = abs0 + pos;
                 float* fs = fstale + (size_t)ch * (DDN_FSK4_MAX_TAPS - 1);
                 for (int k = 0; k < NT - 1; k++) {
                     const long long ja = tnext - (NT - 1) + k;
@@ -209,7 +232,9 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
             };
             while (true) {
-                if (live && sp < tn && !s.in_symbol) {
+                bool began = false;
+                if (live && pos < tile_end && !s.in_symbol) {
+                    began = true;
                     if (s.need_reset) {
                         timing_reset(s);
                     }
@@ -243,19 +268,27 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 const int l_edge = (cfg.dmr_window && s.lastsync != 0) ? 1 : 2;
                 const bool clip = s.have_sync && cfg.rf_mod == 0;
+                // per-symbol constants: which staged row feeds the symbol, the window as integer bounds
+                const bool fo_now = s.filter_on != 0;
+                const bool steady = !fo_now || (cfg.dbg & 128) || (abs0 + pos - s.filt_start) >= (long long)(NT - 1);
+                const float* rowp = fo_now ? frow : rrow;
+                const bool rf0 = cfg.rf_mod == 0;
+                const bool lean = s.span >= 6;
+                const int cw = s.centre;
+                const int wlo = rf0 ? cw - l_edge : cw - 1, whi = rf0 ? cw + 2 : cw + 1;
+                const bool two = !rf0; // GFSK: only the two edge samples wlo and whi
+                const bool has20 = s.span == 20;
+                const float up_lim = s.maxref * 1.25f, dn_lim = s.minref * 1.25f;
+                const int left = s.span - s.i; // samples this symbol still needs
                 // In-frame fast path: no slip, crossing latch already set -> only the window samples and the last one matter
-                if (live && s.in_symbol && s.i == 0 && s.have_sync && s.jitter >= 0 && s.span >= 6 && sp + s.span <= tn
-                    && (!s.filter_on || (abs0 + t0 + sp - s.filt_start) >= (long long)(NT - 1))) {
-                    const bool fo = s.filter_on != 0;
-                    const int c = s.centre;
-                    const int lo = s.span == 20 ? 7 : (cfg.rf_mod == 0 ? c - l_edge : c - 1);
-                    const int hi = s.span == 20 ? 13 : (cfg.rf_mod == 0 ? c + 2 : c + 1);
+                if (live && began && lean && steady && s.have_sync && s.jitter >= 0 && pos + left <= n && !(cfg.dbg & 4)) {
+                    const int lo = has20 ? 7 : wlo, hi = has20 ? 13 : whi;
                     float acc = 0.0f;
                     int cnt = 0;
                     for (int i = lo; i <= hi; i++) {
-                        const int a = adds(i, s.span, c, cfg.rf_mod, l_edge);
+                        const int a = adds(i, s.span, cw, cfg.rf_mod, l_edge);
                         if (a) {
-                            float x = fo ? L.flt[buf][ln][sp + i] : L.raw[buf][ln][sp + i];
+                            float x = rowp[(pos + i) & RMASK];
                             if (clip) {
                                 x = x > s.max ? s.max : (x < s.min ? s.min : x);
                             }
@@ -266,55 +299,91 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             cnt += a;
                         }
                     }
-                    const int jl = sp + s.span - 1;
-                    float xl = fo ? L.flt[buf][ln][jl] : L.raw[buf][ln][jl];
+                    float xl = rowp[(pos + s.span - 1) & RMASK];
                     if (clip) {
                         xl = xl > s.max ? s.max : (xl < s.min ? s.min : xl);
                     }
                     s.sum = acc;
                     s.count = cnt;
                     s.lastsample = xl;
-                    sp += s.span;
+                    pos += s.span;
                     s.i = s.span;
+                } else if (live && began && lean && steady && pos + left <= n && left <= MAXW && !(cfg.dbg & 256)) {
+                    // Whole-symbol pass (hunting, or in frame before the latch is set): every sample read issued up front,
+                    // then crossing latch + window sums in sample order - the arithmetic of the sample-at-a-time loop below
+                    const int i0 = s.i;
+                    float xs[MAXW];
+#pragma unroll
+                    for (int k = 0; k < MAXW; k++) {
+                        xs[k] = rowp[(pos + (k < left ? k : 0)) & RMASK];
+                    }
+                    float last = s.lastsample, sum = 0.0f;
+                    int jit = s.jitter, c = 0;
+#pragma unroll
+                    for (int k = 0; k < MAXW; k++) {
+                        if (k < left) {
+                            float x = xs[k];
+                            if (clip) {
+                                x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                            }
+                            const int i = i0 + k;
+                            const bool up = x > s.center;
+                            const bool within = up ? !(x > up_lim) : !(x < dn_lim);
+                            const bool crossed = up ? (last < s.center) : (last > s.center);
+                            jit = (jit < 0 && within && crossed) ? i : jit;
+                            const bool k1 = two ? (i == wlo || i == whi) : (i >= wlo && i <= whi);
+                            const bool k2 = has20 && i >= 7 && i <= 13;
+                            if (k2) {
+                                sum += x;
+                            }
+                            if (k1) {
+                                sum += x;
+                            }
+                            c += (k1 ? 1 : 0) + (k2 ? 1 : 0);
+                            last = x;
+                        }
+                    }
+                    s.sum = sum;
+                    s.count = c;
+                    s.jitter = jit;
+                    s.lastsample = last;
+                    s.i = s.span;
+                    pos += left;
                 }
-                bool act = live && sp < tn && s.i < s.span;
+                // sample-at-a-time loop: a symbol carried over a call boundary, the filter's cold start, very short symbols
+                bool act = live && s.in_symbol && pos < lim && s.i < s.span;
                 while (__any(act)) {
                     if (act) {
-                        float x = L.raw[buf][ln][sp];
-                        if (s.filter_on) {
-                            const long long a = abs0 + t0 + sp;
-                            if (a - s.filt_start >= (long long)(NT - 1)) {
-                                x = L.flt[buf][ln][sp];
-                            } else { // first NT-1 samples after the enable: FIR over the filter's stale memory + new samples
-                                const long k = t0 + sp;
-                                float acc = 0.0f;
-                                for (int i = 0; i < NT; i++) {
-                                    const long j = k - (NT - 1) + i;
-                                    float v;
-                                    if (abs0 + j >= s.filt_start) {
-                                        v = (j >= 0) ? raw[(size_t)ch * stride + j]
-                                                     : prev_tail[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1) + (NT - 1) + j];
-                                    } else {
-                                        v = fstale[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1)
-                                                   + (size_t)((abs0 + j - s.filt_start) + (NT - 1))];
-                                    }
-                                    acc += taps[i] * v;
+                        float x;
+                        if (!fo_now) {
+                            x = rrow[pos & RMASK];
+                        } else if ((cfg.dbg & 128) || (abs0 + pos - s.filt_start) >= (long long)(NT - 1)) {
+                            x = frow[pos & RMASK];
+                        } else { // first NT-1 samples after the enable: FIR over the filter's stale memory + new samples
+                            float acc = 0.0f;
+                            for (int i = 0; i < NT; i++) {
+                                const long j = (long)pos - (NT - 1) + i;
+                                float v;
+                                if (abs0 + j >= s.filt_start) {
+                                    v = (j >= 0) ? raw[(size_t)ch * stride + j]
+                                                 : prev_tail[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1) + (NT - 1) + j];
+                                } else {
+                                    v = fstale[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1)
+                                               + (size_t)((abs0 + j - s.filt_start) + (NT - 1))];
                                 }
-                                x = acc;
+                                acc += taps[i] * v;
                             }
+                            x = acc;
                         }
                         if (clip) {
                             x = x > s.max ? s.max : (x < s.min ? s.min : x);
                         }
                         const int i = s.i;
-                        if (s.jitter < 0) {
-                            if (x > s.center) {
-                                if (!(x > s.maxref * 1.25f) && s.lastsample < s.center) {
-                                    s.jitter = i;
-                                }
-                            } else if (!(x < s.minref * 1.25f) && s.lastsample > s.center) {
-                                s.jitter = i;
-                            }
+                        {
+                            const bool up = x > s.center;
+                            const bool within = up ? !(x > up_lim) : !(x < dn_lim);
+                            const bool crossed = up ? (s.lastsample < s.center) : (s.lastsample > s.center);
+                            s.jitter = (s.jitter < 0 && within && crossed) ? i : s.jitter;
                         }
                         const int a = adds(i, s.span, s.centre, cfg.rf_mod, l_edge);
                         if (a) {
@@ -326,9 +395,9 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         }
                         s.lastsample = x;
                         s.i++;
-                        sp++;
+                        pos++;
                     }
-                    act = live && sp < tn && s.i < s.span;
+                    act = live && s.in_symbol && pos < lim && s.i < s.span;
                 }
                 // ---- symbol commit ----------------------------------------------------------------------------------
                 if (live && s.in_symbol && s.i >= s.span) {
@@ -341,10 +410,14 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     int dibit, relb = 0, l0 = 0, l1 = 0, fl = 0, pd, pr;
                     const ddn_sl::Thr th = {s.center, s.umid, s.lmid, s.max, s.min};
                     if (s.have_sync) {
-                        const int neg = cfg.pat_neg[s.cur_pat];
+                        const int neg = (cfg.dbg & 32) ? 0 : cfg.pat_neg[s.cur_pat];
                         s.maxref = s.max;
                         s.minref = s.min;
-                        ddn_sl::slice_soft(sym, th, neg, dibit, relb, l0, l1);
+                        if (cfg.dbg & 2) {
+                            dibit = 1;
+                        } else {
+                            ddn_sl::slice_soft(sym, th, neg, dibit, relb, l0, l1);
+                        }
                         pd = neg ? (dibit ^ 2) : dibit;
                         pr = relb;
                         L.ph[slot][ln] = (uint8_t)pd;
@@ -362,7 +435,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         s.hist_count = s.hist_count < 24 ? s.hist_count + 1 : 24;
                         dibit = bit ? 1 : 3;
                         pd = slice4(sym, s);
-                        pr = ddn_sl::rel_from_thresholds(sym, th);
+                        pr = (cfg.dbg & 2) ? 0 : ddn_sl::rel_from_thresholds(sym, th);
                         L.ph[slot][ln] = (uint8_t)pd;
                         L.rh[slot][ln] = (uint8_t)pr;
                         bool accepted = false;
@@ -370,7 +443,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             s.maxref = s.max;
                             s.minref = s.min;
                             int hit = -1;
-                            if (s.hist_count >= cfg.win_len) {
+                            if (s.hist_count >= cfg.win_len && !(cfg.dbg & 8)) {
                                 const uint32_t w = s.hist_bits & wmask;
                                 for (int k = cfg.n_pat - 1; k >= 0; k--) {
                                     hit = (w == cfg.pat_bits[k]) ? k : hit; // lowest matching index wins, as a forward scan
@@ -412,7 +485,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 s.lastsync = type;
                                 if (use_flt && !s.filter_on) {
                                     s.filter_on = 1;
-                                    s.filt_start = abs0 + t0 + sp;
+                                    s.filt_start = abs0 + pos;
                                 }
                                 if (accepted) {
                                     const int wl = cfg.redigitize ? 24 : cfg.warm_len;
@@ -454,7 +527,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     s.cur_pat = hit;
                                     s.lock_left = lock4[(size_t)ch * 4 + (cfg.pat_class[hit] & 3)];
                                     fl = 2 | (cfg.pat_neg[hit] ? 4 : 0) | (hit << 3);
-                                    if (ns < max_sync) {
+                                    if (ns < max_sync && !(cfg.dbg & 64)) {
                                         const size_t so = (size_t)ch * max_sync + ns;
                                         sync_pos[so] = o;
                                         sync_pat[so] = (uint8_t)hit;
@@ -477,7 +550,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             hunt_advance();
                         }
                     }
-                    if ((size_t)o < max_sym) {
+                    if ((size_t)o < max_sym && !(cfg.dbg & 1)) {
                         uint8_t* r = rp + (size_t)o * 10;
                         const uint32_t xb = __float_as_uint(sym);
                         ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
@@ -490,8 +563,8 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     }
                     o++;
                 }
-                const bool busy = live && sp < tn;
-                if (!__any(busy) || ++guard > 2 * TS) {
+                const bool busy = live && pos < tile_end && !s.in_symbol;
+                if (!__any(busy) || ++guard > 4 * TS) {
                     break;
                 }
             }
@@ -612,7 +685,7 @@ k_dmr_burst_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ 
     }
 }
 
-template <int CPW>
+template <int CPW, int MAXW>
 hipError_t
 launch(const float* raw, const float* filt, const float* prev_tail, float* fstale, const float* taps, long n, size_t stride,
        int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state, float* lbuf_store, float* shist_store,
@@ -620,12 +693,12 @@ launch(const float* raw, const float* filt, const float* prev_tail, float* fstal
        size_t max_sym, const int32_t* lock4, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel,
        int32_t* n_sync, int max_sync, hipStream_t st) {
     const size_t shmem = sizeof(Lds4<CPW>);
-    hipError_t e = hipFuncSetAttribute((const void*)k_fsk4_rx<CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = hipFuncSetAttribute((const void*)k_fsk4_rx<CPW, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) {
         return e;
     }
-    hipLaunchKernelGGL((k_fsk4_rx<CPW>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shmem, st, raw, filt,
-                       prev_tail, fstale, taps, n, stride, n_channels, *cfg, state, lbuf_store, shist_store, phist_store,
+    hipLaunchKernelGGL((k_fsk4_rx<CPW, MAXW>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shmem, st, raw, filt,
+                       prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store, phist_store,
                        rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel, n_sync,
                        max_sync);
     return hipGetLastError();
@@ -637,18 +710,28 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
                 size_t stride, int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state, float* lbuf_store,
                 float* shist_store, uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec, uint8_t* flags, uint8_t* pay,
                 int32_t* counts, size_t max_sym, const int32_t* lock4, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre,
-                uint8_t* pre_rel, int32_t* n_sync, int max_sync, int channels_per_wave, hipStream_t st) {
+                uint8_t* pre_rel, int32_t* n_sync, int max_sync, int channels_per_wave, int cfg_sps, hipStream_t st) {
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
+    // MAXW: the longest whole symbol the straight pass takes (samples per symbol + one slip sample); 12 covers 4800 baud at
+    // 48 ksps, 22 covers 2400 baud
+    const int sps = cfg_sps > 0 ? cfg_sps : 64;
+#define DDN_RX4_GO(CPW_, MAXW_)                                                                                            \
+    return launch<CPW_, MAXW_>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store, \
+                               phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre,    \
+                               pre_rel, n_sync, max_sync, st)
     if (channels_per_wave <= 16) {
-        return launch<16>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store,
-                          phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel,
-                          n_sync, max_sync, st);
+        if (sps <= 11) {
+            DDN_RX4_GO(16, 12);
+        }
+        DDN_RX4_GO(16, 22);
     }
-    return launch<32>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store,
-                      phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel,
-                      n_sync, max_sync, st);
+    if (sps <= 11) {
+        DDN_RX4_GO(32, 12);
+    }
+    DDN_RX4_GO(32, 22);
+#undef DDN_RX4_GO
 }
 
 extern "C" hipError_t
