@@ -347,6 +347,7 @@ def main():
         if world == 1 and not args.no_extras:
             line["front_end_stage"] = front_end_stage(torch, ddn, chain, d_iq, B, n, 12)
             line["pcie_inclusive"] = pcie_inclusive(torch, chain, d_iq, B, n)
+            line["configs3_mixed"] = configs3_mixed(torch, ddn, np, chain, d_iq, B, n, 6)
         if cpu is not None:
             line["cpu_baseline"] = cpu
             line["speedup_vs_cpu_1core"] = round(msps / world / cpu["value"], 1)
@@ -355,6 +356,108 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def configs3_mixed(torch, ddn, np, p25_chain, d_iq_p25, B_total, n, steps):
+    """BASELINE configs[3] shape on one GPU (informational; never `value`): B_total channels split in thirds between P25 Phase 1
+    (the headline traffic), DMR and NXDN48.  DMR / NXDN48 traffic = the committed regression captures (tests/golden), every
+    channel a different rotation; each protocol's chain runs back to back on one stream.  Parity: 3 channels per protocol
+    against the CPU restatement, bit-exact records / payload / sync hand-over."""
+    import ddn_chain
+    import ddn_chain_fsk4
+    import rx4
+    from conftest import golden
+    third = B_total // 3
+    Bp, Bd, Bn = B_total - 2 * third, third, third
+    dev = d_iq_p25.device
+    st = torch.cuda.current_stream().cuda_stream
+
+    def tile(name, lo, hi, Bc):
+        iq = torch.from_numpy(np.ascontiguousarray(golden(name)["iq"][lo:hi], np.uint8)).to(dev)       # [m][2]
+        m = iq.shape[0]
+        off = (torch.arange(Bc, device=dev) * 37) % (m - n)
+        idx = off[:, None] + torch.arange(n, device=dev)[None, :]
+        return iq[idx].contiguous(), off.cpu().numpy(), iq.cpu().numpy()
+
+    d_dmr, off_d, iq_d = tile("iq_dmr_t3_ras_cc.npz", 0, 96000, Bd)
+    d_nx, off_n, iq_n = tile("iq_nxdn48.npz", 60000, 288000, Bn)
+    lockp = np.array([840 if (c % 2 == 0) else 156 for c in range(Bp)], np.int32)
+    cp = ddn_chain.P25Chain(torch, Bp, n, lockp, block_len=BLOCK)
+    cd = ddn_chain_fsk4.Fsk4Chain(torch, Bd, n, ddn.FSK4_DMR, rf_mod=2, block_len=BLOCK)
+    cn = ddn_chain_fsk4.Fsk4Chain(torch, Bn, n, ddn.FSK4_NXDN48, rf_mod=0, block_len=BLOCK)
+    d_p25 = d_iq_p25[:Bp]
+
+    # parity (first call of fresh batches = fresh CPU states)
+    cd.run(d_dmr, st)
+    cn.run(d_nx, st)
+    torch.cuda.synchronize()
+    import orc
+    par_ok, checked = True, 0
+    for chain, proto, lpf, iq, offs, rf in ((cd, rx4.PROTO_DMR, 2, iq_d, off_d, 2), (cn, rx4.PROTO_NXDN48, 1, iq_n, off_n, 0)):
+        rec, fl, pay, cnt = (t.cpu().numpy() for t in (chain.rec, chain.fl, chain.pay, chain.cnt))
+        spos, pre, ns = (t.cpu().numpy() for t in (chain.spos, chain.pre, chain.ns))
+        for c in (0, chain.B // 2, chain.B - 1):
+            x = iq[offs[c]:offs[c] + n]
+            disc = orc.OracleFrontEnd(profile=lpf).run_cu8(np.ascontiguousarray(x), BLOCK)
+            want = rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf)).run(disc, max_sync=spos.shape[1])
+            k = int(cnt[c])
+            r = rec[c, :k]
+            ok = (k == len(want["sym"]) and np.array_equal(r[:, 6:10].copy().view(np.uint32).reshape(-1), want["sym"].view(np.uint32))
+                  and np.array_equal(r[:, 0].astype(np.int32), want["rec4"][:, 0]) and np.array_equal(fl[c, :k], want["fl"])
+                  and np.array_equal(pay[c, :k], want["pay"]) and int(ns[c]) == len(want["sync_pos"])
+                  and np.array_equal(spos[c, :int(ns[c])], want["sync_pos"]) and np.array_equal(pre[c, :int(ns[c])], want["pre"]))
+            par_ok = par_ok and bool(ok)
+            checked += 1
+    # DMR known answer on the device outputs: colour code 0, CSBK, BPTC clean on every complete burst
+    valid, st_ok, stb, errs = (t.cpu().numpy() for t in (cd.valid, cd.st_ok, cd.st, cd.errs))
+    rows = np.flatnonzero(valid)
+    rows = rows[(rows % cd.my) != 0]
+    cc_ok = bool(len(rows) > 0 and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0) and np.mean(errs[rows] == 0) > 0.99)
+
+    l = ddn.lib()
+    for _ in range(3):
+        cp.run(d_p25, st)
+        cd.run(d_dmr, st)
+        cn.run(d_nx, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cp.run(d_p25, st)
+        cd.run(d_dmr, st)
+        cn.run(d_nx, st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ms = np.zeros(3)
+    for _ in range(4):
+        ev[0].record()
+        cp.run(d_p25, st)
+        ev[1].record()
+        cd.run(d_dmr, st)
+        ev[2].record()
+        cn.run(d_nx, st)
+        ev[3].record()
+        torch.cuda.synchronize()
+        ms += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+    ms /= 4
+    l.ddn_fsk4_rx_set_timing(cd.rx.h, 1)
+    l.ddn_fsk4_rx_set_timing(cn.rx.h, 1)
+    cd.run(d_dmr, st)
+    cn.run(d_nx, st)
+    t2d, t2n = np.zeros(2, np.float32), np.zeros(2, np.float32)
+    l.ddn_fsk4_rx_get_timing(cd.rx.h, t2d.ctypes.data)
+    l.ddn_fsk4_rx_get_timing(cn.rx.h, t2n.ctypes.data)
+    out = {"workload": "configs[3] shape on one GPU: %d channels = %d P25 Phase 1 + %d DMR (Tier III control channel capture, GFSK rules) + "
+                       "%d NXDN48 (capture), %d cu8 samples each; per protocol front end -> matched filter -> receive loop -> frame FEC "
+                       "(DMR: burst gather + Golay(20,8) + BPTC(196,96); NXDN48: to dibits)" % (B_total, Bp, Bd, Bn, n),
+           "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(B_total * n / dt / 1e6, 1),
+           "chain_ms": {"p25p1": round(float(ms[0]), 3), "dmr": round(float(ms[1]), 3), "nxdn48": round(float(ms[2]), 3)},
+           "k_fsk4_rx_ms": {"dmr": round(float(t2d[1]), 3), "nxdn48": round(float(t2n[1]), 3)},
+           "parity": {"channels_checked": checked, "bit_exact": par_ok, "dmr_colour_code_0_csbk_bptc_clean": cc_ok},
+           "work_per_step": {"dmr_syncs": int(cd.ns.sum().item()), "nxdn_syncs": int(cn.ns.sum().item())}}
+    for c in (cp, cd.fe, cn.fe, cd.rx, cn.rx):
+        c.close()
+    return out
 
 
 def pcie_inclusive(torch, chain, d_iq, B, n):
