@@ -122,6 +122,14 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         ddn_set_error("ddn_fsk4_rx_create: bad configuration (protocol DMR | NXDN48, rf_mod 0 | 2, inverted only for DMR)");
         return DDN_EINVAL;
     }
+    {
+        const int sym_rate = cfg->protocol == DDN_FSK4_DMR ? 4800 : 2400;
+        if (cfg->out_rate_hz / sym_rate < 8 || cfg->out_rate_hz / sym_rate > 21) {
+            // the kernel's per-round hand-off queue and its whole-symbol pass are sized for 8..21 samples per symbol
+            ddn_set_error("ddn_fsk4_rx_create: out_rate_hz / symbol rate must be within 8..21 (48 ksps: DMR 10, NXDN48 20)");
+            return DDN_ERANGE;
+        }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         ddn_set_error("ddn_fsk4_rx_create: no HIP device");

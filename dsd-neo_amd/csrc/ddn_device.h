@@ -86,7 +86,7 @@ typedef struct DdnRxState { /* per-channel words of dsd_state / frame_sync_runti
 /* ---- profile-driven 4-level FSK receive loop (DMR / NXDN48), ddn_rx4.hip ---- */
 #define DDN_FSK4_MAX_PAT  20
 #define DDN_FSK4_MAX_TAPS 135
-#define DDN_FSK4_HIST     96
+#define DDN_FSK4_HIST     128 /* symbol / payload history kept per channel: 90 reachable + what the helper wave lags */
 #define DDN_FSK4_PRE      90
 typedef struct DdnFsk4Config {
     int out_rate, sym_rate, rf_mod, win_len, t_max, warm_len, n_pat;

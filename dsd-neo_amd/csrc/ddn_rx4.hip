@@ -34,6 +34,7 @@ constexpr int TS = 64;
 constexpr int RTILES = 4;               // staged tiles per channel (power of two: ring index = sample index & RMASK)
 constexpr int RMASK = RTILES * TS - 1;
 constexpr int HN = DDN_FSK4_HIST;
+constexpr int QCAP = 12; // symbols a lane can finish in one round (64 / 7 + 1) + one sync entry + slack
 
 template <int CPW>
 struct Lds4 {
@@ -43,6 +44,12 @@ struct Lds4 {
     uint8_t rh[HN][CPW];
     float raw[CPW][RTILES * TS + 1]; // ring of RTILES tiles per channel; the + 1 skews the rows over the LDS banks
     float flt[CPW][RTILES * TS + 1];
+    // hand-off to the helper wave, one buffer per round parity: per lane up to QCAP entries {symbol, centre, umid, lmid,
+    // max, min, meta, aux}.  meta = flags | slot << 8 | kind << 16; a sync entry (kind 1) follows the entry of the accepting
+    // symbol and carries the thresholds AFTER the warm start, meta |= redigitise << 17 | scount << 24, aux = sync index
+    float q[2][QCAP][8][CPW];
+    int qn[2][CPW];
+    int qo[2][CPW];
 };
 
 __device__ __forceinline__ void
@@ -78,10 +85,6 @@ hunt_restart(DdnFsk4State& s) {
     s.hist_bits = 0;
     s.lmin = s.min;
     s.lmax = s.max;
-}
-__device__ __forceinline__ int
-slice4(float x, const DdnFsk4State& s) {
-    return x > s.center ? (x > s.umid ? 1 : 0) : (x < s.lmid ? 3 : 2);
 }
 // how often sample i of the current symbol enters the sum (symbol_accumulate_sample)
 __device__ __forceinline__ int
@@ -136,11 +139,15 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
         for (int k = 0; k < HN; k++) {
             L.sh[k][ln] = shist_store[(size_t)k * n_channels + ch];
-            L.ph[k][ln] = phist_store[(size_t)k * n_channels + ch];
-            L.rh[k][ln] = rhist_store[(size_t)k * n_channels + ch];
         }
     } else {
         s = DdnFsk4State{};
+        if (loader && lane < CPW && ch < n_channels) {
+            for (int k = 0; k < HN; k++) {
+                L.ph[k][ln] = phist_store[(size_t)k * n_channels + ch];
+                L.rh[k][ln] = rhist_store[(size_t)k * n_channels + ch];
+            }
+        }
     }
     // Staged input = a ring of four 64-sample tiles per channel (sample g of the call sits at ring index g & 255): while the
     // symbols STARTING in tile t are evaluated, tile t + 1 is already complete and the loader wave fills t + 2, so a symbol is
@@ -182,10 +189,79 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const int rem = (whole0 < 2 || whole0 > 64) ? 0 : rem0;
     const uint32_t wmask = cfg.win_len >= 24 ? 0xFFFFFFu : ((1u << cfg.win_len) - 1u);
     int o = 0, ns = 0;
-    uint8_t* rp = rec + (size_t)(live ? ch : 0) * max_sym * 10;
-    uint8_t* fp = flags + (size_t)(live ? ch : 0) * max_sym;
-    uint8_t* pp = pay + (size_t)(live ? ch : 0) * max_sym * 2;
     const long long abs0 = s.n_abs;
+    // ---- helper wave: slice / soft decision / record + payload stores / payload history / per-sync hand-over ----------------
+    // None of it feeds back into the recurrence, so it runs one round behind on wave 1 (lane = channel) while wave 0 is
+    // already on the next tile.  The payload history ring (ph / rh) belongs to this wave alone.
+    const bool hlive = loader && lane < CPW && ch < n_channels;
+    uint8_t* hrp = rec + (size_t)(hlive ? ch : 0) * max_sym * 10;
+    uint8_t* hfp = flags + (size_t)(hlive ? ch : 0) * max_sym;
+    uint8_t* hpp = pay + (size_t)(hlive ? ch : 0) * max_sym * 2;
+    auto drain = [&](int qb) {
+        if (!hlive) {
+            return;
+        }
+        const int cnt = L.qn[qb][ln];
+        int oo = L.qo[qb][ln];
+        for (int k = 0; k < QCAP; k++) {
+            if (k >= cnt) {
+                break;
+            }
+            const float sym = L.q[qb][k][0][ln];
+            const ddn_sl::Thr th = {L.q[qb][k][1][ln], L.q[qb][k][2][ln], L.q[qb][k][3][ln], L.q[qb][k][4][ln], L.q[qb][k][5][ln]};
+            const int meta = __float_as_int(L.q[qb][k][6][ln]);
+            const int aux = __float_as_int(L.q[qb][k][7][ln]);
+            const int fl = meta & 0xFF, slot = (meta >> 8) & 0x7F;
+            if (((meta >> 16) & 1) == 0) {
+                int dibit, relb = 0, l0 = 0, l1 = 0, pd, pr;
+                if (fl & 1) {
+                    const int neg = (fl >> 2) & 1;
+                    ddn_sl::slice_soft(sym, th, neg, dibit, relb, l0, l1);
+                    pd = neg ? (dibit ^ 2) : dibit;
+                    pr = relb;
+                } else {
+                    dibit = sym > 0.0f ? 1 : 3;
+                    pd = sym > th.center ? (sym > th.umid ? 1 : 0) : (sym < th.lmid ? 3 : 2);
+                    pr = ddn_sl::rel_from_thresholds(sym, th);
+                }
+                L.ph[slot][ln] = (uint8_t)pd;
+                L.rh[slot][ln] = (uint8_t)pr;
+                if ((size_t)oo < max_sym) {
+                    uint8_t* r = hrp + (size_t)oo * 10;
+                    const uint32_t xb = __float_as_uint(sym);
+                    ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
+                    ((uint16_t*)r)[1] = (uint16_t)(int16_t)l0;
+                    ((uint16_t*)r)[2] = (uint16_t)(int16_t)l1;
+                    ((uint16_t*)r)[3] = (uint16_t)(xb & 0xFFFFu);
+                    ((uint16_t*)r)[4] = (uint16_t)(xb >> 16);
+                    hfp[oo] = (uint8_t)fl;
+                    ((uint16_t*)hpp)[oo] = (uint16_t)((pd & 3) | (pr << 8));
+                }
+                oo++;
+            } else {
+                // accepted sync: `slot` = the sync's last symbol (its own entry was handled just before), oo - 1 its index
+                const int scount = (meta >> 24) & 0xFF;
+                if ((meta >> 17) & 1) { // dmr_resample_cach(): the 66 dibits before the sync, against the warm-started thresholds
+                    for (int i = 0; i < 66; i++) {
+                        const int qi = (slot + 1 - 90 + i) & (HN - 1);
+                        const float v = L.sh[qi][ln];
+                        L.ph[qi][ln] = (uint8_t)(v > th.center ? (v > th.umid ? 1 : 0) : (v < th.lmid ? 3 : 2));
+                    }
+                }
+                if (aux < max_sync) {
+                    const size_t so = (size_t)ch * max_sync + aux;
+                    sync_pos[so] = oo - 1;
+                    sync_pat[so] = (uint8_t)((fl >> 3) & 31);
+                    for (int i = 0; i < DDN_FSK4_PRE; i++) {
+                        const int qi = (slot + 1 - DDN_FSK4_PRE + i) & (HN - 1);
+                        const bool have = (DDN_FSK4_PRE - i) <= scount;
+                        pre[so * DDN_FSK4_PRE + i] = have ? L.ph[qi][ln] : 0;
+                        pre_rel[so * DDN_FSK4_PRE + i] = have ? L.rh[qi][ln] : 0;
+                    }
+                }
+            }
+        }
+    };
     int pos = 0; // call-relative index of this lane's next sample
     const float* rrow = &L.raw[ln][0];
     const float* frow = &L.flt[ln][0];
@@ -195,8 +271,14 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
         const int lim = (t + 2) * TS < n ? (t + 2) * TS : n;       // samples staged so far
         if (loader) {
             stage(t + 2);
+            if (t > 0) {
+                drain((t - 1) & 1);
+            }
         } else {
-            int guard = 0;
+            int guard = 0, qk = 0;
+            if (live) {
+                L.qo[t & 1][ln] = o;
+            }
             auto snapshot_filter = [&]() { // the filter's memory at the moment it is gated off
                 if (!s.filter_on) {
                     return;
@@ -407,21 +489,14 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     L.sh[slot][ln] = sym;
                     s.shead = (s.shead + 1 >= HN) ? 0 : s.shead + 1;
                     s.scount = s.scount < HN ? s.scount + 1 : HN;
-                    int dibit, relb = 0, l0 = 0, l1 = 0, fl = 0, pd, pr;
-                    const ddn_sl::Thr th = {s.center, s.umid, s.lmid, s.max, s.min};
+                    int fl = 0;
+                    bool sync_entry = false;
+                    // thresholds the symbol is sliced against: as they stand before a sync on this symbol changes them
+                    const float q1 = s.center, q2 = s.umid, q3 = s.lmid, q4 = s.max, q5 = s.min;
                     if (s.have_sync) {
                         const int neg = (cfg.dbg & 32) ? 0 : cfg.pat_neg[s.cur_pat];
                         s.maxref = s.max;
                         s.minref = s.min;
-                        if (cfg.dbg & 2) {
-                            dibit = 1;
-                        } else {
-                            ddn_sl::slice_soft(sym, th, neg, dibit, relb, l0, l1);
-                        }
-                        pd = neg ? (dibit ^ 2) : dibit;
-                        pr = relb;
-                        L.ph[slot][ln] = (uint8_t)pd;
-                        L.rh[slot][ln] = (uint8_t)pr;
                         fl = 1 | (neg ? 4 : 0);
                         if (--s.lock_left <= 0) {
                             hunt_restart(s);
@@ -433,11 +508,6 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         const uint32_t bit = sym > 0.0f ? 1u : 0u;
                         s.hist_bits = ((s.hist_bits << 1) | bit) & 0xFFFFFFu;
                         s.hist_count = s.hist_count < 24 ? s.hist_count + 1 : 24;
-                        dibit = bit ? 1 : 3;
-                        pd = slice4(sym, s);
-                        pr = (cfg.dbg & 2) ? 0 : ddn_sl::rel_from_thresholds(sym, th);
-                        L.ph[slot][ln] = (uint8_t)pd;
-                        L.rh[slot][ln] = (uint8_t)pr;
                         bool accepted = false;
                         if (s.hist_count >= 8) {
                             s.maxref = s.max;
@@ -515,31 +585,12 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                                 s.minref = s.min * 0.80f;
                                             }
                                         }
-                                        if (cfg.redigitize && s.scount >= 90) { // dmr_resample_cach()
-                                            for (int i = 0; i < 66; i++) {
-                                                int q = s.shead - 90 + i;
-                                                q += q < 0 ? HN : 0;
-                                                L.ph[q][ln] = (uint8_t)slice4(L.sh[q][ln], s);
-                                            }
-                                        }
                                     }
                                     s.have_sync = 1;
                                     s.cur_pat = hit;
                                     s.lock_left = lock4[(size_t)ch * 4 + (cfg.pat_class[hit] & 3)];
                                     fl = 2 | (cfg.pat_neg[hit] ? 4 : 0) | (hit << 3);
-                                    if (ns < max_sync && !(cfg.dbg & 64)) {
-                                        const size_t so = (size_t)ch * max_sync + ns;
-                                        sync_pos[so] = o;
-                                        sync_pat[so] = (uint8_t)hit;
-                                        for (int i = 0; i < DDN_FSK4_PRE; i++) {
-                                            int q = s.shead - DDN_FSK4_PRE + i;
-                                            q += q < 0 ? HN : 0;
-                                            const bool have = (DDN_FSK4_PRE - i) <= s.scount;
-                                            pre[so * DDN_FSK4_PRE + i] = have ? L.ph[q][ln] : 0;
-                                            pre_rel[so * DDN_FSK4_PRE + i] = have ? L.rh[q][ln] : 0;
-                                        }
-                                    }
-                                    ns++;
+                                    sync_entry = true;
                                     if (s.lock_left <= 0) {
                                         hunt_restart(s);
                                     }
@@ -550,16 +601,29 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             hunt_advance();
                         }
                     }
-                    if ((size_t)o < max_sym && !(cfg.dbg & 1)) {
-                        uint8_t* r = rp + (size_t)o * 10;
-                        const uint32_t xb = __float_as_uint(sym);
-                        ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
-                        ((uint16_t*)r)[1] = (uint16_t)(int16_t)l0;
-                        ((uint16_t*)r)[2] = (uint16_t)(int16_t)l1;
-                        ((uint16_t*)r)[3] = (uint16_t)(xb & 0xFFFFu);
-                        ((uint16_t*)r)[4] = (uint16_t)(xb >> 16);
-                        fp[o] = (uint8_t)fl;
-                        ((uint16_t*)pp)[o] = (uint16_t)((pd & 3) | (pr << 8));
+                    {
+                        const int qb = t & 1;
+                        L.q[qb][qk][0][ln] = sym;
+                        L.q[qb][qk][1][ln] = q1;
+                        L.q[qb][qk][2][ln] = q2;
+                        L.q[qb][qk][3][ln] = q3;
+                        L.q[qb][qk][4][ln] = q4;
+                        L.q[qb][qk][5][ln] = q5;
+                        L.q[qb][qk][6][ln] = __int_as_float(fl | (slot << 8));
+                        qk++;
+                        if (sync_entry) {
+                            const bool redig = cfg.redigitize && s.scount >= 90 && s.scount >= 24;
+                            L.q[qb][qk][1][ln] = s.center;
+                            L.q[qb][qk][2][ln] = s.umid;
+                            L.q[qb][qk][3][ln] = s.lmid;
+                            L.q[qb][qk][4][ln] = s.max;
+                            L.q[qb][qk][5][ln] = s.min;
+                            L.q[qb][qk][6][ln] = __int_as_float(fl | (slot << 8) | (1 << 16) | (redig ? (1 << 17) : 0)
+                                                                | ((s.scount > 255 ? 255 : s.scount) << 24));
+                            L.q[qb][qk][7][ln] = __int_as_float(ns);
+                            qk++;
+                            ns++;
+                        }
                     }
                     o++;
                 }
@@ -568,8 +632,21 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     break;
                 }
             }
+            if (live) {
+                L.qn[t & 1][ln] = qk;
+            }
         }
         __syncthreads();
+    }
+    if (loader && n_tiles > 0) {
+        drain((n_tiles - 1) & 1);
+    }
+    __syncthreads();
+    if (hlive) {
+        for (int k = 0; k < HN; k++) {
+            phist_store[(size_t)k * n_channels + ch] = L.ph[k][ln];
+            rhist_store[(size_t)k * n_channels + ch] = L.rh[k][ln];
+        }
     }
     if (live) {
         s.n_abs = abs0 + n;
@@ -581,8 +658,6 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
         for (int k = 0; k < HN; k++) {
             shist_store[(size_t)k * n_channels + ch] = L.sh[k][ln];
-            phist_store[(size_t)k * n_channels + ch] = L.ph[k][ln];
-            rhist_store[(size_t)k * n_channels + ch] = L.rh[k][ln];
         }
     }
 }
