@@ -328,7 +328,7 @@ ddn_fsk4_rx_run(ddn_fsk4_rx* b, const float* d_disc, size_t n, uint8_t* d_record
     HIP_TRY(ddn_dev_fsk4_rx(d_disc, b->d_filt, b->d_fhist, b->d_fstale, b->d_taps, (long)n, n, B, b->d_cfg, b->d_state, b->d_lbuf,
                             b->d_shist, b->d_phist, b->d_rhist, d_records10, d_flags, d_payload2, d_counts, max_symbols, b->d_lock,
                             d_sync_pos, d_sync_pat, d_pre, d_pre_rel, d_n_sync, (int)max_syncs, b->channels_per_wave,
-                            b->dc.out_rate / b->dc.sym_rate + (b->dc.out_rate % b->dc.sym_rate ? 1 : 0), st));
+                            b->dc.out_rate / b->dc.sym_rate + (b->dc.out_rate % b->dc.sym_rate ? 1 : 0), b->cfg.protocol, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
     }

@@ -157,7 +157,7 @@ hipError_t ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* pre
                            float* lbuf_store, float* shist_store, uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec,
                            uint8_t* flags, uint8_t* pay, int32_t* counts, size_t max_sym, const int32_t* lock4,
                            int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel, int32_t* n_sync,
-                           int max_sync, int channels_per_wave, int samples_per_symbol, hipStream_t st);
+                           int max_sync, int channels_per_wave, int samples_per_symbol, int protocol, hipStream_t st);
 hipError_t ddn_dev_dmr_burst_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
                                     const uint8_t* pre, const int32_t* n_sync, int n_channels, int max_sync, int inverted,
                                     uint8_t* slot_type, uint8_t* info, uint8_t* cach, uint8_t* valid, hipStream_t st);

@@ -50,6 +50,8 @@ struct Lds4 {
     float q[2][QCAP][8][CPW];
     int qn[2][CPW];
     int qo[2][CPW];
+    uint32_t pat_bits[DDN_FSK4_MAX_PAT];
+    uint32_t pat_meta[DDN_FSK4_MAX_PAT]; // type | neg << 8 | class << 16
 };
 
 __device__ __forceinline__ void
@@ -86,6 +88,17 @@ hunt_restart(DdnFsk4State& s) {
     s.lmin = s.min;
     s.lmax = s.max;
 }
+template <int PROTO>
+struct Fsk4Cfg {
+    static constexpr int sym_rate = PROTO == 1 ? 4800 : 2400;
+    static constexpr int win_len = PROTO == 1 ? 24 : 10, t_max = PROTO == 1 ? 24 : 12, warm_len = PROTO == 1 ? 24 : 10;
+    static constexpr int n_pat = PROTO == 1 ? 8 : 10;
+    static constexpr int confirm = PROTO == 1 ? 0 : 1, dmr_window = PROTO == 1 ? 1 : 0, redigitize = PROTO == 1 ? 1 : 0;
+    static constexpr int slow_type = 0;
+    static constexpr int nt = PROTO == 1 ? DDN_DMR_FILTER_TAPS : DDN_NXDN48_FILTER_TAPS;
+    int out_rate, rf_mod, use_filter, dbg;
+};
+
 // how often sample i of the current symbol enters the sum (symbol_accumulate_sample)
 __device__ __forceinline__ int
 adds(int i, int span, int c, int rf_mod, int l_edge) {
@@ -102,7 +115,7 @@ adds(int i, int span, int c, int rf_mod, int l_edge) {
     return k + ((i == c - 1 || i == c + 1) ? 1 : 0);
 }
 
-template <int CPW, int MAXW>
+template <int CPW, int MAXW, int PROTO>
 __global__ __launch_bounds__(128) void
 k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
           float* __restrict__ fstale, const float* __restrict__ taps, long n_long, size_t stride, int n_channels,
@@ -120,16 +133,21 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const int ch = ch0 + lane;
     const bool live = !loader && lane < CPW && ch < n_channels;
     const int ln = lane < CPW ? lane : 0;
-    // the profile lives in device memory; its scalars are read once (uniform loads), its arrays only where a sync is handled
-    struct {
-        int out_rate, sym_rate, rf_mod, win_len, t_max, warm_len, n_pat, confirm, dmr_window, redigitize, slow_type, use_filter, nt, dbg;
-        const uint32_t* pat_bits;
-        const uint8_t *pat_type, *pat_neg, *pat_class;
-    } cfg = {cfgp->out_rate, cfgp->sym_rate, cfgp->rf_mod, cfgp->win_len, cfgp->t_max, cfgp->warm_len, cfgp->n_pat, cfgp->confirm,
-             cfgp->dmr_window, cfgp->redigitize, cfgp->slow_type, cfgp->use_filter, cfgp->nt, cfgp->dbg,
-             cfgp->pat_bits, cfgp->pat_type, cfgp->pat_neg, cfgp->pat_class};
+    // The protocol's constants are compile-time (PROTO 1 = DMR, 2 = NXDN48; the host checks the profile against them), the
+    // batch's choices are read once from the profile in device memory, its pattern table sits in LDS.
+    using Cfg = Fsk4Cfg<PROTO>;
+    Cfg cfg;
+    cfg.out_rate = cfgp->out_rate;
+    cfg.rf_mod = cfgp->rf_mod;
+    cfg.use_filter = cfgp->use_filter;
+    cfg.dbg = cfgp->dbg;
+    if (threadIdx.x < DDN_FSK4_MAX_PAT) {
+        L.pat_bits[threadIdx.x] = cfgp->pat_bits[threadIdx.x];
+        L.pat_meta[threadIdx.x] = (uint32_t)cfgp->pat_type[threadIdx.x] | ((uint32_t)cfgp->pat_neg[threadIdx.x] << 8)
+                                  | ((uint32_t)cfgp->pat_class[threadIdx.x] << 16);
+    }
     const bool use_flt = cfg.use_filter != 0;
-    const int NT = cfg.nt;
+    constexpr int NT = Cfg::nt;
 
     DdnFsk4State s;
     if (live) {
@@ -362,35 +380,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const bool has20 = s.span == 20;
                 const float up_lim = s.maxref * 1.25f, dn_lim = s.minref * 1.25f;
                 const int left = s.span - s.i; // samples this symbol still needs
-                // In-frame fast path: no slip, crossing latch already set -> only the window samples and the last one matter
-                if (live && began && lean && steady && s.have_sync && s.jitter >= 0 && pos + left <= n && !(cfg.dbg & 4)) {
-                    const int lo = has20 ? 7 : wlo, hi = has20 ? 13 : whi;
-                    float acc = 0.0f;
-                    int cnt = 0;
-                    for (int i = lo; i <= hi; i++) {
-                        const int a = adds(i, s.span, cw, cfg.rf_mod, l_edge);
-                        if (a) {
-                            float x = rowp[(pos + i) & RMASK];
-                            if (clip) {
-                                x = x > s.max ? s.max : (x < s.min ? s.min : x);
-                            }
-                            acc += x;
-                            if (a > 1) {
-                                acc += x;
-                            }
-                            cnt += a;
-                        }
-                    }
-                    float xl = rowp[(pos + s.span - 1) & RMASK];
-                    if (clip) {
-                        xl = xl > s.max ? s.max : (xl < s.min ? s.min : xl);
-                    }
-                    s.sum = acc;
-                    s.count = cnt;
-                    s.lastsample = xl;
-                    pos += s.span;
-                    s.i = s.span;
-                } else if (live && began && lean && steady && pos + left <= n && left <= MAXW && !(cfg.dbg & 256)) {
+                if (live && began && lean && steady && pos + left <= n && left <= MAXW && !(cfg.dbg & 256)) {
                     // Whole-symbol pass (hunting, or in frame before the latch is set): every sample read issued up front,
                     // then crossing latch + window sums in sample order - the arithmetic of the sample-at-a-time loop below
                     const int i0 = s.i;
@@ -494,7 +484,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     // thresholds the symbol is sliced against: as they stand before a sync on this symbol changes them
                     const float q1 = s.center, q2 = s.umid, q3 = s.lmid, q4 = s.max, q5 = s.min;
                     if (s.have_sync) {
-                        const int neg = (cfg.dbg & 32) ? 0 : cfg.pat_neg[s.cur_pat];
+                        const int neg = (cfg.dbg & 32) ? 0 : ((L.pat_meta[s.cur_pat] >> 8) & 1);
                         s.maxref = s.max;
                         s.minref = s.min;
                         fl = 1 | (neg ? 4 : 0);
@@ -516,7 +506,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             if (s.hist_count >= cfg.win_len && !(cfg.dbg & 8)) {
                                 const uint32_t w = s.hist_bits & wmask;
                                 for (int k = cfg.n_pat - 1; k >= 0; k--) {
-                                    hit = (w == cfg.pat_bits[k]) ? k : hit; // lowest matching index wins, as a forward scan
+                                    hit = (w == L.pat_bits[k]) ? k : hit; // lowest matching index wins, as a forward scan
                                 }
                             }
                             if (hit >= 0) {
@@ -548,7 +538,8 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     s.lmin = (a0 + a1 + a2) / 3.0f;
                                     s.lmax = (b2 + b1 + b0) / 3.0f;
                                 }
-                                const int type = cfg.pat_type[hit];
+                                const uint32_t pm = L.pat_meta[hit];
+                                const int type = (int)(pm & 0xFF);
                                 s.max = (s.max + s.lmax) / 2;
                                 s.min = (s.min + s.lmin) / 2;
                                 accepted = !(cfg.confirm && s.lastsync != type);
@@ -588,8 +579,8 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     }
                                     s.have_sync = 1;
                                     s.cur_pat = hit;
-                                    s.lock_left = lock4[(size_t)ch * 4 + (cfg.pat_class[hit] & 3)];
-                                    fl = 2 | (cfg.pat_neg[hit] ? 4 : 0) | (hit << 3);
+                                    s.lock_left = lock4[(size_t)ch * 4 + ((pm >> 16) & 3)];
+                                    fl = 2 | (((pm >> 8) & 1) ? 4 : 0) | (hit << 3);
                                     sync_entry = true;
                                     if (s.lock_left <= 0) {
                                         hunt_restart(s);
@@ -760,7 +751,7 @@ k_dmr_burst_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ 
     }
 }
 
-template <int CPW, int MAXW>
+template <int CPW, int MAXW, int PROTO>
 hipError_t
 launch(const float* raw, const float* filt, const float* prev_tail, float* fstale, const float* taps, long n, size_t stride,
        int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state, float* lbuf_store, float* shist_store,
@@ -768,11 +759,11 @@ launch(const float* raw, const float* filt, const float* prev_tail, float* fstal
        size_t max_sym, const int32_t* lock4, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel,
        int32_t* n_sync, int max_sync, hipStream_t st) {
     const size_t shmem = sizeof(Lds4<CPW>);
-    hipError_t e = hipFuncSetAttribute((const void*)k_fsk4_rx<CPW, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = hipFuncSetAttribute((const void*)k_fsk4_rx<CPW, MAXW, PROTO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) {
         return e;
     }
-    hipLaunchKernelGGL((k_fsk4_rx<CPW, MAXW>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shmem, st, raw, filt,
+    hipLaunchKernelGGL((k_fsk4_rx<CPW, MAXW, PROTO>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shmem, st, raw, filt,
                        prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store, phist_store,
                        rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel, n_sync,
                        max_sync);
@@ -785,17 +776,27 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
                 size_t stride, int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state, float* lbuf_store,
                 float* shist_store, uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec, uint8_t* flags, uint8_t* pay,
                 int32_t* counts, size_t max_sym, const int32_t* lock4, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre,
-                uint8_t* pre_rel, int32_t* n_sync, int max_sync, int channels_per_wave, int cfg_sps, hipStream_t st) {
+                uint8_t* pre_rel, int32_t* n_sync, int max_sync, int channels_per_wave, int cfg_sps, int protocol, hipStream_t st) {
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
+    }
+    if (protocol != 1 && protocol != 2) {
+        return hipErrorInvalidValue;
     }
     // MAXW: the longest whole symbol the straight pass takes (samples per symbol + one slip sample); 12 covers 4800 baud at
     // 48 ksps, 22 covers 2400 baud
     const int sps = cfg_sps > 0 ? cfg_sps : 64;
 #define DDN_RX4_GO(CPW_, MAXW_)                                                                                            \
-    return launch<CPW_, MAXW_>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store, \
-                               phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre,    \
-                               pre_rel, n_sync, max_sync, st)
+    do {                                                                                                                   \
+        if (protocol == 1) {                                                                                               \
+            return launch<CPW_, MAXW_, 1>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, \
+                                          shist_store, phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4,  \
+                                          sync_pos, sync_pat, pre, pre_rel, n_sync, max_sync, st);                         \
+        }                                                                                                                  \
+        return launch<CPW_, MAXW_, 2>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store,   \
+                                      shist_store, phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4,      \
+                                      sync_pos, sync_pat, pre, pre_rel, n_sync, max_sync, st);                             \
+    } while (0)
     if (channels_per_wave <= 16) {
         if (sps <= 11) {
             DDN_RX4_GO(16, 12);
