@@ -202,7 +202,12 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         b->cfg.lock_symbols[k] = all_zero ? lock_default[k] : cfg->lock_symbols[k];
     }
     const size_t B = (size_t)cfg->n_channels;
-    b->channels_per_wave = B <= 8192 ? 16 : 32;
+    // fewer channels per wavefront = fewer unsynchronised recurrences sharing one instruction stream; spread a batch over
+    // at least ~512 workgroups (two per CU) before packing more channels into a wavefront
+    b->channels_per_wave = B <= 2048 ? 4 : (B <= 4096 ? 8 : (B <= 8192 ? 16 : 32));
+    if (const char* e = getenv("DDN_RX4_CPW")) {
+        b->channels_per_wave = atoi(e);
+    }
     std::vector<int32_t> lock(B * 4);
     for (size_t c = 0; c < B; c++) {
         for (int k = 0; k < 4; k++) {

@@ -178,21 +178,22 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
         const int slot = (t & (RTILES - 1)) * TS;
+        constexpr int RB = CPW < 16 ? CPW : 16; // rows staged per pass
 #pragma unroll
-        for (int h = 0; h < CPW / 16; h++) {
-            float r[16], f[16];
+        for (int h = 0; h < CPW / RB; h++) {
+            float r[RB], f[RB];
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const int cc = 16 * h + c;
+            for (int c = 0; c < RB; c++) {
+                const int cc = RB * h + c;
                 const bool ok = (ch0 + cc < n_channels) && lane < tn;
                 const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + lane;
                 r[c] = ok ? raw[off] : 0.0f;
                 f[c] = (ok && use_flt) ? filt[off] : 0.0f;
             }
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                L.raw[16 * h + c][slot + lane] = r[c];
-                L.flt[16 * h + c][slot + lane] = f[c];
+            for (int c = 0; c < RB; c++) {
+                L.raw[RB * h + c][slot + lane] = r[c];
+                L.flt[RB * h + c][slot + lane] = f[c];
             }
         }
     };
@@ -797,6 +798,18 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
                                       shist_store, phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4,      \
                                       sync_pos, sync_pat, pre, pre_rel, n_sync, max_sync, st);                             \
     } while (0)
+    if (channels_per_wave <= 4) {
+        if (sps <= 11) {
+            DDN_RX4_GO(4, 12);
+        }
+        DDN_RX4_GO(4, 22);
+    }
+    if (channels_per_wave <= 8) {
+        if (sps <= 11) {
+            DDN_RX4_GO(8, 12);
+        }
+        DDN_RX4_GO(8, 22);
+    }
     if (channels_per_wave <= 16) {
         if (sps <= 11) {
             DDN_RX4_GO(16, 12);
