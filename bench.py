@@ -131,13 +131,17 @@ def cpu_baseline(voice, ctrl, n, Fv):
             "all_cores": all_cores}
 
 
-def parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n):
+def parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n, streams=None):
     """Before any timing: a sample of this rank's channels, first call of a fresh stream, against the chain of CPU oracles -
     dibit records, NIDs, decoded voice parameter bits and PCM all bit-exact."""
     import numpy as np
     import chain_oracle
     import orc
-    chain.run(d_iq)
+    torch.cuda.synchronize()
+    if streams:
+        chain.run_pipelined(d_iq, *streams)      # the same call sequence the timed loop makes
+    else:
+        chain.run(d_iq)
     torch.cuda.synchronize()
     pick = sorted(set([0, 1, 2, 3, B // 2, B // 2 + 1, B - 2, B - 1]))
     cnt = chain.cnt.cpu().numpy()
@@ -194,6 +198,8 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the stage breakdown / PCIe / front-end sub-objects")
+    ap.add_argument("--no-pipeline", action="store_true", help="run every stage of a step on one stream (no overlap of the frame "
+                    "FEC / vocoder stages of step k with the front end / receive loop of step k + 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -247,19 +253,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    parity = parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n)
+    streams = None if args.no_pipeline else (torch.cuda.Stream(), torch.cuda.Stream())
+
+    def step():
+        if streams:
+            chain.run_pipelined(d_iq, *streams)
+        else:
+            chain.run(d_iq, st)
+
+    parity = parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n, streams)
     if not parity["bit_exact"] and not os.environ.get("DDN_BENCH_NOPARITY"):
         raise SystemExit("parity gate failed: %s" % json.dumps(parity))
 
     for _ in range(args.warmup):
-        chain.run(d_iq, st)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        chain.run(d_iq, st)
-    barrier()
+        step()
+    barrier()          # torch.cuda.synchronize(): every stream, i.e. the last step's FEC / voice stages are inside the timed region
     dt = time.perf_counter() - t0
     dt = ddn_shard.reduce_max_seconds(dt, dev)
+    serial_ms = None
+    if streams and rank == 0 and not args.no_extras:
+        for _ in range(2):
+            chain.run(d_iq, st)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(min(args.steps, 10)):
+            chain.run(d_iq, st)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / min(args.steps, 10) * 1e3
 
     # per-stage / per-kernel times: a separate instrumented loop outside the timed region
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -324,6 +348,9 @@ def main():
                                    "MBE synthesis (PCM f32)" % (B, n),
                        "channels_per_gpu": B, "samples_per_channel": n, "block_len": BLOCK,
                        "parallelism": "channel-sharded x%d" % world,
+                       "pipelining": ("none (one stream)" if args.no_pipeline else
+                                      "2 HIP streams: frame FEC + vocoder of step k overlap front end + receive loop of step k+1 "
+                                      "(double-buffered loop outputs); every stage of every step inside the timed region"),
                        "vocoder_tables": "synthetic default blob (include/ddn_mbe.h); mbelib-neo absent -> vocoder parity unpinned"},
             "parity": parity,
             "work_per_step": {"symbols": n_sym, "frames_with_valid_nid": int((nidh[:, 0] == 1).sum()),
@@ -344,6 +371,8 @@ def main():
                          "launch_ms": round(dom_ms, 4),
                          "chain_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
         }
+        if serial_ms is not None:
+            line["one_stream_ms_per_step"] = round(serial_ms, 4)
         if world == 1 and not args.no_extras:
             line["front_end_stage"] = front_end_stage(torch, ddn, chain, d_iq, B, n, 12)
             line["pcie_inclusive"] = pcie_inclusive(torch, chain, d_iq, B, n)

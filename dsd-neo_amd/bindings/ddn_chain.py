@@ -32,7 +32,13 @@ class P25Chain:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         u8, i16, i32, f32, i64 = torch.uint8, torch.int16, torch.int32, torch.float32, torch.int64
         self.disc = z((B, n), f32)
-        self.rec, self.fl, self.cnt = z((B, ms, 10), u8), z((B, ms), u8), z((B,), i32)
+        # the receive loop's outputs are double-buffered so that run_pipelined() can decode batch k on a second stream while the
+        # loop of batch k + 1 writes the other set; run() stays on set 0
+        self.sets = [(z((B, ms, 10), u8), z((B, ms), u8), z((B,), i32)) for _ in range(2)]
+        self.rec, self.fl, self.cnt = self.sets[0]
+        self.step = 0
+        self.ev_produced = [torch.cuda.Event() for _ in range(2)]
+        self.ev_consumed = [torch.cuda.Event() for _ in range(2)]
         self.bits, self.rel, self.par, self.prel, self.v_nid = z((S, 63), u8), z((S, 63), u8), z((S,), u8), z((S,), u8), z((S,), u8)
         self.obs, self.nid = z((S,), i32), z((S, 4), i32)
         self.llr, self.v_blk = z((S, 196), i16), z((S,), u8)
@@ -119,3 +125,23 @@ class P25Chain:
         self.receive(st)
         self.frame_fec(st)
         self.voice(st)
+
+    def run_pipelined(self, d_iq, s_main, s_aux):
+        """One batch interval, software-pipelined over two torch streams: front end + receive loop of this batch on s_main,
+        frame FEC + voice of this batch on s_aux - which overlaps the NEXT call's front end + receive loop (the loop is a
+        per-channel latency chain on one wavefront per CU; the FEC / vocoder kernels fill the idle SIMDs beside it).  Every
+        stage of every batch still runs, in order per stage; results of batch k are complete when s_aux reaches the end of
+        call k.  Carried state stays per stage (front end / loop on s_main, framer / vocoder on s_aux)."""
+        k = self.step
+        cur = k & 1
+        self.rec, self.fl, self.cnt = self.sets[cur]
+        if k >= 2:
+            s_main.wait_event(self.ev_consumed[cur])      # batch k - 2 has been decoded out of this set
+        self.front_end(d_iq, s_main.cuda_stream)
+        self.receive(s_main.cuda_stream)
+        self.ev_produced[cur].record(s_main)
+        s_aux.wait_event(self.ev_produced[cur])
+        self.frame_fec(s_aux.cuda_stream)
+        self.voice(s_aux.cuda_stream)
+        self.ev_consumed[cur].record(s_aux)
+        self.step = k + 1
