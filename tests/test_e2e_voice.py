@@ -131,3 +131,42 @@ def test_voice_chain_on_device_equals_oracle_chain(built):
         else:
             assert np.all(pcm[c] == 0) and crc_ok[c].sum() >= 10
     ch.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_steps_equal_one_stream_steps(built):
+    """P25Chain.run_pipelined (frame FEC + vocoder of batch k on a second stream beside the next batch's front end + receive
+    loop, double-buffered loop outputs) produces, batch after batch, exactly what run() produces on one stream - records,
+    counts, NIDs, TSBKs, voice parameter bits, result flags and PCM, with the state carried across four batch intervals."""
+    import torch
+    import ddn_chain
+    iq, lock, _ = _traffic()
+    # four consecutive intervals of one stream per channel: the traffic cut in four pieces
+    n = N // 4
+    d_iq = [torch.from_numpy(np.ascontiguousarray(iq[:, k * n:(k + 1) * n])).cuda() for k in range(4)]
+    a = ddn_chain.P25Chain(torch, B, n, lock, block_len=4096)
+    b = ddn_chain.P25Chain(torch, B, n, lock, block_len=4096)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    want = []
+    for k in range(4):
+        a.run(d_iq[k])
+        torch.cuda.synchronize()
+        want.append([t.clone() for t in (a.rec, a.fl, a.cnt, a.nid, a.tsbk, a.crc_ok, a.imbe_d, a.res_out, a.pcm)])
+    got = []
+    for k in range(4):          # no host synchronisation between the calls: the overlap is real
+        b.run_pipelined(d_iq[k], s1, s2)
+        # snapshot on the consumer stream, ordered after this batch's last stage
+        with torch.cuda.stream(s2):
+            got.append([t.clone() for t in (b.rec, b.fl, b.cnt, b.nid, b.tsbk, b.crc_ok, b.imbe_d, b.res_out, b.pcm)])
+    torch.cuda.synchronize()
+    names = ("rec", "fl", "cnt", "nid", "tsbk", "crc_ok", "imbe_d", "res_out", "pcm")
+    for k in range(4):
+        cnt = want[k][2].cpu().numpy()
+        for name, x, y in zip(names, want[k], got[k]):
+            if name in ("rec", "fl"):      # entries past a channel's count are leftovers of whichever batch used the buffer before
+                for c in range(B):
+                    assert torch.equal(x[c, :cnt[c]], y[c, :cnt[c]]), (k, name, c)
+            else:
+                assert torch.equal(x, y), (k, name, int((x != y).sum()))
+    assert int(want[3][2].sum()) > 0 and float(want[2][8].abs().sum()) > 0
