@@ -265,6 +265,9 @@ PROTOTYPES.update({
     "ddn_fec_block_code_host": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_fec_bptc_196x96_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_fec_bptc_196x96_host": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_trellis_decode_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "ddn_fec_trellis_decode_host": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_int]),
+    "trellis_decode": (None, [C.c_void_p, C.c_void_p, C.c_int]),
     "ddn_fec_rs_12_9_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_fec_rs_12_9_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "Hamming_7_4_init": (None, []), "Hamming_12_8_init": (None, []), "Hamming_13_9_init": (None, []),
@@ -336,6 +339,8 @@ PROTOTYPES.update({
     "ddn_fsk4_rx_get_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_fsk4_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_fsk4_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_nxdn_frame_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 7),
+    "ddn_nxdn_crc_check_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_dmr_burst_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int]
                              + [C.c_void_p] * 5),
 })

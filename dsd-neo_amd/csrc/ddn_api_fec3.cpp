@@ -133,6 +133,61 @@ ddn_fec_bptc_196x96_host(const uint8_t* in196, int deinterleave, size_t n, uint8
 }
 
 extern "C" int
+ddn_fec_trellis_decode_batch(const uint8_t* d_source_bits, int source_stride, size_t n, int result_len, uint8_t* d_result_bits,
+                             int result_stride, void* hip_stream) {
+    if (n && (!d_source_bits || !d_result_bits)) {
+        ddn_set_error("ddn_fec_trellis_decode_batch: null argument");
+        return DDN_EINVAL;
+    }
+    if (result_len <= 0 || source_stride < 2 * result_len + 6 || result_stride < result_len) {
+        ddn_set_error("ddn_fec_trellis_decode_batch: a row needs 2 * result_len + 6 source bits (the last bit looks 8 ahead)");
+        return DDN_ERANGE;
+    }
+    if (have_device() != DDN_OK) {
+        return DDN_ENODEV;
+    }
+    HIP_TRY(ddn_dev_trellis_greedy(d_source_bits, source_stride, n, result_len, d_result_bits, result_stride, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_trellis_decode_host(const uint8_t* source_bits, int source_stride, size_t n, int result_len, uint8_t* result_bits,
+                            int result_stride) {
+    if (n && (!source_bits || !result_bits)) {
+        return DDN_EINVAL;
+    }
+    if (result_len <= 0 || source_stride < 2 * result_len + 6 || result_stride < result_len) {
+        return DDN_ERANGE;
+    }
+    if (have_device() != DDN_OK) {
+        return DDN_ENODEV;
+    }
+    uint8_t *d_s = nullptr, *d_o = nullptr;
+    int rc = DDN_OK;
+    if (hipMalloc(&d_s, n * (size_t)source_stride + 4) != hipSuccess || hipMalloc(&d_o, n * (size_t)result_stride + 4) != hipSuccess) {
+        rc = DDN_ENOMEM;
+    } else if (hipMemcpy(d_s, source_bits, n * (size_t)source_stride, hipMemcpyHostToDevice) != hipSuccess
+               || hipMemset(d_o, 0, n * (size_t)result_stride) != hipSuccess
+               || ddn_dev_trellis_greedy(d_s, source_stride, n, result_len, d_o, result_stride, nullptr) != hipSuccess
+               || hipMemcpy(result_bits, d_o, n * (size_t)result_stride, hipMemcpyDeviceToHost) != hipSuccess) {
+        rc = DDN_EHIP;
+    }
+    (void)hipFree(d_s);
+    (void)hipFree(d_o);
+    return rc;
+}
+
+// drop-in: include/dsd-neo/fec/trellis.h:22.  The reference reads source[2p .. 2p+7] for p < result_len, i.e. the caller's buffer
+// holds 2 * result_len + 6 bits (its callers pass the zero-padded de-punctured field).
+extern "C" void
+trellis_decode(uint8_t result[], const uint8_t source[], int result_len) {
+    if (!result || !source || result_len <= 0) {
+        return;
+    }
+    (void)ddn_fec_trellis_decode_host(source, 2 * result_len + 6, 1, result_len, result, result_len);
+}
+
+extern "C" int
 ddn_fec_rs_12_9_batch(uint8_t* d_codewords12, size_t n, uint8_t* d_result, uint8_t* d_errors_found, uint8_t* d_syndrome3,
                       void* hip_stream) {
     if (n && (!d_codewords12 || !d_result)) {

@@ -450,3 +450,25 @@ ddn_dmr_burst_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t
                                      inverted, d_slot_type, d_info, d_cach, d_valid, (hipStream_t)hip_stream));
     return DDN_OK;
 }
+
+extern "C" int
+ddn_nxdn_frame_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols, const int32_t* d_sync_pos,
+                      const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_lich, uint8_t* d_sacch_sym,
+                      uint8_t* d_sacch_rel, uint8_t* d_facch_sym, uint8_t* d_facch_rel, uint8_t* d_valid, void* hip_stream) {
+    if (!d_records10 || !d_counts || !d_sync_pos || !d_n_sync || !d_lich || !d_sacch_sym || !d_sacch_rel || !d_facch_sym || !d_facch_rel
+        || !d_valid || n_channels <= 0) {
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_nxdn_frame_gather(d_records10, d_counts, max_symbols, d_sync_pos, d_n_sync, n_channels, (int)max_syncs, d_lich,
+                                      d_sacch_sym, d_sacch_rel, d_facch_sym, d_facch_rel, d_valid, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_nxdn_crc_check_batch(const uint8_t* d_bytes, int stride, size_t n, int kind, uint8_t* d_ok, void* hip_stream) {
+    if (!d_bytes || !d_ok || stride <= 0 || (kind != 0 && kind != 1) || stride * 8 < (kind == 0 ? 32 : 92)) {
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_nxdn_crc(d_bytes, stride, (int)n, kind, d_ok, (hipStream_t)hip_stream));
+    return DDN_OK;
+}

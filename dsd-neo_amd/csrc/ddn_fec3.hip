@@ -553,6 +553,54 @@ ddn_dev_bptc_196x96(const uint8_t* in, int deinterleave, size_t n, uint8_t* out9
     return hipGetLastError();
 }
 
+// trellis_decode() (src/core/util/dsd_misc.c:24-71; include/dsd-neo/fec/trellis.h:22): the hard-decision retry of the NXDN
+// field decoders (nxdn_deperm.c:197-205).  Not a Viterbi search: for every output bit the 16 four-bit continuations of the
+// current 5-bit register are re-encoded (rate 1/2, generators 0x19 / 0x17 as parity masks) and compared with the next 8 input
+// bits; the first bit of the closest one is kept (ties: the lowest candidate index, strict <, candidate 0 taken first).
+// One codeword per lane; the 16 x 8 comparisons are bit-parallel on one 8-bit word per candidate.
+__global__ void
+k_trellis_greedy(const uint8_t* __restrict__ src, int src_stride, size_t n, int result_len, uint8_t* __restrict__ out,
+                 int out_stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint8_t* s = src + i * (size_t)src_stride;
+    uint8_t* o = out + i * (size_t)out_stride;
+    unsigned reg = 0;
+    for (int p = 0; p < result_len; p++) {
+        unsigned want = 0; // source[2p .. 2p+7], first bit in bit 7
+        for (int j = 0; j < 8; j++) {
+            want = (want << 1) | (s[2 * p + j] & 1u);
+        }
+        int min_d = 9999, min_bt = 0;
+        for (int c = 0; c < 16; c++) {
+            unsigned r = reg, enc = 0;
+            for (int b = 0; b < 4; b++) {
+                r = ((r << 1) | ((c >> (3 - b)) & 1u)) & 0x1Fu;
+                enc = (enc << 2) | ((__popc(r & 0x19u) & 1u) << 1) | (__popc(r & 0x17u) & 1u);
+            }
+            const int d = __popc(enc ^ want);
+            if (c == 0 || d < min_d) {
+                min_d = d;
+                min_bt = (c >> 3) & 1;
+            }
+        }
+        o[p] = (uint8_t)min_bt;
+        reg = ((reg << 1) | (unsigned)min_bt) & 0x1Fu;
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_trellis_greedy(const uint8_t* src, int src_stride, size_t n, int result_len, uint8_t* out, int out_stride, hipStream_t st) {
+    if (n == 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_trellis_greedy, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, src, src_stride, n, result_len, out,
+                       out_stride);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t
 ddn_dev_rs_12_9(uint8_t* cw, size_t n, uint8_t* result, uint8_t* found, uint8_t* syn_out, hipStream_t st) {
     if (n == 0) {

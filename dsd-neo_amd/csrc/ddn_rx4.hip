@@ -752,6 +752,111 @@ k_dmr_burst_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ 
     }
 }
 
+// NXDN frame fields for every accepted sync (nxdn_frame(), src/protocol/nxdn/nxdn_frame.c:181-199,311-331,596-621): the 182
+// dibits after the frame sync word are de-scrambled (PN9 x^9 + x^4 + 1 from 0x0E4: a set bit flips the dibit's sign bit,
+// nxdn_descramble.c:35-57), the LICH is read from the first 8, the SACCH (60 bits) and the two FACCH1 fields (144 bits each)
+// are de-interleaved (12 x 5 / 16 x 9 block interleavers, nxdn_const.h:29-40: bit i goes to (i mod R) * C + i / R) and
+// de-punctured (nxdn_deperm.c:139-172) into the symbol / reliability pairs the K = 5 decoder takes (bit << 1; a punctured
+// position is symbol 0 with reliability 0).  One workgroup per sync slot.
+__global__ void
+k_nxdn_frame_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ counts, size_t max_sym,
+                    const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_sync, int max_sync,
+                    uint8_t* __restrict__ lich, uint8_t* __restrict__ sacch_sym, uint8_t* __restrict__ sacch_rel,
+                    uint8_t* __restrict__ facch_sym, uint8_t* __restrict__ facch_rel, uint8_t* __restrict__ valid) {
+    __shared__ uint8_t bit[364], rel[364];
+    __shared__ uint8_t pn[182];
+    const int k = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
+    const size_t so = (size_t)ch * max_sync + k;
+    const bool have = k < n_sync[ch] && k < max_sync;
+    const long pos = have ? sync_pos[so] : 0;
+    const bool ok = have && (pos + 182 < (long)counts[ch]) && ((size_t)(pos + 182) < max_sym);
+    if (t == 0) {
+        unsigned l = 228u;
+        for (int i = 0; i < 182; i++) {
+            pn[i] = (uint8_t)(l & 1u);
+            const unsigned b = ((l >> 4) ^ l) & 1u;
+            l = (l >> 1) | (b << 8);
+        }
+        valid[so] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = t; i < 182; i += blockDim.x) {
+        int d = 0, r = 0;
+        if (ok) {
+            const uint8_t* rr = rec + ((size_t)ch * max_sym + (size_t)(pos + 1 + i)) * 10;
+            d = rr[0] & 3; // getDibitSoft()'s return value
+            r = rr[1];
+        }
+        d ^= pn[i] << 1;
+        bit[2 * i] = (uint8_t)(d >> 1);
+        bit[2 * i + 1] = (uint8_t)(d & 1);
+        rel[2 * i] = rel[2 * i + 1] = (uint8_t)r;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int l = 0;
+        for (int i = 0; i < 8; i++) {
+            l |= bit[2 * i] << (7 - i);
+        }
+        int par = ((l >> 7) + (l >> 6) + (l >> 5) + (l >> 4)) & 1;
+        const int l7 = l >> 1;
+        if (l7 == 0x08 || l7 == 0x4A || l7 == 0x48 || l7 == 0x46) {
+            par = ((l >> 7) + (l >> 6) + (l >> 5) + (l >> 4) + (l >> 3) + (l >> 2) + (l >> 1)) & 1;
+        }
+        lich[so] = (uint8_t)(l7 | (((l & 1) == par && ok) ? 0x80 : 0)); // bit 7: parity good
+    }
+    // SACCH: output position q of 72 <- de-punctured index; groups of 12 from 10
+    for (int q = t; q < 72; q += blockDim.x) {
+        const int g = q / 12, m = q % 12;
+        const bool punct = (m == 5 || m == 11);
+        const int dp = g * 10 + (m < 5 ? m : m - 1); // index into the de-interleaved 60
+        // de-interleave: deperm[(i % 5) * 12 + i / 5] = in[i]  ->  in index of deperm position p: i = (p % 12) * 5 + p / 12
+        const int src = (dp % 12) * 5 + dp / 12;
+        sacch_sym[so * 72 + q] = punct ? 0 : (uint8_t)(bit[16 + src] << 1);
+        sacch_rel[so * 72 + q] = punct ? 0 : rel[16 + src];
+    }
+    // FACCH1 a / b: 144 -> 192: every group of 3 becomes {b0, punctured, b1, b2}
+    for (int q = t; q < 384; q += blockDim.x) {
+        const int f = q / 192, qq = q % 192;
+        const int g = qq / 4, m = qq % 4;
+        const bool punct = (m == 1);
+        const int dp = g * 3 + (m == 0 ? 0 : m - 1);
+        const int src = (dp % 16) * 9 + dp / 16; // deperm[(i % 9) * 16 + i / 9] = in[i]
+        const int base = 16 + 60 + 144 * f;
+        facch_sym[so * 384 + q] = punct ? 0 : (uint8_t)(bit[base + src] << 1);
+        facch_rel[so * 384 + q] = punct ? 0 : rel[base + src];
+    }
+}
+
+// CRC of a decoded NXDN field, bit-serial as the reference computes it (crc6: nxdn_deperm.c:1246-1261, x^6+x^5+x^2+x+1;
+// crc12f: nxdn_dcr_utils.c:21-42, x^12+x^11+x^3+x^2+x+1; registers start all ones): kind 0 = SACCH (26 + 6 bits), 1 = FACCH1
+// (80 + 12).  bytes = the K = 5 decoder's output rows, MSB first.
+__global__ void
+k_nxdn_crc(const uint8_t* __restrict__ bytes, int stride, int n, int kind, uint8_t* __restrict__ ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint8_t* b = bytes + (size_t)i * stride;
+    const int nd = kind == 0 ? 26 : 80, nc = kind == 0 ? 6 : 12;
+    const unsigned poly = kind == 0 ? 0x27u : 0x80Fu; // x^5+x^2+x+1 / x^11+x^3+x^2+x+1 below the leading term
+    const unsigned top = 1u << (nc - 1), mask = (1u << nc) - 1u;
+    unsigned crc = mask;
+    for (int k = 0; k < nd; k++) {
+        const unsigned in = (b[k >> 3] >> (7 - (k & 7))) & 1u;
+        const unsigned fb = ((crc & top) ? 1u : 0u) ^ in;
+        crc = (crc << 1) & mask;
+        if (fb) {
+            crc ^= poly;
+        }
+    }
+    unsigned got = 0;
+    for (int k = nd; k < nd + nc; k++) {
+        got = (got << 1) | ((b[k >> 3] >> (7 - (k & 7))) & 1u);
+    }
+    ok[i] = crc == got ? 1 : 0;
+}
+
 template <int CPW, int MAXW, int PROTO>
 hipError_t
 launch(const float* raw, const float* filt, const float* prev_tail, float* fstale, const float* taps, long n, size_t stride,
@@ -832,6 +937,27 @@ ddn_dev_dmr_burst_gather(const uint8_t* rec, const int32_t* counts, size_t max_s
     }
     hipLaunchKernelGGL(k_dmr_burst_gather, dim3((unsigned)max_sync, (unsigned)n_channels), dim3(64), 0, st, rec, counts, max_sym,
                        sync_pos, pre, n_sync, max_sync, inverted, slot_type, info, cach, valid);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_nxdn_frame_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos, const int32_t* n_sync,
+                          int n_channels, int max_sync, uint8_t* lich, uint8_t* sacch_sym, uint8_t* sacch_rel, uint8_t* facch_sym,
+                          uint8_t* facch_rel, uint8_t* valid, hipStream_t st) {
+    if (n_channels <= 0 || max_sync <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_nxdn_frame_gather, dim3((unsigned)max_sync, (unsigned)n_channels), dim3(128), 0, st, rec, counts, max_sym,
+                       sync_pos, n_sync, max_sync, lich, sacch_sym, sacch_rel, facch_sym, facch_rel, valid);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_nxdn_crc(const uint8_t* bytes, int stride, int n, int kind, uint8_t* ok, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_nxdn_crc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bytes, stride, n, kind, ok);
     return hipGetLastError();
 }
 

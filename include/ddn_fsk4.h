@@ -69,6 +69,20 @@ int ddn_fsk4_rx_get_timing(ddn_fsk4_rx* b, float* ms2); /* {matched filter, rece
 int ddn_dmr_burst_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols, const int32_t* d_sync_pos,
                          const uint8_t* d_pre, const int32_t* d_n_sync, int n_channels, size_t max_syncs, int inverted,
                          uint8_t* d_slot_type, uint8_t* d_info, uint8_t* d_cach, uint8_t* d_valid, void* hip_stream);
+
+/* NXDN frame fields from the records after each accepted frame sync (what nxdn_frame() assembles before its decoders,
+ * src/protocol/nxdn/nxdn_frame.c:181-199,311-331,596-621 + nxdn_descramble.c + nxdn_deperm.c:123-172): per sync slot
+ * (c * max_syncs + k) d_lich u8 = the 7-bit LICH, bit 7 set when its parity checks; d_sacch_sym / _rel u8 [36][2] and
+ * d_facch_sym / _rel u8 [2][96][2] = de-scrambled, de-interleaved, de-punctured symbol / reliability pairs in the layout
+ * ddn_fec_nxdn_conv_batch takes (36 steps -> 32 bits, 96 steps -> 92 bits; pass d_rel = NULL there for the hard-decision
+ * retry the reference falls back to when the soft decode fails its CRC, nxdn_deperm.c:1128-1135,1195-1200);
+ * d_valid = 1 when the 182 dibits lie inside this call's records. */
+int ddn_nxdn_frame_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols, const int32_t* d_sync_pos,
+                          const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_lich, uint8_t* d_sacch_sym,
+                          uint8_t* d_sacch_rel, uint8_t* d_facch_sym, uint8_t* d_facch_rel, uint8_t* d_valid, void* hip_stream);
+/* CRC of decoded NXDN fields, rows = ddn_fec_nxdn_conv_batch output: kind 0 = SACCH (26 bits + CRC6, nxdn_deperm.c:1246-1261),
+ * kind 1 = FACCH1 (80 bits + CRC12, nxdn_dcr_utils.c:21-42); d_ok [n] = 1 when the field's CRC matches */
+int ddn_nxdn_crc_check_batch(const uint8_t* d_bytes, int stride, size_t n, int kind, uint8_t* d_ok, void* hip_stream);
 #ifdef __cplusplus
 }
 #endif

@@ -652,6 +652,15 @@ int ddn_fec_bptc_196x96_host(const uint8_t* in196, int deinterleave, size_t n, u
 int ddn_fec_rs_12_9_batch(uint8_t* d_codewords12, size_t n, uint8_t* d_result, uint8_t* d_errors_found, uint8_t* d_syndrome3,
                           void* hip_stream);
 int ddn_fec_rs_12_9_host(uint8_t* codewords12, size_t n, uint8_t* result, uint8_t* errors_found, uint8_t* syndrome3);
+/* == trellis_decode (include/dsd-neo/fec/trellis.h:22, src/core/util/dsd_misc.c:24-71): the greedy four-bit-lookahead decoder of
+ * the K = 5 rate-1/2 code that the NXDN field decoders retry with when the soft Viterbi result fails its CRC
+ * (src/protocol/nxdn/nxdn_deperm.c:197-205).  One bit per byte; row i reads source bits [0, 2 * result_len + 6) and writes
+ * result_len bits. */
+int ddn_fec_trellis_decode_batch(const uint8_t* d_source_bits, int source_stride, size_t n, int result_len,
+                                 uint8_t* d_result_bits, int result_stride, void* hip_stream);
+int ddn_fec_trellis_decode_host(const uint8_t* source_bits, int source_stride, size_t n, int result_len, uint8_t* result_bits,
+                                int result_stride);
+void trellis_decode(uint8_t result[], const uint8_t source[], int result_len);
 /* drop-ins with the reference's names (single item, host pointers) */
 #ifndef __cplusplus
 #include <stdbool.h>

@@ -272,6 +272,7 @@ int orc_golay_dmr_decode(int n, uint8_t* rx);                               /* n
 int orc_qr_16_7_6_decode(uint8_t* rx);
 uint32_t orc_bptc_196x96(const uint8_t* in196, int deinterleave, uint8_t out96[96], uint8_t r3[3]);
 int orc_bptc_last_col0_failed(void);
+void orc_trellis_decode(uint8_t* result, const uint8_t* source, int result_len);
 int orc_rs_12_9(uint8_t cw[12], uint8_t syn3[3], uint8_t* found);
 
 /* ---- getSymbol()'s sample loop in all its window / timing variants (oracle/ddn_oracle_symbolizer.c) ---------- */

@@ -400,3 +400,29 @@ orc_rs_12_9(uint8_t cw[12], uint8_t syn3[3], uint8_t* found) {
     }
     return 1;
 }
+
+/* trellis_decode(), src/core/util/dsd_misc.c:24-71: greedy decode of the K = 5 rate-1/2 code, four bits of lookahead.
+ * source holds 2 * result_len + 6 bits (the last output bit compares source[2p .. 2p + 7]). */
+void
+orc_trellis_decode(uint8_t* result, const uint8_t* source, int result_len) {
+    static const int par5[32] = {0, 1, 1, 0, 1, 0, 0, 1, 1, 0, 0, 1, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1, 1, 0, 0, 1, 1, 0, 1, 0, 0, 1};
+    unsigned reg = 0;
+    int min_d = 9999, min_bt = 0;
+    for (int p = 0; p < result_len; p++) {
+        for (int c = 0; c < 16; c++) {
+            unsigned r = reg;
+            int sum = 0;
+            for (int b = 0; b < 4; b++) {
+                r = ((r << 1) | (unsigned)((c >> (3 - b)) & 1)) & 0x1Fu;
+                sum += par5[r & 0x19u] ^ source[p * 2 + 2 * b];
+                sum += par5[r & 0x17u] ^ source[p * 2 + 2 * b + 1];
+            }
+            if (c == 0 || sum < min_d) {
+                min_d = sum;
+                min_bt = (c >> 3) & 1;
+            }
+        }
+        result[p] = (uint8_t)min_bt;
+        reg = ((reg << 1) | (unsigned)min_bt) & 0x1Fu;
+    }
+}

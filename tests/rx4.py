@@ -180,3 +180,88 @@ def capture_disc(name, lpf_profile):
     from conftest import golden
     g = golden(name)
     return orc.OracleFrontEnd(profile=lpf_profile).run_cu8(np.ascontiguousarray(g["iq"], np.uint8), 8192)
+
+
+# ---- NXDN frame fields (what nxdn_frame() assembles: src/protocol/nxdn/nxdn_frame.c:181-199,311-331, nxdn_descramble.c,
+# ---- nxdn_deperm.c:123-172) and the CRCs of its decoded fields ---------------------------------------------------------------
+def nxdn_pn9(n=182, seed=228):
+    l, o = seed, []
+    for _ in range(n):
+        o.append(l & 1)
+        b = ((l >> 4) ^ l) & 1
+        l = (l >> 1) | (b << 8)
+    return np.array(o, np.uint8)
+
+
+def nxdn_frame_fields(dibits182, rel182):
+    """-> (lich7, lich_parity_ok, sacch_sym [36][2], sacch_rel, facch_sym [2][96][2], facch_rel)"""
+    d = np.asarray(dibits182, np.uint8) ^ (nxdn_pn9() << 1)
+    lich = 0
+    for i in range(8):
+        lich |= int(d[i] >> 1) << (7 - i)
+    par = ((lich >> 7) + (lich >> 6) + (lich >> 5) + (lich >> 4)) & 1
+    if (lich >> 1) in (0x08, 0x4A, 0x48, 0x46):
+        par = sum((lich >> k) for k in range(1, 8)) & 1
+    bits = np.stack([d >> 1, d & 1], 1).reshape(-1)
+    rel = np.repeat(np.asarray(rel182, np.uint8), 2)
+    dep, depr = np.zeros(60, np.uint8), np.zeros(60, np.uint8)
+    p125 = np.array([(i % 5) * 12 + i // 5 for i in range(60)])
+    dep[p125], depr[p125] = bits[16:76], rel[16:76]
+    ss, sr = [], []
+    for p in range(0, 60, 10):
+        for m in (0, 1, 2, 3, 4, None, 5, 6, 7, 8, 9, None):
+            ss.append(0 if m is None else int(dep[p + m]) << 1)
+            sr.append(0 if m is None else int(depr[p + m]))
+    p169 = np.array([(i % 9) * 16 + i // 9 for i in range(144)])
+    fs, fr = [], []
+    for off in (76, 220):
+        dep, depr = np.zeros(144, np.uint8), np.zeros(144, np.uint8)
+        dep[p169], depr[p169] = bits[off:off + 144], rel[off:off + 144]
+        for i in range(0, 144, 3):
+            fs += [int(dep[i]) << 1, 0, int(dep[i + 1]) << 1, int(dep[i + 2]) << 1]
+            fr += [int(depr[i]), 0, int(depr[i + 1]), int(depr[i + 2])]
+    return (lich >> 1, (lich & 1) == par, np.array(ss, np.uint8).reshape(36, 2), np.array(sr, np.uint8).reshape(36, 2),
+            np.array(fs, np.uint8).reshape(2, 96, 2), np.array(fr, np.uint8).reshape(2, 96, 2))
+
+
+def nxdn_crc_ok(bits, kind):
+    """kind 0: 26 + CRC6 (x^6+x^5+x^2+x+1), kind 1: 80 + CRC12 (x^12+x^11+x^3+x^2+x+1); registers start all ones"""
+    nd, nc, poly = (26, 6, 0x27) if kind == 0 else (80, 12, 0x80F)
+    crc, mask, top = (1 << nc) - 1, (1 << nc) - 1, 1 << (nc - 1)
+    for b in bits[:nd]:
+        fb = (1 if crc & top else 0) ^ int(b)
+        crc = (crc << 1) & mask
+        if fb:
+            crc ^= poly
+    return crc == bits_int(bits[nd:nd + nc])
+
+
+def nxdn_superframes(sacch_rows):
+    """sacch_rows: decoded 32-bit SACCH fields (bit arrays) that passed their CRC, in order -> list of (ran, 72-bit message)"""
+    out, cur = [], []
+    for t in sacch_rows:
+        sf = int(t[0]) * 2 + int(t[1])
+        if sf == 3:
+            cur = [t]
+        elif cur and len(cur) == 3 - sf:
+            cur.append(t)
+        else:
+            cur = []
+        if len(cur) == 4:
+            out.append((bits_int(cur[0][2:8]), np.concatenate([c[8:26] for c in cur])))
+            cur = []
+    return out
+
+
+def oracle_trellis_decode(source_bits, result_len):
+    """rows of 0/1 bits (>= 2 * result_len + 6 each) -> [n][result_len] bits (oracle/ddn_oracle_fec3.c)"""
+    o = orc.oracle()
+    o.orc_trellis_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    o.orc_trellis_decode.restype = None
+    src = np.ascontiguousarray(source_bits, np.uint8)
+    assert src.shape[1] >= 2 * result_len + 6
+    out = np.zeros((src.shape[0], result_len), np.uint8)
+    for i in range(src.shape[0]):
+        row = np.ascontiguousarray(src[i])
+        o.orc_trellis_decode(out[i].ctypes.data, row.ctypes.data, result_len)
+    return out

@@ -117,3 +117,58 @@ def test_nxdn48_capture_frame_sync_cadence(built):
     assert len(acc) >= 20
     d = np.diff(acc)
     assert np.mean(d == 192) > 0.8
+
+
+def test_nxdn48_known_answer_src_901(built):
+    """The reference's NXDN48 capture through front end (6.25 kHz profile) -> NXDN48 receive loop -> de-scramble -> SACCH
+    de-interleave / de-puncture -> K=5 decoder (soft, then the hard-decision retry the reference falls back to) -> CRC6 ->
+    four-part superframes: the VCALL messages carry source unit 901 - the string DECODE_IQ_NXDN48 asserts ("Src=901",
+    tests/CMakeLists.txt:8948; VCALL layout: message type in bits 2..7, source unit ID in bits 24..39)."""
+    import fecgen
+    disc = rx4.capture_disc("iq_nxdn48.npz", 1)
+    out = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_NXDN48)).run(disc)
+    rows, lich_ok, n_fallback = [], 0, 0
+    for pos in out["sync_pos"]:
+        if pos + 183 > len(out["sym"]):
+            break
+        lich, pok, ss, sr, fs, fr = rx4.nxdn_frame_fields(out["rec4"][pos + 1:pos + 183, 0], out["rec4"][pos + 1:pos + 183, 1])
+        lich_ok += int(pok)
+        dec, _ = fecgen.oracle_nxdn(ss[None].copy(), sr[None].copy(), 36, 32)
+        t = np.unpackbits(dec[0])[:32]
+        if not rx4.nxdn_crc_ok(t, 0):       # nxdn_hard_fallback_decode(): trellis_decode on the de-punctured hard bits
+            t = rx4.oracle_trellis_decode((ss.reshape(-1) >> 1)[None], 32)[0]
+            n_fallback += 1
+        if rx4.nxdn_crc_ok(t, 0):
+            rows.append(t)
+    assert lich_ok >= 55 and len(rows) >= 50 and n_fallback > 0
+    msgs = rx4.nxdn_superframes(rows)
+    vcall = [m for ran, m in msgs if rx4.bits_int(m[2:8]) == 1]
+    assert len(vcall) >= 4 and all(ran == 1 for ran, _ in msgs)
+    assert all(rx4.bits_int(m[24:40]) == 901 for m in vcall)
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="needs oracle/_ref")
+def test_trellis_decode_restatement_equals_reference(built):
+    """orc_trellis_decode == the compiled trellis_decode (src/core/util/dsd_misc.c:24-71) on clean, noisy and random inputs"""
+    import ctypes as C
+    r = orc.ref()
+    r.trellis_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    r.trellis_decode.restype = None
+    rng = np.random.default_rng(12)
+    for ln in (32, 92, 5):
+        src = rng.integers(0, 2, (300, 2 * ln + 6), dtype=np.uint8)
+        # a third of the rows: valid code words with a few flips (register starts at 0, generators 0x19 / 0x17)
+        for i in range(0, 300, 3):
+            bits = rng.integers(0, 2, ln + 3, dtype=np.uint8)
+            reg, enc = 0, []
+            for b in bits:
+                reg = ((reg << 1) | int(b)) & 0x1F
+                enc += [bin(reg & 0x19).count("1") & 1, bin(reg & 0x17).count("1") & 1]
+            src[i] = np.array(enc, np.uint8)
+            src[i, rng.choice(2 * ln, int(rng.integers(0, 4)), replace=False)] ^= 1
+        got = rx4.oracle_trellis_decode(src, ln)
+        for i in range(300):
+            want = np.zeros(ln, np.uint8)
+            s_i = np.ascontiguousarray(src[i])
+            r.trellis_decode(want.ctypes.data, s_i.ctypes.data, ln)
+            assert np.array_equal(got[i], want), (ln, i)

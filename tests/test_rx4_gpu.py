@@ -142,3 +142,86 @@ def test_dmr_known_answers_on_device(built):
                 n_aloha += 1
                 assert rx4.bits_int(pdu[40:42]) == 2 and rx4.bits_int(pdu[42:46]) == 1 and rx4.bits_int(pdu[46:54]) == 1
     assert n_aloha >= 40
+
+
+def test_trellis_decode_batch_and_dropin(built):
+    l = ddn.lib()
+    rng = np.random.default_rng(3)
+    for ln in (32, 92):
+        src = rng.integers(0, 2, (500, 2 * ln + 6), dtype=np.uint8)
+        for i in range(0, 500, 2):
+            bits = rng.integers(0, 2, ln + 3, dtype=np.uint8)
+            reg, enc = 0, []
+            for b in bits:
+                reg = ((reg << 1) | int(b)) & 0x1F
+                enc += [bin(reg & 0x19).count("1") & 1, bin(reg & 0x17).count("1") & 1]
+            src[i] = np.array(enc, np.uint8)
+            src[i, rng.choice(2 * ln, int(rng.integers(0, 5)), replace=False)] ^= 1
+        want = rx4.oracle_trellis_decode(src, ln)
+        got = np.zeros((500, ln), np.uint8)
+        assert l.ddn_fec_trellis_decode_host(src.ctypes.data, src.shape[1], 500, ln, got.ctypes.data, ln) == 0
+        assert np.array_equal(got, want)
+        one = np.zeros(ln, np.uint8)
+        row = np.ascontiguousarray(src[7])
+        l.trellis_decode(one.ctypes.data, row.ctypes.data, ln)
+        assert np.array_equal(one, want[7])
+    assert l.ddn_fec_trellis_decode_host(src.ctypes.data, 10, 1, 32, got.ctypes.data, 32) != 0       # row too short for the lookahead
+
+
+def test_nxdn48_known_answer_on_device(built):
+    """NXDN48 capture, everything after the front end on the device: receive loop -> frame gather (de-scramble, LICH, SACCH /
+    FACCH1 de-interleave + de-puncture) -> K=5 soft decode -> CRC6 -> greedy retry for the rows that failed -> CRC6; the host
+    only strings the four SACCH parts together: VCALL source unit 901 ("Src=901", tests/CMakeLists.txt:8948).  The gather is also
+    checked field by field against the python restatement of nxdn_frame()'s unpacking."""
+    import torch
+    l = ddn.lib()
+    disc = rx4.capture_disc("iq_nxdn48.npz", 1)
+    B, n = 2, len(disc)
+    x = torch.from_numpy(np.stack([disc, np.roll(disc, 333)])).cuda()
+    rx = ddn.Fsk4Rx(B, ddn.FSK4_NXDN48)
+    ms, my = l.ddn_fsk4_rx_max_symbols(rx.h, n), l.ddn_fsk4_rx_max_syncs(rx.h, n)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+    u8, i32 = torch.uint8, torch.int32
+    rec, fl, pay = z((B, ms, 10), u8), z((B, ms), u8), z((B, ms, 2), u8)
+    cnt, ns, spos = z((B,), i32), z((B,), i32), z((B, my), i32)
+    spat, pre, prel = z((B, my), u8), z((B, my, 90), u8), z((B, my, 90), u8)
+    p = lambda t: t.data_ptr()
+    assert l.ddn_fsk4_rx_run(rx.h, p(x), n, p(rec), p(fl), p(pay), p(cnt), ms, p(spos), p(spat), p(pre), p(prel), p(ns), my, None) == 0
+    S = B * my
+    lich, valid = z((S,), u8), z((S,), u8)
+    ss, sr, fs, fr = z((S, 36, 2), u8), z((S, 36, 2), u8), z((S, 2, 96, 2), u8), z((S, 2, 96, 2), u8)
+    assert l.ddn_nxdn_frame_gather(p(rec), p(cnt), ms, p(spos), p(ns), B, my, p(lich), p(ss), p(sr), p(fs), p(fr), p(valid), None) == 0
+    soft, ok1 = z((S, 4), u8), z((S,), u8)
+    assert l.ddn_fec_nxdn_conv_batch(p(ss), p(sr), S, 36, 32, None, p(soft), 4, None) == 0
+    assert l.ddn_nxdn_crc_check_batch(p(soft), 4, S, 0, p(ok1), None) == 0
+    hard_in = (ss.reshape(S, 72) >> 1).contiguous()                      # de-punctured hard bits, 72 >= 2 * 32 + 6
+    hard, hard_bytes, ok2 = z((S, 32), u8), z((S, 4), u8), z((S,), u8)
+    assert l.ddn_fec_trellis_decode_batch(p(hard_in), 72, S, 32, p(hard), 32, None) == 0
+    torch.cuda.synchronize()
+    hb = np.packbits(hard.cpu().numpy(), axis=1)
+    hard_bytes.copy_(torch.from_numpy(hb).cuda())
+    assert l.ddn_nxdn_crc_check_batch(p(hard_bytes), 4, S, 0, p(ok2), None) == 0
+    torch.cuda.synchronize()
+    rec_h, spos_h, ns_h, valid_h, lich_h = (t.cpu().numpy() for t in (rec, spos, ns, valid, lich))
+    ss_h, sr_h, fs_h, fr_h = (t.cpu().numpy() for t in (ss, sr, fs, fr))
+    soft_h, ok1_h, ok2_h = soft.cpu().numpy(), ok1.cpu().numpy(), ok2.cpu().numpy()
+    for c in range(B):
+        rows = []
+        for k in range(int(ns_h[c])):
+            s = c * my + k
+            if not valid_h[s]:
+                continue
+            pos = int(spos_h[c, k])
+            wl, wp, wss, wsr, wfs, wfr = rx4.nxdn_frame_fields(rec_h[c, pos + 1:pos + 183, 0] & 3, rec_h[c, pos + 1:pos + 183, 1])
+            assert lich_h[s] == (wl | (0x80 if wp else 0))
+            assert np.array_equal(ss_h[s], wss) and np.array_equal(sr_h[s], wsr)
+            assert np.array_equal(fs_h[s], wfs) and np.array_equal(fr_h[s], wfr)
+            t_soft = np.unpackbits(soft_h[s])[:32]
+            assert bool(ok1_h[s]) == rx4.nxdn_crc_ok(t_soft, 0)
+            t = t_soft if ok1_h[s] else np.unpackbits(hb[s])[:32]
+            if ok1_h[s] or ok2_h[s]:
+                rows.append(t)
+        msgs = rx4.nxdn_superframes(rows)
+        vcall = [m for ran, m in msgs if rx4.bits_int(m[2:8]) == 1]
+        assert len(rows) >= 50 and len(vcall) >= 4
+        assert all(rx4.bits_int(m[24:40]) == 901 for m in vcall)
