@@ -442,6 +442,10 @@ def configs3_mixed(torch, ddn, np, p25_chain, d_iq_p25, B_total, n, steps):
     rows = np.flatnonzero(valid)
     rows = rows[(rows % cd.my) != 0]
     cc_ok = bool(len(rows) > 0 and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0) and np.mean(errs[rows] == 0) > 0.99)
+    # NXDN48: LICH parity and SACCH CRC6 (soft decode or the greedy retry) on the complete frames
+    nv, nl, ns1, ns2 = (t.cpu().numpy() for t in (cn.valid, cn.lich, cn.sacch_ok, cn.sacch_hard_ok))
+    nrows = np.flatnonzero(nv)
+    nx_ok = bool(len(nrows) > 0 and np.mean((nl[nrows] & 0x80) != 0) > 0.9 and np.mean((ns1[nrows] | ns2[nrows]) != 0) > 0.6)   # a fresh stream's first frames fall in the filter's cold start
 
     l = ddn.lib()
     for _ in range(3):
@@ -478,11 +482,15 @@ def configs3_mixed(torch, ddn, np, p25_chain, d_iq_p25, B_total, n, steps):
     l.ddn_fsk4_rx_get_timing(cn.rx.h, t2n.ctypes.data)
     out = {"workload": "configs[3] shape on one GPU: %d channels = %d P25 Phase 1 + %d DMR (Tier III control channel capture, GFSK rules) + "
                        "%d NXDN48 (capture), %d cu8 samples each; per protocol front end -> matched filter -> receive loop -> frame FEC "
-                       "(DMR: burst gather + Golay(20,8) + BPTC(196,96); NXDN48: to dibits)" % (B_total, Bp, Bd, Bn, n),
+                       "(DMR: burst gather + Golay(20,8) + BPTC(196,96); NXDN48: frame gather + SACCH / FACCH1 K=5 decode + CRC + "
+                       "greedy retry)" % (B_total, Bp, Bd, Bn, n),
            "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(B_total * n / dt / 1e6, 1),
            "chain_ms": {"p25p1": round(float(ms[0]), 3), "dmr": round(float(ms[1]), 3), "nxdn48": round(float(ms[2]), 3)},
            "k_fsk4_rx_ms": {"dmr": round(float(t2d[1]), 3), "nxdn48": round(float(t2n[1]), 3)},
-           "parity": {"channels_checked": checked, "bit_exact": par_ok, "dmr_colour_code_0_csbk_bptc_clean": cc_ok},
+           "parity": {"channels_checked": checked, "bit_exact": par_ok, "dmr_colour_code_0_csbk_bptc_clean": cc_ok,
+                      "nxdn_lich_parity_and_sacch_crc": nx_ok,
+                      "nxdn_fractions": [round(float(np.mean((nl[nrows] & 0x80) != 0)), 3), round(float(np.mean(ns1[nrows] != 0)), 3),
+                                         round(float(np.mean((ns1[nrows] | ns2[nrows]) != 0)), 3), int(len(nrows))]},
            "work_per_step": {"dmr_syncs": int(cd.ns.sum().item()), "nxdn_syncs": int(cn.ns.sum().item())}}
     for c in (cp, cd.fe, cn.fe, cd.rx, cn.rx):
         c.close()

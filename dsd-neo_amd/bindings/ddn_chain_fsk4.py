@@ -28,6 +28,13 @@ class Fsk4Chain:
         if dmr:
             self.st, self.info, self.cach, self.valid = z((S, 20), u8), z((S, 196), u8), z((S, 24), u8), z((S,), u8)
             self.st_ok, self.pdu, self.r3, self.errs = z((S,), u8), z((S, 96), u8), z((S, 3), u8), z((S,), i32)
+        else:
+            self.lich, self.valid = z((S,), u8), z((S,), u8)
+            self.ss, self.sr = z((S, 36, 2), u8), z((S, 36, 2), u8)
+            self.fs, self.fr = z((S, 2, 96, 2), u8), z((S, 2, 96, 2), u8)
+            self.sacch, self.sacch_ok = z((S, 4), u8), z((S,), u8)
+            self.sacch_hard, self.sacch_hard_ok = z((S, 32), u8), z((S,), u8)
+            self.facch, self.facch_ok = z((S * 2, 12), u8), z((S * 2,), u8)
 
     def front_end(self, d_iq, st):
         self.fe.run_device(d_iq.data_ptr(), self.n, self.disc.data_ptr(), st)
@@ -38,9 +45,20 @@ class Fsk4Chain:
                                       p(self.spos), p(self.spat), p(self.pre), p(self.prel), p(self.ns), self.my, st) == 0
 
     def burst_fec(self, st):
-        if self.protocol != ddn.FSK4_DMR:
-            return
         l, p = self.l, (lambda t: t.data_ptr())
+        if self.protocol != ddn.FSK4_DMR:
+            # NXDN48: frame gather -> SACCH / FACCH1 K=5 soft decode -> CRC6 / CRC12 -> the reference's greedy retry for the SACCH
+            S = self.S
+            assert l.ddn_nxdn_frame_gather(p(self.rec), p(self.cnt), self.ms, p(self.spos), p(self.ns), self.B, self.my, p(self.lich),
+                                           p(self.ss), p(self.sr), p(self.fs), p(self.fr), p(self.valid), st) == 0
+            assert l.ddn_fec_nxdn_conv_batch(p(self.ss), p(self.sr), S, 36, 32, None, p(self.sacch), 4, st) == 0
+            assert l.ddn_nxdn_crc_check_batch(p(self.sacch), 4, S, 0, p(self.sacch_ok), st) == 0
+            hard_in = self.ss.view(S, 72) >> 1
+            assert l.ddn_fec_trellis_decode_batch(p(hard_in), 72, S, 32, p(self.sacch_hard), 32, st) == 0
+            assert l.ddn_nxdn_crc_check_batch(p(self.sacch_hard), 32, S, 2, p(self.sacch_hard_ok), st) == 0
+            assert l.ddn_fec_nxdn_conv_batch(p(self.fs), p(self.fr), S * 2, 96, 92, None, p(self.facch), 12, st) == 0
+            assert l.ddn_nxdn_crc_check_batch(p(self.facch), 12, S * 2, 1, p(self.facch_ok), st) == 0
+            return
         assert l.ddn_dmr_burst_gather(p(self.rec), p(self.cnt), self.ms, p(self.spos), p(self.pre), p(self.ns), self.B, self.my,
                                       self.inverted, p(self.st), p(self.info), p(self.cach), p(self.valid), st) == 0
         assert l.ddn_fec_block_code_batch(5, p(self.st), self.S, 1, None, p(self.st_ok), st) == 0        # DDN_CODE_GOLAY_20_8

@@ -466,7 +466,7 @@ ddn_nxdn_frame_gather(const uint8_t* d_records10, const int32_t* d_counts, size_
 
 extern "C" int
 ddn_nxdn_crc_check_batch(const uint8_t* d_bytes, int stride, size_t n, int kind, uint8_t* d_ok, void* hip_stream) {
-    if (!d_bytes || !d_ok || stride <= 0 || (kind != 0 && kind != 1) || stride * 8 < (kind == 0 ? 32 : 92)) {
+    if (!d_bytes || !d_ok || stride <= 0 || kind < 0 || kind > 3 || stride * ((kind & 2) ? 1 : 8) < ((kind & 1) == 0 ? 32 : 92)) {
         return DDN_EINVAL;
     }
     HIP_TRY(ddn_dev_nxdn_crc(d_bytes, stride, (int)n, kind, d_ok, (hipStream_t)hip_stream));

@@ -838,12 +838,14 @@ k_nxdn_crc(const uint8_t* __restrict__ bytes, int stride, int n, int kind, uint8
         return;
     }
     const uint8_t* b = bytes + (size_t)i * stride;
+    const bool bitrows = (kind & 2) != 0; // rows hold one bit per byte (trellis_decode output) instead of packed bytes
+    kind &= 1;
     const int nd = kind == 0 ? 26 : 80, nc = kind == 0 ? 6 : 12;
     const unsigned poly = kind == 0 ? 0x27u : 0x80Fu; // x^5+x^2+x+1 / x^11+x^3+x^2+x+1 below the leading term
     const unsigned top = 1u << (nc - 1), mask = (1u << nc) - 1u;
     unsigned crc = mask;
     for (int k = 0; k < nd; k++) {
-        const unsigned in = (b[k >> 3] >> (7 - (k & 7))) & 1u;
+        const unsigned in = bitrows ? (b[k] & 1u) : ((b[k >> 3] >> (7 - (k & 7))) & 1u);
         const unsigned fb = ((crc & top) ? 1u : 0u) ^ in;
         crc = (crc << 1) & mask;
         if (fb) {
@@ -852,7 +854,7 @@ k_nxdn_crc(const uint8_t* __restrict__ bytes, int stride, int n, int kind, uint8
     }
     unsigned got = 0;
     for (int k = nd; k < nd + nc; k++) {
-        got = (got << 1) | ((b[k >> 3] >> (7 - (k & 7))) & 1u);
+        got = (got << 1) | (bitrows ? (b[k] & 1u) : ((b[k >> 3] >> (7 - (k & 7))) & 1u));
     }
     ok[i] = crc == got ? 1 : 0;
 }

@@ -81,7 +81,8 @@ int ddn_nxdn_frame_gather(const uint8_t* d_records10, const int32_t* d_counts, s
                           const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_lich, uint8_t* d_sacch_sym,
                           uint8_t* d_sacch_rel, uint8_t* d_facch_sym, uint8_t* d_facch_rel, uint8_t* d_valid, void* hip_stream);
 /* CRC of decoded NXDN fields, rows = ddn_fec_nxdn_conv_batch output: kind 0 = SACCH (26 bits + CRC6, nxdn_deperm.c:1246-1261),
- * kind 1 = FACCH1 (80 bits + CRC12, nxdn_dcr_utils.c:21-42); d_ok [n] = 1 when the field's CRC matches */
+ * kind 1 = FACCH1 (80 bits + CRC12, nxdn_dcr_utils.c:21-42); kind + 2 = the same on rows of one bit per byte (what
+ * ddn_fec_trellis_decode_batch writes); d_ok [n] = 1 when the field's CRC matches */
 int ddn_nxdn_crc_check_batch(const uint8_t* d_bytes, int stride, size_t n, int kind, uint8_t* d_ok, void* hip_stream);
 #ifdef __cplusplus
 }

@@ -195,13 +195,11 @@ def test_nxdn48_known_answer_on_device(built):
     assert l.ddn_fec_nxdn_conv_batch(p(ss), p(sr), S, 36, 32, None, p(soft), 4, None) == 0
     assert l.ddn_nxdn_crc_check_batch(p(soft), 4, S, 0, p(ok1), None) == 0
     hard_in = (ss.reshape(S, 72) >> 1).contiguous()                      # de-punctured hard bits, 72 >= 2 * 32 + 6
-    hard, hard_bytes, ok2 = z((S, 32), u8), z((S, 4), u8), z((S,), u8)
+    hard, ok2 = z((S, 32), u8), z((S,), u8)
     assert l.ddn_fec_trellis_decode_batch(p(hard_in), 72, S, 32, p(hard), 32, None) == 0
+    assert l.ddn_nxdn_crc_check_batch(p(hard), 32, S, 2, p(ok2), None) == 0      # kind 2: SACCH on bit rows
     torch.cuda.synchronize()
     hb = np.packbits(hard.cpu().numpy(), axis=1)
-    hard_bytes.copy_(torch.from_numpy(hb).cuda())
-    assert l.ddn_nxdn_crc_check_batch(p(hard_bytes), 4, S, 0, p(ok2), None) == 0
-    torch.cuda.synchronize()
     rec_h, spos_h, ns_h, valid_h, lich_h = (t.cpu().numpy() for t in (rec, spos, ns, valid, lich))
     ss_h, sr_h, fs_h, fr_h = (t.cpu().numpy() for t in (ss, sr, fs, fr))
     soft_h, ok1_h, ok2_h = soft.cpu().numpy(), ok1.cpu().numpy(), ok2.cpu().numpy()
