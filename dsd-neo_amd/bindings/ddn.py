@@ -33,6 +33,16 @@ class Cu8Moments(C.Structure):  # == dsd_input_level_cu8_moments (include/ddn_hi
                 ("min_sample", C.c_uint8), ("max_sample", C.c_uint8)]
 
 
+class ModeFlags(C.Structure):  # == ddn_mode_flags
+    _fields_ = [(k, C.c_int) for k in ("p25p1", "p25p2", "provoice", "dmr", "nxdn48", "nxdn96", "x2tdma", "ysf", "dstar", "dpmr", "m17",
+                                       "mod_qpsk", "analog_only")]
+
+
+class ModeResult(C.Structure):  # == ddn_mode_result
+    _fields_ = [(k, C.c_int) for k in ("output_kind", "symbol_rate_hz", "symbol_levels", "lpf_profile", "channel_lpf_enable",
+                                       "cqpsk_enable", "ted_enabled", "samples_per_symbol")]
+
+
 class FskModemState(C.Structure):
     _fields_ = [
         ("cfg_sample_rate_hz", C.c_int),
@@ -339,6 +349,7 @@ PROTOTYPES.update({
     "ddn_fsk4_rx_get_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_fsk4_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_fsk4_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_mode_config": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_nxdn_frame_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 7),
     "ddn_nxdn_crc_check_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_dmr_burst_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int]

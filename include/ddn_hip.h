@@ -253,6 +253,26 @@ int ddn_iq_load_batch(const char* const* paths, int n_captures, void** out_buf, 
                       ddn_iq_capture_info* out_info0);
 void ddn_iq_free(void* p);
 
+/* ---- the demod thread's mode matrix -----------------------------------------------------------------
+ * == rtl_demod_init_for_mode() + demod_apply_channel_lpf_defaults() (src/io/radio/rtl_demod_config.cpp:63-258,491-553): from
+ * the enabled protocol flags (dsd_opts frame_* fields, 1 = enabled), the CQPSK modulation choice and the demod rate to what a
+ * batch must be created with.  Host logic, no device needed. */
+typedef struct ddn_mode_flags {
+    int p25p1, p25p2, provoice, dmr, nxdn48, nxdn96, x2tdma, ysf, dstar, dpmr, m17;
+    int mod_qpsk;    /* opts->mod_qpsk: CQPSK / LSM reception requested */
+    int analog_only; /* opts->analog_only or the M17 encoder: audio monitor, no symbol output */
+} ddn_mode_flags;
+enum { DDN_OUTPUT_AUDIO_MONITOR = 0, DDN_OUTPUT_FSK_DISCRIMINATOR = 1, DDN_OUTPUT_SYMBOL_CQPSK = 2 };
+typedef struct ddn_mode_result {
+    int output_kind;        /* DDN_OUTPUT_*: which of ddn_front_end_run / ddn_cqpsk_run serves the batch */
+    int symbol_rate_hz, symbol_levels;
+    int lpf_profile;        /* DDN_LPF_* */
+    int channel_lpf_enable; /* on from 20 kHz demod rate */
+    int cqpsk_enable, ted_enabled;
+    int samples_per_symbol; /* demod rate / symbol rate, rounded (the Gardner loop's sps on the CQPSK path) */
+} ddn_mode_result;
+int ddn_mode_config(const ddn_mode_flags* flags, int demod_rate_hz, ddn_mode_result* out);
+
 /* ---- the consumer-side seam: serving dsd-neo's stream-read hook from batched results ---------------
  * A dsd-neo decoder thread pulls samples through dsd_rtl_stream_io_hooks.read(rtl_ctx, out, count, &got)
  * (include/dsd-neo/runtime/rtl_stream_io_hooks.h:25-32; callers src/dsp/dsd_symbol.c:889-920,1412-1435: count is 512 or
