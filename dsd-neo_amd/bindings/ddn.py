@@ -350,6 +350,11 @@ PROTOTYPES.update({
     "ddn_fsk4_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_fsk4_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_mode_config": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ddn_audio_agf_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_audio_agf_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "ddn_agf_frame": (C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
+    "ddn_symbol_capture_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "ddn_wav_write_s16": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_float]),
     "ddn_nxdn_frame_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 7),
     "ddn_nxdn_crc_check_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_dmr_burst_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int]

@@ -253,6 +253,22 @@ int ddn_iq_load_batch(const char* const* paths, int n_captures, void** out_buf, 
                       ddn_iq_capture_info* out_info0);
 void ddn_iq_free(void* p);
 
+/* ---- downstream of the vocoder / of the receive loop: what dsd-neo does with the path's results -------------
+ * ddn_audio_agf_*  == agf() (include/dsd-neo/core/audio.h:87, src/core/audio/gain.c:119-139): the float-path auto gain applied
+ *                  to every synthesized 160-sample frame (playSynthesizedVoiceFS / FM, src/core/audio/dsd_audio2.c:1100,1111).
+ *                  pcm f32 [n_streams][n_frames][160] in place (the vocoder's output, int16-scale floats), aout_gain f32
+ *                  [n_streams] = state->aout_gain carried across calls (dsd-neo starts it at 25); audio_gain = opts->audio_gain
+ *                  (0 = automatic), algid_0x21 = the reference's x1.75 for that ALGID.
+ * ddn_symbol_capture_write  dsd-neo's -c symbol-capture file from a receive loop's records + flags (header + records,
+ *                  src/core/file/dsd_file.c:876-890, src/core/frames/dsd_dibit.c:794-818); append != 0 continues a file.
+ * ddn_wav_write_s16  PCM16 RIFF / WAVE file from float PCM (full_scale = the float value that maps to 32767). */
+int ddn_audio_agf_batch(float* d_pcm, int n_streams, int n_frames, float audio_gain, int algid_0x21, float* d_aout_gain,
+                        void* hip_stream);
+int ddn_audio_agf_host(float* pcm, int n_streams, int n_frames, float audio_gain, int algid_0x21, float* aout_gain);
+int ddn_agf_frame(float samp[160], float audio_gain, int algid_0x21, float* aout_gain_io);
+int ddn_symbol_capture_write(const char* path, const uint8_t* records10, const uint8_t* flags, size_t count, int append);
+int ddn_wav_write_s16(const char* path, int sample_rate_hz, int channels, const float* pcm, size_t frames, float full_scale);
+
 /* ---- the demod thread's mode matrix -----------------------------------------------------------------
  * == rtl_demod_init_for_mode() + demod_apply_channel_lpf_defaults() (src/io/radio/rtl_demod_config.cpp:63-258,491-553): from
  * the enabled protocol flags (dsd_opts frame_* fields, 1 = enabled), the CQPSK modulation choice and the demod rate to what a

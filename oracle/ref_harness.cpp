@@ -403,6 +403,24 @@ refh_fsk4_filter_run(int which, const float* in, long n, int sps, int reset, flo
 // dmr_compute_reliability on the slicer harness state is not needed: it is c4fm_reliability_from_thresholds + the SNR
 // weight, both already exercised through getDibitSoft (refh_slicer_*).
 
+extern "C" void agf(const dsd_opts* opts, dsd_state* state, float samp[160], int slot); // include/dsd-neo/core/audio.h:87
+// agf(): the float-path auto gain applied to every synthesized 160-sample voice frame (src/core/audio/gain.c:119-139), frames
+// of one talk path in order; aout_gain is carried in and out like state->aout_gain (slot 0).
+void
+refh_agf_run(float* samp, int n_frames, float audio_gain, int algid_0x21, float* aout_gain_io) {
+    dsd_opts* o = static_cast<dsd_opts*>(calloc(1, sizeof(dsd_opts)));
+    dsd_state* st = static_cast<dsd_state*>(calloc(1, sizeof(dsd_state)));
+    o->audio_gain = audio_gain;
+    st->payload_algid = algid_0x21 ? 0x21 : 0;
+    st->aout_gain = *aout_gain_io;
+    for (int f = 0; f < n_frames; f++) {
+        agf(o, st, samp + (size_t)f * 160, 0);
+    }
+    *aout_gain_io = st->aout_gain;
+    free(o);
+    free(st);
+}
+
 int
 refh_sync_p25p1_pos(void) {
     return DSD_SYNC_P25P1_POS;

@@ -230,3 +230,27 @@ def test_dropin_table_blob_is_loadable(built):
     finally:
         d = mbe.tables()
         assert l.ddn_mbe_dropin_set_tables(C.byref(d)) == 0
+
+
+def test_agf_batch_bit_exact(built):
+    """the voice-frame auto gain on the device == the CPU restatement (itself pinned to the compiled gain.c): samples and the
+    carried gain state, several talk paths, across two calls"""
+    from test_oracle_audio import oracle_agf, voice_like
+    l = ddn.lib()
+    rng = np.random.default_rng(6)
+    S, F = 70, 24
+    pcm = voice_like(rng, S, F)
+    for audio_gain, a21 in ((0.0, 0), (30.0, 0), (0.0, 1)):
+        g_cpu = np.full(S, 25.0, np.float32)
+        g_gpu = g_cpu.copy()
+        for part in (slice(0, 10), slice(10, F)):
+            want, g_cpu = oracle_agf(pcm[:, part], g_cpu, audio_gain, a21)
+            got = np.ascontiguousarray(pcm[:, part]).copy()
+            assert l.ddn_audio_agf_host(got.ctypes.data, S, got.shape[1], audio_gain, a21, g_gpu.ctypes.data) == 0
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            assert np.array_equal(g_gpu, g_cpu)
+    one = np.ascontiguousarray(pcm[3, 0]).copy()
+    g = np.array([25.0], np.float32)
+    assert l.ddn_agf_frame(one.ctypes.data, 0.0, 0, g.ctypes.data) == 0
+    w, gw = oracle_agf(pcm[3:4, 0:1], np.array([25.0], np.float32))
+    assert np.array_equal(one.view(np.uint32), w[0, 0].view(np.uint32)) and g[0] == gw[0]
