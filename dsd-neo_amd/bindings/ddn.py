@@ -297,6 +297,7 @@ PROTOTYPES.update({
     "rs_12_9_correct_errors": (C.c_uint8, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_p25_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_p25_rx_get_timing_avg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_mbe_default_tables": (C.c_int, [C.POINTER(MbeTables)]),
     "ddn_mbe_validate_tables": (C.c_int, [C.POINTER(MbeTables)]),
     "ddn_mbe_frame_decode_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -34,6 +34,10 @@ struct ddn_p25_rx {
     bool timing;
     hipEvent_t ev[3];
     float last_ms[2]; // matched filter, receive-loop kernel
+    // timing history: event triples of the last DDN_RX_TRING launches, so a caller can average launch durations over a run
+    // without synchronising between launches (ddn_p25_rx_get_timing_avg)
+    hipEvent_t ring[64][3];
+    int ring_n, ring_head;
 };
 
 static void
@@ -51,6 +55,13 @@ rx_free(ddn_p25_rx* b) {
     for (int i = 0; i < 3; i++) {
         if (b->ev[i]) {
             (void)hipEventDestroy(b->ev[i]);
+        }
+    }
+    for (int k = 0; k < 64; k++) {
+        for (int i = 0; i < 3; i++) {
+            if (b->ring[k][i]) {
+                (void)hipEventDestroy(b->ring[k][i]);
+            }
         }
     }
 }
@@ -214,8 +225,16 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
                       ddn_p25_rx_max_symbols(b, n));
         return DDN_ERANGE;
     }
+    hipEvent_t* rv = nullptr;
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[0], st));
+        rv = b->ring[b->ring_head];
+        for (int i = 0; i < 3; i++) {
+            if (!rv[i]) {
+                HIP_TRY(hipEventCreate(&rv[i]));
+            }
+        }
+        HIP_TRY(hipEventRecord(rv[0], st));
     }
     if (b->cfg.use_matched_filter) {
         if (b->filt_cap < n) {
@@ -230,6 +249,7 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
     }
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[1], st));
+        HIP_TRY(hipEventRecord(rv[1], st));
     }
     DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0};
     if (const char* e = getenv("DDN_RX_DBG")) {
@@ -240,6 +260,9 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
                            b->channels_per_wave, b->d_lock, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
+        HIP_TRY(hipEventRecord(rv[2], st));
+        b->ring_head = (b->ring_head + 1) % 64;
+        b->ring_n = b->ring_n < 64 ? b->ring_n + 1 : 64;
     }
     // the filter memory (last 90 raw samples) moves on only after the loop has read the previous tail
     HIP_TRY(ddn_dev_p25_filter_hist_update(d_disc, (long)n, n, B, b->d_fhist, st));
@@ -257,6 +280,35 @@ ddn_p25_rx_set_timing(ddn_p25_rx* b, int enable) {
         }
     }
     b->timing = enable != 0;
+    b->ring_n = 0;
+    b->ring_head = 0;
+    return DDN_OK;
+}
+
+// average {matched filter, receive-loop kernel} launch durations over the launches recorded since timing was switched on
+// (the last 64 at most); *n_launches = how many went into it.  Synchronises on the last one.
+extern "C" int
+ddn_p25_rx_get_timing_avg(ddn_p25_rx* b, float* ms2, int* n_launches) {
+    if (!b || !ms2 || !n_launches) {
+        return DDN_EINVAL;
+    }
+    ms2[0] = ms2[1] = 0.0f;
+    *n_launches = b->ring_n;
+    if (b->ring_n == 0) {
+        return DDN_OK;
+    }
+    const int last = (b->ring_head + 63) % 64;
+    HIP_TRY(hipEventSynchronize(b->ring[last][2]));
+    for (int k = 0; k < b->ring_n; k++) {
+        const int idx = (b->ring_head + 64 - 1 - k) % 64;
+        float a = 0.0f, c = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&a, b->ring[idx][0], b->ring[idx][1]));
+        HIP_TRY(hipEventElapsedTime(&c, b->ring[idx][1], b->ring[idx][2]));
+        ms2[0] += a;
+        ms2[1] += c;
+    }
+    ms2[0] /= (float)b->ring_n;
+    ms2[1] /= (float)b->ring_n;
     return DDN_OK;
 }
 

@@ -175,6 +175,8 @@ int ddn_p25_rx_set_lock_symbols(ddn_p25_rx* b, const int32_t* per_channel);
 /* kernel times of the last ddn_p25_rx_run(), HIP events on the launch stream: ms2 = {matched filter, receive-loop kernel} */
 int ddn_p25_rx_set_timing(ddn_p25_rx* b, int enable);
 int ddn_p25_rx_get_timing(ddn_p25_rx* b, float* ms2);
+/* the same averaged over the launches since timing was switched on (at most the last 64), without synchronising between them */
+int ddn_p25_rx_get_timing_avg(ddn_p25_rx* b, float* ms2, int* n_launches);
 int ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave); /* 0 = automatic, else 16 / 32 / 64 */
 size_t ddn_p25_rx_max_symbols(const ddn_p25_rx* b, size_t n);
 int ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records10, uint8_t* d_flags,
