@@ -43,6 +43,14 @@ class ModeResult(C.Structure):  # == ddn_mode_result
                                        "cqpsk_enable", "ted_enabled", "samples_per_symbol")]
 
 
+class DemodState(C.Structure):  # == struct demod_state of include/ddn_demod_adapter.h
+    _fields_ = [("lowpassed", C.POINTER(C.c_float)), ("lp_len", C.c_int), ("result", C.POINTER(C.c_float)), ("result_len", C.c_int),
+                ("rate_in", C.c_int), ("rate_out", C.c_int), ("output_kind", C.c_int), ("symbol_rate_hz", C.c_int),
+                ("symbol_levels", C.c_int), ("channel_lpf_enable", C.c_int), ("channel_lpf_profile", C.c_int),
+                ("channel_squelch_level", C.c_float), ("cqpsk_enable", C.c_int), ("ted_enabled", C.c_int), ("ted_sps", C.c_int),
+                ("ted_gain", C.c_float), ("ddn_adapter", C.c_void_p)]
+
+
 class FskModemState(C.Structure):
     _fields_ = [
         ("cfg_sample_rate_hz", C.c_int),
@@ -351,6 +359,9 @@ PROTOTYPES.update({
     "ddn_fsk4_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_fsk4_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_mode_config": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "full_demod": (None, [C.c_void_p]),
+    "op25_gardner_cc": (None, [C.c_void_p]),
+    "ddn_demod_state_release": (None, [C.c_void_p]),
     "ddn_audio_agf_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_audio_agf_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "ddn_agf_frame": (C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_void_p]),

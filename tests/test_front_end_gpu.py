@@ -305,3 +305,69 @@ def test_halfband_decimation_cascade(built, passes, blk, fmt):
         want = np.concatenate([fe.run_cu8(iq[c, :n1], blk), fe.run_cu8(iq[c, n1:], blk)])
         assert got.shape[1] == len(want)
         assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), c
+
+
+def test_single_stream_adapter_full_demod_and_gardner(built):
+    """B4: full_demod(struct demod_state*) / op25_gardner_cc(struct demod_state*) under the reference's names
+    (include/ddn_demod_adapter.h): block after block on one stream, FSK-discriminator and CQPSK output kinds, equal to the
+    oracle run with the same block boundaries (carried state included); the Gardner entry writes its symbols back into
+    lowpassed like the reference."""
+    import ctypes as C
+    l = ddn.lib()
+    rng = np.random.default_rng(21)
+    # --- FSK discriminator output
+    iq = orc.synth_c4fm_cu8(5, 1, 9000)[0]
+    x = ((iq.astype(np.float32) - np.float32(127.5)) * np.float32(1.0 / 127.5)).astype(np.float32)
+    fe = orc.OracleFrontEnd()
+    s = ddn.DemodState(rate_in=48000, rate_out=48000, output_kind=1, symbol_rate_hz=4800, symbol_levels=4,
+                       channel_lpf_enable=1, channel_lpf_profile=ddn.LPF_P25_C4FM)
+    pos = 0
+    for ln in (4000, 137, 3000, 1863):
+        blk = np.ascontiguousarray(x[pos:pos + ln])
+        out = np.zeros(ln, np.float32)
+        s.lowpassed = blk.ctypes.data_as(C.POINTER(C.c_float))
+        s.lp_len = 2 * ln
+        s.result = out.ctypes.data_as(C.POINTER(C.c_float))
+        l.full_demod(C.byref(s))
+        want = fe.run_f32(blk, ln)
+        assert s.result_len == ln
+        check(out, want, exact=True)
+        pos += ln
+    l.ddn_demod_state_release(C.byref(s))
+    assert not s.ddn_adapter
+    # --- CQPSK symbol output (24 ksps, 5 samples per symbol)
+    sig = orc.synth_dqpsk_f32(3, 1, 1500, 5)[0]
+    cq = orc.OracleCqpskFe(rate=24000, sym_rate=4800, profile=5, lpf_enable=1)
+    s2 = ddn.DemodState(rate_in=24000, rate_out=24000, output_kind=2, symbol_rate_hz=4800, symbol_levels=4, channel_lpf_enable=1,
+                        channel_lpf_profile=ddn.LPF_P25_CQPSK, cqpsk_enable=1, ted_enabled=1, ted_sps=5)
+    pos = 0
+    for ln in (3000, 2048, 2400):
+        blk = np.ascontiguousarray(sig[pos:pos + ln])
+        out = np.zeros(ln, np.float32)
+        s2.lowpassed = blk.ctypes.data_as(C.POINTER(C.c_float))
+        s2.lp_len = 2 * ln
+        s2.result = out.ctypes.data_as(C.POINTER(C.c_float))
+        l.full_demod(C.byref(s2))
+        want = cq.run(blk, ln)
+        assert s2.result_len == len(want) and len(want) > ln // 6
+        check(out[:len(want)], want, exact=True)
+        pos += ln
+    l.ddn_demod_state_release(C.byref(s2))
+    # --- op25_gardner_cc: symbols written back into lowpassed
+    ted = orc.OracleTed(5, 4800)
+    s3 = ddn.DemodState(cqpsk_enable=1, ted_sps=5, symbol_rate_hz=4800)
+    pos = 0
+    for ln in (2500, 1201, 3):
+        blk = np.ascontiguousarray(sig[pos:pos + ln]).copy()
+        keep = blk.copy()
+        s3.lowpassed = blk.ctypes.data_as(C.POINTER(C.c_float))
+        s3.lp_len = 2 * ln
+        l.op25_gardner_cc(C.byref(s3))
+        if ln < 4:
+            assert s3.lp_len == 2 * ln and np.array_equal(blk, keep)      # the reference returns early below four samples
+        else:
+            want = ted.block(keep)
+            assert s3.lp_len == 2 * len(want)
+            check(blk.reshape(-1)[:2 * len(want)], want.reshape(-1), exact=True)
+        pos += ln
+    l.ddn_demod_state_release(C.byref(s3))
