@@ -254,7 +254,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    streams = None if args.no_pipeline else (torch.cuda.Stream(), torch.cuda.Stream())
+    # the receive loop's stream gets the higher priority: its wavefronts are latency chains, the decode kernels beside them are not
+    prio = int(os.environ.get("DDN_BENCH_PRIO", "1"))
+    streams = None if args.no_pipeline else ((torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)) if prio else (torch.cuda.Stream(), torch.cuda.Stream()))
 
     def step():
         if streams:
