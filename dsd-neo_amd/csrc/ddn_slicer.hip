@@ -162,49 +162,72 @@ k_p25_slicer(const float* __restrict__ sym, long n, size_t sym_stride, int n_cha
 }
 
 // Matched filter (apply_sps_fir order: acc += tap[i] * x[o + i], i ascending, product and sum rounded separately).
-// Two adjacent outputs per thread as one packed lane pair: the tile is staged in LDS as overlapping pairs
-// P[k] = {x[k], x[k + 1]}, so tap i of outputs (o, o + 1) is one aligned 8-byte read P[o + i], one v_pk_mul_f32 and one
-// v_pk_add_f32 (1.5 instructions per output and tap instead of 4: two 4-byte LDS reads, a multiply and an add).  Taps
-// are compile-time indices into the constant table (scalar operands) because the tap loop is fully unrolled.
+// Four adjacent outputs per thread as two packed lane pairs.  The tile is staged in LDS twice as aligned pairs: E[m] = {x[2m],
+// x[2m+1]} and O[m] = {x[2m+1], x[2m+2]}.  Outputs (o, o+1) and (o+2, o+3) of tap i need pairs m0 + i/2 and m0 + i/2 + 1 of E
+// (even taps) or O (odd taps), so the two pairs slide through registers and every second tap costs one 8-byte LDS read per
+// array: 2 bytes of LDS traffic per multiply-add instead of 4, four packed VALU instructions per tap.  Pair m sits at
+// [m & 1][m >> 1], so a wavefront's reads (pair 2 * tid + const) are consecutive 8-byte slots (the straight layout would put
+// them 16 bytes apart and use every second LDS bank only).  Taps are compile-time indices into the constant table.
 typedef float mf2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void
 k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const float* __restrict__ hist,
                      float* __restrict__ out) {
-    constexpr int T = 1024, NT = DDN_P25_FILTER_TAPS;
-    __shared__ mf2 P[T + NT]; // P[k] = {x[k], x[k + 1]} for k = 0 .. T + NT - 2
+    constexpr int T = 1024, NT = DDN_P25_FILTER_TAPS, NP = (T + NT + 3) / 2, NH = NP / 2 + 2;
+    __shared__ mf2 E[2][NH], O[2][NH];
     const int ch = blockIdx.y;
     const long t0 = (long)blockIdx.x * T;
     const int tid = threadIdx.x;
-    auto sample = [&](int i) -> float { // x[i], i = 0 .. T + NT - 1 (one past the tile for the last pair's high half)
+    auto sample = [&](int i) -> float { // x[i] of the tile's input span (past the call's end: 0)
         const long j = t0 - (NT - 1) + i;
         if (j < 0) {
             return hist[(size_t)ch * (NT - 1) + (NT - 1) + j];
         }
         return j < n ? in[(size_t)ch * stride + j] : 0.0f;
     };
-    for (int i = tid; i < T + NT - 1; i += 256) {
-        const float v = sample(i);
-        P[i].x = v;
-        if (i > 0) {
-            P[i - 1].y = v;
-        }
-    }
-    if (tid == 0) {
-        P[T + NT - 2].y = 0.0f; // high half of the last pair: never part of a stored output
+    for (int m = tid; m < NP; m += 256) {
+        const float a = sample(2 * m), b = sample(2 * m + 1), c = sample(2 * m + 2);
+        E[m & 1][m >> 1] = mf2{a, b};
+        O[m & 1][m >> 1] = mf2{b, c};
     }
     __syncthreads();
-    for (int o = 2 * tid; o < T; o += 512) {
-        mf2 acc = {0.0f, 0.0f};
+    // this thread's outputs o .. o + 3, o = 4 * tid: pair index m0 = 2 * tid
+    mf2 e0 = E[0][tid], e1 = E[1][tid], q0 = O[0][tid], q1 = O[1][tid];
+    mf2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < NT; i++) {
-            const float t = __uint_as_float(ddn_p25_filter_bits[i]);
+    for (int j = 0; j < (NT + 1) / 2; j++) {
+        {
+            const float t = __uint_as_float(ddn_p25_filter_bits[2 * j]);
             const mf2 tt = {t, t};
-            acc += tt * P[o + i];
+            acc0 += tt * e0;
+            acc1 += tt * e1;
         }
-        if (t0 + o + 1 < n) {
-            *(mf2*)&out[(size_t)ch * stride + t0 + o] = acc;
-        } else if (t0 + o < n) {
-            out[(size_t)ch * stride + t0 + o] = acc.x;
+        if (2 * j + 1 < NT) {
+            const float t = __uint_as_float(ddn_p25_filter_bits[2 * j + 1]);
+            const mf2 tt = {t, t};
+            acc0 += tt * q0;
+            acc1 += tt * q1;
+        }
+        e0 = e1;
+        q0 = q1;
+        if (j + 1 < (NT + 1) / 2) { // pair 2 * tid + j + 2
+            e1 = E[j & 1][tid + (j + 2) / 2];
+            q1 = O[j & 1][tid + (j + 2) / 2];
+        }
+    }
+    const long o = t0 + 4 * tid;
+    float* dst = out + (size_t)ch * stride + o;
+    if (o + 3 < n) {
+        *(mf2*)&dst[0] = acc0;
+        *(mf2*)&dst[2] = acc1;
+    } else {
+        if (o < n) {
+            dst[0] = acc0.x;
+        }
+        if (o + 1 < n) {
+            dst[1] = acc0.y;
+        }
+        if (o + 2 < n) {
+            dst[2] = acc1.x;
         }
     }
 }
