@@ -254,6 +254,8 @@ void orc_fsk4rx_init(orc_fsk4rx* r, const orc_fsk4_profile* p);
 long orc_fsk4rx_run(orc_fsk4rx* r, const float* in, long n, float* out_sym, int* rec4, uint8_t* flags, uint8_t* pay2,
                     long max_out, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel, int max_sync,
                     int* n_sync);
+int orc_fsk4_adjust_timing(int sps, int centre, int rf_mod, int jitter, int have_sync, int span, int start_i, int* jitter_after);
+void orc_fsk4_window(int rf_mod, int narrow, int* l_edge, int* r_edge);
 size_t orc_fsk4rx_sizeof(void);
 size_t orc_fsk4_profile_sizeof(void);
 void orc_fsk4rx_get_thresholds(const orc_fsk4rx* r, float out7[7]);

@@ -87,6 +87,62 @@ matched_filter(orc_fsk4rx* r, float x) { /* apply_sps_fir(): products added olde
     return acc;
 }
 
+/* symbol_adjust_timing_index(), src/dsp/dsd_symbol.c:462-517 (the shape of the reference's own test hook
+ * dsd_symbol_test_adjust_timing_index, :539-553): returns the sample index the symbol starts at (start_i, one less or one
+ * more), *jitter_after = the latch afterwards.  sps 20 has its own rule, then QPSK (rf_mod 1), GFSK (2), C4FM (0). */
+int
+orc_fsk4_adjust_timing(int sps, int centre, int rf_mod, int jitter, int have_sync, int span, int start_i, int* jitter_after) {
+    int i = start_i;
+    *jitter_after = jitter;
+    if (span <= 1 || i != 0 || have_sync != 0 || jitter < 0) {
+        return i;
+    }
+    const int j = jitter, c = centre;
+    if (sps == 20) {
+        if (j >= 7 && j <= 10) {
+            i--;
+        } else if (j >= 11 && j <= 14) {
+            i++;
+        }
+    } else if (rf_mod == 1) {
+        if (j >= 0 && j < c) {
+            i++;
+        } else if (j > c && j < 10) {
+            i--;
+        }
+    } else if (rf_mod == 2) {
+        if (j >= c - 1 && j <= c) {
+            i--;
+        } else if (j >= c + 1 && j <= c + 2) {
+            i++;
+        }
+    } else if (rf_mod == 0) {
+        if (j > 0 && j <= c) {
+            i--;
+        } else if (j > c && j < sps) {
+            i++;
+        }
+    }
+    *jitter_after = -1;
+    return i;
+}
+
+/* select_window_c4fm / _qpsk / _gfsk, src/dsp/dsd_symbol.c:197-224: the samples either side of the centre that enter the symbol.
+ * narrow = the C4FM left edge moved in (YSF sync type, or a DMR type as last sync). */
+void
+orc_fsk4_window(int rf_mod, int narrow, int* l_edge, int* r_edge) {
+    if (rf_mod == 0) {
+        *l_edge = narrow ? 1 : 2;
+        *r_edge = 2;
+    } else if (rf_mod == 1) {
+        *l_edge = 1;
+        *r_edge = 2;
+    } else {
+        *l_edge = 1;
+        *r_edge = 1;
+    }
+}
+
 static void
 symbol_begin(orc_fsk4rx* r) {
     const orc_fsk4_profile* p = &r->p;
@@ -136,30 +192,8 @@ symbol_begin(orc_fsk4rx* r) {
     r->sum = 0.0f;
     r->count = 0;
     r->in_symbol = 1;
-    /* symbol_adjust_timing_index(): at i == 0, hunting only, one of three rules */
-    if (sps > 1 && r->have_sync == 0 && r->jitter >= 0) {
-        const int j = r->jitter, c = r->centre;
-        if (sps == 20) {
-            if (j >= 7 && j <= 10) {
-                r->i--;
-            } else if (j >= 11 && j <= 14) {
-                r->i++;
-            }
-        } else if (p->rf_mod == 2) {
-            if (j >= c - 1 && j <= c) {
-                r->i--;
-            } else if (j >= c + 1 && j <= c + 2) {
-                r->i++;
-            }
-        } else {
-            if (j > 0 && j <= c) {
-                r->i--;
-            } else if (j > c && j < sps) {
-                r->i++;
-            }
-        }
-        r->jitter = -1;
-    }
+    /* symbol_adjust_timing_index(): at i == 0, hunting only, one of the modulation's rules */
+    r->i = orc_fsk4_adjust_timing(sps, r->centre, p->rf_mod, r->jitter, r->have_sync, sps, 0, &r->jitter);
 }
 
 static void
@@ -198,19 +232,14 @@ sample_step(orc_fsk4rx* r, float x) {
     }
     if (r->span == 5 && i == 2) {
         take = 1;
-    } else if (r->span == 5) {
-        take = 0;
-        if (p->rf_mod == 0) {
-            const int l = (p->dmr_window && r->lastsync != 0) ? 1 : 2;
-            take = (i >= c - l && i <= c + 2);
-        } else {
-            take = (r->span <= 4) ? (i == c) : (i == c - 1 || i == c + 1);
-        }
-    } else if (p->rf_mod == 0) {
-        const int l = (p->dmr_window && r->lastsync != 0) ? 1 : 2;
-        take = (i >= c - l && i <= c + 2);
     } else {
-        take = (r->span <= 4) ? (i == c) : (i == c - 1 || i == c + 1);
+        int l, rr;
+        orc_fsk4_window(p->rf_mod, p->dmr_window && r->lastsync != 0, &l, &rr);
+        if (p->rf_mod == 0) {
+            take = (i >= c - l && i <= c + rr);
+        } else {
+            take = (r->span <= 4) ? (i == c) : (i == c - l || i == c + rr);
+        }
     }
     if (take) {
         r->sum += x;

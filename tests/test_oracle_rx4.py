@@ -172,3 +172,36 @@ def test_trellis_decode_restatement_equals_reference(built):
             s_i = np.ascontiguousarray(src[i])
             r.trellis_decode(want.ctypes.data, s_i.ctypes.data, ln)
             assert np.array_equal(got[i], want), (ln, i)
+
+
+def test_window_and_slip_rules_against_the_reference_held_answers(built):
+    """The loop's two per-modulation rule functions against the expectations the reference's own test holds for
+    select_window_* and symbol_adjust_timing_index (tests/dsp/test_dsp_symbol_replay.c:397-443)."""
+    import ctypes as C
+    o = orc.oracle()
+    o.orc_fsk4_adjust_timing.argtypes = [C.c_int] * 7 + [C.c_void_p]
+    o.orc_fsk4_window.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    o.orc_fsk4_window.restype = None
+
+    def window(rf_mod, narrow):
+        l, r = C.c_int(0), C.c_int(0)
+        o.orc_fsk4_window(rf_mod, narrow, C.byref(l), C.byref(r))
+        return l.value, r.value
+
+    assert window(0, 1) == (1, 2)        # C4FM with a YSF / DMR type held: left edge 1
+    assert window(0, 0) == (2, 2)
+    assert window(1, 0) == (1, 2)        # QPSK
+    assert window(2, 0) == (1, 1)        # GFSK
+
+    def adjust(sps, centre, rf_mod, jitter, have_sync, span, start_i):
+        ja = C.c_int(99)
+        return o.orc_fsk4_adjust_timing(sps, centre, rf_mod, jitter, have_sync, span, start_i, C.byref(ja)), ja.value
+
+    assert adjust(20, 9, 0, 8, 0, 20, 0) == (-1, -1)
+    assert adjust(20, 9, 0, 12, 0, 20, 0) == (1, -1)
+    assert adjust(10, 4, 1, 3, 0, 10, 0)[0] == 1 and adjust(10, 4, 1, 7, 0, 10, 0)[0] == -1
+    assert adjust(10, 4, 2, 4, 0, 10, 0)[0] == -1 and adjust(10, 4, 2, 6, 0, 10, 0)[0] == 1
+    assert adjust(10, 4, 0, 4, 0, 10, 0)[0] == -1 and adjust(10, 4, 0, 6, 0, 10, 0)[0] == 1
+    assert adjust(10, 4, 0, 4, 1, 10, 0) == (0, 4)       # in sync: no slip, latch kept
+    assert adjust(10, 4, 0, 4, 0, 1, 0) == (0, 4)        # one-sample span
+    assert adjust(10, 4, 0, 4, 0, 10, 1) == (1, 4)       # not at the symbol's first sample
