@@ -790,6 +790,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const bool offload = whole >= 8;
     // the ordinary symbol length: constant span with the five-sample window (src/dsp/dsd_symbol.c:405-426 special-cases 5 / 20)
     const bool stdspan = rem == 0 && whole >= 6 && whole <= 11; // whole + 1 samples at most with a late slip: the search covers 12
+    const bool lean_ok = offload && stdspan && !(cfg.dbg & 1024); // see "lean trip" in the trip loop
+    const bool coop_search = !(cfg.dbg & 2048);                  // see the crossing search of the trip loop
     auto store_record = [&](uint8_t* r, uint8_t* f, float sym, int dibit, int relb, int l0, int l1, int fl) {
         const uint32_t xb = __float_as_uint(sym);
         ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
@@ -872,7 +874,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     int sp = 0; // this lane's cursor relative to the current tile (negative: a deferred symbol begins in the previous one)
     int it = 0;
     double fill_min_d = (double)s.fill_min, fill_max_d = (double)s.fill_max;
-    size_t ro = (size_t)s.midx * (size_t)n_channels + (size_t)ch; // this lane's slot in the [slot][channel] extrema rings
+    // this lane's slot in the [slot][channel] extrema rings as a 32-bit byte offset (uniform base + lane offset addressing)
+    const uint32_t ro_step = 4u * (uint32_t)n_channels, ro_first = 4u * (uint32_t)ch;
+    uint32_t ro = (uint32_t)s.midx * ro_step + ro_first;
+    auto ring_at = [](float* ring, uint32_t off) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(ring) + off); };
     // ---- per-symbol commit, shared by the fast paths and the generic path of the trip loop ---------------------------
     long t0 = 0;  // call-relative index of the current tile's first sample (the commit stamps filt_start with it)
     int cold_until = 0; // see cold_limit()
@@ -884,7 +889,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         rx_timing_reset(s);
         fill_min_d = (double)s.fill_min;
         fill_max_d = (double)s.fill_max;
-        ro = (size_t)ch;
+        ro = ro_first;
     };
     // the matched filter's memory at the moment it is gated off: the last 90 samples it was fed (older slots keep what
     // an earlier memory held), kept per channel for the cold start of the next enable
@@ -937,19 +942,19 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
         double old_lo = fill_min_d, old_hi = fill_max_d; // a ring refilled by a warm start holds one value (k * v exact, §5b)
         if (s.since_fill >= MS) {
-            old_lo = (double)minring[ro];
-            old_hi = (double)maxring[ro];
+            old_lo = (double)ring_at(minring, ro);
+            old_hi = (double)ring_at(maxring, ro);
         } else {
             s.since_fill++;
         }
         s.min_sum += (double)lo - old_lo;
         s.max_sum += (double)hi - old_hi;
-        minring[ro] = lo;
-        maxring[ro] = hi;
-        ro += (size_t)n_channels;
+        ring_at(minring, ro) = lo;
+        ring_at(maxring, ro) = hi;
+        ro += ro_step;
         if (++s.midx >= MS) {
             s.midx = 0;
-            ro = (size_t)ch;
+            ro = ro_first;
         }
         s.min = (float)(s.min_sum / (double)MS);
         s.max = (float)(s.max_sum / (double)MS);
@@ -1153,6 +1158,40 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 qv.w = __int_as_float(-1);
                 tk++;
+                // ---- lean trip -----------------------------------------------------------------------------------------
+                // Every live lane sits inside a frame with its crossing latched, a whole fresh symbol of the ordinary length
+                // staged, the matched filter warm and more than one symbol of the lock left: nothing per-sample can change
+                // state, so the trip is the five-sample clipped mean and the in-frame commit, with none of the
+                // classification / search / hunting code of the general trip below on the wave's instruction stream.
+                if (lean_ok && tk <= QT) {
+                    // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
+                    const bool lean = (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
+                                      & (sp + whole <= tn) & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0)))
+                                      & (s.min < s.max);
+                    if (!__any(live & !lean) && __any(live)) {
+                        if (live) {
+                            const float* p = (s.filter_on ? frow : rrow) + base + sp + ((whole - 1) / 2 - 2);
+                            float acc = 0.0f;
+#pragma unroll
+                            for (int w = 0; w < 5; w++) {
+                                // min < max and finite samples: the reference's two-sided clip is the median of three (a zero's
+                                // sign may differ, which a sum that starts at +0 cannot show)
+                                acc += __builtin_amdgcn_fmed3f(p[w], s.min, s.max);
+                            }
+                            const float xl = p[whole - 1 - ((whole - 1) / 2 - 2)];
+                            s.lastsample = xl > s.max ? s.max : (xl < s.min ? s.min : xl);
+                            const float sym = acc / 5.0f;
+                            sp += whole;
+                            s.in_symbol = 0;
+                            commit_pre(sym);
+                            int fl = 0;
+                            float q_max = 0.0f, q_min = 0.0f;
+                            commit_inframe(sym, 0, fl, q_max, q_min);
+                            emit(sym, fl, q_max, q_min);
+                        }
+                        continue;
+                    }
+                }
                 // ---- trip classification -----------------------------------------------------------------------------
                 // Symbols of the ordinary length (std) that start fresh - or were deferred whole to this tile - take one
                 // of two straight-line paths: A = in frame (clip, five-sample mean, in-frame commit; the crossing search only
@@ -1199,7 +1238,56 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     const int i0 = do_a ? 0 : s.i;
                     float last = s.lastsample;
                     int jit = s.jitter;
-                    if (__any(fab && jit < 0)) {
+                    if (coop_search && __any(fab && jit < 0)) {
+                        // The crossing test of sample k reads x[k], x[k - 1] and thresholds that are fixed for the whole symbol,
+                        // so the 64 / CPW lanes that share a channel's column (lane = channel + CPW * slot) each test the
+                        // samples k = slot, slot + 64 / CPW, ... and the owner takes the lowest set bit of the ballots: the
+                        // first crossing, as the in-order search finds it.
+                        constexpr int EPL = 64 / CPW;
+                        const int oc = lane % CPW, slot = lane / CPW;
+                        const float hi_lim = s.maxref * 1.25f, lo_lim = s.minref * 1.25f;
+                        const int need_o = __shfl((int)(fab && jit < 0), oc);
+                        const int clip_o = __shfl((int)clip, oc);
+                        const int cnt_o = __shfl(cnt, oc);
+                        const int i0_o = __shfl(i0, oc);
+                        const int flt_o = __shfl(s.filter_on, oc);
+                        const int sp_o = __shfl(sp, oc);
+                        const float cen_o = __shfl(s.center, oc), hl_o = __shfl(hi_lim, oc), ll_o = __shfl(lo_lim, oc);
+                        const float mx_o = __shfl(s.max, oc), mn_o = __shfl(s.min, oc), ls_o = __shfl(s.lastsample, oc);
+                        const float* po = (flt_o ? &L.flt[oc][0] : &L.raw[oc][0]) + base + sp_o;
+                        int found = -1;
+#pragma unroll
+                        for (int r = 0; r < (12 + EPL - 1) / EPL; r++) {
+                            const int k = slot + r * EPL;
+                            bool hit = false;
+                            if (k < 12) {
+                                float x = po[k], xp = po[k - 1];
+                                const float xc = x > mx_o ? mx_o : (x < mn_o ? mn_o : x);
+                                const float xpc = xp > mx_o ? mx_o : (xp < mn_o ? mn_o : xp);
+                                x = clip_o ? xc : x;
+                                xp = k == 0 ? ls_o : (clip_o ? xpc : xp);
+                                const bool cross = (x > cen_o) ? (!(x > hl_o) && xp < cen_o) : (!(x < ll_o) && xp > cen_o);
+                                // a crossing at symbol index -1 (sample 0 of a symbol that slipped early) latches nothing: the
+                                // in-order search stores -1 and keeps looking
+                                hit = need_o && k < cnt_o && cross && (i0_o + k >= 0);
+                            }
+                            const unsigned long long bal = __ballot(hit);
+                            // this channel's column: bits oc, oc + CPW, ... of the ballot
+                            unsigned long long col = bal >> oc;
+                            if (CPW < 64) {
+                                unsigned long long m = 0;
+#pragma unroll
+                                for (int e = 0; e < EPL; e++) {
+                                    m |= 1ull << (e * CPW);
+                                }
+                                col &= m;
+                            }
+                            if (found < 0 && col != 0) {
+                                found = (__ffsll((long long)col) - 1) / CPW + r * EPL;
+                            }
+                        }
+                        jit = (fab && jit < 0 && found >= 0) ? i0 + found : jit;
+                    } else if (__any(fab && jit < 0)) {
                         const float hi_lim = s.maxref * 1.25f, lo_lim = s.minref * 1.25f;
                         const bool anyclip = __any(do_a && jit < 0);
 #pragma unroll
@@ -1555,6 +1643,9 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
                int channels_per_wave, const int32_t* lock_cfg, hipStream_t st) {
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
+    }
+    if ((unsigned long long)n_channels * (unsigned long long)MS * 4ull > 0xFFFFFFFFull) {
+        return hipErrorInvalidValue; // the extrema rings are addressed with 32-bit byte offsets
     }
     {   // the matched-filter taps are a __constant__ of this code object: one upload per device, under a lock
         static std::mutex mu;
