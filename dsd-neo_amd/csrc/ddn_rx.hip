@@ -655,6 +655,12 @@ constexpr int WMAX = 24;
 
 constexpr int WM = 32; // suffix summaries kept per checkpoint (pushes per two tiles: 2 * (ceil((TS + sps) / (sps - 1)) + 1) <= 30 for sps >= 6)
 
+// 1: per-wave cycle counters (tile body / barrier wait / trips by kind) written over the tail of each workgroup's first
+// record area when cfg.dbg bit 8192 is set - timing experiments only (tools/scratch/rx_cyc.py)
+#ifndef DDN_RX_CYCLES
+#define DDN_RX_CYCLES 0
+#endif
+
 template <int CPW>
 struct LdsW {
     float sb[SS][CPW];
@@ -790,8 +796,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const bool offload = whole >= 8;
     // the ordinary symbol length: constant span with the five-sample window (src/dsp/dsd_symbol.c:405-426 special-cases 5 / 20)
     const bool stdspan = rem == 0 && whole >= 6 && whole <= 11; // whole + 1 samples at most with a late slip: the search covers 12
-    const bool lean_ok = offload && stdspan && !(cfg.dbg & 1024); // see "lean trip" in the trip loop
-    const bool coop_search = !(cfg.dbg & 2048);                  // see the crossing search of the trip loop
+    const bool std_ok = stdspan && !(cfg.dbg & 1024); // see "standard trip" in the trip loop
+    const bool lean_ok = offload && stdspan && !(cfg.dbg & 2048); // see "lean trip" in the trip loop
     auto store_record = [&](uint8_t* r, uint8_t* f, float sym, int dibit, int relb, int l0, int l1, int fl) {
         const uint32_t xb = __float_as_uint(sym);
         ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
@@ -1109,7 +1115,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         o++;
     };
 
+    long long dbg_busy = 0, dbg_wait = 0, dbg_cyc[3] = {0, 0, 0}, dbg_prev = 0;
+    int dbg_n[3] = {0, 0, 0}, dbg_kind = -1;
     for (t0 = 0; t0 < n; t0 += TS, it++) {
+        const long long dbg_t0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
         const bool more = (t0 + TS) < n;
         if (loader) {
@@ -1126,7 +1135,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         } else {
             const int base = TS + (it % 3) * TS;
             auto rd = [&](const float* row, int j) { return row[base + j]; };
-            const int done_snap = 0;
             // tile-relative sample index from which the matched filter's output is usable (INT_MIN: filter off or warm)
             auto cold_limit = [&]() {
                 if (!s.filter_on) {
@@ -1151,6 +1159,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
             int guard = 0;
             bool gblocked = false; // generic path: this lane's symbol waits for the next tile
+            // lean trip operands fetched one trip ahead: the five window samples of this lane's next symbol and the suffix
+            // summary its window push will ask for (valid only from one lean trip to the next inside a tile)
+            bool pf_ok = false;
+            float px0 = 0.0f, px1 = 0.0f, px2 = 0.0f, px3 = 0.0f, px4 = 0.0f;
+            float4 psf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             while (true) {
                 // hand the previous trip's symbols (one per lane at most) to wave 1: one 16-byte LDS write at a wave-uniform slot
                 if (offload && tk > 0 && tk <= QT && lane < CPW) {
@@ -1158,185 +1171,234 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 qv.w = __int_as_float(-1);
                 tk++;
+                if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                    const long long now = (long long)clock64();
+                    if (dbg_kind >= 0) {
+                        dbg_cyc[dbg_kind] += now - dbg_prev;
+                        dbg_n[dbg_kind]++;
+                    }
+                    dbg_prev = now;
+                    dbg_kind = 1;
+                }
+                // ---- standard trip -------------------------------------------------------------------------------------
+                // Symbols of the ordinary length that start fresh (or were deferred whole to this tile) with the matched filter
+                // warm: A = in frame (five-sample clipped mean, in-frame commit; crossing search only while the latch is open),
+                // B = hunting (one-sample timing slip, crossing search, plain mean, hunting commit).  When every live lane is in
+                // one of the two states - or waits in one of them for the next tile - the trip is this straight-line block and
+                // none of the general code below is on the wave's instruction stream.  Everything else (filter cold start,
+                // partly consumed symbols at a call's edges, odd spans, degenerate thresholds) takes the general trip.
                 // ---- lean trip -----------------------------------------------------------------------------------------
-                // Every live lane sits inside a frame with its crossing latched, a whole fresh symbol of the ordinary length
-                // staged, the matched filter warm and more than one symbol of the lock left: nothing per-sample can change
-                // state, so the trip is the five-sample clipped mean and the in-frame commit, with none of the
-                // classification / search / hunting code of the general trip below on the wave's instruction stream.
+                // Every live lane sits inside a frame with its crossing latched, a whole fresh symbol staged, the matched filter
+                // warm and more than one symbol of the lock left (or waits in that state for the next tile): nothing per-sample
+                // can change state and nothing reads the last sample or the 24-symbol history (the history is only read by the
+                // warm start of a sync, 24 hunting symbols after the frame), so the trip is: clipped five-sample mean, window
+                // push, extrema rings, thresholds, queue entry.  Its LDS operands were fetched by the previous lean trip, which
+                // takes the two LDS round trips off the recurrence.
+                bool all_lean_wait = false;
                 if (lean_ok && tk <= QT) {
                     // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
-                    const bool lean = (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
-                                      & (sp + whole <= tn) & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0)))
-                                      & (s.min < s.max);
-                    if (!__any(live & !lean) && __any(live)) {
-                        if (live) {
-                            const float* p = (s.filter_on ? frow : rrow) + base + sp + ((whole - 1) / 2 - 2);
-                            float acc = 0.0f;
-#pragma unroll
-                            for (int w = 0; w < 5; w++) {
-                                // min < max and finite samples: the reference's two-sided clip is the median of three (a zero's
-                                // sign may differ, which a sum that starts at +0 cannot show)
-                                acc += __builtin_amdgcn_fmed3f(p[w], s.min, s.max);
+                    const bool lean_state = live & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
+                                            & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0))) & (s.min < s.max);
+                    const bool lean = lean_state & (sp + whole <= tn);
+                    const bool lean_wait = lean_state & !(sp + whole <= tn) & more;
+                    const bool all_lean = !__any(live & !(lean | lean_wait));
+                    if (all_lean && __any(lean)) {
+                        dbg_kind = 2;
+                        const int k0 = (whole - 1) / 2 - 2;
+                        if (__any(lean & !pf_ok)) { // first lean trip of a run: nothing was fetched ahead
+                            if (lean & !pf_ok) {
+                                const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
+                                px0 = pw[0], px1 = pw[1], px2 = pw[2], px3 = pw[3], px4 = pw[4];
+                                int m = npp + npc + 1;
+                                m = m > WM ? WM : m;
+                                psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
                             }
-                            const float xl = p[whole - 1 - ((whole - 1) / 2 - 2)];
-                            s.lastsample = xl > s.max ? s.max : (xl < s.min ? s.min : xl);
+                        }
+                        if (lean) {
+                            // min < max and finite samples: the reference's two-sided clip is the median of three (a zero's sign
+                            // may differ, which a sum that starts at +0 cannot show)
+                            float acc = 0.0f;
+                            acc += __builtin_amdgcn_fmed3f(px0, s.min, s.max);
+                            acc += __builtin_amdgcn_fmed3f(px1, s.min, s.max);
+                            acc += __builtin_amdgcn_fmed3f(px2, s.min, s.max);
+                            acc += __builtin_amdgcn_fmed3f(px3, s.min, s.max);
+                            acc += __builtin_amdgcn_fmed3f(px4, s.min, s.max);
                             const float sym = acc / 5.0f;
                             sp += whole;
                             s.in_symbol = 0;
-                            commit_pre(sym);
-                            int fl = 0;
-                            float q_max = 0.0f, q_min = 0.0f;
-                            commit_inframe(sym, 0, fl, q_max, q_min);
-                            emit(sym, fl, q_max, q_min);
+                            // window push (see window_push) with the prefetched suffix summary
+                            L.sb[s.sidx][ln] = sym;
+                            two_min_insert(sym, pc1, pc2);
+                            two_max_insert(sym, pc3, pc4);
+                            npc++;
+                            const float t1 = fminf(psf.x, pp1), t2 = fminf(fmaxf(psf.x, pp1), fminf(psf.y, pp2));
+                            const float m1 = fminf(t1, pc1), m2 = fminf(fmaxf(t1, pc1), fminf(t2, pc2));
+                            const float u1 = fmaxf(psf.z, pp3), u2 = fmaxf(fminf(psf.z, pp3), fmaxf(psf.w, pp4));
+                            const float x1 = fmaxf(u1, pc3), x2 = fmaxf(fminf(u1, pc3), fmaxf(u2, pc4));
+                            const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
+                            double old_lo = fill_min_d, old_hi = fill_max_d;
+                            if (s.since_fill >= MS) {
+                                old_lo = (double)ring_at(minring, ro);
+                                old_hi = (double)ring_at(maxring, ro);
+                            } else {
+                                s.since_fill++;
+                            }
+                            s.min_sum += (double)lo - old_lo;
+                            s.max_sum += (double)hi - old_hi;
+                            ring_at(minring, ro) = lo;
+                            ring_at(maxring, ro) = hi;
+                            ro += ro_step;
+                            if (++s.midx >= MS) {
+                                s.midx = 0;
+                                ro = ro_first;
+                            }
+                            s.min = (float)(s.min_sum / (double)MS);
+                            s.max = (float)(s.max_sum / (double)MS);
+                            s.center = (s.max + s.min) / 2.0f;
+                            s.maxref = s.max * 0.80f;
+                            s.minref = s.min * 0.80f;
+                            s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+                            s.lock_left--;
+                            qv = make_float4(sym, s.max, s.min, __int_as_float((1 | (s.lastsync == 2 ? 4 : 0)) | ((o - o_tile) << 8)));
+                            o++;
+                        }
+                        // operands of the next lean trip, if this lane's next symbol is staged in this tile too
+                        pf_ok = lean & (sp + whole <= tn);
+                        if (pf_ok) {
+                            const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
+                            px0 = pw[0], px1 = pw[1], px2 = pw[2], px3 = pw[3], px4 = pw[4];
+                            int m = npp + npc + 1;
+                            m = m > WM ? WM : m;
+                            psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
                         }
                         continue;
                     }
+                    all_lean_wait = all_lean; // nobody can go on and nobody needs another kind of trip: the tile is over
                 }
-                // ---- trip classification -----------------------------------------------------------------------------
-                // Symbols of the ordinary length (std) that start fresh - or were deferred whole to this tile - take one
-                // of two straight-line paths: A = in frame (clip, five-sample mean, in-frame commit; the crossing search only
-                // while the latch is open), B = hunting (timing slip, crossing search, mean, hunting commit).  Everything
-                // else - matched-filter cold start, partly consumed symbols at a call's edges, odd spans - goes through the
-                // generic per-sample code below, which the wave skips when no lane needs it.
-                const bool cold0 = sp < cold_until; // == filter_on && (abs0 + t0 + sp - filt_start) < NT - 1
-                const bool ready = live && stdspan && sp < tn && !cold0;
-                const bool ea = ready && s.have_sync && (!s.in_symbol || (s.i == 0 && s.count == 0));
-                const bool eb = ready && !s.have_sync && (!s.in_symbol || (s.i >= -1 && s.i <= 1 && s.count == 0));
-                if (eb && !s.in_symbol) { // symbol start while hunting: one-sample slip by the latched crossing index
-                    if (s.need_reset) {
-                        timing_reset();
-                    }
-                    s.span = whole;
-                    s.centre = (whole - 1) / 2;
-                    s.i = 0;
-                    s.sum = 0.0f;
-                    s.count = 0;
-                    s.in_symbol = 1;
-                    if (s.jitter >= 0) {
-                        if (s.jitter > 0 && s.jitter <= s.centre) {
-                            s.i = -1;
-                        } else if (s.jitter > s.centre && s.jitter < whole) {
-                            s.i = 1;
+                pf_ok = false;
+                bool all_std_wait = all_lean_wait;
+                if (std_ok && !all_lean_wait) {
+                    // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
+                    const bool warm = live & (sp >= cold_until); // == !(filter_on && (abs0 + t0 + sp - filt_start) < NT - 1)
+                    const bool hunting = s.have_sync == 0;
+                    if (warm & hunting & (s.in_symbol == 0) & (sp < tn)) { // symbol start while hunting: slip by the latched crossing
+                        if (s.need_reset) {
+                            timing_reset();
                         }
-                        s.jitter = -1;
-                    }
-                }
-                const int cnt_b = whole - s.i;
-                const bool do_a = ea && (sp + whole <= tn);
-                const bool do_b = eb && (sp + cnt_b <= tn);
-                const bool wait_ab = (ea && !do_a && more) || (eb && !do_b && more);
-                const bool glive = live && !do_a && !do_b && !wait_ab && !gblocked;
-                const bool gneed = glive && (sp < tn || s.in_symbol);
-                if (!__any(do_a || do_b || (gneed && (sp < tn))) || ++guard > 4 * TS) {
-                    break;
-                }
-                if (__any(do_a || do_b)) {
-                    const bool fab = do_a || do_b;
-                    const float* p = (s.filter_on ? frow : rrow) + base + sp;
-                    const bool clip = do_a;
-                    const int cnt = do_a ? whole : cnt_b;
-                    const int i0 = do_a ? 0 : s.i;
-                    float last = s.lastsample;
-                    int jit = s.jitter;
-                    if (coop_search && __any(fab && jit < 0)) {
-                        // The crossing test of sample k reads x[k], x[k - 1] and thresholds that are fixed for the whole symbol,
-                        // so the 64 / CPW lanes that share a channel's column (lane = channel + CPW * slot) each test the
-                        // samples k = slot, slot + 64 / CPW, ... and the owner takes the lowest set bit of the ballots: the
-                        // first crossing, as the in-order search finds it.
-                        constexpr int EPL = 64 / CPW;
-                        const int oc = lane % CPW, slot = lane / CPW;
-                        const float hi_lim = s.maxref * 1.25f, lo_lim = s.minref * 1.25f;
-                        const int need_o = __shfl((int)(fab && jit < 0), oc);
-                        const int clip_o = __shfl((int)clip, oc);
-                        const int cnt_o = __shfl(cnt, oc);
-                        const int i0_o = __shfl(i0, oc);
-                        const int flt_o = __shfl(s.filter_on, oc);
-                        const int sp_o = __shfl(sp, oc);
-                        const float cen_o = __shfl(s.center, oc), hl_o = __shfl(hi_lim, oc), ll_o = __shfl(lo_lim, oc);
-                        const float mx_o = __shfl(s.max, oc), mn_o = __shfl(s.min, oc), ls_o = __shfl(s.lastsample, oc);
-                        const float* po = (flt_o ? &L.flt[oc][0] : &L.raw[oc][0]) + base + sp_o;
-                        int found = -1;
-#pragma unroll
-                        for (int r = 0; r < (12 + EPL - 1) / EPL; r++) {
-                            const int k = slot + r * EPL;
-                            bool hit = false;
-                            if (k < 12) {
-                                float x = po[k], xp = po[k - 1];
-                                const float xc = x > mx_o ? mx_o : (x < mn_o ? mn_o : x);
-                                const float xpc = xp > mx_o ? mx_o : (xp < mn_o ? mn_o : xp);
-                                x = clip_o ? xc : x;
-                                xp = k == 0 ? ls_o : (clip_o ? xpc : xp);
-                                const bool cross = (x > cen_o) ? (!(x > hl_o) && xp < cen_o) : (!(x < ll_o) && xp > cen_o);
-                                // a crossing at symbol index -1 (sample 0 of a symbol that slipped early) latches nothing: the
-                                // in-order search stores -1 and keeps looking
-                                hit = need_o && k < cnt_o && cross && (i0_o + k >= 0);
+                        s.span = whole;
+                        s.centre = (whole - 1) / 2;
+                        s.i = 0;
+                        s.sum = 0.0f;
+                        s.count = 0;
+                        s.in_symbol = 1;
+                        if (s.jitter >= 0) {
+                            if (s.jitter > 0 && s.jitter <= s.centre) {
+                                s.i = -1;
+                            } else if (s.jitter > s.centre && s.jitter < whole) {
+                                s.i = 1;
                             }
-                            const unsigned long long bal = __ballot(hit);
-                            // this channel's column: bits oc, oc + CPW, ... of the ballot
-                            unsigned long long col = bal >> oc;
-                            if (CPW < 64) {
+                            s.jitter = -1;
+                        }
+                    }
+                    const bool in_a = warm & !hunting & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0))) & (s.min < s.max);
+                    const bool in_b = warm & hunting & (s.in_symbol != 0) & (s.i >= -1) & (s.i <= 1) & (s.count == 0);
+                    const bool idle_b = warm & hunting & (s.in_symbol == 0); // tile used up exactly: nothing started
+                    const int i0 = in_b ? s.i : 0;
+                    const int cnt = whole - i0;
+                    const bool fits = sp + cnt <= tn;
+                    const bool can = (in_a | in_b) & fits;
+                    const bool wt = (((in_a | in_b) & !fits) | idle_b) & more; // waits for the next tile (both stay staged)
+                    const bool all_ok = !__any(live & !(can | wt));
+                    if (all_ok && __any(can)) {
+                        dbg_kind = 0;
+                        const float* p = (s.filter_on ? frow : rrow) + base + sp;
+                        int jit = s.jitter;
+                        if (__any(can & (jit < 0))) {
+                            // The crossing test of sample k reads x[k], x[k - 1] and thresholds that are fixed for the whole symbol,
+                            // so the 64 / CPW lanes that share a channel's column (lane = channel + CPW * slot) each test the
+                            // samples k = slot, slot + 64 / CPW, ... and the owner takes the lowest set bit of the ballots: the
+                            // first crossing, as the in-order search finds it.
+                            constexpr int EPL = 64 / CPW;
+                            const int oc = lane % CPW, slot = lane / CPW;
+                            const float hi_lim = s.maxref * 1.25f, lo_lim = s.minref * 1.25f;
+                            const int need_o = __shfl((int)(can & (jit < 0)), oc);
+                            const int clip_o = __shfl((int)in_a, oc);
+                            const int cnt_o = __shfl(cnt, oc);
+                            const int i0_o = __shfl(i0, oc);
+                            const int flt_o = __shfl(s.filter_on, oc);
+                            const int sp_o = __shfl(sp, oc);
+                            const float cen_o = __shfl(s.center, oc), hl_o = __shfl(hi_lim, oc), ll_o = __shfl(lo_lim, oc);
+                            const float mx_o = __shfl(s.max, oc), mn_o = __shfl(s.min, oc), ls_o = __shfl(s.lastsample, oc);
+                            const float* po = (flt_o ? &L.flt[oc][0] : &L.raw[oc][0]) + base + sp_o;
+                            int found = -1;
+#pragma unroll
+                            for (int r = 0; r < (12 + EPL - 1) / EPL; r++) {
+                                const int k = slot + r * EPL;
+                                bool hit = false;
+                                if (k < 12) {
+                                    float x = po[k], xp = po[k - 1];
+                                    const float xc = x > mx_o ? mx_o : (x < mn_o ? mn_o : x);
+                                    const float xpc = xp > mx_o ? mx_o : (xp < mn_o ? mn_o : xp);
+                                    x = clip_o ? xc : x;
+                                    xp = k == 0 ? ls_o : (clip_o ? xpc : xp);
+                                    const bool cross = (x > cen_o) ? (!(x > hl_o) && xp < cen_o) : (!(x < ll_o) && xp > cen_o);
+                                    // a crossing at symbol index -1 (sample 0 of a symbol that slipped early) latches nothing: the
+                                    // in-order search stores -1 and keeps looking
+                                    hit = need_o && k < cnt_o && cross && (i0_o + k >= 0);
+                                }
+                                const unsigned long long bal = __ballot(hit);
+                                // this channel's column: bits oc, oc + CPW, ... of the ballot
+                                unsigned long long col = bal >> oc;
                                 unsigned long long m = 0;
 #pragma unroll
                                 for (int e = 0; e < EPL; e++) {
                                     m |= 1ull << (e * CPW);
                                 }
                                 col &= m;
+                                if (found < 0 && col != 0) {
+                                    found = (__ffsll((long long)col) - 1) / CPW + r * EPL;
+                                }
                             }
-                            if (found < 0 && col != 0) {
-                                found = (__ffsll((long long)col) - 1) / CPW + r * EPL;
-                            }
+                            jit = (can & (jit < 0) & (found >= 0)) ? i0 + found : jit;
                         }
-                        jit = (fab && jit < 0 && found >= 0) ? i0 + found : jit;
-                    } else if (__any(fab && jit < 0)) {
-                        const float hi_lim = s.maxref * 1.25f, lo_lim = s.minref * 1.25f;
-                        const bool anyclip = __any(do_a && jit < 0);
+                        if (can) {
+                            // the five window samples (indices centre - 2 .. centre + 2 of the symbol) and its last sample.  In frame
+                            // min < max and the samples are finite, so the reference's two-sided clip is the median of three (a
+                            // zero's sign may differ, which a sum that starts at +0 cannot show); hunting symbols are not clipped.
+                            const float lo = in_a ? s.min : -inf, hi = in_a ? s.max : inf;
+                            const float* pw = p + ((whole - 1) / 2 - 2 - i0);
+                            float acc = 0.0f;
 #pragma unroll
-                        for (int k = 0; k < 12; k++) {
-                            if ((k & 3) == 0 && k > 0 && !__any(fab && k < cnt && jit < 0)) {
-                                break;
+                            for (int w = 0; w < 5; w++) {
+                                acc += __builtin_amdgcn_fmed3f(pw[w], lo, hi);
                             }
-                            float x = p[k];
-                            if (anyclip) {
-                                const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
-                                x = clip ? xc : x;
+                            const float xl = p[cnt - 1];
+                            const float xlc = xl > s.max ? s.max : (xl < s.min ? s.min : xl);
+                            const float sym = acc / 5.0f;
+                            s.jitter = jit;
+                            s.lastsample = in_a ? xlc : xl;
+                            sp += cnt;
+                            s.in_symbol = 0;
+                            commit_pre(sym);
+                            int fl = 0;
+                            float q_max = 0.0f, q_min = 0.0f;
+                            if (in_a) {
+                                commit_inframe(sym, 0, fl, q_max, q_min);
+                            } else {
+                                commit_hunt(sym, 0, fl);
                             }
-                            const bool in = fab && k < cnt;
-                            const bool cross = (x > s.center) ? (!(x > hi_lim) && last < s.center)
-                                                              : (!(x < lo_lim) && last > s.center);
-                            jit = (in && jit < 0 && cross) ? i0 + k : jit;
-                            last = in ? x : last;
+                            emit(sym, fl, q_max, q_min);
                         }
+                        continue;
                     }
-                    // the five window samples (indices centre - 2 .. centre + 2 of the symbol) and its last sample
-                    const int k0 = (whole - 1) / 2 - 2 - i0;
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int w = 0; w < 5; w++) {
-                        float x = p[k0 + w];
-                        const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
-                        acc += clip ? xc : x;
-                    }
-                    {
-                        float x = p[cnt - 1];
-                        const float xc = x > s.max ? s.max : (x < s.min ? s.min : x);
-                        last = clip ? xc : x;
-                    }
-                    if (fab) {
-                        const float sym = acc / 5.0f;
-                        s.jitter = jit;
-                        s.lastsample = last;
-                        sp += cnt;
-                        s.in_symbol = 0;
-                        commit_pre(sym);
-                        int fl = 0;
-                        float q_max = 0.0f, q_min = 0.0f;
-                        if (do_a) {
-                            commit_inframe(sym, done_snap, fl, q_max, q_min);
-                        } else {
-                            commit_hunt(sym, done_snap, fl);
-                        }
-                        emit(sym, fl, q_max, q_min);
-                    }
+                    all_std_wait = all_ok; // nobody can go on and nobody needs the general trip: the tile is over
+                }
+                // ---- general trip ------------------------------------------------------------------------------------------
+                const int done_snap = 0;
+                const bool glive = live && !gblocked;
+                const bool gneed = glive && (sp < tn || s.in_symbol);
+                if (all_std_wait || !__any(gneed && (sp < tn)) || ++guard > 4 * TS) {
+                    break;
                 }
                 if (!__any(gneed)) {
                     continue;
@@ -1569,6 +1631,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 gblocked = gblocked || blocked;
             }
+            if ((DDN_RX_CYCLES && (cfg.dbg & 8192)) && dbg_kind >= 0) {
+                dbg_cyc[dbg_kind] += (long long)clock64() - dbg_prev;
+                dbg_n[dbg_kind]++;
+                dbg_kind = -1;
+            }
             if (offload && lane == 0) {
                 L.qn[it & 1] = (tk - 1) < QT ? (tk - 1) : QT; // trips that may have queued (the last one broke out at its top)
             }
@@ -1577,7 +1644,22 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 sp -= TS;
             }
         }
-        __syncthreads();
+        if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+            const long long t1 = (long long)clock64();
+            __syncthreads();
+            dbg_busy += t1 - dbg_t0;
+            dbg_wait += (long long)clock64() - t1;
+        } else {
+            __syncthreads();
+        }
+    }
+    if ((DDN_RX_CYCLES && (cfg.dbg & 8192)) && lane == 0) { // timing experiment only: cycles per wave in the tile body / at the tile barrier
+        // (written over the unused tail of the workgroup's first channel's record area)
+        uint8_t* d = rec + ((size_t)ch0 + 1) * max_sym * 10 - 192 + (threadIdx.x >> 6) * 64;
+        const long long v[8] = {dbg_busy, dbg_wait, dbg_cyc[0], dbg_cyc[1], dbg_cyc[2], dbg_n[0], dbg_n[1], dbg_n[2]};
+        for (int k = 0; k < 64; k++) {
+            d[k] = reinterpret_cast<const uint8_t*>(v)[k];
+        }
     }
     if (loader && offload && it > 0) {
         drain((it - 1) & 1);
