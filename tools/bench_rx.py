@@ -21,6 +21,9 @@ def main():
     cpws = [int(a) for a in sys.argv[3:]] or [16, 32, 64]
     base, _, _ = orc.synth_p25_disc(5, 64, n, frame_dibits=864)
     x = np.tile(base, (B // 64 + 1, 1))[:B].copy()
+    if os.environ.get("DDN_BENCH_SPREAD"):  # frame phases spread over the whole frame period instead of within ~40 symbols
+        for c in range(B):
+            x[c] = np.roll(x[c], (c * 977) % 8640)
     d = torch.from_numpy(x).cuda()
     os.makedirs("gpurun_out", exist_ok=True)
     for filt in (1, 0):

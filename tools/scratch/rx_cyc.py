@@ -7,6 +7,9 @@ B, n = 4096, 48000
 cpw = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 base, _, _ = orc.synth_p25_disc(5, 64, n, frame_dibits=864)
 x = np.tile(base, (B // 64, 1))
+if os.environ.get('DDN_BENCH_SPREAD'):  # frame phases spread over the whole frame period
+    for c in range(B):
+        x[c] = np.roll(x[c], (c * 977) % 8640)
 d = torch.from_numpy(x).cuda()
 rx = ddn.P25Rx(B, lock_symbols=840, use_matched_filter=1, channels_per_wave=cpw)
 ms = ddn.lib().ddn_p25_rx_max_symbols(rx.h, n)
