@@ -140,7 +140,7 @@ def parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n, streams=None):
     import orc
     torch.cuda.synchronize()
     if streams:
-        chain.run_pipelined(d_iq, *streams)      # the same call sequence the timed loop makes
+        (chain.run_pipelined3 if len(streams) == 3 else chain.run_pipelined)(d_iq, *streams)      # the same call sequence the timed loop makes
     else:
         chain.run(d_iq)
     torch.cuda.synchronize()
@@ -256,11 +256,17 @@ def main():
 
     # the receive loop's stream gets the higher priority: its wavefronts are latency chains, the decode kernels beside them are not
     prio = int(os.environ.get("DDN_BENCH_PRIO", "1"))
-    streams = None if args.no_pipeline else ((torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)) if prio else (torch.cuda.Stream(), torch.cuda.Stream()))
+    n_streams = int(os.environ.get("DDN_BENCH_STREAMS", "2"))  # 3: measured no faster (the front end displaces the loop)
+    if args.no_pipeline:
+        streams = None
+    elif n_streams == 3:   # front end | receive loop (high priority) | frame FEC + vocoder
+        streams = (torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1 if prio else 0), torch.cuda.Stream(priority=0))
+    else:                  # front end + receive loop (high priority) | frame FEC + vocoder
+        streams = (torch.cuda.Stream(priority=-1 if prio else 0), torch.cuda.Stream(priority=0))
 
     def step():
         if streams:
-            chain.run_pipelined(d_iq, *streams)
+            (chain.run_pipelined3 if len(streams) == 3 else chain.run_pipelined)(d_iq, *streams)
         else:
             chain.run(d_iq, st)
 
@@ -359,8 +365,10 @@ def main():
                        "channels_per_gpu": B, "samples_per_channel": n, "block_len": BLOCK,
                        "parallelism": "channel-sharded x%d" % world,
                        "pipelining": ("none (one stream)" if args.no_pipeline else
-                                      "2 HIP streams: frame FEC + vocoder of step k overlap front end + receive loop of step k+1 "
-                                      "(double-buffered loop outputs); every stage of every step inside the timed region"),
+                                      ("3 HIP streams: front end of step k+1 and frame FEC + vocoder of step k-1 run beside the receive "
+                                       "loop of step k (double-buffered discriminator and loop outputs)" if len(streams) == 3 else
+                                       "2 HIP streams: frame FEC + vocoder of step k overlap front end + receive loop of step k+1 "
+                                       "(double-buffered loop outputs)") + "; every stage of every step inside the timed region"),
                        "vocoder_tables": "synthetic default blob (include/ddn_mbe.h); mbelib-neo absent -> vocoder parity unpinned"},
             "parity": parity,
             "work_per_step": {"symbols": n_sym, "frames_with_valid_nid": int((nidh[:, 0] == 1).sum()),

@@ -82,9 +82,10 @@ class P25Chain:
     def front_end(self, d_iq, st):
         self.fe.run_device(d_iq.data_ptr(), self.n, self.disc.data_ptr(), st)
 
-    def receive(self, st):
+    def receive(self, st, disc=None):
         l = self.l
-        assert l.ddn_p25_rx_run(self.rx.h, self.disc.data_ptr(), self.n, self.rec.data_ptr(), self.fl.data_ptr(),
+        disc = self.disc if disc is None else disc
+        assert l.ddn_p25_rx_run(self.rx.h, disc.data_ptr(), self.n, self.rec.data_ptr(), self.fl.data_ptr(),
                                 self.cnt.data_ptr(), self.ms, st) == 0
 
     def frame_fec(self, st):
@@ -125,6 +126,35 @@ class P25Chain:
         self.receive(st)
         self.frame_fec(st)
         self.voice(st)
+
+    def run_pipelined3(self, d_iq, s_fe, s_rx, s_aux):
+        """One batch interval over three torch streams: the front end of this batch on s_fe, its receive loop on s_rx, its
+        frame FEC + voice on s_aux.  Called back to back, the front end of batch k + 1 and the decode of batch k - 1 run beside
+        the receive loop of batch k: the loop is one latency-bound wavefront per CU for its whole duration, so the other three
+        SIMDs of every CU (and the loop SIMD's idle issue slots) are free for the VALU-bound front end.  The discriminator
+        buffer and the loop's output set are double-buffered; every stage of every batch still runs, in order per stage, and
+        carried state stays per stage."""
+        k = self.step
+        cur = k & 1
+        if not hasattr(self, "discs"):
+            self.discs = [self.disc, self.torch.zeros_like(self.disc)]
+            self.ev_fe = [self.torch.cuda.Event() for _ in range(2)]
+        disc = self.discs[cur]
+        self.rec, self.fl, self.cnt = self.sets[cur]
+        if k >= 2:
+            s_fe.wait_event(self.ev_produced[cur])        # the loop of batch k - 2 has read this discriminator buffer
+        self.fe.run_device(d_iq.data_ptr(), self.n, disc.data_ptr(), s_fe.cuda_stream)
+        self.ev_fe[cur].record(s_fe)
+        s_rx.wait_event(self.ev_fe[cur])
+        if k >= 2:
+            s_rx.wait_event(self.ev_consumed[cur])        # batch k - 2 has been decoded out of this output set
+        self.receive(s_rx.cuda_stream, disc)
+        self.ev_produced[cur].record(s_rx)
+        s_aux.wait_event(self.ev_produced[cur])
+        self.frame_fec(s_aux.cuda_stream)
+        self.voice(s_aux.cuda_stream)
+        self.ev_consumed[cur].record(s_aux)
+        self.step = k + 1
 
     def run_pipelined(self, d_iq, s_main, s_aux):
         """One batch interval, software-pipelined over two torch streams: front end + receive loop of this batch on s_main,

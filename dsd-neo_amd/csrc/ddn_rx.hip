@@ -697,6 +697,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const int ln = lane < CPW ? lane : 0;
     const bool use_flt = cfg.use_filter != 0;
     const float inf = __builtin_inff();
+    // the recurrence wave is a latency chain: when other kernels' wavefronts share its SIMD (the front end of the next batch
+    // runs beside this loop, bindings/ddn_chain.py run_pipelined3) its instructions go first
+    if (recur && !(cfg.dbg & 32768)) {
+        __builtin_amdgcn_s_setprio(3);
+    }
 
     DdnRxState s;
     if (live) {

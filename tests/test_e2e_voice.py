@@ -134,10 +134,12 @@ def test_voice_chain_on_device_equals_oracle_chain(built):
 
 
 @pytest.mark.gpu
-def test_pipelined_steps_equal_one_stream_steps(built):
+@pytest.mark.parametrize("n_streams", [2, 3])
+def test_pipelined_steps_equal_one_stream_steps(built, n_streams):
     """P25Chain.run_pipelined (frame FEC + vocoder of batch k on a second stream beside the next batch's front end + receive
-    loop, double-buffered loop outputs) produces, batch after batch, exactly what run() produces on one stream - records,
-    counts, NIDs, TSBKs, voice parameter bits, result flags and PCM, with the state carried across four batch intervals."""
+    loop, double-buffered loop outputs) and run_pipelined3 (the front end on a third stream as well, double-buffered
+    discriminator) produce, batch after batch, exactly what run() produces on one stream - records, counts, NIDs, TSBKs,
+    voice parameter bits, result flags and PCM, with the state carried across four batch intervals."""
     import torch
     import ddn_chain
     iq, lock, _ = _traffic()
@@ -146,7 +148,7 @@ def test_pipelined_steps_equal_one_stream_steps(built):
     d_iq = [torch.from_numpy(np.ascontiguousarray(iq[:, k * n:(k + 1) * n])).cuda() for k in range(4)]
     a = ddn_chain.P25Chain(torch, B, n, lock, block_len=4096)
     b = ddn_chain.P25Chain(torch, B, n, lock, block_len=4096)
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1, s2, s0 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     want = []
     for k in range(4):
@@ -155,7 +157,10 @@ def test_pipelined_steps_equal_one_stream_steps(built):
         want.append([t.clone() for t in (a.rec, a.fl, a.cnt, a.nid, a.tsbk, a.crc_ok, a.imbe_d, a.res_out, a.pcm)])
     got = []
     for k in range(4):          # no host synchronisation between the calls: the overlap is real
-        b.run_pipelined(d_iq[k], s1, s2)
+        if n_streams == 3:
+            b.run_pipelined3(d_iq[k], s0, s1, s2)
+        else:
+            b.run_pipelined(d_iq[k], s1, s2)
         # snapshot on the consumer stream, ordered after this batch's last stage
         with torch.cuda.stream(s2):
             got.append([t.clone() for t in (b.rec, b.fl, b.cnt, b.nid, b.tsbk, b.crc_ok, b.imbe_d, b.res_out, b.pcm)])
