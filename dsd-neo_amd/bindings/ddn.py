@@ -210,6 +210,11 @@ PROTOTYPES = {
     "ddn_fec_golay24_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_p25_rs_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_p25_rs_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_fec_rs28_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_rs28_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ez_rs28_ess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ez_rs28_facch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ez_rs28_sacch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ddn_fec_golay24_soft_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
     "ddn_fec_golay24_soft_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -615,6 +615,107 @@ check_and_fix_redsolomon_36_20_17(char* data, const char* parity) {
     return rs_one(DDN_RS_36_20_17, data, parity);
 }
 
+// ---- P25 Phase 2 RS(63,35) sections (ESS / FACCH / SACCH) with caller-given erasures ------------------------------------
+static int
+rs28_sizes(int kind, int* n_data, int* n_par) {
+    static const int nd[3] = {16, 26, 30}, np[3] = {28, 19, 22};
+    if (kind < 0 || kind > 2) {
+        ddn_set_error("rs28: kind must be DDN_RS28_ESS, _FACCH or _SACCH");
+        return DDN_EINVAL;
+    }
+    *n_data = nd[kind];
+    *n_par = np[kind];
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_rs28_batch(int kind, uint8_t* d_payload_bits, const uint8_t* d_parity_bits, const int8_t* d_erasures28,
+                   const uint8_t* d_n_erasures, size_t n, int32_t* d_status, void* hip_stream) {
+    int nd, np;
+    int rc = rs28_sizes(kind, &nd, &np);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (!d_payload_bits || !d_parity_bits || !d_status || (d_n_erasures && !d_erasures28)) {
+        ddn_set_error("ddn_fec_rs28_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_rs28(kind, d_payload_bits, d_parity_bits, d_erasures28, d_n_erasures, (int)n, d_status,
+                         (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_rs28_host(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const int8_t* erasures28,
+                  const uint8_t* n_erasures, size_t n, int32_t* status) {
+    int nd, np;
+    int rc = rs28_sizes(kind, &nd, &np);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (!payload_bits || !parity_bits || !status || (n_erasures && !erasures28)) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * (size_t)nd * 6), p(n * (size_t)np * 6), e(n * 28), c(n), s(n * sizeof(int32_t));
+    if (!a.p || !p.p || !e.p || !c.p || !s.p || a.up(payload_bits) || p.up(parity_bits)) {
+        return no_dev();
+    }
+    if (n_erasures && (e.up(erasures28) || c.up(n_erasures))) {
+        return no_dev();
+    }
+    rc = ddn_fec_rs28_batch(kind, (uint8_t*)a.p, (const uint8_t*)p.p, (const int8_t*)e.p,
+                            n_erasures ? (const uint8_t*)c.p : nullptr, n, (int32_t*)s.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (a.down(payload_bits) || s.down(status)) ? no_dev() : DDN_OK;
+}
+
+// reference names (include/dsd-neo/fec/ez.h:29-31): one section per call, int-per-bit arrays.  -2 when the device path is
+// unavailable, the value the reference returns when its decoder object could not be constructed (src/fec/ez.cpp:106-117).
+static int
+rs28_one(int kind, int* payload, const int* parity, const int* erasures, int n_erasures) {
+    int nd, np;
+    if (!payload || !parity || rs28_sizes(kind, &nd, &np) != DDN_OK) {
+        return -2;
+    }
+    uint8_t pl[180], pa[168];
+    int8_t er[28] = {0};
+    for (int i = 0; i < nd * 6; i++) {
+        pl[i] = (uint8_t)(payload[i] & 1);
+    }
+    for (int i = 0; i < np * 6; i++) {
+        pa[i] = (uint8_t)(parity[i] & 1);
+    }
+    uint8_t ne = 0;
+    for (int i = 0; erasures && i < n_erasures && i < 28; i++) {
+        er[ne++] = (int8_t)erasures[i];
+    }
+    int32_t st = -2;
+    if (ddn_fec_rs28_host(kind, pl, pa, er, &ne, 1, &st) != DDN_OK) {
+        return -2;
+    }
+    for (int i = 0; i < nd * 6; i++) {
+        payload[i] = pl[i];
+    }
+    return st;
+}
+
+extern "C" int
+ez_rs28_ess(int payload[96], int parity[168], const int* erasures, int n_erasures) {
+    return rs28_one(0, payload, parity, erasures, n_erasures);
+}
+
+extern "C" int
+ez_rs28_facch(int payload[156], int parity[114], const int* erasures, int n_erasures) {
+    return rs28_one(1, payload, parity, erasures, n_erasures);
+}
+
+extern "C" int
+ez_rs28_sacch(int payload[180], int parity[132], const int* erasures, int n_erasures) {
+    return rs28_one(2, payload, parity, erasures, n_erasures);
+}
+
 // ---- P25 1/2-rate list decoder -------------------------------------------------------------------------------------
 extern "C" int
 ddn_fec_p25_12_soft_list_batch(const int16_t* d_llr196, size_t n, int max_candidates, ddn_p25_12_candidate* d_candidates8,

@@ -998,3 +998,189 @@ ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_re
                        n_par, n_data, t, threshold, n, status);
     return hipGetLastError();
 }
+
+// ---- P25 Phase 2 RS(63,35) sections with caller-given erasures --------------------------------------------------------------
+// == ez_rs28_ess / _facch / _sacch (src/fec/ez.cpp:104-281) over the vendored ezpwd RS<63,35> (GF(64) from x^6+x+1, roots
+// alpha^1..alpha^28; decoder src/third_party/ezpwd/rs_base:1380-1720): block position p carries the coefficient of
+// x^(62-p); syndromes, erasure locator, Berlekamp's iteration from step n_erasures + 1 with the length rule
+// 2 L <= r + n_erasures - 1, Chien search over the 63 positions stopped at deg(lambda) roots, Forney from the last root to
+// the first.  A root count short of the degree, a zero derivative or a non-zero value inside the pad fails the decode (-1)
+// and leaves the section as received (the reference decodes a copy and copies back on a positive count only).
+// One section per thread, its polynomials in LDS columns.
+__global__ __launch_bounds__(64) void
+k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__ parity_bits,
+       const int8_t* __restrict__ erasures, const uint8_t* __restrict__ n_erasures, int n, int32_t* __restrict__ status) {
+    constexpr int R = 28;
+    __shared__ uint8_t ex[128], lg[64];
+    __shared__ uint8_t Cw[63][64], Sy[R][64], La[R + 1][64], Bp[R + 1][64], Tp[R + 1][64], Om[R][64], Rt[R][64];
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        int x = 1;
+        for (int i = 0; i < 63; i++) {
+            ex[i] = (uint8_t)x;
+            ex[i + 63] = (uint8_t)x;
+            lg[x] = (uint8_t)i;
+            x <<= 1;
+            if (x & 0x40) {
+                x ^= 0x43;
+            }
+        }
+        ex[126] = ex[0];
+        ex[127] = ex[1];
+        lg[0] = 0;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 64 + lane;
+    if (i >= n) {
+        return;
+    }
+    auto gmul = [&](int a, int b) -> int { return (a && b) ? ex[lg[a] + lg[b]] : 0; };
+    auto gdiv = [&](int a, int b) -> int { return a ? ex[lg[a] + 63 - lg[b]] : 0; };
+    auto gpow = [&](int a, int e) -> int { return a ? ex[(lg[a] + e) % 63] : 0; }; // a * alpha^e
+    const int n_data = kind == 0 ? 16 : (kind == 1 ? 26 : 30), n_par = kind == 0 ? 28 : (kind == 1 ? 19 : 22);
+    const int first = kind == 0 ? 19 : (kind == 1 ? 9 : 5), pad = kind == 0 ? 19 : 0;
+    uint8_t* pl = payload_bits + (size_t)i * n_data * 6;
+    const uint8_t* pa = parity_bits + (size_t)i * n_par * 6;
+    for (int p = 0; p < 63; p++) {
+        int v = 0;
+        const uint8_t* q = nullptr;
+        if (p >= first && p < 35) {
+            q = pl + 6 * (p - first);
+        } else if (p >= 35 && p < 35 + n_par) {
+            q = pa + 6 * (p - 35);
+        }
+        if (q) {
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                v = (v << 1) | (q[b] != 0);
+            }
+        }
+        Cw[p][lane] = (uint8_t)v;
+    }
+    int any = 0;
+    for (int r = 0; r < R; r++) {
+        int v = 0;
+        for (int p = 0; p < 63; p++) {
+            v = gpow(v, r + 1) ^ Cw[p][lane];
+        }
+        Sy[r][lane] = (uint8_t)v;
+        any |= v;
+    }
+    if (!any) {
+        status[i] = 0;
+        return;
+    }
+    int n_er = n_erasures ? n_erasures[i] : 0;
+    n_er = n_er > R ? R : n_er;
+    for (int k = 0; k <= R; k++) {
+        La[k][lane] = k == 0 ? 1 : 0;
+    }
+    for (int e = 0; e < n_er; e++) {
+        const int bp = (int)erasures[(size_t)i * R + e] + pad; // block position
+        const int X = ex[(((62 - bp) % 63) + 63) % 63];
+        for (int j = e + 1; j > 0; j--) {
+            La[j][lane] ^= (uint8_t)gmul(La[j - 1][lane], X);
+        }
+    }
+    for (int k = 0; k <= R; k++) {
+        Bp[k][lane] = La[k][lane];
+    }
+    int el = n_er;
+    for (int r = n_er + 1; r <= R; r++) {
+        int d = 0;
+        for (int k = 0; k < r; k++) {
+            d ^= gmul(La[k][lane], Sy[r - k - 1][lane]);
+        }
+        if (d == 0) {
+            for (int k = R; k > 0; k--) {
+                Bp[k][lane] = Bp[k - 1][lane];
+            }
+            Bp[0][lane] = 0;
+            continue;
+        }
+        Tp[0][lane] = La[0][lane];
+        for (int k = 0; k < R; k++) {
+            Tp[k + 1][lane] = La[k + 1][lane] ^ (uint8_t)gmul(d, Bp[k][lane]);
+        }
+        if (2 * el <= r + n_er - 1) {
+            el = r + n_er - el;
+            for (int k = 0; k <= R; k++) {
+                Bp[k][lane] = (uint8_t)gdiv(La[k][lane], d);
+            }
+        } else {
+            for (int k = R; k > 0; k--) {
+                Bp[k][lane] = Bp[k - 1][lane];
+            }
+            Bp[0][lane] = 0;
+        }
+        for (int k = 0; k <= R; k++) {
+            La[k][lane] = Tp[k][lane];
+        }
+    }
+    int deg = 0;
+    for (int k = 0; k <= R; k++) {
+        deg = La[k][lane] ? k : deg;
+    }
+    int count = 0;
+    for (int r = 1; r <= 63 && count < deg; r++) {
+        int q = 1;
+        for (int j = 1; j <= deg; j++) {
+            q ^= gpow(La[j][lane], r * j);
+        }
+        if (q == 0) {
+            Rt[count][lane] = (uint8_t)r;
+            count++;
+        }
+    }
+    if (count != deg || deg == 0) {
+        status[i] = -1;
+        return;
+    }
+    for (int k = 0; k < deg; k++) {
+        int v = 0;
+        for (int j = 0; j <= k; j++) {
+            v ^= gmul(Sy[k - j][lane], La[j][lane]);
+        }
+        Om[k][lane] = (uint8_t)v;
+    }
+    const int top = (deg < R - 1 ? deg : R - 1) & ~1;
+    bool ok = true;
+    for (int j = count - 1; j >= 0 && ok; j--) {
+        const int rt = Rt[j][lane], loc = rt - 1;
+        int num = 0, den = 0;
+        for (int k = 0; k < deg; k++) {
+            num ^= gpow(Om[k][lane], k * rt);
+        }
+        for (int k = top; k >= 0; k -= 2) {
+            den ^= gpow(La[k + 1][lane], k * rt);
+        }
+        if (den == 0 || (num != 0 && loc < pad)) {
+            ok = false;
+        } else if (num != 0) {
+            Cw[loc][lane] ^= (uint8_t)gdiv(num, den);
+        }
+    }
+    if (!ok) {
+        status[i] = -1;
+        return;
+    }
+    for (int k = 0; k < n_data; k++) {
+        const int v = Cw[first + k][lane];
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            pl[6 * k + b] = (uint8_t)((v >> (5 - b)) & 1);
+        }
+    }
+    status[i] = count;
+}
+
+extern "C" hipError_t
+ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const int8_t* erasures, const uint8_t* n_erasures,
+             int n, int32_t* status, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures,
+                       n_erasures, n, status);
+    return hipGetLastError();
+}

@@ -577,6 +577,22 @@ int ddn_fec_p25_lsd_batch(uint8_t* d_bits16, const int16_t* d_llr16, size_t n, u
 int ddn_fec_p25_lsd_host(uint8_t* bits16, const int16_t* llr16, size_t n, uint8_t* ok);
 int p25_lsd_fec_16x8(uint8_t* bits16);
 int p25_lsd_fec_16x8_soft(uint8_t* bits16, const int16_t llr16[16]);
+/* P25 Phase 2 RS(63,35) sections with caller-given erasures == ez_rs28_ess / _facch / _sacch (src/fec/ez.cpp:104-281 over
+ * the vendored ezpwd RS<63,35>, src/third_party/ezpwd/rs_base:1380-1720): ESS 16 payload + 28 parity symbols, FACCH 26 + 19
+ * (9 parity symbols punctured), SACCH 30 + 22 (6 punctured).  Bits one per byte, most significant bit of a 6-bit symbol
+ * first; payload corrected in place.  erasures28 [n][28] (int8) / n_erasures [n]: erased symbol positions in the
+ * reference's convention (ESS: 0..43 counted from the first payload symbol; FACCH / SACCH: positions 0..62 of the 63-symbol
+ * block, payload at 9.. / 5.., parity at 35.., so the punctured parity is 54..62 / 57..62); positions must be valid and
+ * distinct (the reference raises otherwise); n_erasures may be NULL (none).  status [n] = the reference's return value:
+ * number of symbols located (errors + erasures), 0 for a clean word, -1 when the word is beyond the code (payload untouched). */
+enum { DDN_RS28_ESS = 0, DDN_RS28_FACCH = 1, DDN_RS28_SACCH = 2 };
+int ddn_fec_rs28_batch(int kind, uint8_t* d_payload_bits, const uint8_t* d_parity_bits, const int8_t* d_erasures28,
+                       const uint8_t* d_n_erasures, size_t n, int32_t* d_status, void* hip_stream);
+int ddn_fec_rs28_host(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const int8_t* erasures28,
+                      const uint8_t* n_erasures, size_t n, int32_t* status);
+int ez_rs28_ess(int payload[96], int parity[168], const int* erasures, int n_erasures);
+int ez_rs28_facch(int payload[156], int parity[114], const int* erasures, int n_erasures);
+int ez_rs28_sacch(int payload[180], int parity[132], const int* erasures, int n_erasures);
 int ddn_fec_p25_rs_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, size_t n, uint8_t* d_status,
                          void* hip_stream);
 int ddn_fec_p25_rs_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, size_t n, uint8_t* status);

@@ -290,6 +290,8 @@ long orc_symbolizer_symbol(orc_symbolizer* s, const float* in, long n, int have_
 int orc_golay_24_decode(uint8_t* data, int len, const uint8_t* parity, int* fixed);
 int orc_rs63_decode(int* word, int t);
 int orc_rs63_decode_erasures(int* word, int t, const int* erasures, int n_er);
+/* P25 Phase 2 RS(63,35) sections with caller-given erasures (== ez_rs28_ess / _facch / _sacch, src/fec/ez.cpp:104-281) */
+int orc_ez_rs28(int kind, int* payload, const int* parity, const int* erasures, int n_erasures);
 int orc_p25_rs_decode_soft(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, const int* erasures,
                            int n_er);
 int orc_p25_rs_ranked_erasures(const uint8_t* data_rel, int n_data, const uint8_t* parity_rel, int n_par, int min_er,

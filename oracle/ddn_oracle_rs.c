@@ -813,3 +813,172 @@ orc_p25_rs_soft_reliability(uint8_t* data6, const uint8_t* parity6, const uint8_
     }
     return 1;
 }
+
+/* ---- P25 Phase 2 RS(63,35) over GF(64) with caller-given erasures (ESS / FACCH / SACCH sections) -------------------------
+ * == ez_rs28_ess / _facch / _sacch (src/fec/ez.cpp:104-281) over the vendored ezpwd RS<63,35> (x^6+x+1, first consecutive
+ * root alpha^1, 28 roots; src/third_party/ezpwd/rs:79, decoder rs_base:1380-1720).  That decoder is the classic
+ * errors-and-erasures procedure, restated here on coefficient values:
+ *   - block position p = 0..62 carries the coefficient of x^(62-p); a section's symbols sit at fixed block positions, the
+ *     rest of the block is zero ("pad" in front of the data, punctured parity behind it);
+ *   - syndromes S_i = c(alpha^(i+1)), i = 0..27; all zero -> 0 corrections;
+ *   - the locator starts as the erasure locator prod (1 + alpha^(62-p) x) and is grown by Berlekamp's iteration from step
+ *     n_erasures + 1 to 28 with the length rule 2 L <= r + n_erasures - 1;
+ *   - Chien search over i = 1..63 (root alpha^i <-> block position i - 1), stopped when deg(lambda) roots are found; a root
+ *     count short of the degree, or degree 0 with a non-zero syndrome, is a failure (-1), nothing touched;
+ *   - errata values by Forney from omega = S lambda mod x^deg; a zero derivative, or a non-zero value inside the pad,
+ *     fails the decode.  The reference decodes a masked copy of the caller's symbols (6-bit symbols in 8-bit storage,
+ *     rs_base:1180-1235) and copies it back only when the count is positive, so a failed decode leaves the section as it
+ *     was received;
+ *   - the return value is the number of roots (errors + erasures, whether or not an erased symbol was actually wrong).
+ * Pinned against the compiled reference by tests/test_oracle_rs28.py. */
+#define RS28_ROOTS 28
+
+static int
+rs28_block_decode(uint8_t c[63], int pad, const int* eras_blockpos, int n_er) {
+    gf_init();
+    int S[RS28_ROOTS];
+    int any = 0;
+    for (int i = 0; i < RS28_ROOTS; i++) {
+        int v = 0;
+        for (int p = 0; p < 63; p++) { /* Horner from the highest coefficient */
+            v = gmul(v, g_ex[i + 1]) ^ c[p];
+        }
+        S[i] = v;
+        any |= v;
+    }
+    if (!any) {
+        return 0;
+    }
+    int lam[RS28_ROOTS + 1] = {1}, b[RS28_ROOTS + 1], t[RS28_ROOTS + 1];
+    for (int e = 0; e < n_er; e++) { /* times (1 + X x), X = alpha^(62 - p) */
+        const int X = g_ex[(62 - eras_blockpos[e]) % 63];
+        for (int j = e + 1; j > 0; j--) {
+            lam[j] ^= gmul(lam[j - 1], X);
+        }
+    }
+    memcpy(b, lam, sizeof(b));
+    int el = n_er;
+    for (int r = n_er + 1; r <= RS28_ROOTS; r++) {
+        int d = 0;
+        for (int i = 0; i < r; i++) {
+            d ^= gmul(lam[i], S[r - i - 1]);
+        }
+        if (d == 0) {
+            memmove(b + 1, b, sizeof(int) * RS28_ROOTS); /* b <- x b */
+            b[0] = 0;
+            continue;
+        }
+        t[0] = lam[0];
+        for (int i = 0; i < RS28_ROOTS; i++) {
+            t[i + 1] = lam[i + 1] ^ gmul(d, b[i]);
+        }
+        if (2 * el <= r + n_er - 1) {
+            el = r + n_er - el;
+            for (int i = 0; i <= RS28_ROOTS; i++) {
+                b[i] = gdiv(lam[i], d);
+            }
+        } else {
+            memmove(b + 1, b, sizeof(int) * RS28_ROOTS);
+            b[0] = 0;
+        }
+        memcpy(lam, t, sizeof(lam));
+    }
+    int deg = 0;
+    for (int i = 0; i <= RS28_ROOTS; i++) {
+        if (lam[i]) {
+            deg = i;
+        }
+    }
+    int root[RS28_ROOTS], loc[RS28_ROOTS], count = 0;
+    for (int i = 1; i <= 63 && count < deg; i++) {
+        int q = 1;
+        for (int j = 1; j <= deg; j++) {
+            if (lam[j]) {
+                q ^= g_ex[(g_lg[lam[j]] + i * j) % 63];
+            }
+        }
+        if (q == 0) {
+            root[count] = i;
+            loc[count] = i - 1;
+            count++;
+        }
+    }
+    if (count != deg || deg == 0) {
+        return -1;
+    }
+    int om[RS28_ROOTS];
+    for (int i = 0; i < deg; i++) {
+        int v = 0;
+        for (int j = 0; j <= i; j++) {
+            v ^= gmul(S[i - j], lam[j]);
+        }
+        om[i] = v;
+    }
+    const int top = (deg < RS28_ROOTS - 1 ? deg : RS28_ROOTS - 1) & ~1;
+    for (int j = count - 1; j >= 0; j--) {
+        int num = 0, den = 0;
+        for (int i = 0; i < deg; i++) {
+            if (om[i]) {
+                num ^= g_ex[(g_lg[om[i]] + i * root[j]) % 63];
+            }
+        }
+        for (int i = top; i >= 0; i -= 2) {
+            if (lam[i + 1]) {
+                den ^= g_ex[(g_lg[lam[i + 1]] + i * root[j]) % 63];
+            }
+        }
+        if (den == 0) {
+            return -1;
+        }
+        if (num != 0) {
+            if (loc[j] < pad) {
+                return -1;
+            }
+            c[loc[j]] ^= (uint8_t)gdiv(num, den); /* first consecutive root 1: no extra factor */
+        }
+    }
+    return count;
+}
+
+/* kind 0 ESS (16 payload + 28 parity symbols, erasure positions 0..43 count from the first payload symbol), 1 FACCH (26 +
+ * 19 at block positions 9.. / 35.., erasure positions are block positions), 2 SACCH (30 + 22 at 5.. / 35..).  Bit arrays
+ * hold one bit per int, most significant bit of a symbol first.  At most 28 erasures are consumed.  Returns what the
+ * reference returns; the payload changes only when that is positive. */
+int
+orc_ez_rs28(int kind, int* payload, const int* parity, const int* erasures, int n_erasures) {
+    static const int n_data[3] = {16, 26, 30}, n_par[3] = {28, 19, 22}, first[3] = {19, 9, 5};
+    if (kind < 0 || kind > 2) {
+        return -2;
+    }
+    uint8_t c[63] = {0};
+    for (int i = 0; i < n_data[kind]; i++) {
+        int v = 0;
+        for (int j = 0; j < 6; j++) {
+            v = (v << 1) + payload[6 * i + j];
+        }
+        c[first[kind] + i] = (uint8_t)(v & 63);
+    }
+    for (int i = 0; i < n_par[kind]; i++) {
+        int v = 0;
+        for (int j = 0; j < 6; j++) {
+            v = (v << 1) + parity[6 * i + j];
+        }
+        c[35 + i] = (uint8_t)(v & 63);
+    }
+    int ep[RS28_ROOTS], n = 0;
+    for (int i = 0; erasures && i < n_erasures && i < RS28_ROOTS; i++) {
+        ep[n++] = erasures[i] + (kind == 0 ? 19 : 0);
+    }
+    uint8_t w[63];
+    memcpy(w, c, sizeof(w));
+    const int ec = rs28_block_decode(w, kind == 0 ? 19 : 0, ep, n);
+    if (ec > 0) {
+        memcpy(c, w, sizeof(c));
+    }
+    for (int i = 0; i < n_data[kind]; i++) {
+        for (int j = 0; j < 6; j++) {
+            payload[6 * i + j] = (c[first[kind] + i] >> (5 - j)) & 1;
+        }
+    }
+    return ec;
+}

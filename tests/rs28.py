@@ -1,0 +1,106 @@
+"""P25 Phase 2 RS(63,35) sections (ESS / FACCH / SACCH): test-side encoder, traffic generator and the oracle / reference
+callers.  Block position p = 0..62 carries the coefficient of x^(62-p); generator roots alpha^1..alpha^28 over GF(64)
+(x^6 + x + 1), the code of src/fec/ez.cpp (ezpwd RS<63,35>)."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+
+KINDS = {"ess": 0, "facch": 1, "sacch": 2}
+N_DATA = (16, 26, 30)
+N_PAR = (28, 19, 22)
+FIRST = (19, 9, 5)
+
+_EX = np.zeros(126, np.int64)
+_LG = np.zeros(64, np.int64)
+_x = 1
+for _i in range(63):
+    _EX[_i] = _EX[_i + 63] = _x
+    _LG[_x] = _i
+    _x <<= 1
+    if _x & 0x40:
+        _x ^= 0x43
+
+
+def gmul(a, b):
+    return int(_EX[_LG[a] + _LG[b]]) if a and b else 0
+
+
+def _generator():
+    g = [1]
+    for r in range(1, 29):           # times (x + alpha^r), coefficients lowest degree first
+        root = int(_EX[r])
+        ng = [0] * (len(g) + 1)
+        for i, c in enumerate(g):
+            ng[i + 1] ^= c
+            ng[i] ^= gmul(c, root)
+        g = ng
+    return g                         # degree 28, monic
+
+
+_GEN = _generator()
+
+
+def encode_block(data35):
+    """35 data symbols (block positions 0..34) -> 63-symbol block with the 28 parity symbols at 35..62."""
+    rem = [0] * 28                   # remainder register, rem[27] = highest degree
+    for d in data35:
+        fb = int(d) ^ rem[27]
+        for i in range(27, 0, -1):
+            rem[i] = rem[i - 1] ^ gmul(fb, _GEN[i])
+        rem[0] = gmul(fb, _GEN[0])
+    return np.array(list(data35) + rem[::-1], np.uint8)
+
+
+def bits_of(symbols):
+    s = np.asarray(symbols, np.uint8)
+    return ((s[:, None] >> np.arange(5, -1, -1)[None, :]) & 1).astype(np.int32).reshape(-1)
+
+
+def make_case(rng, kind, n_err, n_extra_erasures, erase_hits):
+    """One received section: random message, n_err symbol errors at transmitted positions, the punctured parity positions
+    declared erased (FACCH / SACCH) plus n_extra_erasures more, erase_hits of which land on corrupted symbols.
+    -> (payload bits int32, parity bits int32, erasures int32 (the reference's position convention), sent payload bits)"""
+    k = KINDS[kind] if isinstance(kind, str) else kind
+    nd, npar, first = N_DATA[k], N_PAR[k], FIRST[k]
+    data35 = np.zeros(35, np.uint8)
+    data35[first:35] = rng.integers(0, 64, nd)
+    blk = encode_block(data35)
+    sent = blk.copy()
+    tx = np.arange(first, 35 + npar)                      # transmitted block positions
+    bad = rng.choice(tx, size=min(n_err, tx.size), replace=False) if n_err else np.zeros(0, np.int64)
+    for p in bad:
+        blk[p] ^= rng.integers(1, 64)
+    blk[35 + npar:] = 0                                   # punctured parity: never sent
+    er = list(range(35 + npar, 63))
+    hits = list(rng.choice(bad, size=min(erase_hits, len(bad)), replace=False)) if erase_hits and len(bad) else []
+    rest = [p for p in tx if p not in bad]
+    more = list(rng.choice(rest, size=min(max(n_extra_erasures - len(hits), 0), len(rest)), replace=False)) if n_extra_erasures else []
+    er = er + [int(p) for p in hits] + [int(p) for p in more]
+    rng.shuffle(er)
+    er = er[:28]
+    if k == 0:
+        er = [p - 19 for p in er]                         # ESS positions count from the first payload symbol
+    return (bits_of(blk[first:35]), bits_of(blk[35:35 + npar]), np.array(er, np.int32), bits_of(sent[first:35]))
+
+
+def oracle_rs28(kind, payload, parity, erasures):
+    o = orc.oracle()
+    o.orc_ez_rs28.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    pl = np.ascontiguousarray(payload, np.int32).copy()
+    pa = np.ascontiguousarray(parity, np.int32)
+    er = np.ascontiguousarray(erasures, np.int32)
+    rc = o.orc_ez_rs28(kind, pl.ctypes.data, pa.ctypes.data, er.ctypes.data if er.size else None, int(er.size))
+    return pl, rc
+
+
+def ref_rs28(kind, payload, parity, erasures):
+    r = C.CDLL(orc.REF_SO)
+    fn = (r.ez_rs28_ess, r.ez_rs28_facch, r.ez_rs28_sacch)[kind]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    pl = np.ascontiguousarray(payload, np.int32).copy()
+    pa = np.ascontiguousarray(parity, np.int32).copy()
+    er = np.ascontiguousarray(erasures, np.int32)
+    rc = fn(pl.ctypes.data, pa.ctypes.data, er.ctypes.data if er.size else None, int(er.size))
+    return pl, rc
