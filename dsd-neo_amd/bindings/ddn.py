@@ -372,6 +372,11 @@ PROTOTYPES.update({
     "ddn_agf_frame": (C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "ddn_symbol_capture_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "ddn_wav_write_s16": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_float]),
+    "ddn_ambe2450_deinterleave_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_nxdn_voice_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_dmr_voice_burst_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_nxdn_frame_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 7),
     "ddn_nxdn_crc_check_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_dmr_burst_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int]

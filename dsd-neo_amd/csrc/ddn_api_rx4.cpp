@@ -465,6 +465,40 @@ ddn_nxdn_frame_gather(const uint8_t* d_records10, const int32_t* d_counts, size_
 }
 
 extern "C" int
+ddn_ambe2450_deinterleave_batch(const uint8_t* d_dibits36, const uint8_t* d_reliab36, size_t n, uint8_t* d_ambe_fr,
+                                uint8_t* d_ambe_rel, void* hip_stream) {
+    if (!d_dibits36 || !d_ambe_fr || (d_ambe_rel && !d_reliab36)) {
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_ambe2450_deinterleave(d_dibits36, d_reliab36, (int)n, d_ambe_fr, d_ambe_rel, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_nxdn_voice_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols, const int32_t* d_sync_pos,
+                      const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_ambe_fr, uint8_t* d_ambe_rel,
+                      uint8_t* d_valid, void* hip_stream) {
+    if (!d_records10 || !d_counts || !d_sync_pos || !d_n_sync || !d_ambe_fr || n_channels <= 0) {
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_nxdn_voice_gather(d_records10, d_counts, max_symbols, d_sync_pos, d_n_sync, (int)max_syncs, n_channels,
+                                      d_ambe_fr, d_ambe_rel, d_valid, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_dmr_voice_burst_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols,
+                           const int32_t* d_burst_start, int n_channels, size_t max_bursts, int inverted, uint8_t* d_ambe_fr,
+                           uint8_t* d_ambe_rel, uint8_t* d_sync48, uint8_t* d_cach24, uint8_t* d_valid, void* hip_stream) {
+    if (!d_records10 || !d_counts || !d_burst_start || !d_ambe_fr || n_channels <= 0) {
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_dmr_voice_gather(d_records10, d_counts, max_symbols, d_burst_start, (int)max_bursts, n_channels, inverted,
+                                     d_ambe_fr, d_ambe_rel, d_sync48, d_cach24, d_valid, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
 ddn_nxdn_crc_check_batch(const uint8_t* d_bytes, int stride, size_t n, int kind, uint8_t* d_ok, void* hip_stream) {
     if (!d_bytes || !d_ok || stride <= 0 || kind < 0 || kind > 3 || stride * ((kind & 2) ? 1 : 8) < ((kind & 1) == 0 ? 32 : 92)) {
         return DDN_EINVAL;

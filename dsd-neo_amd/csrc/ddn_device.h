@@ -161,6 +161,14 @@ hipError_t ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* pre
 hipError_t ddn_dev_dmr_burst_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
                                     const uint8_t* pre, const int32_t* n_sync, int n_channels, int max_sync, int inverted,
                                     uint8_t* slot_type, uint8_t* info, uint8_t* cach, uint8_t* valid, hipStream_t st);
+hipError_t ddn_dev_ambe2450_deinterleave(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* fr, uint8_t* rl,
+                                         hipStream_t st);
+hipError_t ddn_dev_nxdn_voice_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
+                                     const int32_t* n_sync, int max_sync, int n_channels, uint8_t* fr, uint8_t* rl,
+                                     uint8_t* valid, hipStream_t st);
+hipError_t ddn_dev_dmr_voice_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* burst_start,
+                                    int max_bursts, int n_channels, int inverted, uint8_t* fr, uint8_t* rl, uint8_t* sync48,
+                                    uint8_t* cach24, uint8_t* valid, hipStream_t st);
 hipError_t ddn_dev_nxdn_frame_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
                                      const int32_t* n_sync, int n_channels, int max_sync, uint8_t* lich, uint8_t* sacch_sym,
                                      uint8_t* sacch_rel, uint8_t* facch_sym, uint8_t* facch_rel, uint8_t* valid, hipStream_t st);

@@ -28,6 +28,7 @@
 #include "ddn_device.h"
 #include "ddn_slicer_dev.h"
 #include "ddn_tables_fsk4.h"
+#include "ddn_tables_ambe.h"
 
 namespace {
 constexpr int TS = 64;
@@ -951,6 +952,171 @@ ddn_dev_nxdn_frame_gather(const uint8_t* rec, const int32_t* counts, size_t max_
     }
     hipLaunchKernelGGL(k_nxdn_frame_gather, dim3((unsigned)max_sync, (unsigned)n_channels), dim3(128), 0, st, rec, counts, max_sym,
                        sync_pos, n_sync, max_sync, lich, sacch_sym, sacch_rel, facch_sym, facch_rel, valid);
+    return hipGetLastError();
+}
+
+// ---- AMBE 3600x2450 voice frames: the 36-dibit interleave schedule DMR, NXDN and YSF share ------------------------------
+// include/dsd-neo/core/ambe_interleave.h:25-38 (table measured from the compiled reference, ddn_tables_ambe.h): dibit i puts
+// its high bit at ambe_fr[map[i][0]][map[i][1]] and its low bit at ambe_fr[map[i][2]][map[i][3]]; both bits take the dibit's
+// reliability (nxdn_voice.c:57-74); the 24 cells of the 4 x 24 array the schedule never writes stay 0.
+__constant__ uint8_t c_ambe2450_map[36][4] = DDN_AMBE2450_MAP_INIT;
+
+__device__ __forceinline__ void
+ambe2450_put(uint8_t* fr, uint8_t* rl, int i, int dibit, int reliab) {
+    const int hi = c_ambe2450_map[i][0] * 24 + c_ambe2450_map[i][1], lo = c_ambe2450_map[i][2] * 24 + c_ambe2450_map[i][3];
+    fr[hi] = (uint8_t)((dibit >> 1) & 1);
+    fr[lo] = (uint8_t)(dibit & 1);
+    if (rl) {
+        rl[hi] = (uint8_t)reliab;
+        rl[lo] = (uint8_t)reliab;
+    }
+}
+
+// n frames of 36 dibits (+ optional reliabilities) -> ambe_fr [n][4][24] (+ per-bit reliabilities): one frame per 64 threads
+__global__ __launch_bounds__(64) void
+k_ambe2450_deinterleave(const uint8_t* __restrict__ dibits, const uint8_t* __restrict__ reliab, int n,
+                        uint8_t* __restrict__ fr, uint8_t* __restrict__ rl) {
+    const int f = blockIdx.x, t = threadIdx.x;
+    if (f >= n) {
+        return;
+    }
+    uint8_t* o = fr + (size_t)f * 96;
+    uint8_t* r = rl ? rl + (size_t)f * 96 : nullptr;
+    for (int k = t; k < 96; k += 64) {
+        o[k] = 0;
+        if (r) {
+            r[k] = 0;
+        }
+    }
+    __syncthreads();
+    if (t < 36) {
+        ambe2450_put(o, r, t, dibits[(size_t)f * 36 + t] & 3, reliab ? reliab[(size_t)f * 36 + t] : 0);
+    }
+}
+
+// NXDN voice: the four 36-dibit AMBE frames behind LICH (8 dibits) + SACCH (30) of the frame that follows sync k of channel
+// ch, de-scrambled with the same PN9 sequence as the control fields (nxdn_frame.c:181-199: every one of the 182 dibits after
+// the sync word; nxdn_voice.c:57-66: frame v starts at de-scrambled dibit 38 + 36 v).  Which of the four carry voice is the
+// LICH's business (k_nxdn_frame_gather); all four are de-interleaved here.
+__global__ __launch_bounds__(192) void
+k_nxdn_voice_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ counts, size_t max_sym,
+                    const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_sync, int max_sync,
+                    uint8_t* __restrict__ fr, uint8_t* __restrict__ rl, uint8_t* __restrict__ valid) {
+    __shared__ uint8_t pn[182];
+    const int k = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
+    const size_t so = (size_t)ch * max_sync + k;
+    const bool have = k < n_sync[ch] && k < max_sync;
+    const long pos = have ? sync_pos[so] : 0;
+    const bool ok = have && (pos + 182 < (long)counts[ch]) && ((size_t)(pos + 182) < max_sym);
+    if (t == 0) {
+        unsigned l = 228u;
+        for (int i = 0; i < 182; i++) {
+            pn[i] = (uint8_t)(l & 1u);
+            const unsigned b = ((l >> 4) ^ l) & 1u;
+            l = (l >> 1) | (b << 8);
+        }
+        if (valid) {
+            valid[so] = ok ? 1 : 0;
+        }
+    }
+    uint8_t* o = fr + so * 4 * 96;
+    uint8_t* r = rl ? rl + so * 4 * 96 : nullptr;
+    for (int q = t; q < 4 * 96; q += blockDim.x) {
+        o[q] = 0;
+        if (r) {
+            r[q] = 0;
+        }
+    }
+    __syncthreads();
+    if (ok && t < 144) {
+        const int i = 38 + t;
+        const uint8_t* rr = rec + ((size_t)ch * max_sym + (size_t)(pos + 1 + i)) * 10;
+        const int d = (rr[0] & 3) ^ (pn[i] << 1);
+        ambe2450_put(o + (t / 36) * 96, r ? r + (t / 36) * 96 : nullptr, t % 36, d, rr[1]);
+    }
+}
+
+// DMR voice burst (dmr_bs.c:128-200, dmr_ms.c:96-140): 144 dibits from the burst's first CACH dibit: CACH 0..11, voice frame
+// 1 = dibits 12..47, frame 2 = 48..65 + 90..107 (either side of the 24 sync / EMB dibits 66..89), frame 3 = 108..143.
+// burst_start [n_channels][max_bursts] = record index of the first CACH dibit (< 0: unused).  inverted != 0 applies the MS
+// path's dibit ^= 2 (dmr_ms.c:55-64).
+__global__ __launch_bounds__(160) void
+k_dmr_voice_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ counts, size_t max_sym,
+                   const int32_t* __restrict__ burst_start, int max_bursts, int inverted, uint8_t* __restrict__ fr,
+                   uint8_t* __restrict__ rl, uint8_t* __restrict__ sync48, uint8_t* __restrict__ cach24,
+                   uint8_t* __restrict__ valid) {
+    const int k = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
+    const size_t so = (size_t)ch * max_bursts + k;
+    const long s0 = burst_start[so];
+    const bool ok = s0 >= 0 && s0 + 144 <= (long)counts[ch] && (size_t)(s0 + 144) <= max_sym;
+    uint8_t* o = fr + so * 3 * 96;
+    uint8_t* r = rl ? rl + so * 3 * 96 : nullptr;
+    for (int q = t; q < 3 * 96; q += blockDim.x) {
+        o[q] = 0;
+        if (r) {
+            r[q] = 0;
+        }
+    }
+    if (t == 0 && valid) {
+        valid[so] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (t >= 144) {
+        return;
+    }
+    int d = 0, q = 0;
+    if (ok) {
+        const uint8_t* rr = rec + ((size_t)ch * max_sym + (size_t)(s0 + t)) * 10;
+        d = ((rr[0] & 3) ^ (inverted ? 2 : 0)) & 3;
+        q = rr[1];
+    }
+    if (t < 12) {
+        if (cach24) {
+            cach24[so * 24 + c_cach_il[2 * t]] = (uint8_t)(d >> 1);
+            cach24[so * 24 + c_cach_il[2 * t + 1]] = (uint8_t)(d & 1);
+        }
+    } else if (t >= 66 && t < 90) {
+        if (sync48) {
+            sync48[so * 48 + 2 * (t - 66)] = (uint8_t)(d >> 1);
+            sync48[so * 48 + 2 * (t - 66) + 1] = (uint8_t)(d & 1);
+        }
+    } else {
+        const int f = t < 48 ? 0 : (t < 108 ? 1 : 2);
+        const int i = t < 48 ? t - 12 : (t < 66 ? t - 48 : (t < 108 ? 18 + t - 90 : t - 108));
+        ambe2450_put(o + f * 96, r ? r + f * 96 : nullptr, i, d, q);
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_ambe2450_deinterleave(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* fr, uint8_t* rl, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_ambe2450_deinterleave, dim3((unsigned)n), dim3(64), 0, st, dibits, reliab, n, fr, rl);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_nxdn_voice_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
+                          const int32_t* n_sync, int max_sync, int n_channels, uint8_t* fr, uint8_t* rl, uint8_t* valid,
+                          hipStream_t st) {
+    if (n_channels <= 0 || max_sync <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_nxdn_voice_gather, dim3((unsigned)max_sync, (unsigned)n_channels), dim3(192), 0, st, rec, counts, max_sym,
+                       sync_pos, n_sync, max_sync, fr, rl, valid);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_dmr_voice_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* burst_start, int max_bursts,
+                         int n_channels, int inverted, uint8_t* fr, uint8_t* rl, uint8_t* sync48, uint8_t* cach24,
+                         uint8_t* valid, hipStream_t st) {
+    if (n_channels <= 0 || max_bursts <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_dmr_voice_gather, dim3((unsigned)max_bursts, (unsigned)n_channels), dim3(160), 0, st, rec, counts, max_sym,
+                       burst_start, max_bursts, inverted, fr, rl, sync48, cach24, valid);
     return hipGetLastError();
 }
 

@@ -80,6 +80,29 @@ int ddn_dmr_burst_gather(const uint8_t* d_records10, const int32_t* d_counts, si
 int ddn_nxdn_frame_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols, const int32_t* d_sync_pos,
                           const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_lich, uint8_t* d_sacch_sym,
                           uint8_t* d_sacch_rel, uint8_t* d_facch_sym, uint8_t* d_facch_rel, uint8_t* d_valid, void* hip_stream);
+/* AMBE 3600x2450 voice frames ("AMBE interleave"): the 36-dibit interleave schedule the reference's DMR,
+ * NXDN and YSF voice paths share (include/dsd-neo/core/ambe_interleave.h:25-38; users dmr_bs.c:137-160, dmr_ms.c:73-77,
+ * nxdn_voice.c:57-74).  Outputs feed ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, frames, reliabilities, ...):
+ *   d_ambe_fr  u8 [..][4][24] one bit per byte (char ambe_fr[4][24]; the cells the schedule never writes are 0)
+ *   d_ambe_rel u8 [..][4][24] per-bit reliability = its dibit's (dsd_vocoder_soft_bit.reliability), or NULL
+ * ddn_ambe2450_deinterleave_batch: n frames of 36 dibits (+ optional reliabilities) that the caller has already cut out.
+ * ddn_nxdn_voice_gather: for sync k of channel c (slot c * max_syncs + k, as ddn_nxdn_frame_gather) the four voice frames
+ *   behind LICH + SACCH, de-scrambled (nxdn_frame.c:181-199, nxdn_voice.c:57-66): [slots][4][4][24]; d_valid (or NULL) = 1
+ *   when the frame's 182 dibits lie inside this call's records.  Which of the four carry voice is the LICH's business.
+ * ddn_dmr_voice_burst_gather: d_burst_start i32 [n_channels][max_bursts] = record index of a voice burst's first CACH dibit
+ *   (< 0: unused slot) -> the burst's three voice frames [slots][3][4][24] (frame 2 straddles the 24 sync / EMB dibits),
+ *   d_sync48 u8 [slots][48] sync / EMB bits, d_cach24 u8 [slots][24] de-interleaved CACH bits (TACT first) - either may be
+ *   NULL; inverted != 0 applies the MS path's dibit ^= 2 (dmr_ms.c:55-64). */
+int ddn_ambe2450_deinterleave_batch(const uint8_t* d_dibits36, const uint8_t* d_reliab36, size_t n, uint8_t* d_ambe_fr,
+                                    uint8_t* d_ambe_rel, void* hip_stream);
+int ddn_nxdn_voice_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols, const int32_t* d_sync_pos,
+                          const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_ambe_fr, uint8_t* d_ambe_rel,
+                          uint8_t* d_valid, void* hip_stream);
+int ddn_dmr_voice_burst_gather(const uint8_t* d_records10, const int32_t* d_counts, size_t max_symbols,
+                               const int32_t* d_burst_start, int n_channels, size_t max_bursts, int inverted,
+                               uint8_t* d_ambe_fr, uint8_t* d_ambe_rel, uint8_t* d_sync48, uint8_t* d_cach24, uint8_t* d_valid,
+                               void* hip_stream);
+
 /* CRC of decoded NXDN fields, rows = ddn_fec_nxdn_conv_batch output: kind 0 = SACCH (26 bits + CRC6, nxdn_deperm.c:1246-1261),
  * kind 1 = FACCH1 (80 bits + CRC12, nxdn_dcr_utils.c:21-42); kind + 2 = the same on rows of one bit per byte (what
  * ddn_fec_trellis_decode_batch writes); d_ok [n] = 1 when the field's CRC matches */

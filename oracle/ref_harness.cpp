@@ -653,3 +653,19 @@ refh_iq_read_all(const char* path, uint8_t* buf, long cap, int chunk) {
     return total;
 }
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The AMBE 3600x2450 dibit-to-frame interleave schedule shared by the DMR / NXDN / YSF voice paths
+// (include/dsd-neo/core/ambe_interleave.h:25-38), exposed entry by entry so that tools/gen_tables_ambe.py can measure it.
+#include <dsd-neo/core/ambe_interleave.h>
+extern "C" int
+refh_ambe2450_map(int i, int out4[4]) {
+    if (i < 0 || i >= DSD_AMBE_2450_DIBITS) {
+        return -1;
+    }
+    out4[0] = dsd_ambe_2450_dibit_map[i].high_row;
+    out4[1] = dsd_ambe_2450_dibit_map[i].high_col;
+    out4[2] = dsd_ambe_2450_dibit_map[i].low_row;
+    out4[3] = dsd_ambe_2450_dibit_map[i].low_col;
+    return 0;
+}

@@ -265,3 +265,58 @@ def oracle_trellis_decode(source_bits, result_len):
         row = np.ascontiguousarray(src[i])
         o.orc_trellis_decode(out[i].ctypes.data, row.ctypes.data, result_len)
     return out
+
+
+# ---- AMBE 3600x2450 voice frames (include/dsd-neo/core/ambe_interleave.h; dmr_bs.c:137-160, nxdn_voice.c:57-74) -------------
+def ambe2450_map():
+    """the generated schedule (oracle/ddn_tables_ambe.h, measured from the compiled reference): [36][4] = high row, high col,
+    low row, low col"""
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "ddn_tables_ambe.h")).read()
+    rows = re.findall(r"\{(\d+), (\d+), (\d+), (\d+)\}", txt)
+    assert len(rows) == 36
+    return np.array(rows, np.int32)
+
+
+def ambe2450_deinterleave(dibits36, rel36=None):
+    """-> (ambe_fr uint8 [4][24], reliabilities uint8 [4][24])"""
+    m = ambe2450_map()
+    fr, rl = np.zeros((4, 24), np.uint8), np.zeros((4, 24), np.uint8)
+    for i in range(36):
+        d = int(dibits36[i]) & 3
+        r = 0 if rel36 is None else int(rel36[i])
+        fr[m[i, 0], m[i, 1]], fr[m[i, 2], m[i, 3]] = d >> 1, d & 1
+        rl[m[i, 0], m[i, 1]] = rl[m[i, 2], m[i, 3]] = r
+    return fr, rl
+
+
+def nxdn_voice_frames(dibits182, rel182):
+    """the four voice frames behind LICH + SACCH of one NXDN frame (de-scrambled) -> ([4][4][24], [4][4][24])"""
+    d = np.asarray(dibits182, np.uint8) ^ (nxdn_pn9() << 1)
+    out = [ambe2450_deinterleave(d[38 + 36 * v:74 + 36 * v], np.asarray(rel182)[38 + 36 * v:74 + 36 * v]) for v in range(4)]
+    return np.stack([o[0] for o in out]), np.stack([o[1] for o in out])
+
+
+def nxdn_lich_voice(lich7):
+    """which voice frames a LICH announces (nxdn_frame.c:117-150): 3 = all four, 1 = the first two, 2 = the last two, 0 none"""
+    if lich7 in (0x36, 0x37, 0x56, 0x57, 0x46, 0x76, 0x77):
+        return 3
+    if lich7 in (0x34, 0x35, 0x54, 0x55, 0x75):
+        return 1
+    if lich7 in (0x32, 0x33, 0x52, 0x53, 0x72, 0x73):
+        return 2
+    return 0
+
+
+def dmr_voice_burst_fields(dibits144, rel144, inverted):
+    """-> (ambe_fr [3][4][24], reliabilities [3][4][24], sync / EMB bits [48], cach bits [24]) of one voice burst"""
+    d = np.array([(int(x) ^ (2 if inverted else 0)) & 3 for x in dibits144], np.uint8)
+    r = np.asarray(rel144, np.uint8)
+    f1 = ambe2450_deinterleave(d[12:48], r[12:48])
+    f2 = ambe2450_deinterleave(np.concatenate([d[48:66], d[90:108]]), np.concatenate([r[48:66], r[90:108]]))
+    f3 = ambe2450_deinterleave(d[108:144], r[108:144])
+    sync = np.stack([d[66:90] >> 1, d[66:90] & 1], 1).reshape(-1)
+    cach = np.zeros(24, np.uint8)
+    for i in range(12):
+        cach[CACH_IL[2 * i]], cach[CACH_IL[2 * i + 1]] = d[i] >> 1, d[i] & 1
+    return np.stack([f1[0], f2[0], f3[0]]), np.stack([f1[1], f2[1], f3[1]]), sync, cach
