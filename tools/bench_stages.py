@@ -222,6 +222,31 @@ def main():
             orc.oracle_imbe_deinterleave(d80, z80, z80, 7)
     report("imbe_deinterleave", nf, ms, 72 * 10 + 184 * 3, cpu(cpu_imbe, 2000), "voice frames")
 
+    # P25 Phase 2 RS(63,35) FACCH sections with erasures: 9 punctured parity symbols erased + 4 errors + 2 more erasures
+    import rs28
+    nrs = 32768
+    cases = [rs28.make_case(rng, 1, 4, 2, 1) for _ in range(512)]
+    pl = np.tile(np.stack([c[0] for c in cases]).astype(np.uint8), (nrs // 512, 1))
+    pa = np.tile(np.stack([c[1] for c in cases]).astype(np.uint8), (nrs // 512, 1))
+    er = np.zeros((512, 28), np.int8)
+    ne = np.zeros(512, np.uint8)
+    for i, c in enumerate(cases):
+        er[i, :c[2].size], ne[i] = c[2], c[2].size
+    d_pl0, d_pa = torch.from_numpy(pl).cuda(), torch.from_numpy(pa).cuda()
+    d_er, d_ne = torch.from_numpy(np.tile(er, (nrs // 512, 1))).cuda(), torch.from_numpy(np.tile(ne, nrs // 512)).cuda()
+    d_pl, d_st = d_pl0.clone(), torch.zeros(nrs, dtype=torch.int32, device="cuda")
+
+    def run_rs28():
+        d_pl.copy_(d_pl0)
+        l.ddn_fec_rs28_batch(1, d_pl.data_ptr(), d_pa.data_ptr(), d_er.data_ptr(), d_ne.data_ptr(), nrs, d_st.data_ptr(), st)
+    ms = timeit(run_rs28)
+    assert int((d_st > 0).sum()) == nrs
+
+    def cpu_rs28():
+        for c in cases:
+            rs28.oracle_rs28(1, c[0], c[1], c[2])
+    report("p25p2_rs28_facch", nrs, ms, 45 * 6 + 28 + 4, cpu(cpu_rs28, 512), "sections")
+
 
 if __name__ == "__main__":
     main()
