@@ -6,6 +6,7 @@ without leaving the device.
 Plumbing only (ctypes calls + torch allocations) - what a host application's batch scheduler would do around
 libdsdneo_hip.so; used by bench.py and the end-to-end tests.  Every stage is a library call on the caller's stream."""
 import ctypes as C
+import os
 
 import ddn
 
@@ -16,7 +17,7 @@ class P25Chain:
         self.torch, self.l, self.B, self.n = torch, l, B, n
         dev = "cuda"
         self.fe = ddn.Batch(B, block_len=block_len)
-        self.rx = ddn.P25Rx(B, lock_symbols=840, use_matched_filter=1)
+        self.rx = ddn.P25Rx(B, lock_symbols=840, use_matched_filter=1, channels_per_wave=int(os.environ.get("DDN_RX_CPW", "0")))
         if lock_symbols is not None:
             import numpy as np
             ls = np.ascontiguousarray(lock_symbols, np.int32)

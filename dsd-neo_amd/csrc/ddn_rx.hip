@@ -1755,8 +1755,10 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
     }
     int cpw = channels_per_wave;
     if (cpw != 8 && cpw != 16 && cpw != 32 && cpw != 64) {
-        // fewest lanes per wavefront that still gives every CU (256) no more than ~2 workgroups
-        cpw = n_channels <= 16 * 512 ? 16 : (n_channels <= 32 * 512 ? 32 : 64);
+        // fewest lanes per wavefront that still gives every CU (256) no more than ~2 workgroups: a trip is only a lean trip
+        // when every lane of the wave is in the lean state, so fewer lanes per wave means fewer mixed trips (measured on the
+        // bench traffic at 4096 channels: 6.07 ms with 8 lanes per wave, 6.39 ms with 16)
+        cpw = n_channels <= 8 * 512 ? 8 : (n_channels <= 16 * 512 ? 16 : (n_channels <= 32 * 512 ? 32 : 64));
     }
     // CPW 16 / 32 run the windowed variant (k_p25_rxw); 64 lanes per wavefront keeps the two-tile kernel, whose LDS
     // footprint still fits (cfg.dbg bit 128 forces it for A/B timing)
