@@ -207,6 +207,8 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const int whole0 = cfg.out_rate / cfg.sym_rate, rem0 = cfg.out_rate % cfg.sym_rate;
     const int whole = whole0 < 2 ? 2 : (whole0 > 64 ? 64 : whole0);
     const int rem = (whole0 < 2 || whole0 > 64) ? 0 : rem0;
+    // the lean in-frame trip: fixed symbol length of ordinary size (the 5-sample symbol has its own accumulation rule)
+    const bool lean_ok = rem == 0 && whole >= 6 && whole <= MAXW && !(cfg.dbg & 1024);
     const uint32_t wmask = cfg.win_len >= 24 ? 0xFFFFFFu : ((1u << cfg.win_len) - 1u);
     int o = 0, ns = 0;
     const long long abs0 = s.n_abs;
@@ -334,6 +336,74 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
             };
             while (true) {
+                // ---- lean trip -----------------------------------------------------------------------------------------
+                // Every live lane sits inside a frame with its crossing latched, a whole fresh symbol of the fixed length
+                // staged, the matched filter warm and more than one symbol of the lock left (or has used up its tile): inside a
+                // frame these protocols leave the thresholds alone (use_symbol()'s "no continuous update" branch,
+                // dsd_dibit.c:264-276), the crossing search is off and nothing reads the last sample before the frame ends, so
+                // the symbol is the clipped window sum over its count, pushed to the history ring and the queue - none of the
+                // per-sample pass, the start-up or the hunting commit below is on the wave's instruction stream.
+                if (lean_ok) {
+                    const bool fo_l = s.filter_on != 0;
+                    const bool lean = live & (s.in_symbol == 0) & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1)
+                                      & (s.need_reset == 0) & (pos < tile_end) & (pos + whole <= lim) & (qk < QCAP - 2)
+                                      & (!fo_l | ((abs0 + pos - s.filt_start) >= (long long)(NT - 1)));
+                    const bool idle = live & (s.in_symbol == 0) & !(pos < tile_end);
+                    if (!__any(live & !(lean | idle)) && __any(lean)) {
+                        if (lean) {
+                            const float* rowl = fo_l ? frow : rrow;
+                            const int cw = (whole - 1) / 2;
+                            const int l_e = (Cfg::dmr_window && s.lastsync != 0) ? 1 : 2;
+                            const bool rf0l = cfg.rf_mod == 0;
+                            const int wlo = rf0l ? cw - l_e : cw - 1, whi = rf0l ? cw + 2 : cw + 1;
+                            const bool has20 = whole == 20;
+                            const int i_lo = has20 && 7 < wlo ? 7 : wlo, i_hi = has20 && 13 > whi ? 13 : whi;
+                            float sum = 0.0f;
+                            int c = 0;
+                            // (at most 8 samples: 7..13 of a 20-sample symbol, or the window of 2..5)
+#pragma unroll
+                            for (int k = 0; k < 8; k++) {
+                                const int i = i_lo + k;
+                                if (i <= i_hi) {
+                                    float x = rowl[(pos + i) & RMASK];
+                                    if (rf0l) { // the sync-time clip (C4FM rules only)
+                                        x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                                    }
+                                    const bool k1 = rf0l ? (i >= wlo && i <= whi) : (i == wlo || i == whi);
+                                    const bool k2 = has20 && i >= 7 && i <= 13;
+                                    if (k2) {
+                                        sum += x;
+                                    }
+                                    if (k1) {
+                                        sum += x;
+                                    }
+                                    c += (k1 ? 1 : 0) + (k2 ? 1 : 0);
+                                }
+                            }
+                            const float sym = (c > 0) ? (sum / (float)c) : 0.0f;
+                            pos += whole;
+                            const int slot = s.shead;
+                            L.sh[slot][ln] = sym;
+                            s.shead = (s.shead + 1 >= HN) ? 0 : s.shead + 1;
+                            s.scount = s.scount < HN ? s.scount + 1 : HN;
+                            const int neg = (cfg.dbg & 32) ? 0 : ((L.pat_meta[s.cur_pat] >> 8) & 1);
+                            const int qb = t & 1;
+                            L.q[qb][qk][0][ln] = sym;
+                            L.q[qb][qk][1][ln] = s.center;
+                            L.q[qb][qk][2][ln] = s.umid;
+                            L.q[qb][qk][3][ln] = s.lmid;
+                            L.q[qb][qk][4][ln] = s.max;
+                            L.q[qb][qk][5][ln] = s.min;
+                            L.q[qb][qk][6][ln] = __int_as_float((1 | (neg ? 4 : 0)) | (slot << 8));
+                            qk++;
+                            s.maxref = s.max;
+                            s.minref = s.min;
+                            s.lock_left--;
+                            o++;
+                        }
+                        continue;
+                    }
+                }
                 bool began = false;
                 if (live && pos < tile_end && !s.in_symbol) {
                     began = true;
