@@ -202,9 +202,10 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         b->cfg.lock_symbols[k] = all_zero ? lock_default[k] : cfg->lock_symbols[k];
     }
     const size_t B = (size_t)cfg->n_channels;
-    // fewer channels per wavefront = fewer unsynchronised recurrences sharing one instruction stream; spread a batch over
-    // at least ~512 workgroups (two per CU) before packing more channels into a wavefront
-    b->channels_per_wave = B <= 2048 ? 4 : (B <= 4096 ? 8 : (B <= 8192 ? 16 : 32));
+    // fewer channels per wavefront = fewer unsynchronised recurrences sharing one instruction stream, and a trip is only a
+    // lean trip when every lane of the wave is inside a frame (measured at 4096 DMR channels: 11.8 ms with 4 lanes per wave,
+    // 13.6 with 8, 16.7 with 16); two-wave workgroups, so 4096 channels at 4 per wave are eight wavefronts per CU
+    b->channels_per_wave = B <= 4096 ? 4 : (B <= 8192 ? 8 : (B <= 16384 ? 16 : 32));
     if (const char* e = getenv("DDN_RX4_CPW")) {
         b->channels_per_wave = atoi(e);
     }
