@@ -338,14 +338,14 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
             while (true) {
                 // ---- lean trip -----------------------------------------------------------------------------------------
                 // Every live lane sits inside a frame with its crossing latched, a whole fresh symbol of the fixed length
-                // staged, the matched filter warm and more than one symbol of the lock left (or has used up its tile): inside a
+                // staged and the matched filter warm (or has used up its tile): inside a
                 // frame these protocols leave the thresholds alone (use_symbol()'s "no continuous update" branch,
-                // dsd_dibit.c:264-276), the crossing search is off and nothing reads the last sample before the frame ends, so
+                // dsd_dibit.c:264-276), the crossing search is off and nothing reads the last sample before the frame's last symbol, so
                 // the symbol is the clipped window sum over its count, pushed to the history ring and the queue - none of the
                 // per-sample pass, the start-up or the hunting commit below is on the wave's instruction stream.
                 if (lean_ok) {
                     const bool fo_l = s.filter_on != 0;
-                    const bool lean = live & (s.in_symbol == 0) & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1)
+                    const bool lean = live & (s.in_symbol == 0) & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left >= 1)
                                       & (s.need_reset == 0) & (pos < tile_end) & (pos + whole <= lim) & (qk < QCAP - 2)
                                       & (!fo_l | ((abs0 + pos - s.filt_start) >= (long long)(NT - 1)));
                     const bool idle = live & (s.in_symbol == 0) & !(pos < tile_end);
@@ -381,6 +381,13 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 }
                             }
                             const float sym = (c > 0) ? (sum / (float)c) : 0.0f;
+                            if (s.lock_left == 1) { // the frame's last symbol: the hunt that follows starts from its last sample
+                                float x = rowl[(pos + whole - 1) & RMASK];
+                                if (rf0l) {
+                                    x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                                }
+                                s.lastsample = x;
+                            }
                             pos += whole;
                             const int slot = s.shead;
                             L.sh[slot][ln] = sym;
@@ -398,7 +405,9 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             qk++;
                             s.maxref = s.max;
                             s.minref = s.min;
-                            s.lock_left--;
+                            if (--s.lock_left <= 0) {
+                                hunt_restart(s);
+                            }
                             o++;
                         }
                         continue;
