@@ -1,6 +1,8 @@
 """BASELINE configs[3]'s other two protocols wired through the C-ABI: B DMR or NXDN48 channels, cu8 I/Q in HBM -> front end
 (12.5 kHz / 6.25 kHz channel filter) -> matched filter + receive loop (ddn_fsk4_rx_run) -> for DMR: burst gather -> slot-type
-Golay(20,8) -> BPTC(196,96), without leaving the device.  Plumbing only (ctypes calls + torch allocations), like ddn_chain.py."""
+Golay(20,8) -> BPTC(196,96); for NXDN48: frame gather -> SACCH / FACCH1 decode + CRC, and the four voice frames of every frame
+through AMBE de-interleave -> AMBE 3600x2450 frame FEC -> synthesis (frames the LICH does not announce as voice are muted),
+without leaving the device.  Plumbing only (ctypes calls + torch allocations), like ddn_chain.py."""
 import ctypes as C
 
 import ddn
@@ -35,6 +37,18 @@ class Fsk4Chain:
             self.sacch, self.sacch_ok = z((S, 4), u8), z((S,), u8)
             self.sacch_hard, self.sacch_hard_ok = z((S, 32), u8), z((S,), u8)
             self.facch, self.facch_ok = z((S * 2, 12), u8), z((S * 2,), u8)
+            # voice: four AMBE frames per NXDN frame, one talk path per channel.  With the default handler length (182 symbols
+            # after the sync word) two syncs are at least a 192-symbol frame apart, so a call holds n / (192 * 20) + 2 frames at
+            # most - far fewer than the sync capacity the loop is sized for; the voice stage works on that many slots per channel
+            self.vf = my if lock is not None else min(my, n // (192 * 20) + 2)
+            V = B * self.vf
+            self.v_spos, self.v_ns = z((B, self.vf), i32), z((B,), i32)
+            self.ambe_fr, self.ambe_rel = z((V, 4, 4, 24), u8), z((V, 4, 4, 24), u8)
+            self.ambe_d, self.ambe_res = z((V * 4, 49), u8), z((V * 4, 5), i32)
+            self.voice_skip = z((V * 4,), u8)
+            self.pcm, self.res_out = z((B, self.vf * 4, 160), f32), z((V * 4, 5), i32)
+            self.mbe = C.c_void_p()
+            assert l.ddn_mbe_batch_create(ddn.MBE_AMBE, B, C.byref(self.mbe)) == 0
 
     def front_end(self, d_iq, st):
         self.fe.run_device(d_iq.data_ptr(), self.n, self.disc.data_ptr(), st)
@@ -58,6 +72,25 @@ class Fsk4Chain:
             assert l.ddn_nxdn_crc_check_batch(p(self.sacch_hard), 32, S, 2, p(self.sacch_hard_ok), st) == 0
             assert l.ddn_fec_nxdn_conv_batch(p(self.fs), p(self.fr), S * 2, 96, 92, None, p(self.facch), 12, st) == 0
             assert l.ddn_nxdn_crc_check_batch(p(self.facch), 12, S * 2, 1, p(self.facch_ok), st) == 0
+            # voice (nxdn_voice(): the LICH's profile says which of the four 36-dibit frames are voice), on the first vf sync
+            # slots of every channel (torch ops: the caller keeps torch's current stream == st, as bench.py does)
+            vf, V = self.vf, self.B * self.vf
+            self.v_spos.copy_(self.spos[:, :vf])
+            self.v_ns.copy_(self.torch.clamp(self.ns, max=vf))
+            assert l.ddn_nxdn_voice_gather(p(self.rec), p(self.cnt), self.ms, p(self.v_spos), p(self.v_ns), self.B, vf,
+                                           p(self.ambe_fr), p(self.ambe_rel), None, st) == 0
+            assert l.ddn_mbe_frame_decode_batch(ddn.MBE_AMBE, p(self.ambe_fr), p(self.ambe_rel), V * 4, p(self.ambe_d),
+                                                p(self.ambe_res), st) == 0
+            lich = self.lich.view(self.B, self.my)[:, :vf].reshape(V, 1)
+            l7, good = lich & 0x7F, ((lich & 0x80) != 0) & (self.valid.view(self.B, self.my)[:, :vf].reshape(V, 1) != 0)
+            both = (l7 == 0x36) | (l7 == 0x37) | (l7 == 0x56) | (l7 == 0x57) | (l7 == 0x46) | (l7 == 0x76) | (l7 == 0x77)
+            first = (l7 == 0x34) | (l7 == 0x35) | (l7 == 0x54) | (l7 == 0x55) | (l7 == 0x75)
+            last = (l7 == 0x32) | (l7 == 0x33) | (l7 == 0x52) | (l7 == 0x53) | (l7 == 0x72) | (l7 == 0x73)
+            v = self.torch.arange(4, device=lich.device).view(1, 4)
+            voiced = good & (both | (first & (v < 2)) | (last & (v >= 2)))
+            self.voice_skip.copy_((~voiced).to(self.torch.uint8).view(-1))
+            assert l.ddn_mbe_result_skip_batch(p(self.voice_skip), V * 4, p(self.ambe_res), st) == 0
+            assert l.ddn_mbe_synth_batch(self.mbe, p(self.ambe_d), p(self.ambe_res), vf * 4, p(self.pcm), p(self.res_out), st) == 0
             return
         assert l.ddn_dmr_burst_gather(p(self.rec), p(self.cnt), self.ms, p(self.spos), p(self.pre), p(self.ns), self.B, self.my,
                                       self.inverted, p(self.st), p(self.info), p(self.cach), p(self.valid), st) == 0

@@ -152,3 +152,26 @@ def test_nxdn48_capture_voice_frames_decode_clean(built):
     torch.cuda.synchronize()
     w = pcm.cpu().numpy().reshape(-1)
     assert np.isfinite(w).all() and np.abs(w).max() > 0 and np.mean(np.abs(w) > 1e-3) > 0.3
+
+
+def test_nxdn_chain_voice_stage_on_the_capture(built):
+    """Fsk4Chain (bindings/ddn_chain_fsk4.py) on the NXDN48 capture from cu8 I/Q: the voice stage mutes the frames the LICH
+    does not announce, the announced ones decode with few corrections and the talk path's PCM is audio."""
+    import torch
+    import ddn_chain_fsk4
+    from conftest import golden
+    g = golden("iq_nxdn48.npz")
+    iq = np.ascontiguousarray(g["iq"], np.uint8).reshape(1, -1, 2)
+    n = iq.shape[1]
+    ch = ddn_chain_fsk4.Fsk4Chain(torch, 1, n, ddn.FSK4_NXDN48)
+    ch.run(torch.from_numpy(iq).cuda())
+    torch.cuda.synchronize()
+    skip = ch.voice_skip.cpu().numpy().astype(bool)
+    res = ch.ambe_res.cpu().numpy()
+    assert (~skip).sum() >= 100
+    tot = res[~skip, 3]
+    assert np.mean(tot <= 2) > 0.9
+    assert np.all(res[skip, 0].view(np.uint32) & 0x80000000)          # muted rows carry the skip flag
+    assert int(ch.ns.cpu().numpy()[0]) <= ch.vf                      # the voice stage's slot bound holds on real traffic
+    pcm = ch.pcm.cpu().numpy().reshape(-1, 160)
+    assert np.isfinite(pcm).all() and np.abs(pcm[~skip]).max() > 0 and not pcm[skip].any()
