@@ -509,7 +509,7 @@ def configs3_mixed(torch, ddn, np, p25_chain, d_iq_p25, B_total, n, steps):
     out = {"workload": "configs[3] shape on one GPU: %d channels = %d P25 Phase 1 + %d DMR (Tier III control channel capture, GFSK rules) + "
                        "%d NXDN48 (capture), %d cu8 samples each; per protocol front end -> matched filter -> receive loop -> frame FEC "
                        "(DMR: burst gather + Golay(20,8) + BPTC(196,96); NXDN48: frame gather + SACCH / FACCH1 K=5 decode + CRC + "
-                       "greedy retry)" % (B_total, Bp, Bd, Bn, n),
+                       "greedy retry, and the voice frames the LICHs announce through AMBE de-interleave + frame FEC + synthesis)" % (B_total, Bp, Bd, Bn, n),
            "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(B_total * n / dt / 1e6, 1),
            "streams": "one HIP stream per protocol group (independent channel sets)",
            "chain_ms_alone": {"p25p1": round(float(ms[0]), 3), "dmr": round(float(ms[1]), 3), "nxdn48": round(float(ms[2]), 3)},
