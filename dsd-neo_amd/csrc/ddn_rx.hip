@@ -649,11 +649,8 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
 //    barrier.  Same multiset statistics as the reference's rescan of the 128 values (src/core/frames/dsd_dibit.c:194-241);
 //  * the queue to wave 1 carries {symbol, max, min, flags}; centre / mid thresholds are recomputed there with the
 //    reference's expressions.
-constexpr int RT = 3 * TS;
-constexpr int QT = 20;  // queue slots = trips of a tile that can hand a symbol to wave 1 (later trips store directly)
 constexpr int WMAX = 24;
 
-constexpr int WM = 32; // suffix summaries kept per checkpoint (pushes per two tiles: 2 * (ceil((TS + sps) / (sps - 1)) + 1) <= 30 for sps >= 6)
 
 // 1: per-wave cycle counters (tile body / barrier wait / trips by kind) written over the tail of each workgroup's first
 // record area when cfg.dbg bit 8192 is set - timing experiments only (tools/scratch/rx_cyc.py)
@@ -663,17 +660,21 @@ constexpr int WM = 32; // suffix summaries kept per checkpoint (pushes per two t
 
 template <int CPW>
 struct LdsW {
+    // tile shape: 128-sample tiles where the rows fit (half the tile prologues / closing trips), 64 at 32 lanes per wave
+    static constexpr int TW = CPW <= 16 ? 128 : 64, RTW = 3 * TW;
+    static constexpr int WMW = CPW <= 16 ? 64 : 32; // suffix summaries per checkpoint: pushes per two tiles, 2 * (ceil((TW + sps) / (sps - 1)) + 1)
+    static constexpr int QTW = CPW <= 16 ? 40 : 20; // queue slots = trips of a tile that can hand a symbol to wave 1
     float sb[SS][CPW];
     float lb[24][CPW];
     float sh[24][CPW];
-    // a row = [mirror of slot 2 | slot 0 | slot 1 | slot 2] + pad: sample j (-TS <= j < TS + 12) of the tile in slot b
-    // is row[TS + b * TS + j] with no wrap test (slot 2 precedes slot 0 in the ring)
-    float raw[CPW][RT + TS + 13];
-    float flt[CPW][RT + TS + 13];
-    alignas(16) float q[2][QT][CPW][4]; // [tile parity][trip][lane] = {symbol, max, min, flags | output index << 8}
+    // a row = [mirror of slot 2 | slot 0 | slot 1 | slot 2] + pad: sample j (-TW <= j < TW + 12) of the tile in slot b
+    // is row[TW + b * TW + j] with no wrap test (slot 2 precedes slot 0 in the ring)
+    float raw[CPW][RTW + TW + 13];
+    float flt[CPW][RTW + TW + 13];
+    alignas(16) float q[2][QTW][CPW][4]; // [tile parity][trip][lane] = {symbol, max, min, flags | output index << 8}
     int qn[2];                          // trips of that tile
     int qo[2][CPW];                     // output index of the lane's first symbol of that tile
-    alignas(16) float sfx[2][WM][CPW][4]; // [checkpoint parity][m - 1][lane] = {min1, min2, max1, max2} of ring entries m+1..128
+    alignas(16) float sfx[2][WMW][CPW][4]; // [checkpoint parity][m - 1][lane] = {min1, min2, max1, max2} of ring entries m+1..128
     int sidx0[2][CPW];        // [tile parity] ring slot of the oldest entry at the start of that tile
 };
 
@@ -685,6 +686,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
           float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
           float* __restrict__ maxring, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags,
           int32_t* __restrict__ counts, size_t max_sym, const int32_t* __restrict__ lock_cfg) {
+    constexpr int TW = LdsW<CPW>::TW, RTW = LdsW<CPW>::RTW, WMW = LdsW<CPW>::WMW, QTW = LdsW<CPW>::QTW;
+    (void)RTW;
     extern __shared__ unsigned char smem_raw[];
     LdsW<CPW>& L = *reinterpret_cast<LdsW<CPW>*>(smem_raw);
     const int lane = threadIdx.x & 63;
@@ -720,26 +723,30 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         L.sidx0[0][ln] = s.sidx;
     }
     auto stage = [&](long t0, int slot) {
-        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
         constexpr int RPP = CPW < 16 ? CPW : 16; // rows in flight per pass
 #pragma unroll
-        for (int h = 0; h < CPW / RPP; h++) {
-            float r[RPP], f[RPP];
+        for (int half = 0; half < TW / 64; half++) { // 64 samples of a row per pass
+            const int j = lane + 64 * half;          // sample of the tile
 #pragma unroll
-            for (int c = 0; c < RPP; c++) {
-                const int cc = RPP * h + c;
-                const bool ok = (ch0 + cc < n_channels) && lane < tn;
-                const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + lane;
-                r[c] = ok ? raw[off] : 0.0f;
-                f[c] = (ok && use_flt) ? filt[off] : 0.0f;
-            }
+            for (int h = 0; h < CPW / RPP; h++) {
+                float r[RPP], f[RPP];
 #pragma unroll
-            for (int c = 0; c < RPP; c++) {
-                L.raw[RPP * h + c][TS + slot * TS + lane] = r[c];
-                L.flt[RPP * h + c][TS + slot * TS + lane] = f[c];
-                if (slot == 2) {
-                    L.raw[RPP * h + c][lane] = r[c];
-                    L.flt[RPP * h + c][lane] = f[c];
+                for (int c = 0; c < RPP; c++) {
+                    const int cc = RPP * h + c;
+                    const bool ok = (ch0 + cc < n_channels) && j < tn;
+                    const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + j;
+                    r[c] = ok ? raw[off] : 0.0f;
+                    f[c] = (ok && use_flt) ? filt[off] : 0.0f;
+                }
+#pragma unroll
+                for (int c = 0; c < RPP; c++) {
+                    L.raw[RPP * h + c][TW + slot * TW + j] = r[c];
+                    L.flt[RPP * h + c][TW + slot * TW + j] = f[c];
+                    if (slot == 2) {
+                        L.raw[RPP * h + c][j] = r[c];
+                        L.flt[RPP * h + c][j] = f[c];
+                    }
                 }
             }
         }
@@ -752,8 +759,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const int whole = whole0 < 2 ? 2 : (whole0 > 64 ? 64 : whole0);
     const int rem = (whole0 < 2 || whole0 > 64) ? 0 : rem0;
     // most symbols two consecutive tiles can push (every symbol consumes at least sps - 1 samples)
-    const int mn_raw = 2 * ((TS + whole + whole - 2) / (whole > 1 ? whole - 1 : 1) + 1);
-    const int Mn = mn_raw > WM ? WM : mn_raw;
+    const int mn_raw = 2 * ((TW + whole + whole - 2) / (whole > 1 ? whole - 1 : 1) + 1);
+    const int Mn = mn_raw > WMW ? WMW : mn_raw;
     // wave 2: S_m for m = Mn .. 1 from the ring as it stands at L.sidx0 (entries being overwritten meanwhile are the
     // oldest ones, which only feed summaries nobody will ask for)
     auto compute_sfx = [&](int buf, int tile_parity) {
@@ -827,7 +834,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         const int cnt = L.qn[qb], o0 = L.qo[qb][dc];
         uint8_t* drp = rec + (size_t)dch * max_sym * 10;
         uint8_t* dfp = flags + (size_t)dch * max_sym;
-        for (int k = de; k < QT; k += EPL) {
+        for (int k = de; k < QTW; k += EPL) {
             if (k >= cnt) {
                 break;
             }
@@ -867,7 +874,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         npc++;
         if (global) {
             int m = npp + npc; // ring entries replaced since the checkpoint
-            m = m > WM ? WM : m;
+            m = m > WMW ? WMW : m;
             const float4 sv = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
             const float s1 = sv.x, s2 = sv.y, s3 = sv.z, s4 = sv.w;
             // two smallest of three sorted pairs, two largest likewise (values are finite: min / max pick the same multiset)
@@ -1103,7 +1110,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
     };
     auto emit = [&](float sym, int fl, float q_max, float q_min) {
-    if (offload && tk <= QT) {
+    if (offload && tk <= QTW) {
         qv = make_float4(sym, q_max, q_min, __int_as_float(fl | ((o - o_tile) << 8)));
     } else if ((size_t)o < max_sym) {
         int dibit, relb = 0, l0 = 0, l1 = 0;
@@ -1122,13 +1129,13 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
 
     long long dbg_busy = 0, dbg_wait = 0, dbg_cyc[3] = {0, 0, 0}, dbg_prev = 0;
     int dbg_n[3] = {0, 0, 0}, dbg_kind = -1;
-    for (t0 = 0; t0 < n; t0 += TS, it++) {
+    for (t0 = 0; t0 < n; t0 += TW, it++) {
         const long long dbg_t0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
-        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
-        const bool more = (t0 + TS) < n;
+        const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
+        const bool more = (t0 + TW) < n;
         if (loader) {
             if (more) {
-                stage(t0 + TS, (it + 1) % 3);
+                stage(t0 + TW, (it + 1) % 3);
             }
             if (offload && it > 0 && !(cfg.dbg & 512)) {
                 drain((it - 1) & 1);
@@ -1138,7 +1145,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 compute_sfx(it & 1, it & 1);
             }
         } else {
-            const int base = TS + (it % 3) * TS;
+            const int base = TW + (it % 3) * TW;
             auto rd = [&](const float* row, int j) { return row[base + j]; };
             // tile-relative sample index from which the matched filter's output is usable (INT_MIN: filter off or warm)
             auto cold_limit = [&]() {
@@ -1171,7 +1178,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             float4 psf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             while (true) {
                 // hand the previous trip's symbols (one per lane at most) to wave 1: one 16-byte LDS write at a wave-uniform slot
-                if (offload && tk > 0 && tk <= QT && lane < CPW) {
+                if (offload && tk > 0 && tk <= QTW && lane < CPW) {
                     *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
                 }
                 qv.w = __int_as_float(-1);
@@ -1200,7 +1207,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 // push, extrema rings, thresholds, queue entry.  Its LDS operands were fetched by the previous lean trip, which
                 // takes the two LDS round trips off the recurrence.
                 bool all_lean_wait = false;
-                if (lean_ok && tk <= QT) {
+                if (lean_ok && tk <= QTW) {
                     // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
                     const bool lean_state = live & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
                                             & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0))) & (s.min < s.max);
@@ -1215,7 +1222,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
                                 px0 = pw[0], px1 = pw[1], px2 = pw[2], px3 = pw[3], px4 = pw[4];
                                 int m = npp + npc + 1;
-                                m = m > WM ? WM : m;
+                                m = m > WMW ? WMW : m;
                                 psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
                             }
                         }
@@ -1273,7 +1280,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
                             px0 = pw[0], px1 = pw[1], px2 = pw[2], px3 = pw[3], px4 = pw[4];
                             int m = npp + npc + 1;
-                            m = m > WM ? WM : m;
+                            m = m > WMW ? WMW : m;
                             psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
                         }
                         continue;
@@ -1402,7 +1409,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const int done_snap = 0;
                 const bool glive = live && !gblocked;
                 const bool gneed = glive && (sp < tn || s.in_symbol);
-                if (all_std_wait || !__any(gneed && (sp < tn)) || ++guard > 4 * TS) {
+                if (all_std_wait || !__any(gneed && (sp < tn)) || ++guard > 4 * TW) {
                     break;
                 }
                 if (!__any(gneed)) {
@@ -1581,7 +1588,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     float v;
                                     if (abs0 + j < s.filt_start) { // the filter's memory as the last hunt left it (zeros at first)
                                         v = fstale[(size_t)ch * (NT - 1) + (size_t)((abs0 + j - s.filt_start) + (NT - 1))];
-                                    } else if (jr >= (it > 0 ? -TS : 0)) { // the ring has no previous tile on a call's first
+                                    } else if (jr >= (it > 0 ? -TW : 0)) { // the ring has no previous tile on a call's first
                                         v = rd(rrow, jr);
                                     } else {
                                         v = (j >= 0) ? raw[(size_t)ch * stride + j]
@@ -1642,11 +1649,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 dbg_kind = -1;
             }
             if (offload && lane == 0) {
-                L.qn[it & 1] = (tk - 1) < QT ? (tk - 1) : QT; // trips that may have queued (the last one broke out at its top)
+                L.qn[it & 1] = (tk - 1) < QTW ? (tk - 1) : QTW; // trips that may have queued (the last one broke out at its top)
             }
             if (live) {
                 L.sidx0[(it + 1) & 1][ln] = s.sidx;
-                sp -= TS;
+                sp -= TW;
             }
         }
         if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
