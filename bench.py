@@ -384,7 +384,7 @@ def main():
                          # HBM bytes per launch of k_p25_rxw from separate rocprofv3 --pmc passes of this command on this shape
                          # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B;
                          # profiles/r02_pmc_*.txt): the discriminator stream is read twice (raw + matched-filter output)
-                         "traffic": 2.044e9 if (B == B_PER_GPU and n == N_SAMPLES) else None,
+                         "traffic": 2.059e9 if (B == B_PER_GPU and n == N_SAMPLES) else None,
                          "algorithmic_bytes": alg_bytes, "bytes_per_sample": round(alg_bytes / (B * n), 3),
                          "launch_ms": round(dom_ms, 4), "launches_averaged": int(rx_timed_n.value),
                          "launch_ms_alone": round(float(rx_ms[1]), 4),   # the same kernel with nothing else on the device
