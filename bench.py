@@ -132,6 +132,15 @@ def cpu_baseline(voice, ctrl, n, Fv):
             "all_cores": all_cores}
 
 
+def _pipelined_call(chain, streams):
+    """three streams: front end | loop | decode; two streams: front end + loop | decode, the decode of step k held back until
+    the front end of step k + 1 has run when DDN_BENCH_DEFER=1 (measured no better: 9.6 vs 9.4 ms per step), by default started as
+    soon as the loop of step k is done"""
+    if len(streams) == 3:
+        return chain.run_pipelined3
+    return chain.run_pipelined_deferred if int(os.environ.get("DDN_BENCH_DEFER", "0")) else chain.run_pipelined
+
+
 def parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n, streams=None):
     """Before any timing: a sample of this rank's channels, first call of a fresh stream, against the chain of CPU oracles -
     dibit records, NIDs, decoded voice parameter bits and PCM all bit-exact."""
@@ -140,7 +149,9 @@ def parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n, streams=None):
     import orc
     torch.cuda.synchronize()
     if streams:
-        (chain.run_pipelined3 if len(streams) == 3 else chain.run_pipelined)(d_iq, *streams)      # the same call sequence the timed loop makes
+        _pipelined_call(chain, streams)(d_iq, *streams)      # the same call sequence the timed loop makes
+        if len(streams) == 2:
+            chain.flush(*streams)
     else:
         chain.run(d_iq)
     torch.cuda.synchronize()
@@ -266,7 +277,7 @@ def main():
 
     def step():
         if streams:
-            (chain.run_pipelined3 if len(streams) == 3 else chain.run_pipelined)(d_iq, *streams)
+            _pipelined_call(chain, streams)(d_iq, *streams)
         else:
             chain.run(d_iq, st)
 
@@ -274,8 +285,13 @@ def main():
     if not parity["bit_exact"] and not os.environ.get("DDN_BENCH_NOPARITY"):
         raise SystemExit("parity gate failed: %s" % json.dumps(parity))
 
+    def flush():
+        if streams and len(streams) == 2:
+            chain.flush(*streams)
+
     for _ in range(args.warmup):
         step()
+    flush()
     barrier()
     # HIP events around the dominant kernel on its own stream, recorded inside the C-ABI for every launch of the timed loop
     # (no synchronisation between launches; read back after the closing barrier)
@@ -283,7 +299,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()          # torch.cuda.synchronize(): every stream, i.e. the last step's FEC / voice stages are inside the timed region
+    flush()            # the last step's FEC / voice stages are queued ...
+    barrier()          # ... and inside the timed region: torch.cuda.synchronize() covers every stream
     dt = time.perf_counter() - t0
     rx_timed = np.zeros(2, np.float32)
     rx_timed_n = C.c_int(0)

@@ -38,6 +38,7 @@ class P25Chain:
         self.sets = [(z((B, ms, 10), u8), z((B, ms), u8), z((B,), i32)) for _ in range(2)]
         self.rec, self.fl, self.cnt = self.sets[0]
         self.step = 0
+        self._pending = None
         self.ev_produced = [torch.cuda.Event() for _ in range(2)]
         self.ev_consumed = [torch.cuda.Event() for _ in range(2)]
         self.bits, self.rel, self.par, self.prel, self.v_nid = z((S, 63), u8), z((S, 63), u8), z((S,), u8), z((S,), u8), z((S,), u8)
@@ -156,6 +157,49 @@ class P25Chain:
         self.voice(s_aux.cuda_stream)
         self.ev_consumed[cur].record(s_aux)
         self.step = k + 1
+
+    def run_pipelined_deferred(self, d_iq, s_main, s_aux):
+        """run_pipelined with the decode of batch k held back until the front end of batch k + 1 has run: the front end is
+        a throughput kernel that wants the whole GPU, the receive loop is one latency-bound wavefront per SIMD - so the frame
+        FEC + voice of batch k go beside the matched filter and the loop of batch k + 1 instead of beside its front end.  The
+        decode of the last batch is queued by flush()."""
+        k = self.step
+        cur = k & 1
+        rec, fl, cnt = self.sets[cur]
+        if k >= 2:
+            s_main.wait_event(self.ev_consumed[cur])      # batch k - 2 has been decoded out of this set
+        self.front_end(d_iq, s_main.cuda_stream)
+        if k >= 1:
+            self._decode_pending(s_main, s_aux)           # batch k - 1, after this batch's front end
+        self.rec, self.fl, self.cnt = rec, fl, cnt
+        self.receive(s_main.cuda_stream)
+        self.ev_produced[cur].record(s_main)
+        self._pending = cur
+        self.step = k + 1
+
+    def _decode_pending(self, s_main, s_aux):
+        cur = self._pending
+        if cur is None:
+            return
+        if not hasattr(self, "ev_gate"):
+            self.ev_gate = self.torch.cuda.Event()
+        self.ev_gate.record(s_main)                       # (the front end queued just before)
+        keep = (self.rec, self.fl, self.cnt)
+        self.rec, self.fl, self.cnt = self.sets[cur]
+        s_aux.wait_event(self.ev_produced[cur])
+        s_aux.wait_event(self.ev_gate)
+        self.frame_fec(s_aux.cuda_stream)
+        self.voice(s_aux.cuda_stream)
+        self.ev_consumed[cur].record(s_aux)
+        self.rec, self.fl, self.cnt = keep
+        self._pending = None
+
+    def flush(self, s_main, s_aux):
+        """queue the decode that run_pipelined_deferred still holds back (call before reading the last batch's results)"""
+        if getattr(self, "_pending", None) is not None:
+            cur = self._pending
+            self._decode_pending(s_main, s_aux)
+            self.rec, self.fl, self.cnt = self.sets[cur]
 
     def run_pipelined(self, d_iq, s_main, s_aux):
         """One batch interval, software-pipelined over two torch streams: front end + receive loop of this batch on s_main,

@@ -134,7 +134,7 @@ def test_voice_chain_on_device_equals_oracle_chain(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_streams", [2, 3])
+@pytest.mark.parametrize("n_streams", [2, 3, -2])
 def test_pipelined_steps_equal_one_stream_steps(built, n_streams):
     """P25Chain.run_pipelined (frame FEC + vocoder of batch k on a second stream beside the next batch's front end + receive
     loop, double-buffered loop outputs) and run_pipelined3 (the front end on a third stream as well, double-buffered
@@ -159,6 +159,17 @@ def test_pipelined_steps_equal_one_stream_steps(built, n_streams):
     for k in range(4):          # no host synchronisation between the calls: the overlap is real
         if n_streams == 3:
             b.run_pipelined3(d_iq[k], s0, s1, s2)
+        elif n_streams == -2:      # decode of batch k - 1 is queued by this call, after this batch's front end
+            b.run_pipelined_deferred(d_iq[k], s1, s2)
+            if k >= 1:
+                with torch.cuda.stream(s2):
+                    rec, fl, cnt = b.sets[(k - 1) & 1]
+                    got.append([t.clone() for t in (rec, fl, cnt, b.nid, b.tsbk, b.crc_ok, b.imbe_d, b.res_out, b.pcm)])
+            if k == 3:
+                b.flush(s1, s2)
+                with torch.cuda.stream(s2):
+                    got.append([t.clone() for t in (b.rec, b.fl, b.cnt, b.nid, b.tsbk, b.crc_ok, b.imbe_d, b.res_out, b.pcm)])
+            continue
         else:
             b.run_pipelined(d_iq[k], s1, s2)
         # snapshot on the consumer stream, ordered after this batch's last stage
