@@ -634,7 +634,7 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
 
 
 // =====================================================================================================================
-// k_p25_rxw — the same loop for CPW <= 32 with three changes that cut the instructions on the per-channel chain:
+// k_p25_rxw — the same loop for CPW <= 32 with these changes that cut the instructions on the per-channel chain:
 //  * the staged tiles form a ring of three (previous, current, next being loaded), so a symbol that would straddle a
 //    tile edge is simply deferred to the next tile and every symbol is evaluated whole: the five-sample latched path in
 //    frame, a straight per-sample pass (crossing search included) while hunting.  The sample-at-a-time loop is left for
@@ -648,7 +648,12 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
 //    (pp), pc}: 4 LDS reads and ~30 ALU operations, no rescans, no per-group events, no handshake besides the tile
 //    barrier.  Same multiset statistics as the reference's rescan of the 128 values (src/core/frames/dsd_dibit.c:194-241);
 //  * the queue to wave 1 carries {symbol, max, min, flags}; centre / mid thresholds are recomputed there with the
-//    reference's expressions.
+//    reference's expressions;
+//  * (round 2) three kinds of trip, the cheapest one every live lane qualifies for: the LEAN trip (every lane in frame with
+//    its crossing latched: clipped mean from operands fetched one trip ahead, window push, rings, thresholds, queue entry),
+//    the STANDARD trip (in-frame and hunting lanes with ordinary whole symbols, straight-line, the crossing search shared out
+//    over the wave's 64 / CPW lanes per column) and the GENERAL trip (everything else, and the trip that ends a tile);
+//  * (round 2) 128-sample tiles at <= 16 lanes per wave (LdsW::TW): half the tile prologues and closing trips.
 constexpr int WMAX = 24;
 
 
