@@ -31,24 +31,25 @@
 #include "ddn_tables_ambe.h"
 
 namespace {
-constexpr int TS = 64;
 constexpr int RTILES = 4;               // staged tiles per channel (power of two: ring index = sample index & RMASK)
-constexpr int RMASK = RTILES * TS - 1;
 constexpr int HN = DDN_FSK4_HIST;
-constexpr int QCAP = 12; // symbols a lane can finish in one round (64 / 7 + 1) + one sync entry + slack
 
 template <int CPW>
 struct Lds4 {
+    // tile shape: 128-sample tiles where the rows are few (half the round overhead per symbol: a 64-sample tile holds only
+    // 3.2 NXDN48 symbols), 64 from 16 lanes per wave on (LDS)
+    static constexpr int TSW = CPW <= 8 ? 128 : 64, RMASKW = RTILES * TSW - 1;
+    static constexpr int QCAPW = CPW <= 8 ? 24 : 12; // symbols a lane can finish in one round (TSW / 7 + 1) + sync entries + slack
     float lb[24][CPW];
     float sh[HN][CPW];
     uint8_t ph[HN][CPW];
     uint8_t rh[HN][CPW];
-    float raw[CPW][RTILES * TS + 1]; // ring of RTILES tiles per channel; the + 1 skews the rows over the LDS banks
-    float flt[CPW][RTILES * TS + 1];
-    // hand-off to the helper wave, one buffer per round parity: per lane up to QCAP entries {symbol, centre, umid, lmid,
+    float raw[CPW][RTILES * TSW + 1]; // ring of RTILES tiles per channel; the + 1 skews the rows over the LDS banks
+    float flt[CPW][RTILES * TSW + 1];
+    // hand-off to the helper wave, one buffer per round parity: per lane up to QCAPW entries {symbol, centre, umid, lmid,
     // max, min, meta, aux}.  meta = flags | slot << 8 | kind << 16; a sync entry (kind 1) follows the entry of the accepting
     // symbol and carries the thresholds AFTER the warm start, meta |= redigitise << 17 | scount << 24, aux = sync index
-    float q[2][QCAP][8][CPW];
+    float q[2][QCAPW][8][CPW];
     int qn[2][CPW];
     int qo[2][CPW];
     uint32_t pat_bits[DDN_FSK4_MAX_PAT];
@@ -125,6 +126,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
           uint8_t* __restrict__ rec, uint8_t* __restrict__ flags, uint8_t* __restrict__ pay, int32_t* __restrict__ counts,
           size_t max_sym, const int32_t* __restrict__ lock4, int32_t* __restrict__ sync_pos, uint8_t* __restrict__ sync_pat,
           uint8_t* __restrict__ pre, uint8_t* __restrict__ pre_rel, int32_t* __restrict__ n_sync, int max_sync) {
+    constexpr int TSW = Lds4<CPW>::TSW, RMASKW = Lds4<CPW>::RMASKW, QCAPW = Lds4<CPW>::QCAPW;
     extern __shared__ unsigned char smem_raw[];
     Lds4<CPW>& L = *reinterpret_cast<Lds4<CPW>*>(smem_raw);
     const int n = (int)n_long; // the C-ABI keeps a call below 2^31 samples
@@ -173,28 +175,32 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     // always read whole - no symbol straddles a staging boundary (with 16 unsynchronised channels per wavefront some lane
     // would, on nearly every trip, and drag the whole wavefront through the sample-at-a-time loop).
     auto stage = [&](int t) {
-        const long t0 = (long)t * TS;
+        const long t0 = (long)t * TSW;
         if (t0 >= n) {
             return;
         }
-        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
-        const int slot = (t & (RTILES - 1)) * TS;
+        const int tn = (int)((n - t0) < TSW ? (n - t0) : TSW);
+        const int slot = (t & (RTILES - 1)) * TSW;
         constexpr int RB = CPW < 16 ? CPW : 16; // rows staged per pass
 #pragma unroll
-        for (int h = 0; h < CPW / RB; h++) {
-            float r[RB], f[RB];
+        for (int half = 0; half < TSW / 64; half++) { // 64 samples of a row per pass
+            const int j = lane + 64 * half;
 #pragma unroll
-            for (int c = 0; c < RB; c++) {
-                const int cc = RB * h + c;
-                const bool ok = (ch0 + cc < n_channels) && lane < tn;
-                const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + lane;
-                r[c] = ok ? raw[off] : 0.0f;
-                f[c] = (ok && use_flt) ? filt[off] : 0.0f;
-            }
+            for (int h = 0; h < CPW / RB; h++) {
+                float r[RB], f[RB];
 #pragma unroll
-            for (int c = 0; c < RB; c++) {
-                L.raw[RB * h + c][slot + lane] = r[c];
-                L.flt[RB * h + c][slot + lane] = f[c];
+                for (int c = 0; c < RB; c++) {
+                    const int cc = RB * h + c;
+                    const bool ok = (ch0 + cc < n_channels) && j < tn;
+                    const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + j;
+                    r[c] = ok ? raw[off] : 0.0f;
+                    f[c] = (ok && use_flt) ? filt[off] : 0.0f;
+                }
+#pragma unroll
+                for (int c = 0; c < RB; c++) {
+                    L.raw[RB * h + c][slot + j] = r[c];
+                    L.flt[RB * h + c][slot + j] = f[c];
+                }
             }
         }
     };
@@ -225,7 +231,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
         const int cnt = L.qn[qb][ln];
         int oo = L.qo[qb][ln];
-        for (int k = 0; k < QCAP; k++) {
+        for (int k = 0; k < QCAPW; k++) {
             if (k >= cnt) {
                 break;
             }
@@ -287,10 +293,10 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     int pos = 0; // call-relative index of this lane's next sample
     const float* rrow = &L.raw[ln][0];
     const float* frow = &L.flt[ln][0];
-    const int n_tiles = (n + TS - 1) / TS;
+    const int n_tiles = (n + TSW - 1) / TSW;
     for (int t = 0; t < n_tiles; t++) {
-        const int tile_end = (t + 1) * TS < n ? (t + 1) * TS : n; // symbols starting before this index belong to this round
-        const int lim = (t + 2) * TS < n ? (t + 2) * TS : n;       // samples staged so far
+        const int tile_end = (t + 1) * TSW < n ? (t + 1) * TSW : n; // symbols starting before this index belong to this round
+        const int lim = (t + 2) * TSW < n ? (t + 2) * TSW : n;       // samples staged so far
         if (loader) {
             stage(t + 2);
             if (t > 0) {
@@ -346,7 +352,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 if (lean_ok) {
                     const bool fo_l = s.filter_on != 0;
                     const bool lean = live & (s.in_symbol == 0) & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left >= 1)
-                                      & (s.need_reset == 0) & (pos < tile_end) & (pos + whole <= lim) & (qk < QCAP - 2)
+                                      & (s.need_reset == 0) & (pos < tile_end) & (pos + whole <= lim) & (qk < QCAPW - 2)
                                       & (!fo_l | ((abs0 + pos - s.filt_start) >= (long long)(NT - 1)));
                     const bool idle = live & (s.in_symbol == 0) & !(pos < tile_end);
                     if (!__any(live & !(lean | idle)) && __any(lean)) {
@@ -365,7 +371,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             for (int k = 0; k < 8; k++) {
                                 const int i = i_lo + k;
                                 if (i <= i_hi) {
-                                    float x = rowl[(pos + i) & RMASK];
+                                    float x = rowl[(pos + i) & RMASKW];
                                     if (rf0l) { // the sync-time clip (C4FM rules only)
                                         x = x > s.max ? s.max : (x < s.min ? s.min : x);
                                     }
@@ -382,7 +388,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             }
                             const float sym = (c > 0) ? (sum / (float)c) : 0.0f;
                             if (s.lock_left == 1) { // the frame's last symbol: the hunt that follows starts from its last sample
-                                float x = rowl[(pos + whole - 1) & RMASK];
+                                float x = rowl[(pos + whole - 1) & RMASKW];
                                 if (rf0l) {
                                     x = x > s.max ? s.max : (x < s.min ? s.min : x);
                                 }
@@ -468,7 +474,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     float xs[MAXW];
 #pragma unroll
                     for (int k = 0; k < MAXW; k++) {
-                        xs[k] = rowp[(pos + (k < left ? k : 0)) & RMASK];
+                        xs[k] = rowp[(pos + (k < left ? k : 0)) & RMASKW];
                     }
                     float last = s.lastsample, sum = 0.0f;
                     int jit = s.jitter, c = 0;
@@ -509,9 +515,9 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     if (act) {
                         float x;
                         if (!fo_now) {
-                            x = rrow[pos & RMASK];
+                            x = rrow[pos & RMASKW];
                         } else if ((cfg.dbg & 128) || (abs0 + pos - s.filt_start) >= (long long)(NT - 1)) {
-                            x = frow[pos & RMASK];
+                            x = frow[pos & RMASKW];
                         } else { // first NT-1 samples after the enable: FIR over the filter's stale memory + new samples
                             float acc = 0.0f;
                             for (int i = 0; i < NT; i++) {
@@ -700,7 +706,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     o++;
                 }
                 const bool busy = live && pos < tile_end && !s.in_symbol;
-                if (!__any(busy) || ++guard > 4 * TS) {
+                if (!__any(busy) || ++guard > 4 * TSW) {
                     break;
                 }
             }
