@@ -653,7 +653,7 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
 //    its crossing latched: clipped mean from operands fetched one trip ahead, window push, rings, thresholds, queue entry),
 //    the STANDARD trip (in-frame and hunting lanes with ordinary whole symbols, straight-line, the crossing search shared out
 //    over the wave's 64 / CPW lanes per column) and the GENERAL trip (everything else, and the trip that ends a tile);
-//  * (round 2) 128-sample tiles at <= 16 lanes per wave (LdsW::TW): half the tile prologues and closing trips.
+//  * (round 2) 128-sample tiles at 8 lanes per wave (LdsW::TW): half the tile prologues and closing trips.
 constexpr int WMAX = 24;
 
 
@@ -666,9 +666,11 @@ constexpr int WMAX = 24;
 template <int CPW>
 struct LdsW {
     // tile shape: 128-sample tiles where the rows fit (half the tile prologues / closing trips), 64 at 32 lanes per wave
-    static constexpr int TW = CPW <= 16 ? 128 : 64, RTW = 3 * TW;
-    static constexpr int WMW = CPW <= 16 ? 64 : 32; // suffix summaries per checkpoint: pushes per two tiles, 2 * (ceil((TW + sps) / (sps - 1)) + 1)
-    static constexpr int QTW = CPW <= 16 ? 40 : 20; // queue slots = trips of a tile that can hand a symbol to wave 1
+    // (8 lanes per wave: 66 KB, two workgroups per CU still fit; at 16 lanes the 128-sample shape would take 132 KB and halve
+    // the resident workgroups of an 8192-channel batch)
+    static constexpr int TW = CPW <= 8 ? 128 : 64, RTW = 3 * TW;
+    static constexpr int WMW = CPW <= 8 ? 64 : 32; // suffix summaries per checkpoint: pushes per two tiles, 2 * (ceil((TW + sps) / (sps - 1)) + 1)
+    static constexpr int QTW = CPW <= 8 ? 40 : 20; // queue slots = trips of a tile that can hand a symbol to wave 1
     float sb[SS][CPW];
     float lb[24][CPW];
     float sh[24][CPW];
