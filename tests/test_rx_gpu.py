@@ -34,7 +34,7 @@ def _compare(got, want, ch):
     assert np.array_equal(r4, rec_o), ch
 
 
-@pytest.mark.parametrize("cpw", [16, 32, 64])
+@pytest.mark.parametrize("cpw", [8, 16, 32, 64])
 @pytest.mark.parametrize("use_filter", [0, 1])
 def test_rx_vs_oracle(built, cpw, use_filter):
     B, n, frame = 70, 30000, 432
