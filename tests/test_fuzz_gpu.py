@@ -73,7 +73,7 @@ def test_rx_random_splits(built, seed):
                                  noise=float(rng.choice([200, 800, 2500])))
     cuts = sorted(set([0, n] + [int(v) for v in rng.integers(1, n, int(rng.integers(0, 5)))]))
     rx = ddn.P25Rx(B, out_rate=out_rate, lock_symbols=lock, use_matched_filter=use_filter,
-                   channels_per_wave=int(rng.choice([0, 16, 32, 64])))
+                   channels_per_wave=int(rng.choice([0, 8, 16, 32, 64])))
     recs, fls = [[] for _ in range(B)], [[] for _ in range(B)]
     for a, e in zip(cuts[:-1], cuts[1:]):
         rec, fl, cnt = rx.run(x[:, a:e])
