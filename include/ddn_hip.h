@@ -177,7 +177,9 @@ int ddn_p25_rx_set_timing(ddn_p25_rx* b, int enable);
 int ddn_p25_rx_get_timing(ddn_p25_rx* b, float* ms2);
 /* the same averaged over the launches since timing was switched on (at most the last 64), without synchronising between them */
 int ddn_p25_rx_get_timing_avg(ddn_p25_rx* b, float* ms2, int* n_launches);
-int ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave); /* 0 = automatic, else 16 / 32 / 64 */
+/* lanes (= channels) per recurrence wavefront: 0 = automatic (8 up to 4096 channels, 16 up to 8192, 32 up to 16384, else 64),
+ * else 8 / 16 / 32 / 64.  Results do not depend on it; fewer lanes per wave = fewer trips shared with a hunting lane. */
+int ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave);
 size_t ddn_p25_rx_max_symbols(const ddn_p25_rx* b, size_t n);
 int ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records10, uint8_t* d_flags,
                    int32_t* d_counts, size_t max_symbols, void* hip_stream);
