@@ -212,6 +212,10 @@ PROTOTYPES = {
     "ddn_fec_p25_rs_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddn_fec_rs28_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_rs28_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_fec_isch_lookup_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_isch_lookup_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "isch_lookup": (C.c_int, [C.c_uint64]),
+    "isch_lookup_soft": (C.c_int, [C.c_uint64, C.c_void_p]),
     "ez_rs28_ess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ez_rs28_facch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ez_rs28_sacch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -716,6 +716,47 @@ ez_rs28_sacch(int payload[180], int parity[132], const int* erasures, int n_eras
     return rs28_one(2, payload, parity, erasures, n_erasures);
 }
 
+// ---- P25 Phase 2 I-ISCH lookup ----------------------------------------------------------------------------------------------
+extern "C" int
+ddn_fec_isch_lookup_batch(const uint64_t* d_words, const uint8_t* d_reliab40, size_t n, int32_t* d_out, void* stream) {
+    if (!d_words || !d_out) {
+        ddn_set_error("ddn_fec_isch_lookup_batch: null argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_isch_lookup(d_words, d_reliab40, (int)n, d_out, (hipStream_t)stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_isch_lookup_host(const uint64_t* words, const uint8_t* reliab40, size_t n, int32_t* out) {
+    if (!words || !out) {
+        return DDN_EINVAL;
+    }
+    Dev w(n * sizeof(uint64_t)), r(n * 40), o(n * sizeof(int32_t));
+    if (!w.p || !r.p || !o.p || w.up(words) || (reliab40 && r.up(reliab40))) {
+        return no_dev();
+    }
+    int rc = ddn_fec_isch_lookup_batch((const uint64_t*)w.p, reliab40 ? (const uint8_t*)r.p : nullptr, n, (int32_t*)o.p,
+                                       nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return o.down(out) ? no_dev() : DDN_OK;
+}
+
+// reference names (include/dsd-neo/fec/ez.h): one word per call; -2 (the "nothing found" answer) when no device is there
+extern "C" int
+isch_lookup(uint64_t isch) {
+    int32_t v = -2;
+    return ddn_fec_isch_lookup_host(&isch, nullptr, 1, &v) == DDN_OK ? v : -2;
+}
+
+extern "C" int
+isch_lookup_soft(uint64_t isch, const uint8_t reliab40[40]) {
+    int32_t v = -2;
+    return ddn_fec_isch_lookup_host(&isch, reliab40, 1, &v) == DDN_OK ? v : -2;
+}
+
 // ---- P25 1/2-rate list decoder -------------------------------------------------------------------------------------
 extern "C" int
 ddn_fec_p25_12_soft_list_batch(const int16_t* d_llr196, size_t n, int max_candidates, ddn_p25_12_candidate* d_candidates8,

@@ -190,6 +190,7 @@ hipError_t ddn_dev_golay24_soft(uint8_t* data, const uint8_t* parity, const int3
                                 uint8_t* status, int32_t* fixed, hipStream_t st);
 hipError_t ddn_dev_hamming_10_6_3_soft(const uint8_t* bits, const int32_t* reliab, int n, uint8_t* out, uint8_t* status,
                                        hipStream_t st);
+hipError_t ddn_dev_isch_lookup(const uint64_t* words, const uint8_t* reliab40, int n, int32_t* out, hipStream_t st);
 hipError_t ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const int8_t* erasures,
                         const uint8_t* n_erasures, int n, int32_t* status, hipStream_t st);
 hipError_t ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_rel, const uint8_t* parity_rel,

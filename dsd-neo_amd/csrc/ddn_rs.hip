@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "ddn_device.h"
+#include "ddn_tables_isch.h"
 
 namespace {
 __device__ __forceinline__ uint32_t
@@ -1182,5 +1183,67 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
     }
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures,
                        n_erasures, n, status);
+    return hipGetLastError();
+}
+
+// ---- P25 Phase 2 I-ISCH lookup == isch_lookup / isch_lookup_soft (src/fec/ez.cpp:325-384) ---------------------------------
+// One received 40-bit word per lane against the 128 codewords of the (40,9,16) code plus the S-ISCH word; the table index is
+// wave-uniform, so the codewords arrive through scalar loads from constant memory and the lane work is xor + popcount.  Hard:
+// exact match, else the nearest entry within 7 bits - with minimum distance 16 the only tie is a codeword against the S-ISCH
+// word 14 bits from it, settled by the measured walk order of the reference's map (DDN_ISCH_S_FIRST_INIT).  Soft (a 40-byte
+// reliability row per word): the entry within 7 bits with the least (sum of reliabilities of differing bits, differing bits,
+// answer).  -2 = S-ISCH / nothing within reach.
+__constant__ uint64_t c_isch[128] = DDN_ISCH_TABLE_INIT;
+__constant__ uint8_t c_isch_s_first[128] = DDN_ISCH_S_FIRST_INIT;
+
+__global__ __launch_bounds__(256) void
+k_isch_lookup(const uint64_t* __restrict__ words, const uint8_t* __restrict__ reliab40, int n, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint64_t w = words[i];
+    const uint8_t* rel = reliab40 ? reliab40 + (size_t)i * 40 : nullptr;
+    int exact = -1, hb = -2, hd = 40;            // hard: best index, its distance
+    int sb = -2, sc = 0x7fffffff, sp = 40;       // soft: best answer, cost, distance
+    for (int k = -1; k < 128; k++) {
+        const uint64_t cw = k < 0 ? (uint64_t)DDN_ISCH_S_WORD : c_isch[k];
+        uint64_t diff = w ^ cw;
+        const int d = __popcll(diff);
+        if (d == 0) {
+            exact = k < 0 ? -2 : k;
+        }
+        if (d > 7) {
+            continue;
+        }
+        if (rel) {
+            int cost = 0;
+            while (diff) {
+                const int b = 63 - __clzll((long long)diff);
+                diff &= ~(1ULL << b);
+                cost += rel[39 - b];
+            }
+            const int val = k < 0 ? -2 : k;
+            if (cost < sc || (cost == sc && d < sp) || (cost == sc && d == sp && val < sb)) {
+                sb = val;
+                sc = cost;
+                sp = d;
+            }
+        } else if (k < 0) {
+            hd = d;                              // S-ISCH first; a codeword replaces it when strictly nearer, or on the
+        } else if (d < hd || (d == hd && hb == -2 && !c_isch_s_first[k])) { // 7 / 7 tie when the map reaches it first
+            hb = k;
+            hd = d;
+        }
+    }
+    out[i] = exact != -1 ? exact : (rel ? sb : hb);
+}
+
+hipError_t
+ddn_dev_isch_lookup(const uint64_t* words, const uint8_t* reliab40, int n, int32_t* out, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_isch_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, words, reliab40, n, out);
     return hipGetLastError();
 }

@@ -595,6 +595,18 @@ int ddn_fec_rs28_host(int kind, uint8_t* payload_bits, const uint8_t* parity_bit
 int ez_rs28_ess(int payload[96], int parity[168], const int* erasures, int n_erasures);
 int ez_rs28_facch(int payload[156], int parity[114], const int* erasures, int n_erasures);
 int ez_rs28_sacch(int payload[180], int parity[132], const int* erasures, int n_erasures);
+
+/* P25 Phase 2 I-ISCH (40,9,16) lookup == isch_lookup / isch_lookup_soft (src/fec/ez.cpp:283-384; declared in
+ * include/dsd-neo/fec/ez.h).  words[i] holds the 40 received bits (first bit = bit 39); the answer is the 7-bit ISCH value,
+ * or -2 for the S-ISCH sync word and for anything further than 7 bits from every entry.  reliab40 (n rows of 40 bytes, row
+ * byte b = reliability of bit 39-b) switches the whole batch to the soft rule (least summed reliability of the differing
+ * bits, then fewest bits, then lowest value); NULL = the hard rule (nearest; the one possible 7 / 7 tie, codeword against
+ * S-ISCH, goes the way the reference's map walk takes it).  Exact matches are authoritative in both.  _batch: device
+ * pointers, asynchronous on stream; _host and the two reference-named single-word calls stage through the device. */
+int ddn_fec_isch_lookup_batch(const uint64_t* d_words, const uint8_t* d_reliab40, size_t n, int32_t* d_out, void* stream);
+int ddn_fec_isch_lookup_host(const uint64_t* words, const uint8_t* reliab40, size_t n, int32_t* out);
+int isch_lookup(uint64_t isch);
+int isch_lookup_soft(uint64_t isch, const uint8_t reliab40[40]);
 int ddn_fec_p25_rs_batch(int code, uint8_t* d_data_bits, const uint8_t* d_parity_bits, size_t n, uint8_t* d_status,
                          void* hip_stream);
 int ddn_fec_p25_rs_host(int code, uint8_t* data_bits, const uint8_t* parity_bits, size_t n, uint8_t* status);

@@ -982,3 +982,84 @@ orc_ez_rs28(int kind, int* payload, const int* parity, const int* erasures, int 
     }
     return ec;
 }
+
+/* ---- P25 Phase 2 I-ISCH lookup ((40,9,16) code, 128 codewords + the S-ISCH word) -------------------------------------------
+ * == isch_lookup / isch_lookup_soft (src/fec/ez.cpp:325-384).  Table measured from the compiled reference
+ * (tools/gen_tables_isch.py -> ddn_tables_isch.h).  Hard: exact match, else the nearest entry within 7 bits; the code's
+ * minimum distance is 16, so the only possible tie is between a codeword and the S-ISCH word 14 bits from it, which the
+ * reference resolves by the order its unordered_map happens to be walked in - measured per codeword as well.  Soft: exact
+ * matches stay authoritative, otherwise the entry within 7 bits with the least (sum of the reliabilities of the differing
+ * bits, number of differing bits, answer value) - a total order, independent of the walk.  -2 = S-ISCH or nothing found. */
+#include "ddn_tables_isch.h"
+static const uint64_t g_isch[128] = DDN_ISCH_TABLE_INIT;
+static const uint8_t g_isch_s_first[128] = DDN_ISCH_S_FIRST_INIT;
+
+static int
+popc64(uint64_t v) {
+    int n = 0;
+    while (v) {
+        v &= v - 1;
+        n++;
+    }
+    return n;
+}
+
+int
+orc_isch_lookup(uint64_t isch) {
+    int best = -2, bd = 40;
+    for (int i = 0; i < 128; i++) {
+        if (g_isch[i] == isch) {
+            return i;
+        }
+        const int d = popc64(isch ^ g_isch[i]);
+        if (d <= 7 && d < bd) {
+            best = i;
+            bd = d;
+        }
+    }
+    if (isch == DDN_ISCH_S_WORD) {
+        return -2;
+    }
+    const int ds = popc64(isch ^ DDN_ISCH_S_WORD);
+    if (ds <= 7 && (ds < bd || (ds == bd && best >= 0 && g_isch_s_first[best]))) {
+        return -2;
+    }
+    return best;
+}
+
+int
+orc_isch_lookup_soft(uint64_t isch, const uint8_t* reliab40) {
+    for (int i = 0; i < 128; i++) {
+        if (g_isch[i] == isch) {
+            return i;
+        }
+    }
+    if (isch == DDN_ISCH_S_WORD) {
+        return -2;
+    }
+    if (!reliab40) {
+        return orc_isch_lookup(isch);
+    }
+    int best = -2, bc = 0x7fffffff, bp = 40;
+    for (int i = -1; i < 128; i++) { /* -1: the S-ISCH word, answer -2 */
+        const uint64_t w = i < 0 ? DDN_ISCH_S_WORD : g_isch[i];
+        const int val = i < 0 ? -2 : i;
+        const uint64_t diff = isch ^ w;
+        const int p = popc64(diff);
+        if (p > 7) {
+            continue;
+        }
+        int cost = 0;
+        for (int b = 0; b < 40; b++) {
+            if (diff & (1ULL << (39 - b))) {
+                cost += reliab40[b];
+            }
+        }
+        if (cost < bc || (cost == bc && p < bp) || (cost == bc && p == bp && val < best)) {
+            best = val;
+            bc = cost;
+            bp = p;
+        }
+    }
+    return best;
+}
