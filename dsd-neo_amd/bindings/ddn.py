@@ -212,6 +212,9 @@ PROTOTYPES = {
     "ddn_fec_p25_rs_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddn_fec_rs28_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_rs28_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_audio_s16_state_init": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_audio_s16_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_audio_s16_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_fec_isch_lookup_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_isch_lookup_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "isch_lookup": (C.c_int, [C.c_uint64]),

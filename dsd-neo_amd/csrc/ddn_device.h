@@ -173,6 +173,8 @@ hipError_t ddn_dev_nxdn_frame_gather(const uint8_t* rec, const int32_t* counts, 
                                      const int32_t* n_sync, int n_channels, int max_sync, uint8_t* lich, uint8_t* sacch_sym,
                                      uint8_t* sacch_rel, uint8_t* facch_sym, uint8_t* facch_rel, uint8_t* valid, hipStream_t st);
 hipError_t ddn_dev_nxdn_crc(const uint8_t* bytes, int stride, int n, int kind, uint8_t* ok, hipStream_t st);
+hipError_t ddn_dev_audio_s16(const float* pcm, int n_streams, int n_frames, float audio_gain, int use_hpf, int use_agsm, float coef,
+                             int16_t* out, float* state, float* gain_a, hipStream_t st);
 hipError_t ddn_dev_agf(float* pcm, int n_streams, int n_frames, float gain, float* aout_gain, hipStream_t st);
 hipError_t ddn_dev_channel_lpf_c2c(const void* in, int in_fmt, long n, size_t in_stride, int block_len, int n_channels,
                                    const float* taps_dev, int taps_len, int has_zero_tap, void* hist, void* out,

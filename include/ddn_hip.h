@@ -270,6 +270,24 @@ int ddn_audio_agf_batch(float* d_pcm, int n_streams, int n_frames, float audio_g
                         void* hip_stream);
 int ddn_audio_agf_host(float* pcm, int n_streams, int n_frames, float audio_gain, int algid_0x21, float* aout_gain);
 int ddn_agf_frame(float samp[160], float audio_gain, int algid_0x21, float* aout_gain_io);
+
+/* The short-integer voice path, one talk path per row of d_pcm [n_streams][n_frames][160] (synthesized float frames at int16
+ * scale) -> d_out [n_streams][n_frames][160] int16, three stages in the reference's order:
+ *   1  processAudio()  src/core/audio/dsd_audio.c:427-571 - automatic level when audio_gain == 0 (block peak, 25-block peak
+ *      history, gain = 30000 / peak falling at once and rising at most 5 % per frame up to 50, ramped across the frame), the
+ *      caller's aout_gain applied unchanged when audio_gain > 0, no multiply when audio_gain < 0; clamp and truncate to int16
+ *   2  hpf_dL()        src/core/util/dsd_misc.c:345-371,516-522 (use_hpf_d; opts->use_hpf_d), 960 Hz one-pole at 8 kHz
+ *   3  agsm()          src/core/audio/gain.c:143-184 (use_agsm), per 160-sample frame; d_gain_a[stream] = state->aout_gainA
+ * d_state32: DDN_S16_STATE_FLOATS floats per talk path carried between calls ([0] aout_gain, [1] history index, [2] [3] the
+ * filter's v_in[0] / v_out[0], [4..28] the peak history); ddn_audio_s16_state_init() writes the reference's power-on values
+ * (aout_gain 25, src/core/util/dsd_init.c:580-585) into a HOST array.  Six-fold sample repetition for 48 kHz sinks
+ * (upsample(), src/core/audio/dsd_upsample.c:19-47) is a copy the sink does; it is not a kernel here. */
+#define DDN_S16_STATE_FLOATS 32
+int ddn_audio_s16_state_init(float* state32, int n_streams);
+int ddn_audio_s16_batch(const float* d_pcm, int n_streams, int n_frames, float audio_gain, int use_hpf_d, int use_agsm,
+                        int16_t* d_out, float* d_state32, float* d_gain_a, void* hip_stream);
+int ddn_audio_s16_host(const float* pcm, int n_streams, int n_frames, float audio_gain, int use_hpf_d, int use_agsm, int16_t* out,
+                       float* state32, float* gain_a);
 int ddn_symbol_capture_write(const char* path, const uint8_t* records10, const uint8_t* flags, size_t count, int append);
 int ddn_wav_write_s16(const char* path, int sample_rate_hz, int channels, const float* pcm, size_t frames, float full_scale);
 

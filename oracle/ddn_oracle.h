@@ -293,6 +293,10 @@ int orc_rs63_decode_erasures(int* word, int t, const int* erasures, int n_er);
 /* P25 Phase 2 RS(63,35) sections with caller-given erasures (== ez_rs28_ess / _facch / _sacch, src/fec/ez.cpp:104-281) */
 int orc_ez_rs28(int kind, int* payload, const int* parity, const int* erasures, int n_erasures);
 /* P25 Phase 2 I-ISCH lookup (== isch_lookup / isch_lookup_soft, src/fec/ez.cpp:325-384) */
+/* short-integer voice path (processAudio -> hpf_dL -> agsm), oracle/ddn_oracle_audio.c */
+float orc_hpf_d_coef(void);
+void orc_audio_s16(const float* pcm, int n_frames, float audio_gain, int use_hpf_d, int use_agsm, int16_t* out, float* state32,
+                   float* gain_a);
 int orc_isch_lookup(uint64_t isch);
 int orc_isch_lookup_soft(uint64_t isch, const uint8_t* reliab40);
 int orc_p25_rs_decode_soft(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int t, const int* erasures,

@@ -404,6 +404,9 @@ refh_fsk4_filter_run(int which, const float* in, long n, int sps, int reset, flo
 // weight, both already exercised through getDibitSoft (refh_slicer_*).
 
 extern "C" void agf(const dsd_opts* opts, dsd_state* state, float samp[160], int slot); // include/dsd-neo/core/audio.h:87
+extern "C" void agsm(dsd_opts* opts, dsd_state* state, short* input, int len);            // include/dsd-neo/core/audio.h:89
+extern "C" void init_audio_filters(dsd_state* state, int sample_rate_hz);                 // include/dsd-neo/core/audio_filters.h:22
+extern "C" void hpf_dL(dsd_state* state, short* input, int len);                          // include/dsd-neo/core/audio_filters.h:35
 // agf(): the float-path auto gain applied to every synthesized 160-sample voice frame (src/core/audio/gain.c:119-139), frames
 // of one talk path in order; aout_gain is carried in and out like state->aout_gain (slot 0).
 void
@@ -419,6 +422,27 @@ refh_agf_run(float* samp, int n_frames, float audio_gain, int algid_0x21, float*
     *aout_gain_io = st->aout_gain;
     free(o);
     free(st);
+}
+
+// hpf_dL() (src/core/util/dsd_misc.c:516-522) after init_audio_filters(state, 48000) and agsm() (src/core/audio/gain.c:143-184)
+// on consecutive 160-sample frames of one talk path, each stage switchable; returns the last agsm coefficient.
+float
+refh_s16_post_run(short* pcm, int n_frames, int use_hpf_d, int use_agsm) {
+    dsd_opts* o = static_cast<dsd_opts*>(calloc(1, sizeof(dsd_opts)));
+    dsd_state* st = static_cast<dsd_state*>(calloc(1, sizeof(dsd_state)));
+    init_audio_filters(st, 48000);
+    for (int f = 0; f < n_frames; f++) {
+        if (use_hpf_d) {
+            hpf_dL(st, pcm + (size_t)f * 160, 160);
+        }
+        if (use_agsm) {
+            agsm(o, st, pcm + (size_t)f * 160, 160);
+        }
+    }
+    const float g = st->aout_gainA;
+    free(o);
+    free(st);
+    return g;
 }
 
 int

@@ -254,3 +254,34 @@ def test_agf_batch_bit_exact(built):
     assert l.ddn_agf_frame(one.ctypes.data, 0.0, 0, g.ctypes.data) == 0
     w, gw = oracle_agf(pcm[3:4, 0:1], np.array([25.0], np.float32))
     assert np.array_equal(one.view(np.uint32), w[0, 0].view(np.uint32)) and g[0] == gw[0]
+
+
+@pytest.mark.parametrize("audio_gain,hpf,agsm", [(0.0, 1, 0), (0.0, 0, 0), (-1.0, 1, 1), (20.0, 1, 0), (0.0, 1, 1)])
+def test_audio_s16_batch_bit_exact(built, audio_gain, hpf, agsm):
+    """the short-integer voice path (processAudio -> hpf_dL -> agsm) on 70 talk paths (a full wave + a ragged one), in two
+    calls so the carried state (gain, peak history, filter memory) is exercised, against the restatement"""
+    import ddn
+    from test_oracle_audio import oracle_s16, s16_state, voice_like
+    l = ddn.lib()
+    rng = np.random.default_rng(77)
+    S, F = 70, 45
+    pcm = voice_like(rng, S, F)
+    pcm[3] *= 0.02
+    st_cpu = s16_state(S)
+    st_cpu[:, 0] = rng.choice([25.0, 7.0, 50.0], S)
+    st_gpu = np.zeros((S, 32), np.float32)
+    assert l.ddn_audio_s16_state_init(st_gpu.ctypes.data, S) == 0 and np.array_equal(st_gpu, s16_state(S))
+    st_gpu[:, 0] = st_cpu[:, 0]
+    ga_gpu = np.zeros(S, np.float32)
+    for part in (slice(0, 17), slice(17, F)):
+        x = np.ascontiguousarray(pcm[:, part])
+        want, st_cpu, ga_cpu = oracle_s16(x, st_cpu, audio_gain, hpf, agsm)
+        got = np.zeros(x.shape, np.int16)
+        assert l.ddn_audio_s16_host(x.ctypes.data, S, x.shape[1], audio_gain, hpf, agsm, got.ctypes.data, st_gpu.ctypes.data,
+                                    ga_gpu.ctypes.data) == 0
+        assert np.array_equal(got, want)
+        assert np.array_equal(st_gpu.view(np.uint32), st_cpu.view(np.uint32))
+        if agsm:
+            assert np.array_equal(ga_gpu, ga_cpu)
+    assert np.abs(want.astype(np.int32)).max() > 1000
+    assert l.ddn_audio_s16_host(None, S, 1, 0.0, 1, 0, None, None, None) != 0

@@ -91,3 +91,71 @@ def test_wav_writer(built, tmp_path):
     s = np.frombuffer(raw[44:], np.int16)
     assert list(s) == [0, 16384, -16384, 32767, -32767, 32767, -32768, 8192]
     assert ddn.lib().ddn_wav_write_s16(path, 8000, 3, x.ctypes.data, 2, 1.0) != 0
+
+
+# ---- the short-integer voice path (processAudio -> hpf_dL -> agsm) ------------------------------------------------------------
+S16_STATE = 32
+
+
+def s16_state(n, aout_gain=25.0):
+    """fresh per-talk-path state: aout_gain 25 (src/core/util/dsd_init.c:580), empty peak history, filter at rest"""
+    st = np.zeros((n, S16_STATE), np.float32)
+    st[:, 0] = aout_gain
+    return st
+
+
+def oracle_s16(pcm, state, audio_gain=0.0, hpf=1, agsm=0):
+    o = orc.oracle()
+    o.orc_audio_s16.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_audio_s16.restype = None
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    st = state.copy()
+    out = np.zeros(pcm.shape, np.int16)
+    ga = np.zeros(pcm.shape[0], np.float32)
+    for s in range(pcm.shape[0]):
+        o.orc_audio_s16(pcm[s].ctypes.data, pcm.shape[1], audio_gain, hpf, agsm, out[s].ctypes.data, st[s].ctypes.data, ga[s:s + 1].ctypes.data)
+    return out, st, ga
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="needs oracle/_ref")
+@pytest.mark.parametrize("hpf,agsm", [(1, 0), (0, 1), (1, 1)])
+def test_s16_hpf_and_agsm_equal_compiled_reference(built, hpf, agsm):
+    """audio_gain < 0 makes stage 1 a plain clamp + truncation, so stages 2 and 3 see exactly the shorts the compiled hpf_dL /
+    agsm are given"""
+    r = orc.ref()
+    r.refh_s16_post_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    r.refh_s16_post_run.restype = C.c_float
+    rng = np.random.default_rng(12)
+    pcm = voice_like(rng, 6, 60)
+    pcm[5] *= 0.01                                                    # quiet: agsm's 3x cap
+    got, st, ga = oracle_s16(pcm, s16_state(6), -1.0, hpf, agsm)
+    for s in range(6):
+        want = np.clip(pcm[s], -32768, 32767).astype(np.int16).reshape(-1).copy()
+        g = r.refh_s16_post_run(want.ctypes.data, 60, hpf, agsm)
+        assert np.array_equal(got[s].reshape(-1), want), s
+        if agsm:
+            assert ga[s] == np.float32(g)
+    assert np.abs(got.astype(np.int32)).max() > 1000 and np.abs(pcm).max() > 32767
+
+
+def test_s16_agsm_reference_vectors():
+    """tests/core/test_core_audio_gain.c:251-302: 1000 -> 3000 at the 3x cap, silence stays silence"""
+    pcm = np.full((1, 1, 160), 1000.0, np.float32)
+    out, _, ga = oracle_s16(pcm, s16_state(1), -1.0, 0, 1)
+    assert (out == 3000).all() and ga[0] == 3.0
+    out, _, ga = oracle_s16(np.zeros((1, 2, 160), np.float32), s16_state(1), -1.0, 1, 1)
+    assert (out == 0).all() and np.isfinite(ga[0])
+
+
+def test_s16_auto_gain_walk():
+    """stage 1 by its own rules: the gain drops at once to 30000 / peak, climbs back by at most 5 % per frame, never passes 50,
+    and a loud frame stays in the 25-frame history"""
+    x = np.zeros((1, 40, 160), np.float32)
+    x[0, :, 80] = 100.0
+    x[0, 3, 80] = 6000.0
+    out, st, _ = oracle_s16(x, s16_state(1), 0.0, 0, 0)
+    assert out[0, 3, 80] == 30000 and abs(int(out[0, 4, 80]) - 500) <= 1     # 30000 / 6000 = 5, held by the history
+    assert abs(int(out[0, 30, 80]) - int(out[0, 29, 80]) * 1.05) <= 2         # frame 28 drops the loud block: +5 % per frame
+    assert st[0, 0] <= 50.0 and st[0, 1] == 40 % 25
+    out2, _, _ = oracle_s16(x, s16_state(1, 7.0), 12.0, 0, 0)                 # manual gain: aout_gain as handed in, no ramp
+    assert out2[0, 5, 80] == 700

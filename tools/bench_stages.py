@@ -247,6 +247,28 @@ def main():
             rs28.oracle_rs28(1, c[0], c[1], c[2])
     report("p25p2_rs28_facch", nrs, ms, 45 * 6 + 28 + 4, cpu(cpu_rs28, 512), "sections")
 
+    # short-integer voice path (processAudio -> hpf_dL) and the I-ISCH lookup
+    from test_oracle_audio import oracle_s16, s16_state, voice_like
+    S, F = 4096, 50
+    x1 = voice_like(rng, 64, F)
+    d_x = torch.from_numpy(np.tile(x1, (S // 64, 1, 1))).cuda()
+    d_o = torch.zeros(S, F, 160, dtype=torch.int16, device="cuda")
+    d_s0 = torch.from_numpy(s16_state(S)).cuda()
+    d_s, d_g = d_s0.clone(), torch.zeros(S, device="cuda")
+
+    def run_s16():
+        l.ddn_audio_s16_batch(d_x.data_ptr(), S, F, 0.0, 1, 0, d_o.data_ptr(), d_s.data_ptr(), d_g.data_ptr(), st)
+    ms = timeit(run_s16)
+    report("audio_s16_agc_hpf", S * F, ms, 160 * 6, cpu(lambda: oracle_s16(x1, s16_state(64), 0.0, 1, 0), 64 * F), "voice frames")
+
+    from test_oracle_isch import oracle_hard, words
+    ws = words(rng, 4096)[:4096]
+    nw = 1 << 20
+    d_w = torch.from_numpy(np.tile(np.array(ws, np.uint64).view(np.int64), nw // 4096)).cuda()
+    d_v = torch.zeros(nw, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: l.ddn_fec_isch_lookup_batch(d_w.data_ptr(), None, nw, d_v.data_ptr(), st))
+    report("p25p2_isch_lookup", nw, ms, 12, cpu(lambda: [oracle_hard(w) for w in ws], 4096), "words")
+
 
 if __name__ == "__main__":
     main()
