@@ -215,6 +215,12 @@ PROTOTYPES = {
     "ddn_audio_s16_state_init": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_audio_s16_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_audio_s16_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_bptc_128x77_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_bptc_128x77_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_fec_bptc_16x2_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_bptc_16x2_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "BPTC_128x77_Extract_Data": (C.c_uint32, [C.c_void_p, C.c_void_p]),
+    "BPTC_16x2_Extract_Data": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "ddn_fec_isch_lookup_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_fec_isch_lookup_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "isch_lookup": (C.c_int, [C.c_uint64]),

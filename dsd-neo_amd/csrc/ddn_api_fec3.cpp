@@ -132,6 +132,91 @@ ddn_fec_bptc_196x96_host(const uint8_t* in196, int deinterleave, size_t n, uint8
     return rc;
 }
 
+// BPTC 128x77 (kind 0: item 128 bytes -> 77) and reverse-channel BPTC 16x2 (kind 1 even / 2 odd parity: 32 -> 32)
+static int
+bptc_small(int kind, const uint8_t* d_in, size_t n, uint8_t* d_out, uint32_t* d_errs, hipStream_t st) {
+    hipError_t e = kind == 0 ? ddn_dev_bptc_128x77(d_in, n, d_out, d_errs, st) : ddn_dev_bptc_16x2(d_in, n, kind == 2, d_out, d_errs, st);
+    if (e != hipSuccess) {
+        ddn_set_error("bptc kernel launch failed: %s", hipGetErrorString(e));
+        return DDN_EHIP;
+    }
+    return DDN_OK;
+}
+
+static int
+bptc_small_host(int kind, const uint8_t* in, size_t n, uint8_t* out, uint32_t* errs) {
+    const size_t ni = kind == 0 ? 128 : 32, no = kind == 0 ? 77 : 32;
+    if (n && (!in || !out)) {
+        return DDN_EINVAL;
+    }
+    if (have_device() != DDN_OK) {
+        return DDN_ENODEV;
+    }
+    uint8_t *d_i = nullptr, *d_o = nullptr;
+    uint32_t* d_e = nullptr;
+    int rc = DDN_OK;
+    if (hipMalloc(&d_i, n * ni + 4) != hipSuccess || hipMalloc(&d_o, n * no + 4) != hipSuccess
+        || hipMalloc(&d_e, n * 4 + 4) != hipSuccess) {
+        rc = DDN_ENOMEM;
+    } else if (hipMemcpy(d_i, in, n * ni, hipMemcpyHostToDevice) != hipSuccess || bptc_small(kind, d_i, n, d_o, d_e, nullptr) != DDN_OK
+               || hipMemcpy(out, d_o, n * no, hipMemcpyDeviceToHost) != hipSuccess
+               || (errs && hipMemcpy(errs, d_e, n * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+        rc = DDN_EHIP;
+    }
+    (void)hipFree(d_i);
+    (void)hipFree(d_o);
+    (void)hipFree(d_e);
+    return rc;
+}
+
+extern "C" int
+ddn_fec_bptc_128x77_batch(const uint8_t* d_in128, size_t n, uint8_t* d_out77, uint32_t* d_errs, void* stream) {
+    if (n && (!d_in128 || !d_out77)) {
+        ddn_set_error("ddn_fec_bptc_128x77_batch: null argument");
+        return DDN_EINVAL;
+    }
+    return bptc_small(0, d_in128, n, d_out77, d_errs, (hipStream_t)stream);
+}
+
+extern "C" int
+ddn_fec_bptc_128x77_host(const uint8_t* in128, size_t n, uint8_t* out77, uint32_t* errs) {
+    return bptc_small_host(0, in128, n, out77, errs);
+}
+
+extern "C" int
+ddn_fec_bptc_16x2_batch(const uint8_t* d_in32, size_t n, int parity_odd, uint8_t* d_out32, uint32_t* d_errs, void* stream) {
+    if (n && (!d_in32 || !d_out32)) {
+        ddn_set_error("ddn_fec_bptc_16x2_batch: null argument");
+        return DDN_EINVAL;
+    }
+    return bptc_small(parity_odd ? 2 : 1, d_in32, n, d_out32, d_errs, (hipStream_t)stream);
+}
+
+extern "C" int
+ddn_fec_bptc_16x2_host(const uint8_t* in32, size_t n, int parity_odd, uint8_t* out32, uint32_t* errs) {
+    return bptc_small_host(parity_odd ? 2 : 1, in32, n, out32, errs);
+}
+
+extern "C" uint32_t
+BPTC_128x77_Extract_Data(uint8_t InputDataMatrix[8][16], uint8_t DMRDataExtracted[77]) {
+    uint32_t errs = 0xFFFFFFFFu;
+    if (!InputDataMatrix || !DMRDataExtracted
+        || bptc_small_host(0, &InputDataMatrix[0][0], 1, DMRDataExtracted, &errs) != DDN_OK) {
+        return 0xFFFFFFFFu;
+    }
+    return errs;
+}
+
+extern "C" uint32_t
+BPTC_16x2_Extract_Data(uint8_t InputInterleavedData[32], uint8_t DMRDataExtracted[32], uint32_t ParityCheckTypeOdd) {
+    uint32_t errs = 0xFFFFFFFFu;
+    if (!InputInterleavedData || !DMRDataExtracted
+        || bptc_small_host(ParityCheckTypeOdd ? 2 : 1, InputInterleavedData, 1, DMRDataExtracted, &errs) != DDN_OK) {
+        return 0xFFFFFFFFu;
+    }
+    return errs;
+}
+
 extern "C" int
 ddn_fec_trellis_decode_batch(const uint8_t* d_source_bits, int source_stride, size_t n, int result_len, uint8_t* d_result_bits,
                              int result_stride, void* hip_stream) {

@@ -8,6 +8,8 @@
 
 extern "C" {
 hipError_t ddn_dev_block_code(int code, uint8_t* bits, size_t n_items, int nb, uint8_t* decoded, uint8_t* ok, hipStream_t st);
+hipError_t ddn_dev_bptc_128x77(const uint8_t* in, size_t n, uint8_t* out77, uint32_t* errs, hipStream_t st);
+hipError_t ddn_dev_bptc_16x2(const uint8_t* in, size_t n, int parity_odd, uint8_t* out32, uint32_t* errs, hipStream_t st);
 hipError_t ddn_dev_bptc_196x96(const uint8_t* in, int deinterleave, size_t n, uint8_t* out96, uint8_t* r3, uint32_t* errs,
                                hipStream_t st);
 hipError_t ddn_dev_trellis_greedy(const uint8_t* src, int src_stride, size_t n, int result_len, uint8_t* out, int out_stride,

@@ -21,6 +21,7 @@
 #include "ddn_device.h"
 #include "ddn_fec3.h"
 #include "ddn_tables_fec3.h"
+#include "ddn_tables_bptc.h"
 
 namespace {
 
@@ -550,6 +551,130 @@ ddn_dev_bptc_196x96(const uint8_t* in, int deinterleave, size_t n, uint8_t* out9
     }
     hipLaunchKernelGGL(k_bptc_196x96, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, in, deinterleave, n, out96, r3,
                        errs, T);
+    return hipGetLastError();
+}
+
+// BPTC_128x77_Extract_Data (src/fec/bptc.c:167-258) and BPTC_16x2_Extract_Data (:278-336), one matrix per lane, rows as 16-bit
+// words.  128x77: rows 0..6 through Hamming(16,11,4); a row that cannot be corrected takes the eleven bits the previous row
+// decoded to (the reference's line buffer is written on success only; zeros for row 0, where the reference's is uninitialised),
+// then the 77-bit read-out and the column parities against row 7.  16x2: the measured de-interleave, row 0 through the same
+// code (left as received when it cannot be corrected - the reference reads an uninitialised buffer there), parity row compared
+// bit by bit in the odd or even sense.
+__constant__ uint8_t c_bptc_rc_perm[32] = DDN_BPTC_RC_PERM_INIT;
+
+__global__ __launch_bounds__(128) void
+k_bptc_128x77(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out77, uint32_t* __restrict__ errs,
+              const Tables* __restrict__ T) {
+    const size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint8_t* src = in + i * 128;
+    uint32_t row[8], line = 0, bad = 0;
+    for (int r = 0; r < 8; r++) {
+        uint32_t w = 0;
+        for (int j = 0; j < 16; j++) {
+            w |= (uint32_t)(src[r * 16 + j] & 1u) << j;
+        }
+        row[r] = w;
+    }
+    for (int r = 0; r < 7; r++) {
+        uint32_t w = row[r];
+        const int s = syndrome<5>(w, ddn_hamming_16_11_4_H);
+        bool ok = true;
+        if (s > 0) {
+            const uint8_t p = T->h16114[s];
+            if (p == 0xFF) {
+                ok = false;
+            } else {
+                w ^= 1u << p;
+            }
+        }
+        if (ok) {
+            line = w & 0x7FFu;
+        } else {
+            bad++;
+        }
+        row[r] = (row[r] & ~0x7FFu) | line;
+    }
+    uint8_t* o = out77 + i * 77;
+    int k = 0;
+    for (int r = 0; r < 2; r++) {
+        for (int j = 0; j < 11; j++) {
+            o[k++] = (uint8_t)((row[r] >> j) & 1u);
+        }
+    }
+    for (int r = 2; r < 7; r++) {
+        for (int j = 0; j < 10; j++) {
+            o[k++] = (uint8_t)((row[r] >> j) & 1u);
+        }
+    }
+    for (int r = 2; r < 7; r++) {
+        o[k++] = (uint8_t)((row[r] >> 10) & 1u);
+    }
+    const uint32_t par = row[0] ^ row[1] ^ row[2] ^ row[3] ^ row[4] ^ row[5] ^ row[6];
+    bad += (uint32_t)__popc((par ^ row[7]) & 0xFFFFu);
+    if (errs) {
+        errs[i] = bad;
+    }
+}
+
+__global__ __launch_bounds__(128) void
+k_bptc_16x2(const uint8_t* __restrict__ in, size_t n, int parity_odd, uint8_t* __restrict__ out32, uint32_t* __restrict__ errs,
+            const Tables* __restrict__ T) {
+    const size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    uint32_t m = 0;
+    for (int j = 0; j < 32; j++) {
+        m |= (uint32_t)(in[i * 32 + j] & 1u) << c_bptc_rc_perm[j];
+    }
+    uint32_t bad = 0;
+    const int s = syndrome<5>(m & 0xFFFFu, ddn_hamming_16_11_4_H);
+    if (s > 0) {
+        const uint8_t p = T->h16114[s];
+        if (p == 0xFF) {
+            bad = 1;
+        } else if (p < 11) { // only the eleven data bits are copied back (bptc.c:311-313)
+            m ^= 1u << p;
+        }
+    }
+    for (int j = 0; j < 32; j++) {
+        out32[i * 32 + j] = (uint8_t)((m >> j) & 1u);
+    }
+    const uint32_t diff = (m ^ (m >> 16)) & 0xFFFFu; // row-0 bit != parity-row bit
+    bad += (uint32_t)__popc(parity_odd ? (~diff & 0xFFFFu) : diff);
+    if (errs) {
+        errs[i] = bad;
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_bptc_128x77(const uint8_t* in, size_t n, uint8_t* out77, uint32_t* errs, hipStream_t st) {
+    if (n == 0) {
+        return hipSuccess;
+    }
+    const Tables* T = nullptr;
+    hipError_t e = device_tables(&T, st);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_bptc_128x77, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, in, n, out77, errs, T);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_bptc_16x2(const uint8_t* in, size_t n, int parity_odd, uint8_t* out32, uint32_t* errs, hipStream_t st) {
+    if (n == 0) {
+        return hipSuccess;
+    }
+    const Tables* T = nullptr;
+    hipError_t e = device_tables(&T, st);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_bptc_16x2, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, in, n, parity_odd, out32, errs, T);
     return hipGetLastError();
 }
 

@@ -770,6 +770,19 @@ bool QR_16_7_6_decode(unsigned char* rxBits);
 void InitAllFecFunction(void);
 void BPTCDeInterleaveDMRData(const uint8_t* Input, uint8_t* Output);
 uint32_t BPTC_196x96_Extract_Data(uint8_t InputDeInteleavedData[196], uint8_t DMRDataExtracted[96], uint8_t R[3]);
+/* DMR embedded signalling BPTC(128,77) and the reverse-channel single-burst BPTC (16 x 2) == BPTC_128x77_Extract_Data /
+ * BPTC_16x2_Extract_Data (src/fec/bptc.c:167-258, :278-336; include/dsd-neo/fec/bptc.h).  One byte per bit.  128x77: the 8 x 16
+ * matrix row-major in, 77 bits out (72 payload + the 5 CRC bits); errs = rows Hamming(16,11,4) could not correct + failed
+ * column parities; an uncorrectable row takes the previous row's decoded bits as in the reference (row 0: zeros - the
+ * reference reads an uninitialised buffer there).  16x2: 32 interleaved bits in, 32 out (11 corrected data bits, 5 Hamming
+ * bits, 16 parity-row bits); errs = uncorrectable row + parity mismatches in the odd (reverse channel) or even sense; an
+ * uncorrectable row is left as received (the reference's output is undefined there). */
+int ddn_fec_bptc_128x77_batch(const uint8_t* d_in128, size_t n, uint8_t* d_out77, uint32_t* d_errs, void* stream);
+int ddn_fec_bptc_128x77_host(const uint8_t* in128, size_t n, uint8_t* out77, uint32_t* errs);
+int ddn_fec_bptc_16x2_batch(const uint8_t* d_in32, size_t n, int parity_odd, uint8_t* d_out32, uint32_t* d_errs, void* stream);
+int ddn_fec_bptc_16x2_host(const uint8_t* in32, size_t n, int parity_odd, uint8_t* out32, uint32_t* errs);
+uint32_t BPTC_128x77_Extract_Data(uint8_t InputDataMatrix[8][16], uint8_t DMRDataExtracted[77]);
+uint32_t BPTC_16x2_Extract_Data(uint8_t InputInterleavedData[32], uint8_t DMRDataExtracted[32], uint32_t ParityCheckTypeOdd);
 typedef struct {
     uint8_t data[12];
 } rs_12_9_codeword_t;

@@ -273,6 +273,8 @@ int orc_hamming_multi_decode(int which, uint8_t* rx, uint8_t* dec, int nb); /* w
 int orc_golay_dmr_decode(int n, uint8_t* rx);                               /* n = 20 or 24 */
 int orc_qr_16_7_6_decode(uint8_t* rx);
 uint32_t orc_bptc_196x96(const uint8_t* in196, int deinterleave, uint8_t out96[96], uint8_t r3[3]);
+uint32_t orc_bptc_128x77(const uint8_t in128[128], uint8_t out77[77], int* row0_failed);
+uint32_t orc_bptc_16x2(const uint8_t in32[32], uint8_t out32[32], uint32_t parity_odd, int* hamming_failed);
 int orc_bptc_last_col0_failed(void);
 void orc_trellis_decode(uint8_t* result, const uint8_t* source, int result_len);
 int orc_rs_12_9(uint8_t cw[12], uint8_t syn3[3], uint8_t* found);

@@ -426,3 +426,104 @@ orc_trellis_decode(uint8_t* result, const uint8_t* source, int result_len) {
         reg = ((reg << 1) | (unsigned)min_bt) & 0x1Fu;
     }
 }
+
+/* ---- BPTC_128x77_Extract_Data (src/fec/bptc.c:167-258): embedded-signalling 8 x 16 matrix.  Rows 0..6 through Hamming(16,11,4);
+ * a row that cannot be corrected gets the eleven bits the PREVIOUS row decoded to (the reference's line buffer is only
+ * written on success, fec.c:432-446; for row 0 it is uninitialised there - zeros here, *row0_failed says so); 77 bits out
+ * (2 x 11, 5 x 10, then the 5 CRC bits of rows 2..6); return = failed rows + columns whose parity over rows 0..6 differs
+ * from row 7. */
+uint32_t
+orc_bptc_128x77(const uint8_t in128[128], uint8_t out77[77], int* row0_failed) {
+    uint8_t m[8][16], tab[32], line[11] = {0};
+    hamming_table(tab, 32, ddn_hamming_16_11_4_H, 16, 5);
+    uint32_t bad = 0;
+    if (row0_failed) {
+        *row0_failed = 0;
+    }
+    for (int i = 0; i < 128; i++) {
+        m[i / 16][i % 16] = in128[i] & 1;
+    }
+    for (int i = 0; i < 7; i++) {
+        uint8_t rx[16];
+        memcpy(rx, m[i], 16);
+        const int sy = syn_bits(rx, ddn_hamming_16_11_4_H, 16, 5);
+        int ok = 1;
+        if (sy > 0) {
+            if (tab[sy] == 0xFF) {
+                ok = 0;
+            } else {
+                rx[tab[sy]] ^= 1;
+            }
+        }
+        if (ok) {
+            memcpy(line, rx, 11);
+        } else {
+            bad++;
+            if (i == 0 && row0_failed) {
+                *row0_failed = 1;
+            }
+        }
+        memcpy(m[i], line, 11);
+    }
+    int k = 0;
+    for (int i = 0; i < 2; i++) {
+        for (int j = 0; j < 11; j++) {
+            out77[k++] = m[i][j];
+        }
+    }
+    for (int i = 2; i < 7; i++) {
+        for (int j = 0; j < 10; j++) {
+            out77[k++] = m[i][j];
+        }
+    }
+    for (int i = 2; i < 7; i++) {
+        out77[k++] = m[i][10];
+    }
+    for (int c = 0; c < 16; c++) {
+        int ones = 0;
+        for (int j = 0; j < 7; j++) {
+            ones += m[j][c];
+        }
+        if ((ones & 1) != m[7][c]) {
+            bad++;
+        }
+    }
+    return bad;
+}
+
+/* ---- BPTC_16x2_Extract_Data (src/fec/bptc.c:278-336): reverse-channel single-burst BPTC.  De-interleave (measured from the
+ * compiled reference, tools/gen_tables_bptc.py), row 0 through Hamming(16,11,4), 32 bits out (11 corrected data bits, the 5
+ * Hamming bits and the 16 parity-row bits as received); return = failed row + positions whose parity-row bit is equal to
+ * (odd) / different from (even) the row-0 bit.  When the row cannot be corrected the reference reads its uninitialised line
+ * buffer; here the received bits stay and *hamming_failed is set. */
+#include "ddn_tables_bptc.h"
+uint32_t
+orc_bptc_16x2(const uint8_t in32[32], uint8_t out32[32], uint32_t parity_odd, int* hamming_failed) {
+    static const uint8_t perm[32] = DDN_BPTC_RC_PERM_INIT;
+    uint8_t tab[32], rx[16];
+    hamming_table(tab, 32, ddn_hamming_16_11_4_H, 16, 5);
+    for (int i = 0; i < 32; i++) {
+        out32[perm[i]] = in32[i] & 1;
+    }
+    memcpy(rx, out32, 16);
+    const int sy = syn_bits(rx, ddn_hamming_16_11_4_H, 16, 5);
+    uint32_t bad = 0;
+    if (sy > 0) {
+        if (tab[sy] == 0xFF) {
+            bad = 1;
+        } else {
+            rx[tab[sy]] ^= 1;
+        }
+    }
+    if (hamming_failed) {
+        *hamming_failed = (int)bad;
+    }
+    if (!bad) {
+        memcpy(out32, rx, 11);
+    }
+    for (int i = 0; i < 16; i++) {
+        const int same = out32[i] == out32[i + 16];
+        bad += parity_odd ? (same ? 1u : 0u) : (same ? 0u : 1u);
+    }
+    return bad;
+}
