@@ -185,6 +185,66 @@ void orc_slicer_step_static(orc_slicer* s, float sym, int rec4[4]);
 int orc_slicer_reliability(const orc_slicer* s, float sym);
 void orc_p25_filter_run(float hist[90], const float* in, long n, float* out);
 
+/* ---- protocol handlers as per-symbol state machines: how many symbols a frame reads in frame (ddn_oracle_handlers.c) -- */
+#define ORC_HEV_MAX 4096
+enum {
+    ORC_HEV_P25_NID = 1,     /* a = status, b = nac, c = duid (0xFF invalid) */
+    ORC_HEV_P25_TSBK = 2,    /* a = block, b = crc ok, c = last_block << 8 | selected candidate */
+    ORC_HEV_P25_MPDU = 3,    /* a = header crc ok, b = blocks to read, c = byte 0 */
+    ORC_HEV_NXDN_LICH = 4,   /* a = accepted, b = lich, c = parity ok */
+    ORC_HEV_DMR_DATA = 5,    /* a = slot type ok, b = colour code (-1 Golay failed, -2 TACT failed), c = burst | reject << 8 | pending << 9 */
+    ORC_HEV_DMR_CC_PRINT = 6, /* the reference prints "Color Code=%02d": a = value (16 = XX), b = VC (0 data burst), c = slot */
+    ORC_HEV_DMR_VOICE_BURST = 7, /* a = slot, b = EMB colour code (25 none), c = voice sync | action << 4 */
+    ORC_HEV_DMR_VOICE_END = 8    /* a = 1 bootstrap / 0 loop, b = tact ok, c = emb / sync ok */
+};
+typedef struct orc_hevent {
+    int32_t pos;
+    int16_t kind, a, b, c;
+} orc_hevent;
+typedef struct orc_hevents {
+    int n; /* events pushed (may exceed ORC_HEV_MAX; only the first ORC_HEV_MAX are kept) */
+    orc_hevent ev[ORC_HEV_MAX];
+} orc_hevents;
+
+typedef struct orc_p25h {
+    int phase, idx, left, duid, block, end, skipdibit, k;
+    int nac, p2_cc, threshold, parity, parity_rel;
+    uint8_t bch[63], bch_rel[63];
+    uint8_t dib[98];
+    int16_t llr[196];
+} orc_p25h;
+void orc_p25h_init(orc_p25h* h, int erasure_threshold);
+void orc_p25h_no_carrier(orc_p25h* h);
+int orc_p25h_begin(orc_p25h* h);
+int orc_p25h_symbol(orc_p25h* h, long pos, int d, int l0, int l1, orc_hevents* ev);
+
+typedef struct orc_nxdnh {
+    int idx, lich;
+} orc_nxdnh;
+void orc_nxdnh_init(orc_nxdnh* h);
+int orc_nxdnh_begin(orc_nxdnh* h);
+int orc_nxdnh_symbol(orc_nxdnh* h, long pos, int d, int* bad_sync, orc_hevents* ev);
+
+enum { ORC_DMR_BS_DATA = 0, ORC_DMR_BS_VOICE = 1 };
+typedef struct orc_dmrh {
+    int phase, idx, left, stereo;
+    uint8_t pay[144], rel[144];
+    /* dmr_confidence.c */
+    int locked, conf_cc, cand_cc, cand_count, mismatch;
+    uint8_t vsync_seen[2], vopen[2], vcount[2];
+    int dmr_color_code, color_code, currentslot;
+    int conf_reject, conf_pending;
+    /* dmr_bs_ctx */
+    int vc1, vc2, skipcount, tact_okay, emb_ok, internalslot, boot_slot;
+    uint8_t emb_err[2];
+    uint8_t red_b[36];
+} orc_dmrh;
+void orc_dmrh_init(orc_dmrh* h);
+void orc_dmrh_no_carrier(orc_dmrh* h);
+int orc_dmrh_begin(orc_dmrh* h, long pos, int cls, const uint8_t* pre90, const uint8_t* rel90, orc_hevents* ev);
+int orc_dmrh_begin_fixed(orc_dmrh* h, int symbols);
+int orc_dmrh_symbol(orc_dmrh* h, long pos, int d, int rel, orc_hevents* ev);
+
 /* ---- fixed-protocol P25p1 C4FM receive loop: symbolizer + sync hunt + warm start + slicer (ddn_oracle_rx.c) -- */
 typedef struct orc_p25rx {
     int out_rate, sym_rate, lock_symbols, use_filter;
@@ -203,6 +263,10 @@ typedef struct orc_p25rx {
     orc_slicer sl;
     int hunt_pos;     /* rt.synctest_pos: symbols hunted by this getFrameSync() call */
     int need_reset;   /* noCarrier() zeroed the timing ratio: the next getSymbol() re-initialises timing and slicer */
+    /* lock_symbols < 0: the reference's per-DUID handlers decide the in-frame length (ddn_oracle_handlers.c) */
+    orc_p25h h;
+    long n_sym;       /* symbols emitted since init (event positions) */
+    orc_hevents* ev;  /* optional event log */
 } orc_p25rx;
 
 /* ---- fixed-protocol 4-level FSK receive loop, profile-driven: P25p1 / DMR / NXDN48 (ddn_oracle_rx4.c) ------------- */
@@ -229,6 +293,8 @@ typedef struct orc_fsk4_profile {
     int use_filter, nt;
     uint32_t taps[ORC_FSK4_MAX_TAPS];
     int lock_symbols[4];
+    int handler; /* 0 = lock_symbols[] per sync class, 1 = the reference's handlers decide (ddn_oracle_handlers.c) */
+    int proto;   /* handler family when handler = 1: 0 P25p1, 1 DMR, 2 NXDN */
 } orc_fsk4_profile;
 typedef struct orc_fsk4rx {
     orc_fsk4_profile p;
@@ -245,7 +311,14 @@ typedef struct orc_fsk4rx {
     int shead, scount;
     orc_slicer sl;
     int hunt_pos, need_reset;
+    orc_p25h hp25;
+    orc_dmrh hdmr;
+    orc_nxdnh hnxdn;
+    long n_sym;
+    orc_hevents* ev;
 } orc_fsk4rx;
+void orc_fsk4rx_set_events(orc_fsk4rx* r, orc_hevents* ev);
+void orc_p25rx_set_events(orc_p25rx* r, orc_hevents* ev);
 void orc_fsk4rx_init(orc_fsk4rx* r, const orc_fsk4_profile* p);
 /* per symbol: out_sym, rec4 {dibit, rel, llr0, llr1}, flags (1 in frame, 2 sync accepted, 4 negative, pattern index << 3
  * on the accepting symbol), pay2 {payload dibit, reliability}.  per accepted sync (up to max_sync): sync_pos (index of the

@@ -112,6 +112,15 @@ orc_p25rx_init(orc_p25rx* r, int out_rate_hz, int sym_rate_hz, int lock_symbols,
     orc_slicer_init(&r->sl, 0);
     r->lmin = r->sl.min;
     r->lmax = r->sl.max;
+    orc_p25h_init(&r->h, 64); /* p25p1_get_erasure_threshold() default */
+}
+
+void
+orc_p25rx_set_events(orc_p25rx* r, orc_hevents* ev) {
+    r->ev = ev;
+    if (ev) {
+        ev->n = 0;
+    }
 }
 
 /* noCarrier() as far as this loop can see it (engine.c:1838-1847) */
@@ -124,6 +133,7 @@ no_carrier(orc_p25rx* r) {
     r->sl.min = -15000.0f;
     r->sl.center = 0.0f;
     r->need_reset = 1; /* rtl_fsk_sps_num / _den = 0 */
+    orc_p25h_no_carrier(&r->h);
 }
 
 static void
@@ -284,7 +294,11 @@ symbol_commit(orc_p25rx* r, float sym, int rec4[4]) {
         s->negative = (r->lastsync == 2);
         orc_slicer_step(s, sym, rec4);
         int flags = 1 | (s->negative ? 4 : 0);
-        if (--r->lock_left <= 0) {
+        if (r->lock_symbols < 0) {
+            if (!orc_p25h_symbol(&r->h, r->n_sym, rec4[0], rec4[2], rec4[3], r->ev)) {
+                hunt_enter(r);
+            }
+        } else if (--r->lock_left <= 0) {
             hunt_enter(r);
         }
         return flags;
@@ -338,7 +352,9 @@ symbol_commit(orc_p25rx* r, float sym, int rec4[4]) {
                 r->have_sync = 1;
                 r->lock_left = r->lock_symbols;
                 flags |= 2 | (pol == 2 ? 4 : 0);
-                if (r->lock_left <= 0) {
+                if (r->lock_symbols < 0) {
+                    (void)orc_p25h_begin(&r->h);
+                } else if (r->lock_left <= 0) {
                     hunt_enter(r);
                 }
                 return flags;
@@ -373,6 +389,7 @@ orc_p25rx_run(orc_p25rx* r, const float* in, long n, float* out_sym, int* rec4, 
             r->in_symbol = 0;
             int rr[4];
             const int f = symbol_commit(r, sym, rr);
+            r->n_sym++;
             if (o < max_out) {
                 out_sym[o] = sym;
                 memcpy(rec4 + 4 * o, rr, sizeof(rr));

@@ -45,6 +45,17 @@ orc_fsk4rx_init(orc_fsk4rx* r, const orc_fsk4_profile* p) {
     orc_slicer_init(&r->sl, 0);
     r->lmin = r->sl.min;
     r->lmax = r->sl.max;
+    orc_p25h_init(&r->hp25, 64);
+    orc_dmrh_init(&r->hdmr);
+    orc_nxdnh_init(&r->hnxdn);
+}
+
+void
+orc_fsk4rx_set_events(orc_fsk4rx* r, orc_hevents* ev) {
+    r->ev = ev;
+    if (ev) {
+        ev->n = 0;
+    }
 }
 
 static void
@@ -56,6 +67,8 @@ no_carrier(orc_fsk4rx* r) { /* engine.c:1838-1847 as far as this loop sees it */
     r->sl.min = -15000.0f;
     r->sl.center = 0.0f;
     r->need_reset = 1;
+    orc_p25h_no_carrier(&r->hp25);
+    orc_dmrh_no_carrier(&r->hdmr);
 }
 
 static void
@@ -307,7 +320,24 @@ symbol_commit(orc_fsk4rx* r, float sym, int rec4[4], uint8_t pay2[2]) {
         r->phist[slot] = pay2[0];
         r->rhist[slot] = pay2[1];
         const int flags = 1 | (neg ? 4 : 0);
-        if (--r->lock_left <= 0) {
+        if (p->handler) {
+            int on;
+            if (p->proto == 0) {
+                on = orc_p25h_symbol(&r->hp25, r->n_sym, d, rec4[2], rec4[3], r->ev);
+            } else if (p->proto == 1) {
+                on = orc_dmrh_symbol(&r->hdmr, r->n_sym, pay2[0], pay2[1], r->ev);
+            } else {
+                int bad = 0;
+                on = orc_nxdnh_symbol(&r->hnxdn, r->n_sym, d, &bad, r->ev);
+                if (bad) { /* nxdn_mark_bad_sync(): lastsynctype NONE - the NXDN filter gate and the two-match rule see it */
+                    r->lastsync = 0;
+                    r->filter_on = 0;
+                }
+            }
+            if (!on) {
+                hunt_enter(r);
+            }
+        } else if (--r->lock_left <= 0) {
             hunt_enter(r);
         }
         return flags;
@@ -383,7 +413,30 @@ symbol_commit(orc_fsk4rx* r, float sym, int rec4[4], uint8_t pay2[2]) {
                     r->cur_pat = hit;
                     r->lock_left = p->lock_symbols[p->pat_class[hit] & 3];
                     flags |= 2 | (p->pat_neg[hit] ? 4 : 0) | (hit << 3);
-                    if (r->lock_left <= 0) {
+                    if (p->handler) {
+                        int on;
+                        if (p->proto == 0) {
+                            on = orc_p25h_begin(&r->hp25);
+                        } else if (p->proto == 1) {
+                            if (hit < 2) { /* BS data / BS voice words; the other types keep the configured count */
+                                uint8_t pre[ORC_FSK4_PRE], prel[ORC_FSK4_PRE];
+                                for (int i = 0; i < ORC_FSK4_PRE; i++) {
+                                    const int sl = (r->shead - ORC_FSK4_PRE + i + 4 * ORC_FSK4_HIST) % ORC_FSK4_HIST;
+                                    const int have = (ORC_FSK4_PRE - i) <= r->scount;
+                                    pre[i] = have ? r->phist[sl] : 0;
+                                    prel[i] = have ? r->rhist[sl] : 0;
+                                }
+                                on = orc_dmrh_begin(&r->hdmr, r->n_sym, p->pat_class[hit] & 1, pre, prel, r->ev);
+                            } else {
+                                on = orc_dmrh_begin_fixed(&r->hdmr, r->lock_left);
+                            }
+                        } else {
+                            on = orc_nxdnh_begin(&r->hnxdn);
+                        }
+                        if (!on) {
+                            hunt_enter(r);
+                        }
+                    } else if (r->lock_left <= 0) {
                         hunt_enter(r);
                     }
                     return flags;
@@ -421,6 +474,7 @@ orc_fsk4rx_run(orc_fsk4rx* r, const float* in, long n, float* out_sym, int* rec4
             int rr[4];
             uint8_t pp[2];
             const int f = symbol_commit(r, sym, rr, pp);
+            r->n_sym++;
             if (o < max_out) {
                 out_sym[o] = sym;
                 memcpy(rec4 + 4 * o, rr, sizeof(rr));

@@ -331,7 +331,25 @@ def synth_p25_disc(seed, n_ch, n, frame_dibits=864, sps=10, amp=7000.0, noise=40
     return x.astype(np.float32), dib, starts
 
 
+class HEvent(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("kind", C.c_int16), ("a", C.c_int16), ("b", C.c_int16), ("c", C.c_int16)]
+
+
+class HEvents(C.Structure):
+    """orc_hevents (oracle/ddn_oracle.h): the protocol handlers' event log"""
+    _fields_ = [("n", C.c_int), ("ev", HEvent * 4096)]
+
+    def rows(self):
+        return [(e.pos, e.kind, e.a, e.b, e.c) for e in self.ev[:min(self.n, 4096)]]
+
+
+HEV_P25_NID, HEV_P25_TSBK, HEV_P25_MPDU, HEV_NXDN_LICH, HEV_DMR_DATA, HEV_DMR_CC_PRINT, HEV_DMR_VOICE_BURST, HEV_DMR_VOICE_END = range(1, 9)
+
+
 class OracleP25Rx:
+    """lock_symbols = -1: the reference's per-DUID handlers decide the in-frame length (oracle/ddn_oracle_handlers.c);
+    .events.rows() then lists what they decoded"""
+
     def __init__(self, out_rate=48000, sym_rate=4800, lock_symbols=840, use_filter=1):
         o = oracle()
         o.orc_p25rx_sizeof.restype = C.c_size_t
@@ -342,6 +360,9 @@ class OracleP25Rx:
         self.o = o
         self.st = C.create_string_buffer(o.orc_p25rx_sizeof())
         o.orc_p25rx_init(self.st, out_rate, sym_rate, lock_symbols, use_filter)
+        self.events = HEvents()
+        o.orc_p25rx_set_events.argtypes = [C.c_void_p, C.c_void_p]
+        o.orc_p25rx_set_events(self.st, C.byref(self.events))
 
     def run(self, x):
         x = np.ascontiguousarray(x, np.float32)

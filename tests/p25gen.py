@@ -39,37 +39,72 @@ def crc16_ccitt(bytes10):
     return crc ^ 0xFFFF
 
 
-def make_frames(rng, n_frames, nac, crc=False):
-    """-> (dibits int8 [n_frames*180], states [n_frames,49]).  With crc=True every block is a well-formed TSBK: ten random
-    bytes + their CRC16, two bits per trellis state, flushed with a zero state."""
+def nid_dibits(nac, duid):
+    """32 NID dibits: BCH(63,16,11) code word of NAC + DUID, then the parity bit (1 for LDU1 / LDU2, TIA-102.BAAA table 8-4)"""
+    data16 = [(nac >> (11 - k)) & 1 for k in range(12)] + [(duid >> (3 - k)) & 1 for k in range(4)]
+    cw = list(fecgen.bch_63_16_encode(data16)) + [1 if duid in (0x5, 0xA) else 0]
+    return [(cw[2 * k] << 1) | cw[2 * k + 1] for k in range(32)]
+
+
+def frame_len(blocks):
+    """TSDU length in dibits: 24 FS + 32 NID + 98 per block, a status symbol after every 35, padded to a status boundary"""
+    return -(-(56 + 98 * blocks) // 35) * 36
+
+
+def make_frames(rng, n_frames, nac, crc=False, blocks=1):
+    """-> (dibits int8 [n_frames * frame_len(blocks)], states [n_frames * blocks, 49]).  With crc=True every block is a
+    well-formed TSBK: ten random bytes + their CRC16 (the last-block flag - bit 7 of byte 0, p25p1_tsbk.c:1065 - set on the
+    frame's last block only), two bits per trellis state, flushed with a zero state."""
     t = fecgen.tables()
     il = t["il"].astype(np.int64)
-    st = rng.integers(0, 4, (n_frames, 49)).astype(np.int64)
+    nb = n_frames * blocks
+    st = rng.integers(0, 4, (nb, 49)).astype(np.int64)
     if crc:
-        for f in range(n_frames):
+        for f in range(nb):
             pay = rng.integers(0, 256, 10)
+            pay[0] = (int(pay[0]) & 0x7F) | (0x80 if (f % blocks) == blocks - 1 else 0)
             c = crc16_ccitt(pay)
             bits = np.unpackbits(np.array(list(pay) + [c >> 8, c & 0xFF], np.uint8)).astype(np.int64)
             st[f, :48] = (bits[0::2] << 1) | bits[1::2]
             st[f, 48] = 0
-    prev = np.concatenate([np.zeros((n_frames, 1), np.int64), st[:, :-1]], axis=1)
+    prev = np.concatenate([np.zeros((nb, 1), np.int64), st[:, :-1]], axis=1)
     nib = t["half"][(prev << 2) | st].astype(np.int64)
-    dei = np.stack([(nib >> 2) & 3, nib & 3], axis=2).reshape(n_frames, 98)   # deinterleaved dibits
-    tx = dei[:, il]                                                          # transmit order
-    data16 = [(nac >> (11 - k)) & 1 for k in range(12)] + [(DUID_TSBK >> (3 - k)) & 1 for k in range(4)]
-    cw = list(fecgen.bch_63_16_encode(data16)) + [0]                          # parity bit 0 for DUID 7
-    nid = [(cw[2 * k] << 1) | cw[2 * k + 1] for k in range(32)]
-    out = np.zeros((n_frames, FRAME), np.int8)
-    bp = block_positions()
+    dei = np.stack([(nib >> 2) & 3, nib & 3], axis=2).reshape(nb, 98)   # deinterleaved dibits
+    tx = dei[:, il]                                                     # transmit order
+    nid = nid_dibits(nac, DUID_TSBK)
+    flen = frame_len(blocks)
+    out = np.zeros((n_frames, flen), np.int8)
+    stat = list(range(35, flen, 36))
+    pay_pos = [p for p in range(24, flen) if p not in stat]
     for f in range(n_frames):
-        fr = np.zeros(FRAME, np.int8)
+        fr = np.zeros(flen, np.int8)
         fr[:24] = orc.P25_FS_DIBITS
-        nid_pos = [p for p in range(24, 57) if p != 35]
-        fr[nid_pos] = nid
-        fr[bp] = tx[f]
-        fr[status_positions()] = 2
+        fr[pay_pos[:32]] = nid
+        fr[pay_pos[32:32 + 98 * blocks]] = tx[f * blocks:(f + 1) * blocks].reshape(-1)
+        fr[stat] = 2
         out[f] = fr
     return out.reshape(-1), st
+
+
+def frame_with_duid(rng, nac, duid, n_body):
+    """FS + NID of the given DUID + n_body random dibits (status symbols 2 where the frame has them)"""
+    fr = np.zeros(24 + 33 + n_body, np.int8)
+    fr[:24] = orc.P25_FS_DIBITS
+    fr[24:] = rng.integers(0, 4, 33 + n_body)
+    nid_pos = [p for p in range(24, 57) if p != 35]
+    fr[nid_pos] = nid_dibits(nac, duid)
+    fr[35::36] = 2
+    return fr
+
+
+def modulate_disc(dibits, lead=300, noise=100.0, seed=0, sps=10, amp=7000.0, tail=400):
+    """Dibit stream -> discriminator-scale float32 samples (smoothed 4-level), `lead` noise-only samples first"""
+    rng = np.random.default_rng(seed)
+    win = np.hanning(sps + 3)[1:-1]
+    win /= win.sum()
+    shaped = np.convolve(np.repeat(_LEVEL[dibits], sps), win, mode="same") * amp
+    x = np.concatenate([np.zeros(lead), shaped, np.zeros(tail)])
+    return (x + rng.normal(0.0, noise, x.shape)).astype(np.float32)
 
 
 def modulate_cu8(dibits, n, sps=10, dev=0.06, lead=230, seed=0, noise=0.02):

@@ -41,7 +41,7 @@ class Profile(C.Structure):
                 ("warm_len", C.c_int), ("n_pat", C.c_int), ("pat_bits", C.c_uint32 * MAX_PAT), ("pat_type", C.c_uint8 * MAX_PAT),
                 ("pat_neg", C.c_uint8 * MAX_PAT), ("pat_class", C.c_uint8 * MAX_PAT), ("confirm", C.c_int),
                 ("live_thresholds", C.c_int), ("dmr_window", C.c_int), ("redigitize", C.c_int), ("slow_type", C.c_int),
-                ("use_filter", C.c_int), ("nt", C.c_int), ("taps", C.c_uint32 * MAX_TAPS), ("lock_symbols", C.c_int * 4)]
+                ("use_filter", C.c_int), ("nt", C.c_int), ("taps", C.c_uint32 * MAX_TAPS), ("lock_symbols", C.c_int * 4), ("handler", C.c_int), ("proto", C.c_int)]
 
 
 def _taps(name):
@@ -53,8 +53,9 @@ def _taps(name):
     return [int(x.rstrip("u"), 16) for x in re.findall(r"0x[0-9a-f]+u", m.group(1))]
 
 
-def profile(proto, rf_mod=0, use_filter=1, lock=None, out_rate=48000, inverted=0):
+def profile(proto, rf_mod=0, use_filter=1, lock=None, out_rate=48000, inverted=0, handler=0):
     p = Profile()
+    p.handler, p.proto = handler, proto
     p.out_rate, p.rf_mod, p.use_filter = out_rate, rf_mod, use_filter
     pats = []
     if proto == PROTO_P25P1:
@@ -110,6 +111,9 @@ class OracleFsk4Rx:
         self.o, self.prof = o, prof
         self.st = C.create_string_buffer(o.orc_fsk4rx_sizeof())
         o.orc_fsk4rx_init(self.st, C.byref(prof))
+        self.events = orc.HEvents()
+        o.orc_fsk4rx_set_events.argtypes = [C.c_void_p, C.c_void_p]
+        o.orc_fsk4rx_set_events(self.st, C.byref(self.events))
 
     def run(self, x, max_sync=None):
         """-> dict(sym, rec4, fl, pay [k][2], sync_pos, sync_pat, pre [ns][90], pre_rel)"""
