@@ -119,6 +119,10 @@ PROTOTYPES = {
     "ddn_p25_rx_reset": (C.c_int, [C.c_void_p]),
     "ddn_p25_rx_set_lock_symbols": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_rx_set_channels_per_wave": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_p25_rx_set_handlers": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ddn_p25_rx_set_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ddn_p25_rx_run_host_ev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p, C.c_size_t]),
     "ddn_p25_rx_max_symbols": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "ddn_p25_rx_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
@@ -551,16 +555,22 @@ class P25Rx:
     """Batched fixed-protocol P25p1 receive loop (ddn_p25_rx_*), host-buffer convenience wrapper."""
 
     def __init__(self, n_channels, out_rate=48000, sym_rate=4800, lock_symbols=840, use_matched_filter=1,
-                 channels_per_wave=0):
+                 channels_per_wave=0, handlers=False, max_events=0):
+        """handlers=True: the reference's per-DUID handlers decide the in-frame length (lock_symbols unused); run() then
+        also leaves .events int32 [B, max_events, 4] / .n_events int32 [B] of the call"""
         import numpy as np
         self.np = np
         self.B = n_channels
-        cfg = P25RxConfig(n_channels, out_rate, sym_rate, lock_symbols, use_matched_filter)
+        cfg = P25RxConfig(n_channels, out_rate, sym_rate, max(lock_symbols, 0), use_matched_filter)
         self.h = C.c_void_p()
         rc = lib().ddn_p25_rx_create(C.byref(cfg), C.byref(self.h))
         _check(-abs(rc), "ddn_p25_rx_create")
         if channels_per_wave:
             assert lib().ddn_p25_rx_set_channels_per_wave(self.h, channels_per_wave) == 0
+        self.handlers = bool(handlers)
+        self.max_events = max_events or 4096
+        if handlers:
+            assert lib().ddn_p25_rx_set_handlers(self.h, 1, 64) == 0
 
     def run(self, disc):
         """disc float32 [B, n] -> (records uint8 [B, max_sym, 10], flags uint8 [B, max_sym], counts int32 [B])."""
@@ -571,7 +581,13 @@ class P25Rx:
         rec = np.zeros((self.B, ms, 10), np.uint8)
         fl = np.zeros((self.B, ms), np.uint8)
         cnt = np.zeros(self.B, np.int32)
-        rc = lib().ddn_p25_rx_run_host(self.h, disc.ctypes.data, n, rec.ctypes.data, fl.ctypes.data, cnt.ctypes.data, ms)
+        if self.handlers:
+            self.events = np.zeros((self.B, self.max_events, 4), np.int32)
+            self.n_events = np.zeros(self.B, np.int32)
+            rc = lib().ddn_p25_rx_run_host_ev(self.h, disc.ctypes.data, n, rec.ctypes.data, fl.ctypes.data, cnt.ctypes.data, ms, self.events.ctypes.data,
+                   self.n_events.ctypes.data, self.max_events)
+        else:
+            rc = lib().ddn_p25_rx_run_host(self.h, disc.ctypes.data, n, rec.ctypes.data, fl.ctypes.data, cnt.ctypes.data, ms)
         _check(-abs(rc), "ddn_p25_rx_run_host")
         return rec, fl, cnt
 

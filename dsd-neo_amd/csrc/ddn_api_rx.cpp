@@ -31,6 +31,14 @@ struct ddn_p25_rx {
     size_t filt_cap;
     int channels_per_wave;
     int32_t* d_lock; // [B] in-frame symbols after a sync, per channel (cfg.lock_symbols unless overridden)
+    // handler mode (ddn_p25_rx_set_handlers): per-channel handler words, the in-frame history ring [B][128][4] f32, the
+    // caller's event buffers (or a one-event dummy of our own)
+    int handlers, nid_threshold;
+    DdnP25HState* d_hstate;
+    float* d_hh;
+    int32_t *d_events, *d_n_events;
+    size_t max_events;
+    int32_t *d_ev_dummy, *d_nev_dummy;
     bool timing;
     hipEvent_t ev[3];
     float last_ms[2]; // matched filter, receive-loop kernel
@@ -52,6 +60,10 @@ rx_free(ddn_p25_rx* b) {
     (void)hipFree(b->d_fstale);
     (void)hipFree(b->d_filt);
     (void)hipFree(b->d_lock);
+    (void)hipFree(b->d_hstate);
+    (void)hipFree(b->d_hh);
+    (void)hipFree(b->d_ev_dummy);
+    (void)hipFree(b->d_nev_dummy);
     for (int i = 0; i < 3; i++) {
         if (b->ev[i]) {
             (void)hipEventDestroy(b->ev[i]);
@@ -96,7 +108,9 @@ rx_fill(ddn_p25_rx* b) {
         || hipMemset(b->d_minring, 0, sizeof(float) * 1024 * B) != hipSuccess
         || hipMemset(b->d_maxring, 0, sizeof(float) * 1024 * B) != hipSuccess
         || hipMemset(b->d_fhist, 0, sizeof(float) * 90 * B) != hipSuccess
-        || hipMemset(b->d_fstale, 0, sizeof(float) * 90 * B) != hipSuccess) {
+        || hipMemset(b->d_fstale, 0, sizeof(float) * 90 * B) != hipSuccess
+        || hipMemset(b->d_hstate, 0, sizeof(DdnP25HState) * B) != hipSuccess
+        || hipMemset(b->d_hh, 0, sizeof(float) * 4 * 128 * B) != hipSuccess) {
         ddn_set_error("p25 rx state upload failed");
         return DDN_EHIP;
     }
@@ -136,6 +150,10 @@ ddn_p25_rx_create(const ddn_p25_rx_config* cfg, ddn_p25_rx** out) {
         || hipMalloc(&b->d_maxring, sizeof(float) * 1024 * B) != hipSuccess
         || hipMalloc(&b->d_fhist, sizeof(float) * 90 * B) != hipSuccess
         || hipMalloc(&b->d_fstale, sizeof(float) * 90 * B) != hipSuccess
+        || hipMalloc(&b->d_hstate, sizeof(DdnP25HState) * B) != hipSuccess
+        || hipMalloc(&b->d_hh, sizeof(float) * 4 * 128 * B) != hipSuccess
+        || hipMalloc(&b->d_ev_dummy, sizeof(int32_t) * 4 * B) != hipSuccess
+        || hipMalloc(&b->d_nev_dummy, sizeof(int32_t) * B) != hipSuccess
         || hipMalloc(&b->d_lock, sizeof(int32_t) * B) != hipSuccess || rx_fill(b) != DDN_OK
         || ddn_p25_rx_set_lock_symbols(b, nullptr) != DDN_OK) {
         ddn_set_error("ddn_p25_rx_create: device allocation failed");
@@ -182,6 +200,31 @@ ddn_p25_rx_set_lock_symbols(ddn_p25_rx* b, const int32_t* per_channel) {
         }
     }
     HIP_TRY(hipMemcpy(b->d_lock, v.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_rx_set_handlers(ddn_p25_rx* b, int enable, int nid_erasure_threshold) {
+    if (!b || nid_erasure_threshold > 255) {
+        return DDN_EINVAL;
+    }
+    if (enable && b->cfg.out_rate_hz / b->cfg.sym_rate_hz < 6) {
+        ddn_set_error("ddn_p25_rx_set_handlers: needs at least 6 samples per symbol");
+        return DDN_ERANGE;
+    }
+    b->handlers = enable ? 1 : 0;
+    b->nid_threshold = nid_erasure_threshold > 0 ? nid_erasure_threshold : 64;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_rx_set_events(ddn_p25_rx* b, int32_t* d_events, int32_t* d_n_events, size_t max_events) {
+    if (!b || ((d_events == nullptr) != (d_n_events == nullptr)) || (d_events && max_events == 0) || max_events > 0x7FFFFFFF) {
+        return DDN_EINVAL;
+    }
+    b->d_events = d_events;
+    b->d_n_events = d_n_events;
+    b->max_events = d_events ? max_events : 0;
     return DDN_OK;
 }
 
@@ -251,13 +294,15 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
         HIP_TRY(hipEventRecord(b->ev[1], st));
         HIP_TRY(hipEventRecord(rv[1], st));
     }
-    DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0};
+    DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0,
+                      b->handlers, b->nid_threshold, b->d_events ? (int)b->max_events : 1};
     if (const char* e = getenv("DDN_RX_DBG")) {
         dc.dbg = atoi(e);
     }
     HIP_TRY(ddn_dev_p25_rx(d_disc, b->d_filt, b->d_fhist, b->d_fstale, (long)n, n, B, &dc, b->d_state, b->d_sbuf, b->d_lbuf,
                            b->d_shist, b->d_minring, b->d_maxring, d_records10, d_flags, d_counts, max_symbols,
-                           b->channels_per_wave, b->d_lock, st));
+                           b->channels_per_wave, b->d_lock, b->d_hstate, b->d_hh, b->d_events ? b->d_events : b->d_ev_dummy,
+                           b->d_n_events ? b->d_n_events : b->d_nev_dummy, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
         HIP_TRY(hipEventRecord(rv[2], st));
@@ -324,40 +369,66 @@ ddn_p25_rx_get_timing(ddn_p25_rx* b, float* ms2) {
 }
 
 extern "C" int
-ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
-                    size_t max_symbols) {
-    if (!b || !disc || !records10 || !flags || !counts) {
+ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
+                       size_t max_symbols, int32_t* events, int32_t* n_events, size_t max_events) {
+    if (!b || !disc || !records10 || !flags || !counts || ((events == nullptr) != (n_events == nullptr))
+        || (events && max_events == 0)) {
         return DDN_EINVAL;
     }
     const size_t B = (size_t)b->cfg.n_channels;
     float* d_in = nullptr;
     uint8_t *d_rec = nullptr, *d_fl = nullptr;
-    int32_t* d_cnt = nullptr;
+    int32_t *d_cnt = nullptr, *d_ev = nullptr, *d_nev = nullptr;
+    int32_t* const keep_ev = b->d_events;
+    int32_t* const keep_nev = b->d_n_events;
+    const size_t keep_max = b->max_events;
     int rc;
     if (hipMalloc(&d_in, B * n * 4 + 4) != hipSuccess || hipMalloc(&d_rec, B * max_symbols * 10 + 4) != hipSuccess
-        || hipMalloc(&d_fl, B * max_symbols + 4) != hipSuccess || hipMalloc(&d_cnt, B * 4) != hipSuccess) {
+        || hipMalloc(&d_fl, B * max_symbols + 4) != hipSuccess || hipMalloc(&d_cnt, B * 4) != hipSuccess
+        || (events && (hipMalloc(&d_ev, B * max_events * 16) != hipSuccess || hipMalloc(&d_nev, B * 4) != hipSuccess))) {
         ddn_set_error("ddn_p25_rx_run_host: device allocation failed (no device?)");
         rc = DDN_ENODEV;
     } else if (hipMemcpy(d_in, disc, B * n * 4, hipMemcpyHostToDevice) != hipSuccess
                || hipMemset(d_rec, 0, B * max_symbols * 10) != hipSuccess
-               || hipMemset(d_fl, 0, B * max_symbols) != hipSuccess) {
+               || hipMemset(d_fl, 0, B * max_symbols) != hipSuccess
+               || (events && (hipMemset(d_ev, 0, B * max_events * 16) != hipSuccess || hipMemset(d_nev, 0, B * 4) != hipSuccess))) {
         rc = DDN_EHIP;
     } else {
+        if (events) {
+            b->d_events = d_ev;
+            b->d_n_events = d_nev;
+            b->max_events = max_events;
+        }
         rc = ddn_p25_rx_run(b, d_in, n, d_rec, d_fl, d_cnt, max_symbols, nullptr);
         if (rc == DDN_OK
             && (hipDeviceSynchronize() != hipSuccess
                 || hipMemcpy(records10, d_rec, B * max_symbols * 10, hipMemcpyDeviceToHost) != hipSuccess
                 || hipMemcpy(flags, d_fl, B * max_symbols, hipMemcpyDeviceToHost) != hipSuccess
-                || hipMemcpy(counts, d_cnt, B * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+                || hipMemcpy(counts, d_cnt, B * 4, hipMemcpyDeviceToHost) != hipSuccess
+                || (events
+                    && (hipMemcpy(events, d_ev, B * max_events * 16, hipMemcpyDeviceToHost) != hipSuccess
+                        || hipMemcpy(n_events, d_nev, B * 4, hipMemcpyDeviceToHost) != hipSuccess)))) {
             ddn_set_error("ddn_p25_rx_run_host: %s", hipGetErrorString(hipGetLastError()));
             rc = DDN_EHIP;
         }
     }
+    b->d_events = keep_ev;
+    b->d_n_events = keep_nev;
+    b->max_events = keep_max;
+    (void)hipDeviceSynchronize();
     (void)hipFree(d_in);
     (void)hipFree(d_rec);
     (void)hipFree(d_fl);
     (void)hipFree(d_cnt);
+    (void)hipFree(d_ev);
+    (void)hipFree(d_nev);
     return rc;
+}
+
+extern "C" int
+ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
+                    size_t max_symbols) {
+    return ddn_p25_rx_run_host_ev(b, disc, n, records10, flags, counts, max_symbols, nullptr, nullptr, 0);
 }
 
 extern "C" int

@@ -17,278 +17,9 @@
 #include <stdint.h>
 
 #include "ddn_device.h"
+#include "ddn_nid_dev.h"
 
-namespace {
-
-struct Gf {
-    const uint8_t* ex; // [128]
-    const uint8_t* lg; // [64]
-    __device__ __forceinline__ int mul(int a, int b) const { return (a && b) ? ex[lg[a] + lg[b]] : 0; }
-    __device__ __forceinline__ int div(int a, int b) const { return a ? ex[lg[a] + 63 - lg[b]] : 0; }
-};
-
-__device__ void
-gf_fill(uint8_t* ex, uint8_t* lg) { // one thread
-    int x = 1;
-    for (int i = 0; i < 63; i++) {
-        ex[i] = (uint8_t)x;
-        ex[i + 63] = (uint8_t)x;
-        lg[x] = (uint8_t)i;
-        x <<= 1;
-        if (x & 64) {
-            x ^= 0x43; // x^6 = x + 1
-        }
-    }
-    ex[126] = ex[0];
-    ex[127] = ex[1];
-    lg[0] = 0;
-}
-
-// Per-lane working arrays live in LDS, element k of this lane at base[k * 64] (no scratch memory, no bank
-// conflicts beyond byte-in-word sharing).  Exponent arithmetic mod 63 uses running sums with a conditional
-// subtract instead of integer division.
-struct Work {
-    uint8_t* S; // [23]
-    uint8_t* C; // [24]
-    uint8_t* B; // [24]
-    uint8_t* T; // [24]
-    __device__ __forceinline__ uint8_t& s(int i) const { return S[i * 64]; }
-    __device__ __forceinline__ uint8_t& c(int i) const { return C[i * 64]; }
-    __device__ __forceinline__ uint8_t& b(int i) const { return B[i * 64]; }
-    __device__ __forceinline__ uint8_t& t(int i) const { return T[i * 64]; }
-};
-
-// w: bit p = received bit at input position p (0..62; data 0..15 MSB-first, parity 16..62).
-// Returns 1 on success with *fixed = corrected word and *nerr = flipped bits.
-__device__ int
-bch_63_16_decode(const Gf& gf, const Work& wk, uint64_t w, uint64_t* fixed, int* nerr) {
-    // Odd syndromes S1,S3,..,S21 accumulate in registers (static indices); even ones follow from the binary-code
-    // identity S_2i = S_i^2.  Running exponent e = i*j mod 63 advances by 2j per odd step.
-    int so[11];
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-        so[k] = 0;
-    }
-    {
-        uint64_t m = w;
-        while (m) {
-            const int p = __builtin_ctzll(m);
-            m &= m - 1;
-            const int j = 62 - p; // r-index of this bit; contributes alpha^(i*j) to S_i
-            int j2 = 2 * j;
-            if (j2 >= 63) {
-                j2 -= 63;
-            }
-            int e = j;
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                so[k] ^= gf.ex[e];
-                e += j2;
-                if (e >= 63) {
-                    e -= 63;
-                }
-            }
-        }
-    }
-    int any = 0;
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-        wk.s(2 * k + 1) = (uint8_t)so[k];
-        any |= so[k];
-    }
-    for (int i = 2; i <= 22; i += 2) { // S_i = (S_{i/2})^2, ascending so the source is already final
-        const int h = wk.s(i / 2);
-        wk.s(i) = (uint8_t)(h ? gf.ex[(2 * gf.lg[h]) % 63] : 0);
-    }
-    *nerr = 0;
-    *fixed = w;
-    if (!any) {
-        return 1;
-    }
-    for (int i = 0; i < 24; i++) {
-        wk.c(i) = 0;
-        wk.b(i) = 0;
-    }
-    wk.c(0) = 1;
-    wk.b(0) = 1;
-    int L = 0, m = 1, b = 1;
-    for (int n = 0; n < 22; n++) {
-        int d = wk.s(n + 1);
-        for (int i = 1; i <= L; i++) {
-            d ^= gf.mul(wk.c(i), wk.s(n + 1 - i));
-        }
-        if (d == 0) {
-            m++;
-            continue;
-        }
-        const int f = gf.div(d, b);
-        if (2 * L <= n) {
-            for (int i = 0; i < 24; i++) {
-                wk.t(i) = wk.c(i);
-            }
-            for (int i = 0; i + m < 24; i++) {
-                wk.c(i + m) ^= (uint8_t)gf.mul(f, wk.b(i));
-            }
-            L = n + 1 - L;
-            for (int i = 0; i < 24; i++) {
-                wk.b(i) = wk.t(i);
-            }
-            b = d;
-            m = 1;
-        } else {
-            for (int i = 0; i + m < 24; i++) {
-                wk.c(i + m) ^= (uint8_t)gf.mul(f, wk.b(i));
-            }
-            m++;
-        }
-        if (L > 11) {
-            return 0;
-        }
-    }
-    // Chien search: root alpha^i <-> error at r-index 63-i <-> input position i-1.  The <= 12 coefficients move
-    // to registers (static indices, terms above L predicated off); te[k] is the running exponent
-    // log(C[k]) + i*k (mod 63) of term k.
-    int te[12];
-    bool on[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-        const int ck = (k <= L) ? wk.c(k) : 0;
-        on[k] = ck != 0;
-        te[k] = ck ? gf.lg[ck] : 0;
-    }
-    int count = 0;
-    uint64_t flips = 0;
-    for (int i = 1; i <= 63; i++) {
-        int q = 0;
-#pragma unroll
-        for (int k = 0; k < 12; k++) {
-            int e = te[k] + k;
-            if (e >= 63) {
-                e -= 63;
-            }
-            te[k] = e;
-            q ^= on[k] ? gf.ex[e] : 0;
-        }
-        if (q == 0) {
-            if (count >= 11) {
-                break;
-            }
-            const int loc = (63 - i) % 63;
-            flips |= 1ull << (62 - loc);
-            count++;
-        }
-    }
-    if (count != L) {
-        return 0;
-    }
-    *fixed = w ^ flips;
-    *nerr = count;
-    return 1;
-}
-
-struct NidRes {
-    int status, nac, duid, errs;
-};
-
-__device__ NidRes
-nid_codeword(const Gf& gf, const Work& wk, uint64_t w, int parity, int* bch_failed) {
-    NidRes r = {0, 0, 0, 0};
-    uint64_t fixed;
-    int errs;
-    if (bch_failed) {
-        *bch_failed = 0;
-    }
-    if (!bch_63_16_decode(gf, wk, w, &fixed, &errs)) {
-        if (bch_failed) {
-            *bch_failed = 1;
-        }
-        return r;
-    }
-    r.errs = errs;
-    int nac = 0, duid = 0;
-    for (int i = 0; i < 12; i++) {
-        nac = (nac << 1) | (int)((fixed >> i) & 1);
-    }
-    for (int i = 12; i < 16; i++) {
-        duid = (duid << 1) | (int)((fixed >> i) & 1);
-    }
-    r.nac = nac;
-    r.duid = duid;
-    // DUIDs defined by TIA-102.BAAA-A table 8-4: 0 HDU, 3 TDU, 5 LDU1, 7 TSDU, A LDU2, C PDU, F TDULC
-    const unsigned valid = (1u << 0) | (1u << 3) | (1u << 5) | (1u << 7) | (1u << 10) | (1u << 12) | (1u << 15);
-    if (!((valid >> duid) & 1u)) {
-        r.errs = 0;
-        return r;
-    }
-    const int want = (duid == 5 || duid == 10) ? 1 : 0;
-    r.status = (want == parity) ? 1 : 2;
-    return r;
-}
-
-__device__ __forceinline__ int
-rx_nac(uint64_t w) {
-    int n = 0;
-    for (int i = 0; i < 12; i++) {
-        n = (n << 1) | (int)((w >> i) & 1);
-    }
-    return n;
-}
-
-__device__ __forceinline__ uint64_t
-put_nac(uint64_t w, int nac) {
-    for (int i = 0; i < 12; i++) {
-        const uint64_t bit = (uint64_t)((nac >> (11 - i)) & 1);
-        w = (w & ~(1ull << i)) | (bit << i);
-    }
-    return w;
-}
-
-struct ChaseBest {
-    int found;
-    NidRes dec;
-    int score, changes;
-};
-
-__device__ void
-chase_from(const Gf& gf, const Work& wk, uint64_t base, const uint8_t* rel, uint64_t pool, int np, int parity, int parity_rel,
-           int threshold, ChaseBest* best) {
-    for (int mask = 0; mask < (1 << np); mask++) {
-        const int changed = __popc((unsigned)mask);
-        if (changed > 3) {
-            continue;
-        }
-        uint64_t cand = base;
-        int score = 0;
-        for (int b = 0; b < np; b++) {
-            if (mask & (1 << b)) {
-                const int pos = (int)((pool >> (8 * b)) & 0xFF);
-                cand ^= 1ull << pos;
-                score += rel[pos];
-            }
-        }
-        if (changed && score > threshold * changed) {
-            continue;
-        }
-        const NidRes dec = nid_codeword(gf, wk, cand, parity, nullptr);
-        if (dec.status <= 0) {
-            continue;
-        }
-        const int sc = score + (dec.status == 2 ? parity_rel : 0);
-        const bool better = !best->found || sc < best->score
-                            || (sc == best->score && dec.status == 1 && best->dec.status != 1)
-                            || (sc == best->score && dec.status == best->dec.status && dec.errs < best->dec.errs)
-                            || (sc == best->score && dec.status == best->dec.status && dec.errs == best->dec.errs
-                                && changed < best->changes);
-        if (better) {
-            best->found = 1;
-            best->dec = dec;
-            best->score = sc;
-            best->changes = changed;
-        }
-    }
-}
-
-} // namespace
+using namespace ddn_nid;
 
 __global__ __launch_bounds__(64) void
 k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel63, const int32_t* __restrict__ obs_nac,

@@ -66,7 +66,14 @@ typedef struct DdnSlicerState { /* per-channel slicer words of dsd_state the P25
 typedef struct DdnRxConfig { /* fixed-protocol P25p1 receive loop (ddn_rx.hip) */
     int out_rate, sym_rate, lock_symbols, use_filter;
     int dbg; /* profiling only (env DDN_RX_DBG): 1 = skip symbol commit, 2 = skip record stores, 4 = skip sample loop body */
+    int handlers;      /* 1 = the reference's per-DUID handlers decide the in-frame length (lock_symbols ignored) */
+    int nid_threshold; /* p25p1_get_erasure_threshold() */
+    int max_events;    /* capacity of the per-channel event list */
 } DdnRxConfig;
+
+typedef struct DdnP25HState { /* per-channel words of the P25p1 handlers (ddn_p25h_dev.h) carried across calls */
+    int phase, block, end, skipdibit, nac, p2_cc, r0, r1;
+} DdnP25HState;
 
 typedef struct DdnRxState { /* per-channel words of dsd_state / frame_sync_runtime_ctx the P25p1 loop carries */
     double min_sum, max_sum;
@@ -81,6 +88,10 @@ typedef struct DdnRxState { /* per-channel words of dsd_state / frame_sync_runti
     uint32_t hist_bits;
     int hunt_pos;   /* rt.synctest_pos: symbols hunted since the hunt (re)started */
     int need_reset; /* noCarrier() ran: the next symbol start re-initialises timing and slicer */
+    /* handler mode: hphase != 0 = a handler decision falls due when lock_left runs out (1 the NID, 2 a trellis block);
+       hw = symbols written to the in-frame history ring; hn = symbols of the current phase; hnc = noCarrier() ran since the
+       last NID (the handlers' NAC memory is cleared with it, engine.c:1889) */
+    int hphase, hw, hn, hnc;
 } DdnRxState;
 
 /* ---- profile-driven 4-level FSK receive loop (DMR / NXDN48), ddn_rx4.hip ---- */
@@ -147,7 +158,8 @@ hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev
                           int n_channels, const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store,
                           float* lbuf_store, float* shist_store, float* minring, float* maxring, uint8_t* rec,
                           uint8_t* flags, int32_t* counts, size_t max_sym, int channels_per_wave,
-                          const int32_t* lock_cfg, hipStream_t st);
+                          const int32_t* lock_cfg, DdnP25HState* hstate, float* hh_store, int32_t* events,
+                          int32_t* n_events, hipStream_t st);
 hipError_t ddn_dev_fsk4_matched_filter(int nt, const float* in, long n, size_t stride, int n_channels, const float* hist,
                                        float* out, hipStream_t st);
 hipError_t ddn_dev_fsk4_filter_hist_update(int nt, const float* in, long n, size_t stride, int n_channels, float* hist,

@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "ddn_device.h"
+#include "ddn_p25h_dev.h"
 #include "ddn_slicer_dev.h"
 #include "ddn_tables_p25.h"
 
@@ -685,19 +686,309 @@ struct LdsW {
     int sidx0[2][CPW];        // [tile parity] ring slot of the oldest entry at the start of that tile
 };
 
+// Handler mode (HM): a fourth wave answers, one decision at a time, how long the frame a lane is in goes on (ddn_p25h_dev.h).
+// The recurrence wave keeps every in-frame symbol of a phase that ends in a decision - {symbol, max, min, flags}, what wave 1
+// slices from - in a per-channel history ring, posts a request when the phase's last symbol is in, and that lane sits out until
+// the answer is there (the other lanes go on; the tile does not end while a lane waits).
 template <int CPW>
-__global__ __launch_bounds__(192) void
+struct LdsH {
+    alignas(16) float hh[ddn_p25h::HN][CPW][4];
+    int req_seq[CPW], req_kind[CPW], req_hw[CPW], req_n[CPW], req_o[CPW], req_neg[CPW], req_nc[CPW];
+    int rsp_seq[CPW], rsp_ext[CPW], rsp_more[CPW];
+    int tile_done;
+    ddn_p25h::Scratch sc;
+};
+
+template <int CPW, bool HM>
+__global__ __launch_bounds__(HM ? 256 : 192) void
 k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
           float* __restrict__ fstale, long n,
           size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
           float* __restrict__ lbuf_store, float* __restrict__ shist_store, float* __restrict__ minring,
           float* __restrict__ maxring, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags,
-          int32_t* __restrict__ counts, size_t max_sym, const int32_t* __restrict__ lock_cfg) {
+          int32_t* __restrict__ counts, size_t max_sym, const int32_t* __restrict__ lock_cfg,
+          DdnP25HState* __restrict__ hstate, float* __restrict__ hh_store, int32_t* __restrict__ events,
+          int32_t* __restrict__ n_events) {
     constexpr int TW = LdsW<CPW>::TW, RTW = LdsW<CPW>::RTW, WMW = LdsW<CPW>::WMW, QTW = LdsW<CPW>::QTW;
     (void)RTW;
     extern __shared__ unsigned char smem_raw[];
     LdsW<CPW>& L = *reinterpret_cast<LdsW<CPW>*>(smem_raw);
+    LdsH<CPW>& H = *reinterpret_cast<LdsH<CPW>*>(smem_raw + ((sizeof(LdsW<CPW>) + 15) & ~(size_t)15));
+    const bool hwave = HM && (threadIdx.x >> 6) == 3; // wave 3: the handlers' decisions
     const int lane = threadIdx.x & 63;
+    if (HM && hwave) {
+        // The handler wave runs its own path from here on (its decoders would otherwise be allocated on top of the
+        // recurrence's live registers); it meets the other waves at the same workgroup barriers: two before the tile loop,
+        // one per tile.
+        const int ch0 = blockIdx.x * CPW;
+        const int ch = ch0 + lane;
+        auto wg_barrier = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+    // handler wave: its per-channel words (lane = channel), the history ring, the mailboxes, the decoder tables
+    DdnP25HState hs = DdnP25HState{};
+    int h_served = 0, h_nev = 0;
+    const bool hlive = hwave && lane < CPW && ch < n_channels;
+    {
+        if (hlive) {
+            hs = hstate[ch];
+        }
+        for (int k = lane; k < ddn_p25h::HN * CPW; k += 64) {
+            const int c = k % CPW, slot = k / CPW;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (ch0 + c < n_channels) {
+                v = *reinterpret_cast<const float4*>(hh_store + ((size_t)(ch0 + c) * ddn_p25h::HN + slot) * 4);
+            }
+            *reinterpret_cast<float4*>(&H.hh[slot][c][0]) = v;
+        }
+        if (lane < CPW) {
+            H.req_seq[lane] = 0;
+            H.rsp_seq[lane] = 0;
+        }
+        if (lane == 0) {
+            H.tile_done = 0;
+            ddn_nid::gf_fill(H.sc.ex, H.sc.lg);
+            ddn_nid::chase_masks_fill(H.sc.masks);
+        }
+    }
+        wg_barrier();
+        wg_barrier();
+    // ---- handler wave: one decision, the whole wavefront on it (c and seq are wave-uniform) -------------------------------
+    auto serve = [&](int c, int seq) {
+        using namespace ddn_p25h;
+        Scratch& sc = H.sc;
+        const int kind = H.req_kind[c], hw = H.req_hw[c], nsym = H.req_n[c], o_dec = H.req_o[c], neg = H.req_neg[c];
+        const int gch = ch0 + c;
+        // channel c's handler words live in lane c's registers
+        int phase = __shfl(hs.phase, c), block = __shfl(hs.block, c), end = __shfl(hs.end, c), sk0 = __shfl(hs.skipdibit, c);
+        int nac = __shfl(hs.nac, c), p2cc = __shfl(hs.p2_cc, c);
+        int nev = __shfl(h_nev, c);
+        if (H.req_nc[c]) {
+            nac = 0; // noCarrier(): state->nac = 0, p2_cc stays (engine.c:1889)
+        }
+        if (kind == 1) {
+            phase = PH_NID;
+        }
+        int ext = 0, more = 0;
+        int ev_kind = 0, ev_a = 0, ev_b = 0;
+        auto slice_at = [&](int i, int& d, int& relb, int& l0, int& l1) {
+            const float4 e = *reinterpret_cast<const float4*>(&H.hh[(hw - nsym + i) & (HN - 1)][c][0]);
+            const float mx = e.y, mn = e.z;
+            const float center = (mx + mn) / 2.0f;
+            const ddn_sl::Thr th = {center, ((mx - center) * 5.0f / 8.0f) + center, ((mn - center) * 5.0f / 8.0f) + center, mx, mn};
+            ddn_sl::slice_soft(e.x, th, neg, d, relb, l0, l1);
+        };
+        if (phase == PH_NID) {
+            // dispatch_p25p1.c:86-143: dibit 11 of the 33 is the status symbol; the last dibit = BCH bit 62 + the parity bit
+            if (lane < 33 && lane != 11) {
+                int d, relb, l0, l1;
+                slice_at(lane, d, relb, l0, l1);
+                const int a0 = l0 < 0 ? -l0 : l0, a1 = l1 < 0 ? -l1 : l1; // p25p1_llr_reliability()
+                const int b = (lane < 11) ? 2 * lane : 2 * (lane - 1);
+                sc.nb[b] = (uint8_t)((d >> 1) & 1);
+                sc.nr[b] = (uint8_t)(a0 > 255 ? 255 : a0);
+                sc.nb[b + 1] = (uint8_t)(d & 1); // for lane 32: index 63 = the parity bit
+                sc.nr[b + 1] = (uint8_t)(a1 > 255 ? 255 : a1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint64_t w = __ballot(lane < 63 && sc.nb[lane] != 0);
+            const int par = sc.nb[63], prel = sc.nr[63];
+            const int observed = (nac > 0 && nac < 0xFFF) ? nac : ((p2cc > 0 && p2cc < 0xFFF) ? p2cc : 0);
+            const ddn_nid::Gf gf = {sc.ex, sc.lg};
+            const ddn_nid::Work wk = {sc.work + lane, sc.work + 23 * 64 + lane, sc.work + 47 * 64 + lane, sc.work + 71 * 64 + lane};
+            const ddn_nid::NidRes r = ddn_nid::nid_decode_wave(gf, wk, w, sc.nr, par, prel, observed, cfg.nid_threshold, sc.masks, lane);
+            int duid = 0xFF;
+            if (r.status > 0) { // p25p1_handle_nid_decode_success(): NAC / DUID updates
+                const bool valid = r.nac != 0 && r.nac != 0xFFF;
+                if (r.nac != nac && valid) {
+                    nac = r.nac;
+                    p2cc = r.nac;
+                }
+                duid = r.duid;
+            }
+            ev_kind = EV_NID;
+            ev_a = r.status;
+            ev_b = (r.nac & 0xFFFF) | (duid << 16);
+            phase = PH_IDLE;
+            if (duid == 0x7 || duid == 0xC) {
+                phase = (duid == 0x7) ? PH_TSBK : PH_MPDU;
+                block = 0;
+                end = 3; // TSBK_MAX_BLOCKS; p25_mpdu_context_init()
+                sk0 = 36 - 14;
+                int ska;
+                ext = (duid == 0x7) ? 101 : mpdu_block_symbols(sk0, ska);
+                more = 1;
+            } else {
+                ext = duid == 0x0 ? 339 : ((duid == 0x5 || duid == 0xA) ? 807 : (duid == 0x3 ? 15 : (duid == 0xF ? 159 : 0)));
+            }
+        } else if (phase == PH_TSBK || (phase == PH_MPDU && block == 0)) {
+            // the block's data dibits, de-interleaved: LLR pairs for the list decoder, hard dibits for the short cut
+            bool zero_llr = false;
+            for (int r0 = 0; r0 < 2; r0++) {
+                const int i = lane + 64 * r0;
+                if (i < nsym) {
+                    bool st;
+                    int k, ska, nd;
+                    block_scan(sk0, nsym, i, st, k, ska, nd);
+                    if (!st && k < 98) {
+                        int d, relb, l0, l1;
+                        slice_at(i, d, relb, l0, l1);
+                        const int at = deinterleave98(k);
+                        sc.d[at] = (int32_t)((uint32_t)(uint16_t)(int16_t)l0 | ((uint32_t)(uint16_t)(int16_t)l1 << 16));
+                        sc.hd[at] = (uint8_t)d;
+                        zero_llr |= (l0 == 0) | (l1 == 0);
+                    }
+                }
+            }
+            int sk_after, n_data;
+            {
+                bool st;
+                int k;
+                block_scan(sk0, nsym, -1, st, k, sk_after, n_data);
+            }
+            const bool any_zero = __any(zero_llr) || n_data < 98;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // walk the trellis on the hard dibits from state 0 (every lane the same walk)
+            uint32_t by[3] = {0, 0, 0};
+            bool valid = !any_zero;
+            int st = 0;
+            for (int t = 0; t < 49 && valid; t++) {
+                const int nib = (sc.hd[2 * t] << 2) | sc.hd[2 * t + 1];
+                int nxt = -1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    nxt = (half_rate_nibble((st << 2) | q) == nib) ? q : nxt;
+                }
+                valid = nxt >= 0;
+                st = nxt < 0 ? 0 : nxt;
+                if (t < 48) {
+                    const int byte = t >> 2;
+                    by[byte >> 2] |= (uint32_t)st << (8 * (byte & 3) + 6 - 2 * (t & 3));
+                }
+            }
+            int crc_ok = 0, sel = 0;
+            if (valid && crc16_ok(by)) {
+                crc_ok = 1; // the list decoder's first candidate is this code word and the CRC scan stops at it
+            } else {
+                half_rate_list_wave(sc, lane);
+                const int nout = sc.n_out;
+                sel = 0;
+                for (int q = 0; q < nout; q++) {
+                    const uint32_t cw[3] = {sc.outl[q][0], sc.outl[q][1], sc.outl[q][2]};
+                    if (crc16_ok(cw)) {
+                        sel = q;
+                        crc_ok = 1;
+                        break;
+                    }
+                }
+                by[0] = sc.outl[sel][0];
+                by[1] = sc.outl[sel][1];
+                by[2] = sc.outl[sel][2];
+            }
+            const int byte0 = by[0] & 0xFF;
+            sk0 = sk_after;
+            if (phase == PH_TSBK) {
+                const int last = (byte0 >> 7) & 1;
+                ev_kind = EV_TSBK;
+                ev_a = block;
+                ev_b = crc_ok | (((last << 8) | sel) << 16);
+                block++;
+                if (last || block >= 3) {
+                    phase = PH_IDLE;
+                } else {
+                    ext = 101;
+                    more = 1;
+                }
+            } else {
+                // p25_mpdu_update_header_from_first_block(): aggressive_framesync = 1 keeps the defaults on a bad header CRC
+                if (crc_ok) {
+                    const int sap = (by[0] >> 8) & 0x3F, blks = (by[1] >> 16) & 0x7F;
+                    end = blks + 1;
+                    if ((sap == 61 || sap == 63) && blks > 10) {
+                        end = 4;
+                    }
+                }
+                ev_kind = EV_MPDU;
+                ev_a = crc_ok;
+                ev_b = (end & 0xFFFF) | (byte0 << 16);
+                block = 1;
+                // the remaining repetitions are read without a decision: their symbol counts follow from the status counter
+                int total = 0;
+                for (int bi = 1; bi < end; bi++) {
+                    int ska;
+                    total += mpdu_block_symbols(sk0, ska);
+                    sk0 = ska;
+                }
+                ext = total;
+                more = 0;
+                phase = PH_IDLE;
+            }
+        } else {
+            phase = PH_IDLE; // a request without a phase (not reachable): the handler returns
+        }
+        if (lane == c) {
+            hs.phase = phase;
+            hs.block = block;
+            hs.end = end;
+            hs.skipdibit = sk0;
+            hs.nac = nac;
+            hs.p2_cc = p2cc;
+            h_served = seq;
+            if (ev_kind) {
+                if (nev < cfg.max_events && gch < n_channels) {
+                    int32_t* e = events + ((size_t)gch * cfg.max_events + nev) * 4;
+                    e[0] = o_dec;
+                    e[1] = ev_kind;
+                    e[2] = ev_a;
+                    e[3] = ev_b;
+                }
+                h_nev = nev + 1;
+            }
+            H.rsp_ext[c] = ext;
+            H.rsp_more[c] = more;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&H.rsp_seq[c], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+
+        int it = 0;
+        for (long t0 = 0; t0 < n; t0 += TW, it++) {
+            // serve requests until the recurrence wave has left this tile (it never leaves one with a request open)
+            while (true) {
+                const int rq = (lane < CPW) ? __hip_atomic_load(&H.req_seq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+                const unsigned long long pend = __ballot(lane < CPW && rq != h_served);
+                if (pend == 0) {
+                    if (__hip_atomic_load(&H.tile_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it) {
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int c = __ffsll((long long)pend) - 1;
+                serve(c, __shfl(rq, c));
+            }
+            wg_barrier();
+        }
+    {
+        if (hlive) {
+            hstate[ch] = hs;
+            n_events[ch] = h_nev;
+        }
+        for (int k = lane; k < ddn_p25h::HN * CPW; k += 64) {
+            const int c = k % CPW, slot = k / CPW;
+            if (ch0 + c < n_channels) {
+                *reinterpret_cast<float4*>(hh_store + ((size_t)(ch0 + c) * ddn_p25h::HN + slot) * 4) =
+                    *reinterpret_cast<const float4*>(&H.hh[slot][c][0]);
+            }
+        }
+    }
+        return;
+    }
     const bool loader = (threadIdx.x >> 6) == 1;  // wave 1: tile staging, slice + record stores
     const bool winprep = (threadIdx.x >> 6) == 2; // wave 2: suffix summaries of the symbol window
     const bool recur = threadIdx.x < 64;          // wave 0: the per-channel recurrence
@@ -944,11 +1235,13 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             s.hunt_pos = 0;
             snapshot_filter();
             rx_no_carrier(s);
+            s.hnc = 1;
             cold_until = -2147483647;
         }
         if (s.lastsync != 2 && s.hunt_pos >= 1800) {
             snapshot_filter();
             rx_no_carrier(s);
+            s.hnc = 1;
             cold_until = -2147483647;
             rx_hunt_restart(s);
         }
@@ -958,6 +1251,44 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         L.sh[s.shead][ln] = sym;
         s.shead = (s.shead + 1 >= 24) ? 0 : s.shead + 1;
         s.scount = s.scount < 24 ? s.scount + 1 : 24;
+    };
+    // the handler has returned (or the configured count ran out): the next getFrameSync() call starts
+    auto frame_end = [&]() {
+        s.hunt_pos = 0;
+        // the mid thresholds are read by nobody inside a frame (wave 1 derives its own from max / min): they are
+        // brought up to date when the frame ends (and at the end of the call, below)
+        s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
+        s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
+        s.have_sync = 0;
+        s.lidx = 0;
+        s.level_count = 0;
+        s.hist_count = 0;
+        s.hist_bits = 0;
+        s.lmin = s.min;
+        s.lmax = s.max;
+    };
+    // handler mode, recurrence side: hpost = this symbol ends a phase, hwait = the lane sits out until the answer is there
+    bool hpost = false, hwait = false;
+    int hseq = 0;
+    auto hist_push = [&](float sym, float q_max, float q_min, int fl) {
+        if (HM && live && s.hphase != 0) {
+            *reinterpret_cast<float4*>(&H.hh[s.hw & (ddn_p25h::HN - 1)][ln][0]) = make_float4(sym, q_max, q_min, __int_as_float(fl));
+            s.hw++;
+        }
+        if (HM && hpost) {
+            hpost = false;
+            hwait = true;
+            hseq++;
+            H.req_kind[ln] = s.hphase;
+            H.req_hw[ln] = s.hw;
+            H.req_n[ln] = s.hn;
+            H.req_o[ln] = o;
+            H.req_neg[ln] = (s.lastsync == 2) ? 1 : 0;
+            H.req_nc[ln] = s.hnc;
+            s.hnc = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&H.req_seq[ln], hseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
     auto commit_inframe = [&](float sym, int done_snap, int& fl, float& q_max, float& q_min) {
         // get_dibit_and_analog_signal(): window, extrema rings, thresholds (slice + soft decision on wave 1)
@@ -991,18 +1322,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         q_max = s.max;
         q_min = s.min;
         if (--s.lock_left <= 0) {
-            s.hunt_pos = 0;
-            // the mid thresholds are read by nobody inside a frame (wave 1 derives its own from max / min): they are
-            // brought up to date when the frame ends (and at the end of the call, below)
-            s.umid = ((s.max - s.center) * 5.0f / 8.0f) + s.center;
-            s.lmid = ((s.min - s.center) * 5.0f / 8.0f) + s.center;
-            s.have_sync = 0;
-            s.lidx = 0;
-            s.level_count = 0;
-            s.hist_count = 0;
-            s.hist_bits = 0;
-            s.lmin = s.min;
-            s.lmax = s.max;
+            if (HM && s.hphase != 0) {
+                hpost = true; // the handler decides how the frame goes on: asked once this symbol is in the history ring
+            } else {
+                frame_end();
+            }
         }
     };
     auto commit_hunt = [&](float sym, int done_snap, int& fl) {
@@ -1099,6 +1423,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 s.have_sync = 1;
                 s.lock_left = lock_cfg[ch]; // in-frame symbols after a sync, per channel
+                if (HM) { // the NID: 32 dibits + the status symbol inside it, then p25p1_nid_decode decides
+                    s.lock_left = 33;
+                    s.hphase = 1;
+                    s.hn = 33;
+                }
                 fl = 2 | (pol == 2 ? 4 : 0);
                 if (s.lock_left <= 0) {
                     s.have_sync = 0;
@@ -1117,6 +1446,9 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
     };
     auto emit = [&](float sym, int fl, float q_max, float q_min) {
+    if (fl & 1) {
+        hist_push(sym, q_max, q_min, fl);
+    }
     if (offload && tk <= QTW) {
         qv = make_float4(sym, q_max, q_min, __int_as_float(fl | ((o - o_tile) << 8)));
     } else if ((size_t)o < max_sym) {
@@ -1183,13 +1515,34 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             bool pf_ok = false;
             float px0 = 0.0f, px1 = 0.0f, px2 = 0.0f, px3 = 0.0f, px4 = 0.0f;
             float4 psf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            bool respin = false; // handler mode: the last pass only waited for an answer (no trip was spent)
             while (true) {
-                // hand the previous trip's symbols (one per lane at most) to wave 1: one 16-byte LDS write at a wave-uniform slot
-                if (offload && tk > 0 && tk <= QTW && lane < CPW) {
-                    *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
+                if (HM && __any(hwait)) {
+                    if (hwait
+                        && __hip_atomic_load(&H.rsp_seq[ln], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == hseq) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const int ext = H.rsp_ext[ln];
+                        hwait = false;
+                        if (ext > 0) { // the handler reads on
+                            s.lock_left = ext;
+                            s.hn = ext;
+                            s.hphase = H.rsp_more[ln] ? 2 : 0;
+                        } else {       // it has returned
+                            s.hphase = 0;
+                            frame_end();
+                        }
+                    }
                 }
-                qv.w = __int_as_float(-1);
-                tk++;
+                const bool alive = live & !hwait;
+                // hand the previous trip's symbols (one per lane at most) to wave 1: one 16-byte LDS write at a wave-uniform slot
+                if (!respin) {
+                    if (offload && tk > 0 && tk <= QTW && lane < CPW) {
+                        *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
+                    }
+                    qv.w = __int_as_float(-1);
+                    tk++;
+                }
+                respin = false;
                 if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
                     const long long now = (long long)clock64();
                     if (dbg_kind >= 0) {
@@ -1216,11 +1569,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 bool all_lean_wait = false;
                 if (lean_ok && tk <= QTW) {
                     // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
-                    const bool lean_state = live & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
+                    const bool lean_state = alive & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
                                             & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0))) & (s.min < s.max);
                     const bool lean = lean_state & (sp + whole <= tn);
                     const bool lean_wait = lean_state & !(sp + whole <= tn) & more;
-                    const bool all_lean = !__any(live & !(lean | lean_wait));
+                    const bool all_lean = !__any(alive & !(lean | lean_wait));
                     if (all_lean && __any(lean)) {
                         dbg_kind = 2;
                         const int k0 = (whole - 1) / 2 - 2;
@@ -1279,6 +1632,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
                             s.lock_left--;
                             qv = make_float4(sym, s.max, s.min, __int_as_float((1 | (s.lastsync == 2 ? 4 : 0)) | ((o - o_tile) << 8)));
+                            hist_push(sym, s.max, s.min, 1 | (s.lastsync == 2 ? 4 : 0));
                             o++;
                         }
                         // operands of the next lean trip, if this lane's next symbol is staged in this tile too
@@ -1298,7 +1652,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 bool all_std_wait = all_lean_wait;
                 if (std_ok && !all_lean_wait) {
                     // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
-                    const bool warm = live & (sp >= cold_until); // == !(filter_on && (abs0 + t0 + sp - filt_start) < NT - 1)
+                    const bool warm = alive & (sp >= cold_until); // == !(filter_on && (abs0 + t0 + sp - filt_start) < NT - 1)
                     const bool hunting = s.have_sync == 0;
                     if (warm & hunting & (s.in_symbol == 0) & (sp < tn)) { // symbol start while hunting: slip by the latched crossing
                         if (s.need_reset) {
@@ -1327,7 +1681,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     const bool fits = sp + cnt <= tn;
                     const bool can = (in_a | in_b) & fits;
                     const bool wt = (((in_a | in_b) & !fits) | idle_b) & more; // waits for the next tile (both stay staged)
-                    const bool all_ok = !__any(live & !(can | wt));
+                    const bool all_ok = !__any(alive & !(can | wt));
                     if (all_ok && __any(can)) {
                         dbg_kind = 0;
                         const float* p = (s.filter_on ? frow : rrow) + base + sp;
@@ -1414,10 +1768,18 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 // ---- general trip ------------------------------------------------------------------------------------------
                 const int done_snap = 0;
-                const bool glive = live && !gblocked;
+                const bool glive = alive && !gblocked;
                 const bool gneed = glive && (sp < tn || s.in_symbol);
-                if (all_std_wait || !__any(gneed && (sp < tn)) || ++guard > 4 * TW) {
-                    break;
+                {
+                    const bool tile_over = all_std_wait || !__any(gneed && (sp < tn));
+                    if (HM && tile_over && __any(hwait)) { // nobody can go on, but a lane waits for its handler: not the tile's end
+                        __builtin_amdgcn_s_sleep(2);
+                        respin = true;
+                        continue;
+                    }
+                    if (tile_over || ++guard > 4 * TW) {
+                        break;
+                    }
                 }
                 if (!__any(gneed)) {
                     continue;
@@ -1658,6 +2020,9 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             if (offload && lane == 0) {
                 L.qn[it & 1] = (tk - 1) < QTW ? (tk - 1) : QTW; // trips that may have queued (the last one broke out at its top)
             }
+            if (HM && lane == 0) {
+                __hip_atomic_store(&H.tile_done, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             if (live) {
                 L.sidx0[(it + 1) & 1][ln] = s.sidx;
                 sp -= TW;
@@ -1701,21 +2066,21 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     }
 }
 
-template <int CPW>
+template <int CPW, bool HM>
 static hipError_t
 launch_rxw(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride, int n_channels,
            const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
            float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, const int32_t* lock_cfg,
-           hipStream_t st) {
-    const size_t shm = sizeof(LdsW<CPW>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rxw<CPW>),
+           DdnP25HState* hstate, float* hh_store, int32_t* events, int32_t* n_events, hipStream_t st) {
+    const size_t shm = HM ? (((sizeof(LdsW<CPW>) + 15) & ~(size_t)15) + sizeof(LdsH<CPW>)) : sizeof(LdsW<CPW>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rxw<CPW, HM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) {
         return e;
     }
-    hipLaunchKernelGGL(k_p25_rxw<CPW>, dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(192), shm, st, raw, filt,
-                       prev_tail, fstale, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
-                       maxring, rec, flags, counts, max_sym, lock_cfg);
+    hipLaunchKernelGGL((k_p25_rxw<CPW, HM>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(HM ? 256 : 192), shm, st, raw,
+                       filt, prev_tail, fstale, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
+                       maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store, events, n_events);
     return hipGetLastError();
 }
 
@@ -1741,7 +2106,8 @@ extern "C" hipError_t
 ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride, int n_channels,
                const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
                float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym,
-               int channels_per_wave, const int32_t* lock_cfg, hipStream_t st) {
+               int channels_per_wave, const int32_t* lock_cfg, DdnP25HState* hstate, float* hh_store, int32_t* events,
+               int32_t* n_events, hipStream_t st) {
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
@@ -1768,6 +2134,24 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
         }
     }
     int cpw = channels_per_wave;
+    const int whole = cfg->sym_rate > 0 ? cfg->out_rate / cfg->sym_rate : 0;
+    if (cfg->handlers) {
+        // handler mode: the windowed kernel with its fourth wave, 8 or 16 lanes per wave (the in-frame history ring is LDS)
+        if (whole < 6 || !hstate || !hh_store || !events || !n_events) {
+            return hipErrorInvalidValue;
+        }
+        if (cpw != 8 && cpw != 16) {
+            cpw = n_channels <= 8 * 512 ? 8 : 16;
+        }
+        if (cpw == 8) {
+            return launch_rxw<8, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                       shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store,
+                                       events, n_events, st);
+        }
+        return launch_rxw<16, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                    shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store,
+                                    events, n_events, st);
+    }
     if (cpw != 8 && cpw != 16 && cpw != 32 && cpw != 64) {
         // fewest lanes per wavefront that still gives every CU (256) no more than ~2 workgroups: a trip is only a lean trip
         // when every lane of the wave is in the lean state, so fewer lanes per wave means fewer mixed trips (measured on the
@@ -1777,7 +2161,6 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
     // CPW 16 / 32 run the windowed variant (k_p25_rxw); 64 lanes per wavefront keeps the two-tile kernel, whose LDS
     // footprint still fits (cfg.dbg bit 128 forces it for A/B timing)
     // k_p25_rxw sizes its window bookkeeping for symbols of at least 6 samples; shorter ones keep the two-tile kernel
-    const int whole = cfg->sym_rate > 0 ? cfg->out_rate / cfg->sym_rate : 0;
     if (whole < 6) {
         if (cpw <= 16) {
             return launch_rx<16>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
@@ -1791,16 +2174,19 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
     }
     if (cpw == 8) {
-        return launch_rxw<8>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                             shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
+        return launch_rxw<8, false>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                    shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, nullptr, nullptr, nullptr,
+                                    nullptr, st);
     }
     if (cpw == 16 && !(cfg->dbg & 128)) {
-        return launch_rxw<16>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
+        return launch_rxw<16, false>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                     shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, nullptr, nullptr,
+                                     nullptr, nullptr, st);
     }
     if (cpw == 32 && !(cfg->dbg & 128)) {
-        return launch_rxw<32>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, st);
+        return launch_rxw<32, false>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                     shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, nullptr, nullptr,
+                                     nullptr, nullptr, st);
     }
     switch (cpw) {
         case 16:

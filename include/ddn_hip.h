@@ -147,10 +147,15 @@ int ddn_p25_matched_filter_run_host(ddn_slicer_batch* b, const float* in, size_t
  *                                       to the P25p1 pattern with the modulation locked to C4FM (-mc), incl. the
  *                                       hunting level window and dsd_sync_warm_start_thresholds_outer_only()
  *   getDibitSoft(opts, state, &soft)    include/dsd-neo/core/dibit.h:43-52 for every in-frame symbol
- * Deviations from a full dsd-neo run (stated in DESIGN.md): after a sync the loop stays in frame for
- * cfg.lock_symbols symbols (the reference's per-DUID handlers decide that per frame); carrier-loss reset is not
- * modelled.  Parity: the slicer, warm start and level window are pinned to the compiled reference; the sample /
- * hunting loops are restated from source (dsd_symbol.c / dsd_frame_sync.c do not build here) - "parity unpinned".
+ * How long a frame is read in frame: with ddn_p25_rx_set_handlers(b, 1, ..) the reference's own handlers decide, inside the
+ * loop (processFrame -> dsd_dispatch_handle_p25p1, src/engine/dispatch/dispatch_p25p1.c:86-143,206-225,391-403): the NID's 33
+ * symbols, p25p1_nid_decode (hard decode, NAC retry, Chase search), then per DUID - HDU 339, LDU1 / LDU2 807, TDU 15, TDULC
+ * 159, TSDU 101 per block until the decoded block's last-block flag (p25p1_tsbk.c:1051-1072), PDU by its header block
+ * (p25p1_mdpu.c:270-307), nothing for an undefined DUID or a failed NID.  Without it the loop stays in frame for a
+ * caller-given count (cfg.lock_symbols / ddn_p25_rx_set_lock_symbols) - a deviation kept for experiments.
+ * Parity: the slicer, warm start and level window are pinned to the compiled reference; the sample / hunting loops are
+ * restated from source (dsd_symbol.c / dsd_frame_sync.c do not build here) and anchored on the reference's symbolizer KATs
+ * and its full-chain known answers.
  *   d_disc      : [B][n] f32 discriminator samples (ddn_front_end_run output), channel-major
  *   d_records10 : [B][max_symbols][10] capture records {u8 dibit, u8 reliability, i16 llr0, i16 llr1, f32 symbol}
  *                 (write_symbol_capture_record layout, src/core/frames/dsd_dibit.c:794-818); while hunting the dibit
@@ -172,6 +177,17 @@ int ddn_p25_rx_reset(ddn_p25_rx* b);
 /* in-frame symbol count after a sync, per channel (host array [n_channels]; NULL = cfg.lock_symbols everywhere): lets one
  * batch mix traffic classes, e.g. 840 for voice channels (LDUs) and 156 / 336 for one- / three-block TSDU control channels */
 int ddn_p25_rx_set_lock_symbols(ddn_p25_rx* b, const int32_t* per_channel);
+/* enable != 0: the reference's per-DUID handlers decide the in-frame length (see above); nid_erasure_threshold =
+ * p25p1_get_erasure_threshold() (64 unless the reference's config overrides it; <= 0 selects 64).  Every handler decision is
+ * reported: ddn_p25_rx_set_events() gives the device buffers of the next runs - d_events i32 [B][max_events][4] =
+ * {output index of the deciding symbol, kind, a, b}, d_n_events i32 [B] (decisions of that call; may exceed max_events, only
+ * the first max_events are stored):
+ *   kind 1 NID        a = p25p1_nid_decode status (1 ok, 2 parity override, <= 0 failed), b = NAC | DUID << 16 (DUID 0xFF: none)
+ *   kind 2 TSDU block a = block index, b = CRC16 good | (last-block flag << 8 | selected list candidate) << 16
+ *   kind 3 PDU header a = header CRC16 good, b = blocks to read | byte 0 << 16
+ * Without buffers the decisions are still taken, just not reported. */
+int ddn_p25_rx_set_handlers(ddn_p25_rx* b, int enable, int nid_erasure_threshold);
+int ddn_p25_rx_set_events(ddn_p25_rx* b, int32_t* d_events, int32_t* d_n_events, size_t max_events);
 /* kernel times of the last ddn_p25_rx_run(), HIP events on the launch stream: ms2 = {matched filter, receive-loop kernel} */
 int ddn_p25_rx_set_timing(ddn_p25_rx* b, int enable);
 int ddn_p25_rx_get_timing(ddn_p25_rx* b, float* ms2);
@@ -185,6 +201,9 @@ int ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_reco
                    int32_t* d_counts, size_t max_symbols, void* hip_stream);
 int ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags,
                         int32_t* counts, size_t max_symbols);
+/* the same with the handlers' event list brought back to host arrays (events [B][max_events][4], n_events [B]; both NULL = none) */
+int ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
+                           size_t max_symbols, int32_t* events, int32_t* n_events, size_t max_events);
 int ddn_p25_rx_get_thresholds(ddn_p25_rx* b, int channel, float out7[7]);
 
 /* ---- Gardner symbol-timing recovery (CQPSK branch), batched ----------------------------------------------

@@ -86,6 +86,40 @@ def make_frames(rng, n_frames, nac, crc=False, blocks=1):
     return out.reshape(-1), st
 
 
+def encode_half_rate(bytes12):
+    """12 bytes -> 98 transmit-order dibits of the P25 half-rate trellis (two bits per state, one flush state)"""
+    t = fecgen.tables()
+    il = t["il"].astype(np.int64)
+    bits = np.unpackbits(np.asarray(bytes12, np.uint8)).astype(np.int64)
+    st = np.zeros(49, np.int64)
+    st[:48] = (bits[0::2] << 1) | bits[1::2]
+    prev = np.concatenate([[0], st[:-1]])
+    nib = t["half"][(prev << 2) | st].astype(np.int64)
+    dei = np.stack([(nib >> 2) & 3, nib & 3], axis=1).reshape(98)
+    return dei[il]
+
+
+def make_pdu(rng, nac, blks, sap=0, good_crc=True):
+    """FS + NID (DUID 0xC) + header block (byte 6 = blocks to follow, CRC16 over bytes 0..9) + blks random data blocks, status
+    symbols every 36th dibit, padded to a status boundary (p25p1_mdpu.c reads blks + 1 repetitions of 98 data dibits)"""
+    hdr = rng.integers(0, 256, 10)
+    hdr[1] = (int(hdr[1]) & 0xC0) | (sap & 0x3F)
+    hdr[6] = (int(hdr[6]) & 0x80) | (blks & 0x7F)
+    c = crc16_ccitt(hdr) ^ (0 if good_crc else 0x5A5A)
+    pay = list(encode_half_rate(list(hdr) + [c >> 8, c & 0xFF]))
+    for _ in range(blks):
+        pay += list(rng.integers(0, 4, 98))
+    n_pay = 24 + 32 + len(pay)
+    flen = -(-n_pay // 35) * 36
+    fr = np.zeros(flen, np.int8)
+    stat = list(range(35, flen, 36))
+    pos = [p for p in range(flen) if p not in stat]
+    body = list(orc.P25_FS_DIBITS) + nid_dibits(nac, 0xC) + pay
+    fr[pos[:len(body)]] = body
+    fr[stat] = 2
+    return fr
+
+
 def frame_with_duid(rng, nac, duid, n_body):
     """FS + NID of the given DUID + n_body random dibits (status symbols 2 where the frame has them)"""
     fr = np.zeros(24 + 33 + n_body, np.int8)
@@ -97,12 +131,38 @@ def frame_with_duid(rng, nac, duid, n_body):
     return fr
 
 
-def modulate_disc(dibits, lead=300, noise=100.0, seed=0, sps=10, amp=7000.0, tail=400):
-    """Dibit stream -> discriminator-scale float32 samples (smoothed 4-level), `lead` noise-only samples first"""
+def weaken_nid(dibits, frame_start, rng, strong=10, weak=3):
+    """damage the NID of the frame at dibit `frame_start` so that the BCH hard decode fails (strong + weak > 11 bit errors)
+    and the Chase search over the least reliable bits repairs it: `strong` symbols get the opposite sign (one bit error
+    each, full reliability), `weak` outer symbols are pulled just inside the inner threshold (one low-reliability bit error
+    each).  Returns the per-symbol amplitude scale for modulate_disc()."""
+    scale = np.ones(len(dibits))
+    pos = [frame_start + p for p in range(24, 57) if p != 35]
+    pick = rng.permutation(len(pos))
+    n_s = 0
+    for k in pick:
+        if n_s >= strong:
+            break
+        dibits[pos[k]] ^= 2          # sign flip: high bit wrong, magnitude kept
+        n_s += 1
+    n_w = 0
+    for k in pick[strong:]:
+        if n_w >= weak:
+            break
+        if dibits[pos[k]] in (1, 3):  # outer level: pull it to 0.55 of full scale -> sliced as the inner level, low bit wrong
+            scale[pos[k]] = 0.55
+            n_w += 1
+    return scale
+
+
+def modulate_disc(dibits, lead=300, noise=100.0, seed=0, sps=10, amp=7000.0, tail=400, scale=None):
+    """Dibit stream -> discriminator-scale float32 samples (smoothed 4-level), `lead` noise-only samples first; scale = optional
+    per-symbol amplitude factors"""
     rng = np.random.default_rng(seed)
     win = np.hanning(sps + 3)[1:-1]
     win /= win.sum()
-    shaped = np.convolve(np.repeat(_LEVEL[dibits], sps), win, mode="same") * amp
+    lv = _LEVEL[dibits] * (1.0 if scale is None else scale)
+    shaped = np.convolve(np.repeat(lv, sps), win, mode="same") * amp
     x = np.concatenate([np.zeros(lead), shaped, np.zeros(tail)])
     return (x + rng.normal(0.0, noise, x.shape)).astype(np.float32)
 
