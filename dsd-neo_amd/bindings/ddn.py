@@ -120,6 +120,7 @@ PROTOTYPES = {
     "ddn_p25_rx_set_lock_symbols": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_rx_set_channels_per_wave": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_p25_rx_set_handlers": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ddn_p25_rx_debug_counters": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25_rx_set_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ddn_p25_rx_run_host_ev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -372,6 +373,10 @@ PROTOTYPES.update({
     "ddn_fsk4_rx_create": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_fsk4_rx_destroy": (None, [C.c_void_p]),
     "ddn_fsk4_rx_reset": (C.c_int, [C.c_void_p]),
+    "ddn_fsk4_rx_set_handlers": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_fsk4_rx_set_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ddn_fsk4_rx_events_host_arm": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "ddn_fsk4_rx_events_host_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_fsk4_rx_max_symbols": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "ddn_fsk4_rx_max_syncs": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "ddn_fsk4_rx_set_lock_symbols": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -404,7 +409,9 @@ PROTOTYPES.update({
 class Fsk4Rx:
     """ddn_fsk4_rx batch object (host-buffer convenience wrapper used by the tests)"""
 
-    def __init__(self, n_channels, protocol, rf_mod=0, inverted=0, use_matched_filter=1, lock=None, out_rate=48000):
+    def __init__(self, n_channels, protocol, rf_mod=0, inverted=0, use_matched_filter=1, lock=None, out_rate=48000,
+                 handlers=False, max_events=2048):
+        """handlers=True: the reference's handlers decide the in-frame length; run_host() then also returns events / n_events"""
         import numpy as np
         self.np = np
         cfg = Fsk4RxConfig(n_channels, out_rate, protocol, rf_mod, inverted, use_matched_filter)
@@ -413,6 +420,10 @@ class Fsk4Rx:
         self.h = C.c_void_p()
         _check(lib().ddn_fsk4_rx_create(C.byref(cfg), C.byref(self.h)), "ddn_fsk4_rx_create")
         self.B = n_channels
+        self.handlers, self.max_events = bool(handlers), max_events
+        if handlers:
+            _check(lib().ddn_fsk4_rx_set_handlers(self.h, 1), "ddn_fsk4_rx_set_handlers")
+            _check(lib().ddn_fsk4_rx_events_host_arm(self.h, max_events), "ddn_fsk4_rx_events_host_arm")
 
     def close(self):
         if self.h:
@@ -439,7 +450,12 @@ class Fsk4Rx:
         _check(l.ddn_fsk4_rx_run_host(self.h, disc.ctypes.data, n, rec.ctypes.data, fl.ctypes.data, pay.ctypes.data, cnt.ctypes.data, ms,
                                       spos.ctypes.data, spat.ctypes.data, pre.ctypes.data, prel.ctypes.data, ns.ctypes.data, my),
                "ddn_fsk4_rx_run_host")
-        return dict(rec=rec, fl=fl, pay=pay, cnt=cnt, sync_pos=spos, sync_pat=spat, pre=pre, pre_rel=prel, n_sync=ns)
+        out = dict(rec=rec, fl=fl, pay=pay, cnt=cnt, sync_pos=spos, sync_pat=spat, pre=pre, pre_rel=prel, n_sync=ns)
+        if self.handlers:
+            ev, nev = np.zeros((B, self.max_events, 4), np.int32), np.zeros(B, np.int32)
+            _check(l.ddn_fsk4_rx_events_host_read(self.h, ev.ctypes.data, nev.ctypes.data), "ddn_fsk4_rx_events_host_read")
+            out["events"], out["n_events"] = ev, nev
+        return out
 
     def thresholds(self, ch):
         t = self.np.zeros(7, self.np.float32)

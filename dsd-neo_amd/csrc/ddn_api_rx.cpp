@@ -31,7 +31,7 @@ struct ddn_p25_rx {
     size_t filt_cap;
     int channels_per_wave;
     int32_t* d_lock; // [B] in-frame symbols after a sync, per channel (cfg.lock_symbols unless overridden)
-    // handler mode (ddn_p25_rx_set_handlers): per-channel handler words, the in-frame history ring [B][128][4] f32, the
+    // handler mode (ddn_p25_rx_set_handlers): per-channel handler words, the in-frame history ring [B][104][3] f32, the
     // caller's event buffers (or a one-event dummy of our own)
     int handlers, nid_threshold;
     DdnP25HState* d_hstate;
@@ -110,7 +110,7 @@ rx_fill(ddn_p25_rx* b) {
         || hipMemset(b->d_fhist, 0, sizeof(float) * 90 * B) != hipSuccess
         || hipMemset(b->d_fstale, 0, sizeof(float) * 90 * B) != hipSuccess
         || hipMemset(b->d_hstate, 0, sizeof(DdnP25HState) * B) != hipSuccess
-        || hipMemset(b->d_hh, 0, sizeof(float) * 4 * 128 * B) != hipSuccess) {
+        || hipMemset(b->d_hh, 0, sizeof(float) * 3 * 104 * B) != hipSuccess) {
         ddn_set_error("p25 rx state upload failed");
         return DDN_EHIP;
     }
@@ -151,7 +151,7 @@ ddn_p25_rx_create(const ddn_p25_rx_config* cfg, ddn_p25_rx** out) {
         || hipMalloc(&b->d_fhist, sizeof(float) * 90 * B) != hipSuccess
         || hipMalloc(&b->d_fstale, sizeof(float) * 90 * B) != hipSuccess
         || hipMalloc(&b->d_hstate, sizeof(DdnP25HState) * B) != hipSuccess
-        || hipMalloc(&b->d_hh, sizeof(float) * 4 * 128 * B) != hipSuccess
+        || hipMalloc(&b->d_hh, sizeof(float) * 3 * 104 * B) != hipSuccess
         || hipMalloc(&b->d_ev_dummy, sizeof(int32_t) * 4 * B) != hipSuccess
         || hipMalloc(&b->d_nev_dummy, sizeof(int32_t) * B) != hipSuccess
         || hipMalloc(&b->d_lock, sizeof(int32_t) * B) != hipSuccess || rx_fill(b) != DDN_OK
@@ -208,8 +208,8 @@ ddn_p25_rx_set_handlers(ddn_p25_rx* b, int enable, int nid_erasure_threshold) {
     if (!b || nid_erasure_threshold > 255) {
         return DDN_EINVAL;
     }
-    if (enable && b->cfg.out_rate_hz / b->cfg.sym_rate_hz < 6) {
-        ddn_set_error("ddn_p25_rx_set_handlers: needs at least 6 samples per symbol");
+    if (enable && b->cfg.out_rate_hz / b->cfg.sym_rate_hz < 9) {
+        ddn_set_error("ddn_p25_rx_set_handlers: needs at least 9 samples per symbol");
         return DDN_ERANGE;
     }
     b->handlers = enable ? 1 : 0;
@@ -429,6 +429,20 @@ extern "C" int
 ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
                     size_t max_symbols) {
     return ddn_p25_rx_run_host_ev(b, disc, n, records10, flags, counts, max_symbols, nullptr, nullptr, 0);
+}
+
+// timing experiments (DDN_RX_DBG bit 65536): handler requests of a channel and the cycles its lane spent waiting for the answers
+extern "C" int
+ddn_p25_rx_debug_counters(ddn_p25_rx* b, int channel, long long out2[2]) {
+    if (!b || !out2 || channel < 0 || channel >= b->cfg.n_channels) {
+        return DDN_EINVAL;
+    }
+    DdnRxState s;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&s, b->d_state + channel, sizeof(s), hipMemcpyDeviceToHost));
+    out2[0] = s.dbg_nreq;
+    out2[1] = s.dbg_wait;
+    return DDN_OK;
 }
 
 extern "C" int

@@ -60,6 +60,12 @@ struct ddn_fsk4_rx {
     int32_t* d_lock;
     size_t filt_cap;
     int channels_per_wave;
+    // handler mode (ddn_fsk4_rx_set_handlers): the handlers' words [B][32] i32, the burst's dibits [B][144], event buffers
+    int32_t* d_hwords;
+    uint8_t* d_hpay;
+    int32_t *d_events, *d_n_events;
+    size_t max_events;
+    int32_t *d_ev_own, *d_nev_own; // event buffers of the host convenience calls (ddn_fsk4_rx_events_host_*)
     bool timing;
     hipEvent_t ev[3];
 };
@@ -77,6 +83,10 @@ rx4_free(ddn_fsk4_rx* b) {
     (void)hipFree(b->d_taps);
     (void)hipFree(b->d_cfg);
     (void)hipFree(b->d_lock);
+    (void)hipFree(b->d_hwords);
+    (void)hipFree(b->d_hpay);
+    (void)hipFree(b->d_ev_own);
+    (void)hipFree(b->d_nev_own);
     for (int i = 0; i < 3; i++) {
         if (b->ev[i]) {
             (void)hipEventDestroy(b->ev[i]);
@@ -108,6 +118,16 @@ rx4_fill(ddn_fsk4_rx* b) {
     HIP_TRY(hipMemset(b->d_rhist, 0, DDN_FSK4_HIST * B));
     HIP_TRY(hipMemset(b->d_fhist, 0, sizeof(float) * (DDN_FSK4_MAX_TAPS - 1) * B));
     HIP_TRY(hipMemset(b->d_fstale, 0, sizeof(float) * (DDN_FSK4_MAX_TAPS - 1) * B));
+    {   // dmr_confidence_reset() + state->dmr_color_code = 16 (dsd_init.c:1099): field order of ddn_fsk4h_dev.h
+        std::vector<int32_t> hw(32 * B, 0);
+        for (size_t c = 0; c < B; c++) {
+            hw[32 * c + 1] = 16;  // F_CONF_CC
+            hw[32 * c + 2] = 16;  // F_CAND_CC
+            hw[32 * c + 11] = 16; // F_COLOR
+        }
+        HIP_TRY(hipMemcpy(b->d_hwords, hw.data(), sizeof(int32_t) * 32 * B, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(b->d_hpay, 0, 144 * B));
+    }
     return DDN_OK;
 }
 
@@ -224,6 +244,7 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         || hipMalloc(&b->d_fstale, sizeof(float) * (DDN_FSK4_MAX_TAPS - 1) * B) != hipSuccess
         || hipMalloc(&b->d_taps, sizeof(taps)) != hipSuccess || hipMalloc(&b->d_cfg, sizeof(DdnFsk4Config)) != hipSuccess
         || hipMemcpy(b->d_cfg, &b->dc, sizeof(DdnFsk4Config), hipMemcpyHostToDevice) != hipSuccess || hipMalloc(&b->d_lock, sizeof(int32_t) * 4 * B) != hipSuccess
+        || hipMalloc(&b->d_hwords, sizeof(int32_t) * 32 * B) != hipSuccess || hipMalloc(&b->d_hpay, 144 * B) != hipSuccess
         || hipMemcpy(b->d_taps, taps, sizeof(taps), hipMemcpyHostToDevice) != hipSuccess
         || hipMemcpy(b->d_lock, lock.data(), sizeof(int32_t) * 4 * B, hipMemcpyHostToDevice) != hipSuccess) {
         ddn_set_error("ddn_fsk4_rx_create: device allocation failed");
@@ -247,6 +268,65 @@ ddn_fsk4_rx_destroy(ddn_fsk4_rx* b) {
         rx4_free(b);
         delete b;
     }
+}
+
+extern "C" int
+ddn_fsk4_rx_set_handlers(ddn_fsk4_rx* b, int enable) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    if (enable && b->cfg.inverted) {
+        ddn_set_error("ddn_fsk4_rx_set_handlers: the handlers are the reference's plain -fs ones (inverted = 0)");
+        return DDN_EINVAL;
+    }
+    b->dc.handlers = enable ? 1 : 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(b->d_cfg, &b->dc, sizeof(DdnFsk4Config), hipMemcpyHostToDevice));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fsk4_rx_set_events(ddn_fsk4_rx* b, int32_t* d_events, int32_t* d_n_events, size_t max_events) {
+    if (!b || ((d_events == nullptr) != (d_n_events == nullptr)) || (d_events && max_events == 0) || max_events > 0x7FFFFFFF) {
+        return DDN_EINVAL;
+    }
+    b->d_events = d_events;
+    b->d_n_events = d_n_events;
+    b->max_events = d_events ? max_events : 0;
+    b->dc.max_events = (int)b->max_events;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(b->d_cfg, &b->dc, sizeof(DdnFsk4Config), hipMemcpyHostToDevice));
+    return DDN_OK;
+}
+
+// host convenience: event buffers owned by the batch object, read back after a run
+extern "C" int
+ddn_fsk4_rx_events_host_arm(ddn_fsk4_rx* b, size_t max_events) {
+    if (!b || max_events == 0 || max_events > 0x7FFFFFFF) {
+        return DDN_EINVAL;
+    }
+    const size_t B = (size_t)b->cfg.n_channels;
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(b->d_ev_own);
+    (void)hipFree(b->d_nev_own);
+    b->d_ev_own = b->d_nev_own = nullptr;
+    HIP_TRY(hipMalloc(&b->d_ev_own, B * max_events * 16));
+    HIP_TRY(hipMalloc(&b->d_nev_own, B * 4));
+    HIP_TRY(hipMemset(b->d_ev_own, 0, B * max_events * 16));
+    HIP_TRY(hipMemset(b->d_nev_own, 0, B * 4));
+    return ddn_fsk4_rx_set_events(b, b->d_ev_own, b->d_nev_own, max_events);
+}
+
+extern "C" int
+ddn_fsk4_rx_events_host_read(ddn_fsk4_rx* b, int32_t* events, int32_t* n_events) {
+    if (!b || !events || !n_events || !b->d_ev_own || b->d_events != b->d_ev_own) {
+        return DDN_EINVAL;
+    }
+    const size_t B = (size_t)b->cfg.n_channels;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(events, b->d_ev_own, B * b->max_events * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(n_events, b->d_nev_own, B * 4, hipMemcpyDeviceToHost));
+    return DDN_OK;
 }
 
 extern "C" int
@@ -334,7 +414,8 @@ ddn_fsk4_rx_run(ddn_fsk4_rx* b, const float* d_disc, size_t n, uint8_t* d_record
     HIP_TRY(ddn_dev_fsk4_rx(d_disc, b->d_filt, b->d_fhist, b->d_fstale, b->d_taps, (long)n, n, B, b->d_cfg, b->d_state, b->d_lbuf,
                             b->d_shist, b->d_phist, b->d_rhist, d_records10, d_flags, d_payload2, d_counts, max_symbols, b->d_lock,
                             d_sync_pos, d_sync_pat, d_pre, d_pre_rel, d_n_sync, (int)max_syncs, b->channels_per_wave,
-                            b->dc.out_rate / b->dc.sym_rate + (b->dc.out_rate % b->dc.sym_rate ? 1 : 0), b->cfg.protocol, st));
+                            b->dc.out_rate / b->dc.sym_rate + (b->dc.out_rate % b->dc.sym_rate ? 1 : 0), b->cfg.protocol,
+                            b->dc.handlers, b->d_hwords, b->d_hpay, b->d_events, b->d_n_events, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
     }

@@ -92,6 +92,8 @@ typedef struct DdnRxState { /* per-channel words of dsd_state / frame_sync_runti
        hw = symbols written to the in-frame history ring; hn = symbols of the current phase; hnc = noCarrier() ran since the
        last NID (the handlers' NAC memory is cleared with it, engine.c:1889) */
     int hphase, hw, hn, hnc;
+    int dbg_nreq;           /* timing experiments (cfg.dbg bit 65536): handler requests / cycles spent waiting for the answers */
+    long long dbg_wait;
 } DdnRxState;
 
 /* ---- profile-driven 4-level FSK receive loop (DMR / NXDN48), ddn_rx4.hip ---- */
@@ -105,6 +107,8 @@ typedef struct DdnFsk4Config {
     uint8_t pat_type[DDN_FSK4_MAX_PAT], pat_neg[DDN_FSK4_MAX_PAT], pat_class[DDN_FSK4_MAX_PAT];
     int confirm, dmr_window, redigitize, slow_type, use_filter, nt;
     int dbg; /* profiling only (env DDN_RX4_DBG) */
+    int handlers;   /* 1 = the reference's handlers decide the in-frame length (ddn_fsk4h_dev.h) */
+    int max_events; /* capacity of the per-channel event list */
 } DdnFsk4Config;
 typedef struct DdnFsk4State {
     long long filt_start, n_abs;
@@ -115,6 +119,8 @@ typedef struct DdnFsk4State {
     int lidx, level_count, hist_count, shead, scount;
     uint32_t hist_bits;
     int hunt_pos, need_reset;
+    int hmode, hidx; /* handler mode: phase (ddn_fsk4h_dev.h) and the index of the next dibit inside the burst / frame */
+    int hlich;       /* NXDN: the LICH's high bits so far */
 } DdnFsk4State;
 
 typedef struct DdnCqpskState { /* per-channel words of demod_state the CQPSK chain carries besides ted_state_t */
@@ -169,7 +175,8 @@ hipError_t ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* pre
                            float* lbuf_store, float* shist_store, uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec,
                            uint8_t* flags, uint8_t* pay, int32_t* counts, size_t max_sym, const int32_t* lock4,
                            int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel, int32_t* n_sync,
-                           int max_sync, int channels_per_wave, int samples_per_symbol, int protocol, hipStream_t st);
+                           int max_sync, int channels_per_wave, int samples_per_symbol, int protocol, int handlers,
+                           int32_t* hwords, uint8_t* hpay, int32_t* events, int32_t* n_events, hipStream_t st);
 hipError_t ddn_dev_dmr_burst_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
                                     const uint8_t* pre, const int32_t* n_sync, int n_channels, int max_sync, int inverted,
                                     uint8_t* slot_type, uint8_t* info, uint8_t* cach, uint8_t* valid, hipStream_t st);

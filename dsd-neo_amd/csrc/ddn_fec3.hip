@@ -25,10 +25,7 @@
 
 namespace {
 
-struct Tables {
-    uint8_t h74[8], h128[16], h139[16], h1511[16], h16114[32];
-    uint8_t g208[4096][3], g2412[4096][3], qr[512][2];
-};
+using Tables = DdnFec3Tables;
 
 int
 syn_of(uint32_t w, const uint32_t* H, int r) {
@@ -733,4 +730,9 @@ ddn_dev_rs_12_9(uint8_t* cw, size_t n, uint8_t* result, uint8_t* found, uint8_t*
     }
     hipLaunchKernelGGL(k_rs_12_9, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, cw, n, result, found, syn_out);
     return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_fec3_tables(const DdnFec3Tables** out, hipStream_t st) {
+    return device_tables(out, st);
 }

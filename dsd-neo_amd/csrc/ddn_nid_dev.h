@@ -179,20 +179,23 @@ struct NidRes {
     int status, nac, duid, errs;
 };
 
-__device__ inline NidRes
-nid_codeword(const Gf& gf, const Work& wk, uint64_t w, int parity, int* bch_failed) {
+// w(x) mod g(x) == 0 for the generator of BCH(63,16,11) over GF(2^6) / x^6 + x + 1 (g = lcm of the minimal polynomials of
+// alpha^1 .. alpha^22, degree 47: 0xCD930BDD3B2B with x^j at bit j).  w carries input position p (= x^(62 - p)) at bit p, so
+// the division runs from bit 0 up with g's coefficients reversed.
+__device__ __forceinline__ bool
+bch_63_16_is_codeword(uint64_t w) {
+    const uint64_t grev = 0xD4DCBBD0C9B3ull;
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        w ^= ((w >> p) & 1ull) ? (grev << p) : 0ull;
+    }
+    return w == 0;
+}
+
+// NAC / DUID / status of a corrected NID word (the tail of decode_nid_codeword(), p25p1_check_nid.cpp:262-301)
+__device__ __forceinline__ NidRes
+nid_fields(uint64_t fixed, int errs, int parity) {
     NidRes r = {0, 0, 0, 0};
-    uint64_t fixed;
-    int errs;
-    if (bch_failed) {
-        *bch_failed = 0;
-    }
-    if (!bch_63_16_decode(gf, wk, w, &fixed, &errs)) {
-        if (bch_failed) {
-            *bch_failed = 1;
-        }
-        return r;
-    }
     r.errs = errs;
     int nac = 0, duid = 0;
     for (int i = 0; i < 12; i++) {
@@ -212,6 +215,22 @@ nid_codeword(const Gf& gf, const Work& wk, uint64_t w, int parity, int* bch_fail
     const int want = (duid == 5 || duid == 10) ? 1 : 0;
     r.status = (want == parity) ? 1 : 2;
     return r;
+}
+
+__device__ inline NidRes
+nid_codeword(const Gf& gf, const Work& wk, uint64_t w, int parity, int* bch_failed) {
+    uint64_t fixed;
+    int errs;
+    if (bch_failed) {
+        *bch_failed = 0;
+    }
+    if (!bch_63_16_decode(gf, wk, w, &fixed, &errs)) {
+        if (bch_failed) {
+            *bch_failed = 1;
+        }
+        return NidRes{0, 0, 0, 0};
+    }
+    return nid_fields(fixed, errs, parity);
 }
 
 __device__ __forceinline__ int
@@ -287,6 +306,9 @@ __device__ inline NidRes
 nid_decode_wave(const Gf& gf, const Work& wk, uint64_t w, const uint8_t* rel, int par, int prel, int obs, int threshold,
                 const uint8_t* masks, int lane) {
     const bool obs_ok = obs > 0 && obs < 0xFFF;
+    if (bch_63_16_is_codeword(w)) { // the common case: no bit error - the decoder returns the word with an error count of 0
+        return nid_fields(w, 0, par);
+    }
     int failed = 0;
     NidRes hard = nid_codeword(gf, wk, w, par, &failed);
     if (hard.status == 0 && failed && obs_ok && rx_nac(w) != obs) {

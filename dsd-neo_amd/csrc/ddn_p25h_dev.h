@@ -26,22 +26,28 @@
 
 namespace ddn_p25h {
 
-constexpr int HN = 128; // in-frame history ring, symbols per channel (a phase is at most 101)
+constexpr int HN = 104; // in-frame history ring, symbols per channel (a phase is at most 101)
 enum { PH_IDLE = 0, PH_NID = 1, PH_TSBK = 3, PH_MPDU = 4 };
 enum { EV_NID = 1, EV_TSBK = 2, EV_MPDU = 3 };
 
 struct Scratch { // one decision at a time
     uint8_t ex[128], lg[64];
-    uint8_t work[(23 + 24 + 24 + 24) * 64];
     uint8_t masks[96];
     uint8_t nb[64], nr[64];  // NID bits / reliabilities (index 63 = the parity bit)
     int32_t d[98 + 2];       // de-interleaved LLR pairs (lo 16 = first bit of the dibit)
-    uint8_t hd[100];         // de-interleaved hard dibits
-    uint2 back[49][4];
-    uint4 cand[32];
-    uint8_t cvalid[32];
-    uint32_t outl[8][4];     // the merged candidate list {bytes 0-3, 4-7, 8-11, metric}
-    int n_out;
+    uint16_t crc_cols[80];   // CRC16 register contribution of each message bit
+    union {
+        uint8_t work[(23 + 24 + 24 + 24) * 64]; // NID: the BCH decoder's per-lane arrays
+        struct {                                // trellis block: the list decoder's
+            uint2 back[49][4];       // as bytes [49][4][8]
+            uint16_t ct[49][4][4];   // branch costs [step][state][predecessor]
+            alignas(16) uint32_t mb[2][32]; // survivor metrics [step parity][state * 8 + rank]
+            uint4 cand[32];
+            uint8_t cvalid[32];
+            uint32_t outl[8][4]; // the merged candidate list {bytes 0-3, 4-7, 8-11, metric}
+            int n_out;
+        };
+    };
 };
 
 __device__ __forceinline__ int
@@ -80,168 +86,287 @@ crc16_ok(const uint32_t w[3]) { // p25_crc.c:18-36 over bytes 0..9 of the 12 (bi
     return crc == ((b10 << 8) | b11);
 }
 
-// the list-8 decoder on lanes 0..3 of the wave (lane = next state), LLR pairs in sc.d: leaves the merged candidates in
-// sc.outl[0 .. sc.n_out) sorted as the reference sorts them.  Byte k of a candidate = (outl[.][k >> 2] >> (8 * (k & 3))) & 0xFF.
+// The list-8 decoder (src/protocol/p25/p25_12.c:31-202), the whole wavefront on one block, LLR pairs in sc.d: leaves the merged
+// candidates in sc.outl[0 .. sc.n_out) sorted as the reference sorts them (byte k of a candidate =
+// (outl[.][k >> 2] >> (8 * (k & 3))) & 0xFF).
+// The reference keeps, per state, the 8 smallest of the 32 extensions (4 predecessors x 8 ranks) by inserting them predecessor by
+// predecessor, rank by rank, each before the first strictly larger metric - i.e. the 8 smallest under the order (metric, arrival
+// index).  Here lane (p, r) of each half-wave owns survivor r of state p; every survivor list is sorted, so an extension's place
+// among a state's 32 is its own rank plus, per other predecessor list, the number of entries below a threshold (its metric
+// shifted by the difference of the two branch costs, +1 when that list arrives earlier) - 24 compares instead of an insertion
+// ladder.  The two half-waves take two target states each.  Branch costs of all 49 steps are tabulated first; the per-step chain
+// is one LDS round trip (the 32 metrics) + the counting.
 __device__ inline void
 half_rate_list_wave(Scratch& sc, int lane) {
     constexpr int K = 8;
-    const uint32_t MAXM = 0xFFFFFFFFu;
-    const int ns = lane & 3;
-    const bool on = lane < 4;
-    uint32_t pm[K];
-#pragma unroll
-    for (int r = 0; r < K; r++) {
-        pm[r] = MAXM;
-    }
-    pm[0] = (ns == 0) ? 0u : 256u;
-    int e[4];
-#pragma unroll
-    for (int ps = 0; ps < 4; ps++) {
-        e[ps] = half_rate_nibble((ps << 2) | ns);
-    }
-    for (int t = 0; t < 49; t++) {
+    const uint32_t INF = 0x3FFFFFFFu; // an absent survivor (metrics stay below 2^17)
+    const int L = lane & 31, p = L >> 3, r = L & 7, h = lane >> 5;
+    // ---- branch-cost table ct[t][ns][ps] ------------------------------------------------------------------------------
+    for (int idx = lane; idx < 49 * 16; idx += 64) {
+        const int t = idx >> 4, ns = (idx >> 2) & 3, ps = idx & 3;
         const int32_t p0 = sc.d[2 * t], p1 = sc.d[2 * t + 1];
         const int l[4] = {(int16_t)(p0 & 0xFFFF), (int16_t)(p0 >> 16), (int16_t)(p1 & 0xFFFF), (int16_t)(p1 >> 16)};
-        uint32_t c0[4], c1[4];
+        const int e = half_rate_nibble((ps << 2) | ns);
+        uint32_t c = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            c0[b] = l[b] > 0 ? (uint32_t)l[b] : 0u;
-            c1[b] = l[b] < 0 ? (uint32_t)(-l[b]) : 0u;
+            c += ((e >> (3 - b)) & 1) ? (l[b] < 0 ? (uint32_t)(-l[b]) : 0u) : (l[b] > 0 ? (uint32_t)l[b] : 0u);
         }
-        uint32_t cm[K], cb[K];
-#pragma unroll
-        for (int r = 0; r < K; r++) {
-            cm[r] = MAXM;
-            cb[r] = 0;
-        }
-#pragma unroll
-        for (int ps = 0; ps < 4; ps++) {
-            uint32_t cost = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                cost += ((e[ps] >> (3 - b)) & 1) ? c1[b] : c0[b];
-            }
-#pragma unroll
-            for (int r = 0; r < K; r++) {
-                const uint32_t q = __shfl(pm[r], ps);
-                const uint32_t m = (q == MAXM) ? MAXM : q + cost;
-                const uint32_t bp = (uint32_t)((ps << 3) | r);
-#pragma unroll
-                for (int i = K - 1; i >= 1; i--) {
-                    const bool lt_prev = m < cm[i - 1], lt_cur = m < cm[i];
-                    cb[i] = lt_prev ? cb[i - 1] : (lt_cur ? bp : cb[i]);
-                    cm[i] = lt_prev ? cm[i - 1] : (lt_cur ? m : cm[i]);
-                }
-                const bool lt0 = m < cm[0];
-                cb[0] = lt0 ? bp : cb[0];
-                cm[0] = lt0 ? m : cm[0];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < K; r++) {
-            pm[r] = cm[r];
-        }
-        if (on) {
-            uint2 w;
-            w.x = cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24);
-            w.y = cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24);
-            sc.back[t][ns] = w;
-        }
+        sc.ct[t][ns][ps] = (uint16_t)c;
+    }
+    if (lane < 32) {
+        sc.mb[0][lane] = (r == 0) ? ((p == 0) ? 0u : 256u) : INF;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 1
-    for (int rk = 0; rk < K; rk++) {
-        uint32_t mfin = pm[0];
+    uint8_t* back = reinterpret_cast<uint8_t*>(&sc.back[0][0]); // [49][4][8]: (predecessor << 3) | rank of survivor (state, rank)
+    for (int t = 0; t < 49; t++) {
+        const uint32_t* mb = sc.mb[t & 1];
+        uint32_t* mn = sc.mb[(t + 1) & 1];
+        uint32_t m[32];
 #pragma unroll
-        for (int r = 1; r < K; r++) {
-            mfin = (r == rk) ? pm[r] : mfin;
+        for (int q = 0; q < 8; q++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&mb[4 * q]);
+            m[4 * q] = v.x;
+            m[4 * q + 1] = v.y;
+            m[4 * q + 2] = v.z;
+            m[4 * q + 3] = v.w;
         }
+        const uint32_t mine = mb[L];
+        if (lane < 32) {
+            mn[lane] = INF; // survivors nobody claims stay absent
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int ns = 2 * h + j;
+            const uint2 cw = *reinterpret_cast<const uint2*>(&sc.ct[t][ns][0]);
+            const uint32_t c[4] = {cw.x & 0xFFFFu, cw.x >> 16, cw.y & 0xFFFFu, cw.y >> 16};
+            const uint32_t cp = p == 0 ? c[0] : (p == 1 ? c[1] : (p == 2 ? c[2] : c[3]));
+            const uint32_t val = mine + cp;
+            int rank = r;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // entries of list q that come before (val, arrival): metric + c[q] < val, or == val when list q arrives earlier.
+                // Signed compare: the threshold can be negative, an absent entry (INF) is above every threshold.
+                const int32_t thr = (int32_t)(val - c[q] + (q < p ? 1u : 0u));
+                int cnt = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    cnt += ((int32_t)m[8 * q + i] < thr) ? 1 : 0;
+                }
+                rank += (q != p) ? cnt : 0; // its own list contributes its rank
+            }
+            if (mine < INF && rank < K) {
+                mn[8 * ns + rank] = val;
+                back[(t * 4 + ns) * 8 + rank] = (uint8_t)L;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    // ---- trace the 32 final survivors back (lane = state * 8 + rank) ---------------------------------------------------------
+    const uint32_t mfin = sc.mb[49 & 1][L];
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+    {
         uint32_t w[3] = {0, 0, 0};
-        int s = ns, r = rk;
-        if (on && mfin != MAXM) {
+        int s = p, rk = r;
+        if (lane < 32 && mfin < INF) {
             for (int t = 48; t >= 0; t--) {
                 if (t < 48) {
                     const int byte = t >> 2;
                     w[byte >> 2] |= (uint32_t)s << (8 * (byte & 3) + 6 - 2 * (t & 3));
                 }
-                const uint2 bw = sc.back[t][s];
-                const uint32_t word = (r < 4) ? bw.x : bw.y;
-                const uint32_t p = (word >> (8 * (r & 3))) & 0xFFu;
-                s = (int)((p >> 3) & 3u);
-                r = (int)(p & 7u);
+                const int bp = back[(t * 4 + s) * 8 + rk];
+                s = (bp >> 3) & 3;
+                rk = bp & 7;
             }
         }
-        if (on) {
-            sc.cand[ns * K + rk] = make_uint4(w[0], w[1], w[2], mfin);
-            sc.cvalid[ns * K + rk] = (mfin != MAXM) ? 1 : 0;
-        }
+        w0 = w[0];
+        w1 = w[1];
+        w2 = w[2];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane == 0) { // merge in (state, rank) order: duplicates by the 12 bytes dropped, the rest sorted by metric, strict less
-        int count = 0;
-        for (int k = 0; k < 32; k++) {
-            if (!sc.cvalid[k]) {
-                continue;
-            }
-            const uint4 cd = sc.cand[k];
-            bool dup = false;
-            int at = count;
-            bool found = false;
-            for (int i = 0; i < count; i++) {
-                dup |= (sc.outl[i][0] == cd.x && sc.outl[i][1] == cd.y && sc.outl[i][2] == cd.z);
-                if (!found && cd.w < sc.outl[i][3]) {
-                    at = i;
-                    found = true;
-                }
-            }
-            if (dup) {
-                continue;
-            }
-            if (count < K) {
-                count++;
-            } else if (at >= K) {
-                continue;
-            }
-            for (int i = count - 1; i > at; i--) {
-                for (int j = 0; j < 4; j++) {
-                    sc.outl[i][j] = sc.outl[i - 1][j];
-                }
-            }
-            sc.outl[at][0] = cd.x;
-            sc.outl[at][1] = cd.y;
-            sc.outl[at][2] = cd.z;
-            sc.outl[at][3] = cd.w;
+    // ---- merge in (state, rank) order: a candidate whose 12 bytes are already listed is dropped, the rest kept sorted by metric
+    // (inserted before the first strictly larger one), at most 8.  Slot i of the list lives in lane i; the candidates come round
+    // as scalars.
+    uint32_t o0 = 0, o1 = 0, o2 = 0, om = 0;
+    int count = 0;
+    for (int k = 0; k < 32; k++) {
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)w0, k), c1 = (uint32_t)__builtin_amdgcn_readlane((int)w1, k);
+        const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)w2, k), cm = (uint32_t)__builtin_amdgcn_readlane((int)mfin, k);
+        if (cm >= INF) {
+            continue;
         }
+        const bool mine_on = lane < count;
+        if (__any(mine_on && o0 == c0 && o1 == c1 && o2 == c2)) {
+            continue;
+        }
+        const int at = __popcll(__ballot(mine_on && !(cm < om))); // entries that stay in front: not strictly larger
+        if (count < K) {
+            count++;
+        } else if (at >= K) {
+            continue;
+        }
+        // slots at + 1 .. count - 1 take their left neighbour's entry, slot `at` the candidate
+        const uint32_t s0 = __shfl_up(o0, 1), s1 = __shfl_up(o1, 1), s2 = __shfl_up(o2, 1), sm = __shfl_up(om, 1);
+        const bool shift = lane > at && lane < count;
+        o0 = lane == at ? c0 : (shift ? s0 : o0);
+        o1 = lane == at ? c1 : (shift ? s1 : o1);
+        o2 = lane == at ? c2 : (shift ? s2 : o2);
+        om = lane == at ? cm : (shift ? sm : om);
+    }
+    if (lane < K) {
+        sc.outl[lane][0] = o0;
+        sc.outl[lane][1] = o1;
+        sc.outl[lane][2] = o2;
+        sc.outl[lane][3] = om;
+    }
+    if (lane == 0) {
         sc.n_out = count;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// skipdibit bookkeeping of tsbk_read_repetition_samples() / p25_mpdu_read_repetition(): symbol i of a block read with the
-// counter at sk0 is a status symbol when the counter has reached 36
-__device__ __forceinline__ void
-block_scan(int sk0, int n_sym, int i_query, bool& is_status, int& data_index, int& sk_after, int& n_data) {
-    int sk = sk0, k = 0;
-    is_status = false;
-    data_index = 0;
-    for (int i = 0; i < n_sym; i++) {
-        const bool st = (sk / 36) != 0;
-        if (i == i_query) {
-            is_status = st;
-            data_index = k;
-        }
-        if (st) {
-            sk = 0;
-        } else {
-            k++;
-        }
-        sk++;
+// skipdibit bookkeeping of tsbk_read_repetition_samples() / p25_mpdu_read_repetition() in closed form.  The counter starts a
+// block at sk0 (1..36); a symbol read with the counter at 36 is a status symbol and restarts it, so status symbols sit at
+// i0 = 36 - sk0 and every 36 after.
+__device__ __forceinline__ bool
+block_is_status(int sk0, int i, int& data_index) {
+    const int i0 = 36 - sk0;
+    const int before = (i <= i0) ? 0 : ((i - 1 - i0) / 36 + 1); // status symbols among 0 .. i - 1
+    data_index = i - before;
+    return i >= i0 && ((i - i0) % 36) == 0;
+}
+__device__ __forceinline__ int
+block_counter_after(int sk0, int n_sym, int& n_data) { // the counter after n_sym symbols, and how many of them were data
+    const int i0 = 36 - sk0;
+    if (n_sym <= i0) {
+        n_data = n_sym;
+        return sk0 + n_sym;
     }
-    sk_after = sk;
-    n_data = k;
+    const int n_status = (n_sym - 1 - i0) / 36 + 1;
+    n_data = n_sym - n_status;
+    return n_sym - (i0 + 36 * (n_status - 1));
+}
+
+// XOR over the wavefront: four DPP steps inside each row of 16 lanes, then the four rows through scalar reads
+__device__ __forceinline__ uint32_t
+wave_xor(uint32_t v) {
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); // row_half_mirror
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16)
+           ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// CRC16 (p25_crc.c:18-36: 0x1021, zero start, inverted) of bytes 0..9 against bytes 10..11, the wavefront on it: the register
+// is linear in the message, so lane j adds in the contribution of message bits j and j + 64 (sc.crc_cols: the register after
+// shifting a lone one through the remaining bits) and a wave-wide XOR finishes.  by[] is the same in every lane.
+__device__ inline void
+crc_cols_fill(uint16_t* cols, int lane) { // lanes 0..63 of one wave
+    for (int i = lane; i < 80; i += 64) {
+        unsigned crc = 0;
+        for (int k = 0; k < 80; k++) {
+            const unsigned bit = (k == i) ? 1u : 0u;
+            crc = (((crc >> 15) & 1u) ^ bit) ? (((crc << 1) ^ 0x1021u) & 0xFFFFu) : ((crc << 1) & 0xFFFFu);
+        }
+        cols[i] = (uint16_t)crc;
+    }
+}
+__device__ __forceinline__ int
+crc16_ok_wave(const Scratch& sc, const uint32_t by[3], int lane) {
+    auto msg_bit = [&](int i) { return (by[i >> 5] >> (8 * ((i >> 3) & 3) + 7 - (i & 7))) & 1u; };
+    uint32_t v = msg_bit(lane) ? sc.crc_cols[lane] : 0u;
+    if (lane < 16) {
+        v ^= msg_bit(lane + 64) ? sc.crc_cols[lane + 64] : 0u;
+    }
+    const uint32_t crc = wave_xor(v) ^ 0xFFFFu;
+    const uint32_t b10 = (by[2] >> 16) & 0xFFu, b11 = (by[2] >> 24) & 0xFFu;
+    return crc == ((b10 << 8) | b11);
+}
+
+// Best path of the half-rate trellis over the LLR pairs in sc.d: the decoder p25_12_soft_llr() runs, and the list decoder's
+// first candidate - its rank-0 survivors evolve exactly like this (the smallest of a state's 32 extensions is the smallest rank-0
+// extension, first predecessor on a tie) and its merge keeps the smallest final metric, first state on a tie.
+// Sixteen lanes, lane = state * 4 + predecessor (the rest of the wave repeats them).  Nothing but registers on the 49-step
+// chain: the 98 LLR pairs are spread over the wave first (lane j keeps pairs j and j + 64, a step fetches its two by readlane),
+// a branch's cost is packed 16-bit arithmetic on the pair (negate by the branch bit, clamp at 0, add), the four extensions of
+// a state sit in one quad (two DPP minimum steps), the four new metrics go round as scalars (readlane), every lane keeps its
+// state's decisions two bits per step, and the trace-back runs on scalars.  Every lane returns the 12 bytes (byte k =
+// (by[k >> 2] >> (8 * (k & 3))) & 0xFF).
+typedef short ddn_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void
+half_rate_best_wave(const Scratch& sc, int lane, uint32_t by[3]) {
+    const int ps = lane & 3, ns = (lane >> 2) & 3;
+    const int e = half_rate_nibble((ps << 2) | ns);
+    // branch bits as packed masks: bit set = the branch says 1 = the cost is the LLR's pull towards 0 = max(0, -llr)
+    const ddn_s16x2 m01 = {(short)(((e >> 3) & 1) ? -1 : 0), (short)(((e >> 2) & 1) ? -1 : 0)};
+    const ddn_s16x2 m23 = {(short)(((e >> 1) & 1) ? -1 : 0), (short)((e & 1) ? -1 : 0)};
+    const ddn_s16x2 zero = {0, 0};
+    const int dA = sc.d[lane], dB = (lane < 34) ? sc.d[lane + 64] : 0;
+    uint32_t pm_ps = (ps == 0) ? 0u : 256u; // metric of this lane's predecessor state
+    uint64_t bk_lo = 0, bk_hi = 0;          // this lane's state's decisions, two bits per step
+    uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+#pragma unroll
+    for (int t = 0; t < 49; t++) {
+        const int p0 = (2 * t < 64) ? __builtin_amdgcn_readlane(dA, (2 * t) & 63) : __builtin_amdgcn_readlane(dB, (2 * t) & 63);
+        const int p1 = (2 * t + 1 < 64) ? __builtin_amdgcn_readlane(dA, (2 * t + 1) & 63)
+                                        : __builtin_amdgcn_readlane(dB, (2 * t + 1) & 63);
+        ddn_s16x2 a = __builtin_bit_cast(ddn_s16x2, p0), b = __builtin_bit_cast(ddn_s16x2, p1);
+        a = __builtin_elementwise_max((a ^ m01) - m01, zero);
+        b = __builtin_elementwise_max((b ^ m23) - m23, zero);
+        const ddn_s16x2 c = a + b; // <= 2 * 255 per half
+        const uint32_t cw = __builtin_bit_cast(uint32_t, c);
+        const uint32_t cost = (cw & 0xFFFFu) + (cw >> 16);
+        uint32_t key = ((pm_ps + cost) << 2) | (uint32_t)ps; // smallest metric, lowest predecessor on a tie
+        uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xF, 0xF, true);
+        key = o < key ? o : key;
+        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xF, 0xF, true);
+        key = o < key ? o : key;
+        if (t < 32) {
+            bk_lo |= (uint64_t)(key & 3u) << (2 * t);
+        } else {
+            bk_hi |= (uint64_t)(key & 3u) << (2 * (t - 32));
+        }
+        k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0);
+        k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 4);
+        k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, 8);
+        k3 = (uint32_t)__builtin_amdgcn_readlane((int)key, 12);
+        pm_ps = (ps == 0 ? k0 : (ps == 1 ? k1 : (ps == 2 ? k2 : k3))) >> 2;
+    }
+    // best final state, lowest on a tie; then back along the decisions (scalars)
+    uint32_t f = (k0 >> 2) << 2, g = ((k1 >> 2) << 2) | 1u;
+    f = g < f ? g : f;
+    g = ((k2 >> 2) << 2) | 2u;
+    f = g < f ? g : f;
+    g = ((k3 >> 2) << 2) | 3u;
+    f = g < f ? g : f;
+    uint32_t s = f & 3u;
+    uint32_t lo[4][2], hi[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        lo[q][0] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bk_lo, 4 * q);
+        lo[q][1] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bk_lo >> 32), 4 * q);
+        hi[q][0] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bk_hi, 4 * q);
+        hi[q][1] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bk_hi >> 32), 4 * q);
+    }
+    by[0] = by[1] = by[2] = 0;
+#pragma unroll
+    for (int t = 48; t >= 0; t--) {
+        if (t < 48) {
+            const int byte = t >> 2;
+            by[byte >> 2] |= s << (8 * (byte & 3) + 6 - 2 * (t & 3));
+        }
+        // decisions of step t: word (t / 16) of the state's 128-bit record, bits 2 (t % 16)
+        const int wsel = t >> 4;
+        const uint32_t w0 = wsel == 0 ? lo[0][0] : (wsel == 1 ? lo[0][1] : (wsel == 2 ? hi[0][0] : hi[0][1]));
+        const uint32_t w1 = wsel == 0 ? lo[1][0] : (wsel == 1 ? lo[1][1] : (wsel == 2 ? hi[1][0] : hi[1][1]));
+        const uint32_t w2 = wsel == 0 ? lo[2][0] : (wsel == 1 ? lo[2][1] : (wsel == 2 ? hi[2][0] : hi[2][1]));
+        const uint32_t w3 = wsel == 0 ? lo[3][0] : (wsel == 1 ? lo[3][1] : (wsel == 2 ? hi[3][0] : hi[3][1]));
+        const uint32_t w = s == 0 ? w0 : (s == 1 ? w1 : (s == 2 ? w2 : w3));
+        s = (w >> (2 * (t & 15))) & 3u;
+    }
 }
 
 // symbols p25_mpdu_read_repetition() consumes for one repetition starting with the counter at sk0 (98 data dibits, <= 101 reads)

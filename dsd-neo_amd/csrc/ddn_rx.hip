@@ -664,13 +664,15 @@ constexpr int WMAX = 24;
 #define DDN_RX_CYCLES 0
 #endif
 
-template <int CPW>
+template <int CPW, bool SMALL = false>
 struct LdsW {
     // tile shape: 128-sample tiles where the rows fit (half the tile prologues / closing trips), 64 at 32 lanes per wave
     // (8 lanes per wave: 66 KB, two workgroups per CU still fit; at 16 lanes the 128-sample shape would take 132 KB and halve
     // the resident workgroups of an 8192-channel batch)
     static constexpr int TW = CPW <= 8 ? 128 : 64, RTW = 3 * TW;
-    static constexpr int WMW = CPW <= 8 ? 64 : 32; // suffix summaries per checkpoint: pushes per two tiles, 2 * (ceil((TW + sps) / (sps - 1)) + 1)
+    // suffix summaries per checkpoint: pushes per two tiles, 2 * (ceil((TW + sps) / (sps - 1)) + 1).  SMALL (handler mode, which
+    // needs the LDS for its history ring): sized for at least 9 samples per symbol
+    static constexpr int WMW = CPW <= 8 ? (SMALL ? 40 : 64) : (SMALL ? 24 : 32);
     static constexpr int QTW = CPW <= 8 ? 40 : 20; // queue slots = trips of a tile that can hand a symbol to wave 1
     float sb[SS][CPW];
     float lb[24][CPW];
@@ -692,7 +694,7 @@ struct LdsW {
 // the answer is there (the other lanes go on; the tile does not end while a lane waits).
 template <int CPW>
 struct LdsH {
-    alignas(16) float hh[ddn_p25h::HN][CPW][4];
+    float hh[ddn_p25h::HN][CPW][3]; // {symbol, max, min} of the phase's in-frame symbols, slot = count mod HN
     int req_seq[CPW], req_kind[CPW], req_hw[CPW], req_n[CPW], req_o[CPW], req_neg[CPW], req_nc[CPW];
     int rsp_seq[CPW], rsp_ext[CPW], rsp_more[CPW];
     int tile_done;
@@ -709,11 +711,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
           int32_t* __restrict__ counts, size_t max_sym, const int32_t* __restrict__ lock_cfg,
           DdnP25HState* __restrict__ hstate, float* __restrict__ hh_store, int32_t* __restrict__ events,
           int32_t* __restrict__ n_events) {
-    constexpr int TW = LdsW<CPW>::TW, RTW = LdsW<CPW>::RTW, WMW = LdsW<CPW>::WMW, QTW = LdsW<CPW>::QTW;
+    using LW = LdsW<CPW, HM>;
+    constexpr int TW = LW::TW, RTW = LW::RTW, WMW = LW::WMW, QTW = LW::QTW;
     (void)RTW;
     extern __shared__ unsigned char smem_raw[];
-    LdsW<CPW>& L = *reinterpret_cast<LdsW<CPW>*>(smem_raw);
-    LdsH<CPW>& H = *reinterpret_cast<LdsH<CPW>*>(smem_raw + ((sizeof(LdsW<CPW>) + 15) & ~(size_t)15));
+    LW& L = *reinterpret_cast<LW*>(smem_raw);
+    LdsH<CPW>& H = *reinterpret_cast<LdsH<CPW>*>(smem_raw + ((sizeof(LW) + 15) & ~(size_t)15));
     const bool hwave = HM && (threadIdx.x >> 6) == 3; // wave 3: the handlers' decisions
     const int lane = threadIdx.x & 63;
     if (HM && hwave) {
@@ -727,6 +730,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
+        __builtin_amdgcn_s_setprio(3); // a lane of the recurrence wave (and with it the wave) waits on every decision
     // handler wave: its per-channel words (lane = channel), the history ring, the mailboxes, the decoder tables
     DdnP25HState hs = DdnP25HState{};
     int h_served = 0, h_nev = 0;
@@ -735,18 +739,15 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         if (hlive) {
             hs = hstate[ch];
         }
-        for (int k = lane; k < ddn_p25h::HN * CPW; k += 64) {
-            const int c = k % CPW, slot = k / CPW;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (ch0 + c < n_channels) {
-                v = *reinterpret_cast<const float4*>(hh_store + ((size_t)(ch0 + c) * ddn_p25h::HN + slot) * 4);
-            }
-            *reinterpret_cast<float4*>(&H.hh[slot][c][0]) = v;
+        for (int k = lane; k < ddn_p25h::HN * CPW * 3; k += 64) {
+            const int w = k % 3, c = (k / 3) % CPW, slot = k / (3 * CPW);
+            H.hh[slot][c][w] = (ch0 + c < n_channels) ? hh_store[((size_t)(ch0 + c) * ddn_p25h::HN + slot) * 3 + w] : 0.0f;
         }
         if (lane < CPW) {
             H.req_seq[lane] = 0;
             H.rsp_seq[lane] = 0;
         }
+        ddn_p25h::crc_cols_fill(H.sc.crc_cols, lane);
         if (lane == 0) {
             H.tile_done = 0;
             ddn_nid::gf_fill(H.sc.ex, H.sc.lg);
@@ -761,6 +762,14 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         Scratch& sc = H.sc;
         const int kind = H.req_kind[c], hw = H.req_hw[c], nsym = H.req_n[c], o_dec = H.req_o[c], neg = H.req_neg[c];
         const int gch = ch0 + c;
+        const long long dbg_t0 = (cfg.dbg & 65536) ? (long long)clock64() : 0; // timing experiments: cycles per decision
+        int dbg_path = 0;
+        long long dbg_s[3] = {0, 0, 0};
+        auto dbg_stamp = [&](int k) {
+            if (cfg.dbg & 131072) {
+                dbg_s[k] = (long long)clock64() - dbg_t0;
+            }
+        };
         // channel c's handler words live in lane c's registers
         int phase = __shfl(hs.phase, c), block = __shfl(hs.block, c), end = __shfl(hs.end, c), sk0 = __shfl(hs.skipdibit, c);
         int nac = __shfl(hs.nac, c), p2cc = __shfl(hs.p2_cc, c);
@@ -774,14 +783,52 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         int ext = 0, more = 0;
         int ev_kind = 0, ev_a = 0, ev_b = 0;
         auto slice_at = [&](int i, int& d, int& relb, int& l0, int& l1) {
-            const float4 e = *reinterpret_cast<const float4*>(&H.hh[(hw - nsym + i) & (HN - 1)][c][0]);
-            const float mx = e.y, mn = e.z;
+            int slot = hw - nsym + i; // hw = the ring slot after the phase's last symbol
+            slot += slot < 0 ? HN : 0;
+            const float* e = &H.hh[slot][c][0];
+            const float mx = e[1], mn = e[2];
             const float center = (mx + mn) / 2.0f;
             const ddn_sl::Thr th = {center, ((mx - center) * 5.0f / 8.0f) + center, ((mn - center) * 5.0f / 8.0f) + center, mx, mn};
-            ddn_sl::slice_soft(e.x, th, neg, d, relb, l0, l1);
+            ddn_sl::slice_soft(e[0], th, neg, d, relb, l0, l1);
         };
         if (phase == PH_NID) {
-            // dispatch_p25p1.c:86-143: dibit 11 of the 33 is the status symbol; the last dibit = BCH bit 62 + the parity bit
+            // dispatch_p25p1.c:86-143: dibit 11 of the 33 is the status symbol; the last dibit = BCH bit 62 + the parity bit.
+            // First the hard dibits alone (three compares each): when they spell a code word with a defined DUID the decoder's answer
+            // is that word with an error count of 0 whatever the reliabilities - the soft slice and the ladder are for the rest.
+            bool nid_done = false;
+            ddn_nid::NidRes r = {0, 0, 0, 0};
+            {
+                int hd = 0;
+                if (lane < 33 && lane != 11) {
+                    int slot = hw - nsym + lane;
+                    slot += slot < 0 ? HN : 0;
+                    const float* e = &H.hh[slot][c][0];
+                    const float mx = e[1], mn = e[2], x = e[0];
+                    const float center = (mx + mn) / 2.0f;
+                    const float umid = ((mx - center) * 5.0f / 8.0f) + center, lmid = ((mn - center) * 5.0f / 8.0f) + center;
+                    hd = (x > center) ? ((x > umid) ? (neg ? 3 : 1) : (neg ? 2 : 0)) : ((x < lmid) ? (neg ? 1 : 3) : (neg ? 0 : 2));
+                }
+                // lanes 0..10 and 12..32 -> bit pairs 0..31 of the word (the status symbol's lane squeezed out)
+                const unsigned long long bh = __ballot(hd & 2), bl = __ballot(hd & 1);
+                const uint32_t ph = (uint32_t)((bh & 0x7FFull) | ((bh >> 12) << 11)), pl = (uint32_t)((bl & 0x7FFull) | ((bl >> 12) << 11));
+                auto spread = [](uint32_t v) { // bit k -> bit 2 k
+                    uint64_t x = v;
+                    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+                    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+                    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+                    x = (x | (x << 2)) & 0x3333333333333333ull;
+                    x = (x | (x << 1)) & 0x5555555555555555ull;
+                    return x;
+                };
+                const uint64_t both = spread(ph) | (spread(pl) << 1); // bit 2 k = high bit of dibit k, bit 2 k + 1 = its low bit
+                const uint64_t w0 = both & 0x7FFFFFFFFFFFFFFFull;
+                const int par0 = (int)(both >> 63);
+                if (ddn_nid::bch_63_16_is_codeword(w0)) {
+                    r = ddn_nid::nid_fields(w0, 0, par0);
+                    nid_done = r.status > 0;
+                }
+            }
+            if (!nid_done) {
             if (lane < 33 && lane != 11) {
                 int d, relb, l0, l1;
                 slice_at(lane, d, relb, l0, l1);
@@ -794,12 +841,15 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            dbg_stamp(0);
             const uint64_t w = __ballot(lane < 63 && sc.nb[lane] != 0);
             const int par = sc.nb[63], prel = sc.nr[63];
             const int observed = (nac > 0 && nac < 0xFFF) ? nac : ((p2cc > 0 && p2cc < 0xFFF) ? p2cc : 0);
             const ddn_nid::Gf gf = {sc.ex, sc.lg};
             const ddn_nid::Work wk = {sc.work + lane, sc.work + 23 * 64 + lane, sc.work + 47 * 64 + lane, sc.work + 71 * 64 + lane};
-            const ddn_nid::NidRes r = ddn_nid::nid_decode_wave(gf, wk, w, sc.nr, par, prel, observed, cfg.nid_threshold, sc.masks, lane);
+            r = ddn_nid::nid_decode_wave(gf, wk, w, sc.nr, par, prel, observed, cfg.nid_threshold, sc.masks, lane);
+            }
+            dbg_stamp(1);
             int duid = 0xFF;
             if (r.status > 0) { // p25p1_handle_nid_decode_success(): NAC / DUID updates
                 const bool valid = r.nac != 0 && r.nac != 0xFFF;
@@ -825,58 +875,34 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 ext = duid == 0x0 ? 339 : ((duid == 0x5 || duid == 0xA) ? 807 : (duid == 0x3 ? 15 : (duid == 0xF ? 159 : 0)));
             }
         } else if (phase == PH_TSBK || (phase == PH_MPDU && block == 0)) {
-            // the block's data dibits, de-interleaved: LLR pairs for the list decoder, hard dibits for the short cut
-            bool zero_llr = false;
+            // the block's data dibits, de-interleaved LLR pairs (lo 16 bits = the dibit's first bit)
             for (int r0 = 0; r0 < 2; r0++) {
                 const int i = lane + 64 * r0;
                 if (i < nsym) {
-                    bool st;
-                    int k, ska, nd;
-                    block_scan(sk0, nsym, i, st, k, ska, nd);
-                    if (!st && k < 98) {
+                    int k;
+                    if (!block_is_status(sk0, i, k) && k < 98) {
                         int d, relb, l0, l1;
                         slice_at(i, d, relb, l0, l1);
-                        const int at = deinterleave98(k);
-                        sc.d[at] = (int32_t)((uint32_t)(uint16_t)(int16_t)l0 | ((uint32_t)(uint16_t)(int16_t)l1 << 16));
-                        sc.hd[at] = (uint8_t)d;
-                        zero_llr |= (l0 == 0) | (l1 == 0);
+                        sc.d[deinterleave98(k)] = (int32_t)((uint32_t)(uint16_t)(int16_t)l0 | ((uint32_t)(uint16_t)(int16_t)l1 << 16));
                     }
                 }
             }
-            int sk_after, n_data;
-            {
-                bool st;
-                int k;
-                block_scan(sk0, nsym, -1, st, k, sk_after, n_data);
-            }
-            const bool any_zero = __any(zero_llr) || n_data < 98;
+            int n_data;
+            const int sk_after = block_counter_after(sk0, nsym, n_data);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // walk the trellis on the hard dibits from state 0 (every lane the same walk)
-            uint32_t by[3] = {0, 0, 0};
-            bool valid = !any_zero;
-            int st = 0;
-            for (int t = 0; t < 49 && valid; t++) {
-                const int nib = (sc.hd[2 * t] << 2) | sc.hd[2 * t + 1];
-                int nxt = -1;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    nxt = (half_rate_nibble((st << 2) | q) == nib) ? q : nxt;
-                }
-                valid = nxt >= 0;
-                st = nxt < 0 ? 0 : nxt;
-                if (t < 48) {
-                    const int byte = t >> 2;
-                    by[byte >> 2] |= (uint32_t)st << (8 * (byte & 3) + 6 - 2 * (t & 3));
-                }
-            }
-            int crc_ok = 0, sel = 0;
-            if (valid && crc16_ok(by)) {
-                crc_ok = 1; // the list decoder's first candidate is this code word and the CRC scan stops at it
-            } else {
+            // tsbk_decode_repetition_bytes(): list-8 decode, the first CRC16-clean candidate, else the best one.  The list's
+            // first candidate is the plain best path (ddn_p25h_dev.h), so the list proper is only run when that fails its CRC.
+            dbg_stamp(0);
+            uint32_t by[3];
+            half_rate_best_wave(sc, lane, by);
+            dbg_stamp(1);
+            int crc_ok = crc16_ok_wave(sc, by, lane), sel = 0;
+            dbg_stamp(2);
+            if (!crc_ok) {
+                dbg_path = 1;
                 half_rate_list_wave(sc, lane);
                 const int nout = sc.n_out;
-                sel = 0;
                 for (int q = 0; q < nout; q++) {
                     const uint32_t cw[3] = {sc.outl[q][0], sc.outl[q][1], sc.outl[q][2]};
                     if (crc16_ok(cw)) {
@@ -895,7 +921,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const int last = (byte0 >> 7) & 1;
                 ev_kind = EV_TSBK;
                 ev_a = block;
-                ev_b = crc_ok | (((last << 8) | sel) << 16);
+                ev_b = crc_ok | (((by[0] >> 8) & 0xFF) << 8) | (((last << 8) | sel) << 16); // bits 8..15: byte 1 of the block
                 block++;
                 if (last || block >= 3) {
                     phase = PH_IDLE;
@@ -938,6 +964,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             hs.nac = nac;
             hs.p2_cc = p2cc;
             h_served = seq;
+            H.rsp_ext[c] = ext;
+            H.rsp_more[c] = more;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __hip_atomic_store(&H.rsp_seq[c], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ev_kind) {
                 if (nev < cfg.max_events && gch < n_channels) {
                     int32_t* e = events + ((size_t)gch * cfg.max_events + nev) * 4;
@@ -945,13 +975,17 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     e[1] = ev_kind;
                     e[2] = ev_a;
                     e[3] = ev_b;
+                    if (cfg.dbg & 65536) {
+                        e[2] = dbg_path;
+                        e[3] = (int)((long long)clock64() - dbg_t0);
+                        if (cfg.dbg & 131072) {
+                            e[2] = dbg_path | ((int)(dbg_s[0] >> 4) << 4);
+                            e[3] = (int)(dbg_s[1] >> 4) | ((int)(dbg_s[2] >> 4) << 16);
+                        }
+                    }
                 }
                 h_nev = nev + 1;
             }
-            H.rsp_ext[c] = ext;
-            H.rsp_more[c] = more;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __hip_atomic_store(&H.rsp_seq[c], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
 
@@ -979,11 +1013,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             hstate[ch] = hs;
             n_events[ch] = h_nev;
         }
-        for (int k = lane; k < ddn_p25h::HN * CPW; k += 64) {
-            const int c = k % CPW, slot = k / CPW;
+        for (int k = lane; k < ddn_p25h::HN * CPW * 3; k += 64) {
+            const int w = k % 3, c = (k / 3) % CPW, slot = k / (3 * CPW);
             if (ch0 + c < n_channels) {
-                *reinterpret_cast<float4*>(hh_store + ((size_t)(ch0 + c) * ddn_p25h::HN + slot) * 4) =
-                    *reinterpret_cast<const float4*>(&H.hh[slot][c][0]);
+                hh_store[((size_t)(ch0 + c) * ddn_p25h::HN + slot) * 3 + w] = H.hh[slot][c][w];
             }
         }
     }
@@ -1272,13 +1305,20 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     int hseq = 0;
     auto hist_push = [&](float sym, float q_max, float q_min, int fl) {
         if (HM && live && s.hphase != 0) {
-            *reinterpret_cast<float4*>(&H.hh[s.hw & (ddn_p25h::HN - 1)][ln][0]) = make_float4(sym, q_max, q_min, __int_as_float(fl));
-            s.hw++;
+            float* e = &H.hh[s.hw][ln][0];
+            e[0] = sym;
+            e[1] = q_max;
+            e[2] = q_min;
+            s.hw = (s.hw + 1 >= ddn_p25h::HN) ? 0 : s.hw + 1;
         }
         if (HM && hpost) {
             hpost = false;
             hwait = true;
             hseq++;
+            if (cfg.dbg & 65536) {
+                s.dbg_nreq++;
+                s.dbg_wait -= (long long)clock64();
+            }
             H.req_kind[ln] = s.hphase;
             H.req_hw[ln] = s.hw;
             H.req_n[ln] = s.hn;
@@ -1286,7 +1326,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             H.req_neg[ln] = (s.lastsync == 2) ? 1 : 0;
             H.req_nc[ln] = s.hnc;
             s.hnc = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // the request is LDS traffic only (a wave's LDS operations complete in order): no wait for the ring stores in flight
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __hip_atomic_store(&H.req_seq[ln], hseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
@@ -1520,9 +1561,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 if (HM && __any(hwait)) {
                     if (hwait
                         && __hip_atomic_load(&H.rsp_seq[ln], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == hseq) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
                         const int ext = H.rsp_ext[ln];
                         hwait = false;
+                        if (cfg.dbg & 65536) {
+                            s.dbg_wait += (long long)clock64();
+                        }
                         if (ext > 0) { // the handler reads on
                             s.lock_left = ext;
                             s.hn = ext;
@@ -1531,6 +1575,13 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             s.hphase = 0;
                             frame_end();
                         }
+                    }
+                    // While a lane waits, the wave waits with it: the lanes share their trips, and one that falls behind has to
+                    // make up its symbols in trips of its own afterwards (measured: letting the others run ahead costs about
+                    // three times the decision's latency, standing still costs it once).
+                    if (__any(hwait) && !(cfg.dbg & 262144)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
                     }
                 }
                 const bool alive = live & !hwait;
@@ -2072,7 +2123,10 @@ launch_rxw(const float* raw, const float* filt, const float* prev_tail, float* f
            const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
            float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, const int32_t* lock_cfg,
            DdnP25HState* hstate, float* hh_store, int32_t* events, int32_t* n_events, hipStream_t st) {
-    const size_t shm = HM ? (((sizeof(LdsW<CPW>) + 15) & ~(size_t)15) + sizeof(LdsH<CPW>)) : sizeof(LdsW<CPW>);
+    const size_t shm = HM ? (((sizeof(LdsW<CPW, true>) + 15) & ~(size_t)15) + sizeof(LdsH<CPW>)) : sizeof(LdsW<CPW>);
+    if (HM && (cfg.sym_rate <= 0 || cfg.out_rate / cfg.sym_rate < 9)) {
+        return hipErrorInvalidValue; // the handler-mode window bookkeeping is sized for >= 9 samples per symbol
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rxw<CPW, HM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) {

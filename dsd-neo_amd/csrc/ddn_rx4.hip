@@ -27,6 +27,7 @@
 
 #include "ddn_device.h"
 #include "ddn_slicer_dev.h"
+#include "ddn_fsk4h_dev.h"
 #include "ddn_tables_fsk4.h"
 #include "ddn_tables_ambe.h"
 
@@ -54,6 +55,13 @@ struct Lds4 {
     int qo[2][CPW];
     uint32_t pat_bits[DDN_FSK4_MAX_PAT];
     uint32_t pat_meta[DDN_FSK4_MAX_PAT]; // type | neg << 8 | class << 16
+};
+
+// handler mode: the handlers' per-channel words and the dibits of the burst / frame being read (ddn_fsk4h_dev.h)
+template <int CPW>
+struct Lds4H {
+    int hs[ddn_fsk4h::F_COUNT][CPW];
+    uint8_t pay[144][CPW];
 };
 
 __device__ __forceinline__ void
@@ -117,7 +125,7 @@ adds(int i, int span, int c, int rf_mod, int l_edge) {
     return k + ((i == c - 1 || i == c + 1) ? 1 : 0);
 }
 
-template <int CPW, int MAXW, int PROTO>
+template <int CPW, int MAXW, int PROTO, bool HM>
 __global__ __launch_bounds__(128) void
 k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
           float* __restrict__ fstale, const float* __restrict__ taps, long n_long, size_t stride, int n_channels,
@@ -125,10 +133,13 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
           float* __restrict__ shist_store, uint8_t* __restrict__ phist_store, uint8_t* __restrict__ rhist_store,
           uint8_t* __restrict__ rec, uint8_t* __restrict__ flags, uint8_t* __restrict__ pay, int32_t* __restrict__ counts,
           size_t max_sym, const int32_t* __restrict__ lock4, int32_t* __restrict__ sync_pos, uint8_t* __restrict__ sync_pat,
-          uint8_t* __restrict__ pre, uint8_t* __restrict__ pre_rel, int32_t* __restrict__ n_sync, int max_sync) {
+          uint8_t* __restrict__ pre, uint8_t* __restrict__ pre_rel, int32_t* __restrict__ n_sync, int max_sync,
+          int32_t* __restrict__ hwords, uint8_t* __restrict__ hpay_store, const DdnFec3Tables* __restrict__ htab,
+          int32_t* __restrict__ events, int32_t* __restrict__ n_events) {
     constexpr int TSW = Lds4<CPW>::TSW, RMASKW = Lds4<CPW>::RMASKW, QCAPW = Lds4<CPW>::QCAPW;
     extern __shared__ unsigned char smem_raw[];
     Lds4<CPW>& L = *reinterpret_cast<Lds4<CPW>*>(smem_raw);
+    Lds4H<CPW>& LH = *reinterpret_cast<Lds4H<CPW>*>(smem_raw + ((sizeof(Lds4<CPW>) + 15) & ~(size_t)15));
     const int n = (int)n_long; // the C-ABI keeps a call below 2^31 samples
     const int lane = threadIdx.x & 63;
     const bool loader = threadIdx.x >= 64;
@@ -155,6 +166,15 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     DdnFsk4State s;
     if (live) {
         s = state[ch];
+        if (HM) {
+            for (int k = 0; k < ddn_fsk4h::F_COUNT; k++) {
+                LH.hs[k][ln] = hwords[(size_t)ch * ddn_fsk4h::F_COUNT + k];
+            }
+            LH.hs[ddn_fsk4h::F_NEV][ln] = 0; // events are per call
+            for (int k = 0; k < 144; k++) {
+                LH.pay[k][ln] = hpay_store[(size_t)ch * 144 + k];
+            }
+        }
         for (int k = 0; k < 24; k++) {
             L.lb[k][ln] = lbuf_store[(size_t)k * n_channels + ch];
         }
@@ -290,6 +310,38 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
         }
     };
+    // ---- handler mode (recurrence lane) ---------------------------------------------------------------------------------
+    const int cfg_max_events = cfgp->max_events;
+    auto hctx = [&]() {
+        ddn_fsk4h::Ctx x;
+        x.hs = &LH.hs[0][ln];
+        x.pay = &LH.pay[0][ln];
+        x.stride = CPW;
+        x.T = htab;
+        x.events = events ? events + (size_t)ch * cfg_max_events * 4 : nullptr;
+        x.max_events = cfg_max_events;
+        return x;
+    };
+    // the dibit getDibit() hands the handler: sliced against the frame's (frozen) thresholds, polarity undone
+    auto hard_dibit = [&](float sym, int neg) {
+        const int d = sym > s.center ? (sym > s.umid ? 1 : 0) : (sym < s.lmid ? 3 : 2);
+        return neg ? (d ^ 2) : d;
+    };
+    // one in-frame symbol has been read: keep its dibit for the handler
+    auto hsymbol = [&](float sym, int neg) {
+        using namespace ddn_fsk4h;
+        if (PROTO == 1) {
+            if (s.hmode >= M_DATA_SUFFIX && s.hmode != M_SKIP66 && s.hidx < 144) {
+                LH.pay[s.hidx][ln] = (uint8_t)hard_dibit(sym, neg);
+            }
+            s.hidx++;
+        } else if (s.hmode == M_NX_LICH) {
+            // nxdn_descramble_with_seed(.., 8, 228): the PN9 sequence starts 0 0 1 0 0 1 1 1
+            const int dd = hard_dibit(sym, neg) ^ (((0xE4 >> s.hidx) & 1) << 1);
+            s.hlich |= ((dd >> 1) & 1) << (7 - s.hidx);
+            s.hidx++;
+        }
+    };
     int pos = 0; // call-relative index of this lane's next sample
     const float* rrow = &L.raw[ln][0];
     const float* frow = &L.flt[ln][0];
@@ -334,10 +386,52 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     s.hunt_pos = 0;
                     snapshot_filter();
                     no_carrier(s);
+                    if (HM && PROTO == 1) {
+                        ddn_fsk4h::conf_reset(hctx()); // noCarrier(): dmr_confidence_reset(), engine.c:1856
+                    }
                 }
                 if (!(cfg.slow_type && s.lastsync == cfg.slow_type) && s.hunt_pos >= 1800) {
                     snapshot_filter();
                     no_carrier(s);
+                    if (HM && PROTO == 1) {
+                        ddn_fsk4h::conf_reset(hctx());
+                    }
+                    hunt_restart(s);
+                }
+            };
+            // handler mode: the phase's last symbol is in - the handler decides (lock_left set anew, or the frame is over)
+            auto hphase_end = [&]() {
+                using namespace ddn_fsk4h;
+                int mode = s.hmode, next = 0;
+                bool on;
+                if (PROTO == 1) {
+                    const Ctx x = hctx();
+                    on = dmr_phase_end(x, o, mode, next);
+                    if (on && mode == M_BURST_CACH) {
+                        s.hidx = 0;
+                    }
+                } else {
+                    on = false;
+                    if (mode == M_NX_LICH) {
+                        int lich7, par_ok;
+                        on = nxdn_lich_ok(s.hlich, lich7, par_ok);
+                        const Ctx x = hctx();
+                        x.ev(o, EV_NXDN_LICH, on ? 1 : 0, lich7, par_ok);
+                        if (on) {
+                            mode = M_NX_REST;
+                            next = 174;
+                        } else { // nxdn_mark_bad_sync(): lastsynctype NONE - the NXDN filter gate and the two-match rule see it
+                            snapshot_filter();
+                            s.filter_on = 0;
+                            s.lastsync = 0;
+                        }
+                    }
+                }
+                if (on) {
+                    s.hmode = mode;
+                    s.lock_left = next;
+                } else {
+                    s.hmode = M_IDLE;
                     hunt_restart(s);
                 }
             };
@@ -411,8 +505,15 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             qk++;
                             s.maxref = s.max;
                             s.minref = s.min;
+                            if (HM) {
+                                hsymbol(sym, neg);
+                            }
                             if (--s.lock_left <= 0) {
-                                hunt_restart(s);
+                                if (HM) {
+                                    hphase_end();
+                                } else {
+                                    hunt_restart(s);
+                                }
                             }
                             o++;
                         }
@@ -575,8 +676,15 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         s.maxref = s.max;
                         s.minref = s.min;
                         fl = 1 | (neg ? 4 : 0);
+                        if (HM) {
+                            hsymbol(sym, neg);
+                        }
                         if (--s.lock_left <= 0) {
-                            hunt_restart(s);
+                            if (HM) {
+                                hphase_end();
+                            } else {
+                                hunt_restart(s);
+                            }
                         }
                     } else {
                         L.lb[s.lidx][ln] = sym;
@@ -669,7 +777,39 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     s.lock_left = lock4[(size_t)ch * 4 + ((pm >> 16) & 3)];
                                     fl = 2 | (((pm >> 8) & 1) ? 4 : 0) | (hit << 3);
                                     sync_entry = true;
+                                    if (HM) {
+                                        using namespace ddn_fsk4h;
+                                        if (PROTO == 1 && hit < 2) {
+                                            // the 90 dibits the handler finds at dmr_payload_p - 90: the 66 before the sync as
+                                            // dmr_resample_on_sync() has just re-sliced them (needs 90 symbols of history), the 24 of
+                                            // the sync as they were sliced while hunting
+                                            const bool redig = s.scount >= 90;
+                                            for (int i = 0; i < 90; i++) {
+                                                int idx = s.shead - 90 + i;
+                                                idx += idx < 0 ? HN : 0;
+                                                const float v = L.sh[idx][ln];
+                                                const bool nw = redig && i < 66;
+                                                const float c0 = nw ? s.center : q1, u0 = nw ? s.umid : q2, l0 = nw ? s.lmid : q3;
+                                                const int d = v > c0 ? (v > u0 ? 1 : 0) : (v < l0 ? 3 : 2);
+                                                LH.pay[i][ln] = (uint8_t)(((90 - i) <= s.scount) ? d : 0);
+                                            }
+                                            const Ctx x = hctx();
+                                            int mode = M_IDLE, next = 0;
+                                            const bool on = dmr_begin(x, o, hit == 1, mode, next);
+                                            s.hmode = mode;
+                                            s.hidx = 90;
+                                            s.lock_left = on ? next : 0;
+                                        } else if (PROTO == 1) {
+                                            s.hmode = M_FIXED; // MS / direct-mode words: the configured count
+                                        } else {
+                                            s.hmode = M_NX_LICH;
+                                            s.hidx = 0;
+                                            s.hlich = 0;
+                                            s.lock_left = 8;
+                                        }
+                                    }
                                     if (s.lock_left <= 0) {
+                                        s.hmode = 0;
                                         hunt_restart(s);
                                     }
                                 }
@@ -727,6 +867,17 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
     }
     if (live) {
+        if (HM) {
+            if (n_events) {
+                n_events[ch] = LH.hs[ddn_fsk4h::F_NEV][ln];
+            }
+            for (int k = 0; k < ddn_fsk4h::F_COUNT; k++) {
+                hwords[(size_t)ch * ddn_fsk4h::F_COUNT + k] = LH.hs[k][ln];
+            }
+            for (int k = 0; k < 144; k++) {
+                hpay_store[(size_t)ch * 144 + k] = LH.pay[k][ln];
+            }
+        }
         s.n_abs = abs0 + n;
         state[ch] = s;
         counts[ch] = o;
@@ -945,22 +1096,24 @@ k_nxdn_crc(const uint8_t* __restrict__ bytes, int stride, int n, int kind, uint8
     ok[i] = crc == got ? 1 : 0;
 }
 
-template <int CPW, int MAXW, int PROTO>
+template <int CPW, int MAXW, int PROTO, bool HM>
 hipError_t
 launch(const float* raw, const float* filt, const float* prev_tail, float* fstale, const float* taps, long n, size_t stride,
        int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state, float* lbuf_store, float* shist_store,
        uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec, uint8_t* flags, uint8_t* pay, int32_t* counts,
        size_t max_sym, const int32_t* lock4, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre, uint8_t* pre_rel,
-       int32_t* n_sync, int max_sync, hipStream_t st) {
-    const size_t shmem = sizeof(Lds4<CPW>);
-    hipError_t e = hipFuncSetAttribute((const void*)k_fsk4_rx<CPW, MAXW, PROTO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+       int32_t* n_sync, int max_sync, int32_t* hwords, uint8_t* hpay, const DdnFec3Tables* htab, int32_t* events,
+       int32_t* n_events, hipStream_t st) {
+    const size_t shmem = HM ? (((sizeof(Lds4<CPW>) + 15) & ~(size_t)15) + sizeof(Lds4H<CPW>)) : sizeof(Lds4<CPW>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fsk4_rx<CPW, MAXW, PROTO, HM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) {
         return e;
     }
-    hipLaunchKernelGGL((k_fsk4_rx<CPW, MAXW, PROTO>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shmem, st, raw, filt,
-                       prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store, phist_store,
-                       rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel, n_sync,
-                       max_sync);
+    hipLaunchKernelGGL((k_fsk4_rx<CPW, MAXW, PROTO, HM>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shmem, st,
+                       raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store,
+                       phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel,
+                       n_sync, max_sync, hwords, hpay, htab, events, n_events);
     return hipGetLastError();
 }
 } // namespace
@@ -970,26 +1123,37 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
                 size_t stride, int n_channels, const DdnFsk4Config* cfg, DdnFsk4State* state, float* lbuf_store,
                 float* shist_store, uint8_t* phist_store, uint8_t* rhist_store, uint8_t* rec, uint8_t* flags, uint8_t* pay,
                 int32_t* counts, size_t max_sym, const int32_t* lock4, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre,
-                uint8_t* pre_rel, int32_t* n_sync, int max_sync, int channels_per_wave, int cfg_sps, int protocol, hipStream_t st) {
+                uint8_t* pre_rel, int32_t* n_sync, int max_sync, int channels_per_wave, int cfg_sps, int protocol, int handlers,
+                int32_t* hwords, uint8_t* hpay, int32_t* events, int32_t* n_events, hipStream_t st) {
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
     if (protocol != 1 && protocol != 2) {
         return hipErrorInvalidValue;
     }
+    const DdnFec3Tables* htab = nullptr;
+    if (handlers) {
+        if (!hwords || !hpay) {
+            return hipErrorInvalidValue;
+        }
+        const hipError_t e = ddn_dev_fec3_tables(&htab, st);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
     // MAXW: the longest whole symbol the straight pass takes (samples per symbol + one slip sample); 12 covers 4800 baud at
     // 48 ksps, 22 covers 2400 baud
     const int sps = cfg_sps > 0 ? cfg_sps : 64;
+#define DDN_RX4_ARGS                                                                                                       \
+    raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store, phist_store, rhist_store, rec,  \
+        flags, pay, counts, max_sym, lock4, sync_pos, sync_pat, pre, pre_rel, n_sync, max_sync, hwords, hpay, htab, events,     \
+        n_events, st
 #define DDN_RX4_GO(CPW_, MAXW_)                                                                                            \
     do {                                                                                                                   \
         if (protocol == 1) {                                                                                               \
-            return launch<CPW_, MAXW_, 1>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, \
-                                          shist_store, phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4,  \
-                                          sync_pos, sync_pat, pre, pre_rel, n_sync, max_sync, st);                         \
+            return handlers ? launch<CPW_, MAXW_, 1, true>(DDN_RX4_ARGS) : launch<CPW_, MAXW_, 1, false>(DDN_RX4_ARGS);     \
         }                                                                                                                  \
-        return launch<CPW_, MAXW_, 2>(raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store,   \
-                                      shist_store, phist_store, rhist_store, rec, flags, pay, counts, max_sym, lock4,      \
-                                      sync_pos, sync_pat, pre, pre_rel, n_sync, max_sync, st);                             \
+        return handlers ? launch<CPW_, MAXW_, 2, true>(DDN_RX4_ARGS) : launch<CPW_, MAXW_, 2, false>(DDN_RX4_ARGS);         \
     } while (0)
     if (channels_per_wave <= 4) {
         if (sps <= 11) {
@@ -1014,6 +1178,7 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
     }
     DDN_RX4_GO(32, 22);
 #undef DDN_RX4_GO
+#undef DDN_RX4_ARGS
 }
 
 extern "C" hipError_t

@@ -40,6 +40,28 @@ typedef struct ddn_fsk4_rx ddn_fsk4_rx;
 int ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out);
 void ddn_fsk4_rx_destroy(ddn_fsk4_rx* b);
 int ddn_fsk4_rx_reset(ddn_fsk4_rx* b);
+/* enable != 0: the reference's own handlers decide how long a frame is read in frame (plain -fs / -fi, inverted = 0), inside the
+ * loop - lock_symbols[] then only serves the sync types without a restated handler (DMR MS / direct mode words):
+ *   DMR BS data word   dmr_data_sync() (src/protocol/dmr/dmr_data.c:117-343): TACT Hamming(7,4) on the cached CACH (fails: no live
+ *                      dibit), 5 live dibits, slot type Golay(20,8) (fails: stop) + colour-code gate, 49 more; then skipDibit(66)
+ *   DMR BS voice word  dmrBSBootstrap() + dmrBS() (src/protocol/dmr/dmr_bs.c:697-948): 54 live dibits, then 144 per burst with the
+ *                      TACT / repeated-carrier / sync-word / EMB QR(16,7,6) / colour-code-gate decisions
+ *                      (src/protocol/dmr/dmr_confidence.c) - this is the path that prints the reference's "Color Code=02" on its
+ *                      dmr_voice / dmr_t3_cc captures (tests/CMakeLists.txt:8925-8930)
+ *   NXDN               nxdn_frame() (src/protocol/nxdn/nxdn_frame.c:181-233,592-640): 8 LICH dibits, parity + profile; rejected ->
+ *                      the handler returns and lastsynctype is cleared
+ * ddn_fsk4_rx_set_events: device buffers for the handlers' decisions of the next runs, d_events i32 [B][max_events][4] =
+ * {output index of the deciding symbol, kind, a, b | c << 16}, d_n_events i32 [B]:
+ *   kind 4 NXDN LICH        a = accepted, b = LICH (7 bits), c = parity ok
+ *   kind 5 DMR data burst   a = slot type ok, b = colour code (-1 Golay failed, -2 TACT failed), c = data type | reject << 8 | pending << 9
+ *   kind 6 "Color Code="    a = the value the reference prints (16 = XX), b = VC (0: data burst), c = slot
+ *   kind 7 DMR voice burst  a = slot, b = EMB colour code (25: none), c = voice sync word | action << 4 (1 on, 2 end)
+ *   kind 8 DMR voice end    a = 1 bootstrap / 0 loop, b = TACT ok, c = EMB / sync ok */
+int ddn_fsk4_rx_set_handlers(ddn_fsk4_rx* b, int enable);
+int ddn_fsk4_rx_set_events(ddn_fsk4_rx* b, int32_t* d_events, int32_t* d_n_events, size_t max_events);
+/* host convenience: event buffers owned by the batch object (arm once), copied to host arrays [B][max_events][4] / [B] after a run */
+int ddn_fsk4_rx_events_host_arm(ddn_fsk4_rx* b, size_t max_events);
+int ddn_fsk4_rx_events_host_read(ddn_fsk4_rx* b, int32_t* events, int32_t* n_events);
 size_t ddn_fsk4_rx_max_symbols(const ddn_fsk4_rx* b, size_t n);
 size_t ddn_fsk4_rx_max_syncs(const ddn_fsk4_rx* b, size_t n);
 /* per-channel handler lengths, host array int32 [n_channels][4] */

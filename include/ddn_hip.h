@@ -183,7 +183,7 @@ int ddn_p25_rx_set_lock_symbols(ddn_p25_rx* b, const int32_t* per_channel);
  * {output index of the deciding symbol, kind, a, b}, d_n_events i32 [B] (decisions of that call; may exceed max_events, only
  * the first max_events are stored):
  *   kind 1 NID        a = p25p1_nid_decode status (1 ok, 2 parity override, <= 0 failed), b = NAC | DUID << 16 (DUID 0xFF: none)
- *   kind 2 TSDU block a = block index, b = CRC16 good | (last-block flag << 8 | selected list candidate) << 16
+ *   kind 2 TSDU block a = block index, b = CRC16 good | byte 1 of the block << 8 | (last-block flag << 8 | selected list candidate) << 16
  *   kind 3 PDU header a = header CRC16 good, b = blocks to read | byte 0 << 16
  * Without buffers the decisions are still taken, just not reported. */
 int ddn_p25_rx_set_handlers(ddn_p25_rx* b, int enable, int nid_erasure_threshold);
@@ -205,6 +205,8 @@ int ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* rec
 int ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
                            size_t max_symbols, int32_t* events, int32_t* n_events, size_t max_events);
 int ddn_p25_rx_get_thresholds(ddn_p25_rx* b, int channel, float out7[7]);
+/* timing experiments (environment DDN_RX_DBG bit 65536): handler requests of a channel so far, cycles its lane waited for them */
+int ddn_p25_rx_debug_counters(ddn_p25_rx* b, int channel, long long out2[2]);
 
 /* ---- Gardner symbol-timing recovery (CQPSK branch), batched ----------------------------------------------
  * == op25_gardner_cc(struct demod_state*) (include/dsd-neo/dsp/costas.h; src/dsp/costas.cpp:804-858) applied to B

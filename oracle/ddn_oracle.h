@@ -189,7 +189,7 @@ void orc_p25_filter_run(float hist[90], const float* in, long n, float* out);
 #define ORC_HEV_MAX 4096
 enum {
     ORC_HEV_P25_NID = 1,     /* a = status, b = nac, c = duid (0xFF invalid) */
-    ORC_HEV_P25_TSBK = 2,    /* a = block, b = crc ok, c = last_block << 8 | selected candidate */
+    ORC_HEV_P25_TSBK = 2,    /* a = block, b = crc ok | byte 1 << 8, c = last_block << 8 | selected candidate */
     ORC_HEV_P25_MPDU = 3,    /* a = header crc ok, b = blocks to read, c = byte 0 */
     ORC_HEV_NXDN_LICH = 4,   /* a = accepted, b = lich, c = parity ok */
     ORC_HEV_DMR_DATA = 5,    /* a = slot type ok, b = colour code (-1 Golay failed, -2 TACT failed), c = burst | reject << 8 | pending << 9 */

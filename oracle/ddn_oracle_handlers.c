@@ -205,7 +205,7 @@ orc_p25h_symbol(orc_p25h* h, long pos, int d, int l0, int l1, orc_hevents* ev) {
             int crc_ok;
             const int sel = half_rate_select(h, by, &crc_ok);
             const int last = (by[0] >> 7) & 1;
-            ev_push(ev, pos, ORC_HEV_P25_TSBK, h->block, crc_ok, (last << 8) | (sel & 0xFF));
+            ev_push(ev, pos, ORC_HEV_P25_TSBK, h->block, crc_ok | (by[1] << 8), (last << 8) | (sel & 0xFF));
             h->block++;
             h->idx = 0;
             h->k = 0;

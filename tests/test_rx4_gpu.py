@@ -223,3 +223,76 @@ def test_nxdn48_known_answer_on_device(built):
         vcall = [m for ran, m in msgs if rx4.bits_int(m[2:8]) == 1]
         assert len(rows) >= 50 and len(vcall) >= 4
         assert all(rx4.bits_int(m[24:40]) == 901 for m in vcall)
+
+
+# ---- the reference's handlers inside the loop (ddn_fsk4_rx_set_handlers) ----------------------------------------------------
+def _oracle_handlers(x, proto, rf_mod):
+    rx = rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf_mod, handler=1))
+    out = rx.run(x)
+    out["events"] = np.array([[e[0], e[1], e[2], (e[3] & 0xFFFF) | ((e[4] & 0xFFFF) << 16)] for e in rx.events.rows()],
+                             np.int64).reshape(-1, 4)
+    return out
+
+
+HCASES = [("iq_dmr_t3_cc.npz", 2, rx4.PROTO_DMR, 2), ("iq_dmr_voice.npz", 2, rx4.PROTO_DMR, 2),
+          ("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 2), ("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 0),
+          ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 0)]
+
+
+@pytest.mark.parametrize("cap,lpf,proto,rf_mod", HCASES)
+def test_handlers_in_the_loop_equal_the_oracle(built, cap, lpf, proto, rf_mod):
+    """records, flags, payload, hand-overs AND the handlers' decisions (events) bit for bit, in one call and across call splits;
+    channels = the capture delayed, negated, behind silence"""
+    disc = rx4.capture_disc(cap, lpf)[:96000]
+    n = len(disc)
+    B = 6
+    rng = np.random.default_rng(5)
+    x = np.zeros((B, n), np.float32)
+    for c in range(B):
+        d = 41 * c
+        x[c, :d] = rng.standard_normal(d) * 500
+        x[c, d:] = disc[:n - d]
+    x[3] = -x[3]
+    x[4, :5000] = 0.0
+    want = [_oracle_handlers(x[c], proto, rf_mod) for c in range(B)]
+    gproto = ddn.FSK4_DMR if proto == rx4.PROTO_DMR else ddn.FSK4_NXDN48
+    for splits in ([0, n], [0, 9, 4000, 4001, 30000, 52345, n]):
+        rx = ddn.Fsk4Rx(B, gproto, rf_mod=rf_mod, handlers=True)
+        parts = [rx.run_host(x[:, a:b]) for a, b in zip(splits[:-1], splits[1:])]
+        for c in range(B):
+            got = dict(cnt=[0] * B, n_sync=[0] * B)
+            rec = np.concatenate([p["rec"][c, :p["cnt"][c]] for p in parts])
+            fl = np.concatenate([p["fl"][c, :p["cnt"][c]] for p in parts])
+            pay = np.concatenate([p["pay"][c, :p["cnt"][c]] for p in parts])
+            base = np.cumsum([0] + [int(p["cnt"][c]) for p in parts])
+            ev = []
+            for k, p in enumerate(parts):
+                e = p["events"][c, :p["n_events"][c]].astype(np.int64)
+                e[:, 0] += base[k]
+                ev.append(e)
+            ev = np.concatenate(ev)
+            r4, sym = rec4_of(rec)
+            w = want[c]
+            assert len(sym) == len(w["sym"]) and np.array_equal(sym.view(np.uint32), w["sym"].view(np.uint32)), (c, splits)
+            bad = np.flatnonzero(fl != w["fl"])
+            assert bad.size == 0, (c, splits, bad[:4], fl[bad[:4]], w["fl"][bad[:4]])
+            assert np.array_equal(r4, w["rec4"]) and np.array_equal(pay, w["pay"]), (c, splits)
+            m = np.array([-1, -1, -1, 0xFFFFFFFF])
+            assert len(ev) == len(w["events"]) and np.array_equal(ev & m, w["events"] & m), (c, splits, ev[:5], w["events"][:5])
+
+
+def test_dmr_color_code_02_on_the_device(built):
+    """DECODE_IQ_DMR_VOICE / DECODE_IQ_DMR_T3_CC: the reference prints "Color Code=02" on these captures under plain -fs
+    (tests/CMakeLists.txt:8925-8930); with its handlers inside the loop the device reports the same (event kind 6)"""
+    for cap in ("iq_dmr_t3_cc.npz", "iq_dmr_voice.npz"):
+        disc = rx4.capture_disc(cap, 2)
+        rx = ddn.Fsk4Rx(1, ddn.FSK4_DMR, rf_mod=2, handlers=True)
+        out = rx.run_host(disc[None])
+        ev = out["events"][0, :out["n_events"][0]]
+        printed = ev[ev[:, 1] == 6][:, 2]
+        assert (printed == 2).sum() >= 4, (cap, printed)
+    disc = rx4.capture_disc("iq_dmr_t3_ras_cc.npz", 2)
+    out = ddn.Fsk4Rx(1, ddn.FSK4_DMR, rf_mod=2, handlers=True).run_host(disc[None])
+    ev = out["events"][0, :out["n_events"][0]]
+    printed = ev[ev[:, 1] == 6][:, 2]
+    assert len(printed) >= 58 and set(printed) == {0}                      # DECODE_IQ_DMR_T3_RAS_CC_COLOR_CODE
