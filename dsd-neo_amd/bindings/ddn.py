@@ -406,6 +406,111 @@ PROTOTYPES.update({
 })
 
 
+class P25ChainConfig(C.Structure):  # == ddn_p25_chain_config (include/ddn_chain.h)
+    _fields_ = [("n_channels", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int), ("input_format", C.c_int),
+                ("vocoder", C.c_int), ("max_frames", C.c_int), ("max_ldu", C.c_int), ("max_events", C.c_int),
+                ("carry_symbols", C.c_int)]
+
+
+class P25ChainResults(C.Structure):  # == ddn_p25_chain_results
+    _fields_ = [("stride_symbols", C.c_size_t), ("d_records10", C.c_void_p), ("d_flags", C.c_void_p), ("d_counts", C.c_void_p),
+                ("d_new", C.c_void_p), ("d_events", C.c_void_p), ("d_n_events", C.c_void_p), ("d_n_syncs", C.c_void_p),
+                ("d_sync_pos", C.c_void_p), ("d_nid4", C.c_void_p), ("d_tsbk", C.c_void_p), ("d_tsbk_crc", C.c_void_p),
+                ("d_ldu_words", C.c_void_p * 2), ("d_ldu_rs_data", C.c_void_p * 2), ("d_ldu_rs_status", C.c_void_p * 2),
+                ("d_lsd_bits", C.c_void_p), ("d_lsd_ok", C.c_void_p), ("d_hdu_rs_data", C.c_void_p), ("d_hdu_rs_status", C.c_void_p),
+                ("d_tdulc_rs_data", C.c_void_p), ("d_tdulc_rs_status", C.c_void_p), ("d_n_ldu", C.c_void_p),
+                ("d_imbe_bits", C.c_void_p), ("d_imbe_result", C.c_void_p), ("d_pcm", C.c_void_p)]
+
+
+class P25ChainHostOut(C.Structure):  # == ddn_p25_chain_host_out
+    _fields_ = [("records10", C.c_void_p), ("flags", C.c_void_p), ("counts", C.c_void_p), ("events", C.c_void_p),
+                ("n_events", C.c_void_p), ("nid4", C.c_void_p), ("tsbk", C.c_void_p), ("pcm", C.c_void_p)]
+
+
+PROTOTYPES.update({
+    "ddn_p25_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_p25_chain_destroy": (None, [C.c_void_p]),
+    "ddn_p25_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25_chain_run_pipelined": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_p25_chain_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25_chain_flush": (C.c_int, [C.c_void_p]),
+    "ddn_p25_chain_wait": (C.c_int, [C.c_void_p]),
+    "ddn_p25_chain_get_results": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_p25_chain_stride_symbols": (C.c_size_t, [C.c_void_p]),
+    "ddn_p25_chain_frame_slots": (C.c_int, [C.c_void_p]),
+    "ddn_p25_chain_max_ldu": (C.c_int, [C.c_void_p]),
+    "ddn_p25_chain_max_events": (C.c_int, [C.c_void_p]),
+    "ddn_p25_chain_front_end": (C.c_void_p, [C.c_void_p]),
+    "ddn_p25_chain_rx": (C.c_void_p, [C.c_void_p]),
+    "ddn_p25_chain_mbe": (C.c_void_p, [C.c_void_p]),
+    "ddn_p25p1_framer_device_syncs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_tsbk_select_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_device_alloc": (C.c_int, [C.c_size_t, C.c_void_p]),
+    "ddn_device_free": (None, [C.c_void_p]),
+    "ddn_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ddn_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ddn_host_alloc_pinned": (C.c_int, [C.c_size_t, C.c_void_p]),
+    "ddn_host_free_pinned": (None, [C.c_void_p]),
+})
+
+
+class P25ChainC:
+    """ddn_p25_chain (include/ddn_chain.h): the whole P25 Phase 1 path as one C object.  Thin ctypes view: run() / run_pipelined()
+    take a device pointer; fetch(name, dtype, shape) copies one of the result arrays of the last call to the host."""
+
+    def __init__(self, n_channels, samples_per_call, block_len=8192, vocoder=1, max_frames=0, max_ldu=0, max_events=0,
+                 carry_symbols=0, input_format=0):
+        import numpy as np
+        self.np = np
+        cfg = P25ChainConfig(n_channels, samples_per_call, block_len, input_format, vocoder, max_frames, max_ldu, max_events,
+                             carry_symbols)
+        self.h = C.c_void_p()
+        _check(lib().ddn_p25_chain_create(C.byref(cfg), C.byref(self.h)), "ddn_p25_chain_create")
+        self.B, self.n = n_channels, samples_per_call
+        self.stride = lib().ddn_p25_chain_stride_symbols(self.h)
+        self.F = lib().ddn_p25_chain_frame_slots(self.h)
+        self.Fv = lib().ddn_p25_chain_max_ldu(self.h)
+        self.E = lib().ddn_p25_chain_max_events(self.h)
+        self.T = carry_symbols or 896
+
+    def close(self):
+        if self.h:
+            lib().ddn_p25_chain_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, d_iq_ptr, stream=None):
+        _check(lib().ddn_p25_chain_run(self.h, d_iq_ptr, stream), "ddn_p25_chain_run")
+
+    def run_pipelined(self, d_iq_ptr):
+        _check(lib().ddn_p25_chain_run_pipelined(self.h, d_iq_ptr), "ddn_p25_chain_run_pipelined")
+
+    def run_host(self, h_iq_ptr, out=None):
+        _check(lib().ddn_p25_chain_run_host(self.h, h_iq_ptr, C.byref(out) if out is not None else None), "ddn_p25_chain_run_host")
+
+    def flush(self):
+        _check(lib().ddn_p25_chain_flush(self.h), "ddn_p25_chain_flush")
+
+    def wait(self):
+        _check(lib().ddn_p25_chain_wait(self.h), "ddn_p25_chain_wait")
+
+    def results(self):
+        r = P25ChainResults()
+        _check(lib().ddn_p25_chain_get_results(self.h, C.byref(r)), "ddn_p25_chain_get_results")
+        return r
+
+    def fetch(self, ptr, dtype, shape):
+        np = self.np
+        a = np.zeros(shape, dtype)
+        _check(lib().ddn_device_download(a.ctypes.data, ptr, a.nbytes), "ddn_device_download")
+        return a
+
+
 class Fsk4Rx:
     """ddn_fsk4_rx batch object (host-buffer convenience wrapper used by the tests)"""
 

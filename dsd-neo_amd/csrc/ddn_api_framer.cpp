@@ -120,6 +120,17 @@ ddn_p25p1_framer_index(ddn_p25p1_framer* f, const uint8_t* d_flags, const int32_
     return DDN_OK;
 }
 
+// device views of the index (valid until the next ddn_p25p1_framer_index on the same object)
+extern "C" int
+ddn_p25p1_framer_device_syncs(ddn_p25p1_framer* f, const int32_t** d_n_syncs, const int32_t** d_sync_pos) {
+    if (!f || !d_n_syncs || !d_sync_pos) {
+        return DDN_EINVAL;
+    }
+    *d_n_syncs = f->d_n_syncs;
+    *d_sync_pos = f->d_sync_pos;
+    return DDN_OK;
+}
+
 extern "C" int
 ddn_p25p1_framer_get_syncs(ddn_p25p1_framer* f, int32_t* n_syncs, int32_t* sync_pos) {
     if (!f || !n_syncs) {

@@ -259,6 +259,12 @@ hipError_t ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, i
 hipError_t ddn_dev_launch_carry(const void* in, int in_fmt, size_t ch_stride, long n, void* carry, int n_channels,
                                 hipStream_t st);
 hipError_t ddn_dev_zero(void* p, size_t bytes, hipStream_t st);
+hipError_t ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, const int32_t* cnt_prev, int have_prev,
+                               uint8_t* rec_cur, uint8_t* fl_cur, size_t stride_sym, int T, int n_channels, hipStream_t st);
+hipError_t ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, int flush, int32_t* cnt_scan, int32_t* cnt_full,
+                                hipStream_t st);
+hipError_t ddn_dev_tsbk_select(const uint8_t* cand, const int32_t* counts, size_t n, uint8_t* out12, uint8_t* crc_ok, uint8_t* sel,
+                               hipStream_t st);
 #ifdef __cplusplus
 }
 #endif

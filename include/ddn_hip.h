@@ -385,6 +385,14 @@ void ddn_p25p1_framer_destroy(ddn_p25p1_framer* f);
 int ddn_p25p1_framer_index(ddn_p25p1_framer* f, const uint8_t* d_flags, const int32_t* d_counts, size_t max_symbols,
                            void* hip_stream);
 int ddn_p25p1_framer_get_syncs(ddn_p25p1_framer* f, int32_t* n_syncs, int32_t* sync_pos); /* host copies, synchronous */
+/* the same arrays as device pointers: n_syncs [B], sync_pos [B][max_frames] (valid until the next _index on this object) */
+int ddn_p25p1_framer_device_syncs(ddn_p25p1_framer* f, const int32_t** d_n_syncs, const int32_t** d_sync_pos);
+/* tsbk_decode_repetition_bytes() after the list decoder (src/protocol/p25/phase1/p25p1_tsbk.c:108-130): of each item's
+ * candidates [n][8] (ddn_fec_p25_12_soft_list_batch output) the first whose CRC16 is clean, else the first; out12 [n][12],
+ * crc_ok [n], sel [n] (may be NULL) */
+struct ddn_p25_12_candidate;
+int ddn_fec_p25_tsbk_select_batch(const struct ddn_p25_12_candidate* d_candidates8, const int32_t* d_counts, size_t n, uint8_t* d_out12,
+                                  uint8_t* d_crc_ok, uint8_t* d_sel, void* hip_stream);
 int ddn_p25p1_framer_gather_nid(ddn_p25p1_framer* f, const uint8_t* d_records10, const int32_t* d_counts,
                                 size_t max_symbols, uint8_t* d_bits63, uint8_t* d_reliab63, uint8_t* d_parity,
                                 uint8_t* d_parity_reliab, uint8_t* d_valid, void* hip_stream);
