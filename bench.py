@@ -6,20 +6,25 @@
 
 metric  "I/Q Msamples/s end-to-end (demod->FEC->MBE) per GPU; % HBM roofline"
 step    BASELINE configs[2] with the vocoder on: B = 4096 P25 Phase 1 channels per GPU x n = 48000 complex cu8 samples (1 s
-        of air time each), resident in HBM, through the whole chain on the device:
-          widen + 135-tap channel LPF + FSK discriminator -> P25 matched filter -> symbolizer + frame sync + slicer
-          (bit-exact 10-byte dibit records) -> framer -> NID BCH(63,16) -> TSDU 1/2-rate trellis + CRC16 /
-          LDU1-LDU2 24 x Hamming(10,6,3) + RS(24,12,13) / RS(24,16,9) -> 9 IMBE frames per LDU: de-interleave ->
-          Golay / Hamming / PN frame decode -> parameter unpack -> enhancement -> synthesis to f32 PCM.
-        Traffic: even channels carry voice (LDU1 / LDU2 back to back), odd channels a control channel (TSDUs); 64 distinct
-        channels of each kind tiled to B.  Carried state streams from step to step.
+        of air time each), resident in HBM, through the whole chain on the device - ONE C call per step
+        (ddn_p25_chain_run_pipelined, include/ddn_chain.h):
+          widen + 135-tap channel LPF + FSK discriminator -> P25 matched filter -> symbolizer + frame sync + slicer with the
+          reference's per-DUID handlers deciding every in-frame length inside the loop (NID BCH + Chase, TSDU last-block flag,
+          PDU header; no per-channel lock length is configured) -> bit-exact 10-byte dibit records -> framer -> NID BCH(63,16) ->
+          TSDU blocks 0..2: 1/2-rate list-8 trellis + CRC16 selection / LDU1-LDU2: 24 x Hamming(10,6,3) + RS(24,12,13) /
+          RS(24,16,9) + low speed data (16,8) / HDU: 36 x Golay(24,6) + RS(36,20,17) / TDULC: 12 x Golay(24,12) + RS(24,12,13) ->
+          9 IMBE frames per LDU: de-interleave -> Golay / Hamming / PN frame decode -> parameter unpack -> enhancement ->
+          synthesis to f32 PCM.
+        Traffic: even channels carry voice calls (HDU, LDU1 / LDU2 ..., TDULC, TDU), odd channels a control channel (TSDUs of one
+        to three blocks); 64 distinct channels of each kind tiled to B.  Carried state streams from step to step; frames that
+        cross a call boundary are decoded whole in the next call (the chain object's carry).
 Weak scaling: every rank owns its own B channels (independent streams, no data-path collective).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the chain's dominant kernel (k_p25_rxw, timed with HIP events on the
 launch stream inside the C-ABI) against the chain's algorithmic bytes (2 B cu8 in + 10 B per symbol record
-out = 3.0 B/sample, + 640 B per synthesized voice frame).  `cpu_baseline` is the same chain on the host (compiled reference
-front end where oracle/_ref exists + the C restatement of everything after it), 1 core and all cores.  `front_end_stage`
-keeps BASELINE configs[1] (FIR + discriminator only) as a named sub-object with its own roofline."""
+out = 3.0 B/sample, + 640 B per synthesized voice frame).  `cpu_baseline` is the same chain on the host, stage by stage with
+its own `kind` (compiled reference where oracle/_ref holds the stage, the C restatement elsewhere), 1 core and all cores.
+`front_end_stage` keeps BASELINE configs[1] (FIR + discriminator only) as a named sub-object with its own roofline."""
 import argparse
 import ctypes as C
 import json
@@ -36,24 +41,38 @@ N_SAMPLES = 48000
 BLOCK = 8192
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
 N_BASE = 64                  # distinct channels of each traffic kind
+RXW_TRAFFIC_BYTES = None     # filled from profiles/r03_pmc_*.txt once measured
 
 
 def make_base_traffic(n):
-    """-> (voice cu8 [N_BASE][n][2], control cu8 [N_BASE][n][2]); deterministic."""
+    """-> (voice cu8 [N_BASE][n][2], control cu8 [N_BASE][n][2]); deterministic.  Whole frames only: a voice channel is one call
+    (header, voice frames, terminators) inside the second, a control channel back-to-back TSDUs of one to three blocks, so the
+    replayed buffer never cuts a frame at its seam."""
     import numpy as np
     import mbe
     import p25gen
     rng = np.random.default_rng(20260928)
-    n_ldus = n // 8640 + 2
+    n_sym = n // 10
     voice = np.zeros((N_BASE, n, 2), np.uint8)
     ctrl = np.zeros((N_BASE, n, 2), np.uint8)
     for c in range(N_BASE):
+        lead = 200 + 11 * c
+        room = n_sym - lead // 10 - 40
+        head = [p25gen.make_hdu(rng, 0x293)[0]] if c % 2 == 0 else []
+        tail = [p25gen.make_tdulc(rng, 0x293)[0], p25gen.make_tdu(0x293)]
+        n_ldus = (room - sum(len(p) for p in head + tail)) // p25gen.LDU
         bits = mbe.random_imbe_bits(rng, (n_ldus * 9,))
         frames = np.stack([mbe.imbe_encode(b) for b in bits])
-        dib, _ = p25gen.make_ldus(rng, n_ldus, 0x293, frames)
-        voice[c] = p25gen.modulate_cu8(dib, n, lead=200 + 11 * c, seed=c)
-        dib, _ = p25gen.make_frames(rng, n // 1800 + 1, 0x293, crc=True)
-        ctrl[c] = p25gen.modulate_cu8(dib, n, lead=200 + 13 * c, seed=1000 + c)
+        dib = np.concatenate(head + [p25gen.make_ldus(rng, n_ldus, 0x293, frames)[0]] + tail)
+        voice[c] = p25gen.modulate_cu8(dib, n, lead=lead, seed=c)
+        lead = 200 + 13 * c
+        room, parts = n_sym - lead // 10 - 40, []
+        while True:
+            fr = p25gen.make_frames(rng, 1, 0x293, crc=True, blocks=int(rng.integers(1, 4)))[0]
+            if sum(len(p) for p in parts) + len(fr) > room:
+                break
+            parts.append(fr)
+        ctrl[c] = p25gen.modulate_cu8(np.concatenate(parts), n, lead=lead, seed=1000 + c)
     return voice, ctrl
 
 
@@ -77,31 +96,38 @@ def usable_cores():
 
 def _cpu_worker(args):
     """One process of the CPU baseline: run the chain on `iq` (k channels) `reps` times; returns stage seconds."""
-    iq, locks, Fv, reps = args
-    import chain_oracle
+    iq, reps = args
+    import chain_stream
     T = {}
     t0 = time.perf_counter()
     for _ in range(reps):
         for c in range(iq.shape[0]):
-            chain_oracle.run_channel(iq[c], locks[c], Fv, seed=c, timers=T, use_ref_front_end=True)
+            chain_stream.run_stream(iq[c], iq.shape[1], seed=c, timers=T, use_ref=True)
     T["wall"] = time.perf_counter() - t0
+    # the handlers' NID / half-rate decodes run inside "rx" through the restatement; where the compiled reference timed the same
+    # decodes ("nid", "trellis") the restatement's share is taken out of "rx", otherwise it simply stays in
+    port = T.pop("rx_fec_port", 0.0)
+    if "nid" in T or "trellis" in T:
+        T["rx"] = max(T["rx"] - port, 0.0)
     return T
 
 
-def cpu_baseline(voice, ctrl, n, Fv):
-    """The same chain on the host, timed INSIDE the C calls (Python glue excluded): compiled reference front end
-    (oracle/_ref, AVX2 unit) where present, the C restatement for the receive loop, NID, trellis, IMBE and synthesis
-    (Hamming(10,6,3) / Reed-Solomon words of the LDUs are not in the CPU figure - in the CPU's favour)."""
+def cpu_baseline(voice, ctrl, n):
+    """The same chain on the host (tests/chain_stream.py), timed INSIDE the C calls (Python glue excluded), stage by stage: the
+    compiled reference (oracle/_ref: its own sources built where they lie) for the stages it holds - front end (AVX2 unit), NID
+    decode, half-rate list decode (the handlers' decodes, timed outside the loop on the same inputs; the restatement's time for them
+    is taken out of the loop's) - and the C restatement for the rest (the receive loop needs the reference's global decoder state
+    and its I/O layer; mbelib-neo is absent).  Hamming(10,6,3) / Reed-Solomon / Golay words of the LDU / HDU / TDULC frames
+    are not in the CPU figure - in the CPU's favour."""
     import numpy as np
     import multiprocessing as mp
     import orc
     iq = np.stack([voice[0], ctrl[0], voice[1], ctrl[1]])
-    locks = [840, 156, 840, 156]
-    _cpu_worker((iq, locks, Fv, 1))                      # warm-up (page-in, table builds)
+    _cpu_worker((iq, 1))                      # warm-up (page-in, table builds)
     reps, T = 0, {}
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 10.0:
-        t = _cpu_worker((iq, locks, Fv, 1))
+        t = _cpu_worker((iq, 1))
         for k, v in t.items():
             T[k] = T.get(k, 0.0) + v
         reps += 1
@@ -116,70 +142,51 @@ def cpu_baseline(voice, ctrl, n, Fv):
         ctx = mp.get_context("fork")
         with ctx.Pool(cores) as pool:
             t0 = time.perf_counter()
-            res = pool.map(_cpu_worker, [(iq, locks, Fv, per)] * cores)
+            res = pool.map(_cpu_worker, [(iq, per)] * cores)
             wall = time.perf_counter() - t0
         # aggregate rate over the pool, again counting only time inside the C calls of the slowest worker
         slow = max(sum(v for k, v in r.items() if k != "wall") for r in res)
         all_cores = {"value": round(cores * per * iq.shape[0] * n / slow / 1e6, 3), "unit": "Msamples/s", "cores": cores,
                      "wall_s": round(wall, 2)}
-    kind = "reference+port" if orc.have_ref() else "port"
+    ref = orc.have_ref()
+    kinds = {"front_end": "reference" if ref else "port", "rx": "port", "nid": "reference", "trellis": "reference",
+             "imbe_deint": "port", "imbe_fec": "port", "mbe_synth": "port"}
     return {"value": round(one, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": "%d channels (2 voice + 2 control) x %d samples x %d reps of the bench traffic through the whole chain on "
-                      "one core, time inside the C calls only; front end = %s, everything after it = oracle C restatement "
-                      "(kind=%s)" % (iq.shape[0], n, reps, "oracle/_ref compiled reference (AVX2 unit)" if orc.have_ref()
-                                     else "oracle C restatement", kind),
-            "stage_share": {k: round(v / c_seconds, 3) for k, v in sorted(stages.items())},
+                      "one core, time inside the C calls only; per-stage kind below (reference = oracle/_ref, the reference's own "
+                      "sources compiled; port = oracle C restatement)" % (iq.shape[0], n, reps),
+            "stages": {k: {"share": round(v / c_seconds, 3), "kind": kinds.get(k, "port")} for k, v in sorted(stages.items())},
             "all_cores": all_cores}
 
 
-def _pipelined_call(chain, streams):
-    """three streams: front end | loop | decode; two streams: front end + loop | decode, the decode of step k held back until
-    the front end of step k + 1 has run when DDN_BENCH_DEFER=1 (measured no better: 9.6 vs 9.4 ms per step), by default started as
-    soon as the loop of step k is done"""
-    if len(streams) == 3:
-        return chain.run_pipelined3
-    return chain.run_pipelined_deferred if int(os.environ.get("DDN_BENCH_DEFER", "0")) else chain.run_pipelined
-
-
-def parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n, streams=None):
-    """Before any timing: a sample of this rank's channels, first call of a fresh stream, against the chain of CPU oracles -
-    dibit records, NIDs, decoded voice parameter bits and PCM all bit-exact."""
+def parity_gate(chain, d_iq_ptr, voice, ctrl, ch_first, B, n):
+    """Before any timing: a sample of this rank's channels, the first two calls of a fresh stream + the flush, through the same C
+    call the timed loop makes, against the whole-stream CPU oracle (tests/chain_stream.py) - dibit records, flags, the handlers'
+    decisions, NIDs, TSDU blocks, voice parameter bits and PCM all bit-exact, every sync decoded exactly once."""
     import numpy as np
-    import chain_oracle
-    import orc
-    torch.cuda.synchronize()
-    if streams:
-        _pipelined_call(chain, streams)(d_iq, *streams)      # the same call sequence the timed loop makes
-        if len(streams) == 2:
-            chain.flush(*streams)
-    else:
-        chain.run(d_iq)
-    torch.cuda.synchronize()
+    import chain_stream
     pick = sorted(set([0, 1, 2, 3, B // 2, B // 2 + 1, B - 2, B - 1]))
-    cnt = chain.cnt.cpu().numpy()
-    out = {"checked_channels": len(pick), "records_bit_exact": True, "nid_equal": True, "voice_bits_equal": True,
-           "pcm_bit_exact": True, "voice_frames_checked": 0}
-    for c in pick:
+    col = chain_stream.Collector(chain, channels=pick)
+    for _ in range(2):
+        chain.run_pipelined(d_iq_ptr)
+        chain.wait()
+        col.take()
+    chain.flush()
+    col.take()
+    out = {"checked_channels": len(pick), "calls": "2 + flush", "bit_exact": True, "nids": 0, "tsbk_blocks": 0, "voice_frames": 0}
+    for i, c in enumerate(pick):
         kind, bi = channel_source(ch_first + c)
         iq_c = voice[bi] if kind == "voice" else ctrl[bi]
-        w = chain_oracle.run_channel(iq_c, 840 if kind == "voice" else 156, chain.Fv, seed=c)
-        rec = chain.rec[c, :cnt[c]].cpu().numpy()
-        r4, sym = orc.unpack_records10(rec)
-        if not (cnt[c] == len(w["sym"]) and np.array_equal(r4, w["rec4"]) and np.array_equal(sym.view(np.uint32), w["sym"].view(np.uint32))):
-            out["records_bit_exact"] = False
-        nid = chain.nid[c * chain.F:(c + 1) * chain.F].cpu().numpy()
-        for k, nd in enumerate(w["nids"]):
-            if nd is not None and not np.array_equal(nid[k], nd):
-                out["nid_equal"] = False
-        live = ~w["skip"]
-        d = chain.imbe_d[c * chain.Fv * 9:(c + 1) * chain.Fv * 9].cpu().numpy()
-        if not np.array_equal(d[live], w["imbe_d"][live]):
-            out["voice_bits_equal"] = False
-        pcm = chain.pcm[c].cpu().numpy()
-        if not np.array_equal(pcm.view(np.uint32), w["pcm"].view(np.uint32)):
-            out["pcm_bit_exact"] = False
-        out["voice_frames_checked"] += int(live.sum())
-    out["bit_exact"] = all(out[k] for k in ("records_bit_exact", "nid_equal", "voice_bits_equal", "pcm_bit_exact"))
+        want = chain_stream.run_stream(np.concatenate([iq_c, iq_c]), n, seed=c)
+        try:
+            a, b, v = chain_stream.check_channel(col, i, want)
+        except AssertionError as e:
+            out["bit_exact"] = False
+            out["first_difference"] = "channel %d: %s" % (c, str(e)[:200])
+            break
+        out["nids"] += a
+        out["tsbk_blocks"] += b
+        out["voice_frames"] += v
     return out
 
 
@@ -237,14 +244,21 @@ def vocoder_c5(torch, ddn, np, steps):
 
 
 def front_end_stage(torch, ddn, chain, d_iq, B, n, steps):
-    """BASELINE configs[1] (FIR + discriminator only) as a stage figure: the fused front-end kernel alone."""
+    """BASELINE configs[1] (FIR + discriminator only) as a stage figure: the fused front-end kernel alone (the chain object's own
+    front-end batch; its carried state just streams on)."""
+    import numpy as np
+    l = ddn.lib()
     st = torch.cuda.current_stream().cuda_stream
-    chain.fe.set_timing(True)
+    out = torch.empty((B, n), dtype=torch.float32, device=d_iq.device)
+    fe = chain.fe
+    assert l.ddn_batch_set_timing(fe, 1) == 0
     ms = []
+    t = np.zeros(3, np.float32)
     for _ in range(steps):
-        chain.front_end(d_iq, st)
-        ms.append(float(chain.fe.timing()[0]))
-    chain.fe.set_timing(False)
+        assert l.ddn_front_end_run(fe, d_iq.data_ptr(), n, out.data_ptr(), st) == 0
+        assert l.ddn_batch_get_timing(fe, t.ctypes.data) == 0
+        ms.append(float(t[0]))
+    assert l.ddn_batch_set_timing(fe, 0) == 0
     ms = sorted(ms)[:max(1, len(ms) // 2)]
     avg = sum(ms) / len(ms)
     alg = 6.0 * B * n
@@ -276,17 +290,15 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     n = args.samples
     voice, ctrl = make_base_traffic(n)
-    Fv = n // 8640 + 2
 
     # the CPU leg runs first: its worker pool forks, which must happen before this process holds a HIP context
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(voice, ctrl, n, Fv)
+        cpu = cpu_baseline(voice, ctrl, n)
 
     import torch
     import torch.distributed as dist
     import ddn
-    import ddn_chain
     import ddn_shard
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -309,108 +321,122 @@ def main():
     d_iq[is_v] = d_voice[idx_v]
     d_iq[~is_v] = d_ctrl[idx_c]
     del d_voice, d_ctrl
-    lock = np.array([840 if k == "voice" else 156 for (k, _) in kinds], np.int32)
-    chain = ddn_chain.P25Chain(torch, B, n, lock, block_len=BLOCK)
-    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    # the whole chain as one C object (include/ddn_chain.h); the handlers inside the receive loop decide every in-frame length
+    chain = ddn.P25ChainC(B, n, block_len=BLOCK)
+    l = ddn.lib()
+    iq_ptr = d_iq.data_ptr()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the receive loop's stream gets the higher priority: its wavefronts are latency chains, the decode kernels beside them are not
-    prio = int(os.environ.get("DDN_BENCH_PRIO", "1"))
-    n_streams = int(os.environ.get("DDN_BENCH_STREAMS", "2"))  # 3: measured no faster (the front end displaces the loop)
     if args.no_pipeline:
-        streams = None
-    elif n_streams == 3:   # front end | receive loop (high priority) | frame FEC + vocoder
-        streams = (torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1 if prio else 0), torch.cuda.Stream(priority=0))
-    else:                  # front end + receive loop (high priority) | frame FEC + vocoder
-        streams = (torch.cuda.Stream(priority=-1 if prio else 0), torch.cuda.Stream(priority=0))
+        def step():
+            chain.run(iq_ptr, None)
+    else:
+        def step():
+            chain.run_pipelined(iq_ptr)
 
-    def step():
-        if streams:
-            _pipelined_call(chain, streams)(d_iq, *streams)
-        else:
-            chain.run(d_iq, st)
-
-    parity = parity_gate(torch, chain, d_iq, voice, ctrl, ch_first, B, n, streams)
+    parity = parity_gate(chain, iq_ptr, voice, ctrl, ch_first, B, n)
     if not parity["bit_exact"] and not os.environ.get("DDN_BENCH_NOPARITY"):
         raise SystemExit("parity gate failed: %s" % json.dumps(parity))
 
-    def flush():
-        if streams and len(streams) == 2:
-            chain.flush(*streams)
-
     for _ in range(args.warmup):
         step()
-    flush()
     barrier()
     # HIP events around the dominant kernel on its own stream, recorded inside the C-ABI for every launch of the timed loop
     # (no synchronisation between launches; read back after the closing barrier)
-    ddn.lib().ddn_p25_rx_set_timing(chain.rx.h, 1)
+    l.ddn_p25_rx_set_timing(chain.rx, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    flush()            # the last step's FEC / voice stages are queued ...
-    barrier()          # ... and inside the timed region: torch.cuda.synchronize() covers every stream
+    barrier()          # every stage of every step inside the timed region: torch.cuda.synchronize() covers every stream
     dt = time.perf_counter() - t0
     rx_timed = np.zeros(2, np.float32)
     rx_timed_n = C.c_int(0)
-    ddn.lib().ddn_p25_rx_get_timing_avg(chain.rx.h, rx_timed.ctypes.data, C.byref(rx_timed_n))
-    ddn.lib().ddn_p25_rx_set_timing(chain.rx.h, 0)
+    l.ddn_p25_rx_get_timing_avg(chain.rx, rx_timed.ctypes.data, C.byref(rx_timed_n))
+    l.ddn_p25_rx_set_timing(chain.rx, 0)
     dt = ddn_shard.reduce_max_seconds(dt, dev)
+
+    # what one step decoded (the last one): counted from the chain's result arrays
+    F, Fv, S = chain.F, chain.Fv, B * chain.F
+    r = chain.results()
+    n_sym = int(chain.fetch(r.d_new, np.int32, (B,)).sum())
+    ns = chain.fetch(r.d_n_syncs, np.int32, (B,))
+    used = (np.arange(F)[None, :] < ns[:, None]).reshape(S)
+    nidh = chain.fetch(r.d_nid4, np.int32, (S, 4))
+    ok = used & (nidh[:, 0] > 0)
+    duid = nidh[:, 2]
+    tcrc = chain.fetch(r.d_tsbk_crc, np.uint8, (3, S))
+    tsbk = chain.fetch(r.d_tsbk, np.uint8, (3, S, 12))
+    tsdu = ok & (duid == 7)
+    last = (tsbk[:, :, 0] & 0x80) != 0
+    in_tsdu = np.stack([tsdu, tsdu & ~last[0], tsdu & ~last[0] & ~last[1]])       # block k belongs to the TSDU
+    rs = [chain.fetch(r.d_ldu_rs_status[i], np.uint8, (S,)) for i in range(2)]
+    lsd_ok = chain.fetch(r.d_lsd_ok, np.uint8, (S, 2))
+    hdu_rs = chain.fetch(r.d_hdu_rs_status, np.uint8, (S,))
+    td_rs = chain.fetch(r.d_tdulc_rs_status, np.uint8, (S,))
+    skipv = (chain.fetch(r.d_imbe_result, np.int32, (B * Fv * 9, 5))[:, 0].view(np.uint32) & 0x80000000) != 0
+    res = chain.fetch(r.d_synth_result, np.int32, (B * Fv * 9, 5))
+    voice_frames = int((~skipv).sum())
+    nev = chain.fetch(r.d_n_events, np.int32, (B,))
+    work = {"symbols": n_sym, "syncs": int(ns.sum()), "frames_with_valid_nid": int(ok.sum()),
+            "handler_decisions": int(nev.sum()),
+            "tsdu": int(tsdu.sum()), "tsbk_blocks": int(in_tsdu.sum()), "tsbk_blocks_crc_ok": int((in_tsdu & (tcrc != 0)).sum()),
+            "ldu1": int((ok & (duid == 5)).sum()), "ldu1_rs_ok": int((ok & (duid == 5) & (rs[0] == 0)).sum()),
+            "ldu2": int((ok & (duid == 10)).sum()), "ldu2_rs_ok": int((ok & (duid == 10) & (rs[1] == 0)).sum()),
+            "lsd_words_ok": int(lsd_ok[ok & ((duid == 5) | (duid == 10))].sum()),
+            "hdu": int((ok & (duid == 0)).sum()), "hdu_rs_ok": int((ok & (duid == 0) & (hdu_rs == 0)).sum()),
+            "tdulc": int((ok & (duid == 15)).sum()), "tdulc_rs_ok": int((ok & (duid == 15) & (td_rs == 0)).sum()),
+            "tdu": int((ok & (duid == 3)).sum()),
+            "voice_frames_synthesized": voice_frames,
+            "voice_frames_muted_or_repeated": int((((res[:, 0] & 0x18) != 0) & ~skipv).sum())}
+
     serial_ms = None
-    if streams and rank == 0 and not args.no_extras:
+    if not args.no_pipeline and rank == 0 and not args.no_extras:
         for _ in range(2):
-            chain.run(d_iq, st)
+            chain.run(iq_ptr, None)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(min(args.steps, 10)):
-            chain.run(d_iq, st)
+            chain.run(iq_ptr, None)
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - t1) / min(args.steps, 10) * 1e3
 
-    # per-stage / per-kernel times: a separate instrumented loop outside the timed region
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-    l = ddn.lib()
-    l.ddn_p25_rx_set_timing(chain.rx.h, 1)
+    # per-stage / per-kernel times: a separate instrumented loop outside the timed region (one stream, stage boundaries marked
+    # with HIP events inside the C object)
+    chain.set_timing(True)
+    l.ddn_p25_rx_set_timing(chain.rx, 1)
     l.ddn_mbe_batch_set_timing(chain.mbe, 1)
     stage_ms = np.zeros(4)
     rx_ms = np.zeros(2)
     mbe_ms = np.zeros(2)
     reps = min(args.steps, 8)
     for _ in range(reps):
-        ev[0].record()
-        chain.front_end(d_iq, st)
-        ev[1].record()
-        chain.receive(st)
-        ev[2].record()
-        chain.frame_fec(st)
-        ev[3].record()
-        chain.voice(st)
-        ev[4].record()
-        torch.cuda.synchronize()
-        stage_ms += [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+        chain.run(iq_ptr, None)
+        stage_ms += chain.stage_ms()
         t2 = np.zeros(2, np.float32)
-        l.ddn_p25_rx_get_timing(chain.rx.h, t2.ctypes.data)
+        l.ddn_p25_rx_get_timing(chain.rx, t2.ctypes.data)
         rx_ms += t2
         l.ddn_mbe_batch_get_timing(chain.mbe, t2.ctypes.data)
         mbe_ms += t2
     stage_ms /= reps
     rx_ms /= reps
     mbe_ms /= reps
-    l.ddn_p25_rx_set_timing(chain.rx.h, 0)
+    chain.set_timing(False)
+    l.ddn_p25_rx_set_timing(chain.rx, 0)
     l.ddn_mbe_batch_set_timing(chain.mbe, 0)
+
+    # BASELINE configs[3] (mixed protocols), sharded over all ranks: every rank runs its part, rank 0 reports
+    mixed = None
+    if not args.no_extras:
+        mixed = configs3_mixed(torch, ddn, np, d_iq, args.channels, n, 6, rank, world, dev)
 
     if rank == 0:
         total_samples = float(world) * B * n * args.steps
         msps = total_samples / dt / 1e6
-        res = chain.res_out.cpu().numpy()
-        skipv = (chain.imbe_res.cpu().numpy()[:, 0].view(np.uint32) & 0x80000000) != 0
-        voice_frames = int((~skipv).sum())
-        n_sym = int(chain.cnt.sum().item())
-        nidh = chain.nid.cpu().numpy()
         # algorithmic bytes of one step: cu8 in, one 10-byte record per symbol out, 640 B per voice frame
         alg_bytes = 2.0 * B * n + 10.0 * n_sym + 640.0 * voice_frames
         dom_ms = float(rx_timed[1]) if rx_timed_n.value > 0 else float(rx_ms[1])
@@ -428,33 +454,32 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[2] + vocoder: %d P25 Phase 1 channels/GPU @48 ksps x %d cu8 samples, half voice (LDU1/LDU2) "
-                                   "half control (TSDU); front end -> matched filter -> symbolizer/sync/slicer -> framer -> NID BCH -> "
-                                   "1/2-rate trellis + CRC16 | Hamming(10,6,3) + RS -> IMBE de-interleave + Golay/Hamming/PN decode -> "
-                                   "MBE synthesis (PCM f32)" % (B, n),
+            "config": {"workload": "configs[2] + vocoder: %d P25 Phase 1 channels/GPU @48 ksps x %d cu8 samples, half voice calls (HDU, "
+                                   "LDU1/LDU2, TDULC, TDU) half control (TSDUs of 1-3 blocks); front end -> matched filter -> "
+                                   "symbolizer/sync/slicer with the reference's per-DUID handlers inside the loop (no configured lock "
+                                   "length) -> framer -> NID BCH -> TSDU blocks 0-2 list-8 trellis + CRC16 | Hamming(10,6,3) + RS + LSD | "
+                                   "HDU Golay(24,6) + RS(36,20,17) | TDULC Golay(24,12) + RS(24,12,13) -> IMBE de-interleave + "
+                                   "Golay/Hamming/PN decode -> MBE synthesis (PCM f32)" % (B, n),
                        "channels_per_gpu": B, "samples_per_channel": n, "block_len": BLOCK,
                        "parallelism": "channel-sharded x%d" % world,
+                       "host": "one C call per step (ddn_p25_chain_run%s, include/ddn_chain.h)" % ("" if args.no_pipeline else "_pipelined"),
                        "pipelining": ("none (one stream)" if args.no_pipeline else
-                                      ("3 HIP streams: front end of step k+1 and frame FEC + vocoder of step k-1 run beside the receive "
-                                       "loop of step k (double-buffered discriminator and loop outputs)" if len(streams) == 3 else
-                                       "2 HIP streams: frame FEC + vocoder of step k overlap front end + receive loop of step k+1 "
-                                       "(double-buffered loop outputs)") + "; every stage of every step inside the timed region"),
+                                      "2 HIP streams inside the C object: frame FEC + vocoder of step k overlap front end + receive "
+                                      "loop of step k+1 (double-buffered loop outputs)") + "; every stage of every step inside the "
+                                     "timed region",
                        "vocoder_tables": "synthetic default blob (include/ddn_mbe.h); mbelib-neo absent -> vocoder parity unpinned"},
             "parity": parity,
-            "work_per_step": {"symbols": n_sym, "frames_with_valid_nid": int((nidh[:, 0] == 1).sum()),
-                              "tsbk_crc_ok": int(chain.crc_ok.sum().item()), "voice_frames_synthesized": voice_frames,
-                              "voice_frames_muted_or_repeated": int(((res[:, 0] & 0x18) != 0).sum())},
+            "work_per_step": work,
             "stages_ms": {"front_end": round(float(stage_ms[0]), 3), "receive_loop": round(float(stage_ms[1]), 3),
-                          "framer_nid_trellis_hamming_rs": round(float(stage_ms[2]), 3),
+                          "framer_nid_trellis_hamming_golay_rs": round(float(stage_ms[2]), 3),
                           "imbe_deinterleave_decode_synthesis": round(float(stage_ms[3]), 3)},
             "kernels_ms": {"k_p25_matched_filter": round(float(rx_ms[0]), 4), "k_p25_rxw": round(float(rx_ms[1]), 4),
                            "k_mbe_params": round(float(mbe_ms[0]), 4), "k_mbe_synth": round(float(mbe_ms[1]), 4)},
             "roofline": {"bound": "hbm", "kernel": "k_p25_rxw", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # HBM bytes per launch of k_p25_rxw from separate rocprofv3 --pmc passes of this command on this shape
-                         # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B;
-                         # profiles/r02_pmc_*.txt): the discriminator stream is read twice (raw + matched-filter output)
-                         "traffic": 2.059e9 if (B == B_PER_GPU and n == N_SAMPLES) else None,
+                         # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B; profiles/r03_pmc_*.txt)
+                         "traffic": RXW_TRAFFIC_BYTES if (B == B_PER_GPU and n == N_SAMPLES) else None,
                          "algorithmic_bytes": alg_bytes, "bytes_per_sample": round(alg_bytes / (B * n), 3),
                          "launch_ms": round(dom_ms, 4), "launches_averaged": int(rx_timed_n.value),
                          "launch_ms_alone": round(float(rx_ms[1]), 4),   # the same kernel with nothing else on the device
@@ -464,163 +489,203 @@ def main():
             line["one_stream_ms_per_step"] = round(serial_ms, 4)
         if world == 1 and not args.no_extras:
             line["front_end_stage"] = front_end_stage(torch, ddn, chain, d_iq, B, n, 12)
-            line["pcie_inclusive"] = pcie_inclusive(torch, chain, d_iq, B, n)
-            line["configs3_mixed"] = configs3_mixed(torch, ddn, np, chain, d_iq, B, n, 6)
+            line["pcie_inclusive"] = pcie_inclusive(torch, ddn, chain, d_iq, B, n)
             line["vocoder_c5"] = vocoder_c5(torch, ddn, np, 10)
+        if mixed is not None:
+            line["configs3_mixed"] = mixed
         if cpu is not None:
             line["cpu_baseline"] = cpu
             line["speedup_vs_cpu_1core"] = round(msps / world / cpu["value"], 1)
             if cpu.get("all_cores"):
                 line["speedup_vs_cpu_all_cores"] = round(msps / world / cpu["all_cores"]["value"], 1)
         print(json.dumps(line))
+    chain.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def configs3_mixed(torch, ddn, np, p25_chain, d_iq_p25, B_total, n, steps):
-    """BASELINE configs[3] shape on one GPU (informational; never `value`): B_total channels split in thirds between P25 Phase 1
-    (the headline traffic), DMR and NXDN48.  DMR / NXDN48 traffic = the committed regression captures (tests/golden), every
-    channel a different rotation; each protocol's chain runs back to back on one stream.  Parity: 3 channels per protocol
-    against the CPU restatement, bit-exact records / payload / sync hand-over."""
-    import ddn_chain
-    import ddn_chain_fsk4
+def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, dev):
+    """BASELINE configs[3] shape (informational; never `value`): B_per_gpu x world channels, a third each P25 Phase 1 (the headline
+    traffic), DMR and NXDN48, every receive loop with the reference's handlers inside it (no configured lock length), as ONE C object
+    per GPU (ddn_mixed_chain, include/ddn_chain.h).  The global channel index [P25 | DMR | NXDN48] is block-partitioned over the
+    ranks (ddn_mixed_partition): a rank owns a contiguous range of each group, no data-path collective.  DMR / NXDN48 traffic = the
+    committed regression captures (tests/golden), every channel a different rotation.  Parity: 3 channels per DMR / NXDN48 group
+    of this rank against the CPU restatement, bit-exact records / payload / sync hand-over."""
+    import ddn_shard
     import rx4
+    import orc
     from conftest import golden
-    third = B_total // 3
-    Bp, Bd, Bn = B_total - 2 * third, third, third
-    dev = d_iq_p25.device
-    st = torch.cuda.current_stream().cuda_stream
+    total = B_per_gpu * world
+    third = total // 3
+    groups = (total - 2 * third, third, third)
+    part = ddn.mixed_partition(*groups, rank, world)
+    (fp, Bp), (fd, Bd), (fn, Bn) = part
 
-    def tile(name, lo, hi, Bc):
+    def tile(name, lo, hi, first, Bc):
         iq = torch.from_numpy(np.ascontiguousarray(golden(name)["iq"][lo:hi], np.uint8)).to(dev)       # [m][2]
         m = iq.shape[0]
-        off = (torch.arange(Bc, device=dev) * 37) % (m - n)
+        off = ((torch.arange(Bc, device=dev) + first) * 37) % (m - n)
         idx = off[:, None] + torch.arange(n, device=dev)[None, :]
-        return iq[idx].contiguous(), off.cpu().numpy(), iq.cpu().numpy()
+        return (iq[idx].contiguous() if Bc else iq[:0]), off.cpu().numpy(), iq.cpu().numpy()
 
-    d_dmr, off_d, iq_d = tile("iq_dmr_t3_ras_cc.npz", 0, 96000, Bd)
-    d_nx, off_n, iq_n = tile("iq_nxdn48.npz", 60000, 288000, Bn)
-    lockp = np.array([840 if (c % 2 == 0) else 156 for c in range(Bp)], np.int32)
-    cp = ddn_chain.P25Chain(torch, Bp, n, lockp, block_len=BLOCK)
-    cd = ddn_chain_fsk4.Fsk4Chain(torch, Bd, n, ddn.FSK4_DMR, rf_mod=2, block_len=BLOCK)
-    cn = ddn_chain_fsk4.Fsk4Chain(torch, Bn, n, ddn.FSK4_NXDN48, rf_mod=0, block_len=BLOCK)
-    d_p25 = d_iq_p25[:Bp]
+    d_dmr, off_d, iq_d = tile("iq_dmr_t3_ras_cc.npz", 0, 96000, fd, Bd)
+    d_nx, off_n, iq_n = tile("iq_nxdn48.npz", 60000, 288000, fn, Bn)
+    d_p25 = d_iq_p25[:Bp].contiguous() if Bp else d_iq_p25[:0]
+    m = ddn.MixedChainC(Bp, Bd, Bn, n, block_len=BLOCK)
+    ptr = lambda t, k: t.data_ptr() if k else None
+    args = (ptr(d_p25, Bp), ptr(d_dmr, Bd), ptr(d_nx, Bn))
 
     # parity (first call of fresh batches = fresh CPU states)
-    cd.run(d_dmr, st)
-    cn.run(d_nx, st)
-    torch.cuda.synchronize()
-    import orc
+    m.run(*args)
+    m.wait()
     par_ok, checked = True, 0
-    for chain, proto, lpf, iq, offs, rf in ((cd, rx4.PROTO_DMR, 2, iq_d, off_d, 2), (cn, rx4.PROTO_NXDN48, 1, iq_n, off_n, 0)):
-        rec, fl, pay, cnt = (t.cpu().numpy() for t in (chain.rec, chain.fl, chain.pay, chain.cnt))
-        spos, pre, ns = (t.cpu().numpy() for t in (chain.spos, chain.pre, chain.ns))
-        for c in (0, chain.B // 2, chain.B - 1):
+    res = {}
+    for which, proto, lpf, iq, offs, rf, Bc in ((1, rx4.PROTO_DMR, 2, iq_d, off_d, 2, Bd), (2, rx4.PROTO_NXDN48, 1, iq_n, off_n, 0, Bn)):
+        if not Bc:
+            continue
+        ch = m.part(which)
+        r = ch.results()
+        ms, my = r.max_symbols, r.max_syncs
+        f = ch.fetch
+        rec, fl, pay = f(r.d_records10, np.uint8, (Bc, ms, 10)), f(r.d_flags, np.uint8, (Bc, ms)), f(r.d_payload2, np.uint8, (Bc, ms, 2))
+        cnt, ns = f(r.d_counts, np.int32, (Bc,)), f(r.d_n_sync, np.int32, (Bc,))
+        spos, pre = f(r.d_sync_pos, np.int32, (Bc, my)), f(r.d_pre, np.uint8, (Bc, my, 90))
+        res[which] = (ch, r, ns, my)
+        for c in sorted(set([0, Bc // 2, Bc - 1])):
             x = iq[offs[c]:offs[c] + n]
             disc = orc.OracleFrontEnd(profile=lpf).run_cu8(np.ascontiguousarray(x), BLOCK)
-            want = rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf)).run(disc, max_sync=spos.shape[1])
+            want = rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf, handler=1)).run(disc, max_sync=my)
             k = int(cnt[c])
-            r = rec[c, :k]
-            ok = (k == len(want["sym"]) and np.array_equal(r[:, 6:10].copy().view(np.uint32).reshape(-1), want["sym"].view(np.uint32))
-                  and np.array_equal(r[:, 0].astype(np.int32), want["rec4"][:, 0]) and np.array_equal(fl[c, :k], want["fl"])
+            rr = rec[c, :k]
+            ok = (k == len(want["sym"]) and np.array_equal(rr[:, 6:10].copy().view(np.uint32).reshape(-1), want["sym"].view(np.uint32))
+                  and np.array_equal(rr[:, 0].astype(np.int32), want["rec4"][:, 0]) and np.array_equal(fl[c, :k], want["fl"])
                   and np.array_equal(pay[c, :k], want["pay"]) and int(ns[c]) == len(want["sync_pos"])
                   and np.array_equal(spos[c, :int(ns[c])], want["sync_pos"]) and np.array_equal(pre[c, :int(ns[c])], want["pre"]))
             par_ok = par_ok and bool(ok)
             checked += 1
-    # DMR known answer on the device outputs: colour code 0, CSBK, BPTC clean on every complete burst
-    valid, st_ok, stb, errs = (t.cpu().numpy() for t in (cd.valid, cd.st_ok, cd.st, cd.errs))
-    rows = np.flatnonzero(valid)
-    rows = rows[(rows % cd.my) != 0]
-    cc_ok = bool(len(rows) > 0 and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0) and np.mean(errs[rows] == 0) > 0.99)
-    # NXDN48: LICH parity and SACCH CRC6 (soft decode or the greedy retry) on the complete frames
-    nv, nl, ns1, ns2 = (t.cpu().numpy() for t in (cn.valid, cn.lich, cn.sacch_ok, cn.sacch_hard_ok))
-    nrows = np.flatnonzero(nv)
-    nx_ok = bool(len(nrows) > 0 and np.mean((nl[nrows] & 0x80) != 0) > 0.9 and np.mean((ns1[nrows] | ns2[nrows]) != 0) > 0.6)   # a fresh stream's first frames fall in the filter's cold start
+    cc_ok = nx_ok = None
+    nx_frac = None
+    if 1 in res:   # DMR known answer on the device outputs: colour code 0, CSBK, BPTC clean on every complete burst
+        ch, r, ns, my = res[1]
+        S = Bd * my
+        valid, st_ok = ch.fetch(r.d_valid, np.uint8, (S,)), ch.fetch(r.d_dmr_slot_type_ok, np.uint8, (S,))
+        stb, errs = ch.fetch(r.d_dmr_slot_type, np.uint8, (S, 20)), ch.fetch(r.d_dmr_bptc_errs, np.uint32, (S,))
+        rows = np.flatnonzero(valid)
+        rows = rows[(rows % my) != 0]
+        cc_ok = bool(len(rows) > 0 and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0) and np.mean(errs[rows] == 0) > 0.99)
+    if 2 in res:   # NXDN48: LICH parity and SACCH CRC6 (soft decode or the greedy retry) on the complete frames
+        ch, r, ns, my = res[2]
+        S = Bn * my
+        nv, nl = ch.fetch(r.d_valid, np.uint8, (S,)), ch.fetch(r.d_nxdn_lich, np.uint8, (S,))
+        ns1, ns2 = ch.fetch(r.d_nxdn_sacch_ok, np.uint8, (S,)), ch.fetch(r.d_nxdn_sacch_hard_ok, np.uint8, (S,))
+        nrows = np.flatnonzero(nv)
+        nx_frac = [round(float(np.mean((nl[nrows] & 0x80) != 0)), 3), round(float(np.mean(ns1[nrows] != 0)), 3),
+                   round(float(np.mean((ns1[nrows] | ns2[nrows]) != 0)), 3), int(len(nrows))]
+        # a fresh stream's first frames fall in the filter's cold start; with the handlers in the loop a frame whose LICH fails is
+        # dropped at once (nxdn_frame.c), so the complete frames are the ones whose LICH parity held
+        nx_ok = bool(len(nrows) > 0 and nx_frac[0] > 0.9 and nx_frac[2] > 0.5)
 
     l = ddn.lib()
-    # the three protocol groups are independent channel sets: one stream each, so the three receive loops (per-channel latency
-    # chains that occupy a third of the CUs each) overlap instead of queueing behind one another
-    streams3 = [torch.cuda.Stream() for _ in range(3)]
-
-    def step3():
-        for sx, chain, d in zip(streams3, (cp, cd, cn), (d_p25, d_dmr, d_nx)):
-            with torch.cuda.stream(sx):
-                chain.run(d, sx.cuda_stream)
-
-    torch.cuda.synchronize()
     for _ in range(3):
-        step3()
-    torch.cuda.synchronize()
+        m.run(*args)
+    m.wait()
+    if world > 1:
+        torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step3()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    # one stream, back to back, with per-chain events
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    ms = np.zeros(3)
-    for _ in range(4):
-        ev[0].record()
-        cp.run(d_p25, st)
-        ev[1].record()
-        cd.run(d_dmr, st)
-        ev[2].record()
-        cn.run(d_nx, st)
-        ev[3].record()
-        torch.cuda.synchronize()
-        ms += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
-    ms /= 4
-    l.ddn_fsk4_rx_set_timing(cd.rx.h, 1)
-    l.ddn_fsk4_rx_set_timing(cn.rx.h, 1)
-    cd.run(d_dmr, st)
-    cn.run(d_nx, st)
-    t2d, t2n = np.zeros(2, np.float32), np.zeros(2, np.float32)
-    l.ddn_fsk4_rx_get_timing(cd.rx.h, t2d.ctypes.data)
-    l.ddn_fsk4_rx_get_timing(cn.rx.h, t2n.ctypes.data)
-    out = {"workload": "configs[3] shape on one GPU: %d channels = %d P25 Phase 1 + %d DMR (Tier III control channel capture, GFSK rules) + "
-                       "%d NXDN48 (capture), %d cu8 samples each; per protocol front end -> matched filter -> receive loop -> frame FEC "
-                       "(DMR: burst gather + Golay(20,8) + BPTC(196,96); NXDN48: frame gather + SACCH / FACCH1 K=5 decode + CRC + "
-                       "greedy retry, and the voice frames the LICHs announce through AMBE de-interleave + frame FEC + synthesis)" % (B_total, Bp, Bd, Bn, n),
-           "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(B_total * n / dt / 1e6, 1),
+        m.run(*args)
+    m.wait()
+    dt = ddn_shard.reduce_max_seconds((time.perf_counter() - t0) / steps, dev)
+    out = {"workload": "configs[3] shape: %d channels over %d GPU(s) = %d P25 Phase 1 + %d DMR (Tier III control channel capture, GFSK rules) "
+                       "+ %d NXDN48 (capture), %d cu8 samples each, handlers inside every receive loop; per protocol front end -> matched "
+                       "filter -> receive loop -> frame FEC (P25: the headline chain; DMR: burst gather + Golay(20,8) + BPTC(196,96); NXDN48: "
+                       "frame gather + SACCH / FACCH1 K=5 decode + CRC + greedy retry, and the voice frames the LICHs announce through "
+                       "AMBE de-interleave + frame FEC + synthesis)" % (total, world, groups[0], groups[1], groups[2], n),
+           "host": "one C object per GPU (ddn_mixed_chain), one C call per step; ranks take contiguous blocks of the global channel index "
+                   "(ddn_mixed_partition), no data-path collective",
+           "this_rank": {"p25p1": Bp, "dmr": Bd, "nxdn48": Bn},
+           "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(total * n / dt / 1e6, 1),
            "streams": "one HIP stream per protocol group (independent channel sets)",
-           "chain_ms_alone": {"p25p1": round(float(ms[0]), 3), "dmr": round(float(ms[1]), 3), "nxdn48": round(float(ms[2]), 3)},
-           "k_fsk4_rx_ms": {"dmr": round(float(t2d[1]), 3), "nxdn48": round(float(t2n[1]), 3)},
            "parity": {"channels_checked": checked, "bit_exact": par_ok, "dmr_colour_code_0_csbk_bptc_clean": cc_ok,
-                      "nxdn_lich_parity_and_sacch_crc": nx_ok,
-                      "nxdn_fractions": [round(float(np.mean((nl[nrows] & 0x80) != 0)), 3), round(float(np.mean(ns1[nrows] != 0)), 3),
-                                         round(float(np.mean((ns1[nrows] | ns2[nrows]) != 0)), 3), int(len(nrows))]},
-           "work_per_step": {"dmr_syncs": int(cd.ns.sum().item()), "nxdn_syncs": int(cn.ns.sum().item())}}
-    for c in (cp, cd.fe, cn.fe, cd.rx, cn.rx):
-        c.close()
+                      "nxdn_lich_parity_and_sacch_crc": nx_ok, "nxdn_fractions": nx_frac}}
+    if rank == 0:
+        # each group alone on its stream, and its receive-loop kernel
+        alone = {}
+        for which, name, a in ((0, "p25p1", (args[0], None, None)), (1, "dmr", (None, args[1], None)), (2, "nxdn48", (None, None, args[2]))):
+            if not part[which][1]:
+                continue
+            h = l.ddn_mixed_chain_part(m.h, which)
+            st = torch.cuda.current_stream().cuda_stream
+            run1 = (lambda: l.ddn_p25_chain_run(h, a[0], st)) if which == 0 else (lambda: l.ddn_fsk4_chain_run(h, a[which], st))
+            run1()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                assert run1() == 0
+            e1.record()
+            torch.cuda.synchronize()
+            alone[name] = round(e0.elapsed_time(e1) / 4, 3)
+        out["chain_ms_alone"] = alone
+        k4 = {}
+        for which, name in ((1, "dmr"), (2, "nxdn48")):
+            if which in res:
+                rxh = res[which][0].rx
+                l.ddn_fsk4_rx_set_timing(rxh, 1)
+                l.ddn_fsk4_chain_run(l.ddn_mixed_chain_part(m.h, which), args[which], None)
+                t2 = np.zeros(2, np.float32)
+                l.ddn_fsk4_rx_get_timing(rxh, t2.ctypes.data)
+                l.ddn_fsk4_rx_set_timing(rxh, 0)
+                k4[name] = round(float(t2[1]), 3)
+        out["k_fsk4_rx_ms"] = k4
+        out["work_per_step"] = {"dmr_syncs": int(res[1][2].sum()) if 1 in res else 0, "nxdn_syncs": int(res[2][2].sum()) if 2 in res else 0}
+    torch.cuda.synchronize()
+    m.close()
     return out
 
 
-def pcie_inclusive(torch, chain, d_iq, B, n):
-    """the same step with the raw I/Q coming from pinned host memory and the results (dibit records, counts,
-    NIDs, PCM) going back to it, serialised on one stream - never `value`."""
-    h_iq = torch.empty(d_iq.shape, dtype=torch.uint8).pin_memory()
-    h_iq.copy_(d_iq)
-    h_rec = torch.empty(chain.rec.shape, dtype=torch.uint8).pin_memory()
-    h_cnt = torch.empty(chain.cnt.shape, dtype=torch.int32).pin_memory()
-    h_nid = torch.empty(chain.nid.shape, dtype=torch.int32).pin_memory()
-    h_pcm = torch.empty(chain.pcm.shape, dtype=torch.float32).pin_memory()
-    st = torch.cuda.current_stream().cuda_stream
-    best = None
-    for _ in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        d_iq.copy_(h_iq, non_blocking=True)
-        chain.run(d_iq, st)
-        h_rec.copy_(chain.rec, non_blocking=True)
-        h_cnt.copy_(chain.cnt, non_blocking=True)
-        h_nid.copy_(chain.nid, non_blocking=True)
-        h_pcm.copy_(chain.pcm, non_blocking=True)
-        torch.cuda.synchronize()
-        t = time.perf_counter() - t0
-        best = t if best is None else min(best, t)
-    moved = h_iq.numel() + h_rec.numel() + 4 * (h_cnt.numel() + h_nid.numel() + h_pcm.numel())
-    return {"note": "host pinned I/Q in, records + counts + NIDs + PCM out, no overlap", "ms_per_step": round(best * 1e3, 3),
-            "Msamples_per_s": round(B * n / best / 1e6, 1), "bytes_over_pcie": moved}
+def pcie_inclusive(torch, ddn, chain, d_iq, B, n):
+    """the same step with the raw I/Q coming from pinned host memory and the results (dibit records, flags, counts,
+    handler decisions, NIDs, TSDU blocks, PCM) going back to it - ddn_p25_chain_run_host: the H2D copy of step k + 1 and the D2H
+    copy of step k - 1 run on two copy streams beside the kernels of step k.  Never `value`."""
+    import numpy as np
+    l = ddn.lib()
+    S, V, st, E = B * chain.F, B * chain.Fv * 9, chain.stride, chain.E
+    sizes = {"records10": B * st * 10, "flags": B * st, "counts": B * 4, "events": B * E * 16, "n_events": B * 4, "nid4": S * 16,
+             "tsbk": 3 * S * 12, "pcm": V * 640}
+    iq_bytes = B * n * 2
+    pinned = []
+
+    def pin(nbytes):
+        p = C.c_void_p()
+        assert l.ddn_host_alloc_pinned(nbytes, C.byref(p)) == 0
+        pinned.append(p)
+        return p
+    h_iq = [pin(iq_bytes) for _ in range(2)]
+    for p in h_iq:
+        assert l.ddn_device_download(p, d_iq.data_ptr(), iq_bytes) == 0
+    outs = []
+    for _ in range(2):
+        o = ddn.P25ChainHostOut()
+        for k, nb in sizes.items():
+            setattr(o, k, pin(nb).value)
+        outs.append(o)
+    for k in range(3):
+        chain.run_host(h_iq[k & 1], outs[k & 1])
+    chain.wait()
+    steps = 6
+    t0 = time.perf_counter()
+    for k in range(steps):
+        chain.run_host(h_iq[(k + 1) & 1], outs[(k + 1) & 1])
+    chain.wait()
+    t = (time.perf_counter() - t0) / steps
+    for p in pinned:
+        l.ddn_host_free_pinned(p)
+    moved = iq_bytes + sum(sizes.values())
+    return {"note": "pinned host I/Q in; records + flags + counts + handler decisions + NIDs + TSDU blocks + PCM out; copies on two copy "
+                    "streams overlapped with the kernels (ddn_p25_chain_run_host), steady state over %d steps" % steps,
+            "ms_per_step": round(t * 1e3, 3), "Msamples_per_s": round(B * n / t / 1e6, 1), "bytes_over_pcie": moved,
+            "GB_per_s_over_pcie": round(moved / t / 1e9, 1)}
 
 
 if __name__ == "__main__":

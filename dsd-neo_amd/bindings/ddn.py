@@ -123,7 +123,8 @@ PROTOTYPES = {
     "ddn_p25_rx_debug_counters": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25_rx_set_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ddn_p25_rx_run_host_ev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                         C.c_void_p, C.c_void_p, C.c_size_t]),
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_p25_rx_set_event_data": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_rx_max_symbols": (C.c_size_t, [C.c_void_p, C.c_size_t]),
     "ddn_p25_rx_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
@@ -414,17 +415,18 @@ class P25ChainConfig(C.Structure):  # == ddn_p25_chain_config (include/ddn_chain
 
 class P25ChainResults(C.Structure):  # == ddn_p25_chain_results
     _fields_ = [("stride_symbols", C.c_size_t), ("d_records10", C.c_void_p), ("d_flags", C.c_void_p), ("d_counts", C.c_void_p),
-                ("d_new", C.c_void_p), ("d_events", C.c_void_p), ("d_n_events", C.c_void_p), ("d_n_syncs", C.c_void_p),
+                ("d_new", C.c_void_p), ("d_events", C.c_void_p), ("d_n_events", C.c_void_p), ("d_event_data", C.c_void_p),
+                ("d_n_syncs", C.c_void_p),
                 ("d_sync_pos", C.c_void_p), ("d_nid4", C.c_void_p), ("d_tsbk", C.c_void_p), ("d_tsbk_crc", C.c_void_p),
                 ("d_ldu_words", C.c_void_p * 2), ("d_ldu_rs_data", C.c_void_p * 2), ("d_ldu_rs_status", C.c_void_p * 2),
                 ("d_lsd_bits", C.c_void_p), ("d_lsd_ok", C.c_void_p), ("d_hdu_rs_data", C.c_void_p), ("d_hdu_rs_status", C.c_void_p),
                 ("d_tdulc_rs_data", C.c_void_p), ("d_tdulc_rs_status", C.c_void_p), ("d_n_ldu", C.c_void_p),
-                ("d_imbe_bits", C.c_void_p), ("d_imbe_result", C.c_void_p), ("d_pcm", C.c_void_p)]
+                ("d_imbe_bits", C.c_void_p), ("d_imbe_result", C.c_void_p), ("d_pcm", C.c_void_p), ("d_synth_result", C.c_void_p)]
 
 
 class P25ChainHostOut(C.Structure):  # == ddn_p25_chain_host_out
     _fields_ = [("records10", C.c_void_p), ("flags", C.c_void_p), ("counts", C.c_void_p), ("events", C.c_void_p),
-                ("n_events", C.c_void_p), ("nid4", C.c_void_p), ("tsbk", C.c_void_p), ("pcm", C.c_void_p)]
+                ("n_events", C.c_void_p), ("event_data", C.c_void_p), ("nid4", C.c_void_p), ("tsbk", C.c_void_p), ("pcm", C.c_void_p)]
 
 
 PROTOTYPES.update({
@@ -440,6 +442,8 @@ PROTOTYPES.update({
     "ddn_p25_chain_frame_slots": (C.c_int, [C.c_void_p]),
     "ddn_p25_chain_max_ldu": (C.c_int, [C.c_void_p]),
     "ddn_p25_chain_max_events": (C.c_int, [C.c_void_p]),
+    "ddn_p25_chain_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_p25_chain_get_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_chain_front_end": (C.c_void_p, [C.c_void_p]),
     "ddn_p25_chain_rx": (C.c_void_p, [C.c_void_p]),
     "ddn_p25_chain_mbe": (C.c_void_p, [C.c_void_p]),
@@ -452,6 +456,126 @@ PROTOTYPES.update({
     "ddn_host_alloc_pinned": (C.c_int, [C.c_size_t, C.c_void_p]),
     "ddn_host_free_pinned": (None, [C.c_void_p]),
 })
+
+
+class Fsk4ChainConfig(C.Structure):  # == ddn_fsk4_chain_config
+    _fields_ = [("n_channels", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int), ("input_format", C.c_int),
+                ("protocol", C.c_int), ("rf_mod", C.c_int), ("inverted", C.c_int), ("handlers", C.c_int), ("vocoder", C.c_int)]
+
+
+class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
+    _fields_ = [("max_symbols", C.c_size_t), ("max_syncs", C.c_size_t), ("voice_slots", C.c_int)] + [
+        (k, C.c_void_p) for k in ("d_records10", "d_flags", "d_payload2", "d_counts", "d_n_sync", "d_sync_pos", "d_sync_pat", "d_pre",
+                                  "d_valid", "d_dmr_slot_type", "d_dmr_slot_type_ok", "d_dmr_pdu96", "d_dmr_bptc_errs", "d_nxdn_lich",
+                                  "d_nxdn_sacch", "d_nxdn_sacch_ok", "d_nxdn_sacch_hard", "d_nxdn_sacch_hard_ok", "d_nxdn_facch",
+                                  "d_nxdn_facch_ok", "d_nxdn_voice_skip", "d_nxdn_ambe_bits", "d_nxdn_pcm")]
+
+
+class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config
+    _fields_ = [("n_p25", C.c_int), ("n_dmr", C.c_int), ("n_nxdn48", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int),
+                ("input_format", C.c_int), ("vocoder", C.c_int)]
+
+
+PROTOTYPES.update({
+    "ddn_fsk4_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_fsk4_chain_destroy": (None, [C.c_void_p]),
+    "ddn_fsk4_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fsk4_chain_get_results": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_fsk4_chain_front_end": (C.c_void_p, [C.c_void_p]),
+    "ddn_fsk4_chain_rx": (C.c_void_p, [C.c_void_p]),
+    "ddn_mixed_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_mixed_chain_destroy": (None, [C.c_void_p]),
+    "ddn_mixed_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_mixed_chain_wait": (C.c_int, [C.c_void_p]),
+    "ddn_mixed_chain_part": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ddn_mixed_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+})
+
+
+def mixed_partition(n_p25, n_dmr, n_nxdn48, rank, world):
+    """ddn_mixed_partition -> ((first, count) of P25, DMR, NXDN48 for this rank)"""
+    f, c = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    _check(lib().ddn_mixed_partition(n_p25, n_dmr, n_nxdn48, rank, world, f, c), "ddn_mixed_partition")
+    return [(f[k], c[k]) for k in range(3)]
+
+
+class Fsk4ChainC:
+    """ddn_fsk4_chain (include/ddn_chain.h): the DMR / NXDN48 path as one C object; fetch() copies a result array to the host"""
+
+    def __init__(self, n_channels, samples_per_call, protocol, rf_mod=0, inverted=0, block_len=8192, handlers=1, vocoder=1, handle=None):
+        import numpy as np
+        self.np = np
+        self.own = handle is None
+        if handle is None:
+            cfg = Fsk4ChainConfig(n_channels, samples_per_call, block_len, 0, protocol, rf_mod, inverted, handlers, vocoder)
+            self.h = C.c_void_p()
+            _check(lib().ddn_fsk4_chain_create(C.byref(cfg), C.byref(self.h)), "ddn_fsk4_chain_create")
+        else:
+            self.h = C.c_void_p(handle)
+        self.B, self.n = n_channels, samples_per_call
+
+    def close(self):
+        if self.h and self.own:
+            lib().ddn_fsk4_chain_destroy(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, d_iq_ptr, stream=None):
+        _check(lib().ddn_fsk4_chain_run(self.h, d_iq_ptr, stream), "ddn_fsk4_chain_run")
+
+    def results(self):
+        r = Fsk4ChainResults()
+        _check(lib().ddn_fsk4_chain_get_results(self.h, C.byref(r)), "ddn_fsk4_chain_get_results")
+        return r
+
+    @property
+    def rx(self):
+        return lib().ddn_fsk4_chain_rx(self.h)
+
+    def fetch(self, ptr, dtype, shape):
+        a = self.np.zeros(shape, dtype)
+        _check(lib().ddn_device_download(a.ctypes.data, ptr, a.nbytes), "ddn_device_download")
+        return a
+
+
+class MixedChainC:
+    """ddn_mixed_chain: P25 Phase 1 + DMR + NXDN48 channel groups of one GPU (BASELINE configs[3])"""
+
+    def __init__(self, n_p25, n_dmr, n_nxdn48, samples_per_call, block_len=8192, vocoder=1):
+        cfg = MixedChainConfig(n_p25, n_dmr, n_nxdn48, samples_per_call, block_len, 0, vocoder)
+        self.h = C.c_void_p()
+        _check(lib().ddn_mixed_chain_create(C.byref(cfg), C.byref(self.h)), "ddn_mixed_chain_create")
+        self.counts = (n_p25, n_dmr, n_nxdn48)
+        self.n = samples_per_call
+
+    def close(self):
+        if self.h:
+            lib().ddn_mixed_chain_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, p25_ptr, dmr_ptr, nxdn_ptr):
+        _check(lib().ddn_mixed_chain_run(self.h, p25_ptr, dmr_ptr, nxdn_ptr), "ddn_mixed_chain_run")
+
+    def wait(self):
+        _check(lib().ddn_mixed_chain_wait(self.h), "ddn_mixed_chain_wait")
+
+    def part(self, which):
+        """the group's chain object as a non-owning view (0 P25ChainC is not wrapped: use the handle with the ddn_p25_chain_* calls)"""
+        h = lib().ddn_mixed_chain_part(self.h, which)
+        if not h or which == 0:
+            return h
+        return Fsk4ChainC(self.counts[which], self.n, 0, handle=h)
 
 
 class P25ChainC:
@@ -503,6 +627,26 @@ class P25ChainC:
         r = P25ChainResults()
         _check(lib().ddn_p25_chain_get_results(self.h, C.byref(r)), "ddn_p25_chain_get_results")
         return r
+
+    def set_timing(self, on):
+        _check(lib().ddn_p25_chain_set_timing(self.h, 1 if on else 0), "ddn_p25_chain_set_timing")
+
+    def stage_ms(self):
+        t = self.np.zeros(4, self.np.float32)
+        _check(lib().ddn_p25_chain_get_stage_ms(self.h, t.ctypes.data), "ddn_p25_chain_get_stage_ms")
+        return t
+
+    @property
+    def rx(self):
+        return lib().ddn_p25_chain_rx(self.h)
+
+    @property
+    def fe(self):
+        return lib().ddn_p25_chain_front_end(self.h)
+
+    @property
+    def mbe(self):
+        return lib().ddn_p25_chain_mbe(self.h)
 
     def fetch(self, ptr, dtype, shape):
         np = self.np
@@ -705,8 +849,9 @@ class P25Rx:
         if self.handlers:
             self.events = np.zeros((self.B, self.max_events, 4), np.int32)
             self.n_events = np.zeros(self.B, np.int32)
+            self.event_data = np.zeros((self.B, self.max_events, 4), np.int32)
             rc = lib().ddn_p25_rx_run_host_ev(self.h, disc.ctypes.data, n, rec.ctypes.data, fl.ctypes.data, cnt.ctypes.data, ms, self.events.ctypes.data,
-                   self.n_events.ctypes.data, self.max_events)
+                   self.n_events.ctypes.data, self.max_events, self.event_data.ctypes.data)
         else:
             rc = lib().ddn_p25_rx_run_host(self.h, disc.ctypes.data, n, rec.ctypes.data, fl.ctypes.data, cnt.ctypes.data, ms)
         _check(-abs(rc), "ddn_p25_rx_run_host")

@@ -9,13 +9,13 @@ import ddn
 
 
 class Fsk4Chain:
-    def __init__(self, torch, B, n, protocol, rf_mod=0, inverted=0, block_len=8192, lock=None):
+    def __init__(self, torch, B, n, protocol, rf_mod=0, inverted=0, block_len=8192, lock=None, handlers=False):
         l = ddn.lib()
         self.torch, self.l, self.B, self.n, self.protocol, self.inverted = torch, l, B, n, protocol, inverted
         dmr = protocol == ddn.FSK4_DMR
         self.fe = ddn.Batch(B, symbol_rate_hz=4800 if dmr else 2400, lpf_profile=ddn.LPF_12K5 if dmr else ddn.LPF_6K25,
                             block_len=block_len)
-        self.rx = ddn.Fsk4Rx(B, protocol, rf_mod=rf_mod, inverted=inverted, lock=lock)
+        self.rx = ddn.Fsk4Rx(B, protocol, rf_mod=rf_mod, inverted=inverted, lock=lock, handlers=handlers)
         self.ms = l.ddn_fsk4_rx_max_symbols(self.rx.h, n)
         self.my = l.ddn_fsk4_rx_max_syncs(self.rx.h, n)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")

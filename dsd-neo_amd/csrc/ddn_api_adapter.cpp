@@ -4,6 +4,7 @@
 
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "ddn_demod_adapter.h"
 #include "ddn_device.h"
@@ -21,6 +22,7 @@ struct Adapter {
     float cq_gain = 0.0f;
     int ted_key[2] = {0, 0};
     float ted_gain = 0.0f;
+    std::vector<float> cq_row; // CQPSK symbols of one call at the loop's own row capacity
 };
 
 Adapter*
@@ -109,9 +111,17 @@ full_demod(struct demod_state* s) {
             memcpy(a->cq_key, key, sizeof(key));
             a->cq_gain = s->ted_gain;
         }
+        // the loop's row capacity (n / sps + n / (100 sps) + 8) can exceed the caller's result buffer (>= lp_len / 2 floats) on
+        // very short blocks: run into a scratch row of that capacity and hand back the symbols that were produced
         int32_t cnt = 0;
-        if (ddn_cqpsk_run_host(a->cq, s->lowpassed, (size_t)n, s->result, ddn_cqpsk_max_symbols(a->cq, (size_t)n), &cnt) == DDN_OK) {
-            s->result_len = cnt;
+        const size_t cap = ddn_cqpsk_max_symbols(a->cq, (size_t)n);
+        if (a->cq_row.size() < cap) {
+            a->cq_row.resize(cap);
+        }
+        if (ddn_cqpsk_run_host(a->cq, s->lowpassed, (size_t)n, a->cq_row.data(), cap, &cnt) == DDN_OK) {
+            const int keep = cnt < n ? cnt : n;
+            memcpy(s->result, a->cq_row.data(), sizeof(float) * (size_t)(keep > 0 ? keep : 0));
+            s->result_len = keep;
         }
         return;
     }

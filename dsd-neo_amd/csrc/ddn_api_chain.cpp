@@ -33,7 +33,8 @@
 
 struct ddn_p25_chain {
     ddn_p25_chain_config cfg;
-    int B, n, T, F, Fv, E;
+    int B, n, T, F, Fv, E, EL;
+    int off97[3]; // symbol a TSDU block's decision falls on, counted from the sync's last symbol
     size_t ms, stride, S, V;
     ddn_batch* fe;
     ddn_p25_rx* rx;
@@ -42,15 +43,12 @@ struct ddn_p25_chain {
     float* d_disc;
     // receive-loop outputs, two sets: the loop of call k + 1 writes one while call k is decoded out of the other
     uint8_t *d_rec[2], *d_fl[2];
-    int32_t *d_new[2], *d_ev[2], *d_nev[2];
+    int32_t *d_new[2], *d_ev[2], *d_nev[2], *d_evd[2];
+    // the decisions of the records a row holds (carried + new), by row index: what files NIDs and TSDU blocks by frame
+    int32_t *d_evl[2], *d_evdl[2], *d_nevl[2];
     int32_t *d_cnt_scan, *d_cnt_full;
     // decode buffers
-    uint8_t *d_bits, *d_rel, *d_par, *d_prel, *d_vnid;
-    int32_t *d_obs, *d_nid;
-    int16_t* d_llr;
-    uint8_t* d_vblk;
-    uint8_t* d_cand;
-    int32_t* d_ccnt;
+    int32_t* d_nid;
     uint8_t *d_tsbk, *d_tsbk_crc;
     uint8_t *d_words[2], *d_wrel, *d_werrs, *d_vldu;
     uint8_t *d_rs_d[2], *d_rs_p[2], *d_rs_st[2];
@@ -69,6 +67,9 @@ struct ddn_p25_chain {
     size_t iq_bytes;
     long step;
     int last_set;
+    // stage timing (ddn_p25_chain_set_timing): events at the stage boundaries of the most recent call
+    int timing;
+    hipEvent_t ev_t[6];
 };
 
 template <typename T>
@@ -91,8 +92,8 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     ddn_p25p1_framer_destroy(c->fr);
     ddn_mbe_batch_destroy(c->mbe);
     void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_new[0], c->d_new[1], c->d_ev[0], c->d_ev[1],
-                   c->d_nev[0], c->d_nev[1], c->d_cnt_scan, c->d_cnt_full, c->d_bits, c->d_rel, c->d_par, c->d_prel, c->d_vnid,
-                   c->d_obs, c->d_nid, c->d_llr, c->d_vblk, c->d_cand, c->d_ccnt, c->d_tsbk, c->d_tsbk_crc, c->d_words[0],
+                   c->d_nev[0], c->d_nev[1], c->d_evd[0], c->d_evd[1], c->d_evl[0], c->d_evl[1], c->d_evdl[0], c->d_evdl[1],
+                   c->d_nevl[0], c->d_nevl[1], c->d_cnt_scan, c->d_cnt_full, c->d_nid, c->d_tsbk, c->d_tsbk_crc, c->d_words[0],
                    c->d_words[1], c->d_wrel, c->d_werrs, c->d_vldu, c->d_rs_d[0], c->d_rs_d[1], c->d_rs_p[0], c->d_rs_p[1],
                    c->d_rs_st[0], c->d_rs_st[1], c->d_lsd, c->d_lsd_ok, c->d_lsd_llr, c->d_hdu_hex, c->d_hdu_par, c->d_hdu_st,
                    c->d_hdu_d, c->d_hdu_p, c->d_hdu_rs, c->d_td_d, c->d_td_p, c->d_td_st, c->d_td_rd, c->d_td_rp, c->d_td_rs,
@@ -114,7 +115,8 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
         (void)hipStreamDestroy(c->s_copy2);
     }
     hipEvent_t evs[] = {c->ev_produced[0], c->ev_produced[1], c->ev_consumed[0], c->ev_consumed[1], c->ev_in[0], c->ev_in[1],
-                        c->ev_in_free[0], c->ev_in_free[1], c->ev_out[0], c->ev_out[1]};
+                        c->ev_in_free[0], c->ev_in_free[1], c->ev_out[0], c->ev_out[1], c->ev_t[0], c->ev_t[1], c->ev_t[2],
+                        c->ev_t[3], c->ev_t[4], c->ev_t[5]};
     for (hipEvent_t e : evs) {
         if (e) {
             (void)hipEventDestroy(e);
@@ -142,6 +144,7 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
     c->F = cfg->max_frames > 0 ? cfg->max_frames : cfg->samples_per_call / 1800 + 6;
     c->Fv = cfg->max_ldu > 0 ? cfg->max_ldu : cfg->samples_per_call / 8640 + 3;
     c->E = cfg->max_events > 0 ? cfg->max_events : 4 * c->F;
+    c->EL = c->E + 64; // + the decisions inside a carried tail
     int rc = DDN_OK;
     do {
         ddn_front_end_config fc = {c->B, 48000, 4800, 4, DDN_LPF_P25_C4FM, cfg->input_format, cfg->block_len, 0.0f};
@@ -155,6 +158,11 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
         if ((rc = ddn_p25p1_framer_create(c->B, c->F, &c->fr)) != DDN_OK) {
             break;
         }
+        // a TSDU block's decision falls on the last of the 101 symbols the handler reads for it (98 data dibits + the status
+        // symbols among them; the third block's 101st symbol is a status symbol): 33 NID symbols + 101 per block after the sync
+        for (int b = 0; b < 3; b++) {
+            c->off97[b] = 33 + 101 * (b + 1);
+        }
         if ((rc = ddn_mbe_batch_create(DDN_MBE_IMBE_7200X4400, c->B, &c->mbe)) != DDN_OK
             || (rc = ddn_mbe_batch_set_p25p1_tail_rule(c->mbe, 1)) != DDN_OK) {
             break;
@@ -167,11 +175,10 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
         bool ok = dalloc(&c->d_disc, B * (size_t)c->n);
         for (int k = 0; k < 2 && ok; k++) {
             ok = dalloc(&c->d_rec[k], B * c->stride * 10) && dalloc(&c->d_fl[k], B * c->stride) && dalloc(&c->d_new[k], B)
-                 && dalloc(&c->d_ev[k], B * (size_t)c->E * 4) && dalloc(&c->d_nev[k], B);
+                 && dalloc(&c->d_ev[k], B * (size_t)c->E * 4) && dalloc(&c->d_nev[k], B) && dalloc(&c->d_evd[k], B * (size_t)c->E * 4)
+                 && dalloc(&c->d_evl[k], B * (size_t)c->EL * 4) && dalloc(&c->d_evdl[k], B * (size_t)c->EL * 4) && dalloc(&c->d_nevl[k], B);
         }
-        ok = ok && dalloc(&c->d_cnt_scan, B) && dalloc(&c->d_cnt_full, B) && dalloc(&c->d_bits, S * 63) && dalloc(&c->d_rel, S * 63)
-             && dalloc(&c->d_par, S) && dalloc(&c->d_prel, S) && dalloc(&c->d_vnid, S) && dalloc(&c->d_obs, S) && dalloc(&c->d_nid, S * 4)
-             && dalloc(&c->d_llr, S * 196) && dalloc(&c->d_vblk, S) && dalloc(&c->d_cand, S * 8 * 16) && dalloc(&c->d_ccnt, S)
+        ok = ok && dalloc(&c->d_cnt_scan, B) && dalloc(&c->d_cnt_full, B) && dalloc(&c->d_nid, S * 4)
              && dalloc(&c->d_tsbk, 3 * S * 12) && dalloc(&c->d_tsbk_crc, 3 * S) && dalloc(&c->d_words[0], S * 240)
              && dalloc(&c->d_words[1], S * 240) && dalloc(&c->d_wrel, S * 240) && dalloc(&c->d_werrs, S * 24) && dalloc(&c->d_vldu, S)
              && dalloc(&c->d_rs_d[0], S * 72) && dalloc(&c->d_rs_d[1], S * 96) && dalloc(&c->d_rs_p[0], S * 72)
@@ -203,6 +210,11 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
                 rc = DDN_EHIP;
             }
         }
+        for (hipEvent_t& e : c->ev_t) {
+            if (hipEventCreate(&e) != hipSuccess) {
+                rc = DDN_EHIP;
+            }
+        }
         c->iq_bytes = B * (size_t)c->n * (cfg->input_format == DDN_IN_CF32 ? 8 : 2);
     } while (0);
     if (rc != DDN_OK) {
@@ -217,13 +229,23 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
 static int
 chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st) {
     const int prev = cur ^ 1;
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t[0], st));
+    }
     HIP_TRY(ddn_dev_chain_carry(c->d_rec[prev], c->d_fl[prev], c->d_new[prev], c->step > 0 ? 1 : 0, c->d_rec[cur], c->d_fl[cur],
                                 c->stride, c->T, c->B, st));
     DDN_TRY(ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st));
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t[1], st));
+    }
     DDN_TRY(ddn_p25_rx_set_events(c->rx, c->d_ev[cur], c->d_nev[cur], (size_t)c->E));
+    DDN_TRY(ddn_p25_rx_set_event_data(c->rx, c->d_evd[cur]));
     // the loop writes its records behind the T carried ones: row pointer + T records, row stride unchanged
     DDN_TRY(ddn_p25_rx_run(c->rx, c->d_disc, (size_t)c->n, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T, c->d_new[cur],
                            c->stride, st));
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t[2], st));
+    }
     return DDN_OK;
 }
 
@@ -232,16 +254,22 @@ static int
 chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
     const size_t S = c->S, V = c->V, stride = c->stride;
     const uint8_t* rec = c->d_rec[cur];
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t[3], st));
+    }
     HIP_TRY(ddn_dev_chain_counts(c->d_new[cur], c->T, c->B, flush, c->d_cnt_scan, c->d_cnt_full, st));
     DDN_TRY(ddn_p25p1_framer_index(c->fr, c->d_fl[cur], c->d_cnt_scan, stride, st));
-    DDN_TRY(ddn_p25p1_framer_gather_nid(c->fr, rec, c->d_cnt_full, stride, c->d_bits, c->d_rel, c->d_par, c->d_prel, c->d_vnid, st));
-    DDN_TRY(ddn_p25p1_nid_decode_batch(c->d_bits, c->d_rel, c->d_obs, c->d_par, c->d_prel, 64, S, c->d_nid, st));
-    // TSDU: up to three blocks, each through the list decoder and the CRC16 scan
-    for (int blk = 0; blk < 3; blk++) {
-        DDN_TRY(ddn_p25p1_framer_gather_trellis_block(c->fr, blk, rec, c->d_cnt_full, stride, c->d_llr, nullptr, c->d_vblk, st));
-        DDN_TRY(ddn_fec_p25_12_soft_list_batch(c->d_llr, S, 8, (ddn_p25_12_candidate*)c->d_cand, c->d_ccnt, st));
-        DDN_TRY(ddn_fec_p25_tsbk_select_batch((const ddn_p25_12_candidate*)c->d_cand, c->d_ccnt, S, c->d_tsbk + (size_t)blk * S * 12,
-                                              c->d_tsbk_crc + (size_t)blk * S, nullptr, st));
+    // the NID and the TSDU blocks of every frame were decoded inside the loop by its handlers (p25p1_nid_decode,
+    // tsbk_decode_repetition_bytes: ddn_p25_rx_set_event_data); they are filed by frame here, not decoded a second time
+    {
+        const int prev = cur ^ 1;
+        HIP_TRY(ddn_dev_chain_events(c->d_evl[prev], c->d_evdl[prev], c->d_nevl[prev], c->d_new[prev], c->step > 0 ? 1 : 0, c->d_ev[cur],
+                                     c->d_evd[cur], c->d_nev[cur], c->E, c->EL, c->T, c->B, c->d_evl[cur], c->d_evdl[cur], c->d_nevl[cur],
+                                     st));
+        const int32_t *d_ns = nullptr, *d_sp = nullptr;
+        DDN_TRY(ddn_p25p1_framer_device_syncs(c->fr, &d_ns, &d_sp));
+        HIP_TRY(ddn_dev_chain_frames(c->d_evl[cur], c->d_evdl[cur], c->d_nevl[cur], c->EL, d_sp, d_ns, c->B, c->F, c->off97[0],
+                                     c->off97[1], c->off97[2], c->d_nid, c->d_tsbk, c->d_tsbk_crc, st));
     }
     // LDU1 / LDU2: Hamming words -> Reed-Solomon; low speed data
     for (int i = 0; i < 2; i++) {
@@ -263,6 +291,9 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
     DDN_TRY(ddn_fec_golay24_batch(12, c->d_td_d, c->d_td_p, S * 12, c->d_td_st, nullptr, st));
     DDN_TRY(ddn_p25p1_framer_pack_tdulc_rs(c->fr, c->d_td_d, c->d_td_rd, c->d_td_rp, st));
     DDN_TRY(ddn_fec_p25_rs_batch(DDN_RS_24_12_13, c->d_td_rd, c->d_td_rp, S, c->d_td_rs, st));
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t[4], st));
+    }
     // voice: nine IMBE frames per LDU
     DDN_TRY(ddn_p25p1_framer_voice_index(c->fr, c->d_nid, c->d_cnt_full, c->Fv, stride, c->d_first, c->d_sc, c->d_nldu, st));
     DDN_TRY(ddn_p25p1_imbe_deinterleave_batch(rec, (size_t)c->B * stride, c->d_first, c->d_sc, V, c->d_imbe_fr, c->d_imbe_soft,
@@ -272,6 +303,32 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
     if (c->cfg.vocoder) {
         DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_imbe_d, c->d_imbe_res, (size_t)c->Fv * 9, c->d_pcm, c->d_res_out, st));
     }
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t[5], st));
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_chain_set_timing(ddn_p25_chain* c, int enable) {
+    if (!c) {
+        return DDN_EINVAL;
+    }
+    c->timing = enable ? 1 : 0;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_chain_get_stage_ms(ddn_p25_chain* c, float out4[4]) {
+    if (!c || !out4) {
+        return DDN_EINVAL;
+    }
+    DDN_TRY(ddn_p25_chain_wait(c));
+    HIP_TRY(hipEventSynchronize(c->ev_t[5]));
+    HIP_TRY(hipEventElapsedTime(&out4[0], c->ev_t[0], c->ev_t[1]));
+    HIP_TRY(hipEventElapsedTime(&out4[1], c->ev_t[1], c->ev_t[2]));
+    HIP_TRY(hipEventElapsedTime(&out4[2], c->ev_t[3], c->ev_t[4]));
+    HIP_TRY(hipEventElapsedTime(&out4[3], c->ev_t[4], c->ev_t[5]));
     return DDN_OK;
 }
 
@@ -353,6 +410,9 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
         if (out->events) {
             HIP_TRY(hipMemcpyAsync(out->events, c->d_ev[cur], B * (size_t)c->E * 16, hipMemcpyDeviceToHost, c->s_copy2));
         }
+        if (out->event_data) {
+            HIP_TRY(hipMemcpyAsync(out->event_data, c->d_evd[cur], B * (size_t)c->E * 16, hipMemcpyDeviceToHost, c->s_copy2));
+        }
         if (out->n_events) {
             HIP_TRY(hipMemcpyAsync(out->n_events, c->d_nev[cur], B * 4, hipMemcpyDeviceToHost, c->s_copy2));
         }
@@ -422,6 +482,7 @@ ddn_p25_chain_get_results(ddn_p25_chain* c, ddn_p25_chain_results* r) {
     r->d_new = c->d_new[cur];
     r->d_events = c->d_ev[cur];
     r->d_n_events = c->d_nev[cur];
+    r->d_event_data = c->d_evd[cur];
     DDN_TRY(ddn_p25p1_framer_device_syncs(c->fr, &r->d_n_syncs, &r->d_sync_pos));
     r->d_nid4 = c->d_nid;
     r->d_tsbk = c->d_tsbk;
@@ -441,6 +502,7 @@ ddn_p25_chain_get_results(ddn_p25_chain* c, ddn_p25_chain_results* r) {
     r->d_imbe_bits = c->d_imbe_d;
     r->d_imbe_result = c->d_imbe_res;
     r->d_pcm = c->d_pcm;
+    r->d_synth_result = c->d_res_out;
     return DDN_OK;
 }
 

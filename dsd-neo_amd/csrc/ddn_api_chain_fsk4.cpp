@@ -1,0 +1,370 @@
+// ddn_api_chain_fsk4.cpp - the DMR / NXDN48 chain object and the mixed-protocol object over the three chains
+// (include/ddn_chain.h): stage order, buffers and streams on top of the library's own C-ABI stage calls.  Host-only code.
+//
+// What it stands in for in a dsd-neo host: the demodulator thread's per-block loop (src/io/radio/rtl_sdr_fm.cpp:3458-3516) and
+// processFrame()'s DMR / NXDN branches (src/engine/protocol_dispatch.c -> dmr_data.c / dmr_bs.c, nxdn_frame.c), B channels wide.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "ddn_chain.h"
+#include "ddn_device.h"
+#include "ddn_fsk4.h"
+#include "ddn_hip.h"
+#include "ddn_mbe.h"
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            ddn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);                  \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorNoBinaryForGpu)             \
+                       ? DDN_ENODEV                                                                                    \
+                       : (e_ == hipErrorOutOfMemory ? DDN_ENOMEM : DDN_EHIP);                                          \
+        }                                                                                                              \
+    } while (0)
+#define DDN_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        const int rc_ = (expr);                                                                                        \
+        if (rc_ != DDN_OK) {                                                                                           \
+            return rc_;                                                                                                \
+        }                                                                                                              \
+    } while (0)
+
+struct ddn_fsk4_chain {
+    ddn_fsk4_chain_config cfg;
+    int B, n, dmr, vf;
+    size_t ms, my, S, V;
+    ddn_batch* fe;
+    ddn_fsk4_rx* rx;
+    ddn_mbe_batch* mbe;
+    float* d_disc;
+    uint8_t *d_rec, *d_fl, *d_pay, *d_spat, *d_pre, *d_prel;
+    int32_t *d_cnt, *d_ns, *d_spos;
+    // DMR
+    uint8_t *d_st, *d_info, *d_cach, *d_valid, *d_st_ok, *d_pdu, *d_r3;
+    uint32_t* d_errs;
+    // NXDN48
+    uint8_t *d_lich, *d_ss, *d_sr, *d_fs, *d_fr, *d_sacch, *d_sacch_ok, *d_hard_in, *d_sacch_hard, *d_sacch_hard_ok, *d_facch, *d_facch_ok;
+    int32_t *d_vpos, *d_vn, *d_ambe_res, *d_res_out;
+    uint8_t *d_ambe_fr, *d_ambe_rel, *d_ambe_d, *d_skip;
+    float* d_pcm;
+};
+
+template <typename T>
+static bool
+dalloc(T** p, size_t count) {
+    if (hipMalloc((void**)p, count * sizeof(T) + 16) != hipSuccess) {
+        return false;
+    }
+    return hipMemset(*p, 0, count * sizeof(T)) == hipSuccess;
+}
+
+extern "C" void
+ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
+    if (!c) {
+        return;
+    }
+    (void)hipDeviceSynchronize();
+    ddn_batch_destroy(c->fe);
+    ddn_fsk4_rx_destroy(c->rx);
+    ddn_mbe_batch_destroy(c->mbe);
+    void* all[] = {c->d_disc, c->d_rec, c->d_fl, c->d_pay, c->d_spat, c->d_pre, c->d_prel, c->d_cnt, c->d_ns, c->d_spos, c->d_st, c->d_info,
+                   c->d_cach, c->d_valid, c->d_st_ok, c->d_pdu, c->d_r3, c->d_errs, c->d_lich, c->d_ss, c->d_sr, c->d_fs, c->d_fr,
+                   c->d_sacch, c->d_sacch_ok, c->d_hard_in, c->d_sacch_hard, c->d_sacch_hard_ok, c->d_facch, c->d_facch_ok, c->d_vpos,
+                   c->d_vn, c->d_ambe_res, c->d_res_out, c->d_ambe_fr, c->d_ambe_rel, c->d_ambe_d, c->d_skip, c->d_pcm};
+    for (void* p : all) {
+        (void)hipFree(p);
+    }
+    delete c;
+}
+
+extern "C" int
+ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
+    if (!cfg || !out || cfg->n_channels <= 0 || cfg->samples_per_call <= 0 || cfg->block_len <= 0
+        || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48)) {
+        ddn_set_error("ddn_fsk4_chain_create: bad configuration");
+        return DDN_EINVAL;
+    }
+    *out = nullptr;
+    ddn_fsk4_chain* c = new (std::nothrow) ddn_fsk4_chain();
+    if (!c) {
+        return DDN_ENOMEM;
+    }
+    memset(c, 0, sizeof(*c));
+    c->cfg = *cfg;
+    c->B = cfg->n_channels;
+    c->n = cfg->samples_per_call;
+    c->dmr = cfg->protocol == DDN_FSK4_DMR;
+    int rc = DDN_OK;
+    do {
+        ddn_front_end_config fc = {c->B, 48000, c->dmr ? 4800 : 2400, 4, c->dmr ? DDN_LPF_12K5 : DDN_LPF_6K25, cfg->input_format,
+                                   cfg->block_len, 0.0f};
+        if ((rc = ddn_batch_create(&fc, &c->fe)) != DDN_OK) {
+            break;
+        }
+        ddn_fsk4_rx_config rcfg;
+        memset(&rcfg, 0, sizeof(rcfg));
+        rcfg.n_channels = c->B;
+        rcfg.out_rate_hz = 48000;
+        rcfg.protocol = cfg->protocol;
+        rcfg.rf_mod = cfg->rf_mod;
+        rcfg.inverted = cfg->inverted;
+        rcfg.use_matched_filter = 1;
+        if ((rc = ddn_fsk4_rx_create(&rcfg, &c->rx)) != DDN_OK) {
+            break;
+        }
+        if (cfg->handlers && (rc = ddn_fsk4_rx_set_handlers(c->rx, 1)) != DDN_OK) {
+            break;
+        }
+        c->ms = ddn_fsk4_rx_max_symbols(c->rx, (size_t)c->n);
+        c->my = ddn_fsk4_rx_max_syncs(c->rx, (size_t)c->n);
+        c->S = (size_t)c->B * c->my;
+        const size_t B = (size_t)c->B, S = c->S, ms = c->ms, my = c->my;
+        bool ok = dalloc(&c->d_disc, B * (size_t)c->n) && dalloc(&c->d_rec, B * ms * 10) && dalloc(&c->d_fl, B * ms)
+                  && dalloc(&c->d_pay, B * ms * 2) && dalloc(&c->d_cnt, B) && dalloc(&c->d_ns, B) && dalloc(&c->d_spos, B * my)
+                  && dalloc(&c->d_spat, B * my) && dalloc(&c->d_pre, B * my * 90) && dalloc(&c->d_prel, B * my * 90);
+        if (ok && c->dmr) {
+            ok = dalloc(&c->d_st, S * 20) && dalloc(&c->d_info, S * 196) && dalloc(&c->d_cach, S * 24) && dalloc(&c->d_valid, S)
+                 && dalloc(&c->d_st_ok, S) && dalloc(&c->d_pdu, S * 96) && dalloc(&c->d_r3, S * 3) && dalloc(&c->d_errs, S);
+        } else if (ok) {
+            // voice: four AMBE frames per NXDN frame, one talk path per channel.  With the handlers deciding the frame length two
+            // syncs are at least a 192-symbol frame apart: a call holds n / (192 * 20) + 2 frames at most
+            const size_t cap = (size_t)c->n / (192 * 20) + 2;
+            c->vf = (int)(cfg->handlers ? (cap < my ? cap : my) : my);
+            c->V = B * (size_t)c->vf;
+            const size_t V = c->V;
+            ok = dalloc(&c->d_lich, S) && dalloc(&c->d_valid, S) && dalloc(&c->d_ss, S * 72) && dalloc(&c->d_sr, S * 72)
+                 && dalloc(&c->d_fs, S * 384) && dalloc(&c->d_fr, S * 384) && dalloc(&c->d_sacch, S * 4) && dalloc(&c->d_sacch_ok, S)
+                 && dalloc(&c->d_hard_in, S * 72) && dalloc(&c->d_sacch_hard, S * 32) && dalloc(&c->d_sacch_hard_ok, S)
+                 && dalloc(&c->d_facch, S * 2 * 12) && dalloc(&c->d_facch_ok, S * 2) && dalloc(&c->d_vpos, V) && dalloc(&c->d_vn, B)
+                 && dalloc(&c->d_ambe_fr, V * 384) && dalloc(&c->d_ambe_rel, V * 384) && dalloc(&c->d_ambe_d, V * 4 * 49)
+                 && dalloc(&c->d_ambe_res, V * 4 * 5) && dalloc(&c->d_skip, V * 4) && dalloc(&c->d_pcm, V * 4 * 160)
+                 && dalloc(&c->d_res_out, V * 4 * 5);
+            if (ok && (rc = ddn_mbe_batch_create(DDN_MBE_AMBE_3600X2450, c->B, &c->mbe)) != DDN_OK) {
+                break;
+            }
+        }
+        if (!ok) {
+            ddn_set_error("ddn_fsk4_chain_create: device allocation failed");
+            rc = DDN_ENOMEM;
+        }
+    } while (0);
+    if (rc != DDN_OK) {
+        ddn_fsk4_chain_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fsk4_chain_run(ddn_fsk4_chain* c, const void* d_iq, void* hip_stream) {
+    if (!c || !d_iq) {
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t S = c->S;
+    DDN_TRY(ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st));
+    DDN_TRY(ddn_fsk4_rx_run(c->rx, c->d_disc, (size_t)c->n, c->d_rec, c->d_fl, c->d_pay, c->d_cnt, c->ms, c->d_spos, c->d_spat, c->d_pre,
+                            c->d_prel, c->d_ns, c->my, st));
+    if (c->dmr) {
+        // burst gather -> slot type Golay(20,8) -> BPTC(196,96)
+        DDN_TRY(ddn_dmr_burst_gather(c->d_rec, c->d_cnt, c->ms, c->d_spos, c->d_pre, c->d_ns, c->B, c->my, c->cfg.inverted, c->d_st,
+                                     c->d_info, c->d_cach, c->d_valid, st));
+        DDN_TRY(ddn_fec_block_code_batch(5 /* DDN_CODE_GOLAY_20_8 */, c->d_st, S, 1, nullptr, c->d_st_ok, st));
+        DDN_TRY(ddn_fec_bptc_196x96_batch(c->d_info, 1, S, c->d_pdu, c->d_r3, c->d_errs, st));
+        return DDN_OK;
+    }
+    // NXDN48: frame gather -> SACCH / FACCH1 K=5 soft decode -> CRC6 / CRC12 -> the reference's greedy retry for the SACCH
+    DDN_TRY(ddn_nxdn_frame_gather(c->d_rec, c->d_cnt, c->ms, c->d_spos, c->d_ns, c->B, c->my, c->d_lich, c->d_ss, c->d_sr, c->d_fs, c->d_fr,
+                                  c->d_valid, st));
+    DDN_TRY(ddn_fec_nxdn_conv_batch(c->d_ss, c->d_sr, S, 36, 32, nullptr, c->d_sacch, 4, st));
+    DDN_TRY(ddn_nxdn_crc_check_batch(c->d_sacch, 4, S, 0, c->d_sacch_ok, st));
+    HIP_TRY(ddn_dev_u8_shr1(c->d_ss, S * 72, c->d_hard_in, st));
+    DDN_TRY(ddn_fec_trellis_decode_batch(c->d_hard_in, 72, S, 32, c->d_sacch_hard, 32, st));
+    DDN_TRY(ddn_nxdn_crc_check_batch(c->d_sacch_hard, 32, S, 2, c->d_sacch_hard_ok, st));
+    DDN_TRY(ddn_fec_nxdn_conv_batch(c->d_fs, c->d_fr, S * 2, 96, 92, nullptr, c->d_facch, 12, st));
+    DDN_TRY(ddn_nxdn_crc_check_batch(c->d_facch, 12, S * 2, 1, c->d_facch_ok, st));
+    if (c->cfg.vocoder) {
+        // voice (nxdn_voice()): the frames the LICHs announce, through AMBE de-interleave -> frame FEC -> synthesis
+        const size_t V4 = c->V * 4;
+        HIP_TRY(ddn_dev_nxdn_voice_select(c->d_spos, c->d_ns, c->d_lich, c->d_valid, c->B, (int)c->my, c->vf, c->d_vpos, c->d_vn, c->d_skip,
+                                          st));
+        DDN_TRY(ddn_nxdn_voice_gather(c->d_rec, c->d_cnt, c->ms, c->d_vpos, c->d_vn, c->B, (size_t)c->vf, c->d_ambe_fr, c->d_ambe_rel,
+                                      nullptr, st));
+        DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, c->d_ambe_fr, c->d_ambe_rel, V4, c->d_ambe_d, c->d_ambe_res, st));
+        DDN_TRY(ddn_mbe_result_skip_batch(c->d_skip, V4, c->d_ambe_res, st));
+        DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_ambe_d, c->d_ambe_res, (size_t)c->vf * 4, c->d_pcm, c->d_res_out, st));
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
+    if (!c || !r) {
+        return DDN_EINVAL;
+    }
+    memset(r, 0, sizeof(*r));
+    r->max_symbols = c->ms;
+    r->max_syncs = c->my;
+    r->voice_slots = c->vf;
+    r->d_records10 = c->d_rec;
+    r->d_flags = c->d_fl;
+    r->d_payload2 = c->d_pay;
+    r->d_counts = c->d_cnt;
+    r->d_n_sync = c->d_ns;
+    r->d_sync_pos = c->d_spos;
+    r->d_sync_pat = c->d_spat;
+    r->d_pre = c->d_pre;
+    r->d_valid = c->d_valid;
+    r->d_dmr_slot_type = c->d_st;
+    r->d_dmr_slot_type_ok = c->d_st_ok;
+    r->d_dmr_pdu96 = c->d_pdu;
+    r->d_dmr_bptc_errs = c->d_errs;
+    r->d_nxdn_lich = c->d_lich;
+    r->d_nxdn_sacch = c->d_sacch;
+    r->d_nxdn_sacch_ok = c->d_sacch_ok;
+    r->d_nxdn_sacch_hard = c->d_sacch_hard;
+    r->d_nxdn_sacch_hard_ok = c->d_sacch_hard_ok;
+    r->d_nxdn_facch = c->d_facch;
+    r->d_nxdn_facch_ok = c->d_facch_ok;
+    r->d_nxdn_voice_skip = c->d_skip;
+    r->d_nxdn_ambe_bits = c->d_ambe_d;
+    r->d_nxdn_pcm = c->d_pcm;
+    return DDN_OK;
+}
+
+extern "C" void*
+ddn_fsk4_chain_front_end(ddn_fsk4_chain* c) {
+    return c ? c->fe : nullptr;
+}
+extern "C" void*
+ddn_fsk4_chain_rx(ddn_fsk4_chain* c) {
+    return c ? c->rx : nullptr;
+}
+
+// ---- the three protocol groups of a mixed batch (BASELINE configs[3]) -------------------------------------------------------
+struct ddn_mixed_chain {
+    ddn_mixed_chain_config cfg;
+    ddn_p25_chain* p25;
+    ddn_fsk4_chain *dmr, *nxdn;
+    hipStream_t st[3];
+};
+
+extern "C" void
+ddn_mixed_chain_destroy(ddn_mixed_chain* m) {
+    if (!m) {
+        return;
+    }
+    (void)hipDeviceSynchronize();
+    ddn_p25_chain_destroy(m->p25);
+    ddn_fsk4_chain_destroy(m->dmr);
+    ddn_fsk4_chain_destroy(m->nxdn);
+    for (hipStream_t s : m->st) {
+        if (s) {
+            (void)hipStreamDestroy(s);
+        }
+    }
+    delete m;
+}
+
+extern "C" int
+ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out) {
+    if (!cfg || !out || cfg->n_p25 < 0 || cfg->n_dmr < 0 || cfg->n_nxdn48 < 0 || cfg->n_p25 + cfg->n_dmr + cfg->n_nxdn48 <= 0
+        || cfg->samples_per_call <= 0 || cfg->block_len <= 0) {
+        ddn_set_error("ddn_mixed_chain_create: bad configuration");
+        return DDN_EINVAL;
+    }
+    *out = nullptr;
+    ddn_mixed_chain* m = new (std::nothrow) ddn_mixed_chain();
+    if (!m) {
+        return DDN_ENOMEM;
+    }
+    memset(m, 0, sizeof(*m));
+    m->cfg = *cfg;
+    int rc = DDN_OK;
+    if (cfg->n_p25 > 0) {
+        ddn_p25_chain_config pc = {cfg->n_p25, cfg->samples_per_call, cfg->block_len, cfg->input_format, cfg->vocoder, 0, 0, 0, 0};
+        rc = ddn_p25_chain_create(&pc, &m->p25);
+    }
+    if (rc == DDN_OK && cfg->n_dmr > 0) {
+        ddn_fsk4_chain_config dc = {cfg->n_dmr, cfg->samples_per_call, cfg->block_len, cfg->input_format, DDN_FSK4_DMR, 2, 0, 1, 0};
+        rc = ddn_fsk4_chain_create(&dc, &m->dmr);
+    }
+    if (rc == DDN_OK && cfg->n_nxdn48 > 0) {
+        ddn_fsk4_chain_config nc = {cfg->n_nxdn48, cfg->samples_per_call, cfg->block_len, cfg->input_format, DDN_FSK4_NXDN48, 0, 0, 1,
+                                    cfg->vocoder};
+        rc = ddn_fsk4_chain_create(&nc, &m->nxdn);
+    }
+    for (int k = 0; k < 3 && rc == DDN_OK; k++) {
+        if (hipStreamCreateWithFlags(&m->st[k], hipStreamNonBlocking) != hipSuccess) {
+            rc = DDN_EHIP;
+        }
+    }
+    if (rc != DDN_OK) {
+        ddn_mixed_chain_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_dmr, const void* d_iq_nxdn48) {
+    if (!m || (m->p25 && !d_iq_p25) || (m->dmr && !d_iq_dmr) || (m->nxdn && !d_iq_nxdn48)) {
+        return DDN_EINVAL;
+    }
+    // the protocol groups are independent channel sets: one stream each, so their receive loops (per-channel latency chains)
+    // share the device instead of queueing behind one another
+    if (m->p25) {
+        DDN_TRY(ddn_p25_chain_run(m->p25, d_iq_p25, m->st[0]));
+    }
+    if (m->dmr) {
+        DDN_TRY(ddn_fsk4_chain_run(m->dmr, d_iq_dmr, m->st[1]));
+    }
+    if (m->nxdn) {
+        DDN_TRY(ddn_fsk4_chain_run(m->nxdn, d_iq_nxdn48, m->st[2]));
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_mixed_chain_wait(ddn_mixed_chain* m) {
+    if (!m) {
+        return DDN_EINVAL;
+    }
+    for (hipStream_t s : m->st) {
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return DDN_OK;
+}
+
+extern "C" void*
+ddn_mixed_chain_part(ddn_mixed_chain* m, int which) {
+    if (!m) {
+        return nullptr;
+    }
+    return which == 0 ? (void*)m->p25 : (which == 1 ? (void*)m->dmr : (which == 2 ? (void*)m->nxdn : nullptr));
+}
+
+// Block partition of a mixed batch over the ranks of a node: the global channel index is [P25 | DMR | NXDN48]; rank
+// r of `world` owns a contiguous block of it (the first total % world ranks one channel more) and therefore a contiguous range of
+// each protocol group.  Pure arithmetic: every rank computes the same table.
+extern "C" int
+ddn_mixed_partition(int n_p25, int n_dmr, int n_nxdn48, int rank, int world, int32_t first3[3], int32_t count3[3]) {
+    if (n_p25 < 0 || n_dmr < 0 || n_nxdn48 < 0 || world <= 0 || rank < 0 || rank >= world || !first3 || !count3) {
+        return DDN_EINVAL;
+    }
+    const long total = (long)n_p25 + n_dmr + n_nxdn48;
+    const long base = total / world, extra = total % world;
+    const long lo = rank * base + (rank < extra ? rank : extra), hi = lo + base + (rank < extra ? 1 : 0);
+    const long start[3] = {0, n_p25, (long)n_p25 + n_dmr}, len[3] = {n_p25, n_dmr, n_nxdn48};
+    for (int k = 0; k < 3; k++) {
+        const long a = lo > start[k] ? lo : start[k], b = hi < start[k] + len[k] ? hi : start[k] + len[k];
+        first3[k] = (int32_t)(b > a ? a - start[k] : 0);
+        count3[k] = (int32_t)(b > a ? b - a : 0);
+    }
+    return DDN_OK;
+}

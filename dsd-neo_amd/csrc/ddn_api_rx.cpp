@@ -36,7 +36,7 @@ struct ddn_p25_rx {
     int handlers, nid_threshold;
     DdnP25HState* d_hstate;
     float* d_hh;
-    int32_t *d_events, *d_n_events;
+    int32_t *d_events, *d_n_events, *d_event_data;
     size_t max_events;
     int32_t *d_ev_dummy, *d_nev_dummy;
     bool timing;
@@ -225,12 +225,24 @@ ddn_p25_rx_set_events(ddn_p25_rx* b, int32_t* d_events, int32_t* d_n_events, siz
     b->d_events = d_events;
     b->d_n_events = d_n_events;
     b->max_events = d_events ? max_events : 0;
+    if (!d_events) {
+        b->d_event_data = nullptr;
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25_rx_set_event_data(ddn_p25_rx* b, int32_t* d_event_data) {
+    if (!b || (d_event_data && !b->d_events)) {
+        return DDN_EINVAL; // the payload rows follow the event list's indexing: set the list first
+    }
+    b->d_event_data = d_event_data;
     return DDN_OK;
 }
 
 extern "C" int
 ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave) {
-    if (!b || (channels_per_wave != 0 && channels_per_wave != 8 && channels_per_wave != 16 && channels_per_wave != 32
+    if (!b || (channels_per_wave != 0 && channels_per_wave != 4 && channels_per_wave != 8 && channels_per_wave != 16 && channels_per_wave != 32
                && channels_per_wave != 64)) {
         return DDN_EINVAL;
     }
@@ -295,7 +307,8 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
         HIP_TRY(hipEventRecord(rv[1], st));
     }
     DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0,
-                      b->handlers, b->nid_threshold, b->d_events ? (int)b->max_events : 1};
+                      b->handlers, b->nid_threshold, b->d_events ? (int)b->max_events : 1,
+                      b->d_events ? b->d_event_data : nullptr};
     if (const char* e = getenv("DDN_RX_DBG")) {
         dc.dbg = atoi(e);
     }
@@ -370,34 +383,38 @@ ddn_p25_rx_get_timing(ddn_p25_rx* b, float* ms2) {
 
 extern "C" int
 ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
-                       size_t max_symbols, int32_t* events, int32_t* n_events, size_t max_events) {
+                       size_t max_symbols, int32_t* events, int32_t* n_events, size_t max_events, int32_t* event_data) {
     if (!b || !disc || !records10 || !flags || !counts || ((events == nullptr) != (n_events == nullptr))
-        || (events && max_events == 0)) {
+        || (events && max_events == 0) || (event_data && !events)) {
         return DDN_EINVAL;
     }
     const size_t B = (size_t)b->cfg.n_channels;
     float* d_in = nullptr;
     uint8_t *d_rec = nullptr, *d_fl = nullptr;
-    int32_t *d_cnt = nullptr, *d_ev = nullptr, *d_nev = nullptr;
+    int32_t *d_cnt = nullptr, *d_ev = nullptr, *d_nev = nullptr, *d_evd = nullptr;
+    int32_t* const keep_evd = b->d_event_data;
     int32_t* const keep_ev = b->d_events;
     int32_t* const keep_nev = b->d_n_events;
     const size_t keep_max = b->max_events;
     int rc;
     if (hipMalloc(&d_in, B * n * 4 + 4) != hipSuccess || hipMalloc(&d_rec, B * max_symbols * 10 + 4) != hipSuccess
         || hipMalloc(&d_fl, B * max_symbols + 4) != hipSuccess || hipMalloc(&d_cnt, B * 4) != hipSuccess
-        || (events && (hipMalloc(&d_ev, B * max_events * 16) != hipSuccess || hipMalloc(&d_nev, B * 4) != hipSuccess))) {
+        || (events && (hipMalloc(&d_ev, B * max_events * 16) != hipSuccess || hipMalloc(&d_nev, B * 4) != hipSuccess))
+        || (event_data && hipMalloc(&d_evd, B * max_events * 16) != hipSuccess)) {
         ddn_set_error("ddn_p25_rx_run_host: device allocation failed (no device?)");
         rc = DDN_ENODEV;
     } else if (hipMemcpy(d_in, disc, B * n * 4, hipMemcpyHostToDevice) != hipSuccess
                || hipMemset(d_rec, 0, B * max_symbols * 10) != hipSuccess
                || hipMemset(d_fl, 0, B * max_symbols) != hipSuccess
-               || (events && (hipMemset(d_ev, 0, B * max_events * 16) != hipSuccess || hipMemset(d_nev, 0, B * 4) != hipSuccess))) {
+               || (events && (hipMemset(d_ev, 0, B * max_events * 16) != hipSuccess || hipMemset(d_nev, 0, B * 4) != hipSuccess))
+               || (event_data && hipMemset(d_evd, 0, B * max_events * 16) != hipSuccess)) {
         rc = DDN_EHIP;
     } else {
         if (events) {
             b->d_events = d_ev;
             b->d_n_events = d_nev;
             b->max_events = max_events;
+            b->d_event_data = d_evd;
         }
         rc = ddn_p25_rx_run(b, d_in, n, d_rec, d_fl, d_cnt, max_symbols, nullptr);
         if (rc == DDN_OK
@@ -407,7 +424,8 @@ ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* reco
                 || hipMemcpy(counts, d_cnt, B * 4, hipMemcpyDeviceToHost) != hipSuccess
                 || (events
                     && (hipMemcpy(events, d_ev, B * max_events * 16, hipMemcpyDeviceToHost) != hipSuccess
-                        || hipMemcpy(n_events, d_nev, B * 4, hipMemcpyDeviceToHost) != hipSuccess)))) {
+                        || hipMemcpy(n_events, d_nev, B * 4, hipMemcpyDeviceToHost) != hipSuccess))
+                || (event_data && hipMemcpy(event_data, d_evd, B * max_events * 16, hipMemcpyDeviceToHost) != hipSuccess))) {
             ddn_set_error("ddn_p25_rx_run_host: %s", hipGetErrorString(hipGetLastError()));
             rc = DDN_EHIP;
         }
@@ -415,7 +433,9 @@ ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* reco
     b->d_events = keep_ev;
     b->d_n_events = keep_nev;
     b->max_events = keep_max;
+    b->d_event_data = keep_evd;
     (void)hipDeviceSynchronize();
+    (void)hipFree(d_evd);
     (void)hipFree(d_in);
     (void)hipFree(d_rec);
     (void)hipFree(d_fl);
@@ -428,7 +448,7 @@ ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* reco
 extern "C" int
 ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
                     size_t max_symbols) {
-    return ddn_p25_rx_run_host_ev(b, disc, n, records10, flags, counts, max_symbols, nullptr, nullptr, 0);
+    return ddn_p25_rx_run_host_ev(b, disc, n, records10, flags, counts, max_symbols, nullptr, nullptr, 0, nullptr);
 }
 
 // timing experiments (DDN_RX_DBG bit 65536): handler requests of a channel and the cycles its lane spent waiting for the answers

@@ -43,6 +43,138 @@ k_chain_counts(const int32_t* __restrict__ cnt_new, int T, int n_channels, int f
     }
 }
 
+// The handler decisions of the records a row holds: the ones carried over from the previous call's list (position >= that call's
+// new-record count, i.e. inside the carried tail; shifted into this row's indexing) followed by this call's (staged by the receive
+// loop with positions relative to the new records).  {row index, kind, a, b} + the decoded payload, in position order.
+__global__ void
+k_chain_events(const int32_t* __restrict__ list_prev, const int32_t* __restrict__ data_prev, const int32_t* __restrict__ n_prev,
+               const int32_t* __restrict__ new_prev, int have_prev, const int32_t* __restrict__ ev_new,
+               const int32_t* __restrict__ evd_new, const int32_t* __restrict__ n_new, int E, int EL, int T, int n_channels,
+               int32_t* __restrict__ list_cur, int32_t* __restrict__ data_cur, int32_t* __restrict__ n_cur) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) {
+        return;
+    }
+    int4* lc = reinterpret_cast<int4*>(list_cur) + (size_t)c * EL;
+    int4* dc = reinterpret_cast<int4*>(data_cur) + (size_t)c * EL;
+    int k = 0;
+    if (have_prev) {
+        const int4* lp = reinterpret_cast<const int4*>(list_prev) + (size_t)c * EL;
+        const int4* dp = reinterpret_cast<const int4*>(data_prev) + (size_t)c * EL;
+        const int np = n_prev[c] < EL ? n_prev[c] : EL, shift = new_prev[c];
+        for (int j = 0; j < np; j++) {
+            int4 e = lp[j];
+            if (e.x >= shift && k < EL) {
+                e.x -= shift;
+                lc[k] = e;
+                dc[k] = dp[j];
+                k++;
+            }
+        }
+    }
+    const int4* en = reinterpret_cast<const int4*>(ev_new) + (size_t)c * E;
+    const int4* dn = reinterpret_cast<const int4*>(evd_new) + (size_t)c * E;
+    const int nn = n_new[c] < E ? n_new[c] : E;
+    for (int j = 0; j < nn && k < EL; j++) {
+        int4 e = en[j];
+        e.x += T;
+        lc[k] = e;
+        dc[k] = dn[j];
+        k++;
+    }
+    n_cur[c] = k;
+}
+
+// Per frame slot (the k-th sync the framer indexed in this row): the NID the loop's handler decoded for it (kind 1, 33 symbols
+// after the sync's last one) and its TSDU blocks (kind 2, at the block's last dibit) - p25p1_nid_decode / tsbk_decode_repetition_bytes
+// ran once, inside the loop, exactly as the reference's handlers run them; this only files their results by frame.
+__global__ void
+k_chain_frames(const int32_t* __restrict__ list, const int32_t* __restrict__ data, const int32_t* __restrict__ n_list, int EL,
+               const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_syncs, int n_channels, int F, int off0, int off1,
+               int off2, int32_t* __restrict__ nid4, uint8_t* __restrict__ tsbk, uint8_t* __restrict__ tsbk_crc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) {
+        return;
+    }
+    const size_t S = (size_t)n_channels * F;
+    const int ns = n_syncs[c] < F ? n_syncs[c] : F;
+    const int32_t* sp = sync_pos + (size_t)c * F;
+    for (int k = 0; k < F; k++) {
+        const size_t slot = (size_t)c * F + k;
+        reinterpret_cast<int4*>(nid4)[slot] = make_int4(0, 0, 0, 0);
+        for (int b = 0; b < 3; b++) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(tsbk + ((size_t)b * S + slot) * 12);
+            o[0] = o[1] = o[2] = 0;
+            tsbk_crc[(size_t)b * S + slot] = 0;
+        }
+    }
+    const int4* l = reinterpret_cast<const int4*>(list) + (size_t)c * EL;
+    const int4* d = reinterpret_cast<const int4*>(data) + (size_t)c * EL;
+    const int n = n_list[c] < EL ? n_list[c] : EL;
+    int k = 0;
+    for (int j = 0; j < n; j++) {
+        const int4 e = l[j];
+        if (e.y != 1 && e.y != 2) {
+            continue;
+        }
+        const int4 v = d[j];
+        const int blk = (v.w >> 16) & 0xFF;
+        const int a = e.y == 1 ? e.x - 33 : e.x - (blk == 0 ? off0 : (blk == 1 ? off1 : off2));
+        while (k < ns && sp[k] < a) {
+            k++;
+        }
+        if (k >= ns || sp[k] != a) {
+            continue; // the frame's sync is not among this call's (it lies in the tail that is carried on)
+        }
+        const size_t slot = (size_t)c * F + k;
+        if (e.y == 1) {
+            reinterpret_cast<int4*>(nid4)[slot] = v;
+        } else if (blk < 3) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(tsbk + ((size_t)blk * S + slot) * 12);
+            o[0] = (uint32_t)v.x;
+            o[1] = (uint32_t)v.y;
+            o[2] = (uint32_t)v.z;
+            tsbk_crc[(size_t)blk * S + slot] = (uint8_t)(v.w & 1);
+        }
+    }
+}
+
+// NXDN voice stage bookkeeping (nxdn_voice(): the LICH's profile says which of a frame's four 36-dibit fields are voice): the
+// first vf sync slots of every channel feed the voice gather; field v of slot (c, j) is skipped unless the LICH parity held, the
+// frame is complete and the LICH value announces voice in that half.
+__global__ void
+k_nxdn_voice_select(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_sync, const uint8_t* __restrict__ lich,
+                    const uint8_t* __restrict__ valid, int n_channels, int my, int vf, int32_t* __restrict__ v_pos,
+                    int32_t* __restrict__ v_n, uint8_t* __restrict__ skip4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_channels * vf) {
+        return;
+    }
+    const int c = i / vf, j = i - c * vf;
+    v_pos[i] = sync_pos[(size_t)c * my + j];
+    if (j == 0) {
+        v_n[c] = n_sync[c] < vf ? n_sync[c] : vf;
+    }
+    const int l = lich[(size_t)c * my + j];
+    const int l7 = l & 0x7F;
+    const bool good = (l & 0x80) != 0 && valid[(size_t)c * my + j] != 0;
+    const bool both = l7 == 0x36 || l7 == 0x37 || l7 == 0x56 || l7 == 0x57 || l7 == 0x46 || l7 == 0x76 || l7 == 0x77;
+    const bool first = l7 == 0x34 || l7 == 0x35 || l7 == 0x54 || l7 == 0x55 || l7 == 0x75;
+    const bool last = l7 == 0x32 || l7 == 0x33 || l7 == 0x52 || l7 == 0x53 || l7 == 0x72 || l7 == 0x73;
+    for (int v = 0; v < 4; v++) {
+        const bool voiced = good && (both || (first && v < 2) || (last && v >= 2));
+        skip4[(size_t)i * 4 + v] = voiced ? 0 : 1;
+    }
+}
+
+__global__ void
+k_u8_shr1(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[i] = in[i] >> 1;
+    }
+}
+
 __device__ __forceinline__ bool
 crc16_clean(const uint8_t* b) { // p25_crc.c:18-36 over 10 bytes against the next two
     unsigned crc = 0;
@@ -104,6 +236,51 @@ ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, int flush, i
     }
     hipLaunchKernelGGL(k_chain_counts, dim3((unsigned)((n_channels + 255) / 256)), dim3(256), 0, st, cnt_new, T, n_channels, flush,
                        cnt_scan, cnt_full);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_prev, const int32_t* n_prev, const int32_t* new_prev, int have_prev,
+                     const int32_t* ev_new, const int32_t* evd_new, const int32_t* n_new, int E, int EL, int T, int n_channels,
+                     int32_t* list_cur, int32_t* data_cur, int32_t* n_cur, hipStream_t st) {
+    if (n_channels <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_events, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, list_prev, data_prev, n_prev, new_prev,
+                       have_prev, ev_new, evd_new, n_new, E, EL, T, n_channels, list_cur, data_cur, n_cur);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
+                     const int32_t* n_syncs, int n_channels, int F, int off0, int off1, int off2, int32_t* nid4, uint8_t* tsbk,
+                     uint8_t* tsbk_crc, hipStream_t st) {
+    if (n_channels <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_frames, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, list, data, n_list, EL, sync_pos,
+                       n_syncs, n_channels, F, off0, off1, off2, nid4, tsbk, tsbk_crc);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_nxdn_voice_select(const int32_t* sync_pos, const int32_t* n_sync, const uint8_t* lich, const uint8_t* valid, int n_channels,
+                          int my, int vf, int32_t* v_pos, int32_t* v_n, uint8_t* skip4, hipStream_t st) {
+    if (n_channels <= 0 || vf <= 0) {
+        return hipSuccess;
+    }
+    const int n = n_channels * vf;
+    hipLaunchKernelGGL(k_nxdn_voice_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sync_pos, n_sync, lich, valid, n_channels,
+                       my, vf, v_pos, v_n, skip4);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_u8_shr1(const uint8_t* in, size_t n, uint8_t* out, hipStream_t st) {
+    if (n == 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_u8_shr1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, out);
     return hipGetLastError();
 }
 

@@ -69,6 +69,8 @@ typedef struct DdnRxConfig { /* fixed-protocol P25p1 receive loop (ddn_rx.hip) *
     int handlers;      /* 1 = the reference's per-DUID handlers decide the in-frame length (lock_symbols ignored) */
     int nid_threshold; /* p25p1_get_erasure_threshold() */
     int max_events;    /* capacity of the per-channel event list */
+    int32_t* event_data; /* [B][max_events][4] what each decision decoded (NULL = not wanted): NID {status, nac, duid, errors}, TSBK /
+                            PDU header block {12 bytes as three words, crc good | candidate << 8 | block << 16} */
 } DdnRxConfig;
 
 typedef struct DdnP25HState { /* per-channel words of the P25p1 handlers (ddn_p25h_dev.h) carried across calls */
@@ -263,6 +265,15 @@ hipError_t ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, 
                                uint8_t* rec_cur, uint8_t* fl_cur, size_t stride_sym, int T, int n_channels, hipStream_t st);
 hipError_t ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, int flush, int32_t* cnt_scan, int32_t* cnt_full,
                                 hipStream_t st);
+hipError_t ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_prev, const int32_t* n_prev, const int32_t* new_prev,
+                                int have_prev, const int32_t* ev_new, const int32_t* evd_new, const int32_t* n_new, int E, int EL, int T,
+                                int n_channels, int32_t* list_cur, int32_t* data_cur, int32_t* n_cur, hipStream_t st);
+hipError_t ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
+                                const int32_t* n_syncs, int n_channels, int F, int off0, int off1, int off2, int32_t* nid4,
+                                uint8_t* tsbk, uint8_t* tsbk_crc, hipStream_t st);
+hipError_t ddn_dev_nxdn_voice_select(const int32_t* sync_pos, const int32_t* n_sync, const uint8_t* lich, const uint8_t* valid,
+                                     int n_channels, int my, int vf, int32_t* v_pos, int32_t* v_n, uint8_t* skip4, hipStream_t st);
+hipError_t ddn_dev_u8_shr1(const uint8_t* in, size_t n, uint8_t* out, hipStream_t st);
 hipError_t ddn_dev_tsbk_select(const uint8_t* cand, const int32_t* counts, size_t n, uint8_t* out12, uint8_t* crc_ok, uint8_t* sel,
                                hipStream_t st);
 #ifdef __cplusplus

@@ -594,7 +594,9 @@ k_mbe_params(const uint8_t* __restrict__ bits, const int32_t* __restrict__ res_i
         } else {
             cur.repeat = 0;
         }
-        if (bad == 0 && cur.repeat <= 3) {
+        // mbelib 1.3: mbe_processImbe4400Dataf synthesizes whenever repeat <= 3 (a frame with an invalid fundamental repeats the
+        // last good one up to three times, the fourth mutes); only mbe_processAmbe2450Dataf also asks for bad == 0
+        if ((CODEC == DDN_MBE_IMBE_7200X4400 || bad == 0) && cur.repeat <= 3) {
             prev = cur; // mbe_moveMbeParms (cur, prev)
             // ---- mbe_spectralAmpEnhance ----
             const int cL = cur.L;

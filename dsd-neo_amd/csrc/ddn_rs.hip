@@ -1221,7 +1221,9 @@ k_isch_lookup(const uint64_t* __restrict__ words, const uint8_t* __restrict__ re
             while (diff) {
                 const int b = 63 - __clzll((long long)diff);
                 diff &= ~(1ULL << b);
-                cost += rel[39 - b];
+                if (b < 40) { // isch_weighted_mismatch_cost() walks the 40 field bits only; stray high bits count in d alone
+                    cost += rel[39 - b];
+                }
             }
             const int val = k < 0 ? -2 : k;
             if (cost < sc || (cost == sc && d < sp) || (cost == sc && d == sp && val < sb)) {

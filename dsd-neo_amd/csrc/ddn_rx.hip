@@ -673,7 +673,8 @@ struct LdsW {
     // suffix summaries per checkpoint: pushes per two tiles, 2 * (ceil((TW + sps) / (sps - 1)) + 1).  SMALL (handler mode, which
     // needs the LDS for its history ring): sized for at least 9 samples per symbol
     static constexpr int WMW = CPW <= 8 ? (SMALL ? 40 : 64) : (SMALL ? 24 : 32);
-    static constexpr int QTW = CPW <= 8 ? 40 : 20; // queue slots = trips of a tile that can hand a symbol to wave 1
+    static constexpr int QTW = CPW <= 4 ? 24 : (CPW <= 8 ? 40 : 20); // queue slots = trips of a tile that can hand a symbol to wave 1
+                                                                      // (later trips of the tile store their records themselves)
     float sb[SS][CPW];
     float lb[24][CPW];
     float sh[24][CPW];
@@ -701,6 +702,7 @@ struct LdsH {
     ddn_p25h::Scratch sc;
 };
 
+static_assert(((sizeof(LdsW<4, true>) + 15) & ~(size_t)15) + sizeof(LdsH<4>) <= 40960, "four workgroups of the 4-lane handler shape per CU");
 template <int CPW, bool HM>
 __global__ __launch_bounds__(HM ? 256 : 192) void
 k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
@@ -782,6 +784,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
         int ext = 0, more = 0;
         int ev_kind = 0, ev_a = 0, ev_b = 0;
+        int32_t pay0 = 0, pay1 = 0, pay2 = 0, pay3 = 0; // what the decision decoded (cfg.event_data)
         auto slice_at = [&](int i, int& d, int& relb, int& l0, int& l1) {
             int slot = hw - nsym + i; // hw = the ring slot after the phase's last symbol
             slot += slot < 0 ? HN : 0;
@@ -862,6 +865,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             ev_kind = EV_NID;
             ev_a = r.status;
             ev_b = (r.nac & 0xFFFF) | (duid << 16);
+            pay0 = r.status, pay1 = r.nac, pay2 = r.duid, pay3 = r.errs;
             phase = PH_IDLE;
             if (duid == 0x7 || duid == 0xC) {
                 phase = (duid == 0x7) ? PH_TSBK : PH_MPDU;
@@ -916,6 +920,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 by[2] = sc.outl[sel][2];
             }
             const int byte0 = by[0] & 0xFF;
+            pay0 = (int32_t)by[0], pay1 = (int32_t)by[1], pay2 = (int32_t)by[2];
+            pay3 = (crc_ok & 1) | ((sel & 0xFF) << 8) | ((phase == PH_TSBK ? block : 0) << 16);
             sk0 = sk_after;
             if (phase == PH_TSBK) {
                 const int last = (byte0 >> 7) & 1;
@@ -975,6 +981,9 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     e[1] = ev_kind;
                     e[2] = ev_a;
                     e[3] = ev_b;
+                    if (cfg.event_data) {
+                        *reinterpret_cast<int4*>(cfg.event_data + ((size_t)gch * cfg.max_events + nev) * 4) = make_int4(pay0, pay1, pay2, pay3);
+                    }
                     if (cfg.dbg & 65536) {
                         e[2] = dbg_path;
                         e[3] = (int)((long long)clock64() - dbg_t0);
@@ -1507,7 +1516,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         o++;
     };
 
-    long long dbg_busy = 0, dbg_wait = 0, dbg_cyc[3] = {0, 0, 0}, dbg_prev = 0;
+    long long dbg_busy = 0, dbg_wait = 0, dbg_cyc[3] = {0, 0, 0}, dbg_prev = 0, dbg_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_st = 0;
+#define DBG_SEC(k) do { if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { const long long n_ = (long long)clock64(); dbg_sec[k] += n_ - dbg_st; dbg_st = n_; } } while (0)
     int dbg_n[3] = {0, 0, 0}, dbg_kind = -1;
     for (t0 = 0; t0 < n; t0 += TW, it++) {
         const long long dbg_t0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
@@ -1735,6 +1745,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     const bool all_ok = !__any(alive & !(can | wt));
                     if (all_ok && __any(can)) {
                         dbg_kind = 0;
+                        if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                            dbg_sec[0] += (long long)clock64() - dbg_prev; // trip top .. here (pause, queue hand-over, lean / std tests)
+                            dbg_st = (long long)clock64();
+                        }
                         const float* p = (s.filter_on ? frow : rrow) + base + sp;
                         int jit = s.jitter;
                         if (__any(can & (jit < 0))) {
@@ -1785,6 +1799,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             }
                             jit = (can & (jit < 0) & (found >= 0)) ? i0 + found : jit;
                         }
+                        DBG_SEC(1);
                         if (can) {
                             // the five window samples (indices centre - 2 .. centre + 2 of the symbol) and its last sample.  In frame
                             // min < max and the samples are finite, so the reference's two-sided clip is the median of three (a
@@ -1804,14 +1819,19 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             sp += cnt;
                             s.in_symbol = 0;
                             commit_pre(sym);
+                            DBG_SEC(2);
                             int fl = 0;
                             float q_max = 0.0f, q_min = 0.0f;
                             if (in_a) {
                                 commit_inframe(sym, 0, fl, q_max, q_min);
-                            } else {
+                            }
+                            DBG_SEC(3);
+                            if (!in_a) {
                                 commit_hunt(sym, 0, fl);
                             }
+                            DBG_SEC(4);
                             emit(sym, fl, q_max, q_min);
+                            DBG_SEC(5);
                         }
                         continue;
                     }
@@ -2095,6 +2115,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         for (int k = 0; k < 64; k++) {
             d[k] = reinterpret_cast<const uint8_t*>(v)[k];
         }
+        if ((threadIdx.x >> 6) == 0) { // the recurrence wave's standard-trip sections, one block further down
+            uint8_t* d2 = rec + ((size_t)ch0 + 1) * max_sym * 10 - 256;
+            for (int k = 0; k < 64; k++) {
+                d2[k] = reinterpret_cast<const uint8_t*>(dbg_sec)[k];
+            }
+        }
     }
     if (loader && offload && it > 0) {
         drain((it - 1) & 1);
@@ -2194,8 +2220,13 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
         if (whole < 6 || !hstate || !hh_store || !events || !n_events) {
             return hipErrorInvalidValue;
         }
-        if (cpw != 8 && cpw != 16) {
+        if (cpw != 4 && cpw != 8 && cpw != 16) {
             cpw = n_channels <= 8 * 512 ? 8 : 16;
+        }
+        if (cpw == 4) {
+            return launch_rxw<4, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                       shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store,
+                                       events, n_events, st);
         }
         if (cpw == 8) {
             return launch_rxw<8, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,

@@ -6,8 +6,8 @@
  *                   -> receive loop with the reference's handlers inside it   getSymbol / getFrameSync / getDibitSoft, per-DUID
  *                      (ddn_p25_rx_run, ddn_p25_rx_set_handlers)              in-frame lengths, TSDU last-block flag
  *                   -> framer (ddn_p25p1_framer_*)                            field gathers at fixed offsets from each sync
- *                   -> NID BCH(63,16,11) + Chase                              p25p1_nid_decode
- *                   -> TSDU blocks 0..2: list-8 half-rate decode, first CRC16-clean candidate   tsbk_decode_repetition_bytes
+ *                      (the handlers' own decodes - NID BCH(63,16,11) + Chase, p25p1_nid_decode; TSDU blocks: list-8 half-rate decode,
+ *                      first CRC16-clean candidate, tsbk_decode_repetition_bytes - are kept and filed by frame, not repeated)
  *                   -> LDU1 / LDU2: 24 x Hamming(10,6,3) + RS(24,12,13) / RS(24,16,9), low speed data (16,8)
  *                   -> HDU: 36 x Golay(24,6) + RS(36,20,17); TDULC: 12 x Golay(24,12) + RS(24,12,13)
  *                   -> nine IMBE frames per LDU: de-interleave, frame FEC, parameters, synthesis -> f32 PCM
@@ -47,10 +47,13 @@ typedef struct ddn_p25_chain_results {
     const int32_t* d_new;       /* [B] new records of this call (they start at index carry_symbols) */
     const int32_t* d_events;    /* [B][max_events][4] handler decisions of this call (ddn_p25_rx_set_events; index + carry_symbols) */
     const int32_t* d_n_events;  /* [B] */
+    const int32_t* d_event_data; /* [B][max_events][4] what each decision decoded (ddn_p25_rx_set_event_data) */
     const int32_t* d_n_syncs;   /* [B] frame slots used */
     const int32_t* d_sync_pos;  /* [S] index of the sync's last symbol in the row */
+    /* the NID and the TSDU blocks are decoded once, by the handlers inside the receive loop (with the reference's running NAC as the
+     * decoder's observed NAC), and filed by frame here; a block the handler did not read (behind the last-block flag) is zero */
     const int32_t* d_nid4;      /* [S][4] status, NAC, DUID, corrected bits */
-    const uint8_t* d_tsbk;      /* [3][S][12] decoded TSDU blocks 0..2 (a slot's blocks after its last-block flag are not part of the TSDU) */
+    const uint8_t* d_tsbk;      /* [3][S][12] decoded TSDU blocks 0..2 */
     const uint8_t* d_tsbk_crc;  /* [3][S] CRC16 good */
     const uint8_t* d_ldu_words[2];  /* [S][24][10] Hamming-corrected words of LDU1 / LDU2 */
     const uint8_t* d_ldu_rs_data[2]; /* [S][12][6] / [S][16][6] after Reed-Solomon */
@@ -65,6 +68,7 @@ typedef struct ddn_p25_chain_results {
     const uint8_t* d_imbe_bits; /* [B][max_ldu * 9][88] voice parameter bits */
     const int32_t* d_imbe_result; /* [B][max_ldu * 9][5] */
     const float* d_pcm;         /* [B][max_ldu * 9][160] (vocoder = 1) */
+    const int32_t* d_synth_result; /* [B][max_ldu * 9][5] result words after synthesis (repeat / mute flags added) */
 } ddn_p25_chain_results;
 
 typedef struct ddn_p25_chain ddn_p25_chain;
@@ -85,6 +89,7 @@ typedef struct ddn_p25_chain_host_out {
     int32_t* counts;    /* [B] */
     int32_t* events;    /* [B][max_events][4] */
     int32_t* n_events;  /* [B] */
+    int32_t* event_data; /* [B][max_events][4] */
     int32_t* nid4;      /* [S][4] */
     uint8_t* tsbk;      /* [3][S][12] */
     float* pcm;         /* [B][max_ldu * 9][160] */
@@ -104,6 +109,80 @@ int ddn_p25_chain_max_events(const ddn_p25_chain* c);
 void* ddn_p25_chain_front_end(ddn_p25_chain* c);
 void* ddn_p25_chain_rx(ddn_p25_chain* c);
 void* ddn_p25_chain_mbe(ddn_p25_chain* c);
+/* HIP events at the stage boundaries of every call while enabled; _get_stage_ms waits for the most recent call and returns the
+ * milliseconds of {front end, receive loop, framer + frame FEC, voice} (meaningful for ddn_p25_chain_run on one stream) */
+int ddn_p25_chain_set_timing(ddn_p25_chain* c, int enable);
+int ddn_p25_chain_get_stage_ms(ddn_p25_chain* c, float out4[4]);
+/* ---- DMR / NXDN48: the same shape for BASELINE configs[3]'s other two protocols ------------------------------------------------
+ *   cu8 / cf32 I/Q -> front end (12.5 kHz / 6.25 kHz channel filter) -> matched filter + receive loop (ddn_fsk4_rx_run; handlers = 1:
+ *   dmr_data_sync / dmrBSBootstrap + dmrBS / nxdn_frame's LICH gate decide the in-frame lengths inside the loop)
+ *   DMR:    burst gather -> slot type Golay(20,8) -> BPTC(196,96)
+ *   NXDN48: frame gather -> SACCH / FACCH1 K=5 decode + CRC6 / CRC12 + the greedy SACCH retry -> the voice frames the LICHs announce:
+ *           AMBE de-interleave -> AMBE 3600x2450 frame FEC -> synthesis (vocoder = 1)
+ * One call per batch of samples_per_call samples; carried state streams from call to call (frames cut by a call boundary are
+ * reported as far as their fields are complete: d_valid). */
+typedef struct ddn_fsk4_chain_config {
+    int n_channels;
+    int samples_per_call;
+    int block_len;
+    int input_format; /* DDN_IN_CU8 / DDN_IN_CF32 */
+    int protocol;     /* DDN_FSK4_DMR / DDN_FSK4_NXDN48 (include/ddn_fsk4.h) */
+    int rf_mod;       /* 0 = C4FM rules, 2 = GFSK rules (what dsd-neo runs DMR with) */
+    int inverted;     /* DMR: opts->inverted_dmr (handlers need 0) */
+    int handlers;     /* 1 = the reference's handlers decide the in-frame lengths (ddn_fsk4_rx_set_handlers) */
+    int vocoder;      /* NXDN48: 1 = AMBE synthesis to PCM */
+} ddn_fsk4_chain_config;
+typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max_syncs sync slots */
+    size_t max_symbols, max_syncs;
+    int voice_slots;                /* NXDN48: sync slots per channel the voice stage works on */
+    const uint8_t* d_records10;     /* [B][max_symbols][10] */
+    const uint8_t* d_flags;         /* [B][max_symbols] */
+    const uint8_t* d_payload2;      /* [B][max_symbols][2] */
+    const int32_t* d_counts;        /* [B] */
+    const int32_t* d_n_sync;        /* [B] */
+    const int32_t* d_sync_pos;      /* [S] */
+    const uint8_t* d_sync_pat;      /* [S] */
+    const uint8_t* d_pre;           /* [S][90] the payload history handed over at each sync */
+    const uint8_t* d_valid;         /* [S] frame / burst complete inside the call */
+    const uint8_t* d_dmr_slot_type; /* [S][20] after Golay(20,8) */
+    const uint8_t* d_dmr_slot_type_ok; /* [S] */
+    const uint8_t* d_dmr_pdu96;     /* [S][96] BPTC(196,96) payload bits */
+    const uint32_t* d_dmr_bptc_errs; /* [S] */
+    const uint8_t* d_nxdn_lich;     /* [S] 7-bit LICH, bit 7 = parity good */
+    const uint8_t* d_nxdn_sacch;    /* [S][4] */
+    const uint8_t* d_nxdn_sacch_ok; /* [S] CRC6 */
+    const uint8_t* d_nxdn_sacch_hard; /* [S][32] the greedy retry's bits */
+    const uint8_t* d_nxdn_sacch_hard_ok; /* [S] */
+    const uint8_t* d_nxdn_facch;    /* [S][2][12] */
+    const uint8_t* d_nxdn_facch_ok; /* [S][2] CRC12 */
+    const uint8_t* d_nxdn_voice_skip; /* [B][voice_slots][4] 1 = not a voice frame */
+    const uint8_t* d_nxdn_ambe_bits; /* [B][voice_slots * 4][49] */
+    const float* d_nxdn_pcm;        /* [B][voice_slots * 4][160] */
+} ddn_fsk4_chain_results;
+typedef struct ddn_fsk4_chain ddn_fsk4_chain;
+int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);
+void ddn_fsk4_chain_destroy(ddn_fsk4_chain* c);
+int ddn_fsk4_chain_run(ddn_fsk4_chain* c, const void* d_iq, void* hip_stream);
+int ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* out);
+void* ddn_fsk4_chain_front_end(ddn_fsk4_chain* c); /* ddn_batch* */
+void* ddn_fsk4_chain_rx(ddn_fsk4_chain* c);        /* ddn_fsk4_rx* */
+
+/* ---- a mixed batch (BASELINE configs[3]): P25 Phase 1 + DMR + NXDN48 channel groups of one GPU, every receive loop with the
+ * reference's handlers inside it; one stream per group inside the object.  _run queues one call of all three, _wait blocks. */
+typedef struct ddn_mixed_chain_config {
+    int n_p25, n_dmr, n_nxdn48; /* channels of each group on this GPU (a group may be empty) */
+    int samples_per_call, block_len, input_format, vocoder;
+} ddn_mixed_chain_config;
+typedef struct ddn_mixed_chain ddn_mixed_chain;
+int ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out);
+void ddn_mixed_chain_destroy(ddn_mixed_chain* m);
+int ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_dmr, const void* d_iq_nxdn48);
+int ddn_mixed_chain_wait(ddn_mixed_chain* m);
+void* ddn_mixed_chain_part(ddn_mixed_chain* m, int which); /* 0: ddn_p25_chain*, 1: DMR ddn_fsk4_chain*, 2: NXDN48 ddn_fsk4_chain* */
+/* how a mixed batch of [P25 | DMR | NXDN48] channels is split over the GPUs of a node: rank r of `world` owns a contiguous block of
+ * the global channel index, i.e. first3[k] / count3[k] of group k (no data-path collective: channels are independent streams) */
+int ddn_mixed_partition(int n_p25, int n_dmr, int n_nxdn48, int rank, int world, int32_t first3[3], int32_t count3[3]);
+
 /* device / pinned-host memory for callers without a HIP binding of their own (synchronous copies) */
 int ddn_device_alloc(size_t bytes, void** out);
 void ddn_device_free(void* p);

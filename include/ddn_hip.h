@@ -188,6 +188,11 @@ int ddn_p25_rx_set_lock_symbols(ddn_p25_rx* b, const int32_t* per_channel);
  * Without buffers the decisions are still taken, just not reported. */
 int ddn_p25_rx_set_handlers(ddn_p25_rx* b, int enable, int nid_erasure_threshold);
 int ddn_p25_rx_set_events(ddn_p25_rx* b, int32_t* d_events, int32_t* d_n_events, size_t max_events);
+/* what each decision decoded, row for row beside d_events: d_event_data i32 [B][max_events][4] (NULL = not wanted; set the event
+ * list first) - kind 1: p25p1_nid_decode's {status, NAC, DUID, corrected bits}; kind 2 / 3: the block's 12 bytes as three
+ * little-endian words + {CRC16 good | selected list candidate << 8 | block index << 16}.  With these the frames' NIDs and TSDU blocks
+ * need no second decode after the loop (the chain object, include/ddn_chain.h, takes them from here). */
+int ddn_p25_rx_set_event_data(ddn_p25_rx* b, int32_t* d_event_data);
 /* kernel times of the last ddn_p25_rx_run(), HIP events on the launch stream: ms2 = {matched filter, receive-loop kernel} */
 int ddn_p25_rx_set_timing(ddn_p25_rx* b, int enable);
 int ddn_p25_rx_get_timing(ddn_p25_rx* b, float* ms2);
@@ -201,9 +206,10 @@ int ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_reco
                    int32_t* d_counts, size_t max_symbols, void* hip_stream);
 int ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags,
                         int32_t* counts, size_t max_symbols);
-/* the same with the handlers' event list brought back to host arrays (events [B][max_events][4], n_events [B]; both NULL = none) */
+/* the same with the handlers' event list brought back to host arrays (events [B][max_events][4], n_events [B]; both NULL = none;
+ * event_data [B][max_events][4] or NULL: the decoded payload of each event, ddn_p25_rx_set_event_data) */
 int ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
-                           size_t max_symbols, int32_t* events, int32_t* n_events, size_t max_events);
+                           size_t max_symbols, int32_t* events, int32_t* n_events, size_t max_events, int32_t* event_data);
 int ddn_p25_rx_get_thresholds(ddn_p25_rx* b, int channel, float out7[7]);
 /* timing experiments (environment DDN_RX_DBG bit 65536): handler requests of a channel so far, cycles its lane waited for them */
 int ddn_p25_rx_debug_counters(ddn_p25_rx* b, int channel, long long out2[2]);

@@ -200,6 +200,9 @@ enum {
 typedef struct orc_hevent {
     int32_t pos;
     int16_t kind, a, b, c;
+    /* what the decision decoded: P25 NID = p25p1_nid_decode's {status, nac, duid, error count}; P25 TSBK / PDU header block = its 12
+     * bytes (little-endian words) + {CRC16 good | candidate index << 8 | block << 16}; zero for the other kinds */
+    int32_t data[4];
 } orc_hevent;
 typedef struct orc_hevents {
     int n; /* events pushed (may exceed ORC_HEV_MAX; only the first ORC_HEV_MAX are kept) */

@@ -30,7 +30,7 @@
 #include "ddn_oracle.h"
 
 static void
-ev_push(orc_hevents* e, long pos, int kind, int a, int b, int c) {
+ev_push_data(orc_hevents* e, long pos, int kind, int a, int b, int c, const int32_t* data4) {
     if (!e) {
         return;
     }
@@ -41,8 +41,25 @@ ev_push(orc_hevents* e, long pos, int kind, int a, int b, int c) {
         v->a = (int16_t)a;
         v->b = (int16_t)b;
         v->c = (int16_t)c;
+        for (int k = 0; k < 4; k++) {
+            v->data[k] = data4 ? data4[k] : 0;
+        }
     }
     e->n++;
+}
+
+static void
+ev_push(orc_hevents* e, long pos, int kind, int a, int b, int c) {
+    ev_push_data(e, pos, kind, a, b, c, 0);
+}
+
+static void
+block_words(const uint8_t by[12], int crc_ok, int sel, int block, int32_t out4[4]) {
+    for (int w = 0; w < 3; w++) {
+        out4[w] = (int32_t)((uint32_t)by[4 * w] | ((uint32_t)by[4 * w + 1] << 8) | ((uint32_t)by[4 * w + 2] << 16)
+                            | ((uint32_t)by[4 * w + 3] << 24));
+    }
+    out4[3] = (crc_ok & 1) | ((sel & 0xFF) << 8) | (block << 16);
 }
 
 /* ------------------------------------------------------------------------------------------------ P25 Phase 1 ---- */
@@ -172,7 +189,10 @@ orc_p25h_symbol(orc_p25h* h, long pos, int d, int l0, int l1, orc_hevents* ev) {
                 duid = out4[2];
             }
             h->duid = duid;
-            ev_push(ev, pos, ORC_HEV_P25_NID, out4[0], out4[1], duid);
+            {
+                const int32_t d4[4] = {out4[0], out4[1], out4[2], out4[3]};
+                ev_push_data(ev, pos, ORC_HEV_P25_NID, out4[0], out4[1], duid, d4);
+            }
             if (duid == 0x7 || duid == 0xC) {
                 h->phase = (duid == 0x7) ? P25H_TSBK : P25H_MPDU;
                 h->block = 0;
@@ -205,7 +225,11 @@ orc_p25h_symbol(orc_p25h* h, long pos, int d, int l0, int l1, orc_hevents* ev) {
             int crc_ok;
             const int sel = half_rate_select(h, by, &crc_ok);
             const int last = (by[0] >> 7) & 1;
-            ev_push(ev, pos, ORC_HEV_P25_TSBK, h->block, crc_ok | (by[1] << 8), (last << 8) | (sel & 0xFF));
+            {
+                int32_t d4[4];
+                block_words(by, crc_ok, sel, h->block, d4);
+                ev_push_data(ev, pos, ORC_HEV_P25_TSBK, h->block, crc_ok | (by[1] << 8), (last << 8) | (sel & 0xFF), d4);
+            }
             h->block++;
             h->idx = 0;
             h->k = 0;
@@ -224,7 +248,7 @@ orc_p25h_symbol(orc_p25h* h, long pos, int d, int l0, int l1, orc_hevents* ev) {
             if (h->block == 0) {
                 uint8_t by[12];
                 int crc_ok;
-                (void)half_rate_select(h, by, &crc_ok);
+                const int sel = half_rate_select(h, by, &crc_ok);
                 /* p25_mpdu_update_header_from_first_block(): opts->aggressive_framesync = 1 (dsd_init.c:246) keeps the
                  * defaults when the header CRC fails */
                 if (crc_ok) {
@@ -234,7 +258,11 @@ orc_p25h_symbol(orc_p25h* h, long pos, int d, int l0, int l1, orc_hevents* ev) {
                         h->end = 4;
                     }
                 }
-                ev_push(ev, pos, ORC_HEV_P25_MPDU, crc_ok, h->end, by[0]);
+                {
+                    int32_t d4[4];
+                    block_words(by, crc_ok, sel, 0, d4);
+                    ev_push_data(ev, pos, ORC_HEV_P25_MPDU, crc_ok, h->end, by[0], d4);
+                }
             }
             h->block++;
             h->idx = 0;

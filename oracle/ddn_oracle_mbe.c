@@ -663,7 +663,9 @@ om_process(int codec, const ddn_mbe_tables* T, const uint8_t* bits, const int32_
             cur->repeat = 0;
         }
     }
-    if (bad == 0 && cur->repeat <= 3) {
+    /* mbelib 1.3 imbe7200x4400.c mbe_processImbe4400Dataf: `if (cur_mp->repeat <= 3)` alone; ambe3600x2450.c
+     * mbe_processAmbe2450Dataf: `if ((bad == 0) && (cur_mp->repeat <= 3))` */
+    if ((codec == DDN_MBE_IMBE_7200X4400 || bad == 0) && cur->repeat <= 3) {
         const int un = cur->un;
         *prev = *cur; /* mbe_moveMbeParms (cur, prev) */
         enhance(cur);

@@ -332,7 +332,7 @@ def synth_p25_disc(seed, n_ch, n, frame_dibits=864, sps=10, amp=7000.0, noise=40
 
 
 class HEvent(C.Structure):
-    _fields_ = [("pos", C.c_int32), ("kind", C.c_int16), ("a", C.c_int16), ("b", C.c_int16), ("c", C.c_int16)]
+    _fields_ = [("pos", C.c_int32), ("kind", C.c_int16), ("a", C.c_int16), ("b", C.c_int16), ("c", C.c_int16), ("data", C.c_int32 * 4)]
 
 
 class HEvents(C.Structure):
@@ -341,6 +341,11 @@ class HEvents(C.Structure):
 
     def rows(self):
         return [(e.pos, e.kind, e.a, e.b, e.c) for e in self.ev[:min(self.n, 4096)]]
+
+    def data(self):
+        """the decoded payload of every event, int32 [n][4] (orc_hevent.data)"""
+        import numpy as np
+        return np.array([list(e.data) for e in self.ev[:min(self.n, 4096)]], np.int32).reshape(-1, 4)
 
 
 HEV_P25_NID, HEV_P25_TSBK, HEV_P25_MPDU, HEV_NXDN_LICH, HEV_DMR_DATA, HEV_DMR_CC_PRINT, HEV_DMR_VOICE_BURST, HEV_DMR_VOICE_END = range(1, 9)

@@ -131,6 +131,68 @@ def frame_with_duid(rng, nac, duid, n_body):
     return fr
 
 
+def _walk(idx, n):
+    """the next n frame positions from idx on that are not status symbols -> (positions, next idx)"""
+    out = []
+    while len(out) < n:
+        if idx % 36 != 35:
+            out.append(idx)
+        idx += 1
+    return out, idx
+
+
+def make_hdu(rng, nac):
+    """One header data unit (p25p1_hdu.c:191-268): 20 random hex words -> RS(36,20,17) -> Golay(24,6) per word, hex_data[19..0] then
+    hex_parity[15..0] on the air -> (dibits int8 [396], hex words sent [20])"""
+    d = rng.integers(0, 64, 20)
+    syms = np.concatenate([d, fecgen.rs63_encode(d, 8)])
+    fr = np.full(396, 2, np.int8)
+    fr[:24] = orc.P25_FS_DIBITS
+    fr[[q for q in range(24, 57) if q != 35]] = nid_dibits(nac, 0x0)
+    idx = 57
+    for seq in range(36):
+        word = 19 - seq if seq < 20 else 20 + (15 - (seq - 20))
+        hp, idx = _walk(idx, 3)
+        pp, idx = _walk(idx, 6)
+        b6 = np.array([(int(syms[word]) >> (5 - k)) & 1 for k in range(6)], np.uint8)
+        d12 = np.zeros(12, np.uint8)
+        d12[6:] = b6
+        par = np.array(fecgen.golay24_encode(d12), np.uint8)
+        fr[hp] = (b6[0::2] << 1) | b6[1::2]
+        fr[pp] = (par[0::2] << 1) | par[1::2]
+    return fr, d
+
+
+def make_tdulc(rng, nac):
+    """One terminator with link control (p25p1_tdulc.c:199-207): 12 random hex words -> RS(24,12,13) -> six + six Golay(24,12) words
+    -> (dibits int8 [216], hex words sent [12])"""
+    d = rng.integers(0, 64, 12)
+    hexw = np.concatenate([d, fecgen.rs63_encode(d, 6)])
+    fr = np.full(216, 2, np.int8)
+    fr[:24] = orc.P25_FS_DIBITS
+    fr[[q for q in range(24, 57) if q != 35]] = nid_dibits(nac, 0xF)
+    idx = 57
+    for seq in range(12):
+        w = 5 - seq if seq < 6 else 6 + (5 - (seq - 6))
+        dp, idx = _walk(idx, 6)
+        pp, idx = _walk(idx, 6)
+        hi, lo = int(hexw[2 * w + 1]), int(hexw[2 * w])
+        b12 = np.array([(hi >> (5 - k)) & 1 for k in range(6)] + [(lo >> (5 - k)) & 1 for k in range(6)], np.uint8)
+        par = np.array(fecgen.golay24_encode(b12), np.uint8)
+        fr[dp] = (b12[0::2] << 1) | b12[1::2]
+        fr[pp] = (par[0::2] << 1) | par[1::2]
+    return fr, d
+
+
+def make_tdu(nac):
+    """Simple terminator: FS + NID (DUID 3) + 14 null dibits and the status symbol -> int8 [72]"""
+    fr = np.zeros(72, np.int8)
+    fr[:24] = orc.P25_FS_DIBITS
+    fr[[q for q in range(24, 57) if q != 35]] = nid_dibits(nac, 0x3)
+    fr[35::36] = 2
+    return fr
+
+
 def weaken_nid(dibits, frame_start, rng, strong=10, weak=3):
     """damage the NID of the frame at dibit `frame_start` so that the BCH hard decode fails (strong + weak > 11 bit errors)
     and the Chase search over the least reliable bits repairs it: `strong` symbols get the opposite sign (one bit error

@@ -1,0 +1,151 @@
+"""The P25 Phase 1 chain object (include/ddn_chain.h: ddn_p25_chain_*) against the whole-stream oracle (tests/chain_stream.py):
+a stream handed over in several calls + a flush gives, frame for frame, what the oracle gives for the stream in one piece -
+including the frames that straddle call boundaries (the carried tail) - and the three ways of running a call (one stream,
+pipelined over two, from pinned host memory) agree bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import chain_stream
+import ddn
+import mbe
+import p25gen
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream(B, n_total):
+    """B channels of cu8 I/Q: the reference's two P25 captures, then synthetic voice, control and mixed traffic"""
+    iq = np.full((B, n_total, 2), 127, np.uint8)
+    rng = np.random.default_rng(4242)
+    for c in range(B):
+        if c == 0:
+            g = golden("iq_p25p1_c4fm_vc.npz")["iq"]
+            iq[c, :min(n_total, len(g))] = g[:n_total]
+        elif c == 1:
+            g = golden("iq_p25p1_c4fm_cc.npz")["iq"]
+            iq[c, :min(n_total, len(g))] = g[:n_total]
+        elif c % 3 == 2:
+            n_ldus = n_total // 8640 + 1
+            bits = mbe.random_imbe_bits(rng, (n_ldus * 9,))
+            dib, _ = p25gen.make_ldus(rng, n_ldus, 0x293, np.stack([mbe.imbe_encode(b) for b in bits]))
+            iq[c] = p25gen.modulate_cu8(dib, n_total, lead=200 + 37 * c, seed=c, noise=0.02 + 0.04 * (c % 2))
+        elif c % 3 == 0:
+            parts = []
+            while sum(len(p) for p in parts) * 10 < n_total:
+                parts.append(p25gen.make_frames(rng, 1, 0x293, crc=True, blocks=int(rng.integers(1, 4)))[0])
+                parts.append(np.zeros(int(rng.integers(0, 40)), np.int8))
+            iq[c] = p25gen.modulate_cu8(np.concatenate(parts), n_total, lead=300 + 11 * c, seed=c, noise=0.03)
+        else:
+            parts = []
+            while sum(len(p) for p in parts) * 10 < n_total:
+                k = int(rng.integers(0, 5))
+                if k == 0:
+                    bits = mbe.random_imbe_bits(rng, (18,))
+                    parts.append(p25gen.make_ldus(rng, 2, 0x293, np.stack([mbe.imbe_encode(b) for b in bits]))[0])
+                elif k == 1:
+                    parts.append(p25gen.make_frames(rng, 2, 0x293, crc=True, blocks=3)[0])
+                elif k == 2:
+                    parts.append(p25gen.frame_with_duid(rng, 0x293, 0x0, 339 + 5))
+                elif k == 3:
+                    parts.append(p25gen.frame_with_duid(rng, 0x293, 0xF, 159 + 5))
+                else:
+                    parts.append(p25gen.make_pdu(rng, 0x293, int(rng.integers(0, 4))))
+            iq[c] = p25gen.modulate_cu8(np.concatenate(parts), n_total, lead=250 + 7 * c, seed=c, noise=0.03)
+    return iq
+
+
+def _upload(a):
+    p = C.c_void_p()
+    assert ddn.lib().ddn_device_alloc(a.nbytes, C.byref(p)) == 0
+    assert ddn.lib().ddn_device_upload(p, a.ctypes.data, a.nbytes) == 0
+    return p
+
+
+def _run(iq, n_call, how="run", everything=False, max_ldu=0):
+    B, n_total = iq.shape[0], iq.shape[1]
+    ch = ddn.P25ChainC(B, n_call, max_ldu=max_ldu)
+    col = chain_stream.Collector(ch, everything)
+    pinned = []
+    for a in range(0, n_total, n_call):
+        part = np.ascontiguousarray(iq[:, a:a + n_call])
+        if how == "host":
+            p = C.c_void_p()
+            assert ddn.lib().ddn_host_alloc_pinned(part.nbytes, C.byref(p)) == 0
+            C.memmove(p, part.ctypes.data, part.nbytes)
+            pinned.append(p)
+            ch.run_host(p, None)
+            ch.wait()
+        else:
+            d = _upload(part)
+            if how == "run":
+                ch.run(d)
+            else:
+                ch.run_pipelined(d)
+                ch.wait()
+            ddn.lib().ddn_device_free(d)
+        col.take()
+    ch.flush()
+    col.take()
+    for p in pinned:
+        ddn.lib().ddn_host_free_pinned(p)
+    ch.close()
+    return col
+
+
+_check_against_oracle = chain_stream.check_channel
+
+
+def test_stream_in_calls_equals_the_oracle(built):
+    B, n_call, calls = 6, 24000, 6
+    iq = _stream(B, n_call * calls)
+    col = _run(iq, n_call)
+    tot = np.zeros(3, np.int64)
+    for c in range(B):
+        want = chain_stream.run_stream(iq[c], n_call, seed=c)
+        tot += _check_against_oracle(col, c, want)
+    assert tot[0] > 150 and tot[1] > 150 and tot[2] > 250, tot
+
+
+def test_short_calls_and_frames_across_boundaries(built):
+    """calls shorter than a voice frame: every LDU straddles one or more call boundaries"""
+    B, n_call, calls = 3, 6000, 16
+    iq = _stream(B, n_call * calls)
+    col = _run(iq, n_call, max_ldu=4)
+    for c in range(B):
+        want = chain_stream.run_stream(iq[c], n_call, seed=c)
+        _check_against_oracle(col, c, want)
+
+
+def _same(a, b):
+    assert sorted(a) == sorted(b)
+    for g in a:
+        for k, v in a[g].items():
+            w = b[g][k]
+            if k == "tsbk":
+                assert all(np.array_equal(x[0], y[0]) and x[1] == y[1] for x, y in zip(v, w)), (g, k)
+            else:
+                assert np.array_equal(v, w), (g, k)
+
+
+def test_split_invariance_and_the_three_run_forms(built):
+    """every output array (LDU words, Reed-Solomon data and status, low speed data, HDU, TDULC too), frame by frame: one long call
+    == many short ones == pipelined == from pinned host memory"""
+    B, n_total = 6, 98304        # whole front-end blocks per call in every split: the block partition is part of the result
+    iq = _stream(B, n_total)
+    one = _run(iq, n_total, everything=True)
+    for how, n_call in (("run", 16384), ("pipelined", 8192), ("host", 24576)):
+        got = _run(iq, n_call, how=how, everything=True)
+        for c in range(B):
+            assert np.array_equal(np.concatenate(got.rec[c]), np.concatenate(one.rec[c])), (how, c)
+            # frames near the end of the stream see a shorter tail in the flush than inside the long call
+            cnt = len(np.concatenate(one.rec[c]))
+            a = {g: v for g, v in one.frames[c].items() if g + 900 < cnt}
+            b = {g: v for g, v in got.frames[c].items() if g + 900 < cnt}
+            _same(a, b)
+            va = [v for v in one.voice[c] if v[0] + 900 < cnt]
+            vb = [v for v in got.voice[c] if v[0] + 900 < cnt]
+            assert len(va) == len(vb) and all(x[0] == y[0] and np.array_equal(x[2], y[2]) and np.array_equal(x[4].view(np.uint32), y[4].view(np.uint32))
+                                              for x, y in zip(va, vb)), (how, c)

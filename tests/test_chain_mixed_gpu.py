@@ -1,0 +1,131 @@
+"""The DMR / NXDN48 chain object and the mixed-protocol object (include/ddn_chain.h: ddn_fsk4_chain_*, ddn_mixed_chain_*) on the
+reference's own captures: receive-loop outputs with the handlers inside the loop equal the CPU restatement bit for bit over two
+streamed calls, the frame FEC behind it gives the captures' known answers, and the three groups of a mixed batch run side by side."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ddn
+import orc
+import rx4
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+N = 48000
+
+
+def _upload(a):
+    p = C.c_void_p()
+    assert ddn.lib().ddn_device_alloc(a.nbytes, C.byref(p)) == 0
+    assert ddn.lib().ddn_device_upload(p, a.ctypes.data, a.nbytes) == 0
+    return p
+
+
+def _tiles(name, lo, B, calls, n=N):
+    iq = np.ascontiguousarray(golden(name)["iq"], np.uint8)
+    offs = [lo + 371 * c for c in range(B)]
+    return [np.stack([iq[o + k * n:o + (k + 1) * n] for o in offs]) for k in range(calls)], offs, iq
+
+
+def _check_rx(ch, Bc, calls_iq, proto, lpf, rf):
+    """two streamed calls against the restatement fed the same two pieces"""
+    fes = [orc.OracleFrontEnd(profile=lpf) for _ in range(Bc)]
+    rxs = [rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf, handler=1)) for _ in range(Bc)]
+    out = []
+    for part in calls_iq:
+        d = _upload(part)
+        ch.run(d)
+        r = ch.results()
+        ms, my = r.max_symbols, r.max_syncs
+        f = ch.fetch
+        rec, fl, pay = f(r.d_records10, np.uint8, (Bc, ms, 10)), f(r.d_flags, np.uint8, (Bc, ms)), f(r.d_payload2, np.uint8, (Bc, ms, 2))
+        cnt, ns = f(r.d_counts, np.int32, (Bc,)), f(r.d_n_sync, np.int32, (Bc,))
+        spos, pre = f(r.d_sync_pos, np.int32, (Bc, my)), f(r.d_pre, np.uint8, (Bc, my, 90))
+        ddn.lib().ddn_device_free(d)
+        for c in range(Bc):
+            disc = fes[c].run_cu8(np.ascontiguousarray(part[c]), 8192)
+            want = rxs[c].run(disc, max_sync=my)
+            k = int(cnt[c])
+            assert k == len(want["sym"]), (c, k, len(want["sym"]))
+            rr = rec[c, :k]
+            assert np.array_equal(rr[:, 6:10].copy().view(np.uint32).reshape(-1), want["sym"].view(np.uint32)), c
+            assert np.array_equal(rr[:, 0].astype(np.int32), want["rec4"][:, 0]) and np.array_equal(fl[c, :k], want["fl"]), c
+            assert np.array_equal(pay[c, :k], want["pay"]), c
+            assert int(ns[c]) == len(want["sync_pos"]) and np.array_equal(spos[c, :int(ns[c])], want["sync_pos"]), c
+            assert np.array_equal(pre[c, :int(ns[c])], want["pre"]), c
+        out.append((r, ns))
+    return out
+
+
+def test_dmr_chain_two_calls_and_known_answer(built):
+    B = 4
+    n = 44000                                  # the capture holds 96000 samples
+    calls, _, _ = _tiles("iq_dmr_t3_ras_cc.npz", 0, B, 2, n)
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_DMR, rf_mod=2)
+    (r, ns), _ = _check_rx(ch, B, calls, rx4.PROTO_DMR, 2, 2)[-1], None
+    my = r.max_syncs
+    S = B * my
+    valid, st_ok = ch.fetch(r.d_valid, np.uint8, (S,)), ch.fetch(r.d_dmr_slot_type_ok, np.uint8, (S,))
+    stb, errs = ch.fetch(r.d_dmr_slot_type, np.uint8, (S, 20)), ch.fetch(r.d_dmr_bptc_errs, np.uint32, (S,))
+    rows = np.flatnonzero(valid)
+    # Tier III control channel: colour code 0 in every slot type, the BPTC words clean
+    assert len(rows) > 20 and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0) and np.mean(errs[rows] == 0) > 0.99
+    ch.close()
+
+
+def test_nxdn48_chain_two_calls_voice(built):
+    B = 3
+    calls, _, _ = _tiles("iq_nxdn48.npz", 60000, B, 2)
+    ch = ddn.Fsk4ChainC(B, N, ddn.FSK4_NXDN48, rf_mod=0)
+    r, ns = _check_rx(ch, B, calls, rx4.PROTO_NXDN48, 1, 0)[-1]
+    my, vf = r.max_syncs, r.voice_slots
+    S = B * my
+    nv, nl = ch.fetch(r.d_valid, np.uint8, (S,)), ch.fetch(r.d_nxdn_lich, np.uint8, (S,))
+    s1, s2 = ch.fetch(r.d_nxdn_sacch_ok, np.uint8, (S,)), ch.fetch(r.d_nxdn_sacch_hard_ok, np.uint8, (S,))
+    rows = np.flatnonzero(nv)
+    assert len(rows) >= 10 and np.mean((nl[rows] & 0x80) != 0) > 0.9 and np.mean((s1[rows] | s2[rows]) != 0) > 0.5
+    skip = ch.fetch(r.d_nxdn_voice_skip, np.uint8, (B, vf, 4))
+    pcm = ch.fetch(r.d_nxdn_pcm, np.float32, (B, vf * 4, 160))
+    assert np.all(np.isfinite(pcm)) and (skip == 0).sum() >= 8            # the capture is a voice call: frames were synthesized
+    assert np.all(pcm.reshape(B, vf, 4, 160)[skip != 0] == 0)
+    ch.close()
+
+
+def test_mixed_chain_groups_side_by_side(built):
+    """the three groups through ddn_mixed_chain give what each group's own chain object gives alone"""
+    import p25gen
+    rng = np.random.default_rng(5)
+    Bp, Bd, Bn = 3, 2, 2
+    p25 = np.stack([p25gen.modulate_cu8(np.concatenate([p25gen.make_frames(rng, 1, 0x293, crc=True, blocks=1 + (c + k) % 3)[0] for k in range(20)]),
+                                        N, lead=250 + 31 * c, seed=c) for c in range(Bp)])
+    dmr, _, _ = _tiles("iq_dmr_t3_ras_cc.npz", 0, Bd, 1)
+    nx, _, _ = _tiles("iq_nxdn48.npz", 60000, Bn, 1)
+    m = ddn.MixedChainC(Bp, Bd, Bn, N)
+    dp, dd, dn = _upload(p25), _upload(dmr[0]), _upload(nx[0])
+    m.run(dp, dd, dn)
+    m.wait()
+    l = ddn.lib()
+    # P25 group: the same call through a chain object of its own
+    own = ddn.P25ChainC(Bp, N)
+    own.run(dp)
+    ro = own.results()
+    rm = ddn.P25ChainResults()
+    assert l.ddn_p25_chain_get_results(l.ddn_mixed_chain_part(m.h, 0), C.byref(rm)) == 0
+    for name, dt, shape in (("d_new", np.int32, (Bp,)), ("d_nid4", np.int32, (Bp * own.F, 4)), ("d_tsbk", np.uint8, (3, Bp * own.F, 12)),
+                            ("d_records10", np.uint8, (Bp, own.stride, 10))):
+        assert np.array_equal(own.fetch(getattr(ro, name), dt, shape), own.fetch(getattr(rm, name), dt, shape)), name
+    assert own.fetch(ro.d_tsbk_crc, np.uint8, (3, Bp * own.F)).sum() >= 30
+    for which, Bc, proto, iq in ((1, Bd, ddn.FSK4_DMR, dd), (2, Bn, ddn.FSK4_NXDN48, dn)):
+        a = m.part(which)
+        b = ddn.Fsk4ChainC(Bc, N, proto, rf_mod=2 if which == 1 else 0)
+        b.run(iq)
+        ra, rb = a.results(), b.results()
+        for name, dt, shape in (("d_counts", np.int32, (Bc,)), ("d_n_sync", np.int32, (Bc,)), ("d_records10", np.uint8, (Bc, ra.max_symbols, 10)),
+                                ("d_valid", np.uint8, (Bc * ra.max_syncs,))):
+            assert np.array_equal(a.fetch(getattr(ra, name), dt, shape), b.fetch(getattr(rb, name), dt, shape)), (which, name)
+        b.close()
+    own.close()
+    m.close()
+    for p in (dp, dd, dn):
+        l.ddn_device_free(p)

@@ -124,9 +124,11 @@ def test_synth_batch_bit_exact_with_history(built, codec):
     res_in[..., 0] = 1
     o = mbe.OracleVocoder(codec, S)
     g = GpuVocoder(codec, S)
+    seen = 0
     for (a, b) in ((0, 25), (25, F)):
         want_pcm, want_res, rc = o.run(bits[:, a:b], res_in[:, a:b])
         assert rc == 0
+        seen |= int(np.bitwise_or.reduce(want_res[..., 0].reshape(-1)))
         got_pcm, got_res = g.run(bits[:, a:b], res_in[:, a:b])
         assert np.array_equal(got_res, want_res)
         assert np.array_equal(got_pcm.view(np.uint32), want_pcm.view(np.uint32)), float(np.abs(got_pcm - want_pcm).max())
@@ -134,7 +136,32 @@ def test_synth_batch_bit_exact_with_history(built, codec):
         for s in (0, 3, S - 1):
             c, p, e = g.state(s)
             assert mbe.parms_equal(c, o.cur[s]) and mbe.parms_equal(p, o.prev[s]) and mbe.parms_equal(e, o.enh[s]), s
-    assert (want_res[..., 0] & 0x10).any() and (want_res[..., 0] & 0x8).any()    # the case exercised repeat and mute
+    assert (seen & 0x10) and (seen & 0x8)    # the case exercised repeat and mute
+
+
+def test_imbe_invalid_fundamental_repeats_three_times_then_mutes(built):
+    """mbelib 1.3 mbe_processImbe4400Dataf: b0 > 207 frames repeat the last good frame (synthesized) up to three times in a row, the
+    fourth mutes and re-initialises the talk path; flags, PCM and state equal the restatement"""
+    rng = np.random.default_rng(77)
+    S, F = 5, 12
+    bits = mbe.random_imbe_bits(rng, (S, F))
+    bits[0, 2:6, :6] = 1
+    bits[1, 3:5, :6] = 1
+    bits[2, 1:9, :6] = 1
+    bits[3, 0:2, :6] = 1
+    o = mbe.OracleVocoder(ddn.MBE_IMBE, S)
+    g = GpuVocoder(ddn.MBE_IMBE, S)
+    want_pcm, want_res, rc = o.run(bits)
+    got_pcm, got_res = g.run(bits)
+    assert rc == 0 and np.array_equal(got_res, want_res)
+    assert np.array_equal(got_pcm.view(np.uint32), want_pcm.view(np.uint32))
+    REPEAT, MUTE = 0x8, 0x10
+    assert [int(f) & 0x18 for f in got_res[0, :8, 0]] == [0, 0, REPEAT, REPEAT, REPEAT, REPEAT | MUTE, 0, 0]
+    assert all(np.abs(got_pcm[0, k]).max() > 0 for k in (2, 3, 4)) and np.all(got_pcm[0, 5] == 0)
+    assert [int(f) & 0x18 for f in got_res[1, 2:6, 0]] == [0, REPEAT, REPEAT, 0]
+    for s in range(S):
+        c, p, e = g.state(s)
+        assert mbe.parms_equal(c, o.cur[s]) and mbe.parms_equal(p, o.prev[s]) and mbe.parms_equal(e, o.enh[s]), s
 
 
 def test_c5_shape_8192_frames_properties(built):

@@ -83,8 +83,8 @@ def test_default_tables_are_flagged_synthetic_and_consistent(built):
 
 @pytest.mark.parametrize("codec", [ddn.MBE_IMBE, ddn.MBE_AMBE])
 def test_process_control_flow(built, codec):
-    """repeat after too many corrections, mute after four repeats in a row, invalid fundamental mutes and re-initialises,
-    AMBE erasure / tone frames mute; audio is finite and non-trivial on valid frames."""
+    """repeat after too many corrections, mute after four repeats in a row, an invalid IMBE fundamental repeats (synthesized) and
+    only the fourth in a row mutes, AMBE erasure / tone frames mute; audio is finite and non-trivial on valid frames."""
     rng = np.random.default_rng(3)
     F = 12
     bits = (mbe.random_imbe_bits if codec == ddn.MBE_IMBE else mbe.random_ambe_bits)(rng, (1, F))
@@ -101,20 +101,29 @@ def test_process_control_flow(built, codec):
     assert v.cur[0].un == F
     # invalid fundamental / special frames
     v = mbe.OracleVocoder(codec, 1)
-    special = bits[:, :3].copy()
     if codec == ddn.MBE_IMBE:
-        special[0, 1, :6] = 1                                  # b0 >= 252 > 207
-        want = [0, MUTE | REPEAT, 0]                         # mbelib marks "R" then mutes
+        # mbelib 1.3 mbe_processImbe4400Dataf: an invalid fundamental (b0 > 207) repeats the last good frame - synthesized, not muted -
+        # up to three times in a row; the fourth mutes and re-initialises the talk path (the `bad == 0` gate is AMBE's only)
+        special = bits[:, :8].copy()
+        special[0, 2:6, :6] = 1                                # frames 2..5: b0 >= 252 > 207
+        want = [0, 0, REPEAT, REPEAT, REPEAT, REPEAT | MUTE, 0, 0]
+        pcm, res, rc = v.run(special)
+        assert rc == 0 and [int(f) & 0x78 for f in res[0, :, 0]] == want
+        assert all(np.abs(pcm[0, k]).max() > 0 for k in (2, 3, 4)) and np.all(pcm[0, 5] == 0) and np.abs(pcm[0, 6]).max() > 0
+        assert v.prev[0].L == bits_L(special[0, 7])
+        # the repeated frames carry the last good frame's parameters: same L, and the history survives the bad frame
+        v2 = mbe.OracleVocoder(codec, 1)
+        v2.run(special[:, :3])
+        assert v2.prev[0].L == bits_L(special[0, 1]) and v2.cur[0].repeat == 1
     else:
+        special = bits[:, :3].copy()
         for k, p in enumerate((0, 1, 2, 3, 37, 38, 39)):
             special[0, 1, p] = (120 >> (6 - k)) & 1            # erasure
             special[0, 2, p] = (126 >> (6 - k)) & 1            # tone
         want = [0, MUTE | 0x40, MUTE | 0x20]
-    pcm, res, rc = v.run(special)
-    assert rc == 0 and [int(f) & 0x78 for f in res[0, :, 0]] == want
-    assert np.all(pcm[0, 1] == 0)
-    if codec == ddn.MBE_IMBE:
-        assert v.prev[0].L == bits_L(special[0, 2])
+        pcm, res, rc = v.run(special)
+        assert rc == 0 and [int(f) & 0x78 for f in res[0, :, 0]] == want
+        assert np.all(pcm[0, 1] == 0)
 
 
 def bits_L(b):

@@ -17,11 +17,11 @@ def _oracle(x, use_filter=1):
     rx = orc.OracleP25Rx(lock_symbols=-1, use_filter=use_filter)
     sym, rec, fl = rx.run(x)
     ev = [[e[0], e[1], e[2], (e[3] & 0xFFFF) | ((e[4] & 0xFFFF) << 16)] for e in rx.events.rows()]
-    return sym, rec, fl, np.array(ev, np.int64).reshape(-1, 4)
+    return sym, rec, fl, np.array(ev, np.int64).reshape(-1, 4), rx.events.data()
 
 
-def _check(rec, fl, cnt, events, n_events, c, want):
-    sym_o, rec_o, fl_o, ev_o = want
+def _check(rec, fl, cnt, events, n_events, c, want, event_data=None):
+    sym_o, rec_o, fl_o, ev_o, evd_o = want
     k = int(cnt[c])
     assert k == len(sym_o), (c, k, len(sym_o))
     r4, sy = orc.unpack_records10(rec[c, :k])
@@ -32,6 +32,9 @@ def _check(rec, fl, cnt, events, n_events, c, want):
     ne = int(n_events[c])
     got = events[c, :ne].astype(np.int64) & np.array([-1, -1, -1, 0xFFFFFFFF])
     assert ne == len(ev_o) and np.array_equal(got, ev_o & np.array([-1, -1, -1, 0xFFFFFFFF])), (c, got[:6], ev_o[:6])
+    if event_data is not None:       # what each decision decoded: NID result words, TSDU / PDU header block bytes
+        bad = np.flatnonzero((event_data[c, :ne] != evd_o).any(axis=1))
+        assert bad.size == 0, (c, bad[:4], event_data[c, bad[:2]], evd_o[bad[:2]], ev_o[bad[:2]])
 
 
 @pytest.mark.parametrize("name", ["iq_p25p1_c4fm_cc.npz", "iq_p25p1_c4fm_vc.npz"])
@@ -42,7 +45,7 @@ def test_reference_captures_with_handlers(built, name):
     want = _oracle(disc[0])
     rx = ddn.P25Rx(1, use_matched_filter=1, handlers=True)
     rec, fl, cnt = rx.run(disc)
-    _check(rec, fl, cnt, rx.events, rx.n_events, 0, want)
+    _check(rec, fl, cnt, rx.events, rx.n_events, 0, want, rx.event_data)
     ev = rx.events[0, :rx.n_events[0]]
     if "cc" in name:      # every TSDU: NID ok, three blocks, CRC16 good, last-block flag on the third
         tsbk = ev[ev[:, 1] == 2]
@@ -104,7 +107,7 @@ def test_every_frame_type_clean_and_noisy(built, cpw):
     rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=2048)
     rec, fl, cnt = rx.run(x)
     for c in range(B):
-        _check(rec, fl, cnt, rx.events, rx.n_events, c, want[c])
+        _check(rec, fl, cnt, rx.events, rx.n_events, c, want[c], rx.event_data)
     ev = np.concatenate([rx.events[c, :rx.n_events[c]] for c in range(B)])
     nid = ev[ev[:, 1] == 1]
     tsbk = ev[ev[:, 1] == 2]
@@ -124,7 +127,7 @@ def test_call_splits(built):
         x[c, :len(s)] = s
     want = [_oracle(x[c], 1) for c in range(B)]
     rx = ddn.P25Rx(B, use_matched_filter=1, handlers=True, max_events=1024)
-    recs, fls, evs = [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)]
+    recs, fls, evs, evds = [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)]
     base = np.zeros(B, np.int64)
     for a, b in zip(splits[:-1], splits[1:]):
         rec, fl, cnt = rx.run(x[:, a:b])
@@ -134,9 +137,10 @@ def test_call_splits(built):
             e = rx.events[c, :rx.n_events[c]].astype(np.int64)
             e[:, 0] += base[c]
             evs[c].append(e)
+            evds[c].append(rx.event_data[c, :rx.n_events[c]])
             base[c] += cnt[c]
     for c in range(B):
         rec = np.concatenate(recs[c])[None]
         fl = np.concatenate(fls[c])[None]
         ev = np.concatenate(evs[c])[None]
-        _check(rec, fl, np.array([rec.shape[1]]), ev, np.array([ev.shape[1]]), 0, want[c])
+        _check(rec, fl, np.array([rec.shape[1]]), ev, np.array([ev.shape[1]]), 0, want[c], np.concatenate(evds[c])[None])

@@ -54,3 +54,74 @@ def test_two_rank_gather_matches_single_process(built, tmp_path):
     got = np.load(out)
     want = orc.oracle_batch_cu8(orc.synth_c4fm_cu8(0, B, n), blk)
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---- mixed-protocol batches (BASELINE configs[3]): [P25 | DMR | NXDN48] channel groups split over the ranks ----------------------
+def test_mixed_partition_covers_every_group(built):
+    import ddn
+    for world in (1, 2, 3, 8):
+        for groups in ((1366, 1365, 1365), (5, 0, 3), (0, 0, 1), (4096 * 8 + 1, 4096 * 8, 4096 * 8 - 1), (1, 1, 1)):
+            total = sum(groups)
+            got = [ddn.mixed_partition(*groups, r, world) for r in range(world)]
+            sizes = [sum(c for _, c in g) for g in got]
+            assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
+            for k in range(3):      # every group: the ranks' ranges are contiguous, in rank order, and cover it once
+                pos = 0
+                for g in got:
+                    f, c = g[k]
+                    if c:
+                        assert f == pos
+                        pos += c
+                assert pos == groups[k]
+            # the global index a rank owns is one contiguous block
+            starts = [0, groups[0], groups[0] + groups[1]]
+            for r, g in enumerate(got):
+                idx = [starts[k] + f + j for k, (f, c) in enumerate(g) for j in range(c)]
+                assert idx == list(range(idx[0], idx[0] + len(idx))) if idx else True
+                assert ddn_shard.channel_range(r, world, total) == ((idx[0] if idx else ddn_shard.channel_range(r, world, total)[0]), len(idx))
+
+
+def _mixed_worker(rank, world, port, groups, n, out_path):
+    """each rank runs the CPU oracles of ITS channels of every group (what the GPU ranks do with ddn_mixed_chain), rank 0 gathers the
+    per-channel symbol counts in global channel order"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ddn
+    import rx4
+    desc = ddn_shard.broadcast_descriptor({"groups": groups, "n": n} if rank == 0 else None)
+    part = ddn.mixed_partition(*desc["groups"], rank, world)
+    rows = []
+    for k, (first, count) in enumerate(part):
+        for c in range(first, first + count):
+            rows.append(_mixed_channel(k, c, desc["n"]))
+    local = torch.tensor(rows, dtype=torch.int64).reshape(-1, 2)
+    full = ddn_shard.gather_channel_major(local, sum(desc["groups"]))
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    dist.destroy_process_group()
+
+
+def _mixed_channel(group, c, n):
+    """-> [symbols, syncs] of channel c of group 0 (P25), 1 (DMR), 2 (NXDN48) through the receive-loop oracle with the handlers in it"""
+    import rx4
+    import p25gen
+    rng = np.random.default_rng(1000 * group + c)
+    if group == 0:
+        dib = p25gen.make_frames(rng, 6, 0x293, crc=True, blocks=1 + c % 3)[0]
+        rx = orc.OracleP25Rx(lock_symbols=-1, use_filter=1)
+        sym, _, fl = rx.run(p25gen.modulate_disc(dib, lead=200 + 17 * c, noise=200.0, seed=c)[:n])
+        return [len(sym), int((fl & 2).sum())]
+    proto = rx4.PROTO_DMR if group == 1 else rx4.PROTO_NXDN48
+    x = rng.normal(0, 3000, n).astype(np.float32)
+    w = rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=2 if group == 1 else 0, handler=1)).run(x, max_sync=64)
+    return [len(w["sym"]), len(w["sync_pos"])]
+
+
+def test_two_rank_mixed_batch_matches_single_process(built, tmp_path):
+    groups, n = (3, 2, 2), 6000         # 7 channels: rank 0 owns P25 0-2 + DMR 0, rank 1 DMR 1 + NXDN48 0-1
+    out = str(tmp_path / "mixed.npy")
+    mp.spawn(_mixed_worker, args=(2, _free_port(), groups, n, out), nprocs=2, join=True)
+    got = np.load(out)
+    want = np.array([_mixed_channel(k, c, n) for k in range(3) for c in range(groups[k])], np.int64)
+    assert np.array_equal(got, want) and got[:3, 1].min() >= 1

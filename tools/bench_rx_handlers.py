@@ -76,5 +76,20 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
             assert l.ddn_p25_rx_debug_counters(rx.h, c, o) == 0
             tot += [o[0], o[1]]
         extra += " | lane wait: %.0f cycles per request (%d requests)" % (tot[1] / max(tot[0], 1), tot[0])
+    if int(os.environ.get("DDN_RX_DBG", "0")) & 8192:      # library built with EXTRA=-DDDN_RX_CYCLES=1
+        r = rec.cpu().numpy().reshape(B, -1)
+        tails = np.stack([r[c, -192:] for c in range(0, B, cpw)]).copy().view(np.int64).reshape(-1, 3, 8)
+        tiles = (n + 127) // 128
+        for w, nm in enumerate(["recurrence", "loader", "winprep"]):
+            extra += "\n   %s busy/tile %.0f wait/tile %.0f cycles" % (nm, tails[:, w, 0].mean() / tiles, tails[:, w, 1].mean() / tiles)
+        tt = tails[:, 0]
+        for k in range(3):
+            extra += "\n   trip kind %d: %.2f per tile at %.0f cycles (share of busy %.2f)" % (
+                k, tt[:, 5 + k].mean() / tiles, tt[:, 2 + k].sum() / max(1, tt[:, 5 + k].sum()), tt[:, 2 + k].sum() / max(1, tt[:, 0].sum()))
+    if int(os.environ.get("DDN_RX_DBG", "0")) & 8192:
+        sec = np.stack([r[c, -256:-192] for c in range(0, B, cpw)]).copy().view(np.int64)
+        nstd = max(1, tt[:, 5].sum())
+        extra += "\n   std trip sections (cycles per trip): top %.0f search %.0f mean %.0f inframe %.0f hunt %.0f emit %.0f" % tuple(
+            sec[:, k].sum() / nstd for k in range(6))
     print("%-8s cpw %2d: loop %.3f ms (mf %.3f) in-frame share %.3f syncs/ch %.1f%s" % (
         mode, cpw, t[1], t[0], (flc & 1).mean() * ms / (n / 10), (flc & 2).sum() / B, extra), flush=True)
