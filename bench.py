@@ -41,7 +41,7 @@ N_SAMPLES = 48000
 BLOCK = 8192
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
 N_BASE = 64                  # distinct channels of each traffic kind
-RXW_TRAFFIC_BYTES = None     # filled from profiles/r03_pmc_*.txt once measured
+RXW_TRAFFIC_BYTES = 2.612e9   # profiles/r03_pmc_FETCH_SIZE.txt, r03_pmc_WRITE_SIZE.txt: 2 x 778 749 KB + 1 054 790 KB per launch of k_p25_rxw<8, true>
 
 
 def make_base_traffic(n):
