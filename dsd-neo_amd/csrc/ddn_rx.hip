@@ -673,8 +673,7 @@ struct LdsW {
     // suffix summaries per checkpoint: pushes per two tiles, 2 * (ceil((TW + sps) / (sps - 1)) + 1).  SMALL (handler mode, which
     // needs the LDS for its history ring): sized for at least 9 samples per symbol
     static constexpr int WMW = CPW <= 8 ? (SMALL ? 40 : 64) : (SMALL ? 24 : 32);
-    static constexpr int QTW = CPW <= 4 ? 24 : (CPW <= 8 ? 40 : 20); // queue slots = trips of a tile that can hand a symbol to wave 1
-                                                                      // (later trips of the tile store their records themselves)
+    static constexpr int QTW = CPW <= 8 ? 40 : 20; // queue slots = trips of a tile that can hand a symbol to wave 1
     float sb[SS][CPW];
     float lb[24][CPW];
     float sh[24][CPW];
@@ -683,7 +682,7 @@ struct LdsW {
     float raw[CPW][RTW + TW + 13];
     float flt[CPW][RTW + TW + 13];
     alignas(16) float q[2][QTW][CPW][4]; // [tile parity][trip][lane] = {symbol, max, min, flags | output index << 8}
-    int qn[2];                          // trips of that tile
+    int qn[2][2];                       // trips of that tile, per recurrence wave
     int qo[2][CPW];                     // output index of the lane's first symbol of that tile
     alignas(16) float sfx[2][WMW][CPW][4]; // [checkpoint parity][m - 1][lane] = {min1, min2, max1, max2} of ring entries m+1..128
     int sidx0[2][CPW];        // [tile parity] ring slot of the oldest entry at the start of that tile
@@ -698,11 +697,10 @@ struct LdsH {
     float hh[ddn_p25h::HN][CPW][3]; // {symbol, max, min} of the phase's in-frame symbols, slot = count mod HN
     int req_seq[CPW], req_kind[CPW], req_hw[CPW], req_n[CPW], req_o[CPW], req_neg[CPW], req_nc[CPW];
     int rsp_seq[CPW], rsp_ext[CPW], rsp_more[CPW];
-    int tile_done;
+    int tile_done[2]; // per recurrence wave
     ddn_p25h::Scratch sc;
 };
 
-static_assert(((sizeof(LdsW<4, true>) + 15) & ~(size_t)15) + sizeof(LdsH<4>) <= 40960, "four workgroups of the 4-lane handler shape per CU");
 template <int CPW, bool HM>
 __global__ __launch_bounds__(HM ? 256 : 192) void
 k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
@@ -751,7 +749,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
         ddn_p25h::crc_cols_fill(H.sc.crc_cols, lane);
         if (lane == 0) {
-            H.tile_done = 0;
+            H.tile_done[0] = 0;
+            H.tile_done[1] = 0;
             ddn_nid::gf_fill(H.sc.ex, H.sc.lg);
             ddn_nid::chase_masks_fill(H.sc.masks);
         }
@@ -826,10 +825,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const uint64_t both = spread(ph) | (spread(pl) << 1); // bit 2 k = high bit of dibit k, bit 2 k + 1 = its low bit
                 const uint64_t w0 = both & 0x7FFFFFFFFFFFFFFFull;
                 const int par0 = (int)(both >> 63);
+                dbg_stamp(0);
                 if (ddn_nid::bch_63_16_is_codeword(w0)) {
                     r = ddn_nid::nid_fields(w0, 0, par0);
                     nid_done = r.status > 0;
                 }
+                dbg_stamp(2);
             }
             if (!nid_done) {
             if (lane < 33 && lane != 11) {
@@ -1005,7 +1006,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const int rq = (lane < CPW) ? __hip_atomic_load(&H.req_seq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
                 const unsigned long long pend = __ballot(lane < CPW && rq != h_served);
                 if (pend == 0) {
-                    if (__hip_atomic_load(&H.tile_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it) {
+                    if (__hip_atomic_load(&H.tile_done[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it
+                        && __hip_atomic_load(&H.tile_done[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it) {
                         break;
                     }
                     __builtin_amdgcn_s_sleep(4);
@@ -1031,13 +1033,22 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     }
         return;
     }
-    const bool loader = (threadIdx.x >> 6) == 1;  // wave 1: tile staging, slice + record stores
-    const bool winprep = (threadIdx.x >> 6) == 2; // wave 2: suffix summaries of the symbol window
-    const bool recur = threadIdx.x < 64;          // wave 0: the per-channel recurrence
+    // Wave roles.  Plain mode: wave 0 the recurrence of all CPW channels, wave 1 tile staging + slice + record stores, wave 2 the
+    // window's suffix summaries.  Handler mode: the channels are split over TWO recurrence waves (waves 0 and 1, LPR = CPW / 2
+    // lanes each) - a trip is only lean when every lane of its wave is, a handler decision only holds up the wave of the lane
+    // that asked, and the crossing search has twice the lanes per channel - and wave 2 does both the staging and the summaries
+    // (together about half a tile's time), wave 3 the handlers' decisions.
+    constexpr int NRW = HM ? 2 : 1;   // recurrence waves
+    constexpr int LPR = CPW / NRW;    // lanes (channels) per recurrence wave
+    const int wave = threadIdx.x >> 6;
+    const bool loader = wave == NRW;                      // tile staging, slice + record stores
+    const bool winprep = wave == (HM ? NRW : NRW + 1);    // suffix summaries of the symbol window
+    const bool recur = wave < NRW;                        // the per-channel recurrence
+    const int rw = recur ? wave : 0;
     const int ch0 = blockIdx.x * CPW;
-    const int ch = ch0 + lane;
-    const bool live = recur && lane < CPW && ch < n_channels;
-    const int ln = lane < CPW ? lane : 0;
+    const int ln = rw * LPR + (lane < LPR ? lane : 0);    // this lane's channel column in the workgroup's LDS arrays
+    const int ch = ch0 + ln;
+    const bool live = recur && lane < LPR && ch < n_channels;
     const bool use_flt = cfg.use_filter != 0;
     const float inf = __builtin_inff();
     // the recurrence wave is a latency chain: when other kernels' wavefronts share its SIMD (the front end of the next batch
@@ -1171,7 +1182,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         if (dch >= n_channels) {
             return;
         }
-        const int cnt = L.qn[qb], o0 = L.qo[qb][dc];
+        const int cnt = L.qn[qb][dc / LPR], o0 = L.qo[qb][dc];
         uint8_t* drp = rec + (size_t)dch * max_sym * 10;
         uint8_t* dfp = flags + (size_t)dch * max_sym;
         for (int k = de; k < QTW; k += EPL) {
@@ -1523,16 +1534,19 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         const long long dbg_t0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
         const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
         const bool more = (t0 + TW) < n;
-        if (loader) {
-            if (more) {
-                stage(t0 + TW, (it + 1) % 3);
+        if (loader || winprep) { // handler mode: one wave does both, one after the other
+            if (loader) {
+                if (more) {
+                    stage(t0 + TW, (it + 1) % 3);
+                }
+                if (offload && it > 0 && !(cfg.dbg & 512)) {
+                    drain((it - 1) & 1);
+                }
             }
-            if (offload && it > 0 && !(cfg.dbg & 512)) {
-                drain((it - 1) & 1);
-            }
-        } else if (winprep) {
-            if (it >= 1 && !(cfg.dbg & 256)) {
-                compute_sfx(it & 1, it & 1);
+            if (winprep) {
+                if (it >= 1 && !(cfg.dbg & 256)) {
+                    compute_sfx(it & 1, it & 1);
+                }
             }
         } else {
             const int base = TW + (it % 3) * TW;
@@ -1597,7 +1611,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const bool alive = live & !hwait;
                 // hand the previous trip's symbols (one per lane at most) to wave 1: one 16-byte LDS write at a wave-uniform slot
                 if (!respin) {
-                    if (offload && tk > 0 && tk <= QTW && lane < CPW) {
+                    if (offload && tk > 0 && tk <= QTW && lane < LPR) {
                         *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
                     }
                     qv.w = __int_as_float(-1);
@@ -1756,8 +1770,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             // so the 64 / CPW lanes that share a channel's column (lane = channel + CPW * slot) each test the
                             // samples k = slot, slot + 64 / CPW, ... and the owner takes the lowest set bit of the ballots: the
                             // first crossing, as the in-order search finds it.
-                            constexpr int EPL = 64 / CPW;
-                            const int oc = lane % CPW, slot = lane / CPW;
+                            constexpr int EPL = 64 / LPR;
+                            const int oc = lane % LPR, slot = lane / LPR;
                             const float hi_lim = s.maxref * 1.25f, lo_lim = s.minref * 1.25f;
                             const int need_o = __shfl((int)(can & (jit < 0)), oc);
                             const int clip_o = __shfl((int)in_a, oc);
@@ -1767,7 +1781,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             const int sp_o = __shfl(sp, oc);
                             const float cen_o = __shfl(s.center, oc), hl_o = __shfl(hi_lim, oc), ll_o = __shfl(lo_lim, oc);
                             const float mx_o = __shfl(s.max, oc), mn_o = __shfl(s.min, oc), ls_o = __shfl(s.lastsample, oc);
-                            const float* po = (flt_o ? &L.flt[oc][0] : &L.raw[oc][0]) + base + sp_o;
+                            const float* po = (flt_o ? &L.flt[rw * LPR + oc][0] : &L.raw[rw * LPR + oc][0]) + base + sp_o;
                             int found = -1;
 #pragma unroll
                             for (int r = 0; r < (12 + EPL - 1) / EPL; r++) {
@@ -1790,11 +1804,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 unsigned long long m = 0;
 #pragma unroll
                                 for (int e = 0; e < EPL; e++) {
-                                    m |= 1ull << (e * CPW);
+                                    m |= 1ull << (e * LPR);
                                 }
                                 col &= m;
                                 if (found < 0 && col != 0) {
-                                    found = (__ffsll((long long)col) - 1) / CPW + r * EPL;
+                                    found = (__ffsll((long long)col) - 1) / LPR + r * EPL;
                                 }
                             }
                             jit = (can & (jit < 0) & (found >= 0)) ? i0 + found : jit;
@@ -2089,10 +2103,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 dbg_kind = -1;
             }
             if (offload && lane == 0) {
-                L.qn[it & 1] = (tk - 1) < QTW ? (tk - 1) : QTW; // trips that may have queued (the last one broke out at its top)
+                L.qn[it & 1][rw] = (tk - 1) < QTW ? (tk - 1) : QTW; // trips that may have queued (the last one broke out at its top)
             }
             if (HM && lane == 0) {
-                __hip_atomic_store(&H.tile_done, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&H.tile_done[rw], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (live) {
                 L.sidx0[(it + 1) & 1][ln] = s.sidx;
@@ -2220,13 +2234,8 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
         if (whole < 6 || !hstate || !hh_store || !events || !n_events) {
             return hipErrorInvalidValue;
         }
-        if (cpw != 4 && cpw != 8 && cpw != 16) {
+        if (cpw != 8 && cpw != 16) {
             cpw = n_channels <= 8 * 512 ? 8 : 16;
-        }
-        if (cpw == 4) {
-            return launch_rxw<4, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
-                                       shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store,
-                                       events, n_events, st);
         }
         if (cpw == 8) {
             return launch_rxw<8, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
