@@ -49,6 +49,7 @@ struct ddn_p25_chain {
     int32_t *d_cnt_scan, *d_cnt_full;
     // decode buffers
     int32_t* d_nid;
+    uint8_t* d_cls; // frame type of every slot (DDN_CLS_*): the per-type decode launches only work on their own frames
     uint8_t *d_tsbk, *d_tsbk_crc;
     uint8_t *d_words[2], *d_wrel, *d_werrs, *d_vldu;
     uint8_t *d_rs_d[2], *d_rs_p[2], *d_rs_st[2];
@@ -93,7 +94,7 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     ddn_mbe_batch_destroy(c->mbe);
     void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_new[0], c->d_new[1], c->d_ev[0], c->d_ev[1],
                    c->d_nev[0], c->d_nev[1], c->d_evd[0], c->d_evd[1], c->d_evl[0], c->d_evl[1], c->d_evdl[0], c->d_evdl[1],
-                   c->d_nevl[0], c->d_nevl[1], c->d_cnt_scan, c->d_cnt_full, c->d_nid, c->d_tsbk, c->d_tsbk_crc, c->d_words[0],
+                   c->d_nevl[0], c->d_nevl[1], c->d_cnt_scan, c->d_cnt_full, c->d_nid, c->d_cls, c->d_tsbk, c->d_tsbk_crc, c->d_words[0],
                    c->d_words[1], c->d_wrel, c->d_werrs, c->d_vldu, c->d_rs_d[0], c->d_rs_d[1], c->d_rs_p[0], c->d_rs_p[1],
                    c->d_rs_st[0], c->d_rs_st[1], c->d_lsd, c->d_lsd_ok, c->d_lsd_llr, c->d_hdu_hex, c->d_hdu_par, c->d_hdu_st,
                    c->d_hdu_d, c->d_hdu_p, c->d_hdu_rs, c->d_td_d, c->d_td_p, c->d_td_st, c->d_td_rd, c->d_td_rp, c->d_td_rs,
@@ -178,7 +179,7 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
                  && dalloc(&c->d_ev[k], B * (size_t)c->E * 4) && dalloc(&c->d_nev[k], B) && dalloc(&c->d_evd[k], B * (size_t)c->E * 4)
                  && dalloc(&c->d_evl[k], B * (size_t)c->EL * 4) && dalloc(&c->d_evdl[k], B * (size_t)c->EL * 4) && dalloc(&c->d_nevl[k], B);
         }
-        ok = ok && dalloc(&c->d_cnt_scan, B) && dalloc(&c->d_cnt_full, B) && dalloc(&c->d_nid, S * 4)
+        ok = ok && dalloc(&c->d_cnt_scan, B) && dalloc(&c->d_cnt_full, B) && dalloc(&c->d_nid, S * 4) && dalloc(&c->d_cls, S)
              && dalloc(&c->d_tsbk, 3 * S * 12) && dalloc(&c->d_tsbk_crc, 3 * S) && dalloc(&c->d_words[0], S * 240)
              && dalloc(&c->d_words[1], S * 240) && dalloc(&c->d_wrel, S * 240) && dalloc(&c->d_werrs, S * 24) && dalloc(&c->d_vldu, S)
              && dalloc(&c->d_rs_d[0], S * 72) && dalloc(&c->d_rs_d[1], S * 96) && dalloc(&c->d_rs_p[0], S * 72)
@@ -227,7 +228,7 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
 
 // front end + receive loop of one call into buffer set `cur` on stream st (the carried tail is copied in first)
 static int
-chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st) {
+chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEvent_t before_loop = nullptr) {
     const int prev = cur ^ 1;
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[0], st));
@@ -237,6 +238,13 @@ chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st) {
     DDN_TRY(ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st));
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[1], st));
+    }
+    // The receive loop fills the device on its own (two workgroups per CU take its registers and LDS) and every workgroup runs
+    // for the whole launch: one that has to wait for a CU another kernel still holds makes the launch half as long again.  In the
+    // pipelined forms the loop therefore starts once the previous call's decode has drained; that decode overlaps this call's
+    // carry, front end and matched filter instead.
+    if (before_loop) {
+        HIP_TRY(hipStreamWaitEvent(st, before_loop, 0));
     }
     DDN_TRY(ddn_p25_rx_set_events(c->rx, c->d_ev[cur], c->d_nev[cur], (size_t)c->E));
     DDN_TRY(ddn_p25_rx_set_event_data(c->rx, c->d_evd[cur]));
@@ -269,28 +277,38 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
         const int32_t *d_ns = nullptr, *d_sp = nullptr;
         DDN_TRY(ddn_p25p1_framer_device_syncs(c->fr, &d_ns, &d_sp));
         HIP_TRY(ddn_dev_chain_frames(c->d_evl[cur], c->d_evdl[cur], c->d_nevl[cur], c->EL, d_sp, d_ns, c->B, c->F, c->off97[0],
-                                     c->off97[1], c->off97[2], c->d_nid, c->d_tsbk, c->d_tsbk_crc, st));
+                                     c->off97[1], c->off97[2], c->d_nid, c->d_tsbk, c->d_tsbk_crc, c->d_cls, st));
     }
+    // Every decode below is launched over all frame slots but works only on the slots whose NID names its frame type (d_cls): a
+    // slot's LDU / HDU / TDULC outputs are meaningful for that type alone.  The selection is cleared on every way out.
+    struct SelGuard {
+        ~SelGuard() { ddn_sel_clear(); }
+    } sel_guard;
     // LDU1 / LDU2: Hamming words -> Reed-Solomon; low speed data
     for (int i = 0; i < 2; i++) {
         const int ldu = i + 1;
+        ddn_sel_set(c->d_cls, i == 0 ? DDN_CLS_LDU1 : DDN_CLS_LDU2);
         DDN_TRY(ddn_p25p1_framer_gather_ldu_words(c->fr, ldu, rec, c->d_cnt_full, stride, c->d_words[i], c->d_wrel, c->d_vldu, st));
         DDN_TRY(ddn_fec_hamming_10_6_3_batch(c->d_words[i], S * 24, c->d_werrs, st));
         DDN_TRY(ddn_p25p1_framer_pack_ldu_rs(c->fr, ldu, c->d_words[i], c->d_rs_d[i], c->d_rs_p[i], st));
         DDN_TRY(ddn_fec_p25_rs_batch(i == 0 ? DDN_RS_24_12_13 : DDN_RS_24_16_9, c->d_rs_d[i], c->d_rs_p[i], S, c->d_rs_st[i], st));
     }
+    ddn_sel_set(c->d_cls, DDN_CLS_LDU1 | DDN_CLS_LDU2);
     DDN_TRY(ddn_p25p1_framer_gather_lsd(c->fr, rec, c->d_cnt_full, stride, c->d_lsd, c->d_lsd_llr, c->d_vldu, st));
     DDN_TRY(ddn_fec_p25_lsd_batch(c->d_lsd, c->d_lsd_llr, S * 2, c->d_lsd_ok, st));
     // HDU: 36 Golay(24,6) words -> RS(36,20,17)
+    ddn_sel_set(c->d_cls, DDN_CLS_HDU);
     DDN_TRY(ddn_p25p1_framer_gather_hdu(c->fr, rec, c->d_cnt_full, stride, c->d_hdu_hex, c->d_hdu_par, nullptr, nullptr, c->d_vldu, st));
     DDN_TRY(ddn_fec_golay24_batch(6, c->d_hdu_hex, c->d_hdu_par, S * 36, c->d_hdu_st, nullptr, st));
     DDN_TRY(ddn_p25p1_framer_pack_hdu_rs(c->fr, c->d_hdu_hex, c->d_hdu_d, c->d_hdu_p, st));
     DDN_TRY(ddn_fec_p25_rs_batch(DDN_RS_36_20_17, c->d_hdu_d, c->d_hdu_p, S, c->d_hdu_rs, st));
     // TDULC: 12 Golay(24,12) words -> RS(24,12,13)
+    ddn_sel_set(c->d_cls, DDN_CLS_TDULC);
     DDN_TRY(ddn_p25p1_framer_gather_tdulc(c->fr, rec, c->d_cnt_full, stride, c->d_td_d, c->d_td_p, nullptr, nullptr, c->d_vldu, st));
     DDN_TRY(ddn_fec_golay24_batch(12, c->d_td_d, c->d_td_p, S * 12, c->d_td_st, nullptr, st));
     DDN_TRY(ddn_p25p1_framer_pack_tdulc_rs(c->fr, c->d_td_d, c->d_td_rd, c->d_td_rp, st));
     DDN_TRY(ddn_fec_p25_rs_batch(DDN_RS_24_12_13, c->d_td_rd, c->d_td_rp, S, c->d_td_rs, st));
+    ddn_sel_clear();
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[4], st));
     }
@@ -355,7 +373,7 @@ ddn_p25_chain_run_pipelined(ddn_p25_chain* c, const void* d_iq) {
     if (c->step >= 2) { // the decode of call k - 2 has read this set (and call k - 1's decode has read its carried tail source)
         HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_consumed[cur], 0));
     }
-    DDN_TRY(chain_receive(c, d_iq, cur, c->s_main));
+    DDN_TRY(chain_receive(c, d_iq, cur, c->s_main, c->step >= 1 ? c->ev_consumed[cur ^ 1] : nullptr));
     HIP_TRY(hipEventRecord(c->ev_produced[cur], c->s_main));
     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_produced[cur], 0));
     DDN_TRY(chain_decode(c, cur, 0, c->s_aux));
@@ -385,7 +403,7 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
         HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_consumed[cur], 0)); // call k - 2 decoded out of this set ...
         HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_out[cur], 0));      // ... and its results have left it
     }
-    DDN_TRY(chain_receive(c, c->d_iq[cur], cur, c->s_main));
+    DDN_TRY(chain_receive(c, c->d_iq[cur], cur, c->s_main, c->step >= 1 ? c->ev_consumed[cur ^ 1] : nullptr));
     HIP_TRY(hipEventRecord(c->ev_in_free[cur], c->s_main));
     HIP_TRY(hipEventRecord(c->ev_produced[cur], c->s_main));
     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_produced[cur], 0));

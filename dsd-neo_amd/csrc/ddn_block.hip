@@ -101,10 +101,13 @@ k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel
 // bits10: [n][10] one bit per byte, 6 data bits then 4 parity bits.  data6 (in place: the first 6 bytes of each
 // row) is rewritten only for single-bit corrections, exactly like hamming_10_6_3_decode(); errs[n] = 0/1/2.
 __global__ void
-k_hamming_10_6_3(uint8_t* __restrict__ bits10, int n, uint8_t* __restrict__ errs) {
+k_hamming_10_6_3(uint8_t* __restrict__ bits10, int n, uint8_t* __restrict__ errs, DdnSel sel) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) {
         return;
+    }
+    if (sel.cls && !(sel.cls[c / sel.per_slot] & sel.mask)) {
+        return; // not a frame of the type this launch is for
     }
     uint8_t* b = bits10 + (size_t)c * 10;
     int word = 0;
@@ -300,7 +303,7 @@ ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_hamming_10_6_3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits10, n, errs);
+    hipLaunchKernelGGL(k_hamming_10_6_3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits10, n, errs, ddn_sel_for(24));
     return hipGetLastError();
 }
 
@@ -341,10 +344,13 @@ lsd_hard(int word) {
 }
 
 __global__ void
-k_p25_lsd(uint8_t* __restrict__ bits16, const int16_t* __restrict__ llr16, int n, uint8_t* __restrict__ ok) {
+k_p25_lsd(uint8_t* __restrict__ bits16, const int16_t* __restrict__ llr16, int n, uint8_t* __restrict__ ok, DdnSel sel) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) {
         return;
+    }
+    if (sel.cls && !(sel.cls[i / sel.per_slot] & sel.mask)) {
+        return; // not a frame of the type this launch is for
     }
     uint8_t* b = bits16 + (size_t)i * 16;
     int word = 0;
@@ -408,7 +414,7 @@ ddn_dev_p25_lsd(uint8_t* bits16, const int16_t* llr16, int n, uint8_t* ok, hipSt
     if (n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_lsd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits16, llr16, n, ok);
+    hipLaunchKernelGGL(k_p25_lsd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits16, llr16, n, ok, ddn_sel_for(2));
     return hipGetLastError();
 }
 

@@ -91,7 +91,8 @@ k_chain_events(const int32_t* __restrict__ list_prev, const int32_t* __restrict_
 __global__ void
 k_chain_frames(const int32_t* __restrict__ list, const int32_t* __restrict__ data, const int32_t* __restrict__ n_list, int EL,
                const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_syncs, int n_channels, int F, int off0, int off1,
-               int off2, int32_t* __restrict__ nid4, uint8_t* __restrict__ tsbk, uint8_t* __restrict__ tsbk_crc) {
+               int off2, int32_t* __restrict__ nid4, uint8_t* __restrict__ tsbk, uint8_t* __restrict__ tsbk_crc,
+               uint8_t* __restrict__ cls) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_channels) {
         return;
@@ -102,6 +103,7 @@ k_chain_frames(const int32_t* __restrict__ list, const int32_t* __restrict__ dat
     for (int k = 0; k < F; k++) {
         const size_t slot = (size_t)c * F + k;
         reinterpret_cast<int4*>(nid4)[slot] = make_int4(0, 0, 0, 0);
+        cls[slot] = 0;
         for (int b = 0; b < 3; b++) {
             uint32_t* o = reinterpret_cast<uint32_t*>(tsbk + ((size_t)b * S + slot) * 12);
             o[0] = o[1] = o[2] = 0;
@@ -129,6 +131,9 @@ k_chain_frames(const int32_t* __restrict__ list, const int32_t* __restrict__ dat
         const size_t slot = (size_t)c * F + k;
         if (e.y == 1) {
             reinterpret_cast<int4*>(nid4)[slot] = v;
+            // frame type for the per-type decode launches that follow (DDN_CLS_*): only a decoded NID names one
+            const int duid = v.z;
+            cls[slot] = v.x > 0 ? (uint8_t)(duid == 0x5 ? 1 : (duid == 0xA ? 2 : (duid == 0x0 ? 4 : (duid == 0xF ? 8 : 0)))) : 0;
         } else if (blk < 3) {
             uint32_t* o = reinterpret_cast<uint32_t*>(tsbk + ((size_t)blk * S + slot) * 12);
             o[0] = (uint32_t)v.x;
@@ -218,6 +223,24 @@ k_tsbk_select(const uint8_t* __restrict__ cand, const int32_t* __restrict__ coun
 
 } // namespace
 
+static thread_local DdnSel g_sel = {nullptr, 0, 1};
+extern "C" void
+ddn_sel_set(const uint8_t* cls, int mask) {
+    g_sel.cls = cls;
+    g_sel.mask = mask;
+}
+extern "C" void
+ddn_sel_clear(void) {
+    g_sel.cls = nullptr;
+    g_sel.mask = 0;
+}
+extern "C" DdnSel
+ddn_sel_for(int per_slot) {
+    DdnSel r = g_sel;
+    r.per_slot = per_slot > 0 ? per_slot : 1;
+    return r;
+}
+
 extern "C" hipError_t
 ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, const int32_t* cnt_prev, int have_prev, uint8_t* rec_cur,
                     uint8_t* fl_cur, size_t stride_sym, int T, int n_channels, hipStream_t st) {
@@ -254,12 +277,12 @@ ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_prev, const i
 extern "C" hipError_t
 ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
                      const int32_t* n_syncs, int n_channels, int F, int off0, int off1, int off2, int32_t* nid4, uint8_t* tsbk,
-                     uint8_t* tsbk_crc, hipStream_t st) {
+                     uint8_t* tsbk_crc, uint8_t* cls, hipStream_t st) {
     if (n_channels <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_chain_frames, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, list, data, n_list, EL, sync_pos,
-                       n_syncs, n_channels, F, off0, off1, off2, nid4, tsbk, tsbk_crc);
+                       n_syncs, n_channels, F, off0, off1, off2, nid4, tsbk, tsbk_crc, cls);
     return hipGetLastError();
 }
 

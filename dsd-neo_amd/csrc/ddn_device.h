@@ -261,6 +261,17 @@ hipError_t ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, i
 hipError_t ddn_dev_launch_carry(const void* in, int in_fmt, size_t ch_stride, long n, void* carry, int n_channels,
                                 hipStream_t st);
 hipError_t ddn_dev_zero(void* p, size_t bytes, hipStream_t st);
+/* Frame-slot selection for the per-slot framer / FEC launches of a chain (ddn_api_chain.cpp): cls [slots] carries one bit per
+ * frame type, a launch made while a selection is set only works on the slots whose byte has a bit of `mask` (the others' outputs are
+ * left as they are).  Thread-local, set around the launches it is meant for; {NULL, 0, 1} = every item. */
+typedef struct DdnSel {
+    const uint8_t* cls;
+    int mask;
+    int per_slot; /* items of this launch per frame slot */
+} DdnSel;
+void ddn_sel_set(const uint8_t* cls, int mask);
+void ddn_sel_clear(void);
+DdnSel ddn_sel_for(int per_slot);
 hipError_t ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, const int32_t* cnt_prev, int have_prev,
                                uint8_t* rec_cur, uint8_t* fl_cur, size_t stride_sym, int T, int n_channels, hipStream_t st);
 hipError_t ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, int flush, int32_t* cnt_scan, int32_t* cnt_full,
@@ -270,7 +281,8 @@ hipError_t ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_pr
                                 int n_channels, int32_t* list_cur, int32_t* data_cur, int32_t* n_cur, hipStream_t st);
 hipError_t ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
                                 const int32_t* n_syncs, int n_channels, int F, int off0, int off1, int off2, int32_t* nid4,
-                                uint8_t* tsbk, uint8_t* tsbk_crc, hipStream_t st);
+                                uint8_t* tsbk, uint8_t* tsbk_crc, uint8_t* cls, hipStream_t st);
+enum { DDN_CLS_LDU1 = 1, DDN_CLS_LDU2 = 2, DDN_CLS_HDU = 4, DDN_CLS_TDULC = 8 }; /* frame-type bits of a slot's class byte */
 hipError_t ddn_dev_nxdn_voice_select(const int32_t* sync_pos, const int32_t* n_sync, const uint8_t* lich, const uint8_t* valid,
                                      int n_channels, int my, int vf, int32_t* v_pos, int32_t* v_n, uint8_t* skip4, hipStream_t st);
 hipError_t ddn_dev_u8_shr1(const uint8_t* in, size_t n, uint8_t* out, hipStream_t st);

@@ -48,11 +48,14 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
                 int max_frames, const int32_t* __restrict__ offsets, int n_off, int max_off, uint8_t* __restrict__ bits,
                 uint8_t* __restrict__ rel, int16_t* __restrict__ llr, int stride, int split_last,
                 uint8_t* __restrict__ last_bit, uint8_t* __restrict__ last_rel, uint8_t* __restrict__ valid,
-                uint8_t* __restrict__ dibits, uint8_t* __restrict__ dibit_rel) {
+                uint8_t* __restrict__ dibits, uint8_t* __restrict__ dibit_rel, DdnSel sel) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const long slot = t / n_off;
     const int i = (int)(t % n_off);
     if (slot >= (long)n_channels * max_frames) {
+        return;
+    }
+    if (sel.cls && !(sel.cls[slot] & sel.mask)) {
         return;
     }
     const int ch = (int)(slot / max_frames), k = (int)(slot % max_frames);
@@ -140,7 +143,7 @@ ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32_t* counts,
     }
     hipLaunchKernelGGL(k_gather_fields, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rec, max_sym, counts,
                        sync_pos, n_syncs, n_channels, max_frames, offsets, n_off, max_off, bits, rel, llr, stride,
-                       split_last, last_bit, last_rel, valid, dibits, dibit_rel);
+                       split_last, last_bit, last_rel, valid, dibits, dibit_rel, ddn_sel_for(1));
     return hipGetLastError();
 }
 
@@ -170,13 +173,16 @@ namespace {
 // (LDU1 p25p1_ldu1.c:233-245, LDU2 p25p1_ldu2.c:256-262, HDU p25p1_hdu.c:252-270)
 __global__ void
 k_rs_pack(const uint8_t* __restrict__ words, long n_slots, int n_words, int wstride, int n_data,
-          uint8_t* __restrict__ data, uint8_t* __restrict__ parity) {
+          uint8_t* __restrict__ data, uint8_t* __restrict__ parity, DdnSel sel) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const int per = n_words * 6;
     if (t >= n_slots * per) {
         return;
     }
     const long slot = t / per;
+    if (sel.cls && !(sel.cls[slot] & sel.mask)) {
+        return;
+    }
     const int r = (int)(t % per), w = r / 6, b = r % 6;
     const uint8_t v = words[(slot * n_words + w) * (long)wstride + b];
     if (w < n_data) {
@@ -194,7 +200,7 @@ ddn_dev_rs_pack(const uint8_t* words, long n_slots, int n_words, int wstride, in
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_rs_pack, dim3((unsigned)((n_slots * n_words * 6 + 255) / 256)), dim3(256), 0, st, words, n_slots,
-                       n_words, wstride, n_data, data, parity);
+                       n_words, wstride, n_data, data, parity, ddn_sel_for(1));
     return hipGetLastError();
 }
 
@@ -203,12 +209,16 @@ namespace {
 // the two hex halves of every dodeca word swapped (swap_hex_words, p25p1_tdulc.c:47-72,210-213): hex 2i = bits 6..11,
 // hex 2i + 1 = bits 0..5 of word i
 __global__ void
-k_tdulc_rs_pack(const uint8_t* __restrict__ words, long n_slots, uint8_t* __restrict__ data, uint8_t* __restrict__ parity) {
+k_tdulc_rs_pack(const uint8_t* __restrict__ words, long n_slots, uint8_t* __restrict__ data, uint8_t* __restrict__ parity,
+                DdnSel sel) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_slots * 144) {
         return;
     }
     const long slot = t / 144;
+    if (sel.cls && !(sel.cls[slot] & sel.mask)) {
+        return;
+    }
     const int r = (int)(t % 144), hexw = r / 6, b = r % 6; // hexw 0..11 data, 12..23 parity
     const int dodeca = hexw / 2, half = hexw & 1;
     const uint8_t v = words[(slot * 12 + dodeca) * 12 + (half ? b : 6 + b)];
@@ -226,7 +236,7 @@ ddn_dev_tdulc_rs_pack(const uint8_t* words, long n_slots, uint8_t* data, uint8_t
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_tdulc_rs_pack, dim3((unsigned)((n_slots * 144 + 255) / 256)), dim3(256), 0, st, words, n_slots,
-                       data, parity);
+                       data, parity, ddn_sel_for(1));
     return hipGetLastError();
 }
 

@@ -52,7 +52,7 @@ k_golay_table(uint32_t* __restrict__ tab) {
 
 __global__ __launch_bounds__(256) void
 k_golay24(uint8_t* __restrict__ data, const uint8_t* __restrict__ parity, int len, int n,
-          const uint32_t* __restrict__ tab_g, uint8_t* __restrict__ status, int32_t* __restrict__ fixed) {
+          const uint32_t* __restrict__ tab_g, uint8_t* __restrict__ status, int32_t* __restrict__ fixed, DdnSel sel) {
     __shared__ uint32_t tab[2048];
     for (int i = threadIdx.x; i < 2048; i += 256) {
         tab[i] = tab_g[i];
@@ -61,6 +61,9 @@ k_golay24(uint8_t* __restrict__ data, const uint8_t* __restrict__ parity, int le
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) {
         return;
+    }
+    if (sel.cls && !(sel.cls[i / sel.per_slot] & sel.mask)) {
+        return; // not a frame of the type this launch is for
     }
     uint8_t* d = data + (size_t)i * len;
     const uint8_t* p = parity + (size_t)i * 12;
@@ -110,7 +113,7 @@ k_golay24(uint8_t* __restrict__ data, const uint8_t* __restrict__ parity, int le
 
 __global__ __launch_bounds__(64) void
 k_rs63(uint8_t* __restrict__ data6, const uint8_t* __restrict__ parity6, int n_par, int n_data, int t, int n,
-       uint8_t* __restrict__ status) {
+       uint8_t* __restrict__ status, DdnSel sel) {
     __shared__ uint8_t ex[128], lg[64];
     __shared__ uint8_t W[36][64];                   // received symbols
     __shared__ uint8_t S[17][64], Cc[18][64], Bb[18][64], Tt[18][64], Om[16][64], Pos[8][64];
@@ -134,6 +137,9 @@ k_rs63(uint8_t* __restrict__ data6, const uint8_t* __restrict__ parity6, int n_p
     const int i = blockIdx.x * 64 + lane;
     if (i >= n) {
         return;
+    }
+    if (sel.cls && !(sel.cls[i / sel.per_slot] & sel.mask)) {
+        return; // not a frame of the type this launch is for (no block-wide barrier follows)
     }
     auto gmul = [&](int a, int b) -> int { return (a && b) ? ex[lg[a] + lg[b]] : 0; };
     auto gdiv = [&](int a, int b) -> int { return a ? ex[lg[a] + 63 - lg[b]] : 0; };
@@ -974,7 +980,7 @@ ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* s
         return e0;
     }
     hipLaunchKernelGGL(k_golay24, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, parity, len, n,
-                       (const uint32_t*)tab, status, fixed);
+                       (const uint32_t*)tab, status, fixed, ddn_sel_for(len == 6 ? 36 : 12));
     return hipGetLastError();
 }
 
@@ -985,7 +991,7 @@ ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int 
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_rs63, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, data6, parity6, n_par, n_data, t, n,
-                       status);
+                       status, ddn_sel_for(1));
     return hipGetLastError();
 }
 

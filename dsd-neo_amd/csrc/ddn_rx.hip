@@ -1600,10 +1600,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             frame_end();
                         }
                     }
-                    // While a lane waits, the wave waits with it: the lanes share their trips, and one that falls behind has to
-                    // make up its symbols in trips of its own afterwards (measured: letting the others run ahead costs about
-                    // three times the decision's latency, standing still costs it once).
-                    if (__any(hwait) && !(cfg.dbg & 262144)) {
+                    // With eight lanes per wave the wave waits with a waiting lane: the lanes share their trips, and one that falls
+                    // behind has to make up its symbols in trips of its own afterwards (measured: letting the others run ahead costs
+                    // about three times the decision's latency, standing still costs it once).  With four lanes per wave the others
+                    // go on (measured 9.47 against 9.66 ms): fewer lanes share the trips a straggler adds.
+                    if (__any(hwait) && (LPR > 4) != ((cfg.dbg & 262144) != 0)) {
                         __builtin_amdgcn_s_sleep(1);
                         continue;
                     }

@@ -55,6 +55,8 @@ typedef struct ddn_p25_chain_results {
     const int32_t* d_nid4;      /* [S][4] status, NAC, DUID, corrected bits */
     const uint8_t* d_tsbk;      /* [3][S][12] decoded TSDU blocks 0..2 */
     const uint8_t* d_tsbk_crc;  /* [3][S] CRC16 good */
+    /* the per-frame-type outputs below are written for the slots whose NID names that type (DUID 5 / A / 0 / F, status > 0) and are
+     * left untouched for every other slot */
     const uint8_t* d_ldu_words[2];  /* [S][24][10] Hamming-corrected words of LDU1 / LDU2 */
     const uint8_t* d_ldu_rs_data[2]; /* [S][12][6] / [S][16][6] after Reed-Solomon */
     const uint8_t* d_ldu_rs_status[2]; /* [S] */
