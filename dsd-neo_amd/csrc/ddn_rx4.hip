@@ -346,6 +346,37 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const float* rrow = &L.raw[ln][0];
     const float* frow = &L.flt[ln][0];
     const int n_tiles = (n + TSW - 1) / TSW;
+    // Matched-filter cold start.  For the NT - 1 samples after the filter is gated on its output is a FIR over the filter's stale
+    // memory followed by the new samples (the always-on stream in `filt` assumes the raw samples before it instead).  Those
+    // outputs do not depend on anything the recurrence does, so the whole wavefront computes them - each one the same ordered sum
+    // as the reference's filter, one output per lane - straight into the staged LDS rows, tile by tile as the tiles arrive,
+    // instead of one lane working through NT taps per sample (in noise a first sync-word match, which gates the NXDN filter on
+    // before the second match confirms it, comes along every ~100 symbols: that path was most of the hunting time).
+    long long cold_fs = -1; // filt_start these outputs belong to (-1: none; a cold start inherited from the previous call is not)
+    int cold_p0 = 0, cold_next = 0, cold_end = 0;
+    auto cold_fill = [&](int limit) {
+        unsigned long long m = __ballot(live && cold_fs >= 0 && cold_next < (cold_end < limit ? cold_end : limit));
+        while (m) {
+            const int c = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int p0 = __shfl(cold_p0, c), a = __shfl(cold_next, c), e0 = __shfl(cold_end, c);
+            const int e = e0 < limit ? e0 : limit;
+            const float* fsrc = fstale + (size_t)(ch0 + c) * (DDN_FSK4_MAX_TAPS - 1);
+            const float* rw = raw + (size_t)(ch0 + c) * stride;
+            for (int jp = a + lane; jp < e; jp += 64) {
+                float acc = 0.0f;
+                for (int i = 0; i < NT; i++) {
+                    const int idx = jp - (NT - 1) + i; // call-relative; new samples from p0 on, the stale memory before it
+                    const float v = idx >= p0 ? rw[idx] : fsrc[(idx - p0) + (NT - 1)];
+                    acc += taps[i] * v;
+                }
+                L.flt[c][jp & RMASKW] = acc;
+            }
+            if (lane == c) {
+                cold_next = e;
+            }
+        }
+    };
     for (int t = 0; t < n_tiles; t++) {
         const int tile_end = (t + 1) * TSW < n ? (t + 1) * TSW : n; // symbols starting before this index belong to this round
         const int lim = (t + 2) * TSW < n ? (t + 2) * TSW : n;       // samples staged so far
@@ -358,6 +389,9 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
             int guard = 0, qk = 0;
             if (live) {
                 L.qo[t & 1][ln] = o;
+            }
+            if (use_flt) {
+                cold_fill(lim); // the part of a pending cold start that lies in the tile staged during the previous round
             }
             auto snapshot_filter = [&]() { // the filter's memory at the moment it is gated off
                 if (!s.filter_on) {
@@ -447,7 +481,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     const bool fo_l = s.filter_on != 0;
                     const bool lean = live & (s.in_symbol == 0) & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left >= 1)
                                       & (s.need_reset == 0) & (pos < tile_end) & (pos + whole <= lim) & (qk < QCAPW - 2)
-                                      & (!fo_l | ((abs0 + pos - s.filt_start) >= (long long)(NT - 1)));
+                                      & (!fo_l | ((abs0 + pos - s.filt_start) >= (long long)(NT - 1)) | (cold_fs == s.filt_start));
                     const bool idle = live & (s.in_symbol == 0) & !(pos < tile_end);
                     if (!__any(live & !(lean | idle)) && __any(lean)) {
                         if (lean) {
@@ -558,7 +592,8 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const bool clip = s.have_sync && cfg.rf_mod == 0;
                 // per-symbol constants: which staged row feeds the symbol, the window as integer bounds
                 const bool fo_now = s.filter_on != 0;
-                const bool steady = !fo_now || (cfg.dbg & 128) || (abs0 + pos - s.filt_start) >= (long long)(NT - 1);
+                const bool steady = !fo_now || (cfg.dbg & 128) || (abs0 + pos - s.filt_start) >= (long long)(NT - 1)
+                                    || cold_fs == s.filt_start;
                 const float* rowp = fo_now ? frow : rrow;
                 const bool rf0 = cfg.rf_mod == 0;
                 const bool lean = s.span >= 6;
@@ -617,7 +652,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         float x;
                         if (!fo_now) {
                             x = rrow[pos & RMASKW];
-                        } else if ((cfg.dbg & 128) || (abs0 + pos - s.filt_start) >= (long long)(NT - 1)) {
+                        } else if ((cfg.dbg & 128) || (abs0 + pos - s.filt_start) >= (long long)(NT - 1) || cold_fs == s.filt_start) {
                             x = frow[pos & RMASKW];
                         } else { // first NT-1 samples after the enable: FIR over the filter's stale memory + new samples
                             float acc = 0.0f;
@@ -742,6 +777,12 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 if (use_flt && !s.filter_on) {
                                     s.filter_on = 1;
                                     s.filt_start = abs0 + pos;
+                                    if (!(cfg.dbg & 2048)) {
+                                        cold_fs = s.filt_start;
+                                        cold_p0 = pos;
+                                        cold_next = pos;
+                                        cold_end = (pos + (NT - 1)) < n ? (pos + (NT - 1)) : n;
+                                    }
                                 }
                                 if (accepted) {
                                     const int wl = cfg.redigitize ? 24 : cfg.warm_len;
@@ -844,6 +885,9 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         }
                     }
                     o++;
+                }
+                if (use_flt) {
+                    cold_fill(lim); // a filter gated on in this trip: its cold outputs inside the tiles staged so far
                 }
                 const bool busy = live && pos < tile_end && !s.in_symbol;
                 if (!__any(busy) || ++guard > 4 * TSW) {

@@ -21,10 +21,12 @@ def main():
     l = ddn.lib()
     for name, cap, lpf, proto, rf in (("dmr c4fm", "iq_dmr_t3_ras_cc.npz", 2, ddn.FSK4_DMR, 0), ("dmr gfsk", "iq_dmr_t3_ras_cc.npz", 2, ddn.FSK4_DMR, 2),
                                       ("nxdn48", "iq_nxdn48.npz", 1, ddn.FSK4_NXDN48, 0)):
+        if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+            continue
         disc = torch.from_numpy(rx4.capture_disc(cap, lpf)[:n + 4096]).cuda()
         idx = (torch.arange(n, device="cuda")[None, :] + (torch.arange(B, device="cuda")[:, None] * 37) % 4096)
         x = disc[idx].contiguous()
-        rx = ddn.Fsk4Rx(B, proto, rf_mod=rf)
+        rx = ddn.Fsk4Rx(B, proto, rf_mod=rf, handlers=bool(int(os.environ.get("HANDLERS", "0"))))
         ms, my = l.ddn_fsk4_rx_max_symbols(rx.h, n), l.ddn_fsk4_rx_max_syncs(rx.h, n)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
         rec, fl, pay = z((B, ms, 10), torch.uint8), z((B, ms), torch.uint8), z((B, ms, 2), torch.uint8)
@@ -39,7 +41,8 @@ def main():
             assert l.ddn_fsk4_rx_get_timing(rx.h, t.ctypes.data) == 0
             ts.append(t.copy())
         t = np.median(np.stack(ts[2:]), axis=0)
-        print("%-9s B=%d n=%d: matched filter %.3f ms, loop %.3f ms, syncs/ch %.1f, symbols/ch %.0f" % (name, B, n, t[0], t[1], float(ns.float().mean()), float(cnt.float().mean())))
+        print("%-9s B=%d n=%d: matched filter %.3f ms, loop %.3f ms, syncs/ch %.1f, symbols/ch %.0f, in-frame share %.3f" % (
+            name, B, n, t[0], t[1], float(ns.float().mean()), float(cnt.float().mean()), float((fl & 1).float().sum() / cnt.float().sum())))
 
 
 if __name__ == "__main__":
