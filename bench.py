@@ -467,7 +467,9 @@ def main():
                                       "2 HIP streams inside the C object: frame FEC + vocoder of step k overlap front end + receive "
                                       "loop of step k+1 (double-buffered loop outputs)") + "; every stage of every step inside the "
                                      "timed region",
-                       "vocoder_tables": "synthetic default blob (include/ddn_mbe.h); mbelib-neo absent -> vocoder parity unpinned"},
+                       "vocoder_tables": ("synthetic = %d as ddn_mbe_batch_tables_synthetic reports it: the built-in placeholder blob "
+                                          "(include/ddn_mbe.h; a real blob loads with ddn_mbe_batch_load_tables_file); mbelib-neo absent -> "
+                                          "vocoder parity unpinned" % l.ddn_mbe_batch_tables_synthetic(chain.mbe))},
             "parity": parity,
             "work_per_step": work,
             "stages_ms": {"front_end": round(float(stage_ms[0]), 3), "receive_loop": round(float(stage_ms[1]), 3),
@@ -545,22 +547,24 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
             continue
         ch = m.part(which)
         r = ch.results()
-        ms, my = r.max_symbols, r.max_syncs
+        st, T, my = r.stride_symbols, r.carry_symbols, r.max_syncs
         f = ch.fetch
-        rec, fl, pay = f(r.d_records10, np.uint8, (Bc, ms, 10)), f(r.d_flags, np.uint8, (Bc, ms)), f(r.d_payload2, np.uint8, (Bc, ms, 2))
-        cnt, ns = f(r.d_counts, np.int32, (Bc,)), f(r.d_n_sync, np.int32, (Bc,))
+        rec, fl, pay = f(r.d_records10, np.uint8, (Bc, st, 10)), f(r.d_flags, np.uint8, (Bc, st)), f(r.d_payload2, np.uint8, (Bc, st, 2))
+        new, ns = f(r.d_new, np.int32, (Bc,)), f(r.d_n_sync, np.int32, (Bc,))
         spos, pre = f(r.d_sync_pos, np.int32, (Bc, my)), f(r.d_pre, np.uint8, (Bc, my, 90))
         res[which] = (ch, r, ns, my)
         for c in sorted(set([0, Bc // 2, Bc - 1])):
             x = iq[offs[c]:offs[c] + n]
             disc = orc.OracleFrontEnd(profile=lpf).run_cu8(np.ascontiguousarray(x), BLOCK)
-            want = rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf, handler=1)).run(disc, max_sync=my)
-            k = int(cnt[c])
-            rr = rec[c, :k]
+            want = rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf, handler=1)).run(disc, max_sync=512)
+            k = int(new[c])
+            rr = rec[c, T:T + k]
+            # the syncs decoded in this first call: the ones whose burst / frame the call's records complete (the rest wait in the carry)
+            first = [j for j, p in enumerate(want["sync_pos"]) if int(p) + T < k]
             ok = (k == len(want["sym"]) and np.array_equal(rr[:, 6:10].copy().view(np.uint32).reshape(-1), want["sym"].view(np.uint32))
-                  and np.array_equal(rr[:, 0].astype(np.int32), want["rec4"][:, 0]) and np.array_equal(fl[c, :k], want["fl"])
-                  and np.array_equal(pay[c, :k], want["pay"]) and int(ns[c]) == len(want["sync_pos"])
-                  and np.array_equal(spos[c, :int(ns[c])], want["sync_pos"]) and np.array_equal(pre[c, :int(ns[c])], want["pre"]))
+                  and np.array_equal(rr[:, 0].astype(np.int32), want["rec4"][:, 0]) and np.array_equal(fl[c, T:T + k], want["fl"])
+                  and np.array_equal(pay[c, T:T + k], want["pay"]) and int(ns[c]) == len(first)
+                  and np.array_equal(spos[c, :int(ns[c])] - T, want["sync_pos"][first]) and np.array_equal(pre[c, :int(ns[c])], want["pre"][first]))
             par_ok = par_ok and bool(ok)
             checked += 1
     cc_ok = nx_ok = None
@@ -571,7 +575,7 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
         valid, st_ok = ch.fetch(r.d_valid, np.uint8, (S,)), ch.fetch(r.d_dmr_slot_type_ok, np.uint8, (S,))
         stb, errs = ch.fetch(r.d_dmr_slot_type, np.uint8, (S, 20)), ch.fetch(r.d_dmr_bptc_errs, np.uint32, (S,))
         rows = np.flatnonzero(valid)
-        rows = rows[(rows % my) != 0]
+        rows = rows[(rows % my) != 0]        # a fresh stream's first burst falls in the filter's cold start
         cc_ok = bool(len(rows) > 0 and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0) and np.mean(errs[rows] == 0) > 0.99)
     if 2 in res:   # NXDN48: LICH parity and SACCH CRC6 (soft decode or the greedy retry) on the complete frames
         ch, r, ns, my = res[2]

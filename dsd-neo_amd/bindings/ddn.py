@@ -430,6 +430,10 @@ class P25ChainHostOut(C.Structure):  # == ddn_p25_chain_host_out
 
 
 PROTOTYPES.update({
+    "ddn_mbe_tables_save_file": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "ddn_mbe_tables_load_file": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "ddn_mbe_batch_load_tables_file": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "ddn_mbe_batch_tables_synthetic": (C.c_int, [C.c_void_p]),
     "ddn_p25_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_chain_destroy": (None, [C.c_void_p]),
     "ddn_p25_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -464,8 +468,8 @@ class Fsk4ChainConfig(C.Structure):  # == ddn_fsk4_chain_config
 
 
 class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
-    _fields_ = [("max_symbols", C.c_size_t), ("max_syncs", C.c_size_t), ("voice_slots", C.c_int)] + [
-        (k, C.c_void_p) for k in ("d_records10", "d_flags", "d_payload2", "d_counts", "d_n_sync", "d_sync_pos", "d_sync_pat", "d_pre",
+    _fields_ = [("stride_symbols", C.c_size_t), ("carry_symbols", C.c_size_t), ("max_syncs", C.c_size_t), ("voice_slots", C.c_int)] + [
+        (k, C.c_void_p) for k in ("d_records10", "d_flags", "d_payload2", "d_new", "d_counts", "d_n_sync", "d_sync_pos", "d_sync_pat", "d_pre",
                                   "d_valid", "d_dmr_slot_type", "d_dmr_slot_type_ok", "d_dmr_pdu96", "d_dmr_bptc_errs", "d_nxdn_lich",
                                   "d_nxdn_sacch", "d_nxdn_sacch_ok", "d_nxdn_sacch_hard", "d_nxdn_sacch_hard_ok", "d_nxdn_facch",
                                   "d_nxdn_facch_ok", "d_nxdn_voice_skip", "d_nxdn_ambe_bits", "d_nxdn_pcm")]
@@ -477,10 +481,13 @@ class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config
 
 
 PROTOTYPES.update({
+    "ddn_p25_chain_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_fsk4_chain_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_fsk4_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_fsk4_chain_destroy": (None, [C.c_void_p]),
     "ddn_fsk4_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_fsk4_chain_get_results": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_fsk4_chain_flush": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_fsk4_chain_front_end": (C.c_void_p, [C.c_void_p]),
     "ddn_fsk4_chain_rx": (C.c_void_p, [C.c_void_p]),
     "ddn_mixed_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -527,6 +534,9 @@ class Fsk4ChainC:
 
     def run(self, d_iq_ptr, stream=None):
         _check(lib().ddn_fsk4_chain_run(self.h, d_iq_ptr, stream), "ddn_fsk4_chain_run")
+
+    def flush(self, stream=None):
+        _check(lib().ddn_fsk4_chain_flush(self.h, stream), "ddn_fsk4_chain_flush")
 
     def results(self):
         r = Fsk4ChainResults()

@@ -226,9 +226,9 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
     return DDN_OK;
 }
 
-// front end + receive loop of one call into buffer set `cur` on stream st (the carried tail is copied in first)
+// carry + front end of one call into buffer set `cur` on stream st
 static int
-chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEvent_t before_loop = nullptr) {
+chain_front(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st) {
     const int prev = cur ^ 1;
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[0], st));
@@ -239,13 +239,12 @@ chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEv
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[1], st));
     }
-    // The receive loop fills the device on its own (two workgroups per CU take its registers and LDS) and every workgroup runs
-    // for the whole launch: one that has to wait for a CU another kernel still holds makes the launch half as long again.  In the
-    // pipelined forms the loop therefore starts once the previous call's decode has drained; that decode overlaps this call's
-    // carry, front end and matched filter instead.
-    if (before_loop) {
-        HIP_TRY(hipStreamWaitEvent(st, before_loop, 0));
-    }
+    return DDN_OK;
+}
+
+// the receive loop of that call
+static int
+chain_loop(ddn_p25_chain* c, int cur, hipStream_t st) {
     DDN_TRY(ddn_p25_rx_set_events(c->rx, c->d_ev[cur], c->d_nev[cur], (size_t)c->E));
     DDN_TRY(ddn_p25_rx_set_event_data(c->rx, c->d_evd[cur]));
     // the loop writes its records behind the T carried ones: row pointer + T records, row stride unchanged
@@ -255,6 +254,20 @@ chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEv
         HIP_TRY(hipEventRecord(c->ev_t[2], st));
     }
     return DDN_OK;
+}
+
+// front end + receive loop of one call into buffer set `cur` on stream st (the carried tail is copied in first)
+static int
+chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEvent_t before_loop = nullptr) {
+    DDN_TRY(chain_front(c, d_iq, cur, st));
+    // The receive loop fills the device on its own (two workgroups per CU take its registers and LDS) and every workgroup runs
+    // for the whole launch: one that has to wait for a CU another kernel still holds makes the launch half as long again.  In the
+    // pipelined forms the loop therefore starts once the previous call's decode has drained; that decode overlaps this call's
+    // carry, front end and matched filter instead.
+    if (before_loop) {
+        HIP_TRY(hipStreamWaitEvent(st, before_loop, 0));
+    }
+    return chain_loop(c, cur, st);
 }
 
 // framer + every frame type's FEC + voice of buffer set `cur` on stream st
@@ -358,6 +371,26 @@ ddn_p25_chain_run(ddn_p25_chain* c, const void* d_iq, void* hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     const int cur = (int)(c->step & 1);
     DDN_TRY(chain_receive(c, d_iq, cur, st));
+    DDN_TRY(chain_decode(c, cur, 0, st));
+    c->last_set = cur;
+    c->step++;
+    return DDN_OK;
+}
+
+// the three stages of ddn_p25_chain_run as separate calls (the mixed-protocol object interleaves them across its groups)
+extern "C" int
+ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip_stream) {
+    if (!c || stage < 0 || stage > 2 || (stage == 0 && !d_iq)) {
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int cur = (int)(c->step & 1);
+    if (stage == 0) {
+        return chain_front(c, d_iq, cur, st);
+    }
+    if (stage == 1) {
+        return chain_loop(c, cur, st);
+    }
     DDN_TRY(chain_decode(c, cur, 0, st));
     c->last_set = cur;
     c->step++;

@@ -34,14 +34,18 @@
 
 struct ddn_fsk4_chain {
     ddn_fsk4_chain_config cfg;
-    int B, n, dmr, vf;
-    size_t ms, my, S, V;
+    int B, n, dmr, vf, T, myc, myd;
+    size_t ms, my, stride, S, V;
     ddn_batch* fe;
     ddn_fsk4_rx* rx;
     ddn_mbe_batch* mbe;
     float* d_disc;
-    uint8_t *d_rec, *d_fl, *d_pay, *d_spat, *d_pre, *d_prel;
-    int32_t *d_cnt, *d_ns, *d_spos;
+    // rows = T carried records + this call's (two sets: the carry reads the previous call's)
+    uint8_t *d_rec[2], *d_fl[2], *d_pay;
+    int32_t *d_new[2], *d_cnt_full, *d_cnt_scan;
+    // what the loop reports per call, the syncs waiting for the next call (two sets), the syncs decoded in this one
+    int32_t *s_pos, *s_n, *c_pos[2], *c_n[2], *d_spos, *d_ns;
+    uint8_t *s_pat, *s_pre, *s_prel, *c_pat[2], *c_pre[2], *c_prel[2], *d_spat, *d_pre, *d_prel;
     // DMR
     uint8_t *d_st, *d_info, *d_cach, *d_valid, *d_st_ok, *d_pdu, *d_r3;
     uint32_t* d_errs;
@@ -50,6 +54,8 @@ struct ddn_fsk4_chain {
     int32_t *d_vpos, *d_vn, *d_ambe_res, *d_res_out;
     uint8_t *d_ambe_fr, *d_ambe_rel, *d_ambe_d, *d_skip;
     float* d_pcm;
+    long step;
+    int last_set;
 };
 
 template <typename T>
@@ -70,10 +76,13 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
     ddn_batch_destroy(c->fe);
     ddn_fsk4_rx_destroy(c->rx);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->d_disc, c->d_rec, c->d_fl, c->d_pay, c->d_spat, c->d_pre, c->d_prel, c->d_cnt, c->d_ns, c->d_spos, c->d_st, c->d_info,
-                   c->d_cach, c->d_valid, c->d_st_ok, c->d_pdu, c->d_r3, c->d_errs, c->d_lich, c->d_ss, c->d_sr, c->d_fs, c->d_fr,
-                   c->d_sacch, c->d_sacch_ok, c->d_hard_in, c->d_sacch_hard, c->d_sacch_hard_ok, c->d_facch, c->d_facch_ok, c->d_vpos,
-                   c->d_vn, c->d_ambe_res, c->d_res_out, c->d_ambe_fr, c->d_ambe_rel, c->d_ambe_d, c->d_skip, c->d_pcm};
+    void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_pay, c->d_new[0], c->d_new[1], c->d_cnt_full,
+                   c->d_cnt_scan, c->s_pos, c->s_n, c->c_pos[0], c->c_pos[1], c->c_n[0], c->c_n[1], c->d_spos, c->d_ns, c->s_pat, c->s_pre,
+                   c->s_prel, c->c_pat[0], c->c_pat[1], c->c_pre[0], c->c_pre[1], c->c_prel[0], c->c_prel[1], c->d_spat, c->d_pre,
+                   c->d_prel, c->d_st, c->d_info, c->d_cach, c->d_valid, c->d_st_ok, c->d_pdu, c->d_r3, c->d_errs, c->d_lich, c->d_ss,
+                   c->d_sr, c->d_fs, c->d_fr, c->d_sacch, c->d_sacch_ok, c->d_hard_in, c->d_sacch_hard, c->d_sacch_hard_ok, c->d_facch,
+                   c->d_facch_ok, c->d_vpos, c->d_vn, c->d_ambe_res, c->d_res_out, c->d_ambe_fr, c->d_ambe_rel, c->d_ambe_d, c->d_skip,
+                   c->d_pcm};
     for (void* p : all) {
         (void)hipFree(p);
     }
@@ -97,6 +106,8 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
     c->B = cfg->n_channels;
     c->n = cfg->samples_per_call;
     c->dmr = cfg->protocol == DDN_FSK4_DMR;
+    c->T = 256;  // a DMR burst ends 54 symbols after its sync, an NXDN frame 182: the tail kept back for the next call
+    c->myc = 16; // syncs that can lie inside that tail (a new sync needs 24 / 10 fresh symbols)
     int rc = DDN_OK;
     do {
         ddn_front_end_config fc = {c->B, 48000, c->dmr ? 4800 : 2400, 4, c->dmr ? DDN_LPF_12K5 : DDN_LPF_6K25, cfg->input_format,
@@ -120,19 +131,27 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
         }
         c->ms = ddn_fsk4_rx_max_symbols(c->rx, (size_t)c->n);
         c->my = ddn_fsk4_rx_max_syncs(c->rx, (size_t)c->n);
-        c->S = (size_t)c->B * c->my;
-        const size_t B = (size_t)c->B, S = c->S, ms = c->ms, my = c->my;
-        bool ok = dalloc(&c->d_disc, B * (size_t)c->n) && dalloc(&c->d_rec, B * ms * 10) && dalloc(&c->d_fl, B * ms)
-                  && dalloc(&c->d_pay, B * ms * 2) && dalloc(&c->d_cnt, B) && dalloc(&c->d_ns, B) && dalloc(&c->d_spos, B * my)
-                  && dalloc(&c->d_spat, B * my) && dalloc(&c->d_pre, B * my * 90) && dalloc(&c->d_prel, B * my * 90);
+        c->stride = (size_t)c->T + c->ms;
+        c->myd = (int)c->my + c->myc;
+        c->S = (size_t)c->B * (size_t)c->myd;
+        const size_t B = (size_t)c->B, S = c->S, my = c->my, myc = (size_t)c->myc;
+        bool ok = dalloc(&c->d_disc, B * (size_t)c->n) && dalloc(&c->d_pay, B * c->stride * 2) && dalloc(&c->d_cnt_full, B)
+                  && dalloc(&c->d_cnt_scan, B) && dalloc(&c->s_pos, B * my) && dalloc(&c->s_n, B) && dalloc(&c->s_pat, B * my)
+                  && dalloc(&c->s_pre, B * my * 90) && dalloc(&c->s_prel, B * my * 90) && dalloc(&c->d_spos, S) && dalloc(&c->d_ns, B)
+                  && dalloc(&c->d_spat, S) && dalloc(&c->d_pre, S * 90) && dalloc(&c->d_prel, S * 90);
+        for (int k = 0; k < 2 && ok; k++) {
+            ok = dalloc(&c->d_rec[k], B * c->stride * 10) && dalloc(&c->d_fl[k], B * c->stride) && dalloc(&c->d_new[k], B)
+                 && dalloc(&c->c_pos[k], B * myc) && dalloc(&c->c_n[k], B) && dalloc(&c->c_pat[k], B * myc)
+                 && dalloc(&c->c_pre[k], B * myc * 90) && dalloc(&c->c_prel[k], B * myc * 90);
+        }
         if (ok && c->dmr) {
             ok = dalloc(&c->d_st, S * 20) && dalloc(&c->d_info, S * 196) && dalloc(&c->d_cach, S * 24) && dalloc(&c->d_valid, S)
                  && dalloc(&c->d_st_ok, S) && dalloc(&c->d_pdu, S * 96) && dalloc(&c->d_r3, S * 3) && dalloc(&c->d_errs, S);
         } else if (ok) {
             // voice: four AMBE frames per NXDN frame, one talk path per channel.  With the handlers deciding the frame length two
-            // syncs are at least a 192-symbol frame apart: a call holds n / (192 * 20) + 2 frames at most
-            const size_t cap = (size_t)c->n / (192 * 20) + 2;
-            c->vf = (int)(cfg->handlers ? (cap < my ? cap : my) : my);
+            // syncs are at least a 192-symbol frame apart: a call decodes n / (192 * 20) + 3 frames at most
+            const size_t cap = (size_t)c->n / (192 * 20) + 3;
+            c->vf = (int)(cfg->handlers ? (cap < (size_t)c->myd ? cap : (size_t)c->myd) : (size_t)c->myd);
             c->V = B * (size_t)c->vf;
             const size_t V = c->V;
             ok = dalloc(&c->d_lich, S) && dalloc(&c->d_valid, S) && dalloc(&c->d_ss, S * 72) && dalloc(&c->d_sr, S * 72)
@@ -159,27 +178,28 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
     return DDN_OK;
 }
 
-extern "C" int
-ddn_fsk4_chain_run(ddn_fsk4_chain* c, const void* d_iq, void* hip_stream) {
-    if (!c || !d_iq) {
-        return DDN_EINVAL;
-    }
-    hipStream_t st = (hipStream_t)hip_stream;
+// frame FEC (+ voice) of the syncs this call decodes, out of buffer set `cur`
+static int
+fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
     const size_t S = c->S;
-    DDN_TRY(ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st));
-    DDN_TRY(ddn_fsk4_rx_run(c->rx, c->d_disc, (size_t)c->n, c->d_rec, c->d_fl, c->d_pay, c->d_cnt, c->ms, c->d_spos, c->d_spat, c->d_pre,
-                            c->d_prel, c->d_ns, c->my, st));
+    const int prev = cur ^ 1;
+    const uint8_t* rec = c->d_rec[cur];
+    HIP_TRY(ddn_dev_chain_counts(c->d_new[cur], c->T, c->B, flush, c->d_cnt_scan, c->d_cnt_full, st));
+    HIP_TRY(ddn_dev_fsk4_chain_syncs(c->c_pos[prev], c->c_pat[prev], c->c_pre[prev], c->c_prel[prev], c->c_n[prev], c->myc, c->s_pos,
+                                     c->s_pat, c->s_pre, c->s_prel, c->s_n, (int)c->my, c->d_new[cur], c->T, flush, c->d_spos, c->d_spat,
+                                     c->d_pre, c->d_prel, c->d_ns, c->myd, c->c_pos[cur], c->c_pat[cur], c->c_pre[cur], c->c_prel[cur],
+                                     c->c_n[cur], c->B, st));
     if (c->dmr) {
         // burst gather -> slot type Golay(20,8) -> BPTC(196,96)
-        DDN_TRY(ddn_dmr_burst_gather(c->d_rec, c->d_cnt, c->ms, c->d_spos, c->d_pre, c->d_ns, c->B, c->my, c->cfg.inverted, c->d_st,
-                                     c->d_info, c->d_cach, c->d_valid, st));
+        DDN_TRY(ddn_dmr_burst_gather(rec, c->d_cnt_full, c->stride, c->d_spos, c->d_pre, c->d_ns, c->B, (size_t)c->myd, c->cfg.inverted,
+                                     c->d_st, c->d_info, c->d_cach, c->d_valid, st));
         DDN_TRY(ddn_fec_block_code_batch(5 /* DDN_CODE_GOLAY_20_8 */, c->d_st, S, 1, nullptr, c->d_st_ok, st));
         DDN_TRY(ddn_fec_bptc_196x96_batch(c->d_info, 1, S, c->d_pdu, c->d_r3, c->d_errs, st));
         return DDN_OK;
     }
     // NXDN48: frame gather -> SACCH / FACCH1 K=5 soft decode -> CRC6 / CRC12 -> the reference's greedy retry for the SACCH
-    DDN_TRY(ddn_nxdn_frame_gather(c->d_rec, c->d_cnt, c->ms, c->d_spos, c->d_ns, c->B, c->my, c->d_lich, c->d_ss, c->d_sr, c->d_fs, c->d_fr,
-                                  c->d_valid, st));
+    DDN_TRY(ddn_nxdn_frame_gather(rec, c->d_cnt_full, c->stride, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->d_lich, c->d_ss, c->d_sr,
+                                  c->d_fs, c->d_fr, c->d_valid, st));
     DDN_TRY(ddn_fec_nxdn_conv_batch(c->d_ss, c->d_sr, S, 36, 32, nullptr, c->d_sacch, 4, st));
     DDN_TRY(ddn_nxdn_crc_check_batch(c->d_sacch, 4, S, 0, c->d_sacch_ok, st));
     HIP_TRY(ddn_dev_u8_shr1(c->d_ss, S * 72, c->d_hard_in, st));
@@ -190,9 +210,8 @@ ddn_fsk4_chain_run(ddn_fsk4_chain* c, const void* d_iq, void* hip_stream) {
     if (c->cfg.vocoder) {
         // voice (nxdn_voice()): the frames the LICHs announce, through AMBE de-interleave -> frame FEC -> synthesis
         const size_t V4 = c->V * 4;
-        HIP_TRY(ddn_dev_nxdn_voice_select(c->d_spos, c->d_ns, c->d_lich, c->d_valid, c->B, (int)c->my, c->vf, c->d_vpos, c->d_vn, c->d_skip,
-                                          st));
-        DDN_TRY(ddn_nxdn_voice_gather(c->d_rec, c->d_cnt, c->ms, c->d_vpos, c->d_vn, c->B, (size_t)c->vf, c->d_ambe_fr, c->d_ambe_rel,
+        HIP_TRY(ddn_dev_nxdn_voice_select(c->d_spos, c->d_ns, c->d_lich, c->d_valid, c->B, c->myd, c->vf, c->d_vpos, c->d_vn, c->d_skip, st));
+        DDN_TRY(ddn_nxdn_voice_gather(rec, c->d_cnt_full, c->stride, c->d_vpos, c->d_vn, c->B, (size_t)c->vf, c->d_ambe_fr, c->d_ambe_rel,
                                       nullptr, st));
         DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, c->d_ambe_fr, c->d_ambe_rel, V4, c->d_ambe_d, c->d_ambe_res, st));
         DDN_TRY(ddn_mbe_result_skip_batch(c->d_skip, V4, c->d_ambe_res, st));
@@ -201,19 +220,79 @@ ddn_fsk4_chain_run(ddn_fsk4_chain* c, const void* d_iq, void* hip_stream) {
     return DDN_OK;
 }
 
+// stage 0: front end, 1: carry + matched filter + receive loop, 2: frame FEC (+ voice)
+extern "C" int
+ddn_fsk4_chain_stage(ddn_fsk4_chain* c, int stage, const void* d_iq, void* hip_stream) {
+    if (!c || stage < 0 || stage > 2 || (stage == 0 && !d_iq)) {
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int cur = (int)(c->step & 1), prev = cur ^ 1;
+    if (stage == 0) {
+        return ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st);
+    }
+    if (stage == 1) {
+        HIP_TRY(ddn_dev_chain_carry(c->d_rec[prev], c->d_fl[prev], c->d_new[prev], c->step > 0 ? 1 : 0, c->d_rec[cur], c->d_fl[cur],
+                                    c->stride, c->T, c->B, st));
+        // the loop writes behind the T carried records: row pointers + T, row stride unchanged
+        return ddn_fsk4_rx_run(c->rx, c->d_disc, (size_t)c->n, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T,
+                               c->d_pay + (size_t)c->T * 2, c->d_new[cur], c->stride, c->s_pos, c->s_pat, c->s_pre, c->s_prel, c->s_n,
+                               c->my, st);
+    }
+    DDN_TRY(fsk4_decode(c, cur, 0, st));
+    c->last_set = cur;
+    c->step++;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fsk4_chain_run(ddn_fsk4_chain* c, const void* d_iq, void* hip_stream) {
+    if (!c || !d_iq) {
+        return DDN_EINVAL;
+    }
+    for (int stage = 0; stage < 3; stage++) {
+        DDN_TRY(ddn_fsk4_chain_stage(c, stage, d_iq, hip_stream));
+    }
+    return DDN_OK;
+}
+
+// decode what the carry still holds back (end of a stream): one more decode pass without new samples
+extern "C" int
+ddn_fsk4_chain_flush(ddn_fsk4_chain* c, void* hip_stream) {
+    if (!c) {
+        return DDN_EINVAL;
+    }
+    if (c->step == 0) {
+        return DDN_OK;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int cur = (int)(c->step & 1), prev = cur ^ 1;
+    HIP_TRY(ddn_dev_chain_carry(c->d_rec[prev], c->d_fl[prev], c->d_new[prev], 1, c->d_rec[cur], c->d_fl[cur], c->stride, c->T, c->B, st));
+    HIP_TRY(hipMemsetAsync(c->d_new[cur], 0, sizeof(int32_t) * (size_t)c->B, st));
+    HIP_TRY(hipMemsetAsync(c->s_n, 0, sizeof(int32_t) * (size_t)c->B, st));
+    DDN_TRY(fsk4_decode(c, cur, 1, st));
+    c->last_set = cur;
+    c->step++;
+    HIP_TRY(hipStreamSynchronize(st));
+    return DDN_OK;
+}
+
 extern "C" int
 ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
     if (!c || !r) {
         return DDN_EINVAL;
     }
+    const int cur = c->last_set;
     memset(r, 0, sizeof(*r));
-    r->max_symbols = c->ms;
-    r->max_syncs = c->my;
+    r->stride_symbols = c->stride;
+    r->carry_symbols = (size_t)c->T;
+    r->max_syncs = (size_t)c->myd;
     r->voice_slots = c->vf;
-    r->d_records10 = c->d_rec;
-    r->d_flags = c->d_fl;
+    r->d_records10 = c->d_rec[cur];
+    r->d_flags = c->d_fl[cur];
     r->d_payload2 = c->d_pay;
-    r->d_counts = c->d_cnt;
+    r->d_new = c->d_new[cur];
+    r->d_counts = c->d_cnt_full;
     r->d_n_sync = c->d_ns;
     r->d_sync_pos = c->d_spos;
     r->d_sync_pat = c->d_spat;
@@ -251,6 +330,7 @@ struct ddn_mixed_chain {
     ddn_p25_chain* p25;
     ddn_fsk4_chain *dmr, *nxdn;
     hipStream_t st[3];
+    hipEvent_t ev_front[3];
 };
 
 extern "C" void
@@ -265,6 +345,11 @@ ddn_mixed_chain_destroy(ddn_mixed_chain* m) {
     for (hipStream_t s : m->st) {
         if (s) {
             (void)hipStreamDestroy(s);
+        }
+    }
+    for (hipEvent_t e : m->ev_front) {
+        if (e) {
+            (void)hipEventDestroy(e);
         }
     }
     delete m;
@@ -299,7 +384,8 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
         rc = ddn_fsk4_chain_create(&nc, &m->nxdn);
     }
     for (int k = 0; k < 3 && rc == DDN_OK; k++) {
-        if (hipStreamCreateWithFlags(&m->st[k], hipStreamNonBlocking) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&m->st[k], hipStreamNonBlocking) != hipSuccess
+            || hipEventCreateWithFlags(&m->ev_front[k], hipEventDisableTiming) != hipSuccess) {
             rc = DDN_EHIP;
         }
     }
@@ -311,21 +397,46 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
     return DDN_OK;
 }
 
+
+
 extern "C" int
 ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_dmr, const void* d_iq_nxdn48) {
     if (!m || (m->p25 && !d_iq_p25) || (m->dmr && !d_iq_dmr) || (m->nxdn && !d_iq_nxdn48)) {
         return DDN_EINVAL;
     }
-    // the protocol groups are independent channel sets: one stream each, so their receive loops (per-channel latency chains)
-    // share the device instead of queueing behind one another
-    if (m->p25) {
-        DDN_TRY(ddn_p25_chain_run(m->p25, d_iq_p25, m->st[0]));
+    // The protocol groups are independent channel sets, one stream each.  Their stages are lined up across the groups: the three
+    // front ends first (throughput kernels that would otherwise be starved by - and delay the workgroups of - another group's
+    // receive loop), then the three receive loops side by side (latency chains that fit on the device together), each followed on
+    // its own stream by its frame FEC / voice stage.
+    const void* iq[3] = {d_iq_p25, d_iq_dmr, d_iq_nxdn48};
+    const bool on[3] = {m->p25 != nullptr, m->dmr != nullptr, m->nxdn != nullptr};
+    auto stage = [&](int g, int st_no) -> int {
+        if (g == 0) {
+            return ddn_p25_chain_stage(m->p25, st_no, iq[0], m->st[0]);
+        }
+        return ddn_fsk4_chain_stage(g == 1 ? m->dmr : m->nxdn, st_no, iq[g], m->st[g]);
+    };
+    for (int g = 0; g < 3; g++) {
+        if (on[g]) {
+            DDN_TRY(stage(g, 0));
+            HIP_TRY(hipEventRecord(m->ev_front[g], m->st[g]));
+        }
     }
-    if (m->dmr) {
-        DDN_TRY(ddn_fsk4_chain_run(m->dmr, d_iq_dmr, m->st[1]));
+    for (int g = 0; g < 3; g++) {
+        if (!on[g]) {
+            continue;
+        }
+        for (int h = 0; h < 3; h++) {
+            if (h != g && on[h]) {
+                HIP_TRY(hipStreamWaitEvent(m->st[g], m->ev_front[h], 0));
+            }
+        }
+        DDN_TRY(stage(g, 1));
     }
-    if (m->nxdn) {
-        DDN_TRY(ddn_fsk4_chain_run(m->nxdn, d_iq_nxdn48, m->st[2]));
+    for (int g = 0; g < 3; g++) {
+        if (on[g]) {
+            DDN_TRY(stage(g, 2));
+        }
     }
     return DDN_OK;
 }

@@ -26,6 +26,7 @@
 
 struct ddn_mbe_batch {
     int codec, n_streams, tail_rule;
+    int synthetic; // the loaded table blob's `synthetic` word (1 until ddn_mbe_batch_set_tables() brings real tables)
     ddn_mbe_tables* d_tables;
     float* d_half_log2;     // [57] 0.5 * log2(L)
     DdnMbeStream* d_streams;
@@ -118,6 +119,7 @@ ddn_mbe_batch_create(int codec, int n_streams, ddn_mbe_batch** out) {
         delete b;
         return DDN_ENOMEM;
     }
+    b->synthetic = t->synthetic ? 1 : 0;
     delete t;
     *out = b;
     return DDN_OK;
@@ -153,7 +155,30 @@ ddn_mbe_batch_set_tables(ddn_mbe_batch* b, const ddn_mbe_tables* t) {
     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(b->d_tables, t, sizeof(ddn_mbe_tables), hipMemcpyHostToDevice));
+    b->synthetic = t->synthetic ? 1 : 0;
     return DDN_OK;
+}
+
+extern "C" int
+ddn_mbe_batch_tables_synthetic(const ddn_mbe_batch* b) {
+    return b ? b->synthetic : -1;
+}
+
+extern "C" int
+ddn_mbe_batch_load_tables_file(ddn_mbe_batch* b, const char* path) {
+    if (!b || !path) {
+        return DDN_EINVAL;
+    }
+    ddn_mbe_tables* t = new (std::nothrow) ddn_mbe_tables;
+    if (!t) {
+        return DDN_ENOMEM;
+    }
+    int rc = ddn_mbe_tables_load_file(path, t);
+    if (rc == DDN_OK) {
+        rc = ddn_mbe_batch_set_tables(b, t);
+    }
+    delete t;
+    return rc;
 }
 
 extern "C" int

@@ -172,6 +172,64 @@ k_nxdn_voice_select(const int32_t* __restrict__ sync_pos, const int32_t* __restr
     }
 }
 
+// DMR / NXDN48 chain: which accepted syncs are decoded in this call and which wait for the next one.  A row holds the T records
+// carried from the previous call, then this call's new ones; a sync (position = row index of its last symbol, with the 90-dibit
+// hand-over the loop made for it) is decoded when the T records behind it are in the row, i.e. when its position is below the
+// number of new records - the rest go to the carry list, re-based to the next row.  One workgroup per channel.
+__global__ __launch_bounds__(64) void
+k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict__ c_pat, const uint8_t* __restrict__ c_pre,
+                   const uint8_t* __restrict__ c_prel, const int32_t* __restrict__ c_n, int myc, const int32_t* __restrict__ s_pos,
+                   const uint8_t* __restrict__ s_pat, const uint8_t* __restrict__ s_pre, const uint8_t* __restrict__ s_prel,
+                   const int32_t* __restrict__ s_n, int my, const int32_t* __restrict__ n_new, int T, int flush,
+                   int32_t* __restrict__ d_pos, uint8_t* __restrict__ d_pat, uint8_t* __restrict__ d_pre, uint8_t* __restrict__ d_prel,
+                   int32_t* __restrict__ d_n, int myd, int32_t* __restrict__ o_pos, uint8_t* __restrict__ o_pat,
+                   uint8_t* __restrict__ o_pre, uint8_t* __restrict__ o_prel, int32_t* __restrict__ o_n) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int nc = c_n[c] < myc ? c_n[c] : myc, nsn = s_n[c] < my ? s_n[c] : my;
+    const int limit = flush ? 0x7FFFFFFF : n_new[c], shift = n_new[c];
+    int kd = 0, ko = 0;
+    for (int i = 0; i < nc + nsn; i++) {
+        const bool carried = i < nc;
+        const int j = carried ? i : i - nc;
+        const int p = carried ? c_pos[(size_t)c * myc + j] : s_pos[(size_t)c * my + j] + T;
+        const uint8_t pat = carried ? c_pat[(size_t)c * myc + j] : s_pat[(size_t)c * my + j];
+        const uint8_t* pre = carried ? c_pre + ((size_t)c * myc + j) * 90 : s_pre + ((size_t)c * my + j) * 90;
+        const uint8_t* prel = carried ? c_prel + ((size_t)c * myc + j) * 90 : s_prel + ((size_t)c * my + j) * 90;
+        uint8_t *qp, *qr;
+        if (p < limit) {
+            if (kd >= myd) {
+                continue;
+            }
+            if (lane == 0) {
+                d_pos[(size_t)c * myd + kd] = p;
+                d_pat[(size_t)c * myd + kd] = pat;
+            }
+            qp = d_pre + ((size_t)c * myd + kd) * 90;
+            qr = d_prel + ((size_t)c * myd + kd) * 90;
+            kd++;
+        } else {
+            if (ko >= myc) {
+                continue;
+            }
+            if (lane == 0) {
+                o_pos[(size_t)c * myc + ko] = p - shift;
+                o_pat[(size_t)c * myc + ko] = pat;
+            }
+            qp = o_pre + ((size_t)c * myc + ko) * 90;
+            qr = o_prel + ((size_t)c * myc + ko) * 90;
+            ko++;
+        }
+        for (int k = lane; k < 90; k += 64) {
+            qp[k] = pre[k];
+            qr[k] = prel[k];
+        }
+    }
+    if (lane == 0) {
+        d_n[c] = kd;
+        o_n[c] = ko;
+    }
+}
+
 __global__ void
 k_u8_shr1(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,6 +353,20 @@ ddn_dev_nxdn_voice_select(const int32_t* sync_pos, const int32_t* n_sync, const 
     const int n = n_channels * vf;
     hipLaunchKernelGGL(k_nxdn_voice_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sync_pos, n_sync, lich, valid, n_channels,
                        my, vf, v_pos, v_n, skip4);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_fsk4_chain_syncs(const int32_t* c_pos, const uint8_t* c_pat, const uint8_t* c_pre, const uint8_t* c_prel, const int32_t* c_n, int myc,
+                         const int32_t* s_pos, const uint8_t* s_pat, const uint8_t* s_pre, const uint8_t* s_prel, const int32_t* s_n, int my,
+                         const int32_t* n_new, int T, int flush, int32_t* d_pos, uint8_t* d_pat, uint8_t* d_pre, uint8_t* d_prel,
+                         int32_t* d_n, int myd, int32_t* o_pos, uint8_t* o_pat, uint8_t* o_pre, uint8_t* o_prel, int32_t* o_n,
+                         int n_channels, hipStream_t st) {
+    if (n_channels <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_fsk4_chain_syncs, dim3((unsigned)n_channels), dim3(64), 0, st, c_pos, c_pat, c_pre, c_prel, c_n, myc, s_pos, s_pat,
+                       s_pre, s_prel, s_n, my, n_new, T, flush, d_pos, d_pat, d_pre, d_prel, d_n, myd, o_pos, o_pat, o_pre, o_prel, o_n);
     return hipGetLastError();
 }
 

@@ -285,6 +285,12 @@ hipError_t ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const 
 enum { DDN_CLS_LDU1 = 1, DDN_CLS_LDU2 = 2, DDN_CLS_HDU = 4, DDN_CLS_TDULC = 8 }; /* frame-type bits of a slot's class byte */
 hipError_t ddn_dev_nxdn_voice_select(const int32_t* sync_pos, const int32_t* n_sync, const uint8_t* lich, const uint8_t* valid,
                                      int n_channels, int my, int vf, int32_t* v_pos, int32_t* v_n, uint8_t* skip4, hipStream_t st);
+hipError_t ddn_dev_fsk4_chain_syncs(const int32_t* c_pos, const uint8_t* c_pat, const uint8_t* c_pre, const uint8_t* c_prel,
+                                    const int32_t* c_n, int myc, const int32_t* s_pos, const uint8_t* s_pat, const uint8_t* s_pre,
+                                    const uint8_t* s_prel, const int32_t* s_n, int my, const int32_t* n_new, int T, int flush,
+                                    int32_t* d_pos, uint8_t* d_pat, uint8_t* d_pre, uint8_t* d_prel, int32_t* d_n, int myd,
+                                    int32_t* o_pos, uint8_t* o_pat, uint8_t* o_pre, uint8_t* o_prel, int32_t* o_n, int n_channels,
+                                    hipStream_t st);
 hipError_t ddn_dev_u8_shr1(const uint8_t* in, size_t n, uint8_t* out, hipStream_t st);
 hipError_t ddn_dev_tsbk_select(const uint8_t* cand, const int32_t* counts, size_t n, uint8_t* out12, uint8_t* crc_ok, uint8_t* sel,
                                hipStream_t st);

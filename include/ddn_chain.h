@@ -79,6 +79,9 @@ int ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out);
 void ddn_p25_chain_destroy(ddn_p25_chain* c);
 /* every stage of one call on one stream (NULL = the default stream) */
 int ddn_p25_chain_run(ddn_p25_chain* c, const void* d_iq, void* hip_stream);
+/* the same call in its three stages (0: carry + front end, 1: matched filter + receive loop, 2: framer + FEC + voice; d_iq is read by
+ * stage 0 only), for a host that lines the stages of several chain objects up itself - ddn_mixed_chain does */
+int ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip_stream);
 /* the same work over the object's two streams: front end + receive loop on one, framer + FEC + voice on the other, so the decode
  * of call k runs beside the front end and loop of call k + 1.  Returns once everything is queued. */
 int ddn_p25_chain_run_pipelined(ddn_p25_chain* c, const void* d_iq);
@@ -121,8 +124,9 @@ int ddn_p25_chain_get_stage_ms(ddn_p25_chain* c, float out4[4]);
  *   DMR:    burst gather -> slot type Golay(20,8) -> BPTC(196,96)
  *   NXDN48: frame gather -> SACCH / FACCH1 K=5 decode + CRC6 / CRC12 + the greedy SACCH retry -> the voice frames the LICHs announce:
  *           AMBE de-interleave -> AMBE 3600x2450 frame FEC -> synthesis (vocoder = 1)
- * One call per batch of samples_per_call samples; carried state streams from call to call (frames cut by a call boundary are
- * reported as far as their fields are complete: d_valid). */
+ * One call per batch of samples_per_call samples; carried state streams from call to call.  Bursts / frames that cross a call
+ * boundary decode whole: a row holds the last carry_symbols records of the previous call, then this call's, and a sync is decoded
+ * in the call that brings the carry_symbols records behind it (ddn_fsk4_chain_flush at the end of a stream decodes the rest). */
 typedef struct ddn_fsk4_chain_config {
     int n_channels;
     int samples_per_call;
@@ -135,14 +139,15 @@ typedef struct ddn_fsk4_chain_config {
     int vocoder;      /* NXDN48: 1 = AMBE synthesis to PCM */
 } ddn_fsk4_chain_config;
 typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max_syncs sync slots */
-    size_t max_symbols, max_syncs;
+    size_t stride_symbols, carry_symbols, max_syncs; /* records per row; carried records at its front; sync slots per channel */
     int voice_slots;                /* NXDN48: sync slots per channel the voice stage works on */
-    const uint8_t* d_records10;     /* [B][max_symbols][10] */
-    const uint8_t* d_flags;         /* [B][max_symbols] */
-    const uint8_t* d_payload2;      /* [B][max_symbols][2] */
-    const int32_t* d_counts;        /* [B] */
-    const int32_t* d_n_sync;        /* [B] */
-    const int32_t* d_sync_pos;      /* [S] */
+    const uint8_t* d_records10;     /* [B][stride][10]: the carried records, then this call's */
+    const uint8_t* d_flags;         /* [B][stride] */
+    const uint8_t* d_payload2;      /* [B][stride][2] (this call's records only, from index carry_symbols) */
+    const int32_t* d_new;           /* [B] new records of this call */
+    const int32_t* d_counts;        /* [B] records in the row (carried + new) */
+    const int32_t* d_n_sync;        /* [B] syncs decoded in this call */
+    const int32_t* d_sync_pos;      /* [S] row index of the sync's last symbol */
     const uint8_t* d_sync_pat;      /* [S] */
     const uint8_t* d_pre;           /* [S][90] the payload history handed over at each sync */
     const uint8_t* d_valid;         /* [S] frame / burst complete inside the call */
@@ -165,12 +170,15 @@ typedef struct ddn_fsk4_chain ddn_fsk4_chain;
 int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);
 void ddn_fsk4_chain_destroy(ddn_fsk4_chain* c);
 int ddn_fsk4_chain_run(ddn_fsk4_chain* c, const void* d_iq, void* hip_stream);
+int ddn_fsk4_chain_flush(ddn_fsk4_chain* c, void* hip_stream); /* end of a stream: decode the syncs the carry still holds back */
+int ddn_fsk4_chain_stage(ddn_fsk4_chain* c, int stage, const void* d_iq, void* hip_stream); /* 0 front end, 1 loop, 2 frame FEC + voice */
 int ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* out);
 void* ddn_fsk4_chain_front_end(ddn_fsk4_chain* c); /* ddn_batch* */
 void* ddn_fsk4_chain_rx(ddn_fsk4_chain* c);        /* ddn_fsk4_rx* */
 
 /* ---- a mixed batch (BASELINE configs[3]): P25 Phase 1 + DMR + NXDN48 channel groups of one GPU, every receive loop with the
- * reference's handlers inside it; one stream per group inside the object.  _run queues one call of all three, _wait blocks. */
+ * reference's handlers inside it; one stream per group inside the object, the groups' stages lined up (the three front ends, then the
+ * three receive loops side by side, each followed by its frame FEC / voice stage).  _run queues one call of all three, _wait blocks. */
 typedef struct ddn_mixed_chain_config {
     int n_p25, n_dmr, n_nxdn48; /* channels of each group on this GPU (a group may be empty) */
     int samples_per_call, block_len, input_format, vocoder;

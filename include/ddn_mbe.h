@@ -119,6 +119,10 @@ int ddn_mbe_default_tables(ddn_mbe_tables* out);
 /* checks shapes / ranges of a blob (bit counts sum to 73 - K per L, bit order is a permutation of the fields' bits,
  * block lengths sum to L ...); 0 = usable */
 int ddn_mbe_validate_tables(const ddn_mbe_tables* t);
+/* table blob files ("DDNMBET1", blob size, the struct, a checksum; host only): what an integrator who holds the standard's
+ * quantiser tables writes once (synthetic = 0) and every run loads - _load_file validates like ddn_mbe_validate_tables */
+int ddn_mbe_tables_save_file(const char* path, const ddn_mbe_tables* t);
+int ddn_mbe_tables_load_file(const char* path, ddn_mbe_tables* out);
 
 /* ---- (1) batched, device pointers ------------------------------------------------------------------------------ */
 
@@ -148,6 +152,10 @@ int ddn_mbe_batch_create(int codec, int n_streams, ddn_mbe_batch** out);
 void ddn_mbe_batch_destroy(ddn_mbe_batch* b);
 int ddn_mbe_batch_reset(ddn_mbe_batch* b, void* hip_stream);
 int ddn_mbe_batch_set_tables(ddn_mbe_batch* b, const ddn_mbe_tables* t);
+int ddn_mbe_batch_load_tables_file(ddn_mbe_batch* b, const char* path); /* ddn_mbe_tables_load_file + _set_tables */
+/* 1 while the batch synthesizes from the built-in placeholder tables (PCM is then not intelligible speech for real traffic),
+ * 0 once a blob with synthetic = 0 has been loaded; -1 for a null batch.  bench.py reports it in config.vocoder_tables. */
+int ddn_mbe_batch_tables_synthetic(const ddn_mbe_batch* b);
 /* the same for the single-stream mbe_* entry points below (they run on two cached one-path batches, one per codec) */
 int ddn_mbe_dropin_set_tables(const ddn_mbe_tables* t);
 /* P25 Phase 1 teardown rule of mbe_process_p25p1 (dsd_mbe.c:447-463,540-566): a clear-mode frame that decodes to

@@ -29,32 +29,51 @@ def _tiles(name, lo, B, calls, n=N):
 
 
 def _check_rx(ch, Bc, calls_iq, proto, lpf, rf):
-    """two streamed calls against the restatement fed the same two pieces"""
+    """streamed calls + the flush against the restatement fed the same pieces: this call's records / flags / payload dibits bit for
+    bit, and every accepted sync of the stream decoded exactly once (in the call that brings the records behind it, or in the
+    flush), with its position and 90-dibit hand-over"""
     fes = [orc.OracleFrontEnd(profile=lpf) for _ in range(Bc)]
     rxs = [rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf, handler=1)) for _ in range(Bc)]
+    base = np.zeros(Bc, np.int64)
+    got = [[] for _ in range(Bc)]
+    want = [[] for _ in range(Bc)]
     out = []
+
+    def take():
+        r = ch.results()
+        st, T, my = r.stride_symbols, r.carry_symbols, r.max_syncs
+        f = ch.fetch
+        ns = f(r.d_n_sync, np.int32, (Bc,))
+        spos, pre = f(r.d_sync_pos, np.int32, (Bc, my)), f(r.d_pre, np.uint8, (Bc, my, 90))
+        for c in range(Bc):
+            got[c] += [(int(base[c]) + int(spos[c, k]) - int(T), pre[c, k].copy()) for k in range(int(ns[c]))]
+        out.append((r, ns))
+        return r, st, T
+
     for part in calls_iq:
         d = _upload(part)
         ch.run(d)
-        r = ch.results()
-        ms, my = r.max_symbols, r.max_syncs
+        r, st, T = take()
         f = ch.fetch
-        rec, fl, pay = f(r.d_records10, np.uint8, (Bc, ms, 10)), f(r.d_flags, np.uint8, (Bc, ms)), f(r.d_payload2, np.uint8, (Bc, ms, 2))
-        cnt, ns = f(r.d_counts, np.int32, (Bc,)), f(r.d_n_sync, np.int32, (Bc,))
-        spos, pre = f(r.d_sync_pos, np.int32, (Bc, my)), f(r.d_pre, np.uint8, (Bc, my, 90))
+        rec, fl, pay = f(r.d_records10, np.uint8, (Bc, st, 10)), f(r.d_flags, np.uint8, (Bc, st)), f(r.d_payload2, np.uint8, (Bc, st, 2))
+        new, cnt = f(r.d_new, np.int32, (Bc,)), f(r.d_counts, np.int32, (Bc,))
         ddn.lib().ddn_device_free(d)
         for c in range(Bc):
             disc = fes[c].run_cu8(np.ascontiguousarray(part[c]), 8192)
-            want = rxs[c].run(disc, max_sync=my)
-            k = int(cnt[c])
-            assert k == len(want["sym"]), (c, k, len(want["sym"]))
-            rr = rec[c, :k]
-            assert np.array_equal(rr[:, 6:10].copy().view(np.uint32).reshape(-1), want["sym"].view(np.uint32)), c
-            assert np.array_equal(rr[:, 0].astype(np.int32), want["rec4"][:, 0]) and np.array_equal(fl[c, :k], want["fl"]), c
-            assert np.array_equal(pay[c, :k], want["pay"]), c
-            assert int(ns[c]) == len(want["sync_pos"]) and np.array_equal(spos[c, :int(ns[c])], want["sync_pos"]), c
-            assert np.array_equal(pre[c, :int(ns[c])], want["pre"]), c
-        out.append((r, ns))
+            w = rxs[c].run(disc, max_sync=512)
+            k = int(new[c])
+            assert k == len(w["sym"]) and cnt[c] == k + T, (c, k, len(w["sym"]))
+            rr = rec[c, T:T + k]
+            assert np.array_equal(rr[:, 6:10].copy().view(np.uint32).reshape(-1), w["sym"].view(np.uint32)), c
+            assert np.array_equal(rr[:, 0].astype(np.int32), w["rec4"][:, 0]) and np.array_equal(fl[c, T:T + k], w["fl"]), c
+            assert np.array_equal(pay[c, T:T + k], w["pay"]), c
+            want[c] += [(int(base[c]) + int(p), q) for p, q in zip(w["sync_pos"], w["pre"])]
+            base[c] += k
+    ch.flush()
+    take()
+    for c in range(Bc):
+        assert [g for g, _ in got[c]] == [g for g, _ in want[c]], (c, len(got[c]), len(want[c]))
+        assert all(np.array_equal(a[1], b[1]) for a, b in zip(got[c], want[c])), c
     return out
 
 
@@ -63,14 +82,25 @@ def test_dmr_chain_two_calls_and_known_answer(built):
     n = 44000                                  # the capture holds 96000 samples
     calls, _, _ = _tiles("iq_dmr_t3_ras_cc.npz", 0, B, 2, n)
     ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_DMR, rf_mod=2)
-    (r, ns), _ = _check_rx(ch, B, calls, rx4.PROTO_DMR, 2, 2)[-1], None
+    _check_rx(ch, B, calls, rx4.PROTO_DMR, 2, 2)
+    ch.close()
+    # known answer on a fresh object, the decode outputs of its second call (the bursts that straddle the first boundary included)
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_DMR, rf_mod=2)
+    for part in calls:
+        d = _upload(part)
+        ch.run(d)
+        ddn.lib().ddn_device_free(d)
+    r = ch.results()
     my = r.max_syncs
     S = B * my
+    ns = ch.fetch(r.d_n_sync, np.int32, (B,))
     valid, st_ok = ch.fetch(r.d_valid, np.uint8, (S,)), ch.fetch(r.d_dmr_slot_type_ok, np.uint8, (S,))
     stb, errs = ch.fetch(r.d_dmr_slot_type, np.uint8, (S, 20)), ch.fetch(r.d_dmr_bptc_errs, np.uint32, (S,))
-    rows = np.flatnonzero(valid)
-    # Tier III control channel: colour code 0 in every slot type, the BPTC words clean
-    assert len(rows) > 20 and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0) and np.mean(errs[rows] == 0) > 0.99
+    used = (np.arange(my)[None, :] < ns[:, None]).reshape(S)
+    rows = np.flatnonzero(used)
+    # every burst the call decodes is complete (the carry), Tier III control channel: colour code 0 in every slot type, BPTC clean
+    assert len(rows) > 20 and np.all(valid[rows] == 1) and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0)
+    assert np.mean(errs[rows] == 0) > 0.99
     ch.close()
 
 
@@ -78,12 +108,22 @@ def test_nxdn48_chain_two_calls_voice(built):
     B = 3
     calls, _, _ = _tiles("iq_nxdn48.npz", 60000, B, 2)
     ch = ddn.Fsk4ChainC(B, N, ddn.FSK4_NXDN48, rf_mod=0)
-    r, ns = _check_rx(ch, B, calls, rx4.PROTO_NXDN48, 1, 0)[-1]
+    _check_rx(ch, B, calls, rx4.PROTO_NXDN48, 1, 0)
+    ch.close()
+    ch = ddn.Fsk4ChainC(B, N, ddn.FSK4_NXDN48, rf_mod=0)
+    for part in calls:
+        d = _upload(part)
+        ch.run(d)
+        ddn.lib().ddn_device_free(d)
+    r = ch.results()
     my, vf = r.max_syncs, r.voice_slots
     S = B * my
+    ns = ch.fetch(r.d_n_sync, np.int32, (B,))
     nv, nl = ch.fetch(r.d_valid, np.uint8, (S,)), ch.fetch(r.d_nxdn_lich, np.uint8, (S,))
     s1, s2 = ch.fetch(r.d_nxdn_sacch_ok, np.uint8, (S,)), ch.fetch(r.d_nxdn_sacch_hard_ok, np.uint8, (S,))
-    rows = np.flatnonzero(nv)
+    used = (np.arange(my)[None, :] < ns[:, None]).reshape(S)
+    assert np.all(nv[used] == 1)                                  # the carry: every frame decoded in a call is complete
+    rows = np.flatnonzero(used)
     assert len(rows) >= 10 and np.mean((nl[rows] & 0x80) != 0) > 0.9 and np.mean((s1[rows] | s2[rows]) != 0) > 0.5
     skip = ch.fetch(r.d_nxdn_voice_skip, np.uint8, (B, vf, 4))
     pcm = ch.fetch(r.d_nxdn_pcm, np.float32, (B, vf * 4, 160))
@@ -121,7 +161,7 @@ def test_mixed_chain_groups_side_by_side(built):
         b = ddn.Fsk4ChainC(Bc, N, proto, rf_mod=2 if which == 1 else 0)
         b.run(iq)
         ra, rb = a.results(), b.results()
-        for name, dt, shape in (("d_counts", np.int32, (Bc,)), ("d_n_sync", np.int32, (Bc,)), ("d_records10", np.uint8, (Bc, ra.max_symbols, 10)),
+        for name, dt, shape in (("d_counts", np.int32, (Bc,)), ("d_n_sync", np.int32, (Bc,)), ("d_records10", np.uint8, (Bc, ra.stride_symbols, 10)),
                                 ("d_valid", np.uint8, (Bc * ra.max_syncs,))):
             assert np.array_equal(a.fetch(getattr(ra, name), dt, shape), b.fetch(getattr(rb, name), dt, shape)), (which, name)
         b.close()

@@ -259,6 +259,32 @@ def test_dropin_table_blob_is_loadable(built):
         assert l.ddn_mbe_dropin_set_tables(C.byref(d)) == 0
 
 
+def test_table_blob_file_flips_the_synthetic_flag(built, tmp_path):
+    """ddn_mbe_batch_tables_synthetic: 1 on the built-in placeholder blob, 0 once a synthetic = 0 blob file is loaded - and the loaded
+    tables are the ones synthesis runs on (PCM follows the changed gain table, state and flags stay those of the restatement)"""
+    l = ddn.lib()
+    g = GpuVocoder(ddn.MBE_AMBE, 2)
+    assert l.ddn_mbe_batch_tables_synthetic(g.h) == 1
+    t = mbe.tables()
+    t2 = ddn.MbeTables.from_buffer_copy(bytes(t))
+    t2.synthetic = 0
+    for k in range(32):
+        t2.ambe_dg[k] = t.ambe_dg[k] * 0.5
+    path = str(tmp_path / "tables.ddnmbet").encode()
+    assert l.ddn_mbe_tables_save_file(path, C.byref(t2)) == 0
+    rng = np.random.default_rng(9)
+    bits = mbe.random_ambe_bits(rng, (2, 6))
+    before, _ = g.run(bits)
+    g2 = GpuVocoder(ddn.MBE_AMBE, 2)
+    assert l.ddn_mbe_batch_load_tables_file(g2.h, path) == 0 and l.ddn_mbe_batch_tables_synthetic(g2.h) == 0
+    after, res = g2.run(bits)
+    o = mbe.OracleVocoder(ddn.MBE_AMBE, 2, tab=t2)
+    want, want_res, rc = o.run(bits)
+    assert rc == 0 and np.array_equal(after.view(np.uint32), want.view(np.uint32)) and np.array_equal(res, want_res)
+    assert not np.array_equal(after, before)
+    assert l.ddn_mbe_batch_load_tables_file(g2.h, b"/nonexistent/tables") != 0 and l.ddn_mbe_batch_tables_synthetic(g2.h) == 0
+
+
 def test_agf_batch_bit_exact(built):
     """the voice-frame auto gain on the device == the CPU restatement (itself pinned to the compiled gain.c): samples and the
     carried gain state, several talk paths, across two calls"""

@@ -157,3 +157,29 @@ def test_p25p1_tail_erasure_rule(built):
             assert all(np.array_equal(a, b) for a, b in zip(before, mbe.parms_tuple(v.enh[0])))
         else:
             assert out[0, 0, 3] == 12 and v.cur[0].un == 1
+
+
+def test_table_blob_file_round_trip(built, tmp_path):
+    """a blob marked synthetic = 0 survives save -> load byte for byte and keeps the flag; damaged files and blobs that fail
+    validation are refused (host only: no device)"""
+    import ctypes as C
+    l = ddn.lib()
+    t = ddn.MbeTables()
+    assert l.ddn_mbe_default_tables(C.byref(t)) == 0 and t.synthetic == 1
+    t.synthetic = 0                                     # what an integrator's blob says
+    t.ambe_dg[3] = 0.25                                 # ... and some content of its own
+    path = str(tmp_path / "tables.ddnmbet").encode()
+    assert l.ddn_mbe_tables_save_file(path, C.byref(t)) == 0
+    u = ddn.MbeTables()
+    assert l.ddn_mbe_tables_load_file(path, C.byref(u)) == 0
+    assert bytes(u) == bytes(t) and u.synthetic == 0 and u.ambe_dg[3] == 0.25
+    raw = bytearray(open(path, "rb").read())
+    assert raw[:8] == b"DDNMBET1" and len(raw) == 8 + 4 + C.sizeof(ddn.MbeTables) + 4
+    raw[100] ^= 1                                       # one flipped bit: the checksum no longer fits
+    bad = str(tmp_path / "bad.ddnmbet").encode()
+    open(bad, "wb").write(raw)
+    assert l.ddn_mbe_tables_load_file(bad, C.byref(u)) != 0
+    open(bad, "wb").write(bytes(raw[:-9]))              # truncated
+    assert l.ddn_mbe_tables_load_file(bad, C.byref(u)) != 0
+    t.ambe_L[5] = 3                                     # out of range: refused at save time
+    assert l.ddn_mbe_tables_save_file(bad, C.byref(t)) != 0
