@@ -603,47 +603,91 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const bool has20 = s.span == 20;
                 const float up_lim = s.maxref * 1.25f, dn_lim = s.minref * 1.25f;
                 const int left = s.span - s.i; // samples this symbol still needs
-                if (live && began && lean && steady && pos + left <= n && left <= MAXW && !(cfg.dbg & 256)) {
-                    // Whole-symbol pass (hunting, or in frame before the latch is set): every sample read issued up front,
-                    // then crossing latch + window sums in sample order - the arithmetic of the sample-at-a-time loop below
+                const bool whole_ok = live && began && lean && steady && pos + left <= n && left <= MAXW && !(cfg.dbg & 256);
+                if (__any(whole_ok)) {
+                    // Whole-symbol pass (hunting, or in frame before the latch is set) - the arithmetic of the sample-at-a-time loop
+                    // below, laid out over the wave: the crossing test of sample k reads x[k], x[k - 1] and values that are fixed
+                    // for the whole symbol, so the 64 / CPW lanes that share a channel's column (lane = channel + CPW * slot) each
+                    // test the samples k = slot, slot + 64 / CPW, ... and the owner takes the lowest set bit of the ballots: the
+                    // first crossing, as the in-order search latches it.  The window sums stay on the owner lane, in sample order.
+                    constexpr int EPL = 64 / CPW;
+                    const int oc = lane % CPW, slot = lane / CPW;
                     const int i0 = s.i;
-                    float xs[MAXW];
+                    const int need_o = __shfl((int)(whole_ok && s.jitter < 0), oc);
+                    const int left_o = __shfl(left, oc), pos_o = __shfl(pos, oc), i0_o = __shfl(i0, oc);
+                    const int flt_o = __shfl((int)fo_now, oc), clip_o = __shfl((int)clip, oc);
+                    const float cen_o = __shfl(s.center, oc), ul_o = __shfl(up_lim, oc), dl_o = __shfl(dn_lim, oc);
+                    const float mx_o = __shfl(s.max, oc), mn_o = __shfl(s.min, oc), ls_o = __shfl(s.lastsample, oc);
+                    const float* po = flt_o ? &L.flt[oc][0] : &L.raw[oc][0];
+                    int found = -1;
+                    if (__any(need_o != 0)) {
 #pragma unroll
-                    for (int k = 0; k < MAXW; k++) {
-                        xs[k] = rowp[(pos + (k < left ? k : 0)) & RMASKW];
-                    }
-                    float last = s.lastsample, sum = 0.0f;
-                    int jit = s.jitter, c = 0;
+                        for (int r = 0; r < (MAXW + EPL - 1) / EPL; r++) {
+                            const int k = slot + r * EPL;
+                            bool hit = false;
+                            if (need_o && k < left_o) {
+                                float x = po[(pos_o + k) & RMASKW];
+                                float xp = k == 0 ? ls_o : po[(pos_o + k - 1) & RMASKW];
+                                if (clip_o) {
+                                    x = x > mx_o ? mx_o : (x < mn_o ? mn_o : x);
+                                    if (k > 0) { // (the symbol's first sample compares with lastsample as it was stored)
+                                        xp = xp > mx_o ? mx_o : (xp < mn_o ? mn_o : xp);
+                                    }
+                                }
+                                const bool up = x > cen_o;
+                                const bool within = up ? !(x > ul_o) : !(x < dl_o);
+                                const bool crossed = up ? (xp < cen_o) : (xp > cen_o);
+                                // a crossing at symbol index -1 (sample 0 of a symbol that slipped early) stores -1: nothing latched
+                                hit = within && crossed && (i0_o + k >= 0);
+                            }
+                            unsigned long long col = __ballot(hit) >> oc; // this channel's column: bits oc, oc + CPW, ...
+                            unsigned long long m = 0;
 #pragma unroll
-                    for (int k = 0; k < MAXW; k++) {
-                        if (k < left) {
-                            float x = xs[k];
-                            if (clip) {
-                                x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                            for (int e = 0; e < EPL; e++) {
+                                m |= 1ull << (e * CPW);
                             }
-                            const int i = i0 + k;
-                            const bool up = x > s.center;
-                            const bool within = up ? !(x > up_lim) : !(x < dn_lim);
-                            const bool crossed = up ? (last < s.center) : (last > s.center);
-                            jit = (jit < 0 && within && crossed) ? i : jit;
-                            const bool k1 = two ? (i == wlo || i == whi) : (i >= wlo && i <= whi);
-                            const bool k2 = has20 && i >= 7 && i <= 13;
-                            if (k2) {
-                                sum += x;
+                            col &= m;
+                            if (found < 0 && col != 0) {
+                                found = (__ffsll((long long)col) - 1) / CPW + r * EPL;
                             }
-                            if (k1) {
-                                sum += x;
-                            }
-                            c += (k1 ? 1 : 0) + (k2 ? 1 : 0);
-                            last = x;
                         }
                     }
-                    s.sum = sum;
-                    s.count = c;
-                    s.jitter = jit;
-                    s.lastsample = last;
-                    s.i = s.span;
-                    pos += left;
+                    if (whole_ok) {
+                        // window sums in sample order: index i of the symbol adds once when it lies in 7..13 of a 20-sample symbol,
+                        // once more when it lies in the modulation's window (symbol_accumulate_sample)
+                        const int i_lo = has20 && 7 < wlo ? 7 : wlo, i_hi = has20 && 13 > whi ? 13 : whi;
+                        float sum = 0.0f;
+                        int c = 0;
+#pragma unroll
+                        for (int q = 0; q < 12; q++) {
+                            const int i = i_lo + q, k = i - i0;
+                            if (i <= i_hi && k >= 0 && k < left) {
+                                float x = rowp[(pos + k) & RMASKW];
+                                if (clip) {
+                                    x = x > s.max ? s.max : (x < s.min ? s.min : x);
+                                }
+                                const bool k1 = two ? (i == wlo || i == whi) : (i >= wlo && i <= whi);
+                                const bool k2 = has20 && i >= 7 && i <= 13;
+                                if (k2) {
+                                    sum += x;
+                                }
+                                if (k1) {
+                                    sum += x;
+                                }
+                                c += (k1 ? 1 : 0) + (k2 ? 1 : 0);
+                            }
+                        }
+                        float last = rowp[(pos + left - 1) & RMASKW];
+                        if (clip) {
+                            last = last > s.max ? s.max : (last < s.min ? s.min : last);
+                        }
+                        s.sum = sum;
+                        s.count = c;
+                        s.jitter = (s.jitter < 0 && found >= 0) ? i0 + found : s.jitter;
+                        s.lastsample = last;
+                        s.i = s.span;
+                        pos += left;
+                    }
                 }
                 // sample-at-a-time loop: a symbol carried over a call boundary, the filter's cold start, very short symbols
                 bool act = live && s.in_symbol && pos < lim && s.i < s.span;
