@@ -21,6 +21,8 @@
 #define DDN_CHAIN_H
 #include <stddef.h>
 #include <stdint.h>
+
+#include "ddn_hip.h" /* DDN_OK ..., DDN_IN_*, ddn_last_error() */
 #ifdef __cplusplus
 extern "C" {
 #endif

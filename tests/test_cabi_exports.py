@@ -49,3 +49,18 @@ def test_product_does_not_reference_oracle():
                     continue
                 t = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "ddn_oracle" not in t and "oracle/" not in t.replace("oracle/_ref", ""), os.path.join(dp, fn)
+
+
+def test_c_host_example_compiles_and_links(built, tmp_path):
+    """INTEGRATION.md's C host over ddn_p25_chain (examples/p25_chain_host.c) builds with plain gcc against include/ and the
+    library - the boundary is C, no HIP or torch on the caller's side; without a GPU it fails loudly at create"""
+    import subprocess
+    exe = str(tmp_path / "p25_chain_host")
+    lib_dir = os.path.dirname(ddn.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ddn.ROOT, "include"),
+                           os.path.join(ddn.ROOT, "examples", "p25_chain_host.c"), "-L", lib_dir, "-ldsdneo_hip",
+                           "-Wl,-rpath," + lib_dir, "-o", exe])
+    import torch
+    if not torch.cuda.is_available():
+        p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 1 and p.stderr.strip()       # ddn_last_error(): no device - never a CPU fallback
