@@ -659,7 +659,7 @@ constexpr int WMAX = 24;
 
 
 // 1: per-wave cycle counters (tile body / barrier wait / trips by kind) written over the tail of each workgroup's first
-// record area when cfg.dbg bit 8192 is set - timing experiments only (tools/scratch/rx_cyc.py)
+// record area when cfg.dbg bit 8192 is set - timing experiments only (tools/bench_rx_handlers.py with DDN_RX_DBG=8192 and a library built with EXTRA=-DDDN_RX_CYCLES=1)
 #ifndef DDN_RX_CYCLES
 #define DDN_RX_CYCLES 0
 #endif

@@ -91,9 +91,10 @@ def test_dmr_inverted_captures_decode_clean_under_xr(built, cap):
     """These two captures are discriminator audio of inverted polarity as this chain (pinned to the reference's front end)
     sees it: only the BS voice word matches.  Under the reference's -xr rules (opts->inverted_dmr: voice word = data burst,
     digitize() un-inverts, cached dibits ^= 2) every burst decodes clean: Golay(20,8) slot types under one colour code,
-    BPTC(196,96) without residual errors and the CSBK CRC-CCITT (mask 0xA5A5) on every CSBK.  NOTE: the reference's suite
-    asserts "Color Code=02" on both with plain -fs (tests/CMakeLists.txt:8925-8930), which this chain cannot reproduce
-    (it reads colour code 1 here); the self-checking FEC is what pins the loop on these two."""
+    BPTC(196,96) without residual errors and the CSBK CRC-CCITT (mask 0xA5A5) on every CSBK: the channel's colour code is 1.
+    The reference's suite asserts "Color Code=02" on both with plain -fs (tests/CMakeLists.txt:8925-8930): that reading - the
+    voice handler decoding the sync word's own dibits as an EMB - is reproduced with the handlers in the loop, see
+    tests/test_oracle_handlers.py::test_dmr_plain_fs_reading_prints_color_code_02 and DESIGN.md 5g."""
     disc = rx4.capture_disc(cap, 2)
     out = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_DMR, rf_mod=0, inverted=1)).run(disc)
     assert len(out["sync_pos"]) >= 60 and np.all(out["sync_pat"] == 1)
