@@ -759,14 +759,16 @@ k_mbe_synth(const DdnMbeFrameRec* __restrict__ recs, float* __restrict__ pcm) {
                 const float c3 = unvoiced_mix(cw0, cw0l, l, n, base, 0x200u);
                 return (((c3 * MBE_UVSINE) * w) * cM) * MBE_QFACTOR;
             };
-            if (inA) {
+            // a side whose amplitude is exactly zero (the harmonics above that frame's L) likewise adds +-0: not evaluated
+            const bool p_on = pM != 0.0f, c_on = cM != 0.0f;
+            if (inA && p_on) {
                 acc[0] = acc[0] + prev_side(nA, wpA);
             }
-            if (inB) {
+            if (inB && (p_on || c_on)) {
                 // (the reference adds the two sides in an order that depends on the voicing pair; the sum is the same)
-                acc[1] = acc[1] + (prev_side(nB, wpB) + cur_side(nB, wcB));
+                acc[1] = acc[1] + ((p_on ? prev_side(nB, wpB) : 0.0f) + (c_on ? cur_side(nB, wcB) : 0.0f));
             }
-            if (inC) {
+            if (inC && c_on) {
                 acc[2] = acc[2] + cur_side(nC, wcC);
             }
         }
