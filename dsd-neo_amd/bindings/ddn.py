@@ -469,7 +469,7 @@ class Fsk4ChainConfig(C.Structure):  # == ddn_fsk4_chain_config
 
 class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
     _fields_ = [("stride_symbols", C.c_size_t), ("carry_symbols", C.c_size_t), ("max_syncs", C.c_size_t), ("voice_slots", C.c_int)] + [
-        (k, C.c_void_p) for k in ("d_records10", "d_flags", "d_payload2", "d_new", "d_counts", "d_n_sync", "d_sync_pos", "d_sync_pat", "d_pre",
+        (k, C.c_void_p) for k in ("d_records10", "d_flags", "d_payload2", "d_new", "d_counts", "d_n_sync", "d_dropped_syncs", "d_sync_pos", "d_sync_pat", "d_pre",
                                   "d_valid", "d_dmr_slot_type", "d_dmr_slot_type_ok", "d_dmr_pdu96", "d_dmr_bptc_errs", "d_nxdn_lich",
                                   "d_nxdn_sacch", "d_nxdn_sacch_ok", "d_nxdn_sacch_hard", "d_nxdn_sacch_hard_ok", "d_nxdn_facch",
                                   "d_nxdn_facch_ok", "d_nxdn_voice_skip", "d_nxdn_ambe_bits", "d_nxdn_pcm")]

@@ -44,7 +44,7 @@ struct ddn_fsk4_chain {
     uint8_t *d_rec[2], *d_fl[2], *d_pay;
     int32_t *d_new[2], *d_cnt_full, *d_cnt_scan;
     // what the loop reports per call, the syncs waiting for the next call (two sets), the syncs decoded in this one
-    int32_t *s_pos, *s_n, *c_pos[2], *c_n[2], *d_spos, *d_ns;
+    int32_t *s_pos, *s_n, *c_pos[2], *c_n[2], *d_spos, *d_ns, *d_dropped;
     uint8_t *s_pat, *s_pre, *s_prel, *c_pat[2], *c_pre[2], *c_prel[2], *d_spat, *d_pre, *d_prel;
     // DMR
     uint8_t *d_st, *d_info, *d_cach, *d_valid, *d_st_ok, *d_pdu, *d_r3;
@@ -77,7 +77,7 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
     ddn_fsk4_rx_destroy(c->rx);
     ddn_mbe_batch_destroy(c->mbe);
     void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_pay, c->d_new[0], c->d_new[1], c->d_cnt_full,
-                   c->d_cnt_scan, c->s_pos, c->s_n, c->c_pos[0], c->c_pos[1], c->c_n[0], c->c_n[1], c->d_spos, c->d_ns, c->s_pat, c->s_pre,
+                   c->d_cnt_scan, c->d_dropped, c->s_pos, c->s_n, c->c_pos[0], c->c_pos[1], c->c_n[0], c->c_n[1], c->d_spos, c->d_ns, c->s_pat, c->s_pre,
                    c->s_prel, c->c_pat[0], c->c_pat[1], c->c_pre[0], c->c_pre[1], c->c_prel[0], c->c_prel[1], c->d_spat, c->d_pre,
                    c->d_prel, c->d_st, c->d_info, c->d_cach, c->d_valid, c->d_st_ok, c->d_pdu, c->d_r3, c->d_errs, c->d_lich, c->d_ss,
                    c->d_sr, c->d_fs, c->d_fr, c->d_sacch, c->d_sacch_ok, c->d_hard_in, c->d_sacch_hard, c->d_sacch_hard_ok, c->d_facch,
@@ -132,11 +132,17 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
         c->ms = ddn_fsk4_rx_max_symbols(c->rx, (size_t)c->n);
         c->my = ddn_fsk4_rx_max_syncs(c->rx, (size_t)c->n);
         c->stride = (size_t)c->T + c->ms;
-        c->myd = (int)c->my + c->myc;
+        // Decode slots per channel and call.  The loop's own bound (a sync per window length) is what noise could do in theory;
+        // with the handlers in the loop accepted syncs are bursts / frames (144 / 192 symbols apart), so twice the densest real
+        // traffic + the carried ones is what every decode launch is sized for - a sync beyond that is counted in d_dropped_syncs.
+        {
+            const size_t dense = c->ms / 64 + 24 + (size_t)c->myc, loop_bound = c->my + (size_t)c->myc;
+            c->myd = (int)(cfg->handlers && dense < loop_bound ? dense : loop_bound);
+        }
         c->S = (size_t)c->B * (size_t)c->myd;
         const size_t B = (size_t)c->B, S = c->S, my = c->my, myc = (size_t)c->myc;
         bool ok = dalloc(&c->d_disc, B * (size_t)c->n) && dalloc(&c->d_pay, B * c->stride * 2) && dalloc(&c->d_cnt_full, B)
-                  && dalloc(&c->d_cnt_scan, B) && dalloc(&c->s_pos, B * my) && dalloc(&c->s_n, B) && dalloc(&c->s_pat, B * my)
+                  && dalloc(&c->d_cnt_scan, B) && dalloc(&c->d_dropped, B) && dalloc(&c->s_pos, B * my) && dalloc(&c->s_n, B) && dalloc(&c->s_pat, B * my)
                   && dalloc(&c->s_pre, B * my * 90) && dalloc(&c->s_prel, B * my * 90) && dalloc(&c->d_spos, S) && dalloc(&c->d_ns, B)
                   && dalloc(&c->d_spat, S) && dalloc(&c->d_pre, S * 90) && dalloc(&c->d_prel, S * 90);
         for (int k = 0; k < 2 && ok; k++) {
@@ -188,7 +194,7 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
     HIP_TRY(ddn_dev_fsk4_chain_syncs(c->c_pos[prev], c->c_pat[prev], c->c_pre[prev], c->c_prel[prev], c->c_n[prev], c->myc, c->s_pos,
                                      c->s_pat, c->s_pre, c->s_prel, c->s_n, (int)c->my, c->d_new[cur], c->T, flush, c->d_spos, c->d_spat,
                                      c->d_pre, c->d_prel, c->d_ns, c->myd, c->c_pos[cur], c->c_pat[cur], c->c_pre[cur], c->c_prel[cur],
-                                     c->c_n[cur], c->B, st));
+                                     c->c_n[cur], c->d_dropped, c->B, st));
     if (c->dmr) {
         // burst gather -> slot type Golay(20,8) -> BPTC(196,96)
         DDN_TRY(ddn_dmr_burst_gather(rec, c->d_cnt_full, c->stride, c->d_spos, c->d_pre, c->d_ns, c->B, (size_t)c->myd, c->cfg.inverted,
@@ -294,6 +300,7 @@ ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
     r->d_new = c->d_new[cur];
     r->d_counts = c->d_cnt_full;
     r->d_n_sync = c->d_ns;
+    r->d_dropped_syncs = c->d_dropped;
     r->d_sync_pos = c->d_spos;
     r->d_sync_pat = c->d_spat;
     r->d_pre = c->d_pre;

@@ -183,11 +183,12 @@ k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict_
                    const int32_t* __restrict__ s_n, int my, const int32_t* __restrict__ n_new, int T, int flush,
                    int32_t* __restrict__ d_pos, uint8_t* __restrict__ d_pat, uint8_t* __restrict__ d_pre, uint8_t* __restrict__ d_prel,
                    int32_t* __restrict__ d_n, int myd, int32_t* __restrict__ o_pos, uint8_t* __restrict__ o_pat,
-                   uint8_t* __restrict__ o_pre, uint8_t* __restrict__ o_prel, int32_t* __restrict__ o_n) {
+                   uint8_t* __restrict__ o_pre, uint8_t* __restrict__ o_prel, int32_t* __restrict__ o_n,
+                   int32_t* __restrict__ dropped) {
     const int c = blockIdx.x, lane = threadIdx.x;
     const int nc = c_n[c] < myc ? c_n[c] : myc, nsn = s_n[c] < my ? s_n[c] : my;
     const int limit = flush ? 0x7FFFFFFF : n_new[c], shift = n_new[c];
-    int kd = 0, ko = 0;
+    int kd = 0, ko = 0, lost = 0;
     for (int i = 0; i < nc + nsn; i++) {
         const bool carried = i < nc;
         const int j = carried ? i : i - nc;
@@ -198,6 +199,7 @@ k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict_
         uint8_t *qp, *qr;
         if (p < limit) {
             if (kd >= myd) {
+                lost++; // more accepted syncs than decode slots: counted, never silent
                 continue;
             }
             if (lane == 0) {
@@ -209,6 +211,7 @@ k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict_
             kd++;
         } else {
             if (ko >= myc) {
+                lost++;
                 continue;
             }
             if (lane == 0) {
@@ -227,6 +230,7 @@ k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict_
     if (lane == 0) {
         d_n[c] = kd;
         o_n[c] = ko;
+        dropped[c] += lost;
     }
 }
 
@@ -361,12 +365,12 @@ ddn_dev_fsk4_chain_syncs(const int32_t* c_pos, const uint8_t* c_pat, const uint8
                          const int32_t* s_pos, const uint8_t* s_pat, const uint8_t* s_pre, const uint8_t* s_prel, const int32_t* s_n, int my,
                          const int32_t* n_new, int T, int flush, int32_t* d_pos, uint8_t* d_pat, uint8_t* d_pre, uint8_t* d_prel,
                          int32_t* d_n, int myd, int32_t* o_pos, uint8_t* o_pat, uint8_t* o_pre, uint8_t* o_prel, int32_t* o_n,
-                         int n_channels, hipStream_t st) {
+                         int32_t* dropped, int n_channels, hipStream_t st) {
     if (n_channels <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_fsk4_chain_syncs, dim3((unsigned)n_channels), dim3(64), 0, st, c_pos, c_pat, c_pre, c_prel, c_n, myc, s_pos, s_pat,
-                       s_pre, s_prel, s_n, my, n_new, T, flush, d_pos, d_pat, d_pre, d_prel, d_n, myd, o_pos, o_pat, o_pre, o_prel, o_n);
+                       s_pre, s_prel, s_n, my, n_new, T, flush, d_pos, d_pat, d_pre, d_prel, d_n, myd, o_pos, o_pat, o_pre, o_prel, o_n, dropped);
     return hipGetLastError();
 }
 

@@ -149,6 +149,8 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const int32_t* d_new;           /* [B] new records of this call */
     const int32_t* d_counts;        /* [B] records in the row (carried + new) */
     const int32_t* d_n_sync;        /* [B] syncs decoded in this call */
+    const int32_t* d_dropped_syncs; /* [B] running count of accepted syncs that found no decode slot (max_syncs is sized for twice
+                                       the densest burst / frame traffic when the handlers run in the loop; 0 in every test) */
     const int32_t* d_sync_pos;      /* [S] row index of the sync's last symbol */
     const uint8_t* d_sync_pat;      /* [S] */
     const uint8_t* d_pre;           /* [S][90] the payload history handed over at each sync */

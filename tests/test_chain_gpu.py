@@ -157,3 +157,56 @@ def test_split_invariance_and_the_three_run_forms(built):
             vb = [v for v in got.voice[c] if v[0] + 900 < cnt]
             assert len(va) == len(vb) and all(x[0] == y[0] and np.array_equal(x[2], y[2]) and np.array_equal(x[4].view(np.uint32), y[4].view(np.uint32))
                                               for x, y in zip(va, vb)), (how, c)
+
+
+def test_run_host_copies_back_what_the_device_holds(built):
+    """ddn_p25_chain_run_host with output buffers: the pinned-host copies of a call (records, flags, counts, decisions + payloads,
+    NIDs, TSDU blocks, PCM) equal the device arrays of that call, call after call (the D2H copies run on their own stream behind
+    the decode, double buffered against the next call)"""
+    l = ddn.lib()
+    B, n_call, calls = 4, 16384, 4
+    iq = _stream(B, n_call * calls)
+    ch = ddn.P25ChainC(B, n_call)
+    S, V, st, E = B * ch.F, B * ch.Fv * 9, ch.stride, ch.E
+    shapes = {"records10": (np.uint8, (B, st, 10)), "flags": (np.uint8, (B, st)), "counts": (np.int32, (B,)),
+              "events": (np.int32, (B, E, 4)), "n_events": (np.int32, (B,)), "event_data": (np.int32, (B, E, 4)),
+              "nid4": (np.int32, (S, 4)), "tsbk": (np.uint8, (3, S, 12)), "pcm": (np.float32, (V, 160))}
+    pinned, outs, views = [], [], []
+    for _ in range(2):                                   # two sets: call k's copies finish while call k + 1 runs
+        o, v = ddn.P25ChainHostOut(), {}
+        for name, (dt, shp) in shapes.items():
+            nbytes = int(np.prod(shp)) * np.dtype(dt).itemsize
+            p = C.c_void_p()
+            assert l.ddn_host_alloc_pinned(nbytes, C.byref(p)) == 0
+            pinned.append(p)
+            setattr(o, name, p.value)
+            v[name] = np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=dt).reshape(shp)
+        outs.append(o)
+        views.append(v)
+    h_iq = []
+    for k in range(calls):
+        part = np.ascontiguousarray(iq[:, k * n_call:(k + 1) * n_call])
+        p = C.c_void_p()
+        assert l.ddn_host_alloc_pinned(part.nbytes, C.byref(p)) == 0
+        C.memmove(p, part.ctypes.data, part.nbytes)
+        h_iq.append(p)
+    names = {"records10": "d_records10", "flags": "d_flags", "counts": "d_counts", "events": "d_events", "n_events": "d_n_events",
+             "event_data": "d_event_data", "nid4": "d_nid4", "tsbk": "d_tsbk", "pcm": "d_pcm"}
+    seen_pcm = 0.0
+    for k in range(calls):
+        ch.run_host(h_iq[k], outs[k & 1])
+        ch.wait()
+        r = ch.results()
+        for name, (dt, shp) in shapes.items():
+            dev = ch.fetch(getattr(r, names[name]), dt, shp)
+            host = views[k & 1][name]
+            if name in ("events", "event_data"):          # rows beyond n_events are not written by the loop
+                ne = ch.fetch(r.d_n_events, np.int32, (B,))
+                assert all(np.array_equal(dev[c, :ne[c]], host[c, :ne[c]]) for c in range(B)), (k, name)
+            else:
+                assert np.array_equal(dev.view(np.uint8), host.view(np.uint8)), (k, name)
+        seen_pcm += float(np.abs(views[k & 1]["pcm"]).sum())
+    assert seen_pcm > 0
+    ch.close()
+    for p in pinned + h_iq:
+        l.ddn_host_free_pinned(p)

@@ -70,7 +70,8 @@ def _check_rx(ch, Bc, calls_iq, proto, lpf, rf):
             want[c] += [(int(base[c]) + int(p), q) for p, q in zip(w["sync_pos"], w["pre"])]
             base[c] += k
     ch.flush()
-    take()
+    r, _, _ = take()
+    assert not ch.fetch(r.d_dropped_syncs, np.int32, (Bc,)).any()
     for c in range(Bc):
         assert [g for g, _ in got[c]] == [g for g, _ in want[c]], (c, len(got[c]), len(want[c]))
         assert all(np.array_equal(a[1], b[1]) for a, b in zip(got[c], want[c])), c
