@@ -49,6 +49,7 @@ struct ddn_p25_chain {
     int32_t *d_cnt_scan, *d_cnt_full;
     // decode buffers
     int32_t* d_nid;
+    int32_t *d_lists, *d_list_n; // per frame type: the slots holding a frame of it (k_chain_frames), what the decode launches walk
     uint8_t* d_cls; // frame type of every slot (DDN_CLS_*): the per-type decode launches only work on their own frames
     uint8_t *d_tsbk, *d_tsbk_crc;
     uint8_t *d_words[2], *d_wrel, *d_werrs, *d_vldu;
@@ -94,7 +95,7 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     ddn_mbe_batch_destroy(c->mbe);
     void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_new[0], c->d_new[1], c->d_ev[0], c->d_ev[1],
                    c->d_nev[0], c->d_nev[1], c->d_evd[0], c->d_evd[1], c->d_evl[0], c->d_evl[1], c->d_evdl[0], c->d_evdl[1],
-                   c->d_nevl[0], c->d_nevl[1], c->d_cnt_scan, c->d_cnt_full, c->d_nid, c->d_cls, c->d_tsbk, c->d_tsbk_crc, c->d_words[0],
+                   c->d_nevl[0], c->d_nevl[1], c->d_cnt_scan, c->d_cnt_full, c->d_nid, c->d_cls, c->d_lists, c->d_list_n, c->d_tsbk, c->d_tsbk_crc, c->d_words[0],
                    c->d_words[1], c->d_wrel, c->d_werrs, c->d_vldu, c->d_rs_d[0], c->d_rs_d[1], c->d_rs_p[0], c->d_rs_p[1],
                    c->d_rs_st[0], c->d_rs_st[1], c->d_lsd, c->d_lsd_ok, c->d_lsd_llr, c->d_hdu_hex, c->d_hdu_par, c->d_hdu_st,
                    c->d_hdu_d, c->d_hdu_p, c->d_hdu_rs, c->d_td_d, c->d_td_p, c->d_td_st, c->d_td_rd, c->d_td_rp, c->d_td_rs,
@@ -179,7 +180,7 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
                  && dalloc(&c->d_ev[k], B * (size_t)c->E * 4) && dalloc(&c->d_nev[k], B) && dalloc(&c->d_evd[k], B * (size_t)c->E * 4)
                  && dalloc(&c->d_evl[k], B * (size_t)c->EL * 4) && dalloc(&c->d_evdl[k], B * (size_t)c->EL * 4) && dalloc(&c->d_nevl[k], B);
         }
-        ok = ok && dalloc(&c->d_cnt_scan, B) && dalloc(&c->d_cnt_full, B) && dalloc(&c->d_nid, S * 4) && dalloc(&c->d_cls, S)
+        ok = ok && dalloc(&c->d_cnt_scan, B) && dalloc(&c->d_cnt_full, B) && dalloc(&c->d_nid, S * 4) && dalloc(&c->d_cls, S) && dalloc(&c->d_lists, S * DDN_LIST_COUNT) && dalloc(&c->d_list_n, 8)
              && dalloc(&c->d_tsbk, 3 * S * 12) && dalloc(&c->d_tsbk_crc, 3 * S) && dalloc(&c->d_words[0], S * 240)
              && dalloc(&c->d_words[1], S * 240) && dalloc(&c->d_wrel, S * 240) && dalloc(&c->d_werrs, S * 24) && dalloc(&c->d_vldu, S)
              && dalloc(&c->d_rs_d[0], S * 72) && dalloc(&c->d_rs_d[1], S * 96) && dalloc(&c->d_rs_p[0], S * 72)
@@ -289,34 +290,36 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
                                      st));
         const int32_t *d_ns = nullptr, *d_sp = nullptr;
         DDN_TRY(ddn_p25p1_framer_device_syncs(c->fr, &d_ns, &d_sp));
+        HIP_TRY(hipMemsetAsync(c->d_list_n, 0, sizeof(int32_t) * 8, st));
         HIP_TRY(ddn_dev_chain_frames(c->d_evl[cur], c->d_evdl[cur], c->d_nevl[cur], c->EL, d_sp, d_ns, c->B, c->F, c->off97[0],
-                                     c->off97[1], c->off97[2], c->d_nid, c->d_tsbk, c->d_tsbk_crc, c->d_cls, st));
+                                     c->off97[1], c->off97[2], c->d_nid, c->d_tsbk, c->d_tsbk_crc, c->d_cls, c->d_lists, c->d_list_n,
+                                     st));
     }
-    // Every decode below is launched over all frame slots but works only on the slots whose NID names its frame type (d_cls): a
-    // slot's LDU / HDU / TDULC outputs are meaningful for that type alone.  The selection is cleared on every way out.
+    // Every decode below walks the work list of its frame type (the slots whose NID names it, k_chain_frames): a slot's LDU / HDU /
+    // TDULC outputs are meaningful for that type alone.  The selection is cleared on every way out.
     struct SelGuard {
         ~SelGuard() { ddn_sel_clear(); }
     } sel_guard;
     // LDU1 / LDU2: Hamming words -> Reed-Solomon; low speed data
     for (int i = 0; i < 2; i++) {
         const int ldu = i + 1;
-        ddn_sel_set(c->d_cls, i == 0 ? DDN_CLS_LDU1 : DDN_CLS_LDU2);
+        ddn_sel_set(c->d_lists + (size_t)i * S, c->d_list_n + i);
         DDN_TRY(ddn_p25p1_framer_gather_ldu_words(c->fr, ldu, rec, c->d_cnt_full, stride, c->d_words[i], c->d_wrel, c->d_vldu, st));
         DDN_TRY(ddn_fec_hamming_10_6_3_batch(c->d_words[i], S * 24, c->d_werrs, st));
         DDN_TRY(ddn_p25p1_framer_pack_ldu_rs(c->fr, ldu, c->d_words[i], c->d_rs_d[i], c->d_rs_p[i], st));
         DDN_TRY(ddn_fec_p25_rs_batch(i == 0 ? DDN_RS_24_12_13 : DDN_RS_24_16_9, c->d_rs_d[i], c->d_rs_p[i], S, c->d_rs_st[i], st));
     }
-    ddn_sel_set(c->d_cls, DDN_CLS_LDU1 | DDN_CLS_LDU2);
+    ddn_sel_set(c->d_lists + (size_t)DDN_LIST_LSD * S, c->d_list_n + DDN_LIST_LSD);
     DDN_TRY(ddn_p25p1_framer_gather_lsd(c->fr, rec, c->d_cnt_full, stride, c->d_lsd, c->d_lsd_llr, c->d_vldu, st));
     DDN_TRY(ddn_fec_p25_lsd_batch(c->d_lsd, c->d_lsd_llr, S * 2, c->d_lsd_ok, st));
     // HDU: 36 Golay(24,6) words -> RS(36,20,17)
-    ddn_sel_set(c->d_cls, DDN_CLS_HDU);
+    ddn_sel_set(c->d_lists + (size_t)DDN_LIST_HDU * S, c->d_list_n + DDN_LIST_HDU);
     DDN_TRY(ddn_p25p1_framer_gather_hdu(c->fr, rec, c->d_cnt_full, stride, c->d_hdu_hex, c->d_hdu_par, nullptr, nullptr, c->d_vldu, st));
     DDN_TRY(ddn_fec_golay24_batch(6, c->d_hdu_hex, c->d_hdu_par, S * 36, c->d_hdu_st, nullptr, st));
     DDN_TRY(ddn_p25p1_framer_pack_hdu_rs(c->fr, c->d_hdu_hex, c->d_hdu_d, c->d_hdu_p, st));
     DDN_TRY(ddn_fec_p25_rs_batch(DDN_RS_36_20_17, c->d_hdu_d, c->d_hdu_p, S, c->d_hdu_rs, st));
     // TDULC: 12 Golay(24,12) words -> RS(24,12,13)
-    ddn_sel_set(c->d_cls, DDN_CLS_TDULC);
+    ddn_sel_set(c->d_lists + (size_t)DDN_LIST_TDULC * S, c->d_list_n + DDN_LIST_TDULC);
     DDN_TRY(ddn_p25p1_framer_gather_tdulc(c->fr, rec, c->d_cnt_full, stride, c->d_td_d, c->d_td_p, nullptr, nullptr, c->d_vldu, st));
     DDN_TRY(ddn_fec_golay24_batch(12, c->d_td_d, c->d_td_p, S * 12, c->d_td_st, nullptr, st));
     DDN_TRY(ddn_p25p1_framer_pack_tdulc_rs(c->fr, c->d_td_d, c->d_td_rd, c->d_td_rp, st));

@@ -102,13 +102,7 @@ k_nid_decode(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel
 // row) is rewritten only for single-bit corrections, exactly like hamming_10_6_3_decode(); errs[n] = 0/1/2.
 __global__ void
 k_hamming_10_6_3(uint8_t* __restrict__ bits10, int n, uint8_t* __restrict__ errs, DdnSel sel) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) {
-        return;
-    }
-    if (sel.cls && !(sel.cls[c / sel.per_slot] & sel.mask)) {
-        return; // not a frame of the type this launch is for
-    }
+    auto one = [&](long c) {
     uint8_t* b = bits10 + (size_t)c * 10;
     int word = 0;
     bool bad = false;
@@ -143,6 +137,8 @@ k_hamming_10_6_3(uint8_t* __restrict__ bits10, int n, uint8_t* __restrict__ errs
         }
     }
     errs[c] = (uint8_t)e;
+    };
+    ddn_sel_for_each(sel, (long)n, one);
 }
 
 // Chase search of one NID per wavefront: lane t evaluates candidate t of the reference's sequence (base word, then the
@@ -303,7 +299,8 @@ ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_hamming_10_6_3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits10, n, errs, ddn_sel_for(24));
+    const DdnSel sel = ddn_sel_for(24);
+    hipLaunchKernelGGL(k_hamming_10_6_3, dim3(ddn_sel_grid(&sel, ((unsigned long)n + 255) / 256)), dim3(256), 0, st, bits10, n, errs, sel);
     return hipGetLastError();
 }
 
@@ -345,13 +342,7 @@ lsd_hard(int word) {
 
 __global__ void
 k_p25_lsd(uint8_t* __restrict__ bits16, const int16_t* __restrict__ llr16, int n, uint8_t* __restrict__ ok, DdnSel sel) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
-    }
-    if (sel.cls && !(sel.cls[i / sel.per_slot] & sel.mask)) {
-        return; // not a frame of the type this launch is for
-    }
+    auto one = [&](long i) {
     uint8_t* b = bits16 + (size_t)i * 16;
     int word = 0;
     for (int k = 0; k < 16; k++) {
@@ -406,6 +397,8 @@ k_p25_lsd(uint8_t* __restrict__ bits16, const int16_t* __restrict__ llr16, int n
         }
     }
     ok[i] = fixed >= 0 ? 1 : 0;
+    };
+    ddn_sel_for_each(sel, (long)n, one);
 }
 } // namespace
 
@@ -414,7 +407,8 @@ ddn_dev_p25_lsd(uint8_t* bits16, const int16_t* llr16, int n, uint8_t* ok, hipSt
     if (n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_lsd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits16, llr16, n, ok, ddn_sel_for(2));
+    const DdnSel sel = ddn_sel_for(2);
+    hipLaunchKernelGGL(k_p25_lsd, dim3(ddn_sel_grid(&sel, ((unsigned long)n + 255) / 256)), dim3(256), 0, st, bits16, llr16, n, ok, sel);
     return hipGetLastError();
 }
 

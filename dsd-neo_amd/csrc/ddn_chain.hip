@@ -92,7 +92,7 @@ __global__ void
 k_chain_frames(const int32_t* __restrict__ list, const int32_t* __restrict__ data, const int32_t* __restrict__ n_list, int EL,
                const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_syncs, int n_channels, int F, int off0, int off1,
                int off2, int32_t* __restrict__ nid4, uint8_t* __restrict__ tsbk, uint8_t* __restrict__ tsbk_crc,
-               uint8_t* __restrict__ cls) {
+               uint8_t* __restrict__ cls, int32_t* __restrict__ lists, int32_t* __restrict__ list_n) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_channels) {
         return;
@@ -133,7 +133,14 @@ k_chain_frames(const int32_t* __restrict__ list, const int32_t* __restrict__ dat
             reinterpret_cast<int4*>(nid4)[slot] = v;
             // frame type for the per-type decode launches that follow (DDN_CLS_*): only a decoded NID names one
             const int duid = v.z;
-            cls[slot] = v.x > 0 ? (uint8_t)(duid == 0x5 ? 1 : (duid == 0xA ? 2 : (duid == 0x0 ? 4 : (duid == 0xF ? 8 : 0)))) : 0;
+            const int ty = v.x > 0 ? (duid == 0x5 ? 0 : (duid == 0xA ? 1 : (duid == 0x0 ? 2 : (duid == 0xF ? 3 : -1)))) : -1;
+            cls[slot] = ty >= 0 ? (uint8_t)(1 << ty) : 0;
+            if (ty >= 0) { // the slot joins its frame type's work list (and the LDUs the low-speed-data list, 4): DDN_LIST_*
+                lists[(size_t)ty * S + atomicAdd(&list_n[ty], 1)] = (int32_t)slot;
+                if (ty < 2) {
+                    lists[(size_t)4 * S + atomicAdd(&list_n[4], 1)] = (int32_t)slot;
+                }
+            }
         } else if (blk < 3) {
             uint32_t* o = reinterpret_cast<uint32_t*>(tsbk + ((size_t)blk * S + slot) * 12);
             o[0] = (uint32_t)v.x;
@@ -285,16 +292,16 @@ k_tsbk_select(const uint8_t* __restrict__ cand, const int32_t* __restrict__ coun
 
 } // namespace
 
-static thread_local DdnSel g_sel = {nullptr, 0, 1};
+static thread_local DdnSel g_sel = {nullptr, nullptr, 1};
 extern "C" void
-ddn_sel_set(const uint8_t* cls, int mask) {
-    g_sel.cls = cls;
-    g_sel.mask = mask;
+ddn_sel_set(const int32_t* list, const int32_t* count) {
+    g_sel.list = list;
+    g_sel.count = count;
 }
 extern "C" void
 ddn_sel_clear(void) {
-    g_sel.cls = nullptr;
-    g_sel.mask = 0;
+    g_sel.list = nullptr;
+    g_sel.count = nullptr;
 }
 extern "C" DdnSel
 ddn_sel_for(int per_slot) {
@@ -339,12 +346,12 @@ ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_prev, const i
 extern "C" hipError_t
 ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
                      const int32_t* n_syncs, int n_channels, int F, int off0, int off1, int off2, int32_t* nid4, uint8_t* tsbk,
-                     uint8_t* tsbk_crc, uint8_t* cls, hipStream_t st) {
+                     uint8_t* tsbk_crc, uint8_t* cls, int32_t* lists, int32_t* list_n, hipStream_t st) {
     if (n_channels <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_chain_frames, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, list, data, n_list, EL, sync_pos,
-                       n_syncs, n_channels, F, off0, off1, off2, nid4, tsbk, tsbk_crc, cls);
+                       n_syncs, n_channels, F, off0, off1, off2, nid4, tsbk, tsbk_crc, cls, lists, list_n);
     return hipGetLastError();
 }
 

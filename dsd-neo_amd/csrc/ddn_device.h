@@ -261,17 +261,25 @@ hipError_t ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, i
 hipError_t ddn_dev_launch_carry(const void* in, int in_fmt, size_t ch_stride, long n, void* carry, int n_channels,
                                 hipStream_t st);
 hipError_t ddn_dev_zero(void* p, size_t bytes, hipStream_t st);
-/* Frame-slot selection for the per-slot framer / FEC launches of a chain (ddn_api_chain.cpp): cls [slots] carries one bit per
- * frame type, a launch made while a selection is set only works on the slots whose byte has a bit of `mask` (the others' outputs are
- * left as they are).  Thread-local, set around the launches it is meant for; {NULL, 0, 1} = every item. */
+/* Frame-slot selection for the per-slot framer / FEC launches of a chain (ddn_api_chain.cpp): a launch made while a selection is
+ * set walks `*count` frame slots taken from `list` (per_slot items each) instead of every slot - the work follows the frames of
+ * that type, not the slot capacity; the other slots' outputs are left as they are.  Thread-local, set around the launches it is
+ * meant for; list == NULL = every item. */
 typedef struct DdnSel {
-    const uint8_t* cls;
-    int mask;
-    int per_slot; /* items of this launch per frame slot */
+    const int32_t* list;  /* frame slots of the type, any order */
+    const int32_t* count; /* device word: entries in list */
+    int per_slot;         /* items of this launch per frame slot */
 } DdnSel;
-void ddn_sel_set(const uint8_t* cls, int mask);
+void ddn_sel_set(const int32_t* list, const int32_t* count);
 void ddn_sel_clear(void);
 DdnSel ddn_sel_for(int per_slot);
+/* blocks for a launch of n_blocks_full blocks when a selection is active (the list decides the work, the grid only has to fill the
+ * device) */
+static inline unsigned
+ddn_sel_grid(const DdnSel* sel, unsigned long n_blocks_full) {
+    const unsigned long cap = 4096;
+    return (unsigned)((sel->list && n_blocks_full > cap) ? cap : (n_blocks_full ? n_blocks_full : 1));
+}
 hipError_t ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, const int32_t* cnt_prev, int have_prev,
                                uint8_t* rec_cur, uint8_t* fl_cur, size_t stride_sym, int T, int n_channels, hipStream_t st);
 hipError_t ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, int flush, int32_t* cnt_scan, int32_t* cnt_full,
@@ -281,8 +289,9 @@ hipError_t ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_pr
                                 int n_channels, int32_t* list_cur, int32_t* data_cur, int32_t* n_cur, hipStream_t st);
 hipError_t ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
                                 const int32_t* n_syncs, int n_channels, int F, int off0, int off1, int off2, int32_t* nid4,
-                                uint8_t* tsbk, uint8_t* tsbk_crc, uint8_t* cls, hipStream_t st);
+                                uint8_t* tsbk, uint8_t* tsbk_crc, uint8_t* cls, int32_t* lists, int32_t* list_n, hipStream_t st);
 enum { DDN_CLS_LDU1 = 1, DDN_CLS_LDU2 = 2, DDN_CLS_HDU = 4, DDN_CLS_TDULC = 8 }; /* frame-type bits of a slot's class byte */
+enum { DDN_LIST_LDU1 = 0, DDN_LIST_LDU2 = 1, DDN_LIST_HDU = 2, DDN_LIST_TDULC = 3, DDN_LIST_LSD = 4, DDN_LIST_COUNT = 5 }; /* work lists [k][S] */
 hipError_t ddn_dev_nxdn_voice_select(const int32_t* sync_pos, const int32_t* n_sync, const uint8_t* lich, const uint8_t* valid,
                                      int n_channels, int my, int vf, int32_t* v_pos, int32_t* v_n, uint8_t* skip4, hipStream_t st);
 hipError_t ddn_dev_fsk4_chain_syncs(const int32_t* c_pos, const uint8_t* c_pat, const uint8_t* c_pre, const uint8_t* c_prel,
@@ -297,4 +306,25 @@ hipError_t ddn_dev_tsbk_select(const uint8_t* cand, const int32_t* counts, size_
 #ifdef __cplusplus
 }
 #endif
+#if defined(__HIPCC__)
+/* f(item) for every item of the launch: all n_items, or the selected slots' items, grid-strided */
+template <typename F>
+__device__ __forceinline__ void
+ddn_sel_for_each(const DdnSel& sel, long n_items, F&& f) {
+    const long stride = (long)gridDim.x * (long)blockDim.x;
+    long t = (long)blockIdx.x * (long)blockDim.x + (long)threadIdx.x;
+    if (!sel.list) {
+        for (; t < n_items; t += stride) {
+            f(t);
+        }
+        return;
+    }
+    const long total = (long)(*sel.count) * (long)sel.per_slot;
+    for (; t < total; t += stride) {
+        const long e = t / sel.per_slot;
+        f((long)sel.list[e] * (long)sel.per_slot + (t - e * (long)sel.per_slot));
+    }
+}
+#endif
+
 #endif

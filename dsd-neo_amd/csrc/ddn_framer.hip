@@ -49,15 +49,9 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
                 uint8_t* __restrict__ rel, int16_t* __restrict__ llr, int stride, int split_last,
                 uint8_t* __restrict__ last_bit, uint8_t* __restrict__ last_rel, uint8_t* __restrict__ valid,
                 uint8_t* __restrict__ dibits, uint8_t* __restrict__ dibit_rel, DdnSel sel) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    auto one = [&](long t) {
     const long slot = t / n_off;
     const int i = (int)(t % n_off);
-    if (slot >= (long)n_channels * max_frames) {
-        return;
-    }
-    if (sel.cls && !(sel.cls[slot] & sel.mask)) {
-        return;
-    }
     const int ch = (int)(slot / max_frames), k = (int)(slot % max_frames);
     const int cnt = counts[ch] < (int)max_sym ? counts[ch] : (int)max_sym;
     bool ok = k < n_syncs[ch];
@@ -117,6 +111,8 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
     if (i == 0 && valid) {
         valid[slot] = ok ? 1 : 0;
     }
+    };
+    ddn_sel_for_each(sel, (long)n_channels * max_frames * n_off, one);
 }
 } // namespace
 
@@ -141,9 +137,10 @@ ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32_t* counts,
     if (total <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_gather_fields, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rec, max_sym, counts,
+    const DdnSel sel = ddn_sel_for(n_off);
+    hipLaunchKernelGGL(k_gather_fields, dim3(ddn_sel_grid(&sel, ((unsigned long)total + 255) / 256)), dim3(256), 0, st, rec, max_sym, counts,
                        sync_pos, n_syncs, n_channels, max_frames, offsets, n_off, max_off, bits, rel, llr, stride,
-                       split_last, last_bit, last_rel, valid, dibits, dibit_rel, ddn_sel_for(1));
+                       split_last, last_bit, last_rel, valid, dibits, dibit_rel, sel);
     return hipGetLastError();
 }
 
@@ -174,15 +171,9 @@ namespace {
 __global__ void
 k_rs_pack(const uint8_t* __restrict__ words, long n_slots, int n_words, int wstride, int n_data,
           uint8_t* __restrict__ data, uint8_t* __restrict__ parity, DdnSel sel) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const int per = n_words * 6;
-    if (t >= n_slots * per) {
-        return;
-    }
+    auto one = [&](long t) {
     const long slot = t / per;
-    if (sel.cls && !(sel.cls[slot] & sel.mask)) {
-        return;
-    }
     const int r = (int)(t % per), w = r / 6, b = r % 6;
     const uint8_t v = words[(slot * n_words + w) * (long)wstride + b];
     if (w < n_data) {
@@ -190,6 +181,8 @@ k_rs_pack(const uint8_t* __restrict__ words, long n_slots, int n_words, int wstr
     } else {
         parity[slot * (long)((n_words - n_data) * 6) + (w - n_data) * 6 + b] = v;
     }
+    };
+    ddn_sel_for_each(sel, n_slots * per, one);
 }
 } // namespace
 
@@ -199,8 +192,9 @@ ddn_dev_rs_pack(const uint8_t* words, long n_slots, int n_words, int wstride, in
     if (n_slots <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_rs_pack, dim3((unsigned)((n_slots * n_words * 6 + 255) / 256)), dim3(256), 0, st, words, n_slots,
-                       n_words, wstride, n_data, data, parity, ddn_sel_for(1));
+    const DdnSel sel = ddn_sel_for(n_words * 6);
+    hipLaunchKernelGGL(k_rs_pack, dim3(ddn_sel_grid(&sel, ((unsigned long)n_slots * n_words * 6 + 255) / 256)), dim3(256), 0, st, words, n_slots,
+                       n_words, wstride, n_data, data, parity, sel);
     return hipGetLastError();
 }
 
@@ -211,14 +205,8 @@ namespace {
 __global__ void
 k_tdulc_rs_pack(const uint8_t* __restrict__ words, long n_slots, uint8_t* __restrict__ data, uint8_t* __restrict__ parity,
                 DdnSel sel) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_slots * 144) {
-        return;
-    }
+    auto one = [&](long t) {
     const long slot = t / 144;
-    if (sel.cls && !(sel.cls[slot] & sel.mask)) {
-        return;
-    }
     const int r = (int)(t % 144), hexw = r / 6, b = r % 6; // hexw 0..11 data, 12..23 parity
     const int dodeca = hexw / 2, half = hexw & 1;
     const uint8_t v = words[(slot * 12 + dodeca) * 12 + (half ? b : 6 + b)];
@@ -227,6 +215,8 @@ k_tdulc_rs_pack(const uint8_t* __restrict__ words, long n_slots, uint8_t* __rest
     } else {
         parity[slot * 72 + (hexw - 12) * 6 + b] = v;
     }
+    };
+    ddn_sel_for_each(sel, n_slots * 144, one);
 }
 } // namespace
 
@@ -235,8 +225,9 @@ ddn_dev_tdulc_rs_pack(const uint8_t* words, long n_slots, uint8_t* data, uint8_t
     if (n_slots <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_tdulc_rs_pack, dim3((unsigned)((n_slots * 144 + 255) / 256)), dim3(256), 0, st, words, n_slots,
-                       data, parity, ddn_sel_for(1));
+    const DdnSel sel = ddn_sel_for(144);
+    hipLaunchKernelGGL(k_tdulc_rs_pack, dim3(ddn_sel_grid(&sel, ((unsigned long)n_slots * 144 + 255) / 256)), dim3(256), 0, st, words, n_slots,
+                       data, parity, sel);
     return hipGetLastError();
 }
 

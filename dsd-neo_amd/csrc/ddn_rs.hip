@@ -58,13 +58,7 @@ k_golay24(uint8_t* __restrict__ data, const uint8_t* __restrict__ parity, int le
         tab[i] = tab_g[i];
     }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) {
-        return;
-    }
-    if (sel.cls && !(sel.cls[i / sel.per_slot] & sel.mask)) {
-        return; // not a frame of the type this launch is for
-    }
+    auto one = [&](long i) {
     uint8_t* d = data + (size_t)i * len;
     const uint8_t* p = parity + (size_t)i * 12;
     uint32_t cw = 0;
@@ -109,6 +103,8 @@ k_golay24(uint8_t* __restrict__ data, const uint8_t* __restrict__ parity, int le
     if (fixed) {
         fixed[i] = fx;
     }
+    };
+    ddn_sel_for_each(sel, (long)n, one);
 }
 
 __global__ __launch_bounds__(64) void
@@ -134,13 +130,7 @@ k_rs63(uint8_t* __restrict__ data6, const uint8_t* __restrict__ parity6, int n_p
         lg[0] = 0;
     }
     __syncthreads();
-    const int i = blockIdx.x * 64 + lane;
-    if (i >= n) {
-        return;
-    }
-    if (sel.cls && !(sel.cls[i / sel.per_slot] & sel.mask)) {
-        return; // not a frame of the type this launch is for (no block-wide barrier follows)
-    }
+    auto one = [&](long i) {
     auto gmul = [&](int a, int b) -> int { return (a && b) ? ex[lg[a] + lg[b]] : 0; };
     auto gdiv = [&](int a, int b) -> int { return a ? ex[lg[a] + 63 - lg[b]] : 0; };
     auto gpow = [&](int a, int e) -> int { return a ? ex[(lg[a] + e) % 63] : 0; }; // a * alpha^e, e >= 0
@@ -303,6 +293,8 @@ k_rs63(uint8_t* __restrict__ data6, const uint8_t* __restrict__ parity6, int n_p
         }
     }
     status[i] = (uint8_t)rc;
+    };
+    ddn_sel_for_each(sel, (long)n, one);
 }
 
 // ---- RS errors-and-erasures with reliability-ranked erasures ------------------------------------------------------------
@@ -979,8 +971,9 @@ ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* s
     if (e0 != hipSuccess) {
         return e0;
     }
-    hipLaunchKernelGGL(k_golay24, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, parity, len, n,
-                       (const uint32_t*)tab, status, fixed, ddn_sel_for(len == 6 ? 36 : 12));
+    const DdnSel sel = ddn_sel_for(len == 6 ? 36 : 12);
+    hipLaunchKernelGGL(k_golay24, dim3(ddn_sel_grid(&sel, ((unsigned long)n + 255) / 256)), dim3(256), 0, st, data, parity, len, n,
+                       (const uint32_t*)tab, status, fixed, sel);
     return hipGetLastError();
 }
 
@@ -990,8 +983,9 @@ ddn_dev_rs63(uint8_t* data6, const uint8_t* parity6, int n_par, int n_data, int 
     if (n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_rs63, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, data6, parity6, n_par, n_data, t, n,
-                       status, ddn_sel_for(1));
+    const DdnSel sel = ddn_sel_for(1);
+    hipLaunchKernelGGL(k_rs63, dim3(ddn_sel_grid(&sel, ((unsigned long)n + 63) / 64)), dim3(64), 0, st, data6, parity6, n_par, n_data, t, n,
+                       status, sel);
     return hipGetLastError();
 }
 
