@@ -41,7 +41,7 @@ N_SAMPLES = 48000
 BLOCK = 8192
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
 N_BASE = 64                  # distinct channels of each traffic kind
-RXW_TRAFFIC_BYTES = 2.612e9   # profiles/r03_pmc_FETCH_SIZE.txt, r03_pmc_WRITE_SIZE.txt: 2 x 778 749 KB + 1 054 790 KB per launch of k_p25_rxw<8, true>
+RXW_TRAFFIC_BYTES = 2.620e9   # profiles/r03_bench_pmc_FETCH_SIZE.txt, _WRITE_SIZE.txt: 2 x 778 556 KB + 1 062 950 KB per launch of k_p25_rxw<8, true>
 
 
 def make_base_traffic(n):
@@ -480,7 +480,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_p25_rxw", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # HBM bytes per launch of k_p25_rxw from separate rocprofv3 --pmc passes of this command on this shape
-                         # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B; profiles/r03_pmc_*.txt)
+                         # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B; profiles/r03_bench_pmc_*.txt)
                          "traffic": RXW_TRAFFIC_BYTES if (B == B_PER_GPU and n == N_SAMPLES) else None,
                          "algorithmic_bytes": alg_bytes, "bytes_per_sample": round(alg_bytes / (B * n), 3),
                          "launch_ms": round(dom_ms, 4), "launches_averaged": int(rx_timed_n.value),

@@ -277,7 +277,7 @@ DdnSel ddn_sel_for(int per_slot);
  * device) */
 static inline unsigned
 ddn_sel_grid(const DdnSel* sel, unsigned long n_blocks_full) {
-    const unsigned long cap = 4096;
+    const unsigned long cap = 1024;
     return (unsigned)((sel->list && n_blocks_full > cap) ? cap : (n_blocks_full ? n_blocks_full : 1));
 }
 hipError_t ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, const int32_t* cnt_prev, int have_prev,
