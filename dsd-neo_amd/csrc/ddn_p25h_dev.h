@@ -36,6 +36,7 @@ struct Scratch { // one decision at a time
     uint8_t nb[64], nr[64];  // NID bits / reliabilities (index 63 = the parity bit)
     int32_t d[98 + 2];       // de-interleaved LLR pairs (lo 16 = first bit of the dibit)
     uint16_t crc_cols[80];   // CRC16 register contribution of each message bit
+    uint32_t byw[4];         // half_rate_best_wave: the decoded block, or-ed together lane by lane
     union {
         uint8_t work[(23 + 24 + 24 + 24) * 64]; // NID: the BCH decoder's per-lane arrays
         struct {                                // trellis block: the list decoder's
@@ -296,77 +297,88 @@ crc16_ok_wave(const Scratch& sc, const uint32_t by[3], int lane) {
 // state's decisions two bits per step, and the trace-back runs on scalars.  Every lane returns the 12 bytes (byte k =
 // (by[k >> 2] >> (8 * (k & 3))) & 0xFF).
 typedef short ddn_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t
+map4_compose(uint32_t m, uint32_t b) { // (m o b)(x) = m(b(x)) for maps of {0..3} kept as four 2-bit fields
+    uint32_t r = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const uint32_t bx = (b >> (2 * x)) & 3u;
+        r |= ((m >> (2 * bx)) & 3u) << (2 * x);
+    }
+    return r;
+}
+// Round 3 shape: (1) the branch costs of all 49 steps first - no chain between them, the LLR pairs are LDS broadcast reads - packed
+// two per register; (2) the add-compare-select chain: two DPP quad minima, the four states' decisions or-ed across the row (two
+// row rotations) and kept by lane t as step t's map state -> predecessor, the next step's predecessor metric by one ds_bpermute
+// (was four readlanes + selects, whose scalar results stall the vector pipe; three DPP row rotations + selects measured slower); (3) the trace-back as a suffix composition of
+// those maps over the lanes (six shuffle rounds) instead of 49 dependent scalar steps, the decoded dibits or-ed into three LDS
+// words.  Same survivors, same ties (lowest predecessor, lowest final state) as before: 11.7 k -> 9.2 k cycles.
 __device__ __forceinline__ void
-half_rate_best_wave(const Scratch& sc, int lane, uint32_t by[3]) {
+half_rate_best_wave(Scratch& sc, int lane, uint32_t by[3]) {
     const int ps = lane & 3, ns = (lane >> 2) & 3;
     const int e = half_rate_nibble((ps << 2) | ns);
     // branch bits as packed masks: bit set = the branch says 1 = the cost is the LLR's pull towards 0 = max(0, -llr)
     const ddn_s16x2 m01 = {(short)(((e >> 3) & 1) ? -1 : 0), (short)(((e >> 2) & 1) ? -1 : 0)};
     const ddn_s16x2 m23 = {(short)(((e >> 1) & 1) ? -1 : 0), (short)((e & 1) ? -1 : 0)};
     const ddn_s16x2 zero = {0, 0};
-    const int dA = sc.d[lane], dB = (lane < 34) ? sc.d[lane + 64] : 0;
-    uint32_t pm_ps = (ps == 0) ? 0u : 256u; // metric of this lane's predecessor state
-    uint64_t bk_lo = 0, bk_hi = 0;          // this lane's state's decisions, two bits per step
-    uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+    uint32_t cst[25];
 #pragma unroll
     for (int t = 0; t < 49; t++) {
-        const int p0 = (2 * t < 64) ? __builtin_amdgcn_readlane(dA, (2 * t) & 63) : __builtin_amdgcn_readlane(dB, (2 * t) & 63);
-        const int p1 = (2 * t + 1 < 64) ? __builtin_amdgcn_readlane(dA, (2 * t + 1) & 63)
-                                        : __builtin_amdgcn_readlane(dB, (2 * t + 1) & 63);
-        ddn_s16x2 a = __builtin_bit_cast(ddn_s16x2, p0), b = __builtin_bit_cast(ddn_s16x2, p1);
+        ddn_s16x2 a = __builtin_bit_cast(ddn_s16x2, sc.d[2 * t]), b = __builtin_bit_cast(ddn_s16x2, sc.d[2 * t + 1]);
         a = __builtin_elementwise_max((a ^ m01) - m01, zero);
         b = __builtin_elementwise_max((b ^ m23) - m23, zero);
         const ddn_s16x2 c = a + b; // <= 2 * 255 per half
         const uint32_t cw = __builtin_bit_cast(uint32_t, c);
         const uint32_t cost = (cw & 0xFFFFu) + (cw >> 16);
-        uint32_t key = ((pm_ps + cost) << 2) | (uint32_t)ps; // smallest metric, lowest predecessor on a tie
+        if (t & 1) {
+            cst[t >> 1] |= cost << 16;
+        } else {
+            cst[t >> 1] = cost;
+        }
+    }
+    if (lane < 3) {
+        sc.byw[lane] = 0;
+    }
+    uint32_t pm_ps = (ps == 0) ? 0u : 256u; // metric of this lane's predecessor state
+    uint32_t mymap = 0xE4u, key = 0;        // lane t: step t's map state -> best predecessor (0xE4 = identity)
+    const int from_quad = ((lane & 48) | (ps << 2)) << 2; // a lane of the quad that holds state ps, this row (byte address)
+#pragma unroll
+    for (int t = 0; t < 49; t++) {
+        const uint32_t cost = (t & 1) ? (cst[t >> 1] >> 16) : (cst[t >> 1] & 0xFFFFu);
+        key = ((pm_ps + cost) << 2) | (uint32_t)ps; // smallest metric, lowest predecessor on a tie
         uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xF, 0xF, true);
         key = o < key ? o : key;
         o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xF, 0xF, true);
         key = o < key ? o : key;
-        if (t < 32) {
-            bk_lo |= (uint64_t)(key & 3u) << (2 * t);
-        } else {
-            bk_hi |= (uint64_t)(key & 3u) << (2 * (t - 32));
-        }
-        k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0);
-        k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 4);
-        k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, 8);
-        k3 = (uint32_t)__builtin_amdgcn_readlane((int)key, 12);
-        pm_ps = (ps == 0 ? k0 : (ps == 1 ? k1 : (ps == 2 ? k2 : k3))) >> 2;
+        uint32_t v = (key & 3u) << (2 * ns);
+        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true); // row_ror:4
+        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); // row_ror:8
+        mymap = (lane == t) ? v : mymap;
+        pm_ps = (uint32_t)__builtin_amdgcn_ds_bpermute(from_quad, (int)(key >> 2));
     }
-    // best final state, lowest on a tie; then back along the decisions (scalars)
-    uint32_t f = (k0 >> 2) << 2, g = ((k1 >> 2) << 2) | 1u;
+    // best final state, lowest on a tie: every quad holds its state's metric
+    uint32_t f = ((key >> 2) << 2) | (uint32_t)ns;
+    uint32_t g = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xF, 0xF, true);
     f = g < f ? g : f;
-    g = ((k2 >> 2) << 2) | 2u;
+    g = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x128, 0xF, 0xF, true);
     f = g < f ? g : f;
-    g = ((k3 >> 2) << 2) | 3u;
-    f = g < f ? g : f;
-    uint32_t s = f & 3u;
-    uint32_t lo[4][2], hi[4][2];
+    const uint32_t s48 = f & 3u;
+    // sigma_t (the state after step t = the decoded dibit t) = (D_{t+1} o ... o D_48)(s48): suffix composition over lanes 0..47
+    uint32_t m = (uint32_t)__shfl_down((int)mymap, 1);
+    m = lane < 48 ? m : 0xE4u;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        lo[q][0] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bk_lo, 4 * q);
-        lo[q][1] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bk_lo >> 32), 4 * q);
-        hi[q][0] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bk_hi, 4 * q);
-        hi[q][1] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bk_hi >> 32), 4 * q);
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t bmap = (uint32_t)__shfl_down((int)m, d);
+        bmap = (lane + d > 63) ? 0xE4u : bmap;
+        m = map4_compose(m, bmap);
     }
-    by[0] = by[1] = by[2] = 0;
-#pragma unroll
-    for (int t = 48; t >= 0; t--) {
-        if (t < 48) {
-            const int byte = t >> 2;
-            by[byte >> 2] |= s << (8 * (byte & 3) + 6 - 2 * (t & 3));
-        }
-        // decisions of step t: word (t / 16) of the state's 128-bit record, bits 2 (t % 16)
-        const int wsel = t >> 4;
-        const uint32_t w0 = wsel == 0 ? lo[0][0] : (wsel == 1 ? lo[0][1] : (wsel == 2 ? hi[0][0] : hi[0][1]));
-        const uint32_t w1 = wsel == 0 ? lo[1][0] : (wsel == 1 ? lo[1][1] : (wsel == 2 ? hi[1][0] : hi[1][1]));
-        const uint32_t w2 = wsel == 0 ? lo[2][0] : (wsel == 1 ? lo[2][1] : (wsel == 2 ? hi[2][0] : hi[2][1]));
-        const uint32_t w3 = wsel == 0 ? lo[3][0] : (wsel == 1 ? lo[3][1] : (wsel == 2 ? hi[3][0] : hi[3][1]));
-        const uint32_t w = s == 0 ? w0 : (s == 1 ? w1 : (s == 2 ? w2 : w3));
-        s = (w >> (2 * (t & 15))) & 3u;
+    if (lane < 48) {
+        const uint32_t sig = (m >> (2 * s48)) & 3u;
+        atomicOr(&sc.byw[lane >> 4], sig << (8 * ((lane >> 2) & 3) + 6 - 2 * (lane & 3)));
     }
+    by[0] = sc.byw[0];
+    by[1] = sc.byw[1];
+    by[2] = sc.byw[2];
 }
 
 // symbols p25_mpdu_read_repetition() consumes for one repetition starting with the counter at sk0 (98 data dibits, <= 101 reads)
