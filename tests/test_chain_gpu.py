@@ -210,3 +210,45 @@ def test_run_host_copies_back_what_the_device_holds(built):
     ch.close()
     for p in pinned + h_iq:
         l.ddn_host_free_pinned(p)
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_odd_call_sizes_and_noise_against_the_oracle(built, case):
+    """the chain at call sizes that cut the front end's blocks, the receive loop's tiles and the frames at odd places, on noisy mixed
+    traffic (NIDs through the Chase search, TSDU blocks through the list decoder, failed NIDs): a stream in calls + flush equals the
+    whole-stream oracle; DDN_FUZZ_BASE shifts the seeds"""
+    import os
+    base = int(os.environ.get("DDN_FUZZ_BASE", "0"))
+    rng = np.random.default_rng(9000 + 17 * base + case)
+    n_call = int(rng.choice([4999, 8192, 12345, 20011, 33333]))
+    calls = int(rng.integers(3, 7))
+    B = 4
+    n_total = n_call * calls
+    iq = np.full((B, n_total, 2), 127, np.uint8)
+    for c in range(B):
+        parts = []
+        while sum(len(p) for p in parts) * 10 < n_total:
+            k = int(rng.integers(0, 7))
+            if k == 0:
+                bits = mbe.random_imbe_bits(rng, (18,), 215)
+                parts.append(p25gen.make_ldus(rng, 2, 0x293, np.stack([mbe.imbe_encode(b) for b in bits]))[0])
+            elif k == 1:
+                parts.append(p25gen.make_frames(rng, 1, 0x293, crc=bool(rng.integers(0, 4)), blocks=int(rng.integers(1, 4)))[0])
+            elif k == 2:
+                parts.append(p25gen.make_hdu(rng, 0x293)[0])
+            elif k == 3:
+                parts.append(p25gen.make_tdulc(rng, 0x293)[0])
+            elif k == 4:
+                parts.append(p25gen.make_pdu(rng, 0x293, int(rng.integers(0, 4)), good_crc=bool(rng.integers(0, 2))))
+            elif k == 5:
+                parts.append(p25gen.frame_with_duid(rng, 0x293, int(rng.choice([0x1, 0x9, 0x3])), int(rng.integers(10, 60))))
+            else:
+                parts.append(np.zeros(int(rng.integers(5, 120)), np.int8))
+        noise = float(rng.choice([0.02, 0.08, 0.16, 0.24]))
+        iq[c] = p25gen.modulate_cu8(np.concatenate(parts), n_total, lead=int(rng.integers(50, 600)), seed=int(rng.integers(0, 1 << 30)),
+                                    noise=noise)
+    col = _run(iq, n_call, how=["run", "pipelined", "host"][case % 3])
+    tot = np.zeros(3, np.int64)
+    for c in range(B):
+        tot += _check_against_oracle(col, c, chain_stream.run_stream(iq[c], n_call, seed=c))
+    assert tot[0] > 10
