@@ -251,4 +251,4 @@ def test_odd_call_sizes_and_noise_against_the_oracle(built, case):
     tot = np.zeros(3, np.int64)
     for c in range(B):
         tot += _check_against_oracle(col, c, chain_stream.run_stream(iq[c], n_call, seed=c))
-    assert tot[0] > 10
+    assert tot[0] > 3
