@@ -697,7 +697,8 @@ struct LdsH {
     float hh[ddn_p25h::HN][CPW][3]; // {symbol, max, min} of the phase's in-frame symbols, slot = count mod HN
     int req_seq[CPW], req_kind[CPW], req_hw[CPW], req_n[CPW], req_o[CPW], req_neg[CPW], req_nc[CPW];
     int rsp_seq[CPW], rsp_ext[CPW], rsp_more[CPW];
-    int tile_done[2]; // per recurrence wave
+    int tile_done[2]; // per recurrence wave: tiles it has finished
+    int ready;        // tiles the staging wave has made enterable (staged + window summaries of the checkpoint before)
     ddn_p25h::Scratch sc;
 };
 
@@ -751,6 +752,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         if (lane == 0) {
             H.tile_done[0] = 0;
             H.tile_done[1] = 0;
+            H.ready = 1; // tile 0 is staged and summarised by the prologue
             ddn_nid::gf_fill(H.sc.ex, H.sc.lg);
             ddn_nid::chase_masks_fill(H.sc.masks);
         }
@@ -1017,7 +1019,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const int c = __ffsll((long long)pend) - 1;
                 serve(c, __shfl(rq, c));
             }
-            wg_barrier();
+            // (no workgroup barrier per tile in handler mode: the waves meet through tile_done / ready, see the tile loop)
         }
     {
         if (hlive) {
@@ -1534,6 +1536,31 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         const long long dbg_t0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
         const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
         const bool more = (t0 + TW) < n;
+        // Handler mode has no barrier per tile: the staging wave prepares tile it + 1 (and drains tile it - 1's queue) once BOTH
+        // recurrence waves have finished tile it - 1, a recurrence wave enters tile it once that preparation is published - so
+        // the two recurrence waves may be up to a tile apart and a tile that is slow for one of them is not waited out by the
+        // other (with the barrier each waited ~10 k of 62 k cycles per tile for its sister).
+        long long dbg_spin = 0;
+        if (HM && (loader || winprep)) {
+            const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
+            while (__hip_atomic_load(&H.tile_done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it
+                   || __hip_atomic_load(&H.tile_done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it) {
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                dbg_spin = (long long)clock64() - w0;
+            }
+        } else if (HM) {
+            const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
+            while (__hip_atomic_load(&H.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= it) {
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                dbg_spin = (long long)clock64() - w0;
+            }
+        }
         if (loader || winprep) { // handler mode: one wave does both, one after the other
             if (loader) {
                 if (more) {
@@ -1546,6 +1573,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             if (winprep) {
                 if (it >= 1 && !(cfg.dbg & 256)) {
                     compute_sfx(it & 1, it & 1);
+                }
+            }
+            if (HM) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) {
+                    __hip_atomic_store(&H.ready, it + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         } else {
@@ -2106,22 +2139,34 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             if (offload && lane == 0) {
                 L.qn[it & 1][rw] = (tk - 1) < QTW ? (tk - 1) : QTW; // trips that may have queued (the last one broke out at its top)
             }
-            if (HM && lane == 0) {
-                __hip_atomic_store(&H.tile_done[rw], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
             if (live) {
                 L.sidx0[(it + 1) & 1][ln] = s.sidx;
                 sp -= TW;
             }
+            if (HM) { // this wave's queue half, trip count and checkpoint slots are in LDS: the tile is done
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) {
+                    __hip_atomic_store(&H.tile_done[rw], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
         if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
             const long long t1 = (long long)clock64();
-            __syncthreads();
-            dbg_busy += t1 - dbg_t0;
-            dbg_wait += (long long)clock64() - t1;
-        } else {
+            if (!HM) {
+                __syncthreads();
+            }
+            dbg_busy += t1 - dbg_t0 - dbg_spin;
+            dbg_wait += (long long)clock64() - t1 + dbg_spin;
+        } else if (!HM) {
             __syncthreads();
         }
+    }
+    if (HM && loader) { // the last tile's queue is drained below: both recurrence waves have to be through
+        while (__hip_atomic_load(&H.tile_done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it
+               || __hip_atomic_load(&H.tile_done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it) {
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if ((DDN_RX_CYCLES && (cfg.dbg & 8192)) && lane == 0) { // timing experiment only: cycles per wave in the tile body / at the tile barrier
         // (written over the unused tail of the workgroup's first channel's record area)
