@@ -698,6 +698,7 @@ struct LdsH {
     int req_seq[CPW], req_kind[CPW], req_hw[CPW], req_n[CPW], req_o[CPW], req_neg[CPW], req_nc[CPW];
     int rsp_seq[CPW], rsp_ext[CPW], rsp_more[CPW];
     int tile_done[2]; // per recurrence wave: tiles it has finished
+    int hwid[4];      // HW_ID of the workgroup's waves (role placement)
     int ready;        // tiles the staging wave has made enterable (staged + window summaries of the checkpoint before)
     ddn_p25h::Scratch sc;
 };
@@ -718,8 +719,33 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     extern __shared__ unsigned char smem_raw[];
     LW& L = *reinterpret_cast<LW*>(smem_raw);
     LdsH<CPW>& H = *reinterpret_cast<LdsH<CPW>*>(smem_raw + ((sizeof(LW) + 15) & ~(size_t)15));
-    const bool hwave = HM && (threadIdx.x >> 6) == 3; // wave 3: the handlers' decisions
     const int lane = threadIdx.x & 63;
+    // Which wave takes which role.  The dispatcher puts the four waves of a workgroup on the four SIMDs of its CU in an order that
+    // changes from workgroup to workgroup, and two workgroups share a CU: with the roles tied to the wave index a quarter of the
+    // SIMDs ended up with two recurrence waves (two latency chains taking turns) and a quarter with none.  So the roles go by SIMD:
+    // the workgroup in the SIMDs' wave slot 0 runs its recurrences on SIMDs 0 / 1, the staging wave on 2, the handlers on 3, the
+    // workgroup in slot 1 the other way round - every SIMD hosts one recurrence and one light wave.
+    int wave_role = threadIdx.x >> 6;
+    if (HM && !(cfg.dbg & 524288)) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (lane == 0) {
+            H.hwid[threadIdx.x >> 6] = (int)hwid;
+        }
+        __syncthreads();
+        int seen = 0, slot_of_simd0 = 0;
+        for (int w = 0; w < 4; w++) {
+            const int v = H.hwid[w];
+            seen |= 1 << ((v >> 4) & 3);
+            if (((v >> 4) & 3) == 0) {
+                slot_of_simd0 = v & 15;
+            }
+        }
+        if (seen == 15) { // one wave per SIMD (else: roles by wave index, as before)
+            wave_role = ((int)((hwid >> 4) & 3) - 2 * (slot_of_simd0 & 1)) & 3;
+        }
+    }
+    const bool hwave = HM && wave_role == 3; // the handlers' decisions
     if (HM && hwave) {
         // The handler wave runs its own path from here on (its decoders would otherwise be allocated on top of the
         // recurrence's live registers); it meets the other waves at the same workgroup barriers: two before the tile loop,
@@ -1042,7 +1068,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     // (together about half a tile's time), wave 3 the handlers' decisions.
     constexpr int NRW = HM ? 2 : 1;   // recurrence waves
     constexpr int LPR = CPW / NRW;    // lanes (channels) per recurrence wave
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_role;
     const bool loader = wave == NRW;                      // tile staging, slice + record stores
     const bool winprep = wave == (HM ? NRW : NRW + 1);    // suffix summaries of the symbol window
     const bool recur = wave < NRW;                        // the per-channel recurrence
@@ -2170,12 +2196,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     }
     if ((DDN_RX_CYCLES && (cfg.dbg & 8192)) && lane == 0) { // timing experiment only: cycles per wave in the tile body / at the tile barrier
         // (written over the unused tail of the workgroup's first channel's record area)
-        uint8_t* d = rec + ((size_t)ch0 + 1) * max_sym * 10 - 192 + (threadIdx.x >> 6) * 64;
+        uint8_t* d = rec + ((size_t)ch0 + 1) * max_sym * 10 - 192 + wave * 64;
         const long long v[8] = {dbg_busy, dbg_wait, dbg_cyc[0], dbg_cyc[1], dbg_cyc[2], dbg_n[0], dbg_n[1], dbg_n[2]};
         for (int k = 0; k < 64; k++) {
             d[k] = reinterpret_cast<const uint8_t*>(v)[k];
         }
-        if ((threadIdx.x >> 6) == 0) { // the recurrence wave's standard-trip sections, one block further down
+        if (wave == 0) { // the recurrence wave's standard-trip sections, one block further down
             uint8_t* d2 = rec + ((size_t)ch0 + 1) * max_sym * 10 - 256;
             for (int k = 0; k < 64; k++) {
                 d2[k] = reinterpret_cast<const uint8_t*>(dbg_sec)[k];
