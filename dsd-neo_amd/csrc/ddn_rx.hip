@@ -660,6 +660,9 @@ constexpr int WMAX = 24;
 
 // 1: per-wave cycle counters (tile body / barrier wait / trips by kind) written over the tail of each workgroup's first
 // record area when cfg.dbg bit 8192 is set - timing experiments only (tools/bench_rx_handlers.py with DDN_RX_DBG=8192 and a library built with EXTRA=-DDDN_RX_CYCLES=1)
+#ifndef BV
+#define BV 0
+#endif
 #ifndef DDN_RX_CYCLES
 #define DDN_RX_CYCLES 0
 #endif
@@ -704,7 +707,7 @@ struct LdsH {
 };
 
 template <int CPW, bool HM>
-__global__ __launch_bounds__(HM ? 256 : 192) void
+__global__ __launch_bounds__(HM ? 256 : 192) __attribute__((amdgpu_waves_per_eu(2))) void
 k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
           float* __restrict__ fstale, long n,
           size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
@@ -1189,6 +1192,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const bool stdspan = rem == 0 && whole >= 6 && whole <= 11; // whole + 1 samples at most with a late slip: the search covers 12
     const bool std_ok = stdspan && !(cfg.dbg & 1024); // see "standard trip" in the trip loop
     const bool lean_ok = offload && stdspan && !(cfg.dbg & 2048); // see "lean trip" in the trip loop
+    const bool bulk_ok = std_ok && offload && !(cfg.dbg & 1048576); // see "bulk hunting pass" in the trip loop
     auto store_record = [&](uint8_t* r, uint8_t* f, float sym, int dibit, int relb, int l0, int l1, int fl) {
         const uint32_t xb = __float_as_uint(sym);
         ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
@@ -1640,6 +1644,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             float px0 = 0.0f, px1 = 0.0f, px2 = 0.0f, px3 = 0.0f, px4 = 0.0f;
             float4 psf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             bool respin = false; // handler mode: the last pass only waited for an answer (no trip was spent)
+            int blk_o = -1;      // bulk hunting pass: output index at which it left this lane's next symbol to the standard trip
             while (true) {
                 if (HM && __any(hwait)) {
                     if (hwait
@@ -1669,6 +1674,168 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     }
                 }
                 const bool alive = live & !hwait;
+                // ---- bulk hunting pass ---------------------------------------------------------------------------------------
+                // A lane that hunts with its thresholds parked (no sync: max / min / centre stand still) runs a recurrence with
+                // three words of state - where the next symbol starts, the latched crossing, the sign history - so its symbols
+                // up to the end of the tile are found at once by the whole wavefront instead of one standard trip each (which the
+                // in-frame lanes of the wave would sit through at 2.7 times the cost of a lean trip): the crossing test of every
+                // staged sample as a 192-bit mask (three ballots), the chain symbol start -> first crossing inside the symbol
+                // -> one-sample slip of the next start as scalar bit operations, then lane j takes symbol j: five-sample mean,
+                // sign, its 24-symbol history word and the sync compare.  The pass stops in front of the symbol that completes a
+                // sync pattern (the standard trip takes that one: warm start, lock) and at the eighth symbol of a hunt (the
+                // commit of that symbol moves the crossing limits to the parked max / min).
+                // hunt_wait: such a lane has nothing left that fits this tile - it waits for the next one like a lean lane does.
+                bool hunt_wait = false;
+                if (bulk_ok) {
+                    const int jt = s.jitter;
+                    const int i0n = (jt > 0 && jt <= (whole - 1) / 2) ? -1 : ((jt > (whole - 1) / 2 && jt < whole) ? 1 : 0);
+                    const bool be = alive & (s.have_sync == 0) & (s.in_symbol == 0) & (s.need_reset == 0) & (sp >= cold_until)
+                                    & (s.hunt_pos + 20 < 1800) & (blk_o != o) & ((size_t)(o + 20) < max_sym);
+                    const bool fitsn = sp + whole - i0n <= tn;
+                    hunt_wait = be & !fitsn & more;
+                    unsigned long long bm = __ballot(be & fitsn);
+                    if (__builtin_expect(bm != 0, 0)) {
+#if BV == 1
+                        if (lane < 64) { blk_o = o; }
+                        bm = 0;
+#endif
+                        while (bm) {
+                            const int ow = __ffsll((long long)bm) - 1; // owner lane of this pass (wave-uniform)
+                            bm &= bm - 1;
+                            const int cln = rw * LPR + ow;
+                            const int sp0 = __builtin_amdgcn_readlane(sp, ow);
+                            const int c0 = __builtin_amdgcn_readlane(s.hist_count, ow);
+                            const int flt_o = __builtin_amdgcn_readlane(s.filter_on, ow);
+                            int jit = __builtin_amdgcn_readlane(s.jitter, ow);
+                            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)s.hist_bits, ow);
+                            const int o_o = __builtin_amdgcn_readlane(o, ow);
+                            const float cen_o = __shfl(s.center, ow), hl_o = __shfl(s.maxref * 1.25f, ow);
+                            const float ll_o = __shfl(s.minref * 1.25f, ow), ls_o = __shfl(s.lastsample, ow);
+                            const float* pr = (flt_o ? &L.flt[cln][0] : &L.raw[cln][0]) + base;
+                            // crossing test of the samples sp0 .. tn - 1 (bit a - sp0)
+                            unsigned long long cm[3];
+#pragma unroll
+                            for (int r = 0; r < 3; r++) {
+                                const int a = sp0 + lane + 64 * r;
+                                bool hit = false;
+                                if (a < tn) {
+                                    const float x = pr[a];
+                                    const float xp = (a == sp0) ? ls_o : pr[a - 1];
+                                    hit = (x > cen_o) ? (!(x > hl_o) && xp < cen_o) : (!(x < ll_o) && xp > cen_o);
+                                }
+                                cm[r] = __ballot(hit);
+                            }
+                            const int mmax = c0 < 8 ? 8 - c0 : 16;
+                            int q = sp0, m = 0, myq = 0, myi0 = 0, myjin = 0;
+                            while (m < (BV == 4 ? 1 : mmax)) {
+                                const int i0 = (jit > 0 && jit <= (whole - 1) / 2) ? -1 : ((jit > (whole - 1) / 2 && jit < whole) ? 1 : 0);
+                                const int cnt = whole - i0;
+                                if (q + cnt > tn) {
+                                    break;
+                                }
+                                if (lane == m) {
+                                    myq = q;
+                                    myi0 = i0;
+                                    myjin = jit;
+                                }
+                                const int k0 = i0 < 0 ? 1 : 0; // a crossing at symbol index -1 latches nothing
+                                const int b = q - sp0 + k0, wi = b >> 6, sf = b & 63;
+                                const unsigned long long lo = wi == 0 ? cm[0] : (wi == 1 ? cm[1] : cm[2]);
+                                const unsigned long long hi = wi == 0 ? cm[1] : (wi == 1 ? cm[2] : 0ull);
+                                const uint32_t wv = (uint32_t)((lo >> sf) | (sf ? (hi << (64 - sf)) : 0ull)) & ((1u << (cnt - k0)) - 1u);
+                                jit = wv ? i0 + k0 + (__ffs((int)wv) - 1) : -1;
+                                q += cnt;
+                                m++;
+                            }
+                            if (lane == m) { // where the symbol after the pass starts, and the latch it starts with
+                                myq = q;
+                                myjin = jit;
+                            }
+                            float sym = 0.0f;
+                            if (lane < m) {
+                                const float* pw = pr + myq + ((whole - 1) / 2 - 2 - myi0);
+                                float acc = 0.0f;
+#pragma unroll
+                                for (int w = 0; w < 5; w++) {
+                                    acc += __builtin_amdgcn_fmed3f(pw[w], -inf, inf);
+                                }
+                                sym = acc / 5.0f;
+                            }
+                            const uint32_t sw = (uint32_t)__ballot(lane < m && sym > 0.0f);
+                            const int lj = lane < 31 ? lane : 31;
+                            const uint32_t hj = ((h0 << (lj + 1)) | __brev(sw << (31 - lj))) & 0xFFFFFFu;
+                            const bool syn = lane < m && (c0 + lane + 1 >= 24) && (hj == kSyncBits || hj == (~kSyncBits & 0xFFFFFFu));
+                            const unsigned long long sm = __ballot(syn);
+                            if (sm) {
+                                m = __ffsll((long long)sm) - 1;
+                            }
+                            if (m == 0) { // the next symbol completes a sync: the standard trip's
+                                if (lane == ow) {
+                                    blk_o = o;
+                                }
+                                continue;
+                            }
+                            const int qf = __builtin_amdgcn_readlane(myq, m), jf = __builtin_amdgcn_readlane(myjin, m);
+                            const int il = __builtin_amdgcn_readlane(myi0, m - 1);
+                            const uint32_t hf = (uint32_t)__builtin_amdgcn_readlane((int)hj, m - 1);
+                            const int sh_o = __builtin_amdgcn_readlane(s.shead, ow), li_o = __builtin_amdgcn_readlane(s.lidx, ow);
+                            const int si_o = __builtin_amdgcn_readlane(s.sidx, ow);
+                            if (lane < m) { // symbol history, level window, extrema window, record
+                                int k = sh_o + lane;
+                                L.sh[k >= 24 ? k - 24 : k][cln] = sym;
+                                k = li_o + lane;
+                                L.lb[k >= 24 ? k - 24 : k][cln] = sym;
+                                L.sb[(si_o + lane) & (SS - 1)][cln] = sym;
+                                const size_t oo = (size_t)(o_o + lane);
+                                if (BV != 2 && oo < max_sym) {
+                                    const size_t cho = (size_t)(ch0 + cln);
+                                    store_record(rec + (cho * max_sym + oo) * 10, flags + cho * max_sym + oo, sym, sym > 0.0f ? 1 : 3, 0, 0, 0, 0);
+                                }
+                            }
+                            float a1 = lane < m ? sym : inf, a2 = inf, b1 = lane < m ? sym : -inf, b2 = -inf;
+#pragma unroll
+                            for (int d = 1; d < (BV == 3 ? 2 : 16); d <<= 1) {
+                                const float o1 = __shfl_xor(a1, d), o2 = __shfl_xor(a2, d), p1 = __shfl_xor(b1, d), p2 = __shfl_xor(b2, d);
+                                two_min_insert(o1, a1, a2);
+                                two_min_insert(o2, a1, a2);
+                                two_max_insert(p1, b1, b2);
+                                two_max_insert(p2, b1, b2);
+                            }
+                            a1 = __shfl(a1, 0), a2 = __shfl(a2, 0), b1 = __shfl(b1, 0), b2 = __shfl(b2, 0);
+                            const float lsf = pr[qf - 1];
+                            if (lane == ow) {
+                                two_min_insert(a1, pc1, pc2);
+                                two_min_insert(a2, pc1, pc2);
+                                two_max_insert(b1, pc3, pc4);
+                                two_max_insert(b2, pc3, pc4);
+                                npc += m;
+                                s.shead = (s.shead + m) % 24;
+                                s.scount = s.scount + m < 24 ? s.scount + m : 24;
+                                s.lidx = (s.lidx + m) % 24;
+                                s.level_count = s.level_count + m < 24 ? s.level_count + m : 24;
+                                s.sidx = (s.sidx + m) & (SS - 1);
+                                s.hist_bits = hf;
+                                s.hist_count = c0 + m < 24 ? c0 + m : 24;
+                                if (s.hist_count >= 8) {
+                                    s.maxref = s.max;
+                                    s.minref = s.min;
+                                }
+                                s.hunt_pos += m;
+                                s.span = whole;
+                                s.centre = (whole - 1) / 2;
+                                s.i = il;
+                                s.sum = 0.0f;
+                                s.count = 0;
+                                s.in_symbol = 0;
+                                s.jitter = jf;
+                                s.lastsample = lsf;
+                                sp = qf;
+                                o += m;
+                            }
+                        }
+                        continue;
+                    }
+                }
                 // hand the previous trip's symbols (one per lane at most) to wave 1: one 16-byte LDS write at a wave-uniform slot
                 if (!respin) {
                     if (offload && tk > 0 && tk <= QTW && lane < LPR) {
@@ -1708,7 +1875,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                             & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0))) & (s.min < s.max);
                     const bool lean = lean_state & (sp + whole <= tn);
                     const bool lean_wait = lean_state & !(sp + whole <= tn) & more;
-                    const bool all_lean = !__any(alive & !(lean | lean_wait));
+                    const bool all_lean = !__any(alive & !(lean | lean_wait | hunt_wait));
                     if (all_lean && __any(lean)) {
                         dbg_kind = 2;
                         const int k0 = (whole - 1) / 2 - 2;
@@ -1789,7 +1956,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
                     const bool warm = alive & (sp >= cold_until); // == !(filter_on && (abs0 + t0 + sp - filt_start) < NT - 1)
                     const bool hunting = s.have_sync == 0;
-                    if (warm & hunting & (s.in_symbol == 0) & (sp < tn)) { // symbol start while hunting: slip by the latched crossing
+                    if (warm & hunting & (s.in_symbol == 0) & (sp < tn) & !hunt_wait) { // symbol start while hunting: slip by the latched crossing
                         if (s.need_reset) {
                             timing_reset();
                         }
