@@ -660,9 +660,6 @@ constexpr int WMAX = 24;
 
 // 1: per-wave cycle counters (tile body / barrier wait / trips by kind) written over the tail of each workgroup's first
 // record area when cfg.dbg bit 8192 is set - timing experiments only (tools/bench_rx_handlers.py with DDN_RX_DBG=8192 and a library built with EXTRA=-DDDN_RX_CYCLES=1)
-#ifndef BV
-#define BV 0
-#endif
 #ifndef DDN_RX_CYCLES
 #define DDN_RX_CYCLES 0
 #endif
@@ -1695,10 +1692,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     hunt_wait = be & !fitsn & more;
                     unsigned long long bm = __ballot(be & fitsn);
                     if (__builtin_expect(bm != 0, 0)) {
-#if BV == 1
-                        if (lane < 64) { blk_o = o; }
-                        bm = 0;
-#endif
                         while (bm) {
                             const int ow = __ffsll((long long)bm) - 1; // owner lane of this pass (wave-uniform)
                             bm &= bm - 1;
@@ -1727,7 +1720,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             }
                             const int mmax = c0 < 8 ? 8 - c0 : 16;
                             int q = sp0, m = 0, myq = 0, myi0 = 0, myjin = 0;
-                            while (m < (BV == 4 ? 1 : mmax)) {
+                            while (m < mmax) {
                                 const int i0 = (jit > 0 && jit <= (whole - 1) / 2) ? -1 : ((jit > (whole - 1) / 2 && jit < whole) ? 1 : 0);
                                 const int cnt = whole - i0;
                                 if (q + cnt > tn) {
@@ -1787,14 +1780,14 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 L.lb[k >= 24 ? k - 24 : k][cln] = sym;
                                 L.sb[(si_o + lane) & (SS - 1)][cln] = sym;
                                 const size_t oo = (size_t)(o_o + lane);
-                                if (BV != 2 && oo < max_sym) {
+                                if (oo < max_sym) {
                                     const size_t cho = (size_t)(ch0 + cln);
                                     store_record(rec + (cho * max_sym + oo) * 10, flags + cho * max_sym + oo, sym, sym > 0.0f ? 1 : 3, 0, 0, 0, 0);
                                 }
                             }
                             float a1 = lane < m ? sym : inf, a2 = inf, b1 = lane < m ? sym : -inf, b2 = -inf;
 #pragma unroll
-                            for (int d = 1; d < (BV == 3 ? 2 : 16); d <<= 1) {
+                            for (int d = 1; d < 16; d <<= 1) {
                                 const float o1 = __shfl_xor(a1, d), o2 = __shfl_xor(a2, d), p1 = __shfl_xor(b1, d), p2 = __shfl_xor(b2, d);
                                 two_min_insert(o1, a1, a2);
                                 two_min_insert(o2, a1, a2);
@@ -1888,63 +1881,97 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
                             }
                         }
-                        if (lean) {
-                            // min < max and finite samples: the reference's two-sided clip is the median of three (a zero's sign
-                            // may differ, which a sum that starts at +0 cannot show)
-                            float acc = 0.0f;
-                            acc += __builtin_amdgcn_fmed3f(px0, s.min, s.max);
-                            acc += __builtin_amdgcn_fmed3f(px1, s.min, s.max);
-                            acc += __builtin_amdgcn_fmed3f(px2, s.min, s.max);
-                            acc += __builtin_amdgcn_fmed3f(px3, s.min, s.max);
-                            acc += __builtin_amdgcn_fmed3f(px4, s.min, s.max);
-                            const float sym = acc / 5.0f;
-                            sp += whole;
-                            s.in_symbol = 0;
-                            // window push (see window_push) with the prefetched suffix summary
-                            L.sb[s.sidx][ln] = sym;
-                            two_min_insert(sym, pc1, pc2);
-                            two_max_insert(sym, pc3, pc4);
-                            npc++;
-                            const float t1 = fminf(psf.x, pp1), t2 = fminf(fmaxf(psf.x, pp1), fminf(psf.y, pp2));
-                            const float m1 = fminf(t1, pc1), m2 = fminf(fmaxf(t1, pc1), fminf(t2, pc2));
-                            const float u1 = fmaxf(psf.z, pp3), u2 = fmaxf(fminf(psf.z, pp3), fmaxf(psf.w, pp4));
-                            const float x1 = fmaxf(u1, pc3), x2 = fmaxf(fminf(u1, pc3), fmaxf(u2, pc4));
-                            const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
-                            double old_lo = fill_min_d, old_hi = fill_max_d;
-                            if (s.since_fill >= MS) {
-                                old_lo = (double)ring_at(minring, ro);
-                                old_hi = (double)ring_at(maxring, ro);
-                            } else {
-                                s.since_fill++;
+                        // A lean run: as long as the same lanes stay lean (or have moved on to waiting for the next tile) the wave
+                        // goes from one lean trip straight into the next - what can end the run is known from the trip itself (the
+                        // lock running out, a symbol that no longer fits, a handler's answer arriving for a lane that sat out), so
+                        // none of the trip loop's other tests are on the instruction stream between two lean trips.
+                        bool lz = lean, did = false;
+                        while (true) {
+                            int rs = -1;
+                            if (HM && hwait) {
+                                rs = __hip_atomic_load(&H.rsp_seq[ln], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
-                            s.min_sum += (double)lo - old_lo;
-                            s.max_sum += (double)hi - old_hi;
-                            ring_at(minring, ro) = lo;
-                            ring_at(maxring, ro) = hi;
-                            ro += ro_step;
-                            if (++s.midx >= MS) {
-                                s.midx = 0;
-                                ro = ro_first;
+                            if (lz) {
+                                // min < max and finite samples: the reference's two-sided clip is the median of three (a zero's sign
+                                // may differ, which a sum that starts at +0 cannot show)
+                                float acc = 0.0f;
+                                acc += __builtin_amdgcn_fmed3f(px0, s.min, s.max);
+                                acc += __builtin_amdgcn_fmed3f(px1, s.min, s.max);
+                                acc += __builtin_amdgcn_fmed3f(px2, s.min, s.max);
+                                acc += __builtin_amdgcn_fmed3f(px3, s.min, s.max);
+                                acc += __builtin_amdgcn_fmed3f(px4, s.min, s.max);
+                                const float sym = acc / 5.0f;
+                                sp += whole;
+                                s.in_symbol = 0;
+                                did = true;
+                                // window push (see window_push) with the prefetched suffix summary
+                                L.sb[s.sidx][ln] = sym;
+                                two_min_insert(sym, pc1, pc2);
+                                two_max_insert(sym, pc3, pc4);
+                                npc++;
+                                const float t1 = fminf(psf.x, pp1), t2 = fminf(fmaxf(psf.x, pp1), fminf(psf.y, pp2));
+                                const float m1 = fminf(t1, pc1), m2 = fminf(fmaxf(t1, pc1), fminf(t2, pc2));
+                                const float u1 = fmaxf(psf.z, pp3), u2 = fmaxf(fminf(psf.z, pp3), fmaxf(psf.w, pp4));
+                                const float x1 = fmaxf(u1, pc3), x2 = fmaxf(fminf(u1, pc3), fmaxf(u2, pc4));
+                                const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
+                                double old_lo = fill_min_d, old_hi = fill_max_d;
+                                if (s.since_fill >= MS) {
+                                    old_lo = (double)ring_at(minring, ro);
+                                    old_hi = (double)ring_at(maxring, ro);
+                                } else {
+                                    s.since_fill++;
+                                }
+                                s.min_sum += (double)lo - old_lo;
+                                s.max_sum += (double)hi - old_hi;
+                                ring_at(minring, ro) = lo;
+                                ring_at(maxring, ro) = hi;
+                                ro += ro_step;
+                                if (++s.midx >= MS) {
+                                    s.midx = 0;
+                                    ro = ro_first;
+                                }
+                                s.min = (float)(s.min_sum / (double)MS);
+                                s.max = (float)(s.max_sum / (double)MS);
+                                s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
+                                s.lock_left--;
+                                qv = make_float4(sym, s.max, s.min, __int_as_float((1 | (s.lastsync == 2 ? 4 : 0)) | ((o - o_tile) << 8)));
+                                hist_push(sym, s.max, s.min, 1 | (s.lastsync == 2 ? 4 : 0));
+                                o++;
                             }
-                            s.min = (float)(s.min_sum / (double)MS);
-                            s.max = (float)(s.max_sum / (double)MS);
+                            // operands of the next lean trip, if this lane's next symbol is staged in this tile too
+                            pf_ok = lz & (sp + whole <= tn);
+                            if (pf_ok) {
+                                const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
+                                px0 = pw[0], px1 = pw[1], px2 = pw[2], px3 = pw[3], px4 = pw[4];
+                                int m = npp + npc + 1;
+                                m = m > WMW ? WMW : m;
+                                psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
+                            }
+                            // straight into another lean trip?  (the lanes that were waiting for the next tile still are)
+                            const bool st = lz & (s.lock_left > 1) & (s.min < s.max);
+                            const bool nl = st & pf_ok;
+                            const bool nw = st & !pf_ok & more;
+                            if (__any(lz & !(nl | nw)) || !__any(nl) || tk >= QTW || (cfg.dbg & 2097152)
+                                || (HM && __any(hwait & (rs == hseq)))) {
+                                break;
+                            }
+                            if (lane < LPR) { // this trip's symbols to wave 1, the next trip's slot opened (as at the trip loop's top)
+                                *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
+                            }
+                            qv.w = __int_as_float(-1);
+                            tk++;
+                            if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                                const long long now = (long long)clock64();
+                                dbg_cyc[2] += now - dbg_prev;
+                                dbg_n[2]++;
+                                dbg_prev = now;
+                            }
+                            lz = nl;
+                        }
+                        if (did) { // the thresholds that follow max / min: nothing inside a lean run reads them
                             s.center = (s.max + s.min) / 2.0f;
                             s.maxref = s.max * 0.80f;
                             s.minref = s.min * 0.80f;
-                            s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
-                            s.lock_left--;
-                            qv = make_float4(sym, s.max, s.min, __int_as_float((1 | (s.lastsync == 2 ? 4 : 0)) | ((o - o_tile) << 8)));
-                            hist_push(sym, s.max, s.min, 1 | (s.lastsync == 2 ? 4 : 0));
-                            o++;
-                        }
-                        // operands of the next lean trip, if this lane's next symbol is staged in this tile too
-                        pf_ok = lean & (sp + whole <= tn);
-                        if (pf_ok) {
-                            const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
-                            px0 = pw[0], px1 = pw[1], px2 = pw[2], px3 = pw[3], px4 = pw[4];
-                            int m = npp + npc + 1;
-                            m = m > WMW ? WMW : m;
-                            psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
                         }
                         continue;
                     }
