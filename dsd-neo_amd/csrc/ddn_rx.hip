@@ -699,7 +699,8 @@ struct LdsH {
     int rsp_seq[CPW], rsp_ext[CPW], rsp_more[CPW];
     int tile_done[2]; // per recurrence wave: tiles it has finished
     int hwid[4];      // HW_ID of the workgroup's waves (role placement)
-    int ready;        // tiles the staging wave has made enterable (staged + window summaries of the checkpoint before)
+    int ready[2];     // per recurrence wave: tiles the staging wave has made enterable for its channels (staged + window
+                      // summaries of the checkpoint before)
     ddn_p25h::Scratch sc;
 };
 
@@ -778,7 +779,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         if (lane == 0) {
             H.tile_done[0] = 0;
             H.tile_done[1] = 0;
-            H.ready = 1; // tile 0 is staged and summarised by the prologue
+            H.ready[0] = 1; // tile 0 is staged and summarised by the prologue
+            H.ready[1] = 1;
             ddn_nid::gf_fill(H.sc.ex, H.sc.lg);
             ddn_nid::chase_masks_fill(H.sc.masks);
         }
@@ -1241,6 +1243,107 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
         }
     };
+    // Handler mode: the staging wave's three jobs for the channels of ONE recurrence wave (h) - the two recurrence waves share
+    // nothing but this wave's time, so each runs as far ahead of the other as its own channels let it.
+    auto stage_half = [&](long t0, int slot, int h) {
+        const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
+        float r[TW / 64][LPR], f[TW / 64][LPR];
+#pragma unroll
+        for (int half = 0; half < TW / 64; half++) { // every load of the tile in flight before the first LDS write
+            const int j = lane + 64 * half;
+#pragma unroll
+            for (int c = 0; c < LPR; c++) {
+                const int cc = h * LPR + c;
+                const bool ok = (ch0 + cc < n_channels) && j < tn;
+                const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + j;
+                r[half][c] = ok ? raw[off] : 0.0f;
+                f[half][c] = (ok && use_flt) ? filt[off] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < TW / 64; half++) {
+            const int j = lane + 64 * half;
+#pragma unroll
+            for (int c = 0; c < LPR; c++) {
+                const int cc = h * LPR + c;
+                L.raw[cc][TW + slot * TW + j] = r[half][c];
+                L.flt[cc][TW + slot * TW + j] = f[half][c];
+                if (slot == 2) {
+                    L.raw[cc][j] = r[half][c];
+                    L.flt[cc][j] = f[half][c];
+                }
+            }
+        }
+    };
+    auto compute_sfx_half = [&](int buf, int tile_parity, int h) {
+        constexpr int EPL = 64 / LPR;
+        const int c = h * LPR + lane % LPR, part = lane / LPR;
+        const int s0 = L.sidx0[tile_parity][c];
+        const int total = SS - Mn, per = (total + EPL - 1) / EPL;
+        const int i_lo = Mn + 1 + part * per;
+        const int i_hi = (i_lo + per - 1) < SS ? (i_lo + per - 1) : SS;
+        float a1 = inf, a2 = inf, b1 = -inf, b2 = -inf;
+        for (int i = i_lo; i <= i_hi; i++) {
+            const float v = L.sb[(s0 + i - 1) & (SS - 1)][c];
+            two_min_insert(v, a1, a2);
+            two_max_insert(v, b1, b2);
+        }
+#pragma unroll
+        for (int d = LPR; d < 64; d <<= 1) {
+            const float o1 = __shfl_xor(a1, d), o2 = __shfl_xor(a2, d), p1 = __shfl_xor(b1, d), p2 = __shfl_xor(b2, d);
+            two_min_insert(o1, a1, a2);
+            two_min_insert(o2, a1, a2);
+            two_max_insert(p1, b1, b2);
+            two_max_insert(p2, b1, b2);
+        }
+        for (int m = Mn; m >= 1; m--) {
+            if (m < Mn) {
+                const float v = L.sb[(s0 + m) & (SS - 1)][c]; // entry m + 1
+                two_min_insert(v, a1, a2);
+                two_max_insert(v, b1, b2);
+            }
+            if (part == 0) {
+                *reinterpret_cast<float4*>(&L.sfx[buf][m - 1][c][0]) = make_float4(a1, a2, b1, b2);
+            }
+        }
+    };
+    auto drain_half = [&](int qb, int h) {
+        constexpr int EPL = 64 / LPR;
+        const int dc = h * LPR + lane % LPR, de = lane / LPR;
+        const int dch = ch0 + dc;
+        if (dch >= n_channels) {
+            return;
+        }
+        const int cnt = L.qn[qb][h], o0 = L.qo[qb][dc];
+        uint8_t* drp = rec + (size_t)dch * max_sym * 10;
+        uint8_t* dfp = flags + (size_t)dch * max_sym;
+        for (int k = de; k < QTW; k += EPL) {
+            if (k >= cnt) {
+                break;
+            }
+            const float4 e = *reinterpret_cast<const float4*>(&L.q[qb][k][dc][0]);
+            const int fw = __float_as_int(e.w);
+            if (fw < 0) {
+                continue; // this lane handed nothing over in that trip
+            }
+            const float sym = e.x;
+            const int fl = fw & 0xFF;
+            int dibit, relb = 0, l0 = 0, l1 = 0;
+            if (fl & 1) {
+                const float mx = e.y, mn = e.z;
+                const float center = (mx + mn) / 2.0f;
+                const ddn_sl::Thr th = {center, ((mx - center) * 5.0f / 8.0f) + center,
+                                        ((mn - center) * 5.0f / 8.0f) + center, mx, mn};
+                ddn_sl::slice_soft(sym, th, (fl >> 2) & 1, dibit, relb, l0, l1);
+            } else {
+                dibit = sym > 0.0f ? 1 : 3;
+            }
+            const size_t oo = (size_t)(o0 + (fw >> 8));
+            if (oo < max_sym) {
+                store_record(drp + oo * 10, dfp + oo, sym, dibit, relb, l0, l1, fl);
+            }
+        }
+    };
     // window state of this lane: summaries {min1, min2, max1, max2} of the symbols pushed during this tile (pc) and during the
     // previous one (pp), their counts, and which checkpoint's suffix summaries apply
     float pc1 = inf, pc2 = inf, pc3 = -inf, pc4 = -inf;
@@ -1559,6 +1662,55 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     long long dbg_busy = 0, dbg_wait = 0, dbg_cyc[3] = {0, 0, 0}, dbg_prev = 0, dbg_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_st = 0;
 #define DBG_SEC(k) do { if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { const long long n_ = (long long)clock64(); dbg_sec[k] += n_ - dbg_st; dbg_st = n_; } } while (0)
     int dbg_n[3] = {0, 0, 0}, dbg_kind = -1;
+    if (HM && loader) {
+        // Handler mode, staging wave: job j of recurrence wave h's channels (stage tile j + 1, drain tile j - 1's queue, the
+        // window summaries of checkpoint j) falls due when that wave has finished tile j - 1, and lets it into tile j + 1; job
+        // n_tiles is the last tile's drain.  Whichever half is due is served.
+        const int n_tiles = (int)((n + TW - 1) / TW);
+        int job[2] = {0, 0};
+        while (job[0] <= n_tiles || job[1] <= n_tiles) {
+            bool served = false;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = job[h];
+                if (j > n_tiles || __hip_atomic_load(&H.tile_done[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < j) {
+                    continue;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
+                if (j < n_tiles) {
+                    if (j + 1 < n_tiles) {
+                        stage_half((long)(j + 1) * TW, (j + 1) % 3, h);
+                    }
+                    if (offload && j > 0 && !(cfg.dbg & 512)) {
+                        drain_half((j - 1) & 1, h);
+                    }
+                    if (j >= 1 && !(cfg.dbg & 256)) {
+                        compute_sfx_half(j & 1, j & 1, h);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) {
+                        __hip_atomic_store(&H.ready[h], j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else if (offload && n_tiles > 0) {
+                    drain_half((n_tiles - 1) & 1, h);
+                }
+                if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                    dbg_busy += (long long)clock64() - w0;
+                }
+                job[h] = j + 1;
+                served = true;
+            }
+            if (!served) {
+                const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
+                __builtin_amdgcn_s_sleep(1);
+                if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                    dbg_wait += (long long)clock64() - w0;
+                }
+            }
+        }
+        it = n_tiles;
+    } else
     for (t0 = 0; t0 < n; t0 += TW, it++) {
         const long long dbg_t0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
         const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
@@ -1568,19 +1720,9 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         // the two recurrence waves may be up to a tile apart and a tile that is slow for one of them is not waited out by the
         // other (with the barrier each waited ~10 k of 62 k cycles per tile for its sister).
         long long dbg_spin = 0;
-        if (HM && (loader || winprep)) {
+        if (HM) {
             const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
-            while (__hip_atomic_load(&H.tile_done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it
-                   || __hip_atomic_load(&H.tile_done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it) {
-                __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
-                dbg_spin = (long long)clock64() - w0;
-            }
-        } else if (HM) {
-            const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
-            while (__hip_atomic_load(&H.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= it) {
+            while (__hip_atomic_load(&H.ready[rw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= it) {
                 __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1600,12 +1742,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             if (winprep) {
                 if (it >= 1 && !(cfg.dbg & 256)) {
                     compute_sfx(it & 1, it & 1);
-                }
-            }
-            if (HM) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) {
-                    __hip_atomic_store(&H.ready, it + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         } else {
@@ -1692,6 +1828,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     hunt_wait = be & !fitsn & more;
                     unsigned long long bm = __ballot(be & fitsn);
                     if (__builtin_expect(bm != 0, 0)) {
+                        const long long bt0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
                         while (bm) {
                             const int ow = __ffsll((long long)bm) - 1; // owner lane of this pass (wave-uniform)
                             bm &= bm - 1;
@@ -1705,42 +1842,60 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             const float cen_o = __shfl(s.center, ow), hl_o = __shfl(s.maxref * 1.25f, ow);
                             const float ll_o = __shfl(s.minref * 1.25f, ow), ls_o = __shfl(s.lastsample, ow);
                             const float* pr = (flt_o ? &L.flt[cln][0] : &L.raw[cln][0]) + base;
-                            // crossing test of the samples sp0 .. tn - 1 (bit a - sp0)
-                            unsigned long long cm[3];
-#pragma unroll
-                            for (int r = 0; r < 3; r++) {
-                                const int a = sp0 + lane + 64 * r;
-                                bool hit = false;
-                                if (a < tn) {
-                                    const float x = pr[a];
-                                    const float xp = (a == sp0) ? ls_o : pr[a - 1];
-                                    hit = (x > cen_o) ? (!(x > hl_o) && xp < cen_o) : (!(x < ll_o) && xp > cen_o);
-                                }
-                                cm[r] = __ballot(hit);
-                            }
-                            const int mmax = c0 < 8 ? 8 - c0 : 16;
+                            // the chain: symbol start -> first crossing inside the symbol -> slip of the next start, on scalars.
+                            // cm[] = crossing test of the samples q .. tn - 1 (bit a - q), shifted along with q.  The eighth
+                            // symbol of a hunt moves the crossing limits to the parked max / min: the mask is taken again there.
+                            float hl = hl_o, ll = ll_o;
+                            const float hl_n = __shfl(s.max * 1.25f, ow), ll_n = __shfl(s.min * 1.25f, ow);
                             int q = sp0, m = 0, myq = 0, myi0 = 0, myjin = 0;
-                            while (m < mmax) {
-                                const int i0 = (jit > 0 && jit <= (whole - 1) / 2) ? -1 : ((jit > (whole - 1) / 2 && jit < whole) ? 1 : 0);
-                                const int cnt = whole - i0;
-                                if (q + cnt > tn) {
+                            int lim = c0 < 8 ? 8 - c0 : 16;
+                            for (int ph = 0; ph < 2; ph++) {
+                                unsigned long long cm[3];
+#pragma unroll
+                                for (int r = 0; r < 3; r++) {
+                                    cm[r] = 0ull;
+                                    if (q + 64 * r < tn) {
+                                        const int a = q + lane + 64 * r;
+                                        bool hit = false;
+                                        if (a < tn) {
+                                            const float x = pr[a];
+                                            const float xp = (a == sp0) ? ls_o : pr[a - 1];
+                                            hit = (x > cen_o) ? (!(x > hl) && xp < cen_o) : (!(x < ll) && xp > cen_o);
+                                        }
+                                        cm[r] = __ballot(hit);
+                                    }
+                                }
+                                bool full = false;
+                                while (m < lim) {
+                                    const int i0 = (jit > 0 && jit <= (whole - 1) / 2) ? -1 : ((jit > (whole - 1) / 2 && jit < whole) ? 1 : 0);
+                                    const int cnt = whole - i0;
+                                    if (q + cnt > tn) {
+                                        full = true;
+                                        break;
+                                    }
+                                    if (lane == m) {
+                                        myq = q;
+                                        myi0 = i0;
+                                        myjin = jit;
+                                    }
+                                    const int k0 = i0 < 0 ? 1 : 0; // a crossing at symbol index -1 latches nothing
+                                    const uint32_t wv = (uint32_t)(cm[0] >> k0) & ((1u << (cnt - k0)) - 1u);
+                                    jit = wv ? i0 + k0 + (__ffs((int)wv) - 1) : -1;
+                                    cm[0] = (cm[0] >> cnt) | (cm[1] << (64 - cnt));
+                                    cm[1] = (cm[1] >> cnt) | (cm[2] << (64 - cnt));
+                                    cm[2] >>= cnt;
+                                    q += cnt;
+                                    m++;
+                                }
+                                if (full || lim >= 16) {
                                     break;
                                 }
-                                if (lane == m) {
-                                    myq = q;
-                                    myi0 = i0;
-                                    myjin = jit;
-                                }
-                                const int k0 = i0 < 0 ? 1 : 0; // a crossing at symbol index -1 latches nothing
-                                const int b = q - sp0 + k0, wi = b >> 6, sf = b & 63;
-                                const unsigned long long lo = wi == 0 ? cm[0] : (wi == 1 ? cm[1] : cm[2]);
-                                const unsigned long long hi = wi == 0 ? cm[1] : (wi == 1 ? cm[2] : 0ull);
-                                const uint32_t wv = (uint32_t)((lo >> sf) | (sf ? (hi << (64 - sf)) : 0ull)) & ((1u << (cnt - k0)) - 1u);
-                                jit = wv ? i0 + k0 + (__ffs((int)wv) - 1) : -1;
-                                q += cnt;
-                                m++;
+                                lim = 16;
+                                hl = hl_n;
+                                ll = ll_n;
                             }
-                            if (lane == m) { // where the symbol after the pass starts, and the latch it starts with
+                            // where the symbol after the pass starts, and the latch it starts with
+                            if (lane == m) {
                                 myq = q;
                                 myjin = jit;
                             }
@@ -1825,6 +1980,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 sp = qf;
                                 o += m;
                             }
+                        }
+                        if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { // the pass is no trip: its cycles are kept apart
+                            const long long now = (long long)clock64();
+                            dbg_sec[6] += now - bt0;
+                            dbg_sec[7]++;
+                            dbg_prev += now - bt0;
                         }
                         continue;
                     }
@@ -2381,13 +2542,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             __syncthreads();
         }
     }
-    if (HM && loader) { // the last tile's queue is drained below: both recurrence waves have to be through
-        while (__hip_atomic_load(&H.tile_done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it
-               || __hip_atomic_load(&H.tile_done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it) {
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
     if ((DDN_RX_CYCLES && (cfg.dbg & 8192)) && lane == 0) { // timing experiment only: cycles per wave in the tile body / at the tile barrier
         // (written over the unused tail of the workgroup's first channel's record area)
         uint8_t* d = rec + ((size_t)ch0 + 1) * max_sym * 10 - 192 + wave * 64;
@@ -2402,7 +2556,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
         }
     }
-    if (loader && offload && it > 0) {
+    if (!HM && loader && offload && it > 0) { // (handler mode: the staging wave's last job)
         drain((it - 1) & 1);
     }
     if (live) {

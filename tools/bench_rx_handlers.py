@@ -91,5 +91,6 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
         nstd = max(1, tt[:, 5].sum())
         extra += "\n   std trip sections (cycles per trip): top %.0f search %.0f mean %.0f inframe %.0f hunt %.0f emit %.0f" % tuple(
             sec[:, k].sum() / nstd for k in range(6))
+        extra += "\n   bulk hunting passes: %.2f per tile at %.0f cycles" % (sec[:, 7].sum() / (len(sec) * tiles), sec[:, 6].sum() / max(1, sec[:, 7].sum()))
     print("%-8s cpw %2d: loop %.3f ms (mf %.3f) in-frame share %.3f syncs/ch %.1f%s" % (
         mode, cpw, t[1], t[0], (flc & 1).mean() * ms / (n / 10), (flc & 2).sum() / B, extra), flush=True)
