@@ -1276,6 +1276,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
     };
     auto compute_sfx_half = [&](int buf, int tile_parity, int h) {
+        // S_m = summary of ring entries m + 1 .. SS for m = Mn .. 1, all of them at once: the 64 / LPR lanes of a channel's
+        // column first share the entries past Mn (B), then each takes K consecutive m: its own entries' summary, a suffix scan
+        // of those over the column (what the parts after it hold), and its K results on top of B and that.  (Two smallest /
+        // two largest of a union of disjoint sets do not depend on the order of the merges.)
         constexpr int EPL = 64 / LPR;
         const int c = h * LPR + lane % LPR, part = lane / LPR;
         const int s0 = L.sidx0[tile_parity][c];
@@ -1296,13 +1300,50 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             two_max_insert(p1, b1, b2);
             two_max_insert(p2, b1, b2);
         }
-        for (int m = Mn; m >= 1; m--) {
-            if (m < Mn) {
-                const float v = L.sb[(s0 + m) & (SS - 1)][c]; // entry m + 1
-                two_min_insert(v, a1, a2);
-                two_max_insert(v, b1, b2);
+        const int K = (Mn + EPL - 1) / EPL;   // m values per part: m = part * K + 1 .. part * K + K (those <= Mn)
+        const int m_lo = part * K + 1;
+        // own entries: e_(m + 1) for the part's m, as far as they lie inside 2 .. Mn
+        float ev[3] = {0.0f, 0.0f, 0.0f};
+        float c1 = inf, c2 = inf, d1 = -inf, d2 = -inf;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int m = m_lo + k;
+            if (k < K && m + 1 <= Mn) {
+                ev[k] = L.sb[(s0 + m) & (SS - 1)][c]; // entry m + 1
+                two_min_insert(ev[k], c1, c2);
+                two_max_insert(ev[k], d1, d2);
             }
-            if (part == 0) {
+        }
+        // inclusive suffix over the parts, then shifted by one part
+#pragma unroll
+        for (int d = 1; d < EPL; d <<= 1) {
+            const float o1 = __shfl_down(c1, d * LPR), o2 = __shfl_down(c2, d * LPR);
+            const float p1 = __shfl_down(d1, d * LPR), p2 = __shfl_down(d2, d * LPR);
+            if (part + d < EPL) {
+                two_min_insert(o1, c1, c2);
+                two_min_insert(o2, c1, c2);
+                two_max_insert(p1, d1, d2);
+                two_max_insert(p2, d1, d2);
+            }
+        }
+        {
+            const float o1 = __shfl_down(c1, LPR), o2 = __shfl_down(c2, LPR), p1 = __shfl_down(d1, LPR), p2 = __shfl_down(d2, LPR);
+            if (part + 1 < EPL) {
+                two_min_insert(o1, a1, a2);
+                two_min_insert(o2, a1, a2);
+                two_max_insert(p1, b1, b2);
+                two_max_insert(p2, b1, b2);
+            }
+        }
+        // the part's own m, from the highest down: each adds entry m + 1
+#pragma unroll
+        for (int k = 2; k >= 0; k--) {
+            const int m = m_lo + k;
+            if (k < K && m <= Mn) {
+                if (m + 1 <= Mn) {
+                    two_min_insert(ev[k], a1, a2);
+                    two_max_insert(ev[k], b1, b2);
+                }
                 *reinterpret_cast<float4*>(&L.sfx[buf][m - 1][c][0]) = make_float4(a1, a2, b1, b2);
             }
         }
