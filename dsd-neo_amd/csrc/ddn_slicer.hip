@@ -162,18 +162,18 @@ k_p25_slicer(const float* __restrict__ sym, long n, size_t sym_stride, int n_cha
 }
 
 // Matched filter (apply_sps_fir order: acc += tap[i] * x[o + i], i ascending, product and sum rounded separately).
-// Four adjacent outputs per thread as two packed lane pairs.  The tile is staged in LDS twice as aligned pairs: E[m] = {x[2m],
-// x[2m+1]} and O[m] = {x[2m+1], x[2m+2]}.  Outputs (o, o+1) and (o+2, o+3) of tap i need pairs m0 + i/2 and m0 + i/2 + 1 of E
-// (even taps) or O (odd taps), so the two pairs slide through registers and every second tap costs one 8-byte LDS read per
-// array: 2 bytes of LDS traffic per multiply-add instead of 4, four packed VALU instructions per tap.  Pair m sits at
-// [m & 1][m >> 1], so a wavefront's reads (pair 2 * tid + const) are consecutive 8-byte slots (the straight layout would put
-// them 16 bytes apart and use every second LDS bank only).  Taps are compile-time indices into the constant table.
+// Eight adjacent outputs per thread as four packed lane pairs.  The tile is staged in LDS twice as aligned pairs: E[m] = {x[2m],
+// x[2m+1]} and O[m] = {x[2m+1], x[2m+2]}.  Outputs (o + 2r, o + 2r + 1) of tap i need pair m0 + r + i/2 of E (even taps) or O
+// (odd taps), so the four pairs slide through registers and every second tap costs one 8-byte LDS read per array: 1 byte of LDS
+// traffic per multiply-add (the LDS, not the VALU, is this kernel's busiest unit: at four outputs per thread it moved 2 bytes per
+// multiply-add), eight packed VALU instructions per tap.  Pair m sits at [m & 3][m >> 2], so a wavefront's reads (pair 4 * tid +
+// const) are consecutive 8-byte slots.  Taps are compile-time indices into the constant table.
 typedef float mf2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(128) void
 k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const float* __restrict__ hist,
                      float* __restrict__ out) {
-    constexpr int T = 1024, NT = DDN_P25_FILTER_TAPS, NP = (T + NT + 3) / 2, NH = NP / 2 + 2;
-    __shared__ mf2 E[2][NH], O[2][NH];
+    constexpr int T = 1024, NT = DDN_P25_FILTER_TAPS, NP = (T + NT + 3) / 2, NH = NP / 4 + 2;
+    __shared__ mf2 E[4][NH], O[4][NH];
     const int ch = blockIdx.y;
     const long t0 = (long)blockIdx.x * T;
     const int tid = threadIdx.x;
@@ -184,50 +184,64 @@ k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const 
         }
         return j < n ? in[(size_t)ch * stride + j] : 0.0f;
     };
-    for (int m = tid; m < NP; m += 256) {
+    for (int m = tid; m < NP; m += 128) {
         const float a = sample(2 * m), b = sample(2 * m + 1), c = sample(2 * m + 2);
-        E[m & 1][m >> 1] = mf2{a, b};
-        O[m & 1][m >> 1] = mf2{b, c};
+        E[m & 3][m >> 2] = mf2{a, b};
+        O[m & 3][m >> 2] = mf2{b, c};
     }
     __syncthreads();
-    // this thread's outputs o .. o + 3, o = 4 * tid: pair index m0 = 2 * tid
-    mf2 e0 = E[0][tid], e1 = E[1][tid], q0 = O[0][tid], q1 = O[1][tid];
-    mf2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+    // this thread's outputs o .. o + 7, o = 8 * tid: pair index m0 = 4 * tid
+    mf2 e[4], q[4], acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        e[r] = E[r][tid];
+        q[r] = O[r][tid];
+        acc[r] = mf2{0.0f, 0.0f};
+    }
 #pragma unroll
     for (int j = 0; j < (NT + 1) / 2; j++) {
         {
             const float t = __uint_as_float(ddn_p25_filter_bits[2 * j]);
             const mf2 tt = {t, t};
-            acc0 += tt * e0;
-            acc1 += tt * e1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[r] += tt * e[r];
+            }
         }
         if (2 * j + 1 < NT) {
             const float t = __uint_as_float(ddn_p25_filter_bits[2 * j + 1]);
             const mf2 tt = {t, t};
-            acc0 += tt * q0;
-            acc1 += tt * q1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[r] += tt * q[r];
+            }
         }
-        e0 = e1;
-        q0 = q1;
-        if (j + 1 < (NT + 1) / 2) { // pair 2 * tid + j + 2
-            e1 = E[j & 1][tid + (j + 2) / 2];
-            q1 = O[j & 1][tid + (j + 2) / 2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            e[r] = e[r + 1];
+            q[r] = q[r + 1];
+        }
+        if (j + 1 < (NT + 1) / 2) { // pair 4 * tid + j + 4
+            e[3] = E[j & 3][tid + (j + 4) / 4];
+            q[3] = O[j & 3][tid + (j + 4) / 4];
         }
     }
-    const long o = t0 + 4 * tid;
+    const long o = t0 + 8 * tid;
     float* dst = out + (size_t)ch * stride + o;
-    if (o + 3 < n) {
-        *(mf2*)&dst[0] = acc0;
-        *(mf2*)&dst[2] = acc1;
+    if (o + 7 < n) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            *(mf2*)&dst[2 * r] = acc[r];
+        }
     } else {
-        if (o < n) {
-            dst[0] = acc0.x;
-        }
-        if (o + 1 < n) {
-            dst[1] = acc0.y;
-        }
-        if (o + 2 < n) {
-            dst[2] = acc1.x;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (o + 2 * r < n) {
+                dst[2 * r] = acc[r].x;
+            }
+            if (o + 2 * r + 1 < n) {
+                dst[2 * r + 1] = acc[r].y;
+            }
         }
     }
 }
@@ -260,7 +274,7 @@ ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channel
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_matched_filter, dim3((unsigned)((n + 1023) / 1024), (unsigned)n_channels), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_p25_matched_filter, dim3((unsigned)((n + 1023) / 1024), (unsigned)n_channels), dim3(128), 0, st,
                        in, n, stride, (const float*)hist, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -277,7 +291,7 @@ ddn_dev_p25_matched_filter_only(const float* in, long n, size_t stride, int n_ch
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_matched_filter, dim3((unsigned)((n + 1023) / 1024), (unsigned)n_channels), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_p25_matched_filter, dim3((unsigned)((n + 1023) / 1024), (unsigned)n_channels), dim3(128), 0, st,
                        in, n, stride, hist, out);
     return hipGetLastError();
 }
