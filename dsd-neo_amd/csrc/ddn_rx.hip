@@ -2087,7 +2087,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         // goes from one lean trip straight into the next - what can end the run is known from the trip itself (the
                         // lock running out, a symbol that no longer fits, a handler's answer arriving for a lane that sat out), so
                         // none of the trip loop's other tests are on the instruction stream between two lean trips.
-                        bool lz = lean, did = false;
+                        bool lz = lean, did = false, now_waits = false;
                         while (true) {
                             int rs = -1;
                             if (HM && hwait) {
@@ -2153,6 +2153,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             const bool st = lz & (s.lock_left > 1) & (s.min < s.max);
                             const bool nl = st & pf_ok;
                             const bool nw = st & !pf_ok & more;
+                            now_waits = nw;
                             if (__any(lz & !(nl | nw)) || !__any(nl) || tk >= QTW || (cfg.dbg & 2097152)
                                 || (HM && __any(hwait & (rs == hseq)))) {
                                 break;
@@ -2174,6 +2175,16 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             s.center = (s.max + s.min) / 2.0f;
                             s.maxref = s.max * 0.80f;
                             s.minref = s.min * 0.80f;
+                        }
+                        // every lane of the run now waits for the next tile (the others already did) and no lane sits out for a
+                        // handler: the tile is over - its last trip handed over as the trip loop's top would, no empty pass
+                        if (!__any(lz & !now_waits) && !(HM && __any(hwait)) && !(cfg.dbg & 4194304)) {
+                            if (tk <= QTW && lane < LPR) {
+                                *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
+                            }
+                            qv.w = __int_as_float(-1);
+                            tk++;
+                            break;
                         }
                         continue;
                     }
