@@ -43,6 +43,7 @@ struct ddn_p25_chain {
     float* d_disc;
     // receive-loop outputs, two sets: the loop of call k + 1 writes one while call k is decoded out of the other
     uint8_t *d_rec[2], *d_fl[2];
+    uint8_t* d_rec2[2] = {nullptr, nullptr}; // host form of the records (run_host with records2), allocated on first use
     int32_t *d_new[2], *d_ev[2], *d_nev[2], *d_evd[2];
     // the decisions of the records a row holds (carried + new), by row index: what files NIDs and TSDU blocks by frame
     int32_t *d_evl[2], *d_evdl[2], *d_nevl[2];
@@ -93,7 +94,7 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     ddn_p25_rx_destroy(c->rx);
     ddn_p25p1_framer_destroy(c->fr);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_new[0], c->d_new[1], c->d_ev[0], c->d_ev[1],
+    void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_rec2[0], c->d_rec2[1], c->d_fl[0], c->d_fl[1], c->d_new[0], c->d_new[1], c->d_ev[0], c->d_ev[1],
                    c->d_nev[0], c->d_nev[1], c->d_evd[0], c->d_evd[1], c->d_evl[0], c->d_evl[1], c->d_evdl[0], c->d_evdl[1],
                    c->d_nevl[0], c->d_nevl[1], c->d_cnt_scan, c->d_cnt_full, c->d_nid, c->d_cls, c->d_lists, c->d_list_n, c->d_tsbk, c->d_tsbk_crc, c->d_words[0],
                    c->d_words[1], c->d_wrel, c->d_werrs, c->d_vldu, c->d_rs_d[0], c->d_rs_d[1], c->d_rs_p[0], c->d_rs_p[1],
@@ -447,6 +448,13 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
         HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_out[cur ^ 1], 0)); // the previous call's results have left the decode buffers
     }
     DDN_TRY(chain_decode(c, cur, 0, c->s_aux));
+    if (out && out->records2) { // the records' host form, packed beside the decode stage
+        if (!c->d_rec2[0]) {
+            HIP_TRY(hipMalloc(&c->d_rec2[0], (size_t)c->B * c->stride * 2));
+            HIP_TRY(hipMalloc(&c->d_rec2[1], (size_t)c->B * c->stride * 2));
+        }
+        HIP_TRY(ddn_dev_chain_pack2(c->d_rec[cur], c->d_fl[cur], (size_t)c->B * c->stride, c->d_rec2[cur], c->s_aux));
+    }
     HIP_TRY(hipEventRecord(c->ev_consumed[cur], c->s_aux));
     // results of this call to the host, behind its decode, on the second copy stream
     HIP_TRY(hipStreamWaitEvent(c->s_copy2, c->ev_consumed[cur], 0));
@@ -457,6 +465,9 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
         }
         if (out->flags) {
             HIP_TRY(hipMemcpyAsync(out->flags, c->d_fl[cur], B * c->stride, hipMemcpyDeviceToHost, c->s_copy2));
+        }
+        if (out->records2) {
+            HIP_TRY(hipMemcpyAsync(out->records2, c->d_rec2[cur], B * c->stride * 2, hipMemcpyDeviceToHost, c->s_copy2));
         }
         if (out->counts) {
             HIP_TRY(hipMemcpyAsync(out->counts, c->d_cnt_full, B * 4, hipMemcpyDeviceToHost, c->s_copy2));

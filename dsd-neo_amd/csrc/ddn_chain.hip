@@ -32,6 +32,16 @@ k_chain_carry(const uint8_t* __restrict__ rec_prev, const uint8_t* __restrict__ 
     }
 }
 
+// the host form of a record: {dibit | flags << 2, reliability} - what the reference's consumers of a dibit stream read
+// (dibit, in-frame / sync / polarity marks, the reliability byte); the 16-bit soft values and the float symbol stay on the device
+__global__ __launch_bounds__(256) void
+k_chain_pack2(const uint8_t* __restrict__ rec, const uint8_t* __restrict__ fl, size_t n, uint16_t* __restrict__ out2) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint16_t w = *reinterpret_cast<const uint16_t*>(rec + i * 10); // dibit | reliability << 8
+        out2[i] = (uint16_t)((w & 0xFF03u) | ((uint16_t)(fl[i] & 0x3Fu) << 2));
+    }
+}
+
 // scan limit (syncs accepted before it are decoded in this call: the T symbols behind it are there) and full length
 __global__ void
 k_chain_counts(const int32_t* __restrict__ cnt_new, int T, int n_channels, int flush, int32_t* __restrict__ cnt_scan,
@@ -318,6 +328,17 @@ ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, const int32
     }
     hipLaunchKernelGGL(k_chain_carry, dim3(4, (unsigned)n_channels), dim3(256), 0, st, rec_prev, fl_prev, cnt_prev, have_prev, rec_cur,
                        fl_cur, stride_sym, T, n_channels);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pack2(const uint8_t* rec, const uint8_t* fl, size_t n, uint8_t* out2, hipStream_t st) {
+    if (n == 0) {
+        return hipSuccess;
+    }
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_chain_pack2, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, rec, fl, n,
+                       reinterpret_cast<uint16_t*>(out2));
     return hipGetLastError();
 }
 

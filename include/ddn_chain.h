@@ -100,6 +100,8 @@ typedef struct ddn_p25_chain_host_out {
     int32_t* nid4;      /* [S][4] */
     uint8_t* tsbk;      /* [3][S][12] */
     float* pcm;         /* [B][max_ldu * 9][160] */
+    uint8_t* records2;  /* [B][stride][2]: {dibit | flags << 2, reliability} - the records as a host consumer of the dibit stream
+                           reads them, a fifth of records10 + flags over PCIe (the soft values and the float symbol stay on the device) */
 } ddn_p25_chain_host_out;
 int ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_host_out* out);
 /* decode what the carry still holds back (end of a stream): one more decode pass without new samples */

@@ -170,7 +170,8 @@ def test_run_host_copies_back_what_the_device_holds(built):
     S, V, st, E = B * ch.F, B * ch.Fv * 9, ch.stride, ch.E
     shapes = {"records10": (np.uint8, (B, st, 10)), "flags": (np.uint8, (B, st)), "counts": (np.int32, (B,)),
               "events": (np.int32, (B, E, 4)), "n_events": (np.int32, (B,)), "event_data": (np.int32, (B, E, 4)),
-              "nid4": (np.int32, (S, 4)), "tsbk": (np.uint8, (3, S, 12)), "pcm": (np.float32, (V, 160))}
+              "nid4": (np.int32, (S, 4)), "tsbk": (np.uint8, (3, S, 12)), "pcm": (np.float32, (V, 160)),
+              "records2": (np.uint8, (B, st, 2))}
     pinned, outs, views = [], [], []
     for _ in range(2):                                   # two sets: call k's copies finish while call k + 1 runs
         o, v = ddn.P25ChainHostOut(), {}
@@ -198,8 +199,13 @@ def test_run_host_copies_back_what_the_device_holds(built):
         ch.wait()
         r = ch.results()
         for name, (dt, shp) in shapes.items():
-            dev = ch.fetch(getattr(r, names[name]), dt, shp)
             host = views[k & 1][name]
+            if name == "records2":                        # the host form: {dibit | flags << 2, reliability} of every record
+                rec, fl = views[k & 1]["records10"], views[k & 1]["flags"]
+                assert np.array_equal(host[..., 0], (rec[..., 0] & 3) | ((fl & 0x3F) << 2)), k
+                assert np.array_equal(host[..., 1], rec[..., 1]), k
+                continue
+            dev = ch.fetch(getattr(r, names[name]), dt, shp)
             if name in ("events", "event_data"):          # rows beyond n_events are not written by the loop
                 ne = ch.fetch(r.d_n_events, np.int32, (B,))
                 assert all(np.array_equal(dev[c, :ne[c]], host[c, :ne[c]]) for c in range(B)), (k, name)
