@@ -1,3 +1,6 @@
+// Where the dispatcher puts the waves of a 256-thread workgroup (HW_REG_HW_ID: SIMD, wave slot, CU, SE; HW_REG_XCC_ID) at the receive
+// loop's launch shape (512 workgroups, 78 KB LDS each) - the measurement behind the "roles by SIMD" step of DESIGN 5g.
+// hipcc --offload-arch=gfx950 -O2 hwid.hip -o hwid && ./hwid
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
