@@ -356,6 +356,8 @@ PROTOTYPES.update({
     "mbe_decodeAmbe3600x2450SoftFrame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MbeProcessResult)]),
     "mbe_processImbe4400Dataf": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, _PP, _PP, _PP]),
     "mbe_processAmbe2450Dataf": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, _PP, _PP, _PP]),
+    "mbe_processAmbe2400Dataf": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, _PP, _PP, _PP]),
+    "mbe_decodeImbe7100x4400Frame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MbeProcessResult)]),
     "mbe_processAmbe3600x2450Framef": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, C.c_void_p, _PP, _PP, _PP]),
     "mbe_processAmbe3600x2450SoftFramef": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, C.c_void_p, _PP, _PP, _PP]),
 })

@@ -570,3 +570,34 @@ mbe_processAmbe3600x2450SoftFramef(float* aout_buf, mbe_process_result* result, 
     }
     return mbe_processAmbe2450Dataf(aout_buf, r, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
+
+// ---- the two rates that are not restated (include/ddn_mbe.h): present so that dsd-neo's configure probe links ----------------
+extern "C" int
+mbe_decodeImbe7100x4400Frame(const char imbe_fr[7][24], char imbe_d[88], mbe_process_result* result) {
+    if (!imbe_fr || !imbe_d) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    memset(imbe_d, 0, 88);
+    if (result) {
+        mbe_initProcessResult(result);
+        result->flags = MBE_PROCESS_FLAG_MUTE;
+    }
+    return MBE_STATUS_UNSUPPORTED;
+}
+
+extern "C" int
+mbe_processAmbe2400Dataf(float* aout_buf, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp,
+                         mbe_parms* prev_mp_enhanced) {
+    (void)cur_mp;
+    (void)prev_mp;
+    (void)prev_mp_enhanced;
+    if (!aout_buf || !ambe_d) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbe_synthesizeSilencef(aout_buf);
+    if (result) {
+        mbe_initProcessResult(result);
+        result->flags = MBE_PROCESS_FLAG_MUTE;
+    }
+    return MBE_STATUS_UNSUPPORTED;
+}

@@ -68,6 +68,7 @@ typedef struct mbe_process_result {
 #define MBE_STATUS_INVALID_ARGUMENT (-1)
 #define MBE_STATUS_INVALID_BITS     (-2) /* a bit array held something other than 0 / 1 */
 #define MBE_STATUS_NO_DEVICE        (-3)
+#define MBE_STATUS_UNSUPPORTED      (-4) /* the rate is not restated here: nothing is decoded, silence is written */
 
 /* decoder history of one talk path: the public mbelib layout (mbelib.h `struct mbe_parameters`); index 0 unused,
  * harmonics 1..L.  dsd-neo treats it as opaque (include/dsd-neo/core/state.h: cur_mp / prev_mp / prev_mp_enhanced). */
@@ -199,6 +200,15 @@ int mbe_processAmbe3600x2450Framef(float* aout_buf, mbe_process_result* result, 
 int mbe_processAmbe3600x2450SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
                                        char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp,
                                        mbe_parms* prev_mp_enhanced);
+/* The two other symbols dsd-neo's configure step links against (CMakeLists.txt:626-657 probes them at :648 and :654; callers
+ * src/core/vocoder/dsd_mbe.c:603 - ProVoice's IMBE 7100x4400 - and :300 - D-STAR AMBE 2400 data files).  They exist so that
+ * the reference builds and runs against this library; neither rate is restated: the 7100 -> 7200 parameter-bit re-ordering
+ * (mbelib's mbe_convertImbe7100to7200) and the 2400 rate's bit layout and table set are not in the reference tree and a guess
+ * would be worse than saying so.  Both report MBE_STATUS_UNSUPPORTED (< 0: the reference clears its error display and plays
+ * silence for the frame, dsd_mbe.c:127-148), zero what they would have written and set MBE_PROCESS_FLAG_MUTE. */
+int mbe_decodeImbe7100x4400Frame(const char imbe_fr[7][24], char imbe_d[88], mbe_process_result* result);
+int mbe_processAmbe2400Dataf(float* aout_buf, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur_mp,
+                             mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced);
 
 #ifdef __cplusplus
 }

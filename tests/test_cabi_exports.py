@@ -64,3 +64,43 @@ def test_c_host_example_compiles_and_links(built, tmp_path):
     if not torch.cuda.is_available():
         p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
         assert p.returncode == 1 and p.stderr.strip()       # ddn_last_error(): no device - never a CPU fallback
+
+
+def test_configure_probe_of_the_reference_links_and_unsupported_rates_say_so(built, tmp_path):
+    """dsd-neo's configure step links a probe that names every mbelib-neo symbol it uses (CMakeLists.txt:626-657); the two rates
+    that are not restated here (IMBE 7100x4400, AMBE 2400 data) are present, decode nothing and report MBE_STATUS_UNSUPPORTED"""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "probe.c"
+    src.write_text('''
+#include "ddn_mbe.h"
+int main(void) {
+    char imbe_fr[8][23] = {{0}}, ambe_fr[4][24] = {{0}}, imbe7100_fr[7][24] = {{0}}, imbe_d[88] = {0}, ambe_d[49] = {0}, str[64];
+    float audio[160];
+    mbe_parms cur, prev, prev_enhanced;
+    mbe_process_result result;
+    mbe_initMbeParms(&cur, &prev, &prev_enhanced);
+    mbe_initProcessResult(&result);
+    (void)mbe_decodeImbe7200x4400Frame(imbe_fr, imbe_d, &result);
+    (void)mbe_decodeAmbe3600x2450Frame(ambe_fr, ambe_d, &result);
+    (void)mbe_decodeImbe7100x4400Frame(imbe7100_fr, imbe_d, &result);
+    (void)mbe_processImbe4400Dataf(audio, &result, imbe_d, &cur, &prev, &prev_enhanced);
+    (void)mbe_processAmbe2450Dataf(audio, &result, ambe_d, &cur, &prev, &prev_enhanced);
+    (void)mbe_processAmbe2400Dataf(audio, &result, ambe_d, &cur, &prev, &prev_enhanced);
+    mbe_formatProcessResult(str, sizeof str, &result);
+    mbe_synthesizeSilencef(audio);
+    return 0;
+}
+''')
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", os.path.join(root, "dsd-neo_amd"),
+                    "-ldsdneo_hip", "-Wl,-rpath," + os.path.join(root, "dsd-neo_amd")], check=True)
+    l = ddn.lib()
+    res = ddn.MbeProcessResult()
+    fr, d = np.ones((7, 24), np.uint8), np.ones(88, np.uint8)
+    assert l.mbe_decodeImbe7100x4400Frame(fr.ctypes.data, d.ctypes.data, C.byref(res)) == -4 and not d.any() and res.flags == 0x10
+    pcm, ad = np.ones(160, np.float32), np.zeros(49, np.uint8)
+    assert l.mbe_processAmbe2400Dataf(pcm.ctypes.data, C.byref(res), ad.ctypes.data, None, None, None) == -4
+    assert not pcm.any() and res.flags == 0x10
