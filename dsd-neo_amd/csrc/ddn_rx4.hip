@@ -236,6 +236,24 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
     // the lean in-frame trip: fixed symbol length of ordinary size (the 5-sample symbol has its own accumulation rule)
     const bool lean_ok = rem == 0 && whole >= 6 && whole <= MAXW && !(cfg.dbg & 1024);
     const uint32_t wmask = cfg.win_len >= 24 ? 0xFFFFFFu : ((1u << cfg.win_len) - 1u);
+    // bulk hunting pass (see the trip loop): the slip of a hunting symbol's start by the latch the one before left
+    // (symbol start in the general trip below), + 1, two bits per latch value -1 .. 30
+    const bool bulk_ok = lean_ok && !(cfg.dbg & 4096);
+    unsigned long long i0lut = 0;
+    for (int j = -1; j < 31; j++) {
+        const int c = (whole - 1) / 2;
+        int i0 = 0;
+        if (j >= 0 && whole > 1) {
+            if (whole == 20) {
+                i0 = (j >= 7 && j <= 10) ? -1 : ((j >= 11 && j <= 14) ? 1 : 0);
+            } else if (cfg.rf_mod == 2) {
+                i0 = (j >= c - 1 && j <= c) ? -1 : ((j >= c + 1 && j <= c + 2) ? 1 : 0);
+            } else {
+                i0 = (j > 0 && j <= c) ? -1 : ((j > c && j < whole) ? 1 : 0);
+            }
+        }
+        i0lut |= (unsigned long long)(i0 + 1) << (2 * (j + 1));
+    }
     int o = 0, ns = 0;
     const long long abs0 = s.n_abs;
     // ---- helper wave: slice / soft decision / record + payload stores / payload history / per-sync hand-over ----------------
@@ -387,6 +405,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
         } else {
             int guard = 0, qk = 0;
+            int blk_o = -1; // bulk hunting pass: output index at which it left this lane's next symbol to the general trip
             if (live) {
                 L.qo[t & 1][ln] = o;
             }
@@ -470,6 +489,197 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
             };
             while (true) {
+                // ---- bulk hunting pass ---------------------------------------------------------------------------------------
+                // As in the P25 loop (ddn_rx.hip): a lane that hunts has its thresholds parked, so its recurrence is the symbol
+                // start, the latched crossing and the sign history - its symbols that start in this tile are found at once by the
+                // whole wavefront (crossing mask by ballots, the start -> crossing -> slip chain on scalars, lane j = symbol j:
+                // window sum, sign, history word, the compare with every sync pattern) and handed to the helper wave through the
+                // queue like any other symbol.  The pass stops in front of the symbol that matches a pattern (the general trip
+                // takes that one: level window, filter gate, confirm rule, warm start, handler) and at the eighth symbol of a hunt
+                // (whose commit moves the crossing limits to the parked max / min: the mask is taken again).  Without it a lane
+                // that hunts drags its wave's in-frame lanes through general trips (54 % of the trips on the DMR capture).
+                if (bulk_ok) {
+                    const bool fo_b = s.filter_on != 0;
+                    const bool be = live & (s.have_sync == 0) & (s.in_symbol == 0) & (s.need_reset == 0) & (pos < tile_end) & (blk_o != o)
+                                    & (s.hunt_pos + 20 < 1800) & (qk + 4 < QCAPW) & (pos + whole + 1 <= n)
+                                    & (!fo_b | ((abs0 + pos - s.filt_start) >= (long long)(NT - 1)) | (cold_fs == s.filt_start));
+                    unsigned long long bm = __ballot(be);
+                    if (__builtin_expect(bm != 0, 0)) {
+                        while (bm) {
+                            const int ow = __ffsll((long long)bm) - 1; // owner lane (= channel column) of this pass
+                            bm &= bm - 1;
+                            const int sp0 = __builtin_amdgcn_readlane(pos, ow);
+                            const int c0 = __builtin_amdgcn_readlane(s.hist_count, ow);
+                            const int flt_o = __builtin_amdgcn_readlane(s.filter_on, ow);
+                            int jit = __builtin_amdgcn_readlane(s.jitter, ow);
+                            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)s.hist_bits, ow);
+                            const int sh_o = __builtin_amdgcn_readlane(s.shead, ow), li_o = __builtin_amdgcn_readlane(s.lidx, ow);
+                            const int qk_o = __builtin_amdgcn_readlane(qk, ow), ls_type = __builtin_amdgcn_readlane(s.lastsync, ow);
+                            const float cen_o = __shfl(s.center, ow), ls_o = __shfl(s.lastsample, ow);
+                            const float um_o = __shfl(s.umid, ow), lm_o = __shfl(s.lmid, ow), mx_o = __shfl(s.max, ow), mn_o = __shfl(s.min, ow);
+                            float hl = __shfl(s.maxref * 1.25f, ow), ll = __shfl(s.minref * 1.25f, ow);
+                            const float* pr = flt_o ? &L.flt[ow][0] : &L.raw[ow][0];
+                            const int a_end = lim < n ? lim : n; // samples staged
+                            int q = sp0, m = 0, myq = 0, myi0 = 0, myjin = 0;
+                            int cap = QCAPW - 2 - qk_o;
+                            cap = cap > 16 ? 16 : cap;
+                            cap = cap > cfg.t_max ? cfg.t_max : cap;
+                            // crossing limits: a symbol is searched against maxref / minref as the commit before it left them -
+                            // from the eighth symbol of a hunt on that is the parked max / min, except right after a pattern match
+                            // that was not accepted (it moved max / min behind the commit's back): that one symbol stands alone
+                            const bool refs_stale = __shfl((int)((s.maxref != s.max) | (s.minref != s.min)), ow) != 0;
+                            int lm = c0 < 8 ? 8 - c0 : (refs_stale ? 1 : cap);
+                            lm = lm > cap ? cap : lm;
+                            for (int ph = 0; ph < 2; ph++) {
+                                unsigned long long cm[3];
+#pragma unroll
+                                for (int r = 0; r < 3; r++) {
+                                    cm[r] = 0ull;
+                                    if (q + 64 * r < a_end) {
+                                        const int a = q + lane + 64 * r;
+                                        bool hit = false;
+                                        if (a < a_end) {
+                                            const float x = pr[a & RMASKW];
+                                            const float xp = (a == sp0) ? ls_o : pr[(a - 1) & RMASKW];
+                                            const bool up = x > cen_o;
+                                            const bool within = up ? !(x > hl) : !(x < ll);
+                                            const bool crossed = up ? (xp < cen_o) : (xp > cen_o);
+                                            hit = within && crossed;
+                                        }
+                                        cm[r] = __ballot(hit);
+                                    }
+                                }
+                                bool full = false;
+                                while (m < lm) {
+                                    const int i0 = (int)((i0lut >> (2 * (jit + 1))) & 3ull) - 1;
+                                    const int cnt = whole - i0;
+                                    if (q >= tile_end || q + cnt > n) {
+                                        full = true;
+                                        break;
+                                    }
+                                    if (lane == m) {
+                                        myq = q;
+                                        myi0 = i0;
+                                        myjin = jit;
+                                    }
+                                    const int k0 = i0 < 0 ? 1 : 0; // a crossing at symbol index -1 latches nothing
+                                    const uint32_t wv = (uint32_t)(cm[0] >> k0) & ((1u << (cnt - k0)) - 1u);
+                                    jit = wv ? i0 + k0 + (__ffs((int)wv) - 1) : -1;
+                                    cm[0] = (cm[0] >> cnt) | (cm[1] << (64 - cnt));
+                                    cm[1] = (cm[1] >> cnt) | (cm[2] << (64 - cnt));
+                                    cm[2] >>= cnt;
+                                    q += cnt;
+                                    m++;
+                                }
+                                if (full || lm >= cap) {
+                                    break;
+                                }
+                                lm = cap;
+                                hl = mx_o * 1.25f;
+                                ll = mn_o * 1.25f;
+                            }
+                            if (lane == m) { // where the symbol after the pass starts, and the latch it starts with
+                                myq = q;
+                                myjin = jit;
+                            }
+                            // lane j: the window sum of symbol j (symbol_accumulate_sample's rule, in sample order; no clip while hunting)
+                            float sym = 0.0f, wsum = 0.0f;
+                            int wc = 0;
+                            if (lane < m) {
+                                const int cw = (whole - 1) / 2;
+                                const int l_e = (Cfg::dmr_window && ls_type != 0) ? 1 : 2;
+                                const bool rf0b = cfg.rf_mod == 0;
+                                const int wlo = rf0b ? cw - l_e : cw - 1, whi = rf0b ? cw + 2 : cw + 1;
+                                const bool has20 = whole == 20;
+                                const int i_lo = has20 && 7 < wlo ? 7 : wlo, i_hi = has20 && 13 > whi ? 13 : whi;
+                                const int leftj = whole - myi0;
+#pragma unroll
+                                for (int qq = 0; qq < 12; qq++) {
+                                    const int i = i_lo + qq, k = i - myi0;
+                                    if (i <= i_hi && k >= 0 && k < leftj) {
+                                        const float x = pr[(myq + k) & RMASKW];
+                                        const bool k1 = rf0b ? (i >= wlo && i <= whi) : (i == wlo || i == whi);
+                                        const bool k2 = has20 && i >= 7 && i <= 13;
+                                        if (k2) {
+                                            wsum += x;
+                                        }
+                                        if (k1) {
+                                            wsum += x;
+                                        }
+                                        wc += (k1 ? 1 : 0) + (k2 ? 1 : 0);
+                                    }
+                                }
+                                sym = (wc > 0) ? (wsum / (float)wc) : 0.0f;
+                            }
+                            const uint32_t sw = (uint32_t)__ballot(lane < m && sym > 0.0f);
+                            const int lj = lane < 31 ? lane : 31;
+                            const uint32_t hj = ((h0 << (lj + 1)) | __brev(sw << (31 - lj))) & 0xFFFFFFu;
+                            bool syn = false;
+                            if (lane < m && (c0 + lane + 1 >= cfg.win_len) && !(cfg.dbg & 8)) {
+                                const uint32_t w = hj & wmask;
+                                for (int k = 0; k < cfg.n_pat; k++) {
+                                    syn |= (w == L.pat_bits[k]);
+                                }
+                            }
+                            const unsigned long long sm = __ballot(syn);
+                            if (sm) {
+                                m = __ffsll((long long)sm) - 1;
+                            }
+                            if (m == 0) { // the next symbol matches a sync pattern: the general trip's
+                                if (lane == ow) {
+                                    blk_o = o;
+                                }
+                                continue;
+                            }
+                            const int qf = __builtin_amdgcn_readlane(myq, m), jf = __builtin_amdgcn_readlane(myjin, m);
+                            const float sumf = __shfl(wsum, m - 1);
+                            const int cntf = __builtin_amdgcn_readlane(wc, m - 1);
+                            const uint32_t hf = (uint32_t)__builtin_amdgcn_readlane((int)hj, m - 1);
+                            if (lane < m) { // symbol history, level window, the queue entry the helper wave slices and stores
+                                const int slot = (sh_o + lane) & (HN - 1);
+                                L.sh[slot][ow] = sym;
+                                int k = li_o + lane;
+                                k = k >= cfg.t_max ? k - cfg.t_max : k;
+                                L.lb[k][ow] = sym;
+                                const int qb = t & 1, qe = qk_o + lane;
+                                L.q[qb][qe][0][ow] = sym;
+                                L.q[qb][qe][1][ow] = cen_o;
+                                L.q[qb][qe][2][ow] = um_o;
+                                L.q[qb][qe][3][ow] = lm_o;
+                                L.q[qb][qe][4][ow] = mx_o;
+                                L.q[qb][qe][5][ow] = mn_o;
+                                L.q[qb][qe][6][ow] = __int_as_float(slot << 8);
+                            }
+                            const float lsf = pr[(qf - 1) & RMASKW];
+                            if (lane == ow) {
+                                s.shead = (s.shead + m) & (HN - 1);
+                                s.scount = s.scount + m < HN ? s.scount + m : HN;
+                                int k = s.lidx + m;
+                                s.lidx = k >= cfg.t_max ? k - cfg.t_max : k;
+                                s.level_count = s.level_count + m < cfg.t_max ? s.level_count + m : cfg.t_max;
+                                s.hist_bits = hf;
+                                s.hist_count = c0 + m < 24 ? c0 + m : 24;
+                                if (s.hist_count >= 8) {
+                                    s.maxref = s.max;
+                                    s.minref = s.min;
+                                }
+                                s.hunt_pos += m;
+                                s.span = whole;
+                                s.centre = (whole - 1) / 2;
+                                s.i = whole;
+                                s.sum = sumf;
+                                s.count = cntf;
+                                s.in_symbol = 0;
+                                s.jitter = jf;
+                                s.lastsample = lsf;
+                                pos = qf;
+                                o += m;
+                                qk += m;
+                            }
+                        }
+                        continue;
+                    }
+                }
                 // ---- lean trip -----------------------------------------------------------------------------------------
                 // Every live lane sits inside a frame with its crossing latched, a whole fresh symbol of the fixed length
                 // staged and the matched filter warm (or has used up its tile): inside a
