@@ -390,6 +390,22 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
                                     cfg->vocoder};
         rc = ddn_fsk4_chain_create(&nc, &m->nxdn);
     }
+    { // the three loops share the device: the DMR / NXDN48 kernels take the shape that suits the whole batch
+        const int total = cfg->n_p25 + cfg->n_dmr + cfg->n_nxdn48;
+        int cpw = 32;
+        for (int c = 1; c <= 32; c *= 2) {
+            if ((total + c - 1) / c <= 1536) {
+                cpw = c;
+                break;
+            }
+        }
+        if (rc == DDN_OK && m->dmr) {
+            rc = ddn_fsk4_rx_set_channels_per_wave(m->dmr->rx, cpw);
+        }
+        if (rc == DDN_OK && m->nxdn) {
+            rc = ddn_fsk4_rx_set_channels_per_wave(m->nxdn->rx, cpw);
+        }
+    }
     for (int k = 0; k < 3 && rc == DDN_OK; k++) {
         if (hipStreamCreateWithFlags(&m->st[k], hipStreamNonBlocking) != hipSuccess
             || hipEventCreateWithFlags(&m->ev_front[k], hipEventDisableTiming) != hipSuccess) {

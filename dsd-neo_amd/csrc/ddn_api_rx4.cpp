@@ -225,7 +225,15 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
     // fewer channels per wavefront = fewer unsynchronised recurrences sharing one instruction stream, and a trip is only a
     // lean trip when every lane of the wave is inside a frame (measured at 4096 DMR channels: 11.8 ms with 4 lanes per wave,
     // 13.6 with 8, 16.7 with 16); two-wave workgroups, so 4096 channels at 4 per wave are eight wavefronts per CU
-    b->channels_per_wave = B <= 4096 ? 4 : (B <= 8192 ? 8 : (B <= 16384 ? 16 : 32));
+    // (round 3, with the bulk hunting pass: at 1365 channels 9.5 / 7.6 / 6.2 ms DMR and 6.5 / 4.0 / 2.6 ms NXDN48 with 4 / 2 / 1
+    // lanes per wave - as long as all the workgroups are resident at once: 2048 one-channel workgroups run in two rounds)
+    b->channels_per_wave = 32;
+    for (int cpw = 1; cpw <= 32; cpw *= 2) {
+        if ((B + cpw - 1) / cpw <= 1536) {
+            b->channels_per_wave = cpw;
+            break;
+        }
+    }
     if (const char* e = getenv("DDN_RX4_CPW")) {
         b->channels_per_wave = atoi(e);
     }
@@ -420,6 +428,15 @@ ddn_fsk4_rx_run(ddn_fsk4_rx* b, const float* d_disc, size_t n, uint8_t* d_record
         HIP_TRY(hipEventRecord(b->ev[2], st));
     }
     HIP_TRY(ddn_dev_fsk4_filter_hist_update(b->dc.nt, d_disc, (long)n, n, B, b->d_fhist, st));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fsk4_rx_set_channels_per_wave(ddn_fsk4_rx* b, int channels_per_wave) {
+    if (!b || channels_per_wave < 1 || channels_per_wave > 32 || (channels_per_wave & (channels_per_wave - 1))) {
+        return DDN_EINVAL;
+    }
+    b->channels_per_wave = channels_per_wave;
     return DDN_OK;
 }
 

@@ -1453,6 +1453,18 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
         }                                                                                                                  \
         return handlers ? launch<CPW_, MAXW_, 2, true>(DDN_RX4_ARGS) : launch<CPW_, MAXW_, 2, false>(DDN_RX4_ARGS);         \
     } while (0)
+    if (channels_per_wave <= 1) {
+        if (sps <= 11) {
+            DDN_RX4_GO(1, 12);
+        }
+        DDN_RX4_GO(1, 22);
+    }
+    if (channels_per_wave <= 2) {
+        if (sps <= 11) {
+            DDN_RX4_GO(2, 12);
+        }
+        DDN_RX4_GO(2, 22);
+    }
     if (channels_per_wave <= 4) {
         if (sps <= 11) {
             DDN_RX4_GO(4, 12);

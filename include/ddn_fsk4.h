@@ -79,6 +79,10 @@ int ddn_fsk4_rx_run_host(ddn_fsk4_rx* b, const float* disc, size_t n, uint8_t* r
                          int32_t* counts, size_t max_symbols, int32_t* sync_pos, uint8_t* sync_pat, uint8_t* pre,
                          uint8_t* pre_rel, int32_t* n_sync, size_t max_syncs);
 int ddn_fsk4_rx_get_thresholds(ddn_fsk4_rx* b, int channel, float out7[7]); /* center umid lmid max min maxref minref */
+/* kernel shape: channels per recurrence wavefront (1, 2, 4 ... 32; results do not depend on it).  The default is the fewest that
+ * keeps every workgroup resident for this batch alone; a host that runs other loops beside this one on the same GPU (the mixed
+ * chain does) picks it for the whole device's channel count. */
+int ddn_fsk4_rx_set_channels_per_wave(ddn_fsk4_rx* b, int channels_per_wave);
 int ddn_fsk4_rx_set_timing(ddn_fsk4_rx* b, int enable);
 int ddn_fsk4_rx_get_timing(ddn_fsk4_rx* b, float* ms2); /* {matched filter, receive loop} of the last run */
 

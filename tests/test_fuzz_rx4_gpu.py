@@ -54,6 +54,10 @@ def test_fuzz_rx4(built, case):
         lock[c] = [int(rng.choice([0, 54, 120, 182, 700, 3000])), int(rng.choice([0, 54, 342, 1782])), 0, 0]
     gpu = ddn.Fsk4Rx(B, ddn.FSK4_NXDN48 if nxdn else ddn.FSK4_DMR, rf_mod=rf_mod, inverted=inv, use_matched_filter=use_filter)
     assert ddn.lib().ddn_fsk4_rx_set_lock_symbols(gpu.h, lock.ctypes.data) == 0
+    # every kernel shape (the default for a batch this small is one channel per wavefront); drawn from its own stream so the traffic
+    # of a case stays what it was
+    cpw = int(np.random.default_rng(5000 * BASE + case).choice([1, 2, 4, 8, 16, 32]))
+    assert ddn.lib().ddn_fsk4_rx_set_channels_per_wave(gpu.h, cpw) == 0
     cpu = [rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf_mod, use_filter=use_filter, inverted=inv, lock=[int(v) for v in lock[c]]))
            for c in range(B)]
     cuts = sorted(set([0, n] + [int(v) for v in rng.integers(1, n, int(rng.integers(0, 4)))]))
