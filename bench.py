@@ -41,7 +41,7 @@ N_SAMPLES = 48000
 BLOCK = 8192
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
 N_BASE = 64                  # distinct channels of each traffic kind
-RXW_TRAFFIC_BYTES = 2.807e9   # profiles/r03_bench_pmc_FETCH_SIZE.txt, _WRITE_SIZE.txt: 2 x 782 528 KB + 1 242 235 KB per launch of k_p25_rxw<8, true>
+RXW_TRAFFIC_BYTES = 2.806e9   # profiles/r03_bench_pmc_FETCH_SIZE.txt, _WRITE_SIZE.txt: 2 x 782 516 KB + 1 240 722 KB per launch of k_p25_rxw<8, true>
 
 
 def make_base_traffic(n):
