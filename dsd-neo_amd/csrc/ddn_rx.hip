@@ -2706,8 +2706,15 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
         if (whole < 6 || !hstate || !hh_store || !events || !n_events) {
             return hipErrorInvalidValue;
         }
-        if (cpw != 8 && cpw != 16) {
-            cpw = n_channels <= 8 * 512 ? 8 : 16;
+        if (cpw != 4 && cpw != 8 && cpw != 16) {
+            // two workgroups per CU are resident: up to 2048 channels four per workgroup (two lanes per recurrence wave - a lane's
+            // standard trip, bulk pass or wait then holds up one other lane instead of three), up to 4096 eight
+            cpw = n_channels <= 4 * 512 ? 4 : (n_channels <= 8 * 512 ? 8 : 16);
+        }
+        if (cpw == 4) {
+            return launch_rxw<4, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                       shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store,
+                                       events, n_events, st);
         }
         if (cpw == 8) {
             return launch_rxw<8, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,

@@ -93,7 +93,7 @@ def _traffic(seed, n, noise, weak_nids=False):
     return p25gen.modulate_disc(dib, lead=200 + 13 * (seed % 17), noise=noise, seed=seed, scale=scale)[:n]
 
 
-@pytest.mark.parametrize("cpw", [8, 16])
+@pytest.mark.parametrize("cpw", [4, 8, 16])
 def test_every_frame_type_clean_and_noisy(built, cpw):
     B, n = 24, 40000
     x = np.zeros((B, n), np.float32)
