@@ -65,6 +65,8 @@ struct ddn_p25_chain {
     float* d_pcm;
     // pipelining
     hipStream_t s_main, s_aux, s_copy, s_copy2; // front end + loop | decode | H2D | D2H
+    hipStream_t s_voice = nullptr;              // the voice stage of a decode, beside its frame FEC
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_produced[2], ev_consumed[2], ev_in[2], ev_in_free[2], ev_out[2];
     void* d_iq[2];
     size_t iq_bytes;
@@ -116,6 +118,15 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     }
     if (c->s_copy2) {
         (void)hipStreamDestroy(c->s_copy2);
+    }
+    if (c->s_voice) {
+        (void)hipStreamDestroy(c->s_voice);
+    }
+    if (c->ev_fork) {
+        (void)hipEventDestroy(c->ev_fork);
+    }
+    if (c->ev_join) {
+        (void)hipEventDestroy(c->ev_join);
     }
     hipEvent_t evs[] = {c->ev_produced[0], c->ev_produced[1], c->ev_consumed[0], c->ev_consumed[1], c->ev_in[0], c->ev_in[1],
                         c->ev_in_free[0], c->ev_in_free[1], c->ev_out[0], c->ev_out[1], c->ev_t[0], c->ev_t[1], c->ev_t[2],
@@ -202,7 +213,10 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
         if (hipStreamCreateWithPriority(&c->s_main, hipStreamNonBlocking, -1) != hipSuccess
             || hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking) != hipSuccess
             || hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) != hipSuccess
-            || hipStreamCreateWithFlags(&c->s_copy2, hipStreamNonBlocking) != hipSuccess) {
+            || hipStreamCreateWithFlags(&c->s_copy2, hipStreamNonBlocking) != hipSuccess
+            || hipStreamCreateWithFlags(&c->s_voice, hipStreamNonBlocking) != hipSuccess
+            || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
             rc = DDN_EHIP;
             break;
         }
@@ -296,6 +310,15 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
                                      c->off97[1], c->off97[2], c->d_nid, c->d_tsbk, c->d_tsbk_crc, c->d_cls, c->d_lists, c->d_list_n,
                                      st));
     }
+    // The frame FEC below (per-type work lists) and the voice stage (voice index by NID -> IMBE frames -> PCM) read the same records
+    // and NIDs and write nothing the other reads: the voice stage runs on a stream of its own beside the FEC (0.7 ms of small
+    // kernels) and joins this one at the end.  With stage timing on everything stays on one stream.
+    hipStream_t vst = st;
+    if (!c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(c->s_voice, c->ev_fork, 0));
+        vst = c->s_voice;
+    }
     // Every decode below walks the work list of its frame type (the slots whose NID names it, k_chain_frames): a slot's LDU / HDU /
     // TDULC outputs are meaningful for that type alone.  The selection is cleared on every way out.
     struct SelGuard {
@@ -330,13 +353,17 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
         HIP_TRY(hipEventRecord(c->ev_t[4], st));
     }
     // voice: nine IMBE frames per LDU
-    DDN_TRY(ddn_p25p1_framer_voice_index(c->fr, c->d_nid, c->d_cnt_full, c->Fv, stride, c->d_first, c->d_sc, c->d_nldu, st));
+    DDN_TRY(ddn_p25p1_framer_voice_index(c->fr, c->d_nid, c->d_cnt_full, c->Fv, stride, c->d_first, c->d_sc, c->d_nldu, vst));
     DDN_TRY(ddn_p25p1_imbe_deinterleave_batch(rec, (size_t)c->B * stride, c->d_first, c->d_sc, V, c->d_imbe_fr, c->d_imbe_soft,
-                                              c->d_imbe_fl, c->d_sc_out, st));
-    DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_IMBE_7200X4400, c->d_imbe_fr, nullptr, V, c->d_imbe_d, c->d_imbe_res, st));
-    DDN_TRY(ddn_mbe_result_skip_batch(c->d_imbe_fl, V, c->d_imbe_res, st));
+                                              c->d_imbe_fl, c->d_sc_out, vst));
+    DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_IMBE_7200X4400, c->d_imbe_fr, nullptr, V, c->d_imbe_d, c->d_imbe_res, vst));
+    DDN_TRY(ddn_mbe_result_skip_batch(c->d_imbe_fl, V, c->d_imbe_res, vst));
     if (c->cfg.vocoder) {
-        DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_imbe_d, c->d_imbe_res, (size_t)c->Fv * 9, c->d_pcm, c->d_res_out, st));
+        DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_imbe_d, c->d_imbe_res, (size_t)c->Fv * 9, c->d_pcm, c->d_res_out, vst));
+    }
+    if (vst != st) {
+        HIP_TRY(hipEventRecord(c->ev_join, vst));
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
     }
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[5], st));
