@@ -312,9 +312,10 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
     }
     // The frame FEC below (per-type work lists) and the voice stage (voice index by NID -> IMBE frames -> PCM) read the same records
     // and NIDs and write nothing the other reads: the voice stage runs on a stream of its own beside the FEC (0.7 ms of small
-    // kernels) and joins this one at the end.  With stage timing on everything stays on one stream.
+    // kernels) and joins this one at the end - in the pipelined forms (decode on the object's second stream); the one-stream form
+    // and stage timing keep everything on the caller's stream.
     hipStream_t vst = st;
-    if (!c->timing) {
+    if (!c->timing && st == c->s_aux) {
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(c->s_voice, c->ev_fork, 0));
         vst = c->s_voice;
