@@ -22,6 +22,7 @@
 //                       640 B of PCM per frame written coalesced.
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 #include "ddn_device.h"
@@ -54,6 +55,25 @@ golay_table_lds(uint32_t* tab, int tid, int nthreads) {
     }
     if (tid == 0) {
         tab[0] = 0;
+    }
+}
+
+// The syndrome -> pattern table once per device in global memory (8 KB): a decode block copies it into LDS instead of walking the
+// 23^3 patterns itself (that walk was most of a block's work: 190 iterations per lane against the 64 frames' few hundred
+// instructions).
+__device__ uint32_t g_golay_tab[2048];
+
+__global__ __launch_bounds__(256) void
+k_golay_tab_init() {
+    __shared__ uint32_t tab[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+        tab[i] = 0;
+    }
+    __syncthreads();
+    golay_table_lds(tab, threadIdx.x, 256);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+        g_golay_tab[i] = tab[i];
     }
 }
 
@@ -97,7 +117,9 @@ k_mbe_frame_decode(const uint8_t* __restrict__ frames, const uint8_t* __restrict
     const int lane = threadIdx.x;
     const size_t f0 = (size_t)blockIdx.x * 64;
     const size_t nf = (n - f0) < 64 ? (n - f0) : 64;
-    golay_table_lds(tab, lane, 64);
+    for (int i = lane; i < 2048; i += 64) {
+        tab[i] = g_golay_tab[i];
+    }
     const uint8_t* src = frames + f0 * FB;
     for (size_t i = lane; i < nf * FB; i += 64) {
         stage[i] = src[i];
@@ -815,6 +837,28 @@ ddn_dev_mbe_frame_decode(int codec, const uint8_t* frames, const uint8_t* soft, 
                          hipStream_t st) {
     if (n == 0) {
         return hipSuccess;
+    }
+    { // the Golay table of this device, built at the first decode
+        static std::mutex mu;
+        static bool up[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            return hipErrorInvalidDevice;
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= 64 || !up[dev]) {
+            hipLaunchKernelGGL(k_golay_tab_init, dim3(1), dim3(256), 0, st);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) {
+                e = hipStreamSynchronize(st); // other streams' decodes may follow at once
+            }
+            if (e != hipSuccess) {
+                return e;
+            }
+            if (dev >= 0 && dev < 64) {
+                up[dev] = true;
+            }
+        }
     }
     const dim3 grid((unsigned)((n + 63) / 64)), blk(64);
     if (codec == DDN_MBE_IMBE_7200X4400) {
