@@ -658,8 +658,10 @@ def pcie_inclusive(torch, ddn, chain, d_iq, B, n):
     S, V, st, E = B * chain.F, B * chain.Fv * 9, chain.stride, chain.E
     full = {"records10": B * st * 10, "flags": B * st, "counts": B * 4, "events": B * E * 16, "n_events": B * 4, "nid4": S * 16,
             "tsbk": 3 * S * 12, "pcm": V * 640}
-    compact = {k: v for k, v in full.items() if k not in ("records10", "flags")}
+    compact = {k: v for k, v in full.items() if k not in ("records10", "flags", "pcm")}
     compact["records2"] = B * st * 2
+    dense_frames = V // 3          # host-side capacity for the dense PCM: a third of the slots (the traffic fills 28 %)
+    compact["pcm_dense"], compact["pcm_slot"], compact["pcm_count"] = dense_frames * 640, dense_frames * 4, 4
     iq_bytes = B * n * 2
     pinned = []
 
@@ -678,6 +680,8 @@ def pcie_inclusive(torch, ddn, chain, d_iq, B, n):
             o = ddn.P25ChainHostOut()
             for k, nb in sizes.items():
                 setattr(o, k, pin(nb).value)
+            if "pcm_dense" in sizes:
+                o.pcm_dense_frames = dense_frames
             outs.append(o)
         for k in range(3):
             chain.run_host(h_iq[k & 1], outs[k & 1])
@@ -695,7 +699,9 @@ def pcie_inclusive(torch, ddn, chain, d_iq, B, n):
                    "streams beside the kernels (ddn_p25_chain_run_host), steady state over 6 steps.  The H2D copies are SDMA "
                    "transfers and hide; the D2H copies are shader kernels on this ROCm and wait for the receive loop (DESIGN 6)")
     out["compact"] = run(compact)
-    out["compact"]["note"] = "the same with the records as {dibit | flags << 2, reliability} pairs (records2) instead of records10 + flags"
+    out["compact"]["note"] = ("the same with the records as {dibit | flags << 2, reliability} pairs (records2) instead of records10 + flags "
+                              "and the synthesized PCM frames dense (pcm_dense / pcm_slot / pcm_count, host capacity a third of the slots) "
+                              "instead of every slot's 640 bytes")
     for p in pinned:
         l.ddn_host_free_pinned(p)
     return out

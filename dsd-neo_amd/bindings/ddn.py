@@ -430,7 +430,8 @@ class P25ChainResults(C.Structure):  # == ddn_p25_chain_results
 class P25ChainHostOut(C.Structure):  # == ddn_p25_chain_host_out
     _fields_ = [("records10", C.c_void_p), ("flags", C.c_void_p), ("counts", C.c_void_p), ("events", C.c_void_p),
                 ("n_events", C.c_void_p), ("event_data", C.c_void_p), ("nid4", C.c_void_p), ("tsbk", C.c_void_p), ("pcm", C.c_void_p),
-                ("records2", C.c_void_p)]
+                ("records2", C.c_void_p), ("pcm_dense", C.c_void_p), ("pcm_slot", C.c_void_p), ("pcm_count", C.c_void_p),
+                ("pcm_dense_frames", C.c_int64)]
 
 
 PROTOTYPES.update({

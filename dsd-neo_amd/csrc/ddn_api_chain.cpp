@@ -44,6 +44,8 @@ struct ddn_p25_chain {
     // receive-loop outputs, two sets: the loop of call k + 1 writes one while call k is decoded out of the other
     uint8_t *d_rec[2], *d_fl[2];
     uint8_t* d_rec2[2] = {nullptr, nullptr}; // host form of the records (run_host with records2), allocated on first use
+    float* d_pcm_dense = nullptr;            // dense PCM (run_host with pcm_dense), allocated on first use: [V][160]
+    int32_t *d_pcm_slot = nullptr, *d_pcm_bcnt = nullptr, *d_pcm_boff = nullptr, *d_pcm_total = nullptr;
     int32_t *d_new[2], *d_ev[2], *d_nev[2], *d_evd[2];
     // the decisions of the records a row holds (carried + new), by row index: what files NIDs and TSDU blocks by frame
     int32_t *d_evl[2], *d_evdl[2], *d_nevl[2];
@@ -96,7 +98,8 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     ddn_p25_rx_destroy(c->rx);
     ddn_p25p1_framer_destroy(c->fr);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_rec2[0], c->d_rec2[1], c->d_fl[0], c->d_fl[1], c->d_new[0], c->d_new[1], c->d_ev[0], c->d_ev[1],
+    void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_rec2[0], c->d_rec2[1], c->d_pcm_dense, c->d_pcm_slot, c->d_pcm_bcnt,
+                   c->d_pcm_boff, c->d_pcm_total, c->d_fl[0], c->d_fl[1], c->d_new[0], c->d_new[1], c->d_ev[0], c->d_ev[1],
                    c->d_nev[0], c->d_nev[1], c->d_evd[0], c->d_evd[1], c->d_evl[0], c->d_evl[1], c->d_evdl[0], c->d_evdl[1],
                    c->d_nevl[0], c->d_nevl[1], c->d_cnt_scan, c->d_cnt_full, c->d_nid, c->d_cls, c->d_lists, c->d_list_n, c->d_tsbk, c->d_tsbk_crc, c->d_words[0],
                    c->d_words[1], c->d_wrel, c->d_werrs, c->d_vldu, c->d_rs_d[0], c->d_rs_d[1], c->d_rs_p[0], c->d_rs_p[1],
@@ -483,6 +486,19 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
         }
         HIP_TRY(ddn_dev_chain_pack2(c->d_rec[cur], c->d_fl[cur], (size_t)c->B * c->stride, c->d_rec2[cur], c->s_aux));
     }
+    const bool dense_pcm = out && out->pcm_dense && out->pcm_slot && out->pcm_count && out->pcm_dense_frames > 0 && c->cfg.vocoder;
+    if (dense_pcm) { // the synthesized frames only, compacted beside the decode stage
+        const size_t V = c->V;
+        if (!c->d_pcm_dense) {
+            HIP_TRY(hipMalloc(&c->d_pcm_dense, V * 160 * sizeof(float)));
+            HIP_TRY(hipMalloc(&c->d_pcm_slot, V * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&c->d_pcm_bcnt, ((V + 1023) / 1024) * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&c->d_pcm_boff, ((V + 1023) / 1024) * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&c->d_pcm_total, sizeof(int32_t)));
+        }
+        HIP_TRY(ddn_dev_chain_pcm_compact(c->d_imbe_res, c->d_pcm, (int)V, (long)V, c->d_pcm_bcnt, c->d_pcm_boff, c->d_pcm_dense,
+                                          c->d_pcm_slot, c->d_pcm_total, c->s_aux));
+    }
     HIP_TRY(hipEventRecord(c->ev_consumed[cur], c->s_aux));
     // results of this call to the host, behind its decode, on the second copy stream
     HIP_TRY(hipStreamWaitEvent(c->s_copy2, c->ev_consumed[cur], 0));
@@ -517,6 +533,12 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
         }
         if (out->pcm && c->cfg.vocoder) {
             HIP_TRY(hipMemcpyAsync(out->pcm, c->d_pcm, V * 160 * 4, hipMemcpyDeviceToHost, c->s_copy2));
+        }
+        if (dense_pcm) {
+            const size_t nf = (size_t)out->pcm_dense_frames < V ? (size_t)out->pcm_dense_frames : V;
+            HIP_TRY(hipMemcpyAsync(out->pcm_dense, c->d_pcm_dense, nf * 160 * 4, hipMemcpyDeviceToHost, c->s_copy2));
+            HIP_TRY(hipMemcpyAsync(out->pcm_slot, c->d_pcm_slot, nf * 4, hipMemcpyDeviceToHost, c->s_copy2));
+            HIP_TRY(hipMemcpyAsync(out->pcm_count, c->d_pcm_total, 4, hipMemcpyDeviceToHost, c->s_copy2));
         }
     }
     HIP_TRY(hipEventRecord(c->ev_out[cur], c->s_copy2));

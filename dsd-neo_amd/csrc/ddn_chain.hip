@@ -42,6 +42,108 @@ k_chain_pack2(const uint8_t* __restrict__ rec, const uint8_t* __restrict__ fl, s
     }
 }
 
+// The synthesized PCM frames of a call, dense: frame slots whose vocoder result does not carry the skip mark, in slot order, with
+// their slot numbers - what a host reads instead of every slot's 640 bytes (most slots of a batch are empty: control channels,
+// unused LDU slots).  Three small kernels: used slots per 1024-slot block, the blocks' offsets, the copy.
+__global__ __launch_bounds__(256) void
+k_pcm_count(const int32_t* __restrict__ result5, int n_slots, int32_t* __restrict__ block_cnt) {
+    __shared__ int part[4];
+    const int base = blockIdx.x * 1024;
+    int c = 0;
+    for (int k = 0; k < 4; k++) {
+        const int i = base + k * 256 + (int)threadIdx.x;
+        c += (i < n_slots && result5[(size_t)i * 5] >= 0) ? 1 : 0; // the skip mark is the word's top bit
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        c += __shfl_down(c, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    }
+}
+
+__global__ __launch_bounds__(64) void
+k_pcm_offsets(const int32_t* __restrict__ block_cnt, int n_blocks, int32_t* __restrict__ block_off, int32_t* __restrict__ total) {
+    // one wavefront: running offsets over the blocks, 64 at a time
+    int run = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+        const int b = b0 + (int)threadIdx.x;
+        const int v = b < n_blocks ? block_cnt[b] : 0;
+        int inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            inc += ((int)threadIdx.x >= d) ? t : 0;
+        }
+        if (b < n_blocks) {
+            block_off[b] = run + inc - v;
+        }
+        run += __shfl(inc, 63);
+    }
+    if (threadIdx.x == 0) {
+        *total = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void
+k_pcm_compact(const int32_t* __restrict__ result5, const float* __restrict__ pcm, int n_slots, const int32_t* __restrict__ block_off,
+              long capacity, float* __restrict__ dense, int32_t* __restrict__ slot_of) {
+    __shared__ int woff[17];
+    __shared__ int list[1024];
+    const int base = blockIdx.x * 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // slot order: wave w, round k covers slots base + (4 k + w) * 64 .. + 63
+    int pos[4];
+    unsigned long long m[4];
+    int cnt[4];
+    for (int k = 0; k < 4; k++) {
+        const int i = base + (4 * k + wave) * 64 + lane;
+        const bool used = i < n_slots && result5[(size_t)i * 5] >= 0;
+        m[k] = __ballot(used);
+        cnt[k] = __popcll(m[k]);
+        pos[k] = used ? __popcll(m[k] & ((1ull << lane) - 1ull)) : -1;
+    }
+    if (lane == 0) {
+        for (int k = 0; k < 4; k++) {
+            woff[1 + 4 * k + wave] = cnt[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        woff[0] = 0;
+        for (int j = 1; j <= 16; j++) {
+            woff[j] += woff[j - 1];
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        if (pos[k] >= 0) {
+            list[woff[4 * k + wave] + pos[k]] = base + (4 * k + wave) * 64 + lane;
+        }
+    }
+    __syncthreads();
+    const int n_used = woff[16];
+    const long out0 = block_off[blockIdx.x];
+    for (int j = wave; j < n_used; j += 4) { // one wavefront per frame: 160 floats
+        const long o = out0 + j;
+        if (o >= capacity) {
+            break;
+        }
+        const int sl = list[j];
+        const float* src = pcm + (size_t)sl * 160;
+        float* dst = dense + (size_t)o * 160;
+        for (int t = lane; t < 160; t += 64) {
+            dst[t] = src[t];
+        }
+        if (lane == 0) {
+            slot_of[o] = sl;
+        }
+    }
+}
+
 // scan limit (syncs accepted before it are decoded in this call: the T symbols behind it are there) and full length
 __global__ void
 k_chain_counts(const int32_t* __restrict__ cnt_new, int T, int n_channels, int flush, int32_t* __restrict__ cnt_scan,
@@ -328,6 +430,19 @@ ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, const int32
     }
     hipLaunchKernelGGL(k_chain_carry, dim3(4, (unsigned)n_channels), dim3(256), 0, st, rec_prev, fl_prev, cnt_prev, have_prev, rec_cur,
                        fl_cur, stride_sym, T, n_channels);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pcm_compact(const int32_t* result5, const float* pcm, int n_slots, long capacity, int32_t* block_cnt, int32_t* block_off,
+                          float* dense, int32_t* slot_of, int32_t* total, hipStream_t st) {
+    if (n_slots <= 0) {
+        return hipSuccess;
+    }
+    const int nb = (n_slots + 1023) / 1024;
+    hipLaunchKernelGGL(k_pcm_count, dim3((unsigned)nb), dim3(256), 0, st, result5, n_slots, block_cnt);
+    hipLaunchKernelGGL(k_pcm_offsets, dim3(1), dim3(64), 0, st, block_cnt, nb, block_off, total);
+    hipLaunchKernelGGL(k_pcm_compact, dim3((unsigned)nb), dim3(256), 0, st, result5, pcm, n_slots, block_off, capacity, dense, slot_of);
     return hipGetLastError();
 }
 

@@ -280,6 +280,8 @@ ddn_sel_grid(const DdnSel* sel, unsigned long n_blocks_full) {
     const unsigned long cap = 1024;
     return (unsigned)((sel->list && n_blocks_full > cap) ? cap : (n_blocks_full ? n_blocks_full : 1));
 }
+hipError_t ddn_dev_chain_pcm_compact(const int32_t* result5, const float* pcm, int n_slots, long capacity, int32_t* block_cnt,
+                                     int32_t* block_off, float* dense, int32_t* slot_of, int32_t* total, hipStream_t st);
 hipError_t ddn_dev_chain_pack2(const uint8_t* rec, const uint8_t* fl, size_t n, uint8_t* out2, hipStream_t st);
 hipError_t ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, const int32_t* cnt_prev, int have_prev,
                                uint8_t* rec_cur, uint8_t* fl_cur, size_t stride_sym, int T, int n_channels, hipStream_t st);

@@ -102,6 +102,13 @@ typedef struct ddn_p25_chain_host_out {
     float* pcm;         /* [B][max_ldu * 9][160] */
     uint8_t* records2;  /* [B][stride][2]: {dibit | flags << 2, reliability} - the records as a host consumer of the dibit stream
                            reads them, a fifth of records10 + flags over PCIe (the soft values and the float symbol stay on the device) */
+    /* the synthesized frames only, dense and in slot order (slot = channel * max_ldu * 9 + frame slot), instead of every slot's
+     * 640 bytes: up to pcm_dense_frames of them are copied (all three pointers set, pcm_dense_frames > 0); *pcm_count is the number
+     * the call produced - if it exceeds pcm_dense_frames the rest is still in d_pcm (ddn_p25_chain_get_results) */
+    float* pcm_dense;        /* [pcm_dense_frames][160] */
+    int32_t* pcm_slot;       /* [pcm_dense_frames] */
+    int32_t* pcm_count;      /* [1] */
+    int64_t pcm_dense_frames;
 } ddn_p25_chain_host_out;
 int ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_host_out* out);
 /* decode what the carry still holds back (end of a stream): one more decode pass without new samples */

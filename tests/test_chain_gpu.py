@@ -171,7 +171,8 @@ def test_run_host_copies_back_what_the_device_holds(built):
     shapes = {"records10": (np.uint8, (B, st, 10)), "flags": (np.uint8, (B, st)), "counts": (np.int32, (B,)),
               "events": (np.int32, (B, E, 4)), "n_events": (np.int32, (B,)), "event_data": (np.int32, (B, E, 4)),
               "nid4": (np.int32, (S, 4)), "tsbk": (np.uint8, (3, S, 12)), "pcm": (np.float32, (V, 160)),
-              "records2": (np.uint8, (B, st, 2))}
+              "records2": (np.uint8, (B, st, 2)), "pcm_dense": (np.float32, (V, 160)), "pcm_slot": (np.int32, (V,)),
+              "pcm_count": (np.int32, (1,))}
     pinned, outs, views = [], [], []
     for _ in range(2):                                   # two sets: call k's copies finish while call k + 1 runs
         o, v = ddn.P25ChainHostOut(), {}
@@ -182,6 +183,7 @@ def test_run_host_copies_back_what_the_device_holds(built):
             pinned.append(p)
             setattr(o, name, p.value)
             v[name] = np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=dt).reshape(shp)
+        o.pcm_dense_frames = V
         outs.append(o)
         views.append(v)
     h_iq = []
@@ -200,6 +202,14 @@ def test_run_host_copies_back_what_the_device_holds(built):
         r = ch.results()
         for name, (dt, shp) in shapes.items():
             host = views[k & 1][name]
+            if name in ("pcm_slot", "pcm_count"):
+                continue
+            if name == "pcm_dense":                       # the synthesized frames only, dense, in slot order
+                used = np.flatnonzero(ch.fetch(r.d_imbe_result, np.int32, (V, 5))[:, 0] >= 0)
+                cnt = int(views[k & 1]["pcm_count"][0])
+                assert cnt == len(used) and np.array_equal(views[k & 1]["pcm_slot"][:cnt], used), (k, cnt, len(used))
+                assert np.array_equal(host[:cnt].view(np.uint32), views[k & 1]["pcm"][used].view(np.uint32)), k
+                continue
             if name == "records2":                        # the host form: {dibit | flags << 2, reliability} of every record
                 rec, fl = views[k & 1]["records10"], views[k & 1]["flags"]
                 assert np.array_equal(host[..., 0], (rec[..., 0] & 3) | ((fl & 0x3F) << 2)), k
