@@ -360,6 +360,9 @@ PROTOTYPES.update({
     "mbe_decodeImbe7100x4400Frame": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MbeProcessResult)]),
     "mbe_processAmbe3600x2450Framef": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, C.c_void_p, _PP, _PP, _PP]),
     "mbe_processAmbe3600x2450SoftFramef": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, C.c_void_p, _PP, _PP, _PP]),
+    "mbe_processAmbe3600x2400Framef": (C.c_int, [C.c_void_p, C.POINTER(MbeProcessResult), C.c_void_p, C.c_void_p, _PP, _PP, _PP]),
+    "mbe_floattoshort": (None, [C.c_void_p, C.c_void_p]),
+    "mbe_versionString": (C.c_char_p, []),
 })
 
 

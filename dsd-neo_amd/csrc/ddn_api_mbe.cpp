@@ -601,3 +601,44 @@ mbe_processAmbe2400Dataf(float* aout_buf, mbe_process_result* result, const char
     }
     return MBE_STATUS_UNSUPPORTED;
 }
+
+// D-STAR's AMBE 3600x2400 frames (src/core/vocoder/dsd_mbe.c:633, mbe_process_dstar): the 2400 rate is not restated (see
+// mbe_processAmbe2400Dataf above); the symbol is here so that dsd-neo links, and it says so the same way
+extern "C" int
+mbe_processAmbe3600x2400Framef(float* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
+                               mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    (void)cur_mp;
+    (void)prev_mp;
+    (void)prev_mp_enhanced;
+    if (!aout_buf || !ambe_fr || !ambe_d) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    memset(ambe_d, 0, 49);
+    mbe_synthesizeSilencef(aout_buf);
+    if (result) {
+        mbe_initProcessResult(result);
+        result->flags = MBE_PROCESS_FLAG_MUTE;
+    }
+    return MBE_STATUS_UNSUPPORTED;
+}
+
+// src/core/audio/dsd_audio2.c:1376 (soft tones on the short-integer output path): mbelib's float -> short conversion of one
+// 160-sample frame - gain 7, clipped to +-32760, truncated toward zero (mbelib 1.3 mbe_floattoshort; host arithmetic on 160 values,
+// not a device stage)
+extern "C" void
+mbe_floattoshort(const float* float_buf, short* aout_buf) {
+    if (!float_buf || !aout_buf) {
+        return;
+    }
+    for (int i = 0; i < 160; i++) {
+        float a = 7.0f * float_buf[i];
+        a = a > 32760.0f ? 32760.0f : (a < -32760.0f ? -32760.0f : a);
+        aout_buf[i] = (short)a;
+    }
+}
+
+// src/runtime/bootstrap/bootstrap.c:695 prints it in the start-up banner
+extern "C" const char*
+mbe_versionString(void) {
+    return "libdsdneo_hip (gfx950) behind the mbelib-neo 2.0 C API";
+}

@@ -209,6 +209,15 @@ int mbe_processAmbe3600x2450SoftFramef(float* aout_buf, mbe_process_result* resu
 int mbe_decodeImbe7100x4400Frame(const char imbe_fr[7][24], char imbe_d[88], mbe_process_result* result);
 int mbe_processAmbe2400Dataf(float* aout_buf, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur_mp,
                              mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced);
+/* The three remaining mbelib-neo symbols the reference's sources call outside the configure probe (found by tools/gen_mbe_symbols.py,
+ * which lists every mbe_* call in the reference's src/ that the reference does not define itself):
+ *   mbe_processAmbe3600x2400Framef  src/core/vocoder/dsd_mbe.c:633 (D-STAR) - refused like the 2400 data call above
+ *   mbe_floattoshort                src/core/audio/dsd_audio2.c:1376 - 160 floats -> shorts, gain 7, clip +-32760 (mbelib 1.3 rule)
+ *   mbe_versionString               src/runtime/bootstrap/bootstrap.c:695 - the start-up banner */
+int mbe_processAmbe3600x2400Framef(float* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
+                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced);
+void mbe_floattoshort(const float* float_buf, short* aout_buf);
+const char* mbe_versionString(void);
 
 #ifdef __cplusplus
 }

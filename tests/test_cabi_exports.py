@@ -104,3 +104,27 @@ int main(void) {
     pcm, ad = np.ones(160, np.float32), np.zeros(49, np.uint8)
     assert l.mbe_processAmbe2400Dataf(pcm.ctypes.data, C.byref(res), ad.ctypes.data, None, None, None) == -4
     assert not pcm.any() and res.flags == 0x10
+
+
+def test_every_mbelib_symbol_the_reference_calls_is_exported(built):
+    """tests/golden/mbe_symbols_called.json (tools/gen_mbe_symbols.py) lists every mbe_* function the reference's src/ and include/
+    call without defining it - the link-time contract of B6, wider than the configure probe.  Each one is an exported symbol of the
+    library; the three outside the probe behave as include/ddn_mbe.h says"""
+    import ctypes as C
+    import json
+    import numpy as np
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mbe_symbols_called.json")))["symbols"]
+    assert len(want) >= 15
+    l = ddn.lib()
+    missing = [name for name in want if not hasattr(l, name)]
+    assert not missing, missing
+    res = ddn.MbeProcessResult()
+    fr, d, pcm = np.ones((4, 24), np.uint8), np.ones(49, np.uint8), np.ones(160, np.float32)
+    assert l.mbe_processAmbe3600x2400Framef(pcm.ctypes.data, C.byref(res), fr.ctypes.data, d.ctypes.data, None, None, None) == -4
+    assert not pcm.any() and not d.any() and res.flags == 0x10
+    f = np.array([0.0, 1.0, -1.0, 0.99, -0.5, 5000.0, -5000.0, 4680.1] + [0.25] * 152, np.float32)
+    sh = np.zeros(160, np.int16)
+    l.mbe_floattoshort(f.ctypes.data, sh.ctypes.data)
+    assert sh[:8].tolist() == [0, 7, -7, 6, -3, 32760, -32760, 32760] and (sh[8:] == 1).all()
+    l.mbe_versionString.restype = C.c_char_p
+    assert b"mbelib-neo 2.0" in l.mbe_versionString()
