@@ -461,6 +461,15 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
         HIP_TRY(hipMalloc(&c->d_iq[0], c->iq_bytes + 16));
         HIP_TRY(hipMalloc(&c->d_iq[1], c->iq_bytes + 16));
     }
+    // The header's contract, kept on the host side (stream-to-stream waits alone do not): the previous call's h_iq has left the host
+    // before this call returns, and the results of the call before that are in the caller's buffers.  This also bounds what a host
+    // that never calls _wait can have queued: two calls.
+    if (c->step >= 1) {
+        HIP_TRY(hipEventSynchronize(c->ev_in[cur ^ 1]));
+    }
+    if (c->step >= 2) {
+        HIP_TRY(hipEventSynchronize(c->ev_out[cur]));
+    }
     if (c->step >= 2) {
         HIP_TRY(hipStreamWaitEvent(c->s_copy, c->ev_in_free[cur], 0)); // the front end of call k - 2 has read this input buffer
     }

@@ -244,7 +244,8 @@ ddn_dev_imbe_index(const int32_t* sync_pos, const int32_t* n_syncs, int n_channe
 }
 
 namespace {
-// voice frames of every channel in air order, compacted: the slots whose NID decoded (status 1) to LDU1 / LDU2 - the
+// voice frames of every channel in air order, compacted: the slots whose NID decoded (status > 0: NID_OK or NID_PARITY_OVERRIDE,
+// include/dsd-neo/protocol/p25/p25p1_check_nid.h:30-41) to LDU1 / LDU2 - the
 // only callers of process_IMBE (processLDU1 / processLDU2, src/engine/dispatch/dispatch_p25p1.c) - in sync order, nine
 // frames each; unused entries get first = -1 (k_imbe_deinterleave flags those 0xFF).  One thread per channel: a
 // channel has a handful of frames per call.
@@ -262,7 +263,7 @@ k_voice_index(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ 
     const int cnt = counts[ch] < (int)max_sym ? counts[ch] : (int)max_sym;
     for (int slot = 0; slot < ns && k < max_ldu; slot++) {
         const int32_t* nd = nid4 + ((size_t)ch * max_frames + slot) * 4;
-        if (nd[0] == 1 && (nd[2] == 0x5 || nd[2] == 0xA)) {
+        if (nd[0] > 0 && (nd[2] == 0x5 || nd[2] == 0xA)) { // NID_OK and NID_PARITY_OVERRIDE both dispatch (dispatch_p25p1.c:214-218)
             const int start = sync_pos[(size_t)ch * max_frames + slot] - 23;
             const int64_t base = (int64_t)((size_t)ch * max_sym) + start;
             for (int v = 0; v < 9; v++) {

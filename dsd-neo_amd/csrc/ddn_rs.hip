@@ -1192,7 +1192,9 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
 // exact match, else the nearest entry within 7 bits - with minimum distance 16 the only tie is a codeword against the S-ISCH
 // word 14 bits from it, settled by the measured walk order of the reference's map (DDN_ISCH_S_FIRST_INIT).  Soft (a 40-byte
 // reliability row per word): the entry within 7 bits with the least (sum of reliabilities of differing bits, differing bits,
-// answer).  -2 = S-ISCH / nothing within reach.
+// answer).  -2 = S-ISCH / nothing within reach.  The word is NOT masked to 40 bits: the reference is not (dsd_popcount64 of the
+// whole xor, src/fec/ez.cpp:335, while isch_weighted_mismatch_cost :345-352 walks the 40 field bits only), so a stray high bit
+// adds to the distance, never to the cost, and never indexes the reliability row (`b < 40` below; tests: words_high, bit 47 set).
 __constant__ uint64_t c_isch[128] = DDN_ISCH_TABLE_INIT;
 __constant__ uint8_t c_isch_s_first[128] = DDN_ISCH_S_FIRST_INIT;
 

@@ -8,8 +8,9 @@
 //                                              P25p1 pattern :698-716, accept :385-392,603-625)
 //   threshold warm start                       src/dsp/sync_calibration.c:156-233
 //   in-frame symbols                           get_dibit_and_analog_signal, src/core/frames/dsd_dibit.c (ddn_slicer_dev.h)
-// Scope and deviations: P25p1 only, modulation locked to C4FM, a caller-given in-frame
-// symbol count instead of the per-DUID handlers, no carrier-loss reset.
+// Scope and deviations: P25p1 only, modulation locked to C4FM.  The in-frame symbol count comes from the reference's
+// per-DUID handlers running inside the loop (HANDLERS = true, ddn_p25h_dev.h / ddn_nid_dev.h; ddn_p25_rx_set_handlers) or, for the
+// stage tests, from a caller-given lock length; 1800 sync-less symbols reset the loop as the reference's noCarrier() does.
 //
 // GPU shape.  Everything here is a per-sample / per-symbol recurrence, so the only parallelism is across channels,
 // and one wavefront issues about one VALU instruction every ~5 cycles however many of its lanes are active.  At the

@@ -88,8 +88,11 @@ int ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip
  * of call k runs beside the front end and loop of call k + 1.  Returns once everything is queued. */
 int ddn_p25_chain_run_pipelined(ddn_p25_chain* c, const void* d_iq);
 /* pipelined, from pinned host memory: the H2D copy of this call's I/Q and the D2H copy of the previous call's results (any of the
- * out pointers may be NULL) run on a third stream beside the kernels.  h_iq must stay untouched until the next call returns;
- * the outputs named at call k are complete when call k + 2 returns, or after ddn_p25_chain_wait(). */
+ * out pointers may be NULL) run on copy streams beside the kernels.  h_iq must stay untouched until the next call returns (that call
+ * waits on the host for the copy): two input buffers, used in turn, are enough.  The outputs named at call k are complete when call
+ * k + 2 returns (it waits for them on the host), or after ddn_p25_chain_wait(); call k + 2's own copies may already be running by
+ * then, so a host that reads call k's outputs after call k + 2 returned needs THREE output sets used in turn (two if it calls
+ * ddn_p25_chain_wait() before reading). */
 typedef struct ddn_p25_chain_host_out {
     uint8_t* records10; /* [B][stride][10] */
     uint8_t* flags;     /* [B][stride] */

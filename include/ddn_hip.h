@@ -446,7 +446,7 @@ int ddn_p25p1_framer_gather_lsd(ddn_p25p1_framer* f, const uint8_t* d_records10,
 int ddn_p25p1_framer_imbe_index(ddn_p25p1_framer* f, size_t max_symbols, int64_t* d_first_record,
                                 int32_t* d_status_count, void* hip_stream);
 /* The same index compacted to voice traffic: for every channel the slots whose decoded NID (d_nid4 [slots][4] from
- * ddn_p25p1_nid_decode_batch: status 1, DUID 0x5 / 0xA - processLDU1 / processLDU2 are the only callers of process_IMBE,
+ * ddn_p25p1_nid_decode_batch: status > 0 (NID_OK or NID_PARITY_OVERRIDE), DUID 0x5 / 0xA - processLDU1 / processLDU2 are the only callers of process_IMBE,
  * src/engine/dispatch/dispatch_p25p1.c) in sync order, nine voice frames each: d_first_record / d_status_count
  * [n_channels][max_ldu_per_channel][9] (unused entries and frames that run past the channel's d_counts records: -1 -> ddn_p25p1_imbe_deinterleave_batch
  * flags them 0xFF),
@@ -579,7 +579,7 @@ int ddn_fec_viterbi_k5_host(const uint16_t* soft, size_t n, int in_len, const ui
  *                            [n][n_par][6], status [n] 0 ok / 1 irrecoverable (data then unchanged)
  *                            == check_and_fix_reedsolomon_24_12_13 / _24_16_9 (p25p1_check_ldu.h),
  *                               check_and_fix_redsolomon_36_20_17 (p25p1_check_hdu.h)   (hard decision; the erasure
- *                               variants *_soft are not built yet) */
+ *                               variants are ddn_fec_p25_rs_soft_* further down) */
 enum { DDN_RS_24_12_13 = 0, DDN_RS_24_16_9 = 1, DDN_RS_36_20_17 = 2 };
 int ddn_fec_golay24_batch(int data_len, uint8_t* d_data_bits, const uint8_t* d_parity12, size_t n, uint8_t* d_status,
                           int32_t* d_fixed, void* hip_stream);

@@ -141,7 +141,7 @@ def run_stream(iq_c, samples_per_call, seed, vocoder=True, timers=None, use_ref=
         for a in acc:
             a = int(a)
             n = frames[a].get("nid")
-            if n is None or n[0] != 1 or n[2] not in (5, 10):
+            if n is None or n[0] <= 0 or n[2] not in (5, 10):     # NID_OK and NID_PARITY_OVERRIDE both reach processLDU1 / 2 (dispatch_p25p1.c:214-218)
                 continue
             for v in range(9):
                 s0 = a - 23 + int(first9[v])
@@ -237,7 +237,7 @@ class Collector:
                 for name, a in extra.items():
                     d[name] = a[c, s].copy()
                 self.frames[c][g] = d
-                if nid[c, s, 0] == 1 and nid[c, s, 2] in (5, 10) and kv < Fv:
+                if nid[c, s, 0] > 0 and nid[c, s, 2] in (5, 10) and kv < Fv:
                     for v in range(9):
                         i = kv * 9 + v
                         self.voice[c].append((g, v, bits[c, i].copy(), res[c, i].copy(), pcm[c, i].copy()))

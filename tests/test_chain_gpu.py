@@ -119,6 +119,31 @@ def test_short_calls_and_frames_across_boundaries(built):
         _check_against_oracle(col, c, want)
 
 
+def test_parity_override_ldu_still_gives_voice(built):
+    """an LDU whose 64th NID bit (the parity bit, outside the BCH word) arrives flipped decodes as NID_PARITY_OVERRIDE (status 2,
+    src/protocol/p25/phase1/p25p1_check_nid.cpp:293-303) and is dispatched like any accepted frame (dispatch_p25p1.c:214-218:
+    status > 0): Hamming / RS run AND its nine IMBE frames are synthesized"""
+    rng = np.random.default_rng(77)
+    n_call, calls = 12000, 3
+    bits = mbe.random_imbe_bits(rng, (36,))
+    dib, _ = p25gen.make_ldus(rng, 4, 0x293, np.stack([mbe.imbe_encode(b) for b in bits]))
+    dib = dib.copy()
+    for f in (1, 2):
+        dib[f * 864 + 56] ^= 1            # frame dibit 56 = BCH bit 62 | parity bit
+    iq = p25gen.modulate_cu8(dib, n_call * calls, lead=260, seed=5, noise=0.02)[None]
+    col = _run(iq, n_call, everything=True)
+    want = chain_stream.run_stream(iq[0], n_call, seed=0)
+    n_nid, _, n_voice = _check_against_oracle(col, 0, want)
+    st = sorted((g, int(d["nid"][0]), int(d["nid"][2])) for g, d in col.frames[0].items())
+    assert [s[1] for s in st] == [1, 2, 2, 1] and [s[2] for s in st] == [5, 10, 5, 10], st
+    assert n_nid == 4 and n_voice == 36
+    for g, status, duid in st:
+        d = col.frames[0][g]
+        assert (d["rs1s"] if duid == 5 else d["rs2s"]) == 0
+    pcm = np.stack([v[4] for v in col.voice[0]])
+    assert len(pcm) == 36 and (np.abs(pcm).sum(axis=1) > 0).all()
+
+
 _BY_TYPE = {"words1": 5, "rs1": 5, "rs1s": 5, "words2": 10, "rs2": 10, "rs2s": 10, "hdu": 0, "hdus": 0, "tdulc": 15, "tdulcs": 15}
 
 
@@ -226,6 +251,77 @@ def test_run_host_copies_back_what_the_device_holds(built):
     ch.close()
     for p in pinned + h_iq:
         l.ddn_host_free_pinned(p)
+
+
+def test_run_host_streaming_host_never_waits(built):
+    """the contract of ddn_p25_chain_run_host as include/ddn_chain.h words it, used the way a streaming host would: two pinned input
+    buffers refilled in turn as soon as the NEXT call has returned, three output sets read as soon as the call after the next has
+    returned, no ddn_p25_chain_wait() until the end.  Every call's outputs equal those of a run that waits after every call"""
+    l = ddn.lib()
+    B, n_call, calls = 4, 16384, 7
+    iq = _stream(B, n_call * calls)
+    fields = {"records2": np.uint8, "counts": np.int32, "nid4": np.int32, "tsbk": np.uint8, "pcm_dense": np.float32,
+              "pcm_slot": np.int32, "pcm_count": np.int32, "n_events": np.int32}
+
+    def pin(nbytes):
+        p = C.c_void_p()
+        assert l.ddn_host_alloc_pinned(nbytes, C.byref(p)) == 0
+        return p
+
+    def go(streaming):
+        ch = ddn.P25ChainC(B, n_call)
+        S, V, st = B * ch.F, B * ch.Fv * 9, ch.stride
+        sizes = {"records2": B * st * 2, "counts": B * 4, "nid4": S * 16, "tsbk": 3 * S * 12, "pcm_dense": V * 640, "pcm_slot": V * 4,
+                 "pcm_count": 4, "n_events": B * 4}
+        pinned, outs, views = [], [], []
+        for _ in range(3):
+            o, v = ddn.P25ChainHostOut(), {}
+            for name, nb in sizes.items():
+                p = pin(nb)
+                pinned.append(p)
+                setattr(o, name, p.value)
+                v[name] = np.frombuffer((C.c_uint8 * nb).from_address(p.value), dtype=fields[name])
+            o.pcm_dense_frames = V
+            outs.append(o)
+            views.append(v)
+        h_in = [pin(B * n_call * 2) for _ in range(2)]
+        got = []
+
+        def read(k):
+            v = views[k % 3]
+            cnt = int(v["pcm_count"][0])
+            got.append({name: (a[:cnt * 160].copy() if name == "pcm_dense" else a[:cnt].copy() if name == "pcm_slot" else a.copy())
+                        for name, a in v.items()})
+            for a in v.values():
+                a[...] = 0xA5 if a.dtype == np.uint8 else 0      # a stale set must not pass for a result
+
+        for k in range(calls):
+            part = np.ascontiguousarray(iq[:, k * n_call:(k + 1) * n_call])
+            C.memmove(h_in[k & 1], part.ctypes.data, part.nbytes)     # legal: call k - 1 (the last user of k - 2's buffer) has returned
+            ch.run_host(h_in[k & 1], outs[k % 3])
+            if streaming:
+                if k >= 2:
+                    read(k - 2)
+            else:
+                ch.wait()
+                read(k)
+        if streaming:
+            ch.wait()
+            read(calls - 2)
+            read(calls - 1)
+        ch.close()
+        for p in pinned + h_in:
+            l.ddn_host_free_pinned(p)
+        return got
+
+    want, got = go(False), go(True)
+    assert len(want) == len(got) == calls
+    frames = 0
+    for k in range(calls):
+        for name in fields:
+            assert np.array_equal(want[k][name].view(np.uint8), got[k][name].view(np.uint8)), (k, name)
+        frames += int(want[k]["pcm_count"][0])
+    assert frames > 100
 
 
 @pytest.mark.parametrize("case", range(4))

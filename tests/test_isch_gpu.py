@@ -5,14 +5,14 @@ import numpy as np
 import pytest
 
 import ddn
-from test_oracle_isch import FZ, oracle_hard, oracle_soft, table, words
+from test_oracle_isch import FZ, oracle_hard, oracle_soft, table, words, words_high
 
 pytestmark = pytest.mark.gpu
 
 
 def test_isch_lookup_batch_equals_oracle(built):
     rng = np.random.default_rng(31 + FZ)
-    ws = words(rng, 20000)
+    ws = words(rng, 20000) + words_high(rng, 4000)      # incl. stray bits above the field (bit 47): counted, never indexed
     w = np.array(ws, dtype=np.uint64)
     out = np.full(len(ws), 99, np.int32)
     assert ddn.lib().ddn_fec_isch_lookup_host(w.ctypes.data, None, len(ws), out.ctypes.data) == 0

@@ -48,6 +48,23 @@ def words(rng, n):
     return out
 
 
+def words_high(rng, n):
+    """words with stray bits above the 40-bit field (bit 47 always, others at random): the reference does not mask its argument -
+    dsd_popcount64 counts those bits toward the distance, isch_weighted_mismatch_cost walks the 40 field bits only
+    (src/fec/ez.cpp:335-352) - so neither does the restatement nor the kernel, and no reliability outside the row is read"""
+    t = table()
+    out = []
+    for _ in range(n):
+        w = t[int(rng.integers(0, 128))] if rng.integers(0, 8) else 0x575D57F7FF
+        for p in rng.choice(40, size=int(rng.integers(0, 7)), replace=False):
+            w ^= 1 << int(p)
+        w |= 1 << 47
+        for p in rng.choice(np.arange(40, 64), size=int(rng.integers(0, 3)), replace=False):
+            w |= 1 << int(p)
+        out.append(w)
+    return out
+
+
 def oracle_hard(w):
     o = orc.oracle()
     o.orc_isch_lookup.argtypes = [C.c_uint64]
@@ -67,7 +84,7 @@ def test_isch_lookup_equals_compiled_reference():
     r.isch_lookup_soft.argtypes = [C.c_uint64, C.c_void_p]
     rng = np.random.default_rng(9 + FZ)
     seen = set()
-    for w in words(rng, 6000):
+    for w in words(rng, 6000) + words_high(rng, 1500):
         a, b = r.isch_lookup(w), oracle_hard(w)
         assert a == b, (hex(w), a, b)
         seen.add(a >= 0)
