@@ -124,24 +124,29 @@ def test_parity_override_ldu_still_gives_voice(built):
     src/protocol/p25/phase1/p25p1_check_nid.cpp:293-303) and is dispatched like any accepted frame (dispatch_p25p1.c:214-218:
     status > 0): Hamming / RS run AND its nine IMBE frames are synthesized"""
     rng = np.random.default_rng(77)
-    n_call, calls = 12000, 3
-    bits = mbe.random_imbe_bits(rng, (36,))
-    dib, _ = p25gen.make_ldus(rng, 4, 0x293, np.stack([mbe.imbe_encode(b) for b in bits]))
+    n_call, calls = 15000, 3
+    bits = mbe.random_imbe_bits(rng, (45,))
+    dib, _ = p25gen.make_ldus(rng, 5, 0x293, np.stack([mbe.imbe_encode(b) for b in bits]))
     dib = dib.copy()
-    for f in (1, 2):
+    for f in (2, 3):
         dib[f * 864 + 56] ^= 1            # frame dibit 56 = BCH bit 62 | parity bit
     iq = p25gen.modulate_cu8(dib, n_call * calls, lead=260, seed=5, noise=0.02)[None]
     col = _run(iq, n_call, everything=True)
     want = chain_stream.run_stream(iq[0], n_call, seed=0)
-    n_nid, _, n_voice = _check_against_oracle(col, 0, want)
+    _check_against_oracle(col, 0, want)
     st = sorted((g, int(d["nid"][0]), int(d["nid"][2])) for g, d in col.frames[0].items())
-    assert [s[1] for s in st] == [1, 2, 2, 1] and [s[2] for s in st] == [5, 10, 5, 10], st
-    assert n_nid == 4 and n_voice == 36
-    for g, status, duid in st:
+    assert len(st) == 5
+    # (the stream's very first NID is read before the slicer has settled and may fail; the flipped ones are frames 2 and 3)
+    assert [s[1] for s in st[1:]] == [1, 2, 2, 1] and [s[2] for s in st[1:]] == [10, 5, 10, 5], st
+    for g, status, duid in st[1:]:
         d = col.frames[0][g]
         assert (d["rs1s"] if duid == 5 else d["rs2s"]) == 0
-    pcm = np.stack([v[4] for v in col.voice[0]])
-    assert len(pcm) == 36 and (np.abs(pcm).sum(axis=1) > 0).all()
+    ok = {g for g, status, _ in st if status > 0}
+    voiced = [v for v in col.voice[0] if v[0] in ok]
+    assert len(voiced) == 9 * len(ok) and {v[0] for v in voiced} == ok
+    by_frame = {g: np.stack([v[4] for v in voiced if v[0] == g]) for g in ok}
+    for g, status, _ in st[1:]:
+        assert (np.abs(by_frame[g]).sum(axis=1) > 0).all(), (g, status)      # PCM for the parity-override frames too
 
 
 _BY_TYPE = {"words1": 5, "rs1": 5, "rs1s": 5, "words2": 10, "rs2": 10, "rs2s": 10, "hdu": 0, "hdus": 0, "tdulc": 15, "tdulcs": 15}
