@@ -658,6 +658,71 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
 //  * (round 2) 128-sample tiles at 8 lanes per wave (LdsW::TW): half the tile prologues and closing trips.
 constexpr int WMAX = 24;
 
+// three-operand min / max / median as single VALU instructions.  fminf / fmaxf go through the compiler's IEEE canonicalisation
+// (an extra v_max_f32 x, x, x per operand that comes from memory); on the recurrence wave every instruction is ~5 cycles of issue and
+// a dependent one ~9 (tools/ubench/chain_latency.hip), so the lean run spells its extrema bookkeeping out.  Operands are never NaN on
+// the paths that use these (a NaN channel's statistics are unspecified, tests/test_nonfinite_gpu.py).
+__device__ __forceinline__ float
+v_min2(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float
+v_max2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float
+v_min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float
+v_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float
+v_med3(float a, float b, float c) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// What a helper wave does while it has nothing to do.  A dependent chain runs up to three times slower on a SIMD whose vector unit
+// falls idle between its instructions than beside a wave that keeps it issuing (tools/ubench/lonely_wave.hip: 150 ns per step alone,
+// 56 beside a sleeping wave, 47 beside a wave that spins on VALU instructions), so the staging and handler waves - one of them shares
+// every SIMD with a recurrence wave - idle on a short burst of register-only VALU instructions at the lowest priority instead of
+// s_sleep.  cfg.dbg bit 8388608 restores the sleep for A/B timing.
+__device__ __forceinline__ void
+helper_idle(float& spin, bool sleep_instead, int sleep_arg) {
+    if (sleep_instead) {
+        if (sleep_arg >= 4) {
+            __builtin_amdgcn_s_sleep(4);
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        asm volatile("v_max_f32 %0, %0, %0" : "+v"(spin));
+    }
+}
+// x / 5.0f, correctly rounded, in three instructions: q = RN(x * RN(1/5)), r = x - 5 q (exact in the fma), q + r * RN(1/5).  Equal to
+// the IEEE quotient for every finite binary32 x except -0 (checked exhaustively on the host, tests/test_oracle_rx_kat.py holds the
+// sampled form); the callers' sums start from +0 and can never be -0.
+__device__ __forceinline__ float
+div5_exact(float x) {
+    const float y = 0.2f;
+    const float q = x * y;
+    const float r = __builtin_fmaf(-5.0f, q, x);
+    return __builtin_fmaf(r, y, q);
+}
+
 
 // 1: per-wave cycle counters (tile body / barrier wait / trips by kind) written over the tail of each workgroup's first
 // record area when cfg.dbg bit 8192 is set - timing experiments only (tools/bench_rx_handlers.py with DDN_RX_DBG=8192 and a library built with EXTRA=-DDDN_RX_CYCLES=1)
@@ -673,8 +738,8 @@ struct LdsW {
     static constexpr int TW = CPW <= 8 ? 128 : 64, RTW = 3 * TW;
     // suffix summaries per checkpoint: pushes per two tiles, 2 * (ceil((TW + sps) / (sps - 1)) + 1).  SMALL (handler mode, which
     // needs the LDS for its history ring): sized for at least 9 samples per symbol
-    static constexpr int WMW = CPW <= 8 ? (SMALL ? 40 : 64) : (SMALL ? 24 : 32);
-    static constexpr int QTW = CPW <= 8 ? 40 : 20; // queue slots = trips of a tile that can hand a symbol to wave 1
+    static constexpr int WMW = TW == 128 ? (SMALL ? 40 : 64) : (SMALL ? 24 : 32);
+    static constexpr int QTW = TW == 128 ? 40 : 20; // queue slots = trips of a tile that can hand a symbol to wave 1
     float sb[SS][CPW];
     float lb[24][CPW];
     float sh[24][CPW];
@@ -702,6 +767,7 @@ struct LdsH {
     int hwid[4];      // HW_ID of the workgroup's waves (role placement)
     int ready[2];     // per recurrence wave: tiles the staging wave has made enterable for its channels (staged + window
                       // summaries of the checkpoint before)
+    float hh_dummy[CPW][4]; // where the lean run's history store goes for a lane whose phase does not end in a decision
     ddn_p25h::Scratch sc;
 };
 
@@ -1031,6 +1097,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     };
 
         int it = 0;
+        float idle_spin = 0.0f;
         for (long t0 = 0; t0 < n; t0 += TW, it++) {
             // serve requests until the recurrence wave has left this tile (it never leaves one with a request open)
             while (true) {
@@ -1041,7 +1108,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         && __hip_atomic_load(&H.tile_done[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it) {
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(4);
+                    helper_idle(idle_spin, (cfg.dbg & 8388608) != 0, 4);
                     continue;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1101,8 +1168,13 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     } else {
         s = DdnRxState{};
     }
+    // a bound on the magnitude of every value in the 128-symbol window (kept as a running maximum: the lean run's entry test)
+    float wabs = 0.0f;
     if (live) {
         L.sidx0[0][ln] = s.sidx;
+        for (int k = 0; k < SS; k++) {
+            wabs = fmaxf(wabs, fabsf(L.sb[k][ln]));
+        }
     }
     auto stage = [&](long t0, int slot) {
         const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
@@ -1135,6 +1207,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     };
     if (loader && n > 0) {
         stage(0, 0);
+    }
+    if (loader) { // every queue slot starts as "nothing handed over" (and returns to that when drained)
+        for (int k = lane; k < 2 * QTW * CPW; k += 64) {
+            (&L.q[0][0][0][0])[4 * k + 3] = __int_as_float(-1);
+        }
     }
     __syncthreads();
     const int whole0 = cfg.out_rate / cfg.sym_rate, rem0 = cfg.out_rate % cfg.sym_rate;
@@ -1226,6 +1303,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             if (fw < 0) {
                 continue; // this lane handed nothing over in that trip
             }
+            L.q[qb][k][dc][3] = __int_as_float(-1); // slots read "nothing" until written again: a lean run only writes its own lanes'
             const float sym = e.x;
             const int fl = fw & 0xFF;
             int dibit, relb = 0, l0 = 0, l1 = 0;
@@ -1368,6 +1446,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             if (fw < 0) {
                 continue; // this lane handed nothing over in that trip
             }
+            L.q[qb][k][dc][3] = __int_as_float(-1); // slots read "nothing" until written again: a lean run only writes its own lanes'
             const float sym = e.x;
             const int fl = fw & 0xFF;
             int dibit, relb = 0, l0 = 0, l1 = 0;
@@ -1397,6 +1476,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         two_min_insert(sym, pc1, pc2);
         two_max_insert(sym, pc3, pc4);
         npc++;
+        wabs = fmaxf(wabs, fabsf(sym));
         if (global) {
             int m = npp + npc; // ring entries replaced since the checkpoint
             m = m > WMW ? WMW : m;
@@ -1704,12 +1784,14 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     long long dbg_busy = 0, dbg_wait = 0, dbg_cyc[3] = {0, 0, 0}, dbg_prev = 0, dbg_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_st = 0;
 #define DBG_SEC(k) do { if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { const long long n_ = (long long)clock64(); dbg_sec[k] += n_ - dbg_st; dbg_st = n_; } } while (0)
     int dbg_n[3] = {0, 0, 0}, dbg_kind = -1;
+    long long dbg_run[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // lean runs: count, trips, -, -, -, runs polling a mailbox, cycles inside the run, phases
     if (HM && loader) {
         // Handler mode, staging wave: job j of recurrence wave h's channels (stage tile j + 1, drain tile j - 1's queue, the
         // window summaries of checkpoint j) falls due when that wave has finished tile j - 1, and lets it into tile j + 1; job
         // n_tiles is the last tile's drain.  Whichever half is due is served.
         const int n_tiles = (int)((n + TW - 1) / TW);
         int job[2] = {0, 0};
+        float idle_spin = 0.0f;
         while (job[0] <= n_tiles || job[1] <= n_tiles) {
             bool served = false;
 #pragma unroll
@@ -1745,7 +1827,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
             if (!served) {
                 const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
-                __builtin_amdgcn_s_sleep(1);
+                helper_idle(idle_spin, (cfg.dbg & 8388608) != 0, 1);
                 if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
                     dbg_wait += (long long)clock64() - w0;
                 }
@@ -1815,9 +1897,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             bool gblocked = false; // generic path: this lane's symbol waits for the next tile
             // lean trip operands fetched one trip ahead: the five window samples of this lane's next symbol and the suffix
             // summary its window push will ask for (valid only from one lean trip to the next inside a tile)
-            bool pf_ok = false;
-            float px0 = 0.0f, px1 = 0.0f, px2 = 0.0f, px3 = 0.0f, px4 = 0.0f;
-            float4 psf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             bool respin = false; // handler mode: the last pass only waited for an answer (no trip was spent)
             int blk_o = -1;      // bulk hunting pass: output index at which it left this lane's next symbol to the standard trip
             while (true) {
@@ -1999,6 +2078,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 two_max_insert(b1, pc3, pc4);
                                 two_max_insert(b2, pc3, pc4);
                                 npc += m;
+                                wabs = fmaxf(wabs, fmaxf(fabsf(a1), fabsf(b1))); // the pass's smallest and largest symbol
                                 s.shead = (s.shead + m) % 24;
                                 s.scount = s.scount + m < 24 ? s.scount + m : 24;
                                 s.lidx = (s.lidx + m) % 24;
@@ -2067,119 +2147,176 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 bool all_lean_wait = false;
                 if (lean_ok && tk <= QTW) {
                     // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
-                    const bool lean_state = alive & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
-                                            & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0))) & (s.min < s.max);
+                    bool lean_state = alive & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
+                                      & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0))) & (s.min < s.max)
+                                      & (s.since_fill < MS) & (npp + npc < WMW);
+                    if (__any(lean_state)) {
+                        // A lean run clips with the median of three and never looks at min < max again, so a lane only enters one when
+                        // that order provably holds to the run's end (QTW trips at most).  With D = max_sum - min_sum, G = the rings'
+                        // fill gap (every ring slot a run replaces still holds the fill value: since_fill < MS), A = the larger sum's
+                        // magnitude and S a bound on every window value, threshold and fill value: a push changes D by (hi - lo) - G
+                        // >= -max(G, 0) and the sums by at most 6 S, so D stays above D - 40 max(G, 0) and max / 1024 and min / 1024
+                        // round to different binary32 values while that exceeds 2^-22 of the sums.  (Real traffic: D ~ 4e7, the
+                        // right side ~ 50.)  Anything else takes the standard trip, which tests min < max symbol by symbol.
+                        const double d0 = s.max_sum - s.min_sum;
+                        const double gap = fill_max_d - fill_min_d;
+                        const double gp = __builtin_fmax(gap, 0.0);
+                        const double am = __builtin_fmax(__builtin_fabs(s.max_sum), __builtin_fabs(s.min_sum));
+                        const float sf = fmaxf(fmaxf(wabs, fmaxf(fabsf(s.min), fabsf(s.max))), fmaxf(fabsf(s.fill_min), fabsf(s.fill_max)));
+                        lean_state &= (d0 - 40.0 * gp) > (am * 0x1p-19 + (double)sf * 0x1p-12);
+                    }
                     const bool lean = lean_state & (sp + whole <= tn);
                     const bool lean_wait = lean_state & !(sp + whole <= tn) & more;
                     const bool all_lean = !__any(alive & !(lean | lean_wait | hunt_wait));
                     if (all_lean && __any(lean)) {
                         dbg_kind = 2;
                         const int k0 = (whole - 1) / 2 - 2;
-                        if (__any(lean & !pf_ok)) { // first lean trip of a run: nothing was fetched ahead
-                            if (lean & !pf_ok) {
-                                const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
-                                px0 = pw[0], px1 = pw[1], px2 = pw[2], px3 = pw[3], px4 = pw[4];
-                                int m = npp + npc + 1;
-                                m = m > WMW ? WMW : m;
-                                psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
+                        // A lean run: K trips back to back, K known before the first one - the fewest symbols any lean lane still has
+                        // in this tile, in its lock, before a ring index wraps (window 128, extrema 1024, history HN), before the
+                        // extrema rings' fill runs out or the queue is full.  Nothing inside the run depends on a lane's data any more
+                        // (no test, no select): a scalar trip counter, straight-line trips, the state words that only count brought
+                        // up to date once at the end.  The lanes that wait for the next tile, or sit out for a handler, are masked
+                        // off for the whole run.  (Tried and dropped: going on in phases with the lanes that have symbols left, and
+                        // polling a waiting lane's mailbox once per trip instead of capping the run - 1.5 runs per tile instead of
+                        // 2.7, the same kernel time, 30 more registers.)
+                        int kl = 0x7fffffff;
+                        const bool hp = HM && (s.hphase != 0);
+                        if (lean) {
+                            kl = ((tn - sp) * (65536 / whole + 1)) >> 16; // == (tn - sp) / whole for these small numbers
+                            kl = min(kl, s.lock_left - 1);
+                            kl = min(kl, MS - s.since_fill);
+                            kl = min(kl, WMW - (npp + npc));
+                            kl = min(kl, SS - s.sidx);
+                            kl = min(kl, MS - s.midx);
+                            kl = hp ? min(kl, ddn_p25h::HN - s.hw) : kl;
+                        }
+                        int K = 0x7fffffff;
+                        {
+                            const unsigned long long lm = __ballot(lean);
+                            for (int c = 0; c < LPR; c++) {
+                                if ((lm >> c) & 1) {
+                                    K = min(K, __builtin_amdgcn_readlane(kl, c));
+                                }
                             }
                         }
-                        // A lean run: as long as the same lanes stay lean (or have moved on to waiting for the next tile) the wave
-                        // goes from one lean trip straight into the next - what can end the run is known from the trip itself (the
-                        // lock running out, a symbol that no longer fits, a handler's answer arriving for a lane that sat out), so
-                        // none of the trip loop's other tests are on the instruction stream between two lean trips.
-                        bool lz = lean, did = false, now_waits = false;
-                        while (true) {
-                            int rs = -1;
-                            if (HM && hwait) {
-                                rs = __hip_atomic_load(&H.rsp_seq[ln], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        K = min(K, QTW - tk + 1);
+                        if (HM && __any(hwait)) { // an answer may arrive: look again soon
+                            K = min(K, 2);
+                        }
+                        if (cfg.dbg & 2097152) {
+                            K = 1;
+                        }
+                        K = __builtin_amdgcn_readfirstlane(K); // (tk is uniform, but not provably so: keep the counter scalar)
+                        long long dbg_l0 = 0;
+                        if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                            dbg_run[0]++;
+                            dbg_run[1] += K;
+                            dbg_run[5] += (HM && __any(hwait)) ? 1 : 0;
+                            dbg_run[7]++;
+                            dbg_l0 = (long long)clock64();
+                        }
+                        if (lean) {
+                            const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
+                            const float4* psp = reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][npp + npc][ln][0]);
+                            float* sbp = &L.sb[s.sidx][ln];
+                            float4* qp = reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]);
+                            float* hhp = &L.sb[0][ln];
+                            int hstep = 0;
+                            if (HM) {
+                                hhp = hp ? &H.hh[s.hw][ln][0] : &H.hh_dummy[ln][0];
+                                hstep = hp ? CPW * 3 : 0;
                             }
-                            if (lz) {
+                            uint32_t rof = ro;
+                            float mn = s.min, mx = s.max;
+                            double smin = s.min_sum, smax = s.max_sum;
+                            float x0 = pw[0], x1 = pw[1], x2 = pw[2], x3 = pw[3], x4 = pw[4];
+                            float4 sf4 = *psp;
+                            float sym = 0.0f;
+                            int fw = (1 | (s.lastsync == 2 ? 4 : 0)) | ((o - o_tile) << 8);
+                            for (int j = 0; j < K; j++) {
                                 // min < max and finite samples: the reference's two-sided clip is the median of three (a zero's sign
                                 // may differ, which a sum that starts at +0 cannot show)
                                 float acc = 0.0f;
-                                acc += __builtin_amdgcn_fmed3f(px0, s.min, s.max);
-                                acc += __builtin_amdgcn_fmed3f(px1, s.min, s.max);
-                                acc += __builtin_amdgcn_fmed3f(px2, s.min, s.max);
-                                acc += __builtin_amdgcn_fmed3f(px3, s.min, s.max);
-                                acc += __builtin_amdgcn_fmed3f(px4, s.min, s.max);
-                                const float sym = acc / 5.0f;
-                                sp += whole;
-                                s.in_symbol = 0;
-                                did = true;
-                                // window push (see window_push) with the prefetched suffix summary
-                                L.sb[s.sidx][ln] = sym;
-                                two_min_insert(sym, pc1, pc2);
-                                two_max_insert(sym, pc3, pc4);
-                                npc++;
-                                const float t1 = fminf(psf.x, pp1), t2 = fminf(fmaxf(psf.x, pp1), fminf(psf.y, pp2));
-                                const float m1 = fminf(t1, pc1), m2 = fminf(fmaxf(t1, pc1), fminf(t2, pc2));
-                                const float u1 = fmaxf(psf.z, pp3), u2 = fmaxf(fminf(psf.z, pp3), fmaxf(psf.w, pp4));
-                                const float x1 = fmaxf(u1, pc3), x2 = fmaxf(fminf(u1, pc3), fmaxf(u2, pc4));
-                                const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
-                                double old_lo = fill_min_d, old_hi = fill_max_d;
-                                if (s.since_fill >= MS) {
-                                    old_lo = (double)ring_at(minring, ro);
-                                    old_hi = (double)ring_at(maxring, ro);
-                                } else {
-                                    s.since_fill++;
+                                acc += v_med3(x0, mn, mx);
+                                acc += v_med3(x1, mn, mx);
+                                acc += v_med3(x2, mn, mx);
+                                acc += v_med3(x3, mn, mx);
+                                acc += v_med3(x4, mn, mx);
+                                sym = div5_exact(acc);
+                                // the window summaries that do not depend on this symbol: suffix summary + the previous tile's pushes
+                                const float t1 = v_min2(sf4.x, pp1), t2 = v_min3(v_max2(sf4.x, pp1), sf4.y, pp2);
+                                const float u1 = v_max2(sf4.z, pp3), u2 = v_max3(v_min2(sf4.z, pp3), sf4.w, pp4);
+                                // the next trip's operands (a run's last trip fetches past what it may use: inside the arrays, unread)
+                                pw += whole;
+                                psp += CPW;
+                                x0 = pw[0], x1 = pw[1], x2 = pw[2], x3 = pw[3], x4 = pw[4];
+                                sf4 = *psp;
+                                *sbp = sym;
+                                sbp += CPW;
+                                // this tile's pushes + the symbol (two smallest / two largest of a sorted pair and one value)
+                                const float n2 = v_med3(pc1, pc2, sym), n4 = v_med3(pc3, pc4, sym);
+                                pc1 = v_min2(pc1, sym);
+                                pc3 = v_max2(pc3, sym);
+                                pc2 = n2;
+                                pc4 = n4;
+                                const float m1 = v_min2(t1, pc1), m2 = v_min3(v_max2(t1, pc1), t2, pc2);
+                                const float w1 = v_max2(u1, pc3), w2 = v_max3(v_min2(u1, pc3), u2, pc4);
+                                const float lo = (m1 + m2) * 0.5f, hi = (w1 + w2) * 0.5f;
+                                ring_at(minring, rof) = lo;
+                                ring_at(maxring, rof) = hi;
+                                rof += ro_step;
+                                smin += (double)lo - fill_min_d; // every slot a run replaces still holds the fill value
+                                smax += (double)hi - fill_max_d;
+                                mn = (float)(smin / (double)MS);
+                                mx = (float)(smax / (double)MS);
+                                *qp = make_float4(sym, mx, mn, __int_as_float(fw));
+                                qp += CPW;
+                                fw += 256;
+                                if (HM) {
+                                    hhp[0] = sym;
+                                    hhp[1] = mx;
+                                    hhp[2] = mn;
+                                    hhp += hstep;
                                 }
-                                s.min_sum += (double)lo - old_lo;
-                                s.max_sum += (double)hi - old_hi;
-                                ring_at(minring, ro) = lo;
-                                ring_at(maxring, ro) = hi;
-                                ro += ro_step;
-                                if (++s.midx >= MS) {
-                                    s.midx = 0;
-                                    ro = ro_first;
-                                }
-                                s.min = (float)(s.min_sum / (double)MS);
-                                s.max = (float)(s.max_sum / (double)MS);
-                                s.sidx = (s.sidx >= SS - 1) ? 0 : s.sidx + 1;
-                                s.lock_left--;
-                                qv = make_float4(sym, s.max, s.min, __int_as_float((1 | (s.lastsync == 2 ? 4 : 0)) | ((o - o_tile) << 8)));
-                                hist_push(sym, s.max, s.min, 1 | (s.lastsync == 2 ? 4 : 0));
-                                o++;
                             }
-                            // operands of the next lean trip, if this lane's next symbol is staged in this tile too
-                            pf_ok = lz & (sp + whole <= tn);
-                            if (pf_ok) {
-                                const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;
-                                px0 = pw[0], px1 = pw[1], px2 = pw[2], px3 = pw[3], px4 = pw[4];
-                                int m = npp + npc + 1;
-                                m = m > WMW ? WMW : m;
-                                psf = *reinterpret_cast<const float4*>(&L.sfx[sbuf_sel][m - 1][ln][0]);
+                            // the words that only count
+                            sp += K * whole;
+                            s.in_symbol = 0;
+                            npc += K;
+                            s.since_fill += K;
+                            s.sidx = (s.sidx + K) & (SS - 1);
+                            s.midx += K;
+                            ro = rof;
+                            if (s.midx >= MS) {
+                                s.midx = 0;
+                                ro = ro_first;
                             }
-                            // straight into another lean trip?  (the lanes that were waiting for the next tile still are)
-                            const bool st = lz & (s.lock_left > 1) & (s.min < s.max);
-                            const bool nl = st & pf_ok;
-                            const bool nw = st & !pf_ok & more;
-                            now_waits = nw;
-                            if (__any(lz & !(nl | nw)) || !__any(nl) || tk >= QTW || (cfg.dbg & 2097152)
-                                || (HM && __any(hwait & (rs == hseq)))) {
-                                break;
+                            s.lock_left -= K;
+                            o += K;
+                            if (hp) {
+                                s.hw = (s.hw + K >= ddn_p25h::HN) ? 0 : s.hw + K;
                             }
-                            if (lane < LPR) { // this trip's symbols to wave 1, the next trip's slot opened (as at the trip loop's top)
-                                *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
-                            }
-                            qv.w = __int_as_float(-1);
-                            tk++;
-                            if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
-                                const long long now = (long long)clock64();
-                                dbg_cyc[2] += now - dbg_prev;
-                                dbg_n[2]++;
-                                dbg_prev = now;
-                            }
-                            lz = nl;
-                        }
-                        if (did) { // the thresholds that follow max / min: nothing inside a lean run reads them
+                            s.min_sum = smin;
+                            s.max_sum = smax;
+                            s.min = mn;
+                            s.max = mx;
+                            wabs = fmaxf(wabs, fmaxf(fabsf(pc1), fabsf(pc3)));
+                            // the thresholds that follow max / min: nothing inside a lean run reads them
                             s.center = (s.max + s.min) / 2.0f;
                             s.maxref = s.max * 0.80f;
                             s.minref = s.min * 0.80f;
+                            qv = make_float4(sym, mx, mn, __int_as_float(fw - 256)); // the run's last entry, as the trip loop's top hands it over
+                        }
+                        tk += K - 1;
+                        if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                            dbg_n[2] += K - 1;
+                            dbg_run[6] += (long long)clock64() - dbg_l0;
                         }
                         // every lane of the run now waits for the next tile (the others already did) and no lane sits out for a
                         // handler: the tile is over - its last trip handed over as the trip loop's top would, no empty pass
-                        if (!__any(lz & !now_waits) && !(HM && __any(hwait)) && !(cfg.dbg & 4194304)) {
+                        const bool st = lean & (s.lock_left > 1) & (s.min < s.max);
+                        const bool now_waits = st & !(sp + whole <= tn) & more;
+                        if (!__any(lean & !now_waits) && !(HM && __any(hwait)) && !(cfg.dbg & 4194304)) {
                             if (tk <= QTW && lane < LPR) {
                                 *reinterpret_cast<float4*>(&L.q[itq][tk - 1][ln][0]) = qv;
                             }
@@ -2191,7 +2328,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     }
                     all_lean_wait = all_lean; // nobody can go on and nobody needs another kind of trip: the tile is over
                 }
-                pf_ok = false;
                 bool all_std_wait = all_lean_wait;
                 if (std_ok && !all_lean_wait) {
                     // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
@@ -2602,10 +2738,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         for (int k = 0; k < 64; k++) {
             d[k] = reinterpret_cast<const uint8_t*>(v)[k];
         }
-        if (wave == 0) { // the recurrence wave's standard-trip sections, one block further down
+        if (wave == 0) { // the recurrence wave's standard-trip sections, one block further down; its lean-run figures, another one
             uint8_t* d2 = rec + ((size_t)ch0 + 1) * max_sym * 10 - 256;
             for (int k = 0; k < 64; k++) {
                 d2[k] = reinterpret_cast<const uint8_t*>(dbg_sec)[k];
+                d2[k - 64] = reinterpret_cast<const uint8_t*>(dbg_run)[k];
             }
         }
     }

@@ -92,5 +92,8 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
         extra += "\n   std trip sections (cycles per trip): top %.0f search %.0f mean %.0f inframe %.0f hunt %.0f emit %.0f" % tuple(
             sec[:, k].sum() / nstd for k in range(6))
         extra += "\n   bulk hunting passes: %.2f per tile at %.0f cycles" % (sec[:, 7].sum() / (len(sec) * tiles), sec[:, 6].sum() / max(1, sec[:, 7].sum()))
+        run = np.stack([r[c, -320:-256] for c in range(0, B, cpw)]).copy().view(np.int64).sum(axis=0)
+        extra += "\n   lean runs: %.2f per tile, %.2f trips and %.2f phases each (%.2f of them polling a handler mailbox), %.0f cycles inside the run per trip" % (
+            run[0] / (len(sec) * tiles), run[1] / max(1, run[0]), run[7] / max(1, run[0]), run[5] / max(1, run[0]), run[6] / max(1, run[1]))
     print("%-8s cpw %2d: loop %.3f ms (mf %.3f) in-frame share %.3f syncs/ch %.1f%s" % (
         mode, cpw, t[1], t[0], (flc & 1).mean() * ms / (n / 10), (flc & 2).sum() / B, extra), flush=True)
