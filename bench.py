@@ -2,7 +2,9 @@
 """bench.py - BASELINE.json's metric on its end-to-end configuration.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: launched by torch.distributed.run, one rank per GPU)
+    N > 1: one rank per GPU over RCCL.  Started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment) it is one of the ranks; started from a plain shell it launches the N ranks itself (torch.distributed.run on
+    127.0.0.1, a free port) and passes rank 0's JSON line through.  Fewer than N visible devices: one line on stderr, exit 2.
 
 metric  "I/Q Msamples/s end-to-end (demod->FEC->MBE) per GPU; % HBM roofline"
 step    BASELINE configs[2] with the vocoder on: B = 4096 P25 Phase 1 channels per GPU x n = 48000 complex cu8 samples (1 s
@@ -268,6 +270,74 @@ def front_end_stage(torch, ddn, chain, d_iq, B, n, steps):
                          "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": 6.0}}
 
 
+def self_launch(args, argv):
+    """--gpus N from a plain shell: start the N ranks (one per GPU) and hand their output through"""
+    import socket
+    import subprocess
+    if args.dry_run_cpu:
+        have = args.gpus
+    else:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node - nothing run\n" % (args.gpus, have))
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run_cpu(args, rank, world, voice, ctrl):
+    """TEST MODE (tests/test_bench_launch.py), never a measurement: the launch, sharding, timing and reporting logic of this file with
+    gloo between the ranks and the CPU oracle as each rank's compute - what can be checked of the N > 1 path without N GPUs.  The
+    line it prints says so ("dry_run_cpu": true, "data": "synthetic, CPU oracle - not a measurement")."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import chain_stream
+    import ddn_shard
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n = args.samples
+    desc = ddn_shard.broadcast_descriptor({"B_total": args.channels * world, "n": n, "blk": BLOCK} if rank == 0 else None)
+    ch_first, B = ddn_shard.channel_range(rank, world, desc["B_total"])
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n_sym = n_frames = 0
+    for _ in range(args.steps):
+        for c in range(B):
+            kind, bi = channel_source(ch_first + c)
+            got = chain_stream.run_stream((voice if kind == "voice" else ctrl)[bi], n, seed=ch_first + c, vocoder=False)
+            n_sym += len(got["sym"])
+            n_frames += len(got["frames"])
+    if world > 1:
+        dist.barrier()
+    dt = ddn_shard.reduce_max_seconds(time.perf_counter() - t0, torch.device("cpu"))
+    counts = torch.tensor([B, n_sym, n_frames], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(counts)
+    if rank == 0:
+        print(json.dumps({"metric": "I/Q Msamples/s end-to-end (demod->FEC->MBE) per GPU; % HBM roofline", "dry_run_cpu": True,
+                          "value": round(float(counts[0]) * n * args.steps / dt / 1e6, 4), "unit": "Msamples/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic, CPU oracle - not a measurement",
+                          "config": {"workload": "launch / sharding self-test", "channels_per_gpu": args.channels,
+                                     "channels_total": int(counts[0]), "samples_per_channel": n, "parallelism": "channel-sharded x%d" % world},
+                          "work": {"symbols": int(counts[1]), "syncs": int(counts[2])}}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,17 +349,24 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the stage breakdown / PCIe / front-end sub-objects")
     ap.add_argument("--no-pipeline", action="store_true", help="run every stage of a step on one stream (no overlap of the frame "
                     "FEC / vocoder stages of step k with the front end / receive loop of step k + 1)")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="test mode, never a measurement: gloo between the ranks and the CPU "
+                    "oracle as compute (the launch / sharding / reporting logic without GPUs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import numpy as np
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d" % (args.gpus, world))
     n = args.samples
     voice, ctrl = make_base_traffic(n)
+    if args.dry_run_cpu:
+        raise SystemExit(dry_run_cpu(args, rank, world, voice, ctrl))
 
     # the CPU leg runs first: its worker pool forks, which must happen before this process holds a HIP context
     cpu = None
