@@ -422,7 +422,7 @@ class P25ChainConfig(C.Structure):  # == ddn_p25_chain_config (include/ddn_chain
 class P25ChainResults(C.Structure):  # == ddn_p25_chain_results
     _fields_ = [("stride_symbols", C.c_size_t), ("d_records10", C.c_void_p), ("d_flags", C.c_void_p), ("d_counts", C.c_void_p),
                 ("d_new", C.c_void_p), ("d_events", C.c_void_p), ("d_n_events", C.c_void_p), ("d_event_data", C.c_void_p),
-                ("d_n_syncs", C.c_void_p),
+                ("d_n_syncs", C.c_void_p), ("d_dropped_syncs", C.c_void_p),
                 ("d_sync_pos", C.c_void_p), ("d_nid4", C.c_void_p), ("d_tsbk", C.c_void_p), ("d_tsbk_crc", C.c_void_p),
                 ("d_ldu_words", C.c_void_p * 2), ("d_ldu_rs_data", C.c_void_p * 2), ("d_ldu_rs_status", C.c_void_p * 2),
                 ("d_lsd_bits", C.c_void_p), ("d_lsd_ok", C.c_void_p), ("d_hdu_rs_data", C.c_void_p), ("d_hdu_rs_status", C.c_void_p),
@@ -442,6 +442,7 @@ PROTOTYPES.update({
     "ddn_mbe_tables_load_file": (C.c_int, [C.c_char_p, C.c_void_p]),
     "ddn_mbe_batch_load_tables_file": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ddn_mbe_batch_tables_synthetic": (C.c_int, [C.c_void_p]),
+    "ddn_p25p1_framer_device_dropped": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_chain_destroy": (None, [C.c_void_p]),
     "ddn_p25_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -74,6 +74,8 @@ struct ddn_p25_chain {
     size_t iq_bytes;
     long step;
     int last_set;
+    hipStream_t user_stream; // the caller's stream of the last _run / _stage call (flush and wait order themselves behind it)
+    int have_user_stream;
     // stage timing (ddn_p25_chain_set_timing): events at the stage boundaries of the most recent call
     int timing;
     hipEvent_t ev_t[6];
@@ -404,6 +406,8 @@ ddn_p25_chain_run(ddn_p25_chain* c, const void* d_iq, void* hip_stream) {
         return DDN_EINVAL;
     }
     hipStream_t st = (hipStream_t)hip_stream;
+    c->user_stream = st;
+    c->have_user_stream = 1;
     const int cur = (int)(c->step & 1);
     DDN_TRY(chain_receive(c, d_iq, cur, st));
     DDN_TRY(chain_decode(c, cur, 0, st));
@@ -419,6 +423,8 @@ ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip_str
         return DDN_EINVAL;
     }
     hipStream_t st = (hipStream_t)hip_stream;
+    c->user_stream = st;
+    c->have_user_stream = 1;
     const int cur = (int)(c->step & 1);
     if (stage == 0) {
         return chain_front(c, d_iq, cur, st);
@@ -585,6 +591,9 @@ ddn_p25_chain_wait(ddn_p25_chain* c) {
     if (!c) {
         return DDN_EINVAL;
     }
+    if (c->have_user_stream) {
+        HIP_TRY(hipStreamSynchronize(c->user_stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->s_main));
     HIP_TRY(hipStreamSynchronize(c->s_aux));
     HIP_TRY(hipStreamSynchronize(c->s_copy));
@@ -608,6 +617,7 @@ ddn_p25_chain_get_results(ddn_p25_chain* c, ddn_p25_chain_results* r) {
     r->d_n_events = c->d_nev[cur];
     r->d_event_data = c->d_evd[cur];
     DDN_TRY(ddn_p25p1_framer_device_syncs(c->fr, &r->d_n_syncs, &r->d_sync_pos));
+    DDN_TRY(ddn_p25p1_framer_device_dropped(c->fr, &r->d_dropped_syncs));
     r->d_nid4 = c->d_nid;
     r->d_tsbk = c->d_tsbk;
     r->d_tsbk_crc = c->d_tsbk_crc;

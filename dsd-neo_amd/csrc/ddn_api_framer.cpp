@@ -26,6 +26,7 @@ struct ddn_p25p1_framer {
     int n_channels, max_frames;
     int32_t* d_sync_pos; // [B][F]
     int32_t* d_n_syncs;  // [B]
+    int32_t* d_dropped;  // [B] running count of syncs that found no frame slot
     int32_t* d_tab[T_COUNT];
     int n_off[T_COUNT], max_off[T_COUNT];
     int32_t *d_first9, *d_status9;
@@ -72,6 +73,8 @@ ddn_p25p1_framer_create(int n_channels, int max_frames_per_channel, ddn_p25p1_fr
     bool ok = hipMalloc(&f->d_sync_pos, sizeof(int32_t) * slots) == hipSuccess
               && hipMalloc(&f->d_n_syncs, sizeof(int32_t) * (size_t)n_channels) == hipSuccess
               && hipMemset(f->d_n_syncs, 0, sizeof(int32_t) * (size_t)n_channels) == hipSuccess
+              && hipMalloc(&f->d_dropped, sizeof(int32_t) * (size_t)n_channels) == hipSuccess
+              && hipMemset(f->d_dropped, 0, sizeof(int32_t) * (size_t)n_channels) == hipSuccess
               && hipMalloc(&f->d_first9, sizeof(first9)) == hipSuccess
               && hipMalloc(&f->d_status9, sizeof(status9)) == hipSuccess
               && hipMemcpy(f->d_first9, first9, sizeof(first9), hipMemcpyHostToDevice) == hipSuccess
@@ -100,6 +103,7 @@ ddn_p25p1_framer_destroy(ddn_p25p1_framer* f) {
     }
     (void)hipFree(f->d_sync_pos);
     (void)hipFree(f->d_n_syncs);
+    (void)hipFree(f->d_dropped);
     (void)hipFree(f->d_first9);
     (void)hipFree(f->d_status9);
     for (int t = 0; t < T_COUNT; t++) {
@@ -116,7 +120,7 @@ ddn_p25p1_framer_index(ddn_p25p1_framer* f, const uint8_t* d_flags, const int32_
         return DDN_EINVAL;
     }
     HIP_TRY(ddn_dev_find_syncs(d_flags, d_counts, f->n_channels, max_symbols, f->max_frames, f->d_sync_pos,
-                               f->d_n_syncs, (hipStream_t)hip_stream));
+                               f->d_n_syncs, f->d_dropped, (hipStream_t)hip_stream));
     return DDN_OK;
 }
 
@@ -128,6 +132,17 @@ ddn_p25p1_framer_device_syncs(ddn_p25p1_framer* f, const int32_t** d_n_syncs, co
     }
     *d_n_syncs = f->d_n_syncs;
     *d_sync_pos = f->d_sync_pos;
+    return DDN_OK;
+}
+
+// [B] running count (since the object was created) of accepted syncs that found no frame slot in their call: 0 unless
+// max_frames_per_channel is too small for the traffic
+extern "C" int
+ddn_p25p1_framer_device_dropped(ddn_p25p1_framer* f, const int32_t** d_dropped) {
+    if (!f || !d_dropped) {
+        return DDN_EINVAL;
+    }
+    *d_dropped = f->d_dropped;
     return DDN_OK;
 }
 

@@ -227,7 +227,7 @@ hipError_t ddn_dev_iq_cond_disc(const void* in, long n, size_t stride, int block
                                 const DdnIqCondConfig* cfg, DdnFskState* fsk, DdnIqCondState* cond, float* out,
                                 size_t out_stride, hipStream_t st);
 hipError_t ddn_dev_find_syncs(const uint8_t* flags, const int32_t* counts, int n_channels, size_t max_sym, int max_frames,
-                              int32_t* sync_pos, int32_t* n_syncs, hipStream_t st);
+                              int32_t* sync_pos, int32_t* n_syncs, int32_t* dropped, hipStream_t st);
 hipError_t ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32_t* counts, const int32_t* sync_pos,
                                  const int32_t* n_syncs, int n_channels, int max_frames, const int32_t* offsets, int n_off,
                                  int max_off, uint8_t* bits, uint8_t* rel, int16_t* llr, int stride, int split_last,

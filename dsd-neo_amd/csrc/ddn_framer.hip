@@ -19,7 +19,7 @@
 namespace {
 __global__ __launch_bounds__(64) void
 k_find_syncs(const uint8_t* __restrict__ flags, const int32_t* __restrict__ counts, size_t max_sym, int max_frames,
-             int32_t* __restrict__ sync_pos, int32_t* __restrict__ n_syncs) {
+             int32_t* __restrict__ sync_pos, int32_t* __restrict__ n_syncs, int32_t* __restrict__ dropped) {
     const int ch = blockIdx.x;
     const int lane = threadIdx.x;
     const int cnt = counts[ch] < (int)max_sym ? counts[ch] : (int)max_sym; // the rx loop counts symbols it could not store
@@ -39,6 +39,9 @@ k_find_syncs(const uint8_t* __restrict__ flags, const int32_t* __restrict__ coun
     }
     if (lane == 0) {
         n_syncs[ch] = found < max_frames ? found : max_frames;
+        if (dropped && found > max_frames) { // syncs that found no frame slot in this call: counted, never silently lost
+            dropped[ch] += found - max_frames;
+        }
     }
 }
 
@@ -118,12 +121,12 @@ k_gather_fields(const uint8_t* __restrict__ rec, size_t max_sym, const int32_t* 
 
 extern "C" hipError_t
 ddn_dev_find_syncs(const uint8_t* flags, const int32_t* counts, int n_channels, size_t max_sym, int max_frames,
-                   int32_t* sync_pos, int32_t* n_syncs, hipStream_t st) {
+                   int32_t* sync_pos, int32_t* n_syncs, int32_t* dropped, hipStream_t st) {
     if (n_channels <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_find_syncs, dim3((unsigned)n_channels), dim3(64), 0, st, flags, counts, max_sym, max_frames,
-                       sync_pos, n_syncs);
+                       sync_pos, n_syncs, dropped);
     return hipGetLastError();
 }
 

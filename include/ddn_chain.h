@@ -33,14 +33,20 @@ typedef struct ddn_p25_chain_config {
     int block_len;        /* front end: samples per reference full_demod() block (8192) */
     int input_format;     /* DDN_IN_CU8 / DDN_IN_CF32 */
     int vocoder;          /* 1 = IMBE synthesis to PCM, 0 = stop after the voice frames' FEC */
-    int max_frames;       /* frame slots per channel and call; 0 = samples_per_call / 1800 + 6 */
+    int max_frames;       /* frame slots per channel and call; 0 = samples_per_call / 1800 + 6 (back-to-back single-block TSDUs, the
+                             densest traffic a control channel carries; a run of 72-symbol TDUs or of false syncs can exceed it -
+                             what then finds no slot is counted in d_dropped_syncs, and a host that expects such traffic sets
+                             samples_per_call / 720 + 6) */
     int max_ldu;          /* voice LDUs per channel and call; 0 = samples_per_call / 8640 + 3 */
     int max_events;       /* handler decisions per channel and call; 0 = 4 * max_frames */
     int carry_symbols;    /* records carried into the next call; 0 = 896 (an LDU is 864 symbols) */
 } ddn_p25_chain_config;
 
-/* device pointers to the outputs of the most recent run (valid until the run after the next; S = n_channels * max_frames frame
- * slots, slot = channel * max_frames + k for the k-th decoded sync of the channel in this call) */
+/* device pointers to the outputs of the most recent run (S = n_channels * max_frames frame slots, slot = channel * max_frames + k
+ * for the k-th decoded sync of the channel in this call).  Lifetime: d_records10 / d_flags / d_new / d_events / d_n_events /
+ * d_event_data are double buffered and stay valid until the run after the next; everything else (counts, sync index, NIDs, TSDU
+ * blocks, the per-frame-type outputs, voice bits, PCM) is single buffered and is overwritten by the NEXT run's decode stage - read
+ * it (or have _run_host copy it out) before queueing another run, or after ddn_p25_chain_wait() of this one. */
 typedef struct ddn_p25_chain_results {
     size_t stride_symbols;     /* records per channel row = carry_symbols + ddn_p25_rx_max_symbols(samples_per_call) */
     const uint8_t* d_records10; /* [B][stride][10]: the carried records, then this call's */
@@ -51,6 +57,7 @@ typedef struct ddn_p25_chain_results {
     const int32_t* d_n_events;  /* [B] */
     const int32_t* d_event_data; /* [B][max_events][4] what each decision decoded (ddn_p25_rx_set_event_data) */
     const int32_t* d_n_syncs;   /* [B] frame slots used */
+    const int32_t* d_dropped_syncs; /* [B] running count of accepted syncs that found no frame slot (0 unless max_frames is too small) */
     const int32_t* d_sync_pos;  /* [S] index of the sync's last symbol in the row */
     /* the NID and the TSDU blocks are decoded once, by the handlers inside the receive loop (with the reference's running NAC as the
      * decoder's observed NAC), and filed by frame here; a block the handler did not read (behind the last-block flag) is zero */
@@ -114,9 +121,10 @@ typedef struct ddn_p25_chain_host_out {
     int64_t pcm_dense_frames;
 } ddn_p25_chain_host_out;
 int ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_host_out* out);
-/* decode what the carry still holds back (end of a stream): one more decode pass without new samples */
+/* decode what the carry still holds back (end of a stream): one more decode pass without new samples.  Blocking; it first waits for
+ * everything queued before it - the object's own streams and the caller's stream of the last ddn_p25_chain_run / _stage call */
 int ddn_p25_chain_flush(ddn_p25_chain* c);
-/* block until everything queued by the pipelined forms has run */
+/* block until everything queued so far has run (the pipelined forms' streams and the last _run / _stage caller stream) */
 int ddn_p25_chain_wait(ddn_p25_chain* c);
 int ddn_p25_chain_get_results(ddn_p25_chain* c, ddn_p25_chain_results* out);
 /* sizes derived from the configuration */

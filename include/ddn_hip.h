@@ -393,6 +393,9 @@ int ddn_p25p1_framer_index(ddn_p25p1_framer* f, const uint8_t* d_flags, const in
 int ddn_p25p1_framer_get_syncs(ddn_p25p1_framer* f, int32_t* n_syncs, int32_t* sync_pos); /* host copies, synchronous */
 /* the same arrays as device pointers: n_syncs [B], sync_pos [B][max_frames] (valid until the next _index on this object) */
 int ddn_p25p1_framer_device_syncs(ddn_p25p1_framer* f, const int32_t** d_n_syncs, const int32_t** d_sync_pos);
+/* d_dropped [B]: running count of accepted syncs that found no frame slot in their call (n_syncs is clamped to
+ * max_frames_per_channel; what the clamp cut off is counted here instead of vanishing).  0 unless the slots are too few. */
+int ddn_p25p1_framer_device_dropped(ddn_p25p1_framer* f, const int32_t** d_dropped);
 /* tsbk_decode_repetition_bytes() after the list decoder (src/protocol/p25/phase1/p25p1_tsbk.c:108-130): of each item's
  * candidates [n][8] (ddn_fec_p25_12_soft_list_batch output) the first whose CRC16 is clean, else the first; out12 [n][12],
  * crc_ok [n], sel [n] (may be NULL) */

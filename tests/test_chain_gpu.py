@@ -258,6 +258,39 @@ def test_run_host_copies_back_what_the_device_holds(built):
         l.ddn_host_free_pinned(p)
 
 
+def test_syncs_beyond_the_frame_slots_are_counted_not_lost_silently(built):
+    """max_frames too small for the traffic: the chain decodes the first max_frames syncs of a call and reports the rest in
+    d_dropped_syncs (a running count per channel) - and with the default slots the same traffic drops nothing"""
+    rng = np.random.default_rng(5)
+    n_call, calls = 24000, 2
+    parts = [p25gen.make_frames(rng, 1, 0x293, crc=True, blocks=1)[0] for _ in range(26)]     # 13 single-block TSDUs per call
+    iq = p25gen.modulate_cu8(np.concatenate(parts), n_call * calls, lead=240, seed=3, noise=0.02)[None]
+    want = chain_stream.run_stream(iq[0], n_call, seed=0)
+    found = len(want["frames"])
+    assert found >= 24
+    for max_frames, expect_drop in ((4, True), (0, False)):
+        ch = ddn.P25ChainC(1, n_call, max_frames=max_frames)
+        used = 0
+        for k in range(calls):
+            d = _upload(np.ascontiguousarray(iq[:, k * n_call:(k + 1) * n_call]))
+            ch.run(d)
+            ch.wait()
+            r = ch.results()
+            ns = int(ch.fetch(r.d_n_syncs, np.int32, (1,))[0])
+            assert ns <= ch.F
+            used += ns
+            ddn.lib().ddn_device_free(d)
+        ch.flush()
+        r = ch.results()
+        used += int(ch.fetch(r.d_n_syncs, np.int32, (1,))[0])
+        dropped = int(ch.fetch(r.d_dropped_syncs, np.int32, (1,))[0])
+        ch.close()
+        if expect_drop:
+            assert dropped > 0 and used <= 3 * 4 and used + dropped >= found, (used, dropped, found)
+        else:
+            assert dropped == 0 and used == found, (used, dropped, found)
+
+
 def test_run_host_streaming_host_never_waits(built):
     """the contract of ddn_p25_chain_run_host as include/ddn_chain.h words it, used the way a streaming host would: two pinned input
     buffers refilled in turn as soon as the NEXT call has returned, three output sets read as soon as the call after the next has
