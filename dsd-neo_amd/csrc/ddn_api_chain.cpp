@@ -11,6 +11,7 @@
 #include "ddn_chain.h"
 #include "ddn_device.h"
 #include "ddn_hip.h"
+#include "ddn_internal.h"
 #include "ddn_mbe.h"
 
 #define HIP_TRY(expr)                                                                                                  \
@@ -70,6 +71,10 @@ struct ddn_p25_chain {
     hipStream_t s_voice = nullptr;              // the voice stage of a decode, beside its frame FEC
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_produced[2], ev_consumed[2], ev_in[2], ev_in_free[2], ev_out[2];
+    hipEvent_t ev_loop[2] = {nullptr, nullptr}; // the receive loop of that set's call is next on s_main
+    // _run_host: the result copies of a call are issued in the NEXT call (or by _wait / _flush), beside that call's receive loop
+    ddn_p25_chain_host_out pending_out;
+    int have_pending = 0, pending_set = 0;
     void* d_iq[2];
     size_t iq_bytes;
     long step;
@@ -134,8 +139,8 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
         (void)hipEventDestroy(c->ev_join);
     }
     hipEvent_t evs[] = {c->ev_produced[0], c->ev_produced[1], c->ev_consumed[0], c->ev_consumed[1], c->ev_in[0], c->ev_in[1],
-                        c->ev_in_free[0], c->ev_in_free[1], c->ev_out[0], c->ev_out[1], c->ev_t[0], c->ev_t[1], c->ev_t[2],
-                        c->ev_t[3], c->ev_t[4], c->ev_t[5]};
+                        c->ev_in_free[0], c->ev_in_free[1], c->ev_out[0], c->ev_out[1], c->ev_loop[0], c->ev_loop[1], c->ev_t[0],
+                        c->ev_t[1], c->ev_t[2], c->ev_t[3], c->ev_t[4], c->ev_t[5]};
     for (hipEvent_t e : evs) {
         if (e) {
             (void)hipEventDestroy(e);
@@ -226,7 +231,8 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
             break;
         }
         hipEvent_t* evs[] = {&c->ev_produced[0], &c->ev_produced[1], &c->ev_consumed[0], &c->ev_consumed[1], &c->ev_in[0],
-                             &c->ev_in[1], &c->ev_in_free[0], &c->ev_in_free[1], &c->ev_out[0], &c->ev_out[1]};
+                             &c->ev_in[1], &c->ev_in_free[0], &c->ev_in_free[1], &c->ev_out[0], &c->ev_out[1], &c->ev_loop[0],
+                             &c->ev_loop[1]};
         for (hipEvent_t* e : evs) {
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
                 rc = DDN_EHIP;
@@ -279,7 +285,8 @@ chain_loop(ddn_p25_chain* c, int cur, hipStream_t st) {
 
 // front end + receive loop of one call into buffer set `cur` on stream st (the carried tail is copied in first)
 static int
-chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEvent_t before_loop = nullptr) {
+chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEvent_t before_loop = nullptr,
+              hipEvent_t loop_next = nullptr) {
     DDN_TRY(chain_front(c, d_iq, cur, st));
     // The receive loop fills the device on its own (two workgroups per CU take its registers and LDS) and every workgroup runs
     // for the whole launch: one that has to wait for a CU another kernel still holds makes the launch half as long again.  In the
@@ -288,7 +295,73 @@ chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEv
     if (before_loop) {
         HIP_TRY(hipStreamWaitEvent(st, before_loop, 0));
     }
+    if (loop_next) { // recorded inside ddn_p25_rx_run, after the matched filter
+        DDN_TRY(ddn_p25_rx_mark_loop_start(c->rx, loop_next));
+    }
     return chain_loop(c, cur, st);
+}
+
+// the device -> pinned-host copies of the results of the call that used buffer set `set`, on the second copy stream
+static int
+chain_copy_out(ddn_p25_chain* c, const ddn_p25_chain_host_out* out, int set) {
+    const size_t B = (size_t)c->B, S = c->S, V = c->V;
+    const bool dense_pcm = out->pcm_dense && out->pcm_slot && out->pcm_count && out->pcm_dense_frames > 0 && c->cfg.vocoder;
+    if (out->records10) {
+        HIP_TRY(hipMemcpyAsync(out->records10, c->d_rec[set], B * c->stride * 10, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->flags) {
+        HIP_TRY(hipMemcpyAsync(out->flags, c->d_fl[set], B * c->stride, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->records2) {
+        HIP_TRY(hipMemcpyAsync(out->records2, c->d_rec2[set], B * c->stride * 2, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->counts) {
+        HIP_TRY(hipMemcpyAsync(out->counts, c->d_cnt_full, B * 4, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->events) {
+        HIP_TRY(hipMemcpyAsync(out->events, c->d_ev[set], B * (size_t)c->E * 16, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->event_data) {
+        HIP_TRY(hipMemcpyAsync(out->event_data, c->d_evd[set], B * (size_t)c->E * 16, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->n_events) {
+        HIP_TRY(hipMemcpyAsync(out->n_events, c->d_nev[set], B * 4, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->nid4) {
+        HIP_TRY(hipMemcpyAsync(out->nid4, c->d_nid, S * 16, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->tsbk) {
+        HIP_TRY(hipMemcpyAsync(out->tsbk, c->d_tsbk, 3 * S * 12, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (out->pcm && c->cfg.vocoder) {
+        HIP_TRY(hipMemcpyAsync(out->pcm, c->d_pcm, V * 160 * 4, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    if (dense_pcm) {
+        const size_t nf = (size_t)out->pcm_dense_frames < V ? (size_t)out->pcm_dense_frames : V;
+        HIP_TRY(hipMemcpyAsync(out->pcm_dense, c->d_pcm_dense, nf * 160 * 4, hipMemcpyDeviceToHost, c->s_copy2));
+        HIP_TRY(hipMemcpyAsync(out->pcm_slot, c->d_pcm_slot, nf * 4, hipMemcpyDeviceToHost, c->s_copy2));
+        HIP_TRY(hipMemcpyAsync(out->pcm_count, c->d_pcm_total, 4, hipMemcpyDeviceToHost, c->s_copy2));
+    }
+    return DDN_OK;
+}
+
+// _run_host defers the result copies of a call to the next call, where they run beside that call's receive loop (the loop is a
+// latency chain that leaves the copy engines' shader waves room; beside the front end or the decode stage the copies and the
+// kernels slow each other).  Whoever needs the results earlier - _wait, _flush - issues them here.
+static int
+chain_issue_pending(ddn_p25_chain* c, hipEvent_t beside) {
+    if (!c->have_pending) {
+        return DDN_OK;
+    }
+    const int set = c->pending_set;
+    HIP_TRY(hipStreamWaitEvent(c->s_copy2, c->ev_consumed[set], 0)); // that call's decode (and its pack kernels) are done
+    if (beside) {
+        HIP_TRY(hipStreamWaitEvent(c->s_copy2, beside, 0));
+    }
+    DDN_TRY(chain_copy_out(c, &c->pending_out, set));
+    HIP_TRY(hipEventRecord(c->ev_out[set], c->s_copy2));
+    c->have_pending = 0;
+    return DDN_OK;
 }
 
 // framer + every frame type's FEC + voice of buffer set `cur` on stream st
@@ -467,28 +540,31 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
         HIP_TRY(hipMalloc(&c->d_iq[0], c->iq_bytes + 16));
         HIP_TRY(hipMalloc(&c->d_iq[1], c->iq_bytes + 16));
     }
-    // The header's contract, kept on the host side (stream-to-stream waits alone do not): the previous call's h_iq has left the host
-    // before this call returns, and the results of the call before that are in the caller's buffers.  This also bounds what a host
-    // that never calls _wait can have queued: two calls.
+    if (c->step >= 2) {
+        HIP_TRY(hipStreamWaitEvent(c->s_copy, c->ev_in_free[cur], 0)); // the front end of call k - 2 has read this input buffer
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_iq[cur], h_iq, c->iq_bytes, hipMemcpyHostToDevice, c->s_copy));
+    HIP_TRY(hipEventRecord(c->ev_in[cur], c->s_copy));
+    // The header's contract, kept on the host side (stream-to-stream waits alone do not), once this call's input copy is queued and
+    // before anything below records ev_out[cur] anew: the previous call's h_iq has left the host before this call returns, and the
+    // results of the call before that are in the caller's buffers.  This also bounds what a host that never calls _wait can have
+    // queued: two calls.
     if (c->step >= 1) {
         HIP_TRY(hipEventSynchronize(c->ev_in[cur ^ 1]));
     }
     if (c->step >= 2) {
         HIP_TRY(hipEventSynchronize(c->ev_out[cur]));
     }
-    if (c->step >= 2) {
-        HIP_TRY(hipStreamWaitEvent(c->s_copy, c->ev_in_free[cur], 0)); // the front end of call k - 2 has read this input buffer
-    }
-    HIP_TRY(hipMemcpyAsync(c->d_iq[cur], h_iq, c->iq_bytes, hipMemcpyHostToDevice, c->s_copy));
-    HIP_TRY(hipEventRecord(c->ev_in[cur], c->s_copy));
     HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_in[cur], 0));
     if (c->step >= 2) {
         HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_consumed[cur], 0)); // call k - 2 decoded out of this set ...
         HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_out[cur], 0));      // ... and its results have left it
     }
-    DDN_TRY(chain_receive(c, c->d_iq[cur], cur, c->s_main, c->step >= 1 ? c->ev_consumed[cur ^ 1] : nullptr));
+    DDN_TRY(chain_receive(c, c->d_iq[cur], cur, c->s_main, c->step >= 1 ? c->ev_consumed[cur ^ 1] : nullptr, c->ev_loop[cur]));
     HIP_TRY(hipEventRecord(c->ev_in_free[cur], c->s_main));
     HIP_TRY(hipEventRecord(c->ev_produced[cur], c->s_main));
+    // the previous call's results leave now, beside this call's receive loop
+    DDN_TRY(chain_issue_pending(c, c->ev_loop[cur]));
     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_produced[cur], 0));
     if (c->step >= 1) {
         HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_out[cur ^ 1], 0)); // the previous call's results have left the decode buffers
@@ -515,48 +591,14 @@ ddn_p25_chain_run_host(ddn_p25_chain* c, const void* h_iq, const ddn_p25_chain_h
                                           c->d_pcm_slot, c->d_pcm_total, c->s_aux));
     }
     HIP_TRY(hipEventRecord(c->ev_consumed[cur], c->s_aux));
-    // results of this call to the host, behind its decode, on the second copy stream
-    HIP_TRY(hipStreamWaitEvent(c->s_copy2, c->ev_consumed[cur], 0));
-    if (out) {
-        const size_t B = (size_t)c->B, S = c->S, V = c->V;
-        if (out->records10) {
-            HIP_TRY(hipMemcpyAsync(out->records10, c->d_rec[cur], B * c->stride * 10, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->flags) {
-            HIP_TRY(hipMemcpyAsync(out->flags, c->d_fl[cur], B * c->stride, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->records2) {
-            HIP_TRY(hipMemcpyAsync(out->records2, c->d_rec2[cur], B * c->stride * 2, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->counts) {
-            HIP_TRY(hipMemcpyAsync(out->counts, c->d_cnt_full, B * 4, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->events) {
-            HIP_TRY(hipMemcpyAsync(out->events, c->d_ev[cur], B * (size_t)c->E * 16, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->event_data) {
-            HIP_TRY(hipMemcpyAsync(out->event_data, c->d_evd[cur], B * (size_t)c->E * 16, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->n_events) {
-            HIP_TRY(hipMemcpyAsync(out->n_events, c->d_nev[cur], B * 4, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->nid4) {
-            HIP_TRY(hipMemcpyAsync(out->nid4, c->d_nid, S * 16, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->tsbk) {
-            HIP_TRY(hipMemcpyAsync(out->tsbk, c->d_tsbk, 3 * S * 12, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (out->pcm && c->cfg.vocoder) {
-            HIP_TRY(hipMemcpyAsync(out->pcm, c->d_pcm, V * 160 * 4, hipMemcpyDeviceToHost, c->s_copy2));
-        }
-        if (dense_pcm) {
-            const size_t nf = (size_t)out->pcm_dense_frames < V ? (size_t)out->pcm_dense_frames : V;
-            HIP_TRY(hipMemcpyAsync(out->pcm_dense, c->d_pcm_dense, nf * 160 * 4, hipMemcpyDeviceToHost, c->s_copy2));
-            HIP_TRY(hipMemcpyAsync(out->pcm_slot, c->d_pcm_slot, nf * 4, hipMemcpyDeviceToHost, c->s_copy2));
-            HIP_TRY(hipMemcpyAsync(out->pcm_count, c->d_pcm_total, 4, hipMemcpyDeviceToHost, c->s_copy2));
-        }
+    if (out) { // this call's results: copied out beside the next call's loop, or when _wait / _flush asks
+        c->pending_out = *out;
+        c->pending_set = cur;
+        c->have_pending = 1;
+    } else {
+        HIP_TRY(hipStreamWaitEvent(c->s_copy2, c->ev_consumed[cur], 0));
+        HIP_TRY(hipEventRecord(c->ev_out[cur], c->s_copy2));
     }
-    HIP_TRY(hipEventRecord(c->ev_out[cur], c->s_copy2));
     c->last_set = cur;
     c->step++;
     return DDN_OK;
@@ -591,6 +633,7 @@ ddn_p25_chain_wait(ddn_p25_chain* c) {
     if (!c) {
         return DDN_EINVAL;
     }
+    DDN_TRY(chain_issue_pending(c, nullptr));
     if (c->have_user_stream) {
         HIP_TRY(hipStreamSynchronize(c->user_stream));
     }

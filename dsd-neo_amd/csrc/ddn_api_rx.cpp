@@ -46,6 +46,7 @@ struct ddn_p25_rx {
     // without synchronising between launches (ddn_p25_rx_get_timing_avg)
     hipEvent_t ring[64][3];
     int ring_n, ring_head;
+    hipEvent_t loop_event; // recorded between the matched filter and the loop kernel of the next run (ddn_p25_rx_mark_loop_start)
 };
 
 static void
@@ -306,6 +307,10 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
         HIP_TRY(hipEventRecord(b->ev[1], st));
         HIP_TRY(hipEventRecord(rv[1], st));
     }
+    if (b->loop_event) { // one shot: the chain object releases its result copies when the loop kernel is next on the stream
+        HIP_TRY(hipEventRecord(b->loop_event, st));
+        b->loop_event = nullptr;
+    }
     DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0,
                       b->handlers, b->nid_threshold, b->d_events ? (int)b->max_events : 1,
                       b->d_events ? b->d_event_data : nullptr};
@@ -324,6 +329,17 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
     }
     // the filter memory (last 90 raw samples) moves on only after the loop has read the previous tail
     HIP_TRY(ddn_dev_p25_filter_hist_update(d_disc, (long)n, n, B, b->d_fhist, st));
+    return DDN_OK;
+}
+
+// internal (ddn_internal.h): the next ddn_p25_rx_run records `hip_event` on its stream after the matched filter, right before the
+// loop kernel
+extern "C" int
+ddn_p25_rx_mark_loop_start(ddn_p25_rx* b, void* hip_event) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    b->loop_event = (hipEvent_t)hip_event;
     return DDN_OK;
 }
 

@@ -23,6 +23,8 @@ int ddn_p25p1_layout_hdu(int32_t hex3[36 * 3], int32_t par6[36 * 6]);
 int ddn_p25p1_layout_tdulc(int32_t data6[72], int32_t par6[72]);
 int ddn_p25p1_layout_ldu_lsd(int32_t out16[16]);
 void ddn_set_error(const char* fmt, ...);
+/* the next ddn_p25_rx_run() records this HIP event between its matched filter and its loop kernel (one shot) */
+int ddn_p25_rx_mark_loop_start(ddn_p25_rx* b, void* hip_event);
 #ifdef __cplusplus
 }
 #endif

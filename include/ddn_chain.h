@@ -94,8 +94,10 @@ int ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip
 /* the same work over the object's two streams: front end + receive loop on one, framer + FEC + voice on the other, so the decode
  * of call k runs beside the front end and loop of call k + 1.  Returns once everything is queued. */
 int ddn_p25_chain_run_pipelined(ddn_p25_chain* c, const void* d_iq);
-/* pipelined, from pinned host memory: the H2D copy of this call's I/Q and the D2H copy of the previous call's results (any of the
- * out pointers may be NULL) run on copy streams beside the kernels.  h_iq must stay untouched until the next call returns (that call
+/* pipelined, from pinned host memory: the H2D copy of this call's I/Q and the D2H copies of the PREVIOUS call's results (any of the
+ * out pointers may be NULL; the structure is copied, the buffers it names must stay valid) run on copy streams beside this call's
+ * receive loop - a latency chain that leaves the copies room, where beside the front end or the decode stage they would slow the
+ * kernels.  ddn_p25_chain_wait() / _flush() issue the copies of the last call.  h_iq must stay untouched until the next call returns (that call
  * waits on the host for the copy): two input buffers, used in turn, are enough.  The outputs named at call k are complete when call
  * k + 2 returns (it waits for them on the host), or after ddn_p25_chain_wait(); call k + 2's own copies may already be running by
  * then, so a host that reads call k's outputs after call k + 2 returned needs THREE output sets used in turn (two if it calls
