@@ -608,6 +608,13 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
         return (iq[idx].contiguous() if Bc else iq[:0]), off.cpu().numpy(), iq.cpu().numpy()
 
     d_dmr, off_d, iq_d = tile("iq_dmr_t3_ras_cc.npz", 0, 96000, fd, Bd)
+    # every fourth DMR channel carries voice: the reference's dmr_voice capture (its BS voice handlers pass 11 bursts of it on to the
+    # vocoder); the others the Tier III control channel
+    if Bd:
+        d_dv, off_v, iq_dv = tile("iq_dmr_voice.npz", 0, 96000, fd, Bd)
+        is_voice_ch = ((np.arange(Bd) + fd) % 4) == 3
+        d_dmr[torch.from_numpy(is_voice_ch).to(dev)] = d_dv[torch.from_numpy(is_voice_ch).to(dev)]
+        del d_dv
     d_nx, off_n, iq_n = tile("iq_nxdn48.npz", 60000, 288000, fn, Bn)
     d_p25 = d_iq_p25[:Bp].contiguous() if Bp else d_iq_p25[:0]
     m = ddn.MixedChainC(Bp, Bd, Bn, n, block_len=BLOCK)
@@ -632,6 +639,8 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
         res[which] = (ch, r, ns, my)
         for c in sorted(set([0, Bc // 2, Bc - 1])):
             x = iq[offs[c]:offs[c] + n]
+            if which == 1 and is_voice_ch[c]:
+                x = iq_dv[off_v[c]:off_v[c] + n]
             disc = orc.OracleFrontEnd(profile=lpf).run_cu8(np.ascontiguousarray(x), BLOCK)
             want = rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf, handler=1)).run(disc, max_sync=512)
             k = int(new[c])
@@ -653,6 +662,7 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
         stb, errs = ch.fetch(r.d_dmr_slot_type, np.uint8, (S, 20)), ch.fetch(r.d_dmr_bptc_errs, np.uint32, (S,))
         rows = np.flatnonzero(valid)
         rows = rows[(rows % my) != 0]        # a fresh stream's first burst falls in the filter's cold start
+        rows = rows[~is_voice_ch[rows // my]]   # (the known answer of the control-channel capture; the voice channels carry colour code 2)
         cc_ok = bool(len(rows) > 0 and np.all(st_ok[rows] == 1) and np.all(stb[rows][:, :4] == 0) and np.mean(errs[rows] == 0) > 0.99)
     if 2 in res:   # NXDN48: LICH parity and SACCH CRC6 (soft decode or the greedy retry) on the complete frames
         ch, r, ns, my = res[2]
@@ -679,7 +689,7 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
     dt = ddn_shard.reduce_max_seconds((time.perf_counter() - t0) / steps, dev)
     out = {"workload": "configs[3] shape: %d channels over %d GPU(s) = %d P25 Phase 1 + %d DMR (Tier III control channel capture, GFSK rules) "
                        "+ %d NXDN48 (capture), %d cu8 samples each, handlers inside every receive loop; per protocol front end -> matched "
-                       "filter -> receive loop -> frame FEC (P25: the headline chain; DMR: burst gather + Golay(20,8) + BPTC(196,96); NXDN48: "
+                       "filter -> receive loop -> frame FEC (P25: the headline chain; DMR: burst gather + Golay(20,8) + BPTC(196,96), every fourth channel a voice capture whose bursts go through AMBE frame FEC + synthesis; NXDN48: "
                        "frame gather + SACCH / FACCH1 K=5 decode + CRC + greedy retry, and the voice frames the LICHs announce through "
                        "AMBE de-interleave + frame FEC + synthesis)" % (total, world, groups[0], groups[1], groups[2], n),
            "host": "one C object per GPU (ddn_mixed_chain), one C call per step; ranks take contiguous blocks of the global channel index "
@@ -720,6 +730,9 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
                 k4[name] = round(float(t2[1]), 3)
         out["k_fsk4_rx_ms"] = k4
         out["work_per_step"] = {"dmr_syncs": int(res[1][2].sum()) if 1 in res else 0, "nxdn_syncs": int(res[2][2].sum()) if 2 in res else 0}
+        if 1 in res:
+            r1 = res[1][0].results()
+            out["work_per_step"]["dmr_voice_bursts_synthesized"] = int(res[1][0].fetch(r1.d_dmr_n_voice, np.int32, (2 * Bd,)).sum())
     torch.cuda.synchronize()
     m.close()
     return out

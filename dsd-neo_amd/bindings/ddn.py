@@ -481,7 +481,10 @@ class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
         (k, C.c_void_p) for k in ("d_records10", "d_flags", "d_payload2", "d_new", "d_counts", "d_n_sync", "d_dropped_syncs", "d_sync_pos", "d_sync_pat", "d_pre",
                                   "d_valid", "d_dmr_slot_type", "d_dmr_slot_type_ok", "d_dmr_pdu96", "d_dmr_bptc_errs", "d_nxdn_lich",
                                   "d_nxdn_sacch", "d_nxdn_sacch_ok", "d_nxdn_sacch_hard", "d_nxdn_sacch_hard_ok", "d_nxdn_facch",
-                                  "d_nxdn_facch_ok", "d_nxdn_voice_skip", "d_nxdn_ambe_bits", "d_nxdn_pcm")]
+                                  "d_nxdn_facch_ok", "d_nxdn_voice_skip", "d_nxdn_ambe_bits", "d_nxdn_pcm")] + [
+        ("dmr_voice_bursts", C.c_int)] + [(k, C.c_void_p) for k in (
+            "d_dmr_n_voice", "d_dmr_voice_start", "d_dmr_voice_pre", "d_dmr_voice_skip", "d_dmr_ambe_frames", "d_dmr_ambe_bits",
+            "d_dmr_ambe_result", "d_dmr_pcm", "d_events", "d_n_events")] + [("max_events", C.c_int)]
 
 
 class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config

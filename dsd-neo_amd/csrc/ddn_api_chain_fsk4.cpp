@@ -49,6 +49,10 @@ struct ddn_fsk4_chain {
     // DMR
     uint8_t *d_st, *d_info, *d_cach, *d_valid, *d_st_ok, *d_pdu, *d_r3;
     uint32_t* d_errs;
+    // DMR voice (vocoder = 1): the loop's handler decisions of the call, the voice bursts they name filed by talk path (2 per
+    // channel: time slots 1 / 2), three AMBE frames each
+    int E, vb;
+    int32_t *d_ev, *d_nev, *d_vstart, *d_vpre, *d_vnb;
     // NXDN48
     uint8_t *d_lich, *d_ss, *d_sr, *d_fs, *d_fr, *d_sacch, *d_sacch_ok, *d_hard_in, *d_sacch_hard, *d_sacch_hard_ok, *d_facch, *d_facch_ok;
     int32_t *d_vpos, *d_vn, *d_ambe_res, *d_res_out;
@@ -82,7 +86,7 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
                    c->d_prel, c->d_st, c->d_info, c->d_cach, c->d_valid, c->d_st_ok, c->d_pdu, c->d_r3, c->d_errs, c->d_lich, c->d_ss,
                    c->d_sr, c->d_fs, c->d_fr, c->d_sacch, c->d_sacch_ok, c->d_hard_in, c->d_sacch_hard, c->d_sacch_hard_ok, c->d_facch,
                    c->d_facch_ok, c->d_vpos, c->d_vn, c->d_ambe_res, c->d_res_out, c->d_ambe_fr, c->d_ambe_rel, c->d_ambe_d, c->d_skip,
-                   c->d_pcm};
+                   c->d_pcm, c->d_ev, c->d_nev, c->d_vstart, c->d_vpre, c->d_vnb};
     for (void* p : all) {
         (void)hipFree(p);
     }
@@ -153,6 +157,22 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
         if (ok && c->dmr) {
             ok = dalloc(&c->d_st, S * 20) && dalloc(&c->d_info, S * 196) && dalloc(&c->d_cach, S * 24) && dalloc(&c->d_valid, S)
                  && dalloc(&c->d_st_ok, S) && dalloc(&c->d_pdu, S * 96) && dalloc(&c->d_r3, S * 3) && dalloc(&c->d_errs, S);
+            if (ok && cfg->vocoder && cfg->handlers) {
+                // voice (dmrBSBootstrap / dmrBS -> processMbeFrame, dmr_bs.c:128-200,585-640): a time slot carries a burst every
+                // 288 symbols, three AMBE 3600x2450 frames each; which bursts reach the vocoder is the handlers' decision (events)
+                c->vb = (int)(c->ms / 288 + 3);
+                c->E = (int)(c->ms / 36 + 32);
+                c->V = 2 * B * (size_t)c->vb; // bursts
+                const size_t V = c->V;
+                ok = dalloc(&c->d_ev, B * (size_t)c->E * 4) && dalloc(&c->d_nev, B) && dalloc(&c->d_vstart, V) && dalloc(&c->d_vpre, V)
+                     && dalloc(&c->d_vnb, 2 * B) && dalloc(&c->d_ambe_fr, V * 3 * 96) && dalloc(&c->d_ambe_d, V * 3 * 49)
+                     && dalloc(&c->d_ambe_res, V * 3 * 5) && dalloc(&c->d_skip, V * 3) && dalloc(&c->d_pcm, V * 3 * 160)
+                     && dalloc(&c->d_res_out, V * 3 * 5);
+                if (ok && ((rc = ddn_mbe_batch_create(DDN_MBE_AMBE_3600X2450, 2 * c->B, &c->mbe)) != DDN_OK
+                           || (rc = ddn_fsk4_rx_set_events(c->rx, c->d_ev, c->d_nev, (size_t)c->E)) != DDN_OK)) {
+                    break;
+                }
+            }
         } else if (ok) {
             // voice: four AMBE frames per NXDN frame, one talk path per channel.  With the handlers deciding the frame length two
             // syncs are at least a 192-symbol frame apart: a call decodes n / (192 * 20) + 3 frames at most
@@ -201,6 +221,22 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
                                      c->d_st, c->d_info, c->d_cach, c->d_valid, st));
         DDN_TRY(ddn_fec_block_code_batch(5 /* DDN_CODE_GOLAY_20_8 */, c->d_st, S, 1, nullptr, c->d_st_ok, st));
         DDN_TRY(ddn_fec_bptc_196x96_batch(c->d_info, 1, S, c->d_pdu, c->d_r3, c->d_errs, st));
+        if (c->mbe) {
+            // voice: the bursts the handlers handed to the vocoder in this call (they end inside it; a burst that began in the
+            // previous call reaches back into the carried records), filed by time slot -> 3 AMBE frames -> frame FEC -> synthesis.
+            // (hard bits: the reference passes no soft frame here, processMbeFrame(opts, state, NULL, frame, NULL))
+            const size_t V3 = c->V * 3;
+            if (flush) { // no new records, no new decisions
+                HIP_TRY(hipMemsetAsync(c->d_nev, 0, sizeof(int32_t) * (size_t)c->B, st));
+            }
+            HIP_TRY(ddn_dev_dmr_voice_select(c->d_ev, c->d_nev, c->E, c->T, c->d_spos, c->d_ns, c->myd, c->B, c->vb, c->d_vstart,
+                                             c->d_vpre, c->d_vnb, st));
+            HIP_TRY(ddn_dev_dmr_voice_gather_paths(rec, c->d_cnt_full, c->stride, c->d_vstart, c->d_vpre, c->d_pre, c->vb, c->B, 0,
+                                                   c->d_ambe_fr, c->d_skip, st));
+            DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, c->d_ambe_fr, nullptr, V3, c->d_ambe_d, c->d_ambe_res, st));
+            DDN_TRY(ddn_mbe_result_skip_batch(c->d_skip, V3, c->d_ambe_res, st));
+            DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_ambe_d, c->d_ambe_res, (size_t)c->vb * 3, c->d_pcm, c->d_res_out, st));
+        }
         return DDN_OK;
     }
     // NXDN48: frame gather -> SACCH / FACCH1 K=5 soft decode -> CRC6 / CRC12 -> the reference's greedy retry for the SACCH
@@ -316,9 +352,24 @@ ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
     r->d_nxdn_sacch_hard_ok = c->d_sacch_hard_ok;
     r->d_nxdn_facch = c->d_facch;
     r->d_nxdn_facch_ok = c->d_facch_ok;
-    r->d_nxdn_voice_skip = c->d_skip;
-    r->d_nxdn_ambe_bits = c->d_ambe_d;
-    r->d_nxdn_pcm = c->d_pcm;
+    if (c->dmr) {
+        r->dmr_voice_bursts = c->vb;
+        r->d_dmr_voice_start = c->d_vstart;
+        r->d_dmr_voice_pre = c->d_vpre;
+        r->d_dmr_n_voice = c->d_vnb;
+        r->d_dmr_voice_skip = c->d_skip;
+        r->d_dmr_ambe_frames = c->d_ambe_fr;
+        r->d_dmr_ambe_bits = c->d_ambe_d;
+        r->d_dmr_ambe_result = c->d_res_out;
+        r->d_dmr_pcm = c->d_pcm;
+        r->d_events = c->d_ev;
+        r->d_n_events = c->d_nev;
+        r->max_events = c->E;
+    } else {
+        r->d_nxdn_voice_skip = c->d_skip;
+        r->d_nxdn_ambe_bits = c->d_ambe_d;
+        r->d_nxdn_pcm = c->d_pcm;
+    }
     return DDN_OK;
 }
 
@@ -382,7 +433,8 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
         rc = ddn_p25_chain_create(&pc, &m->p25);
     }
     if (rc == DDN_OK && cfg->n_dmr > 0) {
-        ddn_fsk4_chain_config dc = {cfg->n_dmr, cfg->samples_per_call, cfg->block_len, cfg->input_format, DDN_FSK4_DMR, 2, 0, 1, 0};
+        ddn_fsk4_chain_config dc = {cfg->n_dmr, cfg->samples_per_call, cfg->block_len, cfg->input_format, DDN_FSK4_DMR, 2, 0, 1,
+                                    cfg->vocoder};
         rc = ddn_fsk4_chain_create(&dc, &m->dmr);
     }
     if (rc == DDN_OK && cfg->n_nxdn48 > 0) {

@@ -190,6 +190,12 @@ hipError_t ddn_dev_nxdn_voice_gather(const uint8_t* rec, const int32_t* counts, 
 hipError_t ddn_dev_dmr_voice_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* burst_start,
                                     int max_bursts, int n_channels, int inverted, uint8_t* fr, uint8_t* rl, uint8_t* sync48,
                                     uint8_t* cach24, uint8_t* valid, hipStream_t st);
+hipError_t ddn_dev_dmr_voice_select(const int32_t* events, const int32_t* n_events, int max_events, int carry, const int32_t* sync_pos,
+                                    const int32_t* n_sync, int max_syncs, int n_channels, int max_bursts, int32_t* vstart,
+                                    int32_t* vpre, int32_t* vn, hipStream_t st);
+hipError_t ddn_dev_dmr_voice_gather_paths(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* vstart,
+                                          const int32_t* vpre, const uint8_t* pre90, int max_bursts, int n_channels, int inverted,
+                                          uint8_t* fr, uint8_t* skip3, hipStream_t st);
 hipError_t ddn_dev_nxdn_frame_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
                                      const int32_t* n_sync, int n_channels, int max_sync, uint8_t* lich, uint8_t* sacch_sym,
                                      uint8_t* sacch_rel, uint8_t* facch_sym, uint8_t* facch_rel, uint8_t* valid, hipStream_t st);

@@ -1604,11 +1604,18 @@ __global__ __launch_bounds__(160) void
 k_dmr_voice_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ counts, size_t max_sym,
                    const int32_t* __restrict__ burst_start, int max_bursts, int inverted, uint8_t* __restrict__ fr,
                    uint8_t* __restrict__ rl, uint8_t* __restrict__ sync48, uint8_t* __restrict__ cach24,
-                   uint8_t* __restrict__ valid) {
-    const int k = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
-    const size_t so = (size_t)ch * max_bursts + k;
+                   uint8_t* __restrict__ valid, int rows_per_channel, const int32_t* __restrict__ pre_slot,
+                   const uint8_t* __restrict__ pre90, uint8_t* __restrict__ skip3) {
+    // (the chain's talk paths: row = 2 * channel + time slot, rows_per_channel = 2; a burst whose sync the frame sync search found
+    // takes its first 90 dibits from that sync's hand-over, pre90[pre_slot] - dmrBSBootstrap(), dmr_bs.c:697-760)
+    const int k = blockIdx.x, row = blockIdx.y, ch = row / rows_per_channel, t = threadIdx.x;
+    const size_t so = (size_t)row * max_bursts + k;
     const long s0 = burst_start[so];
+    const long ps = (pre_slot && s0 >= 0) ? (long)pre_slot[so] : -1;
     const bool ok = s0 >= 0 && s0 + 144 <= (long)counts[ch] && (size_t)(s0 + 144) <= max_sym;
+    if (skip3 && t < 3) {
+        skip3[so * 3 + t] = ok ? 0 : 0xFF;
+    }
     uint8_t* o = fr + so * 3 * 96;
     uint8_t* r = rl ? rl + so * 3 * 96 : nullptr;
     for (int q = t; q < 3 * 96; q += blockDim.x) {
@@ -1629,6 +1636,10 @@ k_dmr_voice_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ 
         const uint8_t* rr = rec + ((size_t)ch * max_sym + (size_t)(s0 + t)) * 10;
         d = ((rr[0] & 3) ^ (inverted ? 2 : 0)) & 3;
         q = rr[1];
+        if (ps >= 0 && t < 90) {
+            d = pre90[(size_t)ps * 90 + t] & 3; // seed_dmr_bs_bootstrap_payload(): already turned round when inverted
+            q = 0;
+        }
     }
     if (t < 12) {
         if (cach24) {
@@ -1676,7 +1687,80 @@ ddn_dev_dmr_voice_gather(const uint8_t* rec, const int32_t* counts, size_t max_s
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_dmr_voice_gather, dim3((unsigned)max_bursts, (unsigned)n_channels), dim3(160), 0, st, rec, counts, max_sym,
-                       burst_start, max_bursts, inverted, fr, rl, sync48, cach24, valid);
+                       burst_start, max_bursts, inverted, fr, rl, sync48, cach24, valid, 1, nullptr, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+// ---- the DMR chain's voice stage -------------------------------------------------------------------------------------------------
+// Which bursts the reference's BS voice handlers hand to the vocoder is decided inside the receive loop (ddn_fsk4h_dev.h): every
+// "voice burst proper" of dmrBS() and the bootstrap burst of dmrBSBootstrap() while the slot's voice gate is open leave a kind-6
+// event {position of the burst's last symbol, 6, colour code, VC >= 1 | slot << 16} (process_dmr_bs_voice_burst(), dmr_bs.c:585-640;
+// process_dmr_bs_bootstrap_voice_if_open()).  One thread per channel files them by time slot: talk path = 2 * channel + slot, in air
+// order; start = row index of the burst's first CACH dibit (the row holds `carry` records of the previous call, then this call's);
+// pre = the sync slot whose 90-dibit hand-over are the burst's first 90 dibits when the burst is the one the sync search found
+// (the sync's last symbol is the burst's dibit 89), else -1.
+__global__ void
+k_dmr_voice_select(const int32_t* __restrict__ events, const int32_t* __restrict__ n_events, int max_events, int carry,
+                   const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_sync, int max_syncs, int n_channels,
+                   int max_bursts, int32_t* __restrict__ vstart, int32_t* __restrict__ vpre, int32_t* __restrict__ vn) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= n_channels) {
+        return;
+    }
+    int n[2] = {0, 0};
+    const int ne = n_events[ch] < max_events ? n_events[ch] : max_events;
+    const int ns = n_sync[ch] < max_syncs ? n_sync[ch] : max_syncs;
+    for (int i = 0; i < ne; i++) {
+        const int32_t* e = events + ((size_t)ch * max_events + i) * 4;
+        const int vc = e[3] & 0xFFFF, slot = (e[3] >> 16) & 1;
+        if (e[1] != 6 || vc < 1) {
+            continue;
+        }
+        const int k = n[slot]++;
+        if (k >= max_bursts) {
+            continue;
+        }
+        const size_t so = ((size_t)ch * 2 + slot) * max_bursts + k;
+        vstart[so] = carry + e[0] - 143;
+        int pre = -1;
+        for (int j = 0; j < ns; j++) {
+            if (sync_pos[(size_t)ch * max_syncs + j] == carry + e[0] - 54) {
+                pre = ch * max_syncs + j;
+            }
+        }
+        vpre[so] = pre;
+    }
+    for (int slot = 0; slot < 2; slot++) {
+        vn[ch * 2 + slot] = n[slot] < max_bursts ? n[slot] : max_bursts;
+        for (int k = n[slot]; k < max_bursts; k++) {
+            vstart[((size_t)ch * 2 + slot) * max_bursts + k] = -1;
+            vpre[((size_t)ch * 2 + slot) * max_bursts + k] = -1;
+        }
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_dmr_voice_select(const int32_t* events, const int32_t* n_events, int max_events, int carry, const int32_t* sync_pos,
+                         const int32_t* n_sync, int max_syncs, int n_channels, int max_bursts, int32_t* vstart, int32_t* vpre,
+                         int32_t* vn, hipStream_t st) {
+    if (n_channels <= 0 || max_bursts <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_dmr_voice_select, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, events, n_events, max_events, carry,
+                       sync_pos, n_sync, max_syncs, n_channels, max_bursts, vstart, vpre, vn);
+    return hipGetLastError();
+}
+
+// the bursts k_dmr_voice_select filed -> three AMBE frames each [2 B][max_bursts][3][4][24] + a skip flag per frame
+extern "C" hipError_t
+ddn_dev_dmr_voice_gather_paths(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* vstart, const int32_t* vpre,
+                               const uint8_t* pre90, int max_bursts, int n_channels, int inverted, uint8_t* fr, uint8_t* skip3,
+                               hipStream_t st) {
+    if (n_channels <= 0 || max_bursts <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_dmr_voice_gather, dim3((unsigned)max_bursts, (unsigned)(2 * n_channels)), dim3(160), 0, st, rec, counts, max_sym,
+                       vstart, max_bursts, inverted, fr, nullptr, nullptr, nullptr, nullptr, 2, vpre, pre90, skip3);
     return hipGetLastError();
 }
 

@@ -145,7 +145,8 @@ int ddn_p25_chain_get_stage_ms(ddn_p25_chain* c, float out4[4]);
 /* ---- DMR / NXDN48: the same shape for BASELINE configs[3]'s other two protocols ------------------------------------------------
  *   cu8 / cf32 I/Q -> front end (12.5 kHz / 6.25 kHz channel filter) -> matched filter + receive loop (ddn_fsk4_rx_run; handlers = 1:
  *   dmr_data_sync / dmrBSBootstrap + dmrBS / nxdn_frame's LICH gate decide the in-frame lengths inside the loop)
- *   DMR:    burst gather -> slot type Golay(20,8) -> BPTC(196,96)
+ *   DMR:    burst gather -> slot type Golay(20,8) -> BPTC(196,96); the voice bursts the BS handlers pass on (dmrBSBootstrap / dmrBS):
+ *           three AMBE 3600x2450 frames each -> frame FEC -> synthesis, one talk path per time slot (vocoder = 1)
  *   NXDN48: frame gather -> SACCH / FACCH1 K=5 decode + CRC6 / CRC12 + the greedy SACCH retry -> the voice frames the LICHs announce:
  *           AMBE de-interleave -> AMBE 3600x2450 frame FEC -> synthesis (vocoder = 1)
  * One call per batch of samples_per_call samples; carried state streams from call to call.  Bursts / frames that cross a call
@@ -160,7 +161,7 @@ typedef struct ddn_fsk4_chain_config {
     int rf_mod;       /* 0 = C4FM rules, 2 = GFSK rules (what dsd-neo runs DMR with) */
     int inverted;     /* DMR: opts->inverted_dmr (handlers need 0) */
     int handlers;     /* 1 = the reference's handlers decide the in-frame lengths (ddn_fsk4_rx_set_handlers) */
-    int vocoder;      /* NXDN48: 1 = AMBE synthesis to PCM */
+    int vocoder;      /* 1 = AMBE synthesis to PCM (NXDN48 voice frames; DMR voice bursts when handlers = 1) */
 } ddn_fsk4_chain_config;
 typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max_syncs sync slots */
     size_t stride_symbols, carry_symbols, max_syncs; /* records per row; carried records at its front; sync slots per channel */
@@ -191,6 +192,22 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const uint8_t* d_nxdn_voice_skip; /* [B][voice_slots][4] 1 = not a voice frame */
     const uint8_t* d_nxdn_ambe_bits; /* [B][voice_slots * 4][49] */
     const float* d_nxdn_pcm;        /* [B][voice_slots * 4][160] */
+    /* DMR voice (protocol DMR, handlers = 1, vocoder = 1; NULL otherwise): the bursts the reference's BS voice handlers hand to the
+     * vocoder (dmrBSBootstrap / dmrBS, src/protocol/dmr/dmr_bs.c:585-640,697-760: decided inside the receive loop, event kind 6 with
+     * VC >= 1), filed by talk path = 2 * channel + time slot in air order, three AMBE 3600x2450 frames each; a talk path's voice
+     * history streams from call to call.  A burst is decoded in the call that holds its last symbol. */
+    int dmr_voice_bursts;            /* burst slots per talk path and call */
+    const int32_t* d_dmr_n_voice;    /* [2 B] voice bursts of this call */
+    const int32_t* d_dmr_voice_start; /* [2 B][dmr_voice_bursts] row index of the burst's first CACH dibit (-1: unused) */
+    const int32_t* d_dmr_voice_pre;  /* [2 B][dmr_voice_bursts] sync slot whose 90-dibit hand-over opens the burst (the bootstrap burst), else -1 */
+    const uint8_t* d_dmr_voice_skip; /* [2 B][dmr_voice_bursts][3] 0xFF = unused slot */
+    const uint8_t* d_dmr_ambe_frames; /* [2 B][dmr_voice_bursts][3][4][24] */
+    const uint8_t* d_dmr_ambe_bits;  /* [2 B][dmr_voice_bursts * 3][49] */
+    const int32_t* d_dmr_ambe_result; /* [2 B][dmr_voice_bursts * 3][5] */
+    const float* d_dmr_pcm;          /* [2 B][dmr_voice_bursts * 3][160] */
+    const int32_t* d_events;         /* [B][max_events][4] the handlers' decisions of this call (include/ddn_fsk4.h) */
+    const int32_t* d_n_events;       /* [B] */
+    int max_events;
 } ddn_fsk4_chain_results;
 typedef struct ddn_fsk4_chain ddn_fsk4_chain;
 int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);

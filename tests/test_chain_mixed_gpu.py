@@ -170,3 +170,80 @@ def test_mixed_chain_groups_side_by_side(built):
     m.close()
     for p in (dp, dd, dn):
         l.ddn_device_free(p)
+
+
+def test_dmr_chain_voice_bursts_to_pcm(built):
+    """DMR voice inside the chain object: the bursts the reference's BS voice handlers hand to the vocoder (dmrBSBootstrap / dmrBS,
+    src/protocol/dmr/dmr_bs.c:585-640,697-760 - decided inside the receive loop, event kind 6 with VC >= 1) -> three AMBE 3600x2450
+    frames each -> frame FEC -> synthesis, one talk path per time slot.  The reference's two DMR voice captures streamed in three
+    calls + the flush against the CPU restatement of the whole stream: the same bursts in the same order on the same talk paths, the
+    same AMBE frames, parameter bits and PCM bit for bit - bursts that straddle a call boundary included"""
+    import mbe
+    caps = ("iq_dmr_voice.npz", "iq_dmr_t3_cc.npz")
+    B, n, calls = len(caps), 32000, 3
+    iq = np.stack([np.ascontiguousarray(golden(c)["iq"], np.uint8)[:n * calls] for c in caps])
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_DMR, rf_mod=2)
+    got = [[] for _ in range(2 * B)]           # per talk path: (stream position of the burst's last symbol, frames, bits, pcm)
+    base = np.zeros(B, np.int64)
+
+    def take():
+        r = ch.results()
+        vb, T = r.dmr_voice_bursts, int(r.carry_symbols)
+        f = ch.fetch
+        nv, vs = f(r.d_dmr_n_voice, np.int32, (2 * B,)), f(r.d_dmr_voice_start, np.int32, (2 * B, vb))
+        fr = f(r.d_dmr_ambe_frames, np.uint8, (2 * B, vb, 3, 4, 24))
+        bits, pcm = f(r.d_dmr_ambe_bits, np.uint8, (2 * B, vb * 3, 49)), f(r.d_dmr_pcm, np.float32, (2 * B, vb * 3, 160))
+        res = f(r.d_dmr_ambe_result, np.int32, (2 * B, vb * 3, 5))
+        skip = f(r.d_dmr_voice_skip, np.uint8, (2 * B, vb, 3))
+        for tp in range(2 * B):
+            assert nv[tp] <= vb and np.all(skip[tp, :nv[tp]] == 0) and np.all(skip[tp, nv[tp]:] == 0xFF)
+            assert not pcm[tp, 3 * nv[tp]:].any()
+            for k in range(int(nv[tp])):
+                got[tp].append((int(base[tp // 2]) + int(vs[tp, k]) - T + 143, fr[tp, k].copy(), bits[tp, 3 * k:3 * k + 3].copy(),
+                                pcm[tp, 3 * k:3 * k + 3].copy(), res[tp, 3 * k:3 * k + 3].copy()))
+        return f(r.d_new, np.int32, (B,))
+
+    for k in range(calls):
+        d = _upload(np.ascontiguousarray(iq[:, k * n:(k + 1) * n]))
+        ch.run(d)
+        base += take() * 0
+        new = ch.fetch(ch.results().d_new, np.int32, (B,))
+        base += new
+        ddn.lib().ddn_device_free(d)
+    ch.flush()
+    # (the flush decodes no voice: a burst is decoded in the call that holds its last symbol)
+    r = ch.results()
+    assert not ch.fetch(r.d_dmr_n_voice, np.int32, (2 * B,)).any()
+    ch.close()
+    total = 0
+    for c in range(B):
+        fe = orc.OracleFrontEnd(profile=2)
+        disc = np.concatenate([fe.run_cu8(np.ascontiguousarray(iq[c, k * n:(k + 1) * n]), 8192) for k in range(calls)])
+        o = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_DMR, rf_mod=2, handler=1))
+        w = o.run(disc, max_sync=512)
+        ev = [e for e in o.events.rows() if e[1] == 6 and e[3] >= 1]
+        syncs = {int(p): i for i, p in enumerate(w["sync_pos"])}
+        for slot in range(2):
+            tp = 2 * c + slot
+            mine = [e for e in ev if e[4] == slot]
+            assert [g[0] for g in got[tp]] == [int(e[0]) for e in mine], (tp, [g[0] for g in got[tp]], [int(e[0]) for e in mine])
+            voc = mbe.OracleVocoder(ddn.MBE_AMBE, 1)
+            for g, e in zip(got[tp], mine):
+                pos = int(e[0])
+                dib = (w["rec4"][pos - 143:pos + 1, 0] & 3).astype(np.uint8)
+                if pos - 54 in syncs:                  # the burst the sync search found: its first 90 dibits are the hand-over
+                    dib[:90] = w["pre"][syncs[pos - 54]] & 3
+                frames = rx4.dmr_voice_burst_fields(dib, np.zeros(144, np.uint8), 0)[0]
+                assert np.array_equal(g[1], frames), (tp, pos)
+                bits, res, rc = mbe.oracle_frame_decode(ddn.MBE_AMBE, frames)
+                assert np.array_equal(g[2], bits), (tp, pos)
+                pcm = np.zeros((1, 3, 160), np.float32)
+                ro = np.zeros((1, 3, 5), np.int32)
+                lb, lr = np.ascontiguousarray(bits[None]), np.ascontiguousarray(res[None])
+                assert mbe._o().om_process_batch(ddn.MBE_AMBE, C.addressof(voc.tab), lb.ctypes.data, lr.ctypes.data, 0, tp, 1, 3,
+                                                 pcm.ctypes.data, ro.ctypes.data, C.addressof(voc.cur), C.addressof(voc.prev),
+                                                 C.addressof(voc.enh)) == 0
+                assert np.array_equal(g[3].view(np.uint32), pcm[0].view(np.uint32)), (tp, pos, float(np.abs(g[3] - pcm[0]).max()))
+                assert np.array_equal(g[4], ro[0]), (tp, pos)
+                total += 1
+    assert total >= 18, total
