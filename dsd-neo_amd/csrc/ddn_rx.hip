@@ -26,6 +26,8 @@
 // binary64 for k <= 1024 and a binary32 v, so the reference's sequential rebuild gives the same bits).
 
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <stdint.h>
 
@@ -748,7 +750,7 @@ struct LdsW {
     float raw[CPW][RTW + TW + 13];
     float flt[CPW][RTW + TW + 13];
     alignas(16) float q[2][QTW][CPW][4]; // [tile parity][trip][lane] = {symbol, max, min, flags | output index << 8}
-    int qn[2][2];                       // trips of that tile, per recurrence wave
+    int qn[2][4];                       // trips of that tile, per recurrence wave
     int qo[2][CPW];                     // output index of the lane's first symbol of that tile
     alignas(16) float sfx[2][WMW][CPW][4]; // [checkpoint parity][m - 1][lane] = {min1, min2, max1, max2} of ring entries m+1..128
     int sidx0[2][CPW];        // [tile parity] ring slot of the oldest entry at the start of that tile
@@ -763,16 +765,21 @@ struct LdsH {
     float hh[ddn_p25h::HN][CPW][3]; // {symbol, max, min} of the phase's in-frame symbols, slot = count mod HN
     int req_seq[CPW], req_kind[CPW], req_hw[CPW], req_n[CPW], req_o[CPW], req_neg[CPW], req_nc[CPW];
     int rsp_seq[CPW], rsp_ext[CPW], rsp_more[CPW];
-    int tile_done[2]; // per recurrence wave: tiles it has finished
-    int hwid[4];      // HW_ID of the workgroup's waves (role placement)
-    int ready[2];     // per recurrence wave: tiles the staging wave has made enterable for its channels (staged + window
+    int tile_done[4]; // per recurrence wave: tiles it has finished
+    int hwid[8];      // HW_ID of the workgroup's waves (role placement)
+    int ready[4];     // per recurrence wave: tiles the staging wave has made enterable for its channels (staged + window
                       // summaries of the checkpoint before)
     float hh_dummy[CPW][4]; // where the lean run's history store goes for a lane whose phase does not end in a decision
     ddn_p25h::Scratch sc;
 };
 
-template <int CPW, bool HM>
-__global__ __launch_bounds__(HM ? 256 : 192) __attribute__((amdgpu_waves_per_eu(2))) void
+// NRW_T = recurrence waves per workgroup.  Handler mode runs two (four lanes each at eight channels per workgroup: four waves, two
+// workgroups per CU, one recurrence and one light wave per SIMD) or four (two lanes each: six waves per workgroup, three waves per
+// SIMD = two recurrences and one light wave, 168 registers per wave) - a recurrence is a latency chain that leaves its SIMD idle
+// most cycles, two of them interleave almost for free (tools/ubench/simd_share.hip), and every special trip (a sync's warm start, a
+// bulk hunting pass, a handler's answer) then holds up one other channel instead of three.
+template <int CPW, bool HM, int NRW_T = (HM ? 2 : 1)>
+__global__ __launch_bounds__(HM ? 64 * (NRW_T + 2) * (NRW_T == 4 ? 2 : 1) : 192) __attribute__((amdgpu_waves_per_eu(NRW_T == 4 ? 3 : 2))) void
 k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const float* __restrict__ prev_tail,
           float* __restrict__ fstale, long n,
           size_t stride, int n_channels, DdnRxConfig cfg, DdnRxState* __restrict__ state, float* __restrict__ sbuf_store,
@@ -784,21 +791,32 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     using LW = LdsW<CPW, HM>;
     constexpr int TW = LW::TW, RTW = LW::RTW, WMW = LW::WMW, QTW = LW::QTW;
     (void)RTW;
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ unsigned char smem_all[];
+    // NRW_T = 4: a launch workgroup is TWO logical ones of six waves, each with its own half of the LDS and its own channels.  The
+    // hardware deals a workgroup's waves round the four SIMDs in order, so twelve waves land three per SIMD (two six-wave workgroups
+    // of their own would both start at SIMD 0 and ask two SIMDs for four waves' registers: only one would be resident), and waves
+    // 0-5 / 6-11 sit on SIMDs (0 1 2 3 0 1) / (2 3 0 1 2 3): every SIMD gets two recurrences and one helper.  The halves share
+    // nothing but the three workgroup barriers of the prologue.
+    constexpr int LTHREADS = HM ? 64 * (NRW_T + 2) : 192;   // threads of a logical workgroup
+    constexpr size_t LBYTES = HM ? ((((sizeof(LW) + 15) & ~(size_t)15) + sizeof(LdsH<CPW>) + 15) & ~(size_t)15) : sizeof(LW);
+    const int lhalf = (NRW_T == 4) ? (int)(threadIdx.x / LTHREADS) : 0;
+    const int ltid = (int)threadIdx.x - lhalf * LTHREADS;
+    const int lblock = (NRW_T == 4) ? (int)blockIdx.x * 2 + lhalf : (int)blockIdx.x;
+    unsigned char* smem_raw = smem_all + (size_t)lhalf * LBYTES;
     LW& L = *reinterpret_cast<LW*>(smem_raw);
     LdsH<CPW>& H = *reinterpret_cast<LdsH<CPW>*>(smem_raw + ((sizeof(LW) + 15) & ~(size_t)15));
-    const int lane = threadIdx.x & 63;
+    const int lane = ltid & 63;
     // Which wave takes which role.  The dispatcher puts the four waves of a workgroup on the four SIMDs of its CU in an order that
     // changes from workgroup to workgroup, and two workgroups share a CU: with the roles tied to the wave index a quarter of the
     // SIMDs ended up with two recurrence waves (two latency chains taking turns) and a quarter with none.  So the roles go by SIMD:
     // the workgroup in the SIMDs' wave slot 0 runs its recurrences on SIMDs 0 / 1, the staging wave on 2, the handlers on 3, the
     // workgroup in slot 1 the other way round - every SIMD hosts one recurrence and one light wave.
-    int wave_role = threadIdx.x >> 6;
+    int wave_role = ltid >> 6;
     if (HM && !(cfg.dbg & 524288)) {
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         if (lane == 0) {
-            H.hwid[threadIdx.x >> 6] = (int)hwid;
+            H.hwid[ltid >> 6] = (int)hwid;
         }
         __syncthreads();
         int seen = 0, slot_of_simd0 = 0;
@@ -809,16 +827,37 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 slot_of_simd0 = v & 15;
             }
         }
-        if (seen == 15) { // one wave per SIMD (else: roles by wave index, as before)
+        if (NRW_T == 2 && seen == 15) { // one wave per SIMD (else: roles by wave index, as before)
             wave_role = ((int)((hwid >> 4) & 3) - 2 * (slot_of_simd0 & 1)) & 3;
         }
+        if (NRW_T == 4) {
+            // six waves over four SIMDs: two SIMDs get two of them.  The first wave of the workgroup on a SIMD runs a recurrence, a
+            // second one is a helper (staging, then handlers) - with two workgroups per CU placed (2, 2, 1, 1) and (1, 1, 2, 2)
+            // every SIMD hosts two recurrences and one helper.  Any other placement: roles by wave index.
+            constexpr int NW = NRW_T + 2;
+            const int me = ltid >> 6, my_simd = (int)((hwid >> 4) & 3);
+            int cnt[4] = {0, 0, 0, 0}, my_rank = 0;
+            for (int w = 0; w < NW; w++) {
+                const int sd = (H.hwid[w] >> 4) & 3;
+                cnt[sd]++;
+                my_rank += (w < me && sd == my_simd) ? 1 : 0;
+            }
+            const bool good = cnt[0] >= 1 && cnt[1] >= 1 && cnt[2] >= 1 && cnt[3] >= 1 && cnt[0] <= 2 && cnt[1] <= 2 && cnt[2] <= 2 && cnt[3] <= 2;
+            if (good) {
+                int before = 0; // waves of the same kind (first / second on their SIMD) on lower SIMDs
+                for (int sd = 0; sd < my_simd; sd++) {
+                    before += my_rank == 0 ? 1 : (cnt[sd] == 2 ? 1 : 0);
+                }
+                wave_role = my_rank == 0 ? before : NRW_T + before;
+            }
+        }
     }
-    const bool hwave = HM && wave_role == 3; // the handlers' decisions
+    const bool hwave = HM && wave_role == NRW_T + 1; // the handlers' decisions
     if (HM && hwave) {
         // The handler wave runs its own path from here on (its decoders would otherwise be allocated on top of the
         // recurrence's live registers); it meets the other waves at the same workgroup barriers: two before the tile loop,
         // one per tile.
-        const int ch0 = blockIdx.x * CPW;
+        const int ch0 = lblock * CPW;
         const int ch = ch0 + lane;
         auto wg_barrier = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -844,10 +883,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
         ddn_p25h::crc_cols_fill(H.sc.crc_cols, lane);
         if (lane == 0) {
-            H.tile_done[0] = 0;
-            H.tile_done[1] = 0;
-            H.ready[0] = 1; // tile 0 is staged and summarised by the prologue
-            H.ready[1] = 1;
+            for (int w = 0; w < 4; w++) {
+                H.tile_done[w] = 0;
+                H.ready[w] = 1; // tile 0 is staged and summarised by the prologue
+            }
             ddn_nid::gf_fill(H.sc.ex, H.sc.lg);
             ddn_nid::chase_masks_fill(H.sc.masks);
         }
@@ -1104,8 +1143,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const int rq = (lane < CPW) ? __hip_atomic_load(&H.req_seq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
                 const unsigned long long pend = __ballot(lane < CPW && rq != h_served);
                 if (pend == 0) {
-                    if (__hip_atomic_load(&H.tile_done[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it
-                        && __hip_atomic_load(&H.tile_done[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it) {
+                    bool all_done = true;
+                    for (int w = 0; w < NRW_T; w++) {
+                        all_done = all_done && __hip_atomic_load(&H.tile_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it;
+                    }
+                    if (all_done) {
                         break;
                     }
                     helper_idle(idle_spin, (cfg.dbg & 8388608) != 0, 4);
@@ -1136,14 +1178,14 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     // lanes each) - a trip is only lean when every lane of its wave is, a handler decision only holds up the wave of the lane
     // that asked, and the crossing search has twice the lanes per channel - and wave 2 does both the staging and the summaries
     // (together about half a tile's time), wave 3 the handlers' decisions.
-    constexpr int NRW = HM ? 2 : 1;   // recurrence waves
+    constexpr int NRW = NRW_T;        // recurrence waves
     constexpr int LPR = CPW / NRW;    // lanes (channels) per recurrence wave
     const int wave = wave_role;
     const bool loader = wave == NRW;                      // tile staging, slice + record stores
     const bool winprep = wave == (HM ? NRW : NRW + 1);    // suffix summaries of the symbol window
     const bool recur = wave < NRW;                        // the per-channel recurrence
     const int rw = recur ? wave : 0;
-    const int ch0 = blockIdx.x * CPW;
+    const int ch0 = lblock * CPW;
     const int ln = rw * LPR + (lane < LPR ? lane : 0);    // this lane's channel column in the workgroup's LDS arrays
     const int ch = ch0 + ln;
     const bool live = recur && lane < LPR && ch < n_channels;
@@ -1790,12 +1832,22 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         // window summaries of checkpoint j) falls due when that wave has finished tile j - 1, and lets it into tile j + 1; job
         // n_tiles is the last tile's drain.  Whichever half is due is served.
         const int n_tiles = (int)((n + TW - 1) / TW);
-        int job[2] = {0, 0};
+        int job[NRW];
+        for (int h = 0; h < NRW; h++) {
+            job[h] = 0;
+        }
         float idle_spin = 0.0f;
-        while (job[0] <= n_tiles || job[1] <= n_tiles) {
+        auto jobs_left = [&]() {
+            bool any = false;
+            for (int h = 0; h < NRW; h++) {
+                any = any || job[h] <= n_tiles;
+            }
+            return any;
+        };
+        while (jobs_left()) {
             bool served = false;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < NRW; h++) {
                 const int j = job[h];
                 if (j > n_tiles || __hip_atomic_load(&H.tile_done[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < j) {
                     continue;
@@ -2733,7 +2785,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     }
     if ((DDN_RX_CYCLES && (cfg.dbg & 8192)) && lane == 0) { // timing experiment only: cycles per wave in the tile body / at the tile barrier
         // (written over the unused tail of the workgroup's first channel's record area)
-        uint8_t* d = rec + ((size_t)ch0 + 1) * max_sym * 10 - 192 + wave * 64;
+        uint8_t* d = rec + ((size_t)ch0 + 1) * max_sym * 10 - 192 + (wave < NRW ? (wave ? 1 : 0) : 2) * 64; // (recurrence 0, another one, staging)
         const long long v[8] = {dbg_busy, dbg_wait, dbg_cyc[0], dbg_cyc[1], dbg_cyc[2], dbg_n[0], dbg_n[1], dbg_n[2]};
         for (int k = 0; k < 64; k++) {
             d[k] = reinterpret_cast<const uint8_t*>(v)[k];
@@ -2767,22 +2819,33 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     }
 }
 
-template <int CPW, bool HM>
+template <int CPW, bool HM, int NRW_T = (HM ? 2 : 1)>
 static hipError_t
 launch_rxw(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride, int n_channels,
            const DdnRxConfig& cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
            float* minring, float* maxring, uint8_t* rec, uint8_t* flags, int32_t* counts, size_t max_sym, const int32_t* lock_cfg,
            DdnP25HState* hstate, float* hh_store, int32_t* events, int32_t* n_events, hipStream_t st) {
-    const size_t shm = HM ? (((sizeof(LdsW<CPW, true>) + 15) & ~(size_t)15) + sizeof(LdsH<CPW>)) : sizeof(LdsW<CPW>);
+    const size_t shm1 = HM ? (((((sizeof(LdsW<CPW, true>) + 15) & ~(size_t)15) + sizeof(LdsH<CPW>)) + 15) & ~(size_t)15) : sizeof(LdsW<CPW>);
+    const size_t shm = shm1 * (NRW_T == 4 ? 2 : 1); // (two logical workgroups per launch workgroup, see the kernel)
+    const unsigned lblocks = (unsigned)((n_channels + CPW - 1) / CPW);
+    const unsigned nblocks = NRW_T == 4 ? (lblocks + 1) / 2 : lblocks;
+    const unsigned nthreads = HM ? 64 * (NRW_T + 2) * (NRW_T == 4 ? 2 : 1) : 192;
     if (HM && (cfg.sym_rate <= 0 || cfg.out_rate / cfg.sym_rate < 9)) {
         return hipErrorInvalidValue; // the handler-mode window bookkeeping is sized for >= 9 samples per symbol
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rxw<CPW, HM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_p25_rxw<CPW, HM, NRW_T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) {
         return e;
     }
-    hipLaunchKernelGGL((k_p25_rxw<CPW, HM>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(HM ? 256 : 192), shm, st, raw,
+    if (getenv("DDN_RX_OCC")) {
+        int nb = -1;
+        hipFuncAttributes fa;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_p25_rxw<CPW, HM, NRW_T>), (int)nthreads, shm);
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_p25_rxw<CPW, HM, NRW_T>));
+        fprintf(stderr, "k_p25_rxw<%d,%d,%d>: %d blocks per CU, %d regs, %zu B dynamic LDS, %zu B static\n", CPW, (int)HM, NRW_T, nb, fa.numRegs, shm, fa.sharedSizeBytes);
+    }
+    hipLaunchKernelGGL((k_p25_rxw<CPW, HM, NRW_T>), dim3(nblocks), dim3(nthreads), shm, st, raw,
                        filt, prev_tail, fstale, n, stride, n_channels, cfg, state, sbuf_store, lbuf_store, shist_store, minring,
                        maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store, events, n_events);
     return hipGetLastError();
@@ -2855,6 +2918,15 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
                                        events, n_events, st);
         }
         if (cpw == 8) {
+            // cfg.dbg bit 16777216: four recurrence waves of two lanes (six-wave logical workgroups, two per launch workgroup).  Measured
+            // at 4096 x 48000 of the bench traffic: 6.4 ms against 5.4 ms for the two-wave shape - the one staging wave then serves four
+            // halves a tile (35 k cycles of work for a tile the recurrences finish in 29 k) and becomes the critical path; the shape
+            // pays once the slice / record stores leave that wave.  Kept selectable, off by default.
+            if (cfg->dbg & 16777216) {
+                return launch_rxw<8, true, 4>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
+                                              shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store,
+                                              events, n_events, st);
+            }
             return launch_rxw<8, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,
                                        shist_store, minring, maxring, rec, flags, counts, max_sym, lock_cfg, hstate, hh_store,
                                        events, n_events, st);
