@@ -426,7 +426,10 @@ class P25ChainResults(C.Structure):  # == ddn_p25_chain_results
                 ("d_sync_pos", C.c_void_p), ("d_nid4", C.c_void_p), ("d_tsbk", C.c_void_p), ("d_tsbk_crc", C.c_void_p),
                 ("d_ldu_words", C.c_void_p * 2), ("d_ldu_rs_data", C.c_void_p * 2), ("d_ldu_rs_status", C.c_void_p * 2),
                 ("d_lsd_bits", C.c_void_p), ("d_lsd_ok", C.c_void_p), ("d_hdu_rs_data", C.c_void_p), ("d_hdu_rs_status", C.c_void_p),
-                ("d_tdulc_rs_data", C.c_void_p), ("d_tdulc_rs_status", C.c_void_p), ("d_n_ldu", C.c_void_p),
+                ("d_tdulc_rs_data", C.c_void_p), ("d_tdulc_rs_status", C.c_void_p),
+                ("pdu_per_channel", C.c_int), ("pdu_blocks", C.c_int), ("d_n_pdu", C.c_void_p), ("d_pdu_slot", C.c_void_p),
+                ("d_pdu_header", C.c_void_p), ("d_pdu_info", C.c_void_p), ("d_pdu_blocks", C.c_void_p), ("d_pdu_block_valid", C.c_void_p),
+                ("d_n_ldu", C.c_void_p),
                 ("d_imbe_bits", C.c_void_p), ("d_imbe_result", C.c_void_p), ("d_pcm", C.c_void_p), ("d_synth_result", C.c_void_p)]
 
 

@@ -62,6 +62,11 @@ struct ddn_p25_chain {
     int16_t* d_lsd_llr;
     uint8_t *d_hdu_hex, *d_hdu_par, *d_hdu_st, *d_hdu_d, *d_hdu_p, *d_hdu_rs;
     uint8_t *d_td_d, *d_td_p, *d_td_st, *d_td_rd, *d_td_rp, *d_td_rs;
+    // data units (DUID 0xC): PF entries per channel and call, PB data blocks each
+    int PF, PB;
+    int32_t *d_pdu_slot, *d_pdu_info, *d_n_pdu, *d_pdu_metric;
+    uint8_t *d_pdu_hdr, *d_pdu_valid, *d_pdu_blocks;
+    int16_t* d_pdu_llr;
     int64_t* d_first;
     int32_t *d_sc, *d_nldu, *d_sc_out, *d_imbe_res, *d_res_out;
     uint8_t *d_imbe_fr, *d_imbe_soft, *d_imbe_fl, *d_imbe_d;
@@ -113,7 +118,8 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
                    c->d_rs_st[0], c->d_rs_st[1], c->d_lsd, c->d_lsd_ok, c->d_lsd_llr, c->d_hdu_hex, c->d_hdu_par, c->d_hdu_st,
                    c->d_hdu_d, c->d_hdu_p, c->d_hdu_rs, c->d_td_d, c->d_td_p, c->d_td_st, c->d_td_rd, c->d_td_rp, c->d_td_rs,
                    c->d_first, c->d_sc, c->d_nldu, c->d_sc_out, c->d_imbe_res, c->d_res_out, c->d_imbe_fr, c->d_imbe_soft,
-                   c->d_imbe_fl, c->d_imbe_d, c->d_pcm, c->d_iq[0], c->d_iq[1]};
+                   c->d_imbe_fl, c->d_imbe_d, c->d_pcm, c->d_iq[0], c->d_iq[1], c->d_pdu_slot, c->d_pdu_info, c->d_n_pdu,
+                   c->d_pdu_metric, c->d_pdu_hdr, c->d_pdu_valid, c->d_pdu_blocks, c->d_pdu_llr};
     for (void* p : all) {
         (void)hipFree(p);
     }
@@ -169,6 +175,8 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
     c->Fv = cfg->max_ldu > 0 ? cfg->max_ldu : cfg->samples_per_call / 8640 + 3;
     c->E = cfg->max_events > 0 ? cfg->max_events : 4 * c->F;
     c->EL = c->E + 64; // + the decisions inside a carried tail
+    c->PF = 2;         // data units per channel and call (a second's worth of calls rarely holds one)
+    c->PB = 8;         // data blocks per unit: header + 8 blocks = 57 + 9 * 101 symbols lie inside the carried tail's reach
     int rc = DDN_OK;
     do {
         ddn_front_end_config fc = {c->B, 48000, 4800, 4, DDN_LPF_P25_C4FM, cfg->input_format, cfg->block_len, 0.0f};
@@ -214,7 +222,10 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
              && dalloc(&c->d_first, V) && dalloc(&c->d_sc, V) && dalloc(&c->d_nldu, B) && dalloc(&c->d_sc_out, V)
              && dalloc(&c->d_imbe_res, V * 5) && dalloc(&c->d_res_out, V * 5) && dalloc(&c->d_imbe_fr, V * 184)
              && dalloc(&c->d_imbe_soft, V * 368) && dalloc(&c->d_imbe_fl, V) && dalloc(&c->d_imbe_d, V * 88)
-             && dalloc(&c->d_pcm, V * 160);
+             && dalloc(&c->d_pcm, V * 160) && dalloc(&c->d_pdu_slot, B * (size_t)c->PF) && dalloc(&c->d_pdu_info, B * (size_t)c->PF * 4)
+             && dalloc(&c->d_n_pdu, B) && dalloc(&c->d_pdu_hdr, B * (size_t)c->PF * 12)
+             && dalloc(&c->d_pdu_valid, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_blocks, B * (size_t)c->PF * (size_t)c->PB * 12)
+             && dalloc(&c->d_pdu_metric, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_llr, B * (size_t)c->PF * (size_t)c->PB * 196);
         if (!ok) {
             ddn_set_error("ddn_p25_chain_create: device allocation failed");
             rc = DDN_ENOMEM;
@@ -387,6 +398,18 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
         HIP_TRY(ddn_dev_chain_frames(c->d_evl[cur], c->d_evdl[cur], c->d_nevl[cur], c->EL, d_sp, d_ns, c->B, c->F, c->off97[0],
                                      c->off97[1], c->off97[2], c->d_nid, c->d_tsbk, c->d_tsbk_crc, c->d_cls, c->d_lists, c->d_list_n,
                                      st));
+    }
+    // data units (DUID 0xC): the header the loop decoded + the data blocks behind it (half-rate trellis, best path) + CRC32
+    {
+        const int32_t *d_ns = nullptr, *d_sp = nullptr;
+        DDN_TRY(ddn_p25p1_framer_device_syncs(c->fr, &d_ns, &d_sp));
+        const size_t NE = (size_t)c->B * (size_t)c->PF, NB = NE * (size_t)c->PB;
+        HIP_TRY(ddn_dev_chain_pdu_index(c->d_evl[cur], c->d_evdl[cur], c->d_nevl[cur], c->EL, d_sp, d_ns, c->d_nid, c->B, c->F, c->off97[0],
+                                        c->PF, c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_n_pdu, st));
+        HIP_TRY(ddn_dev_chain_pdu_gather(rec, c->d_cnt_full, stride, d_sp, c->d_pdu_slot, c->d_pdu_info, c->B, c->F, c->PF, c->PB,
+                                         c->d_pdu_llr, c->d_pdu_valid, st));
+        DDN_TRY(ddn_fec_p25_12_soft_batch(c->d_pdu_llr, NB, c->d_pdu_blocks, c->d_pdu_metric, st));
+        HIP_TRY(ddn_dev_chain_pdu_finish(c->d_pdu_slot, c->d_pdu_blocks, c->d_pdu_valid, (int)NE, c->PB, c->d_pdu_hdr, c->d_pdu_info, st));
     }
     // The frame FEC below (per-type work lists) and the voice stage (voice index by NID -> IMBE frames -> PCM) read the same records
     // and NIDs and write nothing the other reads: the voice stage runs on a stream of its own beside the FEC (0.7 ms of small
@@ -675,6 +698,14 @@ ddn_p25_chain_get_results(ddn_p25_chain* c, ddn_p25_chain_results* r) {
     r->d_hdu_rs_status = c->d_hdu_rs;
     r->d_tdulc_rs_data = c->d_td_rd;
     r->d_tdulc_rs_status = c->d_td_rs;
+    r->pdu_per_channel = c->PF;
+    r->pdu_blocks = c->PB;
+    r->d_n_pdu = c->d_n_pdu;
+    r->d_pdu_slot = c->d_pdu_slot;
+    r->d_pdu_header = c->d_pdu_hdr;
+    r->d_pdu_info = c->d_pdu_info;
+    r->d_pdu_blocks = c->d_pdu_blocks;
+    r->d_pdu_block_valid = c->d_pdu_valid;
     r->d_n_ldu = c->d_nldu;
     r->d_imbe_bits = c->d_imbe_d;
     r->d_imbe_result = c->d_imbe_res;

@@ -263,6 +263,176 @@ k_chain_frames(const int32_t* __restrict__ list, const int32_t* __restrict__ dat
     }
 }
 
+// ---- P25 Phase 1 data units (DUID 0xC, processMPDU(), src/protocol/p25/phase1/p25p1_mdpu.c) -------------------------------------
+// The header block is decoded inside the receive loop (its blocks-to-follow field decides how long the frame is read: event kind 3,
+// p25_mpdu_update_header_from_first_block :309-326); the data blocks behind it are decoded here.  k_chain_pdu_index: one thread per
+// channel files the call's data units - entry = channel * PF + rank in air order: the frame slot, the header as the loop decoded it
+// {12 bytes, CRC16 good}, the number of blocks the reference reads (ctx->end, 3 when the header's CRC fails) - so that every later
+// array has a fixed place.  k_chain_pdu_gather: block b >= 1 of an entry -> its 98 dibits' LLR pairs in received order (payload
+// dibit n = 56 + 98 b + j of the frame sits at frame symbol n + n / 35: a status symbol follows every 35 dibits, :195-217).
+// k_chain_pdu_finish: header fields, the data blocks' bytes, CRC32 over the data (crc32mbf :47-60, p25_mpdu_handle_rate12 :636-650),
+// and - when the first header fails its CRC16 and the header says nothing about the length - the reference's first fallback: blocks
+// 1 and 2 read as repetitions of the header, the first one with a good CRC16 taken (p25_mpdu_finalize_header :381-395).
+__global__ void
+k_chain_pdu_index(const int32_t* __restrict__ list, const int32_t* __restrict__ data, const int32_t* __restrict__ n_list, int EL,
+                  const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_syncs, const int32_t* __restrict__ nid4,
+                  int n_channels, int F, int off0, int PF, int32_t* __restrict__ pdu_slot, uint8_t* __restrict__ pdu_hdr,
+                  int32_t* __restrict__ pdu_info, int32_t* __restrict__ n_pdu) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) {
+        return;
+    }
+    const int ns = n_syncs[c] < F ? n_syncs[c] : F;
+    const int32_t* sp = sync_pos + (size_t)c * F;
+    const int4* l = reinterpret_cast<const int4*>(list) + (size_t)c * EL;
+    const int4* d = reinterpret_cast<const int4*>(data) + (size_t)c * EL;
+    const int n = n_list[c] < EL ? n_list[c] : EL;
+    int k = 0, r = 0, total = 0;
+    for (int j = 0; j < n; j++) {
+        const int4 e = l[j];
+        if (e.y != 3) {
+            continue;
+        }
+        const int a = e.x - off0;
+        while (k < ns && sp[k] < a) {
+            k++;
+        }
+        if (k >= ns || sp[k] != a) {
+            continue; // the frame's sync is carried on to the next call
+        }
+        const size_t slot = (size_t)c * F + k;
+        if (nid4[slot * 4] <= 0 || nid4[slot * 4 + 2] != 0xC) {
+            continue;
+        }
+        total++;
+        if (r >= PF) {
+            continue;
+        }
+        const int4 v = d[j];
+        const size_t o = (size_t)c * PF + r;
+        pdu_slot[o] = (int32_t)slot;
+        uint32_t* h = reinterpret_cast<uint32_t*>(pdu_hdr + o * 12);
+        h[0] = (uint32_t)v.x;
+        h[1] = (uint32_t)v.y;
+        h[2] = (uint32_t)v.z;
+        pdu_info[o * 4 + 0] = v.w & 1;          // header CRC16 good
+        pdu_info[o * 4 + 1] = e.w & 0xFFFF;     // blocks the reference reads (header included)
+        pdu_info[o * 4 + 2] = 0;
+        pdu_info[o * 4 + 3] = 0;
+        r++;
+    }
+    for (int q = r; q < PF; q++) {
+        pdu_slot[(size_t)c * PF + q] = -1;
+    }
+    n_pdu[c] = total;
+}
+
+__global__ __launch_bounds__(128) void
+k_chain_pdu_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ counts, size_t max_sym, const int32_t* __restrict__ sync_pos,
+                   const int32_t* __restrict__ pdu_slot, const int32_t* __restrict__ pdu_info, int F, int PF, int PB,
+                   int16_t* __restrict__ llr, uint8_t* __restrict__ valid) {
+    const int e = blockIdx.x, b = blockIdx.y + 1, j = threadIdx.x;
+    const int slot = pdu_slot[e];
+    const int ch = e / PF;
+    const size_t o = (size_t)e * PB + (b - 1);
+    const int end = slot >= 0 ? pdu_info[(size_t)e * 4 + 1] : 0;
+    const int cnt = counts[ch] < (int)max_sym ? counts[ch] : (int)max_sym;
+    // the block's last payload dibit decides whether the whole block lies inside this call's records
+    const int n_last = 56 + 98 * b + 97;
+    const bool ok = slot >= 0 && b < end && (slot >= 0 ? sync_pos[slot] - 23 + n_last + n_last / 35 < cnt : false);
+    if (j == 0) {
+        valid[o] = ok ? 1 : 0;
+    }
+    if (j >= 98) {
+        return;
+    }
+    int l0 = 0, l1 = 0;
+    if (ok) {
+        const int nn = 56 + 98 * b + j;
+        const uint8_t* q = rec + ((size_t)ch * max_sym + (size_t)(sync_pos[slot] - 23 + nn + nn / 35)) * 10;
+        l0 = (int16_t)((uint16_t)q[2] | ((uint16_t)q[3] << 8));
+        l1 = (int16_t)((uint16_t)q[4] | ((uint16_t)q[5] << 8));
+    }
+    llr[o * 196 + 2 * j] = (int16_t)l0;
+    llr[o * 196 + 2 * j + 1] = (int16_t)l1;
+}
+
+__device__ __forceinline__ bool
+pdu_crc16_ok(const uint8_t* b12) { // crc16_lb_bridge(bits, 80) == 0 (src/protocol/p25/p25_crc.c:18-36): CRC-CCITT over 80 bits, inverted
+    uint32_t crc = 0;
+    for (int i = 0; i < 80; i++) {
+        const uint32_t bit = (b12[i >> 3] >> (7 - (i & 7))) & 1;
+        crc = (((crc >> 15) & 1) ^ bit) ? ((crc << 1) ^ 0x1021) & 0xFFFF : (crc << 1) & 0xFFFF;
+    }
+    crc ^= 0xFFFF;
+    return crc == (((uint32_t)b12[10] << 8) | b12[11]);
+}
+
+__global__ void
+k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restrict__ blocks12, const uint8_t* __restrict__ valid,
+                   int n_entries, int PB, uint8_t* __restrict__ pdu_hdr, int32_t* __restrict__ pdu_info) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries || pdu_slot[e] < 0) {
+        return;
+    }
+    uint8_t* h = pdu_hdr + (size_t)e * 12;
+    int hdr_ok = pdu_info[(size_t)e * 4 + 0];
+    const int end = pdu_info[(size_t)e * 4 + 1];
+    const uint8_t* blk = blocks12 + (size_t)e * PB * 12;
+    const uint8_t* vld = valid + (size_t)e * PB;
+    int flags = 0; // 1 header taken from repetition 1, 2 from repetition 2, 4 confirmed (rate 3/4) data: blocks not decoded here,
+                   // 8 a block lies beyond the call's records or beyond PB, 16 header unusable (every repetition fails its CRC16)
+    if (!hdr_ok) { // the header said nothing: the reference has read three blocks and tries the other two as header repetitions
+        for (int rep = 1; rep <= 2 && !hdr_ok; rep++) {
+            if (rep < end && rep - 1 < PB && vld[rep - 1] && pdu_crc16_ok(blk + (size_t)(rep - 1) * 12)) {
+                for (int i = 0; i < 12; i++) {
+                    h[i] = blk[(size_t)(rep - 1) * 12 + i];
+                }
+                hdr_ok = 1;
+                flags |= rep;
+            }
+        }
+        if (!hdr_ok) {
+            flags |= 16;
+        }
+    }
+    const int an = (h[0] >> 6) & 1, fmt = h[0] & 0x1F, blks = h[6] & 0x7F;
+    if (an == 1 && fmt == 0x16) {
+        flags |= 4;
+    }
+    int crc32_ok = 0;
+    const int nd = end - 1; // data blocks read
+    bool all = nd <= PB;
+    for (int b = 0; b < nd && b < PB; b++) {
+        all = all && vld[b] != 0;
+    }
+    if (!all) {
+        flags |= 8;
+    }
+    if (hdr_ok && !(flags & (1 | 2 | 4)) && all) { // p25_mpdu_handle_rate12(): CRC32 over the data blocks but the last four bytes
+        if (blks == 0) {
+            crc32_ok = 1;
+        } else if (blks == nd) {
+            const int len = 96 * blks - 32;
+            uint64_t crc = 0;
+            for (int i = 0; i < len; i++) {
+                crc <<= 1;
+                const int bit = (blk[i >> 3] >> (7 - (i & 7))) & 1;
+                if (((crc >> 32) ^ (uint64_t)bit) & 1) {
+                    crc ^= 0x04c11db7ull;
+                }
+            }
+            const uint32_t got = (uint32_t)((crc & 0xffffffffull) ^ 0xffffffffull);
+            const uint8_t* t = blk + (size_t)blks * 12 - 4;
+            const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+            crc32_ok = got == want ? 1 : 0;
+        }
+    }
+    pdu_info[(size_t)e * 4 + 0] = hdr_ok;
+    pdu_info[(size_t)e * 4 + 2] = flags;
+    pdu_info[(size_t)e * 4 + 3] = crc32_ok;
+}
+
 // NXDN voice stage bookkeeping (nxdn_voice(): the LICH's profile says which of a frame's four 36-dibit fields are voice): the
 // first vf sync slots of every channel feed the voice gather; field v of slot (c, j) is skipped unless the LICH parity held, the
 // frame is complete and the LICH value announces voice in that half.
@@ -488,6 +658,40 @@ ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_
     }
     hipLaunchKernelGGL(k_chain_frames, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, list, data, n_list, EL, sync_pos,
                        n_syncs, n_channels, F, off0, off1, off2, nid4, tsbk, tsbk_crc, cls, lists, list_n);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pdu_index(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
+                        const int32_t* n_syncs, const int32_t* nid4, int n_channels, int F, int off0, int PF, int32_t* pdu_slot,
+                        uint8_t* pdu_hdr, int32_t* pdu_info, int32_t* n_pdu, hipStream_t st) {
+    if (n_channels <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_pdu_index, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, list, data, n_list, EL, sync_pos,
+                       n_syncs, nid4, n_channels, F, off0, PF, pdu_slot, pdu_hdr, pdu_info, n_pdu);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pdu_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos, const int32_t* pdu_slot,
+                         const int32_t* pdu_info, int n_channels, int F, int PF, int PB, int16_t* llr, uint8_t* valid, hipStream_t st) {
+    if (n_channels <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_pdu_gather, dim3((unsigned)(n_channels * PF), (unsigned)PB), dim3(128), 0, st, rec, counts, max_sym, sync_pos,
+                       pdu_slot, pdu_info, F, PF, PB, llr, valid);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, int n_entries, int PB, uint8_t* pdu_hdr,
+                         int32_t* pdu_info, hipStream_t st) {
+    if (n_entries <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_pdu_finish, dim3((unsigned)((n_entries + 63) / 64)), dim3(64), 0, st, pdu_slot, blocks12, valid, n_entries, PB,
+                       pdu_hdr, pdu_info);
     return hipGetLastError();
 }
 

@@ -296,6 +296,14 @@ hipError_t ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, i
 hipError_t ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_prev, const int32_t* n_prev, const int32_t* new_prev,
                                 int have_prev, const int32_t* ev_new, const int32_t* evd_new, const int32_t* n_new, int E, int EL, int T,
                                 int n_channels, int32_t* list_cur, int32_t* data_cur, int32_t* n_cur, hipStream_t st);
+hipError_t ddn_dev_chain_pdu_index(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
+                                   const int32_t* n_syncs, const int32_t* nid4, int n_channels, int F, int off0, int PF,
+                                   int32_t* pdu_slot, uint8_t* pdu_hdr, int32_t* pdu_info, int32_t* n_pdu, hipStream_t st);
+hipError_t ddn_dev_chain_pdu_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
+                                    const int32_t* pdu_slot, const int32_t* pdu_info, int n_channels, int F, int PF, int PB,
+                                    int16_t* llr, uint8_t* valid, hipStream_t st);
+hipError_t ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, int n_entries, int PB,
+                                    uint8_t* pdu_hdr, int32_t* pdu_info, hipStream_t st);
 hipError_t ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
                                 const int32_t* n_syncs, int n_channels, int F, int off0, int off1, int off2, int32_t* nid4,
                                 uint8_t* tsbk, uint8_t* tsbk_crc, uint8_t* cls, int32_t* lists, int32_t* list_n, hipStream_t st);

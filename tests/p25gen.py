@@ -120,6 +120,54 @@ def make_pdu(rng, nac, blks, sap=0, good_crc=True):
     return fr
 
 
+def crc32mbf(data, nbits):
+    """crc32mbf() of src/protocol/p25/phase1/p25p1_mdpu.c:47-60 over the first nbits of `data` (bytes, MSB first)"""
+    crc = 0
+    for i in range(nbits):
+        crc <<= 1
+        b = (int(data[i // 8]) >> (7 - (i % 8))) & 1
+        if ((crc >> 32) ^ b) & 1:
+            crc ^= 0x04C11DB7
+    return (crc & 0xFFFFFFFF) ^ 0xFFFFFFFF
+
+
+def make_pdu_coded(rng, nac, blks, sap=0, good_crc16=True, good_crc32=True, confirmed=False, header_reps=0):
+    """an unconfirmed data unit as the reference decodes it: header block (CRC16), blks half-rate coded data blocks whose last four
+    bytes are the CRC32 of the rest -> (dibits, header12, data [blks][12]).  header_reps > 0 (with good_crc16 = False and blks = 0 in
+    the header): the first header fails its CRC16 and header_reps good copies follow, as the reference's repetition fallback expects"""
+    hdr = rng.integers(0, 256, 10)
+    hdr[0] = (int(hdr[0]) & 0xA0) | ((0x40 | 0x16) if confirmed else (int(hdr[0]) & 0x0F))      # AN / format
+    hdr[1] = (int(hdr[1]) & 0xC0) | (sap & 0x3F)
+    hdr[6] = (int(hdr[6]) & 0x80) | (blks & 0x7F)
+    c = crc16_ccitt(hdr)
+    good = np.array(list(hdr) + [c >> 8, c & 0xFF], np.uint8)
+    bad = good.copy()
+    bad[10] ^= 0x5A
+    bad[3] ^= 0x81
+    first = good if good_crc16 else bad
+    pay = list(encode_half_rate(list(first)))
+    data = np.zeros((max(blks, header_reps), 12), np.uint8)
+    if header_reps:
+        for k in range(header_reps):
+            data[k] = good
+    elif blks:
+        flat = rng.integers(0, 256, 12 * blks).astype(np.uint8)
+        c32 = crc32mbf(flat, 96 * blks - 32) ^ (0 if good_crc32 else 0x00010000)
+        flat[-4:] = [(c32 >> 24) & 0xFF, (c32 >> 16) & 0xFF, (c32 >> 8) & 0xFF, c32 & 0xFF]
+        data = flat.reshape(blks, 12)
+    for k in range(len(data)):
+        pay += list(encode_half_rate(list(data[k])))
+    n_pay = 24 + 32 + len(pay)
+    flen = -(-n_pay // 35) * 36
+    fr = np.zeros(flen, np.int8)
+    stat = list(range(35, flen, 36))
+    pos = [p for p in range(flen) if p not in stat]
+    body = list(orc.P25_FS_DIBITS) + nid_dibits(nac, 0xC) + pay
+    fr[pos[:len(body)]] = body
+    fr[stat] = 2
+    return fr, first, data
+
+
 def frame_with_duid(rng, nac, duid, n_body):
     """FS + NID of the given DUID + n_body random dibits (status symbols 2 where the frame has them)"""
     fr = np.zeros(24 + 33 + n_body, np.int8)

@@ -10,6 +10,7 @@ import pytest
 import chain_stream
 import ddn
 import mbe
+import orc
 import p25gen
 from conftest import golden
 
@@ -256,6 +257,124 @@ def test_run_host_copies_back_what_the_device_holds(built):
     ch.close()
     for p in pinned + h_iq:
         l.ddn_host_free_pinned(p)
+
+
+def test_data_units_header_blocks_and_crc32(built):
+    """P25 data units (DUID 0xC, processMPDU): the chain files every unit of a call - header as the loop decoded it, the data blocks
+    behind it through the half-rate trellis (best path, p25p1_mdpu.c:263-273), CRC32 over the data (crc32mbf) - and follows the
+    reference's first fallback when the header fails its CRC16 (blocks 1 / 2 read as header repetitions).  Stream in calls + flush
+    against the restatement on the whole stream (the handlers' header decisions from the loop oracle, the blocks from the oracle's
+    half-rate list decoder, candidate 0), units that straddle a call boundary included; confirmed (rate 3/4) units are flagged"""
+    rng = np.random.default_rng(11)
+    nac = 0x293
+    units = []
+    parts = []
+    plan = [dict(blks=2), dict(blks=0), dict(blks=5), dict(blks=1, good_crc32=False), dict(blks=3, confirmed=True),
+            dict(blks=0, good_crc16=False, header_reps=2), dict(blks=7), dict(blks=4), dict(blks=2, good_crc16=False), dict(blks=6)]
+    for kw in plan:
+        fr, hdr, data = p25gen.make_pdu_coded(rng, nac, **kw)
+        units.append((kw, hdr, data, sum(len(q) for q in parts)))
+        parts += [fr, np.zeros(int(rng.integers(20, 60)), np.int8)]
+    dib = np.concatenate(parts)
+    n_call = 9000
+    calls = -(-(len(dib) * 10 + 600) // n_call)
+    iq = p25gen.modulate_cu8(dib, n_call * calls, lead=260, seed=9, noise=0.02)[None]
+    ch = ddn.P25ChainC(1, n_call)
+    PFn = PBn = None
+    got = {}
+    base = 0
+    for k in range(calls + 1):
+        if k < calls:
+            d = _upload(np.ascontiguousarray(iq[:, k * n_call:(k + 1) * n_call]))
+            ch.run(d)
+            ch.wait()
+            ddn.lib().ddn_device_free(d)
+        else:
+            ch.flush()
+        r = ch.results()
+        PFn, PBn = r.pdu_per_channel, r.pdu_blocks
+        npdu = int(ch.fetch(r.d_n_pdu, np.int32, (1,))[0])
+        slot = ch.fetch(r.d_pdu_slot, np.int32, (PFn,))
+        hdr = ch.fetch(r.d_pdu_header, np.uint8, (PFn, 12))
+        info = ch.fetch(r.d_pdu_info, np.int32, (PFn, 4))
+        blk = ch.fetch(r.d_pdu_blocks, np.uint8, (PFn, PBn, 12))
+        vld = ch.fetch(r.d_pdu_block_valid, np.uint8, (PFn, PBn))
+        pos = ch.fetch(r.d_sync_pos, np.int32, (ch.F,))
+        assert npdu <= PFn
+        for e in range(PFn):
+            if slot[e] >= 0:
+                g = base + int(pos[slot[e] % ch.F]) - ch.T
+                assert g not in got
+                got[g] = (hdr[e].copy(), info[e].copy(), blk[e].copy(), vld[e].copy())
+        base += int(ch.fetch(r.d_new, np.int32, (1,))[0])
+    ch.close()
+    want = chain_stream.run_stream(iq[0], n_call, seed=0, vocoder=False)
+    rec4 = want["rec4"]
+    cnt = len(want["sym"])
+    evs = {int(e[0]): (e, d) for e, d in zip(want["events"], want["event_data"]) if e[1] == 3}
+    pdus = [a for a, f in sorted(want["frames"].items()) if "nid" in f and f["nid"][0] > 0 and f["nid"][2] == 0xC and a + 33 + 101 in evs]
+    assert sorted(got) == pdus and len(pdus) >= len(plan) - 1, (sorted(got), pdus)
+    # which unit a decoded sync belongs to: the stream positions differ by a constant (lead, filter delays)
+    shift = int(np.median([a - u[3] for a, u in zip(pdus, units)])) if len(pdus) == len(units) else None
+    if shift is None:
+        shift = min((pdus[0] - units[0][3], pdus[-1] - units[-1][3]), key=abs)
+    by_pos = {u[3]: u for u in units}
+    seen_flags = set()
+    for a in pdus:
+        near = min(by_pos, key=lambda q: abs(a - shift - q))
+        assert abs(a - shift - near) <= 3, (a, shift, near)
+        kw, hdr_sent, data_sent, _ = by_pos[near]
+        e, d = evs[a + 33 + 101]
+        w_hdr = d[:3].copy().view(np.uint8)
+        w_crc, w_end = int(d[3]) & 1, int(e[3]) & 0xFFFF
+        hdr, info, blk, vld = got[a]
+        blocks = []
+        for b in range(1, w_end):
+            idx = [a - 23 + n + n // 35 for n in range(56 + 98 * b, 56 + 98 * b + 98)]
+            if idx[-1] >= cnt or b > PBn:
+                blocks.append(None)
+                continue
+            llr = np.stack([rec4[idx, 2], rec4[idx, 3]], axis=1).reshape(196)
+            o = orc.oracle()
+            o.orc_p25_12_soft_llr_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            ob, om = np.zeros((8, 12), np.uint8), np.zeros(8, np.uint32)
+            assert o.orc_p25_12_soft_llr_list(np.ascontiguousarray(llr, np.int16).ctypes.data, ob.ctypes.data, om.ctypes.data, 8) >= 1
+            blocks.append(ob[0].copy())
+        flags = 0
+        ok = w_crc
+        if not ok:
+            for rep in (1, 2):
+                bb = blocks[rep - 1] if rep < w_end and rep - 1 < len(blocks) else None
+                if bb is not None and p25gen.crc16_ccitt(bb[:10]) == ((int(bb[10]) << 8) | int(bb[11])):
+                    w_hdr, ok, flags = bb, 1, flags | rep
+                    break
+            if not ok:
+                flags |= 16
+        if (w_hdr[0] >> 6) & 1 and (w_hdr[0] & 0x1F) == 0x16:
+            flags |= 4
+        if any(b is None for b in blocks):
+            flags |= 8
+        blks = int(w_hdr[6]) & 0x7F
+        crc32 = 0
+        if ok and not (flags & 15):
+            if blks == 0:
+                crc32 = 1
+            elif blks == w_end - 1:
+                flat = np.concatenate(blocks)
+                crc32 = int(p25gen.crc32mbf(flat, 96 * blks - 32) == int.from_bytes(bytes(flat[-4:].tolist()), "big"))
+        assert np.array_equal(hdr, w_hdr) and tuple(info) == (ok, w_end, flags, crc32), (a, kw, hdr, w_hdr, info, (ok, w_end, flags, crc32))
+        for b, bb in enumerate(blocks):
+            if bb is not None:
+                assert vld[b] == 1 and np.array_equal(blk[b], bb), (a, b)
+            elif b < PBn:
+                assert vld[b] == 0
+        seen_flags.add(flags)
+        # the clean units decode to what was sent
+        if kw.get("good_crc16", True) and not kw.get("confirmed"):
+            assert ok == 1 and np.array_equal(hdr, hdr_sent) and w_end == kw["blks"] + 1
+            assert crc32 == (1 if kw.get("good_crc32", True) else 0), (a, kw)
+            assert all(np.array_equal(blk[b], data_sent[b]) for b in range(kw["blks"]))
+    assert {0, 1, 4} <= seen_flags, seen_flags
 
 
 def test_syncs_beyond_the_frame_slots_are_counted_not_lost_silently(built):
