@@ -43,7 +43,7 @@ N_SAMPLES = 48000
 BLOCK = 8192
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
 N_BASE = 64                  # distinct channels of each traffic kind
-RXW_TRAFFIC_BYTES = 2.806e9   # profiles/r03_bench_pmc_FETCH_SIZE.txt, _WRITE_SIZE.txt: 2 x 782 516 KB + 1 240 722 KB per launch of k_p25_rxw<8, true>
+RXW_TRAFFIC_BYTES = 2.799e9   # profiles/r04_bench_pmc_FETCH_SIZE.txt, _WRITE_SIZE.txt: 2 x 781 238 KB + 1 236 434 KB per launch of k_p25_rxw<8, true, 2>
 
 
 def make_base_traffic(n):
@@ -557,7 +557,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_p25_rxw", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # HBM bytes per launch of k_p25_rxw from separate rocprofv3 --pmc passes of this command on this shape
-                         # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B; profiles/r03_bench_pmc_*.txt)
+                         # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B; profiles/r04_bench_pmc_*.txt)
                          "traffic": RXW_TRAFFIC_BYTES if (B == B_PER_GPU and n == N_SAMPLES) else None,
                          "algorithmic_bytes": alg_bytes, "bytes_per_sample": round(alg_bytes / (B * n), 3),
                          "launch_ms": round(dom_ms, 4), "launches_averaged": int(rx_timed_n.value),
@@ -569,6 +569,13 @@ def main():
         if world == 1 and not args.no_extras:
             line["front_end_stage"] = front_end_stage(torch, ddn, chain, d_iq, B, n, 12)
             line["pcie_inclusive"] = pcie_inclusive(torch, ddn, chain, d_iq, B, n)
+            # `value` is the bench contract's figure (inputs resident in HBM when the timed region starts); SURVEY 8(d)'s wall time with the
+            # I/Q coming from pinned host memory and the results going back is reported beside it, both forms
+            line["value_pcie_inclusive"] = {"compact_results_Msamples_per_s": line["pcie_inclusive"]["compact"]["Msamples_per_s"],
+                                            "compact_results_ms_per_step": line["pcie_inclusive"]["compact"]["ms_per_step"],
+                                            "all_results_Msamples_per_s": line["pcie_inclusive"]["Msamples_per_s"],
+                                            "all_results_ms_per_step": line["pcie_inclusive"]["ms_per_step"],
+                                            "resident_ms_per_step": line["ms_per_step"]}
             line["vocoder_c5"] = vocoder_c5(torch, ddn, np, 10)
         if mixed is not None:
             line["configs3_mixed"] = mixed
@@ -740,8 +747,8 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
 
 def pcie_inclusive(torch, ddn, chain, d_iq, B, n):
     """the same step with the raw I/Q coming from pinned host memory and the results going back to it -
-    ddn_p25_chain_run_host: the H2D copy of step k + 1 and the D2H copy of step k - 1 run on two copy streams beside the kernels of
-    step k.  Two result sets: everything (10-byte records + flags + counts + handler decisions + NIDs + TSDU blocks + PCM) and the
+    ddn_p25_chain_run_host: the H2D copy of step k + 1 and the D2H copies of step k - 1 run on two copy streams beside the kernels of
+    step k (the result copies beside its receive loop).  Two result sets: everything (10-byte records + flags + counts + handler decisions + NIDs + TSDU blocks + PCM) and the
     compact one (records as {dibit | flags, reliability} pairs - `records2` - instead of the 10-byte records and the flag bytes).
     Never `value`."""
     l = ddn.lib()
@@ -787,7 +794,8 @@ def pcie_inclusive(torch, ddn, chain, d_iq, B, n):
     out = run(full)
     out["note"] = ("pinned host I/Q in; records + flags + counts + handler decisions + NIDs + TSDU blocks + PCM out; copies on two copy "
                    "streams beside the kernels (ddn_p25_chain_run_host), steady state over 6 steps.  The H2D copies are SDMA "
-                   "transfers and hide; the D2H copies are shader kernels on this ROCm and wait for the receive loop (DESIGN 6)")
+                   "transfers; the D2H copies are shader kernels on this ROCm: a call's results are released when the NEXT call's "
+                   "receive loop starts and leave beside it (DESIGN 6)")
     out["compact"] = run(compact)
     out["compact"]["note"] = ("the same with the records as {dibit | flags << 2, reliability} pairs (records2) instead of records10 + flags "
                               "and the synthesized PCM frames dense (pcm_dense / pcm_slot / pcm_count, host capacity a third of the slots) "
