@@ -121,3 +121,38 @@ def test_p25_receive_loop_restatement_agrees_with_the_general_symbolizer(built):
         got.append(out.value)
         pos += k
     assert len(got) == len(sym) and np.array_equal(np.array(got, np.float32).view(np.uint32), sym.view(np.uint32))
+
+
+def test_division_by_five_as_mul_and_two_fma_is_the_ieee_quotient(tmp_path):
+    """the lean run's x / 5.0f (dsd_symbol.c's window mean) is computed as q = x * RN(1/5), r = fma(-5, q, x), q + r * RN(1/5)
+    (ddn_rx.hip: div5_exact).  That equals the correctly rounded quotient for every finite binary32 x except -0 - checked over all
+    2^32 patterns once (64 s); here every 251st pattern plus the neighbourhood of every power of two, compiled with the host's gcc"""
+    import subprocess
+    src = tmp_path / "div5.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+static int check(uint32_t u) {
+    float x; memcpy(&x, &u, 4);
+    if (!isfinite(x) || u == 0x80000000u) return 0;
+    volatile float want = x / 5.0f;
+    const float y = 0.2f, q0 = x * y, r = fmaf(-5.0f, q0, x), q1 = fmaf(r, y, q0);
+    float w = want; uint32_t a, c; memcpy(&a, &w, 4); memcpy(&c, &q1, 4);
+    return a != c;
+}
+int main(void) {
+    unsigned long bad = 0, n = 0;
+    for (uint64_t b = 0; b < (1ull << 32); b += 251) { bad += check((uint32_t)b); n++; }
+    for (uint32_t e = 0; e < 256; e++) for (uint32_t s = 0; s < 2; s++) for (int d = -4096; d <= 4096; d++) { bad += check(((s << 31) | (e << 23)) + (uint32_t)d); n++; }
+    printf("%lu %lu\n", n, bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "div5"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout
+    n, bad = map(int, out.stdout.split())
+    assert n > 2 ** 24 and bad == 0
