@@ -1952,6 +1952,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             bool respin = false; // handler mode: the last pass only waited for an answer (no trip was spent)
             int blk_o = -1;      // bulk hunting pass: output index at which it left this lane's next symbol to the standard trip
             while (true) {
+                const long long dbg_p0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
+                long long dbg_p1 = 0;
                 if (HM && __any(hwait)) {
                     if (hwait
                         && __hip_atomic_load(&H.rsp_seq[ln], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == hseq) {
@@ -2164,6 +2166,9 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         continue;
                     }
                 }
+                if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                    dbg_p1 = (long long)clock64();
+                }
                 // hand the previous trip's symbols (one per lane at most) to wave 1: one 16-byte LDS write at a wave-uniform slot
                 if (!respin) {
                     if (offload && tk > 0 && tk <= QTW && lane < LPR) {
@@ -2266,6 +2271,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             dbg_run[5] += (HM && __any(hwait)) ? 1 : 0;
                             dbg_run[7]++;
                             dbg_l0 = (long long)clock64();
+                            dbg_run[2] += dbg_p1 - dbg_p0;  // pass top: handler answers, bulk-pass test
+                            dbg_run[3] += dbg_l0 - dbg_p1;  // queue hand-over, lean tests, entry proof, run length
                         }
                         if (lean) {
                             const float* pw = (s.filter_on ? frow : rrow) + base + sp + k0;

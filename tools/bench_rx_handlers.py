@@ -95,5 +95,7 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
         run = np.stack([r[c, -320:-256] for c in range(0, B, cpw)]).copy().view(np.int64).sum(axis=0)
         extra += "\n   lean runs: %.2f per tile, %.2f trips and %.2f phases each (%.2f of them polling a handler mailbox), %.0f cycles inside the run per trip" % (
             run[0] / (len(sec) * tiles), run[1] / max(1, run[0]), run[7] / max(1, run[0]), run[5] / max(1, run[0]), run[6] / max(1, run[1]))
+        extra += "\n   a lean run's pass: %.0f cycles from the pass's top to the bulk test's end, %.0f from there to the run's first trip" % (
+            run[2] / max(1, run[0]), run[3] / max(1, run[0]))
     print("%-8s cpw %2d: loop %.3f ms (mf %.3f) in-frame share %.3f syncs/ch %.1f%s" % (
         mode, cpw, t[1], t[0], (flc & 1).mean() * ms / (n / 10), (flc & 2).sum() / B, extra), flush=True)
