@@ -428,7 +428,7 @@ class P25ChainResults(C.Structure):  # == ddn_p25_chain_results
                 ("d_lsd_bits", C.c_void_p), ("d_lsd_ok", C.c_void_p), ("d_hdu_rs_data", C.c_void_p), ("d_hdu_rs_status", C.c_void_p),
                 ("d_tdulc_rs_data", C.c_void_p), ("d_tdulc_rs_status", C.c_void_p),
                 ("pdu_per_channel", C.c_int), ("pdu_blocks", C.c_int), ("d_n_pdu", C.c_void_p), ("d_pdu_slot", C.c_void_p),
-                ("d_pdu_header", C.c_void_p), ("d_pdu_info", C.c_void_p), ("d_pdu_blocks", C.c_void_p), ("d_pdu_block_valid", C.c_void_p),
+                ("d_pdu_header", C.c_void_p), ("d_pdu_info", C.c_void_p), ("d_pdu_blocks", C.c_void_p), ("d_pdu_block_valid", C.c_void_p), ("d_pdu_blocks18", C.c_void_p), ("d_pdu_crc9_ok", C.c_void_p),
                 ("d_n_ldu", C.c_void_p),
                 ("d_imbe_bits", C.c_void_p), ("d_imbe_result", C.c_void_p), ("d_pcm", C.c_void_p), ("d_synth_result", C.c_void_p)]
 
@@ -446,6 +446,9 @@ PROTOTYPES.update({
     "ddn_mbe_batch_load_tables_file": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ddn_mbe_batch_tables_synthetic": (C.c_int, [C.c_void_p]),
     "ddn_p25p1_framer_device_dropped": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_mbf34_list_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_fec_p25_mbf34_list_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "p25_mbf34_decode_soft_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ddn_p25_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_chain_destroy": (None, [C.c_void_p]),
     "ddn_p25_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -65,7 +65,8 @@ struct ddn_p25_chain {
     // data units (DUID 0xC): PF entries per channel and call, PB data blocks each
     int PF, PB;
     int32_t *d_pdu_slot, *d_pdu_info, *d_n_pdu, *d_pdu_metric;
-    uint8_t *d_pdu_hdr, *d_pdu_valid, *d_pdu_blocks;
+    uint8_t *d_pdu_hdr, *d_pdu_valid, *d_pdu_blocks, *d_pdu_wanted, *d_pdu_cand, *d_pdu_blocks18, *d_pdu_crc9;
+    int32_t* d_pdu_cnt;
     int16_t* d_pdu_llr;
     int64_t* d_first;
     int32_t *d_sc, *d_nldu, *d_sc_out, *d_imbe_res, *d_res_out;
@@ -119,7 +120,8 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
                    c->d_hdu_d, c->d_hdu_p, c->d_hdu_rs, c->d_td_d, c->d_td_p, c->d_td_st, c->d_td_rd, c->d_td_rp, c->d_td_rs,
                    c->d_first, c->d_sc, c->d_nldu, c->d_sc_out, c->d_imbe_res, c->d_res_out, c->d_imbe_fr, c->d_imbe_soft,
                    c->d_imbe_fl, c->d_imbe_d, c->d_pcm, c->d_iq[0], c->d_iq[1], c->d_pdu_slot, c->d_pdu_info, c->d_n_pdu,
-                   c->d_pdu_metric, c->d_pdu_hdr, c->d_pdu_valid, c->d_pdu_blocks, c->d_pdu_llr};
+                   c->d_pdu_metric, c->d_pdu_hdr, c->d_pdu_valid, c->d_pdu_blocks, c->d_pdu_llr, c->d_pdu_wanted, c->d_pdu_cand,
+                   c->d_pdu_blocks18, c->d_pdu_crc9, c->d_pdu_cnt};
     for (void* p : all) {
         (void)hipFree(p);
     }
@@ -225,7 +227,10 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
              && dalloc(&c->d_pcm, V * 160) && dalloc(&c->d_pdu_slot, B * (size_t)c->PF) && dalloc(&c->d_pdu_info, B * (size_t)c->PF * 4)
              && dalloc(&c->d_n_pdu, B) && dalloc(&c->d_pdu_hdr, B * (size_t)c->PF * 12)
              && dalloc(&c->d_pdu_valid, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_blocks, B * (size_t)c->PF * (size_t)c->PB * 12)
-             && dalloc(&c->d_pdu_metric, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_llr, B * (size_t)c->PF * (size_t)c->PB * 196);
+             && dalloc(&c->d_pdu_metric, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_llr, B * (size_t)c->PF * (size_t)c->PB * 196)
+             && dalloc(&c->d_pdu_wanted, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_cand, B * (size_t)c->PF * (size_t)c->PB * 8 * 24)
+             && dalloc(&c->d_pdu_blocks18, B * (size_t)c->PF * (size_t)c->PB * 18) && dalloc(&c->d_pdu_crc9, B * (size_t)c->PF * (size_t)c->PB)
+             && dalloc(&c->d_pdu_cnt, B * (size_t)c->PF * (size_t)c->PB);
         if (!ok) {
             ddn_set_error("ddn_p25_chain_create: device allocation failed");
             rc = DDN_ENOMEM;
@@ -408,8 +413,15 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
                                         c->PF, c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_n_pdu, st));
         HIP_TRY(ddn_dev_chain_pdu_gather(rec, c->d_cnt_full, stride, d_sp, c->d_pdu_slot, c->d_pdu_info, c->B, c->F, c->PF, c->PB,
                                          c->d_pdu_llr, c->d_pdu_valid, st));
-        DDN_TRY(ddn_fec_p25_12_soft_batch(c->d_pdu_llr, NB, c->d_pdu_blocks, c->d_pdu_metric, st));
-        HIP_TRY(ddn_dev_chain_pdu_finish(c->d_pdu_slot, c->d_pdu_blocks, c->d_pdu_valid, (int)NE, c->PB, c->d_pdu_hdr, c->d_pdu_info, st));
+        // (d_pdu_cand: scratch for the 1/2-rate candidates first, then the rate 3/4 ones - same stream)
+        DDN_TRY(ddn_fec_p25_12_soft_list_batch(c->d_pdu_llr, NB, 8, (ddn_p25_12_candidate*)c->d_pdu_cand, c->d_pdu_cnt, st));
+        HIP_TRY(ddn_dev_chain_pdu_take_first(c->d_pdu_cand, c->d_pdu_cnt, (int)NB, c->d_pdu_blocks, c->d_pdu_metric, st));
+        // confirmed data: the same blocks through the rate 3/4 LLR list decoder, first candidate with a good CRC9 (:219-241)
+        HIP_TRY(ddn_dev_chain_pdu_r34_wanted(c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_pdu_valid, (int)NB, c->PB, c->d_pdu_wanted, st));
+        DDN_TRY(ddn_fec_p25_mbf34_list_batch(c->d_pdu_llr, NB, 8, c->d_pdu_wanted, (ddn_p25_mbf34_candidate*)c->d_pdu_cand, c->d_pdu_cnt, st));
+        HIP_TRY(ddn_dev_chain_pdu_r34_select(c->d_pdu_cand, c->d_pdu_cnt, c->d_pdu_wanted, (int)NB, c->d_pdu_blocks18, c->d_pdu_crc9, st));
+        HIP_TRY(ddn_dev_chain_pdu_finish(c->d_pdu_slot, c->d_pdu_blocks, c->d_pdu_valid, c->d_pdu_blocks18, (int)NE, c->PB, c->d_pdu_hdr,
+                                         c->d_pdu_info, st));
     }
     // The frame FEC below (per-type work lists) and the voice stage (voice index by NID -> IMBE frames -> PCM) read the same records
     // and NIDs and write nothing the other reads: the voice stage runs on a stream of its own beside the FEC (0.7 ms of small
@@ -706,6 +718,8 @@ ddn_p25_chain_get_results(ddn_p25_chain* c, ddn_p25_chain_results* r) {
     r->d_pdu_info = c->d_pdu_info;
     r->d_pdu_blocks = c->d_pdu_blocks;
     r->d_pdu_block_valid = c->d_pdu_valid;
+    r->d_pdu_blocks18 = c->d_pdu_blocks18;
+    r->d_pdu_crc9_ok = c->d_pdu_crc9;
     r->d_n_ldu = c->d_nldu;
     r->d_imbe_bits = c->d_imbe_d;
     r->d_imbe_result = c->d_imbe_res;

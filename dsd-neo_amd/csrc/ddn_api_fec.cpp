@@ -808,6 +808,54 @@ p25_12_soft_llr_list(const uint8_t* input, const int16_t* bit_llr196, ddn_p25_12
     return cnt;
 }
 
+// ---- P25 confirmed data: rate 3/4 blocks on LLR pairs (p25p1_mbf34.c) --------------------------------------------------------
+extern "C" int
+ddn_fec_p25_mbf34_list_batch(const int16_t* d_llr196, size_t n, int max_candidates, const uint8_t* d_wanted,
+                             ddn_p25_mbf34_candidate* d_candidates8, int32_t* d_counts, void* hip_stream) {
+    if (!d_llr196 || !d_candidates8 || !d_counts || max_candidates <= 0) {
+        ddn_set_error("ddn_fec_p25_mbf34_list_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    if (n == 0) {
+        return DDN_OK;
+    }
+    HIP_TRY(ddn_dev_p25_mbf34_list(d_llr196, (int)n, max_candidates, d_wanted, (uint8_t*)d_candidates8, d_counts, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fec_p25_mbf34_list_host(const int16_t* llr196, size_t n, int max_candidates, ddn_p25_mbf34_candidate* candidates8, int32_t* counts) {
+    if (!llr196 || !candidates8 || !counts || max_candidates <= 0) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * 196 * 2), c(n * 8 * sizeof(ddn_p25_mbf34_candidate)), k(n * 4);
+    if (!a.p || !c.p || !k.p || a.up(llr196)) {
+        return no_dev();
+    }
+    const int rc = ddn_fec_p25_mbf34_list_batch((const int16_t*)a.p, n, max_candidates, nullptr, (ddn_p25_mbf34_candidate*)c.p, (int32_t*)k.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (c.down(candidates8) || k.down(counts)) ? no_dev() : DDN_OK;
+}
+
+// reference: p25_mbf34_decode_soft_list (include/dsd-neo/protocol/p25/p25p1_mbf34.h:28-29); dibits is unused there too
+extern "C" int
+p25_mbf34_decode_soft_list(const uint8_t dibits[98], const int16_t bit_llr[196], ddn_p25_mbf34_candidate* candidates, int max_candidates) {
+    if (!dibits || !bit_llr || !candidates || max_candidates <= 0) {
+        return 0;
+    }
+    ddn_p25_mbf34_candidate tmp[8];
+    int32_t cnt = 0;
+    if (ddn_fec_p25_mbf34_list_host(bit_llr, 1, max_candidates, tmp, &cnt) != DDN_OK) {
+        return 0;
+    }
+    for (int i = 0; i < cnt; i++) {
+        candidates[i] = tmp[i];
+    }
+    return cnt;
+}
+
 // ---- 3/4-rate list decoder -------------------------------------------------------------------------------------------
 extern "C" int
 ddn_fec_r34_list_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, int max_candidates,

@@ -368,9 +368,76 @@ pdu_crc16_ok(const uint8_t* b12) { // crc16_lb_bridge(bits, 80) == 0 (src/protoc
     return crc == (((uint32_t)b12[10] << 8) | b12[11]);
 }
 
+// data blocks (block_idx >= 1) take the list decoder's first candidate (p25_mpdu_decode_r12_block(), :236-239), which is not always
+// p25_12_soft_llr()'s path: the two break ties at the unprotected tail differently
+__global__ void
+k_chain_pdu_take_first(const uint8_t* __restrict__ cand16, const int32_t* __restrict__ counts, int n_blocks, uint8_t* __restrict__ blocks12,
+                       int32_t* __restrict__ metric) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks) {
+        return;
+    }
+    const uint8_t* c = cand16 + (size_t)i * 8 * 16;
+    const bool have = counts[i] > 0;
+    for (int b = 0; b < 12; b++) {
+        blocks12[(size_t)i * 12 + b] = have ? c[b] : 0;
+    }
+    metric[i] = have ? (int32_t)((uint32_t)c[12] | ((uint32_t)c[13] << 8) | ((uint32_t)c[14] << 16) | ((uint32_t)c[15] << 24)) : -1;
+}
+
+// confirmed data (the first header has a good CRC16, A/N = 1, format 0x16: ctx->r34, :319): which block entries go through the rate 3/4
+// list decoder
+__global__ void
+k_chain_pdu_r34_wanted(const int32_t* __restrict__ pdu_slot, const uint8_t* __restrict__ pdu_hdr, const int32_t* __restrict__ pdu_info,
+                       const uint8_t* __restrict__ valid, int n_blocks, int PB, uint8_t* __restrict__ wanted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks) {
+        return;
+    }
+    const int e = i / PB;
+    const uint8_t* h = pdu_hdr + (size_t)e * 12;
+    const bool r34 = pdu_slot[e] >= 0 && pdu_info[(size_t)e * 4] != 0 && ((h[0] >> 6) & 1) && (h[0] & 0x1F) == 0x16;
+    wanted[i] = (r34 && valid[i]) ? 1 : 0;
+}
+
+__device__ __forceinline__ uint32_t
+pdu_crc9(const uint8_t* b18) { // p25_mpdu_candidate_crc9(): 7 DBSN bits + the 16 payload bytes, ComputeCrc9Bit (dmr_utils.c:410-435)
+    uint32_t crc = 0;
+    for (int i = 0; i < 135; i++) {
+        const int bit = i < 7 ? (b18[0] >> (7 - i)) & 1 : (b18[2 + ((i - 7) >> 3)] >> (7 - ((i - 7) & 7))) & 1;
+        crc = (((crc >> 8) & 1) ^ (uint32_t)bit) ? ((crc << 1) ^ 0x059u) : (crc << 1);
+    }
+    return (crc & 0x1FFu) ^ 0x1FFu;
+}
+
+// p25_mpdu_select_mbf34_candidate(:176-187): the first candidate whose CRC9 matches, else the cheapest
+__global__ void
+k_chain_pdu_r34_select(const uint8_t* __restrict__ cand24, const int32_t* __restrict__ counts, const uint8_t* __restrict__ wanted,
+                       int n_blocks, uint8_t* __restrict__ blocks18, uint8_t* __restrict__ crc9_ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks) {
+        return;
+    }
+    uint8_t* o = blocks18 + (size_t)i * 18;
+    int ok = 0, pick = 0;
+    const int n = wanted[i] ? counts[i] : 0;
+    for (int k = 0; k < n && !ok; k++) {
+        const uint8_t* b = cand24 + ((size_t)i * 8 + k) * 24;
+        if (pdu_crc9(b) == ((((uint32_t)b[0] & 1u) << 8) | b[1])) {
+            ok = 1;
+            pick = k;
+        }
+    }
+    for (int b = 0; b < 18; b++) {
+        o[b] = n > 0 ? cand24[((size_t)i * 8 + pick) * 24 + b] : 0;
+    }
+    crc9_ok[i] = (uint8_t)ok;
+}
+
 __global__ void
 k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restrict__ blocks12, const uint8_t* __restrict__ valid,
-                   int n_entries, int PB, uint8_t* __restrict__ pdu_hdr, int32_t* __restrict__ pdu_info) {
+                   const uint8_t* __restrict__ blocks18, int n_entries, int PB, uint8_t* __restrict__ pdu_hdr,
+                   int32_t* __restrict__ pdu_info) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries || pdu_slot[e] < 0) {
         return;
@@ -380,7 +447,8 @@ k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restri
     const int end = pdu_info[(size_t)e * 4 + 1];
     const uint8_t* blk = blocks12 + (size_t)e * PB * 12;
     const uint8_t* vld = valid + (size_t)e * PB;
-    int flags = 0; // 1 header taken from repetition 1, 2 from repetition 2, 4 confirmed (rate 3/4) data: blocks not decoded here,
+    const bool r34 = hdr_ok && ((h[0] >> 6) & 1) && (h[0] & 0x1F) == 0x16; // (from the FIRST header, as ctx->r34)
+    int flags = 0; // 1 header taken from repetition 1, 2 from repetition 2, 4 confirmed data: the blocks are rate 3/4 (blocks18),
                    // 8 a block lies beyond the call's records or beyond PB, 16 header unusable (every repetition fails its CRC16)
     if (!hdr_ok) { // the header said nothing: the reference has read three blocks and tries the other two as header repetitions
         for (int rep = 1; rep <= 2 && !hdr_ok; rep++) {
@@ -397,7 +465,9 @@ k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restri
         }
     }
     const int an = (h[0] >> 6) & 1, fmt = h[0] & 0x1F, blks = h[6] & 0x7F;
-    if (an == 1 && fmt == 0x16) {
+    (void)an;
+    (void)fmt;
+    if (r34) {
         flags |= 4;
     }
     int crc32_ok = 0;
@@ -426,6 +496,26 @@ k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restri
             const uint8_t* t = blk + (size_t)blks * 12 - 4;
             const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
             crc32_ok = got == want ? 1 : 0;
+        }
+    }
+    if (r34 && all) { // p25_mpdu_compute_rate34_crc(:501-519): CRC32 over the blocks' 16 payload bytes but the last four
+        if (blks > 0 && blks == nd) {
+            const uint8_t* b18 = blocks18 + (size_t)e * PB * 18;
+            const int len = 128 * blks - 32;
+            uint64_t crc = 0;
+            for (int i = 0; i < len; i++) {
+                crc <<= 1;
+                const int bit = (b18[(size_t)(i >> 7) * 18 + 2 + ((i & 127) >> 3)] >> (7 - (i & 7))) & 1;
+                if (((crc >> 32) ^ (uint64_t)bit) & 1) {
+                    crc ^= 0x04c11db7ull;
+                }
+            }
+            const uint32_t got = (uint32_t)((crc & 0xffffffffull) ^ 0xffffffffull);
+            const uint8_t* t = b18 + (size_t)(blks - 1) * 18 + 14;
+            const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+            crc32_ok = got == want ? 1 : 0;
+        } else if (blks == 0) {
+            crc32_ok = 1; // (crc_extracted = crc_computed = 0, :515-519)
         }
     }
     pdu_info[(size_t)e * 4 + 0] = hdr_ok;
@@ -685,13 +775,45 @@ ddn_dev_chain_pdu_gather(const uint8_t* rec, const int32_t* counts, size_t max_s
 }
 
 extern "C" hipError_t
-ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, int n_entries, int PB, uint8_t* pdu_hdr,
-                         int32_t* pdu_info, hipStream_t st) {
+ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, const uint8_t* blocks18, int n_entries,
+                         int PB, uint8_t* pdu_hdr, int32_t* pdu_info, hipStream_t st) {
     if (n_entries <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_chain_pdu_finish, dim3((unsigned)((n_entries + 63) / 64)), dim3(64), 0, st, pdu_slot, blocks12, valid, n_entries, PB,
-                       pdu_hdr, pdu_info);
+    hipLaunchKernelGGL(k_chain_pdu_finish, dim3((unsigned)((n_entries + 63) / 64)), dim3(64), 0, st, pdu_slot, blocks12, valid, blocks18,
+                       n_entries, PB, pdu_hdr, pdu_info);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pdu_take_first(const uint8_t* cand16, const int32_t* counts, int n_blocks, uint8_t* blocks12, int32_t* metric, hipStream_t st) {
+    if (n_blocks <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_pdu_take_first, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, cand16, counts, n_blocks, blocks12,
+                       metric);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pdu_r34_wanted(const int32_t* pdu_slot, const uint8_t* pdu_hdr, const int32_t* pdu_info, const uint8_t* valid, int n_blocks,
+                             int PB, uint8_t* wanted, hipStream_t st) {
+    if (n_blocks <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_pdu_r34_wanted, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, pdu_slot, pdu_hdr, pdu_info, valid,
+                       n_blocks, PB, wanted);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pdu_r34_select(const uint8_t* cand24, const int32_t* counts, const uint8_t* wanted, int n_blocks, uint8_t* blocks18,
+                             uint8_t* crc9_ok, hipStream_t st) {
+    if (n_blocks <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_pdu_r34_select, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, cand24, counts, wanted, n_blocks,
+                       blocks18, crc9_ok);
     return hipGetLastError();
 }
 

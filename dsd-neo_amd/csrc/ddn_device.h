@@ -255,6 +255,8 @@ hipError_t ddn_dev_imbe_deinterleave(const uint8_t* rec, long n_records, const i
                                      hipStream_t st);
 hipError_t ddn_dev_r34_list(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, uint8_t* backs,
                             uint32_t* cand, int32_t* count, hipStream_t st);
+hipError_t ddn_dev_p25_mbf34_list(const int16_t* llr, int n, int max_cand, const uint8_t* wanted, uint8_t* cand24, int32_t* count,
+                                  hipStream_t st);
 hipError_t ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, uint32_t* cand, int32_t* count,
                                       hipStream_t st);
 hipError_t ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st);
@@ -302,8 +304,14 @@ hipError_t ddn_dev_chain_pdu_index(const int32_t* list, const int32_t* data, con
 hipError_t ddn_dev_chain_pdu_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
                                     const int32_t* pdu_slot, const int32_t* pdu_info, int n_channels, int F, int PF, int PB,
                                     int16_t* llr, uint8_t* valid, hipStream_t st);
-hipError_t ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, int n_entries, int PB,
-                                    uint8_t* pdu_hdr, int32_t* pdu_info, hipStream_t st);
+hipError_t ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, const uint8_t* blocks18,
+                                    int n_entries, int PB, uint8_t* pdu_hdr, int32_t* pdu_info, hipStream_t st);
+hipError_t ddn_dev_chain_pdu_take_first(const uint8_t* cand16, const int32_t* counts, int n_blocks, uint8_t* blocks12, int32_t* metric,
+                                        hipStream_t st);
+hipError_t ddn_dev_chain_pdu_r34_wanted(const int32_t* pdu_slot, const uint8_t* pdu_hdr, const int32_t* pdu_info, const uint8_t* valid,
+                                        int n_blocks, int PB, uint8_t* wanted, hipStream_t st);
+hipError_t ddn_dev_chain_pdu_r34_select(const uint8_t* cand24, const int32_t* counts, const uint8_t* wanted, int n_blocks,
+                                        uint8_t* blocks18, uint8_t* crc9_ok, hipStream_t st);
 hipError_t ddn_dev_chain_frames(const int32_t* list, const int32_t* data, const int32_t* n_list, int EL, const int32_t* sync_pos,
                                 const int32_t* n_syncs, int n_channels, int F, int off0, int off1, int off2, int32_t* nid4,
                                 uint8_t* tsbk, uint8_t* tsbk_crc, uint8_t* cls, int32_t* lists, int32_t* list_n, hipStream_t st);

@@ -805,3 +805,174 @@ ddn_dev_r34_list(const uint8_t* dibits, const uint8_t* reliab, int n, int max_ca
     }
     return hipGetLastError();
 }
+
+
+// ---- P25 Phase 1 confirmed data: the rate 3/4 blocks' LLR list decoder (p25_mbf34_decode_soft_list, src/protocol/p25/phase1/
+// p25p1_mbf34.c:129-213) ----------------------------------------------------------------------------------------------------------
+// One wavefront per block, lane (p, r) = survivor r of state p (8 x 8 = P25_MBF34_MAX_CANDIDATES per state).  The reference inserts,
+// per target state, every extension in front of the first strictly more expensive survivor - the 8 cheapest of up to 64 under the
+// order (metric, arrival), arrival = previous state major, rank minor.  Here every lane finds its extension's place among the 64 by
+// counting the extensions that come first (one LDS broadcast read of the 64 metrics per step, the 8 x 8 branch costs tabulated per
+// step by the 64 lanes), and writes {metric, where it came from} into that place when it is below 8.  The 64 paths are then traced
+// back lane by lane, packed from their first 48 states, and merged by one lane with the reference's rule: insert by metric, skip a
+// path whose bytes are already in the list (:77-109).  Rare work (confirmed data units): no attempt to shorten the per-step chain.
+namespace {
+struct Mbf34Lds {
+    int16_t d[196];
+    uint32_t m[2][64];
+    uint32_t ct[64];          // [ns][ps]
+    uint8_t bp[49][64];       // survivor (ns, pos) of step t came from (ps << 3) | rank
+    uint8_t path[64][18];
+    uint32_t fin[64];
+};
+
+__global__ __launch_bounds__(64) void
+k_p25_mbf34_list(const int16_t* __restrict__ llr, int n, int max_cand, uint8_t* __restrict__ cand24, int32_t* __restrict__ count,
+                 const uint8_t* __restrict__ wanted) {
+    __shared__ Mbf34Lds L;
+    const int lane = threadIdx.x;
+    const uint32_t INF = 0x3FFFFFFFu;
+    for (long item = blockIdx.x; item < n; item += gridDim.x) {
+        if (wanted && !wanted[item]) { // (block-uniform) an item nobody asked for: no candidates
+            if (lane == 0) {
+                count[item] = 0;
+            }
+            continue;
+        }
+        const int16_t* in = llr + (size_t)item * 196;
+        // de-interleave: received dibit i carries de-interleaved dibit il[i] (13 + 12 + 12 + 12 pairs dealt with stride 4 pairs)
+        for (int i = lane; i < 98; i += 64) {
+            const int pair_rx = i >> 1;
+            int ln4, k;
+            if (pair_rx < 13) {
+                ln4 = 0;
+                k = pair_rx;
+            } else {
+                ln4 = 1 + (pair_rx - 13) / 12;
+                k = (pair_rx - 13) % 12;
+            }
+            const int p = 2 * (ln4 + 4 * k) + (i & 1);
+            L.d[2 * p] = in[2 * i];
+            L.d[2 * p + 1] = in[2 * i + 1];
+        }
+        const int ps = lane >> 3, r = lane & 7;
+        L.m[0][lane] = r == 0 ? (ps == 0 ? 0u : 1024u) : INF;
+        __syncthreads();
+        for (int t = 0; t < 49; t++) {
+            const uint32_t* mb = L.m[t & 1];
+            uint32_t* mn = L.m[(t + 1) & 1];
+            { // branch cost of (q -> ns), q = lane >> 3, ns = lane & 7
+                const int e = c_r34_point_to_nibble[c_r34_fsm[(lane >> 3) * 8 + (lane & 7)] & 15] & 15;
+                uint32_t c = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int v = L.d[4 * t + b];
+                    c += ((e >> (3 - b)) & 1) ? (v < 0 ? (uint32_t)(-v) : 0u) : (v > 0 ? (uint32_t)v : 0u);
+                }
+                L.ct[(lane & 7) * 8 + (lane >> 3)] = c;
+            }
+            mn[lane] = INF;
+            __syncthreads();
+            const uint32_t mine = mb[lane];
+            if (mine != INF) {
+                for (int ns = 0; ns < 8; ns++) {
+                    const uint32_t val = mine + L.ct[ns * 8 + ps];
+                    int pos = 0;
+                    for (int q = 0; q < 8; q++) {
+                        const uint32_t cq = L.ct[ns * 8 + q];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const uint32_t o = mb[q * 8 + i];
+                            const uint32_t ov = o + cq;
+                            pos += (o != INF && (ov < val || (ov == val && (q * 8 + i) < lane))) ? 1 : 0;
+                        }
+                    }
+                    if (pos < 8) {
+                        mn[ns * 8 + pos] = val;
+                        L.bp[t][ns * 8 + pos] = (uint8_t)lane;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        { // trace back this lane's path, pack its first 48 states
+            const uint32_t fm = L.m[1][lane]; // 49 steps: the last write went to m[49 & 1]
+            L.fin[lane] = fm;
+            if (fm != INF) {
+                uint8_t st[49];
+                int cur = lane;
+                for (int t = 48; t >= 0; t--) {
+                    st[t] = (uint8_t)(cur >> 3);
+                    cur = L.bp[t][cur];
+                }
+                for (int g = 0; g < 6; g++) {
+                    uint32_t w = 0;
+                    for (int k = 0; k < 8; k++) {
+                        w = (w << 3) | st[8 * g + k];
+                    }
+                    L.path[lane][3 * g] = (uint8_t)(w >> 16);
+                    L.path[lane][3 * g + 1] = (uint8_t)(w >> 8);
+                    L.path[lane][3 * g + 2] = (uint8_t)w;
+                }
+            }
+        }
+        __syncthreads();
+        if (lane == 0) { // p25_mbf34_collect_candidates(): arrival order = state major, rank minor
+            uint8_t* out = cand24 + (size_t)item * 8 * 24;
+            const int mx = max_cand > 8 ? 8 : max_cand;
+            int cnt = 0;
+            for (int a = 0; a < 64; a++) {
+                const uint32_t me = L.fin[a];
+                if (me == INF) {
+                    continue;
+                }
+                bool dup = false;
+                for (int i = 0; i < cnt && !dup; i++) {
+                    bool same = true;
+                    for (int b = 0; b < 18; b++) {
+                        same = same && out[i * 24 + b] == L.path[a][b];
+                    }
+                    dup = same;
+                }
+                if (dup) {
+                    continue;
+                }
+                int at = cnt;
+                for (int i = 0; i < cnt; i++) {
+                    if (me < *reinterpret_cast<const uint32_t*>(out + i * 24 + 20)) {
+                        at = i;
+                        break;
+                    }
+                }
+                if (cnt < mx) {
+                    cnt++;
+                } else if (at >= mx) {
+                    continue;
+                }
+                for (int i = cnt - 1; i > at; i--) {
+                    for (int b = 0; b < 24; b++) {
+                        out[i * 24 + b] = out[(i - 1) * 24 + b];
+                    }
+                }
+                for (int b = 0; b < 18; b++) {
+                    out[at * 24 + b] = L.path[a][b];
+                }
+                out[at * 24 + 18] = out[at * 24 + 19] = 0;
+                *reinterpret_cast<uint32_t*>(out + at * 24 + 20) = me;
+            }
+            count[item] = cnt;
+        }
+        __syncthreads();
+    }
+}
+} // namespace
+
+extern "C" hipError_t
+ddn_dev_p25_mbf34_list(const int16_t* llr, int n, int max_cand, const uint8_t* wanted, uint8_t* cand24, int32_t* count, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    const int grid = n < 65536 ? n : 65536;
+    hipLaunchKernelGGL(k_p25_mbf34_list, dim3((unsigned)grid), dim3(64), 0, st, llr, n, max_cand, cand24, count, wanted);
+    return hipGetLastError();
+}

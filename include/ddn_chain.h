@@ -78,17 +78,21 @@ typedef struct ddn_p25_chain_results {
     /* data units (DUID 0xC, processMPDU() src/protocol/p25/phase1/p25p1_mdpu.c): entry = channel * pdu_per_channel + rank in air order.
      * The header is the one the loop's handler decoded (list-8 + CRC16, it decides the frame's length); the data blocks behind it are
      * decoded here: half-rate trellis, best path (p25_mpdu_decode_r12_block :263-273), CRC32 over the data (crc32mbf).  When the header
-     * fails its CRC16 the reference reads three blocks and tries blocks 1 / 2 as repetitions of the header: so does this.  Not built:
-     * the LLR-combined / majority header (:335-379) and the rate-3/4 blocks of confirmed data (p25p1_mbf34.c) - flagged, not guessed. */
+     * fails its CRC16 the reference reads three blocks and tries blocks 1 / 2 as repetitions of the header: so does this.  Confirmed
+     * data (A/N = 1, format 0x16 in a header with a good CRC16): the blocks go through the rate 3/4 LLR list decoder (p25p1_mbf34.c),
+     * first candidate with a good CRC9, CRC32 over the 16 payload bytes per block.  Not built: the LLR-combined / majority header
+     * (:335-379) - flagged (16), not guessed. */
     int pdu_per_channel, pdu_blocks;
     const int32_t* d_n_pdu;        /* [B] data units whose sync this call decodes (entries beyond pdu_per_channel are counted only) */
     const int32_t* d_pdu_slot;     /* [B][pdu_per_channel] frame slot, -1 = unused entry */
     const uint8_t* d_pdu_header;   /* [..][12] */
     const int32_t* d_pdu_info;     /* [..][4] {header CRC16 good, blocks read (header included), flags, CRC32 good}; flags: 1 / 2 header
-                                      taken from repetition 1 / 2, 4 confirmed data (rate 3/4 blocks: not decoded), 8 a block beyond the
+                                      taken from repetition 1 / 2, 4 confirmed data (the blocks are in d_pdu_blocks18), 8 a block beyond the
                                       call's records or beyond pdu_blocks, 16 no header repetition with a good CRC16 */
     const uint8_t* d_pdu_blocks;   /* [..][pdu_blocks][12] data blocks 1.. */
     const uint8_t* d_pdu_block_valid; /* [..][pdu_blocks] */
+    const uint8_t* d_pdu_blocks18; /* [..][pdu_blocks][18] confirmed data (flag 4): DBSN(7) | CRC9, then 16 payload bytes per block */
+    const uint8_t* d_pdu_crc9_ok;  /* [..][pdu_blocks] a candidate with a good CRC9 was found (else the cheapest one is stored) */
     const int32_t* d_n_ldu;     /* [B] voice LDUs of this call */
     const uint8_t* d_imbe_bits; /* [B][max_ldu * 9][88] voice parameter bits */
     const int32_t* d_imbe_result; /* [B][max_ldu * 9][5] */

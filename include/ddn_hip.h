@@ -551,6 +551,20 @@ typedef struct ddn_r34_candidate {
     int32_t metric;
     uint8_t bytes18[18];
 } ddn_r34_candidate;
+/* P25 Phase 1 confirmed data: the rate 3/4 blocks' LLR list decoder == p25_mbf34_decode_soft_list (include/dsd-neo/protocol/p25/
+ * p25p1_mbf34.h:19-29, src/protocol/p25/phase1/p25p1_mbf34.c:129-213): 98 LLR pairs in received order -> up to 8 candidates
+ * {18 bytes: DBSN(7) | CRC9 | 16 payload bytes, metric}, cheapest first, ties by arrival, identical payloads once; d_counts [n].
+ * d_wanted u8 [n] (optional): only items with a non-zero byte are decoded, the others get count 0. */
+typedef struct ddn_p25_mbf34_candidate {
+    uint8_t bytes[18];
+    uint32_t metric;
+} ddn_p25_mbf34_candidate; /* == p25_mbf34_candidate_t */
+int ddn_fec_p25_mbf34_list_batch(const int16_t* d_llr196, size_t n, int max_candidates, const uint8_t* d_wanted,
+                                 ddn_p25_mbf34_candidate* d_candidates8, int32_t* d_counts, void* hip_stream);
+int ddn_fec_p25_mbf34_list_host(const int16_t* llr196, size_t n, int max_candidates, ddn_p25_mbf34_candidate* candidates8,
+                                int32_t* counts);
+int p25_mbf34_decode_soft_list(const uint8_t dibits[98], const int16_t bit_llr[196], ddn_p25_mbf34_candidate* candidates,
+                               int max_candidates);
 int ddn_fec_r34_list_batch(const uint8_t* d_dibits98, const uint8_t* d_reliab98, size_t n, int max_candidates,
                            ddn_r34_candidate* d_candidates32, int32_t* d_counts, void* hip_stream);
 int ddn_fec_r34_list_host(const uint8_t* dibits98, const uint8_t* reliab98, size_t n, int max_candidates,

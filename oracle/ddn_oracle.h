@@ -103,6 +103,9 @@ const uint8_t* orc_tbl_r34_fsm(void);
 int orc_p25_12_soft_llr(const int16_t* llr196, uint8_t out12[12]);
 int orc_p25_12_soft_llr_list(const int16_t* llr196, uint8_t* out_bytes, uint32_t* out_metric, int max);
 int orc_r34_decode(const uint8_t* dibits98, const uint8_t* reliab98 /* NULL = hard */, uint8_t out18[18]);
+/* P25 Phase 1 confirmed-data rate 3/4 blocks on LLR pairs (p25p1_mbf34.c): list of <= 8 {18 bytes, metric}; plain best path */
+int orc_p25_mbf34_list(const int16_t* llr196, int max, uint8_t* out_bytes, uint32_t* out_metric);
+int orc_p25_mbf34_best(const int16_t* llr196, uint8_t out18[18]);
 int orc_r34_decode_list(const uint8_t* dibits98, const uint8_t* reliab98, int max, int32_t* out_metric, uint8_t* out_bytes);
 void orc_nxdn_conv_decode(const uint8_t* sym, const uint8_t* rel /* NULL = hard */, int n_steps,
                           uint16_t metrics16[16], uint8_t* out, int n_bits);

@@ -538,3 +538,177 @@ orc_m17_viterbi_decode_punctured(uint8_t* out, const uint16_t* in, const uint8_t
     }
     return orc_m17_viterbi_decode(out, um, u) - (uint32_t)(u - in_len) * 0x7FFFu;
 }
+
+
+/* ---- P25 Phase 1 confirmed data, rate 3/4 blocks with LLRs (src/protocol/p25/phase1/p25p1_mbf34.c) -------------------------------
+ * TEST INFRASTRUCTURE.  p25_mbf34_decode_soft_list(:189-213): the 98 LLR pairs are de-interleaved (dsd_trellis_interleave_98), every
+ * state starts with one survivor (metric 0 for state 0, 1024 otherwise), and at each of the 49 steps every target state keeps the 8
+ * cheapest of the up to 64 extensions, an extension going in front of the first strictly more expensive one (:46-63) - so the order
+ * is (metric, arrival), arrival = previous state major, rank minor (:139-151).  Branch cost = the four LLRs' disagreement with the
+ * expected dibit pair of the transition (:123-127).  At the end the up to 64 paths are packed to 18 bytes from their first 48 states
+ * (:65-75; the 49th is not part of the bytes, so paths can coincide) and merged into one list by the same insertion rule, a path whose
+ * bytes are already IN the list being skipped (:85-109).  orc_p25_mbf34_best = p25_mbf34_decode_soft (:215-257): plain Viterbi, lowest
+ * previous state on a tie, lowest final state on a tie; returns metric >> 8. */
+typedef struct {
+    uint32_t metric;
+    uint8_t st[49];
+    uint8_t on;
+} mbf_path;
+
+static uint32_t
+mbf_cost(const int16_t* d, int step, int prev, int next) {
+    const int expect = k_r34_point_to_nibble[k_r34_fsm[prev * 8 + next] & 15] & 15;
+    uint32_t c = 0;
+    for (int b = 0; b < 4; b++) {
+        c += llr_disagreement(d[4 * step + b], (expect >> (3 - b)) & 1);
+    }
+    return c;
+}
+
+static void
+mbf_deinterleave(const int16_t* llr196, int16_t* d) {
+    uint8_t il[98];
+    orc_trellis_interleave_98(il);
+    memset(d, 0, 196 * sizeof(int16_t));
+    for (int i = 0; i < 98; i++) {
+        d[2 * il[i]] = llr196[2 * i];
+        d[2 * il[i] + 1] = llr196[2 * i + 1];
+    }
+}
+
+static void
+mbf_pack(const uint8_t* st, uint8_t out[18]) {
+    for (int g = 0; g < 6; g++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 8; k++) {
+            w = (w << 3) | st[8 * g + k];
+        }
+        out[3 * g] = (uint8_t)(w >> 16);
+        out[3 * g + 1] = (uint8_t)(w >> 8);
+        out[3 * g + 2] = (uint8_t)w;
+    }
+}
+
+int
+orc_p25_mbf34_list(const int16_t* llr196, int max, uint8_t* out_bytes, uint32_t* out_metric) {
+    enum { K = 8 };
+    if (!llr196 || !out_bytes || !out_metric || max <= 0) {
+        return 0;
+    }
+    max = max > K ? K : max;
+    int16_t d[196];
+    mbf_deinterleave(llr196, d);
+    static mbf_path a[8][K], b[8][K]; /* (not re-entrant: test infrastructure) */
+    memset(a, 0, sizeof(a));
+    for (int s = 0; s < 8; s++) {
+        a[s][0].on = 1;
+        a[s][0].metric = s == 0 ? 0u : 1024u;
+    }
+    for (int t = 0; t < 49; t++) {
+        memset(b, 0, sizeof(b));
+        for (int ps = 0; ps < 8; ps++) {
+            for (int r = 0; r < K; r++) {
+                if (!a[ps][r].on) {
+                    continue;
+                }
+                for (int ns = 0; ns < 8; ns++) {
+                    mbf_path c = a[ps][r];
+                    c.metric += mbf_cost(d, t, ps, ns);
+                    c.st[t] = (uint8_t)ns;
+                    int at = -1;
+                    for (int i = 0; i < K; i++) {
+                        if (!b[ns][i].on || c.metric < b[ns][i].metric) {
+                            at = i;
+                            break;
+                        }
+                    }
+                    if (at < 0) {
+                        continue;
+                    }
+                    for (int i = K - 1; i > at; i--) {
+                        b[ns][i] = b[ns][i - 1];
+                    }
+                    b[ns][at] = c;
+                }
+            }
+        }
+        memcpy(a, b, sizeof(a));
+    }
+    int n = 0;
+    for (int s = 0; s < 8; s++) {
+        for (int r = 0; r < K; r++) {
+            if (!a[s][r].on) {
+                continue;
+            }
+            uint8_t by[18];
+            mbf_pack(a[s][r].st, by);
+            int dup = 0;
+            for (int i = 0; i < n; i++) {
+                dup |= memcmp(out_bytes + 18 * i, by, 18) == 0;
+            }
+            if (dup) {
+                continue;
+            }
+            int at = n;
+            for (int i = 0; i < n; i++) {
+                if (a[s][r].metric < out_metric[i]) {
+                    at = i;
+                    break;
+                }
+            }
+            if (n < max) {
+                n++;
+            } else if (at >= max) {
+                continue;
+            }
+            for (int i = n - 1; i > at; i--) {
+                memcpy(out_bytes + 18 * i, out_bytes + 18 * (i - 1), 18);
+                out_metric[i] = out_metric[i - 1];
+            }
+            memcpy(out_bytes + 18 * at, by, 18);
+            out_metric[at] = a[s][r].metric;
+        }
+    }
+    return n;
+}
+
+int
+orc_p25_mbf34_best(const int16_t* llr196, uint8_t out18[18]) {
+    int16_t d[196];
+    mbf_deinterleave(llr196, d);
+    uint32_t pm[8], cm[8];
+    uint8_t bp[49][8];
+    for (int s = 0; s < 8; s++) {
+        pm[s] = s == 0 ? 0u : 1024u;
+    }
+    for (int t = 0; t < 49; t++) {
+        for (int ns = 0; ns < 8; ns++) {
+            uint32_t best = 0xFFFFFFFFu;
+            int bpv = 0;
+            for (int ps = 0; ps < 8; ps++) {
+                const uint32_t m = pm[ps] + mbf_cost(d, t, ps, ns);
+                if (m < best) {
+                    best = m;
+                    bpv = ps;
+                }
+            }
+            cm[ns] = best;
+            bp[t][ns] = (uint8_t)bpv;
+        }
+        memcpy(pm, cm, sizeof(pm));
+    }
+    int st = 0;
+    for (int s = 1; s < 8; s++) {
+        if (cm[s] < cm[st]) {
+            st = s;
+        }
+    }
+    const uint32_t best_final = cm[st];
+    uint8_t tri[49];
+    for (int t = 48; t >= 0; t--) {
+        tri[t] = (uint8_t)st;
+        st = bp[t][st];
+    }
+    mbf_pack(tri, out18);
+    return (int)(best_final >> 8);
+}

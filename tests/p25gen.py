@@ -131,9 +131,55 @@ def crc32mbf(data, nbits):
     return (crc & 0xFFFFFFFF) ^ 0xFFFFFFFF
 
 
-def make_pdu_coded(rng, nac, blks, sap=0, good_crc16=True, good_crc32=True, confirmed=False, header_reps=0):
-    """an unconfirmed data unit as the reference decodes it: header block (CRC16), blks half-rate coded data blocks whose last four
-    bytes are the CRC32 of the rest -> (dibits, header12, data [blks][12]).  header_reps > 0 (with good_crc16 = False and blks = 0 in
+_R34 = None
+
+
+def _r34_tables():
+    global _R34
+    if _R34 is None:
+        import ctypes as C
+        o = orc.oracle()
+        for f in ("orc_tbl_r34_point_to_nibble", "orc_tbl_r34_fsm"):
+            getattr(o, f).restype = C.POINTER(C.c_uint8)
+        il = np.zeros(98, np.uint8)
+        o.orc_trellis_interleave_98.argtypes = [C.c_void_p]
+        o.orc_trellis_interleave_98(il.ctypes.data)
+        _R34 = (np.array(o.orc_tbl_r34_point_to_nibble()[:16]), np.array(o.orc_tbl_r34_fsm()[:64]), il)
+    return _R34
+
+
+def encode_three_quarter_rate(bytes18):
+    """18 bytes -> 98 dibits on the air (48 tribits + a flushing zero through the rate 3/4 FSM, interleaved)"""
+    p2n, fsm, il = _r34_tables()
+    bits = np.unpackbits(np.asarray(bytes18, np.uint8))
+    tri = [int(bits[3 * k] << 2 | bits[3 * k + 1] << 1 | bits[3 * k + 2]) for k in range(48)] + [0]
+    st, dib = 0, []
+    for t in tri:
+        nib = int(p2n[fsm[st * 8 + t] & 15])
+        dib += [nib >> 2, nib & 3]
+        st = t
+    return np.array(dib, np.uint8)[il]            # received dibit i carries de-interleaved dibit il[i]
+
+
+def crc9(bits135):
+    """ComputeCrc9Bit (src/protocol/dmr/dmr_utils.c:410-435): polynomial 0x059 over the bits, inverted"""
+    crc = 0
+    for b in bits135:
+        crc = ((crc << 1) ^ 0x059) if (((crc >> 8) & 1) ^ int(b)) else (crc << 1)
+    return (crc & 0x1FF) ^ 0x1FF
+
+
+def confirmed_block(dbsn, payload16, good_crc9=True):
+    """DBSN(7) | CRC9(9) | 16 payload bytes -> 18 bytes"""
+    bits = [(dbsn >> (6 - i)) & 1 for i in range(7)] + list(np.unpackbits(np.asarray(payload16, np.uint8)))
+    c = crc9(bits) ^ (0 if good_crc9 else 0x011)
+    return np.array([((dbsn & 0x7F) << 1) | (c >> 8), c & 0xFF] + [int(x) for x in payload16], np.uint8)
+
+
+def make_pdu_coded(rng, nac, blks, sap=0, good_crc16=True, good_crc32=True, confirmed=False, header_reps=0, bad_crc9_at=()):
+    """a data unit as the reference decodes it: header block (CRC16), blks half-rate coded data blocks whose last four bytes are the
+    CRC32 of the rest -> (dibits, header12, data [blks][12]); confirmed = True: A/N = 1, format 0x16 and rate 3/4 blocks
+    (data [blks][18]).  header_reps > 0 (with good_crc16 = False and blks = 0 in
     the header): the first header fails its CRC16 and header_reps good copies follow, as the reference's repetition fallback expects"""
     hdr = rng.integers(0, 256, 10)
     hdr[0] = (int(hdr[0]) & 0xA0) | ((0x40 | 0x16) if confirmed else (int(hdr[0]) & 0x0F))      # AN / format
@@ -150,13 +196,21 @@ def make_pdu_coded(rng, nac, blks, sap=0, good_crc16=True, good_crc32=True, conf
     if header_reps:
         for k in range(header_reps):
             data[k] = good
+    elif blks and confirmed and good_crc16:       # confirmed data: rate 3/4 blocks of DBSN | CRC9 | 16 bytes, CRC32 ends the payload
+        flat = rng.integers(0, 256, 16 * blks).astype(np.uint8)
+        c32 = crc32mbf(flat, 128 * blks - 32) ^ (0 if good_crc32 else 0x00010000)
+        flat[-4:] = [(c32 >> 24) & 0xFF, (c32 >> 16) & 0xFF, (c32 >> 8) & 0xFF, c32 & 0xFF]
+        data = np.stack([confirmed_block(k, flat[16 * k:16 * k + 16], k not in bad_crc9_at) for k in range(blks)])
+        for k in range(blks):
+            pay += list(encode_three_quarter_rate(data[k]))
     elif blks:
         flat = rng.integers(0, 256, 12 * blks).astype(np.uint8)
         c32 = crc32mbf(flat, 96 * blks - 32) ^ (0 if good_crc32 else 0x00010000)
         flat[-4:] = [(c32 >> 24) & 0xFF, (c32 >> 16) & 0xFF, (c32 >> 8) & 0xFF, c32 & 0xFF]
         data = flat.reshape(blks, 12)
-    for k in range(len(data)):
-        pay += list(encode_half_rate(list(data[k])))
+    if data.shape[1] == 12:
+        for k in range(len(data)):
+            pay += list(encode_half_rate(list(data[k])))
     n_pay = 24 + 32 + len(pay)
     flen = -(-n_pay // 35) * 36
     fr = np.zeros(flen, np.int8)
