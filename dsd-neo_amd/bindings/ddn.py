@@ -490,7 +490,11 @@ class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
                                   "d_nxdn_facch_ok", "d_nxdn_voice_skip", "d_nxdn_ambe_bits", "d_nxdn_pcm")] + [
         ("dmr_voice_bursts", C.c_int)] + [(k, C.c_void_p) for k in (
             "d_dmr_n_voice", "d_dmr_voice_start", "d_dmr_voice_pre", "d_dmr_voice_skip", "d_dmr_ambe_frames", "d_dmr_ambe_bits",
-            "d_dmr_ambe_result", "d_dmr_pcm", "d_events", "d_n_events")] + [("max_events", C.c_int)]
+            "d_dmr_ambe_result", "d_dmr_pcm", "d_events", "d_n_events")] + [("max_events", C.c_int), ("dmr_data_bursts", C.c_int)] + [
+        (k, C.c_void_p) for k in ("d_dmr_n_data", "d_dmr_data_start", "d_dmr_data_slot", "d_dmr_data_type", "d_dmr_data_info196",
+                                  "d_dmr_data_bits96", "d_dmr_data_bytes12", "d_dmr_data_errs", "d_dmr_data_crc", "d_dmr_r34_unconfirmed",
+                                  "d_dmr_r34_confirmed", "d_dmr_r34_confirmed_crc", "d_dmr_r34_pool", "d_dmr_r34_pool_n")] + [
+        ("dmr_emb_lcs", C.c_int)] + [(k, C.c_void_p) for k in ("d_dmr_n_emb", "d_dmr_emb_pos", "d_dmr_emb_lc77", "d_dmr_emb_errs", "d_dmr_emb_ok")]
 
 
 class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config

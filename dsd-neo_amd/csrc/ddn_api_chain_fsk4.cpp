@@ -53,6 +53,15 @@ struct ddn_fsk4_chain {
     // channel: time slots 1 / 2), three AMBE frames each
     int E, vb;
     int32_t *d_ev, *d_nev, *d_vstart, *d_vpre, *d_vnb;
+    // DMR data bursts the handlers dispatch (handlers = 1): db per channel and call, D = B * db; embedded link control: lb per talk
+    // path and call, L = 2 B * lb (ddn_dmr_data.hip)
+    int db, lb;
+    size_t D, L;
+    int32_t *dd_start, *dd_pre, *dd_n, *dd_listn, *dd_pooln, *de_pos, *de_n;
+    uint32_t *dd_errs, *de_errs;
+    uint8_t *dd_slot, *dd_st, *dd_st_ok, *dd_info, *dd_td, *dd_rel, *dd_pdu, *dd_r3, *dd_type, *dd_bytes, *dd_cw, *dd_rsres, *dd_rsfound,
+        *dd_crc, *dd_want, *dd_hard, *dd_soft, *dd_list, *dd_backs, *dd_pool, *dd_unconf, *dd_conf, *dd_confcrc, *de_sig, *de_in, *de_out,
+        *de_ok;
     // NXDN48
     uint8_t *d_lich, *d_ss, *d_sr, *d_fs, *d_fr, *d_sacch, *d_sacch_ok, *d_hard_in, *d_sacch_hard, *d_sacch_hard_ok, *d_facch, *d_facch_ok;
     int32_t *d_vpos, *d_vn, *d_ambe_res, *d_res_out;
@@ -86,7 +95,10 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
                    c->d_prel, c->d_st, c->d_info, c->d_cach, c->d_valid, c->d_st_ok, c->d_pdu, c->d_r3, c->d_errs, c->d_lich, c->d_ss,
                    c->d_sr, c->d_fs, c->d_fr, c->d_sacch, c->d_sacch_ok, c->d_hard_in, c->d_sacch_hard, c->d_sacch_hard_ok, c->d_facch,
                    c->d_facch_ok, c->d_vpos, c->d_vn, c->d_ambe_res, c->d_res_out, c->d_ambe_fr, c->d_ambe_rel, c->d_ambe_d, c->d_skip,
-                   c->d_pcm, c->d_ev, c->d_nev, c->d_vstart, c->d_vpre, c->d_vnb};
+                   c->d_pcm, c->d_ev, c->d_nev, c->d_vstart, c->d_vpre, c->d_vnb, c->dd_start, c->dd_pre, c->dd_n, c->dd_listn, c->dd_pooln, c->de_pos,
+                   c->de_n, c->dd_errs, c->de_errs, c->dd_slot, c->dd_st, c->dd_st_ok, c->dd_info, c->dd_td, c->dd_rel, c->dd_pdu, c->dd_r3,
+                   c->dd_type, c->dd_bytes, c->dd_cw, c->dd_rsres, c->dd_rsfound, c->dd_crc, c->dd_want, c->dd_hard, c->dd_soft, c->dd_list,
+                   c->dd_backs, c->dd_pool, c->dd_unconf, c->dd_conf, c->dd_confcrc, c->de_sig, c->de_in, c->de_out, c->de_ok};
     for (void* p : all) {
         (void)hipFree(p);
     }
@@ -157,19 +169,41 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
         if (ok && c->dmr) {
             ok = dalloc(&c->d_st, S * 20) && dalloc(&c->d_info, S * 196) && dalloc(&c->d_cach, S * 24) && dalloc(&c->d_valid, S)
                  && dalloc(&c->d_st_ok, S) && dalloc(&c->d_pdu, S * 96) && dalloc(&c->d_r3, S * 3) && dalloc(&c->d_errs, S);
+            if (ok && cfg->handlers) {
+                // the handlers' decisions of every call (events): which bursts go to dmr_data_burst_handler(), which to the vocoder,
+                // under which VC a burst's sync field was filed.  Data bursts: at most one per 144 symbols; an embedded link control
+                // per six voice bursts of a time slot
+                c->E = (int)(c->ms / 36 + 32);
+                c->db = (int)(c->ms / 144 + 3);
+                c->lb = (int)(c->ms / (288 * 6) + 2);
+                c->D = B * (size_t)c->db;
+                c->L = 2 * B * (size_t)c->lb;
+                const size_t D = c->D, L = c->L;
+                ok = dalloc(&c->d_ev, B * (size_t)c->E * 4) && dalloc(&c->d_nev, B) && dalloc(&c->dd_start, D) && dalloc(&c->dd_pre, D) && dalloc(&c->dd_n, B)
+                     && dalloc(&c->dd_listn, D) && dalloc(&c->dd_pooln, D) && dalloc(&c->de_pos, L) && dalloc(&c->de_n, 2 * B)
+                     && dalloc(&c->dd_errs, D) && dalloc(&c->de_errs, L) && dalloc(&c->dd_slot, D) && dalloc(&c->dd_st, D * 20)
+                     && dalloc(&c->dd_st_ok, D) && dalloc(&c->dd_info, D * 196) && dalloc(&c->dd_td, D * 98) && dalloc(&c->dd_rel, D * 98)
+                     && dalloc(&c->dd_pdu, D * 96) && dalloc(&c->dd_r3, D * 3) && dalloc(&c->dd_type, D) && dalloc(&c->dd_bytes, D * 12)
+                     && dalloc(&c->dd_cw, D * 12) && dalloc(&c->dd_rsres, D) && dalloc(&c->dd_rsfound, D) && dalloc(&c->dd_crc, D)
+                     && dalloc(&c->dd_want, D) && dalloc(&c->dd_hard, D * 18) && dalloc(&c->dd_soft, D * 18)
+                     && dalloc(&c->dd_list, D * 32 * 24) && dalloc(&c->dd_backs, D * 49 * 8 * 32) && dalloc(&c->dd_pool, D * 34 * 24)
+                     && dalloc(&c->dd_unconf, D * 18) && dalloc(&c->dd_conf, D * 18) && dalloc(&c->dd_confcrc, D)
+                     && dalloc(&c->de_sig, B * 2 * 7 * 48) && dalloc(&c->de_in, L * 128) && dalloc(&c->de_out, L * 77) && dalloc(&c->de_ok, L);
+                if (ok && (rc = ddn_fsk4_rx_set_events(c->rx, c->d_ev, c->d_nev, (size_t)c->E)) != DDN_OK) {
+                    break;
+                }
+            }
             if (ok && cfg->vocoder && cfg->handlers) {
                 // voice (dmrBSBootstrap / dmrBS -> processMbeFrame, dmr_bs.c:128-200,585-640): a time slot carries a burst every
                 // 288 symbols, three AMBE 3600x2450 frames each; which bursts reach the vocoder is the handlers' decision (events)
                 c->vb = (int)(c->ms / 288 + 3);
-                c->E = (int)(c->ms / 36 + 32);
                 c->V = 2 * B * (size_t)c->vb; // bursts
                 const size_t V = c->V;
-                ok = dalloc(&c->d_ev, B * (size_t)c->E * 4) && dalloc(&c->d_nev, B) && dalloc(&c->d_vstart, V) && dalloc(&c->d_vpre, V)
+                ok = dalloc(&c->d_vstart, V) && dalloc(&c->d_vpre, V)
                      && dalloc(&c->d_vnb, 2 * B) && dalloc(&c->d_ambe_fr, V * 3 * 96) && dalloc(&c->d_ambe_d, V * 3 * 49)
                      && dalloc(&c->d_ambe_res, V * 3 * 5) && dalloc(&c->d_skip, V * 3) && dalloc(&c->d_pcm, V * 3 * 160)
                      && dalloc(&c->d_res_out, V * 3 * 5);
-                if (ok && ((rc = ddn_mbe_batch_create(DDN_MBE_AMBE_3600X2450, 2 * c->B, &c->mbe)) != DDN_OK
-                           || (rc = ddn_fsk4_rx_set_events(c->rx, c->d_ev, c->d_nev, (size_t)c->E)) != DDN_OK)) {
+                if (ok && (rc = ddn_mbe_batch_create(DDN_MBE_AMBE_3600X2450, 2 * c->B, &c->mbe)) != DDN_OK) {
                     break;
                 }
             }
@@ -221,18 +255,44 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
                                      c->d_st, c->d_info, c->d_cach, c->d_valid, st));
         DDN_TRY(ddn_fec_block_code_batch(5 /* DDN_CODE_GOLAY_20_8 */, c->d_st, S, 1, nullptr, c->d_st_ok, st));
         DDN_TRY(ddn_fec_bptc_196x96_batch(c->d_info, 1, S, c->d_pdu, c->d_r3, c->d_errs, st));
+        if (c->E && flush) { // no new records, no new decisions
+            HIP_TRY(hipMemsetAsync(c->d_nev, 0, sizeof(int32_t) * (size_t)c->B, st));
+        }
+        if (c->E) {
+            // the bursts the handlers dispatched to dmr_data_burst_handler() in this call (each ends inside it; one that began in the
+            // previous call reaches back into the carried records): slot type, BPTC(196,96), the type's CRC / RS(12,9), and for
+            // rate 3/4 bursts the three trellis decoders and the candidate pool (dmr_dburst.c:502-536)
+            const size_t D = c->D, L = c->L;
+            HIP_TRY(ddn_dev_dmr_data_select(c->d_ev, c->d_nev, c->E, c->T, c->B, c->db, c->d_spos, c->d_ns, c->myd, c->c_pos[cur], c->c_n[cur],
+                                            c->myc, c->d_new[cur], c->dd_start, c->dd_slot, c->dd_pre, c->dd_n, st));
+            HIP_TRY(ddn_dev_dmr_data_gather(rec, c->stride, c->dd_start, c->dd_pre, c->d_pre, c->d_prel, c->c_pre[cur], c->c_prel[cur],
+                                            (long)c->S, c->db, c->B, c->dd_st, c->dd_info, c->dd_td, c->dd_rel, st));
+            DDN_TRY(ddn_fec_block_code_batch(5 /* DDN_CODE_GOLAY_20_8 */, c->dd_st, D, 1, nullptr, c->dd_st_ok, st));
+            DDN_TRY(ddn_fec_bptc_196x96_batch(c->dd_info, 1, D, c->dd_pdu, c->dd_r3, c->dd_errs, st));
+            HIP_TRY(ddn_dev_dmr_data_prep(c->dd_start, c->dd_st, c->dd_st_ok, c->dd_pdu, (int)D, c->dd_type, c->dd_bytes, c->dd_cw, st));
+            DDN_TRY(ddn_fec_rs_12_9_batch(c->dd_cw, D, c->dd_rsres, c->dd_rsfound, nullptr, st));
+            HIP_TRY(ddn_dev_dmr_data_finish(c->dd_type, c->dd_pdu, c->dd_info, c->dd_cw, c->dd_rsres, (int)D, c->dd_bytes, c->dd_crc,
+                                            c->dd_want, st));
+            DDN_TRY(ddn_fec_r34_batch(c->dd_td, nullptr, D, c->dd_hard, st));
+            DDN_TRY(ddn_fec_r34_batch(c->dd_td, c->dd_rel, D, c->dd_soft, st));
+            HIP_TRY(ddn_dev_r34_list_wanted(c->dd_td, c->dd_rel, (int)D, 32, c->dd_want, c->dd_backs, (uint32_t*)c->dd_list, c->dd_listn, st));
+            HIP_TRY(ddn_dev_dmr_r34_pick(c->dd_td, c->dd_rel, c->dd_want, c->dd_hard, c->dd_soft, c->dd_list, c->dd_listn, (int)D, c->dd_pool,
+                                         c->dd_pooln, c->dd_unconf, c->dd_conf, c->dd_confcrc, st));
+            // embedded link control: the sync fields filed under VC 2..6, BPTC(128,77) at every voice burst with VC 6
+            HIP_TRY(ddn_dev_dmr_emb_collect(c->d_ev, c->d_nev, c->E, c->T, rec, c->stride, c->B, c->lb, c->de_sig, c->de_in, c->de_pos,
+                                            c->de_n, st));
+            DDN_TRY(ddn_fec_bptc_128x77_batch(c->de_in, L, c->de_out, c->de_errs, st));
+            HIP_TRY(ddn_dev_dmr_emb_finish(c->de_out, c->de_pos, (int)L, c->de_ok, st));
+        }
         if (c->mbe) {
             // voice: the bursts the handlers handed to the vocoder in this call (they end inside it; a burst that began in the
             // previous call reaches back into the carried records), filed by time slot -> 3 AMBE frames -> frame FEC -> synthesis.
             // (hard bits: the reference passes no soft frame here, processMbeFrame(opts, state, NULL, frame, NULL))
             const size_t V3 = c->V * 3;
-            if (flush) { // no new records, no new decisions
-                HIP_TRY(hipMemsetAsync(c->d_nev, 0, sizeof(int32_t) * (size_t)c->B, st));
-            }
             HIP_TRY(ddn_dev_dmr_voice_select(c->d_ev, c->d_nev, c->E, c->T, c->d_spos, c->d_ns, c->myd, c->B, c->vb, c->d_vstart,
-                                             c->d_vpre, c->d_vnb, st));
+                                             c->d_vpre, c->d_vnb, c->c_pos[cur], c->c_n[cur], c->myc, c->d_new[cur], st));
             HIP_TRY(ddn_dev_dmr_voice_gather_paths(rec, c->d_cnt_full, c->stride, c->d_vstart, c->d_vpre, c->d_pre, c->vb, c->B, 0,
-                                                   c->d_ambe_fr, c->d_skip, st));
+                                                   c->d_ambe_fr, c->d_skip, c->c_pre[cur], (long)c->S, st));
             DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, c->d_ambe_fr, nullptr, V3, c->d_ambe_d, c->d_ambe_res, st));
             DDN_TRY(ddn_mbe_result_skip_batch(c->d_skip, V3, c->d_ambe_res, st));
             DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_ambe_d, c->d_ambe_res, (size_t)c->vb * 3, c->d_pcm, c->d_res_out, st));
@@ -352,6 +412,32 @@ ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
     r->d_nxdn_sacch_hard_ok = c->d_sacch_hard_ok;
     r->d_nxdn_facch = c->d_facch;
     r->d_nxdn_facch_ok = c->d_facch_ok;
+    if (c->dmr && c->E) {
+        r->d_events = c->d_ev;
+        r->d_n_events = c->d_nev;
+        r->max_events = c->E;
+        r->dmr_data_bursts = c->db;
+        r->d_dmr_n_data = c->dd_n;
+        r->d_dmr_data_start = c->dd_start;
+        r->d_dmr_data_slot = c->dd_slot;
+        r->d_dmr_data_type = c->dd_type;
+        r->d_dmr_data_info196 = c->dd_info;
+        r->d_dmr_data_bits96 = c->dd_pdu;
+        r->d_dmr_data_bytes12 = c->dd_bytes;
+        r->d_dmr_data_errs = c->dd_errs;
+        r->d_dmr_data_crc = c->dd_crc;
+        r->d_dmr_r34_unconfirmed = c->dd_unconf;
+        r->d_dmr_r34_confirmed = c->dd_conf;
+        r->d_dmr_r34_confirmed_crc = c->dd_confcrc;
+        r->d_dmr_r34_pool = (const ddn_r34_candidate*)c->dd_pool;
+        r->d_dmr_r34_pool_n = c->dd_pooln;
+        r->dmr_emb_lcs = c->lb;
+        r->d_dmr_n_emb = c->de_n;
+        r->d_dmr_emb_pos = c->de_pos;
+        r->d_dmr_emb_lc77 = c->de_out;
+        r->d_dmr_emb_errs = c->de_errs;
+        r->d_dmr_emb_ok = c->de_ok;
+    }
     if (c->dmr) {
         r->dmr_voice_bursts = c->vb;
         r->d_dmr_voice_start = c->d_vstart;

@@ -192,10 +192,11 @@ hipError_t ddn_dev_dmr_voice_gather(const uint8_t* rec, const int32_t* counts, s
                                     uint8_t* cach24, uint8_t* valid, hipStream_t st);
 hipError_t ddn_dev_dmr_voice_select(const int32_t* events, const int32_t* n_events, int max_events, int carry, const int32_t* sync_pos,
                                     const int32_t* n_sync, int max_syncs, int n_channels, int max_bursts, int32_t* vstart,
-                                    int32_t* vpre, int32_t* vn, hipStream_t st);
+                                    int32_t* vpre, int32_t* vn, const int32_t* out_pos, const int32_t* out_n, int max_out,
+                                    const int32_t* n_new, hipStream_t st);
 hipError_t ddn_dev_dmr_voice_gather_paths(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* vstart,
                                           const int32_t* vpre, const uint8_t* pre90, int max_bursts, int n_channels, int inverted,
-                                          uint8_t* fr, uint8_t* skip3, hipStream_t st);
+                                          uint8_t* fr, uint8_t* skip3, const uint8_t* pre90_out, long split, hipStream_t st);
 hipError_t ddn_dev_nxdn_frame_gather(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
                                      const int32_t* n_sync, int n_channels, int max_sync, uint8_t* lich, uint8_t* sacch_sym,
                                      uint8_t* sacch_rel, uint8_t* facch_sym, uint8_t* facch_rel, uint8_t* valid, hipStream_t st);
@@ -261,6 +262,27 @@ hipError_t ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, u
                                       hipStream_t st);
 hipError_t ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_t* metric, hipStream_t st);
 hipError_t ddn_dev_r34(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* out, hipStream_t st);
+hipError_t ddn_dev_r34_list_wanted(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, const uint8_t* wanted, uint8_t* backs,
+                                   uint32_t* cand, int32_t* count, hipStream_t st);
+// the DMR chain's data-burst / embedded-signalling stages (ddn_dmr_data.hip, k_dmr_r34_pick in ddn_trellis.hip)
+hipError_t ddn_dev_dmr_data_select(const int32_t* events, const int32_t* n_events, int max_events, int carry, int n_channels,
+                                   int max_bursts, const int32_t* sync_pos, const int32_t* n_sync, int max_syncs, const int32_t* out_pos,
+                                   const int32_t* out_n, int max_out, const int32_t* n_new, int32_t* dstart, uint8_t* dslot,
+                                   int32_t* dpre, int32_t* dn, hipStream_t st);
+hipError_t ddn_dev_dmr_data_gather(const uint8_t* rec, size_t max_sym, const int32_t* dstart, const int32_t* dpre, const uint8_t* pre90,
+                                   const uint8_t* prel90, const uint8_t* pre90_out, const uint8_t* prel90_out, long split, int max_bursts,
+                                   int n_channels, uint8_t* slot_type, uint8_t* info, uint8_t* td98, uint8_t* rel98, hipStream_t st);
+hipError_t ddn_dev_dmr_data_prep(const int32_t* dstart, const uint8_t* slot_type, const uint8_t* st_ok, const uint8_t* pdu96, int n,
+                                 uint8_t* type, uint8_t* bytes12, uint8_t* cw12, hipStream_t st);
+hipError_t ddn_dev_dmr_data_finish(const uint8_t* type, const uint8_t* pdu96, const uint8_t* info, const uint8_t* cw12,
+                                   const uint8_t* rs_result, int n, uint8_t* bytes12, uint8_t* crc, uint8_t* r34_wanted, hipStream_t st);
+hipError_t ddn_dev_dmr_r34_pick(const uint8_t* td98, const uint8_t* rel98, const uint8_t* wanted, const uint8_t* hard18,
+                                const uint8_t* soft18, const uint8_t* list24, const int32_t* list_n, int n, uint8_t* pool24,
+                                int32_t* pool_n, uint8_t* unconf18, uint8_t* conf18, uint8_t* conf_crc, hipStream_t st);
+hipError_t ddn_dev_dmr_emb_collect(const int32_t* events, const int32_t* n_events, int max_events, int carry, const uint8_t* rec,
+                                   size_t max_sym, int n_channels, int max_lc, uint8_t* sig, uint8_t* in128, int32_t* lc_pos,
+                                   int32_t* lc_n, hipStream_t st);
+hipError_t ddn_dev_dmr_emb_finish(const uint8_t* out77, const int32_t* lc_pos, int n, uint8_t* ok, hipStream_t st);
 hipError_t ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int n_bits, uint16_t* metrics_io,
                            uint8_t* out, int out_stride, hipStream_t st);
 hipError_t ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out,

@@ -338,6 +338,7 @@ bs_burst_done(const Ctx& x, int pos) {
     const int slot = x.f(F_ISLOT);
     const int kind = sync_kind(x);
     const bool is_voice = kind == 1, is_data = kind == 2;
+    const int vc_read = x.f(F_VC1 + slot); // the VC read_dmr_bs_sync_segment() filed the sync segment under (dmr_bs.c:161-180)
     if (is_voice) { // note_dmr_bs_voice_sync()
         x.f(F_VC1 + slot) = 1;
         x.f(F_EMBERR0 + slot) = 0;
@@ -417,7 +418,7 @@ bs_burst_done(const Ctx& x, int pos) {
             if (ended) {
                 action = 2;
             }
-            x.ev(pos, EV_DMR_VOICE_BURST, slot, cc, (is_voice ? 1 : 0) | (action << 4));
+            x.ev(pos, EV_DMR_VOICE_BURST, slot, cc, (is_voice ? 1 : 0) | (action << 4) | (vc_read << 8));
         }
     }
     if (action == 2) {

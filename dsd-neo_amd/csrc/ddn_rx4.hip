@@ -1605,7 +1605,7 @@ k_dmr_voice_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ 
                    const int32_t* __restrict__ burst_start, int max_bursts, int inverted, uint8_t* __restrict__ fr,
                    uint8_t* __restrict__ rl, uint8_t* __restrict__ sync48, uint8_t* __restrict__ cach24,
                    uint8_t* __restrict__ valid, int rows_per_channel, const int32_t* __restrict__ pre_slot,
-                   const uint8_t* __restrict__ pre90, uint8_t* __restrict__ skip3) {
+                   const uint8_t* __restrict__ pre90, uint8_t* __restrict__ skip3, const uint8_t* __restrict__ pre90_b, long split) {
     // (the chain's talk paths: row = 2 * channel + time slot, rows_per_channel = 2; a burst whose sync the frame sync search found
     // takes its first 90 dibits from that sync's hand-over, pre90[pre_slot] - dmrBSBootstrap(), dmr_bs.c:697-760)
     const int k = blockIdx.x, row = blockIdx.y, ch = row / rows_per_channel, t = threadIdx.x;
@@ -1637,7 +1637,9 @@ k_dmr_voice_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ 
         d = ((rr[0] & 3) ^ (inverted ? 2 : 0)) & 3;
         q = rr[1];
         if (ps >= 0 && t < 90) {
-            d = pre90[(size_t)ps * 90 + t] & 3; // seed_dmr_bs_bootstrap_payload(): already turned round when inverted
+            // seed_dmr_bs_bootstrap_payload(): already turned round when inverted.  (pre_slot >= split: the sync waits for the
+            // next call's decode pass - its hand-over is in the carry-out list)
+            d = (pre90_b && ps >= split ? pre90_b[(size_t)(ps - split) * 90 + t] : pre90[(size_t)ps * 90 + t]) & 3;
             q = 0;
         }
     }
@@ -1687,7 +1689,7 @@ ddn_dev_dmr_voice_gather(const uint8_t* rec, const int32_t* counts, size_t max_s
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_dmr_voice_gather, dim3((unsigned)max_bursts, (unsigned)n_channels), dim3(160), 0, st, rec, counts, max_sym,
-                       burst_start, max_bursts, inverted, fr, rl, sync48, cach24, valid, 1, nullptr, nullptr, nullptr);
+                       burst_start, max_bursts, inverted, fr, rl, sync48, cach24, valid, 1, nullptr, nullptr, nullptr, nullptr, 0L);
     return hipGetLastError();
 }
 
@@ -1698,11 +1700,14 @@ ddn_dev_dmr_voice_gather(const uint8_t* rec, const int32_t* counts, size_t max_s
 // process_dmr_bs_bootstrap_voice_if_open()).  One thread per channel files them by time slot: talk path = 2 * channel + slot, in air
 // order; start = row index of the burst's first CACH dibit (the row holds `carry` records of the previous call, then this call's);
 // pre = the sync slot whose 90-dibit hand-over are the burst's first 90 dibits when the burst is the one the sync search found
-// (the sync's last symbol is the burst's dibit 89), else -1.
+// (the sync's last symbol is the burst's dibit 89), else -1.  The sync is either in this call's decode list (slot index) or, when
+// the records behind it are not all in yet, in the list carried to the next call (n_channels * max_syncs + its index there).
 __global__ void
 k_dmr_voice_select(const int32_t* __restrict__ events, const int32_t* __restrict__ n_events, int max_events, int carry,
                    const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_sync, int max_syncs, int n_channels,
-                   int max_bursts, int32_t* __restrict__ vstart, int32_t* __restrict__ vpre, int32_t* __restrict__ vn) {
+                   int max_bursts, int32_t* __restrict__ vstart, int32_t* __restrict__ vpre, int32_t* __restrict__ vn,
+                   const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_n, int max_out,
+                   const int32_t* __restrict__ n_new) {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= n_channels) {
         return;
@@ -1728,6 +1733,14 @@ k_dmr_voice_select(const int32_t* __restrict__ events, const int32_t* __restrict
                 pre = ch * max_syncs + j;
             }
         }
+        if (pre < 0 && out_pos) {
+            const int no = out_n[ch] < max_out ? out_n[ch] : max_out;
+            for (int j = 0; j < no; j++) {
+                if (out_pos[(size_t)ch * max_out + j] == carry + e[0] - 54 - n_new[ch]) {
+                    pre = n_channels * max_syncs + ch * max_out + j;
+                }
+            }
+        }
         vpre[so] = pre;
     }
     for (int slot = 0; slot < 2; slot++) {
@@ -1742,12 +1755,12 @@ k_dmr_voice_select(const int32_t* __restrict__ events, const int32_t* __restrict
 extern "C" hipError_t
 ddn_dev_dmr_voice_select(const int32_t* events, const int32_t* n_events, int max_events, int carry, const int32_t* sync_pos,
                          const int32_t* n_sync, int max_syncs, int n_channels, int max_bursts, int32_t* vstart, int32_t* vpre,
-                         int32_t* vn, hipStream_t st) {
+                         int32_t* vn, const int32_t* out_pos, const int32_t* out_n, int max_out, const int32_t* n_new, hipStream_t st) {
     if (n_channels <= 0 || max_bursts <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_dmr_voice_select, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, events, n_events, max_events, carry,
-                       sync_pos, n_sync, max_syncs, n_channels, max_bursts, vstart, vpre, vn);
+                       sync_pos, n_sync, max_syncs, n_channels, max_bursts, vstart, vpre, vn, out_pos, out_n, max_out, n_new);
     return hipGetLastError();
 }
 
@@ -1755,12 +1768,12 @@ ddn_dev_dmr_voice_select(const int32_t* events, const int32_t* n_events, int max
 extern "C" hipError_t
 ddn_dev_dmr_voice_gather_paths(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* vstart, const int32_t* vpre,
                                const uint8_t* pre90, int max_bursts, int n_channels, int inverted, uint8_t* fr, uint8_t* skip3,
-                               hipStream_t st) {
+                               const uint8_t* pre90_out, long split, hipStream_t st) {
     if (n_channels <= 0 || max_bursts <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_dmr_voice_gather, dim3((unsigned)max_bursts, (unsigned)(2 * n_channels)), dim3(160), 0, st, rec, counts, max_sym,
-                       vstart, max_bursts, inverted, fr, nullptr, nullptr, nullptr, nullptr, 2, vpre, pre90, skip3);
+                       vstart, max_bursts, inverted, fr, nullptr, nullptr, nullptr, nullptr, 2, vpre, pre90, skip3, pre90_out, split);
     return hipGetLastError();
 }
 

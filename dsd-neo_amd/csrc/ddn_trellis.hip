@@ -581,13 +581,23 @@ k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint3
 template <bool SOFT>
 __global__ __launch_bounds__(64) void
 k_r34_list(const uint8_t* __restrict__ dibits, const uint8_t* __restrict__ reliab, int n, int max_cand,
-           uint8_t* __restrict__ backs, uint32_t* __restrict__ cand_out, int32_t* __restrict__ count_out) {
+           uint8_t* __restrict__ backs, uint32_t* __restrict__ cand_out, int32_t* __restrict__ count_out,
+           const uint8_t* __restrict__ wanted) {
     constexpr int CW = 8, K = 32;
     constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     __shared__ uint8_t dd[CW][100];
     __shared__ uint8_t rr[CW][100];
     const int tid = threadIdx.x;
     const int cw0 = blockIdx.x * CW;
+    // wanted (optional): only the codewords with a non-zero byte are decoded, the others report count 0
+    const bool in_range = (cw0 + (tid >> 3)) < n;
+    const bool want_me = in_range && (!wanted || wanted[cw0 + (tid >> 3)] != 0);
+    if (!__any(want_me)) {
+        if ((tid & 7) == 0 && in_range) {
+            count_out[cw0 + (tid >> 3)] = 0;
+        }
+        return;
+    }
     for (int idx = tid; idx < CW * 98; idx += 64) {
         const int c = idx / 98, i = idx - c * 98;
         if (cw0 + c < n) {
@@ -601,7 +611,7 @@ k_r34_list(const uint8_t* __restrict__ dibits, const uint8_t* __restrict__ relia
     __syncthreads();
     const int c = tid >> 3, ns = tid & 7;
     const int base = tid & ~7;
-    const bool live = (cw0 + c) < n;
+    const bool live = want_me;
     const size_t cw = (size_t)(cw0 + (live ? c : 0));
     uint32_t pk[K];
 #pragma unroll
@@ -723,6 +733,8 @@ k_r34_list(const uint8_t* __restrict__ dibits, const uint8_t* __restrict__ relia
         if (ns == 0) {
             count_out[cw] = count;
         }
+    } else if (ns == 0 && in_range) {
+        count_out[cw0 + c] = 0;
     }
 }
 
@@ -792,20 +804,157 @@ ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, uint32_t* ca
 }
 
 extern "C" hipError_t
-ddn_dev_r34_list(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, uint8_t* backs, uint32_t* cand,
-                 int32_t* count, hipStream_t st) {
+ddn_dev_r34_list_wanted(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, const uint8_t* wanted, uint8_t* backs,
+                        uint32_t* cand, int32_t* count, hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
     }
     const dim3 grid((unsigned)((n + 7) / 8)), blk(64);
     if (reliab) {
-        hipLaunchKernelGGL((k_r34_list<true>), grid, blk, 0, st, dibits, reliab, n, max_cand, backs, cand, count);
+        hipLaunchKernelGGL((k_r34_list<true>), grid, blk, 0, st, dibits, reliab, n, max_cand, backs, cand, count, wanted);
     } else {
-        hipLaunchKernelGGL((k_r34_list<false>), grid, blk, 0, st, dibits, reliab, n, max_cand, backs, cand, count);
+        hipLaunchKernelGGL((k_r34_list<false>), grid, blk, 0, st, dibits, reliab, n, max_cand, backs, cand, count, wanted);
     }
     return hipGetLastError();
 }
 
+extern "C" hipError_t
+ddn_dev_r34_list(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, uint8_t* backs, uint32_t* cand,
+                 int32_t* count, hipStream_t st) {
+    return ddn_dev_r34_list_wanted(dibits, reliab, n, max_cand, nullptr, backs, cand, count, st);
+}
+
+
+// ---- DMR rate 3/4 data bursts: the candidate pool of dmr_dburst_pick_trellis_payload() (src/protocol/dmr/dmr_dburst.c:397-536) ----------
+// One thread per wanted burst: pool = {hard decode, soft decode, the list decoder's candidates} in that order, identical payloads
+// once, each with dmr_r34_candidate_metric() (dmr_34_viterbi.c:410-444: the weighted cost of the payload's own path), its DBSN and
+// whether its CRC9 checks (dmr_dburst_trellis_candidate_metrics()).  Two picks: the one the reference makes while
+// state->data_conf_data = 0 (the cheaper of hard and soft - the list is not consulted then) and the one it makes for confirmed data
+// before the DBSN expectation is applied (cheapest candidate with a good CRC9, else the cheapest); the pool itself is kept for the
+// caller that tracks the DBSN sequence.  Pool entry = ddn_r34_candidate {metric, 18 bytes} + {crc9 ok, DBSN} in the two pad bytes.
+__global__ void
+k_dmr_r34_pick(const uint8_t* __restrict__ td98, const uint8_t* __restrict__ rel98, const uint8_t* __restrict__ wanted,
+               const uint8_t* __restrict__ hard18, const uint8_t* __restrict__ soft18, const uint8_t* __restrict__ list24,
+               const int32_t* __restrict__ list_n, int n, uint8_t* __restrict__ pool24, int32_t* __restrict__ pool_n,
+               uint8_t* __restrict__ unconf18, uint8_t* __restrict__ conf18, uint8_t* __restrict__ conf_crc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    if (!wanted[i]) {
+        pool_n[i] = 0;
+        conf_crc[i] = 0;
+        for (int b = 0; b < 18; b++) {
+            unconf18[(size_t)i * 18 + b] = 0;
+            conf18[(size_t)i * 18 + b] = 0;
+        }
+        return;
+    }
+    uint8_t nib[49], rhi[49], rlo[49];
+    {
+        uint8_t dei[98], rdei[98];
+        for (int k = 0; k < 98; k++) {
+            const int p = deinterleave98(k);
+            dei[p] = td98[(size_t)i * 98 + k] & 3;
+            rdei[p] = rel98[(size_t)i * 98 + k];
+        }
+        for (int t = 0; t < 49; t++) {
+            nib[t] = (uint8_t)((dei[2 * t] << 2) | dei[2 * t + 1]);
+            rhi[t] = rdei[2 * t];
+            rlo[t] = rdei[2 * t + 1];
+        }
+    }
+    uint8_t* pool = pool24 + (size_t)i * 34 * 24;
+    int count = 0;
+    const int nl = list_n[i] < 32 ? list_n[i] : 32;
+    int n_hs = 0;
+    for (int src = 0; src < 2 + nl; src++) {
+        const uint8_t* b18 = src == 0 ? hard18 + (size_t)i * 18 : (src == 1 ? soft18 + (size_t)i * 18 : list24 + ((size_t)i * 32 + (src - 2)) * 24 + 4);
+        bool dup = false;
+        for (int c = 0; c < count && !dup; c++) {
+            bool same = true;
+            for (int b = 0; b < 18; b++) {
+                same = same && pool[c * 24 + 4 + b] == b18[b];
+            }
+            dup = same;
+        }
+        if (!dup && count < 34) {
+            int metric = 0, prev = 0;
+            for (int t = 0; t < 49; t++) {
+                int next = 0;
+                if (t < 48) {
+                    const int g = t >> 3, item = t & 7;
+                    const uint32_t packed = ((uint32_t)b18[3 * g] << 16) | ((uint32_t)b18[3 * g + 1] << 8) | b18[3 * g + 2];
+                    next = (int)((packed >> (21 - 3 * item)) & 7u);
+                }
+                const int x = c_r34_point_to_nibble[c_r34_fsm[prev * 8 + next]] ^ nib[t];
+                metric += ((x >> 3) & 1) * rhi[t] + ((x >> 2) & 1) * rhi[t] + ((x >> 1) & 1) * rlo[t] + (x & 1) * rlo[t];
+                prev = next;
+            }
+            // DBSN(7) | CRC9 ^ 0x1FF | 16 bytes: ComputeCrc9Bit over the 128 payload bits, then the DBSN
+            uint32_t c9 = 0;
+            for (int b = 16; b < 144; b++) {
+                const int bit = (b18[b >> 3] >> (7 - (b & 7))) & 1;
+                c9 = (((c9 >> 8) & 1) ^ (uint32_t)bit) ? ((c9 << 1) ^ 0x059u) : (c9 << 1);
+            }
+            for (int b = 0; b < 7; b++) {
+                const int bit = (b18[0] >> (7 - b)) & 1;
+                c9 = (((c9 >> 8) & 1) ^ (uint32_t)bit) ? ((c9 << 1) ^ 0x059u) : (c9 << 1);
+            }
+            const uint32_t ext = ((((uint32_t)b18[0] & 1u) << 8) | b18[1]) ^ 0x1FFu;
+            uint8_t* o = pool + count * 24;
+            o[0] = (uint8_t)metric;
+            o[1] = (uint8_t)(metric >> 8);
+            o[2] = (uint8_t)(metric >> 16);
+            o[3] = (uint8_t)(metric >> 24);
+            for (int b = 0; b < 18; b++) {
+                o[4 + b] = b18[b];
+            }
+            o[22] = (((c9 & 0x1FFu) ^ 0x1FFu) == ext) ? 1 : 0;
+            o[23] = (uint8_t)(b18[0] >> 1);
+            count++;
+        }
+        if (src == 1) {
+            n_hs = count;
+        }
+    }
+    pool_n[i] = count;
+    int best_u = -1, best_any = -1, best_crc = -1, mu = 0, ma = 0, mc = 0;
+    for (int c = 0; c < count; c++) {
+        const uint8_t* o = pool + c * 24;
+        const int m = (int)((uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24));
+        if (c < n_hs && (best_u < 0 || m < mu)) {
+            best_u = c;
+            mu = m;
+        }
+        if (best_any < 0 || m < ma) {
+            best_any = c;
+            ma = m;
+        }
+        if (o[22] && (best_crc < 0 || m < mc)) {
+            best_crc = c;
+            mc = m;
+        }
+    }
+    const int pick_c = best_crc >= 0 ? best_crc : best_any;
+    for (int b = 0; b < 18; b++) {
+        unconf18[(size_t)i * 18 + b] = best_u >= 0 ? pool[best_u * 24 + 4 + b] : 0;
+        conf18[(size_t)i * 18 + b] = pick_c >= 0 ? pool[pick_c * 24 + 4 + b] : 0;
+    }
+    conf_crc[i] = best_crc >= 0 ? 1 : 0;
+}
+
+extern "C" hipError_t
+ddn_dev_dmr_r34_pick(const uint8_t* td98, const uint8_t* rel98, const uint8_t* wanted, const uint8_t* hard18, const uint8_t* soft18,
+                     const uint8_t* list24, const int32_t* list_n, int n, uint8_t* pool24, int32_t* pool_n, uint8_t* unconf18,
+                     uint8_t* conf18, uint8_t* conf_crc, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_dmr_r34_pick, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, td98, rel98, wanted, hard18, soft18, list24, list_n, n,
+                       pool24, pool_n, unconf18, conf18, conf_crc);
+    return hipGetLastError();
+}
 
 // ---- P25 Phase 1 confirmed data: the rate 3/4 blocks' LLR list decoder (p25_mbf34_decode_soft_list, src/protocol/p25/phase1/
 // p25p1_mbf34.c:129-213) ----------------------------------------------------------------------------------------------------------

@@ -163,8 +163,10 @@ int ddn_p25_chain_get_stage_ms(ddn_p25_chain* c, float out4[4]);
 /* ---- DMR / NXDN48: the same shape for BASELINE configs[3]'s other two protocols ------------------------------------------------
  *   cu8 / cf32 I/Q -> front end (12.5 kHz / 6.25 kHz channel filter) -> matched filter + receive loop (ddn_fsk4_rx_run; handlers = 1:
  *   dmr_data_sync / dmrBSBootstrap + dmrBS / nxdn_frame's LICH gate decide the in-frame lengths inside the loop)
- *   DMR:    burst gather -> slot type Golay(20,8) -> BPTC(196,96); the voice bursts the BS handlers pass on (dmrBSBootstrap / dmrBS):
- *           three AMBE 3600x2450 frames each -> frame FEC -> synthesis, one talk path per time slot (vocoder = 1)
+ *   DMR:    burst gather -> slot type Golay(20,8) -> BPTC(196,96); the data bursts the handlers dispatch: type CRC / RS(12,9) full
+ *           link control / rate 3/4 candidates; embedded link control BPTC(128,77) (handlers = 1); the voice bursts the BS handlers
+ *           pass on (dmrBSBootstrap / dmrBS): three AMBE 3600x2450 frames each -> frame FEC -> synthesis, one talk path per time slot
+ *           (vocoder = 1)
  *   NXDN48: frame gather -> SACCH / FACCH1 K=5 decode + CRC6 / CRC12 + the greedy SACCH retry -> the voice frames the LICHs announce:
  *           AMBE de-interleave -> AMBE 3600x2450 frame FEC -> synthesis (vocoder = 1)
  * One call per batch of samples_per_call samples; carried state streams from call to call.  Bursts / frames that cross a call
@@ -217,7 +219,8 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     int dmr_voice_bursts;            /* burst slots per talk path and call */
     const int32_t* d_dmr_n_voice;    /* [2 B] voice bursts of this call */
     const int32_t* d_dmr_voice_start; /* [2 B][dmr_voice_bursts] row index of the burst's first CACH dibit (-1: unused) */
-    const int32_t* d_dmr_voice_pre;  /* [2 B][dmr_voice_bursts] sync slot whose 90-dibit hand-over opens the burst (the bootstrap burst), else -1 */
+    const int32_t* d_dmr_voice_pre;  /* [2 B][dmr_voice_bursts] sync slot whose 90-dibit hand-over opens the burst (the bootstrap burst), else -1
+                                        (>= n_channels * max_syncs: a sync that waits for the next call's decode pass) */
     const uint8_t* d_dmr_voice_skip; /* [2 B][dmr_voice_bursts][3] 0xFF = unused slot */
     const uint8_t* d_dmr_ambe_frames; /* [2 B][dmr_voice_bursts][3][4][24] */
     const uint8_t* d_dmr_ambe_bits;  /* [2 B][dmr_voice_bursts * 3][49] */
@@ -226,6 +229,47 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const int32_t* d_events;         /* [B][max_events][4] the handlers' decisions of this call (include/ddn_fsk4.h) */
     const int32_t* d_n_events;       /* [B] */
     int max_events;
+    /* DMR data bursts (protocol DMR, handlers = 1; NULL otherwise): the bursts dmr_data_dispatch_burst() hands to
+     * dmr_data_burst_handler() (src/protocol/dmr/dmr_data.c:262-280 - found by the sync search or read inside dmrBS(); decided in the
+     * receive loop, event kind 6 with VC = 0), in air order per channel, decoded in the call that holds the burst's last symbol.  What
+     * the handler computes before it hands over to the protocol layer (src/protocol/dmr/dmr_dburst.c:323-650):
+     *   type    the slot type's data type (0 PI, 1 VLC, 2 TLC, 3 CSBK, 4 MBC header, 5 MBC continuation, 6 data header, 7 rate 1/2,
+     *           8 rate 3/4, 9 idle, 10 rate 1, 11 USBD; 0xFF: unused entry)
+     *   bytes12 the BPTC(196,96) payload; for VLC / TLC after RS(12,9) (ComputeAndCorrectFullLinkControlCrc(), dmr_utils.c:291-351: a
+     *           decodable word replaces the received bytes)
+     *   crc     bit 0 = crc_correct as the handler computes it while state->data_conf_data = 0 (RS(12,9) for VLC / TLC, CRC-CCITT
+     *           with the type's mask, 1 for unconfirmed rate 1/2, 3/4, 1 blocks); bit 1 = the CRC9 of a confirmed rate 1/2 / rate 1
+     *           block (what crc_correct is while data_conf_data = 1); bit 2 = RS(12,9) corrected symbols
+     *   rate 3/4 (type 8): unconfirmed = the cheaper of the hard and soft Viterbi paths (dmr_dburst_pick_trellis_payload() while
+     *           data_conf_data = 0); confirmed = the pick over hard + soft + the list-32 candidates before the DBSN expectation is
+     *           applied (cheapest candidate with a good CRC9, else the cheapest; confirmed_crc = a good CRC9 was found); pool = every
+     *           candidate in the reference's order {metric, 18 bytes} with {CRC9 ok, DBSN} in the entry's two pad bytes, for the
+     *           caller that tracks state->data_dbsn_expected.
+     * The protocol layer's running state (confirmed / unconfirmed, DBSN sequence, block assembly: dmr_block.c) is the caller's. */
+    int dmr_data_bursts;                 /* entries per channel and call */
+    const int32_t* d_dmr_n_data;         /* [B] */
+    const int32_t* d_dmr_data_start;     /* [B][dmr_data_bursts] row index of the burst's first CACH dibit (-1: unused) */
+    const uint8_t* d_dmr_data_slot;      /* [B][dmr_data_bursts] time slot 0 / 1 */
+    const uint8_t* d_dmr_data_type;      /* [..] */
+    const uint8_t* d_dmr_data_info196;   /* [..][196] the burst's info bits as received (rate 1 payload) */
+    const uint8_t* d_dmr_data_bits96;    /* [..][96] BPTC(196,96) output bits */
+    const uint8_t* d_dmr_data_bytes12;   /* [..][12] */
+    const uint32_t* d_dmr_data_errs;     /* [..] BPTC irrecoverable errors */
+    const uint8_t* d_dmr_data_crc;       /* [..] */
+    const uint8_t* d_dmr_r34_unconfirmed; /* [..][18] */
+    const uint8_t* d_dmr_r34_confirmed;  /* [..][18] */
+    const uint8_t* d_dmr_r34_confirmed_crc; /* [..] */
+    const ddn_r34_candidate* d_dmr_r34_pool; /* [..][34] */
+    const int32_t* d_dmr_r34_pool_n;     /* [..] */
+    /* DMR embedded link control: dmr_data_burst_handler(.., 0xEB, ..) at every voice burst with VC 6 (handle_dmr_bs_slot_vc6_pre_link(),
+     * dmr_bs.c:428-446) over the sync fields read under VC 2..5 (the store streams from call to call like
+     * state->dmr_embedded_signalling): BPTC(128,77) -> 72 LC bits + 5 checksum bits, ok = ComputeCrc5Bit matches.  Per talk path. */
+    int dmr_emb_lcs;                     /* entries per talk path and call */
+    const int32_t* d_dmr_n_emb;          /* [2 B] */
+    const int32_t* d_dmr_emb_pos;        /* [2 B][dmr_emb_lcs] row index of the VC 6 burst's last symbol (-1: unused) */
+    const uint8_t* d_dmr_emb_lc77;       /* [2 B][dmr_emb_lcs][77] */
+    const uint32_t* d_dmr_emb_errs;      /* [..] */
+    const uint8_t* d_dmr_emb_ok;         /* [..] */
 } ddn_fsk4_chain_results;
 typedef struct ddn_fsk4_chain ddn_fsk4_chain;
 int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);

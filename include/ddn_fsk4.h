@@ -55,7 +55,8 @@ int ddn_fsk4_rx_reset(ddn_fsk4_rx* b);
  *   kind 4 NXDN LICH        a = accepted, b = LICH (7 bits), c = parity ok
  *   kind 5 DMR data burst   a = slot type ok, b = colour code (-1 Golay failed, -2 TACT failed), c = data type | reject << 8 | pending << 9
  *   kind 6 "Color Code="    a = the value the reference prints (16 = XX), b = VC (0: data burst), c = slot
- *   kind 7 DMR voice burst  a = slot, b = EMB colour code (25: none), c = voice sync word | action << 4 (1 on, 2 end)
+ *   kind 7 DMR voice burst  a = slot, b = EMB colour code (25: none), c = voice sync word | action << 4 (1 on, 2 end) | the VC the
+ *                           burst's sync segment was read under << 8 (2..6: filed as that burst's embedded signalling)
  *   kind 8 DMR voice end    a = 1 bootstrap / 0 loop, b = TACT ok, c = EMB / sync ok */
 int ddn_fsk4_rx_set_handlers(ddn_fsk4_rx* b, int enable);
 int ddn_fsk4_rx_set_events(ddn_fsk4_rx* b, int32_t* d_events, int32_t* d_n_events, size_t max_events);

@@ -588,6 +588,9 @@ bs_burst_done(orc_dmrh* h, long pos, orc_hevents* ev) {
         emb[i + 8] = sd[i + 40];
     }
     const int is_voice = sync_is(h->pay + 66, k_bs_voice), is_data = sync_is(h->pay + 66, k_bs_data);
+    /* the VC the sync segment was read under (read_dmr_bs_sync_segment(), dmr_bs.c:161-180: 2..6 files the 48 bits as that burst's
+     * embedded signalling) */
+    const int vc_read = slot == 0 ? h->vc1 : h->vc2;
     if (is_voice) { /* note_dmr_bs_voice_sync() */
         if (slot == 0) {
             h->vc1 = 1;
@@ -685,7 +688,7 @@ bs_burst_done(orc_dmrh* h, long pos, orc_hevents* ev) {
             if (ended) {
                 action = 2;
             }
-            ev_push(ev, pos, ORC_HEV_DMR_VOICE_BURST, slot, cc, (is_voice ? 1 : 0) | (action << 4));
+            ev_push(ev, pos, ORC_HEV_DMR_VOICE_BURST, slot, cc, (is_voice ? 1 : 0) | (action << 4) | (vc_read << 8));
         }
     }
     if (action == 2) {

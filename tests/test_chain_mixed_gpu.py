@@ -247,3 +247,165 @@ def test_dmr_chain_voice_bursts_to_pcm(built):
                 assert np.array_equal(g[4], ro[0]), (tp, pos)
                 total += 1
     assert total >= 18, total
+
+
+def _dmr_data_stream(rng):
+    """a BS stream of data bursts (both time slots alternating): CSBKs until the colour-code gate locks, then every data type the
+    handler treats differently -> (dibits, [(type, kwargs, what was sent)])"""
+    import dmrgen
+    plan = [(3, {})] * 8 + [(6, {}), (8, {}), (8, {}), (8, dict(confirmed=True, dbsn=0)), (8, dict(confirmed=True, dbsn=1)),
+                            (8, dict(confirmed=True, dbsn=2, good_crc=False)), (7, {}), (7, dict(confirmed=True, dbsn=3)),
+                            (10, dict(confirmed=True)), (1, {}), (2, {}), (1, dict(hurt=True)), (3, dict(good_crc=False)), (0, {}), (11, {}),
+                            (4, {}), (5, {}), (9, {}), (6, dict(good_crc=False)), (3, {})]
+    plan = plan + plan[8:]
+    out, sent = [], []
+    for k, (ty, kw) in enumerate(plan):
+        kw = dict(kw)
+        hurt = kw.pop("hurt", False)
+        if ty == 8:
+            s = dmrgen.r34_bytes(rng, **kw)
+            info = dmrgen.r34_info(s)
+        elif ty == 10:
+            info = rng.integers(0, 2, 196).astype(np.uint8)
+            info[96:100] = 0
+            c = dmrgen.crc9_confirmed_rate1(info)
+            info[7:16] = [(c >> (8 - i)) & 1 for i in range(9)]
+            s = info.copy()
+        else:
+            s = dmrgen.payload_bits(ty, rng, **kw)
+            t = s.copy()
+            if hurt:
+                t[16:24] ^= np.unpackbits(np.array([0xA5], np.uint8))          # one wrong byte: RS(12,9) repairs it
+            info = dmrgen.bptc_196x96(t)
+        out.append(dmrgen.burst(k & 1, 7, ty, info))
+        sent.append((ty, kw, hurt, s))
+    return np.concatenate(out), sent
+
+
+def _dmr_voice_stream(rng, n_superframes=4):
+    """CSBKs on both slots until the colour-code gate locks, then voice superframes on slot 1 (link control embedded in bursts B..E,
+    the third one with a wrong checksum) beside idle data bursts on slot 2 -> (dibits, the link controls sent)"""
+    import dmrgen
+    out = [dmrgen.burst(k & 1, 7, 3, dmrgen.bptc_196x96(dmrgen.payload_bits(3, rng))) for k in range(8)]
+    lcs = []
+    for q in range(n_superframes):
+        lc = rng.integers(0, 2, 72).astype(np.uint8)
+        good = q != 2
+        crc5 = None if good else (int(np.packbits(lc).astype(np.int64).sum()) % 31) ^ 0x0A
+        lcs.append((lc, good))
+        for b in dmrgen.voice_superframe(0, 7, lc, rng, crc5):
+            out += [b, dmrgen.burst(1, 7, 9, dmrgen.bptc_196x96(rng.integers(0, 2, 96)))]
+    return np.concatenate(out), lcs
+
+
+def test_dmr_chain_data_bursts_link_control_rate34_and_embedded_lc(built):
+    """The DMR chain's data-burst and embedded-signalling stages (include/ddn_chain.h: d_dmr_data_*, d_dmr_r34_*, d_dmr_emb_*): three of
+    the reference's DMR captures and a synthetic stream with every data type, streamed in three calls + the flush, against the CPU
+    restatement of the whole stream (tests/dmr_data.py): the same dispatched bursts in the same order with the same type, BPTC bits,
+    RS(12,9)-repaired link control, CRC flags, rate 3/4 picks and candidate pools, and the same embedded link controls per talk path -
+    bursts that straddle a call boundary included."""
+    import dmr_data
+    import p25gen
+    rng = np.random.default_rng(23)
+    caps = ("iq_dmr_t3_ras_cc.npz", "iq_dmr_voice.npz", "iq_dmr_t3_cc.npz")
+    n, calls = 32000, 3
+    dib, sent = _dmr_data_stream(rng)
+    syn = p25gen.modulate_cu8(dib, n * calls, lead=300, seed=4, noise=0.02)
+    vdib, lcs_sent = _dmr_voice_stream(rng)
+    vsyn = p25gen.modulate_cu8(vdib, n * calls, lead=300, seed=5, noise=0.02)
+    iq = np.stack([np.ascontiguousarray(golden(c)["iq"], np.uint8)[:n * calls] for c in caps] + [vsyn, syn])
+    B = iq.shape[0]
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_DMR, rf_mod=2, vocoder=0)
+    got = [[] for _ in range(B)]
+    got_lc = [[] for _ in range(2 * B)]
+    base = np.zeros(B, np.int64)
+    for k in range(calls + 1):
+        if k < calls:
+            d = _upload(np.ascontiguousarray(iq[:, k * n:(k + 1) * n]))
+            ch.run(d)
+        else:
+            ch.flush()
+        r = ch.results()
+        f = ch.fetch
+        db, lb, T = r.dmr_data_bursts, r.dmr_emb_lcs, int(r.carry_symbols)
+        nd, st = f(r.d_dmr_n_data, np.int32, (B,)), f(r.d_dmr_data_start, np.int32, (B, db))
+        slot, ty = f(r.d_dmr_data_slot, np.uint8, (B, db)), f(r.d_dmr_data_type, np.uint8, (B, db))
+        bits, by = f(r.d_dmr_data_bits96, np.uint8, (B, db, 96)), f(r.d_dmr_data_bytes12, np.uint8, (B, db, 12))
+        info, errs = f(r.d_dmr_data_info196, np.uint8, (B, db, 196)), f(r.d_dmr_data_errs, np.uint32, (B, db))
+        crc = f(r.d_dmr_data_crc, np.uint8, (B, db))
+        un, co = f(r.d_dmr_r34_unconfirmed, np.uint8, (B, db, 18)), f(r.d_dmr_r34_confirmed, np.uint8, (B, db, 18))
+        cc, pn = f(r.d_dmr_r34_confirmed_crc, np.uint8, (B, db)), f(r.d_dmr_r34_pool_n, np.int32, (B, db))
+        pool = f(r.d_dmr_r34_pool, np.uint8, (B, db, 34, 24))
+        ne, ep = f(r.d_dmr_n_emb, np.int32, (2 * B,)), f(r.d_dmr_emb_pos, np.int32, (2 * B, lb))
+        lc, le, lo = f(r.d_dmr_emb_lc77, np.uint8, (2 * B, lb, 77)), f(r.d_dmr_emb_errs, np.uint32, (2 * B, lb)), f(r.d_dmr_emb_ok, np.uint8, (2 * B, lb))
+        for c in range(B):
+            assert nd[c] <= db and np.all(st[c, nd[c]:] == -1)
+            for j in range(int(nd[c])):
+                got[c].append(dict(pos=int(base[c]) + int(st[c, j]) - T + 143, slot=int(slot[c, j]), type=int(ty[c, j]), bits96=bits[c, j].copy(),
+                                   bytes12=by[c, j].copy(), info=info[c, j].copy(), errs=int(errs[c, j]), crc=int(crc[c, j]),
+                                   unconfirmed=un[c, j].copy(), confirmed=co[c, j].copy(), confirmed_crc=int(cc[c, j]),
+                                   pool=pool[c, j, :int(pn[c, j])].copy()))
+        for tp in range(2 * B):
+            assert ne[tp] <= lb and np.all(ep[tp, ne[tp]:] == -1)
+            for j in range(int(ne[tp])):
+                got_lc[tp].append((int(base[tp // 2]) + int(ep[tp, j]) - T, lc[tp, j].copy(), int(le[tp, j]), int(lo[tp, j])))
+        if k < calls:
+            base += f(r.d_new, np.int32, (B,))
+            ddn.lib().ddn_device_free(d)
+        else:
+            assert not nd.any() and not ne.any()         # (a burst is decoded in the call that holds its last symbol)
+    ch.close()
+    types_seen, n_lc, n_r34 = set(), 0, 0
+    for c in range(B):
+        fe = orc.OracleFrontEnd(profile=2)
+        disc = np.concatenate([fe.run_cu8(np.ascontiguousarray(iq[c, k * n:(k + 1) * n]), 8192) for k in range(calls)])
+        o = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_DMR, rf_mod=2, handler=1))
+        w = o.run(disc, max_sync=512)
+        want, want_lc = dmr_data.stream_expectation(w, o.events.rows())
+        assert [g["pos"] for g in got[c]] == [p for p, _, _ in want], (c, len(got[c]), len(want))
+        for g, (pos, slot, x) in zip(got[c], want):
+            assert g["slot"] == slot and g["type"] == x["type"] and np.array_equal(g["info"], x["info"]), (c, pos)
+            assert g["errs"] == x["errs"] and g["crc"] == x["crc"], (c, pos, g["type"], g["crc"], x["crc"])
+            if not x["undefined"]:
+                assert np.array_equal(g["bits96"], x["bits96"]) and np.array_equal(g["bytes12"], x["bytes12"]), (c, pos)
+            types_seen.add(x["type"])
+            if x["type"] == 8:
+                n_r34 += 1
+                assert np.array_equal(g["unconfirmed"], x["unconfirmed"]) and np.array_equal(g["confirmed"], x["confirmed"]), (c, pos)
+                assert g["confirmed_crc"] == x["confirmed_crc"] and len(g["pool"]) == len(x["pool"]), (c, pos)
+                for e, (b18, metric, ok9, dbsn) in zip(g["pool"], x["pool"]):
+                    assert int(e[:4].copy().view(np.int32)[0]) == metric and np.array_equal(e[4:22], b18) and (e[22], e[23]) == (ok9, dbsn), (c, pos)
+            else:
+                assert len(g["pool"]) == 0
+        for slot in range(2):
+            tp = 2 * c + slot
+            assert [g[0] for g in got_lc[tp]] == [x[0] for x in want_lc[slot]], (tp, got_lc[tp], want_lc[slot])
+            for g, (pos, lc77, e, ok, undefined) in zip(got_lc[tp], want_lc[slot]):
+                assert g[2] == e and (undefined or (np.array_equal(g[1], lc77) and g[3] == ok)), (tp, pos)
+                n_lc += 1
+        if c == B - 2:
+            # the synthetic voice stream: the link controls sent come back on talk path 0, the one with the wrong checksum flagged;
+            # the idle bursts of the other slot were read inside dmrBS() (no hand-over: all 144 dibits live)
+            back = [(x[1][:72], x[3]) for x in want_lc[0]]
+            assert len(back) >= len(lcs_sent) - 1 and not want_lc[1], (len(back), len(lcs_sent))
+            for (lc72, ok), (s72, good) in zip(back, lcs_sent[len(lcs_sent) - len(back):]):
+                assert np.array_equal(lc72, s72) and ok == (1 if good else 0)
+            assert sum(1 for _, _, x in want if x["type"] == 9) >= 20
+        if c == B - 1:
+            # the synthetic stream: what the clean bursts carried comes back (the first bursts feed the colour-code gate)
+            assert len(want) >= len(sent) - 8, (len(want), len(sent))
+            tail = sent[len(sent) - len(want):]
+            for (pos, slot, x), (ty, kw, hurt, s) in zip(want, tail):
+                assert x["type"] == ty, (pos, x["type"], ty)
+                if ty == 8:
+                    key = "confirmed" if kw.get("confirmed") and kw.get("good_crc", True) else "unconfirmed"
+                    assert np.array_equal(x[key], s), (pos, kw)
+                elif ty == 10:
+                    assert np.array_equal(x["info"], s) and x["crc"] == 3
+                elif ty in (1, 2):
+                    assert np.array_equal(np.unpackbits(x["bytes12"]), s) and x["crc"] == (5 if hurt else 1), (pos, ty, x["crc"])
+                elif ty != 9:
+                    assert np.array_equal(x["bits96"], s), (pos, ty)
+                    if ty != 5:          # (an MBC continuation carries no CRC: the handler's compare against 0 says nothing)
+                        assert (x["crc"] & 1) == (1 if kw.get("good_crc", True) or ty == 7 else 0), (pos, ty, kw)
+    assert {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11} <= types_seen and n_r34 >= 10 and n_lc >= 4, (types_seen, n_r34, n_lc)
