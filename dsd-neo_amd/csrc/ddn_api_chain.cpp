@@ -414,7 +414,8 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st) {
         HIP_TRY(ddn_dev_chain_pdu_gather(rec, c->d_cnt_full, stride, d_sp, c->d_pdu_slot, c->d_pdu_info, c->B, c->F, c->PF, c->PB,
                                          c->d_pdu_llr, c->d_pdu_valid, st));
         // (d_pdu_cand: scratch for the 1/2-rate candidates first, then the rate 3/4 ones - same stream)
-        DDN_TRY(ddn_fec_p25_12_soft_list_batch(c->d_pdu_llr, NB, 8, (ddn_p25_12_candidate*)c->d_pdu_cand, c->d_pdu_cnt, st));
+        // (only the blocks that lie inside the call's records: groups of 32 without one leave at once)
+        HIP_TRY(ddn_dev_p25_half_rate_list_wanted(c->d_pdu_llr, (int)NB, 8, c->d_pdu_valid, (uint32_t*)c->d_pdu_cand, c->d_pdu_cnt, st));
         HIP_TRY(ddn_dev_chain_pdu_take_first(c->d_pdu_cand, c->d_pdu_cnt, (int)NB, c->d_pdu_blocks, c->d_pdu_metric, st));
         // confirmed data: the same blocks through the rate 3/4 LLR list decoder, first candidate with a good CRC9 (:219-241)
         HIP_TRY(ddn_dev_chain_pdu_r34_wanted(c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_pdu_valid, (int)NB, c->PB, c->d_pdu_wanted, st));

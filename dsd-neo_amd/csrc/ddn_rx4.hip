@@ -738,85 +738,90 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         kfit = kfit < QCAPW - 2 - qk ? kfit : QCAPW - 2 - qk;
                         kfit = kfit < 32 ? kfit : 32;
                     }
-                    unsigned long long im = __ballot(ie && kfit >= 2);
+                    // lane -> (owner = channel column, symbol index): 64 / CPW lanes per owner, all owners at once
+                    constexpr int G = CPW >= 64 ? 1 : 64 / CPW;
+                    if (ie) {
+                        kfit = kfit < G ? kfit : G;
+                    }
+                    const unsigned long long im = __ballot(ie && kfit >= 2);
                     if (im != 0) {
-                        while (im) {
-                            const int ow = __ffsll((long long)im) - 1; // owner lane (= channel column) of this pass
-                            im &= im - 1;
-                            const int K = __builtin_amdgcn_readlane(kfit, ow), p0 = __builtin_amdgcn_readlane(pos, ow);
-                            const int flt_o = __builtin_amdgcn_readlane(s.filter_on, ow), sh_o = __builtin_amdgcn_readlane(s.shead, ow);
-                            const int qk_o = __builtin_amdgcn_readlane(qk, ow), ls_type = __builtin_amdgcn_readlane(s.lastsync, ow);
-                            const int pat_o = __builtin_amdgcn_readlane(s.cur_pat, ow);
-                            const float cen_o = __shfl(s.center, ow), um_o = __shfl(s.umid, ow), lm_o = __shfl(s.lmid, ow);
-                            const float mx_o = __shfl(s.max, ow), mn_o = __shfl(s.min, ow);
+                        const int ow = lane / G, jj = lane % G;
+                        const bool ow_ok = ow < CPW && ((im >> ow) & 1ull) != 0;
+                        const int k_ow = __shfl(kfit, ow); // (every lane takes part in the shuffles: the owners' lanes are sources)
+                        const int K = ow_ok ? k_ow : 0;
+                        const int p0 = __shfl(pos, ow), flt_o = __shfl(s.filter_on, ow), sh_o = __shfl(s.shead, ow);
+                        const int qk_o = __shfl(qk, ow), ls_type = __shfl(s.lastsync, ow), pat_o = __shfl(s.cur_pat, ow);
+                        const float cen_o = __shfl(s.center, ow), um_o = __shfl(s.umid, ow), lm_o = __shfl(s.lmid, ow);
+                        const float mx_o = __shfl(s.max, ow), mn_o = __shfl(s.min, ow);
+                        int hm_o = 0, hidx_o = 0;
+                        if (HM && PROTO == 1) {
+                            hm_o = __shfl(s.hmode, ow);
+                            hidx_o = __shfl(s.hidx, ow);
+                        }
+                        if (jj < K) {
+                            const int owc = ow < CPW ? ow : 0;
                             const int neg = (cfg.dbg & 32) ? 0 : (int)((L.pat_meta[pat_o] >> 8) & 1);
-                            const float* pr = flt_o ? &L.flt[ow][0] : &L.raw[ow][0];
-                            int hm_o = 0, hidx_o = 0;
-                            if (HM && PROTO == 1) {
-                                hm_o = __builtin_amdgcn_readlane(s.hmode, ow);
-                                hidx_o = __builtin_amdgcn_readlane(s.hidx, ow);
-                            }
-                            if (lane < K) {
-                                const int p = p0 + lane * whole;
-                                const int cw = (whole - 1) / 2;
-                                const int l_e = (Cfg::dmr_window && ls_type != 0) ? 1 : 2;
-                                const bool rf0l = cfg.rf_mod == 0;
-                                const int wlo = rf0l ? cw - l_e : cw - 1, whi = rf0l ? cw + 2 : cw + 1;
-                                const bool has20 = whole == 20;
-                                const int i_lo = has20 && 7 < wlo ? 7 : wlo, i_hi = has20 && 13 > whi ? 13 : whi;
-                                float sum = 0.0f;
-                                int c = 0;
+                            const float* pr = flt_o ? &L.flt[owc][0] : &L.raw[owc][0];
+                            const int p = p0 + jj * whole;
+                            const int cw = (whole - 1) / 2;
+                            const int l_e = (Cfg::dmr_window && ls_type != 0) ? 1 : 2;
+                            const bool rf0l = cfg.rf_mod == 0;
+                            const int wlo = rf0l ? cw - l_e : cw - 1, whi = rf0l ? cw + 2 : cw + 1;
+                            const bool has20 = whole == 20;
+                            const int i_lo = has20 && 7 < wlo ? 7 : wlo, i_hi = has20 && 13 > whi ? 13 : whi;
+                            float sum = 0.0f;
+                            int c = 0;
 #pragma unroll
-                                for (int k = 0; k < 8; k++) {
-                                    const int i = i_lo + k;
-                                    if (i <= i_hi) {
-                                        float x = pr[(p + i) & RMASKW];
-                                        if (rf0l) { // the sync-time clip (C4FM rules only)
-                                            x = x > mx_o ? mx_o : (x < mn_o ? mn_o : x);
-                                        }
-                                        const bool k1 = rf0l ? (i >= wlo && i <= whi) : (i == wlo || i == whi);
-                                        const bool k2 = has20 && i >= 7 && i <= 13;
-                                        if (k2) {
-                                            sum += x;
-                                        }
-                                        if (k1) {
-                                            sum += x;
-                                        }
-                                        c += (k1 ? 1 : 0) + (k2 ? 1 : 0);
+                            for (int k = 0; k < 8; k++) {
+                                const int i = i_lo + k;
+                                if (i <= i_hi) {
+                                    float x = pr[(p + i) & RMASKW];
+                                    if (rf0l) { // the sync-time clip (C4FM rules only)
+                                        x = x > mx_o ? mx_o : (x < mn_o ? mn_o : x);
                                     }
-                                }
-                                const float sym = (c > 0) ? (sum / (float)c) : 0.0f;
-                                const int slot = (sh_o + lane) & (HN - 1);
-                                L.sh[slot][ow] = sym;
-                                const int qb = t & 1, qe = qk_o + lane;
-                                L.q[qb][qe][0][ow] = sym;
-                                L.q[qb][qe][1][ow] = cen_o;
-                                L.q[qb][qe][2][ow] = um_o;
-                                L.q[qb][qe][3][ow] = lm_o;
-                                L.q[qb][qe][4][ow] = mx_o;
-                                L.q[qb][qe][5][ow] = mn_o;
-                                L.q[qb][qe][6][ow] = __int_as_float((1 | (neg ? 4 : 0)) | (slot << 8));
-                                if (HM && PROTO == 1) {
-                                    using namespace ddn_fsk4h;
-                                    if (hm_o >= M_DATA_SUFFIX && hm_o != M_SKIP66 && hidx_o + lane < 144) {
-                                        const int d = sym > cen_o ? (sym > um_o ? 1 : 0) : (sym < lm_o ? 3 : 2);
-                                        LH.pay[hidx_o + lane][ow] = (uint8_t)(neg ? (d ^ 2) : d);
+                                    const bool k1 = rf0l ? (i >= wlo && i <= whi) : (i == wlo || i == whi);
+                                    const bool k2 = has20 && i >= 7 && i <= 13;
+                                    if (k2) {
+                                        sum += x;
                                     }
+                                    if (k1) {
+                                        sum += x;
+                                    }
+                                    c += (k1 ? 1 : 0) + (k2 ? 1 : 0);
                                 }
                             }
-                            if (lane == ow) {
-                                pos += K * whole;
-                                s.shead = (s.shead + K) & (HN - 1);
-                                s.scount = s.scount + K < HN ? s.scount + K : HN;
-                                qk += K;
-                                if (HM && PROTO == 1) {
-                                    s.hidx += K;
+                            const float sym = (c > 0) ? (sum / (float)c) : 0.0f;
+                            const int slot = (sh_o + jj) & (HN - 1);
+                            L.sh[slot][owc] = sym;
+                            const int qb = t & 1, qe = qk_o + jj;
+                            L.q[qb][qe][0][owc] = sym;
+                            L.q[qb][qe][1][owc] = cen_o;
+                            L.q[qb][qe][2][owc] = um_o;
+                            L.q[qb][qe][3][owc] = lm_o;
+                            L.q[qb][qe][4][owc] = mx_o;
+                            L.q[qb][qe][5][owc] = mn_o;
+                            L.q[qb][qe][6][owc] = __int_as_float((1 | (neg ? 4 : 0)) | (slot << 8));
+                            if (HM && PROTO == 1) {
+                                using namespace ddn_fsk4h;
+                                if (hm_o >= M_DATA_SUFFIX && hm_o != M_SKIP66 && hidx_o + jj < 144) {
+                                    const int d = sym > cen_o ? (sym > um_o ? 1 : 0) : (sym < lm_o ? 3 : 2);
+                                    LH.pay[hidx_o + jj][owc] = (uint8_t)(neg ? (d ^ 2) : d);
                                 }
-                                s.lock_left -= K;
-                                s.maxref = s.max;
-                                s.minref = s.min;
-                                o += K;
                             }
+                        }
+                        if (ie && kfit >= 2) { // the owners move their counters
+                            const int K2 = kfit;
+                            pos += K2 * whole;
+                            s.shead = (s.shead + K2) & (HN - 1);
+                            s.scount = s.scount + K2 < HN ? s.scount + K2 : HN;
+                            qk += K2;
+                            if (HM && PROTO == 1) {
+                                s.hidx += K2;
+                            }
+                            s.lock_left -= K2;
+                            s.maxref = s.max;
+                            s.minref = s.min;
+                            o += K2;
                         }
                         continue;
                     }

@@ -402,7 +402,7 @@ k_k5_m17(const uint16_t* __restrict__ in, int n, int in_len, int u_len, DdnPunct
 // candidates in (state, rank) order: duplicates by the 12 output bytes are dropped, the rest kept sorted by metric.
 __global__ __launch_bounds__(128) void
 k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint32_t* __restrict__ cand_out,
-                     int32_t* __restrict__ count_out) {
+                     int32_t* __restrict__ count_out, const uint8_t* __restrict__ wanted) {
     constexpr int CW = 32, K = 8;
     __shared__ int32_t d[CW][98 + 1];
     __shared__ uint2 back[CW][49][4];   // 8 back-pointer bytes per (step, state)
@@ -410,6 +410,15 @@ k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint3
     __shared__ uint8_t cvalid[CW][32];
     const int tid = threadIdx.x;
     const int cw0 = blockIdx.x * CW;
+    if (wanted) { // optional: a group of 32 code words none of which is wanted reports count 0 and leaves
+        const bool in = tid < CW && cw0 + tid < n;
+        if (!__syncthreads_or(in && wanted[cw0 + tid] != 0)) {
+            if (in) {
+                count_out[cw0 + tid] = 0;
+            }
+            return;
+        }
+    }
     for (int idx = tid; idx < CW * 98; idx += 128) {
         const int c = idx / 98, i = idx - c * 98;
         if (cw0 + c < n) {
@@ -794,13 +803,19 @@ ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, const DdnPunctu
 }
 
 extern "C" hipError_t
-ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, uint32_t* cand, int32_t* count, hipStream_t st) {
+ddn_dev_p25_half_rate_list_wanted(const int16_t* llr, int n, int max_cand, const uint8_t* wanted, uint32_t* cand, int32_t* count,
+                                  hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_p25_half_rate_list, dim3((unsigned)((n + 31) / 32)), dim3(128), 0, st, llr, n, max_cand, cand,
-                       count);
+                       count, wanted);
     return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_p25_half_rate_list(const int16_t* llr, int n, int max_cand, uint32_t* cand, int32_t* count, hipStream_t st) {
+    return ddn_dev_p25_half_rate_list_wanted(llr, n, max_cand, nullptr, cand, count, st);
 }
 
 extern "C" hipError_t
