@@ -537,11 +537,18 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
                 break;
             }
         }
+        int cpw_d = cpw, cpw_n = cpw;
+        if (const char* e = getenv("DDN_MIX_CPW_DMR")) { // (experiments)
+            cpw_d = atoi(e);
+        }
+        if (const char* e = getenv("DDN_MIX_CPW_NXDN")) {
+            cpw_n = atoi(e);
+        }
         if (rc == DDN_OK && m->dmr) {
-            rc = ddn_fsk4_rx_set_channels_per_wave(m->dmr->rx, cpw);
+            rc = ddn_fsk4_rx_set_channels_per_wave(m->dmr->rx, cpw_d);
         }
         if (rc == DDN_OK && m->nxdn) {
-            rc = ddn_fsk4_rx_set_channels_per_wave(m->nxdn->rx, cpw);
+            rc = ddn_fsk4_rx_set_channels_per_wave(m->nxdn->rx, cpw_n);
         }
     }
     for (int k = 0; k < 3 && rc == DDN_OK; k++) {
