@@ -544,6 +544,17 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
         if (const char* e = getenv("DDN_MIX_CPW_NXDN")) {
             cpw_n = atoi(e);
         }
+        // Residency decides the step: a CU holds 8 of these wavefronts (~200 registers each).  At 4096 channels in thirds the P25
+        // loop's own choice (4 channels per workgroup of 4 waves: 342 workgroups) + 2 x 342 two-wave workgroups are 2736 waves for
+        // 2048 places - the loop launched last waits for the first to finish (measured: NXDN48 loop 9 ms, step 15.1 ms).  With 8
+        // channels per P25 workgroup it is 2052 waves: step 14.2 ms.
+        int cpw_p = (total > 2048 && (m->dmr || m->nxdn)) ? 8 : 0;
+        if (const char* e = getenv("DDN_MIX_CPW_P25")) {
+            cpw_p = atoi(e);
+        }
+        if (rc == DDN_OK && m->p25 && cpw_p) {
+            rc = ddn_p25_rx_set_channels_per_wave((ddn_p25_rx*)ddn_p25_chain_rx(m->p25), cpw_p);
+        }
         if (rc == DDN_OK && m->dmr) {
             rc = ddn_fsk4_rx_set_channels_per_wave(m->dmr->rx, cpw_d);
         }

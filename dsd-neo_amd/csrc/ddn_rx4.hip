@@ -23,6 +23,8 @@
 // 64-sample tile of every channel (raw + always-on matched-filter output) with coalesced row loads; lanes advance symbol by
 // symbol.  P25p1 stays on its own kernels (live thresholds need the window / ring machinery of ddn_rx.hip).
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "ddn_device.h"
@@ -1553,6 +1555,14 @@ launch(const float* raw, const float* filt, const float* prev_tail, float* fstal
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) {
         return e;
+    }
+    if (getenv("DDN_RX_OCC")) {
+        int nb = -1;
+        hipFuncAttributes fa;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_fsk4_rx<CPW, MAXW, PROTO, HM>), 128, shmem);
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_fsk4_rx<CPW, MAXW, PROTO, HM>));
+        fprintf(stderr, "k_fsk4_rx<%d,%d,%d,%d>: %d blocks per CU alone, %d regs, %zu B dynamic LDS, %d blocks\n", CPW, MAXW, PROTO, (int)HM, nb,
+                fa.numRegs, shmem, (n_channels + CPW - 1) / CPW);
     }
     hipLaunchKernelGGL((k_fsk4_rx<CPW, MAXW, PROTO, HM>), dim3((unsigned)((n_channels + CPW - 1) / CPW)), dim3(128), shmem, st,
                        raw, filt, prev_tail, fstale, taps, n, stride, n_channels, cfg, state, lbuf_store, shist_store,
