@@ -302,12 +302,14 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
     // NXDN48: frame gather -> SACCH / FACCH1 K=5 soft decode -> CRC6 / CRC12 -> the reference's greedy retry for the SACCH
     DDN_TRY(ddn_nxdn_frame_gather(rec, c->d_cnt_full, c->stride, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->d_lich, c->d_ss, c->d_sr,
                                   c->d_fs, c->d_fr, c->d_valid, st));
-    DDN_TRY(ddn_fec_nxdn_conv_batch(c->d_ss, c->d_sr, S, 36, 32, nullptr, c->d_sacch, 4, st));
+    // (the decoders skip the slots that hold no complete frame - d_valid - and write zeros there: the slot arrays are sized for the
+    // densest traffic, a call of the bench capture uses an eighth of them)
+    HIP_TRY(ddn_dev_k5_nxdn_wanted(c->d_ss, c->d_sr, (int)S, 36, 32, nullptr, c->d_sacch, 4, c->d_valid, 1, st));
     DDN_TRY(ddn_nxdn_crc_check_batch(c->d_sacch, 4, S, 0, c->d_sacch_ok, st));
     HIP_TRY(ddn_dev_u8_shr1(c->d_ss, S * 72, c->d_hard_in, st));
-    DDN_TRY(ddn_fec_trellis_decode_batch(c->d_hard_in, 72, S, 32, c->d_sacch_hard, 32, st));
+    HIP_TRY(ddn_dev_trellis_greedy_wanted(c->d_hard_in, 72, S, 32, c->d_sacch_hard, 32, c->d_valid, st));
     DDN_TRY(ddn_nxdn_crc_check_batch(c->d_sacch_hard, 32, S, 2, c->d_sacch_hard_ok, st));
-    DDN_TRY(ddn_fec_nxdn_conv_batch(c->d_fs, c->d_fr, S * 2, 96, 92, nullptr, c->d_facch, 12, st));
+    HIP_TRY(ddn_dev_k5_nxdn_wanted(c->d_fs, c->d_fr, (int)(S * 2), 96, 92, nullptr, c->d_facch, 12, c->d_valid, 2, st));
     DDN_TRY(ddn_nxdn_crc_check_batch(c->d_facch, 12, S * 2, 1, c->d_facch_ok, st));
     if (c->cfg.vocoder) {
         // voice (nxdn_voice()): the frames the LICHs announce, through AMBE de-interleave -> frame FEC -> synthesis
@@ -473,8 +475,9 @@ struct ddn_mixed_chain {
     ddn_mixed_chain_config cfg;
     ddn_p25_chain* p25;
     ddn_fsk4_chain *dmr, *nxdn;
-    hipStream_t st[3];
-    hipEvent_t ev_front[3];
+    hipStream_t st[3], st2[3]; // per group: front end + matched filter + loop / frame FEC + voice
+    hipEvent_t ev_front[3], ev_loop[3], ev_dec[3];
+    bool have_dec[3];
 };
 
 extern "C" void
@@ -486,14 +489,16 @@ ddn_mixed_chain_destroy(ddn_mixed_chain* m) {
     ddn_p25_chain_destroy(m->p25);
     ddn_fsk4_chain_destroy(m->dmr);
     ddn_fsk4_chain_destroy(m->nxdn);
-    for (hipStream_t s : m->st) {
-        if (s) {
-            (void)hipStreamDestroy(s);
+    for (int k = 0; k < 3; k++) {
+        for (hipStream_t s : {m->st[k], m->st2[k]}) {
+            if (s) {
+                (void)hipStreamDestroy(s);
+            }
         }
-    }
-    for (hipEvent_t e : m->ev_front) {
-        if (e) {
-            (void)hipEventDestroy(e);
+        for (hipEvent_t e : {m->ev_front[k], m->ev_loop[k], m->ev_dec[k]}) {
+            if (e) {
+                (void)hipEventDestroy(e);
+            }
         }
     }
     delete m;
@@ -564,7 +569,10 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
     }
     for (int k = 0; k < 3 && rc == DDN_OK; k++) {
         if (hipStreamCreateWithFlags(&m->st[k], hipStreamNonBlocking) != hipSuccess
-            || hipEventCreateWithFlags(&m->ev_front[k], hipEventDisableTiming) != hipSuccess) {
+            || (k == 0 && hipStreamCreateWithFlags(&m->st2[0], hipStreamNonBlocking) != hipSuccess)
+            || hipEventCreateWithFlags(&m->ev_front[k], hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&m->ev_loop[k], hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&m->ev_dec[k], hipEventDisableTiming) != hipSuccess) {
             rc = DDN_EHIP;
         }
     }
@@ -583,17 +591,22 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
     if (!m || (m->p25 && !d_iq_p25) || (m->dmr && !d_iq_dmr) || (m->nxdn && !d_iq_nxdn48)) {
         return DDN_EINVAL;
     }
-    // The protocol groups are independent channel sets, one stream each.  Their stages are lined up across the groups: the three
-    // front ends first (throughput kernels that would otherwise be starved by - and delay the workgroups of - another group's
-    // receive loop), then the three receive loops side by side (latency chains that fit on the device together), each followed on
-    // its own stream by its frame FEC / voice stage.
+    // The protocol groups are independent channel sets, two streams each.  Their stages are lined up across the groups: the three
+    // front ends first (kernels that would otherwise be starved by - and delay the workgroups of - another group's receive loop),
+    // then the three receive loops side by side (latency chains that fit on the device together).  A group's frame FEC / voice stage
+    // runs on its second stream behind its loop, so the NEXT call's front end does not queue up behind it (a front end of <= 2048
+    // channels is a 3 ms latency chain whatever the batch: what it runs beside costs it little) - the next call's loop waits for it
+    // (the loop's sync lists, handler events and payload rows are single buffers the decode stage reads).
     const void* iq[3] = {d_iq_p25, d_iq_dmr, d_iq_nxdn48};
     const bool on[3] = {m->p25 != nullptr, m->dmr != nullptr, m->nxdn != nullptr};
     auto stage = [&](int g, int st_no) -> int {
+        // (one decode stream for the three groups: HIP maps streams onto four hardware queues, a fifth stream would share a queue
+        // with one of the loops - measured: the NXDN48 loop then ran behind the P25 loop)
+        hipStream_t s = st_no == 2 ? m->st2[0] : m->st[g];
         if (g == 0) {
-            return ddn_p25_chain_stage(m->p25, st_no, iq[0], m->st[0]);
+            return ddn_p25_chain_stage(m->p25, st_no, iq[0], s);
         }
-        return ddn_fsk4_chain_stage(g == 1 ? m->dmr : m->nxdn, st_no, iq[g], m->st[g]);
+        return ddn_fsk4_chain_stage(g == 1 ? m->dmr : m->nxdn, st_no, iq[g], s);
     };
     for (int g = 0; g < 3; g++) {
         if (on[g]) {
@@ -610,11 +623,18 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
                 HIP_TRY(hipStreamWaitEvent(m->st[g], m->ev_front[h], 0));
             }
         }
+        if (m->have_dec[g]) {
+            HIP_TRY(hipStreamWaitEvent(m->st[g], m->ev_dec[g], 0));
+        }
         DDN_TRY(stage(g, 1));
+        HIP_TRY(hipEventRecord(m->ev_loop[g], m->st[g]));
     }
     for (int g = 0; g < 3; g++) {
         if (on[g]) {
+            HIP_TRY(hipStreamWaitEvent(m->st2[0], m->ev_loop[g], 0));
             DDN_TRY(stage(g, 2));
+            HIP_TRY(hipEventRecord(m->ev_dec[g], m->st2[0]));
+            m->have_dec[g] = true;
         }
     }
     return DDN_OK;
@@ -625,8 +645,11 @@ ddn_mixed_chain_wait(ddn_mixed_chain* m) {
     if (!m) {
         return DDN_EINVAL;
     }
-    for (hipStream_t s : m->st) {
-        HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 3; k++) {
+        HIP_TRY(hipStreamSynchronize(m->st[k]));
+        if (m->st2[k]) {
+            HIP_TRY(hipStreamSynchronize(m->st2[k]));
+        }
     }
     return DDN_OK;
 }

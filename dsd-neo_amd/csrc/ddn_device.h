@@ -264,6 +264,10 @@ hipError_t ddn_dev_p25_half_rate(const int16_t* llr, int n, uint8_t* out, int32_
 hipError_t ddn_dev_r34(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* out, hipStream_t st);
 hipError_t ddn_dev_p25_half_rate_list_wanted(const int16_t* llr, int n, int max_cand, const uint8_t* wanted, uint32_t* cand, int32_t* count,
                                              hipStream_t st);
+hipError_t ddn_dev_k5_nxdn_wanted(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int n_bits, uint16_t* metrics_io,
+                                  uint8_t* out, int out_stride, const uint8_t* wanted, int wanted_div, hipStream_t st);
+hipError_t ddn_dev_trellis_greedy_wanted(const uint8_t* src, int src_stride, size_t n, int result_len, uint8_t* out, int out_stride,
+                                         const uint8_t* wanted, hipStream_t st);
 hipError_t ddn_dev_r34_list_wanted(const uint8_t* dibits, const uint8_t* reliab, int n, int max_cand, const uint8_t* wanted, uint8_t* backs,
                                    uint32_t* cand, int32_t* count, hipStream_t st);
 // the DMR chain's data-burst / embedded-signalling stages (ddn_dmr_data.hip, k_dmr_r34_pick in ddn_trellis.hip)

@@ -682,13 +682,19 @@ ddn_dev_bptc_16x2(const uint8_t* in, size_t n, int parity_odd, uint8_t* out32, u
 // One codeword per lane; the 16 x 8 comparisons are bit-parallel on one 8-bit word per candidate.
 __global__ void
 k_trellis_greedy(const uint8_t* __restrict__ src, int src_stride, size_t n, int result_len, uint8_t* __restrict__ out,
-                 int out_stride) {
+                 int out_stride, const uint8_t* __restrict__ wanted) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) {
         return;
     }
     const uint8_t* s = src + i * (size_t)src_stride;
     uint8_t* o = out + i * (size_t)out_stride;
+    if (wanted && !wanted[i]) { // optional: rows that are not wanted read zeros
+        for (int p = 0; p < result_len; p++) {
+            o[p] = 0;
+        }
+        return;
+    }
     unsigned reg = 0;
     for (int p = 0; p < result_len; p++) {
         unsigned want = 0; // source[2p .. 2p+7], first bit in bit 7
@@ -714,13 +720,19 @@ k_trellis_greedy(const uint8_t* __restrict__ src, int src_stride, size_t n, int 
 }
 
 extern "C" hipError_t
-ddn_dev_trellis_greedy(const uint8_t* src, int src_stride, size_t n, int result_len, uint8_t* out, int out_stride, hipStream_t st) {
+ddn_dev_trellis_greedy_wanted(const uint8_t* src, int src_stride, size_t n, int result_len, uint8_t* out, int out_stride,
+                              const uint8_t* wanted, hipStream_t st) {
     if (n == 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_trellis_greedy, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, src, src_stride, n, result_len, out,
-                       out_stride);
+                       out_stride, wanted);
     return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_trellis_greedy(const uint8_t* src, int src_stride, size_t n, int result_len, uint8_t* out, int out_stride, hipStream_t st) {
+    return ddn_dev_trellis_greedy_wanted(src, src_stride, n, result_len, out, out_stride, nullptr, st);
 }
 
 extern "C" hipError_t

@@ -2908,6 +2908,9 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
         }
     }
     int cpw = channels_per_wave;
+    if (const char* e = getenv("DDN_RX_CPW")) { // (experiments)
+        cpw = atoi(e);
+    }
     const int whole = cfg->sym_rate > 0 ? cfg->out_rate / cfg->sym_rate : 0;
     if (cfg->handlers) {
         // handler mode: the windowed kernel with its fourth wave, 8 or 16 lanes per wave (the in-frame history ring is LDS)

@@ -1453,6 +1453,13 @@ k_nxdn_frame_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__
     const bool have = k < n_sync[ch] && k < max_sync;
     const long pos = have ? sync_pos[so] : 0;
     const bool ok = have && (pos + 182 < (long)counts[ch]) && ((size_t)(pos + 182) < max_sym);
+    if (!ok) { // an unused slot (most of them: the slots are sized for the densest traffic) or a frame the records do not hold yet:
+        if (t == 0) { // flagged, its fields are not defined (the decoders behind skip what is not valid)
+            valid[so] = 0;
+            lich[so] = 0;
+        }
+        return;
+    }
     if (t == 0) {
         unsigned l = 228u;
         for (int i = 0; i < 182; i++) {

@@ -237,7 +237,8 @@ k_r34(const uint8_t* __restrict__ dibits, const uint8_t* __restrict__ reliab, in
 template <bool SOFT>
 __global__ __launch_bounds__(256) void
 k_k5_nxdn(const uint8_t* __restrict__ sym, const uint8_t* __restrict__ rel, int n, int n_steps, int n_bits,
-          uint16_t* __restrict__ metrics_io, uint8_t* __restrict__ out, int out_stride) {
+          uint16_t* __restrict__ metrics_io, uint8_t* __restrict__ out, int out_stride, const uint8_t* __restrict__ wanted,
+          int wanted_div) {
     constexpr int CW = 16;
     extern __shared__ uint8_t smem[];
     const int row = 2 * n_steps + 2;                 // bytes per codeword of symbols
@@ -246,6 +247,19 @@ k_k5_nxdn(const uint8_t* __restrict__ sym, const uint8_t* __restrict__ rel, int 
     uint16_t* dec = (uint16_t*)(r + (SOFT ? CW * row : 0)); // [CW][n_steps]
     const int tid = threadIdx.x;
     const int cw0 = blockIdx.x * CW;
+    if (wanted) { // optional (the chains' sparse slot arrays): a block of 16 code words none of which is wanted writes zeros and leaves
+        const bool in = tid < CW && cw0 + tid < n;
+        if (!__syncthreads_or(in && wanted[(cw0 + tid) / wanted_div] != 0)) {
+            const int nby = (n_bits + 7) / 8;
+            for (int idx = tid; idx < CW * nby; idx += 256) {
+                const int c = idx / nby;
+                if (cw0 + c < n) {
+                    out[(size_t)(cw0 + c) * out_stride + (idx - c * nby)] = 0;
+                }
+            }
+            return;
+        }
+    }
     for (int idx = tid; idx < CW * 2 * n_steps; idx += 256) {
         const int c = idx / (2 * n_steps), i = idx - c * 2 * n_steps;
         if (cw0 + c < n) {
@@ -772,8 +786,8 @@ ddn_dev_r34(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* out, h
 }
 
 extern "C" hipError_t
-ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int n_bits, uint16_t* metrics_io,
-                uint8_t* out, int out_stride, hipStream_t st) {
+ddn_dev_k5_nxdn_wanted(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int n_bits, uint16_t* metrics_io,
+                       uint8_t* out, int out_stride, const uint8_t* wanted, int wanted_div, hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
     }
@@ -782,12 +796,18 @@ ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int 
     const size_t shm = 16 * row * (rel ? 2 : 1) + 16 * (size_t)n_steps * 2 + 16;
     if (rel) {
         hipLaunchKernelGGL((k_k5_nxdn<true>), grid, dim3(256), shm, st, sym, rel, n, n_steps, n_bits, metrics_io, out,
-                           out_stride);
+                           out_stride, wanted, wanted_div > 0 ? wanted_div : 1);
     } else {
         hipLaunchKernelGGL((k_k5_nxdn<false>), grid, dim3(256), shm, st, sym, rel, n, n_steps, n_bits, metrics_io, out,
-                           out_stride);
+                           out_stride, wanted, wanted_div > 0 ? wanted_div : 1);
     }
     return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int n_bits, uint16_t* metrics_io,
+                uint8_t* out, int out_stride, hipStream_t st) {
+    return ddn_dev_k5_nxdn_wanted(sym, rel, n, n_steps, n_bits, metrics_io, out, out_stride, nullptr, 1, st);
 }
 
 extern "C" hipError_t
