@@ -283,7 +283,10 @@ void* ddn_fsk4_chain_rx(ddn_fsk4_chain* c);        /* ddn_fsk4_rx* */
 
 /* ---- a mixed batch (BASELINE configs[3]): P25 Phase 1 + DMR + NXDN48 channel groups of one GPU, every receive loop with the
  * reference's handlers inside it; one stream per group inside the object, the groups' stages lined up (the three front ends, then the
- * three receive loops side by side, each followed by its frame FEC / voice stage).  _run queues one call of all three, _wait blocks. */
+ * three receive loops side by side), the frame FEC / voice stages on a fourth stream behind their loops so that the next call's
+ * front ends need not wait for them (the next call's loop does).  _run queues one call of all three, _wait blocks; results of a
+ * call are complete - and the d_iq buffers of that call free - after _wait.  When the batch is shared the P25 group runs eight
+ * channels per workgroup so that the three loops' wavefronts are resident together. */
 typedef struct ddn_mixed_chain_config {
     int n_p25, n_dmr, n_nxdn48; /* channels of each group on this GPU (a group may be empty) */
     int samples_per_call, block_len, input_format, vocoder;
