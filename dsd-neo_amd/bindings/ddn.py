@@ -504,6 +504,14 @@ class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config
 
 PROTOTYPES.update({
     "ddn_p25_chain_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_scramble_bits_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_descramble_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "p25p2_generate_scramble_bits": (None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]),
+    "ddn_p25p2_burst_fields_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_burst_fields_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_xcch_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_xcch_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_fsk4_chain_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_fsk4_chain_create": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_fsk4_chain_destroy": (None, [C.c_void_p]),

@@ -671,6 +671,129 @@ ddn_fec_rs28_host(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, c
     return (a.down(payload_bits) || s.down(status)) ? no_dev() : DDN_OK;
 }
 
+// P25 Phase 2 FACCH / SACCH burst stage (include/ddn_hip.h): gather + ranked soft erasures + RS(63,35) with retries
+extern "C" int
+ddn_p25p2_xcch_batch(int kind, const uint8_t* d_bits360, const int16_t* d_llr360, size_t n, int threshold, uint8_t* d_payload_bits,
+                     int32_t* d_ec, uint8_t* d_used_dynamic, void* hip_stream) {
+    if ((kind != 0 && kind != 1) || !d_bits360 || !d_llr360 || !d_payload_bits || !d_ec || !d_used_dynamic) {
+        ddn_set_error("ddn_p25p2_xcch_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    if (n == 0) {
+        return DDN_OK;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    // scratch (parity bits, erasure lists and their lengths), stream-ordered so concurrent calls never share it
+    uint8_t* scratch = nullptr;
+    const size_t n_pa = kind == 0 ? 114 : 132;
+    HIP_TRY(hipMallocAsync((void**)&scratch, n * (n_pa + 28 + 1) + 64, st));
+    uint8_t* parity = scratch;
+    int8_t* er = (int8_t*)(scratch + n * n_pa);
+    uint8_t* n_total = scratch + n * (n_pa + 28);
+    const hipError_t e = ddn_dev_p25p2_xcch(kind, d_bits360, d_llr360, (int)n, threshold, d_payload_bits, parity, er, n_total, d_ec,
+                                            d_used_dynamic, st);
+    HIP_TRY(hipFreeAsync(scratch, st));
+    HIP_TRY(e);
+    return DDN_OK;
+}
+
+// P25 Phase 2 frame scrambler (include/ddn_hip.h)
+extern "C" int
+ddn_p25p2_scramble_bits_batch(const uint64_t* d_seed44, size_t n, size_t bit_count, uint8_t* d_out_bits, void* hip_stream) {
+    if (!d_seed44 || !d_out_bits || bit_count > (1u << 20)) {
+        ddn_set_error("ddn_p25p2_scramble_bits_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_p25p2_scramble_bits(d_seed44, (int)n, (int)bit_count, d_out_bits, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p2_descramble_batch(const uint8_t* d_bits, const int16_t* d_llr, const uint8_t* d_scramble4320, const int32_t* d_offset,
+                           const int32_t* d_sequence_of, size_t n, int n_bits, int n_llr, uint8_t* d_xbits, int16_t* d_xllr,
+                           void* hip_stream) {
+    if (!d_bits || !d_scramble4320 || !d_offset || !d_xbits || n_bits <= 0 || n_llr < 0 || n_llr > n_bits || (n_llr > 0 && (!d_llr || !d_xllr))) {
+        ddn_set_error("ddn_p25p2_descramble_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_p25p2_descramble(d_bits, d_llr, d_scramble4320, d_offset, d_sequence_of, (int)n, n_bits, n_llr, d_xbits, d_xllr,
+                                     (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+// the reference's name (src/protocol/p25/phase2/p25p2_frame_internal.h:28): one sequence, host pointers, staged through the device
+extern "C" void
+p25p2_generate_scramble_bits(uint64_t wacn, uint64_t sysid, uint64_t nac, uint8_t* out_bits, size_t bit_count) {
+    if (!out_bits || bit_count == 0) {
+        return;
+    }
+    const uint64_t seed = (wacn * 16777216ULL) + (sysid * 4096ULL) + nac;
+    Dev a(8), o(bit_count);
+    if (!a.p || !o.p || a.up(&seed) || ddn_p25p2_scramble_bits_batch((const uint64_t*)a.p, 1, bit_count, (uint8_t*)o.p, nullptr) != DDN_OK
+        || o.down(out_bits)) {
+        (void)no_dev(); // (the reference's function cannot fail: the error is in ddn_last_error())
+    }
+}
+
+extern "C" int
+ddn_p25p2_burst_fields_batch(const uint8_t* d_bits360, const int16_t* d_llr360, size_t n, int threshold, int32_t* d_duid, int32_t* d_isch,
+                             void* hip_stream) {
+    if (!d_bits360 || !d_llr360 || !d_duid || !d_isch) {
+        ddn_set_error("ddn_p25p2_burst_fields_batch: null argument");
+        return DDN_EINVAL;
+    }
+    if (n == 0) {
+        return DDN_OK;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    uint8_t* scratch = nullptr; // the I-ISCH words and their reliability rows
+    HIP_TRY(hipMallocAsync((void**)&scratch, n * 48 + 64, st));
+    uint64_t* words = (uint64_t*)scratch;
+    uint8_t* rel = scratch + n * 8;
+    hipError_t e = ddn_dev_p25p2_burst_fields(d_bits360, d_llr360, (int)n, threshold, d_duid, words, rel, st);
+    if (e == hipSuccess) {
+        e = ddn_dev_isch_lookup(words, rel, (int)n, d_isch, st);
+    }
+    HIP_TRY(hipFreeAsync(scratch, st));
+    HIP_TRY(e);
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p2_burst_fields_host(const uint8_t* bits360, const int16_t* llr360, size_t n, int threshold, int32_t* duid, int32_t* isch) {
+    if (!bits360 || !llr360 || !duid || !isch) {
+        return DDN_EINVAL;
+    }
+    Dev b(n * 360), l(n * 360 * 2), d(n * sizeof(int32_t)), q(n * sizeof(int32_t));
+    if (!b.p || !l.p || !d.p || !q.p || b.up(bits360) || l.up(llr360)) {
+        return no_dev();
+    }
+    const int rc = ddn_p25p2_burst_fields_batch((const uint8_t*)b.p, (const int16_t*)l.p, n, threshold, (int32_t*)d.p, (int32_t*)q.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (d.down(duid) || q.down(isch)) ? no_dev() : DDN_OK;
+}
+
+extern "C" int
+ddn_p25p2_xcch_host(int kind, const uint8_t* bits360, const int16_t* llr360, size_t n, int threshold, uint8_t* payload_bits, int32_t* ec,
+                    uint8_t* used_dynamic) {
+    if ((kind != 0 && kind != 1) || !bits360 || !llr360 || !payload_bits || !ec || !used_dynamic) {
+        return DDN_EINVAL;
+    }
+    const size_t n_pl = kind == 0 ? 156 : 180;
+    Dev b(n * 360), l(n * 360 * 2), p(n * n_pl), s(n * sizeof(int32_t)), u(n);
+    if (!b.p || !l.p || !p.p || !s.p || !u.p || b.up(bits360) || l.up(llr360)) {
+        return no_dev();
+    }
+    const int rc = ddn_p25p2_xcch_batch(kind, (const uint8_t*)b.p, (const int16_t*)l.p, n, threshold, (uint8_t*)p.p, (int32_t*)s.p,
+                                        (uint8_t*)u.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (p.down(payload_bits) || s.down(ec) || u.down(used_dynamic)) ? no_dev() : DDN_OK;
+}
+
 // reference names (include/dsd-neo/fec/ez.h:29-31): one section per call, int-per-bit arrays.  -2 when the device path is
 // unavailable, the value the reference returns when its decoder object could not be constructed (src/fec/ez.cpp:106-117).
 static int

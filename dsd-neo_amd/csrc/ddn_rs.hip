@@ -1010,7 +1010,12 @@ ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_re
 // One section per thread, its polynomials in LDS columns.
 __global__ __launch_bounds__(64) void
 k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__ parity_bits,
-       const int8_t* __restrict__ erasures, const uint8_t* __restrict__ n_erasures, int n, int32_t* __restrict__ status) {
+       const int8_t* __restrict__ erasures, const uint8_t* __restrict__ n_erasures, int n, int32_t* __restrict__ status,
+       int attempt, int n_fixed, uint8_t* __restrict__ used_dynamic) {
+    // attempt >= 0 (the Phase 2 burst stage's ranked retries, p25p2_decode_facch_ranked()): this launch decodes with the first
+    // n_fixed + attempt erasures of each list - attempt 0 every section, attempt a > 0 only the sections that have failed so far
+    // and whose list (n_erasures = its full length) reaches that far; a failed decode leaves the payload as received, so every
+    // retry starts from the original like the reference's
     constexpr int R = 28;
     __shared__ uint8_t ex[128], lg[64];
     __shared__ uint8_t Cw[63][64], Sy[R][64], La[R + 1][64], Bp[R + 1][64], Tp[R + 1][64], Om[R][64], Rt[R][64];
@@ -1033,6 +1038,9 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
     __syncthreads();
     const int i = blockIdx.x * 64 + lane;
     if (i >= n) {
+        return;
+    }
+    if (attempt > 0 && (status[i] >= 0 || n_fixed + attempt > (int)n_erasures[i])) {
         return;
     }
     auto gmul = [&](int a, int b) -> int { return (a && b) ? ex[lg[a] + lg[b]] : 0; };
@@ -1071,7 +1079,7 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         status[i] = 0;
         return;
     }
-    int n_er = n_erasures ? n_erasures[i] : 0;
+    int n_er = attempt >= 0 ? n_fixed + attempt : (n_erasures ? n_erasures[i] : 0);
     n_er = n_er > R ? R : n_er;
     for (int k = 0; k <= R; k++) {
         La[k][lane] = k == 0 ? 1 : 0;
@@ -1173,6 +1181,83 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         }
     }
     status[i] = count;
+    if (attempt > 0 && used_dynamic) {
+        used_dynamic[i] = 1;
+    }
+}
+
+// ---- P25 Phase 2 FACCH / SACCH burst gather + ranked erasure list -----------------------------------------------------------------
+// p25p2_process_facchc() / process_SACCHs() (src/protocol/p25/phase2/p25p2_frame.c:473-495,652-671): where the RS(63,35) section's
+// payload and parity bits sit in the 360 bits of a timeslot (around the DUID fields and, for the FACCH, the sync);
+// p25p2_facch_soft_erasures() / p25p2_sacch_soft_erasures() (p25p2_soft.c:40-108,255-329): reliability of a 6-bit symbol = the least
+// min(|LLR|, 255) of its bits; the symbols not erased yet ordered by (reliability, position); as many as fall below the threshold, at
+// least 5 / 8, at most 10 / 16, appended to the fixed erasures (the unsent and punctured symbols).  One burst per thread.
+__global__ void
+k_p2_xcch_gather(int kind, const uint8_t* __restrict__ bits360, const int16_t* __restrict__ llr360, int n, int threshold,
+                 uint8_t* __restrict__ payload_bits, uint8_t* __restrict__ parity_bits, int8_t* __restrict__ erasures28,
+                 uint8_t* __restrict__ n_total, uint8_t* __restrict__ used_dynamic) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const int n_pl = kind == 0 ? 156 : 180, n_pa = kind == 0 ? 114 : 132;
+    const int first = kind == 0 ? 9 : 5, max_add = kind == 0 ? 10 : 16, min_add = kind == 0 ? 5 : 8;
+    const uint8_t* b = bits360 + (size_t)i * 360;
+    const int16_t* l = llr360 + (size_t)i * 360;
+    auto pos_pl = [&](int k) { return kind == 0 ? (k < 72 ? k + 2 : (k < 134 ? k - 72 + 76 : k - 134 + 180)) : (k < 72 ? k + 2 : k - 72 + 76); };
+    auto pos_pa = [&](int k) { return kind == 0 ? (k < 42 ? k + 202 : k - 42 + 246) : (k < 60 ? k + 184 : k - 60 + 246); };
+    for (int k = 0; k < n_pl; k++) {
+        payload_bits[(size_t)i * n_pl + k] = b[pos_pl(k)] & 1;
+    }
+    for (int k = 0; k < n_pa; k++) {
+        parity_bits[(size_t)i * n_pa + k] = b[pos_pa(k)] & 1;
+    }
+    // fixed erasures: positions 0 .. first - 1 and 35 + n_pa / 6 .. 62; every transmitted symbol is a candidate
+    int8_t* er = erasures28 + (size_t)i * 28;
+    int ne = 0;
+    for (int p = 0; p < first; p++) {
+        er[ne++] = (int8_t)p;
+    }
+    for (int p = 35 + n_pa / 6; p < 63; p++) {
+        er[ne++] = (int8_t)p;
+    }
+    uint16_t key[52]; // reliability << 8 | position: the order of sort_candidates()
+    int nc = 0;
+    for (int part = 0; part < 2; part++) {
+        const int nh = (part == 0 ? n_pl : n_pa) / 6;
+        for (int hb = 0; hb < nh; hb++) {
+            int r = 255;
+            for (int q = 0; q < 6; q++) {
+                int v = l[part == 0 ? pos_pl(6 * hb + q) : pos_pa(6 * hb + q)];
+                v = v < 0 ? -v : v;
+                v = v > 255 ? 255 : v;
+                r = v < r ? v : r;
+            }
+            key[nc++] = (uint16_t)((r << 8) | ((part == 0 ? first : 35) + hb));
+        }
+    }
+    int add = 0;
+    for (int k = 0; k < nc; k++) {
+        add += (key[k] >> 8) < threshold ? 1 : 0;
+    }
+    add = add < min_add ? min_add : add;
+    add = add > max_add ? max_add : add;
+    add = add > nc ? nc : add;
+    for (int k = 0; k < add; k++) { // the `add` smallest keys, in order
+        int best = k;
+        for (int j = k + 1; j < nc; j++) {
+            best = key[j] < key[best] ? j : best;
+        }
+        const uint16_t t = key[k];
+        key[k] = key[best];
+        key[best] = t;
+        er[ne++] = (int8_t)(key[k] & 0xFF);
+    }
+    for (int k = ne; k < 28; k++) {
+        er[k] = 0;
+    }
+    n_total[i] = (uint8_t)ne;
+    used_dynamic[i] = 0;
 }
 
 extern "C" hipError_t
@@ -1182,7 +1267,186 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures,
-                       n_erasures, n, status);
+                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr);
+    return hipGetLastError();
+}
+
+// ---- P25 Phase 2 frame scrambler ----------------------------------------------------------------------------------------------------
+// p25p2_generate_scramble_bits() (src/protocol/p25/phase2/p25p2_scramble.c:12-26): the 44-bit Fibonacci LFSR x^44 + x^34 + x^20 + x^15 +
+// x^9 + x^4 + 1 seeded with WACN | SYSID | NAC; process_Frame_Scramble() (p25p2_frame.c:370-392): a superframe's 4320 sequence bits,
+// the received bit i against sequence bit i + 20 + 360 * offset (the sequence doubled up = taken mod 4320), the soft metric's sign
+// flipped where the sequence bit is set.  The sequence is a 4320-step recurrence: one thread per system, 64 steps per word.
+__global__ void
+k_p2_scramble_bits(const uint64_t* __restrict__ seed44, int n, int bit_count, uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    uint64_t s = seed44[i];
+    uint8_t* o = out + (size_t)i * bit_count;
+    for (int k = 0; k < bit_count; k++) {
+        o[k] = (uint8_t)((s >> 43) & 1u);
+        const uint64_t b = ((s >> 33) ^ (s >> 19) ^ (s >> 14) ^ (s >> 8) ^ (s >> 3) ^ (s >> 43)) & 1u;
+        s = (s << 1) | b;
+    }
+}
+
+__global__ void
+k_p2_descramble(const uint8_t* __restrict__ bits, const int16_t* __restrict__ llr, const uint8_t* __restrict__ lbits4320,
+                const int32_t* __restrict__ offset, const int32_t* __restrict__ seq_of, int n_bits, int n_llr, uint8_t* __restrict__ xbits,
+                int16_t* __restrict__ xllr) {
+    const int item = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bits) {
+        return;
+    }
+    const uint8_t* lb = lbits4320 + (size_t)(seq_of ? seq_of[item] : item) * 4320;
+    const int q = (i + 20 + 360 * offset[item]) % 4320;
+    const int l = lb[q < 0 ? q + 4320 : q];
+    xbits[(size_t)item * n_bits + i] = (uint8_t)((bits[(size_t)item * n_bits + i] ^ l) & 1);
+    if (i < n_llr) {
+        const int16_t v = llr[(size_t)item * n_llr + i];
+        xllr[(size_t)item * n_llr + i] = l ? (int16_t)-v : v;
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_p25p2_scramble_bits(const uint64_t* seed44, int n, int bit_count, uint8_t* out, hipStream_t st) {
+    if (n <= 0 || bit_count <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p2_scramble_bits, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, seed44, n, bit_count, out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_p25p2_descramble(const uint8_t* bits, const int16_t* llr, const uint8_t* lbits4320, const int32_t* offset, const int32_t* seq_of,
+                         int n, int n_bits, int n_llr, uint8_t* xbits, int16_t* xllr, hipStream_t st) {
+    if (n <= 0 || n_bits <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p2_descramble, dim3((unsigned)((n_bits + 255) / 256), (unsigned)n), dim3(256), 0, st, bits, llr, lbits4320, offset,
+                       seq_of, n_bits, n_llr, xbits, xllr);
+    return hipGetLastError();
+}
+
+// ---- P25 Phase 2 timeslot fields: DUID and I-ISCH ----------------------------------------------------------------------------------
+// p25p2_duid_collect_and_decode() (p25p2_frame.c:1462-1478): the eight DUID bits at offsets 0, 1, 74, 75, 244, 245, 318, 319 of the
+// timeslot -> p25p2_duid_lookup_soft() (:208-248): the (8,4) code's table (a canonical word or a word one bit from exactly one of
+// them; 0x80 is withheld - "triggers false 4V on bad signal"); a word the table rejects is given to the canonical words one or two
+// bits away whose differing bits all have reliability below the threshold, the cheapest (sum of those reliabilities) if it is
+// alone; 0x80 only goes to 0, and only when its first bit alone is weak.  p25p2_process_isch() (:708-745): bits 320..359 and their
+// reliabilities -> isch_lookup_soft() (k_isch_lookup).  One timeslot per thread; the I-ISCH word and its reliability row are laid out
+// for the lookup kernel.
+__device__ __forceinline__ int
+p2_duid_hard(int r) {
+    if (r == 0x80) {
+        return -1;
+    }
+    int found = -1, n = 0;
+    for (int d = 0; d < 16; d++) {
+        // canonical word d: data nibble d, then the parity nibble of the (8,4,4) code
+        const int canon[16] = {0x00, 0x17, 0x2E, 0x39, 0x4B, 0x5C, 0x65, 0x72, 0x8D, 0x9A, 0xA3, 0xB4, 0xC6, 0xD1, 0xE8, 0xFF};
+        if (__popc((unsigned)(r ^ canon[d])) <= 1) {
+            found = d;
+            n++;
+        }
+    }
+    return n == 1 ? found : -1;
+}
+
+__global__ void
+k_p2_burst_fields(const uint8_t* __restrict__ bits360, const int16_t* __restrict__ llr360, int n, int threshold,
+                  int32_t* __restrict__ duid, uint64_t* __restrict__ isch_word, uint8_t* __restrict__ isch_rel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const uint8_t* b = bits360 + (size_t)i * 360;
+    const int16_t* l = llr360 + (size_t)i * 360;
+    auto rel_of = [&](int k) {
+        int v = l[k];
+        v = v < 0 ? -v : v;
+        return v > 255 ? 255 : v;
+    };
+    const int off[8] = {0, 1, 74, 75, 244, 245, 318, 319};
+    const int canon[16] = {0x00, 0x17, 0x2E, 0x39, 0x4B, 0x5C, 0x65, 0x72, 0x8D, 0x9A, 0xA3, 0xB4, 0xC6, 0xD1, 0xE8, 0xFF};
+    int r = 0, rel[8];
+    for (int k = 0; k < 8; k++) {
+        r = (r << 1) | (b[off[k]] & 1);
+        rel[k] = rel_of(off[k]);
+    }
+    const int hard = p2_duid_hard(r);
+    int out = hard;
+    const bool exact = hard >= 0 && r == canon[hard];
+    bool allowed = true;
+    if (r == 0x80) { // p25p2_duid_080_soft_allowed()
+        allowed = rel[0] < threshold;
+        for (int k = 1; k < 8; k++) {
+            allowed = allowed && rel[k] >= threshold;
+        }
+    }
+    if (!exact && allowed) {
+        int best = hard, best_cost = 999999;
+        bool tied = false;
+        for (int d = 0; d < 16; d++) {
+            const int dist = __popc((unsigned)(r ^ canon[d]));
+            if (dist < 1 || dist > 2 || (r == 0x80 && d != 0)) {
+                continue;
+            }
+            int cost = 0;
+            for (int k = 0; k < 8; k++) {
+                if (((r ^ canon[d]) >> (7 - k)) & 1) {
+                    cost = (rel[k] >= threshold || cost >= 999999) ? 999999 : cost + rel[k];
+                }
+            }
+            if (cost >= 999999) {
+                continue;
+            }
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = d;
+                tied = false;
+            } else if (cost == best_cost && d != best) {
+                tied = true;
+            }
+        }
+        out = tied ? hard : best;
+    }
+    duid[i] = out;
+    uint64_t w = 0;
+    for (int k = 0; k < 40; k++) {
+        w = (w << 1) | (uint64_t)(b[320 + k] & 1);
+        isch_rel[(size_t)i * 40 + k] = (uint8_t)rel_of(320 + k);
+    }
+    isch_word[i] = w;
+}
+
+extern "C" hipError_t
+ddn_dev_p25p2_burst_fields(const uint8_t* bits360, const int16_t* llr360, int n, int threshold, int32_t* duid, uint64_t* isch_word,
+                           uint8_t* isch_rel, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p2_burst_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, bits360, llr360, n, threshold, duid, isch_word,
+                       isch_rel);
+    return hipGetLastError();
+}
+
+// the Phase 2 FACCH (kind 0) / SACCH (kind 1) burst stage: gather + ranked list, then the decode with the fixed erasures and the
+// retries with one more erasure each (a launch per attempt: only the sections that still fail do any work)
+extern "C" hipError_t
+ddn_dev_p25p2_xcch(int kind, const uint8_t* bits360, const int16_t* llr360, int n, int threshold, uint8_t* payload_bits,
+                   uint8_t* parity_bits, int8_t* erasures28, uint8_t* n_total, int32_t* status, uint8_t* used_dynamic, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p2_xcch_gather, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, bits360, llr360, n, threshold,
+                       payload_bits, parity_bits, erasures28, n_total, used_dynamic);
+    const int n_fixed = kind == 0 ? 18 : 11, max_add = kind == 0 ? 10 : 16;
+    for (int attempt = 0; attempt <= max_add; attempt++) {
+        hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind + 1, payload_bits, parity_bits, erasures28,
+                           n_total, n, status, attempt, n_fixed, used_dynamic);
+    }
     return hipGetLastError();
 }
 

@@ -662,6 +662,36 @@ int ddn_fec_rs28_batch(int kind, uint8_t* d_payload_bits, const uint8_t* d_parit
                        const uint8_t* d_n_erasures, size_t n, int32_t* d_status, void* hip_stream);
 int ddn_fec_rs28_host(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const int8_t* erasures28,
                       const uint8_t* n_erasures, size_t n, int32_t* status);
+/* P25 Phase 2 FACCH (kind 0) / SACCH (kind 1) burst stage: what p25p2_process_facchc() / process_FACCHs() / process_SACCHc() /
+ * process_SACCHs() do between the timeslot's bits and the MAC PDU (src/protocol/p25/phase2/p25p2_frame.c:473-495,534-560,652-671):
+ * the RS(63,35) section's payload and parity bits are taken from their places in the 360 bits of the timeslot (p2bit / p2xbit from
+ * ts_counter * 360 on: the caller passes the plain or the de-scrambled row), decoded with the fixed erasures, and - when that fails -
+ * retried with 1, 2, ... more erasures from the list p25p2_facch_soft_erasures() / p25p2_sacch_soft_erasures() rank by the bits'
+ * soft metrics (p25p2_decode_facch_ranked() / _sacch_ranked(), :408-470; src/protocol/p25/phase2/p25p2_soft.c:40-108,255-329;
+ * threshold = p25p2_soft_erasure_threshold(), 64 unless configured).  d_bits360 u8 [n][360] one bit per byte, d_llr360 i16 [n][360]
+ * (p2llr / p2xllr), d_payload_bits u8 [n][156 | 180] (corrected, or as received when ec < 0), d_ec i32 [n] = the reference's ec,
+ * d_used_dynamic u8 [n] = its used_dynamic_erasure. */
+/* P25 Phase 2 frame scrambler == p25p2_generate_scramble_bits() (src/protocol/p25/phase2/p25p2_scramble.c:12-26: 44-bit LFSR seeded with
+ * wacn << 24 | sysid << 12 | nac; d_seed44 u64 [n] holds that value, d_out_bits u8 [n][bit_count]) and the de-scrambling of
+ * process_Frame_Scramble() (p25p2_frame.c:370-392): xbit[i] = bit[i] ^ sequence[(i + 20 + 360 * offset) mod 4320], the soft metric's
+ * sign flipped with it (d_llr / d_xllr i16 [n][n_llr], n_llr <= n_bits: the reference keeps metrics for the first 1400 bits of its
+ * 4300); d_scramble4320 u8 [..][4320]; d_sequence_of i32 [n] (optional) picks each item's sequence row (channels of one system share
+ * theirs), NULL = row i; d_offset i32 [n] = state->p2_scramble_offset. */
+int ddn_p25p2_scramble_bits_batch(const uint64_t* d_seed44, size_t n, size_t bit_count, uint8_t* d_out_bits, void* hip_stream);
+int ddn_p25p2_descramble_batch(const uint8_t* d_bits, const int16_t* d_llr, const uint8_t* d_scramble4320, const int32_t* d_offset,
+                               const int32_t* d_sequence_of, size_t n, int n_bits, int n_llr, uint8_t* d_xbits, int16_t* d_xllr,
+                               void* hip_stream);
+void p25p2_generate_scramble_bits(uint64_t wacn, uint64_t sysid, uint64_t nac, uint8_t* out_bits, size_t bit_count);
+/* the timeslot's DUID and I-ISCH: d_duid i32 [n] = p25p2_duid_lookup_soft() over the eight DUID bits (p25p2_frame.c:208-248,1462-1478;
+ * 0..15, -1 rejected), d_isch i32 [n] = isch_lookup_soft() over bits 320..359 (p25p2_process_isch(), :708-745; the 7-bit value, -2 for
+ * the S-ISCH word or nothing within reach) - reliabilities min(|LLR|, 255) as p25p2_reliability_for_abs_bit() */
+int ddn_p25p2_burst_fields_batch(const uint8_t* d_bits360, const int16_t* d_llr360, size_t n, int threshold, int32_t* d_duid,
+                                 int32_t* d_isch, void* hip_stream);
+int ddn_p25p2_burst_fields_host(const uint8_t* bits360, const int16_t* llr360, size_t n, int threshold, int32_t* duid, int32_t* isch);
+int ddn_p25p2_xcch_batch(int kind, const uint8_t* d_bits360, const int16_t* d_llr360, size_t n, int threshold, uint8_t* d_payload_bits,
+                         int32_t* d_ec, uint8_t* d_used_dynamic, void* hip_stream);
+int ddn_p25p2_xcch_host(int kind, const uint8_t* bits360, const int16_t* llr360, size_t n, int threshold, uint8_t* payload_bits,
+                        int32_t* ec, uint8_t* used_dynamic);
 int ez_rs28_ess(int payload[96], int parity[168], const int* erasures, int n_erasures);
 int ez_rs28_facch(int payload[156], int parity[114], const int* erasures, int n_erasures);
 int ez_rs28_sacch(int payload[180], int parity[132], const int* erasures, int n_erasures);

@@ -1063,3 +1063,160 @@ orc_isch_lookup_soft(uint64_t isch, const uint8_t* reliab40) {
     }
     return best;
 }
+
+/* ---- P25 Phase 2 FACCH / SACCH burst decode (test infrastructure, like everything in oracle/) --------------------------------
+ * p25p2_process_facchc() / process_SACCHs() (src/protocol/p25/phase2/p25p2_frame.c:473-495,652-671): the burst's 360 bits (one
+ * timeslot of p2bit / p2xbit, offsets relative to its start) -> payload + parity bits of the RS(63,35) section;
+ * p25p2_decode_facch_ranked() / _sacch_ranked() (:408-470): the section with its fixed erasures (the punctured and the unsent
+ * symbols), and when that fails the retries with 1, 2, ... more erasures from the ranked list of
+ * p25p2_facch_soft_erasures() / p25p2_sacch_soft_erasures() (src/protocol/p25/phase2/p25p2_soft.c:40-108,255-329): a hexbit's
+ * reliability = the least min(|LLR|, 255) of its six bits, candidates = the symbols not erased yet, ordered by (reliability,
+ * position); as many as fall below the threshold, at least 5 / 8, at most 10 / 16.  Returns the reference's ec (>= 0 symbols
+ * located, -1 beyond the code: payload as received); *used_dynamic as the reference's flag.  kind 0 = FACCH, 1 = SACCH. */
+int
+orc_p25p2_xcch(int kind, const uint8_t* bits360, const int16_t* llr360, int threshold, uint8_t* payload_out, int* used_dynamic) {
+    static const int facch_fixed[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 54, 55, 56, 57, 58, 59, 60, 61, 62};
+    static const int sacch_fixed[11] = {0, 1, 2, 3, 4, 57, 58, 59, 60, 61, 62};
+    int pos_pl[180], pos_pa[132]; /* burst offset of every payload / parity bit */
+    int n_pl = 0, n_pa = 0;
+    if (kind == 0) {
+        for (int i = 0; i < 72; i++) pos_pl[n_pl++] = i + 2;
+        for (int i = 0; i < 62; i++) pos_pl[n_pl++] = i + 76;
+        for (int i = 0; i < 22; i++) pos_pl[n_pl++] = i + 180;
+        for (int i = 0; i < 42; i++) pos_pa[n_pa++] = i + 202;
+        for (int i = 0; i < 72; i++) pos_pa[n_pa++] = i + 246;
+    } else if (kind == 1) {
+        for (int i = 0; i < 72; i++) pos_pl[n_pl++] = i + 2;
+        for (int i = 0; i < 108; i++) pos_pl[n_pl++] = i + 76;
+        for (int i = 0; i < 60; i++) pos_pa[n_pa++] = i + 184;
+        for (int i = 0; i < 72; i++) pos_pa[n_pa++] = i + 246;
+    } else {
+        return -2;
+    }
+    const int rk = kind == 0 ? 1 : 2; /* orc_ez_rs28's section kind */
+    const int n_fixed = kind == 0 ? 18 : 11, max_add = kind == 0 ? 10 : 16, min_add = kind == 0 ? 5 : 8;
+    const int first = kind == 0 ? 9 : 5;
+    const int* fixed = kind == 0 ? facch_fixed : sacch_fixed;
+    int payload[180], parity[132];
+    for (int i = 0; i < n_pl; i++) payload[i] = bits360[pos_pl[i]] & 1;
+    for (int i = 0; i < n_pa; i++) parity[i] = bits360[pos_pa[i]] & 1;
+    *used_dynamic = 0;
+    int ec = orc_ez_rs28(rk, payload, parity, fixed, n_fixed);
+    if (ec < 0) {
+        /* ranked candidates */
+        int c_rel[52], c_pos[52], nc = 0;
+        for (int part = 0; part < 2; part++) {
+            const int nh = (part == 0 ? n_pl : n_pa) / 6;
+            const int* pos = part == 0 ? pos_pl : pos_pa;
+            for (int hb = 0; hb < nh; hb++) {
+                int r = 255;
+                for (int b = 0; b < 6; b++) {
+                    int v = llr360[pos[6 * hb + b]];
+                    v = v < 0 ? -v : v;
+                    v = v > 255 ? 255 : v;
+                    r = v < r ? v : r;
+                }
+                const int rs_pos = (part == 0 ? first : 35) + hb;
+                int is_fixed = 0;
+                for (int k = 0; k < n_fixed; k++) is_fixed |= fixed[k] == rs_pos;
+                if (!is_fixed) {
+                    c_rel[nc] = r;
+                    c_pos[nc] = rs_pos;
+                    nc++;
+                }
+            }
+        }
+        for (int i = 0; i < nc; i++) { /* sort_candidates(): selection by (reliability, position) */
+            for (int j = i + 1; j < nc; j++) {
+                if (c_rel[j] < c_rel[i] || (c_rel[j] == c_rel[i] && c_pos[j] < c_pos[i])) {
+                    int t = c_rel[i]; c_rel[i] = c_rel[j]; c_rel[j] = t;
+                    t = c_pos[i]; c_pos[i] = c_pos[j]; c_pos[j] = t;
+                }
+            }
+        }
+        int add = 0;
+        for (int i = 0; i < nc; i++) add += c_rel[i] < threshold;
+        add = add < min_add ? min_add : add;
+        add = add > max_add ? max_add : add;
+        add = add > nc ? nc : add;
+        int erasures[28];
+        for (int k = 0; k < n_fixed; k++) erasures[k] = fixed[k];
+        for (int k = 0; k < add; k++) erasures[n_fixed + k] = c_pos[k];
+        const int n_er = n_fixed + add;
+        for (int n = n_fixed + 1; n <= n_er; n++) {
+            for (int i = 0; i < n_pl; i++) payload[i] = bits360[pos_pl[i]] & 1;
+            ec = orc_ez_rs28(rk, payload, parity, erasures, n);
+            if (ec >= 0) {
+                *used_dynamic = 1;
+                break;
+            }
+        }
+        if (ec < 0) {
+            for (int i = 0; i < n_pl; i++) payload[i] = bits360[pos_pl[i]] & 1;
+        }
+    }
+    for (int i = 0; i < n_pl; i++) payload_out[i] = (uint8_t)payload[i];
+    return ec;
+}
+
+/* p25p2_duid_lookup_soft() (src/protocol/p25/phase2/p25p2_frame.c:127-248; the file does not compile here - it needs the whole
+ * protocol library - so this restatement is anchored on the reference's own answers for it, tests/protocol/p25/
+ * test_p25_p2_reliability.c:970-974,1372-1440, and its hard table is checked entry by entry against the source's where the tree is
+ * present: tests/test_oracle_p25p2_xcch.py).  The table: a canonical word of the (8,4) code or a word one bit from exactly one of
+ * them, 0x80 withheld. */
+static const uint8_t k_duid_canonical[16] = {0x00, 0x17, 0x2E, 0x39, 0x4B, 0x5C, 0x65, 0x72, 0x8D, 0x9A, 0xA3, 0xB4, 0xC6, 0xD1, 0xE8, 0xFF};
+int
+orc_p25p2_duid_hard(int r) {
+    if ((r & 0xFF) == 0x80) {
+        return -1;
+    }
+    int found = -1, n = 0;
+    for (int d = 0; d < 16; d++) {
+        if (__builtin_popcount((unsigned)((r ^ k_duid_canonical[d]) & 0xFF)) <= 1) {
+            found = d;
+            n++;
+        }
+    }
+    return n == 1 ? found : -1;
+}
+int
+orc_p25p2_duid_lookup_soft(int received, const uint8_t* reliab8, int threshold) {
+    received &= 0xFF;
+    const int hard = orc_p25p2_duid_hard(received);
+    if (!reliab8 || (hard >= 0 && received == k_duid_canonical[hard])) {
+        return hard;
+    }
+    if (received == 0x80) {
+        int ok = reliab8[0] < threshold;
+        for (int i = 1; i < 8; i++) {
+            ok = ok && reliab8[i] >= threshold;
+        }
+        if (!ok) {
+            return hard;
+        }
+    }
+    int best = hard, best_cost = 999999, tied = 0;
+    for (int d = 0; d < 16; d++) {
+        const int diff = (received ^ k_duid_canonical[d]) & 0xFF, dist = __builtin_popcount((unsigned)diff);
+        if (dist < 1 || dist > 2 || (received == 0x80 && d != 0)) {
+            continue;
+        }
+        int cost = 0;
+        for (int i = 0; i < 8 && cost < 999999; i++) {
+            if ((diff >> (7 - i)) & 1) {
+                cost = reliab8[i] >= threshold ? 999999 : cost + reliab8[i];
+            }
+        }
+        if (cost >= 999999) {
+            continue;
+        }
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = d;
+            tied = 0;
+        } else if (cost == best_cost && d != best) {
+            tied = 1;
+        }
+    }
+    return tied ? hard : best;
+}

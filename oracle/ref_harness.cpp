@@ -693,3 +693,103 @@ refh_ambe2450_map(int i, int out4[4]) {
     out4[3] = dsd_ambe_2450_dibit_map[i].low_col;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// P25 Phase 2 FACCH / SACCH burst decode: the gather loops and the ranked-erasure retry of p25p2_process_facchc() /
+// process_SACCHs() -> p25p2_decode_facch_ranked() / _sacch_ranked() (src/protocol/p25/phase2/p25p2_frame.c:395-470,473-495,
+// 652-700; static there, so their few lines are repeated here) around the reference's own ez_rs28_facch / ez_rs28_sacch
+// (src/fec/ez.cpp) and p25p2_facch_soft_erasures / p25p2_sacch_soft_erasures (src/protocol/p25/phase2/p25p2_soft.c, compiled in
+// place).  p2llr / p2xllr are the frame layer's soft-metric buffers p25p2_soft.c reads; the reference's own unit test
+// (tests/protocol/p25/test_p25p2_soft_erasure.c:24-26) defines them the same way.
+#include <dsd-neo/fec/ez.h>
+#include <dsd-neo/protocol/p25/p25p2_soft.h>
+int16_t p2llr[1400] = {0};
+int16_t p2xllr[1400] = {0};
+extern "C" int
+refh_p25p2_xcch(int kind /* 0 FACCH, 1 SACCH */, const uint8_t* bits360, const int16_t* llr360, int ts_counter, uint8_t* payload_out,
+                int* used_dynamic) {
+    static const int facch_fixed[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 54, 55, 56, 57, 58, 59, 60, 61, 62};
+    static const int sacch_fixed[11] = {0, 1, 2, 3, 4, 57, 58, 59, 60, 61, 62};
+    if (ts_counter < 0 || ts_counter > 3) {
+        return -3;
+    }
+    for (int i = 0; i < 1400; i++) {
+        p2llr[i] = 0;
+    }
+    for (int i = 0; i < 360 && i + 360 * ts_counter < 1400; i++) {
+        p2llr[i + 360 * ts_counter] = llr360[i];
+    }
+    int payload[180], parity[132], orig_payload[180], orig_parity[132];
+    int n_pl, n_pa, n_fixed, max_add;
+    const int* fixed;
+    if (kind == 0) {
+        for (int i = 0; i < 72; i++) {
+            payload[i] = bits360[i + 2];
+        }
+        for (int i = 0; i < 62; i++) {
+            payload[i + 72] = bits360[i + 76];
+        }
+        for (int i = 0; i < 22; i++) {
+            payload[i + 134] = bits360[i + 180];
+        }
+        for (int i = 0; i < 42; i++) {
+            parity[i] = bits360[i + 202];
+        }
+        for (int i = 0; i < 72; i++) {
+            parity[i + 42] = bits360[i + 246];
+        }
+        n_pl = 156, n_pa = 114, n_fixed = 18, max_add = 10, fixed = facch_fixed;
+    } else {
+        for (int i = 0; i < 72; i++) { // process_SACCHs(): 72 + 108 payload bits, 60 + 72 parity bits
+            payload[i] = bits360[i + 2];
+        }
+        for (int i = 0; i < 108; i++) {
+            payload[i + 72] = bits360[i + 76];
+        }
+        for (int i = 0; i < 60; i++) {
+            parity[i] = bits360[i + 184];
+        }
+        for (int i = 0; i < 72; i++) {
+            parity[i + 60] = bits360[i + 246];
+        }
+        n_pl = 180, n_pa = 132, n_fixed = 11, max_add = 16, fixed = sacch_fixed;
+    }
+    for (int i = 0; i < n_pl; i++) {
+        orig_payload[i] = payload[i];
+    }
+    for (int i = 0; i < n_pa; i++) {
+        orig_parity[i] = parity[i];
+    }
+    *used_dynamic = 0;
+    int ec = kind == 0 ? ez_rs28_facch(payload, parity, fixed, n_fixed) : ez_rs28_sacch(payload, parity, fixed, n_fixed);
+    if (ec < 0) {
+        int erasures[28] = {0};
+        for (int i = 0; i < n_fixed; i++) {
+            erasures[i] = fixed[i];
+        }
+        const int n_er = kind == 0 ? p25p2_facch_soft_erasures(ts_counter, 0, erasures, n_fixed, max_add)
+                                   : p25p2_sacch_soft_erasures(ts_counter, 0, erasures, n_fixed, max_add);
+        for (int n = n_fixed + 1; n <= n_er; n++) {
+            for (int i = 0; i < n_pl; i++) {
+                payload[i] = orig_payload[i];
+            }
+            for (int i = 0; i < n_pa; i++) {
+                parity[i] = orig_parity[i];
+            }
+            ec = kind == 0 ? ez_rs28_facch(payload, parity, erasures, n) : ez_rs28_sacch(payload, parity, erasures, n);
+            if (ec >= 0) {
+                *used_dynamic = 1;
+                break;
+            }
+        }
+        if (ec < 0) {
+            for (int i = 0; i < n_pl; i++) {
+                payload[i] = orig_payload[i];
+            }
+        }
+    }
+    for (int i = 0; i < n_pl; i++) {
+        payload_out[i] = (uint8_t)payload[i];
+    }
+    return ec;
+}

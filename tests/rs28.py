@@ -104,3 +104,39 @@ def ref_rs28(kind, payload, parity, erasures):
     er = np.ascontiguousarray(erasures, np.int32)
     rc = fn(pl.ctypes.data, pa.ctypes.data, er.ctypes.data if er.size else None, int(er.size))
     return pl, rc
+
+
+# ---- P25 Phase 2 FACCH / SACCH bursts (p25p2_frame.c:473-495,652-671: where the section's bits sit in a 360-bit timeslot) ----------
+XCCH_PAYLOAD_POS = {0: list(range(2, 74)) + list(range(76, 138)) + list(range(180, 202)),
+                    1: list(range(2, 74)) + list(range(76, 184))}
+XCCH_PARITY_POS = {0: list(range(202, 244)) + list(range(246, 318)), 1: list(range(184, 244)) + list(range(246, 318))}
+
+
+def make_xcch_burst(rng, kind, n_err, weak_errors, n_weak_good=0, strong=200):
+    """kind 0 FACCH / 1 SACCH -> (bits360 u8, llr360 i16, sent payload bits): a valid RS(63,35) section laid into the burst, n_err
+    corrupted symbols of which weak_errors carry low |LLR| (what the ranked erasures find), n_weak_good clean symbols made weak too"""
+    k = kind + 1
+    nd, npar, first = N_DATA[k], N_PAR[k], FIRST[k]
+    data35 = np.zeros(35, np.uint8)
+    data35[first:35] = rng.integers(0, 64, nd)
+    blk = encode_block(data35)
+    sent = bits_of(blk[first:35]).astype(np.uint8)
+    tx = np.arange(first, 35 + npar)
+    bad = rng.choice(tx, size=min(n_err, tx.size), replace=False) if n_err else np.zeros(0, np.int64)
+    rx = blk.copy()
+    for p in bad:
+        rx[p] ^= rng.integers(1, 64)
+    bits = rng.integers(0, 2, 360).astype(np.uint8)
+    llr = (rng.integers(strong - 40, strong + 40, 360) * rng.choice([-1, 1], 360)).astype(np.int16)
+    pl, pa = bits_of(rx[first:35]), bits_of(rx[35:35 + npar])
+    bits[XCCH_PAYLOAD_POS[kind]] = pl
+    bits[XCCH_PARITY_POS[kind]] = pa
+    sym_pos = {int(p): (XCCH_PAYLOAD_POS[kind][6 * (p - first):6 * (p - first) + 6] if p < 35
+                        else XCCH_PARITY_POS[kind][6 * (p - 35):6 * (p - 35) + 6]) for p in tx}
+    weak = [int(p) for p in (rng.choice(bad, size=min(weak_errors, len(bad)), replace=False) if weak_errors and len(bad) else [])]
+    good = [int(p) for p in tx if p not in set(int(q) for q in bad)]
+    weak += [int(p) for p in (rng.choice(good, size=min(n_weak_good, len(good)), replace=False) if n_weak_good else [])]
+    for p in weak:
+        b = sym_pos[p][int(rng.integers(0, 6))]
+        llr[b] = int(rng.integers(0, 60)) * int(rng.choice([-1, 1]))
+    return bits, llr, sent

@@ -14,7 +14,7 @@ def declared_functions():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b([A-Za-z_0-9]+)\s*\([^;{]*\)\s*;", text)
     return sorted(set(n for n in names if n.startswith(("ddn_", "simd_", "widen_", "p25_", "dmr_", "viterbi_",
-                                                         "CNXDN", "check_", "hamming_", "golay_", "bch_", "p25p1_", "dsd_", "crc16_", "mbe_", "Hamming_", "Golay_", "QR_", "BPTC", "rs_12_9_", "InitAll", "trellis_", "full_demod", "op25_", "ez_rs28_", "isch_"))))
+                                                         "CNXDN", "check_", "hamming_", "golay_", "bch_", "p25p1_", "dsd_", "crc16_", "mbe_", "Hamming_", "Golay_", "QR_", "BPTC", "rs_12_9_", "InitAll", "trellis_", "full_demod", "op25_", "ez_rs28_", "isch_", "p25p2_"))))
 
 
 def test_header_and_binding_agree(built):

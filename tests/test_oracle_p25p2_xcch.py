@@ -1,0 +1,133 @@
+"""CPU: the P25 Phase 2 FACCH / SACCH burst decode restatement (oracle/ddn_oracle_rs.c: orc_p25p2_xcch - burst gather, RS(63,35)
+with the fixed erasures, the ranked soft-erasure retries) against the reference's own pieces compiled in place (oracle/_ref:
+ez_rs28_facch / _sacch of src/fec/ez.cpp and p25p2_facch_soft_erasures / _sacch_soft_erasures of
+src/protocol/p25/phase2/p25p2_soft.c behind the gather / retry loops of p25p2_frame.c:408-495,652-671)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import rs28
+
+FZ = 7919 * int(os.environ.get("DDN_FUZZ_BASE", "0"))
+needs_ref = pytest.mark.skipif(not orc.have_ref(), reason="compiled reference (oracle/_ref) not present")
+N_PL = {0: 156, 1: 180}
+
+
+def oracle_xcch(kind, bits, llr, threshold=64):
+    o = orc.oracle()
+    o.orc_p25p2_xcch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    out, used = np.zeros(180, np.uint8), C.c_int(0)
+    b, l = np.ascontiguousarray(bits, np.uint8), np.ascontiguousarray(llr, np.int16)
+    ec = o.orc_p25p2_xcch(kind, b.ctypes.data, l.ctypes.data, threshold, out.ctypes.data, C.byref(used))
+    return ec, out[:N_PL[kind]].copy(), used.value
+
+
+def ref_xcch(kind, bits, llr, ts):
+    r = C.CDLL(orc.REF_SO)
+    r.refh_p25p2_xcch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    out, used = np.zeros(180, np.uint8), C.c_int(0)
+    b, l = np.ascontiguousarray(bits, np.uint8), np.ascontiguousarray(llr, np.int16)
+    ec = r.refh_p25p2_xcch(kind, b.ctypes.data, l.ctypes.data, ts, out.ctypes.data, C.byref(used))
+    return ec, out[:N_PL[kind]].copy(), used.value
+
+
+def cases(rng, n):
+    out = []
+    for i in range(n):
+        kind = i & 1
+        n_err = int(rng.integers(0, 14))
+        weak = int(rng.integers(0, n_err + 1))
+        out.append((kind,) + rs28.make_xcch_burst(rng, kind, n_err, weak, int(rng.integers(0, 6))) + (n_err, weak))
+    return out
+
+
+def test_clean_and_repairable_bursts_decode_to_what_was_sent():
+    rng = np.random.default_rng(41 + FZ)
+    seen_dynamic = 0
+    for kind in (0, 1):
+        for n_err in (0, 3, 5 if kind == 0 else 8):      # (28 parity symbols less 18 / 11 fixed erasures: 5 / 8 errors)
+            bits, llr, sent = rs28.make_xcch_burst(rng, kind, n_err, 0)
+            ec, pl, used = oracle_xcch(kind, bits, llr)
+            assert ec >= 0 and used == 0 and np.array_equal(pl, sent), (kind, n_err, ec)
+        for n_err in ((7, 8) if kind == 0 else (10, 11)):                      # beyond the fixed erasures' reach: the weak symbols have to be found
+            bits, llr, sent = rs28.make_xcch_burst(rng, kind, n_err, n_err)
+            ec, pl, used = oracle_xcch(kind, bits, llr)
+            assert ec >= 0 and used == 1 and np.array_equal(pl, sent), (kind, n_err, ec)
+            seen_dynamic += used
+        bits, llr, sent = rs28.make_xcch_burst(rng, kind, 15, 0)
+        ec, pl, used = oracle_xcch(kind, bits, llr)
+        assert ec < 0 and np.array_equal(pl, bits[rs28.XCCH_PAYLOAD_POS[kind]])      # hopeless: as received
+    assert seen_dynamic == 4
+
+
+@needs_ref
+def test_restatement_equals_the_compiled_reference_pieces():
+    rng = np.random.default_rng(43 + FZ)
+    kinds = set()
+    for k, (kind, bits, llr, sent, n_err, weak) in enumerate(cases(rng, 300)):
+        want = ref_xcch(kind, bits, llr, k % 4)
+        got = oracle_xcch(kind, bits, llr)
+        assert got[0] == want[0] and got[2] == want[2] and np.array_equal(got[1], want[1]), (k, kind, n_err, weak, got[0], want[0])
+        kinds.add((kind, want[0] >= 0, want[2]))
+    assert len(kinds) >= 6, kinds
+
+
+def oracle_duid(received, rel, threshold=64):
+    o = orc.oracle()
+    o.orc_p25p2_duid_lookup_soft.argtypes = [C.c_int, C.c_void_p, C.c_int]
+    r = None if rel is None else np.ascontiguousarray(rel, np.uint8)
+    return o.orc_p25p2_duid_lookup_soft(int(received), None if r is None else r.ctypes.data, threshold)
+
+
+def test_duid_soft_lookup_known_answers_of_the_reference():
+    """tests/protocol/p25/test_p25_p2_reliability.c:970-974 and :1372-1440 - every answer the reference's suite holds for
+    p25p2_duid_lookup_soft (threshold 64, the default)"""
+    s = [200] * 8
+    assert oracle_duid(0x17, [0] * 8) == 1 and oracle_duid(0x17, None) == 1
+    assert oracle_duid(0x07, s[:7] + [5]) == 1                       # a valid hard decision is kept
+    assert oracle_duid(0x03, s[:6] + [5, 5]) == 0                    # the weakest invalid bits are flipped
+    assert oracle_duid(0x03, s) == -1                                # confident invalid bits are not
+    assert oracle_duid(0x80, [5] + s[1:]) == 0 and oracle_duid(0x80, s) == -1 and oracle_duid(0x80, [5, 5] + s[2:]) == -1
+    r = list(s)
+    for k in (3, 5, 6, 7):
+        r[k] = 5
+    assert oracle_duid(0x03, r) == -1                                # tied candidates: the hard answer stands
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/protocol/p25/phase2/p25p2_frame.c"), reason="reference tree not present")
+def test_duid_hard_table_equals_the_source_table():
+    """the rule the restatement (and the kernel) derive the 256-entry table from, against the table in the reference's source"""
+    import re
+    src = open("/root/reference/src/protocol/p25/phase2/p25p2_frame.c").read()
+    body = src[src.index("duid_lookup[256] = {"):]
+    body = body[body.index("{") + 1:body.index("};")]
+    vals = [int(v) for v in re.findall(r"-?\d+", re.sub(r"//[^\n]*", "", body))]
+    assert len(vals) == 256
+    o = orc.oracle()
+    assert [o.orc_p25p2_duid_hard(r) for r in range(256)] == vals
+
+
+def scramble_bits(wacn, sysid, nac, count):
+    """p25p2_generate_scramble_bits (p25p2_scramble.c:12-26) in Python"""
+    s = (wacn * 16777216 + sysid * 4096 + nac) & ((1 << 64) - 1)
+    out = np.zeros(count, np.uint8)
+    for i in range(count):
+        out[i] = (s >> 43) & 1
+        b = ((s >> 33) ^ (s >> 19) ^ (s >> 14) ^ (s >> 8) ^ (s >> 3) ^ (s >> 43)) & 1
+        s = ((s << 1) | b) & ((1 << 64) - 1)
+    return out
+
+
+@needs_ref
+def test_scramble_sequence_equals_the_reference():
+    r = C.CDLL(orc.REF_SO)
+    r.p25p2_generate_scramble_bits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(59 + FZ)
+    for _ in range(6):
+        w, s, n = int(rng.integers(1, 1 << 20)), int(rng.integers(1, 1 << 12)), int(rng.integers(1, 1 << 12))
+        out = np.zeros(4320, np.uint8)
+        r.p25p2_generate_scramble_bits(w, s, n, out.ctypes.data, 4320)
+        assert np.array_equal(out, scramble_bits(w, s, n, 4320))

@@ -1,0 +1,123 @@
+"""GPU: the P25 Phase 2 FACCH / SACCH burst stage (ddn_p25p2_xcch_batch / _host: burst gather, ranked soft erasures, RS(63,35) with
+the fixed erasures and the retries) against the CPU restatement, which tests/test_oracle_p25p2_xcch.py pins to the reference's own
+ez.cpp + p25p2_soft.c compiled in place: ec, the used-dynamic flag and the payload bit for bit, every outcome class covered."""
+import os
+
+import numpy as np
+import pytest
+
+import ddn
+import rs28
+from test_oracle_p25p2_xcch import N_PL, oracle_xcch
+
+pytestmark = pytest.mark.gpu
+FZ = 7919 * int(os.environ.get("DDN_FUZZ_BASE", "0"))
+
+
+def test_xcch_batch_equals_oracle(built):
+    rng = np.random.default_rng(47 + FZ)
+    for kind in (0, 1):
+        n = 1500
+        bits, llr, want = np.zeros((n, 360), np.uint8), np.zeros((n, 360), np.int16), []
+        for i in range(n):
+            n_err = int(rng.integers(0, 15))
+            b, l, _ = rs28.make_xcch_burst(rng, kind, n_err, int(rng.integers(0, n_err + 1)), int(rng.integers(0, 8)))
+            if i % 97 == 0:
+                l[:] = rng.integers(-300, 300, 360)         # all-weak metrics: the minimum / maximum list lengths
+            bits[i], llr[i] = b, l
+            want.append(oracle_xcch(kind, b, l))
+        pl, ec, used = np.zeros((n, N_PL[kind]), np.uint8), np.zeros(n, np.int32), np.zeros(n, np.uint8)
+        assert ddn.lib().ddn_p25p2_xcch_host(kind, bits.ctypes.data, llr.ctypes.data, n, 64, pl.ctypes.data, ec.ctypes.data, used.ctypes.data) == 0
+        classes = set()
+        for i, (wec, wpl, wused) in enumerate(want):
+            assert ec[i] == wec and used[i] == wused and np.array_equal(pl[i], wpl), (kind, i, ec[i], wec, used[i], wused)
+            classes.add((wec >= 0, wused))
+        assert classes == {(True, 0), (True, 1), (False, 0)}, classes
+        # another threshold moves the list lengths, not the rule
+        thr = 20
+        want2 = [oracle_xcch(kind, bits[i], llr[i], thr) for i in range(0, n, 7)]
+        assert ddn.lib().ddn_p25p2_xcch_host(kind, bits.ctypes.data, llr.ctypes.data, n, thr, pl.ctypes.data, ec.ctypes.data, used.ctypes.data) == 0
+        for j, i in enumerate(range(0, n, 7)):
+            assert ec[i] == want2[j][0] and used[i] == want2[j][2] and np.array_equal(pl[i], want2[j][1]), (kind, i)
+
+
+def test_burst_fields_duid_and_isch_equal_oracle(built):
+    import ctypes as C
+    import orc
+    from test_oracle_p25p2_xcch import oracle_duid
+    rng = np.random.default_rng(53 + FZ)
+    n = 4000
+    canon = [0x00, 0x17, 0x2E, 0x39, 0x4B, 0x5C, 0x65, 0x72, 0x8D, 0x9A, 0xA3, 0xB4, 0xC6, 0xD1, 0xE8, 0xFF]
+    o = orc.oracle()
+    o.orc_isch_lookup_soft.argtypes = [C.c_uint64, C.c_void_p]
+    bits = rng.integers(0, 2, (n, 360)).astype(np.uint8)
+    llr = (rng.integers(0, 300, (n, 360)) * rng.choice([-1, 1], (n, 360))).astype(np.int16)
+    off = [0, 1, 74, 75, 244, 245, 318, 319]
+    for i in range(n):                       # DUID words near the code: canonical, one or two flips, the 0x80 guard; weak bits here and there
+        w = canon[int(rng.integers(0, 16))] if i % 5 else 0x80
+        for _ in range(int(rng.integers(0, 3))):
+            w ^= 1 << int(rng.integers(0, 8))
+        bits[i, off] = [(w >> (7 - k)) & 1 for k in range(8)]
+        for k in rng.choice(8, int(rng.integers(0, 4)), replace=False):
+            llr[i, off[k]] = int(rng.integers(0, 70))
+        if i % 3 == 0:                       # an I-ISCH word a few bits from the one another burst carries, some of them weak
+            src = bits[(i * 7) % n, 320:360].copy()
+            for k in rng.choice(40, int(rng.integers(0, 9)), replace=False):
+                src[k] ^= 1
+                llr[i, 320 + k] = int(rng.integers(0, 40))
+            bits[i, 320:360] = src
+    duid, isch = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    assert ddn.lib().ddn_p25p2_burst_fields_host(bits.ctypes.data, llr.ctypes.data, n, 64, duid.ctypes.data, isch.ctypes.data) == 0
+    seen = set()
+    for i in range(n):
+        rel = np.minimum(np.abs(llr[i].astype(np.int32)), 255).astype(np.uint8)
+        w = 0
+        for k in range(8):
+            w = (w << 1) | int(bits[i, off[k]])
+        want = oracle_duid(w, rel[off])
+        assert duid[i] == want, (i, hex(w), duid[i], want)
+        seen.add(want)
+        word = 0
+        for k in range(40):
+            word = (word << 1) | int(bits[i, 320 + k])
+        r40 = np.ascontiguousarray(rel[320:360])
+        assert isch[i] == o.orc_isch_lookup_soft(C.c_uint64(word), r40.ctypes.data), i
+    assert seen >= set(range(16)) | {-1}, seen
+
+
+def test_scramble_sequence_and_descramble(built):
+    """ddn_p25p2_scramble_bits_batch / _descramble_batch / the reference-named p25p2_generate_scramble_bits: the LFSR sequence bit for bit
+    (the Python restatement is pinned to the compiled p25p2_scramble.c in tests/test_oracle_p25p2_xcch.py), de-scrambled bits and
+    sign-flipped metrics against process_Frame_Scramble()'s two loops (p25p2_frame.c:381-392), offsets that wrap included"""
+    import ctypes as C
+    import torch
+    from test_oracle_p25p2_xcch import scramble_bits
+    rng = np.random.default_rng(61 + FZ)
+    l = ddn.lib()
+    ns = 5
+    ids = [(int(rng.integers(1, 1 << 20)), int(rng.integers(1, 1 << 12)), int(rng.integers(1, 1 << 12))) for _ in range(ns)]
+    seeds = torch.tensor([w * 16777216 + s * 4096 + n for w, s, n in ids], dtype=torch.int64, device="cuda")
+    seq = torch.zeros((ns, 4320), dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p2_scramble_bits_batch(seeds.data_ptr(), ns, 4320, seq.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    want = np.stack([scramble_bits(w, s, n, 4320) for w, s, n in ids])
+    assert np.array_equal(seq.cpu().numpy(), want)
+    one = np.zeros(1000, np.uint8)
+    l.p25p2_generate_scramble_bits(ids[0][0], ids[0][1], ids[0][2], one.ctypes.data, 1000)
+    assert np.array_equal(one, want[0, :1000])
+    n, nb, nl = 40, 4300, 1400
+    bits = rng.integers(0, 2, (n, nb)).astype(np.uint8)
+    llr = rng.integers(-300, 300, (n, nl)).astype(np.int16)
+    off = rng.integers(0, 12, n).astype(np.int32)
+    which = rng.integers(0, ns, n).astype(np.int32)
+    tb, tl = torch.from_numpy(bits).cuda(), torch.from_numpy(llr).cuda()
+    to, tw = torch.from_numpy(off).cuda(), torch.from_numpy(which).cuda()
+    xb, xl = torch.zeros_like(tb), torch.zeros_like(tl)
+    assert l.ddn_p25p2_descramble_batch(tb.data_ptr(), tl.data_ptr(), seq.data_ptr(), to.data_ptr(), tw.data_ptr(), n, nb, nl, xb.data_ptr(),
+                                        xl.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    for i in range(n):
+        lb = np.concatenate([want[which[i]], want[which[i]]])          # "doubling up for offset roll-over"
+        s = lb[20 + 360 * int(off[i]):20 + 360 * int(off[i]) + nb]
+        assert np.array_equal(xb[i].cpu().numpy(), bits[i] ^ s), i
+        assert np.array_equal(xl[i].cpu().numpy(), np.where(s[:nl] == 1, -llr[i], llr[i]).astype(np.int16)), i
