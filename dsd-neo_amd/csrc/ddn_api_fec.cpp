@@ -697,6 +697,58 @@ ddn_p25p2_xcch_batch(int kind, const uint8_t* d_bits360, const int16_t* d_llr360
     return DDN_OK;
 }
 
+// P25 Phase 2 ESS and voice bursts (include/ddn_hip.h)
+extern "C" int
+ddn_p25p2_ess_batch(const uint8_t* d_payload_bits96, const int16_t* d_payload_llr96, const uint8_t* d_parity_bits168,
+                    const int16_t* d_parity_llr168, size_t n, int threshold, uint8_t* d_payload_out96, int32_t* d_ec, uint8_t* d_used_dynamic,
+                    void* hip_stream) {
+    if (!d_payload_bits96 || !d_payload_llr96 || !d_parity_bits168 || !d_parity_llr168 || !d_payload_out96 || !d_ec || !d_used_dynamic) {
+        ddn_set_error("ddn_p25p2_ess_batch: null argument");
+        return DDN_EINVAL;
+    }
+    if (n == 0) {
+        return DDN_OK;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    uint8_t* scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&scratch, n * 29 + 64, st));
+    const hipError_t e = ddn_dev_p25p2_ess(d_payload_bits96, d_payload_llr96, d_parity_bits168, d_parity_llr168, (int)n, threshold,
+                                           d_payload_out96, (int8_t*)scratch, scratch + n * 28, d_ec, d_used_dynamic, st);
+    HIP_TRY(hipFreeAsync(scratch, st));
+    HIP_TRY(e);
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p2_ess_host(const uint8_t* payload_bits96, const int16_t* payload_llr96, const uint8_t* parity_bits168, const int16_t* parity_llr168,
+                   size_t n, int threshold, uint8_t* payload_out96, int32_t* ec, uint8_t* used_dynamic) {
+    if (!payload_bits96 || !payload_llr96 || !parity_bits168 || !parity_llr168 || !payload_out96 || !ec || !used_dynamic) {
+        return DDN_EINVAL;
+    }
+    Dev a(n * 96), al(n * 96 * 2), b(n * 168), bl(n * 168 * 2), o(n * 96), s(n * sizeof(int32_t)), u(n);
+    if (!a.p || !al.p || !b.p || !bl.p || !o.p || !s.p || !u.p || a.up(payload_bits96) || al.up(payload_llr96) || b.up(parity_bits168)
+        || bl.up(parity_llr168)) {
+        return no_dev();
+    }
+    const int rc = ddn_p25p2_ess_batch((const uint8_t*)a.p, (const int16_t*)al.p, (const uint8_t*)b.p, (const int16_t*)bl.p, n, threshold,
+                                       (uint8_t*)o.p, (int32_t*)s.p, (uint8_t*)u.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (o.down(payload_out96) || s.down(ec) || u.down(used_dynamic)) ? no_dev() : DDN_OK;
+}
+
+extern "C" int
+ddn_p25p2_voice_frames_batch(const uint8_t* d_xbits360, const int16_t* d_xllr360, size_t n, int frame_count, uint8_t* d_ambe_fr,
+                             uint8_t* d_ambe_rel, void* hip_stream) {
+    if (!d_xbits360 || !d_xllr360 || !d_ambe_fr || !d_ambe_rel || frame_count < 1 || frame_count > 4) {
+        ddn_set_error("ddn_p25p2_voice_frames_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_p25p2_voice_unpack(d_xbits360, d_xllr360, (int)n, frame_count, d_ambe_fr, d_ambe_rel, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
 // P25 Phase 2 frame scrambler (include/ddn_hip.h)
 extern "C" int
 ddn_p25p2_scramble_bits_batch(const uint64_t* d_seed44, size_t n, size_t bit_count, uint8_t* d_out_bits, void* hip_stream) {

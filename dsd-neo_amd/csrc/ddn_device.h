@@ -221,6 +221,11 @@ hipError_t ddn_dev_golay24_soft(uint8_t* data, const uint8_t* parity, const int3
 hipError_t ddn_dev_hamming_10_6_3_soft(const uint8_t* bits, const int32_t* reliab, int n, uint8_t* out, uint8_t* status,
                                        hipStream_t st);
 hipError_t ddn_dev_isch_lookup(const uint64_t* words, const uint8_t* reliab40, int n, int32_t* out, hipStream_t st);
+hipError_t ddn_dev_p25p2_ess(const uint8_t* payload_bits, const int16_t* payload_llr, const uint8_t* parity_bits, const int16_t* parity_llr,
+                             int n, int threshold, uint8_t* work, int8_t* erasures28, uint8_t* n_total, int32_t* status,
+                             uint8_t* used_dynamic, hipStream_t st);
+hipError_t ddn_dev_p25p2_voice_unpack(const uint8_t* xbits360, const int16_t* xllr360, int n, int frame_count, uint8_t* fr, uint8_t* rl,
+                                      hipStream_t st);
 hipError_t ddn_dev_p25p2_scramble_bits(const uint64_t* seed44, int n, int bit_count, uint8_t* out, hipStream_t st);
 hipError_t ddn_dev_p25p2_descramble(const uint8_t* bits, const int16_t* llr, const uint8_t* lbits4320, const int32_t* offset,
                                     const int32_t* seq_of, int n, int n_bits, int n_llr, uint8_t* xbits, int16_t* xllr, hipStream_t st);

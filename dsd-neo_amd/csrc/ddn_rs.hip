@@ -1271,6 +1271,86 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
     return hipGetLastError();
 }
 
+// ---- P25 Phase 2 ESS: ranked erasure list and the rule for the plain decode ---------------------------------------------------------
+// p25p2_ess_soft_erasures_ranked() (p25p2_soft.c:331-383) and p25p2_ess_decode_with_soft_erasures() (p25p2_frame.c:1061-1091): the
+// plain decode stands when it located fewer than 15 symbols; otherwise the section goes back to its received bits and is retried
+// with the first 1, 2, ... erasures of the list (k_rs28 in attempt mode, n_fixed = 0).
+__global__ void
+k_p2_ess_prepare(const uint8_t* __restrict__ payload_bits, const int16_t* __restrict__ payload_llr, const int16_t* __restrict__ parity_llr,
+                 int n, int threshold, uint8_t* __restrict__ work, int8_t* __restrict__ erasures28, uint8_t* __restrict__ n_total,
+                 uint8_t* __restrict__ used_dynamic) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    for (int k = 0; k < 96; k++) {
+        work[(size_t)i * 96 + k] = payload_bits[(size_t)i * 96 + k] & 1;
+    }
+    uint16_t key[44];
+    int below = 0;
+    for (int hb = 0; hb < 44; hb++) {
+        const int16_t* l = hb < 16 ? payload_llr + (size_t)i * 96 + 6 * hb : parity_llr + (size_t)i * 168 + 6 * (hb - 16);
+        int r = 255;
+        for (int b = 0; b < 6; b++) {
+            int v = l[b];
+            v = v < 0 ? -v : v;
+            v = v > 255 ? 255 : v;
+            r = v < r ? v : r;
+        }
+        key[hb] = (uint16_t)((r << 8) | hb);
+        below += r < threshold ? 1 : 0;
+    }
+    int cnt = below < 14 ? 14 : below;
+    cnt = cnt > 28 ? 28 : cnt;
+    int8_t* er = erasures28 + (size_t)i * 28;
+    for (int k = 0; k < cnt; k++) {
+        int best = k;
+        for (int j = k + 1; j < 44; j++) {
+            best = key[j] < key[best] ? j : best;
+        }
+        const uint16_t t = key[k];
+        key[k] = key[best];
+        key[best] = t;
+        er[k] = (int8_t)(key[k] & 0xFF);
+    }
+    for (int k = cnt; k < 28; k++) {
+        er[k] = 0;
+    }
+    n_total[i] = (uint8_t)cnt;
+    used_dynamic[i] = 0;
+}
+
+__global__ void
+k_p2_ess_after_plain(const uint8_t* __restrict__ payload_bits, int n, uint8_t* __restrict__ work, int32_t* __restrict__ status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    if (status[i] >= 15) { // decoded, but with too many corrections to be believed: back to the received bits, on to the retries
+        for (int k = 0; k < 96; k++) {
+            work[(size_t)i * 96 + k] = payload_bits[(size_t)i * 96 + k] & 1;
+        }
+        status[i] = -1;
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_p25p2_ess(const uint8_t* payload_bits, const int16_t* payload_llr, const uint8_t* parity_bits, const int16_t* parity_llr, int n,
+                  int threshold, uint8_t* work, int8_t* erasures28, uint8_t* n_total, int32_t* status, uint8_t* used_dynamic, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    const dim3 grid((unsigned)((n + 63) / 64)), blk(64);
+    hipLaunchKernelGGL(k_p2_ess_prepare, grid, blk, 0, st, payload_bits, payload_llr, parity_llr, n, threshold, work, erasures28, n_total,
+                       used_dynamic);
+    hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 0, 0, used_dynamic);
+    hipLaunchKernelGGL(k_p2_ess_after_plain, grid, blk, 0, st, payload_bits, n, work, status);
+    for (int attempt = 1; attempt <= 28; attempt++) {
+        hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, attempt, 0, used_dynamic);
+    }
+    return hipGetLastError();
+}
+
 // ---- P25 Phase 2 frame scrambler ----------------------------------------------------------------------------------------------------
 // p25p2_generate_scramble_bits() (src/protocol/p25/phase2/p25p2_scramble.c:12-26): the 44-bit Fibonacci LFSR x^44 + x^34 + x^20 + x^15 +
 // x^9 + x^4 + 1 seeded with WACN | SYSID | NAC; process_Frame_Scramble() (p25p2_frame.c:370-392): a superframe's 4320 sequence bits,

@@ -1823,6 +1823,45 @@ k_dmr_voice_gather(const uint8_t* __restrict__ rec, const int32_t* __restrict__ 
     }
 }
 
+// P25 Phase 2 4V / 2V bursts: p25p2_unpack_voice_frames() (src/protocol/p25/phase2/p25p2_frame.c:250-262,849-900) - frame f's 72 bits
+// start at bit 2 / 76 / 172 / 246 of the (de-scrambled) timeslot; bit x goes to ambe_fr[w][b] by the csubset / c0..c3 schedule, which is
+// the AMBE 3600x2450 dibit schedule read bit by bit (bit 2 i = dibit i's high bit, 2 i + 1 its low bit: checked entry by entry
+// against the table measured from the compiled reference, tests/test_oracle_p25p2_xcch.py); soft bit = {bit, min(|LLR|, 255)}
+// (p25p2_soft_bit_from_abs_bit()).  One workgroup per burst, thread = (frame, bit).
+__global__ __launch_bounds__(288) void
+k_p2_voice_unpack(const uint8_t* __restrict__ xbits360, const int16_t* __restrict__ xllr360, int frame_count, uint8_t* __restrict__ fr,
+                  uint8_t* __restrict__ rl) {
+    const int i = blockIdx.x, t = threadIdx.x, f = t / 72, x = t % 72;
+    uint8_t* o = fr + (size_t)i * frame_count * 96;
+    uint8_t* r = rl + (size_t)i * frame_count * 96;
+    for (int q = t; q < frame_count * 96; q += blockDim.x) {
+        o[q] = 0;
+        r[q] = 0;
+    }
+    __syncthreads();
+    if (f >= frame_count) {
+        return;
+    }
+    const int off = f == 0 ? 2 : (f == 1 ? 76 : (f == 2 ? 172 : 246));
+    const int bit = xbits360[(size_t)i * 360 + off + x] & 1;
+    int v = xllr360[(size_t)i * 360 + off + x];
+    v = v < 0 ? -v : v;
+    v = v > 255 ? 255 : v;
+    const int d = x >> 1, lo = x & 1;
+    const int cell = lo ? c_ambe2450_map[d][2] * 24 + c_ambe2450_map[d][3] : c_ambe2450_map[d][0] * 24 + c_ambe2450_map[d][1];
+    o[f * 96 + cell] = (uint8_t)bit;
+    r[f * 96 + cell] = (uint8_t)v;
+}
+
+extern "C" hipError_t
+ddn_dev_p25p2_voice_unpack(const uint8_t* xbits360, const int16_t* xllr360, int n, int frame_count, uint8_t* fr, uint8_t* rl, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p2_voice_unpack, dim3((unsigned)n), dim3(288), 0, st, xbits360, xllr360, frame_count, fr, rl);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t
 ddn_dev_ambe2450_deinterleave(const uint8_t* dibits, const uint8_t* reliab, int n, uint8_t* fr, uint8_t* rl, hipStream_t st) {
     if (n <= 0) {

@@ -671,6 +671,21 @@ int ddn_fec_rs28_host(int kind, uint8_t* payload_bits, const uint8_t* parity_bit
  * threshold = p25p2_soft_erasure_threshold(), 64 unless configured).  d_bits360 u8 [n][360] one bit per byte, d_llr360 i16 [n][360]
  * (p2llr / p2xllr), d_payload_bits u8 [n][156 | 180] (corrected, or as received when ec < 0), d_ec i32 [n] = the reference's ec,
  * d_used_dynamic u8 [n] = its used_dynamic_erasure. */
+/* P25 Phase 2 ESS == p25p2_ess_decode_with_soft_erasures() (src/protocol/p25/phase2/p25p2_frame.c:1061-1091): payload = the four ESS-B
+ * fragments (96 bits, 24 from bit 148 of each 4V burst: p25p2_collect_ess_b_fragment(), :902-915), parity = ESS-A (96 bits from bit
+ * 148 + 72 from bit 246 of the 2V burst: p25p2_collect_ess_a(), :1399-1411), with their soft metrics (p2xllr).  The plain RS(44,16)
+ * decode stands when it located fewer than 15 symbols, else retries with 1, 2, ... erasures of p25p2_ess_soft_erasures_ranked()'s
+ * list (p25p2_soft.c:331-383).  d_payload_out96 = corrected (d_ec >= 0) or as received; d_used_dynamic = a retry decoded it. */
+int ddn_p25p2_ess_batch(const uint8_t* d_payload_bits96, const int16_t* d_payload_llr96, const uint8_t* d_parity_bits168,
+                        const int16_t* d_parity_llr168, size_t n, int threshold, uint8_t* d_payload_out96, int32_t* d_ec,
+                        uint8_t* d_used_dynamic, void* hip_stream);
+int ddn_p25p2_ess_host(const uint8_t* payload_bits96, const int16_t* payload_llr96, const uint8_t* parity_bits168,
+                       const int16_t* parity_llr168, size_t n, int threshold, uint8_t* payload_out96, int32_t* ec, uint8_t* used_dynamic);
+/* P25 Phase 2 4V / 2V bursts == p25p2_unpack_voice_frames() (p25p2_frame.c:250-262,849-900): frame_count (4 / 2) AMBE 3600x2450 frames
+ * of 72 bits from bit 2 / 76 / 172 / 246 of the de-scrambled timeslot -> d_ambe_fr u8 [n][frame_count][4][24] + d_ambe_rel (the soft
+ * bits' reliabilities, min(|LLR|, 255)): the input of ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, ..). */
+int ddn_p25p2_voice_frames_batch(const uint8_t* d_xbits360, const int16_t* d_xllr360, size_t n, int frame_count, uint8_t* d_ambe_fr,
+                                 uint8_t* d_ambe_rel, void* hip_stream);
 /* P25 Phase 2 frame scrambler == p25p2_generate_scramble_bits() (src/protocol/p25/phase2/p25p2_scramble.c:12-26: 44-bit LFSR seeded with
  * wacn << 24 | sysid << 12 | nac; d_seed44 u64 [n] holds that value, d_out_bits u8 [n][bit_count]) and the de-scrambling of
  * process_Frame_Scramble() (p25p2_frame.c:370-392): xbit[i] = bit[i] ^ sequence[(i + 20 + 360 * offset) mod 4320], the soft metric's

@@ -374,6 +374,8 @@ int orc_rs63_decode_erasures(int* word, int t, const int* erasures, int n_er);
 /* P25 Phase 2 RS(63,35) sections with caller-given erasures (== ez_rs28_ess / _facch / _sacch, src/fec/ez.cpp:104-281) */
 int orc_ez_rs28(int kind, int* payload, const int* parity, const int* erasures, int n_erasures);
 /* P25 Phase 2 FACCH (kind 0) / SACCH (kind 1) burst decode with the ranked soft erasures (p25p2_frame.c:408-495,652-671, p25p2_soft.c) */
+int orc_p25p2_ess(const uint8_t* payload_bits96, const int16_t* payload_llr96, const uint8_t* parity_bits168, const int16_t* parity_llr168,
+                  int threshold, uint8_t* payload_out96, int* ec);
 int orc_p25p2_duid_hard(int received);
 int orc_p25p2_duid_lookup_soft(int received, const uint8_t* reliab8, int threshold);
 int orc_p25p2_xcch(int kind, const uint8_t* bits360, const int16_t* llr360, int threshold, uint8_t* payload_out, int* used_dynamic);

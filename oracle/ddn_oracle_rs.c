@@ -1220,3 +1220,58 @@ orc_p25p2_duid_lookup_soft(int received, const uint8_t* reliab8, int threshold) 
     }
     return tied ? hard : best;
 }
+
+/* P25 Phase 2 ESS (RS(44,16) over the four ESS-B fragments + ESS-A): p25p2_ess_decode_with_soft_erasures() (src/protocol/p25/phase2/
+ * p25p2_frame.c:1061-1091) - the plain decode is taken when it located fewer than 15 symbols; otherwise the retries with the first
+ * 1, 2, ... of p25p2_ess_soft_erasures_ranked()'s list (p25p2_soft.c:331-383: the 44 symbols by (least min(|LLR|, 255) of their six
+ * bits, position), as many as fall below the threshold, at least 14, at most 28), each from the bits as received; the first that
+ * decodes is taken.  Returns accepted (payload corrected) or 0 (payload as received); *ec = the last decode's return value. */
+int
+orc_p25p2_ess(const uint8_t* payload_bits96, const int16_t* payload_llr96, const uint8_t* parity_bits168, const int16_t* parity_llr168,
+              int threshold, uint8_t* payload_out96, int* ec) {
+    int payload[96], parity[168];
+    for (int i = 0; i < 96; i++) payload[i] = payload_bits96[i] & 1;
+    for (int i = 0; i < 168; i++) parity[i] = parity_bits168[i] & 1;
+    int accepted = 0;
+    *ec = orc_ez_rs28(0, payload, parity, 0, 0);
+    if (*ec >= 0 && *ec < 15) {
+        accepted = 1;
+    } else {
+        int rel[44], pos[44];
+        for (int hb = 0; hb < 44; hb++) {
+            const int16_t* l = hb < 16 ? payload_llr96 + 6 * hb : parity_llr168 + 6 * (hb - 16);
+            int r = 255;
+            for (int b = 0; b < 6; b++) {
+                int v = l[b] < 0 ? -(int)l[b] : (int)l[b];
+                v = v > 255 ? 255 : v;
+                r = v < r ? v : r;
+            }
+            rel[hb] = r;
+            pos[hb] = hb;
+        }
+        for (int i = 0; i < 44; i++) {
+            for (int j = i + 1; j < 44; j++) {
+                if (rel[j] < rel[i] || (rel[j] == rel[i] && pos[j] < pos[i])) {
+                    int t = rel[i]; rel[i] = rel[j]; rel[j] = t;
+                    t = pos[i]; pos[i] = pos[j]; pos[j] = t;
+                }
+            }
+        }
+        int n_er = 0;
+        for (int i = 0; i < 44; i++) n_er += rel[i] < threshold;
+        n_er = n_er < 14 ? 14 : n_er;
+        n_er = n_er > 28 ? 28 : n_er;
+        for (int n = 1; n <= n_er && !accepted; n++) {
+            for (int i = 0; i < 96; i++) payload[i] = payload_bits96[i] & 1;
+            *ec = orc_ez_rs28(0, payload, parity, pos, n);
+            if (*ec >= 0) {
+                accepted = 1;
+            }
+        }
+        if (!accepted) {
+            for (int i = 0; i < 96; i++) payload[i] = payload_bits96[i] & 1;
+        }
+    }
+    for (int i = 0; i < 96; i++) payload_out96[i] = (uint8_t)payload[i];
+    return accepted;
+}

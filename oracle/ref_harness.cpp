@@ -793,3 +793,49 @@ refh_p25p2_xcch(int kind /* 0 FACCH, 1 SACCH */, const uint8_t* bits360, const i
     }
     return ec;
 }
+
+// P25 Phase 2 ESS: p25p2_ess_decode_with_soft_erasures() (p25p2_frame.c:1061-1091; static there) around the reference's ez_rs28_ess and
+// p25p2_ess_soft_erasures_ranked (p25p2_soft.c, compiled in place).  Returns accepted; *ec as the reference leaves it.
+extern "C" int
+refh_p25p2_ess(const uint8_t* payload_bits96, const int16_t* payload_llr96, const uint8_t* parity_bits168, const int16_t* parity_llr168,
+               uint8_t* payload_out96, int* ec) {
+    int payload[96], parity[168], op[96], oq[168];
+    for (int i = 0; i < 96; i++) {
+        payload[i] = op[i] = payload_bits96[i] & 1;
+    }
+    for (int i = 0; i < 168; i++) {
+        parity[i] = oq[i] = parity_bits168[i] & 1;
+    }
+    int accepted = 0;
+    *ec = ez_rs28_ess(payload, parity, NULL, 0);
+    if (*ec >= 0 && *ec < 15) {
+        accepted = 1;
+    } else {
+        for (int i = 0; i < 96; i++) {
+            payload[i] = op[i];
+        }
+        int erasures[44];
+        const int n_er = p25p2_ess_soft_erasures_ranked(payload_llr96, parity_llr168, erasures, 28);
+        for (int n = 1; n <= n_er && !accepted; n++) {
+            for (int i = 0; i < 96; i++) {
+                payload[i] = op[i];
+            }
+            for (int i = 0; i < 168; i++) {
+                parity[i] = oq[i];
+            }
+            *ec = ez_rs28_ess(payload, parity, erasures, n);
+            if (*ec >= 0) {
+                accepted = 1;
+            }
+        }
+        if (!accepted) {
+            for (int i = 0; i < 96; i++) {
+                payload[i] = op[i];
+            }
+        }
+    }
+    for (int i = 0; i < 96; i++) {
+        payload_out96[i] = (uint8_t)payload[i];
+    }
+    return accepted;
+}

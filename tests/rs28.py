@@ -140,3 +140,25 @@ def make_xcch_burst(rng, kind, n_err, weak_errors, n_weak_good=0, strong=200):
         b = sym_pos[p][int(rng.integers(0, 6))]
         llr[b] = int(rng.integers(0, 60)) * int(rng.choice([-1, 1]))
     return bits, llr, sent
+
+
+def make_ess_case(rng, n_err, weak_errors, n_weak_good=0, strong=200):
+    """-> (payload bits u8 [96], payload llr i16 [96], parity bits u8 [168], parity llr i16 [168], sent payload bits): a valid
+    RS(44,16) ESS section with n_err corrupted symbols, weak_errors of them with a low |LLR|"""
+    data35 = np.zeros(35, np.uint8)
+    data35[19:35] = rng.integers(0, 64, 16)
+    blk = encode_block(data35)
+    sent = bits_of(blk[19:35]).astype(np.uint8)
+    tx = np.arange(19, 63)
+    bad = rng.choice(tx, size=min(n_err, 44), replace=False) if n_err else np.zeros(0, np.int64)
+    rx = blk.copy()
+    for p in bad:
+        rx[p] ^= rng.integers(1, 64)
+    pl, pa = bits_of(rx[19:35]).astype(np.uint8), bits_of(rx[35:63]).astype(np.uint8)
+    llr = (rng.integers(strong - 40, strong + 40, 264) * rng.choice([-1, 1], 264)).astype(np.int16)
+    weak = [int(p) for p in (rng.choice(bad, size=min(weak_errors, len(bad)), replace=False) if weak_errors and len(bad) else [])]
+    good = [int(p) for p in tx if p not in set(int(q) for q in bad)]
+    weak += [int(p) for p in (rng.choice(good, size=min(n_weak_good, len(good)), replace=False) if n_weak_good else [])]
+    for p in weak:
+        llr[6 * (p - 19) + int(rng.integers(0, 6))] = int(rng.integers(0, 60)) * int(rng.choice([-1, 1]))
+    return pl, llr[:96].copy(), pa, llr[96:].copy(), sent

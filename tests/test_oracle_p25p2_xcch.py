@@ -131,3 +131,45 @@ def test_scramble_sequence_equals_the_reference():
         out = np.zeros(4320, np.uint8)
         r.p25p2_generate_scramble_bits(w, s, n, out.ctypes.data, 4320)
         assert np.array_equal(out, scramble_bits(w, s, n, 4320))
+
+
+def oracle_ess(pl, pll, pa, pal, threshold=64):
+    o = orc.oracle()
+    o.orc_p25p2_ess.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p]
+    out, ec = np.zeros(96, np.uint8), C.c_int(0)
+    a, b, c, d = (np.ascontiguousarray(x) for x in (pl, pll, pa, pal))
+    acc = o.orc_p25p2_ess(a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, threshold, out.ctypes.data, C.byref(ec))
+    return acc, ec.value, out
+
+
+@needs_ref
+def test_ess_restatement_equals_the_compiled_reference_pieces():
+    r = C.CDLL(orc.REF_SO)
+    r.refh_p25p2_ess.argtypes = [C.c_void_p] * 6
+    rng = np.random.default_rng(67 + FZ)
+    classes = set()
+    for k in range(300):
+        n_err = int(rng.integers(0, 24))
+        pl, pll, pa, pal, sent = rs28.make_ess_case(rng, n_err, int(rng.integers(0, n_err + 1)), int(rng.integers(0, 6)))
+        out, ec = np.zeros(96, np.uint8), C.c_int(0)
+        acc = r.refh_p25p2_ess(pl.ctypes.data, pll.ctypes.data, pa.ctypes.data, pal.ctypes.data, out.ctypes.data, C.byref(ec))
+        got = oracle_ess(pl, pll, pa, pal)
+        assert got[0] == acc and got[1] == ec.value and np.array_equal(got[2], out), (k, n_err, got[:2], acc, ec.value)
+        classes.add((acc, ec.value >= 15 if acc else False))
+        if acc and n_err <= 14:
+            assert np.array_equal(out, sent)
+    assert len(classes) >= 3, classes
+
+
+def test_p25p2_voice_schedule_is_the_measured_ambe_dibit_map():
+    """p25p2_frame.c:250-262 (c0..c3 / csubset: where bit x of a 4V / 2V frame goes) against the AMBE 3600x2450 dibit schedule measured
+    from the compiled reference (include/dsd-neo/core/ambe_interleave.h through tools/gen_tables_ambe.py): the same, read bit by bit"""
+    import rx4
+    c = [[23, 5, 22, 4, 21, 3, 20, 2, 19, 1, 18, 0, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6],
+         [10, 9, 8, 7, 6, 5, 22, 4, 21, 3, 20, 2, 19, 1, 18, 0, 17, 16, 15, 14, 13, 12, 11],
+         [3, 2, 1, 0, 10, 9, 8, 7, 6, 5, 4], [13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0]]
+    cs = [0, 0, 1, 2] * 4 + [0, 0, 1, 3] * 2 + [0, 1, 1, 3] * 5 + [0, 1, 2, 3] * 7
+    its = [iter(x) for x in c]
+    sched = [(w, next(its[w])) for w in cs]
+    m = np.asarray(rx4.ambe2450_map())
+    assert len(sched) == 72 and all(sched[2 * i] == (m[i][0], m[i][1]) and sched[2 * i + 1] == (m[i][2], m[i][3]) for i in range(36))

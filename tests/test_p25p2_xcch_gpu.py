@@ -121,3 +121,50 @@ def test_scramble_sequence_and_descramble(built):
         s = lb[20 + 360 * int(off[i]):20 + 360 * int(off[i]) + nb]
         assert np.array_equal(xb[i].cpu().numpy(), bits[i] ^ s), i
         assert np.array_equal(xl[i].cpu().numpy(), np.where(s[:nl] == 1, -llr[i], llr[i]).astype(np.int16)), i
+
+
+def test_ess_batch_equals_oracle(built):
+    from test_oracle_p25p2_xcch import oracle_ess
+    rng = np.random.default_rng(71 + FZ)
+    n = 1200
+    pl, pll = np.zeros((n, 96), np.uint8), np.zeros((n, 96), np.int16)
+    pa, pal = np.zeros((n, 168), np.uint8), np.zeros((n, 168), np.int16)
+    want = []
+    for i in range(n):
+        n_err = int(rng.integers(0, 26))
+        a, b, c, d, _ = rs28.make_ess_case(rng, n_err, int(rng.integers(0, n_err + 1)), int(rng.integers(0, 8)))
+        if i % 89 == 0:
+            b[:], d[:] = rng.integers(-300, 300, 96), rng.integers(-300, 300, 168)
+        pl[i], pll[i], pa[i], pal[i] = a, b, c, d
+        want.append(oracle_ess(a, b, c, d))
+    out, ec, used = np.zeros((n, 96), np.uint8), np.zeros(n, np.int32), np.zeros(n, np.uint8)
+    assert ddn.lib().ddn_p25p2_ess_host(pl.ctypes.data, pll.ctypes.data, pa.ctypes.data, pal.ctypes.data, n, 64, out.ctypes.data, ec.ctypes.data,
+                                        used.ctypes.data) == 0
+    classes = set()
+    for i, (acc, wec, wout) in enumerate(want):
+        assert (ec[i] >= 0) == bool(acc) and ec[i] == wec and np.array_equal(out[i], wout), (i, ec[i], acc, wec)
+        classes.add((acc, int(used[i])))
+    assert classes == {(1, 0), (1, 1), (0, 0)}, classes
+
+
+def test_voice_frames_unpack(built):
+    import torch
+    import rx4
+    rng = np.random.default_rng(73 + FZ)
+    m = np.asarray(rx4.ambe2450_map())
+    n = 50
+    bits = rng.integers(0, 2, (n, 360)).astype(np.uint8)
+    llr = rng.integers(-400, 400, (n, 360)).astype(np.int16)
+    tb, tl = torch.from_numpy(bits).cuda(), torch.from_numpy(llr).cuda()
+    for fc in (4, 2):
+        fr = torch.full((n, fc, 4, 24), 9, dtype=torch.uint8, device="cuda")
+        rl = torch.full((n, fc, 4, 24), 9, dtype=torch.uint8, device="cuda")
+        assert ddn.lib().ddn_p25p2_voice_frames_batch(tb.data_ptr(), tl.data_ptr(), n, fc, fr.data_ptr(), rl.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        wf, wr = np.zeros((n, fc, 4, 24), np.uint8), np.zeros((n, fc, 4, 24), np.uint8)
+        for f, off in enumerate((2, 76, 172, 246)[:fc]):
+            for x in range(72):
+                row, col = (m[x // 2][0], m[x // 2][1]) if x % 2 == 0 else (m[x // 2][2], m[x // 2][3])
+                wf[:, f, row, col] = bits[:, off + x]
+                wr[:, f, row, col] = np.minimum(np.abs(llr[:, off + x].astype(np.int32)), 255)
+        assert np.array_equal(fr.cpu().numpy(), wf) and np.array_equal(rl.cpu().numpy(), wr), fc
