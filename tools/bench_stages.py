@@ -269,6 +269,25 @@ def main():
     ms = timeit(lambda: l.ddn_fec_isch_lookup_batch(d_w.data_ptr(), None, nw, d_v.data_ptr(), st))
     report("p25p2_isch_lookup", nw, ms, 12, cpu(lambda: [oracle_hard(w) for w in ws], 4096), "words")
 
+    # P25 Phase 2 burst layer: a timeslot's DUID + I-ISCH, its FACCH decode (gather, fixed erasures, ranked retries), the ESS section
+    from test_oracle_p25p2_xcch import oracle_duid, oracle_ess, oracle_xcch
+    nb = 65536
+    bursts = [rs28.make_xcch_burst(rng, 0, int(rng.integers(0, 9)), 3, 2) for _ in range(512)]
+    d_bits = torch.from_numpy(np.tile(np.stack([b[0] for b in bursts]), (nb // 512, 1))).cuda()
+    d_llr = torch.from_numpy(np.tile(np.stack([b[1] for b in bursts]), (nb // 512, 1))).cuda()
+    d_pay, d_ec, d_used = torch.zeros(nb, 156, dtype=torch.uint8, device="cuda"), torch.zeros(nb, dtype=torch.int32, device="cuda"), torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: l.ddn_p25p2_xcch_batch(0, d_bits.data_ptr(), d_llr.data_ptr(), nb, 64, d_pay.data_ptr(), d_ec.data_ptr(), d_used.data_ptr(), st))
+    report("p25p2_facch_burst", nb, ms, 360 * 3 + 156 + 5, cpu(lambda: [oracle_xcch(0, b[0], b[1]) for b in bursts], 512), "bursts")
+    d_du, d_is = torch.zeros(nb, dtype=torch.int32, device="cuda"), torch.zeros(nb, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: l.ddn_p25p2_burst_fields_batch(d_bits.data_ptr(), d_llr.data_ptr(), nb, 64, d_du.data_ptr(), d_is.data_ptr(), st))
+    report("p25p2_duid_isch", nb, ms, 48 * 3 + 8, cpu(lambda: [oracle_duid(0x17, np.minimum(np.abs(b[1][[0, 1, 74, 75, 244, 245, 318, 319]].astype(np.int32)), 255).astype(np.uint8)) for b in bursts], 512), "timeslots")
+    ess = [rs28.make_ess_case(rng, int(rng.integers(0, 18)), 4, 2) for _ in range(512)]
+    t = lambda k, dt: torch.from_numpy(np.tile(np.stack([e[k] for e in ess]).astype(dt), (nb // 512, 1))).cuda()
+    e_pl, e_pll, e_pa, e_pal = t(0, np.uint8), t(1, np.int16), t(2, np.uint8), t(3, np.int16)
+    e_out = torch.zeros(nb, 96, dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: l.ddn_p25p2_ess_batch(e_pl.data_ptr(), e_pll.data_ptr(), e_pa.data_ptr(), e_pal.data_ptr(), nb, 64, e_out.data_ptr(), d_ec.data_ptr(), d_used.data_ptr(), st))
+    report("p25p2_ess", nb, ms, 264 * 3 + 96 + 5, cpu(lambda: [oracle_ess(*e[:4]) for e in ess], 512), "sections")
+
 
 if __name__ == "__main__":
     main()
