@@ -1011,7 +1011,7 @@ ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_re
 __global__ __launch_bounds__(64) void
 k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__ parity_bits,
        const int8_t* __restrict__ erasures, const uint8_t* __restrict__ n_erasures, int n, int32_t* __restrict__ status,
-       int attempt, int n_fixed, uint8_t* __restrict__ used_dynamic) {
+       int attempt, int n_fixed, uint8_t* __restrict__ used_dynamic, int loop_to, int ess_rule) {
     // attempt >= 0 (the Phase 2 burst stage's ranked retries, p25p2_decode_facch_ranked()): this launch decodes with the first
     // n_fixed + attempt erasures of each list - attempt 0 every section, attempt a > 0 only the sections that have failed so far
     // and whose list (n_erasures = its full length) reaches that far; a failed decode leaves the payload as received, so every
@@ -1079,111 +1079,145 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         status[i] = 0;
         return;
     }
-    int n_er = attempt >= 0 ? n_fixed + attempt : (n_erasures ? n_erasures[i] : 0);
-    n_er = n_er > R ? R : n_er;
-    for (int k = 0; k <= R; k++) {
-        La[k][lane] = k == 0 ? 1 : 0;
-    }
-    for (int e = 0; e < n_er; e++) {
-        const int bp = (int)erasures[(size_t)i * R + e] + pad; // block position
-        const int X = ex[(((62 - bp) % 63) + 63) % 63];
-        for (int j = e + 1; j > 0; j--) {
-            La[j][lane] ^= (uint8_t)gmul(La[j - 1][lane], X);
-        }
-    }
-    for (int k = 0; k <= R; k++) {
-        Bp[k][lane] = La[k][lane];
-    }
-    int el = n_er;
-    for (int r = n_er + 1; r <= R; r++) {
-        int d = 0;
-        for (int k = 0; k < r; k++) {
-            d ^= gmul(La[k][lane], Sy[r - k - 1][lane]);
-        }
-        if (d == 0) {
-            for (int k = R; k > 0; k--) {
-                Bp[k][lane] = Bp[k - 1][lane];
-            }
-            Bp[0][lane] = 0;
-            continue;
-        }
-        Tp[0][lane] = La[0][lane];
-        for (int k = 0; k < R; k++) {
-            Tp[k + 1][lane] = La[k + 1][lane] ^ (uint8_t)gmul(d, Bp[k][lane]);
-        }
-        if (2 * el <= r + n_er - 1) {
-            el = r + n_er - el;
-            for (int k = 0; k <= R; k++) {
-                Bp[k][lane] = (uint8_t)gdiv(La[k][lane], d);
-            }
-        } else {
-            for (int k = R; k > 0; k--) {
-                Bp[k][lane] = Bp[k - 1][lane];
-            }
-            Bp[0][lane] = 0;
-        }
-        for (int k = 0; k <= R; k++) {
-            La[k][lane] = Tp[k][lane];
-        }
-    }
-    int deg = 0;
-    for (int k = 0; k <= R; k++) {
-        deg = La[k][lane] ? k : deg;
-    }
-    int count = 0;
-    for (int r = 1; r <= 63 && count < deg; r++) {
-        int q = 1;
-        for (int j = 1; j <= deg; j++) {
-            q ^= gpow(La[j][lane], r * j);
-        }
-        if (q == 0) {
-            Rt[count][lane] = (uint8_t)r;
-            count++;
-        }
-    }
-    if (count != deg || deg == 0) {
-        status[i] = -1;
-        return;
-    }
-    for (int k = 0; k < deg; k++) {
-        int v = 0;
-        for (int j = 0; j <= k; j++) {
-            v ^= gmul(Sy[k - j][lane], La[j][lane]);
-        }
-        Om[k][lane] = (uint8_t)v;
-    }
-    const int top = (deg < R - 1 ? deg : R - 1) & ~1;
-    bool ok = true;
-    for (int j = count - 1; j >= 0 && ok; j--) {
-        const int rt = Rt[j][lane], loc = rt - 1;
-        int num = 0, den = 0;
-        for (int k = 0; k < deg; k++) {
-            num ^= gpow(Om[k][lane], k * rt);
-        }
-        for (int k = top; k >= 0; k -= 2) {
-            den ^= gpow(La[k + 1][lane], k * rt);
-        }
-        if (den == 0 || (num != 0 && loc < pad)) {
-            ok = false;
-        } else if (num != 0) {
-            Cw[loc][lane] ^= (uint8_t)gdiv(num, den);
-        }
-    }
-    if (!ok) {
-        status[i] = -1;
-        return;
-    }
-    for (int k = 0; k < n_data; k++) {
-        const int v = Cw[first + k][lane];
+    // loop_to >= attempt: this thread goes on to the next attempt itself (n_fixed + attempt + 1 erasures, ...) until one decodes,
+    // the list ends or loop_to is reached; ess_rule: a plain decode (attempt 0) that located 15 or more symbols is not taken
+    // (p25p2_ess_decode_with_soft_erasures(), p25p2_frame.c:1063-1066) - the retries start from the received bits
+    const int att_last = loop_to > attempt ? loop_to : attempt;
+    int result = -1;
+    for (int att = attempt;; att++) {
+        if (att > attempt) { // a failed attempt may have touched the block: take it again as received
+            for (int p = 0; p < 63; p++) {
+                int v = 0;
+                const uint8_t* q = nullptr;
+                if (p >= first && p < 35) {
+                    q = pl + 6 * (p - first);
+                } else if (p >= 35 && p < 35 + n_par) {
+                    q = pa + 6 * (p - 35);
+                }
+                if (q) {
 #pragma unroll
-        for (int b = 0; b < 6; b++) {
-            pl[6 * k + b] = (uint8_t)((v >> (5 - b)) & 1);
+                    for (int b = 0; b < 6; b++) {
+                        v = (v << 1) | (q[b] != 0);
+                    }
+                }
+                Cw[p][lane] = (uint8_t)v;
+            }
+        }
+        int n_er = att >= 0 ? n_fixed + att : (n_erasures ? n_erasures[i] : 0);
+        n_er = n_er > R ? R : n_er;
+        result = -1;
+        do {
+            for (int k = 0; k <= R; k++) {
+                La[k][lane] = k == 0 ? 1 : 0;
+            }
+            for (int e = 0; e < n_er; e++) {
+                const int bp = (int)erasures[(size_t)i * R + e] + pad; // block position
+                const int X = ex[(((62 - bp) % 63) + 63) % 63];
+                for (int j = e + 1; j > 0; j--) {
+                    La[j][lane] ^= (uint8_t)gmul(La[j - 1][lane], X);
+                }
+            }
+            for (int k = 0; k <= R; k++) {
+                Bp[k][lane] = La[k][lane];
+            }
+            int el = n_er;
+            for (int r = n_er + 1; r <= R; r++) {
+                int d = 0;
+                for (int k = 0; k < r; k++) {
+                    d ^= gmul(La[k][lane], Sy[r - k - 1][lane]);
+                }
+                if (d == 0) {
+                    for (int k = R; k > 0; k--) {
+                        Bp[k][lane] = Bp[k - 1][lane];
+                    }
+                    Bp[0][lane] = 0;
+                    continue;
+                }
+                Tp[0][lane] = La[0][lane];
+                for (int k = 0; k < R; k++) {
+                    Tp[k + 1][lane] = La[k + 1][lane] ^ (uint8_t)gmul(d, Bp[k][lane]);
+                }
+                if (2 * el <= r + n_er - 1) {
+                    el = r + n_er - el;
+                    for (int k = 0; k <= R; k++) {
+                        Bp[k][lane] = (uint8_t)gdiv(La[k][lane], d);
+                    }
+                } else {
+                    for (int k = R; k > 0; k--) {
+                        Bp[k][lane] = Bp[k - 1][lane];
+                    }
+                    Bp[0][lane] = 0;
+                }
+                for (int k = 0; k <= R; k++) {
+                    La[k][lane] = Tp[k][lane];
+                }
+            }
+            int deg = 0;
+            for (int k = 0; k <= R; k++) {
+                deg = La[k][lane] ? k : deg;
+            }
+            int count = 0;
+            for (int r = 1; r <= 63 && count < deg; r++) {
+                int q = 1;
+                for (int j = 1; j <= deg; j++) {
+                    q ^= gpow(La[j][lane], r * j);
+                }
+                if (q == 0) {
+                    Rt[count][lane] = (uint8_t)r;
+                    count++;
+                }
+            }
+            if (count != deg || deg == 0) {
+                break;
+            }
+            for (int k = 0; k < deg; k++) {
+                int v = 0;
+                for (int j = 0; j <= k; j++) {
+                    v ^= gmul(Sy[k - j][lane], La[j][lane]);
+                }
+                Om[k][lane] = (uint8_t)v;
+            }
+            const int top = (deg < R - 1 ? deg : R - 1) & ~1;
+            bool ok = true;
+            for (int j = count - 1; j >= 0 && ok; j--) {
+                const int rt = Rt[j][lane], loc = rt - 1;
+                int num = 0, den = 0;
+                for (int k = 0; k < deg; k++) {
+                    num ^= gpow(Om[k][lane], k * rt);
+                }
+                for (int k = top; k >= 0; k -= 2) {
+                    den ^= gpow(La[k + 1][lane], k * rt);
+                }
+                if (den == 0 || (num != 0 && loc < pad)) {
+                    ok = false;
+                } else if (num != 0) {
+                    Cw[loc][lane] ^= (uint8_t)gdiv(num, den);
+                }
+            }
+            if (ok) {
+                result = count;
+            }
+        } while (0);
+        const bool rejected = ess_rule && att == 0 && result >= 15;
+        if (result >= 0 && !rejected) {
+            for (int k = 0; k < n_data; k++) {
+                const int v = Cw[first + k][lane];
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    pl[6 * k + b] = (uint8_t)((v >> (5 - b)) & 1);
+                }
+            }
+            if (att > 0 && used_dynamic) {
+                used_dynamic[i] = 1;
+            }
+            break;
+        }
+        result = -1;
+        if (att >= att_last || n_fixed + att + 1 > (n_erasures ? (int)n_erasures[i] : 0)) {
+            break;
         }
     }
-    status[i] = count;
-    if (attempt > 0 && used_dynamic) {
-        used_dynamic[i] = 1;
-    }
+    status[i] = result;
 }
 
 // ---- P25 Phase 2 FACCH / SACCH burst gather + ranked erasure list -----------------------------------------------------------------
@@ -1267,14 +1301,14 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures,
-                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr);
+                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr, -1, 0);
     return hipGetLastError();
 }
 
 // ---- P25 Phase 2 ESS: ranked erasure list and the rule for the plain decode ---------------------------------------------------------
 // p25p2_ess_soft_erasures_ranked() (p25p2_soft.c:331-383) and p25p2_ess_decode_with_soft_erasures() (p25p2_frame.c:1061-1091): the
-// plain decode stands when it located fewer than 15 symbols; otherwise the section goes back to its received bits and is retried
-// with the first 1, 2, ... erasures of the list (k_rs28 in attempt mode, n_fixed = 0).
+// plain decode stands when it located fewer than 15 symbols; otherwise the section is retried from its received bits with the first
+// 1, 2, ... erasures of the list (k_rs28: ess_rule on the plain attempt, then one launch whose threads loop over their retries).
 __global__ void
 k_p2_ess_prepare(const uint8_t* __restrict__ payload_bits, const int16_t* __restrict__ payload_llr, const int16_t* __restrict__ parity_llr,
                  int n, int threshold, uint8_t* __restrict__ work, int8_t* __restrict__ erasures28, uint8_t* __restrict__ n_total,
@@ -1320,20 +1354,6 @@ k_p2_ess_prepare(const uint8_t* __restrict__ payload_bits, const int16_t* __rest
     used_dynamic[i] = 0;
 }
 
-__global__ void
-k_p2_ess_after_plain(const uint8_t* __restrict__ payload_bits, int n, uint8_t* __restrict__ work, int32_t* __restrict__ status) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) {
-        return;
-    }
-    if (status[i] >= 15) { // decoded, but with too many corrections to be believed: back to the received bits, on to the retries
-        for (int k = 0; k < 96; k++) {
-            work[(size_t)i * 96 + k] = payload_bits[(size_t)i * 96 + k] & 1;
-        }
-        status[i] = -1;
-    }
-}
-
 extern "C" hipError_t
 ddn_dev_p25p2_ess(const uint8_t* payload_bits, const int16_t* payload_llr, const uint8_t* parity_bits, const int16_t* parity_llr, int n,
                   int threshold, uint8_t* work, int8_t* erasures28, uint8_t* n_total, int32_t* status, uint8_t* used_dynamic, hipStream_t st) {
@@ -1343,11 +1363,9 @@ ddn_dev_p25p2_ess(const uint8_t* payload_bits, const int16_t* payload_llr, const
     const dim3 grid((unsigned)((n + 63) / 64)), blk(64);
     hipLaunchKernelGGL(k_p2_ess_prepare, grid, blk, 0, st, payload_bits, payload_llr, parity_llr, n, threshold, work, erasures28, n_total,
                        used_dynamic);
-    hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 0, 0, used_dynamic);
-    hipLaunchKernelGGL(k_p2_ess_after_plain, grid, blk, 0, st, payload_bits, n, work, status);
-    for (int attempt = 1; attempt <= 28; attempt++) {
-        hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, attempt, 0, used_dynamic);
-    }
+    // the plain decode for every section (not taken when it located 15 symbols or more), then one launch for the retries
+    hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 0, 0, used_dynamic, -1, 1);
+    hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 1, 0, used_dynamic, 28, 0);
     return hipGetLastError();
 }
 
@@ -1523,10 +1541,12 @@ ddn_dev_p25p2_xcch(int kind, const uint8_t* bits360, const int16_t* llr360, int 
     hipLaunchKernelGGL(k_p2_xcch_gather, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, bits360, llr360, n, threshold,
                        payload_bits, parity_bits, erasures28, n_total, used_dynamic);
     const int n_fixed = kind == 0 ? 18 : 11, max_add = kind == 0 ? 10 : 16;
-    for (int attempt = 0; attempt <= max_add; attempt++) {
-        hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind + 1, payload_bits, parity_bits, erasures28,
-                           n_total, n, status, attempt, n_fixed, used_dynamic);
-    }
+    // the decode with the fixed erasures for every burst, then one launch in which the bursts that failed work through their retries
+    // themselves (most bursts of real traffic never get there: the second launch's threads leave at once)
+    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind + 1, payload_bits, parity_bits, erasures28, n_total, n,
+                       status, 0, n_fixed, used_dynamic, -1, 0);
+    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind + 1, payload_bits, parity_bits, erasures28, n_total, n,
+                       status, 1, n_fixed, used_dynamic, max_add, 0);
     return hipGetLastError();
 }
 
