@@ -5,7 +5,7 @@
 // dmr_data_dispatch_burst() (src/protocol/dmr/dmr_data.c:262-280) lets through - found by the sync search or read inside dmrBS() -
 // leaves a kind-6 event with VC = 0 at the burst's last symbol, carrying the time slot.  This file turns those events into the
 // handler's FEC-level results (src/protocol/dmr/dmr_dburst.c):
-//   k_dmr_data_select    one thread per channel: the dispatched bursts of this call in air order
+//   k_dmr_data_select    one wavefront per channel: the dispatched bursts of this call in air order
 //   k_dmr_data_gather    one workgroup per burst: slot type, the 196 info bits, the 98 info dibits + reliabilities (rel98)
 //   (Golay(20,8), BPTC(196,96), RS(12,9): ddn_fec3.hip)
 //   k_dmr_data_prep      data type, the 12 BPTC bytes, the masked RS(12,9) codeword of a full link control (VLC / TLC)
@@ -33,28 +33,30 @@ __constant__ uint8_t c_crclen[12] = {16, 24, 24, 16, 16, 0, 16, 9, 9, 0, 9, 16};
 // dpre: a burst the sync search found takes its first 90 dibits (and their reliabilities) from the hand-over the loop made at the sync
 // (dmr_data_sync() reads them from the payload / soft history, dmr_data.c:56-100) - the sync's slot in this call's decode list, or
 // n_channels * max_syncs + its index in the list carried to the next call; -1: a burst read inside dmrBS(), all 144 dibits live
-__global__ void
+__global__ __launch_bounds__(64) void
 k_dmr_data_select(const int32_t* __restrict__ events, const int32_t* __restrict__ n_events, int max_events, int carry, int n_channels,
                   int max_bursts, const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_sync, int max_syncs,
                   const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_n, int max_out, const int32_t* __restrict__ n_new,
                   int32_t* __restrict__ dstart, uint8_t* __restrict__ dslot, int32_t* __restrict__ dpre, int32_t* __restrict__ dn) {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= n_channels) {
-        return;
-    }
+    // one wavefront per channel: lane = event of the current chunk of 64, its place in the list = the dispatched events ahead of it
+    const int ch = blockIdx.x, lane = threadIdx.x;
     int n = 0;
     const int ne = n_events[ch] < max_events ? n_events[ch] : max_events;
     const int ns = n_sync[ch] < max_syncs ? n_sync[ch] : max_syncs, no = out_n[ch] < max_out ? out_n[ch] : max_out;
-    for (int i = 0; i < ne; i++) {
-        const int32_t* e = events + ((size_t)ch * max_events + i) * 4;
-        if (e[1] != 6 || (e[3] & 0xFFFF) != 0) {
-            continue;
+    for (int base = 0; base < ne; base += 64) {
+        const int i = base + lane;
+        int4 e = make_int4(0, 0, 0, 0);
+        if (i < ne) {
+            e = *reinterpret_cast<const int4*>(events + ((size_t)ch * max_events + i) * 4);
         }
-        if (n < max_bursts) {
-            dstart[(size_t)ch * max_bursts + n] = carry + e[0] - 143;
-            dslot[(size_t)ch * max_bursts + n] = (uint8_t)((e[3] >> 16) & 1);
+        const bool hit = i < ne && e.y == 6 && (e.w & 0xFFFF) == 0;
+        const unsigned long long m = __ballot(hit);
+        const int k = n + __popcll(m & ((1ull << lane) - 1ull));
+        if (hit && k < max_bursts) {
+            dstart[(size_t)ch * max_bursts + k] = carry + e.x - 143;
+            dslot[(size_t)ch * max_bursts + k] = (uint8_t)((e.w >> 16) & 1);
             int pre = -1;
-            const int want = carry + e[0] - 54;
+            const int want = carry + e.x - 54;
             for (int j = 0; j < ns; j++) {
                 if (sync_pos[(size_t)ch * max_syncs + j] == want) {
                     pre = ch * max_syncs + j;
@@ -65,12 +67,14 @@ k_dmr_data_select(const int32_t* __restrict__ events, const int32_t* __restrict_
                     pre = n_channels * max_syncs + ch * max_out + j;
                 }
             }
-            dpre[(size_t)ch * max_bursts + n] = pre;
+            dpre[(size_t)ch * max_bursts + k] = pre;
         }
-        n++;
+        n += __popcll(m);
     }
-    dn[ch] = n < max_bursts ? n : max_bursts;
-    for (int k = n; k < max_bursts; k++) {
+    if (lane == 0) {
+        dn[ch] = n < max_bursts ? n : max_bursts;
+    }
+    for (int k = n + lane; k < max_bursts; k += 64) {
         dstart[(size_t)ch * max_bursts + k] = -1;
         dslot[(size_t)ch * max_bursts + k] = 0xFF;
         dpre[(size_t)ch * max_bursts + k] = -1;
@@ -330,7 +334,7 @@ ddn_dev_dmr_data_select(const int32_t* events, const int32_t* n_events, int max_
     if (n_channels <= 0 || max_bursts <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_dmr_data_select, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, events, n_events, max_events, carry,
+    hipLaunchKernelGGL(k_dmr_data_select, dim3((unsigned)n_channels), dim3(64), 0, st, events, n_events, max_events, carry,
                        n_channels, max_bursts, sync_pos, n_sync, max_syncs, out_pos, out_n, max_out, n_new, dstart, dslot, dpre, dn);
     return hipGetLastError();
 }
