@@ -697,6 +697,33 @@ ddn_p25p2_xcch_batch(int kind, const uint8_t* d_bits360, const int16_t* d_llr360
     return DDN_OK;
 }
 
+extern "C" int
+ddn_p25p2_mac_crc_batch(int kind, const uint8_t* d_payload_bits, size_t n, uint8_t* d_crc12_ok, uint8_t* d_crc16_ok, void* hip_stream) {
+    if ((kind != 0 && kind != 1) || !d_payload_bits || !d_crc12_ok) {
+        ddn_set_error("ddn_p25p2_mac_crc_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_p25p2_mac_crc(kind, d_payload_bits, (int)n, d_crc12_ok, d_crc16_ok, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p2_mac_crc_host(int kind, const uint8_t* payload_bits, size_t n, uint8_t* crc12_ok, uint8_t* crc16_ok) {
+    if ((kind != 0 && kind != 1) || !payload_bits || !crc12_ok) {
+        return DDN_EINVAL;
+    }
+    const size_t n_pl = kind == 0 ? 156 : 180;
+    Dev a(n * n_pl), b(n), c(n);
+    if (!a.p || !b.p || !c.p || a.up(payload_bits)) {
+        return no_dev();
+    }
+    const int rc = ddn_p25p2_mac_crc_batch(kind, (const uint8_t*)a.p, n, (uint8_t*)b.p, crc16_ok ? (uint8_t*)c.p : nullptr, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    return (b.down(crc12_ok) || (crc16_ok && c.down(crc16_ok))) ? no_dev() : DDN_OK;
+}
+
 // P25 Phase 2 ESS and voice bursts (include/ddn_hip.h)
 extern "C" int
 ddn_p25p2_ess_batch(const uint8_t* d_payload_bits96, const int16_t* d_payload_llr96, const uint8_t* d_parity_bits168,

@@ -221,6 +221,7 @@ hipError_t ddn_dev_golay24_soft(uint8_t* data, const uint8_t* parity, const int3
 hipError_t ddn_dev_hamming_10_6_3_soft(const uint8_t* bits, const int32_t* reliab, int n, uint8_t* out, uint8_t* status,
                                        hipStream_t st);
 hipError_t ddn_dev_isch_lookup(const uint64_t* words, const uint8_t* reliab40, int n, int32_t* out, hipStream_t st);
+hipError_t ddn_dev_p25p2_mac_crc(int kind, const uint8_t* payload_bits, int n, uint8_t* crc12_ok, uint8_t* crc16_ok, hipStream_t st);
 hipError_t ddn_dev_p25p2_ess(const uint8_t* payload_bits, const int16_t* payload_llr, const uint8_t* parity_bits, const int16_t* parity_llr,
                              int n, int threshold, uint8_t* work, int8_t* erasures28, uint8_t* n_total, int32_t* status,
                              uint8_t* used_dynamic, hipStream_t st);

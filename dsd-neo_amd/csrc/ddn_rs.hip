@@ -1305,6 +1305,54 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
     return hipGetLastError();
 }
 
+// ---- P25 Phase 2 MAC PDU checksums ------------------------------------------------------------------------------------------------------
+// p25p2_xcch_validate_facch_crc() / _sacch_crc() (src/protocol/p25/phase2/p25p2_xcch.c:444-497): CRC12 over the section's payload less
+// its last 12 bits (crc12_xb_bridge(), src/protocol/p25/p25_crc.c:78-147: x^12 + x^11 + x^7 + x^4 + x^2 + x + 1, remainder inverted),
+// and for a SACCH on a control channel (LCCH) CRC-CCITT16 over the first 164 bits (crc16_lb_bridge(), :17-75).  One burst per thread.
+__global__ void
+k_p2_mac_crc(int kind, const uint8_t* __restrict__ payload_bits, int n, uint8_t* __restrict__ crc12_ok, uint8_t* __restrict__ crc16_ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const int n_pl = kind == 0 ? 156 : 180, len = n_pl - 12;
+    const uint8_t* b = payload_bits + (size_t)i * n_pl;
+    uint32_t reg = 0; // the long division: 13-bit register, the polynomial's bits 1 1000 1001 0111
+    for (int k = 0; k < len + 12; k++) {
+        reg = (reg << 1) | (k < len ? (uint32_t)(b[k] & 1) : 0u);
+        if (reg & 0x1000u) {
+            reg ^= 0x1897u;
+        }
+    }
+    uint32_t got = 0;
+    for (int k = 0; k < 12; k++) {
+        got = (got << 1) | (uint32_t)(b[len + k] & 1);
+    }
+    crc12_ok[i] = ((reg ^ 0xFFFu) & 0xFFFu) == got ? 1 : 0;
+    if (crc16_ok) {
+        uint32_t c = 0, g16 = 0;
+        if (kind == 1) {
+            for (int k = 0; k < 164; k++) {
+                c = ((((c >> 15) & 1u) ^ (uint32_t)(b[k] & 1)) ? ((c << 1) ^ 0x1021u) : (c << 1)) & 0xFFFFu;
+            }
+            c ^= 0xFFFFu;
+            for (int k = 0; k < 16; k++) {
+                g16 = (g16 << 1) | (uint32_t)(b[164 + k] & 1);
+            }
+        }
+        crc16_ok[i] = (kind == 1 && c == g16) ? 1 : 0;
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_p25p2_mac_crc(int kind, const uint8_t* payload_bits, int n, uint8_t* crc12_ok, uint8_t* crc16_ok, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p2_mac_crc, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, kind, payload_bits, n, crc12_ok, crc16_ok);
+    return hipGetLastError();
+}
+
 // ---- P25 Phase 2 ESS: ranked erasure list and the rule for the plain decode ---------------------------------------------------------
 // p25p2_ess_soft_erasures_ranked() (p25p2_soft.c:331-383) and p25p2_ess_decode_with_soft_erasures() (p25p2_frame.c:1061-1091): the
 // plain decode stands when it located fewer than 15 symbols; otherwise the section is retried from its received bits with the first

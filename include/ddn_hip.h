@@ -671,6 +671,11 @@ int ddn_fec_rs28_host(int kind, uint8_t* payload_bits, const uint8_t* parity_bit
  * threshold = p25p2_soft_erasure_threshold(), 64 unless configured).  d_bits360 u8 [n][360] one bit per byte, d_llr360 i16 [n][360]
  * (p2llr / p2xllr), d_payload_bits u8 [n][156 | 180] (corrected, or as received when ec < 0), d_ec i32 [n] = the reference's ec,
  * d_used_dynamic u8 [n] = its used_dynamic_erasure. */
+/* the decoded section's MAC PDU checksums == p25p2_xcch_validate_facch_crc() / _sacch_crc() (src/protocol/p25/phase2/p25p2_xcch.c:444-497):
+ * d_crc12_ok u8 [n] = crc12_xb_bridge(payload, 156 - 12 | 180 - 12) == 0; d_crc16_ok (optional; SACCH on a control channel, LCCH)
+ * = crc16_lb_bridge(payload, 164) == 0 (src/protocol/p25/p25_crc.c:17-147); d_payload_bits as ddn_p25p2_xcch_batch writes them */
+int ddn_p25p2_mac_crc_batch(int kind, const uint8_t* d_payload_bits, size_t n, uint8_t* d_crc12_ok, uint8_t* d_crc16_ok, void* hip_stream);
+int ddn_p25p2_mac_crc_host(int kind, const uint8_t* payload_bits, size_t n, uint8_t* crc12_ok, uint8_t* crc16_ok);
 /* P25 Phase 2 ESS == p25p2_ess_decode_with_soft_erasures() (src/protocol/p25/phase2/p25p2_frame.c:1061-1091): payload = the four ESS-B
  * fragments (96 bits, 24 from bit 148 of each 4V burst: p25p2_collect_ess_b_fragment(), :902-915), parity = ESS-A (96 bits from bit
  * 148 + 72 from bit 246 of the 2V burst: p25p2_collect_ess_a(), :1399-1411), with their soft metrics (p2xllr).  The plain RS(44,16)

@@ -173,3 +173,58 @@ def test_p25p2_voice_schedule_is_the_measured_ambe_dibit_map():
     sched = [(w, next(its[w])) for w in cs]
     m = np.asarray(rx4.ambe2450_map())
     assert len(sched) == 72 and all(sched[2 * i] == (m[i][0], m[i][1]) and sched[2 * i + 1] == (m[i][2], m[i][3]) for i in range(36))
+
+
+def crc12_ok(bits, length):
+    """crc12_xb_bridge(payload, length) == 0 (src/protocol/p25/p25_crc.c:78-147)"""
+    reg = 0
+    for k in range(length + 12):
+        reg = (reg << 1) | (int(bits[k]) & 1 if k < length else 0)
+        if reg & 0x1000:
+            reg ^= 0x1897
+    got = 0
+    for k in range(12):
+        got = (got << 1) | (int(bits[length + k]) & 1)
+    return int(((reg ^ 0xFFF) & 0xFFF) == got)
+
+
+def crc16_ok(bits, length=164):
+    c = 0
+    for k in range(length):
+        c = (((c << 1) ^ 0x1021) if (((c >> 15) & 1) ^ (int(bits[k]) & 1)) else (c << 1)) & 0xFFFF
+    c ^= 0xFFFF
+    got = 0
+    for k in range(16):
+        got = (got << 1) | (int(bits[length + k]) & 1)
+    return int(c == got)
+
+
+def with_crc12(rng, n_pl):
+    """random MAC PDU bits with a good CRC12 in the last 12"""
+    b = rng.integers(0, 2, n_pl).astype(np.uint8)
+    reg = 0
+    for k in range(n_pl):
+        reg = (reg << 1) | (int(b[k]) if k < n_pl - 12 else 0)
+        if reg & 0x1000:
+            reg ^= 0x1897
+    v = (reg ^ 0xFFF) & 0xFFF
+    b[n_pl - 12:] = [(v >> (11 - k)) & 1 for k in range(12)]
+    assert crc12_ok(b, n_pl - 12)
+    return b
+
+
+@needs_ref
+def test_mac_crcs_equal_the_reference():
+    r = C.CDLL(orc.REF_SO)
+    r.crc12_xb_bridge.argtypes = [C.c_void_p, C.c_int]
+    r.crc16_lb_bridge.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(79 + FZ)
+    for k in range(60):
+        n_pl = 156 if k & 1 else 180
+        b = with_crc12(rng, n_pl) if k % 3 else rng.integers(0, 2, n_pl).astype(np.uint8)
+        if k % 7 == 3:
+            b[int(rng.integers(0, n_pl))] ^= 1
+        ib = b.astype(np.int32)
+        assert crc12_ok(b, n_pl - 12) == int(r.crc12_xb_bridge(ib.ctypes.data, n_pl - 12) == 0), k
+        if n_pl == 180:
+            assert crc16_ok(b) == int(r.crc16_lb_bridge(ib.ctypes.data, 164) == 0), k

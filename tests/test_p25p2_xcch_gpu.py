@@ -168,3 +168,30 @@ def test_voice_frames_unpack(built):
                 wf[:, f, row, col] = bits[:, off + x]
                 wr[:, f, row, col] = np.minimum(np.abs(llr[:, off + x].astype(np.int32)), 255)
         assert np.array_equal(fr.cpu().numpy(), wf) and np.array_equal(rl.cpu().numpy(), wr), fc
+
+
+def test_mac_crc_batch(built):
+    from test_oracle_p25p2_xcch import crc12_ok, crc16_ok, with_crc12
+    rng = np.random.default_rng(83 + FZ)
+    for kind, n_pl in ((0, 156), (1, 180)):
+        n = 300
+        rows = np.zeros((n, n_pl), np.uint8)
+        for i in range(n):
+            rows[i] = with_crc12(rng, n_pl) if i % 3 else rng.integers(0, 2, n_pl)
+            if i % 5 == 2:
+                rows[i, int(rng.integers(0, n_pl))] ^= 1
+            if kind == 1 and i % 4 == 1:          # a good CRC16 over the first 164 bits (LCCH)
+                c = 0
+                for k in range(164):
+                    c = (((c << 1) ^ 0x1021) if (((c >> 15) & 1) ^ int(rows[i, k])) else (c << 1)) & 0xFFFF
+                c ^= 0xFFFF
+                rows[i, 164:180] = [(c >> (15 - k)) & 1 for k in range(16)]
+        a, b = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        assert ddn.lib().ddn_p25p2_mac_crc_host(kind, rows.ctypes.data, n, a.ctypes.data, b.ctypes.data) == 0
+        w12 = [crc12_ok(rows[i], n_pl - 12) for i in range(n)]
+        assert a.tolist() == w12 and 0 < sum(w12) < n
+        if kind == 1:
+            w16 = [crc16_ok(rows[i]) for i in range(n)]
+            assert b.tolist() == w16 and sum(w16) >= 50
+        else:
+            assert not b.any()
