@@ -195,3 +195,45 @@ def test_mac_crc_batch(built):
             assert b.tolist() == w16 and sum(w16) >= 50
         else:
             assert not b.any()
+
+
+def test_the_reference_capture_through_the_burst_layer(built):
+    """the reference's own Phase 2 capture (tests/p2capture.py) through the C-ABI: DUID and I-ISCH of all 66 timeslots, the scrambler
+    sequence of the system, de-scrambling at the superframe slot the I-ISCH names, SACCH RS(63,35) and the MAC CRC-12 - equal to the
+    CPU restatement on every timeslot, and the ten SACCH bursts give the known MAC PDUs (tests/test_oracle_p25p2_capture.py)"""
+    import torch
+    import p2capture
+    from test_oracle_p25p2_capture import SACCH_OCTETS, expected_isch
+    from test_oracle_p25p2_xcch import crc12_ok
+    l = ddn.lib()
+    bits, llr, sf, _ = p2capture.timeslots()
+    n = len(bits)
+    duid, isch = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    assert l.ddn_p25p2_burst_fields_host(bits.ctypes.data, llr.ctypes.data, n, 64, duid.ctypes.data, isch.ctypes.data) == 0
+    assert [int(v) for v in isch] == [expected_isch(i) for i in range(n)]
+    assert [int(v) for v in duid] == [3 if s >= 10 else 10 for s in sf]
+    seed = torch.tensor([p2capture.WACN * 16777216 + p2capture.SYSID * 4096 + p2capture.NAC], dtype=torch.int64, device="cuda")
+    seq = torch.zeros((1, 4320), dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p2_scramble_bits_batch(seed.data_ptr(), 1, 4320, seq.data_ptr(), None) == 0
+    tb, tl = torch.from_numpy(bits).cuda(), torch.from_numpy(llr).cuda()
+    to, tw = torch.from_numpy(sf).cuda(), torch.zeros(n, dtype=torch.int32, device="cuda")
+    xb, xl = torch.zeros_like(tb), torch.zeros_like(tl)
+    assert l.ddn_p25p2_descramble_batch(tb.data_ptr(), tl.data_ptr(), seq.data_ptr(), to.data_ptr(), tw.data_ptr(), n, 360, 360, xb.data_ptr(),
+                                        xl.data_ptr(), None) == 0
+    pl = torch.zeros((n, 180), dtype=torch.uint8, device="cuda")
+    ec = torch.zeros(n, dtype=torch.int32, device="cuda")
+    used = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    c12 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert l.ddn_p25p2_xcch_batch(1, xb.data_ptr(), xl.data_ptr(), n, 64, pl.data_ptr(), ec.data_ptr(), used.data_ptr(), None) == 0
+    assert l.ddn_p25p2_mac_crc_batch(1, pl.data_ptr(), n, c12.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    xbn, xln, pln, ecn, usedn, c12n = xb.cpu().numpy(), xl.cpu().numpy(), pl.cpu().numpy(), ec.cpu().numpy(), used.cpu().numpy(), c12.cpu().numpy()
+    got = []
+    for i in range(n):
+        wec, wpl, wused = oracle_xcch(1, xbn[i], xln[i])
+        assert ecn[i] == wec and usedn[i] == wused and np.array_equal(pln[i], wpl), (i, ecn[i], wec)
+        assert c12n[i] == crc12_ok(wpl, 168), i
+        if sf[i] >= 10:
+            assert ecn[i] == 11 and c12n[i] == 1, (i, ecn[i], c12n[i])
+            got.append(bytes(np.packbits(pln[i])[:12]).hex())
+    assert got == SACCH_OCTETS
