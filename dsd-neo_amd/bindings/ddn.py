@@ -515,6 +515,8 @@ PROTOTYPES.update({
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "p25p2_generate_scramble_bits": (None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]),
     "ddn_p25p2_burst_fields_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_groups_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_burst_fields_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_xcch_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_xcch_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -955,3 +957,42 @@ class CqpskBatch:
             lib().ddn_cqpsk_batch_destroy(self.h)
         except Exception:
             pass
+
+
+P25P2_SEQ_STATE_BYTES = 592   # sizeof(ddn_p25p2_seq_state): offset, fourv[2], reserved, ess_b u8 [2][96], ess_b_llr i16 [2][96]
+
+
+class P25P2Groups:
+    """ddn_p25p2_groups_batch with its carried per-channel state on the device (torch tensors for memory only):
+    run(bits u8 [C][G][1400], llr i16 [C][G][1400]) -> (info i32 [C][G][4][8], payload u8 [..][180], ambe_fr, ambe_rel u8 [..][4][4][24],
+    ess u8 [..][96]) as numpy arrays"""
+
+    def __init__(self, seeds44, threshold=64):
+        import torch
+        self.torch = torch
+        self.C = len(seeds44)
+        self.seed = torch.tensor([int(v) for v in seeds44], dtype=torch.int64, device="cuda")
+        self.state = torch.zeros((self.C, P25P2_SEQ_STATE_BYTES), dtype=torch.uint8, device="cuda")
+        self.threshold = threshold
+
+    def run(self, bits, llr):
+        import numpy as np
+        torch = self.torch
+        Cn, G = bits.shape[0], bits.shape[1]
+        assert Cn == self.C and bits.shape == llr.shape == (Cn, G, 1400)
+        tb = torch.from_numpy(np.ascontiguousarray(bits, np.uint8)).cuda()
+        tl = torch.from_numpy(np.ascontiguousarray(llr, np.int16)).cuda()
+        n = Cn * G * 4
+        info = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+        pay = torch.zeros((n, 180), dtype=torch.uint8, device="cuda")
+        fr = torch.zeros((n, 4, 4, 24), dtype=torch.uint8, device="cuda")
+        rel = torch.zeros((n, 4, 4, 24), dtype=torch.uint8, device="cuda")
+        ess = torch.zeros((n, 96), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        _check(lib().ddn_p25p2_groups_batch(tb.data_ptr(), tl.data_ptr(), Cn, G, self.seed.data_ptr(), self.state.data_ptr(), self.threshold,
+                                            info.data_ptr(), pay.data_ptr(), fr.data_ptr(), rel.data_ptr(), ess.data_ptr(), st),
+               "ddn_p25p2_groups_batch")
+        torch.cuda.synchronize()
+        shp = (Cn, G, 4)
+        return (info.cpu().numpy().reshape(shp + (8,)), pay.cpu().numpy().reshape(shp + (180,)), fr.cpu().numpy().reshape(shp + (4, 4, 24)),
+                rel.cpu().numpy().reshape(shp + (4, 4, 24)), ess.cpu().numpy().reshape(shp + (96,)))

@@ -1,0 +1,159 @@
+// ddn_api_p25p2.cpp - C-ABI of the P25 Phase 2 sequencing stage (include/ddn_hip.h: ddn_p25p2_groups_batch): processP2()'s work on
+// the 700 dibits behind a sync, batched.  The stage strings the burst layer's own batched calls (ddn_api_fec.cpp) behind the
+// sequencing pass of ddn_p25p2_seq.hip; nothing here computes on the CPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ddn_device.h"
+#include "ddn_p25p2_seq.h"
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            ddn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);                  \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorNoBinaryForGpu)             \
+                       ? DDN_ENODEV                                                                                    \
+                       : (e_ == hipErrorOutOfMemory ? DDN_ENOMEM : DDN_EHIP);                                          \
+        }                                                                                                              \
+    } while (0)
+#define DDN_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        const int r_ = (expr);                                                                                         \
+        if (r_ != DDN_OK) {                                                                                            \
+            return r_;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
+
+namespace {
+// stream-ordered scratch, released when the call leaves (also on its error paths)
+struct Scratch {
+    hipStream_t st;
+    void* p[64];
+    int n = 0;
+    explicit Scratch(hipStream_t s) : st(s) {}
+    ~Scratch() {
+        for (int i = 0; i < n; i++) {
+            (void)hipFreeAsync(p[i], st);
+        }
+    }
+    template <class T>
+    hipError_t get(T** out, size_t count) {
+        void* q = nullptr;
+        const hipError_t e = hipMallocAsync(&q, (count ? count : 1) * sizeof(T), st);
+        if (e == hipSuccess) {
+            p[n++] = q;
+        }
+        *out = (T*)q;
+        return e;
+    }
+};
+} // namespace
+
+extern "C" int
+ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int n_channels, int n_groups, const uint64_t* d_seed44,
+                       ddn_p25p2_seq_state* d_state, int threshold, int32_t* d_info, uint8_t* d_payload, uint8_t* d_ambe_fr,
+                       uint8_t* d_ambe_rel, uint8_t* d_ess, void* hip_stream) {
+    if (!d_bits1400 || !d_llr1400 || !d_seed44 || !d_state || !d_info || !d_payload || !d_ambe_fr || !d_ambe_rel || !d_ess || n_channels < 0
+        || n_groups < 0 || (size_t)n_channels * (size_t)n_groups * 4 > 0x7fffffffu / 360) {
+        ddn_set_error("ddn_p25p2_groups_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    if (n_channels == 0 || n_groups == 0) {
+        return DDN_OK;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t n_gr = (size_t)n_channels * n_groups, n_rows = n_gr * 4;
+    Scratch s(st);
+    uint8_t *rb, *xb, *seq;
+    int16_t *rl, *xl;
+    int32_t *duid, *isch, *row_off, *counts, *list, *ess_src, *final_src, *seq_of;
+    HIP_TRY(s.get(&rb, n_rows * 360));
+    HIP_TRY(s.get(&rl, n_rows * 360));
+    HIP_TRY(s.get(&xb, n_rows * 360));
+    HIP_TRY(s.get(&xl, n_rows * 360));
+    HIP_TRY(s.get(&seq, (size_t)n_channels * 4320));
+    HIP_TRY(s.get(&duid, n_rows));
+    HIP_TRY(s.get(&isch, n_rows));
+    HIP_TRY(s.get(&row_off, n_rows));
+    HIP_TRY(s.get(&counts, 4));
+    HIP_TRY(s.get(&list, 4 * n_rows));
+    HIP_TRY(s.get(&ess_src, n_rows * 4));
+    HIP_TRY(s.get(&final_src, (size_t)n_channels * 8));
+    HIP_TRY(s.get(&seq_of, n_rows));
+    HIP_TRY(hipMemsetAsync(counts, 0, 16, st));
+    // timeslot rows, their DUID / I-ISCH, the channels' scrambler sequences
+    HIP_TRY(ddn_dev_p2_rows(d_bits1400, d_llr1400, n_gr, rb, rl, st));
+    DDN_TRY(ddn_p25p2_burst_fields_batch(rb, rl, n_rows, threshold, duid, isch, st));
+    DDN_TRY(ddn_p25p2_scramble_bits_batch(d_seed44, (size_t)n_channels, 4320, seq, st));
+    // the sequencing pass: offsets, logical channels, actions, decoder lists
+    HIP_TRY(ddn_dev_p2_sequence(duid, isch, n_channels, n_groups, d_seed44, d_state, d_info, row_off, seq_of, counts, list, ess_src, final_src,
+                                st));
+    int32_t h_counts[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, st));
+    DDN_TRY(ddn_p25p2_descramble_batch(rb, rl, seq, row_off, seq_of, n_rows, 360, 360, xb, xl, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int n_f = h_counts[0], n_s = h_counts[1], n_4v = h_counts[2], n_2v = h_counts[3];
+    const int rows_per_channel = n_groups * 4;
+    // FACCH (class 0) and SACCH / LCCH (class 1) bursts
+    for (int cls = 0; cls < 2; cls++) {
+        const int cnt = cls == 0 ? n_f : n_s;
+        if (cnt == 0) {
+            continue;
+        }
+        const int n_pl = cls == 0 ? 156 : 180;
+        uint8_t *db, *pl, *used, *c12, *c16;
+        int16_t* dl;
+        int32_t* ec;
+        HIP_TRY(s.get(&db, (size_t)cnt * 360));
+        HIP_TRY(s.get(&dl, (size_t)cnt * 360));
+        HIP_TRY(s.get(&pl, (size_t)cnt * n_pl));
+        HIP_TRY(s.get(&used, (size_t)cnt));
+        HIP_TRY(s.get(&c12, (size_t)cnt));
+        HIP_TRY(s.get(&c16, (size_t)cnt));
+        HIP_TRY(s.get(&ec, (size_t)cnt));
+        const int32_t* lst = list + (size_t)cls * n_rows;
+        HIP_TRY(ddn_dev_p2_gather(cls, cnt, lst, d_info, rb, rl, xb, xl, db, dl, ess_src, d_state, rows_per_channel, nullptr, nullptr, nullptr,
+                                  nullptr, st));
+        DDN_TRY(ddn_p25p2_xcch_batch(cls, db, dl, (size_t)cnt, threshold, pl, ec, used, st));
+        DDN_TRY(ddn_p25p2_mac_crc_batch(cls, pl, (size_t)cnt, c12, cls == 1 ? c16 : nullptr, st));
+        HIP_TRY(ddn_dev_p2_scatter(cls, cnt, lst, d_info, pl, n_pl, ec, used, c12, cls == 1 ? c16 : nullptr, nullptr, nullptr, 0, nullptr, d_payload,
+                                   d_ambe_fr, d_ambe_rel, d_ess, st));
+    }
+    // 4V (class 2) and 2V (class 3) bursts; the 2V bursts' ESS
+    for (int cls = 2; cls < 4; cls++) {
+        const int cnt = cls == 2 ? n_4v : n_2v;
+        if (cnt == 0) {
+            continue;
+        }
+        const int fc = cls == 2 ? 4 : 2;
+        uint8_t *db, *fr, *rel, *e_pl = nullptr, *e_pa = nullptr, *e_out = nullptr, *e_used = nullptr;
+        int16_t *dl, *e_pll = nullptr, *e_pal = nullptr;
+        int32_t* e_ec = nullptr;
+        HIP_TRY(s.get(&db, (size_t)cnt * 360));
+        HIP_TRY(s.get(&dl, (size_t)cnt * 360));
+        HIP_TRY(s.get(&fr, (size_t)cnt * fc * 96));
+        HIP_TRY(s.get(&rel, (size_t)cnt * fc * 96));
+        if (cls == 3) {
+            HIP_TRY(s.get(&e_pl, (size_t)cnt * 96));
+            HIP_TRY(s.get(&e_pll, (size_t)cnt * 96));
+            HIP_TRY(s.get(&e_pa, (size_t)cnt * 168));
+            HIP_TRY(s.get(&e_pal, (size_t)cnt * 168));
+            HIP_TRY(s.get(&e_out, (size_t)cnt * 96));
+            HIP_TRY(s.get(&e_used, (size_t)cnt));
+            HIP_TRY(s.get(&e_ec, (size_t)cnt));
+        }
+        const int32_t* lst = list + (size_t)cls * n_rows;
+        HIP_TRY(ddn_dev_p2_gather(cls, cnt, lst, d_info, rb, rl, xb, xl, db, dl, ess_src, d_state, rows_per_channel, e_pl, e_pll, e_pa, e_pal, st));
+        DDN_TRY(ddn_p25p2_voice_frames_batch(db, dl, (size_t)cnt, fc, fr, rel, st));
+        if (cls == 3) {
+            DDN_TRY(ddn_p25p2_ess_batch(e_pl, e_pll, e_pa, e_pal, (size_t)cnt, threshold, e_out, e_ec, e_used, st));
+        }
+        HIP_TRY(ddn_dev_p2_scatter(cls, cnt, lst, d_info, nullptr, 0, e_ec, e_used, nullptr, nullptr, fr, rel, fc, e_out, d_payload, d_ambe_fr,
+                                   d_ambe_rel, d_ess, st));
+    }
+    // the carried ESS-B fragments (after every gather that still reads the old ones)
+    HIP_TRY(ddn_dev_p2_state_ess(final_src, xb, xl, n_channels, d_state, st));
+    return DDN_OK;
+}

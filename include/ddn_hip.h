@@ -712,6 +712,38 @@ int ddn_p25p2_xcch_batch(int kind, const uint8_t* d_bits360, const int16_t* d_ll
                          int32_t* d_ec, uint8_t* d_used_dynamic, void* hip_stream);
 int ddn_p25p2_xcch_host(int kind, const uint8_t* bits360, const int16_t* llr360, size_t n, int threshold, uint8_t* payload_bits,
                         int32_t* ec, uint8_t* used_dynamic);
+/* P25 Phase 2 above the bursts == processP2() on the 700 dibits behind a sync (src/protocol/p25/phase2/p25p2_frame.c:1760-1798),
+ * batched over channels x groups.  A group = 1400 bits + metrics as p2_dibit_buffer() leaves them in p2bit / p2llr (:354-370; the
+ * fourth timeslot's ISCH is not captured: zeros, reliability 0).  Per group: the four ISCH words move the channel's
+ * p2_scramble_offset when one is a channel-1 I-ISCH (p25p2_process_isch(), :708-745), the first timeslot's logical channel is
+ * offset % 2, the bits are de-scrambled at offset (process_Frame_Scramble(), :372-392), and each timeslot's DUID is dispatched
+ * (p25p2_process_duid(), :1742-1760; p25p2_duid_dispatch(), :1580-1640): 4V / 2V voice (frames unpacked, ESS-B fragment filed under
+ * the slot's fourv_counter, ESS decoded at the 2V burst, :902-925,1377-1452), SACCH / FACCH / LCCH clear or scrambled (RS(63,35) with
+ * the ranked retries, MAC CRC-12 / LCCH CRC-16), bursts that need a valid site skipped without one (:1455-1459), an unknown DUID
+ * counted - the second one ends the group and zeroes both 4V counters (:1642-1655).
+ * Carried per channel across calls: ddn_p25p2_seq_state (all zeros = a fresh channel, p25_p2_frame_reset()).
+ * d_bits1400 u8 / d_llr1400 i16 [n_channels][n_groups][1400]; d_seed44 u64 [n_channels] = wacn << 24 | sysid << 12 | cc.
+ * Results per timeslot row r = (channel * n_groups + group) * 4 + ts:
+ *   d_info i32 [rows][8] = { duid (-1 rejected, -3 not reached), isch (7-bit value, -2 none), scramble offset of the group, logical
+ *                            channel 0 / 1 (-1 not reached), DDN_P2_* action, ec (RS return value of the burst / of the ESS),
+ *                            fourv_counter the burst met, flags: 1 used_dynamic_erasure | 2 CRC-12 good | 4 CRC-16 good | 8 ESS accepted }
+ *   d_payload u8 [rows][180]        the MAC PDU bits of a FACCH (156) / SACCH / LCCH (180) burst, corrected or as received
+ *   d_ambe_fr / d_ambe_rel u8 [rows][4][4][24]   the 4 (4V) or 2 (2V) AMBE 3600x2450 frames = ddn_mbe_frame_decode_batch() input
+ *   d_ess u8 [rows][96]             the ESS payload a 2V burst decoded (corrected when accepted)
+ * Rows a decoder did not write keep what the caller put there (clear them once).  The call waits for the sequencing pass (one
+ * hipStreamSynchronize on hip_stream: the decoders are launched over exact counts). */
+enum { DDN_P2_NONE = 0, DDN_P2_4V, DDN_P2_2V, DDN_P2_SACCH_S, DDN_P2_SACCH_C, DDN_P2_FACCH_C, DDN_P2_FACCH_S, DDN_P2_LCCH_C, DDN_P2_LCCH_S,
+       DDN_P2_ERR, DDN_P2_NOSITE };
+typedef struct ddn_p25p2_seq_state {
+    int32_t offset;        /* state->p2_scramble_offset */
+    int32_t fourv[2];      /* state->fourv_counter */
+    int32_t reserved;
+    uint8_t ess_b[2][96];  /* state->ess_b / ess_b_llr */
+    int16_t ess_b_llr[2][96];
+} ddn_p25p2_seq_state;
+int ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int n_channels, int n_groups, const uint64_t* d_seed44,
+                           ddn_p25p2_seq_state* d_state, int threshold, int32_t* d_info, uint8_t* d_payload, uint8_t* d_ambe_fr,
+                           uint8_t* d_ambe_rel, uint8_t* d_ess, void* hip_stream);
 int ez_rs28_ess(int payload[96], int parity[168], const int* erasures, int n_erasures);
 int ez_rs28_facch(int payload[156], int parity[114], const int* erasures, int n_erasures);
 int ez_rs28_sacch(int payload[180], int parity[132], const int* erasures, int n_erasures);
