@@ -515,8 +515,10 @@ PROTOTYPES.update({
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "p25p2_generate_scramble_bits": (None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]),
     "ddn_p25p2_burst_fields_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ddn_p25p2_groups_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_groups_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_sync_cut_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_burst_fields_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_xcch_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_xcch_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -975,13 +977,34 @@ class P25P2Groups:
         self.state = torch.zeros((self.C, P25P2_SEQ_STATE_BYTES), dtype=torch.uint8, device="cuda")
         self.threshold = threshold
 
-    def run(self, bits, llr):
+    def run_stream(self, dibits, llr2, cursor=None, max_groups=8):
+        """dibits u8 [C][n], llr2 i16 [C][n][2] -> (n_groups [C], group_pos [C][max_groups], cursor_out [C], run()'s arrays):
+        ddn_p25p2_sync_cut_batch feeding ddn_p25p2_groups_batch on the device"""
+        import numpy as np
+        torch = self.torch
+        Cn, n = dibits.shape
+        td = torch.from_numpy(np.ascontiguousarray(dibits, np.uint8)).cuda()
+        tl = torch.from_numpy(np.ascontiguousarray(llr2, np.int16)).cuda()
+        cur = None if cursor is None else torch.tensor([int(v) for v in cursor], dtype=torch.int32, device="cuda")
+        ng = torch.zeros(Cn, dtype=torch.int32, device="cuda")
+        gp = torch.full((Cn, max_groups), -1, dtype=torch.int32, device="cuda")
+        co = torch.zeros(Cn, dtype=torch.int32, device="cuda")
+        gb = torch.zeros((Cn, max_groups, 1400), dtype=torch.uint8, device="cuda")
+        gl = torch.zeros((Cn, max_groups, 1400), dtype=torch.int16, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        _check(lib().ddn_p25p2_sync_cut_batch(td.data_ptr(), tl.data_ptr(), Cn, n, n, None if cur is None else cur.data_ptr(), max_groups,
+                                              ng.data_ptr(), gp.data_ptr(), co.data_ptr(), gb.data_ptr(), gl.data_ptr(), st),
+               "ddn_p25p2_sync_cut_batch")
+        res = self.run(gb, gl, groups_of=ng)
+        return ng.cpu().numpy(), gp.cpu().numpy(), co.cpu().numpy(), res, gb.cpu().numpy(), gl.cpu().numpy()
+
+    def run(self, bits, llr, groups_of=None):
         import numpy as np
         torch = self.torch
         Cn, G = bits.shape[0], bits.shape[1]
-        assert Cn == self.C and bits.shape == llr.shape == (Cn, G, 1400)
-        tb = torch.from_numpy(np.ascontiguousarray(bits, np.uint8)).cuda()
-        tl = torch.from_numpy(np.ascontiguousarray(llr, np.int16)).cuda()
+        assert Cn == self.C and tuple(bits.shape) == tuple(llr.shape) == (Cn, G, 1400)
+        tb = bits if torch.is_tensor(bits) else torch.from_numpy(np.ascontiguousarray(bits, np.uint8)).cuda()
+        tl = llr if torch.is_tensor(llr) else torch.from_numpy(np.ascontiguousarray(llr, np.int16)).cuda()
         n = Cn * G * 4
         info = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
         pay = torch.zeros((n, 180), dtype=torch.uint8, device="cuda")
@@ -989,7 +1012,8 @@ class P25P2Groups:
         rel = torch.zeros((n, 4, 4, 24), dtype=torch.uint8, device="cuda")
         ess = torch.zeros((n, 96), dtype=torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
-        _check(lib().ddn_p25p2_groups_batch(tb.data_ptr(), tl.data_ptr(), Cn, G, self.seed.data_ptr(), self.state.data_ptr(), self.threshold,
+        _check(lib().ddn_p25p2_groups_batch(tb.data_ptr(), tl.data_ptr(), Cn, G, None if groups_of is None else groups_of.data_ptr(),
+                                            self.seed.data_ptr(), self.state.data_ptr(), self.threshold,
                                             info.data_ptr(), pay.data_ptr(), fr.data_ptr(), rel.data_ptr(), ess.data_ptr(), st),
                "ddn_p25p2_groups_batch")
         torch.cuda.synchronize()

@@ -52,8 +52,8 @@ struct Scratch {
 } // namespace
 
 extern "C" int
-ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int n_channels, int n_groups, const uint64_t* d_seed44,
-                       ddn_p25p2_seq_state* d_state, int threshold, int32_t* d_info, uint8_t* d_payload, uint8_t* d_ambe_fr,
+ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int n_channels, int n_groups, const int32_t* d_groups_of,
+                       const uint64_t* d_seed44, ddn_p25p2_seq_state* d_state, int threshold, int32_t* d_info, uint8_t* d_payload, uint8_t* d_ambe_fr,
                        uint8_t* d_ambe_rel, uint8_t* d_ess, void* hip_stream) {
     if (!d_bits1400 || !d_llr1400 || !d_seed44 || !d_state || !d_info || !d_payload || !d_ambe_fr || !d_ambe_rel || !d_ess || n_channels < 0
         || n_groups < 0 || (size_t)n_channels * (size_t)n_groups * 4 > 0x7fffffffu / 360) {
@@ -88,7 +88,7 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
     DDN_TRY(ddn_p25p2_burst_fields_batch(rb, rl, n_rows, threshold, duid, isch, st));
     DDN_TRY(ddn_p25p2_scramble_bits_batch(d_seed44, (size_t)n_channels, 4320, seq, st));
     // the sequencing pass: offsets, logical channels, actions, decoder lists
-    HIP_TRY(ddn_dev_p2_sequence(duid, isch, n_channels, n_groups, d_seed44, d_state, d_info, row_off, seq_of, counts, list, ess_src, final_src,
+    HIP_TRY(ddn_dev_p2_sequence(duid, isch, n_channels, n_groups, d_groups_of, d_seed44, d_state, d_info, row_off, seq_of, counts, list, ess_src, final_src,
                                 st));
     int32_t h_counts[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, st));
@@ -155,5 +155,22 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
     }
     // the carried ESS-B fragments (after every gather that still reads the old ones)
     HIP_TRY(ddn_dev_p2_state_ess(final_src, xb, xl, n_channels, d_state, st));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p2_sync_cut_batch(const uint8_t* d_dibits, const int16_t* d_llr2, int n_channels, int n, size_t stride, const int32_t* d_cursor_in,
+                         int max_groups, int32_t* d_n_groups, int32_t* d_group_pos, int32_t* d_cursor_out, uint8_t* d_bits1400, int16_t* d_llr1400,
+                         void* hip_stream) {
+    if (!d_dibits || !d_llr2 || !d_n_groups || !d_group_pos || !d_cursor_out || !d_bits1400 || !d_llr1400 || n_channels < 0 || n < 0
+        || max_groups < 0 || stride < (size_t)n || max_groups > 65535) {
+        ddn_set_error("ddn_p25p2_sync_cut_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    if (n_channels == 0) {
+        return DDN_OK;
+    }
+    HIP_TRY(ddn_dev_p2_sync_cut(d_dibits, d_llr2, n_channels, n, stride, d_cursor_in, max_groups, d_n_groups, d_group_pos, d_cursor_out,
+                                d_bits1400, d_llr1400, (hipStream_t)hip_stream));
     return DDN_OK;
 }

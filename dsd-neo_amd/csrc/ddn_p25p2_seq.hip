@@ -58,6 +58,7 @@ action_of_duid(int d) {
 
 __global__ __launch_bounds__(64) void
 k_p2_sequence(const int32_t* __restrict__ duid, const int32_t* __restrict__ isch, int n_channels, int n_groups,
+              const int32_t* __restrict__ groups_of,
               const uint64_t* __restrict__ seed44, ddn_p25p2_seq_state* __restrict__ state, int32_t* __restrict__ info, int32_t* __restrict__ row_off,
               int32_t* __restrict__ seq_of, int32_t* __restrict__ counts, int32_t* __restrict__ list, size_t n_rows,
               int32_t* __restrict__ ess_src, int32_t* __restrict__ final_src) {
@@ -76,7 +77,22 @@ k_p2_sequence(const int32_t* __restrict__ duid, const int32_t* __restrict__ isch
             src[s][j] = -2 - j;
         }
     }
-    for (int g = 0; g < n_groups; g++) {
+    const int held = groups_of ? min(max(groups_of[c], 0), n_groups) : n_groups;
+    for (int g = held; g < n_groups; g++) {                   // places without a group: reported "not reached"
+        for (int ts = 0; ts < 4; ts++) {
+            const size_t row = ((size_t)c * n_groups + g) * 4 + ts;
+            int32_t* o = info + row * 8;
+            o[0] = -3;
+            o[1] = -2;
+            o[2] = off;
+            o[3] = -1;
+            o[4] = DDN_P2_NONE;
+            o[5] = o[6] = o[7] = 0;
+            row_off[row] = 0;
+            seq_of[row] = c;
+        }
+    }
+    for (int g = 0; g < held; g++) {
         const size_t row0 = ((size_t)c * n_groups + g) * 4;
         for (int f = 0; f < 4; f++) {
             const int v = isch[row0 + f];
@@ -260,6 +276,87 @@ k_p2_scatter(int cls, const int32_t* __restrict__ list, int32_t* __restrict__ in
     }
 }
 
+// ---- the dibit-level sync cut -----------------------------------------------------------------------------------------------------
+// One wavefront per channel.  A search position is independent of its neighbours (an exact 20-dibit compare), so the wavefront tests
+// 64 candidate sync ends at a time and takes the first; only the choice "which sync, then skip 700 dibits" is serial.
+__device__ __forceinline__ int
+sync_at(const uint8_t* d, int e) {                           // sync ending at dibit e: 1 = P25P2_SYNC, 2 = its inverse, 0 = neither
+    const uint64_t want = 0x575D57F7FFull;                    // "11131131111333133333" as 20 dibits, first dibit on top
+    uint64_t w = 0;
+    for (int k = 0; k < 20; k++) {
+        w = (w << 2) | (uint64_t)(d[e - 19 + k] & 3);
+    }
+    return w == want ? 1 : (w == (want ^ 0xAAAAAAAAAAull) ? 2 : 0);
+}
+
+__global__ __launch_bounds__(64) void
+k_p2_sync_cut(const uint8_t* __restrict__ dibits, int n, size_t stride, const int32_t* __restrict__ cursor_in, int max_groups,
+              int32_t* __restrict__ n_groups, int32_t* __restrict__ group_pos, int32_t* __restrict__ cursor_out) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint8_t* d = dibits + (size_t)c * stride;
+    int start = cursor_in ? max(cursor_in[c], 0) : 0;        // the search window fills from here
+    int count = 0;
+    int out = -1;
+    while (out < 0) {
+        int found = -1, kind = 0;
+        for (int base = start + 19; base < n && found < 0; base += 64) {
+            const int e = base + lane;
+            const int k = e < n ? sync_at(d, e) : 0;
+            const unsigned long long m = __ballot(k != 0);
+            if (m) {
+                const int first = __ffsll((long long)m) - 1;
+                found = base + first;
+                kind = __shfl(k, first);
+            }
+        }
+        if (found < 0) {
+            out = max(start, n - 19);                         // nothing open: the last 19 dibits may begin a sync
+        } else if (found + 700 >= n || count >= max_groups) {
+            out = found - 19;                                 // the group is not all here (or has no place): find this sync again
+        } else {
+            if (lane == 0) {
+                group_pos[(size_t)c * max_groups + count] = (kind == 2 ? -(found + 1) - 1 : found + 1);   // inverted: -(pos) - 1
+            }
+            count++;
+            start = found + 701;
+        }
+    }
+    if (lane == 0) {
+        n_groups[c] = count;
+        cursor_out[c] = min(out, n);
+    }
+}
+
+// a group's 700 dibits -> 1400 bits + metrics (first bit = the dibit's high bit), through invert_dibit() behind an inverted sync
+__global__ __launch_bounds__(256) void
+k_p2_cut_copy(const uint8_t* __restrict__ dibits, const int16_t* __restrict__ llr2, size_t stride, int max_groups,
+              const int32_t* __restrict__ n_groups, int32_t* __restrict__ group_pos, uint8_t* __restrict__ bits1400, int16_t* __restrict__ llr1400) {
+    const int c = blockIdx.y, g = blockIdx.x;
+    if (g >= n_groups[c]) {
+        return;
+    }
+    const size_t gi = (size_t)c * max_groups + g;
+    int pos = group_pos[gi];
+    const bool inv = pos < 0;
+    if (inv) {
+        pos = -(pos + 1);
+    }
+    for (int k = threadIdx.x; k < 700; k += 256) {
+        const size_t at = (size_t)c * stride + pos + k;
+        const int v = (dibits[at] & 3) ^ (inv ? 2 : 0);
+        const int16_t l0 = llr2[at * 2], l1 = llr2[at * 2 + 1];
+        bits1400[gi * 1400 + 2 * k] = (uint8_t)(v >> 1);
+        bits1400[gi * 1400 + 2 * k + 1] = (uint8_t)(v & 1);
+        llr1400[gi * 1400 + 2 * k] = inv ? (int16_t)(l0 == -32768 ? 32767 : -l0) : l0;
+        llr1400[gi * 1400 + 2 * k + 1] = l1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && inv) {
+        group_pos[gi] = pos;                                  // reported positions are plain; the polarity is in the copy
+    }
+}
+
 } // namespace
 
 hipError_t
@@ -270,11 +367,12 @@ ddn_dev_p2_rows(const uint8_t* bits1400, const int16_t* llr1400, size_t n_groups
 }
 
 hipError_t
-ddn_dev_p2_sequence(const int32_t* duid, const int32_t* isch, int n_channels, int n_groups, const uint64_t* seed44, ddn_p25p2_seq_state* state,
+ddn_dev_p2_sequence(const int32_t* duid, const int32_t* isch, int n_channels, int n_groups, const int32_t* groups_of, const uint64_t* seed44,
+                    ddn_p25p2_seq_state* state,
                     int32_t* info, int32_t* row_off, int32_t* seq_of, int32_t* counts, int32_t* list, int32_t* ess_src, int32_t* final_src,
                     hipStream_t st) {
     const size_t n_rows = (size_t)n_channels * n_groups * 4;
-    hipLaunchKernelGGL(k_p2_sequence, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, duid, isch, n_channels, n_groups, seed44, state,
+    hipLaunchKernelGGL(k_p2_sequence, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, duid, isch, n_channels, n_groups, groups_of, seed44, state,
                        info, row_off, seq_of, counts, list, n_rows, ess_src, final_src);
     return hipGetLastError();
 }
@@ -306,5 +404,19 @@ ddn_dev_p2_scatter(int cls, int count, const int32_t* list, int32_t* info, const
     }
     hipLaunchKernelGGL(k_p2_scatter, dim3((unsigned)count), dim3(128), 0, st, cls, list, info, x_payload, n_pl, ec, used, c12, c16, fr, rel,
                        frame_count, ess_out, o_payload, o_fr, o_rel, o_ess);
+    return hipGetLastError();
+}
+
+hipError_t
+ddn_dev_p2_sync_cut(const uint8_t* dibits, const int16_t* llr2, int n_channels, int n, size_t stride, const int32_t* cursor_in, int max_groups,
+                    int32_t* n_groups, int32_t* group_pos, int32_t* cursor_out, uint8_t* bits1400, int16_t* llr1400, hipStream_t st) {
+    hipLaunchKernelGGL(k_p2_sync_cut, dim3((unsigned)n_channels), dim3(64), 0, st, dibits, n, stride, cursor_in, max_groups, n_groups, group_pos,
+                       cursor_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || max_groups == 0) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_p2_cut_copy, dim3((unsigned)max_groups, (unsigned)n_channels), dim3(256), 0, st, dibits, llr2, stride, max_groups,
+                       n_groups, group_pos, bits1400, llr1400);
     return hipGetLastError();
 }

@@ -722,7 +722,9 @@ int ddn_p25p2_xcch_host(int kind, const uint8_t* bits360, const int16_t* llr360,
  * the ranked retries, MAC CRC-12 / LCCH CRC-16), bursts that need a valid site skipped without one (:1455-1459), an unknown DUID
  * counted - the second one ends the group and zeroes both 4V counters (:1642-1655).
  * Carried per channel across calls: ddn_p25p2_seq_state (all zeros = a fresh channel, p25_p2_frame_reset()).
- * d_bits1400 u8 / d_llr1400 i16 [n_channels][n_groups][1400]; d_seed44 u64 [n_channels] = wacn << 24 | sysid << 12 | cc.
+ * d_bits1400 u8 / d_llr1400 i16 [n_channels][n_groups][1400]; d_groups_of i32 [n_channels] (optional, NULL = n_groups each) = how many
+ * of a channel's n_groups places hold a group (the rest are reported "not reached"); d_seed44 u64 [n_channels] = wacn << 24 | sysid <<
+ * 12 | cc.
  * Results per timeslot row r = (channel * n_groups + group) * 4 + ts:
  *   d_info i32 [rows][8] = { duid (-1 rejected, -3 not reached), isch (7-bit value, -2 none), scramble offset of the group, logical
  *                            channel 0 / 1 (-1 not reached), DDN_P2_* action, ec (RS return value of the burst / of the ESS),
@@ -741,9 +743,25 @@ typedef struct ddn_p25p2_seq_state {
     uint8_t ess_b[2][96];  /* state->ess_b / ess_b_llr */
     int16_t ess_b_llr[2][96];
 } ddn_p25p2_seq_state;
-int ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int n_channels, int n_groups, const uint64_t* d_seed44,
-                           ddn_p25p2_seq_state* d_state, int threshold, int32_t* d_info, uint8_t* d_payload, uint8_t* d_ambe_fr,
-                           uint8_t* d_ambe_rel, uint8_t* d_ess, void* hip_stream);
+int ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int n_channels, int n_groups, const int32_t* d_groups_of,
+                           const uint64_t* d_seed44, ddn_p25p2_seq_state* d_state, int threshold, int32_t* d_info, uint8_t* d_payload,
+                           uint8_t* d_ambe_fr, uint8_t* d_ambe_rel, uint8_t* d_ess, void* hip_stream);
+/* The step below the groups, on a channel's dibit stream: the frame search's Phase 2 test is an exact match of the last 20 dibits with
+ * P25P2_SYNC "11131131111333133333" or its inverse (frame_sync_try_p25p2(), src/dsp/dsd_frame_sync.c:800-816; include/dsd-neo/core/
+ * sync_patterns.h:36-37), a window that must have filled since the search (re)started (frame_sync_match_window_ready(), :352-355);
+ * processP2() then takes the next 700 dibits (p2_dibit_buffer()) and the search starts again behind them.  Inverted sync: the dibits
+ * are taken through invert_dibit() (src/core/frames/dsd_dibit.c:301-311: dibit ^ 2; the first bit's metric changes sign with it).
+ * This is the dibit-level rule only - the symbol-rate receive loop in front of it (timing, thresholds, the CQPSK rotations the radio
+ * build tries) is the CQPSK chain's (a7) and not part of this call.
+ * d_dibits u8 [n_channels][stride] (0..3), d_llr2 i16 [n_channels][stride][2], n dibits valid per channel; d_cursor_in i32 [n_channels]
+ * (optional, NULL = 0) = where each channel's search starts in this buffer.  A group is cut only when its 700 dibits are inside the
+ * buffer; d_cursor_out = where the next call's search must start (the unfinished sync's first dibit, or n - 19 when none is open: the
+ * caller re-presents the stream from there).  d_group_pos i32 [n_channels][max_groups] = first dibit of each group, d_n_groups i32
+ * [n_channels] (syncs beyond max_groups stay for the next call), d_bits1400 / d_llr1400 [n_channels][max_groups][1400] = the input
+ * of ddn_p25p2_groups_batch (d_groups_of = d_n_groups). */
+int ddn_p25p2_sync_cut_batch(const uint8_t* d_dibits, const int16_t* d_llr2, int n_channels, int n, size_t stride, const int32_t* d_cursor_in,
+                             int max_groups, int32_t* d_n_groups, int32_t* d_group_pos, int32_t* d_cursor_out, uint8_t* d_bits1400,
+                             int16_t* d_llr1400, void* hip_stream);
 int ez_rs28_ess(int payload[96], int parity[168], const int* erasures, int n_erasures);
 int ez_rs28_facch(int payload[156], int parity[114], const int* erasures, int n_erasures);
 int ez_rs28_sacch(int payload[180], int parity[132], const int* erasures, int n_erasures);

@@ -227,3 +227,38 @@ def make_stream(rng, n_groups, wacn, sysid, nac, start_sf=0, noise=0.0, plan=Non
         bits ^= flip.astype(np.uint8)
         llr = np.where(flip, (llr.astype(np.int32) * rng.integers(0, 60, (nts, 360)) // 240), llr).astype(np.int16)
     return bits.reshape(n_groups, 1440)[:, :1400].copy(), llr.reshape(n_groups, 1440)[:, :1400].copy()
+
+
+# ---- the dibit-level sync cut ----------------------------------------------------------------------------------------------------
+SYNC20 = np.array([1, 1, 1, 3, 1, 1, 3, 1, 1, 1, 1, 3, 3, 3, 1, 3, 3, 3, 3, 3], np.uint8)      # P25P2_SYNC, sync_patterns.h:36
+
+
+def sync_cut(dibits, llr2, cursor=0, max_groups=1 << 30):
+    """frame_sync_try_p25p2()'s exact 20-dibit test (dsd_frame_sync.c:800-816) over a dibit stream, the window filling from `cursor`;
+    behind a sync processP2() takes 700 dibits and the search starts again -> (positions, bits [g][1400], llr [g][1400], cursor_out)"""
+    n = len(dibits)
+    pos, gb, gl = [], [], []
+    start, out = max(cursor, 0), None
+    while out is None:
+        found, inv = -1, False
+        for e in range(start + 19, n):
+            w = dibits[e - 19:e + 1]
+            if np.array_equal(w, SYNC20) or np.array_equal(w, SYNC20 ^ 2):
+                found, inv = e, not np.array_equal(w, SYNC20)
+                break
+        if found < 0:
+            out = max(start, n - 19)
+        elif found + 700 >= n or len(pos) >= max_groups:
+            out = found - 19
+        else:
+            d = dibits[found + 1:found + 701] ^ (2 if inv else 0)
+            l = llr2[found + 1:found + 701].astype(np.int32).copy()
+            if inv:
+                l[:, 0] = np.where(l[:, 0] == -32768, 32767, -l[:, 0])
+            b = np.zeros(1400, np.uint8)
+            b[0::2], b[1::2] = d >> 1, d & 1
+            pos.append(found + 1)
+            gb.append(b)
+            gl.append(l.reshape(1400).astype(np.int16))
+            start = found + 701
+    return pos, np.array(gb, np.uint8).reshape(-1, 1400), np.array(gl, np.int16).reshape(-1, 1400), min(out, n)

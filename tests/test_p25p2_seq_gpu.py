@@ -95,3 +95,65 @@ def test_synthetic_channels_across_call_boundaries(built):
     for a in range(1, 11):
         assert any(k[0] == a for k in seen), (a, seen)
     assert (p2seq.A_2V, False) in seen and (p2seq.A_SACCH_S, False) in seen, seen
+
+
+def test_dibit_stream_to_mac_pdus_on_the_capture(built):
+    """the capture's dibits -> sync cut -> groups -> bursts, all on the device.  The first S-ISCH of the capture (dibits 65..84) has one
+    wrong dibit, so the exact test locks on the second (245..264) and the groups start at 265 + 720 k, superframe slots 3, 7, 11: the
+    SACCH burst of slot 11 opens its group and decodes (the known PDUs 1, 3, 5, ...: "P25p2 SACCH", what the reference's own
+    DECODE_IQ_P25P2_CC test asks of this capture, tests/CMakeLists.txt:8923); the one of slot 10 is the fourth timeslot of a group the
+    two unknown DUIDs before it already ended.  The same stream inverted, and handed over in two pieces."""
+    dib, rel = p2capture.dibits()
+    n = len(dib)
+    llr2 = np.repeat(np.maximum(rel, 1)[:, None], 2, axis=1).astype(np.int16)
+    seed = p2capture.WACN * 16777216 + p2capture.SYSID * 4096 + p2capture.NAC
+    pos, wb, wl, wcur = p2seq.sync_cut(dib, llr2)
+    assert pos[:3] == [265, 985, 1705] and len(pos) == 15
+    obj = ddn.P25P2Groups([seed, seed])
+    ng, gp, co, res, gb, gl = obj.run_stream(np.stack([dib, dib ^ 2]), np.stack([llr2, llr2]), max_groups=20)
+    assert ng.tolist() == [15, 15] and gp[0, :15].tolist() == pos and gp[1, :15].tolist() == pos and co.tolist() == [wcur, wcur]
+    assert np.array_equal(gb[0, :15], wb) and np.array_equal(gl[0, :15], wl) and np.array_equal(gb[1, :15], wb)
+    assert np.array_equal(np.abs(gl[1, :15].astype(np.int32)), np.abs(wl.astype(np.int32)))
+    want = p2seq.run_groups(wb, wl, p2capture.WACN, p2capture.SYSID, p2capture.NAC, p2seq.new_state())
+    trimmed = tuple(a[:, :15] for a in res)
+    compare(trimmed, want, 0)
+    info, pay = res[0], res[1]
+    assert (info[0, 15:, :, 4] == 0).all() and (info[0, 15:, :, 0] == -3).all()
+    for c in (0, 1):
+        octets = [bytes(np.packbits(pay[c, g, ts])[:12]).hex() for g in range(15) for ts in range(4) if info[c, g, ts, 4] == p2seq.A_SACCH_S]
+        assert octets == SACCH_OCTETS[1::2][:len(octets)] and len(octets) >= 4, (c, octets)
+        assert all(info[c, g, 0, 3] == 1 and info[c, g, 0, 2] == 11 for g in range(15) if info[c, g, 0, 4] == p2seq.A_SACCH_S)
+    # two pieces: the second call starts where the first one's cursor points
+    cut = 6000
+    o2 = ddn.P25P2Groups([seed])
+    ng1, gp1, co1, r1, _, _ = o2.run_stream(dib[None, :cut], llr2[None, :cut], max_groups=20)
+    p1, b1, l1, c1 = p2seq.sync_cut(dib[:cut], llr2[:cut])
+    assert ng1[0] == len(p1) and gp1[0, :len(p1)].tolist() == p1 and co1[0] == c1
+    ng2, gp2, co2, r2, _, _ = o2.run_stream(dib[None, c1:], llr2[None, c1:], max_groups=20)
+    assert [int(v) + c1 for v in gp2[0, :ng2[0]]] == pos[len(p1):]
+    compare(tuple(a[:, :ng1[0]] for a in r1), want[:4 * len(p1)], 0)
+    compare(tuple(a[:, :ng2[0]] for a in r2), want[4 * len(p1):], 0)
+
+
+def test_sync_cut_equals_oracle_on_planted_streams(built):
+    import torch
+    rng = np.random.default_rng(19 + FZ)
+    Cn, n = 40, 5000
+    dib = rng.integers(0, 4, (Cn, n)).astype(np.uint8)
+    llr2 = rng.integers(-32768, 32767, (Cn, n, 2)).astype(np.int16)
+    for c in range(Cn):
+        for _ in range(int(rng.integers(0, 9))):
+            at = int(rng.integers(0, n - 20))
+            dib[c, at:at + 20] = p2seq.SYNC20 ^ (2 if rng.integers(0, 3) == 0 else 0)
+        if c % 5 == 0:
+            dib[c, n - 20:] = p2seq.SYNC20                    # a sync ending on the last dibit
+        if c % 7 == 0:
+            dib[c, :20] = p2seq.SYNC20                        # and one on the first 20
+    cursor = [int(rng.integers(0, 30)) if c % 3 == 0 else 0 for c in range(Cn)]
+    for mg in (8, 2):
+        obj = ddn.P25P2Groups([0x123456789] * Cn)
+        ng, gp, co, res, gb, gl = obj.run_stream(dib, llr2, cursor=cursor, max_groups=mg)
+        for c in range(Cn):
+            pos, wb, wl, wcur = p2seq.sync_cut(dib[c], llr2[c], cursor[c], mg)
+            assert ng[c] == len(pos) and gp[c, :len(pos)].tolist() == pos and co[c] == wcur, (c, mg, ng[c], pos, co[c], wcur)
+            assert np.array_equal(gb[c, :len(pos)], wb) and np.array_equal(gl[c, :len(pos)], wl), (c, mg)
