@@ -77,3 +77,22 @@ def test_two_unknown_duids_end_the_group_and_zero_the_4v_counters():
     res = p2seq.run_groups(gb, gl, wacn, sysid, nac, p2seq.new_state())
     assert [r["action"] for r in res[8:12]] == [p2seq.A_ERR, p2seq.A_ERR, p2seq.A_NONE, p2seq.A_NONE]
     assert [r["duid"] for r in res[10:12]] == [-3, -3]
+
+
+def test_sync_cut_on_the_capture_dibits():
+    """frame_sync_try_p25p2()'s exact test over the capture's dibits: the first S-ISCH (one wrong dibit) is passed over, the lock moves
+    by a timeslot where another one is damaged; the groups decode the known SACCH PDUs 1, 3, 4 .. 9"""
+    dib, rel = p2capture.dibits()
+    llr2 = np.repeat(np.maximum(rel, 1)[:, None], 2, axis=1).astype(np.int16)
+    pos, gb, gl, cur = p2seq.sync_cut(dib, llr2)
+    assert pos == [265, 985, 1705, 2425, 3145, 3865, 5125, 5845, 6565, 7285, 8005, 8725, 9445, 10165, 10885] and cur == 11585
+    res = p2seq.run_groups(gb, gl, p2capture.WACN, p2capture.SYSID, p2capture.NAC, p2seq.new_state())
+    got = [bytes(np.packbits(r["payload"])[:12]).hex() for r in res if r["action"] == p2seq.A_SACCH_S]
+    assert got == [SACCH_OCTETS[k] for k in (1, 3, 4, 5, 6, 7, 8, 9)]
+    # inverted polarity gives the same groups; a cursor past the first syncs skips them; a cut stream resumes at the cursor
+    pos2, gb2, _, _ = p2seq.sync_cut(dib ^ 2, llr2)
+    assert pos2 == pos and np.array_equal(gb2, gb)
+    assert p2seq.sync_cut(dib, llr2, cursor=pos[0] + 700)[0] == pos[1:] and p2seq.sync_cut(dib, llr2, cursor=300)[0][0] == 805
+    p1, _, _, c1 = p2seq.sync_cut(dib[:6000], llr2[:6000])
+    p2, _, _, _ = p2seq.sync_cut(dib[c1:], llr2[c1:])
+    assert p1 + [v + c1 for v in p2] == pos

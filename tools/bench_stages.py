@@ -288,6 +288,38 @@ def main():
     ms = timeit(lambda: l.ddn_p25p2_ess_batch(e_pl.data_ptr(), e_pll.data_ptr(), e_pa.data_ptr(), e_pal.data_ptr(), nb, 64, e_out.data_ptr(), d_ec.data_ptr(), d_used.data_ptr(), st))
     report("p25p2_ess", nb, ms, 264 * 3 + 96 + 5, cpu(lambda: [oracle_ess(*e[:4]) for e in ess], 512), "sections")
 
+    # P25 Phase 2 above the bursts: processP2() on the groups behind each sync (ISCH -> offset, de-scrambling, DUID dispatch, burst
+    # decodes, ESS), 4096 channels x 6 groups = one second of a TDMA channel each; and the dibit-level sync cut in front of it
+    import p2seq
+    Cn, G = 4096, 6
+    base = [p2seq.make_stream(rng, G, 0xBEE00 + k, 0x164, 0x161, start_sf=int(rng.integers(0, 12)), noise=0.002) for k in range(16)]
+    gb = np.stack([base[c % 16][0] for c in range(Cn)])
+    gl = np.stack([base[c % 16][1] for c in range(Cn)])
+    obj = ddn.P25P2Groups([((0xBEE00 + c % 16) << 24) | (0x164 << 12) | 0x161 for c in range(Cn)])
+    tb, tl = torch.from_numpy(gb).cuda(), torch.from_numpy(gl).cuda()
+    nr = Cn * G * 4
+    o_info, o_pay = torch.zeros((nr, 8), dtype=torch.int32, device="cuda"), torch.zeros((nr, 180), dtype=torch.uint8, device="cuda")
+    o_fr, o_rel = torch.zeros((nr, 384), dtype=torch.uint8, device="cuda"), torch.zeros((nr, 384), dtype=torch.uint8, device="cuda")
+    o_ess = torch.zeros((nr, 96), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: l.ddn_p25p2_groups_batch(tb.data_ptr(), tl.data_ptr(), Cn, G, None, obj.seed.data_ptr(), obj.state.data_ptr(), 64,
+                                                 o_info.data_ptr(), o_pay.data_ptr(), o_fr.data_ptr(), o_rel.data_ptr(), o_ess.data_ptr(), st))
+    def cpu_groups():
+        stt = p2seq.new_state()
+        p2seq.run_groups(base[0][0], base[0][1], 0xBEE00, 0x164, 0x161, stt)
+    report("p25p2_groups", nr, ms, 360 * 3 + 32 + 180, cpu(cpu_groups, G * 4), "timeslots")
+    nd = 6000
+    dib = rng.integers(0, 4, (Cn, nd)).astype(np.uint8)
+    for c in range(Cn):
+        for k in range(int(rng.integers(0, 720)), nd - 20, 720):
+            dib[c, k:k + 20] = p2seq.SYNC20
+    llr2 = rng.integers(-300, 300, (Cn, nd, 2)).astype(np.int16)
+    td, tl2 = torch.from_numpy(dib).cuda(), torch.from_numpy(llr2).cuda()
+    ng, gp, co = (torch.zeros(Cn * k, dtype=torch.int32, device="cuda") for k in (1, 8, 1))
+    cb, cl = torch.zeros((Cn, 8, 1400), dtype=torch.uint8, device="cuda"), torch.zeros((Cn, 8, 1400), dtype=torch.int16, device="cuda")
+    ms = timeit(lambda: l.ddn_p25p2_sync_cut_batch(td.data_ptr(), tl2.data_ptr(), Cn, nd, nd, None, 8, ng.data_ptr(), gp.data_ptr(), co.data_ptr(),
+                                                   cb.data_ptr(), cl.data_ptr(), st))
+    report("p25p2_sync_cut", Cn * nd, ms, 5 + 3, cpu(lambda: p2seq.sync_cut(dib[0], llr2[0]), nd), "dibits")
+
 
 if __name__ == "__main__":
     main()
