@@ -27,26 +27,41 @@
     } while (0)
 
 namespace {
-// stream-ordered scratch, released when the call leaves (also on its error paths)
+// stream-ordered scratch: arenas (one hipMallocAsync each, carved by get()), released when the call leaves (also on its error paths)
 struct Scratch {
     hipStream_t st;
-    void* p[64];
+    void* p[4];
     int n = 0;
+    uint8_t* cur = nullptr;
+    size_t left = 0;
     explicit Scratch(hipStream_t s) : st(s) {}
     ~Scratch() {
         for (int i = 0; i < n; i++) {
             (void)hipFreeAsync(p[i], st);
         }
     }
-    template <class T>
-    hipError_t get(T** out, size_t count) {
+    hipError_t arena(size_t bytes) {
         void* q = nullptr;
-        const hipError_t e = hipMallocAsync(&q, (count ? count : 1) * sizeof(T), st);
+        const hipError_t e = n < 4 ? hipMallocAsync(&q, bytes + 256, st) : hipErrorOutOfMemory;
         if (e == hipSuccess) {
             p[n++] = q;
+            cur = (uint8_t*)q;
+            left = bytes + 256;
         }
-        *out = (T*)q;
         return e;
+    }
+    static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+    template <class T>
+    hipError_t get(T** out, size_t count) {
+        const size_t b = pad((count ? count : 1) * sizeof(T));
+        if (b > left) {
+            *out = nullptr;
+            return hipErrorOutOfMemory;
+        }
+        *out = (T*)cur;
+        cur += b;
+        left -= b;
+        return hipSuccess;
     }
 };
 } // namespace
@@ -69,6 +84,7 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
     uint8_t *rb, *xb, *seq;
     int16_t *rl, *xl;
     int32_t *duid, *isch, *row_off, *counts, *list, *ess_src, *final_src, *seq_of;
+    HIP_TRY(s.arena(n_rows * (360 * 6 + 4 * 4 + 16 + 16) + (size_t)n_channels * (4320 + 32) + 16 * 256));
     HIP_TRY(s.get(&rb, n_rows * 360));
     HIP_TRY(s.get(&rl, n_rows * 360));
     HIP_TRY(s.get(&xb, n_rows * 360));
@@ -96,6 +112,8 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
     HIP_TRY(hipStreamSynchronize(st));
     const int n_f = h_counts[0], n_s = h_counts[1], n_4v = h_counts[2], n_2v = h_counts[3];
     const int rows_per_channel = n_groups * 4;
+    HIP_TRY(s.arena((size_t)(n_f + n_s) * (360 * 3 + 180 + 8) + (size_t)(n_4v + n_2v) * (360 * 3 + 768) + (size_t)n_2v * (96 * 4 + 168 * 3 + 8)
+                    + 40 * 256));
     // FACCH (class 0) and SACCH / LCCH (class 1) bursts
     for (int cls = 0; cls < 2; cls++) {
         const int cnt = cls == 0 ? n_f : n_s;

@@ -162,9 +162,21 @@ k_p2_sequence(const int32_t* __restrict__ duid, const int32_t* __restrict__ isch
             o[7] = 0;
             row_off[row] = off + ts;
             seq_of[row] = c;                                  // the de-scrambler's sequence row
-            if (cls >= 0) {
-                const int pos = atomicAdd(&counts[cls], 1);   // the order inside a list is whatever the lanes made it: results go back by row
-                list[(size_t)cls * n_rows + pos] = (int32_t)row;
+            // a place in its decoder's list: one atomic per class and wavefront step (the lanes of a class share it by rank); the order
+            // inside a list is whatever the wavefronts made it - results go back by row
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long m = __ballot(cls == k);
+                if (m == 0 || cls != k) {
+                    continue;
+                }
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if ((int)threadIdx.x == leader) {
+                    base = atomicAdd(&counts[k], __popcll(m));
+                }
+                base = __shfl(base, leader);
+                const int pos = base + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+                list[(size_t)k * n_rows + pos] = (int32_t)row;
             }
         }
     }
