@@ -1008,10 +1008,17 @@ ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_re
 // the first.  A root count short of the degree, a zero derivative or a non-zero value inside the pad fails the decode (-1)
 // and leaves the section as received (the reference decodes a copy and copies back on a positive count only).
 // One section per thread, its polynomials in LDS columns.
+enum { DDN_RS28_PROBE = -3, DDN_RS28_FINAL = -4 };
 __global__ __launch_bounds__(64) void
 k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__ parity_bits,
        const int8_t* __restrict__ erasures, const uint8_t* __restrict__ n_erasures, int n, int32_t* __restrict__ status,
-       int attempt, int n_fixed, uint8_t* __restrict__ used_dynamic, int loop_to, int ess_rule) {
+       int attempt, int n_fixed, uint8_t* __restrict__ used_dynamic, int loop_to, int ess_rule, int probe_A,
+       int32_t* __restrict__ probe_res) {
+    // probe_A > 0: the retries of a section are independent of each other (attempt a decodes the received block with the first
+    // n_fixed + a erasures of the ranked list; the reference takes the first that succeeds), so they run side by side instead of
+    // one after the other: the PROBE pass (attempt == DDN_RS28_PROBE) gives every (section, attempt 1 .. probe_A) pair a thread that
+    // only reports whether its decode succeeds, the FINAL pass (attempt == DDN_RS28_FINAL) decodes each failed section once more
+    // with the first attempt that did and writes the result - two decodes deep instead of up to probe_A.
     // attempt >= 0 (the Phase 2 burst stage's ranked retries, p25p2_decode_facch_ranked()): this launch decodes with the first
     // n_fixed + attempt erasures of each list - attempt 0 every section, attempt a > 0 only the sections that have failed so far
     // and whose list (n_erasures = its full length) reaches that far; a failed decode leaves the payload as received, so every
@@ -1036,9 +1043,34 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         lg[0] = 0;
     }
     __syncthreads();
-    const int i = blockIdx.x * 64 + lane;
-    if (i >= n) {
+    const long gid = (long)blockIdx.x * 64 + lane;
+    const bool probe = probe_A > 0 && attempt == DDN_RS28_PROBE, fin = probe_A > 0 && attempt == DDN_RS28_FINAL;
+    const int i = probe ? (int)(gid / probe_A) : (int)gid;
+    if (i >= n || (probe && gid >= (long)n * probe_A)) {
         return;
+    }
+    if (probe) {
+        attempt = 1 + (int)(gid % probe_A);
+        loop_to = attempt;
+        if (status[i] >= 0) {
+            return;
+        }
+        if (n_fixed + attempt > (int)n_erasures[i]) {
+            probe_res[gid] = -2;
+            return;
+        }
+    } else if (fin) {
+        if (status[i] >= 0) {
+            return;
+        }
+        attempt = 0;
+        for (int k = 0; k < probe_A && attempt == 0; k++) {
+            attempt = probe_res[(long)i * probe_A + k] >= 0 ? k + 1 : 0;
+        }
+        if (attempt == 0) {
+            return; // every retry failed (or none was due): status stays the failed decode's -1, the payload as received
+        }
+        loop_to = attempt;
     }
     if (attempt > 0 && (status[i] >= 0 || n_fixed + attempt > (int)n_erasures[i])) {
         return;
@@ -1076,7 +1108,11 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         any |= v;
     }
     if (!any) {
-        status[i] = 0;
+        if (probe) {
+            probe_res[gid] = 0;
+        } else {
+            status[i] = 0;
+        }
         return;
     }
     // loop_to >= attempt: this thread goes on to the next attempt itself (n_fixed + attempt + 1 erasures, ...) until one decodes,
@@ -1200,14 +1236,14 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         } while (0);
         const bool rejected = ess_rule && att == 0 && result >= 15;
         if (result >= 0 && !rejected) {
-            for (int k = 0; k < n_data; k++) {
+            for (int k = 0; k < (probe ? 0 : n_data); k++) {
                 const int v = Cw[first + k][lane];
 #pragma unroll
                 for (int b = 0; b < 6; b++) {
                     pl[6 * k + b] = (uint8_t)((v >> (5 - b)) & 1);
                 }
             }
-            if (att > 0 && used_dynamic) {
+            if (att > 0 && used_dynamic && !probe) {
                 used_dynamic[i] = 1;
             }
             break;
@@ -1217,7 +1253,30 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
             break;
         }
     }
-    status[i] = result;
+    if (probe) {
+        probe_res[gid] = result;
+    } else {
+        status[i] = result;
+    }
+}
+
+// the retries of every failed section side by side (see k_rs28): probe pass over (section, attempt) pairs, final pass per section
+static hipError_t
+rs28_retries(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const int8_t* erasures28, const uint8_t* n_total, int n,
+             int32_t* status, int n_fixed, uint8_t* used_dynamic, int max_add, hipStream_t st) {
+    int32_t* res = nullptr;
+    hipError_t e = hipMallocAsync((void**)&res, (size_t)n * max_add * sizeof(int32_t), st);
+    if (e != hipSuccess) {
+        return e;
+    }
+    const long pairs = (long)n * max_add;
+    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
+                       status, DDN_RS28_PROBE, n_fixed, used_dynamic, 0, 0, max_add, res);
+    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
+                       status, DDN_RS28_FINAL, n_fixed, used_dynamic, 0, 0, max_add, res);
+    e = hipGetLastError();
+    const hipError_t f = hipFreeAsync(res, st);
+    return e != hipSuccess ? e : f;
 }
 
 // ---- P25 Phase 2 FACCH / SACCH burst gather + ranked erasure list -----------------------------------------------------------------
@@ -1301,7 +1360,7 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures,
-                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr, -1, 0);
+                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr, -1, 0, 0, (int32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -1356,7 +1415,7 @@ ddn_dev_p25p2_mac_crc(int kind, const uint8_t* payload_bits, int n, uint8_t* crc
 // ---- P25 Phase 2 ESS: ranked erasure list and the rule for the plain decode ---------------------------------------------------------
 // p25p2_ess_soft_erasures_ranked() (p25p2_soft.c:331-383) and p25p2_ess_decode_with_soft_erasures() (p25p2_frame.c:1061-1091): the
 // plain decode stands when it located fewer than 15 symbols; otherwise the section is retried from its received bits with the first
-// 1, 2, ... erasures of the list (k_rs28: ess_rule on the plain attempt, then one launch whose threads loop over their retries).
+// 1, 2, ... erasures of the list (k_rs28: ess_rule on the plain attempt, then the retries side by side - rs28_retries()).
 __global__ void
 k_p2_ess_prepare(const uint8_t* __restrict__ payload_bits, const int16_t* __restrict__ payload_llr, const int16_t* __restrict__ parity_llr,
                  int n, int threshold, uint8_t* __restrict__ work, int8_t* __restrict__ erasures28, uint8_t* __restrict__ n_total,
@@ -1412,9 +1471,9 @@ ddn_dev_p25p2_ess(const uint8_t* payload_bits, const int16_t* payload_llr, const
     hipLaunchKernelGGL(k_p2_ess_prepare, grid, blk, 0, st, payload_bits, payload_llr, parity_llr, n, threshold, work, erasures28, n_total,
                        used_dynamic);
     // the plain decode for every section (not taken when it located 15 symbols or more), then one launch for the retries
-    hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 0, 0, used_dynamic, -1, 1);
-    hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 1, 0, used_dynamic, 28, 0);
-    return hipGetLastError();
+    hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 0, 0, used_dynamic, -1, 1, 0,
+                       (int32_t*)nullptr);
+    return rs28_retries(0, work, parity_bits, erasures28, n_total, n, status, 0, used_dynamic, 28, st);
 }
 
 // ---- P25 Phase 2 frame scrambler ----------------------------------------------------------------------------------------------------
@@ -1579,7 +1638,7 @@ ddn_dev_p25p2_burst_fields(const uint8_t* bits360, const int16_t* llr360, int n,
 }
 
 // the Phase 2 FACCH (kind 0) / SACCH (kind 1) burst stage: gather + ranked list, then the decode with the fixed erasures and the
-// retries with one more erasure each (a launch per attempt: only the sections that still fail do any work)
+// retries with one more erasure each, side by side (rs28_retries(): only the sections that failed do any work)
 extern "C" hipError_t
 ddn_dev_p25p2_xcch(int kind, const uint8_t* bits360, const int16_t* llr360, int n, int threshold, uint8_t* payload_bits,
                    uint8_t* parity_bits, int8_t* erasures28, uint8_t* n_total, int32_t* status, uint8_t* used_dynamic, hipStream_t st) {
@@ -1589,13 +1648,11 @@ ddn_dev_p25p2_xcch(int kind, const uint8_t* bits360, const int16_t* llr360, int 
     hipLaunchKernelGGL(k_p2_xcch_gather, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, bits360, llr360, n, threshold,
                        payload_bits, parity_bits, erasures28, n_total, used_dynamic);
     const int n_fixed = kind == 0 ? 18 : 11, max_add = kind == 0 ? 10 : 16;
-    // the decode with the fixed erasures for every burst, then one launch in which the bursts that failed work through their retries
-    // themselves (most bursts of real traffic never get there: the second launch's threads leave at once)
+    // the decode with the fixed erasures for every burst, then the failed bursts' retries (most bursts of real traffic never get
+    // there: those threads leave at once)
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind + 1, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, 0, n_fixed, used_dynamic, -1, 0);
-    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind + 1, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, 1, n_fixed, used_dynamic, max_add, 0);
-    return hipGetLastError();
+                       status, 0, n_fixed, used_dynamic, -1, 0, 0, (int32_t*)nullptr);
+    return rs28_retries(kind + 1, payload_bits, parity_bits, erasures28, n_total, n, status, n_fixed, used_dynamic, max_add, st);
 }
 
 // ---- P25 Phase 2 I-ISCH lookup == isch_lookup / isch_lookup_soft (src/fec/ez.cpp:325-384) ---------------------------------
