@@ -41,6 +41,32 @@ def test_xcch_batch_equals_oracle(built):
             assert ec[i] == want2[j][0] and used[i] == want2[j][2] and np.array_equal(pl[i], want2[j][1]), (kind, i)
 
 
+def test_xcch_large_batches_take_the_in_thread_retries_and_agree(built):
+    """the retries run side by side for small batches and inside the thread for large ones of short lists (rs28_retries(),
+    ddn_rs.hip): the same bursts through both routes give the same answers, which are the oracle's"""
+    rng = np.random.default_rng(59 + FZ)
+    for kind, tiles in ((0, 88), (1, 56)):                      # 45 056 x 10 and 28 672 x 16 (section, attempt) pairs: beyond 400 k
+        u = 512
+        bits, llr = np.zeros((u, 360), np.uint8), np.zeros((u, 360), np.int16)
+        for i in range(u):
+            n_err = int(rng.integers(0, 14))
+            bits[i], llr[i], _ = rs28.make_xcch_burst(rng, kind, n_err, int(rng.integers(0, n_err + 1)), int(rng.integers(0, 6)))
+        outs = []
+        for reps in (1, tiles):
+            n = u * reps
+            b, l = np.tile(bits, (reps, 1)), np.tile(llr, (reps, 1))
+            pl, ec, used = np.zeros((n, N_PL[kind]), np.uint8), np.zeros(n, np.int32), np.zeros(n, np.uint8)
+            assert ddn.lib().ddn_p25p2_xcch_host(kind, b.ctypes.data, l.ctypes.data, n, 64, pl.ctypes.data, ec.ctypes.data, used.ctypes.data) == 0
+            outs.append((pl.reshape(reps, u, -1), ec.reshape(reps, u), used.reshape(reps, u)))
+        small, large = outs
+        for t in range(tiles):
+            assert np.array_equal(large[0][t], small[0][0]) and np.array_equal(large[1][t], small[1][0]) and np.array_equal(large[2][t], small[2][0]), (kind, t)
+        for i in range(0, u, 5):
+            wec, wpl, wused = oracle_xcch(kind, bits[i], llr[i])
+            assert small[1][0][i] == wec and small[2][0][i] == wused and np.array_equal(small[0][0][i], wpl), (kind, i)
+        assert (small[2][0] == 1).sum() >= 10 and (small[1][0] < 0).sum() >= 10
+
+
 def test_burst_fields_duid_and_isch_equal_oracle(built):
     import ctypes as C
     import orc
