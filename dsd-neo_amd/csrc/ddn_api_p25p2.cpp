@@ -192,3 +192,87 @@ ddn_p25p2_sync_cut_batch(const uint8_t* d_dibits, const int16_t* d_llr2, int n_c
                                 d_bits1400, d_llr1400, (hipStream_t)hip_stream));
     return DDN_OK;
 }
+
+namespace {
+struct Dev {
+    void* p = nullptr;
+    size_t bytes;
+    explicit Dev(size_t b) : bytes(b) {
+        if (hipMalloc(&p, b ? b : 4) != hipSuccess) {
+            p = nullptr;
+        }
+    }
+    ~Dev() { (void)hipFree(p); }
+    Dev(const Dev&) = delete;
+    Dev& operator=(const Dev&) = delete;
+    int up(const void* h) { return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+    int down(void* h) { return hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+};
+
+int
+no_dev() {
+    ddn_set_error("device allocation/copy failed (no HIP device?)");
+    return DDN_ENODEV;
+}
+} // namespace
+
+extern "C" int
+ddn_p25p2_groups_host(const uint8_t* bits1400, const int16_t* llr1400, int n_channels, int n_groups, const int32_t* groups_of,
+                      const uint64_t* seed44, ddn_p25p2_seq_state* state, int threshold, int32_t* info, uint8_t* payload, uint8_t* ambe_fr,
+                      uint8_t* ambe_rel, uint8_t* ess) {
+    if (!bits1400 || !llr1400 || !seed44 || !state || !info || !payload || !ambe_fr || !ambe_rel || !ess || n_channels < 0 || n_groups < 0) {
+        ddn_set_error("ddn_p25p2_groups_host: bad argument");
+        return DDN_EINVAL;
+    }
+    if (n_channels == 0 || n_groups == 0) {
+        return DDN_OK;
+    }
+    const size_t ng = (size_t)n_channels * n_groups, nr = ng * 4;
+    Dev b(ng * 1400), l(ng * 2800), go((size_t)n_channels * 4), sd((size_t)n_channels * 8), st((size_t)n_channels * sizeof(ddn_p25p2_seq_state));
+    Dev oi(nr * 32), op(nr * 180), of(nr * 384), orl(nr * 384), oe(nr * 96);
+    if (!b.p || !l.p || !go.p || !sd.p || !st.p || !oi.p || !op.p || !of.p || !orl.p || !oe.p || b.up(bits1400) || l.up(llr1400)
+        || (groups_of && go.up(groups_of)) || sd.up(seed44) || st.up(state) || oi.up(info) || op.up(payload) || of.up(ambe_fr) || orl.up(ambe_rel)
+        || oe.up(ess)) {
+        return no_dev();
+    }
+    const int rc = ddn_p25p2_groups_batch((const uint8_t*)b.p, (const int16_t*)l.p, n_channels, n_groups, groups_of ? (const int32_t*)go.p : nullptr,
+                                          (const uint64_t*)sd.p, (ddn_p25p2_seq_state*)st.p, threshold, (int32_t*)oi.p, (uint8_t*)op.p,
+                                          (uint8_t*)of.p, (uint8_t*)orl.p, (uint8_t*)oe.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (st.down(state) || oi.down(info) || op.down(payload) || of.down(ambe_fr) || orl.down(ambe_rel) || oe.down(ess)) {
+        return no_dev();
+    }
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_p25p2_sync_cut_host(const uint8_t* dibits, const int16_t* llr2, int n_channels, int n, size_t stride, const int32_t* cursor_in, int max_groups,
+                        int32_t* n_groups, int32_t* group_pos, int32_t* cursor_out, uint8_t* bits1400, int16_t* llr1400) {
+    if (!dibits || !llr2 || !n_groups || !group_pos || !cursor_out || !bits1400 || !llr1400 || n_channels < 0 || n < 0 || max_groups < 0
+        || stride < (size_t)n) {
+        ddn_set_error("ddn_p25p2_sync_cut_host: bad argument");
+        return DDN_EINVAL;
+    }
+    if (n_channels == 0) {
+        return DDN_OK;
+    }
+    const size_t C = (size_t)n_channels, G = (size_t)max_groups;
+    Dev d(C * stride), l(C * stride * 4), ci(C * 4), ng(C * 4), gp(C * G * 4), co(C * 4), gb(C * G * 1400), gl(C * G * 2800);
+    if (!d.p || !l.p || !ci.p || !ng.p || !gp.p || !co.p || !gb.p || !gl.p || d.up(dibits) || l.up(llr2) || (cursor_in && ci.up(cursor_in))
+        || gp.up(group_pos) || gb.up(bits1400) || gl.up(llr1400)) {
+        return no_dev();
+    }
+    const int rc = ddn_p25p2_sync_cut_batch((const uint8_t*)d.p, (const int16_t*)l.p, n_channels, n, stride, cursor_in ? (const int32_t*)ci.p : nullptr,
+                                            max_groups, (int32_t*)ng.p, (int32_t*)gp.p, (int32_t*)co.p, (uint8_t*)gb.p, (int16_t*)gl.p, nullptr);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (ng.down(n_groups) || gp.down(group_pos) || co.down(cursor_out) || gb.down(bits1400) || gl.down(llr1400)) {
+        return no_dev();
+    }
+    return DDN_OK;
+}

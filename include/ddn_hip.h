@@ -762,6 +762,12 @@ int ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, 
 int ddn_p25p2_sync_cut_batch(const uint8_t* d_dibits, const int16_t* d_llr2, int n_channels, int n, size_t stride, const int32_t* d_cursor_in,
                              int max_groups, int32_t* d_n_groups, int32_t* d_group_pos, int32_t* d_cursor_out, uint8_t* d_bits1400,
                              int16_t* d_llr1400, void* hip_stream);
+/* the two calls with host pointers (staged through the device, synchronous; state = the host's copy of the carried structs, in / out) */
+int ddn_p25p2_groups_host(const uint8_t* bits1400, const int16_t* llr1400, int n_channels, int n_groups, const int32_t* groups_of,
+                          const uint64_t* seed44, ddn_p25p2_seq_state* state, int threshold, int32_t* info, uint8_t* payload, uint8_t* ambe_fr,
+                          uint8_t* ambe_rel, uint8_t* ess);
+int ddn_p25p2_sync_cut_host(const uint8_t* dibits, const int16_t* llr2, int n_channels, int n, size_t stride, const int32_t* cursor_in,
+                            int max_groups, int32_t* n_groups, int32_t* group_pos, int32_t* cursor_out, uint8_t* bits1400, int16_t* llr1400);
 int ez_rs28_ess(int payload[96], int parity[168], const int* erasures, int n_erasures);
 int ez_rs28_facch(int payload[156], int parity[114], const int* erasures, int n_erasures);
 int ez_rs28_sacch(int payload[180], int parity[132], const int* erasures, int n_erasures);

@@ -158,3 +158,34 @@ def test_sync_cut_equals_oracle_on_planted_streams(built):
             pos, wb, wl, wcur = p2seq.sync_cut(dib[c], llr2[c], cursor[c], mg)
             assert ng[c] == len(pos) and gp[c, :len(pos)].tolist() == pos and co[c] == wcur, (c, mg, ng[c], pos, co[c], wcur)
             assert np.array_equal(gb[c, :len(pos)], wb) and np.array_equal(gl[c, :len(pos)], wl), (c, mg)
+
+
+def test_host_pointer_calls_on_the_capture(built):
+    """ddn_p25p2_sync_cut_host -> ddn_p25p2_groups_host with plain host buffers (what a C caller does): the capture's dibits to the
+    known SACCH PDUs, the carried state in the caller's memory across two calls"""
+    import ctypes as C
+    l = ddn.lib()
+    dib, rel = p2capture.dibits()
+    llr2 = np.ascontiguousarray(np.repeat(np.maximum(rel, 1)[:, None], 2, axis=1).astype(np.int16))
+    dib = np.ascontiguousarray(dib)
+    seed = np.array([p2capture.WACN * 16777216 + p2capture.SYSID * 4096 + p2capture.NAC], np.uint64)
+    state = np.zeros(ddn.P25P2_SEQ_STATE_BYTES, np.uint8)
+    octets, cursor, base = [], np.zeros(1, np.int32), 0
+    for lo, hi in ((0, 6000), (None, len(dib))):
+        lo = base if lo is None else lo
+        d, q = np.ascontiguousarray(dib[lo:hi]), np.ascontiguousarray(llr2[lo:hi])
+        mg = 12
+        ng, gp, co = np.zeros(1, np.int32), np.zeros(mg, np.int32), np.zeros(1, np.int32)
+        gb, gl = np.zeros((mg, 1400), np.uint8), np.zeros((mg, 1400), np.int16)
+        assert l.ddn_p25p2_sync_cut_host(d.ctypes.data, q.ctypes.data, 1, len(d), len(d), None, mg, ng.ctypes.data, gp.ctypes.data, co.ctypes.data,
+                                         gb.ctypes.data, gl.ctypes.data) == 0
+        n = int(ng[0])
+        info, pay = np.zeros((mg * 4, 8), np.int32), np.zeros((mg * 4, 180), np.uint8)
+        fr, rl, ess = np.zeros((mg * 4, 384), np.uint8), np.zeros((mg * 4, 384), np.uint8), np.zeros((mg * 4, 96), np.uint8)
+        assert l.ddn_p25p2_groups_host(gb.ctypes.data, gl.ctypes.data, 1, mg, ng.ctypes.data, seed.ctypes.data, state.ctypes.data, 64,
+                                       info.ctypes.data, pay.ctypes.data, fr.ctypes.data, rl.ctypes.data, ess.ctypes.data) == 0
+        octets += [bytes(np.packbits(pay[r])[:12]).hex() for r in range(4 * n) if info[r, 4] == p2seq.A_SACCH_S]
+        assert (info[4 * n:, 4] == 0).all()
+        base = lo + int(co[0])
+    assert octets == [SACCH_OCTETS[k] for k in (1, 3, 4, 5, 6, 7, 8, 9)]
+    assert int(state.view(np.int32)[0]) in (2, 6, 10)          # the carried scramble offset came back to the caller
