@@ -1008,17 +1008,19 @@ ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_re
 // the first.  A root count short of the degree, a zero derivative or a non-zero value inside the pad fails the decode (-1)
 // and leaves the section as received (the reference decodes a copy and copies back on a positive count only).
 // One section per thread, its polynomials in LDS columns.
-enum { DDN_RS28_PROBE = -3, DDN_RS28_FINAL = -4 };
+enum { DDN_RS28_PROBE = -3, DDN_RS28_FINAL = -4, DDN_RS28_SYN = -5 };
 __global__ __launch_bounds__(64) void
 k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__ parity_bits,
        const int8_t* __restrict__ erasures, const uint8_t* __restrict__ n_erasures, int n, int32_t* __restrict__ status,
        int attempt, int n_fixed, uint8_t* __restrict__ used_dynamic, int loop_to, int ess_rule, int probe_A,
-       int32_t* __restrict__ probe_res) {
+       int32_t* __restrict__ probe_res, uint8_t* __restrict__ syn) {
     // probe_A > 0: the retries of a section are independent of each other (attempt a decodes the received block with the first
     // n_fixed + a erasures of the ranked list; the reference takes the first that succeeds), so they run side by side instead of
     // one after the other: the PROBE pass (attempt == DDN_RS28_PROBE) gives every (section, attempt 1 .. probe_A) pair a thread that
     // only reports whether its decode succeeds, the FINAL pass (attempt == DDN_RS28_FINAL) decodes each failed section once more
-    // with the first attempt that did and writes the result - two decodes deep instead of up to probe_A.
+    // with the first attempt that did and writes the result - two decodes deep instead of up to probe_A.  The syndromes do not depend
+    // on the attempt: a pass of its own (attempt == DDN_RS28_SYN) leaves those of every failed section in syn [n][28], and a probe
+    // thread starts from them - it never reads the code word (it only has to say whether the decode succeeds).
     // attempt >= 0 (the Phase 2 burst stage's ranked retries, p25p2_decode_facch_ranked()): this launch decodes with the first
     // n_fixed + attempt erasures of each list - attempt 0 every section, attempt a > 0 only the sections that have failed so far
     // and whose list (n_erasures = its full length) reaches that far; a failed decode leaves the payload as received, so every
@@ -1045,6 +1047,7 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
     __syncthreads();
     const long gid = (long)blockIdx.x * 64 + lane;
     const bool probe = probe_A > 0 && attempt == DDN_RS28_PROBE, fin = probe_A > 0 && attempt == DDN_RS28_FINAL;
+    const bool synp = probe_A > 0 && attempt == DDN_RS28_SYN;
     const int i = probe ? (int)(gid / probe_A) : (int)gid;
     if (i >= n || (probe && gid >= (long)n * probe_A)) {
         return;
@@ -1057,6 +1060,10 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         }
         if (n_fixed + attempt > (int)n_erasures[i]) {
             probe_res[gid] = -2;
+            return;
+        }
+    } else if (synp) {
+        if (status[i] >= 0) {
             return;
         }
     } else if (fin) {
@@ -1082,30 +1089,43 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
     const int first = kind == 0 ? 19 : (kind == 1 ? 9 : 5), pad = kind == 0 ? 19 : 0;
     uint8_t* pl = payload_bits + (size_t)i * n_data * 6;
     const uint8_t* pa = parity_bits + (size_t)i * n_par * 6;
-    for (int p = 0; p < 63; p++) {
-        int v = 0;
-        const uint8_t* q = nullptr;
-        if (p >= first && p < 35) {
-            q = pl + 6 * (p - first);
-        } else if (p >= 35 && p < 35 + n_par) {
-            q = pa + 6 * (p - 35);
-        }
-        if (q) {
-#pragma unroll
-            for (int b = 0; b < 6; b++) {
-                v = (v << 1) | (q[b] != 0);
-            }
-        }
-        Cw[p][lane] = (uint8_t)v;
-    }
     int any = 0;
-    for (int r = 0; r < R; r++) {
-        int v = 0;
-        for (int p = 0; p < 63; p++) {
-            v = gpow(v, r + 1) ^ Cw[p][lane];
+    if (probe) { // the section failed its plain decode: its syndromes are on file and not all zero
+        for (int r = 0; r < R; r++) {
+            Sy[r][lane] = syn[(size_t)i * R + r];
         }
-        Sy[r][lane] = (uint8_t)v;
-        any |= v;
+        any = 1;
+    } else {
+        for (int p = 0; p < 63; p++) {
+            int v = 0;
+            const uint8_t* q = nullptr;
+            if (p >= first && p < 35) {
+                q = pl + 6 * (p - first);
+            } else if (p >= 35 && p < 35 + n_par) {
+                q = pa + 6 * (p - 35);
+            }
+            if (q) {
+    #pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    v = (v << 1) | (q[b] != 0);
+                }
+            }
+            Cw[p][lane] = (uint8_t)v;
+        }
+        for (int r = 0; r < R; r++) {
+            int v = 0;
+            for (int p = 0; p < 63; p++) {
+                v = gpow(v, r + 1) ^ Cw[p][lane];
+            }
+            Sy[r][lane] = (uint8_t)v;
+            any |= v;
+        }
+    }
+    if (synp) {
+        for (int r = 0; r < R; r++) {
+            syn[(size_t)i * R + r] = Sy[r][lane];
+        }
+        return;
     }
     if (!any) {
         if (probe) {
@@ -1226,7 +1246,7 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
                 }
                 if (den == 0 || (num != 0 && loc < pad)) {
                     ok = false;
-                } else if (num != 0) {
+                } else if (num != 0 && !probe) {
                     Cw[loc][lane] ^= (uint8_t)gdiv(num, den);
                 }
             }
@@ -1270,19 +1290,22 @@ rs28_retries(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
     // already full) 3.1 -> 3.7 ms - so large batches of short lists keep the loop in the thread.
     if ((long)n * max_add > 400000 && max_add < 28) {
         hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
-                           status, 1, n_fixed, used_dynamic, max_add, 0, 0, (int32_t*)nullptr);
+                           status, 1, n_fixed, used_dynamic, max_add, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr);
         return hipGetLastError();
     }
     int32_t* res = nullptr;
-    hipError_t e = hipMallocAsync((void**)&res, (size_t)n * max_add * sizeof(int32_t), st);
+    hipError_t e = hipMallocAsync((void**)&res, (size_t)n * max_add * sizeof(int32_t) + (size_t)n * 28, st);
     if (e != hipSuccess) {
         return e;
     }
+    uint8_t* syn = (uint8_t*)(res + (size_t)n * max_add);
     const long pairs = (long)n * max_add;
-    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, DDN_RS28_PROBE, n_fixed, used_dynamic, 0, 0, max_add, res);
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, DDN_RS28_FINAL, n_fixed, used_dynamic, 0, 0, max_add, res);
+                       status, DDN_RS28_SYN, n_fixed, used_dynamic, 0, 0, max_add, res, syn);
+    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
+                       status, DDN_RS28_PROBE, n_fixed, used_dynamic, 0, 0, max_add, res, syn);
+    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
+                       status, DDN_RS28_FINAL, n_fixed, used_dynamic, 0, 0, max_add, res, syn);
     e = hipGetLastError();
     const hipError_t f = hipFreeAsync(res, st);
     return e != hipSuccess ? e : f;
@@ -1369,7 +1392,7 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures,
-                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr, -1, 0, 0, (int32_t*)nullptr);
+                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr, -1, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -1481,7 +1504,7 @@ ddn_dev_p25p2_ess(const uint8_t* payload_bits, const int16_t* payload_llr, const
                        used_dynamic);
     // the plain decode for every section (not taken when it located 15 symbols or more), then one launch for the retries
     hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 0, 0, used_dynamic, -1, 1, 0,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, (uint8_t*)nullptr);
     return rs28_retries(0, work, parity_bits, erasures28, n_total, n, status, 0, used_dynamic, 28, st);
 }
 
@@ -1660,7 +1683,7 @@ ddn_dev_p25p2_xcch(int kind, const uint8_t* bits360, const int16_t* llr360, int 
     // the decode with the fixed erasures for every burst, then the failed bursts' retries (most bursts of real traffic never get
     // there: those threads leave at once)
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind + 1, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, 0, n_fixed, used_dynamic, -1, 0, 0, (int32_t*)nullptr);
+                       status, 0, n_fixed, used_dynamic, -1, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr);
     return rs28_retries(kind + 1, payload_bits, parity_bits, erasures28, n_total, n, status, n_fixed, used_dynamic, max_add, st);
 }
 
