@@ -1008,19 +1008,19 @@ ddn_dev_rs63_soft(uint8_t* data6, const uint8_t* parity6, const uint8_t* data_re
 // the first.  A root count short of the degree, a zero derivative or a non-zero value inside the pad fails the decode (-1)
 // and leaves the section as received (the reference decodes a copy and copies back on a positive count only).
 // One section per thread, its polynomials in LDS columns.
-enum { DDN_RS28_PROBE = -3, DDN_RS28_FINAL = -4, DDN_RS28_SYN = -5 };
+enum { DDN_RS28_PROBE = -3, DDN_RS28_SYN = -5 };
 __global__ __launch_bounds__(64) void
 k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__ parity_bits,
        const int8_t* __restrict__ erasures, const uint8_t* __restrict__ n_erasures, int n, int32_t* __restrict__ status,
        int attempt, int n_fixed, uint8_t* __restrict__ used_dynamic, int loop_to, int ess_rule, int probe_A,
-       int32_t* __restrict__ probe_res, uint8_t* __restrict__ syn) {
+       int32_t* __restrict__ probe_res, uint8_t* __restrict__ syn, uint8_t* __restrict__ stage) {
     // probe_A > 0: the retries of a section are independent of each other (attempt a decodes the received block with the first
     // n_fixed + a erasures of the ranked list; the reference takes the first that succeeds), so they run side by side instead of
     // one after the other: the PROBE pass (attempt == DDN_RS28_PROBE) gives every (section, attempt 1 .. probe_A) pair a thread that
-    // only reports whether its decode succeeds, the FINAL pass (attempt == DDN_RS28_FINAL) decodes each failed section once more
-    // with the first attempt that did and writes the result - two decodes deep instead of up to probe_A.  The syndromes do not depend
-    // on the attempt: a pass of its own (attempt == DDN_RS28_SYN) leaves those of every failed section in syn [n][28], and a probe
-    // thread starts from them - it never reads the code word (it only has to say whether the decode succeeds).
+    // decodes on its own and leaves its verdict in probe_res and, when it succeeded, the corrected data symbols in stage
+    // [pair][n_data]; k_rs28_pick then takes, per failed section, the first attempt that succeeded - one decode deep instead of up to
+    // probe_A.  The syndromes do not depend on the attempt: a pass of its own (attempt == DDN_RS28_SYN) leaves those of every failed
+    // section in syn [n][28], and a probe thread starts from them - it reads the code word only when its decode reaches Forney's step.
     // attempt >= 0 (the Phase 2 burst stage's ranked retries, p25p2_decode_facch_ranked()): this launch decodes with the first
     // n_fixed + attempt erasures of each list - attempt 0 every section, attempt a > 0 only the sections that have failed so far
     // and whose list (n_erasures = its full length) reaches that far; a failed decode leaves the payload as received, so every
@@ -1046,7 +1046,7 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
     }
     __syncthreads();
     const long gid = (long)blockIdx.x * 64 + lane;
-    const bool probe = probe_A > 0 && attempt == DDN_RS28_PROBE, fin = probe_A > 0 && attempt == DDN_RS28_FINAL;
+    const bool probe = probe_A > 0 && attempt == DDN_RS28_PROBE;
     const bool synp = probe_A > 0 && attempt == DDN_RS28_SYN;
     const int i = probe ? (int)(gid / probe_A) : (int)gid;
     if (i >= n || (probe && gid >= (long)n * probe_A)) {
@@ -1066,18 +1066,6 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         if (status[i] >= 0) {
             return;
         }
-    } else if (fin) {
-        if (status[i] >= 0) {
-            return;
-        }
-        attempt = 0;
-        for (int k = 0; k < probe_A && attempt == 0; k++) {
-            attempt = probe_res[(long)i * probe_A + k] >= 0 ? k + 1 : 0;
-        }
-        if (attempt == 0) {
-            return; // every retry failed (or none was due): status stays the failed decode's -1, the payload as received
-        }
-        loop_to = attempt;
     }
     if (attempt > 0 && (status[i] >= 0 || n_fixed + attempt > (int)n_erasures[i])) {
         return;
@@ -1089,13 +1077,7 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
     const int first = kind == 0 ? 19 : (kind == 1 ? 9 : 5), pad = kind == 0 ? 19 : 0;
     uint8_t* pl = payload_bits + (size_t)i * n_data * 6;
     const uint8_t* pa = parity_bits + (size_t)i * n_par * 6;
-    int any = 0;
-    if (probe) { // the section failed its plain decode: its syndromes are on file and not all zero
-        for (int r = 0; r < R; r++) {
-            Sy[r][lane] = syn[(size_t)i * R + r];
-        }
-        any = 1;
-    } else {
+    auto load_cw = [&]() { // the block as received, one symbol per LDS row
         for (int p = 0; p < 63; p++) {
             int v = 0;
             const uint8_t* q = nullptr;
@@ -1105,13 +1087,22 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
                 q = pa + 6 * (p - 35);
             }
             if (q) {
-    #pragma unroll
+#pragma unroll
                 for (int b = 0; b < 6; b++) {
                     v = (v << 1) | (q[b] != 0);
                 }
             }
             Cw[p][lane] = (uint8_t)v;
         }
+    };
+    int any = 0;
+    if (probe) { // the section failed its plain decode: its syndromes are on file and not all zero
+        for (int r = 0; r < R; r++) {
+            Sy[r][lane] = syn[(size_t)i * R + r];
+        }
+        any = 1;
+    } else {
+        load_cw();
         for (int r = 0; r < R; r++) {
             int v = 0;
             for (int p = 0; p < 63; p++) {
@@ -1142,22 +1133,7 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
     int result = -1;
     for (int att = attempt;; att++) {
         if (att > attempt) { // a failed attempt may have touched the block: take it again as received
-            for (int p = 0; p < 63; p++) {
-                int v = 0;
-                const uint8_t* q = nullptr;
-                if (p >= first && p < 35) {
-                    q = pl + 6 * (p - first);
-                } else if (p >= 35 && p < 35 + n_par) {
-                    q = pa + 6 * (p - 35);
-                }
-                if (q) {
-#pragma unroll
-                    for (int b = 0; b < 6; b++) {
-                        v = (v << 1) | (q[b] != 0);
-                    }
-                }
-                Cw[p][lane] = (uint8_t)v;
-            }
+            load_cw();
         }
         int n_er = att >= 0 ? n_fixed + att : (n_erasures ? n_erasures[i] : 0);
         n_er = n_er > R ? R : n_er;
@@ -1235,6 +1211,9 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
             }
             const int top = (deg < R - 1 ? deg : R - 1) & ~1;
             bool ok = true;
+            if (probe) {
+                load_cw();
+            }
             for (int j = count - 1; j >= 0 && ok; j--) {
                 const int rt = Rt[j][lane], loc = rt - 1;
                 int num = 0, den = 0;
@@ -1246,7 +1225,7 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
                 }
                 if (den == 0 || (num != 0 && loc < pad)) {
                     ok = false;
-                } else if (num != 0 && !probe) {
+                } else if (num != 0) {
                     Cw[loc][lane] ^= (uint8_t)gdiv(num, den);
                 }
             }
@@ -1256,6 +1235,9 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
         } while (0);
         const bool rejected = ess_rule && att == 0 && result >= 15;
         if (result >= 0 && !rejected) {
+            for (int k = 0; k < (probe ? n_data : 0); k++) {
+                stage[(size_t)gid * n_data + k] = Cw[first + k][lane];
+            }
             for (int k = 0; k < (probe ? 0 : n_data); k++) {
                 const int v = Cw[first + k][lane];
 #pragma unroll
@@ -1280,32 +1262,67 @@ k_rs28(int kind, uint8_t* __restrict__ payload_bits, const uint8_t* __restrict__
     }
 }
 
-// the retries of every failed section side by side (see k_rs28): probe pass over (section, attempt) pairs, final pass per section
+// per failed section: the first attempt whose probe succeeded - its corrected data symbols become the payload, its count the status
+__global__ __launch_bounds__(256) void
+k_rs28_pick(int kind, uint8_t* __restrict__ payload_bits, int n, int32_t* __restrict__ status, uint8_t* __restrict__ used_dynamic, int probe_A,
+            const int32_t* __restrict__ probe_res, const uint8_t* __restrict__ stage) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || status[i] >= 0) {
+        return;
+    }
+    const int n_data = kind == 0 ? 16 : (kind == 1 ? 26 : 30);
+    for (int k = 0; k < probe_A; k++) {
+        const int r = probe_res[(long)i * probe_A + k];
+        if (r == -2) {
+            return; // the list ends here: every due retry failed, the payload stays as received
+        }
+        if (r >= 0) {
+            const uint8_t* sy = stage + ((size_t)i * probe_A + k) * n_data;
+            uint8_t* pl = payload_bits + (size_t)i * n_data * 6;
+            for (int d = 0; d < n_data; d++) {
+                const int v = sy[d];
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    pl[6 * d + b] = (uint8_t)((v >> (5 - b)) & 1);
+                }
+            }
+            status[i] = r;
+            if (used_dynamic) {
+                used_dynamic[i] = 1;
+            }
+            return;
+        }
+    }
+}
+
+// the retries of every failed section side by side (see k_rs28): syndromes on file, probe pass over (section, attempt) pairs, pick
 static hipError_t
 rs28_retries(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const int8_t* erasures28, const uint8_t* n_total, int n,
              int32_t* status, int n_fixed, uint8_t* used_dynamic, int max_add, hipStream_t st) {
     // Side by side costs more decodes in total (every due attempt of a failed section runs, not only those up to the first success)
-    // and buys depth: measured on one MI355X, 4096 channels x 6 groups of Phase 2 traffic (12 k - 20 k sections per call) 12.8 -> 8.0 ms
-    // and 65 536 ESS sections (lists up to 28 deep) 6.4 -> 4.8 ms, but 65 536 FACCH bursts (655 k pairs, lists 10 deep: the device is
-    // already full) 3.1 -> 3.7 ms - so large batches of short lists keep the loop in the thread.
-    if ((long)n * max_add > 400000 && max_add < 28) {
+    // and buys depth - a decode is ~0.5 ms deep for its thread however many run: measured on one MI355X, 4096 channels x 6 groups of
+    // Phase 2 traffic (12 k - 30 k sections per call) and 65 536 ESS sections (lists up to 28 deep) gain, 65 536 FACCH bursts (655 k
+    // pairs, lists 10 deep: the device is already full) lose - so very large batches of short lists keep the loop in the thread.
+    const long pairs = (long)n * max_add;
+    if (pairs > 600000 && max_add < 28) {
         hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
-                           status, 1, n_fixed, used_dynamic, max_add, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr);
+                           status, 1, n_fixed, used_dynamic, max_add, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr);
         return hipGetLastError();
     }
+    const int n_data = kind == 0 ? 16 : (kind == 1 ? 26 : 30);
     int32_t* res = nullptr;
-    hipError_t e = hipMallocAsync((void**)&res, (size_t)n * max_add * sizeof(int32_t) + (size_t)n * 28, st);
+    hipError_t e = hipMallocAsync((void**)&res, (size_t)pairs * sizeof(int32_t) + (size_t)n * 28 + (size_t)pairs * n_data, st);
     if (e != hipSuccess) {
         return e;
     }
-    uint8_t* syn = (uint8_t*)(res + (size_t)n * max_add);
-    const long pairs = (long)n * max_add;
+    uint8_t* syn = (uint8_t*)(res + pairs);
+    uint8_t* stage = syn + (size_t)n * 28;
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, DDN_RS28_SYN, n_fixed, used_dynamic, 0, 0, max_add, res, syn);
+                       status, DDN_RS28_SYN, n_fixed, used_dynamic, 0, 0, max_add, res, syn, stage);
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, DDN_RS28_PROBE, n_fixed, used_dynamic, 0, 0, max_add, res, syn);
-    hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, DDN_RS28_FINAL, n_fixed, used_dynamic, 0, 0, max_add, res, syn);
+                       status, DDN_RS28_PROBE, n_fixed, used_dynamic, 0, 0, max_add, res, syn, stage);
+    hipLaunchKernelGGL(k_rs28_pick, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kind, payload_bits, n, status, used_dynamic, max_add, res,
+                       stage);
     e = hipGetLastError();
     const hipError_t f = hipFreeAsync(res, st);
     return e != hipSuccess ? e : f;
@@ -1392,7 +1409,7 @@ ddn_dev_rs28(int kind, uint8_t* payload_bits, const uint8_t* parity_bits, const 
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind, payload_bits, parity_bits, erasures,
-                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr, -1, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr);
+                       n_erasures, n, status, -1, 0, (uint8_t*)nullptr, -1, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -1504,7 +1521,7 @@ ddn_dev_p25p2_ess(const uint8_t* payload_bits, const int16_t* payload_llr, const
                        used_dynamic);
     // the plain decode for every section (not taken when it located 15 symbols or more), then one launch for the retries
     hipLaunchKernelGGL(k_rs28, grid, blk, 0, st, 0, work, parity_bits, erasures28, n_total, n, status, 0, 0, used_dynamic, -1, 1, 0,
-                       (int32_t*)nullptr, (uint8_t*)nullptr);
+                       (int32_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr);
     return rs28_retries(0, work, parity_bits, erasures28, n_total, n, status, 0, used_dynamic, 28, st);
 }
 
@@ -1683,7 +1700,7 @@ ddn_dev_p25p2_xcch(int kind, const uint8_t* bits360, const int16_t* llr360, int 
     // the decode with the fixed erasures for every burst, then the failed bursts' retries (most bursts of real traffic never get
     // there: those threads leave at once)
     hipLaunchKernelGGL(k_rs28, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, kind + 1, payload_bits, parity_bits, erasures28, n_total, n,
-                       status, 0, n_fixed, used_dynamic, -1, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr);
+                       status, 0, n_fixed, used_dynamic, -1, 0, 0, (int32_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr);
     return rs28_retries(kind + 1, payload_bits, parity_bits, erasures28, n_total, n, status, n_fixed, used_dynamic, max_add, st);
 }
 

@@ -45,7 +45,7 @@ def test_xcch_large_batches_take_the_in_thread_retries_and_agree(built):
     """the retries run side by side for small batches and inside the thread for large ones of short lists (rs28_retries(),
     ddn_rs.hip): the same bursts through both routes give the same answers, which are the oracle's"""
     rng = np.random.default_rng(59 + FZ)
-    for kind, tiles in ((0, 88), (1, 56)):                      # 45 056 x 10 and 28 672 x 16 (section, attempt) pairs: beyond 400 k
+    for kind, tiles in ((0, 128), (1, 80)):                     # 65 536 x 10 and 40 960 x 16 (section, attempt) pairs: beyond 600 k
         u = 512
         bits, llr = np.zeros((u, 360), np.uint8), np.zeros((u, 360), np.int16)
         for i in range(u):
