@@ -64,6 +64,49 @@ struct Scratch {
         return hipSuccess;
     }
 };
+// The decoder classes of a call are independent of each other and each is a chain of latency-bound launches (an RS decode is ~0.5 ms
+// deep for its thread): FACCH, SACCH / LCCH and the voice bursts (with the ESS) run on three streams of the calling thread's own,
+// side by side, between the call's host wait and its last kernel.
+struct Aux {
+    hipStream_t s[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t done[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr;
+    bool ok = false;
+    Aux() {
+        ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 3; k++) {
+            ok = ok && hipStreamCreateWithFlags(&s[k], hipStreamNonBlocking) == hipSuccess
+                 && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
+        }
+    }
+    ~Aux() {
+        if (fork) {
+            (void)hipEventDestroy(fork);
+        }
+        for (int k = 0; k < 3; k++) {
+            if (done[k]) {
+                (void)hipEventDestroy(done[k]);
+            }
+            if (s[k]) {
+                (void)hipStreamDestroy(s[k]);
+            }
+        }
+    }
+};
+
+// an early return (error path) must not free the arenas under work still queued on the side streams
+struct AuxGuard {
+    Aux* a;
+    bool joined = false;
+    explicit AuxGuard(Aux* x) : a(x) {}
+    ~AuxGuard() {
+        if (a && !joined) {
+            for (int k = 0; k < 3; k++) {
+                (void)hipStreamSynchronize(a->s[k]);
+            }
+        }
+    }
+};
 } // namespace
 
 extern "C" int
@@ -112,14 +155,24 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
     HIP_TRY(hipStreamSynchronize(st));
     const int n_f = h_counts[0], n_s = h_counts[1], n_4v = h_counts[2], n_2v = h_counts[3];
     const int rows_per_channel = n_groups * 4;
+    static thread_local Aux aux;
+    Aux* ax = aux.ok ? &aux : nullptr;
     HIP_TRY(s.arena((size_t)(n_f + n_s) * (360 * 3 + 180 + 8) + (size_t)(n_4v + n_2v) * (360 * 3 + 768) + (size_t)n_2v * (96 * 4 + 168 * 3 + 8)
                     + 40 * 256));
+    AuxGuard guard(ax);
+    if (ax) { // the arena exists (in the caller's stream's order) before the side streams touch it
+        HIP_TRY(hipEventRecord(ax->fork, st));
+        for (int k = 0; k < 3; k++) {
+            HIP_TRY(hipStreamWaitEvent(ax->s[k], ax->fork, 0));
+        }
+    }
     // FACCH (class 0) and SACCH / LCCH (class 1) bursts
     for (int cls = 0; cls < 2; cls++) {
         const int cnt = cls == 0 ? n_f : n_s;
         if (cnt == 0) {
             continue;
         }
+        hipStream_t cs = ax ? ax->s[cls] : st;
         const int n_pl = cls == 0 ? 156 : 180;
         uint8_t *db, *pl, *used, *c12, *c16;
         int16_t* dl;
@@ -133,11 +186,11 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
         HIP_TRY(s.get(&ec, (size_t)cnt));
         const int32_t* lst = list + (size_t)cls * n_rows;
         HIP_TRY(ddn_dev_p2_gather(cls, cnt, lst, d_info, rb, rl, xb, xl, db, dl, ess_src, d_state, rows_per_channel, nullptr, nullptr, nullptr,
-                                  nullptr, st));
-        DDN_TRY(ddn_p25p2_xcch_batch(cls, db, dl, (size_t)cnt, threshold, pl, ec, used, st));
-        DDN_TRY(ddn_p25p2_mac_crc_batch(cls, pl, (size_t)cnt, c12, cls == 1 ? c16 : nullptr, st));
+                                  nullptr, cs));
+        DDN_TRY(ddn_p25p2_xcch_batch(cls, db, dl, (size_t)cnt, threshold, pl, ec, used, cs));
+        DDN_TRY(ddn_p25p2_mac_crc_batch(cls, pl, (size_t)cnt, c12, cls == 1 ? c16 : nullptr, cs));
         HIP_TRY(ddn_dev_p2_scatter(cls, cnt, lst, d_info, pl, n_pl, ec, used, c12, cls == 1 ? c16 : nullptr, nullptr, nullptr, 0, nullptr, d_payload,
-                                   d_ambe_fr, d_ambe_rel, d_ess, st));
+                                   d_ambe_fr, d_ambe_rel, d_ess, cs));
     }
     // 4V (class 2) and 2V (class 3) bursts; the 2V bursts' ESS
     for (int cls = 2; cls < 4; cls++) {
@@ -146,6 +199,7 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
             continue;
         }
         const int fc = cls == 2 ? 4 : 2;
+        hipStream_t cs = ax ? ax->s[2] : st;
         uint8_t *db, *fr, *rel, *e_pl = nullptr, *e_pa = nullptr, *e_out = nullptr, *e_used = nullptr;
         int16_t *dl, *e_pll = nullptr, *e_pal = nullptr;
         int32_t* e_ec = nullptr;
@@ -163,13 +217,20 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
             HIP_TRY(s.get(&e_ec, (size_t)cnt));
         }
         const int32_t* lst = list + (size_t)cls * n_rows;
-        HIP_TRY(ddn_dev_p2_gather(cls, cnt, lst, d_info, rb, rl, xb, xl, db, dl, ess_src, d_state, rows_per_channel, e_pl, e_pll, e_pa, e_pal, st));
-        DDN_TRY(ddn_p25p2_voice_frames_batch(db, dl, (size_t)cnt, fc, fr, rel, st));
+        HIP_TRY(ddn_dev_p2_gather(cls, cnt, lst, d_info, rb, rl, xb, xl, db, dl, ess_src, d_state, rows_per_channel, e_pl, e_pll, e_pa, e_pal, cs));
+        DDN_TRY(ddn_p25p2_voice_frames_batch(db, dl, (size_t)cnt, fc, fr, rel, cs));
         if (cls == 3) {
-            DDN_TRY(ddn_p25p2_ess_batch(e_pl, e_pll, e_pa, e_pal, (size_t)cnt, threshold, e_out, e_ec, e_used, st));
+            DDN_TRY(ddn_p25p2_ess_batch(e_pl, e_pll, e_pa, e_pal, (size_t)cnt, threshold, e_out, e_ec, e_used, cs));
         }
         HIP_TRY(ddn_dev_p2_scatter(cls, cnt, lst, d_info, nullptr, 0, e_ec, e_used, nullptr, nullptr, fr, rel, fc, e_out, d_payload, d_ambe_fr,
-                                   d_ambe_rel, d_ess, st));
+                                   d_ambe_rel, d_ess, cs));
+    }
+    if (ax) { // the caller's stream goes on behind the three
+        for (int k = 0; k < 3; k++) {
+            HIP_TRY(hipEventRecord(ax->done[k], ax->s[k]));
+            HIP_TRY(hipStreamWaitEvent(st, ax->done[k], 0));
+        }
+        guard.joined = true;
     }
     // the carried ESS-B fragments (after every gather that still reads the old ones)
     HIP_TRY(ddn_dev_p2_state_ess(final_src, xb, xl, n_channels, d_state, st));
