@@ -71,9 +71,11 @@ struct Aux {
     hipStream_t s[3] = {nullptr, nullptr, nullptr};
     hipEvent_t done[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
+    int32_t* counts = nullptr; // pinned: the decoder lists' lengths come back without a staging copy
     bool ok = false;
     Aux() {
-        ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+        ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess
+             && hipHostMalloc((void**)&counts, 4 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
         for (int k = 0; k < 3; k++) {
             ok = ok && hipStreamCreateWithFlags(&s[k], hipStreamNonBlocking) == hipSuccess
                  && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
@@ -82,6 +84,9 @@ struct Aux {
     ~Aux() {
         if (fork) {
             (void)hipEventDestroy(fork);
+        }
+        if (counts) {
+            (void)hipHostFree(counts);
         }
         for (int k = 0; k < 3; k++) {
             if (done[k]) {
@@ -149,14 +154,15 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
     // the sequencing pass: offsets, logical channels, actions, decoder lists
     HIP_TRY(ddn_dev_p2_sequence(duid, isch, n_channels, n_groups, d_groups_of, d_seed44, d_state, d_info, row_off, seq_of, counts, list, ess_src, final_src,
                                 st));
-    int32_t h_counts[4] = {0, 0, 0, 0};
+    static thread_local Aux aux;
+    Aux* ax = aux.ok ? &aux : nullptr;
+    int32_t stack_counts[4] = {0, 0, 0, 0};
+    int32_t* h_counts = ax ? ax->counts : stack_counts;
     HIP_TRY(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, st));
     DDN_TRY(ddn_p25p2_descramble_batch(rb, rl, seq, row_off, seq_of, n_rows, 360, 360, xb, xl, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int n_f = h_counts[0], n_s = h_counts[1], n_4v = h_counts[2], n_2v = h_counts[3];
     const int rows_per_channel = n_groups * 4;
-    static thread_local Aux aux;
-    Aux* ax = aux.ok ? &aux : nullptr;
     HIP_TRY(s.arena((size_t)(n_f + n_s) * (360 * 3 + 180 + 8) + (size_t)(n_4v + n_2v) * (360 * 3 + 768) + (size_t)n_2v * (96 * 4 + 168 * 3 + 8)
                     + 40 * 256));
     AuxGuard guard(ax);
