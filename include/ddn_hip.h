@@ -733,7 +733,8 @@ int ddn_p25p2_xcch_host(int kind, const uint8_t* bits360, const int16_t* llr360,
  *   d_ambe_fr / d_ambe_rel u8 [rows][4][4][24]   the 4 (4V) or 2 (2V) AMBE 3600x2450 frames = ddn_mbe_frame_decode_batch() input
  *   d_ess u8 [rows][96]             the ESS payload a 2V burst decoded (corrected when accepted)
  * Rows a decoder did not write keep what the caller put there (clear them once).  The call waits for the sequencing pass (one
- * hipStreamSynchronize on hip_stream: the decoders are launched over exact counts). */
+ * hipStreamSynchronize on hip_stream: the decoders are launched over exact counts); the decoders then run on three streams of the
+ * calling thread's own, and hip_stream continues behind them (results are in hip_stream's order as for any other call). */
 enum { DDN_P2_NONE = 0, DDN_P2_4V, DDN_P2_2V, DDN_P2_SACCH_S, DDN_P2_SACCH_C, DDN_P2_FACCH_C, DDN_P2_FACCH_S, DDN_P2_LCCH_C, DDN_P2_LCCH_S,
        DDN_P2_ERR, DDN_P2_NOSITE };
 typedef struct ddn_p25p2_seq_state {
