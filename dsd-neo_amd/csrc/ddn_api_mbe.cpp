@@ -35,10 +35,6 @@ struct ddn_mbe_batch {
     bool timing;
     hipEvent_t ev[3];
     float last_ms[2];
-    // large batches: the parameter kernel (one wavefront per talk path, frame after frame: latency) and the oscillator bank (one
-    // wavefront per frame: throughput) of different frame ranges run side by side - ranges of frames, synthesis on s_synth
-    hipStream_t s_synth;
-    hipEvent_t ev_rng, ev_done;
 };
 
 static int
@@ -85,16 +81,6 @@ mbe_free(ddn_mbe_batch* b) {
         if (b->ev[i]) {
             (void)hipEventDestroy(b->ev[i]);
         }
-    }
-    if (b->s_synth) {
-        (void)hipStreamSynchronize(b->s_synth);
-        (void)hipStreamDestroy(b->s_synth);
-    }
-    if (b->ev_rng) {
-        (void)hipEventDestroy(b->ev_rng);
-    }
-    if (b->ev_done) {
-        (void)hipEventDestroy(b->ev_done);
     }
 }
 
@@ -226,32 +212,12 @@ ddn_mbe_synth_batch(ddn_mbe_batch* b, const uint8_t* d_bits, const int32_t* d_re
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[0], st));
     }
-    const int nf = (int)n_frames;
-    if (!b->timing && nf >= 9 && b->n_streams >= 256) {
-        if (!b->s_synth) {
-            HIP_TRY(hipStreamCreateWithFlags(&b->s_synth, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_rng, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
-        }
-        const int ranges = 3;
-        for (int k = 0; k < ranges; k++) {
-            const int f0 = nf * k / ranges, f1 = nf * (k + 1) / ranges;
-            HIP_TRY(ddn_dev_mbe_params(b->codec, d_bits, d_result_in, b->n_streams, nf, f0, f1, b->d_tables, b->d_half_log2, b->d_streams,
-                                       b->tail_rule, b->d_recs, d_result_out, st));
-            HIP_TRY(hipEventRecord(b->ev_rng, st));
-            HIP_TRY(hipStreamWaitEvent(b->s_synth, b->ev_rng, 0));
-            HIP_TRY(ddn_dev_mbe_synth(b->d_recs, b->n_streams, nf, f0, f1, d_pcm, b->s_synth));
-        }
-        HIP_TRY(hipEventRecord(b->ev_done, b->s_synth));
-        HIP_TRY(hipStreamWaitEvent(st, b->ev_done, 0));
-        return DDN_OK;
-    }
-    HIP_TRY(ddn_dev_mbe_params(b->codec, d_bits, d_result_in, b->n_streams, nf, 0, nf, b->d_tables, b->d_half_log2,
+    HIP_TRY(ddn_dev_mbe_params(b->codec, d_bits, d_result_in, b->n_streams, (int)n_frames, b->d_tables, b->d_half_log2,
                                b->d_streams, b->tail_rule, b->d_recs, d_result_out, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[1], st));
     }
-    HIP_TRY(ddn_dev_mbe_synth(b->d_recs, b->n_streams, nf, 0, nf, d_pcm, st));
+    HIP_TRY(ddn_dev_mbe_synth(b->d_recs, (size_t)b->n_streams * n_frames, d_pcm, st));
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[2], st));
         HIP_TRY(hipEventSynchronize(b->ev[2]));

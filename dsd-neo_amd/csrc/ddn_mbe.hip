@@ -318,7 +318,7 @@ idct_term(const float* C, int J, int j) {
 
 template <int CODEC>
 __global__ __launch_bounds__(64) void
-k_mbe_params(const uint8_t* __restrict__ bits, const int32_t* __restrict__ res_in, int n_frames, int f_begin, int f_end,
+k_mbe_params(const uint8_t* __restrict__ bits, const int32_t* __restrict__ res_in, int n_frames,
              const ddn_mbe_tables* __restrict__ T, const float* __restrict__ half_log2, DdnMbeStream* __restrict__ streams,
              int tail_rule, DdnMbeFrameRec* __restrict__ recs, int32_t* __restrict__ res_out) {
     constexpr int NB = CODEC == DDN_MBE_IMBE_7200X4400 ? 88 : 49;
@@ -332,7 +332,7 @@ k_mbe_params(const uint8_t* __restrict__ bits, const int32_t* __restrict__ res_i
     uint32_t frame_no = st->frame_no;
     const uint32_t seed = st->seed;
 
-    for (int f = f_begin; f < f_end; f++) { // (a range of the call's frames: the history is carried in `streams` between launches)
+    for (int f = 0; f < n_frames; f++) {
         const size_t fi = (size_t)s * (size_t)n_frames + (size_t)f;
         const uint8_t* d = bits + fi * NB;
         int32_t r[5] = {0, 0, 0, 0, 0};
@@ -743,11 +743,9 @@ unvoiced_mix(float w0, float w0l, int l, int n, uint32_t base, uint32_t tag) {
 }
 
 __global__ __launch_bounds__(64) void
-k_mbe_synth(const DdnMbeFrameRec* __restrict__ recs, float* __restrict__ pcm, int n_frames, int f_begin, int f_count) {
-    // workgroup b = frame f_begin + b % f_count of talk path b / f_count, in the [talk path][n_frames] layout
-    const size_t at = (size_t)(blockIdx.x / (unsigned)f_count) * (size_t)n_frames + (size_t)f_begin + (size_t)(blockIdx.x % (unsigned)f_count);
-    const DdnMbeFrameRec* rec = recs + at;
-    float* out = pcm + at * 160;
+k_mbe_synth(const DdnMbeFrameRec* __restrict__ recs, float* __restrict__ pcm) {
+    const DdnMbeFrameRec* rec = recs + blockIdx.x;
+    float* out = pcm + (size_t)blockIdx.x * 160;
     const int lane = threadIdx.x;
     const int maxl = rec->maxl;
     float acc[3] = {0.0f, 0.0f, 0.0f};
@@ -881,30 +879,29 @@ ddn_dev_mbe_stream_init(DdnMbeStream* streams, int n_streams, uint32_t seed0, hi
 }
 
 extern "C" hipError_t
-ddn_dev_mbe_params(int codec, const uint8_t* bits, const int32_t* res_in, int n_streams, int n_frames, int f_begin, int f_end,
+ddn_dev_mbe_params(int codec, const uint8_t* bits, const int32_t* res_in, int n_streams, int n_frames,
                    const ddn_mbe_tables* d_tables, const float* d_half_log2, DdnMbeStream* streams, int tail_rule,
                    DdnMbeFrameRec* recs, int32_t* res_out, hipStream_t st) {
-    if (n_streams <= 0 || n_frames <= 0 || f_end <= f_begin) {
+    if (n_streams <= 0 || n_frames <= 0) {
         return hipSuccess;
     }
     const dim3 grid((unsigned)n_streams), blk(64);
     if (codec == DDN_MBE_IMBE_7200X4400) {
-        hipLaunchKernelGGL(k_mbe_params<DDN_MBE_IMBE_7200X4400>, grid, blk, 0, st, bits, res_in, n_frames, f_begin, f_end, d_tables,
+        hipLaunchKernelGGL(k_mbe_params<DDN_MBE_IMBE_7200X4400>, grid, blk, 0, st, bits, res_in, n_frames, d_tables,
                            d_half_log2, streams, tail_rule, recs, res_out);
     } else {
-        hipLaunchKernelGGL(k_mbe_params<DDN_MBE_AMBE_3600X2450>, grid, blk, 0, st, bits, res_in, n_frames, f_begin, f_end, d_tables,
+        hipLaunchKernelGGL(k_mbe_params<DDN_MBE_AMBE_3600X2450>, grid, blk, 0, st, bits, res_in, n_frames, d_tables,
                            d_half_log2, streams, tail_rule, recs, res_out);
     }
     return hipGetLastError();
 }
 
 extern "C" hipError_t
-ddn_dev_mbe_synth(const DdnMbeFrameRec* recs, int n_streams, int n_frames, int f_begin, int f_end, float* pcm, hipStream_t st) {
-    if (n_streams <= 0 || f_end <= f_begin) {
+ddn_dev_mbe_synth(const DdnMbeFrameRec* recs, size_t n_frames_total, float* pcm, hipStream_t st) {
+    if (n_frames_total == 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_mbe_synth, dim3((unsigned)((size_t)n_streams * (size_t)(f_end - f_begin))), dim3(64), 0, st, recs, pcm, n_frames, f_begin,
-                       f_end - f_begin);
+    hipLaunchKernelGGL(k_mbe_synth, dim3((unsigned)n_frames_total), dim3(64), 0, st, recs, pcm);
     return hipGetLastError();
 }
 

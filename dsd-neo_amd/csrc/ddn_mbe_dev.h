@@ -33,9 +33,9 @@ hipError_t ddn_dev_mbe_frame_decode(int codec, const uint8_t* frames, const uint
                                     int32_t* result, hipStream_t st);
 hipError_t ddn_dev_mbe_result_skip(const uint8_t* skip, size_t n, int32_t* result, hipStream_t st);
 hipError_t ddn_dev_mbe_stream_init(DdnMbeStream* streams, int n_streams, uint32_t seed0, hipStream_t st);
-hipError_t ddn_dev_mbe_params(int codec, const uint8_t* bits, const int32_t* res_in, int n_streams, int n_frames, int f_begin, int f_end,
+hipError_t ddn_dev_mbe_params(int codec, const uint8_t* bits, const int32_t* res_in, int n_streams, int n_frames,
                               const ddn_mbe_tables* d_tables, const float* d_half_log2, DdnMbeStream* streams,
                               int tail_rule, DdnMbeFrameRec* recs, int32_t* res_out, hipStream_t st);
-hipError_t ddn_dev_mbe_synth(const DdnMbeFrameRec* recs, int n_streams, int n_frames, int f_begin, int f_end, float* pcm, hipStream_t st);
+hipError_t ddn_dev_mbe_synth(const DdnMbeFrameRec* recs, size_t n_frames_total, float* pcm, hipStream_t st);
 }
 #endif
