@@ -147,36 +147,25 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
     HIP_TRY(s.get(&final_src, (size_t)n_channels * 8));
     HIP_TRY(s.get(&seq_of, n_rows));
     HIP_TRY(hipMemsetAsync(counts, 0, 16, st));
-    static thread_local Aux aux;
-    Aux* ax = aux.ok ? &aux : nullptr;
-    AuxGuard guard(ax);
     // timeslot rows, their DUID / I-ISCH, the channels' scrambler sequences
     HIP_TRY(ddn_dev_p2_rows(d_bits1400, d_llr1400, n_gr, rb, rl, st));
-    // (the channels' scrambler sequences depend on nothing but the seeds: beside the row / field / sequencing kernels, on a side stream)
-    if (ax) {
-        HIP_TRY(hipEventRecord(ax->fork, st));
-        HIP_TRY(hipStreamWaitEvent(ax->s[0], ax->fork, 0));
-        DDN_TRY(ddn_p25p2_scramble_bits_batch(d_seed44, (size_t)n_channels, 4320, seq, ax->s[0]));
-        HIP_TRY(hipEventRecord(ax->done[0], ax->s[0]));
-    } else {
-        DDN_TRY(ddn_p25p2_scramble_bits_batch(d_seed44, (size_t)n_channels, 4320, seq, st));
-    }
     DDN_TRY(ddn_p25p2_burst_fields_batch(rb, rl, n_rows, threshold, duid, isch, st));
+    DDN_TRY(ddn_p25p2_scramble_bits_batch(d_seed44, (size_t)n_channels, 4320, seq, st));
     // the sequencing pass: offsets, logical channels, actions, decoder lists
     HIP_TRY(ddn_dev_p2_sequence(duid, isch, n_channels, n_groups, d_groups_of, d_seed44, d_state, d_info, row_off, seq_of, counts, list, ess_src, final_src,
                                 st));
+    static thread_local Aux aux;
+    Aux* ax = aux.ok ? &aux : nullptr;
     int32_t stack_counts[4] = {0, 0, 0, 0};
     int32_t* h_counts = ax ? ax->counts : stack_counts;
     HIP_TRY(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, st));
-    if (ax) {
-        HIP_TRY(hipStreamWaitEvent(st, ax->done[0], 0));
-    }
     DDN_TRY(ddn_p25p2_descramble_batch(rb, rl, seq, row_off, seq_of, n_rows, 360, 360, xb, xl, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int n_f = h_counts[0], n_s = h_counts[1], n_4v = h_counts[2], n_2v = h_counts[3];
     const int rows_per_channel = n_groups * 4;
     HIP_TRY(s.arena((size_t)(n_f + n_s) * (360 * 3 + 180 + 8) + (size_t)(n_4v + n_2v) * (360 * 3 + 768) + (size_t)n_2v * (96 * 4 + 168 * 3 + 8)
                     + 40 * 256));
+    AuxGuard guard(ax);
     if (ax) { // the arena exists (in the caller's stream's order) before the side streams touch it
         HIP_TRY(hipEventRecord(ax->fork, st));
         for (int k = 0; k < 3; k++) {
