@@ -1363,7 +1363,8 @@ k_p2_xcch_gather(int kind, const uint8_t* __restrict__ bits360, const int16_t* _
     for (int p = 35 + n_pa / 6; p < 63; p++) {
         er[ne++] = (int8_t)p;
     }
-    uint16_t key[52]; // reliability << 8 | position: the order of sort_candidates()
+    __shared__ uint16_t keys[52][64]; // reliability << 8 | position: the order of sort_candidates(); a column per thread (64 per block)
+#define key(j) keys[j][threadIdx.x]
     int nc = 0;
     for (int part = 0; part < 2; part++) {
         const int nh = (part == 0 ? n_pl : n_pa) / 6;
@@ -1375,12 +1376,12 @@ k_p2_xcch_gather(int kind, const uint8_t* __restrict__ bits360, const int16_t* _
                 v = v > 255 ? 255 : v;
                 r = v < r ? v : r;
             }
-            key[nc++] = (uint16_t)((r << 8) | ((part == 0 ? first : 35) + hb));
+            key(nc++) = (uint16_t)((r << 8) | ((part == 0 ? first : 35) + hb));
         }
     }
     int add = 0;
     for (int k = 0; k < nc; k++) {
-        add += (key[k] >> 8) < threshold ? 1 : 0;
+        add += (key(k) >> 8) < threshold ? 1 : 0;
     }
     add = add < min_add ? min_add : add;
     add = add > max_add ? max_add : add;
@@ -1388,18 +1389,19 @@ k_p2_xcch_gather(int kind, const uint8_t* __restrict__ bits360, const int16_t* _
     for (int k = 0; k < add; k++) { // the `add` smallest keys, in order
         int best = k;
         for (int j = k + 1; j < nc; j++) {
-            best = key[j] < key[best] ? j : best;
+            best = key(j) < key(best) ? j : best;
         }
-        const uint16_t t = key[k];
-        key[k] = key[best];
-        key[best] = t;
-        er[ne++] = (int8_t)(key[k] & 0xFF);
+        const uint16_t t = key(k);
+        key(k) = key(best);
+        key(best) = t;
+        er[ne++] = (int8_t)(key(k) & 0xFF);
     }
     for (int k = ne; k < 28; k++) {
         er[k] = 0;
     }
     n_total[i] = (uint8_t)ne;
     used_dynamic[i] = 0;
+#undef key
 }
 
 extern "C" hipError_t
@@ -1476,7 +1478,8 @@ k_p2_ess_prepare(const uint8_t* __restrict__ payload_bits, const int16_t* __rest
     for (int k = 0; k < 96; k++) {
         work[(size_t)i * 96 + k] = payload_bits[(size_t)i * 96 + k] & 1;
     }
-    uint16_t key[44];
+    __shared__ uint16_t keys[44][64]; // a column per thread (64 per block)
+#define key(j) keys[j][threadIdx.x]
     int below = 0;
     for (int hb = 0; hb < 44; hb++) {
         const int16_t* l = hb < 16 ? payload_llr + (size_t)i * 96 + 6 * hb : parity_llr + (size_t)i * 168 + 6 * (hb - 16);
@@ -1487,7 +1490,7 @@ k_p2_ess_prepare(const uint8_t* __restrict__ payload_bits, const int16_t* __rest
             v = v > 255 ? 255 : v;
             r = v < r ? v : r;
         }
-        key[hb] = (uint16_t)((r << 8) | hb);
+        key(hb) = (uint16_t)((r << 8) | hb);
         below += r < threshold ? 1 : 0;
     }
     int cnt = below < 14 ? 14 : below;
@@ -1496,18 +1499,19 @@ k_p2_ess_prepare(const uint8_t* __restrict__ payload_bits, const int16_t* __rest
     for (int k = 0; k < cnt; k++) {
         int best = k;
         for (int j = k + 1; j < 44; j++) {
-            best = key[j] < key[best] ? j : best;
+            best = key(j) < key(best) ? j : best;
         }
-        const uint16_t t = key[k];
-        key[k] = key[best];
-        key[best] = t;
-        er[k] = (int8_t)(key[k] & 0xFF);
+        const uint16_t t = key(k);
+        key(k) = key(best);
+        key(best) = t;
+        er[k] = (int8_t)(key(k) & 0xFF);
     }
     for (int k = cnt; k < 28; k++) {
         er[k] = 0;
     }
     n_total[i] = (uint8_t)cnt;
     used_dynamic[i] = 0;
+#undef key
 }
 
 extern "C" hipError_t
