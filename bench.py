@@ -43,7 +43,26 @@ N_SAMPLES = 48000
 BLOCK = 8192
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s
 N_BASE = 64                  # distinct channels of each traffic kind
-RXW_TRAFFIC_BYTES = 2.799e9   # profiles/r04_bench_pmc_FETCH_SIZE.txt, _WRITE_SIZE.txt: 2 x 781 238 KB + 1 236 434 KB per launch of k_p25_rxw<8, true, 2>
+
+
+def rxw_traffic_from_profiles():
+    """HBM bytes per launch of the dominant kernel from the newest committed counter passes (profiles/rNN_bench_pmc_FETCH_SIZE.txt +
+    _WRITE_SIZE.txt, written by tools/prof_rNN.sh: separate rocprofv3 --pmc runs of this command on this shape).  rocprofv3 reports
+    both in KiB; gfx950 tallies a 128-B read request as 64 B (MI355X_MICROARCH.md, HBM), so FETCH_SIZE counts double.
+    -> (bytes or None, the files read)"""
+    import glob
+    import re
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_FETCH_SIZE.txt")), reverse=True):
+        w = f.replace("FETCH_SIZE", "WRITE_SIZE")
+        if not os.path.exists(w):
+            continue
+        vals = []
+        for path in (f, w):
+            m = [re.search(r"mean\s+([0-9.]+)", ln) for ln in open(path) if ln.startswith("k_p25_rxw")]
+            vals.append(float(m[0].group(1)) if m and m[0] else None)
+        if None not in vals:
+            return (2.0 * vals[0] + vals[1]) * 1024.0, [os.path.relpath(f, ROOT), os.path.relpath(w, ROOT)]
+    return None, []
 
 
 def make_base_traffic(n):
@@ -370,7 +389,9 @@ def main():
 
     # the CPU leg runs first: its worker pool forks, which must happen before this process holds a HIP context
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # (N > 1: rank 0 alone, before the process group forms - the other ranks wait in init_process_group meanwhile, blocked, not
+    # spinning; the CPU figure belongs in the same run as the GPU figure it is compared with)
+    if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(voice, ctrl, n)
 
     import torch
@@ -517,10 +538,12 @@ def main():
         # algorithmic bytes of one step: cu8 in, one 10-byte record per symbol out, 640 B per voice frame
         alg_bytes = 2.0 * B * n + 10.0 * n_sym + 640.0 * voice_frames
         dom_ms = float(rx_timed[1]) if rx_timed_n.value > 0 else float(rx_ms[1])
+        traffic, traffic_src = rxw_traffic_from_profiles()
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "I/Q Msamples/s end-to-end (demod->FEC->MBE) per GPU; % HBM roofline",
             "value": round(msps, 3),
+            "value_per_gpu": round(msps / world, 3),      # `value` is the whole-job aggregate the bench contract asks for
             "unit": "Msamples/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -558,7 +581,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # HBM bytes per launch of k_p25_rxw from separate rocprofv3 --pmc passes of this command on this shape
                          # (2 x FETCH_SIZE [gfx950 tallies 128-B requests as 64 B] + WRITE_SIZE, KB -> B; profiles/r04_bench_pmc_*.txt)
-                         "traffic": RXW_TRAFFIC_BYTES if (B == B_PER_GPU and n == N_SAMPLES) else None,
+                         "traffic": traffic if (B == B_PER_GPU and n == N_SAMPLES) else None, "traffic_source": traffic_src,
                          "algorithmic_bytes": alg_bytes, "bytes_per_sample": round(alg_bytes / (B * n), 3),
                          "launch_ms": round(dom_ms, 4), "launches_averaged": int(rx_timed_n.value),
                          "launch_ms_alone": round(float(rx_ms[1]), 4),   # the same kernel with nothing else on the device
@@ -577,6 +600,7 @@ def main():
                                             "all_results_ms_per_step": line["pcie_inclusive"]["ms_per_step"],
                                             "resident_ms_per_step": line["ms_per_step"]}
             line["vocoder_c5"] = vocoder_c5(torch, ddn, np, 10)
+            line["batch_sweep"] = batch_sweep(torch, ddn, np, d_iq, n, B, dt / args.steps * 1e3, dom_ms)
         if mixed is not None:
             line["configs3_mixed"] = mixed
         if cpu is not None:
@@ -588,6 +612,43 @@ def main():
     chain.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def batch_sweep(torch, ddn, np, d_iq, n, base_B, base_ms, base_loop_ms, steps=4):
+    """The same resident step at larger batches on ONE GPU (informational; `value` stays at BASELINE's 4096 channels): the receive
+    loop is a latency chain with 4 live lanes per recurrence wavefront at 4096 channels, so per-GPU throughput keeps rising with
+    the batch until the wavefronts are full - this is where it saturates, and what configs[3]'s 32 768 channels cost on one device."""
+    l = ddn.lib()
+    rows = [{"channels": base_B, "ms_per_step": round(base_ms, 3), "k_p25_rxw_ms": round(base_loop_ms, 3),
+             "Msamples_per_s": round(base_B * n / base_ms / 1e3, 1)}]
+    for mult in (2, 4, 8):
+        Bs = base_B * mult
+        try:
+            big = d_iq.repeat(mult, 1, 1).contiguous()
+            ch = ddn.P25ChainC(Bs, n, block_len=BLOCK)
+        except Exception as e:          # (an allocation that does not fit is reported, not hidden)
+            rows.append({"channels": Bs, "error": str(e)[:120]})
+            break
+        for _ in range(2):
+            ch.run_pipelined(big.data_ptr())
+        ch.wait()
+        l.ddn_p25_rx_set_timing(ch.rx, 1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ch.run_pipelined(big.data_ptr())
+        ch.wait()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        t2 = np.zeros(2, np.float32)
+        k = C.c_int(0)
+        l.ddn_p25_rx_get_timing_avg(ch.rx, t2.ctypes.data, C.byref(k))
+        l.ddn_p25_rx_set_timing(ch.rx, 0)
+        rows.append({"channels": Bs, "ms_per_step": round(ms, 3), "k_p25_rxw_ms": round(float(t2[1]), 3),
+                     "Msamples_per_s": round(Bs * n / ms / 1e3, 1)})
+        ch.close()
+        del big
+        torch.cuda.empty_cache()
+    return {"workload": "the headline step (same traffic tiled) at B = %s channels on one GPU, resident, %d pipelined steps each"
+                        % (", ".join(str(r["channels"]) for r in rows), steps), "rows": rows}
 
 
 def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, dev):

@@ -44,7 +44,7 @@ class ModeResult(C.Structure):  # == ddn_mode_result
 
 
 class DemodState(C.Structure):  # == struct demod_state of include/ddn_demod_adapter.h
-    _fields_ = [("lowpassed", C.POINTER(C.c_float)), ("lp_len", C.c_int), ("result", C.POINTER(C.c_float)), ("result_len", C.c_int),
+    _fields_ = [("result", C.c_float * (16 * 16384)), ("lowpassed", C.POINTER(C.c_float)), ("lp_len", C.c_int), ("result_len", C.c_int),
                 ("rate_in", C.c_int), ("rate_out", C.c_int), ("output_kind", C.c_int), ("symbol_rate_hz", C.c_int),
                 ("symbol_levels", C.c_int), ("channel_lpf_enable", C.c_int), ("channel_lpf_profile", C.c_int),
                 ("channel_squelch_level", C.c_float), ("cqpsk_enable", C.c_int), ("ted_enabled", C.c_int), ("ted_sps", C.c_int),

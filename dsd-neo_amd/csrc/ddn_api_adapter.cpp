@@ -59,7 +59,7 @@ full_demod(struct demod_state* s) {
         return;
     }
     s->result_len = 0;
-    if (!s->lowpassed || !s->result || s->lp_len < 2) {
+    if (!s->lowpassed || s->lp_len < 2) {
         return;
     }
     const int n = s->lp_len >> 1;

@@ -85,7 +85,9 @@ struct ddn_p25_chain {
     size_t iq_bytes;
     long step;
     int last_set;
-    hipStream_t user_stream; // the caller's stream of the last _run / _stage call (flush and wait order themselves behind it)
+    // the caller's stream of the last _run / _stage call is not kept (the caller may destroy it): an event recorded on it at the end of
+    // that call is what _wait and _flush order themselves behind
+    hipEvent_t ev_user = nullptr;
     int have_user_stream;
     // stage timing (ddn_p25_chain_set_timing): events at the stage boundaries of the most recent call
     int timing;
@@ -146,6 +148,9 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     if (c->ev_join) {
         (void)hipEventDestroy(c->ev_join);
     }
+    if (c->ev_user) {
+        (void)hipEventDestroy(c->ev_user);
+    }
     hipEvent_t evs[] = {c->ev_produced[0], c->ev_produced[1], c->ev_consumed[0], c->ev_consumed[1], c->ev_in[0], c->ev_in[1],
                         c->ev_in_free[0], c->ev_in_free[1], c->ev_out[0], c->ev_out[1], c->ev_loop[0], c->ev_loop[1], c->ev_t[0],
                         c->ev_t[1], c->ev_t[2], c->ev_t[3], c->ev_t[4], c->ev_t[5]};
@@ -178,7 +183,11 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
     c->E = cfg->max_events > 0 ? cfg->max_events : 4 * c->F;
     c->EL = c->E + 64; // + the decisions inside a carried tail
     c->PF = 2;         // data units per channel and call (a second's worth of calls rarely holds one)
-    c->PB = 8;         // data blocks per unit: header + 8 blocks = 57 + 9 * 101 symbols lie inside the carried tail's reach
+    // data blocks per unit: a sync decoded in this call is only guaranteed T symbols behind it, and data block b ends
+    // (56 + 98 b + 97) dibits + one status symbol per 35 - 23 symbols behind its sync: 839 for b = 7, 940 for b = 8.  With the default
+    // T = 896 the eighth block of a unit whose sync falls late in the scan range would lie beyond the call's records, so the
+    // default reads seven blocks per unit (a longer unit is flagged 8, as before); a carry of 941+ symbols reads eight.
+    c->PB = c->T >= 941 ? 8 : 7;
     int rc = DDN_OK;
     do {
         ddn_front_end_config fc = {c->B, 48000, 4800, 4, DDN_LPF_P25_C4FM, cfg->input_format, cfg->block_len, 0.0f};
@@ -242,7 +251,8 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
             || hipStreamCreateWithFlags(&c->s_copy2, hipStreamNonBlocking) != hipSuccess
             || hipStreamCreateWithFlags(&c->s_voice, hipStreamNonBlocking) != hipSuccess
             || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess
-            || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+            || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&c->ev_user, hipEventDisableTiming) != hipSuccess) {
             rc = DDN_EHIP;
             break;
         }
@@ -377,6 +387,20 @@ chain_issue_pending(ddn_p25_chain* c, hipEvent_t beside) {
     DDN_TRY(chain_copy_out(c, &c->pending_out, set));
     HIP_TRY(hipEventRecord(c->ev_out[set], c->s_copy2));
     c->have_pending = 0;
+    return DDN_OK;
+}
+
+// A device-form call (_run, _run_pipelined, _stage) after a _run_host call whose results have not left yet: the decode buffers are
+// single (d_nid, d_tsbk, d_cnt_full, d_pcm ...), so that call's result copies are issued now and stream `st` - the one the next
+// decode will run on - waits for them.
+static int
+chain_settle_pending(ddn_p25_chain* c, hipStream_t st) {
+    if (!c->have_pending) {
+        return DDN_OK;
+    }
+    const int set = c->pending_set;
+    DDN_TRY(chain_issue_pending(c, nullptr));
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_out[set], 0));
     return DDN_OK;
 }
 
@@ -515,11 +539,12 @@ ddn_p25_chain_run(ddn_p25_chain* c, const void* d_iq, void* hip_stream) {
         return DDN_EINVAL;
     }
     hipStream_t st = (hipStream_t)hip_stream;
-    c->user_stream = st;
-    c->have_user_stream = 1;
+    DDN_TRY(chain_settle_pending(c, st));
     const int cur = (int)(c->step & 1);
     DDN_TRY(chain_receive(c, d_iq, cur, st));
     DDN_TRY(chain_decode(c, cur, 0, st));
+    HIP_TRY(hipEventRecord(c->ev_user, st));
+    c->have_user_stream = 1;
     c->last_set = cur;
     c->step++;
     return DDN_OK;
@@ -532,19 +557,26 @@ ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip_str
         return DDN_EINVAL;
     }
     hipStream_t st = (hipStream_t)hip_stream;
-    c->user_stream = st;
-    c->have_user_stream = 1;
     const int cur = (int)(c->step & 1);
+    int rc = DDN_OK;
     if (stage == 0) {
-        return chain_front(c, d_iq, cur, st);
+        DDN_TRY(chain_settle_pending(c, st));
+        rc = chain_front(c, d_iq, cur, st);
+    } else if (stage == 1) {
+        rc = chain_loop(c, cur, st);
+    } else {
+        DDN_TRY(chain_settle_pending(c, st)); // (a no-op after a stage 0 of the same step)
+        rc = chain_decode(c, cur, 0, st);
+        if (rc == DDN_OK) {
+            c->last_set = cur;
+            c->step++;
+        }
     }
-    if (stage == 1) {
-        return chain_loop(c, cur, st);
+    if (rc == DDN_OK) {
+        HIP_TRY(hipEventRecord(c->ev_user, st));
+        c->have_user_stream = 1;
     }
-    DDN_TRY(chain_decode(c, cur, 0, st));
-    c->last_set = cur;
-    c->step++;
-    return DDN_OK;
+    return rc;
 }
 
 extern "C" int
@@ -552,6 +584,7 @@ ddn_p25_chain_run_pipelined(ddn_p25_chain* c, const void* d_iq) {
     if (!c || !d_iq) {
         return DDN_EINVAL;
     }
+    DDN_TRY(chain_settle_pending(c, c->s_aux));
     const int cur = (int)(c->step & 1);
     if (c->step >= 2) { // the decode of call k - 2 has read this set (and call k - 1's decode has read its carried tail source)
         HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_consumed[cur], 0));
@@ -671,7 +704,7 @@ ddn_p25_chain_wait(ddn_p25_chain* c) {
     }
     DDN_TRY(chain_issue_pending(c, nullptr));
     if (c->have_user_stream) {
-        HIP_TRY(hipStreamSynchronize(c->user_stream));
+        HIP_TRY(hipEventSynchronize(c->ev_user));
     }
     HIP_TRY(hipStreamSynchronize(c->s_main));
     HIP_TRY(hipStreamSynchronize(c->s_aux));

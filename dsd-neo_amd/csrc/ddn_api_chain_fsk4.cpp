@@ -543,19 +543,23 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
             }
         }
         int cpw_d = cpw, cpw_n = cpw;
-        if (const char* e = getenv("DDN_MIX_CPW_DMR")) { // (experiments)
-            cpw_d = atoi(e);
-        }
-        if (const char* e = getenv("DDN_MIX_CPW_NXDN")) {
-            cpw_n = atoi(e);
-        }
+        // (experiments: values the setters reject are ignored, not passed on)
+        auto pow2_1_32 = [](const char* e, int dflt) {
+            const int v = e ? atoi(e) : 0;
+            return (v >= 1 && v <= 32 && (v & (v - 1)) == 0) ? v : dflt;
+        };
+        cpw_d = pow2_1_32(getenv("DDN_MIX_CPW_DMR"), cpw_d);
+        cpw_n = pow2_1_32(getenv("DDN_MIX_CPW_NXDN"), cpw_n);
         // Residency decides the step: a CU holds 8 of these wavefronts (~200 registers each).  At 4096 channels in thirds the P25
         // loop's own choice (4 channels per workgroup of 4 waves: 342 workgroups) + 2 x 342 two-wave workgroups are 2736 waves for
         // 2048 places - the loop launched last waits for the first to finish (measured: NXDN48 loop 9 ms, step 15.1 ms).  With 8
         // channels per P25 workgroup it is 2052 waves: step 14.2 ms.
         int cpw_p = (total > 2048 && (m->dmr || m->nxdn)) ? 8 : 0;
         if (const char* e = getenv("DDN_MIX_CPW_P25")) {
-            cpw_p = atoi(e);
+            const int v = atoi(e);
+            if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) {
+                cpw_p = v;
+            }
         }
         if (rc == DDN_OK && m->p25 && cpw_p) {
             rc = ddn_p25_rx_set_channels_per_wave((ddn_p25_rx*)ddn_p25_chain_rx(m->p25), cpw_p);

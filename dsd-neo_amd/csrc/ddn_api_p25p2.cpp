@@ -3,6 +3,8 @@
 // sequencing pass of ddn_p25p2_seq.hip; nothing here computes on the CPU.
 #include <hip/hip_runtime.h>
 
+#include <new>
+
 #include <cstdint>
 
 #include "ddn_device.h"
@@ -67,6 +69,7 @@ struct Scratch {
 // The decoder classes of a call are independent of each other and each is a chain of latency-bound launches (an RS decode is ~0.5 ms
 // deep for its thread): FACCH, SACCH / LCCH and the voice bursts (with the ESS) run on three streams of the calling thread's own,
 // side by side, between the call's host wait and its last kernel.
+// They belong to ONE device: a host thread that drives several GPUs gets one set per device (aux_for_current_device).
 struct Aux {
     hipStream_t s[3] = {nullptr, nullptr, nullptr};
     hipEvent_t done[3] = {nullptr, nullptr, nullptr};
@@ -81,23 +84,23 @@ struct Aux {
                  && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
         }
     }
-    ~Aux() {
-        if (fork) {
-            (void)hipEventDestroy(fork);
-        }
-        if (counts) {
-            (void)hipHostFree(counts);
-        }
-        for (int k = 0; k < 3; k++) {
-            if (done[k]) {
-                (void)hipEventDestroy(done[k]);
-            }
-            if (s[k]) {
-                (void)hipStreamDestroy(s[k]);
-            }
-        }
-    }
+    // no destructor: the objects live as long as the thread's first use of a device and are deliberately left to the runtime's own
+    // teardown (a thread-exit destructor could run after the HIP runtime is gone)
 };
+
+static Aux*
+aux_for_current_device() {
+    enum { MAX_DEV = 64 };
+    static thread_local Aux* per_dev[MAX_DEV] = {nullptr};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+        return nullptr; // the single-stream path
+    }
+    if (!per_dev[dev]) {
+        per_dev[dev] = new (std::nothrow) Aux(); // created with `dev` current: its streams and events are that device's
+    }
+    return (per_dev[dev] && per_dev[dev]->ok) ? per_dev[dev] : nullptr;
+}
 
 // an early return (error path) must not free the arenas under work still queued on the side streams
 struct AuxGuard {
@@ -154,8 +157,7 @@ ddn_p25p2_groups_batch(const uint8_t* d_bits1400, const int16_t* d_llr1400, int 
     // the sequencing pass: offsets, logical channels, actions, decoder lists
     HIP_TRY(ddn_dev_p2_sequence(duid, isch, n_channels, n_groups, d_groups_of, d_seed44, d_state, d_info, row_off, seq_of, counts, list, ess_src, final_src,
                                 st));
-    static thread_local Aux aux;
-    Aux* ax = aux.ok ? &aux : nullptr;
+    Aux* ax = aux_for_current_device();
     int32_t stack_counts[4] = {0, 0, 0, 0};
     int32_t* h_counts = ax ? ax->counts : stack_counts;
     HIP_TRY(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, st));

@@ -234,8 +234,11 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
             break;
         }
     }
-    if (const char* e = getenv("DDN_RX4_CPW")) {
-        b->channels_per_wave = atoi(e);
+    if (const char* e = getenv("DDN_RX4_CPW")) { // (experiments; the same values ddn_fsk4_rx_set_channels_per_wave accepts)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) {
+            b->channels_per_wave = v;
+        }
     }
     std::vector<int32_t> lock(B * 4);
     for (size_t c = 0; c < B; c++) {

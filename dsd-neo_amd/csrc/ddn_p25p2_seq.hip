@@ -69,8 +69,10 @@ k_p2_sequence(const int32_t* __restrict__ duid, const int32_t* __restrict__ isch
     const uint64_t seed = seed44[c];
     const uint32_t wacn = (uint32_t)((seed >> 24) & 0xFFFFF), sysid = (uint32_t)((seed >> 12) & 0xFFF), cc = (uint32_t)(seed & 0xFFF);
     const bool valid = wacn != 0 && cc != 0 && sysid != 0 && wacn != 0xFFFFF && cc != 0xFFF && sysid != 0xFFF;
-    int off = state[c].offset;
-    int fourv[2] = {state[c].fourv[0], state[c].fourv[1]};
+    // the carried state is the caller's memory: a stale or never-initialised block must not index out of the private arrays below
+    // (offsets the I-ISCH rule can produce are 0..12; the 4V counter runs 0..3)
+    int off = min(max(state[c].offset, 0), 12);
+    int fourv[2] = {state[c].fourv[0] & 3, state[c].fourv[1] & 3};
     int src[2][4];                                            // where each ESS-B fragment lives: row >= 0, -1 zeros, -2 - j carried fragment j
     for (int s = 0; s < 2; s++) {
         for (int j = 0; j < 4; j++) {
@@ -107,7 +109,7 @@ k_p2_sequence(const int32_t* __restrict__ duid, const int32_t* __restrict__ isch
                 }
             }
         }
-        int slot = off % 2;
+        int slot = (off % 2) != 0 ? 1 : 0; // any non-zero remainder is slot 1 (p25p2_frame.c:1774-1779)
         int errs = 0;
         bool dead = false;
         for (int ts = 0; ts < 4; ts++) {

@@ -19,10 +19,21 @@ extern "C" {
 
 enum { DSD_DEMOD_OUTPUT_AUDIO_MONITOR = 0, DSD_DEMOD_OUTPUT_FSK_DISCRIMINATOR = 1, DSD_DEMOD_OUTPUT_SYMBOL_CQPSK = 2 };
 
+/* the reference's own sizing (include/dsd-neo/dsp/demod_state.h:28-30) */
+#ifndef MAXIMUM_BUF_LENGTH
+#define DEFAULT_BUF_LENGTH 16384
+#define MAXIMUM_OVERSAMPLE 16
+#define MAXIMUM_BUF_LENGTH (MAXIMUM_OVERSAMPLE * DEFAULT_BUF_LENGTH)
+#endif
+
 struct demod_state {
+    /* out: discriminator samples / CQPSK symbols.  An in-struct array as in the reference (demod_state.h:78), so a test that reads
+     * s->result[i] after full_demod(s) needs no allocation of its own (1 MB: allocate the struct on the heap or statically, as the
+     * reference's callers do).  The member ORDER and the struct's size are still not the reference's: source-compatible for the
+     * members below, not ABI-compatible. */
+    float result[MAXIMUM_BUF_LENGTH];
     float* lowpassed;  /* in: interleaved I/Q floats of one block (op25_gardner_cc: also out, the symbols) */
     int lp_len;        /* floats in lowpassed (2 per complex sample) */
-    float* result;     /* out: discriminator samples / CQPSK symbols; the caller provides at least lp_len / 2 floats */
     int result_len;
     int rate_in, rate_out;                     /* demod sample rate (rate_out is what the modem / loops are configured with) */
     int output_kind;                           /* DSD_DEMOD_OUTPUT_* */

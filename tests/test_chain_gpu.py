@@ -259,6 +259,64 @@ def test_run_host_copies_back_what_the_device_holds(built):
         l.ddn_host_free_pinned(p)
 
 
+def test_run_host_then_device_form_keeps_the_host_results(built):
+    """A _run_host call defers its result copies; a device-form call right behind it (no _wait in between) must not decode over the
+    single decode buffers before those copies have left: host buffers = what a run of the same stream with a _wait after every
+    call delivers for that call (NIDs, TSDU blocks, counts, PCM, records)"""
+    l = ddn.lib()
+    B, n_call = 4, 16384
+    iq = _stream(B, n_call * 3)
+    parts = [np.ascontiguousarray(iq[:, k * n_call:(k + 1) * n_call]) for k in range(3)]
+
+    def host_bufs(ch):
+        S, V, st = B * ch.F, B * ch.Fv * 9, ch.stride
+        shapes = {"records10": (np.uint8, (B, st, 10)), "counts": (np.int32, (B,)), "nid4": (np.int32, (S, 4)),
+                  "tsbk": (np.uint8, (3, S, 12)), "pcm": (np.float32, (V, 160))}
+        o, v, pins = ddn.P25ChainHostOut(), {}, []
+        for name, (dt, shp) in shapes.items():
+            nbytes = int(np.prod(shp)) * np.dtype(dt).itemsize
+            p = C.c_void_p()
+            assert l.ddn_host_alloc_pinned(nbytes, C.byref(p)) == 0
+            pins.append(p)
+            setattr(o, name, p.value)
+            v[name] = np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=dt).reshape(shp)
+        return o, v, pins
+
+    def pin_iq(part):
+        p = C.c_void_p()
+        assert l.ddn_host_alloc_pinned(part.nbytes, C.byref(p)) == 0
+        C.memmove(p, part.ctypes.data, part.nbytes)
+        return p
+
+    results = {}
+    for how in ("waited", "pipelined", "run", "stage"):
+        ch = ddn.P25ChainC(B, n_call)
+        o, v, pins = host_bufs(ch)
+        h0, h1 = pin_iq(parts[0]), pin_iq(parts[1])
+        ch.run_host(h0, None)
+        ch.run_host(h1, o)                       # call 1: the results this test is about
+        d2 = _upload(parts[2])
+        if how == "waited":
+            ch.wait()
+        if how in ("waited", "pipelined"):
+            ch.run_pipelined(d2)
+        elif how == "run":
+            ch.run(d2)
+        else:
+            for stage in range(3):
+                assert l.ddn_p25_chain_stage(ch.h, stage, d2 if stage == 0 else None, None) == 0
+        ch.wait()
+        results[how] = {k: a.copy() for k, a in v.items()}
+        ch.close()
+        l.ddn_device_free(d2)
+        for p in pins + [h0, h1]:
+            l.ddn_host_free_pinned(p)
+    assert float(np.abs(results["waited"]["pcm"]).sum()) > 0
+    for how in ("pipelined", "run", "stage"):
+        for k, a in results["waited"].items():
+            assert np.array_equal(a.view(np.uint8), results[how][k].view(np.uint8)), (how, k)
+
+
 def test_data_units_header_blocks_and_crc32(built):
     """P25 data units (DUID 0xC, processMPDU): the chain files every unit of a call - header as the loop decoded it, the data blocks
     behind it through the half-rate trellis (best path, p25p1_mdpu.c:263-273), CRC32 over the data (crc32mbf) - and follows the

@@ -117,3 +117,44 @@ def test_mixed_chain_at_the_per_gpu_share_of_configs3(built):
     assert par["bit_exact"] is True and par["channels_checked"] == 6, par
     assert par["dmr_colour_code_0_csbk_bptc_clean"] is True and par["nxdn_lich_parity_and_sacch_crc"] is True, par
     assert out["work_per_step"]["dmr_syncs"] > 1365 * 20 and out["work_per_step"]["nxdn_syncs"] > 1365 * 5, out["work_per_step"]
+
+
+def test_gardner_full_c2_shape_properties(built):
+    """BASELINE configs[1]'s Gardner leg at its full shape: 4096 channels x 48000 complex samples (sps 10) through ddn_gardner_run in
+    ONE call.  Size-independent properties over the whole batch - every count within the loop's bounds, every symbol finite, the
+    same bits after a reset (determinism), tiled channels identical to their source channel - and a sample of channels bit-exact
+    against the oracle (pinned to the compiled costas.cpp)."""
+    import ctypes as C
+    import torch
+    import ddn
+    import orc
+    l = ddn.lib()
+    B, sps, n, base = 4096, 10, 48000, 16
+    iq1 = np.ascontiguousarray(orc.synth_qpsk_f32(9, base, 4900, sps, noise=0.05)[:, :n])
+    assert iq1.shape[1] == n
+    d_iq = torch.from_numpy(iq1).cuda().repeat(B // base, 1, 1).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    stride = n // sps + 64
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    outs = []
+    for rep in range(2):            # two fresh batch objects = the determinism check (a fresh object is a reset state)
+        h = C.c_void_p()
+        assert l.ddn_ted_batch_create(B, sps, 4800, 0.0, C.byref(h)) == 0
+        d_sym = torch.zeros((B, stride, 2), dtype=torch.float32, device="cuda")
+        assert l.ddn_gardner_run(h, d_iq.data_ptr(), n, d_sym.data_ptr(), stride, d_cnt.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        outs.append((d_sym, d_cnt.clone()))
+        l.ddn_ted_batch_destroy(h)
+    (sym, cnt), (sym2, cnt2) = outs
+    assert torch.equal(cnt, cnt2) and torch.equal(sym.view(torch.int32), sym2.view(torch.int32))
+    assert int(cnt.min()) >= n // sps - 60 and int(cnt.max()) <= n // sps + 60
+    assert bool(torch.isfinite(sym).all())
+    # channel c carries source channel c % base
+    tiled = sym.view(B // base, base, stride, 2)
+    assert torch.equal(tiled.view(torch.int32), tiled[:1].expand_as(tiled).contiguous().view(torch.int32))
+    for c in (0, 5, base - 1, 2048 + 3, B - 1):
+        want = orc.OracleTed(sps, 4800).block(iq1[c % base])
+        k = int(cnt[c])
+        assert k == len(want), (c, k, len(want))
+        got = sym[c, :k].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32)), c
