@@ -832,9 +832,9 @@ def pcie_inclusive(torch, ddn, chain, d_iq, B, n):
     for p in h_iq:
         assert l.ddn_device_download(p, d_iq.data_ptr(), iq_bytes) == 0
 
-    def run(sizes, steps=6):
+    def run(sizes, steps=12):
         outs = []
-        for _ in range(2):
+        for _ in range(3):          # three output sets used in turn (include/ddn_chain.h: call k's results are complete when call k + 3 returns)
             o = ddn.P25ChainHostOut()
             for k, nb in sizes.items():
                 setattr(o, k, pin(nb).value)
@@ -842,21 +842,23 @@ def pcie_inclusive(torch, ddn, chain, d_iq, B, n):
                 o.pcm_dense_frames = dense_frames
             outs.append(o)
         for k in range(3):
-            chain.run_host(h_iq[k & 1], outs[k & 1])
+            chain.run_host(h_iq[k & 1], outs[k % 3])
         chain.wait()
         t0 = time.perf_counter()
         for k in range(steps):
-            chain.run_host(h_iq[(k + 1) & 1], outs[(k + 1) & 1])
+            chain.run_host(h_iq[(k + 1) & 1], outs[k % 3])
         chain.wait()
         t = (time.perf_counter() - t0) / steps
         moved = iq_bytes + sum(sizes.values())
         return {"ms_per_step": round(t * 1e3, 3), "Msamples_per_s": round(B * n / t / 1e6, 1), "bytes_over_pcie": moved,
                 "GB_per_s_over_pcie": round(moved / t / 1e9, 1)}
     out = run(full)
-    out["note"] = ("pinned host I/Q in; records + flags + counts + handler decisions + NIDs + TSDU blocks + PCM out; copies on two copy "
-                   "streams beside the kernels (ddn_p25_chain_run_host), steady state over 6 steps.  The H2D copies are SDMA "
-                   "transfers; the D2H copies are shader kernels on this ROCm: a call's results are released when the NEXT call's "
-                   "receive loop starts and leave beside it (DESIGN 6)")
+    out["d2h_route"] = "0x%x" % l.ddn_p25_chain_d2h_route(chain.h)
+    out["note"] = ("pinned host I/Q in; records + flags + counts + handler decisions + NIDs + TSDU blocks + PCM out (ddn_p25_chain_run_host), "
+                   "12 steps between two waits (the drain of the last results included).  H2D: hipMemcpyAsync on a copy stream (an SDMA "
+                   "engine); D2H: d2h_route != 0x0 = an SDMA engine driven below HIP (hsa_amd_memory_async_copy_on_engine, the engine bit "
+                   "shown) from a worker thread that waits for the call's decode - runs beside any kernel and duplex with the input copy; "
+                   "0x0 = hipMemcpyAsync (shader blit kernels on this ROCm).  Three device-side buffer sets, three host output sets in turn")
     out["compact"] = run(compact)
     out["compact"]["note"] = ("the same with the records as {dibit | flags << 2, reliability} pairs (records2) instead of records10 + flags "
                               "and the synthesized PCM frames dense (pcm_dense / pcm_slot / pcm_count, host capacity a third of the slots) "

@@ -504,6 +504,7 @@ class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config
 
 PROTOTYPES.update({
     "ddn_p25_chain_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_p25_chain_d2h_route": (C.c_int, [C.c_void_p]),
     "ddn_p25p2_mac_crc_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_mac_crc_host": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_ess_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -227,6 +227,46 @@ ddn_mbe_synth_batch(ddn_mbe_batch* b, const uint8_t* d_bits, const int32_t* d_re
     return DDN_OK;
 }
 
+// internal (ddn_internal.h): the two kernels of ddn_mbe_synth_batch as separate calls - the chain object runs the parameter kernel
+// (one wave per talk path, latency-bound, wants occupancy) ahead of the next call's receive loop and the synthesis kernel (16
+// registers, no LDS, throughput-bound) beside it.  Same order on one stream = ddn_mbe_synth_batch.
+extern "C" int
+ddn_mbe_params_only(ddn_mbe_batch* b, const uint8_t* d_bits, const int32_t* d_result_in, size_t n_frames, int32_t* d_result_out,
+                    void* hip_stream) {
+    if (!b || (n_frames && !d_bits) || n_frames > (size_t)1 << 24) {
+        ddn_set_error("ddn_mbe_params_only: bad argument");
+        return DDN_EINVAL;
+    }
+    if (n_frames == 0) {
+        return DDN_OK;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (b->rec_frames < n_frames) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(b->d_recs);
+        b->d_recs = nullptr;
+        b->rec_frames = 0;
+        HIP_TRY(hipMalloc(&b->d_recs, sizeof(DdnMbeFrameRec) * (size_t)b->n_streams * n_frames));
+        b->rec_frames = n_frames;
+    }
+    HIP_TRY(ddn_dev_mbe_params(b->codec, d_bits, d_result_in, b->n_streams, (int)n_frames, b->d_tables, b->d_half_log2, b->d_streams,
+                               b->tail_rule, b->d_recs, d_result_out, st));
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_mbe_synth_only(ddn_mbe_batch* b, size_t n_frames, float* d_pcm, void* hip_stream) {
+    if (!b || (n_frames && !d_pcm) || n_frames > b->rec_frames) {
+        ddn_set_error("ddn_mbe_synth_only: bad argument");
+        return DDN_EINVAL;
+    }
+    if (n_frames == 0) {
+        return DDN_OK;
+    }
+    HIP_TRY(ddn_dev_mbe_synth(b->d_recs, (size_t)b->n_streams * n_frames, d_pcm, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
 extern "C" int
 ddn_mbe_batch_set_timing(ddn_mbe_batch* b, int enable) {
     if (!b) {

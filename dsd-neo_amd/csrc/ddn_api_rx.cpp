@@ -46,6 +46,7 @@ struct ddn_p25_rx {
     // without synchronising between launches (ddn_p25_rx_get_timing_avg)
     hipEvent_t ring[64][3];
     int ring_n, ring_head;
+    hipEvent_t gate_event; // the next run's loop kernel waits for it (ddn_p25_rx_gate_loop)
     hipEvent_t loop_event; // recorded between the matched filter and the loop kernel of the next run (ddn_p25_rx_mark_loop_start)
 };
 
@@ -307,6 +308,10 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
         HIP_TRY(hipEventRecord(b->ev[1], st));
         HIP_TRY(hipEventRecord(rv[1], st));
     }
+    if (b->gate_event) { // one shot: the loop kernel (not the matched filter above) waits for this event
+        HIP_TRY(hipStreamWaitEvent(st, b->gate_event, 0));
+        b->gate_event = nullptr;
+    }
     if (b->loop_event) { // one shot: the chain object releases its result copies when the loop kernel is next on the stream
         HIP_TRY(hipEventRecord(b->loop_event, st));
         b->loop_event = nullptr;
@@ -334,6 +339,17 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
 
 // internal (ddn_internal.h): the next ddn_p25_rx_run records `hip_event` on its stream after the matched filter, right before the
 // loop kernel
+// internal: the next ddn_p25_rx_run makes its stream wait for `hip_event` between the matched filter and the loop kernel (the loop
+// fills the device and must not start while the previous call's LDS-hungry decode kernels hold CUs; the matched filter may)
+extern "C" int
+ddn_p25_rx_gate_loop(ddn_p25_rx* b, void* hip_event) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    b->gate_event = (hipEvent_t)hip_event;
+    return DDN_OK;
+}
+
 extern "C" int
 ddn_p25_rx_mark_loop_start(ddn_p25_rx* b, void* hip_event) {
     if (!b) {

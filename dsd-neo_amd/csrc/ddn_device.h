@@ -337,6 +337,7 @@ hipError_t ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, 
                                uint8_t* rec_cur, uint8_t* fl_cur, size_t stride_sym, int T, int n_channels, hipStream_t st);
 hipError_t ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, int flush, int32_t* cnt_scan, int32_t* cnt_full,
                                 hipStream_t st);
+hipError_t ddn_dev_zero_words(int32_t* p, int n, hipStream_t st);
 hipError_t ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_prev, const int32_t* n_prev, const int32_t* new_prev,
                                 int have_prev, const int32_t* ev_new, const int32_t* evd_new, const int32_t* n_new, int E, int EL, int T,
                                 int n_channels, int32_t* list_cur, int32_t* data_cur, int32_t* n_cur, hipStream_t st);

@@ -25,6 +25,13 @@ int ddn_p25p1_layout_ldu_lsd(int32_t out16[16]);
 void ddn_set_error(const char* fmt, ...);
 /* the next ddn_p25_rx_run() records this HIP event between its matched filter and its loop kernel (one shot) */
 int ddn_p25_rx_mark_loop_start(ddn_p25_rx* b, void* hip_event);
+/* the next ddn_p25_rx_run() makes its stream wait for this HIP event between its matched filter and its loop kernel (one shot) */
+int ddn_p25_rx_gate_loop(ddn_p25_rx* b, void* hip_event);
+/* the two kernels of ddn_mbe_synth_batch as separate calls (ddn_api_mbe.cpp) */
+struct ddn_mbe_batch;
+int ddn_mbe_params_only(struct ddn_mbe_batch* b, const uint8_t* d_bits, const int32_t* d_result_in, size_t n_frames, int32_t* d_result_out,
+                        void* hip_stream);
+int ddn_mbe_synth_only(struct ddn_mbe_batch* b, size_t n_frames, float* d_pcm, void* hip_stream);
 #ifdef __cplusplus
 }
 #endif

@@ -2919,8 +2919,11 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
         }
         if (cpw != 4 && cpw != 8 && cpw != 16) {
             // two workgroups per CU are resident: up to 2048 channels four per workgroup (two lanes per recurrence wave - a lane's
-            // standard trip, bulk pass or wait then holds up one other lane instead of three), up to 4096 eight
-            cpw = n_channels <= 4 * 512 ? 4 : (n_channels <= 8 * 512 ? 8 : 16);
+            // standard trip, bulk pass or wait then holds up one other lane instead of three), beyond that eight.  Larger batches
+            // keep eight and run in rounds of 512 resident workgroups (a workgroup never waits for another): measured on the bench
+            // traffic, 8192 channels take 19.6 ms sixteen per workgroup (eight lanes per recurrence wave) against two rounds of
+            // the 5.3 ms the eight-channel shape takes for 4096 (bench.py batch_sweep, round 5)
+            cpw = n_channels <= 4 * 512 ? 4 : 8;
         }
         if (cpw == 4) {
             return launch_rxw<4, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,

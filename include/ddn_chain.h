@@ -112,14 +112,22 @@ int ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip
 /* the same work over the object's two streams: front end + receive loop on one, framer + FEC + voice on the other, so the decode
  * of call k runs beside the front end and loop of call k + 1.  Returns once everything is queued. */
 int ddn_p25_chain_run_pipelined(ddn_p25_chain* c, const void* d_iq);
-/* pipelined, from pinned host memory: the H2D copy of this call's I/Q and the D2H copies of the PREVIOUS call's results (any of the
- * out pointers may be NULL; the structure is copied, the buffers it names must stay valid) run on copy streams beside this call's
- * receive loop - a latency chain that leaves the copies room, where beside the front end or the decode stage they would slow the
- * kernels.  ddn_p25_chain_wait() / _flush() issue the copies of the last call.  h_iq must stay untouched until the next call returns (that call
- * waits on the host for the copy): two input buffers, used in turn, are enough.  The outputs named at call k are complete when call
- * k + 2 returns (it waits for them on the host), or after ddn_p25_chain_wait(); call k + 2's own copies may already be running by
- * then, so a host that reads call k's outputs after call k + 2 returned needs THREE output sets used in turn (two if it calls
- * ddn_p25_chain_wait() before reading). */
+/* pipelined, from pinned host memory (hipHostMalloc / hipHostRegister / ddn_host_alloc_pinned; any of the out pointers may be NULL; the
+ * structure is copied, the buffers it names must stay valid): the H2D copy of this call's I/Q runs on a copy stream beside the
+ * previous call's decode; the D2H copies of the PREVIOUS call's results are handed to an SDMA engine at the end of this call (below
+ * HIP: hsa_amd_memory_async_copy_on_engine - a device -> host hipMemcpyAsync is a shader kernel on this ROCm and cannot start while
+ * the receive loop holds every CU; the engine runs beside any kernel and duplex with the input copy).  This call first queues all
+ * of its own work, then waits on the host for the previous call's decode (which runs beside this call's front end) and issues
+ * those copies.  The outputs a result set names (counts, NIDs, TSDU blocks, PCM) exist once per buffer set on the device, so a
+ * call's results can still be leaving while the next call is decoded.  DDN_D2H=blit in the environment (or result buffers the
+ * runtime does not know as pinned) keeps the earlier route: hipMemcpyAsync on a copy stream, released beside this call's receive
+ * loop.  ddn_p25_chain_wait() / _flush() issue the copies of the last call and wait for them.  h_iq must stay untouched until
+ * the next call returns (that call waits on the host for the copy): two input buffers, used in turn, are enough.  The outputs
+ * named at call k are complete when call k + 3 returns (it waits for them on the host before its loop overwrites the device-side
+ * buffer set they come from - the object holds three), or after ddn_p25_chain_wait(): THREE output sets used in turn (a host that
+ * reads call k's outputs after call k + 3 returned, while later calls run, needs four; one that calls ddn_p25_chain_wait() before
+ * reading needs one).  The depth is what keeps the pipe full: an input copy (7 ms at 4096 x 48000), a step (9-10 ms) and a full
+ * result set (10 ms on the engine) are in flight at once. */
 typedef struct ddn_p25_chain_host_out {
     uint8_t* records10; /* [B][stride][10] */
     uint8_t* flags;     /* [B][stride] */
@@ -152,6 +160,9 @@ size_t ddn_p25_chain_stride_symbols(const ddn_p25_chain* c);
 int ddn_p25_chain_frame_slots(const ddn_p25_chain* c); /* max_frames as resolved */
 int ddn_p25_chain_max_ldu(const ddn_p25_chain* c);
 int ddn_p25_chain_max_events(const ddn_p25_chain* c);
+/* which way _run_host's result copies go, once a call with result buffers has been made: 0 = hipMemcpyAsync on a copy stream (shader
+ * blit), otherwise an SDMA engine - the hsa_amd_sdma_engine_id_t bit in use, or 0x10000 when the runtime picks the engine */
+int ddn_p25_chain_d2h_route(const ddn_p25_chain* c);
 /* the stage objects, for timing switches and state queries (ddn_batch*, ddn_p25_rx*, ddn_mbe_batch*) */
 void* ddn_p25_chain_front_end(ddn_p25_chain* c);
 void* ddn_p25_chain_rx(ddn_p25_chain* c);

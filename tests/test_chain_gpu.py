@@ -502,8 +502,9 @@ def test_syncs_beyond_the_frame_slots_are_counted_not_lost_silently(built):
 
 def test_run_host_streaming_host_never_waits(built):
     """the contract of ddn_p25_chain_run_host as include/ddn_chain.h words it, used the way a streaming host would: two pinned input
-    buffers refilled in turn as soon as the NEXT call has returned, three output sets read as soon as the call after the next has
-    returned, no ddn_p25_chain_wait() until the end.  Every call's outputs equal those of a run that waits after every call"""
+    buffers refilled in turn as soon as the NEXT call has returned, three output sets, call k's read as soon as call k + 3 has returned
+    (and before call k + 4 is made), no ddn_p25_chain_wait() until the end.  Every call's outputs equal those of a run that waits
+    after every call"""
     l = ddn.lib()
     B, n_call, calls = 4, 16384, 7
     iq = _stream(B, n_call * calls)
@@ -547,13 +548,14 @@ def test_run_host_streaming_host_never_waits(built):
             C.memmove(h_in[k & 1], part.ctypes.data, part.nbytes)     # legal: call k - 1 (the last user of k - 2's buffer) has returned
             ch.run_host(h_in[k & 1], outs[k % 3])
             if streaming:
-                if k >= 2:
-                    read(k - 2)
+                if k >= 3:
+                    read(k - 3)
             else:
                 ch.wait()
                 read(k)
         if streaming:
             ch.wait()
+            read(calls - 3)
             read(calls - 2)
             read(calls - 1)
         ch.close()

@@ -38,10 +38,10 @@ def pin(nb):
 h_iq = [pin(B * n * 2) for _ in range(2)]
 for p in h_iq:
     assert l.ddn_device_download(p, d_iq.data_ptr(), B * n * 2) == 0
-bufs = [{k: pin(v) for k, v in sizes.items()} for _ in range(2)]
+bufs = [{k: pin(v) for k, v in sizes.items()} for _ in range(3)]
 
 
-def run(fields, steps=6):
+def run(fields, steps=12):
     outs = []
     for b in bufs:
         o = ddn.P25ChainHostOut()
@@ -49,11 +49,11 @@ def run(fields, steps=6):
             setattr(o, k, b[k].value)
         outs.append(o)
     for k in range(3):
-        chain.run_host(h_iq[k & 1], outs[k & 1] if fields else None)
+        chain.run_host(h_iq[k & 1], outs[k % 3] if fields else None)
     chain.wait()
     t0 = time.perf_counter()
     for k in range(steps):
-        chain.run_host(h_iq[(k + 1) & 1], outs[(k + 1) & 1] if fields else None)
+        chain.run_host(h_iq[(k + 1) & 1], outs[k % 3] if fields else None)
     chain.wait()
     return (time.perf_counter() - t0) / steps * 1e3
 
@@ -61,7 +61,7 @@ def run(fields, steps=6):
 for name, f in (("H2D only", ()), ("+ small results", ("counts", "n_events", "nid4", "tsbk", "events", "event_data")),
                 ("+ pcm", ("counts", "n_events", "nid4", "tsbk", "events", "event_data", "pcm")),
                 ("+ records + flags (everything)", tuple(sizes))):
-    print("%-32s %.2f ms per step" % (name, run(f)), flush=True)
+    print("%-32s %.2f ms per step   (D2H route 0x%x)" % (name, run(f), l.ddn_p25_chain_d2h_route(chain.h)), flush=True)
 for _ in range(3):
     chain.run_pipelined(d_iq.data_ptr())
 chain.wait()

@@ -12,7 +12,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(mode, steps=8):
+def run(mode, steps=12):
     import bench
     import numpy as np
     import torch
@@ -69,7 +69,8 @@ def run(mode, steps=8):
     for k in range(steps):
         chain.run_host(h_iq[(k + 1) & 1], outs[k % 3] if sizes else None)
     chain.wait()
-    print("%s %.3f ms per step, %.1f MB out" % (mode, (time.perf_counter() - t0) / steps * 1e3, sum(sizes.values()) / 1e6))
+    print("%s %.3f ms per step, %.1f MB out, D2H route 0x%x" % (mode, (time.perf_counter() - t0) / steps * 1e3, sum(sizes.values()) / 1e6,
+                                                                l.ddn_p25_chain_d2h_route(chain.h)))
 
 
 def summarise(d):
