@@ -752,26 +752,6 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st, hipEvent_t ev
                                      c->off97[1], c->off97[2], c->d_nid[cur], c->d_tsbk[cur], c->d_tsbk_crc, c->d_cls, c->d_lists, c->d_list_n,
                                      st));
     }
-    // data units (DUID 0xC): the header the loop decoded + the data blocks behind it (half-rate trellis, best path) + CRC32
-    {
-        const int32_t *d_ns = nullptr, *d_sp = nullptr;
-        DDN_TRY(ddn_p25p1_framer_device_syncs(c->fr, &d_ns, &d_sp));
-        const size_t NE = (size_t)c->B * (size_t)c->PF, NB = NE * (size_t)c->PB;
-        HIP_TRY(ddn_dev_chain_pdu_index(c->d_evl[cur], c->d_evdl[cur], c->d_nevl[cur], c->EL, d_sp, d_ns, c->d_nid[cur], c->B, c->F, c->off97[0],
-                                        c->PF, c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_n_pdu, st));
-        HIP_TRY(ddn_dev_chain_pdu_gather(rec, c->d_cnt_full[cur], stride, d_sp, c->d_pdu_slot, c->d_pdu_info, c->B, c->F, c->PF, c->PB,
-                                         c->d_pdu_llr, c->d_pdu_valid, st));
-        // (d_pdu_cand: scratch for the 1/2-rate candidates first, then the rate 3/4 ones - same stream)
-        // (only the blocks that lie inside the call's records: groups of 32 without one leave at once)
-        HIP_TRY(ddn_dev_p25_half_rate_list_wanted(c->d_pdu_llr, (int)NB, 8, c->d_pdu_valid, (uint32_t*)c->d_pdu_cand, c->d_pdu_cnt, st));
-        HIP_TRY(ddn_dev_chain_pdu_take_first(c->d_pdu_cand, c->d_pdu_cnt, (int)NB, c->d_pdu_blocks, c->d_pdu_metric, st));
-        // confirmed data: the same blocks through the rate 3/4 LLR list decoder, first candidate with a good CRC9 (:219-241)
-        HIP_TRY(ddn_dev_chain_pdu_r34_wanted(c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_pdu_valid, (int)NB, c->PB, c->d_pdu_wanted, st));
-        DDN_TRY(ddn_fec_p25_mbf34_list_batch(c->d_pdu_llr, NB, 8, c->d_pdu_wanted, (ddn_p25_mbf34_candidate*)c->d_pdu_cand, c->d_pdu_cnt, st));
-        HIP_TRY(ddn_dev_chain_pdu_r34_select(c->d_pdu_cand, c->d_pdu_cnt, c->d_pdu_wanted, (int)NB, c->d_pdu_blocks18, c->d_pdu_crc9, st));
-        HIP_TRY(ddn_dev_chain_pdu_finish(c->d_pdu_slot, c->d_pdu_blocks, c->d_pdu_valid, c->d_pdu_blocks18, (int)NE, c->PB, c->d_pdu_hdr,
-                                         c->d_pdu_info, st));
-    }
     // The frame FEC below (per-type work lists) and the voice stage (voice index by NID -> IMBE frames -> PCM) read the same records
     // and NIDs and write nothing the other reads: the voice stage runs on a stream of its own beside the FEC (0.7 ms of small
     // kernels) and joins this one at the end - in the pipelined forms (decode on the object's second stream); the one-stream form
@@ -796,9 +776,6 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st, hipEvent_t ev
         DDN_TRY(ddn_p25p1_framer_pack_ldu_rs(c->fr, ldu, c->d_words[i], c->d_rs_d[i], c->d_rs_p[i], st));
         DDN_TRY(ddn_fec_p25_rs_batch(i == 0 ? DDN_RS_24_12_13 : DDN_RS_24_16_9, c->d_rs_d[i], c->d_rs_p[i], S, c->d_rs_st[i], st));
     }
-    ddn_sel_set(c->d_lists + (size_t)DDN_LIST_LSD * S, c->d_list_n + DDN_LIST_LSD);
-    DDN_TRY(ddn_p25p1_framer_gather_lsd(c->fr, rec, c->d_cnt_full[cur], stride, c->d_lsd, c->d_lsd_llr, c->d_vldu, st));
-    DDN_TRY(ddn_fec_p25_lsd_batch(c->d_lsd, c->d_lsd_llr, S * 2, c->d_lsd_ok, st));
     // HDU: 36 Golay(24,6) words -> RS(36,20,17)
     ddn_sel_set(c->d_lists + (size_t)DDN_LIST_HDU * S, c->d_list_n + DDN_LIST_HDU);
     DDN_TRY(ddn_p25p1_framer_gather_hdu(c->fr, rec, c->d_cnt_full[cur], stride, c->d_hdu_hex, c->d_hdu_par, nullptr, nullptr, c->d_vldu, st));
@@ -811,7 +788,34 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st, hipEvent_t ev
     DDN_TRY(ddn_fec_golay24_batch(12, c->d_td_d, c->d_td_p, S * 12, c->d_td_st, nullptr, st));
     DDN_TRY(ddn_p25p1_framer_pack_tdulc_rs(c->fr, c->d_td_d, c->d_td_rd, c->d_td_rp, st));
     DDN_TRY(ddn_fec_p25_rs_batch(DDN_RS_24_12_13, c->d_td_rd, c->d_td_rp, S, c->d_td_rs, st));
+    // Last on this stream, the kernels that take a large share of a CU's LDS (k_p25_lsd 49 KB, k_p25_half_rate_list 80 KB per
+    // workgroup): in the pipelined forms the next call's front end (153 KB per CU) runs beside this decode, and a workgroup that needs
+    // more LDS than the front end leaves (10 KB) waits for one of its workgroups to end - i.e. ~2 ms, with everything queued behind
+    // it.  Everything above fits beside the front end (k_rs63 7.6 KB, k_golay24 8 KB).
+    ddn_sel_set(c->d_lists + (size_t)DDN_LIST_LSD * S, c->d_list_n + DDN_LIST_LSD);
+    DDN_TRY(ddn_p25p1_framer_gather_lsd(c->fr, rec, c->d_cnt_full[cur], stride, c->d_lsd, c->d_lsd_llr, c->d_vldu, st));
+    DDN_TRY(ddn_fec_p25_lsd_batch(c->d_lsd, c->d_lsd_llr, S * 2, c->d_lsd_ok, st));
     ddn_sel_clear();
+    // data units (DUID 0xC): the header the loop decoded + the data blocks behind it (half-rate trellis, best path) + CRC32
+    {
+        const int32_t *d_ns = nullptr, *d_sp = nullptr;
+        DDN_TRY(ddn_p25p1_framer_device_syncs(c->fr, &d_ns, &d_sp));
+        const size_t NE = (size_t)c->B * (size_t)c->PF, NB = NE * (size_t)c->PB;
+        HIP_TRY(ddn_dev_chain_pdu_index(c->d_evl[cur], c->d_evdl[cur], c->d_nevl[cur], c->EL, d_sp, d_ns, c->d_nid[cur], c->B, c->F, c->off97[0],
+                                        c->PF, c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_n_pdu, st));
+        HIP_TRY(ddn_dev_chain_pdu_gather(rec, c->d_cnt_full[cur], stride, d_sp, c->d_pdu_slot, c->d_pdu_info, c->B, c->F, c->PF, c->PB,
+                                         c->d_pdu_llr, c->d_pdu_valid, st));
+        // (d_pdu_cand: scratch for the 1/2-rate candidates first, then the rate 3/4 ones - same stream)
+        // (only the blocks that lie inside the call's records: groups of 32 without one leave at once)
+        HIP_TRY(ddn_dev_p25_half_rate_list_wanted(c->d_pdu_llr, (int)NB, 8, c->d_pdu_valid, (uint32_t*)c->d_pdu_cand, c->d_pdu_cnt, st));
+        HIP_TRY(ddn_dev_chain_pdu_take_first(c->d_pdu_cand, c->d_pdu_cnt, (int)NB, c->d_pdu_blocks, c->d_pdu_metric, st));
+        // confirmed data: the same blocks through the rate 3/4 LLR list decoder, first candidate with a good CRC9 (:219-241)
+        HIP_TRY(ddn_dev_chain_pdu_r34_wanted(c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_pdu_valid, (int)NB, c->PB, c->d_pdu_wanted, st));
+        DDN_TRY(ddn_fec_p25_mbf34_list_batch(c->d_pdu_llr, NB, 8, c->d_pdu_wanted, (ddn_p25_mbf34_candidate*)c->d_pdu_cand, c->d_pdu_cnt, st));
+        HIP_TRY(ddn_dev_chain_pdu_r34_select(c->d_pdu_cand, c->d_pdu_cnt, c->d_pdu_wanted, (int)NB, c->d_pdu_blocks18, c->d_pdu_crc9, st));
+        HIP_TRY(ddn_dev_chain_pdu_finish(c->d_pdu_slot, c->d_pdu_blocks, c->d_pdu_valid, c->d_pdu_blocks18, (int)NE, c->PB, c->d_pdu_hdr,
+                                         c->d_pdu_info, st));
+    }
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[4], st));
     }

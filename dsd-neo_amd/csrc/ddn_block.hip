@@ -300,7 +300,7 @@ ddn_dev_hamming_10_6_3(uint8_t* bits10, int n, uint8_t* errs, hipStream_t st) {
         return hipSuccess;
     }
     const DdnSel sel = ddn_sel_for(24);
-    hipLaunchKernelGGL(k_hamming_10_6_3, dim3(ddn_sel_grid(&sel, ((unsigned long)n + 255) / 256)), dim3(256), 0, st, bits10, n, errs, sel);
+    hipLaunchKernelGGL(k_hamming_10_6_3, dim3(ddn_sel_grid(&sel, ((unsigned long)n + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, bits10, n, errs, sel);
     return hipGetLastError();
 }
 
@@ -408,7 +408,7 @@ ddn_dev_p25_lsd(uint8_t* bits16, const int16_t* llr16, int n, uint8_t* ok, hipSt
         return hipSuccess;
     }
     const DdnSel sel = ddn_sel_for(2);
-    hipLaunchKernelGGL(k_p25_lsd, dim3(ddn_sel_grid(&sel, ((unsigned long)n + 255) / 256)), dim3(256), 0, st, bits16, llr16, n, ok, sel);
+    hipLaunchKernelGGL(k_p25_lsd, dim3(ddn_sel_grid(&sel, ((unsigned long)n + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, bits16, llr16, n, ok, sel);
     return hipGetLastError();
 }
 

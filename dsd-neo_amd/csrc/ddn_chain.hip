@@ -743,7 +743,7 @@ ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, int flush, i
     if (n_channels <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_chain_counts, dim3((unsigned)((n_channels + 255) / 256)), dim3(256), 0, st, cnt_new, T, n_channels, flush,
+    hipLaunchKernelGGL(k_chain_counts, dim3((unsigned)((n_channels + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, cnt_new, T, n_channels, flush,
                        cnt_scan, cnt_full);
     return hipGetLastError();
 }
@@ -811,7 +811,7 @@ ddn_dev_chain_pdu_take_first(const uint8_t* cand16, const int32_t* counts, int n
     if (n_blocks <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_chain_pdu_take_first, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, cand16, counts, n_blocks, blocks12,
+    hipLaunchKernelGGL(k_chain_pdu_take_first, dim3((unsigned)((n_blocks + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, cand16, counts, n_blocks, blocks12,
                        metric);
     return hipGetLastError();
 }
@@ -822,7 +822,7 @@ ddn_dev_chain_pdu_r34_wanted(const int32_t* pdu_slot, const uint8_t* pdu_hdr, co
     if (n_blocks <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_chain_pdu_r34_wanted, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, pdu_slot, pdu_hdr, pdu_info, valid,
+    hipLaunchKernelGGL(k_chain_pdu_r34_wanted, dim3((unsigned)((n_blocks + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, pdu_slot, pdu_hdr, pdu_info, valid,
                        n_blocks, PB, wanted);
     return hipGetLastError();
 }
@@ -833,7 +833,7 @@ ddn_dev_chain_pdu_r34_select(const uint8_t* cand24, const int32_t* counts, const
     if (n_blocks <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_chain_pdu_r34_select, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, cand24, counts, wanted, n_blocks,
+    hipLaunchKernelGGL(k_chain_pdu_r34_select, dim3((unsigned)((n_blocks + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, cand24, counts, wanted, n_blocks,
                        blocks18, crc9_ok);
     return hipGetLastError();
 }

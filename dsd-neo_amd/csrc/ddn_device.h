@@ -315,6 +315,11 @@ hipError_t ddn_dev_zero(void* p, size_t bytes, hipStream_t st);
  * set walks `*count` frame slots taken from `list` (per_slot items each) instead of every slot - the work follows the frames of
  * that type, not the slot capacity; the other slots' outputs are left as they are.  Thread-local, set around the launches it is
  * meant for; list == NULL = every item. */
+/* Workgroup size of the chains' small decode kernels (gathers, packs, block codes, selections): ONE wavefront.  In the pipelined chain
+ * they run beside the next call's front-end kernel, whose ten waves per CU take every register of two of a CU's four SIMDs (3 x 168):
+ * a workgroup of several waves needs room on every SIMD at once and waited for a front-end workgroup to end (~2 ms, measured);
+ * single-wave workgroups go to the SIMDs that have room. */
+#define DDN_WG 64
 typedef struct DdnSel {
     const int32_t* list;  /* frame slots of the type, any order */
     const int32_t* count; /* device word: entries in list */
@@ -327,7 +332,7 @@ DdnSel ddn_sel_for(int per_slot);
  * device) */
 static inline unsigned
 ddn_sel_grid(const DdnSel* sel, unsigned long n_blocks_full) {
-    const unsigned long cap = 1024;
+    const unsigned long cap = 4096; /* x DDN_WG (64 threads) */
     return (unsigned)((sel->list && n_blocks_full > cap) ? cap : (n_blocks_full ? n_blocks_full : 1));
 }
 hipError_t ddn_dev_chain_pcm_compact(const int32_t* result5, const float* pcm, int n_slots, long capacity, int32_t* block_cnt,

@@ -141,7 +141,7 @@ ddn_dev_gather_fields(const uint8_t* rec, size_t max_sym, const int32_t* counts,
         return hipSuccess;
     }
     const DdnSel sel = ddn_sel_for(n_off);
-    hipLaunchKernelGGL(k_gather_fields, dim3(ddn_sel_grid(&sel, ((unsigned long)total + 255) / 256)), dim3(256), 0, st, rec, max_sym, counts,
+    hipLaunchKernelGGL(k_gather_fields, dim3(ddn_sel_grid(&sel, ((unsigned long)total + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, rec, max_sym, counts,
                        sync_pos, n_syncs, n_channels, max_frames, offsets, n_off, max_off, bits, rel, llr, stride,
                        split_last, last_bit, last_rel, valid, dibits, dibit_rel, sel);
     return hipGetLastError();
@@ -196,7 +196,7 @@ ddn_dev_rs_pack(const uint8_t* words, long n_slots, int n_words, int wstride, in
         return hipSuccess;
     }
     const DdnSel sel = ddn_sel_for(n_words * 6);
-    hipLaunchKernelGGL(k_rs_pack, dim3(ddn_sel_grid(&sel, ((unsigned long)n_slots * n_words * 6 + 255) / 256)), dim3(256), 0, st, words, n_slots,
+    hipLaunchKernelGGL(k_rs_pack, dim3(ddn_sel_grid(&sel, ((unsigned long)n_slots * n_words * 6 + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, words, n_slots,
                        n_words, wstride, n_data, data, parity, sel);
     return hipGetLastError();
 }
@@ -229,7 +229,7 @@ ddn_dev_tdulc_rs_pack(const uint8_t* words, long n_slots, uint8_t* data, uint8_t
         return hipSuccess;
     }
     const DdnSel sel = ddn_sel_for(144);
-    hipLaunchKernelGGL(k_tdulc_rs_pack, dim3(ddn_sel_grid(&sel, ((unsigned long)n_slots * 144 + 255) / 256)), dim3(256), 0, st, words, n_slots,
+    hipLaunchKernelGGL(k_tdulc_rs_pack, dim3(ddn_sel_grid(&sel, ((unsigned long)n_slots * 144 + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, words, n_slots,
                        data, parity, sel);
     return hipGetLastError();
 }

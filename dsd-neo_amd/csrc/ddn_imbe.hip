@@ -16,15 +16,16 @@
 #include "ddn_device.h"
 
 namespace {
-__global__ __launch_bounds__(192) void
+__global__ __launch_bounds__(64) void
 k_imbe_deinterleave(const uint8_t* __restrict__ rec, long n_records, const int64_t* __restrict__ first,
                     const int32_t* __restrict__ status_count, int n_frames, uint8_t* __restrict__ fr,
                     uint8_t* __restrict__ soft, uint8_t* __restrict__ flags, int32_t* __restrict__ status_out) {
     __shared__ uint8_t c0[23];
     __shared__ int short_read;
     const int f = blockIdx.x;
-    const int t = threadIdx.x;
-    if (t == 0) {
+    const int t0 = threadIdx.x; // one wavefront per frame, three passes over the 184 cells (a single-wave workgroup finds room beside
+                                // the front-end kernel of the next call, a three-wave one waited for it: DDN_WG, ddn_device.h)
+    if (t0 == 0) {
         short_read = 0;
     }
     __syncthreads();
@@ -34,7 +35,7 @@ k_imbe_deinterleave(const uint8_t* __restrict__ rec, long n_records, const int64
     // every 35 steps); dibit step j therefore sits j + skips(j) records after the frame's first record
     const int t1 = 35 - sc0;
     auto skips = [&](int j) { return (sc0 <= 35 && j >= t1) ? 1 + (j - t1) / 35 : 0; };
-    if (t < 184) {
+    for (int t = t0; t < 184; t += 64) {
         const int v = t / 23, i = t % 23;
         const int len = v < 4 ? 23 : (v < 7 ? 15 : 7);
         const int off = v < 4 ? 23 * v : (v < 7 ? 92 + 15 * (v - 4) : 137);
@@ -66,7 +67,7 @@ k_imbe_deinterleave(const uint8_t* __restrict__ rec, long n_records, const int64
         }
     }
     __syncthreads();
-    if (t == 0) {
+    if (t0 == 0) {
         int ns = 1;
         for (int i = 0; i < 23; i++) {
             ns &= (c0[i] == ((i >= 15 && i <= 17) ? 1 : 0));
@@ -85,7 +86,7 @@ ddn_dev_imbe_deinterleave(const uint8_t* rec, long n_records, const int64_t* fir
     if (n_frames <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_imbe_deinterleave, dim3((unsigned)n_frames), dim3(192), 0, st, rec, n_records, first,
+    hipLaunchKernelGGL(k_imbe_deinterleave, dim3((unsigned)n_frames), dim3(64), 0, st, rec, n_records, first,
                        status_count, n_frames, fr, soft, flags, status_out);
     return hipGetLastError();
 }

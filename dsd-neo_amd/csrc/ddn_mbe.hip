@@ -104,6 +104,7 @@ hamming_fix(uint32_t w, int& errs) {
     return w;
 }
 
+#define DDN_MBE_FRAMES_PER_WG 32
 template <int CODEC>
 __global__ __launch_bounds__(64) void
 k_mbe_frame_decode(const uint8_t* __restrict__ frames, const uint8_t* __restrict__ soft, size_t n,
@@ -111,15 +112,16 @@ k_mbe_frame_decode(const uint8_t* __restrict__ frames, const uint8_t* __restrict
     constexpr int FB = CODEC == DDN_MBE_IMBE_7200X4400 ? 184 : 96; // bytes per frame
     constexpr int OB = CODEC == DDN_MBE_IMBE_7200X4400 ? 88 : 49;
     constexpr int ROWLEN = CODEC == DDN_MBE_IMBE_7200X4400 ? 23 : 24;
-    __shared__ uint32_t tab[2048];
-    __shared__ uint8_t stage[64 * FB];
-    __shared__ uint8_t outb[64 * OB];
+    // 32 frames per workgroup, the Golay table read in place (8 KB: it stays in the L1): 8.7 KB of LDS per workgroup instead of 25.6,
+    // which fits beside the front-end kernel of the next call (153 KB of a CU's 160) - in the chain object this kernel is on the path
+    // the next receive loop waits for, and with 25.6 KB it waited for a front-end workgroup to end
+    constexpr int FPW = DDN_MBE_FRAMES_PER_WG;
+    __shared__ uint8_t stage[FPW * FB];
+    __shared__ uint8_t outb[FPW * OB];
+    const uint32_t* tab = g_golay_tab;
     const int lane = threadIdx.x;
-    const size_t f0 = (size_t)blockIdx.x * 64;
-    const size_t nf = (n - f0) < 64 ? (n - f0) : 64;
-    for (int i = lane; i < 2048; i += 64) {
-        tab[i] = g_golay_tab[i];
-    }
+    const size_t f0 = (size_t)blockIdx.x * FPW;
+    const size_t nf = (n - f0) < (size_t)FPW ? (n - f0) : (size_t)FPW;
     const uint8_t* src = frames + f0 * FB;
     for (size_t i = lane; i < nf * FB; i += 64) {
         stage[i] = src[i];
@@ -808,7 +810,7 @@ k_mbe_synth(const DdnMbeFrameRec* __restrict__ recs, float* __restrict__ pcm) {
 
 __global__ void
 k_mbe_result_skip(const uint8_t* __restrict__ skip, size_t n, int32_t* __restrict__ result) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && skip[i]) {
         result[i * 5] = (int32_t)((uint32_t)result[i * 5] | DDN_MBE_RESULT_INVALID);
     }
@@ -860,7 +862,7 @@ ddn_dev_mbe_frame_decode(int codec, const uint8_t* frames, const uint8_t* soft, 
             }
         }
     }
-    const dim3 grid((unsigned)((n + 63) / 64)), blk(64);
+    const dim3 grid((unsigned)((n + DDN_MBE_FRAMES_PER_WG - 1) / DDN_MBE_FRAMES_PER_WG)), blk(64);
     if (codec == DDN_MBE_IMBE_7200X4400) {
         hipLaunchKernelGGL(k_mbe_frame_decode<DDN_MBE_IMBE_7200X4400>, grid, blk, 0, st, frames, soft, n, bits, result);
     } else {
@@ -910,6 +912,6 @@ ddn_dev_mbe_result_skip(const uint8_t* skip, size_t n, int32_t* result, hipStrea
     if (n == 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_mbe_result_skip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, skip, n, result);
+    hipLaunchKernelGGL(k_mbe_result_skip, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, skip, n, result);
     return hipGetLastError();
 }

@@ -53,11 +53,7 @@ k_golay_table(uint32_t* __restrict__ tab) {
 __global__ __launch_bounds__(256) void
 k_golay24(uint8_t* __restrict__ data, const uint8_t* __restrict__ parity, int len, int n,
           const uint32_t* __restrict__ tab_g, uint8_t* __restrict__ status, int32_t* __restrict__ fixed, DdnSel sel) {
-    __shared__ uint32_t tab[2048];
-    for (int i = threadIdx.x; i < 2048; i += 256) {
-        tab[i] = tab_g[i];
-    }
-    __syncthreads();
+    const uint32_t* tab = tab_g; // (read in place - 8 KB, it stays in the L1: single-wave workgroups, no LDS; see DDN_WG)
     auto one = [&](long i) {
     uint8_t* d = data + (size_t)i * len;
     const uint8_t* p = parity + (size_t)i * 12;
@@ -972,7 +968,7 @@ ddn_dev_golay24(uint8_t* data, const uint8_t* parity, int len, int n, uint8_t* s
         return e0;
     }
     const DdnSel sel = ddn_sel_for(len == 6 ? 36 : 12);
-    hipLaunchKernelGGL(k_golay24, dim3(ddn_sel_grid(&sel, ((unsigned long)n + 255) / 256)), dim3(256), 0, st, data, parity, len, n,
+    hipLaunchKernelGGL(k_golay24, dim3(ddn_sel_grid(&sel, ((unsigned long)n + DDN_WG - 1) / DDN_WG)), dim3(DDN_WG), 0, st, data, parity, len, n,
                        (const uint32_t*)tab, status, fixed, sel);
     return hipGetLastError();
 }

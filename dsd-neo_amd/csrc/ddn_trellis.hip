@@ -414,26 +414,35 @@ k_k5_m17(const uint16_t* __restrict__ in, int n, int in_len, int u_len, DdnPunct
 // absent survivor is UINT32_MAX and never inserts).  Back-pointers ((prev_state << 3) | prev_rank, one byte per
 // survivor) go to LDS; after the last step every lane traces its 8 paths and lane 0 of the group merges the 32
 // candidates in (state, rank) order: duplicates by the 12 output bytes are dropped, the rest kept sorted by metric.
-__global__ __launch_bounds__(128) void
+// CW code words per workgroup of NT threads (4 lanes each; NT = max(64, 4 CW)).  <32, 128> for dense batches; <4, 64> for the chains'
+// sparse lists: 10 KB of LDS and one wavefront per workgroup, which finds room beside a kernel that fills the device (DDN_WG).
+template <int CW, int NT>
+__global__ __launch_bounds__(NT) void
 k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint32_t* __restrict__ cand_out,
                      int32_t* __restrict__ count_out, const uint8_t* __restrict__ wanted) {
-    constexpr int CW = 32, K = 8;
+    constexpr int K = 8;
     __shared__ int32_t d[CW][98 + 1];
     __shared__ uint2 back[CW][49][4];   // 8 back-pointer bytes per (step, state)
     __shared__ uint4 cand[CW][32];      // {bytes 0-3, 4-7, 8-11, metric}
     __shared__ uint8_t cvalid[CW][32];
     const int tid = threadIdx.x;
-    const int cw0 = blockIdx.x * CW;
-    if (wanted) { // optional: a group of 32 code words none of which is wanted reports count 0 and leaves
+    // a workgroup walks groups of 32 code words: with a `wanted` list (the chains' sparse data-unit blocks) the launch is a few
+    // workgroups that skip the groups nobody wants - each needs 80 KB of LDS to start at all, and 1792 of them queued behind the
+    // matched filter held the decode stream (and with it the next receive loop) for 0.9 ms; without a list it is one group each
+    const int n_groups = (n + CW - 1) / CW;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int cw0 = g * CW;
+    __syncthreads(); // (the LDS arrays of the previous group are free)
+    if (wanted) { // a group of 32 code words none of which is wanted reports count 0 and is skipped
         const bool in = tid < CW && cw0 + tid < n;
         if (!__syncthreads_or(in && wanted[cw0 + tid] != 0)) {
             if (in) {
                 count_out[cw0 + tid] = 0;
             }
-            return;
+            continue;
         }
     }
-    for (int idx = tid; idx < CW * 98; idx += 128) {
+    for (int idx = tid; idx < CW * 98; idx += NT) {
         const int c = idx / 98, i = idx - c * 98;
         if (cw0 + c < n) {
             const int32_t pair = *(const int32_t*)(llr + ((size_t)(cw0 + c) * 196 + 2 * i));
@@ -443,7 +452,8 @@ k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint3
     __syncthreads();
     const int c = tid >> 2, ns = tid & 3;
     const int lane = tid & 63, base = lane & ~3;
-    const bool live = (cw0 + c) < n;
+    const bool lane_on = c < CW;                 // (NT > 4 CW: the spare lanes of the wavefront carry nothing)
+    const bool live = lane_on && (cw0 + c) < n;
     const uint32_t MAXM = 0xFFFFFFFFu;
     uint32_t pm[K];
 #pragma unroll
@@ -501,7 +511,9 @@ k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint3
         uint2 w;
         w.x = cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24);
         w.y = cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24);
-        back[c][t][ns] = w;
+        if (lane_on) {
+            back[c][t][ns] = w;
+        }
     }
     __syncthreads();
     // every lane traces its 8 survivors
@@ -514,7 +526,7 @@ k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint3
         }
         uint32_t w[3] = {0, 0, 0};
         int s = ns, r = rk;
-        if (mfin != MAXM) {
+        if (mfin != MAXM && lane_on) {
             for (int t = 48; t >= 0; t--) {
                 if (t < 48) {
                     const int byte = t >> 2;
@@ -527,8 +539,10 @@ k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint3
                 r = (int)(p & 7u);
             }
         }
-        cand[c][ns * K + rk] = make_uint4(w[0], w[1], w[2], mfin);
-        cvalid[c][ns * K + rk] = (mfin != MAXM) ? 1 : 0;
+        if (lane_on) {
+            cand[c][ns * K + rk] = make_uint4(w[0], w[1], w[2], mfin);
+            cvalid[c][ns * K + rk] = (mfin != MAXM) ? 1 : 0;
+        }
     }
     __syncthreads();
     if (ns == 0 && live) {
@@ -590,6 +604,7 @@ k_p25_half_rate_list(const int16_t* __restrict__ llr, int n, int max_cand, uint3
         }
         count_out[cw0 + c] = count;
     }
+    } // groups
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -828,8 +843,14 @@ ddn_dev_p25_half_rate_list_wanted(const int16_t* llr, int n, int max_cand, const
     if (n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_half_rate_list, dim3((unsigned)((n + 31) / 32)), dim3(128), 0, st, llr, n, max_cand, cand,
-                       count, wanted);
+    if (wanted) {
+        const unsigned groups = (unsigned)((n + 3) / 4);
+        hipLaunchKernelGGL((k_p25_half_rate_list<4, 64>), dim3(groups > 1024 ? 1024u : groups), dim3(64), 0, st, llr, n, max_cand, cand, count,
+                           wanted);
+    } else {
+        hipLaunchKernelGGL((k_p25_half_rate_list<32, 128>), dim3((unsigned)((n + 31) / 32)), dim3(128), 0, st, llr, n, max_cand, cand, count,
+                           wanted);
+    }
     return hipGetLastError();
 }
 
