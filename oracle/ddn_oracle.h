@@ -275,6 +275,36 @@ typedef struct orc_p25rx {
     orc_hevents* ev;  /* optional event log */
 } orc_p25rx;
 
+/* ---- symbol-rate receive loop behind the CQPSK demodulator: P25 Phase 1 (LSM) / Phase 2 (ddn_oracle_cqrx.c) ------------------ */
+enum { ORC_CQ_P25P1 = 0, ORC_CQ_P25P2 = 1 };
+typedef struct orc_cqrx {
+    int protocol, sync_len, t_max, lock_symbols; /* lock_symbols < 0: the P25p1 handlers decide (Phase 2: 700 per sync) */
+    double snr_db;                               /* what dsd_rtl_stream_metrics_hook_snr_cqpsk_db() would return; <= -50: no weight */
+    int have_sync, lock_left, lastsync;          /* lastsync: 0 none, 1 positive, 2 inverted pattern */
+    int map_idx;                                 /* DSD_P25_CQPSK_DIBIT_MAP_* of the last sync */
+    int lidx, level_count, hist_count;
+    uint64_t hist;                               /* the last sync_len raw dibits, oldest in the high bits */
+    uint64_t target[2][4];                       /* [polarity][identity, X2400, N1200, P1200] raw-dibit images of the sync word */
+    float lbuf[24], lmin, lmax;
+    float shist[24];
+    int shead, scount;
+    orc_slicer sl;
+    int hunt_pos;
+    orc_p25h h;
+    long n_sym;
+    orc_hevents* ev;
+} orc_cqrx;
+void orc_cqrx_init(orc_cqrx* r, int protocol, int lock_symbols, double snr_db);
+void orc_cqrx_set_events(orc_cqrx* r, orc_hevents* ev);
+int orc_cqrx_symbol(orc_cqrx* r, float sym, int rec4[4]);
+long orc_cqrx_run(orc_cqrx* r, const float* sym, long n, int* rec4, uint8_t* flags);
+size_t orc_cqrx_sizeof(void);
+size_t orc_cqrx_slicer_offset(void);
+void orc_cqrx_get_state(const orc_cqrx* r, float out8[8]);
+int orc_cq_reliability(float sym_c, double snr_db);
+void orc_cq_digitize(const orc_slicer* s, float sym, int map_idx, int negative, double snr_db, int rec4[4]);
+void orc_cq_inframe_step(orc_slicer* s, float sym, int map_idx, int negative, double snr_db, int rec4[4]);
+
 /* ---- fixed-protocol 4-level FSK receive loop, profile-driven: P25p1 / DMR / NXDN48 (ddn_oracle_rx4.c) ------------- */
 #define ORC_FSK4_MAX_PAT  20
 #define ORC_FSK4_MAX_TAPS 135

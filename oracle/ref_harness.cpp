@@ -279,6 +279,7 @@ refh_mmse(const float* samples, float mu, float* re, float* im) {
 namespace {
 const float* g_sym_src = nullptr;
 long g_sym_n = 0, g_sym_pos = 0;
+int g_cq_fast_path = 0; // the symbol-rate fast path's threshold constants ahead of every symbol (refh_cq_slicer_run)
 } // namespace
 
 extern "C" {
@@ -289,6 +290,15 @@ getSymbol(dsd_opts* opts, dsd_state* state, int have_sync) {
     (void)have_sync;
     if (!g_sym_src || g_sym_pos >= g_sym_n) {
         return 0.0f;
+    }
+    if (g_cq_fast_path) { // apply_rtl_symbol_thresholds(state, 4), src/dsp/dsd_symbol.c:744-765
+        state->center = 0.0f;
+        state->min = -3.0f;
+        state->max = 3.0f;
+        state->lmid = -2.0f;
+        state->umid = 2.0f;
+        state->minref = -2.4f;
+        state->maxref = 2.4f;
     }
     const float v = g_sym_src[g_sym_pos++];
     state->lastsample = v;
@@ -375,6 +385,80 @@ refh_slicer_run(void* h, const float* symbols, long n, int* out4, float* thr5) {
         }
     }
     g_sym_src = nullptr;
+}
+
+// ---- the same digitize() path behind the CQPSK demodulator (symbol-rate output) ---------------------------------------------------
+// rf_mod 1, RTL input, the metrics hooks reporting "CQPSK + timing active" and a caller-given CQPSK SNR
+// (dsd_rtl_stream_metrics_hooks_set, include/dsd-neo/runtime/rtl_stream_metrics_hooks.h): select_four_level_dibit() then takes the
+// fixed CQPSK slice, the rotation map and the CQPSK ideals (src/core/frames/dsd_dibit.c:951-1000,658-721).  The harness getSymbol()
+// above hands out the caller's symbols; with g_cq_fast_path set it first does what dsd_symbol.c's symbol-rate fast path does before
+// it returns a symbol - apply_rtl_symbol_thresholds(state, 4), constants only (src/dsp/dsd_symbol.c:744-765,1594).
+#include <dsd-neo/runtime/rtl_stream_metrics_hooks.h>
+
+namespace {
+double g_cq_snr = -100.0;
+int
+cq_status_hook(int* out_cqpsk, int* out_timing) {
+    if (out_cqpsk) {
+        *out_cqpsk = 1;
+    }
+    if (out_timing) {
+        *out_timing = 1;
+    }
+    return 0;
+}
+double
+cq_snr_hook(void) {
+    return g_cq_snr;
+}
+} // namespace
+
+void*
+refh_cq_slicer_create(int synctype, int map_idx, double snr_db) {
+    RefSlicer* s = static_cast<RefSlicer*>(refh_slicer_create(synctype));
+    dsd_opts* o = s->opts;
+    dsd_state* st = s->state;
+    o->audio_in_type = AUDIO_IN_RTL;
+    o->frame_p25p1 = 1;
+    o->frame_p25p2 = 1;
+    st->rf_mod = 1;
+    st->p25_cqpsk_dibit_map_idx = (uint8_t)map_idx;
+    // initState() values (src/core/util/dsd_init.c:519-539), not the FSK-discriminator reset
+    st->center = 0.0f;
+    st->min = -15000.0f;
+    st->max = 15000.0f;
+    st->lmid = 0.0f;
+    st->umid = 0.0f;
+    const int cap = (int)(sizeof(st->minbuf) / sizeof(st->minbuf[0]));
+    for (int i = 0; i < cap; i++) {
+        st->minbuf[i] = -15000.0f;
+        st->maxbuf[i] = 15000.0f;
+    }
+    st->midx = 0;
+    dsd_state_invalidate_minmax_sums(st);
+    g_cq_snr = snr_db;
+    dsd_rtl_stream_metrics_hooks hooks;
+    memset(&hooks, 0, sizeof(hooks));
+    hooks.cqpsk_status = cq_status_hook;
+    hooks.snr_cqpsk_db = cq_snr_hook;
+    dsd_rtl_stream_metrics_hooks_set(&hooks);
+    return s;
+}
+
+void
+refh_cq_slicer_destroy(void* h) {
+    dsd_rtl_stream_metrics_hooks none;
+    memset(&none, 0, sizeof(none));
+    dsd_rtl_stream_metrics_hooks_set(&none);
+    refh_slicer_destroy(h);
+}
+
+// n symbols through getDibitSoft() in that context: out4 / thr5 as refh_slicer_run
+void
+refh_cq_slicer_run(void* h, const float* symbols, long n, int* out4, float* thr5) {
+    g_cq_fast_path = 1;
+    refh_slicer_run(h, symbols, n, out4, thr5);
+    g_cq_fast_path = 0;
 }
 
 // P25 matched (de-emphasis) filter exactly as the symbolizer applies it per sample: p25_filter(sample, sps)

@@ -385,6 +385,69 @@ class OracleP25Rx:
         return t
 
 
+# ---- symbol-rate receive loop behind the CQPSK demodulator (oracle/ddn_oracle_cqrx.c) ---------------------------------
+CQ_P25P1, CQ_P25P2 = 0, 1
+
+
+class OracleCqRx:
+    """protocol CQ_P25P1: the per-DUID handlers decide the in-frame length (lock_symbols = -1) unless a count is given;
+    CQ_P25P2: 700 dibits per sync.  run(symbols) -> (rec4 [n][4] {dibit, reliability, llr0, llr1}, flags [n])"""
+
+    def __init__(self, protocol=CQ_P25P1, lock_symbols=-1, snr_db=-100.0):
+        o = oracle()
+        o.orc_cqrx_sizeof.restype = C.c_size_t
+        o.orc_cqrx_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+        o.orc_cqrx_run.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+        o.orc_cqrx_run.restype = C.c_long
+        o.orc_cqrx_set_events.argtypes = [C.c_void_p, C.c_void_p]
+        o.orc_cqrx_get_state.argtypes = [C.c_void_p, C.c_void_p]
+        self.o = o
+        self.st = C.create_string_buffer(o.orc_cqrx_sizeof())
+        o.orc_cqrx_init(self.st, protocol, lock_symbols, snr_db)
+        self.events = HEvents()
+        o.orc_cqrx_set_events(self.st, C.byref(self.events))
+
+    def run(self, sym):
+        sym = np.ascontiguousarray(sym, np.float32)
+        rec = np.zeros((len(sym), 4), np.int32)
+        fl = np.zeros(len(sym), np.uint8)
+        self.o.orc_cqrx_run(self.st, sym.ctypes.data, len(sym), rec.ctypes.data, fl.ctypes.data)
+        return rec, fl
+
+    def state(self):
+        t = np.zeros(8, np.float32)
+        self.o.orc_cqrx_get_state(self.st, t.ctypes.data)
+        return t
+
+
+def oracle_cq_inframe(sym, map_idx=0, negative=0, snr_db=-100.0):
+    """the in-frame path alone from initState(): -> (rec4 [n][4], thr5 [n][5] {centre, umid, lmid, max, min})"""
+    o = oracle()
+    o.orc_cq_inframe_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    o.orc_cqrx_sizeof.restype = C.c_size_t
+    o.orc_cqrx_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+    st = C.create_string_buffer(o.orc_cqrx_sizeof())
+    o.orc_cqrx_init(st, CQ_P25P1, -1, snr_db)
+    # orc_cqrx.sl sits behind the loop's own words: take its address from a probe of the struct layout
+    off = _cqrx_slicer_offset()
+    sl = C.addressof(st) + off
+    sym = np.ascontiguousarray(sym, np.float32)
+    rec = np.zeros((len(sym), 4), np.int32)
+    thr = np.zeros((len(sym), 5), np.float32)
+    f7 = (C.c_float * 7)
+    for i, v in enumerate(sym):
+        o.orc_cq_inframe_step(sl, float(v), map_idx, negative, snr_db, rec[i].ctypes.data)
+        t = f7.from_address(sl + 4)         # orc_slicer: int negative; float center, umid, lmid, max, min, maxref, minref
+        thr[i] = (t[0], t[1], t[2], t[3], t[4])
+    return rec, thr
+
+
+def _cqrx_slicer_offset():
+    o = oracle()
+    o.orc_cqrx_slicer_offset.restype = C.c_size_t
+    return o.orc_cqrx_slicer_offset()
+
+
 # ---- CQPSK front end (oracle/ddn_oracle_cqpsk.c) --------------------------------------------------------------------
 def synth_dqpsk_f32(seed, n_ch, n_sym, sps, cfo=0.002, noise=0.03, amp=0.6):
     """pi/4-DQPSK-like stream (differential +-pi/4, +-3pi/4 steps) with a carrier offset (rad/sample), band-limited."""
