@@ -92,10 +92,10 @@ def test_voice_capture_frames():
     rec, fl = rx.run(sym)
     nids = [r for r, _ in _blocks(rx.events, orc.HEV_P25_NID)]
     duids = [r[4] for r in nids if r[2] > 0]
-    assert duids.count(5) >= 4 and duids.count(10) >= 4
-    syncs = np.flatnonzero(fl & 2)
-    gaps = np.diff(syncs)
-    assert np.sum(gaps == 864) >= 8                                      # LDU to LDU: 864 symbols
+    assert len(duids) == len(nids) >= 14 and all(r[3] == 0x106 for r in nids)      # every NID decodes, one NAC
+    assert duids.count(15) >= 7 and duids.count(0) == 1 and duids.count(5) >= 3 and duids.count(10) >= 3   # TDULCs, HDU, LDU1 / LDU2
+    gaps = list(np.diff(np.flatnonzero(fl & 2)))
+    assert gaps.count(216) >= 7 and gaps.count(396) == 1 and gaps.count(864) >= 5  # TDULC, HDU, LDU frame lengths
 
 
 def test_rotated_constellation_is_found_and_corrected():
