@@ -114,6 +114,13 @@ PROTOTYPES = {
     "ddn_cqpsk_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_cqpsk_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddn_cqpsk_get_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ddn_cq_rx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ddn_cq_rx_destroy": (None, [C.c_void_p]),
+    "ddn_cq_rx_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_cq_rx_set_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ddn_cq_rx_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.c_void_p]),
+    "ddn_cq_rx_get_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25_rx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ddn_p25_rx_destroy": (None, [C.c_void_p]),
     "ddn_p25_rx_reset": (C.c_int, [C.c_void_p]),
@@ -962,6 +969,82 @@ class CqpskBatch:
     def __del__(self):
         try:
             lib().ddn_cqpsk_batch_destroy(self.h)
+        except Exception:
+            pass
+
+
+CQ_P25P1, CQ_P25P2 = 0, 1
+
+
+class CqRxConfig(C.Structure):  # == ddn_cq_rx_config
+    _fields_ = [("n_channels", C.c_int), ("protocol", C.c_int), ("lock_symbols", C.c_int), ("nid_erasure_threshold", C.c_int),
+                ("snr_cqpsk_db", C.c_float)]
+
+
+class CqRx:
+    """ddn_cq_rx batch object with device buffers of its own (host-buffer convenience wrapper used by the tests):
+    run(symbols f32 [B][n], counts) -> (rec u8 [B][n][10], flags u8 [B][n], counts i32 [B], events [B] lists of (pos, kind, a, b, data4))"""
+
+    def __init__(self, n_channels, protocol=CQ_P25P1, lock_symbols=0, snr_db=0.0, max_events=1024):
+        self.B, self.E = n_channels, max_events
+        cfg = CqRxConfig(n_channels, protocol, lock_symbols, 0, snr_db)
+        self.h = C.c_void_p()
+        _check(lib().ddn_cq_rx_create(C.byref(cfg), C.byref(self.h)), "ddn_cq_rx_create")
+        self.d_ev, self.d_nev, self.d_evd = (C.c_void_p() for _ in range(3))
+        l = lib()
+        _check(l.ddn_device_alloc(n_channels * max_events * 16, C.byref(self.d_ev)), "alloc")
+        _check(l.ddn_device_alloc(n_channels * 4, C.byref(self.d_nev)), "alloc")
+        _check(l.ddn_device_alloc(n_channels * max_events * 16, C.byref(self.d_evd)), "alloc")
+        _check(l.ddn_cq_rx_set_events(self.h, self.d_ev, self.d_nev, self.d_evd, max_events), "ddn_cq_rx_set_events")
+
+    def run(self, sym, counts=None):
+        import numpy as np
+        l = lib()
+        sym = np.ascontiguousarray(sym, np.float32)
+        B, n = sym.shape
+        assert B == self.B
+        d = {k: C.c_void_p() for k in ("sym", "cin", "rec", "fl", "cnt")}
+        _check(l.ddn_device_alloc(max(sym.nbytes, 4), C.byref(d["sym"])), "alloc")
+        _check(l.ddn_device_alloc(B * 4, C.byref(d["cin"])), "alloc")
+        _check(l.ddn_device_alloc(max(B * n * 10, 4), C.byref(d["rec"])), "alloc")
+        _check(l.ddn_device_alloc(max(B * n, 4), C.byref(d["fl"])), "alloc")
+        _check(l.ddn_device_alloc(B * 4, C.byref(d["cnt"])), "alloc")
+        if sym.nbytes:
+            _check(l.ddn_device_upload(d["sym"], sym.ctypes.data, sym.nbytes), "upload")
+        cin = None
+        if counts is not None:
+            c = np.ascontiguousarray(counts, np.int32)
+            _check(l.ddn_device_upload(d["cin"], c.ctypes.data, c.nbytes), "upload")
+            cin = d["cin"]
+        _check(l.ddn_cq_rx_run(self.h, d["sym"], cin, n, n, d["rec"], d["fl"], d["cnt"], n, None), "ddn_cq_rx_run")
+        rec, fl, cnt = np.zeros((B, n, 10), np.uint8), np.zeros((B, n), np.uint8), np.zeros(B, np.int32)
+        ev, nev, evd = np.zeros((B, self.E, 4), np.int32), np.zeros(B, np.int32), np.zeros((B, self.E, 4), np.int32)
+        for a, p in ((rec, d["rec"]), (fl, d["fl"]), (cnt, d["cnt"]), (ev, self.d_ev), (nev, self.d_nev), (evd, self.d_evd)):
+            if a.nbytes:
+                _check(l.ddn_device_download(a.ctypes.data, p, a.nbytes), "download")
+        for p in d.values():
+            l.ddn_device_free(p)
+        events = [[(int(ev[c, k, 0]), int(ev[c, k, 1]), int(ev[c, k, 2]), int(ev[c, k, 3]), evd[c, k].copy()) for k in range(min(int(nev[c]), self.E))]
+                  for c in range(B)]
+        return rec, fl, cnt, events
+
+    def state(self, ch):
+        import numpy as np
+        s = np.zeros(8, np.float32)
+        _check(lib().ddn_cq_rx_get_state(self.h, ch, s.ctypes.data), "ddn_cq_rx_get_state")
+        return s
+
+    def close(self):
+        if self.h:
+            l = lib()
+            l.ddn_cq_rx_destroy(self.h)
+            for p in (self.d_ev, self.d_nev, self.d_evd):
+                l.ddn_device_free(p)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

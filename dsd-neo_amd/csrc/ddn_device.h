@@ -342,6 +342,35 @@ hipError_t ddn_dev_chain_carry(const uint8_t* rec_prev, const uint8_t* fl_prev, 
                                uint8_t* rec_cur, uint8_t* fl_cur, size_t stride_sym, int T, int n_channels, hipStream_t st);
 hipError_t ddn_dev_chain_counts(const int32_t* cnt_new, int T, int n_channels, int flush, int32_t* cnt_scan, int32_t* cnt_full,
                                 hipStream_t st);
+/* ---- ddn_cqrx.hip: the symbol-rate receive loop behind the CQPSK demodulator ---- */
+typedef struct DdnCqConfig {
+    int protocol;      /* 0 P25 Phase 1, 1 P25 Phase 2 */
+    int sync_len;      /* 24 / 20 dibits */
+    int t_max;         /* level ring: 24 / 19 */
+    int lock_symbols;  /* < 0: the P25p1 handlers decide; Phase 2: 700 */
+    int snr_scale;     /* the CQPSK SNR weight as the numerator over 256 (204 + (w256 >> 2)), -1 = no weight (SNR not available) */
+    int nid_threshold; /* p25p1_get_erasure_threshold() */
+    int max_events;
+    uint64_t target[2][4]; /* [polarity][identity, X2400, N1200, P1200]: the sync word as raw dibits, oldest in the high bits */
+} DdnCqConfig;
+typedef struct DdnCqState { /* one channel, carried from call to call */
+    float minbuf[1024], maxbuf[1024]; /* the extrema average's window (dsd_state: minbuf / maxbuf, msize 1024) */
+    float sbuf[128];                  /* the slicer window (ssize 128) */
+    float lbuf[24], shist[24];        /* level ring of the frame search, symbol history */
+    int32_t d[100];                   /* a trellis block being read: de-interleaved LLR pairs */
+    uint8_t nb[64], nr[64];           /* a NID being read: bits / reliabilities */
+    double min_sum, max_sum;
+    uint64_t hist;
+    float max, min, lmin, lmax;
+    int32_t sidx, midx, sums_valid;
+    int32_t have_sync, lock_left, lastsync, map_idx, lidx, level_count, hist_count, shead, scount, hunt_pos;
+    int32_t h_phase, h_idx, h_left, h_block, h_end, h_skip, h_k, h_nac, h_p2cc;
+    int32_t pad_;
+} DdnCqState;
+hipError_t ddn_dev_cq_rx_init(DdnCqState* states, int n_channels, hipStream_t st);
+hipError_t ddn_dev_cq_rx(const float* symbols, const int32_t* counts_in, size_t sym_stride, int n_fixed, int n_channels, const DdnCqConfig* cfg,
+                         DdnCqState* states, uint8_t* rec, uint8_t* flags, int32_t* counts_out, size_t max_sym, int32_t* events,
+                         int32_t* n_events, int32_t* event_data, hipStream_t st);
 hipError_t ddn_dev_zero_words(int32_t* p, int n, hipStream_t st);
 hipError_t ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_prev, const int32_t* n_prev, const int32_t* new_prev,
                                 int have_prev, const int32_t* ev_new, const int32_t* evd_new, const int32_t* n_new, int E, int EL, int T,

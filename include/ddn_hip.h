@@ -514,6 +514,45 @@ int ddn_cqpsk_run_host(ddn_cqpsk_batch* b, const void* iq, size_t n, float* symb
                        int32_t* counts);
 int ddn_cqpsk_get_state(ddn_cqpsk_batch* b, int channel, float out8[8]);
 
+/* ---- the symbol-rate receive loop behind the CQPSK demodulator ---------------------------------------------------------------
+ * ddn_cqpsk_run() ends at one float per symbol (levels +-1 / +-3).  What dsd-neo's consumer thread does with them until they are
+ * capture records - getSymbol()'s symbol-rate fast path (src/dsp/dsd_symbol.c:1581-1624: the slicer thresholds reset to fixed values
+ * at every symbol), getFrameSync() on a QPSK profile (src/dsp/dsd_frame_sync.c:3098-3148: 4-level slice :2061-2075, the level window
+ * feeding the 1024-deep extrema average :2319-2336, P25 Phase 1 (24) / Phase 2 (20) sync compared exactly :698-716 / :801-816 and
+ * under the rotated constellations X2400 / N1200 / P1200 with the raw-level fit :417-548, :668-696) and the in-frame symbol
+ * (src/core/frames/dsd_dibit.c:243-275 use_symbol, :951-1000 the fixed CQPSK slice around the running centre + rotation map +
+ * polarity, :376-430, :609-721 soft metrics) - for B channels at once, one wavefront per channel.
+ *   protocol DDN_CQ_P25P1: the reference's per-DUID handlers run inside the loop and decide how long a frame is read in frame (NID
+ *     BCH + Chase, TSDU blocks list-8 + CRC16 until the last-block flag, data-unit header; lock_symbols = 0) - their decisions and
+ *     payloads go to the event list exactly as ddn_p25_rx_set_events / _set_event_data describe; lock_symbols > 0 reads that many
+ *     symbols per sync instead.
+ *   protocol DDN_CQ_P25P2: 700 dibits per sync (p2_dibit_buffer(), src/protocol/p25/phase2/p25p2_frame.c:352-370).
+ * Output = the C4FM loop's: d_records10 [B][max_symbols][10] {dibit, reliability, llr0 i16, llr1 i16, symbol f32} (hunting symbols:
+ * the raw 4-level dibit, zeros), d_flags [B][max_symbols] bit 0 in frame, bit 1 a sync completed on this symbol, bit 2 inverted
+ * polarity, bits 4-6 (with bit 1) the rotation map the sync was found under (DSD_P25_CQPSK_DIBIT_MAP_*); d_counts [B].  A call
+ * consumes d_counts_in[c] symbols of row c (NULL: n for every channel) and writes as many records; state carries across calls.
+ * snr_cqpsk_db: what dsd_rtl_stream_metrics_hook_snr_cqpsk_db() would report - in the reference an asynchronous estimate of the radio
+ * thread; 0 or <= -50 = not available (no reliability weight, dsd_dibit.c:411-413).  Modulation is locked (as -mq): no voting. */
+enum { DDN_CQ_P25P1 = 0, DDN_CQ_P25P2 = 1 };
+typedef struct ddn_cq_rx_config {
+    int n_channels;
+    int protocol;              /* DDN_CQ_* */
+    int lock_symbols;          /* P25p1: 0 = handlers; Phase 2: 0 = 700 */
+    int nid_erasure_threshold; /* 0 = 64 */
+    float snr_cqpsk_db;
+} ddn_cq_rx_config;
+typedef struct ddn_cq_rx ddn_cq_rx;
+int ddn_cq_rx_create(const ddn_cq_rx_config* cfg, ddn_cq_rx** out);
+void ddn_cq_rx_destroy(ddn_cq_rx* b);
+int ddn_cq_rx_reset(ddn_cq_rx* b, void* hip_stream);
+/* d_events i32 [B][max_events][4] {record index in this call, kind, a, b}, d_n_events i32 [B] (per call), d_event_data i32
+ * [B][max_events][4] or NULL: kinds and words as ddn_p25_rx_set_events / ddn_p25_rx_set_event_data */
+int ddn_cq_rx_set_events(ddn_cq_rx* b, int32_t* d_events, int32_t* d_n_events, int32_t* d_event_data, size_t max_events);
+int ddn_cq_rx_run(ddn_cq_rx* b, const float* d_symbols, const int32_t* d_counts_in, size_t n, size_t sym_stride, uint8_t* d_records10,
+                  uint8_t* d_flags, int32_t* d_counts, size_t max_symbols, void* hip_stream);
+/* {centre, max, min, map index, last sync (0 none, 1 +, 2 -), in frame, hunted symbols, extrema window index} of one channel */
+int ddn_cq_rx_get_state(ddn_cq_rx* b, int channel, float out8[8]);
+
 /* ---- batched trellis / Viterbi decoders (bit-exact integer) ------------------------------------------
  * d_* = device pointers, asynchronous on hip_stream; *_host = host pointers, synchronous.
  *   ddn_fec_p25_12_soft_*   P25 1/2-rate 4-state trellis on bit LLRs: [n][196] int16 -> [n][12] bytes (+ metric>>8)
