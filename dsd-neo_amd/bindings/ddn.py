@@ -423,7 +423,7 @@ PROTOTYPES.update({
 class P25ChainConfig(C.Structure):  # == ddn_p25_chain_config (include/ddn_chain.h)
     _fields_ = [("n_channels", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int), ("input_format", C.c_int),
                 ("vocoder", C.c_int), ("max_frames", C.c_int), ("max_ldu", C.c_int), ("max_events", C.c_int),
-                ("carry_symbols", C.c_int)]
+                ("carry_symbols", C.c_int), ("modulation", C.c_int), ("sample_rate_hz", C.c_int), ("snr_cqpsk_db", C.c_float)]
 
 
 class P25ChainResults(C.Structure):  # == ddn_p25_chain_results
@@ -645,11 +645,11 @@ class P25ChainC:
     take a device pointer; fetch(name, dtype, shape) copies one of the result arrays of the last call to the host."""
 
     def __init__(self, n_channels, samples_per_call, block_len=8192, vocoder=1, max_frames=0, max_ldu=0, max_events=0,
-                 carry_symbols=0, input_format=0):
+                 carry_symbols=0, input_format=0, modulation=0, sample_rate_hz=0, snr_cqpsk_db=0.0):
         import numpy as np
         self.np = np
         cfg = P25ChainConfig(n_channels, samples_per_call, block_len, input_format, vocoder, max_frames, max_ldu, max_events,
-                             carry_symbols)
+                             carry_symbols, modulation, sample_rate_hz, snr_cqpsk_db)
         self.h = C.c_void_p()
         _check(lib().ddn_p25_chain_create(C.byref(cfg), C.byref(self.h)), "ddn_p25_chain_create")
         self.B, self.n = n_channels, samples_per_call

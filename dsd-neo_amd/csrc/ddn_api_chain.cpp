@@ -56,6 +56,10 @@ struct ddn_p25_chain {
     size_t ms, stride, S, V;
     ddn_batch* fe;
     ddn_p25_rx* rx;
+    // modulation = CQPSK: these two instead (symbols in d_disc, their per-channel counts in d_sym_cnt)
+    ddn_cqpsk_batch* cq_fe = nullptr;
+    ddn_cq_rx* cq = nullptr;
+    int32_t* d_sym_cnt = nullptr;
     ddn_p25p1_framer* fr;
     ddn_mbe_batch* mbe;
     float* d_disc;
@@ -177,6 +181,9 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     delete c->out_mu;
     ddn_batch_destroy(c->fe);
     ddn_p25_rx_destroy(c->rx);
+    ddn_cqpsk_batch_destroy(c->cq_fe);
+    ddn_cq_rx_destroy(c->cq);
+    (void)hipFree(c->d_sym_cnt);
     ddn_p25p1_framer_destroy(c->fr);
     ddn_mbe_batch_destroy(c->mbe);
     void* all[] = {c->d_disc, c->d_pcm_bcnt,
@@ -275,13 +282,31 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
     c->PB = c->T >= 941 ? 8 : 7;
     int rc = DDN_OK;
     do {
-        ddn_front_end_config fc = {c->B, 48000, 4800, 4, DDN_LPF_P25_C4FM, cfg->input_format, cfg->block_len, 0.0f};
-        if ((rc = ddn_batch_create(&fc, &c->fe)) != DDN_OK) {
+        const bool cqpsk = cfg->modulation == DDN_P25_MOD_CQPSK;
+        if (cfg->modulation != DDN_P25_MOD_C4FM && !cqpsk) {
+            ddn_set_error("ddn_p25_chain_create: modulation %d", cfg->modulation);
+            rc = DDN_EINVAL;
             break;
         }
-        ddn_p25_rx_config rc_cfg = {c->B, 48000, 4800, 0, 1};
-        if ((rc = ddn_p25_rx_create(&rc_cfg, &c->rx)) != DDN_OK || (rc = ddn_p25_rx_set_handlers(c->rx, 1, 64)) != DDN_OK) {
-            break;
+        if (cqpsk) {
+            const int rate = cfg->sample_rate_hz > 0 ? cfg->sample_rate_hz : 48000;
+            ddn_cqpsk_config qc = {c->B, rate, 4800, DDN_LPF_P25_CQPSK, 1, cfg->input_format, cfg->block_len, 0.0f};
+            if ((rc = ddn_cqpsk_batch_create(&qc, &c->cq_fe)) != DDN_OK) {
+                break;
+            }
+            ddn_cq_rx_config rq = {c->B, DDN_CQ_P25P1, 0, 64, cfg->snr_cqpsk_db};
+            if ((rc = ddn_cq_rx_create(&rq, &c->cq)) != DDN_OK) {
+                break;
+            }
+        } else {
+            ddn_front_end_config fc = {c->B, 48000, 4800, 4, DDN_LPF_P25_C4FM, cfg->input_format, cfg->block_len, 0.0f};
+            if ((rc = ddn_batch_create(&fc, &c->fe)) != DDN_OK) {
+                break;
+            }
+            ddn_p25_rx_config rc_cfg = {c->B, 48000, 4800, 0, 1};
+            if ((rc = ddn_p25_rx_create(&rc_cfg, &c->rx)) != DDN_OK || (rc = ddn_p25_rx_set_handlers(c->rx, 1, 64)) != DDN_OK) {
+                break;
+            }
         }
         if ((rc = ddn_p25p1_framer_create(c->B, c->F, &c->fr)) != DDN_OK) {
             break;
@@ -295,12 +320,12 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
             || (rc = ddn_mbe_batch_set_p25p1_tail_rule(c->mbe, 1)) != DDN_OK) {
             break;
         }
-        c->ms = ddn_p25_rx_max_symbols(c->rx, (size_t)c->n);
+        c->ms = c->cq ? ddn_cqpsk_max_symbols(c->cq_fe, (size_t)c->n) : ddn_p25_rx_max_symbols(c->rx, (size_t)c->n);
         c->stride = (size_t)c->T + c->ms;
         c->S = (size_t)c->B * (size_t)c->F;
         c->V = (size_t)c->B * (size_t)c->Fv * 9;
         const size_t B = (size_t)c->B, S = c->S, V = c->V;
-        bool ok = dalloc(&c->d_disc, B * (size_t)c->n);
+        bool ok = dalloc(&c->d_disc, B * (size_t)c->n) && dalloc(&c->d_sym_cnt, B);
         for (int k = 0; k < NSET && ok; k++) {
             ok = dalloc(&c->d_rec[k], B * c->stride * 10) && dalloc(&c->d_fl[k], B * c->stride) && dalloc(&c->d_new[k], B)
                  && dalloc(&c->d_ev[k], B * (size_t)c->E * 4) && dalloc(&c->d_nev[k], B) && dalloc(&c->d_evd[k], B * (size_t)c->E * 4)
@@ -380,7 +405,11 @@ chain_front(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st) {
     }
     HIP_TRY(ddn_dev_chain_carry(c->d_rec[prev], c->d_fl[prev], c->d_new[prev], c->step > 0 ? 1 : 0, c->d_rec[cur], c->d_fl[cur],
                                 c->stride, c->T, c->B, st));
-    DDN_TRY(ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st));
+    if (c->cq) { // CQPSK: I/Q -> one float per symbol (row stride ms <= n), counts per channel
+        DDN_TRY(ddn_cqpsk_run(c->cq_fe, d_iq, (size_t)c->n, c->d_disc, c->ms, c->d_sym_cnt, st));
+    } else {
+        DDN_TRY(ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st));
+    }
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[1], st));
     }
@@ -390,6 +419,15 @@ chain_front(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st) {
 // the receive loop of that call
 static int
 chain_loop(ddn_p25_chain* c, int cur, hipStream_t st) {
+    if (c->cq) { // the symbol-rate loop: same records, flags, counts and event lists
+        DDN_TRY(ddn_cq_rx_set_events(c->cq, c->d_ev[cur], c->d_nev[cur], c->d_evd[cur], (size_t)c->E));
+        DDN_TRY(ddn_cq_rx_run(c->cq, c->d_disc, c->d_sym_cnt, c->ms, c->ms, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T, c->d_new[cur],
+                              c->stride, st));
+        if (c->timing) {
+            HIP_TRY(hipEventRecord(c->ev_t[2], st));
+        }
+        return DDN_OK;
+    }
     DDN_TRY(ddn_p25_rx_set_events(c->rx, c->d_ev[cur], c->d_nev[cur], (size_t)c->E));
     DDN_TRY(ddn_p25_rx_set_event_data(c->rx, c->d_evd[cur]));
     // the loop writes its records behind the T carried ones: row pointer + T records, row stride unchanged
@@ -410,6 +448,15 @@ chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEv
     // for the whole launch: one that has to wait for a CU another kernel still holds makes the launch half as long again.  In the
     // pipelined forms the loop therefore starts once the previous call's decode has drained; that decode overlaps this call's
     // carry, front end and matched filter instead.
+    if (c->cq) { // (no matched filter between the demodulator and the loop)
+        if (before_loop) {
+            HIP_TRY(hipStreamWaitEvent(st, before_loop, 0));
+        }
+        if (loop_next) {
+            HIP_TRY(hipEventRecord(loop_next, st));
+        }
+        return chain_loop(c, cur, st);
+    }
     if (before_loop) { // (waited for inside ddn_p25_rx_run, behind the matched filter: that one may run beside the decode kernels)
         DDN_TRY(ddn_p25_rx_gate_loop(c->rx, before_loop));
     }

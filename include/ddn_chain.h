@@ -40,7 +40,16 @@ typedef struct ddn_p25_chain_config {
     int max_ldu;          /* voice LDUs per channel and call; 0 = samples_per_call / 8640 + 3 */
     int max_events;       /* handler decisions per channel and call; 0 = 4 * max_frames */
     int carry_symbols;    /* records carried into the next call; 0 = 896 (an LDU is 864 symbols) */
+    /* appended in round 5 (a config zero-filled beyond carry_symbols is the C4FM chain as before): */
+    int modulation;       /* DDN_P25_MOD_C4FM 0: front end -> FSK discriminator -> matched filter + sample-rate loop (ddn_p25_rx);
+                             DDN_P25_MOD_CQPSK 1 (LSM / simulcast sites): CQPSK demodulator (ddn_cqpsk_run: channel LPF, RMS AGC, FLL,
+                             Gardner, differential phasor, Costas) -> one symbol per call of the symbol-rate loop (ddn_cq_rx: 4-level
+                             slice, sync incl. the rotated-constellation retries, running centre, the same per-DUID handlers) -
+                             everything behind the records is the same decode */
+    int sample_rate_hz;   /* CQPSK: demodulator rate, 0 = 48000 (10 samples per symbol); 24000 = 5 */
+    float snr_cqpsk_db;   /* CQPSK: ddn_cq_rx_config.snr_cqpsk_db (0 = not available) */
 } ddn_p25_chain_config;
+enum { DDN_P25_MOD_C4FM = 0, DDN_P25_MOD_CQPSK = 1 };
 
 /* device pointers to the outputs of the most recent run (S = n_channels * max_frames frame slots, slot = channel * max_frames + k
  * for the k-th decoded sync of the channel in this call).  Lifetime: d_records10 / d_flags / d_new / d_events / d_n_events /
