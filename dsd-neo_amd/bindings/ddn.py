@@ -512,6 +512,11 @@ class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config
 PROTOTYPES.update({
     "ddn_p25_chain_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_p25_chain_d2h_route": (C.c_int, [C.c_void_p]),
+    "ddn_p25p2_chain_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ddn_p25p2_chain_destroy": (None, [C.c_void_p]),
+    "ddn_p25p2_chain_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_chain_flush": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_p25p2_chain_get_results": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25p2_mac_crc_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_mac_crc_host": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_p25p2_ess_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -974,6 +979,59 @@ class CqpskBatch:
 
 
 CQ_P25P1, CQ_P25P2 = 0, 1
+
+
+class P25P2ChainConfig(C.Structure):  # == ddn_p25p2_chain_config (include/ddn_chain.h)
+    _fields_ = [("n_channels", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int), ("input_format", C.c_int),
+                ("sample_rate_hz", C.c_int), ("vocoder", C.c_int), ("max_groups", C.c_int), ("snr_cqpsk_db", C.c_float)]
+
+
+class P25P2ChainResults(C.Structure):  # == ddn_p25p2_chain_results
+    _fields_ = [("stride_symbols", C.c_size_t), ("carry_symbols", C.c_int), ("max_groups", C.c_int), ("voice_frames", C.c_int)] + [
+        (k, C.c_void_p) for k in ("d_records10", "d_flags", "d_new", "d_counts", "d_n_groups", "d_group_pos", "d_dropped_syncs", "d_info",
+                                  "d_payload", "d_ambe_fr", "d_ambe_rel", "d_ess", "d_voice_src", "d_voice_count", "d_voice_bits",
+                                  "d_voice_result", "d_pcm")]
+
+
+class P25P2ChainC:
+    """ddn_p25p2_chain: I/Q of B Phase 2 channels -> MAC PDUs + PCM of both logical channels, one C call per batch of samples"""
+
+    def __init__(self, seeds44, samples_per_call, block_len=8192, input_format=0, vocoder=1, max_groups=0):
+        import numpy as np
+        self.np = np
+        self.B, self.n = len(seeds44), samples_per_call
+        cfg = P25P2ChainConfig(self.B, samples_per_call, block_len, input_format, 0, vocoder, max_groups, 0.0)
+        seeds = np.ascontiguousarray(seeds44, np.uint64)
+        self.h = C.c_void_p()
+        _check(lib().ddn_p25p2_chain_create(C.byref(cfg), seeds.ctypes.data, C.byref(self.h)), "ddn_p25p2_chain_create")
+
+    def run(self, d_iq_ptr, stream=None):
+        _check(lib().ddn_p25p2_chain_run(self.h, d_iq_ptr, stream), "ddn_p25p2_chain_run")
+
+    def flush(self, stream=None):
+        _check(lib().ddn_p25p2_chain_flush(self.h, stream), "ddn_p25p2_chain_flush")
+
+    def results(self):
+        r = P25P2ChainResults()
+        _check(lib().ddn_p25p2_chain_get_results(self.h, C.byref(r)), "ddn_p25p2_chain_get_results")
+        return r
+
+    def fetch(self, ptr, dtype, shape):
+        np = self.np
+        a = np.zeros(shape, dtype)
+        _check(lib().ddn_device_download(a.ctypes.data, ptr, a.nbytes), "ddn_device_download")
+        return a
+
+    def close(self):
+        if self.h:
+            lib().ddn_p25p2_chain_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class CqRxConfig(C.Structure):  # == ddn_cq_rx_config

@@ -722,10 +722,10 @@ ddn_dev_chain_pack2(const uint8_t* rec, const uint8_t* fl, size_t n, uint8_t* ou
 // of the front-end kernel running beside it - and held back every decode kernel behind it, so the receive loop (which waits for the
 // previous call's decode) started 1.5 ms late in every step.
 __global__ void
-k_zero_words(int32_t* __restrict__ p, int n) {
+k_zero_words(int32_t* __restrict__ p, int n, int32_t value) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        p[i] = 0;
+        p[i] = value;
     }
 }
 
@@ -734,7 +734,16 @@ ddn_dev_zero_words(int32_t* p, int n, hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, p, n);
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, p, n, 0);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_fill_words(int32_t* p, int n, int32_t value, hipStream_t st) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, p, n, value);
     return hipGetLastError();
 }
 

@@ -372,6 +372,7 @@ hipError_t ddn_dev_cq_rx(const float* symbols, const int32_t* counts_in, size_t 
                          DdnCqState* states, uint8_t* rec, uint8_t* flags, int32_t* counts_out, size_t max_sym, int32_t* events,
                          int32_t* n_events, int32_t* event_data, hipStream_t st);
 hipError_t ddn_dev_zero_words(int32_t* p, int n, hipStream_t st);
+hipError_t ddn_dev_fill_words(int32_t* p, int n, int32_t value, hipStream_t st);
 hipError_t ddn_dev_chain_events(const int32_t* list_prev, const int32_t* data_prev, const int32_t* n_prev, const int32_t* new_prev,
                                 int have_prev, const int32_t* ev_new, const int32_t* evd_new, const int32_t* n_new, int E, int EL, int T,
                                 int n_channels, int32_t* list_cur, int32_t* data_cur, int32_t* n_cur, hipStream_t st);

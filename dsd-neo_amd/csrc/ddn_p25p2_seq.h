@@ -8,6 +8,10 @@
 #include "ddn_hip.h"
 
 hipError_t ddn_dev_p2_rows(const uint8_t* bits1400, const int16_t* llr1400, size_t n_groups_total, uint8_t* rb, int16_t* rl, hipStream_t st);
+hipError_t ddn_dev_p2_voice_gather(const int32_t* info, const int32_t* groups_of, int n_channels, int n_groups, int cap, const uint8_t* fr,
+                                   const uint8_t* rel, int32_t* src, int32_t* count, uint8_t* o_fr, uint8_t* o_rel, uint8_t* skip, hipStream_t st);
+hipError_t ddn_dev_p2_cut_records(const uint8_t* rec, size_t stride, const int32_t* sync_pos, const int32_t* n_sync, int n_channels, int max_groups,
+                                  uint8_t* bits1400, int16_t* llr1400, hipStream_t st);
 hipError_t ddn_dev_p2_sequence(const int32_t* duid, const int32_t* isch, int n_channels, int n_groups, const int32_t* groups_of,
                                const uint64_t* seed44,
                                ddn_p25p2_seq_state* state, int32_t* info, int32_t* row_off, int32_t* seq_of, int32_t* counts, int32_t* list,

@@ -380,6 +380,102 @@ ddn_dev_p2_rows(const uint8_t* bits1400, const int16_t* llr1400, size_t n_groups
     return hipGetLastError();
 }
 
+// the 700 dibits behind every sync the symbol-rate loop marked (ddn_cq_rx, protocol Phase 2: flag bit 1 on the sync's last symbol, the
+// in-frame records behind it already polarity-corrected with their soft decisions): p2_dibit_buffer()'s p2bit / p2llr
+// (src/protocol/p25/phase2/p25p2_frame.c:352-370), one workgroup per (group, channel)
+__global__ __launch_bounds__(256) void
+k_p2_cut_records(const uint8_t* __restrict__ rec, size_t stride, const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_sync,
+                 int max_groups, uint8_t* __restrict__ bits1400, int16_t* __restrict__ llr1400) {
+    const int c = blockIdx.y, g = blockIdx.x;
+    if (g >= n_sync[c]) {
+        return;
+    }
+    const size_t gi = (size_t)c * max_groups + g;
+    const int p = sync_pos[gi];
+    for (int k = threadIdx.x; k < 700; k += 256) {
+        const uint8_t* q = rec + ((size_t)c * stride + (size_t)(p + 1 + k)) * 10;
+        const int d = q[0] & 3;
+        bits1400[gi * 1400 + 2 * k] = (uint8_t)(d >> 1);
+        bits1400[gi * 1400 + 2 * k + 1] = (uint8_t)(d & 1);
+        llr1400[gi * 1400 + 2 * k] = (int16_t)((uint16_t)q[2] | ((uint16_t)q[3] << 8));
+        llr1400[gi * 1400 + 2 * k + 1] = (int16_t)((uint16_t)q[4] | ((uint16_t)q[5] << 8));
+    }
+}
+
+// Voice of a call's timeslots by logical channel, in air order: talk path tp = channel * 2 + slot takes the 4 (4V) / 2 (2V) AMBE frames
+// of every timeslot the sequencing filed under its slot (process_4V / process_2V hand them to the vocoder one by one,
+// src/protocol/p25/phase2/p25p2_frame.c:1029-1047,1435-1460).  src[tp][k] = row * 4 + frame of the k-th frame, -1 beyond the count.
+__global__ void
+k_p2_voice_index(const int32_t* __restrict__ info, const int32_t* __restrict__ groups_of, int n_channels, int n_groups, int cap,
+                 int32_t* __restrict__ src, int32_t* __restrict__ count) {
+    const int tp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tp >= 2 * n_channels) {
+        return;
+    }
+    const int c = tp >> 1, slot = tp & 1;
+    const int held = groups_of ? min(max(groups_of[c], 0), n_groups) : n_groups;
+    int k = 0;
+    for (int g = 0; g < held; g++) {
+        for (int ts = 0; ts < 4; ts++) {
+            const int row = (c * n_groups + g) * 4 + ts;
+            const int32_t* i8 = info + (size_t)row * 8;
+            const int act = i8[4];
+            if (i8[3] != slot || (act != DDN_P2_4V && act != DDN_P2_2V)) {
+                continue;
+            }
+            const int nf = act == DDN_P2_4V ? 4 : 2;
+            for (int f = 0; f < nf && k < cap; f++) {
+                src[(size_t)tp * cap + k++] = row * 4 + f;
+            }
+        }
+    }
+    count[tp] = k;
+    for (; k < cap; k++) {
+        src[(size_t)tp * cap + k] = -1;
+    }
+}
+
+__global__ __launch_bounds__(64) void
+k_p2_voice_gather(const int32_t* __restrict__ src, size_t n_slots, const uint8_t* __restrict__ fr, const uint8_t* __restrict__ rel,
+                  uint8_t* __restrict__ o_fr, uint8_t* __restrict__ o_rel, uint8_t* __restrict__ skip) {
+    const size_t i = blockIdx.x;
+    if (i >= n_slots) {
+        return;
+    }
+    const int s = src[i];
+    for (int k = threadIdx.x; k < 96; k += 64) {
+        o_fr[i * 96 + k] = s >= 0 ? fr[(size_t)s * 96 + k] : (uint8_t)0;
+        o_rel[i * 96 + k] = s >= 0 ? rel[(size_t)s * 96 + k] : (uint8_t)0;
+    }
+    if (threadIdx.x == 0) {
+        skip[i] = s >= 0 ? 0 : 1;
+    }
+}
+
+hipError_t
+ddn_dev_p2_voice_gather(const int32_t* info, const int32_t* groups_of, int n_channels, int n_groups, int cap, const uint8_t* fr, const uint8_t* rel,
+                        int32_t* src, int32_t* count, uint8_t* o_fr, uint8_t* o_rel, uint8_t* skip, hipStream_t st) {
+    if (n_channels <= 0 || cap <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p2_voice_index, dim3((unsigned)((2 * n_channels + 63) / 64)), dim3(64), 0, st, info, groups_of, n_channels, n_groups, cap, src,
+                       count);
+    hipLaunchKernelGGL(k_p2_voice_gather, dim3((unsigned)((size_t)2 * n_channels * cap)), dim3(64), 0, st, src, (size_t)2 * n_channels * cap, fr, rel,
+                       o_fr, o_rel, skip);
+    return hipGetLastError();
+}
+
+hipError_t
+ddn_dev_p2_cut_records(const uint8_t* rec, size_t stride, const int32_t* sync_pos, const int32_t* n_sync, int n_channels, int max_groups,
+                       uint8_t* bits1400, int16_t* llr1400, hipStream_t st) {
+    if (n_channels <= 0 || max_groups <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_p2_cut_records, dim3((unsigned)max_groups, (unsigned)n_channels), dim3(256), 0, st, rec, stride, sync_pos, n_sync, max_groups,
+                       bits1400, llr1400);
+    return hipGetLastError();
+}
+
 hipError_t
 ddn_dev_p2_sequence(const int32_t* duid, const int32_t* isch, int n_channels, int n_groups, const int32_t* groups_of, const uint64_t* seed44,
                     ddn_p25p2_seq_state* state,

@@ -180,6 +180,54 @@ void* ddn_p25_chain_mbe(ddn_p25_chain* c);
  * milliseconds of {front end, receive loop, framer + frame FEC, voice} (meaningful for ddn_p25_chain_run on one stream) */
 int ddn_p25_chain_set_timing(ddn_p25_chain* c, int enable);
 int ddn_p25_chain_get_stage_ms(ddn_p25_chain* c, float out4[4]);
+/* ---- P25 Phase 2: the TDMA channel as one object -----------------------------------------------------------------------------------
+ *   cu8 / cf32 I/Q -> CQPSK demodulator at 6000 symbols/s (ddn_cqpsk_run) -> symbol-rate receive loop (ddn_cq_rx, DDN_CQ_P25P2: S-ISCH
+ *   sync exact or under the rotated constellations, 700 in-frame dibits per sync) -> the 700 dibits behind every sync
+ *   (p2_dibit_buffer(), src/protocol/p25/phase2/p25p2_frame.c:352-370) -> processP2() (ddn_p25p2_groups_batch: I-ISCH, scramble
+ *   offset, DUID dispatch, FACCH / SACCH / LCCH with RS(63,35) + MAC CRCs, 4V / 2V + ESS) -> vocoder = 1: the AMBE 3600x2450 frames
+ *   of the two logical channels in air order through frame FEC + synthesis (process_4V / process_2V -> processMbeFrame, :1029-1047,
+ *   :1435-1460; src/core/vocoder/dsd_mbe.c:172-190), one talk path per logical channel with its parameters carried.
+ * One call per batch of samples_per_call samples; every state carries across calls; a group whose 700 dibits cross a call boundary is
+ * decoded whole by the next call (the last 720 records are carried), ddn_p25p2_chain_flush() decodes what the carry still holds.
+ * seed44[B] = wacn << 24 | sysid << 12 | colour code per channel (the scrambler's seed; 0 = no valid site: scrambled bursts and voice
+ * are skipped as the reference skips them).  The calls wait for the sequencing pass on the host once per call (ddn_p25p2_groups_batch). */
+typedef struct ddn_p25p2_chain_config {
+    int n_channels;
+    int samples_per_call;
+    int block_len;       /* the demodulator's full_demod() block (8192) */
+    int input_format;    /* DDN_IN_CU8 / DDN_IN_CF32 */
+    int sample_rate_hz;  /* 0 = 48000 (8 samples per symbol) */
+    int vocoder;         /* 1 = AMBE synthesis to PCM */
+    int max_groups;      /* syncs decoded per channel and call; 0 = samples_per_call * 6000 / rate / 720 + 3 */
+    float snr_cqpsk_db;  /* ddn_cq_rx_config.snr_cqpsk_db (0 = not available) */
+} ddn_p25p2_chain_config;
+typedef struct ddn_p25p2_chain_results { /* device pointers, valid until the next run */
+    size_t stride_symbols;          /* records per channel row = carry_symbols + ddn_cqpsk_max_symbols(samples_per_call) */
+    int carry_symbols, max_groups, voice_frames; /* 720; G; AMBE frame slots per talk path and call (8 G) */
+    const uint8_t* d_records10;     /* [B][stride][10] the carried records, then this call's (ddn_cq_rx) */
+    const uint8_t* d_flags;         /* [B][stride] */
+    const int32_t* d_new;           /* [B] new records of this call */
+    const int32_t* d_counts;        /* [B] records in the row */
+    const int32_t* d_n_groups;      /* [B] syncs decoded in this call */
+    const int32_t* d_group_pos;     /* [B][G] row index of each sync's last dibit (its group = the 700 records behind it) */
+    const int32_t* d_dropped_syncs; /* [B] running count of syncs that found no place (max_groups too small) */
+    const int32_t* d_info;          /* [B][G][4][8] as ddn_p25p2_groups_batch */
+    const uint8_t* d_payload;       /* [B][G][4][180] MAC PDU bits */
+    const uint8_t* d_ambe_fr;       /* [B][G][4][4][4][24] */
+    const uint8_t* d_ambe_rel;
+    const uint8_t* d_ess;           /* [B][G][4][96] */
+    const int32_t* d_voice_src;     /* [2 B][voice_frames] timeslot row * 4 + frame of every synthesized frame, talk path = channel * 2 + slot */
+    const int32_t* d_voice_count;   /* [2 B] */
+    const uint8_t* d_voice_bits;    /* [2 B][voice_frames][49] */
+    const int32_t* d_voice_result;  /* [2 B][voice_frames][5] */
+    const float* d_pcm;             /* [2 B][voice_frames][160] */
+} ddn_p25p2_chain_results;
+typedef struct ddn_p25p2_chain ddn_p25p2_chain;
+int ddn_p25p2_chain_create(const ddn_p25p2_chain_config* cfg, const uint64_t* seed44, ddn_p25p2_chain** out);
+void ddn_p25p2_chain_destroy(ddn_p25p2_chain* c);
+int ddn_p25p2_chain_run(ddn_p25p2_chain* c, const void* d_iq, void* hip_stream);
+int ddn_p25p2_chain_flush(ddn_p25p2_chain* c, void* hip_stream);
+int ddn_p25p2_chain_get_results(ddn_p25p2_chain* c, ddn_p25p2_chain_results* out);
 /* ---- DMR / NXDN48: the same shape for BASELINE configs[3]'s other two protocols ------------------------------------------------
  *   cu8 / cf32 I/Q -> front end (12.5 kHz / 6.25 kHz channel filter) -> matched filter + receive loop (ddn_fsk4_rx_run; handlers = 1:
  *   dmr_data_sync / dmrBSBootstrap + dmrBS / nxdn_frame's LICH gate decide the in-frame lengths inside the loop)
