@@ -49,6 +49,20 @@ def oracle_frame_decode(codec, frames, soft=False):
     return bits, res, rc
 
 
+def oracle_process_stream(v, codec, bits, talk_path, res_in=None):
+    """one talk path's frames in order through OracleVocoder `v` (n_streams = 1; its parameters carry on): bits u8 [F][nb],
+    res_in i32 [F][5] = the frame decode's results -> pcm f32 [F][160].  talk_path = the path's index in its batch (the noise seed)"""
+    bits = np.ascontiguousarray(bits, np.uint8)
+    F = bits.shape[0]
+    pcm = np.zeros((F, 160), np.float32)
+    if res_in is not None:
+        res_in = np.ascontiguousarray(res_in, np.int32)
+    rc = _o().om_process_batch(codec, C.addressof(v.tab), bits.ctypes.data, res_in.ctypes.data if res_in is not None else None, v.tail,
+                               talk_path, 1, F, pcm.ctypes.data, None, C.addressof(v.cur), C.addressof(v.prev), C.addressof(v.enh))
+    assert rc == 0
+    return pcm
+
+
 class OracleVocoder:
     """S talk paths of om_process (mbe_processImbe4400Dataf / mbe_processAmbe2450Dataf restated)."""
 

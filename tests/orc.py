@@ -470,6 +470,28 @@ def synth_dqpsk_f32(seed, n_ch, n_sym, sps, cfo=0.002, noise=0.03, amp=0.6):
     return out
 
 
+def modulate_dqpsk_cu8(dibits, sps, seed=0, cfo=0.002, noise=0.02, amp=0.6, lead=40):
+    """a dibit stream as pi/4-DQPSK (phase step = level * pi/4, levels +1 / +3 / -1 / -3 for dibits 0 / 1 / 2 / 3), band-limited like
+    synth_dqpsk_f32, `sps` samples per symbol, a small carrier offset -> cu8 [n][2]"""
+    rng = np.random.default_rng(seed)
+    d = np.concatenate([rng.integers(0, 4, lead), np.asarray(dibits, np.int64) & 3, rng.integers(0, 4, 12)])
+    n_sym = len(d)
+    steps = np.array([1, 3, -1, -3])[d] * np.pi / 4
+    ph = np.cumsum(steps)
+    n = n_sym * sps
+    t = np.arange(n) / sps + 0.37
+    x = np.zeros(n, complex)
+    for off in range(-3, 4):
+        idx = np.clip(np.floor(t).astype(int) + off, 0, n_sym - 1)
+        tau = t - idx
+        x += np.exp(1j * ph[idx]) * np.sinc(tau) * np.cos(np.pi * 0.2 * tau) / (1 - (0.4 * tau) ** 2 + 1e-9)
+    x *= np.exp(1j * (cfo * np.arange(n) + 1.1))
+    x += noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty((n, 2), np.float64)
+    out[:, 0], out[:, 1] = amp * x.real, amp * x.imag
+    return np.clip(np.round(127.5 + 127.5 * out), 0, 255).astype(np.uint8)
+
+
 class OracleCqpskFe:
     def __init__(self, rate=24000, sym_rate=4800, profile=5, lpf_enable=1, ted_gain=0.0):
         o = oracle()

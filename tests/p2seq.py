@@ -166,7 +166,7 @@ def _word_bits(w):
     return np.array([(w >> (39 - k)) & 1 for k in range(40)], np.uint8)
 
 
-def make_stream(rng, n_groups, wacn, sysid, nac, start_sf=0, noise=0.0, plan=None):
+def make_stream(rng, n_groups, wacn, sysid, nac, start_sf=0, noise=0.0, plan=None, voice=None):
     """-> (bits u8 [n_groups][1400], llr i16 [n_groups][1400]): a TDMA channel from superframe slot start_sf on.  Slot s of the
     superframe carries logical channel s % 2; channel 0 a voice call (4V 4V 4V 4V 2V, ESS valid), channel 1 signalling in turn
     (FACCH scrambled / clear, unknown DUIDs); slots 10 / 11 SACCH (scrambled / LCCH clear) - or plan(sf_index) -> kind.
@@ -200,6 +200,14 @@ def make_stream(rng, n_groups, wacn, sysid, nac, start_sf=0, noise=0.0, plan=Non
             else:
                 body[148:244], body[246:318] = pa[:96], pa[96:]
                 _put_duid(body, 6)
+            if voice is not None:      # voice() -> the next AMBE 3600x2450 frame [4][24] of this logical channel, planted through the interleave
+                import rx4
+                m = np.asarray(rx4.ambe2450_map())
+                for f in range(4 if kind == "4v" else 2):
+                    fr = voice()
+                    for x in range(72):
+                        row, col = (m[x // 2][0], m[x // 2][1]) if x % 2 == 0 else (m[x // 2][2], m[x // 2][3])
+                        body[VOICE_OFF[f] + x] = fr[row, col]
             voice_k += 1
         elif kind == "err":
             _put_duid(body, (1, 2, 5, 7, 8, 10, 11, 14)[int(rng.integers(0, 8))])
