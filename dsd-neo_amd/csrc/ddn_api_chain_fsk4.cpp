@@ -108,7 +108,7 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
 extern "C" int
 ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
     if (!cfg || !out || cfg->n_channels <= 0 || cfg->samples_per_call <= 0 || cfg->block_len <= 0
-        || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48)) {
+        || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48 && cfg->protocol != DDN_FSK4_NXDN96)) {
         ddn_set_error("ddn_fsk4_chain_create: bad configuration");
         return DDN_EINVAL;
     }
@@ -126,7 +126,9 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
     c->myc = 16; // syncs that can lie inside that tail (a new sync needs 24 / 10 fresh symbols)
     int rc = DDN_OK;
     do {
-        ddn_front_end_config fc = {c->B, 48000, c->dmr ? 4800 : 2400, 4, c->dmr ? DDN_LPF_12K5 : DDN_LPF_6K25, cfg->input_format,
+        // (NXDN96: a 12.5 kHz channel at 4800 symbols/s)
+        const bool wide = c->dmr || cfg->protocol == DDN_FSK4_NXDN96;
+        ddn_front_end_config fc = {c->B, 48000, wide ? 4800 : 2400, 4, wide ? DDN_LPF_12K5 : DDN_LPF_6K25, cfg->input_format,
                                    cfg->block_len, 0.0f};
         if ((rc = ddn_batch_create(&fc, &c->fe)) != DDN_OK) {
             break;

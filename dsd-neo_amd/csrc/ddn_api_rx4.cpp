@@ -137,13 +137,13 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         return DDN_EINVAL;
     }
     *out = nullptr;
-    if (cfg->n_channels <= 0 || cfg->out_rate_hz <= 0 || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48)
+    if (cfg->n_channels <= 0 || cfg->out_rate_hz <= 0 || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48 && cfg->protocol != DDN_FSK4_NXDN96)
         || (cfg->rf_mod != 0 && cfg->rf_mod != 2) || (cfg->inverted && cfg->protocol != DDN_FSK4_DMR)) {
-        ddn_set_error("ddn_fsk4_rx_create: bad configuration (protocol DMR | NXDN48, rf_mod 0 | 2, inverted only for DMR)");
+        ddn_set_error("ddn_fsk4_rx_create: bad configuration (protocol DMR | NXDN48 | NXDN96, rf_mod 0 | 2, inverted only for DMR)");
         return DDN_EINVAL;
     }
     {
-        const int sym_rate = cfg->protocol == DDN_FSK4_DMR ? 4800 : 2400;
+        const int sym_rate = cfg->protocol == DDN_FSK4_NXDN48 ? 2400 : 4800;
         if (cfg->out_rate_hz / sym_rate < 8 || cfg->out_rate_hz / sym_rate > 21) {
             // the kernel's per-round hand-off queue and its whole-symbol pass are sized for 8..21 samples per symbol
             ddn_set_error("ddn_fsk4_rx_create: out_rate_hz / symbol rate must be within 8..21 (48 ksps: DMR 10, NXDN48 20)");
@@ -197,9 +197,10 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         lock_default[0] = 120;
         lock_default[1] = 54 + 6 * 288;
     } else {
-        d.sym_rate = 2400;
+        const bool n96 = cfg->protocol == DDN_FSK4_NXDN96;
+        d.sym_rate = n96 ? 4800 : 2400;
         d.win_len = 10;
-        d.t_max = 12;
+        d.t_max = n96 ? 24 : 12;
         d.warm_len = 10;
         d.confirm = 1;
         d.n_pat = 10;
@@ -210,8 +211,8 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
             d.pat_type[5 + k] = T_NX_NEG;
             d.pat_neg[5 + k] = 1;
         }
-        d.nt = DDN_NXDN48_FILTER_TAPS;
-        tap_bits = ddn_nxdn48_filter_bits;
+        d.nt = n96 ? DDN_DMR_FILTER_TAPS : DDN_NXDN48_FILTER_TAPS;
+        tap_bits = n96 ? ddn_dmr_filter_bits : ddn_nxdn48_filter_bits;
         lock_default[0] = 182;
     }
     bool all_zero = true;

@@ -102,12 +102,15 @@ hunt_restart(DdnFsk4State& s) {
 }
 template <int PROTO>
 struct Fsk4Cfg {
-    static constexpr int sym_rate = PROTO == 1 ? 4800 : 2400;
-    static constexpr int win_len = PROTO == 1 ? 24 : 10, t_max = PROTO == 1 ? 24 : 12, warm_len = PROTO == 1 ? 24 : 10;
+    // PROTO 1 DMR, 2 NXDN48, 3 NXDN96: NXDN's sync words, two-match confirmation and LICH gate at 4800 symbols/s on the 4800_4 hunt
+    // profile (level ring 24, src/dsp/dsd_frame_sync.c:1525-1556,1729-1744) behind the DMR matched filter
+    // (symbol_apply_matched_filter(), src/dsp/dsd_symbol.c:323-335)
+    static constexpr int sym_rate = PROTO == 2 ? 2400 : 4800;
+    static constexpr int win_len = PROTO == 1 ? 24 : 10, t_max = PROTO == 2 ? 12 : 24, warm_len = PROTO == 1 ? 24 : 10;
     static constexpr int n_pat = PROTO == 1 ? 8 : 10;
     static constexpr int confirm = PROTO == 1 ? 0 : 1, dmr_window = PROTO == 1 ? 1 : 0, redigitize = PROTO == 1 ? 1 : 0;
     static constexpr int slow_type = 0;
-    static constexpr int nt = PROTO == 1 ? DDN_DMR_FILTER_TAPS : DDN_NXDN48_FILTER_TAPS;
+    static constexpr int nt = PROTO == 2 ? DDN_NXDN48_FILTER_TAPS : DDN_DMR_FILTER_TAPS;
     int out_rate, rf_mod, use_filter, dbg;
 };
 
@@ -728,7 +731,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     const bool warm_i = !fo_i | ((abs0 + pos - s.filt_start) >= (long long)(NT - 1)) | (cold_fs == s.filt_start);
                     bool ie = live & (s.in_symbol == 0) & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left >= 3) & (s.need_reset == 0)
                               & (pos < tile_end) & warm_i;
-                    if (HM && PROTO == 2) {
+                    if (HM && PROTO != 1) {
                         ie = ie & (s.hmode != ddn_fsk4h::M_NX_LICH); // (the LICH symbols feed a word of the recurrence lane)
                     }
                     int kfit = 0;
@@ -1589,7 +1592,7 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    if (protocol != 1 && protocol != 2) {
+    if (protocol != 1 && protocol != 2 && protocol != 3) {
         return hipErrorInvalidValue;
     }
     const DdnFec3Tables* htab = nullptr;
@@ -1613,6 +1616,9 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
     do {                                                                                                                   \
         if (protocol == 1) {                                                                                               \
             return handlers ? launch<CPW_, MAXW_, 1, true>(DDN_RX4_ARGS) : launch<CPW_, MAXW_, 1, false>(DDN_RX4_ARGS);     \
+        }                                                                                                                  \
+        if (protocol == 3) { /* NXDN96: 10 samples per symbol at 48 ksps - the straight pass of 12 */                      \
+            return handlers ? launch<CPW_, 12, 3, true>(DDN_RX4_ARGS) : launch<CPW_, 12, 3, false>(DDN_RX4_ARGS);           \
         }                                                                                                                  \
         return handlers ? launch<CPW_, MAXW_, 2, true>(DDN_RX4_ARGS) : launch<CPW_, MAXW_, 2, false>(DDN_RX4_ARGS);         \
     } while (0)

@@ -18,7 +18,8 @@
 extern "C" {
 #endif
 
-enum { DDN_FSK4_DMR = 1, DDN_FSK4_NXDN48 = 2 };
+enum { DDN_FSK4_DMR = 1, DDN_FSK4_NXDN48 = 2, DDN_FSK4_NXDN96 = 3 }; /* NXDN96: NXDN's rules at 4800 symbols/s (level ring 24, the DMR matched
+                                                                       filter: src/dsp/dsd_frame_sync.c:1525-1556, dsd_symbol.c:323-335) */
 enum { DDN_FSK4_CLASS_DATA = 0, DDN_FSK4_CLASS_VOICE = 1 }; /* index into lock_symbols[] */
 /* sync pattern index reported in flags bits 3..6 / d_sync_pat.  DMR: 0 BS data word, 1 BS voice word, 2 MS data, 3 MS voice,
  * 4 / 5 direct-mode TS1 / TS2 data, 6 / 7 direct-mode TS1 / TS2 voice (with inverted = 1 the data words mark voice bursts and

@@ -21,7 +21,7 @@ DMR_DM2_DATA, DMR_DM2_VOICE = "311311111333113333133311", "133133333111331111311
 NXDN_POS = ["3131331131", "3331331131", "3131331111", "3331331111", "3131311131"]
 NXDN_NEG = ["1313113313", "1113113313", "1313113333", "1113113333", "1313133313"]
 
-PROTO_P25P1, PROTO_DMR, PROTO_NXDN48 = 0, 1, 2
+PROTO_P25P1, PROTO_DMR, PROTO_NXDN48, PROTO_NXDN96 = 0, 1, 2, 3
 # sync type ids carried in lastsync (any non-zero numbering works; these mirror synctype_ids.h + 1 so 0 stays "none")
 T_P25_POS, T_P25_NEG = 1, 2
 T_DMR_BS_DATA, T_DMR_BS_VOICE, T_DMR_MS_VOICE, T_DMR_MS_DATA = 11, 13, 33, 34
@@ -79,6 +79,16 @@ def profile(proto, rf_mod=0, use_filter=1, lock=None, out_rate=48000, inverted=0
             pats = [(s_, swap[t][0], swap[t][1], cl ^ 1) for (s_, t, neg, cl) in pats]
         taps = _taps("dmr")
         lock = lock or [120, 54 + 288 * 6, 0, 0]
+    elif proto == PROTO_NXDN96:
+        # 4800 symbols/s on the 4800_4 hunt profile (level ring 24, src/dsp/dsd_frame_sync.c:1729-1744, matcher :1525-1556), the same
+        # frame sync words, LICH gate and 182-symbol frame as NXDN48; the matched filter is the DMR one at every rate but 8 samples
+        # per symbol (symbol_apply_matched_filter(), src/dsp/dsd_symbol.c:323-335)
+        p.proto = PROTO_NXDN48      # (the handlers are NXDN's: the loop's protocol switch knows P25 / DMR / NXDN)
+        p.sym_rate, p.win_len, p.t_max, p.warm_len = 4800, 10, 24, 10
+        p.confirm = 1
+        pats = [(s, T_NXDN_POS, 0, 0) for s in NXDN_POS] + [(s, T_NXDN_NEG, 1, 0) for s in NXDN_NEG]
+        taps = _taps("dmr")
+        lock = lock or [182, 0, 0, 0]
     else:
         p.sym_rate, p.win_len, p.t_max, p.warm_len = 2400, 10, 12, 10
         p.confirm = 1

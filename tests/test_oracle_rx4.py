@@ -206,3 +206,31 @@ def test_window_and_slip_rules_against_the_reference_held_answers(built):
     assert adjust(10, 4, 0, 4, 1, 10, 0) == (0, 4)       # in sync: no slip, latch kept
     assert adjust(10, 4, 0, 4, 0, 1, 0) == (0, 4)        # one-sample span
     assert adjust(10, 4, 0, 4, 0, 10, 1) == (1, 4)       # not at the symbol's first sample
+
+
+def test_nxdn96_known_answer_ran_00(built):
+    """The reference's NXDN96 capture (4800 baud; DECODE_IQ_NXDN96 asserts "RAN 00", tests/CMakeLists.txt:8949) through front end
+    (12.5 kHz profile) -> the receive loop on the NXDN96 profile (level ring 24, the DMR matched filter, NXDN's sync words and two-match
+    rule) -> de-scramble -> SACCH de-interleave / de-puncture -> K=5 decode -> CRC6: frames 192 symbols apart, the SACCH parts count
+    3, 2, 1, 0 through the superframe and every one carries Radio Access Number 0"""
+    import fecgen
+    disc = rx4.capture_disc("iq_nxdn96.npz", 2)
+    out = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_NXDN96, rf_mod=2)).run(disc)
+    acc = out["sync_pos"]
+    assert len(acc) >= 40 and np.mean(np.diff(acc) == 192) > 0.8
+    rows, lich_ok = [], 0
+    for pos in acc:
+        if pos + 183 > len(out["sym"]):
+            break
+        lich, pok, ss, sr, fs, fr = rx4.nxdn_frame_fields(out["rec4"][pos + 1:pos + 183, 0], out["rec4"][pos + 1:pos + 183, 1])
+        lich_ok += int(pok)
+        dec, _ = fecgen.oracle_nxdn(ss[None].copy(), sr[None].copy(), 36, 32)
+        t = np.unpackbits(dec[0])[:32]
+        if not rx4.nxdn_crc_ok(t, 0):
+            t = rx4.oracle_trellis_decode((ss.reshape(-1) >> 1)[None], 32)[0]
+        if rx4.nxdn_crc_ok(t, 0):
+            rows.append(t)
+    assert lich_ok >= 38 and len(rows) >= 34
+    assert all(rx4.bits_int(t[2:8]) == 0 for t in rows)                       # RAN 00
+    parts = [rx4.bits_int(t[0:2]) for t in rows]
+    assert sum(1 for a, b in zip(parts, parts[1:]) if (a - b) % 4 == 1) >= len(parts) - 6

@@ -41,7 +41,9 @@ def check_channel(got, c, want):
 
 CASES = [("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 0, 0), ("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 2, 0),
          ("iq_dmr_voice.npz", 2, rx4.PROTO_DMR, 0, 1), ("iq_dmr_t3_cc.npz", 2, rx4.PROTO_DMR, 2, 1),
-         ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 0, 0), ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 2, 0)]
+         ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 0, 0), ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 2, 0),
+         ("iq_nxdn96.npz", 2, rx4.PROTO_NXDN96, 0, 0), ("iq_nxdn96.npz", 2, rx4.PROTO_NXDN96, 2, 0)]
+GPU_PROTO = {rx4.PROTO_DMR: ddn.FSK4_DMR, rx4.PROTO_NXDN48: ddn.FSK4_NXDN48, rx4.PROTO_NXDN96: ddn.FSK4_NXDN96}
 
 
 @pytest.mark.parametrize("cap,lpf,proto,rf_mod,inv", CASES)
@@ -59,7 +61,7 @@ def test_captures_bit_exact_with_call_splits(built, cap, lpf, proto, rf_mod, inv
         x[c, d:] = disc[:n - d]
     x[3] = -x[3]
     x[4, :25000] = 0
-    gpu = ddn.Fsk4Rx(B, ddn.FSK4_DMR if proto == rx4.PROTO_DMR else ddn.FSK4_NXDN48, rf_mod=rf_mod, inverted=inv,
+    gpu = ddn.Fsk4Rx(B, GPU_PROTO[proto], rf_mod=rf_mod, inverted=inv,
                      use_matched_filter=use_filter)
     cpu = [rx4.OracleFsk4Rx(rx4.profile(proto, rf_mod=rf_mod, use_filter=use_filter, inverted=inv)) for _ in range(B)]
     cuts = [0, 4097, 4097 + 63, 30000, 30001, 61000, n]
@@ -236,7 +238,7 @@ def _oracle_handlers(x, proto, rf_mod):
 
 HCASES = [("iq_dmr_t3_cc.npz", 2, rx4.PROTO_DMR, 2), ("iq_dmr_voice.npz", 2, rx4.PROTO_DMR, 2),
           ("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 2), ("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 0),
-          ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 0)]
+          ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 0), ("iq_nxdn96.npz", 2, rx4.PROTO_NXDN96, 2)]
 
 
 @pytest.mark.parametrize("cap,lpf,proto,rf_mod", HCASES)
@@ -255,7 +257,7 @@ def test_handlers_in_the_loop_equal_the_oracle(built, cap, lpf, proto, rf_mod):
     x[3] = -x[3]
     x[4, :5000] = 0.0
     want = [_oracle_handlers(x[c], proto, rf_mod) for c in range(B)]
-    gproto = ddn.FSK4_DMR if proto == rx4.PROTO_DMR else ddn.FSK4_NXDN48
+    gproto = GPU_PROTO[proto]
     for splits in ([0, n], [0, 9, 4000, 4001, 30000, 52345, n]):
         rx = ddn.Fsk4Rx(B, gproto, rf_mod=rf_mod, handlers=True)
         parts = [rx.run_host(x[:, a:b]) for a, b in zip(splits[:-1], splits[1:])]
@@ -296,3 +298,39 @@ def test_dmr_color_code_02_on_the_device(built):
     ev = out["events"][0, :out["n_events"][0]]
     printed = ev[ev[:, 1] == 6][:, 2]
     assert len(printed) >= 58 and set(printed) == {0}                      # DECODE_IQ_DMR_T3_RAS_CC_COLOR_CODE
+
+
+def test_nxdn96_capture_ran_00_through_the_chain_object(built):
+    """The reference's NXDN96 capture (4800 baud, tests/fixtures/iq/nxdn96.iq; DECODE_IQ_NXDN96 asserts "RAN 00",
+    tests/CMakeLists.txt:8949) through ddn_fsk4_chain with protocol NXDN96 - front end (12.5 kHz filter), receive loop with the LICH gate
+    inside, frame gather, SACCH K=5 decode + CRC6 - on the device: the frames' LICHs pass their parity, the SACCH parts pass their CRC
+    and carry Radio Access Number 0 in every superframe part; the loop's records equal the CPU restatement's"""
+    import ctypes as C
+    from conftest import golden
+    l = ddn.lib()
+    iq = np.ascontiguousarray(golden("iq_nxdn96.npz")["iq"])
+    n = len(iq)
+    ch = ddn.Fsk4ChainC(1, n, ddn.FSK4_NXDN96, rf_mod=2, handlers=1, vocoder=0)
+    d = C.c_void_p()
+    assert l.ddn_device_alloc(iq.nbytes, C.byref(d)) == 0 and l.ddn_device_upload(d, iq.ctypes.data, iq.nbytes) == 0
+    rans, n_valid, n_lich = [], 0, 0
+    for step in ("run", "flush"):
+        ch.run(d) if step == "run" else ch.flush()
+        r = ch.results()
+        S = int(r.max_syncs)
+        valid = ch.fetch(r.d_valid, np.uint8, (S,))
+        lich = ch.fetch(r.d_nxdn_lich, np.uint8, (S,))
+        ok_soft, ok_hard = ch.fetch(r.d_nxdn_sacch_ok, np.uint8, (S,)), ch.fetch(r.d_nxdn_sacch_hard_ok, np.uint8, (S,))
+        sacch = ch.fetch(r.d_nxdn_sacch, np.uint8, (S, 4))
+        sacch_hard = ch.fetch(r.d_nxdn_sacch_hard, np.uint8, (S, 32))
+        rows = np.flatnonzero(valid)
+        n_valid += len(rows)
+        n_lich += int(np.sum((lich[rows] & 0x80) != 0))
+        for s in rows:
+            bits = np.unpackbits(sacch[s])[:32] if ok_soft[s] else (sacch_hard[s] if ok_hard[s] else None)
+            if bits is not None:
+                rans.append(rx4.bits_int(bits[2:8]))
+    assert n_valid >= 30 and n_lich >= n_valid - 6      # (the first frames fall in the filter's cold start)
+    assert len(rans) >= 25 and all(v == 0 for v in rans)         # "RAN 00"
+    ch.close()
+    l.ddn_device_free(d)
