@@ -470,6 +470,8 @@ PROTOTYPES.update({
     "ddn_p25_chain_max_ldu": (C.c_int, [C.c_void_p]),
     "ddn_p25_chain_max_events": (C.c_int, [C.c_void_p]),
     "ddn_p25_chain_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_p25_chain_set_first_channel": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_mbe_batch_set_first_stream": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "ddn_p25_chain_get_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_chain_front_end": (C.c_void_p, [C.c_void_p]),
     "ddn_p25_chain_rx": (C.c_void_p, [C.c_void_p]),
@@ -644,6 +646,80 @@ class MixedChainC:
         if not h or which == 0:
             return h
         return Fsk4ChainC(self.counts[which], self.n, 0, handle=h)
+
+
+class NodeConfig(C.Structure):  # == ddn_node_config (include/ddn_node.h)
+    _fields_ = [("n_channels", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int), ("input_format", C.c_int),
+                ("vocoder", C.c_int), ("modulation", C.c_int), ("n_devices", C.c_int)]
+
+
+PROTOTYPES.update({
+    "ddn_node_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_node_create": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_node_destroy": (None, [C.c_void_p]),
+    "ddn_node_parts": (C.c_int, [C.c_void_p]),
+    "ddn_node_part_info": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_node_chain": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ddn_node_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ddn_node_run_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddn_node_wait": (C.c_int, [C.c_void_p]),
+    "ddn_node_flush": (C.c_int, [C.c_void_p]),
+    "ddn_node_device_alloc": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "ddn_node_device_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ddn_node_device_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ddn_node_device_free": (None, [C.c_void_p, C.c_int, C.c_void_p]),
+})
+
+
+def node_partition(n_channels, rank, world):
+    """ddn_node_partition: the block partition every multi-device layer here uses (== ddn_shard.channel_range)"""
+    a, b = C.c_int(), C.c_int()
+    _check(lib().ddn_node_partition(n_channels, rank, world, C.byref(a), C.byref(b)), "ddn_node_partition")
+    return a.value, b.value
+
+
+class NodeC:
+    """ddn_node (include/ddn_node.h): one P25 chain object + one host thread per device, the channel index block-partitioned"""
+
+    def __init__(self, n_channels, samples_per_call, block_len=8192, vocoder=1, input_format=0, modulation=0, n_devices=0):
+        cfg = NodeConfig(n_channels, samples_per_call, block_len, input_format, vocoder, modulation, n_devices)
+        self.h = C.c_void_p()
+        _check(lib().ddn_node_create(C.byref(cfg), C.byref(self.h)), "ddn_node_create")
+        self.parts = lib().ddn_node_parts(self.h)
+        self.info = []
+        for p in range(self.parts):
+            d, f, n = C.c_int(), C.c_int(), C.c_int()
+            _check(lib().ddn_node_part_info(self.h, p, C.byref(d), C.byref(f), C.byref(n)), "ddn_node_part_info")
+            self.info.append((d.value, f.value, n.value))
+
+    def close(self):
+        if self.h:
+            lib().ddn_node_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def chain(self, part):
+        return lib().ddn_node_chain(self.h, part)
+
+    def run_host(self, h_iq_ptr, outs=None):
+        arr = (P25ChainHostOut * self.parts)(*outs) if outs is not None else None
+        self._outs = arr                                         # the worker threads read the array during the call only
+        _check(lib().ddn_node_run_host(self.h, h_iq_ptr, arr), "ddn_node_run_host")
+
+    def run_device(self, d_ptrs):
+        arr = (C.c_void_p * self.parts)(*d_ptrs)
+        _check(lib().ddn_node_run_device(self.h, arr), "ddn_node_run_device")
+
+    def wait(self):
+        _check(lib().ddn_node_wait(self.h), "ddn_node_wait")
+
+    def flush(self):
+        _check(lib().ddn_node_flush(self.h), "ddn_node_flush")
 
 
 class P25ChainC:

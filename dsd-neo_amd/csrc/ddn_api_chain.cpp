@@ -947,6 +947,18 @@ ddn_p25_chain_set_timing(ddn_p25_chain* c, int enable) {
 }
 
 extern "C" int
+ddn_p25_chain_set_first_channel(ddn_p25_chain* c, int first) {
+    if (!c || first < 0) {
+        return DDN_EINVAL;
+    }
+    if (!c->mbe) {
+        return DDN_OK; // no vocoder: nothing here depends on a channel's number
+    }
+    const int rc = ddn_mbe_batch_set_first_stream(c->mbe, (uint32_t)first, nullptr);
+    return rc != DDN_OK ? rc : (hipDeviceSynchronize() == hipSuccess ? DDN_OK : DDN_EHIP);
+}
+
+extern "C" int
 ddn_p25_chain_get_stage_ms(ddn_p25_chain* c, float out4[4]) {
     if (!c || !out4) {
         return DDN_EINVAL;
@@ -1310,7 +1322,7 @@ ddn_host_alloc_pinned(size_t bytes, void** out) {
         return DDN_EINVAL;
     }
     *out = nullptr;
-    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable));
     return DDN_OK;
 }
 extern "C" void

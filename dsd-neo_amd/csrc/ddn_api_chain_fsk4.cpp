@@ -522,7 +522,13 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
     m->cfg = *cfg;
     int rc = DDN_OK;
     if (cfg->n_p25 > 0) {
-        ddn_p25_chain_config pc = {cfg->n_p25, cfg->samples_per_call, cfg->block_len, cfg->input_format, cfg->vocoder, 0, 0, 0, 0};
+        ddn_p25_chain_config pc;
+        memset(&pc, 0, sizeof(pc));
+        pc.n_channels = cfg->n_p25;
+        pc.samples_per_call = cfg->samples_per_call;
+        pc.block_len = cfg->block_len;
+        pc.input_format = cfg->input_format;
+        pc.vocoder = cfg->vocoder;
         rc = ddn_p25_chain_create(&pc, &m->p25);
     }
     if (rc == DDN_OK && cfg->n_dmr > 0) {

@@ -26,6 +26,7 @@
 
 struct ddn_mbe_batch {
     int codec, n_streams, tail_rule;
+    uint32_t first_stream; // number of stream 0 in the caller's numbering (the unvoiced-noise sequence of a path is a function of its number)
     int synthetic; // the loaded table blob's `synthetic` word (1 until ddn_mbe_batch_set_tables() brings real tables)
     ddn_mbe_tables* d_tables;
     float* d_half_log2;     // [57] 0.5 * log2(L)
@@ -139,8 +140,17 @@ ddn_mbe_batch_reset(ddn_mbe_batch* b, void* hip_stream) {
     if (!b) {
         return DDN_EINVAL;
     }
-    HIP_TRY(ddn_dev_mbe_stream_init(b->d_streams, b->n_streams, 0u, (hipStream_t)hip_stream));
+    HIP_TRY(ddn_dev_mbe_stream_init(b->d_streams, b->n_streams, b->first_stream, (hipStream_t)hip_stream));
     return DDN_OK;
+}
+
+extern "C" int
+ddn_mbe_batch_set_first_stream(ddn_mbe_batch* b, uint32_t first_stream, void* hip_stream) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    b->first_stream = first_stream;
+    return ddn_mbe_batch_reset(b, hip_stream);
 }
 
 extern "C" int

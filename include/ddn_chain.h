@@ -179,6 +179,9 @@ void* ddn_p25_chain_mbe(ddn_p25_chain* c);
 /* HIP events at the stage boundaries of every call while enabled; _get_stage_ms waits for the most recent call and returns the
  * milliseconds of {front end, receive loop, framer + frame FEC, voice} (meaningful for ddn_p25_chain_run on one stream) */
 int ddn_p25_chain_set_timing(ddn_p25_chain* c, int enable);
+/* Channel 0 of this object is channel `first` of a set split over several objects (include/ddn_node.h): the one result that depends on
+ * a channel's number - the vocoder's unvoiced-noise sequence - follows the global number.  Before the first call only. */
+int ddn_p25_chain_set_first_channel(ddn_p25_chain* c, int first);
 int ddn_p25_chain_get_stage_ms(ddn_p25_chain* c, float out4[4]);
 /* ---- P25 Phase 2: the TDMA channel as one object -----------------------------------------------------------------------------------
  *   cu8 / cf32 I/Q -> CQPSK demodulator at 6000 symbols/s (ddn_cqpsk_run) -> symbol-rate receive loop (ddn_cq_rx, DDN_CQ_P25P2: S-ISCH

@@ -152,6 +152,9 @@ typedef struct ddn_mbe_batch ddn_mbe_batch;
 int ddn_mbe_batch_create(int codec, int n_streams, ddn_mbe_batch** out);
 void ddn_mbe_batch_destroy(ddn_mbe_batch* b);
 int ddn_mbe_batch_reset(ddn_mbe_batch* b, void* hip_stream);
+/* Path s of this batch is path first_stream + s of a larger set split over several batches (devices): its unvoiced-noise sequence is
+ * that path's, so a partition of the paths does not show in the PCM.  Resets every path (call before the first frame). */
+int ddn_mbe_batch_set_first_stream(ddn_mbe_batch* b, uint32_t first_stream, void* hip_stream);
 int ddn_mbe_batch_set_tables(ddn_mbe_batch* b, const ddn_mbe_tables* t);
 int ddn_mbe_batch_load_tables_file(ddn_mbe_batch* b, const char* path); /* ddn_mbe_tables_load_file + _set_tables */
 /* 1 while the batch synthesizes from the built-in placeholder tables (PCM is then not intelligible speech for real traffic),

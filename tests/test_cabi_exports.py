@@ -60,10 +60,15 @@ def test_c_host_example_compiles_and_links(built, tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ddn.ROOT, "include"),
                            os.path.join(ddn.ROOT, "examples", "p25_chain_host.c"), "-L", lib_dir, "-ldsdneo_hip",
                            "-Wl,-rpath," + lib_dir, "-o", exe])
+    exe2 = str(tmp_path / "p25_node_host")                  # the same for every GPU of the node (include/ddn_node.h)
+    subprocess.check_call(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Werror", "-I", os.path.join(ddn.ROOT, "include"),
+                           os.path.join(ddn.ROOT, "examples", "p25_node_host.c"), "-L", lib_dir, "-ldsdneo_hip",
+                           "-Wl,-rpath," + lib_dir, "-o", exe2])
     import torch
     if not torch.cuda.is_available():
-        p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-        assert p.returncode == 1 and p.stderr.strip()       # ddn_last_error(): no device - never a CPU fallback
+        for e in (exe, exe2):
+            p = subprocess.run([e], capture_output=True, text=True, timeout=120)
+            assert p.returncode == 1 and p.stderr.strip()   # ddn_last_error(): no device - never a CPU fallback
 
 
 def test_configure_probe_of_the_reference_links_and_unsupported_rates_say_so(built, tmp_path):

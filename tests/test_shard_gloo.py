@@ -125,3 +125,14 @@ def test_two_rank_mixed_batch_matches_single_process(built, tmp_path):
     got = np.load(out)
     want = np.array([_mixed_channel(k, c, n) for k in range(3) for c in range(groups[k])], np.int64)
     assert np.array_equal(got, want) and got[:3, 1].min() >= 1
+
+
+def test_c_node_partition_is_the_same_rule(built):
+    """ddn_node_partition (include/ddn_node.h, the C driver of a node's devices) == ddn_shard.channel_range (one process per GPU)"""
+    import ddn
+    for n, w in ((7, 3), (32768, 8), (5, 8), (0, 2), (9, 1)):
+        got = [ddn.node_partition(n, r, w) for r in range(w)]
+        assert sum(c for _, c in got) == n and got[0][0] == 0
+        assert all(got[r + 1][0] == got[r][0] + got[r][1] for r in range(w - 1))
+        assert max(c for _, c in got) - min(c for _, c in got) <= 1 and [c for _, c in got] == sorted((c for _, c in got), reverse=True)
+        assert got == [ddn_shard.channel_range(r, w, n) for r in range(w)]
