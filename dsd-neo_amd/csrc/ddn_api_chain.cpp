@@ -90,7 +90,7 @@ struct ddn_p25_chain {
     int32_t *d_pdu_slot, *d_pdu_info, *d_n_pdu, *d_pdu_metric;
     uint8_t *d_pdu_hdr, *d_pdu_valid, *d_pdu_blocks, *d_pdu_wanted, *d_pdu_cand, *d_pdu_blocks18, *d_pdu_crc9;
     int32_t* d_pdu_cnt;
-    int16_t* d_pdu_llr;
+    int16_t *d_pdu_llr, *d_pdu_hllr;
     int64_t* d_first;
     int32_t *d_sc, *d_nldu, *d_sc_out, *d_imbe_res, *d_res_out;
     uint8_t *d_imbe_fr, *d_imbe_soft, *d_imbe_fl, *d_imbe_d;
@@ -194,7 +194,7 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
                    c->d_first, c->d_sc, c->d_nldu, c->d_sc_out, c->d_imbe_res, c->d_res_out, c->d_imbe_fr, c->d_imbe_soft,
                    c->d_imbe_fl, c->d_imbe_d, c->d_iq[0], c->d_iq[1], c->d_pdu_slot, c->d_pdu_info, c->d_n_pdu,
                    c->d_pdu_metric, c->d_pdu_hdr, c->d_pdu_valid, c->d_pdu_blocks, c->d_pdu_llr, c->d_pdu_wanted, c->d_pdu_cand,
-                   c->d_pdu_blocks18, c->d_pdu_crc9, c->d_pdu_cnt};
+                   c->d_pdu_blocks18, c->d_pdu_crc9, c->d_pdu_cnt, c->d_pdu_hllr};
     for (void* p : all) {
         (void)hipFree(p);
     }
@@ -350,7 +350,7 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
              && dalloc(&c->d_pdu_metric, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_llr, B * (size_t)c->PF * (size_t)c->PB * 196)
              && dalloc(&c->d_pdu_wanted, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_cand, B * (size_t)c->PF * (size_t)c->PB * 8 * 24)
              && dalloc(&c->d_pdu_blocks18, B * (size_t)c->PF * (size_t)c->PB * 18) && dalloc(&c->d_pdu_crc9, B * (size_t)c->PF * (size_t)c->PB)
-             && dalloc(&c->d_pdu_cnt, B * (size_t)c->PF * (size_t)c->PB);
+             && dalloc(&c->d_pdu_cnt, B * (size_t)c->PF * (size_t)c->PB) && dalloc(&c->d_pdu_hllr, B * (size_t)c->PF * 196);
         if (!ok) {
             ddn_set_error("ddn_p25_chain_create: device allocation failed");
             rc = DDN_ENOMEM;
@@ -860,8 +860,13 @@ chain_decode(ddn_p25_chain* c, int cur, int flush, hipStream_t st, hipEvent_t ev
         HIP_TRY(ddn_dev_chain_pdu_r34_wanted(c->d_pdu_slot, c->d_pdu_hdr, c->d_pdu_info, c->d_pdu_valid, (int)NB, c->PB, c->d_pdu_wanted, st));
         DDN_TRY(ddn_fec_p25_mbf34_list_batch(c->d_pdu_llr, NB, 8, c->d_pdu_wanted, (ddn_p25_mbf34_candidate*)c->d_pdu_cand, c->d_pdu_cnt, st));
         HIP_TRY(ddn_dev_chain_pdu_r34_select(c->d_pdu_cand, c->d_pdu_cnt, c->d_pdu_wanted, (int)NB, c->d_pdu_blocks18, c->d_pdu_crc9, st));
-        HIP_TRY(ddn_dev_chain_pdu_finish(c->d_pdu_slot, c->d_pdu_blocks, c->d_pdu_valid, c->d_pdu_blocks18, (int)NE, c->PB, c->d_pdu_hdr,
-                                         c->d_pdu_info, st));
+        // a header that failed its CRC16 three times over: the repetitions' LLRs summed through the list decoder, then the bitwise
+        // majority (p25_mpdu_finalize_header :381-410); the candidate / count / wanted scratch is free again here
+        HIP_TRY(ddn_dev_chain_pdu_combine(rec, c->d_cnt_full[cur], stride, d_sp, c->d_pdu_slot, c->d_pdu_info, c->d_pdu_llr, c->d_pdu_valid,
+                                          c->d_pdu_blocks, (int)NE, c->PF, c->PB, c->d_pdu_hllr, c->d_pdu_wanted, st));
+        HIP_TRY(ddn_dev_p25_half_rate_list_wanted(c->d_pdu_hllr, (int)NE, 8, c->d_pdu_wanted, (uint32_t*)c->d_pdu_cand, c->d_pdu_cnt, st));
+        HIP_TRY(ddn_dev_chain_pdu_finish(c->d_pdu_slot, c->d_pdu_blocks, c->d_pdu_valid, c->d_pdu_blocks18, c->d_pdu_cand, c->d_pdu_cnt,
+                                         c->d_pdu_wanted, (int)NE, c->PB, c->d_pdu_hdr, c->d_pdu_info, st));
     }
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[4], st));

@@ -368,6 +368,51 @@ pdu_crc16_ok(const uint8_t* b12) { // crc16_lb_bridge(bits, 80) == 0 (src/protoc
     return crc == (((uint32_t)b12[10] << 8) | b12[11]);
 }
 
+// The reference's second header fallback (p25_mpdu_try_combined_header, :336-360): when the first header block fails its CRC16 the three
+// blocks read are three repetitions of the header; if neither of the other two passes on its own, the three blocks' LLRs are added
+// position by position (saturating at int16, saturating_llr_add :36-45) and the sum goes through the half-rate list decoder.  One
+// workgroup per entry: the header block's own LLRs come from the records (payload dibit 56 + j of the frame), the other two from the
+// gather above.  wanted[e] says whether the entry takes this road at all.
+__global__ __launch_bounds__(128) void
+k_chain_pdu_combine(const uint8_t* __restrict__ rec, const int32_t* __restrict__ counts, size_t max_sym, const int32_t* __restrict__ sync_pos,
+                    const int32_t* __restrict__ pdu_slot, const int32_t* __restrict__ pdu_info, const int16_t* __restrict__ llr,
+                    const uint8_t* __restrict__ valid, const uint8_t* __restrict__ blocks12, int PF, int PB, int16_t* __restrict__ hllr,
+                    uint8_t* __restrict__ wanted) {
+    const int e = blockIdx.x, j = threadIdx.x;
+    const int slot = pdu_slot[e];
+    const int ch = e / PF;
+    bool want = slot >= 0 && pdu_info[(size_t)e * 4 + 0] == 0 && pdu_info[(size_t)e * 4 + 1] >= 3 && PB >= 2 && valid[(size_t)e * PB] != 0
+                && valid[(size_t)e * PB + 1] != 0;
+    if (want) {
+        const int cnt = counts[ch] < (int)max_sym ? counts[ch] : (int)max_sym;
+        const int n_last = 56 + 97;
+        want = sync_pos[slot] - 23 >= 0 && sync_pos[slot] - 23 + n_last + n_last / 35 < cnt
+               && !pdu_crc16_ok(blocks12 + (size_t)e * PB * 12) && !pdu_crc16_ok(blocks12 + ((size_t)e * PB + 1) * 12);
+    }
+    if (j == 0) {
+        wanted[e] = want ? 1 : 0;
+    }
+    if (j >= 98) {
+        return;
+    }
+    int a0 = 0, a1 = 0;
+    if (want) {
+        const int nn = 56 + j;
+        const uint8_t* q = rec + ((size_t)ch * max_sym + (size_t)(sync_pos[slot] - 23 + nn + nn / 35)) * 10;
+        a0 = (int16_t)((uint16_t)q[2] | ((uint16_t)q[3] << 8));
+        a1 = (int16_t)((uint16_t)q[4] | ((uint16_t)q[5] << 8));
+        for (int rep = 0; rep < 2; rep++) {
+            const int16_t* l = llr + ((size_t)e * PB + rep) * 196 + 2 * j;
+            a0 += l[0];
+            a0 = a0 > 32767 ? 32767 : (a0 < -32768 ? -32768 : a0);
+            a1 += l[1];
+            a1 = a1 > 32767 ? 32767 : (a1 < -32768 ? -32768 : a1);
+        }
+    }
+    hllr[(size_t)e * 196 + 2 * j] = (int16_t)a0;
+    hllr[(size_t)e * 196 + 2 * j + 1] = (int16_t)a1;
+}
+
 // data blocks (block_idx >= 1) take the list decoder's first candidate (p25_mpdu_decode_r12_block(), :236-239), which is not always
 // p25_12_soft_llr()'s path: the two break ties at the unprotected tail differently
 __global__ void
@@ -436,7 +481,8 @@ k_chain_pdu_r34_select(const uint8_t* __restrict__ cand24, const int32_t* __rest
 
 __global__ void
 k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restrict__ blocks12, const uint8_t* __restrict__ valid,
-                   const uint8_t* __restrict__ blocks18, int n_entries, int PB, uint8_t* __restrict__ pdu_hdr,
+                   const uint8_t* __restrict__ blocks18, const uint8_t* __restrict__ hcand16, const int32_t* __restrict__ hcount,
+                   const uint8_t* __restrict__ hwanted, int n_entries, int PB, uint8_t* __restrict__ pdu_hdr,
                    int32_t* __restrict__ pdu_info) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries || pdu_slot[e] < 0) {
@@ -449,7 +495,8 @@ k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restri
     const uint8_t* vld = valid + (size_t)e * PB;
     const bool r34 = hdr_ok && ((h[0] >> 6) & 1) && (h[0] & 0x1F) == 0x16; // (from the FIRST header, as ctx->r34)
     int flags = 0; // 1 header taken from repetition 1, 2 from repetition 2, 4 confirmed data: the blocks are rate 3/4 (blocks18),
-                   // 8 a block lies beyond the call's records or beyond PB, 16 header unusable (every repetition fails its CRC16)
+                   // 8 a block lies beyond the call's records or beyond PB, 16 header unusable (its CRC16 fails whatever was tried),
+                   // 32 header from the three repetitions' summed LLRs, 64 header = bitwise majority of the three decoded repetitions
     if (!hdr_ok) { // the header said nothing: the reference has read three blocks and tries the other two as header repetitions
         for (int rep = 1; rep <= 2 && !hdr_ok; rep++) {
             if (rep < end && rep - 1 < PB && vld[rep - 1] && pdu_crc16_ok(blk + (size_t)(rep - 1) * 12)) {
@@ -458,6 +505,28 @@ k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restri
                 }
                 hdr_ok = 1;
                 flags |= rep;
+            }
+        }
+        if (!hdr_ok && hwanted[e]) {
+            // p25_mpdu_try_combined_header (:336-360): the first candidate of the summed LLRs with a good CRC16
+            const int nc = hcount[e] < 8 ? hcount[e] : 8;
+            for (int k = 0; k < nc && !hdr_ok; k++) {
+                const uint8_t* cb = hcand16 + ((size_t)e * 8 + k) * 16;
+                if (pdu_crc16_ok(cb)) {
+                    for (int i = 0; i < 12; i++) {
+                        h[i] = cb[i];
+                    }
+                    hdr_ok = 1;
+                    flags |= 32;
+                }
+            }
+            if (!hdr_ok) { // p25_mpdu_rebuild_header_from_majority (:362-379): two of three, bit by bit; kept whether or not its CRC16 holds
+                for (int i = 0; i < 12; i++) {
+                    const uint32_t a = h[i], b = blk[i], cc = blk[12 + i];
+                    h[i] = (uint8_t)((a & b) | (a & cc) | (b & cc));
+                }
+                flags |= 64;
+                hdr_ok = pdu_crc16_ok(h) ? 1 : 0;
             }
         }
         if (!hdr_ok) {
@@ -479,7 +548,7 @@ k_chain_pdu_finish(const int32_t* __restrict__ pdu_slot, const uint8_t* __restri
     if (!all) {
         flags |= 8;
     }
-    if (hdr_ok && !(flags & (1 | 2 | 4)) && all) { // p25_mpdu_handle_rate12(): CRC32 over the data blocks but the last four bytes
+    if (hdr_ok && !(flags & (1 | 2 | 4 | 32 | 64)) && all) { // p25_mpdu_handle_rate12(): CRC32 over the data blocks but the last four bytes
         if (blks == 0) {
             crc32_ok = 1;
         } else if (blks == nd) {
@@ -805,13 +874,26 @@ ddn_dev_chain_pdu_gather(const uint8_t* rec, const int32_t* counts, size_t max_s
 }
 
 extern "C" hipError_t
-ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, const uint8_t* blocks18, int n_entries,
-                         int PB, uint8_t* pdu_hdr, int32_t* pdu_info, hipStream_t st) {
+ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, const uint8_t* blocks18,
+                         const uint8_t* hcand16, const int32_t* hcount, const uint8_t* hwanted, int n_entries, int PB, uint8_t* pdu_hdr,
+                         int32_t* pdu_info, hipStream_t st) {
     if (n_entries <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_chain_pdu_finish, dim3((unsigned)((n_entries + 63) / 64)), dim3(64), 0, st, pdu_slot, blocks12, valid, blocks18,
-                       n_entries, PB, pdu_hdr, pdu_info);
+                       hcand16, hcount, hwanted, n_entries, PB, pdu_hdr, pdu_info);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_chain_pdu_combine(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos, const int32_t* pdu_slot,
+                          const int32_t* pdu_info, const int16_t* llr, const uint8_t* valid, const uint8_t* blocks12, int n_entries, int PF,
+                          int PB, int16_t* hllr, uint8_t* wanted, hipStream_t st) {
+    if (n_entries <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_chain_pdu_combine, dim3((unsigned)n_entries), dim3(128), 0, st, rec, counts, max_sym, sync_pos, pdu_slot, pdu_info,
+                       llr, valid, blocks12, PF, PB, hllr, wanted);
     return hipGetLastError();
 }
 

@@ -383,7 +383,11 @@ hipError_t ddn_dev_chain_pdu_gather(const uint8_t* rec, const int32_t* counts, s
                                     const int32_t* pdu_slot, const int32_t* pdu_info, int n_channels, int F, int PF, int PB,
                                     int16_t* llr, uint8_t* valid, hipStream_t st);
 hipError_t ddn_dev_chain_pdu_finish(const int32_t* pdu_slot, const uint8_t* blocks12, const uint8_t* valid, const uint8_t* blocks18,
-                                    int n_entries, int PB, uint8_t* pdu_hdr, int32_t* pdu_info, hipStream_t st);
+                                    const uint8_t* hcand16, const int32_t* hcount, const uint8_t* hwanted, int n_entries, int PB,
+                                    uint8_t* pdu_hdr, int32_t* pdu_info, hipStream_t st);
+hipError_t ddn_dev_chain_pdu_combine(const uint8_t* rec, const int32_t* counts, size_t max_sym, const int32_t* sync_pos,
+                                     const int32_t* pdu_slot, const int32_t* pdu_info, const int16_t* llr, const uint8_t* valid,
+                                     const uint8_t* blocks12, int n_entries, int PF, int PB, int16_t* hllr, uint8_t* wanted, hipStream_t st);
 hipError_t ddn_dev_chain_pdu_take_first(const uint8_t* cand16, const int32_t* counts, int n_blocks, uint8_t* blocks12, int32_t* metric,
                                         hipStream_t st);
 hipError_t ddn_dev_chain_pdu_r34_wanted(const int32_t* pdu_slot, const uint8_t* pdu_hdr, const int32_t* pdu_info, const uint8_t* valid,

@@ -89,15 +89,17 @@ typedef struct ddn_p25_chain_results {
      * decoded here: half-rate trellis, best path (p25_mpdu_decode_r12_block :263-273), CRC32 over the data (crc32mbf).  When the header
      * fails its CRC16 the reference reads three blocks and tries blocks 1 / 2 as repetitions of the header: so does this.  Confirmed
      * data (A/N = 1, format 0x16 in a header with a good CRC16): the blocks go through the rate 3/4 LLR list decoder (p25p1_mbf34.c),
-     * first candidate with a good CRC9, CRC32 over the 16 payload bytes per block.  Not built: the LLR-combined / majority header
-     * (:335-379) - flagged (16), not guessed. */
+     * first candidate with a good CRC9, CRC32 over the 16 payload bytes per block.  When none of the three repetitions passes: the
+     * three blocks' LLRs summed (saturating) through the half-rate list decoder, first CRC16-clean candidate (:336-360, flag 32), else
+     * the bitwise majority of the three decoded repetitions, kept whether or not its CRC16 holds (:362-379, flag 64; + 16 when not). */
     int pdu_per_channel, pdu_blocks;
     const int32_t* d_n_pdu;        /* [B] data units whose sync this call decodes (entries beyond pdu_per_channel are counted only) */
     const int32_t* d_pdu_slot;     /* [B][pdu_per_channel] frame slot, -1 = unused entry */
     const uint8_t* d_pdu_header;   /* [..][12] */
     const int32_t* d_pdu_info;     /* [..][4] {header CRC16 good, blocks read (header included), flags, CRC32 good}; flags: 1 / 2 header
                                       taken from repetition 1 / 2, 4 confirmed data (the blocks are in d_pdu_blocks18), 8 a block beyond the
-                                      call's records or beyond pdu_blocks, 16 no header repetition with a good CRC16 */
+                                      call's records or beyond pdu_blocks, 16 the header's CRC16 fails whatever was tried, 32 header from the summed LLRs of
+                                      the three repetitions, 64 header = bitwise majority of the three decoded repetitions */
     const uint8_t* d_pdu_blocks;   /* [..][pdu_blocks][12] data blocks 1.. */
     const uint8_t* d_pdu_block_valid; /* [..][pdu_blocks] */
     const uint8_t* d_pdu_blocks18; /* [..][pdu_blocks][18] confirmed data (flag 4): DBSN(7) | CRC9, then 16 payload bytes per block */

@@ -223,6 +223,8 @@ void orc_p25h_init(orc_p25h* h, int erasure_threshold);
 void orc_p25h_no_carrier(orc_p25h* h);
 int orc_p25h_begin(orc_p25h* h);
 int orc_p25h_symbol(orc_p25h* h, long pos, int d, int l0, int l1, orc_hevents* ev);
+/* p25_mpdu_finalize_header (p25p1_mdpu.c:336-410): repetitions -> header; 0/1/2 repetition, 32 combined LLRs, 64 majority (| 16 CRC bad) */
+int orc_p25_mpdu_finalize_header(const uint8_t* rep_bytes, const int16_t* rep_llr, int hdr_reps, uint8_t out12[12]);
 
 typedef struct orc_nxdnh {
     int idx, lich;

@@ -277,6 +277,65 @@ orc_p25h_symbol(orc_p25h* h, long pos, int d, int l0, int l1, orc_hevents* ev) {
     }
 }
 
+/* p25_mpdu_finalize_header() (src/protocol/p25/phase1/p25p1_mdpu.c:381-410) with its two helpers, p25_mpdu_try_combined_header()
+ * (:336-360; saturating_llr_add :36-45) and p25_mpdu_rebuild_header_from_majority() (:362-379).
+ *   rep_bytes [3][12]  the repetitions as p25_mpdu_collect_blocks() stored them (hdr_rep_bytes: block 0 = the CRC16-selected candidate,
+ *                      blocks 1 / 2 = the list decoder's first candidate, :233-243,250-261)
+ *   rep_llr   [3][196] the blocks' LLRs (hdr_rep_llr)
+ *   hdr_reps           1..3 (:382-383: 1 when the header announces data blocks, else min(end, 3))
+ * out12 = ctx->mpdu_byte[0..11] afterwards.  Returns how it got there: 0 / 1 / 2 = that repetition's CRC16 held, 32 = the summed LLRs'
+ * list decode (first candidate with a good CRC16), 64 = bitwise majority with a good CRC16, 64 | 16 = majority, CRC16 still bad
+ * (ctx->err[0] != 0). */
+int
+orc_p25_mpdu_finalize_header(const uint8_t* rep_bytes, const int16_t* rep_llr, int hdr_reps, uint8_t out12[12]) {
+    int selected = -1;
+    for (int rep = 0; rep < hdr_reps; rep++) {
+        if (orc_p25_crc16_ok(rep_bytes + 12 * rep, 10) == 0) {
+            selected = rep;
+            break;
+        }
+    }
+    if (selected >= 0) {
+        memcpy(out12, rep_bytes + 12 * selected, 12);
+        return selected;
+    }
+    memcpy(out12, rep_bytes, 12); /* (ctx->mpdu_byte[0..11] holds block 0 as stored, :263-277) */
+    if (hdr_reps > 1) {
+        int16_t comb[196];
+        for (int bit = 0; bit < 196; bit++) {
+            int acc = 0;
+            for (int rep = 0; rep < hdr_reps; rep++) {
+                acc += rep_llr[196 * rep + bit];
+                acc = acc > 32767 ? 32767 : (acc < -32768 ? -32768 : (int16_t)acc);
+            }
+            comb[bit] = (int16_t)acc;
+        }
+        uint8_t cand[8][12];
+        uint32_t metric[8];
+        const int n = orc_p25_12_soft_llr_list(comb, &cand[0][0], metric, 8);
+        for (int c = 0; c < n; c++) {
+            if (orc_p25_crc16_ok(cand[c], 10) == 0) {
+                memcpy(out12, cand[c], 12);
+                return 32;
+            }
+        }
+    }
+    const int thresh = (hdr_reps >= 2) ? ((hdr_reps + 1) / 2) : 1;
+    uint8_t maj[12];
+    memset(maj, 0, sizeof(maj));
+    for (int bit = 0; bit < 96; bit++) {
+        int sum = 0;
+        for (int rep = 0; rep < hdr_reps; rep++) {
+            sum += (rep_bytes[12 * rep + (bit >> 3)] >> (7 - (bit & 7))) & 1;
+        }
+        if (sum >= thresh) {
+            maj[bit >> 3] |= (uint8_t)(0x80 >> (bit & 7));
+        }
+    }
+    memcpy(out12, maj, 12);
+    return orc_p25_crc16_ok(maj, 10) == 0 ? 64 : (64 | 16);
+}
+
 /* ---------------------------------------------------------------------------------------------------- NXDN ---- */
 static const uint8_t k_nxdn_lich_ok[] = {0x01, 0x05, 0x28, 0x29, 0x49, 0x2E, 0x2F, 0x4E, 0x4F, 0x32, 0x33, 0x52, 0x53,
                                          0x34, 0x35, 0x54, 0x55, 0x36, 0x37, 0x56, 0x57, 0x20, 0x21, 0x30, 0x31, 0x40,

@@ -176,11 +176,13 @@ def confirmed_block(dbsn, payload16, good_crc9=True):
     return np.array([((dbsn & 0x7F) << 1) | (c >> 8), c & 0xFF] + [int(x) for x in payload16], np.uint8)
 
 
-def make_pdu_coded(rng, nac, blks, sap=0, good_crc16=True, good_crc32=True, confirmed=False, header_reps=0, bad_crc9_at=()):
+def make_pdu_coded(rng, nac, blks, sap=0, good_crc16=True, good_crc32=True, confirmed=False, header_reps=0, bad_crc9_at=(), combined=False):
     """a data unit as the reference decodes it: header block (CRC16), blks half-rate coded data blocks whose last four bytes are the
     CRC32 of the rest -> (dibits, header12, data [blks][12]); confirmed = True: A/N = 1, format 0x16 and rate 3/4 blocks
     (data [blks][18]).  header_reps > 0 (with good_crc16 = False and blks = 0 in
-    the header): the first header fails its CRC16 and header_reps good copies follow, as the reference's repetition fallback expects"""
+    the header): the first header fails its CRC16 and header_reps good copies follow, as the reference's repetition fallback expects.
+    combined = True (blks = 0): three copies of a good header, each with a different third of its 98 dibits sent with the wrong sign -
+    none decodes on its own, the position-wise sum of their LLRs does (p25_mpdu_try_combined_header)"""
     hdr = rng.integers(0, 256, 10)
     hdr[0] = (int(hdr[0]) & 0xA0) | ((0x40 | 0x16) if confirmed else (int(hdr[0]) & 0x0F))      # AN / format
     hdr[1] = (int(hdr[1]) & 0xC0) | (sap & 0x3F)
@@ -193,7 +195,14 @@ def make_pdu_coded(rng, nac, blks, sap=0, good_crc16=True, good_crc32=True, conf
     first = good if good_crc16 else bad
     pay = list(encode_half_rate(list(first)))
     data = np.zeros((max(blks, header_reps), 12), np.uint8)
-    if header_reps:
+    if combined:
+        pay = []
+        for k, (a, b) in enumerate(((0, 33), (33, 66), (66, 98))):
+            d = np.array(encode_half_rate(list(good)))
+            d[a:b] ^= 2
+            pay += list(d)
+        data = np.stack([good, good])
+    elif header_reps:
         for k in range(header_reps):
             data[k] = good
     elif blks and confirmed and good_crc16:       # confirmed data: rate 3/4 blocks of DBSN | CRC9 | 16 bytes, CRC32 ends the payload
@@ -208,7 +217,7 @@ def make_pdu_coded(rng, nac, blks, sap=0, good_crc16=True, good_crc32=True, conf
         c32 = crc32mbf(flat, 96 * blks - 32) ^ (0 if good_crc32 else 0x00010000)
         flat[-4:] = [(c32 >> 24) & 0xFF, (c32 >> 16) & 0xFF, (c32 >> 8) & 0xFF, c32 & 0xFF]
         data = flat.reshape(blks, 12)
-    if data.shape[1] == 12:
+    if data.shape[1] == 12 and not combined:
         for k in range(len(data)):
             pay += list(encode_half_rate(list(data[k])))
     n_pay = 24 + 32 + len(pay)

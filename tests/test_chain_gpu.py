@@ -329,7 +329,8 @@ def test_data_units_header_blocks_and_crc32(built):
     parts = [p25gen.make_frames(rng, 1, nac, crc=True, blocks=1)[0], np.zeros(160, np.int8)]      # (the slicer settles on this one)
     plan = [dict(blks=2), dict(blks=0), dict(blks=5), dict(blks=1, good_crc32=False), dict(blks=3, confirmed=True),
             dict(blks=4, confirmed=True, bad_crc9_at=(1,)), dict(blks=2, confirmed=True, good_crc32=False),
-            dict(blks=0, good_crc16=False, header_reps=2), dict(blks=7), dict(blks=4), dict(blks=2, good_crc16=False), dict(blks=6)]
+            dict(blks=0, good_crc16=False, header_reps=2), dict(blks=7), dict(blks=4), dict(blks=2, good_crc16=False), dict(blks=6),
+            dict(blks=0, combined=True), dict(blks=1), dict(blks=0, combined=True)]
     for kw in plan:
         fr, hdr, data = p25gen.make_pdu_coded(rng, nac, **kw)
         units.append((kw, hdr, data, sum(len(q) for q in parts)))
@@ -411,7 +412,19 @@ def test_data_units_header_blocks_and_crc32(built):
                 if bb is not None and p25gen.crc16_ccitt(bb[:10]) == ((int(bb[10]) << 8) | int(bb[11])):
                     w_hdr, ok, flags = bb, 1, flags | rep
                     break
-            if not ok:
+            if not ok and w_end >= 3 and len(blocks) >= 2 and blocks[0] is not None and blocks[1] is not None:
+                # every repetition failed: the summed LLRs through the list decoder, then the bitwise majority (:336-410)
+                idx0 = [a - 23 + n + n // 35 for n in range(56, 56 + 98)]
+                l0 = np.stack([rec4[idx0, 2], rec4[idx0, 3]], axis=1).reshape(196).astype(np.int16)
+                o.orc_p25_mpdu_finalize_header.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                rb = np.ascontiguousarray(np.stack([w_hdr, blocks[0], blocks[1]]).astype(np.uint8))
+                ll = np.ascontiguousarray(np.stack([l0, llrs[0], llrs[1]]))
+                out = np.zeros(12, np.uint8)
+                how = o.orc_p25_mpdu_finalize_header(rb.ctypes.data, ll.ctypes.data, 3, out.ctypes.data)
+                assert how in (32, 64, 64 | 16), how
+                w_hdr, flags = out, flags | how
+                ok = 0 if how & 16 else 1
+            elif not ok:
                 flags |= 16
         r34 = bool(w_crc) and bool((w_hdr[0] >> 6) & 1) and (w_hdr[0] & 0x1F) == 0x16          # (the FIRST header decides)
         if r34:
@@ -420,7 +433,7 @@ def test_data_units_header_blocks_and_crc32(built):
             flags |= 8
         blks = int(w_hdr[6]) & 0x7F
         crc32 = 0
-        if ok and not (flags & 15):
+        if ok and not (flags & (15 | 32 | 64)):
             if blks == 0:
                 crc32 = 1
             elif blks == w_end - 1:
@@ -460,11 +473,13 @@ def test_data_units_header_blocks_and_crc32(built):
                 assert np.array_equal(blk18[b], data_sent[b]) and crc9ok[b] == (0 if b in kw.get("bad_crc9_at", ()) else 1), (a, kw, b)
         seen_flags.add(flags)
         # the clean units decode to what was sent
-        if kw.get("good_crc16", True) and not kw.get("confirmed"):
+        if kw.get("combined"):
+            assert flags == 32 and ok == 1 and np.array_equal(hdr, hdr_sent), (a, kw, flags, hdr, hdr_sent)
+        elif kw.get("good_crc16", True) and not kw.get("confirmed"):
             assert ok == 1 and np.array_equal(hdr, hdr_sent) and w_end == kw["blks"] + 1
             assert crc32 == (1 if kw.get("good_crc32", True) else 0), (a, kw)
             assert all(np.array_equal(blk[b], data_sent[b]) for b in range(kw["blks"]))
-    assert {0, 1, 4} <= seen_flags, seen_flags
+    assert {0, 1, 4, 32, 64 | 16} <= seen_flags, seen_flags
 
 
 def test_syncs_beyond_the_frame_slots_are_counted_not_lost_silently(built):

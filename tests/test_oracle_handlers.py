@@ -146,3 +146,85 @@ def test_nxdn48_lich_gate(built):
             while fl[a + 1 + n_in] & 1 and not fl[a + 1 + n_in] & 2:
                 n_in += 1
             assert n_in == (182 if ok else 8)
+
+
+# ---- P25 data-unit header fallbacks (p25_mpdu_finalize_header) ------------------------------------------------------------------------
+# The reference's own known answers (tests/protocol/p25/test_p25_p1_mdpu_helpers.c:160-165,463-521: three CRC16-clean headers; "best
+# rep", "majority rebuilt", "combined header" cases).  Its test feeds the static function through stubs (fake CRC words, a stubbed list
+# decoder); here the same three outcomes are reached through real inputs - the CRC16 is computed, the list decoder runs.
+HDR_A = bytes([0x00, 0x00, 0x00, 0x10, 0x0A, 0x11, 0x11, 0x00, 0x01, 0x01, 0xAE, 0x8E])
+HDR_B = bytes([0x80, 0x00, 0x00, 0x10, 0x0A, 0x22, 0x22, 0x00, 0x02, 0x02, 0x7A, 0x83])
+HDR_C = bytes([0xBB, 0x00, 0x00, 0xAB, 0xCD, 0xE1, 0x23, 0x81, 0x23, 0x00, 0x51, 0x97])
+
+
+def _finalize(reps, llr, n):
+    import ctypes as C
+    o = orc.oracle()
+    o.orc_p25_mpdu_finalize_header.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    rb = np.ascontiguousarray(np.array([list(r) for r in reps], np.uint8))
+    ll = np.ascontiguousarray(llr, np.int16)
+    out = np.zeros(12, np.uint8)
+    how = o.orc_p25_mpdu_finalize_header(rb.ctypes.data, ll.ctypes.data, n, out.ctypes.data)
+    return how, bytes(out.tolist())
+
+
+def _llr_of(bytes12, amp=600):
+    import p25gen
+    d = np.asarray(p25gen.encode_half_rate(list(bytes12)), np.int64)
+    l = np.zeros(196, np.int64)
+    l[0::2] = (2 * ((d >> 1) & 1) - 1) * amp
+    l[1::2] = (2 * (d & 1) - 1) * amp
+    return l
+
+
+def test_mpdu_header_reference_vectors_are_crc_clean():
+    import p25gen
+    for h in (HDR_A, HDR_B, HDR_C):
+        assert p25gen.crc16_ccitt(np.frombuffer(h[:10], np.uint8)) == (h[10] << 8 | h[11])
+
+
+def test_mpdu_finalize_header_best_repetition():
+    """repetition 1 is the only one whose CRC16 holds (reference test: hdr_rep_crc {7, 0, 9}) -> it is the header"""
+    junk = bytes(range(0xA0, 0xAC))
+    how, out = _finalize([junk, HDR_A, junk], np.zeros((3, 196)), 3)
+    assert (how, out) == (1, HDR_A)
+    how, out = _finalize([HDR_B, HDR_A, junk], np.zeros((3, 196)), 3)       # the FIRST clean one
+    assert (how, out) == (0, HDR_B)
+    how, out = _finalize([junk, HDR_A, junk], np.zeros((3, 196)), 1)        # the header announced data: only block 0 counts (:382-383)
+    assert how == (64 | 16) and out == junk
+
+
+def test_mpdu_finalize_header_majority():
+    """no repetition is clean and the summed LLRs decode to nothing clean: two of three, bit by bit (reference test: three copies of
+    header C -> header C, CRC 0); here each copy has its own bit error"""
+    reps = []
+    for k, (byte, bit) in enumerate(((0, 0x80), (5, 0x01), (11, 0x10))):
+        b = bytearray(HDR_C)
+        b[byte] ^= bit
+        reps.append(bytes(b))
+    how, out = _finalize(reps, np.zeros((3, 196)), 3)
+    assert (how, out) == (64, HDR_C)
+    reps[1] = reps[0]                                                        # two copies share the error: it wins, CRC16 stays bad
+    how, out = _finalize(reps, np.zeros((3, 196)), 3)
+    assert how == (64 | 16) and out == reps[0]
+
+
+def test_mpdu_finalize_header_combined_llrs():
+    """no repetition decodes clean on its own, the position-wise sum of the three does (reference test: stubbed candidates {junk, header B}
+    -> header B, soft-combined counter 1).  Each repetition is header B with a different third of the block wiped out with strong wrong
+    values: the decoded bytes are whatever they are, the sum is right two to one everywhere"""
+    good = _llr_of(HDR_B)
+    llr = np.stack([good, good, good])
+    for k in range(3):
+        llr[k, 64 * k:64 * k + 64] *= -1
+    import chain_stream
+    reps = []
+    for k in range(3):
+        by, ok, _ = chain_stream.oracle_tsbk(llr[k])
+        assert not ok
+        reps.append(bytes(by.tolist()))
+    how, out = _finalize(reps, llr, 3)
+    assert (how, out) == (32, HDR_B)
+    # saturation (saturating_llr_add :36-45): 3 x 32767 stays 32767 and still decodes
+    how, out = _finalize(reps, np.clip(llr * 1000, -32768, 32767), 3)
+    assert (how, out) == (32, HDR_B)
