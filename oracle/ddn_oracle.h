@@ -333,6 +333,8 @@ typedef struct orc_fsk4_profile {
     int lock_symbols[4];
     int handler; /* 0 = lock_symbols[] per sync class, 1 = the reference's handlers decide (ddn_oracle_handlers.c) */
     int proto;   /* handler family when handler = 1: 0 P25p1, 1 DMR, 2 NXDN */
+    int m17;     /* 1: frame_sync_try_m17()'s matcher (8-symbol words, one error allowed, accepted by what came before) in place of
+                    the exact pattern table; the table then only carries type / polarity / class of the twelve outcomes */
 } orc_fsk4_profile;
 typedef struct orc_fsk4rx {
     orc_fsk4_profile p;
@@ -354,7 +356,11 @@ typedef struct orc_fsk4rx {
     orc_nxdnh hnxdn;
     long n_sym;
     orc_hevents* ev;
+    int m17_pol; /* state->m17_polarity: 0 unknown, 1 normal, 2 inverted (set by the preamble, cleared by EOT / no carrier) */
+    float* sync_thr; /* optional: {center, umid, lmid, max, min} as every accepted sync leaves them, [sync_thr_max][5] */
+    int sync_thr_max, sync_thr_n;
 } orc_fsk4rx;
+void orc_fsk4rx_set_sync_thresholds(orc_fsk4rx* r, float* buf, int max_syncs);
 void orc_fsk4rx_set_events(orc_fsk4rx* r, orc_hevents* ev);
 void orc_p25rx_set_events(orc_p25rx* r, orc_hevents* ev);
 void orc_fsk4rx_init(orc_fsk4rx* r, const orc_fsk4_profile* p);
@@ -370,6 +376,17 @@ void orc_fsk4_window(int rf_mod, int narrow, int* l_edge, int* r_edge);
 size_t orc_fsk4rx_sizeof(void);
 size_t orc_fsk4_profile_sizeof(void);
 void orc_fsk4rx_get_thresholds(const orc_fsk4rx* r, float out7[7]);
+
+/* ---- M17 frames behind the loop (oracle/ddn_oracle_m17.c) ---------------------------------------------------------- */
+int orc_m17_rand_bit(int i);
+int orc_m17_interleave_index(int i);
+uint16_t orc_m17_crc16(const uint8_t* in, int len);
+uint16_t orc_m17_soft_cost(float symbol, const float thr5[5], int bit);
+void orc_m17_lsf_costs(const float* sym184, const float thr5[5], uint16_t cost488[488]);
+int orc_m17_lsf_decode(const uint16_t cost488[488], uint8_t lsf30[30], uint32_t* path_cost);
+void orc_m17_payload_bits(const uint8_t* dibits184, uint8_t bits368[368]);
+int orc_m17_str_decode(const uint8_t* dibits184, uint8_t lich6[6], int* lich_cnt, uint8_t fn_payload18[18]);
+int orc_m17_callsign(uint64_t address, char out10[10]);
 
 void orc_level_estimate(const float* sorted, int count, float* lo, float* hi);
 int orc_slicer_warm_start(orc_slicer* s, const float* newest_first, int sync_len);

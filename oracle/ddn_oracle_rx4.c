@@ -32,6 +32,13 @@
  * hunting; non-inverted DMR only; the handler of a sync type consumes a configured number of symbols
  * (lock_symbols[class]: DMR data 54 + 66 = 120, src/protocol/dmr/dmr_data.c:213-302; NXDN 182; DMR voice = the host's
  * call length) instead of running the protocol decoders.
+ *
+ * M17 (profile.m17, round 5): -fz = C4FM lock at 4800 symbols/s with NO matched filter (decode_mode_apply_m17(),
+ * src/runtime/decode_mode.c:486-510: use_cosine_filter = 0), static in-frame thresholds (use_symbol() :269-283 keeps them live for
+ * P25p1 / QPSK only), 8-symbol warm start.  The matcher is frame_sync_try_m17() (src/dsp/dsd_frame_sync.c:1060-1100): Hamming
+ * distance of the last eight sign dibits to the preamble / EOT / LSF / BERT / stream / packet words, each accepted only after the
+ * sync type that may precede it, polarity learnt from the preamble; the handlers consume fixed counts (dispatch_m17.c:25-68:
+ * preamble skipDibit(8), EOT skipDibit(184) then lastsynctype = NONE, every frame type 184 dibits).
  */
 #include <string.h>
 
@@ -59,7 +66,8 @@ orc_fsk4rx_set_events(orc_fsk4rx* r, orc_hevents* ev) {
 }
 
 static void
-no_carrier(orc_fsk4rx* r) { /* engine.c:1838-1847 as far as this loop sees it */
+no_carrier(orc_fsk4rx* r) { /* engine.c:1838-1848 as far as this loop sees it */
+    r->m17_pol = 0;
     r->jitter = -1;
     r->lastsync = 0;
     r->filter_on = 0;
@@ -295,6 +303,77 @@ warm_start(orc_fsk4rx* r, int len) {
     (void)orc_slicer_warm_start(&r->sl, nf, len);
 }
 
+/* frame_sync_try_m17(), src/dsp/dsd_frame_sync.c:865-1100, with only M17 enabled (max_hamming 1 for the preamble, no repeated-marker
+ * rule: that one is D-STAR's).  w8 = the last eight sign dibits ('1' -> 1), oldest first.  Returns the outcome's row in the M17 table
+ * (tests/rx4.py: 0 / 1 preamble + / -, 2 / 3 EOT, 4 / 5 LSF, 6 / 7 BERT, 8 / 9 stream, 10 / 11 packet) or -1. */
+enum { M17_W_LSF = 0xF2, M17_W_STR = 0x0D, M17_W_PRE = 0x55, M17_W_PIV = 0xAA, M17_W_BRT = 0x4F, M17_W_PKT = 0xB0, M17_W_EOT = 0xFD, M17_W_EOT_INV = 0x02 };
+static int
+m17_ham(uint32_t w8, uint32_t word) {
+    return __builtin_popcount((w8 ^ word) & 0xFFu);
+}
+static int
+m17_match(orc_fsk4rx* r, uint32_t w8) {
+    const orc_fsk4_profile* p = &r->p;
+    const int last = r->lastsync;
+    const int t_pre_p = p->pat_type[0], t_pre_n = p->pat_type[1], t_lsf_p = p->pat_type[4], t_lsf_n = p->pat_type[5];
+    const int t_brt_p = p->pat_type[6], t_brt_n = p->pat_type[7], t_str_p = p->pat_type[8], t_str_n = p->pat_type[9];
+    const int t_pkt_p = p->pat_type[10], t_pkt_n = p->pat_type[11];
+    const int inv = r->m17_pol == 2; /* opts->inverted_m17 = 0 */
+    /* preamble first (:865-903) */
+    if (m17_ham(w8, M17_W_PRE) <= 1) {
+        r->m17_pol = 1;
+        return 0;
+    }
+    if (m17_ham(w8, M17_W_PIV) <= 1) {
+        r->m17_pol = 2;
+        return 1;
+    }
+    /* EOT, only after a frame type (:905-933) */
+    {
+        const int ham = inv ? m17_ham(w8, M17_W_EOT_INV) : m17_ham(w8, M17_W_EOT);
+        const int after_frame = last == t_lsf_p || last == t_lsf_n || last == t_str_p || last == t_str_n || last == t_pkt_p
+                                || last == t_pkt_n || last == t_brt_p || last == t_brt_n;
+        if (ham <= 1 && after_frame) {
+            r->m17_pol = 0;
+            return inv ? 3 : 2;
+        }
+    }
+    /* LSF after the preamble, BERT after the preamble or a BERT frame (:1005-1058) */
+    {
+        const int after_pre = (!inv && last == t_pre_p) || (inv && last == t_pre_n);
+        const int after_brt = (!inv && last == t_brt_p) || (inv && last == t_brt_n);
+        if (after_pre || after_brt) {
+            if (after_pre && (inv ? m17_ham(w8, M17_W_STR) : m17_ham(w8, M17_W_LSF)) <= 1) {
+                return inv ? 5 : 4;
+            }
+            if ((inv ? m17_ham(w8, M17_W_PKT) : m17_ham(w8, M17_W_BRT)) <= 1) {
+                return inv ? 7 : 6;
+            }
+        }
+    }
+    /* stream frames after an LSF or a stream frame (:965-995) */
+    if (m17_ham(w8, M17_W_STR) <= 1 && !inv) {
+        if (last == t_lsf_p || last == t_str_p) {
+            return 8;
+        }
+    } else if (m17_ham(w8, M17_W_LSF) <= 1 && inv) {
+        if (last == t_lsf_n || last == t_str_n) {
+            return 9;
+        }
+    }
+    /* packet frames after an LSF or a packet frame (:935-963) */
+    if (m17_ham(w8, M17_W_PKT) <= 1 && !inv) {
+        if (last == t_lsf_p || last == t_pkt_p) {
+            return 10;
+        }
+    } else if (m17_ham(w8, M17_W_BRT) <= 1 && inv) {
+        if (last == t_lsf_n || last == t_pkt_n) {
+            return 11;
+        }
+    }
+    return -1;
+}
+
 /* One finished symbol.  pay2 = {payload dibit, reliability}.  Returns the flag bits. */
 static int
 symbol_commit(orc_fsk4rx* r, float sym, int rec4[4], uint8_t pay2[2]) {
@@ -338,6 +417,10 @@ symbol_commit(orc_fsk4rx* r, float sym, int rec4[4], uint8_t pay2[2]) {
                 hunt_enter(r);
             }
         } else if (--r->lock_left <= 0) {
+            if (p->m17 && (r->cur_pat == 2 || r->cur_pat == 3)) { /* dsd_dispatch_handle_m17(): the EOT handler ends the transmission */
+                r->lastsync = 0;
+                r->m17_pol = 0;
+            }
             hunt_enter(r);
         }
         return flags;
@@ -375,10 +458,14 @@ symbol_commit(orc_fsk4rx* r, float sym, int rec4[4], uint8_t pay2[2]) {
             const uint32_t mask = (p->win_len >= 24) ? 0xFFFFFFu : ((1u << p->win_len) - 1u);
             const uint32_t w = r->hist_bits & mask;
             int hit = -1;
-            for (int k = 0; k < p->n_pat; k++) {
-                if (w == p->pat_bits[k]) {
-                    hit = k;
-                    break;
+            if (p->m17) {
+                hit = m17_match(r, w);
+            } else {
+                for (int k = 0; k < p->n_pat; k++) {
+                    if (w == p->pat_bits[k]) {
+                        hit = k;
+                        break;
+                    }
                 }
             }
             if (hit >= 0) {
@@ -406,9 +493,14 @@ symbol_commit(orc_fsk4rx* r, float sym, int rec4[4], uint8_t pay2[2]) {
                                 }
                             }
                         }
-                    } else {
+                    } else if (!(p->m17 && (hit == 2 || hit == 3))) { /* (the EOT marker takes the basic lock only, :905-933) */
                         warm_start(r, p->warm_len);
                     }
+                    if (r->sync_thr && r->sync_thr_n < r->sync_thr_max) {
+                        float* t = r->sync_thr + 5 * (size_t)r->sync_thr_n;
+                        t[0] = s->center, t[1] = s->umid, t[2] = s->lmid, t[3] = s->max, t[4] = s->min;
+                    }
+                    r->sync_thr_n++;
                     r->have_sync = 1;
                     r->cur_pat = hit;
                     r->lock_left = p->lock_symbols[p->pat_class[hit] & 3];
@@ -500,6 +592,13 @@ orc_fsk4rx_run(orc_fsk4rx* r, const float* in, long n, float* out_sym, int* rec4
     }
     *n_sync = ns;
     return o;
+}
+
+void
+orc_fsk4rx_set_sync_thresholds(orc_fsk4rx* r, float* buf, int max_syncs) { /* restarts the count */
+    r->sync_thr = buf;
+    r->sync_thr_max = max_syncs;
+    r->sync_thr_n = 0;
 }
 
 size_t

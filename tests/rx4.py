@@ -21,11 +21,17 @@ DMR_DM2_DATA, DMR_DM2_VOICE = "311311111333113333133311", "133133333111331111311
 NXDN_POS = ["3131331131", "3331331131", "3131331111", "3331331111", "3131311131"]
 NXDN_NEG = ["1313113313", "1113113313", "1313113333", "1113113333", "1313133313"]
 
-PROTO_P25P1, PROTO_DMR, PROTO_NXDN48, PROTO_NXDN96 = 0, 1, 2, 3
+PROTO_P25P1, PROTO_DMR, PROTO_NXDN48, PROTO_NXDN96, PROTO_M17 = 0, 1, 2, 3, 4
 # sync type ids carried in lastsync (any non-zero numbering works; these mirror synctype_ids.h + 1 so 0 stays "none")
 T_P25_POS, T_P25_NEG = 1, 2
 T_DMR_BS_DATA, T_DMR_BS_VOICE, T_DMR_MS_VOICE, T_DMR_MS_DATA = 11, 13, 33, 34
 T_NXDN_POS, T_NXDN_NEG = 29, 30
+# M17: the twelve outcomes of frame_sync_try_m17() in the order the loops number them (flags pattern index / sync_pat)
+M17_PRE_POS, M17_PRE_NEG, M17_EOT_POS, M17_EOT_NEG, M17_LSF_POS, M17_LSF_NEG = 0, 1, 2, 3, 4, 5
+M17_BRT_POS, M17_BRT_NEG, M17_STR_POS, M17_STR_NEG, M17_PKT_POS, M17_PKT_NEG = 6, 7, 8, 9, 10, 11
+M17_TYPES = [99, 100, 101, 102, 17, 18, 77, 78, 9, 10, 87, 88]      # synctype_ids.h:52-63, + 1
+M17_WORDS = {"LSF": "11113313", "STR": "33331131", "PRE": "31313131", "PIV": "13131313", "BRT": "31331111", "PKT": "13113333",
+             "EOT": "11111131", "EOT_INV": "33333313"}                # include/dsd-neo/core/sync_patterns.h:18-28
 CLASS_DATA, CLASS_VOICE = 0, 1
 
 
@@ -41,7 +47,8 @@ class Profile(C.Structure):
                 ("warm_len", C.c_int), ("n_pat", C.c_int), ("pat_bits", C.c_uint32 * MAX_PAT), ("pat_type", C.c_uint8 * MAX_PAT),
                 ("pat_neg", C.c_uint8 * MAX_PAT), ("pat_class", C.c_uint8 * MAX_PAT), ("confirm", C.c_int),
                 ("live_thresholds", C.c_int), ("dmr_window", C.c_int), ("redigitize", C.c_int), ("slow_type", C.c_int),
-                ("use_filter", C.c_int), ("nt", C.c_int), ("taps", C.c_uint32 * MAX_TAPS), ("lock_symbols", C.c_int * 4), ("handler", C.c_int), ("proto", C.c_int)]
+                ("use_filter", C.c_int), ("nt", C.c_int), ("taps", C.c_uint32 * MAX_TAPS), ("lock_symbols", C.c_int * 4), ("handler", C.c_int), ("proto", C.c_int),
+                ("m17", C.c_int)]
 
 
 def _taps(name):
@@ -79,6 +86,17 @@ def profile(proto, rf_mod=0, use_filter=1, lock=None, out_rate=48000, inverted=0
             pats = [(s_, swap[t][0], swap[t][1], cl ^ 1) for (s_, t, neg, cl) in pats]
         taps = _taps("dmr")
         lock = lock or [120, 54 + 288 * 6, 0, 0]
+    elif proto == PROTO_M17:
+        # -fz: C4FM lock at 4800 symbols/s, no matched filter (decode_mode_apply_m17: use_cosine_filter = 0), 8-symbol words matched
+        # with one error allowed by frame_sync_try_m17() (the pattern table only names the twelve outcomes: type, polarity, class);
+        # class 0 = a frame or the EOT marker (184 dibits), class 1 = the preamble (skipDibit(8))
+        p.m17 = 1
+        p.proto = PROTO_P25P1       # (no handler family: fixed counts)
+        p.use_filter = 0
+        p.sym_rate, p.win_len, p.t_max, p.warm_len = 4800, 8, 24, 8
+        pats = [("11111111", t, k & 1, 1 if k < 2 else 0) for k, t in enumerate(M17_TYPES)]
+        taps = _taps("dmr")         # (unused)
+        lock = lock or [184, 8, 0, 0]
     elif proto == PROTO_NXDN96:
         # 4800 symbols/s on the 4800_4 hunt profile (level ring 24, src/dsp/dsd_frame_sync.c:1729-1744, matcher :1525-1556), the same
         # frame sync words, LICH gate and 182-symbol frame as NXDN48; the matched filter is the DMR one at every rate but 8 samples
@@ -135,12 +153,15 @@ class OracleFsk4Rx:
         spos, spat = np.zeros(ms, np.int32), np.zeros(ms, np.uint8)
         pre, prel = np.zeros((ms, PRE), np.uint8), np.zeros((ms, PRE), np.uint8)
         ns = C.c_int(0)
+        thr = np.zeros((ms, 5), np.float32)       # {center, umid, lmid, max, min} as each accepted sync leaves them
+        self.o.orc_fsk4rx_set_sync_thresholds.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.o.orc_fsk4rx_set_sync_thresholds(self.st, thr.ctypes.data, ms)
         k = self.o.orc_fsk4rx_run(self.st, x.ctypes.data, x.size, sym.ctypes.data, rec.ctypes.data, fl.ctypes.data, pay.ctypes.data,
                                   cap, spos.ctypes.data, spat.ctypes.data, pre.ctypes.data, prel.ctypes.data, ms, C.byref(ns))
         assert k <= cap and ns.value <= ms
         n = ns.value
         return dict(sym=sym[:k].copy(), rec4=rec[:k].copy(), fl=fl[:k].copy(), pay=pay[:k].copy(), sync_pos=spos[:n].copy(),
-                    sync_pat=spat[:n].copy(), pre=pre[:n].copy(), pre_rel=prel[:n].copy())
+                    sync_pat=spat[:n].copy(), pre=pre[:n].copy(), pre_rel=prel[:n].copy(), sync_thr=thr[:n].copy())
 
     def thresholds(self):
         t = np.zeros(7, np.float32)
