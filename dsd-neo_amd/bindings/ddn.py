@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
-LIB_PATH = os.path.join(ROOT, "dsd-neo_amd", "libdsdneo_hip.so")
+LIB_PATH = os.environ.get("DDN_LIB_PATH") or os.path.join(ROOT, "dsd-neo_amd", "libdsdneo_hip.so")  # DDN_LIB_PATH: timing-experiment builds (tools/build_variant.sh)
 
 DDN_OK, DDN_EINVAL, DDN_ENODEV, DDN_ENOMEM, DDN_EHIP, DDN_ERANGE = 0, -1, -2, -3, -4, -5
 LPF_WIDE, LPF_6K25, LPF_12K5, LPF_PROVOICE, LPF_P25_C4FM, LPF_P25_CQPSK = range(6)

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
 #include "ddn_device.h"
 #include "ddn_nid_dev.h"
 
@@ -254,11 +255,65 @@ k_nid_chase(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel6
     }
 }
 
+// One NID per wavefront through nid_decode_wave() - the decoder the receive loops' handler waves run (ddn_rx.hip, ddn_cqrx.hip):
+// hard decode with the polynomials spread over the lanes, then the Chase candidates one per lane.  Small batches take this route:
+// a word with bit errors costs one lane of k_nid_decode ~100 k cycles of dependent table look-ups, a wavefront ~10 k.
+__global__ __launch_bounds__(64) void
+k_nid_wave(const uint8_t* __restrict__ bits63, const uint8_t* __restrict__ rel63, const int32_t* __restrict__ obs_nac,
+           const uint8_t* __restrict__ parity, const uint8_t* __restrict__ parity_rel, int threshold, int n,
+           int32_t* __restrict__ out4) {
+    __shared__ uint8_t ex[128];
+    __shared__ uint8_t lg[64];
+    __shared__ uint8_t work[(23 + 24 + 24 + 24) * 64];
+    __shared__ uint8_t masks[96];
+    __shared__ uint8_t relb[64];
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        gf_fill(ex, lg);
+        chase_masks_fill(masks);
+    }
+    const int c = blockIdx.x;
+    const uint8_t* bp = bits63 + (size_t)c * 63;
+    const uint64_t w = __ballot(lane < 63 && bp[lane < 63 ? lane : 0] != 0);
+    relb[lane] = (rel63 && lane < 63) ? rel63[(size_t)c * 63 + lane] : 0;
+    __syncthreads();
+    const Gf gf = {ex, lg};
+    const Work wk = {work + lane, work + 23 * 64 + lane, work + 47 * 64 + lane, work + 71 * 64 + lane};
+    const int par = parity ? (parity[c] ? 1 : 0) : 0;
+    const int prel = parity_rel ? parity_rel[c] : 0;
+    const int obs = obs_nac ? obs_nac[c] : 0;
+    const NidRes r = nid_decode_wave(gf, wk, w, rel63 ? relb : nullptr, par, prel, obs, threshold, masks, lane);
+    if (lane == 0) {
+        int32_t* o = out4 + (size_t)c * 4;
+        o[0] = r.status;
+        o[1] = r.nac;
+        o[2] = r.duid;
+        o[3] = r.errs;
+    }
+}
+
+// batches up to this many NIDs take the wavefront-per-NID route (environment DDN_NID_WAVE_MAX overrides: 0 = never)
+static int
+nid_wave_max() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDN_NID_WAVE_MAX");
+        const long x = e ? strtol(e, nullptr, 10) : 16384;
+        v = (x < 0 || x > (1 << 24)) ? 16384 : (int)x;
+    }
+    return v;
+}
+
 extern "C" hipError_t
 ddn_dev_nid_decode(const uint8_t* bits63, const uint8_t* rel63, const int32_t* obs_nac, const uint8_t* parity,
                    const uint8_t* parity_rel, int threshold, int n, int32_t* out4, hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
+    }
+    if (n <= nid_wave_max()) {
+        hipLaunchKernelGGL(k_nid_wave, dim3((unsigned)n), dim3(64), 0, st, bits63, rel63, obs_nac, parity, parity_rel, threshold, n,
+                           out4);
+        return hipGetLastError();
     }
     // pass 1: hard decode (+ observed-NAC retry) for every NID, NIDs that need the Chase search are listed;
     // pass 2: one wavefront per listed NID.  The list and its counter are stream-ordered scratch (hipMallocAsync), so

@@ -251,6 +251,138 @@ put_nac(uint64_t w, int nac) {
     return w;
 }
 
+// bch_63_16_decode() for ONE word decided by a whole wavefront (every lane calls with the same w; results are wave-uniform): the same
+// Massey iteration and Chien search - the same connection polynomial after every step, the same failure tests - with the work
+// spread over the lanes instead of ~100 k cycles of dependent LDS table look-ups on one: the odd syndromes as a wave-wide xor of one
+// term per received bit, the even ones S_i = S_odd^(2^a) directly, the polynomials C and B one coefficient per lane (a step's
+// discrepancy = one product per lane and six ballots, the update = one shifted product per lane), the Chien search one candidate
+// root per lane.  Logarithms of C and of the syndromes are carried beside the values (0xFF = zero).
+__device__ inline int
+bch_63_16_decode_wave(const Gf& gf, uint64_t w, int lane, uint64_t* fixed, int* nerr) {
+    const bool bit = lane < 63 && ((w >> lane) & 1ull);
+    uint32_t acc[3] = {0u, 0u, 0u};
+    {
+        const int j = lane < 63 ? 62 - lane : 0; // this bit contributes alpha^(k * j) to S_k
+        int j2 = 2 * j;
+        j2 -= j2 >= 63 ? 63 : 0;
+        int e = j;
+#pragma unroll
+        for (int k = 0; k < 11; k++) { // S_1, S_3, .., S_21: four to a word
+            const uint32_t v = bit ? gf.ex[e] : 0u;
+            acc[k >> 2] |= v << (8 * (k & 3));
+            e += j2;
+            e -= e >= 63 ? 63 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                acc[q] ^= (uint32_t)__shfl_xor((int)acc[q], off);
+            }
+        }
+    }
+    *nerr = 0;
+    *fixed = w;
+    if ((acc[0] | acc[1] | acc[2]) == 0u) {
+        return 1;
+    }
+    // lane i (1 .. 22) holds S_i: i = odd * 2^a, S_i = S_odd^(2^a) (the serial decoder's S_i = S_{i/2}^2, unrolled)
+    int slg = 0xFF;
+    if (lane >= 1 && lane <= 22) {
+        const int a = __builtin_ctz((unsigned)lane), odd = lane >> a, k = odd >> 1;
+        const int h0 = (int)((acc[k >> 2] >> (8 * (k & 3))) & 63u);
+        if (h0) {
+            int lg = gf.lg[h0];
+            for (int r = 0; r < a; r++) {
+                lg *= 2;
+                lg -= lg >= 63 ? 63 : 0;
+            }
+            slg = lg;
+        }
+    }
+    int c = lane == 0 ? 1 : 0, b = c;    // coefficient `lane` of the connection polynomial and of its last length change
+    int clg = lane == 0 ? 0 : 0xFF;      // log of c (0xFF: c == 0)
+    int L = 0, m = 1, bs = 1;
+    for (int n = 0; n < 22; n++) {
+        const int idx = n + 1 - lane;
+        const int sl = __shfl(slg, idx & 63);
+        int p = 0;
+        if (lane <= L && idx >= 1 && clg != 0xFF && sl != 0xFF) {
+            p = gf.ex[clg + sl];
+        }
+        int d = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            d |= (__popcll(__ballot((p >> q) & 1)) & 1) << q;
+        }
+        if (d == 0) {
+            m++;
+            continue;
+        }
+        const int flg = gf.lg[d] + 63 - gf.lg[bs]; // log of d / b, 1 .. 125
+        const int src = lane - m;
+        const int bsh = __shfl(b, src & 63);
+        int upd = 0;
+        if (lane < 24 && src >= 0 && bsh) {
+            int e = flg + gf.lg[bsh];
+            e -= e >= 126 ? 126 : (e >= 63 ? 63 : 0);
+            upd = gf.ex[e];
+        }
+        const int cold = c;
+        c ^= upd;
+        if (upd) {
+            clg = c ? gf.lg[c] : 0xFF;
+        }
+        if (2 * L <= n) {
+            L = n + 1 - L;
+            b = cold;
+            bs = d;
+            m = 1;
+        } else {
+            m++;
+        }
+        if (L > 11) {
+            return 0;
+        }
+    }
+    // Chien search: lane r tests alpha^(r + 1); a root there = an error at input position r (i = 63 -> position 62)
+    int q = 0;
+    {
+        const int i = lane + 1;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int lk = __builtin_amdgcn_readlane(clg, k);
+            if (k <= L && lk != 0xFF) {
+                q ^= gf.ex[(lk + i * k) % 63];
+            }
+        }
+    }
+    const uint64_t roots = __ballot(lane < 63 && q == 0);
+    const int count = __popcll(roots);
+    if (count != L) {
+        return 0;
+    }
+    *fixed = w ^ roots;
+    *nerr = count;
+    return 1;
+}
+
+__device__ inline NidRes
+nid_codeword_wave(const Gf& gf, uint64_t w, int parity, int lane, int* bch_failed) {
+    uint64_t fixed;
+    int errs;
+    if (bch_failed) {
+        *bch_failed = 0;
+    }
+    if (!bch_63_16_decode_wave(gf, w, lane, &fixed, &errs)) {
+        if (bch_failed) {
+            *bch_failed = 1;
+        }
+        return NidRes{0, 0, 0, 0};
+    }
+    return nid_fields(fixed, errs, parity);
+}
+
 struct ChaseBest {
     int found;
     NidRes dec;
@@ -310,11 +442,11 @@ nid_decode_wave(const Gf& gf, const Work& wk, uint64_t w, const uint8_t* rel, in
         return nid_fields(w, 0, par);
     }
     int failed = 0;
-    NidRes hard = nid_codeword(gf, wk, w, par, &failed);
+    NidRes hard = nid_codeword_wave(gf, w, par, lane, &failed);
     if (hard.status == 0 && failed && obs_ok && rx_nac(w) != obs) {
-        hard = nid_codeword(gf, wk, put_nac(w, obs), par, nullptr);
+        hard = nid_codeword_wave(gf, put_nac(w, obs), par, lane, nullptr);
     }
-    if (hard.status > 0) {
+    if (hard.status > 0 || rel == nullptr) { // rel == nullptr: hard decision only
         return hard;
     }
     const bool two_bases = obs_ok && rx_nac(w) != obs;

@@ -765,6 +765,9 @@ struct LdsH {
     float hh[ddn_p25h::HN][CPW][3]; // {symbol, max, min} of the phase's in-frame symbols, slot = count mod HN
     int req_seq[CPW], req_kind[CPW], req_hw[CPW], req_n[CPW], req_o[CPW], req_neg[CPW], req_nc[CPW];
     int rsp_seq[CPW], rsp_ext[CPW], rsp_more[CPW];
+#if DDN_RX_CYCLES
+    int req_t[CPW], rsp_t[CPW], rsp_pick[CPW]; // timing experiments: when the request was posted / answered, how long it lay unserved
+#endif
     int tile_done[4]; // per recurrence wave: tiles it has finished
     int hwid[8];      // HW_ID of the workgroup's waves (role placement)
     int ready[4];     // per recurrence wave: tiles the staging wave has made enterable for its channels (staged + window
@@ -894,12 +897,20 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         wg_barrier();
         wg_barrier();
     // ---- handler wave: one decision, the whole wavefront on it (c and seq are wave-uniform) -------------------------------
+    int dbg_pend = 0, dbg_free = 0; // timing experiments: requests open when this one was picked up; when the last service ended
     auto serve = [&](int c, int seq) {
         using namespace ddn_p25h;
         Scratch& sc = H.sc;
         const int kind = H.req_kind[c], hw = H.req_hw[c], nsym = H.req_n[c], o_dec = H.req_o[c], neg = H.req_neg[c];
         const int gch = ch0 + c;
         const long long dbg_t0 = (cfg.dbg & 65536) ? (long long)clock64() : 0; // timing experiments: cycles per decision
+#if DDN_RX_CYCLES
+        if (lane == c) {
+            const int since_req = (int)dbg_t0 - H.req_t[c];
+            const int since_free = dbg_free == 0 ? 0x7fffffff : (int)((unsigned)(int)dbg_t0 - (unsigned)dbg_free);
+            H.rsp_pick[c] = (cfg.dbg & 268435456) ? 1000 * dbg_pend : ((cfg.dbg & 536870912) ? (since_req < since_free ? since_req : since_free) : since_req);
+        }
+#endif
         int dbg_path = 0;
         long long dbg_s[3] = {0, 0, 0};
         auto dbg_stamp = [&](int k) {
@@ -1109,6 +1120,14 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             h_served = seq;
             H.rsp_ext[c] = ext;
             H.rsp_more[c] = more;
+#if DDN_RX_CYCLES
+            H.rsp_t[c] = (int)clock64();
+#endif
+        }
+#if DDN_RX_CYCLES
+        dbg_free = (int)clock64();
+#endif
+        if (lane == c) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __hip_atomic_store(&H.rsp_seq[c], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ev_kind) {
@@ -1155,6 +1174,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const int c = __ffsll((long long)pend) - 1;
+                dbg_pend = __popcll(pend);
                 serve(c, __shfl(rq, c));
             }
             // (no workgroup barrier per tile in handler mode: the waves meet through tile_done / ready, see the tile loop)
@@ -1633,7 +1653,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             hseq++;
             if (cfg.dbg & 65536) {
                 s.dbg_nreq++;
-                s.dbg_wait -= (long long)clock64();
+                if (!(cfg.dbg & (67108864 | 134217728))) {
+                    s.dbg_wait -= (long long)clock64();
+                }
+#if DDN_RX_CYCLES
+                H.req_t[ln] = (int)clock64();
+#endif
             }
             H.req_kind[ln] = s.hphase;
             H.req_hw[ln] = s.hw;
@@ -1960,9 +1985,17 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
                         const int ext = H.rsp_ext[ln];
                         hwait = false;
-                        if (cfg.dbg & 65536) {
+                        if ((cfg.dbg & 65536) && !(cfg.dbg & (67108864 | 134217728))) {
                             s.dbg_wait += (long long)clock64();
                         }
+#if DDN_RX_CYCLES
+                        if (cfg.dbg & 67108864) { // how long the answer lay unread
+                            s.dbg_wait += (long long)((int)clock64() - H.rsp_t[ln]);
+                        }
+                        if (cfg.dbg & 134217728) { // how long the request lay unserved
+                            s.dbg_wait += (long long)H.rsp_pick[ln];
+                        }
+#endif
                         if (ext > 0) { // the handler reads on
                             s.lock_left = ext;
                             s.hn = ext;

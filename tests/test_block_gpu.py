@@ -31,7 +31,8 @@ def test_nid_golden_and_fresh(built):
     assert np.array_equal(gpu_nid(g["bits"], g["rel"], obs, g["parity"], g["parity_rel"]), g["out_soft"])
     assert np.array_equal(gpu_nid(g["bits"], None, obs, g["parity"], g["parity_rel"]), g["out_hard"])
     rng = np.random.default_rng(FZ + 31)
-    for n, thr in ((1, 64), (65, 64), (3000, 40), (500, 200)):
+    # up to 16384 NIDs a call takes the wavefront-per-NID route (the receive loops' nid_decode_wave), larger ones lane-per-NID + Chase list
+    for n, thr in ((1, 64), (65, 64), (3000, 40), (500, 200), (17000, 64)):
         bits, rel, obs, par, prel = fecgen.gen_nid(rng, n, max_err=16)
         rel[: n // 4] = rng.integers(0, 256, (n // 4, 63))  # ties / everything below threshold
         want = oracle_nid(bits, rel, obs, par, prel, thr)

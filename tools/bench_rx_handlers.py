@@ -20,6 +20,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 48000
 voice, ctrl = bench.make_base_traffic(n)
 idx = [bench.channel_source(c) for c in range(B)]
+if os.environ.get("TRAFFIC") in ("voice", "ctrl"):  # timing experiments: one kind of channel only
+    idx = [(os.environ["TRAFFIC"], i) for _, i in idx]
 iq = np.stack([(voice if k == "voice" else ctrl)[i] for k, i in idx])
 d_iq = torch.from_numpy(iq).cuda()
 fe = ddn.Batch(B, block_len=8192)
@@ -66,6 +68,7 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
                     v = a[a[:, 2] == path][:, 3]
                     if len(v):
                         extra += " | kind %d path %d: n %d cycles mean %.0f max %d" % (kd, path, len(v), v.mean(), v.max())
+                        extra += " pct[10,50,80,90,95,99] %s" % np.percentile(v, [10, 50, 80, 90, 95, 99]).astype(int).tolist()
         else:
             extra = " events/ch %.1f nid_ok %.3f tsbk_crc %.3f" % (ne.mean(), (allev[allev[:, 1] == 1][:, 2] > 0).mean(),
                                                                    (allev[allev[:, 1] == 2][:, 3] & 1).mean())
