@@ -312,18 +312,28 @@ map4_compose(uint32_t m, uint32_t b) { // (m o b)(x) = m(b(x)) for maps of {0..3
 // row rotations) and kept by lane t as step t's map state -> predecessor, the next step's predecessor metric by one ds_bpermute
 // (was four readlanes + selects, whose scalar results stall the vector pipe; three DPP row rotations + selects measured slower); (3) the trace-back as a suffix composition of
 // those maps over the lanes (six shuffle rounds) instead of 49 dependent scalar steps, the decoded dibits or-ed into three LDS
-// words.  Same survivors, same ties (lowest predecessor, lowest final state) as before: 11.7 k -> 9.2 k cycles.
+// words.  Same survivors, same ties (lowest predecessor, lowest final state) as before: 11.7 k -> 9.2 k cycles.  Round 5: the
+// ds_bpermute went too (alternating lane layouts, below).
 __device__ __forceinline__ void
 half_rate_best_wave(Scratch& sc, int lane, uint32_t by[3]) {
-    const int ps = lane & 3, ns = (lane >> 2) & 3;
-    const int e = half_rate_nibble((ps << 2) | ns);
+    // Round 5: the (predecessor, state) pairs sit on the lanes in two layouts that take turns - even steps: predecessor = lane & 3,
+    // state = quad (minimum over the quad, decisions or-ed across the quads); odd steps: state = lane & 3, predecessor = quad
+    // (minimum across the quads, decisions or-ed inside the quad).  After an even step a quad holds its state's new metric, which is
+    // the odd step's predecessor metric of that quad's lanes; after an odd step the lanes with the same lane & 3 hold it, the even
+    // step's predecessor: no lane ever asks another for a metric (the ds_bpermute per step - an LDS round trip on the chain - is gone).
+    const int lo = lane & 3, hi = (lane >> 2) & 3;
+    const int eA = half_rate_nibble((lo << 2) | hi); // even steps: ps = lo, ns = hi
+    const int eB = half_rate_nibble((hi << 2) | lo); // odd steps: ps = hi, ns = lo
     // branch bits as packed masks: bit set = the branch says 1 = the cost is the LLR's pull towards 0 = max(0, -llr)
-    const ddn_s16x2 m01 = {(short)(((e >> 3) & 1) ? -1 : 0), (short)(((e >> 2) & 1) ? -1 : 0)};
-    const ddn_s16x2 m23 = {(short)(((e >> 1) & 1) ? -1 : 0), (short)((e & 1) ? -1 : 0)};
+    const ddn_s16x2 a01 = {(short)(((eA >> 3) & 1) ? -1 : 0), (short)(((eA >> 2) & 1) ? -1 : 0)};
+    const ddn_s16x2 a23 = {(short)(((eA >> 1) & 1) ? -1 : 0), (short)((eA & 1) ? -1 : 0)};
+    const ddn_s16x2 b01 = {(short)(((eB >> 3) & 1) ? -1 : 0), (short)(((eB >> 2) & 1) ? -1 : 0)};
+    const ddn_s16x2 b23 = {(short)(((eB >> 1) & 1) ? -1 : 0), (short)((eB & 1) ? -1 : 0)};
     const ddn_s16x2 zero = {0, 0};
     uint32_t cst[25];
 #pragma unroll
     for (int t = 0; t < 49; t++) {
+        const ddn_s16x2 m01 = (t & 1) ? b01 : a01, m23 = (t & 1) ? b23 : a23;
         ddn_s16x2 a = __builtin_bit_cast(ddn_s16x2, sc.d[2 * t]), b = __builtin_bit_cast(ddn_s16x2, sc.d[2 * t + 1]);
         a = __builtin_elementwise_max((a ^ m01) - m01, zero);
         b = __builtin_elementwise_max((b ^ m23) - m23, zero);
@@ -339,23 +349,35 @@ half_rate_best_wave(Scratch& sc, int lane, uint32_t by[3]) {
     if (lane < 3) {
         sc.byw[lane] = 0;
     }
-    uint32_t pm_ps = (ps == 0) ? 0u : 256u; // metric of this lane's predecessor state
+    uint32_t pm_ps = (lo == 0) ? 0u : 256u; // metric of this lane's predecessor state (step 0: predecessor = lane & 3)
     uint32_t mymap = 0xE4u, key = 0;        // lane t: step t's map state -> best predecessor (0xE4 = identity)
-    const int from_quad = ((lane & 48) | (ps << 2)) << 2; // a lane of the quad that holds state ps, this row (byte address)
 #pragma unroll
     for (int t = 0; t < 49; t++) {
         const uint32_t cost = (t & 1) ? (cst[t >> 1] >> 16) : (cst[t >> 1] & 0xFFFFu);
-        key = ((pm_ps + cost) << 2) | (uint32_t)ps; // smallest metric, lowest predecessor on a tie
-        uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xF, 0xF, true);
-        key = o < key ? o : key;
-        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xF, 0xF, true);
-        key = o < key ? o : key;
-        uint32_t v = (key & 3u) << (2 * ns);
-        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true); // row_ror:4
-        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); // row_ror:8
+        uint32_t v;
+        if (!(t & 1)) {
+            key = ((pm_ps + cost) << 2) | (uint32_t)lo; // smallest metric, lowest predecessor on a tie
+            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xF, 0xF, true);
+            key = o < key ? o : key;
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xF, 0xF, true);
+            key = o < key ? o : key;
+            v = (key & 3u) << (2 * hi);
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true); // row_ror:4
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); // row_ror:8
+        } else {
+            key = ((pm_ps + cost) << 2) | (uint32_t)hi;
+            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x124, 0xF, 0xF, true);
+            key = o < key ? o : key;
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x128, 0xF, 0xF, true);
+            key = o < key ? o : key;
+            v = (key & 3u) << (2 * lo);
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+        }
         mymap = (lane == t) ? v : mymap;
-        pm_ps = (uint32_t)__builtin_amdgcn_ds_bpermute(from_quad, (int)(key >> 2));
+        pm_ps = key >> 2;
     }
+    const int ns = hi; // step 48 is an even one: every quad holds its state's metric
     // best final state, lowest on a tie: every quad holds its state's metric
     uint32_t f = ((key >> 2) << 2) | (uint32_t)ns;
     uint32_t g = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xF, 0xF, true);

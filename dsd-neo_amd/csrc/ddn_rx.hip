@@ -1147,6 +1147,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             e[2] = dbg_path | ((int)(dbg_s[0] >> 4) << 4);
                             e[3] = (int)(dbg_s[1] >> 4) | ((int)(dbg_s[2] >> 4) << 16);
                         }
+#if DDN_RX_CYCLES
+                        if (cfg.dbg & 1073741824) { // how long the request lay unserved, per decision
+                            e[2] = H.rsp_pick[c];
+                        }
+#endif
                     }
                 }
                 h_nev = nev + 1;

@@ -61,6 +61,11 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
                 a = allev[(allev[:, 1] == kd) & ((allev[:, 2] & 15) == 0)]
                 extra += " | kind %d stamps(cycles): %.0f %.0f %.0f" % (kd, (a[:, 2] >> 4).mean() * 16, (a[:, 3] & 0xFFFF).mean() * 16,
                                                                       ((a[:, 3] >> 16) & 0xFFFF).mean() * 16)
+        elif int(os.environ.get("DDN_RX_DBG", "0")) & 1073741824:  # DDN_RX_CYCLES build: e[2] = cycles the request lay unserved
+            for kd in (1, 2):
+                a = allev[allev[:, 1] == kd]
+                extra += " | kind %d: pick-up delay mean %.0f pct[10,50,80,90,95,99] %s, service mean %.0f" % (
+                    kd, a[:, 2].mean(), np.percentile(a[:, 2], [10, 50, 80, 90, 95, 99]).astype(int).tolist(), a[:, 3].mean())
         elif int(os.environ.get("DDN_RX_DBG", "0")) & 65536:
             for kd in (1, 2):
                 a = allev[allev[:, 1] == kd]
