@@ -1391,9 +1391,14 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     };
     // Handler mode: the staging wave's three jobs for the channels of ONE recurrence wave (h) - the two recurrence waves share
     // nothing but this wave's time, so each runs as far ahead of the other as its own channels let it.
-    auto stage_half = [&](long t0, int slot, int h) {
-        const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
+    // (round 5) in two parts - the loads of a tile go out before the staging wave's other two jobs and land in the LDS after them:
+    // ~3 k cycles of memory latency per half and tile that the wave used to sit out (the staging wave is what a tile of quiet
+    // traffic waits for)
+    struct StageRegs {
         float r[TW / 64][LPR], f[TW / 64][LPR];
+    };
+    auto stage_half_load = [&](long t0, int h, StageRegs& g) {
+        const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
 #pragma unroll
         for (int half = 0; half < TW / 64; half++) { // every load of the tile in flight before the first LDS write
             const int j = lane + 64 * half;
@@ -1402,24 +1407,31 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const int cc = h * LPR + c;
                 const bool ok = (ch0 + cc < n_channels) && j < tn;
                 const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + j;
-                r[half][c] = ok ? raw[off] : 0.0f;
-                f[half][c] = (ok && use_flt) ? filt[off] : 0.0f;
+                g.r[half][c] = ok ? raw[off] : 0.0f;
+                g.f[half][c] = (ok && use_flt) ? filt[off] : 0.0f;
             }
         }
+    };
+    auto stage_half_store = [&](int slot, int h, const StageRegs& g) {
 #pragma unroll
         for (int half = 0; half < TW / 64; half++) {
             const int j = lane + 64 * half;
 #pragma unroll
             for (int c = 0; c < LPR; c++) {
                 const int cc = h * LPR + c;
-                L.raw[cc][TW + slot * TW + j] = r[half][c];
-                L.flt[cc][TW + slot * TW + j] = f[half][c];
+                L.raw[cc][TW + slot * TW + j] = g.r[half][c];
+                L.flt[cc][TW + slot * TW + j] = g.f[half][c];
                 if (slot == 2) {
-                    L.raw[cc][j] = r[half][c];
-                    L.flt[cc][j] = f[half][c];
+                    L.raw[cc][j] = g.r[half][c];
+                    L.flt[cc][j] = g.f[half][c];
                 }
             }
         }
+    };
+    auto stage_half = [&](long t0, int slot, int h) {
+        StageRegs g;
+        stage_half_load(t0, h, g);
+        stage_half_store(slot, h, g);
     };
     auto compute_sfx_half = [&](int buf, int tile_parity, int h) {
         // S_m = summary of ring entries m + 1 .. SS for m = Mn .. 1, all of them at once: the 64 / LPR lanes of a channel's
@@ -1644,15 +1656,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     // handler mode, recurrence side: hpost = this symbol ends a phase, hwait = the lane sits out until the answer is there
     bool hpost = false, hwait = false;
     int hseq = 0;
-    auto hist_push = [&](float sym, float q_max, float q_min, int fl) {
-        if (HM && live && s.hphase != 0) {
-            float* e = &H.hh[s.hw][ln][0];
-            e[0] = sym;
-            e[1] = q_max;
-            e[2] = q_min;
-            s.hw = (s.hw + 1 >= ddn_p25h::HN) ? 0 : s.hw + 1;
-        }
-        if (HM && hpost) {
+    auto post_request = [&](int o_last) { // o_last: output index of the phase's last symbol
+        {
             hpost = false;
             hwait = true;
             hseq++;
@@ -1668,13 +1673,25 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             H.req_kind[ln] = s.hphase;
             H.req_hw[ln] = s.hw;
             H.req_n[ln] = s.hn;
-            H.req_o[ln] = o;
+            H.req_o[ln] = o_last;
             H.req_neg[ln] = (s.lastsync == 2) ? 1 : 0;
             H.req_nc[ln] = s.hnc;
             s.hnc = 0;
             // the request is LDS traffic only (a wave's LDS operations complete in order): no wait for the ring stores in flight
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __hip_atomic_store(&H.req_seq[ln], hseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto hist_push = [&](float sym, float q_max, float q_min, int fl) {
+        if (HM && live && s.hphase != 0) {
+            float* e = &H.hh[s.hw][ln][0];
+            e[0] = sym;
+            e[1] = q_max;
+            e[2] = q_min;
+            s.hw = (s.hw + 1 >= ddn_p25h::HN) ? 0 : s.hw + 1;
+        }
+        if (HM && hpost) {
+            post_request(o);
         }
     };
     auto commit_inframe = [&](float sym, int done_snap, int& fl, float& q_max, float& q_min) {
@@ -1856,6 +1873,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     long long dbg_busy = 0, dbg_wait = 0, dbg_cyc[3] = {0, 0, 0}, dbg_prev = 0, dbg_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_st = 0;
 #define DBG_SEC(k) do { if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { const long long n_ = (long long)clock64(); dbg_sec[k] += n_ - dbg_st; dbg_st = n_; } } while (0)
     int dbg_n[3] = {0, 0, 0}, dbg_kind = -1;
+    long long dbg_blk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_bt = 0; // bulk hunting pass, by section
+#define DBG_BLK(k) do { if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { const long long n_ = (long long)clock64(); dbg_blk[k] += n_ - dbg_bt; dbg_bt = n_; } } while (0)
     long long dbg_run[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // lean runs: count, trips, -, -, -, runs polling a mailbox, cycles inside the run, phases
     if (HM && loader) {
         // Handler mode, staging wave: job j of recurrence wave h's channels (stage tile j + 1, drain tile j - 1's queue, the
@@ -1885,14 +1904,37 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
                 if (j < n_tiles) {
+                    long long c0 = w0;
+                    StageRegs sg;
                     if (j + 1 < n_tiles) {
-                        stage_half((long)(j + 1) * TW, (j + 1) % 3, h);
+                        stage_half_load((long)(j + 1) * TW, h, sg);
+                    }
+                    if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { // the staging wave's three jobs, timed apart
+                        const long long c1 = (long long)clock64();
+                        dbg_cyc[0] += c1 - c0;
+                        c0 = c1;
                     }
                     if (offload && j > 0 && !(cfg.dbg & 512)) {
                         drain_half((j - 1) & 1, h);
                     }
+                    if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                        const long long c1 = (long long)clock64();
+                        dbg_cyc[1] += c1 - c0;
+                        c0 = c1;
+                    }
                     if (j >= 1 && !(cfg.dbg & 256)) {
                         compute_sfx_half(j & 1, j & 1, h);
+                    }
+                    if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                        const long long c1 = (long long)clock64();
+                        dbg_cyc[2] += c1 - c0;
+                        c0 = c1;
+                    }
+                    if (j + 1 < n_tiles) {
+                        stage_half_store((j + 1) % 3, h, sg);
+                    }
+                    if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                        dbg_cyc[0] += (long long)clock64() - c0;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) {
@@ -2045,6 +2087,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         while (bm) {
                             const int ow = __ffsll((long long)bm) - 1; // owner lane of this pass (wave-uniform)
                             bm &= bm - 1;
+                            if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                                dbg_bt = (long long)clock64();
+                                dbg_blk[7]++;
+                            }
                             const int cln = rw * LPR + ow;
                             const int sp0 = __builtin_amdgcn_readlane(sp, ow);
                             const int c0 = __builtin_amdgcn_readlane(s.hist_count, ow);
@@ -2062,6 +2108,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             const float hl_n = __shfl(s.max * 1.25f, ow), ll_n = __shfl(s.min * 1.25f, ow);
                             int q = sp0, m = 0, myq = 0, myi0 = 0, myjin = 0;
                             int lim = c0 < 8 ? 8 - c0 : 16;
+                            DBG_BLK(0);
                             for (int ph = 0; ph < 2; ph++) {
                                 unsigned long long cm[3];
 #pragma unroll
@@ -2079,6 +2126,19 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     }
                                 }
                                 bool full = false;
+                                // (the chain's words are wave-uniform; said so explicitly - left to itself the compiler keeps them in
+                                // vector registers and runs the loop under an execution mask: ~680 cycles per symbol against scalar code)
+                                auto uni64 = [](unsigned long long v) {
+                                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+                                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+                                    return ((unsigned long long)hi << 32) | lo;
+                                };
+                                cm[0] = uni64(cm[0]);
+                                cm[1] = uni64(cm[1]);
+                                cm[2] = uni64(cm[2]);
+                                q = __builtin_amdgcn_readfirstlane(q);
+                                m = __builtin_amdgcn_readfirstlane(m);
+                                jit = __builtin_amdgcn_readfirstlane(jit);
                                 while (m < lim) {
                                     const int i0 = (jit > 0 && jit <= (whole - 1) / 2) ? -1 : ((jit > (whole - 1) / 2 && jit < whole) ? 1 : 0);
                                     const int cnt = whole - i0;
@@ -2107,6 +2167,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 hl = hl_n;
                                 ll = ll_n;
                             }
+                            DBG_BLK(1);
                             // where the symbol after the pass starts, and the latch it starts with
                             if (lane == m) {
                                 myq = q;
@@ -2130,6 +2191,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             if (sm) {
                                 m = __ffsll((long long)sm) - 1;
                             }
+                            DBG_BLK(2);
                             if (m == 0) { // the next symbol completes a sync: the standard trip's
                                 if (lane == ow) {
                                     blk_o = o;
@@ -2153,6 +2215,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     store_record(rec + (cho * max_sym + oo) * 10, flags + cho * max_sym + oo, sym, sym > 0.0f ? 1 : 3, 0, 0, 0, 0);
                                 }
                             }
+                            DBG_BLK(3);
                             float a1 = lane < m ? sym : inf, a2 = inf, b1 = lane < m ? sym : -inf, b2 = -inf;
 #pragma unroll
                             for (int d = 1; d < 16; d <<= 1) {
@@ -2164,6 +2227,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             }
                             a1 = __shfl(a1, 0), a2 = __shfl(a2, 0), b1 = __shfl(b1, 0), b2 = __shfl(b2, 0);
                             const float lsf = pr[qf - 1];
+                            DBG_BLK(4);
                             if (lane == ow) {
                                 two_min_insert(a1, pc1, pc2);
                                 two_min_insert(a2, pc1, pc2);
@@ -2193,6 +2257,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 s.lastsample = lsf;
                                 sp = qf;
                                 o += m;
+                            }
+                            DBG_BLK(5);
+                            if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                                dbg_blk[6] += m;
                             }
                         }
                         if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { // the pass is no trip: its cycles are kept apart
@@ -2242,7 +2310,10 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 bool all_lean_wait = false;
                 if (lean_ok && tk <= QTW) {
                     // (bitwise on purpose: one compare each, no short-circuit branches on the recurrence wave)
-                    bool lean_state = alive & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > 1) & (sp >= cold_until)
+                    // (round 5) a phase that ends in a handler's decision takes its last symbol inside the run too (the request is posted
+                    // after the run, below); any other lock keeps its last symbol for the standard trip (frame_end, the last sample)
+                    const bool hpl = HM && (s.hphase != 0) && (s.hn >= 2) && !(cfg.dbg & 33554432);
+                    bool lean_state = alive & (s.have_sync != 0) & (s.jitter >= 0) & (s.lock_left > (hpl ? 0 : 1)) & (sp >= cold_until)
                                       & ((s.in_symbol == 0) | ((s.i == 0) & (s.count == 0))) & (s.min < s.max)
                                       & (s.since_fill < MS) & (npp + npc < WMW);
                     if (__any(lean_state)) {
@@ -2278,7 +2349,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         const bool hp = HM && (s.hphase != 0);
                         if (lean) {
                             kl = ((tn - sp) * (65536 / whole + 1)) >> 16; // == (tn - sp) / whole for these small numbers
-                            kl = min(kl, s.lock_left - 1);
+                            kl = min(kl, s.lock_left - (hpl ? 0 : 1));
                             kl = min(kl, MS - s.since_fill);
                             kl = min(kl, WMW - (npp + npc));
                             kl = min(kl, SS - s.sidx);
@@ -2403,6 +2474,16 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             s.maxref = s.max * 0.80f;
                             s.minref = s.min * 0.80f;
                             qv = make_float4(sym, mx, mn, __int_as_float(fw - 256)); // the run's last entry, as the trip loop's top hands it over
+                            if (HM && hpl && s.lock_left == 0) {
+                                // The phase's last symbol was one of the run's.  What the standard trip does beyond a lean one: the
+                                // symbol's last sample, clipped to max / min as they stood BEFORE this symbol (= the previous history
+                                // entry of the phase; read by the first hunting symbol if the handler returns), and the request.
+                                const int pv = s.hw - 2 + (s.hw < 2 ? ddn_p25h::HN : 0);
+                                const float pmx = H.hh[pv][ln][1], pmn = H.hh[pv][ln][2];
+                                const float xl = ((s.filter_on ? frow : rrow) + base)[sp - 1];
+                                s.lastsample = xl > pmx ? pmx : (xl < pmn ? pmn : xl);
+                                post_request(o - 1);
+                            }
                         }
                         tk += K - 1;
                         if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
@@ -2840,6 +2921,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             for (int k = 0; k < 64; k++) {
                 d2[k] = reinterpret_cast<const uint8_t*>(dbg_sec)[k];
                 d2[k - 64] = reinterpret_cast<const uint8_t*>(dbg_run)[k];
+                d2[k - 128] = reinterpret_cast<const uint8_t*>(dbg_blk)[k];
             }
         }
     }

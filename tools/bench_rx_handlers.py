@@ -90,6 +90,8 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
         tiles = (n + 127) // 128
         for w, nm in enumerate(["recurrence", "loader", "winprep"]):
             extra += "\n   %s busy/tile %.0f wait/tile %.0f cycles" % (nm, tails[:, w, 0].mean() / tiles, tails[:, w, 1].mean() / tiles)
+        extra += "\n   staging wave per tile (both halves): stage %.0f drain %.0f window summaries %.0f cycles" % tuple(
+            tails[:, 2, 2 + k].mean() / tiles for k in range(3))
         tt = tails[:, 0]
         for k in range(3):
             extra += "\n   trip kind %d: %.2f per tile at %.0f cycles (share of busy %.2f)" % (
@@ -100,6 +102,9 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
         extra += "\n   std trip sections (cycles per trip): top %.0f search %.0f mean %.0f inframe %.0f hunt %.0f emit %.0f" % tuple(
             sec[:, k].sum() / nstd for k in range(6))
         extra += "\n   bulk hunting passes: %.2f per tile at %.0f cycles" % (sec[:, 7].sum() / (len(sec) * tiles), sec[:, 6].sum() / max(1, sec[:, 7].sum()))
+        blk = np.stack([r[c, -384:-320] for c in range(0, B, cpw)]).copy().view(np.int64).sum(axis=0)
+        extra += "\n   bulk pass per owner lane (%.2f owners per pass, %.1f symbols each): set-up %.0f masks + slip chain %.0f means + sync test %.0f stores %.0f window reduction %.0f owner's words %.0f cycles" % (
+            (blk[7] / max(1, sec[:, 7].sum()), blk[6] / max(1, blk[7])) + tuple(blk[k] / max(1, blk[7]) for k in range(6)))
         run = np.stack([r[c, -320:-256] for c in range(0, B, cpw)]).copy().view(np.int64).sum(axis=0)
         extra += "\n   lean runs: %.2f per tile, %.2f trips and %.2f phases each (%.2f of them polling a handler mailbox), %.0f cycles inside the run per trip" % (
             run[0] / (len(sec) * tiles), run[1] / max(1, run[0]), run[7] / max(1, run[0]), run[5] / max(1, run[0]), run[6] / max(1, run[1]))
