@@ -1337,6 +1337,13 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const bool std_ok = stdspan && !(cfg.dbg & 1024); // see "standard trip" in the trip loop
     const bool lean_ok = offload && stdspan && !(cfg.dbg & 2048); // see "lean trip" in the trip loop
     const bool bulk_ok = std_ok && offload && !(cfg.dbg & 1048576); // see "bulk hunting pass" in the trip loop
+    // bulk hunting pass: the slip of a symbol's start by the latched crossing jit (-1 .. whole), as (slip + 1) in two bits per jit + 1
+    uint32_t i0tab = 0;
+    for (int jt = -1; jt <= 14; jt++) {
+        const int i0 = (jt > 0 && jt <= (whole - 1) / 2) ? -1 : ((jt > (whole - 1) / 2 && jt < whole) ? 1 : 0);
+        i0tab |= (uint32_t)(i0 + 1) << (2 * (jt + 1));
+    }
+    i0tab = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0tab);
     auto store_record = [&](uint8_t* r, uint8_t* f, float sym, int dibit, int relb, int l0, int l1, int fl) {
         const uint32_t xb = __float_as_uint(sym);
         ((uint16_t*)r)[0] = (uint16_t)((dibit & 3) | (relb << 8));
@@ -2106,11 +2113,16 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             // symbol of a hunt moves the crossing limits to the parked max / min: the mask is taken again there.
                             float hl = hl_o, ll = ll_o;
                             const float hl_n = __shfl(s.max * 1.25f, ow), ll_n = __shfl(s.min * 1.25f, ow);
-                            int q = sp0, m = 0, myq = 0, myi0 = 0, myjin = 0;
+                            int q = sp0, m = 0, mypk = 0;
                             int lim = c0 < 8 ? 8 - c0 : 16;
                             DBG_BLK(0);
                             for (int ph = 0; ph < 2; ph++) {
                                 unsigned long long cm[3];
+                                // (the chain's words are wave-uniform; said so explicitly - left to itself the compiler keeps them in
+                                // vector registers and runs the loop under an execution mask: ~680 cycles per symbol against scalar code)
+                                q = __builtin_amdgcn_readfirstlane(q);
+                                m = __builtin_amdgcn_readfirstlane(m);
+                                jit = __builtin_amdgcn_readfirstlane(jit);
 #pragma unroll
                                 for (int r = 0; r < 3; r++) {
                                     cm[r] = 0ull;
@@ -2126,8 +2138,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     }
                                 }
                                 bool full = false;
-                                // (the chain's words are wave-uniform; said so explicitly - left to itself the compiler keeps them in
-                                // vector registers and runs the loop under an execution mask: ~680 cycles per symbol against scalar code)
                                 auto uni64 = [](unsigned long long v) {
                                     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
                                     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
@@ -2136,21 +2146,17 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 cm[0] = uni64(cm[0]);
                                 cm[1] = uni64(cm[1]);
                                 cm[2] = uni64(cm[2]);
-                                q = __builtin_amdgcn_readfirstlane(q);
-                                m = __builtin_amdgcn_readfirstlane(m);
-                                jit = __builtin_amdgcn_readfirstlane(jit);
                                 while (m < lim) {
-                                    const int i0 = (jit > 0 && jit <= (whole - 1) / 2) ? -1 : ((jit > (whole - 1) / 2 && jit < whole) ? 1 : 0);
+                                    // slip of this symbol's start by the latched crossing: -1 / 0 / +1 as a two-bit code from a table
+                                    // over the latch value (i0tab, one entry per jit + 1)
+                                    const int c = (int)((i0tab >> (2 * (jit + 1))) & 3u), i0 = c - 1;
                                     const int cnt = whole - i0;
                                     if (q + cnt > tn) {
                                         full = true;
                                         break;
                                     }
-                                    if (lane == m) {
-                                        myq = q;
-                                        myi0 = i0;
-                                        myjin = jit;
-                                    }
+                                    // lane m's symbol: {start, slip code, latch on entry} as one word written into that lane
+                                    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mypk) : "s"((q + 256) | (c << 10) | ((jit + 1) << 12)), "s"(m) : "m0");
                                     const int k0 = i0 < 0 ? 1 : 0; // a crossing at symbol index -1 latches nothing
                                     const uint32_t wv = (uint32_t)(cm[0] >> k0) & ((1u << (cnt - k0)) - 1u);
                                     jit = wv ? i0 + k0 + (__ffs((int)wv) - 1) : -1;
@@ -2169,10 +2175,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             }
                             DBG_BLK(1);
                             // where the symbol after the pass starts, and the latch it starts with
-                            if (lane == m) {
-                                myq = q;
-                                myjin = jit;
-                            }
+                            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mypk) : "s"((q + 256) | ((jit + 1) << 12)), "s"(m) : "m0");
+                            const int myq = (mypk & 1023) - 256, myi0 = ((mypk >> 10) & 3) - 1, myjin = ((mypk >> 12) & 15) - 1; // (starts may lie in the previous tile)
                             float sym = 0.0f;
                             if (lane < m) {
                                 const float* pw = pr + myq + ((whole - 1) / 2 - 2 - myi0);
