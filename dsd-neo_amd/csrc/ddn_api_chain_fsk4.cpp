@@ -3,6 +3,7 @@
 //
 // What it stands in for in a dsd-neo host: the demodulator thread's per-block loop (src/io/radio/rtl_sdr_fm.cpp:3458-3516) and
 // processFrame()'s DMR / NXDN branches (src/engine/protocol_dispatch.c -> dmr_data.c / dmr_bs.c, nxdn_frame.c), B channels wide.
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -620,8 +621,22 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
         }
         return ddn_fsk4_chain_stage(g == 1 ? m->dmr : m->nxdn, st_no, iq[g], s);
     };
+    // (round 5, measured and left off) DDN_MIX_PHASED=1: a call's front ends start when ALL loops of the call before have ended
+    // instead of each behind its own group's loop (where it crawls beside the other groups' loops, 4-5 ms).  Lined up, the three
+    // front ends take ~3 ms together, but the loops then have nothing beside them either: 14.4-15.4 ms per step against 13.2.
+    static const bool phased = [] {
+        const char* e = getenv("DDN_MIX_PHASED");
+        return e && e[0] == '1';
+    }();
     for (int g = 0; g < 3; g++) {
         if (on[g]) {
+            if (phased) {
+                for (int h = 0; h < 3; h++) {
+                    if (h != g && on[h] && m->have_dec[h]) { // (have_dec: the group's events have been recorded once)
+                        HIP_TRY(hipStreamWaitEvent(m->st[g], m->ev_loop[h], 0));
+                    }
+                }
+            }
             DDN_TRY(stage(g, 0));
             HIP_TRY(hipEventRecord(m->ev_front[g], m->st[g]));
         }

@@ -21,6 +21,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n = 48000
 third = B // 3
 Bp, Bd, Bn = B - 2 * third, third, third
+if os.environ.get("MIX"):  # "p25,dmr,nxdn" channel counts (timing experiments: which splits leave every loop workgroup resident)
+    Bp, Bd, Bn = (int(v) for v in os.environ["MIX"].split(","))
 voice, ctrl = bench.make_base_traffic(n)
 iq = np.stack([(voice if k == "voice" else ctrl)[i] for k, i in (bench.channel_source(c) for c in range(Bp))])
 dev = torch.device("cuda")
