@@ -63,6 +63,8 @@ struct ddn_p25_chain {
     ddn_p25p1_framer* fr;
     ddn_mbe_batch* mbe;
     float* d_disc;
+    float* d_disc2; // mixed chain only (ddn_p25_chain_double_disc): odd steps' discriminator output, so that the front end of call
+                    // k + 1 (issued through _stage on a stream of its own) may run beside the loop of call k
     // receive-loop outputs, two sets: the loop of call k + 1 writes one while call k is decoded out of the other
     uint8_t *d_rec[NSET], *d_fl[NSET];
     uint8_t* d_rec2[NSET] = {nullptr, nullptr, nullptr}; // host form of the records (run_host with records2), allocated on first use
@@ -186,7 +188,7 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     (void)hipFree(c->d_sym_cnt);
     ddn_p25p1_framer_destroy(c->fr);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->d_disc, c->d_pcm_bcnt,
+    void* all[] = {c->d_disc, c->d_disc2, c->d_pcm_bcnt,
                    c->d_pcm_boff, c->d_cnt_scan, c->d_cls, c->d_lists, c->d_list_n, c->d_tsbk_crc, c->d_words[0],
                    c->d_words[1], c->d_wrel, c->d_werrs, c->d_vldu, c->d_rs_d[0], c->d_rs_d[1], c->d_rs_p[0], c->d_rs_p[1],
                    c->d_rs_st[0], c->d_rs_st[1], c->d_lsd, c->d_lsd_ok, c->d_lsd_llr, c->d_hdu_hex, c->d_hdu_par, c->d_hdu_st,
@@ -396,19 +398,34 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
     return DDN_OK;
 }
 
-// carry + front end of one call into buffer set `cur` on stream st
+// the discriminator buffer of this step (two of them only in the mixed chain)
+static float*
+chain_disc(ddn_p25_chain* c) {
+    return (c->d_disc2 && (c->step & 1)) ? c->d_disc2 : c->d_disc;
+}
+
 static int
-chain_front(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st) {
+chain_carry(ddn_p25_chain* c, int cur, hipStream_t st) {
     const int prev = set_prev(cur);
+    HIP_TRY(ddn_dev_chain_carry(c->d_rec[prev], c->d_fl[prev], c->d_new[prev], c->step > 0 ? 1 : 0, c->d_rec[cur], c->d_fl[cur],
+                                c->stride, c->T, c->B, st));
+    return DDN_OK;
+}
+
+// carry + front end of one call into buffer set `cur` on stream st (with_carry = false: the caller copies the carried tail
+// itself, ahead of the loop - the mixed chain, whose front ends run on streams of their own beside the previous call's loops)
+static int
+chain_front(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, bool with_carry = true) {
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[0], st));
     }
-    HIP_TRY(ddn_dev_chain_carry(c->d_rec[prev], c->d_fl[prev], c->d_new[prev], c->step > 0 ? 1 : 0, c->d_rec[cur], c->d_fl[cur],
-                                c->stride, c->T, c->B, st));
+    if (with_carry) {
+        DDN_TRY(chain_carry(c, cur, st));
+    }
     if (c->cq) { // CQPSK: I/Q -> one float per symbol (row stride ms <= n), counts per channel
-        DDN_TRY(ddn_cqpsk_run(c->cq_fe, d_iq, (size_t)c->n, c->d_disc, c->ms, c->d_sym_cnt, st));
+        DDN_TRY(ddn_cqpsk_run(c->cq_fe, d_iq, (size_t)c->n, chain_disc(c), c->ms, c->d_sym_cnt, st));
     } else {
-        DDN_TRY(ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st));
+        DDN_TRY(ddn_front_end_run(c->fe, d_iq, (size_t)c->n, chain_disc(c), st));
     }
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[1], st));
@@ -421,7 +438,7 @@ static int
 chain_loop(ddn_p25_chain* c, int cur, hipStream_t st) {
     if (c->cq) { // the symbol-rate loop: same records, flags, counts and event lists
         DDN_TRY(ddn_cq_rx_set_events(c->cq, c->d_ev[cur], c->d_nev[cur], c->d_evd[cur], (size_t)c->E));
-        DDN_TRY(ddn_cq_rx_run(c->cq, c->d_disc, c->d_sym_cnt, c->ms, c->ms, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T, c->d_new[cur],
+        DDN_TRY(ddn_cq_rx_run(c->cq, chain_disc(c), c->d_sym_cnt, c->ms, c->ms, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T, c->d_new[cur],
                               c->stride, st));
         if (c->timing) {
             HIP_TRY(hipEventRecord(c->ev_t[2], st));
@@ -431,7 +448,7 @@ chain_loop(ddn_p25_chain* c, int cur, hipStream_t st) {
     DDN_TRY(ddn_p25_rx_set_events(c->rx, c->d_ev[cur], c->d_nev[cur], (size_t)c->E));
     DDN_TRY(ddn_p25_rx_set_event_data(c->rx, c->d_evd[cur]));
     // the loop writes its records behind the T carried ones: row pointer + T records, row stride unchanged
-    DDN_TRY(ddn_p25_rx_run(c->rx, c->d_disc, (size_t)c->n, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T, c->d_new[cur],
+    DDN_TRY(ddn_p25_rx_run(c->rx, chain_disc(c), (size_t)c->n, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T, c->d_new[cur],
                            c->stride, st));
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t[2], st));
@@ -1005,8 +1022,11 @@ ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip_str
     int rc = DDN_OK;
     if (stage == 0) {
         DDN_TRY(chain_settle_pending(c, st));
-        rc = chain_front(c, d_iq, cur, st);
+        rc = chain_front(c, d_iq, cur, st, c->d_disc2 == nullptr);
     } else if (stage == 1) {
+        if (c->d_disc2) {
+            DDN_TRY(chain_carry(c, cur, st));
+        }
         rc = chain_loop(c, cur, st);
     } else {
         DDN_TRY(chain_settle_pending(c, st)); // (a no-op after a stage 0 of the same step)
@@ -1021,6 +1041,19 @@ ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip_str
         c->have_user_stream = 1;
     }
     return rc;
+}
+
+// (internal, the mixed chain) a second discriminator buffer: the staged form then keeps the front end (stage 0) free of anything the
+// previous call's loop writes - the carried tail is copied at the head of stage 1 - and alternates the buffer by step
+extern "C" int
+ddn_p25_chain_double_disc(ddn_p25_chain* c) {
+    if (!c || c->cq) {
+        return DDN_EINVAL;
+    }
+    if (!c->d_disc2) {
+        HIP_TRY(hipMalloc((void**)&c->d_disc2, sizeof(float) * (size_t)c->B * (size_t)c->n));
+    }
+    return DDN_OK;
 }
 
 extern "C" int

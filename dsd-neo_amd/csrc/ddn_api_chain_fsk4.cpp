@@ -41,6 +41,7 @@ struct ddn_fsk4_chain {
     ddn_fsk4_rx* rx;
     ddn_mbe_batch* mbe;
     float* d_disc;
+    float* d_disc2; // mixed chain only: odd steps' discriminator output (the next call's front end beside this call's loop)
     // rows = T carried records + this call's (two sets: the carry reads the previous call's)
     uint8_t *d_rec[2], *d_fl[2], *d_pay;
     int32_t *d_new[2], *d_cnt_full, *d_cnt_scan;
@@ -90,7 +91,7 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
     ddn_batch_destroy(c->fe);
     ddn_fsk4_rx_destroy(c->rx);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->d_disc, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_pay, c->d_new[0], c->d_new[1], c->d_cnt_full,
+    void* all[] = {c->d_disc, c->d_disc2, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_pay, c->d_new[0], c->d_new[1], c->d_cnt_full,
                    c->d_cnt_scan, c->d_dropped, c->s_pos, c->s_n, c->c_pos[0], c->c_pos[1], c->c_n[0], c->c_n[1], c->d_spos, c->d_ns, c->s_pat, c->s_pre,
                    c->s_prel, c->c_pat[0], c->c_pat[1], c->c_pre[0], c->c_pre[1], c->c_prel[0], c->c_prel[1], c->d_spat, c->d_pre,
                    c->d_prel, c->d_st, c->d_info, c->d_cach, c->d_valid, c->d_st_ok, c->d_pdu, c->d_r3, c->d_errs, c->d_lich, c->d_ss,
@@ -335,14 +336,15 @@ ddn_fsk4_chain_stage(ddn_fsk4_chain* c, int stage, const void* d_iq, void* hip_s
     }
     hipStream_t st = (hipStream_t)hip_stream;
     const int cur = (int)(c->step & 1), prev = cur ^ 1;
+    float* disc = (c->d_disc2 && (c->step & 1)) ? c->d_disc2 : c->d_disc;
     if (stage == 0) {
-        return ddn_front_end_run(c->fe, d_iq, (size_t)c->n, c->d_disc, st);
+        return ddn_front_end_run(c->fe, d_iq, (size_t)c->n, disc, st);
     }
     if (stage == 1) {
         HIP_TRY(ddn_dev_chain_carry(c->d_rec[prev], c->d_fl[prev], c->d_new[prev], c->step > 0 ? 1 : 0, c->d_rec[cur], c->d_fl[cur],
                                     c->stride, c->T, c->B, st));
         // the loop writes behind the T carried records: row pointers + T, row stride unchanged
-        return ddn_fsk4_rx_run(c->rx, c->d_disc, (size_t)c->n, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T,
+        return ddn_fsk4_rx_run(c->rx, disc, (size_t)c->n, c->d_rec[cur] + (size_t)c->T * 10, c->d_fl[cur] + c->T,
                                c->d_pay + (size_t)c->T * 2, c->d_new[cur], c->stride, c->s_pos, c->s_pat, c->s_pre, c->s_prel, c->s_n,
                                c->my, st);
     }
@@ -481,7 +483,14 @@ struct ddn_mixed_chain {
     hipStream_t st[3], st2[3]; // per group: front end + matched filter + loop / frame FEC + voice
     hipEvent_t ev_front[3], ev_loop[3], ev_dec[3];
     bool have_dec[3];
+    // (round 5) front ends on streams of their own into two discriminator buffers per group: call k + 1's front end runs beside call
+    // k's loop (ev_read[g][parity]: the loop that read that buffer has ended)
+    bool overlap;
+    hipStream_t stF[3];
+    hipEvent_t ev_read[3][2];
+    unsigned long long calls;
 };
+extern "C" int ddn_p25_chain_double_disc(ddn_p25_chain* c);
 
 extern "C" void
 ddn_mixed_chain_destroy(ddn_mixed_chain* m) {
@@ -493,12 +502,12 @@ ddn_mixed_chain_destroy(ddn_mixed_chain* m) {
     ddn_fsk4_chain_destroy(m->dmr);
     ddn_fsk4_chain_destroy(m->nxdn);
     for (int k = 0; k < 3; k++) {
-        for (hipStream_t s : {m->st[k], m->st2[k]}) {
+        for (hipStream_t s : {m->st[k], m->st2[k], m->stF[k]}) {
             if (s) {
                 (void)hipStreamDestroy(s);
             }
         }
-        for (hipEvent_t e : {m->ev_front[k], m->ev_loop[k], m->ev_dec[k]}) {
+        for (hipEvent_t e : {m->ev_front[k], m->ev_loop[k], m->ev_dec[k], m->ev_read[k][0], m->ev_read[k][1]}) {
             if (e) {
                 (void)hipEventDestroy(e);
             }
@@ -557,6 +566,14 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
             const int v = e ? atoi(e) : 0;
             return (v >= 1 && v <= 32 && (v & (v - 1)) == 0) ? v : dflt;
         };
+        {   // the overlapped schedule runs the fsk4 loops one channel per wavefront where a group allows it (<= 1536 channels: the
+            // loop's fastest shape - 2.7 / 3.1 ms alone against 5.2 / 6.8 at four; the two loops then take turns on the device)
+            const char* e = getenv("DDN_MIX_OVERLAP");
+            if (e && e[0] == '1') {
+                cpw_d = cfg->n_dmr <= 1536 ? 1 : cpw_d;
+                cpw_n = cfg->n_nxdn48 <= 1536 ? 1 : cpw_n;
+            }
+        }
         cpw_d = pow2_1_32(getenv("DDN_MIX_CPW_DMR"), cpw_d);
         cpw_n = pow2_1_32(getenv("DDN_MIX_CPW_NXDN"), cpw_n);
         // Residency decides the step: a CU holds 8 of these wavefronts (~200 registers each).  At 4096 channels in thirds the P25
@@ -578,6 +595,31 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
         }
         if (rc == DDN_OK && m->nxdn) {
             rc = ddn_fsk4_rx_set_channels_per_wave(m->nxdn->rx, cpw_n);
+        }
+    }
+    {   // DDN_MIX_OVERLAP=1 (off by default): front ends on streams of their own, two discriminator buffers per group - call k + 1's
+        // front ends beside call k's loops.  Seven streams: it needs GPU_MAX_HW_QUEUES=6 or 7 in the process environment (HIP's default
+        // four hardware queues make streams share queues: 17-18 ms per step; with 6: 11.75 ms against 13.2 - profiles/README.md)
+        const char* e = getenv("DDN_MIX_OVERLAP");
+        m->overlap = e && e[0] == '1';
+    }
+    if (rc == DDN_OK && m->overlap) {
+        if (m->p25) {
+            rc = ddn_p25_chain_double_disc(m->p25);
+        }
+        for (ddn_fsk4_chain* c : {m->dmr, m->nxdn}) {
+            if (rc == DDN_OK && c && !c->d_disc2) {
+                if (hipMalloc((void**)&c->d_disc2, sizeof(float) * (size_t)c->B * (size_t)c->n) != hipSuccess) {
+                    rc = DDN_ENOMEM;
+                }
+            }
+        }
+        for (int k = 0; k < 3 && rc == DDN_OK; k++) {
+            if (hipStreamCreateWithFlags(&m->stF[k], hipStreamNonBlocking) != hipSuccess
+                || hipEventCreateWithFlags(&m->ev_read[k][0], hipEventDisableTiming) != hipSuccess
+                || hipEventCreateWithFlags(&m->ev_read[k][1], hipEventDisableTiming) != hipSuccess) {
+                rc = DDN_EHIP;
+            }
         }
     }
     for (int k = 0; k < 3 && rc == DDN_OK; k++) {
@@ -628,6 +670,38 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
         const char* e = getenv("DDN_MIX_PHASED");
         return e && e[0] == '1';
     }();
+    const int par = (int)(m->calls & 1);
+    if (m->overlap) {
+        // (round 5) A group is a chain front end -> matched filter -> loop, and with one discriminator buffer the step could not be
+        // shorter than the slowest group's chain (NXDN48: 4.4 + 1.4 + 6.8 ms).  With two buffers and the front ends on streams of
+        // their own, call k + 1's front end runs beside call k's loop (the host runs ahead); it waits for the loop that read its
+        // buffer two calls ago.  The carried record tails are copied at the head of stage 1, so stage 0 touches nothing a loop writes.
+        for (int g = 0; g < 3; g++) {
+            if (on[g]) {
+                if (m->calls >= 2) {
+                    HIP_TRY(hipStreamWaitEvent(m->stF[g], m->ev_read[g][par], 0));
+                }
+                if (g == 0) {
+                    DDN_TRY(ddn_p25_chain_stage(m->p25, 0, iq[0], m->stF[0]));
+                } else {
+                    DDN_TRY(ddn_fsk4_chain_stage(g == 1 ? m->dmr : m->nxdn, 0, iq[g], m->stF[g]));
+                }
+                HIP_TRY(hipEventRecord(m->ev_front[g], m->stF[g]));
+            }
+        }
+        for (int g = 0; g < 3; g++) {
+            if (!on[g]) {
+                continue;
+            }
+            HIP_TRY(hipStreamWaitEvent(m->st[g], m->ev_front[g], 0));
+            if (m->have_dec[g]) {
+                HIP_TRY(hipStreamWaitEvent(m->st[g], m->ev_dec[g], 0));
+            }
+            DDN_TRY(stage(g, 1));
+            HIP_TRY(hipEventRecord(m->ev_loop[g], m->st[g]));
+            HIP_TRY(hipEventRecord(m->ev_read[g][par], m->st[g]));
+        }
+    } else {
     for (int g = 0; g < 3; g++) {
         if (on[g]) {
             if (phased) {
@@ -656,6 +730,8 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
         DDN_TRY(stage(g, 1));
         HIP_TRY(hipEventRecord(m->ev_loop[g], m->st[g]));
     }
+    }
+    m->calls++;
     for (int g = 0; g < 3; g++) {
         if (on[g]) {
             HIP_TRY(hipStreamWaitEvent(m->st2[0], m->ev_loop[g], 0));
@@ -673,6 +749,9 @@ ddn_mixed_chain_wait(ddn_mixed_chain* m) {
         return DDN_EINVAL;
     }
     for (int k = 0; k < 3; k++) {
+        if (m->stF[k]) {
+            HIP_TRY(hipStreamSynchronize(m->stF[k]));
+        }
         HIP_TRY(hipStreamSynchronize(m->st[k]));
         if (m->st2[k]) {
             HIP_TRY(hipStreamSynchronize(m->st2[k]));

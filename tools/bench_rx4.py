@@ -27,6 +27,8 @@ def main():
         idx = (torch.arange(n, device="cuda")[None, :] + (torch.arange(B, device="cuda")[:, None] * 37) % 4096)
         x = disc[idx].contiguous()
         rx = ddn.Fsk4Rx(B, proto, rf_mod=rf, handlers=bool(int(os.environ.get("HANDLERS", "0"))))
+        if os.environ.get("FSK4_CPW"):  # channels per wavefront (the mixed chain runs 4 at 4096 channels)
+            assert l.ddn_fsk4_rx_set_channels_per_wave(rx.h, int(os.environ["FSK4_CPW"])) == 0
         ms, my = l.ddn_fsk4_rx_max_symbols(rx.h, n), l.ddn_fsk4_rx_max_syncs(rx.h, n)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
         rec, fl, pay = z((B, ms, 10), torch.uint8), z((B, ms), torch.uint8), z((B, ms, 2), torch.uint8)
