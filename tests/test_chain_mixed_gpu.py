@@ -172,6 +172,69 @@ def test_mixed_chain_groups_side_by_side(built):
         l.ddn_device_free(p)
 
 
+def test_mixed_chain_overlapped_schedule_equals_default(built, monkeypatch):
+    """DDN_MIX_OVERLAP=1 (front ends on streams of their own into two discriminator buffers per group, the next call's front ends
+    beside this call's loops, fsk4 loops one channel per wavefront): five calls issued back to back without a wait give, array for
+    array, what the default schedule gives for the same five calls - every group, the carried tails included"""
+    import p25gen
+    rng = np.random.default_rng(11)
+    Bp, Bd, Bn, calls = 4, 3, 3, 4
+    dib = [np.concatenate([p25gen.make_frames(rng, 1, 0x293, crc=True, blocks=1 + (c + k) % 3)[0] for k in range(20 * calls)]) for c in range(Bp)]
+    p25 = np.stack([p25gen.modulate_cu8(dib[c], N * calls, lead=250 + 31 * c, seed=c) for c in range(Bp)])
+    dmr, _, _ = _tiles("iq_dmr_t3_ras_cc.npz", 0, Bd, 1)      # (the DMR capture is two seconds long: the same second in every call)
+    nx, _, _ = _tiles("iq_nxdn48.npz", 60000, Bn, calls)
+
+    def piece(k):
+        return np.ascontiguousarray(p25[:, k * N:(k + 1) * N]), dmr[0], nx[k]
+
+    l = ddn.lib()
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DDN_MIX_OVERLAP", mode)
+        m = ddn.MixedChainC(Bp, Bd, Bn, N)
+        monkeypatch.delenv("DDN_MIX_OVERLAP")
+        ptrs = []
+        for k in range(calls):
+            ps = [_upload(x) for x in piece(k)]
+            ptrs += ps
+            m.run(*ps)  # no wait: the host runs ahead, which is what lets the overlapped schedule overlap
+        m.wait()
+        out = {}
+        rm = ddn.P25ChainResults()
+        assert l.ddn_p25_chain_get_results(l.ddn_mixed_chain_part(m.h, 0), C.byref(rm)) == 0
+        own = ddn.P25ChainC(Bp, N)  # (for its shapes only)
+        for name, dt, shape in (("d_new", np.int32, (Bp,)), ("d_nid4", np.int32, (Bp * own.F, 4)), ("d_tsbk", np.uint8, (3, Bp * own.F, 12)),
+                                ("d_records10", np.uint8, (Bp, own.stride, 10)), ("d_tsbk_crc", np.uint8, (3, Bp * own.F))):
+            out["p25." + name] = own.fetch(getattr(rm, name), dt, shape)
+        own.close()
+        for which, Bc in ((1, Bd), (2, Bn)):
+            a = m.part(which)
+            ra = a.results()
+            for name, dt, shape in (("d_counts", np.int32, (Bc,)), ("d_new", np.int32, (Bc,)), ("d_n_sync", np.int32, (Bc,)),
+                                    ("d_records10", np.uint8, (Bc, ra.stride_symbols, 10)), ("d_flags", np.uint8, (Bc, ra.stride_symbols)),
+                                    ("d_valid", np.uint8, (Bc * ra.max_syncs,)), ("d_sync_pos", np.int32, (Bc, ra.max_syncs))):
+                out["%d.%s" % (which, name)] = a.fetch(getattr(ra, name), dt, shape)
+        got[mode] = out
+        m.close()
+        for q in ptrs:
+            l.ddn_device_free(q)
+    assert got["0"].keys() == got["1"].keys()
+    for name in got["0"]:
+        a, b = got["0"][name], got["1"][name]
+        if name.endswith("d_sync_pos") or name.endswith("d_records10") or name.endswith("d_flags"):
+            continue  # compared below up to the counts (what lies beyond them is scratch)
+        assert np.array_equal(a, b), name
+    assert got["0"]["p25.d_tsbk_crc"].sum() >= 30 and got["0"]["1.d_n_sync"].sum() > 0
+    for which, Bc in ((1, Bd), (2, Bn)):
+        for c in range(Bc):
+            k = int(got["0"]["%d.d_counts" % which][c])
+            assert np.array_equal(got["0"]["%d.d_records10" % which][c, :k], got["1"]["%d.d_records10" % which][c, :k]), (which, c)
+            assert np.array_equal(got["0"]["%d.d_flags" % which][c, :k], got["1"]["%d.d_flags" % which][c, :k]), (which, c)
+            ns = int(got["0"]["%d.d_n_sync" % which][c])
+            assert np.array_equal(got["0"]["%d.d_sync_pos" % which][c, :ns], got["1"]["%d.d_sync_pos" % which][c, :ns]), (which, c)
+    assert np.array_equal(got["0"]["p25.d_records10"], got["1"]["p25.d_records10"])
+
+
 def test_dmr_chain_voice_bursts_to_pcm(built):
     """DMR voice inside the chain object: the bursts the reference's BS voice handlers hand to the vocoder (dmrBSBootstrap / dmrBS,
     src/protocol/dmr/dmr_bs.c:585-640,697-760 - decided inside the receive loop, event kind 6 with VC >= 1) -> three AMBE 3600x2450
