@@ -383,6 +383,7 @@ class Fsk4RxConfig(C.Structure):  # == ddn_fsk4_rx_config (include/ddn_fsk4.h)
 
 FSK4_DMR, FSK4_NXDN48, FSK4_PRE = 1, 2, 90
 FSK4_NXDN96 = 3
+FSK4_M17 = 4
 PROTOTYPES.update({
     "ddn_fsk4_rx_create": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_fsk4_rx_destroy": (None, [C.c_void_p]),

@@ -137,9 +137,10 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         return DDN_EINVAL;
     }
     *out = nullptr;
-    if (cfg->n_channels <= 0 || cfg->out_rate_hz <= 0 || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48 && cfg->protocol != DDN_FSK4_NXDN96)
+    if (cfg->n_channels <= 0 || cfg->out_rate_hz <= 0
+        || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48 && cfg->protocol != DDN_FSK4_NXDN96 && cfg->protocol != DDN_FSK4_M17)
         || (cfg->rf_mod != 0 && cfg->rf_mod != 2) || (cfg->inverted && cfg->protocol != DDN_FSK4_DMR)) {
-        ddn_set_error("ddn_fsk4_rx_create: bad configuration (protocol DMR | NXDN48 | NXDN96, rf_mod 0 | 2, inverted only for DMR)");
+        ddn_set_error("ddn_fsk4_rx_create: bad configuration (protocol DMR | NXDN48 | NXDN96 | M17, rf_mod 0 | 2, inverted only for DMR)");
         return DDN_EINVAL;
     }
     {
@@ -167,7 +168,29 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
     d.use_filter = cfg->use_matched_filter ? 1 : 0;
     const unsigned int* tap_bits;
     int lock_default[4] = {0, 0, 0, 0};
-    if (cfg->protocol == DDN_FSK4_DMR) {
+    if (cfg->protocol == DDN_FSK4_M17) {
+        // -fz: C4FM lock at 4800 symbols/s, NO matched filter (decode_mode_apply_m17(), src/runtime/decode_mode.c:486-510), the
+        // eight-symbol words matched by frame_sync_try_m17()'s rules inside the kernel (m17_hit, ddn_rx4.hip); the table names the
+        // twelve outcomes: type ids = synctype_ids.h:52-63 + 1, odd rows negative polarity, class 1 = the preamble (skipDibit(8)),
+        // class 0 = a frame or the EOT marker (184 dibits) - dispatch_m17.c:25-68
+        static const uint8_t kM17Types[12] = {99, 100, 101, 102, 17, 18, 77, 78, 9, 10, 87, 88};
+        d.sym_rate = 4800;
+        d.win_len = 8;
+        d.t_max = 24;
+        d.warm_len = 8;
+        d.n_pat = 12;
+        d.use_filter = 0;
+        for (int k = 0; k < 12; k++) {
+            d.pat_bits[k] = 0xFFu;
+            d.pat_type[k] = kM17Types[k];
+            d.pat_neg[k] = (uint8_t)(k & 1);
+            d.pat_class[k] = (uint8_t)(k < 2 ? 1 : 0);
+        }
+        d.nt = DDN_DMR_FILTER_TAPS; // (unused)
+        tap_bits = ddn_dmr_filter_bits;
+        lock_default[0] = 184;
+        lock_default[1] = 8;
+    } else if (cfg->protocol == DDN_FSK4_DMR) {
         d.sym_rate = 4800;
         d.win_len = d.t_max = d.warm_len = 24;
         d.dmr_window = 1;

@@ -105,10 +105,16 @@ struct Fsk4Cfg {
     // PROTO 1 DMR, 2 NXDN48, 3 NXDN96: NXDN's sync words, two-match confirmation and LICH gate at 4800 symbols/s on the 4800_4 hunt
     // profile (level ring 24, src/dsp/dsd_frame_sync.c:1525-1556,1729-1744) behind the DMR matched filter
     // (symbol_apply_matched_filter(), src/dsp/dsd_symbol.c:323-335)
+    // PROTO 4 M17 (round 5): C4FM lock at 4800 symbols/s without a matched filter (decode_mode_apply_m17(),
+    // src/runtime/decode_mode.c:486-510), eight-symbol words matched with one error allowed by frame_sync_try_m17()
+    // (src/dsp/dsd_frame_sync.c:865-1100: m17_hit() below; the pattern table only names the twelve outcomes), 8-symbol warm start,
+    // fixed counts behind a sync (dispatch_m17.c:25-68: preamble 8, everything else 184)
     static constexpr int sym_rate = PROTO == 2 ? 2400 : 4800;
-    static constexpr int win_len = PROTO == 1 ? 24 : 10, t_max = PROTO == 2 ? 12 : 24, warm_len = PROTO == 1 ? 24 : 10;
-    static constexpr int n_pat = PROTO == 1 ? 8 : 10;
-    static constexpr int confirm = PROTO == 1 ? 0 : 1, dmr_window = PROTO == 1 ? 1 : 0, redigitize = PROTO == 1 ? 1 : 0;
+    static constexpr int win_len = PROTO == 1 ? 24 : (PROTO == 4 ? 8 : 10), t_max = PROTO == 2 ? 12 : 24;
+    static constexpr int warm_len = PROTO == 1 ? 24 : (PROTO == 4 ? 8 : 10);
+    static constexpr int n_pat = PROTO == 1 ? 8 : (PROTO == 4 ? 12 : 10);
+    static constexpr int confirm = (PROTO == 1 || PROTO == 4) ? 0 : 1, dmr_window = PROTO == 1 ? 1 : 0, redigitize = PROTO == 1 ? 1 : 0;
+    static constexpr bool m17 = PROTO == 4;
     static constexpr int slow_type = 0;
     static constexpr int nt = PROTO == 2 ? DDN_NXDN48_FILTER_TAPS : DDN_DMR_FILTER_TAPS;
     int out_rate, rf_mod, use_filter, dbg;
@@ -128,6 +134,62 @@ adds(int i, int span, int c, int rf_mod, int l_edge) {
         return k + (i == c ? 1 : 0);
     }
     return k + ((i == c - 1 || i == c + 1) ? 1 : 0);
+}
+
+// frame_sync_try_m17() with only M17 enabled (src/dsp/dsd_frame_sync.c:865-1100; restated as m17_match() in oracle/ddn_oracle_rx4.c):
+// w8 = the last eight sign dibits, oldest first; last = lastsynctype; pol = state->m17_polarity (0 unknown, 1 normal, 2 inverted);
+// ty[k] = the type id of outcome k (0 / 1 preamble + / -, 2 / 3 EOT, 4 / 5 LSF, 6 / 7 BERT, 8 / 9 stream, 10 / 11 packet).
+// Returns the outcome or -1; pol_after = the polarity the match leaves (preamble sets it, EOT clears it).
+__device__ __forceinline__ int
+m17_hit(uint32_t w8, int last, int pol, const uint32_t* pat_meta, int& pol_after) {
+    enum { W_LSF = 0xF2, W_STR = 0x0D, W_PRE = 0x55, W_PIV = 0xAA, W_BRT = 0x4F, W_PKT = 0xB0, W_EOT = 0xFD, W_EOT_INV = 0x02 };
+    auto ham1 = [&](uint32_t word) { return __popc((w8 ^ word) & 0xFFu) <= 1; };
+    auto ty = [&](int k) { return (int)(pat_meta[k] & 0xFFu); };
+    const bool inv = pol == 2;
+    pol_after = pol;
+    if (ham1(W_PRE)) {
+        pol_after = 1;
+        return 0;
+    }
+    if (ham1(W_PIV)) {
+        pol_after = 2;
+        return 1;
+    }
+    const bool after_frame = last == ty(4) || last == ty(5) || last == ty(8) || last == ty(9) || last == ty(10) || last == ty(11)
+                             || last == ty(6) || last == ty(7);
+    if (ham1(inv ? W_EOT_INV : W_EOT) && after_frame) {
+        pol_after = 0;
+        return inv ? 3 : 2;
+    }
+    const bool after_pre = (!inv && last == ty(0)) || (inv && last == ty(1));
+    const bool after_brt = (!inv && last == ty(6)) || (inv && last == ty(7));
+    if (after_pre || after_brt) {
+        if (after_pre && ham1(inv ? W_STR : W_LSF)) {
+            return inv ? 5 : 4;
+        }
+        if (ham1(inv ? W_PKT : W_BRT)) {
+            return inv ? 7 : 6;
+        }
+    }
+    if (ham1(W_STR) && !inv) {
+        if (last == ty(4) || last == ty(8)) {
+            return 8;
+        }
+    } else if (ham1(W_LSF) && inv) {
+        if (last == ty(5) || last == ty(9)) {
+            return 9;
+        }
+    }
+    if (ham1(W_PKT) && !inv) {
+        if (last == ty(4) || last == ty(10)) {
+            return 10;
+        }
+    } else if (ham1(W_BRT) && inv) {
+        if (last == ty(5) || last == ty(11)) {
+            return 11;
+        }
+    }
+    return -1;
 }
 
 // (one channel per wave is what a batch of <= 1536 channels runs: three waves per SIMD keep all of its workgroups resident at once)
@@ -478,6 +540,9 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     s.hunt_pos = 0;
                     snapshot_filter();
                     no_carrier(s);
+                    if (Cfg::m17) {
+                        s.hlich = 0; // state->m17_polarity
+                    }
                     if (HM && PROTO == 1) {
                         ddn_fsk4h::conf_reset(hctx()); // noCarrier(): dmr_confidence_reset(), engine.c:1856
                     }
@@ -485,6 +550,9 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 if (!(cfg.slow_type && s.lastsync == cfg.slow_type) && s.hunt_pos >= 1800) {
                     snapshot_filter();
                     no_carrier(s);
+                    if (Cfg::m17) {
+                        s.hlich = 0;
+                    }
                     if (HM && PROTO == 1) {
                         ddn_fsk4h::conf_reset(hctx());
                     }
@@ -554,6 +622,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)s.hist_bits, ow);
                             const int sh_o = __builtin_amdgcn_readlane(s.shead, ow), li_o = __builtin_amdgcn_readlane(s.lidx, ow);
                             const int qk_o = __builtin_amdgcn_readlane(qk, ow), ls_type = __builtin_amdgcn_readlane(s.lastsync, ow);
+                            const int m17_pol_o = Cfg::m17 ? __builtin_amdgcn_readlane(s.hlich, ow) : 0; // (M17 keeps its polarity in hlich)
                             const float cen_o = __shfl(s.center, ow), ls_o = __shfl(s.lastsample, ow);
                             const float um_o = __shfl(s.umid, ow), lm_o = __shfl(s.lmid, ow), mx_o = __shfl(s.max, ow), mn_o = __shfl(s.min, ow);
                             float hl = __shfl(s.maxref * 1.25f, ow), ll = __shfl(s.minref * 1.25f, ow);
@@ -656,8 +725,13 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             bool syn = false;
                             if (lane < m && (c0 + lane + 1 >= cfg.win_len) && !(cfg.dbg & 8)) {
                                 const uint32_t w = hj & wmask;
-                                for (int k = 0; k < cfg.n_pat; k++) {
-                                    syn |= (w == L.pat_bits[k]);
+                                if (Cfg::m17) { // (the owner's sync type and polarity stand still while it hunts)
+                                    int pa;
+                                    syn = m17_hit(w, ls_type, m17_pol_o, L.pat_meta, pa) >= 0;
+                                } else {
+                                    for (int k = 0; k < cfg.n_pat; k++) {
+                                        syn |= (w == L.pat_bits[k]);
+                                    }
                                 }
                             }
                             const unsigned long long sm = __ballot(syn);
@@ -907,6 +981,10 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 if (HM) {
                                     hphase_end();
                                 } else {
+                                    if (Cfg::m17 && (s.cur_pat == 2 || s.cur_pat == 3)) { // dsd_dispatch_handle_m17(): EOT ends the transmission
+                                        s.lastsync = 0;
+                                        s.hlich = 0;
+                                    }
                                     hunt_restart(s);
                                 }
                             }
@@ -1123,6 +1201,10 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             if (HM) {
                                 hphase_end();
                             } else {
+                                if (Cfg::m17 && (s.cur_pat == 2 || s.cur_pat == 3)) {
+                                    s.lastsync = 0;
+                                    s.hlich = 0;
+                                }
                                 hunt_restart(s);
                             }
                         }
@@ -1140,8 +1222,14 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             int hit = -1;
                             if (s.hist_count >= cfg.win_len && !(cfg.dbg & 8)) {
                                 const uint32_t w = s.hist_bits & wmask;
-                                for (int k = cfg.n_pat - 1; k >= 0; k--) {
-                                    hit = (w == L.pat_bits[k]) ? k : hit; // lowest matching index wins, as a forward scan
+                                if (Cfg::m17) {
+                                    int pa;
+                                    hit = m17_hit(w, s.lastsync, s.hlich, L.pat_meta, pa);
+                                    s.hlich = pa;
+                                } else {
+                                    for (int k = cfg.n_pat - 1; k >= 0; k--) {
+                                        hit = (w == L.pat_bits[k]) ? k : hit; // lowest matching index wins, as a forward scan
+                                    }
                                 }
                             }
                             if (hit >= 0) {
@@ -1191,7 +1279,8 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 }
                                 if (accepted) {
                                     const int wl = cfg.redigitize ? 24 : cfg.warm_len;
-                                    if (s.scount >= wl) { // dsd_sync_warm_start_thresholds_outer_only(opts, state, wl)
+                                    // (M17: the EOT marker takes the basic lock only, no warm start - dsd_frame_sync.c:905-933)
+                                    if (s.scount >= wl && !(Cfg::m17 && (hit == 2 || hit == 3))) { // dsd_sync_warm_start_thresholds_outer_only(opts, state, wl)
                                         float sp_ = 0.0f, sn_ = 0.0f;
                                         int np = 0, nn = 0, idx = s.shead;
                                         for (int k = 0; k < wl; k++) {
@@ -1592,8 +1681,11 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    if (protocol != 1 && protocol != 2 && protocol != 3) {
+    if (protocol != 1 && protocol != 2 && protocol != 3 && protocol != 4) {
         return hipErrorInvalidValue;
+    }
+    if (protocol == 4 && handlers) {
+        return hipErrorInvalidValue; // M17 frames are fixed counts: no handler family
     }
     const DdnFec3Tables* htab = nullptr;
     if (handlers) {
@@ -1619,6 +1711,9 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
         }                                                                                                                  \
         if (protocol == 3) { /* NXDN96: 10 samples per symbol at 48 ksps - the straight pass of 12 */                      \
             return handlers ? launch<CPW_, 12, 3, true>(DDN_RX4_ARGS) : launch<CPW_, 12, 3, false>(DDN_RX4_ARGS);           \
+        }                                                                                                                  \
+        if (protocol == 4) { /* M17: 4800 symbols/s, fixed counts */                                                       \
+            return launch<CPW_, 12, 4, false>(DDN_RX4_ARGS);                                                                \
         }                                                                                                                  \
         return handlers ? launch<CPW_, MAXW_, 2, true>(DDN_RX4_ARGS) : launch<CPW_, MAXW_, 2, false>(DDN_RX4_ARGS);         \
     } while (0)

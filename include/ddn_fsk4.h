@@ -18,8 +18,13 @@
 extern "C" {
 #endif
 
-enum { DDN_FSK4_DMR = 1, DDN_FSK4_NXDN48 = 2, DDN_FSK4_NXDN96 = 3 }; /* NXDN96: NXDN's rules at 4800 symbols/s (level ring 24, the DMR matched
-                                                                       filter: src/dsp/dsd_frame_sync.c:1525-1556, dsd_symbol.c:323-335) */
+enum { DDN_FSK4_DMR = 1, DDN_FSK4_NXDN48 = 2, DDN_FSK4_NXDN96 = 3, DDN_FSK4_M17 = 4 };
+/* NXDN96: NXDN's rules at 4800 symbols/s (level ring 24, the DMR matched filter: src/dsp/dsd_frame_sync.c:1525-1556, dsd_symbol.c:323-335).
+ * M17 (-fz): C4FM lock at 4800 symbols/s, no matched filter (use_matched_filter is ignored), frame_sync_try_m17()'s matcher
+ * (src/dsp/dsd_frame_sync.c:865-1100: eight-symbol words with one error allowed, each accepted only after the sync type that may precede
+ * it, polarity learnt from the preamble and cleared by EOT / carrier loss), fixed counts behind a sync (dispatch_m17.c:25-68):
+ * lock_symbols[0] = 184 for every frame type and the EOT marker, lock_symbols[1] = 8 for the preamble; no handler family.
+ * Sync pattern index: 0 / 1 preamble + / -, 2 / 3 EOT, 4 / 5 LSF, 6 / 7 BERT, 8 / 9 stream, 10 / 11 packet. */
 enum { DDN_FSK4_CLASS_DATA = 0, DDN_FSK4_CLASS_VOICE = 1 }; /* index into lock_symbols[] */
 /* sync pattern index reported in flags bits 3..6 / d_sync_pat.  DMR: 0 BS data word, 1 BS voice word, 2 MS data, 3 MS voice,
  * 4 / 5 direct-mode TS1 / TS2 data, 6 / 7 direct-mode TS1 / TS2 voice (with inverted = 1 the data words mark voice bursts and

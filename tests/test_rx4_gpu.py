@@ -43,7 +43,7 @@ CASES = [("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR, 0, 0), ("iq_dmr_t3_ras_cc.np
          ("iq_dmr_voice.npz", 2, rx4.PROTO_DMR, 0, 1), ("iq_dmr_t3_cc.npz", 2, rx4.PROTO_DMR, 2, 1),
          ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 0, 0), ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48, 2, 0),
          ("iq_nxdn96.npz", 2, rx4.PROTO_NXDN96, 0, 0), ("iq_nxdn96.npz", 2, rx4.PROTO_NXDN96, 2, 0)]
-GPU_PROTO = {rx4.PROTO_DMR: ddn.FSK4_DMR, rx4.PROTO_NXDN48: ddn.FSK4_NXDN48, rx4.PROTO_NXDN96: ddn.FSK4_NXDN96}
+GPU_PROTO = {rx4.PROTO_DMR: ddn.FSK4_DMR, rx4.PROTO_NXDN48: ddn.FSK4_NXDN48, rx4.PROTO_NXDN96: ddn.FSK4_NXDN96, rx4.PROTO_M17: ddn.FSK4_M17}
 
 
 @pytest.mark.parametrize("cap,lpf,proto,rf_mod,inv", CASES)
@@ -334,3 +334,80 @@ def test_nxdn96_capture_ran_00_through_the_chain_object(built):
     assert len(rans) >= 25 and all(v == 0 for v in rans)         # "RAN 00"
     ch.close()
     l.ddn_device_free(d)
+
+
+def _m17_out_of(got, c, sync_thr):
+    """the device loop's arrays of channel c in the shape tests/m17.py decodes (the oracle loop's output dict)"""
+    k, ns = int(got["cnt"][c]), int(got["n_sync"][c])
+    r4, sym = rec4_of(got["rec"][c, :k])
+    return dict(sym=sym, rec4=r4, fl=got["fl"][c, :k], sync_pos=got["sync_pos"][c, :ns], sync_pat=got["sync_pat"][c, :ns], sync_thr=sync_thr)
+
+
+@pytest.mark.parametrize("cpw", [0, 4])
+def test_m17_loop_bit_exact_and_src_n0call_from_the_device(built, cpw):
+    """DDN_FSK4_M17: frame_sync_try_m17()'s matcher inside the loop kernel (eight-symbol words, one error allowed, each word only after
+    the sync type that may precede it, polarity from the preamble, EOT ends the transmission) = the restatement bit for bit on the
+    reference's M17 capture - delayed, negated, behind silence, across ragged call splits - and the stream frames behind the DEVICE
+    loop's syncs give the capture's known answer: the LSF reassembled from the LICH chunks passes its CRC16 and names N0CALL"""
+    import m17
+    disc = rx4.capture_disc("iq_m17.npz", 2)
+    n = len(disc)
+    B = 5
+    rng = np.random.default_rng(4)
+    x = np.zeros((B, n), np.float32)
+    for c in range(B):
+        d = 41 * c
+        x[c, :d] = rng.standard_normal(d) * 500
+        x[c, d:] = disc[:n - d]
+    x[3] = -x[3]
+    x[4, :20000] = 0
+    gpu = ddn.Fsk4Rx(B, ddn.FSK4_M17)
+    if cpw:
+        assert ddn.lib().ddn_fsk4_rx_set_channels_per_wave(gpu.h, cpw) == 0
+    cpu = [rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_M17)) for _ in range(B)]
+    cuts = [0, 4097, 4097 + 63, 30000, 30001, n]
+    n_sync = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got = gpu.run_host(x[:, a:b])
+        for c in range(B):
+            want = cpu[c].run(x[c, a:b], max_sync=got["sync_pos"].shape[1])
+            check_channel(got, c, want)
+            n_sync += len(want["sync_pos"])
+            assert np.array_equal(gpu.thresholds(c).view(np.uint32), cpu[c].thresholds().view(np.uint32)), (c, a)
+    assert n_sync > 100
+    # one call over the whole capture: the frames behind the device's syncs
+    gpu = ddn.Fsk4Rx(2, ddn.FSK4_M17)
+    got = gpu.run_host(np.stack([disc, -disc]))
+    want = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_M17)).run(disc, max_sync=got["sync_pos"].shape[1])
+    check_channel(got, 0, want)
+    fr = m17.decode_stream(_m17_out_of(got, 0, want["sync_thr"]))
+    srcs = [m17.callsign(int.from_bytes(bytes(f["lich_lsf30"][6:12].tolist()), "big"))[1] for f in fr if f.get("lich_crc_ok")]
+    assert len(srcs) >= 5 and set(srcs) == {"N0CALL"}
+    st = [f for f in fr if f["kind"] == "str" and f["lich_err"] == 0]
+    assert len(st) >= 35 and any(f["kind"] == "eot" for f in fr)
+
+
+def test_m17_synthetic_transmissions_on_the_device(built):
+    """preamble -> LSF -> 14 stream frames -> EOT built by the reference's own encoder, twice (with and without a gap: the second
+    preamble is then matched on the other phase and taken inverted): device loop = restatement bit for bit, and the LSF / stream
+    payloads decode from the device's records (the LSF's soft costs with the thresholds the sync left)"""
+    if orc.ref() is None:
+        pytest.skip("oracle/_ref not built")
+    import m17
+    import p25gen
+    from test_oracle_m17 import two_transmissions
+    for gap, seed in (([1, 3, 1], 5), ([], 1)):
+        d, by, sent = two_transmissions(gap, seed)
+        iq = p25gen.modulate_cu8(d, len(d) * 10 + 1200, lead=20, seed=seed, noise=0.02)
+        disc = orc.OracleFrontEnd(profile=2).run_cu8(iq, 8192)
+        gpu = ddn.Fsk4Rx(3, ddn.FSK4_M17)
+        x = np.stack([disc, np.roll(disc, 7), -disc])
+        got = gpu.run_host(x)
+        wants = [rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_M17)).run(x[c], max_sync=got["sync_pos"].shape[1]) for c in range(3)]
+        for c in range(3):
+            check_channel(got, c, wants[c])
+        fr = m17.decode_stream(_m17_out_of(got, 0, wants[0]["sync_thr"]))
+        lsf = [f for f in fr if f["kind"] == "lsf" and f["crc_ok"]]
+        assert len(lsf) >= 1 and np.array_equal(lsf[0]["lsf30"], by)
+        st = [f for f in fr if f["kind"] == "str" and f["lich_err"] == 0]
+        assert [(f["fn"], bytes(f["payload"].tolist())) for f in st[:14]] == [(fn, bytes(p.tolist())) for fn, p in sent]
