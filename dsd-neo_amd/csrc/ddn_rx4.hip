@@ -136,7 +136,7 @@ adds(int i, int span, int c, int rf_mod, int l_edge) {
     return k + ((i == c - 1 || i == c + 1) ? 1 : 0);
 }
 
-// frame_sync_try_m17() with only M17 enabled (src/dsp/dsd_frame_sync.c:865-1100; restated as m17_match() in oracle/ddn_oracle_rx4.c):
+// frame_sync_try_m17() with only M17 enabled (src/dsp/dsd_frame_sync.c:865-1100; max_hamming 1 for the preamble, no repeated-marker rule):
 // w8 = the last eight sign dibits, oldest first; last = lastsynctype; pol = state->m17_polarity (0 unknown, 1 normal, 2 inverted);
 // ty[k] = the type id of outcome k (0 / 1 preamble + / -, 2 / 3 EOT, 4 / 5 LSF, 6 / 7 BERT, 8 / 9 stream, 10 / 11 packet).
 // Returns the outcome or -1; pol_after = the polarity the match leaves (preamble sets it, EOT clears it).
