@@ -467,6 +467,18 @@ ddn_fsk4_rx_set_channels_per_wave(ddn_fsk4_rx* b, int channels_per_wave) {
     return DDN_OK;
 }
 
+// per-sync thresholds {center, umid, lmid, max, min} [B][max_syncs][5] (device memory, NULL = off): written by the loop's helper wave
+// beside sync_pos / sync_pat; max_syncs = the value the run calls are given
+extern "C" int
+ddn_fsk4_rx_set_sync_thresholds(ddn_fsk4_rx* b, float* d_thr5) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    b->dc.sync_thr = d_thr5;
+    HIP_TRY(hipMemcpy(b->d_cfg, &b->dc, sizeof(DdnFsk4Config), hipMemcpyHostToDevice));
+    return DDN_OK;
+}
+
 extern "C" int
 ddn_fsk4_rx_set_timing(ddn_fsk4_rx* b, int enable) {
     if (!b) {

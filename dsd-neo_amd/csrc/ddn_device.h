@@ -111,6 +111,8 @@ typedef struct DdnFsk4Config {
     int dbg; /* profiling only (env DDN_RX4_DBG) */
     int handlers;   /* 1 = the reference's handlers decide the in-frame length (ddn_fsk4h_dev.h) */
     int max_events; /* capacity of the per-channel event list */
+    float* sync_thr; /* optional [B][max_sync][5]: {center, umid, lmid, max, min} as every accepted sync leaves them (after the warm
+                        start) - what a frame decoder that works on soft symbols needs (M17 LSF: thresholds are static inside a frame) */
 } DdnFsk4Config;
 typedef struct DdnFsk4State {
     long long filt_start, n_abs;

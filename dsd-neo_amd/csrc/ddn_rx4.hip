@@ -229,6 +229,7 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                   | ((uint32_t)cfgp->pat_class[threadIdx.x] << 16);
     }
     const bool use_flt = cfg.use_filter != 0;
+    float* const sync_thr_out = cfgp->sync_thr;
     constexpr int NT = Cfg::nt;
 
     DdnFsk4State s;
@@ -418,6 +419,12 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     if (lane == 0) {
                         sync_pos[so] = s_oo - 1;
                         sync_pat[so] = (uint8_t)((s_fl >> 3) & 31);
+                    }
+                    if (sync_thr_out) { // the sync entry carries the thresholds after the warm start
+                        const float s_mx = __shfl(th.max, sl), s_mn = __shfl(th.min, sl);
+                        if (lane < 5) {
+                            sync_thr_out[so * 5 + lane] = lane == 0 ? s_cen : (lane == 1 ? s_um : (lane == 2 ? s_lm : (lane == 3 ? s_mx : s_mn)));
+                        }
                     }
                     for (int i = lane; i < DDN_FSK4_PRE; i += 64) {
                         const int qi = (s_slot + 1 - DDN_FSK4_PRE + i) & (HN - 1);

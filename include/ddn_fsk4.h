@@ -90,6 +90,23 @@ int ddn_fsk4_rx_get_thresholds(ddn_fsk4_rx* b, int channel, float out7[7]); /* c
  * keeps every workgroup resident for this batch alone; a host that runs other loops beside this one on the same GPU (the mixed
  * chain does) picks it for the whole device's channel count. */
 int ddn_fsk4_rx_set_channels_per_wave(ddn_fsk4_rx* b, int channels_per_wave);
+/* optional output beside d_sync_pos / d_sync_pat: the slicer thresholds {center, umid, lmid, max, min} as every accepted sync leaves them
+ * (after the warm start), [B][max_syncs][5] floats in device memory, NULL = off.  Thresholds are static inside a DMR / NXDN / M17 frame,
+ * so these are what a soft-symbol frame decoder reads (M17 LSF: soft_symbol_to_viterbi_cost(), src/core/frames/dsd_dibit.c:1189-1242) */
+int ddn_fsk4_rx_set_sync_thresholds(ddn_fsk4_rx* b, float* d_thr5);
+
+/* ---- M17 link setup frames behind the loop (the consumer of the libM17-style K = 5 decoder, ddn_fec_viterbi_k5_*) ---------------------
+ * == processM17LSF() (src/protocol/m17/m17.c:1395-1408) for every accepted LSF sync (pattern 4 / 5) of a DDN_FSK4_M17 loop call whose 184
+ * payload symbols lie inside the call's records: soft symbols -> soft_symbol_to_viterbi_cost() per bit against the thresholds the sync left
+ * (d_sync_thr5: ddn_fsk4_rx_set_sync_thresholds; src/core/frames/dsd_dibit.c:1189-1242 - its expf evaluated as the host's libm does) ->
+ * de-randomise -> de-interleave -> de-puncture P1 -> viterbi_decode(488 costs) -> the 30 LSF bytes (DST 48, SRC 48, TYPE 16, META 112,
+ * CRC 16: m17_parse_lsf(), src/protocol/m17/m17_parse.c:369-420) + CRC16 (m17_crc16, m17_algorithms.c:19-35).
+ * d_records10 [B][stride_symbols][10], d_counts [B] = records of the call per channel, d_sync_pos / d_sync_pat [B][max_syncs], d_n_sync [B]:
+ * the loop's outputs.  Out, per sync slot [B][max_syncs]: d_lsf30 [..][30], d_status (0 = not an LSF sync or its frame is not complete in
+ * this call, 1 = decoded with a bad CRC, 2 = CRC good), d_path_cost (optional) = the decoder's path cost. */
+int ddn_m17_lsf_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
+                             const uint8_t* d_sync_pat, const int32_t* d_n_sync, const float* d_sync_thr5, int n_channels, size_t max_syncs,
+                             uint8_t* d_lsf30, uint8_t* d_status, uint32_t* d_path_cost, void* hip_stream);
 int ddn_fsk4_rx_set_timing(ddn_fsk4_rx* b, int enable);
 int ddn_fsk4_rx_get_timing(ddn_fsk4_rx* b, float* ms2); /* {matched filter, receive loop} of the last run */
 
