@@ -402,6 +402,8 @@ PROTOTYPES.update({
     "ddn_fsk4_rx_set_channels_per_wave": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_fsk4_rx_set_sync_thresholds": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_m17_lsf_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 5 + [C.c_int, C.c_size_t] + [C.c_void_p] * 4),
+    "ddn_m17_str_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4 + [C.c_int, C.c_size_t] + [C.c_void_p] * 5),
+    "ddn_m17_lich_assemble_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 9),
     "ddn_fsk4_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_mode_config": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "full_demod": (None, [C.c_void_p]),

@@ -69,3 +69,67 @@ ddn_m17_lsf_decode_batch(const uint8_t* d_records10, size_t stride_symbols, cons
     HIP_TRY(ef);
     return DDN_OK;
 }
+
+extern "C" hipError_t ddn_dev_m17_str_bits(const uint8_t* rec, size_t stride, const int32_t* counts, const int32_t* sync_pos,
+                                           const uint8_t* sync_pat, const int32_t* n_sync, int n_channels, int max_syncs, int lmax,
+                                           uint8_t* sym296, int32_t* slot_sync, uint8_t* slot_lich6, uint8_t* slot_cnt, uint8_t* slot_ok,
+                                           hipStream_t st);
+extern "C" hipError_t ddn_dev_m17_str_finish(const uint8_t* dec, int dec_stride, const int32_t* slot_sync, const uint8_t* slot_lich6,
+                                             const uint8_t* slot_cnt, const uint8_t* slot_ok, int n_channels, int lmax, int max_syncs,
+                                             uint8_t* lich6, uint8_t* lich_cnt, uint8_t* fn_payload18, uint8_t* status, hipStream_t st);
+extern "C" hipError_t ddn_dev_m17_lich(const uint8_t* sync_pat, const int32_t* n_sync, int n_channels, int max_syncs, const uint8_t* lsf30,
+                                       const uint8_t* lsf_status, const uint8_t* lich6, const uint8_t* lich_cnt, const uint8_t* str_status,
+                                       uint8_t* asm30, uint8_t* lich_lsf30, uint8_t* lich_status, hipStream_t st);
+
+extern "C" int
+ddn_m17_str_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
+                         const uint8_t* d_sync_pat, const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_lich6,
+                         uint8_t* d_lich_cnt, uint8_t* d_fn_payload18, uint8_t* d_status, void* hip_stream) {
+    if (!d_records10 || !d_counts || !d_sync_pos || !d_sync_pat || !d_n_sync || !d_lich6 || !d_lich_cnt || !d_fn_payload18 || !d_status
+        || n_channels <= 0 || max_syncs == 0 || max_syncs > (1u << 24) || stride_symbols == 0) {
+        ddn_set_error("ddn_m17_str_decode_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int lmax = (int)(stride_symbols / 192 + 1); // a stream frame takes 192 symbols
+    const size_t S = (size_t)n_channels * (size_t)lmax;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_sym = up(S * 296), b_dec = up(S * 18), b_slot = up(S * sizeof(int32_t)), b_l6 = up(S * 6), b_1 = up(S);
+    uint8_t* scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&scratch, b_sym + b_dec + b_slot + b_l6 + 2 * b_1, st));
+    uint8_t* sym = scratch;
+    uint8_t* dec = sym + b_sym;
+    int32_t* slot = (int32_t*)(dec + b_dec);
+    uint8_t* l6 = (uint8_t*)slot + b_slot;
+    uint8_t* cnt = l6 + b_l6;
+    uint8_t* ok = cnt + b_1;
+    hipError_t e = hipMemsetAsync(d_status, 0, (size_t)n_channels * max_syncs, st);
+    if (e == hipSuccess) {
+        e = ddn_dev_m17_str_bits(d_records10, stride_symbols, d_counts, d_sync_pos, d_sync_pat, d_n_sync, n_channels, (int)max_syncs, lmax, sym,
+                                 slot, l6, cnt, ok, st);
+    }
+    if (e == hipSuccess) { // (blocks of 16 frames none of which has a LICH that decoded write zeros and leave)
+        e = ddn_dev_k5_nxdn_wanted(sym, nullptr, (int)S, 148, 144, nullptr, dec, 18, ok, 1, st);
+    }
+    if (e == hipSuccess) {
+        e = ddn_dev_m17_str_finish(dec, 18, slot, l6, cnt, ok, n_channels, lmax, (int)max_syncs, d_lich6, d_lich_cnt, d_fn_payload18, d_status, st);
+    }
+    const hipError_t ef = hipFreeAsync(scratch, st);
+    HIP_TRY(e);
+    HIP_TRY(ef);
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_m17_lich_assemble_batch(const uint8_t* d_sync_pat, const int32_t* d_n_sync, int n_channels, size_t max_syncs, const uint8_t* d_lsf30,
+                            const uint8_t* d_lsf_status, const uint8_t* d_lich6, const uint8_t* d_lich_cnt, const uint8_t* d_str_status,
+                            uint8_t* d_assembly32, uint8_t* d_lich_lsf30, uint8_t* d_lich_status, void* hip_stream) {
+    if (!d_sync_pat || !d_n_sync || !d_lich6 || !d_lich_cnt || !d_str_status || !d_assembly32 || !d_lich_lsf30 || !d_lich_status
+        || n_channels <= 0 || max_syncs == 0 || max_syncs > (1u << 24) || ((d_lsf30 == nullptr) != (d_lsf_status == nullptr))) {
+        ddn_set_error("ddn_m17_lich_assemble_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    HIP_TRY(ddn_dev_m17_lich(d_sync_pat, d_n_sync, n_channels, (int)max_syncs, d_lsf30, d_lsf_status, d_lich6, d_lich_cnt, d_str_status,
+                             d_assembly32, d_lich_lsf30, d_lich_status, (hipStream_t)hip_stream));
+    return DDN_OK;
+}

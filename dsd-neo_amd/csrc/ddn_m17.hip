@@ -10,10 +10,23 @@
 //   k_m17_lsf_cost    one wavefront per (channel, j): finds the channel's j-th LSF sync whose frame lies inside the records, computes
 //                     its 368 costs (expf as the host's libm computes it: ddn_expf.h) and writes the 488 de-punctured ones
 //   k_m17_lsf_finish  one lane per (channel, j): LSF bytes, CRC16, scattered to the sync's slot
+//
+// processM17STR() (:1122-1176): the 184 payload dibits of a stream frame as hard bits -> de-randomised -> de-interleaved -> 96 LICH
+// bits = four Golay(24,12) words (m17_lich_decode_bits, m17_algorithms.c:598-612 over Golay_24_12_decode, src/fec/fec.c:656-690) ->
+// 40 LSF bits + 3-bit chunk counter (m17_lich_parse_content :562-583); when all four words decode and the counter is < 6:
+// M17prepareStream() :1039-1120 = the other 272 bits de-punctured with P2 (11 of 12 kept, the cut bit reads 0) -> symbol values
+// bit << 1 -> CNXDNConvolution over 148 steps, 144 bits chained back (k_k5_nxdn, ddn_trellis.hip) -> frame number + 16 payload bytes.
+//   k_m17_str_bits    one wavefront per (channel, j): the channel's j-th stream sync with a complete frame -> LICH + the 296 symbols
+//   k_m17_str_finish  one lane per (channel, j): scatter to the sync's slot
+//   k_m17_lich        one lane per channel: the LSF reassembled from six LICH chunks in the order of the syncs (dispatch_m17.c:39,
+//                     m17.c:250, M17finalizeLICH: CRC16 over the reassembled 30 bytes), with the decoded LSF frames and EOT markers
+//                     in between as the reference applies them
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "ddn_expf.h"
+#include "ddn_fec3.h"
+#include "ddn_tables_fec3.h"
 
 namespace {
 
@@ -174,7 +187,221 @@ k_m17_lsf_finish(const uint8_t* __restrict__ dec, int dec_stride, const uint32_t
         path_cost[so] = cost[slot];
     }
 }
+// the channel's j-th sync of one of two patterns whose 184 payload symbols lie inside the call's records (whole wavefront; -1: none)
+__device__ __forceinline__ int
+m17_find_sync(const int32_t* sync_pos, const uint8_t* sync_pat, int ns, int cnt, int j, int pat_a, int pat_b, int lane) {
+    int found = -1, seen = 0;
+    for (int k0 = 0; k0 < ns && found < 0; k0 += 64) {
+        const int k = k0 + lane;
+        bool is = false;
+        if (k < ns) {
+            const int pat = sync_pat[k];
+            is = (pat == pat_a || pat == pat_b) && sync_pos[k] + 185 <= cnt;
+        }
+        const unsigned long long b = __ballot(is);
+        const int nb = __popcll(b);
+        if (seen + nb > j) {
+            unsigned long long m = b;
+            for (int q = 0; q < j - seen; q++) {
+                m &= m - 1;
+            }
+            found = k0 + __ffsll((long long)m) - 1;
+        }
+        seen += nb;
+    }
+    return found;
+}
+
+__global__ __launch_bounds__(64) void
+k_m17_str_bits(const uint8_t* __restrict__ rec, size_t stride, const int32_t* __restrict__ counts, const int32_t* __restrict__ sync_pos,
+               const uint8_t* __restrict__ sync_pat, const int32_t* __restrict__ n_sync, int max_syncs, int lmax,
+               const DdnFec3Tables* __restrict__ T, uint8_t* __restrict__ sym296, int32_t* __restrict__ slot_sync,
+               uint8_t* __restrict__ slot_lich6, uint8_t* __restrict__ slot_cnt, uint8_t* __restrict__ slot_ok) {
+    __shared__ uint8_t bits[368]; // de-randomised, de-interleaved
+    __shared__ uint32_t word[4];
+    __shared__ int werr[4];
+    const int ch = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    const size_t slot = (size_t)ch * lmax + j;
+    int ns = n_sync[ch];
+    ns = ns < max_syncs ? ns : max_syncs;
+    const int found = m17_find_sync(sync_pos + (size_t)ch * max_syncs, sync_pat + (size_t)ch * max_syncs, ns, counts[ch], j, 8, 9, lane);
+    if (lane == 0) {
+        slot_sync[slot] = found;
+        slot_ok[slot] = 0;
+    }
+    if (found < 0) {
+        return;
+    }
+    const int pos = sync_pos[(size_t)ch * max_syncs + found];
+    const uint8_t* r0 = rec + ((size_t)ch * stride + (size_t)pos + 1) * 10;
+    for (int i = lane; i < 368; i += 64) {
+        const int x = (45 * i + 92 * i * i) % 368; // bits[i] = rnd[x] ^ rand(x)
+        const int d = r0[(size_t)(x >> 1) * 10] & 3;
+        const int b = (x & 1) ? (d & 1) : (d >> 1);
+        bits[i] = (uint8_t)((b ^ ((k_m17_rand[x >> 3] >> (7 - (x & 7))) & 1)) & 1);
+    }
+    __syncthreads();
+    if (lane < 4) { // Golay_24_12_decode on rx[0 .. 23] (bit j of the word = rx[j]), fec.c:656-690
+        uint32_t w = 0;
+        for (int q = 0; q < 24; q++) {
+            w |= (uint32_t)bits[24 * lane + q] << q;
+        }
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            s |= (__popc(w & ddn_golay_24_12_H[i]) & 1) << (11 - i);
+        }
+        bool ok = true;
+        if (s > 0) {
+            int k = 0;
+            for (; k < 3; k++) {
+                const uint8_t p = T->g2412[s][k];
+                if (p == 0xFF) {
+                    break;
+                }
+                w ^= 1u << p;
+            }
+            ok = k != 0;
+        }
+        word[lane] = w;
+        werr[lane] = ok ? 0 : 1;
+    }
+    __syncthreads();
+    // content bit 12 b + q = corrected word b, bit q (the first twelve of each word)
+    const int c40 = (word[3] >> 4) & 1, c41 = (word[3] >> 5) & 1, c42 = (word[3] >> 6) & 1;
+    const int cnt = (c40 << 2) | (c41 << 1) | c42;
+    const bool err = (werr[0] | werr[1] | werr[2] | werr[3]) != 0 || cnt >= 6;
+    if (lane < 6) {
+        uint32_t by = 0;
+        for (int q = 0; q < 8; q++) {
+            const int i = 8 * lane + q;
+            by |= ((word[i / 12] >> (i % 12)) & 1u) << (7 - q);
+        }
+        slot_lich6[slot * 6 + lane] = (uint8_t)by;
+    }
+    if (lane == 0) {
+        slot_cnt[slot] = (uint8_t)cnt;
+        slot_ok[slot] = err ? 1 : 2;
+    }
+    uint8_t* out = sym296 + slot * 296;
+    for (int i = lane; i < 296; i += 64) { // P2: groups of 11 kept + 1 cut; 272 bits fill 24 groups and 8 of the 25th
+        const int g = i / 12, q = i - g * 12;
+        const int x = g * 11 + q;
+        const int b = (q < 11 && x < 272 && !err) ? bits[96 + x] : 0;
+        out[i] = (uint8_t)(b << 1);
+    }
+}
+
+__global__ void
+k_m17_str_finish(const uint8_t* __restrict__ dec, int dec_stride, const int32_t* __restrict__ slot_sync, const uint8_t* __restrict__ slot_lich6,
+                 const uint8_t* __restrict__ slot_cnt, const uint8_t* __restrict__ slot_ok, int n_channels, int lmax, int max_syncs,
+                 uint8_t* __restrict__ lich6, uint8_t* __restrict__ lich_cnt, uint8_t* __restrict__ fn_payload18, uint8_t* __restrict__ status) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_channels * lmax) {
+        return;
+    }
+    const int k = slot_sync[slot];
+    if (k < 0) {
+        return;
+    }
+    const size_t so = (size_t)(slot / lmax) * max_syncs + k;
+    const int ok = slot_ok[slot];
+    for (int i = 0; i < 6; i++) {
+        lich6[so * 6 + i] = slot_lich6[(size_t)slot * 6 + i];
+    }
+    lich_cnt[so] = slot_cnt[slot];
+    for (int i = 0; i < 18; i++) {
+        fn_payload18[so * 18 + i] = ok == 2 ? dec[(size_t)slot * dec_stride + i] : 0;
+    }
+    status[so] = (uint8_t)ok;
+}
+
+// One lane per channel: walks the channel's syncs in order.  asm30 [B][32] is the carried assembly buffer (30 bytes + 2 spare).
+__global__ void
+k_m17_lich(const uint8_t* __restrict__ sync_pat, const int32_t* __restrict__ n_sync, int n_channels, int max_syncs,
+           const uint8_t* __restrict__ lsf30, const uint8_t* __restrict__ lsf_status, const uint8_t* __restrict__ lich6,
+           const uint8_t* __restrict__ lich_cnt, const uint8_t* __restrict__ str_status, uint8_t* __restrict__ asm30,
+           uint8_t* __restrict__ lich_lsf30, uint8_t* __restrict__ lich_status) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_channels) {
+        return;
+    }
+    uint8_t* a = asm30 + (size_t)ch * 32;
+    int ns = n_sync[ch];
+    ns = ns < max_syncs ? ns : max_syncs;
+    for (int k = 0; k < ns; k++) {
+        const size_t so = (size_t)ch * max_syncs + k;
+        const int pat = sync_pat[so];
+        lich_status[so] = 0;
+        if (pat == 2 || pat == 3) { // EOT: state->m17_lsf cleared (dispatch_m17.c:39)
+            for (int i = 0; i < 30; i++) {
+                a[i] = 0;
+            }
+        } else if ((pat == 4 || pat == 5) && lsf_status && lsf_status[so] != 0) { // m17_decode_lsf_soft_bits: m17_lsf = the decoded LSF
+            for (int i = 0; i < 30; i++) {
+                a[i] = lsf30[so * 30 + i];
+            }
+        } else if ((pat == 8 || pat == 9) && str_status[so] == 2) {
+            const int cnt = lich_cnt[so];
+            for (int i = 0; i < 5; i++) { // 40 bits of chunk cnt
+                a[5 * cnt + i] = lich6[so * 6 + i];
+            }
+            if (cnt == 5) { // M17finalizeLICH: CRC over the reassembled LSF, then the buffer is cleared (:250)
+                uint32_t crc = 0xFFFFu;
+                for (int i = 0; i < 30; i++) {
+                    lich_lsf30[so * 30 + i] = a[i];
+                    if (i < 28) {
+                        crc ^= (uint32_t)a[i] << 8;
+                        for (int q = 0; q < 8; q++) {
+                            crc <<= 1;
+                            if (crc & 0x10000u) {
+                                crc = (crc ^ 0x5935u) & 0xFFFFu;
+                            }
+                        }
+                    }
+                }
+                lich_status[so] = (crc & 0xFFFFu) == (((uint32_t)a[28] << 8) | a[29]) ? 2 : 1;
+                for (int i = 0; i < 30; i++) {
+                    a[i] = 0;
+                }
+            }
+        }
+    }
+}
 } // namespace
+
+extern "C" hipError_t
+ddn_dev_m17_str_bits(const uint8_t* rec, size_t stride, const int32_t* counts, const int32_t* sync_pos, const uint8_t* sync_pat,
+                     const int32_t* n_sync, int n_channels, int max_syncs, int lmax, uint8_t* sym296, int32_t* slot_sync, uint8_t* slot_lich6,
+                     uint8_t* slot_cnt, uint8_t* slot_ok, hipStream_t st) {
+    const DdnFec3Tables* T = nullptr;
+    const hipError_t e = ddn_dev_fec3_tables(&T, st);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(k_m17_str_bits, dim3((unsigned)n_channels, (unsigned)lmax), dim3(64), 0, st, rec, stride, counts, sync_pos, sync_pat,
+                       n_sync, max_syncs, lmax, T, sym296, slot_sync, slot_lich6, slot_cnt, slot_ok);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_m17_str_finish(const uint8_t* dec, int dec_stride, const int32_t* slot_sync, const uint8_t* slot_lich6, const uint8_t* slot_cnt,
+                       const uint8_t* slot_ok, int n_channels, int lmax, int max_syncs, uint8_t* lich6, uint8_t* lich_cnt,
+                       uint8_t* fn_payload18, uint8_t* status, hipStream_t st) {
+    const int n = n_channels * lmax;
+    hipLaunchKernelGGL(k_m17_str_finish, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, dec, dec_stride, slot_sync, slot_lich6, slot_cnt,
+                       slot_ok, n_channels, lmax, max_syncs, lich6, lich_cnt, fn_payload18, status);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_m17_lich(const uint8_t* sync_pat, const int32_t* n_sync, int n_channels, int max_syncs, const uint8_t* lsf30,
+                 const uint8_t* lsf_status, const uint8_t* lich6, const uint8_t* lich_cnt, const uint8_t* str_status, uint8_t* asm30,
+                 uint8_t* lich_lsf30, uint8_t* lich_status, hipStream_t st) {
+    hipLaunchKernelGGL(k_m17_lich, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, sync_pat, n_sync, n_channels, max_syncs, lsf30,
+                       lsf_status, lich6, lich_cnt, str_status, asm30, lich_lsf30, lich_status);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t
 ddn_dev_m17_lsf_cost(const uint8_t* rec, size_t stride, const int32_t* counts, const int32_t* sync_pos, const uint8_t* sync_pat,

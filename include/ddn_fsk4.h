@@ -107,6 +107,21 @@ int ddn_fsk4_rx_set_sync_thresholds(ddn_fsk4_rx* b, float* d_thr5);
 int ddn_m17_lsf_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
                              const uint8_t* d_sync_pat, const int32_t* d_n_sync, const float* d_sync_thr5, int n_channels, size_t max_syncs,
                              uint8_t* d_lsf30, uint8_t* d_status, uint32_t* d_path_cost, void* hip_stream);
+/* == processM17STR() (src/protocol/m17/m17.c:1122-1176) for every accepted stream sync (pattern 8 / 9) whose frame is complete: hard dibits ->
+ * de-randomise -> de-interleave -> LICH = four Golay(24,12) words (m17_lich_decode_bits) -> 48 content bits (d_lich6, packed) with the
+ * 3-bit chunk counter (d_lich_cnt); when all four decode and the counter is < 6: P2 de-puncture -> CNXDNConvolution (148 steps) ->
+ * d_fn_payload18 = frame number (2 bytes, big endian) + the 16 payload bytes.  d_status: 0 = not a stream sync / frame not complete,
+ * 1 = LICH failed (no payload, as the reference), 2 = decoded. */
+int ddn_m17_str_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
+                             const uint8_t* d_sync_pat, const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_lich6,
+                             uint8_t* d_lich_cnt, uint8_t* d_fn_payload18, uint8_t* d_status, void* hip_stream);
+/* The LSF reassembled from the LICH chunks, in the order of the syncs of a call: a decoded LSF frame seeds the buffer (m17_decode_lsf_soft_
+ * bits), an EOT marker clears it (dispatch_m17.c:39), chunk c fills bytes 5 c .. 5 c + 4, chunk 5 closes it: d_lich_lsf30 [B][max_syncs][30]
+ * + d_lich_status (0 none here, 1 CRC bad, 2 CRC good: M17finalizeLICH), then the buffer is cleared.  d_assembly32 [B][32] is the carried
+ * buffer (zero it before a stream's first call).  d_lsf30 / d_lsf_status = ddn_m17_lsf_decode_batch's outputs, or both NULL. */
+int ddn_m17_lich_assemble_batch(const uint8_t* d_sync_pat, const int32_t* d_n_sync, int n_channels, size_t max_syncs, const uint8_t* d_lsf30,
+                                const uint8_t* d_lsf_status, const uint8_t* d_lich6, const uint8_t* d_lich_cnt, const uint8_t* d_str_status,
+                                uint8_t* d_assembly32, uint8_t* d_lich_lsf30, uint8_t* d_lich_status, void* hip_stream);
 int ddn_fsk4_rx_set_timing(ddn_fsk4_rx* b, int enable);
 int ddn_fsk4_rx_get_timing(ddn_fsk4_rx* b, float* ms2); /* {matched filter, receive loop} of the last run */
 
