@@ -509,7 +509,9 @@ class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
         (k, C.c_void_p) for k in ("d_dmr_n_data", "d_dmr_data_start", "d_dmr_data_slot", "d_dmr_data_type", "d_dmr_data_info196",
                                   "d_dmr_data_bits96", "d_dmr_data_bytes12", "d_dmr_data_errs", "d_dmr_data_crc", "d_dmr_r34_unconfirmed",
                                   "d_dmr_r34_confirmed", "d_dmr_r34_confirmed_crc", "d_dmr_r34_pool", "d_dmr_r34_pool_n")] + [
-        ("dmr_emb_lcs", C.c_int)] + [(k, C.c_void_p) for k in ("d_dmr_n_emb", "d_dmr_emb_pos", "d_dmr_emb_lc77", "d_dmr_emb_errs", "d_dmr_emb_ok")]
+        ("dmr_emb_lcs", C.c_int)] + [(k, C.c_void_p) for k in ("d_dmr_n_emb", "d_dmr_emb_pos", "d_dmr_emb_lc77", "d_dmr_emb_errs", "d_dmr_emb_ok")] + [
+        (k, C.c_void_p) for k in ("d_sync_thr5", "d_m17_lsf30", "d_m17_lsf_status", "d_m17_lsf_cost", "d_m17_lich6", "d_m17_lich_cnt",
+                                  "d_m17_fn_payload18", "d_m17_str_status", "d_m17_lich_lsf30", "d_m17_lich_status")]
 
 
 class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config

@@ -632,7 +632,9 @@ k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict_
                    int32_t* __restrict__ d_pos, uint8_t* __restrict__ d_pat, uint8_t* __restrict__ d_pre, uint8_t* __restrict__ d_prel,
                    int32_t* __restrict__ d_n, int myd, int32_t* __restrict__ o_pos, uint8_t* __restrict__ o_pat,
                    uint8_t* __restrict__ o_pre, uint8_t* __restrict__ o_prel, int32_t* __restrict__ o_n,
-                   int32_t* __restrict__ dropped) {
+                   int32_t* __restrict__ dropped, const float* __restrict__ c_thr, const float* __restrict__ s_thr,
+                   float* __restrict__ d_thr, float* __restrict__ o_thr) {
+    // (c_thr / s_thr / d_thr / o_thr: optional [..][5] thresholds every sync left, filed with it - M17)
     const int c = blockIdx.x, lane = threadIdx.x;
     const int nc = c_n[c] < myc ? c_n[c] : myc, nsn = s_n[c] < my ? s_n[c] : my;
     const int limit = flush ? 0x7FFFFFFF : n_new[c], shift = n_new[c];
@@ -645,6 +647,7 @@ k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict_
         const uint8_t* pre = carried ? c_pre + ((size_t)c * myc + j) * 90 : s_pre + ((size_t)c * my + j) * 90;
         const uint8_t* prel = carried ? c_prel + ((size_t)c * myc + j) * 90 : s_prel + ((size_t)c * my + j) * 90;
         uint8_t *qp, *qr;
+        const float* th = s_thr ? (carried ? c_thr + ((size_t)c * myc + j) * 5 : s_thr + ((size_t)c * my + j) * 5) : nullptr;
         if (p < limit) {
             if (kd >= myd) {
                 lost++; // more accepted syncs than decode slots: counted, never silent
@@ -653,6 +656,9 @@ k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict_
             if (lane == 0) {
                 d_pos[(size_t)c * myd + kd] = p;
                 d_pat[(size_t)c * myd + kd] = pat;
+            }
+            if (th && lane < 5) {
+                d_thr[((size_t)c * myd + kd) * 5 + lane] = th[lane];
             }
             qp = d_pre + ((size_t)c * myd + kd) * 90;
             qr = d_prel + ((size_t)c * myd + kd) * 90;
@@ -665,6 +671,9 @@ k_fsk4_chain_syncs(const int32_t* __restrict__ c_pos, const uint8_t* __restrict_
             if (lane == 0) {
                 o_pos[(size_t)c * myc + ko] = p - shift;
                 o_pat[(size_t)c * myc + ko] = pat;
+            }
+            if (th && lane < 5) {
+                o_thr[((size_t)c * myc + ko) * 5 + lane] = th[lane];
             }
             qp = o_pre + ((size_t)c * myc + ko) * 90;
             qr = o_prel + ((size_t)c * myc + ko) * 90;
@@ -941,17 +950,38 @@ ddn_dev_nxdn_voice_select(const int32_t* sync_pos, const int32_t* n_sync, const 
     return hipGetLastError();
 }
 
+extern "C" hipError_t ddn_dev_fsk4_chain_syncs_thr(const int32_t* c_pos, const uint8_t* c_pat, const uint8_t* c_pre, const uint8_t* c_prel,
+                                                   const int32_t* c_n, int myc, const int32_t* s_pos, const uint8_t* s_pat, const uint8_t* s_pre,
+                                                   const uint8_t* s_prel, const int32_t* s_n, int my, const int32_t* n_new, int T, int flush,
+                                                   int32_t* d_pos, uint8_t* d_pat, uint8_t* d_pre, uint8_t* d_prel, int32_t* d_n, int myd,
+                                                   int32_t* o_pos, uint8_t* o_pat, uint8_t* o_pre, uint8_t* o_prel, int32_t* o_n,
+                                                   int32_t* dropped, int n_channels, const float* c_thr, const float* s_thr, float* d_thr,
+                                                   float* o_thr, hipStream_t st);
 extern "C" hipError_t
 ddn_dev_fsk4_chain_syncs(const int32_t* c_pos, const uint8_t* c_pat, const uint8_t* c_pre, const uint8_t* c_prel, const int32_t* c_n, int myc,
                          const int32_t* s_pos, const uint8_t* s_pat, const uint8_t* s_pre, const uint8_t* s_prel, const int32_t* s_n, int my,
                          const int32_t* n_new, int T, int flush, int32_t* d_pos, uint8_t* d_pat, uint8_t* d_pre, uint8_t* d_prel,
                          int32_t* d_n, int myd, int32_t* o_pos, uint8_t* o_pat, uint8_t* o_pre, uint8_t* o_prel, int32_t* o_n,
                          int32_t* dropped, int n_channels, hipStream_t st) {
+    return ddn_dev_fsk4_chain_syncs_thr(c_pos, c_pat, c_pre, c_prel, c_n, myc, s_pos, s_pat, s_pre, s_prel, s_n, my, n_new, T, flush, d_pos, d_pat,
+                                        d_pre, d_prel, d_n, myd, o_pos, o_pat, o_pre, o_prel, o_n, dropped, n_channels, nullptr, nullptr, nullptr,
+                                        nullptr, st);
+}
+
+// the same with the thresholds every sync left filed beside it ([..][5] floats: carried in, loop's, decode list, carried out)
+extern "C" hipError_t
+ddn_dev_fsk4_chain_syncs_thr(const int32_t* c_pos, const uint8_t* c_pat, const uint8_t* c_pre, const uint8_t* c_prel, const int32_t* c_n,
+                             int myc, const int32_t* s_pos, const uint8_t* s_pat, const uint8_t* s_pre, const uint8_t* s_prel,
+                             const int32_t* s_n, int my, const int32_t* n_new, int T, int flush, int32_t* d_pos, uint8_t* d_pat,
+                             uint8_t* d_pre, uint8_t* d_prel, int32_t* d_n, int myd, int32_t* o_pos, uint8_t* o_pat, uint8_t* o_pre,
+                             uint8_t* o_prel, int32_t* o_n, int32_t* dropped, int n_channels, const float* c_thr, const float* s_thr,
+                             float* d_thr, float* o_thr, hipStream_t st) {
     if (n_channels <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(k_fsk4_chain_syncs, dim3((unsigned)n_channels), dim3(64), 0, st, c_pos, c_pat, c_pre, c_prel, c_n, myc, s_pos, s_pat,
-                       s_pre, s_prel, s_n, my, n_new, T, flush, d_pos, d_pat, d_pre, d_prel, d_n, myd, o_pos, o_pat, o_pre, o_prel, o_n, dropped);
+                       s_pre, s_prel, s_n, my, n_new, T, flush, d_pos, d_pat, d_pre, d_prel, d_n, myd, o_pos, o_pat, o_pre, o_prel, o_n, dropped,
+                       c_thr, s_thr, d_thr, o_thr);
     return hipGetLastError();
 }
 

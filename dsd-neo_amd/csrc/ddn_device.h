@@ -409,6 +409,12 @@ hipError_t ddn_dev_fsk4_chain_syncs(const int32_t* c_pos, const uint8_t* c_pat, 
                                     int32_t* d_pos, uint8_t* d_pat, uint8_t* d_pre, uint8_t* d_prel, int32_t* d_n, int myd,
                                     int32_t* o_pos, uint8_t* o_pat, uint8_t* o_pre, uint8_t* o_prel, int32_t* o_n, int32_t* dropped,
                                     int n_channels, hipStream_t st);
+hipError_t ddn_dev_fsk4_chain_syncs_thr(const int32_t* c_pos, const uint8_t* c_pat, const uint8_t* c_pre, const uint8_t* c_prel,
+                                        const int32_t* c_n, int myc, const int32_t* s_pos, const uint8_t* s_pat, const uint8_t* s_pre,
+                                        const uint8_t* s_prel, const int32_t* s_n, int my, const int32_t* n_new, int T, int flush,
+                                        int32_t* d_pos, uint8_t* d_pat, uint8_t* d_pre, uint8_t* d_prel, int32_t* d_n, int myd,
+                                        int32_t* o_pos, uint8_t* o_pat, uint8_t* o_pre, uint8_t* o_prel, int32_t* o_n, int32_t* dropped,
+                                        int n_channels, const float* c_thr, const float* s_thr, float* d_thr, float* o_thr, hipStream_t st);
 hipError_t ddn_dev_u8_shr1(const uint8_t* in, size_t n, uint8_t* out, hipStream_t st);
 hipError_t ddn_dev_tsbk_select(const uint8_t* cand, const int32_t* counts, size_t n, uint8_t* out12, uint8_t* crc_ok, uint8_t* sel,
                                hipStream_t st);

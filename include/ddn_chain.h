@@ -343,6 +343,20 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const uint8_t* d_dmr_emb_lc77;       /* [2 B][dmr_emb_lcs][77] */
     const uint32_t* d_dmr_emb_errs;      /* [..] */
     const uint8_t* d_dmr_emb_ok;         /* [..] */
+    /* M17 (protocol DDN_FSK4_M17; NULL otherwise), per sync slot [S] of this call's decode list (d_sync_pos / d_sync_pat; pattern index
+     * 0 / 1 preamble, 2 / 3 EOT, 4 / 5 LSF, 6 / 7 BERT, 8 / 9 stream, 10 / 11 packet): what ddn_m17_lsf_decode_batch /
+     * ddn_m17_str_decode_batch / ddn_m17_lich_assemble_batch give for it (include/ddn_fsk4.h); the LICH assembly buffer streams
+     * from call to call like every other carried word */
+    const float* d_sync_thr5;            /* [S][5] {center, umid, lmid, max, min} the sync left */
+    const uint8_t* d_m17_lsf30;          /* [S][30] */
+    const uint8_t* d_m17_lsf_status;     /* [S] 0 not an LSF frame, 1 CRC bad, 2 CRC good */
+    const uint32_t* d_m17_lsf_cost;      /* [S] the decoder's path cost */
+    const uint8_t* d_m17_lich6;          /* [S][6] */
+    const uint8_t* d_m17_lich_cnt;       /* [S] */
+    const uint8_t* d_m17_fn_payload18;   /* [S][18] frame number + payload */
+    const uint8_t* d_m17_str_status;     /* [S] 0 not a stream frame, 1 LICH failed, 2 decoded */
+    const uint8_t* d_m17_lich_lsf30;     /* [S][30] the LSF a chunk counter of 5 completed */
+    const uint8_t* d_m17_lich_status;    /* [S] 0 none, 1 CRC bad, 2 CRC good */
 } ddn_fsk4_chain_results;
 typedef struct ddn_fsk4_chain ddn_fsk4_chain;
 int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);

@@ -166,3 +166,80 @@ def test_stream_frames_and_lich_reassembly_on_the_device(built):
     good = np.flatnonzero(o["ll_st"][0] == 2)
     assert len(good) >= 5
     assert {m17.callsign(int.from_bytes(bytes(o["ll"][0, k, 6:12].tolist()), "big"))[1] for k in good} == {"N0CALL"}
+
+
+def test_m17_capture_through_the_chain_object_src_n0call(built):
+    """ddn_fsk4_chain with protocol M17: cu8 I/Q of the reference's capture in three calls + the flush -> front end (12.5 kHz filter) ->
+    loop -> the frames behind every sync, decoded in the call that holds their last symbol (frames that cross a call boundary wait in
+    the carried tail; the LICH assembly buffer and the syncs' thresholds are carried with them) = the Python decode of the CPU
+    pipeline's whole-stream output, frame for frame; SRC N0CALL"""
+    import m17
+    from conftest import golden
+    iq = np.ascontiguousarray(golden("iq_m17.npz")["iq"], np.uint8)
+    n = 40000
+    calls = len(iq) // n
+    assert calls >= 3
+    B = 2
+    x = np.stack([iq[:calls * n], np.roll(iq[:calls * n], 2 * 77)])     # channel 1: the capture 77 samples later
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_M17, rf_mod=0, handlers=0, vocoder=0)
+    l = ddn.lib()
+    got = [[] for _ in range(B)]
+    base = np.zeros(B, np.int64)
+
+    def take():
+        r = ch.results()
+        S, T = r.max_syncs, r.carry_symbols
+        f = ch.fetch
+        ns, pos, pat = f(r.d_n_sync, np.int32, (B,)), f(r.d_sync_pos, np.int32, (B, S)), f(r.d_sync_pat, np.uint8, (B, S))
+        lsf, lst = f(r.d_m17_lsf30, np.uint8, (B, S, 30)), f(r.d_m17_lsf_status, np.uint8, (B, S))
+        l6, cnt = f(r.d_m17_lich6, np.uint8, (B, S, 6)), f(r.d_m17_lich_cnt, np.uint8, (B, S))
+        fp, st = f(r.d_m17_fn_payload18, np.uint8, (B, S, 18)), f(r.d_m17_str_status, np.uint8, (B, S))
+        ll, lls = f(r.d_m17_lich_lsf30, np.uint8, (B, S, 30)), f(r.d_m17_lich_status, np.uint8, (B, S))
+        new = f(r.d_new, np.int32, (B,))
+        for c in range(B):
+            for k in range(int(ns[c])):
+                got[c].append(dict(pos=int(base[c]) + int(pos[c, k]) - int(T), pat=int(pat[c, k]), lsf=lsf[c, k].copy(), lst=int(lst[c, k]),
+                                   l6=l6[c, k].copy(), cnt=int(cnt[c, k]), fp=fp[c, k].copy(), st=int(st[c, k]), ll=ll[c, k].copy(),
+                                   lls=int(lls[c, k])))
+            base[c] += int(new[c])
+
+    for k in range(calls):
+        part = np.ascontiguousarray(x[:, k * n:(k + 1) * n])
+        p = C.c_void_p()
+        assert l.ddn_device_alloc(part.nbytes, C.byref(p)) == 0 and l.ddn_device_upload(p, part.ctypes.data, part.nbytes) == 0
+        ch.run(p)
+        take()
+        l.ddn_device_free(p)
+    ch.flush()   # (no new records: the row is the last call's carried tail re-based, positions count on from the same base)
+    take()
+    ch.close()
+    n_named = 0
+    for c in range(B):
+        fe = orc.OracleFrontEnd(profile=2)
+        disc = np.concatenate([fe.run_cu8(np.ascontiguousarray(x[c, k * n:(k + 1) * n]), 8192) for k in range(calls)])
+        want = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_M17)).run(disc, max_sync=4096)
+        fr = [f for f in m17.decode_stream(want) if f["kind"] != "cut"]
+        # every sync of the stream is decoded exactly once, in order (the flush also hands out a frame sync whose frame the stream's end
+        # cut short - all statuses 0 -, which the Python decode files as "cut")
+        total = len(want["sym"])
+        mine = [g for g in got[c] if g["pat"] < 4 or g["pos"] + 185 <= total]
+        assert all(g["lst"] == 0 and g["st"] == 0 for g in got[c] if not (g["pat"] < 4 or g["pos"] + 185 <= total))
+        assert [g["pos"] for g in mine] == [f["pos"] for f in fr], (c, len(mine), len(fr))
+        for g, f in zip(mine, fr):
+            assert g["pat"] == f["pat"]
+            if f["kind"] == "lsf":
+                assert g["lst"] == (2 if f["crc_ok"] else 1) and np.array_equal(g["lsf"], f["lsf30"])
+            elif f["kind"] == "str":
+                assert g["st"] == (2 if f["lich_err"] == 0 else 1) and np.array_equal(g["l6"], f["lich6"]) and g["cnt"] == f["cnt"]
+                if f["lich_err"] == 0:
+                    assert ((int(g["fp"][0]) << 8) | int(g["fp"][1])) == f["fn"] and np.array_equal(g["fp"][2:], f["payload"])
+                if "lich_lsf30" in f:
+                    assert g["lls"] == (2 if f["lich_crc_ok"] else 1) and np.array_equal(g["ll"], f["lich_lsf30"])
+                    if f["lich_crc_ok"]:
+                        assert m17.callsign(int.from_bytes(bytes(g["ll"][6:12].tolist()), "big"))[1] == "N0CALL"
+                        n_named += 1
+                else:
+                    assert g["lls"] == 0
+            else:
+                assert g["lst"] == 0 and g["st"] == 0 and g["lls"] == 0
+    assert n_named >= 8
