@@ -377,6 +377,11 @@ size_t orc_fsk4rx_sizeof(void);
 size_t orc_fsk4_profile_sizeof(void);
 void orc_fsk4rx_get_thresholds(const orc_fsk4rx* r, float out7[7]);
 
+/* ---- YSF frame information channel (oracle/ddn_oracle_ysf.c) ---------------------------------------------------------- */
+uint16_t orc_ysf_crc16(const uint8_t* bits, int len);
+uint32_t orc_ysf_soft_viterbi(const uint8_t* dibits, int n, int decoded_bytes, int offset_bits, int output_bits, uint8_t* out_bits);
+int orc_ysf_fich(const uint8_t in100[100], uint8_t fich32[32], uint32_t* v_error);
+
 /* ---- M17 frames behind the loop (oracle/ddn_oracle_m17.c) ---------------------------------------------------------- */
 int orc_m17_rand_bit(int i);
 int orc_m17_interleave_index(int i);

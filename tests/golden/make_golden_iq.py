@@ -26,6 +26,8 @@ for name, nac_hex, note in (("p25p1_c4fm_cc", "140", "control channel: TSDU fram
                             ("nxdn96", "", "NXDN96 (4800 baud); DECODE_IQ_NXDN96 (-fn) expects 'RAN 00' (tests/CMakeLists.txt:8949)"),
                             ("m17", "", "M17 stream transmission (preamble, LSF, stream frames, EOT); DECODE_IQ_M17 (-fz) expects "
                                         "'SRC: N0CALL' (tests/CMakeLists.txt:8964)"),
+                            ("ysf", "", "Yaesu System Fusion, V/D mode 2 communication channel frames; DECODE_IQ_YSF (-fy) expects "
+                                        "'V/D2 RID Mode Repeater CC' (tests/CMakeLists.txt:8953-8957)"),
                             ("p25p2_cc", "", "P25 Phase 2 TDMA control channel; DECODE_IQ_P25P2_CC (-f2) expects 'P25p2 SACCH' "
                                              "(tests/CMakeLists.txt:8923)")):
     iq = np.fromfile(os.path.join(SRC, name + ".iq"), dtype=np.uint8).reshape(-1, 2)

@@ -21,7 +21,9 @@ DMR_DM2_DATA, DMR_DM2_VOICE = "311311111333113333133311", "133133333111331111311
 NXDN_POS = ["3131331131", "3331331131", "3131331111", "3331331111", "3131311131"]
 NXDN_NEG = ["1313113313", "1113113313", "1313113333", "1113113333", "1313133313"]
 
-PROTO_P25P1, PROTO_DMR, PROTO_NXDN48, PROTO_NXDN96, PROTO_M17 = 0, 1, 2, 3, 4
+PROTO_P25P1, PROTO_DMR, PROTO_NXDN48, PROTO_NXDN96, PROTO_M17, PROTO_YSF = 0, 1, 2, 3, 4, 5
+YSF_SYNC = "31111311313113131131"      # FUSION_SYNC, include/dsd-neo/core/sync_patterns.h:30-31; types = synctype_ids.h:109-110, + 1
+T_YSF_POS, T_YSF_NEG = 31, 32
 # sync type ids carried in lastsync (any non-zero numbering works; these mirror synctype_ids.h + 1 so 0 stays "none")
 T_P25_POS, T_P25_NEG = 1, 2
 T_DMR_BS_DATA, T_DMR_BS_VOICE, T_DMR_MS_VOICE, T_DMR_MS_DATA = 11, 13, 33, 34
@@ -97,6 +99,17 @@ def profile(proto, rf_mod=0, use_filter=1, lock=None, out_rate=48000, inverted=0
         pats = [("11111111", t, k & 1, 1 if k < 2 else 0) for k, t in enumerate(M17_TYPES)]
         taps = _taps("dmr")         # (unused)
         lock = lock or [184, 8, 0, 0]
+    elif proto == PROTO_YSF:
+        # -fy: C4FM at 4800 symbols/s on the 4800_4 hunt profile, the 20-symbol FUSION_SYNC compared exactly in both polarities
+        # (frame_sync_try_ysf(), src/dsp/dsd_frame_sync.c:770-797), 20-symbol warm start, the DMR matched filter once a YSF sync is the last
+        # type (symbol_apply_matched_filter(), src/dsp/dsd_symbol.c:306-309); processYSF() reads the 100 FICH dibits and - for every frame
+        # type but FI = 3 with DT != 1 - 360 more (src/protocol/ysf/ysf.c:668-686,725-740,836-851,906-918): a fixed 460 here
+        p.proto = PROTO_P25P1       # (no handler family: fixed counts)
+        p.sym_rate, p.win_len, p.t_max, p.warm_len = 4800, 20, 24, 20
+        inv = "".join("1" if c == "3" else "3" for c in YSF_SYNC)
+        pats = [(YSF_SYNC, T_YSF_POS, 0, 0), (inv, T_YSF_NEG, 1, 0)]
+        taps = _taps("dmr")
+        lock = lock or [460, 0, 0, 0]
     elif proto == PROTO_NXDN96:
         # 4800 symbols/s on the 4800_4 hunt profile (level ring 24, src/dsp/dsd_frame_sync.c:1729-1744, matcher :1525-1556), the same
         # frame sync words, LICH gate and 182-symbol frame as NXDN48; the matched filter is the DMR one at every rate but 8 samples

@@ -1,0 +1,45 @@
+"""Yaesu System Fusion helpers of the tests: the frame information channel through the CPU restatement (oracle/ddn_oracle_ysf.c)."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+
+
+def fich(dibits100):
+    """-> (err, 32 FICH bits, Viterbi path cost)"""
+    o = orc.oracle()
+    o.orc_ysf_fich.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_ysf_fich.restype = C.c_int
+    d = np.ascontiguousarray(dibits100, np.uint8)
+    out = np.zeros(32, np.uint8)
+    ve = C.c_uint32()
+    err = o.orc_ysf_fich(d.ctypes.data, out.ctypes.data, C.byref(ve))
+    return int(err), out, int(ve.value)
+
+
+def fields(bits32):
+    """ysf_parse_fich(), src/protocol/ysf/ysf.c:534-546"""
+    v = lambda a, n: int("".join(str(int(b)) for b in bits32[a:a + n]), 2)
+    return dict(fi=v(0, 2), cm=v(4, 2), bn=v(6, 2), bt=v(8, 2), fn=v(10, 3), ft=v(13, 3), mr=v(18, 3), vp=int(bits32[21]), dt=v(22, 2),
+                st=int(bits32[24]), sc=v(25, 7))
+
+
+def summary(f):
+    """ysf_print_fich_type / _call_mode / _path_and_frame (:562-619) for a frame without errors"""
+    return "%s %s %s %s" % (["V/D1", "DATA", "V/D2", "VWFR"][f["dt"]], ["Group/CQ", "RID Mode", "Res: 2", "Private"][f["cm"]],
+                            ["-Simplex", "Repeater"][f["vp"]], ["HC", "CC", "TC", "XX"][f["fi"]])
+
+
+def decode_frames(out):
+    """out = the loop's output (oracle or device arrays: rec4, sync_pos) -> per sync with its 100 FICH dibits inside: dict(pos, err,
+    bits, cost, fields)"""
+    n = len(out["rec4"])
+    fr = []
+    for pos in out["sync_pos"]:
+        pos = int(pos)
+        if pos + 101 > n:
+            continue
+        err, bits, cost = fich(out["rec4"][pos + 1:pos + 101, 0])
+        fr.append(dict(pos=pos, err=err, bits=bits, cost=cost, fields=fields(bits)))
+    return fr
