@@ -384,6 +384,7 @@ class Fsk4RxConfig(C.Structure):  # == ddn_fsk4_rx_config (include/ddn_fsk4.h)
 FSK4_DMR, FSK4_NXDN48, FSK4_PRE = 1, 2, 90
 FSK4_NXDN96 = 3
 FSK4_M17 = 4
+FSK4_YSF = 5
 PROTOTYPES.update({
     "ddn_fsk4_rx_create": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_fsk4_rx_destroy": (None, [C.c_void_p]),
@@ -404,6 +405,7 @@ PROTOTYPES.update({
     "ddn_m17_lsf_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 5 + [C.c_int, C.c_size_t] + [C.c_void_p] * 4),
     "ddn_m17_str_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4 + [C.c_int, C.c_size_t] + [C.c_void_p] * 5),
     "ddn_m17_lich_assemble_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 9),
+    "ddn_ysf_fich_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int, C.c_size_t] + [C.c_void_p] * 4),
     "ddn_fsk4_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_mode_config": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "full_demod": (None, [C.c_void_p]),
@@ -511,7 +513,8 @@ class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
                                   "d_dmr_r34_confirmed", "d_dmr_r34_confirmed_crc", "d_dmr_r34_pool", "d_dmr_r34_pool_n")] + [
         ("dmr_emb_lcs", C.c_int)] + [(k, C.c_void_p) for k in ("d_dmr_n_emb", "d_dmr_emb_pos", "d_dmr_emb_lc77", "d_dmr_emb_errs", "d_dmr_emb_ok")] + [
         (k, C.c_void_p) for k in ("d_sync_thr5", "d_m17_lsf30", "d_m17_lsf_status", "d_m17_lsf_cost", "d_m17_lich6", "d_m17_lich_cnt",
-                                  "d_m17_fn_payload18", "d_m17_str_status", "d_m17_lich_lsf30", "d_m17_lich_status")]
+                                  "d_m17_fn_payload18", "d_m17_str_status", "d_m17_lich_lsf30", "d_m17_lich_status", "d_ysf_fich4",
+                                  "d_ysf_fich_status", "d_ysf_fich_cost")]
 
 
 class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config

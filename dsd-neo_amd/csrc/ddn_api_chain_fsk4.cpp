@@ -75,6 +75,10 @@ struct ddn_fsk4_chain {
     float *s_thr, *c_thr[2], *d_thr;
     uint8_t *m_lsf, *m_lsf_st, *m_l6, *m_cnt, *m_fp, *m_st, *m_asm, *m_ll, *m_ll_st;
     uint32_t* m_cost;
+    // YSF (protocol DDN_FSK4_YSF): the frame information channel of every decoded sync
+    bool ysf;
+    uint8_t *y_fich4, *y_st;
+    uint32_t* y_ve;
     long step;
     int last_set;
 };
@@ -89,6 +93,9 @@ extern "C" int ddn_m17_lich_assemble_batch(const uint8_t* d_sync_pat, const int3
                                            const uint8_t* d_str_status, uint8_t* d_assembly32, uint8_t* d_lich_lsf30, uint8_t* d_lich_status,
                                            void* hip_stream);
 extern "C" int ddn_fsk4_rx_set_sync_thresholds(ddn_fsk4_rx* b, float* d_thr5);
+extern "C" int ddn_ysf_fich_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
+                                         const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_fich4, uint8_t* d_status,
+                                         uint32_t* d_v_error, void* hip_stream);
 
 template <typename T>
 static bool
@@ -108,7 +115,7 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
     ddn_batch_destroy(c->fe);
     ddn_fsk4_rx_destroy(c->rx);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->s_thr, c->c_thr[0], c->c_thr[1], c->d_thr, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_fp, c->m_st, c->m_asm, c->m_ll,
+    void* all[] = {c->y_fich4, c->y_st, c->y_ve, c->s_thr, c->c_thr[0], c->c_thr[1], c->d_thr, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_fp, c->m_st, c->m_asm, c->m_ll,
                    c->m_ll_st, c->m_cost, c->d_disc, c->d_disc2, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_pay, c->d_new[0], c->d_new[1], c->d_cnt_full,
                    c->d_cnt_scan, c->d_dropped, c->s_pos, c->s_n, c->c_pos[0], c->c_pos[1], c->c_n[0], c->c_n[1], c->d_spos, c->d_ns, c->s_pat, c->s_pre,
                    c->s_prel, c->c_pat[0], c->c_pat[1], c->c_pre[0], c->c_pre[1], c->c_prel[0], c->c_prel[1], c->d_spat, c->d_pre,
@@ -128,8 +135,9 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
 extern "C" int
 ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
     if (!cfg || !out || cfg->n_channels <= 0 || cfg->samples_per_call <= 0 || cfg->block_len <= 0
-        || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48 && cfg->protocol != DDN_FSK4_NXDN96 && cfg->protocol != DDN_FSK4_M17)
-        || (cfg->protocol == DDN_FSK4_M17 && (cfg->handlers || cfg->inverted))) {
+        || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48 && cfg->protocol != DDN_FSK4_NXDN96 && cfg->protocol != DDN_FSK4_M17
+            && cfg->protocol != DDN_FSK4_YSF)
+        || ((cfg->protocol == DDN_FSK4_M17 || cfg->protocol == DDN_FSK4_YSF) && (cfg->handlers || cfg->inverted))) {
         ddn_set_error("ddn_fsk4_chain_create: bad configuration");
         return DDN_EINVAL;
     }
@@ -144,12 +152,13 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
     c->n = cfg->samples_per_call;
     c->dmr = cfg->protocol == DDN_FSK4_DMR;
     c->m17 = cfg->protocol == DDN_FSK4_M17; // (an M17 frame ends 184 symbols after its sync: inside the same tail)
+    c->ysf = cfg->protocol == DDN_FSK4_YSF; // (the FICH ends 100 symbols after its sync)
     c->T = 256;  // a DMR burst ends 54 symbols after its sync, an NXDN frame 182: the tail kept back for the next call
     c->myc = 16; // syncs that can lie inside that tail (a new sync needs 24 / 10 fresh symbols)
     int rc = DDN_OK;
     do {
         // (NXDN96: a 12.5 kHz channel at 4800 symbols/s)
-        const bool wide = c->dmr || cfg->protocol == DDN_FSK4_NXDN96 || c->m17;
+        const bool wide = c->dmr || cfg->protocol == DDN_FSK4_NXDN96 || c->m17 || c->ysf;
         ddn_front_end_config fc = {c->B, 48000, wide ? 4800 : 2400, 4, wide ? DDN_LPF_12K5 : DDN_LPF_6K25, cfg->input_format,
                                    cfg->block_len, 0.0f};
         if ((rc = ddn_batch_create(&fc, &c->fe)) != DDN_OK) {
@@ -190,7 +199,9 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
                  && dalloc(&c->c_pos[k], B * myc) && dalloc(&c->c_n[k], B) && dalloc(&c->c_pat[k], B * myc)
                  && dalloc(&c->c_pre[k], B * myc * 90) && dalloc(&c->c_prel[k], B * myc * 90);
         }
-        if (ok && c->m17) {
+        if (ok && c->ysf) {
+            ok = dalloc(&c->y_fich4, S * 4) && dalloc(&c->y_st, S) && dalloc(&c->y_ve, S);
+        } else if (ok && c->m17) {
             ok = dalloc(&c->s_thr, B * my * 5) && dalloc(&c->c_thr[0], B * myc * 5) && dalloc(&c->c_thr[1], B * myc * 5) && dalloc(&c->d_thr, S * 5)
                  && dalloc(&c->m_lsf, S * 30) && dalloc(&c->m_lsf_st, S) && dalloc(&c->m_l6, S * 6) && dalloc(&c->m_cnt, S) && dalloc(&c->m_fp, S * 18)
                  && dalloc(&c->m_st, S) && dalloc(&c->m_asm, B * 32) && dalloc(&c->m_ll, S * 30) && dalloc(&c->m_ll_st, S) && dalloc(&c->m_cost, S);
@@ -281,6 +292,10 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
                                          c->d_pre, c->d_prel, c->d_ns, c->myd, c->c_pos[cur], c->c_pat[cur], c->c_pre[cur], c->c_prel[cur],
                                          c->c_n[cur], c->d_dropped, c->B, c->m17 ? c->c_thr[prev] : nullptr, c->m17 ? c->s_thr : nullptr,
                                          c->d_thr, c->m17 ? c->c_thr[cur] : nullptr, st));
+    if (c->ysf) { // the frame information channel behind every sync of the decode list (row a17's second consumer)
+        DDN_TRY(ddn_ysf_fich_decode_batch(rec, c->stride, c->d_cnt_full, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->y_fich4, c->y_st, c->y_ve, st));
+        return DDN_OK;
+    }
     if (c->m17) {
         // the frames behind the syncs of this call's decode list (each complete inside the row): link setup frames through the K = 5
         // decoder of row a17, stream frames (LICH + payload), the LSF reassembled from the LICH chunks across calls
@@ -501,6 +516,11 @@ ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
         r->d_nxdn_voice_skip = c->d_skip;
         r->d_nxdn_ambe_bits = c->d_ambe_d;
         r->d_nxdn_pcm = c->d_pcm;
+    }
+    if (c->ysf) {
+        r->d_ysf_fich4 = c->y_fich4;
+        r->d_ysf_fich_status = c->y_st;
+        r->d_ysf_fich_cost = c->y_ve;
     }
     if (c->m17) {
         r->d_sync_thr5 = c->d_thr;

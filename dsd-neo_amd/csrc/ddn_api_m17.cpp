@@ -133,3 +133,52 @@ ddn_m17_lich_assemble_batch(const uint8_t* d_sync_pat, const int32_t* d_n_sync, 
                              d_assembly32, d_lich_lsf30, d_lich_status, (hipStream_t)hip_stream));
     return DDN_OK;
 }
+
+extern "C" hipError_t ddn_dev_ysf_fich_cost(const uint8_t* rec, size_t stride, const int32_t* counts, const int32_t* sync_pos,
+                                            const int32_t* n_sync, int n_channels, int max_syncs, int lmax, uint16_t* cost200,
+                                            int32_t* slot_sync, hipStream_t st);
+extern "C" hipError_t ddn_dev_ysf_fich_finish(const uint8_t* dec, int dec_stride, const uint32_t* cost, const int32_t* slot_sync,
+                                              int n_channels, int lmax, int max_syncs, uint8_t* fich4, uint8_t* status, uint32_t* v_error,
+                                              hipStream_t st);
+
+extern "C" int
+ddn_ysf_fich_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
+                          const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_fich4, uint8_t* d_status, uint32_t* d_v_error,
+                          void* hip_stream) {
+    if (!d_records10 || !d_counts || !d_sync_pos || !d_n_sync || !d_fich4 || !d_status || n_channels <= 0 || max_syncs == 0
+        || max_syncs > (1u << 24) || stride_symbols == 0) {
+        ddn_set_error("ddn_ysf_fich_decode_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    // syncs are at least a window (20 symbols) + the FICH apart
+    const int lmax = (int)(stride_symbols / 120 + 1);
+    const size_t S = (size_t)n_channels * (size_t)lmax;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_cost = up(S * 200 * sizeof(uint16_t)), b_dec = up(S * 16), b_pc = up(S * sizeof(uint32_t)), b_slot = up(S * sizeof(int32_t));
+    uint8_t* scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&scratch, b_cost + b_dec + b_pc + b_slot, st));
+    uint16_t* cost = (uint16_t*)scratch;
+    uint8_t* dec = scratch + b_cost;
+    uint32_t* pc = (uint32_t*)(dec + b_dec);
+    int32_t* slot = (int32_t*)((uint8_t*)pc + b_pc);
+    int rc = DDN_OK;
+    hipError_t e = hipMemsetAsync(d_status, 0, (size_t)n_channels * max_syncs, st);
+    if (e == hipSuccess) {
+        e = ddn_dev_ysf_fich_cost(d_records10, stride_symbols, d_counts, d_sync_pos, d_n_sync, n_channels, (int)max_syncs, lmax, cost, slot, st);
+    }
+    if (e == hipSuccess) {
+        static const uint8_t none[4] = {1, 1, 1, 1}; // DSD_YSF_PUNCTURE_NONE
+        rc = ddn_fec_viterbi_k5_batch(cost, S, 200, none, 4, dec, 16, pc, st);
+    }
+    if (e == hipSuccess && rc == DDN_OK) {
+        e = ddn_dev_ysf_fich_finish(dec, 16, pc, slot, n_channels, lmax, (int)max_syncs, d_fich4, d_status, d_v_error, st);
+    }
+    const hipError_t ef = hipFreeAsync(scratch, st);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    HIP_TRY(e);
+    HIP_TRY(ef);
+    return DDN_OK;
+}

@@ -138,9 +138,10 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
     }
     *out = nullptr;
     if (cfg->n_channels <= 0 || cfg->out_rate_hz <= 0
-        || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48 && cfg->protocol != DDN_FSK4_NXDN96 && cfg->protocol != DDN_FSK4_M17)
+        || (cfg->protocol != DDN_FSK4_DMR && cfg->protocol != DDN_FSK4_NXDN48 && cfg->protocol != DDN_FSK4_NXDN96 && cfg->protocol != DDN_FSK4_M17
+            && cfg->protocol != DDN_FSK4_YSF)
         || (cfg->rf_mod != 0 && cfg->rf_mod != 2) || (cfg->inverted && cfg->protocol != DDN_FSK4_DMR)) {
-        ddn_set_error("ddn_fsk4_rx_create: bad configuration (protocol DMR | NXDN48 | NXDN96 | M17, rf_mod 0 | 2, inverted only for DMR)");
+        ddn_set_error("ddn_fsk4_rx_create: bad configuration (protocol DMR | NXDN48 | NXDN96 | M17 | YSF, rf_mod 0 | 2, inverted only for DMR)");
         return DDN_EINVAL;
     }
     {
@@ -190,6 +191,28 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
         tap_bits = ddn_dmr_filter_bits;
         lock_default[0] = 184;
         lock_default[1] = 8;
+    } else if (cfg->protocol == DDN_FSK4_YSF) {
+        // -fy: the 20-symbol FUSION_SYNC exact in both polarities (include/dsd-neo/core/sync_patterns.h:30-31; types = synctype_ids.h:
+        // 109-110 + 1), the DMR matched filter once a YSF sync is the last type, 100 FICH + 360 payload dibits behind a sync
+        static const char kYsf[] = "31111311313113131131";
+        char inv[21];
+        for (int k = 0; k < 20; k++) {
+            inv[k] = kYsf[k] == '3' ? '1' : '3';
+        }
+        inv[20] = 0;
+        d.sym_rate = 4800;
+        d.win_len = 20;
+        d.t_max = 24;
+        d.warm_len = 20;
+        d.n_pat = 2;
+        d.pat_bits[0] = sign_bits(kYsf);
+        d.pat_type[0] = 31;
+        d.pat_bits[1] = sign_bits(inv);
+        d.pat_type[1] = 32;
+        d.pat_neg[1] = 1;
+        d.nt = DDN_DMR_FILTER_TAPS;
+        tap_bits = ddn_dmr_filter_bits;
+        lock_default[0] = 460;
     } else if (cfg->protocol == DDN_FSK4_DMR) {
         d.sym_rate = 4800;
         d.win_len = d.t_max = d.warm_len = 24;

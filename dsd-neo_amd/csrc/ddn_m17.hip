@@ -368,7 +368,137 @@ k_m17_lich(const uint8_t* __restrict__ sync_pat, const int32_t* __restrict__ n_s
         }
     }
 }
+// ---- Yaesu System Fusion: the frame information channel (ysf_conv_fich(), src/protocol/ysf/ysf.c:357-424) - the K = 5 decoder's second
+// consumer.  k_ysf_fich_cost: one wavefront per (channel, j-th sync with its 100 FICH dibits inside the records): dibit de-interleave
+// (20 x 5) -> hard costs 0 / 65535 per bit (ysf_dibit_to_soft_costs, ysf_frame.c:74-80) -> 200 costs for viterbi_decode_punctured()
+// with a pattern of all ones.  k_ysf_fich_finish: bits 8 .. 103 of the decoded bytes -> four Golay(24,12) words -> CRC16 (ysf_crc16,
+// ysf.c:229-242) -> the 32 FICH bits packed into four bytes, status 1 good / 2 a Golay word failed / 3 CRC failed.
+__global__ __launch_bounds__(64) void
+k_ysf_fich_cost(const uint8_t* __restrict__ rec, size_t stride, const int32_t* __restrict__ counts, const int32_t* __restrict__ sync_pos,
+                const int32_t* __restrict__ n_sync, int max_syncs, int lmax, uint16_t* __restrict__ cost200, int32_t* __restrict__ slot_sync) {
+    const int ch = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    const size_t slot = (size_t)ch * lmax + j;
+    int ns = n_sync[ch];
+    ns = ns < max_syncs ? ns : max_syncs;
+    const int cnt = counts[ch];
+    // the j-th sync whose FICH is complete
+    int found = -1, seen = 0;
+    for (int k0 = 0; k0 < ns && found < 0; k0 += 64) {
+        const int k = k0 + lane;
+        const bool is = k < ns && sync_pos[(size_t)ch * max_syncs + k] + 101 <= cnt;
+        const unsigned long long b = __ballot(is);
+        const int nb = __popcll(b);
+        if (seen + nb > j) {
+            unsigned long long m = b;
+            for (int q = 0; q < j - seen; q++) {
+                m &= m - 1;
+            }
+            found = k0 + __ffsll((long long)m) - 1;
+        }
+        seen += nb;
+    }
+    if (lane == 0) {
+        slot_sync[slot] = found;
+    }
+    uint16_t* out = cost200 + slot * 200;
+    if (found < 0) {
+        for (int i = lane; i < 200; i += 64) {
+            out[i] = 0;
+        }
+        return;
+    }
+    const int pos = sync_pos[(size_t)ch * max_syncs + found];
+    const uint8_t* r0 = rec + ((size_t)ch * stride + (size_t)pos + 1) * 10;
+    for (int q = lane; q < 100; q += 64) { // buf[jj + 5 i] = input[i + 20 jj]
+        const int i = q / 5, jj = q - 5 * i;
+        const int d = r0[(size_t)(i + 20 * jj) * 10] & 3;
+        out[2 * q] = (d & 2) ? 0xFFFFu : 0u;
+        out[2 * q + 1] = (d & 1) ? 0xFFFFu : 0u;
+    }
+}
+
+__global__ void
+k_ysf_fich_finish(const uint8_t* __restrict__ dec, int dec_stride, const uint32_t* __restrict__ cost, const int32_t* __restrict__ slot_sync,
+                  int n_channels, int lmax, int max_syncs, const DdnFec3Tables* __restrict__ T, uint8_t* __restrict__ fich4,
+                  uint8_t* __restrict__ status, uint32_t* __restrict__ v_error) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_channels * lmax) {
+        return;
+    }
+    const int k = slot_sync[slot];
+    if (k < 0) {
+        return;
+    }
+    const size_t so = (size_t)(slot / lmax) * max_syncs + k;
+    const uint8_t* by = dec + (size_t)slot * dec_stride;
+    bool bad = false;
+    uint64_t fich = 0; // 48 bits, first bit = bit 47
+    for (int w4 = 0; w4 < 4; w4++) {
+        uint32_t w = 0;
+        for (int q = 0; q < 24; q++) { // trellis bit 24 w4 + q = decoded bit 8 + 24 w4 + q (MSB first in the bytes)
+            const int b = 8 + 24 * w4 + q;
+            w |= (uint32_t)((by[b >> 3] >> (7 - (b & 7))) & 1) << q;
+        }
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            s |= (__popc(w & ddn_golay_24_12_H[i]) & 1) << (11 - i);
+        }
+        if (s > 0) { // Golay_24_12_decode, src/fec/fec.c:656-690
+            int kk = 0;
+            for (; kk < 3; kk++) {
+                const uint8_t p = T->g2412[s][kk];
+                if (p == 0xFF) {
+                    break;
+                }
+                w ^= 1u << p;
+            }
+            bad = bad || kk == 0;
+        }
+        for (int q = 0; q < 12; q++) {
+            fich = (fich << 1) | ((w >> q) & 1u);
+        }
+    }
+    uint32_t crc = 0; // ysf_crc16 over the 48 bits: a good frame leaves 0
+    for (int i = 0; i < 48; i++) {
+        const uint32_t bit = (uint32_t)((fich >> (47 - i)) & 1u);
+        crc = ((crc << 1) | bit) & 0x1ffffu;
+        if (crc & 0x10000u) {
+            crc = (crc & 0xffffu) ^ 0x1021u;
+        }
+    }
+    crc ^= 0xffffu;
+    for (int i = 0; i < 4; i++) {
+        fich4[so * 4 + i] = (uint8_t)((fich >> (40 - 8 * i)) & 0xFF);
+    }
+    status[so] = (crc & 0xffffu) != 0 ? 3 : (bad ? 2 : 1); // (the reference's err: -2 wins over -1)
+    if (v_error) {
+        v_error[so] = cost[slot];
+    }
+}
 } // namespace
+
+extern "C" hipError_t
+ddn_dev_ysf_fich_cost(const uint8_t* rec, size_t stride, const int32_t* counts, const int32_t* sync_pos, const int32_t* n_sync,
+                      int n_channels, int max_syncs, int lmax, uint16_t* cost200, int32_t* slot_sync, hipStream_t st) {
+    hipLaunchKernelGGL(k_ysf_fich_cost, dim3((unsigned)n_channels, (unsigned)lmax), dim3(64), 0, st, rec, stride, counts, sync_pos, n_sync,
+                       max_syncs, lmax, cost200, slot_sync);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_ysf_fich_finish(const uint8_t* dec, int dec_stride, const uint32_t* cost, const int32_t* slot_sync, int n_channels, int lmax,
+                        int max_syncs, uint8_t* fich4, uint8_t* status, uint32_t* v_error, hipStream_t st) {
+    const DdnFec3Tables* T = nullptr;
+    const hipError_t e = ddn_dev_fec3_tables(&T, st);
+    if (e != hipSuccess) {
+        return e;
+    }
+    const int n = n_channels * lmax;
+    hipLaunchKernelGGL(k_ysf_fich_finish, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, dec, dec_stride, cost, slot_sync, n_channels,
+                       lmax, max_syncs, T, fich4, status, v_error);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t
 ddn_dev_m17_str_bits(const uint8_t* rec, size_t stride, const int32_t* counts, const int32_t* sync_pos, const uint8_t* sync_pat,

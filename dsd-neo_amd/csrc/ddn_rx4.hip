@@ -109,11 +109,14 @@ struct Fsk4Cfg {
     // src/runtime/decode_mode.c:486-510), eight-symbol words matched with one error allowed by frame_sync_try_m17()
     // (src/dsp/dsd_frame_sync.c:865-1100: m17_hit() below; the pattern table only names the twelve outcomes), 8-symbol warm start,
     // fixed counts behind a sync (dispatch_m17.c:25-68: preamble 8, everything else 184)
+    // PROTO 5 YSF (round 5): the 20-symbol FUSION_SYNC compared exactly in both polarities (frame_sync_try_ysf(),
+    // src/dsp/dsd_frame_sync.c:770-797), 20-symbol warm start, the DMR matched filter (src/dsp/dsd_symbol.c:306-309), a fixed count
+    // behind a sync (processYSF() reads 100 + 360 dibits for every frame type but FI = 3 with DT != 1, src/protocol/ysf/ysf.c)
     static constexpr int sym_rate = PROTO == 2 ? 2400 : 4800;
-    static constexpr int win_len = PROTO == 1 ? 24 : (PROTO == 4 ? 8 : 10), t_max = PROTO == 2 ? 12 : 24;
-    static constexpr int warm_len = PROTO == 1 ? 24 : (PROTO == 4 ? 8 : 10);
-    static constexpr int n_pat = PROTO == 1 ? 8 : (PROTO == 4 ? 12 : 10);
-    static constexpr int confirm = (PROTO == 1 || PROTO == 4) ? 0 : 1, dmr_window = PROTO == 1 ? 1 : 0, redigitize = PROTO == 1 ? 1 : 0;
+    static constexpr int win_len = PROTO == 1 ? 24 : (PROTO == 4 ? 8 : (PROTO == 5 ? 20 : 10)), t_max = PROTO == 2 ? 12 : 24;
+    static constexpr int warm_len = PROTO == 1 ? 24 : (PROTO == 4 ? 8 : (PROTO == 5 ? 20 : 10));
+    static constexpr int n_pat = PROTO == 1 ? 8 : (PROTO == 4 ? 12 : (PROTO == 5 ? 2 : 10));
+    static constexpr int confirm = (PROTO == 1 || PROTO == 4 || PROTO == 5) ? 0 : 1, dmr_window = PROTO == 1 ? 1 : 0, redigitize = PROTO == 1 ? 1 : 0;
     static constexpr bool m17 = PROTO == 4;
     static constexpr int slow_type = 0;
     static constexpr int nt = PROTO == 2 ? DDN_NXDN48_FILTER_TAPS : DDN_DMR_FILTER_TAPS;
@@ -1688,11 +1691,11 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    if (protocol != 1 && protocol != 2 && protocol != 3 && protocol != 4) {
+    if (protocol < 1 || protocol > 5) {
         return hipErrorInvalidValue;
     }
-    if (protocol == 4 && handlers) {
-        return hipErrorInvalidValue; // M17 frames are fixed counts: no handler family
+    if ((protocol == 4 || protocol == 5) && handlers) {
+        return hipErrorInvalidValue; // M17 / YSF frames are fixed counts: no handler family
     }
     const DdnFec3Tables* htab = nullptr;
     if (handlers) {
@@ -1721,6 +1724,9 @@ ddn_dev_fsk4_rx(const float* raw, const float* filt, const float* prev_tail, flo
         }                                                                                                                  \
         if (protocol == 4) { /* M17: 4800 symbols/s, fixed counts */                                                       \
             return launch<CPW_, 12, 4, false>(DDN_RX4_ARGS);                                                                \
+        }                                                                                                                  \
+        if (protocol == 5) { /* YSF: 4800 symbols/s, fixed counts */                                                       \
+            return launch<CPW_, 12, 5, false>(DDN_RX4_ARGS);                                                                \
         }                                                                                                                  \
         return handlers ? launch<CPW_, MAXW_, 2, true>(DDN_RX4_ARGS) : launch<CPW_, MAXW_, 2, false>(DDN_RX4_ARGS);         \
     } while (0)

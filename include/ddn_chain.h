@@ -357,6 +357,10 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const uint8_t* d_m17_str_status;     /* [S] 0 not a stream frame, 1 LICH failed, 2 decoded */
     const uint8_t* d_m17_lich_lsf30;     /* [S][30] the LSF a chunk counter of 5 completed */
     const uint8_t* d_m17_lich_status;    /* [S] 0 none, 1 CRC bad, 2 CRC good */
+    /* YSF (protocol DDN_FSK4_YSF; NULL otherwise): ddn_ysf_fich_decode_batch's outputs per sync slot (include/ddn_fsk4.h) */
+    const uint8_t* d_ysf_fich4;          /* [S][4] the 32 FICH bits */
+    const uint8_t* d_ysf_fich_status;    /* [S] 0 none, 1 good, 2 Golay failed, 3 CRC failed */
+    const uint32_t* d_ysf_fich_cost;     /* [S] the decoder's path cost */
 } ddn_fsk4_chain_results;
 typedef struct ddn_fsk4_chain ddn_fsk4_chain;
 int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);

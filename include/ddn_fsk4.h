@@ -18,7 +18,10 @@
 extern "C" {
 #endif
 
-enum { DDN_FSK4_DMR = 1, DDN_FSK4_NXDN48 = 2, DDN_FSK4_NXDN96 = 3, DDN_FSK4_M17 = 4 };
+enum { DDN_FSK4_DMR = 1, DDN_FSK4_NXDN48 = 2, DDN_FSK4_NXDN96 = 3, DDN_FSK4_M17 = 4, DDN_FSK4_YSF = 5 };
+/* YSF (-fy): the 20-symbol FUSION_SYNC compared exactly in both polarities (frame_sync_try_ysf(), src/dsp/dsd_frame_sync.c:770-797;
+ * pattern index 0 = +YSF, 1 = -YSF), 20-symbol warm start, the DMR matched filter, lock_symbols[0] = 460 = the 100 FICH + 360 payload
+ * dibits processYSF() reads (every frame type but FI = 3 with DT != 1, which reads the FICH alone); no handler family. */
 /* NXDN96: NXDN's rules at 4800 symbols/s (level ring 24, the DMR matched filter: src/dsp/dsd_frame_sync.c:1525-1556, dsd_symbol.c:323-335).
  * M17 (-fz): C4FM lock at 4800 symbols/s, no matched filter (use_matched_filter is ignored), frame_sync_try_m17()'s matcher
  * (src/dsp/dsd_frame_sync.c:865-1100: eight-symbol words with one error allowed, each accepted only after the sync type that may precede
@@ -115,6 +118,15 @@ int ddn_m17_lsf_decode_batch(const uint8_t* d_records10, size_t stride_symbols, 
 int ddn_m17_str_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
                              const uint8_t* d_sync_pat, const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_lich6,
                              uint8_t* d_lich_cnt, uint8_t* d_fn_payload18, uint8_t* d_status, void* hip_stream);
+/* ---- YSF frame information channel behind the loop (the K = 5 decoder's second consumer) --------------------------------------------
+ * == ysf_conv_fich() (src/protocol/ysf/ysf.c:357-424) for every accepted sync of a DDN_FSK4_YSF loop call whose 100 FICH dibits lie inside
+ * the records: dibit de-interleave (20 x 5) -> dsd_ysf_soft_viterbi_decode (hard costs through viterbi_decode_punctured, ysf_frame.c:82-126)
+ * -> four Golay(24,12) words -> CRC16.  d_fich4 [B][max_syncs][4] = the 32 information bits packed (FI 2, CS 2, CM 2, BN 2, BT 2, FN 3,
+ * FT 3, reserved 2, MR 3, VoIP path 1, DT 2, SQL type 1, SQL code 7: ysf_parse_fich() :534-546); d_status 0 = no complete FICH behind this
+ * sync in this call, 1 = good, 2 = a Golay word failed (err -1), 3 = CRC failed (err -2); d_v_error (optional) the decoder's path cost. */
+int ddn_ysf_fich_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
+                              const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_fich4, uint8_t* d_status,
+                              uint32_t* d_v_error, void* hip_stream);
 /* The LSF reassembled from the LICH chunks, in the order of the syncs of a call: a decoded LSF frame seeds the buffer (m17_decode_lsf_soft_
  * bits), an EOT marker clears it (dispatch_m17.c:39), chunk c fills bytes 5 c .. 5 c + 4, chunk 5 closes it: d_lich_lsf30 [B][max_syncs][30]
  * + d_lich_status (0 none here, 1 CRC bad, 2 CRC good: M17finalizeLICH), then the buffer is cleared.  d_assembly32 [B][32] is the carried

@@ -1,0 +1,133 @@
+"""Yaesu System Fusion on the device: DDN_FSK4_YSF as the fsk4 loop's fifth protocol and the frame information channel behind its
+syncs (ddn_ysf_fich_decode_batch: the K = 5 decoder's second consumer), against the CPU restatement on the reference's capture; then the
+capture from cu8 I/Q through the chain object - "V/D2 RID Mode Repeater CC" (DECODE_IQ_YSF, tests/CMakeLists.txt:8953-8957)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ddn
+import orc
+import rx4
+import ysf
+from test_rx4_gpu import check_channel, rec4_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cpw", [0, 4])
+def test_ysf_loop_bit_exact_with_call_splits(built, cpw):
+    disc = rx4.capture_disc("iq_ysf.npz", 2)[:120000]
+    n = len(disc)
+    B = 5
+    rng = np.random.default_rng(6)
+    x = np.zeros((B, n), np.float32)
+    for c in range(B):
+        d = 43 * c
+        x[c, :d] = rng.standard_normal(d) * 500
+        x[c, d:] = disc[:n - d]
+    x[3] = -x[3]            # -YSF: the inverted word, negative polarity
+    x[4, :20000] = 0
+    for use_filter in (1, 0):
+        gpu = ddn.Fsk4Rx(B, ddn.FSK4_YSF, use_matched_filter=use_filter)
+        if cpw:
+            assert ddn.lib().ddn_fsk4_rx_set_channels_per_wave(gpu.h, cpw) == 0
+        cpu = [rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_YSF, use_filter=use_filter)) for _ in range(B)]
+        cuts = [0, 4097, 4097 + 63, 30000, 30001, 90000, n]
+        n_sync = 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            got = gpu.run_host(x[:, a:b])
+            for c in range(B):
+                want = cpu[c].run(x[c, a:b], max_sync=got["sync_pos"].shape[1])
+                check_channel(got, c, want)
+                n_sync += len(want["sync_pos"])
+                assert np.array_equal(gpu.thresholds(c).view(np.uint32), cpu[c].thresholds().view(np.uint32)), (c, a)
+        assert n_sync > 60
+    assert int(np.sum(got["sync_pat"][3, :int(got["n_sync"][3])] == 1)) > 0      # the negated channel locks on -YSF
+
+
+def test_fich_on_the_device_equals_the_restatement(built):
+    import torch
+    l = ddn.lib()
+    disc = rx4.capture_disc("iq_ysf.npz", 2)
+    x = np.stack([disc, -disc, np.roll(disc, 3)])
+    B, n = x.shape
+    d = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    rx = ddn.Fsk4Rx(B, ddn.FSK4_YSF)
+    ms, my = l.ddn_fsk4_rx_max_symbols(rx.h, n), l.ddn_fsk4_rx_max_syncs(rx.h, n)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+    rec, fl, pay = z((B, ms, 10), torch.uint8), z((B, ms), torch.uint8), z((B, ms, 2), torch.uint8)
+    cnt, ns, spos = z((B,), torch.int32), z((B,), torch.int32), z((B, my), torch.int32)
+    spat, pre, prel = z((B, my), torch.uint8), z((B, my, 90), torch.uint8), z((B, my, 90), torch.uint8)
+    p = lambda t: t.data_ptr()
+    assert l.ddn_fsk4_rx_run(rx.h, p(d), n, p(rec), p(fl), p(pay), p(cnt), ms, p(spos), p(spat), p(pre), p(prel), p(ns), my, None) == 0
+    f4, st, ve = z((B, my, 4), torch.uint8), z((B, my), torch.uint8), z((B, my), torch.int32)
+    assert l.ddn_ysf_fich_decode_batch(p(rec), ms, p(cnt), p(spos), p(ns), B, my, p(f4), p(st), p(ve), None) == 0, l.ddn_last_error()
+    torch.cuda.synchronize()
+    f4, st, ve = f4.cpu().numpy(), st.cpu().numpy(), ve.cpu().numpy().view(np.uint32)
+    nsy, pos, cn, rc = ns.cpu().numpy(), spos.cpu().numpy(), cnt.cpu().numpy(), rec.cpu().numpy()
+    good = 0
+    for c in range(B):
+        r4, _ = rec4_of(rc[c, :cn[c]])
+        for k in range(int(nsy[c])):
+            q = int(pos[c, k])
+            if q + 101 > cn[c]:
+                assert st[c, k] == 0
+                continue
+            err, bits, cost = ysf.fich(r4[q + 1:q + 101, 0])
+            assert st[c, k] == {0: 1, -1: 2, -2: 3}[err], (c, k, err, st[c, k])
+            assert np.array_equal(np.unpackbits(f4[c, k]), bits) and int(ve[c, k]) == cost, (c, k)
+            good += err == 0
+    assert good >= 40
+
+
+def test_ysf_capture_through_the_chain_object(built):
+    """cu8 I/Q in four calls + the flush -> front end -> loop -> FICH of every sync in the call that holds its last dibit: the same
+    frames as the CPU pipeline over the whole stream, and every FICH that passes its CRC reads "V/D2 RID Mode Repeater CC" """
+    from conftest import golden
+    iq = np.ascontiguousarray(golden("iq_ysf.npz")["iq"], np.uint8)
+    n = 60000
+    calls = len(iq) // n
+    B = 2
+    x = np.stack([iq[:calls * n], np.roll(iq[:calls * n], 2 * 91)])
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_YSF, rf_mod=0, handlers=0, vocoder=0)
+    l = ddn.lib()
+    got = [[] for _ in range(B)]
+    base = np.zeros(B, np.int64)
+
+    def take():
+        r = ch.results()
+        S, T = r.max_syncs, r.carry_symbols
+        f = ch.fetch
+        ns, pos, pat = f(r.d_n_sync, np.int32, (B,)), f(r.d_sync_pos, np.int32, (B, S)), f(r.d_sync_pat, np.uint8, (B, S))
+        f4, st, ve = f(r.d_ysf_fich4, np.uint8, (B, S, 4)), f(r.d_ysf_fich_status, np.uint8, (B, S)), f(r.d_ysf_fich_cost, np.uint32, (B, S))
+        new = f(r.d_new, np.int32, (B,))
+        for c in range(B):
+            for k in range(int(ns[c])):
+                got[c].append(dict(pos=int(base[c]) + int(pos[c, k]) - int(T), f4=f4[c, k].copy(), st=int(st[c, k]), ve=int(ve[c, k])))
+            base[c] += int(new[c])
+
+    for k in range(calls):
+        part = np.ascontiguousarray(x[:, k * n:(k + 1) * n])
+        p = C.c_void_p()
+        assert l.ddn_device_alloc(part.nbytes, C.byref(p)) == 0 and l.ddn_device_upload(p, part.ctypes.data, part.nbytes) == 0
+        ch.run(p)
+        take()
+        l.ddn_device_free(p)
+    ch.flush()
+    take()
+    ch.close()
+    named = 0
+    for c in range(B):
+        fe = orc.OracleFrontEnd(profile=2)
+        disc = np.concatenate([fe.run_cu8(np.ascontiguousarray(x[c, k * n:(k + 1) * n]), 8192) for k in range(calls)])
+        want = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_YSF)).run(disc, max_sync=4096)
+        fr = ysf.decode_frames(want)
+        mine = [g for g in got[c] if g["st"] != 0]
+        assert [g["pos"] for g in mine] == [f["pos"] for f in fr], (c, len(mine), len(fr))
+        for g, f in zip(mine, fr):
+            assert g["st"] == {0: 1, -1: 2, -2: 3}[f["err"]] and np.array_equal(np.unpackbits(g["f4"]), f["bits"]) and g["ve"] == f["cost"]
+            if f["err"] == 0:
+                assert ysf.summary(ysf.fields(np.unpackbits(g["f4"]))) == "V/D2 RID Mode Repeater CC"
+                named += 1
+    assert named >= 30
