@@ -211,6 +211,57 @@ def parity_gate(chain, d_iq_ptr, voice, ctrl, ch_first, B, n):
     return out
 
 
+def m17_ysf_chains(torch, ddn, np, n):
+    """The two consumers of the libM17-style K = 5 decoder as chain objects (ddn_fsk4_chain, protocols M17 and YSF; informational):
+    1365 channels (a third of the headline batch, as a configs[3] group) x n cu8 samples of the reference's own captures, every channel
+    a different rotation; I/Q resident -> front end -> loop -> every frame behind every sync (M17: LSF + stream frames + LICH
+    reassembly; YSF: the frame information channel).  Known answers on the device outputs before the timed steps."""
+    import ctypes as C
+    from conftest import golden
+    dev = torch.device("cuda")
+    out = {"workload": "1365 channels x %d cu8 samples of the reference's M17 / YSF capture (rotated per channel), one C call per step" % n}
+    for name, proto, cap in (("m17", ddn.FSK4_M17, "iq_m17.npz"), ("ysf", ddn.FSK4_YSF, "iq_ysf.npz")):
+        B = 1365
+        iq = torch.from_numpy(np.ascontiguousarray(golden(cap)["iq"], np.uint8)).to(dev)
+        m = iq.shape[0]
+        off = (torch.arange(B, device=dev) * 37) % (m - n)
+        x = iq[off[:, None] + torch.arange(n, device=dev)[None, :]].contiguous()
+        ch = ddn.Fsk4ChainC(B, n, proto, rf_mod=0, handlers=0, vocoder=0)
+        ch.run(x.data_ptr())          # (the known answers are read off this first call: replaying the buffer puts a seam into the stream)
+        torch.cuda.synchronize()
+        r = ch.results()
+        S = B * r.max_syncs
+        if name == "m17":
+            st = ch.fetch(r.d_m17_str_status, np.uint8, (S,))
+            lls = ch.fetch(r.d_m17_lich_status, np.uint8, (S,))
+            ll = ch.fetch(r.d_m17_lich_lsf30, np.uint8, (S, 30))
+            good = np.flatnonzero(lls == 2)
+            src = {bytes(ll[k, 6:12].tolist()) for k in good}
+            # N0CALL in base 40 (m17_address_decode_csd): the six address bytes every CRC-good reassembled LSF carries
+            out[name] = {"stream_frames_decoded": int((st == 2).sum()), "lich_lsf_crc_good": int(len(good)),
+                         "distinct_source_addresses": len(src), "source_address_hex": sorted(v.hex() for v in src)[:2]}
+        else:
+            fs = ch.fetch(r.d_ysf_fich_status, np.uint8, (S,))
+            f4 = ch.fetch(r.d_ysf_fich4, np.uint8, (S, 4))
+            good = np.flatnonzero(fs == 1)
+            bits = np.unpackbits(f4[good], axis=1)
+            v = lambda a, k: (bits[:, a:a + k] * (1 << np.arange(k - 1, -1, -1))).sum(axis=1)
+            out[name] = {"fich_crc_good": int(len(good)), "fich_crc_bad": int((fs == 3).sum()),
+                         "all_good_fich_read_vd2_rid_repeater_cc": bool(len(good) > 0 and np.all(v(22, 2) == 2) and np.all(v(4, 2) == 1)
+                                                                        and np.all(bits[:, 21] == 1) and np.all(v(0, 2) == 1))}
+        ch.run(x.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(6):
+            ch.run(x.data_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 6
+        out[name].update({"channels": B, "ms_per_step": round(ms, 3), "Msamples_per_s": round(B * n / ms / 1e3, 1)})
+        ch.close()
+    return out
+
+
 def vocoder_c5(torch, ddn, np, steps):
     """BASELINE configs[4] / SURVEY 8d C5: 8192 voice frames as 64 talk paths x 128 frames, uniform random valid parameter
     fields (fixed seed), through frame FEC (the encoded 144 / 72-bit frames) -> parameter decode -> synthesis, IMBE 7200x4400
@@ -601,6 +652,7 @@ def main():
                                             "resident_ms_per_step": line["ms_per_step"]}
             line["vocoder_c5"] = vocoder_c5(torch, ddn, np, 10)
             line["batch_sweep"] = batch_sweep(torch, ddn, np, d_iq, n, B, dt / args.steps * 1e3, dom_ms)
+            line["m17_ysf_chains"] = m17_ysf_chains(torch, ddn, np, n)
         if mixed is not None:
             line["configs3_mixed"] = mixed
         if cpu is not None:
