@@ -621,6 +621,211 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     & (s.hunt_pos + 20 < 1800) & (qk + 4 < QCAPW) & (pos + whole + 1 <= n)
                                     & (!fo_b | ((abs0 + pos - s.filt_start) >= (long long)(NT - 1)) | (cold_fs == s.filt_start));
                     unsigned long long bm = __ballot(be);
+                    // ---- (round 5) the same pass for every hunting lane of the wave at once ------------------------------------------
+                    // Several lanes that hunt (idle channels; a group of channels whose bursts end together) used to take the pass one
+                    // after the other, each with the whole wavefront: four lanes = four times ~8 k cycles per tile.  With two or four
+                    // channels per wavefront a lane owns a ROW of 64 / CPW >= 16 lanes, a pass handles at most 16 symbols, so every owner's
+                    // pass fits its own row: the owner's words are broadcast to its row, the crossing mask is taken 64 / CPW samples per
+                    // owner and ballot, the slip chain runs per row on the vector unit (its words are uniform inside a row), lane l of a
+                    // row is symbol l of that row's owner.  Same results lane for lane; DDN_RX4_DBG bit 65536 keeps the serial order.
+                    if constexpr (CPW == 2 || CPW == 4) {
+                    if (__popcll(bm) >= 2 && !(cfg.dbg & 65536)) {
+                        constexpr int OW = 64 / CPW;
+                        constexpr unsigned long long GM = OW == 32 ? 0xFFFFFFFFull : 0xFFFFull;
+                        const int g = lane / OW, l = lane % OW;
+                        const bool gact = (bm >> g) & 1ull;
+                        const int sp0 = __shfl(pos, g), c0 = __shfl(s.hist_count, g), flt_o = __shfl(s.filter_on, g);
+                        int jit = __shfl(s.jitter, g);
+                        const uint32_t h0 = (uint32_t)__shfl((int)s.hist_bits, g);
+                        const int sh_o = __shfl(s.shead, g), li_o = __shfl(s.lidx, g), qk_o = __shfl(qk, g), ls_type = __shfl(s.lastsync, g);
+                        const int m17_pol_o = Cfg::m17 ? __shfl(s.hlich, g) : 0;
+                        const float cen_o = __shfl(s.center, g), ls_o = __shfl(s.lastsample, g);
+                        const float um_o = __shfl(s.umid, g), lm_o = __shfl(s.lmid, g), mx_o = __shfl(s.max, g), mn_o = __shfl(s.min, g);
+                        float hl = __shfl(s.maxref * 1.25f, g), ll = __shfl(s.minref * 1.25f, g);
+                        const float* pr = flt_o ? &L.flt[g][0] : &L.raw[g][0];
+                        const int a_end = lim < n ? lim : n; // samples staged
+                        int q = sp0, m = 0, myq = 0, myi0 = 0, myjin = 0;
+                        int cap = QCAPW - 2 - qk_o;
+                        cap = cap > (OW < 17 ? OW - 1 : 16) ? (OW < 17 ? OW - 1 : 16) : cap; // (lane `m` of the row holds the start after the pass)
+                        cap = cap > cfg.t_max ? cfg.t_max : cap;
+                        const bool refs_stale = __shfl((int)((s.maxref != s.max) | (s.minref != s.min)), g) != 0;
+                        int lm = c0 < 8 ? 8 - c0 : (refs_stale ? 1 : cap);
+                        lm = lm > cap ? cap : lm;
+                        bool gdone = !gact; // this row's chain has ended
+                        for (int ph = 0; ph < 2; ph++) {
+                            unsigned long long cm0 = 0ull, cm1 = 0ull, cm2 = 0ull;
+#pragma unroll
+                            for (int r = 0; r < 192 / OW; r++) {
+                                const int a = q + l + OW * r;
+                                bool hit = false;
+                                if (!gdone && a < a_end) {
+                                    const float x = pr[a & RMASKW];
+                                    const float xp = (a == sp0) ? ls_o : pr[(a - 1) & RMASKW];
+                                    const bool up = x > cen_o;
+                                    const bool within = up ? !(x > hl) : !(x < ll);
+                                    const bool crossed = up ? (xp < cen_o) : (xp > cen_o);
+                                    hit = within && crossed;
+                                }
+                                const unsigned long long bits = (__ballot(hit) >> (g * OW)) & GM;
+                                constexpr int PW = 64 / OW; // rounds per 64-bit word
+                                const unsigned long long put = bits << (OW * (r % PW));
+                                if (r / PW == 0) {
+                                    cm0 |= put;
+                                } else if (r / PW == 1) {
+                                    cm1 |= put;
+                                } else {
+                                    cm2 |= put;
+                                }
+                            }
+                            bool full = false;
+                            while (true) {
+                                const bool go = !gdone && !full && m < lm;
+                                if (!__any(go)) {
+                                    break;
+                                }
+                                if (go) {
+                                    const int i0 = (int)((i0lut >> (2 * (jit + 1))) & 3ull) - 1;
+                                    const int cnt = whole - i0;
+                                    if (q >= tile_end || q + cnt > n) {
+                                        full = true;
+                                    } else {
+                                        if (l == m) {
+                                            myq = q;
+                                            myi0 = i0;
+                                            myjin = jit;
+                                        }
+                                        const int k0 = i0 < 0 ? 1 : 0;
+                                        const uint32_t wv = (uint32_t)(cm0 >> k0) & ((1u << (cnt - k0)) - 1u);
+                                        jit = wv ? i0 + k0 + (__ffs((int)wv) - 1) : -1;
+                                        cm0 = (cm0 >> cnt) | (cm1 << (64 - cnt));
+                                        cm1 = (cm1 >> cnt) | (cm2 << (64 - cnt));
+                                        cm2 >>= cnt;
+                                        q += cnt;
+                                        m++;
+                                    }
+                                }
+                            }
+                            if (!gdone) {
+                                if (full || lm >= cap) {
+                                    gdone = true;
+                                } else {
+                                    lm = cap;
+                                    hl = mx_o * 1.25f;
+                                    ll = mn_o * 1.25f;
+                                }
+                            }
+                            if (!__any(!gdone)) {
+                                break;
+                            }
+                        }
+                        if (l == m) { // where the symbol after the pass starts, and the latch it starts with
+                            myq = q;
+                            myjin = jit;
+                        }
+                        float sym = 0.0f, wsum = 0.0f;
+                        int wc = 0;
+                        if (gact && l < m) {
+                            const int cw = (whole - 1) / 2;
+                            const int l_e = (Cfg::dmr_window && ls_type != 0) ? 1 : 2;
+                            const bool rf0b = cfg.rf_mod == 0;
+                            const int wlo = rf0b ? cw - l_e : cw - 1, whi = rf0b ? cw + 2 : cw + 1;
+                            const bool has20 = whole == 20;
+                            const int i_lo = has20 && 7 < wlo ? 7 : wlo, i_hi = has20 && 13 > whi ? 13 : whi;
+                            const int leftj = whole - myi0;
+#pragma unroll
+                            for (int qq = 0; qq < 12; qq++) {
+                                const int i = i_lo + qq, k = i - myi0;
+                                if (i <= i_hi && k >= 0 && k < leftj) {
+                                    const float x = pr[(myq + k) & RMASKW];
+                                    const bool k1 = rf0b ? (i >= wlo && i <= whi) : (i == wlo || i == whi);
+                                    const bool k2 = has20 && i >= 7 && i <= 13;
+                                    if (k2) {
+                                        wsum += x;
+                                    }
+                                    if (k1) {
+                                        wsum += x;
+                                    }
+                                    wc += (k1 ? 1 : 0) + (k2 ? 1 : 0);
+                                }
+                            }
+                            sym = (wc > 0) ? (wsum / (float)wc) : 0.0f;
+                        }
+                        const uint32_t sw = (uint32_t)((__ballot(gact && l < m && sym > 0.0f) >> (g * OW)) & GM);
+                        const int lj = l < 31 ? l : 31;
+                        const uint32_t hj = ((h0 << (lj + 1)) | __brev(sw << (31 - lj))) & 0xFFFFFFu;
+                        bool syn = false;
+                        if (gact && l < m && (c0 + l + 1 >= cfg.win_len) && !(cfg.dbg & 8)) {
+                            const uint32_t w = hj & wmask;
+                            if (Cfg::m17) {
+                                int pa;
+                                syn = m17_hit(w, ls_type, m17_pol_o, L.pat_meta, pa) >= 0;
+                            } else {
+                                for (int k = 0; k < cfg.n_pat; k++) {
+                                    syn |= (w == L.pat_bits[k]);
+                                }
+                            }
+                        }
+                        const uint32_t smg = (uint32_t)((__ballot(syn) >> (g * OW)) & GM);
+                        if (smg) {
+                            m = __ffs((int)smg) - 1;
+                        }
+                        // the owner lanes (lane = channel column < CPW) read their row's results
+                        const int orow = (lane < CPW ? lane : 0) * OW;
+                        const int m_own = __shfl(m, orow);
+                        const int qf = __shfl(myq, orow + m_own), jf = __shfl(myjin, orow + m_own);
+                        const int src1 = orow + (m_own > 0 ? m_own - 1 : 0);
+                        const float sumf = __shfl(wsum, src1);
+                        const int cntf = __shfl(wc, src1);
+                        const uint32_t hf = (uint32_t)__shfl((int)hj, src1);
+                        if (gact && l < m) { // symbol history, level window, the queue entry the helper wave slices and stores
+                            const int slot = (sh_o + l) & (HN - 1);
+                            L.sh[slot][g] = sym;
+                            int k = li_o + l;
+                            k = k >= cfg.t_max ? k - cfg.t_max : k;
+                            L.lb[k][g] = sym;
+                            const int qb = t & 1, qe = qk_o + l;
+                            L.q[qb][qe][0][g] = sym;
+                            L.q[qb][qe][1][g] = cen_o;
+                            L.q[qb][qe][2][g] = um_o;
+                            L.q[qb][qe][3][g] = lm_o;
+                            L.q[qb][qe][4][g] = mx_o;
+                            L.q[qb][qe][5][g] = mn_o;
+                            L.q[qb][qe][6][g] = __int_as_float(slot << 8);
+                        }
+                        if (lane < CPW && be) {
+                            if (m_own == 0) { // the next symbol matches a sync pattern: the general trip's
+                                blk_o = o;
+                            } else {
+                                const float* prow = s.filter_on ? &L.flt[lane][0] : &L.raw[lane][0];
+                                const float lsf = prow[(qf - 1) & RMASKW];
+                                s.shead = (s.shead + m_own) & (HN - 1);
+                                s.scount = s.scount + m_own < HN ? s.scount + m_own : HN;
+                                int k = s.lidx + m_own;
+                                s.lidx = k >= cfg.t_max ? k - cfg.t_max : k;
+                                s.level_count = s.level_count + m_own < cfg.t_max ? s.level_count + m_own : cfg.t_max;
+                                s.hist_count = s.hist_count + m_own < 24 ? s.hist_count + m_own : 24;
+                                s.hist_bits = hf;
+                                if (s.hist_count >= 8) {
+                                    s.maxref = s.max;
+                                    s.minref = s.min;
+                                }
+                                s.hunt_pos += m_own;
+                                s.span = whole;
+                                s.centre = (whole - 1) / 2;
+                                s.i = whole;
+                                s.sum = sumf;
+                                s.count = cntf;
+                                s.in_symbol = 0;
+                                s.jitter = jf;
+                                s.lastsample = lsf;
+                                pos = qf;
+                                o += m_own;
+                                qk += m_own;
+                            }
+                        }
+                        continue;
+                    }
+                    }
                     if (__builtin_expect(bm != 0, 0)) {
                         while (bm) {
                             const int ow = __ffsll((long long)bm) - 1; // owner lane (= channel column) of this pass

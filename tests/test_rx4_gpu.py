@@ -107,6 +107,31 @@ def test_wide_batch_both_wave_shapes(built):
             check_channel(got, c, rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_DMR)).run(x[c], max_sync=got["sync_pos"].shape[1]))
 
 
+@pytest.mark.parametrize("cap,lpf,proto", [("iq_dmr_t3_ras_cc.npz", 2, rx4.PROTO_DMR), ("iq_nxdn48.npz", 1, rx4.PROTO_NXDN48)])
+@pytest.mark.parametrize("cpw", [2, 4])
+def test_hunting_pass_of_all_rows_at_once_equals_one_owner_at_a_time(built, monkeypatch, cap, lpf, proto, cpw):
+    """two / four channels per wavefront: the lanes that hunt take the bulk hunting pass together, one row of the wavefront
+    each (ddn_rx4.hip); same records as the pass taken one owner after the other (DDN_RX4_DBG bit 65536) and as the oracle"""
+    disc = rx4.capture_disc(cap, lpf)[:30000]
+    B = 41
+    x = np.stack([np.roll(disc, 211 * (c % 23)) * (0.35 + 0.05 * (c % 9)) for c in range(B)]).astype(np.float32)
+    x[5, 9000:] = 0.0                                  # a channel whose carrier goes away hunts for the rest of the call
+    x[6, :15000] = 0.0
+    outs = []
+    for dbg in ("0", "65536"):
+        monkeypatch.setenv("DDN_RX4_DBG", dbg)
+        rx = ddn.Fsk4Rx(B, GPU_PROTO[proto])
+        assert ddn.lib().ddn_fsk4_rx_set_channels_per_wave(rx.h, cpw) == 0
+        outs.append([rx.run_host(x[:, a:b]) for a, b in ((0, 14000), (14000, 30000))])
+    for part in range(2):
+        for k in outs[0][part]:
+            assert np.array_equal(outs[0][part][k], outs[1][part][k]), k
+    cpu = [rx4.OracleFsk4Rx(rx4.profile(proto)) for _ in range(B)]
+    for part, (a, b) in enumerate(((0, 14000), (14000, 30000))):
+        for c in (0, 5, 6, 7, 22, B - 1):
+            check_channel(outs[0][part], c, cpu[c].run(x[c, a:b], max_sync=outs[0][part]["sync_pos"].shape[1]))
+
+
 def test_dmr_known_answers_on_device(built):
     """RAS control-channel capture, everything after the front end on the device: receive loop -> burst gather -> Golay(20,8)
     slot type -> BPTC(196,96): colour code 0 on every burst ("Color Code=00") and C_ALOHA system identity Large / net 1 /
