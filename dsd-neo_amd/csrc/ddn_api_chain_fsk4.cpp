@@ -693,8 +693,30 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
             }
         }
     }
-    for (int k = 0; k < 3 && rc == DDN_OK; k++) {
-        if (hipStreamCreateWithFlags(&m->st[k], hipStreamNonBlocking) != hipSuccess
+    // DDN_MIX_XCD="a,b,c" (experiment): the three groups' loop streams on disjoint sets of XCDs (a + b + c <= 8; CU-mask bit i is
+    // CU i / 8 of XCD i % 8) - different loop kernels then never share a CU's instruction cache
+    int xcd_n[3] = {0, 0, 0};
+    if (const char* e = getenv("DDN_MIX_XCD")) {
+        if (sscanf(e, "%d,%d,%d", &xcd_n[0], &xcd_n[1], &xcd_n[2]) != 3 || xcd_n[0] < 1 || xcd_n[1] < 1 || xcd_n[2] < 1
+            || xcd_n[0] + xcd_n[1] + xcd_n[2] > 8) {
+            xcd_n[0] = xcd_n[1] = xcd_n[2] = 0;
+        }
+    }
+    for (int k = 0, x0 = 0; k < 3 && rc == DDN_OK; k++) {
+        hipError_t se;
+        if (xcd_n[k]) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 256; i++) {
+                if (i % 8 >= x0 && i % 8 < x0 + xcd_n[k]) {
+                    mask[i / 32] |= 1u << (i % 32);
+                }
+            }
+            x0 += xcd_n[k];
+            se = hipExtStreamCreateWithCUMask(&m->st[k], 8, mask);
+        } else {
+            se = hipStreamCreateWithFlags(&m->st[k], hipStreamNonBlocking);
+        }
+        if (se != hipSuccess
             || (k == 0 && hipStreamCreateWithFlags(&m->st2[0], hipStreamNonBlocking) != hipSuccess)
             || hipEventCreateWithFlags(&m->ev_front[k], hipEventDisableTiming) != hipSuccess
             || hipEventCreateWithFlags(&m->ev_loop[k], hipEventDisableTiming) != hipSuccess
