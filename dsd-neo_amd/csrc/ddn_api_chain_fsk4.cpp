@@ -79,6 +79,9 @@ struct ddn_fsk4_chain {
     bool ysf;
     uint8_t *y_fich4, *y_st;
     uint32_t* y_ve;
+    // ... and the payload behind it (ddn_ysf_payload_decode_batch): the frame type carried per channel, the data channels, V/D2 voice bits
+    uint8_t *y_last, *y_info, *y_dch, *y_dst, *y_ambe, *y_errs;
+    uint32_t* y_dcost;
     long step;
     int last_set;
 };
@@ -115,7 +118,7 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
     ddn_batch_destroy(c->fe);
     ddn_fsk4_rx_destroy(c->rx);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->y_fich4, c->y_st, c->y_ve, c->s_thr, c->c_thr[0], c->c_thr[1], c->d_thr, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_fp, c->m_st, c->m_asm, c->m_ll,
+    void* all[] = {c->y_fich4, c->y_st, c->y_ve, c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_ambe, c->y_errs, c->y_dcost, c->s_thr, c->c_thr[0], c->c_thr[1], c->d_thr, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_fp, c->m_st, c->m_asm, c->m_ll,
                    c->m_ll_st, c->m_cost, c->d_disc, c->d_disc2, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_pay, c->d_new[0], c->d_new[1], c->d_cnt_full,
                    c->d_cnt_scan, c->d_dropped, c->s_pos, c->s_n, c->c_pos[0], c->c_pos[1], c->c_n[0], c->c_n[1], c->d_spos, c->d_ns, c->s_pat, c->s_pre,
                    c->s_prel, c->c_pat[0], c->c_pat[1], c->c_pre[0], c->c_pre[1], c->c_prel[0], c->c_prel[1], c->d_spat, c->d_pre,
@@ -155,6 +158,9 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
     c->ysf = cfg->protocol == DDN_FSK4_YSF; // (the FICH ends 100 symbols after its sync)
     c->T = 256;  // a DMR burst ends 54 symbols after its sync, an NXDN frame 182: the tail kept back for the next call
     c->myc = 16; // syncs that can lie inside that tail (a new sync needs 24 / 10 fresh symbols)
+    if (c->ysf) {
+        c->T = 480; // (a YSF frame's payload ends 460 symbols after its sync)
+    }
     int rc = DDN_OK;
     do {
         // (NXDN96: a 12.5 kHz channel at 4800 symbols/s)
@@ -200,7 +206,9 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
                  && dalloc(&c->c_pre[k], B * myc * 90) && dalloc(&c->c_prel[k], B * myc * 90);
         }
         if (ok && c->ysf) {
-            ok = dalloc(&c->y_fich4, S * 4) && dalloc(&c->y_st, S) && dalloc(&c->y_ve, S);
+            ok = dalloc(&c->y_fich4, S * 4) && dalloc(&c->y_st, S) && dalloc(&c->y_ve, S) && dalloc(&c->y_last, B * 2) && dalloc(&c->y_info, S * 2)
+                 && dalloc(&c->y_dch, S * 40) && dalloc(&c->y_dst, S * 2) && dalloc(&c->y_dcost, S * 2) && dalloc(&c->y_ambe, S * 5 * 49)
+                 && dalloc(&c->y_errs, S * 5);
         } else if (ok && c->m17) {
             ok = dalloc(&c->s_thr, B * my * 5) && dalloc(&c->c_thr[0], B * myc * 5) && dalloc(&c->c_thr[1], B * myc * 5) && dalloc(&c->d_thr, S * 5)
                  && dalloc(&c->m_lsf, S * 30) && dalloc(&c->m_lsf_st, S) && dalloc(&c->m_l6, S * 6) && dalloc(&c->m_cnt, S) && dalloc(&c->m_fp, S * 18)
@@ -294,6 +302,9 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
                                          c->d_thr, c->m17 ? c->c_thr[cur] : nullptr, st));
     if (c->ysf) { // the frame information channel behind every sync of the decode list (row a17's second consumer)
         DDN_TRY(ddn_ysf_fich_decode_batch(rec, c->stride, c->d_cnt_full, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->y_fich4, c->y_st, c->y_ve, st));
+        // ... and the payload of every frame: V/D mode 2 voice bits + DCH2, the DCH blocks of V/D mode 1 and of the full-rate data frames
+        DDN_TRY(ddn_ysf_payload_decode_batch(rec, c->stride, c->d_cnt_full, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->y_fich4, c->y_st,
+                                             c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_dcost, c->y_ambe, c->y_errs, st));
         return DDN_OK;
     }
     if (c->m17) {
@@ -521,6 +532,12 @@ ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
         r->d_ysf_fich4 = c->y_fich4;
         r->d_ysf_fich_status = c->y_st;
         r->d_ysf_fich_cost = c->y_ve;
+        r->d_ysf_info2 = c->y_info;
+        r->d_ysf_dch40 = c->y_dch;
+        r->d_ysf_dch_status2 = c->y_dst;
+        r->d_ysf_dch_cost2 = c->y_dcost;
+        r->d_ysf_ambe49x5 = c->y_ambe;
+        r->d_ysf_errs2x5 = c->y_errs;
     }
     if (c->m17) {
         r->d_sync_thr5 = c->d_thr;

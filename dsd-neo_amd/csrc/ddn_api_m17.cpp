@@ -182,3 +182,82 @@ ddn_ysf_fich_decode_batch(const uint8_t* d_records10, size_t stride_symbols, con
     HIP_TRY(ef);
     return DDN_OK;
 }
+
+extern "C" hipError_t ddn_dev_ysf_plan(const int32_t* sync_pos, const int32_t* n_sync, const int32_t* counts, int n_channels, int max_syncs,
+                                       int lmax, const uint8_t* fich4, const uint8_t* fich_status, uint8_t* last2, uint8_t* info,
+                                       int32_t* slot_sync, hipStream_t st);
+extern "C" hipError_t ddn_dev_ysf_payload_costs(const uint8_t* rec, size_t stride, const int32_t* sync_pos, int n_channels, int max_syncs,
+                                                int lmax, const uint8_t* info, const int32_t* slot_sync, uint16_t* cost200,
+                                                uint16_t* cost360, uint8_t* ambe49, uint8_t* errs2, hipStream_t st);
+extern "C" hipError_t ddn_dev_ysf_dch_finish(const uint8_t* decA, const uint32_t* pcA, const uint8_t* decB, const uint32_t* pcB,
+                                             const int32_t* slot_sync, const uint8_t* info, int n_channels, int lmax, int max_syncs,
+                                             uint8_t* dch40, uint8_t* dch_status, uint32_t* dch_cost, hipStream_t st);
+
+// include/ddn_fsk4.h
+extern "C" int
+ddn_ysf_payload_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
+                             const int32_t* d_n_sync, int n_channels, size_t max_syncs, const uint8_t* d_fich4, const uint8_t* d_fich_status,
+                             uint8_t* d_last_dt_fi, uint8_t* d_info2, uint8_t* d_dch40, uint8_t* d_dch_status2, uint32_t* d_dch_cost2,
+                             uint8_t* d_ambe49x5, uint8_t* d_errs2x5, void* hip_stream) {
+    if (!d_records10 || !d_counts || !d_sync_pos || !d_n_sync || !d_fich4 || !d_fich_status || !d_last_dt_fi || !d_info2 || !d_dch40
+        || !d_dch_status2 || !d_dch_cost2 || !d_ambe49x5 || !d_errs2x5 || n_channels <= 0 || max_syncs == 0 || max_syncs > (1u << 24)
+        || stride_symbols == 0) {
+        ddn_set_error("ddn_ysf_payload_decode_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    // frames are a sync window + the lock (20 + 460 symbols) apart
+    const int lmax = (int)(stride_symbols / 480 + 2);
+    const size_t S = (size_t)n_channels * (size_t)lmax, SO = (size_t)n_channels * max_syncs;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_cA = up(S * 200 * sizeof(uint16_t)), b_cB = up(S * 2 * 360 * sizeof(uint16_t)), b_dA = up(S * 16), b_dB = up(S * 2 * 32),
+                 b_pA = up(S * sizeof(uint32_t)), b_pB = up(S * 2 * sizeof(uint32_t)), b_slot = up(S * sizeof(int32_t));
+    uint8_t* scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&scratch, b_cA + b_cB + b_dA + b_dB + b_pA + b_pB + b_slot, st));
+    uint16_t* cA = (uint16_t*)scratch;
+    uint16_t* cB = (uint16_t*)(scratch + b_cA);
+    uint8_t* dA = scratch + b_cA + b_cB;
+    uint8_t* dB = dA + b_dA;
+    uint32_t* pA = (uint32_t*)(dB + b_dB);
+    uint32_t* pB = (uint32_t*)((uint8_t*)pA + b_pA);
+    int32_t* slot = (int32_t*)((uint8_t*)pB + b_pB);
+    int rc = DDN_OK;
+    hipError_t e = hipMemsetAsync(cA, 0, b_cA + b_cB, st);
+    if (e == hipSuccess) {
+        e = hipMemsetAsync(slot, 0xFF, b_slot, st);
+    }
+    if (e == hipSuccess) {
+        e = hipMemsetAsync(d_dch_status2, 0, SO * 2, st);
+    }
+    if (e == hipSuccess) {
+        e = hipMemsetAsync(d_dch_cost2, 0, SO * 2 * sizeof(uint32_t), st);
+    }
+    if (e == hipSuccess) {
+        e = hipMemsetAsync(d_dch40, 0, SO * 40, st);
+    }
+    if (e == hipSuccess) {
+        e = ddn_dev_ysf_plan(d_sync_pos, d_n_sync, d_counts, n_channels, (int)max_syncs, lmax, d_fich4, d_fich_status, d_last_dt_fi, d_info2,
+                             slot, st);
+    }
+    if (e == hipSuccess) {
+        e = ddn_dev_ysf_payload_costs(d_records10, stride_symbols, d_sync_pos, n_channels, (int)max_syncs, lmax, d_info2, slot, cA, cB,
+                                      d_ambe49x5, d_errs2x5, st);
+    }
+    static const uint8_t none[4] = {1, 1, 1, 1}; // DSD_YSF_PUNCTURE_NONE
+    if (e == hipSuccess) {
+        rc = ddn_fec_viterbi_k5_batch(cA, S, 200, none, 4, dA, 16, pA, st);
+    }
+    if (e == hipSuccess && rc == DDN_OK) {
+        rc = ddn_fec_viterbi_k5_batch(cB, S * 2, 360, none, 4, dB, 32, pB, st);
+    }
+    if (e == hipSuccess && rc == DDN_OK) {
+        e = ddn_dev_ysf_dch_finish(dA, pA, dB, pB, slot, d_info2, n_channels, lmax, (int)max_syncs, d_dch40, d_dch_status2, d_dch_cost2, st);
+    }
+    const hipError_t ef = hipFreeAsync(scratch, st);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    HIP_TRY(e);
+    HIP_TRY(ef);
+    return DDN_OK;
+}

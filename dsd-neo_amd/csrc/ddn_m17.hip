@@ -478,6 +478,215 @@ k_ysf_fich_finish(const uint8_t* __restrict__ dec, int dec_stride, const uint32_
 }
 } // namespace
 
+// ---- Yaesu System Fusion: the payload behind the FICH (round 5) ---------------------------------------------------------------------
+// ysf_dispatch_payload() (src/protocol/ysf/ysf.c:908-922) by the type the frame is read as: FI = 1 & DT = 2 -> V/D mode 2 (five
+// sub-frames of 20 data + 52 voice dibits: ysf_handle_vd_type2 :724-774), FI = 1 & DT = 0 -> V/D mode 1 (5 x 36 data + 36 voice:
+// :667-685), DT = 1 or FI = 0 / 2 -> full-rate data (10 x 36 dibits, two data-channel blocks in turn: :844-864).
+//   k_ysf_plan           one thread per channel, the syncs of the decode list in order: a frame whose FICH failed is read as the last
+//                        good frame's DT / FI (ysf_parse_fich's two statics, :553-555 - kept per channel in last2[][2] across calls);
+//                        the frames whose 360 payload dibits lie inside the records get a slot of the dense decode list
+//   k_ysf_payload_costs  one wavefront per slot: V/D2 voice = ysf_read_type2_vech_bits + ysf_build_type2_ambe (:687-722: 26 x 4 bit
+//                        de-interleave, PN9 de-whitening, 27 majority votes + 22 plain bits = ambe_d[49], errs2 = bit 103); the data
+//                        channel(s): dibit de-interleave 20 x 5 (DCH2) / 20 x 9 (DCH) -> hard costs for the K = 5 decoder
+//   k_ysf_dch_finish     ysf_conv_dch2 / ysf_conv_dch (:245-355) behind the decoder: bits 8 .. of the decoded bytes, ysf_crc16 over
+//                        all of them (0 = good), PN9 de-whitening of the 80 / 160 data bits (dsd_ysf_dewhiten_bits, ysf_frame.c:59-73)
+__device__ inline int
+ysf_pn9_next(unsigned& l) {
+    const int bit = (int)(l & 1u);
+    const unsigned fb = ((l >> 4) ^ l) & 1u;
+    l = (l >> 1) | (fb << 8);
+    return bit;
+}
+
+__global__ void
+k_ysf_plan(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_sync, const int32_t* __restrict__ counts, int n_channels,
+           int max_syncs, int lmax, const uint8_t* __restrict__ fich4, const uint8_t* __restrict__ fich_status, uint8_t* __restrict__ last2,
+           uint8_t* __restrict__ info, int32_t* __restrict__ slot_sync) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_channels) {
+        return;
+    }
+    int ns = n_sync[ch];
+    ns = ns < max_syncs ? ns : max_syncs;
+    const int cnt = counts[ch];
+    int dt = last2[2 * ch], fi = last2[2 * ch + 1], j = 0;
+    for (int k = 0; k < ns; k++) {
+        const size_t so = (size_t)ch * max_syncs + k;
+        const int st = fich_status[so];
+        if (st == 0) { // no FICH behind this sync inside the records: not a frame of this call
+            info[2 * so] = 0;
+            info[2 * so + 1] = 0;
+            continue;
+        }
+        if (st == 1) {
+            dt = fich4[4 * so + 2] & 3;
+            fi = fich4[4 * so] >> 6;
+        }
+        int kind = 0;
+        kind |= (fi == 1 && dt == 0) ? 1 : 0;
+        kind |= (fi == 1 && dt == 2) ? 2 : 0;
+        kind |= (fi == 1 && dt == 3) ? 4 : 0;
+        kind |= (dt == 1 || fi == 0 || fi == 2) ? 8 : 0;
+        const bool complete = sync_pos[so] + 461 <= cnt;
+        int flags = fi | (dt << 2) | (st != 1 ? 16 : 0) | 32;
+        if (complete && (kind & 11) != 0) {
+            if (j < lmax) {
+                slot_sync[(size_t)ch * lmax + j] = k;
+                j++;
+            } else {
+                flags |= 64; // (more frames than a row can hold 480 symbols apart: left undecoded, said so)
+            }
+        }
+        info[2 * so] = (uint8_t)((complete && !(flags & 64)) ? kind : 0);
+        info[2 * so + 1] = (uint8_t)flags;
+    }
+    last2[2 * ch] = (uint8_t)dt;
+    last2[2 * ch + 1] = (uint8_t)fi;
+}
+
+__global__ __launch_bounds__(64) void
+k_ysf_payload_costs(const uint8_t* __restrict__ rec, size_t stride, const int32_t* __restrict__ sync_pos, int max_syncs, int lmax,
+                    const uint8_t* __restrict__ info, const int32_t* __restrict__ slot_sync, uint16_t* __restrict__ cost200,
+                    uint16_t* __restrict__ cost360, uint8_t* __restrict__ ambe49, uint8_t* __restrict__ errs2) {
+    const int ch = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    const size_t slot = (size_t)ch * lmax + j;
+    const int k = slot_sync[slot];
+    if (k < 0) {
+        return; // (the cost arrays were cleared as a whole)
+    }
+    const size_t so = (size_t)ch * max_syncs + k;
+    const int kind = info[2 * so];
+    const uint8_t* r0 = rec + ((size_t)ch * stride + (size_t)sync_pos[so] + 101) * 10;
+    auto dib = [&](int x) { return (int)(r0[(size_t)x * 10] & 3); };
+    if (kind & 2) {
+        __shared__ uint8_t pn[104], v[5][104];
+        if (lane == 0) {
+            unsigned l = 0x1C9;
+            for (int i = 0; i < 104; i++) {
+                pn[i] = (uint8_t)ysf_pn9_next(l);
+            }
+        }
+        __syncthreads();
+        for (int t = lane; t < 5 * 104; t += 64) {
+            const int sf = t / 104, kb = t - 104 * sf;            // serial bit kb of sub-frame sf: dibit kb / 2, high bit first
+            const int d = dib(72 * sf + 20 + (kb >> 1));
+            const int dest = (kb & 3) * 26 + (kb >> 2);
+            v[sf][dest] = (uint8_t)((((kb & 1) ? d : (d >> 1)) & 1) ^ pn[dest]);
+        }
+        __syncthreads();
+        for (int t = lane; t < 5 * 49; t += 64) {
+            const int sf = t / 49, b = t - 49 * sf;
+            int o;
+            if (b < 27) {
+                o = (v[sf][3 * b] + v[sf][3 * b + 1] + v[sf][3 * b + 2]) >= 2 ? 1 : 0;
+            } else {
+                o = v[sf][81 + (b - 27)];
+            }
+            ambe49[(so * 5 + sf) * 49 + b] = (uint8_t)o;
+        }
+        if (lane < 5) {
+            errs2[so * 5 + lane] = v[lane][103];
+        }
+        uint16_t* out = cost200 + slot * 200;
+        for (int q = lane; q < 100; q += 64) { // buf[jj + 5 i] = input[i + 20 jj]; input[x] = data dibit x % 20 of sub-frame x / 20
+            const int i = q / 5, jj = q - 5 * i, x = i + 20 * jj;
+            const int d = dib(72 * (x / 20) + x % 20);
+            out[2 * q] = (d & 2) ? 0xFFFFu : 0u;
+            out[2 * q + 1] = (d & 1) ? 0xFFFFu : 0u;
+        }
+    } else if (kind & 1) {
+        uint16_t* out = cost360 + slot * 2 * 360;
+        for (int q = lane; q < 180; q += 64) { // buf[jj + 9 i] = input[i + 20 jj]; input[x] = data dibit x % 36 of sub-frame x / 36
+            const int i = q / 9, jj = q - 9 * i, x = i + 20 * jj;
+            const int d = dib(72 * (x / 36) + x % 36);
+            out[2 * q] = (d & 2) ? 0xFFFFu : 0u;
+            out[2 * q + 1] = (d & 1) ? 0xFFFFu : 0u;
+        }
+    } else if (kind == 8) {
+        for (int b = 0; b < 2; b++) {
+            uint16_t* out = cost360 + (slot * 2 + b) * 360;
+            for (int q = lane; q < 180; q += 64) { // input_b[x] = dibit x % 36 of chunk 2 (x / 36) + b
+                const int i = q / 9, jj = q - 9 * i, x = i + 20 * jj;
+                const int d = dib(36 * (2 * (x / 36) + b) + x % 36);
+                out[2 * q] = (d & 2) ? 0xFFFFu : 0u;
+                out[2 * q + 1] = (d & 1) ? 0xFFFFu : 0u;
+            }
+        }
+    }
+}
+
+__global__ void
+k_ysf_dch_finish(const uint8_t* __restrict__ decA, const uint32_t* __restrict__ pcA, const uint8_t* __restrict__ decB,
+                 const uint32_t* __restrict__ pcB, const int32_t* __restrict__ slot_sync, const uint8_t* __restrict__ info, int n_channels,
+                 int lmax, int max_syncs, uint8_t* __restrict__ dch40, uint8_t* __restrict__ dch_status, uint32_t* __restrict__ dch_cost) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_channels * lmax * 2) {
+        return;
+    }
+    const int slot = t >> 1, blk = t & 1;
+    const int k = slot_sync[slot];
+    if (k < 0) {
+        return;
+    }
+    const size_t so = (size_t)(slot / lmax) * max_syncs + k;
+    const int kind = info[2 * so];
+    const bool vd2 = (kind & 2) != 0;
+    if (blk == 1 && kind != 8) {
+        return; // (one data-channel block per V/D frame)
+    }
+    const uint8_t* by = vd2 ? decA + (size_t)slot * 16 : decB + (size_t)(slot * 2 + blk) * 32;
+    const int nbits = vd2 ? 96 : 176;
+    uint32_t crc = 0;
+    for (int i = 0; i < nbits; i++) {
+        const int b = 8 + i;
+        const uint32_t bit = (by[b >> 3] >> (7 - (b & 7))) & 1u;
+        crc = ((crc << 1) | bit) & 0x1ffff;
+        if (crc & 0x10000) {
+            crc = (crc & 0xffff) ^ 0x1021u;
+        }
+    }
+    crc = (crc ^ 0xffff) & 0xffff;
+    unsigned l = 0x1C9;
+    uint8_t* out = dch40 + (so * 2 + blk) * 20;
+    for (int i = 0; i < (nbits - 16) / 8; i++) {
+        int o = 0;
+        for (int q = 0; q < 8; q++) {
+            const int b = 8 + 8 * i + q;
+            o = (o << 1) | ((int)((by[b >> 3] >> (7 - (b & 7))) & 1u) ^ ysf_pn9_next(l));
+        }
+        out[i] = (uint8_t)o;
+    }
+    dch_status[so * 2 + blk] = crc == 0 ? 1 : 3;
+    dch_cost[so * 2 + blk] = vd2 ? pcA[slot] : pcB[slot * 2 + blk];
+}
+
+extern "C" hipError_t
+ddn_dev_ysf_plan(const int32_t* sync_pos, const int32_t* n_sync, const int32_t* counts, int n_channels, int max_syncs, int lmax,
+                 const uint8_t* fich4, const uint8_t* fich_status, uint8_t* last2, uint8_t* info, int32_t* slot_sync, hipStream_t st) {
+    hipLaunchKernelGGL(k_ysf_plan, dim3((unsigned)((n_channels + 63) / 64)), dim3(64), 0, st, sync_pos, n_sync, counts, n_channels, max_syncs,
+                       lmax, fich4, fich_status, last2, info, slot_sync);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_ysf_payload_costs(const uint8_t* rec, size_t stride, const int32_t* sync_pos, int n_channels, int max_syncs, int lmax,
+                          const uint8_t* info, const int32_t* slot_sync, uint16_t* cost200, uint16_t* cost360, uint8_t* ambe49,
+                          uint8_t* errs2, hipStream_t st) {
+    hipLaunchKernelGGL(k_ysf_payload_costs, dim3((unsigned)n_channels, (unsigned)lmax), dim3(64), 0, st, rec, stride, sync_pos, max_syncs,
+                       lmax, info, slot_sync, cost200, cost360, ambe49, errs2);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_ysf_dch_finish(const uint8_t* decA, const uint32_t* pcA, const uint8_t* decB, const uint32_t* pcB, const int32_t* slot_sync,
+                       const uint8_t* info, int n_channels, int lmax, int max_syncs, uint8_t* dch40, uint8_t* dch_status,
+                       uint32_t* dch_cost, hipStream_t st) {
+    const int n = n_channels * lmax * 2;
+    hipLaunchKernelGGL(k_ysf_dch_finish, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, decA, pcA, decB, pcB, slot_sync, info,
+                       n_channels, lmax, max_syncs, dch40, dch_status, dch_cost);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t
 ddn_dev_ysf_fich_cost(const uint8_t* rec, size_t stride, const int32_t* counts, const int32_t* sync_pos, const int32_t* n_sync,
                       int n_channels, int max_syncs, int lmax, uint16_t* cost200, int32_t* slot_sync, hipStream_t st) {

@@ -361,6 +361,13 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const uint8_t* d_ysf_fich4;          /* [S][4] the 32 FICH bits */
     const uint8_t* d_ysf_fich_status;    /* [S] 0 none, 1 good, 2 Golay failed, 3 CRC failed */
     const uint32_t* d_ysf_fich_cost;     /* [S] the decoder's path cost */
+    /* ... and ddn_ysf_payload_decode_batch's (the frame type is carried per channel inside the object) */
+    const uint8_t* d_ysf_info2;          /* [S][2] what was decoded (1 V/D1, 2 V/D2, 4 full-rate voice, 8 full-rate data) | FI, DT, flags */
+    const uint8_t* d_ysf_dch40;          /* [S][2][20] data-channel bytes (DCH2: 10, DCH: 20; second block: full-rate data frames) */
+    const uint8_t* d_ysf_dch_status2;    /* [S][2] 0 none, 1 CRC16 good, 3 CRC16 failed */
+    const uint32_t* d_ysf_dch_cost2;     /* [S][2] the decoder's path cost */
+    const uint8_t* d_ysf_ambe49x5;       /* [S][5][49] V/D mode 2: ambe_d of the five voice sub-frames */
+    const uint8_t* d_ysf_errs2x5;        /* [S][5] their errs2 */
 } ddn_fsk4_chain_results;
 typedef struct ddn_fsk4_chain ddn_fsk4_chain;
 int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);

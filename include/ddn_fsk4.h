@@ -127,6 +127,25 @@ int ddn_m17_str_decode_batch(const uint8_t* d_records10, size_t stride_symbols, 
 int ddn_ysf_fich_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
                               const int32_t* d_n_sync, int n_channels, size_t max_syncs, uint8_t* d_fich4, uint8_t* d_status,
                               uint32_t* d_v_error, void* hip_stream);
+
+/* The payload behind the FICH == ysf_dispatch_payload() (src/protocol/ysf/ysf.c:908-922) for every frame of the call (a sync of the
+ * decode list with d_fich_status != 0), in stream order per channel:
+ *   the type a frame is read as: FI / DT of its FICH, or - when the FICH failed - of the last good frame of the channel (ysf_parse_fich's
+ *     statics, :553-555): d_last_dt_fi u8 [n_channels][2] {DT, FI}, zero before the first call, carried by the caller from call to call;
+ *   d_info2 [S][2]: [0] = what was decoded, a bit mask: 1 V/D mode 1 (FI 1, DT 0), 2 V/D mode 2 (FI 1, DT 2), 4 full-rate voice
+ *     (FI 1, DT 3), 8 full-rate data (DT 1 or FI 0 / 2) - 0 when the frame's 360 payload dibits are not inside the records;
+ *     [1] = FI | DT << 2 | 16 (FICH failed: type taken over) | 32 (a frame) | 64 (more frames than a row holds 480 symbols apart:
+ *     left undecoded);
+ *   V/D mode 2: the five voice sub-frames, ysf_read_type2_vech_bits + ysf_build_type2_ambe (:687-722): d_ambe49x5 [S][5][49] = ambe_d
+ *     (what mbe_processAmbe2450Dataf takes), d_errs2x5 [S][5] = errs2; the data channel, ysf_conv_dch2 (:245-300): d_dch40 [S][2][20]
+ *     block 0 bytes 0 .. 9, d_dch_status2 [S][2] (0 none, 1 CRC16 good, 3 CRC16 failed), d_dch_cost2 [S][2] = the decoder's path cost;
+ *   V/D mode 1: the data channel, ysf_conv_dch (:302-355), block 0 bytes 0 .. 19 (its voice frames: not decoded here);
+ *   full-rate data (a frame that is nothing else): both blocks, in turn (ysf_handle_full_rate_data :844-864).
+ * S = n_channels x max_syncs, slots as d_sync_pos.  Full-rate voice (IMBE) is not decoded: mask bit 4 only says so. */
+int ddn_ysf_payload_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
+                                 const int32_t* d_n_sync, int n_channels, size_t max_syncs, const uint8_t* d_fich4,
+                                 const uint8_t* d_fich_status, uint8_t* d_last_dt_fi, uint8_t* d_info2, uint8_t* d_dch40,
+                                 uint8_t* d_dch_status2, uint32_t* d_dch_cost2, uint8_t* d_ambe49x5, uint8_t* d_errs2x5, void* hip_stream);
 /* The LSF reassembled from the LICH chunks, in the order of the syncs of a call: a decoded LSF frame seeds the buffer (m17_decode_lsf_soft_
  * bits), an EOT marker clears it (dispatch_m17.c:39), chunk c fills bytes 5 c .. 5 c + 4, chunk 5 closes it: d_lich_lsf30 [B][max_syncs][30]
  * + d_lich_status (0 none here, 1 CRC bad, 2 CRC good: M17finalizeLICH), then the buffer is cleared.  d_assembly32 [B][32] is the carried

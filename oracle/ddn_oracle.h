@@ -381,6 +381,13 @@ void orc_fsk4rx_get_thresholds(const orc_fsk4rx* r, float out7[7]);
 uint16_t orc_ysf_crc16(const uint8_t* bits, int len);
 uint32_t orc_ysf_soft_viterbi(const uint8_t* dibits, int n, int decoded_bytes, int offset_bits, int output_bits, uint8_t* out_bits);
 int orc_ysf_fich(const uint8_t in100[100], uint8_t fich32[32], uint32_t* v_error);
+int orc_ysf_vd2_index(int k);
+int orc_ysf_pn95_bit(int i);
+void orc_ysf_dewhiten(uint8_t* bits, int n);
+int orc_ysf_vd2_voice(const uint8_t dibits52[52], uint8_t ambe_d[49]);
+int orc_ysf_dch(const uint8_t* in, int n, uint8_t* out_bytes, uint32_t* v_error);
+int orc_ysf_payload(const uint8_t p[360], int fi, int dt, uint8_t dch[2][20], uint8_t dch_status[2], uint32_t dch_cost[2],
+                    uint8_t ambe_d[5][49], uint8_t errs2[5]);
 
 /* ---- M17 frames behind the loop (oracle/ddn_oracle_m17.c) ---------------------------------------------------------- */
 int orc_m17_rand_bit(int i);

@@ -89,3 +89,143 @@ orc_ysf_fich(const uint8_t in100[100], uint8_t fich32[32], uint32_t* v_error) {
     memcpy(fich32, fich, 32);
     return err;
 }
+
+/* ---- the frame's payload behind the FICH (round 5): V/D mode 2 voice channel bits, the data channels, the dispatch ----------------
+ *   dsd_ysf_vd2_interleave_index / dsd_ysf_pn95_bit / dsd_ysf_dewhiten_bits   src/protocol/ysf/ysf_frame.c:33-73 (26 x 4 bit matrix;
+ *                     PN9 x^9 + x^4 + 1 seeded 0x1C9, LSB out, restarted every 512 bits) - checked against the compiled file and the
+ *                     numbers tests/protocol/ysf/test_ysf_frame.c asserts (tests/test_oracle_ysf.py)
+ *   ysf_read_type2_vech_bits / ysf_build_type2_ambe   ysf.c:687-722: 52 dibits -> 104 de-interleaved, de-whitened bits -> 27 majority
+ *                     votes over bit triples + 22 plain bits = the 49 AMBE parameter bits; errs2 = bit 103
+ *   ysf_conv_dch2 / ysf_conv_dch   ysf.c:245-355: dibit de-interleave 20 x 5 / 20 x 9 -> dsd_ysf_soft_viterbi_decode(100, 13, 8, 96) /
+ *                     (180, 23, 8, 176) -> ysf_crc16 over all decoded bits (0 = good) -> de-whiten the 80 / 160 data bits -> 10 / 20 bytes
+ *   ysf_parse_fich's fall-back + ysf_dispatch_payload   ysf.c:512-556, 908-922: a frame whose FICH failed is read as the last good
+ *                     frame's type; FI = 1: DT 0 -> V/D1 (5 x 36 data + 36 voice dibits), DT 2 -> V/D2 (5 x 20 data + 52 voice),
+ *                     DT 3 -> full-rate voice; DT = 1 or FI = 0 / 2 -> full-rate data (10 x 36 dibits, two DCH blocks in turn)
+ * PARITY STATUS of this part: the primitives are pinned to the compiled ysf_frame.c; ysf.c's callers are restated (ysf.c needs the
+ * engine and the vocoder).  The reference's capture is V/D2: its DCH2 blocks pass CRC16 through this path (tests/test_oracle_ysf.py). */
+int
+orc_ysf_vd2_index(int k) {
+    return (k % 4) * 26 + k / 4;
+}
+
+static int
+pn95_next(unsigned* lfsr) {
+    const int bit = (int)(*lfsr & 1u);
+    const unsigned fb = ((*lfsr >> 4) ^ *lfsr) & 1u;
+    *lfsr = (*lfsr >> 1) | (fb << 8);
+    return bit;
+}
+
+int
+orc_ysf_pn95_bit(int i) {
+    unsigned l = 0x1C9;
+    i %= 512;
+    for (int k = 0; k < i; k++) {
+        (void)pn95_next(&l);
+    }
+    return pn95_next(&l);
+}
+
+void
+orc_ysf_dewhiten(uint8_t* bits, int n) {
+    int off = 0;
+    while (off < n) {
+        unsigned l = 0x1C9;
+        for (int i = 0; i < 512 && off < n; i++, off++) {
+            bits[off] = (uint8_t)(bits[off] ^ pn95_next(&l));
+        }
+    }
+}
+
+/* 52 voice-channel dibits of one V/D2 sub-frame -> ambe_d[49]; returns errs2 (= de-whitened bit 103) */
+int
+orc_ysf_vd2_voice(const uint8_t dibits52[52], uint8_t ambe_d[49]) {
+    static const uint8_t majority[8] = {0, 0, 0, 1, 0, 1, 1, 1};
+    uint8_t v[104];
+    int k = 0;
+    for (int j = 0; j < 52; j++) {
+        const int msb = orc_ysf_vd2_index(k++), lsb = orc_ysf_vd2_index(k++);
+        v[msb] = (uint8_t)(((dibits52[j] >> 1) & 1) ^ orc_ysf_pn95_bit(msb));
+        v[lsb] = (uint8_t)((dibits52[j] & 1) ^ orc_ysf_pn95_bit(lsb));
+    }
+    for (int t = 0; t < 27; t++) {
+        ambe_d[t] = majority[(v[3 * t] << 2) | (v[3 * t + 1] << 1) | v[3 * t + 2]];
+    }
+    for (int j = 0; j < 22; j++) {
+        ambe_d[27 + j] = v[81 + j];
+    }
+    return v[103];
+}
+
+/* ysf_conv_dch2 (n = 100) / ysf_conv_dch (n = 180): out = 10 / 20 de-whitened bytes; returns 1 good, 3 CRC16 failed */
+int
+orc_ysf_dch(const uint8_t* in, int n, uint8_t* out_bytes, uint32_t* v_error) {
+    uint8_t buf[180], tb[192];
+    const int cols = n / 20, nbits = n == 100 ? 96 : 176, nbytes = n == 100 ? 13 : 23;
+    for (int i = 0; i < 20; i++) {
+        for (int j = 0; j < cols; j++) {
+            buf[j + i * cols] = in[i + j * 20];
+        }
+    }
+    memset(tb, 0, sizeof(tb));
+    const uint32_t ve = orc_ysf_soft_viterbi(buf, n, nbytes, 8, nbits, tb);
+    if (v_error) {
+        *v_error = ve;
+    }
+    const int st = orc_ysf_crc16(tb, nbits) == 0 ? 1 : 3;
+    orc_ysf_dewhiten(tb, nbits - 16);
+    for (int i = 0; i < (nbits - 16) / 8; i++) {
+        int b = 0;
+        for (int k = 0; k < 8; k++) {
+            b = (b << 1) | tb[8 * i + k];
+        }
+        out_bytes[i] = (uint8_t)b;
+    }
+    return st;
+}
+
+/* One frame's payload (the 360 dibits behind the FICH) by the type the frame is read as: kind = 1 V/D1, 2 V/D2, 4 full-rate voice,
+ * 8 full-rate data (ysf_dispatch_payload: several can apply - FI = 0 / 2 with DT = 1 is one full-rate data pass - so a bit mask);
+ * dch[2][20] / dch_status[2] / dch_cost[2]: V/D2 -> block 0 = DCH2 (10 bytes); V/D1 -> block 0 = DCH (20 bytes); full-rate data ->
+ * both blocks; ambe_d[5][49] + errs2[5] for V/D2.  The voice frames of V/D1 and full-rate voice are not restated. */
+int
+orc_ysf_payload(const uint8_t p[360], int fi, int dt, uint8_t dch[2][20], uint8_t dch_status[2], uint32_t dch_cost[2],
+                uint8_t ambe_d[5][49], uint8_t errs2[5]) {
+    int kind = 0;
+    uint8_t d[180];
+    memset(dch, 0, 40);
+    dch_status[0] = dch_status[1] = 0;
+    dch_cost[0] = dch_cost[1] = 0;
+    memset(ambe_d, 0, 5 * 49);
+    memset(errs2, 0, 5);
+    if (fi == 1 && dt == 0) {
+        kind |= 1;
+        for (int i = 0; i < 5; i++) {
+            memcpy(d + 36 * i, p + 72 * i, 36);
+        }
+        dch_status[0] = (uint8_t)orc_ysf_dch(d, 180, dch[0], &dch_cost[0]);
+    }
+    if (fi == 1 && dt == 2) {
+        kind |= 2;
+        for (int i = 0; i < 5; i++) {
+            memcpy(d + 20 * i, p + 72 * i, 20);
+            errs2[i] = (uint8_t)orc_ysf_vd2_voice(p + 72 * i + 20, ambe_d[i]);
+        }
+        dch_status[0] = (uint8_t)orc_ysf_dch(d, 100, dch[0], &dch_cost[0]);
+    }
+    if (fi == 1 && dt == 3) {
+        kind |= 4;
+    }
+    if (dt == 1 || fi == 0 || fi == 2) { /* (after a V/D pass of the same frame the reference reads on: not restated - see kind) */
+        kind |= 8;
+        if (kind == 8) {
+            for (int b = 0; b < 2; b++) {
+                for (int i = 0; i < 5; i++) {
+                    memcpy(d + 36 * i, p + 36 * (2 * i + b), 36);
+                }
+                dch_status[b] = (uint8_t)orc_ysf_dch(d, 180, dch[b], &dch_cost[b]);
+            }
+        }
+    }
+    return kind;
+}

@@ -60,3 +60,50 @@ def test_ysf_capture_known_answer(built):
     for a, b in zip(good[:-1], good[1:]):
         if b["pos"] - a["pos"] == 480:
             assert b["fields"]["fn"] == (a["fields"]["fn"] + 1) % (a["fields"]["ft"] + 1), (a["pos"], a["fields"], b["fields"])
+
+
+def test_payload_primitives_equal_the_compiled_reference_and_its_test_numbers(built):
+    o = orc.oracle()
+    # what tests/protocol/ysf/test_ysf_frame.c asserts (:73-80, :85)
+    assert [o.orc_ysf_vd2_index(k) for k in (0, 1, 2, 3, 4, 99, 100, 103)] == [0, 26, 52, 78, 1, 102, 25, 103]
+    assert [o.orc_ysf_pn95_bit(i) for i in range(16)] == [1, 0, 0, 1, 0, 0, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1]
+    assert o.orc_ysf_pn95_bit(512) == 1
+    r = orc.ref()
+    if r is None:
+        pytest.skip("oracle/_ref not built")
+    r.dsd_ysf_vd2_interleave_index.argtypes = [C.c_size_t]
+    r.dsd_ysf_vd2_interleave_index.restype = C.c_uint8
+    r.dsd_ysf_pn95_bit.argtypes = [C.c_size_t]
+    r.dsd_ysf_pn95_bit.restype = C.c_uint8
+    r.dsd_ysf_dewhiten_bits.argtypes = [C.c_void_p, C.c_size_t]
+    o.orc_ysf_dewhiten.argtypes = [C.c_void_p, C.c_int]
+    assert [o.orc_ysf_vd2_index(k) for k in range(104)] == [r.dsd_ysf_vd2_interleave_index(k) for k in range(104)]
+    assert [o.orc_ysf_pn95_bit(k) for k in range(1100)] == [r.dsd_ysf_pn95_bit(k) for k in range(1100)]
+    rng = np.random.default_rng(3)
+    for n in (80, 160, 511, 512, 513, 1200):
+        a = rng.integers(0, 2, n).astype(np.uint8)
+        b = a.copy()
+        r.dsd_ysf_dewhiten_bits(a.ctypes.data, n)
+        o.orc_ysf_dewhiten(b.ctypes.data, n)
+        assert np.array_equal(a, b), n
+
+
+def test_ysf_capture_payloads(built):
+    """the capture is V/D mode 2: behind every frame five voice sub-frames and the 100-dibit data channel; the data channel of the
+    frames with a good FICH passes CRC16 in most of them (a weak capture), and the blocks that pass repeat their text fields"""
+    disc = rx4.capture_disc("iq_ysf.npz", 2)
+    out = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_YSF)).run(disc, max_sync=2048)
+    fr, last = ysf.decode_payloads(out)
+    full = [f for f in fr if f["payload"] is not None]
+    assert len(full) >= 40 and all(f["payload"]["kind"] == 2 for f in full if f["dt"] == 2 and f["fi"] == 1)
+    vd2 = [f for f in full if f["payload"]["kind"] == 2]
+    assert len(vd2) >= 0.9 * len(full)                                   # frames with a failed FICH are read as the last good type
+    good = [f for f in vd2 if f["payload"]["dch_status"][0] == 1]
+    assert len(good) >= 8, (len(good), len(vd2))
+    assert last == (2, 1)
+    # a block that passes CRC16 is ten bytes of text or addresses: the same frame number of the next round carries the same block
+    seen = {}
+    for f in good:
+        seen.setdefault(bytes(f["payload"]["dch"][0, :10]), 0)
+        seen[bytes(f["payload"]["dch"][0, :10])] += 1
+    assert max(seen.values()) >= 2, seen

@@ -131,3 +131,128 @@ def test_ysf_capture_through_the_chain_object(built):
                 assert ysf.summary(ysf.fields(np.unpackbits(g["f4"]))) == "V/D2 RID Mode Repeater CC"
                 named += 1
     assert named >= 30
+
+
+def _payload_equal(info, dch, dst, dcost, ambe, errs, want, where):
+    pl = want["payload"]
+    flags = want["fi"] | (want["dt"] << 2) | (16 if want["err"] != 0 else 0) | 32
+    assert int(info[1]) == flags, (where, int(info[1]), flags)
+    if pl is None:
+        assert int(info[0]) == 0, where
+        return 0
+    assert int(info[0]) == pl["kind"], (where, int(info[0]), pl["kind"])
+    assert np.array_equal(dst, pl["dch_status"]) and np.array_equal(dcost, pl["dch_cost"]), (where, dst, pl["dch_status"])
+    assert np.array_equal(dch, pl["dch"]), where
+    if pl["kind"] == 2:
+        assert np.array_equal(ambe, pl["ambe_d"]) and np.array_equal(errs, pl["errs2"]), where
+    return int(pl["dch_status"][0] == 1) + int(pl["dch_status"][1] == 1)
+
+
+def test_payload_on_the_device_equals_the_restatement(built):
+    """the capture (V/D mode 2) + the same records read as the other frame types: a second and a third channel whose FICH bytes are
+    replaced before the payload call (FI / DT of a V/D mode 1 frame, of a header) - every branch of ysf_dispatch_payload()"""
+    import torch
+    l = ddn.lib()
+    disc = rx4.capture_disc("iq_ysf.npz", 2)
+    x = np.stack([disc, disc, disc, np.roll(disc, 5)])
+    B, n = x.shape
+    d = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    rx = ddn.Fsk4Rx(B, ddn.FSK4_YSF)
+    ms, my = l.ddn_fsk4_rx_max_symbols(rx.h, n), l.ddn_fsk4_rx_max_syncs(rx.h, n)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+    rec, fl, pay = z((B, ms, 10), torch.uint8), z((B, ms), torch.uint8), z((B, ms, 2), torch.uint8)
+    cnt, ns, spos = z((B,), torch.int32), z((B,), torch.int32), z((B, my), torch.int32)
+    spat, pre, prel = z((B, my), torch.uint8), z((B, my, 90), torch.uint8), z((B, my, 90), torch.uint8)
+    p = lambda t: t.data_ptr()
+    assert l.ddn_fsk4_rx_run(rx.h, p(d), n, p(rec), p(fl), p(pay), p(cnt), ms, p(spos), p(spat), p(pre), p(prel), p(ns), my, None) == 0
+    f4, st, ve = z((B, my, 4), torch.uint8), z((B, my), torch.uint8), z((B, my), torch.int32)
+    assert l.ddn_ysf_fich_decode_batch(p(rec), ms, p(cnt), p(spos), p(ns), B, my, p(f4), p(st), p(ve), None) == 0, l.ddn_last_error()
+    # channel 1: every good FICH says FI 1 / DT 0 (V/D mode 1); channel 2: FI 0 / DT 1 and FI 2 (header, terminator: full-rate data),
+    # one frame in seven DT 3 (full-rate voice: named, not decoded)
+    f4h = f4.cpu().numpy()
+    f4h[1, :, 0] = (f4h[1, :, 0] & 0x3F) | (1 << 6)
+    f4h[1, :, 2] &= 0xFC
+    f4h[2, :, 0] = (f4h[2, :, 0] & 0x3F) | np.where(np.arange(my) % 3 == 0, 2 << 6, 0).astype(np.uint8)
+    f4h[2, :, 2] = (f4h[2, :, 2] & 0xFC) | 1
+    k7 = np.arange(my) % 7 == 3
+    f4h[2, k7, 0] = (f4h[2, k7, 0] & 0x3F) | (1 << 6)
+    f4h[2, k7, 2] |= 3
+    f4 = torch.from_numpy(f4h).cuda()
+    last = z((B, 2), torch.uint8)
+    info, dch, dst = z((B, my, 2), torch.uint8), z((B, my, 2, 20), torch.uint8), z((B, my, 2), torch.uint8)
+    dcost, ambe, errs = z((B, my, 2), torch.int32), z((B, my, 5, 49), torch.uint8), z((B, my, 5), torch.uint8)
+    assert l.ddn_ysf_payload_decode_batch(p(rec), ms, p(cnt), p(spos), p(ns), B, my, p(f4), p(st), p(last), p(info), p(dch), p(dst), p(dcost),
+                                          p(ambe), p(errs), None) == 0, l.ddn_last_error()
+    torch.cuda.synchronize()
+    g = lambda t: t.cpu().numpy()
+    st, info, dch, dst, dcost, ambe, errs, last = g(st), g(info), g(dch), g(dst), g(dcost).view(np.uint32), g(ambe), g(errs), g(last)
+    nsy, pos, cn, rc = g(ns), g(spos), g(cnt), g(rec)
+    good, kinds = 0, set()
+    for c in range(B):
+        r4, _ = rec4_of(rc[c, :cn[c]])
+        dt, fi = 0, 0
+        for k in range(int(nsy[c])):
+            q = int(pos[c, k])
+            if st[c, k] == 0:
+                assert not info[c, k].any()
+                continue
+            if st[c, k] == 1:
+                dt, fi = int(f4h[c, k, 2] & 3), int(f4h[c, k, 0] >> 6)
+            pl = ysf.payload(r4[q + 101:q + 461, 0], fi, dt) if q + 461 <= cn[c] else None
+            want = dict(fi=fi, dt=dt, err=0 if st[c, k] == 1 else -1, payload=pl)
+            good += _payload_equal(info[c, k], dch[c, k], dst[c, k], dcost[c, k], ambe[c, k], errs[c, k], want, (c, k))
+            kinds.add(int(info[c, k, 0]))
+        assert (int(last[c, 0]), int(last[c, 1])) == (dt, fi), c
+    assert kinds >= {1, 2, 4, 8} and good >= 16, (kinds, good)
+
+
+def test_ysf_payload_through_the_chain_object(built):
+    """the capture in four calls + flush: every frame's payload is decoded in the call that holds its last dibit, the frame type is
+    carried from call to call - the same as processYSF() over the whole stream on the CPU"""
+    from conftest import golden
+    iq = np.ascontiguousarray(golden("iq_ysf.npz")["iq"], np.uint8)
+    n = 60000
+    calls = len(iq) // n
+    B = 2
+    x = np.stack([iq[:calls * n], np.roll(iq[:calls * n], 2 * 91)])
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_YSF, rf_mod=0, handlers=0, vocoder=0)
+    l = ddn.lib()
+    got = [[] for _ in range(B)]
+    base = np.zeros(B, np.int64)
+
+    def take():
+        r = ch.results()
+        S, T = r.max_syncs, r.carry_symbols
+        assert T >= 461
+        f = ch.fetch
+        ns, pos, st = f(r.d_n_sync, np.int32, (B,)), f(r.d_sync_pos, np.int32, (B, S)), f(r.d_ysf_fich_status, np.uint8, (B, S))
+        info, dch, dst = f(r.d_ysf_info2, np.uint8, (B, S, 2)), f(r.d_ysf_dch40, np.uint8, (B, S, 2, 20)), f(r.d_ysf_dch_status2, np.uint8, (B, S, 2))
+        dcost, ambe, errs = f(r.d_ysf_dch_cost2, np.uint32, (B, S, 2)), f(r.d_ysf_ambe49x5, np.uint8, (B, S, 5, 49)), f(r.d_ysf_errs2x5, np.uint8, (B, S, 5))
+        new = f(r.d_new, np.int32, (B,))
+        for c in range(B):
+            for k in range(int(ns[c])):
+                if st[c, k] != 0:
+                    got[c].append(dict(pos=int(base[c]) + int(pos[c, k]) - int(T), info=info[c, k].copy(), dch=dch[c, k].copy(),
+                                       dst=dst[c, k].copy(), dcost=dcost[c, k].copy(), ambe=ambe[c, k].copy(), errs=errs[c, k].copy()))
+            base[c] += int(new[c])
+
+    for k in range(calls):
+        part = np.ascontiguousarray(x[:, k * n:(k + 1) * n])
+        p = C.c_void_p()
+        assert l.ddn_device_alloc(part.nbytes, C.byref(p)) == 0 and l.ddn_device_upload(p, part.ctypes.data, part.nbytes) == 0
+        ch.run(p)
+        take()
+        l.ddn_device_free(p)
+    ch.flush()
+    take()
+    ch.close()
+    good = 0
+    for c in range(B):
+        fe = orc.OracleFrontEnd(profile=2)
+        disc = np.concatenate([fe.run_cu8(np.ascontiguousarray(x[c, k * n:(k + 1) * n]), 8192) for k in range(calls)])
+        want = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_YSF)).run(disc, max_sync=4096)
+        fr, _ = ysf.decode_payloads(want)
+        assert [g["pos"] for g in got[c]] == [f["pos"] for f in fr], (c, len(got[c]), len(fr))
+        for g, f in zip(got[c], fr):
+            good += _payload_equal(g["info"], g["dch"], g["dst"], g["dcost"], g["ambe"], g["errs"], f, (c, f["pos"]))
+    assert good >= 16

@@ -43,3 +43,37 @@ def decode_frames(out):
         err, bits, cost = fich(out["rec4"][pos + 1:pos + 101, 0])
         fr.append(dict(pos=pos, err=err, bits=bits, cost=cost, fields=fields(bits)))
     return fr
+
+
+def payload(dibits360, fi, dt):
+    """orc_ysf_payload -> dict(kind, dch[2][20], dch_status[2], dch_cost[2], ambe_d[5][49], errs2[5])"""
+    o = orc.oracle()
+    o.orc_ysf_payload.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+    o.orc_ysf_payload.restype = C.c_int
+    p = np.ascontiguousarray(dibits360, np.uint8)
+    dch, st, cost = np.zeros((2, 20), np.uint8), np.zeros(2, np.uint8), np.zeros(2, np.uint32)
+    ambe, errs = np.zeros((5, 49), np.uint8), np.zeros(5, np.uint8)
+    kind = o.orc_ysf_payload(p.ctypes.data, int(fi), int(dt), dch.ctypes.data, st.ctypes.data, cost.ctypes.data, ambe.ctypes.data,
+                             errs.ctypes.data)
+    return dict(kind=int(kind), dch=dch, dch_status=st, dch_cost=cost, ambe_d=ambe, errs2=errs)
+
+
+def decode_payloads(out, last=(0, 0), n_rec=None):
+    """processYSF() over a stream (ysf.c:924-938): every sync whose FICH lies inside the records is a frame; a frame whose FICH failed is
+    read as the last good frame's DT / FI (ysf_parse_fich's statics, :553-555); the payload is decoded when its 360 dibits lie inside
+    the records.  -> (list of dict(pos, err, fi, dt, payload | None), last)"""
+    n = len(out["rec4"]) if n_rec is None else n_rec
+    last_dt, last_fi = last
+    fr = []
+    for pos in out["sync_pos"]:
+        pos = int(pos)
+        if pos + 101 > n:
+            continue
+        err, bits, cost = fich(out["rec4"][pos + 1:pos + 101, 0])
+        if err == 0:
+            f = fields(bits)
+            last_dt, last_fi = f["dt"], f["fi"]
+        dt, fi = last_dt, last_fi
+        pl = payload(out["rec4"][pos + 101:pos + 461, 0], fi, dt) if pos + 461 <= n else None
+        fr.append(dict(pos=pos, err=err, fi=fi, dt=dt, payload=pl))
+    return fr, (last_dt, last_fi)
