@@ -215,7 +215,8 @@ def m17_ysf_chains(torch, ddn, np, n):
     """The two consumers of the libM17-style K = 5 decoder as chain objects (ddn_fsk4_chain, protocols M17 and YSF; informational):
     1365 channels (a third of the headline batch, as a configs[3] group) x n cu8 samples of the reference's own captures, every channel
     a different rotation; I/Q resident -> front end -> loop -> every frame behind every sync (M17: LSF + stream frames + LICH
-    reassembly; YSF: the frame information channel).  Known answers on the device outputs before the timed steps."""
+    reassembly; YSF: the frame information channel, the payload behind it - V/D mode 2 voice bits -> AMBE synthesis, the DCH2 data
+    channel).  Known answers on the device outputs before the timed steps."""
     import ctypes as C
     from conftest import golden
     dev = torch.device("cuda")
@@ -226,7 +227,7 @@ def m17_ysf_chains(torch, ddn, np, n):
         m = iq.shape[0]
         off = (torch.arange(B, device=dev) * 37) % (m - n)
         x = iq[off[:, None] + torch.arange(n, device=dev)[None, :]].contiguous()
-        ch = ddn.Fsk4ChainC(B, n, proto, rf_mod=0, handlers=0, vocoder=0)
+        ch = ddn.Fsk4ChainC(B, n, proto, rf_mod=0, handlers=0, vocoder=1 if name == "ysf" else 0)
         ch.run(x.data_ptr())          # (the known answers are read off this first call: replaying the buffer puts a seam into the stream)
         torch.cuda.synchronize()
         r = ch.results()
@@ -249,6 +250,12 @@ def m17_ysf_chains(torch, ddn, np, n):
             out[name] = {"fich_crc_good": int(len(good)), "fich_crc_bad": int((fs == 3).sum()),
                          "all_good_fich_read_vd2_rid_repeater_cc": bool(len(good) > 0 and np.all(v(22, 2) == 2) and np.all(v(4, 2) == 1)
                                                                         and np.all(bits[:, 21] == 1) and np.all(v(0, 2) == 1))}
+            info = ch.fetch(r.d_ysf_info2, np.uint8, (S, 2))
+            dst = ch.fetch(r.d_ysf_dch_status2, np.uint8, (S, 2))
+            nv = ch.fetch(r.d_ysf_n_voice, np.int32, (B,))
+            out[name].update({"frames_with_payload_decoded": int((info[:, 0] != 0).sum()), "vd2_frames": int((info[:, 0] == 2).sum()),
+                              "dch2_crc_good": int((dst[:, 0] == 1).sum()), "dch2_crc_bad": int((dst[:, 0] == 3).sum()),
+                              "voice_subframes_synthesized": int(nv.sum()) * 5})
         ch.run(x.data_ptr())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -516,7 +516,8 @@ class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
         (k, C.c_void_p) for k in ("d_sync_thr5", "d_m17_lsf30", "d_m17_lsf_status", "d_m17_lsf_cost", "d_m17_lich6", "d_m17_lich_cnt",
                                   "d_m17_fn_payload18", "d_m17_str_status", "d_m17_lich_lsf30", "d_m17_lich_status", "d_ysf_fich4",
                                   "d_ysf_fich_status", "d_ysf_fich_cost", "d_ysf_info2", "d_ysf_dch40", "d_ysf_dch_status2",
-                                  "d_ysf_dch_cost2", "d_ysf_ambe49x5", "d_ysf_errs2x5")]
+                                  "d_ysf_dch_cost2", "d_ysf_ambe49x5", "d_ysf_errs2x5")] + [("ysf_voice_frames", C.c_int)] + [
+        (k, C.c_void_p) for k in ("d_ysf_n_voice", "d_ysf_voice_slot", "d_ysf_voice_result", "d_ysf_pcm")]
 
 
 class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config

@@ -660,6 +660,58 @@ k_ysf_dch_finish(const uint8_t* __restrict__ decA, const uint32_t* __restrict__ 
     dch_cost[so * 2 + blk] = vd2 ? pcA[slot] : pcB[slot * 2 + blk];
 }
 
+// V/D mode 2 voice of a call filed by talk path (= channel): the voice sub-frames of the channel's frames in stream order -> bits
+// [c][vf5][49], result rows {flags 0, c0 0, c4 0, total = protected = errs2} (ysf_handle_vd_type2, ysf.c:745-752), skip flags behind the
+// last one, v_n[c] = frames filed, v_slot[c][j] = the sync slot frame j came from.  One wavefront per channel.
+__global__ __launch_bounds__(64) void
+k_ysf_voice_file(const int32_t* __restrict__ n_sync, int max_syncs, const uint8_t* __restrict__ info, const uint8_t* __restrict__ ambe49,
+                 const uint8_t* __restrict__ errs2, int vf, uint8_t* __restrict__ bits, int32_t* __restrict__ res, uint8_t* __restrict__ skip,
+                 int32_t* __restrict__ v_n, int32_t* __restrict__ v_slot) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    int ns = n_sync[c];
+    ns = ns < max_syncs ? ns : max_syncs;
+    int j = 0;
+    for (int k0 = 0; k0 < ns; k0 += 64) {
+        const int k = k0 + lane;
+        const bool is = k < ns && (info[2 * ((size_t)c * max_syncs + k)] & 2) != 0;
+        unsigned long long b = __ballot(is);
+        while (b && j < vf) {
+            const int kk = k0 + __ffsll((long long)b) - 1;
+            b &= b - 1;
+            const size_t so = (size_t)c * max_syncs + kk, d0 = ((size_t)c * vf + j) * 5;
+            for (int t = lane; t < 5 * 49; t += 64) {
+                bits[d0 * 49 + t] = ambe49[so * 5 * 49 + t];
+            }
+            if (lane < 5) {
+                const int e = errs2[so * 5 + lane];
+                int32_t* r = res + (d0 + lane) * 5;
+                r[0] = 0, r[1] = 0, r[2] = 0, r[3] = e, r[4] = e;
+                skip[d0 + lane] = 0;
+            }
+            if (lane == 0) {
+                v_slot[(size_t)c * vf + j] = kk;
+            }
+            j++;
+        }
+    }
+    if (lane == 0) {
+        v_n[c] = j;
+    }
+    for (int t = 5 * j + lane; t < 5 * vf; t += 64) {
+        skip[(size_t)c * vf * 5 + t] = 1;
+        int32_t* r = res + ((size_t)c * vf * 5 + t) * 5;
+        r[0] = 0, r[1] = 0, r[2] = 0, r[3] = 0, r[4] = 0;
+    }
+}
+
+extern "C" hipError_t
+ddn_dev_ysf_voice_file(const int32_t* n_sync, int n_channels, int max_syncs, const uint8_t* info, const uint8_t* ambe49, const uint8_t* errs2,
+                       int vf, uint8_t* bits, int32_t* res, uint8_t* skip, int32_t* v_n, int32_t* v_slot, hipStream_t st) {
+    hipLaunchKernelGGL(k_ysf_voice_file, dim3((unsigned)n_channels), dim3(64), 0, st, n_sync, max_syncs, info, ambe49, errs2, vf, bits, res,
+                       skip, v_n, v_slot);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t
 ddn_dev_ysf_plan(const int32_t* sync_pos, const int32_t* n_sync, const int32_t* counts, int n_channels, int max_syncs, int lmax,
                  const uint8_t* fich4, const uint8_t* fich_status, uint8_t* last2, uint8_t* info, int32_t* slot_sync, hipStream_t st) {

@@ -368,6 +368,12 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const uint32_t* d_ysf_dch_cost2;     /* [S][2] the decoder's path cost */
     const uint8_t* d_ysf_ambe49x5;       /* [S][5][49] V/D mode 2: ambe_d of the five voice sub-frames */
     const uint8_t* d_ysf_errs2x5;        /* [S][5] their errs2 */
+    /* ... V/D mode 2 voice through the vocoder (vocoder = 1; 0 / NULL otherwise): talk path = channel, the frames of a call in stream order */
+    int ysf_voice_frames;                /* F: frames (of five sub-frames) per channel and call the arrays below hold */
+    const int32_t* d_ysf_n_voice;        /* [n_channels] V/D mode 2 frames of this call */
+    const int32_t* d_ysf_voice_slot;     /* [n_channels][F] the sync slot each came from */
+    const int32_t* d_ysf_voice_result;   /* [n_channels][F * 5][5] mbe_process_result rows after synthesis */
+    const float* d_ysf_pcm;              /* [n_channels][F * 5][160] 8 kHz PCM (silence behind the last frame) */
 } ddn_fsk4_chain_results;
 typedef struct ddn_fsk4_chain ddn_fsk4_chain;
 int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);

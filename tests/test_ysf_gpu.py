@@ -256,3 +256,66 @@ def test_ysf_payload_through_the_chain_object(built):
         for g, f in zip(got[c], fr):
             good += _payload_equal(g["info"], g["dch"], g["dst"], g["dcost"], g["ambe"], g["errs"], f, (c, f["pos"]))
     assert good >= 16
+
+
+def test_ysf_vd2_voice_to_pcm_through_the_chain_object(built):
+    """vocoder = 1: the V/D mode 2 voice sub-frames of every channel go through AMBE 3600x2450 synthesis in stream order, talk path =
+    channel, the history carried across calls - PCM and result rows bit for bit against the CPU vocoder restatement fed with the
+    restated frames (the vocoder itself is unpinned: DESIGN 1, row a19)"""
+    import mbe
+    from conftest import golden
+    iq = np.ascontiguousarray(golden("iq_ysf.npz")["iq"], np.uint8)
+    n = 60000
+    calls = len(iq) // n
+    B = 2
+    x = np.stack([iq[:calls * n], np.roll(iq[:calls * n], 2 * 137)])
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_YSF, rf_mod=0, handlers=0, vocoder=1)
+    l = ddn.lib()
+    got = [[] for _ in range(B)]
+    base = np.zeros(B, np.int64)
+
+    def take():
+        r = ch.results()
+        S, T, F = r.max_syncs, r.carry_symbols, r.ysf_voice_frames
+        assert F >= 2
+        f = ch.fetch
+        pos, new = f(r.d_sync_pos, np.int32, (B, S)), f(r.d_new, np.int32, (B,))
+        nv, slot = f(r.d_ysf_n_voice, np.int32, (B,)), f(r.d_ysf_voice_slot, np.int32, (B, F))
+        res, pcm = f(r.d_ysf_voice_result, np.int32, (B, F * 5, 5)), f(r.d_ysf_pcm, np.float32, (B, F * 5, 160))
+        for c in range(B):
+            assert not pcm[c, 5 * nv[c]:].any()
+            for j in range(int(nv[c])):
+                got[c].append((int(base[c]) + int(pos[c, slot[c, j]]) - int(T), pcm[c, 5 * j:5 * j + 5].copy(), res[c, 5 * j:5 * j + 5].copy()))
+            base[c] += int(new[c])
+
+    for k in range(calls):
+        part = np.ascontiguousarray(x[:, k * n:(k + 1) * n])
+        p = C.c_void_p()
+        assert l.ddn_device_alloc(part.nbytes, C.byref(p)) == 0 and l.ddn_device_upload(p, part.ctypes.data, part.nbytes) == 0
+        ch.run(p)
+        take()
+        l.ddn_device_free(p)
+    ch.flush()
+    take()
+    ch.close()
+    total = 0
+    for c in range(B):
+        fe = orc.OracleFrontEnd(profile=2)
+        disc = np.concatenate([fe.run_cu8(np.ascontiguousarray(x[c, k * n:(k + 1) * n]), 8192) for k in range(calls)])
+        want = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_YSF)).run(disc, max_sync=4096)
+        fr, _ = ysf.decode_payloads(want)
+        voiced = [f for f in fr if f["payload"] is not None and f["payload"]["kind"] == 2]
+        assert [g[0] for g in got[c]] == [f["pos"] for f in voiced], (c, len(got[c]), len(voiced))
+        voc = mbe.OracleVocoder(ddn.MBE_AMBE, 1)
+        for g, f in zip(got[c], voiced):
+            bits = np.ascontiguousarray(f["payload"]["ambe_d"][None])
+            ri = np.zeros((1, 5, 5), np.int32)
+            ri[0, :, 3] = f["payload"]["errs2"]
+            ri[0, :, 4] = f["payload"]["errs2"]
+            pcm, ro = np.zeros((1, 5, 160), np.float32), np.zeros((1, 5, 5), np.int32)
+            assert mbe._o().om_process_batch(ddn.MBE_AMBE, C.addressof(voc.tab), bits.ctypes.data, ri.ctypes.data, 0, c, 1, 5, pcm.ctypes.data,
+                                             ro.ctypes.data, C.addressof(voc.cur), C.addressof(voc.prev), C.addressof(voc.enh)) == 0
+            assert np.array_equal(g[1].view(np.uint32), pcm[0].view(np.uint32)), (c, f["pos"], float(np.abs(g[1] - pcm[0]).max()))
+            assert np.array_equal(g[2], ro[0]), (c, f["pos"])
+            total += 5
+    assert total >= 200
