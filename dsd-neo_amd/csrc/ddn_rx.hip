@@ -2089,6 +2089,267 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     const bool fitsn = sp + whole - i0n <= tn;
                     hunt_wait = be & !fitsn & more;
                     unsigned long long bm = __ballot(be & fitsn);
+                    // ---- (round 5) two / four channels per recurrence wave: every hunting lane's pass at once ------------------------
+                    // A channel of such a wave has a ROW of 64 / LPR >= 16 lanes and a pass is at most 15 symbols, so every owner's
+                    // pass fits its own row: the owner's words are broadcast over its row, lane l of a row is symbol l of that row's
+                    // owner (mean, sign, history word, sync compare, stores, extrema), the owner lanes read their rows' results.  The
+                    // slip chain: one owner - the crossing mask by three wave-wide ballots and the chain on scalars (as before);
+                    // several owners (1.4 per pass on the bench traffic, 2.4 on voice calls whose frames end together) - the mask
+                    // 64 / LPR samples per owner and ballot, the chain per row on the vector unit (its words are uniform inside a row).
+                    if constexpr (LPR == 2 || LPR == 4) {
+                    if (__builtin_expect(bm != 0, 0)) {
+                        const long long bt0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
+                        constexpr int OW = 64 / LPR;
+                        constexpr int CAP = OW < 17 ? OW - 1 : 16; // (lane `m` of the row holds the start after the pass)
+                        constexpr unsigned long long GM = OW == 32 ? 0xFFFFFFFFull : 0xFFFFull;
+                        const int g = lane / OW, l = lane % OW;
+                        const bool gact = ((bm >> g) & 1ull) != 0;
+                        const int cln = rw * LPR + g;
+                        const int sp0 = __shfl(sp, g);
+                        const float cen_o = __shfl(s.center, g), ls_o = __shfl(s.lastsample, g);
+                        const float* pr = (__shfl(s.filter_on, g) ? &L.flt[cln][0] : &L.raw[cln][0]) + base;
+                        int m = 0, mypk = 0; // mypk: {start + 256, slip code, latch on entry + 1} of this lane's symbol
+                        if ((bm & (bm - 1)) == 0 || (cfg.dbg & 4096)) {
+                            // one owner at a time: wave-wide masks, scalar chain, the symbols' words written into the owner's row
+                            unsigned long long b2 = bm;
+                            while (b2) {
+                                const int ow = __ffsll((long long)b2) - 1;
+                                b2 &= b2 - 1;
+                                const int sp0s = __builtin_amdgcn_readlane(sp, ow), c0s = __builtin_amdgcn_readlane(s.hist_count, ow);
+                                const float cen_s = __shfl(s.center, ow), ls_s = __shfl(s.lastsample, ow);
+                                float hl = __shfl(s.maxref * 1.25f, ow), ll = __shfl(s.minref * 1.25f, ow);
+                                const float hl_n = __shfl(s.max * 1.25f, ow), ll_n = __shfl(s.min * 1.25f, ow);
+                                const float* prs = (__builtin_amdgcn_readlane(s.filter_on, ow) ? &L.flt[rw * LPR + ow][0] : &L.raw[rw * LPR + ow][0]) + base;
+                                int q = sp0s, sm = 0, jit = __builtin_amdgcn_readlane(s.jitter, ow);
+                                int lim = c0s < 8 ? 8 - c0s : CAP;
+                                for (int ph = 0; ph < 2; ph++) {
+                                    unsigned long long cm[3];
+                                    q = __builtin_amdgcn_readfirstlane(q);
+                                    sm = __builtin_amdgcn_readfirstlane(sm);
+                                    jit = __builtin_amdgcn_readfirstlane(jit);
+#pragma unroll
+                                    for (int r = 0; r < 3; r++) {
+                                        cm[r] = 0ull;
+                                        if (q + 64 * r < tn) {
+                                            const int a = q + lane + 64 * r;
+                                            bool hit = false;
+                                            if (a < tn) {
+                                                const float x = prs[a];
+                                                const float xp = (a == sp0s) ? ls_s : prs[a - 1];
+                                                hit = (x > cen_s) ? (!(x > hl) && xp < cen_s) : (!(x < ll) && xp > cen_s);
+                                            }
+                                            cm[r] = __ballot(hit);
+                                        }
+                                    }
+                                    bool full = false;
+                                    auto uni64 = [](unsigned long long v) {
+                                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+                                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+                                        return ((unsigned long long)hi << 32) | lo;
+                                    };
+                                    cm[0] = uni64(cm[0]);
+                                    cm[1] = uni64(cm[1]);
+                                    cm[2] = uni64(cm[2]);
+                                    while (sm < lim) {
+                                        const int c = (int)((i0tab >> (2 * (jit + 1))) & 3u), i0 = c - 1;
+                                        const int cnt = whole - i0;
+                                        if (q + cnt > tn) {
+                                            full = true;
+                                            break;
+                                        }
+                                        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mypk) : "s"((q + 256) | (c << 10) | ((jit + 1) << 12)), "s"(ow * OW + sm) : "m0");
+                                        const int k0 = i0 < 0 ? 1 : 0; // a crossing at symbol index -1 latches nothing
+                                        const uint32_t wv = (uint32_t)(cm[0] >> k0) & ((1u << (cnt - k0)) - 1u);
+                                        jit = wv ? i0 + k0 + (__ffs((int)wv) - 1) : -1;
+                                        cm[0] = (cm[0] >> cnt) | (cm[1] << (64 - cnt));
+                                        cm[1] = (cm[1] >> cnt) | (cm[2] << (64 - cnt));
+                                        cm[2] >>= cnt;
+                                        q += cnt;
+                                        sm++;
+                                    }
+                                    if (full || lim >= CAP) {
+                                        break;
+                                    }
+                                    lim = CAP;
+                                    hl = hl_n;
+                                    ll = ll_n;
+                                }
+                                // where the symbol after the pass starts, and the latch it starts with
+                                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mypk) : "s"((q + 256) | ((jit + 1) << 12)), "s"(ow * OW + sm) : "m0");
+                                m = g == ow ? sm : m;
+                            }
+                        } else {
+                            int jit = __shfl(s.jitter, g), q = sp0;
+                            float hl = __shfl(s.maxref * 1.25f, g), ll = __shfl(s.minref * 1.25f, g);
+                            int lim = __shfl(s.hist_count, g);
+                            lim = lim < 8 ? 8 - lim : CAP;
+                            bool gdone = !gact; // this row's chain has ended
+                            for (int ph = 0; ph < 2; ph++) {
+                                unsigned long long cm0 = 0ull, cm1 = 0ull, cm2 = 0ull;
+                                constexpr int PW = 64 / OW; // ballots per 64-bit word
+#pragma unroll 1
+                                for (int wd = 0; wd < 3; wd++) { // (one word at a time: PW loads in flight, not 192 / OW of them)
+                                    unsigned long long word = 0ull;
+#pragma unroll
+                                    for (int r = 0; r < PW; r++) {
+                                        const int a = q + l + OW * (wd * PW + r);
+                                        bool hit = false;
+                                        if (!gdone && a < tn) {
+                                            const float x = pr[a];
+                                            const float xp = (a == sp0) ? ls_o : pr[a - 1];
+                                            hit = (x > cen_o) ? (!(x > hl) && xp < cen_o) : (!(x < ll) && xp > cen_o);
+                                        }
+                                        word |= ((__ballot(hit) >> (g * OW)) & GM) << (OW * r);
+                                    }
+                                    cm0 = wd == 0 ? word : cm0;
+                                    cm1 = wd == 1 ? word : cm1;
+                                    cm2 = wd == 2 ? word : cm2;
+                                }
+                                bool full = false;
+                                while (true) {
+                                    const bool go = !gdone && !full && m < lim;
+                                    if (!__any(go)) {
+                                        break;
+                                    }
+                                    if (go) {
+                                        const int c = (int)((i0tab >> (2 * (jit + 1))) & 3u), i0 = c - 1;
+                                        const int cnt = whole - i0;
+                                        if (q + cnt > tn) {
+                                            full = true;
+                                        } else {
+                                            if (l == m) {
+                                                mypk = (q + 256) | (c << 10) | ((jit + 1) << 12);
+                                            }
+                                            const int k0 = i0 < 0 ? 1 : 0;
+                                            const uint32_t wv = (uint32_t)(cm0 >> k0) & ((1u << (cnt - k0)) - 1u);
+                                            jit = wv ? i0 + k0 + (__ffs((int)wv) - 1) : -1;
+                                            cm0 = (cm0 >> cnt) | (cm1 << (64 - cnt));
+                                            cm1 = (cm1 >> cnt) | (cm2 << (64 - cnt));
+                                            cm2 >>= cnt;
+                                            q += cnt;
+                                            m++;
+                                        }
+                                    }
+                                }
+                                if (ph == 1) {
+                                    break;
+                                }
+                                const float hl_n = __shfl(s.max * 1.25f, g), ll_n = __shfl(s.min * 1.25f, g);
+                                if (!gdone) {
+                                    if (full || lim >= CAP) {
+                                        gdone = true;
+                                    } else { // the eighth symbol of the hunt moved the crossing limits: the mask is taken again
+                                        lim = CAP;
+                                        hl = hl_n;
+                                        ll = ll_n;
+                                    }
+                                }
+                                if (!__any(!gdone)) {
+                                    break;
+                                }
+                            }
+                            if (l == m) {
+                                mypk = (q + 256) | ((jit + 1) << 12);
+                            }
+                        }
+                        // lane l of row g: symbol l of owner g
+                        const int myq = (mypk & 1023) - 256, myi0 = ((mypk >> 10) & 3) - 1, myjin = ((mypk >> 12) & 15) - 1;
+                        const int c0 = __shfl(s.hist_count, g);
+                        const uint32_t h0 = (uint32_t)__shfl((int)s.hist_bits, g);
+                        float sym = 0.0f;
+                        if (gact && l < m) {
+                            const float* pw = pr + myq + ((whole - 1) / 2 - 2 - myi0);
+                            float acc = 0.0f;
+#pragma unroll
+                            for (int w = 0; w < 5; w++) {
+                                acc += __builtin_amdgcn_fmed3f(pw[w], -inf, inf);
+                            }
+                            sym = acc / 5.0f;
+                        }
+                        const uint32_t sw = (uint32_t)((__ballot(gact && l < m && sym > 0.0f) >> (g * OW)) & GM);
+                        const int lj = l < 31 ? l : 31;
+                        const uint32_t hj = ((h0 << (lj + 1)) | __brev(sw << (31 - lj))) & 0xFFFFFFu;
+                        const bool syn = gact && l < m && (c0 + l + 1 >= 24) && (hj == kSyncBits || hj == (~kSyncBits & 0xFFFFFFu));
+                        const uint32_t smg = (uint32_t)((__ballot(syn) >> (g * OW)) & GM);
+                        if (smg) {
+                            m = __ffs((int)smg) - 1;
+                        }
+                        const int o_o = __shfl(o, g);
+                        const int sh_o = __shfl(s.shead, g), li_o = __shfl(s.lidx, g), si_o = __shfl(s.sidx, g);
+                        if (gact && l < m) { // symbol history, level window, extrema window, record
+                            int k = sh_o + l;
+                            L.sh[k >= 24 ? k - 24 : k][cln] = sym;
+                            k = li_o + l;
+                            L.lb[k >= 24 ? k - 24 : k][cln] = sym;
+                            L.sb[(si_o + l) & (SS - 1)][cln] = sym;
+                            const size_t oo = (size_t)(o_o + l);
+                            if (oo < max_sym) {
+                                const size_t cho = (size_t)(ch0 + cln);
+                                store_record(rec + (cho * max_sym + oo) * 10, flags + cho * max_sym + oo, sym, sym > 0.0f ? 1 : 3, 0, 0, 0, 0);
+                            }
+                        }
+                        float a1 = (gact && l < m) ? sym : inf, a2 = inf, b1 = (gact && l < m) ? sym : -inf, b2 = -inf;
+#pragma unroll
+                        for (int d = 1; d < 16; d <<= 1) { // (a pass is at most 16 symbols: lanes 0 .. 15 of the row)
+                            const float o1 = __shfl_xor(a1, d), o2 = __shfl_xor(a2, d), p1 = __shfl_xor(b1, d), p2 = __shfl_xor(b2, d);
+                            two_min_insert(o1, a1, a2);
+                            two_min_insert(o2, a1, a2);
+                            two_max_insert(p1, b1, b2);
+                            two_max_insert(p2, b1, b2);
+                        }
+                        // the owner lanes (lane = channel of this wave) read their row's results
+                        const int orow = (lane < LPR ? lane : 0) * OW;
+                        const int m_own = __shfl(m, orow);
+                        const int src1 = orow + (m_own > 0 ? m_own - 1 : 0);
+                        const int qf = __shfl(myq, orow + m_own), jf = __shfl(myjin, orow + m_own);
+                        const int il = __shfl(myi0, src1);
+                        const uint32_t hf = (uint32_t)__shfl((int)hj, src1);
+                        a1 = __shfl(a1, orow), a2 = __shfl(a2, orow), b1 = __shfl(b1, orow), b2 = __shfl(b2, orow);
+                        if (lane < LPR && (be & fitsn)) {
+                            if (m_own == 0) { // the next symbol completes a sync: the standard trip's
+                                blk_o = o;
+                            } else {
+                                const float* prow = (s.filter_on ? &L.flt[ln][0] : &L.raw[ln][0]) + base;
+                                const float lsf = prow[qf - 1];
+                                two_min_insert(a1, pc1, pc2);
+                                two_min_insert(a2, pc1, pc2);
+                                two_max_insert(b1, pc3, pc4);
+                                two_max_insert(b2, pc3, pc4);
+                                npc += m_own;
+                                wabs = fmaxf(wabs, fmaxf(fabsf(a1), fabsf(b1))); // the pass's smallest and largest symbol
+                                s.shead = (s.shead + m_own) % 24;
+                                s.scount = s.scount + m_own < 24 ? s.scount + m_own : 24;
+                                s.lidx = (s.lidx + m_own) % 24;
+                                s.level_count = s.level_count + m_own < 24 ? s.level_count + m_own : 24;
+                                s.sidx = (s.sidx + m_own) & (SS - 1);
+                                s.hist_bits = hf;
+                                s.hist_count = s.hist_count + m_own < 24 ? s.hist_count + m_own : 24;
+                                if (s.hist_count >= 8) {
+                                    s.maxref = s.max;
+                                    s.minref = s.min;
+                                }
+                                s.hunt_pos += m_own;
+                                s.span = whole;
+                                s.centre = (whole - 1) / 2;
+                                s.i = il;
+                                s.sum = 0.0f;
+                                s.count = 0;
+                                s.in_symbol = 0;
+                                s.jitter = jf;
+                                s.lastsample = lsf;
+                                sp = qf;
+                                o += m_own;
+                            }
+                        }
+                        if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { // the pass is no trip: its cycles are kept apart
+                            const long long now = (long long)clock64();
+                            dbg_sec[6] += now - bt0;
+                            dbg_sec[7]++;
+                            dbg_prev += now - bt0;
+                        }
+                        continue;
+                    }
+                    } else
                     if (__builtin_expect(bm != 0, 0)) {
                         const long long bt0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
                         while (bm) {
