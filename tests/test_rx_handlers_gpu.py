@@ -117,6 +117,30 @@ def test_every_frame_type_clean_and_noisy(built, cpw):
     assert (ev[:, 1] == 3).sum() > 10
 
 
+@pytest.mark.parametrize("cpw", [4, 8])
+def test_hunting_pass_of_all_rows_at_once_equals_one_owner_at_a_time(built, monkeypatch, cpw):
+    """two / four channels per recurrence wave: the lanes that hunt take the bulk hunting pass together, each in its own row of the
+    wavefront (ddn_rx.hip); the records, flags and decisions are those of the pass taken one owner after the other (DDN_RX_DBG bit
+    4096).  Channels whose frames end together and channels that lose their carrier make sure several lanes hunt at once."""
+    B, n = 32, 30000
+    x = np.zeros((B, n), np.float32)
+    for c in range(B):
+        s = _traffic(300 + c // 4, n, [90.0, 5000.0][c % 2])          # four neighbours carry the same frames: they hunt together
+        x[c, :len(s)] = s
+    x[9, 12000:] = 0.0
+    x[10, :9000] = 0.0
+    outs = []
+    for dbg in ("0", "4096"):
+        monkeypatch.setenv("DDN_RX_DBG", dbg)
+        rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=2048)
+        rec, fl, cnt = rx.run(x)
+        outs.append((rec.copy(), fl.copy(), cnt.copy(), rx.events.copy(), rx.n_events.copy(), rx.event_data.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    for c in (0, 9, 10, 31):
+        _check(outs[0][0], outs[0][1], outs[0][2], outs[0][3], outs[0][4], c, _oracle(x[c], 1), outs[0][5])
+
+
 def test_call_splits(built):
     """decisions, history ring and handler words carried across calls (a block straddling a call boundary)"""
     B = 6
