@@ -2289,14 +2289,24 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                             }
                         }
                         float a1 = (gact && l < m) ? sym : inf, a2 = inf, b1 = (gact && l < m) ? sym : -inf, b2 = -inf;
-#pragma unroll
-                        for (int d = 1; d < 16; d <<= 1) { // (a pass is at most 16 symbols: lanes 0 .. 15 of the row)
-                            const float o1 = __shfl_xor(a1, d), o2 = __shfl_xor(a2, d), p1 = __shfl_xor(b1, d), p2 = __shfl_xor(b2, d);
-                            two_min_insert(o1, a1, a2);
-                            two_min_insert(o2, a1, a2);
-                            two_max_insert(p1, b1, b2);
-                            two_max_insert(p2, b1, b2);
-                        }
+                        // (a pass is at most 16 symbols: lanes 0 .. 15 of the row = one DPP row; quad swaps, then the row rotated by 4 and
+                        // by 8 - every step joins disjoint sets of lanes, so no value is counted twice)
+#define DDN_ROW_STEP(ctl)                                                                                                                   \
+    do {                                                                                                                                    \
+        const float o1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), ctl, 0xF, 0xF, true));                           \
+        const float o2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a2), ctl, 0xF, 0xF, true));                           \
+        const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b1), ctl, 0xF, 0xF, true));                           \
+        const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b2), ctl, 0xF, 0xF, true));                           \
+        two_min_insert(o1, a1, a2);                                                                                                         \
+        two_min_insert(o2, a1, a2);                                                                                                         \
+        two_max_insert(p1, b1, b2);                                                                                                         \
+        two_max_insert(p2, b1, b2);                                                                                                         \
+    } while (0)
+                        DDN_ROW_STEP(0xB1);  // quad_perm [1,0,3,2]
+                        DDN_ROW_STEP(0x4E);  // quad_perm [2,3,0,1]
+                        DDN_ROW_STEP(0x124); // row_ror:4
+                        DDN_ROW_STEP(0x128); // row_ror:8
+#undef DDN_ROW_STEP
                         // the owner lanes (lane = channel of this wave) read their row's results
                         const int orow = (lane < LPR ? lane : 0) * OW;
                         const int m_own = __shfl(m, orow);
