@@ -1650,30 +1650,84 @@ template <int NT>
 __global__ __launch_bounds__(256) void
 k_fsk4_matched_filter(const float* __restrict__ in, long n, size_t stride, const float* __restrict__ hist,
                       float* __restrict__ out) {
-    constexpr int T = 1024;
-    __shared__ float X[T + NT];
+    // y[n] = sum_i taps[i] * x[n - (NT - 1) + i], products added oldest first, mul and add rounded separately (as the reference's
+    // loop compiles).  (round 5) two outputs per packed f32 operation, as k_p25_matched_filter (ddn_slicer.hip): the tile's input span
+    // sits in LDS as pairs at both alignments - E = (x[2m], x[2m+1]), O = (x[2m+1], x[2m+2]) - a thread owns eight consecutive outputs
+    // = four pairs, an even tap multiplies the E pairs, an odd tap the O pairs, and the pairs slide through registers: one LDS read
+    // and four packed mul + four packed add per tap and thread instead of eight reads, eight mul and eight add.  Every output's sum is
+    // formed in the same order as before.
+    typedef float mf2 __attribute__((ext_vector_type(2)));
+    constexpr int T = 1024, NP = (T + NT + 3) / 2, NH = NP / 4 + 2;
+    __shared__ mf2 E[4][NH], O[4][NH];
     const unsigned int* bits = NT == DDN_DMR_FILTER_TAPS ? ddn_dmr_filter_bits : ddn_nxdn48_filter_bits;
     const int ch = blockIdx.y;
     const long t0 = (long)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T + NT - 1; i += 256) {
+    const int tid = threadIdx.x; // 128 threads
+    auto sample = [&](int i) -> float { // x[i] of the tile's input span (past the call's end: 0)
         const long j = t0 - (NT - 1) + i;
-        float v;
         if (j < 0) {
-            v = hist[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1) + (NT - 1) + j];
-        } else {
-            v = j < n ? in[(size_t)ch * stride + j] : 0.0f;
+            return hist[(size_t)ch * (DDN_FSK4_MAX_TAPS - 1) + (NT - 1) + j];
         }
-        X[i] = v;
+        return j < n ? in[(size_t)ch * stride + j] : 0.0f;
+    };
+    for (int m = tid; m < NP; m += 128) {
+        const float a = sample(2 * m), b = sample(2 * m + 1), c = sample(2 * m + 2);
+        E[m & 3][m >> 2] = mf2{a, b};
+        O[m & 3][m >> 2] = mf2{b, c};
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < T; o += 256) {
-        float acc = 0.0f;
+    // this thread's outputs o .. o + 7, o = 8 * tid: pair index m0 = 4 * tid
+    mf2 e[4], q[4], acc[4];
 #pragma unroll
-        for (int i = 0; i < NT; i++) {
-            acc += __uint_as_float(bits[i]) * X[o + i];
+    for (int r = 0; r < 4; r++) {
+        e[r] = E[r][tid];
+        q[r] = O[r][tid];
+        acc[r] = mf2{0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int j = 0; j < (NT + 1) / 2; j++) {
+        {
+            const float t = __uint_as_float(bits[2 * j]);
+            const mf2 tt = {t, t};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[r] += tt * e[r];
+            }
         }
-        if (t0 + o < n) {
-            out[(size_t)ch * stride + t0 + o] = acc;
+        if (2 * j + 1 < NT) {
+            const float t = __uint_as_float(bits[2 * j + 1]);
+            const mf2 tt = {t, t};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[r] += tt * q[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            e[r] = e[r + 1];
+            q[r] = q[r + 1];
+        }
+        if (j + 1 < (NT + 1) / 2) { // pair 4 * tid + j + 4
+            e[3] = E[j & 3][tid + (j + 4) / 4];
+            q[3] = O[j & 3][tid + (j + 4) / 4];
+        }
+    }
+    const long o = t0 + 8 * tid;
+    float* dst = out + (size_t)ch * stride + o;
+    if (o + 7 < n) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            *(mf2*)&dst[2 * r] = acc[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (o + 2 * r < n) {
+                dst[2 * r] = acc[r].x;
+            }
+            if (o + 2 * r + 1 < n) {
+                dst[2 * r + 1] = acc[r].y;
+            }
         }
     }
 }
@@ -2315,9 +2369,9 @@ ddn_dev_fsk4_matched_filter(int nt, const float* in, long n, size_t stride, int 
     }
     const dim3 grid((unsigned)((n + 1023) / 1024), (unsigned)n_channels);
     if (nt == DDN_DMR_FILTER_TAPS) {
-        hipLaunchKernelGGL((k_fsk4_matched_filter<DDN_DMR_FILTER_TAPS>), grid, dim3(256), 0, st, in, n, stride, hist, out);
+        hipLaunchKernelGGL((k_fsk4_matched_filter<DDN_DMR_FILTER_TAPS>), grid, dim3(128), 0, st, in, n, stride, hist, out);
     } else if (nt == DDN_NXDN48_FILTER_TAPS) {
-        hipLaunchKernelGGL((k_fsk4_matched_filter<DDN_NXDN48_FILTER_TAPS>), grid, dim3(256), 0, st, in, n, stride, hist, out);
+        hipLaunchKernelGGL((k_fsk4_matched_filter<DDN_NXDN48_FILTER_TAPS>), grid, dim3(128), 0, st, in, n, stride, hist, out);
     } else {
         return hipErrorInvalidValue;
     }
