@@ -139,6 +139,29 @@ ddn_fec_viterbi_k5_batch(const uint16_t* d_soft, size_t n, int in_len, const uin
     return DDN_OK;
 }
 
+// the same for callers inside the library that know which code words they want (d_wanted [n], 0 = leave undecoded: the YSF payload's
+// dense decode lists are mostly empty for one of the two block lengths)
+extern "C" int
+ddn_fec_viterbi_k5_batch_wanted(const uint16_t* d_soft, size_t n, int in_len, const uint8_t* punct, int p_len, uint8_t* d_out,
+                                int out_stride, uint32_t* d_cost, const uint8_t* d_wanted, void* hip_stream) {
+    if (!d_soft || !d_out || in_len < 2) {
+        ddn_set_error("ddn_fec_viterbi_k5_batch: bad argument");
+        return DDN_EINVAL;
+    }
+    DdnPuncture pu;
+    int u_len = 0;
+    int rc = build_puncture(punct, p_len, in_len, &pu, &u_len);
+    if (rc != DDN_OK) {
+        return rc;
+    }
+    if (u_len > 244 * 2 || out_stride < (u_len / 2 + 3) / 8 + 1) {
+        ddn_set_error("viterbi_k5: %d soft bits / out_stride %d out of range", u_len, out_stride);
+        return DDN_ERANGE;
+    }
+    HIP_TRY(ddn_dev_k5_m17_wanted(d_soft, (int)n, in_len, u_len, &pu, d_out, out_stride, d_cost, d_wanted, (hipStream_t)hip_stream));
+    return DDN_OK;
+}
+
 extern "C" int
 ddn_p25p1_nid_decode_batch(const uint8_t* d_bits63, const uint8_t* d_rel63, const int32_t* d_observed_nac,
                            const uint8_t* d_parity, const uint8_t* d_parity_rel, int erasure_threshold, size_t n,

@@ -188,7 +188,10 @@ extern "C" hipError_t ddn_dev_ysf_plan(const int32_t* sync_pos, const int32_t* n
                                        int32_t* slot_sync, hipStream_t st);
 extern "C" hipError_t ddn_dev_ysf_payload_costs(const uint8_t* rec, size_t stride, const int32_t* sync_pos, int n_channels, int max_syncs,
                                                 int lmax, const uint8_t* info, const int32_t* slot_sync, uint16_t* cost200,
-                                                uint16_t* cost360, uint8_t* ambe49, uint8_t* errs2, hipStream_t st);
+                                                uint16_t* cost360, uint8_t* ambe49, uint8_t* errs2, uint8_t* want200, uint8_t* want360,
+                                                hipStream_t st);
+extern "C" int ddn_fec_viterbi_k5_batch_wanted(const uint16_t* d_soft, size_t n, int in_len, const uint8_t* punct, int p_len, uint8_t* d_out,
+                                               int out_stride, uint32_t* d_cost, const uint8_t* d_wanted, void* hip_stream);
 extern "C" hipError_t ddn_dev_ysf_dch_finish(const uint8_t* decA, const uint32_t* pcA, const uint8_t* decB, const uint32_t* pcB,
                                              const int32_t* slot_sync, const uint8_t* info, int n_channels, int lmax, int max_syncs,
                                              uint8_t* dch40, uint8_t* dch_status, uint32_t* dch_cost, hipStream_t st);
@@ -210,12 +213,14 @@ ddn_ysf_payload_decode_batch(const uint8_t* d_records10, size_t stride_symbols, 
     const int lmax = (int)(stride_symbols / 480 + 2);
     const size_t S = (size_t)n_channels * (size_t)lmax, SO = (size_t)n_channels * max_syncs;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_cA = up(S * 200 * sizeof(uint16_t)), b_cB = up(S * 2 * 360 * sizeof(uint16_t)), b_dA = up(S * 16), b_dB = up(S * 2 * 32),
+    const size_t b_cA = up(S * 200 * sizeof(uint16_t)), b_cB = up(S * 2 * 360 * sizeof(uint16_t) + S * 3), b_dA = up(S * 16), b_dB = up(S * 2 * 32),
                  b_pA = up(S * sizeof(uint32_t)), b_pB = up(S * 2 * sizeof(uint32_t)), b_slot = up(S * sizeof(int32_t));
     uint8_t* scratch = nullptr;
     HIP_TRY(hipMallocAsync((void**)&scratch, b_cA + b_cB + b_dA + b_dB + b_pA + b_pB + b_slot, st));
     uint16_t* cA = (uint16_t*)scratch;
     uint16_t* cB = (uint16_t*)(scratch + b_cA);
+    uint8_t* wA = scratch + b_cA + S * 2 * 360 * sizeof(uint16_t); // which code words of the two lists hold a block (cleared with the costs)
+    uint8_t* wB = wA + S;
     uint8_t* dA = scratch + b_cA + b_cB;
     uint8_t* dB = dA + b_dA;
     uint32_t* pA = (uint32_t*)(dB + b_dB);
@@ -241,14 +246,14 @@ ddn_ysf_payload_decode_batch(const uint8_t* d_records10, size_t stride_symbols, 
     }
     if (e == hipSuccess) {
         e = ddn_dev_ysf_payload_costs(d_records10, stride_symbols, d_sync_pos, n_channels, (int)max_syncs, lmax, d_info2, slot, cA, cB,
-                                      d_ambe49x5, d_errs2x5, st);
+                                      d_ambe49x5, d_errs2x5, wA, wB, st);
     }
     static const uint8_t none[4] = {1, 1, 1, 1}; // DSD_YSF_PUNCTURE_NONE
     if (e == hipSuccess) {
-        rc = ddn_fec_viterbi_k5_batch(cA, S, 200, none, 4, dA, 16, pA, st);
+        rc = ddn_fec_viterbi_k5_batch_wanted(cA, S, 200, none, 4, dA, 16, pA, wA, st);
     }
     if (e == hipSuccess && rc == DDN_OK) {
-        rc = ddn_fec_viterbi_k5_batch(cB, S * 2, 360, none, 4, dB, 32, pB, st);
+        rc = ddn_fec_viterbi_k5_batch_wanted(cB, S * 2, 360, none, 4, dB, 32, pB, wB, st);
     }
     if (e == hipSuccess && rc == DDN_OK) {
         e = ddn_dev_ysf_dch_finish(dA, pA, dB, pB, slot, d_info2, n_channels, lmax, (int)max_syncs, d_dch40, d_dch_status2, d_dch_cost2, st);

@@ -309,6 +309,8 @@ hipError_t ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_
                            uint8_t* out, int out_stride, hipStream_t st);
 hipError_t ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out,
                           int out_stride, uint32_t* cost, hipStream_t st);
+hipError_t ddn_dev_k5_m17_wanted(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out, int out_stride,
+                                 uint32_t* cost, const uint8_t* wanted, hipStream_t st);
 hipError_t ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, hipStream_t st);
 hipError_t ddn_dev_launch_carry(const void* in, int in_fmt, size_t ch_stride, long n, void* carry, int n_channels,
                                 hipStream_t st);

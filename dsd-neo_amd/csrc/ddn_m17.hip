@@ -547,7 +547,8 @@ k_ysf_plan(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_s
 __global__ __launch_bounds__(64) void
 k_ysf_payload_costs(const uint8_t* __restrict__ rec, size_t stride, const int32_t* __restrict__ sync_pos, int max_syncs, int lmax,
                     const uint8_t* __restrict__ info, const int32_t* __restrict__ slot_sync, uint16_t* __restrict__ cost200,
-                    uint16_t* __restrict__ cost360, uint8_t* __restrict__ ambe49, uint8_t* __restrict__ errs2) {
+                    uint16_t* __restrict__ cost360, uint8_t* __restrict__ ambe49, uint8_t* __restrict__ errs2,
+                    uint8_t* __restrict__ want200, uint8_t* __restrict__ want360) {
     const int ch = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
     const size_t slot = (size_t)ch * lmax + j;
     const int k = slot_sync[slot];
@@ -588,6 +589,9 @@ k_ysf_payload_costs(const uint8_t* __restrict__ rec, size_t stride, const int32_
             errs2[so * 5 + lane] = v[lane][103];
         }
         uint16_t* out = cost200 + slot * 200;
+        if (lane == 0) {
+            want200[slot] = 1;
+        }
         for (int q = lane; q < 100; q += 64) { // buf[jj + 5 i] = input[i + 20 jj]; input[x] = data dibit x % 20 of sub-frame x / 20
             const int i = q / 5, jj = q - 5 * i, x = i + 20 * jj;
             const int d = dib(72 * (x / 20) + x % 20);
@@ -596,6 +600,9 @@ k_ysf_payload_costs(const uint8_t* __restrict__ rec, size_t stride, const int32_
         }
     } else if (kind & 1) {
         uint16_t* out = cost360 + slot * 2 * 360;
+        if (lane == 0) {
+            want360[slot * 2] = 1;
+        }
         for (int q = lane; q < 180; q += 64) { // buf[jj + 9 i] = input[i + 20 jj]; input[x] = data dibit x % 36 of sub-frame x / 36
             const int i = q / 9, jj = q - 9 * i, x = i + 20 * jj;
             const int d = dib(72 * (x / 36) + x % 36);
@@ -605,6 +612,9 @@ k_ysf_payload_costs(const uint8_t* __restrict__ rec, size_t stride, const int32_
     } else if (kind == 8) {
         for (int b = 0; b < 2; b++) {
             uint16_t* out = cost360 + (slot * 2 + b) * 360;
+            if (lane == 0) {
+                want360[slot * 2 + b] = 1;
+            }
             for (int q = lane; q < 180; q += 64) { // input_b[x] = dibit x % 36 of chunk 2 (x / 36) + b
                 const int i = q / 9, jj = q - 9 * i, x = i + 20 * jj;
                 const int d = dib(36 * (2 * (x / 36) + b) + x % 36);
@@ -723,9 +733,9 @@ ddn_dev_ysf_plan(const int32_t* sync_pos, const int32_t* n_sync, const int32_t* 
 extern "C" hipError_t
 ddn_dev_ysf_payload_costs(const uint8_t* rec, size_t stride, const int32_t* sync_pos, int n_channels, int max_syncs, int lmax,
                           const uint8_t* info, const int32_t* slot_sync, uint16_t* cost200, uint16_t* cost360, uint8_t* ambe49,
-                          uint8_t* errs2, hipStream_t st) {
+                          uint8_t* errs2, uint8_t* want200, uint8_t* want360, hipStream_t st) {
     hipLaunchKernelGGL(k_ysf_payload_costs, dim3((unsigned)n_channels, (unsigned)lmax), dim3(64), 0, st, rec, stride, sync_pos, max_syncs,
-                       lmax, info, slot_sync, cost200, cost360, ambe49, errs2);
+                       lmax, info, slot_sync, cost200, cost360, ambe49, errs2, want200, want360);
     return hipGetLastError();
 }
 

@@ -332,9 +332,15 @@ k_k5_nxdn(const uint8_t* __restrict__ sym, const uint8_t* __restrict__ rel, int 
 // K=5, libM17 flavour: 16 lanes per codeword, uint32 metrics, uint16 soft symbols, optional depuncture
 __global__ __launch_bounds__(256) void
 k_k5_m17(const uint16_t* __restrict__ in, int n, int in_len, int u_len, DdnPuncture pu, uint8_t* __restrict__ out,
-         int out_stride, uint32_t* __restrict__ cost_out) {
+         int out_stride, uint32_t* __restrict__ cost_out, const uint8_t* __restrict__ wanted) {
     constexpr int CW = 16;
     extern __shared__ uint8_t smem[];
+    if (wanted) { // (optional: a workgroup none of whose sixteen code words is wanted leaves them undecoded)
+        const int i = blockIdx.x * CW + (int)threadIdx.x;
+        if (!__syncthreads_or(threadIdx.x < CW && i < n && wanted[i] != 0)) {
+            return;
+        }
+    }
     uint16_t* um = (uint16_t*)smem;                 // [CW][u_len + 2]
     const int row = u_len + 2;
     const int n_steps = u_len >> 1;
@@ -826,15 +832,21 @@ ddn_dev_k5_nxdn(const uint8_t* sym, const uint8_t* rel, int n, int n_steps, int 
 }
 
 extern "C" hipError_t
-ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out, int out_stride,
-               uint32_t* cost, hipStream_t st) {
+ddn_dev_k5_m17_wanted(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out, int out_stride,
+                      uint32_t* cost, const uint8_t* wanted, hipStream_t st) {
     if (n <= 0) {
         return hipSuccess;
     }
     dim3 grid((unsigned)((n + 15) / 16));
     const size_t shm = 16 * ((size_t)u_len + 2) * 2 + 16 * (size_t)(u_len / 2) * 2 + 16;
-    hipLaunchKernelGGL(k_k5_m17, grid, dim3(256), shm, st, in, n, in_len, u_len, *pu, out, out_stride, cost);
+    hipLaunchKernelGGL(k_k5_m17, grid, dim3(256), shm, st, in, n, in_len, u_len, *pu, out, out_stride, cost, wanted);
     return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out, int out_stride,
+               uint32_t* cost, hipStream_t st) {
+    return ddn_dev_k5_m17_wanted(in, n, in_len, u_len, pu, out, out_stride, cost, nullptr, st);
 }
 
 extern "C" hipError_t
