@@ -1766,21 +1766,24 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
                 float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
                 const int lc = s.level_count;
+                // (straight-line: an entry past the window's fill goes in as +big / -big, which leaves the five unchanged, so the 24
+                // insertions carry no branch and stage i of entry k + 1 only waits for stage i of entry k; four entries at a time -
+                // more in flight costs the kernel its register budget)
+#pragma unroll 4
                 for (int k = 0; k < 24; k++) {
-                    if (k < lc) {
-                        float v = L.lb[k][ln], t;
-                        float w = v;
-                        t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
-                        t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
-                        t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
-                        t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
-                        a4 = fminf(a4, v);
-                        t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
-                        t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
-                        t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
-                        t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
-                        b4 = fmaxf(b4, w);
-                    }
+                    const float x = L.lb[k][ln];
+                    float v = k < lc ? x : big, t;
+                    float w = k < lc ? x : -big;
+                    t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
+                    t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
+                    t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
+                    t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
+                    a4 = fminf(a4, v);
+                    t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
+                    t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
+                    t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
+                    t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
+                    b4 = fmaxf(b4, w);
                 }
                 if (lc >= 13) {
                     s.lmin = (a2 + a3 + a4) / 3.0f;
@@ -1801,16 +1804,17 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     float sp_ = 0.0f, sn_ = 0.0f;
                     int np = 0, nn = 0;
                     int idx = s.shead;
+                    // (no branch: x + (+0) == x for every x but -0, and neither sum can be -0 - both start at +0 - so adding +0 to
+                    // the sum a value does not belong to leaves it as the reference's conditional add does; the loads run ahead)
+#pragma unroll 4
                     for (int k = 0; k < 24; k++) {
                         idx = idx == 0 ? 23 : idx - 1;
                         const float v = L.sh[idx][ln];
-                        if (v > 0.0f) {
-                            sp_ += v;
-                            np++;
-                        } else {
-                            sn_ += v;
-                            nn++;
-                        }
+                        const bool pos = v > 0.0f;
+                        sp_ += pos ? v : 0.0f;
+                        sn_ += pos ? 0.0f : v;
+                        np += pos ? 1 : 0;
+                        nn += pos ? 0 : 1;
                     }
                     if (np != 0 && nn != 0) {
                         const float mp = sp_ / (float)np, mn = sn_ / (float)nn;
