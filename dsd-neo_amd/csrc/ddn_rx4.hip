@@ -1453,21 +1453,23 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                 float a0 = big, a1 = big, a2 = big, a3 = big, a4 = big;
                                 float b0 = -big, b1 = -big, b2 = -big, b3 = -big, b4 = -big;
                                 const int cnt = s.level_count;
+                                // (straight-line, as in the P25 loop: an entry past the fill goes in as +big / -big, which leaves the
+                                // five unchanged; stage i of entry k + 1 then only waits for stage i of entry k, four entries at a time)
+#pragma unroll 4
                                 for (int k = 0; k < 24; k++) {
-                                    if (k < cnt) {
-                                        float v = L.lb[k][ln], t;
-                                        float w = v;
-                                        t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
-                                        t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
-                                        t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
-                                        t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
-                                        a4 = fminf(a4, v);
-                                        t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
-                                        t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
-                                        t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
-                                        t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
-                                        b4 = fmaxf(b4, w);
-                                    }
+                                    const float x = L.lb[k][ln];
+                                    float v = k < cnt ? x : big, t;
+                                    float w = k < cnt ? x : -big;
+                                    t = fminf(a0, v); v = fmaxf(a0, v); a0 = t;
+                                    t = fminf(a1, v); v = fmaxf(a1, v); a1 = t;
+                                    t = fminf(a2, v); v = fmaxf(a2, v); a2 = t;
+                                    t = fminf(a3, v); v = fmaxf(a3, v); a3 = t;
+                                    a4 = fminf(a4, v);
+                                    t = fmaxf(b0, w); w = fminf(b0, w); b0 = t;
+                                    t = fmaxf(b1, w); w = fminf(b1, w); b1 = t;
+                                    t = fmaxf(b2, w); w = fminf(b2, w); b2 = t;
+                                    t = fmaxf(b3, w); w = fminf(b3, w); b3 = t;
+                                    b4 = fmaxf(b4, w);
                                 }
                                 if (cnt >= 13) {
                                     s.lmin = (a2 + a3 + a4) / 3.0f;
@@ -1498,16 +1500,16 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                     if (s.scount >= wl && !(Cfg::m17 && (hit == 2 || hit == 3))) { // dsd_sync_warm_start_thresholds_outer_only(opts, state, wl)
                                         float sp_ = 0.0f, sn_ = 0.0f;
                                         int np = 0, nn = 0, idx = s.shead;
+                                        // (no branch: adding +0 to the sum a value does not belong to is exact - neither sum can be -0)
+#pragma unroll 4
                                         for (int k = 0; k < wl; k++) {
                                             idx = idx == 0 ? HN - 1 : idx - 1;
                                             const float v = L.sh[idx][ln];
-                                            if (v > 0.0f) {
-                                                sp_ += v;
-                                                np++;
-                                            } else {
-                                                sn_ += v;
-                                                nn++;
-                                            }
+                                            const bool posv = v > 0.0f;
+                                            sp_ += posv ? v : 0.0f;
+                                            sn_ += posv ? 0.0f : v;
+                                            np += posv ? 1 : 0;
+                                            nn += posv ? 0 : 1;
                                         }
                                         if (np != 0 && nn != 0) {
                                             const float mp = sp_ / (float)np, mn = sn_ / (float)nn;
