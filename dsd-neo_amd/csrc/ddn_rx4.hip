@@ -1536,7 +1536,8 @@ k_fsk4_rx(const float* __restrict__ raw, const float* __restrict__ filt, const f
                                             // dmr_resample_on_sync() has just re-sliced them (needs 90 symbols of history), the 24 of
                                             // the sync as they were sliced while hunting
                                             const bool redig = s.scount >= 90;
-                                            for (int i = 0; i < 90; i++) {
+#pragma unroll 6
+                                            for (int i = 0; i < 90; i++) { // (independent entries: six in flight)
                                                 int idx = s.shead - 90 + i;
                                                 idx += idx < 0 ? HN : 0;
                                                 const float v = L.sh[idx][ln];
