@@ -406,7 +406,7 @@ PROTOTYPES.update({
     "ddn_m17_str_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4 + [C.c_int, C.c_size_t] + [C.c_void_p] * 5),
     "ddn_m17_lich_assemble_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 9),
     "ddn_ysf_fich_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int, C.c_size_t] + [C.c_void_p] * 4),
-    "ddn_ysf_payload_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int, C.c_size_t] + [C.c_void_p] * 10),
+    "ddn_ysf_payload_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int, C.c_size_t] + [C.c_void_p] * 12),
     "ddn_fsk4_rx_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_mode_config": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "full_demod": (None, [C.c_void_p]),
@@ -516,7 +516,7 @@ class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
         (k, C.c_void_p) for k in ("d_sync_thr5", "d_m17_lsf30", "d_m17_lsf_status", "d_m17_lsf_cost", "d_m17_lich6", "d_m17_lich_cnt",
                                   "d_m17_fn_payload18", "d_m17_str_status", "d_m17_lich_lsf30", "d_m17_lich_status", "d_ysf_fich4",
                                   "d_ysf_fich_status", "d_ysf_fich_cost", "d_ysf_info2", "d_ysf_dch40", "d_ysf_dch_status2",
-                                  "d_ysf_dch_cost2", "d_ysf_ambe49x5", "d_ysf_errs2x5")] + [("ysf_voice_frames", C.c_int)] + [
+                                  "d_ysf_dch_cost2", "d_ysf_ambe49x5", "d_ysf_errs2x5", "d_ysf_frames184x5", "d_ysf_n_frames")] + [("ysf_voice_frames", C.c_int)] + [
         (k, C.c_void_p) for k in ("d_ysf_n_voice", "d_ysf_voice_slot", "d_ysf_voice_result", "d_ysf_pcm")]
 
 

@@ -80,7 +80,7 @@ struct ddn_fsk4_chain {
     uint8_t *y_fich4, *y_st;
     uint32_t* y_ve;
     // ... and the payload behind it (ddn_ysf_payload_decode_batch): the frame type carried per channel, the data channels, V/D2 voice bits
-    uint8_t *y_last, *y_info, *y_dch, *y_dst, *y_ambe, *y_errs;
+    uint8_t *y_last, *y_info, *y_dch, *y_dst, *y_ambe, *y_errs, *y_fr, *y_nfr;
     uint32_t* y_dcost;
     // ... V/D mode 2 voice (vocoder = 1): the sub-frames filed by talk path (= channel) -> AMBE 3600x2450 synthesis (d_ambe_d, d_ambe_res,
     // d_skip, d_pcm, d_res_out, d_vn as for NXDN48; yvf frames of five sub-frames per channel and call)
@@ -122,7 +122,7 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
     ddn_batch_destroy(c->fe);
     ddn_fsk4_rx_destroy(c->rx);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->y_vslot, c->y_fich4, c->y_st, c->y_ve, c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_ambe, c->y_errs, c->y_dcost, c->s_thr, c->c_thr[0], c->c_thr[1], c->d_thr, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_fp, c->m_st, c->m_asm, c->m_ll,
+    void* all[] = {c->y_fr, c->y_nfr, c->y_vslot, c->y_fich4, c->y_st, c->y_ve, c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_ambe, c->y_errs, c->y_dcost, c->s_thr, c->c_thr[0], c->c_thr[1], c->d_thr, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_fp, c->m_st, c->m_asm, c->m_ll,
                    c->m_ll_st, c->m_cost, c->d_disc, c->d_disc2, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_pay, c->d_new[0], c->d_new[1], c->d_cnt_full,
                    c->d_cnt_scan, c->d_dropped, c->s_pos, c->s_n, c->c_pos[0], c->c_pos[1], c->c_n[0], c->c_n[1], c->d_spos, c->d_ns, c->s_pat, c->s_pre,
                    c->s_prel, c->c_pat[0], c->c_pat[1], c->c_pre[0], c->c_pre[1], c->c_prel[0], c->c_prel[1], c->d_spat, c->d_pre,
@@ -216,7 +216,7 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
         if (ok && c->ysf) {
             ok = dalloc(&c->y_fich4, S * 4) && dalloc(&c->y_st, S) && dalloc(&c->y_ve, S) && dalloc(&c->y_last, B * 2) && dalloc(&c->y_info, S * 2)
                  && dalloc(&c->y_dch, S * 40) && dalloc(&c->y_dst, S * 2) && dalloc(&c->y_dcost, S * 2) && dalloc(&c->y_ambe, S * 5 * 49)
-                 && dalloc(&c->y_errs, S * 5);
+                 && dalloc(&c->y_errs, S * 5) && dalloc(&c->y_fr, S * 5 * 184) && dalloc(&c->y_nfr, S);
             if (ok && cfg->vocoder) {
                 c->yvf = (int)(c->stride / 480 + 2);
                 const size_t V5 = B * (size_t)c->yvf * 5;
@@ -321,7 +321,7 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
         DDN_TRY(ddn_ysf_fich_decode_batch(rec, c->stride, c->d_cnt_full, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->y_fich4, c->y_st, c->y_ve, st));
         // ... and the payload of every frame: V/D mode 2 voice bits + DCH2, the DCH blocks of V/D mode 1 and of the full-rate data frames
         DDN_TRY(ddn_ysf_payload_decode_batch(rec, c->stride, c->d_cnt_full, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->y_fich4, c->y_st,
-                                             c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_dcost, c->y_ambe, c->y_errs, st));
+                                             c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_dcost, c->y_ambe, c->y_errs, c->y_fr, c->y_nfr, st));
         if (c->mbe) { // mbe_processAmbe2450Dataf of every V/D mode 2 sub-frame, talk path = channel (ysf_handle_vd_type2, ysf.c:753-755)
             HIP_TRY(ddn_dev_ysf_voice_file(c->d_ns, c->B, c->myd, c->y_info, c->y_ambe, c->y_errs, c->yvf, c->d_ambe_d, c->d_ambe_res, c->d_skip,
                                            c->d_vn, c->y_vslot, st));
@@ -561,6 +561,8 @@ ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
         r->d_ysf_dch_cost2 = c->y_dcost;
         r->d_ysf_ambe49x5 = c->y_ambe;
         r->d_ysf_errs2x5 = c->y_errs;
+        r->d_ysf_frames184x5 = c->y_fr;
+        r->d_ysf_n_frames = c->y_nfr;
         r->ysf_voice_frames = c->mbe ? c->yvf : 0;
         r->d_ysf_n_voice = c->mbe ? c->d_vn : nullptr;
         r->d_ysf_voice_slot = c->mbe ? c->y_vslot : nullptr;

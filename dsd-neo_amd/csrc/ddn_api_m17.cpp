@@ -189,7 +189,7 @@ extern "C" hipError_t ddn_dev_ysf_plan(const int32_t* sync_pos, const int32_t* n
 extern "C" hipError_t ddn_dev_ysf_payload_costs(const uint8_t* rec, size_t stride, const int32_t* sync_pos, int n_channels, int max_syncs,
                                                 int lmax, const uint8_t* info, const int32_t* slot_sync, uint16_t* cost200,
                                                 uint16_t* cost360, uint8_t* ambe49, uint8_t* errs2, uint8_t* want200, uint8_t* want360,
-                                                hipStream_t st);
+                                                uint8_t* frames, uint8_t* n_frames, hipStream_t st);
 extern "C" int ddn_fec_viterbi_k5_batch_wanted(const uint16_t* d_soft, size_t n, int in_len, const uint8_t* punct, int p_len, uint8_t* d_out,
                                                int out_stride, uint32_t* d_cost, const uint8_t* d_wanted, void* hip_stream);
 extern "C" hipError_t ddn_dev_ysf_dch_finish(const uint8_t* decA, const uint32_t* pcA, const uint8_t* decB, const uint32_t* pcB,
@@ -201,9 +201,9 @@ extern "C" int
 ddn_ysf_payload_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
                              const int32_t* d_n_sync, int n_channels, size_t max_syncs, const uint8_t* d_fich4, const uint8_t* d_fich_status,
                              uint8_t* d_last_dt_fi, uint8_t* d_info2, uint8_t* d_dch40, uint8_t* d_dch_status2, uint32_t* d_dch_cost2,
-                             uint8_t* d_ambe49x5, uint8_t* d_errs2x5, void* hip_stream) {
+                             uint8_t* d_ambe49x5, uint8_t* d_errs2x5, uint8_t* d_frames184x5, uint8_t* d_n_frames, void* hip_stream) {
     if (!d_records10 || !d_counts || !d_sync_pos || !d_n_sync || !d_fich4 || !d_fich_status || !d_last_dt_fi || !d_info2 || !d_dch40
-        || !d_dch_status2 || !d_dch_cost2 || !d_ambe49x5 || !d_errs2x5 || n_channels <= 0 || max_syncs == 0 || max_syncs > (1u << 24)
+        || !d_dch_status2 || !d_dch_cost2 || !d_ambe49x5 || !d_errs2x5 || !d_frames184x5 || !d_n_frames || n_channels <= 0 || max_syncs == 0 || max_syncs > (1u << 24)
         || stride_symbols == 0) {
         ddn_set_error("ddn_ysf_payload_decode_batch: bad argument");
         return DDN_EINVAL;
@@ -241,12 +241,18 @@ ddn_ysf_payload_decode_batch(const uint8_t* d_records10, size_t stride_symbols, 
         e = hipMemsetAsync(d_dch40, 0, SO * 40, st);
     }
     if (e == hipSuccess) {
+        e = hipMemsetAsync(d_frames184x5, 0, SO * 5 * 184, st);
+    }
+    if (e == hipSuccess) {
+        e = hipMemsetAsync(d_n_frames, 0, SO, st);
+    }
+    if (e == hipSuccess) {
         e = ddn_dev_ysf_plan(d_sync_pos, d_n_sync, d_counts, n_channels, (int)max_syncs, lmax, d_fich4, d_fich_status, d_last_dt_fi, d_info2,
                              slot, st);
     }
     if (e == hipSuccess) {
         e = ddn_dev_ysf_payload_costs(d_records10, stride_symbols, d_sync_pos, n_channels, (int)max_syncs, lmax, d_info2, slot, cA, cB,
-                                      d_ambe49x5, d_errs2x5, wA, wB, st);
+                                      d_ambe49x5, d_errs2x5, wA, wB, d_frames184x5, d_n_frames, st);
     }
     static const uint8_t none[4] = {1, 1, 1, 1}; // DSD_YSF_PUNCTURE_NONE
     if (e == hipSuccess) {

@@ -21,6 +21,7 @@
 //   k_m17_lich        one lane per channel: the LSF reassembled from six LICH chunks in the order of the syncs (dispatch_m17.c:39,
 //                     m17.c:250, M17finalizeLICH: CRC16 over the reassembled 30 bytes), with the decoded LSF frames and EOT markers
 //                     in between as the reference applies them
+#include "ddn_tables_ambe.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -529,7 +530,12 @@ k_ysf_plan(const int32_t* __restrict__ sync_pos, const int32_t* __restrict__ n_s
         kind |= (dt == 1 || fi == 0 || fi == 2) ? 8 : 0;
         const bool complete = sync_pos[so] + 461 <= cnt;
         int flags = fi | (dt << 2) | (st != 1 ? 16 : 0) | 32;
-        if (complete && (kind & 11) != 0) {
+        // full-rate voice with FT = 1, FN = 0 carries a data-channel block and two voice slots (ysf_is_full_rate_csd3, ysf.c:776-779;
+        // the fields of a failed FICH read 9: never CSD3)
+        if (kind == 4 && st == 1 && (fich4[4 * so + 1] & 7) == 1 && ((fich4[4 * so + 1] >> 3) & 7) == 0) {
+            flags |= 128;
+        }
+        if (complete && kind != 0) {
             if (j < lmax) {
                 slot_sync[(size_t)ch * lmax + j] = k;
                 j++;
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(64) void
 k_ysf_payload_costs(const uint8_t* __restrict__ rec, size_t stride, const int32_t* __restrict__ sync_pos, int max_syncs, int lmax,
                     const uint8_t* __restrict__ info, const int32_t* __restrict__ slot_sync, uint16_t* __restrict__ cost200,
                     uint16_t* __restrict__ cost360, uint8_t* __restrict__ ambe49, uint8_t* __restrict__ errs2,
-                    uint8_t* __restrict__ want200, uint8_t* __restrict__ want360) {
+                    uint8_t* __restrict__ want200, uint8_t* __restrict__ want360, uint8_t* __restrict__ frames, uint8_t* __restrict__ n_frames) {
     const int ch = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
     const size_t slot = (size_t)ch * lmax + j;
     const int k = slot_sync[slot];
@@ -609,7 +615,57 @@ k_ysf_payload_costs(const uint8_t* __restrict__ rec, size_t stride, const int32_
             out[2 * q] = (d & 2) ? 0xFFFFu : 0u;
             out[2 * q + 1] = (d & 1) ? 0xFFFFu : 0u;
         }
-    } else if (kind == 8) {
+    }
+    // the voice frames of V/D mode 1 (ysf_ehr: four AMBE 3600x2450 frames through the 36-dibit schedule) and of full-rate frames
+    // (dsd_ysf_unpack_full_rate_imbe: five IMBE 7200x4400 frames, two behind a CSD3 data block), as processMbeFrame() gets them
+    if (kind == 1) {
+        static const uint8_t __attribute__((address_space(4))) amap[36][4] = DDN_AMBE2450_MAP_INIT;
+        for (int t = lane; t < 4 * 36; t += 64) {
+            const int sf = t / 36, i = t - 36 * sf;
+            const int d = dib(72 * sf + 36 + i);
+            uint8_t* f = frames + (so * 5 + sf) * 184;
+            f[amap[i][0] * 24 + amap[i][1]] = (uint8_t)(d >> 1);
+            f[amap[i][2] * 24 + amap[i][3]] = (uint8_t)(d & 1);
+        }
+        if (lane == 0) {
+            n_frames[so] = 4;
+        }
+    } else if (kind == 4) {
+        const bool csd3 = (info[2 * so + 1] & 128) != 0;
+        const int nf = csd3 ? 2 : 5, off = csd3 ? 216 : 0;
+        for (int t = lane; t < nf * 144; t += 64) {
+            const int i = t / 144, k = t - 144 * i;            // k-th bit of the de-interleaved stream of slot i
+            const int r = k / 24, c = k - 24 * r;
+            const int src = 12 * (c >> 1) + ((c & 1) ? ((r ^ 1) + 6) : r);
+            const int d = dib(off + 72 * i + (src >> 1));
+            const int bit = ((src & 1) ? d : (d >> 1)) & 1;
+            int n, m;                                           // rows 0-3: 23 bits, 4-6: 15, 7: seven; highest column first
+            if (k < 92) {
+                n = k / 23, m = 22 - (k - 23 * n);
+            } else if (k < 137) {
+                n = 4 + (k - 92) / 15, m = 14 - ((k - 92) % 15);
+            } else {
+                n = 7, m = 6 - (k - 137);
+            }
+            frames[(so * 5 + i) * 184 + n * 23 + m] = (uint8_t)bit;
+        }
+        if (lane == 0) {
+            n_frames[so] = (uint8_t)nf;
+        }
+        if (csd3) { // the 180 data dibits as they lie: buf[jj + 9 i] = input[i + 20 jj]
+            uint16_t* out = cost360 + slot * 2 * 360;
+            if (lane == 0) {
+                want360[slot * 2] = 1;
+            }
+            for (int q = lane; q < 180; q += 64) {
+                const int i = q / 9, jj = q - 9 * i;
+                const int d = dib(i + 20 * jj);
+                out[2 * q] = (d & 2) ? 0xFFFFu : 0u;
+                out[2 * q + 1] = (d & 1) ? 0xFFFFu : 0u;
+            }
+        }
+    }
+    if (kind == 8) {
         for (int b = 0; b < 2; b++) {
             uint16_t* out = cost360 + (slot * 2 + b) * 360;
             if (lane == 0) {
@@ -641,8 +697,8 @@ k_ysf_dch_finish(const uint8_t* __restrict__ decA, const uint32_t* __restrict__ 
     const size_t so = (size_t)(slot / lmax) * max_syncs + k;
     const int kind = info[2 * so];
     const bool vd2 = (kind & 2) != 0;
-    if (blk == 1 && kind != 8) {
-        return; // (one data-channel block per V/D frame)
+    if ((blk == 1 && kind != 8) || kind == 0 || (kind == 4 && !(info[2 * so + 1] & 128))) {
+        return; // (one data-channel block per V/D frame, none behind full-rate voice but for CSD3)
     }
     const uint8_t* by = vd2 ? decA + (size_t)slot * 16 : decB + (size_t)(slot * 2 + blk) * 32;
     const int nbits = vd2 ? 96 : 176;
@@ -733,9 +789,9 @@ ddn_dev_ysf_plan(const int32_t* sync_pos, const int32_t* n_sync, const int32_t* 
 extern "C" hipError_t
 ddn_dev_ysf_payload_costs(const uint8_t* rec, size_t stride, const int32_t* sync_pos, int n_channels, int max_syncs, int lmax,
                           const uint8_t* info, const int32_t* slot_sync, uint16_t* cost200, uint16_t* cost360, uint8_t* ambe49,
-                          uint8_t* errs2, uint8_t* want200, uint8_t* want360, hipStream_t st) {
+                          uint8_t* errs2, uint8_t* want200, uint8_t* want360, uint8_t* frames, uint8_t* n_frames, hipStream_t st) {
     hipLaunchKernelGGL(k_ysf_payload_costs, dim3((unsigned)n_channels, (unsigned)lmax), dim3(64), 0, st, rec, stride, sync_pos, max_syncs,
-                       lmax, info, slot_sync, cost200, cost360, ambe49, errs2, want200, want360);
+                       lmax, info, slot_sync, cost200, cost360, ambe49, errs2, want200, want360, frames, n_frames);
     return hipGetLastError();
 }
 

@@ -368,6 +368,8 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const uint32_t* d_ysf_dch_cost2;     /* [S][2] the decoder's path cost */
     const uint8_t* d_ysf_ambe49x5;       /* [S][5][49] V/D mode 2: ambe_d of the five voice sub-frames */
     const uint8_t* d_ysf_errs2x5;        /* [S][5] their errs2 */
+    const uint8_t* d_ysf_frames184x5;    /* [S][5][184] V/D mode 1: four ambe_fr[4][24]; full-rate voice: five (CSD3: two) imbe_fr[8][23] */
+    const uint8_t* d_ysf_n_frames;       /* [S] how many of them */
     /* ... V/D mode 2 voice through the vocoder (vocoder = 1; 0 / NULL otherwise): talk path = channel, the frames of a call in stream order */
     int ysf_voice_frames;                /* F: frames (of five sub-frames) per channel and call the arrays below hold */
     const int32_t* d_ysf_n_voice;        /* [n_channels] V/D mode 2 frames of this call */

@@ -135,17 +135,22 @@ int ddn_ysf_fich_decode_batch(const uint8_t* d_records10, size_t stride_symbols,
  *   d_info2 [S][2]: [0] = what was decoded, a bit mask: 1 V/D mode 1 (FI 1, DT 0), 2 V/D mode 2 (FI 1, DT 2), 4 full-rate voice
  *     (FI 1, DT 3), 8 full-rate data (DT 1 or FI 0 / 2) - 0 when the frame's 360 payload dibits are not inside the records;
  *     [1] = FI | DT << 2 | 16 (FICH failed: type taken over) | 32 (a frame) | 64 (more frames than a row holds 480 symbols apart:
- *     left undecoded);
+ *     left undecoded) | 128 (full-rate voice in the CSD3 layout);
  *   V/D mode 2: the five voice sub-frames, ysf_read_type2_vech_bits + ysf_build_type2_ambe (:687-722): d_ambe49x5 [S][5][49] = ambe_d
  *     (what mbe_processAmbe2450Dataf takes), d_errs2x5 [S][5] = errs2; the data channel, ysf_conv_dch2 (:245-300): d_dch40 [S][2][20]
  *     block 0 bytes 0 .. 9, d_dch_status2 [S][2] (0 none, 1 CRC16 good, 3 CRC16 failed), d_dch_cost2 [S][2] = the decoder's path cost;
- *   V/D mode 1: the data channel, ysf_conv_dch (:302-355), block 0 bytes 0 .. 19 (its voice frames: not decoded here);
+ *   V/D mode 1: the data channel, ysf_conv_dch (:302-355), block 0 bytes 0 .. 19; its voice blocks as ysf_ehr() (:425-476) hands them
+ *     to processMbeFrame: d_frames184x5 [S][5][184], the first four frames, ambe_fr[4][24] as row * 24 + column (d_n_frames [S] = 4);
+ *   full-rate voice (FI 1, DT 3): five IMBE 7200x4400 frames as dsd_ysf_unpack_full_rate_imbe (ysf_frame.c:138-163) builds them,
+ *     imbe_fr[8][23] as row * 23 + column (d_n_frames = 5); with FT = 1 and FN = 0 (CSD3, d_info2[1] bit 128) two frames behind a data
+ *     block that goes through ysf_conv_dch into block 0 (ysf_handle_full_rate_voice :824-842);
  *   full-rate data (a frame that is nothing else): both blocks, in turn (ysf_handle_full_rate_data :844-864).
- * S = n_channels x max_syncs, slots as d_sync_pos.  Full-rate voice (IMBE) is not decoded: mask bit 4 only says so. */
+ * S = n_channels x max_syncs, slots as d_sync_pos.  The frames of V/D mode 1 and of full-rate voice are handed back, not synthesized. */
 int ddn_ysf_payload_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
                                  const int32_t* d_n_sync, int n_channels, size_t max_syncs, const uint8_t* d_fich4,
                                  const uint8_t* d_fich_status, uint8_t* d_last_dt_fi, uint8_t* d_info2, uint8_t* d_dch40,
-                                 uint8_t* d_dch_status2, uint32_t* d_dch_cost2, uint8_t* d_ambe49x5, uint8_t* d_errs2x5, void* hip_stream);
+                                 uint8_t* d_dch_status2, uint32_t* d_dch_cost2, uint8_t* d_ambe49x5, uint8_t* d_errs2x5,
+                                 uint8_t* d_frames184x5, uint8_t* d_n_frames, void* hip_stream);
 /* The LSF reassembled from the LICH chunks, in the order of the syncs of a call: a decoded LSF frame seeds the buffer (m17_decode_lsf_soft_
  * bits), an EOT marker clears it (dispatch_m17.c:39), chunk c fills bytes 5 c .. 5 c + 4, chunk 5 closes it: d_lich_lsf30 [B][max_syncs][30]
  * + d_lich_status (0 none here, 1 CRC bad, 2 CRC good: M17finalizeLICH), then the buffer is cleared.  d_assembly32 [B][32] is the carried

@@ -386,6 +386,9 @@ int orc_ysf_pn95_bit(int i);
 void orc_ysf_dewhiten(uint8_t* bits, int n);
 int orc_ysf_vd2_voice(const uint8_t dibits52[52], uint8_t ambe_d[49]);
 int orc_ysf_dch(const uint8_t* in, int n, uint8_t* out_bytes, uint32_t* v_error);
+void orc_ysf_fr_unpack(const uint8_t dibits72[72], uint8_t imbe_fr[8 * 23]);
+int orc_ysf_voice_frames(const uint8_t p[360], int kind, int csd3, uint8_t fr[5][184], uint8_t dch20[20], uint8_t* dch_status,
+                         uint32_t* dch_cost);
 int orc_ysf_payload(const uint8_t p[360], int fi, int dt, uint8_t dch[2][20], uint8_t dch_status[2], uint32_t dch_cost[2],
                     uint8_t ambe_d[5][49], uint8_t errs2[5]);
 

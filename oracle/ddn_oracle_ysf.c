@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "ddn_oracle.h"
+#include "ddn_tables_ambe.h"
 
 uint16_t
 orc_ysf_crc16(const uint8_t* bits, int len) {
@@ -228,4 +229,68 @@ orc_ysf_payload(const uint8_t p[360], int fi, int dt, uint8_t dch[2][20], uint8_
         }
     }
     return kind;
+}
+
+/* ---- the voice frames of V/D mode 1 and of full-rate frames, as processMbeFrame() gets them (round 5, last part) -------------------
+ *   ysf_ehr()          ysf.c:425-476: 36 voice dibits -> ambe_fr[4][24] through dsd_ambe_2450_dibit_map (the generated schedule,
+ *                      ddn_tables_ambe.h); ysf_handle_vd_type1 decodes the first FOUR of a frame's five voice blocks (:683)
+ *   full rate          ysf_read_full_rate_imbe_raw / dsd_ysf_unpack_full_rate_imbe (ysf.c:794-802, ysf_frame.c:138-163): 72 dibits ->
+ *                      144 bits -> the 24 x 6 interleave (entry r * 24 + c = 12 (c / 2) + (c odd ? (r ^ 1) + 6 : r)) -> imbe_fr[8][23]
+ *                      rows 0-3 23 bits, 4-6 15 bits, 7 seven bits, highest column first; checked against the compiled ysf_frame.c
+ *   CSD3               ysf_handle_full_rate_voice :824-842: FT = 1 & FN = 0 -> five banks of 36 data dibits (a sixth skipped), two
+ *                      voice slots, then ysf_conv_dch over the 180 dibits
+ * -> frames [5][184] (AMBE: the first 96 entries, row * 24 + column; IMBE: row * 23 + column), returns how many */
+void
+orc_ysf_fr_unpack(const uint8_t dibits72[72], uint8_t imbe_fr[8 * 23]) {
+    uint8_t raw[144], vch[144];
+    for (int j = 0; j < 72; j++) {
+        raw[2 * j] = (uint8_t)((dibits72[j] >> 1) & 1);
+        raw[2 * j + 1] = (uint8_t)(dibits72[j] & 1);
+    }
+    for (int j = 0; j < 144; j++) {
+        const int r = j / 24, c = j % 24;
+        vch[j] = raw[12 * (c >> 1) + ((c & 1) ? ((r ^ 1) + 6) : r)];
+    }
+    memset(imbe_fr, 0, 8 * 23);
+    int k = 0;
+    for (int n = 0; n < 4; n++) {
+        for (int m = 22; m >= 0; m--) {
+            imbe_fr[n * 23 + m] = vch[k++];
+        }
+    }
+    for (int n = 4; n < 7; n++) {
+        for (int m = 14; m >= 0; m--) {
+            imbe_fr[n * 23 + m] = vch[k++];
+        }
+    }
+    for (int m = 6; m >= 0; m--) {
+        imbe_fr[7 * 23 + m] = vch[k++];
+    }
+}
+
+int
+orc_ysf_voice_frames(const uint8_t p[360], int kind, int csd3, uint8_t fr[5][184], uint8_t dch20[20], uint8_t* dch_status, uint32_t* dch_cost) {
+    static const uint8_t map[36][4] = DDN_AMBE2450_MAP_INIT;
+    memset(fr, 0, 5 * 184);
+    if (kind == 1) {
+        for (int sf = 0; sf < 4; sf++) {
+            for (int i = 0; i < 36; i++) {
+                const int d = p[72 * sf + 36 + i] & 3;
+                fr[sf][map[i][0] * 24 + map[i][1]] = (uint8_t)(d >> 1);
+                fr[sf][map[i][2] * 24 + map[i][3]] = (uint8_t)(d & 1);
+            }
+        }
+        return 4;
+    }
+    if (kind == 4) {
+        const int n = csd3 ? 2 : 5, off = csd3 ? 216 : 0;
+        for (int i = 0; i < n; i++) {
+            orc_ysf_fr_unpack(p + off + 72 * i, fr[i]);
+        }
+        if (csd3) {
+            *dch_status = (uint8_t)orc_ysf_dch(p, 180, dch20, dch_cost);
+        }
+        return n;
+    }
+    return 0;
 }

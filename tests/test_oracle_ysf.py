@@ -107,3 +107,33 @@ def test_ysf_capture_payloads(built):
         seen.setdefault(bytes(f["payload"]["dch"][0, :10]), 0)
         seen[bytes(f["payload"]["dch"][0, :10])] += 1
     assert max(seen.values()) >= 2, seen
+
+
+def test_full_rate_unpack_equals_the_compiled_reference(built):
+    r = orc.ref()
+    if r is None:
+        pytest.skip("oracle/_ref not built")
+    o = orc.oracle()
+    r.dsd_ysf_unpack_full_rate_imbe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_ysf_fr_unpack.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9)
+    for k in range(50):
+        d = rng.integers(0, 4, 72).astype(np.uint8)
+        raw = np.zeros(144, np.uint8)
+        raw[0::2], raw[1::2] = d >> 1, d & 1
+        vch, a = np.zeros(144, np.uint8), np.zeros((8, 23), np.uint8)
+        r.dsd_ysf_unpack_full_rate_imbe(raw.ctypes.data, vch.ctypes.data, a.ctypes.data)
+        b = np.zeros((8, 23), np.uint8)
+        o.orc_ysf_fr_unpack(d.ctypes.data, b.ctypes.data)
+        assert np.array_equal(a, b), k
+
+
+def test_vd1_frames_are_the_shared_ambe_schedule(built):
+    """ysf_ehr() uses the map nxdn_voice.c and dmr_bs.c use (the generated schedule, pinned in tests/test_oracle_rx4.py)"""
+    rng = np.random.default_rng(10)
+    p = rng.integers(0, 4, 360).astype(np.uint8)
+    pl = ysf.payload(p, 1, 0)
+    assert pl["kind"] == 1 and pl["n_frames"] == 4
+    for sf in range(4):
+        fr, _ = rx4.ambe2450_deinterleave(p[72 * sf + 36:72 * sf + 72])
+        assert np.array_equal(pl["frames"][sf, :96].reshape(4, 24), fr), sf

@@ -133,9 +133,9 @@ def test_ysf_capture_through_the_chain_object(built):
     assert named >= 30
 
 
-def _payload_equal(info, dch, dst, dcost, ambe, errs, want, where):
+def _payload_equal(info, dch, dst, dcost, ambe, errs, want, where, fr=None, nfr=None):
     pl = want["payload"]
-    flags = want["fi"] | (want["dt"] << 2) | (16 if want["err"] != 0 else 0) | 32
+    flags = want["fi"] | (want["dt"] << 2) | (16 if want["err"] != 0 else 0) | 32 | (128 if (pl is not None and pl["csd3"]) or want.get("csd3") else 0)
     assert int(info[1]) == flags, (where, int(info[1]), flags)
     if pl is None:
         assert int(info[0]) == 0, where
@@ -145,6 +145,8 @@ def _payload_equal(info, dch, dst, dcost, ambe, errs, want, where):
     assert np.array_equal(dch, pl["dch"]), where
     if pl["kind"] == 2:
         assert np.array_equal(ambe, pl["ambe_d"]) and np.array_equal(errs, pl["errs2"]), where
+    if fr is not None:
+        assert int(nfr) == pl["n_frames"] and np.array_equal(fr, pl["frames"]), (where, int(nfr), pl["n_frames"])
     return int(pl["dch_status"][0] == 1) + int(pl["dch_status"][1] == 1)
 
 
@@ -177,15 +179,20 @@ def test_payload_on_the_device_equals_the_restatement(built):
     k7 = np.arange(my) % 7 == 3
     f4h[2, k7, 0] = (f4h[2, k7, 0] & 0x3F) | (1 << 6)
     f4h[2, k7, 2] |= 3
+    k14 = np.arange(my) % 14 == 3                       # every other of those in the CSD3 layout: FN = 0, FT = 1
+    f4h[2, k14, 1] = (f4h[2, k14, 1] & 0xC0) | 1
     f4 = torch.from_numpy(f4h).cuda()
     last = z((B, 2), torch.uint8)
     info, dch, dst = z((B, my, 2), torch.uint8), z((B, my, 2, 20), torch.uint8), z((B, my, 2), torch.uint8)
     dcost, ambe, errs = z((B, my, 2), torch.int32), z((B, my, 5, 49), torch.uint8), z((B, my, 5), torch.uint8)
+    fr, nfr = z((B, my, 5, 184), torch.uint8), z((B, my), torch.uint8)
     assert l.ddn_ysf_payload_decode_batch(p(rec), ms, p(cnt), p(spos), p(ns), B, my, p(f4), p(st), p(last), p(info), p(dch), p(dst), p(dcost),
-                                          p(ambe), p(errs), None) == 0, l.ddn_last_error()
+                                          p(ambe), p(errs), p(fr), p(nfr), None) == 0, l.ddn_last_error()
     torch.cuda.synchronize()
     g = lambda t: t.cpu().numpy()
     st, info, dch, dst, dcost, ambe, errs, last = g(st), g(info), g(dch), g(dst), g(dcost).view(np.uint32), g(ambe), g(errs), g(last)
+    fr, nfr = g(fr), g(nfr)
+    n_csd3 = 0
     nsy, pos, cn, rc = g(ns), g(spos), g(cnt), g(rec)
     good, kinds = 0, set()
     for c in range(B):
@@ -196,14 +203,17 @@ def test_payload_on_the_device_equals_the_restatement(built):
             if st[c, k] == 0:
                 assert not info[c, k].any()
                 continue
+            csd3 = False
             if st[c, k] == 1:
                 dt, fi = int(f4h[c, k, 2] & 3), int(f4h[c, k, 0] >> 6)
-            pl = ysf.payload(r4[q + 101:q + 461, 0], fi, dt) if q + 461 <= cn[c] else None
-            want = dict(fi=fi, dt=dt, err=0 if st[c, k] == 1 else -1, payload=pl)
-            good += _payload_equal(info[c, k], dch[c, k], dst[c, k], dcost[c, k], ambe[c, k], errs[c, k], want, (c, k))
+                csd3 = dt == 3 and fi == 1 and (int(f4h[c, k, 1]) & 7) == 1 and ((int(f4h[c, k, 1]) >> 3) & 7) == 0
+            pl = ysf.payload(r4[q + 101:q + 461, 0], fi, dt, csd3) if q + 461 <= cn[c] else None
+            want = dict(fi=fi, dt=dt, err=0 if st[c, k] == 1 else -1, payload=pl, csd3=csd3)
+            good += _payload_equal(info[c, k], dch[c, k], dst[c, k], dcost[c, k], ambe[c, k], errs[c, k], want, (c, k), fr[c, k], nfr[c, k])
+            n_csd3 += int(csd3 and pl is not None)
             kinds.add(int(info[c, k, 0]))
         assert (int(last[c, 0]), int(last[c, 1])) == (dt, fi), c
-    assert kinds >= {1, 2, 4, 8} and good >= 16, (kinds, good)
+    assert kinds >= {1, 2, 4, 8} and good >= 16 and n_csd3 >= 1, (kinds, good, n_csd3)
 
 
 def test_ysf_payload_through_the_chain_object(built):
@@ -228,12 +238,14 @@ def test_ysf_payload_through_the_chain_object(built):
         ns, pos, st = f(r.d_n_sync, np.int32, (B,)), f(r.d_sync_pos, np.int32, (B, S)), f(r.d_ysf_fich_status, np.uint8, (B, S))
         info, dch, dst = f(r.d_ysf_info2, np.uint8, (B, S, 2)), f(r.d_ysf_dch40, np.uint8, (B, S, 2, 20)), f(r.d_ysf_dch_status2, np.uint8, (B, S, 2))
         dcost, ambe, errs = f(r.d_ysf_dch_cost2, np.uint32, (B, S, 2)), f(r.d_ysf_ambe49x5, np.uint8, (B, S, 5, 49)), f(r.d_ysf_errs2x5, np.uint8, (B, S, 5))
+        fr, nfr = f(r.d_ysf_frames184x5, np.uint8, (B, S, 5, 184)), f(r.d_ysf_n_frames, np.uint8, (B, S))
         new = f(r.d_new, np.int32, (B,))
         for c in range(B):
             for k in range(int(ns[c])):
                 if st[c, k] != 0:
                     got[c].append(dict(pos=int(base[c]) + int(pos[c, k]) - int(T), info=info[c, k].copy(), dch=dch[c, k].copy(),
-                                       dst=dst[c, k].copy(), dcost=dcost[c, k].copy(), ambe=ambe[c, k].copy(), errs=errs[c, k].copy()))
+                                       dst=dst[c, k].copy(), dcost=dcost[c, k].copy(), ambe=ambe[c, k].copy(), errs=errs[c, k].copy(),
+                                       fr=fr[c, k].copy(), nfr=int(nfr[c, k])))
             base[c] += int(new[c])
 
     for k in range(calls):
@@ -254,7 +266,7 @@ def test_ysf_payload_through_the_chain_object(built):
         fr, _ = ysf.decode_payloads(want)
         assert [g["pos"] for g in got[c]] == [f["pos"] for f in fr], (c, len(got[c]), len(fr))
         for g, f in zip(got[c], fr):
-            good += _payload_equal(g["info"], g["dch"], g["dst"], g["dcost"], g["ambe"], g["errs"], f, (c, f["pos"]))
+            good += _payload_equal(g["info"], g["dch"], g["dst"], g["dcost"], g["ambe"], g["errs"], f, (c, f["pos"]), g["fr"], g["nfr"])
     assert good >= 16
 
 

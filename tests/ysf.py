@@ -45,8 +45,9 @@ def decode_frames(out):
     return fr
 
 
-def payload(dibits360, fi, dt):
-    """orc_ysf_payload -> dict(kind, dch[2][20], dch_status[2], dch_cost[2], ambe_d[5][49], errs2[5])"""
+def payload(dibits360, fi, dt, csd3=False):
+    """orc_ysf_payload + orc_ysf_voice_frames -> dict(kind, dch[2][20], dch_status[2], dch_cost[2], ambe_d[5][49], errs2[5], frames[5][184],
+    n_frames); csd3: the frame's own FICH is good and says FT = 1, FN = 0 (only looked at for full-rate voice)"""
     o = orc.oracle()
     o.orc_ysf_payload.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     o.orc_ysf_payload.restype = C.c_int
@@ -55,7 +56,15 @@ def payload(dibits360, fi, dt):
     ambe, errs = np.zeros((5, 49), np.uint8), np.zeros(5, np.uint8)
     kind = o.orc_ysf_payload(p.ctypes.data, int(fi), int(dt), dch.ctypes.data, st.ctypes.data, cost.ctypes.data, ambe.ctypes.data,
                              errs.ctypes.data)
-    return dict(kind=int(kind), dch=dch, dch_status=st, dch_cost=cost, ambe_d=ambe, errs2=errs)
+    o.orc_ysf_voice_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.orc_ysf_voice_frames.restype = C.c_int
+    fr = np.zeros((5, 184), np.uint8)
+    d20, st1, c1 = np.zeros(20, np.uint8), C.c_uint8(0), C.c_uint32(0)
+    nf = o.orc_ysf_voice_frames(p.ctypes.data, int(kind), int(bool(csd3) and kind == 4), fr.ctypes.data, d20.ctypes.data, C.byref(st1), C.byref(c1))
+    if kind == 4 and csd3:
+        dch[0], st[0], cost[0] = d20, st1.value, c1.value
+    return dict(kind=int(kind), dch=dch, dch_status=st, dch_cost=cost, ambe_d=ambe, errs2=errs, frames=fr, n_frames=int(nf),
+                csd3=bool(csd3) and kind == 4)
 
 
 def decode_payloads(out, last=(0, 0), n_rec=None):
@@ -70,10 +79,12 @@ def decode_payloads(out, last=(0, 0), n_rec=None):
         if pos + 101 > n:
             continue
         err, bits, cost = fich(out["rec4"][pos + 1:pos + 101, 0])
+        csd3 = False
         if err == 0:
             f = fields(bits)
             last_dt, last_fi = f["dt"], f["fi"]
+            csd3 = f["ft"] == 1 and f["fn"] == 0
         dt, fi = last_dt, last_fi
-        pl = payload(out["rec4"][pos + 101:pos + 461, 0], fi, dt) if pos + 461 <= n else None
+        pl = payload(out["rec4"][pos + 101:pos + 461, 0], fi, dt, csd3) if pos + 461 <= n else None
         fr.append(dict(pos=pos, err=err, fi=fi, dt=dt, payload=pl))
     return fr, (last_dt, last_fi)
