@@ -137,3 +137,19 @@ def test_vd1_frames_are_the_shared_ambe_schedule(built):
     for sf in range(4):
         fr, _ = rx4.ambe2450_deinterleave(p[72 * sf + 36:72 * sf + 72])
         assert np.array_equal(pl["frames"][sf, :96].reshape(4, 24), fr), sf
+
+
+def test_generated_fich_round_trip(built):
+    """tests/ysfgen.py is the inverse of the pinned decoder stages: every field comes back with a path cost of 0"""
+    import ysfgen
+    rng = np.random.default_rng(4)
+    for k in range(12):
+        kw = dict(cm=int(rng.integers(0, 4)), bn=int(rng.integers(0, 4)), bt=int(rng.integers(0, 4)), fn=int(rng.integers(0, 8)),
+                  ft=int(rng.integers(0, 8)), mr=int(rng.integers(0, 8)), vp=int(rng.integers(0, 2)), st=int(rng.integers(0, 2)),
+                  sc=int(rng.integers(0, 128)))
+        fi, dt = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        f = ysfgen.frame(rng, fi, dt, **kw)
+        err, bits, cost = ysf.fich(f[20:120])
+        got = ysf.fields(bits)
+        assert err == 0 and cost == 0 and got["fi"] == fi and got["dt"] == dt and all(got[k2] == v for k2, v in kw.items()), (k, got)
+    assert ysf.fich(ysfgen.frame(rng, 1, 2, break_fich=True)[20:120])[0] != 0

@@ -331,3 +331,63 @@ def test_ysf_vd2_voice_to_pcm_through_the_chain_object(built):
             assert np.array_equal(g[2], ro[0]), (c, f["pos"])
             total += 5
     assert total >= 200
+
+
+def test_generated_frames_of_every_type_through_loop_fich_and_payload(built):
+    """frames built by tests/ysfgen.py (header, V/D mode 1, V/D mode 2, full-rate voice plain and in the CSD3 layout, a data frame, a
+    frame whose FICH is broken - read as the type before it -, terminator) as 4-level discriminator samples, two channels (the second
+    inverted and delayed), in two calls: device loop -> FICH -> payload with the type carried = the CPU pipeline, frame for frame"""
+    import torch
+    import p25gen
+    import ysfgen
+    l = ddn.lib()
+    rng = np.random.default_rng(31)
+    plan = [(0, 1, {}), (1, 0, dict(fn=1, ft=6)), (1, 0, dict(fn=2, ft=6)), (1, 2, dict(fn=3, ft=6)), (1, 2, dict(fn=4, ft=6, break_fich=True)),
+            (1, 3, dict(fn=0, ft=1)), (1, 3, dict(fn=1, ft=1)), (1, 3, dict(fn=2, ft=1, break_fich=True)), (1, 1, dict(fn=0, ft=0)),
+            (1, 2, dict(fn=5, ft=6)), (2, 1, {})]
+    dib = np.concatenate([ysfgen.frame(rng, fi, dt, **kw) for fi, dt, kw in plan] + [rng.integers(0, 4, 60).astype(np.uint8)])
+    d0 = p25gen.modulate_disc(dib, lead=260, noise=250.0, seed=3)
+    n = len(d0)
+    x = np.zeros((2, n), np.float32)
+    x[0] = d0
+    x[1, 57:] = -d0[:n - 57]
+    B = 2
+    rx = ddn.Fsk4Rx(B, ddn.FSK4_YSF)
+    cpu = [rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_YSF)) for _ in range(B)]
+    last = torch.zeros((B, 2), dtype=torch.uint8, device="cuda")
+    want_last = [(0, 0)] * B
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+    p = lambda t: t.data_ptr()
+    seen, csd3_seen, carried = set(), 0, 0
+    for a, b in ((0, 30011), (30011, n)):          # (the cut lies inside a frame: that frame's payload is not in either call's records)
+        part = np.ascontiguousarray(x[:, a:b])
+        m = b - a
+        d = torch.from_numpy(part).cuda()
+        ms, my = l.ddn_fsk4_rx_max_symbols(rx.h, m), l.ddn_fsk4_rx_max_syncs(rx.h, m)
+        rec, fl, pay = z((B, ms, 10), torch.uint8), z((B, ms), torch.uint8), z((B, ms, 2), torch.uint8)
+        cnt, ns, spos = z((B,), torch.int32), z((B,), torch.int32), z((B, my), torch.int32)
+        spat, pre, prel = z((B, my), torch.uint8), z((B, my, 90), torch.uint8), z((B, my, 90), torch.uint8)
+        assert l.ddn_fsk4_rx_run(rx.h, p(d), m, p(rec), p(fl), p(pay), p(cnt), ms, p(spos), p(spat), p(pre), p(prel), p(ns), my, None) == 0
+        f4, st, ve = z((B, my, 4), torch.uint8), z((B, my), torch.uint8), z((B, my), torch.int32)
+        assert l.ddn_ysf_fich_decode_batch(p(rec), ms, p(cnt), p(spos), p(ns), B, my, p(f4), p(st), p(ve), None) == 0
+        info, dch, dst = z((B, my, 2), torch.uint8), z((B, my, 2, 20), torch.uint8), z((B, my, 2), torch.uint8)
+        dcost, ambe, errs = z((B, my, 2), torch.int32), z((B, my, 5, 49), torch.uint8), z((B, my, 5), torch.uint8)
+        fr, nfr = z((B, my, 5, 184), torch.uint8), z((B, my), torch.uint8)
+        assert l.ddn_ysf_payload_decode_batch(p(rec), ms, p(cnt), p(spos), p(ns), B, my, p(f4), p(st), p(last), p(info), p(dch), p(dst),
+                                              p(dcost), p(ambe), p(errs), p(fr), p(nfr), None) == 0, l.ddn_last_error()
+        torch.cuda.synchronize()
+        g = lambda t: t.cpu().numpy()
+        st, info, dch, dst, dcost, ambe, errs, fr, nfr = g(st), g(info), g(dch), g(dst), g(dcost).view(np.uint32), g(ambe), g(errs), g(fr), g(nfr)
+        nsy, pos = g(ns), g(spos)
+        for c in range(B):
+            want = cpu[c].run(part[c], max_sync=my)
+            frames, want_last[c] = ysf.decode_payloads(want, last=want_last[c])
+            mine = [k for k in range(int(nsy[c])) if st[c, k] != 0]
+            assert [int(pos[c, k]) for k in mine] == [f["pos"] for f in frames], (c, a)
+            for k, f in zip(mine, frames):
+                _payload_equal(info[c, k], dch[c, k], dst[c, k], dcost[c, k], ambe[c, k], errs[c, k], f, (c, a, k), fr[c, k], nfr[c, k])
+                seen.add(int(info[c, k, 0]))
+                csd3_seen += int(info[c, k, 1]) >> 7
+                carried += (int(info[c, k, 1]) >> 4) & 1
+        assert [tuple(v) for v in g(last)] == want_last
+    assert seen >= {1, 2, 4, 8} and csd3_seen >= 2 and carried >= 2, (seen, csd3_seen, carried)
