@@ -517,7 +517,8 @@ class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
                                   "d_m17_fn_payload18", "d_m17_str_status", "d_m17_lich_lsf30", "d_m17_lich_status", "d_ysf_fich4",
                                   "d_ysf_fich_status", "d_ysf_fich_cost", "d_ysf_info2", "d_ysf_dch40", "d_ysf_dch_status2",
                                   "d_ysf_dch_cost2", "d_ysf_ambe49x5", "d_ysf_errs2x5", "d_ysf_frames184x5", "d_ysf_n_frames")] + [("ysf_voice_frames", C.c_int)] + [
-        (k, C.c_void_p) for k in ("d_ysf_n_voice", "d_ysf_voice_slot", "d_ysf_voice_result", "d_ysf_pcm")]
+        (k, C.c_void_p) for k in ("d_ysf_n_voice", "d_ysf_voice_slot", "d_ysf_voice_result", "d_ysf_pcm", "d_ysf_voice_skip", "d_ysf_imbe_n_voice",
+                                  "d_ysf_imbe_voice_slot", "d_ysf_imbe_voice_skip", "d_ysf_imbe_voice_result", "d_ysf_imbe_pcm")]
 
 
 class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config

@@ -86,6 +86,12 @@ struct ddn_fsk4_chain {
     // d_skip, d_pcm, d_res_out, d_vn as for NXDN48; yvf frames of five sub-frames per channel and call)
     int yvf;
     int32_t* y_vslot;
+    // ... V/D mode 1 (four AMBE frames through the frame FEC, filed with the V/D mode 2 sub-frames in stream order) and full-rate voice
+    // (IMBE 7200x4400: a vocoder batch, talk-path history and PCM of its own)
+    ddn_mbe_batch* mbe_i;
+    uint8_t *y_f96, *y_b49, *y_b88, *yi_bits, *yi_skip;
+    int32_t *y_r49, *y_r88, *yi_res, *yi_res_out, *yi_vn, *yi_vslot;
+    float* yi_pcm;
     long step;
     int last_set;
 };
@@ -122,7 +128,8 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
     ddn_batch_destroy(c->fe);
     ddn_fsk4_rx_destroy(c->rx);
     ddn_mbe_batch_destroy(c->mbe);
-    void* all[] = {c->y_fr, c->y_nfr, c->y_vslot, c->y_fich4, c->y_st, c->y_ve, c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_ambe, c->y_errs, c->y_dcost, c->s_thr, c->c_thr[0], c->c_thr[1], c->d_thr, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_fp, c->m_st, c->m_asm, c->m_ll,
+    ddn_mbe_batch_destroy(c->mbe_i);
+    void* all[] = {c->y_f96, c->y_b49, c->y_b88, c->yi_bits, c->yi_skip, c->y_r49, c->y_r88, c->yi_res, c->yi_res_out, c->yi_vn, c->yi_vslot, c->yi_pcm, c->y_fr, c->y_nfr, c->y_vslot, c->y_fich4, c->y_st, c->y_ve, c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_ambe, c->y_errs, c->y_dcost, c->s_thr, c->c_thr[0], c->c_thr[1], c->d_thr, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_fp, c->m_st, c->m_asm, c->m_ll,
                    c->m_ll_st, c->m_cost, c->d_disc, c->d_disc2, c->d_rec[0], c->d_rec[1], c->d_fl[0], c->d_fl[1], c->d_pay, c->d_new[0], c->d_new[1], c->d_cnt_full,
                    c->d_cnt_scan, c->d_dropped, c->s_pos, c->s_n, c->c_pos[0], c->c_pos[1], c->c_n[0], c->c_n[1], c->d_spos, c->d_ns, c->s_pat, c->s_pre,
                    c->s_prel, c->c_pat[0], c->c_pat[1], c->c_pre[0], c->c_pre[1], c->c_prel[0], c->c_prel[1], c->d_spat, c->d_pre,
@@ -140,8 +147,10 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
 }
 
 extern "C" hipError_t ddn_dev_ysf_voice_file(const int32_t* n_sync, int n_channels, int max_syncs, const uint8_t* info, const uint8_t* ambe49,
-                                             const uint8_t* errs2, int vf, uint8_t* bits, int32_t* res, uint8_t* skip, int32_t* v_n,
-                                             int32_t* v_slot, hipStream_t st);
+                                             const uint8_t* errs2, const uint8_t* bits_fd, const int32_t* res_fd, const uint8_t* n_frames,
+                                             int mode, int vf, uint8_t* bits, int32_t* res, uint8_t* skip, int32_t* v_n, int32_t* v_slot,
+                                             hipStream_t st);
+extern "C" hipError_t ddn_dev_ysf_pack96(const uint8_t* frames184, size_t n, uint8_t* frames96, hipStream_t st);
 
 extern "C" int
 ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
@@ -222,7 +231,13 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
                 const size_t V5 = B * (size_t)c->yvf * 5;
                 ok = dalloc(&c->y_vslot, B * (size_t)c->yvf) && dalloc(&c->d_vn, B) && dalloc(&c->d_ambe_d, V5 * 49) && dalloc(&c->d_ambe_res, V5 * 5)
                      && dalloc(&c->d_skip, V5) && dalloc(&c->d_pcm, V5 * 160) && dalloc(&c->d_res_out, V5 * 5);
+                ok = ok && dalloc(&c->y_f96, S * 5 * 96) && dalloc(&c->y_b49, S * 5 * 49) && dalloc(&c->y_r49, S * 5 * 5) && dalloc(&c->y_b88, S * 5 * 88)
+                     && dalloc(&c->y_r88, S * 5 * 5) && dalloc(&c->yi_bits, V5 * 88) && dalloc(&c->yi_res, V5 * 5) && dalloc(&c->yi_res_out, V5 * 5)
+                     && dalloc(&c->yi_skip, V5) && dalloc(&c->yi_pcm, V5 * 160) && dalloc(&c->yi_vn, B) && dalloc(&c->yi_vslot, B * (size_t)c->yvf);
                 if (ok && (rc = ddn_mbe_batch_create(DDN_MBE_AMBE_3600X2450, c->B, &c->mbe)) != DDN_OK) {
+                    break;
+                }
+                if (ok && (rc = ddn_mbe_batch_create(DDN_MBE_IMBE_7200X4400, c->B, &c->mbe_i)) != DDN_OK) {
                     break;
                 }
             }
@@ -323,10 +338,19 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
         DDN_TRY(ddn_ysf_payload_decode_batch(rec, c->stride, c->d_cnt_full, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->y_fich4, c->y_st,
                                              c->y_last, c->y_info, c->y_dch, c->y_dst, c->y_dcost, c->y_ambe, c->y_errs, c->y_fr, c->y_nfr, st));
         if (c->mbe) { // mbe_processAmbe2450Dataf of every V/D mode 2 sub-frame, talk path = channel (ysf_handle_vd_type2, ysf.c:753-755)
-            HIP_TRY(ddn_dev_ysf_voice_file(c->d_ns, c->B, c->myd, c->y_info, c->y_ambe, c->y_errs, c->yvf, c->d_ambe_d, c->d_ambe_res, c->d_skip,
-                                           c->d_vn, c->y_vslot, st));
-            DDN_TRY(ddn_mbe_result_skip_batch(c->d_skip, (size_t)c->B * (size_t)c->yvf * 5, c->d_ambe_res, st));
+            // the frames of V/D mode 1 and of full-rate voice through the frame FEC (processMbeFrame's hard decode, dsd_mbe.c:54-92), slot by slot
+            const size_t S5 = c->S * 5, V5 = (size_t)c->B * (size_t)c->yvf * 5;
+            HIP_TRY(ddn_dev_ysf_pack96(c->y_fr, S5, c->y_f96, st));
+            DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, c->y_f96, nullptr, S5, c->y_b49, c->y_r49, st));
+            DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_IMBE_7200X4400, c->y_fr, nullptr, S5, c->y_b88, c->y_r88, st));
+            HIP_TRY(ddn_dev_ysf_voice_file(c->d_ns, c->B, c->myd, c->y_info, c->y_ambe, c->y_errs, c->y_b49, c->y_r49, c->y_nfr, 0, c->yvf,
+                                           c->d_ambe_d, c->d_ambe_res, c->d_skip, c->d_vn, c->y_vslot, st));
+            DDN_TRY(ddn_mbe_result_skip_batch(c->d_skip, V5, c->d_ambe_res, st));
             DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_ambe_d, c->d_ambe_res, (size_t)c->yvf * 5, c->d_pcm, c->d_res_out, st));
+            HIP_TRY(ddn_dev_ysf_voice_file(c->d_ns, c->B, c->myd, c->y_info, c->y_ambe, c->y_errs, c->y_b88, c->y_r88, c->y_nfr, 1, c->yvf,
+                                           c->yi_bits, c->yi_res, c->yi_skip, c->yi_vn, c->yi_vslot, st));
+            DDN_TRY(ddn_mbe_result_skip_batch(c->yi_skip, V5, c->yi_res, st));
+            DDN_TRY(ddn_mbe_synth_batch(c->mbe_i, c->yi_bits, c->yi_res, (size_t)c->yvf * 5, c->yi_pcm, c->yi_res_out, st));
         }
         return DDN_OK;
     }
@@ -568,6 +592,12 @@ ddn_fsk4_chain_get_results(ddn_fsk4_chain* c, ddn_fsk4_chain_results* r) {
         r->d_ysf_voice_slot = c->mbe ? c->y_vslot : nullptr;
         r->d_ysf_voice_result = c->mbe ? c->d_res_out : nullptr;
         r->d_ysf_pcm = c->mbe ? c->d_pcm : nullptr;
+        r->d_ysf_voice_skip = c->mbe ? c->d_skip : nullptr;
+        r->d_ysf_imbe_n_voice = c->mbe_i ? c->yi_vn : nullptr;
+        r->d_ysf_imbe_voice_slot = c->mbe_i ? c->yi_vslot : nullptr;
+        r->d_ysf_imbe_voice_skip = c->mbe_i ? c->yi_skip : nullptr;
+        r->d_ysf_imbe_voice_result = c->mbe_i ? c->yi_res_out : nullptr;
+        r->d_ysf_imbe_pcm = c->mbe_i ? c->yi_pcm : nullptr;
     }
     if (c->m17) {
         r->d_sync_thr5 = c->d_thr;

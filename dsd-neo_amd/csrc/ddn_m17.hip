@@ -726,33 +726,49 @@ k_ysf_dch_finish(const uint8_t* __restrict__ decA, const uint32_t* __restrict__ 
     dch_cost[so * 2 + blk] = vd2 ? pcA[slot] : pcB[slot * 2 + blk];
 }
 
-// V/D mode 2 voice of a call filed by talk path (= channel): the voice sub-frames of the channel's frames in stream order -> bits
-// [c][vf5][49], result rows {flags 0, c0 0, c4 0, total = protected = errs2} (ysf_handle_vd_type2, ysf.c:745-752), skip flags behind the
-// last one, v_n[c] = frames filed, v_slot[c][j] = the sync slot frame j came from.  One wavefront per channel.
+// The voice of a call filed by talk path (= channel), the frames of the channel in stream order, five positions per frame:
+//   mode 0, the AMBE 3600x2450 path: a V/D mode 2 frame -> its five sub-frames' ambe_d + result rows {0, 0, 0, errs2, errs2}
+//     (ysf_handle_vd_type2, ysf.c:745-752); a V/D mode 1 frame -> the four frames ysf_ehr() decodes, as the frame FEC left them
+//     (bits_fd / res_fd by slot x 5), the fifth position skipped;
+//   mode 1, the IMBE 7200x4400 path: a full-rate voice frame -> its five (CSD3: two) frames from the frame FEC, the rest skipped.
+// skip flags behind the last frame too; v_n[c] = frames filed, v_slot[c][j] = the sync slot frame j came from.  One wavefront per channel.
 __global__ __launch_bounds__(64) void
 k_ysf_voice_file(const int32_t* __restrict__ n_sync, int max_syncs, const uint8_t* __restrict__ info, const uint8_t* __restrict__ ambe49,
-                 const uint8_t* __restrict__ errs2, int vf, uint8_t* __restrict__ bits, int32_t* __restrict__ res, uint8_t* __restrict__ skip,
-                 int32_t* __restrict__ v_n, int32_t* __restrict__ v_slot) {
+                 const uint8_t* __restrict__ errs2, const uint8_t* __restrict__ bits_fd, const int32_t* __restrict__ res_fd,
+                 const uint8_t* __restrict__ n_frames, int mode, int vf, uint8_t* __restrict__ bits, int32_t* __restrict__ res,
+                 uint8_t* __restrict__ skip, int32_t* __restrict__ v_n, int32_t* __restrict__ v_slot) {
     const int c = blockIdx.x, lane = threadIdx.x;
+    const int nb = mode ? 88 : 49;
     int ns = n_sync[c];
     ns = ns < max_syncs ? ns : max_syncs;
     int j = 0;
     for (int k0 = 0; k0 < ns; k0 += 64) {
         const int k = k0 + lane;
-        const bool is = k < ns && (info[2 * ((size_t)c * max_syncs + k)] & 2) != 0;
+        const int kd = k < ns ? info[2 * ((size_t)c * max_syncs + k)] : 0;
+        const bool is = mode ? kd == 4 : (kd == 2 || kd == 1);
         unsigned long long b = __ballot(is);
         while (b && j < vf) {
             const int kk = k0 + __ffsll((long long)b) - 1;
             b &= b - 1;
             const size_t so = (size_t)c * max_syncs + kk, d0 = ((size_t)c * vf + j) * 5;
-            for (int t = lane; t < 5 * 49; t += 64) {
-                bits[d0 * 49 + t] = ambe49[so * 5 * 49 + t];
+            const bool direct = !mode && info[2 * so] == 2;
+            const int nf = direct ? 5 : n_frames[so];
+            for (int t = lane; t < 5 * nb; t += 64) {
+                const int f = t / nb;
+                bits[d0 * nb + t] = f < nf ? (direct ? ambe49[so * 5 * 49 + t] : bits_fd[so * 5 * nb + t]) : 0;
             }
             if (lane < 5) {
-                const int e = errs2[so * 5 + lane];
                 int32_t* r = res + (d0 + lane) * 5;
-                r[0] = 0, r[1] = 0, r[2] = 0, r[3] = e, r[4] = e;
-                skip[d0 + lane] = 0;
+                if (lane >= nf) {
+                    r[0] = 0, r[1] = 0, r[2] = 0, r[3] = 0, r[4] = 0;
+                } else if (direct) {
+                    const int e = errs2[so * 5 + lane];
+                    r[0] = 0, r[1] = 0, r[2] = 0, r[3] = e, r[4] = e;
+                } else {
+                    const int32_t* q = res_fd + (so * 5 + lane) * 5;
+                    r[0] = q[0], r[1] = q[1], r[2] = q[2], r[3] = q[3], r[4] = q[4];
+                }
+                skip[d0 + lane] = lane < nf ? 0 : 1;
             }
             if (lane == 0) {
                 v_slot[(size_t)c * vf + j] = kk;
@@ -770,11 +786,29 @@ k_ysf_voice_file(const int32_t* __restrict__ n_sync, int max_syncs, const uint8_
     }
 }
 
+__global__ void
+k_ysf_pack96(const uint8_t* __restrict__ frames184, size_t n, uint8_t* __restrict__ frames96) { // ambe_fr[4][24] out of the 184-byte slots
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * 96) {
+        frames96[i] = frames184[(i / 96) * 184 + i % 96];
+    }
+}
+
 extern "C" hipError_t
 ddn_dev_ysf_voice_file(const int32_t* n_sync, int n_channels, int max_syncs, const uint8_t* info, const uint8_t* ambe49, const uint8_t* errs2,
-                       int vf, uint8_t* bits, int32_t* res, uint8_t* skip, int32_t* v_n, int32_t* v_slot, hipStream_t st) {
-    hipLaunchKernelGGL(k_ysf_voice_file, dim3((unsigned)n_channels), dim3(64), 0, st, n_sync, max_syncs, info, ambe49, errs2, vf, bits, res,
-                       skip, v_n, v_slot);
+                       const uint8_t* bits_fd, const int32_t* res_fd, const uint8_t* n_frames, int mode, int vf, uint8_t* bits, int32_t* res,
+                       uint8_t* skip, int32_t* v_n, int32_t* v_slot, hipStream_t st) {
+    hipLaunchKernelGGL(k_ysf_voice_file, dim3((unsigned)n_channels), dim3(64), 0, st, n_sync, max_syncs, info, ambe49, errs2, bits_fd, res_fd,
+                       n_frames, mode, vf, bits, res, skip, v_n, v_slot);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+ddn_dev_ysf_pack96(const uint8_t* frames184, size_t n, uint8_t* frames96, hipStream_t st) {
+    if (n == 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_ysf_pack96, dim3((unsigned)((n * 96 + 255) / 256)), dim3(256), 0, st, frames184, n, frames96);
     return hipGetLastError();
 }
 

@@ -370,12 +370,21 @@ typedef struct ddn_fsk4_chain_results { /* device pointers, S = n_channels * max
     const uint8_t* d_ysf_errs2x5;        /* [S][5] their errs2 */
     const uint8_t* d_ysf_frames184x5;    /* [S][5][184] V/D mode 1: four ambe_fr[4][24]; full-rate voice: five (CSD3: two) imbe_fr[8][23] */
     const uint8_t* d_ysf_n_frames;       /* [S] how many of them */
-    /* ... V/D mode 2 voice through the vocoder (vocoder = 1; 0 / NULL otherwise): talk path = channel, the frames of a call in stream order */
-    int ysf_voice_frames;                /* F: frames (of five sub-frames) per channel and call the arrays below hold */
-    const int32_t* d_ysf_n_voice;        /* [n_channels] V/D mode 2 frames of this call */
+    /* ... voice through the vocoder (vocoder = 1; 0 / NULL otherwise): talk path = channel, the frames of a call in stream order, five
+     * positions per frame.  AMBE 3600x2450: V/D mode 2 frames (five sub-frames) and V/D mode 1 frames (the four ysf_ehr() decodes; the
+     * fifth position skipped) share one talk-path history; IMBE 7200x4400 (full-rate voice: five frames, two in the CSD3 layout) has its
+     * own - a stream that changed codec inside a call would share mbe_parms in the reference, a case these arrays keep apart */
+    int ysf_voice_frames;                /* F: frames (of five positions) per channel and call the arrays below hold */
+    const int32_t* d_ysf_n_voice;        /* [n_channels] AMBE frames (V/D mode 1 or 2) of this call */
     const int32_t* d_ysf_voice_slot;     /* [n_channels][F] the sync slot each came from */
     const int32_t* d_ysf_voice_result;   /* [n_channels][F * 5][5] mbe_process_result rows after synthesis */
     const float* d_ysf_pcm;              /* [n_channels][F * 5][160] 8 kHz PCM (silence behind the last frame) */
+    const uint8_t* d_ysf_voice_skip;     /* [n_channels][F * 5] 1 = no frame at this position */
+    const int32_t* d_ysf_imbe_n_voice;   /* the same five arrays for the full-rate (IMBE) frames */
+    const int32_t* d_ysf_imbe_voice_slot;
+    const uint8_t* d_ysf_imbe_voice_skip;
+    const int32_t* d_ysf_imbe_voice_result;
+    const float* d_ysf_imbe_pcm;
 } ddn_fsk4_chain_results;
 typedef struct ddn_fsk4_chain ddn_fsk4_chain;
 int ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out);

@@ -145,7 +145,8 @@ int ddn_ysf_fich_decode_batch(const uint8_t* d_records10, size_t stride_symbols,
  *     imbe_fr[8][23] as row * 23 + column (d_n_frames = 5); with FT = 1 and FN = 0 (CSD3, d_info2[1] bit 128) two frames behind a data
  *     block that goes through ysf_conv_dch into block 0 (ysf_handle_full_rate_voice :824-842);
  *   full-rate data (a frame that is nothing else): both blocks, in turn (ysf_handle_full_rate_data :844-864).
- * S = n_channels x max_syncs, slots as d_sync_pos.  The frames of V/D mode 1 and of full-rate voice are handed back, not synthesized. */
+ * S = n_channels x max_syncs, slots as d_sync_pos.  The frames of V/D mode 1 and of full-rate voice are handed back as frames here; the
+ * chain object (include/ddn_chain.h, vocoder = 1) takes them through ddn_mbe_frame_decode_batch and ddn_mbe_synth_batch. */
 int ddn_ysf_payload_decode_batch(const uint8_t* d_records10, size_t stride_symbols, const int32_t* d_counts, const int32_t* d_sync_pos,
                                  const int32_t* d_n_sync, int n_channels, size_t max_syncs, const uint8_t* d_fich4,
                                  const uint8_t* d_fich_status, uint8_t* d_last_dt_fi, uint8_t* d_info2, uint8_t* d_dch40,

@@ -391,3 +391,82 @@ def test_generated_frames_of_every_type_through_loop_fich_and_payload(built):
                 carried += (int(info[c, k, 1]) >> 4) & 1
         assert [tuple(v) for v in g(last)] == want_last
     assert seen >= {1, 2, 4, 8} and csd3_seen >= 2 and carried >= 2, (seen, csd3_seen, carried)
+
+
+def test_generated_voice_of_every_mode_to_pcm_through_the_chain_object(built):
+    """generated frames as cu8 C4FM I/Q through the chain object with vocoder = 1, in three calls + flush: V/D mode 1 (four AMBE frames
+    through the frame FEC) and V/D mode 2 (five sub-frames) share the AMBE talk path in stream order, full-rate voice (five IMBE frames,
+    two in the CSD3 layout) goes down the IMBE one - positions, result rows and PCM bit for bit against the CPU pipeline + CPU vocoder"""
+    import mbe
+    import p25gen
+    import ysfgen
+    rng = np.random.default_rng(77)
+    plan = [(0, 1, {}), (1, 0, dict(fn=1, ft=6)), (1, 2, dict(fn=2, ft=6)), (1, 0, dict(fn=3, ft=6)), (1, 2, dict(fn=4, ft=6, break_fich=True)),
+            (1, 3, dict(fn=0, ft=1)), (1, 3, dict(fn=1, ft=1)), (1, 3, dict(fn=2, ft=1)), (1, 2, dict(fn=5, ft=6)), (1, 0, dict(fn=6, ft=6)),
+            (2, 1, {})]
+    dib = np.concatenate([ysfgen.frame(rng, fi, dt, **kw) for fi, dt, kw in plan] + [rng.integers(0, 4, 80).astype(np.uint8)])
+    n = 20000
+    calls = 3
+    B = 2
+    x = np.stack([p25gen.modulate_cu8(dib, calls * n, lead=230 + 170 * c, seed=5 + c) for c in range(B)])               # [B][calls * n][2]
+    ch = ddn.Fsk4ChainC(B, n, ddn.FSK4_YSF, rf_mod=0, handlers=0, vocoder=1)
+    l = ddn.lib()
+    got = {"a": [[] for _ in range(B)], "i": [[] for _ in range(B)]}
+    base = np.zeros(B, np.int64)
+
+    def take():
+        r = ch.results()
+        S, T, F = r.max_syncs, r.carry_symbols, r.ysf_voice_frames
+        f = ch.fetch
+        pos, new = f(r.d_sync_pos, np.int32, (B, S)), f(r.d_new, np.int32, (B,))
+        for key, nv_p, slot_p, skip_p, res_p, pcm_p in (("a", r.d_ysf_n_voice, r.d_ysf_voice_slot, r.d_ysf_voice_skip, r.d_ysf_voice_result, r.d_ysf_pcm),
+                                                        ("i", r.d_ysf_imbe_n_voice, r.d_ysf_imbe_voice_slot, r.d_ysf_imbe_voice_skip,
+                                                         r.d_ysf_imbe_voice_result, r.d_ysf_imbe_pcm)):
+            nv, slot, skip = f(nv_p, np.int32, (B,)), f(slot_p, np.int32, (B, F)), f(skip_p, np.uint8, (B, F * 5))
+            res, pcm = f(res_p, np.int32, (B, F * 5, 5)), f(pcm_p, np.float32, (B, F * 5, 160))
+            for c in range(B):
+                assert not pcm[c, 5 * nv[c]:].any() and skip[c, 5 * nv[c]:].all()
+                for j in range(int(nv[c])):
+                    got[key][c].append((int(base[c]) + int(pos[c, slot[c, j]]) - int(T), pcm[c, 5 * j:5 * j + 5].copy(), res[c, 5 * j:5 * j + 5].copy(),
+                                        skip[c, 5 * j:5 * j + 5].copy()))
+        base[:] += new
+
+    for k in range(calls):
+        part = np.ascontiguousarray(x[:, k * n:(k + 1) * n])
+        p = C.c_void_p()
+        assert l.ddn_device_alloc(part.nbytes, C.byref(p)) == 0 and l.ddn_device_upload(p, part.ctypes.data, part.nbytes) == 0
+        ch.run(p)
+        take()
+        l.ddn_device_free(p)
+    ch.flush()
+    take()
+    ch.close()
+    total = {"a": 0, "i": 0}
+    for c in range(B):
+        fe = orc.OracleFrontEnd(profile=2)
+        disc = np.concatenate([fe.run_cu8(np.ascontiguousarray(x[c, k * n:(k + 1) * n]), 8192) for k in range(calls)])
+        want = rx4.OracleFsk4Rx(rx4.profile(rx4.PROTO_YSF)).run(disc, max_sync=4096)
+        fr, _ = ysf.decode_payloads(want)
+        for key, codec, kinds, shape in (("a", ddn.MBE_AMBE, (1, 2), (4, 24)), ("i", ddn.MBE_IMBE, (4,), (8, 23))):
+            mine = [f for f in fr if f["payload"] is not None and f["payload"]["kind"] in kinds]
+            assert [g[0] for g in got[key][c]] == [f["pos"] for f in mine], (key, c, len(got[key][c]), len(mine))
+            voc = mbe.OracleVocoder(codec, 1)
+            for g, f in zip(got[key][c], mine):
+                pl = f["payload"]
+                if pl["kind"] == 2:
+                    nf, bits = 5, np.ascontiguousarray(pl["ambe_d"][None])
+                    ri = np.zeros((1, 5, 5), np.int32)
+                    ri[0, :, 3] = ri[0, :, 4] = pl["errs2"]
+                else:
+                    nf = pl["n_frames"]
+                    frames = np.ascontiguousarray(pl["frames"][:nf, :shape[0] * shape[1]].reshape(nf, *shape))
+                    bits, ri, rc = mbe.oracle_frame_decode(codec, frames)
+                    bits, ri = np.ascontiguousarray(bits[None]), np.ascontiguousarray(ri[None])
+                assert list(g[3]) == [0] * nf + [1] * (5 - nf), (key, c, f["pos"], g[3])
+                pcm, ro = np.zeros((1, nf, 160), np.float32), np.zeros((1, nf, 5), np.int32)
+                assert mbe._o().om_process_batch(codec, C.addressof(voc.tab), bits.ctypes.data, ri.ctypes.data, 0, c, 1, nf, pcm.ctypes.data,
+                                                 ro.ctypes.data, C.addressof(voc.cur), C.addressof(voc.prev), C.addressof(voc.enh)) == 0
+                assert np.array_equal(g[1][:nf].view(np.uint32), pcm[0].view(np.uint32)), (key, c, f["pos"])
+                assert not g[1][nf:].any() and np.array_equal(g[2][:nf], ro[0]), (key, c, f["pos"])
+                total[key] += nf
+    assert total["a"] >= 2 * (3 * 4 + 2 * 5) - 9 and total["i"] >= 2 * (2 + 5), total
