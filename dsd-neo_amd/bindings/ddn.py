@@ -126,6 +126,7 @@ PROTOTYPES = {
     "ddn_p25_rx_reset": (C.c_int, [C.c_void_p]),
     "ddn_p25_rx_set_lock_symbols": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_rx_set_channels_per_wave": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_p25_rx_set_filter_in_loop": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_p25_rx_set_handlers": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ddn_p25_rx_debug_counters": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25_rx_set_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -978,9 +979,9 @@ class P25Rx:
     """Batched fixed-protocol P25p1 receive loop (ddn_p25_rx_*), host-buffer convenience wrapper."""
 
     def __init__(self, n_channels, out_rate=48000, sym_rate=4800, lock_symbols=840, use_matched_filter=1,
-                 channels_per_wave=0, handlers=False, max_events=0):
+                 channels_per_wave=0, handlers=False, max_events=0, filter_in_loop=False):
         """handlers=True: the reference's per-DUID handlers decide the in-frame length (lock_symbols unused); run() then
-        also leaves .events int32 [B, max_events, 4] / .n_events int32 [B] of the call"""
+        also leaves .events int32 [B, max_events, 4] / .n_events int32 [B] of the call.  filter_in_loop: ddn_p25_rx_set_filter_in_loop"""
         import numpy as np
         self.np = np
         self.B = n_channels
@@ -994,6 +995,8 @@ class P25Rx:
         self.max_events = max_events or 4096
         if handlers:
             assert lib().ddn_p25_rx_set_handlers(self.h, 1, 64) == 0
+        if filter_in_loop:
+            assert lib().ddn_p25_rx_set_filter_in_loop(self.h, 1) == 0
 
     def run(self, disc):
         """disc float32 [B, n] -> (records uint8 [B, max_sym, 10], flags uint8 [B, max_sym], counts int32 [B])."""

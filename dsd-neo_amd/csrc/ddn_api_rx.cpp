@@ -30,6 +30,7 @@ struct ddn_p25_rx {
     float* d_filt; // always-on matched-filter output of the current call, [B][filt_cap]
     size_t filt_cap;
     int channels_per_wave;
+    int filter_in_loop; // ddn_p25_rx_set_filter_in_loop
     int32_t* d_lock; // [B] in-frame symbols after a sync, per channel (cfg.lock_symbols unless overridden)
     // handler mode (ddn_p25_rx_set_handlers): per-channel handler words, the in-frame history ring [B][104][3] f32, the
     // caller's event buffers (or a one-event dummy of our own)
@@ -252,6 +253,15 @@ ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave) {
     return DDN_OK;
 }
 
+extern "C" int
+ddn_p25_rx_set_filter_in_loop(ddn_p25_rx* b, int on) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    b->filter_in_loop = on != 0;
+    return DDN_OK;
+}
+
 extern "C" size_t
 ddn_p25_rx_max_symbols(const ddn_p25_rx* b, size_t n) {
     if (!b) {
@@ -293,7 +303,16 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
         }
         HIP_TRY(hipEventRecord(rv[0], st));
     }
-    if (b->cfg.use_matched_filter) {
+    DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0,
+                      b->handlers, b->nid_threshold, b->d_events ? (int)b->max_events : 1,
+                      b->d_events ? b->d_event_data : nullptr};
+    if (const char* e = getenv("DDN_RX_DBG")) {
+        dc.dbg = (int)strtoll(e, nullptr, 0);
+    }
+    // handler mode, on request (ddn_p25_rx_set_filter_in_loop): the loop kernel filters each staged tile itself (ddn_rx.hip "the
+    // matched filter inside the loop") - no filter kernel, no second f32 row in HBM
+    const bool fused = b->filter_in_loop && ddn_dev_p25_rx_fuses_filter(&dc, b->channels_per_wave, B) != 0;
+    if (b->cfg.use_matched_filter && !fused) {
         if (b->filt_cap < n) {
             HIP_TRY(hipStreamSynchronize(st));
             (void)hipFree(b->d_filt);
@@ -316,13 +335,7 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
         HIP_TRY(hipEventRecord(b->loop_event, st));
         b->loop_event = nullptr;
     }
-    DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0,
-                      b->handlers, b->nid_threshold, b->d_events ? (int)b->max_events : 1,
-                      b->d_events ? b->d_event_data : nullptr};
-    if (const char* e = getenv("DDN_RX_DBG")) {
-        dc.dbg = atoi(e);
-    }
-    HIP_TRY(ddn_dev_p25_rx(d_disc, b->d_filt, b->d_fhist, b->d_fstale, (long)n, n, B, &dc, b->d_state, b->d_sbuf, b->d_lbuf,
+    HIP_TRY(ddn_dev_p25_rx(d_disc, fused ? nullptr : b->d_filt, b->d_fhist, b->d_fstale, (long)n, n, B, &dc, b->d_state, b->d_sbuf, b->d_lbuf,
                            b->d_shist, b->d_minring, b->d_maxring, d_records10, d_flags, d_counts, max_symbols,
                            b->channels_per_wave, b->d_lock, b->d_hstate, b->d_hh, b->d_events ? b->d_events : b->d_ev_dummy,
                            b->d_n_events ? b->d_n_events : b->d_nev_dummy, st));

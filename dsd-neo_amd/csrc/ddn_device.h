@@ -164,6 +164,7 @@ hipError_t ddn_dev_p25_matched_filter_only(const float* in, long n, size_t strid
                                            float* out, hipStream_t st);
 hipError_t ddn_dev_p25_filter_hist_update(const float* in, long n, size_t stride, int n_channels, float* hist,
                                           hipStream_t st);
+int ddn_dev_p25_rx_fuses_filter(const DdnRxConfig* cfg, int channels_per_wave, int n_channels);
 hipError_t ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride,
                           int n_channels, const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store,
                           float* lbuf_store, float* shist_store, float* minring, float* maxring, uint8_t* rec,

@@ -437,7 +437,7 @@ k_p25_rx(const float* __restrict__ raw, const float* __restrict__ filt, const fl
                             two_max_insert(L.gs[g][3][ln], x1, x2);
                         }
                         const float lo = (m1 + m2) * 0.5f, hi = (x1 + x2) * 0.5f;
-                        const size_t ro = (size_t)s.midx * n_channels + ch;
+                        const size_t ro = (size_t)ch * MS + s.midx; // [channel][slot], see k_p25_rxw
                         float old_lo = s.fill_min, old_hi = s.fill_max;
                         if (s.since_fill >= MS && !(cfg.dbg & 32)) {
                             old_lo = minring[ro];
@@ -772,6 +772,9 @@ struct LdsH {
     int hwid[8];      // HW_ID of the workgroup's waves (role placement)
     int ready[4];     // per recurrence wave: tiles the staging wave has made enterable for its channels (staged + window
                       // summaries of the checkpoint before)
+    int fready[4];    // per recurrence wave: tiles whose matched-filter row the handler wave has computed (filter in the loop)
+    int staged[4];    // per recurrence wave: tiles whose raw samples are in the ring (what the filter pass waits for; `ready` follows
+                      // once the window summaries are written too)
     float hh_dummy[CPW][4]; // where the lean run's history store goes for a lane whose phase does not end in a decision
     ddn_p25h::Scratch sc;
 };
@@ -809,6 +812,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     LW& L = *reinterpret_cast<LW*>(smem_raw);
     LdsH<CPW>& H = *reinterpret_cast<LdsH<CPW>*>(smem_raw + ((sizeof(LW) + 15) & ~(size_t)15));
     const int lane = ltid & 63;
+    // (round 6) The matched filter inside the loop: with `filt` == NULL the always-on filter output of a tile is computed from the raw
+    // tile where it already sits in LDS - by the handler wave, between decisions - instead of by a kernel of its own that writes
+    // a second f32 row to HBM for this one to read back (src/dsp/dsd_filters.c:173-200,299-324: same taps, same order of sums).
+    // (128-sample tiles only: the 90 samples ahead of a tile are then all in the ring's previous slot)
+    const bool fuse_mf = HM && LdsW<CPW, HM>::TW == 128 && cfg.use_filter != 0 && filt == nullptr;
     // Which wave takes which role.  The dispatcher puts the four waves of a workgroup on the four SIMDs of its CU in an order that
     // changes from workgroup to workgroup, and two workgroups share a CU: with the roles tied to the wave index a quarter of the
     // SIMDs ended up with two recurrence waves (two latency chains taking turns) and a quarter with none.  So the roles go by SIMD:
@@ -889,6 +897,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             for (int w = 0; w < 4; w++) {
                 H.tile_done[w] = 0;
                 H.ready[w] = 1; // tile 0 is staged and summarised by the prologue
+                H.fready[w] = 0;
+                H.staged[w] = 1;
             }
             ddn_nid::gf_fill(H.sc.ex, H.sc.lg);
             ddn_nid::chase_masks_fill(H.sc.masks);
@@ -1159,31 +1169,191 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         }
     };
 
-        int it = 0;
-        float idle_spin = 0.0f;
-        for (long t0 = 0; t0 < n; t0 += TW, it++) {
-            // serve requests until the recurrence wave has left this tile (it never leaves one with a request open)
-            while (true) {
-                const int rq = (lane < CPW) ? __hip_atomic_load(&H.req_seq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-                const unsigned long long pend = __ballot(lane < CPW && rq != h_served);
-                if (pend == 0) {
-                    bool all_done = true;
-                    for (int w = 0; w < NRW_T; w++) {
-                        all_done = all_done && __hip_atomic_load(&H.tile_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > it;
+        // ---- handler wave: the matched filter of one pass = 128 outputs (one channel's tile at 128-sample tiles, two channels' at
+        // 64).  Lane k takes outputs k and k + 64 as one packed pair: tap i reads x[k + i - 90] and x[k + 64 + i - 90] - consecutive
+        // lanes, consecutive words, no bank conflict, one LDS read + one packed multiply + one packed add per tap; the products are
+        // added oldest sample first, multiply and add rounded apart, as apply_sps_fir does.  The 90 samples before a tile are the
+        // previous tile's (the ring keeps it; the call's first tile has the carried filter memory there, staged by the prologue).
+        constexpr int LPR_H = CPW / NRW_T;
+        constexpr int NPASS = LPR_H / 2; // two channels a pass (fuse_mf implies 128-sample tiles)
+        static_assert(LPR_H % 2 == 0, "the filter pass takes the channels of a recurrence wave in pairs");
+        typedef float mf2h __attribute__((ext_vector_type(2)));
+        auto mf_pass = [&](int h, int t, int p) {
+            // two channels a pass: their accumulator chains take turns on the vector unit (multiply A, multiply B, add A, add B - every
+            // operand was produced at least two instructions earlier, so nothing waits for a dependent result: ~4.7 cycles per
+            // instruction instead of ~14 per tap with one chain)
+            const int slot = t % 3;
+            const int cA = h * LPR_H + 2 * p, cB = cA + 1;
+            const float* ra = &L.raw[cA][TW + slot * TW + 2 * lane - (NT - 1)];
+            const float* rb = &L.raw[cB][TW + slot * TW + 2 * lane - (NT - 1)];
+            mf2h accA = {0.0f, 0.0f}, accB = {0.0f, 0.0f};
+            {
+                // lane k takes outputs 2 k and 2 k + 1 of both channels: {x[2 k + i - 90], x[2 k + 1 + i - 90]} is ONE ds_read2_b32 (offsets i
+                // and i + 1 words; sixteen lanes = thirty-two consecutive words = every bank once.  Outputs k and k + 64 - offsets i and
+                // i + 64 - put a lane's two words in one bank: measured 3.6 k cycles a pass).  Left to itself the compiler pairs adjacent
+                // taps of one output instead and re-sorts them with moves, waiting on every read; so the reads are spelled out,
+                // seven taps of both channels a group (13 x 7 = 91), the next group's in flight under this group's arithmetic.  LDS
+                // operations of a wave complete in order: lgkmcnt(14) = everything but the fourteen reads issued last.
+                constexpr int G = 7;
+                static_assert(NT == 13 * G, "thirteen groups of seven taps");
+                uint32_t la = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)ra;
+                uint32_t lb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)rb;
+#define DDN_MF_LOAD(d, e, a, b)                                                                                                    \
+    asm volatile("ds_read2_b32 %0, %14 offset1:1\n\tds_read2_b32 %7, %15 offset1:1\n\t"                                          \
+                 "ds_read2_b32 %1, %14 offset0:1 offset1:2\n\tds_read2_b32 %8, %15 offset0:1 offset1:2\n\t"                     \
+                 "ds_read2_b32 %2, %14 offset0:2 offset1:3\n\tds_read2_b32 %9, %15 offset0:2 offset1:3\n\t"                     \
+                 "ds_read2_b32 %3, %14 offset0:3 offset1:4\n\tds_read2_b32 %10, %15 offset0:3 offset1:4\n\t"                    \
+                 "ds_read2_b32 %4, %14 offset0:4 offset1:5\n\tds_read2_b32 %11, %15 offset0:4 offset1:5\n\t"                    \
+                 "ds_read2_b32 %5, %14 offset0:5 offset1:6\n\tds_read2_b32 %12, %15 offset0:5 offset1:6\n\t"                    \
+                 "ds_read2_b32 %6, %14 offset0:6 offset1:7\n\tds_read2_b32 %13, %15 offset0:6 offset1:7"                        \
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(e[0]),         \
+                   "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6])                                    \
+                 : "v"(a), "v"(b)                                                                                                  \
+                 : "memory")
+#define DDN_MF_WAIT(d, e, cnt)                                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" cnt ")"                                                                                      \
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(e[0]), "+v"(e[1]),     \
+                   "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]))
+                mf2h xa0[G], xb0[G], xa1[G], xb1[G];
+                DDN_MF_LOAD(xa0, xb0, la, lb);
+#pragma unroll
+                for (int g = 0; g < 13; g++) {
+                    mf2h* ca = (g & 1) ? xa1 : xa0;
+                    mf2h* cb = (g & 1) ? xb1 : xb0;
+                    if (g + 1 < 13) {
+                        la += 4u * G;
+                        lb += 4u * G;
+                        if (g & 1) {
+                            DDN_MF_LOAD(xa0, xb0, la, lb);
+                        } else {
+                            DDN_MF_LOAD(xa1, xb1, la, lb);
+                        }
+                        DDN_MF_WAIT(ca, cb, "14");
+                    } else {
+                        DDN_MF_WAIT(ca, cb, "0");
                     }
-                    if (all_done) {
-                        break;
+#pragma unroll
+                    for (int k = 0; k < G; k++) {
+                        const float tp = __uint_as_float(ddn_p25_filter_bits[g * G + k]);
+                        const mf2h tt = {tp, tp};
+                        const mf2h pa = tt * ca[k], pb = tt * cb[k];
+                        accA += pa;
+                        accB += pb;
                     }
-                    helper_idle(idle_spin, (cfg.dbg & 8388608) != 0, 4);
-                    continue;
                 }
+#undef DDN_MF_LOAD
+#undef DDN_MF_WAIT
+            }
+            float* fa = &L.flt[cA][TW + slot * TW + 2 * lane];
+            float* fb = &L.flt[cB][TW + slot * TW + 2 * lane];
+            fa[0] = accA.x;
+            fa[1] = accA.y;
+            fb[0] = accB.x;
+            fb[1] = accB.y;
+            if (slot == 2) {
+                fa[-3 * TW] = accA.x;
+                fa[1 - 3 * TW] = accA.y;
+                fb[-3 * TW] = accB.x;
+                fb[1 - 3 * TW] = accB.y;
+            }
+        };
+        const int n_tiles = (int)((n + TW - 1) / TW);
+        int mfj[NRW_T], mfp[NRW_T];
+        for (int w = 0; w < NRW_T; w++) {
+            mfj[w] = 0;
+            mfp[w] = 0;
+        }
+        float idle_spin = 0.0f;
+#if DDN_RX_CYCLES
+        long long dbg_mf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // filter passes: cycles, count; decisions: cycles, count; idle polls
+#endif
+        while (true) {
+            // requests first (a lane of a recurrence wave - and whoever shares its trips - waits on every decision), then one pass of
+            // whichever half has a staged tile without its filter row, then nothing
+            const int rq = (lane < CPW) ? __hip_atomic_load(&H.req_seq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+            const unsigned long long pend = __ballot(lane < CPW && rq != h_served);
+            if (pend != 0) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const int c = __ffsll((long long)pend) - 1;
                 dbg_pend = __popcll(pend);
+#if DDN_RX_CYCLES
+                const long long sv_t0 = (long long)clock64();
+#endif
                 serve(c, __shfl(rq, c));
+#if DDN_RX_CYCLES
+                dbg_mf[2] += (long long)clock64() - sv_t0;
+                dbg_mf[3]++;
+#endif
+                continue;
             }
-            // (no workgroup barrier per tile in handler mode: the waves meet through tile_done / ready, see the tile loop)
+            bool did = false;
+            if (fuse_mf) {
+                // the half whose filter rows are furthest behind goes first (its recurrence wave is the one that may be waiting)
+                int hsel = -1, jsel = 0x7fffffff;
+#pragma unroll
+                for (int h = 0; h < NRW_T; h++) {
+                    if (mfj[h] < n_tiles && mfj[h] < jsel
+                        && __hip_atomic_load(&H.staged[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > mfj[h]) {
+                        hsel = h;
+                        jsel = mfj[h];
+                    }
+                }
+                if (hsel >= 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    int pj = 0;
+#pragma unroll
+                    for (int h = 0; h < NRW_T; h++) {
+                        pj = h == hsel ? mfp[h] : pj;
+                    }
+#if DDN_RX_CYCLES
+                    const long long mf_t0 = (long long)clock64();
+#endif
+                    mf_pass(hsel, jsel, pj);
+#if DDN_RX_CYCLES
+                    dbg_mf[0] += (long long)clock64() - mf_t0;
+                    dbg_mf[1]++;
+#endif
+                    pj++;
+                    const bool tile_filtered = pj == NPASS;
+#pragma unroll
+                    for (int h = 0; h < NRW_T; h++) {
+                        if (h == hsel) {
+                            mfp[h] = tile_filtered ? 0 : pj;
+                            mfj[h] += tile_filtered ? 1 : 0;
+                        }
+                    }
+                    if (tile_filtered) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            __hip_atomic_store(&H.fready[hsel], jsel + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    did = true;
+                }
+            }
+            if (did) {
+                continue;
+            }
+            bool all_done = true;
+            for (int w = 0; w < NRW_T; w++) {
+                all_done = all_done && __hip_atomic_load(&H.tile_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= n_tiles;
+            }
+            if (all_done) { // (a recurrence wave never leaves a tile with a request open)
+                break;
+            }
+            helper_idle(idle_spin, (cfg.dbg & 8388608) != 0, 4);
+#if DDN_RX_CYCLES
+            dbg_mf[4]++;
+#endif
         }
+#if DDN_RX_CYCLES
+        if ((cfg.dbg & 8192) && lane == 0) { // (over the tail of the workgroup's first record area, below the other waves' blocks)
+            uint8_t* d = rec + ((size_t)ch0 + 1) * max_sym * 10 - 448;
+            for (int k = 0; k < 64; k++) {
+                d[k] = reinterpret_cast<const uint8_t*>(dbg_mf)[k];
+            }
+        }
+#endif
     {
         if (hlive) {
             hstate[ch] = hs;
@@ -1215,6 +1385,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const int ch = ch0 + ln;
     const bool live = recur && lane < LPR && ch < n_channels;
     const bool use_flt = cfg.use_filter != 0;
+    const bool ld_flt = use_flt && filt != nullptr; // the filter row comes from HBM (else: computed in place by the handler wave)
     const float inf = __builtin_inff();
     // the recurrence wave is a latency chain: when other kernels' wavefronts share its SIMD (the front end of the next batch
     // runs beside this loop, bindings/ddn_chain.py run_pipelined3) its instructions go first
@@ -1258,15 +1429,19 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     const bool ok = (ch0 + cc < n_channels) && j < tn;
                     const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + j;
                     r[c] = ok ? raw[off] : 0.0f;
-                    f[c] = (ok && use_flt) ? filt[off] : 0.0f;
+                    f[c] = (ok && ld_flt) ? filt[off] : 0.0f;
                 }
 #pragma unroll
                 for (int c = 0; c < RPP; c++) {
                     L.raw[RPP * h + c][TW + slot * TW + j] = r[c];
-                    L.flt[RPP * h + c][TW + slot * TW + j] = f[c];
                     if (slot == 2) {
                         L.raw[RPP * h + c][j] = r[c];
-                        L.flt[RPP * h + c][j] = f[c];
+                    }
+                    if (!fuse_mf) {
+                        L.flt[RPP * h + c][TW + slot * TW + j] = f[c];
+                        if (slot == 2) {
+                            L.flt[RPP * h + c][j] = f[c];
+                        }
                     }
                 }
             }
@@ -1274,6 +1449,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     };
     if (loader && n > 0) {
         stage(0, 0);
+        if (fuse_mf) { // the filter's memory ahead of the call's first tile: the last 90 raw samples of the call before
+            for (int k = lane; k < CPW * (NT - 1); k += 64) {
+                const int c = k / (NT - 1), i = k % (NT - 1);
+                L.raw[c][TW - (NT - 1) + i] = (ch0 + c < n_channels) ? prev_tail[(size_t)(ch0 + c) * (NT - 1) + i] : 0.0f;
+            }
+        }
     }
     if (loader) { // every queue slot starts as "nothing handed over" (and returns to that when drained)
         for (int k = lane; k < 2 * QTW * CPW; k += 64) {
@@ -1415,7 +1596,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const bool ok = (ch0 + cc < n_channels) && j < tn;
                 const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + j;
                 g.r[half][c] = ok ? raw[off] : 0.0f;
-                g.f[half][c] = (ok && use_flt) ? filt[off] : 0.0f;
+                g.f[half][c] = (ok && ld_flt) ? filt[off] : 0.0f;
             }
         }
     };
@@ -1427,10 +1608,14 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             for (int c = 0; c < LPR; c++) {
                 const int cc = h * LPR + c;
                 L.raw[cc][TW + slot * TW + j] = g.r[half][c];
-                L.flt[cc][TW + slot * TW + j] = g.f[half][c];
                 if (slot == 2) {
                     L.raw[cc][j] = g.r[half][c];
-                    L.flt[cc][j] = g.f[half][c];
+                }
+                if (!fuse_mf) {
+                    L.flt[cc][TW + slot * TW + j] = g.f[half][c];
+                    if (slot == 2) {
+                        L.flt[cc][j] = g.f[half][c];
+                    }
                 }
             }
         }
@@ -1583,8 +1768,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     int sp = 0; // this lane's cursor relative to the current tile (negative: a deferred symbol begins in the previous one)
     int it = 0;
     double fill_min_d = (double)s.fill_min, fill_max_d = (double)s.fill_max;
-    // this lane's slot in the [slot][channel] extrema rings as a 32-bit byte offset (uniform base + lane offset addressing)
-    const uint32_t ro_step = 4u * (uint32_t)n_channels, ro_first = 4u * (uint32_t)ch;
+    // this lane's slot in the extrema rings as a 32-bit byte offset (uniform base + lane offset addressing)
+    // (round 6) rings laid out [channel][slot]: a channel's pushes of successive symbols are successive words of one cache line, which
+    // the L2 merges before it writes them back.  [slot][channel] made every push a 16-byte piece (the four lanes of a recurrence wave)
+    // of a line it shares with other workgroups: written back piece by piece, 3.4 x the payload in WRITE_SIZE.
+    const uint32_t ro_step = 4u, ro_first = 4u * (uint32_t)MS * (uint32_t)ch;
     uint32_t ro = (uint32_t)s.midx * ro_step + ro_first;
     auto ring_at = [](float* ring, uint32_t off) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(ring) + off); };
     // ---- per-symbol commit, shared by the fast paths and the generic path of the trip loop ---------------------------
@@ -1933,6 +2121,20 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         dbg_cyc[1] += c1 - c0;
                         c0 = c1;
                     }
+                    if (fuse_mf) { // the raw tile goes into the ring ahead of the summaries: the handler wave filters it meanwhile
+                        if (j + 1 < n_tiles) {
+                            stage_half_store((j + 1) % 3, h, sg);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            __hip_atomic_store(&H.staged[h], j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
+                            const long long c1 = (long long)clock64();
+                            dbg_cyc[0] += c1 - c0;
+                            c0 = c1;
+                        }
+                    }
                     if (j >= 1 && !(cfg.dbg & 256)) {
                         compute_sfx_half(j & 1, j & 1, h);
                     }
@@ -1941,7 +2143,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         dbg_cyc[2] += c1 - c0;
                         c0 = c1;
                     }
-                    if (j + 1 < n_tiles) {
+                    if (!fuse_mf && j + 1 < n_tiles) {
                         stage_half_store((j + 1) % 3, h, sg);
                     }
                     if (DDN_RX_CYCLES && (cfg.dbg & 8192)) {
@@ -1981,7 +2183,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         long long dbg_spin = 0;
         if (HM) {
             const long long w0 = (DDN_RX_CYCLES && (cfg.dbg & 8192)) ? (long long)clock64() : 0;
-            while (__hip_atomic_load(&H.ready[rw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= it) {
+            while (__hip_atomic_load(&H.ready[rw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= it
+                   || (fuse_mf && __hip_atomic_load(&H.fready[rw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= it)) {
                 __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -3275,6 +3478,38 @@ launch_rx(const float* raw, const float* filt, const float* prev_tail, float* fs
     return hipGetLastError();
 }
 
+static inline bool
+use_filter_row_missing(const DdnRxConfig* cfg, const float* filt) {
+    return cfg->use_filter && !filt;
+}
+
+// channels per wavefront of a handler-mode launch (0 = by batch size)
+static int
+handler_mode_cpw(int channels_per_wave, int n_channels) {
+    int cpw = channels_per_wave;
+    if (const char* e = getenv("DDN_RX_CPW")) { // (experiments)
+        cpw = atoi(e);
+    }
+    if (cpw != 4 && cpw != 8 && cpw != 16) {
+        // two workgroups per CU are resident: up to 2048 channels four per workgroup (two lanes per recurrence wave - a lane's
+        // standard trip, bulk pass or wait then holds up one other lane instead of three), beyond that eight.  Larger batches
+        // keep eight and run in rounds of 512 resident workgroups (a workgroup never waits for another): measured on the bench
+        // traffic, 8192 channels take 19.6 ms sixteen per workgroup (eight lanes per recurrence wave) against two rounds of
+        // the 5.3 ms the eight-channel shape takes for 4096 (bench.py batch_sweep, round 5)
+        cpw = n_channels <= 4 * 512 ? 4 : 8;
+    }
+    return cpw;
+}
+
+// 1: this configuration's loop kernel computes the matched filter itself (handler mode with 128-sample tiles: the handler wave filters
+// each staged tile in LDS) - the caller may pass filt = NULL and leave k_p25_matched_filter out.
+extern "C" int
+ddn_dev_p25_rx_fuses_filter(const DdnRxConfig* cfg, int channels_per_wave, int n_channels) {
+    return cfg && cfg->handlers && cfg->use_filter && handler_mode_cpw(channels_per_wave, n_channels) <= 8
+               ? 1
+               : 0;
+}
+
 extern "C" hipError_t
 ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, float* fstale, long n, size_t stride, int n_channels,
                const DdnRxConfig* cfg, DdnRxState* state, float* sbuf_store, float* lbuf_store, float* shist_store,
@@ -3316,13 +3551,9 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
         if (whole < 6 || !hstate || !hh_store || !events || !n_events) {
             return hipErrorInvalidValue;
         }
-        if (cpw != 4 && cpw != 8 && cpw != 16) {
-            // two workgroups per CU are resident: up to 2048 channels four per workgroup (two lanes per recurrence wave - a lane's
-            // standard trip, bulk pass or wait then holds up one other lane instead of three), beyond that eight.  Larger batches
-            // keep eight and run in rounds of 512 resident workgroups (a workgroup never waits for another): measured on the bench
-            // traffic, 8192 channels take 19.6 ms sixteen per workgroup (eight lanes per recurrence wave) against two rounds of
-            // the 5.3 ms the eight-channel shape takes for 4096 (bench.py batch_sweep, round 5)
-            cpw = n_channels <= 4 * 512 ? 4 : 8;
+        cpw = handler_mode_cpw(channels_per_wave, n_channels);
+        if (use_filter_row_missing(cfg, filt) && cpw > 8) {
+            return hipErrorInvalidValue; // sixteen channels per workgroup run 64-sample tiles: the filter row has to be given
         }
         if (cpw == 4) {
             return launch_rxw<4, true>(raw, filt, prev_tail, fstale, n, stride, n_channels, *cfg, state, sbuf_store, lbuf_store,

@@ -201,6 +201,12 @@ int ddn_p25_rx_get_timing_avg(ddn_p25_rx* b, float* ms2, int* n_launches);
 /* lanes (= channels) per recurrence wavefront: 0 = automatic (8 up to 4096 channels, 16 up to 8192, 32 up to 16384, else 64),
  * else 8 / 16 / 32 / 64.  Results do not depend on it; fewer lanes per wave = fewer trips shared with a hunting lane. */
 int ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave);
+/* 1 = handler mode computes the P25 matched filter (src/dsp/dsd_filters.c:173-200,299-324) INSIDE the loop kernel, from the raw tile
+ * where it is staged in LDS (the handler wave, between decisions), instead of in a kernel of its own that writes a second f32 row to
+ * HBM: no filter kernel, 1.57 GB less HBM traffic per 4096 x 48000 call, 786 MB less device memory - and a slower step (round 6,
+ * measured: 8.2 against 7.9 ms; the loop's helper waves have no spare issue slots for 91 taps per sample).  Default 0.
+ * Same records, flags and events bit for bit either way.  No effect outside handler mode or at sixteen channels per workgroup. */
+int ddn_p25_rx_set_filter_in_loop(ddn_p25_rx* b, int on);
 size_t ddn_p25_rx_max_symbols(const ddn_p25_rx* b, size_t n);
 int ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records10, uint8_t* d_flags,
                    int32_t* d_counts, size_t max_symbols, void* hip_stream);

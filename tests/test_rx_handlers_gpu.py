@@ -93,8 +93,10 @@ def _traffic(seed, n, noise, weak_nids=False):
     return p25gen.modulate_disc(dib, lead=200 + 13 * (seed % 17), noise=noise, seed=seed, scale=scale)[:n]
 
 
-@pytest.mark.parametrize("cpw", [4, 8, 16])
-def test_every_frame_type_clean_and_noisy(built, cpw):
+@pytest.mark.parametrize("cpw,fil", [(4, 0), (8, 0), (16, 0), (4, 1), (8, 1), (16, 1)])
+def test_every_frame_type_clean_and_noisy(built, cpw, fil):
+    """fil = 1: the matched filter computed inside the loop kernel (ddn_p25_rx_set_filter_in_loop; sixteen channels per workgroup keep
+    the filter kernel whatever the switch says) - same records, flags and decisions"""
     B, n = 24, 40000
     x = np.zeros((B, n), np.float32)
     for c in range(B):
@@ -104,7 +106,7 @@ def test_every_frame_type_clean_and_noisy(built, cpw):
     x[5] *= -1.0                                   # inverted polarity
     x[7] = np.random.default_rng(7).normal(0, 6000, n).astype(np.float32)
     want = [_oracle(x[c], 1) for c in range(B)]
-    rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=2048)
+    rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=2048, filter_in_loop=bool(fil))
     rec, fl, cnt = rx.run(x)
     for c in range(B):
         _check(rec, fl, cnt, rx.events, rx.n_events, c, want[c], rx.event_data)
@@ -130,19 +132,22 @@ def test_hunting_pass_of_all_rows_at_once_equals_one_owner_at_a_time(built, monk
     x[9, 12000:] = 0.0
     x[10, :9000] = 0.0
     outs = []
-    for dbg in ("0", "4096"):
+    for dbg, fil in (("0", False), ("4096", False), ("0", True)):   # (third run: the matched filter inside the loop, carrier losses incl.)
         monkeypatch.setenv("DDN_RX_DBG", dbg)
-        rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=2048)
+        rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=2048, filter_in_loop=fil)
         rec, fl, cnt = rx.run(x)
         outs.append((rec.copy(), fl.copy(), cnt.copy(), rx.events.copy(), rx.n_events.copy(), rx.event_data.copy()))
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
+    for k in (1, 2):
+        for a, b in zip(outs[0], outs[k]):
+            assert np.array_equal(a, b)
     for c in (0, 9, 10, 31):
         _check(outs[0][0], outs[0][1], outs[0][2], outs[0][3], outs[0][4], c, _oracle(x[c], 1), outs[0][5])
 
 
-def test_call_splits(built):
-    """decisions, history ring and handler words carried across calls (a block straddling a call boundary)"""
+@pytest.mark.parametrize("fil", [0, 1])
+def test_call_splits(built, fil):
+    """decisions, history ring and handler words carried across calls (a block straddling a call boundary); fil = 1: with the filter
+    inside the loop the carried filter memory is staged ahead of each call's first tile"""
     B = 6
     splits = [0, 5, 3000, 3001, 9000, 9640, 17000, 26000]
     x = np.zeros((B, splits[-1]), np.float32)
@@ -150,7 +155,7 @@ def test_call_splits(built):
         s = _traffic(200 + c, splits[-1], [100.0, 14000.0][c % 2], weak_nids=(c >= 4))
         x[c, :len(s)] = s
     want = [_oracle(x[c], 1) for c in range(B)]
-    rx = ddn.P25Rx(B, use_matched_filter=1, handlers=True, max_events=1024)
+    rx = ddn.P25Rx(B, use_matched_filter=1, handlers=True, max_events=1024, filter_in_loop=bool(fil))
     recs, fls, evs, evds = [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)]
     base = np.zeros(B, np.int64)
     for a, b in zip(splits[:-1], splits[1:]):

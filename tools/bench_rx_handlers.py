@@ -56,17 +56,17 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
         e = ev.cpu().numpy()
         ne = nev.cpu().numpy()
         allev = np.concatenate([e[c, :min(ne[c], 256)] for c in range(B)])
-        if int(os.environ.get("DDN_RX_DBG", "0")) & 131072:
+        if int(os.environ.get("DDN_RX_DBG", "0"), 0) & 131072:
             for kd in (1, 2):
                 a = allev[(allev[:, 1] == kd) & ((allev[:, 2] & 15) == 0)]
                 extra += " | kind %d stamps(cycles): %.0f %.0f %.0f" % (kd, (a[:, 2] >> 4).mean() * 16, (a[:, 3] & 0xFFFF).mean() * 16,
                                                                       ((a[:, 3] >> 16) & 0xFFFF).mean() * 16)
-        elif int(os.environ.get("DDN_RX_DBG", "0")) & 1073741824:  # DDN_RX_CYCLES build: e[2] = cycles the request lay unserved
+        elif int(os.environ.get("DDN_RX_DBG", "0"), 0) & 1073741824:  # DDN_RX_CYCLES build: e[2] = cycles the request lay unserved
             for kd in (1, 2):
                 a = allev[allev[:, 1] == kd]
                 extra += " | kind %d: pick-up delay mean %.0f pct[10,50,80,90,95,99] %s, service mean %.0f" % (
                     kd, a[:, 2].mean(), np.percentile(a[:, 2], [10, 50, 80, 90, 95, 99]).astype(int).tolist(), a[:, 3].mean())
-        elif int(os.environ.get("DDN_RX_DBG", "0")) & 65536:
+        elif int(os.environ.get("DDN_RX_DBG", "0"), 0) & 65536:
             for kd in (1, 2):
                 a = allev[allev[:, 1] == kd]
                 for path in (0, 1):
@@ -77,14 +77,14 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
         else:
             extra = " events/ch %.1f nid_ok %.3f tsbk_crc %.3f" % (ne.mean(), (allev[allev[:, 1] == 1][:, 2] > 0).mean(),
                                                                    (allev[allev[:, 1] == 2][:, 3] & 1).mean())
-    if mode == "handlers" and int(os.environ.get("DDN_RX_DBG", "0")) & 65536:
+    if mode == "handlers" and int(os.environ.get("DDN_RX_DBG", "0"), 0) & 65536:
         tot = np.zeros(2)
         for c in range(0, 64):
             o = (C.c_longlong * 2)()
             assert l.ddn_p25_rx_debug_counters(rx.h, c, o) == 0
             tot += [o[0], o[1]]
         extra += " | lane wait: %.0f cycles per request (%d requests)" % (tot[1] / max(tot[0], 1), tot[0])
-    if int(os.environ.get("DDN_RX_DBG", "0")) & 8192:      # library built with EXTRA=-DDDN_RX_CYCLES=1
+    if int(os.environ.get("DDN_RX_DBG", "0"), 0) & 8192:      # library built with EXTRA=-DDDN_RX_CYCLES=1
         r = rec.cpu().numpy().reshape(B, -1)
         tails = np.stack([r[c, -192:] for c in range(0, B, cpw)]).copy().view(np.int64).reshape(-1, 3, 8)
         tiles = (n + 127) // 128
@@ -96,7 +96,7 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
         for k in range(3):
             extra += "\n   trip kind %d: %.2f per tile at %.0f cycles (share of busy %.2f)" % (
                 k, tt[:, 5 + k].mean() / tiles, tt[:, 2 + k].sum() / max(1, tt[:, 5 + k].sum()), tt[:, 2 + k].sum() / max(1, tt[:, 0].sum()))
-    if int(os.environ.get("DDN_RX_DBG", "0")) & 8192:
+    if int(os.environ.get("DDN_RX_DBG", "0"), 0) & 8192:
         sec = np.stack([r[c, -256:-192] for c in range(0, B, cpw)]).copy().view(np.int64)
         nstd = max(1, tt[:, 5].sum())
         extra += "\n   std trip sections (cycles per trip): top %.0f search %.0f mean %.0f inframe %.0f hunt %.0f emit %.0f" % tuple(
@@ -110,5 +110,9 @@ for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get(
             run[0] / (len(sec) * tiles), run[1] / max(1, run[0]), run[7] / max(1, run[0]), run[5] / max(1, run[0]), run[6] / max(1, run[1]))
         extra += "\n   a lean run's pass: %.0f cycles from the pass's top to the bulk test's end, %.0f from there to the run's first trip" % (
             run[2] / max(1, run[0]), run[3] / max(1, run[0]))
+    if mode == "handlers" and int(os.environ.get("DDN_RX_DBG", "0"), 0) & 8192:
+        hm = np.stack([r[c, -448:-384] for c in range(0, B, cpw)]).copy().view(np.int64).sum(axis=0)
+        extra += "\n   handler wave per tile: filter passes %.2f at %.0f cycles, decisions %.2f at %.0f cycles, idle polls %.1f" % (
+            hm[1] / (len(sec) * tiles), hm[0] / max(1, hm[1]), hm[3] / (len(sec) * tiles), hm[2] / max(1, hm[3]), hm[4] / (len(sec) * tiles))
     print("%-8s cpw %2d: loop %.3f ms (mf %.3f) in-frame share %.3f syncs/ch %.1f%s" % (
         mode, cpw, t[1], t[0], (flc & 1).mean() * ms / (n / 10), (flc & 2).sum() / B, extra), flush=True)
