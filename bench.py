@@ -858,17 +858,17 @@ def configs3_mixed(torch, ddn, np, d_iq_p25, B_per_gpu, n, steps, rank, world, d
         out["k_fsk4_rx_ms"] = k4
         out["work_per_step"] = {"dmr_syncs": int(res[1][2].sum()) if 1 in res else 0, "nxdn_syncs": int(res[2][2].sum()) if 2 in res else 0}
         if world == 1:
-            # the overlapped schedule (DDN_MIX_OVERLAP=1: front ends on streams of their own, two discriminator buffers per group, the
+            # the overlapped schedule (ddn_mixed_chain_config.overlap = 1: front ends on streams of their own, two discriminator buffers per group, the
             # fsk4 loops one channel per wavefront) needs more hardware queues than HIP's default four, and more queues cost the
             # headline chain (8.07 -> 8.64 ms at six): a process of its own, same shape, same library
             import subprocess
-            env = dict(os.environ, DDN_MIX_OVERLAP="1", GPU_MAX_HW_QUEUES="6")
+            env = dict(os.environ, MIX_OVERLAP="1", GPU_MAX_HW_QUEUES="6")
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_mixed.py"), str(total), "10"], env=env, capture_output=True,
                                    text=True, timeout=300)
                 ms = float(r.stdout.strip().splitlines()[-1].split(":")[1].split()[0])
                 out["overlapped_schedule"] = {"ms_per_step": ms, "Msamples_per_s": round(total * n / ms / 1e3, 1),
-                                              "env": {"DDN_MIX_OVERLAP": "1", "GPU_MAX_HW_QUEUES": "6"},
+                                              "config": {"ddn_mixed_chain_config.overlap": 1}, "env": {"GPU_MAX_HW_QUEUES": "6"},
                                               "note": "opt-in (tests/test_chain_mixed_gpu.py passes in both modes); separate process"}
             except Exception as ex:  # informational only
                 out["overlapped_schedule"] = {"error": str(ex)[:200]}

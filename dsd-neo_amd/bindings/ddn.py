@@ -127,6 +127,7 @@ PROTOTYPES = {
     "ddn_p25_rx_set_lock_symbols": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_p25_rx_set_channels_per_wave": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_p25_rx_set_filter_in_loop": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_p25_rx_set_debug_flags": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_p25_rx_set_handlers": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ddn_p25_rx_debug_counters": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_p25_rx_set_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -402,6 +403,7 @@ PROTOTYPES.update({
     "ddn_fsk4_rx_get_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_fsk4_rx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_fsk4_rx_set_channels_per_wave": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_fsk4_rx_set_debug_flags": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_fsk4_rx_set_sync_thresholds": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_m17_lsf_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 5 + [C.c_int, C.c_size_t] + [C.c_void_p] * 4),
     "ddn_m17_str_decode_batch": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4 + [C.c_int, C.c_size_t] + [C.c_void_p] * 5),
@@ -433,7 +435,8 @@ PROTOTYPES.update({
 class P25ChainConfig(C.Structure):  # == ddn_p25_chain_config (include/ddn_chain.h)
     _fields_ = [("n_channels", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int), ("input_format", C.c_int),
                 ("vocoder", C.c_int), ("max_frames", C.c_int), ("max_ldu", C.c_int), ("max_events", C.c_int),
-                ("carry_symbols", C.c_int), ("modulation", C.c_int), ("sample_rate_hz", C.c_int), ("snr_cqpsk_db", C.c_float)]
+                ("carry_symbols", C.c_int), ("modulation", C.c_int), ("sample_rate_hz", C.c_int), ("snr_cqpsk_db", C.c_float),
+                ("d2h_blit", C.c_int)]
 
 
 class P25ChainResults(C.Structure):  # == ddn_p25_chain_results
@@ -524,7 +527,7 @@ class Fsk4ChainResults(C.Structure):  # == ddn_fsk4_chain_results
 
 class MixedChainConfig(C.Structure):  # == ddn_mixed_chain_config
     _fields_ = [("n_p25", C.c_int), ("n_dmr", C.c_int), ("n_nxdn48", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int),
-                ("input_format", C.c_int), ("vocoder", C.c_int)]
+                ("input_format", C.c_int), ("vocoder", C.c_int), ("overlap", C.c_int)]
 
 
 PROTOTYPES.update({
@@ -631,8 +634,8 @@ class Fsk4ChainC:
 class MixedChainC:
     """ddn_mixed_chain: P25 Phase 1 + DMR + NXDN48 channel groups of one GPU (BASELINE configs[3])"""
 
-    def __init__(self, n_p25, n_dmr, n_nxdn48, samples_per_call, block_len=8192, vocoder=1):
-        cfg = MixedChainConfig(n_p25, n_dmr, n_nxdn48, samples_per_call, block_len, 0, vocoder)
+    def __init__(self, n_p25, n_dmr, n_nxdn48, samples_per_call, block_len=8192, vocoder=1, overlap=0):
+        cfg = MixedChainConfig(n_p25, n_dmr, n_nxdn48, samples_per_call, block_len, 0, vocoder, overlap)
         self.h = C.c_void_p()
         _check(lib().ddn_mixed_chain_create(C.byref(cfg), C.byref(self.h)), "ddn_mixed_chain_create")
         self.counts = (n_p25, n_dmr, n_nxdn48)
@@ -665,8 +668,13 @@ class MixedChainC:
 
 class NodeConfig(C.Structure):  # == ddn_node_config (include/ddn_node.h)
     _fields_ = [("n_channels", C.c_int), ("samples_per_call", C.c_int), ("block_len", C.c_int), ("input_format", C.c_int),
-                ("vocoder", C.c_int), ("modulation", C.c_int), ("n_devices", C.c_int)]
+                ("vocoder", C.c_int), ("modulation", C.c_int), ("n_devices", C.c_int),
+                ("kind", C.c_int), ("n_dmr", C.c_int), ("n_nxdn48", C.c_int), ("overlap", C.c_int),
+                ("fsk4", C.c_void_p), ("p25p2", C.c_void_p), ("p25p2_seed44", C.c_void_p)]
 
+
+NODE_P25, NODE_MIXED, NODE_FSK4, NODE_P25P2 = 0, 1, 2, 3
+NODE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 PROTOTYPES.update({
     "ddn_node_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -675,6 +683,10 @@ PROTOTYPES.update({
     "ddn_node_parts": (C.c_int, [C.c_void_p]),
     "ddn_node_part_info": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_node_chain": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ddn_node_kind_of": (C.c_int, [C.c_void_p]),
+    "ddn_node_chain_object": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ddn_node_part_groups": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_node_on_part": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ddn_node_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ddn_node_run_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddn_node_wait": (C.c_int, [C.c_void_p]),
@@ -694,10 +706,18 @@ def node_partition(n_channels, rank, world):
 
 
 class NodeC:
-    """ddn_node (include/ddn_node.h): one P25 chain object + one host thread per device, the channel index block-partitioned"""
+    """ddn_node (include/ddn_node.h): one chain object + one host thread per device, the channel index block-partitioned.  kind =
+    NODE_MIXED: n_channels is the P25 group, n_dmr / n_nxdn48 the other two (BASELINE configs[3]); NODE_FSK4 / NODE_P25P2: `chain_cfg` =
+    the ctypes configuration structure of that chain object"""
 
-    def __init__(self, n_channels, samples_per_call, block_len=8192, vocoder=1, input_format=0, modulation=0, n_devices=0):
-        cfg = NodeConfig(n_channels, samples_per_call, block_len, input_format, vocoder, modulation, n_devices)
+    def __init__(self, n_channels, samples_per_call, block_len=8192, vocoder=1, input_format=0, modulation=0, n_devices=0,
+                 kind=0, n_dmr=0, n_nxdn48=0, overlap=0, chain_cfg=None, seed44=None):
+        self._keep = (chain_cfg, seed44)
+        cfg = NodeConfig(n_channels, samples_per_call, block_len, input_format, vocoder, modulation, n_devices, kind, n_dmr, n_nxdn48,
+                         overlap, C.addressof(chain_cfg) if (kind == NODE_FSK4 and chain_cfg is not None) else None,
+                         C.addressof(chain_cfg) if (kind == NODE_P25P2 and chain_cfg is not None) else None,
+                         seed44.ctypes.data if seed44 is not None else None)
+        self.kind = kind
         self.h = C.c_void_p()
         _check(lib().ddn_node_create(C.byref(cfg), C.byref(self.h)), "ddn_node_create")
         self.parts = lib().ddn_node_parts(self.h)
@@ -721,13 +741,29 @@ class NodeC:
     def chain(self, part):
         return lib().ddn_node_chain(self.h, part)
 
+    def chain_object(self, part):
+        return lib().ddn_node_chain_object(self.h, part)
+
+    def groups(self, part):
+        """[(first, count)] of the part's P25 / DMR / NXDN48 blocks (ddn_node_part_groups)"""
+        f, n = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+        _check(lib().ddn_node_part_groups(self.h, part, f, n), "ddn_node_part_groups")
+        return [(f[g], n[g]) for g in range(3)]
+
+    def on_part(self, part, fn, arg=None):
+        """fn(chain object pointer, arg) -> int on the part's host thread (ddn_node_on_part)"""
+        cb = NODE_FN(lambda chain, a: int(fn(chain, a)))
+        return lib().ddn_node_on_part(self.h, part, cb, arg)
+
     def run_host(self, h_iq_ptr, outs=None):
         arr = (P25ChainHostOut * self.parts)(*outs) if outs is not None else None
         self._outs = arr                                         # the worker threads read the array during the call only
         _check(lib().ddn_node_run_host(self.h, h_iq_ptr, arr), "ddn_node_run_host")
 
     def run_device(self, d_ptrs):
-        arr = (C.c_void_p * self.parts)(*d_ptrs)
+        """one device pointer per part; NODE_MIXED: three per part (P25, DMR, NXDN48; None where the part has no such channel)"""
+        k = 3 if self.kind == NODE_MIXED else 1
+        arr = (C.c_void_p * (k * self.parts))(*d_ptrs)
         _check(lib().ddn_node_run_device(self.h, arr), "ddn_node_run_device")
 
     def wait(self):
@@ -742,11 +778,11 @@ class P25ChainC:
     take a device pointer; fetch(name, dtype, shape) copies one of the result arrays of the last call to the host."""
 
     def __init__(self, n_channels, samples_per_call, block_len=8192, vocoder=1, max_frames=0, max_ldu=0, max_events=0,
-                 carry_symbols=0, input_format=0, modulation=0, sample_rate_hz=0, snr_cqpsk_db=0.0):
+                 carry_symbols=0, input_format=0, modulation=0, sample_rate_hz=0, snr_cqpsk_db=0.0, d2h_blit=0):
         import numpy as np
         self.np = np
         cfg = P25ChainConfig(n_channels, samples_per_call, block_len, input_format, vocoder, max_frames, max_ldu, max_events,
-                             carry_symbols, modulation, sample_rate_hz, snr_cqpsk_db)
+                             carry_symbols, modulation, sample_rate_hz, snr_cqpsk_db, d2h_blit)
         self.h = C.c_void_p()
         _check(lib().ddn_p25_chain_create(C.byref(cfg), C.byref(self.h)), "ddn_p25_chain_create")
         self.B, self.n = n_channels, samples_per_call
@@ -979,7 +1015,7 @@ class P25Rx:
     """Batched fixed-protocol P25p1 receive loop (ddn_p25_rx_*), host-buffer convenience wrapper."""
 
     def __init__(self, n_channels, out_rate=48000, sym_rate=4800, lock_symbols=840, use_matched_filter=1,
-                 channels_per_wave=0, handlers=False, max_events=0, filter_in_loop=False):
+                 channels_per_wave=0, handlers=False, max_events=0, filter_in_loop=False, debug_flags=0):
         """handlers=True: the reference's per-DUID handlers decide the in-frame length (lock_symbols unused); run() then
         also leaves .events int32 [B, max_events, 4] / .n_events int32 [B] of the call.  filter_in_loop: ddn_p25_rx_set_filter_in_loop"""
         import numpy as np
@@ -997,6 +1033,8 @@ class P25Rx:
             assert lib().ddn_p25_rx_set_handlers(self.h, 1, 64) == 0
         if filter_in_loop:
             assert lib().ddn_p25_rx_set_filter_in_loop(self.h, 1) == 0
+        if debug_flags:
+            assert lib().ddn_p25_rx_set_debug_flags(self.h, debug_flags) == 0
 
     def run(self, disc):
         """disc float32 [B, n] -> (records uint8 [B, max_sym, 10], flags uint8 [B, max_sym], counts int32 [B])."""

@@ -128,7 +128,7 @@ ddn_batch_create(const ddn_front_end_config* cfg, ddn_batch** out) {
     }
     b->center = (b->taps_len - 1) / 2;
     {
-        const char* gsel = getenv("DDN_GROUP");
+        const char* gsel = DDN_EXP_ENV("DDN_GROUP");
         b->group = (gsel && atoi(gsel) == 16) ? 16 : ((gsel && atoi(gsel) == 8) ? 8 : DDN_DEFAULT_GROUP);
     }
     // the reference routes blocks shorter than 2*taps_len floats to its non-FMA scalar unit
@@ -366,7 +366,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     fa.in = d_iq;
     fa.out = d_disc;
     fa.carry = b->d_carry;
-    fa.carry_out = (n >= (size_t)DDN_CARRY_LEN && !getenv("DDN_CARRY_KERNEL")) ? (ddn_f2*)b->d_carry : nullptr;
+    fa.carry_out = (n >= (size_t)DDN_CARRY_LEN && !DDN_EXP_ENV("DDN_CARRY_KERNEL")) ? (ddn_f2*)b->d_carry : nullptr;
     fa.state = b->d_state;
     fa.taps_dev = b->d_taps;
     fa.ch_stride = n;
@@ -381,7 +381,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     fa.squelch_on = b->cfg.squelch_level > 0.0f ? 1 : 0;
     fa.squelch_level = b->cfg.squelch_level;
     {
-        const char* d = getenv("DDN_DBG");
+        const char* d = DDN_EXP_ENV("DDN_DBG");
         fa.dbg = d ? atoi(d) : 0;
         fa.dbg_out = nullptr;
         if (fa.dbg & 64) {
@@ -407,7 +407,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
         HIP_TRY(hipEventRecord(b->ev[2], st));
         b->ev_valid = 1;
     }
-    if (fa.dbg_out && getenv("DDN_DBG_PRINT")) {
+    if (fa.dbg_out && DDN_EXP_ENV("DDN_DBG_PRINT")) {
         long long h[64 * 4];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, fa.dbg_out, sizeof(h), hipMemcpyDeviceToHost);

@@ -140,6 +140,7 @@ struct ddn_p25_chain {
     std::condition_variable* out_cv = nullptr;
     std::deque<OutJob>* out_q = nullptr;
     int out_stop = 0, out_rc = 0, out_dev = 0;
+    char out_err[256] = {0}; // the worker's error text (ddn_last_error is per thread): handed to the caller's thread with out_rc
     long out_submitted[NSET] = {0, 0, 0}, out_issued[NSET] = {0, 0, 0};
     void* d_iq[2];
     size_t iq_bytes;
@@ -170,13 +171,27 @@ ddn_p25_chain_destroy(ddn_p25_chain* c) {
     }
     (void)hipDeviceSynchronize();
     if (c->out_thread) {
-        {
+        {   // jobs the worker has not picked up are dropped (their host buffers may be gone already); the one it is working on
+            // is finished before the join returns
             std::lock_guard<std::mutex> lk(*c->out_mu);
+            for (const ddn_p25_chain::OutJob& j : *c->out_q) {
+                c->out_issued[j.set]++;
+            }
+            c->out_q->clear();
             c->out_stop = 1;
         }
         c->out_cv->notify_all();
         c->out_thread->join();
         delete c->out_thread;
+        c->out_thread = nullptr;
+    }
+    if (c->sdma > 0 && c->sdma_sig_ok) {
+        // hipDeviceSynchronize() does not cover hsa_amd_memory_async_copy(_on_engine): copies already on the engine still read the
+        // device buffers freed below and write the caller's host buffers - wait for every set's completion signal
+        for (int k = 0; k < NSET; k++) {
+            while (hsa_signal_wait_scacquire(c->sdma_sig[k], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {
+            }
+        }
     }
     delete c->out_q;
     delete c->out_cv;
@@ -386,7 +401,7 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
         }
         c->iq_bytes = B * (size_t)c->n * (cfg->input_format == DDN_IN_CF32 ? 8 : 2);
         c->synth_beside_loop = 1;
-        if (const char* e = getenv("DDN_CHAIN_SYNTH_BESIDE_LOOP")) {
+        if (const char* e = DDN_EXP_ENV("DDN_CHAIN_SYNTH_BESIDE_LOOP")) {
             c->synth_beside_loop = atoi(e) != 0;
         }
     } while (0);
@@ -486,15 +501,15 @@ chain_receive(ddn_p25_chain* c, const void* d_iq, int cur, hipStream_t st, hipEv
 
 // ---- result copies on an SDMA engine ------------------------------------------------------------------------------------------
 // Agents are taken from the pointers themselves (the device buffer's owner = this chain's GPU, whatever HIP_VISIBLE_DEVICES did to the
-// ordinals; the pinned buffer's owner = its NUMA node's CPU agent).  DDN_D2H=blit keeps the hipMemcpyAsync path (A/B runs).
+// ordinals; the pinned buffer's owner = its NUMA node's CPU agent).  cfg.d2h_blit = 1 keeps the hipMemcpyAsync path (A/B runs).
 static bool
 sdma_setup(ddn_p25_chain* c, const void* h_any) {
     if (c->sdma != 0) {
         return c->sdma > 0;
     }
     c->sdma = -1;
-    const char* e = getenv("DDN_D2H");
-    if (e && strcmp(e, "blit") == 0) {
+    const char* e = DDN_EXP_ENV("DDN_D2H");
+    if (c->cfg.d2h_blit || (e && strcmp(e, "blit") == 0)) {
         return false;
     }
     if (hsa_init() != HSA_STATUS_SUCCESS) {
@@ -555,11 +570,11 @@ sdma_setup(ddn_p25_chain* c, const void* h_any) {
         if (mask & ~h2d_engine) {
             mask &= ~h2d_engine;
         }
-        if (getenv("DDN_D2H_VERBOSE")) {
+        if (DDN_EXP_ENV("DDN_D2H_VERBOSE")) {
             fprintf(stderr, "ddn_p25_chain: SDMA engines device->host preferred 0x%x available 0x%x, host->device preferred 0x%x -> 0x%x\n",
                     mask, avail, h2d, mask & (~mask + 1u));
         }
-        if (const char* pick = getenv("DDN_D2H_ENGINE")) { // (experiments: an engine bit of hsa_amd_sdma_engine_id_t)
+        if (const char* pick = DDN_EXP_ENV("DDN_D2H_ENGINE")) { // (experiments: an engine bit of hsa_amd_sdma_engine_id_t)
             const long v = strtol(pick, nullptr, 0);
             if (v > 0 && v <= 0x8000 && (v & (v - 1)) == 0) {
                 mask = (uint32_t)v;
@@ -620,6 +635,22 @@ sdma_wait(ddn_p25_chain* c, int set) {
         while (hsa_signal_wait_scacquire(c->sdma_sig[set], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {
         }
     }
+}
+
+// the worker's verdict on the copies issued so far, taken over by the calling thread (error text included) and cleared
+static int
+out_take_rc(ddn_p25_chain* c) {
+    if (!c->out_thread) {
+        return DDN_OK;
+    }
+    std::lock_guard<std::mutex> lk(*c->out_mu);
+    const int rc = c->out_rc;
+    if (rc != DDN_OK) {
+        ddn_set_error("%s", c->out_err[0] ? c->out_err : "ddn_p25_chain: a result copy failed");
+        c->out_rc = DDN_OK;
+        c->out_err[0] = 0;
+    }
+    return rc;
 }
 
 // the device -> pinned-host copies of the results of the call that used buffer set `set`: on an SDMA engine (the caller has
@@ -702,6 +733,7 @@ out_worker(ddn_p25_chain* c) {
             std::lock_guard<std::mutex> lk(*c->out_mu);
             if (rc != DDN_OK && c->out_rc == DDN_OK) {
                 c->out_rc = rc;
+                snprintf(c->out_err, sizeof(c->out_err), "%s", ddn_last_error());
             }
             c->out_issued[job.set]++;
         }
@@ -746,14 +778,9 @@ chain_issue_pending(ddn_p25_chain* c, hipEvent_t beside) {
             job.out = c->pending_out;
             c->out_q->push_back(job);
             c->out_submitted[set]++;
-            if (c->out_rc != DDN_OK) { // an earlier set's copies failed (the error text is the failing thread's)
-                const int rc = c->out_rc;
-                c->out_rc = DDN_OK;
-                return rc;
-            }
         }
         c->out_cv->notify_all();
-        return DDN_OK;
+        return out_take_rc(c); // (an earlier set's copies may have failed)
     }
     HIP_TRY(hipStreamWaitEvent(c->s_copy2, c->ev_consumed[set], 0)); // that call's decode (and its pack kernels) are done
     if (beside) {
@@ -1233,7 +1260,7 @@ ddn_p25_chain_wait(ddn_p25_chain* c) {
     for (int k = 0; k < NSET; k++) {
         sdma_wait(c, k);
     }
-    return DDN_OK;
+    return out_take_rc(c); // a failed engine copy of the last sets is this call's error, not a later one's
 }
 
 extern "C" int

@@ -716,20 +716,20 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
         };
         {   // the overlapped schedule runs the fsk4 loops one channel per wavefront where a group allows it (<= 1536 channels: the
             // loop's fastest shape - 2.7 / 3.1 ms alone against 5.2 / 6.8 at four; the two loops then take turns on the device)
-            const char* e = getenv("DDN_MIX_OVERLAP");
-            if (e && e[0] == '1') {
+            const char* e = DDN_EXP_ENV("DDN_MIX_OVERLAP");
+            if (cfg->overlap || (e && e[0] == '1')) {
                 cpw_d = cfg->n_dmr <= 1536 ? 1 : cpw_d;
                 cpw_n = cfg->n_nxdn48 <= 1536 ? 1 : cpw_n;
             }
         }
-        cpw_d = pow2_1_32(getenv("DDN_MIX_CPW_DMR"), cpw_d);
-        cpw_n = pow2_1_32(getenv("DDN_MIX_CPW_NXDN"), cpw_n);
+        cpw_d = pow2_1_32(DDN_EXP_ENV("DDN_MIX_CPW_DMR"), cpw_d);
+        cpw_n = pow2_1_32(DDN_EXP_ENV("DDN_MIX_CPW_NXDN"), cpw_n);
         // Residency decides the step: a CU holds 8 of these wavefronts (~200 registers each).  At 4096 channels in thirds the P25
         // loop's own choice (4 channels per workgroup of 4 waves: 342 workgroups) + 2 x 342 two-wave workgroups are 2736 waves for
         // 2048 places - the loop launched last waits for the first to finish (measured: NXDN48 loop 9 ms, step 15.1 ms).  With 8
         // channels per P25 workgroup it is 2052 waves: step 14.2 ms.
         int cpw_p = (total > 2048 && (m->dmr || m->nxdn)) ? 8 : 0;
-        if (const char* e = getenv("DDN_MIX_CPW_P25")) {
+        if (const char* e = DDN_EXP_ENV("DDN_MIX_CPW_P25")) {
             const int v = atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) {
                 cpw_p = v;
@@ -745,11 +745,11 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
             rc = ddn_fsk4_rx_set_channels_per_wave(m->nxdn->rx, cpw_n);
         }
     }
-    {   // DDN_MIX_OVERLAP=1 (off by default): front ends on streams of their own, two discriminator buffers per group - call k + 1's
+    {   // cfg.overlap = 1 (off by default): front ends on streams of their own, two discriminator buffers per group - call k + 1's
         // front ends beside call k's loops.  Seven streams: it needs GPU_MAX_HW_QUEUES=6 or 7 in the process environment (HIP's default
         // four hardware queues make streams share queues: 17-18 ms per step; with 6: 11.75 ms against 13.2 - profiles/README.md)
-        const char* e = getenv("DDN_MIX_OVERLAP");
-        m->overlap = e && e[0] == '1';
+        const char* e = DDN_EXP_ENV("DDN_MIX_OVERLAP");
+        m->overlap = cfg->overlap != 0 || (e && e[0] == '1');
     }
     if (rc == DDN_OK && m->overlap) {
         if (m->p25) {
@@ -773,7 +773,7 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
     // DDN_MIX_XCD="a,b,c" (experiment): the three groups' loop streams on disjoint sets of XCDs (a + b + c <= 8; CU-mask bit i is
     // CU i / 8 of XCD i % 8) - different loop kernels then never share a CU's instruction cache
     int xcd_n[3] = {0, 0, 0};
-    if (const char* e = getenv("DDN_MIX_XCD")) {
+    if (const char* e = DDN_EXP_ENV("DDN_MIX_XCD")) {
         if (sscanf(e, "%d,%d,%d", &xcd_n[0], &xcd_n[1], &xcd_n[2]) != 3 || xcd_n[0] < 1 || xcd_n[1] < 1 || xcd_n[2] < 1
             || xcd_n[0] + xcd_n[1] + xcd_n[2] > 8) {
             xcd_n[0] = xcd_n[1] = xcd_n[2] = 0;
@@ -837,7 +837,7 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
     // instead of each behind its own group's loop (where it crawls beside the other groups' loops, 4-5 ms).  Lined up, the three
     // front ends take ~3 ms together, but the loops then have nothing beside them either: 14.4-15.4 ms per step against 13.2.
     static const bool phased = [] {
-        const char* e = getenv("DDN_MIX_PHASED");
+        const char* e = DDN_EXP_ENV("DDN_MIX_PHASED");
         return e && e[0] == '1';
     }();
     const int par = (int)(m->calls & 1);

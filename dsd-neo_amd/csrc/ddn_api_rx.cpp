@@ -31,6 +31,7 @@ struct ddn_p25_rx {
     size_t filt_cap;
     int channels_per_wave;
     int filter_in_loop; // ddn_p25_rx_set_filter_in_loop
+    int dbg_flags;      // ddn_p25_rx_set_debug_flags
     int32_t* d_lock; // [B] in-frame symbols after a sync, per channel (cfg.lock_symbols unless overridden)
     // handler mode (ddn_p25_rx_set_handlers): per-channel handler words, the in-frame history ring [B][104][3] f32, the
     // caller's event buffers (or a one-event dummy of our own)
@@ -254,6 +255,15 @@ ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave) {
 }
 
 extern "C" int
+ddn_p25_rx_set_debug_flags(ddn_p25_rx* b, int flags) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    b->dbg_flags = flags;
+    return DDN_OK;
+}
+
+extern "C" int
 ddn_p25_rx_set_filter_in_loop(ddn_p25_rx* b, int on) {
     if (!b) {
         return DDN_EINVAL;
@@ -306,7 +316,8 @@ ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records1
     DdnRxConfig dc = {b->cfg.out_rate_hz, b->cfg.sym_rate_hz, b->cfg.lock_symbols, b->cfg.use_matched_filter ? 1 : 0, 0,
                       b->handlers, b->nid_threshold, b->d_events ? (int)b->max_events : 1,
                       b->d_events ? b->d_event_data : nullptr};
-    if (const char* e = getenv("DDN_RX_DBG")) {
+    dc.dbg = b->dbg_flags;
+    if (const char* e = DDN_EXP_ENV("DDN_RX_DBG")) {
         dc.dbg = (int)strtoll(e, nullptr, 0);
     }
     // handler mode, on request (ddn_p25_rx_set_filter_in_loop): the loop kernel filters each staged tile itself (ddn_rx.hip "the

@@ -60,6 +60,7 @@ struct ddn_fsk4_rx {
     int32_t* d_lock;
     size_t filt_cap;
     int channels_per_wave;
+    int dbg_flags; // ddn_fsk4_rx_set_debug_flags
     // handler mode (ddn_fsk4_rx_set_handlers): the handlers' words [B][32] i32, the burst's dibits [B][144], event buffers
     int32_t* d_hwords;
     uint8_t* d_hpay;
@@ -281,7 +282,7 @@ ddn_fsk4_rx_create(const ddn_fsk4_rx_config* cfg, ddn_fsk4_rx** out) {
             break;
         }
     }
-    if (const char* e = getenv("DDN_RX4_CPW")) { // (experiments; the same values ddn_fsk4_rx_set_channels_per_wave accepts)
+    if (const char* e = DDN_EXP_ENV("DDN_RX4_CPW")) { // (experiments; the same values ddn_fsk4_rx_set_channels_per_wave accepts)
         const int v = atoi(e);
         if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) {
             b->channels_per_wave = v;
@@ -463,9 +464,13 @@ ddn_fsk4_rx_run(ddn_fsk4_rx* b, const float* d_disc, size_t n, uint8_t* d_record
     if (b->timing) {
         HIP_TRY(hipEventRecord(b->ev[1], st));
     }
-    if (const char* e = getenv("DDN_RX4_DBG")) {
-        if (b->dc.dbg != atoi(e)) {
-            b->dc.dbg = atoi(e);
+    {
+        int want = b->dbg_flags;
+        if (const char* e = DDN_EXP_ENV("DDN_RX4_DBG")) {
+            want = atoi(e);
+        }
+        if (b->dc.dbg != want) {
+            b->dc.dbg = want;
             HIP_TRY(hipMemcpy(b->d_cfg, &b->dc, sizeof(DdnFsk4Config), hipMemcpyHostToDevice));
         }
     }
@@ -487,6 +492,15 @@ ddn_fsk4_rx_set_channels_per_wave(ddn_fsk4_rx* b, int channels_per_wave) {
         return DDN_EINVAL;
     }
     b->channels_per_wave = channels_per_wave;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_fsk4_rx_set_debug_flags(ddn_fsk4_rx* b, int flags) {
+    if (!b) {
+        return DDN_EINVAL;
+    }
+    b->dbg_flags = flags;
     return DDN_OK;
 }
 

@@ -118,7 +118,7 @@ ddn_p25_slicer_run(ddn_slicer_batch* b, const float* d_symbols, size_t n, uint8_
     }
     // The sequential kernel (one lane per channel walking every symbol) remains for short calls; from a few hundred
     // symbols on the parallel decomposition (ddn_slicer_par.hip) wins.  DDN_SLICER_SEQ forces the sequential one (A/B).
-    static const bool force_seq = getenv("DDN_SLICER_SEQ") != nullptr;
+    static const bool force_seq = DDN_EXP_ENV("DDN_SLICER_SEQ") != nullptr;
     if (n >= 256 && !force_seq) {
         const size_t need = sizeof(float) * 4 * n * (size_t)b->n_channels;
         float* scratch = nullptr;

@@ -297,7 +297,7 @@ static int
 nid_wave_max() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("DDN_NID_WAVE_MAX");
+        const char* e = DDN_EXP_ENV("DDN_NID_WAVE_MAX");
         const long x = e ? strtol(e, nullptr, 10) : 16384;
         v = (x < 0 || x > (1 << 24)) ? 16384 : (int)x;
     }

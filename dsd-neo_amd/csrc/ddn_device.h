@@ -8,6 +8,16 @@
 
 #include "ddn_internal.h"
 
+/* Experiment knobs.  The product build reads nothing from the environment: DDN_EXP_ENV(name) is NULL there, so every "if the variable
+ * is set" branch folds away and the library's schedule depends on its arguments alone.  The timing tools build a second library
+ * with -DDDN_EXPERIMENTS (tools/build_variant.sh exp), in which the knobs DESIGN / profiles/README.md name are live. */
+#ifdef DDN_EXPERIMENTS
+#include <stdlib.h>
+#define DDN_EXP_ENV(name) getenv(name)
+#else
+#define DDN_EXP_ENV(name) ((const char*)0)
+#endif
+
 #define DDN_TILE 256        /* time tile (samples) of the fused front-end kernel */
 #define DDN_DEFAULT_GROUP 8 /* channels per workgroup */
 #define DDN_CARRY_LEN 72 /* >= DDN_MAX_CENTER widened samples of FIR look-back per channel */

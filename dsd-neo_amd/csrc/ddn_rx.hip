@@ -3447,7 +3447,7 @@ launch_rxw(const float* raw, const float* filt, const float* prev_tail, float* f
     if (e != hipSuccess) {
         return e;
     }
-    if (getenv("DDN_RX_OCC")) {
+    if (DDN_EXP_ENV("DDN_RX_OCC")) {
         int nb = -1;
         hipFuncAttributes fa;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_p25_rxw<CPW, HM, NRW_T>), (int)nthreads, shm);
@@ -3487,7 +3487,7 @@ use_filter_row_missing(const DdnRxConfig* cfg, const float* filt) {
 static int
 handler_mode_cpw(int channels_per_wave, int n_channels) {
     int cpw = channels_per_wave;
-    if (const char* e = getenv("DDN_RX_CPW")) { // (experiments)
+    if (const char* e = DDN_EXP_ENV("DDN_RX_CPW")) { // (experiments)
         cpw = atoi(e);
     }
     if (cpw != 4 && cpw != 8 && cpw != 16) {
@@ -3542,7 +3542,7 @@ ddn_dev_p25_rx(const float* raw, const float* filt, const float* prev_tail, floa
         }
     }
     int cpw = channels_per_wave;
-    if (const char* e = getenv("DDN_RX_CPW")) { // (experiments)
+    if (const char* e = DDN_EXP_ENV("DDN_RX_CPW")) { // (experiments)
         cpw = atoi(e);
     }
     const int whole = cfg->sym_rate > 0 ? cfg->out_rate / cfg->sym_rate : 0;

@@ -1927,7 +1927,7 @@ launch(const float* raw, const float* filt, const float* prev_tail, float* fstal
     if (e != hipSuccess) {
         return e;
     }
-    if (getenv("DDN_RX_OCC")) {
+    if (DDN_EXP_ENV("DDN_RX_OCC")) {
         int nb = -1;
         hipFuncAttributes fa;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_fsk4_rx<CPW, MAXW, PROTO, HM>), 128, shmem);

@@ -582,7 +582,7 @@ ddn_dev_gardner(const void* in, long n, size_t in_stride, int n_channels, int sp
     }
     // ring variant while the look-back fits one tile and the batch is latency-bound (few wavefronts), unless
     // DDN_TED_CLASSIC is set (A/B timing, tests)
-    static const bool classic = getenv("DDN_TED_CLASSIC") != nullptr;
+    static const bool classic = DDN_EXP_ENV("DDN_TED_CLASSIC") != nullptr;
     if (!classic && tw <= GTW_MAX && n_channels <= 32 * 1024) {
         if (n_channels <= 16 * 1024) {
             return launch_gardner_ring<16>(in, n, in_stride, n_channels, sps, ted_gain, symbol_rate_hz, block_len, state,

@@ -48,6 +48,10 @@ typedef struct ddn_p25_chain_config {
                              everything behind the records is the same decode */
     int sample_rate_hz;   /* CQPSK: demodulator rate, 0 = 48000 (10 samples per symbol); 24000 = 5 */
     float snr_cqpsk_db;   /* CQPSK: ddn_cq_rx_config.snr_cqpsk_db (0 = not available) */
+    /* appended in round 6: */
+    int d2h_blit;         /* _run_host's result copies: 0 = on an SDMA engine below HIP when the result buffers are pinned memory the
+                             runtime knows (probed at the first call with result buffers, reported by ddn_p25_chain_d2h_route), 1 =
+                             always hipMemcpyAsync on a copy stream (a shader blit: it cannot start while the loop holds every CU) */
 } ddn_p25_chain_config;
 enum { DDN_P25_MOD_C4FM = 0, DDN_P25_MOD_CQPSK = 1 };
 
@@ -130,7 +134,7 @@ int ddn_p25_chain_run_pipelined(ddn_p25_chain* c, const void* d_iq);
  * the receive loop holds every CU; the engine runs beside any kernel and duplex with the input copy).  This call first queues all
  * of its own work, then waits on the host for the previous call's decode (which runs beside this call's front end) and issues
  * those copies.  The outputs a result set names (counts, NIDs, TSDU blocks, PCM) exist once per buffer set on the device, so a
- * call's results can still be leaving while the next call is decoded.  DDN_D2H=blit in the environment (or result buffers the
+ * call's results can still be leaving while the next call is decoded.  cfg.d2h_blit = 1 (or result buffers the
  * runtime does not know as pinned) keeps the earlier route: hipMemcpyAsync on a copy stream, released beside this call's receive
  * loop.  ddn_p25_chain_wait() / _flush() issue the copies of the last call and wait for them.  h_iq must stay untouched until
  * the next call returns (that call waits on the host for the copy): two input buffers, used in turn, are enough.  The outputs
@@ -405,6 +409,11 @@ void* ddn_fsk4_chain_rx(ddn_fsk4_chain* c);        /* ddn_fsk4_rx* */
 typedef struct ddn_mixed_chain_config {
     int n_p25, n_dmr, n_nxdn48; /* channels of each group on this GPU (a group may be empty) */
     int samples_per_call, block_len, input_format, vocoder;
+    /* appended in round 6: */
+    int overlap; /* 1 = the overlapped schedule: the front ends on streams of their own into two discriminator buffers per group (call
+                    k + 1's front ends beside call k's loops), the fsk4 loops one channel per wavefront where a group has <= 1536
+                    channels.  Seven streams: it pays only with GPU_MAX_HW_QUEUES >= 6 in the process environment (HIP's default
+                    four hardware queues make streams share queues - slower than the default schedule).  Same results. */
 } ddn_mixed_chain_config;
 typedef struct ddn_mixed_chain ddn_mixed_chain;
 int ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out);

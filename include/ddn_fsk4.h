@@ -93,6 +93,9 @@ int ddn_fsk4_rx_get_thresholds(ddn_fsk4_rx* b, int channel, float out7[7]); /* c
  * keeps every workgroup resident for this batch alone; a host that runs other loops beside this one on the same GPU (the mixed
  * chain does) picks it for the whole device's channel count. */
 int ddn_fsk4_rx_set_channels_per_wave(ddn_fsk4_rx* b, int channels_per_wave);
+/* A/B selectors of the loop kernel's schedule (which of two equivalent code paths a launch takes; the results never depend on them):
+ * 65536 = the bulk hunting passes one owner lane at a time.  For the parity tests and timing tools; 0 = the product's choice. */
+int ddn_fsk4_rx_set_debug_flags(ddn_fsk4_rx* b, int flags);
 /* optional output beside d_sync_pos / d_sync_pat: the slicer thresholds {center, umid, lmid, max, min} as every accepted sync leaves them
  * (after the warm start), [B][max_syncs][5] floats in device memory, NULL = off.  Thresholds are static inside a DMR / NXDN / M17 frame,
  * so these are what a soft-symbol frame decoder reads (M17 LSF: soft_symbol_to_viterbi_cost(), src/core/frames/dsd_dibit.c:1189-1242) */

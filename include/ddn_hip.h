@@ -207,6 +207,10 @@ int ddn_p25_rx_set_channels_per_wave(ddn_p25_rx* b, int channels_per_wave);
  * measured: 8.2 against 7.9 ms; the loop's helper waves have no spare issue slots for 91 taps per sample).  Default 0.
  * Same records, flags and events bit for bit either way.  No effect outside handler mode or at sixteen channels per workgroup. */
 int ddn_p25_rx_set_filter_in_loop(ddn_p25_rx* b, int on);
+/* A/B selectors of the loop kernel's schedule (which of two equivalent code paths a launch takes; the results never depend on them):
+ * 4096 = the bulk hunting passes one owner lane at a time, 2097152 = lean runs of one trip, 16777216 = four recurrence waves of two
+ * lanes ... (ddn_rx.hip documents each bit where it is read).  For the parity tests and timing tools; 0 = the product's choice. */
+int ddn_p25_rx_set_debug_flags(ddn_p25_rx* b, int flags);
 size_t ddn_p25_rx_max_symbols(const ddn_p25_rx* b, size_t n);
 int ddn_p25_rx_run(ddn_p25_rx* b, const float* d_disc, size_t n, uint8_t* d_records10, uint8_t* d_flags,
                    int32_t* d_counts, size_t max_symbols, void* hip_stream);

@@ -36,6 +36,18 @@ def test_gpus_2_launches_its_own_ranks(built):
     assert one["n_gpus"] == 1 and one["work"] == line["work"]
 
 
+def test_gpus_8_the_drivers_scaling_shape(built):
+    """the shape the driver's scaling run uses (--gpus 8): eight ranks over gloo, one channel each, one line with the whole job's work"""
+    p = _run("--gpus", "8", "--steps", "1", "--warmup", "0", "--channels", "1", "--samples", "24000", "--dry-run-cpu", timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["dry_run_cpu"] is True and line["scaling"] == "weak"
+    assert line["config"]["channels_total"] == 8 and line["config"]["channels_per_gpu"] == 1
+    assert line["value"] > 0 and line["work"]["symbols"] > 8 * 2300 and line["work"]["syncs"] >= 8
+
+
 def test_more_gpus_than_the_node_has_is_a_clear_error(built):
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0

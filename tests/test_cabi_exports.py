@@ -38,6 +38,21 @@ def test_no_cpu_fallback_without_gpu(built):
     assert "rc=-2" in str(e.value)
 
 
+def test_product_library_reads_no_environment(built):
+    """the experiment knobs of the timing tools (DDN_EXP_ENV, dsd-neo_amd/csrc/ddn_device.h) compile to nothing in the product build:
+    libdsdneo_hip.so does not import getenv at all, and the sources call it nowhere but in that one macro"""
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", ddn.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\b(secure_)?getenv\b", und), [l for l in und.splitlines() if "getenv" in l]
+    src = os.path.join(ddn.ROOT, "dsd-neo_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(src)):
+        for k, line in enumerate(open(os.path.join(src, f), errors="replace")):
+            if re.search(r"\bgetenv\s*\(", line):
+                hits.append((f, k + 1))
+    assert hits == [("ddn_device.h", hits[0][1])] if hits else False, hits
+
+
 def test_product_does_not_reference_oracle():
     """The shipped sources never include/link anything under oracle/."""
     for sub in ("dsd-neo_amd", "include"):
@@ -64,9 +79,13 @@ def test_c_host_example_compiles_and_links(built, tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Werror", "-I", os.path.join(ddn.ROOT, "include"),
                            os.path.join(ddn.ROOT, "examples", "p25_node_host.c"), "-L", lib_dir, "-ldsdneo_hip",
                            "-Wl,-rpath," + lib_dir, "-o", exe2])
+    exe3 = str(tmp_path / "mixed_node_host")                # BASELINE configs[3] from C: kind = DDN_NODE_MIXED
+    subprocess.check_call(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Werror", "-I", os.path.join(ddn.ROOT, "include"),
+                           os.path.join(ddn.ROOT, "examples", "mixed_node_host.c"), "-L", lib_dir, "-ldsdneo_hip",
+                           "-Wl,-rpath," + lib_dir, "-o", exe3])
     import torch
     if not torch.cuda.is_available():
-        for e in (exe, exe2):
+        for e in (exe, exe2, exe3):
             p = subprocess.run([e], capture_output=True, text=True, timeout=120)
             assert p.returncode == 1 and p.stderr.strip()   # ddn_last_error(): no device - never a CPU fallback
 

@@ -173,7 +173,7 @@ def test_mixed_chain_groups_side_by_side(built):
 
 
 def test_mixed_chain_overlapped_schedule_equals_default(built, monkeypatch):
-    """DDN_MIX_OVERLAP=1 (front ends on streams of their own into two discriminator buffers per group, the next call's front ends
+    """ddn_mixed_chain_config.overlap = 1 (front ends on streams of their own into two discriminator buffers per group, the next call's front ends
     beside this call's loops, fsk4 loops one channel per wavefront): five calls issued back to back without a wait give, array for
     array, what the default schedule gives for the same five calls - every group, the carried tails included"""
     import p25gen
@@ -190,9 +190,7 @@ def test_mixed_chain_overlapped_schedule_equals_default(built, monkeypatch):
     l = ddn.lib()
     got = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("DDN_MIX_OVERLAP", mode)
-        m = ddn.MixedChainC(Bp, Bd, Bn, N)
-        monkeypatch.delenv("DDN_MIX_OVERLAP")
+        m = ddn.MixedChainC(Bp, Bd, Bn, N, overlap=int(mode))
         ptrs = []
         for k in range(calls):
             ps = [_upload(x) for x in piece(k)]

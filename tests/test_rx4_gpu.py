@@ -111,17 +111,18 @@ def test_wide_batch_both_wave_shapes(built):
 @pytest.mark.parametrize("cpw", [2, 4])
 def test_hunting_pass_of_all_rows_at_once_equals_one_owner_at_a_time(built, monkeypatch, cap, lpf, proto, cpw):
     """two / four channels per wavefront: the lanes that hunt take the bulk hunting pass together, one row of the wavefront
-    each (ddn_rx4.hip); same records as the pass taken one owner after the other (DDN_RX4_DBG bit 65536) and as the oracle"""
+    each (ddn_rx4.hip); same records as the pass taken one owner after the other (ddn_fsk4_rx_set_debug_flags bit 65536) and as the
+    oracle"""
     disc = rx4.capture_disc(cap, lpf)[:30000]
     B = 41
     x = np.stack([np.roll(disc, 211 * (c % 23)) * (0.35 + 0.05 * (c % 9)) for c in range(B)]).astype(np.float32)
     x[5, 9000:] = 0.0                                  # a channel whose carrier goes away hunts for the rest of the call
     x[6, :15000] = 0.0
     outs = []
-    for dbg in ("0", "65536"):
-        monkeypatch.setenv("DDN_RX4_DBG", dbg)
+    for dbg in (0, 65536):
         rx = ddn.Fsk4Rx(B, GPU_PROTO[proto])
         assert ddn.lib().ddn_fsk4_rx_set_channels_per_wave(rx.h, cpw) == 0
+        assert ddn.lib().ddn_fsk4_rx_set_debug_flags(rx.h, dbg) == 0
         outs.append([rx.run_host(x[:, a:b]) for a, b in ((0, 14000), (14000, 30000))])
     for part in range(2):
         for k in outs[0][part]:

@@ -122,8 +122,8 @@ def test_every_frame_type_clean_and_noisy(built, cpw, fil):
 @pytest.mark.parametrize("cpw", [4, 8])
 def test_hunting_pass_of_all_rows_at_once_equals_one_owner_at_a_time(built, monkeypatch, cpw):
     """two / four channels per recurrence wave: the lanes that hunt take the bulk hunting pass together, each in its own row of the
-    wavefront (ddn_rx.hip); the records, flags and decisions are those of the pass taken one owner after the other (DDN_RX_DBG bit
-    4096).  Channels whose frames end together and channels that lose their carrier make sure several lanes hunt at once."""
+    wavefront (ddn_rx.hip); the records, flags and decisions are those of the pass taken one owner after the other
+    (ddn_p25_rx_set_debug_flags bit 4096).  Channels whose frames end together and channels that lose their carrier make sure several lanes hunt at once."""
     B, n = 32, 30000
     x = np.zeros((B, n), np.float32)
     for c in range(B):
@@ -132,9 +132,8 @@ def test_hunting_pass_of_all_rows_at_once_equals_one_owner_at_a_time(built, monk
     x[9, 12000:] = 0.0
     x[10, :9000] = 0.0
     outs = []
-    for dbg, fil in (("0", False), ("4096", False), ("0", True)):   # (third run: the matched filter inside the loop, carrier losses incl.)
-        monkeypatch.setenv("DDN_RX_DBG", dbg)
-        rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=2048, filter_in_loop=fil)
+    for dbg, fil in ((0, False), (4096, False), (0, True)):   # (third run: the matched filter inside the loop, carrier losses incl.)
+        rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=2048, filter_in_loop=fil, debug_flags=dbg)
         rec, fl, cnt = rx.run(x)
         outs.append((rec.copy(), fl.copy(), cnt.copy(), rx.events.copy(), rx.n_events.copy(), rx.event_data.copy()))
     for k in (1, 2):

@@ -35,7 +35,7 @@ def tile(name, lo, hi, Bc):
 
 
 d_p, d_d, d_n = torch.from_numpy(iq).to(dev), tile("iq_dmr_t3_ras_cc.npz", 0, 96000, Bd), tile("iq_nxdn48.npz", 60000, 288000, Bn)
-m = ddn.MixedChainC(Bp, Bd, Bn, n)
+m = ddn.MixedChainC(Bp, Bd, Bn, n, overlap=int(os.environ.get("MIX_OVERLAP", "0")))  # (ddn_mixed_chain_config.overlap)
 for _ in range(2):
     m.run(d_p.data_ptr(), d_d.data_ptr(), d_n.data_ptr())
 m.wait()

@@ -29,7 +29,9 @@ disc = torch.zeros((B, n), dtype=torch.float32, device="cuda")
 l = ddn.lib()
 locks = np.array([840 if k == "voice" else int(os.environ.get("LOCK_CC", "156")) for k, _ in idx], np.int32)
 for mode, cpw in [(m, int(c)) for m, c in (x.split(":") for x in os.environ.get("MODES", "locks:8,handlers:8,handlers:16,locks:16").split(","))]:
-    rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=(mode == "handlers"))
+    # (the product library reads no environment: the schedule selectors and the filter-in-the-loop switch go through the setters)
+    rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=(mode == "handlers"),
+                   debug_flags=int(os.environ.get("DDN_RX_DBG", "0"), 0) & 0x7FFFFFFF, filter_in_loop=os.environ.get("FIL", "0") == "1")
     if mode == "locks":
         assert l.ddn_p25_rx_set_lock_symbols(rx.h, locks.ctypes.data) == 0
     ms = l.ddn_p25_rx_max_symbols(rx.h, n)
