@@ -75,6 +75,9 @@ PROTOTYPES = {
     "ddn_batch_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ddn_front_end_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_front_end_run_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddn_batch_set_channels_per_workgroup": (C.c_int, [C.c_void_p, C.c_int]),
+    "ddn_batch_set_segments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ddn_front_end_run_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ddn_batch_get_fsk_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ddn_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ddn_batch_get_timing": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -62,8 +62,12 @@ struct ddn_batch {
     float taps[DDN_MAX_TAPS + 1];
     int taps_len;
     int center;
-    int group; // channels per workgroup of the fused kernel (8 or 16)
+    int group; // channels per workgroup of the fused kernel (8 or 16; 0 = by batch size)
     float* d_taps;
+    // segments (ddn_batch_set_segments): tap sets of the second and third run of the channel index, where those runs start
+    int n_seg, seg_first[3];
+    float taps_s[2][DDN_MAX_TAPS + 1];
+    float* d_taps_s[2];
     ddn_f2* d_carry;      // [B][DDN_CARRY_LEN]
     DdnFskState* d_state; // [B]
     // host-call staging
@@ -129,7 +133,7 @@ ddn_batch_create(const ddn_front_end_config* cfg, ddn_batch** out) {
     b->center = (b->taps_len - 1) / 2;
     {
         const char* gsel = DDN_EXP_ENV("DDN_GROUP");
-        b->group = (gsel && atoi(gsel) == 16) ? 16 : ((gsel && atoi(gsel) == 8) ? 8 : DDN_DEFAULT_GROUP);
+        b->group = (gsel && atoi(gsel) == 16) ? 16 : ((gsel && atoi(gsel) == 8) ? 8 : 0);
     }
     // the reference routes blocks shorter than 2*taps_len floats to its non-FMA scalar unit
     // (src/dsp/simd_fir.cpp:303-306); this build implements the FMA (AVX2-unit) order only.
@@ -176,6 +180,8 @@ ddn_batch_destroy(ddn_batch* b) {
         return;
     }
     (void)hipFree(b->d_taps);
+    (void)hipFree(b->d_taps_s[0]);
+    (void)hipFree(b->d_taps_s[1]);
     (void)hipFree(b->d_carry);
     (void)hipFree(b->d_state);
     (void)hipFree(b->d_in);
@@ -290,6 +296,122 @@ grow(void** p, size_t* cap, size_t need) {
 }
 
 extern "C" int
+ddn_batch_set_channels_per_workgroup(ddn_batch* b, int channels) {
+    if (!b || (channels != 0 && channels != 8 && channels != 16)) {
+        return DDN_EINVAL;
+    }
+    b->group = channels;
+    return DDN_OK;
+}
+
+// Segments: the batch's channel index cut into up to three runs, each with its own channel low-pass profile and (at run time) its own
+// input and output arrays - the protocol groups of a mixed batch behind ONE front-end launch of ceil(n_channels / 16) workgroups.
+extern "C" int
+ddn_batch_set_segments(ddn_batch* b, int n_seg, const int32_t* seg_channels, const int32_t* lpf_profiles) {
+    if (!b || n_seg < 1 || n_seg > 3 || !seg_channels || !lpf_profiles) {
+        return DDN_EINVAL;
+    }
+    long total = 0;
+    for (int k = 0; k < n_seg; k++) {
+        if (seg_channels[k] <= 0) {
+            ddn_set_error("ddn_batch_set_segments: empty segment %d", k);
+            return DDN_EINVAL;
+        }
+        total += seg_channels[k];
+    }
+    if (total != b->cfg.n_channels || lpf_profiles[0] != b->cfg.lpf_profile || b->passes > 0 || b->iqc.dc_enable || b->iqc.bal_enable
+        || b->cfg.squelch_level > 0.0f) {
+        ddn_set_error("ddn_batch_set_segments: the segments must add up to the batch, segment 0 keeps the batch's profile, and the "
+                      "half-band cascade / IQ conditioning / squelch routes have no segmented form");
+        return DDN_EINVAL;
+    }
+    for (int k = 1; k < n_seg; k++) {
+        const int len = ddn_design_channel_lpf(b->cfg.sample_rate_hz, lpf_profiles[k], b->taps_s[k - 1], DDN_MAX_TAPS);
+        if (len != b->taps_len) { // one kernel instance walks every channel: the tap count is the launch's
+            ddn_set_error("ddn_batch_set_segments: profile %d designs %d taps, the batch's %d", lpf_profiles[k], len, b->taps_len);
+            return DDN_ERANGE;
+        }
+        if (!b->d_taps_s[k - 1]) {
+            HIP_TRY(hipMalloc(&b->d_taps_s[k - 1], sizeof(float) * (DDN_MAX_TAPS + 1)));
+        }
+        HIP_TRY(hipMemcpy(b->d_taps_s[k - 1], b->taps_s[k - 1], sizeof(float) * (size_t)len, hipMemcpyHostToDevice));
+    }
+    b->n_seg = n_seg;
+    b->seg_first[0] = 0;
+    b->seg_first[1] = n_seg > 1 ? seg_channels[0] : b->cfg.n_channels;
+    b->seg_first[2] = n_seg > 2 ? seg_channels[0] + seg_channels[1] : b->cfg.n_channels;
+    return DDN_OK;
+}
+
+extern "C" int
+ddn_front_end_run_segments(ddn_batch* b, const void* const* d_iq, size_t n, float* const* d_disc, void* hip_stream) {
+    if (!b || !d_iq || !d_disc || b->n_seg < 1) {
+        ddn_set_error("ddn_front_end_run_segments: null argument or no segments set");
+        return DDN_EINVAL;
+    }
+    for (int k = 0; k < b->n_seg; k++) {
+        if (!d_iq[k] || !d_disc[k]) {
+            ddn_set_error("ddn_front_end_run_segments: segment %d without arrays", k);
+            return DDN_EINVAL;
+        }
+    }
+    if (n == 0) {
+        return DDN_OK;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int block_len = b->cfg.block_len;
+    const long n_blocks = (long)((n + (size_t)block_len - 1) / (size_t)block_len);
+    const int tiles_per_block = (block_len + DDN_TILE - 1) / DDN_TILE;
+    DdnFusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.in = d_iq[0];
+    fa.out = d_disc[0];
+    fa.carry = b->d_carry;
+    // (the kernel refreshes the carried look-back itself; a call shorter than the look-back has no segmented carry kernel)
+    if (n < (size_t)DDN_CARRY_LEN) {
+        ddn_set_error("ddn_front_end_run_segments: n = %zu < %d samples", n, DDN_CARRY_LEN);
+        return DDN_ERANGE;
+    }
+    fa.carry_out = (ddn_f2*)b->d_carry;
+    fa.state = b->d_state;
+    fa.taps_dev = b->d_taps;
+    fa.ch_stride = n;
+    fa.out_stride = n;
+    fa.n = (long)n;
+    fa.n_tiles = n_blocks * tiles_per_block;
+    fa.n_channels = b->cfg.n_channels;
+    fa.in_fmt = b->cfg.input_format;
+    fa.block_len = block_len;
+    fa.tiles_per_block = tiles_per_block;
+    fa.center = b->center;
+    fa.n_seg = b->n_seg;
+    fa.seg_first1 = b->seg_first[1];
+    fa.seg_first2 = b->seg_first[2];
+    fa.seg_in0 = d_iq[0];
+    fa.seg_out0 = d_disc[0];
+    fa.seg_in1 = b->n_seg > 1 ? d_iq[1] : nullptr;
+    fa.seg_out1 = b->n_seg > 1 ? d_disc[1] : nullptr;
+    fa.seg_in2 = b->n_seg > 2 ? d_iq[2] : nullptr;
+    fa.seg_out2 = b->n_seg > 2 ? d_disc[2] : nullptr;
+    fa.seg_taps1 = b->d_taps_s[0];
+    fa.seg_taps2 = b->d_taps_s[1];
+    bool has_zero = taps_have_zero(b->taps, b->taps_len);
+    for (int k = 1; k < b->n_seg; k++) {
+        has_zero = has_zero || taps_have_zero(b->taps_s[k - 1], b->taps_len);
+    }
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[0], st));
+    }
+    HIP_TRY(ddn_dev_launch_fused_ex(&fa, has_zero, b->group ? b->group : 16, st));
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev[1], st));
+        HIP_TRY(hipEventRecord(b->ev[2], st));
+        b->ev_valid = 1;
+    }
+    return DDN_OK;
+}
+
+extern "C" int
 ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void* hip_stream) {
     if (!b || !d_iq || !d_disc) {
         ddn_set_error("ddn_front_end_run: null argument");
@@ -380,6 +502,11 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
     fa.center = b->center;
     fa.squelch_on = b->cfg.squelch_level > 0.0f ? 1 : 0;
     fa.squelch_level = b->cfg.squelch_level;
+    fa.n_seg = 0;
+    fa.seg_first1 = fa.seg_first2 = 0;
+    fa.seg_in0 = fa.seg_in1 = fa.seg_in2 = nullptr;
+    fa.seg_out0 = fa.seg_out1 = fa.seg_out2 = nullptr;
+    fa.seg_taps1 = fa.seg_taps2 = nullptr;
     {
         const char* d = DDN_EXP_ENV("DDN_DBG");
         fa.dbg = d ? atoi(d) : 0;

@@ -1070,6 +1070,28 @@ ddn_p25_chain_stage(ddn_p25_chain* c, int stage, const void* d_iq, void* hip_str
     return rc;
 }
 
+// (internal, the mixed chain's shared front end) stage 0 without the front end itself: what has to be on `st` ahead of a front end
+// launch that writes this call's discriminator rows to *disc_out ([B][samples_per_call] f32)
+extern "C" int
+ddn_p25_chain_stage0_prepare(ddn_p25_chain* c, void* hip_stream, float** disc_out) {
+    if (!c || !disc_out || c->cq) {
+        return DDN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int cur = (int)(c->step % NSET);
+    DDN_TRY(chain_settle_pending(c, st));
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t[0], st));
+    }
+    if (c->d_disc2 == nullptr) {
+        DDN_TRY(chain_carry(c, cur, st));
+    }
+    *disc_out = chain_disc(c);
+    HIP_TRY(hipEventRecord(c->ev_user, st));
+    c->have_user_stream = 1;
+    return DDN_OK;
+}
+
 // (internal, the mixed chain) a second discriminator buffer: the staged form then keeps the front end (stage 0) free of anything the
 // previous call's loop writes - the carried tail is copied at the head of stage 1 - and alternates the buffer by step
 extern "C" int

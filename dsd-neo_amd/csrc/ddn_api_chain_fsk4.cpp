@@ -42,6 +42,10 @@ struct ddn_fsk4_chain {
     ddn_mbe_batch* mbe;
     float* d_disc;
     float* d_disc2; // mixed chain only: odd steps' discriminator output (the next call's front end beside this call's loop)
+    // (round 6) recorded inside the decode stage once its last reader of the loop's single buffers (sync lists, events) and of the
+    // records has been queued: what the NEXT call's loop has to wait for (the frame FEC and the synthesis behind it work on gathered
+    // copies) - the mixed chain gates the group's next loop on it instead of on the whole decode stage
+    hipEvent_t ev_reads;
     // rows = T carried records + this call's (two sets: the carry reads the previous call's)
     uint8_t *d_rec[2], *d_fl[2], *d_pay;
     int32_t *d_new[2], *d_cnt_full, *d_cnt_scan;
@@ -125,6 +129,9 @@ ddn_fsk4_chain_destroy(ddn_fsk4_chain* c) {
         return;
     }
     (void)hipDeviceSynchronize();
+    if (c->ev_reads) {
+        (void)hipEventDestroy(c->ev_reads);
+    }
     ddn_batch_destroy(c->fe);
     ddn_fsk4_rx_destroy(c->rx);
     ddn_mbe_batch_destroy(c->mbe);
@@ -185,6 +192,10 @@ ddn_fsk4_chain_create(const ddn_fsk4_chain_config* cfg, ddn_fsk4_chain** out) {
         ddn_front_end_config fc = {c->B, 48000, wide ? 4800 : 2400, 4, wide ? DDN_LPF_12K5 : DDN_LPF_6K25, cfg->input_format,
                                    cfg->block_len, 0.0f};
         if ((rc = ddn_batch_create(&fc, &c->fe)) != DDN_OK) {
+            break;
+        }
+        if (hipEventCreateWithFlags(&c->ev_reads, hipEventDisableTiming) != hipSuccess) {
+            rc = DDN_EHIP;
             break;
         }
         ddn_fsk4_rx_config rcfg;
@@ -326,6 +337,7 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
     const size_t S = c->S;
     const int prev = cur ^ 1;
     const uint8_t* rec = c->d_rec[cur];
+    bool reads_recorded = false;
     HIP_TRY(ddn_dev_chain_counts(c->d_new[cur], c->T, c->B, flush, c->d_cnt_scan, c->d_cnt_full, st));
     HIP_TRY(ddn_dev_fsk4_chain_syncs_thr(c->c_pos[prev], c->c_pat[prev], c->c_pre[prev], c->c_prel[prev], c->c_n[prev], c->myc, c->s_pos,
                                          c->s_pat, c->s_pre, c->s_prel, c->s_n, (int)c->my, c->d_new[cur], c->T, flush, c->d_spos, c->d_spat,
@@ -352,6 +364,7 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
             DDN_TRY(ddn_mbe_result_skip_batch(c->yi_skip, V5, c->yi_res, st));
             DDN_TRY(ddn_mbe_synth_batch(c->mbe_i, c->yi_bits, c->yi_res, (size_t)c->yvf * 5, c->yi_pcm, c->yi_res_out, st));
         }
+        HIP_TRY(hipEventRecord(c->ev_reads, st));
         return DDN_OK;
     }
     if (c->m17) {
@@ -363,6 +376,7 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
                                          c->m_fp, c->m_st, st));
         DDN_TRY(ddn_m17_lich_assemble_batch(c->d_spat, c->d_ns, c->B, (size_t)c->myd, c->m_lsf, c->m_lsf_st, c->m_l6, c->m_cnt, c->m_st, c->m_asm,
                                             c->m_ll, c->m_ll_st, st));
+        HIP_TRY(hipEventRecord(c->ev_reads, st));
         return DDN_OK;
     }
     if (c->dmr) {
@@ -409,15 +423,28 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
                                              c->d_vpre, c->d_vnb, c->c_pos[cur], c->c_n[cur], c->myc, c->d_new[cur], st));
             HIP_TRY(ddn_dev_dmr_voice_gather_paths(rec, c->d_cnt_full, c->stride, c->d_vstart, c->d_vpre, c->d_pre, c->vb, c->B, 0,
                                                    c->d_ambe_fr, c->d_skip, c->c_pre[cur], (long)c->S, st));
+            HIP_TRY(hipEventRecord(c->ev_reads, st)); // (everything below works on the gathered frames)
+            reads_recorded = true;
             DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, c->d_ambe_fr, nullptr, V3, c->d_ambe_d, c->d_ambe_res, st));
             DDN_TRY(ddn_mbe_result_skip_batch(c->d_skip, V3, c->d_ambe_res, st));
             DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_ambe_d, c->d_ambe_res, (size_t)c->vb * 3, c->d_pcm, c->d_res_out, st));
+        }
+        if (!reads_recorded) {
+            HIP_TRY(hipEventRecord(c->ev_reads, st));
         }
         return DDN_OK;
     }
     // NXDN48: frame gather -> SACCH / FACCH1 K=5 soft decode -> CRC6 / CRC12 -> the reference's greedy retry for the SACCH
     DDN_TRY(ddn_nxdn_frame_gather(rec, c->d_cnt_full, c->stride, c->d_spos, c->d_ns, c->B, (size_t)c->myd, c->d_lich, c->d_ss, c->d_sr,
                                   c->d_fs, c->d_fr, c->d_valid, st));
+    if (c->cfg.vocoder) {
+        // voice, first half: which frames the LICHs announce, and their AMBE words out of the records (both only need the frame
+        // gather's LICHs; done here so that every reader of the loop's buffers sits at the head of the stage)
+        HIP_TRY(ddn_dev_nxdn_voice_select(c->d_spos, c->d_ns, c->d_lich, c->d_valid, c->B, c->myd, c->vf, c->d_vpos, c->d_vn, c->d_skip, st));
+        DDN_TRY(ddn_nxdn_voice_gather(rec, c->d_cnt_full, c->stride, c->d_vpos, c->d_vn, c->B, (size_t)c->vf, c->d_ambe_fr, c->d_ambe_rel,
+                                      nullptr, st));
+    }
+    HIP_TRY(hipEventRecord(c->ev_reads, st)); // (the decoders and the synthesis below work on the gathered words)
     // (the decoders skip the slots that hold no complete frame - d_valid - and write zeros there: the slot arrays are sized for the
     // densest traffic, a call of the bench capture uses an eighth of them)
     HIP_TRY(ddn_dev_k5_nxdn_wanted(c->d_ss, c->d_sr, (int)S, 36, 32, nullptr, c->d_sacch, 4, c->d_valid, 1, st));
@@ -428,11 +455,8 @@ fsk4_decode(ddn_fsk4_chain* c, int cur, int flush, hipStream_t st) {
     HIP_TRY(ddn_dev_k5_nxdn_wanted(c->d_fs, c->d_fr, (int)(S * 2), 96, 92, nullptr, c->d_facch, 12, c->d_valid, 2, st));
     DDN_TRY(ddn_nxdn_crc_check_batch(c->d_facch, 12, S * 2, 1, c->d_facch_ok, st));
     if (c->cfg.vocoder) {
-        // voice (nxdn_voice()): the frames the LICHs announce, through AMBE de-interleave -> frame FEC -> synthesis
+        // voice (nxdn_voice()): the frames the LICHs announce (selected and gathered above), through frame FEC -> synthesis
         const size_t V4 = c->V * 4;
-        HIP_TRY(ddn_dev_nxdn_voice_select(c->d_spos, c->d_ns, c->d_lich, c->d_valid, c->B, c->myd, c->vf, c->d_vpos, c->d_vn, c->d_skip, st));
-        DDN_TRY(ddn_nxdn_voice_gather(rec, c->d_cnt_full, c->stride, c->d_vpos, c->d_vn, c->B, (size_t)c->vf, c->d_ambe_fr, c->d_ambe_rel,
-                                      nullptr, st));
         DDN_TRY(ddn_mbe_frame_decode_batch(DDN_MBE_AMBE_3600X2450, c->d_ambe_fr, c->d_ambe_rel, V4, c->d_ambe_d, c->d_ambe_res, st));
         DDN_TRY(ddn_mbe_result_skip_batch(c->d_skip, V4, c->d_ambe_res, st));
         DDN_TRY(ddn_mbe_synth_batch(c->mbe, c->d_ambe_d, c->d_ambe_res, (size_t)c->vf * 4, c->d_pcm, c->d_res_out, st));
@@ -464,6 +488,18 @@ ddn_fsk4_chain_stage(ddn_fsk4_chain* c, int stage, const void* d_iq, void* hip_s
     c->last_set = cur;
     c->step++;
     return DDN_OK;
+}
+
+// (internal, the mixed chain) the event the decode stage records once everything that reads the loop's buffers has been queued
+extern "C" void*
+ddn_fsk4_chain_reads_done_event(ddn_fsk4_chain* c) {
+    return c ? (void*)c->ev_reads : nullptr;
+}
+
+// (internal, the mixed chain's shared front end) where this call's stage 0 would write its discriminator rows
+extern "C" float*
+ddn_fsk4_chain_disc_buffer(ddn_fsk4_chain* c) {
+    return !c ? nullptr : ((c->d_disc2 && (c->step & 1)) ? c->d_disc2 : c->d_disc);
 }
 
 extern "C" int
@@ -637,6 +673,9 @@ struct ddn_mixed_chain {
     hipStream_t stF[3];
     hipEvent_t ev_read[3][2];
     unsigned long long calls;
+    // (round 6) one front-end launch for all the groups (ddn_batch_set_segments): the groups' channels share workgroups of sixteen, so a
+    // 4096-channel mixed batch is one round of 256 workgroups instead of three launches of 171 eight-channel ones (two rounds and a half)
+    ddn_batch* fe_all;
 };
 extern "C" int ddn_p25_chain_double_disc(ddn_p25_chain* c);
 
@@ -649,6 +688,7 @@ ddn_mixed_chain_destroy(ddn_mixed_chain* m) {
     ddn_p25_chain_destroy(m->p25);
     ddn_fsk4_chain_destroy(m->dmr);
     ddn_fsk4_chain_destroy(m->nxdn);
+    ddn_batch_destroy(m->fe_all);
     for (int k = 0; k < 3; k++) {
         for (hipStream_t s : {m->st[k], m->st2[k], m->stF[k]}) {
             if (s) {
@@ -801,6 +841,27 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
             rc = DDN_EHIP;
         }
     }
+    if (rc == DDN_OK && !m->overlap && (m->p25 != nullptr) + (m->dmr != nullptr) + (m->nxdn != nullptr) >= 2) {
+        // the shared front end: one batch object over all channels, a segment per group present (the profiles the groups' own chain
+        // objects design: P25 C4FM / 12.5 kHz / 6.25 kHz - all 135 taps at 48 kHz; a set of profiles with different tap counts
+        // keeps the groups' own front ends)
+        int32_t cnt[3], prof[3];
+        int ns = 0;
+        const int gcnt[3] = {cfg->n_p25, cfg->n_dmr, cfg->n_nxdn48}, gprof[3] = {DDN_LPF_P25_C4FM, DDN_LPF_12K5, DDN_LPF_6K25};
+        for (int g = 0; g < 3; g++) {
+            if (gcnt[g] > 0) {
+                cnt[ns] = gcnt[g];
+                prof[ns++] = gprof[g];
+            }
+        }
+        ddn_front_end_config fc = {cfg->n_p25 + cfg->n_dmr + cfg->n_nxdn48, 48000, 4800, 4, prof[0], cfg->input_format, cfg->block_len, 0.0f};
+        if (!DDN_EXP_ENV("DDN_MIX_OWN_FE") && ddn_batch_create(&fc, &m->fe_all) == DDN_OK) {
+            if (ddn_batch_set_segments(m->fe_all, ns, cnt, prof) != DDN_OK || cfg->samples_per_call < DDN_CARRY_LEN) {
+                ddn_batch_destroy(m->fe_all);
+                m->fe_all = nullptr;
+            }
+        }
+    }
     if (rc != DDN_OK) {
         ddn_mixed_chain_destroy(m);
         return rc;
@@ -871,6 +932,55 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
             HIP_TRY(hipEventRecord(m->ev_loop[g], m->st[g]));
             HIP_TRY(hipEventRecord(m->ev_read[g][par], m->st[g]));
         }
+    } else if (m->fe_all) {
+        // one front-end launch for every group.  It writes every group's discriminator buffer, so it waits for all the loops of the
+        // call before; every group's matched filter + loop then follows it on the group's stream.  It goes on the stream of the
+        // LAST group present - the loop that ends last (NXDN48 6 ms, DMR 5, P25 4.8 side by side): queued right behind that loop
+        // it is dispatched the moment the loop ends.  On another stream it is released by an event, in a race with that group's
+        // decode stage (released by the same event), whose many small workgroups keep taking a little LDS on every CU while a front-end
+        // workgroup needs a CU's whole LDS: measured 4.0 ms for the launch instead of 2.2.
+        const int g0 = on[2] ? 2 : (on[1] ? 1 : 0);
+        hipStream_t sf = m->st[g0];
+        for (int g = 0; g < 3; g++) {
+            if (on[g] && g != g0 && m->calls > 0) {
+                HIP_TRY(hipStreamWaitEvent(sf, m->ev_loop[g], 0));
+            }
+        }
+        const void* in[3];
+        float* disc[3];
+        int ns = 0;
+        if (on[0]) {
+            DDN_TRY(ddn_p25_chain_stage0_prepare(m->p25, sf, &disc[ns]));
+            in[ns++] = iq[0];
+        }
+        if (on[1]) {
+            disc[ns] = ddn_fsk4_chain_disc_buffer(m->dmr);
+            in[ns++] = iq[1];
+        }
+        if (on[2]) {
+            disc[ns] = ddn_fsk4_chain_disc_buffer(m->nxdn);
+            in[ns++] = iq[2];
+        }
+        DDN_TRY(ddn_front_end_run_segments(m->fe_all, in, (size_t)m->cfg.samples_per_call, disc, sf));
+        HIP_TRY(hipEventRecord(m->ev_front[g0], sf));
+        for (int g = 0; g < 3; g++) {
+            if (!on[g]) {
+                continue;
+            }
+            if (g != g0) {
+                HIP_TRY(hipStreamWaitEvent(m->st[g], m->ev_front[g0], 0));
+            }
+            if (m->have_dec[g]) {
+                // the loop overwrites what the decode stage of the call before reads of it: P25 - the whole stage (its records and
+                // events are triple-buffered, but a loop that starts beside LDS-hungry decode kernels is slowed for its whole
+                // length); DMR / NXDN48 - the stage's gathers only (their loop's sync lists and events are single buffers), the
+                // frame FEC and synthesis behind them run on beside the loop
+                hipEvent_t gate = g == 0 ? m->ev_dec[0] : (hipEvent_t)ddn_fsk4_chain_reads_done_event(g == 1 ? m->dmr : m->nxdn);
+                HIP_TRY(hipStreamWaitEvent(m->st[g], gate, 0));
+            }
+            DDN_TRY(stage(g, 1));
+            HIP_TRY(hipEventRecord(m->ev_loop[g], m->st[g]));
+        }
     } else {
     for (int g = 0; g < 3; g++) {
         if (on[g]) {
@@ -902,6 +1012,27 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
     }
     }
     m->calls++;
+    if (m->fe_all && !m->overlap) {
+        // (round 6) With one decode stream for the three groups that stream was the step: its kernels run beside the front end and
+        // the loops at a fraction of their speed (k_p25_lsd 1.6 ms for 0.05, k_mbe_synth 2 ms for 0.5), one group after the other -
+        // 11.6 of a 12.5 ms step busy, whatever the front end and the loops did.  Now a group's decode stage follows its loop on the
+        // loop's own stream (it runs beside the loops that are still going; the group's next loop comes behind the shared front
+        // end anyway) - except the last group's, whose stream carries the front end of the next call right behind its loop: its
+        // decode goes to the decode stream, beside that front end.
+        const int g0 = on[2] ? 2 : (on[1] ? 1 : 0);
+        for (int g = 0; g < 3; g++) {
+            if (on[g]) {
+                hipStream_t sd = g == g0 ? m->st2[0] : m->st[g];
+                if (g == g0) {
+                    HIP_TRY(hipStreamWaitEvent(sd, m->ev_loop[g], 0));
+                }
+                DDN_TRY(g == 0 ? ddn_p25_chain_stage(m->p25, 2, iq[0], sd) : ddn_fsk4_chain_stage(g == 1 ? m->dmr : m->nxdn, 2, iq[g], sd));
+                HIP_TRY(hipEventRecord(m->ev_dec[g], sd));
+                m->have_dec[g] = true;
+            }
+        }
+        return DDN_OK;
+    }
     for (int g = 0; g < 3; g++) {
         if (on[g]) {
             HIP_TRY(hipStreamWaitEvent(m->st2[0], m->ev_loop[g], 0));

@@ -58,6 +58,14 @@ typedef struct DdnFusedArgs {
     float squelch_level;
     long long* dbg_out; /* optional: per-wave phase timings of workgroup 0 (DDN_DBG bit 6) */
     int dbg; /* timing experiments only (DDN_DBG env): 1 skip recurrences, 2 skip filter, 4 skip finish, 8 skip staging */
+    /* (round 6) segments: the batch's channel index is cut into up to three runs [seg_first1, seg_first2) ... with an input array, an
+     * output array and a tap set of their own (same tap count) - three protocol groups of a mixed batch in ONE launch, so the grid is
+     * ceil(total / G) workgroups however the groups' sizes fall (a workgroup may hold channels of two groups).  n_seg <= 1: in / out /
+     * taps_dev above, as before.  carry / state are the batch's arrays, indexed by the batch's channel index either way. */
+    int n_seg, seg_first1, seg_first2;
+    const void *seg_in0, *seg_in1, *seg_in2;
+    float *seg_out0, *seg_out1, *seg_out2;
+    const float *seg_taps1, *seg_taps2; /* (segment 0's are taps_dev) */
 } DdnFusedArgs;
 
 #define DDN_TED_DL 100 /* == TED_DL_SIZE (include/dsd-neo/dsp/ted.h:19) */
@@ -323,6 +331,7 @@ hipError_t ddn_dev_k5_m17(const uint16_t* in, int n, int in_len, int u_len, cons
 hipError_t ddn_dev_k5_m17_wanted(const uint16_t* in, int n, int in_len, int u_len, const DdnPuncture* pu, uint8_t* out, int out_stride,
                                  uint32_t* cost, const uint8_t* wanted, hipStream_t st);
 hipError_t ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, hipStream_t st);
+hipError_t ddn_dev_launch_fused_ex(const DdnFusedArgs* a, bool has_zero, int group, hipStream_t st);
 hipError_t ddn_dev_launch_carry(const void* in, int in_fmt, size_t ch_stride, long n, void* carry, int n_channels,
                                 hipStream_t st);
 hipError_t ddn_dev_zero(void* p, size_t bytes, hipStream_t st);

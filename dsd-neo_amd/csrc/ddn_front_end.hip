@@ -74,7 +74,7 @@ ddn_phase_delta(f2 cur, f2 prev) {
         const float x2 = x * x;
         return x * (1.0f + x2 * (-0.3333333333333333f + x2 * 0.2f));
     }
-    return ddn_atan2f(im, re);
+    return ddn_atan2f_fast(im, re);
 }
 
 // One sample of the peak-tracking AGC recurrence (src/dsp/fsk_modem.c:116-133) on the centred value c.
@@ -176,7 +176,9 @@ k_front_end_fused(DdnFusedArgs a) {
     __shared__ int tflag[3][G];
     __shared__ float gmin[3][G][TT / 8 + 1]; // min |centred| of each 8-sample group, written by S1 for S2's guard test
     __shared__ int next_item; // filter work-item counter of the current tile // per tile/channel: 1 = squelched (zeros + modem reset), 2 = first sample skipped
-    __shared__ __attribute__((aligned(8))) float stap[DDN_MAX_CENTER + 4];
+    constexpr int STAP = DDN_MAX_CENTER + 5; // (odd + 1 = even: every segment's tap row starts 8-byte aligned)
+    static_assert(STAP % 2 == 0, "tap rows are read in 8-byte pairs");
+    __shared__ __attribute__((aligned(8))) float stap[3 * STAP]; // one row of taps per segment (a plain batch uses row 0)
     extern __shared__ f2 ysq[]; // [1 or 2][G][256] first LPF outputs of a block (squelch builds only)
 
     // The two recurrence waves are the FIRST waves of the workgroup: VALU issue on a SIMD is arbitrated by age
@@ -194,6 +196,12 @@ k_front_end_fused(DdnFusedArgs a) {
     const int C = (CENTER_T > 0) ? CENTER_T : a.center;
     const int ch = ch0 + (g < nch ? g : 0); // clamp: surplus slots recompute channel ch0, never store
     const bool ch_ok = g < nch;
+    // segment of this thread's channel: its input / output arrays and its row inside them (a plain batch: segment 0 = the batch)
+    const bool segs = a.n_seg > 1;
+    const int seg = segs ? ((ch >= a.seg_first1 ? 1 : 0) + ((a.n_seg > 2 && ch >= a.seg_first2) ? 1 : 0)) : 0;
+    const int chl = ch - (seg == 0 ? 0 : (seg == 1 ? a.seg_first1 : a.seg_first2));
+    const void* const in_s = segs ? (seg == 0 ? a.seg_in0 : (seg == 1 ? a.seg_in1 : a.seg_in2)) : a.in;
+    float* const out_s = segs ? (seg == 0 ? a.seg_out0 : (seg == 1 ? a.seg_out1 : a.seg_out2)) : a.out;
     const long NT = a.n_tiles;
 
     // recurrence state (S1: dc / have_prev / squelched, S2: peak)
@@ -212,6 +220,12 @@ k_front_end_fused(DdnFusedArgs a) {
     }
     if (tid <= C) {
         stap[tid] = a.taps_dev[tid];
+        if (a.n_seg > 1) {
+            stap[STAP + tid] = a.seg_taps1[tid];
+        }
+        if (a.n_seg > 2) {
+            stap[2 * STAP + tid] = a.seg_taps2[tid];
+        }
     }
     // raw samples of the NEXT tile, fetched while the current one is filtered (hides HBM latency)
     uint32_t pre_u[(FMT == DDN_IN_CU8) ? NPRE : 1];
@@ -245,7 +259,7 @@ k_front_end_fused(DdnFusedArgs a) {
                 const TileDesc t3 = tq[4];
                 const int bf = (int)((it - 3) % 3);
                 const int bp = (int)((it - 3) & 1);
-                float* o = a.out + (size_t)ch * a.out_stride + t3.start;
+                float* o = out_s + (size_t)chl * a.out_stride + t3.start;
                 const bool al = ((((size_t)o) & 15) == 0);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
@@ -288,7 +302,7 @@ k_front_end_fused(DdnFusedArgs a) {
                             if (p > tc.blk_end - 1) {
                                 p = tc.blk_end - 1; // the reference replicates the block's last sample
                             }
-                            v = ddn_load_iq(a.in, FMT, a.ch_stride, ch, p);
+                            v = ddn_load_iq(in_s, FMT, a.ch_stride, chl, p);
                         }
                         win[g][i + i / R] = v;
                     }
@@ -340,9 +354,9 @@ k_front_end_fused(DdnFusedArgs a) {
                         }
                         if (i < Weff) {
                             if constexpr (FMT == DDN_IN_CU8) {
-                                pre_u[k] = *((const uint16_t*)a.in + (size_t)ch * a.ch_stride + p);
+                                pre_u[k] = *((const uint16_t*)in_s + (size_t)chl * a.ch_stride + p);
                             } else {
-                                pre_f[k] = *((const f2*)a.in + (size_t)ch * a.ch_stride + p);
+                                pre_f[k] = *((const f2*)in_s + (size_t)chl * a.ch_stride + p);
                             }
                         }
                     }
@@ -366,6 +380,10 @@ k_front_end_fused(DdnFusedArgs a) {
                 }
                 const int g = item;      // channel slot of this item
                 const int u = lane64;    // position inside the tile: outputs u*R .. u*R+R-1
+                // the item's tap row (one channel per item: uniform over the wave)
+                const int ich = ch0 + item;
+                const int irow = segs ? STAP * ((ich >= a.seg_first1 ? 1 : 0) + ((a.n_seg > 2 && ich >= a.seg_first2) ? 1 : 0)) : 0;
+                const float* const stp = &stap[irow];
                 f2 acc[R];
                 const f2 zero = {0.0f, 0.0f};
                 // a block shorter than taps_len samples goes to the reference's non-fused scalar unit
@@ -376,10 +394,10 @@ k_front_end_fused(DdnFusedArgs a) {
 #pragma unroll
                     for (int j = 0; j < R; j++) {
                         const int o = u * R + j + C;
-                        acc[j] = zero + stap[C] * w[o + o / R];
+                        acc[j] = zero + stp[C] * w[o + o / R];
                     }
                     for (int k = 0; k < C; k++) {
-                        const float h = stap[k];
+                        const float h = stp[k];
                         if (h == 0.0f) {
                             continue;
                         }
@@ -403,7 +421,7 @@ k_front_end_fused(DdnFusedArgs a) {
                     // prove equal (opaque index copies; the pointers stay LDS pointers): with one base it fuses each step's pair of 8-byte reads into ds_read2_b64, which
                     // gfx950 services at 128 B/clk (8 LDS cycles) where two ds_read_b64 take 2 + 2 cycles at 256 B/clk —
                     // and at R = 4 the fused form makes the LDS, not the VALU, the busiest unit of the CU.
-                    int olo = u * (R + 1), ohi = u * (R + 1), otap = 0;
+                    int olo = u * (R + 1), ohi = u * (R + 1), otap = irow;
                     asm volatile("" : "+v"(olo));
                     asm volatile("" : "+v"(ohi));
                     asm volatile("" : "+v"(otap));
@@ -412,7 +430,7 @@ k_front_end_fused(DdnFusedArgs a) {
                     const float* tp = &stap[otap]; // a base register + immediate offsets instead of one v_mov per tap
                     f2 xm[R], xp[R], qm[PF], qp[PF];
                     float qh[PF]; // taps ride the same prefetch queue (LDS broadcast reads of stap[])
-                    const float hcs = stap[CENTER_T];
+                    const float hcs = stp[CENTER_T];
                     const f2 hc = {hcs, hcs};
 #pragma unroll
                     for (int j = 0; j < R; j++) {
@@ -480,14 +498,14 @@ k_front_end_fused(DdnFusedArgs a) {
 #undef PH
                 } else {
                     const f2* w = &win[g][0];
-                    const f2 hc = {stap[C], stap[C]};
+                    const f2 hc = {stp[C], stp[C]};
 #pragma unroll
                     for (int j = 0; j < R; j++) {
                         const int o = u * R + j + C;
                         acc[j] = __builtin_elementwise_fma(hc, w[o + o / R], zero);
                     }
                     for (int k = 0; k < C; k++) {
-                        const float h = stap[k];
+                        const float h = stp[k];
                         if (h == 0.0f) {
                             continue;
                         }
@@ -726,7 +744,7 @@ k_front_end_fused(DdnFusedArgs a) {
         // or writes this channel's row (it read it at tile 0), so no other ordering is needed.
         f2* c = a.carry_out + (size_t)ch * DDN_CARRY_LEN;
         for (int i = u; i < DDN_CARRY_LEN; i += 32) {
-            c[i] = ddn_load_iq(a.in, FMT, a.ch_stride, ch, a.n - DDN_CARRY_LEN + i);
+            c[i] = ddn_load_iq(in_s, FMT, a.ch_stride, chl, a.n - DDN_CARRY_LEN + i);
         }
     }
     if (role == 1 && ch_ok && g < G && a.n > 0) {
@@ -803,19 +821,15 @@ launch_fused_c(const DdnFusedArgs& a, const DdnTapsK& tp, bool has_zero, hipStre
     }
 }
 
+// group: channels per workgroup, 8 / 16, or 0 = by batch size.  A workgroup walks its channels' whole call, so the grid is
+// n_channels / G workgroups: below ~2048 channels the 16-channel shape leaves CUs idle and the 8-channel one (twice the workgroups, same
+// work per thread) wins - when the launch has the device to itself.  (round 6) A caller that runs several front ends side by side (the
+// mixed chain) asks for 16: a workgroup's time does not depend on how many of its channel slots are filled (the two recurrence waves
+// run lane = channel), so 8-channel workgroups of three launches fill the CUs twice over (measured: 6.3 ms for three groups of 1365
+// where one launch of 4096 takes 2.1).
 extern "C" hipError_t
-ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, hipStream_t st) {
-    const int C = a->center;
-    DdnTapsK tp;
-    bool has_zero = false;
-    tp.centre = taps_host[C];
-    for (int k = 0; k < DDN_MAX_CENTER; k++) {
-        tp.side[k] = (k < C) ? taps_host[k] : 0.0f;
-        if (k < C && taps_host[k] == 0.0f) {
-            has_zero = true;
-        }
-    }
-    (void)group;
+ddn_dev_launch_fused_ex(const DdnFusedArgs* a, bool has_zero, int group, hipStream_t st) {
+    DdnTapsK tp = {}; // (the kernels take their taps from a->taps_dev; the structure only selects the instance)
     if (a->squelch_on) {
         // squelch builds keep the first 256 LPF outputs of each block in LDS for the block-power sum: use the
         // 8-channel workgroup so everything still fits in 160 KB
@@ -824,9 +838,8 @@ ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, h
         }
         return launch_fused_c<8, DDN_IN_CF32>(*a, tp, has_zero, st);
     }
-    // A workgroup walks its channels' whole call, so the grid is n_channels / G workgroups: below ~2048 channels the
-    // 16-channel shape leaves CUs idle and the 8-channel one (twice the workgroups, same work per thread) wins.
-    if (a->n_channels <= 2048) {
+    const bool small = group == 8 || (group != 16 && a->n_channels <= 2048);
+    if (small) {
         if (a->in_fmt == DDN_IN_CU8) {
             return launch_fused_c<8, DDN_IN_CU8>(*a, tp, has_zero, st);
         }
@@ -836,6 +849,15 @@ ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, h
         return launch_fused_c<DDN_GROUP, DDN_IN_CU8>(*a, tp, has_zero, st);
     }
     return launch_fused_c<DDN_GROUP, DDN_IN_CF32>(*a, tp, has_zero, st);
+}
+
+extern "C" hipError_t
+ddn_dev_launch_fused(const DdnFusedArgs* a, const float* taps_host, int group, hipStream_t st) {
+    bool has_zero = false;
+    for (int k = 0; k < a->center && k < DDN_MAX_CENTER; k++) {
+        has_zero = has_zero || taps_host[k] == 0.0f;
+    }
+    return ddn_dev_launch_fused_ex(a, has_zero, group, st);
 }
 
 extern "C" hipError_t

@@ -27,6 +27,12 @@ void ddn_set_error(const char* fmt, ...);
 int ddn_p25_rx_mark_loop_start(ddn_p25_rx* b, void* hip_event);
 /* the next ddn_p25_rx_run() makes its stream wait for this HIP event between its matched filter and its loop kernel (one shot) */
 int ddn_p25_rx_gate_loop(ddn_p25_rx* b, void* hip_event);
+/* the mixed chain's shared front end: a part's stage 0 without its own front-end launch, and where that launch has to write */
+struct ddn_p25_chain;
+struct ddn_fsk4_chain;
+int ddn_p25_chain_stage0_prepare(struct ddn_p25_chain* c, void* hip_stream, float** disc_out);
+float* ddn_fsk4_chain_disc_buffer(struct ddn_fsk4_chain* c);
+void* ddn_fsk4_chain_reads_done_event(struct ddn_fsk4_chain* c);
 /* the two kernels of ddn_mbe_synth_batch as separate calls (ddn_api_mbe.cpp) */
 struct ddn_mbe_batch;
 int ddn_mbe_params_only(struct ddn_mbe_batch* b, const uint8_t* d_bits, const int32_t* d_result_in, size_t n_frames, int32_t* d_result_out,

@@ -111,6 +111,18 @@ int ddn_batch_set_iq_conditioning(ddn_batch* b, int dc_block_enable, int dc_shif
 int ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void* hip_stream);
 /* same, host buffers (H2D, run, D2H, synchronous) */
 int ddn_front_end_run_host(ddn_batch* b, const void* h_iq, size_t n, float* h_disc);
+/* channels per workgroup of the fused kernel: 0 = by batch size (8 up to 2048 channels - twice the workgroups for a launch that has
+ * the device to itself - else 16), 8, 16.  A workgroup's time does not depend on how many of its slots are filled, so a host that runs
+ * several front ends side by side asks for 16.  Results do not depend on it. */
+int ddn_batch_set_channels_per_workgroup(ddn_batch* b, int channels);
+/* Segments (round 6): the batch's channel index as up to three runs with a channel low-pass profile each (DDN_LPF_*; segment 0 keeps
+ * the batch's own; all must design the same tap count, DDN_ERANGE otherwise) - the protocol groups of a mixed batch, each a separate
+ * dsd-neo demodulator configuration (src/dsp/demod_pipeline.cpp:443-524), behind ONE launch of ceil(n_channels / 16) workgroups
+ * whatever the groups' sizes (a workgroup may hold channels of two groups).  seg_channels add up to n_channels.  Not with the
+ * half-band cascade, IQ conditioning or squelch. */
+int ddn_batch_set_segments(ddn_batch* b, int n_seg, const int32_t* seg_channels, const int32_t* lpf_profiles);
+/* ddn_front_end_run over the segments: d_iq[k] / d_disc[k] = segment k's [seg_channels[k]][n] arrays; n >= 72 */
+int ddn_front_end_run_segments(ddn_batch* b, const void* const* d_iq, size_t n, float* const* d_disc, void* hip_stream);
 
 /* per-channel modem state after the last run: {prev_i, prev_q, have_prev, dc_est, peak_est} (synchronous) */
 int ddn_batch_get_fsk_state(ddn_batch* b, int channel, float out5[5]);

@@ -359,3 +359,53 @@ def test_single_stream_adapter_full_demod_and_gardner(built):
             check(blk.reshape(-1)[:2 * len(want)], want.reshape(-1), exact=True)
         pos += ln
     l.ddn_demod_state_release(C.byref(s3))
+
+
+@pytest.mark.parametrize("counts", [(21, 19, 10), (5, 30), (16, 16, 16), (1, 1, 45)])
+def test_segments_one_launch_equals_a_batch_per_group(built, counts):
+    """ddn_batch_set_segments / ddn_front_end_run_segments: the protocol groups of a mixed batch (a channel low-pass profile, an input
+    array and an output array each) behind one launch of ceil(total / 16) workgroups - workgroups that hold channels of two groups
+    included - give every group what a batch object of its own gives it, bit for bit, over two calls (carried look-back and modem
+    state in the shared batch) and with sixteen or eight channels per workgroup"""
+    import ctypes as C
+    l = ddn.lib()
+    profiles = [ddn.LPF_P25_C4FM, ddn.LPF_12K5, ddn.LPF_6K25][:len(counts)]
+    n1, n2, blk = 10000, 6000, 4096
+    iqs = [orc.synth_c4fm_cu8(40 + k, B, n1 + n2) for k, B in enumerate(counts)]
+    want = []
+    for iq, B, prof in zip(iqs, counts, profiles):
+        b = ddn.Batch(B, lpf_profile=prof, block_len=blk)
+        want.append(np.concatenate([b.run_host(iq[:, :n1], n1), b.run_host(iq[:, n1:], n2)], axis=1))
+        b.close()
+
+    def dev(a):
+        p = C.c_void_p()
+        assert l.ddn_device_alloc(a.nbytes, C.byref(p)) == 0 and l.ddn_device_upload(p, a.ctypes.data, a.nbytes) == 0
+        return p
+
+    for group in (0, 8):
+        b = ddn.Batch(sum(counts), lpf_profile=profiles[0], block_len=blk)
+        cnt, prof = np.array(counts, np.int32), np.array(profiles, np.int32)
+        assert l.ddn_batch_set_segments(b.h, len(counts), cnt.ctypes.data, prof.ctypes.data) == 0
+        assert l.ddn_batch_set_channels_per_workgroup(b.h, group) == 0
+        got = [[] for _ in counts]
+        for lo, n in ((0, n1), (n1, n2)):
+            ins = [dev(np.ascontiguousarray(iq[:, lo:lo + n])) for iq in iqs]
+            outs = [dev(np.zeros((B, n), np.float32)) for B in counts]
+            ia, oa = (C.c_void_p * len(counts))(*ins), (C.c_void_p * len(counts))(*outs)
+            assert l.ddn_front_end_run_segments(b.h, ia, n, oa, None) == 0
+            for k, B in enumerate(counts):
+                h = np.zeros((B, n), np.float32)
+                assert l.ddn_device_download(h.ctypes.data, outs[k], h.nbytes) == 0
+                got[k].append(h)
+            for p in ins + outs:
+                l.ddn_device_free(p)
+        for k in range(len(counts)):
+            a = np.concatenate(got[k], axis=1)
+            assert np.array_equal(a.view(np.uint32), want[k].view(np.uint32)), (group, k)
+        b.close()
+    # the segments must add up, keep the batch's profile first, and design one tap count
+    b = ddn.Batch(10, block_len=blk)
+    bad = np.array([4, 5], np.int32)
+    assert l.ddn_batch_set_segments(b.h, 2, bad.ctypes.data, np.array([ddn.LPF_P25_C4FM, ddn.LPF_12K5], np.int32).ctypes.data) == -1
+    b.close()
