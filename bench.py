@@ -269,6 +269,65 @@ def m17_ysf_chains(torch, ddn, np, n):
     return out
 
 
+def cqpsk_p2_chains(torch, ddn, np, n):
+    """What round 5 built, at batch scale (informational): the P25 Phase 1 chain with modulation = CQPSK (CQPSK demodulator -> symbol-rate
+    loop with the handlers inside -> the same decode) and the P25 Phase 2 chain (demodulator at 6000 symbols/s -> loop -> processP2 ->
+    AMBE synthesis of both logical channels), 1365 and 4096 channels x n cu8 samples of the reference's own captures, every channel a
+    different rotation, I/Q resident, one C call per step."""
+    from conftest import golden
+    dev = torch.device("cuda")
+    out = {"workload": "channels x %d cu8 samples of the reference's P25p1 CQPSK control-channel / voice captures and its Phase 2 capture "
+                       "(rotated per channel), one C call per step" % n}
+
+    def tile(cap, B):
+        iq = torch.from_numpy(np.ascontiguousarray(golden(cap)["iq"], np.uint8)).to(dev)
+        m = iq.shape[0]
+        reps = (n + 40 * B + m - 1) // m + 1
+        iq = iq.repeat(reps, 1)
+        off = (torch.arange(B, device=dev) * 37) % (iq.shape[0] - n)
+        return iq[off[:, None] + torch.arange(n, device=dev)[None, :]].contiguous()
+
+    def timed(run, reps=5):
+        run()
+        run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for B in (1365, 4096):
+        row = {}
+        x = torch.cat([tile("iq_p25p1_cqpsk_cc.npz", B - B // 2), tile("iq_p25p1_cqpsk_vc.npz", B // 2)])
+        ch = ddn.P25ChainC(B, n, block_len=8192, modulation=1)
+        ms = timed(lambda: ch.run(x.data_ptr()))
+        r = ch.results()
+        nid = ch.fetch(r.d_nid4, np.int32, (B * ch.F, 4))
+        row["p25p1_cqpsk"] = {"ms_per_step": round(ms, 3), "Msamples_per_s": round(B * n / ms / 1e3, 1),
+                              "nids_decoded_last_call": int((nid[:, 0] > 0).sum())}
+        ch.close()
+        del x
+        x2 = tile("iq_p25p2_cc.npz", B)
+        seed = (0xBEE00 << 24) | (0x001 << 12) | 0x293
+        try:
+            import p2capture
+            seed = (p2capture.WACN << 24) | (p2capture.SYSID << 12) | p2capture.NAC
+        except Exception:
+            pass
+        c2 = ddn.P25P2ChainC([seed] * B, n, vocoder=1)
+        ms2 = timed(lambda: c2.run(x2.data_ptr()))
+        r2 = c2.results()
+        ng = c2.fetch(r2.d_n_groups, np.int32, (B,))
+        row["p25p2"] = {"ms_per_step": round(ms2, 3), "Msamples_per_s": round(B * n / ms2 / 1e3, 1), "sync_groups_last_call": int(ng.sum())}
+        c2.close()
+        del x2
+        out["%d_channels" % B] = row
+    return out
+
+
 def vocoder_c5(torch, ddn, np, steps):
     """BASELINE configs[4] / SURVEY 8d C5: 8192 voice frames as 64 talk paths x 128 frames, uniform random valid parameter
     fields (fixed seed), through frame FEC (the encoded 144 / 72-bit frames) -> parameter decode -> synthesis, IMBE 7200x4400
@@ -341,10 +400,45 @@ def front_end_stage(torch, ddn, chain, d_iq, B, n, steps):
     ms = sorted(ms)[:max(1, len(ms) // 2)]
     avg = sum(ms) / len(ms)
     alg = 6.0 * B * n
-    return {"workload": "configs[1]: widen + 135-tap channel LPF + FSK discriminator, cu8 in -> f32 out",
-            "kernel": "k_front_end_fused", "launch_ms": round(avg, 4), "Msamples_per_s": round(B * n / (avg * 1e-3) / 1e6, 1),
-            "roofline": {"bound": "hbm", "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": 6.0}}
+    out_d = {"workload": "configs[1]: widen + 135-tap channel LPF + FSK discriminator, cu8 in -> f32 out",
+             "kernel": "k_front_end_fused", "launch_ms": round(avg, 4), "Msamples_per_s": round(B * n / (avg * 1e-3) / 1e6, 1),
+             "roofline": {"bound": "hbm", "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": 6.0}}
+    # configs[1]'s third leg, Gardner symbol timing (the reference's bench shape, tests/dsp/bench_dsp.cpp:1101-1114: op25_gardner_cc on
+    # the complex baseband of the same B x n): the batched Gardner kernel on B channels of complex samples at 10 samples per symbol -
+    # complex f32 in (8 B per sample), one complex symbol per ten samples out
+    import ctypes as C
+    import orc
+    sps = 10
+    iq1 = orc.synth_qpsk_f32(9, 8, n // sps, sps)
+    nn = iq1.shape[1]
+    d_c = torch.from_numpy(np.tile(iq1, ((B + 7) // 8, 1, 1))[:B].copy()).to(d_iq.device)
+    h = C.c_void_p()
+    assert l.ddn_ted_batch_create(B, sps, 4800, 0.0, C.byref(h)) == 0
+    stride = nn // sps + 64
+    d_sym = torch.zeros((B, stride, 2), dtype=torch.float32, device=d_iq.device)
+    d_cnt = torch.zeros(B, dtype=torch.int32, device=d_iq.device)
+    for _ in range(2):
+        assert l.ddn_gardner_run(h, d_c.data_ptr(), nn, d_sym.data_ptr(), stride, d_cnt.data_ptr(), st) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(6):
+        assert l.ddn_gardner_run(h, d_c.data_ptr(), nn, d_sym.data_ptr(), stride, d_cnt.data_ptr(), st) == 0
+    e1.record()
+    torch.cuda.synchronize()
+    g_ms = e0.elapsed_time(e1) / 6
+    l.ddn_ted_batch_destroy(h)
+    g_alg = 8.8 * B * nn
+    out_d["gardner"] = {"workload": "Gardner + MMSE interpolator, %d channels x %d complex f32 samples at %d samples per symbol" % (B, nn, sps),
+                        "kernel": "k_gardner_ring", "launch_ms": round(g_ms, 4), "Msamples_per_s": round(B * nn / (g_ms * 1e-3) / 1e6, 1),
+                        "symbols_out_per_channel": int(d_cnt.float().mean().item()),
+                        "roofline": {"bound": "hbm", "achieved": round(g_alg / (g_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(g_alg / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": 8.8}}
+    out_d["configs1_all_three_legs"] = {"ms": round(avg + g_ms, 4), "Msamples_per_s": round(B * n / ((avg + g_ms) * 1e-3) / 1e6, 1),
+                                        "note": "front end and Gardner kernel one after the other on the same B x n (the fused front end "
+                                                "keeps no complex baseband in HBM for the C4FM path; the CQPSK chain, where the Gardner "
+                                                "loop runs in a dsd-neo decode, is timed in cqpsk_p2_chains)"}
+    return out_d
 
 
 def self_launch(args, argv):
@@ -660,6 +754,7 @@ def main():
             line["vocoder_c5"] = vocoder_c5(torch, ddn, np, 10)
             line["batch_sweep"] = batch_sweep(torch, ddn, np, d_iq, n, B, dt / args.steps * 1e3, dom_ms)
             line["m17_ysf_chains"] = m17_ysf_chains(torch, ddn, np, n)
+            line["cqpsk_p2_chains"] = cqpsk_p2_chains(torch, ddn, np, n)
         if mixed is not None:
             line["configs3_mixed"] = mixed
         if cpu is not None:

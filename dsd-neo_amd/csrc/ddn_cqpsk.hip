@@ -806,6 +806,9 @@ ddn_dev_cqpsk_agc_fll(const void* in, long n, size_t stride, int n_channels, int
     } else if (nt == 21) {
         hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<21>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
                            d_fll_taps, state, delay_store, (f2*)out); // sps 10
+    } else if (nt == 17) { // (eight samples per symbol: the Phase 2 chain at 48 kHz)
+        hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<17>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
+                           d_fll_taps, state, delay_store, (f2*)out);
     } else if (nt == 9) {
         hipLaunchKernelGGL(k_cqpsk_agc_fll_reg<9>, rgrid, blk, 0, st, (const f2*)in, n, stride, n_channels, alpha, beta,
                            d_fll_taps, state, delay_store, (f2*)out); // sps 4 (P25p2 6000 sym/s at 24 ksps)

@@ -30,7 +30,8 @@ constexpr int MSZ = 1024, SSZ = 128;
 enum { PH_IDLE = 0, PH_NID = 1, PH_BODY = 2, PH_TSBK = 3, PH_MPDU = 4 };
 
 struct Lds {
-    float minbuf[MSZ], maxbuf[MSZ];
+    // (round 6) the 1024-deep extrema rings stay where the carried state keeps them, in HBM (one slot read - a slot ahead, so off the
+    // recurrence - and one written per in-frame symbol): 8 KB less LDS per channel, sixteen channels per CU instead of nine
     float sbuf[SSZ];
     float lbuf[24], shist[24];
     Scratch sc;
@@ -135,7 +136,15 @@ cq_digitize(float sym, float center, int map_idx, int negative, int snr_scale, i
     rel8 = clamp255(a1 < a0 ? a1 : a0);
 }
 
-__global__ __launch_bounds__(64) void
+// (round 6) three wavefronts per SIMD: left to itself the kernel compiled to 256 + registers (the handlers' decoders, inlined) - ONE
+// wavefront per SIMD, four channels per CU, 4096 channels in four rounds (29 ms per 4096 x 4800 symbols).  The per-symbol path needs a
+// fraction of that.  Capped at 168 registers twelve channels are resident per CU (the chain objects at 4096 channels: P25 CQPSK 72.6
+// -> 55.8 ms, Phase 2 - with the 17-tap band-edge instance - 138 -> 57 ms); at 128 (sixteen per CU) the spills reach the per-symbol
+// path and it is slower again (84.8 / 94.3 ms); two per SIMD measures the same as three.
+#ifndef DDN_CQ_WAVES
+#define DDN_CQ_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DDN_CQ_WAVES, DDN_CQ_WAVES))) void
 k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in, size_t sym_stride, int n_fixed, int n_channels,
         DdnCqConfig cfg, DdnCqState* __restrict__ states, uint8_t* __restrict__ rec, uint8_t* __restrict__ flags,
         int32_t* __restrict__ counts_out, size_t max_sym, int32_t* __restrict__ events, int32_t* __restrict__ n_events,
@@ -147,10 +156,8 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
     }
     DdnCqState* gs = states + ch;
     // ---- carried state in -----------------------------------------------------------------------------------------------------
-    for (int i = lane; i < MSZ; i += 64) {
-        L.minbuf[i] = gs->minbuf[i];
-        L.maxbuf[i] = gs->maxbuf[i];
-    }
+    float* const gmin = gs->minbuf;
+    float* const gmax = gs->maxbuf;
     for (int i = lane; i < SSZ; i += 64) {
         L.sbuf[i] = gs->sbuf[i];
     }
@@ -179,6 +186,8 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
         h_k = gs->h_k, h_nac = gs->h_nac, h_p2cc = gs->h_p2cc;
     int nev = 0;
     wave_sync();
+    // the ring slot the next push replaces, fetched ahead (refreshed by whatever rewrites the ring)
+    float pre_lo = gmin[(midx >= 0 && midx < MSZ) ? midx : 0], pre_hi = gmax[(midx >= 0 && midx < MSZ) ? midx : 0];
 
     const int sync_len = cfg.sync_len, t_max = cfg.t_max;
     const uint64_t hmask = sync_len == 24 ? 0xFFFFFFFFFFFFull : 0xFFFFFFFFFFull;
@@ -192,8 +201,8 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
         if (!sums_valid) { // (after a raw fit seeded the window: every slot holds the same pair)
             double a = 0.0, b = 0.0;
             for (int i = 0; i < MSZ; i++) {
-                a += (double)L.minbuf[i];
-                b += (double)L.maxbuf[i];
+                a += (double)gmin[i];
+                b += (double)gmax[i];
             }
             min_sum = a;
             max_sum = b;
@@ -201,15 +210,18 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
             if (midx < 0 || midx >= MSZ) {
                 midx = 0;
             }
+            pre_lo = gmin[midx];
+            pre_hi = gmax[midx];
         }
-        min_sum += (double)lo - (double)L.minbuf[midx];
-        max_sum += (double)hi - (double)L.maxbuf[midx];
-        wave_sync(); // every lane has read the old slot
+        min_sum += (double)lo - (double)pre_lo;
+        max_sum += (double)hi - (double)pre_hi;
         if (lane == 0) {
-            L.minbuf[midx] = lo;
-            L.maxbuf[midx] = hi;
+            gmin[midx] = lo;
+            gmax[midx] = hi;
         }
         midx = (midx + 1 >= MSZ) ? 0 : midx + 1;
+        pre_lo = gmin[midx]; // (a slot this wave wrote 1023 pushes ago, or never: no store of this wave is in flight to it)
+        pre_hi = gmax[midx];
         s_min = (float)(min_sum / (double)MSZ);
         s_max = (float)(max_sum / (double)MSZ);
     };
@@ -551,9 +563,13 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
                                 s_max = fc + half;
                                 wave_sync();
                                 for (int i = lane; i < MSZ; i += 64) {
-                                    L.minbuf[i] = s_min;
-                                    L.maxbuf[i] = s_max;
+                                    gmin[i] = s_min;
+                                    gmax[i] = s_max;
                                 }
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (read back by every lane at the next push)
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                pre_lo = s_min;
+                                pre_hi = s_max;
                                 for (int i = lane; i < SSZ; i += 64) {
                                     L.sbuf[i] = (i & 1) ? s_max : s_min;
                                 }
@@ -607,10 +623,6 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
     }
     // ---- carried state out ------------------------------------------------------------------------------------------------------
     wave_sync();
-    for (int i = lane; i < MSZ; i += 64) {
-        gs->minbuf[i] = L.minbuf[i];
-        gs->maxbuf[i] = L.maxbuf[i];
-    }
     for (int i = lane; i < SSZ; i += 64) {
         gs->sbuf[i] = L.sbuf[i];
     }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Reads a rocprofv3 --kernel-trace CSV and prints, for the last steady step, the kernels in start order with start / end
-relative to the step, so that what runs beside what (several HIP streams) can be seen.  usage: trace_overlap.py kernel_trace.csv [first_kernel_regex]"""
+relative to the step, so that what runs beside what (several HIP streams) can be seen.
+usage: trace_overlap.py kernel_trace.csv [first_kernel_regex] [step index, default -3 = the third last]"""
 import csv
 import re
 import sys
@@ -19,7 +20,8 @@ for i in starts:
 if len(groups) < 3:
     print("too few steps", len(groups))
     sys.exit(0)
-a, b = groups[-3][0], groups[-2][0]
+idx = int(sys.argv[3]) if len(sys.argv) > 3 else -3
+a, b = groups[idx][0], groups[idx + 1][0]
 t0 = ev[a][0]
 print("step %.3f ms" % ((ev[b][0] - t0) / 1e6))
 for s, e, nme, q in ev[a:b]:
