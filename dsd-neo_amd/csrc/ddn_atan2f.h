@@ -120,7 +120,10 @@ ddn_atan2f(float y, float x) {
 // single-rounded expressions, the same operations as above), and ONE correctly rounded division serves all of them; |x| < 7/16 divides
 // by 1 (exact).  The result selects follow the same way.  Everything rare - NaN, infinities, zeros, x == 1, exponent gaps beyond 2^60,
 // |q| >= 2^25 or < 2^-29 - leaves through one branch to the function above, so the common path carries no other branch.
-__device__ __forceinline__ float
+#ifndef DDN_ATAN2_FAST_INLINE
+#define DDN_ATAN2_FAST_INLINE __forceinline__
+#endif
+__device__ DDN_ATAN2_FAST_INLINE float
 ddn_atan2f_fast(float y, float x) {
     const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
     const int32_t hx = __float_as_int(x), hy = __float_as_int(y);

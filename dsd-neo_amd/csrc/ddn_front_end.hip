@@ -158,7 +158,7 @@ ddn_tile_next(TileWalk& w, const DdnFusedArgs& a) {
 //            wave S2 (lane = channel): peak AGC recurrence, tile it-2 -> Pb[(it-2) % 2] (peak to divide by)
 // A single wave issues roughly one VALU instruction per 5 cycles whatever the lane count, so the two
 // recurrences are split over two waves to keep each under the filter threads' time per tile.
-template <int CENTER_T, int G, bool SKIPZ, int FMT>
+template <int CENTER_T, int G, bool SKIPZ, int FMT, bool SEGS = false>
 __global__ __launch_bounds__(G * 32 + 128, 3) void
 k_front_end_fused(DdnFusedArgs a) {
     constexpr int TT = DDN_TT;
@@ -197,7 +197,7 @@ k_front_end_fused(DdnFusedArgs a) {
     const int ch = ch0 + (g < nch ? g : 0); // clamp: surplus slots recompute channel ch0, never store
     const bool ch_ok = g < nch;
     // segment of this thread's channel: its input / output arrays and its row inside them (a plain batch: segment 0 = the batch)
-    const bool segs = a.n_seg > 1;
+    const bool segs = SEGS && a.n_seg > 1; // (an instance of its own: the plain batch's kernel carries none of the look-ups)
     const int seg = segs ? ((ch >= a.seg_first1 ? 1 : 0) + ((a.n_seg > 2 && ch >= a.seg_first2) ? 1 : 0)) : 0;
     const int chl = ch - (seg == 0 ? 0 : (seg == 1 ? a.seg_first1 : a.seg_first2));
     const void* const in_s = segs ? (seg == 0 ? a.seg_in0 : (seg == 1 ? a.seg_in1 : a.seg_in2)) : a.in;
@@ -802,6 +802,17 @@ launch_fused_t(const DdnFusedArgs& a, const DdnTapsK& tp, bool has_zero, hipStre
         if (e != hipSuccess) {
             return e;
         }
+    }
+    if (a.n_seg > 1) {
+        if (dyn) {
+            return hipErrorInvalidValue; // (the squelch route has no segmented form)
+        }
+        if (has_zero) {
+            hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, true, FMT, true>), grid, block, 0, st, a);
+        } else {
+            hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, false, FMT, true>), grid, block, 0, st, a);
+        }
+        return hipGetLastError();
     }
     if (has_zero) {
         hipLaunchKernelGGL((k_front_end_fused<CENTER_T, G, true, FMT>), grid, block, dyn, st, a);
