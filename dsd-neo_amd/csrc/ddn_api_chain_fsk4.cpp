@@ -797,7 +797,7 @@ ddn_mixed_chain_create(const ddn_mixed_chain_config* cfg, ddn_mixed_chain** out)
         }
         for (ddn_fsk4_chain* c : {m->dmr, m->nxdn}) {
             if (rc == DDN_OK && c && !c->d_disc2) {
-                if (hipMalloc((void**)&c->d_disc2, sizeof(float) * (size_t)c->B * (size_t)c->n) != hipSuccess) {
+                if (!dalloc(&c->d_disc2, (size_t)c->B * (size_t)c->n)) { // (zero-filled and padded like every other buffer)
                     rc = DDN_ENOMEM;
                 }
             }
@@ -901,6 +901,10 @@ ddn_mixed_chain_run(ddn_mixed_chain* m, const void* d_iq_p25, const void* d_iq_d
         const char* e = DDN_EXP_ENV("DDN_MIX_PHASED");
         return e && e[0] == '1';
     }();
+    // (the discriminator buffer a group's call uses is picked by that chain's own step parity, the event that guards it by m->calls'.
+    // A part-level flush through ddn_mixed_chain_part() advances the part's step and shifts the two against each other; it also
+    // synchronises everything first, so the call after it has no reader to wait for, and from the call after that the event waited
+    // for is that of a LATER loop than the buffer's last reader - an over-wait, never a race)
     const int par = (int)(m->calls & 1);
     if (m->overlap) {
         // (round 5) A group is a chain front end -> matched filter -> loop, and with one discriminator buffer the step could not be
