@@ -409,3 +409,31 @@ def test_segments_one_launch_equals_a_batch_per_group(built, counts):
     bad = np.array([4, 5], np.int32)
     assert l.ddn_batch_set_segments(b.h, 2, bad.ctypes.data, np.array([ddn.LPF_P25_C4FM, ddn.LPF_12K5], np.int32).ctypes.data) == -1
     b.close()
+
+
+def test_large_angle_branch_on_noise_of_every_kind(built):
+    """the discriminator's atan2f as straight-line code (ddn_atan2f.h: one division for atanf's four argument reductions, every rare
+    case through one branch to the branchy original): ~5 million evaluations against the host libm the oracle calls - noise at full
+    scale, noise of a few counts around mid-scale (zeros in I or Q: the iy == 0 / ix == 0 cases), a constant input, and cf32 samples
+    whose magnitudes span sixty binades between neighbours (the exponent-gap and |q| >= 2^25 / < 2^-29 cases)"""
+    rng = np.random.default_rng(77)
+    B, n, blk = 48, 50000, 8192
+    iq = rng.integers(0, 256, size=(B, n, 2), dtype=np.uint8)
+    iq[16:32] = rng.integers(125, 131, size=(16, n, 2), dtype=np.uint8)
+    iq[32:40] = rng.integers(127, 129, size=(8, n, 2), dtype=np.uint8)
+    iq[40:44, :, 0] = 128
+    iq[44:48] = 127
+    got = ddn.Batch(B, block_len=blk).run_host(iq, n)
+    want = orc.oracle_batch_cu8(iq, blk)
+    check(got, want)
+    assert np.count_nonzero(np.abs(want[:16]) > 20000) > 1000        # (large angles were there)
+    # cf32: every sample's magnitude drawn from 2^-40 .. 2^40, and runs of exact zeros
+    Bf, nf = 6, 30000
+    mag = np.exp2(rng.integers(-40, 41, size=(Bf, nf, 1))).astype(np.float32)
+    x = (rng.standard_normal((Bf, nf, 2)).astype(np.float32) * mag).astype(np.float32)
+    x[2, 1000:1400] = 0.0
+    x[3, ::7, 1] = 0.0
+    x[4, ::5, 0] = 0.0
+    gotf = ddn.Batch(Bf, block_len=4096, input_format=ddn.IN_CF32).run_host(x, nf)
+    wantf = np.stack([orc.OracleFrontEnd().run_f32(x[c], 4096) for c in range(Bf)])
+    check(gotf, wantf)
