@@ -26,7 +26,10 @@ Rank 0 prints ONE JSON line.  `roofline` describes the chain's dominant kernel (
 launch stream inside the C-ABI) against the chain's algorithmic bytes (2 B cu8 in + 10 B per symbol record
 out = 3.0 B/sample, + 640 B per synthesized voice frame).  `cpu_baseline` is the same chain on the host, stage by stage with
 its own `kind` (compiled reference where oracle/_ref holds the stage, the C restatement elsewhere), 1 core and all cores.
-`front_end_stage` keeps BASELINE configs[1] (FIR + discriminator only) as a named sub-object with its own roofline."""
+`front_end_stage` keeps BASELINE configs[1] as a named sub-object: the fused FIR + discriminator kernel with its own roofline, and (round
+6) its third leg - the batched Gardner kernel on the same B x n - as `gardner` / `configs1_all_three_legs`.  Further informational
+sub-objects: `configs3_mixed` (the configs[3] mix through ddn_mixed_chain), `cqpsk_p2_chains` (the P25 CQPSK chain and the Phase 2 chain at
+1365 and 4096 channels), `m17_ysf_chains`, `vocoder_c5`, `batch_sweep`, `pcie_inclusive`."""
 import argparse
 import ctypes as C
 import json
