@@ -152,3 +152,31 @@ def test_every_mbelib_symbol_the_reference_calls_is_exported(built):
     assert sh[:8].tolist() == [0, 7, -7, 6, -3, 32760, -32760, 32760] and (sh[8:] == 1).all()
     l.mbe_versionString.restype = C.c_char_p
     assert b"mbelib-neo 2.0" in l.mbe_versionString()
+
+
+def test_node_configuration_is_checked_before_any_device_is_touched(built):
+    """ddn_node_create (include/ddn_node.h): a configuration that names no chain kind, a kind without its settings, or no channels is
+    DDN_EINVAL with a message - on a box without a GPU too; a good one without a device is DDN_ENODEV (never a CPU path)"""
+    import ctypes as C
+    import torch
+    l = ddn.lib()
+    h = C.c_void_p()
+
+    def create(**kw):
+        base = dict(n_channels=8, samples_per_call=4096, block_len=4096, input_format=0, vocoder=0, modulation=0, n_devices=1, kind=0,
+                    n_dmr=0, n_nxdn48=0, overlap=0, fsk4=None, p25p2=None, p25p2_seed44=None)
+        base.update(kw)
+        cfg = ddn.NodeConfig(*[base[k] for k, _ in ddn.NodeConfig._fields_])
+        return l.ddn_node_create(C.byref(cfg), C.byref(h))
+
+    assert create(kind=7) == -1 and b"kind" in l.ddn_last_error()
+    assert create(kind=ddn.NODE_FSK4) == -1            # no ddn_fsk4_chain_config
+    assert create(kind=ddn.NODE_P25P2) == -1           # no ddn_p25p2_chain_config
+    assert create(n_channels=0) == -1
+    assert create(kind=ddn.NODE_MIXED, n_channels=0, n_dmr=-1) == -1
+    assert create(samples_per_call=0) == -1
+    assert l.ddn_node_kind_of(None) == -1 and l.ddn_node_chain_object(None, 0) is None
+    assert l.ddn_node_on_part(None, 0, None, None) == -1
+    if not torch.cuda.is_available():
+        assert create() == -2 and l.ddn_last_error()
+        assert create(kind=ddn.NODE_MIXED, n_dmr=4, n_nxdn48=4) == -2
