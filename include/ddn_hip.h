@@ -233,7 +233,7 @@ int ddn_p25_rx_run_host(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* rec
 int ddn_p25_rx_run_host_ev(ddn_p25_rx* b, const float* disc, size_t n, uint8_t* records10, uint8_t* flags, int32_t* counts,
                            size_t max_symbols, int32_t* events, int32_t* n_events, size_t max_events, int32_t* event_data);
 int ddn_p25_rx_get_thresholds(ddn_p25_rx* b, int channel, float out7[7]);
-/* timing experiments (environment DDN_RX_DBG bit 65536): handler requests of a channel so far, cycles its lane waited for them */
+/* timing experiments (ddn_p25_rx_set_debug_flags bit 65536): handler requests of a channel so far, cycles its lane waited for them */
 int ddn_p25_rx_debug_counters(ddn_p25_rx* b, int channel, long long out2[2]);
 
 /* ---- Gardner symbol-timing recovery (CQPSK branch), batched ----------------------------------------------
