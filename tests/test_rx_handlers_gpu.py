@@ -143,6 +143,38 @@ def test_hunting_pass_of_all_rows_at_once_equals_one_owner_at_a_time(built, monk
         _check(outs[0][0], outs[0][1], outs[0][2], outs[0][3], outs[0][4], c, _oracle(x[c], 1), outs[0][5])
 
 
+@pytest.mark.parametrize("cpw", [4, 8])
+def test_unfiltered_row_left_in_hbm_for_channels_in_sync(built, cpw):
+    """The staging wave leaves a channel's unfiltered samples in HBM while its matched filter is on and warm; the recurrence lane
+    loads the tiles it turns out to need when the filter is gated off (no carrier) in the middle of a tile, and the staging wave
+    takes them up again until the next sync's cold start is over (ddn_rx.hip, skip_raw).  Carriers that come and go at offsets
+    spread over the 128-sample tile: same records, flags and decisions as with every tile staged whole
+    (ddn_p25_rx_set_debug_flags bit 16384), and as the oracle's."""
+    B, n = 8, 130000
+    x = np.zeros((B, n), np.float32)
+    for c in range(B):
+        a0, a1 = 37 * c, 20000 + 211 * c              # carrier, silence (no carrier after 1800 symbols without a sync) ...
+        b0, b1 = 61000 + 173 * c, 84000 + 59 * c      # ... carrier again: cold start of the filter; and lost again
+        s = _traffic(400 + c, a1 - a0, [90.0, 4000.0][c % 2])
+        x[c, a0:a0 + len(s)] = s
+        s = _traffic(420 + c, b1 - b0, [90.0, 4000.0][c % 2])
+        x[c, b0:b0 + len(s)] = s
+    x[3, 30000:50000] = np.random.default_rng(3).normal(0, 900, 20000).astype(np.float32)   # noise instead of silence
+    outs = []
+    for dbg in (0, 16384):
+        rx = ddn.P25Rx(B, use_matched_filter=1, channels_per_wave=cpw, handlers=True, max_events=4096, debug_flags=dbg)
+        rec, fl, cnt = rx.run(x)
+        outs.append((rec.copy(), fl.copy(), cnt.copy(), rx.events.copy(), rx.n_events.copy(), rx.event_data.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    for c in (0, 3, 5, 6):
+        _check(outs[0][0], outs[0][1], outs[0][2], outs[0][3], outs[0][4], c, _oracle(x[c], 1), outs[0][5])
+    for c in range(B):                                   # both carriers were received: decoded NIDs before and after the gap
+        ev = outs[0][3][c, :outs[0][4][c]]
+        at = ev[(ev[:, 1] == 1) & (ev[:, 2] > 0), 0]
+        assert (at < 2200).sum() >= 1 and (at > 6000).sum() >= 1, (c, at[:4], at[-4:])
+
+
 @pytest.mark.parametrize("fil", [0, 1])
 def test_call_splits(built, fil):
     """decisions, history ring and handler words carried across calls (a block straddling a call boundary); fil = 1: with the filter
