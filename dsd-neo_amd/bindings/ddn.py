@@ -793,7 +793,7 @@ class P25ChainC:
         self.F = lib().ddn_p25_chain_frame_slots(self.h)
         self.Fv = lib().ddn_p25_chain_max_ldu(self.h)
         self.E = lib().ddn_p25_chain_max_events(self.h)
-        self.T = carry_symbols or 896
+        self.T = carry_symbols or 960
 
     def close(self):
         if self.h:

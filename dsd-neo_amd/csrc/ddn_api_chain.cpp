@@ -286,16 +286,16 @@ ddn_p25_chain_create(const ddn_p25_chain_config* cfg, ddn_p25_chain** out) {
     c->cfg = *cfg;
     c->B = cfg->n_channels;
     c->n = cfg->samples_per_call;
-    c->T = cfg->carry_symbols > 0 ? cfg->carry_symbols : 896;
+    c->T = cfg->carry_symbols > 0 ? cfg->carry_symbols : 960;
     c->F = cfg->max_frames > 0 ? cfg->max_frames : cfg->samples_per_call / 1800 + 6;
     c->Fv = cfg->max_ldu > 0 ? cfg->max_ldu : cfg->samples_per_call / 8640 + 3;
     c->E = cfg->max_events > 0 ? cfg->max_events : 4 * c->F;
     c->EL = c->E + 64; // + the decisions inside a carried tail
     c->PF = 2;         // data units per channel and call (a second's worth of calls rarely holds one)
     // data blocks per unit: a sync decoded in this call is only guaranteed T symbols behind it, and data block b ends
-    // (56 + 98 b + 97) dibits + one status symbol per 35 - 23 symbols behind its sync: 839 for b = 7, 940 for b = 8.  With the default
-    // T = 896 the eighth block of a unit whose sync falls late in the scan range would lie beyond the call's records, so the
-    // default reads seven blocks per unit (a longer unit is flagged 8, as before); a carry of 941+ symbols reads eight.
+    // (56 + 98 b + 97) dibits + one status symbol per 35 - 23 symbols behind its sync: 839 for b = 7, 940 for b = 8.  The default
+    // T = 960 (round 6; it was 896) guarantees the eighth block of a unit whose sync falls late in the scan range, so the default
+    // reads eight blocks per unit (a longer unit is flagged 8); a caller's carry below 941 symbols reads seven.
     c->PB = c->T >= 941 ? 8 : 7;
     int rc = DDN_OK;
     do {

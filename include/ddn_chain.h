@@ -39,7 +39,7 @@ typedef struct ddn_p25_chain_config {
                              samples_per_call / 720 + 6) */
     int max_ldu;          /* voice LDUs per channel and call; 0 = samples_per_call / 8640 + 3 */
     int max_events;       /* handler decisions per channel and call; 0 = 4 * max_frames */
-    int carry_symbols;    /* records carried into the next call; 0 = 896 (an LDU is 864 symbols) */
+    int carry_symbols;    /* records carried into the next call; 0 = 960 (an LDU is 864 symbols, a data unit's eighth block ends 940 behind its sync) */
     /* appended in round 5 (a config zero-filled beyond carry_symbols is the C4FM chain as before): */
     int modulation;       /* DDN_P25_MOD_C4FM 0: front end -> FSK discriminator -> matched filter + sample-rate loop (ddn_p25_rx);
                              DDN_P25_MOD_CQPSK 1 (LSM / simulcast sites): CQPSK demodulator (ddn_cqpsk_run: channel LPF, RMS AGC, FLL,
