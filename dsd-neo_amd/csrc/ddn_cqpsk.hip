@@ -461,6 +461,14 @@ k_cqpsk_agc_fll(const f2* __restrict__ in, long n, size_t stride, int n_channels
 // quad-permutes (VALU, no LDS), and a tile holds a whole number of NT-sample chunks (TS = 3 NT or 2 NT) so the circular
 // alignment survives tile boundaries; only the last tile of a call can end mid-chunk, and the carried state stores the
 // delay line oldest-first so the next call starts aligned again.
+// (round 6) The loop wave is bound by its own instruction stream - one wavefront issues a vector instruction every ~4.7 cycles and
+// there is one such wave per sixteen channels, whatever the batch - so the work per sample is cut where the arithmetic allows:
+//   * the RMS AGC does not depend on the frequency loop: the helper wave (which stages and drains the tiles) runs it, lane = channel,
+//     on the tile it has just staged, a tile ahead of the loop wave (the `avg` recurrence is its own; sqrt and division off the loop
+//     wave's stream);
+//   * delay line and taps as (re, im) / (a, b) pairs: one packed multiply per tap gives both products, two adds follow
+//     (acc += z.re a + z.im b with every product and sum rounded as before) - three instructions a tap instead of four and the moves
+//     that paired the registers.
 template <int NT>
 __global__ __launch_bounds__(128) void
 k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_channels, float alpha, float beta,
@@ -474,34 +482,51 @@ k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_chan
     const int cl = lane >> 2, q = lane & 3;
     const int ch = ch0 + cl;
     const bool live = !helper && ch < n_channels;
+    __shared__ float avg_end[CPW];
+    __shared__ float agc_t[CPW][TS + 1]; // 0.45 |x|^2, then the running mean square, of the tile being gain-controlled
     DdnCqpskState s = {};
-    float zr[NT], zi[NT]; // z[i] = rotated sample written at chunk position i; before a chunk z[i] = x_(i - NT)
+    f2 z[NT]; // z[i] = rotated sample written at chunk position i; before a chunk z[i] = x_(i - NT)
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        zr[k] = 0.0f;
-        zi[k] = 0.0f;
+        z[k].x = 0.0f;
+        z[k].y = 0.0f;
     }
     if (live) {
         s = state[ch];
 #pragma unroll
         for (int k = 0; k < NT; k++) { // stored oldest first
-            zr[k] = delay_store[((size_t)k * 2) * n_channels + ch];
-            zi[k] = delay_store[((size_t)k * 2 + 1) * n_channels + ch];
+            z[k].x = delay_store[((size_t)k * 2) * n_channels + ch];
+            z[k].y = delay_store[((size_t)k * 2 + 1) * n_channels + ch];
         }
     }
     const int ia = q, ib = q ^ 1;
     const float sb = (q == 0 || q == 2) ? -1.0f : 1.0f;
-    float ta[NT], tb[NT];
+    f2 tt[NT];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        ta[k] = fll[ia * DDN_FLL_MAX_TAPS + k];
-        tb[k] = sb * fll[ib * DDN_FLL_MAX_TAPS + k];
+        tt[k].x = fll[ia * DDN_FLL_MAX_TAPS + k];
+        tt[k].y = sb * fll[ib * DDN_FLL_MAX_TAPS + k];
     }
-    float avg = s.agc_avg;
-    if (avg <= 0.0f) {
-        avg = 1.0f;
+    // helper wave, lane = channel: the AGC's running mean square
+    const bool agc_lane = helper && lane < CPW && ch0 + lane < n_channels;
+    float avg = 1.0f;
+    if (agc_lane) {
+        avg = state[ch0 + lane].agc_avg;
+        if (avg <= 0.0f) {
+            avg = 1.0f;
+        }
     }
     float phase = s.fll_phase, freq = s.fll_freq;
+    // ps[k], k = 1 .. NT - 1: the NEXT sample's product sums of the taps that look back (z.re a + z.im b of tap k on the sample k
+    // back) - all of them known as soon as the current sample is rotated, so they are formed between the dependent adds of the current
+    // sample's chain instead of each in front of the add that needs it (a whole chunk at a time: see the sample loop)
+    float ps[NT];
+#pragma unroll
+    for (int k = 1; k < NT; k++) { // the call's first sample sits at chunk position 0: tap k looks at slot NT - k
+        const f2 p = z[NT - k] * tt[k];
+        ps[k] = p.x + p.y;
+    }
+    ps[0] = 0.0f;
     auto stage = [&](long t0, int buf) {
         const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
 #pragma unroll
@@ -524,6 +549,44 @@ k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_chan
             }
         }
     };
+    // RMS AGC of a staged tile, in place (the wave's own LDS writes of stage() are in the queue ahead of these reads).  Only the
+    // running mean square is serial in time - two dependent operations a sample, lane = channel; its input 0.45 |x|^2 before it and the
+    // gain 0.85 / sqrt(avg) after it are formed lane = sample (a serial sqrt + division per sample made this wave the slower one).
+    auto agc_tile = [&](long t0, int buf) {
+        const int tn = (int)((n - t0) < TS ? (n - t0) : TS);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < tn) {
+#pragma unroll
+            for (int r = 0; r < CPW; r++) {
+                const f2 x = tiles[buf][r][lane];
+                const float m2 = x.x * x.x + x.y * x.y;
+                agc_t[r][lane] = 0.45f * m2;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (agc_lane) {
+            float* row = &agc_t[lane][0];
+#pragma unroll 8
+            for (int i = 0; i < tn; i++) {
+                avg = 0.55f * avg + row[i];
+                row[i] = avg;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < tn) {
+#pragma unroll
+            for (int r = 0; r < CPW; r++) {
+                const float a = agc_t[r][lane];
+                if (ch0 + r < n_channels && a > 0.0f) {
+                    const float sc = 0.85f / sqrtf(a);
+                    f2 x = tiles[buf][r][lane];
+                    x.x = x.x * sc;
+                    x.y = x.y * sc;
+                    tiles[buf][r][lane] = x;
+                }
+            }
+        }
+    };
     auto bcast = [&](float v, int src) -> float { // value of lane `src` of this quad, via DPP quad_perm
         int iv = __float_as_int(v), r;
         switch (src) {
@@ -536,6 +599,7 @@ k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_chan
     };
     if (helper && n > 0) {
         stage(0, 0);
+        agc_tile(0, 0);
     }
     __syncthreads();
     long t0 = 0;
@@ -549,34 +613,67 @@ k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_chan
             }
             if (t0 + TS < n) {
                 stage(t0 + TS, (it + 1) % 3);
+                agc_tile(t0 + TS, (it + 1) % 3);
             }
         } else if (live) {
             f2* row = &tiles[buf][cl][0];
-            for (int c0 = 0; c0 < tn; c0 += NT) {
+            int c0 = 0;
+            for (; c0 + NT <= tn; c0 += NT) { // whole chunks: straight-line code, no test per sample
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const f2 x = row[c0 + j]; // (gain-controlled by the helper wave)
+                    float ns, nc;
+                    sincos_two_pi(phase, &ns, &nc);
+                    const float orr = x.x * nc - x.y * ns;
+                    const float oi = x.x * ns + x.y * nc;
+                    z[j].x = orr;
+                    z[j].y = oi;
+                    const f2 p0 = z[j] * tt[0];
+                    float acc = 0.0f;
+                    acc += p0.x + p0.y;
+#pragma unroll
+                    for (int k = 1; k < NT; k++) {
+                        acc += ps[k];
+                        const f2 pn = z[(j + 1 - k + NT) % NT] * tt[k]; // the next sample's tap k
+                        ps[k] = pn.x + pn.y;
+                        // (an empty statement that "touches" both: the product sum is formed before it, the chain's next add after
+                        // it - left to itself the compiler runs the 21 dependent adds back to back and forms the sums afterwards)
+                        asm volatile("" : "+v"(acc), "+v"(ps[k]));
+                    }
+                    const float lr = bcast(acc, 0), li = bcast(acc, 1), ur = bcast(acc, 2), ui = bcast(acc, 3);
+                    const float lm = lr * lr + li * li, um = ur * ur + ui * ui;
+                    const float err = clipf(um - lm, 1.0f);
+                    freq += beta * err;
+                    freq = clampr(freq, -1.0f, 1.0f);
+                    phase += freq + alpha * err;
+                    phase = phase > kTwoPi ? phase - kTwoPi : phase;
+                    phase = phase < -kTwoPi ? phase + kTwoPi : phase;
+                    if (q == 0) {
+                        const f2 y = {orr, oi};
+                        row[c0 + j] = y;
+                    }
+                }
+            }
+            for (; c0 < tn; c0 += NT) { // the call's last, partial chunk (ps[] is not kept up: nothing follows)
 #pragma unroll
                 for (int j = 0; j < NT; j++) {
                     if (c0 + j < tn) {
-                        f2 x = row[c0 + j];
-                        const float m2 = x.x * x.x + x.y * x.y;
-                        avg = 0.55f * avg + 0.45f * m2;
-                        if (avg > 0.0f) {
-                            const float sc = 0.85f / sqrtf(avg);
-                            x.x = x.x * sc;
-                            x.y = x.y * sc;
-                        }
+                        const f2 x = row[c0 + j];
                         float ns, nc;
                         sincos_two_pi(phase, &ns, &nc);
                         const float orr = x.x * nc - x.y * ns;
                         const float oi = x.x * ns + x.y * nc;
-                        zr[j] = orr;
-                        zi[j] = oi;
+                        z[j].x = orr;
+                        z[j].y = oi;
                         float acc = 0.0f;
 #pragma unroll
                         for (int k = 0; k < NT; k++) {
-                            constexpr int dummy = 0;
-                            (void)dummy;
                             const int slot = (j - k + NT) % NT;
-                            acc += zr[slot] * ta[k] + zi[slot] * tb[k];
+                            const f2 p = z[slot] * tt[k];
+                            float ps; // (as one instruction: left alone, the vectoriser pairs two taps' sums into a packed add and
+                                      // spends three moves on lining their halves up)
+                            asm("v_add_f32 %0, %1, %2" : "=v"(ps) : "v"(p.x), "v"(p.y));
+                            acc += ps;
                         }
                         const float lr = bcast(acc, 0), li = bcast(acc, 1), ur = bcast(acc, 2), ui = bcast(acc, 3);
                         const float lm = lr * lr + li * li, um = ur * ur + ui * ui;
@@ -600,8 +697,12 @@ k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_chan
     if (helper && it > 0) {
         drain(t0 - TS, (it + 2) % 3);
     }
+    if (agc_lane) {
+        avg_end[lane] = avg;
+    }
+    __syncthreads();
     if (live && q == 0) {
-        s.agc_avg = avg;
+        s.agc_avg = avg_end[cl];
         s.fll_phase = phase;
         s.fll_freq = freq;
         s.fll_idx = 0;
@@ -610,8 +711,8 @@ k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_chan
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             const int dst = (k - tail + NT) % NT;
-            delay_store[((size_t)dst * 2) * n_channels + ch] = zr[k];
-            delay_store[((size_t)dst * 2 + 1) * n_channels + ch] = zi[k];
+            delay_store[((size_t)dst * 2) * n_channels + ch] = z[k].x;
+            delay_store[((size_t)dst * 2 + 1) * n_channels + ch] = z[k].y;
         }
     }
 }
