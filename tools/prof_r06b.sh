@@ -27,3 +27,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 head -6 $OUT/r06b_bench_kernel_stats.csv | cut -c1-150
 grep rxw $OUT/r06b_bench_pmc_*.txt
+# the CQPSK-side chains after the AGC / FLL kernel's rework (AGC on the helper wave, packed taps, product sums inside the chain)
+rm -rf /tmp/pr_ch; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pr_ch -o b -- python $R/tools/bench_chains.py all > $OUT/chains_under_trace.log 2>&1
+f=$(find /tmp/pr_ch -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/r06b_chains_kernel_stats.csv
+grep -h "^{" $OUT/chains_under_trace.log > $OUT/r06b_chains_bench.jsonl
+cut -c1-700 $OUT/r06b_chains_bench.jsonl
