@@ -39,6 +39,7 @@
 using ddn_sl::two_max_insert;
 using ddn_sl::two_min_insert;
 
+#define DDN_RXW_RAW (1 << 30)
 namespace {
 constexpr int TS = 64;       // samples per staged tile
 constexpr int SS = 128;      // opts->ssize
@@ -768,18 +769,18 @@ struct LdsH {
 #if DDN_RX_CYCLES
     int req_t[CPW], rsp_t[CPW], rsp_pick[CPW]; // timing experiments: when the request was posted / answered, how long it lay unserved
 #endif
-    int tile_done[4]; // per recurrence wave: tiles it has finished
+    int tile_done[4]; // per recurrence wave: tiles it has finished; bit 30 (DDN_RXW_RAW): the tile its staging picks up next may be read
+                      // unfiltered by one of its channels (see stage_half_load)
     int hwid[8];      // HW_ID of the workgroup's waves (role placement)
     int ready[4];     // per recurrence wave: tiles the staging wave has made enterable for its channels (staged + window
                       // summaries of the checkpoint before)
     int fready[4];    // per recurrence wave: tiles whose matched-filter row the handler wave has computed (filter in the loop)
     int staged[4];    // per recurrence wave: tiles whose raw samples are in the ring (what the filter pass waits for; `ready` follows
                       // once the window summaries are written too)
-    int need_raw[CPW];    // per channel: the recurrence lane reads the unfiltered row (filter off, or inside its cold start) - what
-                          // the staging wave goes by; a hint only, see raw_tile
-    int raw_tile[3][CPW]; // per ring slot and channel: the tile whose unfiltered samples the slot holds (-1: not staged)
     float hh_dummy[CPW][4]; // where the lean run's history store goes for a lane whose phase does not end in a decision
     ddn_p25h::Scratch sc;
+    // (at the end: the members above keep the LDS addresses they had - the handler wave's scratch sits right below the 64 KB that an
+    // LDS instruction's immediate offset reaches, and the loop's time moved by 2.5 % with these 128 bytes in front of it)
 };
 
 // NRW_T = recurrence waves per workgroup.  Handler mode runs two (four lanes each at eight channels per workgroup: four waves, two
@@ -894,15 +895,11 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
         if (lane < CPW) {
             H.req_seq[lane] = 0;
             H.rsp_seq[lane] = 0;
-            H.need_raw[lane] = 1;
-            H.raw_tile[0][lane] = 0; // the prologue stages tile 0 whole
-            H.raw_tile[1][lane] = -1;
-            H.raw_tile[2][lane] = -1;
         }
         ddn_p25h::crc_cols_fill(H.sc.crc_cols, lane);
         if (lane == 0) {
             for (int w = 0; w < 4; w++) {
-                H.tile_done[w] = 0;
+                H.tile_done[w] = DDN_RXW_RAW; // (tiles 0 and 1 of a call are staged whole)
                 H.ready[w] = 1; // tile 0 is staged and summarised by the prologue
                 H.fready[w] = 0;
                 H.staged[w] = 1;
@@ -1343,7 +1340,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             }
             bool all_done = true;
             for (int w = 0; w < NRW_T; w++) {
-                all_done = all_done && __hip_atomic_load(&H.tile_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= n_tiles;
+                all_done = all_done
+                           && (__hip_atomic_load(&H.tile_done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & (DDN_RXW_RAW - 1)) >= n_tiles;
             }
             if (all_done) { // (a recurrence wave never leaves a tile with a request open)
                 break;
@@ -1393,12 +1391,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     const bool live = recur && lane < LPR && ch < n_channels;
     const bool use_flt = cfg.use_filter != 0;
     const bool ld_flt = use_flt && filt != nullptr; // the filter row comes from HBM (else: computed in place by the handler wave)
-    // Handler mode with the filter row in HBM: a channel whose matched filter is on and warm reads that row only, so the staging
-    // wave leaves its unfiltered samples in HBM (half the loop's fetches on a batch in sync).  H.need_raw is what the staging wave
-    // goes by, H.raw_tile what the ring holds; the recurrence lane loads a tile itself when it needs one that was not staged (the
-    // filter gated off, rx_no_carrier: rare), so what it reads never depends on when the staging wave looked.
-    // (cfg.dbg bit 16384: every tile's unfiltered samples staged, as before)
-    const bool skip_raw = HM && ld_flt && !fuse_mf && !(cfg.dbg & 16384);
+    const bool raw_always = !ld_flt || (cfg.dbg & 16384) != 0; // the unfiltered row is staged whatever the channels' filters do
     const float inf = __builtin_inff();
     // the recurrence wave is a latency chain: when other kernels' wavefronts share its SIMD (the front end of the next batch
     // runs beside this loop, bindings/ddn_chain.py run_pipelined3) its instructions go first
@@ -1597,17 +1590,16 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
     // traffic waits for)
     struct StageRegs {
         float r[TW / 64][LPR], f[TW / 64][LPR];
-        unsigned need; // bit c: channel c's unfiltered samples are part of this tile's staging
     };
-    auto stage_half_load = [&](long t0, int h, StageRegs& g) {
+    auto stage_half_load = [&](long t0, int h, StageRegs& g, bool need) {
         const int tn = (int)((n - t0) < TW ? (n - t0) : TW);
-        g.need = 0;
-#pragma unroll
-        for (int c = 0; c < LPR; c++) {
-            if (!skip_raw || H.need_raw[h * LPR + c]) {
-                g.need |= 1u << c;
-            }
-        }
+        // A channel whose matched filter is on and warm reads the filter's row only, so the unfiltered samples of a half whose channels
+        // are all in that state stay in HBM (half the loop's fetches on a batch in sync).  The recurrence lanes say so a tile ahead
+        // (bit 30 of tile_done, written at the end of every tile for the tile picked up here), and they can: the filter is gated off only by
+        // rx_no_carrier, which takes 1800 hunting symbols without a sync to reach - a lane asks for the unfiltered row again 64
+        // symbols (more than four tiles' worth) before that count can be reached, keeps asking while the filter is off and through
+        // its next cold start, and always asks where the row is needed whatever the filter does (no filter row in HBM; cfg.dbg bit
+        // 16384: staged always, as before).  One decision for the half: both forms of the staging are straight-line code.
 #pragma unroll
         for (int half = 0; half < TW / 64; half++) { // every load of the tile in flight before the first LDS write
             const int j = lane + 64 * half;
@@ -1616,27 +1608,35 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 const int cc = h * LPR + c;
                 const bool ok = (ch0 + cc < n_channels) && j < tn;
                 const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + j;
-                g.r[half][c] = (ok && ((g.need >> c) & 1)) ? raw[off] : 0.0f;
                 g.f[half][c] = (ok && ld_flt) ? filt[off] : 0.0f;
+                g.r[half][c] = 0.0f;
+            }
+        }
+        if (need) {
+#pragma unroll
+            for (int half = 0; half < TW / 64; half++) {
+                const int j = lane + 64 * half;
+#pragma unroll
+                for (int c = 0; c < LPR; c++) {
+                    const int cc = h * LPR + c;
+                    const bool ok = (ch0 + cc < n_channels) && j < tn;
+                    const size_t off = (size_t)(ch0 + cc) * stride + (size_t)t0 + j;
+                    g.r[half][c] = ok ? raw[off] : 0.0f;
+                }
             }
         }
     };
     auto stage_half_store = [&](int tile, int h, const StageRegs& g) {
         const int slot = tile % 3;
-        if (lane < LPR) {
-            H.raw_tile[slot][h * LPR + lane] = ((g.need >> lane) & 1) ? tile : -1;
-        }
 #pragma unroll
         for (int half = 0; half < TW / 64; half++) {
             const int j = lane + 64 * half;
 #pragma unroll
             for (int c = 0; c < LPR; c++) {
                 const int cc = h * LPR + c;
-                if ((g.need >> c) & 1) {
-                    L.raw[cc][TW + slot * TW + j] = g.r[half][c];
-                    if (slot == 2) {
-                        L.raw[cc][j] = g.r[half][c];
-                    }
+                L.raw[cc][TW + slot * TW + j] = g.r[half][c]; // (zeros where the row was left in HBM: never read)
+                if (slot == 2) {
+                    L.raw[cc][j] = g.r[half][c];
                 }
                 if (!fuse_mf) {
                     L.flt[cc][TW + slot * TW + j] = g.f[half][c];
@@ -1830,40 +1830,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             fs[k] = v;
         }
     };
-    // The unfiltered samples of this tile and the one before, in the ring for this lane's channel: loaded here, by the lane
-    // itself, where the staging wave left them out (skip_raw).  Called wherever the lane starts to read that row - at a tile's
-    // entry with the filter off or cold, and where the filter is gated off in the middle of a tile.
-    auto ensure_raw = [&]() {
-        if (!skip_raw) {
-            return;
-        }
-        for (int tt = it > 0 ? it - 1 : 0; tt <= it; tt++) {
-            const int sl = tt % 3;
-            if (H.raw_tile[sl][ln] == tt) {
-                continue;
-            }
-            const long b = (long)tt * TW;
-            const int cnt = (int)((n - b) < TW ? (n - b) : TW);
-            const float* src = raw + (size_t)ch * stride + b;
-            float* dst = &L.raw[ln][TW + sl * TW];
-            for (int j0 = 0; j0 < TW; j0 += 8) {
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    v[k] = (j0 + k < cnt) ? src[j0 + k] : 0.0f;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    dst[j0 + k] = v[k];
-                    if (sl == 2) {
-                        L.raw[ln][j0 + k] = v[k];
-                    }
-                }
-            }
-            H.raw_tile[sl][ln] = tt;
-        }
-    };
-    bool raw_miss = false; // the filter was gated off in this trip: ensure_raw() before the next one reads a sample
     // frame_sync_advance_sync_window() + frame_sync_handle_no_sync_timeout() after a hunting symbol without a sync
     auto hunt_advance = [&]() {
         if (s.hunt_pos < 10200) {
@@ -1872,14 +1838,12 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
             s.hunt_pos = 0;
             snapshot_filter();
             rx_no_carrier(s);
-            raw_miss = true;
             s.hnc = 1;
             cold_until = -2147483647;
         }
         if (s.lastsync != 2 && s.hunt_pos >= 1800) {
             snapshot_filter();
             rx_no_carrier(s);
-            raw_miss = true;
             s.hnc = 1;
             cold_until = -2147483647;
             rx_hunt_restart(s);
@@ -2155,7 +2119,8 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
 #pragma unroll
             for (int h = 0; h < NRW; h++) {
                 const int j = job[h];
-                if (j > n_tiles || __hip_atomic_load(&H.tile_done[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < j) {
+                const int tdw = __hip_atomic_load(&H.tile_done[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (j > n_tiles || (tdw & (DDN_RXW_RAW - 1)) < j) {
                     continue;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2164,7 +2129,7 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                     long long c0 = w0;
                     StageRegs sg;
                     if (j + 1 < n_tiles) {
-                        stage_half_load((long)(j + 1) * TW, h, sg);
+                        stage_half_load((long)(j + 1) * TW, h, sg, (tdw & DDN_RXW_RAW) != 0);
                     }
                     if (DDN_RX_CYCLES && (cfg.dbg & 8192)) { // the staging wave's three jobs, timed apart
                         const long long c1 = (long long)clock64();
@@ -2276,9 +2241,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 return d <= -2147483647LL ? -2147483647 : (d > 1000000LL ? 1000000 : (int)d);
             };
             cold_until = cold_limit();
-            if (HM && live && (!s.filter_on || cold_until > 0)) {
-                ensure_raw();
-            }
             if (it >= 1) { // the checkpoint moves to the start of the previous tile
                 pp1 = pc1, pp2 = pc2, pp3 = pc3, pp4 = pc4;
                 npp = npc;
@@ -2335,10 +2297,6 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                         __builtin_amdgcn_s_sleep(1);
                         continue;
                     }
-                }
-                if (HM && raw_miss) {
-                    ensure_raw();
-                    raw_miss = false;
                 }
                 const bool alive = live & !hwait;
                 // ---- bulk hunting pass ---------------------------------------------------------------------------------------
@@ -3438,15 +3396,17 @@ k_p25_rxw(const float* __restrict__ raw, const float* __restrict__ filt, const f
                 L.sidx0[(it + 1) & 1][ln] = s.sidx;
                 sp -= TW;
             }
-            if (HM && live) {
-                // the staging wave picks tile it + 2 up next: its unfiltered samples are wanted with the filter off, and for as
-                // long as a tile still holds (or follows one that holds) samples of the filter's cold start
-                H.need_raw[ln] = (!s.filter_on || (abs0 + t0 + 3 * (long long)TW - s.filt_start) < (long long)(NT - 1) + TW) ? 1 : 0;
-            }
             if (HM) { // this wave's queue half, trip count and checkpoint slots are in LDS: the tile is done
+                // ... and with it goes the word on the unfiltered row: wanted with the filter off, in the tile a cold start began in
+                // or reaches into (the hint of tile it serves tile it + 1 or it + 2, a cold start reaches one tile on), from 64
+                // hunting symbols before the count that gates the filter off (1800; a lane with lastsync == 2 goes on to 10200 and
+                // is served all the way), and always where there is no filter row to read instead
+                const bool want = live
+                                  && (!s.filter_on || cold_until > 0 || (!s.have_sync && s.hunt_pos + 64 >= 1800) || raw_always);
+                const int raw_bit = __any(want) ? DDN_RXW_RAW : 0;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) {
-                    __hip_atomic_store(&H.tile_done[rw], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&H.tile_done[rw], (it + 1) | raw_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }

@@ -145,10 +145,10 @@ def test_hunting_pass_of_all_rows_at_once_equals_one_owner_at_a_time(built, monk
 
 @pytest.mark.parametrize("cpw", [4, 8])
 def test_unfiltered_row_left_in_hbm_for_channels_in_sync(built, cpw):
-    """The staging wave leaves a channel's unfiltered samples in HBM while its matched filter is on and warm; the recurrence lane
-    loads the tiles it turns out to need when the filter is gated off (no carrier) in the middle of a tile, and the staging wave
-    takes them up again until the next sync's cold start is over (ddn_rx.hip, skip_raw).  Carriers that come and go at offsets
-    spread over the 128-sample tile: same records, flags and decisions as with every tile staged whole
+    """The staging wave leaves the unfiltered samples of a half in HBM while the matched filters of its channels are on and warm; the
+    recurrence lanes ask for them again ahead of time - 64 hunting symbols before the count that gates a filter off (no carrier) can
+    be reached, while a filter is off, and through its next cold start (ddn_rx.hip, stage_half_load; bit 30 of tile_done).  Carriers
+    that come and go at offsets spread over the 128-sample tile: same records, flags and decisions as with every tile staged whole
     (ddn_p25_rx_set_debug_flags bit 16384), and as the oracle's."""
     B, n = 8, 130000
     x = np.zeros((B, n), np.float32)
