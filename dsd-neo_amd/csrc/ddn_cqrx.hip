@@ -56,8 +56,10 @@ cq_slice(float s) {
 
 __device__ __forceinline__ int
 map_dibit(int map_idx, int raw) { // include/dsd-neo/core/p25_cqpsk_dibit.h: identity, reverse, X2400, N1200, P1200 (2 bits per entry)
-    const uint32_t maps[5] = {0xE4u, 0x4Eu, 0x1Bu, 0x8Du, 0x72u};
-    return (int)((maps[map_idx] >> (2 * raw)) & 3u);
+    // the five maps 0xE4, 0x4E, 0x1B, 0x8D, 0x72 in one constant.  (As an indexed array the table went to constant memory: a global
+    // load and a wait for EVERY outstanding load - the extrema ring's prefetch among them - in every in-frame symbol.)
+    const uint64_t maps = 0x728D1B4EE4ull;
+    return (int)((maps >> (8 * map_idx + 2 * raw)) & 3u);
 }
 
 __device__ __forceinline__ int
