@@ -102,20 +102,31 @@ bit_magnitude(float sym, const float ideal[4], int bit_index) { // soft_metric_f
     return clamp255(__float2int_rn(fabsf(best0 - best1) * scale));
 }
 
-// digitize() + compute_dibit_soft_metric() on the CQPSK slice
+// the nominal level of each corrected dibit under the lock's dibit map and polarity: what the soft metrics measure against.  It only
+// changes with a sync, so it is kept beside the lock's words instead of being unmapped again in every in-frame symbol.
 __device__ __forceinline__ void
-cq_digitize(float sym, float center, int map_idx, int negative, int snr_scale, int& dibit, int& rel8, int& l0, int& l1) {
-    dibit = map_dibit(map_idx, cq_slice(sym - center));
-    if (negative) {
-        dibit ^= 2;
-    }
+cq_levels(int map_idx, int negative, float level[4]) {
     const float base_ideal[4] = {1.0f, 3.0f, -1.0f, -3.0f};
-    float ideal[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         const int corrected = negative ? (d ^ 2) : d;
         const int raw = unmap_dibit(map_idx, corrected);
-        ideal[d] = center + (raw == 0 ? base_ideal[0] : (raw == 1 ? base_ideal[1] : (raw == 2 ? base_ideal[2] : base_ideal[3])));
+        level[d] = raw == 0 ? base_ideal[0] : (raw == 1 ? base_ideal[1] : (raw == 2 ? base_ideal[2] : base_ideal[3]));
+    }
+}
+
+// digitize() + compute_dibit_soft_metric() on the CQPSK slice
+__device__ __forceinline__ void
+cq_digitize(float sym, float center, int map_idx, int negative, const float level[4], int snr_scale, int& dibit, int& rel8, int& l0,
+            int& l1) {
+    dibit = map_dibit(map_idx, cq_slice(sym - center));
+    if (negative) {
+        dibit ^= 2;
+    }
+    float ideal[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        ideal[d] = center + level[d];
     }
     int mag0 = bit_magnitude(sym, ideal, 0), mag1 = bit_magnitude(sym, ideal, 1);
     // dmr_compute_reliability(), rf_mod 1
@@ -402,6 +413,8 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
         return false;
     };
 
+    float lv[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // cq_levels() of (lv_map, lv_neg)
+    int lv_map = -1, lv_neg = -1;
     int o = 0; // records written by this call
     for (int base = 0; base < n; base += 64) {
         const int cnt = (n - base) < 64 ? (n - base) : 64;
@@ -441,7 +454,12 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
                 const float center = (s_max + s_min) / 2.0f;
                 sidx = (sidx >= SSZ - 1) ? 0 : sidx + 1;
                 const int neg = lastsync == 2;
-                cq_digitize(x, center, map_idx, neg, cfg.snr_scale, dibit, rel8, l0, l1);
+                if (lv_map != map_idx || lv_neg != neg) {
+                    cq_levels(map_idx, neg, lv);
+                    lv_map = map_idx;
+                    lv_neg = neg;
+                }
+                cq_digitize(x, center, map_idx, neg, lv, cfg.snr_scale, dibit, rel8, l0, l1);
                 fl = 1 | (neg ? 4 : 0);
                 if (cfg.lock_symbols < 0) {
                     if (!handler_symbol(o, dibit, l0, l1)) {
