@@ -191,6 +191,8 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
     float s_max = gs->max, s_min = gs->min, lmin = gs->lmin, lmax = gs->lmax;
     double min_sum = gs->min_sum, max_sum = gs->max_sum;
     int sidx = gs->sidx, midx = gs->midx, sums_valid = gs->sums_valid;
+    bool win_ok = false;                                          // the slicer window's carried extrema below are current
+    float w_lo1 = 0.0f, w_lo2 = 0.0f, w_hi1 = 0.0f, w_hi2 = 0.0f; // its two smallest and two largest values
     int have_sync = gs->have_sync, lock_left = gs->lock_left, lastsync = gs->lastsync, map_idx = gs->map_idx;
     int lidx = gs->lidx, level_count = gs->level_count, hist_count = gs->hist_count, shead = gs->shead, scount = gs->scount;
     int hunt_pos = gs->hunt_pos;
@@ -432,23 +434,48 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
             scount = scount < 24 ? scount + 1 : 24;
             if (have_sync) {
                 // ---- in frame: window slot, use_symbol(), digitize() --------------------------------------------------------
+                // the window's two smallest and two largest are carried from symbol to symbol: the slot's old value leaves, the symbol
+                // enters.  If the value that leaves lies strictly between the second smallest and the second largest the four stay
+                // what they were but for the newcomer, which takes its place by plain compares; otherwise (it is, or ties with, one
+                // of the four: a few per cent of the symbols; a zero or a NaN coming in; the first symbol after anything else wrote
+                // the window) the whole window is scanned as before
+                const float old = L.sbuf[sidx];
                 if (lane == 0) {
                     L.sbuf[sidx] = x;
                 }
-                wave_sync();
-                float a = L.sbuf[lane], b = L.sbuf[lane + 64];
-                float lo1 = a < b ? a : b, lo2 = a < b ? b : a, hi1 = lo2, hi2 = lo1;
+                float lo1 = w_lo1, lo2 = w_lo2, hi1 = w_hi1, hi2 = w_hi2;
+                if (!win_ok || !(old > w_lo2 && old < w_hi2) || !(x != 0.0f)) {
+                    wave_sync();
+                    const float a = L.sbuf[lane], b = L.sbuf[lane + 64];
+                    lo1 = a < b ? a : b, lo2 = a < b ? b : a, hi1 = lo2, hi2 = lo1;
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const float o1 = __shfl_xor(lo1, off), o2 = __shfl_xor(lo2, off);
-                    const float n1 = lo1 < o1 ? lo1 : o1, mx = lo1 < o1 ? o1 : lo1, m2 = lo2 < o2 ? lo2 : o2;
-                    lo2 = mx < m2 ? mx : m2;
-                    lo1 = n1;
-                    const float p1 = __shfl_xor(hi1, off), p2 = __shfl_xor(hi2, off);
-                    const float g1 = hi1 > p1 ? hi1 : p1, mn = hi1 > p1 ? p1 : hi1, g2 = hi2 > p2 ? hi2 : p2;
-                    hi2 = mn > g2 ? mn : g2;
-                    hi1 = g1;
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const float o1 = __shfl_xor(lo1, off), o2 = __shfl_xor(lo2, off);
+                        const float n1 = lo1 < o1 ? lo1 : o1, mx = lo1 < o1 ? o1 : lo1, m2 = lo2 < o2 ? lo2 : o2;
+                        lo2 = mx < m2 ? mx : m2;
+                        lo1 = n1;
+                        const float p1 = __shfl_xor(hi1, off), p2 = __shfl_xor(hi2, off);
+                        const float g1 = hi1 > p1 ? hi1 : p1, mn = hi1 > p1 ? p1 : hi1, g2 = hi2 > p2 ? hi2 : p2;
+                        hi2 = mn > g2 ? mn : g2;
+                        hi1 = g1;
+                    }
+                    // (a scan that met a NaN is not carried: its compares have no order to update from)
+                    win_ok = (lo1 == lo1) && (lo2 == lo2) && (hi1 == hi1) && (hi2 == hi2);
+                } else {
+                    if (x < lo1) {
+                        lo2 = lo1;
+                        lo1 = x;
+                    } else if (x < lo2) {
+                        lo2 = x;
+                    }
+                    if (x > hi1) {
+                        hi2 = hi1;
+                        hi1 = x;
+                    } else if (x > hi2) {
+                        hi2 = x;
+                    }
                 }
+                w_lo1 = lo1, w_lo2 = lo2, w_hi1 = hi1, w_hi2 = hi2;
                 const float wlo = (lo1 + lo2) * 0.5f, whi = (hi1 + hi2) * 0.5f;
                 push_minmax(wlo, whi);
                 const float center = (s_max + s_min) / 2.0f;
@@ -474,6 +501,7 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
                     L.lbuf[lidx] = x;
                     L.sbuf[sidx] = x;
                 }
+                win_ok = false;
                 level_count = level_count < t_max ? level_count + 1 : level_count;
                 lidx = (lidx == t_max - 1) ? 0 : lidx + 1;
                 sidx = (sidx == SSZ - 1) ? 0 : sidx + 1;
@@ -593,6 +621,7 @@ k_cq_rx(const float* __restrict__ symbols, const int32_t* __restrict__ counts_in
                                 for (int i = lane; i < SSZ; i += 64) {
                                     L.sbuf[i] = (i & 1) ? s_max : s_min;
                                 }
+                                win_ok = false;
                                 sums_valid = 0;
                                 wave_sync();
                             }
