@@ -168,12 +168,18 @@ k_p25_slicer(const float* __restrict__ sym, long n, size_t sym_stride, int n_cha
 // traffic per multiply-add (the LDS, not the VALU, is this kernel's busiest unit: at four outputs per thread it moved 2 bytes per
 // multiply-add), eight packed VALU instructions per tap.  Pair m sits at [m & 3][m >> 2], so a wavefront's reads (pair 4 * tid +
 // const) are consecutive 8-byte slots.  Taps are compile-time indices into the constant table.
+#ifndef DDN_MF_R
+#define DDN_MF_R 4 /* packed pairs per thread; 8 (half the LDS reads per multiply-add, twice the tile) measured 0.75 against 0.67 ms */
+#endif
 typedef float mf2 __attribute__((ext_vector_type(2)));
+// R = packed lane pairs per thread (2 R adjacent outputs): pair m sits at [m % R][m / R], so a wavefront's reads (pair R * tid + const)
+// are consecutive 8-byte slots.
+template <int R>
 __global__ __launch_bounds__(128) void
 k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const float* __restrict__ hist,
                      float* __restrict__ out) {
-    constexpr int T = 1024, NT = DDN_P25_FILTER_TAPS, NP = (T + NT + 3) / 2, NH = NP / 4 + 2;
-    __shared__ mf2 E[4][NH], O[4][NH];
+    constexpr int T = 128 * 2 * R, NT = DDN_P25_FILTER_TAPS, NP = (T + NT + 3) / 2, NH = NP / R + 2;
+    __shared__ mf2 E[R][NH], O[R][NH];
     const int ch = blockIdx.y;
     const long t0 = (long)blockIdx.x * T;
     const int tid = threadIdx.x;
@@ -193,21 +199,21 @@ k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const 
         const mf2* pr = (const mf2*)span;
         for (int m = tid; m < NP; m += 128) {
             const mf2 e = pr[m], nx = pr[m + 1];
-            E[m & 3][m >> 2] = e;
-            O[m & 3][m >> 2] = mf2{e.y, nx.x};
+            E[m % R][m / R] = e;
+            O[m % R][m / R] = mf2{e.y, nx.x};
         }
     } else {
         for (int m = tid; m < NP; m += 128) {
             const float a = sample(2 * m), b = sample(2 * m + 1), c = sample(2 * m + 2);
-            E[m & 3][m >> 2] = mf2{a, b};
-            O[m & 3][m >> 2] = mf2{b, c};
+            E[m % R][m / R] = mf2{a, b};
+            O[m % R][m / R] = mf2{b, c};
         }
     }
     __syncthreads();
-    // this thread's outputs o .. o + 7, o = 8 * tid: pair index m0 = 4 * tid
-    mf2 e[4], q[4], acc[4];
+    // this thread's outputs o .. o + 2 R - 1, o = 2 R * tid: pair index m0 = R * tid
+    mf2 e[R], q[R], acc[R];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < R; r++) {
         e[r] = E[r][tid];
         q[r] = O[r][tid];
         acc[r] = mf2{0.0f, 0.0f};
@@ -218,7 +224,7 @@ k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const 
             const float t = __uint_as_float(ddn_p25_filter_bits[2 * j]);
             const mf2 tt = {t, t};
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < R; r++) {
                 acc[r] += tt * e[r];
             }
         }
@@ -226,30 +232,30 @@ k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const 
             const float t = __uint_as_float(ddn_p25_filter_bits[2 * j + 1]);
             const mf2 tt = {t, t};
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < R; r++) {
                 acc[r] += tt * q[r];
             }
         }
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < R - 1; r++) {
             e[r] = e[r + 1];
             q[r] = q[r + 1];
         }
-        if (j + 1 < (NT + 1) / 2) { // pair 4 * tid + j + 4
-            e[3] = E[j & 3][tid + (j + 4) / 4];
-            q[3] = O[j & 3][tid + (j + 4) / 4];
+        if (j + 1 < (NT + 1) / 2) { // pair R * tid + j + R
+            e[R - 1] = E[(j + R) % R][tid + (j + R) / R];
+            q[R - 1] = O[(j + R) % R][tid + (j + R) / R];
         }
     }
-    const long o = t0 + 8 * tid;
+    const long o = t0 + 2 * R * tid;
     float* dst = out + (size_t)ch * stride + o;
-    if (o + 7 < n) {
+    if (o + 2 * R - 1 < n) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < R; r++) {
             *(mf2*)&dst[2 * r] = acc[r];
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < R; r++) {
             if (o + 2 * r < n) {
                 dst[2 * r] = acc[r].x;
             }
@@ -288,8 +294,8 @@ ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channel
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_matched_filter, dim3((unsigned)((n + 1023) / 1024), (unsigned)n_channels), dim3(128), 0, st,
-                       in, n, stride, (const float*)hist, out);
+    hipLaunchKernelGGL(k_p25_matched_filter<DDN_MF_R>, dim3((unsigned)((n + 256 * DDN_MF_R - 1) / (256 * DDN_MF_R)), (unsigned)n_channels),
+                       dim3(128), 0, st, in, n, stride, (const float*)hist, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         return e;
@@ -305,8 +311,8 @@ ddn_dev_p25_matched_filter_only(const float* in, long n, size_t stride, int n_ch
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_matched_filter, dim3((unsigned)((n + 1023) / 1024), (unsigned)n_channels), dim3(128), 0, st,
-                       in, n, stride, hist, out);
+    hipLaunchKernelGGL(k_p25_matched_filter<DDN_MF_R>, dim3((unsigned)((n + 256 * DDN_MF_R - 1) / (256 * DDN_MF_R)), (unsigned)n_channels),
+                       dim3(128), 0, st, in, n, stride, hist, out);
     return hipGetLastError();
 }
 
