@@ -1673,10 +1673,23 @@ k_fsk4_matched_filter(const float* __restrict__ in, long n, size_t stride, const
         }
         return j < n ? in[(size_t)ch * stride + j] : 0.0f;
     };
-    for (int m = tid; m < NP; m += 128) {
-        const float a = sample(2 * m), b = sample(2 * m + 1), c = sample(2 * m + 2);
-        E[m & 3][m >> 2] = mf2{a, b};
-        O[m & 3][m >> 2] = mf2{b, c};
+    // (round 6, as k_p25_matched_filter) a tile whose whole input span lies inside the call's samples on an 8-byte boundary is read as
+    // the aligned pairs E is made of: two 8-byte loads per pair index instead of three tested 4-byte loads
+    const long j0 = t0 - (NT - 1);
+    const float* span = in + (size_t)ch * stride + j0;
+    if (j0 >= 0 && j0 + 2 * NP + 2 <= n && (((size_t)span) & 7) == 0) {
+        const mf2* pr = (const mf2*)span;
+        for (int m = tid; m < NP; m += 128) {
+            const mf2 e = pr[m], nx = pr[m + 1];
+            E[m & 3][m >> 2] = e;
+            O[m & 3][m >> 2] = mf2{e.y, nx.x};
+        }
+    } else {
+        for (int m = tid; m < NP; m += 128) {
+            const float a = sample(2 * m), b = sample(2 * m + 1), c = sample(2 * m + 2);
+            E[m & 3][m >> 2] = mf2{a, b};
+            O[m & 3][m >> 2] = mf2{b, c};
+        }
     }
     __syncthreads();
     // this thread's outputs o .. o + 7, o = 8 * tid: pair index m0 = 4 * tid
