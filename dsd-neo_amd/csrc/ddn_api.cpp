@@ -515,6 +515,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
             static long long* dbg_buf = nullptr;
             if (!dbg_buf) {
                 (void)hipMalloc(&dbg_buf, 64 * 4 * sizeof(long long));
+                (void)hipMemset(dbg_buf, 0, 64 * 4 * sizeof(long long)); // (rows 8, 9 stay zero without the extra filter waves)
             }
             fa.dbg_out = dbg_buf;
         }
@@ -538,7 +539,7 @@ ddn_front_end_run(ddn_batch* b, const void* d_iq, size_t n, float* d_disc, void*
         long long h[64 * 4];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, fa.dbg_out, sizeof(h), hipMemcpyDeviceToHost);
-        for (int w = 0; w < 10; w++) {
+        for (int w = 0; w < 12; w++) { // 0-9 filter waves (8, 9: the two that only take work items), 10 = dc wave S1, 11 = peak wave S2
             fprintf(stderr, "wave %d: simd %lld  phaseA %lld  phaseB %lld  barrier-wait %lld cycles/tile\n", w, h[w * 4],
                     h[w * 4 + 1] / (long long)fa.n_tiles, h[w * 4 + 2] / (long long)fa.n_tiles,
                     h[w * 4 + 3] / (long long)fa.n_tiles);

@@ -45,6 +45,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define DDN_GROUP 16 /* channels per workgroup */
 #endif
 #define DDN_R  4
+#ifndef DDN_FE_EXTRA
+#define DDN_FE_EXTRA 0 /* filter waves beyond the G / 2 that stage and finish tiles (sixteen-channel workgroups only): they take the
+                          filter's work items and nothing else.  With 2 the workgroup has twelve waves, three on every SIMD: alone the
+                          kernel is 1-2 % faster on clean C4FM and 6 % on noise (2.42 against 2.59 ms) - and the step 0.35 ms SLOWER
+                          (8.17 against 7.82 ms; the mixed step 11.8 against 10.8): ten waves leave 176 registers free on two SIMDs of
+                          every CU, which is where the previous call's decode kernels run beside the front end; with twelve they
+                          run beside the loop instead and that costs the loop 0.27 ms */
+#endif
+#define DDN_FE_THREADS(G) ((G) * 32 + 128 + ((G) == 16 ? DDN_FE_EXTRA * 64 : 0))
 
 // ------------------------------------------------------------------------------------------------------
 // helpers
@@ -102,7 +111,11 @@ ddn_peak_step(float c, float& peak) {
 __device__ __forceinline__ float
 ddn_peak_step_fast(float c, float& peak) {
     const float d = fabsf(c) - peak;
-    peak = peak + fmaxf(0.125f * d, 0.00005f * d);
+    // (both products from one packed multiply: the peak wave's time is its instruction count - a wave that shares its SIMD with busy
+    // filter waves is served about every 2.4th issue slot)
+    const f2 k = {0.125f, 0.00005f}, dd = {d, d};
+    const f2 p = k * dd;
+    peak = peak + fmaxf(p.x, p.y);
     return peak;
 }
 
@@ -159,7 +172,7 @@ ddn_tile_next(TileWalk& w, const DdnFusedArgs& a) {
 // A single wave issues roughly one VALU instruction per 5 cycles whatever the lane count, so the two
 // recurrences are split over two waves to keep each under the filter threads' time per tile.
 template <int CENTER_T, int G, bool SKIPZ, int FMT, bool SEGS = false>
-__global__ __launch_bounds__(G * 32 + 128, 3) void
+__global__ __launch_bounds__(DDN_FE_THREADS(G), 3) void
 k_front_end_fused(DdnFusedArgs a) {
     constexpr int TT = DDN_TT;
     constexpr int R = DDN_R;
@@ -188,6 +201,8 @@ k_front_end_fused(DdnFusedArgs a) {
     const bool is_filter = tid >= 128;
     const int role = is_filter ? 0 : (tid < 64 ? 1 : 2);      // 0 filter, 1 = S1 (dc), 2 = S2 (peak)
     const int ft = tid - 128;                                  // filter-thread index
+    const bool stager = is_filter && ft < G * 32;              // a filter thread with a share of the staging and finishing (the extra
+                                                               // waves only take work items of the filter)
     const int g = is_filter ? (ft >> 5) : (tid & 63);          // channel slot
     const int u = ft & 31;
     const int lane64 = tid & 63;
@@ -254,7 +269,7 @@ k_front_end_fused(DdnFusedArgs a) {
             tm0 = __builtin_readcyclecounter();
         }
         // ================= phase A: finish tile it-3, stage tile it =====================================
-        if (is_filter) {
+        if (stager) {
             if (it >= 3 && !(a.dbg & 4)) {
                 const TileDesc t3 = tq[4];
                 const int bf = (int)((it - 3) % 3);
@@ -341,7 +356,7 @@ k_front_end_fused(DdnFusedArgs a) {
         // ================= phase B ======================================================================
         if (role == 0) {
             // ---- filter threads: prefetch tile it+1, LPF + phase delta of tile it ------------------------
-            if (it + 1 < NT && !(a.dbg & 8)) {
+            if (stager && it + 1 < NT && !(a.dbg & 8)) {
                 const TileDesc tn = tq[0];
                 const int Weff = TT + 2 * C;
                 if (tn.valid > 0) {
@@ -363,12 +378,15 @@ k_front_end_fused(DdnFusedArgs a) {
                 }
             }
             const TileDesc tc = tq[1];
-            if (it < NT && tc.valid <= 0 && u == 0) {
+            if (stager && it < NT && tc.valid <= 0 && u == 0) {
                 chan_last[(it & 1) ^ 1][g] = chan_last[it & 1][g]; // surplus tile of a short last block
             }
             // Filter work is handed out dynamically: one item = one channel's tile on a full wave (64 lanes x R = 4
             // outputs).  Waves that share their SIMD with a recurrence wave simply come back for fewer items, so all
             // four SIMDs finish together.  (Results do not depend on which wave computes which channel.)
+            // (round 6, DDN_FE_EXTRA = 2: two more waves come here for items only.  VALU issue on a SIMD goes to the oldest wave that can
+            // issue, so the first waves of each SIMD take two items a tile and the last one what is left; capping the second items
+            // per wave made no difference, the split 5 / 5 / 3 / 3 items over the SIMDs is what the item size allows.)
             while (it < NT && tc.valid > 0 && !(a.dbg & 2)) {
                 int item = 0;
                 if (lane64 == 0) {
@@ -732,14 +750,14 @@ k_front_end_fused(DdnFusedArgs a) {
     if ((a.dbg & 64) && a.dbg_out && blockIdx.x == 0 && (tid & 63) == 0) {
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        long long* o = a.dbg_out + (is_filter ? (ft >> 6) : (8 + (tid >> 6))) * 4;
+        long long* o = a.dbg_out + (is_filter ? (ft >> 6) : (10 + (tid >> 6))) * 4;
         o[0] = (hw >> 4) & 3;
         o[1] = tA;
         o[2] = tB;
         o[3] = tW;
     }
 
-    if (is_filter && ch_ok && a.carry_out) {
+    if (stager && ch_ok && a.carry_out) {
         // next call's FIR look-back: the channel's last DDN_CARRY_LEN widened samples.  Only this half-wave ever reads
         // or writes this channel's row (it read it at tile 0), so no other ordering is needed.
         f2* c = a.carry_out + (size_t)ch * DDN_CARRY_LEN;
@@ -792,7 +810,7 @@ template <int CENTER_T, int G, int FMT>
 static hipError_t
 launch_fused_t(const DdnFusedArgs& a, const DdnTapsK& tp, bool has_zero, hipStream_t st) {
     dim3 grid((unsigned)((a.n_channels + G - 1) / G));
-    dim3 block(G * 32 + 128);
+    dim3 block(DDN_FE_THREADS(G));
     // squelch builds: the block's first 256 LPF outputs, twice when a block is a single tile (see the filter's store)
     const size_t dyn = a.squelch_on ? (size_t)G * 256 * sizeof(f2) * (a.tiles_per_block == 1 ? 2 : 1) : 0;
     if (dyn) {
