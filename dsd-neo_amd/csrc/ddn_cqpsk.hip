@@ -474,7 +474,8 @@ __global__ __launch_bounds__(128) void
 k_cqpsk_agc_fll_reg(const f2* __restrict__ in, long n, size_t stride, int n_channels, float alpha, float beta,
                     const float* __restrict__ fll, DdnCqpskState* __restrict__ state, float* __restrict__ delay_store,
                     f2* __restrict__ out) {
-    constexpr int TS = (NT > 16) ? 2 * NT : 3 * NT, CPW = 16;
+    constexpr int TS = 3 * NT, CPW = 16; // (a tile is staged lane = sample: 3 NT <= 63 for the tap counts in use)
+    static_assert(TS <= 64, "a tile is staged one sample per lane");
     __shared__ f2 tiles[3][CPW][TS + 1];
     const int lane = threadIdx.x & 63;
     const bool helper = threadIdx.x >= 64;
