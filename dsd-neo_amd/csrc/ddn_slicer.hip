@@ -168,6 +168,9 @@ k_p25_slicer(const float* __restrict__ sym, long n, size_t sym_stride, int n_cha
 // traffic per multiply-add (the LDS, not the VALU, is this kernel's busiest unit: at four outputs per thread it moved 2 bytes per
 // multiply-add), eight packed VALU instructions per tap.  Pair m sits at [m & 3][m >> 2], so a wavefront's reads (pair 4 * tid +
 // const) are consecutive 8-byte slots.  Taps are compile-time indices into the constant table.
+#ifndef DDN_MF_THREADS
+#define DDN_MF_THREADS 128
+#endif
 #ifndef DDN_MF_R
 #define DDN_MF_R 4 /* packed pairs per thread; 8 (half the LDS reads per multiply-add, twice the tile) measured 0.75 against 0.67 ms */
 #endif
@@ -175,10 +178,10 @@ typedef float mf2 __attribute__((ext_vector_type(2)));
 // R = packed lane pairs per thread (2 R adjacent outputs): pair m sits at [m % R][m / R], so a wavefront's reads (pair R * tid + const)
 // are consecutive 8-byte slots.
 template <int R>
-__global__ __launch_bounds__(128) void
+__global__ __launch_bounds__(DDN_MF_THREADS) void
 k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const float* __restrict__ hist,
                      float* __restrict__ out) {
-    constexpr int T = 128 * 2 * R, NT = DDN_P25_FILTER_TAPS, NP = (T + NT + 3) / 2, NH = NP / R + 2;
+    constexpr int NTH = DDN_MF_THREADS, T = NTH * 2 * R, NT = DDN_P25_FILTER_TAPS, NP = (T + NT + 3) / 2, NH = NP / R + 2;
     __shared__ mf2 E[R][NH], O[R][NH];
     const int ch = blockIdx.y;
     const long t0 = (long)blockIdx.x * T;
@@ -197,13 +200,13 @@ k_p25_matched_filter(const float* __restrict__ in, long n, size_t stride, const 
     const float* span = in + (size_t)ch * stride + j0;
     if (j0 >= 0 && j0 + 2 * NP + 2 <= n && (((size_t)span) & 7) == 0) {
         const mf2* pr = (const mf2*)span;
-        for (int m = tid; m < NP; m += 128) {
+        for (int m = tid; m < NP; m += NTH) {
             const mf2 e = pr[m], nx = pr[m + 1];
             E[m % R][m / R] = e;
             O[m % R][m / R] = mf2{e.y, nx.x};
         }
     } else {
-        for (int m = tid; m < NP; m += 128) {
+        for (int m = tid; m < NP; m += NTH) {
             const float a = sample(2 * m), b = sample(2 * m + 1), c = sample(2 * m + 2);
             E[m % R][m / R] = mf2{a, b};
             O[m % R][m / R] = mf2{b, c};
@@ -294,8 +297,8 @@ ddn_dev_p25_matched_filter(const float* in, long n, size_t stride, int n_channel
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_matched_filter<DDN_MF_R>, dim3((unsigned)((n + 256 * DDN_MF_R - 1) / (256 * DDN_MF_R)), (unsigned)n_channels),
-                       dim3(128), 0, st, in, n, stride, (const float*)hist, out);
+    hipLaunchKernelGGL(k_p25_matched_filter<DDN_MF_R>, dim3((unsigned)((n + 2 * DDN_MF_THREADS * DDN_MF_R - 1) / (2 * DDN_MF_THREADS * DDN_MF_R)), (unsigned)n_channels),
+                       dim3(DDN_MF_THREADS), 0, st, in, n, stride, (const float*)hist, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         return e;
@@ -311,8 +314,8 @@ ddn_dev_p25_matched_filter_only(const float* in, long n, size_t stride, int n_ch
     if (n_channels <= 0 || n <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_p25_matched_filter<DDN_MF_R>, dim3((unsigned)((n + 256 * DDN_MF_R - 1) / (256 * DDN_MF_R)), (unsigned)n_channels),
-                       dim3(128), 0, st, in, n, stride, hist, out);
+    hipLaunchKernelGGL(k_p25_matched_filter<DDN_MF_R>, dim3((unsigned)((n + 2 * DDN_MF_THREADS * DDN_MF_R - 1) / (2 * DDN_MF_THREADS * DDN_MF_R)), (unsigned)n_channels),
+                       dim3(DDN_MF_THREADS), 0, st, in, n, stride, hist, out);
     return hipGetLastError();
 }
 
